@@ -1,0 +1,155 @@
+/*
+ * ref_shim.cpp — extern "C" harness over the *unmodified, compiled reference sources*.
+ *
+ * TEST INFRASTRUCTURE ONLY.  oracle/Makefile compiles this file together with
+ *   /root/reference/src/crass/{PatternMatcher,StringCheck,kseq}.cpp
+ *   /root/reference/src/aho-corasick/{acism,acism_create,acism_file,msutil}.c
+ * straight from where they lie into oracle/_ref/libcrass_ref.so (git-ignored).
+ * Those are the hot-path reference files that compile without generated code
+ * (autoconf config.h) or Xerces-C; libcrispr.cpp / ReadHolder.cpp / WorkHorse.cpp
+ * need both and are therefore NOT built (see DESIGN.md "Oracle").
+ *
+ * The functions here only marshal arguments; the algorithms are the reference's.
+ */
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdlib>
+#include <cstdint>
+#include <zlib.h>
+
+#include "PatternMatcher.h"
+#include "StringCheck.h"
+#include "kseq.h"
+
+extern "C" {
+#include "msutil.h"
+#include "acism.h"
+}
+
+extern "C" {
+
+/* PatternMatcher::bmpSearch (PatternMatcher.cpp:26) */
+int ref_bmp_search(const char *text, size_t tlen, const char *pat, size_t plen)
+{
+    std::string t(text, tlen), p(pat, plen);
+    return PatternMatcher::bmpSearch(t, p);
+}
+
+/* PatternMatcher::levenstheinDistance (PatternMatcher.cpp:111) */
+int ref_levenshtein(const char *s, int n, const char *t, int m)
+{
+    std::string a(s, (size_t)n), b(t, (size_t)m);
+    return PatternMatcher::levenstheinDistance(a, b);
+}
+
+/* PatternMatcher::getStringSimilarity (PatternMatcher.cpp:197) */
+float ref_similarity(const char *s, int n, const char *t, int m)
+{
+    std::string a(s, (size_t)n), b(t, (size_t)m);
+    return PatternMatcher::getStringSimilarity(a, b);
+}
+
+/* ---- ACISM driven exactly the way findSingletons drives it (libcrispr.cpp:452-469,503,441) */
+typedef struct {
+    char *concstr;
+    MEMREF *pattv;
+    int npatts;
+    ACISM *psp;
+} ref_acism;
+
+typedef struct { int strnum; int textpos; int calls; } ref_hit;
+
+static int ref_on_match(int strnum, int textpos, void *ctx)
+{
+    ref_hit *h = (ref_hit *)ctx;
+    h->strnum = strnum; h->textpos = textpos; h->calls++;
+    return 1;                        /* on_match always returns 1 (libcrispr.cpp:441) */
+}
+
+void *ref_acism_build(const char *const *pats, const uint32_t *lens, uint32_t n)
+{
+    std::string conc;
+    for (uint32_t i = 0; i < n; i++) { conc.append(pats[i], lens[i]); conc += "\n"; }
+    ref_acism *r = (ref_acism *)calloc(1, sizeof(ref_acism));
+    r->concstr = (char *)malloc(conc.size() + 1);
+    memcpy(r->concstr, conc.data(), conc.size());
+    r->concstr[conc.size()] = '\0';
+    r->concstr[conc.size() - 1] = '\0';          /* the trailing-newline hack (libcrispr.cpp:458-464) */
+    r->pattv = refsplit(r->concstr, '\n', &r->npatts);
+    r->psp = acism_create(r->pattv, r->npatts);
+    return r;
+}
+
+/* returns 1 if the callback fired; (*end_excl, *len) from the first callback */
+int ref_acism_first(void *handle, const char *text, size_t tlen, uint32_t *end_excl, uint32_t *len)
+{
+    ref_acism *r = (ref_acism *)handle;
+    ref_hit h = { -1, -1, 0 };
+    MEMREF tmp = { text, tlen };
+    (void)acism_scan(r->psp, tmp, (ACISM_ACTION *)ref_on_match, &h);
+    if (!h.calls) return 0;
+    *end_excl = (uint32_t)h.textpos;
+    *len = (uint32_t)r->pattv[h.strnum].len;
+    return 1;
+}
+
+void ref_acism_free(void *handle)
+{
+    ref_acism *r = (ref_acism *)handle;
+    if (!r) return;
+    acism_destroy(r->psp);
+    free(r->pattv);
+    free(r->concstr);
+    free(r);
+}
+
+/* ---- StringCheck (StringCheck.cpp:46-81): feed strings in order, get tokens back */
+void ref_stringcheck_tokens(const char *const *strs, const uint32_t *lens, uint32_t n, int32_t *tokens_out)
+{
+    StringCheck sc;
+    for (uint32_t i = 0; i < n; i++) {
+        std::string s(strs[i], lens[i]);
+        StringToken t = sc.getToken(s);
+        if (0 == t) t = sc.addString(s);
+        tokens_out[i] = t;
+    }
+}
+
+/* ---- kseq (kseq.cpp:171-226): read every record of a FASTA/FASTQ(.gz) file.
+ * Output is a flat byte stream: for each record four length-prefixed (u32 LE) fields
+ * name, comment, seq, qual — comment/qual are what searchFile would pass to setComment/
+ * setQual (i.e. the *stale pointer* semantics of libcrispr.cpp:124-131: the field is emitted
+ * whenever the kstring's buffer pointer is non-NULL).  Returns number of records or <0. */
+long ref_kseq_dump(const char *path, unsigned char **out, size_t *out_len, int *last_ret)
+{
+    gzFile fp = gzopen(path, "r");
+    if (!fp) return -1;
+    kseq_t *seq = kseq_init(fp);
+    std::string buf;
+    long n = 0;
+    int l;
+    auto put = [&buf](const char *p) {
+        uint32_t len = p ? (uint32_t)strlen(p) : 0xFFFFFFFFu;
+        buf.append((const char *)&len, 4);
+        if (p) buf.append(p, len);
+    };
+    while ((l = kseq_read(seq)) >= 0) {
+        put(seq->name.s);
+        put(seq->comment.s);
+        put(seq->seq.s);
+        put(seq->qual.s);
+        n++;
+    }
+    if (last_ret) *last_ret = l;
+    kseq_destroy(seq);
+    gzclose(fp);
+    *out = (unsigned char *)malloc(buf.size() ? buf.size() : 1);
+    memcpy(*out, buf.data(), buf.size());
+    *out_len = buf.size();
+    return n;
+}
+
+void ref_free(void *p) { free(p); }
+
+} /* extern "C" */

@@ -1,0 +1,251 @@
+"""ctypes bindings for the test-only checkers under oracle/.
+
+* ``liboracle.so``  — the plain-C restatement (oracle/crass_oracle.c)
+* ``_ref/libcrass_ref.so`` — the reference's own leaf sources compiled where they lie
+  (only present where oracle/Makefile found /root/reference; optional)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+
+
+class Params(C.Structure):
+    _fields_ = [("lowDRsize", C.c_uint32), ("highDRsize", C.c_uint32),
+                ("lowSpacerSize", C.c_uint32), ("highSpacerSize", C.c_uint32),
+                ("searchWindowLength", C.c_uint32), ("minNumRepeats", C.c_uint32),
+                ("kmer_clust_size", C.c_int32)]
+
+    @classmethod
+    def default(cls, **kw):
+        p = cls(23, 47, 26, 50, 8, 2, 6)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def astuple(self):
+        return tuple(getattr(self, f[0]) for f in self._fields_)
+
+
+class View(C.Structure):
+    _fields_ = [("n_pass1", C.c_uint64), ("n_pass2", C.c_uint64),
+                ("n_tokens", C.c_uint32), ("n_groups", C.c_uint32),
+                ("n_patterns", C.c_uint32), ("max_read_len", C.c_uint32),
+                ("error", C.c_int32),
+                ("rec_read", C.POINTER(C.c_uint64)), ("rec_lowlexi", C.POINTER(C.c_uint8)),
+                ("rec_token", C.POINTER(C.c_uint32)), ("rec_replen", C.POINTER(C.c_uint32)),
+                ("rec_nss", C.POINTER(C.c_uint32)), ("rec_ss_off", C.POINTER(C.c_uint64)),
+                ("ss_pool", C.POINTER(C.c_uint32)),
+                ("tok_chars", C.POINTER(C.c_char)), ("tok_off", C.POINTER(C.c_uint64)),
+                ("grp_tokens", C.POINTER(C.c_uint32)), ("grp_off", C.POINTER(C.c_uint64)),
+                ("pat_chars", C.POINTER(C.c_char)), ("pat_off", C.POINTER(C.c_uint64)),
+                ("pat_group", C.POINTER(C.c_uint32))]
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_bmp_search.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.orc_bmp_search.restype = C.c_int
+        L.orc_levenshtein.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.orc_levenshtein.restype = C.c_int
+        L.orc_similarity.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.orc_similarity.restype = C.c_float
+        L.orc_revcomp.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+        L.orc_is_low_complexity.argtypes = [C.c_char_p, C.c_int]
+        L.orc_scan_right.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_int,
+                                     C.c_char_p, C.c_int, C.c_uint32, C.c_uint32]
+        L.orc_extend_pre_repeat.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_int]
+        L.orc_extend_pre_repeat.restype = C.c_uint32
+        L.orc_qc_found_repeats.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_int]
+        L.orc_search_core.argtypes = [C.c_char_p, C.c_int, C.POINTER(Params), C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint32)]
+        L.orc_has_lattice_hit.argtypes = [C.c_char_p, C.c_int, C.POINTER(Params)]
+        L.orc_dr_low_lexi.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_char_p,
+                                      C.POINTER(C.c_int)]
+        L.orc_ac_create.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32]
+        L.orc_ac_create.restype = C.c_void_p
+        L.orc_ac_destroy.argtypes = [C.c_void_p]
+        L.orc_ac_first_match.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint32)]
+        L.orc_pipeline_run.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                       C.POINTER(Params), C.c_int]
+        L.orc_pipeline_run.restype = C.c_void_p
+        L.orc_result_free.argtypes = [C.c_void_p]
+        L.orc_result_view.argtypes = [C.c_void_p, C.POINTER(View)]
+        L.orc_pipeline_time.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Params)] + \
+            [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_uint64)] * 2 + [C.POINTER(C.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The compiled reference leaf library, or None when it is not available."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libcrass_ref.so")
+        if not os.path.exists(path):
+            if os.path.isdir("/root/reference"):
+                build()
+            if not os.path.exists(path):
+                return None
+        R = C.CDLL(path)
+        R.ref_bmp_search.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        R.ref_levenshtein.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        R.ref_similarity.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        R.ref_similarity.restype = C.c_float
+        R.ref_acism_build.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32]
+        R.ref_acism_build.restype = C.c_void_p
+        R.ref_acism_first.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32)]
+        R.ref_acism_free.argtypes = [C.c_void_p]
+        R.ref_stringcheck_tokens.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32,
+                                             C.POINTER(C.c_int32)]
+        R.ref_kseq_dump.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_size_t),
+                                    C.POINTER(C.c_int)]
+        R.ref_kseq_dump.restype = C.c_long
+        R.ref_free.argtypes = [C.c_void_p]
+        _ref = R
+    return _ref
+
+
+def _strarr(strs):
+    arr = (C.c_char_p * len(strs))(*strs)
+    lens = (C.c_uint32 * len(strs))(*[len(s) for s in strs])
+    return arr, lens
+
+
+class PatternSet:
+    """first-match searcher over a pattern list; impl = 'oracle' or 'ref'."""
+
+    def __init__(self, patterns, impl="oracle"):
+        self.impl = impl
+        self._keep = _strarr(list(patterns))
+        if impl == "oracle":
+            self.h = lib().orc_ac_create(self._keep[0], self._keep[1], len(patterns))
+        else:
+            self.h = ref().ref_acism_build(self._keep[0], self._keep[1], len(patterns))
+
+    def first(self, text):
+        e, l = C.c_uint32(), C.c_uint32()
+        if self.impl == "oracle":
+            r = lib().orc_ac_first_match(self.h, text, len(text), C.byref(e), C.byref(l))
+        else:
+            r = ref().ref_acism_first(self.h, text, len(text), C.byref(e), C.byref(l))
+        return (e.value, l.value) if r else None
+
+    def close(self):
+        if self.h:
+            (lib().orc_ac_destroy if self.impl == "oracle" else ref().ref_acism_free)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def search_core(seq, params=None):
+    p = params or Params.default()
+    cap = len(seq) + 8
+    ss = (C.c_uint32 * cap)()
+    nss = C.c_int(0)
+    rl = C.c_uint32(0)
+    r = lib().orc_search_core(seq, len(seq), C.byref(p), ss, C.byref(nss), cap, C.byref(rl))
+    return r, list(ss[:nss.value]), rl.value
+
+
+def concat(items):
+    """list of bytes -> (uint8 array, uint64 offsets[n+1])"""
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    if items:
+        off[1:] = np.cumsum([len(s) for s in items], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(items), dtype=np.uint8).copy() if items else np.zeros(0, np.uint8)
+    return buf, off
+
+
+class PipelineResult:
+    """numpy copies of an orc_view"""
+
+    def __init__(self, v):
+        n = int(v.n_pass1 + v.n_pass2)
+        self.n_pass1, self.n_pass2 = int(v.n_pass1), int(v.n_pass2)
+        self.n_tokens, self.n_groups, self.n_patterns = v.n_tokens, v.n_groups, v.n_patterns
+        self.max_read_len, self.error = v.max_read_len, v.error
+
+        def arr(ptr, cnt, dt):
+            if cnt == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(ptr, shape=(cnt,)).astype(dt, copy=True)
+        self.rec_read = arr(v.rec_read, n, np.uint64)
+        self.rec_lowlexi = arr(v.rec_lowlexi, n, np.uint8)
+        self.rec_token = arr(v.rec_token, n, np.uint32)
+        self.rec_replen = arr(v.rec_replen, n, np.uint32)
+        self.rec_nss = arr(v.rec_nss, n, np.uint32)
+        self.rec_ss_off = arr(v.rec_ss_off, n, np.uint64)
+        nss_total = int(self.rec_nss.sum())
+        self.ss_pool = arr(v.ss_pool, nss_total, np.uint32)
+        self.tok_off = arr(v.tok_off, v.n_tokens + 1, np.uint64)
+        tc = C.string_at(v.tok_chars, int(self.tok_off[-1])) if v.n_tokens else b""
+        self.tokens = [tc[int(self.tok_off[i]):int(self.tok_off[i + 1])] for i in range(v.n_tokens)]
+        self.grp_off = arr(v.grp_off, v.n_groups + 1, np.uint64)
+        gt = arr(v.grp_tokens, int(self.grp_off[-1]) if v.n_groups else 0, np.uint32)
+        self.groups = [gt[int(self.grp_off[i]):int(self.grp_off[i + 1])].tolist() for i in range(v.n_groups)]
+        self.pat_off = arr(v.pat_off, v.n_patterns + 1, np.uint64)
+        pc = C.string_at(v.pat_chars, int(self.pat_off[-1])) if v.n_patterns else b""
+        self.patterns = [pc[int(self.pat_off[i]):int(self.pat_off[i + 1])] for i in range(v.n_patterns)]
+        self.pat_group = arr(v.pat_group, v.n_patterns, np.uint32)
+
+    def ss(self, k):
+        o = int(self.rec_ss_off[k])
+        return self.ss_pool[o:o + int(self.rec_nss[k])].tolist()
+
+
+def pipeline(seqs, headers=None, params=None, do_pass2=True):
+    """seqs: list[bytes] or (uint8 array, uint64 offsets)."""
+    p = params or Params.default()
+    if isinstance(seqs, (list, tuple)) and (not seqs or isinstance(seqs[0], (bytes, bytearray))):
+        sbuf, soff = concat(list(seqs))
+    else:
+        sbuf, soff = seqs
+    n = len(soff) - 1
+    if headers is not None:
+        hbuf, hoff = concat(list(headers))
+        hp, hop = hbuf.ctypes.data, hoff.ctypes.data
+    else:
+        hp, hop = None, None
+    r = lib().orc_pipeline_run(sbuf.ctypes.data, soff.ctypes.data, n, hp, hop, C.byref(p), int(do_pass2))
+    v = View()
+    lib().orc_result_view(r, C.byref(v))
+    out = PipelineResult(v)
+    lib().orc_result_free(r)
+    return out
+
+
+def pipeline_time(sbuf, soff, params=None):
+    p = params or Params.default()
+    t = [C.c_double() for _ in range(3)]
+    n1, n2, npat = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    err = lib().orc_pipeline_time(sbuf.ctypes.data, soff.ctypes.data, len(soff) - 1, C.byref(p),
+                                  C.byref(t[0]), C.byref(t[1]), C.byref(t[2]),
+                                  C.byref(n1), C.byref(n2), C.byref(npat))
+    return dict(error=err, t_pass1=t[0].value, t_merge=t[1].value, t_pass2=t[2].value,
+                n_pass1=n1.value, n_pass2=n2.value, n_patterns=npat.value)

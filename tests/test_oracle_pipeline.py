@@ -1,0 +1,84 @@
+"""Oracle pipeline vs the known answers recorded from the compiled reference
+(default options): reads, pass-1 reads, DR variants, groups,
+non-redundant patterns, reads after pass 2."""
+import os
+
+import pytest
+
+from tests import orc, fastx
+
+DATA = os.path.join(os.path.dirname(__file__), "golden", "data")
+
+# file: (reads, pass-1 reads, variants, groups, patterns, reads after pass 2)
+KNOWN = {
+    "Ill100.fx.gz": (4324, 837, 140, 1, 42, 4312),
+    "CN_gDC.fa.gz": (4740, 2761, 92, 1, 36, 4740),
+    "front_offset_bug.fa.gz": (618, 54, 50, 2, 58, 589),
+    "Ill.nr.miss.fa.gz": (395, 10, 9, 1, 12, 344),
+    "poor_dr_ext.fa.gz": (8, 6, 4, 1, 4, 8),
+}
+
+
+@pytest.mark.parametrize("fname", sorted(KNOWN))
+def test_known_answers(fname):
+    recs = fastx.read_fastx(os.path.join(DATA, fname))
+    res = orc.pipeline([r[2] for r in recs], [r[0] for r in recs])
+    assert res.error == 0
+    got = (len(recs), res.n_pass1, res.n_tokens, res.n_groups, res.n_patterns, res.n_pass1 + res.n_pass2)
+    assert got == KNOWN[fname]
+    # structural invariants the downstream stage relies on
+    for k in range(res.n_pass1 + res.n_pass2):
+        ss = res.ss(k)
+        assert len(ss) % 2 == 0 and len(ss) >= 2
+        assert all(a <= b for a, b in zip(ss[0::2], ss[1::2]))
+        assert ss == sorted(ss)
+    # every token belongs to exactly one group
+    flat = sorted(t for g in res.groups for t in g)
+    assert flat == list(range(2, 2 + res.n_tokens))
+    # patterns: per group, survivors then their reverse complements
+    assert res.n_patterns % 2 == 0
+
+
+def test_filter_contract_no_lattice_hit_means_not_found():
+    """searchCore can only succeed if some stride-lattice seed hits."""
+    import ctypes as C
+    recs = fastx.read_fastx(os.path.join(DATA, "Ill100.fx.gz"))
+    p = orc.Params.default()
+    L = orc.lib()
+    n_hit = 0
+    for _, _, seq, _ in recs:
+        hit = L.orc_has_lattice_hit(seq, len(seq), C.byref(p))
+        found, _, _ = orc.search_core(seq, p)
+        assert found in (0, 1)
+        if found:
+            assert hit == 1
+        n_hit += hit
+    assert n_hit >= 837
+
+
+@pytest.mark.slow
+def test_one_million_synthetic_known_answer():
+    """SURVEY appendix C generator (random.seed(42)); the compiled reference gave
+    5 575 pass-1 reads, 1 988 variants, 52 groups, 700 patterns, 9 931 reads after pass 2."""
+    import random
+    random.seed(42)
+    L = 150
+
+    def rand_seq(n):
+        return "".join(random.choice("ACGT") for _ in range(n))
+    drs = [rand_seq(random.randint(28, 37)) for _ in range(50)]
+    seqs = []
+    for _ in range(1000000):
+        if random.random() < 0.01:
+            s = rand_seq(random.randint(0, 40))
+            dr = random.choice(drs)
+            while len(s) < L + 60:
+                s += dr + rand_seq(random.randint(30, 38))
+            off = random.randint(0, 40)
+            s = s[off:off + L]
+        else:
+            s = rand_seq(L)
+        seqs.append(s.encode())
+    res = orc.pipeline(seqs)
+    assert (res.n_pass1, res.n_tokens, res.n_groups, res.n_patterns, res.n_pass1 + res.n_pass2) == \
+        (5575, 1988, 52, 700, 9931)
