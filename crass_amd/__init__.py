@@ -1,0 +1,13 @@
+"""crass_amd — MI355X-native (gfx950) engine for crass's DR search + read recruitment path.
+
+The product is ``libcrass_hip.so`` (hand-written HIP kernels + C-ABI host engine, see
+``include/crass_hip.h``); this package is the thin Python host layer used by tests, bench.py
+and the multi-GPU driver.  There is no CPU fallback: importing works everywhere, but every
+search entry point needs the compiled library and a GPU.
+"""
+from ._abi import LIB_PATH, SYMBOLS, load  # noqa: F401
+from .engine import (CrassError, FastxFile, PackedReads, SearchEngine, default_params,  # noqa: F401
+                     search_pipeline, synth_packed, synth_spec, unpack_ascii)
+
+__all__ = ["CrassError", "FastxFile", "PackedReads", "SearchEngine", "default_params", "search_pipeline",
+           "synth_packed", "synth_spec", "unpack_ascii", "load", "LIB_PATH", "SYMBOLS"]

@@ -1,0 +1,123 @@
+"""ctypes declarations for libcrass_hip.so — one entry per function in include/crass_hip.h.
+
+The library is the product: if it cannot be loaded this module raises, it never falls back
+to a CPU implementation."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcrass_hip.so")
+
+u8p, u16p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+charp = C.POINTER(C.c_char)
+
+
+class Params(C.Structure):
+    _fields_ = [("lowDRsize", C.c_uint32), ("highDRsize", C.c_uint32), ("lowSpacerSize", C.c_uint32),
+                ("highSpacerSize", C.c_uint32), ("searchWindowLength", C.c_uint32),
+                ("minNumRepeats", C.c_uint32), ("kmer_clust_size", C.c_int32)]
+
+
+class Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("packed", C.c_void_p), ("stride_words", C.c_uint32),
+                ("word_off", C.c_void_p), ("uniform_len", C.c_uint32), ("lengths", C.c_void_p),
+                ("n_exceptions", C.c_uint64), ("exc_read", C.c_void_p), ("exc_off", C.c_void_p),
+                ("exc_bytes", C.c_void_p), ("header_id", C.c_void_p), ("read_index_base", C.c_uint64)]
+
+
+class Candidates(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("read_idx", u64p), ("low_lexi", u8p), ("repeat_len", u32p), ("n_ss", u32p),
+                ("ss_off", u64p), ("ss_pool", u32p), ("dr_stride", C.c_uint32), ("dr_len", u16p),
+                ("dr_chars", charp), ("max_read_len", C.c_uint32)]
+
+
+class MergeView(C.Structure):
+    _fields_ = [("n_tokens", C.c_uint32), ("tok_chars", charp), ("tok_off", u64p), ("n_candidates", C.c_uint64),
+                ("cand_token", u32p), ("n_groups", C.c_uint32), ("grp_tokens", u32p), ("grp_off", u64p),
+                ("n_patterns", C.c_uint32), ("pat_chars", charp), ("pat_off", u64p), ("pat_group", u32p),
+                ("next_free_gid", C.c_int32)]
+
+
+class Recruits(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("read_idx", u64p), ("low_lexi", u8p), ("start", u32p), ("end", u32p),
+                ("dr_stride", C.c_uint32), ("dr_len", u16p), ("dr_chars", charp), ("token", u32p)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_exceptions", C.c_uint64), ("n_filter_survivors", C.c_uint64),
+                ("n_pass1_found", C.c_uint64), ("n_pass2_found", C.c_uint64), ("n_patterns", C.c_uint32),
+                ("ac_states", C.c_uint32), ("used_fast_filter", C.c_uint32), ("used_lds_automaton", C.c_uint32),
+                ("ms_filter", C.c_float), ("ms_compact", C.c_float), ("ms_survivor", C.c_float),
+                ("ms_pass1_total", C.c_float), ("ms_recruit", C.c_float), ("ms_recruit_finish", C.c_float),
+                ("ms_pass2_total", C.c_float), ("ms_merge_host", C.c_float), ("ms_sink_host", C.c_float),
+                ("bytes_reads_device", C.c_uint64)]
+
+    def asdict(self):
+        return {f[0]: getattr(self, f[0]) for f in self._fields_}
+
+
+class Packed(C.Structure):
+    _fields_ = [("reads", Reads), ("owner", C.c_void_p)]
+
+
+class Fastx(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("seq", u8p), ("seq_off", u64p), ("name", u8p), ("name_off", u64p),
+                ("comment", u8p), ("comment_off", u64p), ("has_comment", u8p), ("qual", u8p), ("qual_off", u64p),
+                ("has_qual", u8p), ("header_id", u64p), ("max_len", C.c_uint32), ("last_ret", C.c_int32)]
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("n_dr", C.c_uint32), ("dr_len_min", C.c_uint32),
+                ("dr_len_max", C.c_uint32), ("spacer_len_min", C.c_uint32), ("spacer_len_max", C.c_uint32),
+                ("crispr_per_million", C.c_uint32), ("gc_classes", C.c_uint32)]
+
+
+# every exported symbol of include/crass_hip.h: name -> (restype, argtypes)
+SYMBOLS = {
+    "crass_hip_abi_version": (C.c_int, []),
+    "crass_default_params": (None, [C.POINTER(Params)]),
+    "crass_hip_create": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]),
+    "crass_hip_destroy": (None, [C.c_void_p]),
+    "crass_hip_strerror": (C.c_char_p, [C.c_int]),
+    "crass_hip_last_hip_error": (C.c_int, [C.c_void_p]),
+    "crass_hip_load_reads": (C.c_int, [C.c_void_p, C.POINTER(Reads)]),
+    "crass_hip_attach_device_reads": (C.c_int, [C.c_void_p, C.POINTER(Reads)]),
+    "crass_hip_seed_scan": (C.c_int, [C.c_void_p]),
+    "crass_hip_get_candidates": (C.c_int, [C.c_void_p, C.POINTER(Candidates)]),
+    "crass_hip_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
+    "crass_hip_get_merge": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),
+    "crass_hip_set_patterns": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), u32p, C.c_uint32]),
+    "crass_hip_recruit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "crass_hip_get_recruits": (C.c_int, [C.c_void_p, C.POINTER(Recruits)]),
+    "crass_hip_levenshtein_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "crass_hip_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "crass_hip_stream": (C.c_void_p, [C.c_void_p]),
+    "crass_pack_reads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Packed)]),
+    "crass_free_packed": (None, [C.POINTER(Packed)]),
+    "crass_read_fastx": (C.c_int, [C.c_char_p, C.POINTER(Fastx)]),
+    "crass_free_fastx": (None, [C.POINTER(Fastx)]),
+    "crass_synth_default": (None, [C.POINTER(SynthSpec)]),
+    "crass_synth_packed": (C.c_int, [C.POINTER(SynthSpec), C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]),
+    "crass_unpack_ascii": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcrass_hip.so and bind every symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "crass_amd: %s is missing. Build it with `python -m crass_amd.build` (needs hipcc). "
+            "There is no CPU fallback for the search path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

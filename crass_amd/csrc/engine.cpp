@@ -1,0 +1,734 @@
+// engine.cpp — the context behind include/crass_hip.h: device residency of the packed reads,
+// kernel sequencing on one HIP stream, and the host-side sink that turns device records into
+// the ordered hand-off (candidates, tokens, groups, patterns, recruits).
+//
+// There is no CPU fallback anywhere in this file: every search decision is made by the HIP
+// kernels in kernels.hip; the host only orders, tokenises and clusters their output
+// ("stays on host").
+#include "../../include/crass_hip.h"
+#include "engine_internal.h"
+#include "merge.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace crass;
+
+namespace {
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t want)
+    {
+        if (want <= n && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (want == 0) want = 1;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+template <typename T> struct PinBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t want)
+    {
+        if (want <= n && p) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+        if (want == 0) want = 1;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+
+} // namespace
+
+struct crass_hip_ctx {
+    crass_params prm{};
+    DevParams dp{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int last_hip = 0;
+
+    // resident reads
+    DevReads R{};
+    bool have_reads = false;
+    uint64_t read_base = 0;
+    uint32_t max_len = 0;
+    bool uniform = false;
+    DevBuf<uint32_t> r_packed; DevBuf<uint64_t> r_word_off; DevBuf<uint32_t> r_lengths; DevBuf<uint64_t> r_header_id;
+    DevBuf<uint32_t> r_exc_mask; DevBuf<uint64_t> r_exc_read; DevBuf<uint64_t> r_exc_off; DevBuf<uint8_t> r_exc_bytes;
+    std::vector<uint64_t> h_exc_read;        // host copy of the exception read indices (local)
+
+    // scratch
+    DevBuf<uint64_t> d_mask; DevBuf<uint32_t> d_word_prefix; DevBuf<uint32_t> d_block_sums;
+    DevBuf<uint64_t> d_idx; DevBuf<uint32_t> d_count; DevBuf<uint8_t> d_found; DevBuf<uint32_t> d_hit_info;
+    DevBuf<SurvOut> d_surv; DevBuf<char> d_dr; DevBuf<uint32_t> d_ss_pool; DevBuf<uint32_t> d_ss_used;
+    DevBuf<RecruitOut> d_rec; DevBuf<uint32_t> d_exc_hit; DevBuf<uint64_t> d_extra;
+    PinBuf<uint32_t> h_count; PinBuf<SurvOut> h_surv; PinBuf<char> h_dr; PinBuf<uint32_t> h_ss; PinBuf<uint64_t> h_idx;
+    PinBuf<RecruitOut> h_rec;
+    // automaton
+    DevBuf<uint16_t> a_go16; DevBuf<uint32_t> a_go32; DevBuf<uint16_t> a_out; DevBuf<uint16_t> a_go4;
+    DevAutomaton A{};
+    bool have_patterns = false;
+    std::vector<std::string> patterns;
+
+    // pass-1 results (host)
+    bool have_pass1 = false;
+    std::vector<uint64_t> c_read; std::vector<uint8_t> c_low; std::vector<uint32_t> c_replen, c_nss;
+    std::vector<uint64_t> c_ss_off; std::vector<uint32_t> c_ss; std::vector<uint16_t> c_dr_len; std::vector<char> c_dr;
+    uint32_t dr_stride = 48;
+    // merge
+    MergeResult merge;
+    bool have_merge = false;
+    // pass-2 results
+    bool have_pass2 = false;
+    std::vector<uint64_t> q_read; std::vector<uint8_t> q_low; std::vector<uint32_t> q_start, q_end, q_token;
+    std::vector<uint16_t> q_dr_len; std::vector<char> q_dr;
+
+    crass_counters cnt{};
+    hipEvent_t ev[8]{};
+};
+
+#define HIPCHK(ctx, call)                                                       \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) { (ctx)->last_hip = (int)e__; return e__ == hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP; } \
+    } while (0)
+
+extern "C" {
+
+int crass_hip_abi_version(void) { return CRASS_HIP_ABI_VERSION; }
+
+void crass_default_params(crass_params *p)
+{
+    p->lowDRsize = 23; p->highDRsize = 47; p->lowSpacerSize = 26; p->highSpacerSize = 50;
+    p->searchWindowLength = 8; p->minNumRepeats = 2; p->kmer_clust_size = 6;
+}
+
+const char *crass_hip_strerror(int s)
+{
+    switch (s) {
+        case CRASS_OK: return "ok";
+        case CRASS_ERR_INVALID_ARG: return "invalid argument";
+        case CRASS_ERR_UNSUPPORTED: return "parameter outside the device path's implementation limits";
+        case CRASS_ERR_NO_DEVICE: return "no usable HIP device";
+        case CRASS_ERR_HIP: return "HIP runtime call failed";
+        case CRASS_ERR_OOM: return "out of memory";
+        case CRASS_ERR_STATE: return "call order violated";
+        case CRASS_ERR_SEARCH_FATAL: return "Fatal error in search algorithm!";
+        case CRASS_ERR_OVERFLOW: return "device pool overflow";
+        case CRASS_ERR_IO: return "I/O error";
+        default: return "unknown status";
+    }
+}
+
+int crass_hip_last_hip_error(const crass_hip_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+void *crass_hip_stream(const crass_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
+{
+    if (!p || !out) return CRASS_ERR_INVALID_ARG;
+    *out = nullptr;
+    // option validation as crass.cpp:264-271,316-324,351-358,366-374,388-400
+    if (p->searchWindowLength < CRASS_HIP_MIN_WINDOW || p->searchWindowLength > CRASS_HIP_MAX_WINDOW) return CRASS_ERR_INVALID_ARG;
+    if (p->lowDRsize < 8 || p->lowSpacerSize < 8) return CRASS_ERR_INVALID_ARG;
+    if (p->lowDRsize >= p->highDRsize || p->lowSpacerSize >= p->highSpacerSize) return CRASS_ERR_INVALID_ARG;
+    if (p->minNumRepeats < 2) return CRASS_ERR_INVALID_ARG;
+    if (p->highDRsize > CRASS_HIP_MAX_DR) return CRASS_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CRASS_ERR_NO_DEVICE;
+    crass_hip_ctx *c = new (std::nothrow) crass_hip_ctx();
+    if (!c) return CRASS_ERR_OOM;
+    c->prm = *p;
+    c->device = device;
+    c->dp.lowDR = p->lowDRsize; c->dp.highDR = p->highDRsize; c->dp.lowSp = p->lowSpacerSize; c->dp.highSp = p->highSpacerSize;
+    c->dp.window = p->searchWindowLength; c->dp.minRepeats = p->minNumRepeats;
+    uint32_t skips = p->lowDRsize - (2 * p->searchWindowLength - 1);     // unsigned, libcrispr.cpp:281
+    if (skips < 1) skips = 1;
+    c->dp.skips = skips;
+    c->dr_stride = (p->highDRsize + 15u) & ~15u;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
+    for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
+    unsigned char tab[128];
+    build_comp_table(tab);
+    if (upload_comp_table(tab) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
+    *out = c;
+    return CRASS_OK;
+}
+
+void crass_hip_destroy(crass_hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->r_packed.release(); c->r_word_off.release(); c->r_lengths.release(); c->r_header_id.release();
+    c->r_exc_mask.release(); c->r_exc_read.release(); c->r_exc_off.release(); c->r_exc_bytes.release();
+    c->d_mask.release(); c->d_word_prefix.release(); c->d_block_sums.release(); c->d_idx.release(); c->d_count.release();
+    c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
+    c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
+    c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
+    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release();
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int validate_reads(const crass_reads *r)
+{
+    if (!r) return CRASS_ERR_INVALID_ARG;
+    if (r->n_reads && !r->packed) return CRASS_ERR_INVALID_ARG;
+    if (!r->stride_words && r->n_reads && !r->word_off) return CRASS_ERR_INVALID_ARG;
+    if (!r->uniform_len && r->n_reads && !r->lengths) return CRASS_ERR_INVALID_ARG;
+    if (r->n_exceptions && (!r->exc_read || !r->exc_off || !r->exc_bytes)) return CRASS_ERR_INVALID_ARG;
+    if (r->uniform_len > CRASS_HIP_MAX_READ_LEN) return CRASS_ERR_UNSUPPORTED;
+    return CRASS_OK;
+}
+
+static int alloc_scratch(crass_hip_ctx *c)
+{
+    const uint64_t n = c->R.n_reads;
+    const uint64_t n_words = (n + 63) / 64;
+    HIPCHK(c, c->d_mask.ensure(n_words + 1));
+    HIPCHK(c, c->d_word_prefix.ensure(n_words + 1));
+    HIPCHK(c, c->d_block_sums.ensure((n_words + 255) / 256 + 2));
+    HIPCHK(c, c->d_idx.ensure(n + 1));
+    HIPCHK(c, c->d_count.ensure(4));
+    HIPCHK(c, c->d_found.ensure(n + 1));
+    HIPCHK(c, c->d_hit_info.ensure(n + 1));
+    HIPCHK(c, c->d_ss_used.ensure(4));
+    HIPCHK(c, c->h_count.ensure(4));
+    HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
+    return CRASS_OK;
+}
+
+static void reset_results(crass_hip_ctx *c)
+{
+    c->have_pass1 = c->have_merge = c->have_pass2 = c->have_patterns = false;
+    memset(&c->cnt, 0, sizeof(c->cnt));
+}
+
+int crass_hip_load_reads(crass_hip_ctx *c, const crass_reads *h)
+{
+    if (!c) return CRASS_ERR_INVALID_ARG;
+    int v = validate_reads(h);
+    if (v) return v;
+    (void)hipSetDevice(c->device);
+    reset_results(c);
+    const uint64_t n = h->n_reads;
+    // host-side scan for the total word count / max length
+    uint64_t total_words = 0;
+    uint32_t max_len = h->uniform_len;
+    if (!h->uniform_len) for (uint64_t i = 0; i < n; i++) max_len = std::max(max_len, h->lengths[i]);
+    if (max_len > CRASS_HIP_MAX_READ_LEN) return CRASS_ERR_UNSUPPORTED;
+    if (h->stride_words) total_words = n * (uint64_t)h->stride_words;
+    else if (n) {
+        uint32_t lastL = h->uniform_len ? h->uniform_len : h->lengths[n - 1];
+        total_words = h->word_off[n - 1] + (lastL + 15) / 16;
+    }
+    HIPCHK(c, c->r_packed.ensure(total_words + 4));
+    HIPCHK(c, hipMemcpyAsync(c->r_packed.p, h->packed, total_words * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->r_packed.p + total_words, 0, 16, c->stream));
+    DevReads R{};
+    R.packed = c->r_packed.p; R.n_reads = n; R.stride_words = h->stride_words; R.uniform_len = h->uniform_len;
+    if (!h->stride_words) {
+        HIPCHK(c, c->r_word_off.ensure(n));
+        HIPCHK(c, hipMemcpyAsync(c->r_word_off.p, h->word_off, n * 8, hipMemcpyHostToDevice, c->stream));
+        R.word_off = c->r_word_off.p;
+    }
+    if (!h->uniform_len) {
+        HIPCHK(c, c->r_lengths.ensure(n));
+        HIPCHK(c, hipMemcpyAsync(c->r_lengths.p, h->lengths, n * 4, hipMemcpyHostToDevice, c->stream));
+        R.lengths = c->r_lengths.p;
+    }
+    if (h->header_id) {
+        HIPCHK(c, c->r_header_id.ensure(n));
+        HIPCHK(c, hipMemcpyAsync(c->r_header_id.p, h->header_id, n * 8, hipMemcpyHostToDevice, c->stream));
+        R.header_id = c->r_header_id.p;
+    }
+    const uint64_t mask_words = (n + 31) / 32 + 1;
+    HIPCHK(c, c->r_exc_mask.ensure(mask_words));
+    HIPCHK(c, hipMemsetAsync(c->r_exc_mask.p, 0, mask_words * 4, c->stream));
+    R.exc_mask = c->r_exc_mask.p;
+    R.n_exc = h->n_exceptions;
+    c->h_exc_read.assign(h->exc_read, h->exc_read + h->n_exceptions);
+    if (h->n_exceptions) {
+        const uint64_t ne = h->n_exceptions;
+        for (uint64_t i = 0; i < ne; i++) {
+            uint64_t l = h->exc_off[i + 1] - h->exc_off[i];
+            if (l > CRASS_HIP_MAX_READ_LEN) return CRASS_ERR_UNSUPPORTED;
+            max_len = std::max<uint32_t>(max_len, (uint32_t)l);
+        }
+        HIPCHK(c, c->r_exc_read.ensure(ne));
+        HIPCHK(c, c->r_exc_off.ensure(ne + 1));
+        HIPCHK(c, c->r_exc_bytes.ensure(h->exc_off[ne] + 16));
+        HIPCHK(c, hipMemcpyAsync(c->r_exc_read.p, h->exc_read, ne * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->r_exc_off.p, h->exc_off, (ne + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->r_exc_bytes.p, h->exc_bytes, h->exc_off[ne], hipMemcpyHostToDevice, c->stream));
+        R.exc_read = c->r_exc_read.p; R.exc_off = c->r_exc_off.p; R.exc_bytes = c->r_exc_bytes.p;
+        HIPCHK(c, launch_build_exc_mask(R.exc_read, ne, c->r_exc_mask.p, c->stream));
+    }
+    c->R = R;
+    c->read_base = h->read_index_base;
+    c->max_len = max_len;
+    c->uniform = h->uniform_len != 0;
+    c->have_reads = true;
+    int s = alloc_scratch(c);
+    if (s) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cnt.n_reads = n; c->cnt.n_exceptions = h->n_exceptions; c->cnt.bytes_reads_device = total_words * 4;
+    return CRASS_OK;
+}
+
+int crass_hip_attach_device_reads(crass_hip_ctx *c, const crass_reads *d)
+{
+    if (!c) return CRASS_ERR_INVALID_ARG;
+    int v = validate_reads(d);
+    if (v) return v;
+    if (!d->uniform_len || !d->stride_words) return CRASS_ERR_UNSUPPORTED;   // attach mode: uniform shards only
+    if (d->n_exceptions) return CRASS_ERR_UNSUPPORTED;
+    (void)hipSetDevice(c->device);
+    reset_results(c);
+    DevReads R{};
+    R.packed = d->packed; R.n_reads = d->n_reads; R.stride_words = d->stride_words; R.uniform_len = d->uniform_len;
+    R.header_id = d->header_id;
+    const uint64_t mask_words = (d->n_reads + 31) / 32 + 1;
+    HIPCHK(c, c->r_exc_mask.ensure(mask_words));
+    HIPCHK(c, hipMemsetAsync(c->r_exc_mask.p, 0, mask_words * 4, c->stream));
+    R.exc_mask = c->r_exc_mask.p;
+    c->h_exc_read.clear();
+    c->R = R;
+    c->read_base = d->read_index_base;
+    c->max_len = d->uniform_len;
+    c->uniform = true;
+    c->have_reads = true;
+    int s = alloc_scratch(c);
+    if (s) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cnt.n_reads = d->n_reads; c->cnt.n_exceptions = 0;
+    c->cnt.bytes_reads_device = d->n_reads * (uint64_t)d->stride_words * 4;
+    return CRASS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 1
+// ------------------------------------------------------------------------------------------
+struct P1Rec { uint64_t read; SurvOut o; const char *dr; };
+
+static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, std::vector<P1Rec> &recs,
+                         std::vector<std::vector<char>> &dr_keep, std::vector<std::vector<uint32_t>> &ss_keep,
+                         std::vector<uint64_t> &ss_base, const std::vector<uint64_t> *surv_idx_host)
+{
+    if (n_total == 0) return CRASS_OK;
+    const SurvLds lds = survivor_lds_layout(c->max_len, c->dp);
+    if (lds.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
+    const uint64_t chunk_cap = std::min<uint64_t>(n_total, 1u << 20);
+    const uint64_t ss_per = std::min<uint64_t>(lds.ss_cap, 64);
+    const uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(chunk_cap * ss_per, 1u << 16), 1ull << 28);
+    HIPCHK(c, c->d_surv.ensure(chunk_cap));
+    HIPCHK(c, c->d_dr.ensure(chunk_cap * c->dr_stride));
+    HIPCHK(c, c->d_ss_pool.ensure(pool_cap));
+    HIPCHK(c, c->h_surv.ensure(chunk_cap));
+    HIPCHK(c, c->h_dr.ensure(chunk_cap * c->dr_stride));
+    int grid = 256 * 8;
+    for (uint64_t off = 0; off < n_total; off += chunk_cap) {
+        const uint64_t nchunk = std::min(chunk_cap, n_total - off);
+        HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
+        DevReads R = c->R;
+        if (exc) {      // shift the exception window
+            R.exc_read = c->R.exc_read + off; R.exc_off = c->R.exc_off + off; R.n_exc = nchunk;
+        }
+        // for the non-exception path the count lives on the device; chunking uses a host-known bound
+        HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
+                                  c->d_surv.p, c->d_dr.p, c->dr_stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
+                                  c->d_found.p, lds, (int)std::min<uint64_t>(grid, nchunk), c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->d_surv.p, nchunk * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, nchunk * c->dr_stride, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint32_t used = c->h_count.p[2];
+        if (used > pool_cap) return CRASS_ERR_OVERFLOW;
+        HIPCHK(c, c->h_ss.ensure(used + 1));
+        if (used) {
+            HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->d_ss_pool.p, (size_t)used * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        dr_keep.emplace_back(c->h_dr.p, c->h_dr.p + nchunk * c->dr_stride);
+        ss_keep.emplace_back(c->h_ss.p, c->h_ss.p + used);
+        const char *drbase = dr_keep.back().data();
+        const uint64_t ssb = ss_keep.size() - 1;
+        for (uint64_t k = 0; k < nchunk; k++) {
+            const SurvOut &o = c->h_surv.p[k];
+            if (o.err == 1) return CRASS_ERR_SEARCH_FATAL;
+            if (o.err) return CRASS_ERR_OVERFLOW;
+            if (!o.found) continue;
+            P1Rec r;
+            r.read = exc ? c->h_exc_read[off + k] : (*surv_idx_host)[off + k];
+            r.o = o;
+            r.dr = drbase + k * c->dr_stride;
+            recs.push_back(r);
+            ss_base.push_back(ssb);
+        }
+    }
+    return CRASS_OK;
+}
+
+int crass_hip_seed_scan(crass_hip_ctx *c)
+{
+    if (!c) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_reads) return CRASS_ERR_STATE;
+    (void)hipSetDevice(c->device);
+    c->have_pass1 = c->have_merge = c->have_pass2 = false;
+    const uint64_t n = c->R.n_reads;
+    const uint64_t n_words = (n + 63) / 64;
+    HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    // step 1: filter.  Reads longer than 2 kbp almost surely contain a spurious lattice hit
+    // (P ~ seeds*49/4^w), so the filter is skipped and every read goes to the survivor kernel.
+    bool fast = false;
+    const bool use_filter = c->max_len <= 2048;
+    if (use_filter) {
+        hipError_t fe = hipErrorNotSupported;
+        if (c->uniform && c->R.stride_words >= 4 && c->R.stride_words <= 16) fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->stream);
+        if (fe == hipSuccess) fast = true;
+        else if (fe == hipErrorNotSupported) { HIPCHK(c, launch_filter_general(c->R, c->dp, c->d_mask.p, c->max_len, c->stream)); }
+        else { c->last_hip = (int)fe; return CRASS_ERR_HIP; }
+    } else {
+        // all non-exception reads survive: mask = ~exc_mask (exc_mask is 32-bit words of the same bit order)
+        HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0xFF, n_words * 8, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    // step 2: ordered compaction
+    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t n_surv = c->h_count.p[0];
+    // host copy of the survivor indices (needed to label records with their read index)
+    std::vector<uint64_t> surv_idx(n_surv);
+    if (n_surv) {
+        HIPCHK(c, c->h_idx.ensure(n_surv));
+        HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_idx.p, n_surv * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(surv_idx.data(), c->h_idx.p, n_surv * 8);
+    }
+    if (!use_filter && c->R.n_exc) {
+        // drop exception reads from the all-ones mask result on the host (rare path: long reads)
+        std::vector<uint64_t> keep; keep.reserve(n_surv);
+        size_t e = 0;
+        for (uint64_t r : surv_idx) {
+            while (e < c->h_exc_read.size() && c->h_exc_read[e] < r) e++;
+            if (e < c->h_exc_read.size() && c->h_exc_read[e] == r) continue;
+            keep.push_back(r);
+        }
+        surv_idx.swap(keep);
+        n_surv = surv_idx.size();
+        if (n_surv) HIPCHK(c, hipMemcpyAsync(c->d_idx.p, surv_idx.data(), n_surv * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    // the survivor kernel reads its count from d_count[1] (chunk-local bound is passed separately)
+    {
+        uint32_t big = 0xFFFFFFFFu;
+        c->h_count.p[1] = big;
+        HIPCHK(c, hipMemcpyAsync(c->d_count.p + 1, c->h_count.p + 1, 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    std::vector<P1Rec> recs, recs_exc;
+    std::vector<std::vector<char>> dr_keep;
+    std::vector<std::vector<uint32_t>> ss_keep;
+    std::vector<uint64_t> ssb, ssb_exc;
+    int s = run_survivors(c, false, n_surv, recs, dr_keep, ss_keep, ssb, &surv_idx);
+    if (s) return s;
+    s = run_survivors(c, true, c->R.n_exc, recs_exc, dr_keep, ss_keep, ssb_exc, nullptr);
+    if (s) return s;
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double t_sink0 = now_ms();
+    // sink: merge the two ascending record lists by read index
+    const size_t total = recs.size() + recs_exc.size();
+    c->c_read.clear(); c->c_low.clear(); c->c_replen.clear(); c->c_nss.clear(); c->c_ss_off.clear(); c->c_ss.clear();
+    c->c_dr_len.clear(); c->c_dr.clear();
+    c->c_read.reserve(total); c->c_low.reserve(total); c->c_replen.reserve(total); c->c_nss.reserve(total);
+    c->c_ss_off.reserve(total); c->c_dr_len.reserve(total); c->c_dr.resize(total * c->dr_stride);
+    size_t ia = 0, ib = 0, k = 0;
+    while (ia < recs.size() || ib < recs_exc.size()) {
+        const bool takeA = ib >= recs_exc.size() || (ia < recs.size() && recs[ia].read < recs_exc[ib].read);
+        const P1Rec &r = takeA ? recs[ia] : recs_exc[ib];
+        const std::vector<uint32_t> &pool = ss_keep[takeA ? ssb[ia] : ssb_exc[ib]];
+        c->c_read.push_back(c->read_base + r.read);
+        c->c_low.push_back(r.o.low_lexi);
+        c->c_replen.push_back(r.o.repeat_len);
+        c->c_nss.push_back(r.o.n_ss);
+        c->c_ss_off.push_back(c->c_ss.size());
+        c->c_ss.insert(c->c_ss.end(), pool.begin() + r.o.ss_off, pool.begin() + r.o.ss_off + r.o.n_ss);
+        c->c_dr_len.push_back(r.o.dr_len);
+        memcpy(c->c_dr.data() + k * c->dr_stride, r.dr, r.o.dr_len);
+        if (takeA) ia++; else ib++;
+        k++;
+    }
+    c->have_pass1 = true;
+    c->cnt.ms_sink_host = (float)(now_ms() - t_sink0);
+    c->cnt.n_filter_survivors = n_surv + c->R.n_exc;
+    c->cnt.n_pass1_found = total;
+    c->cnt.used_fast_filter = fast ? 1 : 0;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->cnt.ms_filter = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->cnt.ms_compact = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->cnt.ms_survivor = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); c->cnt.ms_pass1_total = ms;
+    return CRASS_OK;
+}
+
+int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
+{
+    if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_pass1) return CRASS_ERR_STATE;
+    o->n = c->c_read.size();
+    o->read_idx = c->c_read.data(); o->low_lexi = c->c_low.data(); o->repeat_len = c->c_replen.data();
+    o->n_ss = c->c_nss.data(); o->ss_off = c->c_ss_off.data(); o->ss_pool = c->c_ss.data();
+    o->dr_stride = c->dr_stride; o->dr_len = c->c_dr_len.data(); o->dr_chars = c->c_dr.data();
+    o->max_read_len = c->max_len;
+    return CRASS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// merge + patterns
+// ------------------------------------------------------------------------------------------
+static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pats)
+{
+    c->patterns = pats;
+    c->have_patterns = false;
+    c->cnt.n_patterns = (uint32_t)pats.size();
+    if (pats.empty()) { c->cnt.ac_states = 0; return CRASS_OK; }
+    for (const auto &p : pats) if (p.empty() || p.size() > 255) return CRASS_ERR_UNSUPPORTED;
+    HostAutomaton H;
+    build_automaton(H, pats);
+    DevAutomaton A{};
+    A.n_states = H.n_states; A.n_sym1 = H.n_sym1;
+    memcpy(A.sym, H.sym, 256);
+    (void)hipSetDevice(c->device);
+    if (H.n_states <= 65535) {
+        std::vector<uint16_t> g16(H.go.size());
+        for (size_t i = 0; i < H.go.size(); i++) g16[i] = (uint16_t)H.go[i];
+        HIPCHK(c, c->a_go16.ensure(g16.size()));
+        HIPCHK(c, hipMemcpyAsync(c->a_go16.p, g16.data(), g16.size() * 2, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, c->a_go4.ensure(H.go4.size()));
+        HIPCHK(c, hipMemcpyAsync(c->a_go4.p, H.go4.data(), H.go4.size() * 2, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));     // g16 is a local
+        A.go16 = c->a_go16.p; A.go4 = c->a_go4.p; A.acgt_ok = 1;
+    } else {
+        HIPCHK(c, c->a_go32.ensure(H.go.size()));
+        HIPCHK(c, hipMemcpyAsync(c->a_go32.p, H.go.data(), H.go.size() * 4, hipMemcpyHostToDevice, c->stream));
+        A.go32 = c->a_go32.p; A.acgt_ok = 0;
+    }
+    HIPCHK(c, c->a_out.ensure(H.out_len.size()));
+    HIPCHK(c, hipMemcpyAsync(c->a_out.p, H.out_len.data(), H.out_len.size() * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    A.out_len = c->a_out.p;
+    c->A = A;
+    c->have_patterns = true;
+    c->cnt.ac_states = H.n_states;
+    return CRASS_OK;
+}
+
+int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n)
+{
+    if (!c) return CRASS_ERR_INVALID_ARG;
+    const double t0 = now_ms();
+    if (!dr_chars) {
+        if (!c->have_pass1) return CRASS_ERR_STATE;
+        dr_chars = c->c_dr.data(); dr_len = c->c_dr_len.data(); dr_stride = c->dr_stride; n = c->c_read.size();
+    } else if (!dr_len || !dr_stride) return CRASS_ERR_INVALID_ARG;
+    merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n, c->prm.kmer_clust_size);
+    c->have_merge = true;
+    c->have_pass2 = false;
+    int s = install_patterns(c, c->merge.patterns);
+    c->cnt.ms_merge_host = (float)(now_ms() - t0);
+    return s;
+}
+
+int crass_hip_get_merge(const crass_hip_ctx *c, crass_merge_view *o)
+{
+    if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_merge) return CRASS_ERR_STATE;
+    const MergeResult &m = c->merge;
+    o->n_tokens = m.tokens.size(); o->tok_chars = m.tok_chars.data(); o->tok_off = m.tok_off.data();
+    o->n_candidates = m.cand_token.size(); o->cand_token = m.cand_token.data();
+    o->n_groups = (uint32_t)m.groups.size(); o->grp_tokens = m.grp_tokens.data(); o->grp_off = m.grp_off.data();
+    o->n_patterns = (uint32_t)m.patterns.size(); o->pat_chars = m.pat_chars.data(); o->pat_off = m.pat_off.data();
+    o->pat_group = m.pat_group.data(); o->next_free_gid = m.next_free_gid;
+    return CRASS_OK;
+}
+
+int crass_hip_set_patterns(crass_hip_ctx *c, const char *const *patterns, const uint32_t *lengths, uint32_t n)
+{
+    if (!c || (n && (!patterns || !lengths))) return CRASS_ERR_INVALID_ARG;
+    std::vector<std::string> pats;
+    for (uint32_t i = 0; i < n; i++) pats.emplace_back(patterns[i], lengths[i]);
+    c->have_pass2 = false;
+    return install_patterns(c, pats);
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 2
+// ------------------------------------------------------------------------------------------
+int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_extra)
+{
+    if (!c) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_reads) return CRASS_ERR_STATE;
+    (void)hipSetDevice(c->device);
+    c->q_read.clear(); c->q_low.clear(); c->q_start.clear(); c->q_end.clear(); c->q_token.clear(); c->q_dr_len.clear(); c->q_dr.clear();
+    c->have_pass2 = false;
+    c->cnt.n_pass2_found = 0;
+    // findSingletons is only called when the non-redundant set is non-empty (WorkHorse.cpp:373)
+    if (c->patterns.empty()) { c->have_pass2 = true; return CRASS_OK; }
+    if (!c->have_patterns) return CRASS_ERR_STATE;
+    const uint64_t n = c->R.n_reads;
+    const uint64_t n_words = (n + 63) / 64;
+    if (n_extra) {
+        // mark additional found headers (local read indices) — a handful of bytes
+        std::vector<uint8_t> one(1, 1);
+        for (uint64_t i = 0; i < n_extra; i++) {
+            if (extra_found[i] >= n) return CRASS_ERR_INVALID_ARG;
+            HIPCHK(c, hipMemsetAsync(c->d_found.p + extra_found[i], 1, 1, c->stream));
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    hipError_t re = launch_recruit_lds(c->R, c->A, c->d_found.p, c->d_mask.p, c->d_hit_info.p, c->stream);
+    bool lds = (re == hipSuccess);
+    if (re == hipErrorNotSupported) { HIPCHK(c, launch_recruit_general(c->R, c->A, c->d_found.p, c->d_mask.p, c->d_hit_info.p, c->stream)); }
+    else if (re != hipSuccess) { c->last_hip = (int)re; return CRASS_ERR_HIP; }
+    if (c->R.n_exc) {
+        HIPCHK(c, c->d_exc_hit.ensure(c->R.n_exc));
+        HIPCHK(c, launch_recruit_exceptions(c->R, c->A, c->d_found.p, c->d_exc_hit.p, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t n_hits = c->h_count.p[0];
+    const uint64_t n_slots = n_hits + c->R.n_exc;
+    HIPCHK(c, c->d_rec.ensure(n_slots + 1));
+    HIPCHK(c, c->d_dr.ensure((n_slots + 1) * c->dr_stride));
+    HIPCHK(c, c->h_rec.ensure(n_slots + 1));
+    HIPCHK(c, c->h_dr.ensure((n_slots + 1) * c->dr_stride));
+    HIPCHK(c, c->h_idx.ensure(n_hits + 1));
+    HIPCHK(c, launch_recruit_finish(c->R, c->d_idx.p, c->d_count.p, n_hits, c->d_hit_info.p, false, c->d_rec.p, c->d_dr.p, c->dr_stride, c->stream));
+    if (c->R.n_exc)
+        HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, c->R.n_exc, c->d_exc_hit.p, true, c->d_rec.p + n_hits,
+                                        c->d_dr.p + n_hits * c->dr_stride, c->dr_stride, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    if (n_slots) {
+        HIPCHK(c, hipMemcpyAsync(c->h_rec.p, c->d_rec.p, n_slots * sizeof(RecruitOut), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, n_slots * c->dr_stride, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (n_hits) HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_idx.p, n_hits * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double t0 = now_ms();
+    // sink: merge packed hits and exception hits by read index; token = existing or new (addReadHolder)
+    size_t ia = 0, ib = 0;
+    const size_t nb = c->R.n_exc;
+    auto exc_valid = [&](size_t b) { return c->h_rec.p[n_hits + b].dr_len != 0; };
+    while (ib < nb && !exc_valid(ib)) ib++;
+    c->q_dr.reserve(n_slots * c->dr_stride);
+    while (ia < n_hits || ib < nb) {
+        const bool takeA = ib >= nb || (ia < n_hits && c->h_idx.p[ia] < c->h_exc_read[ib]);
+        const size_t slot = takeA ? ia : n_hits + ib;
+        const RecruitOut &o = c->h_rec.p[slot];
+        const uint64_t r = takeA ? c->h_idx.p[ia] : c->h_exc_read[ib];
+        c->q_read.push_back(c->read_base + r);
+        c->q_low.push_back(o.low_lexi);
+        c->q_start.push_back(o.start);
+        c->q_end.push_back(o.end);
+        c->q_dr_len.push_back(o.dr_len);
+        const char *dr = c->h_dr.p + slot * c->dr_stride;
+        const size_t at = c->q_dr.size();
+        c->q_dr.resize(at + c->dr_stride);
+        memcpy(c->q_dr.data() + at, dr, o.dr_len);
+        uint32_t tok = 0;
+        if (c->have_merge) {
+            std::string s(dr, o.dr_len);
+            tok = c->merge.tokens.get(s);
+            if (!tok) tok = c->merge.tokens.add(s);
+        }
+        c->q_token.push_back(tok);
+        if (takeA) ia++; else { ib++; while (ib < nb && !exc_valid(ib)) ib++; }
+    }
+    if (c->have_merge) c->merge.flatten();
+    c->have_pass2 = true;
+    c->cnt.ms_sink_host += (float)(now_ms() - t0);
+    c->cnt.n_pass2_found = c->q_read.size();
+    c->cnt.used_lds_automaton = lds ? 1 : 0;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->cnt.ms_recruit = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->cnt.ms_recruit_finish = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[7]); c->cnt.ms_pass2_total = ms;
+    return CRASS_OK;
+}
+
+int crass_hip_get_recruits(const crass_hip_ctx *c, crass_recruits *o)
+{
+    if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_pass2) return CRASS_ERR_STATE;
+    o->n = c->q_read.size(); o->read_idx = c->q_read.data(); o->low_lexi = c->q_low.data();
+    o->start = c->q_start.data(); o->end = c->q_end.data(); o->dr_stride = c->dr_stride;
+    o->dr_len = c->q_dr_len.data(); o->dr_chars = c->q_dr.data(); o->token = c->q_token.data();
+    return CRASS_OK;
+}
+
+int crass_hip_levenshtein_batch(crass_hip_ctx *c, const char *chars, uint64_t n_chars, const uint64_t *a_off,
+                                const uint32_t *a_len, const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,
+                                int32_t *dist_out, float *sim_out)
+{
+    if (!c || (n_pairs && (!chars || !a_off || !a_len || !b_off || !b_len))) return CRASS_ERR_INVALID_ARG;
+    if (n_pairs == 0) return CRASS_OK;
+    (void)hipSetDevice(c->device);
+    uint32_t max_len = 1;
+    for (uint64_t k = 0; k < n_pairs; k++) {
+        if (a_off[k] + a_len[k] > n_chars || b_off[k] + b_len[k] > n_chars) return CRASS_ERR_INVALID_ARG;
+        max_len = std::max(max_len, std::max(a_len[k], b_len[k]));
+    }
+    if (max_len > 30000) return CRASS_ERR_UNSUPPORTED;
+    DevBuf<uint8_t> d_chars; DevBuf<uint64_t> d_ao, d_bo; DevBuf<uint32_t> d_al, d_bl; DevBuf<int32_t> d_dist; DevBuf<float> d_sim;
+    int rc = CRASS_OK;
+    auto body = [&]() -> int {
+        HIPCHK(c, d_chars.ensure(n_chars + 1)); HIPCHK(c, d_ao.ensure(n_pairs)); HIPCHK(c, d_bo.ensure(n_pairs));
+        HIPCHK(c, d_al.ensure(n_pairs)); HIPCHK(c, d_bl.ensure(n_pairs)); HIPCHK(c, d_dist.ensure(n_pairs)); HIPCHK(c, d_sim.ensure(n_pairs));
+        HIPCHK(c, hipMemcpyAsync(d_chars.p, chars, n_chars, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_ao.p, a_off, n_pairs * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_bo.p, b_off, n_pairs * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_al.p, a_len, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_bl.p, b_len, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, launch_levenshtein_batch(d_chars.p, d_ao.p, d_al.p, d_bo.p, d_bl.p, n_pairs, d_dist.p, sim_out ? d_sim.p : nullptr, max_len, c->stream));
+        if (dist_out) HIPCHK(c, hipMemcpyAsync(dist_out, d_dist.p, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+        if (sim_out) HIPCHK(c, hipMemcpyAsync(sim_out, d_sim.p, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return CRASS_OK;
+    };
+    rc = body();
+    d_chars.release(); d_ao.release(); d_bo.release(); d_al.release(); d_bl.release(); d_dist.release(); d_sim.release();
+    return rc;
+}
+
+int crass_hip_get_counters(const crass_hip_ctx *c, crass_counters *o)
+{
+    if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    *o = c->cnt;
+    return CRASS_OK;
+}
+
+} // extern "C"

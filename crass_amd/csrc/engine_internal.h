@@ -1,0 +1,102 @@
+// engine_internal.h — types shared by the HIP kernels (kernels.hip) and the host engine
+// (engine.cpp).  Not part of the public ABI (include/crass_hip.h is).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <hip/hip_runtime.h>
+
+namespace crass {
+
+// device view of the resident reads (all pointers are device pointers)
+struct DevReads {
+    const uint32_t *packed;
+    const uint64_t *word_off;     // nullptr when stride_words > 0
+    const uint32_t *lengths;      // nullptr when uniform_len > 0
+    const uint64_t *header_id;    // nullptr: unique headers
+    const uint32_t *exc_mask;     // bit per read, 1 = exception read (never nullptr; may be all zero)
+    uint64_t n_reads;
+    uint32_t stride_words;
+    uint32_t uniform_len;
+    // exception reads (raw bytes)
+    const uint64_t *exc_read;
+    const uint64_t *exc_off;
+    const uint8_t  *exc_bytes;
+    uint64_t n_exc;
+};
+
+struct DevParams {
+    uint32_t lowDR, highDR, lowSp, highSp, window, minRepeats;
+    uint32_t skips;               // lowDR - (2w-1) as unsigned, clamped to >=1 only when 0 (libcrispr.cpp:281-285)
+};
+
+// per-survivor output slot of the pass-1 survivor kernel
+struct SurvOut {
+    uint32_t found;               // searchCore returned true
+    uint32_t n_ss;
+    uint32_t repeat_len;
+    uint32_t ss_off;              // offset into the ss pool
+    uint16_t dr_len;
+    uint8_t  low_lexi;
+    uint8_t  err;                 // 1: reference would throw, 2: start/stop capacity, 3: pool overflow
+};
+
+// per-hit output of the pass-2 finish kernel
+struct RecruitOut {
+    uint32_t start, end;
+    uint16_t dr_len;
+    uint8_t  low_lexi;
+    uint8_t  pad;
+};
+
+// pass-2 automaton (byte-wise Aho-Corasick, goto fully resolved)
+struct DevAutomaton {
+    const uint16_t *go16;         // [n_states][n_sym1] when n_states <= 65535
+    const uint32_t *go32;         // otherwise
+    const uint16_t *out_len;      // [n_states] longest pattern ending at the state (0 = none)
+    const uint16_t *go4;          // [n_states][4] ACGT-only compact table (packed reads), may be nullptr
+    uint32_t n_states;
+    uint32_t n_sym1;              // symbols + 1 (symbol 0 = byte in no pattern)
+    uint8_t  sym[256];            // byte -> symbol
+    uint32_t acgt_ok;             // n_states <= 65535 (go4 valid)
+};
+
+// layout of the survivor kernel's dynamic LDS (bytes), computed on the host
+struct SurvLds {
+    uint32_t seq_bytes;           // >= maxL + 16, multiple of 16
+    uint32_t ss_cap;              // entries (uint32)
+    uint32_t row_elems;           // uint16 entries per Levenshtein boundary row
+    uint32_t total_bytes;
+};
+
+// ---- launch wrappers implemented in kernels.hip (all asynchronous on `st`) ----
+hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t *hitmask,
+                                 uint32_t max_len, hipStream_t st);
+hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, hipStream_t st);
+// mask (n_words 64-bit words) -> ascending index list; *d_count receives the number of set bits.
+// scratch: word_prefix[n_words] u32, block_sums[(n_words+255)/256 + 1] u32
+hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
+                          uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count,
+                          hipStream_t st);
+hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exceptions,
+                           const uint64_t *surv_idx, const uint32_t *d_n_surv, uint64_t n_surv_max,
+                           SurvOut *out, char *dr_chars, uint32_t dr_stride,
+                           uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
+                           uint8_t *found_flag, const SurvLds &lds, int grid, hipStream_t st);
+hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
+                                  uint64_t *hitmask, uint32_t *hit_info, hipStream_t st);
+hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
+                              uint64_t *hitmask, uint32_t *hit_info, hipStream_t st);
+hipError_t launch_recruit_exceptions(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
+                                     uint32_t *exc_hit_info /*[n_exc], 0 = none*/, hipStream_t st);
+hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, const uint32_t *d_n_hits,
+                                 uint64_t n_hits_max, const uint32_t *hit_info, bool exceptions,
+                                 RecruitOut *out, char *dr_chars, uint32_t dr_stride, hipStream_t st);
+hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off, const uint32_t *a_len,
+                                    const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,
+                                    int32_t *dist, float *sim, uint32_t max_len, hipStream_t st);
+hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st);
+
+SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P);
+hipError_t upload_comp_table(const unsigned char *tab128);
+
+} // namespace crass

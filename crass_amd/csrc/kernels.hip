@@ -1,0 +1,1113 @@
+// kernels.hip — hand-written HIP kernels for gfx950 (MI355X, CDNA4, wave64).
+//
+// The hot path of crass's WorkHorse search (reference citations are relative to the
+// crass v1.0.1 tree):
+//   pass 1  searchCore / scanRight / extendPreRepeat / qcFoundRepeats / DRLowLexi
+//           (src/crass/libcrispr.cpp:170-395,520-1069, ReadHolder.cpp:513-609,
+//            PatternMatcher.cpp:26-204)
+//   pass 2  findSingletons / on_match over an Aho-Corasick automaton
+//           (src/crass/libcrispr.cpp:399-518, src/aho-corasick/acism.c:25-106)
+//
+// Integer/byte work, HBM- and issue-bound: no MFMA.  Reads are 2-bit packed and streamed
+// once per pass; wave64 ballot/ffs gives Boyer-Moore's "leftmost occurrence" for free;
+// the pass-2 automaton is staged in LDS when it fits.  Compile with -ffp-contract=off:
+// qcFoundRepeats' float evaluation order is part of the parity contract.
+#include "engine_internal.h"
+
+namespace crass {
+
+#define WAVE 64
+
+__constant__ unsigned char c_comp[128];     // reverseComplement table, SeqUtils.cpp:50-59
+
+static __device__ __forceinline__ void wave_sync()
+{
+    // LDS traffic of one wave is executed in order; this only stops the compiler from
+    // moving LDS accesses across the point where lanes exchange data through LDS.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+static __device__ __forceinline__ uint64_t rd_word_off(const DevReads &R, uint64_t r)
+{
+    return R.stride_words ? r * (uint64_t)R.stride_words : R.word_off[r];
+}
+static __device__ __forceinline__ uint32_t rd_len(const DevReads &R, uint64_t r)
+{
+    return R.uniform_len ? R.uniform_len : R.lengths[r];
+}
+static __device__ __forceinline__ bool rd_is_exc(const DevReads &R, uint64_t r)
+{
+    return (R.exc_mask[r >> 5] >> (r & 31)) & 1u;
+}
+static __device__ __forceinline__ uint64_t rd_header_id(const DevReads &R, uint64_t r)
+{
+    return R.header_id ? R.header_id[r] : r;
+}
+
+// ------------------------------------------------------------------------------------
+// exception bit mask
+// ------------------------------------------------------------------------------------
+__global__ void k_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask)
+{
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n_exc) {
+        uint64_t r = exc_read[i];
+        atomicOr(&exc_mask[r >> 5], 1u << (r & 31));
+    }
+}
+
+hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st)
+{
+    if (!n_exc) return hipSuccess;
+    hipLaunchKernelGGL(k_build_exc_mask, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, st, exc_read, n_exc, exc_mask);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// pass 1, step 1: seed-scan filter (general parameters, any read length)
+//
+// Contract: bit r of hitmask is set if searchCore's seed loop (libcrispr.cpp:295-348) finds a
+// w-mer hit for SOME seed j on the stride-`skips` lattice.  searchCore leaves the lattice only
+// after a hit (:390), so a clear bit proves searchCore returns false.  A superset is allowed
+// (survivors are re-evaluated exactly by k_survivor).
+// One wave scans 64 consecutive reads (one mask word); per read the packed words are staged in
+// LDS, lanes span the <=64 candidate positions of a seed window and a ballot says "found".
+// ------------------------------------------------------------------------------------
+#define FG_WAVES 4
+
+static __device__ __forceinline__ uint32_t lds_code(const uint32_t *w, uint32_t p, uint32_t mask)
+{
+    uint32_t wi = p >> 4, sh = (p & 15u) * 2u;
+    uint64_t v = ((uint64_t)w[wi + 1] << 32) | w[wi];
+    return (uint32_t)(v >> sh) & mask;
+}
+
+__global__ __launch_bounds__(FG_WAVES * WAVE) void k_filter_general(DevReads R, DevParams P, uint64_t *hitmask,
+                                                                      uint32_t lds_words_per_wave)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t fg_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint32_t *words = fg_lds + (size_t)wave * lds_words_per_wave;
+    const uint64_t n_words = (R.n_reads + 63) / 64;
+    const uint32_t w = P.window;
+    const uint32_t cmask = (1u << (2 * w)) - 1u;
+    for (uint64_t mw = blockIdx.x * (uint64_t)FG_WAVES + wave; mw < n_words; mw += (uint64_t)gridDim.x * FG_WAVES) {
+        uint64_t bits = 0;
+        for (int k = 0; k < 64; k++) {
+            uint64_t r = mw * 64 + k;
+            if (r >= R.n_reads) break;
+            if (rd_is_exc(R, r)) continue;
+            uint32_t L = rd_len(R, r);
+            int searchEnd = (int)(L - P.lowDR - P.lowSp - w - 1);
+            if (searchEnd < 0) continue;
+            uint32_t nw = (L + 15) >> 4;
+            const uint32_t *g = R.packed + rd_word_off(R, r);
+            wave_sync();
+            for (uint32_t i = lane; i < nw + 1; i += 64) words[i] = (i < nw) ? g[i] : 0u;
+            wave_sync();
+            bool hit = false;
+            for (uint32_t j = 0; j <= (uint32_t)searchEnd && !hit; j += P.skips) {
+                uint32_t begin = j + P.lowDR + P.lowSp;
+                uint32_t end = j + P.highDR + P.highSp + w;
+                if (end >= L) end = L - 1;
+                if (end < begin) end = begin;
+                uint32_t sj = lds_code(words, j, cmask);
+                for (uint32_t p0 = begin; p0 + w <= end; p0 += 64) {
+                    uint32_t p = p0 + lane;
+                    bool ok = (p + w <= end) && (lds_code(words, p, cmask) == sj);
+                    if (__ballot(ok)) { hit = true; break; }
+                }
+                if (j + P.skips < j) break;          // unsigned wrap of the reference's `j = j + skips`
+            }
+            if (hit) bits |= (1ull << k);
+        }
+        if (lane == 0) hitmask[mw] = bits;
+    }
+}
+
+hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t max_len, hipStream_t st)
+{
+    uint32_t wpw = ((max_len + 15) / 16 + 2 + 3) & ~3u;
+    size_t lds = (size_t)FG_WAVES * wpw * 4;
+    uint64_t n_words = (R.n_reads + 63) / 64;
+    uint64_t blocks = (n_words + FG_WAVES - 1) / FG_WAVES;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_filter_general, dim3((unsigned)blocks), dim3(FG_WAVES * WAVE), lds, st, R, P, hitmask, wpw);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// pass 1, step 1 (fast path): lane-per-read bit-parallel seed scan.
+// Requirements: window == 8 and skips == 8 (defaults: every lattice seed is exactly one
+// aligned halfword of the packed read), uniform stride <= 16 words (reads <= 256 bp).
+// For a shift d, X = R ^ (R >> 2d) has a zero halfword h  <=>  the 8-mer at seed j=8h
+// re-occurs at j+d.  v_pk_min_u16 accumulates "any zero so far" per halfword over all
+// shifts d in [lowDR+lowSp, highDR+highSp]; a final per-halfword test yields the hit bit.
+// The window's right clamp (libcrispr.cpp:301-304) and bases in the padding are ignored:
+// that can only ADD survivors (superset contract), never lose one.
+// ------------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));   // v_pk_min_u16
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// Fully unrolled implementation: D0..D1 are compile-time so every register index is static.
+template <int W, int D0, int D1>
+__global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams P, uint64_t *hitmask)
+{
+    const uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const bool active = r < R.n_reads;
+    constexpr int WX = W + (D1 >> 4) + 2;
+    uint32_t w[WX];
+#pragma unroll
+    for (int i = 0; i < WX; i++) w[i] = 0;
+    uint32_t L = 0;
+    bool exc = false;
+    if (active) {
+        const uint32_t *g = R.packed + r * (uint64_t)W;
+#pragma unroll
+        for (int i = 0; i < W; i++) w[i] = g[i];
+        L = rd_len(R, r);
+        exc = rd_is_exc(R, r);
+    }
+    // seeds live in halfwords 0 .. searchEnd/8 with searchEnd = L-58 <= 16W-58: only words < SW hold one
+    constexpr int SW = ((16 * W - 58) / 8 + 2) / 2;
+    uint32_t acc[SW];
+#pragma unroll
+    for (int i = 0; i < SW; i++) acc[i] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = D0; d <= D1; d++) {
+        const int q = d >> 4;
+        const int sh = (d & 15) * 2;
+#pragma unroll
+        for (int k = 0; k < SW; k++) {
+            uint32_t lo = w[k + q], hi = w[k + q + 1];
+            uint32_t s = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;      // v_alignbit_b32
+            uint32_t x = s ^ w[k];
+            // per-halfword running minimum: a halfword of acc becomes 0 iff some x halfword was 0
+            acc[k] = pk_min_u16(acc[k], x);
+        }
+    }
+    bool hit = false;
+    int searchEnd = (int)(L - P.lowDR - P.lowSp - 8 - 1);
+    if (active && !exc && searchEnd >= 0) {
+        int n_seed = searchEnd / 8 + 1;                 // halfwords 0 .. n_seed-1 hold lattice seeds
+#pragma unroll
+        for (int k = 0; k < SW; k++) {
+            bool z0 = (acc[k] & 0xFFFFu) == 0 && (2 * k) < n_seed;
+            bool z1 = (acc[k] >> 16) == 0 && (2 * k + 1) < n_seed;
+            hit = hit || z0 || z1;
+        }
+    }
+    uint64_t m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && active) hitmask[r >> 6] = m;
+}
+
+hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, hipStream_t st)
+{
+    // defaults only: w = 8, skips = 8, shifts 49..97
+    if (P.window != 8 || P.skips != 8) return hipErrorNotSupported;
+    if (P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return hipErrorNotSupported;
+    if (!R.stride_words || R.n_reads == 0) return hipErrorNotSupported;
+    uint64_t blocks = (R.n_reads + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorNotSupported;
+    dim3 g((unsigned)blocks), b(256);
+    switch (R.stride_words) {
+#define FF_CASE(WW) case WW: hipLaunchKernelGGL((k_filter_fast_impl<WW, 49, 97>), g, b, 0, st, R, P, hitmask); break;
+        FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8) FF_CASE(9) FF_CASE(10)
+        FF_CASE(11) FF_CASE(12) FF_CASE(13) FF_CASE(14) FF_CASE(15) FF_CASE(16)
+#undef FF_CASE
+        default: return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// ordered compaction: bit mask -> ascending list of set-bit indices
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mask_count(const uint64_t *mask, uint64_t n_words, uint64_t n_bits,
+                                                     uint32_t *word_prefix, uint32_t *block_sums)
+{
+    __shared__ uint32_t sh[256];
+    uint64_t wi = blockIdx.x * 256ull + threadIdx.x;
+    uint32_t c = 0;
+    if (wi < n_words) {
+        uint64_t m = mask[wi];
+        uint64_t rem = n_bits - wi * 64;
+        if (rem < 64) m &= (1ull << rem) - 1ull;
+        c = (uint32_t)__popcll(m);
+    }
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (wi < n_words) word_prefix[wi] = sh[threadIdx.x] - c;
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
+}
+
+__global__ __launch_bounds__(1024) void k_block_scan(uint32_t *block_sums, uint32_t n_blocks, uint32_t *d_count)
+{
+    __shared__ uint32_t sh[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t c = (i < n_blocks) ? block_sums[i] : 0;
+        sh[threadIdx.x] = c;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t v = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t excl = sh[threadIdx.x] - c + carry;
+        if (i < n_blocks) block_sums[i] = excl;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *d_count = carry;
+}
+
+__global__ __launch_bounds__(256) void k_mask_scatter(const uint64_t *mask, uint64_t n_words, uint64_t n_bits,
+                                                       const uint32_t *word_prefix, const uint32_t *block_sums,
+                                                       uint64_t *out_idx, uint64_t out_cap)
+{
+    uint64_t wi = blockIdx.x * 256ull + threadIdx.x;
+    if (wi >= n_words) return;
+    uint64_t m = mask[wi];
+    uint64_t rem = n_bits - wi * 64;
+    if (rem < 64) m &= (1ull << rem) - 1ull;
+    uint64_t o = (uint64_t)block_sums[blockIdx.x] + word_prefix[wi];
+    while (m) {
+        int b = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        if (o < out_cap) out_idx[o] = wi * 64 + b;
+        o++;
+    }
+}
+
+hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
+                          uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count, hipStream_t st)
+{
+    if (n_words == 0) { return hipMemsetAsync(d_count, 0, 4, st); }
+    unsigned nb = (unsigned)((n_words + 255) / 256);
+    hipLaunchKernelGGL(k_mask_count, dim3(nb), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums);
+    hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, d_count);
+    hipLaunchKernelGGL(k_mask_scatter, dim3(nb), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// pass 1, step 2: the survivor kernel — one wave executes the reference's searchCore for
+// one read, byte for byte, with wave-parallel inner operations.
+// ------------------------------------------------------------------------------------
+struct RH {                 // ReadHolder state (ReadHolder.h:440-451), wave-uniform
+    uint8_t *seq;           // LDS, L bytes
+    int L;
+    uint32_t *ss;           // LDS, RH_StartStops
+    int nss, cap;
+    int replen;             // RH_RepeatLength
+    int err;
+    uint16_t *rowA, *rowB;  // Levenshtein block-boundary rows (LDS)
+};
+
+// leftmost occurrence of seq[pat, pat+plen) in seq[begin, end): PatternMatcher::bmpSearch
+// semantics (PatternMatcher.cpp:26-59: -1 for empty text/pattern or pattern longer than text)
+static __device__ int wave_find(const uint8_t *seq, int begin, int end, int pat, int plen, int lane)
+{
+    int tlen = end - begin;
+    if (tlen <= 0 || plen <= 0 || plen > tlen) return -1;
+    for (int p0 = begin; p0 + plen <= end; p0 += WAVE) {
+        int p = p0 + lane;
+        bool ok = (p + plen <= end);
+        if (ok) {
+            for (int k = 0; k < plen; k++) {
+                if (seq[p + k] != seq[pat + k]) { ok = false; break; }
+            }
+        }
+        uint64_t m = __ballot(ok);
+        if (m) return p0 + (__ffsll((unsigned long long)m) - 1);
+    }
+    return -1;
+}
+
+// ReadHolder::startStopsAdd, ReadHolder.cpp:263-297
+static __device__ void rh_add(RH &h, uint32_t i, uint32_t j, int lane)
+{
+    if (h.nss + 2 > h.cap) { h.err = 2; return; }
+    if (j >= (uint32_t)h.L) j = (uint32_t)h.L - 1;
+    if (lane == 0) { h.ss[h.nss] = i; h.ss[h.nss + 1] = j; }
+    h.nss += 2;
+    wave_sync();
+}
+
+// scanRight, libcrispr.cpp:170-263
+static __device__ void scan_right(RH &h, int pat, uint32_t pattern_length, uint32_t minSpacerLength,
+                                  uint32_t scanRange, int lane)
+{
+    uint32_t last_repeat_index = h.ss[h.nss - 2];
+    uint32_t second_last_repeat_index = h.ss[h.nss - 4];
+    uint32_t repeat_spacing = last_repeat_index - second_last_repeat_index;
+    const uint32_t read_length = (uint32_t)h.L;
+    bool more_to_search = true;
+    while (more_to_search) {
+        int candidate_repeat_index = (int)(last_repeat_index + repeat_spacing);
+        uint32_t begin_search = (uint32_t)candidate_repeat_index - scanRange;
+        uint32_t end_search = (uint32_t)candidate_repeat_index + pattern_length + scanRange;
+        uint32_t scanRightMinBegin = last_repeat_index + pattern_length + minSpacerLength;
+        if (begin_search < scanRightMinBegin) begin_search = scanRightMinBegin;
+        if (begin_search > read_length - 1) return;
+        if (end_search > read_length) end_search = read_length;
+        if (begin_search >= end_search) return;
+        int position = wave_find(h.seq, (int)begin_search, (int)end_search, pat, (int)pattern_length, lane);
+        if (position >= 0) {
+            uint32_t found = (uint32_t)position;        // wave_find returns absolute positions
+            rh_add(h, found, found + pattern_length - 1, lane);
+            if (h.err) return;
+            second_last_repeat_index = last_repeat_index;
+            last_repeat_index = found;
+            repeat_spacing = last_repeat_index - second_last_repeat_index;
+            if (repeat_spacing < (minSpacerLength + pattern_length)) more_to_search = false;
+        } else {
+            more_to_search = false;
+        }
+    }
+}
+
+// extendPreRepeat, libcrispr.cpp:520-772.  The per-column A/C/G/T votes run over repeats in lanes.
+static __device__ uint32_t extend_pre_repeat(RH &h, int searchWindowLength, int minSpacerLength, int lane)
+{
+    const uint32_t num_repeats = (uint32_t)h.nss / 2;
+    h.replen = searchWindowLength;
+    int cut_off = (int)(num_repeats - 1);
+    if (2 > cut_off) cut_off = 2;
+    const uint32_t first_repeat_start_index = h.ss[0];
+    const uint32_t last_repeat_start_index = h.ss[h.nss - 2];
+    const uint32_t end_index = (uint32_t)h.nss;
+    const uint32_t seqlen = (uint32_t)h.L;
+    // shortest spacing between consecutive starts (:557-575)
+    uint32_t shortest = 0xFFFFFFFFu;
+    for (uint32_t i = 2 + 2 * lane; i < end_index; i += 2 * WAVE) {
+        uint32_t sp = (uint32_t)((int)h.ss[i] - (int)h.ss[i - 2]);
+        shortest = min(shortest, sp);
+    }
+    for (int off = 32; off > 0; off >>= 1) shortest = min(shortest, (uint32_t)__shfl_xor((int)shortest, off));
+    const uint32_t shortest_repeat_spacing = shortest;
+
+    uint32_t right_extension_length = 0;
+    uint32_t max_right_extension_length = shortest_repeat_spacing - (uint32_t)minSpacerLength;
+    int DR_index_end = (int)end_index;
+    while (max_right_extension_length > 0) {
+        if ((last_repeat_start_index + (uint32_t)searchWindowLength + right_extension_length) >= seqlen) DR_index_end -= 2;
+        int cA = 0, cC = 0, cG = 0, cT = 0;
+        // the serial loop (:617-646) stops at the first repeat whose next base is off the read;
+        // starts are ascending so that is a suffix: counting the in-range repeats is identical.
+        for (int k0 = 0; k0 < DR_index_end; k0 += 2 * WAVE) {
+            int k = k0 + 2 * lane;
+            uint8_t ch = 0;
+            if (k < DR_index_end) {
+                uint32_t pos = h.ss[k] + (uint32_t)h.replen;
+                if (pos < seqlen) ch = h.seq[pos];
+            }
+            cA += __popcll(__ballot(ch == 'A'));
+            cC += __popcll(__ballot(ch == 'C'));
+            cG += __popcll(__ballot(ch == 'G'));
+            cT += __popcll(__ballot(ch == 'T'));
+        }
+        if ((cA >= cut_off) || (cC >= cut_off) || (cG >= cut_off) || (cT >= cut_off)) {
+            h.replen++;
+            max_right_extension_length--;
+            right_extension_length++;
+        } else {
+            break;
+        }
+    }
+
+    uint32_t left_extension_length = 0;
+    int test_for_negative = (int)(shortest_repeat_spacing - (uint32_t)h.replen);
+    uint32_t max_left_extension_length = (test_for_negative >= 0) ? (uint32_t)test_for_negative : 0;
+    uint32_t DR_index_start = 0;
+    while (left_extension_length < max_left_extension_length) {
+        if ((int)first_repeat_start_index - (int)left_extension_length <= 0) DR_index_start += 2;
+        int cA = 0, cC = 0, cG = 0, cT = 0;
+        for (uint32_t k0 = DR_index_start; k0 < end_index; k0 += 2 * WAVE) {
+            uint32_t k = k0 + 2 * (uint32_t)lane;
+            uint8_t ch = 0;
+            if (k < end_index) {
+                int idx = (int)(h.ss[k] - left_extension_length - 1);
+                if (idx >= 0 && idx < h.L) ch = h.seq[idx];
+            }
+            cA += __popcll(__ballot(ch == 'A'));
+            cC += __popcll(__ballot(ch == 'C'));
+            cG += __popcll(__ballot(ch == 'G'));
+            cT += __popcll(__ballot(ch == 'T'));
+        }
+        if ((cA >= cut_off) || (cC >= cut_off) || (cG >= cut_off) || (cT >= cut_off)) {
+            h.replen++;
+            left_extension_length++;
+        } else {
+            break;
+        }
+    }
+    wave_sync();
+    for (int r = 2 * lane; r + 1 < h.nss; r += 2 * WAVE) {
+        uint32_t a = h.ss[r], b = h.ss[r + 1];
+        a = (a < left_extension_length) ? 0 : a - left_extension_length;
+        b = (b + right_extension_length >= seqlen) ? seqlen - 1 : b + right_extension_length;
+        h.ss[r] = a; h.ss[r + 1] = b;
+    }
+    wave_sync();
+    return (uint32_t)h.replen;
+}
+
+// isRepeatLowComplexity, libcrispr.cpp:1031-1069
+static __device__ bool is_low_complexity(const uint8_t *rep, int n, int lane)
+{
+    int a = 0, c = 0, g = 0, t = 0, o = 0;
+    for (int i0 = 0; i0 < n; i0 += WAVE) {
+        int i = i0 + lane;
+        bool v = i < n;
+        uint8_t ch = v ? rep[i] : 0;
+        uint8_t up = ch & 0xDF;          // case-insensitive for letters
+        bool isA = v && up == 'A', isC = v && up == 'C', isG = v && up == 'G', isT = v && up == 'T';
+        a += __popcll(__ballot(isA)); c += __popcll(__ballot(isC));
+        g += __popcll(__ballot(isG)); t += __popcll(__ballot(isT));
+        o += __popcll(__ballot(v && !(isA || isC || isG || isT)));
+    }
+    int cut_off = (int)((double)n * 0.75);
+    return (a > cut_off) || (t > cut_off) || (g > cut_off) || (c > cut_off) || (o > cut_off);
+}
+
+// PatternMatcher::levenstheinDistance, PatternMatcher.cpp:111-195, as an anti-diagonal wavefront:
+// lane = DP row inside a 64-row block, one DP column step per iteration; neighbours arrive by
+// lane shuffles, block-boundary rows go through LDS.  The recurrence (including the
+// non-standard transposition term for i>2 && j>2) is symmetric in its arguments, so the
+// shorter string is put on the rows.
+static __device__ int wave_lev(const uint8_t *s, int n, const uint8_t *t, int m,
+                               uint16_t *rowA, uint16_t *rowB, int lane)
+{
+    if (n == 0) return m;
+    if (m == 0) return n;
+    if (n > m) { const uint8_t *x = s; s = t; t = x; int y = n; n = m; m = y; }
+    int res = 0;
+    const int nblocks = (n + WAVE - 1) / WAVE;
+    for (int b = 0; b < nblocks; b++) {
+        const int i = b * WAVE + lane + 1;               // DP row (1-based)
+        const bool rowvalid = i <= n;
+        const uint8_t s_i = rowvalid ? s[i - 1] : 0;                  // source[i-1]
+        const uint8_t s_im = (rowvalid && i >= 2) ? s[i - 2] : 0;     // source[i-2]
+        int left = i;                 // M[i][j-1]; M[i][0] = i
+        int pa = 0, ppa = 0, pppa = 0;   // `above` values used at the previous three active steps
+        const int rows_here = min(WAVE, n - b * WAVE);
+        const int steps = m + rows_here - 1;
+        const bool more = (b + 1 < nblocks);
+        for (int d = 0; d < steps; d++) {
+            const int j = d - lane + 1;                  // my column this step
+            int up_left = __shfl_up(left, 1);            // lane-1: M[i-1][j]
+            int up_pppa = __shfl_up(pppa, 1);            // lane-1: M[i-2][j-2]
+            const bool act = rowvalid && j >= 1 && j <= m;
+            if (lane == 0) {
+                if (b == 0) { up_left = j; up_pppa = 0; }
+                else {
+                    up_left = (j >= 0 && j <= m) ? (int)rowA[j] : 0;
+                    up_pppa = (j >= 2 && j - 2 <= m) ? (int)rowB[j - 2] : 0;
+                }
+            }
+            if (act) {
+                const uint8_t t_j = t[j - 1];
+                const int above = up_left;
+                const int diag = (j == 1) ? (i - 1) : pa;
+                const int cost = (s_i == t_j) ? 0 : 1;
+                int cell = min(above + 1, min(left + 1, diag + cost));
+                if (i > 2 && j > 2) {
+                    int trans = up_pppa + 1;
+                    if (s_im != t_j) trans++;
+                    if (s_i != t[j - 2]) trans++;
+                    if (cell > trans) cell = trans;
+                }
+                pppa = ppa; ppa = pa; pa = above;
+                left = cell;
+                if (i == n && j == m) res = cell;
+                if (more) {
+                    if (lane == WAVE - 1) rowA[j] = (uint16_t)cell;       // M[64(b+1)][j]
+                    if (lane == WAVE - 2) rowB[j] = (uint16_t)cell;       // M[64(b+1)-1][j]
+                }
+            }
+        }
+        if (more) {
+            if (lane == WAVE - 1) rowA[0] = (uint16_t)(b * WAVE + WAVE);
+            if (lane == WAVE - 2) rowB[0] = (uint16_t)(b * WAVE + WAVE - 1);
+            wave_sync();
+        }
+    }
+    // broadcast the result from the lane that owns row n
+    const int owner = (n - 1) & (WAVE - 1);
+    return __shfl(res, owner);
+}
+
+// PatternMatcher::getStringSimilarity, PatternMatcher.cpp:197-204
+static __device__ float wave_similarity(const uint8_t *s1, int n, const uint8_t *s2, int m,
+                                        uint16_t *rowA, uint16_t *rowB, int lane)
+{
+    float max_length = (float)(n > m ? n : m);
+    if (n < 3 || m < 3) return 0.0f;
+    float edit_distance = (float)wave_lev(s1, n, s2, m, rowA, rowB, lane);
+    return (float)(1.0 - (double)(edit_distance / max_length));
+}
+
+// std::string::substr(pos, n) length: throws if pos > size
+static __device__ __forceinline__ bool substr_len(int L, uint32_t pos, uint32_t n, uint32_t &len)
+{
+    if (pos > (uint32_t)L) return false;
+    uint32_t avail = (uint32_t)L - pos;
+    len = n < avail ? n : avail;
+    return true;
+}
+
+// qcFoundRepeats, libcrispr.cpp:869-1029.  1 pass / 0 fail / -1 reference would throw.
+// Internal spacer i (getAllSpacerStrings, ReadHolder.cpp:199-239) = seq[ss[2i+1]+1, ss[2i+2]).
+static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacerLength, int lane)
+{
+    const int num_repeats = h.nss / 2;
+    if (num_repeats < 2) return -1;
+    uint32_t rep_len;
+    if (!substr_len(h.L, h.ss[0], h.ss[1] - h.ss[0] + 1, rep_len)) return -1;
+    const uint8_t *repeat = h.seq + h.ss[0];
+    if (is_low_complexity(repeat, (int)rep_len, lane)) return 0;
+
+    bool is_short = (2 > (num_repeats - 1));
+    if (!is_short) {
+        float ave_spacer_to_spacer_len_difference = 0.0f;
+        float ave_repeat_to_spacer_len_difference = 0.0f;
+        float ave_spacer_to_spacer_difference = 0.0f;
+        float ave_repeat_to_spacer_difference = 0.0f;
+        int min_spacer_length = 10000000;
+        int max_spacer_length = 0;
+        int num_compared = 0;
+        const int nsp = num_repeats - 1;
+        uint32_t cur_start = h.ss[1] + 1, cur_len;
+        if (!substr_len(h.L, cur_start, h.ss[2] - cur_start, cur_len)) return -1;
+        for (int i = 0; i < nsp; i++) {
+            if ((int)cur_len < min_spacer_length) min_spacer_length = (int)cur_len;
+            if ((int)cur_len > max_spacer_length) max_spacer_length = (int)cur_len;
+            if (i + 1 < nsp) {
+                uint32_t nxt_start = h.ss[2 * i + 3] + 1, nxt_len;
+                if (!substr_len(h.L, nxt_start, h.ss[2 * i + 4] - nxt_start, nxt_len)) return -1;
+                num_compared++;
+                ave_repeat_to_spacer_difference += wave_similarity(repeat, (int)rep_len, h.seq + cur_start, (int)cur_len, h.rowA, h.rowB, lane);
+                float ss_diff = 0;
+                ss_diff += wave_similarity(h.seq + cur_start, (int)cur_len, h.seq + nxt_start, (int)nxt_len, h.rowA, h.rowB, lane);
+                ave_spacer_to_spacer_difference += ss_diff;
+                ave_spacer_to_spacer_len_difference += ((float)cur_len - (float)nxt_len);
+                ave_repeat_to_spacer_len_difference += ((float)rep_len - (float)cur_len);
+                cur_start = nxt_start; cur_len = nxt_len;
+            }
+        }
+        // num_compared == nsp-1 >= 1 here (the reference's num_compared == 0 branch needs <2 spacers)
+        ave_spacer_to_spacer_difference /= (float)num_compared;
+        ave_repeat_to_spacer_difference /= (float)num_compared;
+        ave_spacer_to_spacer_len_difference /= (float)num_compared;
+        ave_spacer_to_spacer_len_difference = fabsf(ave_spacer_to_spacer_len_difference);
+        ave_repeat_to_spacer_len_difference /= (float)num_compared;
+        ave_repeat_to_spacer_len_difference = fabsf(ave_repeat_to_spacer_len_difference);
+        if (min_spacer_length < minSpacerLength) return 0;                 // testSpacerLength :773-800
+        if (max_spacer_length > maxSpacerLength) return 0;
+        if ((double)ave_spacer_to_spacer_difference > 0.82) return 0;      // :802-834
+        if ((double)ave_repeat_to_spacer_difference > 0.82) return 0;
+        if ((int)ave_spacer_to_spacer_len_difference > 12) return 0;       // int parameter: truncation (:836)
+        if ((int)ave_repeat_to_spacer_len_difference > 30) return 0;       // (:853)
+    }
+    if (is_short) {
+        // spacerStringAt(0), ReadHolder.cpp:102-147 — one base short
+        uint32_t s = h.ss[1] + 1;
+        uint32_t e = h.ss[2] - 1;
+        uint32_t sp_len;
+        if (!substr_len(h.L, s, e - s, sp_len)) return -1;
+        if ((int)sp_len < minSpacerLength) return 0;
+        if ((int)sp_len > maxSpacerLength) return 0;
+        float similarity = wave_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, h.rowA, h.rowB, lane);
+        if ((double)similarity > 0.82) return 0;
+        int dlen = (int)sp_len - (int)rep_len;
+        if (dlen < 0) dlen = -dlen;
+        if (dlen > 30) return 0;
+    }
+    return 1;
+}
+
+// searchCore, libcrispr.cpp:265-395.  1 found / 0 not / <0 error
+static __device__ int search_core(RH &h, const DevParams &o, int lane)
+{
+    const uint32_t seq_length = (uint32_t)h.L;
+    const uint32_t skips = o.skips;
+    int searchEnd = (int)(seq_length - o.lowDR - o.lowSp - o.window - 1);
+    if (searchEnd < 0) return 0;
+    h.nss = 0;
+    for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
+        uint32_t beginSearch = j + o.lowDR + o.lowSp;
+        uint32_t endSearch = j + o.highDR + o.highSp + o.window;
+        if (endSearch >= seq_length) endSearch = seq_length - 1;
+        if (endSearch < beginSearch) endSearch = beginSearch;
+        if (beginSearch > seq_length) return -1;                       // substr would throw
+        int pos = wave_find(h.seq, (int)beginSearch, (int)endSearch, (int)j, (int)o.window, lane);
+        if (pos >= 0) {
+            rh_add(h, j, j + o.window - 1, lane);
+            rh_add(h, (uint32_t)pos, (uint32_t)pos + o.window - 1, lane);
+            if (h.err) return -2;
+            scan_right(h, (int)j, o.window, o.lowSp, 24, lane);
+            if (h.err) return -2;
+        }
+        if ((uint32_t)(h.nss / 2) >= o.minRepeats) {
+            uint32_t actual_repeat_length = extend_pre_repeat(h, (int)o.window, (int)o.lowSp, lane);
+            if ((actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {
+                int qc = qc_found_repeats(h, (int)o.lowSp, (int)o.highSp, lane);
+                if (qc < 0) return -1;
+                if (qc) return 1;
+            }
+            j = h.ss[h.nss - 1] - 1;
+        }
+        h.nss = 0;
+        wave_sync();
+        if (j + skips < j) break;      // uint32 wrap ends the reference's loop as well (j > searchEnd)
+    }
+    return 0;
+}
+
+// ReadHolder::DRLowLexi + reverseStartStops (ReadHolder.cpp:513-591, 321-380).  Writes the
+// low-lexi DR to dr_out (global), mirrors ss in LDS if the read is flipped; returns dr length
+// (<0 error) and the RH_WasLowLexi flag.
+static __device__ int dr_low_lexi(RH &h, char *dr_out, int &was_low_lexi, int lane)
+{
+    const int num_repeats = h.nss / 2;
+    int pick;
+    if (num_repeats == 1) pick = 0;
+    else if (num_repeats == 2) {
+        if (h.ss[0] == 0) pick = 2;
+        else if (h.ss[h.nss - 1] == (uint32_t)h.L) pick = 0;          // dead branch, kept (:541)
+        else {
+            int lenA = (int)(h.ss[1] - h.ss[0]);
+            int lenB = (int)(h.ss[3] - h.ss[2]);
+            pick = (lenA > lenB) ? 0 : 2;
+        }
+    } else pick = 2;
+    uint32_t dlen;
+    if (!substr_len(h.L, h.ss[pick], h.ss[pick + 1] - h.ss[pick] + 1, dlen)) return -1;
+    const uint8_t *dr = h.seq + h.ss[pick];
+    // tmp_dr < rev_comp ?  (std::string operator<, unsigned bytes; equal => not less => flip)
+    int less = 0;
+    for (int i0 = 0; i0 < (int)dlen; i0 += WAVE) {
+        int i = i0 + lane;
+        uint8_t a = 0, b = 0;
+        if (i < (int)dlen) { a = dr[i]; b = c_comp[dr[dlen - 1 - i] & 127]; }
+        uint64_t m = __ballot(a != b);
+        if (m) {
+            int f = __ffsll((unsigned long long)m) - 1;
+            int av = __shfl((int)a, f), bv = __shfl((int)b, f);
+            less = av < bv;
+            break;
+        }
+    }
+    if (less) {
+        for (int i = lane; i < (int)dlen; i += WAVE) dr_out[i] = (char)dr[i];
+        was_low_lexi = 1;
+    } else {
+        for (int i = lane; i < (int)dlen; i += WAVE) dr_out[i] = (char)c_comp[dr[dlen - 1 - i] & 127];
+        // reverseStartStops: new[k] = L-1 - ss[nss-1-k]
+        wave_sync();
+        for (int k0 = 0; k0 < h.nss; k0 += WAVE) {       // read everything of a chunk pair-wise before writing
+            int k = k0 + lane;
+            int mirror = h.nss - 1 - k;
+            // swap in place: handle k < mirror pairs only
+            if (k < h.nss && k < mirror) {
+                uint32_t a = h.ss[k], b = h.ss[mirror];
+                h.ss[k] = (uint32_t)h.L - 1 - b;
+                h.ss[mirror] = (uint32_t)h.L - 1 - a;
+            }
+        }
+        wave_sync();
+        was_low_lexi = 0;
+    }
+    return (int)dlen;
+}
+
+static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *seq, int L, int lane)
+{
+    const uint32_t *g = R.packed + rd_word_off(R, r);
+    const uint32_t lut = ('A') | ('C' << 8) | ('G' << 16) | ('T' << 24);
+    const int nw = (L + 15) >> 4;
+    for (int wi = lane; wi < nw; wi += WAVE) {
+        uint32_t v = g[wi];
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t c = (v >> (2 * (4 * q + k))) & 3u;
+                x |= ((lut >> (8 * c)) & 0xFFu) << (8 * k);
+            }
+            o[q] = x;
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(seq + 16 * wi);   // seq region is 16-B aligned and padded
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+    }
+}
+
+template <bool EXC>
+__global__ __launch_bounds__(WAVE) void k_survivor(DevReads R, DevParams P, const uint64_t *surv_idx,
+                                                   const uint32_t *d_n_surv, uint64_t n_max, SurvOut *out,
+                                                   char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
+                                                   uint32_t ss_pool_cap, uint32_t *d_ss_used,
+                                                   uint8_t *found_flag, SurvLds lds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sv_lds[];
+    const int lane = threadIdx.x;
+    RH h;
+    h.seq = sv_lds;
+    h.ss = reinterpret_cast<uint32_t *>(sv_lds + lds.seq_bytes);
+    h.cap = (int)lds.ss_cap;
+    h.rowA = reinterpret_cast<uint16_t *>(h.ss + lds.ss_cap);
+    h.rowB = h.rowA + lds.row_elems;
+    uint64_t n_surv = EXC ? R.n_exc : (uint64_t)(*d_n_surv);
+    if (n_surv > n_max) n_surv = n_max;
+    for (uint64_t s = blockIdx.x; s < n_surv; s += gridDim.x) {
+        uint64_t r;
+        int L;
+        wave_sync();
+        if (EXC) {
+            r = R.exc_read[s];
+            uint64_t o0 = R.exc_off[s];
+            L = (int)(R.exc_off[s + 1] - o0);
+            for (int i = lane; i < L; i += WAVE) h.seq[i] = R.exc_bytes[o0 + i];
+        } else {
+            r = surv_idx[s];
+            L = (int)rd_len(R, r);
+            load_read_to_lds(R, r, h.seq, L, lane);
+        }
+        wave_sync();
+        h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
+        int f = search_core(h, P, lane);
+        SurvOut o;
+        o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
+        if (f < 0) o.err = (f == -2) ? 2 : 1;
+        if (f == 1) {
+            int low = 0;
+            int dlen = dr_low_lexi(h, dr_chars + s * (uint64_t)dr_stride, low, lane);
+            if (dlen < 0 || dlen > (int)dr_stride) o.err = 1;
+            else {
+                uint32_t off = 0;
+                if (lane == 0) off = atomicAdd(d_ss_used, (uint32_t)h.nss);
+                off = (uint32_t)__shfl((int)off, 0);
+                if ((uint64_t)off + (uint64_t)h.nss > ss_pool_cap) o.err = 3;
+                else {
+                    for (int k = lane; k < h.nss; k += WAVE) ss_pool[off + k] = h.ss[k];
+                    o.found = 1; o.n_ss = (uint32_t)h.nss; o.repeat_len = (uint32_t)h.replen;
+                    o.ss_off = off; o.dr_len = (uint16_t)dlen; o.low_lexi = (uint8_t)low;
+                    if (lane == 0) found_flag[rd_header_id(R, r)] = 1;      // readsFound[header] = true (:138)
+                }
+            }
+        }
+        if (lane == 0) out[s] = o;
+    }
+}
+
+SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P)
+{
+    SurvLds l;
+    l.seq_bytes = ((max_len + 16 + 16) + 15u) & ~15u;
+    uint32_t reps = max_len / (P.window + P.lowSp) + 4;
+    l.ss_cap = ((2 * reps) + 3u) & ~3u;
+    l.row_elems = ((max_len + 8) + 7u) & ~7u;
+    l.total_bytes = l.seq_bytes + l.ss_cap * 4 + 2 * l.row_elems * 2;
+    return l;
+}
+
+hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exceptions, const uint64_t *surv_idx,
+                           const uint32_t *d_n_surv, uint64_t n_surv_max, SurvOut *out, char *dr_chars,
+                           uint32_t dr_stride, uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
+                           uint8_t *found_flag, const SurvLds &lds, int grid, hipStream_t st)
+{
+    if (n_surv_max == 0) return hipSuccess;
+    hipError_t e;
+    if (exceptions) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_survivor<true>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, lds);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_survivor<false>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, lds);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// pass 2: first-match multi-pattern scan (findSingletons/on_match semantics: the first ACISM
+// callback = occurrence with the smallest end position, ties -> longest pattern;
+// libcrispr.cpp:441, acism.c:73-102).  Lane per read, 64 consecutive reads per wave so the
+// ballot is the mask word.  hit_info[r] = (end_exclusive << 8) | pattern_length.
+// ------------------------------------------------------------------------------------
+template <bool LDS_TABLE>
+__global__ __launch_bounds__(256) void k_recruit(DevReads R, DevAutomaton A, const uint8_t *found_flag,
+                                                 uint64_t *hitmask, uint32_t *hit_info)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t rc_lds[];
+    const uint16_t *go4 = A.go4;
+    const uint16_t *outl = A.out_len;
+    if (LDS_TABLE) {
+        // stage [n_states][4] transitions + out_len in LDS
+        uint16_t *l_go = rc_lds;
+        uint16_t *l_out = rc_lds + (size_t)A.n_states * 4;
+        for (uint32_t i = threadIdx.x; i < A.n_states * 4; i += blockDim.x) l_go[i] = A.go4[i];
+        for (uint32_t i = threadIdx.x; i < A.n_states; i += blockDim.x) l_out[i] = A.out_len[i];
+        __syncthreads();
+        go4 = l_go; outl = l_out;
+    }
+    const uint64_t n_tiles = (R.n_reads + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_global = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave_total = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_total) {
+        const uint64_t r = tile * 64 + lane;
+        bool hit = false;
+        if (r < R.n_reads && !rd_is_exc(R, r) && !found_flag[rd_header_id(R, r)]) {
+            const uint32_t L = rd_len(R, r);
+            const uint32_t *g = R.packed + rd_word_off(R, r);
+            uint32_t state = 0;
+            uint32_t word = 0;
+            for (uint32_t i = 0; i < L; i++) {
+                if ((i & 15u) == 0) word = g[i >> 4];
+                uint32_t c = word & 3u;
+                word >>= 2;
+                state = go4[state * 4 + c];
+                uint32_t ol = outl[state];
+                if (ol) { hit_info[r] = ((i + 1) << 8) | ol; hit = true; break; }
+            }
+        }
+        uint64_t m = __ballot(hit);
+        if (lane == 0) hitmask[tile] = m;
+    }
+}
+
+// generic transition tables (any symbol count / state count), global memory
+__global__ __launch_bounds__(256) void k_recruit_wide(DevReads R, DevAutomaton A, const uint8_t *found_flag,
+                                                       uint64_t *hitmask, uint32_t *hit_info)
+{
+    const uint64_t n_tiles = (R.n_reads + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_global = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave_total = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t symA = A.sym['A'], symC = A.sym['C'], symG = A.sym['G'], symT = A.sym['T'];
+    for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_total) {
+        const uint64_t r = tile * 64 + lane;
+        bool hit = false;
+        if (r < R.n_reads && !rd_is_exc(R, r) && !found_flag[rd_header_id(R, r)]) {
+            const uint32_t L = rd_len(R, r);
+            const uint32_t *g = R.packed + rd_word_off(R, r);
+            uint32_t state = 0, word = 0;
+            for (uint32_t i = 0; i < L; i++) {
+                if ((i & 15u) == 0) word = g[i >> 4];
+                uint32_t c = word & 3u;
+                word >>= 2;
+                uint32_t sy = c == 0 ? symA : c == 1 ? symC : c == 2 ? symG : symT;
+                state = A.go16 ? (uint32_t)A.go16[(size_t)state * A.n_sym1 + sy] : A.go32[(size_t)state * A.n_sym1 + sy];
+                uint32_t ol = A.out_len[state];
+                if (ol) { hit_info[r] = ((i + 1) << 8) | ol; hit = true; break; }
+            }
+        }
+        uint64_t m = __ballot(hit);
+        if (lane == 0) hitmask[tile] = m;
+    }
+}
+
+hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
+                                  uint64_t *hitmask, uint32_t *hit_info, hipStream_t st)
+{
+    if (R.n_reads == 0) return hipSuccess;
+    uint64_t n_tiles = (R.n_reads + 63) / 64;
+    uint64_t blocks = (n_tiles + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (A.acgt_ok && A.go4)
+        hipLaunchKernelGGL(k_recruit<false>, dim3((unsigned)blocks), dim3(256), 0, st, R, A, found_flag, hitmask, hit_info);
+    else
+        hipLaunchKernelGGL(k_recruit_wide, dim3((unsigned)blocks), dim3(256), 0, st, R, A, found_flag, hitmask, hit_info);
+    return hipGetLastError();
+}
+
+hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
+                              uint64_t *hitmask, uint32_t *hit_info, hipStream_t st)
+{
+    if (R.n_reads == 0) return hipSuccess;
+    if (!A.acgt_ok || !A.go4) return hipErrorNotSupported;
+    size_t lds = (size_t)A.n_states * 10;       // 4 x u16 transitions + u16 out_len
+    if (lds > 160 * 1024) return hipErrorNotSupported;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recruit<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    uint64_t n_tiles = (R.n_reads + 63) / 64;
+    // one workgroup per CU-slot; LDS footprint decides how many fit, so size the block to fill the CU
+    int threads = lds > 80 * 1024 ? 1024 : (lds > 40 * 1024 ? 512 : 256);
+    uint64_t waves_per_block = threads / 64;
+    uint64_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
+    uint64_t cap = lds > 80 * 1024 ? 256 : (lds > 40 * 1024 ? 512 : (lds > 20 * 1024 ? 1024 : 2048));
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_recruit<true>, dim3((unsigned)blocks), dim3(threads), lds, st, R, A, found_flag, hitmask, hit_info);
+    return hipGetLastError();
+}
+
+// exception reads: raw bytes through the byte-symbol automaton, lane per exception read
+__global__ __launch_bounds__(256) void k_recruit_exc(DevReads R, DevAutomaton A, const uint8_t *found_flag, uint32_t *exc_hit_info)
+{
+    uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (s >= R.n_exc) return;
+    uint64_t r = R.exc_read[s];
+    uint32_t info = 0;
+    if (!found_flag[rd_header_id(R, r)]) {
+        uint64_t o0 = R.exc_off[s];
+        uint32_t L = (uint32_t)(R.exc_off[s + 1] - o0);
+        uint32_t state = 0;
+        for (uint32_t i = 0; i < L; i++) {
+            uint32_t sy = A.sym[R.exc_bytes[o0 + i]];
+            state = A.go16 ? (uint32_t)A.go16[(size_t)state * A.n_sym1 + sy] : A.go32[(size_t)state * A.n_sym1 + sy];
+            uint32_t ol = A.out_len[state];
+            if (ol) { info = ((i + 1) << 8) | ol; break; }
+        }
+    }
+    exc_hit_info[s] = info;
+}
+
+hipError_t launch_recruit_exceptions(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
+                                     uint32_t *exc_hit_info, hipStream_t st)
+{
+    if (R.n_exc == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_recruit_exc, dim3((unsigned)((R.n_exc + 255) / 256)), dim3(256), 0, st, R, A, found_flag, exc_hit_info);
+    return hipGetLastError();
+}
+
+// on_match + addReadHolder's DRLowLexi for the single recruited repeat
+// (libcrispr.cpp:408-442, ReadHolder.cpp:524-528,573-590).  Thread per hit.
+template <bool EXC>
+__global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64_t *hit_idx, const uint32_t *d_n_hits,
+                                                        uint64_t n_max, const uint32_t *hit_info, RecruitOut *out,
+                                                        char *dr_chars, uint32_t dr_stride)
+{
+    uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t n = EXC ? R.n_exc : (uint64_t)(*d_n_hits);
+    if (n > n_max) n = n_max;
+    if (k >= n) return;
+    RecruitOut o; o.start = 0; o.end = 0; o.dr_len = 0; o.low_lexi = 0; o.pad = 0;
+    uint32_t info;
+    uint32_t L;
+    uint64_t r = 0, o0 = 0;
+    const uint32_t *g = nullptr;
+    if (EXC) {
+        info = hit_info[k];
+        o0 = R.exc_off[k];
+        L = (uint32_t)(R.exc_off[k + 1] - o0);
+    } else {
+        r = hit_idx[k];
+        info = hit_info[r];
+        L = rd_len(R, r);
+        g = R.packed + rd_word_off(R, r);
+    }
+    if (info == 0) { out[k] = o; return; }              // EXC only: no match for this exception read
+    uint32_t textpos = info >> 8, len = info & 0xFFu;
+    uint32_t DR_end = textpos - 1;
+    if (DR_end >= L) DR_end = L - 1;
+    uint32_t start = DR_end - (len - 1);
+    auto base_at = [&](uint32_t i) -> uint8_t {
+        if (EXC) return R.exc_bytes[o0 + i];
+        uint32_t c = (g[i >> 4] >> ((i & 15u) * 2u)) & 3u;
+        return (uint8_t)("ACGT"[c]);
+    };
+    int less = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        uint8_t a = base_at(start + i);
+        uint8_t b = c_comp[base_at(start + len - 1 - i) & 127];
+        if (a != b) { less = a < b; break; }
+    }
+    char *dr = dr_chars + k * (uint64_t)dr_stride;
+    if (less) {
+        for (uint32_t i = 0; i < len; i++) dr[i] = (char)base_at(start + i);
+        o.start = start; o.end = DR_end; o.low_lexi = 1;
+    } else {
+        for (uint32_t i = 0; i < len; i++) dr[i] = (char)c_comp[base_at(start + len - 1 - i) & 127];
+        o.start = L - 1 - DR_end; o.end = L - 1 - start; o.low_lexi = 0;
+    }
+    o.dr_len = (uint16_t)len;
+    out[k] = o;
+}
+
+hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, const uint32_t *d_n_hits, uint64_t n_hits_max,
+                                 const uint32_t *hit_info, bool exceptions, RecruitOut *out, char *dr_chars,
+                                 uint32_t dr_stride, hipStream_t st)
+{
+    if (n_hits_max == 0) return hipSuccess;
+    unsigned nb = (unsigned)((n_hits_max + 255) / 256);
+    if (exceptions)
+        hipLaunchKernelGGL(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, out, dr_chars, dr_stride);
+    else
+        hipLaunchKernelGGL(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, out, dr_chars, dr_stride);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Levenshtein / similarity batch: one wave per string pair
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_lev_batch(const uint8_t *chars, const uint64_t *a_off, const uint32_t *a_len,
+                                                     const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,
+                                                     int32_t *dist, float *sim, uint32_t row_elems, uint32_t str_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lv_lds[];
+    uint8_t *sa = lv_lds;
+    uint8_t *sb = lv_lds + str_bytes;
+    uint16_t *rowA = reinterpret_cast<uint16_t *>(lv_lds + 2 * (size_t)str_bytes);
+    uint16_t *rowB = rowA + row_elems;
+    const int lane = threadIdx.x;
+    for (uint64_t k = blockIdx.x; k < n_pairs; k += gridDim.x) {
+        int n = (int)a_len[k], m = (int)b_len[k];
+        wave_sync();
+        for (int i = lane; i < n; i += WAVE) sa[i] = chars[a_off[k] + i];
+        for (int i = lane; i < m; i += WAVE) sb[i] = chars[b_off[k] + i];
+        wave_sync();
+        int d = wave_lev(sa, n, sb, m, rowA, rowB, lane);
+        float s = 0.0f;
+        if (sim) s = wave_similarity(sa, n, sb, m, rowA, rowB, lane);
+        if (lane == 0) { if (dist) dist[k] = d; if (sim) sim[k] = s; }
+    }
+}
+
+hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off, const uint32_t *a_len,
+                                    const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,
+                                    int32_t *dist, float *sim, uint32_t max_len, hipStream_t st)
+{
+    if (n_pairs == 0) return hipSuccess;
+    uint32_t str_bytes = (max_len + 16 + 15u) & ~15u;
+    uint32_t row_elems = ((max_len + 8) + 7u) & ~7u;
+    size_t lds = 2 * (size_t)str_bytes + 2 * (size_t)row_elems * 2;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lev_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    uint64_t grid = n_pairs < 4096 ? n_pairs : 4096;
+    hipLaunchKernelGGL(k_lev_batch, dim3((unsigned)grid), dim3(WAVE), lds, st, chars, a_off, a_len, b_off, b_len, n_pairs, dist, sim, row_elems, str_bytes);
+    return hipGetLastError();
+}
+
+hipError_t upload_comp_table(const unsigned char *tab128)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_comp), tab128, 128);
+}
+
+} // namespace crass

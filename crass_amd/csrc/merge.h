@@ -1,0 +1,57 @@
+// merge.h — host side of the boundary: token registry (StringCheck), DR-variant clustering
+// and the non-redundant pattern set (WorkHorse::createNonRedundantSet), plus the pass-2
+// automaton builder.  Plain C++17, no HIP.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <unordered_map>
+
+namespace crass {
+
+void build_comp_table(unsigned char tab[128]);                 // SeqUtils.cpp:50-59
+std::string reverse_complement(const std::string &s);          // SeqUtils.cpp:61-87
+
+// StringCheck (StringCheck.h:52-71, StringCheck.cpp:46-81): first token is 2, discovery order
+struct TokenTable {
+    std::vector<std::string> strings;                          // token t -> strings[t-2]
+    std::unordered_map<std::string, uint32_t> s2t;
+    uint32_t get(const std::string &s) const { auto it = s2t.find(s); return it == s2t.end() ? 0u : it->second; }
+    uint32_t add(const std::string &s) { strings.push_back(s); uint32_t t = (uint32_t)strings.size() + 1; s2t.emplace(s, t); return t; }
+    uint32_t size() const { return (uint32_t)strings.size(); }
+    void clear() { strings.clear(); s2t.clear(); }
+};
+
+struct MergeResult {
+    TokenTable tokens;
+    std::vector<uint32_t> cand_token;                          // token of every candidate fed in
+    std::vector<std::vector<uint32_t>> groups;                 // mDR2GIDMap: groups[g] = tokens of GID g+1
+    std::vector<std::string> patterns;                         // createNonRedundantSet's Vecstr
+    std::vector<uint32_t> pat_group;
+    int next_free_gid = 1;
+    // flat copies for the C views
+    std::vector<char> tok_chars; std::vector<uint64_t> tok_off;
+    std::vector<uint32_t> grp_tokens; std::vector<uint64_t> grp_off;
+    std::vector<char> pat_chars; std::vector<uint64_t> pat_off;
+    void flatten();
+    void clear();
+};
+
+// addReadHolder's token assignment (libcrispr.cpp:1137-1143) for every candidate DR in read
+// order, then createNonRedundantSet (WorkHorse.cpp:648-709).
+void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
+                      uint64_t n, int kmer_clust_size);
+
+// byte-wise Aho-Corasick with fully resolved goto; semantics of acism_create + the first
+// callback of acism_scan (acism_create.c:71-392, acism.c:25-106)
+struct HostAutomaton {
+    uint32_t n_states = 0, n_sym1 = 1;
+    uint8_t sym[256];
+    std::vector<uint32_t> go;          // [n_states][n_sym1]
+    std::vector<uint16_t> out_len;     // longest pattern ending at the state
+    std::vector<uint16_t> go4;         // [n_states][4] for A,C,G,T (empty if n_states > 65535)
+    uint32_t max_pat_len = 0;
+};
+void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns);
+
+} // namespace crass

@@ -1,0 +1,425 @@
+"""Python host layer over the C ABI (include/crass_hip.h).
+
+Used by the tests, bench.py and the multi-GPU driver (torch.distributed is plumbing only).
+The compiled C++ adapter with the reference's own function shapes (searchFile /
+createNonRedundantSet / findSingletons / addReadHolder) lives in csrc/adapter/ — see
+INTEGRATION.md.  Nothing here computes search results on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+class CrassError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = _abi.load().crass_hip_strerror(status).decode()
+        super().__init__("%s: %s (status %d)" % (where or "crass_hip", msg, status))
+
+
+def _chk(status, where):
+    if status != 0:
+        raise CrassError(status, where)
+
+
+def default_params(**kw):
+    p = _abi.Params()
+    _abi.load().crass_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _np(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(int(n),)).view(dtype).copy()
+
+
+def concat(items):
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    if items:
+        off[1:] = np.cumsum([len(s) for s in items], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(items), dtype=np.uint8).copy() if items else np.zeros(0, np.uint8)
+    return buf, off
+
+
+class PackedReads:
+    """2-bit packed reads + exception list produced by the C++ packer (crass_pack_reads)."""
+
+    def __init__(self, seqs, pad_uniform=False):
+        lib = _abi.load()
+        if isinstance(seqs, (list, tuple)) and (not seqs or isinstance(seqs[0], (bytes, bytearray))):
+            buf, off = concat(list(seqs))
+        else:
+            buf, off = seqs
+        self._src = (buf, off)
+        self.p = _abi.Packed()
+        _chk(lib.crass_pack_reads(buf.ctypes.data, off.ctypes.data, len(off) - 1, int(pad_uniform), C.byref(self.p)),
+             "crass_pack_reads")
+        self.header_id = None
+
+    @property
+    def reads(self):
+        return self.p.reads
+
+    @property
+    def n_reads(self):
+        return int(self.p.reads.n_reads)
+
+    def packed_array(self):
+        r = self.p.reads
+        if r.stride_words:
+            n = int(r.n_reads) * int(r.stride_words)
+        else:
+            raise ValueError("ragged layout")
+        return np.ctypeslib.as_array(C.cast(r.packed, _abi.u32p), shape=(n,))
+
+    def close(self):
+        if self.p.owner:
+            _abi.load().crass_free_packed(C.byref(self.p))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FastxFile:
+    """FASTA/FASTQ(.gz) records with kseq_read semantics (C++ reader, crass_read_fastx)."""
+
+    def __init__(self, path):
+        lib = _abi.load()
+        f = _abi.Fastx()
+        _chk(lib.crass_read_fastx(str(path).encode(), C.byref(f)), "crass_read_fastx(%s)" % path)
+        n = int(f.n_reads)
+        self.n_reads = n
+        self.max_len = int(f.max_len)
+        self.last_ret = int(f.last_ret)
+        self.seq_off = _np(f.seq_off, n + 1, np.uint64)
+        self.seq = _np(f.seq, int(self.seq_off[-1]), np.uint8)
+        self.name_off = _np(f.name_off, n + 1, np.uint64)
+        self.name = _np(f.name, int(self.name_off[-1]), np.uint8)
+        self.comment_off = _np(f.comment_off, n + 1, np.uint64)
+        self.comment = _np(f.comment, int(self.comment_off[-1]), np.uint8)
+        self.has_comment = _np(f.has_comment, n, np.uint8)
+        self.qual_off = _np(f.qual_off, n + 1, np.uint64)
+        self.qual = _np(f.qual, int(self.qual_off[-1]), np.uint8)
+        self.has_qual = _np(f.has_qual, n, np.uint8)
+        self.header_id = _np(f.header_id, n, np.uint64)
+        lib.crass_free_fastx(C.byref(f))
+
+    def _field(self, buf, off, i):
+        return buf[int(off[i]):int(off[i + 1])].tobytes()
+
+    def record(self, i):
+        return (self._field(self.name, self.name_off, i),
+                self._field(self.comment, self.comment_off, i) if self.has_comment[i] else None,
+                self._field(self.seq, self.seq_off, i),
+                self._field(self.qual, self.qual_off, i) if self.has_qual[i] else None)
+
+    def records(self):
+        return [self.record(i) for i in range(self.n_reads)]
+
+    def unique_headers(self):
+        return bool(np.all(self.header_id == np.arange(self.n_reads, dtype=np.uint64)))
+
+
+def synth_spec(**kw):
+    s = _abi.SynthSpec()
+    _abi.load().crass_synth_default(C.byref(s))
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise AttributeError(k)
+        setattr(s, k, v)
+    return s
+
+
+def synth_packed(spec, first_read, n_reads, out=None, n_threads=0):
+    """Deterministic synthetic reads [first_read, first_read+n_reads) as packed uint32 words
+    (uniform stride ceil(L/16)).  `out` may be a preallocated (e.g. pinned) uint32 array."""
+    W = (spec.read_len + 15) // 16
+    if out is None:
+        out = np.empty(int(n_reads) * W, dtype=np.uint32)
+    assert out.dtype == np.uint32 and out.size >= int(n_reads) * W
+    _chk(_abi.load().crass_synth_packed(C.byref(spec), int(first_read), int(n_reads), out.ctypes.data, int(n_threads)),
+         "crass_synth_packed")
+    return out
+
+
+def unpack_ascii(packed, stride_words, read_len, n_reads):
+    out = np.empty(int(n_reads) * int(read_len), dtype=np.uint8)
+    _chk(_abi.load().crass_unpack_ascii(packed.ctypes.data, int(stride_words), int(read_len), int(n_reads),
+                                        out.ctypes.data), "crass_unpack_ascii")
+    return out
+
+
+class CandidateSet:
+    def __init__(self, v):
+        n = int(v.n)
+        self.n = n
+        self.read_idx = _np(v.read_idx, n, np.uint64)
+        self.low_lexi = _np(v.low_lexi, n, np.uint8)
+        self.repeat_len = _np(v.repeat_len, n, np.uint32)
+        self.n_ss = _np(v.n_ss, n, np.uint32)
+        self.ss_off = _np(v.ss_off, n, np.uint64)
+        self.ss_pool = _np(v.ss_pool, int(self.n_ss.sum()), np.uint32)
+        self.dr_stride = int(v.dr_stride)
+        self.dr_len = _np(v.dr_len, n, np.uint16)
+        self.dr_chars = _np(C.cast(v.dr_chars, _abi.u8p), n * self.dr_stride, np.uint8)
+        self.max_read_len = int(v.max_read_len)
+
+    def ss(self, k):
+        o = int(self.ss_off[k])
+        return self.ss_pool[o:o + int(self.n_ss[k])].tolist()
+
+    def dr(self, k):
+        o = k * self.dr_stride
+        return self.dr_chars[o:o + int(self.dr_len[k])].tobytes()
+
+
+class MergeResult:
+    def __init__(self, v):
+        self.n_tokens = int(v.n_tokens)
+        self.tok_off = _np(v.tok_off, self.n_tokens + 1, np.uint64)
+        tc = C.string_at(v.tok_chars, int(self.tok_off[-1])) if self.n_tokens else b""
+        self.tokens = [tc[int(self.tok_off[i]):int(self.tok_off[i + 1])] for i in range(self.n_tokens)]
+        self.cand_token = _np(v.cand_token, int(v.n_candidates), np.uint32)
+        self.n_groups = int(v.n_groups)
+        self.grp_off = _np(v.grp_off, self.n_groups + 1, np.uint64)
+        gt = _np(v.grp_tokens, int(self.grp_off[-1]) if self.n_groups else 0, np.uint32)
+        self.groups = [gt[int(self.grp_off[i]):int(self.grp_off[i + 1])].tolist() for i in range(self.n_groups)]
+        self.n_patterns = int(v.n_patterns)
+        self.pat_off = _np(v.pat_off, self.n_patterns + 1, np.uint64)
+        pc = C.string_at(v.pat_chars, int(self.pat_off[-1])) if self.n_patterns else b""
+        self.patterns = [pc[int(self.pat_off[i]):int(self.pat_off[i + 1])] for i in range(self.n_patterns)]
+        self.pat_group = _np(v.pat_group, self.n_patterns, np.uint32)
+        self.next_free_gid = int(v.next_free_gid)
+
+
+class RecruitSet:
+    def __init__(self, v):
+        n = int(v.n)
+        self.n = n
+        self.read_idx = _np(v.read_idx, n, np.uint64)
+        self.low_lexi = _np(v.low_lexi, n, np.uint8)
+        self.start = _np(v.start, n, np.uint32)
+        self.end = _np(v.end, n, np.uint32)
+        self.dr_stride = int(v.dr_stride)
+        self.dr_len = _np(v.dr_len, n, np.uint16)
+        self.dr_chars = _np(C.cast(v.dr_chars, _abi.u8p), n * self.dr_stride, np.uint8)
+        self.token = _np(v.token, n, np.uint32)
+
+    def dr(self, k):
+        o = k * self.dr_stride
+        return self.dr_chars[o:o + int(self.dr_len[k])].tobytes()
+
+
+class SearchEngine:
+    """One context per GPU (crass_hip_create).  Call order mirrors WorkHorse::parseSeqFiles
+    (WorkHorse.cpp:321-414): load_reads -> seed_scan (searchFile) -> merge
+    (createNonRedundantSet) -> recruit (findSingletons)."""
+
+    def __init__(self, params=None, device=0):
+        self.lib = _abi.load()
+        self.params = params or default_params()
+        h = C.c_void_p()
+        _chk(self.lib.crass_hip_create(C.byref(self.params), int(device), C.byref(h)), "crass_hip_create")
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.crass_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- reads ----
+    def load_reads(self, packed, header_id=None, read_index_base=0):
+        r = _abi.Reads()
+        C.memmove(C.byref(r), C.byref(packed.reads), C.sizeof(r))
+        hid = None
+        if header_id is not None:
+            hid = np.ascontiguousarray(header_id, dtype=np.uint64)
+            r.header_id = hid.ctypes.data
+        r.read_index_base = int(read_index_base)
+        _chk(self.lib.crass_hip_load_reads(self.h, C.byref(r)), "crass_hip_load_reads")
+        self._keep = (packed, hid)
+
+    def load_packed_uniform(self, words, n_reads, read_len, read_index_base=0):
+        """Host uint32 array of uniform-stride packed reads (synthetic generator output)."""
+        r = _abi.Reads()
+        r.n_reads = int(n_reads)
+        r.packed = words.ctypes.data
+        r.stride_words = (int(read_len) + 15) // 16
+        r.uniform_len = int(read_len)
+        r.read_index_base = int(read_index_base)
+        _chk(self.lib.crass_hip_load_reads(self.h, C.byref(r)), "crass_hip_load_reads")
+
+    def attach_device_tensor(self, tensor, n_reads, read_len, read_index_base=0):
+        """Zero-copy: a torch int32 CUDA tensor holding uniform-stride packed reads."""
+        r = _abi.Reads()
+        r.n_reads = int(n_reads)
+        r.packed = int(tensor.data_ptr())
+        r.stride_words = (int(read_len) + 15) // 16
+        r.uniform_len = int(read_len)
+        r.read_index_base = int(read_index_base)
+        _chk(self.lib.crass_hip_attach_device_reads(self.h, C.byref(r)), "crass_hip_attach_device_reads")
+        self._keep = tensor
+
+    # ---- passes ----
+    def seed_scan(self, fetch=True):
+        _chk(self.lib.crass_hip_seed_scan(self.h), "crass_hip_seed_scan")
+        return self.candidates() if fetch else None
+
+    def candidates(self):
+        v = _abi.Candidates()
+        _chk(self.lib.crass_hip_get_candidates(self.h, C.byref(v)), "crass_hip_get_candidates")
+        return CandidateSet(v)
+
+    def candidate_dr_view(self):
+        """(uint8 array [n, dr_stride], uint16 lengths) without copying the other fields."""
+        v = _abi.Candidates()
+        _chk(self.lib.crass_hip_get_candidates(self.h, C.byref(v)), "crass_hip_get_candidates")
+        n = int(v.n)
+        chars = _np(C.cast(v.dr_chars, _abi.u8p), n * int(v.dr_stride), np.uint8).reshape(n, int(v.dr_stride))
+        return chars, _np(v.dr_len, n, np.uint16)
+
+    def merge(self, dr_chars=None, dr_len=None, fetch=True):
+        """dr_chars: uint8 array [n, stride] of ALL candidates in global read order (multi-GPU),
+        or None for this context's own candidates."""
+        if dr_chars is None:
+            _chk(self.lib.crass_hip_merge(self.h, None, None, 0, 0), "crass_hip_merge")
+        else:
+            dr_chars = np.ascontiguousarray(dr_chars, dtype=np.uint8)
+            dr_len = np.ascontiguousarray(dr_len, dtype=np.uint16)
+            n = dr_chars.shape[0]
+            stride = dr_chars.shape[1] if n else 16
+            _chk(self.lib.crass_hip_merge(self.h, dr_chars.ctypes.data, dr_len.ctypes.data, int(stride), int(n)),
+                 "crass_hip_merge")
+        return self.merge_view() if fetch else None
+
+    def merge_view(self):
+        v = _abi.MergeView()
+        _chk(self.lib.crass_hip_get_merge(self.h, C.byref(v)), "crass_hip_get_merge")
+        return MergeResult(v)
+
+    def set_patterns(self, patterns):
+        arr = (C.c_char_p * len(patterns))(*patterns)
+        lens = (C.c_uint32 * len(patterns))(*[len(p) for p in patterns])
+        _chk(self.lib.crass_hip_set_patterns(self.h, arr, lens, len(patterns)), "crass_hip_set_patterns")
+
+    def recruit(self, extra_found=None, fetch=True):
+        if extra_found is not None and len(extra_found):
+            ef = np.ascontiguousarray(extra_found, dtype=np.uint64)
+            _chk(self.lib.crass_hip_recruit(self.h, ef.ctypes.data, len(ef)), "crass_hip_recruit")
+        else:
+            _chk(self.lib.crass_hip_recruit(self.h, None, 0), "crass_hip_recruit")
+        return self.recruits() if fetch else None
+
+    def recruits(self):
+        v = _abi.Recruits()
+        _chk(self.lib.crass_hip_get_recruits(self.h, C.byref(v)), "crass_hip_get_recruits")
+        return RecruitSet(v)
+
+    def counters(self):
+        c = _abi.Counters()
+        _chk(self.lib.crass_hip_get_counters(self.h, C.byref(c)), "crass_hip_get_counters")
+        return c.asdict()
+
+    def stream_handle(self):
+        return self.lib.crass_hip_stream(self.h)
+
+    def levenshtein_batch(self, pairs, want_similarity=True):
+        """pairs: list of (bytes, bytes) -> (int32 distances, float32 similarities)"""
+        items = []
+        a_off, a_len, b_off, b_len = [], [], [], []
+        pos = 0
+        for a, b in pairs:
+            a_off.append(pos); a_len.append(len(a)); items.append(a); pos += len(a)
+            b_off.append(pos); b_len.append(len(b)); items.append(b); pos += len(b)
+        chars = np.frombuffer(b"".join(items) + b"\0", dtype=np.uint8).copy()
+        a_off = np.array(a_off, np.uint64); b_off = np.array(b_off, np.uint64)
+        a_len = np.array(a_len, np.uint32); b_len = np.array(b_len, np.uint32)
+        dist = np.zeros(len(pairs), np.int32)
+        sim = np.zeros(len(pairs), np.float32)
+        _chk(self.lib.crass_hip_levenshtein_batch(self.h, chars.ctypes.data, pos, a_off.ctypes.data, a_len.ctypes.data,
+                                                  b_off.ctypes.data, b_len.ctypes.data, len(pairs), dist.ctypes.data,
+                                                  sim.ctypes.data if want_similarity else None),
+             "crass_hip_levenshtein_batch")
+        return dist, sim
+
+
+class PipelineResult:
+    """Same field names as tests/orc.PipelineResult so parity tests compare attribute by attribute."""
+
+    def __init__(self, cand, merge, rec, max_read_len):
+        self.n_pass1, self.n_pass2 = cand.n, rec.n
+        self.n_tokens, self.n_groups, self.n_patterns = merge.n_tokens, merge.n_groups, merge.n_patterns
+        self.max_read_len = max_read_len
+        self.error = 0
+        self.rec_read = np.concatenate([cand.read_idx, rec.read_idx])
+        self.rec_lowlexi = np.concatenate([cand.low_lexi, rec.low_lexi])
+        self.rec_token = np.concatenate([merge.cand_token[:cand.n] if len(merge.cand_token) == cand.n
+                                         else merge.cand_token, rec.token]).astype(np.uint32)
+        self.rec_replen = np.concatenate([cand.repeat_len, np.zeros(rec.n, np.uint32)])
+        self.rec_nss = np.concatenate([cand.n_ss, np.full(rec.n, 2, np.uint32)])
+        rec_ss = np.stack([rec.start, rec.end], axis=1).reshape(-1) if rec.n else np.zeros(0, np.uint32)
+        self.ss_pool = np.concatenate([cand.ss_pool, rec_ss]).astype(np.uint32)
+        off1 = cand.ss_off
+        base = int(cand.n_ss.sum())
+        off2 = base + 2 * np.arange(rec.n, dtype=np.uint64)
+        self.rec_ss_off = np.concatenate([off1, off2]).astype(np.uint64)
+        self.tokens, self.groups, self.patterns, self.pat_group = merge.tokens, merge.groups, merge.patterns, merge.pat_group
+        self.cand, self.merge, self.rec = cand, merge, rec
+
+    def ss(self, k):
+        o = int(self.rec_ss_off[k])
+        return self.ss_pool[o:o + int(self.rec_nss[k])].tolist()
+
+
+def search_pipeline(seqs, headers=None, params=None, device=0, do_pass2=True, engine=None):
+    """pass 1 -> merge -> pass 2 on one GPU for host reads (list[bytes]); returns PipelineResult."""
+    packed = PackedReads(seqs)
+    header_id = None
+    if headers is not None:
+        first = {}
+        header_id = np.empty(len(headers), np.uint64)
+        for i, h in enumerate(headers):
+            header_id[i] = first.setdefault(h, i)
+        if np.all(header_id == np.arange(len(headers), dtype=np.uint64)):
+            header_id = None
+    own = engine is None
+    eng = engine or SearchEngine(params, device)
+    try:
+        eng.load_reads(packed, header_id)
+        cand = eng.seed_scan()
+        merge = eng.merge()
+        if do_pass2:
+            rec = eng.recruit()
+            merge = eng.merge_view()        # pass 2 may add tokens (addReadHolder)
+        else:
+            rec = RecruitSet(_abi.Recruits())
+        res = PipelineResult(cand, merge, rec, cand.max_read_len)
+        res.counters = eng.counters()
+        return res
+    finally:
+        if own:
+            eng.close()
+        packed.close()

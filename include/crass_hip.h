@@ -1,0 +1,258 @@
+/*
+ * crass_hip.h — C ABI of the MI355X-native crass search engine (libcrass_hip.so).
+ *
+ * This is the drop-in boundary for crass's WorkHorse search path.  The reference has no
+ * FFI layer: the seam is three C++ free functions called from WorkHorse::parseSeqFiles
+ * (reference paths are relative to the crass v1.0.1 tree):
+ *
+ *   searchFile()               src/crass/libcrispr.h:74-80   (call: WorkHorse.cpp:340-346)
+ *   createNonRedundantSet()    src/crass/WorkHorse.h:111-112 (call: WorkHorse.cpp:370)
+ *   findSingletons()           src/crass/libcrispr.h:86-92   (call: WorkHorse.cpp:386)
+ *   sink: addReadHolder()      src/crass/libcrispr.h:123-125
+ *
+ * Each entry point below names the reference interface it replaces.  Plain pointers and
+ * sizes only; caller-allocated/caller-freed flat buffers or views into context-owned
+ * memory; no C++ objects or exceptions cross this boundary; every function returns an
+ * int status (0 = CRASS_OK) and crass_hip_strerror() explains it.  One context per GPU,
+ * one host thread per context (the reference is single-threaded).
+ *
+ * INTEGRATION.md shows the C++ adapter a crass maintainer would add on top of this.
+ */
+#ifndef CRASS_HIP_H
+#define CRASS_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRASS_HIP_ABI_VERSION 1
+
+/* ---- status codes (reference: crispr::exception -> exit code) ---- */
+enum {
+    CRASS_OK = 0,
+    CRASS_ERR_INVALID_ARG   = 1,   /* bad pointer / size / parameter combination             */
+    CRASS_ERR_UNSUPPORTED   = 2,   /* parameter outside the engine's implementation limits   */
+    CRASS_ERR_NO_DEVICE     = 3,   /* no HIP device / HIP runtime failure at init            */
+    CRASS_ERR_HIP           = 4,   /* a HIP call failed (crass_hip_last_hip_error())         */
+    CRASS_ERR_OOM           = 5,   /* host or device allocation failed                       */
+    CRASS_ERR_STATE         = 6,   /* call order violated (e.g. recruit before patterns)     */
+    CRASS_ERR_SEARCH_FATAL  = 7,   /* the reference would have thrown "Fatal error in search
+                                      algorithm!" (libcrispr.cpp:141-149)                    */
+    CRASS_ERR_OVERFLOW      = 8,   /* an internal device pool overflowed                     */
+    CRASS_ERR_IO            = 9    /* file could not be opened / parsed                      */
+};
+
+/* implementation limits of the device path (checked by crass_hip_create) */
+#define CRASS_HIP_MAX_WINDOW   9      /* CRASS_DEF_MAX_SEARCH_WINDOW_LENGTH, crassDefines.h:55 */
+#define CRASS_HIP_MIN_WINDOW   6
+#define CRASS_HIP_MAX_DR       240    /* highDRsize upper bound handled on device             */
+#define CRASS_HIP_MAX_READ_LEN 60000  /* longest read the device path accepts                 */
+
+/* ---- options: POD mirror of the hot-path fields of `options` (crassDefines.h:140-170) ---- */
+typedef struct {
+    uint32_t lowDRsize;          /* -d  default 23  (crassDefines.h:121) */
+    uint32_t highDRsize;         /* -D  default 47  (:122)               */
+    uint32_t lowSpacerSize;      /* -s  default 26  (:123)               */
+    uint32_t highSpacerSize;     /* -S  default 50  (:124)               */
+    uint32_t searchWindowLength; /* -w  default 8   (:56), 6..9          */
+    uint32_t minNumRepeats;      /* -n  default 2   (:91)                */
+    int32_t  kmer_clust_size;    /* -k  default 6   (:67)                */
+} crass_params;
+
+void crass_default_params(crass_params *p);       /* crass.cpp:430-460 */
+
+typedef struct crass_hip_ctx crass_hip_ctx;
+
+/* ---- reads: the device-resident replacement for "re-read every file twice" ---- *
+ * 2-bit packed bases (A=0 C=1 G=2 T=3), 16 bases per uint32, base i of a read in bits
+ * [2*(i%16), 2*(i%16)+2) of word i/16; every read starts on a word boundary.
+ * A read containing any byte outside {A,C,G,T} is an *exception read*: it keeps its slot in
+ * `packed` (content ignored) and is listed, as raw bytes, in the exception arrays, so that
+ * the reference's raw-byte semantics (N matches N, lower case is not ACGT)
+ * are kept on the device's byte-wise kernels.                                              */
+typedef struct {
+    uint64_t        n_reads;
+    const uint32_t *packed;        /* all reads, word-aligned                                      */
+    uint32_t        stride_words;  /* >0: read i starts at word i*stride_words; 0: use word_off    */
+    const uint64_t *word_off;      /* [n_reads] start word of each read (stride_words == 0)        */
+    uint32_t        uniform_len;   /* >0: every read has this length; 0: use lengths               */
+    const uint32_t *lengths;       /* [n_reads] (uniform_len == 0)                                 */
+    uint64_t        n_exceptions;
+    const uint64_t *exc_read;      /* [n_exceptions] ascending read indices                        */
+    const uint64_t *exc_off;       /* [n_exceptions+1] offsets into exc_bytes                      */
+    const uint8_t  *exc_bytes;     /* raw sequence bytes of the exception reads                    */
+    const uint64_t *header_id;     /* [n_reads] or NULL.  header_id[i] = index of the FIRST read
+                                      with the same header (readsFound is keyed by header string,
+                                      libcrispr.cpp:138,411); NULL = all headers unique            */
+    uint64_t        read_index_base; /* global index of read 0 (multi-GPU shards)                  */
+} crass_reads;
+
+/* ---- lifecycle ---- */
+/* replaces: the `options` argument of searchFile/findSingletons */
+int  crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out);
+void crass_hip_destroy(crass_hip_ctx *ctx);
+const char *crass_hip_strerror(int status);
+int  crass_hip_last_hip_error(const crass_hip_ctx *ctx);
+
+/* replaces: getFileHandle/kseq_read loops of searchFile+findSingletons (libcrispr.cpp:84-96,
+ * 471-487): host buffers are copied to HBM once and stay resident for both passes. */
+int crass_hip_load_reads(crass_hip_ctx *ctx, const crass_reads *host_reads);
+/* same, but every pointer in `dev_reads` is a DEVICE pointer the caller owns (e.g. torch
+ * tensors) and keeps alive until the context is destroyed or new reads are set. */
+int crass_hip_attach_device_reads(crass_hip_ctx *ctx, const crass_reads *dev_reads);
+
+/* ---- pass 1 : searchFile / searchCore (libcrispr.cpp:68-166, 265-395) ---- *
+ * Runs the seed-scan filter, ordered compaction, and the survivor kernel (scanRight,
+ * extendPreRepeat, qcFoundRepeats incl. Levenshtein, DRLowLexi) on the device.  Results are
+ * kept in the context in read order.                                                       */
+int crass_hip_seed_scan(crass_hip_ctx *ctx);
+
+/* candidates found by pass 1, in read order (views into context memory, valid until the
+ * next seed_scan/load).  One entry per read for which searchCore returned true.           */
+typedef struct {
+    uint64_t        n;
+    const uint64_t *read_idx;     /* global read index (read_index_base + local)                  */
+    const uint8_t  *low_lexi;     /* RH_WasLowLexi after DRLowLexi (ReadHolder.cpp:513-591)       */
+    const uint32_t *repeat_len;   /* RH_RepeatLength                                              */
+    const uint32_t *n_ss;         /* RH_StartStops.size()                                         */
+    const uint64_t *ss_off;       /* offset of this read's start/stops in ss_pool                 */
+    const uint32_t *ss_pool;      /* start/stop pairs AFTER DRLowLexi (mirrored if flipped)       */
+    uint32_t        dr_stride;    /* bytes per DR slot                                            */
+    const uint16_t *dr_len;
+    const char     *dr_chars;     /* low-lexi representative DR of read k at dr_chars+k*dr_stride */
+    uint32_t        max_read_len; /* searchFile's return value (libcrispr.cpp:98,165)             */
+} crass_candidates;
+int crass_hip_get_candidates(const crass_hip_ctx *ctx, crass_candidates *out);
+
+/* ---- merge : addReadHolder token order + createNonRedundantSet (libcrispr.cpp:1119-1162,
+ * StringCheck.cpp:46-81, WorkHorse.cpp:612-709, 1404-1637) ---- *
+ * Input: the representative DR strings of ALL pass-1 candidates in global read order (for
+ * one GPU: the context's own; for several GPUs: the all-gathered slots of every rank, rank
+ * order == read order).  dr_chars == NULL means "use this context's candidates".
+ * Deterministic: every rank that feeds the same list builds the same tokens, groups and
+ * pattern list.  Also installs the pattern list for crass_hip_recruit().                   */
+int crass_hip_merge(crass_hip_ctx *ctx, const char *dr_chars, const uint16_t *dr_len,
+                    uint32_t dr_stride, uint64_t n_candidates);
+
+typedef struct {
+    uint32_t        n_tokens;     /* StringCheck size; tokens are 2 .. n_tokens+1                 */
+    const char     *tok_chars;    /* token t string = tok_chars[tok_off[t-2] .. tok_off[t-1])     */
+    const uint64_t *tok_off;      /* [n_tokens+1]                                                 */
+    uint64_t        n_candidates; /* length of cand_token                                         */
+    const uint32_t *cand_token;   /* token of every candidate fed to merge, in the same order     */
+    uint32_t        n_groups;     /* mDR2GIDMap size; GIDs are 1 .. n_groups                      */
+    const uint32_t *grp_tokens;   /* group g (GID g+1) = grp_tokens[grp_off[g] .. grp_off[g+1])   */
+    const uint64_t *grp_off;      /* [n_groups+1]                                                 */
+    uint32_t        n_patterns;   /* Vecstr* returned by createNonRedundantSet                    */
+    const char     *pat_chars;
+    const uint64_t *pat_off;      /* [n_patterns+1]                                               */
+    const uint32_t *pat_group;    /* GID of each pattern                                          */
+    int32_t         next_free_gid;/* nextFreeGID after clustering (WorkHorse.cpp:369-370)         */
+} crass_merge_view;
+int crass_hip_get_merge(const crass_hip_ctx *ctx, crass_merge_view *out);
+
+/* ---- pass 2 : findSingletons / on_match (libcrispr.cpp:399-518) ---- */
+/* replaces: refsplit + acism_create (libcrispr.cpp:452-469).  Optional: merge() already
+ * installed the non-redundant set; use this to recruit with an explicit pattern list.     */
+int crass_hip_set_patterns(crass_hip_ctx *ctx, const char *const *patterns,
+                           const uint32_t *lengths, uint32_t n);
+/* replaces: the acism_scan loop.  Reads whose header was found in pass 1 (readsFound,
+ * libcrispr.cpp:411) are skipped; `extra_found` (may be NULL) lists further header ids,
+ * as global read indices, found by OTHER ranks' pass 1 (duplicate headers across shards).  */
+int crass_hip_recruit(crass_hip_ctx *ctx, const uint64_t *extra_found, uint64_t n_extra);
+
+typedef struct {
+    uint64_t        n;
+    const uint64_t *read_idx;     /* global read index, ascending                                 */
+    const uint8_t  *low_lexi;     /* RH_WasLowLexi                                                */
+    const uint32_t *start;        /* the single repeat [start, end] AFTER DRLowLexi               */
+    const uint32_t *end;
+    uint32_t        dr_stride;
+    const uint16_t *dr_len;
+    const char     *dr_chars;     /* low-lexi DR (== a stored token string)                       */
+    const uint32_t *token;        /* StringToken (existing, or newly added like addReadHolder)    */
+} crass_recruits;
+int crass_hip_get_recruits(const crass_hip_ctx *ctx, crass_recruits *out);
+
+/* ---- Levenshtein / similarity batch (PatternMatcher.cpp:111-204) on the device ---- *
+ * pair k compares chars[a_off[k] .. a_off[k]+a_len[k]) with chars[b_off[k] ..)              */
+int crass_hip_levenshtein_batch(crass_hip_ctx *ctx, const char *chars, uint64_t n_chars,
+                                const uint64_t *a_off, const uint32_t *a_len,
+                                const uint64_t *b_off, const uint32_t *b_len,
+                                uint64_t n_pairs, int32_t *dist_out, float *sim_out);
+
+/* ---- observability (the reference only has a wall-clock progress line) ---- */
+typedef struct {
+    uint64_t n_reads, n_exceptions;
+    uint64_t n_filter_survivors;    /* reads with a lattice seed hit (superset allowed)           */
+    uint64_t n_pass1_found, n_pass2_found;
+    uint32_t n_patterns, ac_states;
+    uint32_t used_fast_filter;      /* 1: bit-parallel lane-per-read kernel, 0: general           */
+    uint32_t used_lds_automaton;    /* 1: pass-2 automaton fitted in LDS                          */
+    /* HIP-event timings of the last call, milliseconds, measured on the context's stream      */
+    float ms_filter, ms_compact, ms_survivor, ms_pass1_total;
+    float ms_recruit, ms_recruit_finish, ms_pass2_total;
+    float ms_merge_host, ms_sink_host;
+    uint64_t bytes_reads_device;    /* packed read bytes resident in HBM                          */
+} crass_counters;
+int crass_hip_get_counters(const crass_hip_ctx *ctx, crass_counters *out);
+
+/* raw stream handle (hipStream_t) the context launches on, for callers that time with HIP
+ * events or want to order their own work (torch.cuda.ExternalStream) */
+void *crass_hip_stream(const crass_hip_ctx *ctx);
+
+/* ---- host utilities: ingest side of the boundary ("next" row f-2) ---- */
+/* 2-bit packer.  seqs: concatenated raw bytes, off[n+1].  Allocates the output arrays with
+ * malloc (free with crass_free_packed).  stride_words = ceil(max_len/16) when pad_uniform
+ * != 0, else per-read word offsets.                                                        */
+typedef struct {
+    crass_reads reads;              /* host pointers, owned by this struct                        */
+    void *owner;
+} crass_packed;
+int  crass_pack_reads(const uint8_t *seqs, const uint64_t *off, uint64_t n_reads,
+                      int pad_uniform, crass_packed *out);
+void crass_free_packed(crass_packed *p);
+
+/* FASTA/FASTQ(.gz) reader with kseq_read record semantics (kseq.cpp:171-226).  Buffers are
+ * malloc'd, free with crass_free_fastx.                                                    */
+typedef struct {
+    uint64_t  n_reads;
+    uint8_t  *seq;   uint64_t *seq_off;     /* [n+1] */
+    uint8_t  *name;  uint64_t *name_off;
+    uint8_t  *comment; uint64_t *comment_off; uint8_t *has_comment; /* stale-pointer semantics,
+                                                                       libcrispr.cpp:124-127 */
+    uint8_t  *qual;  uint64_t *qual_off;   uint8_t *has_qual;
+    uint64_t *header_id;                    /* first read with the same name                     */
+    uint32_t  max_len;
+    int32_t   last_ret;                     /* kseq_read's final return value (-1 EOF, -2 trunc) */
+} crass_fastx;
+int  crass_read_fastx(const char *path, crass_fastx *out);
+void crass_free_fastx(crass_fastx *f);
+
+/* deterministic synthetic metagenome: counter-based, so any shard can be
+ * generated independently.  Writes 2-bit packed reads with uniform stride ceil(L/16).      */
+typedef struct {
+    uint64_t seed;
+    uint32_t read_len;          /* 150                                                        */
+    uint32_t n_dr;              /* 50 (config 2/3), 500 (config 5)                            */
+    uint32_t dr_len_min, dr_len_max;       /* 28..37                                          */
+    uint32_t spacer_len_min, spacer_len_max; /* 30..38                                        */
+    uint32_t crispr_per_million; /* 10000 = 1 %                                               */
+    uint32_t gc_classes;        /* 0/1 = uniform; 4 = GC 30/45/55/70 % background mix         */
+} crass_synth_spec;
+void crass_synth_default(crass_synth_spec *s);
+int  crass_synth_packed(const crass_synth_spec *s, uint64_t first_read, uint64_t n_reads,
+                        uint32_t *packed_out /* n_reads*ceil(L/16) words */, int n_threads);
+/* unpack reads [first, first+n) of a uniform-stride packed buffer to ASCII (for the CPU baseline) */
+int  crass_unpack_ascii(const uint32_t *packed, uint32_t stride_words, uint32_t read_len,
+                        uint64_t n_reads, uint8_t *ascii_out /* n_reads*read_len */);
+
+int crass_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRASS_HIP_H */
