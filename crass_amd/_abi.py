@@ -86,6 +86,9 @@ SYMBOLS = {
     "crass_hip_get_candidates": (C.c_int, [C.c_void_p, C.POINTER(Candidates)]),
     "crass_hip_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     "crass_hip_get_merge": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),
+    "crass_merge_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "crass_merge_get": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),
+    "crass_merge_destroy": (None, [C.c_void_p]),
     "crass_hip_set_patterns": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), u32p, C.c_uint32]),
     "crass_hip_recruit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "crass_hip_get_recruits": (C.c_int, [C.c_void_p, C.POINTER(Recruits)]),

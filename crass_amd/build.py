@@ -41,5 +41,31 @@ def build(force=False, verbose=False):
     return LIB
 
 
+ADAPTER_DIR = os.path.join(CSRC, "adapter")
+CLI = os.path.join(HERE, "crass-hip")
+ADAPTER_LIB = os.path.join(HERE, "libcrass_adapter.so")
+
+
+def build_adapter(force=False, verbose=False):
+    """C++ host adapter with the reference's seam (searchFile/createNonRedundantSet/findSingletons)
+    + the `crass-hip` command line.  Plain g++; links against libcrass_hip.so."""
+    build(force=force, verbose=verbose)
+    srcs = [os.path.join(ADAPTER_DIR, "crass_adapter.cpp")]
+    deps = srcs + [os.path.join(ADAPTER_DIR, "crass_adapter.h"), os.path.join(ADAPTER_DIR, "crass_hip_cli.cpp"), LIB]
+    if not force and os.path.exists(CLI) and os.path.exists(ADAPTER_LIB) and \
+            all(os.path.getmtime(d) <= min(os.path.getmtime(CLI), os.path.getmtime(ADAPTER_LIB)) for d in deps):
+        return CLI
+    cxx = shutil.which("g++") or "g++"
+    common = [cxx, "-O2", "-std=c++17", "-Wall", "-fPIC"]
+    rpath = ["-L" + HERE, "-lcrass_hip", "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN"]
+    for cmd in (common + ["-shared", "-o", ADAPTER_LIB] + srcs + rpath,
+                common + ["-o", CLI, os.path.join(ADAPTER_DIR, "crass_hip_cli.cpp")] + srcs + rpath):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_adapter(force="--force" in sys.argv, verbose=True))

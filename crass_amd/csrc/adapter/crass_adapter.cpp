@@ -1,0 +1,308 @@
+// crass_adapter.cpp — the reference's seam (searchFile / createNonRedundantSet / findSingletons /
+// addReadHolder) implemented over the C ABI of libcrass_hip.so.  See crass_adapter.h.
+#include "crass_adapter.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <unordered_map>
+
+namespace crass_hip {
+
+namespace {
+
+int g_device = -1;
+
+int device()
+{
+    if (g_device >= 0) return g_device;
+    const char *e = getenv("CRASS_HIP_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+const unsigned char *comp_tab()
+{
+    // reverseComplement table (SeqUtils.cpp:50-59): IUPAC pairs, U->A, identity otherwise, [96] = 64
+    static unsigned char tab[128];
+    static bool ready = false;
+    if (!ready) {
+        for (int i = 0; i < 128; i++) tab[i] = (unsigned char)i;
+        const char *a = "ACBDKRSWN", *b = "TGVHMYSWN";
+        for (int i = 0; a[i]; i++) {
+            tab[(int)a[i]] = (unsigned char)b[i]; tab[(int)b[i]] = (unsigned char)a[i];
+            tab[(int)a[i] + 32] = (unsigned char)(b[i] + 32); tab[(int)b[i] + 32] = (unsigned char)(a[i] + 32);
+        }
+        tab['U'] = 'A'; tab['u'] = 'a'; tab[96] = 64;
+        ready = true;
+    }
+    return tab;
+}
+
+std::string revcomp(const std::string &s)
+{
+    const unsigned char *t = comp_tab();
+    std::string r(s.size(), '\0');
+    for (size_t i = 0; i < s.size(); i++) r[i] = (char)t[(unsigned char)s[s.size() - 1 - i] & 127];
+    return r;
+}
+
+#define CRASS_THROW(msg) throw exception(__FILE__, __LINE__, __PRETTY_FUNCTION__, (msg))
+
+void chk(int status, const char *what)
+{
+    if (status == CRASS_OK) return;
+    if (status == CRASS_ERR_SEARCH_FATAL) CRASS_THROW("Fatal error in search algorithm!");     // libcrispr.cpp:145-148
+    CRASS_THROW(std::string(what) + ": " + crass_hip_strerror(status));
+}
+
+crass_params to_params(const options &o)
+{
+    crass_params p;
+    p.lowDRsize = o.lowDRsize; p.highDRsize = o.highDRsize; p.lowSpacerSize = o.lowSpacerSize;
+    p.highSpacerSize = o.highSpacerSize; p.searchWindowLength = o.searchWindowLength;
+    p.minNumRepeats = o.minNumRepeats; p.kmer_clust_size = o.kmer_clust_size;
+    return p;
+}
+
+// one input file, resident on the GPU between the two passes
+struct FileState {
+    crass_fastx fx{};
+    crass_packed pk{};
+    crass_hip_ctx *ctx = nullptr;
+    bool unique_headers = true;
+    uint64_t n_found_own = 0;
+    std::unordered_map<std::string, uint64_t> first_idx;   // header -> first read index (built lazily)
+    ~FileState()
+    {
+        if (ctx) crass_hip_destroy(ctx);
+        crass_free_packed(&pk);
+        crass_free_fastx(&fx);
+    }
+    std::string field(const uint8_t *buf, const uint64_t *off, uint64_t i) const { return std::string((const char *)buf + off[i], off[i + 1] - off[i]); }
+    std::string name(uint64_t i) const { return field(fx.name, fx.name_off, i); }
+    std::string seq(uint64_t i) const { return field(fx.seq, fx.seq_off, i); }
+};
+
+std::map<std::string, std::unique_ptr<FileState>> &session()
+{
+    static std::map<std::string, std::unique_ptr<FileState>> s;
+    return s;
+}
+
+int g_read_counter_p1 = 0, g_read_counter_p2 = 0;     // `static int read_counter` (libcrispr.cpp:92,477)
+
+FileState &open_file(const char *path, const options &opts)
+{
+    auto &s = session();
+    auto it = s.find(path);
+    if (it != s.end()) return *it->second;
+    std::unique_ptr<FileState> f(new FileState());
+    int rc = crass_read_fastx(path, &f->fx);
+    if (rc == CRASS_ERR_IO) {
+        // getFileHandle prints and exit(1)s (SeqUtils.cpp:112-124); a library throws instead
+        CRASS_THROW(std::string("Could not open FASTQ ") + path + " for reading.");
+    }
+    chk(rc, "crass_read_fastx");
+    chk(crass_pack_reads(f->fx.seq, f->fx.seq_off, f->fx.n_reads, 0, &f->pk), "crass_pack_reads");
+    for (uint64_t i = 0; i < f->fx.n_reads; i++) if (f->fx.header_id[i] != i) { f->unique_headers = false; break; }
+    crass_params p = to_params(opts);
+    chk(crass_hip_create(&p, device(), &f->ctx), "crass_hip_create");
+    crass_reads r = f->pk.reads;
+    r.header_id = f->unique_headers ? nullptr : f->fx.header_id;
+    chk(crass_hip_load_reads(f->ctx, &r), "crass_hip_load_reads");
+    FileState &ref = *f;
+    s[path] = std::move(f);
+    return ref;
+}
+
+// fill the per-read fields searchFile/on_match copy from the kseq record (libcrispr.cpp:112-131,425-435)
+void fill_from_record(ReadHolder &h, const FileState &f, uint64_t i, bool low_lexi)
+{
+    std::string seq = f.seq(i);
+    h.RH_Seq = low_lexi ? seq : revcomp(seq);          // reverseComplementSeq (ReadHolder.cpp:593-609)
+    h.RH_Header = f.name(i);
+    if (f.fx.has_comment[i]) h.RH_Comment = f.field(f.fx.comment, f.fx.comment_off, i);
+    if (f.fx.has_qual[i]) { h.RH_Qual = f.field(f.fx.qual, f.fx.qual_off, i); h.RH_IsFasta = false; }
+    h.RH_WasLowLexi = low_lexi;
+}
+
+void sink(ReadMap *mReads, StringCheck *mStringCheck, ReadHolder *candidate, const std::string &dr_lowlexi)
+{
+    StringToken st = mStringCheck->getToken(dr_lowlexi);
+    if (0 == st) {
+        st = mStringCheck->addString(dr_lowlexi);
+        (*mReads)[st] = new ReadList();
+    }
+    (*mReads)[st]->push_back(candidate);
+}
+
+} // namespace
+
+std::string StringCheck::getString(StringToken token) const
+{
+    auto it = mT2S_map.find(token);
+    if (it == mT2S_map.end()) CRASS_THROW("Token not stored");
+    return it->second;
+}
+
+void setDevice(int d) { g_device = d; }
+void releaseDeviceReads() { session().clear(); }
+
+void clearReadMap(ReadMap *m)
+{
+    for (auto &kv : *m) {
+        if (!kv.second) continue;
+        for (ReadHolder *h : *kv.second) delete h;
+        delete kv.second;
+    }
+    m->clear();
+}
+
+// addReadHolder (libcrispr.cpp:1119-1162) for a holder that has NOT been oriented yet: applies
+// ReadHolder::DRLowLexi (ReadHolder.cpp:513-591) on the host copy, then sinks it.  The device
+// path does not use this (its records arrive oriented); it exists for interface parity.
+void addReadHolder(ReadMap *mReads, StringCheck *mStringCheck, ReadHolder &tmp)
+{
+    ReadHolder *c = new ReadHolder(tmp);
+    const StartStopList &ss = c->RH_StartStops;
+    if (ss.size() < 2 || (ss.size() & 1)) { delete c; CRASS_THROW("Cannot obtain read in lowlexi form"); }
+    const int n = (int)ss.size() / 2;
+    unsigned pick;
+    if (n == 1) pick = 0;
+    else if (n == 2) {
+        if (ss.front() == 0) pick = 2;
+        else if (ss.back() == (unsigned)c->RH_Seq.length()) pick = 0;
+        else pick = ((int)(ss[1] - ss[0]) > (int)(ss[3] - ss[2])) ? 0 : 2;
+    } else pick = 2;
+    std::string dr = c->repeatStringAt(pick), rc = revcomp(dr);
+    if (dr < rc) c->RH_WasLowLexi = true;
+    else {
+        c->RH_Seq = revcomp(c->RH_Seq);
+        StartStopList m(ss.size());
+        const unsigned L = (unsigned)c->RH_Seq.length();
+        for (size_t k = 0; k < ss.size(); k++) m[k] = L - 1 - ss[ss.size() - 1 - k];     // reverseStartStops
+        c->RH_StartStops = m;
+        c->RH_WasLowLexi = false;
+        dr = rc;
+    }
+    sink(mReads, mStringCheck, c, dr);
+}
+
+int searchFile(const char *inputFastq, const options &opts, ReadMap *mReads, StringCheck *mStringCheck,
+               lookupTable &patternsHash, lookupTable &readsFound, time_t &time_start)
+{
+    FileState &f = open_file(inputFastq, opts);
+    try {
+        chk(crass_hip_seed_scan(f.ctx), "crass_hip_seed_scan");
+    } catch (exception &e) {
+        std::cerr << e.what() << std::endl;
+        CRASS_THROW("Fatal error in search algorithm!");
+    }
+    crass_candidates c;
+    chk(crass_hip_get_candidates(f.ctx, &c), "crass_hip_get_candidates");
+    for (uint64_t k = 0; k < c.n; k++) {
+        const uint64_t i = c.read_idx[k];
+        ReadHolder *h = new ReadHolder();
+        fill_from_record(*h, f, i, c.low_lexi[k] != 0);
+        h->RH_StartStops.assign(c.ss_pool + c.ss_off[k], c.ss_pool + c.ss_off[k] + c.n_ss[k]);
+        h->RH_RepeatLength = (int)c.repeat_len[k];
+        sink(mReads, mStringCheck, h, std::string(c.dr_chars + k * (uint64_t)c.dr_stride, c.dr_len[k]));
+        // patternsHash[tmp_holder.repeatStringAt(0)] on the UN-oriented holder (libcrispr.cpp:137)
+        const StartStopList &ss = h->RH_StartStops;
+        std::string first_rep;
+        if (c.low_lexi[k]) first_rep = h->repeatStringAt(0);
+        else first_rep = revcomp(h->RH_Seq.substr(ss[ss.size() - 2], ss[ss.size() - 1] - ss[ss.size() - 2] + 1));
+        patternsHash[first_rep] = true;
+        readsFound[h->RH_Header] = true;
+    }
+    f.n_found_own = c.n;
+    g_read_counter_p1 += (int)f.fx.n_reads;
+    time_t now; time(&now);
+    std::cout << "\r[crass_patternFinder]: Processed " << g_read_counter_p1 << " ..." << difftime(now, time_start) << " sec" << std::flush;
+    return (int)f.fx.max_len;
+}
+
+Vecstr *createNonRedundantSet(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map &mDR2GIDMap,
+                              std::map<int, bool> &mGroupMap, GroupKmerMap &groupKmerCountsMap, int &nextFreeGID,
+                              const options &opts)
+{
+    // tokens in ascending order (std::map iteration of mReads, WorkHorse.cpp:660-665)
+    std::vector<StringToken> toks;
+    std::vector<std::string> strs;
+    uint32_t stride = 16;
+    for (auto &kv : mReads) {
+        toks.push_back(kv.first);
+        strs.push_back(mStringCheck.getString(kv.first));
+        stride = std::max<uint32_t>(stride, (uint32_t)((strs.back().size() + 15) & ~15u));
+    }
+    std::vector<char> chars(strs.size() * (size_t)stride, 0);
+    std::vector<uint16_t> lens(strs.size());
+    for (size_t i = 0; i < strs.size(); i++) { memcpy(chars.data() + i * stride, strs[i].data(), strs[i].size()); lens[i] = (uint16_t)strs[i].size(); }
+    crass_merge_handle *mh = nullptr;
+    chk(crass_merge_create(chars.data(), lens.data(), stride, strs.size(), opts.kmer_clust_size, &mh), "crass_merge_create");
+    crass_merge_view v;
+    chk(crass_merge_get(mh, &v), "crass_merge_get");
+    const int gid_base = nextFreeGID;                 // GIDs continue from the caller's counter (1 in parseSeqFiles)
+    for (uint32_t g = 0; g < v.n_groups; g++) {
+        const int gid = gid_base + (int)g;
+        mGroupMap[gid] = true;
+        DR_Cluster *cl = new DR_Cluster();
+        std::map<std::string, int> *counts = new std::map<std::string, int>();
+        for (uint64_t q = v.grp_off[g]; q < v.grp_off[g + 1]; q++) {
+            const uint32_t internal = v.grp_tokens[q];                      // 2 + index into `toks`
+            cl->push_back(toks[internal - 2]);
+            const std::string &dr = strs[internal - 2];
+            for (size_t i = 0; i + 11 <= dr.size(); i++) {                  // local_kmer_CountMap (WorkHorse.cpp:1547-1560,1620-1625)
+                std::string km = dr.substr(i, 11), rc = revcomp(km);
+                (*counts)[km < rc ? km : rc] += 1;
+            }
+        }
+        mDR2GIDMap[gid] = cl;
+        groupKmerCountsMap[gid] = counts;
+    }
+    nextFreeGID = gid_base + (int)v.n_groups;
+    std::cout << '[' << "crass" << "_clusterCore]: " << mReads.size() << " variants mapped to " << mDR2GIDMap.size() << " clusters" << std::endl;
+    std::cout << '[' << "crass" << "_clusterCore]: creating non-redundant set" << std::endl;
+    Vecstr *out = new Vecstr();
+    for (uint32_t i = 0; i < v.n_patterns; i++) out->push_back(std::string(v.pat_chars + v.pat_off[i], v.pat_off[i + 1] - v.pat_off[i]));
+    crass_merge_destroy(mh);
+    return out;
+}
+
+void findSingletons(const char *inputFastq, const options &opts, std::vector<std::string> *nonRedundantPatterns,
+                    lookupTable &readsFound, ReadMap *mReads, StringCheck *mStringCheck, time_t &startTime)
+{
+    FileState &f = open_file(inputFastq, opts);
+    std::vector<const char *> pp;
+    std::vector<uint32_t> pl;
+    for (const auto &s : *nonRedundantPatterns) { pp.push_back(s.data()); pl.push_back((uint32_t)s.size()); }
+    chk(crass_hip_set_patterns(f.ctx, pp.data(), pl.data(), (uint32_t)pp.size()), "crass_hip_set_patterns");
+    // readsFound is keyed by header (libcrispr.cpp:411): headers found in OTHER files must suppress
+    // recruitment here too.  The device already knows this file's own pass-1 hits.
+    std::vector<uint64_t> extra;
+    if (readsFound.size() != f.n_found_own || !f.unique_headers) {
+        if (f.first_idx.empty())
+            for (uint64_t i = 0; i < f.fx.n_reads; i++) f.first_idx.emplace(f.name(i), i);
+        for (const auto &kv : readsFound) {
+            auto it = f.first_idx.find(kv.first);
+            if (it != f.first_idx.end()) extra.push_back(it->second);
+        }
+    }
+    chk(crass_hip_recruit(f.ctx, extra.empty() ? nullptr : extra.data(), extra.size()), "crass_hip_recruit");
+    crass_recruits r;
+    chk(crass_hip_get_recruits(f.ctx, &r), "crass_hip_get_recruits");
+    for (uint64_t k = 0; k < r.n; k++) {
+        ReadHolder *h = new ReadHolder();
+        fill_from_record(*h, f, r.read_idx[k], r.low_lexi[k] != 0);
+        h->RH_StartStops.push_back(r.start[k]);
+        h->RH_StartStops.push_back(r.end[k]);
+        sink(mReads, mStringCheck, h, std::string(r.dr_chars + k * (uint64_t)r.dr_stride, r.dr_len[k]));
+    }
+    g_read_counter_p2 += (int)f.fx.n_reads;
+    time_t now; time(&now);
+    std::cout << "\r[crass_singletonFinder]: Processed " << g_read_counter_p2 << " ..." << difftime(now, startTime) << " sec" << std::flush;
+}
+
+} // namespace crass_hip

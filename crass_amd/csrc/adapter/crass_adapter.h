@@ -1,0 +1,120 @@
+// crass_adapter.h — C++ host adapter: the reference's own seam, re-implemented over the C ABI.
+//
+// WorkHorse::parseSeqFiles (src/crass/WorkHorse.cpp:321-414) calls three functions; this header
+// offers the same three shapes (names, argument meaning, error behaviour) so that swapping the
+// include + link line is the whole integration:
+//
+//   int   searchFile(const char*, const options&, ReadMap*, StringCheck*, lookupTable& patternsHash,
+//                    lookupTable& readsFound, time_t&)                       libcrispr.h:74-80
+//   Vecstr* createNonRedundantSet(ReadMap&, StringCheck&, DR_Cluster_Map&, std::map<int,bool>&,
+//                    GroupKmerMap&, int& nextFreeGID, const options&)        WorkHorse.h:111-112 (was a
+//                    private member; state passed explicitly)
+//   void  findSingletons(const char*, const options&, std::vector<std::string>*, lookupTable& readsFound,
+//                    ReadMap*, StringCheck*, time_t&)                        libcrispr.h:86-92
+//   void  addReadHolder(ReadMap*, StringCheck*, ReadHolder&)                 libcrispr.h:123-125
+//
+// The hand-off types below carry exactly the fields the downstream stages read
+// (ReadHolder.h:440-451, StringCheck.h:52-71, Types.h:51-67); all search decisions come from the
+// HIP engine (libcrass_hip.so) — nothing here re-runs the search on the CPU.
+#pragma once
+#include <ctime>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/crass_hip.h"
+
+namespace crass_hip {
+
+// crispr::exception (Exception.h:29-61): file, line, function, message
+class exception : public std::runtime_error {
+public:
+    exception(const char *file, int line, const char *function, const std::string &message)
+        : std::runtime_error(std::string("[ERROR]: ") + message + "\n" + file + " : " + std::to_string(line) + " : " + function) {}
+};
+
+// the hot-path subset of `options` (crassDefines.h:140-170) with the reference's field names
+struct options {
+    int logLevel = 1;
+    unsigned int lowDRsize = 23, highDRsize = 47, lowSpacerSize = 26, highSpacerSize = 50;
+    std::string output_fastq = "./";
+    int kmer_clust_size = 6;
+    unsigned int searchWindowLength = 8, minNumRepeats = 2;
+    bool logToScreen = false;
+    int covCutoff = 3;
+};
+
+typedef int StringToken;
+typedef std::vector<unsigned int> StartStopList;
+typedef std::vector<std::string> Vecstr;
+typedef std::map<std::string, bool> lookupTable;
+
+// StringCheck (StringCheck.h:52-71, StringCheck.cpp:46-81)
+class StringCheck {
+public:
+    StringCheck() : mNextFreeToken(1) {}
+    StringToken addString(const std::string &s) { mNextFreeToken++; mT2S_map[mNextFreeToken] = s; mS2T_map[s] = mNextFreeToken; return mNextFreeToken; }
+    std::string getString(StringToken t) const;
+    StringToken getToken(const std::string &s) const { auto it = mS2T_map.find(s); return it == mS2T_map.end() ? 0 : it->second; }
+    StringToken mNextFreeToken;
+    std::map<StringToken, std::string> mT2S_map;
+    std::map<std::string, StringToken> mS2T_map;
+};
+
+// ReadHolder (ReadHolder.h:58-452): the per-read hand-off record, field for field
+class ReadHolder {
+public:
+    ReadHolder() {}
+    std::string getSeq() const { return RH_Seq; }
+    std::string getHeader() const { return RH_Header; }
+    std::string getComment() const { return RH_Comment; }
+    std::string getQual() const { return RH_Qual; }
+    bool getIsFasta() const { return RH_IsFasta; }
+    bool getLowLexi() const { return RH_WasLowLexi; }
+    StartStopList getStartStopList() const { return RH_StartStops; }
+    unsigned int numRepeats() const { return (unsigned int)(RH_StartStops.size() / 2); }
+    unsigned int numSpacers() const { return numRepeats() - 1; }
+    unsigned int getRepeatLength() const { return (unsigned int)RH_RepeatLength; }
+    int getSeqLength() const { return (int)RH_Seq.length(); }
+    unsigned int front() const { return RH_StartStops.front(); }
+    unsigned int back() const { return RH_StartStops.back(); }
+    // ReadHolder::repeatStringAt (ReadHolder.cpp:77-100)
+    std::string repeatStringAt(unsigned int i) const { return RH_Seq.substr(RH_StartStops[i], RH_StartStops[i + 1] - RH_StartStops[i] + 1); }
+
+    std::string RH_Header, RH_Comment, RH_Qual, RH_Seq;
+    bool RH_IsFasta = true;
+    bool RH_WasLowLexi = false;
+    StartStopList RH_StartStops;
+    int RH_RepeatLength = 0;
+};
+
+typedef std::vector<ReadHolder *> ReadList;
+typedef std::map<StringToken, ReadList *> ReadMap;                       // Types.h:51-56
+typedef std::vector<StringToken> DR_Cluster;
+typedef std::map<int, DR_Cluster *> DR_Cluster_Map;                       // Types.h:61-64
+typedef std::map<int, std::map<std::string, int> *> GroupKmerMap;         // Types.h:65-67
+
+// ---- the seam ----
+int searchFile(const char *inputFastq, const options &opts, ReadMap *mReads, StringCheck *mStringCheck,
+               lookupTable &patternsHash, lookupTable &readsFound, time_t &time_start);
+
+Vecstr *createNonRedundantSet(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map &mDR2GIDMap,
+                              std::map<int, bool> &mGroupMap, GroupKmerMap &groupKmerCountsMap, int &nextFreeGID,
+                              const options &opts);
+
+void findSingletons(const char *inputFastq, const options &opts, std::vector<std::string> *nonRedundantPatterns,
+                    lookupTable &readsFound, ReadMap *mReads, StringCheck *mStringCheck, time_t &startTime);
+
+void addReadHolder(ReadMap *mReads, StringCheck *mStringCheck, ReadHolder &tmpReadholder);
+
+// reads of every file searched so far stay resident on the GPU between searchFile() and
+// findSingletons(); call this once the pipeline is past the search stage.
+void releaseDeviceReads();
+// which GPU the adapter uses (default 0, or $CRASS_HIP_DEVICE)
+void setDevice(int device);
+
+// clean-up helpers with the ownership rules of WorkHorse::clearReadMap (WorkHorse.cpp:127-162)
+void clearReadMap(ReadMap *m);
+
+} // namespace crass_hip

@@ -1,0 +1,148 @@
+// crass_hip_cli.cpp — `crass-hip`: crass's command line for the search stage, running on the
+// MI355X engine through the adapter.  Mirrors the call sequence of WorkHorse::parseSeqFiles
+// (WorkHorse.cpp:321-414) and the stdout tags crass prints; the options are the subset of
+// crass's getopt string that the search path reads (-d -D -s -S -w -n -k -l -g -o; crass.cpp:198).
+// Instead of the downstream spacer-graph / XML stages (out of scope), it writes the hand-off —
+// every ReadHolder of mReads, the token table, the DR groups and the pattern list — as a
+// line-oriented text dump (<outdir>/crass_hip_handoff.tsv) that the parity tests diff against
+// the oracle.
+#include "crass_adapter.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <getopt.h>
+#include <iostream>
+
+using namespace crass_hip;
+
+static void usage()
+{
+    std::cout << "crass-hip (MI355X search stage of crass 1.0.1)\n"
+                 "usage: crass-hip [-d minDR] [-D maxDR] [-s minSpacer] [-S maxSpacer] [-w window] [-n minRepeats]\n"
+                 "                 [-k kmerClust] [-l logLevel] [-g] [-o outdir] <reads.f[aq][.gz]> ...\n";
+}
+
+int main(int argc, char *argv[])
+{
+    options opts;
+    static struct option long_options[] = {
+        {"minDR", required_argument, nullptr, 'd'}, {"maxDR", required_argument, nullptr, 'D'},
+        {"minSpacer", required_argument, nullptr, 's'}, {"maxSpacer", required_argument, nullptr, 'S'},
+        {"windowLength", required_argument, nullptr, 'w'}, {"minNumRepeats", required_argument, nullptr, 'n'},
+        {"kmerCount", required_argument, nullptr, 'k'}, {"logLevel", required_argument, nullptr, 'l'},
+        {"logToScreen", no_argument, nullptr, 'g'}, {"outDir", required_argument, nullptr, 'o'},
+        {"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
+    int c, idx = 0;
+    while ((c = getopt_long(argc, argv, "d:D:s:S:w:n:k:l:go:h", long_options, &idx)) != -1) {
+        switch (c) {
+            case 'd':
+                opts.lowDRsize = (unsigned)atoi(optarg);
+                if (opts.lowDRsize < 8) {      // crass.cpp:264-271
+                    std::cerr << "crass [WARNING]: The lower bound for direct repeat sizes cannot be " << opts.lowDRsize << " changing to 23" << std::endl;
+                    opts.lowDRsize = 23;
+                }
+                break;
+            case 'D': opts.highDRsize = (unsigned)atoi(optarg); break;
+            case 's':
+                opts.lowSpacerSize = (unsigned)atoi(optarg);
+                if (opts.lowSpacerSize < 8) {  // crass.cpp:351-358
+                    std::cerr << "crass [WARNING]: The lower bound for spacer sizes cannot be " << opts.lowSpacerSize << " changing to 26" << std::endl;
+                    opts.lowSpacerSize = 26;
+                }
+                break;
+            case 'S': opts.highSpacerSize = (unsigned)atoi(optarg); break;
+            case 'w':
+                opts.searchWindowLength = (unsigned)atoi(optarg);
+                if (opts.searchWindowLength < 6 || opts.searchWindowLength > 9) {   // crass.cpp:366-374
+                    std::cerr << "crass [WARNING]: Specified window length higher than max. Changing window length to 8 instead of " << opts.searchWindowLength << std::endl;
+                    opts.searchWindowLength = 8;
+                }
+                break;
+            case 'n':
+                opts.minNumRepeats = (unsigned)atoi(optarg);
+                if (opts.minNumRepeats < 2) {  // crass.cpp:316-324
+                    std::cerr << "crass [ERROR]: The mininum number of repeats cannot be less than 2" << std::endl;
+                    return 1;
+                }
+                break;
+            case 'k':
+                opts.kmer_clust_size = atoi(optarg);
+                if (opts.kmer_clust_size < 4) {  // crass.cpp:294-301
+                    std::cerr << "crass [WARNING]: Minimum value for kmer clustering size is: 4 changing to 6" << std::endl;
+                    opts.kmer_clust_size = 6;
+                }
+                break;
+            case 'l': opts.logLevel = atoi(optarg); break;
+            case 'g': opts.logToScreen = true; break;
+            case 'o':
+                opts.output_fastq = optarg;
+                if (opts.output_fastq[opts.output_fastq.length() - 1] != '/') opts.output_fastq += '/';
+                break;
+            case 'h': usage(); return 0;
+            default: usage(); return 1;
+        }
+    }
+    if (opts.lowDRsize >= opts.highDRsize) {      // crass.cpp:388-393
+        std::cerr << "crass [ERROR]: The lower direct repeat bound is bigger than the higher bound (" << opts.lowDRsize << " >= " << opts.highDRsize << ")" << std::endl;
+        return 1;
+    }
+    if (opts.lowSpacerSize >= opts.highSpacerSize) {
+        std::cerr << "crass [ERROR]: The lower spacer bound is bigger than the higher bound (" << opts.lowSpacerSize << " >= " << opts.highSpacerSize << ")" << std::endl;
+        return 1;
+    }
+    if (optind >= argc) { std::cerr << "crass [ERROR]: No input files were provided. Try ./crass-hip -h for help." << std::endl; return 1; }
+    std::vector<std::string> seqFiles(argv + optind, argv + argc);
+
+    ReadMap mReads;
+    StringCheck mStringCheck;
+    DR_Cluster_Map mDR2GIDMap;
+    std::map<int, bool> mGroupMap;
+    GroupKmerMap group_kmer_counts_map;
+    lookupTable patterns_lookup, reads_found;
+    int mMaxReadLength = 0;
+    int rc = 0;
+    try {
+        time_t start_time; time(&start_time);
+        for (const auto &f : seqFiles) {
+            int max_len = searchFile(f.c_str(), opts, &mReads, &mStringCheck, patterns_lookup, reads_found, start_time);
+            mMaxReadLength = std::max(mMaxReadLength, max_len);
+        }
+        std::cout << std::endl;
+        int next_free_GID = 1;
+        Vecstr *nr = createNonRedundantSet(mReads, mStringCheck, mDR2GIDMap, mGroupMap, group_kmer_counts_map, next_free_GID, opts);
+        if (nr->size() > 0) {
+            std::cout << "[crass_clusterCore]: " << nr->size() << " non-redundant patterns." << std::endl;
+            time(&start_time);
+            for (const auto &f : seqFiles) findSingletons(f.c_str(), opts, nr, reads_found, &mReads, &mStringCheck, start_time);
+        }
+        std::cout << std::endl;
+        size_t n_reads = 0;
+        for (auto &kv : mReads) n_reads += kv.second->size();
+        std::cout << "[crass_patternFinder]: Found " << n_reads << " reads" << std::endl;
+
+        // ---- hand-off dump ----
+        std::ofstream out((opts.output_fastq + "crass_hip_handoff.tsv").c_str());
+        out << "#max_read_length\t" << mMaxReadLength << "\n#next_free_GID\t" << next_free_GID << "\n";
+        for (auto &kv : mStringCheck.mT2S_map) out << "T\t" << kv.first << "\t" << kv.second << "\n";
+        for (auto &kv : mDR2GIDMap) { out << "G\t" << kv.first; for (StringToken t : *kv.second) out << "\t" << t; out << "\n"; }
+        for (auto &kv : group_kmer_counts_map) for (auto &kc : *kv.second) out << "K\t" << kv.first << "\t" << kc.first << "\t" << kc.second << "\n";
+        for (const auto &p : *nr) out << "P\t" << p << "\n";
+        for (auto &kv : mReads)
+            for (ReadHolder *h : *kv.second) {
+                out << "R\t" << kv.first << "\t" << h->RH_Header << "\t" << (h->RH_WasLowLexi ? 1 : 0) << "\t" << h->RH_RepeatLength << "\t" << (h->RH_IsFasta ? 1 : 0) << "\t";
+                for (size_t i = 0; i < h->RH_StartStops.size(); i++) out << (i ? "," : "") << h->RH_StartStops[i];
+                out << "\t" << h->RH_Seq << "\t" << h->RH_Comment << "\t" << h->RH_Qual << "\n";
+            }
+        delete nr;
+    } catch (std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        rc = 2;            // doWork -> 2 -> process exit code 2
+    }
+    releaseDeviceReads();
+    clearReadMap(&mReads);
+    for (auto &kv : mDR2GIDMap) delete kv.second;
+    for (auto &kv : group_kmer_counts_map) delete kv.second;
+    return rc;
+}

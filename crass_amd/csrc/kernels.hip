@@ -861,8 +861,8 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
 // libcrispr.cpp:441, acism.c:73-102).  Lane per read, 64 consecutive reads per wave so the
 // ballot is the mask word.  hit_info[r] = (end_exclusive << 8) | pattern_length.
 // ------------------------------------------------------------------------------------
-template <bool LDS_TABLE>
-__global__ __launch_bounds__(256) void k_recruit(DevReads R, DevAutomaton A, const uint8_t *found_flag,
+template <bool LDS_TABLE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_recruit(DevReads R, DevAutomaton A, const uint8_t *found_flag,
                                                  uint64_t *hitmask, uint32_t *hit_info)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t rc_lds[];
@@ -942,7 +942,7 @@ hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, cons
     uint64_t blocks = (n_tiles + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (A.acgt_ok && A.go4)
-        hipLaunchKernelGGL(k_recruit<false>, dim3((unsigned)blocks), dim3(256), 0, st, R, A, found_flag, hitmask, hit_info);
+        hipLaunchKernelGGL((k_recruit<false, 256>), dim3((unsigned)blocks), dim3(256), 0, st, R, A, found_flag, hitmask, hit_info);
     else
         hipLaunchKernelGGL(k_recruit_wide, dim3((unsigned)blocks), dim3(256), 0, st, R, A, found_flag, hitmask, hit_info);
     return hipGetLastError();
@@ -955,16 +955,22 @@ hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const ui
     if (!A.acgt_ok || !A.go4) return hipErrorNotSupported;
     size_t lds = (size_t)A.n_states * 10;       // 4 x u16 transitions + u16 out_len
     if (lds > 160 * 1024) return hipErrorNotSupported;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recruit<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
     uint64_t n_tiles = (R.n_reads + 63) / 64;
-    // one workgroup per CU-slot; LDS footprint decides how many fit, so size the block to fill the CU
-    int threads = lds > 80 * 1024 ? 1024 : (lds > 40 * 1024 ? 512 : 256);
+    // one workgroup per CU-slot; the LDS footprint decides how many fit, so size the block to fill the CU
+    const int threads = lds > 80 * 1024 ? 1024 : (lds > 40 * 1024 ? 512 : 256);
     uint64_t waves_per_block = threads / 64;
     uint64_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
     uint64_t cap = lds > 80 * 1024 ? 256 : (lds > 40 * 1024 ? 512 : (lds > 20 * 1024 ? 1024 : 2048));
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_recruit<true>, dim3((unsigned)blocks), dim3(threads), lds, st, R, A, found_flag, hitmask, hit_info);
+    hipError_t e;
+#define RC_LAUNCH(T)                                                                                                   \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recruit<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                                                     \
+    hipLaunchKernelGGL((k_recruit<true, T>), dim3((unsigned)blocks), dim3(T), lds, st, R, A, found_flag, hitmask, hit_info);
+    if (threads == 1024) { RC_LAUNCH(1024) }
+    else if (threads == 512) { RC_LAUNCH(512) }
+    else { RC_LAUNCH(256) }
+#undef RC_LAUNCH
     return hipGetLastError();
 }
 

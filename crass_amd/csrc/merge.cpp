@@ -1,6 +1,7 @@
 // merge.cpp — the serial "merge" step between the two device passes (stays on the host:
 // a few thousand DR variants, negligible next to the scans).
 #include "merge.h"
+#include "../../include/crass_hip.h"
 
 #include <algorithm>
 #include <cstring>
@@ -200,3 +201,34 @@ void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns)
 }
 
 } // namespace crass
+
+// ---- context-free C entry points (include/crass_hip.h) ----
+struct crass_merge_handle { crass::MergeResult m; };
+
+extern "C" {
+
+int crass_merge_create(const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n,
+                       int32_t kmer_clust_size, crass_merge_handle **out)
+{
+    if (!out || (n && (!dr_chars || !dr_len || !dr_stride))) return CRASS_ERR_INVALID_ARG;
+    crass_merge_handle *h = new crass_merge_handle();
+    crass::merge_candidates(h->m, dr_chars, dr_len, dr_stride, n, kmer_clust_size);
+    *out = h;
+    return CRASS_OK;
+}
+
+int crass_merge_get(const crass_merge_handle *h, crass_merge_view *o)
+{
+    if (!h || !o) return CRASS_ERR_INVALID_ARG;
+    const crass::MergeResult &m = h->m;
+    o->n_tokens = m.tokens.size(); o->tok_chars = m.tok_chars.data(); o->tok_off = m.tok_off.data();
+    o->n_candidates = m.cand_token.size(); o->cand_token = m.cand_token.data();
+    o->n_groups = (uint32_t)m.groups.size(); o->grp_tokens = m.grp_tokens.data(); o->grp_off = m.grp_off.data();
+    o->n_patterns = (uint32_t)m.patterns.size(); o->pat_chars = m.pat_chars.data(); o->pat_off = m.pat_off.data();
+    o->pat_group = m.pat_group.data(); o->next_free_gid = m.next_free_gid;
+    return CRASS_OK;
+}
+
+void crass_merge_destroy(crass_merge_handle *h) { delete h; }
+
+} // extern "C"

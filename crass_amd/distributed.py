@@ -1,0 +1,55 @@
+"""Multi-GPU exchange step: one rank per GPU (torch.distributed, backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).
+
+The path shards by contiguous read ranges; the ONLY data-path exchange is the all-gather of
+the pass-1 candidates' representative DR strings between the seed pass and the merge
+(SURVEY §8e).  Rank order == global read order, so every rank replays the same
+addReadHolder token order and builds the identical pattern list locally — no broadcast of
+tables.  Payload: <= a few 10^4 candidates x (stride + 2) bytes, i.e. latency-bound.
+"""
+import numpy as np
+
+
+def allgather_candidates(chars, lens, dist, device=None):
+    """chars: uint8 [n_local, stride], lens: uint16 [n_local]  ->  (uint8 [n_global, stride],
+    uint16 [n_global]) concatenated in rank order.  Two collectives: counts, then fixed-size
+    padded slots (all_gather needs equal shapes)."""
+    import torch
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    stride = int(chars.shape[1]) if chars.ndim == 2 and chars.shape[0] else None
+    meta = torch.tensor([int(chars.shape[0]), stride or 0], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    counts = [int(m[0].item()) for m in metas]
+    strides = {int(m[1].item()) for m in metas if int(m[0].item()) > 0}
+    if not strides:
+        return np.zeros((0, 16), np.uint8), np.zeros(0, np.uint16)
+    assert len(strides) == 1, "ranks disagree on the DR slot stride"
+    stride = strides.pop()
+    cap = max(counts)
+    slot = stride + 2                                   # DR bytes + uint16 length
+    buf = np.zeros((cap, slot), dtype=np.uint8)
+    n = int(chars.shape[0])
+    if n:
+        buf[:n, :stride] = chars
+        buf[:n, stride:] = lens.astype("<u2").view(np.uint8).reshape(n, 2)
+    send = torch.from_numpy(buf).to(dev)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    parts_c, parts_l = [], []
+    for r in range(world):
+        a = recv[r][:counts[r]].cpu().numpy()
+        parts_c.append(a[:, :stride])
+        parts_l.append(np.ascontiguousarray(a[:, stride:]).view("<u2").reshape(-1).astype(np.uint16))
+    return np.ascontiguousarray(np.concatenate(parts_c, axis=0)), np.concatenate(parts_l)
+
+
+def gather_counts(values, dist, device=None):
+    """small helper: all-gather a list of python ints -> [world][len(values)]"""
+    import torch
+    dev = device if device is not None else torch.device("cpu")
+    t = torch.tensor(list(values), dtype=torch.int64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.cpu().tolist() for o in out]

@@ -202,6 +202,36 @@ class MergeResult:
         self.next_free_gid = int(v.next_free_gid)
 
 
+def merge_host(dr_chars, dr_len, kmer_clust_size=6):
+    """createNonRedundantSet on the host without a GPU context (crass_merge_create).
+    dr_chars: uint8 [n, stride]; dr_len: uint16 [n]."""
+    lib = _abi.load()
+    dr_chars = np.ascontiguousarray(dr_chars, dtype=np.uint8)
+    dr_len = np.ascontiguousarray(dr_len, dtype=np.uint16)
+    n = dr_chars.shape[0]
+    stride = dr_chars.shape[1] if dr_chars.ndim == 2 and n else 16
+    h = C.c_void_p()
+    _chk(lib.crass_merge_create(dr_chars.ctypes.data, dr_len.ctypes.data, int(stride), int(n), int(kmer_clust_size),
+                                C.byref(h)), "crass_merge_create")
+    try:
+        v = _abi.MergeView()
+        _chk(lib.crass_merge_get(h, C.byref(v)), "crass_merge_get")
+        return MergeResult(v)
+    finally:
+        lib.crass_merge_destroy(h)
+
+
+def dr_slots(strings, stride=48):
+    """list[bytes] -> (uint8 [n, stride], uint16 [n]) in the C ABI's fixed-slot layout"""
+    n = len(strings)
+    chars = np.zeros((n, stride), np.uint8)
+    lens = np.zeros(n, np.uint16)
+    for i, s in enumerate(strings):
+        chars[i, :len(s)] = np.frombuffer(s, np.uint8)
+        lens[i] = len(s)
+    return chars, lens
+
+
 class RecruitSet:
     def __init__(self, v):
         n = int(v.n)

@@ -154,6 +154,14 @@ typedef struct {
 } crass_merge_view;
 int crass_hip_get_merge(const crass_hip_ctx *ctx, crass_merge_view *out);
 
+/* The same merge as a context-free host function (no GPU needed): used by the multi-rank
+ * driver's CPU tests and by callers that only want createNonRedundantSet's result.        */
+typedef struct crass_merge_handle crass_merge_handle;
+int  crass_merge_create(const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
+                        uint64_t n_candidates, int32_t kmer_clust_size, crass_merge_handle **out);
+int  crass_merge_get(const crass_merge_handle *h, crass_merge_view *out);
+void crass_merge_destroy(crass_merge_handle *h);
+
 /* ---- pass 2 : findSingletons / on_match (libcrispr.cpp:399-518) ---- */
 /* replaces: refsplit + acism_create (libcrispr.cpp:452-469).  Optional: merge() already
  * installed the non-redundant set; use this to recruit with an explicit pattern list.     */

@@ -1,0 +1,115 @@
+"""Host merge (token order + createNonRedundantSet) vs the oracle, and the multi-rank
+exchange step on CPU (gloo, world_size 2).  No GPU needed: crass_merge_create is pure host."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import orc, fastx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import crass_amd
+    from crass_amd import build
+    build.build()
+    crass_amd.load()
+    return crass_amd
+
+
+def oracle_candidates(res):
+    """the representative DR of every pass-1 record, in read order"""
+    return [res.tokens[t - 2] for t in res.rec_token[:res.n_pass1]]
+
+
+@pytest.mark.parametrize("fname", ["Ill100.fx.gz", "front_offset_bug.fa.gz", "CN_gDC.fa.gz"])
+def test_merge_matches_oracle_on_reference_inputs(ca, fname):
+    recs = fastx.read_fastx(os.path.join(DATA, fname))
+    ref = orc.pipeline([r[2] for r in recs], [r[0] for r in recs], do_pass2=False)
+    chars, lens = ca.dr_slots(oracle_candidates(ref))
+    m = ca.merge_host(chars, lens)
+    assert m.tokens == ref.tokens
+    assert m.cand_token.tolist() == ref.rec_token[:ref.n_pass1].tolist()
+    assert m.groups == ref.groups
+    assert m.next_free_gid == ref.n_groups + 1
+    assert m.n_patterns == ref.n_patterns
+    for g in range(1, ref.n_groups + 1):
+        a = [p for p, gg in zip(m.patterns, m.pat_group) if gg == g]
+        b = [p for p, gg in zip(ref.patterns, ref.pat_group) if gg == g]
+        assert sorted(a) == sorted(b)
+        # per group: survivors followed by their reverse complements (WorkHorse.cpp:690-697)
+        h = len(a) // 2
+        rc = bytes.maketrans(b"ACGTN", b"TGCAN")
+        assert [x.translate(rc)[::-1] for x in a[:h]] == a[h:]
+
+
+def test_merge_synthetic_large(ca):
+    spec = ca.synth_spec(read_len=150, crispr_per_million=100000)
+    n = 60000
+    w = ca.synth_packed(spec, 0, n)
+    asc = ca.unpack_ascii(w, 10, 150, n)
+    off = np.arange(0, (n + 1) * 150, 150, dtype=np.uint64)
+    ref = orc.pipeline((asc, off), do_pass2=False)
+    assert ref.n_groups >= 40
+    chars, lens = ca.dr_slots(oracle_candidates(ref))
+    m = ca.merge_host(chars, lens)
+    assert m.tokens == ref.tokens and m.groups == ref.groups
+    assert sorted(m.patterns) == sorted(ref.patterns)
+
+
+WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+import crass_amd as ca
+from crass_amd.distributed import allgather_candidates
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+data = np.load(%(npz)r)
+chars, lens, cut = data["chars"], data["lens"], int(data["cut"])
+lo, hi = (0, cut) if rank == 0 else (cut, chars.shape[0])
+g_chars, g_lens = allgather_candidates(chars[lo:hi], lens[lo:hi], dist)
+m = ca.merge_host(g_chars, g_lens)
+out = dict(n=int(g_chars.shape[0]), same_chars=bool(np.array_equal(g_chars, chars)), same_lens=bool(np.array_equal(g_lens, lens)),
+           tokens=[t.decode() for t in m.tokens], groups=m.groups, patterns=[p.decode() for p in m.patterns])
+json.dump(out, open(%(out)r %% rank, "w"))
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_exchange_builds_identical_pattern_sets(ca, tmp_path):
+    recs = fastx.read_fastx(os.path.join(DATA, "front_offset_bug.fa.gz"))
+    ref = orc.pipeline([r[2] for r in recs], [r[0] for r in recs], do_pass2=False)
+    chars, lens = ca.dr_slots(oracle_candidates(ref))
+    cut = len(lens) // 3                      # uneven shards
+    npz = str(tmp_path / "cand.npz")
+    np.savez(npz, chars=chars, lens=lens, cut=cut)
+    outpat = str(tmp_path / "out%d.json")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(root=ROOT, npz=npz, out=outpat))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    import json
+    o0, o1 = json.load(open(outpat % 0)), json.load(open(outpat % 1))
+    assert o0 == o1                                             # every rank builds the same tables
+    assert o0["same_chars"] and o0["same_lens"] and o0["n"] == len(lens)
+    single = ca.merge_host(chars, lens)
+    assert o0["tokens"] == [t.decode() for t in single.tokens]
+    assert o0["groups"] == single.groups
+    assert o0["patterns"] == [p.decode() for p in single.patterns]
+    assert o0["groups"] == ref.groups

@@ -70,8 +70,8 @@ def test_one_million_synthetic_known_answer():
     seqs = []
     for _ in range(1000000):
         if random.random() < 0.01:
+            dr = random.choice(drs)          # drawn BEFORE the prefix: this order reproduces the survey's stream
             s = rand_seq(random.randint(0, 40))
-            dr = random.choice(drs)
             while len(s) < L + 60:
                 s += dr + rand_seq(random.randint(30, 38))
             off = random.randint(0, 40)
