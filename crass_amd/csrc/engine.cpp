@@ -150,6 +150,10 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     if (p->lowDRsize >= p->highDRsize || p->lowSpacerSize >= p->highSpacerSize) return CRASS_ERR_INVALID_ARG;
     if (p->minNumRepeats < 2) return CRASS_ERR_INVALID_ARG;
     if (p->highDRsize > CRASS_HIP_MAX_DR) return CRASS_ERR_UNSUPPORTED;
+    // lowDR < 2w-1 makes the reference's `unsigned skips = lowDR - (2w-1)` wrap to ~4e9
+    // (libcrispr.cpp:281); its `j = j + skips` then walks BACKWARDS after a failed candidate and
+    // need not terminate.  Ill-defined in the reference, refused here.
+    if (p->lowDRsize < 2 * p->searchWindowLength - 1) return CRASS_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CRASS_ERR_NO_DEVICE;
     crass_hip_ctx *c = new (std::nothrow) crass_hip_ctx();

@@ -120,7 +120,6 @@ __global__ __launch_bounds__(FG_WAVES * WAVE) void k_filter_general(DevReads R, 
                     bool ok = (p + w <= end) && (lds_code(words, p, cmask) == sj);
                     if (__ballot(ok)) { hit = true; break; }
                 }
-                if (j + P.skips < j) break;          // unsigned wrap of the reference's `j = j + skips`
             }
             if (hit) bits |= (1ull << k);
         }
@@ -680,7 +679,6 @@ static __device__ int search_core(RH &h, const DevParams &o, int lane)
         }
         h.nss = 0;
         wave_sync();
-        if (j + skips < j) break;      // uint32 wrap ends the reference's loop as well (j > searchEnd)
     }
     return 0;
 }

@@ -63,49 +63,110 @@ namespace {
 
 constexpr int kClusterKmer = 11;     // CRASS_DEF_KMER_SIZE (crassDefines.h:66)
 
+inline int acgt_code(unsigned char c)
+{
+    switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+// k-mer -> GID map of WorkHorse::clusterDRReads (std::map<std::string,int> there).  ACGT-only
+// 11-mers are kept as 22-bit integers (first base most significant, so integer order ==
+// lexicographic order and laurenize() is a min of two integers) in a flat table; anything else
+// falls back to string keys.  Same lookups, same results, ~50x less host time per variant.
+struct KmerGid {
+    std::vector<int32_t> flat;                                  // 4^11 entries, 0 = unseen
+    std::unordered_map<std::string, int> other;
+    KmerGid() : flat((size_t)1 << 22, 0) {}
+};
+
 // WorkHorse::clusterDRReads (WorkHorse.cpp:1404-1637): greedy, order-dependent assignment of
 // one DR variant to a group through shared laurenized 11-mers.  Returns the GID.
-int cluster_one(const std::string &dr, int &next_free_gid, std::unordered_map<std::string, int> &kmer_gid,
-                int min_shared)
+int cluster_one(const std::string &dr, int &next_free_gid, KmerGid &kg, int min_shared)
 {
     const int n_mers = (int)dr.size() - kClusterKmer + 1;
-    std::vector<std::string> homeless;
-    std::map<int, int> group_count;
+    std::vector<uint32_t> homeless_code;
+    std::vector<std::string> homeless_str;
+    std::vector<std::pair<int, int>> group_count;               // std::map<int,int> in the reference; tiny
     int group = 0;
-    for (int i = 0; i < n_mers; ++i) {
-        std::string km = dr.substr((size_t)i, kClusterKmer);
-        std::string rc = reverse_complement(km);
-        const std::string &lau = (km < rc) ? km : rc;              // laurenize (SeqUtils.cpp:89-97)
-        auto it = kmer_gid.find(lau);
-        if (it == kmer_gid.end()) {
-            homeless.push_back(lau);
-        } else if (group == 0) {
-            auto gc = group_count.find(it->second);
-            if (gc == group_count.end()) group_count[it->second] = 1;    // the first sighting is not tested (:1577-1580)
-            else if (min_shared <= ++gc->second) group = it->second;
+    auto seen = [&](int gid) {
+        if (group != 0) return;
+        for (auto &gc : group_count)
+            if (gc.first == gid) { if (min_shared <= ++gc.second) group = gid; return; }
+        group_count.emplace_back(gid, 1);                       // the first sighting is not tested (:1577-1580)
+    };
+    // rolling forward / reverse-complement codes; `bad` counts positions until the window is ACGT-only again
+    uint32_t fwd = 0, rev = 0;
+    int bad = 0;
+    const uint32_t mask = (1u << 22) - 1;
+    for (int i = 0; i < (int)dr.size(); i++) {
+        int c = acgt_code((unsigned char)dr[i]);
+        if (c < 0) { bad = kClusterKmer; c = 0; } else if (bad > 0) bad--;
+        fwd = ((fwd << 2) | (uint32_t)c) & mask;
+        rev = (rev >> 2) | ((uint32_t)(3 - c) << 20);
+        const int start = i - kClusterKmer + 1;
+        if (start < 0 || start >= n_mers) continue;
+        if (bad == 0) {
+            const uint32_t lau = fwd < rev ? fwd : rev;          // laurenize (SeqUtils.cpp:89-97): seq1 < seq2 ? seq1 : seq2
+            const int32_t gid = kg.flat[lau];
+            if (gid == 0) homeless_code.push_back(lau); else seen(gid);
+        } else {
+            std::string km = dr.substr((size_t)start, kClusterKmer), rc = reverse_complement(km);
+            const std::string &lau = (km < rc) ? km : rc;
+            auto it = kg.other.find(lau);
+            if (it == kg.other.end()) homeless_str.push_back(lau); else seen(it->second);
         }
     }
     if (group == 0) group = next_free_gid++;
-    for (const auto &k : homeless) kmer_gid[k] = group;
+    for (uint32_t k : homeless_code) kg.flat[k] = group;
+    for (const auto &k : homeless_str) kg.other[k] = group;
     return group;
 }
 
 bool shorter_first(const std::string &a, const std::string &b) { return a.length() < b.length(); }
 bool not_empty(const std::string &a) { return !a.empty(); }
 
+inline uint64_t hash_bytes(const char *p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
 // WorkHorse::removeRedundantRepeats (WorkHorse.cpp:612-645) with includeSubstring (:78-86).
-// Uses the same std::sort / std::partition calls so that the surviving ORDER matches the
-// reference built against the same libstdc++ (only the set matters for pass 2).
+// A string is blanked iff some strictly shorter member (or its reverse complement) occurs in it
+// (equal-length members can only contain each other if identical, and tokens are distinct), so
+// the O(n^2) pairwise find() is replaced by an index of every member's leading `kAnchor` bytes.
+// The std::sort / std::partition calls are kept so that the surviving ORDER is what the
+// reference produces with the same libstdc++ (pass 2 depends on the set only).
 void remove_redundant(std::vector<std::string> &v)
 {
     std::sort(v.begin(), v.end(), shorter_first);
-    for (size_t i = 0; i < v.size(); i++) {
-        if (v[i].empty()) continue;
-        const std::string rc = reverse_complement(v[i]);
-        for (size_t j = i + 1; j < v.size(); j++) {
-            if (v[j].empty()) continue;
-            if (v[j].find(v[i]) != std::string::npos || v[j].find(rc) != std::string::npos) v[j].clear();
+    if (v.size() > 1) {
+        size_t min_len = v.front().size();
+        const size_t kAnchor = std::min<size_t>(16, min_len);
+        std::vector<char> blank(v.size(), 0);
+        if (kAnchor == 0) {
+            for (size_t j = 1; j < v.size(); j++) blank[j] = 1;    // an empty string is a substring of everything
+        } else {
+            std::unordered_multimap<uint64_t, uint32_t> index;
+            index.reserve(v.size() * 2);
+            for (uint32_t i = 0; i < v.size(); i++) index.emplace(hash_bytes(v[i].data(), kAnchor), i);
+            for (size_t j = 0; j < v.size(); j++) {
+                const std::string &s = v[j];
+                const std::string rc = reverse_complement(s);
+                // t or revcomp(t) occurs in s  <=>  t occurs in s or in revcomp(s)
+                for (const std::string *hay : {&s, &rc}) {
+                    for (size_t p = 0; p + kAnchor <= hay->size() && !blank[j]; p++) {
+                        auto range = index.equal_range(hash_bytes(hay->data() + p, kAnchor));
+                        for (auto it = range.first; it != range.second; ++it) {
+                            const std::string &t = v[it->second];
+                            if (t.size() < s.size() && p + t.size() <= hay->size() && memcmp(hay->data() + p, t.data(), t.size()) == 0) { blank[j] = 1; break; }
+                        }
+                    }
+                    if (blank[j]) break;
+                }
+            }
         }
+        for (size_t j = 0; j < v.size(); j++) if (blank[j]) v[j].clear();
     }
     v.erase(std::partition(v.begin(), v.end(), not_empty), v.end());
 }
@@ -124,7 +185,7 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
         m.cand_token[k] = t;
     }
     // createNonRedundantSet: cluster every token in ascending token order (std::map iteration)
-    std::unordered_map<std::string, int> kmer_gid;
+    KmerGid kmer_gid;
     int next_gid = 1;
     std::vector<int> gid_of(m.tokens.size());
     for (uint32_t t = 0; t < m.tokens.size(); t++)

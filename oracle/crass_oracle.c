@@ -471,6 +471,9 @@ static int search_core(rh_t *h, const orc_params *o, int lattice_only)
     if (skips < 1) skips = 1;
     int searchEnd = (int)(seq_length - o->lowDRsize - o->lowSpacerSize - o->searchWindowLength - 1);
     if (searchEnd < 0) return 0;
+    /* lowDR < 2w-1 wraps `skips` to ~4e9: after a failed candidate the reference's j then moves
+     * backwards and the loop need not terminate.  Ill-defined there; reported as an error here. */
+    if (o->lowDRsize < 2 * o->searchWindowLength - 1) return -3;
     h->nss = 0;
     for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
         uint32_t beginSearch = j + o->lowDRsize + o->lowSpacerSize;

@@ -56,6 +56,7 @@ def test_param_validation(ca):
         p = ca.default_params(**kw)
         assert lib.crass_hip_create(C.byref(p), 0, C.byref(h)) == 1
     assert lib.crass_hip_create(C.byref(ca.default_params(highDRsize=500)), 0, C.byref(h)) == 2
+    assert lib.crass_hip_create(C.byref(ca.default_params(lowDRsize=8, searchWindowLength=9)), 0, C.byref(h)) == 2
     assert b"Fatal error in search algorithm" in lib.crass_hip_strerror(7)
 
 

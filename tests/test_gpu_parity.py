@@ -92,8 +92,8 @@ def test_synthetic_ragged_with_exceptions_and_duplicate_headers(ca):
 PARAM_SETS = [
     dict(searchWindowLength=6), dict(searchWindowLength=7), dict(searchWindowLength=9),
     dict(minNumRepeats=3), dict(lowDRsize=20, highDRsize=40), dict(lowSpacerSize=20, highSpacerSize=60),
-    dict(lowDRsize=8, highDRsize=60, searchWindowLength=9),     # skips wraps (unsigned), only j=0 is tried
     dict(kmer_clust_size=4), dict(lowDRsize=15, searchWindowLength=8),   # skips == 0 -> 1
+    dict(lowDRsize=11, highDRsize=30, searchWindowLength=6, lowSpacerSize=10, highSpacerSize=40),
 ]
 
 
@@ -106,6 +106,14 @@ def test_non_default_options(ca, kw):
     gpu = ca.search_pipeline(seqs, params=p)
     ref = orc.pipeline(seqs, params=to_orc_params(p))
     assert_same_pipeline(gpu, ref)
+
+
+def test_unsigned_skips_wrap_is_refused(ca):
+    """-d < 2w-1 wraps the reference's unsigned `skips` (libcrispr.cpp:281-285); the reference's
+    seed loop is then ill-defined (can walk backwards forever).  The engine refuses it."""
+    with pytest.raises(ca.CrassError) as e:
+        ca.SearchEngine(ca.default_params(lowDRsize=8, highDRsize=60, searchWindowLength=9))
+    assert e.value.status == 2
 
 
 def test_long_reads(ca):
