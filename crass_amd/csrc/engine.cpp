@@ -84,6 +84,9 @@ struct crass_hip_ctx {
     // automaton
     DevBuf<uint16_t> a_go16; DevBuf<uint32_t> a_go32; DevBuf<uint16_t> a_out; DevBuf<uint16_t> a_go4;
     DevAutomaton A{};
+    DevBuf<uint32_t> a_anchor; DevBuf<uint32_t> d_slot_info;
+    DevAnchors K{};
+    bool have_anchors = false;
     bool have_patterns = false;
     std::vector<std::string> patterns;
 
@@ -187,7 +190,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
     c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
-    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release();
+    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->a_anchor.release(); c->d_slot_info.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -349,7 +352,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, std::vect
     HIPCHK(c, c->d_ss_pool.ensure(pool_cap));
     HIPCHK(c, c->h_surv.ensure(chunk_cap));
     HIPCHK(c, c->h_dr.ensure(chunk_cap * c->dr_stride));
-    int grid = 256 * 8;
+    int grid = 256 * 32;
     for (uint64_t off = 0; off < n_total; off += chunk_cap) {
         const uint64_t nchunk = std::min(chunk_cap, n_total - off);
         HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
@@ -544,6 +547,18 @@ static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pa
     HIPCHK(c, hipStreamSynchronize(c->stream));
     A.out_len = c->a_out.p;
     c->A = A;
+    // anchor keys for the pass-2 fast path
+    c->have_anchors = false;
+    HostAnchors HK;
+    build_anchors(HK, pats);
+    if (HK.ok) {
+        HIPCHK(c, c->a_anchor.ensure(HK.table.size()));
+        HIPCHK(c, hipMemcpyAsync(c->a_anchor.p, HK.table.data(), HK.table.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->K.table = c->a_anchor.p; c->K.log_size = HK.log_size; c->K.s1 = HK.s1; c->K.s2 = HK.s2; c->K.s3 = HK.s3;
+        c->K.c2 = HK.c2; c->K.n_keys = HK.n_keys;
+        c->have_anchors = true;
+    }
     c->have_patterns = true;
     c->cnt.ac_states = H.n_states;
     return CRASS_OK;
@@ -612,10 +627,20 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         }
     }
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    hipError_t re = launch_recruit_lds(c->R, c->A, c->d_found.p, c->d_mask.p, c->d_hit_info.p, c->stream);
-    bool lds = (re == hipSuccess);
-    if (re == hipErrorNotSupported) { HIPCHK(c, launch_recruit_general(c->R, c->A, c->d_found.p, c->d_mask.p, c->d_hit_info.p, c->stream)); }
-    else if (re != hipSuccess) { c->last_hip = (int)re; return CRASS_ERR_HIP; }
+    // fast path: anchor filter (exact superset) then an exact scan of the flagged reads only;
+    // otherwise the automaton scans every read (LDS table when it fits).
+    bool anchors = false, lds = false;
+    if (c->have_anchors) {
+        hipError_t ae = launch_anchor_filter(c->R, c->K, c->d_found.p, c->d_mask.p, c->stream);
+        if (ae == hipSuccess) anchors = true;
+        else if (ae != hipErrorNotSupported) { c->last_hip = (int)ae; return CRASS_ERR_HIP; }
+    }
+    if (!anchors) {
+        hipError_t re = launch_recruit_lds(c->R, c->A, c->d_found.p, c->d_mask.p, c->d_hit_info.p, c->stream);
+        lds = (re == hipSuccess);
+        if (re == hipErrorNotSupported) { HIPCHK(c, launch_recruit_general(c->R, c->A, c->d_found.p, c->d_mask.p, c->d_hit_info.p, c->stream)); }
+        else if (re != hipSuccess) { c->last_hip = (int)re; return CRASS_ERR_HIP; }
+    }
     if (c->R.n_exc) {
         HIPCHK(c, c->d_exc_hit.ensure(c->R.n_exc));
         HIPCHK(c, launch_recruit_exceptions(c->R, c->A, c->d_found.p, c->d_exc_hit.p, c->stream));
@@ -631,9 +656,14 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     HIPCHK(c, c->h_rec.ensure(n_slots + 1));
     HIPCHK(c, c->h_dr.ensure((n_slots + 1) * c->dr_stride));
     HIPCHK(c, c->h_idx.ensure(n_hits + 1));
-    HIPCHK(c, launch_recruit_finish(c->R, c->d_idx.p, c->d_count.p, n_hits, c->d_hit_info.p, false, c->d_rec.p, c->d_dr.p, c->dr_stride, c->stream));
+    if (anchors) {
+        HIPCHK(c, c->d_slot_info.ensure(n_hits + 1));
+        HIPCHK(c, launch_recruit_list(c->R, c->A, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->stream));
+    }
+    HIPCHK(c, launch_recruit_finish(c->R, c->d_idx.p, c->d_count.p, n_hits, anchors ? c->d_slot_info.p : c->d_hit_info.p, anchors, false,
+                                    c->d_rec.p, c->d_dr.p, c->dr_stride, c->stream));
     if (c->R.n_exc)
-        HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, c->R.n_exc, c->d_exc_hit.p, true, c->d_rec.p + n_hits,
+        HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, c->R.n_exc, c->d_exc_hit.p, true, true, c->d_rec.p + n_hits,
                                         c->d_dr.p + n_hits * c->dr_stride, c->dr_stride, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     if (n_slots) {
@@ -648,6 +678,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const size_t nb = c->R.n_exc;
     auto exc_valid = [&](size_t b) { return c->h_rec.p[n_hits + b].dr_len != 0; };
     while (ib < nb && !exc_valid(ib)) ib++;
+    auto hit_valid = [&](size_t a) { return c->h_rec.p[a].dr_len != 0; };
+    while (ia < n_hits && !hit_valid(ia)) ia++;                  // anchor false positives carry no match
     c->q_dr.reserve(n_slots * c->dr_stride);
     while (ia < n_hits || ib < nb) {
         const bool takeA = ib >= nb || (ia < n_hits && c->h_idx.p[ia] < c->h_exc_read[ib]);
@@ -670,13 +702,14 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
             if (!tok) tok = c->merge.tokens.add(s);
         }
         c->q_token.push_back(tok);
-        if (takeA) ia++; else { ib++; while (ib < nb && !exc_valid(ib)) ib++; }
+        if (takeA) { ia++; while (ia < n_hits && !hit_valid(ia)) ia++; }
+        else { ib++; while (ib < nb && !exc_valid(ib)) ib++; }
     }
     if (c->have_merge) c->merge.flatten();
     c->have_pass2 = true;
     c->cnt.ms_sink_host += (float)(now_ms() - t0);
     c->cnt.n_pass2_found = c->q_read.size();
-    c->cnt.used_lds_automaton = lds ? 1 : 0;
+    c->cnt.used_lds_automaton = anchors ? 2 : (lds ? 1 : 0);     // 2 = anchor filter + exact list scan
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->cnt.ms_recruit = ms;
     (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->cnt.ms_recruit_finish = ms;

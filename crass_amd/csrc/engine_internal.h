@@ -60,6 +60,16 @@ struct DevAutomaton {
     uint32_t acgt_ok;             // n_states <= 65535 (go4 valid)
 };
 
+// pass-2 anchor filter: cuckoo hash set (two choices, one slot each) of every 16-mer that
+// starts at offset 0..7 of a pattern, as 32-bit packed values; lives in LDS.
+// h1(V) = (V ^ (V >> s1)) & mask ; h2(V) = ((V >> s2) ^ (V >> s3) ^ c2) & mask
+struct DevAnchors {
+    const uint32_t *table;        // [1 << log_size]; unused slots hold a member key
+    uint32_t log_size;
+    uint32_t s1, s2, s3, c2;
+    uint32_t n_keys;
+};
+
 // layout of the survivor kernel's dynamic LDS (bytes), computed on the host
 struct SurvLds {
     uint32_t seq_bytes;           // >= maxL + 16, multiple of 16
@@ -86,10 +96,14 @@ hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, cons
                                   uint64_t *hitmask, uint32_t *hit_info, hipStream_t st);
 hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
                               uint64_t *hitmask, uint32_t *hit_info, hipStream_t st);
+hipError_t launch_anchor_filter(const DevReads &R, const DevAnchors &K, const uint8_t *found_flag,
+                                uint64_t *hitmask, hipStream_t st);
+hipError_t launch_recruit_list(const DevReads &R, const DevAutomaton &A, const uint64_t *idx, const uint32_t *d_n,
+                               uint64_t n_max, uint32_t *info_by_slot, hipStream_t st);
 hipError_t launch_recruit_exceptions(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
                                      uint32_t *exc_hit_info /*[n_exc], 0 = none*/, hipStream_t st);
 hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, const uint32_t *d_n_hits,
-                                 uint64_t n_hits_max, const uint32_t *hit_info, bool exceptions,
+                                 uint64_t n_hits_max, const uint32_t *hit_info, bool info_by_slot, bool exceptions,
                                  RecruitOut *out, char *dr_chars, uint32_t dr_stride, hipStream_t st);
 hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off, const uint32_t *a_len,
                                     const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,

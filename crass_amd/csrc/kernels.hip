@@ -764,7 +764,7 @@ static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *
 }
 
 template <bool EXC>
-__global__ __launch_bounds__(WAVE) void k_survivor(DevReads R, DevParams P, const uint64_t *surv_idx,
+__global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, const uint64_t *surv_idx,
                                                    const uint32_t *d_n_surv, uint64_t n_max, SurvOut *out,
                                                    char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                                    uint32_t ss_pool_cap, uint32_t *d_ss_used,
@@ -972,6 +972,136 @@ hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const ui
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// pass 2 fast path: anchor filter + exact verification of the flagged reads.
+//
+// Every pattern has length >= 23.  If pattern P occurs at offset o of a read, let a be the
+// smallest multiple of 8 with a >= o (a <= o+7): bases [a, a+16) lie inside the occurrence
+// (a+16 <= o+23 <= o+|P|) and equal P[a-o .. a-o+16).  So the halfword-aligned 32-bit window
+// of the read at base a is one of the keys {P[r..r+16) : r = 0..7}.  The filter probes every
+// aligned window (ceil(L/8)-1 per read, all independent) in an exact LDS hash set of the keys:
+// no false negatives by construction; the rare false positives (a key occurring by chance,
+// ~n_keys * L/8 / 4^16) are removed by the exact automaton scan of the flagged reads
+// (k_recruit_list), which also yields ACISM's first-callback (end, length).
+// ------------------------------------------------------------------------------------
+static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_t V, const DevAnchors &K, uint32_t mask)
+{
+    uint32_t i1 = (V ^ (V >> K.s1)) & mask;
+    uint32_t i2 = ((V >> K.s2) ^ (V >> K.s3) ^ K.c2) & mask;
+    return tab[i1] == V || tab[i2] == V;
+}
+
+template <int W, int THREADS>     // W = uniform stride in words (0: ragged / any stride)
+__global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchors K, const uint8_t *found_flag, uint64_t *hitmask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds[];
+    const uint32_t tsize = 1u << K.log_size;
+    for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds[i] = K.table[i];
+    __syncthreads();
+    const uint32_t mask = tsize - 1;
+    const uint64_t n_tiles = (R.n_reads + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_global = (blockIdx.x * (uint64_t)THREADS + threadIdx.x) >> 6;
+    const uint64_t wave_total = ((uint64_t)gridDim.x * THREADS) >> 6;
+    for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_total) {
+        const uint64_t r = tile * 64 + lane;
+        bool flag = false;
+        if (r < R.n_reads && !rd_is_exc(R, r) && !found_flag[rd_header_id(R, r)]) {
+            const uint32_t L = rd_len(R, r);
+            const uint32_t *g = R.packed + rd_word_off(R, r);
+            if (L >= 16) {
+                const uint32_t h_max = (L - 16) >> 3;            // last halfword position whose 16-mer is inside the read
+                if (W > 0) {
+                    uint32_t w[W + 1];
+#pragma unroll
+                    for (int i = 0; i < W; i++) w[i] = g[i];
+                    w[W] = 0;
+#pragma unroll
+                    for (int h = 0; h < 2 * W - 1; h++) {
+                        uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
+                        bool hit = anchor_probe(ak_lds, V, K, mask);
+                        flag = flag || (hit && (uint32_t)h <= h_max);
+                    }
+                } else {
+                    const uint32_t nw = (L + 15) >> 4;
+                    uint32_t lo = g[0];
+                    for (uint32_t h = 0; h <= h_max; h += 2) {
+                        uint32_t hi = ((h >> 1) + 1 < nw) ? g[(h >> 1) + 1] : 0u;
+                        if (anchor_probe(ak_lds, lo, K, mask)) flag = true;
+                        if (h + 1 <= h_max && anchor_probe(ak_lds, (lo >> 16) | (hi << 16), K, mask)) flag = true;
+                        lo = hi;
+                    }
+                }
+            }
+        }
+        uint64_t m = __ballot(flag);
+        if (lane == 0) hitmask[tile] = m;
+    }
+}
+
+hipError_t launch_anchor_filter(const DevReads &R, const DevAnchors &K, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st)
+{
+    if (R.n_reads == 0) return hipSuccess;
+    const size_t lds = (size_t)4 << K.log_size;
+    if (lds > 128 * 1024) return hipErrorNotSupported;
+    const uint64_t n_tiles = (R.n_reads + 63) / 64;
+    constexpr int T = 1024;
+    uint64_t blocks = (n_tiles + (T / 64) - 1) / (T / 64);
+    const uint64_t cap = lds > 80 * 1024 ? 256 : (lds > 40 * 1024 ? 512 : 1024);
+    if (blocks > cap) blocks = cap;
+    hipError_t e;
+#define AK_LAUNCH(WW)                                                                                                   \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_anchor_filter<WW, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                                                      \
+    hipLaunchKernelGGL((k_anchor_filter<WW, T>), dim3((unsigned)blocks), dim3(T), lds, st, R, K, found_flag, hitmask);
+    switch (R.stride_words) {
+        case 4: AK_LAUNCH(4) break;  case 5: AK_LAUNCH(5) break;  case 6: AK_LAUNCH(6) break;  case 7: AK_LAUNCH(7) break;
+        case 8: AK_LAUNCH(8) break;  case 9: AK_LAUNCH(9) break;  case 10: AK_LAUNCH(10) break; case 11: AK_LAUNCH(11) break;
+        case 12: AK_LAUNCH(12) break; case 13: AK_LAUNCH(13) break; case 14: AK_LAUNCH(14) break; case 15: AK_LAUNCH(15) break;
+        case 16: AK_LAUNCH(16) break;
+        default: AK_LAUNCH(0) break;
+    }
+#undef AK_LAUNCH
+    return hipGetLastError();
+}
+
+// exact first-match scan of the flagged reads (lane per flagged read), transition table in global
+// memory (L2-resident).  info_by_slot[k] = (end_exclusive << 8) | length, 0 = no pattern occurs.
+__global__ __launch_bounds__(256) void k_recruit_list(DevReads R, DevAutomaton A, const uint64_t *idx, const uint32_t *d_n,
+                                                       uint64_t n_max, uint32_t *info_by_slot)
+{
+    uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t n = *d_n;
+    if (n > n_max) n = n_max;
+    if (k >= n) return;
+    const uint64_t r = idx[k];
+    const uint32_t L = rd_len(R, r);
+    const uint32_t *g = R.packed + rd_word_off(R, r);
+    const uint32_t symA = A.sym['A'], symC = A.sym['C'], symG = A.sym['G'], symT = A.sym['T'];
+    uint32_t state = 0, word = 0, info = 0;
+    for (uint32_t i = 0; i < L; i++) {
+        if ((i & 15u) == 0) word = g[i >> 4];
+        uint32_t c = word & 3u;
+        word >>= 2;
+        if (A.go4) state = A.go4[state * 4 + c];
+        else {
+            uint32_t sy = c == 0 ? symA : c == 1 ? symC : c == 2 ? symG : symT;
+            state = A.go16 ? (uint32_t)A.go16[(size_t)state * A.n_sym1 + sy] : A.go32[(size_t)state * A.n_sym1 + sy];
+        }
+        uint32_t ol = A.out_len[state];
+        if (ol) { info = ((i + 1) << 8) | ol; break; }
+    }
+    info_by_slot[k] = info;
+}
+
+hipError_t launch_recruit_list(const DevReads &R, const DevAutomaton &A, const uint64_t *idx, const uint32_t *d_n,
+                               uint64_t n_max, uint32_t *info_by_slot, hipStream_t st)
+{
+    if (n_max == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_recruit_list, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot);
+    return hipGetLastError();
+}
+
 // exception reads: raw bytes through the byte-symbol automaton, lane per exception read
 __global__ __launch_bounds__(256) void k_recruit_exc(DevReads R, DevAutomaton A, const uint8_t *found_flag, uint32_t *exc_hit_info)
 {
@@ -1005,8 +1135,8 @@ hipError_t launch_recruit_exceptions(const DevReads &R, const DevAutomaton &A, c
 // (libcrispr.cpp:408-442, ReadHolder.cpp:524-528,573-590).  Thread per hit.
 template <bool EXC>
 __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64_t *hit_idx, const uint32_t *d_n_hits,
-                                                        uint64_t n_max, const uint32_t *hit_info, RecruitOut *out,
-                                                        char *dr_chars, uint32_t dr_stride)
+                                                        uint64_t n_max, const uint32_t *hit_info, int info_by_slot,
+                                                        RecruitOut *out, char *dr_chars, uint32_t dr_stride)
 {
     uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t n = EXC ? R.n_exc : (uint64_t)(*d_n_hits);
@@ -1023,11 +1153,11 @@ __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64
         L = (uint32_t)(R.exc_off[k + 1] - o0);
     } else {
         r = hit_idx[k];
-        info = hit_info[r];
+        info = info_by_slot ? hit_info[k] : hit_info[r];
         L = rd_len(R, r);
         g = R.packed + rd_word_off(R, r);
     }
-    if (info == 0) { out[k] = o; return; }              // EXC only: no match for this exception read
+    if (info == 0) { out[k] = o; return; }              // no match (exception read / anchor false positive)
     uint32_t textpos = info >> 8, len = info & 0xFFu;
     uint32_t DR_end = textpos - 1;
     if (DR_end >= L) DR_end = L - 1;
@@ -1056,15 +1186,15 @@ __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64
 }
 
 hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, const uint32_t *d_n_hits, uint64_t n_hits_max,
-                                 const uint32_t *hit_info, bool exceptions, RecruitOut *out, char *dr_chars,
-                                 uint32_t dr_stride, hipStream_t st)
+                                 const uint32_t *hit_info, bool info_by_slot, bool exceptions, RecruitOut *out,
+                                 char *dr_chars, uint32_t dr_stride, hipStream_t st)
 {
     if (n_hits_max == 0) return hipSuccess;
     unsigned nb = (unsigned)((n_hits_max + 255) / 256);
     if (exceptions)
-        hipLaunchKernelGGL(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, out, dr_chars, dr_stride);
+        hipLaunchKernelGGL(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, 1, out, dr_chars, dr_stride);
     else
-        hipLaunchKernelGGL(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, out, dr_chars, dr_stride);
+        hipLaunchKernelGGL(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, info_by_slot ? 1 : 0, out, dr_chars, dr_stride);
     return hipGetLastError();
 }
 

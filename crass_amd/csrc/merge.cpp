@@ -261,6 +261,59 @@ void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns)
     }
 }
 
+void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns)
+{
+    k = HostAnchors();
+    std::vector<uint32_t> keys;
+    for (const auto &p : patterns) {
+        bool acgt = true;
+        for (unsigned char c : p) if (acgt_code(c) < 0) { acgt = false; break; }
+        if (!acgt) continue;                       // cannot occur in a packed (ACGT-only) read
+        if (p.size() < 23) return;                 // the anchor argument needs |P| >= 16 + 7
+        for (int r = 0; r < 8; r++) {
+            uint32_t v = 0;
+            for (int i = 0; i < 16; i++) v |= (uint32_t)acgt_code((unsigned char)p[(size_t)r + i]) << (2 * i);
+            keys.push_back(v);
+        }
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    k.n_keys = (uint32_t)keys.size();
+    if (keys.empty()) { k.ok = false; return; }
+    static const uint32_t S1[] = {15, 13, 17, 11, 9};
+    static const uint32_t S23[][2] = {{7, 19}, {9, 21}, {5, 23}, {11, 17}, {3, 14}};
+    for (uint32_t log_size = 10; log_size <= 15; log_size++) {
+        const uint32_t size = 1u << log_size, mask = size - 1;
+        if (keys.size() * 2 > size) continue;                     // keep the load factor <= 0.5
+        for (uint32_t a = 0; a < 5; a++) for (uint32_t b = 0; b < 5; b++) {
+            const uint32_t s1 = S1[a], s2 = S23[b][0], s3 = S23[b][1], c2 = 0x9E3779B9u & mask;
+            auto h1 = [&](uint32_t v) { return (v ^ (v >> s1)) & mask; };
+            auto h2 = [&](uint32_t v) { return ((v >> s2) ^ (v >> s3) ^ c2) & mask; };
+            std::vector<uint32_t> tab(size, 0);
+            std::vector<char> used(size, 0);
+            bool ok = true;
+            for (uint32_t key : keys) {
+                uint32_t cur = key;
+                uint32_t pos = h1(cur);
+                int kicks = 0;
+                for (;;) {
+                    if (!used[pos]) { tab[pos] = cur; used[pos] = 1; break; }
+                    std::swap(cur, tab[pos]);                     // evict
+                    const uint32_t p1 = h1(cur), p2 = h2(cur);
+                    pos = (pos == p1) ? p2 : p1;
+                    if (++kicks > 500) { ok = false; break; }
+                }
+                if (!ok) break;
+            }
+            if (!ok) continue;
+            for (uint32_t i = 0; i < size; i++) if (!used[i]) tab[i] = keys[0];   // unused slots hold a member key
+            k.ok = true; k.log_size = log_size; k.s1 = s1; k.s2 = s2; k.s3 = s3; k.c2 = c2;
+            k.table.swap(tab);
+            return;
+        }
+    }
+}
+
 } // namespace crass
 
 // ---- context-free C entry points (include/crass_hip.h) ----

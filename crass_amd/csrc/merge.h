@@ -54,4 +54,13 @@ struct HostAutomaton {
 };
 void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns);
 
+// pass-2 anchor keys: every 16-mer starting at offset 0..7 of an ACGT-only pattern, packed like
+// the reads (base i in bits 2i..2i+1), in a two-choice cuckoo table (see kernels.hip).
+struct HostAnchors {
+    bool ok = false;                    // false: some pattern is shorter than 23 or the table would not fit
+    uint32_t log_size = 0, s1 = 0, s2 = 0, s3 = 0, c2 = 0, n_keys = 0;
+    std::vector<uint32_t> table;
+};
+void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns);
+
 } // namespace crass

@@ -199,7 +199,8 @@ typedef struct {
     uint64_t n_pass1_found, n_pass2_found;
     uint32_t n_patterns, ac_states;
     uint32_t used_fast_filter;      /* 1: bit-parallel lane-per-read kernel, 0: general           */
-    uint32_t used_lds_automaton;    /* 1: pass-2 automaton fitted in LDS                          */
+    uint32_t used_lds_automaton;    /* pass 2: 2 = anchor filter + exact scan of flagged reads,
+                                       1 = automaton in LDS over all reads, 0 = automaton in L2   */
     /* HIP-event timings of the last call, milliseconds, measured on the context's stream      */
     float ms_filter, ms_compact, ms_survivor, ms_pass1_total;
     float ms_recruit, ms_recruit_finish, ms_pass2_total;
