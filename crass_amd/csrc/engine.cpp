@@ -555,8 +555,8 @@ static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pa
         HIPCHK(c, c->a_anchor.ensure(HK.table.size()));
         HIPCHK(c, hipMemcpyAsync(c->a_anchor.p, HK.table.data(), HK.table.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->K.table = c->a_anchor.p; c->K.log_size = HK.log_size; c->K.s1 = HK.s1; c->K.s2 = HK.s2; c->K.s3 = HK.s3;
-        c->K.c2 = HK.c2; c->K.n_keys = HK.n_keys;
+        c->K.table = c->a_anchor.p; c->K.log_size = HK.log_size; c->K.s1 = HK.s1; c->K.s2 = HK.s2; c->K.m1 = HK.m1;
+        c->K.m2 = HK.m2; c->K.n_keys = HK.n_keys;
         c->have_anchors = true;
     }
     c->have_patterns = true;

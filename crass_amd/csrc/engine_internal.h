@@ -62,11 +62,11 @@ struct DevAutomaton {
 
 // pass-2 anchor filter: cuckoo hash set (two choices, one slot each) of every 16-mer that
 // starts at offset 0..7 of a pattern, as 32-bit packed values; lives in LDS.
-// h1(V) = (V ^ (V >> s1)) & mask ; h2(V) = ((V >> s2) ^ (V >> s3) ^ c2) & mask
+// h_i(V) = mul_u24(V ^ (V >> s_i), m_i) >> (32 - log_size)   (v_mul_u32_u24 is full rate)
 struct DevAnchors {
     const uint32_t *table;        // [1 << log_size]; unused slots hold a member key
     uint32_t log_size;
-    uint32_t s1, s2, s3, c2;
+    uint32_t s1, s2, m1, m2;
     uint32_t n_keys;
 };
 

@@ -984,10 +984,10 @@ hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const ui
 // ~n_keys * L/8 / 4^16) are removed by the exact automaton scan of the flagged reads
 // (k_recruit_list), which also yields ACISM's first-callback (end, length).
 // ------------------------------------------------------------------------------------
-static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_t V, const DevAnchors &K, uint32_t mask)
+static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_t V, const DevAnchors &K, uint32_t rshift)
 {
-    uint32_t i1 = (V ^ (V >> K.s1)) & mask;
-    uint32_t i2 = ((V >> K.s2) ^ (V >> K.s3) ^ K.c2) & mask;
+    uint32_t i1 = __umul24(V ^ (V >> K.s1), K.m1) >> rshift;
+    uint32_t i2 = __umul24(V ^ (V >> K.s2), K.m2) >> rshift;
     return tab[i1] == V || tab[i2] == V;
 }
 
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
     const uint32_t tsize = 1u << K.log_size;
     for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds[i] = K.table[i];
     __syncthreads();
-    const uint32_t mask = tsize - 1;
+    const uint32_t mask = 32u - K.log_size;          // right shift that keeps the top log_size bits
     const uint64_t n_tiles = (R.n_reads + 63) / 64;
     const int lane = threadIdx.x & 63;
     const uint64_t wave_global = (blockIdx.x * (uint64_t)THREADS + threadIdx.x) >> 6;

@@ -280,15 +280,18 @@ void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns)
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     k.n_keys = (uint32_t)keys.size();
     if (keys.empty()) { k.ok = false; return; }
-    static const uint32_t S1[] = {15, 13, 17, 11, 9};
-    static const uint32_t S23[][2] = {{7, 19}, {9, 21}, {5, 23}, {11, 17}, {3, 14}};
+    // h_i(V) = mul_u24(V ^ (V >> s_i), m_i) >> (32 - log_size): 24-bit multiplies are full rate on
+    // the device; a few (shift, multiplier) pairs are tried until the cuckoo insertion succeeds.
+    static const uint32_t SH[][2] = {{15, 13}, {17, 11}, {14, 9}, {16, 12}};
+    static const uint32_t MU[][2] = {{0x9E3779u, 0x85EBCBu}, {0xC2B2AFu, 0x27D4EBu}, {0x7FEB35u, 0x846CA7u}, {0xB5297Bu, 0x68E31Du}};
+    auto mul24 = [](uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) & 0xFFFFFFFFull); };
     for (uint32_t log_size = 10; log_size <= 15; log_size++) {
-        const uint32_t size = 1u << log_size, mask = size - 1;
+        const uint32_t size = 1u << log_size, rsh = 32 - log_size;
         if (keys.size() * 2 > size) continue;                     // keep the load factor <= 0.5
-        for (uint32_t a = 0; a < 5; a++) for (uint32_t b = 0; b < 5; b++) {
-            const uint32_t s1 = S1[a], s2 = S23[b][0], s3 = S23[b][1], c2 = 0x9E3779B9u & mask;
-            auto h1 = [&](uint32_t v) { return (v ^ (v >> s1)) & mask; };
-            auto h2 = [&](uint32_t v) { return ((v >> s2) ^ (v >> s3) ^ c2) & mask; };
+        for (uint32_t a = 0; a < 4; a++) for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t s1 = SH[a][0], s2 = SH[a][1], m1 = MU[b][0], m2 = MU[b][1];
+            auto h1 = [&](uint32_t v) { return mul24(v ^ (v >> s1), m1) >> rsh; };
+            auto h2 = [&](uint32_t v) { return mul24(v ^ (v >> s2), m2) >> rsh; };
             std::vector<uint32_t> tab(size, 0);
             std::vector<char> used(size, 0);
             bool ok = true;
@@ -307,7 +310,7 @@ void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns)
             }
             if (!ok) continue;
             for (uint32_t i = 0; i < size; i++) if (!used[i]) tab[i] = keys[0];   // unused slots hold a member key
-            k.ok = true; k.log_size = log_size; k.s1 = s1; k.s2 = s2; k.s3 = s3; k.c2 = c2;
+            k.ok = true; k.log_size = log_size; k.s1 = s1; k.s2 = s2; k.m1 = m1; k.m2 = m2;
             k.table.swap(tab);
             return;
         }

@@ -58,7 +58,7 @@ void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns)
 // the reads (base i in bits 2i..2i+1), in a two-choice cuckoo table (see kernels.hip).
 struct HostAnchors {
     bool ok = false;                    // false: some pattern is shorter than 23 or the table would not fit
-    uint32_t log_size = 0, s1 = 0, s2 = 0, s3 = 0, c2 = 0, n_keys = 0;
+    uint32_t log_size = 0, s1 = 0, s2 = 0, m1 = 0, m2 = 0, n_keys = 0;
     std::vector<uint32_t> table;
 };
 void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns);
