@@ -986,9 +986,11 @@ hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const ui
 // ------------------------------------------------------------------------------------
 static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_t V, const DevAnchors &K, uint32_t rshift)
 {
-    uint32_t i1 = __umul24(V ^ (V >> K.s1), K.m1) >> rshift;
-    uint32_t i2 = __umul24(V ^ (V >> K.s2), K.m2) >> rshift;
-    return tab[i1] == V || tab[i2] == V;
+    // (cast: __umul24 is declared returning int, a plain >> would be an arithmetic shift)
+    uint32_t i1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1) >> rshift;
+    uint32_t i2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2) >> rshift;
+    const uint32_t a = tab[i1], b = tab[i2];            // both probes always issued: independent LDS reads, no branches
+    return (a == V) | (b == V);
 }
 
 template <int W, int THREADS>     // W = uniform stride in words (0: ragged / any stride)
@@ -1020,7 +1022,7 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
                     for (int h = 0; h < 2 * W - 1; h++) {
                         uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
                         bool hit = anchor_probe(ak_lds, V, K, mask);
-                        flag = flag || (hit && (uint32_t)h <= h_max);
+                        flag = flag | (hit & ((uint32_t)h <= h_max));
                     }
                 } else {
                     const uint32_t nw = (L + 15) >> 4;
