@@ -697,9 +697,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         memcpy(c->q_dr.data() + at, dr, o.dr_len);
         uint32_t tok = 0;
         if (c->have_merge) {
-            std::string s(dr, o.dr_len);
-            tok = c->merge.tokens.get(s);
-            if (!tok) tok = c->merge.tokens.add(s);
+            tok = c->merge.tokens.get(dr, o.dr_len);
+            if (!tok) tok = c->merge.tokens.add(dr, o.dr_len);
         }
         c->q_token.push_back(tok);
         if (takeA) { ia++; while (ia < n_hits && !hit_valid(ia)) ia++; }

@@ -321,6 +321,8 @@ struct RH {                 // ReadHolder state (ReadHolder.h:440-451), wave-uni
     int replen;             // RH_RepeatLength
     int err;
     uint16_t *rowA, *rowB;  // Levenshtein block-boundary rows (LDS)
+    const uint32_t *words;  // LDS copy of the 2-bit packed read (+1 zero word), nullptr for exception reads
+    uint32_t cmask;         // (1 << 2w) - 1
 };
 
 // leftmost occurrence of seq[pat, pat+plen) in seq[begin, end): PatternMatcher::bmpSearch
@@ -341,6 +343,28 @@ static __device__ int wave_find(const uint8_t *seq, int begin, int end, int pat,
         if (m) return p0 + (__ffsll((unsigned long long)m) - 1);
     }
     return -1;
+}
+
+// same contract on the 2-bit packed copy: a w-mer is one <=18-bit code, so a window compare is
+// one LDS word pair + funnel shift per lane instead of w byte compares
+static __device__ int wave_find_packed(const uint32_t *words, uint32_t cmask, int begin, int end, int pat, int plen, int lane)
+{
+    int tlen = end - begin;
+    if (tlen <= 0 || plen <= 0 || plen > tlen) return -1;
+    const uint32_t sj = lds_code(words, (uint32_t)pat, cmask);
+    for (int p0 = begin; p0 + plen <= end; p0 += WAVE) {
+        int p = p0 + lane;
+        bool ok = (p + plen <= end) && (lds_code(words, (uint32_t)p, cmask) == sj);
+        uint64_t m = __ballot(ok);
+        if (m) return p0 + (__ffsll((unsigned long long)m) - 1);
+    }
+    return -1;
+}
+
+static __device__ __forceinline__ int rh_find(const RH &h, int begin, int end, int pat, int plen, int lane)
+{
+    if (h.words) return wave_find_packed(h.words, h.cmask, begin, end, pat, plen, lane);
+    return wave_find(h.seq, begin, end, pat, plen, lane);
 }
 
 // ReadHolder::startStopsAdd, ReadHolder.cpp:263-297
@@ -371,7 +395,7 @@ static __device__ void scan_right(RH &h, int pat, uint32_t pattern_length, uint3
         if (begin_search > read_length - 1) return;
         if (end_search > read_length) end_search = read_length;
         if (begin_search >= end_search) return;
-        int position = wave_find(h.seq, (int)begin_search, (int)end_search, pat, (int)pattern_length, lane);
+        int position = rh_find(h, (int)begin_search, (int)end_search, pat, (int)pattern_length, lane);
         if (position >= 0) {
             uint32_t found = (uint32_t)position;        // wave_find returns absolute positions
             rh_add(h, found, found + pattern_length - 1, lane);
@@ -490,6 +514,14 @@ static __device__ bool is_low_complexity(const uint8_t *rep, int n, int lane)
     return (a > cut_off) || (t > cut_off) || (g > cut_off) || (c > cut_off) || (o > cut_off);
 }
 
+// value of lane-1 (lane 0 receives 0): one DPP move (v_mov_b32_dpp wave_shr:1), a few cycles,
+// instead of a ds_bpermute round trip through the LDS crossbar — the DP below is a dependent
+// chain of these, so their latency is the kernel's critical path.
+static __device__ __forceinline__ int wave_shr1(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
 // PatternMatcher::levenstheinDistance, PatternMatcher.cpp:111-195, as an anti-diagonal wavefront:
 // lane = DP row inside a 64-row block, one DP column step per iteration; neighbours arrive by
 // lane shuffles, block-boundary rows go through LDS.  The recurrence (including the
@@ -515,8 +547,8 @@ static __device__ int wave_lev(const uint8_t *s, int n, const uint8_t *t, int m,
         const bool more = (b + 1 < nblocks);
         for (int d = 0; d < steps; d++) {
             const int j = d - lane + 1;                  // my column this step
-            int up_left = __shfl_up(left, 1);            // lane-1: M[i-1][j]
-            int up_pppa = __shfl_up(pppa, 1);            // lane-1: M[i-2][j-2]
+            int up_left = wave_shr1(left);               // lane-1: M[i-1][j]
+            int up_pppa = wave_shr1(pppa);               // lane-1: M[i-2][j-2]
             const bool act = rowvalid && j >= 1 && j <= m;
             if (lane == 0) {
                 if (b == 0) { up_left = j; up_pppa = 0; }
@@ -660,7 +692,7 @@ static __device__ int search_core(RH &h, const DevParams &o, int lane)
         if (endSearch >= seq_length) endSearch = seq_length - 1;
         if (endSearch < beginSearch) endSearch = beginSearch;
         if (beginSearch > seq_length) return -1;                       // substr would throw
-        int pos = wave_find(h.seq, (int)beginSearch, (int)endSearch, (int)j, (int)o.window, lane);
+        int pos = rh_find(h, (int)beginSearch, (int)endSearch, (int)j, (int)o.window, lane);
         if (pos >= 0) {
             rh_add(h, j, j + o.window - 1, lane);
             rh_add(h, (uint32_t)pos, (uint32_t)pos + o.window - 1, lane);
@@ -740,13 +772,15 @@ static __device__ int dr_low_lexi(RH &h, char *dr_out, int &was_low_lexi, int la
     return (int)dlen;
 }
 
-static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *seq, int L, int lane)
+static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *seq, uint32_t *words, int L, int lane)
 {
     const uint32_t *g = R.packed + rd_word_off(R, r);
     const uint32_t lut = ('A') | ('C' << 8) | ('G' << 16) | ('T' << 24);
     const int nw = (L + 15) >> 4;
+    if (lane == 0) words[nw] = 0;                 // lds_code reads one word past the last
     for (int wi = lane; wi < nw; wi += WAVE) {
         uint32_t v = g[wi];
+        words[wi] = v;
         uint32_t o[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -778,6 +812,9 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
     h.cap = (int)lds.ss_cap;
     h.rowA = reinterpret_cast<uint16_t *>(h.ss + lds.ss_cap);
     h.rowB = h.rowA + lds.row_elems;
+    uint32_t *l_words = reinterpret_cast<uint32_t *>(h.rowB + lds.row_elems);
+    h.words = EXC ? nullptr : l_words;
+    h.cmask = (1u << (2 * P.window)) - 1u;
     uint64_t n_surv = EXC ? R.n_exc : (uint64_t)(*d_n_surv);
     if (n_surv > n_max) n_surv = n_max;
     for (uint64_t s = blockIdx.x; s < n_surv; s += gridDim.x) {
@@ -792,7 +829,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
         } else {
             r = surv_idx[s];
             L = (int)rd_len(R, r);
-            load_read_to_lds(R, r, h.seq, L, lane);
+            load_read_to_lds(R, r, h.seq, l_words, L, lane);
         }
         wave_sync();
         h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
@@ -828,7 +865,8 @@ SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P)
     uint32_t reps = max_len / (P.window + P.lowSp) + 4;
     l.ss_cap = ((2 * reps) + 3u) & ~3u;
     l.row_elems = ((max_len + 8) + 7u) & ~7u;
-    l.total_bytes = l.seq_bytes + l.ss_cap * 4 + 2 * l.row_elems * 2;
+    uint32_t words = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
+    l.total_bytes = l.seq_bytes + l.ss_cap * 4 + 2 * l.row_elems * 2 + words * 4;
     return l;
 }
 

@@ -4,6 +4,9 @@
 #include "../../include/crass_hip.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -42,6 +45,55 @@ std::string reverse_complement(const std::string &s)
     return r;
 }
 
+uint64_t TokenTable::hash(const char *p, size_t n)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xD6E8FEB86659FD93ull);
+    while (n >= 8) { uint64_t v; memcpy(&v, p, 8); h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; p += 8; n -= 8; }
+    if (n) { uint64_t v = 0; memcpy(&v, p, n); h = (h ^ v) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29; }
+    return h ^ (h >> 31);
+}
+
+uint32_t TokenTable::get(const char *p, size_t n) const
+{
+    if (slot_token.empty()) return 0;
+    const uint64_t h = hash(p, n);
+    const size_t mask = slot_token.size() - 1;
+    for (size_t i = (size_t)h & mask;; i = (i + 1) & mask) {
+        const uint32_t t = slot_token[i];
+        if (!t) return 0;
+        if (slot_hash[i] == h) {
+            const std::string &s = strings[t - 2];
+            if (s.size() == n && memcmp(s.data(), p, n) == 0) return t;
+        }
+    }
+}
+
+void TokenTable::grow()
+{
+    const size_t cap = slot_token.empty() ? 1024 : slot_token.size() * 2;
+    std::vector<uint32_t> nt(cap, 0);
+    std::vector<uint64_t> nh(cap, 0);
+    for (size_t i = 0; i < slot_token.size(); i++) if (slot_token[i]) {
+        size_t j = (size_t)slot_hash[i] & (cap - 1);
+        while (nt[j]) j = (j + 1) & (cap - 1);
+        nt[j] = slot_token[i]; nh[j] = slot_hash[i];
+    }
+    slot_token.swap(nt); slot_hash.swap(nh);
+}
+
+uint32_t TokenTable::add(const char *p, size_t n)
+{
+    if ((strings.size() + 1) * 2 > slot_token.size()) grow();
+    strings.emplace_back(p, n);
+    const uint32_t t = (uint32_t)strings.size() + 1;
+    const uint64_t h = hash(p, n);
+    const size_t mask = slot_token.size() - 1;
+    size_t i = (size_t)h & mask;
+    while (slot_token[i]) i = (i + 1) & mask;
+    slot_token[i] = t; slot_hash[i] = h;
+    return t;
+}
+
 void MergeResult::clear()
 {
     tokens.clear(); cand_token.clear(); groups.clear(); patterns.clear(); pat_group.clear();
@@ -73,9 +125,16 @@ inline int acgt_code(unsigned char c)
 // lexicographic order and laurenize() is a min of two integers) in a flat table; anything else
 // falls back to string keys.  Same lookups, same results, ~50x less host time per variant.
 struct KmerGid {
-    std::vector<int32_t> flat;                                  // 4^11 entries, 0 = unseen
+    std::vector<int32_t> &flat;                                 // 4^11 entries, 0 = unseen (16 MB, kept per thread)
+    std::vector<uint32_t> touched;
     std::unordered_map<std::string, int> other;
-    KmerGid() : flat((size_t)1 << 22, 0) {}
+    static std::vector<int32_t> &storage()
+    {
+        static thread_local std::vector<int32_t> v((size_t)1 << 22, 0);
+        return v;
+    }
+    KmerGid() : flat(storage()) {}
+    ~KmerGid() { for (uint32_t k : touched) flat[k] = 0; }      // leave the table all-zero for the next merge
 };
 
 // WorkHorse::clusterDRReads (WorkHorse.cpp:1404-1637): greedy, order-dependent assignment of
@@ -116,7 +175,7 @@ int cluster_one(const std::string &dr, int &next_free_gid, KmerGid &kg, int min_
         }
     }
     if (group == 0) group = next_free_gid++;
-    for (uint32_t k : homeless_code) kg.flat[k] = group;
+    for (uint32_t k : homeless_code) { kg.flat[k] = group; kg.touched.push_back(k); }
     for (const auto &k : homeless_str) kg.other[k] = group;
     return group;
 }
@@ -131,29 +190,81 @@ inline uint64_t hash_bytes(const char *p, size_t n)
     return h;
 }
 
+// 2-bit code of s[pos, pos+16) (first base least significant); false if a non-ACGT byte is inside
+inline bool code16(const std::string &s, size_t pos, uint32_t &out)
+{
+    uint32_t v = 0;
+    for (int i = 0; i < 16; i++) { int c = acgt_code((unsigned char)s[pos + i]); if (c < 0) return false; v |= (uint32_t)c << (2 * i); }
+    out = v;
+    return true;
+}
+
 // WorkHorse::removeRedundantRepeats (WorkHorse.cpp:612-645) with includeSubstring (:78-86).
 // A string is blanked iff some strictly shorter member (or its reverse complement) occurs in it
 // (equal-length members can only contain each other if identical, and tokens are distinct), so
-// the O(n^2) pairwise find() is replaced by an index of every member's leading `kAnchor` bytes.
+// the O(n^2) pairwise find() is replaced by an index of every member's leading 16 bytes: for
+// ACGT-only groups a 32-bit 2-bit code rolled along the haystack and looked up in a small
+// open-addressing table behind a bitmap pre-filter; byte-hash index otherwise.
 // The std::sort / std::partition calls are kept so that the surviving ORDER is what the
 // reference produces with the same libstdc++ (pass 2 depends on the set only).
 void remove_redundant(std::vector<std::string> &v)
 {
     std::sort(v.begin(), v.end(), shorter_first);
     if (v.size() > 1) {
-        size_t min_len = v.front().size();
-        const size_t kAnchor = std::min<size_t>(16, min_len);
+        const size_t min_len = v.front().size();
         std::vector<char> blank(v.size(), 0);
-        if (kAnchor == 0) {
+        bool all_acgt = min_len >= 16;
+        for (size_t i = 0; i < v.size() && all_acgt; i++)
+            for (unsigned char c : v[i]) if (acgt_code(c) < 0) { all_acgt = false; break; }
+        if (min_len == 0) {
             for (size_t j = 1; j < v.size(); j++) blank[j] = 1;    // an empty string is a substring of everything
+        } else if (all_acgt) {
+            // index: leading 16-mer code -> chain of members
+            size_t cap = 64;
+            while (cap < v.size() * 4) cap <<= 1;
+            std::vector<int32_t> head(cap, -1), next(v.size(), -1);
+            std::vector<uint32_t> keyv(v.size());
+            std::vector<uint64_t> bitmap(1024, 0);                 // 65536-bit pre-filter
+            auto slot_of = [&](uint32_t key) { return (size_t)((key * 0x9E3779B1u) >> 7) & (cap - 1); };
+            auto bit_of = [&](uint32_t key) { return (uint32_t)((key * 0x85EBCA6Bu) >> 16); };
+            for (uint32_t i = 0; i < v.size(); i++) {
+                uint32_t key = 0;
+                code16(v[i], 0, key);
+                keyv[i] = key;
+                const size_t sl = slot_of(key);
+                next[i] = head[sl]; head[sl] = (int32_t)i;
+                const uint32_t b = bit_of(key);
+                bitmap[b >> 6] |= 1ull << (b & 63);
+            }
+            std::string rc;
+            for (size_t j = 0; j < v.size(); j++) {
+                const std::string &s = v[j];
+                rc = reverse_complement(s);
+                // t or revcomp(t) occurs in s  <=>  t occurs in s or in revcomp(s)
+                for (const std::string *hay : {&s, (const std::string *)&rc}) {
+                    uint32_t code = 0;
+                    for (size_t p = 0; p + 16 <= hay->size() && !blank[j]; p++) {
+                        if (p == 0) code16(*hay, 0, code);
+                        else code = (code >> 2) | ((uint32_t)acgt_code((unsigned char)(*hay)[p + 15]) << 30);
+                        const uint32_t b = bit_of(code);
+                        if (!(bitmap[b >> 6] >> (b & 63) & 1)) continue;
+                        for (int32_t i = head[slot_of(code)]; i >= 0; i = next[i]) {
+                            if (keyv[i] != code) continue;
+                            const std::string &t = v[(size_t)i];
+                            if (t.size() < s.size() && p + t.size() <= hay->size() && memcmp(hay->data() + p, t.data(), t.size()) == 0) { blank[j] = 1; break; }
+                        }
+                    }
+                    if (blank[j]) break;
+                }
+            }
         } else {
+            const size_t kAnchor = std::min<size_t>(16, min_len);
             std::unordered_multimap<uint64_t, uint32_t> index;
             index.reserve(v.size() * 2);
             for (uint32_t i = 0; i < v.size(); i++) index.emplace(hash_bytes(v[i].data(), kAnchor), i);
             for (size_t j = 0; j < v.size(); j++) {
                 const std::string &s = v[j];
                 const std::string rc = reverse_complement(s);
-                // t or revcomp(t) occurs in s  <=>  t occurs in s or in revcomp(s)
                 for (const std::string *hay : {&s, &rc}) {
                     for (size_t p = 0; p + kAnchor <= hay->size() && !blank[j]; p++) {
                         auto range = index.equal_range(hash_bytes(hay->data() + p, kAnchor));
@@ -173,17 +284,25 @@ void remove_redundant(std::vector<std::string> &v)
 
 } // namespace
 
+static double prof_now()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
                       uint64_t n, int kmer_clust_size)
 {
+    const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
+    const double t0 = prof_now();
     m.clear();
     m.cand_token.resize(n);
     for (uint64_t k = 0; k < n; k++) {
-        std::string dr(dr_chars + k * (uint64_t)dr_stride, dr_len[k]);
-        uint32_t t = m.tokens.get(dr);
-        if (t == 0) t = m.tokens.add(dr);
+        const char *dr = dr_chars + k * (uint64_t)dr_stride;
+        uint32_t t = m.tokens.get(dr, dr_len[k]);
+        if (t == 0) t = m.tokens.add(dr, dr_len[k]);
         m.cand_token[k] = t;
     }
+    const double t1 = prof_now();
     // createNonRedundantSet: cluster every token in ascending token order (std::map iteration)
     KmerGid kmer_gid;
     int next_gid = 1;
@@ -193,6 +312,7 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
     m.next_free_gid = next_gid;
     m.groups.assign((size_t)(next_gid - 1), {});
     for (uint32_t t = 0; t < m.tokens.size(); t++) m.groups[(size_t)gid_of[t] - 1].push_back(t + 2);
+    const double t2 = prof_now();
     for (size_t g = 0; g < m.groups.size(); g++) {
         std::vector<std::string> clustered;
         for (uint32_t tok : m.groups[g]) clustered.push_back(m.tokens.strings[tok - 2]);
@@ -202,7 +322,11 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
         for (size_t i = 0; i < clustered.size(); i++) m.patterns.push_back(reverse_complement(m.patterns[first + i]));
         m.pat_group.insert(m.pat_group.end(), 2 * clustered.size(), (uint32_t)(g + 1));
     }
+    const double t3 = prof_now();
     m.flatten();
+    if (prof)
+        fprintf(stderr, "[crass_merge] tokens %.3f ms, cluster %.3f ms, non-redundant %.3f ms, flatten %.3f ms\n",
+                t1 - t0, t2 - t1, t3 - t2, prof_now() - t3);
 }
 
 void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns)

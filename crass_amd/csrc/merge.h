@@ -12,14 +12,22 @@ namespace crass {
 void build_comp_table(unsigned char tab[128]);                 // SeqUtils.cpp:50-59
 std::string reverse_complement(const std::string &s);          // SeqUtils.cpp:61-87
 
-// StringCheck (StringCheck.h:52-71, StringCheck.cpp:46-81): first token is 2, discovery order
+// StringCheck (StringCheck.h:52-71, StringCheck.cpp:46-81): first token is 2, discovery order.
+// The string -> token side is an open-addressing table over (pointer, length) views so that the
+// per-candidate lookup of the sink allocates nothing.
 struct TokenTable {
     std::vector<std::string> strings;                          // token t -> strings[t-2]
-    std::unordered_map<std::string, uint32_t> s2t;
-    uint32_t get(const std::string &s) const { auto it = s2t.find(s); return it == s2t.end() ? 0u : it->second; }
-    uint32_t add(const std::string &s) { strings.push_back(s); uint32_t t = (uint32_t)strings.size() + 1; s2t.emplace(s, t); return t; }
+    std::vector<uint32_t> slot_token;                          // 0 = empty
+    std::vector<uint64_t> slot_hash;
+    static uint64_t hash(const char *p, size_t n);
+    uint32_t get(const char *p, size_t n) const;
+    uint32_t add(const char *p, size_t n);                     // caller checked get() == 0
+    uint32_t get(const std::string &s) const { return get(s.data(), s.size()); }
+    uint32_t add(const std::string &s) { return add(s.data(), s.size()); }
     uint32_t size() const { return (uint32_t)strings.size(); }
-    void clear() { strings.clear(); s2t.clear(); }
+    void clear() { strings.clear(); slot_token.clear(); slot_hash.clear(); }
+private:
+    void grow();
 };
 
 struct MergeResult {
