@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace crass;
@@ -84,16 +85,22 @@ struct crass_hip_ctx {
     // automaton
     DevBuf<uint16_t> a_go16; DevBuf<uint32_t> a_go32; DevBuf<uint16_t> a_out; DevBuf<uint16_t> a_go4;
     DevAutomaton A{};
-    DevBuf<uint32_t> a_anchor; DevBuf<uint32_t> d_slot_info;
+    DevBuf<uint32_t> a_anchor; DevBuf<uint32_t> d_slot_info; DevBuf<uint32_t> d_slot_pid; DevBuf<uint32_t> a_out_pid; DevBuf<uint32_t> a_pat_token;
+    bool have_pat_token = false;
     DevAnchors K{};
     bool have_anchors = false;
     bool have_patterns = false;
     std::vector<std::string> patterns;
 
-    // pass-1 results (host)
+    // pass-1 results (host), final hand-off layout
     bool have_pass1 = false;
-    std::vector<uint64_t> c_read; std::vector<uint8_t> c_low; std::vector<uint32_t> c_replen, c_nss;
-    std::vector<uint64_t> c_ss_off; std::vector<uint32_t> c_ss; std::vector<uint16_t> c_dr_len; std::vector<char> c_dr;
+    struct P1List {
+        std::vector<uint64_t> read; std::vector<uint8_t> low; std::vector<uint32_t> replen, nss;
+        std::vector<uint64_t> ss_off; std::vector<uint32_t> ss; std::vector<uint16_t> dr_len; std::vector<char> dr;
+        void clear() { read.clear(); low.clear(); replen.clear(); nss.clear(); ss_off.clear(); ss.clear(); dr_len.clear(); dr.clear(); }
+        void reserve(size_t n, uint32_t stride) { read.reserve(n); low.reserve(n); replen.reserve(n); nss.reserve(n); ss_off.reserve(n); ss.reserve(n * 6); dr_len.reserve(n); dr.reserve(n * stride); }
+        size_t size() const { return read.size(); }
+    } cand;
     uint32_t dr_stride = 48;
     // merge
     MergeResult merge;
@@ -104,7 +111,7 @@ struct crass_hip_ctx {
     std::vector<uint16_t> q_dr_len; std::vector<char> q_dr;
 
     crass_counters cnt{};
-    hipEvent_t ev[8]{};
+    hipEvent_t ev[12]{};
 };
 
 #define HIPCHK(ctx, call)                                                       \
@@ -190,7 +197,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
     c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
-    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->a_anchor.release(); c->d_slot_info.release();
+    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -335,11 +342,10 @@ int crass_hip_attach_device_reads(crass_hip_ctx *c, const crass_reads *d)
 // ------------------------------------------------------------------------------------------
 // pass 1
 // ------------------------------------------------------------------------------------------
-struct P1Rec { uint64_t read; SurvOut o; const char *dr; };
-
-static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, std::vector<P1Rec> &recs,
-                         std::vector<std::vector<char>> &dr_keep, std::vector<std::vector<uint32_t>> &ss_keep,
-                         std::vector<uint64_t> &ss_base, const std::vector<uint64_t> *surv_idx_host)
+// runs the survivor kernel over `n_total` survivors (packed list in d_idx, or the exception
+// list) in chunks and appends every found record, in order, to `L`
+static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip_ctx::P1List &L,
+                         const uint64_t *surv_idx_host)
 {
     if (n_total == 0) return CRASS_OK;
     const SurvLds lds = survivor_lds_layout(c->max_len, c->dp);
@@ -352,7 +358,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, std::vect
     HIPCHK(c, c->d_ss_pool.ensure(pool_cap));
     HIPCHK(c, c->h_surv.ensure(chunk_cap));
     HIPCHK(c, c->h_dr.ensure(chunk_cap * c->dr_stride));
-    int grid = 256 * 32;
+    const int grid = 256 * 32;
+    const uint32_t stride = c->dr_stride;
+    L.reserve(L.size() + n_total / 2 + 16, stride);
     for (uint64_t off = 0; off < n_total; off += chunk_cap) {
         const uint64_t nchunk = std::min(chunk_cap, n_total - off);
         HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
@@ -361,11 +369,13 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, std::vect
             R.exc_read = c->R.exc_read + off; R.exc_off = c->R.exc_off + off; R.n_exc = nchunk;
         }
         // for the non-exception path the count lives on the device; chunking uses a host-known bound
+        if (!exc && off == 0) HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
         HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
-                                  c->d_surv.p, c->d_dr.p, c->dr_stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
+                                  c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                   c->d_found.p, lds, (int)std::min<uint64_t>(grid, nchunk), c->stream));
+        if (!exc && off == 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->d_surv.p, nchunk * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, nchunk * c->dr_stride, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, nchunk * stride, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const uint32_t used = c->h_count.p[2];
@@ -375,21 +385,22 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, std::vect
             HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->d_ss_pool.p, (size_t)used * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
-        dr_keep.emplace_back(c->h_dr.p, c->h_dr.p + nchunk * c->dr_stride);
-        ss_keep.emplace_back(c->h_ss.p, c->h_ss.p + used);
-        const char *drbase = dr_keep.back().data();
-        const uint64_t ssb = ss_keep.size() - 1;
+        const SurvOut *so = c->h_surv.p;
+        const char *drs = c->h_dr.p;
+        const uint32_t *pool = c->h_ss.p;
         for (uint64_t k = 0; k < nchunk; k++) {
-            const SurvOut &o = c->h_surv.p[k];
+            const SurvOut &o = so[k];
             if (o.err == 1) return CRASS_ERR_SEARCH_FATAL;
             if (o.err) return CRASS_ERR_OVERFLOW;
             if (!o.found) continue;
-            P1Rec r;
-            r.read = exc ? c->h_exc_read[off + k] : (*surv_idx_host)[off + k];
-            r.o = o;
-            r.dr = drbase + k * c->dr_stride;
-            recs.push_back(r);
-            ss_base.push_back(ssb);
+            L.read.push_back(c->read_base + (exc ? c->h_exc_read[off + k] : surv_idx_host[off + k]));
+            L.low.push_back(o.low_lexi);
+            L.replen.push_back(o.repeat_len);
+            L.nss.push_back(o.n_ss);
+            L.ss_off.push_back(L.ss.size());
+            L.ss.insert(L.ss.end(), pool + o.ss_off, pool + o.ss_off + o.n_ss);
+            L.dr_len.push_back(o.dr_len);
+            L.dr.insert(L.dr.end(), drs + k * stride, drs + (k + 1) * stride);
         }
     }
     return CRASS_OK;
@@ -454,48 +465,45 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         HIPCHK(c, hipMemcpyAsync(c->d_count.p + 1, c->h_count.p + 1, 4, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    std::vector<P1Rec> recs, recs_exc;
-    std::vector<std::vector<char>> dr_keep;
-    std::vector<std::vector<uint32_t>> ss_keep;
-    std::vector<uint64_t> ssb, ssb_exc;
-    int s = run_survivors(c, false, n_surv, recs, dr_keep, ss_keep, ssb, &surv_idx);
+    const double t_sink0 = now_ms();
+    c->cand.clear();
+    int s = run_survivors(c, false, n_surv, c->cand, surv_idx.data());
     if (s) return s;
-    s = run_survivors(c, true, c->R.n_exc, recs_exc, dr_keep, ss_keep, ssb_exc, nullptr);
-    if (s) return s;
+    if (c->R.n_exc) {
+        crass_hip_ctx::P1List el;
+        s = run_survivors(c, true, c->R.n_exc, el, nullptr);
+        if (s) return s;
+        if (el.size()) {
+            // merge the two ascending lists by read index (exception reads are rare)
+            crass_hip_ctx::P1List &a = c->cand, m;
+            m.reserve(a.size() + el.size(), c->dr_stride);
+            size_t ia = 0, ib = 0;
+            while (ia < a.size() || ib < el.size()) {
+                const bool takeA = ib >= el.size() || (ia < a.size() && a.read[ia] < el.read[ib]);
+                const crass_hip_ctx::P1List &src = takeA ? a : el;
+                const size_t k = takeA ? ia++ : ib++;
+                m.read.push_back(src.read[k]); m.low.push_back(src.low[k]); m.replen.push_back(src.replen[k]);
+                m.nss.push_back(src.nss[k]); m.ss_off.push_back(m.ss.size());
+                m.ss.insert(m.ss.end(), src.ss.begin() + src.ss_off[k], src.ss.begin() + src.ss_off[k] + src.nss[k]);
+                m.dr_len.push_back(src.dr_len[k]);
+                m.dr.insert(m.dr.end(), src.dr.begin() + k * c->dr_stride, src.dr.begin() + (k + 1) * c->dr_stride);
+            }
+            c->cand = std::move(m);
+        }
+    }
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const double t_sink0 = now_ms();
-    // sink: merge the two ascending record lists by read index
-    const size_t total = recs.size() + recs_exc.size();
-    c->c_read.clear(); c->c_low.clear(); c->c_replen.clear(); c->c_nss.clear(); c->c_ss_off.clear(); c->c_ss.clear();
-    c->c_dr_len.clear(); c->c_dr.clear();
-    c->c_read.reserve(total); c->c_low.reserve(total); c->c_replen.reserve(total); c->c_nss.reserve(total);
-    c->c_ss_off.reserve(total); c->c_dr_len.reserve(total); c->c_dr.resize(total * c->dr_stride);
-    size_t ia = 0, ib = 0, k = 0;
-    while (ia < recs.size() || ib < recs_exc.size()) {
-        const bool takeA = ib >= recs_exc.size() || (ia < recs.size() && recs[ia].read < recs_exc[ib].read);
-        const P1Rec &r = takeA ? recs[ia] : recs_exc[ib];
-        const std::vector<uint32_t> &pool = ss_keep[takeA ? ssb[ia] : ssb_exc[ib]];
-        c->c_read.push_back(c->read_base + r.read);
-        c->c_low.push_back(r.o.low_lexi);
-        c->c_replen.push_back(r.o.repeat_len);
-        c->c_nss.push_back(r.o.n_ss);
-        c->c_ss_off.push_back(c->c_ss.size());
-        c->c_ss.insert(c->c_ss.end(), pool.begin() + r.o.ss_off, pool.begin() + r.o.ss_off + r.o.n_ss);
-        c->c_dr_len.push_back(r.o.dr_len);
-        memcpy(c->c_dr.data() + k * c->dr_stride, r.dr, r.o.dr_len);
-        if (takeA) ia++; else ib++;
-        k++;
-    }
+    const size_t total = c->cand.size();
     c->have_pass1 = true;
-    c->cnt.ms_sink_host = (float)(now_ms() - t_sink0);
+    c->cnt.ms_sink_host = (float)(now_ms() - t_sink0);     // includes the survivor kernel + D2H it waits for
     c->cnt.n_filter_survivors = n_surv + c->R.n_exc;
     c->cnt.n_pass1_found = total;
     c->cnt.used_fast_filter = fast ? 1 : 0;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->cnt.ms_filter = ms;
     (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->cnt.ms_compact = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->cnt.ms_survivor = ms;
+    ms = 0; if (n_surv) (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]);
+    c->cnt.ms_survivor = ms;                      // first chunk's kernel only (D2H excluded)
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); c->cnt.ms_pass1_total = ms;
     return CRASS_OK;
 }
@@ -504,10 +512,10 @@ int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     if (!c->have_pass1) return CRASS_ERR_STATE;
-    o->n = c->c_read.size();
-    o->read_idx = c->c_read.data(); o->low_lexi = c->c_low.data(); o->repeat_len = c->c_replen.data();
-    o->n_ss = c->c_nss.data(); o->ss_off = c->c_ss_off.data(); o->ss_pool = c->c_ss.data();
-    o->dr_stride = c->dr_stride; o->dr_len = c->c_dr_len.data(); o->dr_chars = c->c_dr.data();
+    o->n = c->cand.size();
+    o->read_idx = c->cand.read.data(); o->low_lexi = c->cand.low.data(); o->repeat_len = c->cand.replen.data();
+    o->n_ss = c->cand.nss.data(); o->ss_off = c->cand.ss_off.data(); o->ss_pool = c->cand.ss.data();
+    o->dr_stride = c->dr_stride; o->dr_len = c->cand.dr_len.data(); o->dr_chars = c->cand.dr.data();
     o->max_read_len = c->max_len;
     return CRASS_OK;
 }
@@ -523,7 +531,12 @@ static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pa
     if (pats.empty()) { c->cnt.ac_states = 0; return CRASS_OK; }
     for (const auto &p : pats) if (p.empty() || p.size() > 255) return CRASS_ERR_UNSUPPORTED;
     HostAutomaton H;
-    build_automaton(H, pats);
+    HostAnchors HK;
+    {
+        std::thread anchors_thread([&]() { build_anchors(HK, pats); });   // independent of the automaton
+        build_automaton(H, pats);
+        anchors_thread.join();
+    }
     DevAutomaton A{};
     A.n_states = H.n_states; A.n_sym1 = H.n_sym1;
     memcpy(A.sym, H.sym, 256);
@@ -546,11 +559,14 @@ static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pa
     HIPCHK(c, hipMemcpyAsync(c->a_out.p, H.out_len.data(), H.out_len.size() * 2, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     A.out_len = c->a_out.p;
+    HIPCHK(c, c->a_out_pid.ensure(H.out_pid.size()));
+    HIPCHK(c, hipMemcpyAsync(c->a_out_pid.p, H.out_pid.data(), H.out_pid.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    A.out_pid = c->a_out_pid.p;
+    c->have_pat_token = false;
     c->A = A;
     // anchor keys for the pass-2 fast path
     c->have_anchors = false;
-    HostAnchors HK;
-    build_anchors(HK, pats);
     if (HK.ok) {
         HIPCHK(c, c->a_anchor.ensure(HK.table.size()));
         HIPCHK(c, hipMemcpyAsync(c->a_anchor.p, HK.table.data(), HK.table.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -570,12 +586,26 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
     const double t0 = now_ms();
     if (!dr_chars) {
         if (!c->have_pass1) return CRASS_ERR_STATE;
-        dr_chars = c->c_dr.data(); dr_len = c->c_dr_len.data(); dr_stride = c->dr_stride; n = c->c_read.size();
+        dr_chars = c->cand.dr.data(); dr_len = c->cand.dr_len.data(); dr_stride = c->dr_stride; n = c->cand.size();
     } else if (!dr_len || !dr_stride) return CRASS_ERR_INVALID_ARG;
     merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n, c->prm.kmer_clust_size);
     c->have_merge = true;
     c->have_pass2 = false;
     int s = install_patterns(c, c->merge.patterns);
+    if (s == CRASS_OK && c->have_patterns) {
+        // token of every pattern's low-lexi form (DRLowLexi: tmp_dr < rev_comp ? tmp_dr : rev_comp),
+        // resolved once per pattern instead of once per recruited read
+        std::vector<uint32_t> pt(c->merge.patterns.size());
+        for (size_t i = 0; i < pt.size(); i++) {
+            const std::string &p = c->merge.patterns[i];
+            const std::string rc = reverse_complement(p);
+            pt[i] = c->merge.tokens.get(p < rc ? p : rc);
+        }
+        HIPCHK(c, c->a_pat_token.ensure(pt.size()));
+        HIPCHK(c, hipMemcpyAsync(c->a_pat_token.p, pt.data(), pt.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->have_pat_token = true;
+    }
     c->cnt.ms_merge_host = (float)(now_ms() - t0);
     return s;
 }
@@ -658,12 +688,15 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     HIPCHK(c, c->h_idx.ensure(n_hits + 1));
     if (anchors) {
         HIPCHK(c, c->d_slot_info.ensure(n_hits + 1));
-        HIPCHK(c, launch_recruit_list(c->R, c->A, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->stream));
+        HIPCHK(c, c->d_slot_pid.ensure(n_hits + 1));
+        HIPCHK(c, launch_recruit_list(c->R, c->A, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->d_slot_pid.p, c->stream));
     }
+    const bool dev_tokens = anchors && c->have_pat_token && c->have_merge;
     HIPCHK(c, launch_recruit_finish(c->R, c->d_idx.p, c->d_count.p, n_hits, anchors ? c->d_slot_info.p : c->d_hit_info.p, anchors, false,
+                                    dev_tokens ? c->d_slot_pid.p : nullptr, dev_tokens ? c->a_pat_token.p : nullptr,
                                     c->d_rec.p, c->d_dr.p, c->dr_stride, c->stream));
     if (c->R.n_exc)
-        HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, c->R.n_exc, c->d_exc_hit.p, true, true, c->d_rec.p + n_hits,
+        HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, c->R.n_exc, c->d_exc_hit.p, true, true, nullptr, nullptr, c->d_rec.p + n_hits,
                                         c->d_dr.p + n_hits * c->dr_stride, c->dr_stride, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     if (n_slots) {
@@ -681,6 +714,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     auto hit_valid = [&](size_t a) { return c->h_rec.p[a].dr_len != 0; };
     while (ia < n_hits && !hit_valid(ia)) ia++;                  // anchor false positives carry no match
     c->q_dr.reserve(n_slots * c->dr_stride);
+    c->q_read.reserve(n_slots); c->q_low.reserve(n_slots); c->q_start.reserve(n_slots); c->q_end.reserve(n_slots);
+    c->q_dr_len.reserve(n_slots); c->q_token.reserve(n_slots);
     while (ia < n_hits || ib < nb) {
         const bool takeA = ib >= nb || (ia < n_hits && c->h_idx.p[ia] < c->h_exc_read[ib]);
         const size_t slot = takeA ? ia : n_hits + ib;
@@ -695,8 +730,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         const size_t at = c->q_dr.size();
         c->q_dr.resize(at + c->dr_stride);
         memcpy(c->q_dr.data() + at, dr, o.dr_len);
-        uint32_t tok = 0;
-        if (c->have_merge) {
+        uint32_t tok = o.token;
+        if (!tok && c->have_merge) {
             tok = c->merge.tokens.get(dr, o.dr_len);
             if (!tok) tok = c->merge.tokens.add(dr, o.dr_len);
         }
@@ -704,7 +739,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         if (takeA) { ia++; while (ia < n_hits && !hit_valid(ia)) ia++; }
         else { ib++; while (ib < nb && !exc_valid(ib)) ib++; }
     }
-    if (c->have_merge) c->merge.flatten();
+    if (c->have_merge && c->merge.tokens.size() + 1 != c->merge.tok_off.size()) c->merge.flatten();   // pass 2 added tokens
     c->have_pass2 = true;
     c->cnt.ms_sink_host += (float)(now_ms() - t0);
     c->cnt.n_pass2_found = c->q_read.size();

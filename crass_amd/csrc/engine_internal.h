@@ -43,6 +43,7 @@ struct SurvOut {
 // per-hit output of the pass-2 finish kernel
 struct RecruitOut {
     uint32_t start, end;
+    uint32_t token;               // StringToken of the low-lexi DR when the device knows it, else 0
     uint16_t dr_len;
     uint8_t  low_lexi;
     uint8_t  pad;
@@ -53,6 +54,7 @@ struct DevAutomaton {
     const uint16_t *go16;         // [n_states][n_sym1] when n_states <= 65535
     const uint32_t *go32;         // otherwise
     const uint16_t *out_len;      // [n_states] longest pattern ending at the state (0 = none)
+    const uint32_t *out_pid;      // [n_states] index of that pattern in the pattern list
     const uint16_t *go4;          // [n_states][4] ACGT-only compact table (packed reads), may be nullptr
     uint32_t n_states;
     uint32_t n_sym1;              // symbols + 1 (symbol 0 = byte in no pattern)
@@ -99,11 +101,12 @@ hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const ui
 hipError_t launch_anchor_filter(const DevReads &R, const DevAnchors &K, const uint8_t *found_flag,
                                 uint64_t *hitmask, hipStream_t st);
 hipError_t launch_recruit_list(const DevReads &R, const DevAutomaton &A, const uint64_t *idx, const uint32_t *d_n,
-                               uint64_t n_max, uint32_t *info_by_slot, hipStream_t st);
+                               uint64_t n_max, uint32_t *info_by_slot, uint32_t *pid_by_slot, hipStream_t st);
 hipError_t launch_recruit_exceptions(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
                                      uint32_t *exc_hit_info /*[n_exc], 0 = none*/, hipStream_t st);
 hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, const uint32_t *d_n_hits,
                                  uint64_t n_hits_max, const uint32_t *hit_info, bool info_by_slot, bool exceptions,
+                                 const uint32_t *pid_by_slot, const uint32_t *pat_token,
                                  RecruitOut *out, char *dr_chars, uint32_t dr_stride, hipStream_t st);
 hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off, const uint32_t *a_len,
                                     const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,

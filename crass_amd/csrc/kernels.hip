@@ -1108,7 +1108,7 @@ hipError_t launch_anchor_filter(const DevReads &R, const DevAnchors &K, const ui
 // exact first-match scan of the flagged reads (lane per flagged read), transition table in global
 // memory (L2-resident).  info_by_slot[k] = (end_exclusive << 8) | length, 0 = no pattern occurs.
 __global__ __launch_bounds__(256) void k_recruit_list(DevReads R, DevAutomaton A, const uint64_t *idx, const uint32_t *d_n,
-                                                       uint64_t n_max, uint32_t *info_by_slot)
+                                                       uint64_t n_max, uint32_t *info_by_slot, uint32_t *pid_by_slot)
 {
     uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t n = *d_n;
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_recruit_list(DevReads R, DevAutomaton A
     const uint32_t L = rd_len(R, r);
     const uint32_t *g = R.packed + rd_word_off(R, r);
     const uint32_t symA = A.sym['A'], symC = A.sym['C'], symG = A.sym['G'], symT = A.sym['T'];
-    uint32_t state = 0, word = 0, info = 0;
+    uint32_t state = 0, word = 0, info = 0, pid = 0;
     for (uint32_t i = 0; i < L; i++) {
         if ((i & 15u) == 0) word = g[i >> 4];
         uint32_t c = word & 3u;
@@ -1129,16 +1129,17 @@ __global__ __launch_bounds__(256) void k_recruit_list(DevReads R, DevAutomaton A
             state = A.go16 ? (uint32_t)A.go16[(size_t)state * A.n_sym1 + sy] : A.go32[(size_t)state * A.n_sym1 + sy];
         }
         uint32_t ol = A.out_len[state];
-        if (ol) { info = ((i + 1) << 8) | ol; break; }
+        if (ol) { info = ((i + 1) << 8) | ol; pid = A.out_pid[state]; break; }
     }
     info_by_slot[k] = info;
+    pid_by_slot[k] = pid;
 }
 
 hipError_t launch_recruit_list(const DevReads &R, const DevAutomaton &A, const uint64_t *idx, const uint32_t *d_n,
-                               uint64_t n_max, uint32_t *info_by_slot, hipStream_t st)
+                               uint64_t n_max, uint32_t *info_by_slot, uint32_t *pid_by_slot, hipStream_t st)
 {
     if (n_max == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_recruit_list, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot);
+    hipLaunchKernelGGL(k_recruit_list, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);
     return hipGetLastError();
 }
 
@@ -1176,13 +1177,14 @@ hipError_t launch_recruit_exceptions(const DevReads &R, const DevAutomaton &A, c
 template <bool EXC>
 __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64_t *hit_idx, const uint32_t *d_n_hits,
                                                         uint64_t n_max, const uint32_t *hit_info, int info_by_slot,
+                                                        const uint32_t *pid_by_slot, const uint32_t *pat_token,
                                                         RecruitOut *out, char *dr_chars, uint32_t dr_stride)
 {
     uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t n = EXC ? R.n_exc : (uint64_t)(*d_n_hits);
     if (n > n_max) n = n_max;
     if (k >= n) return;
-    RecruitOut o; o.start = 0; o.end = 0; o.dr_len = 0; o.low_lexi = 0; o.pad = 0;
+    RecruitOut o; o.start = 0; o.end = 0; o.token = 0; o.dr_len = 0; o.low_lexi = 0; o.pad = 0;
     uint32_t info;
     uint32_t L;
     uint64_t r = 0, o0 = 0;
@@ -1222,19 +1224,23 @@ __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64
         o.start = L - 1 - DR_end; o.end = L - 1 - start; o.low_lexi = 0;
     }
     o.dr_len = (uint16_t)len;
+    // the matched pattern's low-lexi form is a stored DR variant: its token was resolved once per
+    // pattern on the host (addReadHolder's lookup, libcrispr.cpp:1137)
+    if (pid_by_slot && pat_token) o.token = pat_token[pid_by_slot[k]];
     out[k] = o;
 }
 
 hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, const uint32_t *d_n_hits, uint64_t n_hits_max,
-                                 const uint32_t *hit_info, bool info_by_slot, bool exceptions, RecruitOut *out,
+                                 const uint32_t *hit_info, bool info_by_slot, bool exceptions,
+                                 const uint32_t *pid_by_slot, const uint32_t *pat_token, RecruitOut *out,
                                  char *dr_chars, uint32_t dr_stride, hipStream_t st)
 {
     if (n_hits_max == 0) return hipSuccess;
     unsigned nb = (unsigned)((n_hits_max + 255) / 256);
     if (exceptions)
-        hipLaunchKernelGGL(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, 1, out, dr_chars, dr_stride);
+        hipLaunchKernelGGL(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, 1, pid_by_slot, pat_token, out, dr_chars, dr_stride);
     else
-        hipLaunchKernelGGL(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, info_by_slot ? 1 : 0, out, dr_chars, dr_stride);
+        hipLaunchKernelGGL(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, info_by_slot ? 1 : 0, pid_by_slot, pat_token, out, dr_chars, dr_stride);
     return hipGetLastError();
 }
 

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <thread>
 
 namespace crass {
 
@@ -122,19 +124,38 @@ inline int acgt_code(unsigned char c)
 
 // k-mer -> GID map of WorkHorse::clusterDRReads (std::map<std::string,int> there).  ACGT-only
 // 11-mers are kept as 22-bit integers (first base most significant, so integer order ==
-// lexicographic order and laurenize() is a min of two integers) in a flat table; anything else
-// falls back to string keys.  Same lookups, same results, ~50x less host time per variant.
+// lexicographic order and laurenize() is a min of two integers) in a small open-addressing
+// table (variants of one DR share most k-mers, so it stays cache-resident); anything else falls
+// back to string keys.  Same lookups, same results, a fraction of the host time.
 struct KmerGid {
-    std::vector<int32_t> &flat;                                 // 4^11 entries, 0 = unseen (16 MB, kept per thread)
-    std::vector<uint32_t> touched;
+    std::vector<uint32_t> key;                                  // code + 1, 0 = empty
+    std::vector<int32_t> gid;
+    size_t used = 0;
     std::unordered_map<std::string, int> other;
-    static std::vector<int32_t> &storage()
+    KmerGid() : key(1u << 14, 0), gid(1u << 14, 0) {}
+    static size_t slot(uint32_t code, size_t mask) { return (size_t)((code * 0x9E3779B1u) >> 8) & mask; }
+    int32_t find(uint32_t code) const
     {
-        static thread_local std::vector<int32_t> v((size_t)1 << 22, 0);
-        return v;
+        const size_t mask = key.size() - 1;
+        for (size_t i = slot(code, mask);; i = (i + 1) & mask) {
+            if (key[i] == 0) return 0;
+            if (key[i] == code + 1) return gid[i];
+        }
     }
-    KmerGid() : flat(storage()) {}
-    ~KmerGid() { for (uint32_t k : touched) flat[k] = 0; }      // leave the table all-zero for the next merge
+    void put(uint32_t code, int32_t g)                           // insert or overwrite
+    {
+        if ((used + 1) * 2 > key.size()) {
+            std::vector<uint32_t> ok; std::vector<int32_t> og;
+            ok.swap(key); og.swap(gid);
+            key.assign(ok.size() * 2, 0); gid.assign(ok.size() * 2, 0); used = 0;
+            for (size_t i = 0; i < ok.size(); i++) if (ok[i]) put(ok[i] - 1, og[i]);
+        }
+        const size_t mask = key.size() - 1;
+        size_t i = slot(code, mask);
+        while (key[i] != 0 && key[i] != code + 1) i = (i + 1) & mask;
+        if (key[i] == 0) { key[i] = code + 1; used++; }
+        gid[i] = g;
+    }
 };
 
 // WorkHorse::clusterDRReads (WorkHorse.cpp:1404-1637): greedy, order-dependent assignment of
@@ -165,7 +186,7 @@ int cluster_one(const std::string &dr, int &next_free_gid, KmerGid &kg, int min_
         if (start < 0 || start >= n_mers) continue;
         if (bad == 0) {
             const uint32_t lau = fwd < rev ? fwd : rev;          // laurenize (SeqUtils.cpp:89-97): seq1 < seq2 ? seq1 : seq2
-            const int32_t gid = kg.flat[lau];
+            const int32_t gid = kg.find(lau);
             if (gid == 0) homeless_code.push_back(lau); else seen(gid);
         } else {
             std::string km = dr.substr((size_t)start, kClusterKmer), rc = reverse_complement(km);
@@ -175,7 +196,7 @@ int cluster_one(const std::string &dr, int &next_free_gid, KmerGid &kg, int min_
         }
     }
     if (group == 0) group = next_free_gid++;
-    for (uint32_t k : homeless_code) { kg.flat[k] = group; kg.touched.push_back(k); }
+    for (uint32_t k : homeless_code) kg.put(k, group);
     for (const auto &k : homeless_str) kg.other[k] = group;
     return group;
 }
@@ -313,10 +334,28 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
     m.groups.assign((size_t)(next_gid - 1), {});
     for (uint32_t t = 0; t < m.tokens.size(); t++) m.groups[(size_t)gid_of[t] - 1].push_back(t + 2);
     const double t2 = prof_now();
+    // per-group substring de-duplication is independent across groups: a few host threads
+    std::vector<std::vector<std::string>> survivors(m.groups.size());
+    {
+        const size_t ng = m.groups.size();
+        unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8);
+        if (m.tokens.size() < 2000 || ng < 2) nt = 1;
+        std::atomic<size_t> next_group{0};
+        auto work = [&]() {
+            for (size_t g = next_group.fetch_add(1); g < ng; g = next_group.fetch_add(1)) {
+                std::vector<std::string> &clustered = survivors[g];
+                for (uint32_t tok : m.groups[g]) clustered.push_back(m.tokens.strings[tok - 2]);
+                remove_redundant(clustered);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (prof) fprintf(stderr, "[crass_merge]   de-dup section %.3f ms on %u threads\n", prof_now() - t2, nt);
+    }
     for (size_t g = 0; g < m.groups.size(); g++) {
-        std::vector<std::string> clustered;
-        for (uint32_t tok : m.groups[g]) clustered.push_back(m.tokens.strings[tok - 2]);
-        remove_redundant(clustered);
+        const std::vector<std::string> &clustered = survivors[g];
         const size_t first = m.patterns.size();
         m.patterns.insert(m.patterns.end(), clustered.begin(), clustered.end());
         for (size_t i = 0; i < clustered.size(); i++) m.patterns.push_back(reverse_complement(m.patterns[first + i]));
@@ -344,7 +383,9 @@ void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns)
     a.n_sym1 = S;
     std::vector<int32_t> go(total * S, -1);
     std::vector<uint16_t> term(total, 0);
+    std::vector<uint32_t> term_pid(total, 0);
     uint32_t ns = 1;
+    uint32_t pid = 0;
     for (const auto &p : patterns) {
         uint32_t s = 0;
         for (unsigned char c : p) {
@@ -352,7 +393,8 @@ void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns)
             if (go[(size_t)s * S + sy] < 0) go[(size_t)s * S + sy] = (int32_t)ns++;
             s = (uint32_t)go[(size_t)s * S + sy];
         }
-        if (p.size() > term[s]) term[s] = (uint16_t)p.size();
+        if (p.size() > term[s]) { term[s] = (uint16_t)p.size(); term_pid[s] = pid; }
+        pid++;
     }
     std::vector<uint32_t> fail(ns, 0), queue;
     queue.reserve(ns);
@@ -363,7 +405,7 @@ void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns)
     }
     for (size_t qh = 0; qh < queue.size(); qh++) {
         uint32_t s = queue[qh];
-        if (!term[s]) term[s] = term[fail[s]];       // longest pattern that is a suffix of this state
+        if (!term[s]) { term[s] = term[fail[s]]; term_pid[s] = term_pid[fail[s]]; }   // longest pattern that is a suffix of this state
         go[(size_t)s * S] = 0;                        // byte in no pattern: back to ROOT (acism.c:35-40)
         for (uint32_t c = 1; c < S; c++) {
             int32_t t = go[(size_t)s * S + c];
@@ -375,6 +417,7 @@ void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns)
     a.go.resize((size_t)ns * S);
     for (size_t i = 0; i < (size_t)ns * S; i++) a.go[i] = (uint32_t)go[i];
     a.out_len.assign(term.begin(), term.begin() + ns);
+    a.out_pid.assign(term_pid.begin(), term_pid.begin() + ns);
     a.go4.clear();
     if (ns <= 65535) {
         a.go4.resize((size_t)ns * 4);

@@ -57,6 +57,7 @@ struct HostAutomaton {
     uint8_t sym[256];
     std::vector<uint32_t> go;          // [n_states][n_sym1]
     std::vector<uint16_t> out_len;     // longest pattern ending at the state
+    std::vector<uint32_t> out_pid;     // index (into the pattern list) of that pattern
     std::vector<uint16_t> go4;         // [n_states][4] for A,C,G,T (empty if n_states > 65535)
     uint32_t max_pat_len = 0;
 };
