@@ -78,6 +78,7 @@ struct crass_hip_ctx {
     // scratch
     DevBuf<uint64_t> d_mask; DevBuf<uint32_t> d_word_prefix; DevBuf<uint32_t> d_block_sums;
     DevBuf<uint64_t> d_idx; DevBuf<uint32_t> d_count; DevBuf<uint8_t> d_found; DevBuf<uint32_t> d_hit_info;
+    bool hints_valid = false;       // d_hit_info doubles as the pass-1 seed-hint array (pass 2 reuses it afterwards)
     DevBuf<SurvOut> d_surv; DevBuf<char> d_dr; DevBuf<uint32_t> d_ss_pool; DevBuf<uint32_t> d_ss_used;
     DevBuf<RecruitOut> d_rec; DevBuf<uint32_t> d_exc_hit; DevBuf<uint64_t> d_extra;
     PinBuf<uint32_t> h_count; PinBuf<SurvOut> h_surv; PinBuf<char> h_dr; PinBuf<uint32_t> h_ss; PinBuf<uint64_t> h_idx;
@@ -372,7 +373,8 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         if (!exc && off == 0) HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
         HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
                                   c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
-                                  c->d_found.p, lds, (int)std::min<uint64_t>(grid, nchunk), c->stream));
+                                  c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds,
+                                  (int)std::min<uint64_t>(grid, nchunk), c->stream));
         if (!exc && off == 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->d_surv.p, nchunk * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, nchunk * stride, hipMemcpyDeviceToHost, c->stream));
@@ -422,7 +424,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     const bool use_filter = c->max_len <= 2048;
     if (use_filter) {
         hipError_t fe = hipErrorNotSupported;
-        if (c->uniform && c->R.stride_words >= 4 && c->R.stride_words <= 16) fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->stream);
+        if (c->uniform && c->R.stride_words >= 4 && c->R.stride_words <= 16) fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->d_hit_info.p, c->stream);
         if (fe == hipSuccess) fast = true;
         else if (fe == hipErrorNotSupported) { HIPCHK(c, launch_filter_general(c->R, c->dp, c->d_mask.p, c->max_len, c->stream)); }
         else { c->last_hip = (int)fe; return CRASS_ERR_HIP; }
@@ -430,6 +432,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         // all non-exception reads survive: mask = ~exc_mask (exc_mask is 32-bit words of the same bit order)
         HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0xFF, n_words * 8, c->stream));
     }
+    c->hints_valid = fast;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     // step 2: ordered compaction
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));

@@ -83,7 +83,7 @@ struct SurvLds {
 // ---- launch wrappers implemented in kernels.hip (all asynchronous on `st`) ----
 hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t *hitmask,
                                  uint32_t max_len, hipStream_t st);
-hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, hipStream_t st);
+hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st);
 // mask (n_words 64-bit words) -> ascending index list; *d_count receives the number of set bits.
 // scratch: word_prefix[n_words] u32, block_sums[(n_words+255)/256 + 1] u32
 hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
@@ -93,7 +93,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            const uint64_t *surv_idx, const uint32_t *d_n_surv, uint64_t n_surv_max,
                            SurvOut *out, char *dr_chars, uint32_t dr_stride,
                            uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
-                           uint8_t *found_flag, const SurvLds &lds, int grid, hipStream_t st);
+                           uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st);
 hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
                                   uint64_t *hitmask, uint32_t *hit_info, hipStream_t st);
 hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,

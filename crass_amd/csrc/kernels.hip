@@ -158,7 +158,7 @@ static __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
 
 // Fully unrolled implementation: D0..D1 are compile-time so every register index is static.
 template <int W, int D0, int D1>
-__global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams P, uint64_t *hitmask)
+__global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams P, uint64_t *hitmask, uint32_t *seed_hint)
 {
     const uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const bool active = r < R.n_reads;
@@ -197,18 +197,22 @@ __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams 
     int searchEnd = (int)(L - P.lowDR - P.lowSp - 8 - 1);
     if (active && !exc && searchEnd >= 0) {
         int n_seed = searchEnd / 8 + 1;                 // halfwords 0 .. n_seed-1 hold lattice seeds
+        uint32_t hint = 0;                              // bit h: lattice seed j = 8h may have a hit (superset)
 #pragma unroll
         for (int k = 0; k < SW; k++) {
             bool z0 = (acc[k] & 0xFFFFu) == 0 && (2 * k) < n_seed;
             bool z1 = (acc[k] >> 16) == 0 && (2 * k + 1) < n_seed;
-            hit = hit || z0 || z1;
+            hint |= (z0 ? 1u : 0u) << (2 * k);
+            hint |= (z1 ? 1u : 0u) << (2 * k + 1);
         }
+        hit = hint != 0;
+        if (hit) seed_hint[r] = hint;                   // sparse: ~2 % of the lanes
     }
     uint64_t m = __ballot(hit);
     if ((threadIdx.x & 63) == 0 && active) hitmask[r >> 6] = m;
 }
 
-hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, hipStream_t st)
+hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st)
 {
     // defaults only: w = 8, skips = 8, shifts 49..97
     if (P.window != 8 || P.skips != 8) return hipErrorNotSupported;
@@ -218,7 +222,7 @@ hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *h
     if (blocks > 0x7FFFFFFFull) return hipErrorNotSupported;
     dim3 g((unsigned)blocks), b(256);
     switch (R.stride_words) {
-#define FF_CASE(WW) case WW: hipLaunchKernelGGL((k_filter_fast_impl<WW, 49, 97>), g, b, 0, st, R, P, hitmask); break;
+#define FF_CASE(WW) case WW: hipLaunchKernelGGL((k_filter_fast_impl<WW, 49, 97>), g, b, 0, st, R, P, hitmask, seed_hint); break;
         FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8) FF_CASE(9) FF_CASE(10)
         FF_CASE(11) FF_CASE(12) FF_CASE(13) FF_CASE(14) FF_CASE(15) FF_CASE(16)
 #undef FF_CASE
@@ -430,61 +434,58 @@ static __device__ uint32_t extend_pre_repeat(RH &h, int searchWindowLength, int 
     for (int off = 32; off > 0; off >>= 1) shortest = min(shortest, (uint32_t)__shfl_xor((int)shortest, off));
     const uint32_t shortest_repeat_spacing = shortest;
 
+    // The reference extends one column per loop iteration (:612-668, :698-740).  Iteration e of the
+    // right loop runs with right_extension_length == e, RH_RepeatLength == w+e and, because one more
+    // trailing repeat is dropped in EVERY iteration once lastStart+w+e >= L (:614-616),
+    // DR_index_end(e) = end_index - 2*max(0, e - (L-lastStart-w) + 1).  Whether column e passes the
+    // vote does not depend on the earlier columns, so all columns are evaluated at once — lane = column —
+    // and the extension is the number of leading passing columns (capped by max_*_extension_length).
     uint32_t right_extension_length = 0;
-    uint32_t max_right_extension_length = shortest_repeat_spacing - (uint32_t)minSpacerLength;
-    int DR_index_end = (int)end_index;
-    while (max_right_extension_length > 0) {
-        if ((last_repeat_start_index + (uint32_t)searchWindowLength + right_extension_length) >= seqlen) DR_index_end -= 2;
-        int cA = 0, cC = 0, cG = 0, cT = 0;
-        // the serial loop (:617-646) stops at the first repeat whose next base is off the read;
-        // starts are ascending so that is a suffix: counting the in-range repeats is identical.
-        for (int k0 = 0; k0 < DR_index_end; k0 += 2 * WAVE) {
-            int k = k0 + 2 * lane;
-            uint8_t ch = 0;
-            if (k < DR_index_end) {
-                uint32_t pos = h.ss[k] + (uint32_t)h.replen;
-                if (pos < seqlen) ch = h.seq[pos];
+    const uint32_t max_right_extension_length = shortest_repeat_spacing - (uint32_t)minSpacerLength;
+    {
+        const int T = (int)seqlen - (int)last_repeat_start_index - searchWindowLength;     // >= 0
+        for (uint32_t e0 = 0; e0 < max_right_extension_length; e0 += WAVE) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            int drops = (int)e - T + 1;
+            if (drops < 0) drops = 0;
+            const int dr_index_end = (int)end_index - 2 * drops;
+            int cA = 0, cC = 0, cG = 0, cT = 0;
+            for (int k = 0; k < dr_index_end; k += 2) {
+                const uint32_t pos = h.ss[k] + (uint32_t)searchWindowLength + e;
+                if (pos >= seqlen) break;                // starts ascend: every later repeat is off the read too (:624-627)
+                const uint8_t ch = h.seq[pos];
+                cA += (ch == 'A'); cC += (ch == 'C'); cG += (ch == 'G'); cT += (ch == 'T');
             }
-            cA += __popcll(__ballot(ch == 'A'));
-            cC += __popcll(__ballot(ch == 'C'));
-            cG += __popcll(__ballot(ch == 'G'));
-            cT += __popcll(__ballot(ch == 'T'));
-        }
-        if ((cA >= cut_off) || (cC >= cut_off) || (cG >= cut_off) || (cT >= cut_off)) {
-            h.replen++;
-            max_right_extension_length--;
-            right_extension_length++;
-        } else {
-            break;
+            const bool pass = (e < max_right_extension_length) &&
+                              ((cA >= cut_off) || (cC >= cut_off) || (cG >= cut_off) || (cT >= cut_off));
+            const uint64_t fails = ~__ballot(pass);
+            if (fails) { right_extension_length = e0 + (uint32_t)(__ffsll((unsigned long long)fails) - 1); break; }
+            right_extension_length = e0 + WAVE;
         }
     }
+    h.replen = searchWindowLength + (int)right_extension_length;
 
     uint32_t left_extension_length = 0;
-    int test_for_negative = (int)(shortest_repeat_spacing - (uint32_t)h.replen);
-    uint32_t max_left_extension_length = (test_for_negative >= 0) ? (uint32_t)test_for_negative : 0;
-    uint32_t DR_index_start = 0;
-    while (left_extension_length < max_left_extension_length) {
-        if ((int)first_repeat_start_index - (int)left_extension_length <= 0) DR_index_start += 2;
+    const int test_for_negative = (int)(shortest_repeat_spacing - (uint32_t)h.replen);
+    const uint32_t max_left_extension_length = (test_for_negative >= 0) ? (uint32_t)test_for_negative : 0;
+    for (uint32_t e0 = 0; e0 < max_left_extension_length; e0 += WAVE) {
+        const uint32_t e = e0 + (uint32_t)lane;
+        int drops = (int)e - (int)first_repeat_start_index + 1;          // iterations i<=e with firstStart-i <= 0 (:700-704)
+        if (drops < 0) drops = 0;
         int cA = 0, cC = 0, cG = 0, cT = 0;
-        for (uint32_t k0 = DR_index_start; k0 < end_index; k0 += 2 * WAVE) {
-            uint32_t k = k0 + 2 * (uint32_t)lane;
+        for (uint32_t k = 2u * (uint32_t)drops; k < end_index; k += 2) {
+            const int idx = (int)(h.ss[k] - e - 1);
             uint8_t ch = 0;
-            if (k < end_index) {
-                int idx = (int)(h.ss[k] - left_extension_length - 1);
-                if (idx >= 0 && idx < h.L) ch = h.seq[idx];
-            }
-            cA += __popcll(__ballot(ch == 'A'));
-            cC += __popcll(__ballot(ch == 'C'));
-            cG += __popcll(__ballot(ch == 'G'));
-            cT += __popcll(__ballot(ch == 'T'));
+            if (idx >= 0 && idx < h.L) ch = h.seq[idx];
+            cA += (ch == 'A'); cC += (ch == 'C'); cG += (ch == 'G'); cT += (ch == 'T');
         }
-        if ((cA >= cut_off) || (cC >= cut_off) || (cG >= cut_off) || (cT >= cut_off)) {
-            h.replen++;
-            left_extension_length++;
-        } else {
-            break;
-        }
+        const bool pass = (e < max_left_extension_length) &&
+                          ((cA >= cut_off) || (cC >= cut_off) || (cG >= cut_off) || (cT >= cut_off));
+        const uint64_t fails = ~__ballot(pass);
+        if (fails) { left_extension_length = e0 + (uint32_t)(__ffsll((unsigned long long)fails) - 1); break; }
+        left_extension_length = e0 + WAVE;
     }
+    h.replen += (int)left_extension_length;
     wave_sync();
     for (int r = 2 * lane; r + 1 < h.nss; r += 2 * WAVE) {
         uint32_t a = h.ss[r], b = h.ss[r + 1];
@@ -679,14 +680,23 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
 }
 
 // searchCore, libcrispr.cpp:265-395.  1 found / 0 not / <0 error
-static __device__ int search_core(RH &h, const DevParams &o, int lane)
+static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint, int lane)
 {
     const uint32_t seq_length = (uint32_t)h.L;
     const uint32_t skips = o.skips;
     int searchEnd = (int)(seq_length - o.lowDR - o.lowSp - o.window - 1);
     if (searchEnd < 0) return 0;
     h.nss = 0;
+    // seed_hint (from the bit-parallel filter): bit i clear => lattice seed j = i*skips provably has
+    // no hit, so its iteration is a no-op in the reference (no start/stops, numRepeats 0) and can be
+    // skipped.  Only valid while j is still on the lattice, i.e. before the first `j = back()-1`.
+    bool on_lattice = true;
+    uint32_t lattice_i = 0;
     for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
+        if (on_lattice) {
+            const uint32_t li = lattice_i++;
+            if (li < 32 && !((seed_hint >> li) & 1u)) continue;
+        }
         uint32_t beginSearch = j + o.lowDR + o.lowSp;
         uint32_t endSearch = j + o.highDR + o.highSp + o.window;
         if (endSearch >= seq_length) endSearch = seq_length - 1;
@@ -708,6 +718,7 @@ static __device__ int search_core(RH &h, const DevParams &o, int lane)
                 if (qc) return 1;
             }
             j = h.ss[h.nss - 1] - 1;
+            on_lattice = false;
         }
         h.nss = 0;
         wave_sync();
@@ -802,7 +813,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
                                                    const uint32_t *d_n_surv, uint64_t n_max, SurvOut *out,
                                                    char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                                    uint32_t ss_pool_cap, uint32_t *d_ss_used,
-                                                   uint8_t *found_flag, SurvLds lds)
+                                                   uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sv_lds[];
     const int lane = threadIdx.x;
@@ -833,7 +844,8 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
         }
         wave_sync();
         h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
-        int f = search_core(h, P, lane);
+        const uint32_t hint = (!EXC && seed_hint) ? seed_hint[r] : 0xFFFFFFFFu;
+        int f = search_core(h, P, hint, lane);
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
         if (f < 0) o.err = (f == -2) ? 2 : 1;
@@ -873,7 +885,7 @@ SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P)
 hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exceptions, const uint64_t *surv_idx,
                            const uint32_t *d_n_surv, uint64_t n_surv_max, SurvOut *out, char *dr_chars,
                            uint32_t dr_stride, uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
-                           uint8_t *found_flag, const SurvLds &lds, int grid, hipStream_t st)
+                           uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st)
 {
     if (n_surv_max == 0) return hipSuccess;
     hipError_t e;
@@ -881,12 +893,12 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_survivor<true>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, lds);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_survivor<false>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, lds);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds);
     }
     return hipGetLastError();
 }
