@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -176,6 +177,7 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     uint32_t skips = p->lowDRsize - (2 * p->searchWindowLength - 1);     // unsigned, libcrispr.cpp:281
     if (skips < 1) skips = 1;
     c->dp.skips = skips;
+    { const char *dbg = getenv("CRASS_SURV_DEBUG"); c->dp.debug_stop = dbg ? (uint32_t)atoi(dbg) : 0; }
     c->dr_stride = (p->highDRsize + 15u) & ~15u;
     if (hipSetDevice(device) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }

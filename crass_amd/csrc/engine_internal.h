@@ -27,6 +27,7 @@ struct DevReads {
 struct DevParams {
     uint32_t lowDR, highDR, lowSp, highSp, window, minRepeats;
     uint32_t skips;               // lowDR - (2w-1) as unsigned, clamped to >=1 only when 0 (libcrispr.cpp:281-285)
+    uint32_t debug_stop;          // diagnostics only (env CRASS_SURV_DEBUG): 0 = normal; 1..3 cut the survivor kernel short
 };
 
 // per-survivor output slot of the pass-1 survivor kernel
@@ -77,6 +78,7 @@ struct SurvLds {
     uint32_t seq_bytes;           // >= maxL + 16, multiple of 16
     uint32_t ss_cap;              // entries (uint32)
     uint32_t row_elems;           // uint16 entries per Levenshtein boundary row
+    uint32_t words_cap;           // uint32 entries of the packed-read copy
     uint32_t total_bytes;
 };
 

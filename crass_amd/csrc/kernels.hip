@@ -325,6 +325,7 @@ struct RH {                 // ReadHolder state (ReadHolder.h:440-451), wave-uni
     int replen;             // RH_RepeatLength
     int err;
     uint16_t *rowA, *rowB;  // Levenshtein block-boundary rows (LDS)
+    float *sims;            // LDS scratch for the QC similarities (ss_cap floats)
     const uint32_t *words;  // LDS copy of the 2-bit packed read (+1 zero word), nullptr for exception reads
     uint32_t cmask;         // (1 << 2w) - 1
 };
@@ -600,6 +601,62 @@ static __device__ float wave_similarity(const uint8_t *s1, int n, const uint8_t 
     return (float)(1.0 - (double)(edit_distance / max_length));
 }
 
+// The same distance, one pair per LANE, bit-parallel (Myers / Hyyro 2003 OSA recurrences on one
+// 64-bit column word).  The reference's transposition term only ever lowers a cell when both
+// crossed characters match (otherwise M[i-2][j-2]+2 or +3 >= the substitution path), i.e. it is
+// the OSA transposition restricted to i>2 && j>2: TR is masked for rows 1,2 (bits 0,1) and for
+// the first two text columns.  Needs the shorter string to be <= 64 long and ACGT-only (the
+// longer one may hold any byte: it simply matches nothing); returns -1 otherwise and the caller
+// falls back to the wavefront version.  Checked against the oracle / compiled reference in
+// tests (levenshtein batch + every QC decision of the parity suites).
+static __device__ int lane_lev_bp(const uint8_t *s, int n, const uint8_t *t, int m)
+{
+    if (n == 0) return m;
+    if (m == 0) return n;
+    if (n > m) { const uint8_t *x = s; s = t; t = x; int y = n; n = m; m = y; }
+    if (n > 64) return -1;
+    uint64_t pA = 0, pC = 0, pG = 0, pT = 0;
+    for (int i = 0; i < n; i++) {
+        const uint8_t c = s[i];
+        const uint64_t b = 1ull << i;
+        if (c == 'A') pA |= b; else if (c == 'C') pC |= b; else if (c == 'G') pG |= b; else if (c == 'T') pT |= b;
+        else return -1;
+    }
+    uint64_t VP = ~0ull, VN = 0, D0 = 0, PMold = 0;
+    int dist = n;
+    const uint64_t top = 1ull << (n - 1);
+    for (int j = 0; j < m; j++) {
+        const uint8_t c = t[j];
+        const uint64_t PMj = (c == 'A') ? pA : (c == 'C') ? pC : (c == 'G') ? pG : (c == 'T') ? pT : 0ull;
+        uint64_t TR = (((~D0) & PMj) << 1) & PMold & ~3ull;
+        if (j < 2) TR = 0;
+        D0 = (((PMj & VP) + VP) ^ VP) | PMj | VN;
+        D0 |= TR;
+        uint64_t HP = VN | ~(D0 | VP);
+        uint64_t HN = D0 & VP;
+        dist += (HP & top) ? 1 : 0;
+        dist -= (HN & top) ? 1 : 0;
+        HP = (HP << 1) | 1ull;
+        HN = HN << 1;
+        VP = HN | ~(D0 | HP);
+        VN = HP & D0;
+        PMold = PMj;
+    }
+    return dist;
+}
+
+// getStringSimilarity for one pair per lane; *fallback set when the bit-parallel form does not apply
+static __device__ float lane_similarity(const uint8_t *s1, int n, const uint8_t *s2, int m, bool &fallback)
+{
+    fallback = false;
+    float max_length = (float)(n > m ? n : m);
+    if (n < 3 || m < 3) return 0.0f;
+    int d = lane_lev_bp(s1, n, s2, m);
+    if (d < 0) { fallback = true; return 0.0f; }
+    float edit_distance = (float)d;
+    return (float)(1.0 - (double)(edit_distance / max_length));
+}
+
 // std::string::substr(pos, n) length: throws if pos > size
 static __device__ __forceinline__ bool substr_len(int L, uint32_t pos, uint32_t n, uint32_t &len)
 {
@@ -630,6 +687,39 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
         int max_spacer_length = 0;
         int num_compared = 0;
         const int nsp = num_repeats - 1;
+        // all 2*(nsp-1) similarities are independent: one pair per lane (bit-parallel DP), the float
+        // sums below then consume them in the reference's order.  pair 2i = (repeat, spacer_i),
+        // pair 2i+1 = (spacer_i, spacer_i+1)   (:921-950)
+        const int npairs = 2 * (nsp - 1);
+        for (int q0 = 0; q0 < npairs; q0 += WAVE) {
+            const int q = q0 + lane;
+            const bool valid = q < npairs;
+            const int i = valid ? (q >> 1) : 0;
+            uint32_t a_start = h.ss[2 * i + 1] + 1, a_len = 0, b_start = h.ss[2 * i + 3] + 1, b_len = 0;
+            bool bad = !substr_len(h.L, a_start, h.ss[2 * i + 2] - a_start, a_len);
+            bad = bad || !substr_len(h.L, b_start, h.ss[2 * i + 4] - b_start, b_len);
+            if (__ballot(valid && bad)) return -1;
+            bool fb = false;
+            float sim = 0.0f;
+            if (valid) {
+                if (q & 1) sim = lane_similarity(h.seq + a_start, (int)a_len, h.seq + b_start, (int)b_len, fb);
+                else sim = lane_similarity(repeat, (int)rep_len, h.seq + a_start, (int)a_len, fb);
+                h.sims[q] = sim;
+            }
+            uint64_t fbmask = __ballot(valid && fb);
+            while (fbmask) {                              // rare: > 64-long or non-ACGT shorter string
+                const int src = __ffsll((unsigned long long)fbmask) - 1;
+                fbmask &= fbmask - 1;
+                const int qq = q0 + src, ii = qq >> 1;
+                uint32_t as = h.ss[2 * ii + 1] + 1, al = 0, bs = h.ss[2 * ii + 3] + 1, bl = 0;
+                (void)substr_len(h.L, as, h.ss[2 * ii + 2] - as, al);
+                (void)substr_len(h.L, bs, h.ss[2 * ii + 4] - bs, bl);
+                float sw = (qq & 1) ? wave_similarity(h.seq + as, (int)al, h.seq + bs, (int)bl, h.rowA, h.rowB, lane)
+                                    : wave_similarity(repeat, (int)rep_len, h.seq + as, (int)al, h.rowA, h.rowB, lane);
+                if (lane == 0) h.sims[qq] = sw;
+            }
+        }
+        wave_sync();
         uint32_t cur_start = h.ss[1] + 1, cur_len;
         if (!substr_len(h.L, cur_start, h.ss[2] - cur_start, cur_len)) return -1;
         for (int i = 0; i < nsp; i++) {
@@ -639,15 +729,16 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
                 uint32_t nxt_start = h.ss[2 * i + 3] + 1, nxt_len;
                 if (!substr_len(h.L, nxt_start, h.ss[2 * i + 4] - nxt_start, nxt_len)) return -1;
                 num_compared++;
-                ave_repeat_to_spacer_difference += wave_similarity(repeat, (int)rep_len, h.seq + cur_start, (int)cur_len, h.rowA, h.rowB, lane);
+                ave_repeat_to_spacer_difference += h.sims[2 * i];
                 float ss_diff = 0;
-                ss_diff += wave_similarity(h.seq + cur_start, (int)cur_len, h.seq + nxt_start, (int)nxt_len, h.rowA, h.rowB, lane);
+                ss_diff += h.sims[2 * i + 1];
                 ave_spacer_to_spacer_difference += ss_diff;
                 ave_spacer_to_spacer_len_difference += ((float)cur_len - (float)nxt_len);
                 ave_repeat_to_spacer_len_difference += ((float)rep_len - (float)cur_len);
                 cur_start = nxt_start; cur_len = nxt_len;
             }
         }
+        wave_sync();
         // num_compared == nsp-1 >= 1 here (the reference's num_compared == 0 branch needs <2 spacers)
         ave_spacer_to_spacer_difference /= (float)num_compared;
         ave_repeat_to_spacer_difference /= (float)num_compared;
@@ -670,7 +761,9 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
         if (!substr_len(h.L, s, e - s, sp_len)) return -1;
         if ((int)sp_len < minSpacerLength) return 0;
         if ((int)sp_len > maxSpacerLength) return 0;
-        float similarity = wave_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, h.rowA, h.rowB, lane);
+        bool fb = false;
+        float similarity = lane_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, fb);     // same pair in every lane
+        if (fb) similarity = wave_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, h.rowA, h.rowB, lane);
         if ((double)similarity > 0.82) return 0;
         int dlen = (int)sp_len - (int)rep_len;
         if (dlen < 0) dlen = -dlen;
@@ -703,6 +796,7 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
         if (endSearch < beginSearch) endSearch = beginSearch;
         if (beginSearch > seq_length) return -1;                       // substr would throw
         int pos = rh_find(h, (int)beginSearch, (int)endSearch, (int)j, (int)o.window, lane);
+        if (o.debug_stop == 2) pos = -1;
         if (pos >= 0) {
             rh_add(h, j, j + o.window - 1, lane);
             rh_add(h, (uint32_t)pos, (uint32_t)pos + o.window - 1, lane);
@@ -712,7 +806,7 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
         }
         if ((uint32_t)(h.nss / 2) >= o.minRepeats) {
             uint32_t actual_repeat_length = extend_pre_repeat(h, (int)o.window, (int)o.lowSp, lane);
-            if ((actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {
+            if (o.debug_stop != 3 && (actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {
                 int qc = qc_found_repeats(h, (int)o.lowSp, (int)o.highSp, lane);
                 if (qc < 0) return -1;
                 if (qc) return 1;
@@ -825,6 +919,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
     h.rowB = h.rowA + lds.row_elems;
     uint32_t *l_words = reinterpret_cast<uint32_t *>(h.rowB + lds.row_elems);
     h.words = EXC ? nullptr : l_words;
+    h.sims = reinterpret_cast<float *>(l_words + lds.words_cap);
     h.cmask = (1u << (2 * P.window)) - 1u;
     uint64_t n_surv = EXC ? R.n_exc : (uint64_t)(*d_n_surv);
     if (n_surv > n_max) n_surv = n_max;
@@ -845,7 +940,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
         wave_sync();
         h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
         const uint32_t hint = (!EXC && seed_hint) ? seed_hint[r] : 0xFFFFFFFFu;
-        int f = search_core(h, P, hint, lane);
+        int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane);
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
         if (f < 0) o.err = (f == -2) ? 2 : 1;
@@ -877,8 +972,8 @@ SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P)
     uint32_t reps = max_len / (P.window + P.lowSp) + 4;
     l.ss_cap = ((2 * reps) + 3u) & ~3u;
     l.row_elems = ((max_len + 8) + 7u) & ~7u;
-    uint32_t words = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
-    l.total_bytes = l.seq_bytes + l.ss_cap * 4 + 2 * l.row_elems * 2 + words * 4;
+    l.words_cap = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
+    l.total_bytes = l.seq_bytes + l.ss_cap * 4 + 2 * l.row_elems * 2 + l.words_cap * 4 + l.ss_cap * 4;
     return l;
 }
 
@@ -1259,6 +1354,23 @@ hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, con
 // ------------------------------------------------------------------------------------
 // Levenshtein / similarity batch: one wave per string pair
 // ------------------------------------------------------------------------------------
+// lane per pair, bit-parallel; pairs it cannot handle are marked dist = -1 for the wave kernel
+__global__ __launch_bounds__(256) void k_lev_batch_lanes(const uint8_t *chars, const uint64_t *a_off, const uint32_t *a_len,
+                                                          const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,
+                                                          int32_t *dist, float *sim)
+{
+    uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (k >= n_pairs) return;
+    const uint8_t *s = chars + a_off[k], *t = chars + b_off[k];
+    const int n = (int)a_len[k], m = (int)b_len[k];
+    int d = lane_lev_bp(s, n, t, m);
+    dist[k] = d;
+    if (sim && d >= 0) {
+        float max_length = (float)(n > m ? n : m);
+        sim[k] = (n < 3 || m < 3) ? 0.0f : (float)(1.0 - (double)((float)d / max_length));
+    }
+}
+
 __global__ __launch_bounds__(WAVE) void k_lev_batch(const uint8_t *chars, const uint64_t *a_off, const uint32_t *a_len,
                                                      const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,
                                                      int32_t *dist, float *sim, uint32_t row_elems, uint32_t str_bytes)
@@ -1271,6 +1383,7 @@ __global__ __launch_bounds__(WAVE) void k_lev_batch(const uint8_t *chars, const 
     const int lane = threadIdx.x;
     for (uint64_t k = blockIdx.x; k < n_pairs; k += gridDim.x) {
         int n = (int)a_len[k], m = (int)b_len[k];
+        if (dist[k] != -1) continue;                  // already done by the lane kernel
         wave_sync();
         for (int i = lane; i < n; i += WAVE) sa[i] = chars[a_off[k] + i];
         for (int i = lane; i < m; i += WAVE) sb[i] = chars[b_off[k] + i];
@@ -1278,7 +1391,7 @@ __global__ __launch_bounds__(WAVE) void k_lev_batch(const uint8_t *chars, const 
         int d = wave_lev(sa, n, sb, m, rowA, rowB, lane);
         float s = 0.0f;
         if (sim) s = wave_similarity(sa, n, sb, m, rowA, rowB, lane);
-        if (lane == 0) { if (dist) dist[k] = d; if (sim) sim[k] = s; }
+        if (lane == 0) { dist[k] = d; if (sim) sim[k] = s; }
     }
 }
 
@@ -1292,6 +1405,8 @@ hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off,
     size_t lds = 2 * (size_t)str_bytes + 2 * (size_t)row_elems * 2;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lev_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    // `dist` is always a device buffer here (engine.cpp allocates it even if the caller wants only sims)
+    hipLaunchKernelGGL(k_lev_batch_lanes, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, chars, a_off, a_len, b_off, b_len, n_pairs, dist, sim);
     uint64_t grid = n_pairs < 4096 ? n_pairs : 4096;
     hipLaunchKernelGGL(k_lev_batch, dim3((unsigned)grid), dim3(WAVE), lds, st, chars, a_off, a_len, b_off, b_len, n_pairs, dist, sim, row_elems, str_bytes);
     return hipGetLastError();

@@ -184,6 +184,10 @@ def test_levenshtein_batch(ca):
         else:
             t = bytes(rng.choice(b"ACGT") for _ in range(m))
         pairs.append((s, t))
+    # non-ACGT bytes: in the longer string they just never match; in the shorter one the
+    # bit-parallel lane kernel must hand the pair to the wavefront kernel
+    pairs += [(b"ACGTNACGTACGTTTGACNA", b"ACGTACGTACGTTGACA"), (b"ACGTACGTAC", b"ACNTACGTACGGTTACAGT"),
+              (b"acgtacgtacgt", b"ACGTACGTACGT"), (b"A" * 64 + b"C", b"A" * 64), (b"ACGT" * 16, b"ACGT" * 16 + b"TT")]
     with ca.SearchEngine() as eng:
         dist, sim = eng.levenshtein_batch(pairs)
     L = orc.lib()
