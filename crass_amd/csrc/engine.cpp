@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -382,7 +383,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, nchunk * stride, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        const uint32_t used = c->h_count.p[2];
+        // slot mode (kernel: n_surv * ss_cap <= pool_cap): the whole slot area is live, no counter
+        const bool slot_mode = nchunk * (uint64_t)lds.ss_cap <= pool_cap;
+        const uint32_t used = slot_mode ? (uint32_t)(nchunk * lds.ss_cap) : c->h_count.p[2];
         if (used > pool_cap) return CRASS_ERR_OVERFLOW;
         HIPCHK(c, c->h_ss.ensure(used + 1));
         if (used) {
@@ -537,11 +540,16 @@ static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pa
     for (const auto &p : pats) if (p.empty() || p.size() > 255) return CRASS_ERR_UNSUPPORTED;
     HostAutomaton H;
     HostAnchors HK;
+    const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
+    const double tb0 = now_ms();
+    double tb1;
     {
         std::thread anchors_thread([&]() { build_anchors(HK, pats); });   // independent of the automaton
         build_automaton(H, pats);
+        tb1 = now_ms();
         anchors_thread.join();
     }
+    const double tb2 = now_ms();
     DevAutomaton A{};
     A.n_states = H.n_states; A.n_sym1 = H.n_sym1;
     memcpy(A.sym, H.sym, 256);
@@ -582,6 +590,7 @@ static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pa
     }
     c->have_patterns = true;
     c->cnt.ac_states = H.n_states;
+    if (prof) fprintf(stderr, "[crass_merge] automaton %.3f ms (+%.3f ms waiting for anchors), uploads %.3f ms\n", tb1 - tb0, tb2 - tb1, now_ms() - tb2);
     return CRASS_OK;
 }
 

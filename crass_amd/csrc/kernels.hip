@@ -949,9 +949,14 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
             int dlen = dr_low_lexi(h, dr_chars + s * (uint64_t)dr_stride, low, lane);
             if (dlen < 0 || dlen > (int)dr_stride) o.err = 1;
             else {
+                // start/stop pool: a fixed slot per survivor when the pool is large enough (short reads),
+                // otherwise bump allocation (one contended atomic per found read: long reads only)
                 uint32_t off = 0;
-                if (lane == 0) off = atomicAdd(d_ss_used, (uint32_t)h.nss);
-                off = (uint32_t)__shfl((int)off, 0);
+                if ((uint64_t)n_surv * lds.ss_cap <= ss_pool_cap) off = (uint32_t)s * lds.ss_cap;
+                else {
+                    if (lane == 0) off = atomicAdd(d_ss_used, (uint32_t)h.nss);
+                    off = (uint32_t)__shfl((int)off, 0);
+                }
                 if ((uint64_t)off + (uint64_t)h.nss > ss_pool_cap) o.err = 3;
                 else {
                     for (int k = lane; k < h.nss; k += WAVE) ss_pool[off + k] = h.ss[k];

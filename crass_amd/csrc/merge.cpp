@@ -158,22 +158,12 @@ struct KmerGid {
     }
 };
 
-// WorkHorse::clusterDRReads (WorkHorse.cpp:1404-1637): greedy, order-dependent assignment of
-// one DR variant to a group through shared laurenized 11-mers.  Returns the GID.
-int cluster_one(const std::string &dr, int &next_free_gid, KmerGid &kg, int min_shared)
+// laurenized 11-mer codes of one DR in order (laurenize, SeqUtils.cpp:89-97: seq1 < seq2 ? seq1 : seq2);
+// -1 marks a window holding a non-ACGT byte (handled through string keys).  Pure function of the
+// string, so it is computed for all variants in parallel before the order-dependent greedy pass.
+void kmer_codes(const std::string &dr, int32_t *out)
 {
     const int n_mers = (int)dr.size() - kClusterKmer + 1;
-    std::vector<uint32_t> homeless_code;
-    std::vector<std::string> homeless_str;
-    std::vector<std::pair<int, int>> group_count;               // std::map<int,int> in the reference; tiny
-    int group = 0;
-    auto seen = [&](int gid) {
-        if (group != 0) return;
-        for (auto &gc : group_count)
-            if (gc.first == gid) { if (min_shared <= ++gc.second) group = gid; return; }
-        group_count.emplace_back(gid, 1);                       // the first sighting is not tested (:1577-1580)
-    };
-    // rolling forward / reverse-complement codes; `bad` counts positions until the window is ACGT-only again
     uint32_t fwd = 0, rev = 0;
     int bad = 0;
     const uint32_t mask = (1u << 22) - 1;
@@ -184,12 +174,31 @@ int cluster_one(const std::string &dr, int &next_free_gid, KmerGid &kg, int min_
         rev = (rev >> 2) | ((uint32_t)(3 - c) << 20);
         const int start = i - kClusterKmer + 1;
         if (start < 0 || start >= n_mers) continue;
-        if (bad == 0) {
-            const uint32_t lau = fwd < rev ? fwd : rev;          // laurenize (SeqUtils.cpp:89-97): seq1 < seq2 ? seq1 : seq2
-            const int32_t gid = kg.find(lau);
-            if (gid == 0) homeless_code.push_back(lau); else seen(gid);
+        out[start] = (bad == 0) ? (int32_t)(fwd < rev ? fwd : rev) : -1;
+    }
+}
+
+// WorkHorse::clusterDRReads (WorkHorse.cpp:1404-1637): greedy, order-dependent assignment of
+// one DR variant to a group through shared laurenized 11-mers.  Returns the GID.
+int cluster_one(const std::string &dr, const int32_t *codes, int n_mers, int &next_free_gid, KmerGid &kg, int min_shared,
+                std::vector<uint32_t> &homeless_code, std::vector<std::pair<int, int>> &group_count)
+{
+    homeless_code.clear();
+    group_count.clear();                                        // std::map<int,int> in the reference; tiny
+    std::vector<std::string> homeless_str;
+    int group = 0;
+    auto seen = [&](int gid) {
+        if (group != 0) return;
+        for (auto &gc : group_count)
+            if (gc.first == gid) { if (min_shared <= ++gc.second) group = gid; return; }
+        group_count.emplace_back(gid, 1);                       // the first sighting is not tested (:1577-1580)
+    };
+    for (int i = 0; i < n_mers; i++) {
+        if (codes[i] >= 0) {
+            const int32_t gid = kg.find((uint32_t)codes[i]);
+            if (gid == 0) homeless_code.push_back((uint32_t)codes[i]); else seen(gid);
         } else {
-            std::string km = dr.substr((size_t)start, kClusterKmer), rc = reverse_complement(km);
+            std::string km = dr.substr((size_t)i, kClusterKmer), rc = reverse_complement(km);
             const std::string &lau = (km < rc) ? km : rc;
             auto it = kg.other.find(lau);
             if (it == kg.other.end()) homeless_str.push_back(lau); else seen(it->second);
@@ -199,6 +208,73 @@ int cluster_one(const std::string &dr, int &next_free_gid, KmerGid &kg, int min_
     for (uint32_t k : homeless_code) kg.put(k, group);
     for (const auto &k : homeless_str) kg.other[k] = group;
     return group;
+}
+
+// run fn(task) for task in [0, n_tasks) on up to max_threads host threads (dynamic scheduling)
+template <typename F> void parallel_tasks(size_t n_tasks, unsigned max_threads, F fn)
+{
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), max_threads);
+    if (n_tasks < 2) nt = 1;
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (size_t t = next.fetch_add(1); t < n_tasks; t = next.fetch_add(1)) fn(t); };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+}
+
+// addReadHolder's token assignment (libcrispr.cpp:1137-1143) for all candidates: token = 2 + rank of
+// the string's FIRST occurrence.  Deterministic parallel form: candidates are partitioned by hash
+// (all occurrences of a string land in one partition), each partition is scanned in candidate order
+// by one thread to find every candidate's first occurrence, then first occurrences are ranked.
+void assign_tokens(MergeResult &m, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n)
+{
+    m.cand_token.resize(n);
+    if (n < 8192) {
+        for (uint64_t k = 0; k < n; k++) {
+            const char *dr = dr_chars + k * (uint64_t)dr_stride;
+            uint32_t t = m.tokens.get(dr, dr_len[k]);
+            if (t == 0) t = m.tokens.add(dr, dr_len[k]);
+            m.cand_token[k] = t;
+        }
+        return;
+    }
+    constexpr unsigned P = 64;                                   // partitions
+    std::vector<uint64_t> hash(n);
+    const size_t chunk = 4096;
+    parallel_tasks((n + chunk - 1) / chunk, 16, [&](size_t c) {
+        const uint64_t lo = c * chunk, hi = std::min<uint64_t>(n, lo + chunk);
+        for (uint64_t k = lo; k < hi; k++) hash[k] = TokenTable::hash(dr_chars + k * (uint64_t)dr_stride, dr_len[k]);
+    });
+    // stable counting sort of candidate indices by partition
+    std::vector<uint32_t> start(P + 1, 0), order(n);
+    for (uint64_t k = 0; k < n; k++) start[(hash[k] >> 58) + 1]++;
+    for (unsigned p = 0; p < P; p++) start[p + 1] += start[p];
+    {
+        std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+        for (uint64_t k = 0; k < n; k++) order[fill[hash[k] >> 58]++] = (uint32_t)k;
+    }
+    std::vector<uint32_t> rep(n);                                // first occurrence (candidate index) of k's string
+    parallel_tasks(P, 16, [&](size_t p) {
+        const uint32_t lo = start[p], hi = start[p + 1];
+        size_t cap = 64;
+        while (cap < (size_t)(hi - lo) * 2) cap <<= 1;
+        std::vector<uint32_t> slot(cap, 0xFFFFFFFFu);            // candidate index of a first occurrence
+        for (uint32_t q = lo; q < hi; q++) {
+            const uint32_t k = order[q];
+            const char *dr = dr_chars + k * (uint64_t)dr_stride;
+            size_t i = (size_t)(hash[k] >> 6) & (cap - 1);
+            for (;; i = (i + 1) & (cap - 1)) {
+                const uint32_t f = slot[i];
+                if (f == 0xFFFFFFFFu) { slot[i] = k; rep[k] = k; break; }
+                if (hash[f] == hash[k] && dr_len[f] == dr_len[k] && memcmp(dr_chars + f * (uint64_t)dr_stride, dr, dr_len[k]) == 0) { rep[k] = f; break; }
+            }
+        }
+    });
+    // rank first occurrences in candidate order -> tokens; register the strings
+    for (uint64_t k = 0; k < n; k++)
+        if (rep[k] == k) m.cand_token[k] = m.tokens.add(dr_chars + k * (uint64_t)dr_stride, dr_len[k]);
+    for (uint64_t k = 0; k < n; k++) m.cand_token[k] = m.cand_token[rep[k]];
 }
 
 bool shorter_first(const std::string &a, const std::string &b) { return a.length() < b.length(); }
@@ -316,20 +392,29 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
     const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
     const double t0 = prof_now();
     m.clear();
-    m.cand_token.resize(n);
-    for (uint64_t k = 0; k < n; k++) {
-        const char *dr = dr_chars + k * (uint64_t)dr_stride;
-        uint32_t t = m.tokens.get(dr, dr_len[k]);
-        if (t == 0) t = m.tokens.add(dr, dr_len[k]);
-        m.cand_token[k] = t;
-    }
+    assign_tokens(m, dr_chars, dr_len, dr_stride, n);
     const double t1 = prof_now();
-    // createNonRedundantSet: cluster every token in ascending token order (std::map iteration)
+    // createNonRedundantSet: cluster every token in ascending token order (std::map iteration).
+    // The k-mer codes are order-independent and computed up front on several threads.
+    const uint32_t ntok = m.tokens.size();
+    std::vector<uint32_t> code_off(ntok + 1, 0);
+    for (uint32_t t = 0; t < ntok; t++) {
+        const int nm = (int)m.tokens.strings[t].size() - kClusterKmer + 1;
+        code_off[t + 1] = code_off[t] + (uint32_t)(nm > 0 ? nm : 0);
+    }
+    std::vector<int32_t> codes(code_off[ntok]);
+    parallel_tasks((ntok + 255) / 256, 8, [&](size_t c) {
+        for (uint32_t t = (uint32_t)c * 256; t < std::min<uint32_t>(ntok, ((uint32_t)c + 1) * 256); t++)
+            if (code_off[t + 1] > code_off[t]) kmer_codes(m.tokens.strings[t], codes.data() + code_off[t]);
+    });
     KmerGid kmer_gid;
     int next_gid = 1;
-    std::vector<int> gid_of(m.tokens.size());
-    for (uint32_t t = 0; t < m.tokens.size(); t++)
-        gid_of[t] = cluster_one(m.tokens.strings[t], next_gid, kmer_gid, kmer_clust_size);
+    std::vector<int> gid_of(ntok);
+    std::vector<uint32_t> scratch_codes;
+    std::vector<std::pair<int, int>> scratch_counts;
+    for (uint32_t t = 0; t < ntok; t++)
+        gid_of[t] = cluster_one(m.tokens.strings[t], codes.data() + code_off[t], (int)(code_off[t + 1] - code_off[t]), next_gid,
+                                kmer_gid, kmer_clust_size, scratch_codes, scratch_counts);
     m.next_free_gid = next_gid;
     m.groups.assign((size_t)(next_gid - 1), {});
     for (uint32_t t = 0; t < m.tokens.size(); t++) m.groups[(size_t)gid_of[t] - 1].push_back(t + 2);
@@ -338,21 +423,11 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
     std::vector<std::vector<std::string>> survivors(m.groups.size());
     {
         const size_t ng = m.groups.size();
-        unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8);
-        if (m.tokens.size() < 2000 || ng < 2) nt = 1;
-        std::atomic<size_t> next_group{0};
-        auto work = [&]() {
-            for (size_t g = next_group.fetch_add(1); g < ng; g = next_group.fetch_add(1)) {
-                std::vector<std::string> &clustered = survivors[g];
-                for (uint32_t tok : m.groups[g]) clustered.push_back(m.tokens.strings[tok - 2]);
-                remove_redundant(clustered);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
-        if (prof) fprintf(stderr, "[crass_merge]   de-dup section %.3f ms on %u threads\n", prof_now() - t2, nt);
+        parallel_tasks(ng, m.tokens.size() < 2000 ? 1 : 16, [&](size_t g) {
+            std::vector<std::string> &clustered = survivors[g];
+            for (uint32_t tok : m.groups[g]) clustered.push_back(m.tokens.strings[tok - 2]);
+            remove_redundant(clustered);
+        });
     }
     for (size_t g = 0; g < m.groups.size(); g++) {
         const std::vector<std::string> &clustered = survivors[g];
@@ -454,7 +529,7 @@ void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns)
     auto mul24 = [](uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) & 0xFFFFFFFFull); };
     for (uint32_t log_size = 10; log_size <= 15; log_size++) {
         const uint32_t size = 1u << log_size, rsh = 32 - log_size;
-        if (keys.size() * 2 > size) continue;                     // keep the load factor <= 0.5
+        if (keys.size() * 3 > size && log_size < 15) continue;    // load factor <= 1/3: the first hash pair nearly always works
         for (uint32_t a = 0; a < 4; a++) for (uint32_t b = 0; b < 4; b++) {
             const uint32_t s1 = SH[a][0], s2 = SH[a][1], m1 = MU[b][0], m2 = MU[b][1];
             auto h1 = [&](uint32_t v) { return mul24(v ^ (v >> s1), m1) >> rsh; };
