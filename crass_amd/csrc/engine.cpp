@@ -382,7 +382,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->d_surv.p, nchunk * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, nchunk * stride, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
+        const double tq0 = now_ms();
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        const double tq1 = now_ms();
         // slot mode (kernel: n_surv * ss_cap <= pool_cap): the whole slot area is live, no counter
         const bool slot_mode = nchunk * (uint64_t)lds.ss_cap <= pool_cap;
         const uint32_t used = slot_mode ? (uint32_t)(nchunk * lds.ss_cap) : c->h_count.p[2];
@@ -392,6 +394,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->d_ss_pool.p, (size_t)used * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
+        const double tq2 = now_ms();
         const SurvOut *so = c->h_surv.p;
         const char *drs = c->h_dr.p;
         const uint32_t *pool = c->h_ss.p;
@@ -409,6 +412,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             L.dr_len.push_back(o.dr_len);
             L.dr.insert(L.dr.end(), drs + k * stride, drs + (k + 1) * stride);
         }
+        if (getenv("CRASS_MERGE_PROFILE"))
+            fprintf(stderr, "[crass_sink] survivors %llu: kernel+D2H wait %.3f ms, pool D2H %.3f ms, host loop %.3f ms\n",
+                    (unsigned long long)nchunk, tq1 - tq0, tq2 - tq1, now_ms() - tq2);
     }
     return CRASS_OK;
 }

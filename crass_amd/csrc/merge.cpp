@@ -9,7 +9,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <thread>
 
 namespace crass {
@@ -210,17 +213,71 @@ int cluster_one(const std::string &dr, const int32_t *codes, int n_mers, int &ne
     return group;
 }
 
-// run fn(task) for task in [0, n_tasks) on up to max_threads host threads (dynamic scheduling)
+// A small persistent worker pool: spawning std::threads per call costs ~50 us each on a big host,
+// more than the work they would do here.  Workers sleep on a condition variable between jobs.
+class HostPool {
+public:
+    static HostPool &get() { static HostPool p; return p; }
+    // run fn(task) for task in [0, n_tasks) on up to max_threads threads (caller included)
+    void run(size_t n_tasks, unsigned max_threads, const std::function<void(size_t)> &fn)
+    {
+        if (n_tasks == 0) return;
+        unsigned helpers = std::min<unsigned>((unsigned)workers_.size(), max_threads > 0 ? max_threads - 1 : 0);
+        if (n_tasks < 2 || helpers == 0) { for (size_t t = 0; t < n_tasks; t++) fn(t); return; }
+        std::unique_lock<std::mutex> job_lock(job_mutex_);     // one job at a time
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; n_tasks_ = n_tasks; next_.store(0); active_ = helpers; want_ = helpers; epoch_++;
+        }
+        cv_.notify_all();
+        for (size_t t = next_.fetch_add(1); t < n_tasks; t = next_.fetch_add(1)) fn(t);
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [&] { return active_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    HostPool()
+    {
+        unsigned n = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
+        for (unsigned i = 0; i + 1 < n; i++) workers_.emplace_back([this, i] { loop(i); });
+    }
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; epoch_++; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void loop(unsigned id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return epoch_ != seen; });
+            seen = epoch_;
+            if (stop_) return;
+            if (id >= want_) continue;                          // this job wants fewer helpers
+            const std::function<void(size_t)> *fn = fn_;
+            const size_t n = n_tasks_;
+            lk.unlock();
+            for (size_t t = next_.fetch_add(1); t < n; t = next_.fetch_add(1)) (*fn)(t);
+            lk.lock();
+            if (--active_ == 0) done_cv_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, job_mutex_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t n_tasks_ = 0;
+    std::atomic<size_t> next_{0};
+    unsigned active_ = 0, want_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+
 template <typename F> void parallel_tasks(size_t n_tasks, unsigned max_threads, F fn)
 {
-    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), max_threads);
-    if (n_tasks < 2) nt = 1;
-    std::atomic<size_t> next{0};
-    auto work = [&]() { for (size_t t = next.fetch_add(1); t < n_tasks; t = next.fetch_add(1)) fn(t); };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
+    HostPool::get().run(n_tasks, max_threads, std::function<void(size_t)>(fn));
 }
 
 // addReadHolder's token assignment (libcrispr.cpp:1137-1143) for all candidates: token = 2 + rank of
