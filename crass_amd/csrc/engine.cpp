@@ -104,6 +104,23 @@ struct crass_hip_ctx {
         void reserve(size_t n, uint32_t stride) { read.reserve(n); low.reserve(n); replen.reserve(n); nss.reserve(n); ss_off.reserve(n); ss.reserve(n * 6); dr_len.reserve(n); dr.reserve(n * stride); }
         size_t size() const { return read.size(); }
     } cand;
+    // fast path: the found records are gathered on the device into dense arrays and land in pinned
+    // host memory already in the hand-off layout (no per-record host work)
+    struct P1Dense {
+        DevBuf<uint64_t> d_read, d_ss_off; DevBuf<uint8_t> d_low; DevBuf<uint32_t> d_replen, d_nss, d_ss; DevBuf<uint16_t> d_dr_len; DevBuf<char> d_dr;
+        PinBuf<uint64_t> h_read, h_ss_off; PinBuf<uint8_t> h_low; PinBuf<uint32_t> h_replen, h_nss, h_ss; PinBuf<uint16_t> h_dr_len; PinBuf<char> h_dr;
+        uint64_t n = 0;
+        bool active = false;
+        void release()
+        {
+            d_read.release(); d_ss_off.release(); d_low.release(); d_replen.release(); d_nss.release(); d_ss.release(); d_dr_len.release(); d_dr.release();
+            h_read.release(); h_ss_off.release(); h_low.release(); h_replen.release(); h_nss.release(); h_ss.release(); h_dr_len.release(); h_dr.release();
+        }
+    } dense;
+    DevBuf<uint64_t> d_fidx;
+    uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
+    const char *cand_dr() const { return dense.active ? dense.h_dr.p : cand.dr.data(); }
+    const uint16_t *cand_dr_len() const { return dense.active ? dense.h_dr_len.p : cand.dr_len.data(); }
     uint32_t dr_stride = 48;
     // merge
     MergeResult merge;
@@ -201,7 +218,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
     c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
-    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
+    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -419,6 +436,61 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     return CRASS_OK;
 }
 
+// Fast path of the pass-1 sink: one chunk, fixed start/stop slots, no exception reads.  Returns
+// CRASS_ERR_STATE when it does not apply (the caller then uses the host-loop path).
+static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
+{
+    const SurvLds lds = survivor_lds_layout(c->max_len, c->dp);
+    if (lds.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
+    const uint32_t stride = c->dr_stride;
+    const uint64_t pool_cap = std::max<uint64_t>(n_surv * (uint64_t)lds.ss_cap, 1u << 16);
+    if (n_surv == 0 || n_surv > (1u << 20) || lds.ss_cap > 64 || (stride & 15)) return CRASS_ERR_STATE;
+    crass_hip_ctx::P1Dense &D = c->dense;
+    HIPCHK(c, c->d_surv.ensure(n_surv));
+    HIPCHK(c, c->d_dr.ensure(n_surv * stride));
+    HIPCHK(c, c->d_ss_pool.ensure(pool_cap));
+    HIPCHK(c, c->d_fidx.ensure(n_surv));
+    HIPCHK(c, D.d_read.ensure(n_surv)); HIPCHK(c, D.d_ss_off.ensure(n_surv)); HIPCHK(c, D.d_low.ensure(n_surv));
+    HIPCHK(c, D.d_replen.ensure(n_surv)); HIPCHK(c, D.d_nss.ensure(n_surv)); HIPCHK(c, D.d_dr_len.ensure(n_surv));
+    HIPCHK(c, D.d_dr.ensure(n_surv * stride)); HIPCHK(c, D.d_ss.ensure(n_surv * (uint64_t)lds.ss_cap));
+    HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 8, c->stream));            // [2] = found count, [3] = worst error
+    HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+    HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, c->d_count.p + 1, n_surv, c->d_surv.p, c->d_dr.p, stride,
+                              c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p,
+                              c->hints_valid ? c->d_hit_info.p : nullptr, lds, (int)std::min<uint64_t>(256 * 32, n_surv), c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+    const uint64_t n_words = (n_surv + 63) / 64;
+    HIPCHK(c, launch_found_mask(c->d_surv.p, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream));
+    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n_surv, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, n_surv, c->d_count.p + 2, c->stream));
+    HIPCHK(c, launch_gather_found(c->d_fidx.p, c->d_count.p + 2, n_surv, c->d_surv.p, c->d_idx.p, c->read_base, c->d_dr.p, stride,
+                                  c->d_ss_pool.p, lds.ss_cap, D.d_read.p, D.d_low.p, D.d_replen.p, D.d_nss.p, D.d_ss_off.p,
+                                  D.d_dr_len.p, D.d_dr.p, D.d_ss.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t nf = c->h_count.p[2];
+    const uint32_t err = c->h_count.p[3];
+    if (err == 1) return CRASS_ERR_SEARCH_FATAL;
+    if (err) return CRASS_ERR_OVERFLOW;
+    HIPCHK(c, D.h_read.ensure(nf)); HIPCHK(c, D.h_ss_off.ensure(nf)); HIPCHK(c, D.h_low.ensure(nf)); HIPCHK(c, D.h_replen.ensure(nf));
+    HIPCHK(c, D.h_nss.ensure(nf)); HIPCHK(c, D.h_dr_len.ensure(nf)); HIPCHK(c, D.h_dr.ensure(nf * stride + 16));
+    HIPCHK(c, D.h_ss.ensure(nf * (uint64_t)lds.ss_cap + 16));
+    if (nf) {
+        HIPCHK(c, hipMemcpyAsync(D.h_dr.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, c->stream));          // merge needs these first
+        HIPCHK(c, hipMemcpyAsync(D.h_dr_len.p, D.d_dr_len.p, nf * 2, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(D.h_read.p, D.d_read.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(D.h_ss_off.p, D.d_ss_off.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(D.h_low.p, D.d_low.p, nf, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(D.h_replen.p, D.d_replen.p, nf * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(D.h_nss.p, D.d_nss.p, nf * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(D.h_ss.p, D.d_ss.p, nf * (uint64_t)lds.ss_cap * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    D.n = nf;
+    D.active = true;
+    return CRASS_OK;
+}
+
 int crass_hip_seed_scan(crass_hip_ctx *c)
 {
     if (!c) return CRASS_ERR_INVALID_ARG;
@@ -451,27 +523,9 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint64_t n_surv = c->h_count.p[0];
-    // host copy of the survivor indices (needed to label records with their read index)
-    std::vector<uint64_t> surv_idx(n_surv);
-    if (n_surv) {
-        HIPCHK(c, c->h_idx.ensure(n_surv));
-        HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_idx.p, n_surv * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        memcpy(surv_idx.data(), c->h_idx.p, n_surv * 8);
-    }
-    if (!use_filter && c->R.n_exc) {
-        // drop exception reads from the all-ones mask result on the host (rare path: long reads)
-        std::vector<uint64_t> keep; keep.reserve(n_surv);
-        size_t e = 0;
-        for (uint64_t r : surv_idx) {
-            while (e < c->h_exc_read.size() && c->h_exc_read[e] < r) e++;
-            if (e < c->h_exc_read.size() && c->h_exc_read[e] == r) continue;
-            keep.push_back(r);
-        }
-        surv_idx.swap(keep);
-        n_surv = surv_idx.size();
-        if (n_surv) HIPCHK(c, hipMemcpyAsync(c->d_idx.p, surv_idx.data(), n_surv * 8, hipMemcpyHostToDevice, c->stream));
-    }
+    c->dense.active = false;
+    const bool try_dense = use_filter && c->R.n_exc == 0 && n_surv > 0 && n_surv <= (1u << 20);
+    std::vector<uint64_t> surv_idx;
     // the survivor kernel reads its count from d_count[1] (chunk-local bound is passed separately)
     {
         uint32_t big = 0xFFFFFFFFu;
@@ -481,8 +535,31 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     const double t_sink0 = now_ms();
     c->cand.clear();
-    int s = run_survivors(c, false, n_surv, c->cand, surv_idx.data());
-    if (s) return s;
+    int s = try_dense ? run_survivors_dense(c, n_surv) : CRASS_ERR_STATE;
+    if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
+    if (s == CRASS_ERR_STATE) {
+        // host-loop path: label records with their read index from a host copy of the survivor list
+        surv_idx.resize(n_surv);
+        if (n_surv && use_filter) {
+            HIPCHK(c, c->h_idx.ensure(n_surv));
+            HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_idx.p, n_surv * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            memcpy(surv_idx.data(), c->h_idx.p, n_surv * 8);
+        } else if (n_surv) {
+            // no filter: every non-exception read survives, in order
+            size_t e = 0, w = 0;
+            for (uint64_t r = 0; r < n; r++) {
+                while (e < c->h_exc_read.size() && c->h_exc_read[e] < r) e++;
+                if (e < c->h_exc_read.size() && c->h_exc_read[e] == r) continue;
+                surv_idx[w++] = r;
+            }
+            surv_idx.resize(w);
+            n_surv = w;
+            if (n_surv) HIPCHK(c, hipMemcpyAsync(c->d_idx.p, surv_idx.data(), n_surv * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        s = run_survivors(c, false, n_surv, c->cand, surv_idx.data());
+        if (s) return s;
+    }
     if (c->R.n_exc) {
         crass_hip_ctx::P1List el;
         s = run_survivors(c, true, c->R.n_exc, el, nullptr);
@@ -507,7 +584,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     }
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const size_t total = c->cand.size();
+    const size_t total = (size_t)c->n_cand();
     c->have_pass1 = true;
     c->cnt.ms_sink_host = (float)(now_ms() - t_sink0);     // includes the survivor kernel + D2H it waits for
     c->cnt.n_filter_survivors = n_surv + c->R.n_exc;
@@ -526,10 +603,16 @@ int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     if (!c->have_pass1) return CRASS_ERR_STATE;
-    o->n = c->cand.size();
-    o->read_idx = c->cand.read.data(); o->low_lexi = c->cand.low.data(); o->repeat_len = c->cand.replen.data();
-    o->n_ss = c->cand.nss.data(); o->ss_off = c->cand.ss_off.data(); o->ss_pool = c->cand.ss.data();
-    o->dr_stride = c->dr_stride; o->dr_len = c->cand.dr_len.data(); o->dr_chars = c->cand.dr.data();
+    if (c->dense.active) {
+        const crass_hip_ctx::P1Dense &D = c->dense;
+        o->n = D.n; o->read_idx = D.h_read.p; o->low_lexi = D.h_low.p; o->repeat_len = D.h_replen.p; o->n_ss = D.h_nss.p;
+        o->ss_off = D.h_ss_off.p; o->ss_pool = D.h_ss.p; o->dr_stride = c->dr_stride; o->dr_len = D.h_dr_len.p; o->dr_chars = D.h_dr.p;
+    } else {
+        o->n = c->cand.size();
+        o->read_idx = c->cand.read.data(); o->low_lexi = c->cand.low.data(); o->repeat_len = c->cand.replen.data();
+        o->n_ss = c->cand.nss.data(); o->ss_off = c->cand.ss_off.data(); o->ss_pool = c->cand.ss.data();
+        o->dr_stride = c->dr_stride; o->dr_len = c->cand.dr_len.data(); o->dr_chars = c->cand.dr.data();
+    }
     o->max_read_len = c->max_len;
     return CRASS_OK;
 }
@@ -606,7 +689,7 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
     const double t0 = now_ms();
     if (!dr_chars) {
         if (!c->have_pass1) return CRASS_ERR_STATE;
-        dr_chars = c->cand.dr.data(); dr_len = c->cand.dr_len.data(); dr_stride = c->dr_stride; n = c->cand.size();
+        dr_chars = c->cand_dr(); dr_len = c->cand_dr_len(); dr_stride = c->dr_stride; n = c->n_cand();
     } else if (!dr_len || !dr_stride) return CRASS_ERR_INVALID_ARG;
     merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n, c->prm.kmer_clust_size);
     c->have_merge = true;

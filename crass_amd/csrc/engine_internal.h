@@ -115,6 +115,11 @@ hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off,
                                     int32_t *dist, float *sim, uint32_t max_len, hipStream_t st);
 hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st);
 
+hipError_t launch_found_mask(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st);
+hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out,
+                               const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
+                               const uint32_t *ss_pool, uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
+                               uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr, uint32_t *g_ss, hipStream_t st);
 SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P);
 hipError_t upload_comp_table(const unsigned char *tab128);
 

@@ -970,6 +970,67 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
     }
 }
 
+// ---- device-side gather of the found records (fast path: short reads, slot-mode pool) ----
+// mask of slots with found != 0; the worst error code is max-reduced into *d_err
+__global__ __launch_bounds__(256) void k_found_mask(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err)
+{
+    const uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    bool f = false;
+    if (s < n) {
+        const SurvOut o = out[s];
+        f = o.found != 0;
+        if (o.err) atomicMax(d_err, (uint32_t)o.err);
+    }
+    const uint64_t m = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && s < n) mask[s >> 6] = m;
+}
+
+// dense, read-ordered arrays in the hand-off layout (one thread per found record)
+__global__ __launch_bounds__(256) void k_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max,
+                                                       const SurvOut *out, const uint64_t *surv_idx, uint64_t read_base,
+                                                       const char *dr_chars, uint32_t dr_stride, const uint32_t *ss_pool,
+                                                       uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
+                                                       uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr,
+                                                       uint32_t *g_ss)
+{
+    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t n = *d_nf;
+    if (n > n_max) n = n_max;
+    if (k >= n) return;
+    const uint64_t s = fidx[k];
+    const SurvOut o = out[s];
+    g_read[k] = read_base + surv_idx[s];
+    g_low[k] = o.low_lexi;
+    g_replen[k] = o.repeat_len;
+    g_nss[k] = o.n_ss;
+    g_ss_off[k] = k * (uint64_t)ss_cap;
+    g_dr_len[k] = o.dr_len;
+    const uint4 *src = reinterpret_cast<const uint4 *>(dr_chars + s * (uint64_t)dr_stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(g_dr + k * (uint64_t)dr_stride);
+    for (uint32_t i = 0; i < dr_stride / 16; i++) dst[i] = src[i];
+    const uint32_t *ps = ss_pool + o.ss_off;
+    uint32_t *pd = g_ss + k * (uint64_t)ss_cap;
+    for (uint32_t i = 0; i < ss_cap; i++) pd[i] = (i < o.n_ss) ? ps[i] : 0u;
+}
+
+hipError_t launch_found_mask(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_found_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, mask, d_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out,
+                               const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
+                               const uint32_t *ss_pool, uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
+                               uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr, uint32_t *g_ss, hipStream_t st)
+{
+    if (n_max == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_found, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, surv_idx,
+                       read_base, dr_chars, dr_stride, ss_pool, ss_cap, g_read, g_low, g_replen, g_nss, g_ss_off, g_dr_len, g_dr, g_ss);
+    return hipGetLastError();
+}
+
 SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P)
 {
     SurvLds l;
