@@ -168,7 +168,9 @@ class CandidateSet:
         self.repeat_len = _np(v.repeat_len, n, np.uint32)
         self.n_ss = _np(v.n_ss, n, np.uint32)
         self.ss_off = _np(v.ss_off, n, np.uint64)
-        self.ss_pool = _np(v.ss_pool, int(self.n_ss.sum()), np.uint32)
+        # the pool may be fixed-stride slots (ss_off[k] = k*cap) or tightly packed: size it from the offsets
+        pool_len = int((self.ss_off + self.n_ss).max()) if n else 0
+        self.ss_pool = _np(v.ss_pool, pool_len, np.uint32)
         self.dr_stride = int(v.dr_stride)
         self.dr_len = _np(v.dr_len, n, np.uint16)
         self.dr_chars = _np(C.cast(v.dr_chars, _abi.u8p), n * self.dr_stride, np.uint8)
@@ -413,7 +415,7 @@ class PipelineResult:
         rec_ss = np.stack([rec.start, rec.end], axis=1).reshape(-1) if rec.n else np.zeros(0, np.uint32)
         self.ss_pool = np.concatenate([cand.ss_pool, rec_ss]).astype(np.uint32)
         off1 = cand.ss_off
-        base = int(cand.n_ss.sum())
+        base = len(cand.ss_pool)
         off2 = base + 2 * np.arange(rec.n, dtype=np.uint64)
         self.rec_ss_off = np.concatenate([off1, off2]).astype(np.uint64)
         self.tokens, self.groups, self.patterns, self.pat_group = merge.tokens, merge.groups, merge.patterns, merge.pat_group
