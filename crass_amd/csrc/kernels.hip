@@ -609,40 +609,53 @@ static __device__ float wave_similarity(const uint8_t *s1, int n, const uint8_t 
 // longer one may hold any byte: it simply matches nothing); returns -1 otherwise and the caller
 // falls back to the wavefront version.  Checked against the oracle / compiled reference in
 // tests (levenshtein batch + every QC decision of the parity suites).
+template <typename WORD>
+static __device__ __forceinline__ int lane_lev_bp_core(const uint8_t *s, int n, const uint8_t *t, int m)
+{
+    // straight-line selects only (masks of 0 / ~0): a per-character if-ladder compiles to a chain of
+    // exec-mask branches that dominates the loop
+    WORD pA = 0, pC = 0, pG = 0, pT = 0;
+    uint32_t bad = 0;
+    for (int i = 0; i < n; i++) {
+        const uint32_t c = s[i];
+        const WORD b = (WORD)1 << i;
+        const WORD mA = (WORD)0 - (WORD)(c == 'A'), mC = (WORD)0 - (WORD)(c == 'C');
+        const WORD mG = (WORD)0 - (WORD)(c == 'G'), mT = (WORD)0 - (WORD)(c == 'T');
+        pA |= b & mA; pC |= b & mC; pG |= b & mG; pT |= b & mT;
+        bad |= (uint32_t)((mA | mC | mG | mT) == 0);
+    }
+    WORD VP = ~(WORD)0, VN = 0, D0 = 0, PMold = 0;
+    int dist = n;
+    const int topbit = n - 1;
+    for (int j = 0; j < m; j++) {
+        const uint32_t c = t[j];
+        const WORD mA = (WORD)0 - (WORD)(c == 'A'), mC = (WORD)0 - (WORD)(c == 'C');
+        const WORD mG = (WORD)0 - (WORD)(c == 'G'), mT = (WORD)0 - (WORD)(c == 'T');
+        const WORD PMj = (pA & mA) | (pC & mC) | (pG & mG) | (pT & mT);
+        WORD TR = (WORD)((((WORD)~D0) & PMj) << 1) & PMold & ~(WORD)3;
+        TR &= (WORD)0 - (WORD)(j >= 2);
+        D0 = (WORD)((WORD)((WORD)(PMj & VP) + VP) ^ VP) | PMj | VN;
+        D0 |= TR;
+        WORD HP = VN | (WORD)~(D0 | VP);
+        WORD HN = D0 & VP;
+        dist += (int)((HP >> topbit) & 1) - (int)((HN >> topbit) & 1);
+        HP = (WORD)(HP << 1) | (WORD)1;
+        HN = (WORD)(HN << 1);
+        VP = HN | (WORD)~(D0 | HP);
+        VN = HP & D0;
+        PMold = PMj;
+    }
+    return bad ? -1 : dist;
+}
+
 static __device__ int lane_lev_bp(const uint8_t *s, int n, const uint8_t *t, int m)
 {
     if (n == 0) return m;
     if (m == 0) return n;
     if (n > m) { const uint8_t *x = s; s = t; t = x; int y = n; n = m; m = y; }
     if (n > 64) return -1;
-    uint64_t pA = 0, pC = 0, pG = 0, pT = 0;
-    for (int i = 0; i < n; i++) {
-        const uint8_t c = s[i];
-        const uint64_t b = 1ull << i;
-        if (c == 'A') pA |= b; else if (c == 'C') pC |= b; else if (c == 'G') pG |= b; else if (c == 'T') pT |= b;
-        else return -1;
-    }
-    uint64_t VP = ~0ull, VN = 0, D0 = 0, PMold = 0;
-    int dist = n;
-    const uint64_t top = 1ull << (n - 1);
-    for (int j = 0; j < m; j++) {
-        const uint8_t c = t[j];
-        const uint64_t PMj = (c == 'A') ? pA : (c == 'C') ? pC : (c == 'G') ? pG : (c == 'T') ? pT : 0ull;
-        uint64_t TR = (((~D0) & PMj) << 1) & PMold & ~3ull;
-        if (j < 2) TR = 0;
-        D0 = (((PMj & VP) + VP) ^ VP) | PMj | VN;
-        D0 |= TR;
-        uint64_t HP = VN | ~(D0 | VP);
-        uint64_t HN = D0 & VP;
-        dist += (HP & top) ? 1 : 0;
-        dist -= (HN & top) ? 1 : 0;
-        HP = (HP << 1) | 1ull;
-        HN = HN << 1;
-        VP = HN | ~(D0 | HP);
-        VN = HP & D0;
-        PMold = PMj;
-    }
-    return dist;
+    // one 32-bit column word when the shorter string fits: half the VALU work of the 64-bit form
+    return (n <= 32) ? lane_lev_bp_core<uint32_t>(s, n, t, m) : lane_lev_bp_core<uint64_t>(s, n, t, m);
 }
 
 // getStringSimilarity for one pair per lane; *fallback set when the bit-parallel form does not apply
@@ -668,7 +681,7 @@ static __device__ __forceinline__ bool substr_len(int L, uint32_t pos, uint32_t 
 
 // qcFoundRepeats, libcrispr.cpp:869-1029.  1 pass / 0 fail / -1 reference would throw.
 // Internal spacer i (getAllSpacerStrings, ReadHolder.cpp:199-239) = seq[ss[2i+1]+1, ss[2i+2]).
-static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacerLength, int lane)
+static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacerLength, int lane, uint32_t dbg = 0)
 {
     const int num_repeats = h.nss / 2;
     if (num_repeats < 2) return -1;
@@ -701,11 +714,11 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
             if (__ballot(valid && bad)) return -1;
             bool fb = false;
             float sim = 0.0f;
-            if (valid) {
+            if (valid && dbg != 5) {
                 if (q & 1) sim = lane_similarity(h.seq + a_start, (int)a_len, h.seq + b_start, (int)b_len, fb);
                 else sim = lane_similarity(repeat, (int)rep_len, h.seq + a_start, (int)a_len, fb);
-                h.sims[q] = sim;
             }
+            if (valid) h.sims[q] = sim;
             uint64_t fbmask = __ballot(valid && fb);
             while (fbmask) {                              // rare: > 64-long or non-ACGT shorter string
                 const int src = __ffsll((unsigned long long)fbmask) - 1;
@@ -762,7 +775,7 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
         if ((int)sp_len < minSpacerLength) return 0;
         if ((int)sp_len > maxSpacerLength) return 0;
         bool fb = false;
-        float similarity = lane_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, fb);     // same pair in every lane
+        float similarity = (dbg == 5) ? 0.0f : lane_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, fb);     // same pair in every lane
         if (fb) similarity = wave_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, h.rowA, h.rowB, lane);
         if ((double)similarity > 0.82) return 0;
         int dlen = (int)sp_len - (int)rep_len;
@@ -807,7 +820,7 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
         if ((uint32_t)(h.nss / 2) >= o.minRepeats) {
             uint32_t actual_repeat_length = extend_pre_repeat(h, (int)o.window, (int)o.lowSp, lane);
             if (o.debug_stop != 3 && (actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {
-                int qc = qc_found_repeats(h, (int)o.lowSp, (int)o.highSp, lane);
+                int qc = qc_found_repeats(h, (int)o.lowSp, (int)o.highSp, lane, o.debug_stop);
                 if (qc < 0) return -1;
                 if (qc) return 1;
             }
@@ -944,7 +957,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
         if (f < 0) o.err = (f == -2) ? 2 : 1;
-        if (f == 1) {
+        if (f == 1 && P.debug_stop != 4) {
             int low = 0;
             int dlen = dr_low_lexi(h, dr_chars + s * (uint64_t)dr_stride, low, lane);
             if (dlen < 0 || dlen > (int)dr_stride) o.err = 1;
