@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--gc-classes", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads timed on the CPU baseline (0 = skip)")
     ap.add_argument("--check", action="store_true", help="also verify the GPU result against the oracle on the CPU sample")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for single-GPU dry runs)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -63,12 +65,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
+    coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
     L, n = args.read_len, args.reads
     W = (L + 15) // 16
@@ -86,7 +94,7 @@ def main():
         if world > 1:
             from crass_amd.distributed import allgather_candidates
             chars, lens = eng.candidate_dr_view()
-            g_chars, g_lens = allgather_candidates(chars, lens, dist, torch.device("cuda", local_rank))
+            g_chars, g_lens = allgather_candidates(chars, lens, dist, coll_dev)
             eng.merge(g_chars, g_lens, fetch=False)
         else:
             eng.merge(fetch=False)
@@ -110,10 +118,15 @@ def main():
             kern[k].append(c[k])
     sync()
     dt = time.perf_counter() - t0
+    tot_p1, tot_p2 = None, None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        cc = eng.counters()
+        tot = torch.tensor([cc["n_pass1_found"], cc["n_pass2_found"]], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        tot_p1, tot_p2 = int(tot[0].item()), int(tot[1].item())
     c = eng.counters()
     ms_per_step = dt * 1e3 / args.steps
     value = world * n * args.steps / dt
@@ -128,10 +141,28 @@ def main():
     else:
         alg_bytes = n * bytes_per_read_per_pass
     achieved = alg_bytes / (cands[dom] * 1e-3) / 1e9 if cands[dom] > 0 else 0.0
+    # per-kernel view (the two streaming kernels touch every read; the survivor kernel only the ~2 % that
+    # survive the filter, so its algorithmic bytes are tiny and it is latency/issue bound by nature)
+    per_kernel = {}
+    for name, ms, units in (("seed_scan_filter", avg["ms_filter"], n), ("survivor", avg["ms_survivor"], c["n_filter_survivors"]),
+                            ("recruit_scan", avg["ms_recruit"], n)):
+        b = units * bytes_per_read_per_pass
+        gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        per_kernel[name] = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes": int(b), "achieved_GBps": round(gbs, 1),
+                            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
+    traffic = None
+    try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/summarize_pmc.py)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["per_launch"]
+        key = {"seed_scan_filter": "k_filter_fast_impl", "survivor": "k_survivor", "recruit_scan": "k_anchor_filter"}[dom]
+        for k, v in pm.items():
+            if k.startswith(key) and n == 10_000_000 and L == 150:
+                traffic = v["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(cands[dom], 4),
-                "kernels_ms": {k: round(v, 4) for k, v in avg.items()}}
+                "per_kernel": per_kernel, "host_ms": {"merge": round(avg["ms_merge_host"], 3), "sink": round(avg["ms_sink_host"], 3)}}
 
     out = {
         "metric": "reads/sec through DR search+recruit, 150bp synthetic, 1/2/4/8 MI355X",
@@ -141,7 +172,8 @@ def main():
         "config": {"workload": "%d synthetic %d bp reads per GPU, %d seeded DRs, 1%% CRISPR reads "
                                "(BASELINE.json configs[1]); pass1 + merge + pass2" % (n, L, args.n_dr),
                    "reads_per_gpu": n, "read_len": L, "n_dr": args.n_dr, "parallelism": "read-shards x%d" % world,
-                   "pass1_found": int(c["n_pass1_found"]), "pass2_found": int(c["n_pass2_found"]),
+                   "pass1_found": int(c["n_pass1_found"]) if tot_p1 is None else tot_p1,
+                   "pass2_found": int(c["n_pass2_found"]) if tot_p2 is None else tot_p2,
                    "patterns": int(c["n_patterns"]), "ac_states": int(c["ac_states"]),
                    "filter_survivors": int(c["n_filter_survivors"]),
                    "fast_filter": int(c["used_fast_filter"]), "lds_automaton": int(c["used_lds_automaton"]),

@@ -206,3 +206,45 @@ def test_filter_is_superset_of_lattice_hits(ca):
     gpu = ca.search_pipeline(seqs)
     assert gpu.counters["n_filter_survivors"] >= n_hit
     assert gpu.counters["n_filter_survivors"] < n_hit * 1.5 + 100
+
+
+def test_config5_shape_many_drs_gc_classes(ca):
+    """config 5 shape at test size: 500 seeded DRs, 4 GC-content classes (high-diversity background)."""
+    seqs = synth_reads(ca, 150000, read_len=150, n_dr=500, gc_classes=4, crispr_per_million=40000)
+    gpu = ca.search_pipeline(seqs)
+    ref = orc.pipeline(seqs)
+    assert_same_pipeline(gpu, ref)
+    assert gpu.n_groups > 300 and gpu.n_patterns > 1000
+
+
+def test_full_size_properties(ca):
+    """BASELINE configs[1] size (10 M reads) through size-independent properties: determinism across two
+    runs, record order, every recruited read absent from pass 1, tokens within range, and an exact
+    oracle comparison on a 300 k-read prefix processed separately."""
+    n, L = 10_000_000, 150
+    spec = ca.synth_spec(read_len=L)
+    words = ca.synth_packed(spec, 0, n)
+    with ca.SearchEngine() as eng:
+        eng.load_packed_uniform(words, n, L)
+        c1 = eng.seed_scan(); m1 = eng.merge(); r1 = eng.recruit()
+        c2 = eng.seed_scan(); m2 = eng.merge(); r2 = eng.recruit()
+    for a, b in ((c1.read_idx, c2.read_idx), (c1.ss_pool, c2.ss_pool), (c1.dr_chars, c2.dr_chars), (r1.read_idx, r2.read_idx),
+                 (r1.start, r2.start), (r1.token, r2.token), (m1.cand_token, m2.cand_token)):
+        assert np.array_equal(a, b)
+    assert m1.patterns == m2.patterns and m1.groups == m2.groups
+    assert np.all(np.diff(c1.read_idx.astype(np.int64)) > 0) and np.all(np.diff(r1.read_idx.astype(np.int64)) > 0)
+    assert len(np.intersect1d(c1.read_idx, r1.read_idx)) == 0
+    assert r1.token.min() >= 2 and r1.token.max() <= m1.n_tokens + 1
+    assert np.all(r1.end - r1.start + 1 == r1.dr_len)
+    # every recruit's DR is the token's string
+    for k in range(0, r1.n, 997):
+        assert r1.dr(k) == m1.tokens[int(r1.token[k]) - 2]
+    # prefix vs oracle
+    m = 300000
+    asc = ca.unpack_ascii(words, 10, L, m)
+    seqs = [asc[i * L:(i + 1) * L].tobytes() for i in range(m)]
+    assert_same_pipeline(ca.search_pipeline(seqs), orc.pipeline(seqs))
+    # pass-1 decisions are per read: the prefix of the big run equals the small run
+    k = int(np.searchsorted(c1.read_idx, m))
+    small = ca.search_pipeline(seqs, do_pass2=False)
+    assert np.array_equal(c1.read_idx[:k], small.rec_read[:small.n_pass1])
