@@ -836,7 +836,7 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
 // ReadHolder::DRLowLexi + reverseStartStops (ReadHolder.cpp:513-591, 321-380).  Writes the
 // low-lexi DR to dr_out (global), mirrors ss in LDS if the read is flipped; returns dr length
 // (<0 error) and the RH_WasLowLexi flag.
-static __device__ int dr_low_lexi(RH &h, char *dr_out, int &was_low_lexi, int lane)
+static __device__ int dr_low_lexi(RH &h, char *dr_out, int dr_stride, int &was_low_lexi, int lane)
 {
     const int num_repeats = h.nss / 2;
     int pick;
@@ -868,10 +868,10 @@ static __device__ int dr_low_lexi(RH &h, char *dr_out, int &was_low_lexi, int la
         }
     }
     if (less) {
-        for (int i = lane; i < (int)dlen; i += WAVE) dr_out[i] = (char)dr[i];
+        for (int i = lane; i < dr_stride; i += WAVE) dr_out[i] = (i < (int)dlen) ? (char)dr[i] : (char)0;   // zero padding: slots are bit-reproducible
         was_low_lexi = 1;
     } else {
-        for (int i = lane; i < (int)dlen; i += WAVE) dr_out[i] = (char)c_comp[dr[dlen - 1 - i] & 127];
+        for (int i = lane; i < dr_stride; i += WAVE) dr_out[i] = (i < (int)dlen) ? (char)c_comp[dr[dlen - 1 - i] & 127] : (char)0;
         // reverseStartStops: new[k] = L-1 - ss[nss-1-k]
         wave_sync();
         for (int k0 = 0; k0 < h.nss; k0 += WAVE) {       // read everything of a chunk pair-wise before writing
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
         if (f < 0) o.err = (f == -2) ? 2 : 1;
         if (f == 1 && P.debug_stop != 4) {
             int low = 0;
-            int dlen = dr_low_lexi(h, dr_chars + s * (uint64_t)dr_stride, low, lane);
+            int dlen = dr_low_lexi(h, dr_chars + s * (uint64_t)dr_stride, (int)dr_stride, low, lane);
             if (dlen < 0 || dlen > (int)dr_stride) o.err = 1;
             else {
                 // start/stop pool: a fixed slot per survivor when the pool is large enough (short reads),
@@ -1409,6 +1409,7 @@ __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64
         for (uint32_t i = 0; i < len; i++) dr[i] = (char)c_comp[base_at(start + len - 1 - i) & 127];
         o.start = L - 1 - DR_end; o.end = L - 1 - start; o.low_lexi = 0;
     }
+    for (uint32_t i = len; i < dr_stride; i++) dr[i] = 0;
     o.dr_len = (uint16_t)len;
     // the matched pattern's low-lexi form is a stored DR variant: its token was resolved once per
     // pattern on the host (addReadHolder's lookup, libcrispr.cpp:1137)
