@@ -456,9 +456,17 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
     HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 8, c->stream));            // [2] = found count, [3] = worst error
     HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+    // lane-per-read kernel for uniform short reads; whatever it punts (err == 4) and every other
+    // layout goes through the wave-per-read kernel
+    const uint32_t *hints = c->hints_valid ? c->d_hit_info.p : nullptr;
+    const bool no_lanes = getenv("CRASS_NO_LANE_KERNEL") != nullptr;
+    hipError_t le = no_lanes ? hipErrorNotSupported
+                             : launch_survivor_lanes(c->R, c->dp, c->d_idx.p, c->d_count.p + 1, n_surv, c->d_surv.p, c->d_dr.p, stride,
+                                                     c->d_ss_pool.p, lds.ss_cap, c->d_found.p, hints, c->stream);
+    if (le != hipSuccess && le != hipErrorNotSupported) { c->last_hip = (int)le; return CRASS_ERR_HIP; }
     HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, c->d_count.p + 1, n_surv, c->d_surv.p, c->d_dr.p, stride,
-                              c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p,
-                              c->hints_valid ? c->d_hit_info.p : nullptr, lds, (int)std::min<uint64_t>(256 * 32, n_surv), c->stream));
+                              c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, hints, lds,
+                              (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, le == hipSuccess));
     HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
     const uint64_t n_words = (n_surv + 63) / 64;
     HIPCHK(c, launch_found_mask(c->d_surv.p, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream));

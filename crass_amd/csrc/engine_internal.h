@@ -38,7 +38,8 @@ struct SurvOut {
     uint32_t ss_off;              // offset into the ss pool
     uint16_t dr_len;
     uint8_t  low_lexi;
-    uint8_t  err;                 // 1: reference would throw, 2: start/stop capacity, 3: pool overflow
+    uint8_t  err;                 // 1: reference would throw, 2: start/stop capacity, 3: pool overflow,
+                                  // 4: punted by the lane-per-read kernel to the wave-per-read kernel
 };
 
 // per-hit output of the pass-2 finish kernel
@@ -95,7 +96,11 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            const uint64_t *surv_idx, const uint32_t *d_n_surv, uint64_t n_surv_max,
                            SurvOut *out, char *dr_chars, uint32_t dr_stride,
                            uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
-                           uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st);
+                           uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
+                           bool punt_only = false);
+hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
+                                 uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
+                                 uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st);
 hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
                                   uint64_t *hitmask, uint32_t *hit_info, hipStream_t st);
 hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,

@@ -920,7 +920,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
                                                    const uint32_t *d_n_surv, uint64_t n_max, SurvOut *out,
                                                    char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                                    uint32_t ss_pool_cap, uint32_t *d_ss_used,
-                                                   uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds)
+                                                   uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds, int punt_only)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sv_lds[];
     const int lane = threadIdx.x;
@@ -939,6 +939,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
     for (uint64_t s = blockIdx.x; s < n_surv; s += gridDim.x) {
         uint64_t r;
         int L;
+        if (punt_only && out[s].err != 4) continue;     // only the reads the lane kernel handed over
         wave_sync();
         if (EXC) {
             r = R.exc_read[s];
@@ -981,6 +982,374 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
         }
         if (lane == 0) out[s] = o;
     }
+}
+
+
+// ------------------------------------------------------------------------------------
+// pass 1, step 2 (fast path): the same searchCore, one read per LANE.
+//
+// The wave-per-read kernel above spends most of its issue slots with one or two useful lanes
+// (a serial DP, a serial column vote).  For short packed reads every lane can instead run the
+// complete reference control flow for its own read: 64 reads advance together and loops of
+// different length simply mask lanes off.  Per-lane state lives in LDS, word-/entry-interleaved
+// across lanes ([index][lane]) so that lanes working at the same index hit different banks.
+// Anything unusual (string pair with both lengths > 64, start/stop list overflow) is PUNTED
+// (err = 4) to the wave-per-read kernel, which re-runs that read from scratch.
+// Semantics are line-for-line those of search_core()/oracle; the parity suites cover both.
+// ------------------------------------------------------------------------------------
+struct LaneRead {
+    const uint32_t *w;      // LDS: word i of this lane's read at w[i * 64]
+    uint16_t *ss;           // LDS: start/stop entry k at ss[k * 64]
+    int L, nss, cap, replen;
+    uint32_t cmask;
+    int punt;
+};
+
+static __device__ __forceinline__ uint32_t ln_word(const LaneRead &h, int i) { return h.w[i * WAVE]; }
+static __device__ __forceinline__ uint32_t ln_base(const LaneRead &h, int p) { return (ln_word(h, p >> 4) >> ((p & 15) * 2)) & 3u; }
+static __device__ __forceinline__ uint32_t ln_code(const LaneRead &h, int p)
+{
+    const int wi = p >> 4, sh = (p & 15) * 2;
+    const uint64_t v = ((uint64_t)ln_word(h, wi + 1) << 32) | ln_word(h, wi);
+    return (uint32_t)(v >> sh) & h.cmask;
+}
+static __device__ __forceinline__ uint32_t ln_ss(const LaneRead &h, int k) { return h.ss[k * WAVE]; }
+static __device__ __forceinline__ void ln_ss_set(LaneRead &h, int k, uint32_t v) { h.ss[k * WAVE] = (uint16_t)v; }
+
+// bmpSearch semantics (PatternMatcher.cpp:26-59) for the w-mer at `pat` in [begin, end)
+static __device__ int ln_find(const LaneRead &h, int begin, int end, int pat, int plen)
+{
+    if (end - begin <= 0 || plen <= 0 || plen > end - begin) return -1;
+    const uint32_t sj = ln_code(h, pat);
+    for (int p = begin; p + plen <= end; p++)
+        if (ln_code(h, p) == sj) return p;
+    return -1;
+}
+
+static __device__ void ln_add(LaneRead &h, uint32_t i, uint32_t j)          // startStopsAdd, ReadHolder.cpp:263-297
+{
+    if (h.nss + 2 > h.cap) { h.punt = 1; return; }
+    if (j >= (uint32_t)h.L) j = (uint32_t)h.L - 1;
+    ln_ss_set(h, h.nss, i); ln_ss_set(h, h.nss + 1, j);
+    h.nss += 2;
+}
+
+static __device__ void ln_scan_right(LaneRead &h, int pat, uint32_t pattern_length, uint32_t minSpacerLength, uint32_t scanRange)
+{   // scanRight, libcrispr.cpp:170-263
+    uint32_t last_repeat_index = ln_ss(h, h.nss - 2);
+    uint32_t second_last_repeat_index = ln_ss(h, h.nss - 4);
+    uint32_t repeat_spacing = last_repeat_index - second_last_repeat_index;
+    const uint32_t read_length = (uint32_t)h.L;
+    for (;;) {
+        int candidate_repeat_index = (int)(last_repeat_index + repeat_spacing);
+        uint32_t begin_search = (uint32_t)candidate_repeat_index - scanRange;
+        uint32_t end_search = (uint32_t)candidate_repeat_index + pattern_length + scanRange;
+        uint32_t scanRightMinBegin = last_repeat_index + pattern_length + minSpacerLength;
+        if (begin_search < scanRightMinBegin) begin_search = scanRightMinBegin;
+        if (begin_search > read_length - 1) return;
+        if (end_search > read_length) end_search = read_length;
+        if (begin_search >= end_search) return;
+        int position = ln_find(h, (int)begin_search, (int)end_search, pat, (int)pattern_length);
+        if (position < 0) return;
+        ln_add(h, (uint32_t)position, (uint32_t)position + pattern_length - 1);
+        if (h.punt) return;
+        second_last_repeat_index = last_repeat_index;
+        last_repeat_index = (uint32_t)position;
+        repeat_spacing = last_repeat_index - second_last_repeat_index;
+        if (repeat_spacing < (minSpacerLength + pattern_length)) return;
+    }
+}
+
+static __device__ uint32_t ln_extend(LaneRead &h, int searchWindowLength, int minSpacerLength)
+{   // extendPreRepeat, libcrispr.cpp:520-772 (serial columns, like the reference)
+    const uint32_t num_repeats = (uint32_t)h.nss / 2;
+    h.replen = searchWindowLength;
+    int cut_off = (int)(num_repeats - 1);
+    if (2 > cut_off) cut_off = 2;
+    const uint32_t first_repeat_start_index = ln_ss(h, 0);
+    const uint32_t last_repeat_start_index = ln_ss(h, h.nss - 2);
+    const uint32_t end_index = (uint32_t)h.nss;
+    const uint32_t seqlen = (uint32_t)h.L;
+    uint32_t shortest_repeat_spacing = (uint32_t)((int)ln_ss(h, 2) - (int)ln_ss(h, 0));
+    for (uint32_t i = 4; i < end_index; i += 2) {
+        uint32_t sp = (uint32_t)((int)ln_ss(h, i) - (int)ln_ss(h, i - 2));
+        if (sp < shortest_repeat_spacing) shortest_repeat_spacing = sp;
+    }
+    uint32_t right_extension_length = 0;
+    uint32_t max_right_extension_length = shortest_repeat_spacing - (uint32_t)minSpacerLength;
+    int DR_index_end = (int)end_index;
+    while (max_right_extension_length > 0) {
+        if ((last_repeat_start_index + (uint32_t)searchWindowLength + right_extension_length) >= seqlen) DR_index_end -= 2;
+        int cnt[4] = {0, 0, 0, 0};
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int k = 0; k < DR_index_end; k += 2) {
+            const uint32_t pos = ln_ss(h, k) + (uint32_t)h.replen;
+            if (pos >= seqlen) break;
+            const uint32_t b = ln_base(h, (int)pos);
+            c0 += (b == 0); c1 += (b == 1); c2 += (b == 2); c3 += (b == 3);
+        }
+        (void)cnt;
+        if ((c0 >= cut_off) || (c1 >= cut_off) || (c2 >= cut_off) || (c3 >= cut_off)) {
+            h.replen++; max_right_extension_length--; right_extension_length++;
+        } else break;
+    }
+    uint32_t left_extension_length = 0;
+    const int test_for_negative = (int)(shortest_repeat_spacing - (uint32_t)h.replen);
+    const uint32_t max_left_extension_length = (test_for_negative >= 0) ? (uint32_t)test_for_negative : 0;
+    uint32_t DR_index_start = 0;
+    while (left_extension_length < max_left_extension_length) {
+        if ((int)first_repeat_start_index - (int)left_extension_length <= 0) DR_index_start += 2;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (uint32_t k = DR_index_start; k < end_index; k += 2) {
+            const int idx = (int)(ln_ss(h, (int)k) - left_extension_length - 1);
+            if (idx < 0 || idx >= h.L) continue;
+            const uint32_t b = ln_base(h, idx);
+            c0 += (b == 0); c1 += (b == 1); c2 += (b == 2); c3 += (b == 3);
+        }
+        if ((c0 >= cut_off) || (c1 >= cut_off) || (c2 >= cut_off) || (c3 >= cut_off)) {
+            h.replen++; left_extension_length++;
+        } else break;
+    }
+    for (int r = 0; r + 1 < h.nss; r += 2) {
+        uint32_t a = ln_ss(h, r), b = ln_ss(h, r + 1);
+        a = (a < left_extension_length) ? 0 : a - left_extension_length;
+        b = (b + right_extension_length >= seqlen) ? seqlen - 1 : b + right_extension_length;
+        ln_ss_set(h, r, a); ln_ss_set(h, r + 1, b);
+    }
+    return (uint32_t)h.replen;
+}
+
+// bit-parallel distance between read[s0, s0+n) and read[t0, t0+m) on 2-bit codes (see lane_lev_bp)
+template <typename WORD>
+static __device__ __forceinline__ int ln_lev_core(const LaneRead &h, int s0, int n, int t0, int m)
+{
+    WORD pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0;
+    for (int i = 0; i < n; i++) {
+        const uint32_t c = ln_base(h, s0 + i);
+        const WORD b = (WORD)1 << i;
+        pm0 |= b & ((WORD)0 - (WORD)(c == 0)); pm1 |= b & ((WORD)0 - (WORD)(c == 1));
+        pm2 |= b & ((WORD)0 - (WORD)(c == 2)); pm3 |= b & ((WORD)0 - (WORD)(c == 3));
+    }
+    WORD VP = ~(WORD)0, VN = 0, D0 = 0, PMold = 0;
+    int dist = n;
+    const int topbit = n - 1;
+    for (int j = 0; j < m; j++) {
+        const uint32_t c = ln_base(h, t0 + j);
+        const WORD PMj = (pm0 & ((WORD)0 - (WORD)(c == 0))) | (pm1 & ((WORD)0 - (WORD)(c == 1))) |
+                         (pm2 & ((WORD)0 - (WORD)(c == 2))) | (pm3 & ((WORD)0 - (WORD)(c == 3)));
+        WORD TR = (WORD)((((WORD)~D0) & PMj) << 1) & PMold & ~(WORD)3;
+        TR &= (WORD)0 - (WORD)(j >= 2);
+        D0 = (WORD)((WORD)((WORD)(PMj & VP) + VP) ^ VP) | PMj | VN;
+        D0 |= TR;
+        WORD HP = VN | (WORD)~(D0 | VP);
+        WORD HN = D0 & VP;
+        dist += (int)((HP >> topbit) & 1) - (int)((HN >> topbit) & 1);
+        HP = (WORD)(HP << 1) | (WORD)1;
+        HN = (WORD)(HN << 1);
+        VP = HN | (WORD)~(D0 | HP);
+        VN = HP & D0;
+        PMold = PMj;
+    }
+    return dist;
+}
+
+// getStringSimilarity (PatternMatcher.cpp:197-204); sets h.punt when the pair needs the wavefront DP
+static __device__ float ln_similarity(LaneRead &h, int s0, int n, int t0, int m)
+{
+    float max_length = (float)(n > m ? n : m);
+    if (n < 3 || m < 3) return 0.0f;
+    if (n > m) { int x = s0; s0 = t0; t0 = x; x = n; n = m; m = x; }
+    if (n > 64) { h.punt = 1; return 0.0f; }
+    int d = (n <= 32) ? ln_lev_core<uint32_t>(h, s0, n, t0, m) : ln_lev_core<uint64_t>(h, s0, n, t0, m);
+    float edit_distance = (float)d;
+    return (float)(1.0 - (double)(edit_distance / max_length));
+}
+
+static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLength)
+{   // qcFoundRepeats, libcrispr.cpp:869-1029
+    const int num_repeats = h.nss / 2;
+    if (num_repeats < 2) return -1;
+    uint32_t rep_len;
+    const uint32_t rep_start = ln_ss(h, 0);
+    if (!substr_len(h.L, rep_start, ln_ss(h, 1) - rep_start + 1, rep_len)) return -1;
+    {   // isRepeatLowComplexity (:1031-1069); packed reads hold A/C/G/T only
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (uint32_t i = 0; i < rep_len; i++) { const uint32_t b = ln_base(h, (int)(rep_start + i)); c0 += (b == 0); c1 += (b == 1); c2 += (b == 2); c3 += (b == 3); }
+        const int cut_off = (int)((double)(int)rep_len * 0.75);
+        if (c0 > cut_off || c3 > cut_off || c2 > cut_off || c1 > cut_off) return 0;
+    }
+    bool is_short = (2 > (num_repeats - 1));
+    if (!is_short) {
+        float ave_spacer_to_spacer_len_difference = 0.0f, ave_repeat_to_spacer_len_difference = 0.0f;
+        float ave_spacer_to_spacer_difference = 0.0f, ave_repeat_to_spacer_difference = 0.0f;
+        int min_spacer_length = 10000000, max_spacer_length = 0, num_compared = 0;
+        const int nsp = num_repeats - 1;
+        uint32_t cur_start = ln_ss(h, 1) + 1, cur_len;
+        if (!substr_len(h.L, cur_start, ln_ss(h, 2) - cur_start, cur_len)) return -1;
+        for (int i = 0; i < nsp; i++) {
+            if ((int)cur_len < min_spacer_length) min_spacer_length = (int)cur_len;
+            if ((int)cur_len > max_spacer_length) max_spacer_length = (int)cur_len;
+            if (i + 1 < nsp) {
+                uint32_t nxt_start = ln_ss(h, 2 * i + 3) + 1, nxt_len;
+                if (!substr_len(h.L, nxt_start, ln_ss(h, 2 * i + 4) - nxt_start, nxt_len)) return -1;
+                num_compared++;
+                ave_repeat_to_spacer_difference += ln_similarity(h, (int)rep_start, (int)rep_len, (int)cur_start, (int)cur_len);
+                float ss_diff = 0;
+                ss_diff += ln_similarity(h, (int)cur_start, (int)cur_len, (int)nxt_start, (int)nxt_len);
+                ave_spacer_to_spacer_difference += ss_diff;
+                ave_spacer_to_spacer_len_difference += ((float)cur_len - (float)nxt_len);
+                ave_repeat_to_spacer_len_difference += ((float)rep_len - (float)cur_len);
+                cur_start = nxt_start; cur_len = nxt_len;
+                if (h.punt) return 0;
+            }
+        }
+        ave_spacer_to_spacer_difference /= (float)num_compared;
+        ave_repeat_to_spacer_difference /= (float)num_compared;
+        ave_spacer_to_spacer_len_difference /= (float)num_compared;
+        ave_spacer_to_spacer_len_difference = fabsf(ave_spacer_to_spacer_len_difference);
+        ave_repeat_to_spacer_len_difference /= (float)num_compared;
+        ave_repeat_to_spacer_len_difference = fabsf(ave_repeat_to_spacer_len_difference);
+        if (min_spacer_length < minSpacerLength) return 0;
+        if (max_spacer_length > maxSpacerLength) return 0;
+        if ((double)ave_spacer_to_spacer_difference > 0.82) return 0;
+        if ((double)ave_repeat_to_spacer_difference > 0.82) return 0;
+        if ((int)ave_spacer_to_spacer_len_difference > 12) return 0;
+        if ((int)ave_repeat_to_spacer_len_difference > 30) return 0;
+    }
+    if (is_short) {
+        uint32_t s = ln_ss(h, 1) + 1;
+        uint32_t e = ln_ss(h, 2) - 1;
+        uint32_t sp_len;
+        if (!substr_len(h.L, s, e - s, sp_len)) return -1;
+        if ((int)sp_len < minSpacerLength) return 0;
+        if ((int)sp_len > maxSpacerLength) return 0;
+        float similarity = ln_similarity(h, (int)rep_start, (int)rep_len, (int)s, (int)sp_len);
+        if (h.punt) return 0;
+        if ((double)similarity > 0.82) return 0;
+        int dlen = (int)sp_len - (int)rep_len;
+        if (dlen < 0) dlen = -dlen;
+        if (dlen > 30) return 0;
+    }
+    return 1;
+}
+
+static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t seed_hint)
+{   // searchCore, libcrispr.cpp:265-395
+    const uint32_t seq_length = (uint32_t)h.L;
+    const uint32_t skips = o.skips;
+    int searchEnd = (int)(seq_length - o.lowDR - o.lowSp - o.window - 1);
+    if (searchEnd < 0) return 0;
+    h.nss = 0;
+    bool on_lattice = true;
+    uint32_t lattice_i = 0;
+    for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
+        if (on_lattice) {
+            const uint32_t li = lattice_i++;
+            if (li < 32 && !((seed_hint >> li) & 1u)) continue;
+        }
+        uint32_t beginSearch = j + o.lowDR + o.lowSp;
+        uint32_t endSearch = j + o.highDR + o.highSp + o.window;
+        if (endSearch >= seq_length) endSearch = seq_length - 1;
+        if (endSearch < beginSearch) endSearch = beginSearch;
+        if (beginSearch > seq_length) return -1;
+        int pos = ln_find(h, (int)beginSearch, (int)endSearch, (int)j, (int)o.window);
+        if (pos >= 0) {
+            ln_add(h, j, j + o.window - 1);
+            ln_add(h, (uint32_t)pos, (uint32_t)pos + o.window - 1);
+            if (h.punt) return 0;
+            ln_scan_right(h, (int)j, o.window, o.lowSp, 24);
+            if (h.punt) return 0;
+        }
+        if ((uint32_t)(h.nss / 2) >= o.minRepeats) {
+            uint32_t actual_repeat_length = ln_extend(h, (int)o.window, (int)o.lowSp);
+            if ((actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {
+                int qc = ln_qc(h, (int)o.lowSp, (int)o.highSp);
+                if (h.punt) return 0;
+                if (qc < 0) return -1;
+                if (qc) return 1;
+            }
+            j = ln_ss(h, h.nss - 1) - 1;
+            on_lattice = false;
+        }
+        h.nss = 0;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(WAVE) void k_survivor_lanes(DevReads R, DevParams P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
+                                                         uint64_t n_max, SurvOut *out, char *dr_chars, uint32_t dr_stride,
+                                                         uint32_t *ss_pool, uint32_t ss_cap, uint8_t *found_flag,
+                                                         const uint32_t *seed_hint, uint32_t words_per_read)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sl_lds[];
+    const int lane = threadIdx.x;
+    uint64_t n_surv = *d_n_surv;
+    if (n_surv > n_max) n_surv = n_max;
+    const uint64_t s = blockIdx.x * (uint64_t)WAVE + lane;
+    uint32_t *lw = sl_lds + lane;                                      // [word][lane]
+    uint16_t *lss = reinterpret_cast<uint16_t *>(sl_lds + (size_t)(words_per_read + 2) * WAVE) + lane;   // [entry][lane]
+    if (s >= n_surv) return;
+    const uint64_t r = surv_idx[s];
+    const int L = (int)rd_len(R, r);
+    const uint32_t *g = R.packed + rd_word_off(R, r);
+    const int nw = (L + 15) >> 4;
+    for (int i = 0; i < (int)words_per_read + 2; i++) lw[i * WAVE] = (i < nw) ? g[i] : 0u;
+    LaneRead h;
+    h.w = lw; h.ss = lss; h.L = L; h.nss = 0; h.cap = (int)ss_cap; h.replen = 0; h.punt = 0;
+    h.cmask = (1u << (2 * P.window)) - 1u;
+    const uint32_t hint = seed_hint ? seed_hint[r] : 0xFFFFFFFFu;
+    int f = ln_search_core(h, P, hint);
+    SurvOut o;
+    o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
+    if (h.punt) o.err = 4;
+    else if (f < 0) o.err = 1;
+    else if (f == 1) {
+        // ReadHolder::DRLowLexi (ReadHolder.cpp:513-591): representative repeat, orientation
+        const int num_repeats = h.nss / 2;
+        int pick;
+        if (num_repeats == 1) pick = 0;
+        else if (num_repeats == 2) {
+            if (ln_ss(h, 0) == 0) pick = 2;
+            else if (ln_ss(h, h.nss - 1) == (uint32_t)L) pick = 0;
+            else pick = ((int)(ln_ss(h, 1) - ln_ss(h, 0)) > (int)(ln_ss(h, 3) - ln_ss(h, 2))) ? 0 : 2;
+        } else pick = 2;
+        uint32_t dlen = 0;
+        const uint32_t st = ln_ss(h, pick);
+        if (!substr_len(L, st, ln_ss(h, pick + 1) - st + 1, dlen) || dlen > dr_stride) o.err = 1;
+        else {
+            int less = 0;
+            for (uint32_t i = 0; i < dlen; i++) {
+                const uint32_t a = ln_base(h, (int)(st + i)), b = 3u - ln_base(h, (int)(st + dlen - 1 - i));
+                if (a != b) { less = a < b; break; }
+            }
+            char *dr = dr_chars + s * (uint64_t)dr_stride;
+            const uint32_t off = (uint32_t)s * ss_cap;
+            if (less) {
+                for (uint32_t i = 0; i < dr_stride; i++) dr[i] = (i < dlen) ? "ACGT"[ln_base(h, (int)(st + i))] : (char)0;
+                for (int k = 0; k < h.nss; k++) ss_pool[off + k] = ln_ss(h, k);
+            } else {
+                for (uint32_t i = 0; i < dr_stride; i++) dr[i] = (i < dlen) ? "ACGT"[3u - ln_base(h, (int)(st + dlen - 1 - i))] : (char)0;
+                for (int k = 0; k < h.nss; k++) ss_pool[off + k] = (uint32_t)L - 1 - ln_ss(h, h.nss - 1 - k);   // reverseStartStops
+            }
+            o.found = 1; o.n_ss = (uint32_t)h.nss; o.repeat_len = (uint32_t)h.replen; o.ss_off = off;
+            o.dr_len = (uint16_t)dlen; o.low_lexi = (uint8_t)less;
+            found_flag[rd_header_id(R, r)] = 1;
+        }
+    }
+    out[s] = o;
+}
+
+hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
+                                 uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
+                                 uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st)
+{
+    if (n_surv_max == 0) return hipSuccess;
+    if (!R.stride_words || R.stride_words > 16 || ss_cap > 64) return hipErrorNotSupported;
+    const uint32_t wpr = R.stride_words;
+    const size_t lds = (size_t)(wpr + 2) * WAVE * 4 + (size_t)ss_cap * WAVE * 2;
+    hipLaunchKernelGGL(k_survivor_lanes, dim3((unsigned)((n_surv_max + WAVE - 1) / WAVE)), dim3(WAVE), lds, st, R, P, surv_idx, d_n_surv,
+                       n_surv_max, out, dr_chars, dr_stride, ss_pool, ss_cap, found_flag, seed_hint, wpr);
+    return hipGetLastError();
 }
 
 // ---- device-side gather of the found records (fast path: short reads, slot-mode pool) ----
@@ -1059,7 +1428,8 @@ SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P)
 hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exceptions, const uint64_t *surv_idx,
                            const uint32_t *d_n_surv, uint64_t n_surv_max, SurvOut *out, char *dr_chars,
                            uint32_t dr_stride, uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
-                           uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st)
+                           uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
+                           bool punt_only)
 {
     if (n_surv_max == 0) return hipSuccess;
     hipError_t e;
@@ -1067,12 +1437,12 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_survivor<true>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only ? 1 : 0);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_survivor<false>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only ? 1 : 0);
     }
     return hipGetLastError();
 }
