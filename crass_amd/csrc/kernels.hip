@@ -1021,9 +1021,13 @@ static __device__ int ln_find(const LaneRead &h, int begin, int end, int pat, in
 {
     if (end - begin <= 0 || plen <= 0 || plen > end - begin) return -1;
     const uint32_t sj = ln_code(h, pat);
-    for (int p = begin; p + plen <= end; p++)
-        if (ln_code(h, p) == sj) return p;
-    return -1;
+    uint32_t code = ln_code(h, begin);
+    const int top = 2 * (plen - 1);
+    for (int p = begin;; p++) {
+        if (code == sj) return p;
+        if (p + 1 + plen > end) return -1;
+        code = (code >> 2) | (ln_base(h, p + plen) << top);      // slide the window by one base
+    }
 }
 
 static __device__ void ln_add(LaneRead &h, uint32_t i, uint32_t j)          // startStopsAdd, ReadHolder.cpp:263-297
@@ -1242,11 +1246,15 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t s
     h.nss = 0;
     bool on_lattice = true;
     uint32_t lattice_i = 0;
-    for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
-        if (on_lattice) {
-            const uint32_t li = lattice_i++;
-            if (li < 32 && !((seed_hint >> li) & 1u)) continue;
-        }
+    uint32_t j = 0;
+    for (;;) {
+        // Each lane first walks (cheaply) to ITS next seed worth evaluating, so that the expensive body
+        // below runs once per candidate of the busiest lane instead of once per seed index of the wave.
+        // A lattice seed whose hint bit is clear is a no-op iteration in the reference (no hit => no
+        // start/stops => numRepeats 0): skipping it changes nothing.
+        while (on_lattice && j <= (uint32_t)searchEnd && lattice_i < 32 && !((seed_hint >> lattice_i) & 1u)) { j += skips; lattice_i++; }
+        if (j > (uint32_t)searchEnd) break;
+        if (on_lattice) lattice_i++;
         uint32_t beginSearch = j + o.lowDR + o.lowSp;
         uint32_t endSearch = j + o.highDR + o.highSp + o.window;
         if (endSearch >= seq_length) endSearch = seq_length - 1;
@@ -1272,6 +1280,7 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t s
             on_lattice = false;
         }
         h.nss = 0;
+        j = j + skips;
     }
     return 0;
 }
