@@ -157,7 +157,10 @@ static __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
 }
 
 // Fully unrolled implementation: D0..D1 are compile-time so every register index is static.
-template <int W, int D0, int D1>
+// LCT: compile-time read length (0 = unknown).  With it, shifts that would put the window past the
+// read end (libcrispr.cpp:301-304: p <= L-9-w... i.e. d <= L-9-16k for the seeds of word k) are dropped
+// at compile time: 234 instead of 343 (word, shift) pairs at L = 150.
+template <int W, int D0, int D1, int LCT>
 __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams P, uint64_t *hitmask, uint32_t *seed_hint)
 {
     const uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams 
         const int sh = (d & 15) * 2;
 #pragma unroll
         for (int k = 0; k < SW; k++) {
+            if (LCT > 0 && d > LCT - 9 - 16 * k) continue;               // window past the read end for both seeds of word k
             uint32_t lo = w[k + q], hi = w[k + q + 1];
             uint32_t s = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;      // v_alignbit_b32
             uint32_t x = s ^ w[k];
@@ -221,8 +225,12 @@ hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *h
     uint64_t blocks = (R.n_reads + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorNotSupported;
     dim3 g((unsigned)blocks), b(256);
+    // common uniform read lengths get the compile-time clamp
+#define FF_LEN(LL, WW) if (R.uniform_len == LL && R.stride_words == WW) { hipLaunchKernelGGL((k_filter_fast_impl<WW, 49, 97, LL>), g, b, 0, st, R, P, hitmask, seed_hint); return hipGetLastError(); }
+    FF_LEN(100, 7) FF_LEN(101, 7) FF_LEN(125, 8) FF_LEN(126, 8) FF_LEN(150, 10) FF_LEN(151, 10) FF_LEN(250, 16) FF_LEN(251, 16)
+#undef FF_LEN
     switch (R.stride_words) {
-#define FF_CASE(WW) case WW: hipLaunchKernelGGL((k_filter_fast_impl<WW, 49, 97>), g, b, 0, st, R, P, hitmask, seed_hint); break;
+#define FF_CASE(WW) case WW: hipLaunchKernelGGL((k_filter_fast_impl<WW, 49, 97, 0>), g, b, 0, st, R, P, hitmask, seed_hint); break;
         FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8) FF_CASE(9) FF_CASE(10)
         FF_CASE(11) FF_CASE(12) FF_CASE(13) FF_CASE(14) FF_CASE(15) FF_CASE(16)
 #undef FF_CASE
