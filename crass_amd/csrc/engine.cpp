@@ -118,6 +118,10 @@ struct crass_hip_ctx {
         }
     } dense;
     DevBuf<uint64_t> d_fidx;
+    // device-side DR de-duplication (single-GPU merge fast path)
+    DevBuf<unsigned long long> dd_keys; DevBuf<uint32_t> dd_first, dd_slot, dd_rep; DevBuf<uint64_t> dd_hash;
+    PinBuf<uint32_t> h_rep; PinBuf<uint64_t> h_hash;
+    bool have_rep = false;
     uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
     const char *cand_dr() const { return dense.active ? dense.h_dr.p : cand.dr.data(); }
     const uint16_t *cand_dr_len() const { return dense.active ? dense.h_dr_len.p : cand.dr_len.data(); }
@@ -218,7 +222,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
     c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
-    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
+    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -483,6 +487,18 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
     HIPCHK(c, D.h_read.ensure(nf)); HIPCHK(c, D.h_ss_off.ensure(nf)); HIPCHK(c, D.h_low.ensure(nf)); HIPCHK(c, D.h_replen.ensure(nf));
     HIPCHK(c, D.h_nss.ensure(nf)); HIPCHK(c, D.h_dr_len.ensure(nf)); HIPCHK(c, D.h_dr.ensure(nf * stride + 16));
     HIPCHK(c, D.h_ss.ensure(nf * (uint64_t)lds.ss_cap + 16));
+    c->have_rep = false;
+    if (nf && nf < (1u << 22)) {
+        uint32_t tsize = 1024;
+        while (tsize < nf * 2) tsize <<= 1;
+        HIPCHK(c, c->dd_keys.ensure(tsize)); HIPCHK(c, c->dd_first.ensure(tsize)); HIPCHK(c, c->dd_slot.ensure(nf));
+        HIPCHK(c, c->dd_rep.ensure(nf)); HIPCHK(c, c->dd_hash.ensure(nf)); HIPCHK(c, c->h_rep.ensure(nf)); HIPCHK(c, c->h_hash.ensure(nf));
+        HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, (uint32_t)nf, c->dd_keys.p, c->dd_first.p, tsize, c->dd_hash.p,
+                                   c->dd_slot.p, c->dd_rep.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_rep.p, c->dd_rep.p, nf * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_hash.p, c->dd_hash.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
+        c->have_rep = true;
+    }
     if (nf) {
         HIPCHK(c, hipMemcpyAsync(D.h_dr.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, c->stream));          // merge needs these first
         HIPCHK(c, hipMemcpyAsync(D.h_dr_len.p, D.d_dr_len.p, nf * 2, hipMemcpyDeviceToHost, c->stream));
@@ -532,6 +548,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint64_t n_surv = c->h_count.p[0];
     c->dense.active = false;
+    c->have_rep = false;
     const bool try_dense = use_filter && c->R.n_exc == 0 && n_surv > 0 && n_surv <= (1u << 20);
     std::vector<uint64_t> surv_idx;
     // the survivor kernel reads its count from d_count[1] (chunk-local bound is passed separately)
@@ -699,7 +716,10 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
         if (!c->have_pass1) return CRASS_ERR_STATE;
         dr_chars = c->cand_dr(); dr_len = c->cand_dr_len(); dr_stride = c->dr_stride; n = c->n_cand();
     } else if (!dr_len || !dr_stride) return CRASS_ERR_INVALID_ARG;
-    merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n, c->prm.kmer_clust_size);
+    const bool own = (dr_chars == c->cand_dr());
+    merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n, c->prm.kmer_clust_size,
+                     (own && c->have_rep && c->dense.active) ? c->h_rep.p : nullptr,
+                     (own && c->have_rep && c->dense.active) ? c->h_hash.p : nullptr);
     c->have_merge = true;
     c->have_pass2 = false;
     int s = install_patterns(c, c->merge.patterns);

@@ -1430,6 +1430,66 @@ hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint6
     return hipGetLastError();
 }
 
+// ---- device-side de-duplication of the candidates' DR strings (single-GPU merge fast path) ----
+// Same 64-bit hash as TokenTable::hash (merge.cpp) so the host can reuse it.  Every distinct
+// string gets one table slot; `first` keeps the smallest candidate index (= first occurrence in
+// read order).  The host re-checks every (candidate, representative) pair with memcmp, so a hash
+// collision between different strings is detected and only costs the fast path.
+static __device__ uint64_t dr_hash64(const char *p, uint32_t n)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)n * 0xD6E8FEB86659FD93ull);
+    while (n >= 8) {
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
+        h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; p += 8; n -= 8;
+    }
+    if (n) {
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < n; i++) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
+        h = (h ^ v) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
+    }
+    return h ^ (h >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_dr_dedupe_insert(const char *dr, const uint16_t *dr_len, uint32_t stride, uint32_t n,
+                                                           unsigned long long *keys, uint32_t *first, uint32_t mask,
+                                                           uint64_t *hash_out, uint32_t *slot_out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t h = dr_hash64(dr + (uint64_t)k * stride, dr_len[k]);
+    hash_out[k] = h;
+    const unsigned long long key = h | 1ull;                 // 0 marks an empty slot
+    uint32_t slot = (uint32_t)(h >> 17) & mask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&keys[slot], 0ull, key);
+        if (old == 0ull || old == key) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(&first[slot], k);
+    slot_out[k] = slot;
+}
+
+__global__ __launch_bounds__(256) void k_dr_dedupe_rep(const uint32_t *slot_of, const uint32_t *first, uint32_t n, uint32_t *rep)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) rep[k] = first[slot_of[k]];
+}
+
+hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, uint32_t n, unsigned long long *keys,
+                            uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(keys, 0, (size_t)table_size * 8, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(first, 0xFF, (size_t)table_size * 4, st);
+    if (e != hipSuccess) return e;
+    const unsigned nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_dr_dedupe_insert, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, n, keys, first, table_size - 1, hash_out, slot_tmp);
+    hipLaunchKernelGGL(k_dr_dedupe_rep, dim3(nb), dim3(256), 0, st, slot_tmp, first, n, rep);
+    return hipGetLastError();
+}
+
 SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P)
 {
     SurvLds l;

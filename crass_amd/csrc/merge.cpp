@@ -86,12 +86,13 @@ void TokenTable::grow()
     slot_token.swap(nt); slot_hash.swap(nh);
 }
 
-uint32_t TokenTable::add(const char *p, size_t n)
+uint32_t TokenTable::add(const char *p, size_t n) { return add_hashed(p, n, hash(p, n)); }
+
+uint32_t TokenTable::add_hashed(const char *p, size_t n, uint64_t h)
 {
     if ((strings.size() + 1) * 2 > slot_token.size()) grow();
     strings.emplace_back(p, n);
     const uint32_t t = (uint32_t)strings.size() + 1;
-    const uint64_t h = hash(p, n);
     const size_t mask = slot_token.size() - 1;
     size_t i = (size_t)h & mask;
     while (slot_token[i]) i = (i + 1) & mask;
@@ -443,13 +444,39 @@ static double prof_now()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// token assignment from a device-computed first-occurrence map; false if the map is inconsistent
+static bool assign_tokens_from_rep(MergeResult &m, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n,
+                                   const uint32_t *rep, const uint64_t *hash)
+{
+    m.cand_token.resize(n);
+    for (uint64_t k = 0; k < n; k++) {
+        const uint32_t f = rep[k];
+        if (f > k || rep[f] != f) return false;
+        const char *dr = dr_chars + k * (uint64_t)dr_stride;
+        if (f == k) {
+            if (hash[k] != TokenTable::hash(dr, dr_len[k])) return false;
+            // two different first occurrences must be different strings: guaranteed by the table (same
+            // string => same hash => same slot); get() re-checks it exactly
+            if (m.tokens.get(dr, dr_len[k]) != 0) return false;
+            m.cand_token[k] = m.tokens.add_hashed(dr, dr_len[k], hash[k]);
+        } else {
+            if (dr_len[f] != dr_len[k] || memcmp(dr_chars + f * (uint64_t)dr_stride, dr, dr_len[k]) != 0) return false;
+            m.cand_token[k] = m.cand_token[f];
+        }
+    }
+    return true;
+}
+
 void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
-                      uint64_t n, int kmer_clust_size)
+                      uint64_t n, int kmer_clust_size, const uint32_t *rep, const uint64_t *hash)
 {
     const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
     const double t0 = prof_now();
     m.clear();
-    assign_tokens(m, dr_chars, dr_len, dr_stride, n);
+    if (!(rep && hash && assign_tokens_from_rep(m, dr_chars, dr_len, dr_stride, n, rep, hash))) {
+        m.clear();
+        assign_tokens(m, dr_chars, dr_len, dr_stride, n);
+    }
     const double t1 = prof_now();
     // createNonRedundantSet: cluster every token in ascending token order (std::map iteration).
     // The k-mer codes are order-independent and computed up front on several threads.
@@ -564,19 +591,40 @@ void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns)
 {
     k = HostAnchors();
     std::vector<uint32_t> keys;
+    keys.reserve(patterns.size() * 8);
     for (const auto &p : patterns) {
+        if (p.size() < 23) {                       // the anchor argument needs |P| >= 16 + 7 (unless P cannot match at all)
+            bool acgt = true;
+            for (unsigned char c : p) if (acgt_code(c) < 0) { acgt = false; break; }
+            if (acgt) return;
+            continue;
+        }
+        // rolling 2-bit code of p[r, r+16) for r = 0..7; a non-ACGT byte anywhere makes the pattern
+        // unmatchable in a packed read, so it contributes no keys
+        uint32_t v = 0;
         bool acgt = true;
-        for (unsigned char c : p) if (acgt_code(c) < 0) { acgt = false; break; }
-        if (!acgt) continue;                       // cannot occur in a packed (ACGT-only) read
-        if (p.size() < 23) return;                 // the anchor argument needs |P| >= 16 + 7
-        for (int r = 0; r < 8; r++) {
-            uint32_t v = 0;
-            for (int i = 0; i < 16; i++) v |= (uint32_t)acgt_code((unsigned char)p[(size_t)r + i]) << (2 * i);
+        for (size_t i = 0; i < p.size(); i++) if (acgt_code((unsigned char)p[i]) < 0) { acgt = false; break; }
+        if (!acgt) continue;
+        for (int i = 0; i < 16; i++) v |= (uint32_t)acgt_code((unsigned char)p[(size_t)i]) << (2 * i);
+        keys.push_back(v);
+        for (int r = 1; r < 8; r++) {
+            v = (v >> 2) | ((uint32_t)acgt_code((unsigned char)p[(size_t)r + 15]) << 30);
             keys.push_back(v);
         }
     }
-    std::sort(keys.begin(), keys.end());
-    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    {   // de-duplicate (variants of one DR share most 16-mers) with a throw-away open-addressing set
+        size_t cap = 1024;
+        while (cap < keys.size() * 2) cap <<= 1;
+        std::vector<uint32_t> slot(cap, 0);
+        std::vector<uint8_t> full(cap, 0);
+        size_t w = 0;
+        for (uint32_t key : keys) {
+            size_t i = (size_t)((key * 0x9E3779B1u) >> 8) & (cap - 1);
+            while (full[i] && slot[i] != key) i = (i + 1) & (cap - 1);
+            if (!full[i]) { full[i] = 1; slot[i] = key; keys[w++] = key; }
+        }
+        keys.resize(w);
+    }
     k.n_keys = (uint32_t)keys.size();
     if (keys.empty()) { k.ok = false; return; }
     // h_i(V) = mul_u24(V ^ (V >> s_i), m_i) >> (32 - log_size): 24-bit multiplies are full rate on

@@ -22,6 +22,7 @@ struct TokenTable {
     static uint64_t hash(const char *p, size_t n);
     uint32_t get(const char *p, size_t n) const;
     uint32_t add(const char *p, size_t n);                     // caller checked get() == 0
+    uint32_t add_hashed(const char *p, size_t n, uint64_t h);  // same, hash already known
     uint32_t get(const std::string &s) const { return get(s.data(), s.size()); }
     uint32_t add(const std::string &s) { return add(s.data(), s.size()); }
     uint32_t size() const { return (uint32_t)strings.size(); }
@@ -47,8 +48,11 @@ struct MergeResult {
 
 // addReadHolder's token assignment (libcrispr.cpp:1137-1143) for every candidate DR in read
 // order, then createNonRedundantSet (WorkHorse.cpp:648-709).
+// rep/hash (optional, from the device de-duplication): rep[k] = candidate index of the first occurrence
+// of candidate k's string, hash[k] = TokenTable::hash of it.  Verified with memcmp; on any
+// inconsistency the plain host path is used.
 void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
-                      uint64_t n, int kmer_clust_size);
+                      uint64_t n, int kmer_clust_size, const uint32_t *rep = nullptr, const uint64_t *hash = nullptr);
 
 // byte-wise Aho-Corasick with fully resolved goto; semantics of acism_create + the first
 // callback of acism_scan (acism_create.c:71-392, acism.c:25-106)
