@@ -66,10 +66,7 @@ uint32_t TokenTable::get(const char *p, size_t n) const
     for (size_t i = (size_t)h & mask;; i = (i + 1) & mask) {
         const uint32_t t = slot_token[i];
         if (!t) return 0;
-        if (slot_hash[i] == h) {
-            const std::string &s = strings[t - 2];
-            if (s.size() == n && memcmp(s.data(), p, n) == 0) return t;
-        }
+        if (slot_hash[i] == h && strings.len(t - 2) == n && memcmp(strings.data(t - 2), p, n) == 0) return t;
     }
 }
 
@@ -91,7 +88,7 @@ uint32_t TokenTable::add(const char *p, size_t n) { return add_hashed(p, n, hash
 uint32_t TokenTable::add_hashed(const char *p, size_t n, uint64_t h)
 {
     if ((strings.size() + 1) * 2 > slot_token.size()) grow();
-    strings.emplace_back(p, n);
+    strings.push(p, n);
     const uint32_t t = (uint32_t)strings.size() + 1;
     const size_t mask = slot_token.size() - 1;
     size_t i = (size_t)h & mask;
@@ -110,7 +107,7 @@ void MergeResult::clear()
 void MergeResult::flatten()
 {
     tok_chars.clear(); tok_off.assign(1, 0);
-    for (const auto &s : tokens.strings) { tok_chars.insert(tok_chars.end(), s.begin(), s.end()); tok_off.push_back(tok_chars.size()); }
+    tok_chars = tokens.strings.chars; tok_off = tokens.strings.off;
     grp_tokens.clear(); grp_off.assign(1, 0);
     for (const auto &g : groups) { grp_tokens.insert(grp_tokens.end(), g.begin(), g.end()); grp_off.push_back(grp_tokens.size()); }
     pat_chars.clear(); pat_off.assign(1, 0);
@@ -165,13 +162,13 @@ struct KmerGid {
 // laurenized 11-mer codes of one DR in order (laurenize, SeqUtils.cpp:89-97: seq1 < seq2 ? seq1 : seq2);
 // -1 marks a window holding a non-ACGT byte (handled through string keys).  Pure function of the
 // string, so it is computed for all variants in parallel before the order-dependent greedy pass.
-void kmer_codes(const std::string &dr, int32_t *out)
+void kmer_codes(const char *dr, size_t dr_size, int32_t *out)
 {
-    const int n_mers = (int)dr.size() - kClusterKmer + 1;
+    const int n_mers = (int)dr_size - kClusterKmer + 1;
     uint32_t fwd = 0, rev = 0;
     int bad = 0;
     const uint32_t mask = (1u << 22) - 1;
-    for (int i = 0; i < (int)dr.size(); i++) {
+    for (int i = 0; i < (int)dr_size; i++) {
         int c = acgt_code((unsigned char)dr[i]);
         if (c < 0) { bad = kClusterKmer; c = 0; } else if (bad > 0) bad--;
         fwd = ((fwd << 2) | (uint32_t)c) & mask;
@@ -184,7 +181,7 @@ void kmer_codes(const std::string &dr, int32_t *out)
 
 // WorkHorse::clusterDRReads (WorkHorse.cpp:1404-1637): greedy, order-dependent assignment of
 // one DR variant to a group through shared laurenized 11-mers.  Returns the GID.
-int cluster_one(const std::string &dr, const int32_t *codes, int n_mers, int &next_free_gid, KmerGid &kg, int min_shared,
+int cluster_one(const char *dr_p, size_t dr_n, const int32_t *codes, int n_mers, int &next_free_gid, KmerGid &kg, int min_shared,
                 std::vector<uint32_t> &homeless_code, std::vector<std::pair<int, int>> &group_count)
 {
     homeless_code.clear();
@@ -202,7 +199,8 @@ int cluster_one(const std::string &dr, const int32_t *codes, int n_mers, int &ne
             const int32_t gid = kg.find((uint32_t)codes[i]);
             if (gid == 0) homeless_code.push_back((uint32_t)codes[i]); else seen(gid);
         } else {
-            std::string km = dr.substr((size_t)i, kClusterKmer), rc = reverse_complement(km);
+            (void)dr_n;
+            std::string km(dr_p + i, kClusterKmer), rc = reverse_complement(km);
             const std::string &lau = (km < rc) ? km : rc;
             auto it = kg.other.find(lau);
             if (it == kg.other.end()) homeless_str.push_back(lau); else seen(it->second);
@@ -483,13 +481,13 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
     const uint32_t ntok = m.tokens.size();
     std::vector<uint32_t> code_off(ntok + 1, 0);
     for (uint32_t t = 0; t < ntok; t++) {
-        const int nm = (int)m.tokens.strings[t].size() - kClusterKmer + 1;
+        const int nm = (int)m.tokens.strings.len(t) - kClusterKmer + 1;
         code_off[t + 1] = code_off[t] + (uint32_t)(nm > 0 ? nm : 0);
     }
     std::vector<int32_t> codes(code_off[ntok]);
     parallel_tasks((ntok + 255) / 256, 8, [&](size_t c) {
         for (uint32_t t = (uint32_t)c * 256; t < std::min<uint32_t>(ntok, ((uint32_t)c + 1) * 256); t++)
-            if (code_off[t + 1] > code_off[t]) kmer_codes(m.tokens.strings[t], codes.data() + code_off[t]);
+            if (code_off[t + 1] > code_off[t]) kmer_codes(m.tokens.strings.data(t), m.tokens.strings.len(t), codes.data() + code_off[t]);
     });
     KmerGid kmer_gid;
     int next_gid = 1;
@@ -497,7 +495,7 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
     std::vector<uint32_t> scratch_codes;
     std::vector<std::pair<int, int>> scratch_counts;
     for (uint32_t t = 0; t < ntok; t++)
-        gid_of[t] = cluster_one(m.tokens.strings[t], codes.data() + code_off[t], (int)(code_off[t + 1] - code_off[t]), next_gid,
+        gid_of[t] = cluster_one(m.tokens.strings.data(t), m.tokens.strings.len(t), codes.data() + code_off[t], (int)(code_off[t + 1] - code_off[t]), next_gid,
                                 kmer_gid, kmer_clust_size, scratch_codes, scratch_counts);
     m.next_free_gid = next_gid;
     m.groups.assign((size_t)(next_gid - 1), {});

@@ -16,7 +16,18 @@ std::string reverse_complement(const std::string &s);          // SeqUtils.cpp:6
 // The string -> token side is an open-addressing table over (pointer, length) views so that the
 // per-candidate lookup of the sink allocates nothing.
 struct TokenTable {
-    std::vector<std::string> strings;                          // token t -> strings[t-2]
+    // token t -> chars[off[t-2] .. off[t-1]): one arena instead of one heap string per variant
+    // (this is exactly the layout crass_merge_view exposes, so "flattening" is free)
+    struct Strings {
+        std::vector<char> chars;
+        std::vector<uint64_t> off{0};
+        size_t size() const { return off.size() - 1; }
+        std::string operator[](size_t i) const { return std::string(chars.data() + off[i], (size_t)(off[i + 1] - off[i])); }
+        const char *data(size_t i) const { return chars.data() + off[i]; }
+        size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i]); }
+        void push(const char *p, size_t n) { chars.insert(chars.end(), p, p + n); off.push_back(chars.size()); }
+        void clear() { chars.clear(); off.assign(1, 0); }
+    } strings;
     std::vector<uint32_t> slot_token;                          // 0 = empty
     std::vector<uint64_t> slot_hash;
     static uint64_t hash(const char *p, size_t n);
