@@ -92,10 +92,12 @@ def main():
     def step():
         eng.seed_scan(fetch=False)
         if world > 1:
-            from crass_amd.distributed import allgather_candidates
-            chars, lens = eng.candidate_dr_view()
-            g_chars, g_lens = allgather_candidates(chars, lens, dist, coll_dev)
-            eng.merge(g_chars, g_lens, fetch=False)
+            # only the DISTINCT candidate DR strings travel (rank order == read order, so every rank
+            # replays the same global token order and builds the same pattern set locally)
+            from crass_amd.distributed import allgather_distinct
+            chars, lens, _ = eng.distinct()
+            g_chars, g_lens, my_off = allgather_distinct(chars, lens, dist, coll_dev)
+            eng.merge_distinct(g_chars, g_lens, my_off, fetch=False)
         else:
             eng.merge(fetch=False)
         eng.recruit(fetch=False)

@@ -38,6 +38,11 @@ class MergeView(C.Structure):
                 ("next_free_gid", C.c_int32)]
 
 
+class Distinct(C.Structure):
+    _fields_ = [("n_distinct", C.c_uint64), ("dr_stride", C.c_uint32), ("dr_len", u16p), ("dr_chars", charp),
+                ("n_candidates", C.c_uint64), ("cand_distinct", u32p)]
+
+
 class Recruits(C.Structure):
     _fields_ = [("n", C.c_uint64), ("read_idx", u64p), ("low_lexi", u8p), ("start", u32p), ("end", u32p),
                 ("dr_stride", C.c_uint32), ("dr_len", u16p), ("dr_chars", charp), ("token", u32p)]
@@ -85,6 +90,8 @@ SYMBOLS = {
     "crass_hip_seed_scan": (C.c_int, [C.c_void_p]),
     "crass_hip_get_candidates": (C.c_int, [C.c_void_p, C.POINTER(Candidates)]),
     "crass_hip_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
+    "crass_hip_get_distinct": (C.c_int, [C.c_void_p, C.POINTER(Distinct)]),
+    "crass_hip_merge_distinct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "crass_hip_get_merge": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),
     "crass_merge_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
     "crass_merge_get": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),

@@ -122,6 +122,8 @@ struct crass_hip_ctx {
     DevBuf<unsigned long long> dd_keys; DevBuf<uint32_t> dd_first, dd_slot, dd_rep; DevBuf<uint64_t> dd_hash;
     PinBuf<uint32_t> h_rep; PinBuf<uint64_t> h_hash;
     bool have_rep = false;
+    // distinct candidate strings (multi-GPU exchange)
+    std::vector<char> dx_chars; std::vector<uint16_t> dx_len; std::vector<uint32_t> dx_map; bool have_distinct = false;
     uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
     const char *cand_dr() const { return dense.active ? dense.h_dr.p : cand.dr.data(); }
     const uint16_t *cand_dr_len() const { return dense.active ? dense.h_dr_len.p : cand.dr_len.data(); }
@@ -549,6 +551,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     uint64_t n_surv = c->h_count.p[0];
     c->dense.active = false;
     c->have_rep = false;
+    c->have_distinct = false;
     const bool try_dense = use_filter && c->R.n_exc == 0 && n_surv > 0 && n_surv <= (1u << 20);
     std::vector<uint64_t> surv_idx;
     // the survivor kernel reads its count from d_count[1] (chunk-local bound is passed separately)
@@ -708,6 +711,8 @@ static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pa
     return CRASS_OK;
 }
 
+static int finish_merge(crass_hip_ctx *c, double t0);
+
 int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n)
 {
     if (!c) return CRASS_ERR_INVALID_ARG;
@@ -720,6 +725,12 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
     merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n, c->prm.kmer_clust_size,
                      (own && c->have_rep && c->dense.active) ? c->h_rep.p : nullptr,
                      (own && c->have_rep && c->dense.active) ? c->h_hash.p : nullptr);
+    return finish_merge(c, t0);
+}
+
+// shared tail of the merge entry points: automaton/anchors/pattern tokens for pass 2
+static int finish_merge(crass_hip_ctx *c, double t0)
+{
     c->have_merge = true;
     c->have_pass2 = false;
     int s = install_patterns(c, c->merge.patterns);
@@ -739,6 +750,66 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
     }
     c->cnt.ms_merge_host = (float)(now_ms() - t0);
     return s;
+}
+
+static void ensure_distinct(crass_hip_ctx *c)
+{
+    if (c->have_distinct) return;
+    const uint64_t n = c->n_cand();
+    const char *dr = c->cand_dr();
+    const uint16_t *len = c->cand_dr_len();
+    const uint32_t stride = c->dr_stride;
+    c->dx_chars.clear(); c->dx_len.clear(); c->dx_map.assign(n, 0);
+    if (c->have_rep && c->dense.active) {
+        // the device already knows every candidate's first occurrence
+        for (uint64_t k = 0; k < n; k++) {
+            const uint32_t f = c->h_rep.p[k];
+            if (f == k) {
+                c->dx_map[k] = (uint32_t)c->dx_len.size();
+                c->dx_len.push_back(len[k]);
+                c->dx_chars.insert(c->dx_chars.end(), dr + k * (uint64_t)stride, dr + (k + 1) * (uint64_t)stride);
+            } else c->dx_map[k] = c->dx_map[f];
+        }
+    } else {
+        TokenTable t;
+        for (uint64_t k = 0; k < n; k++) {
+            const char *p = dr + k * (uint64_t)stride;
+            uint32_t tok = t.get(p, len[k]);
+            if (!tok) {
+                tok = t.add(p, len[k]);
+                c->dx_len.push_back(len[k]);
+                c->dx_chars.insert(c->dx_chars.end(), p, p + stride);
+            }
+            c->dx_map[k] = tok - 2;
+        }
+    }
+    c->have_distinct = true;
+}
+
+int crass_hip_get_distinct(crass_hip_ctx *c, crass_distinct *o)
+{
+    if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_pass1) return CRASS_ERR_STATE;
+    ensure_distinct(c);
+    o->n_distinct = c->dx_len.size(); o->dr_stride = c->dr_stride; o->dr_len = c->dx_len.data(); o->dr_chars = c->dx_chars.data();
+    o->n_candidates = c->dx_map.size(); o->cand_distinct = c->dx_map.data();
+    return CRASS_OK;
+}
+
+int crass_hip_merge_distinct(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
+                             uint64_t n_global, uint64_t my_offset)
+{
+    if (!c || (n_global && (!dr_chars || !dr_len || !dr_stride))) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_pass1) return CRASS_ERR_STATE;
+    const double t0 = now_ms();
+    ensure_distinct(c);
+    if (my_offset + c->dx_len.size() > n_global) return CRASS_ERR_INVALID_ARG;
+    merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n_global, c->prm.kmer_clust_size);
+    // tokens of this context's own candidates through their distinct index
+    std::vector<uint32_t> own(c->dx_map.size());
+    for (size_t k = 0; k < own.size(); k++) own[k] = c->merge.cand_token[my_offset + c->dx_map[k]];
+    c->merge.cand_token.swap(own);
+    return finish_merge(c, t0);
 }
 
 int crass_hip_get_merge(const crass_hip_ctx *c, crass_merge_view *o)

@@ -45,6 +45,15 @@ def allgather_candidates(chars, lens, dist, device=None):
     return np.ascontiguousarray(np.concatenate(parts_c, axis=0)), np.concatenate(parts_l)
 
 
+def allgather_distinct(chars, lens, dist, device=None):
+    """Compact exchange: every rank contributes only its DISTINCT candidate strings (first-occurrence
+    order).  Returns (global chars, global lens, offset of this rank's list in the concatenation)."""
+    g_chars, g_lens = allgather_candidates(chars, lens, dist, device)
+    counts = gather_counts([int(chars.shape[0])], dist, device)
+    my_off = sum(c[0] for c in counts[:dist.get_rank()])
+    return g_chars, g_lens, my_off
+
+
 def gather_counts(values, dist, device=None):
     """small helper: all-gather a list of python ints -> [world][len(values)]"""
     import torch

@@ -347,6 +347,25 @@ class SearchEngine:
                  "crass_hip_merge")
         return self.merge_view() if fetch else None
 
+    def distinct(self):
+        """(uint8 [n_distinct, stride], uint16 [n_distinct], uint32 cand->distinct map) of this
+        context's pass-1 candidates, first-occurrence order (the compact multi-GPU payload)."""
+        v = _abi.Distinct()
+        _chk(self.lib.crass_hip_get_distinct(self.h, C.byref(v)), "crass_hip_get_distinct")
+        nd, st = int(v.n_distinct), int(v.dr_stride)
+        chars = _np(C.cast(v.dr_chars, _abi.u8p), nd * st, np.uint8).reshape(nd, st)
+        return chars, _np(v.dr_len, nd, np.uint16), _np(v.cand_distinct, int(v.n_candidates), np.uint32)
+
+    def merge_distinct(self, g_chars, g_lens, my_offset, fetch=True):
+        """merge from the rank-ordered concatenation of every rank's distinct list"""
+        g_chars = np.ascontiguousarray(g_chars, dtype=np.uint8)
+        g_lens = np.ascontiguousarray(g_lens, dtype=np.uint16)
+        n = g_chars.shape[0]
+        stride = g_chars.shape[1] if n else 16
+        _chk(self.lib.crass_hip_merge_distinct(self.h, g_chars.ctypes.data, g_lens.ctypes.data, int(stride), int(n),
+                                               int(my_offset)), "crass_hip_merge_distinct")
+        return self.merge_view() if fetch else None
+
     def merge_view(self):
         v = _abi.MergeView()
         _chk(self.lib.crass_hip_get_merge(self.h, C.byref(v)), "crass_hip_get_merge")

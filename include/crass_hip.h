@@ -137,6 +137,24 @@ int crass_hip_get_candidates(const crass_hip_ctx *ctx, crass_candidates *out);
 int crass_hip_merge(crass_hip_ctx *ctx, const char *dr_chars, const uint16_t *dr_len,
                     uint32_t dr_stride, uint64_t n_candidates);
 
+/* Multi-GPU exchange in its compact form: only the DISTINCT representative DR strings of a rank's
+ * candidates travel (first-occurrence order), not one string per candidate.  Scanning the ranks'
+ * lists in rank order reproduces the global first-occurrence order, so tokens come out exactly
+ * as if one process had seen every read (libcrispr.cpp:1137-1143).                            */
+typedef struct {
+    uint64_t        n_distinct;
+    uint32_t        dr_stride;
+    const uint16_t *dr_len;        /* [n_distinct]                                                */
+    const char     *dr_chars;      /* string d at dr_chars + d*dr_stride                          */
+    uint64_t        n_candidates;
+    const uint32_t *cand_distinct; /* [n_candidates] index of each candidate's string in the list */
+} crass_distinct;
+int crass_hip_get_distinct(crass_hip_ctx *ctx, crass_distinct *out);
+/* merge from the concatenation (rank order) of every rank's distinct list; `my_offset` is where this
+ * context's own list starts in it.  crass_merge_view.cand_token then covers this context's candidates. */
+int crass_hip_merge_distinct(crass_hip_ctx *ctx, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
+                             uint64_t n_global, uint64_t my_offset);
+
 typedef struct {
     uint32_t        n_tokens;     /* StringCheck size; tokens are 2 .. n_tokens+1                 */
     const char     *tok_chars;    /* token t string = tok_chars[tok_off[t-2] .. tok_off[t-1])     */

@@ -32,15 +32,25 @@ words = ca.synth_packed(spec, lo, hi - lo)
 eng = ca.SearchEngine(device=0)
 eng.load_packed_uniform(words, hi - lo, L, read_index_base=lo)
 cand = eng.seed_scan()
-chars, lens = eng.candidate_dr_view()
-g_chars, g_lens = allgather_candidates(chars, lens, dist)
-m = eng.merge(g_chars, g_lens)
+if os.environ["EXCHANGE"] == "candidates":
+    # one DR string per candidate travels
+    chars, lens = eng.candidate_dr_view()
+    g_chars, g_lens = allgather_candidates(chars, lens, dist)
+    m = eng.merge(g_chars, g_lens)
+    counts = [None] * world
+    dist.all_gather_object(counts, int(cand.n))
+    off = sum(counts[:rank])                 # this rank's slice of the global candidate token list
+else:
+    # compact form: only the distinct strings travel (what bench.py uses)
+    from crass_amd.distributed import allgather_distinct
+    chars, lens, cmap = eng.distinct()
+    assert len(cmap) == cand.n and [cand.dr(k) for k in range(0, cand.n, 37)] == \
+        [chars[cmap[k], :lens[cmap[k]]].tobytes() for k in range(0, cand.n, 37)]
+    g_chars, g_lens, my_off = allgather_distinct(chars, lens, dist)
+    m = eng.merge_distinct(g_chars, g_lens, my_off)
+    off = 0                                  # cand_token covers this rank's candidates only
 rec = eng.recruit()
 m = eng.merge_view()
-# this rank's slice of the global candidate token list
-counts = [None] * world
-dist.all_gather_object(counts, int(cand.n))
-off = sum(counts[:rank])
 out = dict(read=cand.read_idx.tolist(), low=cand.low_lexi.tolist(), replen=cand.repeat_len.tolist(),
            ss=[cand.ss(k) for k in range(cand.n)], tok=m.cand_token[off:off + cand.n].tolist(),
            r_read=rec.read_idx.tolist(), r_low=rec.low_lexi.tolist(), r_ss=[[int(a), int(b)] for a, b in zip(rec.start, rec.end)],
@@ -50,7 +60,8 @@ dist.destroy_process_group()
 """
 
 
-def test_two_ranks_equal_single_process_oracle(tmp_path):
+@pytest.mark.parametrize("exchange", ["candidates", "distinct"])
+def test_two_ranks_equal_single_process_oracle(tmp_path, exchange):
     import crass_amd as ca
     n = 120000
     outpat = str(tmp_path / "rank%d.json")
@@ -62,7 +73,7 @@ def test_two_ranks_equal_single_process_oracle(tmp_path):
     s.close()
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EXCHANGE=exchange)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
