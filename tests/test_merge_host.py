@@ -77,6 +77,16 @@ chars, lens, cut = data["chars"], data["lens"], int(data["cut"])
 lo, hi = (0, cut) if rank == 0 else (cut, chars.shape[0])
 g_chars, g_lens = allgather_candidates(chars[lo:hi], lens[lo:hi], dist)
 m = ca.merge_host(g_chars, g_lens)
+# compact exchange: each rank sends only its distinct strings (first-occurrence order)
+from crass_amd.distributed import allgather_distinct
+seen = {}
+for k in range(lo, hi):
+    seen.setdefault(bytes(chars[k, :lens[k]]), k)
+order = sorted(seen.values())
+d_chars, d_lens, my_off = allgather_distinct(chars[order], lens[order], dist)
+md = ca.merge_host(d_chars, d_lens)
+assert md.tokens == m.tokens and md.groups == m.groups and md.patterns == m.patterns
+assert my_off == (0 if rank == 0 else int(d_chars.shape[0]) - len(order))
 out = dict(n=int(g_chars.shape[0]), same_chars=bool(np.array_equal(g_chars, chars)), same_lens=bool(np.array_equal(g_lens, lens)),
            tokens=[t.decode() for t in m.tokens], groups=m.groups, patterns=[p.decode() for p in m.patterns])
 json.dump(out, open(%(out)r %% rank, "w"))
