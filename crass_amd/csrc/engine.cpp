@@ -88,12 +88,15 @@ struct crass_hip_ctx {
     // automaton
     DevBuf<uint16_t> a_go16; DevBuf<uint32_t> a_go32; DevBuf<uint16_t> a_out; DevBuf<uint16_t> a_go4;
     DevAutomaton A{};
+    HostAutomaton H;
+    bool full_automaton_uploaded = false;
+    DevBuf<uint32_t> a_go4w;
     DevBuf<uint32_t> a_anchor; DevBuf<uint32_t> d_slot_info; DevBuf<uint32_t> d_slot_pid; DevBuf<uint32_t> a_out_pid; DevBuf<uint32_t> a_pat_token;
     bool have_pat_token = false;
     DevAnchors K{};
     bool have_anchors = false;
     bool have_patterns = false;
-    std::vector<std::string> patterns;
+    uint32_t n_installed_patterns = 0;
 
     // pass-1 results (host), final hand-off layout
     bool have_pass1 = false;
@@ -122,11 +125,27 @@ struct crass_hip_ctx {
     DevBuf<unsigned long long> dd_keys; DevBuf<uint32_t> dd_first, dd_slot, dd_rep; DevBuf<uint64_t> dd_hash;
     PinBuf<uint32_t> h_rep; PinBuf<uint64_t> h_hash;
     bool have_rep = false;
+    // device-side token ranks: distinct strings (first-occurrence order) + every candidate's distinct index.
+    // With these the host merge never touches the per-candidate strings, whose D2H then overlaps the merge
+    // on a second stream (bulk_pending until wait_bulk()).
+    DevBuf<uint32_t> dd_map; DevBuf<char> dd_dx_chars; DevBuf<uint16_t> dd_dx_len; DevBuf<uint64_t> dd_dx_hash;
+    PinBuf<uint32_t> h_dmap; PinBuf<char> h_dx_chars; PinBuf<uint16_t> h_dx_len; PinBuf<uint64_t> h_dx_hash;
+    uint64_t n_dx = 0;
+    bool have_dev_tokens = false;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_gathered = nullptr;
+    mutable bool bulk_pending = false;
+    void wait_bulk() const
+    {
+        if (!bulk_pending) return;
+        (void)hipStreamSynchronize(copy_stream);
+        bulk_pending = false;
+    }
     // distinct candidate strings (multi-GPU exchange)
     std::vector<char> dx_chars; std::vector<uint16_t> dx_len; std::vector<uint32_t> dx_map; bool have_distinct = false;
     uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
-    const char *cand_dr() const { return dense.active ? dense.h_dr.p : cand.dr.data(); }
-    const uint16_t *cand_dr_len() const { return dense.active ? dense.h_dr_len.p : cand.dr_len.data(); }
+    const char *cand_dr() const { wait_bulk(); return dense.active ? dense.h_dr.p : cand.dr.data(); }
+    const uint16_t *cand_dr_len() const { wait_bulk(); return dense.active ? dense.h_dr_len.p : cand.dr_len.data(); }
     uint32_t dr_stride = 48;
     // merge
     MergeResult merge;
@@ -205,7 +224,9 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     c->dr_stride = (p->highDRsize + 15u) & ~15u;
     if (hipSetDevice(device) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
+    if (hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     unsigned char tab[128];
     build_comp_table(tab);
     if (upload_comp_table(tab) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
@@ -218,13 +239,18 @@ void crass_hip_destroy(crass_hip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
+    c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
+    if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->r_packed.release(); c->r_word_off.release(); c->r_lengths.release(); c->r_header_id.release();
     c->r_exc_mask.release(); c->r_exc_read.release(); c->r_exc_off.release(); c->r_exc_bytes.release();
     c->d_mask.release(); c->d_word_prefix.release(); c->d_block_sums.release(); c->d_idx.release(); c->d_count.release();
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
     c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
-    c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
+    c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -249,11 +275,11 @@ static int alloc_scratch(crass_hip_ctx *c)
     HIPCHK(c, c->d_word_prefix.ensure(n_words + 1));
     HIPCHK(c, c->d_block_sums.ensure((n_words + 255) / 256 + 2));
     HIPCHK(c, c->d_idx.ensure(n + 1));
-    HIPCHK(c, c->d_count.ensure(4));
+    HIPCHK(c, c->d_count.ensure(8));
     HIPCHK(c, c->d_found.ensure(n + 1));
     HIPCHK(c, c->d_hit_info.ensure(n + 1));
     HIPCHK(c, c->d_ss_used.ensure(4));
-    HIPCHK(c, c->h_count.ensure(4));
+    HIPCHK(c, c->h_count.ensure(8));
     HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
     return CRASS_OK;
 }
@@ -442,6 +468,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     return CRASS_OK;
 }
 
+// 2^26 survivors = 100 M+ read shards at the ~2 % filter pass rate; the slot pool stays below 2^31 words
+static const uint64_t kDenseMaxSurvivors = 1ull << 26;
+
 // Fast path of the pass-1 sink: one chunk, fixed start/stop slots, no exception reads.  Returns
 // CRASS_ERR_STATE when it does not apply (the caller then uses the host-loop path).
 static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
@@ -450,7 +479,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
     if (lds.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
     const uint32_t stride = c->dr_stride;
     const uint64_t pool_cap = std::max<uint64_t>(n_surv * (uint64_t)lds.ss_cap, 1u << 16);
-    if (n_surv == 0 || n_surv > (1u << 20) || lds.ss_cap > 64 || (stride & 15)) return CRASS_ERR_STATE;
+    if (n_surv == 0 || n_surv > kDenseMaxSurvivors || pool_cap >= (1ull << 31) || lds.ss_cap > 64 || (stride & 15)) return CRASS_ERR_STATE;
     crass_hip_ctx::P1Dense &D = c->dense;
     HIPCHK(c, c->d_surv.ensure(n_surv));
     HIPCHK(c, c->d_dr.ensure(n_surv * stride));
@@ -490,27 +519,54 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
     HIPCHK(c, D.h_nss.ensure(nf)); HIPCHK(c, D.h_dr_len.ensure(nf)); HIPCHK(c, D.h_dr.ensure(nf * stride + 16));
     HIPCHK(c, D.h_ss.ensure(nf * (uint64_t)lds.ss_cap + 16));
     c->have_rep = false;
+    c->have_dev_tokens = false;
     if (nf && nf < (1u << 22)) {
         uint32_t tsize = 1024;
         while (tsize < nf * 2) tsize <<= 1;
         HIPCHK(c, c->dd_keys.ensure(tsize)); HIPCHK(c, c->dd_first.ensure(tsize)); HIPCHK(c, c->dd_slot.ensure(nf));
         HIPCHK(c, c->dd_rep.ensure(nf)); HIPCHK(c, c->dd_hash.ensure(nf)); HIPCHK(c, c->h_rep.ensure(nf)); HIPCHK(c, c->h_hash.ensure(nf));
+        HIPCHK(c, c->dd_map.ensure(nf)); HIPCHK(c, c->dd_dx_chars.ensure(nf * stride)); HIPCHK(c, c->dd_dx_len.ensure(nf));
+        HIPCHK(c, c->dd_dx_hash.ensure(nf)); HIPCHK(c, c->h_dmap.ensure(nf));
         HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, (uint32_t)nf, c->dd_keys.p, c->dd_first.p, tsize, c->dd_hash.p,
                                    c->dd_slot.p, c->dd_rep.p, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_rep.p, c->dd_rep.p, nf * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_hash.p, c->dd_hash.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
+        // distinct strings in first-occurrence order and every candidate's rank among them, exact
+        HIPCHK(c, hipMemsetAsync(c->d_count.p + 4, 0, 8, c->stream));            // [4] = n distinct, [5] = mismatch flag
+        HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, (uint32_t)nf, c->dd_rep.p, c->d_mask.p, c->d_word_prefix.p,
+                                   c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->dd_map.p, c->dd_dx_chars.p,
+                                   c->dd_dx_len.p, c->dd_dx_hash.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_count.p + 4, c->d_count.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_dmap.p, c->dd_map.p, nf * 4, hipMemcpyDeviceToHost, c->stream));
         c->have_rep = true;
     }
     if (nf) {
-        HIPCHK(c, hipMemcpyAsync(D.h_dr.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, c->stream));          // merge needs these first
-        HIPCHK(c, hipMemcpyAsync(D.h_dr_len.p, D.d_dr_len.p, nf * 2, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(D.h_read.p, D.d_read.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(D.h_ss_off.p, D.d_ss_off.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(D.h_low.p, D.d_low.p, nf, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(D.h_replen.p, D.d_replen.p, nf * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(D.h_nss.p, D.d_nss.p, nf * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(D.h_ss.p, D.d_ss.p, nf * (uint64_t)lds.ss_cap * 4, hipMemcpyDeviceToHost, c->stream));
+        // the per-candidate records go out on the copy stream; the merge only needs the distinct strings
+        HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_gathered, 0));
+        hipStream_t cs = c->copy_stream;
+        HIPCHK(c, hipMemcpyAsync(D.h_dr.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipMemcpyAsync(D.h_dr_len.p, D.d_dr_len.p, nf * 2, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipMemcpyAsync(D.h_read.p, D.d_read.p, nf * 8, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipMemcpyAsync(D.h_ss_off.p, D.d_ss_off.p, nf * 8, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipMemcpyAsync(D.h_low.p, D.d_low.p, nf, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipMemcpyAsync(D.h_replen.p, D.d_replen.p, nf * 4, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipMemcpyAsync(D.h_nss.p, D.d_nss.p, nf * 4, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipMemcpyAsync(D.h_ss.p, D.d_ss.p, nf * (uint64_t)lds.ss_cap * 4, hipMemcpyDeviceToHost, cs));
+        if (c->have_rep) {
+            HIPCHK(c, hipMemcpyAsync(c->h_rep.p, c->dd_rep.p, nf * 4, hipMemcpyDeviceToHost, cs));
+            HIPCHK(c, hipMemcpyAsync(c->h_hash.p, c->dd_hash.p, nf * 8, hipMemcpyDeviceToHost, cs));
+        }
+        c->bulk_pending = true;
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->have_rep && c->h_count.p[5] == 0) {
+            const uint64_t nd = c->h_count.p[4];
+            HIPCHK(c, c->h_dx_chars.ensure(nd * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(nd)); HIPCHK(c, c->h_dx_hash.ensure(nd));
+            HIPCHK(c, hipMemcpyAsync(c->h_dx_chars.p, c->dd_dx_chars.p, nd * stride, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_dx_len.p, c->dd_dx_len.p, nd * 2, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_dx_hash.p, c->dd_dx_hash.p, nd * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->n_dx = nd;
+            c->have_dev_tokens = true;
+        }
     }
     D.n = nf;
     D.active = true;
@@ -522,6 +578,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     if (!c) return CRASS_ERR_INVALID_ARG;
     if (!c->have_reads) return CRASS_ERR_STATE;
     (void)hipSetDevice(c->device);
+    c->wait_bulk();
     c->have_pass1 = c->have_merge = c->have_pass2 = false;
     const uint64_t n = c->R.n_reads;
     const uint64_t n_words = (n + 63) / 64;
@@ -551,8 +608,9 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     uint64_t n_surv = c->h_count.p[0];
     c->dense.active = false;
     c->have_rep = false;
+    c->have_dev_tokens = false;
     c->have_distinct = false;
-    const bool try_dense = use_filter && c->R.n_exc == 0 && n_surv > 0 && n_surv <= (1u << 20);
+    const bool try_dense = use_filter && c->R.n_exc == 0 && n_surv > 0 && n_surv <= kDenseMaxSurvivors;
     std::vector<uint64_t> surv_idx;
     // the survivor kernel reads its count from d_count[1] (chunk-local bound is passed separately)
     {
@@ -631,6 +689,7 @@ int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     if (!c->have_pass1) return CRASS_ERR_STATE;
+    c->wait_bulk();
     if (c->dense.active) {
         const crass_hip_ctx::P1Dense &D = c->dense;
         o->n = D.n; o->read_idx = D.h_read.p; o->low_lexi = D.h_low.p; o->repeat_len = D.h_replen.p; o->n_ss = D.h_nss.p;
@@ -648,50 +707,40 @@ int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
 // ------------------------------------------------------------------------------------------
 // merge + patterns
 // ------------------------------------------------------------------------------------------
-static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pats)
+static int install_patterns(crass_hip_ctx *c, const StringArena &pats)
 {
-    c->patterns = pats;
+    c->n_installed_patterns = (uint32_t)pats.size();
     c->have_patterns = false;
     c->cnt.n_patterns = (uint32_t)pats.size();
     if (pats.empty()) { c->cnt.ac_states = 0; return CRASS_OK; }
-    for (const auto &p : pats) if (p.empty() || p.size() > 255) return CRASS_ERR_UNSUPPORTED;
-    HostAutomaton H;
+    for (size_t i = 0; i < pats.size(); i++) if (pats.len(i) == 0 || pats.len(i) > 255) return CRASS_ERR_UNSUPPORTED;
+    HostAutomaton &H = c->H;
     HostAnchors HK;
     const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
     const double tb0 = now_ms();
-    double tb1;
-    {
-        std::thread anchors_thread([&]() { build_anchors(HK, pats); });   // independent of the automaton
-        build_automaton(H, pats);
-        tb1 = now_ms();
-        anchors_thread.join();
-    }
+    build_automaton_and_anchors(H, HK, pats);
     const double tb2 = now_ms();
     DevAutomaton A{};
     A.n_states = H.n_states; A.n_sym1 = H.n_sym1;
     memcpy(A.sym, H.sym, 256);
     (void)hipSetDevice(c->device);
+    // the packed-read scans need the 4-column table only; the full byte-symbol table goes up on demand
+    // (ensure_full_automaton: full scans without anchors, exception reads)
+    c->full_automaton_uploaded = false;
     if (H.n_states <= 65535) {
-        std::vector<uint16_t> g16(H.go.size());
-        for (size_t i = 0; i < H.go.size(); i++) g16[i] = (uint16_t)H.go[i];
-        HIPCHK(c, c->a_go16.ensure(g16.size()));
-        HIPCHK(c, hipMemcpyAsync(c->a_go16.p, g16.data(), g16.size() * 2, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, c->a_go4.ensure(H.go4.size()));
         HIPCHK(c, hipMemcpyAsync(c->a_go4.p, H.go4.data(), H.go4.size() * 2, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));     // g16 is a local
-        A.go16 = c->a_go16.p; A.go4 = c->a_go4.p; A.acgt_ok = 1;
+        A.go4 = c->a_go4.p; A.acgt_ok = 1;
     } else {
-        HIPCHK(c, c->a_go32.ensure(H.go.size()));
-        HIPCHK(c, hipMemcpyAsync(c->a_go32.p, H.go.data(), H.go.size() * 4, hipMemcpyHostToDevice, c->stream));
-        A.go32 = c->a_go32.p; A.acgt_ok = 0;
+        HIPCHK(c, c->a_go4w.ensure(H.go4w.size()));
+        HIPCHK(c, hipMemcpyAsync(c->a_go4w.p, H.go4w.data(), H.go4w.size() * 4, hipMemcpyHostToDevice, c->stream));
+        A.go4w = c->a_go4w.p; A.acgt_ok = 0;
     }
     HIPCHK(c, c->a_out.ensure(H.out_len.size()));
     HIPCHK(c, hipMemcpyAsync(c->a_out.p, H.out_len.data(), H.out_len.size() * 2, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     A.out_len = c->a_out.p;
     HIPCHK(c, c->a_out_pid.ensure(H.out_pid.size()));
     HIPCHK(c, hipMemcpyAsync(c->a_out_pid.p, H.out_pid.data(), H.out_pid.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     A.out_pid = c->a_out_pid.p;
     c->have_pat_token = false;
     c->A = A;
@@ -700,14 +749,36 @@ static int install_patterns(crass_hip_ctx *c, const std::vector<std::string> &pa
     if (HK.ok) {
         HIPCHK(c, c->a_anchor.ensure(HK.table.size()));
         HIPCHK(c, hipMemcpyAsync(c->a_anchor.p, HK.table.data(), HK.table.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->K.table = c->a_anchor.p; c->K.log_size = HK.log_size; c->K.s1 = HK.s1; c->K.s2 = HK.s2; c->K.m1 = HK.m1;
+        c->K.table = c->a_anchor.p; c->K.log_size = HK.log_size; c->K.mode = HK.mode; c->K.s1 = HK.s1; c->K.s2 = HK.s2; c->K.m1 = HK.m1;
         c->K.m2 = HK.m2; c->K.n_keys = HK.n_keys;
         c->have_anchors = true;
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));        // HK's table is a local
     c->have_patterns = true;
     c->cnt.ac_states = H.n_states;
-    if (prof) fprintf(stderr, "[crass_merge] automaton %.3f ms (+%.3f ms waiting for anchors), uploads %.3f ms\n", tb1 - tb0, tb2 - tb1, now_ms() - tb2);
+    if (prof) fprintf(stderr, "[crass_merge] automaton + anchors %.3f ms, uploads %.3f ms\n", tb2 - tb0, now_ms() - tb2);
+    return CRASS_OK;
+}
+
+// full byte-symbol transition table: only the scans that cannot use the 4-column table need it
+static int ensure_full_automaton(crass_hip_ctx *c)
+{
+    if (c->full_automaton_uploaded) return CRASS_OK;
+    const HostAutomaton &H = c->H;
+    if (H.n_states <= 65535) {
+        std::vector<uint16_t> g16(H.go.size());
+        for (size_t i = 0; i < H.go.size(); i++) g16[i] = (uint16_t)H.go[i];
+        HIPCHK(c, c->a_go16.ensure(g16.size()));
+        HIPCHK(c, hipMemcpyAsync(c->a_go16.p, g16.data(), g16.size() * 2, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));     // g16 is a local
+        c->A.go16 = c->a_go16.p;
+    } else {
+        HIPCHK(c, c->a_go32.ensure(H.go.size()));
+        HIPCHK(c, hipMemcpyAsync(c->a_go32.p, H.go.data(), H.go.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->A.go32 = c->a_go32.p;
+    }
+    c->full_automaton_uploaded = true;
     return CRASS_OK;
 }
 
@@ -717,6 +788,10 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
 {
     if (!c) return CRASS_ERR_INVALID_ARG;
     const double t0 = now_ms();
+    if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens &&
+        merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
+                            c->prm.kmer_clust_size))
+        return finish_merge(c, t0);
     if (!dr_chars) {
         if (!c->have_pass1) return CRASS_ERR_STATE;
         dr_chars = c->cand_dr(); dr_len = c->cand_dr_len(); dr_stride = c->dr_stride; n = c->n_cand();
@@ -735,19 +810,15 @@ static int finish_merge(crass_hip_ctx *c, double t0)
     c->have_pass2 = false;
     int s = install_patterns(c, c->merge.patterns);
     if (s == CRASS_OK && c->have_patterns) {
-        // token of every pattern's low-lexi form (DRLowLexi: tmp_dr < rev_comp ? tmp_dr : rev_comp),
-        // resolved once per pattern instead of once per recruited read
-        std::vector<uint32_t> pt(c->merge.patterns.size());
-        for (size_t i = 0; i < pt.size(); i++) {
-            const std::string &p = c->merge.patterns[i];
-            const std::string rc = reverse_complement(p);
-            pt[i] = c->merge.tokens.get(p < rc ? p : rc);
-        }
+        // token of every pattern's low-lexi form, resolved once per pattern (merge.cpp) instead of once per
+        // recruited read
+        const std::vector<uint32_t> &pt = c->merge.pat_token;
         HIPCHK(c, c->a_pat_token.ensure(pt.size()));
         HIPCHK(c, hipMemcpyAsync(c->a_pat_token.p, pt.data(), pt.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->have_pat_token = true;
     }
+    c->wait_bulk();            // the per-candidate records are in host memory when the merge returns
     c->cnt.ms_merge_host = (float)(now_ms() - t0);
     return s;
 }
@@ -755,6 +826,7 @@ static int finish_merge(crass_hip_ctx *c, double t0)
 static void ensure_distinct(crass_hip_ctx *c)
 {
     if (c->have_distinct) return;
+    if (c->dense.active && c->have_dev_tokens) { c->have_distinct = true; return; }   // straight from the device
     const uint64_t n = c->n_cand();
     const char *dr = c->cand_dr();
     const uint16_t *len = c->cand_dr_len();
@@ -791,8 +863,14 @@ int crass_hip_get_distinct(crass_hip_ctx *c, crass_distinct *o)
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     if (!c->have_pass1) return CRASS_ERR_STATE;
     ensure_distinct(c);
-    o->n_distinct = c->dx_len.size(); o->dr_stride = c->dr_stride; o->dr_len = c->dx_len.data(); o->dr_chars = c->dx_chars.data();
-    o->n_candidates = c->dx_map.size(); o->cand_distinct = c->dx_map.data();
+    o->dr_stride = c->dr_stride;
+    if (c->dense.active && c->have_dev_tokens) {
+        o->n_distinct = c->n_dx; o->dr_len = c->h_dx_len.p; o->dr_chars = c->h_dx_chars.p;
+        o->n_candidates = c->dense.n; o->cand_distinct = c->h_dmap.p;
+    } else {
+        o->n_distinct = c->dx_len.size(); o->dr_len = c->dx_len.data(); o->dr_chars = c->dx_chars.data();
+        o->n_candidates = c->dx_map.size(); o->cand_distinct = c->dx_map.data();
+    }
     return CRASS_OK;
 }
 
@@ -803,11 +881,15 @@ int crass_hip_merge_distinct(crass_hip_ctx *c, const char *dr_chars, const uint1
     if (!c->have_pass1) return CRASS_ERR_STATE;
     const double t0 = now_ms();
     ensure_distinct(c);
-    if (my_offset + c->dx_len.size() > n_global) return CRASS_ERR_INVALID_ARG;
+    const bool dev = c->dense.active && c->have_dev_tokens;
+    const uint64_t my_nd = dev ? c->n_dx : c->dx_len.size();
+    const uint32_t *my_map = dev ? c->h_dmap.p : c->dx_map.data();
+    const size_t my_n = dev ? (size_t)c->dense.n : c->dx_map.size();
+    if (my_offset + my_nd > n_global) return CRASS_ERR_INVALID_ARG;
     merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n_global, c->prm.kmer_clust_size);
     // tokens of this context's own candidates through their distinct index
-    std::vector<uint32_t> own(c->dx_map.size());
-    for (size_t k = 0; k < own.size(); k++) own[k] = c->merge.cand_token[my_offset + c->dx_map[k]];
+    std::vector<uint32_t> own(my_n);
+    for (size_t k = 0; k < own.size(); k++) own[k] = c->merge.cand_token[my_offset + my_map[k]];
     c->merge.cand_token.swap(own);
     return finish_merge(c, t0);
 }
@@ -817,10 +899,10 @@ int crass_hip_get_merge(const crass_hip_ctx *c, crass_merge_view *o)
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     if (!c->have_merge) return CRASS_ERR_STATE;
     const MergeResult &m = c->merge;
-    o->n_tokens = m.tokens.size(); o->tok_chars = m.tok_chars.data(); o->tok_off = m.tok_off.data();
+    o->n_tokens = m.tokens.size(); o->tok_chars = m.tokens.strings.chars.data(); o->tok_off = m.tokens.strings.off.data();
     o->n_candidates = m.cand_token.size(); o->cand_token = m.cand_token.data();
     o->n_groups = (uint32_t)m.groups.size(); o->grp_tokens = m.grp_tokens.data(); o->grp_off = m.grp_off.data();
-    o->n_patterns = (uint32_t)m.patterns.size(); o->pat_chars = m.pat_chars.data(); o->pat_off = m.pat_off.data();
+    o->n_patterns = (uint32_t)m.patterns.size(); o->pat_chars = m.patterns.chars.data(); o->pat_off = m.patterns.off.data();
     o->pat_group = m.pat_group.data(); o->next_free_gid = m.next_free_gid;
     return CRASS_OK;
 }
@@ -828,8 +910,8 @@ int crass_hip_get_merge(const crass_hip_ctx *c, crass_merge_view *o)
 int crass_hip_set_patterns(crass_hip_ctx *c, const char *const *patterns, const uint32_t *lengths, uint32_t n)
 {
     if (!c || (n && (!patterns || !lengths))) return CRASS_ERR_INVALID_ARG;
-    std::vector<std::string> pats;
-    for (uint32_t i = 0; i < n; i++) pats.emplace_back(patterns[i], lengths[i]);
+    StringArena pats;
+    for (uint32_t i = 0; i < n; i++) pats.push(patterns[i], lengths[i]);
     c->have_pass2 = false;
     return install_patterns(c, pats);
 }
@@ -846,7 +928,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     c->have_pass2 = false;
     c->cnt.n_pass2_found = 0;
     // findSingletons is only called when the non-redundant set is non-empty (WorkHorse.cpp:373)
-    if (c->patterns.empty()) { c->have_pass2 = true; return CRASS_OK; }
+    if (c->n_installed_patterns == 0) { c->have_pass2 = true; return CRASS_OK; }
     if (!c->have_patterns) return CRASS_ERR_STATE;
     const uint64_t n = c->R.n_reads;
     const uint64_t n_words = (n + 63) / 64;
@@ -867,6 +949,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         if (ae == hipSuccess) anchors = true;
         else if (ae != hipErrorNotSupported) { c->last_hip = (int)ae; return CRASS_ERR_HIP; }
     }
+    if (!anchors || c->R.n_exc) { int fs = ensure_full_automaton(c); if (fs) return fs; }
     if (!anchors) {
         hipError_t re = launch_recruit_lds(c->R, c->A, c->d_found.p, c->d_mask.p, c->d_hit_info.p, c->stream);
         lds = (re == hipSuccess);
@@ -941,11 +1024,12 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         if (takeA) { ia++; while (ia < n_hits && !hit_valid(ia)) ia++; }
         else { ib++; while (ib < nb && !exc_valid(ib)) ib++; }
     }
-    if (c->have_merge && c->merge.tokens.size() + 1 != c->merge.tok_off.size()) c->merge.flatten();   // pass 2 added tokens
     c->have_pass2 = true;
     c->cnt.ms_sink_host += (float)(now_ms() - t0);
     c->cnt.n_pass2_found = c->q_read.size();
     c->cnt.used_lds_automaton = anchors ? 2 : (lds ? 1 : 0);     // 2 = anchor filter + exact list scan
+    c->cnt.anchor_keys = anchors ? c->K.n_keys : 0;
+    c->cnt.anchor_table_kind = !anchors ? 0 : (c->K.log_size > 15 ? 2 : c->K.mode);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->cnt.ms_recruit = ms;
     (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->cnt.ms_recruit_finish = ms;

@@ -53,11 +53,12 @@ struct RecruitOut {
 
 // pass-2 automaton (byte-wise Aho-Corasick, goto fully resolved)
 struct DevAutomaton {
-    const uint16_t *go16;         // [n_states][n_sym1] when n_states <= 65535
-    const uint32_t *go32;         // otherwise
+    const uint16_t *go16;         // [n_states][n_sym1] when n_states <= 65535 (uploaded on demand: full scans and
+    const uint32_t *go32;         // otherwise                                   exception reads only)
     const uint16_t *out_len;      // [n_states] longest pattern ending at the state (0 = none)
     const uint32_t *out_pid;      // [n_states] index of that pattern in the pattern list
     const uint16_t *go4;          // [n_states][4] ACGT-only compact table (packed reads), may be nullptr
+    const uint32_t *go4w;         // the same with 32-bit entries when n_states > 65535, may be nullptr
     uint32_t n_states;
     uint32_t n_sym1;              // symbols + 1 (symbol 0 = byte in no pattern)
     uint8_t  sym[256];            // byte -> symbol
@@ -68,8 +69,10 @@ struct DevAutomaton {
 // starts at offset 0..7 of a pattern, as 32-bit packed values; lives in LDS.
 // h_i(V) = mul_u24(V ^ (V >> s_i), m_i) >> (32 - log_size)   (v_mul_u32_u24 is full rate)
 struct DevAnchors {
-    const uint32_t *table;        // [1 << log_size]; unused slots hold a member key
+    const uint32_t *table;        // [1 << log_size]; mode 0: one key per slot (unused slots hold a member key);
+                                  // mode 1: two 16-bit fingerprints per slot (bucketed cuckoo, superset filter)
     uint32_t log_size;
+    uint32_t mode;
     uint32_t s1, s2, m1, m2;
     uint32_t n_keys;
 };
@@ -125,6 +128,9 @@ hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint6
                                const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
                                const uint32_t *ss_pool, uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
                                uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr, uint32_t *g_ss, hipStream_t st);
+hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, uint32_t n, const uint32_t *rep,
+                            uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
+                            uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash, hipStream_t st);
 hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, uint32_t n, unsigned long long *keys,
                             uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st);
 SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P);

@@ -1490,6 +1490,76 @@ hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t str
     return hipGetLastError();
 }
 
+// ---- device-side token ranks: distinct strings in first-occurrence order ----
+// bit k of `mask` = candidate k is the first occurrence of its string; every other candidate is compared
+// byte for byte with its representative, so a 64-bit hash collision between different strings is
+// DETECTED (flag) and the host then takes its plain path.
+__global__ __launch_bounds__(256) void k_dx_flag(const char *dr, const uint16_t *dr_len, uint32_t stride, uint32_t n, const uint32_t *rep,
+                                                  uint64_t *mask, uint32_t *d_mismatch)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_rep = false;
+    if (k < n) {
+        const uint32_t f = rep[k];
+        is_rep = (f == k);
+        if (!is_rep) {
+            bool same = f < k && dr_len[f] == dr_len[k];
+            if (same) {
+                const uint4 *a = reinterpret_cast<const uint4 *>(dr + (uint64_t)k * stride);
+                const uint4 *b = reinterpret_cast<const uint4 *>(dr + (uint64_t)f * stride);
+                for (uint32_t i = 0; i < stride / 16; i++) {          // slots are zero padded: whole-slot compare
+                    const uint4 x = a[i], y = b[i];
+                    same = same && x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w;
+                }
+            }
+            if (!same) atomicOr(d_mismatch, 1u);
+        }
+    }
+    const uint64_t m = __ballot(is_rep);
+    if ((threadIdx.x & 63) == 0 && k < n) mask[k >> 6] = m;
+}
+
+// dmap[k] = rank of k's representative among the first occurrences (token = rank + 2 on one GPU)
+__global__ __launch_bounds__(256) void k_dx_assign(const uint32_t *rep, uint32_t n, const uint64_t *mask, const uint32_t *word_prefix,
+                                                    const uint32_t *block_sums, uint32_t *dmap)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t f = rep[k], w = f >> 6;
+    dmap[k] = block_sums[w >> 8] + word_prefix[w] + (uint32_t)__popcll(mask[w] & ((1ull << (f & 63)) - 1ull));
+}
+
+__global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const uint32_t *d_nd, uint32_t n_max, const char *dr,
+                                                    const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, char *out_chars,
+                                                    uint16_t *out_len, uint64_t *out_hash)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nd = *d_nd;
+    if (nd > n_max) nd = n_max;
+    if (j >= nd) return;
+    const uint64_t k = dx_idx[j];
+    const uint4 *src = reinterpret_cast<const uint4 *>(dr + k * stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(out_chars + (uint64_t)j * stride);
+    for (uint32_t i = 0; i < stride / 16; i++) dst[i] = src[i];
+    out_len[j] = dr_len[k];
+    out_hash[j] = hash[k];
+}
+
+// needs stride % 16 == 0; mask / word_prefix / block_sums / dx_idx are scratch of >= n bits / words
+hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, uint32_t n, const uint32_t *rep,
+                            uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
+                            uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const unsigned nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, n, rep, mask, d_mismatch);
+    hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, n, mask, word_prefix, block_sums, dmap);
+    hipLaunchKernelGGL(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash);
+    return hipGetLastError();
+}
+
 SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P)
 {
     SurvLds l;
@@ -1655,22 +1725,37 @@ hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const ui
 // ~n_keys * L/8 / 4^16) are removed by the exact automaton scan of the flagged reads
 // (k_recruit_list), which also yields ACISM's first-callback (end, length).
 // ------------------------------------------------------------------------------------
+// MODE 0: exact keys in LDS, 1: buckets of two 16-bit fingerprints in LDS, 2: exact keys in global memory
+template <int MODE>
 static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_t V, const DevAnchors &K, uint32_t rshift)
 {
     // (cast: __umul24 is declared returning int, a plain >> would be an arithmetic shift)
-    uint32_t i1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1) >> rshift;
-    uint32_t i2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2) >> rshift;
-    const uint32_t a = tab[i1], b = tab[i2];            // both probes always issued: independent LDS reads, no branches
+    const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1);
+    const uint32_t h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
+    const uint32_t a = tab[h1 >> rshift], b = tab[h2 >> rshift];   // both probes always issued: independent reads, no branches
+    if (MODE == 1) {
+        // fingerprint = low halfword of h1 ^ h2 (either product alone shares too many input bits with its own
+        // bucket index), replicated into both halves
+        const uint32_t hx = h1 ^ h2;
+        const uint32_t ff = __builtin_amdgcn_perm(hx, hx, 0x01000100u);
+        // a halfword of (slot ^ ff) is zero <=> that fingerprint matches; min(x, 1) per halfword keeps 1 unless zero
+        const uint32_t t = pk_min_u16(a ^ ff, 0x00010001u) & pk_min_u16(b ^ ff, 0x00010001u);
+        return t != 0x00010001u;
+    }
     return (a == V) | (b == V);
 }
 
-template <int W, int THREADS>     // W = uniform stride in words (0: ragged / any stride)
+template <int W, int THREADS, int MODE>     // W = uniform stride in words (0: ragged / any stride)
 __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchors K, const uint8_t *found_flag, uint64_t *hitmask)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
     const uint32_t tsize = 1u << K.log_size;
-    for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds[i] = K.table[i];
-    __syncthreads();
+    const uint32_t *ak_lds = K.table;                   // key sets too large for LDS are probed in global memory (L2)
+    if (MODE != 2) {
+        for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds_buf[i] = K.table[i];
+        __syncthreads();
+        ak_lds = ak_lds_buf;
+    }
     const uint32_t mask = 32u - K.log_size;          // right shift that keeps the top log_size bits
     const uint64_t n_tiles = (R.n_reads + 63) / 64;
     const int lane = threadIdx.x & 63;
@@ -1692,7 +1777,7 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
 #pragma unroll
                     for (int h = 0; h < 2 * W - 1; h++) {
                         uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
-                        bool hit = anchor_probe(ak_lds, V, K, mask);
+                        bool hit = anchor_probe<MODE>(ak_lds, V, K, mask);
                         flag = flag | (hit & ((uint32_t)h <= h_max));
                     }
                 } else {
@@ -1700,8 +1785,8 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
                     uint32_t lo = g[0];
                     for (uint32_t h = 0; h <= h_max; h += 2) {
                         uint32_t hi = ((h >> 1) + 1 < nw) ? g[(h >> 1) + 1] : 0u;
-                        if (anchor_probe(ak_lds, lo, K, mask)) flag = true;
-                        if (h + 1 <= h_max && anchor_probe(ak_lds, (lo >> 16) | (hi << 16), K, mask)) flag = true;
+                        if (anchor_probe<MODE>(ak_lds, lo, K, mask)) flag = true;
+                        if (h + 1 <= h_max && anchor_probe<MODE>(ak_lds, (lo >> 16) | (hi << 16), K, mask)) flag = true;
                         lo = hi;
                     }
                 }
@@ -1715,18 +1800,24 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
 hipError_t launch_anchor_filter(const DevReads &R, const DevAnchors &K, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st)
 {
     if (R.n_reads == 0) return hipSuccess;
-    const size_t lds = (size_t)4 << K.log_size;
-    if (lds > 128 * 1024) return hipErrorNotSupported;
+    const size_t tbytes = (size_t)4 << K.log_size;
+    const bool in_lds = tbytes <= 128 * 1024;
+    if (K.mode == 1 && !in_lds) return hipErrorInvalidValue;
+    const size_t lds = in_lds ? tbytes : 0;
     const uint64_t n_tiles = (R.n_reads + 63) / 64;
     constexpr int T = 1024;
     uint64_t blocks = (n_tiles + (T / 64) - 1) / (T / 64);
     const uint64_t cap = lds > 80 * 1024 ? 256 : (lds > 40 * 1024 ? 512 : 1024);
     if (blocks > cap) blocks = cap;
     hipError_t e;
+#define AK_LAUNCH_M(WW, MM)                                                                                             \
+    {                                                                                                                   \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_anchor_filter<WW, T, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                  \
+        hipLaunchKernelGGL((k_anchor_filter<WW, T, MM>), dim3((unsigned)blocks), dim3(T), lds, st, R, K, found_flag, hitmask); \
+    }
 #define AK_LAUNCH(WW)                                                                                                   \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_anchor_filter<WW, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return e;                                                                                      \
-    hipLaunchKernelGGL((k_anchor_filter<WW, T>), dim3((unsigned)blocks), dim3(T), lds, st, R, K, found_flag, hitmask);
+    if (!in_lds) AK_LAUNCH_M(WW, 2) else if (K.mode == 1) AK_LAUNCH_M(WW, 1) else AK_LAUNCH_M(WW, 0)
     switch (R.stride_words) {
         case 4: AK_LAUNCH(4) break;  case 5: AK_LAUNCH(5) break;  case 6: AK_LAUNCH(6) break;  case 7: AK_LAUNCH(7) break;
         case 8: AK_LAUNCH(8) break;  case 9: AK_LAUNCH(9) break;  case 10: AK_LAUNCH(10) break; case 11: AK_LAUNCH(11) break;
@@ -1735,6 +1826,7 @@ hipError_t launch_anchor_filter(const DevReads &R, const DevAnchors &K, const ui
         default: AK_LAUNCH(0) break;
     }
 #undef AK_LAUNCH
+#undef AK_LAUNCH_M
     return hipGetLastError();
 }
 
@@ -1757,6 +1849,7 @@ __global__ __launch_bounds__(256) void k_recruit_list(DevReads R, DevAutomaton A
         uint32_t c = word & 3u;
         word >>= 2;
         if (A.go4) state = A.go4[state * 4 + c];
+        else if (A.go4w) state = A.go4w[(size_t)state * 4 + c];
         else {
             uint32_t sy = c == 0 ? symA : c == 1 ? symC : c == 2 ? symG : symT;
             state = A.go16 ? (uint32_t)A.go16[(size_t)state * A.n_sym1 + sy] : A.go32[(size_t)state * A.n_sym1 + sy];

@@ -85,6 +85,39 @@ void TokenTable::grow()
 
 uint32_t TokenTable::add(const char *p, size_t n) { return add_hashed(p, n, hash(p, n)); }
 
+void TokenTable::reserve(size_t n_strings, size_t n_chars)
+{
+    size_t cap = slot_token.empty() ? 1024 : slot_token.size();
+    while (cap < (n_strings + 1) * 2) cap <<= 1;
+    if (cap != slot_token.size()) {
+        std::vector<uint32_t> nt(cap, 0);
+        std::vector<uint64_t> nh(cap, 0);
+        for (size_t i = 0; i < slot_token.size(); i++) if (slot_token[i]) {
+            size_t j = (size_t)slot_hash[i] & (cap - 1);
+            while (nt[j]) j = (j + 1) & (cap - 1);
+            nt[j] = slot_token[i]; nh[j] = slot_hash[i];
+        }
+        slot_token.swap(nt); slot_hash.swap(nh);
+    }
+    strings.chars.reserve(n_chars);
+    strings.off.reserve(n_strings + 1);
+}
+
+uint32_t TokenTable::add_unique_hashed(const char *p, size_t n, uint64_t h)
+{
+    if ((strings.size() + 1) * 2 > slot_token.size()) grow();
+    const size_t mask = slot_token.size() - 1;
+    size_t i = (size_t)h & mask;
+    for (; slot_token[i]; i = (i + 1) & mask) {
+        const uint32_t t = slot_token[i];
+        if (slot_hash[i] == h && strings.len(t - 2) == n && memcmp(strings.data(t - 2), p, n) == 0) return 0;
+    }
+    strings.push(p, n);
+    const uint32_t t = (uint32_t)strings.size() + 1;
+    slot_token[i] = t; slot_hash[i] = h;
+    return t;
+}
+
 uint32_t TokenTable::add_hashed(const char *p, size_t n, uint64_t h)
 {
     if ((strings.size() + 1) * 2 > slot_token.size()) grow();
@@ -99,19 +132,15 @@ uint32_t TokenTable::add_hashed(const char *p, size_t n, uint64_t h)
 
 void MergeResult::clear()
 {
-    tokens.clear(); cand_token.clear(); groups.clear(); patterns.clear(); pat_group.clear();
+    tokens.clear(); cand_token.clear(); groups.clear(); patterns.clear(); pat_group.clear(); pat_token.clear();
     next_free_gid = 1;
-    tok_chars.clear(); tok_off.clear(); grp_tokens.clear(); grp_off.clear(); pat_chars.clear(); pat_off.clear();
+    grp_tokens.clear(); grp_off.clear();
 }
 
 void MergeResult::flatten()
 {
-    tok_chars.clear(); tok_off.assign(1, 0);
-    tok_chars = tokens.strings.chars; tok_off = tokens.strings.off;
     grp_tokens.clear(); grp_off.assign(1, 0);
     for (const auto &g : groups) { grp_tokens.insert(grp_tokens.end(), g.begin(), g.end()); grp_off.push_back(grp_tokens.size()); }
-    pat_chars.clear(); pat_off.assign(1, 0);
-    for (const auto &s : patterns) { pat_chars.insert(pat_chars.end(), s.begin(), s.end()); pat_off.push_back(pat_chars.size()); }
 }
 
 namespace {
@@ -129,33 +158,39 @@ inline int acgt_code(unsigned char c)
 // table (variants of one DR share most k-mers, so it stays cache-resident); anything else falls
 // back to string keys.  Same lookups, same results, a fraction of the host time.
 struct KmerGid {
-    std::vector<uint32_t> key;                                  // code + 1, 0 = empty
-    std::vector<int32_t> gid;
+    struct Slot { uint32_t key; int32_t gid; };                  // key = code + 1, 0 = empty
+    std::vector<Slot> tab;
     size_t used = 0;
     std::unordered_map<std::string, int> other;
-    KmerGid() : key(1u << 14, 0), gid(1u << 14, 0) {}
+    explicit KmerGid(size_t expect = 0) : tab(1u << 14, Slot{0, 0})
+    {
+        size_t cap = tab.size();
+        while (cap < expect * 2 && cap < (1u << 22)) cap <<= 1;    // skip the early rehashes
+        if (cap != tab.size()) tab.assign(cap, Slot{0, 0});
+    }
     static size_t slot(uint32_t code, size_t mask) { return (size_t)((code * 0x9E3779B1u) >> 8) & mask; }
+    void prefetch(uint32_t code) const { __builtin_prefetch(&tab[slot(code, tab.size() - 1)]); }
     int32_t find(uint32_t code) const
     {
-        const size_t mask = key.size() - 1;
+        const size_t mask = tab.size() - 1;
         for (size_t i = slot(code, mask);; i = (i + 1) & mask) {
-            if (key[i] == 0) return 0;
-            if (key[i] == code + 1) return gid[i];
+            if (tab[i].key == 0) return 0;
+            if (tab[i].key == code + 1) return tab[i].gid;
         }
     }
     void put(uint32_t code, int32_t g)                           // insert or overwrite
     {
-        if ((used + 1) * 2 > key.size()) {
-            std::vector<uint32_t> ok; std::vector<int32_t> og;
-            ok.swap(key); og.swap(gid);
-            key.assign(ok.size() * 2, 0); gid.assign(ok.size() * 2, 0); used = 0;
-            for (size_t i = 0; i < ok.size(); i++) if (ok[i]) put(ok[i] - 1, og[i]);
+        if ((used + 1) * 2 > tab.size()) {
+            std::vector<Slot> old;
+            old.swap(tab);
+            tab.assign(old.size() * 2, Slot{0, 0}); used = 0;
+            for (const Slot &o : old) if (o.key) put(o.key - 1, o.gid);
         }
-        const size_t mask = key.size() - 1;
+        const size_t mask = tab.size() - 1;
         size_t i = slot(code, mask);
-        while (key[i] != 0 && key[i] != code + 1) i = (i + 1) & mask;
-        if (key[i] == 0) { key[i] = code + 1; used++; }
-        gid[i] = g;
+        while (tab[i].key != 0 && tab[i].key != code + 1) i = (i + 1) & mask;
+        if (tab[i].key == 0) { tab[i].key = code + 1; used++; }
+        tab[i].gid = g;
     }
 };
 
@@ -238,6 +273,7 @@ private:
     HostPool()
     {
         unsigned n = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
+        if (const char *e = getenv("CRASS_HOST_THREADS")) n = (unsigned)std::max(1, atoi(e));    // 1 = everything on the caller
         for (unsigned i = 0; i + 1 < n; i++) workers_.emplace_back([this, i] { loop(i); });
     }
     ~HostPool()
@@ -352,87 +388,132 @@ inline bool code16(const std::string &s, size_t pos, uint32_t &out)
     return true;
 }
 
+// A member of a DR group while the non-redundant set is computed: a view of the token string.
+struct Member {
+    uint32_t tok;          // token - 2
+    uint32_t len;
+    bool blank;
+};
+// 2-bit packing of an ACGT-only token of <= 64 bases (base i in bits 2i..2i+1) and of its reverse complement
+typedef unsigned __int128 u128;
+struct PackedDr {
+    u128 fwd, rev;
+    bool ok;
+};
+bool member_shorter_first(const Member &a, const Member &b) { return a.len < b.len; }     // sortLengthAssending
+bool member_kept(const Member &a) { return !a.blank; }
+
+void pack_dr(const char *p, size_t n, PackedDr &out)
+{
+    static const struct Tab { int8_t t[256]; Tab() { memset(t, -1, sizeof(t)); t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; } } tab;
+    out.fwd = out.rev = 0;
+    out.ok = n <= 64;
+    if (!out.ok) return;
+    uint64_t f[2] = {0, 0};
+    u128 rev = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int c = tab.t[(unsigned char)p[i]];
+        if (c < 0) { out.ok = false; return; }
+        f[i >> 5] |= (uint64_t)c << (2 * (i & 31));
+        rev = (rev << 2) | (unsigned)(3 - c);
+    }
+    out.fwd = ((u128)f[1] << 64) | f[0];
+    out.rev = rev;
+}
+
 // WorkHorse::removeRedundantRepeats (WorkHorse.cpp:612-645) with includeSubstring (:78-86).
 // A string is blanked iff some strictly shorter member (or its reverse complement) occurs in it
 // (equal-length members can only contain each other if identical, and tokens are distinct), so
-// the O(n^2) pairwise find() is replaced by an index of every member's leading 16 bytes: for
-// ACGT-only groups a 32-bit 2-bit code rolled along the haystack and looked up in a small
-// open-addressing table behind a bitmap pre-filter; byte-hash index otherwise.
-// The std::sort / std::partition calls are kept so that the surviving ORDER is what the
-// reference produces with the same libstdc++ (pass 2 depends on the set only).
-void remove_redundant(std::vector<std::string> &v)
+// the O(n^2) pairwise find() is replaced by an index of every member's leading 16 bases: for
+// ACGT-only groups the members are 2-bit packed, a window is one shift of a 128-bit integer, and
+// the index is a small open-addressing table behind a bitmap pre-filter; byte-hash index otherwise.
+// std::sort / std::partition run on the views with the reference's predicates, so the surviving
+// ORDER is what the reference produces with the same libstdc++ (the algorithms only see the
+// comparison results).
+void remove_redundant(std::vector<Member> &v, const StringArena &strs, const PackedDr *packed)
 {
-    std::sort(v.begin(), v.end(), shorter_first);
+    std::sort(v.begin(), v.end(), member_shorter_first);
     if (v.size() > 1) {
-        const size_t min_len = v.front().size();
-        std::vector<char> blank(v.size(), 0);
-        bool all_acgt = min_len >= 16;
-        for (size_t i = 0; i < v.size() && all_acgt; i++)
-            for (unsigned char c : v[i]) if (acgt_code(c) < 0) { all_acgt = false; break; }
+        const size_t min_len = v.front().len;
+        bool all_packed = min_len >= 16;
+        for (size_t i = 0; i < v.size() && all_packed; i++) all_packed = packed[v[i].tok].ok;
         if (min_len == 0) {
-            for (size_t j = 1; j < v.size(); j++) blank[j] = 1;    // an empty string is a substring of everything
-        } else if (all_acgt) {
-            // index: leading 16-mer code -> chain of members
+            for (size_t j = 1; j < v.size(); j++) v[j].blank = true;    // an empty string is a substring of everything
+        } else if (all_packed) {
+            // Members shorter than the longest are the only possible needles.  Variants of one DR mostly share
+            // their leading bases, so the needles are kept in an exact set keyed by (whole packed string,
+            // length); a 65536-bit map of the needles' leading 16-mers rejects almost every window first.
+            const uint32_t max_len = v.back().len;
+            size_t n_needles = 0;
+            while (n_needles < v.size() && v[n_needles].len < max_len) n_needles++;
             size_t cap = 64;
-            while (cap < v.size() * 4) cap <<= 1;
-            std::vector<int32_t> head(cap, -1), next(v.size(), -1);
-            std::vector<uint32_t> keyv(v.size());
-            std::vector<uint64_t> bitmap(1024, 0);                 // 65536-bit pre-filter
-            auto slot_of = [&](uint32_t key) { return (size_t)((key * 0x9E3779B1u) >> 7) & (cap - 1); };
+            while (cap < n_needles * 2 + 2) cap <<= 1;
+            std::vector<int32_t> slot(cap, -1);
+            std::vector<uint64_t> bitmap(1024, 0);
+            std::vector<uint32_t> lens;                              // distinct needle lengths, ascending
             auto bit_of = [&](uint32_t key) { return (uint32_t)((key * 0x85EBCA6Bu) >> 16); };
-            for (uint32_t i = 0; i < v.size(); i++) {
-                uint32_t key = 0;
-                code16(v[i], 0, key);
-                keyv[i] = key;
-                const size_t sl = slot_of(key);
-                next[i] = head[sl]; head[sl] = (int32_t)i;
-                const uint32_t b = bit_of(key);
+            auto slot_of = [&](u128 val, uint32_t len) {
+                const uint64_t h = ((uint64_t)val * 0x9E3779B97F4A7C15ull) ^ (((uint64_t)(val >> 64) + len) * 0xC2B2AE3D27D4EB4Full);
+                return (size_t)((h ^ (h >> 29)) & (cap - 1));
+            };
+            for (uint32_t i = 0; i < n_needles; i++) {
+                const u128 val = packed[v[i].tok].fwd;
+                size_t sl = slot_of(val, v[i].len);
+                while (slot[sl] >= 0) sl = (sl + 1) & (cap - 1);
+                slot[sl] = (int32_t)i;
+                const uint32_t b = bit_of((uint32_t)val);
                 bitmap[b >> 6] |= 1ull << (b & 63);
+                if (lens.empty() || lens.back() != v[i].len) lens.push_back(v[i].len);
             }
-            std::string rc;
             for (size_t j = 0; j < v.size(); j++) {
-                const std::string &s = v[j];
-                rc = reverse_complement(s);
+                const uint32_t sl = v[j].len;
+                if (sl == min_len) continue;                       // nothing is strictly shorter
+                const PackedDr &ps = packed[v[j].tok];
+                bool blank = false;
                 // t or revcomp(t) occurs in s  <=>  t occurs in s or in revcomp(s)
-                for (const std::string *hay : {&s, (const std::string *)&rc}) {
-                    uint32_t code = 0;
-                    for (size_t p = 0; p + 16 <= hay->size() && !blank[j]; p++) {
-                        if (p == 0) code16(*hay, 0, code);
-                        else code = (code >> 2) | ((uint32_t)acgt_code((unsigned char)(*hay)[p + 15]) << 30);
-                        const uint32_t b = bit_of(code);
+                for (int o = 0; o < 2 && !blank; o++) {
+                    u128 hay = o ? ps.rev : ps.fwd;
+                    for (uint32_t p = 0; p + min_len <= sl && !blank; p++, hay >>= 2) {     // the shortest needle must still fit
+                        const uint32_t b = bit_of((uint32_t)hay);
                         if (!(bitmap[b >> 6] >> (b & 63) & 1)) continue;
-                        for (int32_t i = head[slot_of(code)]; i >= 0; i = next[i]) {
-                            if (keyv[i] != code) continue;
-                            const std::string &t = v[(size_t)i];
-                            if (t.size() < s.size() && p + t.size() <= hay->size() && memcmp(hay->data() + p, t.data(), t.size()) == 0) { blank[j] = 1; break; }
+                        for (uint32_t tl : lens) {
+                            if (tl >= sl || p + tl > sl) break;    // ascending: the rest is longer still
+                            const u128 val = hay & ((((u128)1) << (2 * tl)) - 1);     // tl < sl <= 64
+                            for (size_t q = slot_of(val, tl); slot[q] >= 0; q = (q + 1) & (cap - 1)) {
+                                const Member &t = v[(size_t)slot[q]];
+                                if (t.len == tl && packed[t.tok].fwd == val) { blank = true; break; }
+                            }
+                            if (blank) break;
                         }
                     }
-                    if (blank[j]) break;
                 }
+                v[j].blank = blank;
             }
         } else {
             const size_t kAnchor = std::min<size_t>(16, min_len);
             std::unordered_multimap<uint64_t, uint32_t> index;
             index.reserve(v.size() * 2);
-            for (uint32_t i = 0; i < v.size(); i++) index.emplace(hash_bytes(v[i].data(), kAnchor), i);
+            for (uint32_t i = 0; i < v.size(); i++) index.emplace(hash_bytes(strs.data(v[i].tok), kAnchor), i);
             for (size_t j = 0; j < v.size(); j++) {
-                const std::string &s = v[j];
+                const std::string s = strs[v[j].tok];
                 const std::string rc = reverse_complement(s);
+                bool blank = false;
                 for (const std::string *hay : {&s, &rc}) {
-                    for (size_t p = 0; p + kAnchor <= hay->size() && !blank[j]; p++) {
+                    for (size_t p = 0; p + kAnchor <= hay->size() && !blank; p++) {
                         auto range = index.equal_range(hash_bytes(hay->data() + p, kAnchor));
                         for (auto it = range.first; it != range.second; ++it) {
-                            const std::string &t = v[it->second];
-                            if (t.size() < s.size() && p + t.size() <= hay->size() && memcmp(hay->data() + p, t.data(), t.size()) == 0) { blank[j] = 1; break; }
+                            const Member &t = v[it->second];
+                            if (t.len < s.size() && p + t.len <= hay->size() && memcmp(hay->data() + p, strs.data(t.tok), t.len) == 0) { blank = true; break; }
                         }
                     }
-                    if (blank[j]) break;
+                    if (blank) break;
                 }
+                v[j].blank = blank;
             }
         }
-        for (size_t j = 0; j < v.size(); j++) if (blank[j]) v[j].clear();
     }
-    v.erase(std::partition(v.begin(), v.end(), not_empty), v.end());
+    for (auto &m : v) if (m.len == 0) m.blank = true;             // empty strings never survive the partition
+    v.erase(std::partition(v.begin(), v.end(), member_kept), v.end());
 }
 
 } // namespace
@@ -465,17 +546,54 @@ static bool assign_tokens_from_rep(MergeResult &m, const char *dr_chars, const u
     return true;
 }
 
+static void cluster_and_patterns(MergeResult &m, int kmer_clust_size, double t0, double t1);
+
 void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
                       uint64_t n, int kmer_clust_size, const uint32_t *rep, const uint64_t *hash)
 {
-    const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
     const double t0 = prof_now();
     m.clear();
     if (!(rep && hash && assign_tokens_from_rep(m, dr_chars, dr_len, dr_stride, n, rep, hash))) {
         m.clear();
         assign_tokens(m, dr_chars, dr_len, dr_stride, n);
     }
-    const double t1 = prof_now();
+    cluster_and_patterns(m, kmer_clust_size, t0, prof_now());
+}
+
+bool merge_from_distinct(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, const uint64_t *dx_hash, uint32_t dr_stride,
+                         uint64_t n_distinct, const uint32_t *cand_distinct, uint64_t n, int kmer_clust_size)
+{
+    const double t0 = prof_now();
+    m.clear();
+    // the device hashed with the same function (checked here, a few threads) ...
+    std::atomic<int> bad{0};
+    const size_t chunk = 2048;
+    parallel_tasks((n_distinct + chunk - 1) / chunk, 8, [&](size_t c) {
+        const uint64_t lo = c * chunk, hi = std::min<uint64_t>(n_distinct, lo + chunk);
+        for (uint64_t j = lo; j < hi; j++)
+            if (dx_hash[j] != TokenTable::hash(dx_chars + j * (uint64_t)dr_stride, dx_len[j])) bad.store(1);
+    });
+    if (bad.load()) return false;
+    size_t n_chars = 0;
+    for (uint64_t j = 0; j < n_distinct; j++) n_chars += dx_len[j];
+    m.tokens.reserve(n_distinct, n_chars);
+    // ... and the insertion itself proves the strings are pairwise distinct
+    for (uint64_t j = 0; j < n_distinct; j++)
+        if (m.tokens.add_unique_hashed(dx_chars + j * (uint64_t)dr_stride, dx_len[j], dx_hash[j]) == 0) { m.clear(); return false; }
+    m.cand_token.resize(n);
+    uint32_t worst = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        worst = std::max(worst, cand_distinct[k]);
+        m.cand_token[k] = cand_distinct[k] + 2;
+    }
+    if (n && worst >= n_distinct) { m.clear(); return false; }
+    cluster_and_patterns(m, kmer_clust_size, t0, prof_now());
+    return true;
+}
+
+static void cluster_and_patterns(MergeResult &m, int kmer_clust_size, double t0, double t1)
+{
+    const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
     // createNonRedundantSet: cluster every token in ascending token order (std::map iteration).
     // The k-mer codes are order-independent and computed up front on several threads.
     const uint32_t ntok = m.tokens.size();
@@ -489,33 +607,67 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
         for (uint32_t t = (uint32_t)c * 256; t < std::min<uint32_t>(ntok, ((uint32_t)c + 1) * 256); t++)
             if (code_off[t + 1] > code_off[t]) kmer_codes(m.tokens.strings.data(t), m.tokens.strings.len(t), codes.data() + code_off[t]);
     });
-    KmerGid kmer_gid;
+    KmerGid kmer_gid((size_t)ntok * 6);                         // a variant adds about half a dozen new k-mers
     int next_gid = 1;
     std::vector<int> gid_of(ntok);
     std::vector<uint32_t> scratch_codes;
     std::vector<std::pair<int, int>> scratch_counts;
-    for (uint32_t t = 0; t < ntok; t++)
+    for (uint32_t t = 0; t < ntok; t++) {
+        // the table outgrows the caches on big inputs: start the next token's lookups while this one is processed
+        if (t + 1 < ntok) for (uint32_t q = code_off[t + 1]; q < code_off[t + 2]; q++) if (codes[q] >= 0) kmer_gid.prefetch((uint32_t)codes[q]);
         gid_of[t] = cluster_one(m.tokens.strings.data(t), m.tokens.strings.len(t), codes.data() + code_off[t], (int)(code_off[t + 1] - code_off[t]), next_gid,
                                 kmer_gid, kmer_clust_size, scratch_codes, scratch_counts);
+    }
     m.next_free_gid = next_gid;
     m.groups.assign((size_t)(next_gid - 1), {});
     for (uint32_t t = 0; t < m.tokens.size(); t++) m.groups[(size_t)gid_of[t] - 1].push_back(t + 2);
     const double t2 = prof_now();
     // per-group substring de-duplication is independent across groups: a few host threads
-    std::vector<std::vector<std::string>> survivors(m.groups.size());
+    std::vector<PackedDr> packed(ntok);
+    parallel_tasks((ntok + 511) / 512, 8, [&](size_t c) {
+        for (uint32_t t = (uint32_t)c * 512; t < std::min<uint32_t>(ntok, ((uint32_t)c + 1) * 512); t++)
+            pack_dr(m.tokens.strings.data(t), m.tokens.strings.len(t), packed[t]);
+    });
+    const double t2a = prof_now();
+    std::vector<std::vector<Member>> survivors(m.groups.size());
     {
         const size_t ng = m.groups.size();
         parallel_tasks(ng, m.tokens.size() < 2000 ? 1 : 16, [&](size_t g) {
-            std::vector<std::string> &clustered = survivors[g];
-            for (uint32_t tok : m.groups[g]) clustered.push_back(m.tokens.strings[tok - 2]);
-            remove_redundant(clustered);
+            std::vector<Member> &clustered = survivors[g];
+            clustered.reserve(m.groups[g].size());
+            for (uint32_t tok : m.groups[g]) clustered.push_back(Member{tok - 2, (uint32_t)m.tokens.strings.len(tok - 2), false});
+            remove_redundant(clustered, m.tokens.strings, packed.data());
         });
     }
+    const double t2b = prof_now();
+    if (prof) fprintf(stderr, "[crass_merge]   pack %.3f ms, remove_redundant %.3f ms\n", t2a - t2, t2b - t2a);
+    // every group contributes its survivors, then their reverse complements (WorkHorse.cpp:690-705)
+    const unsigned char *ctab = comp_table();
+    size_t n_pat = 0, n_pat_chars = 0;
+    for (const auto &g : survivors) { n_pat += 2 * g.size(); for (const Member &x : g) n_pat_chars += 2 * (size_t)x.len; }
+    m.patterns.chars.reserve(n_pat_chars); m.patterns.off.reserve(n_pat + 1);
+    m.pat_group.reserve(n_pat); m.pat_token.reserve(n_pat);
+    std::string rc;
     for (size_t g = 0; g < m.groups.size(); g++) {
-        const std::vector<std::string> &clustered = survivors[g];
-        const size_t first = m.patterns.size();
-        m.patterns.insert(m.patterns.end(), clustered.begin(), clustered.end());
-        for (size_t i = 0; i < clustered.size(); i++) m.patterns.push_back(reverse_complement(m.patterns[first + i]));
+        const std::vector<Member> &clustered = survivors[g];
+        for (const Member &x : clustered) m.patterns.push(m.tokens.strings.data(x.tok), x.len);
+        const size_t first_rc = m.patterns.size();
+        for (const Member &x : clustered) {
+            const char *p = m.tokens.strings.data(x.tok);
+            rc.resize(x.len);
+            for (uint32_t i = 0; i < x.len; i++) rc[i] = (char)ctab[(unsigned char)p[x.len - 1 - i] & 127];
+            m.patterns.push(rc);
+        }
+        // token of the low-lexi form (DRLowLexi: tmp_dr < rev_comp ? tmp_dr : rev_comp) of the pattern and of
+        // its reverse complement alike; a token string is normally low-lexi already
+        for (size_t i = 0; i < clustered.size(); i++) {
+            const Member &x = clustered[i];
+            const char *p = m.tokens.strings.data(x.tok);
+            const char *q = m.patterns.data(first_rc + i);
+            const int cmp = memcmp(p, q, x.len);
+            m.pat_token.push_back(cmp <= 0 ? x.tok + 2 : m.tokens.get(q, x.len));
+        }
+        for (size_t i = 0; i < clustered.size(); i++) m.pat_token.push_back(m.pat_token[m.pat_token.size() - clustered.size()]);
         m.pat_group.insert(m.pat_group.end(), 2 * clustered.size(), (uint32_t)(g + 1));
     }
     const double t3 = prof_now();
@@ -525,88 +677,104 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
                 t1 - t0, t2 - t1, t3 - t2, prof_now() - t3);
 }
 
-void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns)
+void build_automaton(HostAutomaton &a, const StringArena &patterns)
 {
     memset(a.sym, 0, sizeof(a.sym));
     uint32_t nsym = 0;
-    size_t total = 1;
+    for (char ch : patterns.chars) { const unsigned char c = (unsigned char)ch; if (!a.sym[c]) a.sym[c] = (uint8_t)++nsym; }
+    const size_t total = patterns.chars.size() + 1;
+    const size_t np = patterns.size();
     a.max_pat_len = 0;
-    for (const auto &p : patterns) {
-        total += p.size();
-        if (p.size() > a.max_pat_len) a.max_pat_len = (uint32_t)p.size();
-        for (unsigned char c : p) if (!a.sym[c]) a.sym[c] = (uint8_t)++nsym;
-    }
+    for (size_t i = 0; i < np; i++) if (patterns.len(i) > a.max_pat_len) a.max_pat_len = (uint32_t)patterns.len(i);
     const uint32_t S = nsym + 1;
     a.n_sym1 = S;
-    std::vector<int32_t> go(total * S, -1);
-    std::vector<uint16_t> term(total, 0);
-    std::vector<uint32_t> term_pid(total, 0);
+    const uint32_t NONE = 0xFFFFFFFFu;
+    std::vector<uint32_t> &go = a.go;                 // built in place: [state][symbol], trimmed to the used states below
+    go.assign(total * S, NONE);
+    std::vector<uint16_t> &term = a.out_len;
+    std::vector<uint32_t> &term_pid = a.out_pid;
+    term.assign(total, 0);
+    term_pid.assign(total, 0);
     uint32_t ns = 1;
-    uint32_t pid = 0;
-    for (const auto &p : patterns) {
+    for (size_t pid = 0; pid < np; pid++) {
+        const unsigned char *p = (const unsigned char *)patterns.data(pid);
+        const size_t n = patterns.len(pid);
         uint32_t s = 0;
-        for (unsigned char c : p) {
-            uint32_t sy = a.sym[c];
-            if (go[(size_t)s * S + sy] < 0) go[(size_t)s * S + sy] = (int32_t)ns++;
-            s = (uint32_t)go[(size_t)s * S + sy];
+        for (size_t i = 0; i < n; i++) {
+            uint32_t &g = go[(size_t)s * S + a.sym[p[i]]];
+            if (g == NONE) g = ns++;
+            s = g;
         }
-        if (p.size() > term[s]) { term[s] = (uint16_t)p.size(); term_pid[s] = pid; }
-        pid++;
+        if (n > term[s]) { term[s] = (uint16_t)n; term_pid[s] = (uint32_t)pid; }
     }
     std::vector<uint32_t> fail(ns, 0), queue;
     queue.reserve(ns);
     go[0] = 0;
     for (uint32_t c = 1; c < S; c++) {
-        int32_t t = go[c];
-        if (t < 0) go[c] = 0; else queue.push_back((uint32_t)t);
+        const uint32_t t = go[c];
+        if (t == NONE) go[c] = 0; else queue.push_back(t);
     }
     for (size_t qh = 0; qh < queue.size(); qh++) {
-        uint32_t s = queue[qh];
-        if (!term[s]) { term[s] = term[fail[s]]; term_pid[s] = term_pid[fail[s]]; }   // longest pattern that is a suffix of this state
-        go[(size_t)s * S] = 0;                        // byte in no pattern: back to ROOT (acism.c:35-40)
+        const uint32_t s = queue[qh];
+        const uint32_t f = fail[s];
+        if (!term[s]) { term[s] = term[f]; term_pid[s] = term_pid[f]; }   // longest pattern that is a suffix of this state
+        uint32_t *gs = &go[(size_t)s * S];
+        const uint32_t *gf = &go[(size_t)f * S];
+        gs[0] = 0;                                    // byte in no pattern: back to ROOT (acism.c:35-40)
         for (uint32_t c = 1; c < S; c++) {
-            int32_t t = go[(size_t)s * S + c];
-            if (t < 0) go[(size_t)s * S + c] = go[(size_t)fail[s] * S + c];
-            else { fail[(uint32_t)t] = (uint32_t)go[(size_t)fail[s] * S + c]; queue.push_back((uint32_t)t); }
+            const uint32_t t = gs[c];
+            if (t == NONE) gs[c] = gf[c];
+            else { fail[t] = gf[c]; queue.push_back(t); }
         }
     }
     a.n_states = ns;
-    a.go.resize((size_t)ns * S);
-    for (size_t i = 0; i < (size_t)ns * S; i++) a.go[i] = (uint32_t)go[i];
-    a.out_len.assign(term.begin(), term.begin() + ns);
-    a.out_pid.assign(term_pid.begin(), term_pid.begin() + ns);
+    go.resize((size_t)ns * S);
+    term.resize(ns);
+    term_pid.resize(ns);
     a.go4.clear();
+    a.go4w.clear();
+    const uint32_t sa = a.sym[(unsigned char)'A'], sc = a.sym[(unsigned char)'C'], sg = a.sym[(unsigned char)'G'], st = a.sym[(unsigned char)'T'];
     if (ns <= 65535) {
         a.go4.resize((size_t)ns * 4);
-        const char acgt[4] = {'A', 'C', 'G', 'T'};
-        for (uint32_t s = 0; s < ns; s++)
-            for (int c = 0; c < 4; c++)
-                a.go4[(size_t)s * 4 + c] = (uint16_t)a.go[(size_t)s * S + a.sym[(unsigned char)acgt[c]]];
+        for (uint32_t s = 0; s < ns; s++) {
+            const uint32_t *gs = &go[(size_t)s * S];
+            uint16_t *o = &a.go4[(size_t)s * 4];
+            o[0] = (uint16_t)gs[sa]; o[1] = (uint16_t)gs[sc]; o[2] = (uint16_t)gs[sg]; o[3] = (uint16_t)gs[st];
+        }
+    } else {
+        a.go4w.resize((size_t)ns * 4);
+        for (uint32_t s = 0; s < ns; s++) {
+            const uint32_t *gs = &go[(size_t)s * S];
+            uint32_t *o = &a.go4w[(size_t)s * 4];
+            o[0] = gs[sa]; o[1] = gs[sc]; o[2] = gs[sg]; o[3] = gs[st];
+        }
     }
 }
 
-void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns)
+void build_automaton_and_anchors(HostAutomaton &a, HostAnchors &k, const StringArena &patterns)
+{
+    parallel_tasks(2, 2, [&](size_t t) { if (t == 0) build_automaton(a, patterns); else build_anchors(k, patterns); });
+}
+
+void build_anchors(HostAnchors &k, const StringArena &patterns)
 {
     k = HostAnchors();
     std::vector<uint32_t> keys;
     keys.reserve(patterns.size() * 8);
-    for (const auto &p : patterns) {
-        if (p.size() < 23) {                       // the anchor argument needs |P| >= 16 + 7 (unless P cannot match at all)
-            bool acgt = true;
-            for (unsigned char c : p) if (acgt_code(c) < 0) { acgt = false; break; }
-            if (acgt) return;
-            continue;
-        }
-        // rolling 2-bit code of p[r, r+16) for r = 0..7; a non-ACGT byte anywhere makes the pattern
-        // unmatchable in a packed read, so it contributes no keys
-        uint32_t v = 0;
+    for (size_t pi = 0; pi < patterns.size(); pi++) {
+        const unsigned char *p = (const unsigned char *)patterns.data(pi);
+        const size_t n = patterns.len(pi);
+        // a non-ACGT byte anywhere makes the pattern unmatchable in a packed read: it contributes no keys
         bool acgt = true;
-        for (size_t i = 0; i < p.size(); i++) if (acgt_code((unsigned char)p[i]) < 0) { acgt = false; break; }
+        for (size_t i = 0; i < n; i++) if (acgt_code(p[i]) < 0) { acgt = false; break; }
         if (!acgt) continue;
-        for (int i = 0; i < 16; i++) v |= (uint32_t)acgt_code((unsigned char)p[(size_t)i]) << (2 * i);
+        if (n < 23) return;                          // the anchor argument needs |P| >= 16 + 7
+        // rolling 2-bit code of p[r, r+16) for r = 0..7
+        uint32_t v = 0;
+        for (int i = 0; i < 16; i++) v |= (uint32_t)acgt_code(p[i]) << (2 * i);
         keys.push_back(v);
         for (int r = 1; r < 8; r++) {
-            v = (v >> 2) | ((uint32_t)acgt_code((unsigned char)p[(size_t)r + 15]) << 30);
+            v = (v >> 2) | ((uint32_t)acgt_code(p[(size_t)r + 15]) << 30);
             keys.push_back(v);
         }
     }
@@ -630,9 +798,13 @@ void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns)
     static const uint32_t SH[][2] = {{15, 13}, {17, 11}, {14, 9}, {16, 12}};
     static const uint32_t MU[][2] = {{0x9E3779u, 0x85EBCBu}, {0xC2B2AFu, 0x27D4EBu}, {0x7FEB35u, 0x846CA7u}, {0xB5297Bu, 0x68E31Du}};
     auto mul24 = [](uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) & 0xFFFFFFFFull); };
-    for (uint32_t log_size = 10; log_size <= 15; log_size++) {
+    // Tier 0: exact keys, one per slot, up to 2^15 slots (128 KB of LDS).
+    // Tier 1: key sets beyond that (large shards / many ranks: one error variant per pattern adds up)
+    //         keep the table in LDS as buckets of two 16-bit fingerprints: a superset filter with a
+    //         false-positive rate of 4 * 2^-16 per probe (the flagged reads are verified exactly anyway).
+    // Tier 2: exact keys again, probed in global memory (L2), for anything larger.
+    auto try_exact = [&](uint32_t log_size) -> bool {
         const uint32_t size = 1u << log_size, rsh = 32 - log_size;
-        if (keys.size() * 3 > size && log_size < 15) continue;    // load factor <= 1/3: the first hash pair nearly always works
         for (uint32_t a = 0; a < 4; a++) for (uint32_t b = 0; b < 4; b++) {
             const uint32_t s1 = SH[a][0], s2 = SH[a][1], m1 = MU[b][0], m2 = MU[b][1];
             auto h1 = [&](uint32_t v) { return mul24(v ^ (v >> s1), m1) >> rsh; };
@@ -655,10 +827,75 @@ void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns)
             }
             if (!ok) continue;
             for (uint32_t i = 0; i < size; i++) if (!used[i]) tab[i] = keys[0];   // unused slots hold a member key
-            k.ok = true; k.log_size = log_size; k.s1 = s1; k.s2 = s2; k.m1 = m1; k.m2 = m2;
+            k.ok = true; k.mode = 0; k.log_size = log_size; k.s1 = s1; k.s2 = s2; k.m1 = m1; k.m2 = m2;
             k.table.swap(tab);
-            return;
+            return true;
         }
+        return false;
+    };
+    auto try_buckets = [&](uint32_t log_size) -> bool {
+        const uint32_t nb = 1u << log_size, rsh = 32 - log_size;
+        for (uint32_t a = 0; a < 4; a++) for (uint32_t b = 0; b < 4; b++) {
+            const uint32_t s1 = SH[a][0], s2 = SH[a][1], m1 = MU[b][0], m2 = MU[b][1];
+            auto h1 = [&](uint32_t v) { return mul24(v ^ (v >> s1), m1) >> rsh; };
+            auto h2 = [&](uint32_t v) { return mul24(v ^ (v >> s2), m2) >> rsh; };
+            std::vector<uint32_t> slot_key((size_t)nb * 2, 0);
+            std::vector<uint8_t> fill(nb, 0);                      // occupied slots of the bucket (0..2)
+            uint32_t rnd = 0x2545F491u;
+            bool ok = true;
+            for (uint32_t key : keys) {
+                uint32_t cur = key, avoid = 0xFFFFFFFFu;
+                int kicks = 0;
+                for (;;) {
+                    const uint32_t b1 = h1(cur), b2 = h2(cur);
+                    if (fill[b1] < 2) { slot_key[(size_t)b1 * 2 + fill[b1]++] = cur; break; }
+                    if (fill[b2] < 2) { slot_key[(size_t)b2 * 2 + fill[b2]++] = cur; break; }
+                    if (++kicks > 2000) { ok = false; break; }
+                    rnd ^= rnd << 13; rnd ^= rnd >> 17; rnd ^= rnd << 5;
+                    uint32_t bk = (rnd & 1) ? b1 : b2;
+                    if (bk == avoid && b1 != b2) bk = (bk == b1) ? b2 : b1;      // do not bounce straight back
+                    const size_t sl = (size_t)bk * 2 + ((rnd >> 1) & 1);
+                    std::swap(cur, slot_key[sl]);
+                    avoid = bk;
+                }
+                if (!ok) break;
+            }
+            if (!ok) continue;
+            // fingerprint = low 16 bits of (h1 product ^ h2 product); empty slots keep 0 (any value
+            // there is just one more false-positive source of the same 2^-16 weight)
+            std::vector<uint32_t> tab(nb, 0);
+            for (uint32_t bk = 0; bk < nb; bk++) {
+                uint32_t w = 0;
+                for (uint32_t j = 0; j < fill[bk]; j++) {
+                    const uint32_t v = slot_key[(size_t)bk * 2 + j];
+                    w |= ((mul24(v ^ (v >> s1), m1) ^ mul24(v ^ (v >> s2), m2)) & 0xFFFFu) << (16 * j);
+                }
+                if (fill[bk] == 1) w |= w << 16;
+                tab[bk] = w;
+            }
+            k.ok = true; k.mode = 1; k.log_size = log_size; k.s1 = s1; k.s2 = s2; k.m1 = m1; k.m2 = m2;
+            k.table.swap(tab);
+            return true;
+        }
+        return false;
+    };
+    const size_t nk = keys.size();
+    for (uint32_t log_size = 10; log_size <= 15; log_size++) {
+        const size_t size = (size_t)1 << log_size;
+        if (nk * 3 > size && log_size != 15) continue;            // load <= 1/3: the first hash pair nearly always works
+        if (nk * 2 > size) continue;                              // (<= 1/2 at the LDS limit)
+        if (try_exact(log_size)) return;
+    }
+    for (uint32_t log_size = 14; log_size <= 15; log_size++) {
+        const size_t slots = (size_t)2 << log_size;
+        if (nk * 10 > slots * (log_size == 15 ? 8 : 6)) continue; // load <= 0.6 (<= 0.8 at the LDS limit)
+        if (try_buckets(log_size)) return;
+    }
+    for (uint32_t log_size = 16; log_size <= 22; log_size++) {
+        const size_t size = (size_t)1 << log_size;
+        if (nk * 3 > size && log_size != 22) continue;
+        if (nk * 2 > size) continue;
+        if (try_exact(log_size)) return;
     }
 }
 
@@ -683,10 +920,10 @@ int crass_merge_get(const crass_merge_handle *h, crass_merge_view *o)
 {
     if (!h || !o) return CRASS_ERR_INVALID_ARG;
     const crass::MergeResult &m = h->m;
-    o->n_tokens = m.tokens.size(); o->tok_chars = m.tok_chars.data(); o->tok_off = m.tok_off.data();
+    o->n_tokens = m.tokens.size(); o->tok_chars = m.tokens.strings.chars.data(); o->tok_off = m.tokens.strings.off.data();
     o->n_candidates = m.cand_token.size(); o->cand_token = m.cand_token.data();
     o->n_groups = (uint32_t)m.groups.size(); o->grp_tokens = m.grp_tokens.data(); o->grp_off = m.grp_off.data();
-    o->n_patterns = (uint32_t)m.patterns.size(); o->pat_chars = m.pat_chars.data(); o->pat_off = m.pat_off.data();
+    o->n_patterns = (uint32_t)m.patterns.size(); o->pat_chars = m.patterns.chars.data(); o->pat_off = m.patterns.off.data();
     o->pat_group = m.pat_group.data(); o->next_free_gid = m.next_free_gid;
     return CRASS_OK;
 }

@@ -15,25 +15,32 @@ std::string reverse_complement(const std::string &s);          // SeqUtils.cpp:6
 // StringCheck (StringCheck.h:52-71, StringCheck.cpp:46-81): first token is 2, discovery order.
 // The string -> token side is an open-addressing table over (pointer, length) views so that the
 // per-candidate lookup of the sink allocates nothing.
+// string i -> chars[off[i] .. off[i+1]): one arena instead of one heap string per entry
+// (this is exactly the layout crass_merge_view exposes, so "flattening" is free)
+struct StringArena {
+    std::vector<char> chars;
+    std::vector<uint64_t> off{0};
+    size_t size() const { return off.size() - 1; }
+    bool empty() const { return size() == 0; }
+    std::string operator[](size_t i) const { return std::string(chars.data() + off[i], (size_t)(off[i + 1] - off[i])); }
+    const char *data(size_t i) const { return chars.data() + off[i]; }
+    size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i]); }
+    void push(const char *p, size_t n) { chars.insert(chars.end(), p, p + n); off.push_back(chars.size()); }
+    void push(const std::string &s) { push(s.data(), s.size()); }
+    void clear() { chars.clear(); off.assign(1, 0); }
+};
+
 struct TokenTable {
-    // token t -> chars[off[t-2] .. off[t-1]): one arena instead of one heap string per variant
-    // (this is exactly the layout crass_merge_view exposes, so "flattening" is free)
-    struct Strings {
-        std::vector<char> chars;
-        std::vector<uint64_t> off{0};
-        size_t size() const { return off.size() - 1; }
-        std::string operator[](size_t i) const { return std::string(chars.data() + off[i], (size_t)(off[i + 1] - off[i])); }
-        const char *data(size_t i) const { return chars.data() + off[i]; }
-        size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i]); }
-        void push(const char *p, size_t n) { chars.insert(chars.end(), p, p + n); off.push_back(chars.size()); }
-        void clear() { chars.clear(); off.assign(1, 0); }
-    } strings;
+    typedef StringArena Strings;
+    Strings strings;                                           // token t -> strings[t - 2]
     std::vector<uint32_t> slot_token;                          // 0 = empty
     std::vector<uint64_t> slot_hash;
     static uint64_t hash(const char *p, size_t n);
     uint32_t get(const char *p, size_t n) const;
     uint32_t add(const char *p, size_t n);                     // caller checked get() == 0
     uint32_t add_hashed(const char *p, size_t n, uint64_t h);  // same, hash already known
+    uint32_t add_unique_hashed(const char *p, size_t n, uint64_t h);   // 0 if the string is already present
+    void reserve(size_t n_strings, size_t n_chars);
     uint32_t get(const std::string &s) const { return get(s.data(), s.size()); }
     uint32_t add(const std::string &s) { return add(s.data(), s.size()); }
     uint32_t size() const { return (uint32_t)strings.size(); }
@@ -46,13 +53,12 @@ struct MergeResult {
     TokenTable tokens;
     std::vector<uint32_t> cand_token;                          // token of every candidate fed in
     std::vector<std::vector<uint32_t>> groups;                 // mDR2GIDMap: groups[g] = tokens of GID g+1
-    std::vector<std::string> patterns;                         // createNonRedundantSet's Vecstr
+    StringArena patterns;                                      // createNonRedundantSet's Vecstr
     std::vector<uint32_t> pat_group;
+    std::vector<uint32_t> pat_token;                           // token of each pattern's low-lexi form (0: none)
     int next_free_gid = 1;
-    // flat copies for the C views
-    std::vector<char> tok_chars; std::vector<uint64_t> tok_off;
+    // flat copy of the groups for the C view (tokens and patterns are arenas already)
     std::vector<uint32_t> grp_tokens; std::vector<uint64_t> grp_off;
-    std::vector<char> pat_chars; std::vector<uint64_t> pat_off;
     void flatten();
     void clear();
 };
@@ -65,6 +71,12 @@ struct MergeResult {
 void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
                       uint64_t n, int kmer_clust_size, const uint32_t *rep = nullptr, const uint64_t *hash = nullptr);
 
+// Same, starting from the DISTINCT strings in first-occurrence order (the device computed them, with their
+// TokenTable::hash values) and every candidate's index into that list.  false (m cleared) if the list turns
+// out not to be pairwise distinct or a hash does not match — the caller then uses merge_candidates().
+bool merge_from_distinct(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, const uint64_t *dx_hash, uint32_t dr_stride,
+                         uint64_t n_distinct, const uint32_t *cand_distinct, uint64_t n, int kmer_clust_size);
+
 // byte-wise Aho-Corasick with fully resolved goto; semantics of acism_create + the first
 // callback of acism_scan (acism_create.c:71-392, acism.c:25-106)
 struct HostAutomaton {
@@ -74,17 +86,21 @@ struct HostAutomaton {
     std::vector<uint16_t> out_len;     // longest pattern ending at the state
     std::vector<uint32_t> out_pid;     // index (into the pattern list) of that pattern
     std::vector<uint16_t> go4;         // [n_states][4] for A,C,G,T (empty if n_states > 65535)
+    std::vector<uint32_t> go4w;        // the same, 32-bit, when n_states > 65535
     uint32_t max_pat_len = 0;
 };
-void build_automaton(HostAutomaton &a, const std::vector<std::string> &patterns);
+void build_automaton(HostAutomaton &a, const StringArena &patterns);
 
 // pass-2 anchor keys: every 16-mer starting at offset 0..7 of an ACGT-only pattern, packed like
 // the reads (base i in bits 2i..2i+1), in a two-choice cuckoo table (see kernels.hip).
 struct HostAnchors {
     bool ok = false;                    // false: some pattern is shorter than 23 or the table would not fit
     uint32_t log_size = 0, s1 = 0, s2 = 0, m1 = 0, m2 = 0, n_keys = 0;
+    uint32_t mode = 0;                  // 0: exact 32-bit keys; 1: buckets of two 16-bit fingerprints (see kernels.hip)
     std::vector<uint32_t> table;
 };
-void build_anchors(HostAnchors &k, const std::vector<std::string> &patterns);
+void build_anchors(HostAnchors &k, const StringArena &patterns);
+// both, concurrently on the host pool (they are independent)
+void build_automaton_and_anchors(HostAutomaton &a, HostAnchors &k, const StringArena &patterns);
 
 } // namespace crass

@@ -224,6 +224,9 @@ typedef struct {
     float ms_recruit, ms_recruit_finish, ms_pass2_total;
     float ms_merge_host, ms_sink_host;
     uint64_t bytes_reads_device;    /* packed read bytes resident in HBM                          */
+    uint32_t anchor_keys;           /* distinct 16-mer anchor keys of the pattern set (pass 2)    */
+    uint32_t anchor_table_kind;     /* 0 exact keys in LDS, 1 fingerprint buckets in LDS,
+                                       2 exact keys probed in L2 (key set beyond LDS)             */
 } crass_counters;
 int crass_hip_get_counters(const crass_hip_ctx *ctx, crass_counters *out);
 

@@ -215,6 +215,20 @@ def test_config5_shape_many_drs_gc_classes(ca):
     ref = orc.pipeline(seqs)
     assert_same_pipeline(gpu, ref)
     assert gpu.n_groups > 300 and gpu.n_patterns > 1000
+    # pattern sets too large for the LDS anchor table keep the anchor path (table probed in L2)
+    assert gpu.counters["used_lds_automaton"] == 2
+
+
+@pytest.mark.parametrize("n_dr,kind", [(2000, 1), (9000, 2)])
+def test_anchor_table_tiers(ca, n_dr, kind):
+    """pattern sets beyond the exact LDS anchor table: fingerprint buckets in LDS (kind 1), then exact
+    keys probed in L2 (kind 2) — same records either way."""
+    seqs = synth_reads(ca, 200000, read_len=150, n_dr=n_dr, crispr_per_million=150000)
+    gpu = ca.search_pipeline(seqs)
+    ref = orc.pipeline(seqs)
+    assert_same_pipeline(gpu, ref)
+    assert gpu.counters["used_lds_automaton"] == 2
+    assert gpu.counters["anchor_table_kind"] == kind, gpu.counters
 
 
 def test_full_size_properties(ca):
