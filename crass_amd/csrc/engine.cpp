@@ -488,7 +488,8 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
     HIPCHK(c, D.d_read.ensure(n_surv)); HIPCHK(c, D.d_ss_off.ensure(n_surv)); HIPCHK(c, D.d_low.ensure(n_surv));
     HIPCHK(c, D.d_replen.ensure(n_surv)); HIPCHK(c, D.d_nss.ensure(n_surv)); HIPCHK(c, D.d_dr_len.ensure(n_surv));
     HIPCHK(c, D.d_dr.ensure(n_surv * stride)); HIPCHK(c, D.d_ss.ensure(n_surv * (uint64_t)lds.ss_cap));
-    HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 8, c->stream));            // [2] = found count, [3] = worst error
+    // [2] = found count, [3] = worst error, [4] = n distinct, [5] = de-duplication mismatch flag
+    HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 16, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
     // lane-per-read kernel for uniform short reads; whatever it punts (err == 4) and every other
@@ -509,39 +510,36 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
     HIPCHK(c, launch_gather_found(c->d_fidx.p, c->d_count.p + 2, n_surv, c->d_surv.p, c->d_idx.p, c->read_base, c->d_dr.p, stride,
                                   c->d_ss_pool.p, lds.ss_cap, D.d_read.p, D.d_low.p, D.d_replen.p, D.d_nss.p, D.d_ss_off.p,
                                   D.d_dr_len.p, D.d_dr.p, D.d_ss.p, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 8, hipMemcpyDeviceToHost, c->stream));
+    // de-duplication and token ranks follow without a host round trip (the found count stays on the device);
+    // their small outputs — all the merge needs — are written straight into pinned host memory
+    c->have_rep = false;
+    c->have_dev_tokens = false;
+    const bool dedupe = n_surv < (1u << 22);
+    if (dedupe) {
+        uint32_t tsize = 1024;
+        while (tsize < n_surv * 2) tsize <<= 1;
+        HIPCHK(c, c->dd_keys.ensure(tsize)); HIPCHK(c, c->dd_first.ensure(tsize)); HIPCHK(c, c->dd_slot.ensure(n_surv));
+        HIPCHK(c, c->dd_rep.ensure(n_surv)); HIPCHK(c, c->dd_hash.ensure(n_surv)); HIPCHK(c, c->h_rep.ensure(n_surv)); HIPCHK(c, c->h_hash.ensure(n_surv));
+        HIPCHK(c, c->h_dmap.ensure(n_surv)); HIPCHK(c, c->h_dx_chars.ensure(n_surv * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(n_surv));
+        HIPCHK(c, c->h_dx_hash.ensure(n_surv));
+        HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_keys.p, c->dd_first.p, tsize,
+                                   c->dd_hash.p, c->dd_slot.p, c->dd_rep.p, c->stream));
+        // distinct strings in first-occurrence order and every candidate's rank among them, exact
+        HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->d_mask.p,
+                                   c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
+                                   c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, D.h_read.ensure(n_surv)); HIPCHK(c, D.h_ss_off.ensure(n_surv)); HIPCHK(c, D.h_low.ensure(n_surv)); HIPCHK(c, D.h_replen.ensure(n_surv));
+    HIPCHK(c, D.h_nss.ensure(n_surv)); HIPCHK(c, D.h_dr_len.ensure(n_surv)); HIPCHK(c, D.h_dr.ensure(n_surv * stride + 16));
+    HIPCHK(c, D.h_ss.ensure(n_surv * (uint64_t)lds.ss_cap + 16));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t nf = c->h_count.p[2];
     const uint32_t err = c->h_count.p[3];
     if (err == 1) return CRASS_ERR_SEARCH_FATAL;
     if (err) return CRASS_ERR_OVERFLOW;
-    HIPCHK(c, D.h_read.ensure(nf)); HIPCHK(c, D.h_ss_off.ensure(nf)); HIPCHK(c, D.h_low.ensure(nf)); HIPCHK(c, D.h_replen.ensure(nf));
-    HIPCHK(c, D.h_nss.ensure(nf)); HIPCHK(c, D.h_dr_len.ensure(nf)); HIPCHK(c, D.h_dr.ensure(nf * stride + 16));
-    HIPCHK(c, D.h_ss.ensure(nf * (uint64_t)lds.ss_cap + 16));
-    c->have_rep = false;
-    c->have_dev_tokens = false;
-    if (nf && nf < (1u << 22)) {
-        uint32_t tsize = 1024;
-        while (tsize < nf * 2) tsize <<= 1;
-        HIPCHK(c, c->dd_keys.ensure(tsize)); HIPCHK(c, c->dd_first.ensure(tsize)); HIPCHK(c, c->dd_slot.ensure(nf));
-        HIPCHK(c, c->dd_rep.ensure(nf)); HIPCHK(c, c->dd_hash.ensure(nf)); HIPCHK(c, c->h_rep.ensure(nf)); HIPCHK(c, c->h_hash.ensure(nf));
-        HIPCHK(c, c->dd_map.ensure(nf)); HIPCHK(c, c->dd_dx_chars.ensure(nf * stride)); HIPCHK(c, c->dd_dx_len.ensure(nf));
-        HIPCHK(c, c->dd_dx_hash.ensure(nf)); HIPCHK(c, c->h_dmap.ensure(nf));
-        HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, (uint32_t)nf, c->dd_keys.p, c->dd_first.p, tsize, c->dd_hash.p,
-                                   c->dd_slot.p, c->dd_rep.p, c->stream));
-        // distinct strings in first-occurrence order and every candidate's rank among them, exact
-        HIPCHK(c, hipMemsetAsync(c->d_count.p + 4, 0, 8, c->stream));            // [4] = n distinct, [5] = mismatch flag
-        HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, (uint32_t)nf, c->dd_rep.p, c->d_mask.p, c->d_word_prefix.p,
-                                   c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->dd_map.p, c->dd_dx_chars.p,
-                                   c->dd_dx_len.p, c->dd_dx_hash.p, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_count.p + 4, c->d_count.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_dmap.p, c->dd_map.p, nf * 4, hipMemcpyDeviceToHost, c->stream));
-        c->have_rep = true;
-    }
     if (nf) {
-        // the per-candidate records go out on the copy stream; the merge only needs the distinct strings
-        HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_gathered, 0));
+        // the per-candidate records go out on the copy stream while the host merges
         hipStream_t cs = c->copy_stream;
         HIPCHK(c, hipMemcpyAsync(D.h_dr.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, cs));
         HIPCHK(c, hipMemcpyAsync(D.h_dr_len.p, D.d_dr_len.p, nf * 2, hipMemcpyDeviceToHost, cs));
@@ -551,20 +549,14 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
         HIPCHK(c, hipMemcpyAsync(D.h_replen.p, D.d_replen.p, nf * 4, hipMemcpyDeviceToHost, cs));
         HIPCHK(c, hipMemcpyAsync(D.h_nss.p, D.d_nss.p, nf * 4, hipMemcpyDeviceToHost, cs));
         HIPCHK(c, hipMemcpyAsync(D.h_ss.p, D.d_ss.p, nf * (uint64_t)lds.ss_cap * 4, hipMemcpyDeviceToHost, cs));
-        if (c->have_rep) {
+        if (dedupe) {
             HIPCHK(c, hipMemcpyAsync(c->h_rep.p, c->dd_rep.p, nf * 4, hipMemcpyDeviceToHost, cs));
             HIPCHK(c, hipMemcpyAsync(c->h_hash.p, c->dd_hash.p, nf * 8, hipMemcpyDeviceToHost, cs));
+            c->have_rep = true;
         }
         c->bulk_pending = true;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->have_rep && c->h_count.p[5] == 0) {
-            const uint64_t nd = c->h_count.p[4];
-            HIPCHK(c, c->h_dx_chars.ensure(nd * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(nd)); HIPCHK(c, c->h_dx_hash.ensure(nd));
-            HIPCHK(c, hipMemcpyAsync(c->h_dx_chars.p, c->dd_dx_chars.p, nd * stride, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_dx_len.p, c->dd_dx_len.p, nd * 2, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_dx_hash.p, c->dd_dx_hash.p, nd * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            c->n_dx = nd;
+        if (dedupe && c->h_count.p[5] == 0) {
+            c->n_dx = c->h_count.p[4];
             c->have_dev_tokens = true;
         }
     }

@@ -128,10 +128,10 @@ hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint6
                                const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
                                const uint32_t *ss_pool, uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
                                uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr, uint32_t *g_ss, hipStream_t st);
-hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, uint32_t n, const uint32_t *rep,
+hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, const uint32_t *rep,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash, hipStream_t st);
-hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, uint32_t n, unsigned long long *keys,
+hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n, unsigned long long *keys,
                             uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st);
 SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P);
 hipError_t upload_comp_table(const unsigned char *tab128);

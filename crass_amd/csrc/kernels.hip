@@ -1451,11 +1451,12 @@ static __device__ uint64_t dr_hash64(const char *p, uint32_t n)
     return h ^ (h >> 31);
 }
 
-__global__ __launch_bounds__(256) void k_dr_dedupe_insert(const char *dr, const uint16_t *dr_len, uint32_t stride, uint32_t n,
-                                                           unsigned long long *keys, uint32_t *first, uint32_t mask,
+__global__ __launch_bounds__(256) void k_dr_dedupe_insert(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n,
+                                                           uint32_t n_max, unsigned long long *keys, uint32_t *first, uint32_t mask,
                                                            uint64_t *hash_out, uint32_t *slot_out)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = min(*d_n, n_max);
     if (k >= n) return;
     const uint64_t h = dr_hash64(dr + (uint64_t)k * stride, dr_len[k]);
     hash_out[k] = h;
@@ -1470,13 +1471,15 @@ __global__ __launch_bounds__(256) void k_dr_dedupe_insert(const char *dr, const 
     slot_out[k] = slot;
 }
 
-__global__ __launch_bounds__(256) void k_dr_dedupe_rep(const uint32_t *slot_of, const uint32_t *first, uint32_t n, uint32_t *rep)
+__global__ __launch_bounds__(256) void k_dr_dedupe_rep(const uint32_t *slot_of, const uint32_t *first, const uint32_t *d_n, uint32_t n_max,
+                                                        uint32_t *rep)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) rep[k] = first[slot_of[k]];
+    if (k < min(*d_n, n_max)) rep[k] = first[slot_of[k]];
 }
 
-hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, uint32_t n, unsigned long long *keys,
+// the candidate count lives on the device (*d_n, at most n_max): no host round trip before this launch
+hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n, unsigned long long *keys,
                             uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
@@ -1485,8 +1488,8 @@ hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t str
     e = hipMemsetAsync(first, 0xFF, (size_t)table_size * 4, st);
     if (e != hipSuccess) return e;
     const unsigned nb = (n + 255) / 256;
-    hipLaunchKernelGGL(k_dr_dedupe_insert, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, n, keys, first, table_size - 1, hash_out, slot_tmp);
-    hipLaunchKernelGGL(k_dr_dedupe_rep, dim3(nb), dim3(256), 0, st, slot_tmp, first, n, rep);
+    hipLaunchKernelGGL(k_dr_dedupe_insert, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, keys, first, table_size - 1, hash_out, slot_tmp);
+    hipLaunchKernelGGL(k_dr_dedupe_rep, dim3(nb), dim3(256), 0, st, slot_tmp, first, d_n, n, rep);
     return hipGetLastError();
 }
 
@@ -1494,10 +1497,11 @@ hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t str
 // bit k of `mask` = candidate k is the first occurrence of its string; every other candidate is compared
 // byte for byte with its representative, so a 64-bit hash collision between different strings is
 // DETECTED (flag) and the host then takes its plain path.
-__global__ __launch_bounds__(256) void k_dx_flag(const char *dr, const uint16_t *dr_len, uint32_t stride, uint32_t n, const uint32_t *rep,
-                                                  uint64_t *mask, uint32_t *d_mismatch)
+__global__ __launch_bounds__(256) void k_dx_flag(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n_max,
+                                                  const uint32_t *rep, uint64_t *mask, uint32_t *d_mismatch)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = min(*d_n, n_max);
     bool is_rep = false;
     if (k < n) {
         const uint32_t f = rep[k];
@@ -1516,15 +1520,15 @@ __global__ __launch_bounds__(256) void k_dx_flag(const char *dr, const uint16_t 
         }
     }
     const uint64_t m = __ballot(is_rep);
-    if ((threadIdx.x & 63) == 0 && k < n) mask[k >> 6] = m;
+    if ((threadIdx.x & 63) == 0 && k < n_max) mask[k >> 6] = m;       // words past the count are zero
 }
 
 // dmap[k] = rank of k's representative among the first occurrences (token = rank + 2 on one GPU)
-__global__ __launch_bounds__(256) void k_dx_assign(const uint32_t *rep, uint32_t n, const uint64_t *mask, const uint32_t *word_prefix,
-                                                    const uint32_t *block_sums, uint32_t *dmap)
+__global__ __launch_bounds__(256) void k_dx_assign(const uint32_t *rep, const uint32_t *d_n, uint32_t n_max, const uint64_t *mask,
+                                                    const uint32_t *word_prefix, const uint32_t *block_sums, uint32_t *dmap)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+    if (k >= min(*d_n, n_max)) return;
     const uint32_t f = rep[k], w = f >> 6;
     dmap[k] = block_sums[w >> 8] + word_prefix[w] + (uint32_t)__popcll(mask[w] & ((1ull << (f & 63)) - 1ull));
 }
@@ -1545,17 +1549,19 @@ __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const
     out_hash[j] = hash[k];
 }
 
-// needs stride % 16 == 0; mask / word_prefix / block_sums / dx_idx are scratch of >= n bits / words
-hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, uint32_t n, const uint32_t *rep,
+// needs stride % 16 == 0; mask / word_prefix / block_sums / dx_idx are scratch of >= n bits / words.  The candidate
+// count is *d_n (<= n).  dmap / out_* may be pinned host memory: the kernels then write the merge's inputs
+// straight into it (a few hundred KB; no copy calls on the critical path).
+hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, const uint32_t *rep,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     const unsigned nb = (n + 255) / 256;
-    hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, n, rep, mask, d_mismatch);
+    hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, rep, mask, d_mismatch);
     hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, n, mask, word_prefix, block_sums, dmap);
+    hipLaunchKernelGGL(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap);
     hipLaunchKernelGGL(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash);
     return hipGetLastError();
 }

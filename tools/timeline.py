@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Print the device-side timeline (kernels + copies) of the LAST bench step from a rocprofv3
+--kernel-trace --memory-copy-trace CSV directory:  python tools/timeline.py DIR"""
+import csv
+import glob
+import sys
+
+
+def main():
+    d = sys.argv[1]
+    ev = []
+    for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:60]))
+    for f in glob.glob(d + "/**/*_memory_copy_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") ))
+    ev.sort()
+    # last step = events after the last filter kernel start
+    starts = [i for i, e in enumerate(ev) if "k_filter" in e[2]]
+    if not starts:
+        print("no filter kernel found"); return
+    ev = ev[starts[-1]:]
+    t0 = ev[0][0]
+    prev_end = t0
+    for s, e, n in ev:
+        print("%9.1f us  +%8.1f gap  %8.1f us  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, n))
+        prev_end = max(prev_end, e)
+    print("total span %.1f us" % ((prev_end - t0) / 1e3))
+
+
+if __name__ == "__main__":
+    main()
