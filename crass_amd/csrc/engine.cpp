@@ -533,6 +533,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
     HIPCHK(c, D.h_read.ensure(n_surv)); HIPCHK(c, D.h_ss_off.ensure(n_surv)); HIPCHK(c, D.h_low.ensure(n_surv)); HIPCHK(c, D.h_replen.ensure(n_surv));
     HIPCHK(c, D.h_nss.ensure(n_surv)); HIPCHK(c, D.h_dr_len.ensure(n_surv)); HIPCHK(c, D.h_dr.ensure(n_surv * stride + 16));
     HIPCHK(c, D.h_ss.ensure(n_surv * (uint64_t)lds.ss_cap + 16));
+    host_pool_warm();                                   // the merge follows: wake the host workers while the device finishes
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t nf = c->h_count.p[2];
     const uint32_t err = c->h_count.p[3];

@@ -247,8 +247,10 @@ int cluster_one(const char *dr_p, size_t dr_n, const int32_t *codes, int n_mers,
     return group;
 }
 
-// A small persistent worker pool: spawning std::threads per call costs ~50 us each on a big host,
-// more than the work they would do here.  Workers sleep on a condition variable between jobs.
+// A small persistent worker pool.  Spawning std::threads per call costs ~50 us each on a big host, and even
+// waking a sleeping worker through a condition variable costs 100-200 us there — more than most of the
+// jobs below.  Workers therefore keep polling for a couple of milliseconds after a job (one merge is a
+// burst of short jobs) and only then go to sleep; warm() wakes them ahead of the burst.
 class HostPool {
 public:
     static HostPool &get() { static HostPool p; return p; }
@@ -258,18 +260,42 @@ public:
         if (n_tasks == 0) return;
         unsigned helpers = std::min<unsigned>((unsigned)workers_.size(), max_threads > 0 ? max_threads - 1 : 0);
         if (n_tasks < 2 || helpers == 0) { for (size_t t = 0; t < n_tasks; t++) fn(t); return; }
-        std::unique_lock<std::mutex> job_lock(job_mutex_);     // one job at a time
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn; n_tasks_ = n_tasks; next_.store(0); active_ = helpers; want_ = helpers; epoch_++;
-        }
-        cv_.notify_all();
+        std::lock_guard<std::mutex> job_lock(job_mutex_);      // one job at a time
+        fn_ = &fn; n_tasks_ = n_tasks; want_ = helpers;
+        next_.store(0, std::memory_order_relaxed);
+        active_.store(helpers, std::memory_order_relaxed);
+        epoch_.fetch_add(1);                                   // seq_cst: ordered before the sleepers_ check below
+        wake_sleepers();
         for (size_t t = next_.fetch_add(1); t < n_tasks; t = next_.fetch_add(1)) fn(t);
-        std::unique_lock<std::mutex> lk(m_);
-        done_cv_.wait(lk, [&] { return active_ == 0; });
+        for (unsigned spins = 0; active_.load(std::memory_order_acquire) != 0;) { cpu_relax(); if ((++spins & 31u) == 0) std::this_thread::yield(); }
         fn_ = nullptr;
     }
+    // wake the workers now: the next jobs, within the polling window, start without wake-up latency
+    void warm()
+    {
+        warm_until_.store(now_us() + kPollUs, std::memory_order_relaxed);
+        wake_sleepers();
+    }
 private:
+    static constexpr int64_t kPollUs = 2500;
+    static int64_t now_us()
+    {
+        return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
+    void wake_sleepers()
+    {
+        if (sleepers_.load() == 0) return;
+        { std::lock_guard<std::mutex> lk(m_); wake_seq_++; }
+        cv_.notify_all();
+    }
     HostPool()
     {
         unsigned n = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
@@ -278,36 +304,55 @@ private:
     }
     ~HostPool()
     {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; epoch_++; }
+        stop_.store(true);
+        epoch_.fetch_add(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(m_); wake_seq_++; }
         cv_.notify_all();
         for (auto &t : workers_) t.join();
     }
     void loop(unsigned id)
     {
         uint64_t seen = 0;
+        int64_t poll_until = 0;
         for (;;) {
-            std::unique_lock<std::mutex> lk(m_);
-            cv_.wait(lk, [&] { return epoch_ != seen; });
-            seen = epoch_;
-            if (stop_) return;
-            if (id >= want_) continue;                          // this job wants fewer helpers
-            const std::function<void(size_t)> *fn = fn_;
-            const size_t n = n_tasks_;
-            lk.unlock();
-            for (size_t t = next_.fetch_add(1); t < n; t = next_.fetch_add(1)) (*fn)(t);
-            lk.lock();
-            if (--active_ == 0) done_cv_.notify_one();
+            // poll for a while, then sleep
+            unsigned spins = 0;
+            while (epoch_.load(std::memory_order_acquire) == seen) {
+                cpu_relax();
+                if ((++spins & 31u) == 0) std::this_thread::yield();   // do not starve the caller on an oversubscribed host
+                if ((spins & 255u) != 0) continue;
+                const int64_t now = now_us();
+                if (now < poll_until || now < warm_until_.load(std::memory_order_relaxed)) continue;
+                std::unique_lock<std::mutex> lk(m_);
+                sleepers_.fetch_add(1);
+                const uint64_t ws = wake_seq_;
+                cv_.wait(lk, [&] { return wake_seq_ != ws || epoch_.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+            }
+            seen = epoch_.load(std::memory_order_acquire);
+            if (stop_.load()) return;
+            if (id < want_) {
+                const std::function<void(size_t)> *fn = fn_;
+                const size_t n = n_tasks_;
+                for (size_t t = next_.fetch_add(1); t < n; t = next_.fetch_add(1)) (*fn)(t);
+                active_.fetch_sub(1, std::memory_order_acq_rel);
+            }
+            poll_until = now_us() + kPollUs;
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_, job_mutex_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     const std::function<void(size_t)> *fn_ = nullptr;
     size_t n_tasks_ = 0;
+    unsigned want_ = 0;
     std::atomic<size_t> next_{0};
-    unsigned active_ = 0, want_ = 0;
-    uint64_t epoch_ = 0;
-    bool stop_ = false;
+    std::atomic<unsigned> active_{0};
+    std::atomic<uint64_t> epoch_{0};
+    std::atomic<int> sleepers_{0};
+    std::atomic<int64_t> warm_until_{0};
+    std::atomic<bool> stop_{false};
+    uint64_t wake_seq_ = 0;                                    // guarded by m_
 };
 
 template <typename F> void parallel_tasks(size_t n_tasks, unsigned max_threads, F fn)
@@ -516,7 +561,58 @@ void remove_redundant(std::vector<Member> &v, const StringArena &strs, const Pac
     v.erase(std::partition(v.begin(), v.end(), member_kept), v.end());
 }
 
+// k-mer code -> smallest token index containing it, filled by several threads at once.
+// One 64-bit word per slot: generation (16) | code + 1 (23) | owner (25); a slot of another generation is
+// empty, so the table is reused from merge to merge without clearing.
+class OwnerTable {
+public:
+    static constexpr uint32_t kNone = 0xFFFFFFFFu;
+    void begin(size_t n_instances)
+    {
+        size_t cap = 1024;
+        while (cap < n_instances * 2) cap <<= 1;
+        if (cap > slots_.size() || ++gen_ > 0xFFFFu) {
+            slots_ = std::vector<std::atomic<uint64_t>>(std::max(cap, slots_.size()));
+            for (auto &x : slots_) x.store(0, std::memory_order_relaxed);
+            gen_ = 1;
+        }
+        mask_ = slots_.size() - 1;
+    }
+    void insert(uint32_t code, uint32_t owner)
+    {
+        const uint64_t tag = ((uint64_t)gen_ << 48) | ((uint64_t)(code + 1) << 25);
+        for (size_t i = slot(code);; i = (i + 1) & mask_) {
+            uint64_t cur = slots_[i].load(std::memory_order_relaxed);
+            for (;;) {
+                if ((cur >> 48) != gen_) {                                     // empty in this generation
+                    if (slots_[i].compare_exchange_weak(cur, tag | owner, std::memory_order_relaxed)) return;
+                    continue;                                                  // cur reloaded
+                }
+                if ((cur >> 25) != (tag >> 25)) break;                         // another k-mer: next slot
+                if ((uint32_t)(cur & 0x1FFFFFFu) <= owner) return;
+                if (slots_[i].compare_exchange_weak(cur, tag | owner, std::memory_order_relaxed)) return;
+            }
+        }
+    }
+    uint32_t find(uint32_t code) const
+    {
+        const uint64_t want = (((uint64_t)gen_ << 48) | ((uint64_t)(code + 1) << 25)) >> 25;
+        for (size_t i = slot(code);; i = (i + 1) & mask_) {
+            const uint64_t cur = slots_[i].load(std::memory_order_relaxed);
+            if ((cur >> 48) != gen_) return kNone;
+            if ((cur >> 25) == want) return (uint32_t)(cur & 0x1FFFFFFu);
+        }
+    }
+private:
+    size_t slot(uint32_t code) const { return (size_t)((code * 0x9E3779B1u) >> 7) & mask_; }
+    std::vector<std::atomic<uint64_t>> slots_;
+    size_t mask_ = 0;
+    uint64_t gen_ = 0;
+};
+
 } // namespace
+
+void host_pool_warm() { HostPool::get().warm(); }
 
 static double prof_now()
 {
@@ -607,16 +703,77 @@ static void cluster_and_patterns(MergeResult &m, int kmer_clust_size, double t0,
         for (uint32_t t = (uint32_t)c * 256; t < std::min<uint32_t>(ntok, ((uint32_t)c + 1) * 256); t++)
             if (code_off[t + 1] > code_off[t]) kmer_codes(m.tokens.strings.data(t), m.tokens.strings.len(t), codes.data() + code_off[t]);
     });
-    KmerGid kmer_gid((size_t)ntok * 6);                         // a variant adds about half a dozen new k-mers
+    // WorkHorse::clusterDRReads keeps a map k-mer -> GID that every token extends with its "homeless" k-mers
+    // after it has been placed.  A k-mer is therefore in the map exactly when an earlier token contains it, and
+    // its value is the GID of the FIRST token containing it (its owner).  The owners do not depend on the
+    // greedy order, so they are found on several threads; the order-dependent pass that is left only follows
+    // owner -> GID links and stops as soon as the token's group is decided.
+    const size_t n_inst = codes.size();
+    std::vector<uint32_t> owner_of(n_inst);
+    bool any_string_kmer = false;
+    if (ntok >= (1u << 25)) { fprintf(stderr, "crass merge: too many DR variants\n"); abort(); }
+    {
+        static thread_local OwnerTable owners_tls;               // reused from merge to merge by the calling thread
+        OwnerTable &owners = owners_tls;                         // (the workers must see THIS thread's table)
+        owners.begin(n_inst);
+        const size_t tchunk = 256;
+        parallel_tasks((ntok + tchunk - 1) / tchunk, 8, [&](size_t c) {
+            for (uint32_t t = (uint32_t)(c * tchunk); t < std::min<uint32_t>(ntok, (uint32_t)((c + 1) * tchunk)); t++)
+                for (uint32_t q = code_off[t]; q < code_off[t + 1]; q++)
+                    if (codes[q] >= 0) owners.insert((uint32_t)codes[q], t);
+        });
+        std::atomic<int> neg{0};
+        const size_t qchunk = 8192;
+        parallel_tasks((n_inst + qchunk - 1) / qchunk, 8, [&](size_t c) {
+            bool n = false;
+            for (size_t q = c * qchunk; q < std::min(n_inst, (c + 1) * qchunk); q++) {
+                if (codes[q] >= 0) owner_of[q] = owners.find((uint32_t)codes[q]);
+                else { owner_of[q] = OwnerTable::kNone; n = true; }
+            }
+            if (n) neg.store(1, std::memory_order_relaxed);
+        });
+        any_string_kmer = neg.load() != 0;
+    }
+    std::unordered_map<std::string, int> other;                  // k-mers holding a non-ACGT byte: string keys, serial
     int next_gid = 1;
     std::vector<int> gid_of(ntok);
-    std::vector<uint32_t> scratch_codes;
-    std::vector<std::pair<int, int>> scratch_counts;
+    std::vector<std::pair<int, int>> group_count;                // std::map<int,int> in the reference; tiny
+    std::vector<std::string> homeless_str;
     for (uint32_t t = 0; t < ntok; t++) {
-        // the table outgrows the caches on big inputs: start the next token's lookups while this one is processed
-        if (t + 1 < ntok) for (uint32_t q = code_off[t + 1]; q < code_off[t + 2]; q++) if (codes[q] >= 0) kmer_gid.prefetch((uint32_t)codes[q]);
-        gid_of[t] = cluster_one(m.tokens.strings.data(t), m.tokens.strings.len(t), codes.data() + code_off[t], (int)(code_off[t + 1] - code_off[t]), next_gid,
-                                kmer_gid, kmer_clust_size, scratch_codes, scratch_counts);
+        group_count.clear();
+        int group = 0;
+        auto seen = [&](int gid) {
+            if (group != 0) return;
+            for (auto &gc : group_count)
+                if (gc.first == gid) { if (kmer_clust_size <= ++gc.second) group = gid; return; }
+            group_count.emplace_back(gid, 1);                    // the first sighting is not tested (:1577-1580)
+        };
+        bool strings_here = false;
+        if (any_string_kmer)
+            for (uint32_t q = code_off[t]; q < code_off[t + 1]; q++) if (codes[q] < 0) { strings_here = true; break; }
+        if (!strings_here) {
+            for (uint32_t q = code_off[t]; q < code_off[t + 1] && group == 0; q++) {
+                const uint32_t o = owner_of[q];
+                if (o != t) seen(gid_of[o]);                     // o < t: the k-mer was in the map already
+            }
+        } else {
+            homeless_str.clear();
+            const char *dr_p = m.tokens.strings.data(t);
+            for (uint32_t q = code_off[t]; q < code_off[t + 1]; q++) {
+                if (codes[q] >= 0) {
+                    const uint32_t o = owner_of[q];
+                    if (o != t) seen(gid_of[o]);
+                } else {
+                    std::string km(dr_p + (q - code_off[t]), kClusterKmer), rc = reverse_complement(km);
+                    const std::string &lau = (km < rc) ? km : rc;      // laurenize (SeqUtils.cpp:89-97)
+                    auto it = other.find(lau);
+                    if (it == other.end()) homeless_str.push_back(lau); else seen(it->second);
+                }
+            }
+        }
+        if (group == 0) group = next_gid++;
+        if (strings_here) for (const auto &k : homeless_str) other[k] = group;
+        gid_of[t] = group;
     }
     m.next_free_gid = next_gid;
     m.groups.assign((size_t)(next_gid - 1), {});

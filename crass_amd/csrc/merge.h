@@ -63,6 +63,10 @@ struct MergeResult {
     void clear();
 };
 
+// Wake the host worker pool ahead of a merge (its workers then poll for a few milliseconds): call it while
+// waiting for the device so that the wake-up latency is hidden.
+void host_pool_warm();
+
 // addReadHolder's token assignment (libcrispr.cpp:1137-1143) for every candidate DR in read
 // order, then createNonRedundantSet (WorkHorse.cpp:648-709).
 // rep/hash (optional, from the device de-duplication): rep[k] = candidate index of the first occurrence

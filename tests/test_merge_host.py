@@ -63,6 +63,46 @@ def test_merge_synthetic_large(ca):
     assert sorted(m.patterns) == sorted(ref.patterns)
 
 
+def test_merge_many_variants_and_non_acgt_kmers(ca):
+    """enough DR variants that every multi-threaded phase of the host merge really runs on several
+    threads, plus DRs holding an N (their k-mers take the string-keyed path of clusterDRReads)."""
+    import random
+    rng = random.Random(99)
+
+    def rs(n, alphabet=b"ACGT"):
+        return bytes(rng.choice(alphabet) for _ in range(n))
+    drs = [rs(rng.randint(26, 38)) for _ in range(120)]
+    for i in range(0, 120, 7):                       # some consensus DRs contain an N
+        d = bytearray(drs[i]); d[rng.randint(3, len(d) - 4)] = ord("N"); drs[i] = bytes(d)
+    seqs = []
+    for _ in range(9000):
+        d = bytearray(rng.choice(drs))
+        if rng.random() < 0.7:                       # sequencing-error variant, identical in every repeat of the read
+            k = rng.randrange(len(d))
+            r = rng.random()
+            if r < 0.7: d[k] = rng.choice(b"ACGT")
+            elif r < 0.85: del d[k]
+            else: d.insert(k, rng.choice(b"ACGT"))
+        d = bytes(d)
+        s = rs(rng.randint(0, 12))
+        while len(s) < 190:
+            s += d + rs(rng.randint(28, 38))
+        seqs.append(s[:rng.randint(150, 190)])
+    ref = orc.pipeline(seqs, do_pass2=False)
+    assert ref.n_pass1 > 5000 and len(ref.tokens) > 2500
+    assert any(b"N" in t for t in ref.tokens)
+    chars, lens = ca.dr_slots(oracle_candidates(ref), stride=64)
+    for _ in range(3):                               # repeated: the workers are awake after the first call
+        m = ca.merge_host(chars, lens)
+        assert m.tokens == ref.tokens
+        assert m.cand_token.tolist() == ref.rec_token[:ref.n_pass1].tolist()
+        assert m.groups == ref.groups
+        # the ORDER inside a group is libstdc++'s std::sort/std::partition order in the reference (the oracle is
+        # plain C); pass 2 depends on the set only
+        assert list(m.pat_group) == list(ref.pat_group)
+        assert sorted(zip(list(m.pat_group), m.patterns)) == sorted(zip(list(ref.pat_group), ref.patterns))
+
+
 WORKER = r"""
 import os, sys, json
 sys.path.insert(0, %(root)r)
