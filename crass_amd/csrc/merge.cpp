@@ -254,30 +254,42 @@ int cluster_one(const char *dr_p, size_t dr_n, const int32_t *codes, int n_mers,
 class HostPool {
 public:
     static HostPool &get() { static HostPool p; return p; }
-    // run fn(task) for task in [0, n_tasks) on up to max_threads threads (caller included)
+    // run fn(task) for task in [0, n_tasks) on up to max_threads threads (caller included).  The caller never
+    // waits for a helper to show up, only for the tasks that were actually claimed: a helper that is slow to
+    // wake simply takes no part in the job.
     void run(size_t n_tasks, unsigned max_threads, const std::function<void(size_t)> &fn)
     {
         if (n_tasks == 0) return;
-        unsigned helpers = std::min<unsigned>((unsigned)workers_.size(), max_threads > 0 ? max_threads - 1 : 0);
-        if (n_tasks < 2 || helpers == 0) { for (size_t t = 0; t < n_tasks; t++) fn(t); return; }
+        const unsigned helpers = std::min<unsigned>((unsigned)workers_.size(), max_threads > 0 ? max_threads - 1 : 0);
+        if (n_tasks < 2 || helpers == 0 || n_tasks > 0x7FFFFFFFull) { for (size_t t = 0; t < n_tasks; t++) fn(t); return; }
         std::lock_guard<std::mutex> job_lock(job_mutex_);      // one job at a time
-        fn_ = &fn; n_tasks_ = n_tasks; want_ = helpers;
-        next_.store(0, std::memory_order_relaxed);
-        active_.store(helpers, std::memory_order_relaxed);
-        epoch_.fetch_add(1);                                   // seq_cst: ordered before the sleepers_ check below
+        const uint64_t epoch = (ticket_.load(std::memory_order_relaxed) >> 32) + 1;
+        // two descriptors, indexed by epoch parity: a helper still looking at the previous job's descriptor can
+        // only claim a task while the ticket carries that job's epoch, i.e. before this one is published, and
+        // the descriptor it reads is not rewritten until the job after this one
+        Job &job = jobs_[epoch & 1];
+        job.fn = &fn; job.n_tasks = n_tasks; job.want = helpers;
+        done_.store(0, std::memory_order_relaxed);
+        ticket_.store(epoch << 32);                            // seq_cst: publishes the job, ordered before the sleepers_ check
         wake_sleepers();
-        for (size_t t = next_.fetch_add(1); t < n_tasks; t = next_.fetch_add(1)) fn(t);
-        for (unsigned spins = 0; active_.load(std::memory_order_acquire) != 0;) { cpu_relax(); if ((++spins & 31u) == 0) std::this_thread::yield(); }
-        fn_ = nullptr;
+        size_t mine = 0;
+        for (;;) {
+            uint64_t tk = ticket_.load(std::memory_order_relaxed);
+            if ((tk & 0xFFFFFFFFull) >= n_tasks) break;
+            if (!ticket_.compare_exchange_weak(tk, tk + 1, std::memory_order_acq_rel)) continue;
+            fn((size_t)(tk & 0xFFFFFFFFull));
+            mine++;
+        }
+        done_.fetch_add(mine, std::memory_order_acq_rel);
+        for (unsigned spins = 0; done_.load(std::memory_order_acquire) != n_tasks;) { cpu_relax(); if ((++spins & yield_mask_) == 0) std::this_thread::yield(); }
     }
     // wake the workers now: the next jobs, within the polling window, start without wake-up latency
     void warm()
     {
-        warm_until_.store(now_us() + kPollUs, std::memory_order_relaxed);
+        warm_until_.store(now_us() + poll_us_, std::memory_order_relaxed);
         wake_sleepers();
     }
 private:
-    static constexpr int64_t kPollUs = 2500;
     static int64_t now_us()
     {
         return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -298,61 +310,75 @@ private:
     }
     HostPool()
     {
-        unsigned n = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        unsigned n = std::min<unsigned>(hw, 16);
         if (const char *e = getenv("CRASS_HOST_THREADS")) n = (unsigned)std::max(1, atoi(e));    // 1 = everything on the caller
+        if (const char *e = getenv("CRASS_POOL_POLL_US")) poll_us_ = atoll(e);
+        // a small (possibly oversubscribed) host must not be starved by polling workers: yield often there
+        yield_mask_ = hw <= 16 ? 31u : 4095u;
         for (unsigned i = 0; i + 1 < n; i++) workers_.emplace_back([this, i] { loop(i); });
     }
     ~HostPool()
     {
         stop_.store(true);
-        epoch_.fetch_add(1, std::memory_order_release);
+        ticket_.store(((ticket_.load() >> 32) + 1) << 32 | 0x7FFFFFFFull);
         { std::lock_guard<std::mutex> lk(m_); wake_seq_++; }
         cv_.notify_all();
         for (auto &t : workers_) t.join();
     }
     void loop(unsigned id)
     {
-        uint64_t seen = 0;
+        uint64_t seen = 0;                                      // epoch of the last job this worker looked at
         int64_t poll_until = 0;
         for (;;) {
             // poll for a while, then sleep
             unsigned spins = 0;
-            while (epoch_.load(std::memory_order_acquire) == seen) {
+            while ((ticket_.load(std::memory_order_acquire) >> 32) == seen) {
                 cpu_relax();
-                if ((++spins & 31u) == 0) std::this_thread::yield();   // do not starve the caller on an oversubscribed host
+                if ((++spins & yield_mask_) == 0) std::this_thread::yield();
                 if ((spins & 255u) != 0) continue;
                 const int64_t now = now_us();
                 if (now < poll_until || now < warm_until_.load(std::memory_order_relaxed)) continue;
                 std::unique_lock<std::mutex> lk(m_);
                 sleepers_.fetch_add(1);
                 const uint64_t ws = wake_seq_;
-                cv_.wait(lk, [&] { return wake_seq_ != ws || epoch_.load(std::memory_order_acquire) != seen; });
-                sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+                cv_.wait(lk, [&] { return wake_seq_ != ws || (ticket_.load(std::memory_order_acquire) >> 32) != seen; });
+                sleepers_.fetch_sub(1);
             }
-            seen = epoch_.load(std::memory_order_acquire);
             if (stop_.load()) return;
-            if (id < want_) {
-                const std::function<void(size_t)> *fn = fn_;
-                const size_t n = n_tasks_;
-                for (size_t t = next_.fetch_add(1); t < n; t = next_.fetch_add(1)) (*fn)(t);
-                active_.fetch_sub(1, std::memory_order_acq_rel);
+            uint64_t tk = ticket_.load(std::memory_order_acquire);
+            seen = tk >> 32;
+            // the job fields were written before this epoch was published and stay valid while tasks of this
+            // epoch can still be claimed (the caller waits for every claimed task)
+            const Job &job = jobs_[seen & 1];
+            const std::function<void(size_t)> *fn = job.fn;
+            const size_t n = job.n_tasks;
+            if (id < job.want) {
+                size_t mine = 0;
+                for (;;) {
+                    if ((tk >> 32) != seen || (tk & 0xFFFFFFFFull) >= n) break;
+                    if (!ticket_.compare_exchange_weak(tk, tk + 1, std::memory_order_acq_rel)) continue;   // tk reloaded
+                    (*fn)((size_t)(tk & 0xFFFFFFFFull));
+                    mine++;
+                    tk = ticket_.load(std::memory_order_acquire);
+                }
+                if (mine) done_.fetch_add(mine, std::memory_order_acq_rel);
             }
-            poll_until = now_us() + kPollUs;
+            poll_until = now_us() + poll_us_;
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_, job_mutex_;
     std::condition_variable cv_;
-    const std::function<void(size_t)> *fn_ = nullptr;
-    size_t n_tasks_ = 0;
-    unsigned want_ = 0;
-    std::atomic<size_t> next_{0};
-    std::atomic<unsigned> active_{0};
-    std::atomic<uint64_t> epoch_{0};
+    struct Job { const std::function<void(size_t)> *fn = nullptr; size_t n_tasks = 0; unsigned want = 0; } jobs_[2];
+    std::atomic<uint64_t> ticket_{0};                          // epoch << 32 | next task index
+    std::atomic<size_t> done_{0};
     std::atomic<int> sleepers_{0};
     std::atomic<int64_t> warm_until_{0};
     std::atomic<bool> stop_{false};
     uint64_t wake_seq_ = 0;                                    // guarded by m_
+    int64_t poll_us_ = 2500;
+    unsigned yield_mask_ = 31u;
 };
 
 template <typename F> void parallel_tasks(size_t n_tasks, unsigned max_threads, F fn)
