@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrass_hip.so")
-SOURCES = ["kernels.hip", "engine.cpp", "merge.cpp", "ingest.cpp"]
+SOURCES = ["kernels.hip", "dmerge.hip", "engine.cpp", "merge.cpp", "ingest.cpp"]
 DEPS = SOURCES + ["engine_internal.h", "merge.h", os.path.join("..", "..", "include", "crass_hip.h")]
 
 

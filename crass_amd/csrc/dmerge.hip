@@ -1,0 +1,465 @@
+// dmerge.hip — the DR merge on the device (gfx950, wave64): WorkHorse::createNonRedundantSet
+// (src/crass/WorkHorse.cpp:648-709) = clusterDRReads (:1404-1637) + removeRedundantRepeats
+// (:612-645, includeSubstring :78-86), followed by the construction of everything pass 2 needs
+// (pattern list, anchor key set, exact verification index).  Input: the DISTINCT candidate DR
+// strings in first-occurrence order (= StringCheck token order, StringCheck.cpp:46-81) that the
+// pass-1 tail already produced on the device; nothing here waits for the host.
+//
+// Preconditions (checked by the host before it takes this path, re-checked here -> fail word):
+// every token is ACGT-only, 23 <= length <= 64.  Anything else uses the host merge (merge.cpp).
+//
+// All integer work on a few 10^4 short strings: no MFMA, no HBM roofline to speak of — the point of
+// running it here is that the step no longer leaves the device between pass 1 and pass 2.
+#include "engine_internal.h"
+
+namespace crass {
+
+#define WAVE 64
+static constexpr uint32_t kUnres = 0xFFFFFFFFu;      // root_of[t] not decided yet
+static constexpr uint32_t kNoLane = 0xFFFFFFFEu;     // lane holds no earlier-owned k-mer
+static constexpr uint32_t kNone = 0xFFFFFFFFu;
+static constexpr int kClusterK = 11;                 // CRASS_DEF_KMER_SIZE (crassDefines.h:66)
+
+// (h0,h1) >> bits, low 64 bits; bits in [0,127]
+static __device__ __forceinline__ uint64_t shr128_lo(uint64_t h0, uint64_t h1, uint32_t bits)
+{
+    if (bits == 0) return h0;
+    if (bits < 64) return (h0 >> bits) | (h1 << (64 - bits));
+    return h1 >> (bits - 64);
+}
+static __device__ __forceinline__ uint64_t shr128_hi(uint64_t h1, uint32_t bits)
+{
+    return bits < 64 ? (h1 >> bits) : 0ull;
+}
+// mask of the low 2*len bits of a 128-bit value, len in [1,64]
+static __device__ __forceinline__ void mask128(uint32_t len, uint64_t &m0, uint64_t &m1)
+{
+    if (len >= 32) { m0 = ~0ull; m1 = len >= 64 ? ~0ull : ((1ull << (2 * (len - 32))) - 1ull); }
+    else { m0 = (1ull << (2 * len)) - 1ull; m1 = 0ull; }
+}
+static __device__ __forceinline__ uint32_t kset_hash(uint32_t key, uint32_t log_size)
+{
+    return (key * 0x9E3779B1u) >> (32u - log_size);
+}
+static __device__ __forceinline__ uint32_t ak_h(uint32_t v, uint32_t s, uint32_t m, uint32_t rsh)
+{
+    return ((uint32_t)__umul24(v ^ (v >> s), m)) >> rsh;      // same hash as anchor_probe (kernels.hip)
+}
+
+// ---- 0. initialise every word a later kernel polls, counts into or probes ----
+__global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
+{
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    uint4 ones; ones.x = ones.y = ones.z = ones.w = 0xFFFFFFFFu;
+    uint4 *o4 = reinterpret_cast<uint4 *>(M.owner);
+    for (uint64_t i = tid; i < (1u << 22) / 4; i += nth) o4[i] = ones;
+    for (uint64_t i = tid; i < M.n_tok; i += nth) M.root_of[i] = kUnres;
+    for (uint64_t i = tid; i <= M.n_tok; i += nth) { M.grp_cnt[i] = 0; M.grp_fill[i] = 0; M.surv_cnt[i] = 0; }
+    const uint64_t ks = 1ull << M.kset_log;
+    for (uint64_t i = tid; i < ks; i += nth) { M.kset_key[i] = 0ull; M.kset_head[i] = kNone; }
+    uint4 *t4 = reinterpret_cast<uint4 *>(M.anchor_tab);
+    for (uint64_t i = tid; i < (1ull << M.tab_log_alloc) / 4; i += nth) t4[i] = ones;
+    if (tid == 0) {
+        DevMergeState s{};
+        s.k0 = 0xFFFFFFFFu;
+        *M.st = s;
+    }
+}
+
+// ---- 1. 2-bit packing (forward and reverse complement) + laurenized 11-mer codes + k-mer owners ----
+// owner[code] = smallest token containing the k-mer = the token whose group the k-mer belongs to in the
+// reference's k2GIDMap (homeless k-mers are assigned to their first token's group, WorkHorse.cpp:1612-1617).
+__global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M.n_tok) return;
+    const char *p = M.dx_chars + (uint64_t)t * M.stride;
+    const uint32_t len = M.dx_len[t];
+    if (len > 64 || len < 23) { atomicOr(&M.st->fail, 1u); return; }
+    uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
+    uint32_t fwd = 0, rev = 0;
+    bool bad = false;
+    for (uint32_t i = 0; i < len; i++) {
+        const char ch = p[i];
+        uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;
+        if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') bad = true;
+        if (i < 32) f0 |= (uint64_t)c << (2 * i); else f1 |= (uint64_t)c << (2 * (i - 32));
+        const uint32_t j = len - 1 - i;
+        if (j < 32) r0 |= (uint64_t)(3u - c) << (2 * j); else r1 |= (uint64_t)(3u - c) << (2 * (j - 32));
+        // first base most significant: integer order == lexicographic order, laurenize() == min (SeqUtils.cpp:89-97)
+        fwd = ((fwd << 2) | c) & 0x3FFFFFu;
+        rev = (rev >> 2) | ((3u - c) << 20);
+        if (i + 1 >= (uint32_t)kClusterK) {
+            const uint32_t code = fwd < rev ? fwd : rev;
+            M.codes[(uint64_t)t * M.kmax + (i + 1 - kClusterK)] = code;
+            atomicMin(&M.owner[code], t);
+        }
+    }
+    uint64_t *pk = M.packed + (uint64_t)t * 4;
+    pk[0] = f0; pk[1] = f1; pk[2] = r0; pk[3] = r1;
+    if (bad) atomicOr(&M.st->fail, 1u);
+}
+
+// ---- 2. the greedy, order-dependent group assignment (clusterDRReads) ----
+// One wave per token; wave w of W takes tokens w, w+W, ...  A wave only ever waits for tokens with a
+// smaller index, i.e. for a wave that is in the same or an earlier round, so with all W waves resident
+// (the grid is at most one 256-thread block per CU) the smallest undecided token can always finish.
+// Lane q owns the token's q-th k-mer: if an EARLIER token owns that k-mer the lane fetches that token's
+// root (the first token of its group); the reference's scan ("first group whose count reaches
+// kmer_clust_size on a repeated sighting", :1573-1590) is then a prefix count across lanes.  root_of[]
+// words are their own flags: written once with an agent-scope store, polled with agent-scope loads
+// (8 XCDs, private L2s).  Every spin is bounded: on a time-out the fail word is set and the host merges.
+__global__ __launch_bounds__(256) void k_dm_greedy(DevMerge M)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t t = wave; t < M.n_tok; t += n_waves) {
+        int nk = (int)M.dx_len[t] - kClusterK + 1;
+        if (nk < 0) nk = 0;
+        if (nk > 64) nk = 64;
+        bool valid = false;
+        uint32_t o = 0;
+        if (lane < nk) {
+            o = M.owner[M.codes[(uint64_t)t * M.kmax + lane]];
+            valid = o < t;                      // o == t: homeless k-mer (first seen in this token), not counted
+        }
+        uint32_t r = valid ? kUnres : kNoLane;
+        bool gave_up = false;
+        for (uint32_t spins = 0;; spins++) {
+            if (valid && r == kUnres) r = __hip_atomic_load(&M.root_of[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(valid && r == kUnres) == 0ull) break;
+            if ((spins & 255u) == 255u) {
+                const uint32_t f = __hip_atomic_load(&M.st->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (f != 0 || spins > (1u << 20)) { gave_up = true; break; }
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (gave_up) {
+            if (lane == 0) atomicOr(&M.st->fail, 8u);
+            if (r == kUnres) r = kNoLane;
+        }
+        // c = sightings of this lane's group among lanes 0..lane
+        uint32_t c = 0;
+        for (int j = 0; j < nk; j++) {
+            const uint32_t rj = (uint32_t)__shfl((int)r, j);
+            if (j <= lane && rj == r) c++;
+        }
+        const uint64_t win = __ballot(valid && r != kNoLane && c >= M.thr);
+        uint32_t root = t;                      // no group reached the threshold: new group (:1595-1606)
+        if (win) root = (uint32_t)__shfl((int)r, __ffsll((unsigned long long)win) - 1);
+        if (lane == 0) __hip_atomic_store(&M.root_of[t], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// exclusive scan of n uint32 (n known on the host), one workgroup; *total = sum
+__global__ __launch_bounds__(1024) void k_dm_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_sh;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t i0 = base + threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? in[i0 + k] : 0u;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const uint32_t s = wsum[k]; if (k < wv) wbase += s; all += s; }
+        uint32_t run = carry_sh + wbase + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_sh += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry_sh;
+}
+
+// ---- 3. group ids: roots numbered in token order (= nextFreeGID++ order, :1598) ----
+__global__ __launch_bounds__(256) void k_dm_flag_roots(DevMerge M)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M.n_tok) M.tmp[t] = (M.root_of[t] == t) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_dm_gid(DevMerge M)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M.n_tok) return;
+    const uint32_t g = M.root_rank[M.root_of[t]];
+    M.gid_of[t] = g + 1;
+    atomicAdd(&M.grp_cnt[g], 1u);
+}
+// members[] = tokens ordered by group (order inside a group is irrelevant: it only makes the lanes of
+// a wave walk the same member range below)
+__global__ __launch_bounds__(256) void k_dm_scatter(DevMerge M)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M.n_tok) return;
+    const uint32_t g = M.gid_of[t] - 1;
+    M.members[M.grp_off[g] + atomicAdd(&M.grp_fill[g], 1u)] = t;
+}
+
+// ---- 4. removeRedundantRepeats: a member is dropped iff a strictly shorter member of its group, or
+// that member's reverse complement, occurs in it (equal-length members are distinct strings; the
+// relation is transitive, so "blanked earlier" never matters).  t or rc(t) in s <=> t in s or in rc(s).
+__global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= M.n_tok) return;
+    const uint32_t j = M.members[s];
+    const uint32_t g = M.gid_of[j] - 1;
+    const uint32_t lo = M.grp_off[g], hi = lo + M.grp_cnt[g];
+    const uint32_t lenj = M.dx_len[j];
+    const uint64_t *pj = M.packed + (uint64_t)j * 4;
+    const uint64_t hay[4] = {pj[0], pj[1], pj[2], pj[3]};
+    bool blank = false;
+    for (uint32_t is = lo; is < hi && !blank; is++) {
+        const uint32_t i = M.members[is];
+        const uint32_t leni = M.dx_len[i];
+        if (leni >= lenj) continue;
+        const uint64_t n0 = M.packed[(uint64_t)i * 4], n1 = M.packed[(uint64_t)i * 4 + 1];
+        uint64_t m0, m1;
+        mask128(leni, m0, m1);
+        const uint32_t nshift = lenj - leni;
+        for (int o = 0; o < 2 && !blank; o++) {
+            const uint64_t h0 = hay[2 * o], h1 = hay[2 * o + 1];
+            for (uint32_t p = 0; p <= nshift; p++) {
+                const uint64_t w0 = shr128_lo(h0, h1, 2 * p);
+                if ((uint32_t)w0 != (uint32_t)n0) continue;            // first 16 bases (every member is >= 23 long)
+                const uint64_t w1 = shr128_hi(h1, 2 * p);
+                if ((w0 & m0) == n0 && (w1 & m1) == n1) { blank = true; break; }
+            }
+        }
+    }
+    M.blank[j] = blank ? 1 : 0;
+    if (!blank) atomicAdd(&M.surv_cnt[g], 1u);
+}
+
+// ---- 5. pattern list: per group (ascending GID) the survivors, then their reverse complements
+// (WorkHorse.cpp:690-697).  Inside a group the survivors are ordered by (length, token) — one of the
+// orders an unstable sort by length may produce; pass 2 depends on the SET only.
+__global__ __launch_bounds__(256) void k_dm_patterns(DevMerge M)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= M.n_tok) return;
+    const uint32_t j = M.members[s];
+    if (M.blank[j]) return;
+    const uint32_t g = M.gid_of[j] - 1;
+    const uint32_t lo = M.grp_off[g], hi = lo + M.grp_cnt[g];
+    const uint32_t lenj = M.dx_len[j];
+    uint32_t k = 0;
+    for (uint32_t is = lo; is < hi; is++) {
+        const uint32_t i = M.members[is];
+        if (M.blank[i]) continue;
+        const uint32_t li = M.dx_len[i];
+        if (li < lenj || (li == lenj && i < j)) k++;
+    }
+    const uint32_t E = M.surv_off[g], cnt = M.surv_cnt[g];
+    const uint32_t pf = 2 * E + k, pr = 2 * E + cnt + k;
+    const uint64_t *pj = M.packed + (uint64_t)j * 4;
+    M.pat_packed[(uint64_t)pf * 2] = pj[0]; M.pat_packed[(uint64_t)pf * 2 + 1] = pj[1];
+    M.pat_packed[(uint64_t)pr * 2] = pj[2]; M.pat_packed[(uint64_t)pr * 2 + 1] = pj[3];
+    M.pat_len[pf] = (uint16_t)lenj; M.pat_len[pr] = (uint16_t)lenj;
+    // token of the pattern's low-lexi form: the survivor's own token for the survivor and for its reverse
+    // complement alike (a token string is low-lexi by construction, ReadHolder.cpp:573-590)
+    M.pat_token[pf] = j + 2; M.pat_token[pr] = j + 2;
+}
+
+// ---- 6. anchor keys: every 16-mer at offset 0..7 of a pattern (see kernels.hip, pass-2 fast path).
+// Entry e = pid*8 + r.  Distinct keys are claimed in an open-addressing set; every entry is linked
+// into its key's chain (the exact verification index of k_dm_verify).
+__global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pid = e >> 3, r = e & 7u;
+    const uint32_t n_pat = 2 * M.st->n_survivors;
+    if (pid >= n_pat) return;
+    const uint32_t key = (uint32_t)shr128_lo(M.pat_packed[(uint64_t)pid * 2], M.pat_packed[(uint64_t)pid * 2 + 1], 2 * r);
+    const uint32_t kmask = (1u << M.kset_log) - 1u;
+    const unsigned long long want = (unsigned long long)key | (1ull << 32);
+    uint32_t h = kset_hash(key, M.kset_log);
+    bool winner = false;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&M.kset_key[h], 0ull, want);
+        if (old == 0ull) { winner = true; break; }
+        if (old == want) break;
+        h = (h + 1) & kmask;
+    }
+    M.ent_next[e] = atomicExch(&M.kset_head[h], e);
+    M.ent_win[e] = winner ? 1 : 0;
+    if (winner) {
+        atomicAdd(&M.st->n_keys, 1u);
+        atomicMin(&M.st->k0, key);
+        if (key == 0xFFFFFFFFu) atomicOr(&M.st->all_t, 1u);
+    }
+}
+
+// table size: load <= 1/3 (<= 1/2 at the LDS limit 2^15 and at the allocation limit), as build_anchors (merge.cpp)
+__global__ void k_dm_cuckoo_params(DevMerge M)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const uint32_t n = M.st->n_keys;
+    uint32_t ls = 0;
+    for (uint32_t log = 10; log <= 15 && !ls; log++) {
+        const uint32_t size = 1u << log;
+        if (n * 3 > size && log != 15) continue;
+        if (n * 2 > size) continue;
+        ls = log;
+    }
+    for (uint32_t log = 16; log <= M.tab_log_alloc && !ls; log++) {
+        const uint32_t size = 1u << log;
+        if (n * 3 > size && log != M.tab_log_alloc) continue;
+        if (n * 2 > size) continue;
+        ls = log;
+    }
+    if (ls > M.tab_log_alloc) ls = 0;
+    if (!ls || n == 0) atomicOr(&M.st->fail, 2u);
+    M.st->log_size = ls;
+    M.st->n_patterns = 2 * M.st->n_survivors;
+}
+
+// two-choice cuckoo insertion, all keys at once: a key is always either in the table or in exactly one
+// thread's hand (atomicExch).  0xFFFFFFFF marks a free slot; the all-T key itself is handled by finalize.
+__global__ __launch_bounds__(256) void k_dm_cuckoo_insert(DevMerge M)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pid = e >> 3, r = e & 7u;
+    if (pid >= 2 * M.st->n_survivors || !M.ent_win[e] || M.st->fail) return;
+    uint32_t cur = (uint32_t)shr128_lo(M.pat_packed[(uint64_t)pid * 2], M.pat_packed[(uint64_t)pid * 2 + 1], 2 * r);
+    if (cur == 0xFFFFFFFFu) return;
+    const uint32_t rsh = 32u - M.st->log_size;
+    uint32_t pos = ak_h(cur, M.s1, M.m1, rsh);
+    for (int kicks = 0; kicks < 1000; kicks++) {
+        const uint32_t old = atomicExch(&M.anchor_tab[pos], cur);
+        if (old == 0xFFFFFFFFu) return;
+        cur = old;
+        const uint32_t p1 = ak_h(cur, M.s1, M.m1, rsh), p2 = ak_h(cur, M.s2, M.m2, rsh);
+        pos = (pos == p1) ? p2 : p1;
+    }
+    atomicOr(&M.st->fail, 4u);
+}
+// unused slots hold a member key, so a probe never matches by accident
+__global__ __launch_bounds__(256) void k_dm_cuckoo_finalize(DevMerge M)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ls = M.st->log_size;
+    if (!ls || i >= (1u << ls) || M.st->all_t) return;
+    if (M.anchor_tab[i] == 0xFFFFFFFFu) M.anchor_tab[i] = M.st->k0;
+}
+
+hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
+{
+    if (M.n_tok == 0) return hipErrorInvalidValue;
+    const unsigned nb = (M.n_tok + 255) / 256;
+    hipLaunchKernelGGL(k_dm_init, dim3(1024), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_pack_codes, dim3(nb), dim3(256), 0, st, M);
+    unsigned gb = (M.n_tok + 3) / 4;
+    if (gb > 256) gb = 256;                 // every wave must be resident: at most one small block per CU
+    hipLaunchKernelGGL(k_dm_greedy, dim3(gb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_flag_roots, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.tmp, M.root_rank, M.n_tok, &M.st->n_groups);
+    hipLaunchKernelGGL(k_dm_gid, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.grp_cnt, M.grp_off, M.n_tok, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_dm_scatter, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_redundant, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok, &M.st->n_survivors);
+    hipLaunchKernelGGL(k_dm_patterns, dim3(nb), dim3(256), 0, st, M);
+    const unsigned ne = (16u * M.n_tok + 255) / 256;
+    hipLaunchKernelGGL(k_dm_keys, dim3(ne), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_cuckoo_params, dim3(1), dim3(64), 0, st, M);
+    hipLaunchKernelGGL(k_dm_cuckoo_insert, dim3(ne), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_cuckoo_finalize, dim3((unsigned)(((1ull << M.tab_log_alloc) + 255) / 256)), dim3(256), 0, st, M);
+    return hipGetLastError();
+}
+
+// ---- pass 2, exact verification of the reads the anchor filter flagged (replaces the automaton scan
+// on this path).  Every occurrence of a pattern P at offset o is found through exactly one aligned
+// window a = ceil8(o): the key at a is P[a-o .. a-o+16), so the entry (P, r = a-o) is in that key's
+// chain.  Wanted: ACISM's first callback = smallest end position, ties -> longest pattern
+// (libcrispr.cpp:441, acism.c:73-102).  An occurrence found through window a ends at >= a+16, so the
+// scan stops as soon as the best end so far is <= a+15.
+// info_by_slot[k] = (end_exclusive << 8) | length, 0 = none; pid_by_slot[k] = pattern index.
+static __device__ __forceinline__ uint32_t dm_rd_len(const DevReads &R, uint64_t r) { return R.uniform_len ? R.uniform_len : R.lengths[r]; }
+static __device__ __forceinline__ uint64_t dm_rd_off(const DevReads &R, uint64_t r) { return R.stride_words ? r * (uint64_t)R.stride_words : R.word_off[r]; }
+
+__global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
+                                                    uint32_t *info_by_slot, uint32_t *pid_by_slot)
+{
+    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t n = *d_n;
+    if (n > n_max) n = n_max;
+    if (k >= n) return;
+    const uint64_t r = idx[k];
+    const uint32_t L = dm_rd_len(R, r);
+    const uint32_t *g = R.packed + dm_rd_off(R, r);
+    const uint32_t nw = (L + 15) >> 4;
+    const uint32_t kmask = (1u << M.kset_log) - 1u;
+    uint32_t best_end = 0xFFFFFFFFu, best_len = 0, best_pid = 0;
+    if (L >= 16) {
+        const uint32_t h_max = (L - 16) >> 3;
+        for (uint32_t h = 0; h <= h_max; h++) {
+            const uint32_t a = 8 * h;
+            if (best_end <= a + 15) break;
+            const uint32_t wi = h >> 1;
+            const uint32_t lo = g[wi], hi = (wi + 1 < nw) ? g[wi + 1] : 0u;
+            const uint32_t V = (h & 1) ? ((lo >> 16) | (hi << 16)) : lo;
+            const unsigned long long want = (unsigned long long)V | (1ull << 32);
+            uint32_t s = kset_hash(V, M.kset_log);
+            uint32_t e = kNone;
+            for (;;) {
+                const unsigned long long kk = M.kset_key[s];
+                if (kk == 0ull) break;
+                if (kk == want) { e = M.kset_head[s]; break; }
+                s = (s + 1) & kmask;
+            }
+            for (; e != kNone; e = M.ent_next[e]) {
+                const uint32_t pid = e >> 3, rr = e & 7u;
+                if (a < rr) continue;
+                const uint32_t start = a - rr;
+                const uint32_t len = M.pat_len[pid];
+                const uint32_t end = start + len;
+                if (end > L) continue;
+                if (end > best_end || (end == best_end && len <= best_len)) continue;
+                // read bases [start, start+len) as a 128-bit value
+                const uint32_t w0 = start >> 4, sh = (start & 15u) * 2u;
+                uint32_t x[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) { const uint32_t ii = w0 + q; x[q] = ii < nw ? g[ii] : 0u; }
+                uint32_t y[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) y[q] = sh ? ((x[q] >> sh) | (x[q + 1] << (32 - sh))) : x[q];
+                const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
+                uint64_t m0, m1;
+                mask128(len, m0, m1);
+                if ((v0 & m0) == M.pat_packed[(uint64_t)pid * 2] && (v1 & m1) == M.pat_packed[(uint64_t)pid * 2 + 1]) {
+                    best_end = end; best_len = len; best_pid = pid;
+                }
+            }
+        }
+    }
+    info_by_slot[k] = best_len ? ((best_end << 8) | best_len) : 0u;
+    pid_by_slot[k] = best_pid;
+}
+
+hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
+                            uint32_t *info_by_slot, uint32_t *pid_by_slot, hipStream_t st)
+{
+    if (n_max == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dm_verify, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    return hipGetLastError();
+}
+
+} // namespace crass

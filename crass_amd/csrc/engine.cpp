@@ -141,6 +141,29 @@ struct crass_hip_ctx {
         (void)hipStreamSynchronize(copy_stream);
         bulk_pending = false;
     }
+    // device-side merge (dmerge.hip): clustering, non-redundant set, anchor keys and the pass-2 verification
+    // index are built on the device; the host view (c->merge) is rebuilt from its per-token results while
+    // pass 2 runs.  dm.active: the installed pattern set lives in dm.M, not in the automaton/anchors above.
+    struct DM {
+        DevBuf<uint64_t> packed, pat_packed; DevBuf<uint32_t> codes, owner, root_of, tmp, root_rank, gid_of, grp, members, pat_token;
+        DevBuf<uint32_t> kset_head, ent_next, anchor_tab; DevBuf<uint8_t> blank, ent_win; DevBuf<uint16_t> pat_len;
+        DevBuf<unsigned long long> kset_key; DevBuf<DevMergeState> st;
+        PinBuf<DevMergeState> h_st; PinBuf<uint32_t> h_gid; PinBuf<uint8_t> h_blank;
+        DevMerge M{};
+        bool active = false, host_built = false;
+        uint64_t n_cand = 0;
+        hipEvent_t ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+        void release()
+        {
+            packed.release(); pat_packed.release(); codes.release(); owner.release(); root_of.release(); tmp.release(); root_rank.release();
+            gid_of.release(); grp.release(); members.release(); pat_token.release(); kset_head.release(); ent_next.release(); anchor_tab.release();
+            blank.release(); ent_win.release(); pat_len.release(); kset_key.release(); st.release(); h_st.release(); h_gid.release(); h_blank.release();
+            if (ev_done) (void)hipEventDestroy(ev_done);
+            if (ev_t0) (void)hipEventDestroy(ev_t0);
+            if (ev_t1) (void)hipEventDestroy(ev_t1);
+            ev_done = ev_t0 = ev_t1 = nullptr;
+        }
+    } dm;
     // distinct candidate strings (multi-GPU exchange)
     std::vector<char> dx_chars; std::vector<uint16_t> dx_len; std::vector<uint32_t> dx_map; bool have_distinct = false;
     uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
@@ -240,6 +263,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    c->dm.release();
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
     if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
@@ -287,6 +311,7 @@ static int alloc_scratch(crass_hip_ctx *c)
 static void reset_results(crass_hip_ctx *c)
 {
     c->have_pass1 = c->have_merge = c->have_pass2 = c->have_patterns = false;
+    c->dm.active = false;
     memset(&c->cnt, 0, sizeof(c->cnt));
 }
 
@@ -522,12 +547,13 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
         HIPCHK(c, c->dd_rep.ensure(n_surv)); HIPCHK(c, c->dd_hash.ensure(n_surv)); HIPCHK(c, c->h_rep.ensure(n_surv)); HIPCHK(c, c->h_hash.ensure(n_surv));
         HIPCHK(c, c->h_dmap.ensure(n_surv)); HIPCHK(c, c->h_dx_chars.ensure(n_surv * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(n_surv));
         HIPCHK(c, c->h_dx_hash.ensure(n_surv));
+        HIPCHK(c, c->dd_dx_chars.ensure(n_surv * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_surv));
         HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_keys.p, c->dd_first.p, tsize,
                                    c->dd_hash.p, c->dd_slot.p, c->dd_rep.p, c->stream));
         // distinct strings in first-occurrence order and every candidate's rank among them, exact
         HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->d_mask.p,
                                    c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
-                                   c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->stream));
+                                   c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, D.h_read.ensure(n_surv)); HIPCHK(c, D.h_ss_off.ensure(n_surv)); HIPCHK(c, D.h_low.ensure(n_surv)); HIPCHK(c, D.h_replen.ensure(n_surv));
@@ -573,6 +599,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     (void)hipSetDevice(c->device);
     c->wait_bulk();
     c->have_pass1 = c->have_merge = c->have_pass2 = false;
+    c->dm.active = false;
     const uint64_t n = c->R.n_reads;
     const uint64_t n_words = (n + 63) / 64;
     HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
@@ -704,6 +731,7 @@ static int install_patterns(crass_hip_ctx *c, const StringArena &pats)
 {
     c->n_installed_patterns = (uint32_t)pats.size();
     c->have_patterns = false;
+    c->dm.active = false;                               // the installed set is the host-built one from here on
     c->cnt.n_patterns = (uint32_t)pats.size();
     if (pats.empty()) { c->cnt.ac_states = 0; return CRASS_OK; }
     for (size_t i = 0; i < pats.size(); i++) if (pats.len(i) == 0 || pats.len(i) > 255) return CRASS_ERR_UNSUPPORTED;
@@ -777,10 +805,109 @@ static int ensure_full_automaton(crass_hip_ctx *c)
 
 static int finish_merge(crass_hip_ctx *c, double t0);
 
+// ---- the merge on the device (dmerge.hip) ----
+static bool device_merge_applies(const crass_hip_ctx *c)
+{
+    if (getenv("CRASS_HOST_MERGE")) return false;                 // A/B switch: force the host merge (merge.cpp)
+    return c->have_pass1 && c->dense.active && c->have_dev_tokens && c->R.n_exc == 0 && c->prm.lowDRsize >= 23 &&
+           c->dr_stride <= 64 && c->n_dx > 0 && c->n_dx <= (1u << 20);
+}
+
+static int device_merge(crass_hip_ctx *c)
+{
+    crass_hip_ctx::DM &d = c->dm;
+    const uint32_t n = (uint32_t)c->n_dx, stride = c->dr_stride;
+    if (!d.ev_done) {
+        HIPCHK(c, hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreate(&d.ev_t0)); HIPCHK(c, hipEventCreate(&d.ev_t1));
+    }
+    DevMerge M{};
+    M.dx_chars = c->dd_dx_chars.p; M.dx_len = c->dd_dx_len.p; M.stride = stride; M.n_tok = n;
+    M.thr = (uint32_t)std::max(c->prm.kmer_clust_size, 2); M.kmax = stride - 10;
+    M.kset_log = 10; while ((1ull << M.kset_log) < 32ull * n) M.kset_log++;
+    M.tab_log_alloc = 15; while (M.tab_log_alloc < 24 && (1ull << M.tab_log_alloc) < 48ull * n) M.tab_log_alloc++;
+    HIPCHK(c, d.packed.ensure((size_t)n * 4)); HIPCHK(c, d.codes.ensure((size_t)n * M.kmax)); HIPCHK(c, d.owner.ensure(1u << 22));
+    HIPCHK(c, d.root_of.ensure(n)); HIPCHK(c, d.tmp.ensure(n + 1)); HIPCHK(c, d.root_rank.ensure(n + 1)); HIPCHK(c, d.gid_of.ensure(n));
+    HIPCHK(c, d.grp.ensure(5 * ((size_t)n + 1))); HIPCHK(c, d.members.ensure(n)); HIPCHK(c, d.blank.ensure(n));
+    HIPCHK(c, d.pat_packed.ensure((size_t)n * 4)); HIPCHK(c, d.pat_len.ensure((size_t)n * 2)); HIPCHK(c, d.pat_token.ensure((size_t)n * 2));
+    HIPCHK(c, d.kset_key.ensure((size_t)1 << M.kset_log)); HIPCHK(c, d.kset_head.ensure((size_t)1 << M.kset_log));
+    HIPCHK(c, d.ent_next.ensure((size_t)n * 16)); HIPCHK(c, d.ent_win.ensure((size_t)n * 16));
+    HIPCHK(c, d.anchor_tab.ensure((size_t)1 << M.tab_log_alloc)); HIPCHK(c, d.st.ensure(1));
+    HIPCHK(c, d.h_st.ensure(1)); HIPCHK(c, d.h_gid.ensure(n)); HIPCHK(c, d.h_blank.ensure(n));
+    M.packed = d.packed.p; M.codes = d.codes.p; M.owner = d.owner.p; M.root_of = d.root_of.p; M.tmp = d.tmp.p; M.root_rank = d.root_rank.p;
+    M.gid_of = d.gid_of.p;
+    M.grp_cnt = d.grp.p; M.grp_off = d.grp.p + (n + 1); M.grp_fill = d.grp.p + 2 * ((size_t)n + 1); M.surv_cnt = d.grp.p + 3 * ((size_t)n + 1);
+    M.surv_off = d.grp.p + 4 * ((size_t)n + 1);
+    M.members = d.members.p; M.blank = d.blank.p; M.pat_packed = d.pat_packed.p; M.pat_len = d.pat_len.p; M.pat_token = d.pat_token.p;
+    M.kset_key = d.kset_key.p; M.kset_head = d.kset_head.p; M.ent_next = d.ent_next.p; M.ent_win = d.ent_win.p;
+    M.anchor_tab = d.anchor_tab.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
+    d.M = M;
+    HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
+    HIPCHK(c, launch_device_merge(M, c->stream));
+    HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
+    if (getenv("CRASS_DM_INJECT_FAIL"))                           // tests: exercise the fall-back to the host merge
+        HIPCHK(c, hipMemsetAsync(&d.st.p->fail, 1, 4, c->stream));
+    // the per-token results the host view is rebuilt from (a few 10 KB)
+    HIPCHK(c, hipMemcpyAsync(d.h_st.p, d.st.p, sizeof(DevMergeState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.h_gid.p, d.gid_of.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.h_blank.p, d.blank.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
+    d.active = true; d.host_built = false; d.n_cand = c->dense.n;
+    c->have_merge = true; c->have_pass2 = false;
+    c->have_patterns = true; c->have_anchors = false; c->have_pat_token = false;
+    c->n_installed_patterns = 2;                                  // >= 1 survivor exists; the exact count arrives with h_st
+    return CRASS_OK;
+}
+
+// host merge after all (the device path reported a condition it does not handle)
+static int host_merge_fallback(crass_hip_ctx *c)
+{
+    c->dm.active = false;
+    const double t0 = now_ms();
+    if (!merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
+                             c->prm.kmer_clust_size))
+        merge_candidates(c->merge, c->cand_dr(), c->cand_dr_len(), c->dr_stride, c->n_cand(), c->prm.kmer_clust_size);
+    return finish_merge(c, t0);
+}
+
+// c->merge for a merge that ran on the device: 0 ok, CRASS_ERR_STATE = the device path failed (caller falls back)
+static int ensure_host_merge(crass_hip_ctx *c)
+{
+    crass_hip_ctx::DM &d = c->dm;
+    if (!d.active || d.host_built) return CRASS_OK;
+    HIPCHK(c, hipEventSynchronize(d.ev_done));
+    if (d.h_st.p->fail) return CRASS_ERR_STATE;
+    if (!merge_from_device(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->dr_stride, c->n_dx, c->h_dmap.p, d.n_cand, d.h_gid.p, d.h_blank.p,
+                           d.h_st.p->n_groups) ||
+        c->merge.patterns.size() != d.h_st.p->n_patterns)
+        return CRASS_ERR_STATE;
+    d.host_built = true;
+    c->n_installed_patterns = d.h_st.p->n_patterns;
+    c->cnt.n_patterns = d.h_st.p->n_patterns;
+    c->cnt.ac_states = 0;
+    c->cnt.anchor_keys = d.h_st.p->n_keys;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, d.ev_t0, d.ev_t1); c->cnt.ms_merge_device = ms;
+    return CRASS_OK;
+}
+
 int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n)
 {
     if (!c) return CRASS_ERR_INVALID_ARG;
     const double t0 = now_ms();
+    c->dm.active = false;
+    c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
+    if (!dr_chars && device_merge_applies(c)) {
+        (void)hipSetDevice(c->device);
+        int s = device_merge(c);
+        if (s == CRASS_OK) {
+            c->cnt.used_device_merge = 1;
+            c->cnt.ms_merge_host = (float)(now_ms() - t0);
+            return CRASS_OK;
+        }
+        if (s != CRASS_ERR_HIP) return s;
+        return s;
+    }
     if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens &&
         merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
                             c->prm.kmer_clust_size))
@@ -891,6 +1018,12 @@ int crass_hip_get_merge(const crass_hip_ctx *c, crass_merge_view *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     if (!c->have_merge) return CRASS_ERR_STATE;
+    if (c->dm.active && !c->dm.host_built) {
+        crass_hip_ctx *mc = const_cast<crass_hip_ctx *>(c);
+        int s = ensure_host_merge(mc);
+        if (s == CRASS_ERR_STATE) s = host_merge_fallback(mc);
+        if (s) return s;
+    }
     const MergeResult &m = c->merge;
     o->n_tokens = m.tokens.size(); o->tok_chars = m.tokens.strings.chars.data(); o->tok_off = m.tokens.strings.off.data();
     o->n_candidates = m.cand_token.size(); o->cand_token = m.cand_token.data();
@@ -937,7 +1070,11 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     // fast path: anchor filter (exact superset) then an exact scan of the flagged reads only;
     // otherwise the automaton scans every read (LDS table when it fits).
     bool anchors = false, lds = false;
-    if (c->have_anchors) {
+    const bool dmp = c->dm.active;                  // pattern set built on the device (dmerge.hip)
+    if (dmp) {
+        HIPCHK(c, launch_anchor_filter_dev(c->R, c->dm.M, c->d_found.p, c->d_mask.p, c->stream));
+        anchors = true;
+    } else if (c->have_anchors) {
         hipError_t ae = launch_anchor_filter(c->R, c->K, c->d_found.p, c->d_mask.p, c->stream);
         if (ae == hipSuccess) anchors = true;
         else if (ae != hipErrorNotSupported) { c->last_hip = (int)ae; return CRASS_ERR_HIP; }
@@ -956,6 +1093,19 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+    if (dmp) {
+        // the host view of the merge (tokens, groups, pattern list) is rebuilt while the filter runs
+        const double th0 = now_ms();
+        const int hs = ensure_host_merge(c);
+        c->cnt.ms_merge_host += (float)(now_ms() - th0);
+        if (hs == CRASS_ERR_STATE) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const int fs = host_merge_fallback(c);
+            if (fs) return fs;
+            return crass_hip_recruit(c, extra_found, n_extra);
+        }
+        if (hs) return hs;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t n_hits = c->h_count.p[0];
     const uint64_t n_slots = n_hits + c->R.n_exc;
@@ -967,11 +1117,12 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     if (anchors) {
         HIPCHK(c, c->d_slot_info.ensure(n_hits + 1));
         HIPCHK(c, c->d_slot_pid.ensure(n_hits + 1));
-        HIPCHK(c, launch_recruit_list(c->R, c->A, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->d_slot_pid.p, c->stream));
+        if (dmp) HIPCHK(c, launch_dm_verify(c->R, c->dm.M, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->d_slot_pid.p, c->stream));
+        else HIPCHK(c, launch_recruit_list(c->R, c->A, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->d_slot_pid.p, c->stream));
     }
-    const bool dev_tokens = anchors && c->have_pat_token && c->have_merge;
+    const bool dev_tokens = dmp || (anchors && c->have_pat_token && c->have_merge);
     HIPCHK(c, launch_recruit_finish(c->R, c->d_idx.p, c->d_count.p, n_hits, anchors ? c->d_slot_info.p : c->d_hit_info.p, anchors, false,
-                                    dev_tokens ? c->d_slot_pid.p : nullptr, dev_tokens ? c->a_pat_token.p : nullptr,
+                                    dev_tokens ? c->d_slot_pid.p : nullptr, dev_tokens ? (dmp ? c->dm.M.pat_token : c->a_pat_token.p) : nullptr,
                                     c->d_rec.p, c->d_dr.p, c->dr_stride, c->stream));
     if (c->R.n_exc)
         HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, c->R.n_exc, c->d_exc_hit.p, true, true, nullptr, nullptr, c->d_rec.p + n_hits,
@@ -1021,8 +1172,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     c->cnt.ms_sink_host += (float)(now_ms() - t0);
     c->cnt.n_pass2_found = c->q_read.size();
     c->cnt.used_lds_automaton = anchors ? 2 : (lds ? 1 : 0);     // 2 = anchor filter + exact list scan
-    c->cnt.anchor_keys = anchors ? c->K.n_keys : 0;
-    c->cnt.anchor_table_kind = !anchors ? 0 : (c->K.log_size > 15 ? 2 : c->K.mode);
+    c->cnt.anchor_keys = !anchors ? 0 : (dmp ? c->dm.h_st.p->n_keys : c->K.n_keys);
+    c->cnt.anchor_table_kind = !anchors ? 0 : (dmp ? (c->dm.h_st.p->log_size > 15 ? 2 : 0) : (c->K.log_size > 15 ? 2 : c->K.mode));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->cnt.ms_recruit = ms;
     (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->cnt.ms_recruit_finish = ms;

@@ -77,6 +77,60 @@ struct DevAnchors {
     uint32_t n_keys;
 };
 
+// ---- device-side DR merge (dmerge.hip) ----
+// small device-resident result/flag words of one merge; copied to pinned host memory afterwards
+struct DevMergeState {
+    uint32_t n_groups;            // number of DR groups (next_free_gid - 1)
+    uint32_t n_survivors;         // non-redundant variants
+    uint32_t n_patterns;          // 2 * n_survivors
+    uint32_t n_keys;              // distinct anchor keys
+    uint32_t log_size;            // anchor table holds 1 << log_size slots (<= 15: staged in LDS)
+    uint32_t fail;                // != 0: the device path does not apply (1 token outside ACGT/23..64, 2 key set too
+                                  // large or empty, 4 cuckoo insertion gave up) -> the host merge is used instead
+    uint32_t k0;                  // a member key (fills unused table slots)
+    uint32_t all_t;               // the key 0xFFFFFFFF is a member
+    uint32_t ticket;              // k_dm_greedy's token dispenser
+    uint32_t pad[3];
+};
+
+struct DevMerge {
+    // input: distinct candidate DR strings in first-occurrence (= token) order
+    const char *dx_chars; const uint16_t *dx_len;
+    uint32_t stride, n_tok;
+    uint32_t thr;                 // max(kmer_clust_size, 2): sightings of a group that decide membership
+    uint32_t kmax;                // k-mer slots per token (stride - 10)
+    // per token
+    uint64_t *packed;             // [n_tok][4] 2-bit packed string (lo, hi) and its reverse complement (lo, hi)
+    uint32_t *codes;              // [n_tok][kmax] laurenized 11-mer codes
+    uint32_t *owner;              // [1 << 22] smallest token containing the code
+    uint32_t *root_of;            // [n_tok] first token of the token's group
+    uint32_t *tmp, *root_rank;    // [n_tok + 1]
+    uint32_t *gid_of;             // [n_tok] GID (1-based)
+    uint32_t *grp_cnt, *grp_off, *grp_fill, *surv_cnt, *surv_off;     // [n_tok + 1] per group
+    uint32_t *members;            // [n_tok] tokens ordered by group
+    uint8_t  *blank;              // [n_tok] removed by removeRedundantRepeats
+    // pattern list (capacity 2 * n_tok)
+    uint64_t *pat_packed;         // [n_pat][2]
+    uint16_t *pat_len;
+    uint32_t *pat_token;
+    // anchor keys: entry e = pid * 8 + r (capacity 16 * n_tok)
+    unsigned long long *kset_key; // [1 << kset_log] distinct keys (key | 1 << 32; 0 = empty)
+    uint32_t *kset_head;          // [1 << kset_log] head of the key's entry chain
+    uint32_t kset_log;
+    uint32_t *ent_next;           // [16 * n_tok]
+    uint8_t  *ent_win;            // [16 * n_tok] entry claimed its key's slot
+    uint32_t *anchor_tab;         // [1 << tab_log_alloc] cuckoo table of the keys (see DevAnchors)
+    uint32_t tab_log_alloc;
+    uint32_t s1, s2, m1, m2;      // hash constants of the table
+    DevMergeState *st;
+};
+
+hipError_t launch_device_merge(const DevMerge &M, hipStream_t st);
+// pass-2 anchor filter with table parameters read from the device (M.st); flags nothing when M.st->fail
+hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st);
+hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
+                            uint32_t *info_by_slot, uint32_t *pid_by_slot, hipStream_t st);
+
 // layout of the survivor kernel's dynamic LDS (bytes), computed on the host
 struct SurvLds {
     uint32_t seq_bytes;           // >= maxL + 16, multiple of 16
@@ -130,7 +184,8 @@ hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint6
                                uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr, uint32_t *g_ss, hipStream_t st);
 hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, const uint32_t *rep,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
-                            uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash, hipStream_t st);
+                            uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
+                            char *dev_chars, uint16_t *dev_len, hipStream_t st);
 hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n, unsigned long long *keys,
                             uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st);
 SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P);

@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(256) void k_dx_assign(const uint32_t *rep, const ui
 
 __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const uint32_t *d_nd, uint32_t n_max, const char *dr,
                                                     const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, char *out_chars,
-                                                    uint16_t *out_len, uint64_t *out_hash)
+                                                    uint16_t *out_len, uint64_t *out_hash, char *dev_chars, uint16_t *dev_len)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nd = *d_nd;
@@ -1544,8 +1544,11 @@ __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const
     const uint64_t k = dx_idx[j];
     const uint4 *src = reinterpret_cast<const uint4 *>(dr + k * stride);
     uint4 *dst = reinterpret_cast<uint4 *>(out_chars + (uint64_t)j * stride);
-    for (uint32_t i = 0; i < stride / 16; i++) dst[i] = src[i];
-    out_len[j] = dr_len[k];
+    uint4 *dst2 = reinterpret_cast<uint4 *>(dev_chars + (uint64_t)j * stride);      // device copy for the device merge
+    for (uint32_t i = 0; i < stride / 16; i++) { const uint4 v = src[i]; dst[i] = v; if (dev_chars) dst2[i] = v; }
+    const uint16_t l = dr_len[k];
+    out_len[j] = l;
+    if (dev_len) dev_len[j] = l;
     out_hash[j] = hash[k];
 }
 
@@ -1554,7 +1557,8 @@ __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const
 // straight into it (a few hundred KB; no copy calls on the critical path).
 hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, const uint32_t *rep,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
-                            uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash, hipStream_t st)
+                            uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
+                            char *dev_chars, uint16_t *dev_len, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     const unsigned nb = (n + 255) / 256;
@@ -1562,7 +1566,7 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
     hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap);
-    hipLaunchKernelGGL(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash);
+    hipLaunchKernelGGL(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len);
     return hipGetLastError();
 }
 
@@ -1752,16 +1756,9 @@ static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_
 }
 
 template <int W, int THREADS, int MODE>     // W = uniform stride in words (0: ragged / any stride)
-__global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchors K, const uint8_t *found_flag, uint64_t *hitmask)
+static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, const DevAnchors &K, const uint32_t *ak_lds,
+                                                          const uint8_t *found_flag, uint64_t *hitmask)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
-    const uint32_t tsize = 1u << K.log_size;
-    const uint32_t *ak_lds = K.table;                   // key sets too large for LDS are probed in global memory (L2)
-    if (MODE != 2) {
-        for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds_buf[i] = K.table[i];
-        __syncthreads();
-        ak_lds = ak_lds_buf;
-    }
     const uint32_t mask = 32u - K.log_size;          // right shift that keeps the top log_size bits
     const uint64_t n_tiles = (R.n_reads + 63) / 64;
     const int lane = threadIdx.x & 63;
@@ -1801,6 +1798,68 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
         uint64_t m = __ballot(flag);
         if (lane == 0) hitmask[tile] = m;
     }
+}
+
+template <int W, int THREADS, int MODE>
+__global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchors K, const uint8_t *found_flag, uint64_t *hitmask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
+    const uint32_t tsize = 1u << K.log_size;
+    const uint32_t *ak_lds = K.table;                   // key sets too large for LDS are probed in global memory (L2)
+    if (MODE != 2) {
+        for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds_buf[i] = K.table[i];
+        __syncthreads();
+        ak_lds = ak_lds_buf;
+    }
+    anchor_filter_body<W, THREADS, MODE>(R, K, ak_lds, found_flag, hitmask);
+}
+
+// the same filter when the key table was built on the device (dmerge.hip): its size is only known there
+template <int W, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMerge M, const uint8_t *found_flag, uint64_t *hitmask)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
+    DevAnchors K;
+    K.table = M.anchor_tab; K.log_size = M.st->log_size; K.mode = 0; K.s1 = M.s1; K.s2 = M.s2; K.m1 = M.m1; K.m2 = M.m2; K.n_keys = 0;
+    if (M.st->fail != 0 || K.log_size == 0) {            // the host redoes the merge; flag nothing
+        const uint64_t n_tiles = (R.n_reads + 63) / 64;
+        for (uint64_t t = blockIdx.x * (uint64_t)THREADS + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * THREADS) hitmask[t] = 0ull;
+        return;
+    }
+    if (K.log_size <= 15) {
+        const uint32_t tsize = 1u << K.log_size;
+        for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds_buf[i] = K.table[i];
+        __syncthreads();
+        anchor_filter_body<W, THREADS, 0>(R, K, ak_lds_buf, found_flag, hitmask);
+    } else {
+        anchor_filter_body<W, THREADS, 2>(R, K, K.table, found_flag, hitmask);
+    }
+}
+
+hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st)
+{
+    if (R.n_reads == 0) return hipSuccess;
+    const size_t lds = 128 * 1024;
+    const uint64_t n_tiles = (R.n_reads + 63) / 64;
+    constexpr int T = 1024;
+    uint64_t blocks = (n_tiles + (T / 64) - 1) / (T / 64);
+    if (blocks > 256) blocks = 256;
+    hipError_t e;
+#define AKD_LAUNCH(WW)                                                                                                  \
+    {                                                                                                                   \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_anchor_filter_dev<WW, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                  \
+        hipLaunchKernelGGL((k_anchor_filter_dev<WW, T>), dim3((unsigned)blocks), dim3(T), lds, st, R, M, found_flag, hitmask); \
+    }
+    switch (R.stride_words) {
+        case 4: AKD_LAUNCH(4) break;  case 5: AKD_LAUNCH(5) break;  case 6: AKD_LAUNCH(6) break;  case 7: AKD_LAUNCH(7) break;
+        case 8: AKD_LAUNCH(8) break;  case 9: AKD_LAUNCH(9) break;  case 10: AKD_LAUNCH(10) break; case 11: AKD_LAUNCH(11) break;
+        case 12: AKD_LAUNCH(12) break; case 13: AKD_LAUNCH(13) break; case 14: AKD_LAUNCH(14) break; case 15: AKD_LAUNCH(15) break;
+        case 16: AKD_LAUNCH(16) break;
+        default: AKD_LAUNCH(0) break;
+    }
+#undef AKD_LAUNCH
+    return hipGetLastError();
 }
 
 hipError_t launch_anchor_filter(const DevReads &R, const DevAnchors &K, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st)

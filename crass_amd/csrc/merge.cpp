@@ -668,6 +668,39 @@ static bool assign_tokens_from_rep(MergeResult &m, const char *dr_chars, const u
     return true;
 }
 
+// every group contributes its survivors, then their reverse complements (WorkHorse.cpp:690-705)
+static void emit_patterns(MergeResult &m, const std::vector<std::vector<Member>> &survivors)
+{
+    const unsigned char *ctab = comp_table();
+    size_t n_pat = 0, n_pat_chars = 0;
+    for (const auto &g : survivors) { n_pat += 2 * g.size(); for (const Member &x : g) n_pat_chars += 2 * (size_t)x.len; }
+    m.patterns.chars.reserve(n_pat_chars); m.patterns.off.reserve(n_pat + 1);
+    m.pat_group.reserve(n_pat); m.pat_token.reserve(n_pat);
+    std::string rc;
+    for (size_t g = 0; g < m.groups.size(); g++) {
+        const std::vector<Member> &clustered = survivors[g];
+        for (const Member &x : clustered) m.patterns.push(m.tokens.strings.data(x.tok), x.len);
+        const size_t first_rc = m.patterns.size();
+        for (const Member &x : clustered) {
+            const char *p = m.tokens.strings.data(x.tok);
+            rc.resize(x.len);
+            for (uint32_t i = 0; i < x.len; i++) rc[i] = (char)ctab[(unsigned char)p[x.len - 1 - i] & 127];
+            m.patterns.push(rc);
+        }
+        // token of the low-lexi form (DRLowLexi: tmp_dr < rev_comp ? tmp_dr : rev_comp) of the pattern and of
+        // its reverse complement alike; a token string is normally low-lexi already
+        for (size_t i = 0; i < clustered.size(); i++) {
+            const Member &x = clustered[i];
+            const char *p = m.tokens.strings.data(x.tok);
+            const char *q = m.patterns.data(first_rc + i);
+            const int cmp = memcmp(p, q, x.len);
+            m.pat_token.push_back(cmp <= 0 ? x.tok + 2 : m.tokens.get(q, x.len));
+        }
+        for (size_t i = 0; i < clustered.size(); i++) m.pat_token.push_back(m.pat_token[m.pat_token.size() - clustered.size()]);
+        m.pat_group.insert(m.pat_group.end(), 2 * clustered.size(), (uint32_t)(g + 1));
+    }
+}
+
 static void cluster_and_patterns(MergeResult &m, int kmer_clust_size, double t0, double t1);
 
 void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
@@ -710,6 +743,43 @@ bool merge_from_distinct(MergeResult &m, const char *dx_chars, const uint16_t *d
     }
     if (n && worst >= n_distinct) { m.clear(); return false; }
     cluster_and_patterns(m, kmer_clust_size, t0, prof_now());
+    return true;
+}
+
+// Host view of a merge that ran on the device (dmerge.hip): token table, groups and pattern list are
+// rebuilt from the device's per-token results (gid_of = GID, blank = dropped by removeRedundantRepeats) with
+// the reference's own sort/partition predicates, so the hand-off matches the host merge field for field.
+bool merge_from_device(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
+                       const uint32_t *cand_distinct, uint64_t n, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups)
+{
+    m.clear();
+    size_t n_chars = 0;
+    for (uint64_t j = 0; j < n_distinct; j++) n_chars += dx_len[j];
+    m.tokens.reserve(n_distinct, n_chars);
+    for (uint64_t j = 0; j < n_distinct; j++) {
+        const char *p = dx_chars + j * (uint64_t)dr_stride;
+        if (m.tokens.add_unique_hashed(p, dx_len[j], TokenTable::hash(p, dx_len[j])) == 0) { m.clear(); return false; }
+    }
+    m.cand_token.resize(n);
+    for (uint64_t k = 0; k < n; k++) {
+        if (cand_distinct[k] >= n_distinct) { m.clear(); return false; }
+        m.cand_token[k] = cand_distinct[k] + 2;
+    }
+    m.next_free_gid = (int)n_groups + 1;
+    m.groups.assign(n_groups, {});
+    std::vector<std::vector<Member>> survivors(n_groups);
+    for (uint32_t t = 0; t < n_distinct; t++) {
+        const uint32_t g = gid_of[t];
+        if (g == 0 || g > n_groups) { m.clear(); return false; }
+        m.groups[g - 1].push_back(t + 2);
+        survivors[g - 1].push_back(Member{t, (uint32_t)dx_len[t], blank[t] != 0});
+    }
+    for (auto &v : survivors) {
+        std::sort(v.begin(), v.end(), member_shorter_first);
+        v.erase(std::partition(v.begin(), v.end(), member_kept), v.end());
+    }
+    emit_patterns(m, survivors);
+    m.flatten();
     return true;
 }
 
@@ -824,35 +894,7 @@ static void cluster_and_patterns(MergeResult &m, int kmer_clust_size, double t0,
     }
     const double t2b = prof_now();
     if (prof) fprintf(stderr, "[crass_merge]   pack %.3f ms, remove_redundant %.3f ms\n", t2a - t2, t2b - t2a);
-    // every group contributes its survivors, then their reverse complements (WorkHorse.cpp:690-705)
-    const unsigned char *ctab = comp_table();
-    size_t n_pat = 0, n_pat_chars = 0;
-    for (const auto &g : survivors) { n_pat += 2 * g.size(); for (const Member &x : g) n_pat_chars += 2 * (size_t)x.len; }
-    m.patterns.chars.reserve(n_pat_chars); m.patterns.off.reserve(n_pat + 1);
-    m.pat_group.reserve(n_pat); m.pat_token.reserve(n_pat);
-    std::string rc;
-    for (size_t g = 0; g < m.groups.size(); g++) {
-        const std::vector<Member> &clustered = survivors[g];
-        for (const Member &x : clustered) m.patterns.push(m.tokens.strings.data(x.tok), x.len);
-        const size_t first_rc = m.patterns.size();
-        for (const Member &x : clustered) {
-            const char *p = m.tokens.strings.data(x.tok);
-            rc.resize(x.len);
-            for (uint32_t i = 0; i < x.len; i++) rc[i] = (char)ctab[(unsigned char)p[x.len - 1 - i] & 127];
-            m.patterns.push(rc);
-        }
-        // token of the low-lexi form (DRLowLexi: tmp_dr < rev_comp ? tmp_dr : rev_comp) of the pattern and of
-        // its reverse complement alike; a token string is normally low-lexi already
-        for (size_t i = 0; i < clustered.size(); i++) {
-            const Member &x = clustered[i];
-            const char *p = m.tokens.strings.data(x.tok);
-            const char *q = m.patterns.data(first_rc + i);
-            const int cmp = memcmp(p, q, x.len);
-            m.pat_token.push_back(cmp <= 0 ? x.tok + 2 : m.tokens.get(q, x.len));
-        }
-        for (size_t i = 0; i < clustered.size(); i++) m.pat_token.push_back(m.pat_token[m.pat_token.size() - clustered.size()]);
-        m.pat_group.insert(m.pat_group.end(), 2 * clustered.size(), (uint32_t)(g + 1));
-    }
+    emit_patterns(m, survivors);
     const double t3 = prof_now();
     m.flatten();
     if (prof)

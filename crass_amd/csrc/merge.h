@@ -81,6 +81,11 @@ void merge_candidates(MergeResult &m, const char *dr_chars, const uint16_t *dr_l
 bool merge_from_distinct(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, const uint64_t *dx_hash, uint32_t dr_stride,
                          uint64_t n_distinct, const uint32_t *cand_distinct, uint64_t n, int kmer_clust_size);
 
+// Host view of a merge computed on the device (dmerge.hip): gid_of[t] = GID of token t + 2, blank[t] != 0 when
+// removeRedundantRepeats dropped it.  false (m cleared) if the inputs are inconsistent.
+bool merge_from_device(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
+                       const uint32_t *cand_distinct, uint64_t n, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups);
+
 // byte-wise Aho-Corasick with fully resolved goto; semantics of acism_create + the first
 // callback of acism_scan (acism_create.c:71-392, acism.c:25-106)
 struct HostAutomaton {

@@ -227,6 +227,9 @@ typedef struct {
     uint32_t anchor_keys;           /* distinct 16-mer anchor keys of the pattern set (pass 2)    */
     uint32_t anchor_table_kind;     /* 0 exact keys in LDS, 1 fingerprint buckets in LDS,
                                        2 exact keys probed in L2 (key set beyond LDS)             */
+    uint32_t used_device_merge;     /* 1: clustering / non-redundant set / pass-2 index built on the
+                                       device (dmerge.hip), 0: host merge (merge.cpp)             */
+    float ms_merge_device;          /* HIP-event time of the device merge kernels                 */
 } crass_counters;
 int crass_hip_get_counters(const crass_hip_ctx *ctx, crass_counters *out);
 

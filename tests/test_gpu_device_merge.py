@@ -1,0 +1,109 @@
+"""The DR merge on the device (dmerge.hip) against the host merge (merge.cpp) and the oracle:
+same tokens, groups, pattern list (including its order) and pass-2 records."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import orc, fastx
+from tests.parity import assert_same_pipeline
+from tests.test_gpu_parity import synth_reads, DATA
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import crass_amd
+    crass_amd.load()
+    return crass_amd
+
+
+def both_paths(ca, seqs, hdrs=None):
+    os.environ.pop("CRASS_HOST_MERGE", None)
+    dev = ca.search_pipeline(seqs, hdrs)
+    os.environ["CRASS_HOST_MERGE"] = "1"
+    try:
+        host = ca.search_pipeline(seqs, hdrs)
+    finally:
+        os.environ.pop("CRASS_HOST_MERGE", None)
+    return dev, host
+
+
+def assert_same_paths(dev, host, expect_device=True):
+    if expect_device:
+        assert dev.counters["used_device_merge"] == 1
+    assert host.counters["used_device_merge"] == 0
+    assert dev.tokens == host.tokens
+    assert dev.groups == host.groups
+    assert dev.patterns == host.patterns            # the same ORDER, not just the same set
+    assert list(dev.pat_group) == list(host.pat_group)
+    np.testing.assert_array_equal(dev.rec_read, host.rec_read)
+    np.testing.assert_array_equal(dev.rec_token, host.rec_token)
+    np.testing.assert_array_equal(dev.rec_lowlexi, host.rec_lowlexi)
+    assert dev.n_pass2 == host.n_pass2
+
+
+@pytest.mark.parametrize("fname", ["Ill100.fx.gz", "CN_gDC.fa.gz", "front_offset_bug.fa.gz", "Ill.nr.miss.fa.gz", "poor_dr_ext.fa.gz"])
+def test_reference_inputs_device_vs_host(ca, fname):
+    recs = fastx.read_fastx(os.path.join(DATA, fname))
+    seqs = [r[2] for r in recs]
+    hdrs = [r[0] for r in recs]
+    dev, host = both_paths(ca, seqs, hdrs)
+    assert_same_paths(dev, host, expect_device=False)      # inputs with N reads keep the host merge
+    assert_same_pipeline(dev, orc.pipeline(seqs, hdrs))
+
+
+@pytest.mark.parametrize("L,n_dr,n", [(150, 50, 200000), (101, 5, 60000), (250, 200, 100000)])
+def test_synthetic_device_vs_host(ca, L, n_dr, n):
+    seqs = synth_reads(ca, n, read_len=L, n_dr=n_dr, crispr_per_million=30000)
+    dev, host = both_paths(ca, seqs)
+    assert_same_paths(dev, host)
+    assert dev.n_groups >= min(n_dr, 5)
+    assert_same_pipeline(dev, orc.pipeline(seqs))
+
+
+def test_many_variants_one_group(ca):
+    """one DR, a CRISPR read in every second read: hundreds of variants in a single group (the
+    removeRedundantRepeats stress) and long owner chains in the greedy pass"""
+    seqs = synth_reads(ca, 60000, read_len=150, n_dr=1, crispr_per_million=500000)
+    dev, host = both_paths(ca, seqs)
+    assert_same_paths(dev, host)
+    assert_same_pipeline(dev, orc.pipeline(seqs))
+
+
+def test_non_default_cluster_size(ca):
+    seqs = synth_reads(ca, 80000, read_len=150, n_dr=20, crispr_per_million=40000)
+    for k in (1, 2, 12):
+        p = ca.default_params()
+        p.kmer_clust_size = k
+        os.environ.pop("CRASS_HOST_MERGE", None)
+        dev = ca.search_pipeline(seqs, params=p)
+        assert dev.counters["used_device_merge"] == 1
+        ref = orc.pipeline(seqs, params=orc.Params(p.lowDRsize, p.highDRsize, p.lowSpacerSize, p.highSpacerSize,
+                                                   p.searchWindowLength, p.minNumRepeats, p.kmer_clust_size))
+        assert_same_pipeline(dev, ref)
+
+
+def test_fallback_to_host_merge(ca):
+    """a device-side failure flag (key set too large, cuckoo insertion giving up, ...) must end in the
+    host merge with identical results"""
+    seqs = synth_reads(ca, 50000, read_len=150, n_dr=10, crispr_per_million=30000)
+    ref = orc.pipeline(seqs)
+    os.environ["CRASS_DM_INJECT_FAIL"] = "1"
+    try:
+        got = ca.search_pipeline(seqs)
+        eng = ca.SearchEngine()
+        try:            # the bench's call order: nothing fetched between the stages
+            packed = ca.PackedReads(seqs)
+            eng.load_reads(packed, None)
+            eng.seed_scan(fetch=False)
+            eng.merge(fetch=False)
+            rec = eng.recruit()
+            assert len(rec.read_idx) == ref.n_pass2
+            packed.close()
+        finally:
+            eng.close()
+    finally:
+        os.environ.pop("CRASS_DM_INJECT_FAIL", None)
+    assert_same_pipeline(got, ref)
