@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
     for (uint64_t i = tid; i < M.n_tok; i += nth) M.root_of[i] = kUnres;
     for (uint64_t i = tid; i <= M.n_tok; i += nth) { M.grp_cnt[i] = 0; M.grp_fill[i] = 0; M.surv_cnt[i] = 0; }
     const uint64_t ks = 1ull << M.kset_log;
-    for (uint64_t i = tid; i < ks; i += nth) { M.kset_key[i] = 0ull; M.kset_head[i] = kNone; }
+    for (uint64_t i = tid; i < ks; i += nth) { M.kset_key[i] = 0ull; M.kset_cnt[i] = 0u; M.kset_fill[i] = 0u; }
+    const uint64_t rs = 1ull << M.rset_log;
+    for (uint64_t i = tid; i < rs; i += nth) { M.rset_key[i] = 0ull; M.rset_cnt[i] = 0u; M.rset_fill[i] = 0u; }
     uint4 *t4 = reinterpret_cast<uint4 *>(M.anchor_tab);
     for (uint64_t i = tid; i < (1ull << M.tab_log_alloc) / 4; i += nth) t4[i] = ones;
     if (tid == 0) {
@@ -215,37 +217,98 @@ __global__ __launch_bounds__(256) void k_dm_scatter(DevMerge M)
 // ---- 4. removeRedundantRepeats: a member is dropped iff a strictly shorter member of its group, or
 // that member's reverse complement, occurs in it (equal-length members are distinct strings; the
 // relation is transitive, so "blanked earlier" never matters).  t or rc(t) in s <=> t in s or in rc(s).
+// The needles are indexed by (group, first 16 bases): every member claims its key in an open-addressing
+// set and the members of one key are laid out contiguously ({len | token << 32, bits lo, bits hi}).  A member
+// j then probes the index with every window of its own string and of its reverse complement in which a
+// member (>= 23 bases) could still start, and compares only the few candidates that share the window's
+// first 16 bases — instead of trying every shorter member at every shift.
+static __device__ __forceinline__ uint32_t rset_hash(uint32_t g, uint32_t w, uint32_t log_size)
+{
+    return ((w * 0x9E3779B1u) ^ (g * 0x85EBCA6Bu)) >> (32u - log_size);
+}
+__global__ __launch_bounds__(256) void k_dm_rd_keys(DevMerge M)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M.n_tok) return;
+    const uint32_t g = M.gid_of[t], w = (uint32_t)M.packed[(uint64_t)t * 4];
+    const unsigned long long want = ((unsigned long long)g << 32) | w;            // g >= 1: never 0
+    const uint32_t mask = (1u << M.rset_log) - 1u;
+    uint32_t h = rset_hash(g, w, M.rset_log);
+    bool winner = false;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&M.rset_key[h], 0ull, want);
+        if (old == 0ull) { winner = true; break; }
+        if (old == want) break;
+        h = (h + 1) & mask;
+    }
+    atomicAdd(&M.rset_cnt[h], 1u);
+    M.rd_slot[t] = winner ? (h | 0x80000000u) : h;
+}
+__global__ __launch_bounds__(256) void k_dm_rd_bases(DevMerge M)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M.n_tok) return;
+    const uint32_t hs = M.rd_slot[t];
+    if (!(hs & 0x80000000u)) return;
+    const uint32_t h = hs & 0x7FFFFFFFu;
+    M.rset_base[h] = atomicAdd(&M.st->rd_cursor, M.rset_cnt[h]);
+}
+__global__ __launch_bounds__(256) void k_dm_rd_fill(DevMerge M)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M.n_tok) return;
+    const uint32_t h = M.rd_slot[t] & 0x7FFFFFFFu;
+    const uint32_t pos = M.rset_base[h] + atomicAdd(&M.rset_fill[h], 1u);
+    uint64_t *d = M.rents + (uint64_t)pos * 3;
+    d[0] = (uint64_t)M.dx_len[t] | ((uint64_t)t << 32);
+    d[1] = M.packed[(uint64_t)t * 4];
+    d[2] = M.packed[(uint64_t)t * 4 + 1];
+}
 __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= M.n_tok) return;
-    const uint32_t j = M.members[s];
-    const uint32_t g = M.gid_of[j] - 1;
-    const uint32_t lo = M.grp_off[g], hi = lo + M.grp_cnt[g];
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M.n_tok) return;
+    const uint32_t g = M.gid_of[j];
     const uint32_t lenj = M.dx_len[j];
     const uint64_t *pj = M.packed + (uint64_t)j * 4;
     const uint64_t hay[4] = {pj[0], pj[1], pj[2], pj[3]};
+    const uint32_t mask = (1u << M.rset_log) - 1u;
     bool blank = false;
-    for (uint32_t is = lo; is < hi && !blank; is++) {
-        const uint32_t i = M.members[is];
-        const uint32_t leni = M.dx_len[i];
-        if (leni >= lenj) continue;
-        const uint64_t n0 = M.packed[(uint64_t)i * 4], n1 = M.packed[(uint64_t)i * 4 + 1];
-        uint64_t m0, m1;
-        mask128(leni, m0, m1);
-        const uint32_t nshift = lenj - leni;
-        for (int o = 0; o < 2 && !blank; o++) {
-            const uint64_t h0 = hay[2 * o], h1 = hay[2 * o + 1];
-            for (uint32_t p = 0; p <= nshift; p++) {
-                const uint64_t w0 = shr128_lo(h0, h1, 2 * p);
-                if ((uint32_t)w0 != (uint32_t)n0) continue;            // first 16 bases (every member is >= 23 long)
-                const uint64_t w1 = shr128_hi(h1, 2 * p);
-                if ((w0 & m0) == n0 && (w1 & m1) == n1) { blank = true; break; }
+    const uint32_t p_max = lenj - 23u;                  // a member is >= 23 long and strictly shorter than lenj
+    for (int o = 0; o < 2 && !blank; o++) {
+        const uint64_t h0 = hay[2 * o], h1 = hay[2 * o + 1];
+        for (uint32_t p = 0; p <= p_max && !blank; p++) {
+            const uint64_t w0 = shr128_lo(h0, h1, 2 * p);
+            const uint32_t w = (uint32_t)w0;
+            const unsigned long long want = ((unsigned long long)g << 32) | w;
+            uint32_t h = rset_hash(g, w, M.rset_log);
+            uint32_t cnt = 0, base = 0;
+            for (;;) {
+                const unsigned long long kk = M.rset_key[h];
+                if (kk == 0ull) break;
+                if (kk == want) { cnt = M.rset_cnt[h]; base = M.rset_base[h]; break; }
+                h = (h + 1) & mask;
+            }
+            if (!cnt) continue;
+            const uint64_t w1 = shr128_hi(h1, 2 * p);
+            const uint64_t *ent = M.rents + (uint64_t)base * 3;
+            for (uint32_t c = 0; c < cnt; c++, ent += 3) {
+                const uint32_t leni = (uint32_t)ent[0] & 0xFFu;
+                if (leni >= lenj || p + leni > lenj) continue;
+                uint64_t m0, m1;
+                mask128(leni, m0, m1);
+                if ((w0 & m0) == ent[1] && (w1 & m1) == ent[2]) { blank = true; break; }
             }
         }
     }
     M.blank[j] = blank ? 1 : 0;
-    if (!blank) atomicAdd(&M.surv_cnt[g], 1u);
+    if (!blank) atomicAdd(&M.surv_cnt[g - 1], 1u);
+}
+// the same flag by position in members[] (k_dm_patterns walks member ranges)
+__global__ __launch_bounds__(256) void k_dm_sblank(DevMerge M)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < M.n_tok) M.sblank[s] = M.blank[M.members[s]];
 }
 
 // ---- 5. pattern list: per group (ascending GID) the survivors, then their reverse complements
@@ -253,20 +316,40 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
 // orders an unstable sort by length may produce; pass 2 depends on the SET only.
 __global__ __launch_bounds__(256) void k_dm_patterns(DevMerge M)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= M.n_tok) return;
-    const uint32_t j = M.members[s];
-    if (M.blank[j]) return;
-    const uint32_t g = M.gid_of[j] - 1;
-    const uint32_t lo = M.grp_off[g], hi = lo + M.grp_cnt[g];
-    const uint32_t lenj = M.dx_len[j];
-    uint32_t k = 0;
-    for (uint32_t is = lo; is < hi; is++) {
-        const uint32_t i = M.members[is];
-        if (M.blank[i]) continue;
-        const uint32_t li = M.dx_len[i];
-        if (li < lenj || (li == lenj && i < j)) k++;
+    __shared__ uint32_t t_key[256];                     // (len << 24) | token for survivors, 0xFFFFFFFF for dropped members
+    __shared__ uint32_t r_lo, r_hi;
+    const uint32_t s0 = blockIdx.x * 256u, s = s0 + threadIdx.x;
+    const bool active = s < M.n_tok;
+    uint32_t j = 0, g = 0, lo = 0, hi = 0, lenj = 0;
+    bool mine = false;
+    if (active) {
+        j = M.members[s];
+        g = M.gid_of[j] - 1;
+        lo = M.grp_off[g]; hi = lo + M.grp_cnt[g];
+        lenj = M.dx_len[j];
+        mine = M.sblank[s] == 0;
     }
+    if (threadIdx.x == 0) r_lo = lo;
+    const uint32_t s_last = min(M.n_tok, s0 + 256u) - 1u;
+    if (s == s_last) r_hi = hi;
+    __syncthreads();
+    const uint32_t rlo = r_lo, rhi = r_hi;
+    const uint32_t my_key = (lenj << 24) | j;           // tokens < 2^20, lengths <= 64
+    uint32_t k = 0;
+    for (uint32_t base = rlo; base < rhi; base += 256u) {
+        const uint32_t idx = base + threadIdx.x;
+        if (idx < rhi) {
+            const uint32_t i = M.members[idx];
+            t_key[threadIdx.x] = M.sblank[idx] ? 0xFFFFFFFFu : ((uint32_t)M.dx_len[i] << 24) | i;
+        }
+        __syncthreads();
+        if (mine) {
+            const uint32_t a = max(lo, base), b = min(hi, base + 256u);
+            for (uint32_t is = a; is < b; is++) k += t_key[is - base] < my_key ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    if (!mine) return;
     const uint32_t E = M.surv_off[g], cnt = M.surv_cnt[g];
     const uint32_t pf = 2 * E + k, pr = 2 * E + cnt + k;
     const uint64_t *pj = M.packed + (uint64_t)j * 4;
@@ -279,8 +362,9 @@ __global__ __launch_bounds__(256) void k_dm_patterns(DevMerge M)
 }
 
 // ---- 6. anchor keys: every 16-mer at offset 0..7 of a pattern (see kernels.hip, pass-2 fast path).
-// Entry e = pid*8 + r.  Distinct keys are claimed in an open-addressing set; every entry is linked
-// into its key's chain (the exact verification index of k_dm_verify).
+// Entry e = pid*8 + r.  Distinct keys are claimed in an open-addressing set; the entries of one key are
+// then laid out contiguously (count -> block allocation -> fill) as the exact verification index of
+// k_dm_verify: {r | len << 3 | pid << 32, pattern bits lo, pattern bits hi}.
 __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,13 +382,33 @@ __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
         if (old == want) break;
         h = (h + 1) & kmask;
     }
-    M.ent_next[e] = atomicExch(&M.kset_head[h], e);
+    atomicAdd(&M.kset_cnt[h], 1u);
+    M.ent_slot[e] = h;
     M.ent_win[e] = winner ? 1 : 0;
     if (winner) {
         atomicAdd(&M.st->n_keys, 1u);
         atomicMin(&M.st->k0, key);
         if (key == 0xFFFFFFFFu) atomicOr(&M.st->all_t, 1u);
     }
+}
+__global__ __launch_bounds__(256) void k_dm_key_bases(DevMerge M)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((e >> 3) >= 2 * M.st->n_survivors || !M.ent_win[e]) return;
+    const uint32_t h = M.ent_slot[e];
+    M.kset_base[h] = atomicAdd(&M.st->ent_cursor, M.kset_cnt[h]);
+}
+__global__ __launch_bounds__(256) void k_dm_key_fill(DevMerge M)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pid = e >> 3, r = e & 7u;
+    if (pid >= 2 * M.st->n_survivors) return;
+    const uint32_t h = M.ent_slot[e];
+    const uint32_t pos = M.kset_base[h] + atomicAdd(&M.kset_fill[h], 1u);
+    uint64_t *d = M.ents + (uint64_t)pos * 3;
+    d[0] = (uint64_t)(r | ((uint32_t)M.pat_len[pid] << 3)) | ((uint64_t)pid << 32);
+    d[1] = M.pat_packed[(uint64_t)pid * 2];
+    d[2] = M.pat_packed[(uint64_t)pid * 2 + 1];
 }
 
 // table size: load <= 1/3 (<= 1/2 at the LDS limit 2^15 and at the allocation limit), as build_anchors (merge.cpp)
@@ -374,11 +478,17 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     hipLaunchKernelGGL(k_dm_gid, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.grp_cnt, M.grp_off, M.n_tok, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_dm_scatter, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_rd_keys, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_rd_fill, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_redundant, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_sblank, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok, &M.st->n_survivors);
     hipLaunchKernelGGL(k_dm_patterns, dim3(nb), dim3(256), 0, st, M);
     const unsigned ne = (16u * M.n_tok + 255) / 256;
     hipLaunchKernelGGL(k_dm_keys, dim3(ne), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_key_bases, dim3(ne), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_key_fill, dim3(ne), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_cuckoo_params, dim3(1), dim3(64), 0, st, M);
     hipLaunchKernelGGL(k_dm_cuckoo_insert, dim3(ne), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_cuckoo_finalize, dim3((unsigned)(((1ull << M.tab_log_alloc) + 255) / 256)), dim3(256), 0, st, M);
@@ -395,9 +505,13 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
 static __device__ __forceinline__ uint32_t dm_rd_len(const DevReads &R, uint64_t r) { return R.uniform_len ? R.uniform_len : R.lengths[r]; }
 static __device__ __forceinline__ uint64_t dm_rd_off(const DevReads &R, uint64_t r) { return R.stride_words ? r * (uint64_t)R.stride_words : R.word_off[r]; }
 
+// NW > 0: uniform stride of NW words, the read goes through LDS ([word][thread]) so that the dynamically
+// indexed window extraction does not go back to memory for every candidate; NW == 0: any layout, global loads.
+template <int NW>
 __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
                                                     uint32_t *info_by_slot, uint32_t *pid_by_slot)
 {
+    __shared__ uint32_t rw[(NW > 0 ? NW + 1 : 1) * 256];
     const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t n = *d_n;
     if (n > n_max) n = n_max;
@@ -406,6 +520,15 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
     const uint32_t L = dm_rd_len(R, r);
     const uint32_t *g = R.packed + dm_rd_off(R, r);
     const uint32_t nw = (L + 15) >> 4;
+    if (NW > 0) {
+#pragma unroll
+        for (int q = 0; q < NW; q++) rw[q * 256 + threadIdx.x] = g[q];
+        rw[NW * 256 + threadIdx.x] = 0u;
+    }
+    auto word = [&](uint32_t i) -> uint32_t {
+        if (NW > 0) return rw[min(i, (uint32_t)NW) * 256 + threadIdx.x];
+        return i < nw ? g[i] : 0u;
+    };
     const uint32_t kmask = (1u << M.kset_log) - 1u;
     uint32_t best_end = 0xFFFFFFFFu, best_len = 0, best_pid = 0;
     if (L >= 16) {
@@ -414,22 +537,23 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
             const uint32_t a = 8 * h;
             if (best_end <= a + 15) break;
             const uint32_t wi = h >> 1;
-            const uint32_t lo = g[wi], hi = (wi + 1 < nw) ? g[wi + 1] : 0u;
+            const uint32_t lo = word(wi), hi = word(wi + 1);
             const uint32_t V = (h & 1) ? ((lo >> 16) | (hi << 16)) : lo;
             const unsigned long long want = (unsigned long long)V | (1ull << 32);
             uint32_t s = kset_hash(V, M.kset_log);
-            uint32_t e = kNone;
+            uint32_t cnt = 0, base = 0;
             for (;;) {
                 const unsigned long long kk = M.kset_key[s];
                 if (kk == 0ull) break;
-                if (kk == want) { e = M.kset_head[s]; break; }
+                if (kk == want) { cnt = M.kset_cnt[s]; base = M.kset_base[s]; break; }
                 s = (s + 1) & kmask;
             }
-            for (; e != kNone; e = M.ent_next[e]) {
-                const uint32_t pid = e >> 3, rr = e & 7u;
+            const uint64_t *ent = M.ents + (uint64_t)base * 3;
+            for (uint32_t c = 0; c < cnt; c++, ent += 3) {
+                const uint64_t e0 = ent[0];
+                const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
                 if (a < rr) continue;
                 const uint32_t start = a - rr;
-                const uint32_t len = M.pat_len[pid];
                 const uint32_t end = start + len;
                 if (end > L) continue;
                 if (end > best_end || (end == best_end && len <= best_len)) continue;
@@ -437,16 +561,14 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                 const uint32_t w0 = start >> 4, sh = (start & 15u) * 2u;
                 uint32_t x[5];
 #pragma unroll
-                for (int q = 0; q < 5; q++) { const uint32_t ii = w0 + q; x[q] = ii < nw ? g[ii] : 0u; }
+                for (int q = 0; q < 5; q++) x[q] = word(w0 + q);
                 uint32_t y[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) y[q] = sh ? ((x[q] >> sh) | (x[q + 1] << (32 - sh))) : x[q];
                 const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
                 uint64_t m0, m1;
                 mask128(len, m0, m1);
-                if ((v0 & m0) == M.pat_packed[(uint64_t)pid * 2] && (v1 & m1) == M.pat_packed[(uint64_t)pid * 2 + 1]) {
-                    best_end = end; best_len = len; best_pid = pid;
-                }
+                if ((v0 & m0) == ent[1] && (v1 & m1) == ent[2]) { best_end = end; best_len = len; best_pid = (uint32_t)(e0 >> 32); }
             }
         }
     }
@@ -458,7 +580,14 @@ hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t
                             uint32_t *info_by_slot, uint32_t *pid_by_slot, hipStream_t st)
 {
     if (n_max == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dm_verify, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    const dim3 grid((unsigned)((n_max + 255) / 256)), block(256);
+#define DV_CASE(WW) case WW: hipLaunchKernelGGL((k_dm_verify<WW>), grid, block, 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot); break;
+    switch (R.stride_words) {
+        DV_CASE(4) DV_CASE(5) DV_CASE(6) DV_CASE(7) DV_CASE(8) DV_CASE(9) DV_CASE(10) DV_CASE(11) DV_CASE(12)
+        DV_CASE(13) DV_CASE(14) DV_CASE(15) DV_CASE(16)
+        default: hipLaunchKernelGGL((k_dm_verify<0>), grid, block, 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot); break;
+    }
+#undef DV_CASE
     return hipGetLastError();
 }
 

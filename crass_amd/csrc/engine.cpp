@@ -111,13 +111,15 @@ struct crass_hip_ctx {
     // host memory already in the hand-off layout (no per-record host work)
     struct P1Dense {
         DevBuf<uint64_t> d_read, d_ss_off; DevBuf<uint8_t> d_low; DevBuf<uint32_t> d_replen, d_nss, d_ss; DevBuf<uint16_t> d_dr_len; DevBuf<char> d_dr;
-        PinBuf<uint64_t> h_read, h_ss_off; PinBuf<uint8_t> h_low; PinBuf<uint32_t> h_replen, h_nss, h_ss; PinBuf<uint16_t> h_dr_len; PinBuf<char> h_dr;
         uint64_t n = 0;
         bool active = false;
+        // the used part of the arrays above, packed on the device (p1_blob_layout) and copied with one call
+        DevBuf<uint8_t> d_blob; PinBuf<uint8_t> h_blob;
+        P1Blob lay{};
         void release()
         {
+            d_blob.release(); h_blob.release();
             d_read.release(); d_ss_off.release(); d_low.release(); d_replen.release(); d_nss.release(); d_ss.release(); d_dr_len.release(); d_dr.release();
-            h_read.release(); h_ss_off.release(); h_low.release(); h_replen.release(); h_nss.release(); h_ss.release(); h_dr_len.release(); h_dr.release();
         }
     } dense;
     DevBuf<uint64_t> d_fidx;
@@ -134,9 +136,20 @@ struct crass_hip_ctx {
     bool have_dev_tokens = false;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gathered = nullptr;
-    mutable bool bulk_pending = false;
+    mutable bool bulk_pending = false;          // copy in flight on copy_stream
+    mutable bool bulk_needed = false;           // copy not issued yet (it is issued behind the merge's kernel launches)
+    void issue_bulk() const
+    {
+        if (!bulk_needed) return;
+        bulk_needed = false;
+        if (dense.lay.total) {
+            (void)hipMemcpyAsync(dense.h_blob.p, dense.d_blob.p, dense.lay.total, hipMemcpyDeviceToHost, copy_stream);
+            bulk_pending = true;
+        }
+    }
     void wait_bulk() const
     {
+        issue_bulk();
         if (!bulk_pending) return;
         (void)hipStreamSynchronize(copy_stream);
         bulk_pending = false;
@@ -146,7 +159,8 @@ struct crass_hip_ctx {
     // pass 2 runs.  dm.active: the installed pattern set lives in dm.M, not in the automaton/anchors above.
     struct DM {
         DevBuf<uint64_t> packed, pat_packed; DevBuf<uint32_t> codes, owner, root_of, tmp, root_rank, gid_of, grp, members, pat_token;
-        DevBuf<uint32_t> kset_head, ent_next, anchor_tab; DevBuf<uint8_t> blank, ent_win; DevBuf<uint16_t> pat_len;
+        DevBuf<uint32_t> kset_u32, ent_slot, anchor_tab; DevBuf<uint8_t> blank, sblank, ent_win; DevBuf<uint16_t> pat_len; DevBuf<uint64_t> ents, rents; DevBuf<uint32_t> rset_u32, rd_slot;
+        DevBuf<unsigned long long> rset_key;
         DevBuf<unsigned long long> kset_key; DevBuf<DevMergeState> st;
         PinBuf<DevMergeState> h_st; PinBuf<uint32_t> h_gid; PinBuf<uint8_t> h_blank;
         DevMerge M{};
@@ -156,8 +170,8 @@ struct crass_hip_ctx {
         void release()
         {
             packed.release(); pat_packed.release(); codes.release(); owner.release(); root_of.release(); tmp.release(); root_rank.release();
-            gid_of.release(); grp.release(); members.release(); pat_token.release(); kset_head.release(); ent_next.release(); anchor_tab.release();
-            blank.release(); ent_win.release(); pat_len.release(); kset_key.release(); st.release(); h_st.release(); h_gid.release(); h_blank.release();
+            gid_of.release(); grp.release(); members.release(); pat_token.release(); kset_u32.release(); ent_slot.release(); anchor_tab.release();
+            blank.release(); sblank.release(); ents.release(); ent_win.release(); rents.release(); rset_u32.release(); rd_slot.release(); rset_key.release(); pat_len.release(); kset_key.release(); st.release(); h_st.release(); h_gid.release(); h_blank.release();
             if (ev_done) (void)hipEventDestroy(ev_done);
             if (ev_t0) (void)hipEventDestroy(ev_t0);
             if (ev_t1) (void)hipEventDestroy(ev_t1);
@@ -167,8 +181,8 @@ struct crass_hip_ctx {
     // distinct candidate strings (multi-GPU exchange)
     std::vector<char> dx_chars; std::vector<uint16_t> dx_len; std::vector<uint32_t> dx_map; bool have_distinct = false;
     uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
-    const char *cand_dr() const { wait_bulk(); return dense.active ? dense.h_dr.p : cand.dr.data(); }
-    const uint16_t *cand_dr_len() const { wait_bulk(); return dense.active ? dense.h_dr_len.p : cand.dr_len.data(); }
+    const char *cand_dr() const { wait_bulk(); return dense.active ? (const char *)(dense.h_blob.p + dense.lay.dr) : cand.dr.data(); }
+    const uint16_t *cand_dr_len() const { wait_bulk(); return dense.active ? (const uint16_t *)(dense.h_blob.p + dense.lay.dr_len) : cand.dr_len.data(); }
     uint32_t dr_stride = 48;
     // merge
     MergeResult merge;
@@ -177,6 +191,8 @@ struct crass_hip_ctx {
     bool have_pass2 = false;
     std::vector<uint64_t> q_read; std::vector<uint8_t> q_low; std::vector<uint32_t> q_start, q_end, q_token;
     std::vector<uint16_t> q_dr_len; std::vector<char> q_dr;
+    // ... or, when the sink ran on the device, one pinned blob (p2_blob_layout)
+    DevBuf<uint8_t> d_qblob; PinBuf<uint8_t> h_qblob; P2Blob q_lay{}; uint64_t q_n = 0; bool q_blob_active = false;
 
     crass_counters cnt{};
     hipEvent_t ev[12]{};
@@ -263,7 +279,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    c->dm.release();
+    c->dm.release(); c->d_qblob.release(); c->h_qblob.release();
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
     if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
@@ -510,9 +526,9 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
     HIPCHK(c, c->d_dr.ensure(n_surv * stride));
     HIPCHK(c, c->d_ss_pool.ensure(pool_cap));
     HIPCHK(c, c->d_fidx.ensure(n_surv));
-    HIPCHK(c, D.d_read.ensure(n_surv)); HIPCHK(c, D.d_ss_off.ensure(n_surv)); HIPCHK(c, D.d_low.ensure(n_surv));
-    HIPCHK(c, D.d_replen.ensure(n_surv)); HIPCHK(c, D.d_nss.ensure(n_surv)); HIPCHK(c, D.d_dr_len.ensure(n_surv));
-    HIPCHK(c, D.d_dr.ensure(n_surv * stride)); HIPCHK(c, D.d_ss.ensure(n_surv * (uint64_t)lds.ss_cap));
+    HIPCHK(c, D.d_read.ensure(n_surv + 2)); HIPCHK(c, D.d_ss_off.ensure(n_surv + 2)); HIPCHK(c, D.d_low.ensure(n_surv + 16));
+    HIPCHK(c, D.d_replen.ensure(n_surv + 4)); HIPCHK(c, D.d_nss.ensure(n_surv + 4)); HIPCHK(c, D.d_dr_len.ensure(n_surv + 8));
+    HIPCHK(c, D.d_dr.ensure(n_surv * stride + 16)); HIPCHK(c, D.d_ss.ensure(n_surv * (uint64_t)lds.ss_cap + 4));
     // [2] = found count, [3] = worst error, [4] = n distinct, [5] = de-duplication mismatch flag
     HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 16, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
@@ -556,37 +572,36 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
                                    c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, D.h_read.ensure(n_surv)); HIPCHK(c, D.h_ss_off.ensure(n_surv)); HIPCHK(c, D.h_low.ensure(n_surv)); HIPCHK(c, D.h_replen.ensure(n_surv));
-    HIPCHK(c, D.h_nss.ensure(n_surv)); HIPCHK(c, D.h_dr_len.ensure(n_surv)); HIPCHK(c, D.h_dr.ensure(n_surv * stride + 16));
-    HIPCHK(c, D.h_ss.ensure(n_surv * (uint64_t)lds.ss_cap + 16));
+    {
+        const uint64_t cap = p1_blob_layout(n_surv, stride, lds.ss_cap).total + 64;
+        HIPCHK(c, D.d_blob.ensure(cap)); HIPCHK(c, D.h_blob.ensure(cap));
+        HIPCHK(c, launch_pack_p1_blob(c->d_count.p + 2, n_surv, stride, lds.ss_cap, D.d_read.p, D.d_ss_off.p, D.d_replen.p, D.d_nss.p,
+                                      D.d_dr_len.p, D.d_low.p, D.d_dr.p, D.d_ss.p, D.d_blob.p, c->stream));
+    }
     host_pool_warm();                                   // the merge follows: wake the host workers while the device finishes
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t nf = c->h_count.p[2];
     const uint32_t err = c->h_count.p[3];
     if (err == 1) return CRASS_ERR_SEARCH_FATAL;
     if (err) return CRASS_ERR_OVERFLOW;
+    D.lay = p1_blob_layout(nf, stride, lds.ss_cap);
     if (nf) {
-        // the per-candidate records go out on the copy stream while the host merges
-        hipStream_t cs = c->copy_stream;
-        HIPCHK(c, hipMemcpyAsync(D.h_dr.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipMemcpyAsync(D.h_dr_len.p, D.d_dr_len.p, nf * 2, hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipMemcpyAsync(D.h_read.p, D.d_read.p, nf * 8, hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipMemcpyAsync(D.h_ss_off.p, D.d_ss_off.p, nf * 8, hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipMemcpyAsync(D.h_low.p, D.d_low.p, nf, hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipMemcpyAsync(D.h_replen.p, D.d_replen.p, nf * 4, hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipMemcpyAsync(D.h_nss.p, D.d_nss.p, nf * 4, hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipMemcpyAsync(D.h_ss.p, D.d_ss.p, nf * (uint64_t)lds.ss_cap * 4, hipMemcpyDeviceToHost, cs));
+        // the per-candidate records leave in ONE copy on the copy stream, issued behind the merge's launches
+        // (issue_bulk) so that the host's call overhead stays off the critical path
+        c->bulk_needed = true;
         if (dedupe) {
-            HIPCHK(c, hipMemcpyAsync(c->h_rep.p, c->dd_rep.p, nf * 4, hipMemcpyDeviceToHost, cs));
-            HIPCHK(c, hipMemcpyAsync(c->h_hash.p, c->dd_hash.p, nf * 8, hipMemcpyDeviceToHost, cs));
-            c->have_rep = true;
+            if (c->h_count.p[5] == 0) {
+                c->n_dx = c->h_count.p[4];
+                c->have_dev_tokens = true;
+            } else {
+                // (hash collision among the candidates: the host merge wants the first-occurrence map)
+                HIPCHK(c, hipMemcpyAsync(c->h_rep.p, c->dd_rep.p, nf * 4, hipMemcpyDeviceToHost, c->copy_stream));
+                HIPCHK(c, hipMemcpyAsync(c->h_hash.p, c->dd_hash.p, nf * 8, hipMemcpyDeviceToHost, c->copy_stream));
+                c->bulk_pending = true;
+                c->have_rep = true;
+            }
         }
-        c->bulk_pending = true;
-        if (dedupe && c->h_count.p[5] == 0) {
-            c->n_dx = c->h_count.p[4];
-            c->have_dev_tokens = true;
-        }
-    }
+    } else D.lay.total = 0;
     D.n = nf;
     D.active = true;
     return CRASS_OK;
@@ -712,8 +727,10 @@ int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
     c->wait_bulk();
     if (c->dense.active) {
         const crass_hip_ctx::P1Dense &D = c->dense;
-        o->n = D.n; o->read_idx = D.h_read.p; o->low_lexi = D.h_low.p; o->repeat_len = D.h_replen.p; o->n_ss = D.h_nss.p;
-        o->ss_off = D.h_ss_off.p; o->ss_pool = D.h_ss.p; o->dr_stride = c->dr_stride; o->dr_len = D.h_dr_len.p; o->dr_chars = D.h_dr.p;
+        const uint8_t *hb = D.h_blob.p;
+        o->n = D.n; o->read_idx = (const uint64_t *)(hb + D.lay.read); o->low_lexi = hb + D.lay.low; o->repeat_len = (const uint32_t *)(hb + D.lay.replen);
+        o->n_ss = (const uint32_t *)(hb + D.lay.nss); o->ss_off = (const uint64_t *)(hb + D.lay.ss_off); o->ss_pool = (const uint32_t *)(hb + D.lay.ss);
+        o->dr_stride = c->dr_stride; o->dr_len = (const uint16_t *)(hb + D.lay.dr_len); o->dr_chars = (const char *)(hb + D.lay.dr);
     } else {
         o->n = c->cand.size();
         o->read_idx = c->cand.read.data(); o->low_lexi = c->cand.low.data(); o->repeat_len = c->cand.replen.data();
@@ -830,8 +847,12 @@ static int device_merge(crass_hip_ctx *c)
     HIPCHK(c, d.root_of.ensure(n)); HIPCHK(c, d.tmp.ensure(n + 1)); HIPCHK(c, d.root_rank.ensure(n + 1)); HIPCHK(c, d.gid_of.ensure(n));
     HIPCHK(c, d.grp.ensure(5 * ((size_t)n + 1))); HIPCHK(c, d.members.ensure(n)); HIPCHK(c, d.blank.ensure(n));
     HIPCHK(c, d.pat_packed.ensure((size_t)n * 4)); HIPCHK(c, d.pat_len.ensure((size_t)n * 2)); HIPCHK(c, d.pat_token.ensure((size_t)n * 2));
-    HIPCHK(c, d.kset_key.ensure((size_t)1 << M.kset_log)); HIPCHK(c, d.kset_head.ensure((size_t)1 << M.kset_log));
-    HIPCHK(c, d.ent_next.ensure((size_t)n * 16)); HIPCHK(c, d.ent_win.ensure((size_t)n * 16));
+    HIPCHK(c, d.kset_key.ensure((size_t)1 << M.kset_log)); HIPCHK(c, d.kset_u32.ensure((size_t)3 << M.kset_log));
+    HIPCHK(c, d.ent_slot.ensure((size_t)n * 16)); HIPCHK(c, d.ent_win.ensure((size_t)n * 16)); HIPCHK(c, d.ents.ensure((size_t)n * 48));
+    HIPCHK(c, d.sblank.ensure(n));
+    M.rset_log = 10; while ((1ull << M.rset_log) < 4ull * n) M.rset_log++;
+    HIPCHK(c, d.rset_key.ensure((size_t)1 << M.rset_log)); HIPCHK(c, d.rset_u32.ensure((size_t)3 << M.rset_log));
+    HIPCHK(c, d.rd_slot.ensure(n)); HIPCHK(c, d.rents.ensure((size_t)n * 3));
     HIPCHK(c, d.anchor_tab.ensure((size_t)1 << M.tab_log_alloc)); HIPCHK(c, d.st.ensure(1));
     HIPCHK(c, d.h_st.ensure(1)); HIPCHK(c, d.h_gid.ensure(n)); HIPCHK(c, d.h_blank.ensure(n));
     M.packed = d.packed.p; M.codes = d.codes.p; M.owner = d.owner.p; M.root_of = d.root_of.p; M.tmp = d.tmp.p; M.root_rank = d.root_rank.p;
@@ -839,7 +860,11 @@ static int device_merge(crass_hip_ctx *c)
     M.grp_cnt = d.grp.p; M.grp_off = d.grp.p + (n + 1); M.grp_fill = d.grp.p + 2 * ((size_t)n + 1); M.surv_cnt = d.grp.p + 3 * ((size_t)n + 1);
     M.surv_off = d.grp.p + 4 * ((size_t)n + 1);
     M.members = d.members.p; M.blank = d.blank.p; M.pat_packed = d.pat_packed.p; M.pat_len = d.pat_len.p; M.pat_token = d.pat_token.p;
-    M.kset_key = d.kset_key.p; M.kset_head = d.kset_head.p; M.ent_next = d.ent_next.p; M.ent_win = d.ent_win.p;
+    M.kset_key = d.kset_key.p; M.kset_cnt = d.kset_u32.p; M.kset_base = d.kset_u32.p + ((size_t)1 << M.kset_log);
+    M.kset_fill = d.kset_u32.p + ((size_t)2 << M.kset_log); M.ent_slot = d.ent_slot.p; M.ent_win = d.ent_win.p; M.ents = d.ents.p;
+    M.sblank = d.sblank.p;
+    M.rset_key = d.rset_key.p; M.rset_cnt = d.rset_u32.p; M.rset_base = d.rset_u32.p + ((size_t)1 << M.rset_log);
+    M.rset_fill = d.rset_u32.p + ((size_t)2 << M.rset_log); M.rd_slot = d.rd_slot.p; M.rents = d.rents.p;
     M.anchor_tab = d.anchor_tab.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
     d.M = M;
     HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
@@ -852,6 +877,7 @@ static int device_merge(crass_hip_ctx *c)
     HIPCHK(c, hipMemcpyAsync(d.h_gid.p, d.gid_of.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(d.h_blank.p, d.blank.p, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
+    c->issue_bulk();                                              // the per-candidate records follow on the copy stream
     d.active = true; d.host_built = false; d.n_cand = c->dense.n;
     c->have_merge = true; c->have_pass2 = false;
     c->have_patterns = true; c->have_anchors = false; c->have_pat_token = false;
@@ -908,6 +934,7 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
         if (s != CRASS_ERR_HIP) return s;
         return s;
     }
+    c->issue_bulk();                                    // per-candidate records: copy stream, overlaps the host merge
     if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens &&
         merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
                             c->prm.kmer_clust_size))
@@ -1052,6 +1079,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     (void)hipSetDevice(c->device);
     c->q_read.clear(); c->q_low.clear(); c->q_start.clear(); c->q_end.clear(); c->q_token.clear(); c->q_dr_len.clear(); c->q_dr.clear();
     c->have_pass2 = false;
+    c->q_blob_active = false;
     c->cnt.n_pass2_found = 0;
     // findSingletons is only called when the non-redundant set is non-empty (WorkHorse.cpp:373)
     if (c->n_installed_patterns == 0) { c->have_pass2 = true; return CRASS_OK; }
@@ -1093,20 +1121,12 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
-    if (dmp) {
-        // the host view of the merge (tokens, groups, pattern list) is rebuilt while the filter runs
-        const double th0 = now_ms();
-        const int hs = ensure_host_merge(c);
-        c->cnt.ms_merge_host += (float)(now_ms() - th0);
-        if (hs == CRASS_ERR_STATE) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            const int fs = host_merge_fallback(c);
-            if (fs) return fs;
-            return crass_hip_recruit(c, extra_found, n_extra);
-        }
-        if (hs) return hs;
-    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dmp && c->dm.h_st.p->fail) {                // the device merge gave up: host merge, then pass 2 again
+        const int fs = host_merge_fallback(c);
+        if (fs) return fs;
+        return crass_hip_recruit(c, extra_found, n_extra);
+    }
     const uint64_t n_hits = c->h_count.p[0];
     const uint64_t n_slots = n_hits + c->R.n_exc;
     HIPCHK(c, c->d_rec.ensure(n_slots + 1));
@@ -1128,11 +1148,61 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, c->R.n_exc, c->d_exc_hit.p, true, true, nullptr, nullptr, c->d_rec.p + n_hits,
                                         c->d_dr.p + n_hits * c->dr_stride, c->dr_stride, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    // device merge path: the sink runs on the device too (drop the slots without a match, pack the records in
+    // read order) and ONE copy brings the hand-off arrays to pinned host memory
+    const bool dev_sink = dmp && c->R.n_exc == 0;
+    c->q_blob_active = false;
+    if (dev_sink) {
+        c->q_lay = p2_blob_layout(n_hits, c->dr_stride);
+        HIPCHK(c, c->d_qblob.ensure(c->q_lay.total + 64)); HIPCHK(c, c->h_qblob.ensure(c->q_lay.total + 64));
+        HIPCHK(c, c->d_fidx.ensure(n_hits + 1));
+        if (n_hits) {
+            HIPCHK(c, launch_pack_p2_blob(c->d_rec.p, c->d_dr.p, c->dr_stride, c->d_idx.p, c->read_base, c->d_count.p, n_hits, c->d_mask.p,
+                                          c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 6, c->d_qblob.p, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_qblob.p, c->d_qblob.p, c->q_lay.total, hipMemcpyDeviceToHost, c->stream));
+        } else memset(c->h_qblob.p, 0, 16);
+        const double th0 = now_ms();
+        const int hs = ensure_host_merge(c);            // host view of the merge, rebuilt while the device verifies
+        c->cnt.ms_merge_host += (float)(now_ms() - th0);
+        if (hs == CRASS_ERR_STATE) {                    // inconsistent device results: never expected
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const int fs = host_merge_fallback(c);
+            if (fs) return fs;
+            return crass_hip_recruit(c, extra_found, n_extra);
+        }
+        if (hs) return hs;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->q_n = *reinterpret_cast<const uint64_t *>(c->h_qblob.p);
+        c->q_blob_active = true;
+        c->have_pass2 = true;
+        c->cnt.n_pass2_found = c->q_n;
+        c->cnt.used_lds_automaton = 2;
+        c->cnt.anchor_keys = c->dm.h_st.p->n_keys;
+        c->cnt.anchor_table_kind = c->dm.h_st.p->log_size > 15 ? 2 : 0;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->cnt.ms_recruit = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->cnt.ms_recruit_finish = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[7]); c->cnt.ms_pass2_total = ms;
+        return CRASS_OK;
+    }
     if (n_slots) {
         HIPCHK(c, hipMemcpyAsync(c->h_rec.p, c->d_rec.p, n_slots * sizeof(RecruitOut), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, n_slots * c->dr_stride, hipMemcpyDeviceToHost, c->stream));
     }
     if (n_hits) HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_idx.p, n_hits * 8, hipMemcpyDeviceToHost, c->stream));
+    if (dmp) {
+        // the host view of the merge (tokens, groups, pattern list) is rebuilt while the device verifies
+        const double th0 = now_ms();
+        const int hs = ensure_host_merge(c);
+        c->cnt.ms_merge_host += (float)(now_ms() - th0);
+        if (hs == CRASS_ERR_STATE) {                // inconsistent device results: never expected
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const int fs = host_merge_fallback(c);
+            if (fs) return fs;
+            return crass_hip_recruit(c, extra_found, n_extra);
+        }
+        if (hs) return hs;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const double t0 = now_ms();
     // sink: merge packed hits and exception hits by read index; token = existing or new (addReadHolder)
@@ -1185,6 +1255,14 @@ int crass_hip_get_recruits(const crass_hip_ctx *c, crass_recruits *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     if (!c->have_pass2) return CRASS_ERR_STATE;
+    if (c->q_blob_active) {
+        const uint8_t *hb = c->h_qblob.p;
+        const P2Blob &b = c->q_lay;
+        o->n = c->q_n; o->read_idx = (const uint64_t *)(hb + b.read); o->low_lexi = hb + b.low; o->start = (const uint32_t *)(hb + b.start);
+        o->end = (const uint32_t *)(hb + b.end); o->dr_stride = c->dr_stride; o->dr_len = (const uint16_t *)(hb + b.dr_len);
+        o->dr_chars = (const char *)(hb + b.dr); o->token = (const uint32_t *)(hb + b.token);
+        return CRASS_OK;
+    }
     o->n = c->q_read.size(); o->read_idx = c->q_read.data(); o->low_lexi = c->q_low.data();
     o->start = c->q_start.data(); o->end = c->q_end.data(); o->dr_stride = c->dr_stride;
     o->dr_len = c->q_dr_len.data(); o->dr_chars = c->q_dr.data(); o->token = c->q_token.data();

@@ -89,8 +89,9 @@ struct DevMergeState {
                                   // large or empty, 4 cuckoo insertion gave up) -> the host merge is used instead
     uint32_t k0;                  // a member key (fills unused table slots)
     uint32_t all_t;               // the key 0xFFFFFFFF is a member
-    uint32_t ticket;              // k_dm_greedy's token dispenser
-    uint32_t pad[3];
+    uint32_t ent_cursor;          // entries allocated in the verification index
+    uint32_t rd_cursor;           // entries allocated in the needle index of removeRedundantRepeats
+    uint32_t pad[2];
 };
 
 struct DevMerge {
@@ -109,16 +110,24 @@ struct DevMerge {
     uint32_t *grp_cnt, *grp_off, *grp_fill, *surv_cnt, *surv_off;     // [n_tok + 1] per group
     uint32_t *members;            // [n_tok] tokens ordered by group
     uint8_t  *blank;              // [n_tok] removed by removeRedundantRepeats
+    uint8_t  *sblank;             // [n_tok] the same flag by position in members[]
+    // needle index of removeRedundantRepeats: key = (GID << 32) | first 16 bases
+    unsigned long long *rset_key; // [1 << rset_log]
+    uint32_t *rset_cnt, *rset_base, *rset_fill;   // [1 << rset_log]
+    uint32_t rset_log;
+    uint32_t *rd_slot;            // [n_tok] the member's key slot (bit 31: it claimed the slot)
+    uint64_t *rents;              // [n_tok][3] {len | token << 32, bits lo, bits hi}, grouped by key
     // pattern list (capacity 2 * n_tok)
     uint64_t *pat_packed;         // [n_pat][2]
     uint16_t *pat_len;
     uint32_t *pat_token;
     // anchor keys: entry e = pid * 8 + r (capacity 16 * n_tok)
     unsigned long long *kset_key; // [1 << kset_log] distinct keys (key | 1 << 32; 0 = empty)
-    uint32_t *kset_head;          // [1 << kset_log] head of the key's entry chain
+    uint32_t *kset_cnt, *kset_base, *kset_fill;   // [1 << kset_log] the key's entries: ents[base .. base + cnt)
     uint32_t kset_log;
-    uint32_t *ent_next;           // [16 * n_tok]
+    uint32_t *ent_slot;           // [16 * n_tok] the entry's key slot
     uint8_t  *ent_win;            // [16 * n_tok] entry claimed its key's slot
+    uint64_t *ents;               // [16 * n_tok][3] verification index, grouped by key
     uint32_t *anchor_tab;         // [1 << tab_log_alloc] cuckoo table of the keys (see DevAnchors)
     uint32_t tab_log_alloc;
     uint32_t s1, s2, m1, m2;      // hash constants of the table
@@ -182,6 +191,39 @@ hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint6
                                const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
                                const uint32_t *ss_pool, uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
                                uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr, uint32_t *g_ss, hipStream_t st);
+// pass-1 hand-off blob: the used part (nf records) of the dense arrays, packed back to back so that ONE
+// copy moves them to the host.  The layout is a function of nf, evaluated on the device (the count lives
+// there) and again on the host once it knows nf.
+struct P1Blob { uint64_t read, ss_off, replen, nss, dr_len, low, dr, ss, total; };
+__host__ __device__ inline P1Blob p1_blob_layout(uint64_t nf, uint32_t stride, uint32_t ss_cap)
+{
+    P1Blob b;
+    uint64_t at = 0;
+    auto sec = [&](uint64_t bytes) { const uint64_t o = at; at += (bytes + 15u) & ~15ull; return o; };
+    b.read = sec(nf * 8); b.ss_off = sec(nf * 8); b.replen = sec(nf * 4); b.nss = sec(nf * 4); b.dr_len = sec(nf * 2);
+    b.low = sec(nf); b.dr = sec(nf * stride); b.ss = sec(nf * (uint64_t)ss_cap * 4);
+    b.total = at;
+    return b;
+}
+hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t stride, uint32_t ss_cap, const uint64_t *g_read,
+                               const uint64_t *g_ss_off, const uint32_t *g_replen, const uint32_t *g_nss, const uint16_t *g_dr_len,
+                               const uint8_t *g_low, const char *g_dr, const uint32_t *g_ss, uint8_t *blob, hipStream_t st);
+// pass-2 hand-off blob: header (record count, 16 bytes) + dense arrays with `cap` slots each
+struct P2Blob { uint64_t read, start, end, token, dr_len, low, dr, total; };
+__host__ __device__ inline P2Blob p2_blob_layout(uint64_t cap, uint32_t stride)
+{
+    P2Blob b;
+    uint64_t at = 16;
+    auto sec = [&](uint64_t bytes) { const uint64_t o = at; at += (bytes + 15u) & ~15ull; return o; };
+    b.read = sec(cap * 8); b.start = sec(cap * 4); b.end = sec(cap * 4); b.token = sec(cap * 4); b.dr_len = sec(cap * 2);
+    b.low = sec(cap); b.dr = sec(cap * stride);
+    b.total = at;
+    return b;
+}
+// valid hits (dr_len != 0) of the finish kernel's slots -> compacted, read-ordered dense arrays in `blob`
+hipError_t launch_pack_p2_blob(const RecruitOut *rec, const char *dr, uint32_t stride, const uint64_t *hit_idx, uint64_t read_base,
+                               const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
+                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st);
 hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, const uint32_t *rep,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,

@@ -13,6 +13,7 @@
 // the pass-2 automaton is staged in LDS when it fits.  Compile with -ffp-contract=off:
 // qcFoundRepeats' float evaluation order is part of the parity contract.
 #include "engine_internal.h"
+#include <algorithm>
 
 namespace crass {
 
@@ -1412,6 +1413,40 @@ __global__ __launch_bounds__(256) void k_gather_found(const uint64_t *fidx, cons
     for (uint32_t i = 0; i < ss_cap; i++) pd[i] = (i < o.n_ss) ? ps[i] : 0u;
 }
 
+// used parts of the dense arrays -> one contiguous blob (p1_blob_layout), 16 bytes per thread and step
+__global__ __launch_bounds__(256) void k_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t stride, uint32_t ss_cap,
+                                                       const uint64_t *g_read, const uint64_t *g_ss_off, const uint32_t *g_replen,
+                                                       const uint32_t *g_nss, const uint16_t *g_dr_len, const uint8_t *g_low,
+                                                       const char *g_dr, const uint32_t *g_ss, uint8_t *blob)
+{
+    uint64_t nf = *d_nf;
+    if (nf > n_max) nf = n_max;
+    const P1Blob b = p1_blob_layout(nf, stride, ss_cap);
+    const uint64_t off[9] = {b.read, b.ss_off, b.replen, b.nss, b.dr_len, b.low, b.dr, b.ss, b.total};
+    const void *src[8] = {g_read, g_ss_off, g_replen, g_nss, g_dr_len, g_low, g_dr, g_ss};
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src[k]);
+        uint4 *d4 = reinterpret_cast<uint4 *>(blob + off[k]);
+        const uint64_t n16 = (off[k + 1] - off[k]) / 16;
+        for (uint64_t i = tid; i < n16; i += nth) d4[i] = s4[i];
+    }
+}
+
+hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t stride, uint32_t ss_cap, const uint64_t *g_read,
+                               const uint64_t *g_ss_off, const uint32_t *g_replen, const uint32_t *g_nss, const uint16_t *g_dr_len,
+                               const uint8_t *g_low, const char *g_dr, const uint32_t *g_ss, uint8_t *blob, hipStream_t st)
+{
+    if (n_max == 0) return hipSuccess;
+    const uint64_t total16 = p1_blob_layout(n_max, stride, ss_cap).total / 16;
+    unsigned nb = (unsigned)std::min<uint64_t>((total16 + 255) / 256, 2048);
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_pack_p1_blob, dim3(nb), dim3(256), 0, st, d_nf, n_max, stride, ss_cap, g_read, g_ss_off, g_replen, g_nss, g_dr_len,
+                       g_low, g_dr, g_ss, blob);
+    return hipGetLastError();
+}
+
 hipError_t launch_found_mask(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
@@ -2033,6 +2068,50 @@ hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, con
         hipLaunchKernelGGL(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, 1, pid_by_slot, pat_token, out, dr_chars, dr_stride);
     else
         hipLaunchKernelGGL(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, info_by_slot ? 1 : 0, pid_by_slot, pat_token, out, dr_chars, dr_stride);
+    return hipGetLastError();
+}
+
+// ---- pass-2 sink on the device: drop the slots without a match, pack the rest (read order) ----
+__global__ __launch_bounds__(256) void k_recruit_valid_mask(const RecruitOut *rec, const uint32_t *d_n, uint64_t n_max, uint64_t *mask)
+{
+    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t n = *d_n;
+    if (n > n_max) n = n_max;
+    const bool v = k < n && rec[k].dr_len != 0;
+    const uint64_t m = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && k < n_max) mask[k >> 6] = m;
+}
+__global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, const char *dr, uint32_t stride, const uint64_t *hit_idx,
+                                                       uint64_t read_base, const uint64_t *vidx, const uint32_t *d_nv, uint64_t cap, uint8_t *blob)
+{
+    const uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t nv = *d_nv;
+    if (nv > cap) nv = cap;
+    if (q == 0) { reinterpret_cast<uint64_t *>(blob)[0] = nv; reinterpret_cast<uint64_t *>(blob)[1] = cap; }
+    if (q >= nv) return;
+    const P2Blob b = p2_blob_layout(cap, stride);
+    const uint64_t k = vidx[q];
+    const RecruitOut o = rec[k];
+    reinterpret_cast<uint64_t *>(blob + b.read)[q] = read_base + hit_idx[k];
+    reinterpret_cast<uint32_t *>(blob + b.start)[q] = o.start;
+    reinterpret_cast<uint32_t *>(blob + b.end)[q] = o.end;
+    reinterpret_cast<uint32_t *>(blob + b.token)[q] = o.token;
+    reinterpret_cast<uint16_t *>(blob + b.dr_len)[q] = o.dr_len;
+    (blob + b.low)[q] = o.low_lexi;
+    const uint4 *src = reinterpret_cast<const uint4 *>(dr + k * (uint64_t)stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(blob + b.dr + q * (uint64_t)stride);
+    for (uint32_t i = 0; i < stride / 16; i++) dst[i] = src[i];
+}
+hipError_t launch_pack_p2_blob(const RecruitOut *rec, const char *dr, uint32_t stride, const uint64_t *hit_idx, uint64_t read_base,
+                               const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
+                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st)
+{
+    if (n_hits_max == 0) return hipSuccess;
+    const unsigned nb = (unsigned)((n_hits_max + 255) / 256);
+    hipLaunchKernelGGL(k_recruit_valid_mask, dim3(nb), dim3(256), 0, st, rec, d_n_hits, n_hits_max, mask);
+    hipError_t e = launch_compact(mask, (n_hits_max + 63) / 64, n_hits_max, word_prefix, block_sums, vidx, n_hits_max, d_nv, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, dr, stride, hit_idx, read_base, vidx, d_nv, n_hits_max, blob);
     return hipGetLastError();
 }
 

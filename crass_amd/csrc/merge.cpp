@@ -58,8 +58,41 @@ uint64_t TokenTable::hash(const char *p, size_t n)
     return h ^ (h >> 31);
 }
 
+void TokenTable::load_strings(const char *chars, const uint16_t *len, uint32_t stride, size_t n)
+{
+    clear();
+    size_t total = 0;
+    for (size_t j = 0; j < n; j++) total += len[j];
+    strings.chars.resize(total);
+    strings.off.resize(n + 1);
+    size_t at = 0;
+    for (size_t j = 0; j < n; j++) {
+        strings.off[j] = at;
+        memcpy(strings.chars.data() + at, chars + j * (size_t)stride, len[j]);
+        at += len[j];
+    }
+    strings.off[n] = at;
+    index_stale = n != 0;
+}
+
+void TokenTable::ensure_index() const
+{
+    if (!index_stale) return;
+    index_stale = false;
+    size_t cap = 1024;
+    while (cap < (strings.size() + 1) * 2) cap <<= 1;
+    slot_token.assign(cap, 0); slot_hash.assign(cap, 0);
+    for (size_t t = 0; t < strings.size(); t++) {
+        const uint64_t h = hash(strings.data(t), strings.len(t));
+        size_t i = (size_t)h & (cap - 1);
+        while (slot_token[i]) i = (i + 1) & (cap - 1);
+        slot_token[i] = (uint32_t)t + 2; slot_hash[i] = h;
+    }
+}
+
 uint32_t TokenTable::get(const char *p, size_t n) const
 {
+    ensure_index();
     if (slot_token.empty()) return 0;
     const uint64_t h = hash(p, n);
     const size_t mask = slot_token.size() - 1;
@@ -72,6 +105,7 @@ uint32_t TokenTable::get(const char *p, size_t n) const
 
 void TokenTable::grow()
 {
+    ensure_index();
     const size_t cap = slot_token.empty() ? 1024 : slot_token.size() * 2;
     std::vector<uint32_t> nt(cap, 0);
     std::vector<uint64_t> nh(cap, 0);
@@ -87,6 +121,7 @@ uint32_t TokenTable::add(const char *p, size_t n) { return add_hashed(p, n, hash
 
 void TokenTable::reserve(size_t n_strings, size_t n_chars)
 {
+    ensure_index();
     size_t cap = slot_token.empty() ? 1024 : slot_token.size();
     while (cap < (n_strings + 1) * 2) cap <<= 1;
     if (cap != slot_token.size()) {
@@ -105,6 +140,7 @@ void TokenTable::reserve(size_t n_strings, size_t n_chars)
 
 uint32_t TokenTable::add_unique_hashed(const char *p, size_t n, uint64_t h)
 {
+    ensure_index();
     if ((strings.size() + 1) * 2 > slot_token.size()) grow();
     const size_t mask = slot_token.size() - 1;
     size_t i = (size_t)h & mask;
@@ -120,6 +156,7 @@ uint32_t TokenTable::add_unique_hashed(const char *p, size_t n, uint64_t h)
 
 uint32_t TokenTable::add_hashed(const char *p, size_t n, uint64_t h)
 {
+    ensure_index();
     if ((strings.size() + 1) * 2 > slot_token.size()) grow();
     strings.push(p, n);
     const uint32_t t = (uint32_t)strings.size() + 1;
@@ -753,13 +790,9 @@ bool merge_from_device(MergeResult &m, const char *dx_chars, const uint16_t *dx_
                        const uint32_t *cand_distinct, uint64_t n, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups)
 {
     m.clear();
-    size_t n_chars = 0;
-    for (uint64_t j = 0; j < n_distinct; j++) n_chars += dx_len[j];
-    m.tokens.reserve(n_distinct, n_chars);
-    for (uint64_t j = 0; j < n_distinct; j++) {
-        const char *p = dx_chars + j * (uint64_t)dr_stride;
-        if (m.tokens.add_unique_hashed(p, dx_len[j], TokenTable::hash(p, dx_len[j])) == 0) { m.clear(); return false; }
-    }
+    // the device compared every candidate with its representative byte for byte, so the list is pairwise
+    // distinct; the string -> token side is built lazily (pass 2 resolves its tokens on the device)
+    m.tokens.load_strings(dx_chars, dx_len, dr_stride, n_distinct);
     m.cand_token.resize(n);
     for (uint64_t k = 0; k < n; k++) {
         if (cand_distinct[k] >= n_distinct) { m.clear(); return false; }

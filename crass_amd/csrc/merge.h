@@ -33,8 +33,12 @@ struct StringArena {
 struct TokenTable {
     typedef StringArena Strings;
     Strings strings;                                           // token t -> strings[t - 2]
-    std::vector<uint32_t> slot_token;                          // 0 = empty
-    std::vector<uint64_t> slot_hash;
+    mutable std::vector<uint32_t> slot_token;                  // 0 = empty
+    mutable std::vector<uint64_t> slot_hash;
+    mutable bool index_stale = false;                          // strings loaded in bulk, string -> token side not built yet
+    // token order given (device merge): fill the arena only; the lookup side is built on the first get()/add()
+    void load_strings(const char *chars, const uint16_t *len, uint32_t stride, size_t n);
+    void ensure_index() const;
     static uint64_t hash(const char *p, size_t n);
     uint32_t get(const char *p, size_t n) const;
     uint32_t add(const char *p, size_t n);                     // caller checked get() == 0
@@ -44,7 +48,7 @@ struct TokenTable {
     uint32_t get(const std::string &s) const { return get(s.data(), s.size()); }
     uint32_t add(const std::string &s) { return add(s.data(), s.size()); }
     uint32_t size() const { return (uint32_t)strings.size(); }
-    void clear() { strings.clear(); slot_token.clear(); slot_hash.clear(); }
+    void clear() { strings.clear(); slot_token.clear(); slot_hash.clear(); index_stale = false; }
 private:
     void grow();
 };

@@ -219,12 +219,18 @@ def test_config5_shape_many_drs_gc_classes(ca):
     assert gpu.counters["used_lds_automaton"] == 2
 
 
-@pytest.mark.parametrize("n_dr,kind", [(2000, 1), (9000, 2)])
-def test_anchor_table_tiers(ca, n_dr, kind):
-    """pattern sets beyond the exact LDS anchor table: fingerprint buckets in LDS (kind 1), then exact
-    keys probed in L2 (kind 2) — same records either way."""
+@pytest.mark.parametrize("n_dr,kind,host_merge", [(2000, 1, True), (9000, 2, True), (2000, 2, False), (9000, 2, False)])
+def test_anchor_table_tiers(ca, n_dr, kind, host_merge):
+    """pattern sets beyond the exact LDS anchor table: fingerprint buckets in LDS (kind 1, host-built tables
+    only), then exact keys probed in L2 (kind 2) — same records either way, whichever side built the table."""
     seqs = synth_reads(ca, 200000, read_len=150, n_dr=n_dr, crispr_per_million=150000)
-    gpu = ca.search_pipeline(seqs)
+    if host_merge:
+        os.environ["CRASS_HOST_MERGE"] = "1"
+    try:
+        gpu = ca.search_pipeline(seqs)
+    finally:
+        os.environ.pop("CRASS_HOST_MERGE", None)
+    assert gpu.counters["used_device_merge"] == (0 if host_merge else 1)
     ref = orc.pipeline(seqs)
     assert_same_pipeline(gpu, ref)
     assert gpu.counters["used_lds_automaton"] == 2
