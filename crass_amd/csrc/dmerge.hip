@@ -264,45 +264,72 @@ __global__ __launch_bounds__(256) void k_dm_rd_fill(DevMerge M)
     d[1] = M.packed[(uint64_t)t * 4];
     d[2] = M.packed[(uint64_t)t * 4 + 1];
 }
+// One wave per member j: the lanes probe j's windows (both orientations) in parallel, then every window that
+// hit a key has its candidates compared 64 at a time.
+static __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
+{
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
 __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= M.n_tok) return;
-    const uint32_t g = M.gid_of[j];
-    const uint32_t lenj = M.dx_len[j];
-    const uint64_t *pj = M.packed + (uint64_t)j * 4;
-    const uint64_t hay[4] = {pj[0], pj[1], pj[2], pj[3]};
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t mask = (1u << M.rset_log) - 1u;
-    bool blank = false;
-    const uint32_t p_max = lenj - 23u;                  // a member is >= 23 long and strictly shorter than lenj
-    for (int o = 0; o < 2 && !blank; o++) {
-        const uint64_t h0 = hay[2 * o], h1 = hay[2 * o + 1];
-        for (uint32_t p = 0; p <= p_max && !blank; p++) {
-            const uint64_t w0 = shr128_lo(h0, h1, 2 * p);
-            const uint32_t w = (uint32_t)w0;
-            const unsigned long long want = ((unsigned long long)g << 32) | w;
-            uint32_t h = rset_hash(g, w, M.rset_log);
+    for (uint32_t j = wave; j < M.n_tok; j += n_waves) {
+        const uint32_t g = M.gid_of[j];
+        const uint32_t lenj = M.dx_len[j];
+        const uint64_t *pj = M.packed + (uint64_t)j * 4;
+        const uint64_t f0 = pj[0], f1 = pj[1], r0 = pj[2], r1 = pj[3];
+        const uint32_t nwin = lenj - 22u;               // starts 0 .. lenj-23: a member is >= 23 long and shorter than lenj
+        bool found = false;
+        for (uint32_t wb = 0; wb < 2 * nwin && !found; wb += 64) {
+            const uint32_t wq = wb + lane;
+            const bool act = wq < 2 * nwin;
+            const uint32_t o = wq >= nwin ? 1u : 0u, p = wq - o * nwin;
+            const uint64_t h0 = o ? r0 : f0, h1 = o ? r1 : f1;
+            const uint64_t w0 = shr128_lo(h0, h1, 2 * (act ? p : 0u)), w1 = shr128_hi(h1, 2 * (act ? p : 0u));
             uint32_t cnt = 0, base = 0;
-            for (;;) {
-                const unsigned long long kk = M.rset_key[h];
-                if (kk == 0ull) break;
-                if (kk == want) { cnt = M.rset_cnt[h]; base = M.rset_base[h]; break; }
-                h = (h + 1) & mask;
+            if (act) {
+                const uint32_t w = (uint32_t)w0;
+                const unsigned long long want = ((unsigned long long)g << 32) | w;
+                uint32_t h = rset_hash(g, w, M.rset_log);
+                for (;;) {
+                    const unsigned long long kk = M.rset_key[h];
+                    if (kk == 0ull) break;
+                    if (kk == want) { cnt = M.rset_cnt[h]; base = M.rset_base[h]; break; }
+                    h = (h + 1) & mask;
+                }
             }
-            if (!cnt) continue;
-            const uint64_t w1 = shr128_hi(h1, 2 * p);
-            const uint64_t *ent = M.rents + (uint64_t)base * 3;
-            for (uint32_t c = 0; c < cnt; c++, ent += 3) {
-                const uint32_t leni = (uint32_t)ent[0] & 0xFFu;
-                if (leni >= lenj || p + leni > lenj) continue;
-                uint64_t m0, m1;
-                mask128(leni, m0, m1);
-                if ((w0 & m0) == ent[1] && (w1 & m1) == ent[2]) { blank = true; break; }
+            uint64_t hits = __ballot(cnt > 0);
+            while (hits && !found) {
+                const int src = __ffsll((unsigned long long)hits) - 1;
+                hits &= hits - 1;
+                const uint32_t cnt_s = (uint32_t)__shfl((int)cnt, src), base_s = (uint32_t)__shfl((int)base, src);
+                const uint32_t p_s = (uint32_t)__shfl((int)p, src);
+                const uint64_t w0_s = shfl64(w0, src), w1_s = shfl64(w1, src);
+                for (uint32_t c0 = 0; c0 < cnt_s && !found; c0 += 64) {
+                    const uint32_t c = c0 + lane;
+                    bool hit = false;
+                    if (c < cnt_s) {
+                        const uint64_t *ent = M.rents + (uint64_t)(base_s + c) * 3;
+                        const uint32_t leni = (uint32_t)ent[0] & 0xFFu;
+                        if (leni < lenj && p_s + leni <= lenj) {
+                            uint64_t m0, m1;
+                            mask128(leni, m0, m1);
+                            hit = (w0_s & m0) == ent[1] && (w1_s & m1) == ent[2];
+                        }
+                    }
+                    if (__ballot(hit)) found = true;
+                }
             }
         }
+        if (lane == 0) {
+            M.blank[j] = found ? 1 : 0;
+            if (!found) atomicAdd(&M.surv_cnt[g - 1], 1u);
+        }
     }
-    M.blank[j] = blank ? 1 : 0;
-    if (!blank) atomicAdd(&M.surv_cnt[g - 1], 1u);
 }
 // the same flag by position in members[] (k_dm_patterns walks member ranges)
 __global__ __launch_bounds__(256) void k_dm_sblank(DevMerge M)
@@ -464,6 +491,19 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_finalize(DevMerge M)
     if (M.anchor_tab[i] == 0xFFFFFFFFu) M.anchor_tab[i] = M.st->k0;
 }
 
+// per-token results + state words straight into pinned host memory (a few 10 KB over PCIe): no copy calls
+__global__ __launch_bounds__(256) void k_dm_export(DevMerge M, DevMergeState *h_st, uint32_t *h_gid, uint8_t *h_blank)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *h_st = *M.st;
+    if (t < M.n_tok) { h_gid[t] = M.gid_of[t]; h_blank[t] = M.blank[t]; }
+}
+hipError_t launch_dm_export(const DevMerge &M, DevMergeState *h_st, uint32_t *h_gid, uint8_t *h_blank, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dm_export, dim3((M.n_tok + 255) / 256), dim3(256), 0, st, M, h_st, h_gid, h_blank);
+    return hipGetLastError();
+}
+
 hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
 {
     if (M.n_tok == 0) return hipErrorInvalidValue;
@@ -481,7 +521,9 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     hipLaunchKernelGGL(k_dm_rd_keys, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_fill, dim3(nb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_redundant, dim3(nb), dim3(256), 0, st, M);
+    unsigned rb = (M.n_tok + 3) / 4;
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_sblank, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok, &M.st->n_survivors);
     hipLaunchKernelGGL(k_dm_patterns, dim3(nb), dim3(256), 0, st, M);
@@ -505,89 +547,118 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
 static __device__ __forceinline__ uint32_t dm_rd_len(const DevReads &R, uint64_t r) { return R.uniform_len ? R.uniform_len : R.lengths[r]; }
 static __device__ __forceinline__ uint64_t dm_rd_off(const DevReads &R, uint64_t r) { return R.stride_words ? r * (uint64_t)R.stride_words : R.word_off[r]; }
 
-// NW > 0: uniform stride of NW words, the read goes through LDS ([word][thread]) so that the dynamically
-// indexed window extraction does not go back to memory for every candidate; NW == 0: any layout, global loads.
-template <int NW>
+// One wave per flagged read.  Lanes 0..h_max probe the read's aligned windows in parallel; the windows that
+// hit a key are then taken in ascending order and their candidates compared 64 at a time.  The read's words
+// sit in LDS ([wave][word]) so that the dynamically indexed window extraction costs an LDS read.
+#define DV_MAXW 20                                   // words staged per read (reads up to 304 bases); longer reads use global loads
 __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
                                                     uint32_t *info_by_slot, uint32_t *pid_by_slot)
 {
-    __shared__ uint32_t rw[(NW > 0 ? NW + 1 : 1) * 256];
-    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    __shared__ uint32_t rw_all[4][DV_MAXW + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *rw = rw_all[wv];
+    const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6));
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     uint64_t n = *d_n;
     if (n > n_max) n = n_max;
-    if (k >= n) return;
-    const uint64_t r = idx[k];
-    const uint32_t L = dm_rd_len(R, r);
-    const uint32_t *g = R.packed + dm_rd_off(R, r);
-    const uint32_t nw = (L + 15) >> 4;
-    if (NW > 0) {
-#pragma unroll
-        for (int q = 0; q < NW; q++) rw[q * 256 + threadIdx.x] = g[q];
-        rw[NW * 256 + threadIdx.x] = 0u;
-    }
-    auto word = [&](uint32_t i) -> uint32_t {
-        if (NW > 0) return rw[min(i, (uint32_t)NW) * 256 + threadIdx.x];
-        return i < nw ? g[i] : 0u;
-    };
     const uint32_t kmask = (1u << M.kset_log) - 1u;
-    uint32_t best_end = 0xFFFFFFFFu, best_len = 0, best_pid = 0;
-    if (L >= 16) {
-        const uint32_t h_max = (L - 16) >> 3;
-        for (uint32_t h = 0; h <= h_max; h++) {
-            const uint32_t a = 8 * h;
-            if (best_end <= a + 15) break;
-            const uint32_t wi = h >> 1;
-            const uint32_t lo = word(wi), hi = word(wi + 1);
-            const uint32_t V = (h & 1) ? ((lo >> 16) | (hi << 16)) : lo;
-            const unsigned long long want = (unsigned long long)V | (1ull << 32);
-            uint32_t s = kset_hash(V, M.kset_log);
-            uint32_t cnt = 0, base = 0;
-            for (;;) {
-                const unsigned long long kk = M.kset_key[s];
-                if (kk == 0ull) break;
-                if (kk == want) { cnt = M.kset_cnt[s]; base = M.kset_base[s]; break; }
-                s = (s + 1) & kmask;
-            }
-            const uint64_t *ent = M.ents + (uint64_t)base * 3;
-            for (uint32_t c = 0; c < cnt; c++, ent += 3) {
-                const uint64_t e0 = ent[0];
-                const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
-                if (a < rr) continue;
-                const uint32_t start = a - rr;
-                const uint32_t end = start + len;
-                if (end > L) continue;
-                if (end > best_end || (end == best_end && len <= best_len)) continue;
-                // read bases [start, start+len) as a 128-bit value
-                const uint32_t w0 = start >> 4, sh = (start & 15u) * 2u;
-                uint32_t x[5];
+    for (uint64_t k = wave; k < n; k += n_waves) {
+        const uint64_t r = idx[k];
+        const uint32_t L = dm_rd_len(R, r);
+        const uint32_t *g = R.packed + dm_rd_off(R, r);
+        const uint32_t nw = (L + 15) >> 4;
+        const bool staged = nw <= DV_MAXW;
+        if (staged) {
+            if ((uint32_t)lane < nw) rw[lane] = g[lane];
+            if ((uint32_t)lane == nw) rw[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        auto word = [&](uint32_t i) -> uint32_t {
+            if (staged) return rw[min(i, nw)];
+            return i < nw ? g[i] : 0u;
+        };
+        uint32_t best_end = 0xFFFFFFFFu, best_len = 0, best_pid = 0;      // wave-uniform
+        if (L >= 16) {
+            const uint32_t h_max = (L - 16) >> 3;
+            for (uint32_t hb = 0; hb <= h_max; hb += 64) {
+                if (best_end <= 8 * hb + 15) break;
+                const uint32_t h = hb + lane;
+                uint32_t cnt = 0, base = 0;
+                if (h <= h_max) {
+                    const uint32_t wi = h >> 1;
+                    const uint32_t lo = word(wi), hi = word(wi + 1);
+                    const uint32_t V = (h & 1) ? ((lo >> 16) | (hi << 16)) : lo;
+                    const unsigned long long want = (unsigned long long)V | (1ull << 32);
+                    uint32_t s = kset_hash(V, M.kset_log);
+                    for (;;) {
+                        const unsigned long long kk = M.kset_key[s];
+                        if (kk == 0ull) break;
+                        if (kk == want) { cnt = M.kset_cnt[s]; base = M.kset_base[s]; break; }
+                        s = (s + 1) & kmask;
+                    }
+                }
+                uint64_t hits = __ballot(cnt > 0);
+                while (hits) {
+                    const int src = __ffsll((unsigned long long)hits) - 1;
+                    hits &= hits - 1;
+                    const uint32_t a = 8 * (hb + (uint32_t)src);
+                    if (best_end <= a + 15) { hits = 0; break; }              // later windows cannot end earlier
+                    const uint32_t cnt_s = (uint32_t)__shfl((int)cnt, src), base_s = (uint32_t)__shfl((int)base, src);
+                    for (uint32_t c0 = 0; c0 < cnt_s; c0 += 64) {
+                        const uint32_t c = c0 + lane;
+                        uint32_t cand = 0xFFFFFFFFu, cpid = 0;                // (end << 8) | (255 - len): smaller is better
+                        if (c < cnt_s) {
+                            const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 3;
+                            const uint64_t e0 = ent[0];
+                            const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
+                            if (a >= rr && a - rr + len <= L) {
+                                const uint32_t start = a - rr;
+                                const uint32_t w0 = start >> 4, sh = (start & 15u) * 2u;
+                                uint32_t x[5];
 #pragma unroll
-                for (int q = 0; q < 5; q++) x[q] = word(w0 + q);
-                uint32_t y[4];
+                                for (int q = 0; q < 5; q++) x[q] = word(w0 + q);
+                                uint32_t y[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) y[q] = sh ? ((x[q] >> sh) | (x[q + 1] << (32 - sh))) : x[q];
-                const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
-                uint64_t m0, m1;
-                mask128(len, m0, m1);
-                if ((v0 & m0) == ent[1] && (v1 & m1) == ent[2]) { best_end = end; best_len = len; best_pid = (uint32_t)(e0 >> 32); }
+                                for (int q = 0; q < 4; q++) y[q] = sh ? ((x[q] >> sh) | (x[q + 1] << (32 - sh))) : x[q];
+                                const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
+                                uint64_t m0, m1;
+                                mask128(len, m0, m1);
+                                if ((v0 & m0) == ent[1] && (v1 & m1) == ent[2]) { cand = ((start + len) << 8) | (255u - len); cpid = (uint32_t)(e0 >> 32); }
+                            }
+                        }
+                        // wave minimum of cand (ties: any lane — equal (end, len) means equal strings)
+                        uint32_t mn = cand;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+                        if (mn != 0xFFFFFFFFu) {
+                            const uint32_t e_end = mn >> 8, e_len = 255u - (mn & 0xFFu);
+                            if (e_end < best_end || (e_end == best_end && e_len > best_len)) {
+                                const uint64_t who = __ballot(cand == mn);
+                                best_end = e_end; best_len = e_len;
+                                best_pid = (uint32_t)__shfl((int)cpid, __ffsll((unsigned long long)who) - 1);
+                            }
+                        }
+                    }
+                }
             }
         }
+        if (lane == 0) {
+            info_by_slot[k] = best_len ? ((best_end << 8) | best_len) : 0u;
+            pid_by_slot[k] = best_pid;
+        }
+        __builtin_amdgcn_wave_barrier();                // the next read reuses rw
     }
-    info_by_slot[k] = best_len ? ((best_end << 8) | best_len) : 0u;
-    pid_by_slot[k] = best_pid;
 }
 
 hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
                             uint32_t *info_by_slot, uint32_t *pid_by_slot, hipStream_t st)
 {
     if (n_max == 0) return hipSuccess;
-    const dim3 grid((unsigned)((n_max + 255) / 256)), block(256);
-#define DV_CASE(WW) case WW: hipLaunchKernelGGL((k_dm_verify<WW>), grid, block, 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot); break;
-    switch (R.stride_words) {
-        DV_CASE(4) DV_CASE(5) DV_CASE(6) DV_CASE(7) DV_CASE(8) DV_CASE(9) DV_CASE(10) DV_CASE(11) DV_CASE(12)
-        DV_CASE(13) DV_CASE(14) DV_CASE(15) DV_CASE(16)
-        default: hipLaunchKernelGGL((k_dm_verify<0>), grid, block, 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot); break;
-    }
-#undef DV_CASE
+    uint64_t nb = (n_max + 3) / 4;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_dm_verify, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
     return hipGetLastError();
 }
 

@@ -109,16 +109,21 @@ struct crass_hip_ctx {
     } cand;
     // fast path: the found records are gathered on the device into dense arrays and land in pinned
     // host memory already in the hand-off layout (no per-record host work)
-    struct P1Dense {
+    mutable struct P1Dense {
         DevBuf<uint64_t> d_read, d_ss_off; DevBuf<uint8_t> d_low; DevBuf<uint32_t> d_replen, d_nss, d_ss; DevBuf<uint16_t> d_dr_len; DevBuf<char> d_dr;
         uint64_t n = 0;
         bool active = false;
         // the used part of the arrays above, packed on the device (p1_blob_layout) and copied with one call
-        DevBuf<uint8_t> d_blob; PinBuf<uint8_t> h_blob;
+        PinBuf<uint8_t> h_blob;
         P1Blob lay{};
+        uint64_t pack_cap = 0; uint32_t pack_ss_cap = 0;
+        // the ABI's wide per-candidate arrays (crass_candidates), widened from the compact blob on first request
+        bool wide_ready = false;
+        std::vector<uint32_t> w_replen, w_nss, w_ss; std::vector<uint64_t> w_ss_off; std::vector<uint16_t> w_dr_len; std::vector<char> w_dr;
+        PinBuf<char> h_dr_fb; PinBuf<uint16_t> h_dr_len_fb; bool dr_fallback = false;    // candidates' own strings (no distinct list)
         void release()
         {
-            d_blob.release(); h_blob.release();
+            h_blob.release(); h_dr_fb.release(); h_dr_len_fb.release();
             d_read.release(); d_ss_off.release(); d_low.release(); d_replen.release(); d_nss.release(); d_ss.release(); d_dr_len.release(); d_dr.release();
         }
     } dense;
@@ -134,18 +139,23 @@ struct crass_hip_ctx {
     PinBuf<uint32_t> h_dmap; PinBuf<char> h_dx_chars; PinBuf<uint16_t> h_dx_len; PinBuf<uint64_t> h_dx_hash;
     uint64_t n_dx = 0;
     bool have_dev_tokens = false;
+    uint64_t surv_cap_hint = 0;               // speculative survivor bound for the next seed scan (0: none yet)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gathered = nullptr;
     mutable bool bulk_pending = false;          // copy in flight on copy_stream
     mutable bool bulk_needed = false;           // copy not issued yet (it is issued behind the merge's kernel launches)
+    // The per-candidate records go to pinned host memory on the copy stream: the pack kernel writes them there
+    // itself (PCIe-bound, ~2 MB per 10 M reads).  It is launched right behind the pass-2 filter — a long,
+    // compute-bound kernel next to which the transfer is free — or at the latest when somebody asks for the records.
     void issue_bulk() const
     {
         if (!bulk_needed) return;
         bulk_needed = false;
-        if (dense.lay.total) {
-            (void)hipMemcpyAsync(dense.h_blob.p, dense.d_blob.p, dense.lay.total, hipMemcpyDeviceToHost, copy_stream);
-            bulk_pending = true;
-        }
+        const P1Dense &D = dense;
+        (void)hipStreamWaitEvent(copy_stream, ev_gathered, 0);
+        (void)launch_pack_p1_blob(d_count.p + 2, D.pack_cap, D.pack_ss_cap, D.d_read.p, D.d_replen.p, D.d_nss.p, D.d_low.p, D.d_ss.p,
+                                  D.h_blob.p, copy_stream);
+        bulk_pending = true;
     }
     void wait_bulk() const
     {
@@ -181,8 +191,9 @@ struct crass_hip_ctx {
     // distinct candidate strings (multi-GPU exchange)
     std::vector<char> dx_chars; std::vector<uint16_t> dx_len; std::vector<uint32_t> dx_map; bool have_distinct = false;
     uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
-    const char *cand_dr() const { wait_bulk(); return dense.active ? (const char *)(dense.h_blob.p + dense.lay.dr) : cand.dr.data(); }
-    const uint16_t *cand_dr_len() const { wait_bulk(); return dense.active ? (const uint16_t *)(dense.h_blob.p + dense.lay.dr_len) : cand.dr_len.data(); }
+    void widen_p1() const;
+    const char *cand_dr() const { if (dense.active) { widen_p1(); return dense.w_dr.data(); } return cand.dr.data(); }
+    const uint16_t *cand_dr_len() const { if (dense.active) { widen_p1(); return dense.w_dr_len.data(); } return cand.dr_len.data(); }
     uint32_t dr_stride = 48;
     // merge
     MergeResult merge;
@@ -192,11 +203,40 @@ struct crass_hip_ctx {
     std::vector<uint64_t> q_read; std::vector<uint8_t> q_low; std::vector<uint32_t> q_start, q_end, q_token;
     std::vector<uint16_t> q_dr_len; std::vector<char> q_dr;
     // ... or, when the sink ran on the device, one pinned blob (p2_blob_layout)
-    DevBuf<uint8_t> d_qblob; PinBuf<uint8_t> h_qblob; P2Blob q_lay{}; uint64_t q_n = 0; bool q_blob_active = false;
+    PinBuf<uint8_t> h_qblob; P2Blob q_lay{}; uint64_t q_n = 0; bool q_blob_active = false, q_wide_ready = false;
 
     crass_counters cnt{};
     hipEvent_t ev[12]{};
 };
+
+// crass_candidates' arrays from the compact hand-off blob (and the distinct-string list for the DR strings)
+void crass_hip_ctx::widen_p1() const
+{
+    P1Dense &D = dense;
+    if (D.wide_ready) return;
+    wait_bulk();
+    const uint64_t n = D.n;
+    const uint32_t ss_cap = D.pack_ss_cap, stride = dr_stride;
+    const uint8_t *hb = D.h_blob.p;
+    const uint16_t *b_replen = (const uint16_t *)(hb + D.lay.replen), *b_ss = (const uint16_t *)(hb + D.lay.ss);
+    const uint8_t *b_nss = hb + D.lay.nss;
+    D.w_replen.resize(n); D.w_nss.resize(n); D.w_ss_off.resize(n); D.w_ss.resize(n * (size_t)ss_cap);
+    D.w_dr_len.resize(n); D.w_dr.resize(n * (size_t)stride);
+    for (uint64_t k = 0; k < n; k++) { D.w_replen[k] = b_replen[k]; D.w_nss[k] = b_nss[k]; D.w_ss_off[k] = k * (uint64_t)ss_cap; }
+    for (uint64_t i = 0; i < n * (uint64_t)ss_cap; i++) D.w_ss[i] = b_ss[i];
+    if (D.dr_fallback) {
+        (void)hipStreamSynchronize(copy_stream);
+        memcpy(D.w_dr.data(), D.h_dr_fb.p, n * (size_t)stride);
+        memcpy(D.w_dr_len.data(), D.h_dr_len_fb.p, n * 2);
+    } else {
+        for (uint64_t k = 0; k < n; k++) {
+            const uint32_t j = h_dmap.p[k];
+            memcpy(D.w_dr.data() + k * (size_t)stride, h_dx_chars.p + j * (size_t)stride, stride);
+            D.w_dr_len[k] = h_dx_len.p[j];
+        }
+    }
+    D.wide_ready = true;
+}
 
 #define HIPCHK(ctx, call)                                                       \
     do {                                                                        \
@@ -279,7 +319,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    c->dm.release(); c->d_qblob.release(); c->h_qblob.release();
+    c->dm.release(); c->h_qblob.release();
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
     if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
@@ -514,8 +554,12 @@ static const uint64_t kDenseMaxSurvivors = 1ull << 26;
 
 // Fast path of the pass-1 sink: one chunk, fixed start/stop slots, no exception reads.  Returns
 // CRASS_ERR_STATE when it does not apply (the caller then uses the host-loop path).
-static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
+// n_surv: number of filter survivors, or (speculative mode: d_nsurv = the compaction's device-side count, no host
+// round trip before this call) an upper bound for it.  The exact count then arrives with the final copy of
+// the counters; *overflow is set when it exceeds the bound (nothing of this call is valid then).
+static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t *d_nsurv, bool *overflow)
 {
+    *overflow = false;
     const SurvLds lds = survivor_lds_layout(c->max_len, c->dp);
     if (lds.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
     const uint32_t stride = c->dr_stride;
@@ -538,15 +582,15 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
     const uint32_t *hints = c->hints_valid ? c->d_hit_info.p : nullptr;
     const bool no_lanes = getenv("CRASS_NO_LANE_KERNEL") != nullptr;
     hipError_t le = no_lanes ? hipErrorNotSupported
-                             : launch_survivor_lanes(c->R, c->dp, c->d_idx.p, c->d_count.p + 1, n_surv, c->d_surv.p, c->d_dr.p, stride,
+                             : launch_survivor_lanes(c->R, c->dp, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
                                                      c->d_ss_pool.p, lds.ss_cap, c->d_found.p, hints, c->stream);
     if (le != hipSuccess && le != hipErrorNotSupported) { c->last_hip = (int)le; return CRASS_ERR_HIP; }
-    HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, c->d_count.p + 1, n_surv, c->d_surv.p, c->d_dr.p, stride,
+    HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
                               c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, hints, lds,
                               (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, le == hipSuccess));
     HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
     const uint64_t n_words = (n_surv + 63) / 64;
-    HIPCHK(c, launch_found_mask(c->d_surv.p, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream));
+    HIPCHK(c, launch_found_mask(c->d_surv.p, d_nsurv, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream));
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n_surv, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, n_surv, c->d_count.p + 2, c->stream));
     HIPCHK(c, launch_gather_found(c->d_fidx.p, c->d_count.p + 2, n_surv, c->d_surv.p, c->d_idx.p, c->read_base, c->d_dr.p, stride,
                                   c->d_ss_pool.p, lds.ss_cap, D.d_read.p, D.d_low.p, D.d_replen.p, D.d_nss.p, D.d_ss_off.p,
@@ -571,30 +615,43 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv)
                                    c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
                                    c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 32, hipMemcpyDeviceToHost, c->stream));
     {
-        const uint64_t cap = p1_blob_layout(n_surv, stride, lds.ss_cap).total + 64;
-        HIPCHK(c, D.d_blob.ensure(cap)); HIPCHK(c, D.h_blob.ensure(cap));
-        HIPCHK(c, launch_pack_p1_blob(c->d_count.p + 2, n_surv, stride, lds.ss_cap, D.d_read.p, D.d_ss_off.p, D.d_replen.p, D.d_nss.p,
-                                      D.d_dr_len.p, D.d_low.p, D.d_dr.p, D.d_ss.p, D.d_blob.p, c->stream));
+        // the per-candidate records go to pinned host memory on the copy stream (the pack kernel writes them there
+        // itself), behind the gather: they are not needed before the hand-off
+        const uint64_t cap = p1_blob_layout(n_surv, lds.ss_cap).total + 64;
+        D.wide_ready = false; D.dr_fallback = false;
+        HIPCHK(c, D.h_blob.ensure(cap));
+        HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
+        D.pack_cap = n_surv; D.pack_ss_cap = lds.ss_cap;
+        c->bulk_needed = true;                          // launched by issue_bulk(): next to the pass-2 filter, where it is free
     }
     host_pool_warm();                                   // the merge follows: wake the host workers while the device finishes
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_count.p[0] > n_surv) { *overflow = true; return CRASS_OK; }
     const uint64_t nf = c->h_count.p[2];
     const uint32_t err = c->h_count.p[3];
     if (err == 1) return CRASS_ERR_SEARCH_FATAL;
     if (err) return CRASS_ERR_OVERFLOW;
-    D.lay = p1_blob_layout(nf, stride, lds.ss_cap);
+    D.lay = p1_blob_layout(nf, lds.ss_cap);
+    if (nf && !dedupe) {                                // no distinct list: the candidates' own strings travel
+        HIPCHK(c, D.h_dr_fb.ensure(nf * stride + 16)); HIPCHK(c, D.h_dr_len_fb.ensure(nf + 8));
+        HIPCHK(c, hipMemcpyAsync(D.h_dr_fb.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(c, hipMemcpyAsync(D.h_dr_len_fb.p, D.d_dr_len.p, nf * 2, hipMemcpyDeviceToHost, c->copy_stream));
+        D.dr_fallback = true;
+        c->bulk_pending = true;
+    }
     if (nf) {
-        // the per-candidate records leave in ONE copy on the copy stream, issued behind the merge's launches
-        // (issue_bulk) so that the host's call overhead stays off the critical path
-        c->bulk_needed = true;
         if (dedupe) {
             if (c->h_count.p[5] == 0) {
                 c->n_dx = c->h_count.p[4];
                 c->have_dev_tokens = true;
             } else {
                 // (hash collision among the candidates: the host merge wants the first-occurrence map)
+                HIPCHK(c, D.h_dr_fb.ensure(nf * stride + 16)); HIPCHK(c, D.h_dr_len_fb.ensure(nf + 8));
+                HIPCHK(c, hipMemcpyAsync(D.h_dr_fb.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, c->copy_stream));
+                HIPCHK(c, hipMemcpyAsync(D.h_dr_len_fb.p, D.d_dr_len.p, nf * 2, hipMemcpyDeviceToHost, c->copy_stream));
+                D.dr_fallback = true;
                 HIPCHK(c, hipMemcpyAsync(c->h_rep.p, c->dd_rep.p, nf * 4, hipMemcpyDeviceToHost, c->copy_stream));
                 HIPCHK(c, hipMemcpyAsync(c->h_hash.p, c->dd_hash.p, nf * 8, hipMemcpyDeviceToHost, c->copy_stream));
                 c->bulk_pending = true;
@@ -638,26 +695,57 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     // step 2: ordered compaction
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint64_t n_surv = c->h_count.p[0];
     c->dense.active = false;
     c->have_rep = false;
     c->have_dev_tokens = false;
     c->have_distinct = false;
-    const bool try_dense = use_filter && c->R.n_exc == 0 && n_surv > 0 && n_surv <= kDenseMaxSurvivors;
+    c->cand.clear();
+    const double t_sink0 = now_ms();
+    uint64_t n_surv = 0;
+    int s = CRASS_ERR_STATE;
+    // Speculative fast path: the survivor stage is launched right behind the compaction with the survivor
+    // count still on the device, sized by a bound learnt from the previous call (twice its count).  If the
+    // bound turns out too small the stage is simply redone below with the exact count.
+    if (use_filter && c->R.n_exc == 0 && c->surv_cap_hint && !getenv("CRASS_NO_SPECULATION")) {
+        bool overflow = false;
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        s = run_survivors_dense(c, c->surv_cap_hint, c->d_count.p, &overflow);
+        if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
+        if (s == CRASS_OK) {
+            n_surv = c->h_count.p[0];
+            if (overflow || n_surv == 0) {              // redo below with the exact count; undo the attempt's found flags
+                c->dense.active = false;
+                s = CRASS_ERR_STATE;
+                HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
+            }
+        } else {                                        // nothing was launched (layout limits): plain path
+            HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            n_surv = c->h_count.p[0];
+        }
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        n_surv = c->h_count.p[0];
+    }
+    const bool spec_done = (s == CRASS_OK);
+    const bool try_dense = !spec_done && use_filter && c->R.n_exc == 0 && n_surv > 0 && n_surv <= kDenseMaxSurvivors;
     std::vector<uint64_t> surv_idx;
-    // the survivor kernel reads its count from d_count[1] (chunk-local bound is passed separately)
-    {
+    if (!spec_done) {
+        // the survivor kernel reads its count from d_count[1] (chunk-local bound is passed separately)
         uint32_t big = 0xFFFFFFFFu;
         c->h_count.p[1] = big;
         HIPCHK(c, hipMemcpyAsync(c->d_count.p + 1, c->h_count.p + 1, 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        bool overflow = false;
+        s = try_dense ? run_survivors_dense(c, n_surv, c->d_count.p + 1, &overflow) : CRASS_ERR_STATE;
+        if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
     }
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    const double t_sink0 = now_ms();
-    c->cand.clear();
-    int s = try_dense ? run_survivors_dense(c, n_surv) : CRASS_ERR_STATE;
-    if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
+    if (use_filter && c->R.n_exc == 0) {                // bound for the next call: twice this call's count
+        uint64_t hint = 65536;
+        while (hint < 2 * n_surv) hint <<= 1;
+        c->surv_cap_hint = std::min<uint64_t>(hint, kDenseMaxSurvivors);
+    }
     if (s == CRASS_ERR_STATE) {
         // host-loop path: label records with their read index from a host copy of the survivor list
         surv_idx.resize(n_surv);
@@ -727,10 +815,11 @@ int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
     c->wait_bulk();
     if (c->dense.active) {
         const crass_hip_ctx::P1Dense &D = c->dense;
+        c->widen_p1();
         const uint8_t *hb = D.h_blob.p;
-        o->n = D.n; o->read_idx = (const uint64_t *)(hb + D.lay.read); o->low_lexi = hb + D.lay.low; o->repeat_len = (const uint32_t *)(hb + D.lay.replen);
-        o->n_ss = (const uint32_t *)(hb + D.lay.nss); o->ss_off = (const uint64_t *)(hb + D.lay.ss_off); o->ss_pool = (const uint32_t *)(hb + D.lay.ss);
-        o->dr_stride = c->dr_stride; o->dr_len = (const uint16_t *)(hb + D.lay.dr_len); o->dr_chars = (const char *)(hb + D.lay.dr);
+        o->n = D.n; o->read_idx = (const uint64_t *)(hb + D.lay.read); o->low_lexi = hb + D.lay.low; o->repeat_len = D.w_replen.data();
+        o->n_ss = D.w_nss.data(); o->ss_off = D.w_ss_off.data(); o->ss_pool = D.w_ss.data();
+        o->dr_stride = c->dr_stride; o->dr_len = D.w_dr_len.data(); o->dr_chars = D.w_dr.data();
     } else {
         o->n = c->cand.size();
         o->read_idx = c->cand.read.data(); o->low_lexi = c->cand.low.data(); o->repeat_len = c->cand.replen.data();
@@ -867,17 +956,16 @@ static int device_merge(crass_hip_ctx *c)
     M.rset_fill = d.rset_u32.p + ((size_t)2 << M.rset_log); M.rd_slot = d.rd_slot.p; M.rents = d.rents.p;
     M.anchor_tab = d.anchor_tab.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
     d.M = M;
+    const double tl0 = now_ms();
     HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
     HIPCHK(c, launch_device_merge(M, c->stream));
     HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
+    if (getenv("CRASS_MERGE_PROFILE")) fprintf(stderr, "[crass_dm] host: launching the merge kernels took %.3f ms\n", now_ms() - tl0);
     if (getenv("CRASS_DM_INJECT_FAIL"))                           // tests: exercise the fall-back to the host merge
         HIPCHK(c, hipMemsetAsync(&d.st.p->fail, 1, 4, c->stream));
     // the per-token results the host view is rebuilt from (a few 10 KB)
-    HIPCHK(c, hipMemcpyAsync(d.h_st.p, d.st.p, sizeof(DevMergeState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d.h_gid.p, d.gid_of.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d.h_blank.p, d.blank.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, launch_dm_export(M, d.h_st.p, d.h_gid.p, d.h_blank.p, c->stream));
     HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
-    c->issue_bulk();                                              // the per-candidate records follow on the copy stream
     d.active = true; d.host_built = false; d.n_cand = c->dense.n;
     c->have_merge = true; c->have_pass2 = false;
     c->have_patterns = true; c->have_anchors = false; c->have_pat_token = false;
@@ -1102,6 +1190,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     if (dmp) {
         HIPCHK(c, launch_anchor_filter_dev(c->R, c->dm.M, c->d_found.p, c->d_mask.p, c->stream));
         anchors = true;
+        c->issue_bulk();
     } else if (c->have_anchors) {
         hipError_t ae = launch_anchor_filter(c->R, c->K, c->d_found.p, c->d_mask.p, c->stream);
         if (ae == hipSuccess) anchors = true;
@@ -1153,13 +1242,13 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const bool dev_sink = dmp && c->R.n_exc == 0;
     c->q_blob_active = false;
     if (dev_sink) {
-        c->q_lay = p2_blob_layout(n_hits, c->dr_stride);
-        HIPCHK(c, c->d_qblob.ensure(c->q_lay.total + 64)); HIPCHK(c, c->h_qblob.ensure(c->q_lay.total + 64));
+        c->q_lay = p2_blob_layout(n_hits);
+        c->q_wide_ready = false;
+        HIPCHK(c, c->h_qblob.ensure(c->q_lay.total + 64));
         HIPCHK(c, c->d_fidx.ensure(n_hits + 1));
         if (n_hits) {
-            HIPCHK(c, launch_pack_p2_blob(c->d_rec.p, c->d_dr.p, c->dr_stride, c->d_idx.p, c->read_base, c->d_count.p, n_hits, c->d_mask.p,
-                                          c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 6, c->d_qblob.p, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_qblob.p, c->d_qblob.p, c->q_lay.total, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, launch_pack_p2_blob(c->d_rec.p, c->d_idx.p, c->read_base, c->d_count.p, n_hits, c->d_mask.p,
+                                          c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 6, c->h_qblob.p, c->stream));
         } else memset(c->h_qblob.p, 0, 16);
         const double th0 = now_ms();
         const int hs = ensure_host_merge(c);            // host view of the merge, rebuilt while the device verifies
@@ -1255,13 +1344,25 @@ int crass_hip_get_recruits(const crass_hip_ctx *c, crass_recruits *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     if (!c->have_pass2) return CRASS_ERR_STATE;
-    if (c->q_blob_active) {
+    if (c->q_blob_active && !c->q_wide_ready) {
+        // crass_recruits' arrays from the compact blob; the DR string of a recruit is its token's string
+        crass_hip_ctx *mc = const_cast<crass_hip_ctx *>(c);
         const uint8_t *hb = c->h_qblob.p;
         const P2Blob &b = c->q_lay;
-        o->n = c->q_n; o->read_idx = (const uint64_t *)(hb + b.read); o->low_lexi = hb + b.low; o->start = (const uint32_t *)(hb + b.start);
-        o->end = (const uint32_t *)(hb + b.end); o->dr_stride = c->dr_stride; o->dr_len = (const uint16_t *)(hb + b.dr_len);
-        o->dr_chars = (const char *)(hb + b.dr); o->token = (const uint32_t *)(hb + b.token);
-        return CRASS_OK;
+        const uint64_t n = c->q_n;
+        const uint64_t *b_read = (const uint64_t *)(hb + b.read);
+        const uint32_t *b_tok = (const uint32_t *)(hb + b.token);
+        const uint16_t *b_start = (const uint16_t *)(hb + b.start), *b_end = (const uint16_t *)(hb + b.end);
+        mc->q_read.assign(b_read, b_read + n); mc->q_token.assign(b_tok, b_tok + n);
+        mc->q_low.assign(hb + b.low, hb + b.low + n);
+        mc->q_start.resize(n); mc->q_end.resize(n); mc->q_dr_len.resize(n); mc->q_dr.assign(n * (size_t)c->dr_stride, 0);
+        for (uint64_t k = 0; k < n; k++) {
+            mc->q_start[k] = b_start[k]; mc->q_end[k] = b_end[k]; mc->q_dr_len[k] = (hb + b.dr_len)[k];
+            const uint32_t t = b_tok[k];
+            if (t >= 2 && t - 2 < c->merge.tokens.size())
+                memcpy(mc->q_dr.data() + k * (size_t)c->dr_stride, c->merge.tokens.strings.data(t - 2), c->merge.tokens.strings.len(t - 2));
+        }
+        mc->q_wide_ready = true;
     }
     o->n = c->q_read.size(); o->read_idx = c->q_read.data(); o->low_lexi = c->q_low.data();
     o->start = c->q_start.data(); o->end = c->q_end.data(); o->dr_stride = c->dr_stride;

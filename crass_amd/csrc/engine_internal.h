@@ -135,6 +135,7 @@ struct DevMerge {
 };
 
 hipError_t launch_device_merge(const DevMerge &M, hipStream_t st);
+hipError_t launch_dm_export(const DevMerge &M, DevMergeState *h_st, uint32_t *h_gid, uint8_t *h_blank, hipStream_t st);
 // pass-2 anchor filter with table parameters read from the device (M.st); flags nothing when M.st->fail
 hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st);
 hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
@@ -186,42 +187,42 @@ hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off,
                                     int32_t *dist, float *sim, uint32_t max_len, hipStream_t st);
 hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st);
 
-hipError_t launch_found_mask(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st);
+hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st);
 hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out,
                                const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
                                const uint32_t *ss_pool, uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
                                uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr, uint32_t *g_ss, hipStream_t st);
-// pass-1 hand-off blob: the used part (nf records) of the dense arrays, packed back to back so that ONE
-// copy moves them to the host.  The layout is a function of nf, evaluated on the device (the count lives
-// there) and again on the host once it knows nf.
-struct P1Blob { uint64_t read, ss_off, replen, nss, dr_len, low, dr, ss, total; };
-__host__ __device__ inline P1Blob p1_blob_layout(uint64_t nf, uint32_t stride, uint32_t ss_cap)
+// pass-1 hand-off blob: what the host needs of the nf found records, compact and packed back to back so that
+// it crosses PCIe once: read index, repeat length, start/stop count and list (read positions fit 16 bits:
+// CRASS_HIP_MAX_READ_LEN < 65536), orientation flag.  The DR string of candidate k is the distinct string
+// cand_distinct[k], which the host already has.  The layout is a function of nf, evaluated on the device (the
+// count lives there) and again on the host once it knows nf.
+struct P1Blob { uint64_t read, replen, nss, low, ss, total; };
+__host__ __device__ inline P1Blob p1_blob_layout(uint64_t nf, uint32_t ss_cap)
 {
     P1Blob b;
     uint64_t at = 0;
     auto sec = [&](uint64_t bytes) { const uint64_t o = at; at += (bytes + 15u) & ~15ull; return o; };
-    b.read = sec(nf * 8); b.ss_off = sec(nf * 8); b.replen = sec(nf * 4); b.nss = sec(nf * 4); b.dr_len = sec(nf * 2);
-    b.low = sec(nf); b.dr = sec(nf * stride); b.ss = sec(nf * (uint64_t)ss_cap * 4);
+    b.read = sec(nf * 8); b.replen = sec(nf * 2); b.nss = sec(nf); b.low = sec(nf); b.ss = sec(nf * (uint64_t)ss_cap * 2);
     b.total = at;
     return b;
 }
-hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t stride, uint32_t ss_cap, const uint64_t *g_read,
-                               const uint64_t *g_ss_off, const uint32_t *g_replen, const uint32_t *g_nss, const uint16_t *g_dr_len,
-                               const uint8_t *g_low, const char *g_dr, const uint32_t *g_ss, uint8_t *blob, hipStream_t st);
-// pass-2 hand-off blob: header (record count, 16 bytes) + dense arrays with `cap` slots each
-struct P2Blob { uint64_t read, start, end, token, dr_len, low, dr, total; };
-__host__ __device__ inline P2Blob p2_blob_layout(uint64_t cap, uint32_t stride)
+hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t ss_cap, const uint64_t *g_read, const uint32_t *g_replen,
+                               const uint32_t *g_nss, const uint8_t *g_low, const uint32_t *g_ss, uint8_t *blob, hipStream_t st);
+// pass-2 hand-off blob: header (record count, 16 bytes) + compact arrays with `cap` slots each; the DR string of a
+// recruit is its token's string
+struct P2Blob { uint64_t read, token, start, end, dr_len, low, total; };
+__host__ __device__ inline P2Blob p2_blob_layout(uint64_t cap)
 {
     P2Blob b;
     uint64_t at = 16;
     auto sec = [&](uint64_t bytes) { const uint64_t o = at; at += (bytes + 15u) & ~15ull; return o; };
-    b.read = sec(cap * 8); b.start = sec(cap * 4); b.end = sec(cap * 4); b.token = sec(cap * 4); b.dr_len = sec(cap * 2);
-    b.low = sec(cap); b.dr = sec(cap * stride);
+    b.read = sec(cap * 8); b.token = sec(cap * 4); b.start = sec(cap * 2); b.end = sec(cap * 2); b.dr_len = sec(cap); b.low = sec(cap);
     b.total = at;
     return b;
 }
-// valid hits (dr_len != 0) of the finish kernel's slots -> compacted, read-ordered dense arrays in `blob`
-hipError_t launch_pack_p2_blob(const RecruitOut *rec, const char *dr, uint32_t stride, const uint64_t *hit_idx, uint64_t read_base,
+// valid hits (dr_len != 0) of the finish kernel's slots -> compacted, read-ordered compact arrays in `blob`
+hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base,
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
                                uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st);
 hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, const uint32_t *rep,

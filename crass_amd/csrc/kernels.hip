@@ -1372,11 +1372,11 @@ hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const ui
 
 // ---- device-side gather of the found records (fast path: short reads, slot-mode pool) ----
 // mask of slots with found != 0; the worst error code is max-reduced into *d_err
-__global__ __launch_bounds__(256) void k_found_mask(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err)
+__global__ __launch_bounds__(256) void k_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err)
 {
     const uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     bool f = false;
-    if (s < n) {
+    if (s < n && s < (uint64_t)*d_n) {                  // slots past the device-side count were never written
         const SurvOut o = out[s];
         f = o.found != 0;
         if (o.err) atomicMax(d_err, (uint32_t)o.err);
@@ -1413,44 +1413,65 @@ __global__ __launch_bounds__(256) void k_gather_found(const uint64_t *fidx, cons
     for (uint32_t i = 0; i < ss_cap; i++) pd[i] = (i < o.n_ss) ? ps[i] : 0u;
 }
 
-// used parts of the dense arrays -> one contiguous blob (p1_blob_layout), 16 bytes per thread and step
-__global__ __launch_bounds__(256) void k_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t stride, uint32_t ss_cap,
-                                                       const uint64_t *g_read, const uint64_t *g_ss_off, const uint32_t *g_replen,
-                                                       const uint32_t *g_nss, const uint16_t *g_dr_len, const uint8_t *g_low,
-                                                       const char *g_dr, const uint32_t *g_ss, uint8_t *blob)
+// found records -> compact blob (p1_blob_layout) in pinned host memory: the kernel IS the device-to-host copy
+__global__ __launch_bounds__(256) void k_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t ss_cap, const uint64_t *g_read,
+                                                       const uint32_t *g_replen, const uint32_t *g_nss, const uint8_t *g_low,
+                                                       const uint32_t *g_ss, uint8_t *blob)
 {
     uint64_t nf = *d_nf;
     if (nf > n_max) nf = n_max;
-    const P1Blob b = p1_blob_layout(nf, stride, ss_cap);
-    const uint64_t off[9] = {b.read, b.ss_off, b.replen, b.nss, b.dr_len, b.low, b.dr, b.ss, b.total};
-    const void *src[8] = {g_read, g_ss_off, g_replen, g_nss, g_dr_len, g_low, g_dr, g_ss};
+    const P1Blob b = p1_blob_layout(nf, ss_cap);
     const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    // 16 bytes per thread and step in every section
+    uint4 *d_read = reinterpret_cast<uint4 *>(blob + b.read);
+    const uint4 *s_read = reinterpret_cast<const uint4 *>(g_read);
+    for (uint64_t i = tid; i < (nf + 1) / 2; i += nth) d_read[i] = s_read[i];
+    uint4 *d_rl = reinterpret_cast<uint4 *>(blob + b.replen);
+    for (uint64_t i = tid; i < (nf + 7) / 8; i += nth) {
+        uint32_t v[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(src[k]);
-        uint4 *d4 = reinterpret_cast<uint4 *>(blob + off[k]);
-        const uint64_t n16 = (off[k + 1] - off[k]) / 16;
-        for (uint64_t i = tid; i < n16; i += nth) d4[i] = s4[i];
+        for (int q = 0; q < 8; q++) v[q] = (i * 8 + q < nf) ? g_replen[i * 8 + q] : 0u;
+        uint4 o; o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
+        d_rl[i] = o;
+    }
+    uint4 *d_ns = reinterpret_cast<uint4 *>(blob + b.nss);
+    for (uint64_t i = tid; i < (nf + 15) / 16; i += nth) {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const uint32_t v = (i * 16 + q < nf) ? g_nss[i * 16 + q] : 0u; w[q >> 2] |= (v & 0xFFu) << (8 * (q & 3)); }
+        uint4 o; o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+        d_ns[i] = o;
+    }
+    uint4 *d_low = reinterpret_cast<uint4 *>(blob + b.low);
+    const uint4 *s_low = reinterpret_cast<const uint4 *>(g_low);
+    for (uint64_t i = tid; i < (nf + 15) / 16; i += nth) d_low[i] = s_low[i];
+    uint4 *d_ss = reinterpret_cast<uint4 *>(blob + b.ss);
+    const uint64_t n_ss16 = (nf * ss_cap + 7) / 8;          // 8 entries (16 bytes) per step
+    for (uint64_t i = tid; i < n_ss16; i += nth) {
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = (i * 8 + q < nf * ss_cap) ? g_ss[i * 8 + q] : 0u;
+        uint4 o; o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
+        d_ss[i] = o;
     }
 }
 
-hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t stride, uint32_t ss_cap, const uint64_t *g_read,
-                               const uint64_t *g_ss_off, const uint32_t *g_replen, const uint32_t *g_nss, const uint16_t *g_dr_len,
-                               const uint8_t *g_low, const char *g_dr, const uint32_t *g_ss, uint8_t *blob, hipStream_t st)
+hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t ss_cap, const uint64_t *g_read, const uint32_t *g_replen,
+                               const uint32_t *g_nss, const uint8_t *g_low, const uint32_t *g_ss, uint8_t *blob, hipStream_t st)
 {
     if (n_max == 0) return hipSuccess;
-    const uint64_t total16 = p1_blob_layout(n_max, stride, ss_cap).total / 16;
-    unsigned nb = (unsigned)std::min<uint64_t>((total16 + 255) / 256, 2048);
+    // PCIe-bound: a modest grid keeps enough stores in flight without occupying the chip
+    const uint64_t total16 = p1_blob_layout(n_max, ss_cap).total / 16;
+    unsigned nb = (unsigned)std::min<uint64_t>((total16 + 255) / 256, 256);
     if (nb == 0) nb = 1;
-    hipLaunchKernelGGL(k_pack_p1_blob, dim3(nb), dim3(256), 0, st, d_nf, n_max, stride, ss_cap, g_read, g_ss_off, g_replen, g_nss, g_dr_len,
-                       g_low, g_dr, g_ss, blob);
+    hipLaunchKernelGGL(k_pack_p1_blob, dim3(nb), dim3(256), 0, st, d_nf, n_max, ss_cap, g_read, g_replen, g_nss, g_low, g_ss, blob);
     return hipGetLastError();
 }
 
-hipError_t launch_found_mask(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st)
+hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_found_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, mask, d_err);
+    hipLaunchKernelGGL(k_found_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, d_n, n, mask, d_err);
     return hipGetLastError();
 }
 
@@ -2081,28 +2102,25 @@ __global__ __launch_bounds__(256) void k_recruit_valid_mask(const RecruitOut *re
     const uint64_t m = __ballot(v);
     if ((threadIdx.x & 63) == 0 && k < n_max) mask[k >> 6] = m;
 }
-__global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, const char *dr, uint32_t stride, const uint64_t *hit_idx,
-                                                       uint64_t read_base, const uint64_t *vidx, const uint32_t *d_nv, uint64_t cap, uint8_t *blob)
+__global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base, const uint64_t *vidx,
+                                                       const uint32_t *d_nv, uint64_t cap, uint8_t *blob)
 {
     const uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t nv = *d_nv;
     if (nv > cap) nv = cap;
     if (q == 0) { reinterpret_cast<uint64_t *>(blob)[0] = nv; reinterpret_cast<uint64_t *>(blob)[1] = cap; }
     if (q >= nv) return;
-    const P2Blob b = p2_blob_layout(cap, stride);
+    const P2Blob b = p2_blob_layout(cap);
     const uint64_t k = vidx[q];
     const RecruitOut o = rec[k];
     reinterpret_cast<uint64_t *>(blob + b.read)[q] = read_base + hit_idx[k];
-    reinterpret_cast<uint32_t *>(blob + b.start)[q] = o.start;
-    reinterpret_cast<uint32_t *>(blob + b.end)[q] = o.end;
     reinterpret_cast<uint32_t *>(blob + b.token)[q] = o.token;
-    reinterpret_cast<uint16_t *>(blob + b.dr_len)[q] = o.dr_len;
+    reinterpret_cast<uint16_t *>(blob + b.start)[q] = (uint16_t)o.start;
+    reinterpret_cast<uint16_t *>(blob + b.end)[q] = (uint16_t)o.end;
+    (blob + b.dr_len)[q] = (uint8_t)o.dr_len;
     (blob + b.low)[q] = o.low_lexi;
-    const uint4 *src = reinterpret_cast<const uint4 *>(dr + k * (uint64_t)stride);
-    uint4 *dst = reinterpret_cast<uint4 *>(blob + b.dr + q * (uint64_t)stride);
-    for (uint32_t i = 0; i < stride / 16; i++) dst[i] = src[i];
 }
-hipError_t launch_pack_p2_blob(const RecruitOut *rec, const char *dr, uint32_t stride, const uint64_t *hit_idx, uint64_t read_base,
+hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base,
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
                                uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st)
 {
@@ -2111,7 +2129,7 @@ hipError_t launch_pack_p2_blob(const RecruitOut *rec, const char *dr, uint32_t s
     hipLaunchKernelGGL(k_recruit_valid_mask, dim3(nb), dim3(256), 0, st, rec, d_n_hits, n_hits_max, mask);
     hipError_t e = launch_compact(mask, (n_hits_max + 63) / 64, n_hits_max, word_prefix, block_sums, vidx, n_hits_max, d_nv, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, dr, stride, hit_idx, read_base, vidx, d_nv, n_hits_max, blob);
+    hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob);
     return hipGetLastError();
 }
 

@@ -107,3 +107,24 @@ def test_fallback_to_host_merge(ca):
     finally:
         os.environ.pop("CRASS_DM_INJECT_FAIL", None)
     assert_same_pipeline(got, ref)
+
+
+def test_speculative_survivor_bound_overflow(ca):
+    """the second seed scan of a context launches the survivor stage with a bound learnt from the first
+    (no host round trip); a much larger survivor set must be detected and redone exactly"""
+    small = synth_reads(ca, 20000, read_len=150, n_dr=5, crispr_per_million=10000)
+    big = synth_reads(ca, 200000, read_len=150, n_dr=20, crispr_per_million=600000)
+    eng = ca.SearchEngine()
+    try:
+        a = ca.search_pipeline(small, engine=eng)
+        b = ca.search_pipeline(big, engine=eng)            # > 65536 survivors: over the bound
+        assert b.counters["n_filter_survivors"] > 65536
+        c = ca.search_pipeline(big, engine=eng)            # bound now fits: speculative path
+        d = ca.search_pipeline(small, engine=eng)
+    finally:
+        eng.close()
+    assert_same_pipeline(a, orc.pipeline(small))
+    ref = orc.pipeline(big)
+    assert_same_pipeline(b, ref)
+    assert_same_pipeline(c, ref)
+    assert_same_pipeline(d, orc.pipeline(small))
