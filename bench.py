@@ -94,10 +94,15 @@ def main():
         if world > 1:
             # only the DISTINCT candidate DR strings travel (rank order == read order, so every rank
             # replays the same global token order and builds the same pattern set locally)
-            from crass_amd.distributed import allgather_distinct
-            chars, lens, _ = eng.distinct()
-            g_chars, g_lens, my_off = allgather_distinct(chars, lens, dist, coll_dev)
-            eng.merge_distinct(g_chars, g_lens, my_off, fetch=False)
+            from crass_amd.distributed import allgather_distinct, allgather_distinct_device
+            g = allgather_distinct_device(eng, dist, coll_dev) if args.dist_backend == "nccl" else None
+            if g is not None:                              # RCCL between device buffers; the merge stays on the device
+                g_chars, g_lens, my_off = g
+                eng.merge_distinct_device(g_chars.data_ptr(), g_lens.data_ptr(), g_chars.shape[1], g_chars.shape[0], my_off, fetch=False)
+            else:
+                chars, lens, _ = eng.distinct()
+                g_chars, g_lens, my_off = allgather_distinct(chars, lens, dist, coll_dev)
+                eng.merge_distinct(g_chars, g_lens, my_off, fetch=False)
         else:
             eng.merge(fetch=False)
         eng.recruit(fetch=False)

@@ -62,6 +62,10 @@ class Counters(C.Structure):
         return {f[0]: getattr(self, f[0]) for f in self._fields_}
 
 
+class DistinctDev(C.Structure):
+    _fields_ = [("n_distinct", C.c_uint64), ("dr_stride", C.c_uint32), ("d_chars", C.c_void_p), ("d_len", C.c_void_p)]
+
+
 class Packed(C.Structure):
     _fields_ = [("reads", Reads), ("owner", C.c_void_p)]
 
@@ -93,6 +97,8 @@ SYMBOLS = {
     "crass_hip_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     "crass_hip_get_distinct": (C.c_int, [C.c_void_p, C.POINTER(Distinct)]),
     "crass_hip_merge_distinct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "crass_hip_get_distinct_device": (C.c_int, [C.c_void_p, C.POINTER(DistinctDev)]),
+    "crass_hip_merge_distinct_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "crass_hip_get_merge": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),
     "crass_merge_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
     "crass_merge_get": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),

@@ -176,12 +176,23 @@ struct crass_hip_ctx {
         DevMerge M{};
         bool active = false, host_built = false;
         uint64_t n_cand = 0;
+        // what the host view is rebuilt from: the distinct list (pinned host copy) and every own candidate's index in it
+        const char *hx_chars = nullptr; const uint16_t *hx_len = nullptr; uint64_t n_tok = 0;
+        // multi-rank: the merge runs over the de-duplicated concatenation of every rank's list
+        bool global = false; uint64_t my_off = 0, n_global = 0;
+        DevBuf<char> g_chars, gx_chars; DevBuf<uint16_t> g_len, gx_len; DevBuf<unsigned long long> g_keys;
+        DevBuf<uint32_t> g_first, g_slot, g_rep, g_prefix, g_bsum; DevBuf<uint64_t> g_hash, g_mask, g_idx;
+        PinBuf<uint32_t> h_gmap; PinBuf<char> h_gx_chars; PinBuf<uint16_t> h_gx_len; PinBuf<uint64_t> h_gx_hash;
+        std::vector<uint32_t> cand_map;
         hipEvent_t ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
         void release()
         {
             packed.release(); pat_packed.release(); codes.release(); owner.release(); root_of.release(); tmp.release(); root_rank.release();
             gid_of.release(); grp.release(); members.release(); pat_token.release(); kset_u32.release(); ent_slot.release(); anchor_tab.release();
             blank.release(); sblank.release(); ents.release(); ent_win.release(); rents.release(); rset_u32.release(); rd_slot.release(); rset_key.release(); pat_len.release(); kset_key.release(); st.release(); h_st.release(); h_gid.release(); h_blank.release();
+            g_chars.release(); gx_chars.release(); g_len.release(); gx_len.release(); g_keys.release(); g_first.release(); g_slot.release();
+            g_rep.release(); g_prefix.release(); g_bsum.release(); g_hash.release(); g_mask.release(); g_idx.release();
+            h_gmap.release(); h_gx_chars.release(); h_gx_len.release(); h_gx_hash.release();
             if (ev_done) (void)hipEventDestroy(ev_done);
             if (ev_t0) (void)hipEventDestroy(ev_t0);
             if (ev_t1) (void)hipEventDestroy(ev_t1);
@@ -916,19 +927,22 @@ static bool device_merge_applies(const crass_hip_ctx *c)
 {
     if (getenv("CRASS_HOST_MERGE")) return false;                 // A/B switch: force the host merge (merge.cpp)
     return c->have_pass1 && c->dense.active && c->have_dev_tokens && c->R.n_exc == 0 && c->prm.lowDRsize >= 23 &&
-           c->dr_stride <= 64 && c->n_dx > 0 && c->n_dx <= (1u << 20);
+           c->dr_stride <= 64 && c->n_dx <= (1u << 20);
 }
 
-static int device_merge(crass_hip_ctx *c)
+// dx_*: distinct strings in token order on the device; hx_*: the same list in pinned host memory
+static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const char *hx_chars,
+                        const uint16_t *hx_len)
 {
     crass_hip_ctx::DM &d = c->dm;
-    const uint32_t n = (uint32_t)c->n_dx, stride = c->dr_stride;
+    const uint32_t n = (uint32_t)n_tok, stride = c->dr_stride;
+    d.hx_chars = hx_chars; d.hx_len = hx_len; d.n_tok = n_tok;
     if (!d.ev_done) {
         HIPCHK(c, hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming));
         HIPCHK(c, hipEventCreate(&d.ev_t0)); HIPCHK(c, hipEventCreate(&d.ev_t1));
     }
     DevMerge M{};
-    M.dx_chars = c->dd_dx_chars.p; M.dx_len = c->dd_dx_len.p; M.stride = stride; M.n_tok = n;
+    M.dx_chars = dx_chars; M.dx_len = dx_len; M.stride = stride; M.n_tok = n;
     M.thr = (uint32_t)std::max(c->prm.kmer_clust_size, 2); M.kmax = stride - 10;
     M.kset_log = 10; while ((1ull << M.kset_log) < 32ull * n) M.kset_log++;
     M.tab_log_alloc = 15; while (M.tab_log_alloc < 24 && (1ull << M.tab_log_alloc) < 48ull * n) M.tab_log_alloc++;
@@ -974,10 +988,22 @@ static int device_merge(crass_hip_ctx *c)
 }
 
 // host merge after all (the device path reported a condition it does not handle)
+static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n_global,
+                             uint64_t my_offset, double t0);
+
 static int host_merge_fallback(crass_hip_ctx *c)
 {
     c->dm.active = false;
     const double t0 = now_ms();
+    if (c->dm.global) {
+        // the concatenated list is still on the device (engine-owned copy)
+        crass_hip_ctx::DM &d = c->dm;
+        std::vector<char> gc(d.n_global * (size_t)c->dr_stride);
+        std::vector<uint16_t> gl(d.n_global);
+        HIPCHK(c, hipMemcpy(gc.data(), d.g_chars.p, gc.size(), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(gl.data(), d.g_len.p, gl.size() * 2, hipMemcpyDeviceToHost));
+        return merge_global_host(c, gc.data(), gl.data(), c->dr_stride, d.n_global, d.my_off, t0);
+    }
     if (!merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
                              c->prm.kmer_clust_size))
         merge_candidates(c->merge, c->cand_dr(), c->cand_dr_len(), c->dr_stride, c->n_cand(), c->prm.kmer_clust_size);
@@ -991,7 +1017,13 @@ static int ensure_host_merge(crass_hip_ctx *c)
     if (!d.active || d.host_built) return CRASS_OK;
     HIPCHK(c, hipEventSynchronize(d.ev_done));
     if (d.h_st.p->fail) return CRASS_ERR_STATE;
-    if (!merge_from_device(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->dr_stride, c->n_dx, c->h_dmap.p, d.n_cand, d.h_gid.p, d.h_blank.p,
+    const uint32_t *cmap = c->h_dmap.p;
+    if (d.global) {                                     // own candidate -> own distinct string -> its rank in the global list
+        d.cand_map.resize(d.n_cand);
+        for (uint64_t k = 0; k < d.n_cand; k++) d.cand_map[k] = d.h_gmap.p[d.my_off + c->h_dmap.p[k]];
+        cmap = d.cand_map.data();
+    }
+    if (!merge_from_device(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand, d.h_gid.p, d.h_blank.p,
                            d.h_st.p->n_groups) ||
         c->merge.patterns.size() != d.h_st.p->n_patterns)
         return CRASS_ERR_STATE;
@@ -1013,15 +1045,17 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
     c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
     if (!dr_chars && device_merge_applies(c)) {
         (void)hipSetDevice(c->device);
-        int s = device_merge(c);
+        c->dm.global = false;
+        int s = c->n_dx ? device_merge(c, c->dd_dx_chars.p, c->dd_dx_len.p, c->n_dx, c->h_dx_chars.p, c->h_dx_len.p) : CRASS_ERR_STATE;
+        if (s == CRASS_ERR_STATE) goto host_path;
         if (s == CRASS_OK) {
             c->cnt.used_device_merge = 1;
             c->cnt.ms_merge_host = (float)(now_ms() - t0);
             return CRASS_OK;
         }
-        if (s != CRASS_ERR_HIP) return s;
         return s;
     }
+host_path:
     c->issue_bulk();                                    // per-candidate records: copy stream, overlaps the host merge
     if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens &&
         merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
@@ -1109,24 +1143,120 @@ int crass_hip_get_distinct(crass_hip_ctx *c, crass_distinct *o)
     return CRASS_OK;
 }
 
-int crass_hip_merge_distinct(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
-                             uint64_t n_global, uint64_t my_offset)
+// host merge over the concatenation of every rank's distinct list
+static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n_global,
+                             uint64_t my_offset, double t0)
 {
-    if (!c || (n_global && (!dr_chars || !dr_len || !dr_stride))) return CRASS_ERR_INVALID_ARG;
-    if (!c->have_pass1) return CRASS_ERR_STATE;
-    const double t0 = now_ms();
     ensure_distinct(c);
     const bool dev = c->dense.active && c->have_dev_tokens;
     const uint64_t my_nd = dev ? c->n_dx : c->dx_len.size();
     const uint32_t *my_map = dev ? c->h_dmap.p : c->dx_map.data();
     const size_t my_n = dev ? (size_t)c->dense.n : c->dx_map.size();
     if (my_offset + my_nd > n_global) return CRASS_ERR_INVALID_ARG;
+    c->issue_bulk();
     merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n_global, c->prm.kmer_clust_size);
     // tokens of this context's own candidates through their distinct index
     std::vector<uint32_t> own(my_n);
     for (size_t k = 0; k < own.size(); k++) own[k] = c->merge.cand_token[my_offset + my_map[k]];
     c->merge.cand_token.swap(own);
     return finish_merge(c, t0);
+}
+
+// The same on the device: de-duplicate the concatenation (first occurrence in rank order = global token order,
+// the kernels of the single-GPU pass-1 tail), then the device merge over the global distinct list.  d_chars /
+// d_len are device pointers owned by the engine (dm.g_chars / dm.g_len).  CRASS_ERR_STATE: not applicable,
+// the caller merges on the host.
+static int merge_global_device(crass_hip_ctx *c, uint64_t n_global, uint64_t my_offset)
+{
+    crass_hip_ctx::DM &d = c->dm;
+    const uint32_t stride = c->dr_stride;
+    if (!device_merge_applies(c) || n_global == 0 || n_global > (1u << 22) || my_offset + c->n_dx > n_global) return CRASS_ERR_STATE;
+    const uint32_t n = (uint32_t)n_global;
+    uint32_t tsize = 1024;
+    while (tsize < n * 2) tsize <<= 1;
+    const uint64_t n_words = (n_global + 63) / 64;
+    HIPCHK(c, d.g_keys.ensure(tsize)); HIPCHK(c, d.g_first.ensure(tsize)); HIPCHK(c, d.g_slot.ensure(n)); HIPCHK(c, d.g_rep.ensure(n));
+    HIPCHK(c, d.g_hash.ensure(n)); HIPCHK(c, d.g_mask.ensure(n_words + 1)); HIPCHK(c, d.g_prefix.ensure(n_words + 1));
+    HIPCHK(c, d.g_bsum.ensure((n_words + 255) / 256 + 2)); HIPCHK(c, d.g_idx.ensure(n));
+    HIPCHK(c, d.gx_chars.ensure((size_t)n * stride + 16)); HIPCHK(c, d.gx_len.ensure(n));
+    HIPCHK(c, d.h_gmap.ensure(n)); HIPCHK(c, d.h_gx_chars.ensure((size_t)n * stride + 16)); HIPCHK(c, d.h_gx_len.ensure(n)); HIPCHK(c, d.h_gx_hash.ensure(n));
+    // d_count[7] = n_global, [4] = distinct count, [5] = hash-collision flag
+    c->h_count.p[7] = n;
+    HIPCHK(c, hipMemcpyAsync(c->d_count.p + 7, c->h_count.p + 7, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_count.p + 4, 0, 8, c->stream));
+    HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, c->d_count.p + 7, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p,
+                               d.g_rep.p, c->stream));
+    HIPCHK(c, launch_dx_tokens(d.g_chars.p, d.g_len.p, d.g_hash.p, stride, c->d_count.p + 7, n, d.g_rep.p, d.g_mask.p, d.g_prefix.p, d.g_bsum.p,
+                               d.g_idx.p, c->d_count.p + 4, c->d_count.p + 5, d.h_gmap.p, d.h_gx_chars.p, d.h_gx_len.p, d.h_gx_hash.p,
+                               d.gx_chars.p, d.gx_len.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_count.p + 4, c->d_count.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_count.p[5] != 0 || c->h_count.p[4] == 0 || c->h_count.p[4] > (1u << 20)) return CRASS_ERR_STATE;
+    d.global = true; d.my_off = my_offset; d.n_global = n_global;
+    return device_merge(c, d.gx_chars.p, d.gx_len.p, c->h_count.p[4], d.h_gx_chars.p, d.h_gx_len.p);
+}
+
+int crass_hip_merge_distinct(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
+                             uint64_t n_global, uint64_t my_offset)
+{
+    if (!c || (n_global && (!dr_chars || !dr_len || !dr_stride))) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_pass1) return CRASS_ERR_STATE;
+    const double t0 = now_ms();
+    c->dm.active = false;
+    c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
+    (void)hipSetDevice(c->device);
+    if (dr_stride == c->dr_stride && n_global && n_global <= (1u << 22) && device_merge_applies(c)) {
+        crass_hip_ctx::DM &d = c->dm;
+        HIPCHK(c, d.g_chars.ensure(n_global * (size_t)dr_stride + 16)); HIPCHK(c, d.g_len.ensure(n_global));
+        HIPCHK(c, hipMemcpyAsync(d.g_chars.p, dr_chars, n_global * (size_t)dr_stride, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d.g_len.p, dr_len, n_global * 2, hipMemcpyHostToDevice, c->stream));
+        const int s = merge_global_device(c, n_global, my_offset);
+        if (s == CRASS_OK) { c->cnt.used_device_merge = 1; c->cnt.ms_merge_host = (float)(now_ms() - t0); return CRASS_OK; }
+        if (s != CRASS_ERR_STATE) return s;
+        HIPCHK(c, hipStreamSynchronize(c->stream));                 // (the uploads read the caller's buffers)
+        c->dm.global = false;
+    }
+    return merge_global_host(c, dr_chars, dr_len, dr_stride, n_global, my_offset, t0);
+}
+
+int crass_hip_get_distinct_device(crass_hip_ctx *c, crass_distinct_dev *o)
+{
+    if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_pass1 || !(c->dense.active && c->have_dev_tokens)) return CRASS_ERR_STATE;
+    o->n_distinct = c->n_dx; o->dr_stride = c->dr_stride; o->d_chars = c->dd_dx_chars.p; o->d_len = c->dd_dx_len.p;
+    return CRASS_OK;
+}
+
+int crass_hip_merge_distinct_device(crass_hip_ctx *c, const char *d_chars, const uint16_t *d_len, uint32_t dr_stride,
+                                    uint64_t n_global, uint64_t my_offset)
+{
+    if (!c || (n_global && (!d_chars || !d_len || !dr_stride))) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_pass1) return CRASS_ERR_STATE;
+    if (dr_stride != c->dr_stride) return CRASS_ERR_INVALID_ARG;
+    const double t0 = now_ms();
+    c->dm.active = false;
+    c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
+    (void)hipSetDevice(c->device);
+    crass_hip_ctx::DM &d = c->dm;
+    // engine-owned copy of the concatenation (the caller's buffers belong to its own stream and allocator)
+    HIPCHK(c, d.g_chars.ensure(n_global * (size_t)dr_stride + 16)); HIPCHK(c, d.g_len.ensure(n_global + 1));
+    if (n_global) {
+        HIPCHK(c, hipMemcpyAsync(d.g_chars.p, d_chars, n_global * (size_t)dr_stride, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d.g_len.p, d_len, n_global * 2, hipMemcpyDeviceToDevice, c->stream));
+    }
+    int s = merge_global_device(c, n_global, my_offset);
+    if (s == CRASS_OK) { c->cnt.used_device_merge = 1; c->cnt.ms_merge_host = (float)(now_ms() - t0); return CRASS_OK; }
+    if (s != CRASS_ERR_STATE) return s;
+    // host merge after all
+    c->dm.global = false;
+    std::vector<char> gc(n_global * (size_t)dr_stride);
+    std::vector<uint16_t> gl(n_global);
+    if (n_global) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(gc.data(), d.g_chars.p, gc.size(), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(gl.data(), d.g_len.p, gl.size() * 2, hipMemcpyDeviceToHost));
+    }
+    return merge_global_host(c, gc.data(), gl.data(), dr_stride, n_global, my_offset, t0);
 }
 
 int crass_hip_get_merge(const crass_hip_ctx *c, crass_merge_view *o)

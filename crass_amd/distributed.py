@@ -62,3 +62,46 @@ def gather_counts(values, dist, device=None):
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [o.cpu().tolist() for o in out]
+
+
+class _DevView:
+    """a device buffer of the engine as a __cuda_array_interface__ object (torch.as_tensor makes a view of it)"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def allgather_distinct_device(eng, dist, device):
+    """The exchange with everything left on the device (backend "nccl" = RCCL over xGMI): every rank contributes
+    its distinct candidate strings straight from the engine's device buffers; the rank-ordered concatenation
+    comes back as two device tensors (uint8 [n_global, stride] and uint8 [n_global, 2] = the uint16 lengths).
+    Returns (g_chars, g_lens, my_offset) or None when this rank's list is not on the device (the caller then
+    uses allgather_distinct with host arrays — every rank must take the same branch, see agree_all)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dd = eng.distinct_device()
+    ok = torch.tensor([1 if dd is not None else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        return None
+    p_chars, p_len, n, stride = dd
+    meta = torch.tensor([n, stride], dtype=torch.int64, device=device)
+    metas = torch.empty((world, 2), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(metas, meta)
+    metas = metas.cpu()
+    counts = [int(metas[r, 0]) for r in range(world)]
+    strides = {int(metas[r, 1]) for r in range(world)}
+    assert len(strides) == 1, "ranks disagree on the DR slot stride"
+    cap = max(max(counts), 1)
+    slot = stride + 2                                   # DR bytes + the uint16 length as two bytes: ONE collective
+    send = torch.zeros((cap, slot), dtype=torch.uint8, device=device)
+    if n:
+        send[:n, :stride] = torch.as_tensor(_DevView(p_chars, (n, stride), "|u1"), device=device)
+        send[:n, stride:] = torch.as_tensor(_DevView(p_len, (n, 2), "|u1"), device=device)
+    recv = torch.empty((world, cap, slot), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    cat = torch.cat([recv[r, :counts[r]] for r in range(world)])
+    g_chars = cat[:, :stride].contiguous()
+    g_lens = cat[:, stride:].contiguous()               # [n_global, 2] bytes == uint16 little endian
+    torch.cuda.current_stream(device).synchronize()         # the engine reads them on its own stream
+    return g_chars, g_lens, sum(counts[:rank])

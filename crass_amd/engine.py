@@ -366,6 +366,21 @@ class SearchEngine:
                                                int(my_offset)), "crass_hip_merge_distinct")
         return self.merge_view() if fetch else None
 
+    def distinct_device(self):
+        """(device pointer of the distinct strings, device pointer of their lengths, n, stride) or None when
+        pass 1 did not leave the list on the device"""
+        v = _abi.DistinctDev()
+        st = self.lib.crass_hip_get_distinct_device(self.h, C.byref(v))
+        if st != 0:
+            return None
+        return int(v.d_chars or 0), int(v.d_len or 0), int(v.n_distinct), int(v.dr_stride)
+
+    def merge_distinct_device(self, d_chars_ptr, d_len_ptr, stride, n_global, my_offset, fetch=True):
+        """merge from a DEVICE-resident rank-ordered concatenation of every rank's distinct list"""
+        _chk(self.lib.crass_hip_merge_distinct_device(self.h, C.c_void_p(d_chars_ptr), C.c_void_p(d_len_ptr), int(stride), int(n_global),
+                                                      int(my_offset)), "crass_hip_merge_distinct_device")
+        return self.merge_view() if fetch else None
+
     def merge_view(self):
         v = _abi.MergeView()
         _chk(self.lib.crass_hip_get_merge(self.h, C.byref(v)), "crass_hip_get_merge")

@@ -155,6 +155,20 @@ int crass_hip_get_distinct(crass_hip_ctx *ctx, crass_distinct *out);
 int crass_hip_merge_distinct(crass_hip_ctx *ctx, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
                              uint64_t n_global, uint64_t my_offset);
 
+/* The same exchange with the lists left on the device (RCCL all-gather between device buffers): the device
+ * addresses of this context's distinct list (CRASS_ERR_STATE when pass 1 did not produce it on the device,
+ * use crass_hip_get_distinct then), and the merge from a device-resident concatenation.  The merge copies
+ * the list, so the caller's buffers may be released as soon as the call returns.                          */
+typedef struct {
+    uint64_t        n_distinct;
+    uint32_t        dr_stride;
+    const char     *d_chars;       /* device pointer, n_distinct * dr_stride bytes                */
+    const uint16_t *d_len;         /* device pointer                                              */
+} crass_distinct_dev;
+int crass_hip_get_distinct_device(crass_hip_ctx *ctx, crass_distinct_dev *out);
+int crass_hip_merge_distinct_device(crass_hip_ctx *ctx, const char *d_chars, const uint16_t *d_len, uint32_t dr_stride,
+                                    uint64_t n_global, uint64_t my_offset);
+
 typedef struct {
     uint32_t        n_tokens;     /* StringCheck size; tokens are 2 .. n_tokens+1                 */
     const char     *tok_chars;    /* token t string = tok_chars[tok_off[t-2] .. tok_off[t-1])     */

@@ -124,3 +124,114 @@ def test_bench_two_rank_dry_run(tmp_path):
     d1 = json.loads([l for l in one.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert (d["config"]["pass1_found"], d["config"]["pass2_found"], d["config"]["patterns"]) == \
         (d1["config"]["pass1_found"], d1["config"]["pass2_found"], d1["config"]["patterns"])
+
+
+DEVICE_EXCHANGE = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+torch.cuda.init()                      # torch's HIP runtime first (it does not come up once another one holds the GPU)
+from tests import orc
+import crass_amd as ca
+ca.load()
+n, L = 120000, 150
+spec = ca.synth_spec(read_len=L, crispr_per_million=30000)
+engs, lists = [], []
+for r in range(2):
+    lo, hi = n * r // 2, n * (r + 1) // 2
+    e = ca.SearchEngine(device=0)
+    e.load_packed_uniform(ca.synth_packed(spec, lo, hi - lo), hi - lo, L, read_index_base=lo)
+    e.seed_scan()
+    engs.append(e)
+    lists.append(e.distinct())
+g_chars = np.concatenate([l[0] for l in lists])
+g_lens = np.concatenate([l[1] for l in lists])
+t_chars = torch.from_numpy(g_chars).cuda()
+t_lens = torch.from_numpy(g_lens.view(np.int16)).cuda()
+torch.cuda.synchronize()
+offs = [0, len(lists[0][1])]
+views, recs = [], []
+for r in range(2):
+    assert engs[r].distinct_device() is not None
+    m = engs[r].merge_distinct_device(t_chars.data_ptr(), t_lens.data_ptr(), g_chars.shape[1], g_chars.shape[0], offs[r])
+    assert engs[r].counters()["used_device_merge"] == 1
+    recs.append(engs[r].recruit())
+    views.append(engs[r].merge_view())
+# host-side exchange on fresh state for comparison
+os.environ["CRASS_HOST_MERGE"] = "1"
+try:
+    hv = []
+    for r in range(2):
+        engs[r].seed_scan()
+        engs[r].merge_distinct(g_chars, g_lens, offs[r])
+        assert engs[r].counters()["used_device_merge"] == 0
+        hr = engs[r].recruit()
+        hv.append((engs[r].merge_view(), hr))
+finally:
+    os.environ.pop("CRASS_HOST_MERGE", None)
+for r in range(2):
+    assert views[r].tokens == hv[r][0].tokens and views[r].groups == hv[r][0].groups and views[r].patterns == hv[r][0].patterns
+    assert views[r].cand_token.tolist() == hv[r][0].cand_token.tolist()
+    assert recs[r].read_idx.tolist() == hv[r][1].read_idx.tolist() and recs[r].token.tolist() == hv[r][1].token.tolist()
+    assert recs[r].start.tolist() == hv[r][1].start.tolist() and recs[r].end.tolist() == hv[r][1].end.tolist()
+asc = ca.unpack_ascii(ca.synth_packed(spec, 0, n), 10, L, n)
+ref = orc.pipeline((asc, np.arange(0, (n + 1) * L, L, dtype=np.uint64)))
+assert views[0].tokens == ref.tokens and views[0].groups == ref.groups
+n1, n2 = ref.n_pass1, ref.n_pass2
+assert views[0].cand_token.tolist() + views[1].cand_token.tolist() == ref.rec_token[:n1].tolist()
+assert recs[0].read_idx.tolist() + recs[1].read_idx.tolist() == ref.rec_read[n1:n1 + n2].tolist()
+assert recs[0].token.tolist() + recs[1].token.tolist() == ref.rec_token[n1:n1 + n2].tolist()
+for e in engs:
+    e.close()
+print("OK")
+"""
+
+
+def test_device_resident_exchange_two_shards_one_process():
+    """the device-resident form of the exchange (crass_hip_merge_distinct_device): two contexts hold the two
+    shards, the concatenation of their distinct lists lives in a device tensor, both merge from it on the
+    device; tables must equal the host-side exchange's and the oracle's"""
+    r = subprocess.run([sys.executable, "-c", DEVICE_EXCHANGE % dict(root=ROOT)], capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"OK" in r.stdout, r.stderr.decode()[-3000:]
+
+
+def test_bench_single_rank_rccl_exchange():
+    """bench.py's N>1 step (RCCL all-gather between device buffers + device-resident merge) with a process
+    group of ONE rank: the collective calls, tensor views of the engine's buffers and pointer hand-over are the
+    code the 8-GPU run executes"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import crass_amd as ca
+from crass_amd.distributed import allgather_distinct_device
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+n, L = 300000, 150
+spec = ca.synth_spec(read_len=L)
+eng = ca.SearchEngine(device=0)
+eng.load_packed_uniform(ca.synth_packed(spec, 0, n), n, L)
+eng.seed_scan(fetch=False)
+g = allgather_distinct_device(eng, dist, torch.device("cuda", 0))
+assert g is not None
+g_chars, g_lens, my_off = g
+eng.merge_distinct_device(g_chars.data_ptr(), g_lens.data_ptr(), g_chars.shape[1], g_chars.shape[0], my_off, fetch=False)
+eng.recruit(fetch=False)
+c1 = eng.counters(); v1 = eng.merge_view()
+eng.seed_scan(fetch=False); eng.merge(fetch=False); eng.recruit(fetch=False)
+c2 = eng.counters(); v2 = eng.merge_view()
+assert c1["used_device_merge"] == 1 and c2["used_device_merge"] == 1
+assert (c1["n_pass1_found"], c1["n_pass2_found"], c1["n_patterns"]) == (c2["n_pass1_found"], c2["n_pass2_found"], c2["n_patterns"])
+assert v1.tokens == v2.tokens and v1.groups == v2.groups and v1.patterns == v2.patterns
+assert c1["n_pass2_found"] > 0
+dist.destroy_process_group()
+print("OK")
+""" % ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0 and b"OK" in r.stdout, r.stderr.decode()[-3000:]
