@@ -438,27 +438,31 @@ __global__ __launch_bounds__(256) void k_dm_key_fill(DevMerge M)
     d[2] = M.pat_packed[(uint64_t)pid * 2 + 1];
 }
 
-// table size: load <= 1/3 (<= 1/2 at the LDS limit 2^15 and at the allocation limit), as build_anchors (merge.cpp)
+// table size: load <= 1/3 (<= 1/2 at the limits), as build_anchors (merge.cpp).  Up to 2^14 keys: exact keys in
+// LDS; up to 2^15: a 2^16-slot table whose 16-bit fingerprints are staged in LDS (a superset filter, 2 * 2^-16
+// false positives per probe — the flagged reads are verified exactly anyway); beyond: exact keys probed in L2.
 __global__ void k_dm_cuckoo_params(DevMerge M)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const uint32_t n = M.st->n_keys;
-    uint32_t ls = 0;
+    uint32_t ls = 0, mode = 0;
     for (uint32_t log = 10; log <= 15 && !ls; log++) {
         const uint32_t size = 1u << log;
         if (n * 3 > size && log != 15) continue;
         if (n * 2 > size) continue;
         ls = log;
     }
-    for (uint32_t log = 16; log <= M.tab_log_alloc && !ls; log++) {
+    if (!ls && n * 2 <= 65536u && M.tab_log_alloc >= 16) { ls = 16; mode = 3; }
+    for (uint32_t log = 17; log <= M.tab_log_alloc && !ls; log++) {
         const uint32_t size = 1u << log;
         if (n * 3 > size && log != M.tab_log_alloc) continue;
         if (n * 2 > size) continue;
-        ls = log;
+        ls = log; mode = 2;
     }
     if (ls > M.tab_log_alloc) ls = 0;
     if (!ls || n == 0) atomicOr(&M.st->fail, 2u);
     M.st->log_size = ls;
+    M.st->tab_mode = mode;
     M.st->n_patterns = 2 * M.st->n_survivors;
 }
 
@@ -489,6 +493,20 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_finalize(DevMerge M)
     const uint32_t ls = M.st->log_size;
     if (!ls || i >= (1u << ls) || M.st->all_t) return;
     if (M.anchor_tab[i] == 0xFFFFFFFFu) M.anchor_tab[i] = M.st->k0;
+}
+// tab_mode 3: fingerprint = low 16 bits of (h1 product ^ h2 product) of the slot's key, two per word
+__global__ __launch_bounds__(256) void k_dm_cuckoo_fp(DevMerge M)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (M.st->tab_mode != 3 || w >= (1u << 15)) return;
+    uint32_t out = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t v = M.anchor_tab[2 * w + q];
+        const uint32_t p1 = (uint32_t)__umul24(v ^ (v >> M.s1), M.m1), p2 = (uint32_t)__umul24(v ^ (v >> M.s2), M.m2);
+        out |= ((p1 ^ p2) & 0xFFFFu) << (16 * q);
+    }
+    M.anchor_fp[w] = out;
 }
 
 // per-token results + state words straight into pinned host memory (a few 10 KB over PCIe): no copy calls
@@ -534,6 +552,7 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     hipLaunchKernelGGL(k_dm_cuckoo_params, dim3(1), dim3(64), 0, st, M);
     hipLaunchKernelGGL(k_dm_cuckoo_insert, dim3(ne), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_cuckoo_finalize, dim3((unsigned)(((1ull << M.tab_log_alloc) + 255) / 256)), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_cuckoo_fp, dim3(128), dim3(256), 0, st, M);
     return hipGetLastError();
 }
 

@@ -169,7 +169,7 @@ struct crass_hip_ctx {
     // pass 2 runs.  dm.active: the installed pattern set lives in dm.M, not in the automaton/anchors above.
     struct DM {
         DevBuf<uint64_t> packed, pat_packed; DevBuf<uint32_t> codes, owner, root_of, tmp, root_rank, gid_of, grp, members, pat_token;
-        DevBuf<uint32_t> kset_u32, ent_slot, anchor_tab; DevBuf<uint8_t> blank, sblank, ent_win; DevBuf<uint16_t> pat_len; DevBuf<uint64_t> ents, rents; DevBuf<uint32_t> rset_u32, rd_slot;
+        DevBuf<uint32_t> kset_u32, ent_slot, anchor_tab, anchor_fp; DevBuf<uint8_t> blank, sblank, ent_win; DevBuf<uint16_t> pat_len; DevBuf<uint64_t> ents, rents; DevBuf<uint32_t> rset_u32, rd_slot;
         DevBuf<unsigned long long> rset_key;
         DevBuf<unsigned long long> kset_key; DevBuf<DevMergeState> st;
         PinBuf<DevMergeState> h_st; PinBuf<uint32_t> h_gid; PinBuf<uint8_t> h_blank;
@@ -188,7 +188,7 @@ struct crass_hip_ctx {
         void release()
         {
             packed.release(); pat_packed.release(); codes.release(); owner.release(); root_of.release(); tmp.release(); root_rank.release();
-            gid_of.release(); grp.release(); members.release(); pat_token.release(); kset_u32.release(); ent_slot.release(); anchor_tab.release();
+            gid_of.release(); grp.release(); members.release(); pat_token.release(); kset_u32.release(); ent_slot.release(); anchor_tab.release(); anchor_fp.release();
             blank.release(); sblank.release(); ents.release(); ent_win.release(); rents.release(); rset_u32.release(); rd_slot.release(); rset_key.release(); pat_len.release(); kset_key.release(); st.release(); h_st.release(); h_gid.release(); h_blank.release();
             g_chars.release(); gx_chars.release(); g_len.release(); gx_len.release(); g_keys.release(); g_first.release(); g_slot.release();
             g_rep.release(); g_prefix.release(); g_bsum.release(); g_hash.release(); g_mask.release(); g_idx.release();
@@ -610,7 +610,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     // their small outputs — all the merge needs — are written straight into pinned host memory
     c->have_rep = false;
     c->have_dev_tokens = false;
-    const bool dedupe = n_surv < (1u << 22);
+    const bool dedupe = n_surv < (1u << 24);
     if (dedupe) {
         uint32_t tsize = 1024;
         while (tsize < n_surv * 2) tsize <<= 1;
@@ -753,8 +753,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
     }
     if (use_filter && c->R.n_exc == 0) {                // bound for the next call: twice this call's count
-        uint64_t hint = 65536;
-        while (hint < 2 * n_surv) hint <<= 1;
+        const uint64_t hint = std::max<uint64_t>(65536, (n_surv + n_surv / 2 + 65535) & ~65535ull);
         c->surv_cap_hint = std::min<uint64_t>(hint, kDenseMaxSurvivors);
     }
     if (s == CRASS_ERR_STATE) {
@@ -945,7 +944,7 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     M.dx_chars = dx_chars; M.dx_len = dx_len; M.stride = stride; M.n_tok = n;
     M.thr = (uint32_t)std::max(c->prm.kmer_clust_size, 2); M.kmax = stride - 10;
     M.kset_log = 10; while ((1ull << M.kset_log) < 32ull * n) M.kset_log++;
-    M.tab_log_alloc = 15; while (M.tab_log_alloc < 24 && (1ull << M.tab_log_alloc) < 48ull * n) M.tab_log_alloc++;
+    M.tab_log_alloc = 16; while (M.tab_log_alloc < 24 && (1ull << M.tab_log_alloc) < 48ull * n) M.tab_log_alloc++;
     HIPCHK(c, d.packed.ensure((size_t)n * 4)); HIPCHK(c, d.codes.ensure((size_t)n * M.kmax)); HIPCHK(c, d.owner.ensure(1u << 22));
     HIPCHK(c, d.root_of.ensure(n)); HIPCHK(c, d.tmp.ensure(n + 1)); HIPCHK(c, d.root_rank.ensure(n + 1)); HIPCHK(c, d.gid_of.ensure(n));
     HIPCHK(c, d.grp.ensure(5 * ((size_t)n + 1))); HIPCHK(c, d.members.ensure(n)); HIPCHK(c, d.blank.ensure(n));
@@ -956,7 +955,7 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     M.rset_log = 10; while ((1ull << M.rset_log) < 4ull * n) M.rset_log++;
     HIPCHK(c, d.rset_key.ensure((size_t)1 << M.rset_log)); HIPCHK(c, d.rset_u32.ensure((size_t)3 << M.rset_log));
     HIPCHK(c, d.rd_slot.ensure(n)); HIPCHK(c, d.rents.ensure((size_t)n * 3));
-    HIPCHK(c, d.anchor_tab.ensure((size_t)1 << M.tab_log_alloc)); HIPCHK(c, d.st.ensure(1));
+    HIPCHK(c, d.anchor_tab.ensure((size_t)1 << M.tab_log_alloc)); HIPCHK(c, d.st.ensure(1)); HIPCHK(c, d.anchor_fp.ensure(1u << 15));
     HIPCHK(c, d.h_st.ensure(1)); HIPCHK(c, d.h_gid.ensure(n)); HIPCHK(c, d.h_blank.ensure(n));
     M.packed = d.packed.p; M.codes = d.codes.p; M.owner = d.owner.p; M.root_of = d.root_of.p; M.tmp = d.tmp.p; M.root_rank = d.root_rank.p;
     M.gid_of = d.gid_of.p;
@@ -968,7 +967,7 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     M.sblank = d.sblank.p;
     M.rset_key = d.rset_key.p; M.rset_cnt = d.rset_u32.p; M.rset_base = d.rset_u32.p + ((size_t)1 << M.rset_log);
     M.rset_fill = d.rset_u32.p + ((size_t)2 << M.rset_log); M.rd_slot = d.rd_slot.p; M.rents = d.rents.p;
-    M.anchor_tab = d.anchor_tab.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
+    M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
     d.M = M;
     const double tl0 = now_ms();
     HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
@@ -1397,7 +1396,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         c->cnt.n_pass2_found = c->q_n;
         c->cnt.used_lds_automaton = 2;
         c->cnt.anchor_keys = c->dm.h_st.p->n_keys;
-        c->cnt.anchor_table_kind = c->dm.h_st.p->log_size > 15 ? 2 : 0;
+        c->cnt.anchor_table_kind = c->dm.h_st.p->tab_mode == 3 ? 1 : c->dm.h_st.p->tab_mode;
         float ms = 0;
         (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->cnt.ms_recruit = ms;
         (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->cnt.ms_recruit_finish = ms;
@@ -1462,7 +1461,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     c->cnt.n_pass2_found = c->q_read.size();
     c->cnt.used_lds_automaton = anchors ? 2 : (lds ? 1 : 0);     // 2 = anchor filter + exact list scan
     c->cnt.anchor_keys = !anchors ? 0 : (dmp ? c->dm.h_st.p->n_keys : c->K.n_keys);
-    c->cnt.anchor_table_kind = !anchors ? 0 : (dmp ? (c->dm.h_st.p->log_size > 15 ? 2 : 0) : (c->K.log_size > 15 ? 2 : c->K.mode));
+    c->cnt.anchor_table_kind = !anchors ? 0 : (dmp ? (c->dm.h_st.p->tab_mode == 3 ? 1u : c->dm.h_st.p->tab_mode) : (c->K.log_size > 15 ? 2 : c->K.mode));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->cnt.ms_recruit = ms;
     (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->cnt.ms_recruit_finish = ms;

@@ -91,7 +91,9 @@ struct DevMergeState {
     uint32_t all_t;               // the key 0xFFFFFFFF is a member
     uint32_t ent_cursor;          // entries allocated in the verification index
     uint32_t rd_cursor;           // entries allocated in the needle index of removeRedundantRepeats
-    uint32_t pad[2];
+    uint32_t tab_mode;            // anchor table: 0 exact keys staged in LDS (log_size <= 15), 3 16-bit fingerprints of a
+                                  // 2^16-slot table staged in LDS (anchor_fp), 2 exact keys probed in global memory
+    uint32_t pad[1];
 };
 
 struct DevMerge {
@@ -129,6 +131,7 @@ struct DevMerge {
     uint8_t  *ent_win;            // [16 * n_tok] entry claimed its key's slot
     uint64_t *ents;               // [16 * n_tok][3] verification index, grouped by key
     uint32_t *anchor_tab;         // [1 << tab_log_alloc] cuckoo table of the keys (see DevAnchors)
+    uint32_t *anchor_fp;          // [1 << 15] words = 2^16 16-bit fingerprints of the slots' keys (tab_mode 3)
     uint32_t tab_log_alloc;
     uint32_t s1, s2, m1, m2;      // hash constants of the table
     DevMergeState *st;

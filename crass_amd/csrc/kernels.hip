@@ -1810,6 +1810,15 @@ static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_
     }
     return (a == V) | (b == V);
 }
+// MODE 3 (device-built tables): 2^16 slots, 16-bit fingerprints in LDS
+static __device__ __forceinline__ bool anchor_probe_fp(const uint16_t *tab, uint32_t V, const DevAnchors &K)
+{
+    const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1);
+    const uint32_t h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
+    const uint32_t a = tab[h1 >> 16], b = tab[h2 >> 16];
+    const uint32_t fp = (h1 ^ h2) & 0xFFFFu;
+    return (a == fp) | (b == fp);
+}
 
 template <int W, int THREADS, int MODE>     // W = uniform stride in words (0: ragged / any stride)
 static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, const DevAnchors &K, const uint32_t *ak_lds,
@@ -1836,7 +1845,7 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
 #pragma unroll
                     for (int h = 0; h < 2 * W - 1; h++) {
                         uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
-                        bool hit = anchor_probe<MODE>(ak_lds, V, K, mask);
+                        bool hit = MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K) : anchor_probe<MODE == 3 ? 0 : MODE>(ak_lds, V, K, mask);
                         flag = flag | (hit & ((uint32_t)h <= h_max));
                     }
                 } else {
@@ -1844,8 +1853,9 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                     uint32_t lo = g[0];
                     for (uint32_t h = 0; h <= h_max; h += 2) {
                         uint32_t hi = ((h >> 1) + 1 < nw) ? g[(h >> 1) + 1] : 0u;
-                        if (anchor_probe<MODE>(ak_lds, lo, K, mask)) flag = true;
-                        if (h + 1 <= h_max && anchor_probe<MODE>(ak_lds, (lo >> 16) | (hi << 16), K, mask)) flag = true;
+                        auto probe = [&](uint32_t V) { return MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K) : anchor_probe<MODE == 3 ? 0 : MODE>(ak_lds, V, K, mask); };
+                        if (probe(lo)) flag = true;
+                        if (h + 1 <= h_max && probe((lo >> 16) | (hi << 16))) flag = true;
                         lo = hi;
                     }
                 }
@@ -1887,6 +1897,10 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMe
         for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds_buf[i] = K.table[i];
         __syncthreads();
         anchor_filter_body<W, THREADS, 0>(R, K, ak_lds_buf, found_flag, hitmask);
+    } else if (M.st->tab_mode == 3) {
+        for (uint32_t i = threadIdx.x; i < (1u << 15); i += THREADS) ak_lds_buf[i] = M.anchor_fp[i];
+        __syncthreads();
+        anchor_filter_body<W, THREADS, 3>(R, K, ak_lds_buf, found_flag, hitmask);
     } else {
         anchor_filter_body<W, THREADS, 2>(R, K, K.table, found_flag, hitmask);
     }

@@ -219,7 +219,7 @@ def test_config5_shape_many_drs_gc_classes(ca):
     assert gpu.counters["used_lds_automaton"] == 2
 
 
-@pytest.mark.parametrize("n_dr,kind,host_merge", [(2000, 1, True), (9000, 2, True), (2000, 2, False), (9000, 2, False)])
+@pytest.mark.parametrize("n_dr,kind,host_merge", [(2000, 1, True), (9000, 2, True), (1200, 1, False), (2000, (1, 2), False), (9000, 2, False)])
 def test_anchor_table_tiers(ca, n_dr, kind, host_merge):
     """pattern sets beyond the exact LDS anchor table: fingerprint buckets in LDS (kind 1, host-built tables
     only), then exact keys probed in L2 (kind 2) — same records either way, whichever side built the table."""
@@ -234,7 +234,7 @@ def test_anchor_table_tiers(ca, n_dr, kind, host_merge):
     ref = orc.pipeline(seqs)
     assert_same_pipeline(gpu, ref)
     assert gpu.counters["used_lds_automaton"] == 2
-    assert gpu.counters["anchor_table_kind"] == kind, gpu.counters
+    assert gpu.counters["anchor_table_kind"] in (kind if isinstance(kind, tuple) else (kind,)), gpu.counters
 
 
 def test_full_size_properties(ca):
