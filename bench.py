@@ -89,20 +89,24 @@ def main():
     eng = ca.SearchEngine(device=local_rank)
     eng.load_packed_uniform(words, n, L, read_index_base=first)     # H2D once; resident for every step
 
+    xg = None
+    if world > 1 and args.dist_backend == "nccl":
+        from crass_amd.distributed import GatheredExchange
+        xg = GatheredExchange(eng, dist, coll_dev)          # one RCCL all-gather of fixed-size device buffers per step
+
     def step():
         eng.seed_scan(fetch=False)
-        if world > 1:
+        if xg is not None:
+            while not xg.step():                            # capacity raised (first steps only): repeat the seed scan
+                eng.seed_scan(fetch=False)
+        elif world > 1:
             # only the DISTINCT candidate DR strings travel (rank order == read order, so every rank
             # replays the same global token order and builds the same pattern set locally)
-            from crass_amd.distributed import allgather_distinct, allgather_distinct_device
-            g = allgather_distinct_device(eng, dist, coll_dev) if args.dist_backend == "nccl" else None
-            if g is not None:                              # RCCL between device buffers; the merge stays on the device
-                g_chars, g_lens, my_off = g
-                eng.merge_distinct_device(g_chars.data_ptr(), g_lens.data_ptr(), g_chars.shape[1], g_chars.shape[0], my_off, fetch=False)
-            else:
-                chars, lens, _ = eng.distinct()
-                g_chars, g_lens, my_off = allgather_distinct(chars, lens, dist, coll_dev)
-                eng.merge_distinct(g_chars, g_lens, my_off, fetch=False)
+            # (gloo dry runs: the same exchange through host arrays)
+            from crass_amd.distributed import allgather_distinct
+            chars, lens, _ = eng.distinct()
+            g_chars, g_lens, my_off = allgather_distinct(chars, lens, dist, coll_dev)
+            eng.merge_distinct(g_chars, g_lens, my_off, fetch=False)
         else:
             eng.merge(fetch=False)
         eng.recruit(fetch=False)

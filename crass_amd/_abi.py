@@ -66,6 +66,13 @@ class DistinctDev(C.Structure):
     _fields_ = [("n_distinct", C.c_uint64), ("dr_stride", C.c_uint32), ("d_chars", C.c_void_p), ("d_len", C.c_void_p)]
 
 
+ERR_OVERFLOW = 8          # CRASS_ERR_OVERFLOW (include/crass_hip.h)
+
+
+class Exchange(C.Structure):
+    _fields_ = [("d_send", C.c_void_p), ("send_bytes", C.c_uint64), ("slot_bytes", C.c_uint32), ("cap_rows", C.c_uint64)]
+
+
 class Packed(C.Structure):
     _fields_ = [("reads", Reads), ("owner", C.c_void_p)]
 
@@ -97,6 +104,9 @@ SYMBOLS = {
     "crass_hip_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]),
     "crass_hip_get_distinct": (C.c_int, [C.c_void_p, C.POINTER(Distinct)]),
     "crass_hip_merge_distinct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "crass_hip_exchange_setup": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Exchange)]),
+    "crass_hip_merge_gathered": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "crass_hip_exchange_needed_rows": (C.c_uint64, [C.c_void_p]),
     "crass_hip_get_distinct_device": (C.c_int, [C.c_void_p, C.POINTER(DistinctDev)]),
     "crass_hip_merge_distinct_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "crass_hip_get_merge": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),

@@ -516,6 +516,66 @@ __global__ __launch_bounds__(256) void k_dm_export(DevMerge M, DevMergeState *h_
     if (t == 0) *h_st = *M.st;
     if (t < M.n_tok) { h_gid[t] = M.gid_of[t]; h_blank[t] = M.blank[t]; }
 }
+// ---- one-collective exchange ----
+__global__ __launch_bounds__(256) void k_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride,
+                                                  uint64_t cap_rows, uint32_t slot_bytes, uint8_t *send)
+{
+    const uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t nd = *d_nd;
+    if (j == 0) {
+        uint64_t *h = reinterpret_cast<uint64_t *>(send);
+        h[0] = nd;
+        reinterpret_cast<uint32_t *>(send)[2] = stride;
+        reinterpret_cast<uint32_t *>(send)[3] = (uint32_t)cap_rows;
+    }
+    if (j >= nd || j >= cap_rows) return;
+    uint8_t *row = send + (j + 1) * (uint64_t)slot_bytes;
+    const uint4 *src = reinterpret_cast<const uint4 *>(dx_chars + j * (uint64_t)stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(row);
+    for (uint32_t i = 0; i < stride / 16; i++) dst[i] = src[i];
+    uint4 tail; tail.x = dx_len[j]; tail.y = tail.z = tail.w = 0;
+    dst[stride / 16] = tail;
+}
+hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride, uint64_t cap_rows,
+                          uint32_t slot_bytes, uint8_t *send, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_xg_fill, dim3((unsigned)((cap_rows + 255) / 256)), dim3(256), 0, st, dx_chars, dx_len, d_nd, stride, cap_rows, slot_bytes, send);
+    return hipGetLastError();
+}
+// rank order == global read order: rank r's rows go to [off_r, off_r + n_r)
+__global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows,
+                                                    uint32_t slot_bytes, char *g_chars, uint16_t *g_len, uint32_t *xinfo)
+{
+    const uint64_t send_bytes = (cap_rows + 1) * (uint64_t)slot_bytes;
+    const uint32_t r = blockIdx.y;
+    uint64_t off = 0, total = 0, mx = 0, mine = 0;
+    for (uint32_t q = 0; q < world; q++) {                      // a handful of ranks: every thread sums the headers
+        const uint64_t nq = *reinterpret_cast<const uint64_t *>(recv + q * send_bytes);
+        if (q < r) off += nq;
+        if (q < rank) mine += nq;
+        total += nq;
+        mx = nq > mx ? nq : mx;
+    }
+    const uint64_t n_r = *reinterpret_cast<const uint64_t *>(recv + r * send_bytes);
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (r == 0 && i == 0) {
+        xinfo[0] = (uint32_t)total; xinfo[1] = (uint32_t)mine; xinfo[2] = mx > cap_rows ? 1u : 0u; xinfo[3] = (uint32_t)mx;
+    }
+    if (mx > cap_rows || i >= n_r) return;
+    const uint8_t *row = recv + r * send_bytes + (i + 1) * (uint64_t)slot_bytes;
+    const uint4 *src = reinterpret_cast<const uint4 *>(row);
+    uint4 *dst = reinterpret_cast<uint4 *>(g_chars + (off + i) * (uint64_t)stride);
+    for (uint32_t k = 0; k < stride / 16; k++) dst[k] = src[k];
+    g_len[off + i] = (uint16_t)src[stride / 16].x;
+}
+hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
+                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_xg_unpack, dim3((unsigned)((cap_rows + 255) / 256), world), dim3(256), 0, st, recv, world, rank, stride, cap_rows,
+                       slot_bytes, g_chars, g_len, xinfo);
+    return hipGetLastError();
+}
+
 hipError_t launch_dm_export(const DevMerge &M, DevMergeState *h_st, uint32_t *h_gid, uint8_t *h_blank, hipStream_t st)
 {
     hipLaunchKernelGGL(k_dm_export, dim3((M.n_tok + 255) / 256), dim3(256), 0, st, M, h_st, h_gid, h_blank);

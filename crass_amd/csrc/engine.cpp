@@ -199,6 +199,14 @@ struct crass_hip_ctx {
             ev_done = ev_t0 = ev_t1 = nullptr;
         }
     } dm;
+    // one-collective exchange (crass_hip_exchange_setup): this rank's distinct list in a fixed-size device buffer
+    struct Xchg {
+        bool active = false;
+        uint32_t world = 1, rank = 0, slot = 0;
+        uint64_t cap = 0, needed = 0;
+        DevBuf<uint8_t> send; DevBuf<uint32_t> xinfo; PinBuf<uint32_t> h_xinfo;
+        uint64_t send_bytes() const { return (cap + 1) * (uint64_t)slot; }
+    } xchg;
     // distinct candidate strings (multi-GPU exchange)
     std::vector<char> dx_chars; std::vector<uint16_t> dx_len; std::vector<uint32_t> dx_map; bool have_distinct = false;
     uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
@@ -330,7 +338,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    c->dm.release(); c->h_qblob.release();
+    c->dm.release(); c->h_qblob.release(); c->xchg.send.release(); c->xchg.xinfo.release(); c->xchg.h_xinfo.release();
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
     if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
@@ -484,6 +492,8 @@ int crass_hip_attach_device_reads(crass_hip_ctx *c, const crass_reads *d)
     return CRASS_OK;
 }
 
+static void ensure_distinct(crass_hip_ctx *c);
+
 // ------------------------------------------------------------------------------------------
 // pass 1
 // ------------------------------------------------------------------------------------------
@@ -625,6 +635,8 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->d_mask.p,
                                    c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
                                    c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream));
+        if (c->xchg.active)                             // multi-rank: the list goes straight into the collective's send buffer
+            HIPCHK(c, launch_xg_fill(c->dd_dx_chars.p, c->dd_dx_len.p, c->d_count.p + 4, stride, c->xchg.cap, c->xchg.slot, c->xchg.send.p, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 32, hipMemcpyDeviceToHost, c->stream));
     {
@@ -805,6 +817,24 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t total = (size_t)c->n_cand();
     c->have_pass1 = true;
+    if (c->xchg.active && !(c->dense.active && c->have_dev_tokens)) {
+        // no device-resident distinct list (exception reads, no candidates, ...): the send buffer is filled from the host's
+        ensure_distinct(c);
+        const bool dev = false;
+        (void)dev;
+        const uint64_t nd = c->dx_len.size();
+        std::vector<uint8_t> buf(c->xchg.send_bytes(), 0);
+        reinterpret_cast<uint64_t *>(buf.data())[0] = nd;
+        reinterpret_cast<uint32_t *>(buf.data())[2] = c->dr_stride;
+        reinterpret_cast<uint32_t *>(buf.data())[3] = (uint32_t)c->xchg.cap;
+        for (uint64_t j = 0; j < nd && j < c->xchg.cap; j++) {
+            uint8_t *row = buf.data() + (j + 1) * (size_t)c->xchg.slot;
+            memcpy(row, c->dx_chars.data() + j * (size_t)c->dr_stride, c->dr_stride);
+            const uint32_t l = c->dx_len[j];
+            memcpy(row + c->dr_stride, &l, 4);
+        }
+        HIPCHK(c, hipMemcpy(c->xchg.send.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    }
     c->cnt.ms_sink_host = (float)(now_ms() - t_sink0);     // includes the survivor kernel + D2H it waits for
     c->cnt.n_filter_survivors = n_surv + c->R.n_exc;
     c->cnt.n_pass1_found = total;
@@ -1216,6 +1246,76 @@ int crass_hip_merge_distinct(crass_hip_ctx *c, const char *dr_chars, const uint1
         c->dm.global = false;
     }
     return merge_global_host(c, dr_chars, dr_len, dr_stride, n_global, my_offset, t0);
+}
+
+int crass_hip_exchange_setup(crass_hip_ctx *c, uint32_t world, uint32_t rank, uint64_t cap_rows, crass_exchange *o)
+{
+    if (!c || !o || world == 0 || rank >= world || cap_rows == 0 || cap_rows > (1u << 22)) return CRASS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    crass_hip_ctx::Xchg &X = c->xchg;
+    X.world = world; X.rank = rank; X.cap = cap_rows; X.slot = c->dr_stride + 16; X.needed = 0;
+    HIPCHK(c, X.send.ensure(X.send_bytes())); HIPCHK(c, X.xinfo.ensure(8)); HIPCHK(c, X.h_xinfo.ensure(8));
+    HIPCHK(c, hipMemset(X.send.p, 0, X.send_bytes()));
+    X.active = true;
+    o->d_send = X.send.p; o->send_bytes = X.send_bytes(); o->slot_bytes = X.slot; o->cap_rows = X.cap;
+    return CRASS_OK;
+}
+
+uint64_t crass_hip_exchange_needed_rows(const crass_hip_ctx *c) { return c ? c->xchg.needed : 0; }
+
+int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
+{
+    if (!c || !d_recv) return CRASS_ERR_INVALID_ARG;
+    if (!c->have_pass1 || !c->xchg.active) return CRASS_ERR_STATE;
+    const double t0 = now_ms();
+    crass_hip_ctx::Xchg &X = c->xchg;
+    crass_hip_ctx::DM &d = c->dm;
+    d.active = false;
+    c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
+    (void)hipSetDevice(c->device);
+    const uint32_t stride = c->dr_stride;
+    const uint64_t n_max = X.world * X.cap;
+    const uint32_t n = (uint32_t)n_max;
+    HIPCHK(c, d.g_chars.ensure(n_max * (size_t)stride + 16)); HIPCHK(c, d.g_len.ensure(n_max + 1));
+    HIPCHK(c, launch_xg_unpack((const uint8_t *)d_recv, X.world, X.rank, stride, X.cap, X.slot, d.g_chars.p, d.g_len.p, X.xinfo.p, c->stream));
+    bool dev = device_merge_applies(c) && n_max <= (1u << 22);
+    if (dev) {
+        uint32_t tsize = 1024;
+        while (tsize < n * 2) tsize <<= 1;
+        const uint64_t n_words = (n_max + 63) / 64;
+        HIPCHK(c, d.g_keys.ensure(tsize)); HIPCHK(c, d.g_first.ensure(tsize)); HIPCHK(c, d.g_slot.ensure(n)); HIPCHK(c, d.g_rep.ensure(n));
+        HIPCHK(c, d.g_hash.ensure(n)); HIPCHK(c, d.g_mask.ensure(n_words + 1)); HIPCHK(c, d.g_prefix.ensure(n_words + 1));
+        HIPCHK(c, d.g_bsum.ensure((n_words + 255) / 256 + 2)); HIPCHK(c, d.g_idx.ensure(n));
+        HIPCHK(c, d.gx_chars.ensure((size_t)n * stride + 16)); HIPCHK(c, d.gx_len.ensure(n));
+        HIPCHK(c, d.h_gmap.ensure(n)); HIPCHK(c, d.h_gx_chars.ensure((size_t)n * stride + 16)); HIPCHK(c, d.h_gx_len.ensure(n)); HIPCHK(c, d.h_gx_hash.ensure(n));
+        HIPCHK(c, hipMemsetAsync(c->d_count.p + 4, 0, 8, c->stream));
+        // the global count lives on the device (xinfo[0]); n_max bounds it
+        HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, X.xinfo.p, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p, d.g_rep.p,
+                                   c->stream));
+        HIPCHK(c, launch_dx_tokens(d.g_chars.p, d.g_len.p, d.g_hash.p, stride, X.xinfo.p, n, d.g_rep.p, d.g_mask.p, d.g_prefix.p, d.g_bsum.p,
+                                   d.g_idx.p, c->d_count.p + 4, c->d_count.p + 5, d.h_gmap.p, d.h_gx_chars.p, d.h_gx_len.p, d.h_gx_hash.p,
+                                   d.gx_chars.p, d.gx_len.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_count.p + 4, c->d_count.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(X.h_xinfo.p, X.xinfo.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t n_global = X.h_xinfo.p[0], my_off = X.h_xinfo.p[1];
+    if (X.h_xinfo.p[2]) { X.needed = X.h_xinfo.p[3]; return CRASS_ERR_OVERFLOW; }
+    if (dev && n_global && c->h_count.p[5] == 0 && c->h_count.p[4] != 0 && c->h_count.p[4] <= (1u << 20) && my_off + c->n_dx <= n_global) {
+        d.global = true; d.my_off = my_off; d.n_global = n_global;
+        const int s = device_merge(c, d.gx_chars.p, d.gx_len.p, c->h_count.p[4], d.h_gx_chars.p, d.h_gx_len.p);
+        if (s == CRASS_OK) { c->cnt.used_device_merge = 1; c->cnt.ms_merge_host = (float)(now_ms() - t0); return CRASS_OK; }
+        if (s != CRASS_ERR_STATE) return s;
+    }
+    // host merge
+    d.global = false;
+    std::vector<char> gc(n_global * (size_t)stride);
+    std::vector<uint16_t> gl(n_global);
+    if (n_global) {
+        HIPCHK(c, hipMemcpy(gc.data(), d.g_chars.p, gc.size(), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(gl.data(), d.g_len.p, gl.size() * 2, hipMemcpyDeviceToHost));
+    }
+    return merge_global_host(c, gc.data(), gl.data(), stride, n_global, my_off, t0);
 }
 
 int crass_hip_get_distinct_device(crass_hip_ctx *c, crass_distinct_dev *o)

@@ -137,6 +137,12 @@ struct DevMerge {
     DevMergeState *st;
 };
 
+// one-collective exchange (see crass_hip_exchange_setup): fill this rank's send buffer / unpack the gathered buffers
+hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride, uint64_t cap_rows,
+                          uint32_t slot_bytes, uint8_t *send, hipStream_t st);
+// xinfo (device, 8 words): [0] n_global, [1] my_offset, [2] overflow flag, [3] largest per-rank count
+hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
+                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st);
 hipError_t launch_device_merge(const DevMerge &M, hipStream_t st);
 hipError_t launch_dm_export(const DevMerge &M, DevMergeState *h_st, uint32_t *h_gid, uint8_t *h_blank, hipStream_t st);
 // pass-2 anchor filter with table parameters read from the device (M.st); flags nothing when M.st->fail

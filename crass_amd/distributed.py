@@ -105,3 +105,36 @@ def allgather_distinct_device(eng, dist, device):
     g_lens = cat[:, stride:].contiguous()               # [n_global, 2] bytes == uint16 little endian
     torch.cuda.current_stream(device).synchronize()         # the engine reads them on its own stream
     return g_chars, g_lens, sum(counts[:rank])
+
+
+class GatheredExchange:
+    """The exchange as ONE collective per step (RCCL all-gather of fixed-size device buffers).  The engine's seed
+    scan leaves the rank's distinct list in its send buffer; step() all-gathers it and merges on the device.
+    The row capacity adapts: when some rank's list does not fit (every rank learns that from the gathered
+    headers) the buffers are enlarged and the caller repeats the seed scan."""
+
+    def __init__(self, eng, dist, device, cap_rows=16384):
+        self.eng, self.dist, self.device = eng, dist, device
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self._setup(cap_rows)
+
+    def _setup(self, cap_rows):
+        import torch
+        self.cap_rows = int(cap_rows)
+        ptr, nbytes = self.eng.exchange_setup(self.world, self.rank, self.cap_rows)
+        self.send = torch.as_tensor(_DevView(ptr, (nbytes,), "|u1"), device=self.device)
+        self.recv = torch.empty((self.world * nbytes,), dtype=torch.uint8, device=self.device)
+
+    def step(self):
+        """after eng.seed_scan(): True when merged, False when the capacity was raised (repeat the seed scan)"""
+        import torch
+        self.dist.all_gather_into_tensor(self.recv, self.send)
+        torch.cuda.current_stream(self.device).synchronize()         # the engine reads recv on its own stream
+        need = self.eng.merge_gathered(self.recv.data_ptr(), fetch=False)
+        if need is None:
+            return True
+        cap = self.cap_rows
+        while cap < need * 2:
+            cap *= 2
+        self._setup(cap)
+        return False

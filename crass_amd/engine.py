@@ -381,6 +381,21 @@ class SearchEngine:
                                                       int(my_offset)), "crass_hip_merge_distinct_device")
         return self.merge_view() if fetch else None
 
+    def exchange_setup(self, world, rank, cap_rows):
+        """one-collective exchange: returns (device pointer of the send buffer, its size in bytes)"""
+        x = _abi.Exchange()
+        _chk(self.lib.crass_hip_exchange_setup(self.h, int(world), int(rank), int(cap_rows), C.byref(x)), "crass_hip_exchange_setup")
+        return int(x.d_send), int(x.send_bytes)
+
+    def merge_gathered(self, d_recv_ptr, fetch=True):
+        """merge from the all-gathered send buffers (device pointer).  Returns None, or the number of rows the
+        exchange needs when some rank's list did not fit (set up again, repeat seed scan + collective)."""
+        st = self.lib.crass_hip_merge_gathered(self.h, C.c_void_p(d_recv_ptr))
+        if st == _abi.ERR_OVERFLOW:
+            return int(self.lib.crass_hip_exchange_needed_rows(self.h))
+        _chk(st, "crass_hip_merge_gathered")
+        return self.merge_view() if fetch else None
+
     def merge_view(self):
         v = _abi.MergeView()
         _chk(self.lib.crass_hip_get_merge(self.h, C.byref(v)), "crass_hip_get_merge")

@@ -169,6 +169,23 @@ int crass_hip_get_distinct_device(crass_hip_ctx *ctx, crass_distinct_dev *out);
 int crass_hip_merge_distinct_device(crass_hip_ctx *ctx, const char *d_chars, const uint16_t *d_len, uint32_t dr_stride,
                                     uint64_t n_global, uint64_t my_offset);
 
+/* One-collective form of the exchange.  After crass_hip_exchange_setup every seed scan leaves this rank's
+ * distinct list in a fixed-size device buffer: row 0 = header {uint64 n_distinct, uint32 stride, uint32
+ * rows}, then `cap_rows` slots of `slot_bytes` (DR bytes, zero padded, then the uint16 length).  The caller
+ * all-gathers that buffer (ncclAllGather / torch all_gather_into_tensor: world * send_bytes) and hands the
+ * result to crass_hip_merge_gathered, which compacts, de-duplicates and merges on the device.
+ * CRASS_ERR_OVERFLOW: some rank had more than cap_rows strings (every rank sees that in the headers) —
+ * set up again with crass_hip_exchange_needed_rows() rows, repeat the seed scan and the collective.       */
+typedef struct {
+    void    *d_send;              /* device pointer, send_bytes bytes, owned by the context              */
+    uint64_t send_bytes;          /* (cap_rows + 1) * slot_bytes                                          */
+    uint32_t slot_bytes;
+    uint64_t cap_rows;
+} crass_exchange;
+int crass_hip_exchange_setup(crass_hip_ctx *ctx, uint32_t world, uint32_t rank, uint64_t cap_rows, crass_exchange *out);
+int crass_hip_merge_gathered(crass_hip_ctx *ctx, const void *d_recv);
+uint64_t crass_hip_exchange_needed_rows(const crass_hip_ctx *ctx);
+
 typedef struct {
     uint32_t        n_tokens;     /* StringCheck size; tokens are 2 .. n_tokens+1                 */
     const char     *tok_chars;    /* token t string = tok_chars[tok_off[t-2] .. tok_off[t-1])     */

@@ -182,6 +182,28 @@ n1, n2 = ref.n_pass1, ref.n_pass2
 assert views[0].cand_token.tolist() + views[1].cand_token.tolist() == ref.rec_token[:n1].tolist()
 assert recs[0].read_idx.tolist() + recs[1].read_idx.tolist() == ref.rec_read[n1:n1 + n2].tolist()
 assert recs[0].token.tolist() + recs[1].token.tolist() == ref.rec_token[n1:n1 + n2].tolist()
+# one-collective form: the engines' send buffers, concatenated as the all-gather delivers them
+from crass_amd.distributed import _DevView
+def gathered(cap):
+    xs = [engs[r].exchange_setup(2, r, cap) for r in range(2)]
+    for r in range(2):
+        engs[r].seed_scan()
+    bufs = [torch.as_tensor(_DevView(p_, (nb_,), "|u1"), device="cuda") for p_, nb_ in xs]
+    recv = torch.cat(bufs).contiguous()
+    torch.cuda.synchronize()
+    return recv
+recv = gathered(4096)
+for r in range(2):
+    v2 = engs[r].merge_gathered(recv.data_ptr())
+    assert not isinstance(v2, int) and engs[r].counters()["used_device_merge"] == 1
+    r2 = engs[r].recruit()
+    v2 = engs[r].merge_view()
+    assert v2.tokens == views[r].tokens and v2.groups == views[r].groups and v2.patterns == views[r].patterns
+    assert v2.cand_token.tolist() == views[r].cand_token.tolist()
+    assert r2.read_idx.tolist() == recs[r].read_idx.tolist() and r2.token.tolist() == recs[r].token.tolist()
+recv = gathered(64)                                  # far too few rows: every rank must report the same need
+need = [engs[r].merge_gathered(recv.data_ptr()) for r in range(2)]
+assert isinstance(need[0], int) and need[0] == need[1] == max(len(lists[0][1]), len(lists[1][1]))
 for e in engs:
     e.close()
 print("OK")
@@ -209,7 +231,7 @@ import os, sys, json
 sys.path.insert(0, %r)
 import numpy as np, torch, torch.distributed as dist
 import crass_amd as ca
-from crass_amd.distributed import allgather_distinct_device
+from crass_amd.distributed import allgather_distinct_device, GatheredExchange
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 n, L = 300000, 150
@@ -229,6 +251,18 @@ assert c1["used_device_merge"] == 1 and c2["used_device_merge"] == 1
 assert (c1["n_pass1_found"], c1["n_pass2_found"], c1["n_patterns"]) == (c2["n_pass1_found"], c2["n_pass2_found"], c2["n_patterns"])
 assert v1.tokens == v2.tokens and v1.groups == v2.groups and v1.patterns == v2.patterns
 assert c1["n_pass2_found"] > 0
+# bench.py's form: one collective per step; the capacity starts too small on purpose
+xg = GatheredExchange(eng, dist, torch.device("cuda", 0), cap_rows=128)
+tries = 0
+eng.seed_scan(fetch=False)
+while not xg.step():
+    tries += 1
+    eng.seed_scan(fetch=False)
+assert tries == 1 and xg.cap_rows >= len(v1.tokens)
+eng.recruit(fetch=False)
+c3 = eng.counters(); v3 = eng.merge_view()
+assert c3["used_device_merge"] == 1 and v3.tokens == v1.tokens and v3.patterns == v1.patterns
+assert (c3["n_pass1_found"], c3["n_pass2_found"]) == (c1["n_pass1_found"], c1["n_pass2_found"])
 dist.destroy_process_group()
 print("OK")
 """ % ROOT
