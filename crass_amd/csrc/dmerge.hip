@@ -76,26 +76,38 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M.n_tok) return;
-    const char *p = M.dx_chars + (uint64_t)t * M.stride;
     const uint32_t len = M.dx_len[t];
-    if (len > 64 || len < 23) { atomicOr(&M.st->fail, 1u); return; }
+    if (len > 64 || len < 23 || M.stride > 64) { atomicOr(&M.st->fail, 1u); return; }
+    // the whole slot in registers (16-byte loads), then a fully unrolled walk: every register index is static
+    uint32_t w[16];
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(M.dx_chars + (uint64_t)t * M.stride);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint4 v; v.x = v.y = v.z = v.w = 0;
+        if ((uint32_t)q * 16 < M.stride) v = p4[q];
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
     uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
     uint32_t fwd = 0, rev = 0;
     bool bad = false;
-    for (uint32_t i = 0; i < len; i++) {
-        const char ch = p[i];
-        uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;
-        if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') bad = true;
-        if (i < 32) f0 |= (uint64_t)c << (2 * i); else f1 |= (uint64_t)c << (2 * (i - 32));
-        const uint32_t j = len - 1 - i;
-        if (j < 32) r0 |= (uint64_t)(3u - c) << (2 * j); else r1 |= (uint64_t)(3u - c) << (2 * (j - 32));
-        // first base most significant: integer order == lexicographic order, laurenize() == min (SeqUtils.cpp:89-97)
-        fwd = ((fwd << 2) | c) & 0x3FFFFFu;
-        rev = (rev >> 2) | ((3u - c) << 20);
-        if (i + 1 >= (uint32_t)kClusterK) {
-            const uint32_t code = fwd < rev ? fwd : rev;
-            M.codes[(uint64_t)t * M.kmax + (i + 1 - kClusterK)] = code;
-            atomicMin(&M.owner[code], t);
+    uint32_t *codes = M.codes + (uint64_t)t * M.kmax;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if ((uint32_t)i < len) {
+            const uint32_t ch = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;
+            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') bad = true;
+            if (i < 32) f0 |= (uint64_t)c << (2 * (i & 31)); else f1 |= (uint64_t)c << (2 * (i & 31));
+            const uint32_t j = len - 1 - i;
+            if (j < 32) r0 |= (uint64_t)(3u - c) << (2 * j); else r1 |= (uint64_t)(3u - c) << (2 * (j - 32));
+            // first base most significant: integer order == lexicographic order, laurenize() == min (SeqUtils.cpp:89-97)
+            fwd = ((fwd << 2) | c) & 0x3FFFFFu;
+            rev = (rev >> 2) | ((3u - c) << 20);
+            if (i + 1 >= kClusterK) {
+                const uint32_t code = fwd < rev ? fwd : rev;
+                codes[i + 1 - kClusterK] = code;
+                atomicMin(&M.owner[code], t);
+            }
         }
     }
     uint64_t *pk = M.packed + (uint64_t)t * 4;
@@ -106,13 +118,13 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
 // ---- 2. the greedy, order-dependent group assignment (clusterDRReads) ----
 // One wave per token; wave w of W takes tokens w, w+W, ...  A wave only ever waits for tokens with a
 // smaller index, i.e. for a wave that is in the same or an earlier round, so with all W waves resident
-// (the grid is at most one 256-thread block per CU) the smallest undecided token can always finish.
+// (the grid is at most one block per CU) the smallest undecided token can always finish.
 // Lane q owns the token's q-th k-mer: if an EARLIER token owns that k-mer the lane fetches that token's
 // root (the first token of its group); the reference's scan ("first group whose count reaches
 // kmer_clust_size on a repeated sighting", :1573-1590) is then a prefix count across lanes.  root_of[]
 // words are their own flags: written once with an agent-scope store, polled with agent-scope loads
 // (8 XCDs, private L2s).  Every spin is bounded: on a time-out the fail word is set and the host merges.
-__global__ __launch_bounds__(256) void k_dm_greedy(DevMerge M)
+__global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256) void k_dm_greedy(DevMerge M)
         bool valid = false;
         uint32_t o = 0;
         if (lane < nk) {
-            o = M.owner[M.codes[(uint64_t)t * M.kmax + lane]];
+            o = M.owner[M.codes[(uint64_t)t * M.kmax + lane] & 0x3FFFFFu];
             valid = o < t;                      // o == t: homeless k-mer (first seen in this token), not counted
         }
         uint32_t r = valid ? kUnres : kNoLane;
@@ -156,8 +168,9 @@ __global__ __launch_bounds__(256) void k_dm_greedy(DevMerge M)
 }
 
 // exclusive scan of n uint32 (n known on the host), one workgroup; *total = sum
-__global__ __launch_bounds__(1024) void k_dm_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *total)
+__global__ __launch_bounds__(1024) void k_dm_scan(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n, uint32_t *total)
 {
+    if (d_n && *d_n + 1u < n) n = *d_n + 1u;            // per-group arrays: only the first n_groups (+1) entries are live
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_sh;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -196,22 +209,53 @@ __global__ __launch_bounds__(256) void k_dm_flag_roots(DevMerge M)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < M.n_tok) M.tmp[t] = (M.root_of[t] == t) ? 1u : 0u;
 }
-__global__ __launch_bounds__(256) void k_dm_gid(DevMerge M)
+// Group sizes and member order.  A few large groups would serialise ~n_tok atomics on a few addresses, so up to
+// kLdsGroups groups are first counted per block in LDS and only the block totals go to memory.
+#define kLdsGroups 4096
+__global__ __launch_bounds__(1024) void k_dm_gid(DevMerge M)
 {
+    __shared__ uint32_t cnt[kLdsGroups];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M.n_tok) return;
-    const uint32_t g = M.root_rank[M.root_of[t]];
-    M.gid_of[t] = g + 1;
-    atomicAdd(&M.grp_cnt[g], 1u);
+    const uint32_t ng = M.st->n_groups;
+    const bool lds = ng <= kLdsGroups;
+    if (lds) {
+        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) cnt[i] = 0;
+        __syncthreads();
+    }
+    if (t < M.n_tok) {
+        const uint32_t g = M.root_rank[M.root_of[t]];
+        M.gid_of[t] = g + 1;
+        if (lds) atomicAdd(&cnt[g], 1u); else atomicAdd(&M.grp_cnt[g], 1u);
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint32_t c = cnt[i]; if (c) atomicAdd(&M.grp_cnt[i], c); }
+    }
 }
 // members[] = tokens ordered by group (order inside a group is irrelevant: it only makes the lanes of
 // a wave walk the same member range below)
-__global__ __launch_bounds__(256) void k_dm_scatter(DevMerge M)
+__global__ __launch_bounds__(1024) void k_dm_scatter(DevMerge M)
 {
+    __shared__ uint32_t cnt[kLdsGroups];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M.n_tok) return;
-    const uint32_t g = M.gid_of[t] - 1;
-    M.members[M.grp_off[g] + atomicAdd(&M.grp_fill[g], 1u)] = t;
+    const uint32_t ng = M.st->n_groups;
+    const bool lds = ng <= kLdsGroups;
+    if (lds) {
+        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) cnt[i] = 0;
+        __syncthreads();
+    }
+    uint32_t g = 0, rank = 0;
+    if (t < M.n_tok) {
+        g = M.gid_of[t] - 1;
+        rank = lds ? atomicAdd(&cnt[g], 1u) : atomicAdd(&M.grp_fill[g], 1u);
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint32_t c = cnt[i]; cnt[i] = c ? atomicAdd(&M.grp_fill[i], c) : 0u; }
+        __syncthreads();
+        if (t < M.n_tok) rank += cnt[g];
+    }
+    if (t < M.n_tok) M.members[M.grp_off[g] + rank] = t;
 }
 
 // ---- 4. removeRedundantRepeats: a member is dropped iff a strictly shorter member of its group, or
@@ -588,14 +632,16 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     const unsigned nb = (M.n_tok + 255) / 256;
     hipLaunchKernelGGL(k_dm_init, dim3(1024), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_pack_codes, dim3(nb), dim3(256), 0, st, M);
-    unsigned gb = (M.n_tok + 3) / 4;
-    if (gb > 256) gb = 256;                 // every wave must be resident: at most one small block per CU
-    hipLaunchKernelGGL(k_dm_greedy, dim3(gb), dim3(256), 0, st, M);
+    // every wave must be resident: at most one block per CU (16 waves of the CU's 32 wave slots, no LDS)
+    unsigned gb = (M.n_tok + 15) / 16;
+    if (gb > M.n_cu) gb = M.n_cu;
+    hipLaunchKernelGGL(k_dm_greedy, dim3(gb), dim3(1024), 0, st, M);
     hipLaunchKernelGGL(k_dm_flag_roots, dim3(nb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.tmp, M.root_rank, M.n_tok, &M.st->n_groups);
-    hipLaunchKernelGGL(k_dm_gid, dim3(nb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.grp_cnt, M.grp_off, M.n_tok, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(k_dm_scatter, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.tmp, M.root_rank, M.n_tok, (const uint32_t *)nullptr, &M.st->n_groups);
+    const unsigned nb4 = (M.n_tok + 1023) / 1024;
+    hipLaunchKernelGGL(k_dm_gid, dim3(nb4), dim3(1024), 0, st, M);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.grp_cnt, M.grp_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_dm_scatter, dim3(nb4), dim3(1024), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_keys, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_fill, dim3(nb), dim3(256), 0, st, M);
@@ -603,7 +649,7 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_sblank, dim3(nb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok, &M.st->n_survivors);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, &M.st->n_survivors);
     hipLaunchKernelGGL(k_dm_patterns, dim3(nb), dim3(256), 0, st, M);
     const unsigned ne = (16u * M.n_tok + 255) / 256;
     hipLaunchKernelGGL(k_dm_keys, dim3(ne), dim3(256), 0, st, M);

@@ -16,6 +16,9 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -27,6 +30,58 @@ double now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// One helper thread per context: rebuilds the host view of a device-side merge while the calling thread keeps
+// the device fed (pass 2).  submit() hands over one job; wait() returns when it has finished.
+class HostWorker {
+public:
+    ~HostWorker() { stop(); }
+    void submit(std::function<void()> job)
+    {
+        wait();
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (!started_) { th_ = std::thread([this] { loop(); }); started_ = true; }
+            job_ = std::move(job); busy_ = true;
+        }
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return !busy_; });
+    }
+    void stop()
+    {
+        if (!started_) return;
+        wait();
+        { std::lock_guard<std::mutex> lk(m_); quit_ = true; }
+        cv_.notify_all();
+        th_.join();
+        started_ = false;
+    }
+private:
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { return quit_ || (busy_ && job_); });
+                if (quit_) return;
+                job = std::move(job_); job_ = nullptr;
+            }
+            job();
+            { std::lock_guard<std::mutex> lk(m_); busy_ = false; }
+            cv_.notify_all();
+        }
+    }
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, quit_ = false, started_ = false;
+};
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -139,6 +194,8 @@ struct crass_hip_ctx {
     PinBuf<uint32_t> h_dmap; PinBuf<char> h_dx_chars; PinBuf<uint16_t> h_dx_len; PinBuf<uint64_t> h_dx_hash;
     uint64_t n_dx = 0;
     bool have_dev_tokens = false;
+    uint32_t n_cu = 0;
+    HostWorker worker;
     uint64_t surv_cap_hint = 0;               // speculative survivor bound for the next seed scan (0: none yet)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gathered = nullptr;
@@ -175,6 +232,8 @@ struct crass_hip_ctx {
         PinBuf<DevMergeState> h_st; PinBuf<uint32_t> h_gid; PinBuf<uint8_t> h_blank;
         DevMerge M{};
         bool active = false, host_built = false;
+        int build_status = 0;                       // result of the host-view build that runs on `worker`
+        bool build_pending = false;
         uint64_t n_cand = 0;
         // what the host view is rebuilt from: the distinct list (pinned host copy) and every own candidate's index in it
         const char *hx_chars = nullptr; const uint16_t *hx_len = nullptr; uint64_t n_tok = 0;
@@ -257,6 +316,12 @@ void crass_hip_ctx::widen_p1() const
     D.wide_ready = true;
 }
 
+// the helper thread owns c->merge while a host-view build is in flight: wait for it before touching that state
+static void quiesce_worker(crass_hip_ctx *c)
+{
+    if (c->dm.build_pending) { c->worker.wait(); c->dm.build_pending = false; }
+}
+
 #define HIPCHK(ctx, call)                                                       \
     do {                                                                        \
         hipError_t e__ = (call);                                                \
@@ -336,6 +401,8 @@ void crass_hip_destroy(crass_hip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    quiesce_worker(c);
+    c->worker.stop();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     c->dm.release(); c->h_qblob.release(); c->xchg.send.release(); c->xchg.xinfo.release(); c->xchg.h_xinfo.release();
@@ -385,6 +452,7 @@ static int alloc_scratch(crass_hip_ctx *c)
 
 static void reset_results(crass_hip_ctx *c)
 {
+    quiesce_worker(c);
     c->have_pass1 = c->have_merge = c->have_pass2 = c->have_patterns = false;
     c->dm.active = false;
     memset(&c->cnt, 0, sizeof(c->cnt));
@@ -693,6 +761,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     if (!c->have_reads) return CRASS_ERR_STATE;
     (void)hipSetDevice(c->device);
     c->wait_bulk();
+    quiesce_worker(c);
     c->have_pass1 = c->have_merge = c->have_pass2 = false;
     c->dm.active = false;
     const uint64_t n = c->R.n_reads;
@@ -877,6 +946,7 @@ static int install_patterns(crass_hip_ctx *c, const StringArena &pats)
 {
     c->n_installed_patterns = (uint32_t)pats.size();
     c->have_patterns = false;
+    quiesce_worker(c);
     c->dm.active = false;                               // the installed set is the host-built one from here on
     c->cnt.n_patterns = (uint32_t)pats.size();
     if (pats.empty()) { c->cnt.ac_states = 0; return CRASS_OK; }
@@ -950,6 +1020,7 @@ static int ensure_full_automaton(crass_hip_ctx *c)
 }
 
 static int finish_merge(crass_hip_ctx *c, double t0);
+static int build_host_merge(crass_hip_ctx *c);
 
 // ---- the merge on the device (dmerge.hip) ----
 static bool device_merge_applies(const crass_hip_ctx *c)
@@ -997,6 +1068,12 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     M.sblank = d.sblank.p;
     M.rset_key = d.rset_key.p; M.rset_cnt = d.rset_u32.p; M.rset_base = d.rset_u32.p + ((size_t)1 << M.rset_log);
     M.rset_fill = d.rset_u32.p + ((size_t)2 << M.rset_log); M.rd_slot = d.rd_slot.p; M.rents = d.rents.p;
+    if (!c->n_cu) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || v <= 0) v = 64;
+        c->n_cu = (uint32_t)v;
+    }
+    M.n_cu = c->n_cu;
     M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
     d.M = M;
     const double tl0 = now_ms();
@@ -1010,6 +1087,9 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     HIPCHK(c, launch_dm_export(M, d.h_st.p, d.h_gid.p, d.h_blank.p, c->stream));
     HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
     d.active = true; d.host_built = false; d.n_cand = c->dense.n;
+    // the host view (tokens, groups, pattern list) is rebuilt by the helper thread as soon as the kernels are through
+    d.build_pending = true;
+    c->worker.submit([c] { c->dm.build_status = build_host_merge(c); });
     c->have_merge = true; c->have_pass2 = false;
     c->have_patterns = true; c->have_anchors = false; c->have_pat_token = false;
     c->n_installed_patterns = 2;                                  // >= 1 survivor exists; the exact count arrives with h_st
@@ -1022,6 +1102,7 @@ static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint1
 
 static int host_merge_fallback(crass_hip_ctx *c)
 {
+    quiesce_worker(c);
     c->dm.active = false;
     const double t0 = now_ms();
     if (c->dm.global) {
@@ -1040,10 +1121,25 @@ static int host_merge_fallback(crass_hip_ctx *c)
 }
 
 // c->merge for a merge that ran on the device: 0 ok, CRASS_ERR_STATE = the device path failed (caller falls back)
+static int build_host_merge(crass_hip_ctx *c);
+
 static int ensure_host_merge(crass_hip_ctx *c)
 {
     crass_hip_ctx::DM &d = c->dm;
+    if (d.build_pending) {                              // started by the merge call on the helper thread
+        c->worker.wait();
+        d.build_pending = false;
+        if (d.build_status == CRASS_ERR_HIP || d.build_status == CRASS_ERR_OOM) return d.build_status;
+        if (d.build_status == CRASS_ERR_STATE) return CRASS_ERR_STATE;
+    }
+    return build_host_merge(c);
+}
+
+static int build_host_merge(crass_hip_ctx *c)
+{
+    crass_hip_ctx::DM &d = c->dm;
     if (!d.active || d.host_built) return CRASS_OK;
+    (void)hipSetDevice(c->device);
     HIPCHK(c, hipEventSynchronize(d.ev_done));
     if (d.h_st.p->fail) return CRASS_ERR_STATE;
     const uint32_t *cmap = c->h_dmap.p;
@@ -1070,6 +1166,7 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
 {
     if (!c) return CRASS_ERR_INVALID_ARG;
     const double t0 = now_ms();
+    quiesce_worker(c);
     c->dm.active = false;
     c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
     if (!dr_chars && device_merge_applies(c)) {
@@ -1231,6 +1328,7 @@ int crass_hip_merge_distinct(crass_hip_ctx *c, const char *dr_chars, const uint1
     if (!c || (n_global && (!dr_chars || !dr_len || !dr_stride))) return CRASS_ERR_INVALID_ARG;
     if (!c->have_pass1) return CRASS_ERR_STATE;
     const double t0 = now_ms();
+    quiesce_worker(c);
     c->dm.active = false;
     c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
     (void)hipSetDevice(c->device);
@@ -1270,6 +1368,7 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     const double t0 = now_ms();
     crass_hip_ctx::Xchg &X = c->xchg;
     crass_hip_ctx::DM &d = c->dm;
+    quiesce_worker(c);
     d.active = false;
     c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
     (void)hipSetDevice(c->device);
@@ -1333,6 +1432,7 @@ int crass_hip_merge_distinct_device(crass_hip_ctx *c, const char *d_chars, const
     if (!c->have_pass1) return CRASS_ERR_STATE;
     if (dr_stride != c->dr_stride) return CRASS_ERR_INVALID_ARG;
     const double t0 = now_ms();
+    quiesce_worker(c);
     c->dm.active = false;
     c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
     (void)hipSetDevice(c->device);
@@ -1417,6 +1517,10 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     bool anchors = false, lds = false;
     const bool dmp = c->dm.active;                  // pattern set built on the device (dmerge.hip)
     if (dmp) {
+        // the pass-1 hand-off records leave next to the filter (not next to the merge kernels queued ahead of it)
+        if (c->bulk_needed) {
+            HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
+        }
         HIPCHK(c, launch_anchor_filter_dev(c->R, c->dm.M, c->d_found.p, c->d_mask.p, c->stream));
         anchors = true;
         c->issue_bulk();

@@ -134,6 +134,7 @@ struct DevMerge {
     uint32_t *anchor_fp;          // [1 << 15] words = 2^16 16-bit fingerprints of the slots' keys (tab_mode 3)
     uint32_t tab_log_alloc;
     uint32_t s1, s2, m1, m2;      // hash constants of the table
+    uint32_t n_cu;                // compute units of the device (bounds the grid of the kernel whose waves wait for each other)
     DevMergeState *st;
 };
 
