@@ -1565,7 +1565,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const bool dev_tokens = dmp || (anchors && c->have_pat_token && c->have_merge);
     HIPCHK(c, launch_recruit_finish(c->R, c->d_idx.p, c->d_count.p, n_hits, anchors ? c->d_slot_info.p : c->d_hit_info.p, anchors, false,
                                     dev_tokens ? c->d_slot_pid.p : nullptr, dev_tokens ? (dmp ? c->dm.M.pat_token : c->a_pat_token.p) : nullptr,
-                                    c->d_rec.p, c->d_dr.p, c->dr_stride, c->stream));
+                                    c->d_rec.p, (dmp && c->R.n_exc == 0) ? nullptr : c->d_dr.p, c->dr_stride, c->stream));
     if (c->R.n_exc)
         HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, c->R.n_exc, c->d_exc_hit.p, true, true, nullptr, nullptr, c->d_rec.p + n_hits,
                                         c->d_dr.p + n_hits * c->dr_stride, c->dr_stride, c->stream));

@@ -2065,6 +2065,54 @@ __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64
     uint32_t DR_end = textpos - 1;
     if (DR_end >= L) DR_end = L - 1;
     uint32_t start = DR_end - (len - 1);
+    if (!EXC && len <= 64) {
+        // packed reads: the repeat as a 128-bit value (base i in bits 2i..2i+1), its reverse complement by bit
+        // reversal, and DRLowLexi's string comparison as "first differing base from the low end"
+        const uint32_t nw = (L + 15) >> 4, w0 = start >> 4, sh = (start & 15u) * 2u;
+        uint32_t x[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) x[q] = (w0 + q < nw) ? g[w0 + q] : 0u;
+        uint32_t y[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) y[q] = sh ? ((x[q] >> sh) | (x[q + 1] << (32 - sh))) : x[q];
+        uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
+        const uint64_t m0 = len >= 32 ? ~0ull : ((1ull << (2 * len)) - 1ull);
+        const uint64_t m1 = len >= 64 ? ~0ull : (len > 32 ? ((1ull << (2 * (len - 32))) - 1ull) : 0ull);
+        v0 &= m0; v1 &= m1;
+        auto rev2 = [](uint64_t t) -> uint64_t {          // reverse the order of the 32 two-bit groups
+            t = __brevll(t);
+            return ((t >> 1) & 0x5555555555555555ull) | ((t & 0x5555555555555555ull) << 1);
+        };
+        // complement, reverse all 64 groups of the 128-bit value, then shift the len groups down to bit 0
+        const uint64_t c0 = rev2(~v1), c1 = rev2(~v0);     // (c1:c0) = reversed 128 bits
+        const uint32_t drop = 128u - 2u * len;             // unused high groups became low groups
+        uint64_t r0, r1;
+        if (drop == 0) { r0 = c0; r1 = c1; }
+        else if (drop < 64) { r0 = (c0 >> drop) | (c1 << (64 - drop)); r1 = c1 >> drop; }
+        else { r0 = c1 >> (drop - 64); r1 = 0; }
+        r0 &= m0; r1 &= m1;
+        int less = 0;
+        const uint64_t d0 = v0 ^ r0, d1 = v1 ^ r1;
+        if (d0 | d1) {
+            const uint64_t dv = d0 ? d0 : d1, av = d0 ? v0 : v1, bv = d0 ? r0 : r1;
+            const int p = (__ffsll((unsigned long long)dv) - 1) & ~1;
+            less = ((av >> p) & 3ull) < ((bv >> p) & 3ull);
+        }
+        const uint64_t s0 = less ? v0 : r0, s1 = less ? v1 : r1;
+        if (dr_chars) {
+            char *dr = dr_chars + k * (uint64_t)dr_stride;
+            for (uint32_t i = 0; i < dr_stride; i++) {
+                const uint32_t c = (uint32_t)(((i < 32 ? s0 : s1) >> (2 * (i & 31))) & 3ull);
+                dr[i] = i < len ? "ACGT"[c] : (char)0;
+            }
+        }
+        if (less) { o.start = start; o.end = DR_end; o.low_lexi = 1; }
+        else { o.start = L - 1 - DR_end; o.end = L - 1 - start; o.low_lexi = 0; }
+        o.dr_len = (uint16_t)len;
+        if (pid_by_slot && pat_token) o.token = pat_token[pid_by_slot[k]];
+        out[k] = o;
+        return;
+    }
     auto base_at = [&](uint32_t i) -> uint8_t {
         if (EXC) return R.exc_bytes[o0 + i];
         uint32_t c = (g[i >> 4] >> ((i & 15u) * 2u)) & 3u;
