@@ -3,10 +3,11 @@
 
 One "step" = one pass of the whole hot path over one resident batch of synthetic reads:
 pass 1 (seed scan + extend + QC, crass searchFile/searchCore) -> DR merge
-(createNonRedundantSet; with N>1 ranks preceded by an RCCL all-gather of the candidate DR
-strings) -> pass 2 (multi-pattern recruit, findSingletons).  Packed reads are already
-resident in HBM when the timed region starts; the timed region ends with the ordered
-candidate / recruit records in host memory.
+(createNonRedundantSet, on the device; with N>1 ranks preceded by ONE RCCL all-gather of
+every rank's distinct candidate DR strings) -> pass 2 (multi-pattern recruit,
+findSingletons).  Packed reads are already resident in HBM when the timed region starts;
+the timed region ends with the ordered candidate / recruit records, tokens, groups and
+pattern list in host memory.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -173,7 +174,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(cands[dom], 4),
-                "per_kernel": per_kernel, "host_ms": {"merge": round(avg["ms_merge_host"], 3), "sink": round(avg["ms_sink_host"], 3)}}
+                "per_kernel": per_kernel, "host_ms": {"merge": round(avg["ms_merge_host"], 3), "sink": round(avg["ms_sink_host"], 3)},
+                "merge_device_ms": round(float(c.get("ms_merge_device", 0.0)), 4), "device_merge": int(c.get("used_device_merge", 0))}
 
     out = {
         "metric": "reads/sec through DR search+recruit, 150bp synthetic, 1/2/4/8 MI355X",
