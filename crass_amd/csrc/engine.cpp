@@ -196,7 +196,9 @@ struct crass_hip_ctx {
     bool have_dev_tokens = false;
     uint32_t n_cu = 0;
     HostWorker worker;
-    uint64_t surv_cap_hint = 0;               // speculative survivor bound for the next seed scan (0: none yet)
+    uint64_t surv_cap_hint = 0;
+    uint64_t hit_cap_hint = 0;                // speculative bound for pass 2's flagged reads (0: none yet)
+    bool recruit_exact = false;               // the next recruit call must not speculate (it repeats an overflowed one)               // speculative survivor bound for the next seed scan (0: none yet)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gathered = nullptr;
     mutable bool bulk_pending = false;          // copy in flight on copy_stream
@@ -1543,13 +1545,18 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (dmp && c->dm.h_st.p->fail) {                // the device merge gave up: host merge, then pass 2 again
+    // Speculative tail (device merge path): verification, finish and the hand-off pack are launched with the hit
+    // count still on the device, sized by a bound learnt from the previous call; the exact count arrives with the
+    // final synchronisation, and a bound that was too small repeats the tail with the exact count.
+    const bool spec = dmp && c->R.n_exc == 0 && c->hit_cap_hint && !getenv("CRASS_NO_SPECULATION") && !c->recruit_exact;
+    c->recruit_exact = false;
+    if (!spec) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!spec && dmp && c->dm.h_st.p->fail) {       // the device merge gave up: host merge, then pass 2 again
         const int fs = host_merge_fallback(c);
         if (fs) return fs;
         return crass_hip_recruit(c, extra_found, n_extra);
     }
-    const uint64_t n_hits = c->h_count.p[0];
+    const uint64_t n_hits = spec ? c->hit_cap_hint : c->h_count.p[0];
     const uint64_t n_slots = n_hits + c->R.n_exc;
     HIPCHK(c, c->d_rec.ensure(n_slots + 1));
     HIPCHK(c, c->d_dr.ensure((n_slots + 1) * c->dr_stride));
@@ -1594,6 +1601,22 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         }
         if (hs) return hs;
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (spec) {
+            if (c->dm.h_st.p->fail) {                   // the device merge gave up: host merge, then pass 2 again
+                const int fs = host_merge_fallback(c);
+                if (fs) return fs;
+                return crass_hip_recruit(c, extra_found, n_extra);
+            }
+            if (c->h_count.p[0] > n_hits) {             // bound too small: repeat with the exact count
+                c->hit_cap_hint = 0;
+                c->recruit_exact = true;
+                return crass_hip_recruit(c, extra_found, n_extra);
+            }
+        }
+        {
+            const uint64_t real = c->h_count.p[0];
+            c->hit_cap_hint = std::max<uint64_t>(4096, (real + real / 2 + 4095) & ~4095ull);
+        }
         c->q_n = *reinterpret_cast<const uint64_t *>(c->h_qblob.p);
         c->q_blob_active = true;
         c->have_pass2 = true;
