@@ -1,6 +1,9 @@
 // crass_adapter.cpp — the reference's seam (searchFile / createNonRedundantSet / findSingletons /
 // addReadHolder) implemented over the C ABI of libcrass_hip.so.  See crass_adapter.h.
 #include "crass_adapter.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdlib>
@@ -99,19 +102,27 @@ FileState &open_file(const char *path, const options &opts)
     auto it = s.find(path);
     if (it != s.end()) return *it->second;
     std::unique_ptr<FileState> f(new FileState());
+    const bool timing = getenv("CRASS_TIMING") != nullptr;          // stage times of the ingest side
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     int rc = crass_read_fastx(path, &f->fx);
+    const double t1 = now();
     if (rc == CRASS_ERR_IO) {
         // getFileHandle prints and exit(1)s (SeqUtils.cpp:112-124); a library throws instead
         CRASS_THROW(std::string("Could not open FASTQ ") + path + " for reading.");
     }
     chk(rc, "crass_read_fastx");
     chk(crass_pack_reads(f->fx.seq, f->fx.seq_off, f->fx.n_reads, 0, &f->pk), "crass_pack_reads");
+    const double t2 = now();
     for (uint64_t i = 0; i < f->fx.n_reads; i++) if (f->fx.header_id[i] != i) { f->unique_headers = false; break; }
     crass_params p = to_params(opts);
     chk(crass_hip_create(&p, device(), &f->ctx), "crass_hip_create");
     crass_reads r = f->pk.reads;
     r.header_id = f->unique_headers ? nullptr : f->fx.header_id;
     chk(crass_hip_load_reads(f->ctx, &r), "crass_hip_load_reads");
+    if (timing)
+        fprintf(stderr, "[crass_timing] %s: %llu reads; read+parse %.3f s, 2-bit pack %.3f s, context + H2D %.3f s\n", path,
+                (unsigned long long)f->fx.n_reads, t1 - t0, t2 - t1, now() - t2);
     FileState &ref = *f;
     s[path] = std::move(f);
     return ref;

@@ -4,6 +4,8 @@
 #include "../../include/crass_hip.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -120,106 +122,322 @@ void crass_free_packed(crass_packed *p)
 }
 
 // ---- FASTA/FASTQ reader: kseq_read record semantics (kseq.cpp:171-226) as driven by
-// searchFile (libcrispr.cpp:96-131).  The whole (decompressed) file is parsed from memory.
+// searchFile (libcrispr.cpp:96-131).  The whole (decompressed) file is parsed from memory, in parallel:
+// the buffer is cut at guessed record starts, every piece is parsed by the same byte-exact state machine, and
+// the pieces are accepted only if each one ends exactly where the next one began (otherwise — odd layouts,
+// truncated files — the file is parsed again in one piece).  The reference's reader is single-threaded and
+// byte-at-a-time; on the 800 MB / 5 M-read FASTA of tools/e2e_cli.sh it was 99 % of the wall time.
 static bool is_space(int c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+
+namespace {
+
+struct FxChunk {
+    std::vector<uint8_t> seq, name, comment, qual;                      // concatenated fields of the records parsed here
+    std::vector<uint64_t> seq_end, name_end, comment_end, qual_end;     // local end offsets per record
+    std::vector<uint8_t> own_c, own_q;                                  // the record carried its own comment / quality
+    uint32_t max_len = 0;
+    size_t next_start = 0;     // index of the header char of the first record NOT parsed here
+    bool ended = false;        // kseq_read returned < 0 inside this range
+    int last_ret = -1;         // ... with this value
+    size_t n_rec() const { return seq_end.size(); }
+};
+
+// Parses the records whose header character ('>' / '@') lies in [start, limit).  `start` indexes a header
+// character unless scan_first (then the parser looks for the first one, as kseq_read does at the beginning).
+void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool scan_first, FxChunk &o)
+{
+    size_t pos = start;
+    int last_char = 0;
+    if (!scan_first) { last_char = data[start]; pos = start + 1; }
+    for (;;) {
+        size_t hdr;
+        if (last_char == 0) {
+            while (pos < n && data[pos] != '>' && data[pos] != '@') pos++;
+            if (pos >= n) { o.ended = true; o.last_ret = -1; o.next_start = n; return; }
+            hdr = pos;
+            if (hdr >= limit) { o.next_start = hdr; return; }
+            last_char = data[pos++];
+        } else {
+            hdr = pos - 1;
+            if (hdr >= limit) { o.next_start = hdr; return; }
+        }
+        if (pos >= n) { o.ended = true; o.last_ret = -1; o.next_start = n; return; }      // ks_getuntil < 0 at EOF
+        size_t st = pos;
+        while (pos < n && !is_space(data[pos])) pos++;
+        const size_t name_st = st, name_len = pos - st;
+        int c = pos < n ? data[pos] : -1;
+        pos++;
+        bool own_c = false;
+        size_t com_st = 0, com_len = 0;
+        if (c != -1 && c != '\n') {
+            st = pos;
+            const void *nl = pos < n ? memchr(data + pos, '\n', n - pos) : nullptr;
+            pos = nl ? (size_t)((const uint8_t *)nl - data) : n;
+            com_st = st; com_len = std::min(pos, n) - st;
+            own_c = true;
+            pos++;
+        }
+        const size_t seq_base = o.seq.size();
+        c = -1;
+        while (pos < n) {
+            // fast path: a run of sequence bytes up to the end of the line
+            const uint8_t *p = data + pos, *e = data + n;
+            const uint8_t *q = p;
+            while (q < e && *q != '\n' && *q != '>' && *q != '+' && *q != '@' && *q >= 33 && *q <= 126) q++;
+            if (q > p) { o.seq.insert(o.seq.end(), p, q); pos += (size_t)(q - p); if (pos >= n) break; }
+            c = data[pos++];
+            if (c == '>' || c == '+' || c == '@') break;
+            if (c >= 33 && c <= 126) o.seq.push_back((uint8_t)c);       // isgraph
+            c = -1;
+        }
+        const size_t sq_len = o.seq.size() - seq_base;
+        if (c == '>' || c == '@') last_char = c;
+        bool own_q = false;
+        const size_t qual_base = o.qual.size();
+        if (c == '+') {
+            const void *nl = pos < n ? memchr(data + pos, '\n', n - pos) : nullptr;
+            if (!nl) { o.seq.resize(seq_base); o.ended = true; o.last_ret = -2; o.next_start = n; return; }
+            pos = (size_t)((const uint8_t *)nl - data) + 1;
+            // `while ((c = ks_getc(ks)) != -1 && seq->qual.l < seq->seq.l)`: consumes one byte past the quality
+            size_t ql = 0;
+            while (pos < n) {
+                const int ch = data[pos++];
+                if (!(ql < sq_len)) break;
+                if (ch >= 33 && ch <= 127) { o.qual.push_back((uint8_t)ch); ql++; }
+            }
+            last_char = 0;
+            if (ql != sq_len) { o.seq.resize(seq_base); o.qual.resize(qual_base); o.ended = true; o.last_ret = -2; o.next_start = n; return; }
+            own_q = true;
+        }
+        o.name.insert(o.name.end(), data + name_st, data + name_st + name_len); o.name_end.push_back(o.name.size());
+        o.seq_end.push_back(o.seq.size());
+        if (own_c) o.comment.insert(o.comment.end(), data + com_st, data + com_st + com_len);
+        o.comment_end.push_back(o.comment.size()); o.own_c.push_back(own_c ? 1 : 0);
+        o.qual_end.push_back(o.qual.size()); o.own_q.push_back(own_q ? 1 : 0);
+        o.max_len = std::max<uint32_t>(o.max_len, (uint32_t)sq_len);
+        if (c == -1 && pos >= n) { o.ended = true; o.last_ret = -1; o.next_start = n; return; }
+    }
+}
+
+// first plausible record start at or after `from`: a line that starts with the file's header character
+// (FASTQ: and whose line after next starts with '+', which tells a header from a quality line)
+size_t guess_start(const uint8_t *data, size_t n, size_t from, bool fastq)
+{
+    size_t p = from;
+    while (p < n) {
+        const void *nl = memchr(data + p, '\n', n - p);
+        if (!nl) return n;
+        const size_t cand = (size_t)((const uint8_t *)nl - data) + 1;
+        if (cand >= n) return n;
+        if (!fastq) { if (data[cand] == '>') return cand; }
+        else if (data[cand] == '@') {
+            const void *l1 = memchr(data + cand, '\n', n - cand);
+            if (l1) {
+                const size_t s2 = (size_t)((const uint8_t *)l1 - data) + 1;
+                const void *l2 = s2 < n ? memchr(data + s2, '\n', n - s2) : nullptr;
+                if (l2) { const size_t s3 = (size_t)((const uint8_t *)l2 - data) + 1; if (s3 < n && data[s3] == '+') return cand; }
+            }
+        }
+        p = cand;
+    }
+    return n;
+}
+
+uint64_t name_hash(const uint8_t *p, size_t n)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xD6E8FEB86659FD93ull);
+    while (n >= 8) { uint64_t v; memcpy(&v, p, 8); h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; p += 8; n -= 8; }
+    if (n) { uint64_t v = 0; memcpy(&v, p, n); h = (h ^ v) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29; }
+    return h ^ (h >> 31);
+}
+
+} // namespace
 
 int crass_read_fastx(const char *path, crass_fastx *out)
 {
     if (!path || !out) return CRASS_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
-    gzFile fp = gzopen(path, "r");
-    if (!fp) return CRASS_ERR_IO;
     std::vector<uint8_t> data;
     {
-        std::vector<uint8_t> buf(1 << 20);
-        int got;
-        while ((got = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) data.insert(data.end(), buf.begin(), buf.begin() + got);
-        gzclose(fp);
-        if (got < 0) return CRASS_ERR_IO;
+        FILE *f = fopen(path, "rb");
+        if (!f) return CRASS_ERR_IO;
+        unsigned char magic[2] = {0, 0};
+        const size_t got2 = fread(magic, 1, 2, f);
+        const bool gz = got2 == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (!gz) {                                       // plain text: one read of the whole file
+            fseek(f, 0, SEEK_END);
+            const long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            if (sz < 0) { fclose(f); return CRASS_ERR_IO; }
+            data.resize((size_t)sz);
+            if (sz && fread(data.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return CRASS_ERR_IO; }
+            fclose(f);
+        } else {
+            fclose(f);
+            gzFile fp = gzopen(path, "r");
+            if (!fp) return CRASS_ERR_IO;
+            gzbuffer(fp, 1 << 20);
+            std::vector<uint8_t> buf(4 << 20);
+            int got;
+            while ((got = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) data.insert(data.end(), buf.begin(), buf.begin() + got);
+            gzclose(fp);
+            if (got < 0) return CRASS_ERR_IO;
+        }
     }
     const size_t n = data.size();
-    size_t pos = 0;
-    std::vector<uint8_t> seq, name, comment, qual, has_c, has_q;
-    std::vector<uint64_t> seq_off{0}, name_off{0}, comment_off{0}, qual_off{0}, header_id;
-    std::unordered_map<std::string, uint64_t> first_seen;
-    std::string stale_comment, stale_qual;
-    bool any_comment = false, any_qual = false;
-    int last_char = 0;
-    int last_ret = -1;
-    uint32_t max_len = 0;
-    uint64_t nrec = 0;
-    for (;;) {
-        if (last_char == 0) {
-            while (pos < n && data[pos] != '>' && data[pos] != '@') pos++;
-            if (pos >= n) { last_ret = -1; break; }
-            last_char = data[pos++];
+    const uint8_t *d = data.data();
+    // ---- cut into pieces at guessed record starts ----
+    size_t chunk_bytes = 8u << 20;
+    if (const char *e = getenv("CRASS_FASTX_CHUNK")) chunk_bytes = (size_t)std::max(64ll, atoll(e));     // tests: force small pieces
+    unsigned nt = (unsigned)std::min<size_t>(std::min<unsigned>(hw_threads(), 64u), n / chunk_bytes);
+    if (getenv("CRASS_FASTX_SERIAL")) nt = 1;
+    std::vector<size_t> starts{0};
+    if (nt > 1) {
+        size_t first = 0;
+        while (first < n && d[first] != '>' && d[first] != '@') first++;
+        const bool fastq = first < n && d[first] == '@';
+        for (unsigned k = 1; k < nt; k++) {
+            const size_t g = guess_start(d, n, std::max(starts.back(), (size_t)((unsigned __int128)n * k / nt)), fastq);
+            if (g >= n) break;
+            if (g > starts.back()) starts.push_back(g);
         }
-        if (pos >= n) { last_ret = -1; break; }          // ks_getuntil < 0 at EOF
-        size_t st = pos;
-        while (pos < n && !is_space(data[pos])) pos++;
-        std::string nm((const char *)data.data() + st, pos - st);
-        int c = pos < n ? data[pos] : -1;
-        pos++;
-        if (c != -1 && c != '\n') {
-            st = pos;
-            while (pos < n && data[pos] != '\n') pos++;
-            stale_comment.assign((const char *)data.data() + st, std::min(pos, n) - st);
-            any_comment = true;
-            pos++;
-        }
-        std::string sq;
-        c = -1;
-        while (pos < n) {
-            c = data[pos++];
-            if (c == '>' || c == '+' || c == '@') break;
-            if (c >= 33 && c <= 126) sq.push_back((char)c);       // isgraph
-            c = -1;
-        }
-        if (c == '>' || c == '@') last_char = c;
-        bool ok = true;
-        if (c == '+') {
-            while (pos < n && data[pos] != '\n') pos++;
-            if (pos >= n) { last_ret = -2; break; }
-            pos++;
-            std::string q;
-            // `while ((c = ks_getc(ks)) != -1 && seq->qual.l < seq->seq.l)`: consumes one byte past the quality
-            while (pos < n) {
-                int ch = data[pos++];
-                if (!(q.size() < sq.size())) break;
-                if (ch >= 33 && ch <= 127) q.push_back((char)ch);
-            }
-            last_char = 0;
-            if (q.size() != sq.size()) { last_ret = -2; ok = false; }
-            else { stale_qual = q; any_qual = true; }
-        }
-        if (!ok) break;
-        name.insert(name.end(), nm.begin(), nm.end()); name_off.push_back(name.size());
-        seq.insert(seq.end(), sq.begin(), sq.end()); seq_off.push_back(seq.size());
-        // stale-pointer semantics: once allocated, comment.s / qual.s keep their old bytes and
-        // searchFile passes them on (libcrispr.cpp:124-131)
-        has_c.push_back(any_comment ? 1 : 0);
-        if (any_comment) comment.insert(comment.end(), stale_comment.begin(), stale_comment.end());
-        comment_off.push_back(comment.size());
-        has_q.push_back(any_qual ? 1 : 0);
-        if (any_qual) qual.insert(qual.end(), stale_qual.begin(), stale_qual.end());
-        qual_off.push_back(qual.size());
-        auto it = first_seen.find(nm);
-        if (it == first_seen.end()) { first_seen.emplace(nm, nrec); header_id.push_back(nrec); }
-        else header_id.push_back(it->second);
-        max_len = std::max<uint32_t>(max_len, (uint32_t)sq.size());
-        nrec++;
-        if (c == -1 && pos >= n) { last_ret = -1; break; }
     }
-    auto dup8 = [](const std::vector<uint8_t> &v) { uint8_t *p = (uint8_t *)malloc(v.size() + 1); if (!v.empty()) memcpy(p, v.data(), v.size()); return p; };
-    auto dup64 = [](const std::vector<uint64_t> &v) { uint64_t *p = (uint64_t *)malloc((v.size() + 1) * 8); if (!v.empty()) memcpy(p, v.data(), v.size() * 8); return p; };
+    std::vector<FxChunk> ch(starts.size());
+    auto run = [&](size_t k) { parse_range(d, n, starts[k], k + 1 < starts.size() ? starts[k + 1] : n, k == 0, ch[k]); };
+    if (starts.size() == 1) run(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < starts.size(); k++) th.emplace_back(run, k);
+        run(0);
+        for (auto &t : th) t.join();
+        bool ok = true;
+        for (size_t k = 0; k + 1 < starts.size() && ok; k++) ok = !ch[k].ended && ch[k].next_start == starts[k + 1];
+        if (!ok) {                                       // a guess was wrong or the stream ended early: one piece, exact
+            ch.assign(1, FxChunk());
+            starts.assign(1, 0);
+            parse_range(d, n, 0, n, true, ch[0]);
+        }
+    }
+    // ---- assemble ----
+    const size_t nc = ch.size();
+    std::vector<uint64_t> rec0(nc + 1, 0), seq0(nc + 1, 0), name0(nc + 1, 0), com0(nc + 1, 0), qual0(nc + 1, 0);
+    bool any_c = false, all_c = true, any_q = false, all_q = true;
+    uint32_t max_len = 0;
+    for (size_t k = 0; k < nc; k++) {
+        rec0[k + 1] = rec0[k] + ch[k].n_rec(); seq0[k + 1] = seq0[k] + ch[k].seq.size(); name0[k + 1] = name0[k] + ch[k].name.size();
+        com0[k + 1] = com0[k] + ch[k].comment.size(); qual0[k + 1] = qual0[k] + ch[k].qual.size();
+        for (uint8_t v : ch[k].own_c) { any_c |= v != 0; all_c &= v != 0; }
+        for (uint8_t v : ch[k].own_q) { any_q |= v != 0; all_q &= v != 0; }
+        max_len = std::max(max_len, ch[k].max_len);
+    }
+    const uint64_t nrec = rec0[nc];
+    auto alloc8 = [](uint64_t nb) { return (uint8_t *)malloc(nb + 1); };
+    auto alloc64 = [](uint64_t ne) { return (uint64_t *)malloc((ne + 1) * 8); };
     out->n_reads = nrec;
-    out->seq = dup8(seq); out->seq_off = dup64(seq_off);
-    out->name = dup8(name); out->name_off = dup64(name_off);
-    out->comment = dup8(comment); out->comment_off = dup64(comment_off); out->has_comment = dup8(has_c);
-    out->qual = dup8(qual); out->qual_off = dup64(qual_off); out->has_qual = dup8(has_q);
-    out->header_id = dup64(header_id);
+    out->seq = alloc8(seq0[nc]); out->seq_off = alloc64(nrec + 1);
+    out->name = alloc8(name0[nc]); out->name_off = alloc64(nrec + 1);
+    out->has_comment = alloc8(nrec); out->has_qual = alloc8(nrec);
+    out->comment_off = alloc64(nrec + 1); out->qual_off = alloc64(nrec + 1);
+    out->header_id = alloc64(nrec);
+    out->seq_off[0] = out->name_off[0] = out->comment_off[0] = out->qual_off[0] = 0;
+    // comments / qualities: every record its own, or none at all, is a plain concatenation; a mix follows the
+    // reference's stale-buffer semantics (once allocated, comment.s / qual.s keep their old bytes and searchFile
+    // passes them on, libcrispr.cpp:124-131) in one ordered pass
+    const bool simple_c = !any_c || all_c, simple_q = !any_q || all_q;
+    out->comment = simple_c ? alloc8(com0[nc]) : nullptr;
+    out->qual = simple_q ? alloc8(qual0[nc]) : nullptr;
+    auto copy_chunk = [&](size_t k) {
+        const FxChunk &c = ch[k];
+        if (!c.seq.empty()) memcpy(out->seq + seq0[k], c.seq.data(), c.seq.size());
+        if (!c.name.empty()) memcpy(out->name + name0[k], c.name.data(), c.name.size());
+        if (simple_c && !c.comment.empty()) memcpy(out->comment + com0[k], c.comment.data(), c.comment.size());
+        if (simple_q && !c.qual.empty()) memcpy(out->qual + qual0[k], c.qual.data(), c.qual.size());
+        for (size_t i = 0; i < c.n_rec(); i++) {
+            const uint64_t r = rec0[k] + i;
+            out->seq_off[r + 1] = seq0[k] + c.seq_end[i];
+            out->name_off[r + 1] = name0[k] + c.name_end[i];
+            if (simple_c) { out->comment_off[r + 1] = com0[k] + c.comment_end[i]; out->has_comment[r] = any_c ? 1 : 0; }
+            if (simple_q) { out->qual_off[r + 1] = qual0[k] + c.qual_end[i]; out->has_qual[r] = any_q ? 1 : 0; }
+        }
+    };
+    if (nc == 1) copy_chunk(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < nc; k++) th.emplace_back(copy_chunk, k);
+        copy_chunk(0);
+        for (auto &t : th) t.join();
+    }
+    auto ordered_stale = [&](bool comment) {
+        std::vector<uint8_t> bytes;
+        std::string stale;
+        bool any = false;
+        uint8_t *has = comment ? out->has_comment : out->has_qual;
+        uint64_t *off = comment ? out->comment_off : out->qual_off;
+        for (size_t k = 0; k < nc; k++) {
+            const FxChunk &c = ch[k];
+            const std::vector<uint8_t> &src = comment ? c.comment : c.qual;
+            const std::vector<uint64_t> &end = comment ? c.comment_end : c.qual_end;
+            const std::vector<uint8_t> &own = comment ? c.own_c : c.own_q;
+            for (size_t i = 0; i < c.n_rec(); i++) {
+                const uint64_t r = rec0[k] + i;
+                if (own[i]) { const uint64_t b0 = i ? end[i - 1] : 0; stale.assign((const char *)src.data() + b0, end[i] - b0); any = true; }
+                has[r] = any ? 1 : 0;
+                if (any) bytes.insert(bytes.end(), stale.begin(), stale.end());
+                off[r + 1] = bytes.size();
+            }
+        }
+        uint8_t *p = (uint8_t *)malloc(bytes.size() + 1);
+        if (!bytes.empty()) memcpy(p, bytes.data(), bytes.size());
+        if (comment) out->comment = p; else out->qual = p;
+    };
+    if (!simple_c) ordered_stale(true);
+    if (!simple_q) ordered_stale(false);
+    // ---- header_id: first read with the same name (readsFound is keyed by the header string) ----
+    {
+        size_t cap = 1024;
+        while (cap < nrec * 2) cap <<= 1;
+        struct Slot { std::atomic<uint64_t> hash; std::atomic<uint64_t> first; };
+        std::vector<Slot> tab(cap);
+        for (auto &sl : tab) { sl.hash.store(0, std::memory_order_relaxed); sl.first.store(~0ull, std::memory_order_relaxed); }
+        std::vector<uint64_t> slot_of(nrec);
+        const unsigned ht = (unsigned)std::min<uint64_t>(hw_threads(), std::max<uint64_t>(1, nrec / 65536));
+        parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b, unsigned) {
+            for (uint64_t r = a; r < b; r++) {
+                const uint64_t h = name_hash(out->name + out->name_off[r], out->name_off[r + 1] - out->name_off[r]) | 1ull;
+                size_t i = (size_t)(h >> 7) & (cap - 1);
+                for (;;) {
+                    uint64_t cur = tab[i].hash.load(std::memory_order_relaxed);
+                    if (cur == 0 && tab[i].hash.compare_exchange_strong(cur, h, std::memory_order_relaxed)) cur = h;
+                    if (cur == h) break;
+                    i = (i + 1) & (cap - 1);
+                }
+                uint64_t f = tab[i].first.load(std::memory_order_relaxed);
+                while (r < f && !tab[i].first.compare_exchange_weak(f, r, std::memory_order_relaxed)) {}
+                slot_of[r] = i;
+            }
+        });
+        std::atomic<int> collision{0};
+        parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b, unsigned) {
+            for (uint64_t r = a; r < b; r++) {
+                const uint64_t f = tab[slot_of[r]].first.load(std::memory_order_relaxed);
+                out->header_id[r] = f;
+                if (f != r) {            // same 64-bit hash: must be the same name, or the table cannot be trusted
+                    const uint64_t la = out->name_off[r + 1] - out->name_off[r], lb = out->name_off[f + 1] - out->name_off[f];
+                    if (la != lb || memcmp(out->name + out->name_off[r], out->name + out->name_off[f], la) != 0) collision.store(1);
+                }
+            }
+        });
+        if (collision.load()) {      // exact fallback
+            std::unordered_map<std::string, uint64_t> first_seen;
+            for (uint64_t r = 0; r < nrec; r++) {
+                std::string nm((const char *)out->name + out->name_off[r], out->name_off[r + 1] - out->name_off[r]);
+                auto it = first_seen.find(nm);
+                if (it == first_seen.end()) { first_seen.emplace(nm, r); out->header_id[r] = r; } else out->header_id[r] = it->second;
+            }
+        }
+    }
     out->max_len = max_len;
-    out->last_ret = last_ret;
+    out->last_ret = ch.back().last_ret;
     return CRASS_OK;
 }
 

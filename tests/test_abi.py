@@ -97,3 +97,82 @@ def test_synthetic_generator_is_deterministic_and_shardable(ca):
     gasc = ca.unpack_ascii(gc, 10, 150, 4000).reshape(4000, 150)
     frac = ((gasc == ord("G")) | (gasc == ord("C"))).mean(axis=1)
     assert frac.min() < 0.38 and frac.max() > 0.62
+
+
+def _write_both(tmp_path, name, text):
+    import gzip
+    plain = tmp_path / name
+    plain.write_bytes(text)
+    gz = tmp_path / (name + ".gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(text)
+    return str(plain), str(gz)
+
+
+def _fastx_cases():
+    import random
+    rng = random.Random(11)
+
+    def seq(n):
+        return "".join(rng.choice("ACGTN" if rng.random() < 0.05 else "ACGT") for _ in range(n))
+
+    cases = {}
+    # a. single-line FASTA, comments on some headers only (stale-buffer semantics), duplicate names
+    recs = []
+    for i in range(3000):
+        nm = "r%d" % (i if i % 97 else i // 2)
+        recs.append(">%s%s\n%s\n" % (nm, (" c%d x" % i) if (i > 40 and i % 3 == 0) else "", seq(rng.randint(20, 180))))
+    cases["fa_single"] = "".join(recs)
+    # b. multi-line FASTA
+    recs = []
+    for i in range(1500):
+        s = seq(rng.randint(50, 400))
+        recs.append(">m%d desc\n%s\n" % (i, "\n".join(s[k:k + 60] for k in range(0, len(s), 60))))
+    cases["fa_multi"] = "".join(recs)
+    # c. FASTQ, quality lines that start with '@' or '+'
+    recs = []
+    for i in range(2500):
+        s = seq(rng.randint(30, 150))
+        q = "".join(rng.choice("@+IIIHG5#!~") for _ in s)
+        if i % 5 == 0:
+            q = "@" + q[1:]
+        if i % 7 == 0:
+            q = "+" + q[1:]
+        recs.append("@q%d%s\n%s\n+\n%s\n" % (i, " lane=%d" % (i % 4) if i % 2 else "", s, q))
+    cases["fq"] = "".join(recs)
+    # d. the same, truncated inside the last quality line
+    cases["fq_trunc"] = cases["fq"][:-40]
+    # e. '>' inside a sequence line (ends the record there in kseq): the pieces cannot line up, one-piece parse
+    cases["fa_odd"] = cases["fa_single"][:20000] + ">odd\nACGT>ACGTAC\nGGGG\n" + cases["fa_single"][20000:]
+    # f. CRLF, g. no trailing newline
+    cases["fa_crlf"] = cases["fa_single"].replace("\n", "\r\n")
+    cases["fa_noeol"] = cases["fa_multi"].rstrip("\n")
+    return {k: v.encode() for k, v in cases.items()}
+
+
+@pytest.mark.parametrize("case", ["fa_single", "fa_multi", "fq", "fq_trunc", "fa_odd", "fa_crlf", "fa_noeol"])
+@pytest.mark.parametrize("chunk", ["256", "5000", "serial"])
+def test_parallel_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
+    """the block-parallel reader against the byte-at-a-time kseq reference, with pieces far smaller than in
+    production so that every boundary condition occurs, on plain and gzipped copies of the same text"""
+    text = _fastx_cases()[case]
+    plain, gz = _write_both(tmp_path, case + ".txt", text)
+    ref = fastx.read_fastx(gz)
+    first = {}
+    ref_ids = [first.setdefault(r[0], i) for i, r in enumerate(ref)]
+    os.environ.pop("CRASS_FASTX_CHUNK", None)
+    os.environ.pop("CRASS_FASTX_SERIAL", None)
+    if chunk == "serial":
+        os.environ["CRASS_FASTX_SERIAL"] = "1"
+    else:
+        os.environ["CRASS_FASTX_CHUNK"] = chunk
+    try:
+        for path in (plain, gz):
+            f = ca.FastxFile(path)
+            assert f.records() == ref
+            assert f.header_id.tolist() == ref_ids
+            assert f.max_len == max((len(r[2]) for r in ref), default=0)
+    finally:
+        os.environ.pop("CRASS_FASTX_CHUNK", None)
+        os.environ.pop("CRASS_FASTX_SERIAL", None)
+    assert len(ref) > 1000
