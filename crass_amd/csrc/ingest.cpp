@@ -78,21 +78,29 @@ int crass_pack_reads(const uint8_t *seqs, const uint64_t *off, uint64_t n, int p
         o->packed.assign(n * (uint64_t)stride + 4, 0);
     }
     if (!uniform_len) { o->lengths.resize(n); for (uint64_t i = 0; i < n; i++) o->lengths[i] = (uint32_t)(off[i + 1] - off[i]); }
-    const unsigned nt = std::min<unsigned>(hw_threads(), 32);
+    const unsigned nt = std::min<unsigned>(hw_threads(), 64);
     std::vector<std::vector<uint64_t>> exc_parts(nt);
     uint32_t *packed = o->packed.data();
+    // byte -> 2-bit code, 0x80 for anything outside ACGT; one output word is built in a register per 16 bases
+    static const struct Lut { uint8_t t[256]; Lut() { memset(t, 0x80, sizeof(t)); t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; } } lut;
     parallel_ranges(n, nt, [&](uint64_t a, uint64_t b, unsigned t) {
         for (uint64_t i = a; i < b; i++) {
             const uint8_t *s = seqs + off[i];
             const uint32_t L = (uint32_t)(off[i + 1] - off[i]);
             uint32_t *w = packed + (stride ? i * (uint64_t)stride : o->word_off[i]);
-            bool bad = false;
-            for (uint32_t k = 0; k < L; k++) {
-                int c = base_code(s[k]);
-                if (c < 0) { bad = true; c = 0; }
-                w[k >> 4] |= (uint32_t)c << ((k & 15) * 2);
+            uint32_t bad = 0;
+            uint32_t k = 0;
+            for (; k + 16 <= L; k += 16) {
+                uint32_t acc = 0;
+                for (int q = 0; q < 16; q++) { const uint32_t c = lut.t[s[k + q]]; bad |= c; acc |= (c & 3u) << (2 * q); }
+                w[k >> 4] = acc;
             }
-            if (bad) exc_parts[t].push_back(i);
+            if (k < L) {
+                uint32_t acc = 0;
+                for (uint32_t q = 0; k + q < L; q++) { const uint32_t c = lut.t[s[k + q]]; bad |= c; acc |= (c & 3u) << (2 * q); }
+                w[k >> 4] = acc;
+            }
+            if (bad & 0x80u) exc_parts[t].push_back(i);
         }
     });
     for (auto &p : exc_parts) o->exc_read.insert(o->exc_read.end(), p.begin(), p.end());
