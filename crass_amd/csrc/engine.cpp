@@ -183,6 +183,7 @@ struct crass_hip_ctx {
         }
     } dense;
     DevBuf<uint64_t> d_fidx;
+    DevBuf<uint64_t> d_pos_hint, d_pos_hint_off; uint64_t n_pos_hint_words = 0;     // long reads: per-position seed hints
     // device-side DR de-duplication (single-GPU merge fast path)
     DevBuf<unsigned long long> dd_keys; DevBuf<uint32_t> dd_first, dd_slot, dd_rep; DevBuf<uint64_t> dd_hash;
     PinBuf<uint32_t> h_rep; PinBuf<uint64_t> h_hash;
@@ -418,7 +419,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
     c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
-    c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
+    c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->d_pos_hint.release(); c->d_pos_hint_off.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -449,6 +450,26 @@ static int alloc_scratch(crass_hip_ctx *c)
     HIPCHK(c, c->d_ss_used.ensure(4));
     HIPCHK(c, c->h_count.ensure(8));
     HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
+    return CRASS_OK;
+}
+
+// long reads skip the per-read filter; with the default window and DR/spacer bounds they get one seed-hint bit
+// per base position instead (k_hint_positions).  lengths == nullptr: uniform length.
+static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t uniform_len, uint64_t n)
+{
+    c->n_pos_hint_words = 0;
+    c->R.pos_hint = nullptr; c->R.pos_hint_off = nullptr;
+    const DevParams &P = c->dp;
+    if (c->max_len <= 2048 || n == 0 || P.window != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return CRASS_OK;
+    if (getenv("CRASS_NO_POS_HINTS")) return CRASS_OK;             // A/B switch
+    std::vector<uint64_t> off(n + 1);
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n; i++) { off[i] = at; at += ((uint64_t)(lengths ? lengths[i] : uniform_len) + 63) / 64; }
+    off[n] = at;
+    HIPCHK(c, c->d_pos_hint_off.ensure(n + 1)); HIPCHK(c, c->d_pos_hint.ensure(at + 1));
+    HIPCHK(c, hipMemcpy(c->d_pos_hint_off.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    c->n_pos_hint_words = at;
+    c->R.pos_hint = c->d_pos_hint.p; c->R.pos_hint_off = c->d_pos_hint_off.p;
     return CRASS_OK;
 }
 
@@ -527,6 +548,8 @@ int crass_hip_load_reads(crass_hip_ctx *c, const crass_reads *h)
     c->have_reads = true;
     int s = alloc_scratch(c);
     if (s) return s;
+    s = setup_pos_hints(c, h->uniform_len ? nullptr : h->lengths, h->uniform_len, n);
+    if (s) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnt.n_reads = n; c->cnt.n_exceptions = h->n_exceptions; c->cnt.bytes_reads_device = total_words * 4;
     return CRASS_OK;
@@ -555,6 +578,8 @@ int crass_hip_attach_device_reads(crass_hip_ctx *c, const crass_reads *d)
     c->uniform = true;
     c->have_reads = true;
     int s = alloc_scratch(c);
+    if (s) return s;
+    s = setup_pos_hints(c, nullptr, d->uniform_len, d->n_reads);
     if (s) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnt.n_reads = d->n_reads; c->cnt.n_exceptions = 0;
@@ -783,6 +808,10 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     } else {
         // all non-exception reads survive: mask = ~exc_mask (exc_mask is 32-bit words of the same bit order)
         HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0xFF, n_words * 8, c->stream));
+        if (c->R.pos_hint) {
+            hipError_t he = launch_hint_positions(c->R, c->dp, c->d_pos_hint_off.p, c->n_pos_hint_words, c->d_pos_hint.p, c->stream);
+            if (he != hipSuccess) { c->last_hip = (int)he; return CRASS_ERR_HIP; }
+        }
     }
     c->hints_valid = fast;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

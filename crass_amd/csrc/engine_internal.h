@@ -22,6 +22,10 @@ struct DevReads {
     const uint64_t *exc_off;
     const uint8_t  *exc_bytes;
     uint64_t n_exc;
+    // long reads (no per-read filter): one hint bit per base position, bit p clear => the seed at p provably has
+    // no copy in its search window (k_hint_positions); read r's bits start at word pos_hint_off[r].  May be nullptr.
+    const uint64_t *pos_hint;
+    const uint64_t *pos_hint_off;
 };
 
 struct DevParams {
@@ -163,6 +167,10 @@ struct SurvLds {
 // ---- launch wrappers implemented in kernels.hip (all asynchronous on `st`) ----
 hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t *hitmask,
                                  uint32_t max_len, hipStream_t st);
+// per-position seed hints for long / ragged packed reads (default window and DR/spacer bounds only):
+// hint_off[n_reads + 1] = prefix sums of ceil(L/64) (device), n_words = hint_off[n_reads] (host-known)
+hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, uint64_t n_words, uint64_t *hint_bits,
+                                 hipStream_t st);
 hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st);
 // mask (n_words 64-bit words) -> ascending index list; *d_count receives the number of set bits.
 // scratch: word_prefix[n_words] u32, block_sums[(n_words+255)/256 + 1] u32

@@ -241,6 +241,64 @@ hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *h
 }
 
 // ------------------------------------------------------------------------------------
+// Long reads: per-POSITION seed hints.  A 10 kbp read has ~1 250 lattice seeds and, after the first
+// rejected candidate, the seed loop leaves the lattice (libcrispr.cpp:390), so a per-read filter and
+// per-lattice hints are useless there.  The same bit-parallel test is therefore run for all 8 residues
+// (R >> 2*rho puts the seeds at 8h+rho on the halfword lattice): bit p of the read's hint bitmap is clear
+// => the 8-mer at p has no copy at p+49 .. p+97 => searchCore's iteration at j = p is a no-op, whatever
+// residue j is on.  One lane per 64 positions (4 seed words + 7 halo words), a superset like the short-read
+// filter (padding bases and the right clamp are ignored).  Default window / bounds only.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, uint64_t n_words, uint64_t *hint_bits)
+{
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n_words) return;
+    // read of this tile: largest r with hint_off[r] <= t
+    uint64_t lo = 0, hi = R.n_reads;                                    // invariant: hint_off[lo] <= t < hint_off[hi]
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (hint_off[mid] <= t) lo = mid; else hi = mid; }
+    const uint64_t r = lo;
+    const uint32_t tile = (uint32_t)(t - hint_off[r]);
+    const uint32_t L = rd_len(R, r);
+    const uint32_t nw = (L + 15) >> 4;
+    const uint32_t *g = R.packed + rd_word_off(R, r);
+    uint32_t w[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) { const uint32_t wi = tile * 4 + i; w[i] = wi < nw ? g[wi] : 0u; }
+    uint64_t bits = 0;
+    for (uint32_t rho = 0; rho < 8; rho++) {
+        uint32_t v[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) v[i] = rho ? ((w[i] >> (2 * rho)) | (w[i + 1] << (32 - 2 * rho))) : w[i];
+        uint32_t acc[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+        for (int d = 49; d <= 97; d++) {
+            const int q = d >> 4, sh = (d & 15) * 2;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t a = v[k + q], b = v[k + q + 1];
+                const uint32_t s2 = sh ? ((a >> sh) | (b << (32 - sh))) : a;
+                acc[k] = pk_min_u16(acc[k], s2 ^ v[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((acc[k] & 0xFFFFu) == 0) bits |= 1ull << (16 * k + rho);
+            if ((acc[k] >> 16) == 0) bits |= 1ull << (16 * k + 8 + rho);
+        }
+    }
+    hint_bits[t] = bits;
+}
+
+hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, uint64_t n_words, uint64_t *hint_bits,
+                                 hipStream_t st)
+{
+    if (P.window != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return hipErrorNotSupported;
+    if (n_words == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hint_positions, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, R, hint_off, n_words, hint_bits);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
 // ordered compaction: bit mask -> ascending list of set-bit indices
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mask_count(const uint64_t *mask, uint64_t n_words, uint64_t n_bits,
@@ -795,7 +853,7 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
 }
 
 // searchCore, libcrispr.cpp:265-395.  1 found / 0 not / <0 error
-static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint, int lane)
+static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint, int lane, const uint64_t *pos_hint = nullptr)
 {
     const uint32_t seq_length = (uint32_t)h.L;
     const uint32_t skips = o.skips;
@@ -808,7 +866,19 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
     bool on_lattice = true;
     uint32_t lattice_i = 0;
     for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
-        if (on_lattice) {
+        if (pos_hint) {
+            // per-position hints (k_hint_positions): a clear bit makes this iteration a no-op in the reference, on
+            // or off the lattice.  With skips == 8 the next candidate in the same 64-bit word is one ffs away.
+            const uint64_t wbits = pos_hint[j >> 6] >> (j & 63u);
+            if (!(wbits & 1ull)) {
+                if (skips == 8) {
+                    const uint64_t m = wbits & 0x0101010101010101ull;        // positions j, j+8, ... inside this word
+                    if (m) j += (uint32_t)(__ffsll((unsigned long long)m) - 1) - 8;    // the loop adds 8: lands on it
+                    else j += ((63u - (j & 63u)) & ~7u);                            // last stride-8 position of the word
+                }
+                continue;
+            }
+        } else if (on_lattice) {
             const uint32_t li = lattice_i++;
             if (li < 32 && !((seed_hint >> li) & 1u)) continue;
         }
@@ -963,7 +1033,8 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
         wave_sync();
         h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
         const uint32_t hint = (!EXC && seed_hint) ? seed_hint[r] : 0xFFFFFFFFu;
-        int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane);
+        const uint64_t *ph = (!EXC && R.pos_hint) ? R.pos_hint + R.pos_hint_off[r] : nullptr;
+        int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane, ph);
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
         if (f < 0) o.err = (f == -2) ? 2 : 1;

@@ -268,3 +268,48 @@ def test_full_size_properties(ca):
     k = int(np.searchsorted(c1.read_idx, m))
     small = ca.search_pipeline(seqs, do_pass2=False)
     assert np.array_equal(c1.read_idx[:k], small.rec_read[:small.n_pass1])
+
+
+def test_long_reads_position_hints(ca):
+    """reads beyond the per-read filter get one seed-hint bit per base (k_hint_positions); the hinted seed loop
+    must visit exactly the seeds that matter, on and off the stride lattice (rejected candidates move j off it):
+    random reads with chance 8-mer repeats, short and damaged arrays, arrays at the read ends"""
+    rng = random.Random(23)
+
+    def rs(n):
+        return bytes(rng.choice(b"ACGT") for _ in range(n))
+    drs = [rs(rng.randint(24, 40)) for _ in range(8)]
+    seqs = []
+    for i in range(300):
+        L = rng.randint(2100, 7000)
+        s = bytearray(rs(L))
+        kind = i % 6
+        if kind in (1, 2, 3):
+            dr = bytearray(rng.choice(drs))
+            reps = rng.randint(2, 4) if kind == 1 else rng.randint(5, 25)
+            arr = bytearray()
+            for _ in range(reps):
+                d = bytearray(dr)
+                if kind == 3 and rng.random() < 0.5:
+                    d[rng.randrange(len(d))] = rng.choice(b"ACGT")          # damaged copy
+                arr += d + rs(rng.randint(26, 50))
+            at = rng.choice([0, max(0, L - len(arr)), rng.randint(0, max(0, L - len(arr)))])
+            s[at:at + len(arr)] = arr
+            s = s[:L]
+        elif kind == 4:
+            # a chance-like 8-mer repeat 60 bases apart, several times, on different residues
+            for k in range(6):
+                p = rng.randint(0, L - 200)
+                s[p + 60:p + 68] = s[p:p + 8]
+        seqs.append(bytes(s))
+    ref = orc.pipeline(seqs)
+    os.environ.pop("CRASS_NO_POS_HINTS", None)
+    gpu = ca.search_pipeline(seqs)
+    assert_same_pipeline(gpu, ref)
+    os.environ["CRASS_NO_POS_HINTS"] = "1"
+    try:
+        plain = ca.search_pipeline(seqs)
+    finally:
+        os.environ.pop("CRASS_NO_POS_HINTS", None)
+    assert_same_pipeline(plain, ref)
+    assert gpu.n_pass1 > 60
