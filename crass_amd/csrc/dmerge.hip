@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
     for (uint64_t i = tid; i < ks; i += nth) { M.kset_key[i] = 0ull; M.kset_cnt[i] = 0u; M.kset_fill[i] = 0u; }
     const uint64_t rs = 1ull << M.rset_log;
     for (uint64_t i = tid; i < rs; i += nth) { M.rset_key[i] = 0ull; M.rset_cnt[i] = 0u; M.rset_fill[i] = 0u; }
+    for (uint64_t i = tid; i < (1u << 15); i += nth) M.anchor_fp[i] = 0u;
     uint4 *t4 = reinterpret_cast<uint4 *>(M.anchor_tab);
     for (uint64_t i = tid; i < (1ull << M.tab_log_alloc) / 4; i += nth) t4[i] = ones;
     if (tid == 0) {
@@ -518,6 +519,12 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_insert(DevMerge M)
     const uint32_t pid = e >> 3, r = e & 7u;
     if (pid >= 2 * M.st->n_survivors || !M.ent_win[e] || M.st->fail) return;
     uint32_t cur = (uint32_t)shr128_lo(M.pat_packed[(uint64_t)pid * 2], M.pat_packed[(uint64_t)pid * 2 + 1], 2 * r);
+    if (M.st->tab_mode == 2) {
+        // key sets beyond the LDS tiers: the exact table is probed in L2, behind a 2^20-bit Bloom filter in LDS
+        const uint32_t b1 = ((uint32_t)__umul24(cur ^ (cur >> M.s1), M.m1)) >> 12, b2 = ((uint32_t)__umul24(cur ^ (cur >> M.s2), M.m2)) >> 12;
+        atomicOr(&M.anchor_fp[b1 >> 5], 1u << (b1 & 31u));
+        atomicOr(&M.anchor_fp[b2 >> 5], 1u << (b2 & 31u));
+    }
     if (cur == 0xFFFFFFFFu) return;
     const uint32_t rsh = 32u - M.st->log_size;
     uint32_t pos = ak_h(cur, M.s1, M.m1, rsh);

@@ -670,6 +670,16 @@ static const uint64_t kDenseMaxSurvivors = 1ull << 26;
 
 // Fast path of the pass-1 sink: one chunk, fixed start/stop slots, no exception reads.  Returns
 // CRASS_ERR_STATE when it does not apply (the caller then uses the host-loop path).
+static uint64_t hit_bound(uint64_t n_hits)             // the same for pass 2's flagged reads
+{
+    return std::max<uint64_t>(4096, (n_hits + n_hits / 2 + 4095) & ~4095ull);
+}
+
+static uint64_t survivor_bound(uint64_t n_surv)        // the speculative bound learnt from a call with n_surv survivors
+{
+    return std::min<uint64_t>(std::max<uint64_t>(65536, (n_surv + n_surv / 2 + 65535) & ~65535ull), 1ull << 26);
+}
+
 // n_surv: number of filter survivors, or (speculative mode: d_nsurv = the compaction's device-side count, no host
 // round trip before this call) an upper bound for it.  The exact count then arrives with the final copy of
 // the counters; *overflow is set when it exceeds the bound (nothing of this call is valid then).
@@ -682,13 +692,17 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     const uint64_t pool_cap = std::max<uint64_t>(n_surv * (uint64_t)lds.ss_cap, 1u << 16);
     if (n_surv == 0 || n_surv > kDenseMaxSurvivors || pool_cap >= (1ull << 31) || lds.ss_cap > 64 || (stride & 15)) return CRASS_ERR_STATE;
     crass_hip_ctx::P1Dense &D = c->dense;
-    HIPCHK(c, c->d_surv.ensure(n_surv));
-    HIPCHK(c, c->d_dr.ensure(n_surv * stride));
-    HIPCHK(c, c->d_ss_pool.ensure(pool_cap));
-    HIPCHK(c, c->d_fidx.ensure(n_surv));
-    HIPCHK(c, D.d_read.ensure(n_surv + 2)); HIPCHK(c, D.d_ss_off.ensure(n_surv + 2)); HIPCHK(c, D.d_low.ensure(n_surv + 16));
-    HIPCHK(c, D.d_replen.ensure(n_surv + 4)); HIPCHK(c, D.d_nss.ensure(n_surv + 4)); HIPCHK(c, D.d_dr_len.ensure(n_surv + 8));
-    HIPCHK(c, D.d_dr.ensure(n_surv * stride + 16)); HIPCHK(c, D.d_ss.ensure(n_surv * (uint64_t)lds.ss_cap + 4));
+    // buffers are sized for the bound the NEXT call will speculate with (1.5 x this call's count, see
+    // crass_hip_seed_scan), so that the second call of a context does not re-allocate everything
+    const bool speculative = (d_nsurv == c->d_count.p);          // n_surv is already such a bound
+    const uint64_t n_alloc = speculative ? n_surv : std::max<uint64_t>(n_surv, survivor_bound(n_surv));
+    HIPCHK(c, c->d_surv.ensure(n_alloc));
+    HIPCHK(c, c->d_dr.ensure(n_alloc * stride));
+    HIPCHK(c, c->d_ss_pool.ensure(std::max<uint64_t>(pool_cap, n_alloc * (uint64_t)lds.ss_cap)));
+    HIPCHK(c, c->d_fidx.ensure(n_alloc));
+    HIPCHK(c, D.d_read.ensure(n_alloc + 2)); HIPCHK(c, D.d_ss_off.ensure(n_alloc + 2)); HIPCHK(c, D.d_low.ensure(n_alloc + 16));
+    HIPCHK(c, D.d_replen.ensure(n_alloc + 4)); HIPCHK(c, D.d_nss.ensure(n_alloc + 4)); HIPCHK(c, D.d_dr_len.ensure(n_alloc + 8));
+    HIPCHK(c, D.d_dr.ensure(n_alloc * stride + 16)); HIPCHK(c, D.d_ss.ensure(n_alloc * (uint64_t)lds.ss_cap + 4));
     // [2] = found count, [3] = worst error, [4] = n distinct, [5] = de-duplication mismatch flag
     HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 16, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
@@ -719,11 +733,13 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     if (dedupe) {
         uint32_t tsize = 1024;
         while (tsize < n_surv * 2) tsize <<= 1;
-        HIPCHK(c, c->dd_keys.ensure(tsize)); HIPCHK(c, c->dd_first.ensure(tsize)); HIPCHK(c, c->dd_slot.ensure(n_surv));
-        HIPCHK(c, c->dd_rep.ensure(n_surv)); HIPCHK(c, c->dd_hash.ensure(n_surv)); HIPCHK(c, c->h_rep.ensure(n_surv)); HIPCHK(c, c->h_hash.ensure(n_surv));
-        HIPCHK(c, c->h_dmap.ensure(n_surv)); HIPCHK(c, c->h_dx_chars.ensure(n_surv * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(n_surv));
-        HIPCHK(c, c->h_dx_hash.ensure(n_surv));
-        HIPCHK(c, c->dd_dx_chars.ensure(n_surv * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_surv));
+        uint32_t tsize_alloc = tsize;
+        while (tsize_alloc < n_alloc * 2) tsize_alloc <<= 1;
+        HIPCHK(c, c->dd_keys.ensure(tsize_alloc)); HIPCHK(c, c->dd_first.ensure(tsize_alloc)); HIPCHK(c, c->dd_slot.ensure(n_alloc));
+        HIPCHK(c, c->dd_rep.ensure(n_alloc)); HIPCHK(c, c->dd_hash.ensure(n_alloc)); HIPCHK(c, c->h_rep.ensure(n_alloc)); HIPCHK(c, c->h_hash.ensure(n_alloc));
+        HIPCHK(c, c->h_dmap.ensure(n_alloc)); HIPCHK(c, c->h_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(n_alloc));
+        HIPCHK(c, c->h_dx_hash.ensure(n_alloc));
+        HIPCHK(c, c->dd_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_alloc));
         HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_keys.p, c->dd_first.p, tsize,
                                    c->dd_hash.p, c->dd_slot.p, c->dd_rep.p, c->stream));
         // distinct strings in first-occurrence order and every candidate's rank among them, exact
@@ -737,7 +753,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     {
         // the per-candidate records go to pinned host memory on the copy stream (the pack kernel writes them there
         // itself), behind the gather: they are not needed before the hand-off
-        const uint64_t cap = p1_blob_layout(n_surv, lds.ss_cap).total + 64;
+        const uint64_t cap = p1_blob_layout(n_alloc, lds.ss_cap).total + 64;
         D.wide_ready = false; D.dr_fallback = false;
         HIPCHK(c, D.h_blob.ensure(cap));
         HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
@@ -865,8 +881,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
     }
     if (use_filter && c->R.n_exc == 0) {                // bound for the next call: twice this call's count
-        const uint64_t hint = std::max<uint64_t>(65536, (n_surv + n_surv / 2 + 65535) & ~65535ull);
-        c->surv_cap_hint = std::min<uint64_t>(hint, kDenseMaxSurvivors);
+        c->surv_cap_hint = survivor_bound(n_surv);
     }
     if (s == CRASS_ERR_STATE) {
         // host-loop path: label records with their read index from a host copy of the survivor list
@@ -1587,14 +1602,19 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     }
     const uint64_t n_hits = spec ? c->hit_cap_hint : c->h_count.p[0];
     const uint64_t n_slots = n_hits + c->R.n_exc;
-    HIPCHK(c, c->d_rec.ensure(n_slots + 1));
-    HIPCHK(c, c->d_dr.ensure((n_slots + 1) * c->dr_stride));
-    HIPCHK(c, c->h_rec.ensure(n_slots + 1));
-    HIPCHK(c, c->h_dr.ensure((n_slots + 1) * c->dr_stride));
-    HIPCHK(c, c->h_idx.ensure(n_hits + 1));
+    // (sized for the bound the next call will speculate with, so that it does not re-allocate)
+    const uint64_t h_alloc = spec ? n_hits : std::max<uint64_t>(n_hits, hit_bound(n_hits));
+    const uint64_t s_alloc = h_alloc + c->R.n_exc;
+    HIPCHK(c, c->d_rec.ensure(s_alloc + 1));
+    HIPCHK(c, c->d_dr.ensure((s_alloc + 1) * c->dr_stride));
+    if (!(dmp && c->R.n_exc == 0)) {                // host sink only
+        HIPCHK(c, c->h_rec.ensure(s_alloc + 1));
+        HIPCHK(c, c->h_dr.ensure((s_alloc + 1) * c->dr_stride));
+        HIPCHK(c, c->h_idx.ensure(h_alloc + 1));
+    }
     if (anchors) {
-        HIPCHK(c, c->d_slot_info.ensure(n_hits + 1));
-        HIPCHK(c, c->d_slot_pid.ensure(n_hits + 1));
+        HIPCHK(c, c->d_slot_info.ensure(h_alloc + 1));
+        HIPCHK(c, c->d_slot_pid.ensure(h_alloc + 1));
         if (dmp) HIPCHK(c, launch_dm_verify(c->R, c->dm.M, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->d_slot_pid.p, c->stream));
         else HIPCHK(c, launch_recruit_list(c->R, c->A, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->d_slot_pid.p, c->stream));
     }
@@ -1613,8 +1633,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     if (dev_sink) {
         c->q_lay = p2_blob_layout(n_hits);
         c->q_wide_ready = false;
-        HIPCHK(c, c->h_qblob.ensure(c->q_lay.total + 64));
-        HIPCHK(c, c->d_fidx.ensure(n_hits + 1));
+        HIPCHK(c, c->h_qblob.ensure(p2_blob_layout(h_alloc).total + 64));
+        HIPCHK(c, c->d_fidx.ensure(h_alloc + 1));
         if (n_hits) {
             HIPCHK(c, launch_pack_p2_blob(c->d_rec.p, c->d_idx.p, c->read_base, c->d_count.p, n_hits, c->d_mask.p,
                                           c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 6, c->h_qblob.p, c->stream));
@@ -1643,8 +1663,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
             }
         }
         {
-            const uint64_t real = c->h_count.p[0];
-            c->hit_cap_hint = std::max<uint64_t>(4096, (real + real / 2 + 4095) & ~4095ull);
+            c->hit_cap_hint = hit_bound(c->h_count.p[0]);
         }
         c->q_n = *reinterpret_cast<const uint64_t *>(c->h_qblob.p);
         c->q_blob_active = true;

@@ -135,7 +135,8 @@ struct DevMerge {
     uint8_t  *ent_win;            // [16 * n_tok] entry claimed its key's slot
     uint64_t *ents;               // [16 * n_tok][3] verification index, grouped by key
     uint32_t *anchor_tab;         // [1 << tab_log_alloc] cuckoo table of the keys (see DevAnchors)
-    uint32_t *anchor_fp;          // [1 << 15] words = 2^16 16-bit fingerprints of the slots' keys (tab_mode 3)
+    uint32_t *anchor_fp;          // [1 << 15] words: tab_mode 3 = 2^16 16-bit fingerprints of the slots' keys;
+                                  // tab_mode 2 = a 2^20-bit Bloom filter (2 hashes) staged in LDS in front of the L2 probes
     uint32_t tab_log_alloc;
     uint32_t s1, s2, m1, m2;      // hash constants of the table
     uint32_t n_cu;                // compute units of the device (bounds the grid of the kernel whose waves wait for each other)

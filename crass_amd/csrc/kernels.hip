@@ -1881,6 +1881,18 @@ static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_
     }
     return (a == V) | (b == V);
 }
+// MODE 4 (device-built tables beyond the LDS tiers): 2^20-bit Bloom filter in LDS, exact keys in global memory
+static __device__ __forceinline__ bool anchor_probe_bloom(const uint32_t *bloom, const uint32_t *gtab, uint32_t V, const DevAnchors &K, uint32_t rshift)
+{
+    const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1);
+    const uint32_t h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
+    const uint32_t b1 = h1 >> 12, b2 = h2 >> 12;
+    const uint32_t w1 = bloom[b1 >> 5], w2 = bloom[b2 >> 5];
+    bool hit = false;
+    if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0u)          // ~7 % of the probes at 150 k keys
+        hit = (gtab[h1 >> rshift] == V) | (gtab[h2 >> rshift] == V);
+    return hit;
+}
 // MODE 3 (device-built tables): 2^16 slots, 16-bit fingerprints in LDS
 static __device__ __forceinline__ bool anchor_probe_fp(const uint16_t *tab, uint32_t V, const DevAnchors &K)
 {
@@ -1916,7 +1928,9 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
 #pragma unroll
                     for (int h = 0; h < 2 * W - 1; h++) {
                         uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
-                        bool hit = MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K) : anchor_probe<MODE == 3 ? 0 : MODE>(ak_lds, V, K, mask);
+                        bool hit = MODE == 4 ? anchor_probe_bloom(ak_lds, K.table, V, K, mask)
+                                             : MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
+                                                         : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
                         flag = flag | (hit & ((uint32_t)h <= h_max));
                     }
                 } else {
@@ -1924,7 +1938,11 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                     uint32_t lo = g[0];
                     for (uint32_t h = 0; h <= h_max; h += 2) {
                         uint32_t hi = ((h >> 1) + 1 < nw) ? g[(h >> 1) + 1] : 0u;
-                        auto probe = [&](uint32_t V) { return MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K) : anchor_probe<MODE == 3 ? 0 : MODE>(ak_lds, V, K, mask); };
+                        auto probe = [&](uint32_t V) {
+                            return MODE == 4 ? anchor_probe_bloom(ak_lds, K.table, V, K, mask)
+                                             : MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
+                                                         : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
+                        };
                         if (probe(lo)) flag = true;
                         if (h + 1 <= h_max && probe((lo >> 16) | (hi << 16))) flag = true;
                         lo = hi;
@@ -1973,7 +1991,9 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMe
         __syncthreads();
         anchor_filter_body<W, THREADS, 3>(R, K, ak_lds_buf, found_flag, hitmask);
     } else {
-        anchor_filter_body<W, THREADS, 2>(R, K, K.table, found_flag, hitmask);
+        for (uint32_t i = threadIdx.x; i < (1u << 15); i += THREADS) ak_lds_buf[i] = M.anchor_fp[i];
+        __syncthreads();
+        anchor_filter_body<W, THREADS, 4>(R, K, ak_lds_buf, found_flag, hitmask);
     }
 }
 
