@@ -1015,10 +1015,24 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
     h.cmask = (1u << (2 * P.window)) - 1u;
     uint64_t n_surv = EXC ? R.n_exc : (uint64_t)(*d_n_surv);
     if (n_surv > n_max) n_surv = n_max;
-    for (uint64_t s = blockIdx.x; s < n_surv; s += gridDim.x) {
+    // punt mode: only the reads the lane kernel handed over (err == 4).  Each wave looks at 64 slots at once and
+    // then walks the (rare) flagged ones, instead of every wave polling its slots one dependent load at a time.
+    uint64_t punt_base = (uint64_t)blockIdx.x * WAVE, punt_mask = 0;
+    for (uint64_t s = blockIdx.x;; ) {
+        if (punt_only) {
+            while (punt_mask == 0) {
+                if (punt_base >= n_surv) return;
+                const uint64_t q = punt_base + lane;
+                punt_mask = __ballot(q < n_surv && out[q].err == 4);
+                if (punt_mask == 0) punt_base += (uint64_t)gridDim.x * WAVE;
+            }
+            const int b = __ffsll((unsigned long long)punt_mask) - 1;
+            punt_mask &= punt_mask - 1;
+            s = punt_base + b;
+            if (punt_mask == 0) punt_base += (uint64_t)gridDim.x * WAVE;
+        } else if (s >= n_surv) return;
         uint64_t r;
         int L;
-        if (punt_only && out[s].err != 4) continue;     // only the reads the lane kernel handed over
         wave_sync();
         if (EXC) {
             r = R.exc_read[s];
@@ -1061,6 +1075,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
             }
         }
         if (lane == 0) out[s] = o;
+        if (!punt_only) s += gridDim.x;
     }
 }
 
