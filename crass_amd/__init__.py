@@ -7,7 +7,7 @@ search entry point needs the compiled library and a GPU.
 """
 from ._abi import LIB_PATH, SYMBOLS, load  # noqa: F401
 from .engine import (CrassError, FastxFile, PackedReads, SearchEngine, default_params,  # noqa: F401
-                     dr_slots, merge_host, search_pipeline, synth_packed, synth_spec, unpack_ascii)
+                     dr_slots, merge_host, merge_rebuild, search_pipeline, synth_packed, synth_spec, unpack_ascii)
 
-__all__ = ["CrassError", "FastxFile", "PackedReads", "SearchEngine", "default_params", "search_pipeline", "merge_host", "dr_slots",
+__all__ = ["CrassError", "FastxFile", "PackedReads", "SearchEngine", "default_params", "search_pipeline", "merge_host", "merge_rebuild", "dr_slots",
            "synth_packed", "synth_spec", "unpack_ascii", "load", "LIB_PATH", "SYMBOLS"]

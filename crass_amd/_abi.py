@@ -111,6 +111,8 @@ SYMBOLS = {
     "crass_hip_merge_distinct_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "crass_hip_get_merge": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),
     "crass_merge_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "crass_merge_rebuild": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                      C.c_uint32, C.POINTER(C.c_void_p)]),
     "crass_merge_get": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),
     "crass_merge_destroy": (None, [C.c_void_p]),
     "crass_hip_set_patterns": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), u32p, C.c_uint32]),

@@ -1174,6 +1174,20 @@ int crass_merge_create(const char *dr_chars, const uint16_t *dr_len, uint32_t dr
     return CRASS_OK;
 }
 
+int crass_merge_rebuild(const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
+                        const uint32_t *cand_distinct, uint64_t n, const uint32_t *gid_of, const uint8_t *dropped,
+                        uint32_t n_groups, crass_merge_handle **out)
+{
+    if (!out || (n_distinct && (!dx_chars || !dx_len || !dr_stride || !gid_of || !dropped)) || (n && !cand_distinct)) return CRASS_ERR_INVALID_ARG;
+    crass_merge_handle *h = new crass_merge_handle();
+    if (!crass::merge_from_device(h->m, dx_chars, dx_len, dr_stride, n_distinct, cand_distinct, n, gid_of, dropped, n_groups)) {
+        delete h;
+        return CRASS_ERR_INVALID_ARG;
+    }
+    *out = h;
+    return CRASS_OK;
+}
+
 int crass_merge_get(const crass_merge_handle *h, crass_merge_view *o)
 {
     if (!h || !o) return CRASS_ERR_INVALID_ARG;

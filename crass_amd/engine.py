@@ -223,6 +223,28 @@ def merge_host(dr_chars, dr_len, kmer_clust_size=6):
         lib.crass_merge_destroy(h)
 
 
+def merge_rebuild(dx_chars, dx_len, cand_distinct, gid_of, dropped, n_groups):
+    """host view of a merge from per-token results (crass_merge_rebuild): what the engine does after the device
+    merge, callable without a GPU.  dx_chars: uint8 [n_distinct, stride] in token order."""
+    lib = _abi.load()
+    dx_chars = np.ascontiguousarray(dx_chars, dtype=np.uint8)
+    dx_len = np.ascontiguousarray(dx_len, dtype=np.uint16)
+    cand = np.ascontiguousarray(cand_distinct, dtype=np.uint32)
+    gid = np.ascontiguousarray(gid_of, dtype=np.uint32)
+    drop = np.ascontiguousarray(dropped, dtype=np.uint8)
+    nd = dx_chars.shape[0]
+    stride = dx_chars.shape[1] if nd else 16
+    h = C.c_void_p()
+    _chk(lib.crass_merge_rebuild(dx_chars.ctypes.data, dx_len.ctypes.data, int(stride), int(nd), cand.ctypes.data, int(len(cand)),
+                                 gid.ctypes.data, drop.ctypes.data, int(n_groups), C.byref(h)), "crass_merge_rebuild")
+    try:
+        v = _abi.MergeView()
+        _chk(lib.crass_merge_get(h, C.byref(v)), "crass_merge_get")
+        return MergeResult(v)
+    finally:
+        lib.crass_merge_destroy(h)
+
+
 def dr_slots(strings, stride=48):
     """list[bytes] -> (uint8 [n, stride], uint16 [n]) in the C ABI's fixed-slot layout"""
     n = len(strings)

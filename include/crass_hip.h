@@ -208,6 +208,12 @@ int crass_hip_get_merge(const crass_hip_ctx *ctx, crass_merge_view *out);
 typedef struct crass_merge_handle crass_merge_handle;
 int  crass_merge_create(const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride,
                         uint64_t n_candidates, int32_t kmer_clust_size, crass_merge_handle **out);
+/* the host view of a merge whose per-token results (GID, dropped by removeRedundantRepeats) were computed
+ * elsewhere — by the device merge in the engine; exported so that the rebuild can be tested without a GPU.
+ * dx_*: the distinct DR strings in token order; cand_distinct[k] = index of candidate k's string.          */
+int  crass_merge_rebuild(const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
+                         const uint32_t *cand_distinct, uint64_t n_candidates, const uint32_t *gid_of,
+                         const uint8_t *dropped, uint32_t n_groups, crass_merge_handle **out);
 int  crass_merge_get(const crass_merge_handle *h, crass_merge_view *out);
 void crass_merge_destroy(crass_merge_handle *h);
 

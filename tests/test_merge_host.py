@@ -163,3 +163,40 @@ def test_two_rank_gloo_exchange_builds_identical_pattern_sets(ca, tmp_path):
     assert o0["groups"] == single.groups
     assert o0["patterns"] == [p.decode() for p in single.patterns]
     assert o0["groups"] == ref.groups
+
+
+@pytest.mark.parametrize("fname", ["front_offset_bug.fa.gz", "Ill100.fx.gz", "CN_gDC.fa.gz"])
+def test_host_view_rebuild_from_per_token_results(ca, fname):
+    """what the engine does after the device merge (tokens / groups / pattern list from GID + dropped flag per
+    token, reference sort/partition order, lazily indexed token table), fed with the host merge's own results:
+    it must reproduce that merge field for field"""
+    recs = fastx.read_fastx(os.path.join(DATA, fname))
+    ref = orc.pipeline([r[2] for r in recs], [r[0] for r in recs], do_pass2=False)
+    cands = oracle_candidates(ref)
+    chars, lens = ca.dr_slots(cands)
+    m = ca.merge_host(chars, lens)
+    # distinct strings in first-occurrence order and every candidate's index among them
+    first, order = {}, []
+    cand_distinct = np.empty(len(cands), np.uint32)
+    for k, s in enumerate(cands):
+        if s not in first:
+            first[s] = len(order)
+            order.append(k)
+        cand_distinct[k] = first[s]
+    assert [cands[k] for k in order] == m.tokens
+    gid_of = np.zeros(len(order), np.uint32)
+    for g, toks in enumerate(m.groups):
+        for t in toks:
+            gid_of[t - 2] = g + 1
+    kept = set(m.patterns)
+    dropped = np.array([0 if t in kept else 1 for t in m.tokens], np.uint8)
+    r = ca.merge_rebuild(chars[order], lens[order], cand_distinct, gid_of, dropped, len(m.groups))
+    assert r.tokens == m.tokens and r.groups == m.groups
+    assert r.patterns == m.patterns and list(r.pat_group) == list(m.pat_group)
+    assert r.cand_token.tolist() == m.cand_token.tolist()
+    assert r.next_free_gid == m.next_free_gid
+    # inconsistent input is refused, not trusted
+    bad = gid_of.copy()
+    bad[0] = len(m.groups) + 5
+    with pytest.raises(ca.CrassError):
+        ca.merge_rebuild(chars[order], lens[order], cand_distinct, bad, dropped, len(m.groups))
