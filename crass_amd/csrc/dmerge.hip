@@ -11,6 +11,7 @@
 // All integer work on a few 10^4 short strings: no MFMA, no HBM roofline to speak of — the point of
 // running it here is that the step no longer leaves the device between pass 1 and pass 2.
 #include "engine_internal.h"
+#include <algorithm>
 
 namespace crass {
 
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
     if (tid == 0) {
         DevMergeState s{};
         s.k0 = 0xFFFFFFFFu;
+        s.fail = M.inject_fail ? 16u : 0u;
         *M.st = s;
     }
 }
@@ -169,7 +171,9 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
 }
 
 // exclusive scan of n uint32 (n known on the host), one workgroup; *total = sum
-__global__ __launch_bounds__(1024) void k_dm_scan(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n, uint32_t *total)
+// roots != nullptr: the scanned value of element i is (roots[i] == i), i.e. "token i founded a group"
+__global__ __launch_bounds__(1024) void k_dm_scan(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n, uint32_t *total,
+                                                   const uint32_t *roots)
 {
     if (d_n && *d_n + 1u < n) n = *d_n + 1u;            // per-group arrays: only the first n_groups (+1) entries are live
     __shared__ uint32_t wsum[16];
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(1024) void k_dm_scan(const uint32_t *in, uint32_t *
         const uint32_t i0 = base + threadIdx.x * 4;
         uint32_t v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? in[i0 + k] : 0u;
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? (roots ? (roots[i0 + k] == i0 + k ? 1u : 0u) : in[i0 + k]) : 0u;
         const uint32_t mine = v[0] + v[1] + v[2] + v[3];
         uint32_t incl = mine;
 #pragma unroll
@@ -205,11 +209,6 @@ __global__ __launch_bounds__(1024) void k_dm_scan(const uint32_t *in, uint32_t *
 }
 
 // ---- 3. group ids: roots numbered in token order (= nextFreeGID++ order, :1598) ----
-__global__ __launch_bounds__(256) void k_dm_flag_roots(DevMerge M)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < M.n_tok) M.tmp[t] = (M.root_of[t] == t) ? 1u : 0u;
-}
 // Group sizes and member order.  A few large groups would serialise ~n_tok atomics on a few addresses, so up to
 // kLdsGroups groups are first counted per block in LDS and only the block totals go to memory.
 #define kLdsGroups 4096
@@ -486,29 +485,23 @@ __global__ __launch_bounds__(256) void k_dm_key_fill(DevMerge M)
 // table size: load <= 1/3 (<= 1/2 at the limits), as build_anchors (merge.cpp).  Up to 2^14 keys: exact keys in
 // LDS; up to 2^15: a 2^16-slot table whose 16-bit fingerprints are staged in LDS (a superset filter, 2 * 2^-16
 // false positives per probe — the flagged reads are verified exactly anyway); beyond: exact keys probed in L2.
-__global__ void k_dm_cuckoo_params(DevMerge M)
+static __device__ __forceinline__ void dm_table_params(uint32_t n, uint32_t tab_log_alloc, uint32_t &ls, uint32_t &mode)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const uint32_t n = M.st->n_keys;
-    uint32_t ls = 0, mode = 0;
+    ls = 0; mode = 0;
     for (uint32_t log = 10; log <= 15 && !ls; log++) {
         const uint32_t size = 1u << log;
         if (n * 3 > size && log != 15) continue;
         if (n * 2 > size) continue;
         ls = log;
     }
-    if (!ls && n * 2 <= 65536u && M.tab_log_alloc >= 16) { ls = 16; mode = 3; }
-    for (uint32_t log = 17; log <= M.tab_log_alloc && !ls; log++) {
+    if (!ls && n * 2 <= 65536u && tab_log_alloc >= 16) { ls = 16; mode = 3; }
+    for (uint32_t log = 17; log <= tab_log_alloc && !ls; log++) {
         const uint32_t size = 1u << log;
-        if (n * 3 > size && log != M.tab_log_alloc) continue;
+        if (n * 3 > size && log != tab_log_alloc) continue;
         if (n * 2 > size) continue;
         ls = log; mode = 2;
     }
-    if (ls > M.tab_log_alloc) ls = 0;
-    if (!ls || n == 0) atomicOr(&M.st->fail, 2u);
-    M.st->log_size = ls;
-    M.st->tab_mode = mode;
-    M.st->n_patterns = 2 * M.st->n_survivors;
+    if (ls > tab_log_alloc) ls = 0;
 }
 
 // two-choice cuckoo insertion, all keys at once: a key is always either in the table or in exactly one
@@ -517,16 +510,23 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_insert(DevMerge M)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t pid = e >> 3, r = e & 7u;
-    if (pid >= 2 * M.st->n_survivors || !M.ent_win[e] || M.st->fail) return;
+    // every thread derives the table shape from the key count (a handful of scalar instructions); thread 0 records it
+    uint32_t ls, mode;
+    dm_table_params(M.st->n_keys, M.tab_log_alloc, ls, mode);
+    if (e == 0) {
+        if (!ls || M.st->n_keys == 0) atomicOr(&M.st->fail, 2u);
+        M.st->log_size = ls; M.st->tab_mode = mode; M.st->n_patterns = 2 * M.st->n_survivors;
+    }
+    if (!ls || pid >= 2 * M.st->n_survivors || !M.ent_win[e] || (M.st->fail & ~2u)) return;
     uint32_t cur = (uint32_t)shr128_lo(M.pat_packed[(uint64_t)pid * 2], M.pat_packed[(uint64_t)pid * 2 + 1], 2 * r);
-    if (M.st->tab_mode == 2) {
+    if (mode == 2) {
         // key sets beyond the LDS tiers: the exact table is probed in L2, behind a 2^20-bit Bloom filter in LDS
         const uint32_t b1 = ((uint32_t)__umul24(cur ^ (cur >> M.s1), M.m1)) >> 12, b2 = ((uint32_t)__umul24(cur ^ (cur >> M.s2), M.m2)) >> 12;
         atomicOr(&M.anchor_fp[b1 >> 5], 1u << (b1 & 31u));
         atomicOr(&M.anchor_fp[b2 >> 5], 1u << (b2 & 31u));
     }
     if (cur == 0xFFFFFFFFu) return;
-    const uint32_t rsh = 32u - M.st->log_size;
+    const uint32_t rsh = 32u - ls;
     uint32_t pos = ak_h(cur, M.s1, M.m1, rsh);
     for (int kicks = 0; kicks < 1000; kicks++) {
         const uint32_t old = atomicExch(&M.anchor_tab[pos], cur);
@@ -546,9 +546,13 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_finalize(DevMerge M)
     if (M.anchor_tab[i] == 0xFFFFFFFFu) M.anchor_tab[i] = M.st->k0;
 }
 // tab_mode 3: fingerprint = low 16 bits of (h1 product ^ h2 product) of the slot's key, two per word
+// ... and, in the same launch, the per-token results + state words go straight into pinned host memory (a few
+// 10 KB over PCIe, no copy calls): the helper thread rebuilds the host view from them
 __global__ __launch_bounds__(256) void k_dm_cuckoo_fp(DevMerge M)
 {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w == 0) *M.h_st = *M.st;
+    if (w < M.n_tok) { M.h_gid[w] = M.gid_of[w]; M.h_blank[w] = M.blank[w]; }
     if (M.st->tab_mode != 3 || w >= (1u << 15)) return;
     uint32_t out = 0;
 #pragma unroll
@@ -560,13 +564,6 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_fp(DevMerge M)
     M.anchor_fp[w] = out;
 }
 
-// per-token results + state words straight into pinned host memory (a few 10 KB over PCIe): no copy calls
-__global__ __launch_bounds__(256) void k_dm_export(DevMerge M, DevMergeState *h_st, uint32_t *h_gid, uint8_t *h_blank)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) *h_st = *M.st;
-    if (t < M.n_tok) { h_gid[t] = M.gid_of[t]; h_blank[t] = M.blank[t]; }
-}
 // ---- one-collective exchange ----
 __global__ __launch_bounds__(256) void k_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride,
                                                   uint64_t cap_rows, uint32_t slot_bytes, uint8_t *send)
@@ -627,12 +624,6 @@ hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, 
     return hipGetLastError();
 }
 
-hipError_t launch_dm_export(const DevMerge &M, DevMergeState *h_st, uint32_t *h_gid, uint8_t *h_blank, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_dm_export, dim3((M.n_tok + 255) / 256), dim3(256), 0, st, M, h_st, h_gid, h_blank);
-    return hipGetLastError();
-}
-
 hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
 {
     if (M.n_tok == 0) return hipErrorInvalidValue;
@@ -643,11 +634,11 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     unsigned gb = (M.n_tok + 15) / 16;
     if (gb > M.n_cu) gb = M.n_cu;
     hipLaunchKernelGGL(k_dm_greedy, dim3(gb), dim3(1024), 0, st, M);
-    hipLaunchKernelGGL(k_dm_flag_roots, dim3(nb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.tmp, M.root_rank, M.n_tok, (const uint32_t *)nullptr, &M.st->n_groups);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)nullptr, M.root_rank, M.n_tok, (const uint32_t *)nullptr, &M.st->n_groups,
+                       (const uint32_t *)M.root_of);
     const unsigned nb4 = (M.n_tok + 1023) / 1024;
     hipLaunchKernelGGL(k_dm_gid, dim3(nb4), dim3(1024), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.grp_cnt, M.grp_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.grp_cnt, M.grp_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, (uint32_t *)nullptr, (const uint32_t *)nullptr);
     hipLaunchKernelGGL(k_dm_scatter, dim3(nb4), dim3(1024), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_keys, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
@@ -656,16 +647,15 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_sblank, dim3(nb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, &M.st->n_survivors);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, &M.st->n_survivors, (const uint32_t *)nullptr);
     hipLaunchKernelGGL(k_dm_patterns, dim3(nb), dim3(256), 0, st, M);
     const unsigned ne = (16u * M.n_tok + 255) / 256;
     hipLaunchKernelGGL(k_dm_keys, dim3(ne), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_key_bases, dim3(ne), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_key_fill, dim3(ne), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_cuckoo_params, dim3(1), dim3(64), 0, st, M);
     hipLaunchKernelGGL(k_dm_cuckoo_insert, dim3(ne), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_cuckoo_finalize, dim3((unsigned)(((1ull << M.tab_log_alloc) + 255) / 256)), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_cuckoo_fp, dim3(128), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_cuckoo_fp, dim3(std::max(128u, nb)), dim3(256), 0, st, M);
     return hipGetLastError();
 }
 

@@ -743,7 +743,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_keys.p, c->dd_first.p, tsize,
                                    c->dd_hash.p, c->dd_slot.p, c->dd_rep.p, c->stream));
         // distinct strings in first-occurrence order and every candidate's rank among them, exact
-        HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->d_mask.p,
+        HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->dd_slot.p, c->dd_first.p, c->d_mask.p,
                                    c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
                                    c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream));
         if (c->xchg.active)                             // multi-rank: the list goes straight into the collective's send buffer
@@ -1120,6 +1120,8 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
         c->n_cu = (uint32_t)v;
     }
     M.n_cu = c->n_cu;
+    M.h_st = d.h_st.p; M.h_gid = d.h_gid.p; M.h_blank = d.h_blank.p;
+    M.inject_fail = getenv("CRASS_DM_INJECT_FAIL") ? 1u : 0u;
     M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
     d.M = M;
     const double tl0 = now_ms();
@@ -1127,10 +1129,7 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     HIPCHK(c, launch_device_merge(M, c->stream));
     HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
     if (getenv("CRASS_MERGE_PROFILE")) fprintf(stderr, "[crass_dm] host: launching the merge kernels took %.3f ms\n", now_ms() - tl0);
-    if (getenv("CRASS_DM_INJECT_FAIL"))                           // tests: exercise the fall-back to the host merge
-        HIPCHK(c, hipMemsetAsync(&d.st.p->fail, 1, 4, c->stream));
     // the per-token results the host view is rebuilt from (a few 10 KB)
-    HIPCHK(c, launch_dm_export(M, d.h_st.p, d.h_gid.p, d.h_blank.p, c->stream));
     HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
     d.active = true; d.host_built = false; d.n_cand = c->dense.n;
     // the host view (tokens, groups, pattern list) is rebuilt by the helper thread as soon as the kernels are through
@@ -1358,7 +1357,7 @@ static int merge_global_device(crass_hip_ctx *c, uint64_t n_global, uint64_t my_
     HIPCHK(c, hipMemsetAsync(c->d_count.p + 4, 0, 8, c->stream));
     HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, c->d_count.p + 7, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p,
                                d.g_rep.p, c->stream));
-    HIPCHK(c, launch_dx_tokens(d.g_chars.p, d.g_len.p, d.g_hash.p, stride, c->d_count.p + 7, n, d.g_rep.p, d.g_mask.p, d.g_prefix.p, d.g_bsum.p,
+    HIPCHK(c, launch_dx_tokens(d.g_chars.p, d.g_len.p, d.g_hash.p, stride, c->d_count.p + 7, n, d.g_rep.p, d.g_slot.p, d.g_first.p, d.g_mask.p, d.g_prefix.p, d.g_bsum.p,
                                d.g_idx.p, c->d_count.p + 4, c->d_count.p + 5, d.h_gmap.p, d.h_gx_chars.p, d.h_gx_len.p, d.h_gx_hash.p,
                                d.gx_chars.p, d.gx_len.p, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_count.p + 4, c->d_count.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1437,7 +1436,7 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
         // the global count lives on the device (xinfo[0]); n_max bounds it
         HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, X.xinfo.p, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p, d.g_rep.p,
                                    c->stream));
-        HIPCHK(c, launch_dx_tokens(d.g_chars.p, d.g_len.p, d.g_hash.p, stride, X.xinfo.p, n, d.g_rep.p, d.g_mask.p, d.g_prefix.p, d.g_bsum.p,
+        HIPCHK(c, launch_dx_tokens(d.g_chars.p, d.g_len.p, d.g_hash.p, stride, X.xinfo.p, n, d.g_rep.p, d.g_slot.p, d.g_first.p, d.g_mask.p, d.g_prefix.p, d.g_bsum.p,
                                    d.g_idx.p, c->d_count.p + 4, c->d_count.p + 5, d.h_gmap.p, d.h_gx_chars.p, d.h_gx_len.p, d.h_gx_hash.p,
                                    d.gx_chars.p, d.gx_len.p, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 4, c->d_count.p + 4, 8, hipMemcpyDeviceToHost, c->stream));

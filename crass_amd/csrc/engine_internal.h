@@ -141,6 +141,9 @@ struct DevMerge {
     uint32_t s1, s2, m1, m2;      // hash constants of the table
     uint32_t n_cu;                // compute units of the device (bounds the grid of the kernel whose waves wait for each other)
     DevMergeState *st;
+    // pinned host memory the last kernel exports to (state words, GID and dropped flag per token)
+    DevMergeState *h_st; uint32_t *h_gid; uint8_t *h_blank;
+    uint32_t inject_fail;         // tests only: start with the fail word set (exercises the fall-back to the host merge)
 };
 
 // one-collective exchange (see crass_hip_exchange_setup): fill this rank's send buffer / unpack the gathered buffers
@@ -150,7 +153,6 @@ hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const ui
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
                             char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st);
 hipError_t launch_device_merge(const DevMerge &M, hipStream_t st);
-hipError_t launch_dm_export(const DevMerge &M, DevMergeState *h_st, uint32_t *h_gid, uint8_t *h_blank, hipStream_t st);
 // pass-2 anchor filter with table parameters read from the device (M.st); flags nothing when M.st->fail
 hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st);
 hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
@@ -244,7 +246,8 @@ __host__ __device__ inline P2Blob p2_blob_layout(uint64_t cap)
 hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base,
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
                                uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st);
-hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, const uint32_t *rep,
+hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, uint32_t *rep,
+                            const uint32_t *slot_of, const uint32_t *first,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
                             char *dev_chars, uint16_t *dev_len, hipStream_t st);

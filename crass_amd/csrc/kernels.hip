@@ -1593,6 +1593,11 @@ static __device__ uint64_t dr_hash64(const char *p, uint32_t n)
     return h ^ (h >> 31);
 }
 
+__global__ __launch_bounds__(256) void k_dr_dedupe_clear(unsigned long long *keys, uint32_t *first, uint32_t table_size)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < table_size; i += gridDim.x * blockDim.x) { keys[i] = 0ull; first[i] = 0xFFFFFFFFu; }
+}
+
 __global__ __launch_bounds__(256) void k_dr_dedupe_insert(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n,
                                                            uint32_t n_max, unsigned long long *keys, uint32_t *first, uint32_t mask,
                                                            uint64_t *hash_out, uint32_t *slot_out)
@@ -1613,25 +1618,15 @@ __global__ __launch_bounds__(256) void k_dr_dedupe_insert(const char *dr, const 
     slot_out[k] = slot;
 }
 
-__global__ __launch_bounds__(256) void k_dr_dedupe_rep(const uint32_t *slot_of, const uint32_t *first, const uint32_t *d_n, uint32_t n_max,
-                                                        uint32_t *rep)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < min(*d_n, n_max)) rep[k] = first[slot_of[k]];
-}
-
 // the candidate count lives on the device (*d_n, at most n_max): no host round trip before this launch
 hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n, unsigned long long *keys,
                             uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(keys, 0, (size_t)table_size * 8, st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(first, 0xFF, (size_t)table_size * 4, st);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_dr_dedupe_clear, dim3((unsigned)std::min<uint32_t>((table_size + 255) / 256, 2048u)), dim3(256), 0, st, keys, first, table_size);
     const unsigned nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_dr_dedupe_insert, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, keys, first, table_size - 1, hash_out, slot_tmp);
-    hipLaunchKernelGGL(k_dr_dedupe_rep, dim3(nb), dim3(256), 0, st, slot_tmp, first, d_n, n, rep);
+    (void)rep;                                  // rep[] = first occurrence of every candidate: written by k_dx_flag
     return hipGetLastError();
 }
 
@@ -1640,13 +1635,14 @@ hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t str
 // byte for byte with its representative, so a 64-bit hash collision between different strings is
 // DETECTED (flag) and the host then takes its plain path.
 __global__ __launch_bounds__(256) void k_dx_flag(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n_max,
-                                                  const uint32_t *rep, uint64_t *mask, uint32_t *d_mismatch)
+                                                  const uint32_t *slot_of, const uint32_t *first, uint32_t *rep, uint64_t *mask, uint32_t *d_mismatch)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = min(*d_n, n_max);
     bool is_rep = false;
     if (k < n) {
-        const uint32_t f = rep[k];
+        const uint32_t f = first[slot_of[k]];               // (was k_dr_dedupe_rep: one launch less)
+        rep[k] = f;
         is_rep = (f == k);
         if (!is_rep) {
             bool same = f < k && dr_len[f] == dr_len[k];
@@ -1697,14 +1693,15 @@ __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const
 // needs stride % 16 == 0; mask / word_prefix / block_sums / dx_idx are scratch of >= n bits / words.  The candidate
 // count is *d_n (<= n).  dmap / out_* may be pinned host memory: the kernels then write the merge's inputs
 // straight into it (a few hundred KB; no copy calls on the critical path).
-hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, const uint32_t *rep,
+hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, uint32_t *rep,
+                            const uint32_t *slot_of, const uint32_t *first,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
                             char *dev_chars, uint16_t *dev_len, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     const unsigned nb = (n + 255) / 256;
-    hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, rep, mask, d_mismatch);
+    hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, mask, d_mismatch);
     hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap);
