@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: many synthetic read sets with varied shapes through the HIP path and
+the oracle, field-by-field comparison (tests/parity.py).  Not part of the test suite (minutes of oracle time);
+run it after touching a kernel:  python tools/parity_sweep.py [n_cases] [seed]"""
+import os, sys, random, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import crass_amd as ca
+from tests import orc
+from tests.parity import assert_same_pipeline
+ca.load()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+eng = ca.SearchEngine()          # one context reused: speculative bounds, buffer reuse, helper thread all get exercised
+bad = 0
+t_start = time.time()
+for case in range(n_cases):
+    L = rng.choice([75, 100, 101, 125, 150, 150, 150, 151, 250, 251, 64, 200])
+    n = rng.choice([3000, 20000, 60000, 150000])
+    n_dr = rng.choice([1, 3, 10, 50, 200, 1500])
+    cpm = rng.choice([2000, 10000, 50000, 300000])
+    k = rng.choice([6, 6, 6, 4, 8, 12])
+    spec = ca.synth_spec(read_len=L, n_dr=n_dr, crispr_per_million=cpm, seed=rng.randrange(1 << 30))
+    w = ca.synth_packed(spec, rng.randrange(1 << 20), n)
+    asc = ca.unpack_ascii(w, (L + 15) // 16, L, n)
+    seqs = [asc[i * L:(i + 1) * L].tobytes() for i in range(n)]
+    ragged = rng.random() < 0.25
+    if ragged:
+        seqs = [s[:rng.randint(40, L)] if rng.random() < 0.3 else s for s in seqs]
+    p = ca.default_params(kmer_clust_size=k)
+    host = rng.random() < 0.15
+    if host:
+        os.environ["CRASS_HOST_MERGE"] = "1"
+    try:
+        gpu = ca.search_pipeline(seqs, params=p, engine=eng if rng.random() < 0.7 and k == 6 else None)
+    finally:
+        os.environ.pop("CRASS_HOST_MERGE", None)
+    ref = orc.pipeline(seqs, params=orc.Params(p.lowDRsize, p.highDRsize, p.lowSpacerSize, p.highSpacerSize, p.searchWindowLength,
+                                               p.minNumRepeats, p.kmer_clust_size))
+    tag = "L=%d n=%d n_dr=%d cpm=%d k=%d ragged=%d host=%d" % (L, n, n_dr, cpm, k, ragged, host)
+    try:
+        assert_same_pipeline(gpu, ref)
+        print("ok   %-60s pass1 %6d pass2 %6d groups %4d patterns %5d devmerge %d" % (tag, gpu.n_pass1, gpu.n_pass2, gpu.n_groups, gpu.n_patterns,
+                                                                                      gpu.counters["used_device_merge"]), flush=True)
+    except AssertionError as e:
+        bad += 1
+        print("FAIL %s: %s" % (tag, str(e)[:300]), flush=True)
+print("%d cases, %d failures, %.0fs" % (n_cases, bad, time.time() - t_start))
+sys.exit(1 if bad else 0)
