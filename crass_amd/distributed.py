@@ -117,6 +117,10 @@ class GatheredExchange:
         self.eng, self.dist, self.device = eng, dist, device
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self._setup(cap_rows)
+        # bring the communicator up now (RCCL initialises lazily on the first collective): not inside a timed step
+        import torch
+        self.dist.all_gather_into_tensor(self.recv, self.send)
+        torch.cuda.current_stream(self.device).synchronize()
 
     def _setup(self, cap_rows):
         import torch
