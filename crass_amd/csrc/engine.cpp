@@ -598,8 +598,15 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                          const uint64_t *surv_idx_host)
 {
     if (n_total == 0) return CRASS_OK;
-    const SurvLds lds = survivor_lds_layout(c->max_len, c->dp);
-    if (lds.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
+    // Long reads: the Levenshtein fallback rows are sized for 2 k-long strings (spacers are a few dozen bases), which
+    // is what lets several waves share a CU's LDS; a read that needs longer rows comes back with err == 6 and is
+    // redone by a second launch with the uncapped layout.
+    const SurvLds lds_full = survivor_lds_layout(c->max_len, c->dp);
+    if (lds_full.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
+    uint32_t row_cap = 2048;
+    if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));        // tests: force the second launch
+    const SurvLds lds = survivor_lds_layout(c->max_len, c->dp, row_cap);
+    const bool capped = lds.row_elems != lds_full.row_elems;
     const uint64_t chunk_cap = std::min<uint64_t>(n_total, 1u << 20);
     const uint64_t ss_per = std::min<uint64_t>(lds.ss_cap, 64);
     const uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(chunk_cap * ss_per, 1u << 16), 1ull << 28);
@@ -624,6 +631,11 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                                   c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                   c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds,
                                   (int)std::min<uint64_t>(grid, nchunk), c->stream));
+        if (capped)
+            HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
+                                      c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
+                                      c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds_full,
+                                      (int)std::min<uint64_t>(grid, nchunk), c->stream, 6));
         if (!exc && off == 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->d_surv.p, nchunk * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, nchunk * stride, hipMemcpyDeviceToHost, c->stream));
@@ -717,7 +729,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     if (le != hipSuccess && le != hipErrorNotSupported) { c->last_hip = (int)le; return CRASS_ERR_HIP; }
     HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
                               c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, hints, lds,
-                              (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, le == hipSuccess));
+                              (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, le == hipSuccess ? 4 : 0));
     HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
     const uint64_t n_words = (n_surv + 63) / 64;
     HIPCHK(c, launch_found_mask(c->d_surv.p, d_nsurv, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream));

@@ -185,7 +185,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            SurvOut *out, char *dr_chars, uint32_t dr_stride,
                            uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
                            uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
-                           bool punt_only = false);
+                           int punt_only = 0);
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                  uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st);
@@ -253,7 +253,9 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
                             char *dev_chars, uint16_t *dev_len, hipStream_t st);
 hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n, unsigned long long *keys,
                             uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st);
-SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P);
+// row_len_cap: longest string the Levenshtein fallback rows hold in this layout (reads that need more come back
+// with err == 6 and are redone with the uncapped layout)
+SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P, uint32_t row_len_cap = 0xFFFFFFFFu);
 hipError_t upload_comp_table(const unsigned char *tab128);
 
 } // namespace crass

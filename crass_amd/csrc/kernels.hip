@@ -392,6 +392,7 @@ struct RH {                 // ReadHolder state (ReadHolder.h:440-451), wave-uni
     int replen;             // RH_RepeatLength
     int err;
     uint16_t *rowA, *rowB;  // Levenshtein block-boundary rows (LDS)
+    int row_cap;            // entries per row; a longer string makes qc return -3 (the read is redone with full-size rows)
     float *sims;            // LDS scratch for the QC similarities (ss_cap floats)
     const uint32_t *words;  // LDS copy of the 2-bit packed read (+1 zero word), nullptr for exception reads
     uint32_t cmask;         // (1 << 2w) - 1
@@ -794,6 +795,7 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
                 uint32_t as = h.ss[2 * ii + 1] + 1, al = 0, bs = h.ss[2 * ii + 3] + 1, bl = 0;
                 (void)substr_len(h.L, as, h.ss[2 * ii + 2] - as, al);
                 (void)substr_len(h.L, bs, h.ss[2 * ii + 4] - bs, bl);
+                if ((int)std::max(std::max(al, bl), rep_len) + 8 > h.row_cap) return -3;
                 float sw = (qq & 1) ? wave_similarity(h.seq + as, (int)al, h.seq + bs, (int)bl, h.rowA, h.rowB, lane)
                                     : wave_similarity(repeat, (int)rep_len, h.seq + as, (int)al, h.rowA, h.rowB, lane);
                 if (lane == 0) h.sims[qq] = sw;
@@ -843,6 +845,7 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
         if ((int)sp_len > maxSpacerLength) return 0;
         bool fb = false;
         float similarity = (dbg == 5) ? 0.0f : lane_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, fb);     // same pair in every lane
+        if (fb && (int)std::max(sp_len, rep_len) + 8 > h.row_cap) return -3;
         if (fb) similarity = wave_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, h.rowA, h.rowB, lane);
         if ((double)similarity > 0.82) return 0;
         int dlen = (int)sp_len - (int)rep_len;
@@ -900,6 +903,7 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
             uint32_t actual_repeat_length = extend_pre_repeat(h, (int)o.window, (int)o.lowSp, lane);
             if (o.debug_stop != 3 && (actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {
                 int qc = qc_found_repeats(h, (int)o.lowSp, (int)o.highSp, lane, o.debug_stop);
+                if (qc == -3) return -3;
                 if (qc < 0) return -1;
                 if (qc) return 1;
             }
@@ -1009,13 +1013,14 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
     h.cap = (int)lds.ss_cap;
     h.rowA = reinterpret_cast<uint16_t *>(h.ss + lds.ss_cap);
     h.rowB = h.rowA + lds.row_elems;
+    h.row_cap = (int)lds.row_elems;
     uint32_t *l_words = reinterpret_cast<uint32_t *>(h.rowB + lds.row_elems);
     h.words = EXC ? nullptr : l_words;
     h.sims = reinterpret_cast<float *>(l_words + lds.words_cap);
     h.cmask = (1u << (2 * P.window)) - 1u;
     uint64_t n_surv = EXC ? R.n_exc : (uint64_t)(*d_n_surv);
     if (n_surv > n_max) n_surv = n_max;
-    // punt mode: only the reads the lane kernel handed over (err == 4).  Each wave looks at 64 slots at once and
+    // punt mode: only the reads an earlier launch handed over (err == punt_only: 4 from the lane kernel, 6 = row buffer).  Each wave looks at 64 slots at once and
     // then walks the (rare) flagged ones, instead of every wave polling its slots one dependent load at a time.
     uint64_t punt_base = (uint64_t)blockIdx.x * WAVE, punt_mask = 0;
     for (uint64_t s = blockIdx.x;; ) {
@@ -1023,7 +1028,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
             while (punt_mask == 0) {
                 if (punt_base >= n_surv) return;
                 const uint64_t q = punt_base + lane;
-                punt_mask = __ballot(q < n_surv && out[q].err == 4);
+                punt_mask = __ballot(q < n_surv && out[q].err == (uint8_t)punt_only);
                 if (punt_mask == 0) punt_base += (uint64_t)gridDim.x * WAVE;
             }
             const int b = __ffsll((unsigned long long)punt_mask) - 1;
@@ -1051,7 +1056,8 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
         int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane, ph);
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
-        if (f < 0) o.err = (f == -2) ? 2 : 1;
+        if (f == -3) o.err = 6;                              // Levenshtein rows too short in this launch's LDS layout
+        else if (f < 0) o.err = (f == -2) ? 2 : 1;
         if (f == 1 && P.debug_stop != 4) {
             int low = 0;
             int dlen = dr_low_lexi(h, dr_chars + s * (uint64_t)dr_stride, (int)dr_stride, low, lane);
@@ -1709,13 +1715,13 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
     return hipGetLastError();
 }
 
-SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P)
+SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P, uint32_t row_len_cap)
 {
     SurvLds l;
     l.seq_bytes = ((max_len + 16 + 16) + 15u) & ~15u;
     uint32_t reps = max_len / (P.window + P.lowSp) + 4;
     l.ss_cap = ((2 * reps) + 3u) & ~3u;
-    l.row_elems = ((max_len + 8) + 7u) & ~7u;
+    l.row_elems = ((std::min(max_len, row_len_cap) + 8) + 7u) & ~7u;
     l.words_cap = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
     l.total_bytes = l.seq_bytes + l.ss_cap * 4 + 2 * l.row_elems * 2 + l.words_cap * 4 + l.ss_cap * 4;
     return l;
@@ -1725,7 +1731,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            const uint32_t *d_n_surv, uint64_t n_surv_max, SurvOut *out, char *dr_chars,
                            uint32_t dr_stride, uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
                            uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
-                           bool punt_only)
+                           int punt_only)
 {
     if (n_surv_max == 0) return hipSuccess;
     hipError_t e;
@@ -1733,12 +1739,12 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_survivor<true>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only ? 1 : 0);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_survivor<false>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only ? 1 : 0);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only);
     }
     return hipGetLastError();
 }

@@ -87,6 +87,14 @@ def test_synthetic_ragged_with_exceptions_and_duplicate_headers(ca):
     ref = orc.pipeline(seqs, hdrs)
     assert_same_pipeline(gpu, ref)
     assert gpu.counters["n_exceptions"] > 500
+    # the wave kernel's two-launch form (short Levenshtein rows first, reads that need longer ones redone with the
+    # full layout): rows of 8 entries force the second launch for every fallback comparison
+    os.environ["CRASS_ROW_CAP"] = "8"
+    try:
+        again = ca.search_pipeline(seqs, hdrs)
+    finally:
+        os.environ.pop("CRASS_ROW_CAP", None)
+    assert_same_pipeline(again, ref)
 
 
 PARAM_SETS = [
