@@ -112,7 +112,7 @@ FileState &open_file(const char *path, const options &opts)
         CRASS_THROW(std::string("Could not open FASTQ ") + path + " for reading.");
     }
     chk(rc, "crass_read_fastx");
-    chk(crass_pack_reads(f->fx.seq, f->fx.seq_off, f->fx.n_reads, 0, &f->pk), "crass_pack_reads");
+    chk(crass_pack_reads(f->fx.seq, f->fx.seq_off, f->fx.n_reads, 2, &f->pk), "crass_pack_reads");
     const double t2 = now();
     for (uint64_t i = 0; i < f->fx.n_reads; i++) if (f->fx.header_id[i] != i) { f->unique_headers = false; break; }
     crass_params p = to_params(opts);

@@ -829,7 +829,8 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     const bool use_filter = c->max_len <= 2048;
     if (use_filter) {
         hipError_t fe = hipErrorNotSupported;
-        if (c->uniform && c->R.stride_words >= 4 && c->R.stride_words <= 16) fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->d_hit_info.p, c->stream);
+        // (uniform STRIDE is what the bit-parallel kernel needs; the lengths may differ — trimmed reads padded to one stride)
+        if (c->R.stride_words >= 4 && c->R.stride_words <= 16) fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->d_hit_info.p, c->stream);
         if (fe == hipSuccess) fast = true;
         else if (fe == hipErrorNotSupported) { HIPCHK(c, launch_filter_general(c->R, c->dp, c->d_mask.p, c->max_len, c->stream)); }
         else { c->last_hip = (int)fe; return CRASS_ERR_HIP; }

@@ -67,6 +67,14 @@ int crass_pack_reads(const uint8_t *seqs, const uint64_t *off, uint64_t n, int p
     if (n == 0) min_len = 0;
     const bool uniform_len = (n > 0 && max_len == min_len);
     uint32_t stride = 0;
+    if (pad_uniform == 2) {
+        // auto: short reads of differing lengths (trimmed Illumina data) are padded to one stride when that costs at
+        // most twice the words — the bit-parallel filter and the lane-per-read kernels need a uniform stride
+        uint64_t tight = 0;
+        for (uint64_t i = 0; i < n; i++) tight += (off[i + 1] - off[i] + 15) / 16;
+        const uint64_t padded = n * (uint64_t)((max_len + 15) / 16);
+        pad_uniform = (max_len <= 256 && max_len >= 64 && padded <= 2 * tight) ? 1 : 0;
+    }
     if (pad_uniform || uniform_len) stride = std::max<uint32_t>(1, (max_len + 15) / 16);
     if (!stride) {
         o->word_off.resize(n + 1);

@@ -497,9 +497,10 @@ class PipelineResult:
         return self.ss_pool[o:o + int(self.rec_nss[k])].tolist()
 
 
-def search_pipeline(seqs, headers=None, params=None, device=0, do_pass2=True, engine=None):
-    """pass 1 -> merge -> pass 2 on one GPU for host reads (list[bytes]); returns PipelineResult."""
-    packed = PackedReads(seqs)
+def search_pipeline(seqs, headers=None, params=None, device=0, do_pass2=True, engine=None, pad_uniform=0):
+    """pass 1 -> merge -> pass 2 on one GPU for host reads (list[bytes]); returns PipelineResult.
+    pad_uniform: crass_pack_reads' layout switch (0 tight, 1 one stride, 2 automatic)."""
+    packed = PackedReads(seqs, pad_uniform)
     header_id = None
     if headers is not None:
         first = {}

@@ -276,8 +276,10 @@ void *crass_hip_stream(const crass_hip_ctx *ctx);
 
 /* ---- host utilities: ingest side of the boundary ("next" row f-2) ---- */
 /* 2-bit packer.  seqs: concatenated raw bytes, off[n+1].  Allocates the output arrays with
- * malloc (free with crass_free_packed).  stride_words = ceil(max_len/16) when pad_uniform
- * != 0, else per-read word offsets.                                                        */
+ * malloc (free with crass_free_packed).  pad_uniform: 0 = per-read word offsets, 1 = every
+ * read padded to stride_words = ceil(max_len/16), 2 = pad when the reads are short (64..256
+ * bases) and padding costs at most twice the words (trimmed reads of differing lengths then
+ * take the uniform-stride kernels).                                                        */
 typedef struct {
     crass_reads reads;              /* host pointers, owned by this struct                        */
     void *owner;

@@ -87,6 +87,11 @@ def test_synthetic_ragged_with_exceptions_and_duplicate_headers(ca):
     ref = orc.pipeline(seqs, hdrs)
     assert_same_pipeline(gpu, ref)
     assert gpu.counters["n_exceptions"] > 500
+    # the same reads padded to one stride (what the adapter does for trimmed short reads): bit-parallel filter and
+    # lane-per-read kernels with per-read lengths
+    padded = ca.search_pipeline(seqs, hdrs, pad_uniform=2)
+    assert padded.counters["used_fast_filter"] == 1
+    assert_same_pipeline(padded, ref)
     # the wave kernel's two-launch form (short Levenshtein rows first, reads that need longer ones redone with the
     # full layout): rows of 8 entries force the second launch for every fallback comparison
     os.environ["CRASS_ROW_CAP"] = "8"

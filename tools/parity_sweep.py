@@ -32,7 +32,7 @@ for case in range(n_cases):
     if host:
         os.environ["CRASS_HOST_MERGE"] = "1"
     try:
-        gpu = ca.search_pipeline(seqs, params=p, engine=eng if rng.random() < 0.7 and k == 6 else None)
+        gpu = ca.search_pipeline(seqs, params=p, engine=eng if rng.random() < 0.7 and k == 6 else None, pad_uniform=rng.choice([0, 2]))
     finally:
         os.environ.pop("CRASS_HOST_MERGE", None)
     ref = orc.pipeline(seqs, params=orc.Params(p.lowDRsize, p.highDRsize, p.lowSpacerSize, p.highSpacerSize, p.searchWindowLength,
