@@ -15,6 +15,12 @@ asc = ca.unpack_ascii(w, 10, L, n).reshape(n, L)
 rng = np.random.default_rng(3)
 lens = rng.integers(90, 151, size=n).astype(np.uint64)
 lens[rng.random(n) < 0.5] = 150
+if os.environ.get("UNIFORM"):
+    lens[:] = 150
+n_frac = float(os.environ.get("NFRAC", "0"))
+if n_frac > 0:                                     # reads with an N somewhere (exception reads)
+    rows = np.nonzero(rng.random(n) < n_frac)[0]
+    asc[rows, rng.integers(0, 90, size=len(rows))] = ord("N")
 off = np.zeros(n + 1, np.uint64); off[1:] = np.cumsum(lens)
 t0 = time.time()
 mask = np.arange(L)[None, :] < lens[:, None]
