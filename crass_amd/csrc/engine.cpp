@@ -658,6 +658,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         const uint32_t *pool = c->h_ss.p;
         for (uint64_t k = 0; k < nchunk; k++) {
             const SurvOut &o = so[k];
+            if (o.err == 5) continue;                       // exception read in the survivor list: evaluated by the exception pass
             if (o.err == 1) return CRASS_ERR_SEARCH_FATAL;
             if (o.err) return CRASS_ERR_OVERFLOW;
             if (!o.found) continue;
@@ -730,6 +731,10 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
                               c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, hints, lds,
                               (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, le == hipSuccess ? 4 : 0));
+    if (c->R.n_exc)                                     // exception reads in the list (err == 5): raw bytes, same slots
+        HIPCHK(c, launch_survivor(c->R, c->dp, true, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
+                                  c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, nullptr, lds,
+                                  (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, 5));
     HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
     const uint64_t n_words = (n_surv + 63) / 64;
     HIPCHK(c, launch_found_mask(c->d_surv.p, d_nsurv, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream));
@@ -827,6 +832,9 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     // (P ~ seeds*49/4^w), so the filter is skipped and every read goes to the survivor kernel.
     bool fast = false;
     const bool use_filter = c->max_len <= 2048;
+    // exception reads (a byte outside ACGT) join the survivor list and are evaluated byte-wise in place, so that
+    // the dense pass-1 path also holds for inputs with a few N reads
+    c->dp.exc_survive = (use_filter && c->R.n_exc > 0 && !getenv("CRASS_EXC_SEPARATE")) ? 1u : 0u;
     if (use_filter) {
         hipError_t fe = hipErrorNotSupported;
         // (uniform STRIDE is what the bit-parallel kernel needs; the lengths may differ — trimmed reads padded to one stride)
@@ -858,7 +866,8 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     // Speculative fast path: the survivor stage is launched right behind the compaction with the survivor
     // count still on the device, sized by a bound learnt from the previous call (twice its count).  If the
     // bound turns out too small the stage is simply redone below with the exact count.
-    if (use_filter && c->R.n_exc == 0 && c->surv_cap_hint && !getenv("CRASS_NO_SPECULATION")) {
+    const bool exc_ok = c->R.n_exc == 0 || c->dp.exc_survive;
+    if (use_filter && exc_ok && c->surv_cap_hint && !getenv("CRASS_NO_SPECULATION")) {
         bool overflow = false;
         HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         s = run_survivors_dense(c, c->surv_cap_hint, c->d_count.p, &overflow);
@@ -881,7 +890,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         n_surv = c->h_count.p[0];
     }
     const bool spec_done = (s == CRASS_OK);
-    const bool try_dense = !spec_done && use_filter && c->R.n_exc == 0 && n_surv > 0 && n_surv <= kDenseMaxSurvivors;
+    const bool try_dense = !spec_done && use_filter && exc_ok && n_surv > 0 && n_surv <= kDenseMaxSurvivors;
     std::vector<uint64_t> surv_idx;
     if (!spec_done) {
         // the survivor kernel reads its count from d_count[1] (chunk-local bound is passed separately)
@@ -893,7 +902,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         s = try_dense ? run_survivors_dense(c, n_surv, c->d_count.p + 1, &overflow) : CRASS_ERR_STATE;
         if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
     }
-    if (use_filter && c->R.n_exc == 0) {                // bound for the next call: twice this call's count
+    if (use_filter && exc_ok) {                         // bound for the next call: 1.5 x this call's count
         c->surv_cap_hint = survivor_bound(n_surv);
     }
     if (s == CRASS_ERR_STATE) {
@@ -919,7 +928,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         s = run_survivors(c, false, n_surv, c->cand, surv_idx.data());
         if (s) return s;
     }
-    if (c->R.n_exc) {
+    if (c->R.n_exc && !c->dense.active) {               // (the dense path evaluated them in place)
         crass_hip_ctx::P1List el;
         s = run_survivors(c, true, c->R.n_exc, el, nullptr);
         if (s) return s;
@@ -964,7 +973,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         HIPCHK(c, hipMemcpy(c->xchg.send.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
     }
     c->cnt.ms_sink_host = (float)(now_ms() - t_sink0);     // includes the survivor kernel + D2H it waits for
-    c->cnt.n_filter_survivors = n_surv + c->R.n_exc;
+    c->cnt.n_filter_survivors = n_surv + (c->dp.exc_survive ? 0 : c->R.n_exc);
     c->cnt.n_pass1_found = total;
     c->cnt.used_fast_filter = fast ? 1 : 0;
     float ms = 0;

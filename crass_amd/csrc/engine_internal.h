@@ -32,6 +32,8 @@ struct DevParams {
     uint32_t lowDR, highDR, lowSp, highSp, window, minRepeats;
     uint32_t skips;               // lowDR - (2w-1) as unsigned, clamped to >=1 only when 0 (libcrispr.cpp:281-285)
     uint32_t debug_stop;          // diagnostics only (env CRASS_SURV_DEBUG): 0 = normal; 1..3 cut the survivor kernel short
+    uint32_t exc_survive;         // 1: the filter passes every exception read on (they join the survivor list and are
+                                  // evaluated byte-wise in place, so the dense pass-1 path also holds with N reads)
 };
 
 // per-survivor output slot of the pass-1 survivor kernel

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(FG_WAVES * WAVE) void k_filter_general(DevReads R, 
         for (int k = 0; k < 64; k++) {
             uint64_t r = mw * 64 + k;
             if (r >= R.n_reads) break;
-            if (rd_is_exc(R, r)) continue;
+            if (rd_is_exc(R, r)) { if (P.exc_survive) bits |= (1ull << k); continue; }
             uint32_t L = rd_len(R, r);
             int searchEnd = (int)(L - P.lowDR - P.lowSp - w - 1);
             if (searchEnd < 0) continue;
@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams 
         hit = hint != 0;
         if (hit) seed_hint[r] = hint;                   // sparse: ~2 % of the lanes
     }
+    if (active && exc && P.exc_survive) hit = true;      // evaluated byte-wise by the survivor stage
     uint64_t m = __ballot(hit);
     if ((threadIdx.x & 63) == 0 && active) hitmask[r >> 6] = m;
 }
@@ -1018,7 +1019,8 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
     h.words = EXC ? nullptr : l_words;
     h.sims = reinterpret_cast<float *>(l_words + lds.words_cap);
     h.cmask = (1u << (2 * P.window)) - 1u;
-    uint64_t n_surv = EXC ? R.n_exc : (uint64_t)(*d_n_surv);
+    // EXC with punt_only == 5: exception reads that sit in the survivor list (slot s, read surv_idx[s])
+    uint64_t n_surv = (EXC && punt_only != 5) ? R.n_exc : (uint64_t)(*d_n_surv);
     if (n_surv > n_max) n_surv = n_max;
     // punt mode: only the reads an earlier launch handed over (err == punt_only: 4 from the lane kernel, 6 = row buffer).  Each wave looks at 64 slots at once and
     // then walks the (rare) flagged ones, instead of every wave polling its slots one dependent load at a time.
@@ -1040,12 +1042,23 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
         int L;
         wave_sync();
         if (EXC) {
-            r = R.exc_read[s];
-            uint64_t o0 = R.exc_off[s];
-            L = (int)(R.exc_off[s + 1] - o0);
+            uint64_t e = s;
+            if (punt_only == 5) {
+                r = surv_idx[s];
+                uint64_t lo = 0, hi = R.n_exc;                  // exc_read[] is ascending: first entry >= r is r itself
+                while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (R.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
+                e = lo;
+            } else r = R.exc_read[s];
+            uint64_t o0 = R.exc_off[e];
+            L = (int)(R.exc_off[e + 1] - o0);
             for (int i = lane; i < L; i += WAVE) h.seq[i] = R.exc_bytes[o0 + i];
         } else {
             r = surv_idx[s];
+            if (!punt_only && rd_is_exc(R, r)) {                // left to the exception pass
+                if (lane == 0) { SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = 5; out[s] = x; }
+                s += gridDim.x;
+                continue;
+            }
             L = (int)rd_len(R, r);
             load_read_to_lds(R, r, h.seq, l_words, L, lane);
         }
@@ -1400,6 +1413,12 @@ __global__ __launch_bounds__(WAVE) void k_survivor_lanes(DevReads R, DevParams P
     uint16_t *lss = reinterpret_cast<uint16_t *>(sl_lds + (size_t)(words_per_read + 2) * WAVE) + lane;   // [entry][lane]
     if (s >= n_surv) return;
     const uint64_t r = surv_idx[s];
+    if (rd_is_exc(R, r)) {                              // raw-byte read: the wave kernel's exception pass (err == 5)
+        SurvOut o;
+        o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 5;
+        out[s] = o;
+        return;
+    }
     const int L = (int)rd_len(R, r);
     const uint32_t *g = R.packed + rd_word_off(R, r);
     const int nw = (L + 15) >> 4;

@@ -27,6 +27,13 @@ for case in range(n_cases):
     ragged = rng.random() < 0.25
     if ragged:
         seqs = [s[:rng.randint(40, L)] if rng.random() < 0.3 else s for s in seqs]
+    with_n = rng.random() < 0.35
+    if with_n:                                   # exception reads: a byte outside ACGT somewhere
+        for i in rng.sample(range(n), max(1, n // rng.choice([20, 100, 400]))):
+            b = bytearray(seqs[i])
+            for _ in range(rng.choice([1, 1, 3])):
+                b[rng.randrange(len(b))] = rng.choice(b"NNNna")
+            seqs[i] = bytes(b)
     p = ca.default_params(kmer_clust_size=k)
     host = rng.random() < 0.15
     if host:
@@ -37,7 +44,7 @@ for case in range(n_cases):
         os.environ.pop("CRASS_HOST_MERGE", None)
     ref = orc.pipeline(seqs, params=orc.Params(p.lowDRsize, p.highDRsize, p.lowSpacerSize, p.highSpacerSize, p.searchWindowLength,
                                                p.minNumRepeats, p.kmer_clust_size))
-    tag = "L=%d n=%d n_dr=%d cpm=%d k=%d ragged=%d host=%d" % (L, n, n_dr, cpm, k, ragged, host)
+    tag = "L=%d n=%d n_dr=%d cpm=%d k=%d ragged=%d host=%d N=%d" % (L, n, n_dr, cpm, k, ragged, host, with_n)
     try:
         assert_same_pipeline(gpu, ref)
         print("ok   %-60s pass1 %6d pass2 %6d groups %4d patterns %5d devmerge %d" % (tag, gpu.n_pass1, gpu.n_pass2, gpu.n_groups, gpu.n_patterns,
