@@ -240,6 +240,8 @@ __global__ __launch_bounds__(1024) void k_dm_scatter(DevMerge M)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ng = M.st->n_groups;
     const bool lds = ng <= kLdsGroups;
+    if (blockIdx.x == 0)                                // see DevMerge::group_cap
+        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) if (M.grp_cnt[i] > M.group_cap) atomicOr(&M.st->fail, 32u);
     if (lds) {
         for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) cnt[i] = 0;
         __syncthreads();
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(1024) void k_dm_scatter(DevMerge M)
     if (lds) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint32_t c = cnt[i]; cnt[i] = c ? atomicAdd(&M.grp_fill[i], c) : 0u; }
+
         __syncthreads();
         if (t < M.n_tok) rank += cnt[g];
     }

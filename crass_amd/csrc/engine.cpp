@@ -1144,6 +1144,8 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     M.n_cu = c->n_cu;
     M.h_st = d.h_st.p; M.h_gid = d.h_gid.p; M.h_blank = d.h_blank.p;
     M.inject_fail = getenv("CRASS_DM_INJECT_FAIL") ? 1u : 0u;
+    M.group_cap = 16384;
+    if (const char *e = getenv("CRASS_DM_GROUP_CAP")) M.group_cap = (uint32_t)std::max(1, atoi(e));      // tests
     M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
     d.M = M;
     const double tl0 = now_ms();

@@ -146,6 +146,9 @@ struct DevMerge {
     // pinned host memory the last kernel exports to (state words, GID and dropped flag per token)
     DevMergeState *h_st; uint32_t *h_gid; uint8_t *h_blank;
     uint32_t inject_fail;         // tests only: start with the fail word set (exercises the fall-back to the host merge)
+    uint32_t group_cap;           // a group with more members than this sets fail bit 32: the per-group steps here are
+                                  // quadratic in the group size (rank among survivors) or walk per-key chains that grow
+                                  // with it; the host merge handles such inputs in O(n log n)
 };
 
 // one-collective exchange (see crass_hip_exchange_setup): fill this rank's send buffer / unpack the gathered buffers

@@ -63,6 +63,19 @@ def test_synthetic_device_vs_host(ca, L, n_dr, n):
     assert_same_pipeline(dev, orc.pipeline(seqs))
 
 
+def test_group_size_cap_falls_back(ca):
+    """a group beyond the device merge's size cap (its per-group steps are quadratic) must end in the host merge"""
+    seqs = synth_reads(ca, 40000, read_len=150, n_dr=2, crispr_per_million=300000)
+    ref = orc.pipeline(seqs)
+    os.environ["CRASS_DM_GROUP_CAP"] = "20"
+    try:
+        got = ca.search_pipeline(seqs)
+    finally:
+        os.environ.pop("CRASS_DM_GROUP_CAP", None)
+    assert max(len(g) for g in got.groups) > 20
+    assert_same_pipeline(got, ref)
+
+
 def test_many_variants_one_group(ca):
     """one DR, a CRISPR read in every second read: hundreds of variants in a single group (the
     removeRedundantRepeats stress) and long owner chains in the greedy pass"""
