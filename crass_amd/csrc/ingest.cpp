@@ -5,14 +5,17 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
 #include <zlib.h>
+#include <sys/mman.h>
 
 namespace {
 
@@ -273,20 +276,29 @@ int crass_read_fastx(const char *path, crass_fastx *out)
 {
     if (!path || !out) return CRASS_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
+    const double tr0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     std::vector<uint8_t> data;
+    struct Mapping {                                     // plain text is parsed straight from the page cache
+        void *p = nullptr; size_t n = 0;
+        ~Mapping() { if (p && n) munmap(p, n); }
+    } map;
     {
         FILE *f = fopen(path, "rb");
         if (!f) return CRASS_ERR_IO;
         unsigned char magic[2] = {0, 0};
         const size_t got2 = fread(magic, 1, 2, f);
         const bool gz = got2 == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-        if (!gz) {                                       // plain text: one read of the whole file
+        if (!gz) {
             fseek(f, 0, SEEK_END);
             const long sz = ftell(f);
             fseek(f, 0, SEEK_SET);
             if (sz < 0) { fclose(f); return CRASS_ERR_IO; }
-            data.resize((size_t)sz);
-            if (sz && fread(data.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return CRASS_ERR_IO; }
+            void *m = sz ? mmap(nullptr, (size_t)sz, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fileno(f), 0) : nullptr;
+            if (sz && m != MAP_FAILED) { map.p = m; map.n = (size_t)sz; }
+            else {                                       // (pipes, odd file systems): one read of the whole file
+                data.resize((size_t)sz);
+                if (sz && fread(data.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return CRASS_ERR_IO; }
+            }
             fclose(f);
         } else {
             fclose(f);
@@ -300,8 +312,11 @@ int crass_read_fastx(const char *path, crass_fastx *out)
             if (got < 0) return CRASS_ERR_IO;
         }
     }
-    const size_t n = data.size();
-    const uint8_t *d = data.data();
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tr1 = now_s();
+    const size_t n = map.p ? map.n : data.size();
+    const uint8_t *d = map.p ? (const uint8_t *)map.p : data.data();
     // ---- cut into pieces at guessed record starts ----
     size_t chunk_bytes = 8u << 20;
     if (const char *e = getenv("CRASS_FASTX_CHUNK")) chunk_bytes = (size_t)std::max(64ll, atoll(e));     // tests: force small pieces
@@ -334,6 +349,7 @@ int crass_read_fastx(const char *path, crass_fastx *out)
             parse_range(d, n, 0, n, true, ch[0]);
         }
     }
+    const double tr2 = now_s();
     // ---- assemble ----
     const size_t nc = ch.size();
     std::vector<uint64_t> rec0(nc + 1, 0), seq0(nc + 1, 0), name0(nc + 1, 0), com0(nc + 1, 0), qual0(nc + 1, 0);
@@ -408,52 +424,49 @@ int crass_read_fastx(const char *path, crass_fastx *out)
     };
     if (!simple_c) ordered_stale(true);
     if (!simple_q) ordered_stale(false);
+    const double tr3 = now_s();
     // ---- header_id: first read with the same name (readsFound is keyed by the header string) ----
     {
+        // one 64-bit word per slot: (32-bit hash tag | 1) << 32 | index of the first read with that name; a tag match
+        // is confirmed by comparing the names, so two names never share a slot
         size_t cap = 1024;
-        while (cap < nrec * 2) cap <<= 1;
-        struct Slot { std::atomic<uint64_t> hash; std::atomic<uint64_t> first; };
-        std::vector<Slot> tab(cap);
-        for (auto &sl : tab) { sl.hash.store(0, std::memory_order_relaxed); sl.first.store(~0ull, std::memory_order_relaxed); }
+        while (cap * 10 < nrec * 14) cap <<= 1;                  // load <= ~0.7
+        std::unique_ptr<std::atomic<uint64_t>[]> tab(new std::atomic<uint64_t>[cap]);
         std::vector<uint64_t> slot_of(nrec);
         const unsigned ht = (unsigned)std::min<uint64_t>(hw_threads(), std::max<uint64_t>(1, nrec / 65536));
-        parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b, unsigned) {
-            for (uint64_t r = a; r < b; r++) {
-                const uint64_t h = name_hash(out->name + out->name_off[r], out->name_off[r + 1] - out->name_off[r]) | 1ull;
-                size_t i = (size_t)(h >> 7) & (cap - 1);
+        parallel_ranges(cap, ht, [&](uint64_t a, uint64_t b2, unsigned) { for (uint64_t i = a; i < b2; i++) tab[i].store(0, std::memory_order_relaxed); });
+        auto same_name = [&](uint64_t x, uint64_t y) {
+            const uint64_t lx = out->name_off[x + 1] - out->name_off[x], ly = out->name_off[y + 1] - out->name_off[y];
+            return lx == ly && memcmp(out->name + out->name_off[x], out->name + out->name_off[y], lx) == 0;
+        };
+        parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b2, unsigned) {
+            for (uint64_t r = a; r < b2; r++) {
+                const uint64_t h = name_hash(out->name + out->name_off[r], out->name_off[r + 1] - out->name_off[r]);
+                const uint64_t tag = ((h >> 32) | 1ull) << 32;
+                size_t i = (size_t)h & (cap - 1);
                 for (;;) {
-                    uint64_t cur = tab[i].hash.load(std::memory_order_relaxed);
-                    if (cur == 0 && tab[i].hash.compare_exchange_strong(cur, h, std::memory_order_relaxed)) cur = h;
-                    if (cur == h) break;
+                    uint64_t cur = tab[i].load(std::memory_order_acquire);
+                    if (cur == 0) {
+                        if (tab[i].compare_exchange_strong(cur, tag | r, std::memory_order_acq_rel)) break;      // claimed
+                    }
+                    if ((cur & 0xFFFFFFFF00000000ull) == tag && same_name((uint64_t)(uint32_t)cur, r)) {
+                        while ((uint32_t)cur > r && !tab[i].compare_exchange_weak(cur, tag | r, std::memory_order_acq_rel)) {}
+                        break;
+                    }
                     i = (i + 1) & (cap - 1);
                 }
-                uint64_t f = tab[i].first.load(std::memory_order_relaxed);
-                while (r < f && !tab[i].first.compare_exchange_weak(f, r, std::memory_order_relaxed)) {}
                 slot_of[r] = i;
             }
         });
-        std::atomic<int> collision{0};
-        parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b, unsigned) {
-            for (uint64_t r = a; r < b; r++) {
-                const uint64_t f = tab[slot_of[r]].first.load(std::memory_order_relaxed);
-                out->header_id[r] = f;
-                if (f != r) {            // same 64-bit hash: must be the same name, or the table cannot be trusted
-                    const uint64_t la = out->name_off[r + 1] - out->name_off[r], lb = out->name_off[f + 1] - out->name_off[f];
-                    if (la != lb || memcmp(out->name + out->name_off[r], out->name + out->name_off[f], la) != 0) collision.store(1);
-                }
-            }
+        parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b2, unsigned) {
+            for (uint64_t r = a; r < b2; r++) out->header_id[r] = (uint32_t)tab[slot_of[r]].load(std::memory_order_relaxed);
         });
-        if (collision.load()) {      // exact fallback
-            std::unordered_map<std::string, uint64_t> first_seen;
-            for (uint64_t r = 0; r < nrec; r++) {
-                std::string nm((const char *)out->name + out->name_off[r], out->name_off[r + 1] - out->name_off[r]);
-                auto it = first_seen.find(nm);
-                if (it == first_seen.end()) { first_seen.emplace(nm, r); out->header_id[r] = r; } else out->header_id[r] = it->second;
-            }
-        }
     }
     out->max_len = max_len;
     out->last_ret = ch.back().last_ret;
+    if (timing)
+        fprintf(stderr, "[crass_timing] fastx: %zu bytes, %zu pieces: read %.3f s, parse %.3f s, assemble %.3f s, header ids %.3f s\n", n, nc,
+                tr1 - tr0, tr2 - tr1, tr3 - tr2, now_s() - tr3);
     return CRASS_OK;
 }
 

@@ -176,3 +176,20 @@ def test_parallel_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
         os.environ.pop("CRASS_FASTX_CHUNK", None)
         os.environ.pop("CRASS_FASTX_SERIAL", None)
     assert len(ref) > 1000
+
+
+def test_header_ids_many_threads(ca, tmp_path):
+    """Enough records that the name table is filled by several threads at once; a third of the names repeat
+    (readsFound is keyed by the header string, crass WorkHorse.cpp:1017)."""
+    import random
+    rng = random.Random(5)
+    n = 400_000
+    names = [f"r{rng.randrange(n // 3)}" if i % 3 == 0 else f"u{i}" for i in range(n)]
+    p = tmp_path / "dups.fa"
+    with open(p, "w") as fh:
+        fh.write("".join(f">{nm}\nACGTACGTAC\n" for nm in names))
+    first = {}
+    ref_ids = np.array([first.setdefault(nm, i) for i, nm in enumerate(names)], dtype=np.uint64)
+    f = ca.FastxFile(str(p))
+    assert f.n_reads == n
+    assert np.array_equal(np.asarray(f.header_id), ref_ids)

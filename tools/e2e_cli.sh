@@ -19,6 +19,6 @@ open("/tmp/e2e.fa", "wb").write(rec.tobytes())
 print("fasta MB", rec.size / 1e6)
 EOF
 mkdir -p /tmp/e2e_out
-for i in 1 2; do ( s=$(date +%s.%N); CRASS_TIMING=1 crass_amd/crass-hip -o /tmp/e2e_out /tmp/e2e.fa 2>&1; e=$(date +%s.%N); python3 -c "print(\"wall %.3f s\" % ($e - $s))" ) | tr '\r' '\n' | grep -v "^$" | tail -8; done
+for i in 1 2; do ( s=$(date +%s.%N); CRASS_TIMING=1 crass_amd/crass-hip -o /tmp/e2e_out /tmp/e2e.fa 2>&1; e=$(date +%s.%N); python3 -c "print(\"wall %.3f s\" % ($e - $s))" ) | tr '\r' '\n' | grep "timing\|wall\|Found"; done
 gzip -1 -k /tmp/e2e.fa; ( s=$(date +%s.%N); CRASS_TIMING=1 crass_amd/crass-hip -o /tmp/e2e_out /tmp/e2e.fa.gz 2>&1; e=$(date +%s.%N); python3 -c "print(\"gz wall %.3f s\" % ($e - $s))" ) | tr '\r' '\n' | grep "timing\|wall"
 rm -f /tmp/e2e.fa /tmp/e2e.fa.gz
