@@ -693,6 +693,14 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
         const uint32_t *g = R.packed + dm_rd_off(R, r);
         const uint32_t nw = (L + 15) >> 4;
         const bool staged = nw <= DV_MAXW;
+        // exception read (non-ACGT bytes pack as 'A'): a bit-equal candidate only counts if its bytes are all ACGT —
+        // the automaton the reference runs over the bytes (libcrispr.cpp:503) cannot match across any other byte
+        const uint8_t *raw = nullptr;                    // wave-uniform
+        if (R.n_exc && ((R.exc_mask[r >> 5] >> (r & 31)) & 1u)) {
+            uint64_t lo = 0, hi = R.n_exc - 1;
+            while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (R.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
+            raw = R.exc_bytes + R.exc_off[lo];
+        }
         if (staged) {
             if ((uint32_t)lane < nw) rw[lane] = g[lane];
             if ((uint32_t)lane == nw) rw[lane] = 0u;
@@ -750,7 +758,14 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                                 const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
                                 uint64_t m0, m1;
                                 mask128(len, m0, m1);
-                                if ((v0 & m0) == ent[1] && (v1 & m1) == ent[2]) { cand = ((start + len) << 8) | (255u - len); cpid = (uint32_t)(e0 >> 32); }
+                                bool eq = (v0 & m0) == ent[1] && (v1 & m1) == ent[2];
+                                if (eq && raw) {
+                                    for (uint32_t i = 0; i < len; i++) {
+                                        const uint8_t ch = raw[start + i];
+                                        eq &= (ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T');
+                                    }
+                                }
+                                if (eq) { cand = ((start + len) << 8) | (255u - len); cpid = (uint32_t)(e0 >> 32); }
                             }
                         }
                         // wave minimum of cand (ties: any lane — equal (end, len) means equal strings)

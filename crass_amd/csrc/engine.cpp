@@ -1094,7 +1094,7 @@ static int build_host_merge(crass_hip_ctx *c);
 static bool device_merge_applies(const crass_hip_ctx *c)
 {
     if (getenv("CRASS_HOST_MERGE")) return false;                 // A/B switch: force the host merge (merge.cpp)
-    return c->have_pass1 && c->dense.active && c->have_dev_tokens && c->R.n_exc == 0 && c->prm.lowDRsize >= 23 &&
+    return c->have_pass1 && c->dense.active && c->have_dev_tokens && c->prm.lowDRsize >= 23 &&
            c->dr_stride <= 64 && c->n_dx <= (1u << 20);
 }
 
@@ -1173,6 +1173,7 @@ static int host_merge_fallback(crass_hip_ctx *c)
 {
     quiesce_worker(c);
     c->dm.active = false;
+    c->cnt.used_device_merge = 0;
     const double t0 = now_ms();
     if (c->dm.global) {
         // the concatenated list is still on the device (engine-owned copy)
@@ -1585,6 +1586,10 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     // otherwise the automaton scans every read (LDS table when it fits).
     bool anchors = false, lds = false;
     const bool dmp = c->dm.active;                  // pattern set built on the device (dmerge.hip)
+    // exception reads: with a device-built (pure ACGT) pattern set they go through the anchor filter and the exact
+    // verification on their packed words like every other read (k_dm_verify checks the bytes of a candidate);
+    // otherwise the byte-wise automaton scans them separately
+    const uint64_t n_exc = dmp ? 0 : c->R.n_exc;
     if (dmp) {
         // the pass-1 hand-off records leave next to the filter (not next to the merge kernels queued ahead of it)
         if (c->bulk_needed) {
@@ -1598,15 +1603,15 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         if (ae == hipSuccess) anchors = true;
         else if (ae != hipErrorNotSupported) { c->last_hip = (int)ae; return CRASS_ERR_HIP; }
     }
-    if (!anchors || c->R.n_exc) { int fs = ensure_full_automaton(c); if (fs) return fs; }
+    if (!anchors || n_exc) { int fs = ensure_full_automaton(c); if (fs) return fs; }
     if (!anchors) {
         hipError_t re = launch_recruit_lds(c->R, c->A, c->d_found.p, c->d_mask.p, c->d_hit_info.p, c->stream);
         lds = (re == hipSuccess);
         if (re == hipErrorNotSupported) { HIPCHK(c, launch_recruit_general(c->R, c->A, c->d_found.p, c->d_mask.p, c->d_hit_info.p, c->stream)); }
         else if (re != hipSuccess) { c->last_hip = (int)re; return CRASS_ERR_HIP; }
     }
-    if (c->R.n_exc) {
-        HIPCHK(c, c->d_exc_hit.ensure(c->R.n_exc));
+    if (n_exc) {
+        HIPCHK(c, c->d_exc_hit.ensure(n_exc));
         HIPCHK(c, launch_recruit_exceptions(c->R, c->A, c->d_found.p, c->d_exc_hit.p, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
@@ -1615,7 +1620,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     // Speculative tail (device merge path): verification, finish and the hand-off pack are launched with the hit
     // count still on the device, sized by a bound learnt from the previous call; the exact count arrives with the
     // final synchronisation, and a bound that was too small repeats the tail with the exact count.
-    const bool spec = dmp && c->R.n_exc == 0 && c->hit_cap_hint && !getenv("CRASS_NO_SPECULATION") && !c->recruit_exact;
+    const bool spec = dmp && n_exc == 0 && c->hit_cap_hint && !getenv("CRASS_NO_SPECULATION") && !c->recruit_exact;
     c->recruit_exact = false;
     if (!spec) HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!spec && dmp && c->dm.h_st.p->fail) {       // the device merge gave up: host merge, then pass 2 again
@@ -1624,13 +1629,13 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         return crass_hip_recruit(c, extra_found, n_extra);
     }
     const uint64_t n_hits = spec ? c->hit_cap_hint : c->h_count.p[0];
-    const uint64_t n_slots = n_hits + c->R.n_exc;
+    const uint64_t n_slots = n_hits + n_exc;
     // (sized for the bound the next call will speculate with, so that it does not re-allocate)
     const uint64_t h_alloc = spec ? n_hits : std::max<uint64_t>(n_hits, hit_bound(n_hits));
-    const uint64_t s_alloc = h_alloc + c->R.n_exc;
+    const uint64_t s_alloc = h_alloc + n_exc;
     HIPCHK(c, c->d_rec.ensure(s_alloc + 1));
     HIPCHK(c, c->d_dr.ensure((s_alloc + 1) * c->dr_stride));
-    if (!(dmp && c->R.n_exc == 0)) {                // host sink only
+    if (!(dmp && n_exc == 0)) {                // host sink only
         HIPCHK(c, c->h_rec.ensure(s_alloc + 1));
         HIPCHK(c, c->h_dr.ensure((s_alloc + 1) * c->dr_stride));
         HIPCHK(c, c->h_idx.ensure(h_alloc + 1));
@@ -1644,14 +1649,14 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const bool dev_tokens = dmp || (anchors && c->have_pat_token && c->have_merge);
     HIPCHK(c, launch_recruit_finish(c->R, c->d_idx.p, c->d_count.p, n_hits, anchors ? c->d_slot_info.p : c->d_hit_info.p, anchors, false,
                                     dev_tokens ? c->d_slot_pid.p : nullptr, dev_tokens ? (dmp ? c->dm.M.pat_token : c->a_pat_token.p) : nullptr,
-                                    c->d_rec.p, (dmp && c->R.n_exc == 0) ? nullptr : c->d_dr.p, c->dr_stride, c->stream));
-    if (c->R.n_exc)
-        HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, c->R.n_exc, c->d_exc_hit.p, true, true, nullptr, nullptr, c->d_rec.p + n_hits,
+                                    c->d_rec.p, (dmp && n_exc == 0) ? nullptr : c->d_dr.p, c->dr_stride, c->stream));
+    if (n_exc)
+        HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, n_exc, c->d_exc_hit.p, true, true, nullptr, nullptr, c->d_rec.p + n_hits,
                                         c->d_dr.p + n_hits * c->dr_stride, c->dr_stride, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     // device merge path: the sink runs on the device too (drop the slots without a match, pack the records in
     // read order) and ONE copy brings the hand-off arrays to pinned host memory
-    const bool dev_sink = dmp && c->R.n_exc == 0;
+    const bool dev_sink = dmp && n_exc == 0;
     c->q_blob_active = false;
     if (dev_sink) {
         c->q_lay = p2_blob_layout(n_hits);
@@ -1723,7 +1728,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const double t0 = now_ms();
     // sink: merge packed hits and exception hits by read index; token = existing or new (addReadHolder)
     size_t ia = 0, ib = 0;
-    const size_t nb = c->R.n_exc;
+    const size_t nb = n_exc;
     auto exc_valid = [&](size_t b) { return c->h_rec.p[n_hits + b].dr_len != 0; };
     while (ib < nb && !exc_valid(ib)) ib++;
     auto hit_valid = [&](size_t a) { return c->h_rec.p[a].dr_len != 0; };

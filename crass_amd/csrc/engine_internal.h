@@ -81,6 +81,7 @@ struct DevAnchors {
     uint32_t mode;
     uint32_t s1, s2, m1, m2;
     uint32_t n_keys;
+    uint32_t with_exc;            // 1: exception reads are probed on their packed words too (pattern set known to be pure ACGT)
 };
 
 // ---- device-side DR merge (dmerge.hip) ----

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(FG_WAVES * WAVE) void k_filter_general(DevReads R, 
         for (int k = 0; k < 64; k++) {
             uint64_t r = mw * 64 + k;
             if (r >= R.n_reads) break;
-            if (rd_is_exc(R, r)) { if (P.exc_survive) bits |= (1ull << k); continue; }
+            // exc_survive: exception reads are screened on their packed words like every other read (a non-ACGT byte
+            // packs as 'A', so byte-equal seeds are code-equal: still a superset) and evaluated byte-wise afterwards
+            if (!P.exc_survive && rd_is_exc(R, r)) continue;
             uint32_t L = rd_len(R, r);
             int searchEnd = (int)(L - P.lowDR - P.lowSp - w - 1);
             if (searchEnd < 0) continue;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams 
 #pragma unroll
         for (int i = 0; i < W; i++) w[i] = g[i];
         L = rd_len(R, r);
-        exc = rd_is_exc(R, r);
+        exc = !P.exc_survive && rd_is_exc(R, r);       // see k_filter_general
     }
     // seeds live in halfwords 0 .. searchEnd/8 with searchEnd = L-58 <= 16W-58: only words < SW hold one
     constexpr int SW = ((16 * W - 58) / 8 + 2) / 2;
@@ -213,7 +215,6 @@ __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams 
         hit = hint != 0;
         if (hit) seed_hint[r] = hint;                   // sparse: ~2 % of the lanes
     }
-    if (active && exc && P.exc_survive) hit = true;      // evaluated byte-wise by the survivor stage
     uint64_t m = __ballot(hit);
     if ((threadIdx.x & 63) == 0 && active) hitmask[r >> 6] = m;
 }
@@ -1952,7 +1953,9 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
     for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_total) {
         const uint64_t r = tile * 64 + lane;
         bool flag = false;
-        if (r < R.n_reads && !rd_is_exc(R, r) && !found_flag[rd_header_id(R, r)]) {
+        // with_exc: every pattern is pure ACGT, so an occurrence in an exception read lies in a stretch whose packed
+        // codes are the real bases — the probe stays a superset filter; the verification checks the bytes
+        if (r < R.n_reads && (K.with_exc || !rd_is_exc(R, r)) && !found_flag[rd_header_id(R, r)]) {
             const uint32_t L = rd_len(R, r);
             const uint32_t *g = R.packed + rd_word_off(R, r);
             if (L >= 16) {
@@ -2013,6 +2016,7 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMe
     extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
     DevAnchors K;
     K.table = M.anchor_tab; K.log_size = M.st->log_size; K.mode = 0; K.s1 = M.s1; K.s2 = M.s2; K.m1 = M.m1; K.m2 = M.m2; K.n_keys = 0;
+    K.with_exc = 1;
     if (M.st->fail != 0 || K.log_size == 0) {            // the host redoes the merge; flag nothing
         const uint64_t n_tiles = (R.n_reads + 63) / 64;
         for (uint64_t t = blockIdx.x * (uint64_t)THREADS + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * THREADS) hitmask[t] = 0ull;

@@ -141,3 +141,51 @@ def test_speculative_survivor_bound_overflow(ca):
     assert_same_pipeline(b, ref)
     assert_same_pipeline(c, ref)
     assert_same_pipeline(d, orc.pipeline(small))
+
+
+def test_exception_reads_stay_on_the_device_path(ca):
+    """Reads with non-ACGT bytes: screened on their packed words (a non-ACGT byte packs as 'A': still a superset),
+    evaluated byte-wise in pass 1, and — the pattern set being pure ACGT — filtered and verified on the device in
+    pass 2 with a byte check per candidate (the automaton of libcrispr.cpp:503 cannot match across another byte).
+    N, IUPAC codes and lower-case bases are injected everywhere; reads whose DR would then contain such a byte
+    are restored first, so that the device merge applies."""
+    import random
+    rng = random.Random(11)
+    base = synth_reads(ca, 80000, read_len=150, crispr_per_million=30000)
+    seqs = [bytearray(s) for s in base]
+    for i in range(len(seqs)):
+        r = rng.random()
+        k = 1 if r < 0.04 else 4 if r < 0.06 else 30 if r < 0.062 else 0
+        for _ in range(k):
+            seqs[i][rng.randrange(150)] = ord(rng.choice("NNNNRYacgtn"))
+    ok = set(b"ACGT")
+    for _ in range(6):
+        cur = [bytes(s) for s in seqs]
+        ref = orc.pipeline(cur)
+        bad_tok = {t + 2 for t, s in enumerate(ref.tokens) if not set(s) <= ok}      # token ids start at 2
+        bad_reads = [int(r) for r, t in zip(ref.rec_read[:ref.n_pass1], ref.rec_token[:ref.n_pass1]) if int(t) in bad_tok]
+        if not bad_reads:
+            break
+        for r in bad_reads:
+            seqs[r] = bytearray(base[r])
+    assert not bad_reads
+    dev, host = both_paths(ca, cur)
+    assert dev.counters["n_exceptions"] > 3000
+    assert_same_paths(dev, host)
+    assert_same_pipeline(dev, ref)
+    exc = np.array([not set(s) <= ok for s in cur])
+    n1 = ref.n_pass1
+    assert exc[ref.rec_read[:n1]].sum() > 20          # exception reads found by pass 1 ...
+    assert exc[ref.rec_read[n1:n1 + ref.n_pass2]].sum() > 20   # ... and recruited by pass 2
+    # a DR that contains a non-ACGT byte: the device merge declines, the host merges (same results)
+    for r in ref.rec_read[:n1][:50]:
+        s = bytearray(cur[int(r)])
+        for p in range(0, 150, 3):
+            s[p] = ord("N") if s[p] == ord("A") else s[p]
+        cur[int(r)] = bytes(s)
+    ref2 = orc.pipeline(cur)
+    assert any(not set(s) <= ok for s in ref2.tokens)
+    dev2, host2 = both_paths(ca, cur)
+    assert dev2.counters["used_device_merge"] == 0
+    assert_same_paths(dev2, host2, expect_device=False)
+    assert_same_pipeline(dev2, ref2)

@@ -21,6 +21,25 @@ n_frac = float(os.environ.get("NFRAC", "0"))
 if n_frac > 0:                                     # reads with an N somewhere (exception reads)
     rows = np.nonzero(rng.random(n) < n_frac)[0]
     asc[rows, rng.integers(0, 90, size=len(rows))] = ord("N")
+if n_frac > 0 and os.environ.get("CLEAN_DR"):
+    # keep the N's out of the repeats: reads whose pass-1 DR would contain one get their original bases back
+    # (the device merge takes pure-ACGT DR strings; anything else is merged on the host)
+    assert os.environ.get("UNIFORM")
+    orig = ca.unpack_ascii(w, 10, L, n).reshape(n, L)
+    for _ in range(3):
+        eng0 = ca.SearchEngine(device=0)
+        pk0 = ca.PackedReads((np.ascontiguousarray(asc.reshape(-1)), np.arange(n + 1, dtype=np.uint64) * np.uint64(L)))
+        eng0.load_reads(pk0, None)
+        cands = eng0.seed_scan()
+        chars, clen = eng0.candidate_dr_view()
+        inside = np.arange(chars.shape[1])[None, :] < clen[:, None]
+        bad = ((~np.isin(chars, np.frombuffer(b"ACGT", np.uint8))) & inside).any(axis=1)
+        rows = np.asarray(cands.read_idx)[bad].astype(np.int64)
+        eng0.close(); pk0.close()
+        print("reads with a non-ACGT DR:", len(rows), flush=True)
+        if len(rows) == 0:
+            break
+        asc[rows] = orig[rows]
 off = np.zeros(n + 1, np.uint64); off[1:] = np.cumsum(lens)
 t0 = time.time()
 mask = np.arange(L)[None, :] < lens[:, None]
