@@ -6,7 +6,10 @@
 // pass-1 tail already produced on the device; nothing here waits for the host.
 //
 // Preconditions (checked by the host before it takes this path, re-checked here -> fail word):
-// every token is ACGT-only, 23 <= length <= 64.  Anything else uses the host merge (merge.cpp).
+// every token is over {A,C,G,T,N}, 23 <= length <= 64.  Anything else uses the host merge (merge.cpp).
+// An 'N' (reads with an undetermined base do produce a few such DR variants) is packed as 'A' plus a bit in a
+// 64-bit position mask that every comparison carries along; the handful of 11-mers that contain one get their
+// identity from a small all-pairs pass instead of the 22-bit code (k_dm_pack_codes' last block).
 //
 // All integer work on a few 10^4 short strings: no MFMA, no HBM roofline to speak of — the point of
 // running it here is that the step no longer leaves the device between pass 1 and pass 2.
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
     const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
     uint4 ones; ones.x = ones.y = ones.z = ones.w = 0xFFFFFFFFu;
     uint4 *o4 = reinterpret_cast<uint4 *>(M.owner);
-    for (uint64_t i = tid; i < (1u << 22) / 4; i += nth) o4[i] = ones;
+    for (uint64_t i = tid; i < ((1u << 22) + kDmBadKmerCap) / 4; i += nth) o4[i] = ones;
     for (uint64_t i = tid; i < M.n_tok; i += nth) M.root_of[i] = kUnres;
     for (uint64_t i = tid; i <= M.n_tok; i += nth) { M.grp_cnt[i] = 0; M.grp_fill[i] = 0; M.surv_cnt[i] = 0; }
     const uint64_t ks = 1ull << M.kset_log;
@@ -77,45 +80,97 @@ __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
 // reference's k2GIDMap (homeless k-mers are assigned to their first token's group, WorkHorse.cpp:1612-1617).
 __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
 {
+    __shared__ uint64_t bk_key[kDmBadKmerCap];
+    __shared__ uint32_t last_sh;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M.n_tok) return;
-    const uint32_t len = M.dx_len[t];
-    if (len > 64 || len < 23 || M.stride > 64) { atomicOr(&M.st->fail, 1u); return; }
-    // the whole slot in registers (16-byte loads), then a fully unrolled walk: every register index is static
-    uint32_t w[16];
-    const uint4 *p4 = reinterpret_cast<const uint4 *>(M.dx_chars + (uint64_t)t * M.stride);
+    if (t < M.n_tok) {
+        const uint32_t len = M.dx_len[t];
+        if (len > 64 || len < 23 || M.stride > 64) atomicOr(&M.st->fail, 1u);
+        else {
+            // the whole slot in registers (16-byte loads), then a fully unrolled walk: every register index is static
+            uint32_t w[16];
+            const uint4 *p4 = reinterpret_cast<const uint4 *>(M.dx_chars + (uint64_t)t * M.stride);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        uint4 v; v.x = v.y = v.z = v.w = 0;
-        if ((uint32_t)q * 16 < M.stride) v = p4[q];
-        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-    }
-    uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0;
-    uint32_t fwd = 0, rev = 0;
-    bool bad = false;
-    uint32_t *codes = M.codes + (uint64_t)t * M.kmax;
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-        if ((uint32_t)i < len) {
-            const uint32_t ch = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            const uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : 3u;
-            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') bad = true;
-            if (i < 32) f0 |= (uint64_t)c << (2 * (i & 31)); else f1 |= (uint64_t)c << (2 * (i & 31));
-            const uint32_t j = len - 1 - i;
-            if (j < 32) r0 |= (uint64_t)(3u - c) << (2 * j); else r1 |= (uint64_t)(3u - c) << (2 * (j - 32));
-            // first base most significant: integer order == lexicographic order, laurenize() == min (SeqUtils.cpp:89-97)
-            fwd = ((fwd << 2) | c) & 0x3FFFFFu;
-            rev = (rev >> 2) | ((3u - c) << 20);
-            if (i + 1 >= kClusterK) {
-                const uint32_t code = fwd < rev ? fwd : rev;
-                codes[i + 1 - kClusterK] = code;
-                atomicMin(&M.owner[code], t);
+            for (int q = 0; q < 4; q++) {
+                uint4 v; v.x = v.y = v.z = v.w = 0;
+                if ((uint32_t)q * 16 < M.stride) v = p4[q];
+                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
             }
+            uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0, mf = 0, mr = 0;
+            uint32_t fwd = 0, rev = 0;
+            bool bad = false;
+            uint32_t clean = 0;                         // bases since the last 'N'
+            uint32_t *codes = M.codes + (uint64_t)t * M.kmax;
+#pragma unroll
+            for (int i = 0; i < 64; i++) {
+                if ((uint32_t)i < len) {
+                    const uint32_t ch = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                    const bool isn = ch == 'N';
+                    const uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0u;
+                    if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && !isn) bad = true;
+                    const uint32_t cr = isn ? 0u : 3u - c;
+                    if (i < 32) f0 |= (uint64_t)c << (2 * (i & 31)); else f1 |= (uint64_t)c << (2 * (i & 31));
+                    const uint32_t j = len - 1 - i;
+                    if (j < 32) r0 |= (uint64_t)cr << (2 * j); else r1 |= (uint64_t)cr << (2 * (j - 32));
+                    if (isn) { mf |= 1ull << i; mr |= 1ull << j; }
+                    clean = isn ? 0u : clean + 1u;
+                    // first base most significant: integer order == lexicographic order, laurenize() == min (SeqUtils.cpp:89-97)
+                    fwd = ((fwd << 2) | c) & 0x3FFFFFu;
+                    rev = (rev >> 2) | (cr << 20);
+                    if (i + 1 >= kClusterK) {
+                        if (clean >= (uint32_t)kClusterK) {
+                            const uint32_t code = fwd < rev ? fwd : rev;
+                            codes[i + 1 - kClusterK] = code;
+                            atomicMin(&M.owner[code], t);
+                        } else {                        // an 11-mer with an 'N': identity assigned below
+                            const uint32_t q = atomicAdd(&M.st->n_badk, 1u);
+                            if (q < kDmBadKmerCap) M.bk_list[q] = (t << 6) | (uint32_t)(i + 1 - kClusterK);
+                            codes[i + 1 - kClusterK] = 1u << 22;
+                        }
+                    }
+                }
+            }
+            uint64_t *pk = M.packed + (uint64_t)t * 4;
+            pk[0] = f0; pk[1] = f1; pk[2] = r0; pk[3] = r1;
+            M.tmask[(uint64_t)t * 2] = mf; M.tmask[(uint64_t)t * 2 + 1] = mr;
+            if (bad) atomicOr(&M.st->fail, 1u);
         }
     }
-    uint64_t *pk = M.packed + (uint64_t)t * 4;
-    pk[0] = f0; pk[1] = f1; pk[2] = r0; pk[3] = r1;
-    if (bad) atomicOr(&M.st->fail, 1u);
+    // ---- the last block to finish gives the 11-mers with an 'N' their identity: the laurenized 11-mer over
+    // A < C < G < N < T (ASCII order; comp_tab maps N to N, SeqUtils.cpp:50-59) as a 33-bit key, id = index of the
+    // first equal key, code = (1 << 22) + id.  A handful per merge; none at all for reads without N.
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_sh = (atomicAdd(&M.st->blocks_done, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!last_sh) return;
+    __threadfence();
+    uint32_t m = __hip_atomic_load(&M.st->n_badk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m == 0) return;
+    if (m > kDmBadKmerCap) { if (threadIdx.x == 0) atomicOr(&M.st->fail, 1u); return; }
+    for (uint32_t q = threadIdx.x; q < m; q += blockDim.x) {
+        const uint32_t e = __hip_atomic_load(&M.bk_list[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const char *str = M.dx_chars + (uint64_t)(e >> 6) * M.stride + (e & 63u);
+        uint64_t fk = 0, rk = 0;
+        for (int i = 0; i < kClusterK; i++) {
+            const char ch = str[i];
+            const uint64_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'N' ? 3u : 4u;
+            const uint64_t cc = c == 3u ? 3u : 4u - c;
+            fk = (fk << 3) | c;
+            rk |= cc << (3 * i);
+        }
+        bk_key[q] = fk < rk ? fk : rk;
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < m; q += blockDim.x) {
+        const uint64_t key = bk_key[q];
+        uint32_t id = q;
+        for (uint32_t j = 0; j < q; j++) if (bk_key[j] == key) { id = j; break; }
+        const uint32_t e = __hip_atomic_load(&M.bk_list[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t t2 = e >> 6, code = (1u << 22) + id;
+        M.codes[(uint64_t)t2 * M.kmax + (e & 63u)] = code;
+        atomicMin(&M.owner[code], t2);
+    }
 }
 
 // ---- 2. the greedy, order-dependent group assignment (clusterDRReads) ----
@@ -139,7 +194,7 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
         bool valid = false;
         uint32_t o = 0;
         if (lane < nk) {
-            o = M.owner[M.codes[(uint64_t)t * M.kmax + lane] & 0x3FFFFFu];
+            o = M.owner[M.codes[(uint64_t)t * M.kmax + lane] & 0x7FFFFFu];
             valid = o < t;                      // o == t: homeless k-mer (first seen in this token), not counted
         }
         uint32_t r = valid ? kUnres : kNoLane;
@@ -306,10 +361,11 @@ __global__ __launch_bounds__(256) void k_dm_rd_fill(DevMerge M)
     if (t >= M.n_tok) return;
     const uint32_t h = M.rd_slot[t] & 0x7FFFFFFFu;
     const uint32_t pos = M.rset_base[h] + atomicAdd(&M.rset_fill[h], 1u);
-    uint64_t *d = M.rents + (uint64_t)pos * 3;
+    uint64_t *d = M.rents + (uint64_t)pos * 4;
     d[0] = (uint64_t)M.dx_len[t] | ((uint64_t)t << 32);
     d[1] = M.packed[(uint64_t)t * 4];
     d[2] = M.packed[(uint64_t)t * 4 + 1];
+    d[3] = M.tmask[(uint64_t)t * 2];
 }
 // One wave per member j: the lanes probe j's windows (both orientations) in parallel, then every window that
 // hit a key has its candidates compared 64 at a time.
@@ -329,6 +385,7 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
         const uint32_t lenj = M.dx_len[j];
         const uint64_t *pj = M.packed + (uint64_t)j * 4;
         const uint64_t f0 = pj[0], f1 = pj[1], r0 = pj[2], r1 = pj[3];
+        const uint64_t mfj = M.tmask[(uint64_t)j * 2], mrj = M.tmask[(uint64_t)j * 2 + 1];
         const uint32_t nwin = lenj - 22u;               // starts 0 .. lenj-23: a member is >= 23 long and shorter than lenj
         bool found = false;
         for (uint32_t wb = 0; wb < 2 * nwin && !found; wb += 64) {
@@ -337,6 +394,7 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
             const uint32_t o = wq >= nwin ? 1u : 0u, p = wq - o * nwin;
             const uint64_t h0 = o ? r0 : f0, h1 = o ? r1 : f1;
             const uint64_t w0 = shr128_lo(h0, h1, 2 * (act ? p : 0u)), w1 = shr128_hi(h1, 2 * (act ? p : 0u));
+            const uint64_t wm = (o ? mrj : mfj) >> (act ? p : 0u);           // 'N' positions of the window
             uint32_t cnt = 0, base = 0;
             if (act) {
                 const uint32_t w = (uint32_t)w0;
@@ -355,17 +413,18 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
                 hits &= hits - 1;
                 const uint32_t cnt_s = (uint32_t)__shfl((int)cnt, src), base_s = (uint32_t)__shfl((int)base, src);
                 const uint32_t p_s = (uint32_t)__shfl((int)p, src);
-                const uint64_t w0_s = shfl64(w0, src), w1_s = shfl64(w1, src);
+                const uint64_t w0_s = shfl64(w0, src), w1_s = shfl64(w1, src), wm_s = shfl64(wm, src);
                 for (uint32_t c0 = 0; c0 < cnt_s && !found; c0 += 64) {
                     const uint32_t c = c0 + lane;
                     bool hit = false;
                     if (c < cnt_s) {
-                        const uint64_t *ent = M.rents + (uint64_t)(base_s + c) * 3;
+                        const uint64_t *ent = M.rents + (uint64_t)(base_s + c) * 4;
                         const uint32_t leni = (uint32_t)ent[0] & 0xFFu;
                         if (leni < lenj && p_s + leni <= lenj) {
                             uint64_t m0, m1;
                             mask128(leni, m0, m1);
-                            hit = (w0_s & m0) == ent[1] && (w1_s & m1) == ent[2];
+                            const uint64_t lm = leni >= 64 ? ~0ull : ((1ull << leni) - 1ull);
+                            hit = (w0_s & m0) == ent[1] && (w1_s & m1) == ent[2] && (wm_s & lm) == ent[3];
                         }
                     }
                     if (__ballot(hit)) found = true;
@@ -429,6 +488,7 @@ __global__ __launch_bounds__(256) void k_dm_patterns(DevMerge M)
     const uint64_t *pj = M.packed + (uint64_t)j * 4;
     M.pat_packed[(uint64_t)pf * 2] = pj[0]; M.pat_packed[(uint64_t)pf * 2 + 1] = pj[1];
     M.pat_packed[(uint64_t)pr * 2] = pj[2]; M.pat_packed[(uint64_t)pr * 2 + 1] = pj[3];
+    M.pat_mask[pf] = M.tmask[(uint64_t)j * 2]; M.pat_mask[pr] = M.tmask[(uint64_t)j * 2 + 1];
     M.pat_len[pf] = (uint16_t)lenj; M.pat_len[pr] = (uint16_t)lenj;
     // token of the pattern's low-lexi form: the survivor's own token for the survivor and for its reverse
     // complement alike (a token string is low-lexi by construction, ReadHolder.cpp:573-590)
@@ -479,10 +539,11 @@ __global__ __launch_bounds__(256) void k_dm_key_fill(DevMerge M)
     if (pid >= 2 * M.st->n_survivors) return;
     const uint32_t h = M.ent_slot[e];
     const uint32_t pos = M.kset_base[h] + atomicAdd(&M.kset_fill[h], 1u);
-    uint64_t *d = M.ents + (uint64_t)pos * 3;
+    uint64_t *d = M.ents + (uint64_t)pos * 4;
     d[0] = (uint64_t)(r | ((uint32_t)M.pat_len[pid] << 3)) | ((uint64_t)pid << 32);
     d[1] = M.pat_packed[(uint64_t)pid * 2];
     d[2] = M.pat_packed[(uint64_t)pid * 2 + 1];
+    d[3] = M.pat_mask[pid];
 }
 
 // table size: load <= 1/3 (<= 1/2 at the limits), as build_anchors (merge.cpp).  Up to 2^14 keys: exact keys in
@@ -693,8 +754,9 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
         const uint32_t *g = R.packed + dm_rd_off(R, r);
         const uint32_t nw = (L + 15) >> 4;
         const bool staged = nw <= DV_MAXW;
-        // exception read (non-ACGT bytes pack as 'A'): a bit-equal candidate only counts if its bytes are all ACGT —
-        // the automaton the reference runs over the bytes (libcrispr.cpp:503) cannot match across any other byte
+        // exception read (non-ACGT bytes pack as 'A'): a bit-equal candidate only counts if its non-ACGT bytes are
+        // exactly the pattern's 'N' positions and are 'N' themselves — the automaton the reference runs over the
+        // bytes (libcrispr.cpp:503) matches byte for byte
         const uint8_t *raw = nullptr;                    // wave-uniform
         if (R.n_exc && ((R.exc_mask[r >> 5] >> (r & 31)) & 1u)) {
             uint64_t lo = 0, hi = R.n_exc - 1;
@@ -743,7 +805,7 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                         const uint32_t c = c0 + lane;
                         uint32_t cand = 0xFFFFFFFFu, cpid = 0;                // (end << 8) | (255 - len): smaller is better
                         if (c < cnt_s) {
-                            const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 3;
+                            const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 4;
                             const uint64_t e0 = ent[0];
                             const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
                             if (a >= rr && a - rr + len <= L) {
@@ -760,11 +822,14 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                                 mask128(len, m0, m1);
                                 bool eq = (v0 & m0) == ent[1] && (v1 & m1) == ent[2];
                                 if (eq && raw) {
+                                    uint64_t rm = 0;
+                                    bool other = false;
                                     for (uint32_t i = 0; i < len; i++) {
                                         const uint8_t ch = raw[start + i];
-                                        eq &= (ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T');
+                                        if (!((ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T'))) { rm |= 1ull << i; other |= ch != 'N'; }
                                     }
-                                }
+                                    eq = !other && rm == ent[3];
+                                } else if (eq) eq = ent[3] == 0ull;
                                 if (eq) { cand = ((start + len) << 8) | (255u - len); cpid = (uint32_t)(e0 >> 32); }
                             }
                         }

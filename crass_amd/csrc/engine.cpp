@@ -228,7 +228,7 @@ struct crass_hip_ctx {
     // index are built on the device; the host view (c->merge) is rebuilt from its per-token results while
     // pass 2 runs.  dm.active: the installed pattern set lives in dm.M, not in the automaton/anchors above.
     struct DM {
-        DevBuf<uint64_t> packed, pat_packed; DevBuf<uint32_t> codes, owner, root_of, tmp, root_rank, gid_of, grp, members, pat_token;
+        DevBuf<uint64_t> packed, pat_packed, tmask, pat_mask; DevBuf<uint32_t> bk_list; DevBuf<uint32_t> codes, owner, root_of, tmp, root_rank, gid_of, grp, members, pat_token;
         DevBuf<uint32_t> kset_u32, ent_slot, anchor_tab, anchor_fp; DevBuf<uint8_t> blank, sblank, ent_win; DevBuf<uint16_t> pat_len; DevBuf<uint64_t> ents, rents; DevBuf<uint32_t> rset_u32, rd_slot;
         DevBuf<unsigned long long> rset_key;
         DevBuf<unsigned long long> kset_key; DevBuf<DevMergeState> st;
@@ -249,7 +249,7 @@ struct crass_hip_ctx {
         hipEvent_t ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
         void release()
         {
-            packed.release(); pat_packed.release(); codes.release(); owner.release(); root_of.release(); tmp.release(); root_rank.release();
+            packed.release(); pat_packed.release(); tmask.release(); pat_mask.release(); bk_list.release(); codes.release(); owner.release(); root_of.release(); tmp.release(); root_rank.release();
             gid_of.release(); grp.release(); members.release(); pat_token.release(); kset_u32.release(); ent_slot.release(); anchor_tab.release(); anchor_fp.release();
             blank.release(); sblank.release(); ents.release(); ent_win.release(); rents.release(); rset_u32.release(); rd_slot.release(); rset_key.release(); pat_len.release(); kset_key.release(); st.release(); h_st.release(); h_gid.release(); h_blank.release();
             g_chars.release(); gx_chars.release(); g_len.release(); gx_len.release(); g_keys.release(); g_first.release(); g_slot.release();
@@ -1114,20 +1114,21 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     M.thr = (uint32_t)std::max(c->prm.kmer_clust_size, 2); M.kmax = stride - 10;
     M.kset_log = 10; while ((1ull << M.kset_log) < 32ull * n) M.kset_log++;
     M.tab_log_alloc = 16; while (M.tab_log_alloc < 24 && (1ull << M.tab_log_alloc) < 48ull * n) M.tab_log_alloc++;
-    HIPCHK(c, d.packed.ensure((size_t)n * 4)); HIPCHK(c, d.codes.ensure((size_t)n * M.kmax)); HIPCHK(c, d.owner.ensure(1u << 22));
+    HIPCHK(c, d.packed.ensure((size_t)n * 4)); HIPCHK(c, d.codes.ensure((size_t)n * M.kmax)); HIPCHK(c, d.owner.ensure((1u << 22) + kDmBadKmerCap));
+    HIPCHK(c, d.tmask.ensure((size_t)n * 2)); HIPCHK(c, d.pat_mask.ensure((size_t)n * 2)); HIPCHK(c, d.bk_list.ensure(kDmBadKmerCap));
     HIPCHK(c, d.root_of.ensure(n)); HIPCHK(c, d.tmp.ensure(n + 1)); HIPCHK(c, d.root_rank.ensure(n + 1)); HIPCHK(c, d.gid_of.ensure(n));
     HIPCHK(c, d.grp.ensure(5 * ((size_t)n + 1))); HIPCHK(c, d.members.ensure(n)); HIPCHK(c, d.blank.ensure(n));
     HIPCHK(c, d.pat_packed.ensure((size_t)n * 4)); HIPCHK(c, d.pat_len.ensure((size_t)n * 2)); HIPCHK(c, d.pat_token.ensure((size_t)n * 2));
     HIPCHK(c, d.kset_key.ensure((size_t)1 << M.kset_log)); HIPCHK(c, d.kset_u32.ensure((size_t)3 << M.kset_log));
-    HIPCHK(c, d.ent_slot.ensure((size_t)n * 16)); HIPCHK(c, d.ent_win.ensure((size_t)n * 16)); HIPCHK(c, d.ents.ensure((size_t)n * 48));
+    HIPCHK(c, d.ent_slot.ensure((size_t)n * 16)); HIPCHK(c, d.ent_win.ensure((size_t)n * 16)); HIPCHK(c, d.ents.ensure((size_t)n * 64));
     HIPCHK(c, d.sblank.ensure(n));
     M.rset_log = 10; while ((1ull << M.rset_log) < 4ull * n) M.rset_log++;
     HIPCHK(c, d.rset_key.ensure((size_t)1 << M.rset_log)); HIPCHK(c, d.rset_u32.ensure((size_t)3 << M.rset_log));
-    HIPCHK(c, d.rd_slot.ensure(n)); HIPCHK(c, d.rents.ensure((size_t)n * 3));
+    HIPCHK(c, d.rd_slot.ensure(n)); HIPCHK(c, d.rents.ensure((size_t)n * 4));
     HIPCHK(c, d.anchor_tab.ensure((size_t)1 << M.tab_log_alloc)); HIPCHK(c, d.st.ensure(1)); HIPCHK(c, d.anchor_fp.ensure(1u << 15));
     HIPCHK(c, d.h_st.ensure(1)); HIPCHK(c, d.h_gid.ensure(n)); HIPCHK(c, d.h_blank.ensure(n));
     M.packed = d.packed.p; M.codes = d.codes.p; M.owner = d.owner.p; M.root_of = d.root_of.p; M.tmp = d.tmp.p; M.root_rank = d.root_rank.p;
-    M.gid_of = d.gid_of.p;
+    M.gid_of = d.gid_of.p; M.tmask = d.tmask.p; M.pat_mask = d.pat_mask.p; M.bk_list = d.bk_list.p;
     M.grp_cnt = d.grp.p; M.grp_off = d.grp.p + (n + 1); M.grp_fill = d.grp.p + 2 * ((size_t)n + 1); M.surv_cnt = d.grp.p + 3 * ((size_t)n + 1);
     M.surv_off = d.grp.p + 4 * ((size_t)n + 1);
     M.members = d.members.p; M.blank = d.blank.p; M.pat_packed = d.pat_packed.p; M.pat_len = d.pat_len.p; M.pat_token = d.pat_token.p;
@@ -1649,7 +1650,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const bool dev_tokens = dmp || (anchors && c->have_pat_token && c->have_merge);
     HIPCHK(c, launch_recruit_finish(c->R, c->d_idx.p, c->d_count.p, n_hits, anchors ? c->d_slot_info.p : c->d_hit_info.p, anchors, false,
                                     dev_tokens ? c->d_slot_pid.p : nullptr, dev_tokens ? (dmp ? c->dm.M.pat_token : c->a_pat_token.p) : nullptr,
-                                    c->d_rec.p, (dmp && n_exc == 0) ? nullptr : c->d_dr.p, c->dr_stride, c->stream));
+                                    c->d_rec.p, (dmp && n_exc == 0) ? nullptr : c->d_dr.p, c->dr_stride, c->stream, dmp ? c->dm.M.pat_mask : nullptr));
     if (n_exc)
         HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, n_exc, c->d_exc_hit.p, true, true, nullptr, nullptr, c->d_rec.p + n_hits,
                                         c->d_dr.p + n_hits * c->dr_stride, c->dr_stride, c->stream));

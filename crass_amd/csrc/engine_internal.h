@@ -100,8 +100,12 @@ struct DevMergeState {
     uint32_t rd_cursor;           // entries allocated in the needle index of removeRedundantRepeats
     uint32_t tab_mode;            // anchor table: 0 exact keys staged in LDS (log_size <= 15), 3 16-bit fingerprints of a
                                   // 2^16-slot table staged in LDS (anchor_fp), 2 exact keys probed in global memory
-    uint32_t pad[1];
+    uint32_t n_badk;              // 11-mers that contain an 'N' (resolved by the last block of k_dm_pack_codes)
+    uint32_t blocks_done;         // k_dm_pack_codes: blocks that have finished
+    uint32_t pad[3];
 };
+
+static constexpr uint32_t kDmBadKmerCap = 2048;     // 11-mers with an 'N' the device merge resolves; more -> host merge
 
 struct DevMerge {
     // input: distinct candidate DR strings in first-occurrence (= token) order
@@ -111,8 +115,10 @@ struct DevMerge {
     uint32_t kmax;                // k-mer slots per token (stride - 10)
     // per token
     uint64_t *packed;             // [n_tok][4] 2-bit packed string (lo, hi) and its reverse complement (lo, hi)
-    uint32_t *codes;              // [n_tok][kmax] laurenized 11-mer codes
-    uint32_t *owner;              // [1 << 22] smallest token containing the code
+    uint64_t *tmask;              // [n_tok][2] bit i: base i is an 'N' (packed as 'A'); forward and reverse complement
+    uint32_t *codes;              // [n_tok][kmax] laurenized 11-mer codes; (1 << 22) + id for an 11-mer with an 'N'
+    uint32_t *owner;              // [(1 << 22) + kDmBadKmerCap] smallest token containing the code
+    uint32_t *bk_list;            // [kDmBadKmerCap] (token << 6) | position of the 11-mers with an 'N'
     uint32_t *root_of;            // [n_tok] first token of the token's group
     uint32_t *tmp, *root_rank;    // [n_tok + 1]
     uint32_t *gid_of;             // [n_tok] GID (1-based)
@@ -125,9 +131,10 @@ struct DevMerge {
     uint32_t *rset_cnt, *rset_base, *rset_fill;   // [1 << rset_log]
     uint32_t rset_log;
     uint32_t *rd_slot;            // [n_tok] the member's key slot (bit 31: it claimed the slot)
-    uint64_t *rents;              // [n_tok][3] {len | token << 32, bits lo, bits hi}, grouped by key
+    uint64_t *rents;              // [n_tok][4] {len | token << 32, bits lo, bits hi, N mask}, grouped by key
     // pattern list (capacity 2 * n_tok)
     uint64_t *pat_packed;         // [n_pat][2]
+    uint64_t *pat_mask;           // [n_pat] bit i: base i of the pattern is an 'N'
     uint16_t *pat_len;
     uint32_t *pat_token;
     // anchor keys: entry e = pid * 8 + r (capacity 16 * n_tok)
@@ -136,7 +143,7 @@ struct DevMerge {
     uint32_t kset_log;
     uint32_t *ent_slot;           // [16 * n_tok] the entry's key slot
     uint8_t  *ent_win;            // [16 * n_tok] entry claimed its key's slot
-    uint64_t *ents;               // [16 * n_tok][3] verification index, grouped by key
+    uint64_t *ents;               // [16 * n_tok][4] verification index, grouped by key
     uint32_t *anchor_tab;         // [1 << tab_log_alloc] cuckoo table of the keys (see DevAnchors)
     uint32_t *anchor_fp;          // [1 << 15] words: tab_mode 3 = 2^16 16-bit fingerprints of the slots' keys;
                                   // tab_mode 2 = a 2^20-bit Bloom filter (2 hashes) staged in LDS in front of the L2 probes
@@ -208,7 +215,8 @@ hipError_t launch_recruit_exceptions(const DevReads &R, const DevAutomaton &A, c
 hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, const uint32_t *d_n_hits,
                                  uint64_t n_hits_max, const uint32_t *hit_info, bool info_by_slot, bool exceptions,
                                  const uint32_t *pid_by_slot, const uint32_t *pat_token,
-                                 RecruitOut *out, char *dr_chars, uint32_t dr_stride, hipStream_t st);
+                                 RecruitOut *out, char *dr_chars, uint32_t dr_stride, hipStream_t st,
+                                 const uint64_t *pat_mask = nullptr);   // device-built patterns: 'N' positions per pattern
 hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off, const uint32_t *a_len,
                                     const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,
                                     int32_t *dist, float *sim, uint32_t max_len, hipStream_t st);

@@ -2171,7 +2171,7 @@ template <bool EXC>
 __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64_t *hit_idx, const uint32_t *d_n_hits,
                                                         uint64_t n_max, const uint32_t *hit_info, int info_by_slot,
                                                         const uint32_t *pid_by_slot, const uint32_t *pat_token,
-                                                        RecruitOut *out, char *dr_chars, uint32_t dr_stride)
+                                                        RecruitOut *out, char *dr_chars, uint32_t dr_stride, const uint64_t *pat_mask)
 {
     uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t n = EXC ? R.n_exc : (uint64_t)(*d_n_hits);
@@ -2197,7 +2197,15 @@ __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64
     uint32_t DR_end = textpos - 1;
     if (DR_end >= L) DR_end = L - 1;
     uint32_t start = DR_end - (len - 1);
-    if (!EXC && len <= 64) {
+    // a pattern with an 'N' (device merge, dmerge.hip) matched an exception read: the packed words hold 'A' there,
+    // so the repeat is read from the read's bytes
+    const uint8_t *raw = nullptr;
+    if (!EXC && pat_mask && pid_by_slot && pat_mask[pid_by_slot[k]] != 0ull && R.n_exc) {
+        uint64_t lo = 0, hi = R.n_exc - 1;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (R.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
+        raw = R.exc_bytes + R.exc_off[lo];
+    }
+    if (!EXC && len <= 64 && !raw) {
         // packed reads: the repeat as a 128-bit value (base i in bits 2i..2i+1), its reverse complement by bit
         // reversal, and DRLowLexi's string comparison as "first differing base from the low end"
         const uint32_t nw = (L + 15) >> 4, w0 = start >> 4, sh = (start & 15u) * 2u;
@@ -2247,6 +2255,7 @@ __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64
     }
     auto base_at = [&](uint32_t i) -> uint8_t {
         if (EXC) return R.exc_bytes[o0 + i];
+        if (raw) return raw[i];
         uint32_t c = (g[i >> 4] >> ((i & 15u) * 2u)) & 3u;
         return (uint8_t)("ACGT"[c]);
     };
@@ -2256,15 +2265,15 @@ __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64
         uint8_t b = c_comp[base_at(start + len - 1 - i) & 127];
         if (a != b) { less = a < b; break; }
     }
-    char *dr = dr_chars + k * (uint64_t)dr_stride;
+    char *dr = dr_chars ? dr_chars + k * (uint64_t)dr_stride : nullptr;
     if (less) {
-        for (uint32_t i = 0; i < len; i++) dr[i] = (char)base_at(start + i);
+        if (dr) for (uint32_t i = 0; i < len; i++) dr[i] = (char)base_at(start + i);
         o.start = start; o.end = DR_end; o.low_lexi = 1;
     } else {
-        for (uint32_t i = 0; i < len; i++) dr[i] = (char)c_comp[base_at(start + len - 1 - i) & 127];
+        if (dr) for (uint32_t i = 0; i < len; i++) dr[i] = (char)c_comp[base_at(start + len - 1 - i) & 127];
         o.start = L - 1 - DR_end; o.end = L - 1 - start; o.low_lexi = 0;
     }
-    for (uint32_t i = len; i < dr_stride; i++) dr[i] = 0;
+    if (dr) for (uint32_t i = len; i < dr_stride; i++) dr[i] = 0;
     o.dr_len = (uint16_t)len;
     // the matched pattern's low-lexi form is a stored DR variant: its token was resolved once per
     // pattern on the host (addReadHolder's lookup, libcrispr.cpp:1137)
@@ -2275,14 +2284,14 @@ __global__ __launch_bounds__(256) void k_recruit_finish(DevReads R, const uint64
 hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, const uint32_t *d_n_hits, uint64_t n_hits_max,
                                  const uint32_t *hit_info, bool info_by_slot, bool exceptions,
                                  const uint32_t *pid_by_slot, const uint32_t *pat_token, RecruitOut *out,
-                                 char *dr_chars, uint32_t dr_stride, hipStream_t st)
+                                 char *dr_chars, uint32_t dr_stride, hipStream_t st, const uint64_t *pat_mask)
 {
     if (n_hits_max == 0) return hipSuccess;
     unsigned nb = (unsigned)((n_hits_max + 255) / 256);
     if (exceptions)
-        hipLaunchKernelGGL(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, 1, pid_by_slot, pat_token, out, dr_chars, dr_stride);
+        hipLaunchKernelGGL(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, 1, pid_by_slot, pat_token, out, dr_chars, dr_stride, (const uint64_t *)nullptr);
     else
-        hipLaunchKernelGGL(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, info_by_slot ? 1 : 0, pid_by_slot, pat_token, out, dr_chars, dr_stride);
+        hipLaunchKernelGGL(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, info_by_slot ? 1 : 0, pid_by_slot, pat_token, out, dr_chars, dr_stride, pat_mask);
     return hipGetLastError();
 }
 

@@ -177,15 +177,61 @@ def test_exception_reads_stay_on_the_device_path(ca):
     n1 = ref.n_pass1
     assert exc[ref.rec_read[:n1]].sum() > 20          # exception reads found by pass 1 ...
     assert exc[ref.rec_read[n1:n1 + ref.n_pass2]].sum() > 20   # ... and recruited by pass 2
-    # a DR that contains a non-ACGT byte: the device merge declines, the host merges (same results)
-    for r in ref.rec_read[:n1][:50]:
-        s = bytearray(cur[int(r)])
-        for p in range(0, 150, 3):
-            s[p] = ord("N") if s[p] == ord("A") else s[p]
-        cur[int(r)] = bytes(s)
-    ref2 = orc.pipeline(cur)
-    assert any(not set(s) <= ok for s in ref2.tokens)
-    dev2, host2 = both_paths(ca, cur)
-    assert dev2.counters["used_device_merge"] == 0
-    assert_same_paths(dev2, host2, expect_device=False)
+    # 'N' inside the repeats themselves: DR variants with an N.  The device merge carries an N-position mask
+    # through clustering (11-mers with an N get their identity from an all-pairs pass), removeRedundantRepeats,
+    # the pattern list and the pass-2 verification (byte for byte, as the automaton of libcrispr.cpp:503).
+    L = 150
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    cur2 = list(cur)
+    picked = 0
+    for k in range(n1):
+        r = int(ref.rec_read[k])
+        if exc[r] or picked >= 300:
+            continue
+        ss = ref.ss(k)
+        replen = int(ref.rec_replen[k])
+        # reads with the same variant get their N at the same offset: shared N-containing 11-mers across tokens
+        d = sum(ref.tokens[int(ref.rec_token[k]) - 2]) % replen if k % 3 else rng.randrange(replen)
+        s = bytearray(cur2[r])
+        for q in range(0, len(ss), 2):
+            p = ss[q] + d
+            p = p if ref.rec_lowlexi[k] else L - 1 - p
+            if 0 <= p < L:
+                s[p] = ord("N")
+        cur2[r] = bytes(s)
+        picked += 1
+    ref2 = orc.pipeline(cur2)
+    mixed = [t for t in ref2.tokens if not set(t) <= ok]
+    assert len(mixed) >= 10 and all(set(t) <= set(b"ACGTN") for t in mixed)
+    # single-copy reads that only pass 2 can recruit: a variant with its N, its reverse complement, and two
+    # decoys (N replaced by A / by R) that must not match the N pattern
+    filler = lambda n: bytes(rng.choice(b"ACGT") for _ in range(n))
+    for t in mixed[:25]:
+        for body in (t, t.translate(comp)[::-1], t.replace(b"N", b"A"), t.replace(b"N", b"R")):
+            pre = rng.randrange(5, 60)
+            cur2.append(filler(pre) + body + filler(L - pre - len(body)))
+    ref2 = orc.pipeline(cur2)
+    assert any(not set(t) <= ok for t in ref2.patterns)
+    n12 = ref2.n_pass1
+    assert (ref2.rec_read[n12:n12 + ref2.n_pass2] >= len(cur)).sum() >= 20
+    dev2, host2 = both_paths(ca, cur2)
+    assert_same_paths(dev2, host2)
     assert_same_pipeline(dev2, ref2)
+    # any other byte in a DR (IUPAC code, lower case): the device merge declines, the host merges
+    cur3 = list(cur2)
+    for k0 in range(20):
+        r = int(ref2.rec_read[k0])
+        ss = ref2.ss(k0)
+        s = bytearray(cur3[r])
+        for q in range(0, len(ss), 2):
+            p = ss[q] + 3
+            p = p if ref2.rec_lowlexi[k0] else L - 1 - p
+            if 0 <= p < L:
+                s[p] = ord("R")
+        cur3[r] = bytes(s)
+    ref3 = orc.pipeline(cur3)
+    assert any(b"R" in t or b"Y" in t for t in ref3.tokens)
+    dev3, host3 = both_paths(ca, cur3)
+    assert dev3.counters["used_device_merge"] == 0
+    assert_same_paths(dev3, host3, expect_device=False)
+    assert_same_pipeline(dev3, ref3)
