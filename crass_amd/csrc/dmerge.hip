@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
         for (int i = 0; i < kClusterK; i++) {
             const char ch = str[i];
             const uint64_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'N' ? 3u : 4u;
-            const uint64_t cc = c == 3u ? 3u : 4u - c;
+            const uint64_t cc = c == 0u ? 4u : c == 1u ? 2u : c == 2u ? 1u : c == 3u ? 3u : 0u;      // T G C N A
             fk = (fk << 3) | c;
             rk |= cc << (3 * i);
         }

@@ -2,7 +2,7 @@
 """Randomised parity sweep on the GPU box: many synthetic read sets with varied shapes through the HIP path and
 the oracle, field-by-field comparison (tests/parity.py).  Not part of the test suite (minutes of oracle time);
 run it after touching a kernel:  python tools/parity_sweep.py [n_cases] [seed]"""
-import os, sys, random, time
+import os, sys, random, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import crass_amd as ca
@@ -37,10 +37,15 @@ for case in range(n_cases):
             seqs[i] = bytes(b)
     p = ca.default_params(kmer_clust_size=k)
     host = rng.random() < 0.15
+    only = os.environ.get("ONLY")                # comma-separated case indices: replay just those (same random stream)
+    use_eng = rng.random() < 0.7 and k == 6
+    pad = rng.choice([0, 2])
+    if only and case not in {int(x) for x in only.split(",")}:
+        continue
     if host:
         os.environ["CRASS_HOST_MERGE"] = "1"
     try:
-        gpu = ca.search_pipeline(seqs, params=p, engine=eng if rng.random() < 0.7 and k == 6 else None, pad_uniform=rng.choice([0, 2]))
+        gpu = ca.search_pipeline(seqs, params=p, engine=eng if use_eng else None, pad_uniform=pad)
     finally:
         os.environ.pop("CRASS_HOST_MERGE", None)
     ref = orc.pipeline(seqs, params=orc.Params(p.lowDRsize, p.highDRsize, p.lowSpacerSize, p.highSpacerSize, p.searchWindowLength,
@@ -53,6 +58,11 @@ for case in range(n_cases):
             sum(1 for t in ref.tokens if not set(t) <= set(b"ACGT"))), flush=True)
     except AssertionError as e:
         bad += 1
-        print("FAIL %s: %s" % (tag, str(e)[:300]), flush=True)
+        tb = traceback.extract_tb(e.__traceback__)[-1]
+        print("FAIL case %d %s: %s:%d %s | %s" % (case, tag, os.path.basename(tb.filename), tb.lineno, tb.line, str(e)[:300]), flush=True)
+        if os.environ.get("DUMP_FAIL"):
+            import pickle
+            with open(os.path.join(os.environ["DUMP_FAIL"], "case%d.pkl" % case), "wb") as fh:
+                pickle.dump(dict(seqs=seqs, k=k, pad=pad), fh)
 print("%d cases, %d failures, %.0fs" % (n_cases, bad, time.time() - t_start))
 sys.exit(1 if bad else 0)
