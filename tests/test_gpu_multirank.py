@@ -269,3 +269,73 @@ print("OK")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600, env=env)
     assert r.returncode == 0 and b"OK" in r.stdout, r.stderr.decode()[-3000:]
+
+
+EXCHANGE_WITH_N = r"""
+import os, sys, random
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+torch.cuda.init()
+from tests import orc
+import crass_amd as ca
+from crass_amd.distributed import _DevView
+ca.load()
+n, L = 90000, 150
+rng = random.Random(3)
+spec = ca.synth_spec(read_len=L, crispr_per_million=40000)
+asc = ca.unpack_ascii(ca.synth_packed(spec, 0, n), 10, L, n)
+seqs = [bytearray(asc[i * L:(i + 1) * L].tobytes()) for i in range(n)]
+ref0 = orc.pipeline([bytes(s) for s in seqs])
+for k in range(ref0.n_pass1):                      # an N at the same offset of every repeat of a read: DR variants with an N
+    if k %% 4:
+        continue
+    r, ss, d = int(ref0.rec_read[k]), ref0.ss(k), rng.randrange(int(ref0.rec_replen[k]))
+    for q in range(0, len(ss), 2):
+        p = ss[q] + d
+        p = p if ref0.rec_lowlexi[k] else L - 1 - p
+        if 0 <= p < L:
+            seqs[r][p] = ord("N")
+for i in rng.sample(range(n), 2000):               # and N's anywhere
+    seqs[i][rng.randrange(L)] = ord("N")
+seqs = [bytes(s) for s in seqs]
+ref = orc.pipeline(seqs)
+assert sum(1 for t in ref.tokens if b"N" in t) >= 20
+engs, packs = [], []
+for r in range(3):
+    lo, hi = n * r // 3, n * (r + 1) // 3
+    e = ca.SearchEngine(device=0)
+    pk = ca.PackedReads(seqs[lo:hi])
+    e.load_reads(pk, None, read_index_base=lo)
+    engs.append(e); packs.append(pk)
+xs = [engs[r].exchange_setup(3, r, 8192) for r in range(3)]
+for e in engs:
+    e.seed_scan()
+recv = torch.cat([torch.as_tensor(_DevView(p_, (nb_,), "|u1"), device="cuda") for p_, nb_ in xs]).contiguous()
+torch.cuda.synchronize()
+views, recs = [], []
+for r in range(3):
+    v = engs[r].merge_gathered(recv.data_ptr())
+    assert not isinstance(v, int) and engs[r].counters()["used_device_merge"] == 1
+    recs.append(engs[r].recruit())
+    assert engs[r].counters()["used_device_merge"] == 1
+    views.append(engs[r].merge_view())
+for r in range(3):
+    assert views[r].tokens == ref.tokens and views[r].groups == ref.groups
+    assert sorted(views[r].patterns) == sorted(ref.patterns)
+n1, n2 = ref.n_pass1, ref.n_pass2
+assert sum((v.cand_token.tolist() for v in views), []) == ref.rec_token[:n1].tolist()
+assert sum((q.read_idx.tolist() for q in recs), []) == ref.rec_read[n1:n1 + n2].tolist()
+assert sum((q.token.tolist() for q in recs), []) == ref.rec_token[n1:n1 + n2].tolist()
+assert sum((q.low_lexi.tolist() for q in recs), []) == ref.rec_lowlexi[n1:n1 + n2].tolist()
+for e in engs:
+    e.close()
+print("OK")
+"""
+
+
+def test_exchange_three_shards_with_n_variants():
+    """three shards, reads with N (also inside the repeats, so that DR variants with an N cross the exchange):
+    one-collective form + device merge over the gathered lists against the oracle over all reads"""
+    r = subprocess.run([sys.executable, "-c", EXCHANGE_WITH_N % dict(root=ROOT)], capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"OK" in r.stdout, r.stderr.decode()[-3000:]
