@@ -119,8 +119,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kern = {"ms_filter": [], "ms_survivor": [], "ms_recruit": [], "ms_compact": [], "ms_merge_host": [],
-            "ms_sink_host": [], "ms_pass1_total": [], "ms_pass2_total": []}
+    # timed region: HIP events around the three large kernels only (stage timing level 1 — every event record costs
+    # ~6 us of stream time); the finer stage breakdown comes from a few extra, untimed steps below
+    kern = {"ms_filter": [], "ms_survivor": [], "ms_recruit": [], "ms_merge_host": [], "ms_sink_host": []}
+    eng.set_stage_timing(1)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -141,6 +143,15 @@ def main():
         tot_p1, tot_p2 = int(tot[0].item()), int(tot[1].item())
     c = eng.counters()
     ms_per_step = dt * 1e3 / args.steps
+    eng.set_stage_timing(2)                              # untimed: every stage (device merge, compaction, pass totals)
+    stages = {"ms_compact": [], "ms_pass1_total": [], "ms_merge_device": [], "ms_recruit_finish": [], "ms_pass2_total": []}
+    for _ in range(3):
+        step()
+        cs = eng.counters()
+        for k in stages:
+            stages[k].append(cs[k])
+    eng.set_stage_timing(1)
+    stages = {k: round(float(np.mean(v)), 4) for k, v in stages.items()}
     value = world * n * args.steps / dt
 
     # ---- roofline of the dominant kernel (HIP events on the engine's stream, see engine.cpp) ----
@@ -175,7 +186,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(cands[dom], 4),
                 "per_kernel": per_kernel, "host_ms": {"merge": round(avg["ms_merge_host"], 3), "sink": round(avg["ms_sink_host"], 3)},
-                "merge_device_ms": round(float(c.get("ms_merge_device", 0.0)), 4), "device_merge": int(c.get("used_device_merge", 0))}
+                "merge_device_ms": stages["ms_merge_device"], "device_merge": int(c.get("used_device_merge", 0)),
+                "stages_ms_untimed_steps": stages}
 
     out = {
         "metric": "reads/sec through DR search+recruit, 150bp synthetic, 1/2/4/8 MI355X",

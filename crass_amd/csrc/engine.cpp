@@ -202,6 +202,7 @@ struct crass_hip_ctx {
     bool recruit_exact = false;               // the next recruit call must not speculate (it repeats an overflowed one)               // speculative survivor bound for the next seed scan (0: none yet)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gathered = nullptr;
+    hipEvent_t bulk_gate = nullptr;                 // what issue_bulk() waits for (ev_gathered, or the merge's ev_done)
     mutable bool bulk_pending = false;          // copy in flight on copy_stream
     mutable bool bulk_needed = false;           // copy not issued yet (it is issued behind the merge's kernel launches)
     // The per-candidate records go to pinned host memory on the copy stream: the pack kernel writes them there
@@ -212,7 +213,7 @@ struct crass_hip_ctx {
         if (!bulk_needed) return;
         bulk_needed = false;
         const P1Dense &D = dense;
-        (void)hipStreamWaitEvent(copy_stream, ev_gathered, 0);
+        (void)hipStreamWaitEvent(copy_stream, bulk_gate ? bulk_gate : ev_gathered, 0);
         (void)launch_pack_p1_blob(d_count.p + 2, D.pack_cap, D.pack_ss_cap, D.d_read.p, D.d_replen.p, D.d_nss.p, D.d_low.p, D.d_ss.p,
                                   D.h_blob.p, copy_stream);
         bulk_pending = true;
@@ -288,6 +289,16 @@ struct crass_hip_ctx {
 
     crass_counters cnt{};
     hipEvent_t ev[12]{};
+    // stage timing (crass_hip_set_stage_timing): an event record costs ~6 us of stream time, 14 of them 8 % of a 1 ms step.
+    // 0 none, 1 the three large kernels only (seed scan, survivors, pass-2 scan), 2 every stage
+    int timing_level = 1;
+    hipError_t stamp(int i, int level) { return timing_level >= level ? hipEventRecord(ev[i], stream) : hipSuccess; }
+    float span(int a, int b, int level) const
+    {
+        float ms = 0;
+        if (timing_level < level || hipEventElapsedTime(&ms, ev[a], ev[b]) != hipSuccess) ms = 0;
+        return ms;
+    }
 };
 
 // crass_candidates' arrays from the compact hand-off blob (and the distinct-string list for the DR strings)
@@ -387,6 +398,7 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     if (skips < 1) skips = 1;
     c->dp.skips = skips;
     { const char *dbg = getenv("CRASS_SURV_DEBUG"); c->dp.debug_stop = dbg ? (uint32_t)atoi(dbg) : 0; }
+    if (const char *tl = getenv("CRASS_STAGE_TIMING")) c->timing_level = std::min(2, std::max(0, atoi(tl)));
     c->dr_stride = (p->highDRsize + 15u) & ~15u;
     if (hipSetDevice(device) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
@@ -397,6 +409,13 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     build_comp_table(tab);
     if (upload_comp_table(tab) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     *out = c;
+    return CRASS_OK;
+}
+
+int crass_hip_set_stage_timing(crass_hip_ctx *c, int level)
+{
+    if (!c || level < 0 || level > 2) return CRASS_ERR_INVALID_ARG;
+    c->timing_level = level;
     return CRASS_OK;
 }
 
@@ -626,7 +645,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             R.exc_read = c->R.exc_read + off; R.exc_off = c->R.exc_off + off; R.n_exc = nchunk;
         }
         // for the non-exception path the count lives on the device; chunking uses a host-known bound
-        if (!exc && off == 0) HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+        if (!exc && off == 0) HIPCHK(c, c->stamp(8, 1));
         HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
                                   c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                   c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds,
@@ -636,7 +655,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                                       c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                       c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds_full,
                                       (int)std::min<uint64_t>(grid, nchunk), c->stream, 6));
-        if (!exc && off == 0) HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+        if (!exc && off == 0) HIPCHK(c, c->stamp(9, 1));
         HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->d_surv.p, nchunk * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, nchunk * stride, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -717,9 +736,11 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     HIPCHK(c, D.d_replen.ensure(n_alloc + 4)); HIPCHK(c, D.d_nss.ensure(n_alloc + 4)); HIPCHK(c, D.d_dr_len.ensure(n_alloc + 8));
     HIPCHK(c, D.d_dr.ensure(n_alloc * stride + 16)); HIPCHK(c, D.d_ss.ensure(n_alloc * (uint64_t)lds.ss_cap + 4));
     // [2] = found count, [3] = worst error, [4] = n distinct, [5] = de-duplication mismatch flag
-    HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 16, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+    if (!speculative) {                                 // (speculative launch: cleared by the filter's compaction, see seed scan)
+        HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 16, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
+    }
+    HIPCHK(c, c->stamp(8, 1));
     // lane-per-read kernel for uniform short reads; whatever it punts (err == 4) and every other
     // layout goes through the wave-per-read kernel
     const uint32_t *hints = c->hints_valid ? c->d_hit_info.p : nullptr;
@@ -735,9 +756,18 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         HIPCHK(c, launch_survivor(c->R, c->dp, true, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
                                   c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, nullptr, lds,
                                   (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, 5));
-    HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+    HIPCHK(c, c->stamp(9, 1));
     const uint64_t n_words = (n_surv + 63) / 64;
-    HIPCHK(c, launch_found_mask(c->d_surv.p, d_nsurv, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream));
+    const bool dedupe = n_surv < (1u << 24);
+    uint32_t tsize = 1024;
+    if (dedupe) {
+        while (tsize < n_surv * 2) tsize <<= 1;
+        uint32_t tsize_alloc = tsize;
+        while (tsize_alloc < n_alloc * 2) tsize_alloc <<= 1;
+        HIPCHK(c, c->dd_keys.ensure(tsize_alloc)); HIPCHK(c, c->dd_first.ensure(tsize_alloc));
+    }
+    HIPCHK(c, launch_found_mask(c->d_surv.p, d_nsurv, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream,
+                                dedupe ? c->dd_keys.p : nullptr, dedupe ? c->dd_first.p : nullptr, tsize));
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n_surv, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, n_surv, c->d_count.p + 2, c->stream));
     HIPCHK(c, launch_gather_found(c->d_fidx.p, c->d_count.p + 2, n_surv, c->d_surv.p, c->d_idx.p, c->read_base, c->d_dr.p, stride,
                                   c->d_ss_pool.p, lds.ss_cap, D.d_read.p, D.d_low.p, D.d_replen.p, D.d_nss.p, D.d_ss_off.p,
@@ -746,27 +776,23 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     // their small outputs — all the merge needs — are written straight into pinned host memory
     c->have_rep = false;
     c->have_dev_tokens = false;
-    const bool dedupe = n_surv < (1u << 24);
     if (dedupe) {
-        uint32_t tsize = 1024;
-        while (tsize < n_surv * 2) tsize <<= 1;
-        uint32_t tsize_alloc = tsize;
-        while (tsize_alloc < n_alloc * 2) tsize_alloc <<= 1;
-        HIPCHK(c, c->dd_keys.ensure(tsize_alloc)); HIPCHK(c, c->dd_first.ensure(tsize_alloc)); HIPCHK(c, c->dd_slot.ensure(n_alloc));
+        HIPCHK(c, c->dd_slot.ensure(n_alloc));
         HIPCHK(c, c->dd_rep.ensure(n_alloc)); HIPCHK(c, c->dd_hash.ensure(n_alloc)); HIPCHK(c, c->h_rep.ensure(n_alloc)); HIPCHK(c, c->h_hash.ensure(n_alloc));
         HIPCHK(c, c->h_dmap.ensure(n_alloc)); HIPCHK(c, c->h_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(n_alloc));
         HIPCHK(c, c->h_dx_hash.ensure(n_alloc));
         HIPCHK(c, c->dd_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_alloc));
         HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_keys.p, c->dd_first.p, tsize,
-                                   c->dd_hash.p, c->dd_slot.p, c->dd_rep.p, c->stream));
+                                   c->dd_hash.p, c->dd_slot.p, c->dd_rep.p, c->stream, true));
         // distinct strings in first-occurrence order and every candidate's rank among them, exact
         HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->dd_slot.p, c->dd_first.p, c->d_mask.p,
                                    c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
-                                   c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream));
+                                   c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream,
+                                   c->d_count.p, c->h_count.p, 8));         // (the counters leave with the last kernel: no copy call)
         if (c->xchg.active)                             // multi-rank: the list goes straight into the collective's send buffer
             HIPCHK(c, launch_xg_fill(c->dd_dx_chars.p, c->dd_dx_len.p, c->d_count.p + 4, stride, c->xchg.cap, c->xchg.slot, c->xchg.send.p, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 32, hipMemcpyDeviceToHost, c->stream));
+    if (!dedupe) HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 32, hipMemcpyDeviceToHost, c->stream));
     {
         // the per-candidate records go to pinned host memory on the copy stream (the pack kernel writes them there
         // itself), behind the gather: they are not needed before the hand-off
@@ -774,6 +800,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         D.wide_ready = false; D.dr_fallback = false;
         HIPCHK(c, D.h_blob.ensure(cap));
         HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
+        c->bulk_gate = c->ev_gathered;
         D.pack_cap = n_surv; D.pack_ss_cap = lds.ss_cap;
         c->bulk_needed = true;                          // launched by issue_bulk(): next to the pass-2 filter, where it is free
     }
@@ -827,7 +854,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     const uint64_t n = c->R.n_reads;
     const uint64_t n_words = (n + 63) / 64;
     HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, c->stamp(0, 1));
     // step 1: filter.  Reads longer than 2 kbp almost surely contain a spurious lattice hit
     // (P ~ seeds*49/4^w), so the filter is skipped and every read goes to the survivor kernel.
     bool fast = false;
@@ -851,10 +878,12 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         }
     }
     c->hints_valid = fast;
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, c->stamp(1, 1));
     // step 2: ordered compaction
-    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    // (the scan kernel also clears the survivor stage's counters: d_count[2..6) and the start/stop pool cursor)
+    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream,
+                             c->d_count.p + 2, 4, c->d_ss_used.p, 1));
+    HIPCHK(c, c->stamp(2, 2));
     c->dense.active = false;
     c->have_rep = false;
     c->have_dev_tokens = false;
@@ -869,7 +898,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     const bool exc_ok = c->R.n_exc == 0 || c->dp.exc_survive;
     if (use_filter && exc_ok && c->surv_cap_hint && !getenv("CRASS_NO_SPECULATION")) {
         bool overflow = false;
-        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(c, c->stamp(3, 2));
         s = run_survivors_dense(c, c->surv_cap_hint, c->d_count.p, &overflow);
         if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
         if (s == CRASS_OK) {
@@ -897,7 +926,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         uint32_t big = 0xFFFFFFFFu;
         c->h_count.p[1] = big;
         HIPCHK(c, hipMemcpyAsync(c->d_count.p + 1, c->h_count.p + 1, 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(c, c->stamp(3, 2));
         bool overflow = false;
         s = try_dense ? run_survivors_dense(c, n_surv, c->d_count.p + 1, &overflow) : CRASS_ERR_STATE;
         if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
@@ -950,7 +979,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
             c->cand = std::move(m);
         }
     }
-    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    HIPCHK(c, c->stamp(4, 2));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t total = (size_t)c->n_cand();
     c->have_pass1 = true;
@@ -976,12 +1005,10 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     c->cnt.n_filter_survivors = n_surv + (c->dp.exc_survive ? 0 : c->R.n_exc);
     c->cnt.n_pass1_found = total;
     c->cnt.used_fast_filter = fast ? 1 : 0;
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->cnt.ms_filter = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->cnt.ms_compact = ms;
-    ms = 0; if (n_surv) (void)hipEventElapsedTime(&ms, c->ev[8], c->ev[9]);
-    c->cnt.ms_survivor = ms;                      // first chunk's kernel only (D2H excluded)
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[4]); c->cnt.ms_pass1_total = ms;
+    c->cnt.ms_filter = c->span(0, 1, 1);
+    c->cnt.ms_compact = c->span(1, 2, 2);
+    c->cnt.ms_survivor = n_surv ? c->span(8, 9, 1) : 0.f;          // first chunk's kernel only (D2H excluded)
+    c->cnt.ms_pass1_total = c->span(0, 4, 2);
     return CRASS_OK;
 }
 
@@ -1150,9 +1177,9 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
     d.M = M;
     const double tl0 = now_ms();
-    HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
+    if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
     HIPCHK(c, launch_device_merge(M, c->stream));
-    HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
+    if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
     if (getenv("CRASS_MERGE_PROFILE")) fprintf(stderr, "[crass_dm] host: launching the merge kernels took %.3f ms\n", now_ms() - tl0);
     // the per-token results the host view is rebuilt from (a few 10 KB)
     HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
@@ -1229,7 +1256,8 @@ static int build_host_merge(crass_hip_ctx *c)
     c->cnt.ac_states = 0;
     c->cnt.anchor_keys = d.h_st.p->n_keys;
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, d.ev_t0, d.ev_t1); c->cnt.ms_merge_device = ms;
+    if (c->timing_level >= 2) (void)hipEventElapsedTime(&ms, d.ev_t0, d.ev_t1);
+    c->cnt.ms_merge_device = ms;
     return CRASS_OK;
 }
 
@@ -1582,7 +1610,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
             HIPCHK(c, hipMemsetAsync(c->d_found.p + extra_found[i], 1, 1, c->stream));
         }
     }
-    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(c, c->stamp(5, 1));
     // fast path: anchor filter (exact superset) then an exact scan of the flagged reads only;
     // otherwise the automaton scans every read (LDS table when it fits).
     bool anchors = false, lds = false;
@@ -1593,9 +1621,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const uint64_t n_exc = dmp ? 0 : c->R.n_exc;
     if (dmp) {
         // the pass-1 hand-off records leave next to the filter (not next to the merge kernels queued ahead of it)
-        if (c->bulk_needed) {
-            HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
-        }
+        // (gate: the event recorded behind the merge kernels — nothing has been queued on the stream since)
+        if (c->bulk_needed && c->dm.ev_done) c->bulk_gate = c->dm.ev_done;
         HIPCHK(c, launch_anchor_filter_dev(c->R, c->dm.M, c->d_found.p, c->d_mask.p, c->stream));
         anchors = true;
         c->issue_bulk();
@@ -1615,14 +1642,15 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         HIPCHK(c, c->d_exc_hit.ensure(n_exc));
         HIPCHK(c, launch_recruit_exceptions(c->R, c->A, c->d_found.p, c->d_exc_hit.p, c->stream));
     }
-    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    HIPCHK(c, c->stamp(6, 1));
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
     // Speculative tail (device merge path): verification, finish and the hand-off pack are launched with the hit
     // count still on the device, sized by a bound learnt from the previous call; the exact count arrives with the
     // final synchronisation, and a bound that was too small repeats the tail with the exact count.
     const bool spec = dmp && n_exc == 0 && c->hit_cap_hint && !getenv("CRASS_NO_SPECULATION") && !c->recruit_exact;
     c->recruit_exact = false;
+    // (speculative: the count reaches the host with the last kernel of the tail, k_pack_p2_blob)
+    if (!spec) HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
     if (!spec) HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!spec && dmp && c->dm.h_st.p->fail) {       // the device merge gave up: host merge, then pass 2 again
         const int fs = host_merge_fallback(c);
@@ -1654,7 +1682,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     if (n_exc)
         HIPCHK(c, launch_recruit_finish(c->R, nullptr, nullptr, n_exc, c->d_exc_hit.p, true, true, nullptr, nullptr, c->d_rec.p + n_hits,
                                         c->d_dr.p + n_hits * c->dr_stride, c->dr_stride, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(c, c->stamp(7, 2));
     // device merge path: the sink runs on the device too (drop the slots without a match, pack the records in
     // read order) and ONE copy brings the hand-off arrays to pinned host memory
     const bool dev_sink = dmp && n_exc == 0;
@@ -1666,7 +1694,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         HIPCHK(c, c->d_fidx.ensure(h_alloc + 1));
         if (n_hits) {
             HIPCHK(c, launch_pack_p2_blob(c->d_rec.p, c->d_idx.p, c->read_base, c->d_count.p, n_hits, c->d_mask.p,
-                                          c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 6, c->h_qblob.p, c->stream));
+                                          c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 6, c->h_qblob.p, c->stream,
+                                          spec ? c->h_count.p : nullptr));
         } else memset(c->h_qblob.p, 0, 16);
         const double th0 = now_ms();
         const int hs = ensure_host_merge(c);            // host view of the merge, rebuilt while the device verifies
@@ -1701,10 +1730,9 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         c->cnt.used_lds_automaton = 2;
         c->cnt.anchor_keys = c->dm.h_st.p->n_keys;
         c->cnt.anchor_table_kind = c->dm.h_st.p->tab_mode == 3 ? 1 : c->dm.h_st.p->tab_mode;
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->cnt.ms_recruit = ms;
-        (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->cnt.ms_recruit_finish = ms;
-        (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[7]); c->cnt.ms_pass2_total = ms;
+        c->cnt.ms_recruit = c->span(5, 6, 1);
+        c->cnt.ms_recruit_finish = c->span(6, 7, 2);
+        c->cnt.ms_pass2_total = c->span(5, 7, 2);
         return CRASS_OK;
     }
     if (n_slots) {
@@ -1766,10 +1794,9 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     c->cnt.used_lds_automaton = anchors ? 2 : (lds ? 1 : 0);     // 2 = anchor filter + exact list scan
     c->cnt.anchor_keys = !anchors ? 0 : (dmp ? c->dm.h_st.p->n_keys : c->K.n_keys);
     c->cnt.anchor_table_kind = !anchors ? 0 : (dmp ? (c->dm.h_st.p->tab_mode == 3 ? 1u : c->dm.h_st.p->tab_mode) : (c->K.log_size > 15 ? 2 : c->K.mode));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->cnt.ms_recruit = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->cnt.ms_recruit_finish = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[7]); c->cnt.ms_pass2_total = ms;
+    c->cnt.ms_recruit = c->span(5, 6, 1);
+    c->cnt.ms_recruit_finish = c->span(6, 7, 2);
+    c->cnt.ms_pass2_total = c->span(5, 7, 2);
     return CRASS_OK;
 }
 

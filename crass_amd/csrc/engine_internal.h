@@ -192,7 +192,8 @@ hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *h
 // scratch: word_prefix[n_words] u32, block_sums[(n_words+255)/256 + 1] u32
 hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
                           uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count,
-                          hipStream_t st);
+                          hipStream_t st, uint32_t *zero_a = nullptr, uint32_t n_a = 0, uint32_t *zero_b = nullptr, uint32_t n_b = 0);
+// (zero_a/zero_b: up to 1024 words each that the scan kernel clears on the way)
 hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exceptions,
                            const uint64_t *surv_idx, const uint32_t *d_n_surv, uint64_t n_surv_max,
                            SurvOut *out, char *dr_chars, uint32_t dr_stride,
@@ -222,7 +223,8 @@ hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off,
                                     int32_t *dist, float *sim, uint32_t max_len, hipStream_t st);
 hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st);
 
-hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st);
+hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st,
+                             unsigned long long *dd_keys = nullptr, uint32_t *dd_first = nullptr, uint32_t dd_size = 0);   // also clears that table
 hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out,
                                const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
                                const uint32_t *ss_pool, uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
@@ -259,14 +261,17 @@ __host__ __device__ inline P2Blob p2_blob_layout(uint64_t cap)
 // valid hits (dr_len != 0) of the finish kernel's slots -> compacted, read-ordered compact arrays in `blob`
 hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base,
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
-                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st);
+                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st,
+                               uint32_t *h_n_hits = nullptr);        // pinned word that receives *d_n_hits
 hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, uint32_t *rep,
                             const uint32_t *slot_of, const uint32_t *first,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
-                            char *dev_chars, uint16_t *dev_len, hipStream_t st);
+                            char *dev_chars, uint16_t *dev_len, hipStream_t st,
+                            const uint32_t *cnt_src = nullptr, uint32_t *cnt_dst = nullptr, uint32_t n_cnt = 0);   // counters -> pinned host words
 hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n, unsigned long long *keys,
-                            uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st);
+                            uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st,
+                            bool table_cleared = false);
 // row_len_cap: longest string the Levenshtein fallback rows hold in this layout (reads that need more come back
 // with err == 6 and are redone with the uncapped layout)
 SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P, uint32_t row_len_cap = 0xFFFFFFFFu);

@@ -327,8 +327,12 @@ __global__ __launch_bounds__(256) void k_mask_count(const uint64_t *mask, uint64
     if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
 }
 
-__global__ __launch_bounds__(1024) void k_block_scan(uint32_t *block_sums, uint32_t n_blocks, uint32_t *d_count)
+__global__ __launch_bounds__(1024) void k_block_scan(uint32_t *block_sums, uint32_t n_blocks, uint32_t *d_count, uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b)
 {
+    // counters the NEXT stage accumulates into are cleared here instead of by their own fill launches
+    if (threadIdx.x < n_a) zero_a[threadIdx.x] = 0u;
+    if (threadIdx.x < n_b) zero_b[threadIdx.x] = 0u;
+
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -372,12 +376,17 @@ __global__ __launch_bounds__(256) void k_mask_scatter(const uint64_t *mask, uint
 }
 
 hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
-                          uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count, hipStream_t st)
+                          uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count, hipStream_t st,
+                          uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b)
 {
-    if (n_words == 0) { return hipMemsetAsync(d_count, 0, 4, st); }
+    if (n_words == 0) {
+        if (n_a) (void)hipMemsetAsync(zero_a, 0, 4 * (size_t)n_a, st);
+        if (n_b) (void)hipMemsetAsync(zero_b, 0, 4 * (size_t)n_b, st);
+        return hipMemsetAsync(d_count, 0, 4, st);
+    }
     unsigned nb = (unsigned)((n_words + 255) / 256);
     hipLaunchKernelGGL(k_mask_count, dim3(nb), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums);
-    hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, d_count);
+    hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, d_count, zero_a, n_a, zero_b, n_b);
     hipLaunchKernelGGL(k_mask_scatter, dim3(nb), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap);
     return hipGetLastError();
 }
@@ -1484,9 +1493,12 @@ hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const ui
 
 // ---- device-side gather of the found records (fast path: short reads, slot-mode pool) ----
 // mask of slots with found != 0; the worst error code is max-reduced into *d_err
-__global__ __launch_bounds__(256) void k_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err)
+__global__ __launch_bounds__(256) void k_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err,
+                                                     unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size)
 {
     const uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    // the de-duplication table of the next stage is cleared on the way (saves its own launch)
+    for (uint64_t i = s; i < dd_size; i += (uint64_t)gridDim.x * blockDim.x) { dd_keys[i] = 0ull; dd_first[i] = 0xFFFFFFFFu; }
     bool f = false;
     if (s < n && s < (uint64_t)*d_n) {                  // slots past the device-side count were never written
         const SurvOut o = out[s];
@@ -1580,10 +1592,11 @@ hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t ss
     return hipGetLastError();
 }
 
-hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st)
+hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st,
+                             unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_found_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, d_n, n, mask, d_err);
+    hipLaunchKernelGGL(k_found_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, d_n, n, mask, d_err, dd_keys, dd_first, dd_keys ? dd_size : 0u);
     return hipGetLastError();
 }
 
@@ -1646,10 +1659,11 @@ __global__ __launch_bounds__(256) void k_dr_dedupe_insert(const char *dr, const 
 
 // the candidate count lives on the device (*d_n, at most n_max): no host round trip before this launch
 hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n, unsigned long long *keys,
-                            uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st)
+                            uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st,
+                            bool table_cleared)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dr_dedupe_clear, dim3((unsigned)std::min<uint32_t>((table_size + 255) / 256, 2048u)), dim3(256), 0, st, keys, first, table_size);
+    if (!table_cleared) hipLaunchKernelGGL(k_dr_dedupe_clear, dim3((unsigned)std::min<uint32_t>((table_size + 255) / 256, 2048u)), dim3(256), 0, st, keys, first, table_size);
     const unsigned nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_dr_dedupe_insert, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, keys, first, table_size - 1, hash_out, slot_tmp);
     (void)rep;                                  // rep[] = first occurrence of every candidate: written by k_dx_flag
@@ -1699,9 +1713,11 @@ __global__ __launch_bounds__(256) void k_dx_assign(const uint32_t *rep, const ui
 
 __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const uint32_t *d_nd, uint32_t n_max, const char *dr,
                                                     const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, char *out_chars,
-                                                    uint16_t *out_len, uint64_t *out_hash, char *dev_chars, uint16_t *dev_len)
+                                                    uint16_t *out_len, uint64_t *out_hash, char *dev_chars, uint16_t *dev_len,
+                                                    const uint32_t *cnt_src, uint32_t *cnt_dst, uint32_t n_cnt)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_cnt) cnt_dst[j] = cnt_src[j];             // the stage's counters, straight into pinned host memory
     uint32_t nd = *d_nd;
     if (nd > n_max) nd = n_max;
     if (j >= nd) return;
@@ -1723,7 +1739,7 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
                             const uint32_t *slot_of, const uint32_t *first,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
-                            char *dev_chars, uint16_t *dev_len, hipStream_t st)
+                            char *dev_chars, uint16_t *dev_len, hipStream_t st, const uint32_t *cnt_src, uint32_t *cnt_dst, uint32_t n_cnt)
 {
     if (n == 0) return hipSuccess;
     const unsigned nb = (n + 255) / 256;
@@ -1731,7 +1747,8 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
     hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap);
-    hipLaunchKernelGGL(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len);
+    hipLaunchKernelGGL(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len,
+                       cnt_src, cnt_dst, cnt_dst ? n_cnt : 0u);
     return hipGetLastError();
 }
 
@@ -2306,12 +2323,15 @@ __global__ __launch_bounds__(256) void k_recruit_valid_mask(const RecruitOut *re
     if ((threadIdx.x & 63) == 0 && k < n_max) mask[k >> 6] = m;
 }
 __global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base, const uint64_t *vidx,
-                                                       const uint32_t *d_nv, uint64_t cap, uint8_t *blob)
+                                                       const uint32_t *d_nv, uint64_t cap, uint8_t *blob, const uint32_t *d_n_hits, uint32_t *h_n_hits)
 {
     const uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t nv = *d_nv;
     if (nv > cap) nv = cap;
-    if (q == 0) { reinterpret_cast<uint64_t *>(blob)[0] = nv; reinterpret_cast<uint64_t *>(blob)[1] = cap; }
+    if (q == 0) {
+        reinterpret_cast<uint64_t *>(blob)[0] = nv; reinterpret_cast<uint64_t *>(blob)[1] = cap;
+        if (h_n_hits) *h_n_hits = *d_n_hits;            // the flagged-read count the host checks its bound against
+    }
     if (q >= nv) return;
     const P2Blob b = p2_blob_layout(cap);
     const uint64_t k = vidx[q];
@@ -2325,14 +2345,14 @@ __global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, con
 }
 hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base,
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
-                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st)
+                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st, uint32_t *h_n_hits)
 {
     if (n_hits_max == 0) return hipSuccess;
     const unsigned nb = (unsigned)((n_hits_max + 255) / 256);
     hipLaunchKernelGGL(k_recruit_valid_mask, dim3(nb), dim3(256), 0, st, rec, d_n_hits, n_hits_max, mask);
     hipError_t e = launch_compact(mask, (n_hits_max + 63) / 64, n_hits_max, word_prefix, block_sums, vidx, n_hits_max, d_nv, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob);
+    hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
     return hipGetLastError();
 }
 

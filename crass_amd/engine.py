@@ -441,6 +441,10 @@ class SearchEngine:
         _chk(self.lib.crass_hip_get_recruits(self.h, C.byref(v)), "crass_hip_get_recruits")
         return RecruitSet(v)
 
+    def set_stage_timing(self, level):
+        """0 none, 1 the three large kernels (default), 2 every stage — see crass_hip_set_stage_timing."""
+        _chk(self.lib.crass_hip_set_stage_timing(self.h, int(level)), "crass_hip_set_stage_timing")
+
     def counters(self):
         c = _abi.Counters()
         _chk(self.lib.crass_hip_get_counters(self.h, C.byref(c)), "crass_hip_get_counters")

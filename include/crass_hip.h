@@ -93,6 +93,11 @@ typedef struct {
 /* ---- lifecycle ---- */
 /* replaces: the `options` argument of searchFile/findSingletons */
 int  crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out);
+/* Stage timing with HIP events on the context's stream.  An event record costs ~6 us of stream time, so the
+ * default (1) times only the three large kernels (counters ms_filter, ms_survivor, ms_recruit); 2 adds every
+ * stage (ms_compact, ms_pass1_total, ms_merge_device, ms_recruit_finish, ms_pass2_total), 0 times nothing.
+ * Environment override at creation: CRASS_STAGE_TIMING=0|1|2.  (No reference counterpart: crass has no timers.) */
+int  crass_hip_set_stage_timing(crass_hip_ctx *ctx, int level);
 void crass_hip_destroy(crass_hip_ctx *ctx);
 const char *crass_hip_strerror(int status);
 int  crass_hip_last_hip_error(const crass_hip_ctx *ctx);

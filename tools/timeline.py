@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Print the device-side timeline (kernels + copies) of the LAST bench step from a rocprofv3
---kernel-trace --memory-copy-trace CSV directory:  python tools/timeline.py DIR"""
+--kernel-trace --memory-copy-trace CSV directory:  python tools/timeline.py DIR [STEPS_BACK]
+(bench.py ends with 3 untimed stage-breakdown steps: STEPS_BACK=3 shows the last TIMED step)"""
 import csv
 import glob
 import sys
@@ -20,7 +21,9 @@ def main():
     starts = [i for i, e in enumerate(ev) if "k_filter" in e[2]]
     if not starts:
         print("no filter kernel found"); return
-    ev = ev[starts[-1]:]
+    back = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    first = starts[-1 - back]
+    ev = ev[first:(starts[-back] if back else len(ev))]
     t0 = ev[0][0]
     prev_end = t0
     for s, e, n in ev:
