@@ -78,6 +78,53 @@ __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
 // ---- 1. 2-bit packing (forward and reverse complement) + laurenized 11-mer codes + k-mer owners ----
 // owner[code] = smallest token containing the k-mer = the token whose group the k-mer belongs to in the
 // reference's k2GIDMap (homeless k-mers are assigned to their first token's group, WorkHorse.cpp:1612-1617).
+// one token: WITH_N = false is the plain ACGT walk (any other byte sets `bad`); WITH_N = true also accepts 'N'
+// (packed as 'A' + a position-mask bit) and lists the 11-mers that contain one instead of coding them
+template <bool WITH_N>
+static __device__ __forceinline__ void dm_pack_token(const DevMerge &M, uint32_t t, uint32_t len, const uint32_t (&w)[16])
+{
+    uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0, mf = 0, mr = 0;
+    uint32_t fwd = 0, rev = 0;
+    bool bad = false;
+    uint32_t clean = 0;                                 // bases since the last 'N'
+    uint32_t *codes = M.codes + (uint64_t)t * M.kmax;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if ((uint32_t)i < len) {
+            const uint32_t ch = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const bool isn = WITH_N && ch == 'N';
+            const uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : (WITH_N && isn) ? 0u : 3u;
+            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && !isn) bad = true;
+            const uint32_t cr = isn ? 0u : 3u - c;
+            if (i < 32) f0 |= (uint64_t)c << (2 * (i & 31)); else f1 |= (uint64_t)c << (2 * (i & 31));
+            const uint32_t j = len - 1 - i;
+            if (j < 32) r0 |= (uint64_t)cr << (2 * j); else r1 |= (uint64_t)cr << (2 * (j - 32));
+            if (WITH_N) {
+                if (isn) { mf |= 1ull << i; mr |= 1ull << j; }
+                clean = isn ? 0u : clean + 1u;
+            }
+            // first base most significant: integer order == lexicographic order, laurenize() == min (SeqUtils.cpp:89-97)
+            fwd = ((fwd << 2) | c) & 0x3FFFFFu;
+            rev = (rev >> 2) | (cr << 20);
+            if (i + 1 >= kClusterK) {
+                if (!WITH_N || clean >= (uint32_t)kClusterK) {
+                    const uint32_t code = fwd < rev ? fwd : rev;
+                    codes[i + 1 - kClusterK] = code;
+                    atomicMin(&M.owner[code], t);
+                } else {                                // an 11-mer with an 'N': identity assigned by the last block
+                    const uint32_t q = atomicAdd(&M.st->n_badk, 1u);
+                    if (q < kDmBadKmerCap) M.bk_list[q] = (t << 6) | (uint32_t)(i + 1 - kClusterK);
+                    codes[i + 1 - kClusterK] = 1u << 22;
+                }
+            }
+        }
+    }
+    uint64_t *pk = M.packed + (uint64_t)t * 4;
+    pk[0] = f0; pk[1] = f1; pk[2] = r0; pk[3] = r1;
+    M.tmask[(uint64_t)t * 2] = mf; M.tmask[(uint64_t)t * 2 + 1] = mr;
+    if (bad) atomicOr(&M.st->fail, 1u);
+}
+
 __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
 {
     __shared__ uint64_t bk_key[kDmBadKmerCap];
@@ -90,50 +137,20 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
             // the whole slot in registers (16-byte loads), then a fully unrolled walk: every register index is static
             uint32_t w[16];
             const uint4 *p4 = reinterpret_cast<const uint4 *>(M.dx_chars + (uint64_t)t * M.stride);
+            uint32_t any_n = 0;                         // exact "some byte == 'N'" (slots are zero padded)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 uint4 v; v.x = v.y = v.z = v.w = 0;
                 if ((uint32_t)q * 16 < M.stride) v = p4[q];
                 w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
             }
-            uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0, mf = 0, mr = 0;
-            uint32_t fwd = 0, rev = 0;
-            bool bad = false;
-            uint32_t clean = 0;                         // bases since the last 'N'
-            uint32_t *codes = M.codes + (uint64_t)t * M.kmax;
 #pragma unroll
-            for (int i = 0; i < 64; i++) {
-                if ((uint32_t)i < len) {
-                    const uint32_t ch = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                    const bool isn = ch == 'N';
-                    const uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0u;
-                    if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && !isn) bad = true;
-                    const uint32_t cr = isn ? 0u : 3u - c;
-                    if (i < 32) f0 |= (uint64_t)c << (2 * (i & 31)); else f1 |= (uint64_t)c << (2 * (i & 31));
-                    const uint32_t j = len - 1 - i;
-                    if (j < 32) r0 |= (uint64_t)cr << (2 * j); else r1 |= (uint64_t)cr << (2 * (j - 32));
-                    if (isn) { mf |= 1ull << i; mr |= 1ull << j; }
-                    clean = isn ? 0u : clean + 1u;
-                    // first base most significant: integer order == lexicographic order, laurenize() == min (SeqUtils.cpp:89-97)
-                    fwd = ((fwd << 2) | c) & 0x3FFFFFu;
-                    rev = (rev >> 2) | (cr << 20);
-                    if (i + 1 >= kClusterK) {
-                        if (clean >= (uint32_t)kClusterK) {
-                            const uint32_t code = fwd < rev ? fwd : rev;
-                            codes[i + 1 - kClusterK] = code;
-                            atomicMin(&M.owner[code], t);
-                        } else {                        // an 11-mer with an 'N': identity assigned below
-                            const uint32_t q = atomicAdd(&M.st->n_badk, 1u);
-                            if (q < kDmBadKmerCap) M.bk_list[q] = (t << 6) | (uint32_t)(i + 1 - kClusterK);
-                            codes[i + 1 - kClusterK] = 1u << 22;
-                        }
-                    }
-                }
+            for (int q = 0; q < 16; q++) {
+                const uint32_t x = w[q] ^ 0x4E4E4E4Eu;
+                any_n |= ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
             }
-            uint64_t *pk = M.packed + (uint64_t)t * 4;
-            pk[0] = f0; pk[1] = f1; pk[2] = r0; pk[3] = r1;
-            M.tmask[(uint64_t)t * 2] = mf; M.tmask[(uint64_t)t * 2 + 1] = mr;
-            if (bad) atomicOr(&M.st->fail, 1u);
+            if (any_n) dm_pack_token<true>(M, t, len, w);
+            else dm_pack_token<false>(M, t, len, w);
         }
     }
     // ---- the last block to finish gives the 11-mers with an 'N' their identity: the laurenized 11-mer over
