@@ -292,6 +292,8 @@ struct crass_hip_ctx {
     // stage timing (crass_hip_set_stage_timing): an event record costs ~6 us of stream time, 14 of them 8 % of a 1 ms step.
     // 0 none, 1 the three large kernels only (seed scan, survivors, pass-2 scan), 2 every stage
     int timing_level = 1;
+    double t_p1_sync = 0;                           // CRASS_MERGE_PROFILE: host time line between pass 1 and the merge
+    bool spans_p1 = false, spans_p2 = false, span_survivors = false;     // spans to evaluate at the next counters fetch
     hipError_t stamp(int i, int level) { return timing_level >= level ? hipEventRecord(ev[i], stream) : hipSuccess; }
     float span(int a, int b, int level) const
     {
@@ -806,6 +808,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     }
     host_pool_warm();                                   // the merge follows: wake the host workers while the device finishes
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->t_p1_sync = now_ms();
     if (c->h_count.p[0] > n_surv) { *overflow = true; return CRASS_OK; }
     const uint64_t nf = c->h_count.p[2];
     const uint32_t err = c->h_count.p[3];
@@ -1005,10 +1008,9 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     c->cnt.n_filter_survivors = n_surv + (c->dp.exc_survive ? 0 : c->R.n_exc);
     c->cnt.n_pass1_found = total;
     c->cnt.used_fast_filter = fast ? 1 : 0;
-    c->cnt.ms_filter = c->span(0, 1, 1);
-    c->cnt.ms_compact = c->span(1, 2, 2);
-    c->cnt.ms_survivor = n_surv ? c->span(8, 9, 1) : 0.f;          // first chunk's kernel only (D2H excluded)
-    c->cnt.ms_pass1_total = c->span(0, 4, 2);
+    // (the event spans are evaluated when the counters are fetched: each query costs microseconds of host time
+    // between two stages)
+    c->spans_p1 = true; c->span_survivors = n_surv != 0;
     return CRASS_OK;
 }
 
@@ -1180,7 +1182,9 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
     HIPCHK(c, launch_device_merge(M, c->stream));
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
-    if (getenv("CRASS_MERGE_PROFILE")) fprintf(stderr, "[crass_dm] host: launching the merge kernels took %.3f ms\n", now_ms() - tl0);
+    if (getenv("CRASS_MERGE_PROFILE"))
+        fprintf(stderr, "[crass_dm] host: pass-1 sync -> merge launch start %.1f us, launching the merge kernels %.1f us\n",
+                1e3 * (tl0 - c->t_p1_sync), 1e3 * (now_ms() - tl0));
     // the per-token results the host view is rebuilt from (a few 10 KB)
     HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
     d.active = true; d.host_built = false; d.n_cand = c->dense.n;
@@ -1730,9 +1734,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         c->cnt.used_lds_automaton = 2;
         c->cnt.anchor_keys = c->dm.h_st.p->n_keys;
         c->cnt.anchor_table_kind = c->dm.h_st.p->tab_mode == 3 ? 1 : c->dm.h_st.p->tab_mode;
-        c->cnt.ms_recruit = c->span(5, 6, 1);
-        c->cnt.ms_recruit_finish = c->span(6, 7, 2);
-        c->cnt.ms_pass2_total = c->span(5, 7, 2);
+        c->spans_p2 = true;
         return CRASS_OK;
     }
     if (n_slots) {
@@ -1794,9 +1796,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     c->cnt.used_lds_automaton = anchors ? 2 : (lds ? 1 : 0);     // 2 = anchor filter + exact list scan
     c->cnt.anchor_keys = !anchors ? 0 : (dmp ? c->dm.h_st.p->n_keys : c->K.n_keys);
     c->cnt.anchor_table_kind = !anchors ? 0 : (dmp ? (c->dm.h_st.p->tab_mode == 3 ? 1u : c->dm.h_st.p->tab_mode) : (c->K.log_size > 15 ? 2 : c->K.mode));
-    c->cnt.ms_recruit = c->span(5, 6, 1);
-    c->cnt.ms_recruit_finish = c->span(6, 7, 2);
-    c->cnt.ms_pass2_total = c->span(5, 7, 2);
+    c->spans_p2 = true;
     return CRASS_OK;
 }
 
@@ -1867,6 +1867,20 @@ int crass_hip_levenshtein_batch(crass_hip_ctx *c, const char *chars, uint64_t n_
 int crass_hip_get_counters(const crass_hip_ctx *c, crass_counters *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    crass_hip_ctx *m = const_cast<crass_hip_ctx *>(c);
+    if (m->spans_p1) {
+        m->spans_p1 = false;
+        m->cnt.ms_filter = c->span(0, 1, 1);
+        m->cnt.ms_compact = c->span(1, 2, 2);
+        m->cnt.ms_survivor = c->span_survivors ? c->span(8, 9, 1) : 0.f;      // first chunk's kernel only (D2H excluded)
+        m->cnt.ms_pass1_total = c->span(0, 4, 2);
+    }
+    if (m->spans_p2) {
+        m->spans_p2 = false;
+        m->cnt.ms_recruit = c->span(5, 6, 1);
+        m->cnt.ms_recruit_finish = c->span(6, 7, 2);
+        m->cnt.ms_pass2_total = c->span(5, 7, 2);
+    }
     *o = c->cnt;
     return CRASS_OK;
 }
