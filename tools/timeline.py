@@ -27,6 +27,8 @@ def main():
     t0 = ev[0][0]
     prev_end = t0
     for s, e, n in ev:
+        if back and s - prev_end > 80_000:             # the next step's prologue (after the host fetched the results)
+            break
         print("%9.1f us  +%8.1f gap  %8.1f us  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, n))
         prev_end = max(prev_end, e)
     print("total span %.1f us" % ((prev_end - t0) / 1e3))
