@@ -292,6 +292,40 @@ struct crass_hip_ctx {
     // stage timing (crass_hip_set_stage_timing): an event record costs ~6 us of stream time, 14 of them 8 % of a 1 ms step.
     // 0 none, 1 the three large kernels only (seed scan, survivors, pass-2 scan), 2 every stage
     int timing_level = 1;
+    // single-pass compaction (k_mask_compact_lb): status words + ticket counter shared by every launch of the context
+    DevBuf<unsigned long long> lb_status; DevBuf<uint32_t> lb_ticket; PinBuf<uint32_t> h_lb_fail;
+    uint32_t lb_base = 0, lb_epoch = 0;
+    bool lb_on = true;
+    // nullptr: use the three-kernel form (switched off, or allocation failed)
+    const Lookback *next_lookback(uint64_t n_words, Lookback *out)
+    {
+        if (!lb_on || n_words == 0) return nullptr;
+        const uint32_t tw = lookback_tile_words(n_words);
+        const uint64_t n_tiles = (n_words + tw - 1) / tw;
+        if (n_tiles > (1u << 24)) return nullptr;
+        if (!lb_status.p || lb_status.n < n_tiles) {
+            if (lb_status.ensure(std::max<uint64_t>(n_tiles * 2, 4096)) != hipSuccess) return nullptr;
+            if (hipMemsetAsync(lb_status.p, 0, lb_status.n * 8, stream) != hipSuccess) return nullptr;
+        }
+        if (!lb_ticket.p) {
+            if (lb_ticket.ensure(4) != hipSuccess || h_lb_fail.ensure(4) != hipSuccess) return nullptr;
+            if (hipMemsetAsync(lb_ticket.p, 0, 16, stream) != hipSuccess) return nullptr;
+            h_lb_fail.p[0] = 0; lb_base = 0;
+        }
+        lb_epoch = (lb_epoch + 1) & 0x3FFFFFFFu;
+        if (lb_epoch == 0) lb_epoch = 1;
+        out->status = lb_status.p; out->ticket = lb_ticket.p; out->ticket_base = lb_base; out->epoch = lb_epoch; out->fail = h_lb_fail.p;
+        lb_base += (uint32_t)n_tiles;
+        return out;
+    }
+    // after a synchronisation: a look-back spin that gave up invalidates the stage (never expected)
+    int lookback_ok()
+    {
+        if (!h_lb_fail.p || !h_lb_fail.p[0]) return CRASS_OK;
+        h_lb_fail.p[0] = 0; lb_on = false;
+        last_hip = (int)hipErrorLaunchTimeOut;
+        return CRASS_ERR_HIP;
+    }
     double t_p1_sync = 0;                           // CRASS_MERGE_PROFILE: host time line between pass 1 and the merge
     bool spans_p1 = false, spans_p2 = false, span_survivors = false;     // spans to evaluate at the next counters fetch
     hipError_t stamp(int i, int level) { return timing_level >= level ? hipEventRecord(ev[i], stream) : hipSuccess; }
@@ -401,6 +435,7 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     c->dp.skips = skips;
     { const char *dbg = getenv("CRASS_SURV_DEBUG"); c->dp.debug_stop = dbg ? (uint32_t)atoi(dbg) : 0; }
     if (const char *tl = getenv("CRASS_STAGE_TIMING")) c->timing_level = std::min(2, std::max(0, atoi(tl)));
+    if (getenv("CRASS_NO_LOOKBACK")) c->lb_on = false;           // A/B switch: three-kernel compaction
     c->dr_stride = (p->highDRsize + 15u) & ~15u;
     if (hipSetDevice(device) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
@@ -429,6 +464,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->worker.stop();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    c->lb_status.release(); c->lb_ticket.release(); c->h_lb_fail.release();
     c->dm.release(); c->h_qblob.release(); c->xchg.send.release(); c->xchg.xinfo.release(); c->xchg.h_xinfo.release();
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
@@ -770,7 +806,9 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     }
     HIPCHK(c, launch_found_mask(c->d_surv.p, d_nsurv, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream,
                                 dedupe ? c->dd_keys.p : nullptr, dedupe ? c->dd_first.p : nullptr, tsize));
-    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n_surv, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, n_surv, c->d_count.p + 2, c->stream));
+    Lookback lbf;
+    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n_surv, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, n_surv, c->d_count.p + 2, c->stream,
+                             nullptr, 0, nullptr, 0, c->next_lookback(n_words, &lbf)));
     HIPCHK(c, launch_gather_found(c->d_fidx.p, c->d_count.p + 2, n_surv, c->d_surv.p, c->d_idx.p, c->read_base, c->d_dr.p, stride,
                                   c->d_ss_pool.p, lds.ss_cap, D.d_read.p, D.d_low.p, D.d_replen.p, D.d_nss.p, D.d_ss_off.p,
                                   D.d_dr_len.p, D.d_dr.p, D.d_ss.p, c->stream));
@@ -787,10 +825,12 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_keys.p, c->dd_first.p, tsize,
                                    c->dd_hash.p, c->dd_slot.p, c->dd_rep.p, c->stream, true));
         // distinct strings in first-occurrence order and every candidate's rank among them, exact
+        Lookback lbd;
         HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->dd_slot.p, c->dd_first.p, c->d_mask.p,
                                    c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
                                    c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream,
-                                   c->d_count.p, c->h_count.p, 8));         // (the counters leave with the last kernel: no copy call)
+                                   c->d_count.p, c->h_count.p, 8,           // (the counters leave with the last kernel: no copy call)
+                                   c->next_lookback((n_surv + 63) / 64, &lbd)));
         if (c->xchg.active)                             // multi-rank: the list goes straight into the collective's send buffer
             HIPCHK(c, launch_xg_fill(c->dd_dx_chars.p, c->dd_dx_len.p, c->d_count.p + 4, stride, c->xchg.cap, c->xchg.slot, c->xchg.send.p, c->stream));
     }
@@ -884,8 +924,9 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     HIPCHK(c, c->stamp(1, 1));
     // step 2: ordered compaction
     // (the scan kernel also clears the survivor stage's counters: d_count[2..6) and the start/stop pool cursor)
+    Lookback lbs;
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream,
-                             c->d_count.p + 2, 4, c->d_ss_used.p, 1));
+                             c->d_count.p + 2, 4, c->d_ss_used.p, 1, c->next_lookback(n_words, &lbs)));
     HIPCHK(c, c->stamp(2, 2));
     c->dense.active = false;
     c->have_rep = false;
@@ -1011,7 +1052,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     // (the event spans are evaluated when the counters are fetched: each query costs microseconds of host time
     // between two stages)
     c->spans_p1 = true; c->span_survivors = n_surv != 0;
-    return CRASS_OK;
+    return c->lookback_ok();
 }
 
 int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
@@ -1647,7 +1688,9 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         HIPCHK(c, launch_recruit_exceptions(c->R, c->A, c->d_found.p, c->d_exc_hit.p, c->stream));
     }
     HIPCHK(c, c->stamp(6, 1));
-    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream));
+    Lookback lbr;
+    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream,
+                             nullptr, 0, nullptr, 0, c->next_lookback(n_words, &lbr)));
     // Speculative tail (device merge path): verification, finish and the hand-off pack are launched with the hit
     // count still on the device, sized by a bound learnt from the previous call; the exact count arrives with the
     // final synchronisation, and a bound that was too small repeats the tail with the exact count.
@@ -1696,10 +1739,11 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         c->q_wide_ready = false;
         HIPCHK(c, c->h_qblob.ensure(p2_blob_layout(h_alloc).total + 64));
         HIPCHK(c, c->d_fidx.ensure(h_alloc + 1));
+        Lookback lbq;
         if (n_hits) {
             HIPCHK(c, launch_pack_p2_blob(c->d_rec.p, c->d_idx.p, c->read_base, c->d_count.p, n_hits, c->d_mask.p,
                                           c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 6, c->h_qblob.p, c->stream,
-                                          spec ? c->h_count.p : nullptr));
+                                          spec ? c->h_count.p : nullptr, c->next_lookback((n_hits + 63) / 64, &lbq)));
         } else memset(c->h_qblob.p, 0, 16);
         const double th0 = now_ms();
         const int hs = ensure_host_merge(c);            // host view of the merge, rebuilt while the device verifies
@@ -1735,7 +1779,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         c->cnt.anchor_keys = c->dm.h_st.p->n_keys;
         c->cnt.anchor_table_kind = c->dm.h_st.p->tab_mode == 3 ? 1 : c->dm.h_st.p->tab_mode;
         c->spans_p2 = true;
-        return CRASS_OK;
+        return c->lookback_ok();
     }
     if (n_slots) {
         HIPCHK(c, hipMemcpyAsync(c->h_rec.p, c->d_rec.p, n_slots * sizeof(RecruitOut), hipMemcpyDeviceToHost, c->stream));
@@ -1797,7 +1841,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     c->cnt.anchor_keys = !anchors ? 0 : (dmp ? c->dm.h_st.p->n_keys : c->K.n_keys);
     c->cnt.anchor_table_kind = !anchors ? 0 : (dmp ? (c->dm.h_st.p->tab_mode == 3 ? 1u : c->dm.h_st.p->tab_mode) : (c->K.log_size > 15 ? 2 : c->K.mode));
     c->spans_p2 = true;
-    return CRASS_OK;
+    return c->lookback_ok();
 }
 
 int crass_hip_get_recruits(const crass_hip_ctx *c, crass_recruits *o)

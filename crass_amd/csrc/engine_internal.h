@@ -188,11 +188,25 @@ hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t
 hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, uint64_t n_words, uint64_t *hint_bits,
                                  hipStream_t st);
 hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st);
+// Single-pass ordered compaction (decoupled look-back): per-tile status words, a ticket counter that hands out
+// tile ids in start order (a tile only ever waits for tiles that started before it) and an epoch tag so that
+// neither needs clearing between launches.  Built by crass_hip_ctx::next_lookback().
+struct Lookback {
+    unsigned long long *status;   // [>= tiles] (epoch << 34) | (flag << 32) | value; flag 1 = tile total, 2 = inclusive prefix
+    uint32_t *ticket;             // monotonically increasing; tile id = ticket - ticket_base
+    uint32_t ticket_base;
+    uint32_t epoch;               // 30 bits, never 0
+    uint32_t *fail;               // pinned host word, set when a spin gives up (never expected; reported as an error)
+};
+// mask words per tile (one per thread): fat tiles for the masks over all reads, small ones for the short masks
+static inline uint32_t lookback_tile_words(uint64_t n_words) { return n_words >= 16384 ? 1024u : 256u; }
+
 // mask (n_words 64-bit words) -> ascending index list; *d_count receives the number of set bits.
 // scratch: word_prefix[n_words] u32, block_sums[(n_words+255)/256 + 1] u32
 hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
                           uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count,
-                          hipStream_t st, uint32_t *zero_a = nullptr, uint32_t n_a = 0, uint32_t *zero_b = nullptr, uint32_t n_b = 0);
+                          hipStream_t st, uint32_t *zero_a = nullptr, uint32_t n_a = 0, uint32_t *zero_b = nullptr, uint32_t n_b = 0,
+                          const Lookback *lb = nullptr);     // lb: one kernel instead of three
 // (zero_a/zero_b: up to 1024 words each that the scan kernel clears on the way)
 hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exceptions,
                            const uint64_t *surv_idx, const uint32_t *d_n_surv, uint64_t n_surv_max,
@@ -262,13 +276,15 @@ __host__ __device__ inline P2Blob p2_blob_layout(uint64_t cap)
 hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base,
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
                                uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st,
-                               uint32_t *h_n_hits = nullptr);        // pinned word that receives *d_n_hits
+                               uint32_t *h_n_hits = nullptr,         // pinned word that receives *d_n_hits
+                               const Lookback *lb = nullptr);
 hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, uint32_t *rep,
                             const uint32_t *slot_of, const uint32_t *first,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
                             char *dev_chars, uint16_t *dev_len, hipStream_t st,
-                            const uint32_t *cnt_src = nullptr, uint32_t *cnt_dst = nullptr, uint32_t n_cnt = 0);   // counters -> pinned host words
+                            const uint32_t *cnt_src = nullptr, uint32_t *cnt_dst = nullptr, uint32_t n_cnt = 0,    // counters -> pinned host words
+                            const Lookback *lb = nullptr);
 hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n, unsigned long long *keys,
                             uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st,
                             bool table_cleared = false);

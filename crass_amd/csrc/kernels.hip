@@ -375,10 +375,134 @@ __global__ __launch_bounds__(256) void k_mask_scatter(const uint64_t *mask, uint
     }
 }
 
+// ---- single-pass form: decoupled look-back over tiles of 1024 mask words ----
+static __device__ __forceinline__ unsigned long long lb_pack(uint32_t epoch, uint32_t flag, uint32_t value)
+{
+    return ((unsigned long long)epoch << 34) | ((unsigned long long)flag << 32) | value;
+}
+// Exclusive prefix of this tile's total over the tiles before it.  Called by every thread of the block
+// (one __syncthreads inside); wave 0 does the look-back, 64 predecessor tiles per step.
+static __device__ uint32_t lb_exclusive_prefix(const Lookback &lb, uint32_t tile, uint32_t total)
+{
+    __shared__ uint32_t excl_sh;
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(&lb.status[tile], lb_pack(lb.epoch, tile == 0 ? 2u : 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        int t = (int)tile - 1;                           // wave-uniform: this step looks at tiles t, t-1, ..., t-63
+        while (t >= 0) {
+            const int idx = t - lane;
+            uint32_t flag = 2u, val = 0u;                // tiles before tile 0: an empty prefix
+            if (idx >= 0) {
+                flag = 0u;
+                for (uint32_t spins = 0; spins < (1u << 24); spins++) {
+                    const unsigned long long w = __hip_atomic_load(&lb.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(w >> 34) == lb.epoch && ((w >> 32) & 3ull) != 0ull) { flag = (uint32_t)(w >> 32) & 3u; val = (uint32_t)w; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (flag == 0u) { *lb.fail = 1u; flag = 2u; }               // gave up (pinned host word): terminate, the host reports it
+            }
+            const unsigned long long pm = __ballot(flag == 2u);
+            const int stop = pm ? __ffsll(pm) - 1 : 64;  // nearest tile whose inclusive prefix is known
+            uint32_t v = lane <= stop ? val : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+            excl += v;
+            if (pm) break;
+            t -= 64;
+        }
+        if (lane == 0) {
+            if (tile != 0) __hip_atomic_store(&lb.status[tile], lb_pack(lb.epoch, 2u, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            excl_sh = excl;
+        }
+    }
+    __syncthreads();
+    return excl_sh;
+}
+static __device__ uint32_t lb_tile_id(const Lookback &lb)
+{
+    __shared__ uint32_t tile_sh;
+    if (threadIdx.x == 0) tile_sh = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
+    __syncthreads();
+    return tile_sh;
+}
+// exclusive prefix of v over the T threads of the block; *total = block sum
+template <int T>
+static __device__ uint32_t block_scan_t(uint32_t v, uint32_t *total)
+{
+    __shared__ uint32_t wsum[T / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < T / 64; k++) { const uint32_t s = wsum[k]; if (k < wv) base += s; all += s; }
+    *total = all;
+    return base + incl - v;
+}
+
+// T mask words per tile, one per thread: 1024 for the masks over all reads (few, fat tiles), 256 for the short dense
+// masks of the later stages (more blocks for the per-word scatter loops)
+template <int T>
+__global__ __launch_bounds__(T) void k_mask_compact_lb(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
+                                                        uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count,
+                                                        uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b, Lookback lb,
+                                                        uint32_t n_tiles)
+{
+    const uint32_t tile = lb_tile_id(lb);
+    if (tile == 0) {                                    // counters the NEXT stage accumulates into
+        if (threadIdx.x < n_a) zero_a[threadIdx.x] = 0u;
+        if (threadIdx.x < n_b) zero_b[threadIdx.x] = 0u;
+    }
+    const uint64_t wi = (uint64_t)tile * T + threadIdx.x;
+    uint64_t m = 0;
+    if (wi < n_words) {
+        m = mask[wi];
+        const uint64_t rem = n_bits - wi * 64;
+        if (rem < 64) m &= (1ull << rem) - 1ull;
+    }
+    uint32_t total;
+    const uint32_t in_tile = block_scan_t<T>((uint32_t)__popcll(m), &total);
+    const uint32_t excl = lb_exclusive_prefix(lb, tile, total);
+    if (tile == n_tiles - 1 && threadIdx.x == 0) *d_count = excl + total;
+    if (wi < n_words) {
+        uint64_t o = (uint64_t)excl + in_tile;
+        if (word_prefix) {                              // same meaning as the three-kernel form: block_sums[w >> 8] + word_prefix[w]
+            word_prefix[wi] = (uint32_t)o;
+            if ((wi & 255u) == 0) block_sums[wi >> 8] = 0u;
+        }
+        while (m) {
+            const int b = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            if (o < out_cap) out_idx[o] = wi * 64 + b;
+            o++;
+        }
+    }
+}
+
 hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
                           uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count, hipStream_t st,
-                          uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b)
+                          uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b, const Lookback *lb)
 {
+    if (lb && n_words) {
+        // (the caller reserved ceil(n_words / lookback_tile_words(n_words)) tickets)
+        const uint32_t tw = lookback_tile_words(n_words);
+        const uint32_t n_tiles = (uint32_t)((n_words + tw - 1) / tw);
+        if (tw == 256)
+            hipLaunchKernelGGL(k_mask_compact_lb<256>, dim3(n_tiles), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
+                               d_count, zero_a, n_a, zero_b, n_b, *lb, n_tiles);
+        else
+            hipLaunchKernelGGL(k_mask_compact_lb<1024>, dim3(n_tiles), dim3(1024), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
+                               d_count, zero_a, n_a, zero_b, n_b, *lb, n_tiles);
+        return hipGetLastError();
+    }
     if (n_words == 0) {
         if (n_a) (void)hipMemsetAsync(zero_a, 0, 4 * (size_t)n_a, st);
         if (n_b) (void)hipMemsetAsync(zero_b, 0, 4 * (size_t)n_b, st);
@@ -1739,12 +1863,13 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
                             const uint32_t *slot_of, const uint32_t *first,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
-                            char *dev_chars, uint16_t *dev_len, hipStream_t st, const uint32_t *cnt_src, uint32_t *cnt_dst, uint32_t n_cnt)
+                            char *dev_chars, uint16_t *dev_len, hipStream_t st, const uint32_t *cnt_src, uint32_t *cnt_dst, uint32_t n_cnt,
+                            const Lookback *lb)
 {
     if (n == 0) return hipSuccess;
     const unsigned nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, mask, d_mismatch);
-    hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st);
+    hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st, nullptr, 0, nullptr, 0, lb);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap);
     hipLaunchKernelGGL(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len,
@@ -2345,12 +2470,12 @@ __global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, con
 }
 hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base,
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
-                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st, uint32_t *h_n_hits)
+                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st, uint32_t *h_n_hits, const Lookback *lb)
 {
     if (n_hits_max == 0) return hipSuccess;
     const unsigned nb = (unsigned)((n_hits_max + 255) / 256);
     hipLaunchKernelGGL(k_recruit_valid_mask, dim3(nb), dim3(256), 0, st, rec, d_n_hits, n_hits_max, mask);
-    hipError_t e = launch_compact(mask, (n_hits_max + 63) / 64, n_hits_max, word_prefix, block_sums, vidx, n_hits_max, d_nv, st);
+    hipError_t e = launch_compact(mask, (n_hits_max + 63) / 64, n_hits_max, word_prefix, block_sums, vidx, n_hits_max, d_nv, st, nullptr, 0, nullptr, 0, lb);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
     return hipGetLastError();
