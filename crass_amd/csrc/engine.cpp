@@ -299,9 +299,14 @@ struct crass_hip_ctx {
     // nullptr: use the three-kernel form (switched off, or allocation failed)
     const Lookback *next_lookback(uint64_t n_words, Lookback *out)
     {
-        if (!lb_on || n_words == 0) return nullptr;
         const uint32_t tw = lookback_tile_words(n_words);
-        const uint64_t n_tiles = (n_words + tw - 1) / tw;
+        return next_lookback_tiles((n_words + tw - 1) / tw, out);
+    }
+    // element-wise kernels (k_found_compact, k_dx_flag_rank, k_valid_compact): tiles of 4096 elements
+    const Lookback *next_lookback_elems(uint64_t n, Lookback *out) { return next_lookback_tiles((n + 4095) / 4096, out); }
+    const Lookback *next_lookback_tiles(uint64_t n_tiles, Lookback *out)
+    {
+        if (!lb_on || n_tiles == 0) return nullptr;
         if (n_tiles > (1u << 24)) return nullptr;
         if (!lb_status.p || lb_status.n < n_tiles) {
             if (lb_status.ensure(std::max<uint64_t>(n_tiles * 2, 4096)) != hipSuccess) return nullptr;
@@ -804,11 +809,16 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         while (tsize_alloc < n_alloc * 2) tsize_alloc <<= 1;
         HIPCHK(c, c->dd_keys.ensure(tsize_alloc)); HIPCHK(c, c->dd_first.ensure(tsize_alloc));
     }
-    HIPCHK(c, launch_found_mask(c->d_surv.p, d_nsurv, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream,
-                                dedupe ? c->dd_keys.p : nullptr, dedupe ? c->dd_first.p : nullptr, tsize));
     Lookback lbf;
-    HIPCHK(c, launch_compact(c->d_mask.p, n_words, n_surv, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, n_surv, c->d_count.p + 2, c->stream,
-                             nullptr, 0, nullptr, 0, c->next_lookback(n_words, &lbf)));
+    if (const Lookback *lb = c->next_lookback_elems(n_surv, &lbf)) {
+        // found flags -> ranks in one pass (also clears the de-duplication table)
+        HIPCHK(c, launch_found_compact(c->d_surv.p, d_nsurv, n_surv, c->d_count.p + 3, dedupe ? c->dd_keys.p : nullptr,
+                                       dedupe ? c->dd_first.p : nullptr, tsize, c->d_fidx.p, c->d_count.p + 2, *lb, c->stream));
+    } else {
+        HIPCHK(c, launch_found_mask(c->d_surv.p, d_nsurv, n_surv, c->d_mask.p, c->d_count.p + 3, c->stream,
+                                    dedupe ? c->dd_keys.p : nullptr, dedupe ? c->dd_first.p : nullptr, tsize));
+        HIPCHK(c, launch_compact(c->d_mask.p, n_words, n_surv, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, n_surv, c->d_count.p + 2, c->stream));
+    }
     HIPCHK(c, launch_gather_found(c->d_fidx.p, c->d_count.p + 2, n_surv, c->d_surv.p, c->d_idx.p, c->read_base, c->d_dr.p, stride,
                                   c->d_ss_pool.p, lds.ss_cap, D.d_read.p, D.d_low.p, D.d_replen.p, D.d_nss.p, D.d_ss_off.p,
                                   D.d_dr_len.p, D.d_dr.p, D.d_ss.p, c->stream));
@@ -1743,7 +1753,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         if (n_hits) {
             HIPCHK(c, launch_pack_p2_blob(c->d_rec.p, c->d_idx.p, c->read_base, c->d_count.p, n_hits, c->d_mask.p,
                                           c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 6, c->h_qblob.p, c->stream,
-                                          spec ? c->h_count.p : nullptr, c->next_lookback((n_hits + 63) / 64, &lbq)));
+                                          spec ? c->h_count.p : nullptr, c->next_lookback_elems(n_hits, &lbq)));
         } else memset(c->h_qblob.p, 0, 16);
         const double th0 = now_ms();
         const int hs = ensure_host_merge(c);            // host view of the merge, rebuilt while the device verifies

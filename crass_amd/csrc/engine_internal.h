@@ -237,6 +237,9 @@ hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off,
                                     int32_t *dist, float *sim, uint32_t max_len, hipStream_t st);
 hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st);
 
+// k_found_mask + compaction as one decoupled-look-back kernel (tiles of 256 survivor slots); fidx[rank] = slot
+hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_t n_max, uint32_t *d_err, unsigned long long *dd_keys,
+                                uint32_t *dd_first, uint32_t dd_size, uint64_t *fidx, uint32_t *d_nf, const Lookback &lb, hipStream_t st);
 hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st,
                              unsigned long long *dd_keys = nullptr, uint32_t *dd_first = nullptr, uint32_t dd_size = 0);   // also clears that table
 hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out,

@@ -487,6 +487,19 @@ __global__ __launch_bounds__(T) void k_mask_compact_lb(const uint64_t *mask, uin
     }
 }
 
+// element-wise form: tiles of 4096 elements, 1024 threads x 4 consecutive elements (few, fat tiles keep the look-back
+// to one or two steps).  cnt = flagged elements of this thread; returns the rank of the thread's first flagged element
+// among all flagged elements before it; *upto = flagged elements up to and including this tile.
+static constexpr uint32_t kLbElemsPerTile = 4096;
+static __device__ uint32_t lb_rank4(const Lookback &lb, uint32_t tile, uint32_t cnt, uint32_t *upto)
+{
+    uint32_t all;
+    const uint32_t in_tile = block_scan_t<1024>(cnt, &all);
+    const uint32_t excl = lb_exclusive_prefix(lb, tile, all);
+    *upto = excl + all;
+    return excl + in_tile;
+}
+
 hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
                           uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count, hipStream_t st,
                           uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b, const Lookback *lb)
@@ -1661,6 +1674,44 @@ __global__ __launch_bounds__(256) void k_gather_found(const uint64_t *fidx, cons
     for (uint32_t i = 0; i < ss_cap; i++) pd[i] = (i < o.n_ss) ? ps[i] : 0u;
 }
 
+// k_found_mask + compaction in one pass (decoupled look-back): survivor slot s -> rank among the found records ->
+// fidx[rank] = s.  Also clears the de-duplication table of the next stage.  (The gather itself stays a dense kernel:
+// with one found record in six slots a fused body would run at a sixth of the lanes.)
+__global__ __launch_bounds__(1024) void k_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_t n_max, uint32_t *d_err,
+                                                         unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size,
+                                                         uint64_t *fidx, uint32_t *d_nf, Lookback lb, uint32_t n_tiles)
+{
+    const uint32_t tile = lb_tile_id(lb);
+    const uint64_t s0 = (uint64_t)tile * kLbElemsPerTile + 4u * threadIdx.x;
+    for (uint64_t i = (uint64_t)tile * 1024u + threadIdx.x; i < dd_size; i += (uint64_t)n_tiles * 1024u) { dd_keys[i] = 0ull; dd_first[i] = 0xFFFFFFFFu; }
+    uint64_t n = *d_n;                                   // slots past the device-side count were never written
+    if (n > n_max) n = n_max;
+    uint32_t fm = 0, err = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (s0 + e < n) {
+            const SurvOut o = out[s0 + e];
+            if (o.found) fm |= 1u << e;
+            err = max(err, (uint32_t)o.err);
+        }
+    }
+    if (err) atomicMax(d_err, err);
+    uint32_t upto;
+    uint64_t k = lb_rank4(lb, tile, (uint32_t)__popc(fm), &upto);
+    if (tile == n_tiles - 1 && threadIdx.x == 0) *d_nf = upto;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (fm & (1u << e)) fidx[k++] = s0 + e;
+}
+hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_t n_max, uint32_t *d_err, unsigned long long *dd_keys,
+                                uint32_t *dd_first, uint32_t dd_size, uint64_t *fidx, uint32_t *d_nf, const Lookback &lb, hipStream_t st)
+{
+    if (n_max == 0) return hipSuccess;
+    const uint32_t n_tiles = (uint32_t)((n_max + kLbElemsPerTile - 1) / kLbElemsPerTile);
+    hipLaunchKernelGGL(k_found_compact, dim3(n_tiles), dim3(1024), 0, st, out, d_n, n_max, d_err, dd_keys, dd_first, dd_keys ? dd_size : 0u,
+                       fidx, d_nf, lb, n_tiles);
+    return hipGetLastError();
+}
+
 // found records -> compact blob (p1_blob_layout) in pinned host memory: the kernel IS the device-to-host copy
 __global__ __launch_bounds__(256) void k_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t ss_cap, const uint64_t *g_read,
                                                        const uint32_t *g_replen, const uint32_t *g_nss, const uint8_t *g_low,
@@ -1856,6 +1907,34 @@ __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const
     out_hash[j] = hash[k];
 }
 
+// dense: every candidate's rank (dmap) and, for the first nd threads, the distinct string's slot
+__global__ __launch_bounds__(256) void k_dx_assign_gather(const uint32_t *rep, const uint32_t *d_n, uint32_t n_max, const uint64_t *mask,
+                                                           const uint32_t *word_prefix, const uint32_t *block_sums,
+                                                           uint32_t *dmap, const uint64_t *dx_idx, const uint32_t *d_nd, const char *dr,
+                                                           const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, char *out_chars,
+                                                           uint16_t *out_len, uint64_t *out_hash, char *dev_chars, uint16_t *dev_len,
+                                                           const uint32_t *cnt_src, uint32_t *cnt_dst, uint32_t n_cnt)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_cnt) cnt_dst[j] = cnt_src[j];             // the stage's counters, straight into pinned host memory
+    if (j < min(*d_n, n_max)) {
+        const uint32_t f = rep[j], w = f >> 6;
+        dmap[j] = block_sums[w >> 8] + word_prefix[w] + (uint32_t)__popcll(mask[w] & ((1ull << (f & 63)) - 1ull));
+    }
+    uint32_t nd = *d_nd;
+    if (nd > n_max) nd = n_max;
+    if (j >= nd) return;
+    const uint64_t k = dx_idx[j];
+    const uint4 *src = reinterpret_cast<const uint4 *>(dr + k * stride);
+    uint4 *dst = reinterpret_cast<uint4 *>(out_chars + (uint64_t)j * stride);
+    uint4 *dst2 = reinterpret_cast<uint4 *>(dev_chars + (uint64_t)j * stride);      // device copy for the device merge
+    for (uint32_t i = 0; i < stride / 16; i++) { const uint4 v = src[i]; dst[i] = v; if (dev_chars) dst2[i] = v; }
+    const uint16_t l = dr_len[k];
+    out_len[j] = l;
+    if (dev_len) dev_len[j] = l;
+    out_hash[j] = hash[k];
+}
+
 // needs stride % 16 == 0; mask / word_prefix / block_sums / dx_idx are scratch of >= n bits / words.  The candidate
 // count is *d_n (<= n).  dmap / out_* may be pinned host memory: the kernels then write the merge's inputs
 // straight into it (a few hundred KB; no copy calls on the critical path).
@@ -1868,8 +1947,16 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
 {
     if (n == 0) return hipSuccess;
     const unsigned nb = (n + 255) / 256;
+    if (lb) {           // three launches: flags, single-pass compaction, dense assign + gather
+        hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, mask, d_mismatch);
+        hipError_t e2 = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st, nullptr, 0, nullptr, 0, lb);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(k_dx_assign_gather, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap, dx_idx, d_nd, dr, dr_len,
+                           hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len, cnt_src, cnt_dst, cnt_dst ? n_cnt : 0u);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, mask, d_mismatch);
-    hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st, nullptr, 0, nullptr, 0, lb);
+    hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap);
     hipLaunchKernelGGL(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len,
@@ -2468,14 +2555,38 @@ __global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, con
     (blob + b.dr_len)[q] = (uint8_t)o.dr_len;
     (blob + b.low)[q] = o.low_lexi;
 }
+// k_recruit_valid_mask + compaction in one pass (decoupled look-back): vidx[rank] = slot of the rank-th valid hit
+__global__ __launch_bounds__(1024) void k_valid_compact(const RecruitOut *rec, const uint32_t *d_n_hits, uint64_t cap, uint64_t *vidx, uint32_t *d_nv,
+                                                         Lookback lb, uint32_t n_tiles)
+{
+    const uint32_t tile = lb_tile_id(lb);
+    const uint64_t k0 = (uint64_t)tile * kLbElemsPerTile + 4u * threadIdx.x;
+    uint64_t n = *d_n_hits;
+    if (n > cap) n = cap;
+    uint32_t fm = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (k0 + e < n && rec[k0 + e].dr_len != 0) fm |= 1u << e;
+    uint32_t upto;
+    uint64_t q = lb_rank4(lb, tile, (uint32_t)__popc(fm), &upto);
+    if (tile == n_tiles - 1 && threadIdx.x == 0) *d_nv = upto;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (fm & (1u << e)) vidx[q++] = k0 + e;
+}
+
 hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base,
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
                                uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st, uint32_t *h_n_hits, const Lookback *lb)
 {
     if (n_hits_max == 0) return hipSuccess;
     const unsigned nb = (unsigned)((n_hits_max + 255) / 256);
+    if (lb) {           // (the caller reserved nb tiles)
+        const unsigned nt = (unsigned)((n_hits_max + kLbElemsPerTile - 1) / kLbElemsPerTile);
+        hipLaunchKernelGGL(k_valid_compact, dim3(nt), dim3(1024), 0, st, rec, d_n_hits, n_hits_max, vidx, d_nv, *lb, nt);
+        hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_recruit_valid_mask, dim3(nb), dim3(256), 0, st, rec, d_n_hits, n_hits_max, mask);
-    hipError_t e = launch_compact(mask, (n_hits_max + 63) / 64, n_hits_max, word_prefix, block_sums, vidx, n_hits_max, d_nv, st, nullptr, 0, nullptr, 0, lb);
+    hipError_t e = launch_compact(mask, (n_hits_max + 63) / 64, n_hits_max, word_prefix, block_sums, vidx, n_hits_max, d_nv, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
     return hipGetLastError();

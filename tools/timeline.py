@@ -26,9 +26,11 @@ def main():
     ev = ev[first:(starts[-back] if back else len(ev))]
     t0 = ev[0][0]
     prev_end = t0
+    done = False
     for s, e, n in ev:
-        if back and s - prev_end > 80_000:             # the next step's prologue (after the host fetched the results)
+        if back and done:                               # the next step's prologue (after the host fetched the results)
             break
+        done = "k_pack_p2_blob" in n
         print("%9.1f us  +%8.1f gap  %8.1f us  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, n))
         prev_end = max(prev_end, e)
     print("total span %.1f us" % ((prev_end - t0) / 1e3))
