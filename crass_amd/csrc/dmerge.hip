@@ -454,13 +454,6 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
         }
     }
 }
-// the same flag by position in members[] (k_dm_patterns walks member ranges)
-__global__ __launch_bounds__(256) void k_dm_sblank(DevMerge M)
-{
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < M.n_tok) M.sblank[s] = M.blank[M.members[s]];
-}
-
 // ---- 5. pattern list: per group (ascending GID) the survivors, then their reverse complements
 // (WorkHorse.cpp:690-697).  Inside a group the survivors are ordered by (length, token) — one of the
 // orders an unstable sort by length may produce; pass 2 depends on the SET only.
@@ -477,7 +470,7 @@ __global__ __launch_bounds__(256) void k_dm_patterns(DevMerge M)
         g = M.gid_of[j] - 1;
         lo = M.grp_off[g]; hi = lo + M.grp_cnt[g];
         lenj = M.dx_len[j];
-        mine = M.sblank[s] == 0;
+        mine = M.blank[j] == 0;
     }
     if (threadIdx.x == 0) r_lo = lo;
     const uint32_t s_last = min(M.n_tok, s0 + 256u) - 1u;
@@ -490,7 +483,7 @@ __global__ __launch_bounds__(256) void k_dm_patterns(DevMerge M)
         const uint32_t idx = base + threadIdx.x;
         if (idx < rhi) {
             const uint32_t i = M.members[idx];
-            t_key[threadIdx.x] = M.sblank[idx] ? 0xFFFFFFFFu : ((uint32_t)M.dx_len[i] << 24) | i;
+            t_key[threadIdx.x] = M.blank[i] ? 0xFFFFFFFFu : ((uint32_t)M.dx_len[i] << 24) | i;
         }
         __syncthreads();
         if (mine) {
@@ -618,14 +611,6 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_insert(DevMerge M)
     }
     atomicOr(&M.st->fail, 4u);
 }
-// unused slots hold a member key, so a probe never matches by accident
-__global__ __launch_bounds__(256) void k_dm_cuckoo_finalize(DevMerge M)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ls = M.st->log_size;
-    if (!ls || i >= (1u << ls) || M.st->all_t) return;
-    if (M.anchor_tab[i] == 0xFFFFFFFFu) M.anchor_tab[i] = M.st->k0;
-}
 // tab_mode 3: fingerprint = low 16 bits of (h1 product ^ h2 product) of the slot's key, two per word
 // ... and, in the same launch, the per-token results + state words go straight into pinned host memory (a few
 // 10 KB over PCIe, no copy calls): the helper thread rebuilds the host view from them
@@ -634,11 +619,16 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_fp(DevMerge M)
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w == 0) *M.h_st = *M.st;
     if (w < M.n_tok) { M.h_gid[w] = M.gid_of[w]; M.h_blank[w] = M.blank[w]; }
+    // unused slots get a member key, so that a probe never matches by accident
+    const uint32_t ls = M.st->log_size, k0 = M.st->k0;
+    const bool fill = ls && !M.st->all_t;
+    if (fill && w < (1u << ls) && M.anchor_tab[w] == 0xFFFFFFFFu) M.anchor_tab[w] = k0;
     if (M.st->tab_mode != 3 || w >= (1u << 15)) return;
     uint32_t out = 0;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const uint32_t v = M.anchor_tab[2 * w + q];
+        uint32_t v = M.anchor_tab[2 * w + q];
+        if (fill && v == 0xFFFFFFFFu) v = k0;           // (the slot's own thread stores the same value)
         const uint32_t p1 = (uint32_t)__umul24(v ^ (v >> M.s1), M.m1), p2 = (uint32_t)__umul24(v ^ (v >> M.s2), M.m2);
         out |= ((p1 ^ p2) & 0xFFFFu) << (16 * q);
     }
@@ -727,7 +717,6 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     unsigned rb = (M.n_tok + 3) / 4;
     if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_sblank, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, &M.st->n_survivors, (const uint32_t *)nullptr);
     hipLaunchKernelGGL(k_dm_patterns, dim3(nb), dim3(256), 0, st, M);
     const unsigned ne = (16u * M.n_tok + 255) / 256;
@@ -735,8 +724,7 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     hipLaunchKernelGGL(k_dm_key_bases, dim3(ne), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_key_fill, dim3(ne), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_cuckoo_insert, dim3(ne), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_cuckoo_finalize, dim3((unsigned)(((1ull << M.tab_log_alloc) + 255) / 256)), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_cuckoo_fp, dim3(std::max(128u, nb)), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_cuckoo_fp, dim3(std::max(std::max(128u, nb), (unsigned)(((1ull << M.tab_log_alloc) + 255) / 256))), dim3(256), 0, st, M);
     return hipGetLastError();
 }
 
