@@ -50,6 +50,14 @@ static __device__ __forceinline__ uint32_t ak_h(uint32_t v, uint32_t s, uint32_t
     return ((uint32_t)__umul24(v ^ (v >> s), m)) >> rsh;      // same hash as anchor_probe (kernels.hip)
 }
 
+// number of tokens: M.n_tok, or — when the merge is launched before the host knows the count (crass_hip_seed_scan
+// queues it right behind pass 1) — the device-side count, of which M.n_tok is then only the bound every buffer
+// and grid was sized for
+static __device__ __forceinline__ uint32_t dm_ntok(const DevMerge &M)
+{
+    return M.d_ntok ? min(*M.d_ntok, M.n_tok) : M.n_tok;
+}
+
 // ---- 0. initialise every word a later kernel polls, counts into or probes ----
 __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
 {
@@ -71,6 +79,7 @@ __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
         DevMergeState s{};
         s.k0 = 0xFFFFFFFFu;
         s.fail = M.inject_fail ? 16u : 0u;
+        if (M.d_ntok && *M.d_ntok > M.n_tok) s.fail |= 64u;           // more tokens than the launch was sized for
         *M.st = s;
     }
 }
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
     __shared__ uint64_t bk_key[kDmBadKmerCap];
     __shared__ uint32_t last_sh;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < M.n_tok) {
+    if (t < dm_ntok(M)) {
         const uint32_t len = M.dx_len[t];
         if (len > 64 || len < 23 || M.stride > 64) atomicOr(&M.st->fail, 1u);
         else {
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t t = wave; t < M.n_tok; t += n_waves) {
+    for (uint32_t t = wave; t < dm_ntok(M); t += n_waves) {
         int nk = (int)M.dx_len[t] - kClusterK + 1;
         if (nk < 0) nk = 0;
         if (nk > 64) nk = 64;
@@ -245,9 +254,10 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
 // exclusive scan of n uint32 (n known on the host), one workgroup; *total = sum
 // roots != nullptr: the scanned value of element i is (roots[i] == i), i.e. "token i founded a group"
 __global__ __launch_bounds__(1024) void k_dm_scan(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n, uint32_t *total,
-                                                   const uint32_t *roots)
+                                                   const uint32_t *roots, const uint32_t *d_exact)
 {
     if (d_n && *d_n + 1u < n) n = *d_n + 1u;            // per-group arrays: only the first n_groups (+1) entries are live
+    if (d_exact && *d_exact < n) n = *d_exact;          // per-token arrays when the count is only known on the device
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_sh;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(1024) void k_dm_gid(DevMerge M)
         for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) cnt[i] = 0;
         __syncthreads();
     }
-    if (t < M.n_tok) {
+    if (t < dm_ntok(M)) {
         const uint32_t g = M.root_rank[M.root_of[t]];
         M.gid_of[t] = g + 1;
         if (lds) atomicAdd(&cnt[g], 1u); else atomicAdd(&M.grp_cnt[g], 1u);
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_dm_scatter(DevMerge M)
         __syncthreads();
     }
     uint32_t g = 0, rank = 0;
-    if (t < M.n_tok) {
+    if (t < dm_ntok(M)) {
         g = M.gid_of[t] - 1;
         rank = lds ? atomicAdd(&cnt[g], 1u) : atomicAdd(&M.grp_fill[g], 1u);
     }
@@ -328,9 +338,9 @@ __global__ __launch_bounds__(1024) void k_dm_scatter(DevMerge M)
         for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint32_t c = cnt[i]; cnt[i] = c ? atomicAdd(&M.grp_fill[i], c) : 0u; }
 
         __syncthreads();
-        if (t < M.n_tok) rank += cnt[g];
+        if (t < dm_ntok(M)) rank += cnt[g];
     }
-    if (t < M.n_tok) M.members[M.grp_off[g] + rank] = t;
+    if (t < dm_ntok(M)) M.members[M.grp_off[g] + rank] = t;
 }
 
 // ---- 4. removeRedundantRepeats: a member is dropped iff a strictly shorter member of its group, or
@@ -348,7 +358,7 @@ static __device__ __forceinline__ uint32_t rset_hash(uint32_t g, uint32_t w, uin
 __global__ __launch_bounds__(256) void k_dm_rd_keys(DevMerge M)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M.n_tok) return;
+    if (t >= dm_ntok(M)) return;
     const uint32_t g = M.gid_of[t], w = (uint32_t)M.packed[(uint64_t)t * 4];
     const unsigned long long want = ((unsigned long long)g << 32) | w;            // g >= 1: never 0
     const uint32_t mask = (1u << M.rset_log) - 1u;
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256) void k_dm_rd_keys(DevMerge M)
 __global__ __launch_bounds__(256) void k_dm_rd_bases(DevMerge M)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M.n_tok) return;
+    if (t >= dm_ntok(M)) return;
     const uint32_t hs = M.rd_slot[t];
     if (!(hs & 0x80000000u)) return;
     const uint32_t h = hs & 0x7FFFFFFFu;
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(256) void k_dm_rd_bases(DevMerge M)
 __global__ __launch_bounds__(256) void k_dm_rd_fill(DevMerge M)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M.n_tok) return;
+    if (t >= dm_ntok(M)) return;
     const uint32_t h = M.rd_slot[t] & 0x7FFFFFFFu;
     const uint32_t pos = M.rset_base[h] + atomicAdd(&M.rset_fill[h], 1u);
     uint64_t *d = M.rents + (uint64_t)pos * 4;
@@ -397,7 +407,7 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t mask = (1u << M.rset_log) - 1u;
-    for (uint32_t j = wave; j < M.n_tok; j += n_waves) {
+    for (uint32_t j = wave; j < dm_ntok(M); j += n_waves) {
         const uint32_t g = M.gid_of[j];
         const uint32_t lenj = M.dx_len[j];
         const uint64_t *pj = M.packed + (uint64_t)j * 4;
@@ -462,7 +472,8 @@ __global__ __launch_bounds__(256) void k_dm_patterns(DevMerge M)
     __shared__ uint32_t t_key[256];                     // (len << 24) | token for survivors, 0xFFFFFFFF for dropped members
     __shared__ uint32_t r_lo, r_hi;
     const uint32_t s0 = blockIdx.x * 256u, s = s0 + threadIdx.x;
-    const bool active = s < M.n_tok;
+    if (s0 >= dm_ntok(M)) return;                       // (the grid may be sized for a bound: whole blocks past the count)
+    const bool active = s < dm_ntok(M);
     uint32_t j = 0, g = 0, lo = 0, hi = 0, lenj = 0;
     bool mine = false;
     if (active) {
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(256) void k_dm_patterns(DevMerge M)
         mine = M.blank[j] == 0;
     }
     if (threadIdx.x == 0) r_lo = lo;
-    const uint32_t s_last = min(M.n_tok, s0 + 256u) - 1u;
+    const uint32_t s_last = min(dm_ntok(M), s0 + 256u) - 1u;
     if (s == s_last) r_hi = hi;
     __syncthreads();
     const uint32_t rlo = r_lo, rhi = r_hi;
@@ -618,7 +629,7 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_fp(DevMerge M)
 {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w == 0) *M.h_st = *M.st;
-    if (w < M.n_tok) { M.h_gid[w] = M.gid_of[w]; M.h_blank[w] = M.blank[w]; }
+    if (w < dm_ntok(M)) { M.h_gid[w] = M.gid_of[w]; M.h_blank[w] = M.blank[w]; }
     // unused slots get a member key, so that a probe never matches by accident
     const uint32_t ls = M.st->log_size, k0 = M.st->k0;
     const bool fill = ls && !M.st->all_t;
@@ -706,10 +717,10 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     if (gb > M.n_cu) gb = M.n_cu;
     hipLaunchKernelGGL(k_dm_greedy, dim3(gb), dim3(1024), 0, st, M);
     hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)nullptr, M.root_rank, M.n_tok, (const uint32_t *)nullptr, &M.st->n_groups,
-                       (const uint32_t *)M.root_of);
+                       (const uint32_t *)M.root_of, M.d_ntok);
     const unsigned nb4 = (M.n_tok + 1023) / 1024;
     hipLaunchKernelGGL(k_dm_gid, dim3(nb4), dim3(1024), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.grp_cnt, M.grp_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, (uint32_t *)nullptr, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.grp_cnt, M.grp_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     hipLaunchKernelGGL(k_dm_scatter, dim3(nb4), dim3(1024), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_keys, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
@@ -717,7 +728,7 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     unsigned rb = (M.n_tok + 3) / 4;
     if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, &M.st->n_survivors, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, &M.st->n_survivors, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     hipLaunchKernelGGL(k_dm_patterns, dim3(nb), dim3(256), 0, st, M);
     const unsigned ne = (16u * M.n_tok + 255) / 256;
     hipLaunchKernelGGL(k_dm_keys, dim3(ne), dim3(256), 0, st, M);

@@ -331,6 +331,10 @@ struct crass_hip_ctx {
         last_hip = (int)hipErrorLaunchTimeOut;
         return CRASS_ERR_HIP;
     }
+    // the device merge queued by the seed scan itself, right behind pass 1 (no host round trip in between): sized by a
+    // bound learnt from the previous merge, adopted by crass_hip_merge when the counts turn out to fit
+    uint32_t dx_cap_hint = 0; bool dm_prev_local = false; int premerge = 0;      // premerge: 0 none, 2 queued and valid
+    bool premerge_inflight = false;                 // merge kernels may still be running when the seed scan returns
     double t_p1_sync = 0;                           // CRASS_MERGE_PROFILE: host time line between pass 1 and the merge
     bool spans_p1 = false, spans_p2 = false, span_survivors = false;     // spans to evaluate at the next counters fetch
     hipError_t stamp(int i, int level) { return timing_level >= level ? hipEventRecord(ev[i], stream) : hipSuccess; }
@@ -758,6 +762,8 @@ static uint64_t survivor_bound(uint64_t n_surv)        // the speculative bound 
 // n_surv: number of filter survivors, or (speculative mode: d_nsurv = the compaction's device-side count, no host
 // round trip before this call) an upper bound for it.  The exact count then arrives with the final copy of
 // the counters; *overflow is set when it exceeds the bound (nothing of this call is valid then).
+static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok);
+
 static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t *d_nsurv, bool *overflow)
 {
     *overflow = false;
@@ -845,6 +851,8 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
             HIPCHK(c, launch_xg_fill(c->dd_dx_chars.p, c->dd_dx_len.p, c->d_count.p + 4, stride, c->xchg.cap, c->xchg.slot, c->xchg.send.p, c->stream));
     }
     if (!dedupe) HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 32, hipMemcpyDeviceToHost, c->stream));
+    bool premerge_queued = false;
+    c->premerge = 0;
     {
         // the per-candidate records go to pinned host memory on the copy stream (the pack kernel writes them there
         // itself), behind the gather: they are not needed before the hand-off
@@ -856,8 +864,20 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         D.pack_cap = n_surv; D.pack_ss_cap = lds.ss_cap;
         c->bulk_needed = true;                          // launched by issue_bulk(): next to the pass-2 filter, where it is free
     }
+    // The merge itself is queued here too when the previous call's merge ran on the device: its kernels read the token
+    // count from the device (d_count[4]) and are sized by a bound; crass_hip_merge adopts the result if the counts fit.
+    if (speculative && dedupe && !c->xchg.active && c->dm_prev_local && c->dx_cap_hint && c->prm.lowDRsize >= 23 && stride <= 64 &&
+        !getenv("CRASS_HOST_MERGE") && !getenv("CRASS_NO_SPECULATION")) {
+        const int ps = device_merge_enqueue(c, c->dd_dx_chars.p, c->dd_dx_len.p, c->dx_cap_hint, c->d_count.p + 4);
+        if (ps) return ps;
+        premerge_queued = true;
+    }
     host_pool_warm();                                   // the merge follows: wake the host workers while the device finishes
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (with the merge queued behind it, the host waits for pass 1 only — the event recorded above — and goes on to
+    // adopt the merge and queue pass 2 while the merge kernels run)
+    if (premerge_queued) HIPCHK(c, hipEventSynchronize(c->ev_gathered));
+    else HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->premerge_inflight = premerge_queued;
     c->t_p1_sync = now_ms();
     if (c->h_count.p[0] > n_surv) { *overflow = true; return CRASS_OK; }
     const uint64_t nf = c->h_count.p[2];
@@ -877,6 +897,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
             if (c->h_count.p[5] == 0) {
                 c->n_dx = c->h_count.p[4];
                 c->have_dev_tokens = true;
+                if (premerge_queued && c->n_dx > 0 && c->n_dx <= c->dx_cap_hint) c->premerge = 2;
             } else {
                 // (hash collision among the candidates: the host merge wants the first-occurrence map)
                 HIPCHK(c, D.h_dr_fb.ensure(nf * stride + 16)); HIPCHK(c, D.h_dr_len_fb.ensure(nf + 8));
@@ -904,6 +925,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     quiesce_worker(c);
     c->have_pass1 = c->have_merge = c->have_pass2 = false;
     c->dm.active = false;
+    c->premerge_inflight = false;
     const uint64_t n = c->R.n_reads;
     const uint64_t n_words = (n + 63) / 64;
     HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
@@ -1034,7 +1056,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         }
     }
     HIPCHK(c, c->stamp(4, 2));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!(c->premerge_inflight && c->dense.active)) HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t total = (size_t)c->n_cand();
     c->have_pass1 = true;
     if (c->xchg.active && !(c->dense.active && c->have_dev_tokens)) {
@@ -1179,18 +1201,18 @@ static bool device_merge_applies(const crass_hip_ctx *c)
 }
 
 // dx_*: distinct strings in token order on the device; hx_*: the same list in pinned host memory
-static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const char *hx_chars,
-                        const uint16_t *hx_len)
+// the kernels only (n_tok: the token count, or — with d_ntok — the bound the launch is sized for while the count is
+// still on the device); the context's state is untouched until device_merge_commit
+static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok)
 {
     crass_hip_ctx::DM &d = c->dm;
     const uint32_t n = (uint32_t)n_tok, stride = c->dr_stride;
-    d.hx_chars = hx_chars; d.hx_len = hx_len; d.n_tok = n_tok;
     if (!d.ev_done) {
         HIPCHK(c, hipEventCreateWithFlags(&d.ev_done, hipEventDisableTiming));
         HIPCHK(c, hipEventCreate(&d.ev_t0)); HIPCHK(c, hipEventCreate(&d.ev_t1));
     }
     DevMerge M{};
-    M.dx_chars = dx_chars; M.dx_len = dx_len; M.stride = stride; M.n_tok = n;
+    M.dx_chars = dx_chars; M.dx_len = dx_len; M.stride = stride; M.n_tok = n; M.d_ntok = d_ntok;
     M.thr = (uint32_t)std::max(c->prm.kmer_clust_size, 2); M.kmax = stride - 10;
     M.kset_log = 10; while ((1ull << M.kset_log) < 32ull * n) M.kset_log++;
     M.tab_log_alloc = 16; while (M.tab_log_alloc < 24 && (1ull << M.tab_log_alloc) < 48ull * n) M.tab_log_alloc++;
@@ -1238,6 +1260,14 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
                 1e3 * (tl0 - c->t_p1_sync), 1e3 * (now_ms() - tl0));
     // the per-token results the host view is rebuilt from (a few 10 KB)
     HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
+    return CRASS_OK;
+}
+
+// the merge just queued becomes the context's merge: hx_*: the distinct list in pinned host memory
+static int device_merge_commit(crass_hip_ctx *c, uint64_t n_tok, const char *hx_chars, const uint16_t *hx_len)
+{
+    crass_hip_ctx::DM &d = c->dm;
+    d.hx_chars = hx_chars; d.hx_len = hx_len; d.n_tok = n_tok;
     d.active = true; d.host_built = false; d.n_cand = c->dense.n;
     // the host view (tokens, groups, pattern list) is rebuilt by the helper thread as soon as the kernels are through
     d.build_pending = true;
@@ -1246,6 +1276,15 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     c->have_patterns = true; c->have_anchors = false; c->have_pat_token = false;
     c->n_installed_patterns = 2;                                  // >= 1 survivor exists; the exact count arrives with h_st
     return CRASS_OK;
+}
+
+// dx_*: distinct strings in token order on the device; hx_*: the same list in pinned host memory
+static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const char *hx_chars,
+                        const uint16_t *hx_len)
+{
+    const int s = device_merge_enqueue(c, dx_chars, dx_len, n_tok, nullptr);
+    if (s) return s;
+    return device_merge_commit(c, n_tok, hx_chars, hx_len);
 }
 
 // host merge after all (the device path reported a condition it does not handle)
@@ -1257,6 +1296,7 @@ static int host_merge_fallback(crass_hip_ctx *c)
     quiesce_worker(c);
     c->dm.active = false;
     c->cnt.used_device_merge = 0;
+    c->dm_prev_local = false;                           // (no merge is queued ahead of time after a device-side failure)
     const double t0 = now_ms();
     if (c->dm.global) {
         // the concatenated list is still on the device (engine-owned copy)
@@ -1293,7 +1333,17 @@ static int build_host_merge(crass_hip_ctx *c)
     crass_hip_ctx::DM &d = c->dm;
     if (!d.active || d.host_built) return CRASS_OK;
     (void)hipSetDevice(c->device);
+    // local merge: the token strings and the candidates' tokens only need pass 1's outputs, which the host has
+    // already waited for — that half of the host view is built while the merge kernels are still running
+    const double tb00 = now_ms();
+    bool begun = false;
+    if (!d.global) {
+        if (!merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, c->h_dmap.p, d.n_cand)) return CRASS_ERR_STATE;
+        begun = true;
+    }
+    const double tb0 = now_ms();
     HIPCHK(c, hipEventSynchronize(d.ev_done));
+    const double tb1 = now_ms();
     if (d.h_st.p->fail) return CRASS_ERR_STATE;
     const uint32_t *cmap = c->h_dmap.p;
     if (d.global) {                                     // own candidate -> own distinct string -> its rank in the global list
@@ -1301,11 +1351,14 @@ static int build_host_merge(crass_hip_ctx *c)
         for (uint64_t k = 0; k < d.n_cand; k++) d.cand_map[k] = d.h_gmap.p[d.my_off + c->h_dmap.p[k]];
         cmap = d.cand_map.data();
     }
-    if (!merge_from_device(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand, d.h_gid.p, d.h_blank.p,
-                           d.h_st.p->n_groups) ||
+    if (!begun && !merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand)) return CRASS_ERR_STATE;
+    if (!merge_from_device_finish(c->merge, d.h_gid.p, d.h_blank.p, d.h_st.p->n_groups) ||
         c->merge.patterns.size() != d.h_st.p->n_patterns)
         return CRASS_ERR_STATE;
     d.host_built = true;
+    if (getenv("CRASS_MERGE_PROFILE"))
+        fprintf(stderr, "[crass_dm] helper: first half %.1f us, waited %.1f us for the merge kernels, second half %.1f us (done %.1f us after the pass-1 sync)\n",
+                1e3 * (tb0 - tb00), 1e3 * (tb1 - tb0), 1e3 * (now_ms() - tb1), 1e3 * (now_ms() - c->t_p1_sync));
     c->n_installed_patterns = d.h_st.p->n_patterns;
     c->cnt.n_patterns = d.h_st.p->n_patterns;
     c->cnt.ac_states = 0;
@@ -1323,19 +1376,26 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
     quiesce_worker(c);
     c->dm.active = false;
     c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
+    const bool adopt = !dr_chars && c->premerge == 2;
+    c->premerge = 0;
     if (!dr_chars && device_merge_applies(c)) {
         (void)hipSetDevice(c->device);
         c->dm.global = false;
-        int s = c->n_dx ? device_merge(c, c->dd_dx_chars.p, c->dd_dx_len.p, c->n_dx, c->h_dx_chars.p, c->h_dx_len.p) : CRASS_ERR_STATE;
+        int s = !c->n_dx ? CRASS_ERR_STATE
+                : adopt  ? device_merge_commit(c, c->n_dx, c->h_dx_chars.p, c->h_dx_len.p)        // queued by the seed scan
+                         : device_merge(c, c->dd_dx_chars.p, c->dd_dx_len.p, c->n_dx, c->h_dx_chars.p, c->h_dx_len.p);
         if (s == CRASS_ERR_STATE) goto host_path;
         if (s == CRASS_OK) {
             c->cnt.used_device_merge = 1;
             c->cnt.ms_merge_host = (float)(now_ms() - t0);
+            c->dm_prev_local = true;
+            c->dx_cap_hint = (uint32_t)(((uint64_t)c->n_dx * 3 / 2 + 4095) & ~4095ull);
             return CRASS_OK;
         }
         return s;
     }
 host_path:
+    c->dm_prev_local = false;
     c->issue_bulk();                                    // per-candidate records: copy stream, overlaps the host merge
     if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens &&
         merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
@@ -1427,6 +1487,7 @@ int crass_hip_get_distinct(crass_hip_ctx *c, crass_distinct *o)
 static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n_global,
                              uint64_t my_offset, double t0)
 {
+    c->premerge = 0; c->dm_prev_local = false;          // (multi-rank: nothing is queued ahead of the exchange)
     ensure_distinct(c);
     const bool dev = c->dense.active && c->have_dev_tokens;
     const uint64_t my_nd = dev ? c->n_dx : c->dx_len.size();
@@ -1450,6 +1511,7 @@ static int merge_global_device(crass_hip_ctx *c, uint64_t n_global, uint64_t my_
 {
     crass_hip_ctx::DM &d = c->dm;
     const uint32_t stride = c->dr_stride;
+    c->premerge = 0; c->dm_prev_local = false;          // (multi-rank: nothing is queued ahead of the exchange)
     if (!device_merge_applies(c) || n_global == 0 || n_global > (1u << 22) || my_offset + c->n_dx > n_global) return CRASS_ERR_STATE;
     const uint32_t n = (uint32_t)n_global;
     uint32_t tsize = 1024;
@@ -1758,6 +1820,9 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         const double th0 = now_ms();
         const int hs = ensure_host_merge(c);            // host view of the merge, rebuilt while the device verifies
         c->cnt.ms_merge_host += (float)(now_ms() - th0);
+        if (getenv("CRASS_MERGE_PROFILE"))
+            fprintf(stderr, "[crass_dm] recruit: tail queued %.1f us after the pass-1 sync, then blocked %.1f us on the host view\n",
+                    1e3 * (th0 - c->t_p1_sync), 1e3 * (now_ms() - th0));
         if (hs == CRASS_ERR_STATE) {                    // inconsistent device results: never expected
             HIPCHK(c, hipStreamSynchronize(c->stream));
             const int fs = host_merge_fallback(c);
@@ -1766,6 +1831,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         }
         if (hs) return hs;
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (getenv("CRASS_MERGE_PROFILE"))
+            fprintf(stderr, "[crass_dm] recruit: final synchronisation returned %.1f us after the pass-1 sync\n", 1e3 * (now_ms() - c->t_p1_sync));
         if (spec) {
             if (c->dm.h_st.p->fail) {                   // the device merge gave up: host merge, then pass 2 again
                 const int fs = host_merge_fallback(c);

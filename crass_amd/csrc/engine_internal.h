@@ -93,7 +93,8 @@ struct DevMergeState {
     uint32_t n_keys;              // distinct anchor keys
     uint32_t log_size;            // anchor table holds 1 << log_size slots (<= 15: staged in LDS)
     uint32_t fail;                // != 0: the device path does not apply (1 token outside ACGT/23..64, 2 key set too
-                                  // large or empty, 4 cuckoo insertion gave up) -> the host merge is used instead
+                                  // large or empty, 4 cuckoo insertion gave up, 64 more tokens than the launch was sized for)
+                                  // -> the host merge is used instead
     uint32_t k0;                  // a member key (fills unused table slots)
     uint32_t all_t;               // the key 0xFFFFFFFF is a member
     uint32_t ent_cursor;          // entries allocated in the verification index
@@ -111,6 +112,7 @@ struct DevMerge {
     // input: distinct candidate DR strings in first-occurrence (= token) order
     const char *dx_chars; const uint16_t *dx_len;
     uint32_t stride, n_tok;
+    const uint32_t *d_ntok;       // nullptr, or the device-side token count (n_tok is then the bound the launch is sized for)
     uint32_t thr;                 // max(kmer_clust_size, 2): sightings of a group that decide membership
     uint32_t kmax;                // k-mer slots per token (stride - 10)
     // per token

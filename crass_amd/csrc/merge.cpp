@@ -786,8 +786,10 @@ bool merge_from_distinct(MergeResult &m, const char *dx_chars, const uint16_t *d
 // Host view of a merge that ran on the device (dmerge.hip): token table, groups and pattern list are
 // rebuilt from the device's per-token results (gid_of = GID, blank = dropped by removeRedundantRepeats) with
 // the reference's own sort/partition predicates, so the hand-off matches the host merge field for field.
-bool merge_from_device(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
-                       const uint32_t *cand_distinct, uint64_t n, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups)
+// first half: what only needs pass 1's outputs (token strings, every candidate's token) — the caller runs it while
+// the merge kernels are still busy
+bool merge_from_device_begin(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
+                             const uint32_t *cand_distinct, uint64_t n)
 {
     m.clear();
     // the device compared every candidate with its representative byte for byte, so the list is pairwise
@@ -798,22 +800,52 @@ bool merge_from_device(MergeResult &m, const char *dx_chars, const uint16_t *dx_
         if (cand_distinct[k] >= n_distinct) { m.clear(); return false; }
         m.cand_token[k] = cand_distinct[k] + 2;
     }
+    return true;
+}
+// second half: groups and the pattern list from the device's per-token results
+bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups)
+{
+    const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
+    const double p2 = prof_now();
+    const uint32_t n_distinct = m.tokens.size();
     m.next_free_gid = (int)n_groups + 1;
     m.groups.assign(n_groups, {});
     std::vector<std::vector<Member>> survivors(n_groups);
+    {
+        std::vector<uint32_t> cnt(n_groups, 0);
+        for (uint32_t t = 0; t < n_distinct; t++) {
+            const uint32_t g = gid_of[t];
+            if (g == 0 || g > n_groups) { m.clear(); return false; }
+            cnt[g - 1]++;
+        }
+        for (uint32_t g = 0; g < n_groups; g++) { m.groups[g].reserve(cnt[g]); survivors[g].reserve(cnt[g]); }
+    }
     for (uint32_t t = 0; t < n_distinct; t++) {
         const uint32_t g = gid_of[t];
-        if (g == 0 || g > n_groups) { m.clear(); return false; }
         m.groups[g - 1].push_back(t + 2);
-        survivors[g - 1].push_back(Member{t, (uint32_t)dx_len[t], blank[t] != 0});
+        survivors[g - 1].push_back(Member{t, (uint32_t)m.tokens.strings.len(t), blank[t] != 0});
     }
-    for (auto &v : survivors) {
+    // per group: the reference's sort by length + partition (the same std:: calls on the same sequence, so the same
+    // order among equal lengths); groups are independent
+    parallel_tasks(n_groups, 8, [&](size_t g) {
+        std::vector<Member> &v = survivors[g];
         std::sort(v.begin(), v.end(), member_shorter_first);
         v.erase(std::partition(v.begin(), v.end(), member_kept), v.end());
-    }
+    });
+    const double p3 = prof_now();
     emit_patterns(m, survivors);
+    const double p4 = prof_now();
     m.flatten();
+    if (prof)
+        fprintf(stderr, "[crass_merge] host view: groups %.1f us, patterns %.1f us, flatten %.1f us\n",
+                1e3 * (p3 - p2), 1e3 * (p4 - p3), 1e3 * (prof_now() - p4));
     return true;
+}
+bool merge_from_device(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
+                       const uint32_t *cand_distinct, uint64_t n, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups)
+{
+    return merge_from_device_begin(m, dx_chars, dx_len, dr_stride, n_distinct, cand_distinct, n) &&
+           merge_from_device_finish(m, gid_of, blank, n_groups);
 }
 
 static void cluster_and_patterns(MergeResult &m, int kmer_clust_size, double t0, double t1)

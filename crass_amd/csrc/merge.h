@@ -89,6 +89,11 @@ bool merge_from_distinct(MergeResult &m, const char *dx_chars, const uint16_t *d
 // removeRedundantRepeats dropped it.  false (m cleared) if the inputs are inconsistent.
 bool merge_from_device(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
                        const uint32_t *cand_distinct, uint64_t n, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups);
+// the same in two halves: begin() needs pass 1's outputs only (it can run while the merge kernels are busy),
+// finish() the device's per-token results
+bool merge_from_device_begin(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
+                             const uint32_t *cand_distinct, uint64_t n);
+bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups);
 
 // byte-wise Aho-Corasick with fully resolved goto; semantics of acism_create + the first
 // callback of acism_scan (acism_create.c:71-392, acism.c:25-106)
