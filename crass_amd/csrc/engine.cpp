@@ -1386,6 +1386,9 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
                          : device_merge(c, c->dd_dx_chars.p, c->dd_dx_len.p, c->n_dx, c->h_dx_chars.p, c->h_dx_len.p);
         if (s == CRASS_ERR_STATE) goto host_path;
         if (s == CRASS_OK) {
+            // the merge kernels are already running: the pass-1 hand-off pack (PCIe bound) goes beside them — small,
+            // latency-bound kernels — rather than beside the pass-2 filter, which it would slow down
+            if (adopt && !getenv("CRASS_PACK_LATE")) c->issue_bulk();
             c->cnt.used_device_merge = 1;
             c->cnt.ms_merge_host = (float)(now_ms() - t0);
             c->dm_prev_local = true;
