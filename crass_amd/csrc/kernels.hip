@@ -1761,7 +1761,9 @@ hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t ss
     if (n_max == 0) return hipSuccess;
     // PCIe-bound: a modest grid keeps enough stores in flight without occupying the chip
     const uint64_t total16 = p1_blob_layout(n_max, ss_cap).total / 16;
-    unsigned nb = (unsigned)std::min<uint64_t>((total16 + 255) / 256, 256);
+    unsigned cap = 256;
+    if (const char *e = getenv("CRASS_PACK_BLOCKS")) cap = (unsigned)std::max(1, atoi(e));
+    unsigned nb = (unsigned)std::min<uint64_t>((total16 + 255) / 256, cap);
     if (nb == 0) nb = 1;
     hipLaunchKernelGGL(k_pack_p1_blob, dim3(nb), dim3(256), 0, st, d_nf, n_max, ss_cap, g_read, g_replen, g_nss, g_low, g_ss, blob);
     return hipGetLastError();
