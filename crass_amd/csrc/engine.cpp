@@ -267,6 +267,8 @@ struct crass_hip_ctx {
         bool active = false;
         uint32_t world = 1, rank = 0, slot = 0;
         uint64_t cap = 0, needed = 0;
+        uint32_t gx_cap_hint = 0;                   // bound for the merge queued ahead of the counters (previous global count x 1.5)
+        hipEvent_t ev_counts = nullptr;
         DevBuf<uint8_t> send; DevBuf<uint32_t> xinfo; PinBuf<uint32_t> h_xinfo;
         uint64_t send_bytes() const { return (cap + 1) * (uint64_t)slot; }
     } xchg;
@@ -458,6 +460,14 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     return CRASS_OK;
 }
 
+int crass_hip_stream_wait_event(crass_hip_ctx *c, void *event)
+{
+    if (!c || !event) return CRASS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, hipStreamWaitEvent(c->stream, (hipEvent_t)event, 0));
+    return CRASS_OK;
+}
+
 int crass_hip_set_stage_timing(crass_hip_ctx *c, int level)
 {
     if (!c || level < 0 || level > 2) return CRASS_ERR_INVALID_ARG;
@@ -474,6 +484,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     c->lb_status.release(); c->lb_ticket.release(); c->h_lb_fail.release();
+    if (c->xchg.ev_counts) (void)hipEventDestroy(c->xchg.ev_counts);
     c->dm.release(); c->h_qblob.release(); c->xchg.send.release(); c->xchg.xinfo.release(); c->xchg.h_xinfo.release();
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
@@ -1616,15 +1627,32 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 4, c->d_count.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(X.h_xinfo.p, X.xinfo.p, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // As in the seed scan of the one-GPU path: when the previous step's merge ran on the device, this step's merge is
+    // queued right here (token count read on the device, sized by a bound) and the host only waits for the counters.
+    bool queued = false;
+    if (dev && X.gx_cap_hint && X.gx_cap_hint <= n_max && !getenv("CRASS_NO_SPECULATION")) {
+        if (!X.ev_counts) HIPCHK(c, hipEventCreateWithFlags(&X.ev_counts, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(X.ev_counts, c->stream));
+        const int qs = device_merge_enqueue(c, d.gx_chars.p, d.gx_len.p, X.gx_cap_hint, c->d_count.p + 4);
+        if (qs) return qs;
+        queued = true;
+        HIPCHK(c, hipEventSynchronize(X.ev_counts));
+    } else HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t n_global = X.h_xinfo.p[0], my_off = X.h_xinfo.p[1];
-    if (X.h_xinfo.p[2]) { X.needed = X.h_xinfo.p[3]; return CRASS_ERR_OVERFLOW; }
+    if (X.h_xinfo.p[2]) { X.needed = X.h_xinfo.p[3]; X.gx_cap_hint = 0; return CRASS_ERR_OVERFLOW; }
     if (dev && n_global && c->h_count.p[5] == 0 && c->h_count.p[4] != 0 && c->h_count.p[4] <= (1u << 20) && my_off + c->n_dx <= n_global) {
         d.global = true; d.my_off = my_off; d.n_global = n_global;
-        const int s = device_merge(c, d.gx_chars.p, d.gx_len.p, c->h_count.p[4], d.h_gx_chars.p, d.h_gx_len.p);
-        if (s == CRASS_OK) { c->cnt.used_device_merge = 1; c->cnt.ms_merge_host = (float)(now_ms() - t0); return CRASS_OK; }
+        const uint32_t n_tok = c->h_count.p[4];
+        const int s = (queued && n_tok <= X.gx_cap_hint) ? device_merge_commit(c, n_tok, d.h_gx_chars.p, d.h_gx_len.p)
+                                                         : device_merge(c, d.gx_chars.p, d.gx_len.p, n_tok, d.h_gx_chars.p, d.h_gx_len.p);
+        if (s == CRASS_OK) {
+            c->cnt.used_device_merge = 1; c->cnt.ms_merge_host = (float)(now_ms() - t0);
+            X.gx_cap_hint = (uint32_t)std::min<uint64_t>(n_max, ((uint64_t)n_tok * 3 / 2 + 4095) & ~4095ull);
+            return CRASS_OK;
+        }
         if (s != CRASS_ERR_STATE) return s;
     }
+    X.gx_cap_hint = 0;
     // host merge
     d.global = false;
     std::vector<char> gc(n_global * (size_t)stride);

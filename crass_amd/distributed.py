@@ -116,6 +116,7 @@ class GatheredExchange:
     def __init__(self, eng, dist, device, cap_rows=16384):
         self.eng, self.dist, self.device = eng, dist, device
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self._ev = None
         self._setup(cap_rows)
         # bring the communicator up now (RCCL initialises lazily on the first collective): not inside a timed step
         import torch
@@ -133,7 +134,11 @@ class GatheredExchange:
         """after eng.seed_scan(): True when merged, False when the capacity was raised (repeat the seed scan)"""
         import torch
         self.dist.all_gather_into_tensor(self.recv, self.send)
-        torch.cuda.current_stream(self.device).synchronize()         # the engine reads recv on its own stream
+        # the engine reads recv on its own stream: ordered behind the collective by an event, no host wait
+        if self._ev is None:
+            self._ev = torch.cuda.Event()
+        self._ev.record(torch.cuda.current_stream(self.device))
+        self.eng.stream_wait_event(self._ev.cuda_event)
         need = self.eng.merge_gathered(self.recv.data_ptr(), fetch=False)
         if need is None:
             return True

@@ -441,6 +441,10 @@ class SearchEngine:
         _chk(self.lib.crass_hip_get_recruits(self.h, C.byref(v)), "crass_hip_get_recruits")
         return RecruitSet(v)
 
+    def stream_wait_event(self, event_handle):
+        """order the engine's stream behind a HIP event (raw hipEvent_t handle, e.g. torch.cuda.Event().cuda_event)"""
+        _chk(self.lib.crass_hip_stream_wait_event(self.h, C.c_void_p(int(event_handle))), "crass_hip_stream_wait_event")
+
     def set_stage_timing(self, level):
         """0 none, 1 the three large kernels (default), 2 every stage — see crass_hip_set_stage_timing."""
         _chk(self.lib.crass_hip_set_stage_timing(self.h, int(level)), "crass_hip_set_stage_timing")

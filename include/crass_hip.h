@@ -98,6 +98,9 @@ int  crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out);
  * stage (ms_compact, ms_pass1_total, ms_merge_device, ms_recruit_finish, ms_pass2_total), 0 times nothing.
  * Environment override at creation: CRASS_STAGE_TIMING=0|1|2.  (No reference counterpart: crass has no timers.) */
 int  crass_hip_set_stage_timing(crass_hip_ctx *ctx, int level);
+/* Orders the context's stream behind a HIP event recorded on another stream (hipEvent_t passed as void*): lets the
+ * caller's collective (RCCL all-gather on its own stream) feed crass_hip_merge_gathered without a host wait. */
+int  crass_hip_stream_wait_event(crass_hip_ctx *ctx, void *event);
 void crass_hip_destroy(crass_hip_ctx *ctx);
 const char *crass_hip_strerror(int status);
 int  crass_hip_last_hip_error(const crass_hip_ctx *ctx);
