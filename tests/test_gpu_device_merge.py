@@ -235,3 +235,44 @@ def test_exception_reads_stay_on_the_device_path(ca):
     assert dev3.counters["used_device_merge"] == 0
     assert_same_paths(dev3, host3, expect_device=False)
     assert_same_pipeline(dev3, ref3)
+
+
+def test_queued_merge_call_orders(ca):
+    """From its second call on, a context's seed scan queues the device merge itself (token count on the device);
+    crass_hip_merge adopts it.  Unusual call orders must give the same results: a repeated seed scan, a merge from
+    caller-supplied strings while a queued merge is in flight, a much larger and a much smaller read set on the same
+    context (bounds learnt from the previous call do not fit)."""
+    small = synth_reads(ca, 30000, read_len=150, n_dr=5, crispr_per_million=20000)
+    big = synth_reads(ca, 200000, read_len=150, n_dr=200, crispr_per_million=40000, first=50000)
+    ref_small, ref_big = orc.pipeline(small), orc.pipeline(big)
+    eng = ca.SearchEngine()
+    try:
+        def run(seqs, twice=False, explicit=False):
+            packed = ca.PackedReads(seqs)
+            eng.load_reads(packed, None)
+            cands = eng.seed_scan()
+            if twice:
+                cands = eng.seed_scan()
+            if explicit:
+                chars, lens = eng.candidate_dr_view()
+                m = eng.merge(np.array(chars), np.array(lens))
+            else:
+                m = eng.merge()
+            rec = eng.recruit()
+            used = eng.counters()["used_device_merge"]
+            packed.close()
+            return cands, m, rec, used
+
+        for seqs, ref, kw, want_dev in ((small, ref_small, {}, 1), (small, ref_small, {}, 1), (big, ref_big, {}, 1),
+                                        (big, ref_big, dict(twice=True), 1), (small, ref_small, {}, 1),
+                                        (big, ref_big, dict(explicit=True), 0), (big, ref_big, {}, 1), (small, ref_small, {}, 1)):
+            cands, m, rec, used = run(seqs, **kw)
+            assert used == want_dev
+            assert m.tokens == ref.tokens and m.groups == ref.groups and sorted(m.patterns) == sorted(ref.patterns)
+            n1 = ref.n_pass1
+            assert cands.read_idx.tolist() == ref.rec_read[:n1].tolist()
+            assert m.cand_token.tolist() == ref.rec_token[:n1].tolist()
+            assert rec.read_idx.tolist() == ref.rec_read[n1:n1 + ref.n_pass2].tolist()
+            assert rec.token.tolist() == ref.rec_token[n1:n1 + ref.n_pass2].tolist()
+    finally:
+        eng.close()
