@@ -170,6 +170,7 @@ struct crass_hip_ctx {
         bool active = false;
         // the used part of the arrays above, packed on the device (p1_blob_layout) and copied with one call
         PinBuf<uint8_t> h_blob;
+        DevBuf<uint8_t> d_blob;                     // the hand-off blob is assembled on the device and copied by the runtime
         P1Blob lay{};
         uint64_t pack_cap = 0; uint32_t pack_ss_cap = 0;
         // the ABI's wide per-candidate arrays (crass_candidates), widened from the compact blob on first request
@@ -178,7 +179,7 @@ struct crass_hip_ctx {
         PinBuf<char> h_dr_fb; PinBuf<uint16_t> h_dr_len_fb; bool dr_fallback = false;    // candidates' own strings (no distinct list)
         void release()
         {
-            h_blob.release(); h_dr_fb.release(); h_dr_len_fb.release();
+            h_blob.release(); d_blob.release(); h_dr_fb.release(); h_dr_len_fb.release();
             d_read.release(); d_ss_off.release(); d_low.release(); d_replen.release(); d_nss.release(); d_ss.release(); d_dr_len.release(); d_dr.release();
         }
     } dense;
@@ -214,6 +215,19 @@ struct crass_hip_ctx {
         bulk_needed = false;
         const P1Dense &D = dense;
         (void)hipStreamWaitEvent(copy_stream, bulk_gate ? bulk_gate : ev_gathered, 0);
+        // The blob is assembled in device memory and its used bytes copied by the runtime (the copy engine): a kernel
+        // that stores to pinned host memory stretches whatever compute kernel runs beside it by about its own duration
+        // on this stack (45 us per step at 10 M reads, 0.36 ms at 100 M).  CRASS_PACK_KERNEL: the old way, for A/B.
+        if (!getenv("CRASS_PACK_KERNEL") && D.lay.total) {
+            P1Dense &W = const_cast<P1Dense &>(dense);
+            if (W.d_blob.ensure(D.h_blob.n) == hipSuccess) {
+                (void)launch_pack_p1_blob(d_count.p + 2, D.pack_cap, D.pack_ss_cap, D.d_read.p, D.d_replen.p, D.d_nss.p, D.d_low.p, D.d_ss.p,
+                                          W.d_blob.p, copy_stream);
+                (void)hipMemcpyAsync(D.h_blob.p, W.d_blob.p, D.lay.total, hipMemcpyDeviceToHost, copy_stream);
+                bulk_pending = true;
+                return;
+            }
+        }
         (void)launch_pack_p1_blob(d_count.p + 2, D.pack_cap, D.pack_ss_cap, D.d_read.p, D.d_replen.p, D.d_nss.p, D.d_low.p, D.d_ss.p,
                                   D.h_blob.p, copy_stream);
         bulk_pending = true;
