@@ -119,10 +119,28 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # timed region: HIP events around the three large kernels only (stage timing level 1 — every event record costs
-    # ~6 us of stream time); the finer stage breakdown comes from a few extra, untimed steps below
-    kern = {"ms_filter": [], "ms_survivor": [], "ms_recruit": [], "ms_merge_host": [], "ms_sink_host": []}
+    # untimed scouting steps with every stage timed (level 2): the stage breakdown, and which of the three large
+    # kernels is the dominant one
+    eng.set_stage_timing(2)
+    scout_keys = ("ms_filter", "ms_survivor", "ms_recruit", "ms_compact", "ms_pass1_total", "ms_merge_device", "ms_recruit_finish",
+                  "ms_pass2_total")
+    scout = {k: [] for k in scout_keys}
+    for _ in range(3):
+        step()
+        cs = eng.counters()
+        for k in scout:
+            scout[k].append(cs[k])
+    scout = {k: float(np.mean(v)) for k, v in scout.items()}
+    stages = {k: round(scout[k], 4) for k in ("ms_compact", "ms_pass1_total", "ms_merge_device", "ms_recruit_finish", "ms_pass2_total")}
+    names = {"seed_scan_filter": ("ms_filter", 1), "survivor": ("ms_survivor", 2), "recruit_scan": ("ms_recruit", 4)}
+    dom = max(names, key=lambda k: scout[names[k][0]])
+    # timed region: HIP events around the dominant kernel only (level 1 with a focus: every event record costs ~6 us
+    # of stream time, and the other two kernels' durations are reported from the scouting steps)
     eng.set_stage_timing(1)
+    eng.set_timing_focus(names[dom][1])
+    for _ in range(2):                                   # (settle into the timed configuration)
+        step()
+    kern = {names[dom][0]: [], "ms_merge_host": [], "ms_sink_host": []}
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -132,6 +150,7 @@ def main():
             kern[k].append(c[k])
     sync()
     dt = time.perf_counter() - t0
+    eng.set_timing_focus(7)
     tot_p1, tot_p2 = None, None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
@@ -143,36 +162,27 @@ def main():
         tot_p1, tot_p2 = int(tot[0].item()), int(tot[1].item())
     c = eng.counters()
     ms_per_step = dt * 1e3 / args.steps
-    eng.set_stage_timing(2)                              # untimed: every stage (device merge, compaction, pass totals)
-    stages = {"ms_compact": [], "ms_pass1_total": [], "ms_merge_device": [], "ms_recruit_finish": [], "ms_pass2_total": []}
-    for _ in range(3):
-        step()
-        cs = eng.counters()
-        for k in stages:
-            stages[k].append(cs[k])
-    eng.set_stage_timing(1)
-    stages = {k: round(float(np.mean(v)), 4) for k, v in stages.items()}
     value = world * n * args.steps / dt
 
     # ---- roofline of the dominant kernel (HIP events on the engine's stream, see engine.cpp) ----
     avg = {k: float(np.mean(v)) for k, v in kern.items()}
     bytes_per_read_per_pass = (L + 3) // 4               # ceil(L/4) B per read per pass
-    cands = {"seed_scan_filter": avg["ms_filter"], "recruit_scan": avg["ms_recruit"], "survivor": avg["ms_survivor"]}
-    dom = max(cands, key=cands.get)
+    dom_ms = avg[names[dom][0]]                          # HIP events over the timed region
     if dom == "survivor":
         alg_bytes = c["n_filter_survivors"] * bytes_per_read_per_pass
     else:
         alg_bytes = n * bytes_per_read_per_pass
-    achieved = alg_bytes / (cands[dom] * 1e-3) / 1e9 if cands[dom] > 0 else 0.0
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # per-kernel view (the two streaming kernels touch every read; the survivor kernel only the ~2 % that
     # survive the filter, so its algorithmic bytes are tiny and it is latency/issue bound by nature)
     per_kernel = {}
-    for name, ms, units in (("seed_scan_filter", avg["ms_filter"], n), ("survivor", avg["ms_survivor"], c["n_filter_survivors"]),
-                            ("recruit_scan", avg["ms_recruit"], n)):
+    for name, units in (("seed_scan_filter", n), ("survivor", c["n_filter_survivors"]), ("recruit_scan", n)):
+        ms = dom_ms if name == dom else scout[names[name][0]]
         b = units * bytes_per_read_per_pass
         gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         per_kernel[name] = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes": int(b), "achieved_GBps": round(gbs, 1),
-                            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
+                            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5),
+                            "measured_in": "timed steps" if name == dom else "scouting steps (untimed)"}
     traffic = None
     try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/summarize_pmc.py)
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["per_launch"]
@@ -184,7 +194,7 @@ def main():
         pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(cands[dom], 4),
+                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(dom_ms, 4),
                 "per_kernel": per_kernel, "host_ms": {"merge": round(avg["ms_merge_host"], 3), "sink": round(avg["ms_sink_host"], 3)},
                 "merge_device_ms": stages["ms_merge_device"], "device_merge": int(c.get("used_device_merge", 0)),
                 "stages_ms_untimed_steps": stages}

@@ -353,11 +353,20 @@ struct crass_hip_ctx {
     bool premerge_inflight = false;                 // merge kernels may still be running when the seed scan returns
     double t_p1_sync = 0;                           // CRASS_MERGE_PROFILE: host time line between pass 1 and the merge
     bool spans_p1 = false, spans_p2 = false, span_survivors = false;     // spans to evaluate at the next counters fetch
-    hipError_t stamp(int i, int level) { return timing_level >= level ? hipEventRecord(ev[i], stream) : hipSuccess; }
+    // level 1 only: which of the three large kernels are bracketed (bit 0 seed scan, 1 survivors, 2 pass-2 scan)
+    unsigned timing_focus = 7;
+    bool timed(int i, int level) const
+    {
+        if (timing_level < level) return false;
+        if (timing_level >= 2 || level != 1) return true;
+        const unsigned bit = (i <= 1) ? 1u : (i == 8 || i == 9) ? 2u : 4u;
+        return (timing_focus & bit) != 0;
+    }
+    hipError_t stamp(int i, int level) { return timed(i, level) ? hipEventRecord(ev[i], stream) : hipSuccess; }
     float span(int a, int b, int level) const
     {
         float ms = 0;
-        if (timing_level < level || hipEventElapsedTime(&ms, ev[a], ev[b]) != hipSuccess) ms = 0;
+        if (!timed(a, level) || !timed(b, level) || hipEventElapsedTime(&ms, ev[a], ev[b]) != hipSuccess) ms = 0;
         return ms;
     }
 };
@@ -486,6 +495,13 @@ int crass_hip_set_stage_timing(crass_hip_ctx *c, int level)
 {
     if (!c || level < 0 || level > 2) return CRASS_ERR_INVALID_ARG;
     c->timing_level = level;
+    return CRASS_OK;
+}
+
+int crass_hip_set_timing_focus(crass_hip_ctx *c, unsigned kernels)
+{
+    if (!c || kernels > 7u) return CRASS_ERR_INVALID_ARG;
+    c->timing_focus = kernels;
     return CRASS_OK;
 }
 

@@ -445,6 +445,10 @@ class SearchEngine:
         """order the engine's stream behind a HIP event (raw hipEvent_t handle, e.g. torch.cuda.Event().cuda_event)"""
         _chk(self.lib.crass_hip_stream_wait_event(self.h, C.c_void_p(int(event_handle))), "crass_hip_stream_wait_event")
 
+    def set_timing_focus(self, kernels):
+        """level 1: bit 0 seed scan, bit 1 survivors, bit 2 pass-2 scan (crass_hip_set_timing_focus)"""
+        _chk(self.lib.crass_hip_set_timing_focus(self.h, int(kernels)), "crass_hip_set_timing_focus")
+
     def set_stage_timing(self, level):
         """0 none, 1 the three large kernels (default), 2 every stage — see crass_hip_set_stage_timing."""
         _chk(self.lib.crass_hip_set_stage_timing(self.h, int(level)), "crass_hip_set_stage_timing")

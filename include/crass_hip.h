@@ -98,6 +98,10 @@ int  crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out);
  * stage (ms_compact, ms_pass1_total, ms_merge_device, ms_recruit_finish, ms_pass2_total), 0 times nothing.
  * Environment override at creation: CRASS_STAGE_TIMING=0|1|2.  (No reference counterpart: crass has no timers.) */
 int  crass_hip_set_stage_timing(crass_hip_ctx *ctx, int level);
+/* Level 1 only: which of the three large kernels are bracketed — bit 0 seed scan (ms_filter), bit 1 survivors
+ * (ms_survivor), bit 2 pass-2 scan (ms_recruit); default 7.  A caller that reports one kernel's duration over many
+ * calls (bench.py: the dominant one) times just that kernel: two event records per call instead of six. */
+int  crass_hip_set_timing_focus(crass_hip_ctx *ctx, unsigned kernels);
 /* Orders the context's stream behind a HIP event recorded on another stream (hipEvent_t passed as void*): lets the
  * caller's collective (RCCL all-gather on its own stream) feed crass_hip_merge_gathered without a host wait. */
 int  crass_hip_stream_wait_event(crass_hip_ctx *ctx, void *event);

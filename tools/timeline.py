@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Print the device-side timeline (kernels + copies) of the LAST bench step from a rocprofv3
 --kernel-trace --memory-copy-trace CSV directory:  python tools/timeline.py DIR [STEPS_BACK]
-(bench.py ends with 3 untimed stage-breakdown steps: STEPS_BACK=3 shows the last TIMED step)"""
+(STEPS_BACK: how many steps before the last one; bench.py's last step is a timed one)"""
 import csv
 import glob
 import sys
@@ -28,7 +28,7 @@ def main():
     prev_end = t0
     done = False
     for s, e, n in ev:
-        if back and done:                               # the next step's prologue (after the host fetched the results)
+        if done:                               # the next step's prologue (after the host fetched the results)
             break
         done = "k_pack_p2_blob" in n
         print("%9.1f us  +%8.1f gap  %8.1f us  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, n))

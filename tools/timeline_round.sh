@@ -6,6 +6,6 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/rp -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --cpu-sample 0 > $out/bench.json 2> $out/prof.err
-python3 $GRAFT_REPO_ROOT/tools/timeline.py $out/rp 3 > $out/timeline.txt
+python3 $GRAFT_REPO_ROOT/tools/timeline.py $out/rp 0 > $out/timeline.txt
 rm -rf $out/rp
 tail -1 $out/timeline.txt
