@@ -674,7 +674,7 @@ hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const ui
 }
 // rank order == global read order: rank r's rows go to [off_r, off_r + n_r)
 __global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows,
-                                                    uint32_t slot_bytes, char *g_chars, uint16_t *g_len, uint32_t *xinfo)
+                                                    uint32_t slot_bytes, char *g_chars, uint16_t *g_len, uint32_t *xinfo, uint32_t *h_xinfo)
 {
     const uint64_t send_bytes = (cap_rows + 1) * (uint64_t)slot_bytes;
     const uint32_t r = blockIdx.y;
@@ -690,6 +690,7 @@ __global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (r == 0 && i == 0) {
         xinfo[0] = (uint32_t)total; xinfo[1] = (uint32_t)mine; xinfo[2] = mx > cap_rows ? 1u : 0u; xinfo[3] = (uint32_t)mx;
+        if (h_xinfo) { h_xinfo[0] = (uint32_t)total; h_xinfo[1] = (uint32_t)mine; h_xinfo[2] = mx > cap_rows ? 1u : 0u; h_xinfo[3] = (uint32_t)mx; }   // pinned mirror
     }
     if (mx > cap_rows || i >= n_r) return;
     const uint8_t *row = recv + r * send_bytes + (i + 1) * (uint64_t)slot_bytes;
@@ -699,10 +700,10 @@ __global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t
     g_len[off + i] = (uint16_t)src[stride / 16].x;
 }
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
-                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st)
+                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo)
 {
     hipLaunchKernelGGL(k_xg_unpack, dim3((unsigned)((cap_rows + 255) / 256), world), dim3(256), 0, st, recv, world, rank, stride, cap_rows,
-                       slot_bytes, g_chars, g_len, xinfo);
+                       slot_bytes, g_chars, g_len, xinfo, h_xinfo);
     return hipGetLastError();
 }
 

@@ -1636,7 +1636,8 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     const uint64_t n_max = X.world * X.cap;
     const uint32_t n = (uint32_t)n_max;
     HIPCHK(c, d.g_chars.ensure(n_max * (size_t)stride + 16)); HIPCHK(c, d.g_len.ensure(n_max + 1));
-    HIPCHK(c, launch_xg_unpack((const uint8_t *)d_recv, X.world, X.rank, stride, X.cap, X.slot, d.g_chars.p, d.g_len.p, X.xinfo.p, c->stream));
+    HIPCHK(c, launch_xg_unpack((const uint8_t *)d_recv, X.world, X.rank, stride, X.cap, X.slot, d.g_chars.p, d.g_len.p, X.xinfo.p, c->stream,
+                               X.h_xinfo.p));      // (the four counters also land in pinned host memory: no copy call)
     bool dev = device_merge_applies(c) && n_max <= (1u << 22);
     if (dev) {
         uint32_t tsize = 1024;
@@ -1651,12 +1652,12 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
         // the global count lives on the device (xinfo[0]); n_max bounds it
         HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, X.xinfo.p, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p, d.g_rep.p,
                                    c->stream));
+        Lookback lbg;
         HIPCHK(c, launch_dx_tokens(d.g_chars.p, d.g_len.p, d.g_hash.p, stride, X.xinfo.p, n, d.g_rep.p, d.g_slot.p, d.g_first.p, d.g_mask.p, d.g_prefix.p, d.g_bsum.p,
                                    d.g_idx.p, c->d_count.p + 4, c->d_count.p + 5, d.h_gmap.p, d.h_gx_chars.p, d.h_gx_len.p, d.h_gx_hash.p,
-                                   d.gx_chars.p, d.gx_len.p, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_count.p + 4, c->d_count.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
+                                   d.gx_chars.p, d.gx_len.p, c->stream,
+                                   c->d_count.p, c->h_count.p, 8, c->next_lookback(n_words, &lbg)));   // counters leave with the last kernel
     }
-    HIPCHK(c, hipMemcpyAsync(X.h_xinfo.p, X.xinfo.p, 16, hipMemcpyDeviceToHost, c->stream));
     // As in the seed scan of the one-GPU path: when the previous step's merge ran on the device, this step's merge is
     // queued right here (token count read on the device, sized by a bound) and the host only waits for the counters.
     bool queued = false;

@@ -166,7 +166,7 @@ hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const ui
                           uint32_t slot_bytes, uint8_t *send, hipStream_t st);
 // xinfo (device, 8 words): [0] n_global, [1] my_offset, [2] overflow flag, [3] largest per-rank count
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
-                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st);
+                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo = nullptr);   // h_xinfo: pinned mirror
 hipError_t launch_device_merge(const DevMerge &M, hipStream_t st);
 // pass-2 anchor filter with table parameters read from the device (M.st); flags nothing when M.st->fail
 hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st);
