@@ -87,95 +87,93 @@ __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
 // ---- 1. 2-bit packing (forward and reverse complement) + laurenized 11-mer codes + k-mer owners ----
 // owner[code] = smallest token containing the k-mer = the token whose group the k-mer belongs to in the
 // reference's k2GIDMap (homeless k-mers are assigned to their first token's group, WorkHorse.cpp:1612-1617).
-// one token: WITH_N = false is the plain ACGT walk (any other byte sets `bad`); WITH_N = true also accepts 'N'
-// (packed as 'A' + a position-mask bit) and lists the 11-mers that contain one instead of coding them
-template <bool WITH_N>
-static __device__ __forceinline__ void dm_pack_token(const DevMerge &M, uint32_t t, uint32_t len, const uint32_t (&w)[16])
+// bits of x (32) spread to the even bit positions of a 64-bit word
+static __device__ __forceinline__ uint64_t spread32(uint32_t v)
 {
-    uint64_t f0 = 0, f1 = 0, r0 = 0, r1 = 0, mf = 0, mr = 0;
-    uint32_t fwd = 0, rev = 0;
-    bool bad = false;
-    uint32_t clean = 0;                                 // bases since the last 'N'
-    uint32_t *codes = M.codes + (uint64_t)t * M.kmax;
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-        if ((uint32_t)i < len) {
-            const uint32_t ch = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            const bool isn = WITH_N && ch == 'N';
-            const uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : (WITH_N && isn) ? 0u : 3u;
-            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && !isn) bad = true;
-            const uint32_t cr = isn ? 0u : 3u - c;
-            if (i < 32) f0 |= (uint64_t)c << (2 * (i & 31)); else f1 |= (uint64_t)c << (2 * (i & 31));
-            const uint32_t j = len - 1 - i;
-            if (j < 32) r0 |= (uint64_t)cr << (2 * j); else r1 |= (uint64_t)cr << (2 * (j - 32));
-            if (WITH_N) {
-                if (isn) { mf |= 1ull << i; mr |= 1ull << j; }
-                clean = isn ? 0u : clean + 1u;
-            }
-            // first base most significant: integer order == lexicographic order, laurenize() == min (SeqUtils.cpp:89-97)
-            fwd = ((fwd << 2) | c) & 0x3FFFFFu;
-            rev = (rev >> 2) | (cr << 20);
-            if (i + 1 >= kClusterK) {
-                if (!WITH_N || clean >= (uint32_t)kClusterK) {
-                    const uint32_t code = fwd < rev ? fwd : rev;
-                    codes[i + 1 - kClusterK] = code;
-                    atomicMin(&M.owner[code], t);
-                } else {                                // an 11-mer with an 'N': identity assigned by the last block
-                    const uint32_t q = atomicAdd(&M.st->n_badk, 1u);
-                    if (q < kDmBadKmerCap) M.bk_list[q] = (t << 6) | (uint32_t)(i + 1 - kClusterK);
-                    codes[i + 1 - kClusterK] = 1u << 22;
-                }
-            }
-        }
-    }
-    uint64_t *pk = M.packed + (uint64_t)t * 4;
-    pk[0] = f0; pk[1] = f1; pk[2] = r0; pk[3] = r1;
-    M.tmask[(uint64_t)t * 2] = mf; M.tmask[(uint64_t)t * 2 + 1] = mr;
-    if (bad) atomicOr(&M.st->fail, 1u);
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+// the 11 low bits of v spread to the even positions of a 22-bit value
+static __device__ __forceinline__ uint32_t spread11(uint32_t v)
+{
+    uint32_t x = v & 0x7FFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
 }
 
+// One WAVE per token, lane i = base i: the two bit planes of the 2-bit codes come from ballots, the packed forms are
+// their interleave, and lane i builds the 11-mer that starts at i from an 11-bit window of each plane (first base
+// most significant: integer order == lexicographic order, laurenize() == min, SeqUtils.cpp:89-97).  'N' packs as
+// 'A' + a position-mask bit; an 11-mer with an 'N' is listed for the last block instead of being coded.
 __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
 {
-    __shared__ uint64_t bk_key[kDmBadKmerCap];
-    __shared__ uint32_t last_sh;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (t < dm_ntok(M)) {
         const uint32_t len = M.dx_len[t];
-        if (len > 64 || len < 23 || M.stride > 64) atomicOr(&M.st->fail, 1u);
+        if (len > 64 || len < 23 || M.stride > 64) { if (lane == 0) atomicOr(&M.st->fail, 1u); }
         else {
-            // the whole slot in registers (16-byte loads), then a fully unrolled walk: every register index is static
-            uint32_t w[16];
-            const uint4 *p4 = reinterpret_cast<const uint4 *>(M.dx_chars + (uint64_t)t * M.stride);
-            uint32_t any_n = 0;                         // exact "some byte == 'N'" (slots are zero padded)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint4 v; v.x = v.y = v.z = v.w = 0;
-                if ((uint32_t)q * 16 < M.stride) v = p4[q];
-                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            const bool in = (uint32_t)lane < len;
+            const uint32_t ch = in ? (uint32_t)(uint8_t)M.dx_chars[(uint64_t)t * M.stride + lane] : 0u;
+            const bool isn = in && ch == 'N';
+            const uint32_t c = ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0u;
+            const bool bad = in && ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N';
+            const uint32_t cr = (in && !isn) ? 3u - c : 0u;
+            const uint64_t b0 = __ballot(in && (c & 1u)), b1 = __ballot(in && (c & 2u));      // forward planes, bit i = base i
+            const uint64_t q0 = __ballot(cr & 1u), q1 = __ballot(cr & 2u);                    // complement planes, bit i = base i
+            const uint64_t mf = __ballot(isn);
+            const uint64_t any_bad = __ballot(bad);
+            const uint32_t sh = 64u - len;                                                   // reversal: base i -> position len-1-i
+            const uint64_t rq0 = __brevll(q0) >> sh, rq1 = __brevll(q1) >> sh, mr = __brevll(mf) >> sh;
+            if (lane == 0) {
+                uint64_t *pk = M.packed + (uint64_t)t * 4;
+                pk[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
+                pk[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
+                pk[2] = spread32((uint32_t)rq0) | (spread32((uint32_t)rq1) << 1);
+                pk[3] = spread32((uint32_t)(rq0 >> 32)) | (spread32((uint32_t)(rq1 >> 32)) << 1);
+                M.tmask[(uint64_t)t * 2] = mf; M.tmask[(uint64_t)t * 2 + 1] = mr;
+                if (any_bad) atomicOr(&M.st->fail, 1u);
             }
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const uint32_t x = w[q] ^ 0x4E4E4E4Eu;
-                any_n |= ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+            if ((uint32_t)lane + kClusterK <= len) {                                          // the 11-mer that starts at this lane
+                const uint32_t x0 = (uint32_t)(b0 >> lane) & 0x7FFu, x1 = (uint32_t)(b1 >> lane) & 0x7FFu;
+                uint32_t code;
+                if (((uint32_t)(mf >> lane) & 0x7FFu) == 0u) {
+                    const uint32_t fwd = spread11(__brev(x0) >> 21) | (spread11(__brev(x1) >> 21) << 1);
+                    const uint32_t rev = spread11(~x0) | (spread11(~x1) << 1);
+                    code = fwd < rev ? fwd : rev;
+                    atomicMin(&M.owner[code], t);
+                } else {
+                    const uint32_t q = atomicAdd(&M.st->n_badk, 1u);
+                    if (q < kDmBadKmerCap) M.bk_list[q] = (t << 6) | (uint32_t)lane;
+                    code = 1u << 22;
+                }
+                M.codes[(uint64_t)t * M.kmax + lane] = code;
             }
-            if (any_n) dm_pack_token<true>(M, t, len, w);
-            else dm_pack_token<false>(M, t, len, w);
         }
     }
-    // ---- the last block to finish gives the 11-mers with an 'N' their identity: the laurenized 11-mer over
-    // A < C < G < N < T (ASCII order; comp_tab maps N to N, SeqUtils.cpp:50-59) as a 33-bit key, id = index of the
-    // first equal key, code = (1 << 22) + id.  A handful per merge; none at all for reads without N.
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last_sh = (atomicAdd(&M.st->blocks_done, 1u) == gridDim.x - 1u) ? 1u : 0u;
-    __syncthreads();
-    if (!last_sh) return;
-    __threadfence();
-    uint32_t m = __hip_atomic_load(&M.st->n_badk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- 1b. identity of the 11-mers with an 'N': the laurenized 11-mer over A < C < G < N < T (ASCII order; comp_tab
+// maps N to N, SeqUtils.cpp:50-59) as a 33-bit key, id = index of the first equal key, code = (1 << 22) + id.  One
+// small block, a handful of 11-mers per merge and none at all for reads without N.  (Its own launch rather than
+// "the last block of k_dm_pack_codes": a ticket per block costs more than the launch once there is a block per
+// four tokens — thousands of same-address atomics across the XCDs.)
+__global__ __launch_bounds__(256) void k_dm_badk(DevMerge M)
+{
+    __shared__ uint64_t bk_key[kDmBadKmerCap];
+    const uint32_t m = M.st->n_badk;
     if (m == 0) return;
     if (m > kDmBadKmerCap) { if (threadIdx.x == 0) atomicOr(&M.st->fail, 1u); return; }
     for (uint32_t q = threadIdx.x; q < m; q += blockDim.x) {
-        const uint32_t e = __hip_atomic_load(&M.bk_list[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t e = M.bk_list[q];
         const char *str = M.dx_chars + (uint64_t)(e >> 6) * M.stride + (e & 63u);
         uint64_t fk = 0, rk = 0;
         for (int i = 0; i < kClusterK; i++) {
@@ -192,7 +190,7 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
         const uint64_t key = bk_key[q];
         uint32_t id = q;
         for (uint32_t j = 0; j < q; j++) if (bk_key[j] == key) { id = j; break; }
-        const uint32_t e = __hip_atomic_load(&M.bk_list[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t e = M.bk_list[q];
         const uint32_t t2 = e >> 6, code = (1u << 22) + id;
         M.codes[(uint64_t)t2 * M.kmax + (e & 63u)] = code;
         atomicMin(&M.owner[code], t2);
@@ -712,7 +710,8 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
     if (M.n_tok == 0) return hipErrorInvalidValue;
     const unsigned nb = (M.n_tok + 255) / 256;
     hipLaunchKernelGGL(k_dm_init, dim3(1024), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_pack_codes, dim3(nb), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_pack_codes, dim3((M.n_tok + 3) / 4), dim3(256), 0, st, M);       // one wave per token
+    hipLaunchKernelGGL(k_dm_badk, dim3(1), dim3(256), 0, st, M);
     // every wave must be resident: at most one block per CU (16 waves of the CU's 32 wave slots, no LDS)
     unsigned gb = (M.n_tok + 15) / 16;
     if (gb > M.n_cu) gb = M.n_cu;
