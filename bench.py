@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py — reads/sec through DR search + recruit on synthetic 150 bp reads.
+"""bench.py — reads/sec through DR search + recruit on synthetic reads (BASELINE.json's metric).
 
 One "step" = one pass of the whole hot path over one resident batch of synthetic reads:
 pass 1 (seed scan + extend + QC, crass searchFile/searchCore) -> DR merge
@@ -9,21 +9,30 @@ findSingletons).  Packed reads are already resident in HBM when the timed region
 the timed region ends with the ordered candidate / recruit records, tokens, groups and
 pattern list in host memory.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+Workloads (BASELINE.json `configs`, selected with --config, default by --gpus):
+  --config 1  configs[1]: 10 M x 150 bp, 50 seeded DRs, one GPU               (default at N=1)
+  --config 2  configs[2]: 100 M x 150 bp sharded over the ranks, STRONG scaling (default at N>1;
+              `--gpus 1 --config 2` is the one-GPU base of that curve)
+  --config 3  configs[3]: 1 M x 10 kbp long reads, arrays of 20-60 repeats in 5 % of them
+  --config 4  configs[4]: 200 M x 150 bp, 500 seeded DRs, 4 GC classes
+  --total-reads T  strong scaling over T reads (rank r holds reads [r*T/N, (r+1)*T/N))
+  --reads R        weak scaling, R reads per GPU (the round-1 mode)
 
-Workload (BASELINE.json configs[1]): 10 M synthetic 150 bp reads per GPU, 50 seeded DRs,
-1 % CRISPR reads (weak scaling: every rank holds its own 10 M-read shard of one global
-stream).  Prints ONE JSON line on rank 0.
+Launching:
+    python bench.py                                  # N=1
+    python bench.py --gpus N                         # spawns N rank processes itself (one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N            # the same, as a rank of an external launcher
+Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -31,25 +40,85 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+CONFIGS = {
+    1: dict(name="BASELINE.json configs[1]", read_len=150, n_dr=50, gc_classes=0, total=10_000_000, arrays=(0, 0), cpm=10000,
+            cpu_sample=4_000_000),
+    2: dict(name="BASELINE.json configs[2]", read_len=150, n_dr=50, gc_classes=0, total=100_000_000, arrays=(0, 0), cpm=10000,
+            cpu_sample=4_000_000),
+    3: dict(name="BASELINE.json configs[3]", read_len=10000, n_dr=50, gc_classes=0, total=1_000_000, arrays=(20, 60), cpm=50000,
+            cpu_sample=40_000),
+    4: dict(name="BASELINE.json configs[4]", read_len=150, n_dr=500, gc_classes=4, total=200_000_000, arrays=(0, 0), cpm=10000,
+            cpu_sample=4_000_000),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--n-dr", type=int, default=50)
-    ap.add_argument("--gc-classes", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="BASELINE.json configs[i]; 0 = configs[1] at N=1, configs[2] at N>1")
+    ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: reads of the whole job, sharded over the ranks")
+    ap.add_argument("--reads", type=int, default=0, help="weak scaling: reads per GPU")
+    ap.add_argument("--read-len", type=int, default=0)
+    ap.add_argument("--n-dr", type=int, default=0)
+    ap.add_argument("--gc-classes", type=int, default=-1)
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-strong-base", action="store_true",
+                    help="N>1 strong scaling: skip the untimed one-GPU run of the whole job on rank 0 (speedup_vs_1gpu)")
+    ap.add_argument("--alternate", action="store_true", help="alternate between two resident batches (speculation bounds "
+                    "are then learnt from a different batch than the one being processed)")
     ap.add_argument("--check", action="store_true", help="also verify the GPU result against the oracle on the CPU sample")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a plain interpreter: start N rank processes (one per GPU) BEFORE anything in this
+    process touches the GPU or imports torch, relay rank 0's JSON line, exit non-zero if any rank fails."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CRASS_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            rc = rc or p.wait(timeout=120)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = rc or 1
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    sys.exit(1 if rc else 0)
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "dmerge.hip"):
+        with open(os.path.join(ROOT, "crass_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    import numpy as np
     import torch
     import crass_amd as ca
     ca.load()
@@ -59,10 +128,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world),
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -79,45 +146,70 @@ def main():
             dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
     coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
-    L, n = args.read_len, args.reads
+    # ---- workload ----
+    cfg_id = args.config or (1 if world == 1 else 2)
+    cfg = dict(CONFIGS[cfg_id])
+    L = args.read_len or cfg["read_len"]
+    n_dr = args.n_dr or cfg["n_dr"]
+    gc = cfg["gc_classes"] if args.gc_classes < 0 else args.gc_classes
+    if args.reads:                                          # weak scaling: every rank holds its own shard of one stream
+        scaling, n, first, total = "weak", args.reads, rank * args.reads, world * args.reads
+    else:                                                   # strong scaling: the job's reads are split over the ranks
+        total = args.total_reads or cfg["total"]
+        first, end = total * rank // world, total * (rank + 1) // world
+        n = end - first
+        scaling = "strong" if world > 1 or args.total_reads or cfg_id == 2 else "weak"
+    custom = bool(args.reads or args.total_reads or args.read_len or args.n_dr or args.gc_classes >= 0)
     W = (L + 15) // 16
-    spec = ca.synth_spec(read_len=L, n_dr=args.n_dr, gc_classes=args.gc_classes)
-    first = rank * n                                     # weak scaling: shard `rank` of one global stream
+    spec = ca.synth_spec(read_len=L, n_dr=n_dr, gc_classes=gc, crispr_per_million=cfg["cpm"],
+                         array_min_repeats=cfg["arrays"][0], array_max_repeats=cfg["arrays"][1])
     t0 = time.time()
     words = ca.synth_packed(spec, first, n)
     t_gen = time.time() - t0
 
     eng = ca.SearchEngine(device=local_rank)
     eng.load_packed_uniform(words, n, L, read_index_base=first)     # H2D once; resident for every step
+    engs = [eng]
+    if args.alternate:                                      # a second resident batch (the next reads of the same stream)
+        eng_b = ca.SearchEngine(device=local_rank)
+        words_b = ca.synth_packed(spec, total + first, n)
+        eng_b.load_packed_uniform(words_b, n, L, read_index_base=total + first)
+        del words_b
 
     xg = None
     if world > 1 and args.dist_backend == "nccl":
         from crass_amd.distributed import GatheredExchange
         xg = GatheredExchange(eng, dist, coll_dev)          # one RCCL all-gather of fixed-size device buffers per step
 
-    def step():
-        eng.seed_scan(fetch=False)
+    def step(e=eng):
+        e.seed_scan(fetch=False)
         if xg is not None:
             while not xg.step():                            # capacity raised (first steps only): repeat the seed scan
-                eng.seed_scan(fetch=False)
+                e.seed_scan(fetch=False)
         elif world > 1:
             # only the DISTINCT candidate DR strings travel (rank order == read order, so every rank
             # replays the same global token order and builds the same pattern set locally)
             # (gloo dry runs: the same exchange through host arrays)
             from crass_amd.distributed import allgather_distinct
-            chars, lens, _ = eng.distinct()
+            chars, lens, _ = e.distinct()
             g_chars, g_lens, my_off = allgather_distinct(chars, lens, dist, coll_dev)
-            eng.merge_distinct(g_chars, g_lens, my_off, fetch=False)
+            e.merge_distinct(g_chars, g_lens, my_off, fetch=False)
         else:
-            eng.merge(fetch=False)
-        eng.recruit(fetch=False)
+            e.merge(fetch=False)
+        e.recruit(fetch=False)
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # first call of a fresh context (no speculation bounds, buffers not yet allocated): reported, never part of `value`
+    sync()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    first_call_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(max(0, args.warmup - 1)):
         step()
     # untimed scouting steps with every stage timed (level 2): the stage breakdown, and which of the three large
     # kernels is the dominant one
@@ -138,89 +230,145 @@ def main():
     # of stream time, and the other two kernels' durations are reported from the scouting steps)
     eng.set_stage_timing(1)
     eng.set_timing_focus(names[dom][1])
+    if args.alternate:
+        eng_b.set_stage_timing(1)
+        eng_b.set_timing_focus(names[dom][1])
+        for _ in range(2):
+            step(eng_b)
     for _ in range(2):                                   # (settle into the timed configuration)
         step()
     kern = {names[dom][0]: [], "ms_merge_host": [], "ms_sink_host": []}
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        c = eng.counters()
+    for it in range(args.steps):
+        e = eng_b if (args.alternate and it & 1) else eng
+        step(e)
+        c = e.counters()
         for k in kern:
             kern[k].append(c[k])
     sync()
     dt = time.perf_counter() - t0
     eng.set_timing_focus(7)
     tot_p1, tot_p2 = None, None
+    c = eng.counters()
+    rccl_ranks = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        cc = eng.counters()
-        tot = torch.tensor([cc["n_pass1_found"], cc["n_pass2_found"]], dtype=torch.int64, device=coll_dev)
+        tot = torch.tensor([c["n_pass1_found"], c["n_pass2_found"], 1], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         tot_p1, tot_p2 = int(tot[0].item()), int(tot[1].item())
-    c = eng.counters()
+        if args.dist_backend == "nccl":
+            rccl_ranks = int(tot[2].item())              # ranks that took part in an RCCL all-reduce
     ms_per_step = dt * 1e3 / args.steps
-    value = world * n * args.steps / dt
+    value = total * args.steps / dt if not args.reads else world * n * args.steps / dt
 
     # ---- roofline of the dominant kernel (HIP events on the engine's stream, see engine.cpp) ----
     avg = {k: float(np.mean(v)) for k, v in kern.items()}
     bytes_per_read_per_pass = (L + 3) // 4               # ceil(L/4) B per read per pass
     dom_ms = avg[names[dom][0]]                          # HIP events over the timed region
+    n_surv = c["n_filter_survivors"]
     if dom == "survivor":
-        alg_bytes = c["n_filter_survivors"] * bytes_per_read_per_pass
+        alg_bytes = n_surv * bytes_per_read_per_pass
     else:
         alg_bytes = n * bytes_per_read_per_pass
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # per-kernel view (the two streaming kernels touch every read; the survivor kernel only the ~2 % that
-    # survive the filter, so its algorithmic bytes are tiny and it is latency/issue bound by nature)
+    # per-kernel view (the two streaming kernels touch every read; the survivor kernel only the reads that
+    # survive the filter, so for short reads its algorithmic bytes are tiny and it is issue bound by nature)
     per_kernel = {}
-    for name, units in (("seed_scan_filter", n), ("survivor", c["n_filter_survivors"]), ("recruit_scan", n)):
+    for name, units in (("seed_scan_filter", n), ("survivor", n_surv), ("recruit_scan", n)):
         ms = dom_ms if name == dom else scout[names[name][0]]
         b = units * bytes_per_read_per_pass
         gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         per_kernel[name] = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes": int(b), "achieved_GBps": round(gbs, 1),
                             "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5),
                             "measured_in": "timed steps" if name == dom else "scouting steps (untimed)"}
-    traffic = None
-    try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/summarize_pmc.py)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["per_launch"]
-        key = {"seed_scan_filter": "k_filter_fast_impl", "survivor": "k_survivor", "recruit_scan": "k_anchor_filter"}[dom]
-        for k, v in pm.items():
-            if k.startswith(key) and n == 10_000_000 and L == 150:
-                traffic = v["hbm_bytes"]
+    # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ — only when
+    # they were taken on THIS kernel source (hash recorded by profiles/summarize_pmc.py) and this workload
+    traffic, traffic_src = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        key = {"seed_scan_filter": "k_filter_fast", "survivor": "k_survivor", "recruit_scan": "k_anchor_filter"}[dom]
+        if pm.get("source_hash") == source_hash() and pm.get("reads") == n and pm.get("read_len") == L:
+            for k, v in pm["per_launch"].items():
+                if k.startswith(key):
+                    traffic, traffic_src = v["hbm_bytes"], "profiles/r02_pmc_traffic.json (committed PMC passes, same kernel source hash)"
     except (OSError, KeyError, ValueError):
         pass
+    path_bytes = 2 * bytes_per_read_per_pass             # both passes read every base once at 2 bits
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "path_frac": round(value / world * path_bytes / (HBM_PEAK_GBS * 1e9), 5),
+                "path_frac_note": "whole path per GPU: reads/s/GPU x %d B / 8 TB/s (SURVEY 8d)" % path_bytes,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(dom_ms, 4),
                 "per_kernel": per_kernel, "host_ms": {"merge": round(avg["ms_merge_host"], 3), "sink": round(avg["ms_sink_host"], 3)},
                 "merge_device_ms": stages["ms_merge_device"], "device_merge": int(c.get("used_device_merge", 0)),
-                "stages_ms_untimed_steps": stages}
+                "stages_ms_scouting_steps": stages}
 
+    workload = "%d synthetic %d bp reads%s, %d seeded DRs%s (%s%s); pass1 + merge + pass2" % (
+        total, L, "" if world == 1 else " sharded over %d GPUs" % world, n_dr,
+        ", arrays of %d-%d repeats in %.0f %% of the reads" % (cfg["arrays"] + (cfg["cpm"] / 1e4,)) if cfg["arrays"][1]
+        else ", %.0f %% CRISPR reads" % (cfg["cpm"] / 1e4),
+        cfg["name"], ", modified by command-line options" if custom else "")
     out = {
         "metric": "reads/sec through DR search+recruit, 150bp synthetic, 1/2/4/8 MI355X",
         "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "%d synthetic %d bp reads per GPU, %d seeded DRs, 1%% CRISPR reads "
-                               "(BASELINE.json configs[1]); pass1 + merge + pass2" % (n, L, args.n_dr),
-                   "reads_per_gpu": n, "read_len": L, "n_dr": args.n_dr, "parallelism": "read-shards x%d" % world,
+        "config": {"workload": workload, "baseline_config": cfg_id, "total_reads": total, "reads_per_gpu": n, "read_len": L,
+                   "n_dr": n_dr, "parallelism": "read-shards x%d" % world,
                    "pass1_found": int(c["n_pass1_found"]) if tot_p1 is None else tot_p1,
                    "pass2_found": int(c["n_pass2_found"]) if tot_p2 is None else tot_p2,
                    "patterns": int(c["n_patterns"]), "ac_states": int(c["ac_states"]),
-                   "filter_survivors": int(c["n_filter_survivors"]),
+                   "filter_survivors": int(n_surv),
                    "fast_filter": int(c["used_fast_filter"]), "lds_automaton": int(c["used_lds_automaton"]),
                    "synth_gen_s": round(t_gen, 2)},
+        "first_call_ms": round(first_call_ms, 3),
+        "timed_batches": "two resident batches, alternating" if args.alternate else
+                         "one resident batch repeated (speculation bounds learnt from the previous, identical step; "
+                         "first_call_ms = the same step on a fresh context; --alternate switches batches)",
         "roofline": roofline,
     }
+    if rccl_ranks is not None:
+        out["rccl_ranks"] = rccl_ranks
+
+    # ---- strong scaling: the same job on ONE GPU (rank 0, untimed part of the run; the other ranks wait) ----
+    if world > 1 and scaling == "strong" and not args.no_strong_base and args.dist_backend == "nccl":
+        base = None
+        if rank == 0:
+            try:
+                w_all = ca.synth_packed(spec, 0, total)
+                e1 = ca.SearchEngine(device=local_rank)
+                e1.load_packed_uniform(w_all, total, L, read_index_base=0)
+                del w_all
+                for _ in range(3):
+                    e1.seed_scan(fetch=False); e1.merge(fetch=False); e1.recruit(fetch=False)
+                torch.cuda.synchronize()
+                k1 = max(3, min(args.steps, 10))
+                t0 = time.perf_counter()
+                for _ in range(k1):
+                    e1.seed_scan(fetch=False); e1.merge(fetch=False); e1.recruit(fetch=False)
+                torch.cuda.synchronize()
+                d1 = (time.perf_counter() - t0) / k1
+                c1 = e1.counters()
+                base = {"value": round(total / d1, 1), "ms_per_step": round(d1 * 1e3, 3), "steps": k1,
+                        "pass1_found": int(c1["n_pass1_found"]), "pass2_found": int(c1["n_pass2_found"]),
+                        "note": "the whole job on rank 0's GPU alone, same process, measured after the timed region"}
+                e1.close()
+            except Exception as ex:                     # reported extra; never fails the run
+                base = {"error": str(ex)}
+            out["one_gpu_same_job"] = base
+            if base and "value" in base:
+                out["speedup_vs_1gpu"] = round(value / base["value"], 3)
+        dist.barrier()
 
     # ---- CPU baseline: the oracle (single core, same algorithm class as the reference) on a
     #      bounded prefix of the SAME stream; rank 0 at N=1 only ----
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    cpu_sample = cfg["cpu_sample"] if args.cpu_sample < 0 else args.cpu_sample
+    if rank == 0 and world == 1 and cpu_sample > 0:
         from tests import orc
-        m = min(args.cpu_sample, n)
+        m = min(cpu_sample, n)
         asc = ca.unpack_ascii(words, W, L, m)
         off = np.arange(0, (m + 1) * L, L, dtype=np.uint64)
         r = orc.pipeline_time(asc, off)
@@ -229,13 +377,30 @@ def main():
                                "sample": "first %d reads of the same synthetic stream; pass1 %.2fs merge %.2fs pass2 %.2fs"
                                          % (m, r["t_pass1"], r["t_merge"], r["t_pass2"]),
                                "cpu": _cpu_model()}
+        # calibration of the port against the COMPILED reference's two hot functions (oracle/_ref travels to the GPU
+        # box as a built .so): PatternMatcher::bmpSearch over searchCore's windows, acism_scan over the reads
+        try:
+            mc = min(m, 200_000 if L <= 1000 else 4_000)
+            res = orc.pipeline((asc[:mc * L], off[:mc + 1]))
+            cal = orc.calibrate(asc[:mc * L], mc, L, res.patterns)
+            if cal is None:
+                cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")))
+                cal["measured_on"] = cal.get("measured_on", "?") + " (committed file; oracle/_ref not present in this run)"
+            else:
+                cal["measured_on"] = _cpu_model() + " (this run)"
+                cal["reference_equivalent_value"] = round(m / (r["t_pass1"] * cal["bmp_ratio"] + r["t_merge"] + r["t_pass2"] * cal["ac_ratio"]), 1)
+                cal["note"] = ("ratio = compiled reference time / port time on the same inputs (>1: the port is faster); "
+                               "reference_equivalent_value scales pass 1 by bmp_ratio and pass 2 by ac_ratio")
+            out["cpu_baseline"]["calibration"] = cal
+        except Exception as ex:
+            out["cpu_baseline"]["calibration"] = {"error": str(ex)}
         # the same restatement on every host core (SURVEY §8d "node's host cores" figure): the sample is sharded
         # over T threads, each runs its own pass 1 + merge + pass 2 (ctypes releases the GIL during the C call)
         try:
             import threading
             T = max(1, min(os.cpu_count() or 1, 64))
             per = m // T
-            if T > 1 and per >= 10000:
+            if T > 1 and per >= (10000 if L <= 1000 else 200):
                 res = [None] * T
 
                 def work(t):
@@ -254,10 +419,12 @@ def main():
         except Exception as e:                      # the reported baseline above does not depend on this extra
             out["cpu_baseline"]["all_cores"] = {"error": str(e)}
         if args.check:
-            _check(ca, eng, words, W, L, m, orc)
+            _check(ca, eng, words, W, L, min(m, 200_000 if L <= 1000 else 2000), orc)
     eng.close()
+    if args.alternate:
+        eng_b.close()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -86,7 +86,8 @@ class Fastx(C.Structure):
 class SynthSpec(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("read_len", C.c_uint32), ("n_dr", C.c_uint32), ("dr_len_min", C.c_uint32),
                 ("dr_len_max", C.c_uint32), ("spacer_len_min", C.c_uint32), ("spacer_len_max", C.c_uint32),
-                ("crispr_per_million", C.c_uint32), ("gc_classes", C.c_uint32)]
+                ("crispr_per_million", C.c_uint32), ("gc_classes", C.c_uint32),
+                ("array_min_repeats", C.c_uint32), ("array_max_repeats", C.c_uint32)]
 
 
 # every exported symbol of include/crass_hip.h: name -> (restype, argtypes)

@@ -492,6 +492,7 @@ void crass_synth_default(crass_synth_spec *s)
 {
     s->seed = 42; s->read_len = 150; s->n_dr = 50; s->dr_len_min = 28; s->dr_len_max = 37;
     s->spacer_len_min = 30; s->spacer_len_max = 38; s->crispr_per_million = 10000; s->gc_classes = 0;
+    s->array_min_repeats = 0; s->array_max_repeats = 0;
 }
 
 static inline uint32_t gc_word(uint64_t seed, uint64_t i, uint32_t w, uint32_t cls)
@@ -515,8 +516,11 @@ static inline uint32_t gc_word(uint64_t seed, uint64_t i, uint32_t w, uint32_t c
 int crass_synth_packed(const crass_synth_spec *s, uint64_t first, uint64_t n, uint32_t *packed, int n_threads)
 {
     if (!s || (n && !packed)) return CRASS_ERR_INVALID_ARG;
-    if (s->read_len == 0 || s->read_len > 4096 || s->n_dr == 0 || s->dr_len_max < s->dr_len_min ||
+    if (s->read_len == 0 || s->read_len > CRASS_HIP_MAX_READ_LEN || s->n_dr == 0 || s->dr_len_max < s->dr_len_min ||
         s->spacer_len_max < s->spacer_len_min || s->dr_len_max > 200) return CRASS_ERR_INVALID_ARG;
+    const bool arrays = s->array_max_repeats != 0;           // long-read mode: an array placed inside a random read
+    if (arrays && (s->array_max_repeats < s->array_min_repeats || s->array_max_repeats > 1000 || s->spacer_len_max > 64)) return CRASS_ERR_INVALID_ARG;
+    if (!arrays && s->read_len > 4096) return CRASS_ERR_INVALID_ARG;
     const uint32_t L = s->read_len, W = (L + 15) / 16;
     const uint64_t seed = s->seed;
     // DR table
@@ -534,7 +538,28 @@ int crass_synth_packed(const crass_synth_spec *s, uint64_t first, uint64_t n, ui
             const uint64_t i = first + k;
             uint32_t *w = packed + k * (uint64_t)W;
             const uint64_t h = key3(seed, 1, i);
-            if ((h % 1000000ull) < s->crispr_per_million) {
+            if (arrays) {
+                // BASELINE configs[3] shape: random background, and in a CRISPR read an array of U[min,max] repeats
+                // (DR + spacer units) written over it from a random offset (cut at the read end)
+                const uint32_t cls = s->gc_classes > 1 ? (uint32_t)((h >> 40) % s->gc_classes) : 0;
+                for (uint32_t q = 0; q < W; q++)
+                    w[q] = s->gc_classes > 1 ? gc_word(seed, i, q, cls) : (uint32_t)key3(seed ^ 0xA24BAED4963EE407ull, i, q);
+                if (L & 15) w[W - 1] &= (1u << ((L & 15) * 2)) - 1u;
+                if ((h % 1000000ull) < s->crispr_per_million) {
+                    const uint32_t d = (uint32_t)((h >> 24) % s->n_dr);
+                    const uint32_t reps = s->array_min_repeats + (uint32_t)(key3(seed, 8, i) % (s->array_max_repeats - s->array_min_repeats + 1));
+                    uint32_t pos = (uint32_t)(key3(seed, 3, i) % (L > 64 ? L * 2 / 5 : 1));
+                    auto put = [&](uint32_t at, uint32_t code) { w[at >> 4] = (w[at >> 4] & ~(3u << ((at & 15) * 2))) | (code << ((at & 15) * 2)); };
+                    for (uint32_t u = 0; u < reps; u++) {
+                        const uint32_t sl = s->spacer_len_min + (uint32_t)(key3(seed, 6, i * 1024 + u) % (s->spacer_len_max - s->spacer_len_min + 1));
+                        if (pos + drs[d].size() + sl > L) break;
+                        for (size_t p = 0; p < drs[d].size(); p++) put(pos + (uint32_t)p, drs[d][p]);
+                        pos += (uint32_t)drs[d].size();
+                        for (uint32_t p = 0; p < sl; p++) put(pos + p, (uint32_t)((key3(seed, 7, i * 65536 + (uint64_t)u * 64 + p) >> 11) & 3));
+                        pos += sl;
+                    }
+                }
+            } else if ((h % 1000000ull) < s->crispr_per_million) {
                 const uint32_t d = (uint32_t)((h >> 24) % s->n_dr);
                 const uint32_t prefix = (uint32_t)(key3(seed, 3, i) % 41);
                 const uint32_t cut = (uint32_t)(key3(seed, 4, i) % 41);

@@ -326,6 +326,9 @@ typedef struct {
     uint32_t spacer_len_min, spacer_len_max; /* 30..38                                        */
     uint32_t crispr_per_million; /* 10000 = 1 %                                               */
     uint32_t gc_classes;        /* 0/1 = uniform; 4 = GC 30/45/55/70 % background mix         */
+    uint32_t array_min_repeats, array_max_repeats; /* 0,0 = short-read mode (the read is a cut
+                                   from a tiled DR+spacer stream); else long-read mode (config 4:
+                                   20..60): an array of that many units written into a random read */
 } crass_synth_spec;
 void crass_synth_default(crass_synth_spec *s);
 int  crass_synth_packed(const crass_synth_spec *s, uint64_t first_read, uint64_t n_reads,

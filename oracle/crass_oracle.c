@@ -1005,3 +1005,53 @@ int orc_pipeline_time(const char *seqs, const uint64_t *seq_off, uint64_t n_read
     orc_result_free(r);
     return err;
 }
+
+/* ---- CPU-baseline calibration (bench.py cpu_baseline.calibration, tools/calibrate_cpu.py) ----
+ * The two hot loops of the reference on plain inputs, restated here with the oracle's leaf
+ * functions; oracle/ref_shim.cpp holds the same two loops over the COMPILED reference leaves
+ * (PatternMatcher::bmpSearch, acism_scan).  The ratio of the two timings says how the oracle's
+ * speed relates to the reference's on its two dominant functions (40 % + 34 %).
+ * Window sequence: searchCore's seed loop without a hit (libcrispr.cpp:295-339). */
+static double calib_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+double orc_calib_bmp(const char *seqs, uint64_t n_reads, int L, const orc_params *p, uint64_t *checksum)
+{
+    const int w = (int)p->searchWindowLength;
+    unsigned skips = p->lowDRsize - (2 * p->searchWindowLength - 1);
+    if (skips < 1) skips = 1;
+    const int search_end = L - (int)p->lowDRsize - (int)p->lowSpacerSize - w - 1;
+    uint64_t sum = 0;
+    const double t0 = calib_now();
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const char *seq = seqs + r * (uint64_t)L;
+        for (int j = 0; j <= search_end; j += (int)skips) {
+            int begin = j + (int)p->lowDRsize + (int)p->lowSpacerSize;
+            int end = j + (int)p->highDRsize + (int)p->highSpacerSize + w;
+            if (begin >= L) begin = L - 1;
+            if (end >= L) end = L - 1;
+            if (end - begin < w) break;
+            sum += (uint64_t)(int64_t)orc_bmp_search(seq + begin, (size_t)(end - begin), seq + j, (size_t)w);
+        }
+    }
+    const double t1 = calib_now();
+    *checksum = sum;
+    return t1 - t0;
+}
+
+double orc_calib_ac(const orc_ac *ac, const char *seqs, uint64_t n_reads, int L, uint64_t *checksum)
+{
+    uint64_t sum = 0;
+    const double t0 = calib_now();
+    for (uint64_t r = 0; r < n_reads; r++) {
+        uint32_t e = 0, l = 0;
+        if (orc_ac_first_match(ac, seqs + r * (uint64_t)L, (size_t)L, &e, &l)) sum += ((uint64_t)e << 8) + l;
+    }
+    const double t1 = calib_now();
+    *checksum = sum;
+    return t1 - t0;
+}

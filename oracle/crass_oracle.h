@@ -135,6 +135,10 @@ int orc_pipeline_time(const char *seqs, const uint64_t *seq_off, uint64_t n_read
                       const orc_params *p, double *t_pass1, double *t_merge, double *t_pass2,
                       uint64_t *n_pass1, uint64_t *n_pass2, uint32_t *n_patterns);
 
+/* calibration loops (see crass_oracle.c): seconds spent, *checksum over the results */
+double orc_calib_bmp(const char *seqs, uint64_t n_reads, int L, const orc_params *p, uint64_t *checksum);
+double orc_calib_ac(const orc_ac *ac, const char *seqs, uint64_t n_reads, int L, uint64_t *checksum);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <zlib.h>
+#include <time.h>
 
 #include "PatternMatcher.h"
 #include "StringCheck.h"
@@ -151,5 +152,55 @@ long ref_kseq_dump(const char *path, unsigned char **out, size_t *out_len, int *
 }
 
 void ref_free(void *p) { free(p); }
+
+/* ---- calibration loops (see oracle/crass_oracle.c orc_calib_*): the reference's two hot
+ * functions driven the way searchCore (libcrispr.cpp:295-339: std::string substr of the read
+ * for text and pattern, PatternMatcher::bmpSearch) and findSingletons (libcrispr.cpp:500-503)
+ * drive them. */
+static double calib_now()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+double ref_calib_bmp(const char *seqs, uint64_t n_reads, int L, unsigned lowDR, unsigned highDR, unsigned lowSp,
+                     unsigned highSp, unsigned w, uint64_t *checksum)
+{
+    unsigned skips = lowDR - (2 * w - 1);
+    if (skips < 1) skips = 1;
+    const int search_end = L - (int)lowDR - (int)lowSp - (int)w - 1;
+    uint64_t sum = 0;
+    const double t0 = calib_now();
+    for (uint64_t r = 0; r < n_reads; r++) {
+        std::string read(seqs + r * (uint64_t)L, (size_t)L);
+        for (int j = 0; j <= search_end; j += (int)skips) {
+            int begin = j + (int)lowDR + (int)lowSp;
+            int end = j + (int)highDR + (int)highSp + (int)w;
+            if (begin >= L) begin = L - 1;
+            if (end >= L) end = L - 1;
+            if (end - begin < (int)w) break;
+            std::string text = read.substr((size_t)begin, (size_t)(end - begin));
+            std::string pattern = read.substr((size_t)j, w);
+            sum += (uint64_t)(int64_t)PatternMatcher::bmpSearch(text, pattern);
+        }
+    }
+    const double t1 = calib_now();
+    *checksum = sum;
+    return t1 - t0;
+}
+
+double ref_calib_acism(void *handle, const char *seqs, uint64_t n_reads, int L, uint64_t *checksum)
+{
+    uint64_t sum = 0;
+    const double t0 = calib_now();
+    for (uint64_t r = 0; r < n_reads; r++) {
+        uint32_t e = 0, l = 0;
+        if (ref_acism_first(handle, seqs + r * (uint64_t)L, (size_t)L, &e, &l)) sum += ((uint64_t)e << 8) + l;
+    }
+    const double t1 = calib_now();
+    *checksum = sum;
+    return t1 - t0;
+}
 
 } /* extern "C" */

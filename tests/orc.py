@@ -92,6 +92,10 @@ def lib():
         L.orc_result_view.argtypes = [C.c_void_p, C.POINTER(View)]
         L.orc_pipeline_time.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Params)] + \
             [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_uint64)] * 2 + [C.POINTER(C.c_uint32)]
+        L.orc_calib_bmp.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Params), C.POINTER(C.c_uint64)]
+        L.orc_calib_bmp.restype = C.c_double
+        L.orc_calib_ac.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+        L.orc_calib_ac.restype = C.c_double
         _lib = L
     return _lib
 
@@ -122,6 +126,11 @@ def ref():
                                     C.POINTER(C.c_int)]
         R.ref_kseq_dump.restype = C.c_long
         R.ref_free.argtypes = [C.c_void_p]
+        if hasattr(R, "ref_calib_bmp"):
+            R.ref_calib_bmp.argtypes = [C.c_void_p, C.c_uint64, C.c_int] + [C.c_uint] * 5 + [C.POINTER(C.c_uint64)]
+            R.ref_calib_bmp.restype = C.c_double
+            R.ref_calib_acism.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+            R.ref_calib_acism.restype = C.c_double
         _ref = R
     return _ref
 
@@ -249,3 +258,29 @@ def pipeline_time(sbuf, soff, params=None):
                                   C.byref(n1), C.byref(n2), C.byref(npat))
     return dict(error=err, t_pass1=t[0].value, t_merge=t[1].value, t_pass2=t[2].value,
                 n_pass1=n1.value, n_pass2=n2.value, n_patterns=npat.value)
+
+
+def calibrate(asc, n, L, patterns, params=None):
+    """Speed of the oracle's two hot leaf loops against the compiled reference's on the same reads
+    (asc: uint8 [n*L], patterns: list[bytes]).  None when oracle/_ref is not available.
+    ratio > 1: the oracle is faster than the reference by that factor."""
+    R = ref()
+    if R is None or not hasattr(R, "ref_calib_bmp") or not patterns:
+        return None
+    p = params or Params.default()
+    Lb = lib()
+    ck_o, ck_r = C.c_uint64(), C.c_uint64()
+    t_o_bmp = Lb.orc_calib_bmp(asc.ctypes.data, n, L, C.byref(p), C.byref(ck_o))
+    t_r_bmp = R.ref_calib_bmp(asc.ctypes.data, n, L, p.lowDRsize, p.highDRsize, p.lowSpacerSize, p.highSpacerSize,
+                              p.searchWindowLength, C.byref(ck_r))
+    assert ck_o.value == ck_r.value, "bmpSearch checksums differ"
+    po = PatternSet(patterns, "oracle")
+    pr = PatternSet(patterns, "ref")
+    t_o_ac = Lb.orc_calib_ac(po.h, asc.ctypes.data, n, L, C.byref(ck_o))
+    t_r_ac = R.ref_calib_acism(pr.h, asc.ctypes.data, n, L, C.byref(ck_r))
+    assert ck_o.value == ck_r.value, "first-match checksums differ"
+    po.close()
+    pr.close()
+    return dict(bmp_ratio=round(t_r_bmp / t_o_bmp, 3), ac_ratio=round(t_r_ac / t_o_ac, 3), reads=int(n), read_len=int(L),
+                patterns=len(patterns), ref_bmp_s=round(t_r_bmp, 4), oracle_bmp_s=round(t_o_bmp, 4),
+                ref_acism_s=round(t_r_ac, 4), oracle_ac_s=round(t_o_ac, 4))

@@ -339,3 +339,54 @@ def test_exchange_three_shards_with_n_variants():
     one-collective form + device merge over the gathered lists against the oracle over all reads"""
     r = subprocess.run([sys.executable, "-c", EXCHANGE_WITH_N % dict(root=ROOT)], capture_output=True, timeout=600)
     assert r.returncode == 0 and b"OK" in r.stdout, r.stderr.decode()[-3000:]
+
+
+def _bench_line(r):
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_spawns_its_own_ranks_strong_scaling():
+    """`python bench.py --gpus 2` from a plain interpreter (no torchrun): the parent starts the rank processes before it
+    touches the GPU; --total-reads = strong scaling (each rank holds total/N reads); totals equal the one-process run"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-gpu",
+                        "--total-reads", "1000000", "--steps", "2", "--warmup", "1"], capture_output=True, timeout=900)
+    d = _bench_line(r)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_reads"] == 1000000
+    assert d["config"]["reads_per_gpu"] == 500000 and d["value"] > 0
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--total-reads", "1000000", "--steps", "2",
+                          "--warmup", "1", "--cpu-sample", "100000"], capture_output=True, timeout=900)
+    d1 = _bench_line(one)
+    assert d1["scaling"] == "strong" and "roofline" in d1 and "cpu_baseline" in d1
+    assert 0 < d1["roofline"]["path_frac"] < 1 and d1["roofline"]["frac"] > 0
+    assert (d["config"]["pass1_found"], d["config"]["pass2_found"], d["config"]["patterns"]) == \
+        (d1["config"]["pass1_found"], d1["config"]["pass2_found"], d1["config"]["patterns"])
+    cal = d1["cpu_baseline"]["calibration"]
+    assert "error" not in cal and cal["bmp_ratio"] > 0 and cal["ac_ratio"] > 0
+
+
+def test_bench_rccl_strong_scaling_one_rank_per_gpu():
+    """the RCCL form of the same launch on however many GPUs this box has (1 on the test pool: a one-rank communicator,
+    `--gpus 1` under an external launcher environment)"""
+    import torch
+    ng = torch.cuda.device_count()
+    if ng >= 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-reads", "2000000", "--steps", "3",
+                            "--warmup", "2"], capture_output=True, timeout=900)
+        d = _bench_line(r)
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["rccl_ranks"] == 2
+        assert d["one_gpu_same_job"]["pass1_found"] == d["config"]["pass1_found"]
+        assert d["one_gpu_same_job"]["pass2_found"] == d["config"]["pass2_found"]
+    else:
+        pytest.skip("one GPU: the N>1 RCCL launch needs a multi-GPU node (covered by the gloo run and the 1-rank RCCL exchange test)")
+
+
+@pytest.mark.parametrize("cfg,extra", [(3, ["--total-reads", "20000"]), (4, ["--total-reads", "2000000"])])
+def test_bench_other_configs_small(cfg, extra):
+    """--config 3 (10 kbp reads, arrays of 20-60 repeats) and --config 4 (500 DRs, 4 GC classes) at reduced size, with
+    the oracle check on a prefix"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(cfg), "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "2000" if cfg == 3 else "100000", "--check"] + extra, capture_output=True, timeout=900)
+    d = _bench_line(r)
+    assert d["config"]["baseline_config"] == cfg and d["config"]["pass1_found"] > 0 and d["value"] > 0
+    assert "roofline" in d and "cpu_baseline" in d

@@ -326,3 +326,15 @@ def test_long_reads_position_hints(ca):
         os.environ.pop("CRASS_NO_POS_HINTS", None)
     assert_same_pipeline(plain, ref)
     assert gpu.n_pass1 > 60
+
+
+def test_one_million_reference_known_answer_on_the_hip_path(ca):
+    """The HIP pipeline itself against numbers recorded from the COMPILED REFERENCE (SURVEY.md Appendix C /
+    §8c: 1 M reads, random.seed(42) -> 5 575 pass-1 reads, 1 988 DR variants, 52 groups, 700 patterns, 9 931 reads
+    after pass 2), plus record-level equality with the oracle on the same stream."""
+    from tests import appendix_c
+    seqs = appendix_c.generate(1000000)
+    gpu = ca.search_pipeline(seqs)
+    assert (gpu.n_pass1, gpu.n_tokens, gpu.n_groups, gpu.n_patterns, gpu.n_pass1 + gpu.n_pass2) == appendix_c.KNOWN_1M
+    assert gpu.counters["used_device_merge"] == 1 and gpu.counters["used_fast_filter"] == 1
+    assert_same_pipeline(gpu, orc.pipeline(seqs))

@@ -56,29 +56,16 @@ def test_filter_contract_no_lattice_hit_means_not_found():
     assert n_hit >= 837
 
 
-@pytest.mark.slow
+def test_appendix_c_generators_agree():
+    """the numpy replay of CPython's random stream (tests/appendix_c.generate) is the recipe of SURVEY Appendix C"""
+    from tests import appendix_c
+    assert appendix_c.generate(12000) == appendix_c.generate_reference_loop(12000)
+
+
 def test_one_million_synthetic_known_answer():
     """SURVEY appendix C generator (random.seed(42)); the compiled reference gave
     5 575 pass-1 reads, 1 988 variants, 52 groups, 700 patterns, 9 931 reads after pass 2."""
-    import random
-    random.seed(42)
-    L = 150
-
-    def rand_seq(n):
-        return "".join(random.choice("ACGT") for _ in range(n))
-    drs = [rand_seq(random.randint(28, 37)) for _ in range(50)]
-    seqs = []
-    for _ in range(1000000):
-        if random.random() < 0.01:
-            dr = random.choice(drs)          # drawn BEFORE the prefix: this order reproduces the survey's stream
-            s = rand_seq(random.randint(0, 40))
-            while len(s) < L + 60:
-                s += dr + rand_seq(random.randint(30, 38))
-            off = random.randint(0, 40)
-            s = s[off:off + L]
-        else:
-            s = rand_seq(L)
-        seqs.append(s.encode())
+    from tests import appendix_c
+    seqs = appendix_c.generate(1000000)
     res = orc.pipeline(seqs)
-    assert (res.n_pass1, res.n_tokens, res.n_groups, res.n_patterns, res.n_pass1 + res.n_pass2) == \
-        (5575, 1988, 52, 700, 9931)
+    assert (res.n_pass1, res.n_tokens, res.n_groups, res.n_patterns, res.n_pass1 + res.n_pass2) == appendix_c.KNOWN_1M
