@@ -96,6 +96,7 @@ SYMBOLS = {
     "crass_default_params": (None, [C.POINTER(Params)]),
     "crass_hip_create": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]),
     "crass_hip_set_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "crass_hip_reload_env": (C.c_int, [C.c_void_p]),
     "crass_hip_set_timing_focus": (C.c_int, [C.c_void_p, C.c_uint]),
     "crass_hip_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "crass_hip_destroy": (None, [C.c_void_p]),

@@ -21,7 +21,6 @@ namespace crass {
 #define WAVE 64
 static constexpr uint32_t kUnres = 0xFFFFFFFFu;      // root_of[t] not decided yet
 static constexpr uint32_t kNoLane = 0xFFFFFFFEu;     // lane holds no earlier-owned k-mer
-static constexpr uint32_t kNone = 0xFFFFFFFFu;
 static constexpr int kClusterK = 11;                 // CRASS_DEF_KMER_SIZE (crassDefines.h:66)
 
 // (h0,h1) >> bits, low 64 bits; bits in [0,127]
@@ -58,30 +57,10 @@ static __device__ __forceinline__ uint32_t dm_ntok(const DevMerge &M)
     return M.d_ntok ? min(*M.d_ntok, M.n_tok) : M.n_tok;
 }
 
-// ---- 0. initialise every word a later kernel polls, counts into or probes ----
+// ---- 0. initialise every word a later kernel polls, counts into or probes (dm_init_slice, engine_internal.h) ----
 __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
 {
-    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
-    uint4 ones; ones.x = ones.y = ones.z = ones.w = 0xFFFFFFFFu;
-    uint4 *o4 = reinterpret_cast<uint4 *>(M.owner);
-    for (uint64_t i = tid; i < ((1u << 22) + kDmBadKmerCap) / 4; i += nth) o4[i] = ones;
-    for (uint64_t i = tid; i < M.n_tok; i += nth) M.root_of[i] = kUnres;
-    for (uint64_t i = tid; i <= M.n_tok; i += nth) { M.grp_cnt[i] = 0; M.grp_fill[i] = 0; M.surv_cnt[i] = 0; }
-    const uint64_t ks = 1ull << M.kset_log;
-    for (uint64_t i = tid; i < ks; i += nth) { M.kset_key[i] = 0ull; M.kset_cnt[i] = 0u; M.kset_fill[i] = 0u; }
-    const uint64_t rs = 1ull << M.rset_log;
-    for (uint64_t i = tid; i < rs; i += nth) { M.rset_key[i] = 0ull; M.rset_cnt[i] = 0u; M.rset_fill[i] = 0u; }
-    for (uint64_t i = tid; i < (1u << 15); i += nth) M.anchor_fp[i] = 0u;
-    uint4 *t4 = reinterpret_cast<uint4 *>(M.anchor_tab);
-    for (uint64_t i = tid; i < (1ull << M.tab_log_alloc) / 4; i += nth) t4[i] = ones;
-    if (tid == 0) {
-        DevMergeState s{};
-        s.k0 = 0xFFFFFFFFu;
-        s.fail = M.inject_fail ? 16u : 0u;
-        if (M.d_ntok && *M.d_ntok > M.n_tok) s.fail |= 64u;           // more tokens than the launch was sized for
-        *M.st = s;
-    }
+    dm_init_slice(M, blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
 }
 
 // ---- 1. 2-bit packing (forward and reverse complement) + laurenized 11-mer codes + k-mer owners ----
@@ -112,11 +91,15 @@ static __device__ __forceinline__ uint32_t spread11(uint32_t v)
 // One WAVE per token, lane i = base i: the two bit planes of the 2-bit codes come from ballots, the packed forms are
 // their interleave, and lane i builds the 11-mer that starts at i from an 11-bit window of each plane (first base
 // most significant: integer order == lexicographic order, laurenize() == min, SeqUtils.cpp:89-97).  'N' packs as
-// 'A' + a position-mask bit; an 11-mer with an 'N' is listed for the last block instead of being coded.
+// 'A' + a position-mask bit.  An 11-mer with an 'N' (a handful per merge, none for reads without N) cannot be a 22-bit
+// code: it gets the identity the reference's std::map<std::string,int> would give it — the laurenized 11-mer over
+// A < C < G < N < T (ASCII order; comp_tab maps N to N, SeqUtils.cpp:50-59) as a 33-bit key, claimed in a small
+// open-addressing table whose slot index is the id: code = (1 << 22) + slot.
 __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (t == 0 && lane == 0 && M.d_ntok && *M.d_ntok > M.n_tok) atomicOr(&M.st->fail, 64u);      // more tokens than the launch was sized for
     if (t < dm_ntok(M)) {
         const uint32_t len = M.dx_len[t];
         if (len > 64 || len < 23 || M.stride > 64) { if (lane == 0) atomicOr(&M.st->fail, 1u); }
@@ -140,60 +123,44 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
                 pk[2] = spread32((uint32_t)rq0) | (spread32((uint32_t)rq1) << 1);
                 pk[3] = spread32((uint32_t)(rq0 >> 32)) | (spread32((uint32_t)(rq1 >> 32)) << 1);
                 M.tmask[(uint64_t)t * 2] = mf; M.tmask[(uint64_t)t * 2 + 1] = mr;
+                M.pat_token[2 * t] = t + 2; M.pat_token[2 * t + 1] = t + 2;
                 if (any_bad) atomicOr(&M.st->fail, 1u);
             }
             if ((uint32_t)lane + kClusterK <= len) {                                          // the 11-mer that starts at this lane
                 const uint32_t x0 = (uint32_t)(b0 >> lane) & 0x7FFu, x1 = (uint32_t)(b1 >> lane) & 0x7FFu;
+                const uint32_t xn = (uint32_t)(mf >> lane) & 0x7FFu;
                 uint32_t code;
-                if (((uint32_t)(mf >> lane) & 0x7FFu) == 0u) {
+                if (xn == 0u) {
                     const uint32_t fwd = spread11(__brev(x0) >> 21) | (spread11(__brev(x1) >> 21) << 1);
                     const uint32_t rev = spread11(~x0) | (spread11(~x1) << 1);
                     code = fwd < rev ? fwd : rev;
-                    atomicMin(&M.owner[code], t);
                 } else {
-                    const uint32_t q = atomicAdd(&M.st->n_badk, 1u);
-                    if (q < kDmBadKmerCap) M.bk_list[q] = (t << 6) | (uint32_t)lane;
-                    code = 1u << 22;
+                    uint64_t fk = 0, rk = 0;
+                    for (int i = 0; i < kClusterK; i++) {
+                        const uint32_t c2 = ((x0 >> i) & 1u) | (((x1 >> i) & 1u) << 1);
+                        const uint64_t c5 = ((xn >> i) & 1u) ? 3u : (c2 == 3u ? 4u : c2);          // A C G N T
+                        const uint64_t cc = 4u - c5;                                                // T G C N A
+                        fk = (fk << 3) | c5;
+                        rk |= cc << (3 * i);
+                    }
+                    const unsigned long long want = (fk < rk ? fk : rk) | (1ull << 40);
+                    uint32_t h = (uint32_t)((want * 0x9E3779B97F4A7C15ull) >> 52) & (kDmBadSlots - 1u);
+                    code = 0;
+                    for (uint32_t probes = 0; probes < kDmBadSlots; probes++) {
+                        const unsigned long long old = atomicCAS(&M.bk_key[h], 0ull, want);
+                        if (old == 0ull) {
+                            if (atomicAdd(&M.st->n_badk, 1u) >= kDmBadKmerCap) atomicOr(&M.st->fail, 1u);
+                            code = (1u << 22) + h; break;
+                        }
+                        if (old == want) { code = (1u << 22) + h; break; }
+                        h = (h + 1) & (kDmBadSlots - 1u);
+                    }
+                    if (!code) { atomicOr(&M.st->fail, 1u); code = 1u << 22; }
                 }
+                atomicMin(&M.owner[code], t);
                 M.codes[(uint64_t)t * M.kmax + lane] = code;
             }
         }
-    }
-}
-
-// ---- 1b. identity of the 11-mers with an 'N': the laurenized 11-mer over A < C < G < N < T (ASCII order; comp_tab
-// maps N to N, SeqUtils.cpp:50-59) as a 33-bit key, id = index of the first equal key, code = (1 << 22) + id.  One
-// small block, a handful of 11-mers per merge and none at all for reads without N.  (Its own launch rather than
-// "the last block of k_dm_pack_codes": a ticket per block costs more than the launch once there is a block per
-// four tokens — thousands of same-address atomics across the XCDs.)
-__global__ __launch_bounds__(256) void k_dm_badk(DevMerge M)
-{
-    __shared__ uint64_t bk_key[kDmBadKmerCap];
-    const uint32_t m = M.st->n_badk;
-    if (m == 0) return;
-    if (m > kDmBadKmerCap) { if (threadIdx.x == 0) atomicOr(&M.st->fail, 1u); return; }
-    for (uint32_t q = threadIdx.x; q < m; q += blockDim.x) {
-        const uint32_t e = M.bk_list[q];
-        const char *str = M.dx_chars + (uint64_t)(e >> 6) * M.stride + (e & 63u);
-        uint64_t fk = 0, rk = 0;
-        for (int i = 0; i < kClusterK; i++) {
-            const char ch = str[i];
-            const uint64_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'N' ? 3u : 4u;
-            const uint64_t cc = c == 0u ? 4u : c == 1u ? 2u : c == 2u ? 1u : c == 3u ? 3u : 0u;      // T G C N A
-            fk = (fk << 3) | c;
-            rk |= cc << (3 * i);
-        }
-        bk_key[q] = fk < rk ? fk : rk;
-    }
-    __syncthreads();
-    for (uint32_t q = threadIdx.x; q < m; q += blockDim.x) {
-        const uint64_t key = bk_key[q];
-        uint32_t id = q;
-        for (uint32_t j = 0; j < q; j++) if (bk_key[j] == key) { id = j; break; }
-        const uint32_t e = M.bk_list[q];
-        const uint32_t t2 = e >> 6, code = (1u << 22) + id;
-        M.codes[(uint64_t)t2 * M.kmax + (e & 63u)] = code;
-        atomicMin(&M.owner[code], t2);
     }
 }
 
@@ -206,6 +173,12 @@ __global__ __launch_bounds__(256) void k_dm_badk(DevMerge M)
 // kmer_clust_size on a repeated sighting", :1573-1590) is then a prefix count across lanes.  root_of[]
 // words are their own flags: written once with an agent-scope store, polled with agent-scope loads
 // (8 XCDs, private L2s).  Every spin is bounded: on a time-out the fail word is set and the host merges.
+// The token's needle key of removeRedundantRepeats — (root, first 16 bases) — only needs its own root, so it is
+// claimed and counted right here (step 4a).
+static __device__ __forceinline__ uint32_t rset_hash(uint32_t g, uint32_t w, uint32_t log_size)
+{
+    return ((w * 0x9E3779B1u) ^ (g * 0x85EBCA6Bu)) >> (32u - log_size);
+}
 __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
 {
     const int lane = threadIdx.x & 63;
@@ -228,7 +201,7 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
             if (__ballot(valid && r == kUnres) == 0ull) break;
             if ((spins & 255u) == 255u) {
                 const uint32_t f = __hip_atomic_load(&M.st->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (f != 0 || spins > (1u << 20)) { gave_up = true; break; }
+                if (f != 0 || spins > (1u << 17)) { gave_up = true; break; }
             }
             __builtin_amdgcn_s_sleep(2);
         }
@@ -245,132 +218,34 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
         const uint64_t win = __ballot(valid && r != kNoLane && c >= M.thr);
         uint32_t root = t;                      // no group reached the threshold: new group (:1595-1606)
         if (win) root = (uint32_t)__shfl((int)r, __ffsll((unsigned long long)win) - 1);
-        if (lane == 0) __hip_atomic_store(&M.root_of[t], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// exclusive scan of n uint32 (n known on the host), one workgroup; *total = sum
-// roots != nullptr: the scanned value of element i is (roots[i] == i), i.e. "token i founded a group"
-__global__ __launch_bounds__(1024) void k_dm_scan(const uint32_t *in, uint32_t *out, uint32_t n, const uint32_t *d_n, uint32_t *total,
-                                                   const uint32_t *roots, const uint32_t *d_exact)
-{
-    if (d_n && *d_n + 1u < n) n = *d_n + 1u;            // per-group arrays: only the first n_groups (+1) entries are live
-    if (d_exact && *d_exact < n) n = *d_exact;          // per-token arrays when the count is only known on the device
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_sh;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_sh = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 4096) {
-        const uint32_t i0 = base + threadIdx.x * 4;
-        uint32_t v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? (roots ? (roots[i0 + k] == i0 + k ? 1u : 0u) : in[i0 + k]) : 0u;
-        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-        uint32_t incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t y = (uint32_t)__shfl_up((int)incl, off);
-            if (lane >= off) incl += y;
+        if (lane == 0) {
+            __hip_atomic_store(&M.root_of[t], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // 4a. needle key of this member
+            const uint32_t g = root + 1, w = (uint32_t)M.packed[(uint64_t)t * 4];
+            const unsigned long long want = ((unsigned long long)g << 32) | w;            // g >= 1: never 0
+            const uint32_t mask = (1u << M.rset_log) - 1u;
+            uint32_t h = rset_hash(g, w, M.rset_log);
+            bool winner = false;
+            for (;;) {
+                const unsigned long long old = atomicCAS(&M.rset_key[h], 0ull, want);
+                if (old == 0ull) { winner = true; break; }
+                if (old == want) break;
+                h = (h + 1) & mask;
+            }
+            atomicAdd(&M.rset_cnt[h], 1u);
+            M.rd_slot[t] = winner ? (h | 0x80000000u) : h;
         }
-        if (lane == 63) wsum[wv] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, all = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { const uint32_t s = wsum[k]; if (k < wv) wbase += s; all += s; }
-        uint32_t run = carry_sh + wbase + incl - mine;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
-        __syncthreads();
-        if (threadIdx.x == 0) carry_sh += all;
-        __syncthreads();
     }
-    if (threadIdx.x == 0 && total) *total = carry_sh;
-}
-
-// ---- 3. group ids: roots numbered in token order (= nextFreeGID++ order, :1598) ----
-// Group sizes and member order.  A few large groups would serialise ~n_tok atomics on a few addresses, so up to
-// kLdsGroups groups are first counted per block in LDS and only the block totals go to memory.
-#define kLdsGroups 4096
-__global__ __launch_bounds__(1024) void k_dm_gid(DevMerge M)
-{
-    __shared__ uint32_t cnt[kLdsGroups];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ng = M.st->n_groups;
-    const bool lds = ng <= kLdsGroups;
-    if (lds) {
-        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) cnt[i] = 0;
-        __syncthreads();
-    }
-    if (t < dm_ntok(M)) {
-        const uint32_t g = M.root_rank[M.root_of[t]];
-        M.gid_of[t] = g + 1;
-        if (lds) atomicAdd(&cnt[g], 1u); else atomicAdd(&M.grp_cnt[g], 1u);
-    }
-    if (lds) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint32_t c = cnt[i]; if (c) atomicAdd(&M.grp_cnt[i], c); }
-    }
-}
-// members[] = tokens ordered by group (order inside a group is irrelevant: it only makes the lanes of
-// a wave walk the same member range below)
-__global__ __launch_bounds__(1024) void k_dm_scatter(DevMerge M)
-{
-    __shared__ uint32_t cnt[kLdsGroups];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ng = M.st->n_groups;
-    const bool lds = ng <= kLdsGroups;
-    if (blockIdx.x == 0)                                // see DevMerge::group_cap
-        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) if (M.grp_cnt[i] > M.group_cap) atomicOr(&M.st->fail, 32u);
-    if (lds) {
-        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) cnt[i] = 0;
-        __syncthreads();
-    }
-    uint32_t g = 0, rank = 0;
-    if (t < dm_ntok(M)) {
-        g = M.gid_of[t] - 1;
-        rank = lds ? atomicAdd(&cnt[g], 1u) : atomicAdd(&M.grp_fill[g], 1u);
-    }
-    if (lds) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) { const uint32_t c = cnt[i]; cnt[i] = c ? atomicAdd(&M.grp_fill[i], c) : 0u; }
-
-        __syncthreads();
-        if (t < dm_ntok(M)) rank += cnt[g];
-    }
-    if (t < dm_ntok(M)) M.members[M.grp_off[g] + rank] = t;
 }
 
 // ---- 4. removeRedundantRepeats: a member is dropped iff a strictly shorter member of its group, or
 // that member's reverse complement, occurs in it (equal-length members are distinct strings; the
 // relation is transitive, so "blanked earlier" never matters).  t or rc(t) in s <=> t in s or in rc(s).
-// The needles are indexed by (group, first 16 bases): every member claims its key in an open-addressing
-// set and the members of one key are laid out contiguously ({len | token << 32, bits lo, bits hi}).  A member
-// j then probes the index with every window of its own string and of its reverse complement in which a
-// member (>= 23 bases) could still start, and compares only the few candidates that share the window's
-// first 16 bases — instead of trying every shorter member at every shift.
-static __device__ __forceinline__ uint32_t rset_hash(uint32_t g, uint32_t w, uint32_t log_size)
-{
-    return ((w * 0x9E3779B1u) ^ (g * 0x85EBCA6Bu)) >> (32u - log_size);
-}
-__global__ __launch_bounds__(256) void k_dm_rd_keys(DevMerge M)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= dm_ntok(M)) return;
-    const uint32_t g = M.gid_of[t], w = (uint32_t)M.packed[(uint64_t)t * 4];
-    const unsigned long long want = ((unsigned long long)g << 32) | w;            // g >= 1: never 0
-    const uint32_t mask = (1u << M.rset_log) - 1u;
-    uint32_t h = rset_hash(g, w, M.rset_log);
-    bool winner = false;
-    for (;;) {
-        const unsigned long long old = atomicCAS(&M.rset_key[h], 0ull, want);
-        if (old == 0ull) { winner = true; break; }
-        if (old == want) break;
-        h = (h + 1) & mask;
-    }
-    atomicAdd(&M.rset_cnt[h], 1u);
-    M.rd_slot[t] = winner ? (h | 0x80000000u) : h;
-}
+// The needles are indexed by (group root, first 16 bases): every member claims its key in an open-addressing
+// set (4a, above) and the members of one key are laid out contiguously ({len | token << 32, bits lo, bits hi, N mask}):
+// 4b allocates the keys' ranges, 4c fills them.  A member j then probes the index with every window of its own string
+// and of its reverse complement in which a member (>= 23 bases) could still start, and compares only the few
+// candidates that share the window's first 16 bases — instead of trying every shorter member at every shift.
 __global__ __launch_bounds__(256) void k_dm_rd_bases(DevMerge M)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -378,7 +253,9 @@ __global__ __launch_bounds__(256) void k_dm_rd_bases(DevMerge M)
     const uint32_t hs = M.rd_slot[t];
     if (!(hs & 0x80000000u)) return;
     const uint32_t h = hs & 0x7FFFFFFFu;
-    M.rset_base[h] = atomicAdd(&M.st->rd_cursor, M.rset_cnt[h]);
+    const uint32_t cnt = M.rset_cnt[h];
+    if (cnt > M.group_cap) atomicOr(&M.st->fail, 32u);
+    M.rset_base[h] = atomicAdd(&M.st->rd_cursor, cnt);
 }
 __global__ __launch_bounds__(256) void k_dm_rd_fill(DevMerge M)
 {
@@ -405,8 +282,9 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t mask = (1u << M.rset_log) - 1u;
+    uint32_t n_surv = 0;                                // this wave's contribution to the state word
     for (uint32_t j = wave; j < dm_ntok(M); j += n_waves) {
-        const uint32_t g = M.gid_of[j];
+        const uint32_t g = M.root_of[j] + 1;
         const uint32_t lenj = M.dx_len[j];
         const uint64_t *pj = M.packed + (uint64_t)j * 4;
         const uint64_t f0 = pj[0], f1 = pj[1], r0 = pj[2], r1 = pj[3];
@@ -456,113 +334,44 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
                 }
             }
         }
-        if (lane == 0) {
-            M.blank[j] = found ? 1 : 0;
-            if (!found) atomicAdd(&M.surv_cnt[g - 1], 1u);
-        }
+        if (lane == 0) M.blank[j] = found ? 1 : 0;
+        if (!found) n_surv++;
     }
-}
-// ---- 5. pattern list: per group (ascending GID) the survivors, then their reverse complements
-// (WorkHorse.cpp:690-697).  Inside a group the survivors are ordered by (length, token) — one of the
-// orders an unstable sort by length may produce; pass 2 depends on the SET only.
-__global__ __launch_bounds__(256) void k_dm_patterns(DevMerge M)
-{
-    __shared__ uint32_t t_key[256];                     // (len << 24) | token for survivors, 0xFFFFFFFF for dropped members
-    __shared__ uint32_t r_lo, r_hi;
-    const uint32_t s0 = blockIdx.x * 256u, s = s0 + threadIdx.x;
-    if (s0 >= dm_ntok(M)) return;                       // (the grid may be sized for a bound: whole blocks past the count)
-    const bool active = s < dm_ntok(M);
-    uint32_t j = 0, g = 0, lo = 0, hi = 0, lenj = 0;
-    bool mine = false;
-    if (active) {
-        j = M.members[s];
-        g = M.gid_of[j] - 1;
-        lo = M.grp_off[g]; hi = lo + M.grp_cnt[g];
-        lenj = M.dx_len[j];
-        mine = M.blank[j] == 0;
-    }
-    if (threadIdx.x == 0) r_lo = lo;
-    const uint32_t s_last = min(dm_ntok(M), s0 + 256u) - 1u;
-    if (s == s_last) r_hi = hi;
-    __syncthreads();
-    const uint32_t rlo = r_lo, rhi = r_hi;
-    const uint32_t my_key = (lenj << 24) | j;           // tokens < 2^20, lengths <= 64
-    uint32_t k = 0;
-    for (uint32_t base = rlo; base < rhi; base += 256u) {
-        const uint32_t idx = base + threadIdx.x;
-        if (idx < rhi) {
-            const uint32_t i = M.members[idx];
-            t_key[threadIdx.x] = M.blank[i] ? 0xFFFFFFFFu : ((uint32_t)M.dx_len[i] << 24) | i;
-        }
-        __syncthreads();
-        if (mine) {
-            const uint32_t a = max(lo, base), b = min(hi, base + 256u);
-            for (uint32_t is = a; is < b; is++) k += t_key[is - base] < my_key ? 1u : 0u;
-        }
-        __syncthreads();
-    }
-    if (!mine) return;
-    const uint32_t E = M.surv_off[g], cnt = M.surv_cnt[g];
-    const uint32_t pf = 2 * E + k, pr = 2 * E + cnt + k;
-    const uint64_t *pj = M.packed + (uint64_t)j * 4;
-    M.pat_packed[(uint64_t)pf * 2] = pj[0]; M.pat_packed[(uint64_t)pf * 2 + 1] = pj[1];
-    M.pat_packed[(uint64_t)pr * 2] = pj[2]; M.pat_packed[(uint64_t)pr * 2 + 1] = pj[3];
-    M.pat_mask[pf] = M.tmask[(uint64_t)j * 2]; M.pat_mask[pr] = M.tmask[(uint64_t)j * 2 + 1];
-    M.pat_len[pf] = (uint16_t)lenj; M.pat_len[pr] = (uint16_t)lenj;
-    // token of the pattern's low-lexi form: the survivor's own token for the survivor and for its reverse
-    // complement alike (a token string is low-lexi by construction, ReadHolder.cpp:573-590)
-    M.pat_token[pf] = j + 2; M.pat_token[pr] = j + 2;
+    if (lane == 0 && n_surv) atomicAdd(&M.st->n_survivors, n_surv);
 }
 
-// ---- 6. anchor keys: every 16-mer at offset 0..7 of a pattern (see kernels.hip, pass-2 fast path).
-// Entry e = pid*8 + r.  Distinct keys are claimed in an open-addressing set; the entries of one key are
-// then laid out contiguously (count -> block allocation -> fill) as the exact verification index of
-// k_dm_verify: {r | len << 3 | pid << 32, pattern bits lo, pattern bits hi}.
+// ---- 6a. anchor keys: every 16-mer at offset 0..7 of a pattern (see kernels.hip, pass-2 fast path).  A member that
+// survived is a pattern (pid 2t) and so is its reverse complement (pid 2t + 1, WorkHorse.cpp:690-697); entry
+// e = pid * 8 + r = 16 t + 8 o + r.  Distinct keys are claimed in an open-addressing set and counted (thread per entry:
+// a wave-per-member form inside k_dm_redundant ran the claims at a quarter of the lanes behind that kernel's probe
+// latency, 13 + 11 us -> 48 us).
 __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t pid = e >> 3, r = e & 7u;
-    const uint32_t n_pat = 2 * M.st->n_survivors;
-    if (pid >= n_pat) return;
-    const uint32_t key = (uint32_t)shr128_lo(M.pat_packed[(uint64_t)pid * 2], M.pat_packed[(uint64_t)pid * 2 + 1], 2 * r);
-    const uint32_t kmask = (1u << M.kset_log) - 1u;
-    const unsigned long long want = (unsigned long long)key | (1ull << 32);
-    uint32_t h = kset_hash(key, M.kset_log);
-    bool winner = false;
-    for (;;) {
-        const unsigned long long old = atomicCAS(&M.kset_key[h], 0ull, want);
-        if (old == 0ull) { winner = true; break; }
-        if (old == want) break;
-        h = (h + 1) & kmask;
+    const uint32_t t = e >> 4, o = (e >> 3) & 1u, r = e & 7u;
+    if (t >= dm_ntok(M)) return;
+    uint32_t slot = 0xFFFFFFFFu;
+    if (!M.blank[t]) {
+        const uint32_t key = (uint32_t)shr128_lo(M.packed[(uint64_t)t * 4 + 2 * o], M.packed[(uint64_t)t * 4 + 2 * o + 1], 2 * r);
+        const uint32_t kmask = (1u << M.kset_log) - 1u;
+        const unsigned long long want = (unsigned long long)key | (1ull << 32);
+        uint32_t h = kset_hash(key, M.kset_log);
+        bool winner = false;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&M.kset_key[h], 0ull, want);
+            if (old == 0ull) { winner = true; break; }
+            if (old == want) break;
+            h = (h + 1) & kmask;
+        }
+        atomicAdd(&M.kset_cnt[h], 1u);
+        slot = winner ? (h | 0x80000000u) : h;
+        if (winner) {
+            atomicAdd(&M.st->n_keys, 1u);
+            atomicMin(&M.st->k0, key);
+            if (key == 0xFFFFFFFFu) atomicOr(&M.st->all_t, 1u);
+        }
     }
-    atomicAdd(&M.kset_cnt[h], 1u);
-    M.ent_slot[e] = h;
-    M.ent_win[e] = winner ? 1 : 0;
-    if (winner) {
-        atomicAdd(&M.st->n_keys, 1u);
-        atomicMin(&M.st->k0, key);
-        if (key == 0xFFFFFFFFu) atomicOr(&M.st->all_t, 1u);
-    }
-}
-__global__ __launch_bounds__(256) void k_dm_key_bases(DevMerge M)
-{
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if ((e >> 3) >= 2 * M.st->n_survivors || !M.ent_win[e]) return;
-    const uint32_t h = M.ent_slot[e];
-    M.kset_base[h] = atomicAdd(&M.st->ent_cursor, M.kset_cnt[h]);
-}
-__global__ __launch_bounds__(256) void k_dm_key_fill(DevMerge M)
-{
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t pid = e >> 3, r = e & 7u;
-    if (pid >= 2 * M.st->n_survivors) return;
-    const uint32_t h = M.ent_slot[e];
-    const uint32_t pos = M.kset_base[h] + atomicAdd(&M.kset_fill[h], 1u);
-    uint64_t *d = M.ents + (uint64_t)pos * 4;
-    d[0] = (uint64_t)(r | ((uint32_t)M.pat_len[pid] << 3)) | ((uint64_t)pid << 32);
-    d[1] = M.pat_packed[(uint64_t)pid * 2];
-    d[2] = M.pat_packed[(uint64_t)pid * 2 + 1];
-    d[3] = M.pat_mask[pid];
+    M.ent_slot[e] = slot;
 }
 
 // table size: load <= 1/3 (<= 1/2 at the limits), as build_anchors (merge.cpp).  Up to 2^14 keys: exact keys in
@@ -587,12 +396,14 @@ static __device__ __forceinline__ void dm_table_params(uint32_t n, uint32_t tab_
     if (ls > tab_log_alloc) ls = 0;
 }
 
-// two-choice cuckoo insertion, all keys at once: a key is always either in the table or in exactly one
-// thread's hand (atomicExch).  0xFFFFFFFF marks a free slot; the all-T key itself is handled by finalize.
-__global__ __launch_bounds__(256) void k_dm_cuckoo_insert(DevMerge M)
+// ---- 6b. the keys' entry ranges of the verification index (count -> block allocation -> fill), and the keys
+// themselves into the cuckoo table.  Two-choice cuckoo insertion, all keys at once: a key is always either in the
+// table or in exactly one thread's hand (atomicExch).  0xFFFFFFFF marks a free slot; the all-T key itself is handled
+// by the last kernel.
+__global__ __launch_bounds__(256) void k_dm_key_bases_insert(DevMerge M)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t pid = e >> 3, r = e & 7u;
+    const uint32_t tok = e >> 4;
     // every thread derives the table shape from the key count (a handful of scalar instructions); thread 0 records it
     uint32_t ls, mode;
     dm_table_params(M.st->n_keys, M.tab_log_alloc, ls, mode);
@@ -600,8 +411,13 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_insert(DevMerge M)
         if (!ls || M.st->n_keys == 0) atomicOr(&M.st->fail, 2u);
         M.st->log_size = ls; M.st->tab_mode = mode; M.st->n_patterns = 2 * M.st->n_survivors;
     }
-    if (!ls || pid >= 2 * M.st->n_survivors || !M.ent_win[e] || (M.st->fail & ~2u)) return;
-    uint32_t cur = (uint32_t)shr128_lo(M.pat_packed[(uint64_t)pid * 2], M.pat_packed[(uint64_t)pid * 2 + 1], 2 * r);
+    if (tok >= dm_ntok(M)) return;
+    const uint32_t hs = M.ent_slot[e];
+    if (hs == 0xFFFFFFFFu || !(hs & 0x80000000u)) return;            // no entry / not the key's claimant
+    const uint32_t h = hs & 0x7FFFFFFFu;
+    M.kset_base[h] = atomicAdd(&M.st->ent_cursor, M.kset_cnt[h]);
+    if (!ls || (M.st->fail & ~2u)) return;
+    uint32_t cur = (uint32_t)M.kset_key[h];
     if (mode == 2) {
         // key sets beyond the LDS tiers: the exact table is probed in L2, behind a 2^20-bit Bloom filter in LDS
         const uint32_t b1 = ((uint32_t)__umul24(cur ^ (cur >> M.s1), M.m1)) >> 12, b2 = ((uint32_t)__umul24(cur ^ (cur >> M.s2), M.m2)) >> 12;
@@ -620,15 +436,28 @@ __global__ __launch_bounds__(256) void k_dm_cuckoo_insert(DevMerge M)
     }
     atomicOr(&M.st->fail, 4u);
 }
-// tab_mode 3: fingerprint = low 16 bits of (h1 product ^ h2 product) of the slot's key, two per word
-// ... and, in the same launch, the per-token results + state words go straight into pinned host memory (a few
-// 10 KB over PCIe, no copy calls): the helper thread rebuilds the host view from them
-__global__ __launch_bounds__(256) void k_dm_cuckoo_fp(DevMerge M)
+// ---- 6c. fill the verification index: {r | len << 3 | pid << 32, pattern bits lo, pattern bits hi, N mask} — and, in the
+// same launch (both only need 6b): unused table slots get a member key, so that a probe never matches by accident;
+// tab_mode 3: fingerprint = low 16 bits of (h1 product ^ h2 product) of the slot's key, two per word; the per-token
+// results + state words go straight into pinned host memory (a few 10 KB over PCIe, no copy calls): the helper thread
+// rebuilds the host view from them
+__global__ __launch_bounds__(256) void k_dm_fill_finish(DevMerge M)
 {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((w >> 4) < dm_ntok(M)) {
+        const uint32_t hs = M.ent_slot[w];
+        if (hs != 0xFFFFFFFFu) {
+            const uint32_t h = hs & 0x7FFFFFFFu, pid = w >> 3, r = w & 7u, t = pid >> 1, o = pid & 1u;
+            const uint32_t pos = M.kset_base[h] + atomicAdd(&M.kset_fill[h], 1u);
+            uint64_t *d = M.ents + (uint64_t)pos * 4;
+            d[0] = (uint64_t)(r | ((uint32_t)M.dx_len[t] << 3)) | ((uint64_t)pid << 32);
+            d[1] = M.packed[(uint64_t)t * 4 + 2 * o];
+            d[2] = M.packed[(uint64_t)t * 4 + 2 * o + 1];
+            d[3] = M.tmask[(uint64_t)t * 2 + o];
+        }
+    }
     if (w == 0) *M.h_st = *M.st;
-    if (w < dm_ntok(M)) { M.h_gid[w] = M.gid_of[w]; M.h_blank[w] = M.blank[w]; }
-    // unused slots get a member key, so that a probe never matches by accident
+    if (w < dm_ntok(M)) { M.h_root[w] = M.root_of[w]; M.h_blank[w] = M.blank[w]; }
     const uint32_t ls = M.st->log_size, k0 = M.st->k0;
     const bool fill = ls && !M.st->all_t;
     if (fill && w < (1u << ls) && M.anchor_tab[w] == 0xFFFFFFFFu) M.anchor_tab[w] = k0;
@@ -705,37 +534,25 @@ hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, 
     return hipGetLastError();
 }
 
-hipError_t launch_device_merge(const DevMerge &M, hipStream_t st)
+hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done)
 {
     if (M.n_tok == 0) return hipErrorInvalidValue;
     const unsigned nb = (M.n_tok + 255) / 256;
-    hipLaunchKernelGGL(k_dm_init, dim3(1024), dim3(256), 0, st, M);
+    if (!init_done) hipLaunchKernelGGL(k_dm_init, dim3(1024), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_pack_codes, dim3((M.n_tok + 3) / 4), dim3(256), 0, st, M);       // one wave per token
-    hipLaunchKernelGGL(k_dm_badk, dim3(1), dim3(256), 0, st, M);
     // every wave must be resident: at most one block per CU (16 waves of the CU's 32 wave slots, no LDS)
     unsigned gb = (M.n_tok + 15) / 16;
     if (gb > M.n_cu) gb = M.n_cu;
     hipLaunchKernelGGL(k_dm_greedy, dim3(gb), dim3(1024), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)nullptr, M.root_rank, M.n_tok, (const uint32_t *)nullptr, &M.st->n_groups,
-                       (const uint32_t *)M.root_of, M.d_ntok);
-    const unsigned nb4 = (M.n_tok + 1023) / 1024;
-    hipLaunchKernelGGL(k_dm_gid, dim3(nb4), dim3(1024), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.grp_cnt, M.grp_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-    hipLaunchKernelGGL(k_dm_scatter, dim3(nb4), dim3(1024), 0, st, M);
-    hipLaunchKernelGGL(k_dm_rd_keys, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
     hipLaunchKernelGGL(k_dm_rd_fill, dim3(nb), dim3(256), 0, st, M);
     unsigned rb = (M.n_tok + 3) / 4;
     if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)M.surv_cnt, M.surv_off, M.n_tok + 1, (const uint32_t *)&M.st->n_groups, &M.st->n_survivors, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-    hipLaunchKernelGGL(k_dm_patterns, dim3(nb), dim3(256), 0, st, M);
     const unsigned ne = (16u * M.n_tok + 255) / 256;
     hipLaunchKernelGGL(k_dm_keys, dim3(ne), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_key_bases, dim3(ne), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_key_fill, dim3(ne), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_cuckoo_insert, dim3(ne), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_cuckoo_fp, dim3(std::max(std::max(128u, nb), (unsigned)(((1ull << M.tab_log_alloc) + 255) / 256))), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_key_bases_insert, dim3(ne), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_fill_finish, dim3(std::max(std::max(128u, ne), (unsigned)(((1ull << M.tab_log_alloc) + 255) / 256))), dim3(256), 0, st, M);
     return hipGetLastError();
 }
 

@@ -115,8 +115,32 @@ template <typename T> struct PinBuf {
 
 } // namespace
 
+// A/B and test switches from the environment, read ONCE per context (crass_hip_create; crass_hip_reload_env re-reads
+// them for a live context) — never on the per-call path
+struct EnvSwitches {
+    bool no_lookback = false, no_pos_hints = false, merge_profile = false, no_lane_kernel = false;
+    bool host_merge = false, no_speculation = false, exc_separate = false, dm_inject_fail = false, dm_init_late = false;
+    uint32_t row_cap = 2048, dm_group_cap = 16384, surv_debug = 0;
+    int stage_timing = -1;
+    uint64_t pool_cap_bytes = 0;                     // tests: device allocations beyond this total fail with hipErrorOutOfMemory
+    void read()
+    {
+        auto on = [](const char *n) { return getenv(n) != nullptr; };
+        no_lookback = on("CRASS_NO_LOOKBACK"); no_pos_hints = on("CRASS_NO_POS_HINTS");
+        merge_profile = on("CRASS_MERGE_PROFILE"); no_lane_kernel = on("CRASS_NO_LANE_KERNEL"); host_merge = on("CRASS_HOST_MERGE");
+        no_speculation = on("CRASS_NO_SPECULATION"); exc_separate = on("CRASS_EXC_SEPARATE"); dm_init_late = on("CRASS_DM_INIT_LATE");
+        dm_inject_fail = on("CRASS_DM_INJECT_FAIL");
+        row_cap = 2048; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
+        dm_group_cap = 16384; if (const char *e = getenv("CRASS_DM_GROUP_CAP")) dm_group_cap = (uint32_t)std::max(1, atoi(e));
+        surv_debug = 0; if (const char *e = getenv("CRASS_SURV_DEBUG")) surv_debug = (uint32_t)atoi(e);
+        stage_timing = -1; if (const char *e = getenv("CRASS_STAGE_TIMING")) stage_timing = std::min(2, std::max(0, atoi(e)));
+        pool_cap_bytes = 0; if (const char *e = getenv("CRASS_POOL_CAP_MB")) pool_cap_bytes = (uint64_t)std::max(1ll, atoll(e)) << 20;
+    }
+};
+
 struct crass_hip_ctx {
     crass_params prm{};
+    EnvSwitches env;
     DevParams dp{};
     int device = 0;
     hipStream_t stream = nullptr;
@@ -165,22 +189,22 @@ struct crass_hip_ctx {
     // fast path: the found records are gathered on the device into dense arrays and land in pinned
     // host memory already in the hand-off layout (no per-record host work)
     mutable struct P1Dense {
-        DevBuf<uint64_t> d_read, d_ss_off; DevBuf<uint8_t> d_low; DevBuf<uint32_t> d_replen, d_nss, d_ss; DevBuf<uint16_t> d_dr_len; DevBuf<char> d_dr;
+        DevBuf<uint16_t> d_dr_len; DevBuf<char> d_dr;       // dense DR strings of the found records (input of the de-duplication)
         uint64_t n = 0;
         bool active = false;
-        // the used part of the arrays above, packed on the device (p1_blob_layout) and copied with one call
-        PinBuf<uint8_t> h_blob;
-        DevBuf<uint8_t> d_blob;                     // the hand-off blob is assembled on the device and copied by the runtime
+        // everything else of the found records: the compact hand-off blob (p1_blob_layout), assembled by the gather kernel
+        // in device memory; its used bytes are copied by the runtime on the copy stream once the host knows the record
+        // count (beside the merge kernels; bulk_pending until wait_bulk())
+        PinBuf<uint8_t> h_blob; DevBuf<uint8_t> d_blob;
         P1Blob lay{};
-        uint64_t pack_cap = 0; uint32_t pack_ss_cap = 0;
+        uint32_t pack_ss_cap = 0;
         // the ABI's wide per-candidate arrays (crass_candidates), widened from the compact blob on first request
         bool wide_ready = false;
         std::vector<uint32_t> w_replen, w_nss, w_ss; std::vector<uint64_t> w_ss_off; std::vector<uint16_t> w_dr_len; std::vector<char> w_dr;
         PinBuf<char> h_dr_fb; PinBuf<uint16_t> h_dr_len_fb; bool dr_fallback = false;    // candidates' own strings (no distinct list)
         void release()
         {
-            h_blob.release(); d_blob.release(); h_dr_fb.release(); h_dr_len_fb.release();
-            d_read.release(); d_ss_off.release(); d_low.release(); d_replen.release(); d_nss.release(); d_ss.release(); d_dr_len.release(); d_dr.release();
+            h_blob.release(); d_blob.release(); h_dr_fb.release(); h_dr_len_fb.release(); d_dr_len.release(); d_dr.release();
         }
     } dense;
     DevBuf<uint64_t> d_fidx;
@@ -190,8 +214,7 @@ struct crass_hip_ctx {
     PinBuf<uint32_t> h_rep; PinBuf<uint64_t> h_hash;
     bool have_rep = false;
     // device-side token ranks: distinct strings (first-occurrence order) + every candidate's distinct index.
-    // With these the host merge never touches the per-candidate strings, whose D2H then overlaps the merge
-    // on a second stream (bulk_pending until wait_bulk()).
+    // With these the host merge never touches the per-candidate strings.
     DevBuf<uint32_t> dd_map; DevBuf<char> dd_dx_chars; DevBuf<uint16_t> dd_dx_len; DevBuf<uint64_t> dd_dx_hash;
     PinBuf<uint32_t> h_dmap; PinBuf<char> h_dx_chars; PinBuf<uint16_t> h_dx_len; PinBuf<uint64_t> h_dx_hash;
     uint64_t n_dx = 0;
@@ -203,38 +226,9 @@ struct crass_hip_ctx {
     bool recruit_exact = false;               // the next recruit call must not speculate (it repeats an overflowed one)               // speculative survivor bound for the next seed scan (0: none yet)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gathered = nullptr;
-    hipEvent_t bulk_gate = nullptr;                 // what issue_bulk() waits for (ev_gathered, or the merge's ev_done)
-    mutable bool bulk_pending = false;          // copy in flight on copy_stream
-    mutable bool bulk_needed = false;           // copy not issued yet (it is issued behind the merge's kernel launches)
-    // The per-candidate records go to pinned host memory on the copy stream: the pack kernel writes them there
-    // itself (PCIe-bound, ~2 MB per 10 M reads).  It is launched right behind the pass-2 filter — a long,
-    // compute-bound kernel next to which the transfer is free — or at the latest when somebody asks for the records.
-    void issue_bulk() const
-    {
-        if (!bulk_needed) return;
-        bulk_needed = false;
-        const P1Dense &D = dense;
-        (void)hipStreamWaitEvent(copy_stream, bulk_gate ? bulk_gate : ev_gathered, 0);
-        // The blob is assembled in device memory and its used bytes copied by the runtime (the copy engine): a kernel
-        // that stores to pinned host memory stretches whatever compute kernel runs beside it by about its own duration
-        // on this stack (45 us per step at 10 M reads, 0.36 ms at 100 M).  CRASS_PACK_KERNEL: the old way, for A/B.
-        if (!getenv("CRASS_PACK_KERNEL") && D.lay.total) {
-            P1Dense &W = const_cast<P1Dense &>(dense);
-            if (W.d_blob.ensure(D.h_blob.n) == hipSuccess) {
-                (void)launch_pack_p1_blob(d_count.p + 2, D.pack_cap, D.pack_ss_cap, D.d_read.p, D.d_replen.p, D.d_nss.p, D.d_low.p, D.d_ss.p,
-                                          W.d_blob.p, copy_stream);
-                (void)hipMemcpyAsync(D.h_blob.p, W.d_blob.p, D.lay.total, hipMemcpyDeviceToHost, copy_stream);
-                bulk_pending = true;
-                return;
-            }
-        }
-        (void)launch_pack_p1_blob(d_count.p + 2, D.pack_cap, D.pack_ss_cap, D.d_read.p, D.d_replen.p, D.d_nss.p, D.d_low.p, D.d_ss.p,
-                                  D.h_blob.p, copy_stream);
-        bulk_pending = true;
-    }
+    mutable bool bulk_pending = false;          // rare paths only: D2H copies of the candidates' own strings in flight on copy_stream
     void wait_bulk() const
     {
-        issue_bulk();
         if (!bulk_pending) return;
         (void)hipStreamSynchronize(copy_stream);
         bulk_pending = false;
@@ -243,11 +237,12 @@ struct crass_hip_ctx {
     // index are built on the device; the host view (c->merge) is rebuilt from its per-token results while
     // pass 2 runs.  dm.active: the installed pattern set lives in dm.M, not in the automaton/anchors above.
     struct DM {
-        DevBuf<uint64_t> packed, pat_packed, tmask, pat_mask; DevBuf<uint32_t> bk_list; DevBuf<uint32_t> codes, owner, root_of, tmp, root_rank, gid_of, grp, members, pat_token;
-        DevBuf<uint32_t> kset_u32, ent_slot, anchor_tab, anchor_fp; DevBuf<uint8_t> blank, sblank, ent_win; DevBuf<uint16_t> pat_len; DevBuf<uint64_t> ents, rents; DevBuf<uint32_t> rset_u32, rd_slot;
-        DevBuf<unsigned long long> rset_key;
+        DevBuf<uint64_t> packed, tmask; DevBuf<uint32_t> codes, owner, root_of, pat_token;
+        DevBuf<uint32_t> kset_u32, ent_slot, anchor_tab, anchor_fp; DevBuf<uint8_t> blank; DevBuf<uint64_t> ents, rents; DevBuf<uint32_t> rset_u32, rd_slot;
+        DevBuf<unsigned long long> rset_key, bk_key;
         DevBuf<unsigned long long> kset_key; DevBuf<DevMergeState> st;
-        PinBuf<DevMergeState> h_st; PinBuf<uint32_t> h_gid; PinBuf<uint8_t> h_blank;
+        PinBuf<DevMergeState> h_st; PinBuf<uint32_t> h_root; PinBuf<uint8_t> h_blank;
+        std::vector<uint32_t> gid_tmp;
         DevMerge M{};
         bool active = false, host_built = false;
         int build_status = 0;                       // result of the host-view build that runs on `worker`
@@ -264,9 +259,9 @@ struct crass_hip_ctx {
         hipEvent_t ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
         void release()
         {
-            packed.release(); pat_packed.release(); tmask.release(); pat_mask.release(); bk_list.release(); codes.release(); owner.release(); root_of.release(); tmp.release(); root_rank.release();
-            gid_of.release(); grp.release(); members.release(); pat_token.release(); kset_u32.release(); ent_slot.release(); anchor_tab.release(); anchor_fp.release();
-            blank.release(); sblank.release(); ents.release(); ent_win.release(); rents.release(); rset_u32.release(); rd_slot.release(); rset_key.release(); pat_len.release(); kset_key.release(); st.release(); h_st.release(); h_gid.release(); h_blank.release();
+            packed.release(); tmask.release(); bk_key.release(); codes.release(); owner.release(); root_of.release();
+            pat_token.release(); kset_u32.release(); ent_slot.release(); anchor_tab.release(); anchor_fp.release();
+            blank.release(); ents.release(); rents.release(); rset_u32.release(); rd_slot.release(); rset_key.release(); kset_key.release(); st.release(); h_st.release(); h_root.release(); h_blank.release();
             g_chars.release(); gx_chars.release(); g_len.release(); gx_len.release(); g_keys.release(); g_first.release(); g_slot.release();
             g_rep.release(); g_prefix.release(); g_bsum.release(); g_hash.release(); g_mask.release(); g_idx.release();
             h_gmap.release(); h_gx_chars.release(); h_gx_len.release(); h_gx_hash.release();
@@ -350,6 +345,8 @@ struct crass_hip_ctx {
     // the device merge queued by the seed scan itself, right behind pass 1 (no host round trip in between): sized by a
     // bound learnt from the previous merge, adopted by crass_hip_merge when the counts turn out to fit
     uint32_t dx_cap_hint = 0; bool dm_prev_local = false; int premerge = 0;      // premerge: 0 none, 2 queued and valid
+    // a merge sized ahead of pass 1's survivor stage, whose kernel cleared the merge's tables (device_merge_prepare)
+    uint64_t dm_prepared_n = 0; const char *dm_prepared_src = nullptr;
     bool premerge_inflight = false;                 // merge kernels may still be running when the seed scan returns
     double t_p1_sync = 0;                           // CRASS_MERGE_PROFILE: host time line between pass 1 and the merge
     bool spans_p1 = false, spans_p2 = false, span_survivors = false;     // spans to evaluate at the next counters fetch
@@ -381,11 +378,12 @@ void crass_hip_ctx::widen_p1() const
     const uint32_t ss_cap = D.pack_ss_cap, stride = dr_stride;
     const uint8_t *hb = D.h_blob.p;
     const uint16_t *b_replen = (const uint16_t *)(hb + D.lay.replen), *b_ss = (const uint16_t *)(hb + D.lay.ss);
-    const uint8_t *b_nss = hb + D.lay.nss;
+    const uint8_t *b_nss = hb + D.lay.nss, *b_ss8 = hb + D.lay.ss;
     D.w_replen.resize(n); D.w_nss.resize(n); D.w_ss_off.resize(n); D.w_ss.resize(n * (size_t)ss_cap);
     D.w_dr_len.resize(n); D.w_dr.resize(n * (size_t)stride);
     for (uint64_t k = 0; k < n; k++) { D.w_replen[k] = b_replen[k]; D.w_nss[k] = b_nss[k]; D.w_ss_off[k] = k * (uint64_t)ss_cap; }
-    for (uint64_t i = 0; i < n * (uint64_t)ss_cap; i++) D.w_ss[i] = b_ss[i];
+    if (D.lay.ss_elem == 1) for (uint64_t i = 0; i < n * (uint64_t)ss_cap; i++) D.w_ss[i] = b_ss8[i];
+    else for (uint64_t i = 0; i < n * (uint64_t)ss_cap; i++) D.w_ss[i] = b_ss[i];
     if (D.dr_fallback) {
         (void)hipStreamSynchronize(copy_stream);
         memcpy(D.w_dr.data(), D.h_dr_fb.p, n * (size_t)stride);
@@ -467,9 +465,10 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     uint32_t skips = p->lowDRsize - (2 * p->searchWindowLength - 1);     // unsigned, libcrispr.cpp:281
     if (skips < 1) skips = 1;
     c->dp.skips = skips;
-    { const char *dbg = getenv("CRASS_SURV_DEBUG"); c->dp.debug_stop = dbg ? (uint32_t)atoi(dbg) : 0; }
-    if (const char *tl = getenv("CRASS_STAGE_TIMING")) c->timing_level = std::min(2, std::max(0, atoi(tl)));
-    if (getenv("CRASS_NO_LOOKBACK")) c->lb_on = false;           // A/B switch: three-kernel compaction
+    c->env.read();
+    c->dp.debug_stop = c->env.surv_debug;
+    if (c->env.stage_timing >= 0) c->timing_level = c->env.stage_timing;
+    if (c->env.no_lookback) c->lb_on = false;                    // A/B switch: three-kernel compaction
     c->dr_stride = (p->highDRsize + 15u) & ~15u;
     if (hipSetDevice(device) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
@@ -488,6 +487,16 @@ int crass_hip_stream_wait_event(crass_hip_ctx *c, void *event)
     if (!c || !event) return CRASS_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     HIPCHK(c, hipStreamWaitEvent(c->stream, (hipEvent_t)event, 0));
+    return CRASS_OK;
+}
+
+int crass_hip_reload_env(crass_hip_ctx *c)
+{
+    if (!c) return CRASS_ERR_INVALID_ARG;
+    c->env.read();
+    c->dp.debug_stop = c->env.surv_debug;
+    if (c->env.stage_timing >= 0) c->timing_level = c->env.stage_timing;
+    c->lb_on = !c->env.no_lookback;
     return CRASS_OK;
 }
 
@@ -568,7 +577,7 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     c->R.pos_hint = nullptr; c->R.pos_hint_off = nullptr;
     const DevParams &P = c->dp;
     if (c->max_len <= 2048 || n == 0 || P.window != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return CRASS_OK;
-    if (getenv("CRASS_NO_POS_HINTS")) return CRASS_OK;             // A/B switch
+    if (c->env.no_pos_hints) return CRASS_OK;             // A/B switch
     std::vector<uint64_t> off(n + 1);
     uint64_t at = 0;
     for (uint64_t i = 0; i < n; i++) { off[i] = at; at += ((uint64_t)(lengths ? lengths[i] : uniform_len) + 63) / 64; }
@@ -710,8 +719,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     // redone by a second launch with the uncapped layout.
     const SurvLds lds_full = survivor_lds_layout(c->max_len, c->dp);
     if (lds_full.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
-    uint32_t row_cap = 2048;
-    if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));        // tests: force the second launch
+    const uint32_t row_cap = c->env.row_cap;            // (tests: CRASS_ROW_CAP forces the second launch)
     const SurvLds lds = survivor_lds_layout(c->max_len, c->dp, row_cap);
     const bool capped = lds.row_elems != lds_full.row_elems;
     const uint64_t chunk_cap = std::min<uint64_t>(n_total, 1u << 20);
@@ -778,7 +786,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             L.dr_len.push_back(o.dr_len);
             L.dr.insert(L.dr.end(), drs + k * stride, drs + (k + 1) * stride);
         }
-        if (getenv("CRASS_MERGE_PROFILE"))
+        if (c->env.merge_profile)
             fprintf(stderr, "[crass_sink] survivors %llu: kernel+D2H wait %.3f ms, pool D2H %.3f ms, host loop %.3f ms\n",
                     (unsigned long long)nchunk, tq1 - tq0, tq2 - tq1, now_ms() - tq2);
     }
@@ -803,7 +811,8 @@ static uint64_t survivor_bound(uint64_t n_surv)        // the speculative bound 
 // n_surv: number of filter survivors, or (speculative mode: d_nsurv = the compaction's device-side count, no host
 // round trip before this call) an upper bound for it.  The exact count then arrives with the final copy of
 // the counters; *overflow is set when it exceeds the bound (nothing of this call is valid then).
-static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok);
+static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok);
+static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok, bool prepared = false);
 
 static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t *d_nsurv, bool *overflow)
 {
@@ -822,23 +831,47 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     HIPCHK(c, c->d_dr.ensure(n_alloc * stride));
     HIPCHK(c, c->d_ss_pool.ensure(std::max<uint64_t>(pool_cap, n_alloc * (uint64_t)lds.ss_cap)));
     HIPCHK(c, c->d_fidx.ensure(n_alloc));
-    HIPCHK(c, D.d_read.ensure(n_alloc + 2)); HIPCHK(c, D.d_ss_off.ensure(n_alloc + 2)); HIPCHK(c, D.d_low.ensure(n_alloc + 16));
-    HIPCHK(c, D.d_replen.ensure(n_alloc + 4)); HIPCHK(c, D.d_nss.ensure(n_alloc + 4)); HIPCHK(c, D.d_dr_len.ensure(n_alloc + 8));
-    HIPCHK(c, D.d_dr.ensure(n_alloc * stride + 16)); HIPCHK(c, D.d_ss.ensure(n_alloc * (uint64_t)lds.ss_cap + 4));
+    HIPCHK(c, D.d_dr_len.ensure(n_alloc + 8)); HIPCHK(c, D.d_dr.ensure(n_alloc * stride + 16));
+    const uint32_t ss_elem = c->max_len <= 256 ? 1u : 2u;            // read positions fit a byte
+    HIPCHK(c, D.h_blob.ensure(p1_blob_layout(n_alloc, lds.ss_cap, ss_elem).total + 64));
+    HIPCHK(c, D.d_blob.ensure(D.h_blob.n));
     // [2] = found count, [3] = worst error, [4] = n distinct, [5] = de-duplication mismatch flag
     if (!speculative) {                                 // (speculative launch: cleared by the filter's compaction, see seed scan)
         HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 16, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
     }
+    // The merge that will follow this stage is sized here already when the previous call's merge ran on the device (its
+    // kernels read the token count from the device and are sized by a bound): the survivor kernel then clears the
+    // merge's tables on its way, and the merge is queued right behind pass 1's tail further down.
+    const bool dedupe = n_surv < (1u << 24);
+    c->dm_prepared_n = 0; c->dm_prepared_src = nullptr;
+    const DevMerge *init_merge = nullptr;
+    if (speculative && dedupe && c->prm.lowDRsize >= 23 && stride <= 64 && !c->env.host_merge && !c->env.no_speculation && !c->env.dm_init_late) {
+        const char *src = nullptr; const uint16_t *src_len = nullptr; uint64_t bound = 0;
+        if (!c->xchg.active && c->dm_prev_local && c->dx_cap_hint) {
+            HIPCHK(c, c->dd_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_alloc));
+            src = c->dd_dx_chars.p; src_len = c->dd_dx_len.p; bound = c->dx_cap_hint;
+        } else if (c->xchg.active && c->xchg.gx_cap_hint && c->xchg.gx_cap_hint <= c->xchg.world * c->xchg.cap) {
+            const uint64_t n_max = c->xchg.world * c->xchg.cap;
+            HIPCHK(c, c->dm.gx_chars.ensure((size_t)n_max * stride + 16)); HIPCHK(c, c->dm.gx_len.ensure(n_max));
+            src = c->dm.gx_chars.p; src_len = c->dm.gx_len.p; bound = c->xchg.gx_cap_hint;
+        }
+        if (src) {
+            const int ps = device_merge_prepare(c, src, src_len, bound, c->d_count.p + 4);
+            if (ps) return ps;
+            init_merge = &c->dm.M;
+        }
+    }
     HIPCHK(c, c->stamp(8, 1));
     // lane-per-read kernel for uniform short reads; whatever it punts (err == 4) and every other
     // layout goes through the wave-per-read kernel
     const uint32_t *hints = c->hints_valid ? c->d_hit_info.p : nullptr;
-    const bool no_lanes = getenv("CRASS_NO_LANE_KERNEL") != nullptr;
+    const bool no_lanes = c->env.no_lane_kernel;
     hipError_t le = no_lanes ? hipErrorNotSupported
                              : launch_survivor_lanes(c->R, c->dp, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
-                                                     c->d_ss_pool.p, lds.ss_cap, c->d_found.p, hints, c->stream);
+                                                     c->d_ss_pool.p, lds.ss_cap, c->d_found.p, hints, c->stream, init_merge);
     if (le != hipSuccess && le != hipErrorNotSupported) { c->last_hip = (int)le; return CRASS_ERR_HIP; }
+    if (le == hipSuccess && init_merge) { c->dm_prepared_n = init_merge->n_tok; c->dm_prepared_src = init_merge->dx_chars; }
     HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
                               c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, hints, lds,
                               (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, le == hipSuccess ? 4 : 0));
@@ -848,7 +881,6 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
                                   (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, 5));
     HIPCHK(c, c->stamp(9, 1));
     const uint64_t n_words = (n_surv + 63) / 64;
-    const bool dedupe = n_surv < (1u << 24);
     uint32_t tsize = 1024;
     if (dedupe) {
         while (tsize < n_surv * 2) tsize <<= 1;
@@ -866,9 +898,11 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
                                     dedupe ? c->dd_keys.p : nullptr, dedupe ? c->dd_first.p : nullptr, tsize));
         HIPCHK(c, launch_compact(c->d_mask.p, n_words, n_surv, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, n_surv, c->d_count.p + 2, c->stream));
     }
+    if (dedupe) { HIPCHK(c, c->dd_slot.ensure(n_alloc)); HIPCHK(c, c->dd_hash.ensure(n_alloc)); }
+    // the gather assembles the hand-off blob and inserts every candidate's DR string into the de-duplication table
     HIPCHK(c, launch_gather_found(c->d_fidx.p, c->d_count.p + 2, n_surv, c->d_surv.p, c->d_idx.p, c->read_base, c->d_dr.p, stride,
-                                  c->d_ss_pool.p, lds.ss_cap, D.d_read.p, D.d_low.p, D.d_replen.p, D.d_nss.p, D.d_ss_off.p,
-                                  D.d_dr_len.p, D.d_dr.p, D.d_ss.p, c->stream));
+                                  c->d_ss_pool.p, lds.ss_cap, ss_elem, D.d_blob.p, D.d_dr_len.p, D.d_dr.p, c->stream,
+                                  dedupe ? c->dd_keys.p : nullptr, dedupe ? c->dd_first.p : nullptr, tsize, c->dd_hash.p, c->dd_slot.p));
     // de-duplication and token ranks follow without a host round trip (the found count stays on the device);
     // their small outputs — all the merge needs — are written straight into pinned host memory
     c->have_rep = false;
@@ -879,37 +913,28 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         HIPCHK(c, c->h_dmap.ensure(n_alloc)); HIPCHK(c, c->h_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(n_alloc));
         HIPCHK(c, c->h_dx_hash.ensure(n_alloc));
         HIPCHK(c, c->dd_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_alloc));
-        HIPCHK(c, launch_dr_dedupe(D.d_dr.p, D.d_dr_len.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_keys.p, c->dd_first.p, tsize,
-                                   c->dd_hash.p, c->dd_slot.p, c->dd_rep.p, c->stream, true));
         // distinct strings in first-occurrence order and every candidate's rank among them, exact
         Lookback lbd;
         HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->dd_slot.p, c->dd_first.p, c->d_mask.p,
                                    c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
                                    c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream,
                                    c->d_count.p, c->h_count.p, 8,           // (the counters leave with the last kernel: no copy call)
-                                   c->next_lookback((n_surv + 63) / 64, &lbd)));
+                                   c->next_lookback_tiles((n_surv + 1023) / 1024, &lbd)));
         if (c->xchg.active)                             // multi-rank: the list goes straight into the collective's send buffer
             HIPCHK(c, launch_xg_fill(c->dd_dx_chars.p, c->dd_dx_len.p, c->d_count.p + 4, stride, c->xchg.cap, c->xchg.slot, c->xchg.send.p, c->stream));
     }
     if (!dedupe) HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 32, hipMemcpyDeviceToHost, c->stream));
     bool premerge_queued = false;
     c->premerge = 0;
-    {
-        // the per-candidate records go to pinned host memory on the copy stream (the pack kernel writes them there
-        // itself), behind the gather: they are not needed before the hand-off
-        const uint64_t cap = p1_blob_layout(n_alloc, lds.ss_cap).total + 64;
-        D.wide_ready = false; D.dr_fallback = false;
-        HIPCHK(c, D.h_blob.ensure(cap));
-        HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
-        c->bulk_gate = c->ev_gathered;
-        D.pack_cap = n_surv; D.pack_ss_cap = lds.ss_cap;
-        c->bulk_needed = true;                          // launched by issue_bulk(): next to the pass-2 filter, where it is free
-    }
+    D.wide_ready = false; D.dr_fallback = false;
+    D.pack_ss_cap = lds.ss_cap;
+    HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
     // The merge itself is queued here too when the previous call's merge ran on the device: its kernels read the token
     // count from the device (d_count[4]) and are sized by a bound; crass_hip_merge adopts the result if the counts fit.
     if (speculative && dedupe && !c->xchg.active && c->dm_prev_local && c->dx_cap_hint && c->prm.lowDRsize >= 23 && stride <= 64 &&
-        !getenv("CRASS_HOST_MERGE") && !getenv("CRASS_NO_SPECULATION")) {
-        const int ps = device_merge_enqueue(c, c->dd_dx_chars.p, c->dd_dx_len.p, c->dx_cap_hint, c->d_count.p + 4);
+        !c->env.host_merge && !c->env.no_speculation) {
+        const bool prepared = c->dm_prepared_n == c->dx_cap_hint && c->dm_prepared_src == c->dd_dx_chars.p;
+        const int ps = device_merge_enqueue(c, c->dd_dx_chars.p, c->dd_dx_len.p, c->dx_cap_hint, c->d_count.p + 4, prepared);
         if (ps) return ps;
         premerge_queued = true;
     }
@@ -925,7 +950,11 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     const uint32_t err = c->h_count.p[3];
     if (err == 1) return CRASS_ERR_SEARCH_FATAL;
     if (err) return CRASS_ERR_OVERFLOW;
-    D.lay = p1_blob_layout(nf, lds.ss_cap);
+    D.lay = p1_blob_layout(nf, lds.ss_cap, ss_elem);
+    if (nf) {           // the hand-off records: the host has waited for the gather, the copy runs beside whatever follows
+        HIPCHK(c, hipMemcpyAsync(D.h_blob.p, D.d_blob.p, D.lay.total, hipMemcpyDeviceToHost, c->copy_stream));
+        c->bulk_pending = true;
+    }
     if (nf && !dedupe) {                                // no distinct list: the candidates' own strings travel
         HIPCHK(c, D.h_dr_fb.ensure(nf * stride + 16)); HIPCHK(c, D.h_dr_len_fb.ensure(nf + 8));
         HIPCHK(c, hipMemcpyAsync(D.h_dr_fb.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, c->copy_stream));
@@ -977,7 +1006,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     const bool use_filter = c->max_len <= 2048;
     // exception reads (a byte outside ACGT) join the survivor list and are evaluated byte-wise in place, so that
     // the dense pass-1 path also holds for inputs with a few N reads
-    c->dp.exc_survive = (use_filter && c->R.n_exc > 0 && !getenv("CRASS_EXC_SEPARATE")) ? 1u : 0u;
+    c->dp.exc_survive = (use_filter && c->R.n_exc > 0 && !c->env.exc_separate) ? 1u : 0u;
     if (use_filter) {
         hipError_t fe = hipErrorNotSupported;
         // (uniform STRIDE is what the bit-parallel kernel needs; the lengths may differ — trimmed reads padded to one stride)
@@ -1013,7 +1042,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     // count still on the device, sized by a bound learnt from the previous call (twice its count).  If the
     // bound turns out too small the stage is simply redone below with the exact count.
     const bool exc_ok = c->R.n_exc == 0 || c->dp.exc_survive;
-    if (use_filter && exc_ok && c->surv_cap_hint && !getenv("CRASS_NO_SPECULATION")) {
+    if (use_filter && exc_ok && c->surv_cap_hint && !c->env.no_speculation) {
         bool overflow = false;
         HIPCHK(c, c->stamp(3, 2));
         s = run_survivors_dense(c, c->surv_cap_hint, c->d_count.p, &overflow);
@@ -1164,7 +1193,7 @@ static int install_patterns(crass_hip_ctx *c, const StringArena &pats)
     for (size_t i = 0; i < pats.size(); i++) if (pats.len(i) == 0 || pats.len(i) > 255) return CRASS_ERR_UNSUPPORTED;
     HostAutomaton &H = c->H;
     HostAnchors HK;
-    const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
+    const bool prof = c->env.merge_profile;
     const double tb0 = now_ms();
     build_automaton_and_anchors(H, HK, pats);
     const double tb2 = now_ms();
@@ -1236,7 +1265,7 @@ static int build_host_merge(crass_hip_ctx *c);
 // ---- the merge on the device (dmerge.hip) ----
 static bool device_merge_applies(const crass_hip_ctx *c)
 {
-    if (getenv("CRASS_HOST_MERGE")) return false;                 // A/B switch: force the host merge (merge.cpp)
+    if (c->env.host_merge) return false;                 // A/B switch: force the host merge (merge.cpp)
     return c->have_pass1 && c->dense.active && c->have_dev_tokens && c->prm.lowDRsize >= 23 &&
            c->dr_stride <= 64 && c->n_dx <= (1u << 20);
 }
@@ -1244,7 +1273,8 @@ static bool device_merge_applies(const crass_hip_ctx *c)
 // dx_*: distinct strings in token order on the device; hx_*: the same list in pinned host memory
 // the kernels only (n_tok: the token count, or — with d_ntok — the bound the launch is sized for while the count is
 // still on the device); the context's state is untouched until device_merge_commit
-static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok)
+// buffers + the kernels' argument block for a merge over (up to) n_tok tokens; nothing is launched
+static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok)
 {
     crass_hip_ctx::DM &d = c->dm;
     const uint32_t n = (uint32_t)n_tok, stride = c->dr_stride;
@@ -1257,27 +1287,20 @@ static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const ui
     M.thr = (uint32_t)std::max(c->prm.kmer_clust_size, 2); M.kmax = stride - 10;
     M.kset_log = 10; while ((1ull << M.kset_log) < 32ull * n) M.kset_log++;
     M.tab_log_alloc = 16; while (M.tab_log_alloc < 24 && (1ull << M.tab_log_alloc) < 48ull * n) M.tab_log_alloc++;
-    HIPCHK(c, d.packed.ensure((size_t)n * 4)); HIPCHK(c, d.codes.ensure((size_t)n * M.kmax)); HIPCHK(c, d.owner.ensure((1u << 22) + kDmBadKmerCap));
-    HIPCHK(c, d.tmask.ensure((size_t)n * 2)); HIPCHK(c, d.pat_mask.ensure((size_t)n * 2)); HIPCHK(c, d.bk_list.ensure(kDmBadKmerCap));
-    HIPCHK(c, d.root_of.ensure(n)); HIPCHK(c, d.tmp.ensure(n + 1)); HIPCHK(c, d.root_rank.ensure(n + 1)); HIPCHK(c, d.gid_of.ensure(n));
-    HIPCHK(c, d.grp.ensure(5 * ((size_t)n + 1))); HIPCHK(c, d.members.ensure(n)); HIPCHK(c, d.blank.ensure(n));
-    HIPCHK(c, d.pat_packed.ensure((size_t)n * 4)); HIPCHK(c, d.pat_len.ensure((size_t)n * 2)); HIPCHK(c, d.pat_token.ensure((size_t)n * 2));
+    HIPCHK(c, d.packed.ensure((size_t)n * 4)); HIPCHK(c, d.codes.ensure((size_t)n * M.kmax)); HIPCHK(c, d.owner.ensure((1u << 22) + kDmBadSlots));
+    HIPCHK(c, d.tmask.ensure((size_t)n * 2)); HIPCHK(c, d.bk_key.ensure(kDmBadSlots));
+    HIPCHK(c, d.root_of.ensure(n)); HIPCHK(c, d.blank.ensure(n)); HIPCHK(c, d.pat_token.ensure((size_t)n * 2));
     HIPCHK(c, d.kset_key.ensure((size_t)1 << M.kset_log)); HIPCHK(c, d.kset_u32.ensure((size_t)3 << M.kset_log));
-    HIPCHK(c, d.ent_slot.ensure((size_t)n * 16)); HIPCHK(c, d.ent_win.ensure((size_t)n * 16)); HIPCHK(c, d.ents.ensure((size_t)n * 64));
-    HIPCHK(c, d.sblank.ensure(n));
+    HIPCHK(c, d.ent_slot.ensure((size_t)n * 16)); HIPCHK(c, d.ents.ensure((size_t)n * 64));
     M.rset_log = 10; while ((1ull << M.rset_log) < 4ull * n) M.rset_log++;
     HIPCHK(c, d.rset_key.ensure((size_t)1 << M.rset_log)); HIPCHK(c, d.rset_u32.ensure((size_t)3 << M.rset_log));
     HIPCHK(c, d.rd_slot.ensure(n)); HIPCHK(c, d.rents.ensure((size_t)n * 4));
     HIPCHK(c, d.anchor_tab.ensure((size_t)1 << M.tab_log_alloc)); HIPCHK(c, d.st.ensure(1)); HIPCHK(c, d.anchor_fp.ensure(1u << 15));
-    HIPCHK(c, d.h_st.ensure(1)); HIPCHK(c, d.h_gid.ensure(n)); HIPCHK(c, d.h_blank.ensure(n));
-    M.packed = d.packed.p; M.codes = d.codes.p; M.owner = d.owner.p; M.root_of = d.root_of.p; M.tmp = d.tmp.p; M.root_rank = d.root_rank.p;
-    M.gid_of = d.gid_of.p; M.tmask = d.tmask.p; M.pat_mask = d.pat_mask.p; M.bk_list = d.bk_list.p;
-    M.grp_cnt = d.grp.p; M.grp_off = d.grp.p + (n + 1); M.grp_fill = d.grp.p + 2 * ((size_t)n + 1); M.surv_cnt = d.grp.p + 3 * ((size_t)n + 1);
-    M.surv_off = d.grp.p + 4 * ((size_t)n + 1);
-    M.members = d.members.p; M.blank = d.blank.p; M.pat_packed = d.pat_packed.p; M.pat_len = d.pat_len.p; M.pat_token = d.pat_token.p;
+    HIPCHK(c, d.h_st.ensure(1)); HIPCHK(c, d.h_root.ensure(n)); HIPCHK(c, d.h_blank.ensure(n));
+    M.packed = d.packed.p; M.codes = d.codes.p; M.owner = d.owner.p; M.bk_key = d.bk_key.p; M.root_of = d.root_of.p;
+    M.tmask = d.tmask.p; M.pat_mask = d.tmask.p; M.blank = d.blank.p; M.pat_token = d.pat_token.p;
     M.kset_key = d.kset_key.p; M.kset_cnt = d.kset_u32.p; M.kset_base = d.kset_u32.p + ((size_t)1 << M.kset_log);
-    M.kset_fill = d.kset_u32.p + ((size_t)2 << M.kset_log); M.ent_slot = d.ent_slot.p; M.ent_win = d.ent_win.p; M.ents = d.ents.p;
-    M.sblank = d.sblank.p;
+    M.kset_fill = d.kset_u32.p + ((size_t)2 << M.kset_log); M.ent_slot = d.ent_slot.p; M.ents = d.ents.p;
     M.rset_key = d.rset_key.p; M.rset_cnt = d.rset_u32.p; M.rset_base = d.rset_u32.p + ((size_t)1 << M.rset_log);
     M.rset_fill = d.rset_u32.p + ((size_t)2 << M.rset_log); M.rd_slot = d.rd_slot.p; M.rents = d.rents.p;
     if (!c->n_cu) {
@@ -1286,17 +1309,28 @@ static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const ui
         c->n_cu = (uint32_t)v;
     }
     M.n_cu = c->n_cu;
-    M.h_st = d.h_st.p; M.h_gid = d.h_gid.p; M.h_blank = d.h_blank.p;
-    M.inject_fail = getenv("CRASS_DM_INJECT_FAIL") ? 1u : 0u;
-    M.group_cap = 16384;
-    if (const char *e = getenv("CRASS_DM_GROUP_CAP")) M.group_cap = (uint32_t)std::max(1, atoi(e));      // tests
+    M.h_st = d.h_st.p; M.h_root = d.h_root.p; M.h_blank = d.h_blank.p;
+    M.inject_fail = c->env.dm_inject_fail ? 1u : 0u;
+    M.group_cap = c->env.dm_group_cap;
     M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
     d.M = M;
+    return CRASS_OK;
+}
+
+// dx_*: distinct strings in token order on the device; hx_*: the same list in pinned host memory
+// the kernels only (n_tok: the token count, or — with d_ntok — the bound the launch is sized for while the count is
+// still on the device); the context's state is untouched until device_merge_commit.  prepared: device_merge_prepare
+// ran for exactly these arguments and an earlier kernel of the step cleared the tables (dm_init_slice)
+static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok,
+                                bool prepared)
+{
+    crass_hip_ctx::DM &d = c->dm;
+    if (!prepared) { const int ps = device_merge_prepare(c, dx_chars, dx_len, n_tok, d_ntok); if (ps) return ps; }
     const double tl0 = now_ms();
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
-    HIPCHK(c, launch_device_merge(M, c->stream));
+    HIPCHK(c, launch_device_merge(d.M, c->stream, prepared));
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
-    if (getenv("CRASS_MERGE_PROFILE"))
+    if (c->env.merge_profile)
         fprintf(stderr, "[crass_dm] host: pass-1 sync -> merge launch start %.1f us, launching the merge kernels %.1f us\n",
                 1e3 * (tl0 - c->t_p1_sync), 1e3 * (now_ms() - tl0));
     // the per-token results the host view is rebuilt from (a few 10 KB)
@@ -1393,11 +1427,11 @@ static int build_host_merge(crass_hip_ctx *c)
         cmap = d.cand_map.data();
     }
     if (!begun && !merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand)) return CRASS_ERR_STATE;
-    if (!merge_from_device_finish(c->merge, d.h_gid.p, d.h_blank.p, d.h_st.p->n_groups) ||
+    if (!merge_from_device_finish_roots(c->merge, d.h_root.p, d.h_blank.p, d.gid_tmp) ||
         c->merge.patterns.size() != d.h_st.p->n_patterns)
         return CRASS_ERR_STATE;
     d.host_built = true;
-    if (getenv("CRASS_MERGE_PROFILE"))
+    if (c->env.merge_profile)
         fprintf(stderr, "[crass_dm] helper: first half %.1f us, waited %.1f us for the merge kernels, second half %.1f us (done %.1f us after the pass-1 sync)\n",
                 1e3 * (tb0 - tb00), 1e3 * (tb1 - tb0), 1e3 * (now_ms() - tb1), 1e3 * (now_ms() - c->t_p1_sync));
     c->n_installed_patterns = d.h_st.p->n_patterns;
@@ -1429,7 +1463,6 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
         if (s == CRASS_OK) {
             // the merge kernels are already running: the pass-1 hand-off pack (PCIe bound) goes beside them — small,
             // latency-bound kernels — rather than beside the pass-2 filter, which it would slow down
-            if (adopt && !getenv("CRASS_PACK_LATE")) c->issue_bulk();
             c->cnt.used_device_merge = 1;
             c->cnt.ms_merge_host = (float)(now_ms() - t0);
             c->dm_prev_local = true;
@@ -1440,7 +1473,6 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
     }
 host_path:
     c->dm_prev_local = false;
-    c->issue_bulk();                                    // per-candidate records: copy stream, overlaps the host merge
     if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens &&
         merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
                             c->prm.kmer_clust_size))
@@ -1538,7 +1570,6 @@ static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint1
     const uint32_t *my_map = dev ? c->h_dmap.p : c->dx_map.data();
     const size_t my_n = dev ? (size_t)c->dense.n : c->dx_map.size();
     if (my_offset + my_nd > n_global) return CRASS_ERR_INVALID_ARG;
-    c->issue_bulk();
     merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n_global, c->prm.kmer_clust_size);
     // tokens of this context's own candidates through their distinct index
     std::vector<uint32_t> own(my_n);
@@ -1656,15 +1687,17 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
         HIPCHK(c, launch_dx_tokens(d.g_chars.p, d.g_len.p, d.g_hash.p, stride, X.xinfo.p, n, d.g_rep.p, d.g_slot.p, d.g_first.p, d.g_mask.p, d.g_prefix.p, d.g_bsum.p,
                                    d.g_idx.p, c->d_count.p + 4, c->d_count.p + 5, d.h_gmap.p, d.h_gx_chars.p, d.h_gx_len.p, d.h_gx_hash.p,
                                    d.gx_chars.p, d.gx_len.p, c->stream,
-                                   c->d_count.p, c->h_count.p, 8, c->next_lookback(n_words, &lbg)));   // counters leave with the last kernel
+                                   c->d_count.p, c->h_count.p, 8, c->next_lookback_tiles(((uint64_t)n + 1023) / 1024, &lbg)));   // counters leave with the last kernel
     }
     // As in the seed scan of the one-GPU path: when the previous step's merge ran on the device, this step's merge is
     // queued right here (token count read on the device, sized by a bound) and the host only waits for the counters.
     bool queued = false;
-    if (dev && X.gx_cap_hint && X.gx_cap_hint <= n_max && !getenv("CRASS_NO_SPECULATION")) {
+    if (dev && X.gx_cap_hint && X.gx_cap_hint <= n_max && !c->env.no_speculation) {
         if (!X.ev_counts) HIPCHK(c, hipEventCreateWithFlags(&X.ev_counts, hipEventDisableTiming));
         HIPCHK(c, hipEventRecord(X.ev_counts, c->stream));
-        const int qs = device_merge_enqueue(c, d.gx_chars.p, d.gx_len.p, X.gx_cap_hint, c->d_count.p + 4);
+        const bool prepared = c->dm_prepared_n == X.gx_cap_hint && c->dm_prepared_src == d.gx_chars.p;
+        c->dm_prepared_n = 0;                               // (a repeated exchange after an overflow starts from scratch)
+        const int qs = device_merge_enqueue(c, d.gx_chars.p, d.gx_len.p, X.gx_cap_hint, c->d_count.p + 4, prepared);
         if (qs) return qs;
         queued = true;
         HIPCHK(c, hipEventSynchronize(X.ev_counts));
@@ -1799,12 +1832,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     // otherwise the byte-wise automaton scans them separately
     const uint64_t n_exc = dmp ? 0 : c->R.n_exc;
     if (dmp) {
-        // the pass-1 hand-off records leave next to the filter (not next to the merge kernels queued ahead of it)
-        // (gate: the event recorded behind the merge kernels — nothing has been queued on the stream since)
-        if (c->bulk_needed && c->dm.ev_done) c->bulk_gate = c->dm.ev_done;
         HIPCHK(c, launch_anchor_filter_dev(c->R, c->dm.M, c->d_found.p, c->d_mask.p, c->stream));
         anchors = true;
-        c->issue_bulk();
     } else if (c->have_anchors) {
         hipError_t ae = launch_anchor_filter(c->R, c->K, c->d_found.p, c->d_mask.p, c->stream);
         if (ae == hipSuccess) anchors = true;
@@ -1828,7 +1857,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     // Speculative tail (device merge path): verification, finish and the hand-off pack are launched with the hit
     // count still on the device, sized by a bound learnt from the previous call; the exact count arrives with the
     // final synchronisation, and a bound that was too small repeats the tail with the exact count.
-    const bool spec = dmp && n_exc == 0 && c->hit_cap_hint && !getenv("CRASS_NO_SPECULATION") && !c->recruit_exact;
+    const bool spec = dmp && n_exc == 0 && c->hit_cap_hint && !c->env.no_speculation && !c->recruit_exact;
     c->recruit_exact = false;
     // (speculative: the count reaches the host with the last kernel of the tail, k_pack_p2_blob)
     if (!spec) HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1882,7 +1911,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         const double th0 = now_ms();
         const int hs = ensure_host_merge(c);            // host view of the merge, rebuilt while the device verifies
         c->cnt.ms_merge_host += (float)(now_ms() - th0);
-        if (getenv("CRASS_MERGE_PROFILE"))
+        if (c->env.merge_profile)
             fprintf(stderr, "[crass_dm] recruit: tail queued %.1f us after the pass-1 sync, then blocked %.1f us on the host view\n",
                     1e3 * (th0 - c->t_p1_sync), 1e3 * (now_ms() - th0));
         if (hs == CRASS_ERR_STATE) {                    // inconsistent device results: never expected
@@ -1893,7 +1922,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         }
         if (hs) return hs;
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (getenv("CRASS_MERGE_PROFILE"))
+        if (c->env.merge_profile)
             fprintf(stderr, "[crass_dm] recruit: final synchronisation returned %.1f us after the pass-1 sync\n", 1e3 * (now_ms() - c->t_p1_sync));
         if (spec) {
             if (c->dm.h_st.p->fail) {                   // the device merge gave up: host merge, then pass 2 again
@@ -1910,6 +1939,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         {
             c->hit_cap_hint = hit_bound(c->h_count.p[0]);
         }
+        c->wait_bulk();                                 // the step ends with the pass-1 hand-off records in host memory too
         c->q_n = *reinterpret_cast<const uint64_t *>(c->h_qblob.p);
         c->q_blob_active = true;
         c->have_pass2 = true;

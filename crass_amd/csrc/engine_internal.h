@@ -87,27 +87,31 @@ struct DevAnchors {
 // ---- device-side DR merge (dmerge.hip) ----
 // small device-resident result/flag words of one merge; copied to pinned host memory afterwards
 struct DevMergeState {
-    uint32_t n_groups;            // number of DR groups (next_free_gid - 1)
     uint32_t n_survivors;         // non-redundant variants
     uint32_t n_patterns;          // 2 * n_survivors
     uint32_t n_keys;              // distinct anchor keys
     uint32_t log_size;            // anchor table holds 1 << log_size slots (<= 15: staged in LDS)
-    uint32_t fail;                // != 0: the device path does not apply (1 token outside ACGT/23..64, 2 key set too
-                                  // large or empty, 4 cuckoo insertion gave up, 64 more tokens than the launch was sized for)
-                                  // -> the host merge is used instead
+    uint32_t fail;                // != 0: the device path does not apply (1 token outside ACGT/23..64 or too many 11-mers with
+                                  // an 'N', 2 key set too large or empty, 4 cuckoo insertion gave up, 8 a bounded spin gave up,
+                                  // 16 injected (tests), 32 a needle key with more candidates than DevMerge::group_cap,
+                                  // 64 more tokens than the launch was sized for) -> the host merge is used instead
     uint32_t k0;                  // a member key (fills unused table slots)
     uint32_t all_t;               // the key 0xFFFFFFFF is a member
     uint32_t ent_cursor;          // entries allocated in the verification index
     uint32_t rd_cursor;           // entries allocated in the needle index of removeRedundantRepeats
     uint32_t tab_mode;            // anchor table: 0 exact keys staged in LDS (log_size <= 15), 3 16-bit fingerprints of a
                                   // 2^16-slot table staged in LDS (anchor_fp), 2 exact keys probed in global memory
-    uint32_t n_badk;              // 11-mers that contain an 'N' (resolved by the last block of k_dm_pack_codes)
-    uint32_t blocks_done;         // k_dm_pack_codes: blocks that have finished
-    uint32_t pad[3];
+    uint32_t n_badk;              // distinct 11-mers that contain an 'N'
+    uint32_t pad[5];
 };
 
-static constexpr uint32_t kDmBadKmerCap = 2048;     // 11-mers with an 'N' the device merge resolves; more -> host merge
+static constexpr uint32_t kDmBadSlots = 4096;       // identity table of the 11-mers with an 'N' (open addressing)
+static constexpr uint32_t kDmBadKmerCap = 2048;     // ... of which at most this many distinct ones; more -> host merge
 
+// Pattern ids on the device: pid = 2 * token_index + orientation (0 = the variant, 1 = its reverse complement), i.e. the
+// pattern arrays ARE the per-token arrays (packed[t][2o..2o+1], tmask[t][o]); ids of dropped variants are simply unused.
+// (The reference's pattern ORDER — per group, survivors then reverse complements, WorkHorse.cpp:690-697 — only exists in
+// the host view; pass 2 depends on the set alone, SURVEY a-14.)
 struct DevMerge {
     // input: distinct candidate DR strings in first-occurrence (= token) order
     const char *dx_chars; const uint16_t *dx_len;
@@ -116,35 +120,26 @@ struct DevMerge {
     uint32_t thr;                 // max(kmer_clust_size, 2): sightings of a group that decide membership
     uint32_t kmax;                // k-mer slots per token (stride - 10)
     // per token
-    uint64_t *packed;             // [n_tok][4] 2-bit packed string (lo, hi) and its reverse complement (lo, hi)
-    uint64_t *tmask;              // [n_tok][2] bit i: base i is an 'N' (packed as 'A'); forward and reverse complement
-    uint32_t *codes;              // [n_tok][kmax] laurenized 11-mer codes; (1 << 22) + id for an 11-mer with an 'N'
-    uint32_t *owner;              // [(1 << 22) + kDmBadKmerCap] smallest token containing the code
-    uint32_t *bk_list;            // [kDmBadKmerCap] (token << 6) | position of the 11-mers with an 'N'
+    uint64_t *packed;             // [n_tok][4] 2-bit packed string (lo, hi) and its reverse complement (lo, hi) = pattern bits [pid][2]
+    uint64_t *tmask;              // [n_tok][2] bit i: base i is an 'N' (packed as 'A'); forward and reverse complement = [pid]
+    uint32_t *codes;              // [n_tok][kmax] laurenized 11-mer codes; (1 << 22) + slot for an 11-mer with an 'N'
+    uint32_t *owner;              // [(1 << 22) + kDmBadSlots] smallest token containing the code
+    unsigned long long *bk_key;   // [kDmBadSlots] identity of the 11-mers with an 'N': laurenized 33-bit key | 1 << 40; 0 = empty
     uint32_t *root_of;            // [n_tok] first token of the token's group
-    uint32_t *tmp, *root_rank;    // [n_tok + 1]
-    uint32_t *gid_of;             // [n_tok] GID (1-based)
-    uint32_t *grp_cnt, *grp_off, *grp_fill, *surv_cnt, *surv_off;     // [n_tok + 1] per group
-    uint32_t *members;            // [n_tok] tokens ordered by group
     uint8_t  *blank;              // [n_tok] removed by removeRedundantRepeats
-    uint8_t  *sblank;             // [n_tok] the same flag by position in members[]
-    // needle index of removeRedundantRepeats: key = (GID << 32) | first 16 bases
+    // needle index of removeRedundantRepeats: key = ((root + 1) << 32) | first 16 bases
     unsigned long long *rset_key; // [1 << rset_log]
     uint32_t *rset_cnt, *rset_base, *rset_fill;   // [1 << rset_log]
     uint32_t rset_log;
     uint32_t *rd_slot;            // [n_tok] the member's key slot (bit 31: it claimed the slot)
     uint64_t *rents;              // [n_tok][4] {len | token << 32, bits lo, bits hi, N mask}, grouped by key
-    // pattern list (capacity 2 * n_tok)
-    uint64_t *pat_packed;         // [n_pat][2]
-    uint64_t *pat_mask;           // [n_pat] bit i: base i of the pattern is an 'N'
-    uint16_t *pat_len;
-    uint32_t *pat_token;
+    uint32_t *pat_token;          // [2 * n_tok] StringToken of pattern pid (= (pid >> 1) + 2)
+    const uint64_t *pat_mask;     // = tmask
     // anchor keys: entry e = pid * 8 + r (capacity 16 * n_tok)
     unsigned long long *kset_key; // [1 << kset_log] distinct keys (key | 1 << 32; 0 = empty)
     uint32_t *kset_cnt, *kset_base, *kset_fill;   // [1 << kset_log] the key's entries: ents[base .. base + cnt)
     uint32_t kset_log;
-    uint32_t *ent_slot;           // [16 * n_tok] the entry's key slot
-    uint8_t  *ent_win;            // [16 * n_tok] entry claimed its key's slot
+    uint32_t *ent_slot;           // [16 * n_tok] the entry's key slot | 0x80000000 when the entry claimed it; 0xFFFFFFFF: no entry
     uint64_t *ents;               // [16 * n_tok][4] verification index, grouped by key
     uint32_t *anchor_tab;         // [1 << tab_log_alloc] cuckoo table of the keys (see DevAnchors)
     uint32_t *anchor_fp;          // [1 << 15] words: tab_mode 3 = 2^16 16-bit fingerprints of the slots' keys;
@@ -153,13 +148,38 @@ struct DevMerge {
     uint32_t s1, s2, m1, m2;      // hash constants of the table
     uint32_t n_cu;                // compute units of the device (bounds the grid of the kernel whose waves wait for each other)
     DevMergeState *st;
-    // pinned host memory the last kernel exports to (state words, GID and dropped flag per token)
-    DevMergeState *h_st; uint32_t *h_gid; uint8_t *h_blank;
+    // pinned host memory the last kernel exports to (state words, root and dropped flag per token)
+    DevMergeState *h_st; uint32_t *h_root; uint8_t *h_blank;
     uint32_t inject_fail;         // tests only: start with the fail word set (exercises the fall-back to the host merge)
-    uint32_t group_cap;           // a group with more members than this sets fail bit 32: the per-group steps here are
-                                  // quadratic in the group size (rank among survivors) or walk per-key chains that grow
-                                  // with it; the host merge handles such inputs in O(n log n)
+    uint32_t group_cap;           // a needle key with more candidates than this sets fail bit 32: removeRedundantRepeats here
+                                  // compares a window with every shorter member that shares its first 16 bases, which is
+                                  // quadratic in a group of near-identical variants; the host merge handles such inputs
 };
+
+// the words a merge polls, counts into or probes, cleared by k_dm_init — or, when the launch is sized before pass 1 has
+// finished (crass_hip_seed_scan queues the merge ahead of time), by the survivor kernel on its way: a 148 us, issue-bound
+// kernel next to which 20 MB of stores are free.  tid / nth: this thread's index / the number of threads that share the job.
+static __device__ __forceinline__ void dm_init_slice(const DevMerge &M, uint64_t tid, uint64_t nth)
+{
+    uint4 ones; ones.x = ones.y = ones.z = ones.w = 0xFFFFFFFFu;
+    uint4 *o4 = reinterpret_cast<uint4 *>(M.owner);
+    for (uint64_t i = tid; i < ((1u << 22) + kDmBadSlots) / 4; i += nth) o4[i] = ones;
+    for (uint64_t i = tid; i < kDmBadSlots; i += nth) M.bk_key[i] = 0ull;
+    for (uint64_t i = tid; i < M.n_tok; i += nth) M.root_of[i] = 0xFFFFFFFFu;
+    const uint64_t ks = 1ull << M.kset_log;
+    for (uint64_t i = tid; i < ks; i += nth) { M.kset_key[i] = 0ull; M.kset_cnt[i] = 0u; M.kset_fill[i] = 0u; }
+    const uint64_t rs = 1ull << M.rset_log;
+    for (uint64_t i = tid; i < rs; i += nth) { M.rset_key[i] = 0ull; M.rset_cnt[i] = 0u; M.rset_fill[i] = 0u; }
+    for (uint64_t i = tid; i < (1u << 15); i += nth) M.anchor_fp[i] = 0u;
+    uint4 *t4 = reinterpret_cast<uint4 *>(M.anchor_tab);
+    for (uint64_t i = tid; i < (1ull << M.tab_log_alloc) / 4; i += nth) t4[i] = ones;
+    if (tid == 0) {
+        DevMergeState s{};
+        s.k0 = 0xFFFFFFFFu;
+        s.fail = M.inject_fail ? 16u : 0u;
+        *M.st = s;
+    }
+}
 
 // one-collective exchange (see crass_hip_exchange_setup): fill this rank's send buffer / unpack the gathered buffers
 hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride, uint64_t cap_rows,
@@ -167,7 +187,8 @@ hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const ui
 // xinfo (device, 8 words): [0] n_global, [1] my_offset, [2] overflow flag, [3] largest per-rank count
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
                             char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo = nullptr);   // h_xinfo: pinned mirror
-hipError_t launch_device_merge(const DevMerge &M, hipStream_t st);
+// init_done: the tables were cleared by an earlier kernel of the step (dm_init_slice)
+hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done = false);
 // pass-2 anchor filter with table parameters read from the device (M.st); flags nothing when M.st->fail
 hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st);
 hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
@@ -218,7 +239,8 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            int punt_only = 0);
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
-                                 uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st);
+                                 uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st,
+                                 const DevMerge *init_merge = nullptr);   // also clears that merge's tables (dm_init_slice)
 hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
                                   uint64_t *hitmask, uint32_t *hit_info, hipStream_t st);
 hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
@@ -244,27 +266,31 @@ hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_
                                 uint32_t *dd_first, uint32_t dd_size, uint64_t *fidx, uint32_t *d_nf, const Lookback &lb, hipStream_t st);
 hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st,
                              unsigned long long *dd_keys = nullptr, uint32_t *dd_first = nullptr, uint32_t dd_size = 0);   // also clears that table
+// found records -> (a) the compact hand-off blob (p1_blob_layout; device memory — the runtime copies its used bytes to
+// the host — or pinned host memory); (b) dense device arrays of the DR strings for the de-duplication, which this kernel
+// also starts: every string is inserted into the (cleared) table on the way
 hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out,
                                const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
-                               const uint32_t *ss_pool, uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
-                               uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr, uint32_t *g_ss, hipStream_t st);
+                               const uint32_t *ss_pool, uint32_t ss_cap, uint32_t ss_elem, uint8_t *blob,
+                               uint16_t *g_dr_len, char *g_dr, hipStream_t st,
+                               unsigned long long *dd_keys = nullptr, uint32_t *dd_first = nullptr, uint32_t dd_size = 0,
+                               uint64_t *dd_hash = nullptr, uint32_t *dd_slot = nullptr);
 // pass-1 hand-off blob: what the host needs of the nf found records, compact and packed back to back so that
 // it crosses PCIe once: read index, repeat length, start/stop count and list (read positions fit 16 bits:
 // CRASS_HIP_MAX_READ_LEN < 65536), orientation flag.  The DR string of candidate k is the distinct string
 // cand_distinct[k], which the host already has.  The layout is a function of nf, evaluated on the device (the
 // count lives there) and again on the host once it knows nf.
-struct P1Blob { uint64_t read, replen, nss, low, ss, total; };
-__host__ __device__ inline P1Blob p1_blob_layout(uint64_t nf, uint32_t ss_cap)
+struct P1Blob { uint64_t read, replen, nss, low, ss, total; uint32_t ss_elem; };
+// ss_elem: bytes per start/stop entry — 1 when every read position fits a byte (reads of at most 256 bases), else 2
+__host__ __device__ inline P1Blob p1_blob_layout(uint64_t nf, uint32_t ss_cap, uint32_t ss_elem = 2)
 {
     P1Blob b;
     uint64_t at = 0;
     auto sec = [&](uint64_t bytes) { const uint64_t o = at; at += (bytes + 15u) & ~15ull; return o; };
-    b.read = sec(nf * 8); b.replen = sec(nf * 2); b.nss = sec(nf); b.low = sec(nf); b.ss = sec(nf * (uint64_t)ss_cap * 2);
-    b.total = at;
+    b.read = sec(nf * 8); b.replen = sec(nf * 2); b.nss = sec(nf); b.low = sec(nf); b.ss = sec(nf * (uint64_t)ss_cap * ss_elem);
+    b.total = at; b.ss_elem = ss_elem;
     return b;
 }
-hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t ss_cap, const uint64_t *g_read, const uint32_t *g_replen,
-                               const uint32_t *g_nss, const uint8_t *g_low, const uint32_t *g_ss, uint8_t *blob, hipStream_t st);
 // pass-2 hand-off blob: header (record count, 16 bytes) + compact arrays with `cap` slots each; the DR string of a
 // recruit is its token's string
 struct P2Blob { uint64_t read, token, start, end, dr_len, low, total; };
@@ -284,12 +310,12 @@ hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, u
                                uint32_t *h_n_hits = nullptr,         // pinned word that receives *d_n_hits
                                const Lookback *lb = nullptr);
 hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, uint32_t *rep,
-                            const uint32_t *slot_of, const uint32_t *first,
+                            uint32_t *slot_of, const uint32_t *first,       // slot_of: with lb, overwritten by the representatives' ranks
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
                             char *dev_chars, uint16_t *dev_len, hipStream_t st,
                             const uint32_t *cnt_src = nullptr, uint32_t *cnt_dst = nullptr, uint32_t n_cnt = 0,    // counters -> pinned host words
-                            const Lookback *lb = nullptr);
+                            const Lookback *lb = nullptr);      // lb: look-back over tiles of 1024 candidates (next_lookback_tiles((n + 1023) / 1024))
 hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n, unsigned long long *keys,
                             uint32_t *first, uint32_t table_size, uint64_t *hash_out, uint32_t *slot_tmp, uint32_t *rep, hipStream_t st,
                             bool table_cleared = false);

@@ -1549,10 +1549,12 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t s
 __global__ __launch_bounds__(WAVE) void k_survivor_lanes(DevReads R, DevParams P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                                          uint64_t n_max, SurvOut *out, char *dr_chars, uint32_t dr_stride,
                                                          uint32_t *ss_pool, uint32_t ss_cap, uint8_t *found_flag,
-                                                         const uint32_t *seed_hint, uint32_t words_per_read)
+                                                         const uint32_t *seed_hint, uint32_t words_per_read, DevMerge IM, int do_init)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sl_lds[];
     const int lane = threadIdx.x;
+    // the tables of the merge that follows this stage are cleared on the way (stores next to an issue-bound kernel)
+    if (do_init) dm_init_slice(IM, blockIdx.x * (uint64_t)WAVE + lane, (uint64_t)gridDim.x * WAVE);
     uint64_t n_surv = *d_n_surv;
     if (n_surv > n_max) n_surv = n_max;
     const uint64_t s = blockIdx.x * (uint64_t)WAVE + lane;
@@ -1617,14 +1619,15 @@ __global__ __launch_bounds__(WAVE) void k_survivor_lanes(DevReads R, DevParams P
 
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
-                                 uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st)
+                                 uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st, const DevMerge *init_merge)
 {
-    if (n_surv_max == 0) return hipSuccess;
+    if (n_surv_max == 0) return init_merge ? hipErrorNotSupported : hipSuccess;
     if (!R.stride_words || R.stride_words > 16 || ss_cap > 64) return hipErrorNotSupported;
     const uint32_t wpr = R.stride_words;
     const size_t lds = (size_t)(wpr + 2) * WAVE * 4 + (size_t)ss_cap * WAVE * 2;
     hipLaunchKernelGGL(k_survivor_lanes, dim3((unsigned)((n_surv_max + WAVE - 1) / WAVE)), dim3(WAVE), lds, st, R, P, surv_idx, d_n_surv,
-                       n_surv_max, out, dr_chars, dr_stride, ss_pool, ss_cap, found_flag, seed_hint, wpr);
+                       n_surv_max, out, dr_chars, dr_stride, ss_pool, ss_cap, found_flag, seed_hint, wpr, init_merge ? *init_merge : DevMerge{},
+                       init_merge ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -1646,32 +1649,81 @@ __global__ __launch_bounds__(256) void k_found_mask(const SurvOut *out, const ui
     if ((threadIdx.x & 63) == 0 && s < n) mask[s >> 6] = m;
 }
 
-// dense, read-ordered arrays in the hand-off layout (one thread per found record)
+// ---- device-side de-duplication of the candidates' DR strings (single-GPU merge fast path) ----
+// Same 64-bit hash as TokenTable::hash (merge.cpp) so the host can reuse it.  Every distinct
+// string gets one table slot; `first` keeps the smallest candidate index (= first occurrence in
+// read order).  The host re-checks every (candidate, representative) pair with memcmp, so a hash
+// collision between different strings is detected and only costs the fast path.
+static __device__ uint64_t dr_hash64(const char *p, uint32_t n)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)n * 0xD6E8FEB86659FD93ull);
+    while (n >= 8) {
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
+        h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; p += 8; n -= 8;
+    }
+    if (n) {
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < n; i++) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
+        h = (h ^ v) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
+    }
+    return h ^ (h >> 31);
+}
+
+// found records -> compact hand-off blob in pinned host memory + dense DR strings on the device + de-duplication insert
+// (one thread per found record; see launch_gather_found in engine_internal.h)
 __global__ __launch_bounds__(256) void k_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max,
                                                        const SurvOut *out, const uint64_t *surv_idx, uint64_t read_base,
                                                        const char *dr_chars, uint32_t dr_stride, const uint32_t *ss_pool,
-                                                       uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
-                                                       uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr,
-                                                       uint32_t *g_ss)
+                                                       uint32_t ss_cap, uint32_t ss_elem, uint8_t *blob, uint16_t *g_dr_len, char *g_dr,
+                                                       unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_mask,
+                                                       uint64_t *dd_hash, uint32_t *dd_slot)
 {
     const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t n = *d_nf;
     if (n > n_max) n = n_max;
     if (k >= n) return;
+    const P1Blob b = p1_blob_layout(n, ss_cap, ss_elem);
     const uint64_t s = fidx[k];
     const SurvOut o = out[s];
-    g_read[k] = read_base + surv_idx[s];
-    g_low[k] = o.low_lexi;
-    g_replen[k] = o.repeat_len;
-    g_nss[k] = o.n_ss;
-    g_ss_off[k] = k * (uint64_t)ss_cap;
+    reinterpret_cast<uint64_t *>(blob + b.read)[k] = read_base + surv_idx[s];
+    reinterpret_cast<uint16_t *>(blob + b.replen)[k] = (uint16_t)o.repeat_len;
+    (blob + b.nss)[k] = (uint8_t)o.n_ss;
+    (blob + b.low)[k] = o.low_lexi;
+    const uint32_t *ps = ss_pool + o.ss_off;
+    if (ss_elem == 1) {                                  // ss_cap is a multiple of 4: whole words
+        uint32_t *pd = reinterpret_cast<uint32_t *>(blob + b.ss + k * (uint64_t)ss_cap);
+        for (uint32_t i = 0; i < ss_cap; i += 4) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) v |= ((i + q < o.n_ss) ? (ps[i + q] & 0xFFu) : 0u) << (8 * q);
+            pd[i >> 2] = v;
+        }
+    } else {
+        uint32_t *pd = reinterpret_cast<uint32_t *>(blob + b.ss + k * (uint64_t)ss_cap * 2);
+        for (uint32_t i = 0; i < ss_cap; i += 2) {
+            const uint32_t lo = (i < o.n_ss) ? (ps[i] & 0xFFFFu) : 0u, hi = (i + 1 < o.n_ss) ? (ps[i + 1] & 0xFFFFu) : 0u;
+            pd[i >> 1] = lo | (hi << 16);
+        }
+    }
     g_dr_len[k] = o.dr_len;
     const uint4 *src = reinterpret_cast<const uint4 *>(dr_chars + s * (uint64_t)dr_stride);
     uint4 *dst = reinterpret_cast<uint4 *>(g_dr + k * (uint64_t)dr_stride);
     for (uint32_t i = 0; i < dr_stride / 16; i++) dst[i] = src[i];
-    const uint32_t *ps = ss_pool + o.ss_off;
-    uint32_t *pd = g_ss + k * (uint64_t)ss_cap;
-    for (uint32_t i = 0; i < ss_cap; i++) pd[i] = (i < o.n_ss) ? ps[i] : 0u;
+    if (dd_keys) {
+        // the DR string's slot in the de-duplication table (the table was cleared by the found-flag compaction)
+        const uint64_t h = dr_hash64(dr_chars + s * (uint64_t)dr_stride, o.dr_len);
+        dd_hash[k] = h;
+        const unsigned long long key = h | 1ull;             // 0 marks an empty slot
+        uint32_t slot = (uint32_t)(h >> 17) & dd_mask;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&dd_keys[slot], 0ull, key);
+            if (old == 0ull || old == key) break;
+            slot = (slot + 1) & dd_mask;
+        }
+        atomicMin(&dd_first[slot], (uint32_t)k);
+        dd_slot[k] = slot;
+    }
 }
 
 // k_found_mask + compaction in one pass (decoupled look-back): survivor slot s -> rank among the found records ->
@@ -1712,63 +1764,6 @@ hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_
     return hipGetLastError();
 }
 
-// found records -> compact blob (p1_blob_layout) in pinned host memory: the kernel IS the device-to-host copy
-__global__ __launch_bounds__(256) void k_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t ss_cap, const uint64_t *g_read,
-                                                       const uint32_t *g_replen, const uint32_t *g_nss, const uint8_t *g_low,
-                                                       const uint32_t *g_ss, uint8_t *blob)
-{
-    uint64_t nf = *d_nf;
-    if (nf > n_max) nf = n_max;
-    const P1Blob b = p1_blob_layout(nf, ss_cap);
-    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
-    // 16 bytes per thread and step in every section
-    uint4 *d_read = reinterpret_cast<uint4 *>(blob + b.read);
-    const uint4 *s_read = reinterpret_cast<const uint4 *>(g_read);
-    for (uint64_t i = tid; i < (nf + 1) / 2; i += nth) d_read[i] = s_read[i];
-    uint4 *d_rl = reinterpret_cast<uint4 *>(blob + b.replen);
-    for (uint64_t i = tid; i < (nf + 7) / 8; i += nth) {
-        uint32_t v[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = (i * 8 + q < nf) ? g_replen[i * 8 + q] : 0u;
-        uint4 o; o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
-        d_rl[i] = o;
-    }
-    uint4 *d_ns = reinterpret_cast<uint4 *>(blob + b.nss);
-    for (uint64_t i = tid; i < (nf + 15) / 16; i += nth) {
-        uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 16; q++) { const uint32_t v = (i * 16 + q < nf) ? g_nss[i * 16 + q] : 0u; w[q >> 2] |= (v & 0xFFu) << (8 * (q & 3)); }
-        uint4 o; o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-        d_ns[i] = o;
-    }
-    uint4 *d_low = reinterpret_cast<uint4 *>(blob + b.low);
-    const uint4 *s_low = reinterpret_cast<const uint4 *>(g_low);
-    for (uint64_t i = tid; i < (nf + 15) / 16; i += nth) d_low[i] = s_low[i];
-    uint4 *d_ss = reinterpret_cast<uint4 *>(blob + b.ss);
-    const uint64_t n_ss16 = (nf * ss_cap + 7) / 8;          // 8 entries (16 bytes) per step
-    for (uint64_t i = tid; i < n_ss16; i += nth) {
-        uint32_t v[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = (i * 8 + q < nf * ss_cap) ? g_ss[i * 8 + q] : 0u;
-        uint4 o; o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
-        d_ss[i] = o;
-    }
-}
-
-hipError_t launch_pack_p1_blob(const uint32_t *d_nf, uint64_t n_max, uint32_t ss_cap, const uint64_t *g_read, const uint32_t *g_replen,
-                               const uint32_t *g_nss, const uint8_t *g_low, const uint32_t *g_ss, uint8_t *blob, hipStream_t st)
-{
-    if (n_max == 0) return hipSuccess;
-    // PCIe-bound: a modest grid keeps enough stores in flight without occupying the chip
-    const uint64_t total16 = p1_blob_layout(n_max, ss_cap).total / 16;
-    unsigned cap = 256;
-    if (const char *e = getenv("CRASS_PACK_BLOCKS")) cap = (unsigned)std::max(1, atoi(e));
-    unsigned nb = (unsigned)std::min<uint64_t>((total16 + 255) / 256, cap);
-    if (nb == 0) nb = 1;
-    hipLaunchKernelGGL(k_pack_p1_blob, dim3(nb), dim3(256), 0, st, d_nf, n_max, ss_cap, g_read, g_replen, g_nss, g_low, g_ss, blob);
-    return hipGetLastError();
-}
-
 hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st,
                              unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size)
 {
@@ -1779,34 +1774,16 @@ hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n
 
 hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out,
                                const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
-                               const uint32_t *ss_pool, uint32_t ss_cap, uint64_t *g_read, uint8_t *g_low, uint32_t *g_replen,
-                               uint32_t *g_nss, uint64_t *g_ss_off, uint16_t *g_dr_len, char *g_dr, uint32_t *g_ss, hipStream_t st)
+                               const uint32_t *ss_pool, uint32_t ss_cap, uint32_t ss_elem, uint8_t *h_blob,
+                               uint16_t *g_dr_len, char *g_dr, hipStream_t st,
+                               unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size, uint64_t *dd_hash, uint32_t *dd_slot)
 {
     if (n_max == 0) return hipSuccess;
+    if ((ss_cap & 3u) || (ss_elem != 1 && ss_elem != 2)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_gather_found, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, surv_idx,
-                       read_base, dr_chars, dr_stride, ss_pool, ss_cap, g_read, g_low, g_replen, g_nss, g_ss_off, g_dr_len, g_dr, g_ss);
+                       read_base, dr_chars, dr_stride, ss_pool, ss_cap, ss_elem, h_blob, g_dr_len, g_dr,
+                       dd_keys, dd_first, dd_keys ? dd_size - 1 : 0u, dd_hash, dd_slot);
     return hipGetLastError();
-}
-
-// ---- device-side de-duplication of the candidates' DR strings (single-GPU merge fast path) ----
-// Same 64-bit hash as TokenTable::hash (merge.cpp) so the host can reuse it.  Every distinct
-// string gets one table slot; `first` keeps the smallest candidate index (= first occurrence in
-// read order).  The host re-checks every (candidate, representative) pair with memcmp, so a hash
-// collision between different strings is detected and only costs the fast path.
-static __device__ uint64_t dr_hash64(const char *p, uint32_t n)
-{
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)n * 0xD6E8FEB86659FD93ull);
-    while (n >= 8) {
-        uint64_t v = 0;
-        for (int i = 0; i < 8; i++) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
-        h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; p += 8; n -= 8;
-    }
-    if (n) {
-        uint64_t v = 0;
-        for (uint32_t i = 0; i < n; i++) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
-        h = (h ^ v) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29;
-    }
-    return h ^ (h >> 31);
 }
 
 __global__ __launch_bounds__(256) void k_dr_dedupe_clear(unsigned long long *keys, uint32_t *first, uint32_t table_size)
@@ -1909,9 +1886,44 @@ __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const
     out_hash[j] = hash[k];
 }
 
-// dense: every candidate's rank (dmap) and, for the first nd threads, the distinct string's slot
-__global__ __launch_bounds__(256) void k_dx_assign_gather(const uint32_t *rep, const uint32_t *d_n, uint32_t n_max, const uint64_t *mask,
-                                                           const uint32_t *word_prefix, const uint32_t *block_sums,
+// k_dx_flag + compaction in one pass (decoupled look-back over tiles of 1024 candidates, one per thread: the body is a
+// chain of dependent loads, so it wants many blocks rather than fat ones): candidate k is a first occurrence iff
+// first[slot_of[k]] == k; dx_idx[rank] = k, and the representative's rank is left in slot_of[k] (every thread only
+// ever reads its OWN slot_of entry here, so overwriting it is safe) for the assign kernel that follows.
+__global__ __launch_bounds__(1024) void k_dx_flag_compact(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n_max,
+                                                           uint32_t *slot_of, const uint32_t *first, uint32_t *rep, uint64_t *dx_idx, uint32_t *d_nd,
+                                                           uint32_t *d_mismatch, Lookback lb, uint32_t n_tiles)
+{
+    const uint32_t tile = lb_tile_id(lb);
+    const uint32_t k = tile * 1024u + threadIdx.x;
+    const uint32_t n = min(*d_n, n_max);
+    bool is_rep = false;
+    if (k < n) {
+        const uint32_t f = first[slot_of[k]];
+        rep[k] = f;
+        is_rep = (f == k);
+        if (!is_rep) {
+            bool same = f < k && dr_len[f] == dr_len[k];
+            if (same) {
+                const uint4 *a = reinterpret_cast<const uint4 *>(dr + (uint64_t)k * stride);
+                const uint4 *b = reinterpret_cast<const uint4 *>(dr + (uint64_t)f * stride);
+                for (uint32_t i = 0; i < stride / 16; i++) {          // slots are zero padded: whole-slot compare
+                    const uint4 x = a[i], y = b[i];
+                    same = same && x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w;
+                }
+            }
+            if (!same) atomicOr(d_mismatch, 1u);
+        }
+    }
+    uint32_t all;
+    const uint32_t in_tile = block_scan_t<1024>(is_rep ? 1u : 0u, &all);
+    const uint32_t excl = lb_exclusive_prefix(lb, tile, all);
+    if (tile == n_tiles - 1 && threadIdx.x == 0) *d_nd = excl + all;
+    if (is_rep) { const uint32_t q = excl + in_tile; dx_idx[q] = k; slot_of[k] = q; }
+}
+
+// dense: every candidate's rank (dmap = rank of its representative) and, for the first nd threads, the distinct string's slot
+__global__ __launch_bounds__(256) void k_dx_assign_gather(const uint32_t *rep, const uint32_t *d_n, uint32_t n_max, const uint32_t *rank_of,
                                                            uint32_t *dmap, const uint64_t *dx_idx, const uint32_t *d_nd, const char *dr,
                                                            const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, char *out_chars,
                                                            uint16_t *out_len, uint64_t *out_hash, char *dev_chars, uint16_t *dev_len,
@@ -1919,10 +1931,7 @@ __global__ __launch_bounds__(256) void k_dx_assign_gather(const uint32_t *rep, c
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n_cnt) cnt_dst[j] = cnt_src[j];             // the stage's counters, straight into pinned host memory
-    if (j < min(*d_n, n_max)) {
-        const uint32_t f = rep[j], w = f >> 6;
-        dmap[j] = block_sums[w >> 8] + word_prefix[w] + (uint32_t)__popcll(mask[w] & ((1ull << (f & 63)) - 1ull));
-    }
+    if (j < min(*d_n, n_max)) dmap[j] = rank_of[rep[j]];
     uint32_t nd = *d_nd;
     if (nd > n_max) nd = n_max;
     if (j >= nd) return;
@@ -1941,7 +1950,7 @@ __global__ __launch_bounds__(256) void k_dx_assign_gather(const uint32_t *rep, c
 // count is *d_n (<= n).  dmap / out_* may be pinned host memory: the kernels then write the merge's inputs
 // straight into it (a few hundred KB; no copy calls on the critical path).
 hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, uint32_t *rep,
-                            const uint32_t *slot_of, const uint32_t *first,
+                            uint32_t *slot_of, const uint32_t *first,
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,
                             uint32_t *d_mismatch, uint32_t *dmap, char *out_chars, uint16_t *out_len, uint64_t *out_hash,
                             char *dev_chars, uint16_t *dev_len, hipStream_t st, const uint32_t *cnt_src, uint32_t *cnt_dst, uint32_t n_cnt,
@@ -1949,11 +1958,11 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
 {
     if (n == 0) return hipSuccess;
     const unsigned nb = (n + 255) / 256;
-    if (lb) {           // three launches: flags, single-pass compaction, dense assign + gather
-        hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, mask, d_mismatch);
-        hipError_t e2 = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st, nullptr, 0, nullptr, 0, lb);
-        if (e2 != hipSuccess) return e2;
-        hipLaunchKernelGGL(k_dx_assign_gather, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap, dx_idx, d_nd, dr, dr_len,
+    if (lb) {           // two launches: flags + single-pass compaction (element-wise look-back), dense assign + gather
+        const uint32_t n_tiles = (n + 1023u) / 1024u;                               // (the caller reserved that many tickets)
+        hipLaunchKernelGGL(k_dx_flag_compact, dim3(n_tiles), dim3(1024), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, dx_idx, d_nd, d_mismatch,
+                           *lb, n_tiles);
+        hipLaunchKernelGGL(k_dx_assign_gather, dim3(nb), dim3(256), 0, st, rep, d_n, n, (const uint32_t *)slot_of, dmap, dx_idx, d_nd, dr, dr_len,
                            hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len, cnt_src, cnt_dst, cnt_dst ? n_cnt : 0u);
         return hipGetLastError();
     }

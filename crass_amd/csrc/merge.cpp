@@ -841,6 +841,20 @@ bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint
                 1e3 * (p3 - p2), 1e3 * (p4 - p3), 1e3 * (prof_now() - p4));
     return true;
 }
+// the same from the device merge's per-token ROOTS (first token of the token's group; the device keeps no dense group
+// ids): GIDs number the roots in token order — nextFreeGID++ order, WorkHorse.cpp:1598
+bool merge_from_device_finish_roots(MergeResult &m, const uint32_t *root_of, const uint8_t *blank, std::vector<uint32_t> &gid_tmp)
+{
+    const uint32_t n = m.tokens.size();
+    gid_tmp.resize(n);
+    uint32_t n_groups = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        const uint32_t r = root_of[t];
+        if (r > t || (r < t && root_of[r] != r)) { m.clear(); return false; }
+        gid_tmp[t] = (r == t) ? ++n_groups : gid_tmp[r];
+    }
+    return merge_from_device_finish(m, gid_tmp.data(), blank, n_groups);
+}
 bool merge_from_device(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
                        const uint32_t *cand_distinct, uint64_t n, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups)
 {

@@ -94,6 +94,7 @@ bool merge_from_device(MergeResult &m, const char *dx_chars, const uint16_t *dx_
 bool merge_from_device_begin(MergeResult &m, const char *dx_chars, const uint16_t *dx_len, uint32_t dr_stride, uint64_t n_distinct,
                              const uint32_t *cand_distinct, uint64_t n);
 bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups);
+bool merge_from_device_finish_roots(MergeResult &m, const uint32_t *root_of, const uint8_t *blank, std::vector<uint32_t> &gid_tmp);
 
 // byte-wise Aho-Corasick with fully resolved goto; semantics of acism_create + the first
 // callback of acism_scan (acism_create.c:71-392, acism.c:25-106)

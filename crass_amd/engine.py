@@ -453,6 +453,10 @@ class SearchEngine:
         """0 none, 1 the three large kernels (default), 2 every stage — see crass_hip_set_stage_timing."""
         _chk(self.lib.crass_hip_set_stage_timing(self.h, int(level)), "crass_hip_set_stage_timing")
 
+    def reload_env(self):
+        """re-read the environment's A/B and test switches (they are read once, at creation)"""
+        _chk(self.lib.crass_hip_reload_env(self.h), "crass_hip_reload_env")
+
     def counters(self):
         c = _abi.Counters()
         _chk(self.lib.crass_hip_get_counters(self.h, C.byref(c)), "crass_hip_get_counters")
@@ -523,6 +527,8 @@ def search_pipeline(seqs, headers=None, params=None, device=0, do_pass2=True, en
             header_id = None
     own = engine is None
     eng = engine or SearchEngine(params, device)
+    if not own:
+        eng.reload_env()                # a reused context re-reads the A/B switches (they are read once per context)
     try:
         eng.load_reads(packed, header_id)
         cand = eng.seed_scan()

@@ -98,6 +98,10 @@ int  crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out);
  * stage (ms_compact, ms_pass1_total, ms_merge_device, ms_recruit_finish, ms_pass2_total), 0 times nothing.
  * Environment override at creation: CRASS_STAGE_TIMING=0|1|2.  (No reference counterpart: crass has no timers.) */
 int  crass_hip_set_stage_timing(crass_hip_ctx *ctx, int level);
+/* The A/B and test switches of the environment (CRASS_HOST_MERGE, CRASS_NO_SPECULATION, CRASS_DM_*, ...) are read once,
+ * when the context is created — never on the per-call path.  This re-reads them for a live context (tests that flip
+ * a switch between two runs of one context).  (No reference counterpart.) */
+int  crass_hip_reload_env(crass_hip_ctx *ctx);
 /* Level 1 only: which of the three large kernels are bracketed — bit 0 seed scan (ms_filter), bit 1 survivors
  * (ms_survivor), bit 2 pass-2 scan (ms_recruit); default 7.  A caller that reports one kernel's duration over many
  * calls (bench.py: the dominant one) times just that kernel: two event records per call instead of six. */

@@ -163,6 +163,7 @@ os.environ["CRASS_HOST_MERGE"] = "1"
 try:
     hv = []
     for r in range(2):
+        engs[r].reload_env()               # (the switches are read once per context)
         engs[r].seed_scan()
         engs[r].merge_distinct(g_chars, g_lens, offs[r])
         assert engs[r].counters()["used_device_merge"] == 0
@@ -170,6 +171,8 @@ try:
         hv.append((engs[r].merge_view(), hr))
 finally:
     os.environ.pop("CRASS_HOST_MERGE", None)
+    for e in engs:
+        e.reload_env()
 for r in range(2):
     assert views[r].tokens == hv[r][0].tokens and views[r].groups == hv[r][0].groups and views[r].patterns == hv[r][0].patterns
     assert views[r].cand_token.tolist() == hv[r][0].cand_token.tolist()
