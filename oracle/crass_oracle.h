@@ -135,6 +135,47 @@ int orc_pipeline_time(const char *seqs, const uint64_t *seq_off, uint64_t n_read
                       const orc_params *p, double *t_pass1, double *t_merge, double *t_pass2,
                       uint64_t *n_pass1, uint64_t *n_pass2, uint32_t *n_patterns);
 
+/* ---- the stage behind the hot path (crass_consensus.c): findConsensusDRs ---------------------- */
+/* ksw_align as Aligner calls it (ksw.c:330-360; 16-bit scores); query / target are restored on return */
+void orc_ksw_align(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat, int gapo, int gape, int xtra,
+                   int *score, int *te, int *qe, int *tb, int *qb);
+/* smithWaterman (SmithWaterman.cpp:151-308): 1 = (a_ret, b_ret) returned, 0 = ("", ""), < 0 = the reference would throw;
+ * a_ret = seqA[*a_off, +*a_len), b_ret = seqB[*b_off, +*b_len) */
+int orc_smith_waterman(const char *seqA, int lenA, const char *seqB, int lenB, int *aStartAlign, int *aEndAlign,
+                       int aStartSearch, int aSearchLen, double similarity, int *a_off, int *a_len, int *b_off, int *b_len);
+
+/* the hand-off of the search path, as flat arrays (mReads order = record order: pass-1 records, then pass-2 records) */
+typedef struct {
+    const char *seqs; const uint64_t *seq_off; uint64_t n_reads;          /* the input reads */
+    uint64_t n_rec; const uint64_t *rec_read; const uint8_t *rec_lowlexi; const uint32_t *rec_token;
+    const uint32_t *rec_nss; const uint64_t *rec_ss_off; const uint32_t *ss_pool;
+    uint32_t n_tokens; const char *tok_chars; const uint64_t *tok_off;      /* StringCheck: token t = entry t - 2 */
+    uint32_t n_groups; const uint32_t *grp_tokens; const uint64_t *grp_off; /* mDR2GIDMap: GID g = entry g - 1 */
+    uint32_t max_read_len;                                                  /* mMaxReadLength */
+} orc_cons_input;
+
+typedef struct {
+    int32_t  error;            /* != 0: the reference would have thrown / crashed / not terminated on this input */
+    int32_t  next_free_gid;
+    uint32_t n_tokens;         /* StringCheck after the stage (reversed slaves and split forms add tokens) */
+    const char *tok_chars; const uint64_t *tok_off;
+    uint32_t n_groups;         /* groups with a true DR (mTrueDRs), ascending GID */
+    const int32_t *grp_gid; const char *dr_chars; const uint64_t *dr_off;   /* GID and laurenized true DR */
+    const uint32_t *grp_tokens; const uint64_t *grp_off;                    /* mDR2GIDMap[GID] in order */
+    uint64_t n_rec;            /* per input record: */
+    const uint8_t *rec_alive;  /* 0: the ReadHolder was deleted */
+    const uint8_t *rec_rc;     /* 1: RH_Seq is the reverse complement of the input read */
+    const uint32_t *rec_token; /* the token whose ReadList holds the record (0: none) */
+    const uint32_t *rec_nss; const uint64_t *rec_ss_off; const uint32_t *ss_pool;   /* repaired RH_StartStops */
+    const uint64_t *tokread_off; const uint64_t *tokread_idx;               /* mReads[token]: record ids in order */
+    const uint8_t *tok_has_list;
+} orc_cons_view;
+
+typedef struct orc_cons orc_cons;
+orc_cons *orc_consensus_run(const orc_cons_input *in, const orc_params *p);
+void orc_consensus_view(const orc_cons *c, orc_cons_view *v);
+void orc_consensus_free(orc_cons *c);
+
 /* calibration loops (see crass_oracle.c): seconds spent, *checksum over the results */
 double orc_calib_bmp(const char *seqs, uint64_t n_reads, int L, const orc_params *p, uint64_t *checksum);
 double orc_calib_ac(const orc_ac *ac, const char *seqs, uint64_t n_reads, int L, uint64_t *checksum);

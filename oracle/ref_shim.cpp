@@ -2,7 +2,7 @@
  * ref_shim.cpp — extern "C" harness over the *unmodified, compiled reference sources*.
  *
  * TEST INFRASTRUCTURE ONLY.  oracle/Makefile compiles this file together with
- *   /root/reference/src/crass/{PatternMatcher,StringCheck,kseq}.cpp
+ *   /root/reference/src/crass/{PatternMatcher,StringCheck,kseq}.cpp, ksw.c (klib's SSE2 Smith-Waterman, includes only ksw.h)
  *   /root/reference/src/aho-corasick/{acism,acism_create,acism_file,msutil}.c
  * straight from where they lie into oracle/_ref/libcrass_ref.so (git-ignored).
  * Those are the hot-path reference files that compile without generated code
@@ -27,6 +27,7 @@ extern "C" {
 #include "msutil.h"
 #include "acism.h"
 }
+#include "ksw.h"
 
 extern "C" {
 
@@ -152,6 +153,17 @@ long ref_kseq_dump(const char *path, unsigned char **out, size_t *out_len, int *
 }
 
 void ref_free(void *p) { free(p); }
+
+/* ksw_align (ksw.c:330-360) exactly as Aligner::getOffsetAgainstMaster calls it (Aligner.cpp:280-301): query profile
+ * allocated by the call (*qry == NULL) and freed here */
+void ref_ksw_align(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat, int gapo, int gape, int xtra,
+                   int *score, int *te, int *qe, int *tb, int *qb)
+{
+    kswq_t *qp = 0;
+    kswr_t r = ksw_align(qlen, query, tlen, target, m, mat, gapo, gape, xtra, &qp);
+    free(qp);
+    *score = r.score; *te = r.te; *qe = r.qe; *tb = r.tb; *qb = r.qb;
+}
 
 /* ---- calibration loops (see oracle/crass_oracle.c orc_calib_*): the reference's two hot
  * functions driven the way searchCore (libcrispr.cpp:295-339: std::string substr of the read

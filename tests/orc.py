@@ -51,6 +51,26 @@ class View(C.Structure):
                 ("pat_group", C.POINTER(C.c_uint32))]
 
 
+class ConsInput(C.Structure):
+    _fields_ = [("seqs", C.c_void_p), ("seq_off", C.c_void_p), ("n_reads", C.c_uint64),
+                ("n_rec", C.c_uint64), ("rec_read", C.c_void_p), ("rec_lowlexi", C.c_void_p), ("rec_token", C.c_void_p),
+                ("rec_nss", C.c_void_p), ("rec_ss_off", C.c_void_p), ("ss_pool", C.c_void_p),
+                ("n_tokens", C.c_uint32), ("tok_chars", C.c_void_p), ("tok_off", C.c_void_p),
+                ("n_groups", C.c_uint32), ("grp_tokens", C.c_void_p), ("grp_off", C.c_void_p),
+                ("max_read_len", C.c_uint32)]
+
+
+class ConsView(C.Structure):
+    _fields_ = [("error", C.c_int32), ("next_free_gid", C.c_int32), ("n_tokens", C.c_uint32),
+                ("tok_chars", C.POINTER(C.c_char)), ("tok_off", C.POINTER(C.c_uint64)),
+                ("n_groups", C.c_uint32), ("grp_gid", C.POINTER(C.c_int32)), ("dr_chars", C.POINTER(C.c_char)),
+                ("dr_off", C.POINTER(C.c_uint64)), ("grp_tokens", C.POINTER(C.c_uint32)), ("grp_off", C.POINTER(C.c_uint64)),
+                ("n_rec", C.c_uint64), ("rec_alive", C.POINTER(C.c_uint8)), ("rec_rc", C.POINTER(C.c_uint8)),
+                ("rec_token", C.POINTER(C.c_uint32)), ("rec_nss", C.POINTER(C.c_uint32)), ("rec_ss_off", C.POINTER(C.c_uint64)),
+                ("ss_pool", C.POINTER(C.c_uint32)), ("tokread_off", C.POINTER(C.c_uint64)), ("tokread_idx", C.POINTER(C.c_uint64)),
+                ("tok_has_list", C.POINTER(C.c_uint8))]
+
+
 _lib = None
 _ref = None
 
@@ -92,6 +112,15 @@ def lib():
         L.orc_result_view.argtypes = [C.c_void_p, C.POINTER(View)]
         L.orc_pipeline_time.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Params)] + \
             [C.POINTER(C.c_double)] * 3 + [C.POINTER(C.c_uint64)] * 2 + [C.POINTER(C.c_uint32)]
+        L.orc_ksw_align.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + \
+            [C.POINTER(C.c_int)] * 5
+        L.orc_ksw_align.restype = None
+        L.orc_smith_waterman.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                         C.c_double] + [C.POINTER(C.c_int)] * 4
+        L.orc_consensus_run.argtypes = [C.POINTER(ConsInput), C.POINTER(Params)]
+        L.orc_consensus_run.restype = C.c_void_p
+        L.orc_consensus_view.argtypes = [C.c_void_p, C.POINTER(ConsView)]
+        L.orc_consensus_free.argtypes = [C.c_void_p]
         L.orc_calib_bmp.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Params), C.POINTER(C.c_uint64)]
         L.orc_calib_bmp.restype = C.c_double
         L.orc_calib_ac.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
@@ -126,6 +155,10 @@ def ref():
                                     C.POINTER(C.c_int)]
         R.ref_kseq_dump.restype = C.c_long
         R.ref_free.argtypes = [C.c_void_p]
+        if hasattr(R, "ref_ksw_align"):
+            R.ref_ksw_align.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + \
+                [C.POINTER(C.c_int)] * 5
+            R.ref_ksw_align.restype = None
         if hasattr(R, "ref_calib_bmp"):
             R.ref_calib_bmp.argtypes = [C.c_void_p, C.c_uint64, C.c_int] + [C.c_uint] * 5 + [C.POINTER(C.c_uint64)]
             R.ref_calib_bmp.restype = C.c_double
@@ -284,3 +317,99 @@ def calibrate(asc, n, L, patterns, params=None):
     return dict(bmp_ratio=round(t_r_bmp / t_o_bmp, 3), ac_ratio=round(t_r_ac / t_o_ac, 3), reads=int(n), read_len=int(L),
                 patterns=len(patterns), ref_bmp_s=round(t_r_bmp, 4), oracle_bmp_s=round(t_o_bmp, 4),
                 ref_acism_s=round(t_r_ac, 4), oracle_ac_s=round(t_o_ac, 4))
+
+
+# ---- the stage behind the hot path: findConsensusDRs ----
+KSW_XSTART, KSW_XSUBO = 0x80000, 0x40000
+ALIGNER_MAT = np.array([1, -3, -3, -3, 0, -3, 1, -3, -3, 0, -3, -3, 1, -3, 0, -3, -3, -3, 1, 0, 0, 0, 0, 0, 0], np.int8)   # Aligner.h:124-131
+ALIGNER_XTRA = KSW_XSTART | KSW_XSUBO | 5
+
+
+def ksw_align(query, target, impl="oracle", mat=ALIGNER_MAT, gapo=5, gape=2, xtra=ALIGNER_XTRA):
+    """query / target: sequences of codes 0..4 -> (score, te, qe, tb, qb) as Aligner::getOffsetAgainstMaster sees them"""
+    q = np.array(list(query), np.uint8)
+    t = np.array(list(target), np.uint8)
+    out = [C.c_int() for _ in range(5)]
+    fn = lib().orc_ksw_align if impl == "oracle" else ref().ref_ksw_align
+    fn(len(q), q.ctypes.data, len(t), t.ctypes.data, 5, mat.ctypes.data, gapo, gape, xtra, *[C.byref(o) for o in out])
+    assert q.tolist() == list(query) and t.tolist() == list(target)        # restored
+    return tuple(o.value for o in out)
+
+
+def smith_waterman(a, b, start, length, similarity=0.85):
+    o = [C.c_int() for _ in range(6)]
+    r = lib().orc_smith_waterman(a, len(a), b, len(b), C.byref(o[0]), C.byref(o[1]), start, length, similarity,
+                                 C.byref(o[2]), C.byref(o[3]), C.byref(o[4]), C.byref(o[5]))
+    return r, o[0].value, o[1].value, a[o[2].value:o[2].value + o[3].value], b[o[4].value:o[4].value + o[5].value]
+
+
+class ConsResult:
+    """numpy / python copies of an orc_cons_view (same field names as crass_amd's ConsensusResult)"""
+
+    def __init__(self, v):
+        def arr(ptr, cnt, dt):
+            if cnt == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(ptr, shape=(int(cnt),)).astype(dt, copy=True)
+        self.error, self.next_free_gid, self.n_tokens = int(v.error), int(v.next_free_gid), int(v.n_tokens)
+        off = arr(v.tok_off, v.n_tokens + 1, np.uint64)
+        tc = C.string_at(v.tok_chars, int(off[-1])) if v.n_tokens else b""
+        self.tokens = [tc[int(off[i]):int(off[i + 1])] for i in range(v.n_tokens)]
+        ng = int(v.n_groups)
+        self.gids = arr(v.grp_gid, ng, np.int32).tolist()
+        doff = arr(v.dr_off, ng + 1, np.uint64)
+        dc = C.string_at(v.dr_chars, int(doff[-1])) if ng else b""
+        self.true_drs = [dc[int(doff[i]):int(doff[i + 1])] for i in range(ng)]
+        goff = arr(v.grp_off, ng + 1, np.uint64)
+        gt = arr(v.grp_tokens, int(goff[-1]) if ng else 0, np.uint32)
+        self.groups = [gt[int(goff[i]):int(goff[i + 1])].tolist() for i in range(ng)]
+        n = int(v.n_rec)
+        self.rec_alive = arr(v.rec_alive, n, np.uint8)
+        self.rec_rc = arr(v.rec_rc, n, np.uint8)
+        self.rec_token = arr(v.rec_token, n, np.uint32)
+        self.rec_nss = arr(v.rec_nss, n, np.uint32)
+        self.rec_ss_off = arr(v.rec_ss_off, n, np.uint64)
+        self.ss_pool = arr(v.ss_pool, int(self.rec_nss.sum()), np.uint32)
+        toff = arr(v.tokread_off, v.n_tokens + 1, np.uint64)
+        tidx = arr(v.tokread_idx, int(toff[-1]) if v.n_tokens else 0, np.uint64)
+        has = arr(v.tok_has_list, v.n_tokens, np.uint8)
+        self.reads_of = [tidx[int(toff[i]):int(toff[i + 1])].tolist() if has[i] else None for i in range(v.n_tokens)]
+
+    def ss(self, k):
+        o = int(self.rec_ss_off[k])
+        return self.ss_pool[o:o + int(self.rec_nss[k])].tolist()
+
+    def group_read_counts(self):
+        return [sum(len(self.reads_of[t - 2] or []) for t in g) for g in self.groups]
+
+
+def consensus(seqs, res, params=None):
+    """findConsensusDRs over a search result (an orc.PipelineResult or crass_amd's PipelineResult: same field names).
+    seqs: list[bytes] or (uint8 array, uint64 offsets)."""
+    p = params or Params.default()
+    if isinstance(seqs, (list, tuple)) and (not seqs or isinstance(seqs[0], (bytes, bytearray))):
+        sbuf, soff = concat(list(seqs))
+    else:
+        sbuf, soff = seqs
+    n = res.n_pass1 + res.n_pass2
+    keep = []
+
+    def a(x, dt):
+        y = np.ascontiguousarray(np.asarray(x)[:n] if len(x) >= n else x, dtype=dt)
+        keep.append(y)
+        return y.ctypes.data
+    tbuf, toff = concat(list(res.tokens))
+    goff = np.zeros(len(res.groups) + 1, np.uint64)
+    goff[1:] = np.cumsum([len(g) for g in res.groups], dtype=np.uint64)
+    gt = np.array([t for g in res.groups for t in g], np.uint32)
+    ssp = np.ascontiguousarray(res.ss_pool, np.uint32)
+    i = ConsInput(sbuf.ctypes.data, soff.ctypes.data, len(soff) - 1, n, a(res.rec_read, np.uint64), a(res.rec_lowlexi, np.uint8),
+                  a(res.rec_token, np.uint32), a(res.rec_nss, np.uint32), a(res.rec_ss_off, np.uint64), ssp.ctypes.data,
+                  len(res.tokens), tbuf.ctypes.data, toff.ctypes.data, len(res.groups), gt.ctypes.data, goff.ctypes.data,
+                  int(res.max_read_len))
+    h = lib().orc_consensus_run(C.byref(i), C.byref(p))
+    v = ConsView()
+    lib().orc_consensus_view(h, C.byref(v))
+    out = ConsResult(v)
+    lib().orc_consensus_free(h)
+    return out
