@@ -90,6 +90,34 @@ class SynthSpec(C.Structure):
                 ("array_min_repeats", C.c_uint32), ("array_max_repeats", C.c_uint32)]
 
 
+class ConsInput(C.Structure):
+    _fields_ = [("seqs", C.c_void_p), ("seq_off", C.c_void_p), ("n_reads", C.c_uint64),
+                ("n_rec", C.c_uint64), ("rec_read", C.c_void_p), ("rec_lowlexi", C.c_void_p), ("rec_token", C.c_void_p),
+                ("rec_nss", C.c_void_p), ("rec_ss_off", C.c_void_p), ("ss_pool", C.c_void_p),
+                ("n_tokens", C.c_uint32), ("tok_chars", C.c_void_p), ("tok_off", C.c_void_p),
+                ("n_groups", C.c_uint32), ("grp_tokens", C.c_void_p), ("grp_off", C.c_void_p),
+                ("max_read_len", C.c_uint32)]
+
+
+class ConsCounters(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("n_groups_parsed", "n_ksw_launches", "n_ksw_alignments", "n_placements", "n_flips",
+                                          "n_true_drs", "n_sw_tasks", "n_partials_added")]
+
+    def asdict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class ConsView(C.Structure):
+    _fields_ = [("error", C.c_int32), ("next_free_gid", C.c_int32), ("n_tokens", C.c_uint32),
+                ("tok_chars", C.POINTER(C.c_char)), ("tok_off", C.POINTER(C.c_uint64)),
+                ("n_groups", C.c_uint32), ("grp_gid", C.POINTER(C.c_int32)), ("dr_chars", C.POINTER(C.c_char)),
+                ("dr_off", C.POINTER(C.c_uint64)), ("grp_tokens", C.POINTER(C.c_uint32)), ("grp_off", C.POINTER(C.c_uint64)),
+                ("n_rec", C.c_uint64), ("rec_alive", C.POINTER(C.c_uint8)), ("rec_rc", C.POINTER(C.c_uint8)),
+                ("rec_token", C.POINTER(C.c_uint32)), ("rec_nss", C.POINTER(C.c_uint32)), ("rec_ss_off", C.POINTER(C.c_uint64)),
+                ("ss_pool", C.POINTER(C.c_uint32)), ("tokread_off", C.POINTER(C.c_uint64)), ("tokread_idx", C.POINTER(C.c_uint64)),
+                ("tok_has_list", C.POINTER(C.c_uint8)), ("counters", ConsCounters)]
+
+
 # every exported symbol of include/crass_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "crass_hip_abi_version": (C.c_int, []),
@@ -131,6 +159,9 @@ SYMBOLS = {
     "crass_free_packed": (None, [C.POINTER(Packed)]),
     "crass_read_fastx": (C.c_int, [C.c_char_p, C.POINTER(Fastx)]),
     "crass_free_fastx": (None, [C.POINTER(Fastx)]),
+    "crass_hip_consensus": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(ConsInput), C.POINTER(C.c_void_p)]),
+    "crass_hip_consensus_view": (C.c_int, [C.c_void_p, C.POINTER(ConsView)]),
+    "crass_hip_consensus_free": (None, [C.c_void_p]),
     "crass_synth_default": (None, [C.POINTER(SynthSpec)]),
     "crass_synth_packed": (C.c_int, [C.POINTER(SynthSpec), C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]),
     "crass_unpack_ascii": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),

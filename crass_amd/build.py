@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrass_hip.so")
-SOURCES = ["kernels.hip", "dmerge.hip", "engine.cpp", "merge.cpp", "ingest.cpp"]
-DEPS = SOURCES + ["engine_internal.h", "merge.h", os.path.join("..", "..", "include", "crass_hip.h")]
+SOURCES = ["kernels.hip", "dmerge.hip", "consensus.hip", "engine.cpp", "merge.cpp", "ingest.cpp", "consensus.cpp"]
+DEPS = SOURCES + ["engine_internal.h", "consensus_internal.h", "merge.h", os.path.join("..", "..", "include", "crass_hip.h")]
 
 
 def _hipcc():

@@ -545,3 +545,80 @@ def search_pipeline(seqs, headers=None, params=None, device=0, do_pass2=True, en
         if own:
             eng.close()
         packed.close()
+
+
+class ConsensusResult:
+    """crass_cons_view as numpy / python objects (same field names as the oracle's result in tests/orc.py)"""
+
+    def __init__(self, v):
+        def arr(ptr, cnt, dt):
+            if cnt == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(ptr, shape=(int(cnt),)).astype(dt, copy=True)
+        self.error, self.next_free_gid, self.n_tokens = int(v.error), int(v.next_free_gid), int(v.n_tokens)
+        off = arr(v.tok_off, v.n_tokens + 1, np.uint64)
+        tc = C.string_at(v.tok_chars, int(off[-1])) if v.n_tokens else b""
+        self.tokens = [tc[int(off[i]):int(off[i + 1])] for i in range(v.n_tokens)]
+        ng = int(v.n_groups)
+        self.gids = arr(v.grp_gid, ng, np.int32).tolist()
+        doff = arr(v.dr_off, ng + 1, np.uint64)
+        dc = C.string_at(v.dr_chars, int(doff[-1])) if ng else b""
+        self.true_drs = [dc[int(doff[i]):int(doff[i + 1])] for i in range(ng)]
+        goff = arr(v.grp_off, ng + 1, np.uint64)
+        gt = arr(v.grp_tokens, int(goff[-1]) if ng else 0, np.uint32)
+        self.groups = [gt[int(goff[i]):int(goff[i + 1])].tolist() for i in range(ng)]
+        n = int(v.n_rec)
+        self.rec_alive = arr(v.rec_alive, n, np.uint8)
+        self.rec_rc = arr(v.rec_rc, n, np.uint8)
+        self.rec_token = arr(v.rec_token, n, np.uint32)
+        self.rec_nss = arr(v.rec_nss, n, np.uint32)
+        self.rec_ss_off = arr(v.rec_ss_off, n, np.uint64)
+        self.ss_pool = arr(v.ss_pool, int(self.rec_nss.sum()), np.uint32)
+        toff = arr(v.tokread_off, v.n_tokens + 1, np.uint64)
+        tidx = arr(v.tokread_idx, int(toff[-1]) if v.n_tokens else 0, np.uint64)
+        has = arr(v.tok_has_list, v.n_tokens, np.uint8)
+        self.reads_of = [tidx[int(toff[i]):int(toff[i + 1])].tolist() if has[i] else None for i in range(v.n_tokens)]
+        self.counters = v.counters.asdict()
+
+    def ss(self, k):
+        o = int(self.rec_ss_off[k])
+        return self.ss_pool[o:o + int(self.rec_nss[k])].tolist()
+
+    def group_read_counts(self):
+        return [sum(len(self.reads_of[t - 2] or []) for t in g) for g in self.groups]
+
+
+def consensus(seqs, res, params=None, device=0):
+    """crass_hip_consensus (WorkHorse::findConsensusDRs) over a search result: a PipelineResult of this module or any object
+    with its fields (rec_read, rec_lowlexi, rec_token, rec_nss, rec_ss_off, ss_pool, tokens, groups, max_read_len,
+    n_pass1, n_pass2).  seqs: list[bytes] or (uint8 array, uint64 offsets) — the input reads."""
+    lib = _abi.load()
+    p = params or default_params()
+    if isinstance(seqs, (list, tuple)) and (not seqs or isinstance(seqs[0], (bytes, bytearray))):
+        sbuf, soff = concat(list(seqs))
+    else:
+        sbuf, soff = seqs
+    n = int(res.n_pass1 + res.n_pass2)
+    keep = []
+
+    def a(x, dt):
+        y = np.ascontiguousarray(np.asarray(x)[:n], dtype=dt)
+        keep.append(y)
+        return y.ctypes.data
+    tbuf, toff = concat(list(res.tokens))
+    goff = np.zeros(len(res.groups) + 1, np.uint64)
+    goff[1:] = np.cumsum([len(g) for g in res.groups], dtype=np.uint64)
+    gt = np.array([t for g in res.groups for t in g], np.uint32)
+    ssp = np.ascontiguousarray(res.ss_pool, np.uint32)
+    i = _abi.ConsInput(sbuf.ctypes.data, soff.ctypes.data, len(soff) - 1, n, a(res.rec_read, np.uint64), a(res.rec_lowlexi, np.uint8),
+                       a(res.rec_token, np.uint32), a(res.rec_nss, np.uint32), a(res.rec_ss_off, np.uint64), ssp.ctypes.data,
+                       len(res.tokens), tbuf.ctypes.data, toff.ctypes.data, len(res.groups), gt.ctypes.data, goff.ctypes.data,
+                       int(res.max_read_len))
+    h = C.c_void_p()
+    _chk(lib.crass_hip_consensus(C.byref(p), int(device), C.byref(i), C.byref(h)), "crass_hip_consensus")
+    try:
+        v = _abi.ConsView()
+        _chk(lib.crass_hip_consensus_view(h, C.byref(v)), "crass_hip_consensus_view")
+        return ConsensusResult(v)
+    finally:
+        lib.crass_hip_consensus_free(h)

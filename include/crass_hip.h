@@ -286,6 +286,56 @@ typedef struct {
 } crass_counters;
 int crass_hip_get_counters(const crass_hip_ctx *ctx, crass_counters *out);
 
+/* ---- the stage right behind the hot path: true-DR consensus + start/stop repair ----
+ * replaces: int WorkHorse::findConsensusDRs(GroupKmerMap&, int& nextFreeGID)  (WorkHorse.cpp:578-611, called at :403), i.e.
+ * per DR group parseGroupedDRs (:1135-1379): Aligner (Aligner.cpp:73-468 over ksw_align, ksw.c:330-360) -> consensus and
+ * possible split of the group (calculateDRConsensus :801-938, splitGroupedDR :940-1132) -> ReadHolder::updateStartStops
+ * for every read (ReadHolder.cpp:382-511: smithWaterman, SmithWaterman.cpp:151-308, with its Levenshtein filter :283),
+ * and combineGroupsWithIdenticalDRs (:416-452) after every group.
+ * Input = the hand-off of the search path as flat arrays; mReads[token] = the records of that token in record order
+ * (pass-1 records of all files, then pass-2 records: the push order of addReadHolder, libcrispr.cpp:1161).           */
+typedef struct {
+    const char *seqs; const uint64_t *seq_off; uint64_t n_reads;     /* the input reads (as read from the files)        */
+    uint64_t n_rec;                                                  /* records = ReadHolders                           */
+    const uint64_t *rec_read;        /* index into seqs                                                                 */
+    const uint8_t  *rec_lowlexi;     /* RH_WasLowLexi: 0 = the holder's RH_Seq is the reverse complement of the read    */
+    const uint32_t *rec_token;       /* StringToken of the holder's ReadList                                            */
+    const uint32_t *rec_nss; const uint64_t *rec_ss_off; const uint32_t *ss_pool;    /* RH_StartStops                   */
+    uint32_t n_tokens; const char *tok_chars; const uint64_t *tok_off;               /* StringCheck: token t = entry t-2 */
+    uint32_t n_groups; const uint32_t *grp_tokens; const uint64_t *grp_off;          /* mDR2GIDMap: GID g = entry g-1    */
+    uint32_t max_read_len;                                                           /* mMaxReadLength                   */
+} crass_cons_input;
+
+typedef struct {
+    uint64_t n_groups_parsed;        /* parseGroupedDRs calls that reached the coverage stage (incl. split sub-groups)  */
+    uint64_t n_ksw_launches, n_ksw_alignments, n_placements, n_flips, n_true_drs, n_sw_tasks, n_partials_added;
+} crass_counters_cons;
+
+typedef struct {
+    int32_t  error;                  /* != 0: the reference would have thrown / crashed / not terminated on this input  */
+    int32_t  next_free_gid;
+    uint32_t n_tokens;               /* StringCheck after the stage (reversed slaves and split forms add tokens)        */
+    const char *tok_chars; const uint64_t *tok_off;
+    uint32_t n_groups;               /* groups with a true DR (mTrueDRs), ascending GID                                 */
+    const int32_t *grp_gid; const char *dr_chars; const uint64_t *dr_off;           /* GID, laurenized true DR          */
+    const uint32_t *grp_tokens; const uint64_t *grp_off;                            /* mDR2GIDMap[GID], in order        */
+    uint64_t n_rec;                  /* per input record:                                                               */
+    const uint8_t  *rec_alive;       /* 0: the ReadHolder was deleted                                                   */
+    const uint8_t  *rec_rc;          /* 1: RH_Seq is the reverse complement of the input read                           */
+    const uint32_t *rec_token;       /* the token whose ReadList holds the record (0: none)                             */
+    const uint32_t *rec_nss; const uint64_t *rec_ss_off; const uint32_t *ss_pool;   /* repaired RH_StartStops           */
+    const uint64_t *tokread_off; const uint64_t *tokread_idx;                       /* mReads[token]: records in order  */
+    const uint8_t  *tok_has_list;
+    crass_counters_cons counters;
+} crass_cons_view;
+
+typedef struct crass_cons crass_cons;
+/* runs the whole stage on `device`; CRASS_OK with view.error != 0 when the reference itself would not have survived the
+ * input (the view is then incomplete)                                                                                  */
+int  crass_hip_consensus(const crass_params *p, int device, const crass_cons_input *in, crass_cons **out);
+int  crass_hip_consensus_view(const crass_cons *c, crass_cons_view *v);
+void crass_hip_consensus_free(crass_cons *c);
+
 /* raw stream handle (hipStream_t) the context launches on, for callers that time with HIP
  * events or want to order their own work (torch.cuda.ExternalStream) */
 void *crass_hip_stream(const crass_hip_ctx *ctx);
