@@ -317,3 +317,86 @@ void findSingletons(const char *inputFastq, const options &opts, std::vector<std
 }
 
 } // namespace crass_hip
+
+namespace crass_hip {
+
+int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map &mDR2GIDMap, std::map<int, std::string> &mTrueDRs,
+                     GroupKmerMap &groupKmerCountsMap, int &nextFreeGID, int mMaxReadLength, const options &opts)
+{
+    // ---- flatten the hand-off: holders in mReads order (std::map by token, list order inside) ----
+    std::vector<ReadHolder *> holders;
+    std::vector<uint64_t> seq_off(1, 0), rec_read, rec_ss_off;
+    std::vector<uint8_t> rec_low;
+    std::vector<uint32_t> rec_token, rec_nss, ss_pool;
+    std::string seqs;
+    for (auto &kv : mReads) {
+        if (!kv.second) continue;
+        for (ReadHolder *h : *kv.second) {
+            rec_read.push_back(holders.size());
+            holders.push_back(h);
+            seqs += h->RH_Seq; seq_off.push_back(seqs.size());
+            rec_low.push_back(1);                       // RH_Seq is passed as it stands: nothing to orient
+            rec_token.push_back((uint32_t)kv.first);
+            rec_nss.push_back((uint32_t)h->RH_StartStops.size());
+            rec_ss_off.push_back(ss_pool.size());
+            ss_pool.insert(ss_pool.end(), h->RH_StartStops.begin(), h->RH_StartStops.end());
+        }
+    }
+    // tokens 2 .. mNextFreeToken must be dense for the flat token table (they are: StringCheck hands them out in order)
+    std::string tok_chars; std::vector<uint64_t> tok_off(1, 0);
+    const int n_tok = mStringCheck.mNextFreeToken - 1;
+    for (int t = 2; t <= mStringCheck.mNextFreeToken; t++) { tok_chars += mStringCheck.getString(t); tok_off.push_back(tok_chars.size()); }
+    // the ORIGINAL groups: the keys of groupKmerCountsMap (WorkHorse.cpp:587-594), GIDs 1 .. nextFreeGID - 1
+    std::vector<uint32_t> grp_tokens; std::vector<uint64_t> grp_off(1, 0);
+    const int n_groups = nextFreeGID - 1;
+    for (int g = 1; g <= n_groups; g++) {
+        auto it = mDR2GIDMap.find(g);
+        if (it != mDR2GIDMap.end() && it->second && groupKmerCountsMap.count(g)) for (StringToken t : *it->second) grp_tokens.push_back((uint32_t)t);
+        grp_off.push_back(grp_tokens.size());
+    }
+    if (ss_pool.empty()) ss_pool.push_back(0);
+    if (grp_tokens.empty()) grp_tokens.push_back(0);
+    crass_cons_input in{};
+    in.seqs = seqs.data(); in.seq_off = seq_off.data(); in.n_reads = holders.size();
+    in.n_rec = holders.size(); in.rec_read = rec_read.data(); in.rec_lowlexi = rec_low.data(); in.rec_token = rec_token.data();
+    in.rec_nss = rec_nss.data(); in.rec_ss_off = rec_ss_off.data(); in.ss_pool = ss_pool.data();
+    in.n_tokens = (uint32_t)n_tok; in.tok_chars = tok_chars.data(); in.tok_off = tok_off.data();
+    in.n_groups = (uint32_t)n_groups; in.grp_tokens = grp_tokens.data(); in.grp_off = grp_off.data();
+    in.max_read_len = (uint32_t)mMaxReadLength;
+    const crass_params p = to_params(opts);
+    crass_cons *h = nullptr;
+    chk(crass_hip_consensus(&p, device(), &in, &h), "crass_hip_consensus");
+    crass_cons_view v{};
+    chk(crass_hip_consensus_view(h, &v), "crass_hip_consensus_view");
+    if (v.error) { crass_hip_consensus_free(h); return 1; }
+    // ---- write the results back into the hand-off state ----
+    for (uint32_t t = (uint32_t)n_tok; t < v.n_tokens; t++)
+        mStringCheck.addString(std::string(v.tok_chars + v.tok_off[t], (size_t)(v.tok_off[t + 1] - v.tok_off[t])));
+    for (uint64_t k = 0; k < v.n_rec; k++) {
+        ReadHolder *r = holders[k];
+        if (!v.rec_alive[k]) { delete r; holders[k] = nullptr; continue; }
+        if (v.rec_rc[k]) { r->RH_Seq = revcomp(r->RH_Seq); r->RH_WasLowLexi = !r->RH_WasLowLexi; }     // ReadHolder::reverseComplementSeq
+        r->RH_StartStops.assign(v.ss_pool + v.rec_ss_off[k], v.ss_pool + v.rec_ss_off[k] + v.rec_nss[k]);
+    }
+    for (auto &kv : mReads) { delete kv.second; kv.second = nullptr; }         // (the lists; the holders move)
+    for (uint32_t t = 0; t < v.n_tokens; t++) {
+        if (!v.tok_has_list[t]) { if (mReads.count((StringToken)t + 2)) mReads[(StringToken)t + 2] = nullptr; continue; }
+        ReadList *l = new ReadList();
+        for (uint64_t q = v.tokread_off[t]; q < v.tokread_off[t + 1]; q++) l->push_back(holders[v.tokread_idx[q]]);
+        mReads[(StringToken)t + 2] = l;
+    }
+    for (auto &kv : mDR2GIDMap) { delete kv.second; kv.second = nullptr; }     // killed / split / merged groups stay as NULL entries
+    mTrueDRs.clear();
+    for (uint32_t g = 0; g < v.n_groups; g++) {
+        DR_Cluster *c = new DR_Cluster();
+        for (uint64_t q = v.grp_off[g]; q < v.grp_off[g + 1]; q++) c->push_back((StringToken)v.grp_tokens[q]);
+        mDR2GIDMap[v.grp_gid[g]] = c;
+        mTrueDRs[v.grp_gid[g]] = std::string(v.dr_chars + v.dr_off[g], (size_t)(v.dr_off[g + 1] - v.dr_off[g]));
+    }
+    nextFreeGID = v.next_free_gid;
+    for (auto &kv : groupKmerCountsMap) { delete kv.second; kv.second = nullptr; }      // "delete the kmer count lists" (WorkHorse.cpp:603-607)
+    crass_hip_consensus_free(h);
+    return 0;
+}
+
+} // namespace crass_hip

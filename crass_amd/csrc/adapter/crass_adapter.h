@@ -108,6 +108,17 @@ void findSingletons(const char *inputFastq, const options &opts, std::vector<std
 
 void addReadHolder(ReadMap *mReads, StringCheck *mStringCheck, ReadHolder &tmpReadholder);
 
+// The stage right behind the search: int WorkHorse::findConsensusDRs(GroupKmerMap&, int& nextFreeGID)
+// (WorkHorse.cpp:578-611, called at :403; a private member there, so the state it works on is passed explicitly).  Same
+// effects on the hand-off state: mTrueDRs[GID] = laurenized true DR for every group that survives; groups that are
+// killed / split / merged are removed from (set to NULL in) mDR2GIDMap and new groups appear under new GIDs; slaves that
+// align in reverse get a new token (mStringCheck.addString) and their ReadList moves to it; read lists of slaves that could
+// not be placed are cleared; every surviving ReadHolder has its start/stops repaired (ReadHolder::updateStartStops, partial
+// repeats at the read ends included) and is reverse-complemented when the true DR is not in its laurenized form.
+// Returns 0, or 1 where the reference's caller would have seen an exception (parseSeqFiles then returns 1).
+int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map &mDR2GIDMap, std::map<int, std::string> &mTrueDRs,
+                     GroupKmerMap &groupKmerCountsMap, int &nextFreeGID, int mMaxReadLength, const options &opts);
+
 // reads of every file searched so far stay resident on the GPU between searchFile() and
 // findSingletons(); call this once the pipeline is past the search stage.
 void releaseDeviceReads();

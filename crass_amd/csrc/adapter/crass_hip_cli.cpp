@@ -136,6 +136,27 @@ int main(int argc, char *argv[])
                 out << "\t" << h->RH_Seq << "\t" << h->RH_Comment << "\t" << h->RH_Qual << "\n";
             }
         delete nr;
+        // ---- the stage behind the search: true DRs + repaired start/stops (WorkHorse.cpp:403) ----
+        std::map<int, std::string> mTrueDRs;
+        if (findConsensusDRs(mReads, mStringCheck, mDR2GIDMap, mTrueDRs, group_kmer_counts_map, next_free_GID, mMaxReadLength, opts)) {
+            std::cerr << "[ERROR]: Wierd stuff happend when trying to get the 'true' direct repeat" << std::endl;     // WorkHorse.cpp:405
+            rc = 2;
+        } else {
+            std::ofstream con((opts.output_fastq + "crass_hip_consensus.tsv").c_str());
+            con << "#next_free_GID\t" << next_free_GID << "\n";
+            for (auto &kv : mStringCheck.mT2S_map) con << "T\t" << kv.first << "\t" << kv.second << "\n";
+            for (auto &kv : mTrueDRs) con << "D\t" << kv.first << "\t" << kv.second << "\n";
+            for (auto &kv : mDR2GIDMap) { if (!kv.second) continue; con << "G\t" << kv.first; for (StringToken t : *kv.second) con << "\t" << t; con << "\n"; }
+            for (auto &kv : mReads) {
+                if (!kv.second) continue;
+                for (ReadHolder *h : *kv.second) {
+                    con << "R\t" << kv.first << "\t" << h->RH_Header << "\t" << (h->RH_WasLowLexi ? 1 : 0) << "\t";
+                    for (size_t i = 0; i < h->RH_StartStops.size(); i++) con << (i ? "," : "") << h->RH_StartStops[i];
+                    con << "\t" << h->RH_Seq << "\n";
+                }
+            }
+            std::cout << "[crass_consensus]: " << mTrueDRs.size() << " true direct repeats" << std::endl;
+        }
     } catch (std::exception &e) {
         std::cerr << e.what() << std::endl;
         rc = 2;            // doWork -> 2 -> process exit code 2

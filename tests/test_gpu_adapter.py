@@ -110,3 +110,49 @@ def test_cli_two_files_cross_file_headers(cli, tmp_path):
     n = sum(len(v) for v in h["reads"].values())
     assert n == ref.n_pass1 + ref.n_pass2
     assert [h["tokens"][t] for t in sorted(h["tokens"])] == ref.tokens
+
+
+def parse_consensus(path):
+    out = dict(tokens={}, groups={}, drs={}, reads=collections.defaultdict(list), meta={})
+    for line in open(path, "rb").read().split(b"\n"):
+        if not line:
+            continue
+        f = line.split(b"\t")
+        if f[0].startswith(b"#"):
+            out["meta"][f[0][1:].decode()] = int(f[1])
+        elif f[0] == b"T":
+            out["tokens"][int(f[1])] = f[2]
+        elif f[0] == b"D":
+            out["drs"][int(f[1])] = f[2]
+        elif f[0] == b"G":
+            out["groups"][int(f[1])] = [int(x) for x in f[2:]]
+        elif f[0] == b"R":
+            out["reads"][int(f[1])].append(dict(header=f[2], low=int(f[3]), ss=[int(x) for x in f[4].split(b",")] if f[4] else [], seq=f[5]))
+    return out
+
+
+@pytest.mark.parametrize("fname", ["Ill100.fx.gz", "front_offset_bug.fa.gz", "CN_gDC.fa.gz", "poor_dr_ext.fa.gz"])
+def test_cli_consensus_matches_oracle(cli, tmp_path, fname):
+    """findConsensusDRs through the adapter (the reference's function shape over crass_hip_consensus): true DRs, groups,
+    tokens and every surviving ReadHolder (orientation, repaired start/stops, sequence) against the oracle"""
+    path = os.path.join(DATA, fname)
+    r = subprocess.run([cli, "-o", str(tmp_path), path], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    h = parse_consensus(os.path.join(str(tmp_path), "crass_hip_consensus.tsv"))
+    recs = fastx.read_fastx(path)
+    seqs, hdrs = [x[2] for x in recs], [x[0] for x in recs]
+    ref = orc.pipeline(seqs, hdrs)
+    con = orc.consensus(seqs, ref)
+    assert con.error == 0
+    assert ("[crass_consensus]: %d true direct repeats" % len(con.gids)) in r.stdout.decode()
+    assert h["meta"]["next_free_GID"] == con.next_free_gid
+    assert [h["tokens"][t] for t in sorted(h["tokens"])] == con.tokens
+    assert h["drs"] == dict(zip(con.gids, con.true_drs))
+    assert h["groups"] == dict(zip(con.gids, con.groups))
+    want = collections.defaultdict(list)
+    for t, lst in enumerate(con.reads_of):
+        for k in lst or []:
+            i = int(ref.rec_read[k])
+            rc = int(con.rec_rc[k])
+            want[t + 2].append(dict(header=hdrs[i], low=1 - rc, ss=con.ss(k), seq=seqs[i].translate(RC)[::-1] if rc else seqs[i]))
+    assert {t: v for t, v in h["reads"].items() if v} == {t: v for t, v in want.items() if v}
