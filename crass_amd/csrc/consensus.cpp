@@ -86,9 +86,11 @@ struct crass_cons {
     int next_gid = 1;
     unsigned char comp[128];
     // device
-    DBuf<uint8_t> d_seq, d_comp, d_qcodes, d_target, d_dirs, d_drchars; DBuf<uint64_t> d_roff, d_a_off, d_b_off; DBuf<uint32_t> d_rlen, d_list, d_plc_rec, d_qoff, d_qlen, d_droff, d_drlen, d_a_len, d_b_len;
+    DBuf<uint8_t> d_seq, d_comp, d_qcodes, d_target, d_dirs, d_drchars; DBuf<uint64_t> d_roff, d_a_off, d_b_off; DBuf<uint32_t> d_rlen, d_list, d_plc_rec, d_qoff, d_qlen, d_qtgt, d_toff, d_tlen, d_droff, d_drlen, d_a_len, d_b_len;
     DBuf<int32_t> d_plc_pos, d_ksw_out, d_lev; DBuf<int> d_cov; DBuf<ConsSwTask> d_tasks; DBuf<ConsSwOut> d_swout;
     ConsKswParams ksw{};
+    struct Pre { size_t first = 0, count = 0; };
+    std::map<int, Pre> pre; std::vector<std::array<int, 6>> pre_res;       // the original groups' alignments (prealign_original_groups)
     crass_counters_cons cnt{};
     std::vector<char> dr_tab; std::vector<uint64_t> dr_tab_end;      // the true DRs as found (NOT laurenized), back to back: updateStartStops' DR argument
     // flattened view
@@ -174,27 +176,35 @@ void calc_zone(crass_cons *s, Aligner &al)
     }
 }
 
-// device: ksw batch of strings against the master.  res[v] = {score_f, tb_f, qb_f, score_r, tb_r, qb_r}
-int ksw_batch(crass_cons *s, const std::vector<std::string> &strs, const std::string &master, std::vector<std::array<int, 6>> &res)
+// device: ksw batch — string v against master tgt[v].  res[v] = {score_f, tb_f, qb_f, score_r, tb_r, qb_r}
+int ksw_batch(crass_cons *s, const std::vector<std::string> &strs, const std::vector<uint32_t> &tgt, const std::vector<std::string> &masters,
+              std::vector<std::array<int, 6>> &res)
 {
     res.assign(strs.size(), {0, -1, -1, 0, -1, -1});
     if (strs.empty()) return CRASS_OK;
-    std::vector<uint8_t> codes, tcodes(master.size() + 1);
-    std::vector<uint32_t> off(strs.size()), len(strs.size());
+    std::vector<uint8_t> codes, tcodes;
+    std::vector<uint32_t> off(strs.size()), len(strs.size()), toff(masters.size()), tlen(masters.size());
     uint32_t max_q = 1;
     for (size_t v = 0; v < strs.size(); v++) {
         off[v] = (uint32_t)codes.size(); len[v] = (uint32_t)strs[v].size(); max_q = std::max(max_q, len[v]);
         for (char ch : strs[v]) codes.push_back(nt4(ch));
     }
+    for (size_t m = 0; m < masters.size(); m++) {
+        toff[m] = (uint32_t)tcodes.size(); tlen[m] = (uint32_t)masters[m].size();
+        for (char ch : masters[m]) tcodes.push_back(nt4(ch));
+    }
     if (codes.empty()) codes.push_back(0);
-    for (size_t i = 0; i < master.size(); i++) tcodes[i] = nt4(master[i]);
-    HCHK(s, s->d_qcodes.ensure(codes.size())); HCHK(s, s->d_qoff.ensure(off.size())); HCHK(s, s->d_qlen.ensure(len.size()));
-    HCHK(s, s->d_target.ensure(tcodes.size())); HCHK(s, s->d_ksw_out.ensure(strs.size() * 6));
+    if (tcodes.empty()) tcodes.push_back(0);
+    HCHK(s, s->d_qcodes.ensure(codes.size())); HCHK(s, s->d_qoff.ensure(off.size())); HCHK(s, s->d_qlen.ensure(len.size())); HCHK(s, s->d_qtgt.ensure(tgt.size()));
+    HCHK(s, s->d_target.ensure(tcodes.size())); HCHK(s, s->d_toff.ensure(toff.size())); HCHK(s, s->d_tlen.ensure(tlen.size())); HCHK(s, s->d_ksw_out.ensure(strs.size() * 6));
     HCHK(s, hipMemcpyAsync(s->d_qcodes.p, codes.data(), codes.size(), hipMemcpyHostToDevice, s->st));
     HCHK(s, hipMemcpyAsync(s->d_qoff.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, s->st));
     HCHK(s, hipMemcpyAsync(s->d_qlen.p, len.data(), len.size() * 4, hipMemcpyHostToDevice, s->st));
+    HCHK(s, hipMemcpyAsync(s->d_qtgt.p, tgt.data(), tgt.size() * 4, hipMemcpyHostToDevice, s->st));
     HCHK(s, hipMemcpyAsync(s->d_target.p, tcodes.data(), tcodes.size(), hipMemcpyHostToDevice, s->st));
-    HCHK(s, launch_cons_ksw(s->d_qcodes.p, s->d_qoff.p, s->d_qlen.p, (uint32_t)strs.size(), max_q, s->d_target.p, (int)master.size(), s->ksw,
+    HCHK(s, hipMemcpyAsync(s->d_toff.p, toff.data(), toff.size() * 4, hipMemcpyHostToDevice, s->st));
+    HCHK(s, hipMemcpyAsync(s->d_tlen.p, tlen.data(), tlen.size() * 4, hipMemcpyHostToDevice, s->st));
+    HCHK(s, launch_cons_ksw(s->d_qcodes.p, s->d_qoff.p, s->d_qlen.p, s->d_qtgt.p, (uint32_t)strs.size(), max_q, s->d_target.p, s->d_toff.p, s->d_tlen.p, s->ksw,
                             s->d_ksw_out.p, s->st));
     std::vector<int32_t> out(strs.size() * 6);
     HCHK(s, hipMemcpyAsync(out.data(), s->d_ksw_out.p, out.size() * 4, hipMemcpyDeviceToHost, s->st));
@@ -202,6 +212,38 @@ int ksw_batch(crass_cons *s, const std::vector<std::string> &strs, const std::st
     for (size_t v = 0; v < strs.size(); v++) for (int q = 0; q < 6; q++) res[v][q] = out[v * 6 + q];
     s->cnt.n_ksw_alignments += 2 * strs.size(); s->cnt.n_ksw_launches++;
     return CRASS_OK;
+}
+int ksw_batch(crass_cons *s, const std::vector<std::string> &strs, const std::string &master, std::vector<std::array<int, 6>> &res)
+{
+    return ksw_batch(s, strs, std::vector<uint32_t>(strs.size(), 0u), std::vector<std::string>(1, master), res);
+}
+
+// findMasterDR (WorkHorse.cpp:711-748): the longest DR of the group, the first of equals
+int find_master(const crass_cons *s, const std::vector<int> &g)
+{
+    int master = -1; size_t longest = 0;
+    for (int tok : g) if (s->tok[tok - 2].size() > longest) { master = tok; longest = s->tok[tok - 2].size(); }
+    return master;
+}
+
+// Every ORIGINAL group's slave alignments in ONE launch before the group loop starts: the master of a group depends on
+// its token strings only, and no group is touched before its turn (combineGroupsWithIdenticalDRs only appends to groups
+// that have been through already).  Groups that come out of a split are aligned when they are parsed.
+int prealign_original_groups(crass_cons *s, int n_groups)
+{
+    std::vector<std::string> strs, masters; std::vector<uint32_t> tgt;
+    for (int gid = 1; gid <= n_groups; gid++) {
+        auto it = s->group.find(gid);
+        if (it == s->group.end() || !it->second) continue;
+        const int master = find_master(s, *it->second);
+        if (master < 0) continue;
+        crass_cons::Pre &pre = s->pre[gid];
+        pre.first = strs.size();
+        for (int tok : *it->second) if (tok != master) { strs.push_back(s->tok[tok - 2]); tgt.push_back((uint32_t)masters.size()); }
+        pre.count = strs.size() - pre.first;
+        masters.push_back(s->tok[master - 2]);
+    }
+    return ksw_batch(s, strs, tgt, masters, s->pre_res);
 }
 
 enum { F_REVERSED = 1, F_FAILED = 2, F_EQUAL = 4 };
@@ -407,8 +449,7 @@ int parse_grouped_drs(crass_cons *s, int GID)
 {   // WorkHorse::parseGroupedDRs, WorkHorse.cpp:1135-1379
     if (s->error || s->hip_err) return 0;
     std::vector<int> &g = *s->group[GID];
-    int master = -1; size_t longest = 0;
-    for (int tok : g) if (tstr(s, tok).size() > longest) { master = tok; longest = tstr(s, tok).size(); }     // findMasterDR :711-748
+    const int master = find_master(s, g);
     if (master < 0) { s->error = 11; return 0; }
     Aligner al;
     al.length = kConsArrayMul * s->max_read_len;
@@ -423,7 +464,11 @@ int parse_grouped_drs(crass_cons *s, int GID)
     std::vector<int> slave_pos; std::vector<std::string> strs;
     for (size_t q = 0; q < g.size(); q++) if (g[q] != master) { slave_pos.push_back((int)q); strs.push_back(tstr(s, g[q])); }
     std::vector<std::array<int, 6>> res, res2;
-    if (ksw_batch(s, strs, master_str, res)) return 0;
+    auto pre = s->pre.find(GID);
+    if (pre != s->pre.end() && pre->second.count == strs.size()) {         // aligned up-front with every other original group
+        res.assign(s->pre_res.begin() + (long)pre->second.first, s->pre_res.begin() + (long)(pre->second.first + pre->second.count));
+        s->pre.erase(pre);
+    } else if (ksw_batch(s, strs, master_str, res)) return 0;
     std::vector<int> flags(strs.size(), 0), offs(strs.size(), 0);
     std::vector<int> tie_idx; std::vector<std::string> ext;
     for (size_t v = 0; v < strs.size(); v++) {
@@ -732,6 +777,7 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
             s->group[(int)g + 1].reset(v);
         }
         // ---- findConsensusDRs (WorkHorse.cpp:578-611): the ORIGINAL groups in ascending GID order ----
+        { const int ps = prealign_original_groups(s, (int)in->n_groups); if (ps) return ps; }
         for (int gid = 1; gid <= (int)in->n_groups && !s->error && !s->hip_err; gid++) {
             auto it = s->group.find(gid);
             if (it == s->group.end() || !it->second) continue;

@@ -137,8 +137,9 @@ static __device__ KswIO ksw_i16_dev(QF qf, int qlen, TF tf, int tlen, int gapo, 
 
 // ksw_align (ksw.c:330-360) with xtra = KSW_XSTART | KSW_XSUBO | minsc: the second pass over the reversed prefixes finds the
 // start positions.  Task a = 2 * v + o: string v of the batch, o = 1: its reverse complement (codes 3 - c reversed; 4 stays 4)
-__global__ __launch_bounds__(64) void k_cons_ksw(const uint8_t *q_codes, const uint32_t *q_off, const uint32_t *q_len, uint32_t n_str,
-                                                  const uint8_t *target, int tlen, ConsKswParams P, int nvec_max, int32_t *out /* [2 n][3] score, tb, qb */)
+__global__ __launch_bounds__(64) void k_cons_ksw(const uint8_t *q_codes, const uint32_t *q_off, const uint32_t *q_len, const uint32_t *q_tgt, uint32_t n_str,
+                                                  const uint8_t *t_codes, const uint32_t *t_off, const uint32_t *t_len, ConsKswParams P, int nvec_max,
+                                                  int32_t *out /* [2 n][3] score, tb, qb */)
 {
     extern __shared__ __attribute__((aligned(16))) int16_t ksw_lds[];
     const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,6 +147,8 @@ __global__ __launch_bounds__(64) void k_cons_ksw(const uint8_t *q_codes, const u
     const uint32_t v = a >> 1, o = a & 1u;
     const uint8_t *q = q_codes + q_off[v];
     const int qlen = (int)q_len[v];
+    const uint8_t *target = t_codes + t_off[q_tgt[v]];          // the master DR of the string's group
+    const int tlen = (int)t_len[q_tgt[v]];
     auto qf = [&](int k) -> int { if (!o) return q[k]; const int c = q[qlen - 1 - k]; return c < 4 ? 3 - c : 4; };
     auto tf = [&](int i) -> int { return target[i]; };
     KswIO r = ksw_i16_dev(qf, qlen, tf, tlen, P.gapo, P.gape, 0x10000, P.mat, ksw_lds, nvec_max);
@@ -292,8 +295,8 @@ hipError_t launch_cons_cover(const uint8_t *seq, const uint64_t *roff, const uin
     hipLaunchKernelGGL(k_cons_cover, dim3(std::min<uint32_t>((n_plc + 3) / 4, 8192u)), dim3(256), 0, st, seq, roff, rlen, plc_rec, plc_pos, n_plc, cov, length);
     return hipGetLastError();
 }
-hipError_t launch_cons_ksw(const uint8_t *q_codes, const uint32_t *q_off, const uint32_t *q_len, uint32_t n_str, uint32_t max_qlen,
-                           const uint8_t *target, int tlen, const ConsKswParams &P, int32_t *out, hipStream_t st)
+hipError_t launch_cons_ksw(const uint8_t *q_codes, const uint32_t *q_off, const uint32_t *q_len, const uint32_t *q_tgt, uint32_t n_str, uint32_t max_qlen,
+                           const uint8_t *t_codes, const uint32_t *t_off, const uint32_t *t_len, const ConsKswParams &P, int32_t *out, hipStream_t st)
 {
     if (!n_str) return hipSuccess;
     const int nvec_max = (int)((max_qlen + 7) / 8) * 8;
@@ -301,7 +304,7 @@ hipError_t launch_cons_ksw(const uint8_t *q_codes, const uint32_t *q_off, const 
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cons_ksw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cons_ksw, dim3((2 * n_str + 63) / 64), dim3(64), lds, st, q_codes, q_off, q_len, n_str, target, tlen, P, nvec_max, out);
+    hipLaunchKernelGGL(k_cons_ksw, dim3((2 * n_str + 63) / 64), dim3(64), lds, st, q_codes, q_off, q_len, q_tgt, n_str, t_codes, t_off, t_len, P, nvec_max, out);
     return hipGetLastError();
 }
 hipError_t launch_cons_sw(const uint8_t *seq, const uint64_t *roff, const uint32_t *rlen, const ConsSwTask *tasks, uint32_t n_tasks,

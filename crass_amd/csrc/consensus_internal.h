@@ -12,9 +12,10 @@ struct ConsSwOut { int32_t a_start, a_end, a_off, a_len, b_off, b_len, err; };
 hipError_t launch_cons_flip(uint8_t *seq, const uint64_t *roff, const uint32_t *rlen, const uint32_t *list, uint32_t n, const uint8_t *comp, hipStream_t st);
 hipError_t launch_cons_cover(const uint8_t *seq, const uint64_t *roff, const uint32_t *rlen, const uint32_t *plc_rec, const int32_t *plc_pos,
                              uint32_t n_plc, int *cov, int length, hipStream_t st);
-// strings as codes 0..4 (seq_nt4_table, Aligner.cpp:40-58); out[2 v + o][3] = score, tb, qb of string v (o = 1: its reverse complement)
-hipError_t launch_cons_ksw(const uint8_t *q_codes, const uint32_t *q_off, const uint32_t *q_len, uint32_t n_str, uint32_t max_qlen,
-                           const uint8_t *target, int tlen, const ConsKswParams &P, int32_t *out, hipStream_t st);
+// strings as codes 0..4 (seq_nt4_table, Aligner.cpp:40-58), string v against target q_tgt[v] (its group's master DR);
+// out[2 v + o][3] = score, tb, qb of string v (o = 1: its reverse complement)
+hipError_t launch_cons_ksw(const uint8_t *q_codes, const uint32_t *q_off, const uint32_t *q_len, const uint32_t *q_tgt, uint32_t n_str, uint32_t max_qlen,
+                           const uint8_t *t_codes, const uint32_t *t_off, const uint32_t *t_len, const ConsKswParams &P, int32_t *out, hipStream_t st);
 // dirs: scratch, task t uses [dir_off, dir_off + cons_sw_scratch_bytes(len, dr_len))
 static inline uint64_t cons_sw_scratch_bytes(uint32_t len, uint32_t dr_len)
 {
