@@ -80,7 +80,8 @@ class Packed(C.Structure):
 class Fastx(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("seq", u8p), ("seq_off", u64p), ("name", u8p), ("name_off", u64p),
                 ("comment", u8p), ("comment_off", u64p), ("has_comment", u8p), ("qual", u8p), ("qual_off", u64p),
-                ("has_qual", u8p), ("header_id", u64p), ("max_len", C.c_uint32), ("last_ret", C.c_int32)]
+                ("has_qual", u8p), ("header_id", u64p), ("max_len", C.c_uint32), ("last_ret", C.c_int32),
+                ("name_index", u64p), ("name_index_cap", C.c_uint64)]
 
 
 class SynthSpec(C.Structure):
@@ -162,6 +163,7 @@ SYMBOLS = {
     "crass_hip_consensus": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(ConsInput), C.POINTER(C.c_void_p)]),
     "crass_hip_consensus_view": (C.c_int, [C.c_void_p, C.POINTER(ConsView)]),
     "crass_hip_consensus_free": (None, [C.c_void_p]),
+    "crass_fastx_find": (C.c_uint64, [C.POINTER(Fastx), C.c_char_p, C.c_uint64]),
     "crass_synth_default": (None, [C.POINTER(SynthSpec)]),
     "crass_synth_packed": (C.c_int, [C.POINTER(SynthSpec), C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]),
     "crass_unpack_ascii": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),

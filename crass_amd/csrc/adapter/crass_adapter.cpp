@@ -76,7 +76,6 @@ struct FileState {
     crass_hip_ctx *ctx = nullptr;
     bool unique_headers = true;
     uint64_t n_found_own = 0;
-    std::unordered_map<std::string, uint64_t> first_idx;   // header -> first read index (built lazily)
     ~FileState()
     {
         if (ctx) crass_hip_destroy(ctx);
@@ -290,15 +289,17 @@ void findSingletons(const char *inputFastq, const options &opts, std::vector<std
     std::vector<uint32_t> pl;
     for (const auto &s : *nonRedundantPatterns) { pp.push_back(s.data()); pl.push_back((uint32_t)s.size()); }
     chk(crass_hip_set_patterns(f.ctx, pp.data(), pl.data(), (uint32_t)pp.size()), "crass_hip_set_patterns");
-    // readsFound is keyed by header (libcrispr.cpp:411): headers found in OTHER files must suppress
-    // recruitment here too.  The device already knows this file's own pass-1 hits.
+    // readsFound is keyed by header (libcrispr.cpp:411): headers found in OTHER files must suppress recruitment here too.
+    // The device already knows this file's own pass-1 hits (their count is n_found_own: with one input file, or as long
+    // as every entry of readsFound is this file's, there is nothing to add); otherwise every header of readsFound is
+    // resolved through the table the reader built for header_id (crass_fastx_find) — no second name index — and the
+    // engine sets the flags with one upload + one kernel.
     std::vector<uint64_t> extra;
     if (readsFound.size() != f.n_found_own || !f.unique_headers) {
-        if (f.first_idx.empty())
-            for (uint64_t i = 0; i < f.fx.n_reads; i++) f.first_idx.emplace(f.name(i), i);
+        extra.reserve(readsFound.size());
         for (const auto &kv : readsFound) {
-            auto it = f.first_idx.find(kv.first);
-            if (it != f.first_idx.end()) extra.push_back(it->second);
+            const uint64_t i = crass_fastx_find(&f.fx, kv.first.data(), kv.first.size());
+            if (i != UINT64_MAX) extra.push_back(i);
         }
     }
     chk(crass_hip_recruit(f.ctx, extra.empty() ? nullptr : extra.data(), extra.size()), "crass_hip_recruit");

@@ -92,6 +92,17 @@ int main(int argc, char *argv[])
         std::cerr << "crass [ERROR]: The lower spacer bound is bigger than the higher bound (" << opts.lowSpacerSize << " >= " << opts.highSpacerSize << ")" << std::endl;
         return 1;
     }
+    if (opts.lowDRsize < 2 * opts.searchWindowLength - 1) {
+        // The reference accepts this (crass.cpp:264-271 only rejects -d < 8), but its seed stride `unsigned skips = lowDR -
+        // (2w - 1)` then wraps to ~4e9 (libcrispr.cpp:281-285): after a rejected candidate `j = back() - 1 + skips` walks
+        // BACKWARDS and the search need not terminate.  The engine refuses such parameters (CRASS_ERR_UNSUPPORTED); the
+        // command line warns in crass's style and uses the smallest well-defined bound instead.
+        std::cerr << "crass [WARNING]: The lower bound for direct repeat sizes (" << opts.lowDRsize << ") is smaller than 2 * windowLength - 1 ("
+                  << 2 * opts.searchWindowLength - 1 << "): the seed stride of the search is not defined for it; changing to "
+                  << 2 * opts.searchWindowLength - 1 << std::endl;
+        opts.lowDRsize = 2 * opts.searchWindowLength - 1;
+        if (opts.lowDRsize >= opts.highDRsize) { std::cerr << "crass [ERROR]: The lower direct repeat bound is bigger than the higher bound" << std::endl; return 1; }
+    }
     if (optind >= argc) { std::cerr << "crass [ERROR]: No input files were provided. Try ./crass-hip -h for help." << std::endl; return 1; }
     std::vector<std::string> seqFiles(argv + optind, argv + argc);
 

@@ -10,6 +10,7 @@
 #include "merge.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -83,19 +84,31 @@ private:
     bool busy_ = false, quit_ = false, started_ = false;
 };
 
+// device allocations of this library, and an optional cap on them (tests: CRASS_POOL_CAP_MB makes an allocation beyond the
+// cap fail with hipErrorOutOfMemory, so the error paths can be exercised without exhausting a 288 GB device)
+std::atomic<uint64_t> g_dev_bytes{0};
+std::atomic<uint64_t> g_dev_cap{0};
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     hipError_t ensure(size_t want)
     {
         if (want <= n && p) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        release();
         if (want == 0) want = 1;
+        const uint64_t cap = g_dev_cap.load(std::memory_order_relaxed);
+        if (cap && g_dev_bytes.load(std::memory_order_relaxed) + want * sizeof(T) > cap) return hipErrorOutOfMemory;
         hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if (e == hipSuccess) n = want;
+        if (e == hipSuccess) { n = want; g_dev_bytes.fetch_add(want * sizeof(T), std::memory_order_relaxed); }
+        else p = nullptr;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release()
+    {
+        if (p) { (void)hipFree(p); g_dev_bytes.fetch_sub(n * sizeof(T), std::memory_order_relaxed); }
+        p = nullptr; n = 0;
+    }
 };
 
 template <typename T> struct PinBuf {
@@ -466,6 +479,7 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     if (skips < 1) skips = 1;
     c->dp.skips = skips;
     c->env.read();
+    g_dev_cap.store(c->env.pool_cap_bytes, std::memory_order_relaxed);
     c->dp.debug_stop = c->env.surv_debug;
     if (c->env.stage_timing >= 0) c->timing_level = c->env.stage_timing;
     if (c->env.no_lookback) c->lb_on = false;                    // A/B switch: three-kernel compaction
@@ -494,6 +508,7 @@ int crass_hip_reload_env(crass_hip_ctx *c)
 {
     if (!c) return CRASS_ERR_INVALID_ARG;
     c->env.read();
+    g_dev_cap.store(c->env.pool_cap_bytes, std::memory_order_relaxed);
     c->dp.debug_stop = c->env.surv_debug;
     if (c->env.stage_timing >= 0) c->timing_level = c->env.stage_timing;
     c->lb_on = !c->env.no_lookback;
@@ -604,6 +619,7 @@ int crass_hip_load_reads(crass_hip_ctx *c, const crass_reads *h)
     if (v) return v;
     (void)hipSetDevice(c->device);
     reset_results(c);
+    c->have_reads = false;                              // (a failure below must not leave the previous reads half replaced)
     const uint64_t n = h->n_reads;
     // host-side scan for the total word count / max length
     uint64_t total_words = 0;
@@ -680,6 +696,7 @@ int crass_hip_attach_device_reads(crass_hip_ctx *c, const crass_reads *d)
     if (d->n_exceptions) return CRASS_ERR_UNSUPPORTED;
     (void)hipSetDevice(c->device);
     reset_results(c);
+    c->have_reads = false;
     DevReads R{};
     R.packed = d->packed; R.n_reads = d->n_reads; R.stride_words = d->stride_words; R.uniform_len = d->uniform_len;
     R.header_id = d->header_id;
@@ -1815,12 +1832,12 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const uint64_t n = c->R.n_reads;
     const uint64_t n_words = (n + 63) / 64;
     if (n_extra) {
-        // mark additional found headers (local read indices) — a handful of bytes
-        std::vector<uint8_t> one(1, 1);
-        for (uint64_t i = 0; i < n_extra; i++) {
-            if (extra_found[i] >= n) return CRASS_ERR_INVALID_ARG;
-            HIPCHK(c, hipMemsetAsync(c->d_found.p + extra_found[i], 1, 1, c->stream));
-        }
+        // additional found headers (local read indices, e.g. every header another input file found): one upload, one kernel
+        for (uint64_t i = 0; i < n_extra; i++) if (extra_found[i] >= n) return CRASS_ERR_INVALID_ARG;
+        HIPCHK(c, c->d_extra.ensure(n_extra));
+        HIPCHK(c, hipMemcpyAsync(c->d_extra.p, extra_found, n_extra * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, launch_mark_found(c->d_extra.p, n_extra, c->R.header_id, c->d_found.p, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));        // (the caller's array may go away)
     }
     HIPCHK(c, c->stamp(5, 1));
     // fast path: anchor filter (exact superset) then an exact scan of the flagged reads only;

@@ -259,6 +259,8 @@ hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, con
 hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off, const uint32_t *a_len,
                                     const uint64_t *b_off, const uint32_t *b_len, uint64_t n_pairs,
                                     int32_t *dist, float *sim, uint32_t max_len, hipStream_t st);
+// found_flag[header_id(idx[i])] = 1 for every listed read (readsFound entries of other input files, libcrispr.cpp:411)
+hipError_t launch_mark_found(const uint64_t *idx, uint64_t n, const uint64_t *header_id, uint8_t *found_flag, hipStream_t st);
 hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st);
 
 // k_found_mask + compaction as one decoupled-look-back kernel (tiles of 256 survivor slots); fidx[rank] = slot

@@ -461,6 +461,11 @@ int crass_read_fastx(const char *path, crass_fastx *out)
         parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b2, unsigned) {
             for (uint64_t r = a; r < b2; r++) out->header_id[r] = (uint32_t)tab[slot_of[r]].load(std::memory_order_relaxed);
         });
+        // the table stays with the records: crass_fastx_find() resolves a header name without a second index
+        out->name_index = (uint64_t *)malloc(cap * sizeof(uint64_t));
+        out->name_index_cap = out->name_index ? cap : 0;
+        if (out->name_index)
+            parallel_ranges(cap, ht, [&](uint64_t a, uint64_t b2, unsigned) { for (uint64_t i = a; i < b2; i++) out->name_index[i] = tab[i].load(std::memory_order_relaxed); });
     }
     out->max_len = max_len;
     out->last_ret = ch.back().last_ret;
@@ -474,8 +479,23 @@ void crass_free_fastx(crass_fastx *f)
 {
     if (!f) return;
     free(f->seq); free(f->seq_off); free(f->name); free(f->name_off); free(f->comment); free(f->comment_off);
-    free(f->has_comment); free(f->qual); free(f->qual_off); free(f->has_qual); free(f->header_id);
+    free(f->has_comment); free(f->qual); free(f->qual_off); free(f->has_qual); free(f->header_id); free(f->name_index);
     memset(f, 0, sizeof(*f));
+}
+
+uint64_t crass_fastx_find(const crass_fastx *f, const char *name, uint64_t len)
+{
+    if (!f || !f->name_index || !f->name_index_cap) return UINT64_MAX;
+    const uint64_t h = name_hash((const uint8_t *)name, (size_t)len);
+    const uint64_t tag = ((h >> 32) | 1ull) << 32, cap = f->name_index_cap;
+    for (uint64_t i = h & (cap - 1);; i = (i + 1) & (cap - 1)) {
+        const uint64_t cur = f->name_index[i];
+        if (cur == 0) return UINT64_MAX;
+        if ((cur & 0xFFFFFFFF00000000ull) == tag) {
+            const uint64_t r = (uint32_t)cur;
+            if (f->name_off[r + 1] - f->name_off[r] == len && memcmp(f->name + f->name_off[r], name, (size_t)len) == 0) return r;
+        }
+    }
 }
 
 // ---- synthetic metagenome, counter-based ----

@@ -59,6 +59,18 @@ __global__ void k_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint3
     }
 }
 
+__global__ void k_mark_found(const uint64_t *idx, uint64_t n, const uint64_t *header_id, uint8_t *found_flag)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n) { const uint64_t r = idx[i]; found_flag[header_id ? header_id[r] : r] = 1; }
+}
+hipError_t launch_mark_found(const uint64_t *idx, uint64_t n, const uint64_t *header_id, uint8_t *found_flag, hipStream_t st)
+{
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_mark_found, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, n, header_id, found_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st)
 {
     if (!n_exc) return hipSuccess;

@@ -598,23 +598,28 @@ void remove_redundant(std::vector<Member> &v, const StringArena &strs, const Pac
                 v[j].blank = blank;
             }
         } else {
+            // general strings (a byte outside ACGTN somewhere): includeSubstring(a, b) = b.find(a) || b.find(rc(a))
+            // (WorkHorse.cpp:78-86) literally — BOTH needles against s.  ("a in s or in rc(s)" is only the same thing
+            // when the complement table is an involution, and comp_tab is not: U -> A -> T, [96] = 64.)
             const size_t kAnchor = std::min<size_t>(16, min_len);
-            std::unordered_multimap<uint64_t, uint32_t> index;
-            index.reserve(v.size() * 2);
-            for (uint32_t i = 0; i < v.size(); i++) index.emplace(hash_bytes(strs.data(v[i].tok), kAnchor), i);
+            std::vector<std::string> rcs(v.size());
+            std::unordered_multimap<uint64_t, uint32_t> index;          // anchor hash -> (member << 1) | (1: its reverse complement)
+            index.reserve(v.size() * 4);
+            for (uint32_t i = 0; i < v.size(); i++) {
+                rcs[i] = reverse_complement(strs[v[i].tok]);
+                index.emplace(hash_bytes(strs.data(v[i].tok), kAnchor), i << 1);
+                index.emplace(hash_bytes(rcs[i].data(), kAnchor), (i << 1) | 1u);
+            }
             for (size_t j = 0; j < v.size(); j++) {
                 const std::string s = strs[v[j].tok];
-                const std::string rc = reverse_complement(s);
                 bool blank = false;
-                for (const std::string *hay : {&s, &rc}) {
-                    for (size_t p = 0; p + kAnchor <= hay->size() && !blank; p++) {
-                        auto range = index.equal_range(hash_bytes(hay->data() + p, kAnchor));
-                        for (auto it = range.first; it != range.second; ++it) {
-                            const Member &t = v[it->second];
-                            if (t.len < s.size() && p + t.len <= hay->size() && memcmp(hay->data() + p, strs.data(t.tok), t.len) == 0) { blank = true; break; }
-                        }
+                for (size_t p = 0; p + kAnchor <= s.size() && !blank; p++) {
+                    auto range = index.equal_range(hash_bytes(s.data() + p, kAnchor));
+                    for (auto it = range.first; it != range.second; ++it) {
+                        const Member &t = v[it->second >> 1];
+                        const char *needle = (it->second & 1u) ? rcs[it->second >> 1].data() : strs.data(t.tok);
+                        if (t.len < s.size() && p + t.len <= s.size() && memcmp(s.data() + p, needle, t.len) == 0) { blank = true; break; }
                     }
-                    if (blank) break;
                 }
                 v[j].blank = blank;
             }

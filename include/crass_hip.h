@@ -366,9 +366,12 @@ typedef struct {
     uint64_t *header_id;                    /* first read with the same name                     */
     uint32_t  max_len;
     int32_t   last_ret;                     /* kseq_read's final return value (-1 EOF, -2 trunc) */
+    uint64_t *name_index; uint64_t name_index_cap;   /* open-addressing table name -> first read (crass_fastx_find) */
 } crass_fastx;
 int  crass_read_fastx(const char *path, crass_fastx *out);
 void crass_free_fastx(crass_fastx *f);
+/* index of the FIRST read with this header name (the key of readsFound, libcrispr.cpp:138,411), UINT64_MAX if none */
+uint64_t crass_fastx_find(const crass_fastx *f, const char *name, uint64_t len);
 
 /* deterministic synthetic metagenome: counter-based, so any shard can be
  * generated independently.  Writes 2-bit packed reads with uniform stride ceil(L/16).      */

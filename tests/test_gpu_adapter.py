@@ -94,6 +94,13 @@ def test_cli_option_validation(cli, tmp_path):
     assert subprocess.run([cli], capture_output=True).returncode == 1
     r = subprocess.run([cli, "-o", str(tmp_path), str(tmp_path / "missing.fa")], capture_output=True)
     assert r.returncode == 2 and b"Could not open FASTQ" in r.stderr
+    # -d 8 -w 9 passes the reference's own validation but leaves its seed stride undefined (unsigned wrap, libcrispr.cpp:281):
+    # warned about and clamped to 2w - 1 = 17; the run then equals an explicit -d 17 -w 9 run
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    ra = subprocess.run([cli, "-d", "8", "-w", "9", "-o", str(tmp_path / "a"), path], capture_output=True, timeout=300)
+    rb = subprocess.run([cli, "-d", "17", "-w", "9", "-o", str(tmp_path / "b"), path], capture_output=True, timeout=300)
+    assert ra.returncode == 0 and rb.returncode == 0 and b"changing to 17" in ra.stderr and b"changing to" not in rb.stderr
+    assert open(tmp_path / "a" / "crass_hip_handoff.tsv", "rb").read() == open(tmp_path / "b" / "crass_hip_handoff.tsv", "rb").read()
 
 
 def test_cli_two_files_cross_file_headers(cli, tmp_path):

@@ -276,3 +276,39 @@ def test_queued_merge_call_orders(ca):
             assert rec.token.tolist() == ref.rec_token[n1:n1 + ref.n_pass2].tolist()
     finally:
         eng.close()
+
+
+def test_out_of_memory_is_reported_and_the_context_survives(ca):
+    """fault path: a device allocation that fails (forced with CRASS_POOL_CAP_MB, a cap on this library's device
+    allocations) must come back as CRASS_ERR_OOM from whichever call hit it, and the context must stay usable"""
+    big = synth_reads(ca, 1500000, read_len=150)                 # 60 MB of packed words + ~30 MB of per-read scratch
+    small = synth_reads(ca, 40000, read_len=150, crispr_per_million=30000)
+    ref = orc.pipeline(small)
+    os.environ["CRASS_POOL_CAP_MB"] = "48"
+    try:
+        eng = ca.SearchEngine()
+        pk_big, pk_small = ca.PackedReads(big), ca.PackedReads(small)
+        with pytest.raises(ca.CrassError) as ei:
+            eng.load_reads(pk_big, None)
+        assert ei.value.status == 5 and "memory" in str(ei.value)       # CRASS_ERR_OOM
+        with pytest.raises(ca.CrassError) as ei:                          # nothing half-loaded is left behind
+            eng.seed_scan()
+        assert ei.value.status == 6                                      # CRASS_ERR_STATE
+        got = ca.search_pipeline(small, engine=eng)                      # the same context, a batch that fits
+        assert_same_pipeline(got, ref)
+        # the cap can also bite later, inside the search: lift it, load, lower it below what pass 1 needs
+        os.environ["CRASS_POOL_CAP_MB"] = "400"
+        eng.reload_env()
+        eng.load_reads(pk_big, None)
+        os.environ["CRASS_POOL_CAP_MB"] = "1"
+        eng.reload_env()
+        with pytest.raises(ca.CrassError) as ei:
+            eng.seed_scan()
+        assert ei.value.status == 5
+        os.environ.pop("CRASS_POOL_CAP_MB")
+        eng.reload_env()
+        c = eng.seed_scan()                                              # ... and the retry without the cap succeeds
+        assert c.n > 0
+        eng.close(); pk_big.close(); pk_small.close()
+    finally:
+        os.environ.pop("CRASS_POOL_CAP_MB", None)

@@ -200,3 +200,20 @@ def test_host_view_rebuild_from_per_token_results(ca, fname):
     bad[0] = len(m.groups) + 5
     with pytest.raises(ca.CrassError):
         ca.merge_rebuild(chars[order], lens[order], cand_distinct, bad, dropped, len(m.groups))
+
+
+def test_include_substring_with_non_involutive_complement():
+    """removeRedundantRepeats blanks b when b contains a OR reverseComplement(a) (includeSubstring, WorkHorse.cpp:78-86).
+    comp_tab maps U -> A but A -> T (SeqUtils.cpp:50-59), so for a DR with a 'U' "rc(a) in b" and "a in rc(b)" differ:
+    the host merge must test the reference's two needles literally."""
+    import crass_amd as ca
+    comp = {ord(x): ord(y) for x, y in zip("ACGTU", "TGCAA")}
+    a = b"ACGGTCATTCAAGGCTAGCTTGACU"                          # 25 bases, ends in U
+    rc_a = bytes(comp[c] for c in reversed(a))                # starts with A (the complement of U)
+    b = b"GG" + rc_a + b"CC"                                  # contains rc(a) but not a; rc(b) does not contain a either
+    rc_b = bytes(comp[c] for c in reversed(b))
+    assert a not in b and rc_a in b and a not in rc_b
+    chars, lens = ca.dr_slots([a, b])
+    m = ca.merge_host(chars, lens)
+    assert m.n_groups == 1
+    assert sorted(m.patterns) == sorted([a, rc_a])            # b was dropped, as the reference drops it
