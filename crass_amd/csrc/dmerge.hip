@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
                     for (int i = 0; i < kClusterK; i++) {
                         const uint32_t c2 = ((x0 >> i) & 1u) | (((x1 >> i) & 1u) << 1);
                         const uint64_t c5 = ((xn >> i) & 1u) ? 3u : (c2 == 3u ? 4u : c2);          // A C G N T
-                        const uint64_t cc = 4u - c5;                                                // T G C N A
+                        const uint64_t cc = c5 == 0u ? 4u : c5 == 1u ? 2u : c5 == 2u ? 1u : c5 == 3u ? 3u : 0u;      // T G C N A
                         fk = (fk << 3) | c5;
                         rk |= cc << (3 * i);
                     }

@@ -1396,7 +1396,76 @@ static __device__ uint32_t ln_extend(LaneRead &h, int searchWindowLength, int mi
     return (uint32_t)h.replen;
 }
 
-// bit-parallel distance between read[s0, s0+n) and read[t0, t0+m) on 2-bit codes (see lane_lev_bp)
+// bases [start, start + 64) of the lane's read as two 64-bit words (2 bits per base, base `start` in bits 0-1); bases past
+// the stored words read as 0.  Five independent LDS reads and four funnel shifts: the loops that follow run on registers
+// (a per-base ln_base() in a dependent loop is one LDS round trip per iteration: the QC stage was 82 us of 155 that way).
+static __device__ __forceinline__ void ln_load128(const LaneRead &h, int start, uint64_t &lo, uint64_t &hi)
+{
+    const int wi = start >> 4;
+    const uint32_t sh = (uint32_t)(start & 15) * 2u;
+    const uint32_t a0 = ln_word(h, wi), a1 = ln_word(h, wi + 1), a2 = ln_word(h, wi + 2), a3 = ln_word(h, wi + 3), a4 = ln_word(h, wi + 4);
+    const uint32_t y0 = __builtin_amdgcn_alignbit(a1, a0, sh), y1 = __builtin_amdgcn_alignbit(a2, a1, sh);
+    const uint32_t y2 = __builtin_amdgcn_alignbit(a3, a2, sh), y3 = __builtin_amdgcn_alignbit(a4, a3, sh);
+    lo = (uint64_t)y0 | ((uint64_t)y1 << 32); hi = (uint64_t)y2 | ((uint64_t)y3 << 32);
+}
+// even bits of a 64-bit word compacted into the low 32 bits
+static __device__ __forceinline__ uint32_t ln_even_bits(uint64_t x)
+{
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (uint32_t)x;
+}
+// the two bit planes of n <= 64 bases held in (lo, hi): bit i of p0 / p1 = low / high bit of base i
+static __device__ __forceinline__ void ln_planes(uint64_t lo, uint64_t hi, int n, uint64_t &p0, uint64_t &p1)
+{
+    p0 = (uint64_t)ln_even_bits(lo) | ((uint64_t)ln_even_bits(hi) << 32);
+    p1 = (uint64_t)ln_even_bits(lo >> 1) | ((uint64_t)ln_even_bits(hi >> 1) << 32);
+    const uint64_t m = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    p0 &= m; p1 &= m;
+}
+
+// Bit-parallel distance (see lane_lev_bp: Hyyro's OSA recurrences with the reference's transposition term restricted to
+// i > 2 && j > 2, PatternMatcher.cpp:181-186) between read[s0, s0+n) and read[t0, t0+m), n <= m, n <= 8 * sizeof(WORD),
+// m <= 64, both strings in registers.  stop_at >= 0: the caller only wants to know whether the distance is < stop_at —
+// the bottom-row score changes by at most 1 per column, so once score - (columns left) >= stop_at the answer is "no" and
+// stop_at is returned (any value >= stop_at would do).
+template <typename WORD>
+static __device__ __forceinline__ int ln_lev_regs(uint64_t s_lo, uint64_t s_hi, int n, uint64_t t_lo, uint64_t t_hi, int m, int stop_at)
+{
+    uint64_t q0, q1;
+    ln_planes(s_lo, s_hi, n, q0, q1);
+    const uint64_t nm = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    const WORD pm0 = (WORD)(~q0 & ~q1 & nm), pm1 = (WORD)(q0 & ~q1), pm2 = (WORD)(~q0 & q1 & nm), pm3 = (WORD)(q0 & q1);
+    WORD VP = ~(WORD)0, VN = 0, D0 = 0, PMold = 0;
+    int dist = n;
+    const int topbit = n - 1;
+    for (int j = 0; j < m; j++) {
+        const uint32_t c = (uint32_t)((j < 32 ? t_lo >> (2 * j) : t_hi >> (2 * (j - 32))) & 3ull);
+        const WORD PMj = (pm0 & ((WORD)0 - (WORD)(c == 0))) | (pm1 & ((WORD)0 - (WORD)(c == 1))) |
+                         (pm2 & ((WORD)0 - (WORD)(c == 2))) | (pm3 & ((WORD)0 - (WORD)(c == 3)));
+        WORD TR = (WORD)((((WORD)~D0) & PMj) << 1) & PMold & ~(WORD)3;
+        TR &= (WORD)0 - (WORD)(j >= 2);
+        D0 = (WORD)((WORD)((WORD)(PMj & VP) + VP) ^ VP) | PMj | VN;
+        D0 |= TR;
+        WORD HP = VN | (WORD)~(D0 | VP);
+        WORD HN = D0 & VP;
+        dist += (int)((HP >> topbit) & 1) - (int)((HN >> topbit) & 1);
+        HP = (WORD)(HP << 1) | (WORD)1;
+        HN = (WORD)(HN << 1);
+        VP = HN | (WORD)~(D0 | HP);
+        VN = HP & D0;
+        PMold = PMj;
+        if (stop_at >= 0 && dist - (m - 1 - j) >= stop_at) return stop_at;
+    }
+    return dist;
+}
+
+// bit-parallel distance between read[s0, s0+n) and read[t0, t0+m) on 2-bit codes, one base per LDS access (strings
+// longer than 64 bases: only reachable with DR / spacer bounds far above the defaults)
 template <typename WORD>
 static __device__ __forceinline__ int ln_lev_core(const LaneRead &h, int s0, int n, int t0, int m)
 {
@@ -1430,16 +1499,42 @@ static __device__ __forceinline__ int ln_lev_core(const LaneRead &h, int s0, int
     return dist;
 }
 
+// edit distance of read[s0, s0+n) and read[t0, t0+m); sets h.punt when the pair needs the wavefront DP.  stop_at: see
+// ln_lev_regs (-1: the exact distance)
+static __device__ int ln_distance(LaneRead &h, int s0, int n, int t0, int m, int stop_at)
+{
+    if (n > m) { int x = s0; s0 = t0; t0 = x; x = n; n = m; m = x; }
+    if (n > 64) { h.punt = 1; return 0; }
+    if (m <= 64) {
+        uint64_t sl, sh, tl, th;
+        ln_load128(h, s0, sl, sh); ln_load128(h, t0, tl, th);
+        return (n <= 32) ? ln_lev_regs<uint32_t>(sl, sh, n, tl, th, m, stop_at) : ln_lev_regs<uint64_t>(sl, sh, n, tl, th, m, stop_at);
+    }
+    return (n <= 32) ? ln_lev_core<uint32_t>(h, s0, n, t0, m) : ln_lev_core<uint64_t>(h, s0, n, t0, m);
+}
+
 // getStringSimilarity (PatternMatcher.cpp:197-204); sets h.punt when the pair needs the wavefront DP
 static __device__ float ln_similarity(LaneRead &h, int s0, int n, int t0, int m)
 {
     float max_length = (float)(n > m ? n : m);
     if (n < 3 || m < 3) return 0.0f;
-    if (n > m) { int x = s0; s0 = t0; t0 = x; x = n; n = m; m = x; }
-    if (n > 64) { h.punt = 1; return 0.0f; }
-    int d = (n <= 32) ? ln_lev_core<uint32_t>(h, s0, n, t0, m) : ln_lev_core<uint64_t>(h, s0, n, t0, m);
+    const int d = ln_distance(h, s0, n, t0, m, -1);
     float edit_distance = (float)d;
     return (float)(1.0 - (double)(edit_distance / max_length));
+}
+
+// "(double)getStringSimilarity(a, b) > cut" without the full distance when the answer is no: the similarity falls
+// monotonically with the distance, so the smallest distance d_no whose similarity is NOT above the cut is found first
+// (with the reference's own float expression) and the DP stops as soon as the distance is known to reach it
+static __device__ bool ln_similarity_above(LaneRead &h, int s0, int n, int t0, int m, double cut)
+{
+    if (n < 3 || m < 3) return 0.0 > cut;
+    const float max_length = (float)(n > m ? n : m);
+    int d_no = 0;
+    while (d_no <= (n > m ? n : m) && (double)(float)(1.0 - (double)((float)d_no / max_length)) > cut) d_no++;
+    const int d = ln_distance(h, s0, n, t0, m, d_no);
+    if (h.punt) return false;
+    return (double)(float)(1.0 - (double)((float)d / max_length)) > cut;
 }
 
 static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLength)
@@ -1451,7 +1546,13 @@ static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLengt
     if (!substr_len(h.L, rep_start, ln_ss(h, 1) - rep_start + 1, rep_len)) return -1;
     {   // isRepeatLowComplexity (:1031-1069); packed reads hold A/C/G/T only
         int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        for (uint32_t i = 0; i < rep_len; i++) { const uint32_t b = ln_base(h, (int)(rep_start + i)); c0 += (b == 0); c1 += (b == 1); c2 += (b == 2); c3 += (b == 3); }
+        if (rep_len <= 64) {                            // base counts from the two bit planes
+            uint64_t lo, hi, p0, p1;
+            ln_load128(h, (int)rep_start, lo, hi);
+            ln_planes(lo, hi, (int)rep_len, p0, p1);
+            c3 = __popcll(p0 & p1); c1 = __popcll(p0 & ~p1); c2 = __popcll(~p0 & p1); c0 = (int)rep_len - c1 - c2 - c3;
+        } else
+            for (uint32_t i = 0; i < rep_len; i++) { const uint32_t b = ln_base(h, (int)(rep_start + i)); c0 += (b == 0); c1 += (b == 1); c2 += (b == 2); c3 += (b == 3); }
         const int cut_off = (int)((double)(int)rep_len * 0.75);
         if (c0 > cut_off || c3 > cut_off || c2 > cut_off || c1 > cut_off) return 0;
     }
@@ -1500,9 +1601,9 @@ static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLengt
         if (!substr_len(h.L, s, e - s, sp_len)) return -1;
         if ((int)sp_len < minSpacerLength) return 0;
         if ((int)sp_len > maxSpacerLength) return 0;
-        float similarity = ln_similarity(h, (int)rep_start, (int)rep_len, (int)s, (int)sp_len);
+        const bool too_similar = ln_similarity_above(h, (int)rep_start, (int)rep_len, (int)s, (int)sp_len, 0.82);
         if (h.punt) return 0;
-        if ((double)similarity > 0.82) return 0;
+        if (too_similar) return 0;
         int dlen = (int)sp_len - (int)rep_len;
         if (dlen < 0) dlen = -dlen;
         if (dlen > 30) return 0;
@@ -1534,6 +1635,7 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t s
         if (endSearch < beginSearch) endSearch = beginSearch;
         if (beginSearch > seq_length) return -1;
         int pos = ln_find(h, (int)beginSearch, (int)endSearch, (int)j, (int)o.window);
+        if (o.debug_stop == 2) pos = -1;                // (CRASS_SURV_DEBUG, timing breakdown only: seed finds alone)
         if (pos >= 0) {
             ln_add(h, j, j + o.window - 1);
             ln_add(h, (uint32_t)pos, (uint32_t)pos + o.window - 1);
@@ -1543,7 +1645,7 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t s
         }
         if ((uint32_t)(h.nss / 2) >= o.minRepeats) {
             uint32_t actual_repeat_length = ln_extend(h, (int)o.window, (int)o.lowSp);
-            if ((actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {
+            if (o.debug_stop != 3 && (actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {     // (3: no QC)
                 int qc = ln_qc(h, (int)o.lowSp, (int)o.highSp);
                 if (h.punt) return 0;
                 if (qc < 0) return -1;
@@ -1571,7 +1673,7 @@ __global__ __launch_bounds__(WAVE) void k_survivor_lanes(DevReads R, DevParams P
     if (n_surv > n_max) n_surv = n_max;
     const uint64_t s = blockIdx.x * (uint64_t)WAVE + lane;
     uint32_t *lw = sl_lds + lane;                                      // [word][lane]
-    uint16_t *lss = reinterpret_cast<uint16_t *>(sl_lds + (size_t)(words_per_read + 2) * WAVE) + lane;   // [entry][lane]
+    uint16_t *lss = reinterpret_cast<uint16_t *>(sl_lds + (size_t)(words_per_read + 5) * WAVE) + lane;   // [entry][lane]
     if (s >= n_surv) return;
     const uint64_t r = surv_idx[s];
     if (rd_is_exc(R, r)) {                              // raw-byte read: the wave kernel's exception pass (err == 5)
@@ -1583,12 +1685,13 @@ __global__ __launch_bounds__(WAVE) void k_survivor_lanes(DevReads R, DevParams P
     const int L = (int)rd_len(R, r);
     const uint32_t *g = R.packed + rd_word_off(R, r);
     const int nw = (L + 15) >> 4;
-    for (int i = 0; i < (int)words_per_read + 2; i++) lw[i * WAVE] = (i < nw) ? g[i] : 0u;
+    for (int i = 0; i < (int)words_per_read + 5; i++) lw[i * WAVE] = (i < nw) ? g[i] : 0u;      // (ln_load128 reads up to 4 words past a base)
     LaneRead h;
     h.w = lw; h.ss = lss; h.L = L; h.nss = 0; h.cap = (int)ss_cap; h.replen = 0; h.punt = 0;
     h.cmask = (1u << (2 * P.window)) - 1u;
     const uint32_t hint = seed_hint ? seed_hint[r] : 0xFFFFFFFFu;
-    int f = ln_search_core(h, P, hint);
+    int f = (P.debug_stop == 1) ? 0 : ln_search_core(h, P, hint);      // (1: load only)
+    if (P.debug_stop == 4 && f == 1) f = 0;                           // (4: no orientation / output)
     SurvOut o;
     o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
     if (h.punt) o.err = 4;
@@ -1636,7 +1739,7 @@ hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const ui
     if (n_surv_max == 0) return init_merge ? hipErrorNotSupported : hipSuccess;
     if (!R.stride_words || R.stride_words > 16 || ss_cap > 64) return hipErrorNotSupported;
     const uint32_t wpr = R.stride_words;
-    const size_t lds = (size_t)(wpr + 2) * WAVE * 4 + (size_t)ss_cap * WAVE * 2;
+    const size_t lds = (size_t)(wpr + 5) * WAVE * 4 + (size_t)ss_cap * WAVE * 2;
     hipLaunchKernelGGL(k_survivor_lanes, dim3((unsigned)((n_surv_max + WAVE - 1) / WAVE)), dim3(WAVE), lds, st, R, P, surv_idx, d_n_surv,
                        n_surv_max, out, dr_chars, dr_stride, ss_pool, ss_cap, found_flag, seed_hint, wpr, init_merge ? *init_merge : DevMerge{},
                        init_merge ? 1 : 0);

@@ -312,3 +312,22 @@ def test_out_of_memory_is_reported_and_the_context_survives(ca):
         eng.close(); pk_big.close(); pk_small.close()
     finally:
         os.environ.pop("CRASS_POOL_CAP_MB", None)
+
+
+def test_n_kmers_decide_group_membership(ca):
+    """DR variants with an N whose CLEAN 11-mers alone do not reach kmer_clust_size: they join their group only if the
+    11-mers that contain the N get the reference's identity (laurenized string over A<C<G<N<T, N complements to N) —
+    parity_sweep seed 11 case 74 caught a wrong complement table here"""
+    import random
+    rng = random.Random(74)
+    seqs = [bytearray(s) for s in synth_reads(ca, 60000, read_len=250, n_dr=1, crispr_per_million=300000)]
+    for i in rng.sample(range(len(seqs)), 6000):
+        seqs[i][rng.randrange(250)] = ord("N")
+    seqs = [bytes(s) for s in seqs]
+    p = ca.default_params(kmer_clust_size=12)
+    got = ca.search_pipeline(seqs, params=p)
+    ref = orc.pipeline(seqs, params=orc.Params(p.lowDRsize, p.highDRsize, p.lowSpacerSize, p.highSpacerSize, p.searchWindowLength,
+                                               p.minNumRepeats, p.kmer_clust_size))
+    assert got.counters["used_device_merge"] == 1
+    assert sum(1 for t in ref.tokens if b"N" in t) >= 20
+    assert_same_pipeline(got, ref)
