@@ -1289,17 +1289,61 @@ static __device__ __forceinline__ uint32_t ln_code(const LaneRead &h, int p)
 static __device__ __forceinline__ uint32_t ln_ss(const LaneRead &h, int k) { return h.ss[k * WAVE]; }
 static __device__ __forceinline__ void ln_ss_set(LaneRead &h, int k, uint32_t v) { h.ss[k * WAVE] = (uint16_t)v; }
 
-// bmpSearch semantics (PatternMatcher.cpp:26-59) for the w-mer at `pat` in [begin, end)
+// bases [start, start + 64) of the lane's read as two 64-bit words (2 bits per base, base `start` in bits 0-1); bases past
+// the stored words read as 0.  Five independent LDS reads and four funnel shifts: the loops that follow run on registers
+// (a per-base ln_base() in a dependent loop is one LDS round trip per iteration: the QC stage was 82 us of 155 that way).
+static __device__ __forceinline__ void ln_load128(const LaneRead &h, int start, uint64_t &lo, uint64_t &hi)
+{
+    const int wi = start >> 4;
+    const uint32_t sh = (uint32_t)(start & 15) * 2u;
+    const uint32_t a0 = ln_word(h, wi), a1 = ln_word(h, wi + 1), a2 = ln_word(h, wi + 2), a3 = ln_word(h, wi + 3), a4 = ln_word(h, wi + 4);
+    const uint32_t y0 = __builtin_amdgcn_alignbit(a1, a0, sh), y1 = __builtin_amdgcn_alignbit(a2, a1, sh);
+    const uint32_t y2 = __builtin_amdgcn_alignbit(a3, a2, sh), y3 = __builtin_amdgcn_alignbit(a4, a3, sh);
+    lo = (uint64_t)y0 | ((uint64_t)y1 << 32); hi = (uint64_t)y2 | ((uint64_t)y3 << 32);
+}
+// even bits of a 64-bit word compacted into the low 32 bits
+static __device__ __forceinline__ uint32_t ln_even_bits(uint64_t x)
+{
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (uint32_t)x;
+}
+// the two bit planes of n <= 64 bases held in (lo, hi): bit i of p0 / p1 = low / high bit of base i
+static __device__ __forceinline__ void ln_planes(uint64_t lo, uint64_t hi, int n, uint64_t &p0, uint64_t &p1)
+{
+    p0 = (uint64_t)ln_even_bits(lo) | ((uint64_t)ln_even_bits(hi) << 32);
+    p1 = (uint64_t)ln_even_bits(lo >> 1) | ((uint64_t)ln_even_bits(hi >> 1) << 32);
+    const uint64_t m = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    p0 &= m; p1 &= m;
+}
+
+// bmpSearch semantics (PatternMatcher.cpp:26-59) for the w-mer at `pat` in [begin, end).  The text is pulled through a
+// 64-bit register, 32 bases per refill: no LDS access inside the compare loop (a per-base ln_base() there was one LDS
+// round trip per iteration).
 static __device__ int ln_find(const LaneRead &h, int begin, int end, int pat, int plen)
 {
     if (end - begin <= 0 || plen <= 0 || plen > end - begin) return -1;
     const uint32_t sj = ln_code(h, pat);
     uint32_t code = ln_code(h, begin);
     const int top = 2 * (plen - 1);
+    int nb = begin + plen;                               // next base to shift in
+    uint64_t buf = 0; int left = 0;                      // bases nb .. nb + left - 1, base nb in bits 0-1
     for (int p = begin;; p++) {
         if (code == sj) return p;
         if (p + 1 + plen > end) return -1;
-        code = (code >> 2) | (ln_base(h, p + plen) << top);      // slide the window by one base
+        if (left == 0) {
+            const int wi = nb >> 4;
+            const uint32_t sh = (uint32_t)(nb & 15) * 2u;
+            const uint32_t a0 = ln_word(h, wi), a1 = ln_word(h, wi + 1), a2 = ln_word(h, wi + 2);
+            buf = (uint64_t)__builtin_amdgcn_alignbit(a1, a0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh) << 32);
+            left = 32;
+        }
+        code = (code >> 2) | ((uint32_t)(buf & 3ull) << top);
+        buf >>= 2; left--; nb++;
     }
 }
 
@@ -1337,8 +1381,72 @@ static __device__ void ln_scan_right(LaneRead &h, int pat, uint32_t pattern_leng
     }
 }
 
+// number of leading equal 2-bit groups of two strings given as xor (x0 low): up to n <= 64 groups
+static __device__ __forceinline__ int ln_run_up(uint64_t x0, uint64_t x1, int n)
+{
+    int r = x0 ? (__ffsll((unsigned long long)x0) - 1) >> 1 : (x1 ? 32 + ((__ffsll((unsigned long long)x1) - 1) >> 1) : 64);
+    return r < n ? r : n;
+}
+// ... of trailing equal groups, counted from group n - 1 downwards (n <= 64, n >= 1)
+static __device__ __forceinline__ int ln_run_down(uint64_t x0, uint64_t x1, int n)
+{
+    int r;
+    if (n <= 32) { const uint64_t y = x0 << (64 - 2 * n); r = y ? __clzll((long long)y) >> 1 : n; }
+    else {
+        const uint64_t y1 = x1 << (64 - 2 * (n - 32));
+        if (y1) r = __clzll((long long)y1) >> 1;
+        else r = (n - 32) + (x0 ? __clzll((long long)x0) >> 1 : 32);
+    }
+    return r < n ? r : n;
+}
+
+// extendPreRepeat (libcrispr.cpp:520-772) for exactly TWO repeats, in closed form.  With two repeats cut_off = 2 (:538-544),
+// so a column is accepted iff both copies hold the same base (:617-651; packed reads hold A/C/G/T only), the right phase
+// stops at the first disagreement, after shortest_spacing - minSpacer columns (:581), or when the second copy runs into
+// the read end — there the reference drops the last repeat from the vote (:614-616) and the one that is left cannot reach
+// the cut-off —; the left phase likewise, bounded by shortest_spacing - length so far (:674-675) and by the read start
+// (:700-704).  The agreeing runs are xor + count-zeros on 128-bit pieces of the read instead of a per-column vote.
+static __device__ uint32_t ln_extend2(LaneRead &h, int searchWindowLength, int minSpacerLength)
+{
+    const int j = (int)ln_ss(h, 0), p = (int)ln_ss(h, 2), L = h.L, w = searchWindowLength;
+    const int spacing = p - j;
+    int max_right = spacing - minSpacerLength;                  // (unsigned in the reference; spacing >= minSpacer + w here)
+    if (max_right > L - (p + w)) max_right = L - (p + w);       // the second copy's column must lie inside the read
+    int right = 0;
+    while (right < max_right) {
+        uint64_t a0, a1, b0, b1;
+        ln_load128(h, j + w + right, a0, a1); ln_load128(h, p + w + right, b0, b1);
+        const int n = max_right - right < 64 ? max_right - right : 64;
+        const int r = ln_run_up(a0 ^ b0, a1 ^ b1, n);
+        right += r;
+        if (r < n) break;
+    }
+    const int len_r = w + right;
+    int max_left = spacing - len_r;
+    if (max_left < 0) max_left = 0;
+    if (max_left > j) max_left = j;                             // the first copy's column must lie inside the read
+    int left = 0;
+    while (left < max_left) {
+        const int n = max_left - left < 64 ? max_left - left : 64;
+        uint64_t a0, a1, b0, b1;
+        ln_load128(h, j - left - n, a0, a1); ln_load128(h, p - left - n, b0, b1);
+        const int r = ln_run_down(a0 ^ b0, a1 ^ b1, n);
+        left += r;
+        if (r < n) break;
+    }
+    h.replen = w + right + left;
+    for (int r = 0; r + 1 < h.nss; r += 2) {
+        uint32_t a = ln_ss(h, r), b = ln_ss(h, r + 1);
+        a = (a < (uint32_t)left) ? 0 : a - (uint32_t)left;
+        b = (b + (uint32_t)right >= (uint32_t)L) ? (uint32_t)L - 1 : b + (uint32_t)right;
+        ln_ss_set(h, r, a); ln_ss_set(h, r + 1, b);
+    }
+    return (uint32_t)h.replen;
+}
+
 static __device__ uint32_t ln_extend(LaneRead &h, int searchWindowLength, int minSpacerLength)
 {   // extendPreRepeat, libcrispr.cpp:520-772 (serial columns, like the reference)
+    if (h.nss == 4) return ln_extend2(h, searchWindowLength, minSpacerLength);
     const uint32_t num_repeats = (uint32_t)h.nss / 2;
     h.replen = searchWindowLength;
     int cut_off = (int)(num_repeats - 1);
@@ -1394,38 +1502,6 @@ static __device__ uint32_t ln_extend(LaneRead &h, int searchWindowLength, int mi
         ln_ss_set(h, r, a); ln_ss_set(h, r + 1, b);
     }
     return (uint32_t)h.replen;
-}
-
-// bases [start, start + 64) of the lane's read as two 64-bit words (2 bits per base, base `start` in bits 0-1); bases past
-// the stored words read as 0.  Five independent LDS reads and four funnel shifts: the loops that follow run on registers
-// (a per-base ln_base() in a dependent loop is one LDS round trip per iteration: the QC stage was 82 us of 155 that way).
-static __device__ __forceinline__ void ln_load128(const LaneRead &h, int start, uint64_t &lo, uint64_t &hi)
-{
-    const int wi = start >> 4;
-    const uint32_t sh = (uint32_t)(start & 15) * 2u;
-    const uint32_t a0 = ln_word(h, wi), a1 = ln_word(h, wi + 1), a2 = ln_word(h, wi + 2), a3 = ln_word(h, wi + 3), a4 = ln_word(h, wi + 4);
-    const uint32_t y0 = __builtin_amdgcn_alignbit(a1, a0, sh), y1 = __builtin_amdgcn_alignbit(a2, a1, sh);
-    const uint32_t y2 = __builtin_amdgcn_alignbit(a3, a2, sh), y3 = __builtin_amdgcn_alignbit(a4, a3, sh);
-    lo = (uint64_t)y0 | ((uint64_t)y1 << 32); hi = (uint64_t)y2 | ((uint64_t)y3 << 32);
-}
-// even bits of a 64-bit word compacted into the low 32 bits
-static __device__ __forceinline__ uint32_t ln_even_bits(uint64_t x)
-{
-    x &= 0x5555555555555555ull;
-    x = (x | (x >> 1)) & 0x3333333333333333ull;
-    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-    return (uint32_t)x;
-}
-// the two bit planes of n <= 64 bases held in (lo, hi): bit i of p0 / p1 = low / high bit of base i
-static __device__ __forceinline__ void ln_planes(uint64_t lo, uint64_t hi, int n, uint64_t &p0, uint64_t &p1)
-{
-    p0 = (uint64_t)ln_even_bits(lo) | ((uint64_t)ln_even_bits(hi) << 32);
-    p1 = (uint64_t)ln_even_bits(lo >> 1) | ((uint64_t)ln_even_bits(hi >> 1) << 32);
-    const uint64_t m = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-    p0 &= m; p1 &= m;
 }
 
 // Bit-parallel distance (see lane_lev_bp: Hyyro's OSA recurrences with the reference's transposition term restricted to
@@ -1564,6 +1640,23 @@ static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLengt
         const int nsp = num_repeats - 1;
         uint32_t cur_start = ln_ss(h, 1) + 1, cur_len;
         if (!substr_len(h.L, cur_start, ln_ss(h, 2) - cur_start, cur_len)) return -1;
+        if (nsp == 2) {
+            // three repeats, ONE comparison: every average is the single value itself (x / 1.0f == x), so the two similarity
+            // tests are plain threshold tests and may stop early (ln_similarity_above); the outcome is a boolean either way
+            uint32_t nxt_start = ln_ss(h, 3) + 1, nxt_len;
+            if (!substr_len(h.L, nxt_start, ln_ss(h, 4) - nxt_start, nxt_len)) return -1;
+            const int mn = (int)(cur_len < nxt_len ? cur_len : nxt_len), mx = (int)(cur_len > nxt_len ? cur_len : nxt_len);
+            if (mn < minSpacerLength || mx > maxSpacerLength) return 0;
+            const bool a = ln_similarity_above(h, (int)cur_start, (int)cur_len, (int)nxt_start, (int)nxt_len, 0.82);
+            if (h.punt) return 0;
+            if (a) return 0;
+            const bool b = ln_similarity_above(h, (int)rep_start, (int)rep_len, (int)cur_start, (int)cur_len, 0.82);
+            if (h.punt) return 0;
+            if (b) return 0;
+            if ((int)fabsf(((float)cur_len - (float)nxt_len) / 1.0f) > 12) return 0;
+            if ((int)fabsf(((float)rep_len - (float)cur_len) / 1.0f) > 30) return 0;
+            return 1;
+        }
         for (int i = 0; i < nsp; i++) {
             if ((int)cur_len < min_spacer_length) min_spacer_length = (int)cur_len;
             if ((int)cur_len > max_spacer_length) max_spacer_length = (int)cur_len;
@@ -1711,18 +1804,61 @@ __global__ __launch_bounds__(WAVE) void k_survivor_lanes(DevReads R, DevParams P
         if (!substr_len(L, st, ln_ss(h, pick + 1) - st + 1, dlen) || dlen > dr_stride) o.err = 1;
         else {
             int less = 0;
+            char *dr = dr_chars + s * (uint64_t)dr_stride;
+            const uint32_t off = (uint32_t)s * ss_cap;
+            if (dlen <= 64 && (dr_stride & 15u) == 0) {
+                // the repeat as a 128-bit value, its reverse complement by bit reversal, DRLowLexi's string comparison as
+                // "first differing base from the low end" (as k_recruit_finish), the ASCII string four bases per word
+                uint64_t v0, v1;
+                ln_load128(h, (int)st, v0, v1);
+                const uint64_t m0 = dlen >= 32 ? ~0ull : ((1ull << (2 * dlen)) - 1ull);
+                const uint64_t m1 = dlen >= 64 ? ~0ull : (dlen > 32 ? ((1ull << (2 * (dlen - 32))) - 1ull) : 0ull);
+                v0 &= m0; v1 &= m1;
+                auto rev2 = [](uint64_t t) -> uint64_t { t = __brevll(t); return ((t >> 1) & 0x5555555555555555ull) | ((t & 0x5555555555555555ull) << 1); };
+                const uint64_t c0 = rev2(~v1), c1 = rev2(~v0);
+                const uint32_t drop = 128u - 2u * dlen;
+                uint64_t r0, r1;
+                if (drop == 0) { r0 = c0; r1 = c1; }
+                else if (drop < 64) { r0 = (c0 >> drop) | (c1 << (64 - drop)); r1 = c1 >> drop; }
+                else { r0 = c1 >> (drop - 64); r1 = 0; }
+                r0 &= m0; r1 &= m1;
+                const uint64_t d0 = v0 ^ r0, d1 = v1 ^ r1;
+                if (d0 | d1) {
+                    const uint64_t dv = d0 ? d0 : d1, av = d0 ? v0 : v1, bv = d0 ? r0 : r1;
+                    const int p = (__ffsll((unsigned long long)dv) - 1) & ~1;
+                    less = ((av >> p) & 3ull) < ((bv >> p) & 3ull);
+                }
+                const uint64_t s0 = less ? v0 : r0, s1 = less ? v1 : r1;
+                uint4 *d4 = reinterpret_cast<uint4 *>(dr);
+                for (uint32_t q = 0; q < dr_stride / 16; q++) {             // 16 bases = 32 bits of the packed string per uint4
+                    const uint32_t bits = q < 2 ? (uint32_t)(s0 >> (32 * q)) : (q < 4 ? (uint32_t)(s1 >> (32 * (q - 2))) : 0u);
+                    uint32_t wv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t b8 = (bits >> (8 * k)) & 0xFFu;
+                        const uint32_t Ls = ((b8 & 0x55u) * 0x00041041u) & 0x01010101u, Hs = (((b8 >> 1) & 0x55u) * 0x00041041u) & 0x01010101u;
+                        uint32_t asc = 0x41414141u + (Ls << 1) + Hs * 6u + (Ls & Hs) * 0x0Bu;       // A 41, C 43, G 47, T 54
+                        const int rem = (int)dlen - (int)(q * 16 + k * 4);                           // bases left from this word on
+                        if (rem <= 0) asc = 0u; else if (rem < 4) asc &= (1u << (8 * rem)) - 1u;
+                        wv[k] = asc;
+                    }
+                    uint4 o4; o4.x = wv[0]; o4.y = wv[1]; o4.z = wv[2]; o4.w = wv[3];
+                    d4[q] = o4;
+                }
+                if (less) for (int k = 0; k < h.nss; k++) ss_pool[off + k] = ln_ss(h, k);
+                else for (int k = 0; k < h.nss; k++) ss_pool[off + k] = (uint32_t)L - 1 - ln_ss(h, h.nss - 1 - k);   // reverseStartStops
+            } else {
             for (uint32_t i = 0; i < dlen; i++) {
                 const uint32_t a = ln_base(h, (int)(st + i)), b = 3u - ln_base(h, (int)(st + dlen - 1 - i));
                 if (a != b) { less = a < b; break; }
             }
-            char *dr = dr_chars + s * (uint64_t)dr_stride;
-            const uint32_t off = (uint32_t)s * ss_cap;
             if (less) {
                 for (uint32_t i = 0; i < dr_stride; i++) dr[i] = (i < dlen) ? "ACGT"[ln_base(h, (int)(st + i))] : (char)0;
                 for (int k = 0; k < h.nss; k++) ss_pool[off + k] = ln_ss(h, k);
             } else {
                 for (uint32_t i = 0; i < dr_stride; i++) dr[i] = (i < dlen) ? "ACGT"[3u - ln_base(h, (int)(st + dlen - 1 - i))] : (char)0;
                 for (int k = 0; k < h.nss; k++) ss_pool[off + k] = (uint32_t)L - 1 - ln_ss(h, h.nss - 1 - k);   // reverseStartStops
+            }
             }
             o.found = 1; o.n_ss = (uint32_t)h.nss; o.repeat_len = (uint32_t)h.replen; o.ss_off = off;
             o.dr_len = (uint16_t)dlen; o.low_lexi = (uint8_t)less;
