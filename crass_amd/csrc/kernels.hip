@@ -1519,17 +1519,17 @@ static __device__ __forceinline__ int ln_lev_regs(uint64_t s_lo, uint64_t s_hi, 
     WORD VP = ~(WORD)0, VN = 0, D0 = 0, PMold = 0;
     int dist = n;
     const int topbit = n - 1;
+    const WORD top = (WORD)1 << topbit;
     for (int j = 0; j < m; j++) {
         const uint32_t c = (uint32_t)((j < 32 ? t_lo >> (2 * j) : t_hi >> (2 * (j - 32))) & 3ull);
-        const WORD PMj = (pm0 & ((WORD)0 - (WORD)(c == 0))) | (pm1 & ((WORD)0 - (WORD)(c == 1))) |
-                         (pm2 & ((WORD)0 - (WORD)(c == 2))) | (pm3 & ((WORD)0 - (WORD)(c == 3)));
+        const WORD PMj = (c & 2u) ? ((c & 1u) ? pm3 : pm2) : ((c & 1u) ? pm1 : pm0);         // three selects instead of four masked ors
         WORD TR = (WORD)((((WORD)~D0) & PMj) << 1) & PMold & ~(WORD)3;
-        TR &= (WORD)0 - (WORD)(j >= 2);
+        if (j < 2) TR = 0;
         D0 = (WORD)((WORD)((WORD)(PMj & VP) + VP) ^ VP) | PMj | VN;
         D0 |= TR;
         WORD HP = VN | (WORD)~(D0 | VP);
         WORD HN = D0 & VP;
-        dist += (int)((HP >> topbit) & 1) - (int)((HN >> topbit) & 1);
+        dist += (int)((HP & top) != 0) - (int)((HN & top) != 0);
         HP = (WORD)(HP << 1) | (WORD)1;
         HN = (WORD)(HN << 1);
         VP = HN | (WORD)~(D0 | HP);
@@ -1584,7 +1584,8 @@ static __device__ int ln_distance(LaneRead &h, int s0, int n, int t0, int m, int
     if (m <= 64) {
         uint64_t sl, sh, tl, th;
         ln_load128(h, s0, sl, sh); ln_load128(h, t0, tl, th);
-        return (n <= 32) ? ln_lev_regs<uint32_t>(sl, sh, n, tl, th, m, stop_at) : ln_lev_regs<uint64_t>(sl, sh, n, tl, th, m, stop_at);
+        // (one instantiation for every pair: a wave whose pairs fall on both sides of 32 would issue both loops in turn)
+        return ln_lev_regs<uint64_t>(sl, sh, n, tl, th, m, stop_at);
     }
     return (n <= 32) ? ln_lev_core<uint32_t>(h, s0, n, t0, m) : ln_lev_core<uint64_t>(h, s0, n, t0, m);
 }
@@ -1613,8 +1614,9 @@ static __device__ bool ln_similarity_above(LaneRead &h, int s0, int n, int t0, i
     return (double)(float)(1.0 - (double)((float)d / max_length)) > cut;
 }
 
-static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLength)
+static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLength, uint32_t dbg = 0)
 {   // qcFoundRepeats, libcrispr.cpp:869-1029
+    if (dbg == 6) return 1;                             // (CRASS_SURV_DEBUG, timing breakdown only)
     const int num_repeats = h.nss / 2;
     if (num_repeats < 2) return -1;
     uint32_t rep_len;
@@ -1632,6 +1634,7 @@ static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLengt
         const int cut_off = (int)((double)(int)rep_len * 0.75);
         if (c0 > cut_off || c3 > cut_off || c2 > cut_off || c1 > cut_off) return 0;
     }
+    if (dbg == 5) return 1;
     bool is_short = (2 > (num_repeats - 1));
     if (!is_short) {
         float ave_spacer_to_spacer_len_difference = 0.0f, ave_repeat_to_spacer_len_difference = 0.0f;
@@ -1714,43 +1717,63 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t s
     bool on_lattice = true;
     uint32_t lattice_i = 0;
     uint32_t j = 0;
+    // Two nested loops instead of the reference's one: the inner loop advances a lane from seed to seed (find, chain,
+    // extend — cheap since the closed-form extension) until it holds a candidate that is due for qcFoundRepeats or has
+    // run out of seeds; only then do the lanes of the wave that hold such a candidate run the QC, together.  The
+    // sequence of events per read is the reference's; what changes is that the QC code — by far the longest stretch —
+    // is issued once per round for the whole wave instead of once per seed iteration in which some lane needs it
+    // (lanes reach their first QC in different iterations: 51 us of the kernel's 117 were QC issue slots).
+    bool finished = false; int result = 0;                  // this lane's searchCore has returned `result`
     for (;;) {
-        // Each lane first walks (cheaply) to ITS next seed worth evaluating, so that the expensive body
-        // below runs once per candidate of the busiest lane instead of once per seed index of the wave.
-        // A lattice seed whose hint bit is clear is a no-op iteration in the reference (no hit => no
-        // start/stops => numRepeats 0): skipping it changes nothing.
-        while (on_lattice && j <= (uint32_t)searchEnd && lattice_i < 32 && !((seed_hint >> lattice_i) & 1u)) { j += skips; lattice_i++; }
-        if (j > (uint32_t)searchEnd) break;
-        if (on_lattice) lattice_i++;
-        uint32_t beginSearch = j + o.lowDR + o.lowSp;
-        uint32_t endSearch = j + o.highDR + o.highSp + o.window;
-        if (endSearch >= seq_length) endSearch = seq_length - 1;
-        if (endSearch < beginSearch) endSearch = beginSearch;
-        if (beginSearch > seq_length) return -1;
-        int pos = ln_find(h, (int)beginSearch, (int)endSearch, (int)j, (int)o.window);
-        if (o.debug_stop == 2) pos = -1;                // (CRASS_SURV_DEBUG, timing breakdown only: seed finds alone)
-        if (pos >= 0) {
-            ln_add(h, j, j + o.window - 1);
-            ln_add(h, (uint32_t)pos, (uint32_t)pos + o.window - 1);
-            if (h.punt) return 0;
-            ln_scan_right(h, (int)j, o.window, o.lowSp, 24);
-            if (h.punt) return 0;
-        }
-        if ((uint32_t)(h.nss / 2) >= o.minRepeats) {
-            uint32_t actual_repeat_length = ln_extend(h, (int)o.window, (int)o.lowSp);
-            if (o.debug_stop != 3 && (actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {     // (3: no QC)
-                int qc = ln_qc(h, (int)o.lowSp, (int)o.highSp);
-                if (h.punt) return 0;
-                if (qc < 0) return -1;
-                if (qc) return 1;
+        bool ready = false, error = false, out_of_seeds = false;
+        // (wave-uniform loop condition: the lanes leave this loop TOGETHER, whatever the compiler makes of the control flow)
+        while (__any((int)(!finished && !ready && !out_of_seeds && !error))) {
+            if (finished || ready || out_of_seeds || error) continue;
+            // Each lane first walks (cheaply) to ITS next seed worth evaluating.  A lattice seed whose hint bit is
+            // clear is a no-op iteration in the reference (no hit => no start/stops => numRepeats 0): skipping it
+            // changes nothing.
+            while (on_lattice && j <= (uint32_t)searchEnd && lattice_i < 32 && !((seed_hint >> lattice_i) & 1u)) { j += skips; lattice_i++; }
+            if (j > (uint32_t)searchEnd) { out_of_seeds = true; continue; }
+            if (on_lattice) lattice_i++;
+            uint32_t beginSearch = j + o.lowDR + o.lowSp;
+            uint32_t endSearch = j + o.highDR + o.highSp + o.window;
+            if (endSearch >= seq_length) endSearch = seq_length - 1;
+            if (endSearch < beginSearch) endSearch = beginSearch;
+            if (beginSearch > seq_length) { error = true; continue; }
+            int pos = ln_find(h, (int)beginSearch, (int)endSearch, (int)j, (int)o.window);
+            if (o.debug_stop == 2) pos = -1;                // (CRASS_SURV_DEBUG, timing breakdown only: seed finds alone)
+            if (pos >= 0) {
+                ln_add(h, j, j + o.window - 1);
+                ln_add(h, (uint32_t)pos, (uint32_t)pos + o.window - 1);
+                if (!h.punt) ln_scan_right(h, (int)j, o.window, o.lowSp, 24);
+                if (h.punt) { finished = true; result = 0; continue; }
             }
-            j = ln_ss(h, h.nss - 1) - 1;
-            on_lattice = false;
+            if ((uint32_t)(h.nss / 2) >= o.minRepeats) {
+                uint32_t actual_repeat_length = ln_extend(h, (int)o.window, (int)o.lowSp);
+                if (o.debug_stop != 3 && (actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) { ready = true; continue; }    // (3: no QC)
+                j = ln_ss(h, h.nss - 1) - 1;
+                on_lattice = false;
+            }
+            h.nss = 0;
+            j = j + skips;
         }
-        h.nss = 0;
-        j = j + skips;
+        if (!finished && error) { finished = true; result = -1; }
+        if (!finished && out_of_seeds) { finished = true; result = 0; }
+        if (!__any((int)(!finished))) break;
+        if (!finished) {
+            int qc = ln_qc(h, (int)o.lowSp, (int)o.highSp, o.debug_stop);
+            if (h.punt) { finished = true; result = 0; }
+            else if (qc < 0) { finished = true; result = -1; }
+            else if (qc) { finished = true; result = 1; }
+            else {
+                j = ln_ss(h, h.nss - 1) - 1;                // a rejected candidate: on with the seeds behind it (:390)
+                on_lattice = false;
+                h.nss = 0;
+                j = j + skips;
+            }
+        }
     }
-    return 0;
+    return result;
 }
 
 __global__ __launch_bounds__(WAVE) void k_survivor_lanes(DevReads R, DevParams P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
