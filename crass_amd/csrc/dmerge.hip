@@ -278,6 +278,7 @@ static __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 }
 __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
 {
+    CRASS_VGPR_FLOOR(48);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -402,6 +403,7 @@ static __device__ __forceinline__ void dm_table_params(uint32_t n, uint32_t tab_
 // by the last kernel.
 __global__ __launch_bounds__(256) void k_dm_key_bases_insert(DevMerge M)
 {
+    CRASS_VGPR_FLOOR(8);
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tok = e >> 4;
     // every thread derives the table shape from the key count (a handful of scalar instructions); thread 0 records it

@@ -211,6 +211,15 @@ hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t
 hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, uint64_t n_words, uint64_t *hint_bits,
                                  hipStream_t st);
 hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st);
+// ---- "last VGPR of the allocation" guard ----
+// Observed on the MI355X pool (minimal reproduction: profiles/ubench/vgpr_edge2.hip, write-up in DESIGN.md): a wave
+// that is NOT the first wave on its SIMD can lose the contents of the LAST register of its VGPR allocation (granule
+// 8 registers on gfx950) while it runs next to another wave, so a kernel whose .vgpr_count is a multiple of 8 computes
+// garbage now and then in whatever it keeps in that register.  k_recruit_finish (24 VGPRs, the 128-bit shift amount in
+// v23) flipped DRLowLexi for about 1 recruit in 1000 that way.  The build refuses such kernels (crass_amd/vgpr_guard.py);
+// CRASS_VGPR_FLOOR(n) marks v<n> as used (no instruction is emitted), which moves .vgpr_count to at least n + 1.
+#define CRASS_VGPR_FLOOR(N) asm volatile("" ::: "v" #N)
+
 // Single-pass ordered compaction (decoupled look-back): per-tile status words, a ticket counter that hands out
 // tile ids in start order (a tile only ever waits for tiles that started before it) and an epoch tag so that
 // neither needs clearing between launches.  Built by crass_hip_ctx::next_lookback().

@@ -21,7 +21,17 @@ def load(path, counter):
     return {k: sum(v) / len(v) for k, v in out.items()}
 
 
-def main(fetch_csv, write_csv, out_json):
+def source_hash():
+    import hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ("kernels.hip", "dmerge.hip"):
+        with open(os.path.join(root, "crass_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def main(fetch_csv, write_csv, out_json, reads=10000000, read_len=150):
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     res = {}
     for k in sorted(set(f) | set(w)):
@@ -29,10 +39,11 @@ def main(fetch_csv, write_csv, out_json):
         wr = w.get(k, 0.0)
         res[k] = {"hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes": round(rd + wr),
                   "fetch_size_raw_kb": round(f.get(k, 0.0) / 1024.0, 3), "write_size_raw_kb": round(w.get(k, 0.0) / 1024.0, 3)}
-    json.dump({"workload": "bench.py --steps 1 --warmup 0 (10 M x 150 bp reads)", "correction": "FETCH_SIZE x2 (gfx950)",
+    json.dump({"workload": "bench.py --steps 3 --warmup 1 (%d x %d bp reads)" % (int(reads), int(read_len)), "correction": "FETCH_SIZE x2 (gfx950)",
+               "source_hash": source_hash(), "reads": int(reads), "read_len": int(read_len),      # bench.py only quotes traffic taken on THIS kernel source
                "per_launch": res}, open(out_json, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:])

@@ -35,6 +35,15 @@ def test_header_symbols_all_exported(ca):
     assert ca.load().crass_hip_abi_version() == 1
 
 
+def test_no_kernel_uses_the_last_vgpr_of_its_allocation(ca):
+    """engine_internal.h, CRASS_VGPR_FLOOR: on the MI355X pool a wave that shares its SIMD loses the last register of its
+    VGPR allocation now and then (profiles/ubench/vgpr_edge2.hip), so no kernel's .vgpr_count may be a multiple of 8"""
+    from crass_amd import vgpr_guard
+    counts = vgpr_guard.kernel_vgpr_counts(ca.LIB_PATH)
+    assert len(counts) > 100 and any("k_recruit_finish" in k for k in counts)
+    assert [kv for kv in counts.items() if kv[1] % 8 == 0] == []
+
+
 def test_no_gpu_means_loud_failure_not_fallback(ca):
     import torch
     if torch.cuda.is_available():

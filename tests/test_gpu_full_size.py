@@ -1,0 +1,106 @@
+"""BASELINE.json configs[2], [3], [4] at FULL size on one GPU, through size-independent properties (the oracle needs
+minutes for these sizes): determinism across two runs of one context, ascending record order, pass-2 reads disjoint from
+pass-1 reads, tokens in range, every recruit's DR equal to its token's string and present in the read at the reported
+place — plus exact oracle equality of the pass-1 records of a prefix (pass-1 decisions are per read) and, for the
+long-read config, of the whole pipeline on a prefix processed separately."""
+import numpy as np
+import pytest
+
+from tests import orc
+from tests.parity import assert_same_pipeline
+
+pytestmark = pytest.mark.gpu
+RC = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import crass_amd
+    crass_amd.load()
+    return crass_amd
+
+
+def run_twice(ca, spec, n, L):
+    words = ca.synth_packed(spec, 0, n)
+    with ca.SearchEngine() as eng:
+        eng.load_packed_uniform(words, n, L)
+        c1 = eng.seed_scan(); m1 = eng.merge(); r1 = eng.recruit(); m1 = eng.merge_view()
+        c2 = eng.seed_scan(); m2 = eng.merge(); r2 = eng.recruit(); m2 = eng.merge_view()
+        for _ in range(4):          # pass 2 alone, repeated (the "last VGPR" erratum flipped ~1 low_lexi in 1000 per run here)
+            r3 = eng.recruit()
+            assert np.array_equal(r3.read_idx, r2.read_idx) and np.array_equal(r3.start, r2.start) and np.array_equal(r3.end, r2.end)
+            assert np.array_equal(r3.low_lexi, r2.low_lexi) and np.array_equal(r3.token, r2.token)
+        cnt = eng.counters()
+    for a, b in ((c1.read_idx, c2.read_idx), (c1.ss_pool, c2.ss_pool), (c1.dr_chars, c2.dr_chars), (r1.read_idx, r2.read_idx),
+                 (r1.start, r2.start), (r1.end, r2.end), (r1.low_lexi, r2.low_lexi), (r1.token, r2.token), (m1.cand_token, m2.cand_token)):
+        assert np.array_equal(a, b)
+    assert m1.patterns == m2.patterns and m1.groups == m2.groups and m1.tokens == m2.tokens
+    return words, c1, m1, r1, cnt
+
+
+def check_properties(ca, words, c, m, r, n, L, prefix):
+    W = (L + 15) // 16
+    assert np.all(np.diff(c.read_idx.astype(np.int64)) > 0) and np.all(np.diff(r.read_idx.astype(np.int64)) > 0)
+    assert len(np.intersect1d(c.read_idx, r.read_idx)) == 0
+    assert c.read_idx.max() < n and r.read_idx.max() < n
+    assert r.token.min() >= 2 and r.token.max() <= m.n_tokens + 1
+    assert np.all(r.end - r.start + 1 == r.dr_len)
+    flat = sorted(t for g in m.groups for t in g)
+    assert flat == list(range(2, 2 + m.n_tokens))                   # every token in exactly one group
+    for k in range(0, r.n, max(1, r.n // 400)):                     # the recruit's DR is its token's string, found in the read
+        dr = r.dr(k)
+        assert dr == m.tokens[int(r.token[k]) - 2]
+        i = int(r.read_idx[k])
+        seq = ca.unpack_ascii(words[i * W:(i + 1) * W], W, L, 1).tobytes()
+        if not r.low_lexi[k]:
+            seq = seq.translate(RC)[::-1]
+        assert seq[int(r.start[k]):int(r.end[k]) + 1] == dr
+    for k in range(0, c.n, max(1, c.n // 400)):                     # a candidate's representative repeat sits at one of its start/stops
+        ss = c.ss(k)
+        i = int(c.read_idx[k])
+        seq = ca.unpack_ascii(words[i * W:(i + 1) * W], W, L, 1).tobytes()
+        if not c.low_lexi[k]:
+            seq = seq.translate(RC)[::-1]
+        assert any(seq[ss[q]:ss[q + 1] + 1] == c.dr(k) for q in range(0, len(ss), 2))
+    # pass-1 records of the first `prefix` reads against the oracle
+    asc = ca.unpack_ascii(words, W, L, prefix)
+    off = np.arange(0, (prefix + 1) * L, L, dtype=np.uint64)
+    ref = orc.pipeline((asc, off), do_pass2=False)
+    k = int(np.searchsorted(c.read_idx, prefix))
+    assert k == ref.n_pass1 and np.array_equal(c.read_idx[:k], ref.rec_read[:k])
+    assert np.array_equal(c.low_lexi[:k], ref.rec_lowlexi[:k]) and np.array_equal(c.repeat_len[:k], ref.rec_replen[:k])
+    for q in range(0, k, max(1, k // 2000)):
+        assert c.ss(q) == ref.ss(q)
+        assert c.dr(q) == ref.tokens[int(ref.rec_token[q]) - 2]
+    return asc, off
+
+
+def test_config2_100m_reads(ca):
+    """configs[2] on one GPU: 100 M x 150 bp, 50 seeded DRs (4 GB of packed reads resident)"""
+    n, L = 100_000_000, 150
+    words, c, m, r, cnt = run_twice(ca, ca.synth_spec(read_len=L), n, L)
+    assert cnt["used_device_merge"] == 1 and cnt["used_fast_filter"] == 1
+    assert c.n > 400_000 and r.n > 300_000 and m.n_groups >= 50
+    check_properties(ca, words, c, m, r, n, L, 400_000)
+
+
+def test_config4_200m_reads_500_drs(ca):
+    """configs[4]: 200 M x 150 bp, 500 seeded DRs, 4 GC classes — the pass-2 key set is beyond the LDS tiers"""
+    n, L = 200_000_000, 150
+    words, c, m, r, cnt = run_twice(ca, ca.synth_spec(read_len=L, n_dr=500, gc_classes=4), n, L)
+    assert cnt["used_device_merge"] == 1 and cnt["anchor_table_kind"] == 2
+    assert m.n_groups >= 500 and m.n_patterns > 20_000 and r.n > 500_000
+    check_properties(ca, words, c, m, r, n, L, 300_000)
+
+
+def test_config3_1m_long_reads(ca):
+    """configs[3]: 1 M x 10 kbp reads, arrays of 20-60 repeats in 5 % of them (no per-read filter: position hints + the
+    wave-per-read kernel)"""
+    n, L = 1_000_000, 10_000
+    spec = ca.synth_spec(read_len=L, crispr_per_million=50000, array_min_repeats=20, array_max_repeats=60)
+    words, c, m, r, cnt = run_twice(ca, spec, n, L)
+    assert c.n > 40_000 and m.n_groups >= 50
+    asc, off = check_properties(ca, words, c, m, r, n, L, 3000)
+    # and the whole pipeline on that prefix, processed on its own
+    seqs = [asc[i * L:(i + 1) * L].tobytes() for i in range(3000)]
+    assert_same_pipeline(ca.search_pipeline(seqs), orc.pipeline(seqs))
