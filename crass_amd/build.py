@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-o", LIB]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-lz", "-lpthread"]
+    cmd += ["-lz", "-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -58,7 +58,7 @@ def build_adapter(force=False, verbose=False):
             all(os.path.getmtime(d) <= min(os.path.getmtime(CLI), os.path.getmtime(ADAPTER_LIB)) for d in deps):
         return CLI
     cxx = shutil.which("g++") or "g++"
-    common = [cxx, "-O2", "-std=c++17", "-Wall", "-fPIC"]
+    common = [cxx, "-O2", "-std=c++17", "-Wall", "-fPIC", "-pthread"]
     rpath = ["-L" + HERE, "-lcrass_hip", "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN"]
     for cmd in (common + ["-shared", "-o", ADAPTER_LIB] + srcs + rpath,
                 common + ["-o", CLI, os.path.join(ADAPTER_DIR, "crass_hip_cli.cpp")] + srcs + rpath):

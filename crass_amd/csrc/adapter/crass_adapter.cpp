@@ -2,6 +2,7 @@
 // addReadHolder) implemented over the C ABI of libcrass_hip.so.  See crass_adapter.h.
 #include "crass_adapter.h"
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 
@@ -104,6 +105,16 @@ FileState &open_file(const char *path, const options &opts)
     const bool timing = getenv("CRASS_TIMING") != nullptr;          // stage times of the ingest side
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
+    // the engine context (HIP start-up, code object load, stream and pinned buffers: 0.1-0.2 s) is created on its own
+    // thread while this one reads, parses and packs the file
+    crass_params p = to_params(opts);
+    const int dev = device();
+    struct PendingCtx {
+        std::future<std::pair<int, crass_hip_ctx *>> fut;
+        std::pair<int, crass_hip_ctx *> get() { return fut.get(); }
+        ~PendingCtx() { if (fut.valid()) { auto r = fut.get(); if (r.second) crass_hip_destroy(r.second); } }    // (an exception on the way)
+    } pending;
+    pending.fut = std::async(std::launch::async, [p, dev]() { crass_hip_ctx *c = nullptr; const int rc = crass_hip_create(&p, dev, &c); return std::make_pair(rc, c); });
     int rc = crass_read_fastx(path, &f->fx);
     const double t1 = now();
     if (rc == CRASS_ERR_IO) {
@@ -114,13 +125,16 @@ FileState &open_file(const char *path, const options &opts)
     chk(crass_pack_reads(f->fx.seq, f->fx.seq_off, f->fx.n_reads, 2, &f->pk), "crass_pack_reads");
     const double t2 = now();
     for (uint64_t i = 0; i < f->fx.n_reads; i++) if (f->fx.header_id[i] != i) { f->unique_headers = false; break; }
-    crass_params p = to_params(opts);
-    chk(crass_hip_create(&p, device(), &f->ctx), "crass_hip_create");
+    {
+        auto made = pending.get();
+        f->ctx = made.second;
+        chk(made.first, "crass_hip_create");
+    }
     crass_reads r = f->pk.reads;
     r.header_id = f->unique_headers ? nullptr : f->fx.header_id;
     chk(crass_hip_load_reads(f->ctx, &r), "crass_hip_load_reads");
     if (timing)
-        fprintf(stderr, "[crass_timing] %s: %llu reads; read+parse %.3f s, 2-bit pack %.3f s, context + H2D %.3f s\n", path,
+        fprintf(stderr, "[crass_timing] %s: %llu reads; read+parse %.3f s, 2-bit pack %.3f s, wait for the context + H2D %.3f s\n", path,
                 (unsigned long long)f->fx.n_reads, t1 - t0, t2 - t1, now() - t2);
     FileState &ref = *f;
     s[path] = std::move(f);

@@ -14,6 +14,7 @@
 #include <fstream>
 #include <getopt.h>
 #include <iostream>
+#include <chrono>
 
 using namespace crass_hip;
 
@@ -114,6 +115,11 @@ int main(int argc, char *argv[])
     lookupTable patterns_lookup, reads_found;
     int mMaxReadLength = 0;
     int rc = 0;
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_main = now();
+    double t_prev = t_main;
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[crass_timing] cli: %-28s %.3f s (at %.3f s)\n", what, t - t_prev, t - t_main); t_prev = t; } };
     try {
         time_t start_time; time(&start_time);
         for (const auto &f : seqFiles) {
@@ -121,6 +127,7 @@ int main(int argc, char *argv[])
             mMaxReadLength = std::max(mMaxReadLength, max_len);
         }
         std::cout << std::endl;
+        lap("searchFile (ingest + pass 1)");
         int next_free_GID = 1;
         Vecstr *nr = createNonRedundantSet(mReads, mStringCheck, mDR2GIDMap, mGroupMap, group_kmer_counts_map, next_free_GID, opts);
         if (nr->size() > 0) {
@@ -129,6 +136,7 @@ int main(int argc, char *argv[])
             for (const auto &f : seqFiles) findSingletons(f.c_str(), opts, nr, reads_found, &mReads, &mStringCheck, start_time);
         }
         std::cout << std::endl;
+        lap("merge + findSingletons");
         size_t n_reads = 0;
         for (auto &kv : mReads) n_reads += kv.second->size();
         std::cout << "[crass_patternFinder]: Found " << n_reads << " reads" << std::endl;
@@ -147,6 +155,8 @@ int main(int argc, char *argv[])
                 out << "\t" << h->RH_Seq << "\t" << h->RH_Comment << "\t" << h->RH_Qual << "\n";
             }
         delete nr;
+        out.close();
+        lap("hand-off dump");
         // ---- the stage behind the search: true DRs + repaired start/stops (WorkHorse.cpp:403) ----
         std::map<int, std::string> mTrueDRs;
         if (findConsensusDRs(mReads, mStringCheck, mDR2GIDMap, mTrueDRs, group_kmer_counts_map, next_free_GID, mMaxReadLength, opts)) {
@@ -168,6 +178,7 @@ int main(int argc, char *argv[])
             }
             std::cout << "[crass_consensus]: " << mTrueDRs.size() << " true direct repeats" << std::endl;
         }
+        lap("findConsensusDRs + dump");
     } catch (std::exception &e) {
         std::cerr << e.what() << std::endl;
         rc = 2;            // doWork -> 2 -> process exit code 2
@@ -176,5 +187,6 @@ int main(int argc, char *argv[])
     clearReadMap(&mReads);
     for (auto &kv : mDR2GIDMap) delete kv.second;
     for (auto &kv : group_kmer_counts_map) delete kv.second;
+    lap("release");
     return rc;
 }
