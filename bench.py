@@ -286,7 +286,7 @@ def main():
                             "measured_in": "timed steps" if name == dom else "scouting steps (untimed)"}
     # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ — only when
     # they were taken on THIS kernel source (hash recorded by profiles/summarize_pmc.py) and this workload
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_issue = None, None, None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         key = {"seed_scan_filter": "k_filter_fast", "survivor": "k_survivor", "recruit_scan": "k_anchor_filter"}[dom]
@@ -294,11 +294,19 @@ def main():
             for k, v in pm["per_launch"].items():
                 if k.startswith(key):
                     traffic, traffic_src = v["hbm_bytes"], "profiles/r02_pmc_traffic.json (committed PMC passes, same kernel source hash)"
+                    if "sq" in v and v["sq"].get("SQ_INSTS_VALU"):
+                        # what actually bounds this kernel: a wave64 VALU instruction occupies its SIMD for 4 cycles, the chip
+                        # has 256 CUs x 4 SIMDs and holds at most 2.4 GHz (MI355X_MICROARCH.md)
+                        insts = v["sq"]["SQ_INSTS_VALU"]
+                        bound_ms = insts * 4.0 / (256 * 4) / 2.4e9 * 1e3
+                        valu_issue = {"insts_valu_per_launch": int(insts), "cycles_per_wave64_inst": 4, "simds": 1024, "clock_ghz": 2.4,
+                                      "bound_ms": round(bound_ms, 4), "frac": round(bound_ms / dom_ms, 4) if dom_ms > 0 else None,
+                                      "note": "the kernel is VALU-issue bound, not HBM bound: frac = VALU issue time at peak clock / measured launch time"}
     except (OSError, KeyError, ValueError):
         pass
     path_bytes = 2 * bytes_per_read_per_pass             # both passes read every base once at 2 bits
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu_issue": valu_issue,
                 "path_frac": round(value / world * path_bytes / (HBM_PEAK_GBS * 1e9), 5),
                 "path_frac_note": "whole path per GPU: reads/s/GPU x %d B / 8 TB/s (SURVEY 8d)" % path_bytes,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(dom_ms, 4),

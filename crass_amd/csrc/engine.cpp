@@ -157,7 +157,7 @@ struct crass_hip_ctx {
     DevParams dp{};
     int device = 0;
     hipStream_t stream = nullptr;
-    int last_hip = 0;
+    mutable int last_hip = 0;
 
     // resident reads
     DevReads R{};
@@ -240,12 +240,16 @@ struct crass_hip_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gathered = nullptr;
     mutable bool bulk_pending = false;          // rare paths only: D2H copies of the candidates' own strings in flight on copy_stream
-    void wait_bulk() const
+    // CRASS_OK, or CRASS_ERR_HIP with last_hip set: a failed copy must not be mistaken for delivered records
+    int wait_bulk() const
     {
-        if (!bulk_pending) return;
-        (void)hipStreamSynchronize(copy_stream);
+        if (!bulk_pending) return bulk_status;
+        const hipError_t e = hipStreamSynchronize(copy_stream);
         bulk_pending = false;
+        if (e != hipSuccess) { last_hip = (int)e; bulk_status = CRASS_ERR_HIP; }
+        return bulk_status;
     }
+    mutable int bulk_status = CRASS_OK;         // sticky until the next seed scan issues new copies
     // device-side merge (dmerge.hip): clustering, non-redundant set, anchor keys and the pass-2 verification
     // index are built on the device; the host view (c->merge) is rebuilt from its per-token results while
     // pass 2 runs.  dm.active: the installed pattern set lives in dm.M, not in the automaton/anchors above.
@@ -386,7 +390,7 @@ void crass_hip_ctx::widen_p1() const
 {
     P1Dense &D = dense;
     if (D.wide_ready) return;
-    wait_bulk();
+    (void)wait_bulk();                  // (callers have checked its status)
     const uint64_t n = D.n;
     const uint32_t ss_cap = D.pack_ss_cap, stride = dr_stride;
     const uint8_t *hb = D.h_blob.p;
@@ -1008,7 +1012,8 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     if (!c) return CRASS_ERR_INVALID_ARG;
     if (!c->have_reads) return CRASS_ERR_STATE;
     (void)hipSetDevice(c->device);
-    c->wait_bulk();
+    (void)c->wait_bulk();               // (copies of the previous step: their records are dropped below)
+    c->bulk_status = CRASS_OK;
     quiesce_worker(c);
     c->have_pass1 = c->have_merge = c->have_pass2 = false;
     c->dm.active = false;
@@ -1178,7 +1183,7 @@ int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     if (!c->have_pass1) return CRASS_ERR_STATE;
-    c->wait_bulk();
+    if (const int bs = c->wait_bulk()) return bs;
     if (c->dense.active) {
         const crass_hip_ctx::P1Dense &D = c->dense;
         c->widen_p1();
@@ -1520,7 +1525,7 @@ static int finish_merge(crass_hip_ctx *c, double t0)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->have_pat_token = true;
     }
-    c->wait_bulk();            // the per-candidate records are in host memory when the merge returns
+    if (const int bs = c->wait_bulk()) return bs;            // the per-candidate records are in host memory when the merge returns
     c->cnt.ms_merge_host = (float)(now_ms() - t0);
     return s;
 }
@@ -1956,7 +1961,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         {
             c->hit_cap_hint = hit_bound(c->h_count.p[0]);
         }
-        c->wait_bulk();                                 // the step ends with the pass-1 hand-off records in host memory too
+        if (const int bs = c->wait_bulk()) return bs;   // the step ends with the pass-1 hand-off records in host memory too
         c->q_n = *reinterpret_cast<const uint64_t *>(c->h_qblob.p);
         c->q_blob_active = true;
         c->have_pass2 = true;

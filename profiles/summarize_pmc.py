@@ -31,14 +31,28 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def main(fetch_csv, write_csv, out_json, reads=10000000, read_len=150):
+def load_sq(path):
+    """per-kernel averages of the SQ counter pass (SQ_INSTS_VALU, SQ_INSTS_LDS, SQ_WAVES, SQ_WAIT_ANY, ...)"""
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if "crass::" not in r["Kernel_Name"]:
+            continue
+        name = r["Kernel_Name"].split("crass::")[1].split("(")[0]
+        acc.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: {c: round(sum(x) / len(x)) for c, x in v.items()} for k, v in acc.items()}
+
+
+def main(fetch_csv, write_csv, out_json, reads=10000000, read_len=150, sq_csv=None):
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    sq = load_sq(sq_csv) if sq_csv else {}
     res = {}
     for k in sorted(set(f) | set(w)):
         rd = 2.0 * f.get(k, 0.0)
         wr = w.get(k, 0.0)
         res[k] = {"hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr), "hbm_bytes": round(rd + wr),
                   "fetch_size_raw_kb": round(f.get(k, 0.0) / 1024.0, 3), "write_size_raw_kb": round(w.get(k, 0.0) / 1024.0, 3)}
+        if k in sq:
+            res[k]["sq"] = sq[k]            # instruction counts per launch (wave64 instructions)
     json.dump({"workload": "bench.py --steps 3 --warmup 1 (%d x %d bp reads)" % (int(reads), int(read_len)), "correction": "FETCH_SIZE x2 (gfx950)",
                "source_hash": source_hash(), "reads": int(reads), "read_len": int(read_len),      # bench.py only quotes traffic taken on THIS kernel source
                "per_launch": res}, open(out_json, "w"), indent=1)

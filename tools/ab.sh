@@ -1,11 +1,13 @@
 #!/bin/bash
-# A/B of environment switches on the default bench: prints ms/step and the stage times
+# A/B of an environment switch on the default bench workload: tools/ab.sh CRASS_SOME_SWITCH [steps]
+sw=$1; steps=${2:-200}
 cd $GRAFT_REPO_ROOT
-for v in "" "$@"; do
-  for rep in 1 2; do
-    env $v python bench.py --cpu-sample 0 --steps 100 2>/dev/null | python -c "
+for rep in 1 2; do
+  for v in 0 1; do
+    if [ $v = 1 ]; then export $sw=1; else unset $sw; fi
+    python bench.py --cpu-sample 0 --steps $steps 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('%-32s' % '$v', d['ms_per_step'], d['roofline']['stages_ms_scouting_steps'], d['roofline']['host_ms'])"
+print('$sw=$v', 'ms_per_step', d['ms_per_step'], 'value %.3e' % d['value'], d['roofline'].get('stages_ms_scouting_steps'))"
   done
 done

@@ -13,7 +13,7 @@ done
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/rp_sq -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $out/bench_sq.json 2> $out/sq.err
 f=$(find $out/rp_sq -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/pmc_sq.csv; rm -rf $out/rp_sq
 cd $GRAFT_REPO_ROOT
-python3 profiles/summarize_pmc.py $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv $out/pmc_traffic.json | head -60
+python3 profiles/summarize_pmc.py $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv $out/pmc_traffic.json 10000000 150 $out/pmc_sq.csv | head -80
 python3 - $out/pmc_sq.csv <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
