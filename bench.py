@@ -331,6 +331,7 @@ def main():
                    "patterns": int(c["n_patterns"]), "ac_states": int(c["ac_states"]),
                    "filter_survivors": int(n_surv),
                    "fast_filter": int(c["used_fast_filter"]), "lds_automaton": int(c["used_lds_automaton"]),
+                   "merge_fallbacks": int(c.get("n_merge_fallbacks", 0)),      # device merges redone on the host: must stay 0
                    "synth_gen_s": round(t_gen, 2)},
         "first_call_ms": round(first_call_ms, 3),
         "timed_batches": "two resident batches, alternating" if args.alternate else

@@ -56,7 +56,8 @@ class Counters(C.Structure):
                 ("ms_pass1_total", C.c_float), ("ms_recruit", C.c_float), ("ms_recruit_finish", C.c_float),
                 ("ms_pass2_total", C.c_float), ("ms_merge_host", C.c_float), ("ms_sink_host", C.c_float),
                 ("bytes_reads_device", C.c_uint64), ("anchor_keys", C.c_uint32), ("anchor_table_kind", C.c_uint32),
-                ("used_device_merge", C.c_uint32), ("ms_merge_device", C.c_float)]
+                ("used_device_merge", C.c_uint32), ("ms_merge_device", C.c_float),
+                ("n_merge_fallbacks", C.c_uint32), ("last_fallback_bits", C.c_uint32)]
 
     def asdict(self):
         return {f[0]: getattr(self, f[0]) for f in self._fields_}

@@ -316,6 +316,7 @@ struct crass_hip_ctx {
     PinBuf<uint8_t> h_qblob; P2Blob q_lay{}; uint64_t q_n = 0; bool q_blob_active = false, q_wide_ready = false;
 
     crass_counters cnt{};
+    uint32_t n_merge_fallbacks = 0, last_fallback_bits = 0;
     hipEvent_t ev[12]{};
     // stage timing (crass_hip_set_stage_timing): an event record costs ~6 us of stream time, 14 of them 8 % of a 1 ms step.
     // 0 none, 1 the three large kernels only (seed scan, survivors, pass-2 scan), 2 every stage
@@ -1391,6 +1392,8 @@ static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint1
 static int host_merge_fallback(crass_hip_ctx *c)
 {
     quiesce_worker(c);
+    c->n_merge_fallbacks++;                             // (reported by crass_hip_get_counters: a silent latency cliff otherwise)
+    c->last_fallback_bits = c->dm.h_st.p ? c->dm.h_st.p->fail : 0u;
     c->dm.active = false;
     c->cnt.used_device_merge = 0;
     c->dm_prev_local = false;                           // (no merge is queued ahead of time after a device-side failure)
@@ -2117,6 +2120,8 @@ int crass_hip_get_counters(const crass_hip_ctx *c, crass_counters *o)
         m->cnt.ms_pass2_total = c->span(5, 7, 2);
     }
     *o = c->cnt;
+    o->n_merge_fallbacks = c->n_merge_fallbacks;
+    o->last_fallback_bits = c->last_fallback_bits;
     return CRASS_OK;
 }
 

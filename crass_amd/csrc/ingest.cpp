@@ -414,6 +414,11 @@ int crass_read_fastx(const char *path, crass_fastx *out)
         }
     }
     const double tr2 = now_s();
+    // the pieces hold their own copies of everything: the file image goes before the record arrays are allocated
+    // (peak host memory = pieces + record arrays, not file + pieces + record arrays)
+    if (map.p && map.n) { munmap(map.p, map.n); map.p = nullptr; map.n = 0; }
+    free(inflated.p); inflated.p = nullptr; inflated.n = 0;
+    std::vector<uint8_t>().swap(data);
     // ---- assemble ----
     const size_t nc = ch.size();
     std::vector<uint64_t> rec0(nc + 1, 0), seq0(nc + 1, 0), name0(nc + 1, 0), com0(nc + 1, 0), qual0(nc + 1, 0);
@@ -488,6 +493,8 @@ int crass_read_fastx(const char *path, crass_fastx *out)
     };
     if (!simple_c) ordered_stale(true);
     if (!simple_q) ordered_stale(false);
+    const int last_ret_of_stream = ch.back().last_ret;
+    std::vector<FxChunk>().swap(ch);                    // (and the pieces before the header table is built)
     const double tr3 = now_s();
     // ---- header_id: first read with the same name (readsFound is keyed by the header string) ----
     {
@@ -532,7 +539,7 @@ int crass_read_fastx(const char *path, crass_fastx *out)
             parallel_ranges(cap, ht, [&](uint64_t a, uint64_t b2, unsigned) { for (uint64_t i = a; i < b2; i++) out->name_index[i] = tab[i].load(std::memory_order_relaxed); });
     }
     out->max_len = max_len;
-    out->last_ret = ch.back().last_ret;
+    out->last_ret = last_ret_of_stream;
     if (timing)
         fprintf(stderr, "[crass_timing] fastx: %zu bytes, %zu pieces: read %.3f s, parse %.3f s, assemble %.3f s, header ids %.3f s\n", n, nc,
                 tr1 - tr0, tr2 - tr1, tr3 - tr2, now_s() - tr3);

@@ -283,6 +283,9 @@ typedef struct {
     uint32_t used_device_merge;     /* 1: clustering / non-redundant set / pass-2 index built on the
                                        device (dmerge.hip), 0: host merge (merge.cpp)             */
     float ms_merge_device;          /* HIP-event time of the device merge kernels                 */
+    uint32_t n_merge_fallbacks;     /* since crass_hip_create: device merges that gave up (key set beyond the table,
+                                       cuckoo insertion, a wait that timed out, ...) and were redone on the host     */
+    uint32_t last_fallback_bits;    /* the device merge's `fail` word of the last such case (0: none so far)         */
 } crass_counters;
 int crass_hip_get_counters(const crass_hip_ctx *ctx, crass_counters *out);
 

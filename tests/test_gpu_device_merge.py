@@ -114,6 +114,8 @@ def test_fallback_to_host_merge(ca):
             eng.merge(fetch=False)
             rec = eng.recruit()
             assert len(rec.read_idx) == ref.n_pass2
+            cnt = eng.counters()                       # the fallback is visible, with the device's reason
+            assert cnt["n_merge_fallbacks"] >= 1 and cnt["last_fallback_bits"] != 0 and cnt["used_device_merge"] == 0
             packed.close()
         finally:
             eng.close()

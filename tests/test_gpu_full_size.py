@@ -31,6 +31,7 @@ def run_twice(ca, spec, n, L):
             assert np.array_equal(r3.read_idx, r2.read_idx) and np.array_equal(r3.start, r2.start) and np.array_equal(r3.end, r2.end)
             assert np.array_equal(r3.low_lexi, r2.low_lexi) and np.array_equal(r3.token, r2.token)
         cnt = eng.counters()
+        assert cnt["n_merge_fallbacks"] == 0          # the device merge never gave up
     for a, b in ((c1.read_idx, c2.read_idx), (c1.ss_pool, c2.ss_pool), (c1.dr_chars, c2.dr_chars), (r1.read_idx, r2.read_idx),
                  (r1.start, r2.start), (r1.end, r2.end), (r1.low_lexi, r2.low_lexi), (r1.token, r2.token), (m1.cand_token, m2.cand_token)):
         assert np.array_equal(a, b)
