@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
                     }
                     if (!code) { atomicOr(&M.st->fail, 1u); code = 1u << 22; }
                 }
-                atomicMin(&M.owner[code], t);
+                // look before the atomic: the variants of one repeat family share most 11-mers (1 400-way contention on a
+                // few hundred addresses at 100 M reads), the owner is an early token and everybody after it only confirms
+                if (__hip_atomic_load(&M.owner[code], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > t) atomicMin(&M.owner[code], t);
                 M.codes[(uint64_t)t * M.kmax + lane] = code;
             }
         }
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
             uint32_t h = rset_hash(g, w, M.rset_log);
             bool winner = false;
             for (;;) {
-                const unsigned long long old = atomicCAS(&M.rset_key[h], 0ull, want);
+                unsigned long long old = __hip_atomic_load(&M.rset_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (look first)
+                if (old == 0ull) old = atomicCAS(&M.rset_key[h], 0ull, want);
                 if (old == 0ull) { winner = true; break; }
                 if (old == want) break;
                 h = (h + 1) & mask;
@@ -236,6 +239,33 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
             M.rd_slot[t] = winner ? (h | 0x80000000u) : h;
         }
     }
+}
+
+// ---- one atomic per BLOCK on the state words.  A device-scope atomic on ONE address retires every ~2.5-3.5 ns on this
+// part however many CUs issue them, so "every claimant adds its count to a cursor" serialises: 6.9 k claimants = 24 us
+// of a 26 us kernel at 10 M reads, 30 k = 150 us at 100 M.  block_reserve: exclusive offsets for the threads of a block
+// from one atomicAdd (wave scan by shuffles, wave totals through LDS).  Every thread of the block must call it.
+template <int THREADS>
+static __device__ __forceinline__ uint32_t block_reserve(uint32_t v, uint32_t *counter)
+{
+    __shared__ uint32_t br_tot[THREADS / 64];
+    __shared__ uint32_t br_base;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) br_tot[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < THREADS / 64; i++) { const uint32_t x = br_tot[i]; br_tot[i] = tot; tot += x; }
+        br_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    return br_base + br_tot[w] + incl - v;
 }
 
 // ---- 4. removeRedundantRepeats: a member is dropped iff a strictly shorter member of its group, or
@@ -249,13 +279,14 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
 __global__ __launch_bounds__(256) void k_dm_rd_bases(DevMerge M)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= dm_ntok(M)) return;
-    const uint32_t hs = M.rd_slot[t];
-    if (!(hs & 0x80000000u)) return;
+    uint32_t hs = 0;
+    if (t < dm_ntok(M)) hs = M.rd_slot[t];
+    const bool claim = (hs & 0x80000000u) != 0;         // this thread claimed the key: it allocates the key's range
     const uint32_t h = hs & 0x7FFFFFFFu;
-    const uint32_t cnt = M.rset_cnt[h];
+    const uint32_t cnt = claim ? M.rset_cnt[h] : 0u;
     if (cnt > M.group_cap) atomicOr(&M.st->fail, 32u);
-    M.rset_base[h] = atomicAdd(&M.st->rd_cursor, cnt);
+    const uint32_t base = block_reserve<256>(cnt, &M.st->rd_cursor);
+    if (claim) M.rset_base[h] = base;
 }
 __global__ __launch_bounds__(256) void k_dm_rd_fill(DevMerge M)
 {
@@ -338,7 +369,11 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
         if (lane == 0) M.blank[j] = found ? 1 : 0;
         if (!found) n_surv++;
     }
-    if (lane == 0 && n_surv) atomicAdd(&M.st->n_survivors, n_surv);
+    // (one atomic per block, see block_reserve: 9.5 k waves adding to one word were 21 us of this kernel)
+    __shared__ uint32_t surv_w[4];
+    if (lane == 0) surv_w[threadIdx.x >> 6] = n_surv;
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t tot = surv_w[0] + surv_w[1] + surv_w[2] + surv_w[3]; if (tot) atomicAdd(&M.st->n_survivors, tot); }
 }
 
 // ---- 6a. anchor keys: every 16-mer at offset 0..7 of a pattern (see kernels.hip, pass-2 fast path).  A member that
@@ -350,16 +385,17 @@ __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = e >> 4, o = (e >> 3) & 1u, r = e & 7u;
-    if (t >= dm_ntok(M)) return;
-    uint32_t slot = 0xFFFFFFFFu;
-    if (!M.blank[t]) {
+    uint32_t slot = 0xFFFFFFFFu, my_key = 0xFFFFFFFFu, won = 0u;
+    const bool in_range = t < dm_ntok(M);               // (no early return: the block meets at the end)
+    if (in_range && !M.blank[t]) {
         const uint32_t key = (uint32_t)shr128_lo(M.packed[(uint64_t)t * 4 + 2 * o], M.packed[(uint64_t)t * 4 + 2 * o + 1], 2 * r);
         const uint32_t kmask = (1u << M.kset_log) - 1u;
         const unsigned long long want = (unsigned long long)key | (1ull << 32);
         uint32_t h = kset_hash(key, M.kset_log);
         bool winner = false;
         for (;;) {
-            const unsigned long long old = atomicCAS(&M.kset_key[h], 0ull, want);
+            unsigned long long old = __hip_atomic_load(&M.kset_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (look first)
+            if (old == 0ull) old = atomicCAS(&M.kset_key[h], 0ull, want);
             if (old == 0ull) { winner = true; break; }
             if (old == want) break;
             h = (h + 1) & kmask;
@@ -367,12 +403,27 @@ __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
         atomicAdd(&M.kset_cnt[h], 1u);
         slot = winner ? (h | 0x80000000u) : h;
         if (winner) {
-            atomicAdd(&M.st->n_keys, 1u);
-            atomicMin(&M.st->k0, key);
+            my_key = key; won = 1u;
             if (key == 0xFFFFFFFFu) atomicOr(&M.st->all_t, 1u);
         }
     }
-    M.ent_slot[e] = slot;
+    if (in_range) M.ent_slot[e] = slot;
+    // the key count and the smallest key: one atomic each per block (see block_reserve)
+    __shared__ uint32_t kc_w[4], km_w[4];
+    const int lane = threadIdx.x & 63;
+    const uint32_t cw = (uint32_t)__popcll(__ballot(won != 0u));
+    uint32_t mw = my_key;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mw = min(mw, (uint32_t)__shfl_xor((int)mw, off));
+    if (lane == 0) { kc_w[threadIdx.x >> 6] = cw; km_w[threadIdx.x >> 6] = mw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = kc_w[0] + kc_w[1] + kc_w[2] + kc_w[3];
+        if (tot) {
+            atomicAdd(&M.st->n_keys, tot);
+            atomicMin(&M.st->k0, min(min(km_w[0], km_w[1]), min(km_w[2], km_w[3])));
+        }
+    }
 }
 
 // table size: load <= 1/3 (<= 1/2 at the limits), as build_anchors (merge.cpp).  Up to 2^14 keys: exact keys in
@@ -413,11 +464,13 @@ __global__ __launch_bounds__(256) void k_dm_key_bases_insert(DevMerge M)
         if (!ls || M.st->n_keys == 0) atomicOr(&M.st->fail, 2u);
         M.st->log_size = ls; M.st->tab_mode = mode; M.st->n_patterns = 2 * M.st->n_survivors;
     }
-    if (tok >= dm_ntok(M)) return;
-    const uint32_t hs = M.ent_slot[e];
-    if (hs == 0xFFFFFFFFu || !(hs & 0x80000000u)) return;            // no entry / not the key's claimant
+    uint32_t hs = 0xFFFFFFFFu;
+    if (tok < dm_ntok(M)) hs = M.ent_slot[e];
+    const bool claim = hs != 0xFFFFFFFFu && (hs & 0x80000000u);      // the key's claimant allocates its entry range
     const uint32_t h = hs & 0x7FFFFFFFu;
-    M.kset_base[h] = atomicAdd(&M.st->ent_cursor, M.kset_cnt[h]);
+    const uint32_t ebase = block_reserve<256>(claim ? M.kset_cnt[h] : 0u, &M.st->ent_cursor);
+    if (!claim) return;
+    M.kset_base[h] = ebase;
     if (!ls || (M.st->fail & ~2u)) return;
     uint32_t cur = (uint32_t)M.kset_key[h];
     if (mode == 2) {

@@ -1993,12 +1993,13 @@ __global__ __launch_bounds__(256) void k_gather_found(const uint64_t *fidx, cons
         dd_hash[k] = h;
         const unsigned long long key = h | 1ull;             // 0 marks an empty slot
         uint32_t slot = (uint32_t)(h >> 17) & dd_mask;
-        for (;;) {
-            const unsigned long long old = atomicCAS(&dd_keys[slot], 0ull, key);
+        for (;;) {          // look before the atomic: most records carry one of a few popular strings
+            unsigned long long old = __hip_atomic_load(&dd_keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == 0ull) old = atomicCAS(&dd_keys[slot], 0ull, key);
             if (old == 0ull || old == key) break;
             slot = (slot + 1) & dd_mask;
         }
-        atomicMin(&dd_first[slot], (uint32_t)k);
+        if (__hip_atomic_load(&dd_first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)k) atomicMin(&dd_first[slot], (uint32_t)k);
         dd_slot[k] = slot;
     }
 }
@@ -2080,11 +2081,12 @@ __global__ __launch_bounds__(256) void k_dr_dedupe_insert(const char *dr, const 
     const unsigned long long key = h | 1ull;                 // 0 marks an empty slot
     uint32_t slot = (uint32_t)(h >> 17) & mask;
     for (;;) {
-        const unsigned long long old = atomicCAS(&keys[slot], 0ull, key);
+        unsigned long long old = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0ull) old = atomicCAS(&keys[slot], 0ull, key);
         if (old == 0ull || old == key) break;
         slot = (slot + 1) & mask;
     }
-    atomicMin(&first[slot], k);
+    if (__hip_atomic_load(&first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) atomicMin(&first[slot], k);
     slot_out[k] = slot;
 }
 

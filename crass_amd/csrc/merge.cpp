@@ -807,43 +807,108 @@ bool merge_from_device_begin(MergeResult &m, const char *dx_chars, const uint16_
     }
     return true;
 }
-// second half: groups and the pattern list from the device's per-token results
+// second half: groups and the pattern list from the device's per-token results.  Groups are independent, so everything
+// per group runs on the host pool over flat, pre-sized arrays (41.6 k tokens / 13.3 k patterns at 100 M reads: 0.71 ms
+// on one thread, which outlasted the device's pass 2 as soon as the reads were sharded over several GPUs).
 bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint8_t *blank, uint32_t n_groups)
 {
     const bool prof = getenv("CRASS_MERGE_PROFILE") != nullptr;
     const double p2 = prof_now();
     const uint32_t n_distinct = m.tokens.size();
     m.next_free_gid = (int)n_groups + 1;
-    m.groups.assign(n_groups, {});
-    std::vector<std::vector<Member>> survivors(n_groups);
-    {
-        std::vector<uint32_t> cnt(n_groups, 0);
-        for (uint32_t t = 0; t < n_distinct; t++) {
-            const uint32_t g = gid_of[t];
-            if (g == 0 || g > n_groups) { m.clear(); return false; }
-            cnt[g - 1]++;
-        }
-        for (uint32_t g = 0; g < n_groups; g++) { m.groups[g].reserve(cnt[g]); survivors[g].reserve(cnt[g]); }
-    }
+    // members by group, token order inside a group (stable counting sort) = the sequence the reference sorts
+    std::vector<uint32_t> goff(n_groups + 1, 0);
     for (uint32_t t = 0; t < n_distinct; t++) {
         const uint32_t g = gid_of[t];
-        m.groups[g - 1].push_back(t + 2);
-        survivors[g - 1].push_back(Member{t, (uint32_t)m.tokens.strings.len(t), blank[t] != 0});
+        if (g == 0 || g > n_groups) { m.clear(); return false; }
+        goff[g]++;
     }
+    for (uint32_t g = 0; g < n_groups; g++) goff[g + 1] += goff[g];
+    std::vector<Member> members(n_distinct);
+    m.grp_tokens.resize(n_distinct);
+    m.grp_off.resize(n_groups + 1);
+    for (uint32_t g = 0; g <= n_groups; g++) m.grp_off[g] = goff[g];
+    {
+        std::vector<uint32_t> cur(goff.begin(), goff.end() - 1);
+        for (uint32_t t = 0; t < n_distinct; t++) {
+            const uint32_t q = cur[gid_of[t] - 1]++;
+            members[q] = Member{t, (uint32_t)m.tokens.strings.len(t), blank[t] != 0};
+            m.grp_tokens[q] = t + 2;
+        }
+    }
+    m.groups.assign(n_groups, {});
     // per group: the reference's sort by length + partition (the same std:: calls on the same sequence, so the same
-    // order among equal lengths); groups are independent
-    parallel_tasks(n_groups, 8, [&](size_t g) {
-        std::vector<Member> &v = survivors[g];
-        std::sort(v.begin(), v.end(), member_shorter_first);
-        v.erase(std::partition(v.begin(), v.end(), member_kept), v.end());
+    // order among equal lengths)
+    std::vector<uint32_t> kept(n_groups + 1, 0);
+    std::vector<uint64_t> kept_chars(n_groups + 1, 0);
+    const size_t gchunk = n_distinct >= 4096 ? 1 : std::max<size_t>(n_groups, 1);          // small sets: one task, no dispatch
+    const size_t n_tasks = (n_groups + gchunk - 1) / gchunk;
+    parallel_tasks(n_tasks, 8, [&](size_t c) {
+        for (size_t g = c * gchunk; g < std::min<size_t>(n_groups, (c + 1) * gchunk); g++) {
+            m.groups[g].assign(m.grp_tokens.begin() + goff[g], m.grp_tokens.begin() + goff[g + 1]);
+            Member *lo = members.data() + goff[g], *hi = members.data() + goff[g + 1];
+            std::sort(lo, hi, member_shorter_first);
+            Member *mid = std::partition(lo, hi, member_kept);
+            kept[g + 1] = (uint32_t)(mid - lo);
+            uint64_t ch = 0;
+            for (Member *x = lo; x < mid; x++) ch += x->len;
+            kept_chars[g + 1] = ch;
+        }
     });
     const double p3 = prof_now();
-    emit_patterns(m, survivors);
-    const double p4 = prof_now();
-    m.flatten();
+    // pattern list: per group the survivors, then their reverse complements (WorkHorse.cpp:690-697)
+    for (uint32_t g = 0; g < n_groups; g++) { kept[g + 1] += kept[g]; kept_chars[g + 1] += kept_chars[g]; }
+    const size_t n_pat = 2 * (size_t)kept[n_groups];
+    m.patterns.chars.resize(2 * kept_chars[n_groups]);
+    m.patterns.off.resize(n_pat + 1);
+    m.patterns.off[0] = 0;
+    m.pat_group.resize(n_pat);
+    m.pat_token.resize(n_pat);
+    const unsigned char *ctab = comp_table();
+    std::atomic<int> need_lookup{0};
+    parallel_tasks(n_tasks, 8, [&](size_t c) {
+        for (size_t g = c * gchunk; g < std::min<size_t>(n_groups, (c + 1) * gchunk); g++) {
+            const Member *lo = members.data() + goff[g];
+            const uint32_t k = kept[g + 1] - kept[g];
+            const size_t p0 = 2 * (size_t)kept[g];                     // first pattern of the group
+            uint64_t at = 2 * kept_chars[g];
+            char *out = m.patterns.chars.data();
+            for (uint32_t i = 0; i < k; i++) {                          // forward forms
+                memcpy(out + at, m.tokens.strings.data(lo[i].tok), lo[i].len);
+                at += lo[i].len;
+                m.patterns.off[p0 + i + 1] = at;
+            }
+            for (uint32_t i = 0; i < k; i++) {                          // reverse complements
+                const char *src = m.tokens.strings.data(lo[i].tok);
+                const uint32_t len = lo[i].len;
+                char *q = out + at;
+                for (uint32_t j = 0; j < len; j++) q[j] = (char)ctab[(unsigned char)src[len - 1 - j] & 127];
+                at += len;
+                m.patterns.off[p0 + k + i + 1] = at;
+                // token of the low-lexi form (DRLowLexi: tmp_dr < rev_comp ? tmp_dr : rev_comp) of the pattern and of its
+                // reverse complement alike; a token string is normally low-lexi already (else: looked up below)
+                const int cmp = memcmp(src, q, len);
+                const uint32_t tok = cmp <= 0 ? lo[i].tok + 2 : 0xFFFFFFFFu;
+                if (cmp > 0) need_lookup.store(1, std::memory_order_relaxed);
+                m.pat_token[p0 + i] = tok;
+                m.pat_token[p0 + k + i] = tok;
+            }
+            for (uint32_t i = 0; i < 2 * k; i++) m.pat_group[p0 + i] = (uint32_t)(g + 1);
+        }
+    });
+    if (need_lookup.load())                                            // (the lookup side of the token table is built lazily: one thread)
+        for (size_t g = 0; g < n_groups; g++) {
+            const uint32_t k = kept[g + 1] - kept[g];
+            const size_t p0 = 2 * (size_t)kept[g];
+            for (uint32_t i = 0; i < k; i++)
+                if (m.pat_token[p0 + i] == 0xFFFFFFFFu) {
+                    const uint32_t tok = m.tokens.get(m.patterns.data(p0 + k + i), m.patterns.len(p0 + k + i));
+                    m.pat_token[p0 + i] = tok;
+                    m.pat_token[p0 + k + i] = tok;
+                }
+        }
     if (prof)
-        fprintf(stderr, "[crass_merge] host view: groups %.1f us, patterns %.1f us, flatten %.1f us\n",
-                1e3 * (p3 - p2), 1e3 * (p4 - p3), 1e3 * (prof_now() - p4));
+        fprintf(stderr, "[crass_merge] host view: groups %.1f us, patterns %.1f us\n", 1e3 * (p3 - p2), 1e3 * (prof_now() - p3));
     return true;
 }
 // the same from the device merge's per-token ROOTS (first token of the token's group; the device keeps no dense group
