@@ -1435,23 +1435,21 @@ static int build_host_merge(crass_hip_ctx *c)
     (void)hipSetDevice(c->device);
     // local merge: the token strings and the candidates' tokens only need pass 1's outputs, which the host has
     // already waited for — that half of the host view is built while the merge kernels are still running
+    // (the gathered form too: the global distinct list and every gathered row's rank in it were written to pinned memory
+    // by the de-duplication kernels, which the host has waited for before it committed the merge)
     const double tb00 = now_ms();
-    bool begun = false;
-    if (!d.global) {
-        if (!merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, c->h_dmap.p, d.n_cand)) return CRASS_ERR_STATE;
-        begun = true;
-    }
-    const double tb0 = now_ms();
-    HIPCHK(c, hipEventSynchronize(d.ev_done));
-    const double tb1 = now_ms();
-    if (d.h_st.p->fail) return CRASS_ERR_STATE;
     const uint32_t *cmap = c->h_dmap.p;
     if (d.global) {                                     // own candidate -> own distinct string -> its rank in the global list
         d.cand_map.resize(d.n_cand);
         for (uint64_t k = 0; k < d.n_cand; k++) d.cand_map[k] = d.h_gmap.p[d.my_off + c->h_dmap.p[k]];
         cmap = d.cand_map.data();
     }
-    if (!begun && !merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand)) return CRASS_ERR_STATE;
+    if (!merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand)) return CRASS_ERR_STATE;
+    host_pool_warm();                                   // the second half fans out over the pool: wake it while the device is busy
+    const double tb0 = now_ms();
+    HIPCHK(c, hipEventSynchronize(d.ev_done));
+    const double tb1 = now_ms();
+    if (d.h_st.p->fail) return CRASS_ERR_STATE;
     if (!merge_from_device_finish_roots(c->merge, d.h_root.p, d.h_blank.p, d.gid_tmp) ||
         c->merge.patterns.size() != d.h_st.p->n_patterns)
         return CRASS_ERR_STATE;

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""What ONE rank does per step when BASELINE.json configs[2] (100 M reads) is sharded over W GPUs — measured on one GPU.
+All W shards live on this GPU (W contexts); the other ranks' send buffers are computed once and stay put, and rank 0's
+step is timed with the gathered buffer assembled by a device copy instead of the RCCL all-gather (whose latency over
+xGMI is therefore NOT included: ~1 MB per rank, latency bound).  Prints the per-stage times of rank 0 and the speedup
+over the same job on one GPU that these times would give.   python tools/scaling_projection.py [total_reads] [W ...]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import crass_amd as ca
+from crass_amd.distributed import _DevView
+ca.load()
+total = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+worlds = [int(x) for x in sys.argv[2:]] or [2, 4, 8]
+L = 150
+spec = ca.synth_spec(read_len=L)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+
+def one_gpu():
+    eng = ca.SearchEngine(device=0)
+    eng.load_packed_uniform(ca.synth_packed(spec, 0, total), total, L)
+    for _ in range(3):
+        eng.seed_scan(fetch=False); eng.merge(fetch=False); eng.recruit(fetch=False)
+    K = 10
+    t0 = time.perf_counter()
+    for _ in range(K):
+        eng.seed_scan(fetch=False); eng.merge(fetch=False); eng.recruit(fetch=False)
+    ms = 1e3 * (time.perf_counter() - t0) / K
+    eng.close()
+    return ms
+
+base_ms = one_gpu()
+out = {"total_reads": total, "one_gpu_ms_per_step": round(base_ms, 3), "projection": []}
+print("one GPU, %d reads: %.3f ms/step" % (total, base_ms), flush=True)
+for W in worlds:
+    engs, sends = [], []
+    cap = 16384
+    while True:
+        for e in engs: e.close()
+        engs, sends = [], []
+        for r in range(W):
+            first, end = total * r // W, total * (r + 1) // W
+            e = ca.SearchEngine(device=0)
+            e.load_packed_uniform(ca.synth_packed(spec, first, end - first), end - first, L, read_index_base=first)
+            ptr, nbytes = e.exchange_setup(W, r, cap)
+            engs.append(e); sends.append(torch.as_tensor(_DevView(ptr, (nbytes,), "|u1"), device=dev))
+        for e in engs: e.seed_scan(fetch=False)
+        torch.cuda.synchronize()
+        recv = torch.cat(sends).contiguous()
+        need = engs[0].merge_gathered(recv.data_ptr(), fetch=False)
+        if need is None: break
+        while cap < 2 * need: cap *= 2
+    nb = sends[0].numel()
+    ev = torch.cuda.Event()
+    def step():
+        t = [time.perf_counter()]
+        engs[0].seed_scan(fetch=False); t.append(time.perf_counter())
+        recv[:nb].copy_(sends[0])                      # stands in for the all-gather (rank 0's slot refreshed)
+        ev.record(torch.cuda.current_stream(dev)); engs[0].stream_wait_event(ev.cuda_event)
+        assert engs[0].merge_gathered(recv.data_ptr(), fetch=False) is None; t.append(time.perf_counter())
+        engs[0].recruit(fetch=False); t.append(time.perf_counter())
+        return [1e3 * (b - a) for a, b in zip(t, t[1:])]
+    for _ in range(4): step()
+    K = 30
+    acc = np.zeros(3)
+    t0 = time.perf_counter()
+    for _ in range(K): acc += step()
+    ms = 1e3 * (time.perf_counter() - t0) / K
+    c = engs[0].counters()
+    m = engs[0].merge_view()
+    row = {"world": W, "reads_per_rank": total // W, "rank0_ms_per_step": round(ms, 3), "seed_scan_ms": round(acc[0] / K, 3),
+           "exchange_unpack_merge_ms": round(acc[1] / K, 3), "recruit_ms": round(acc[2] / K, 3), "tokens_global": m.n_tokens,
+           "patterns": m.n_patterns, "cap_rows": cap, "projected_speedup": round(base_ms / ms, 2), "projected_efficiency": round(base_ms / ms / W, 3),
+           "merge_fallbacks": c["n_merge_fallbacks"]}
+    out["projection"].append(row)
+    print(row, flush=True)
+    for e in engs: e.close()
+    del recv, sends
+print(json.dumps(out))
