@@ -187,6 +187,41 @@ def test_parallel_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
     assert len(ref) > 1000
 
 
+def test_gzip_inflate_paths_agree(ca, tmp_path):
+    """.gz inputs: the libdeflate fast path (whole-buffer, member by member), zlib's gzread (CRASS_NO_LIBDEFLATE) and the
+    plain file give the same records — single member, several concatenated members (gzread semantics: one stream),
+    an output far larger than the first size guess, and damaged data (both paths: the same error)."""
+    import gzip, zlib
+    text = _fastx_cases()["fq"]
+    plain = tmp_path / "m.fq"
+    plain.write_bytes(text)
+    single = tmp_path / "single.fq.gz"
+    single.write_bytes(gzip.compress(text, 1))
+    cut = [0, len(text) // 3, len(text) // 3 + 1, len(text)]            # member boundaries in the middle of records
+    multi = tmp_path / "multi.fq.gz"
+    multi.write_bytes(b"".join(gzip.compress(text[a:b], 6) for a, b in zip(cut, cut[1:])))
+    zeros = tmp_path / "ratio.fa.gz"                                     # compresses 1000:1: the first buffer guess is too small
+    big = b">z\n" + b"A" * 3_000_000 + b"\n"
+    zeros.write_bytes(gzip.compress(big, 9))
+    ref = ca.FastxFile(plain).records()
+    try:
+        for env in (None, "1"):
+            if env: os.environ["CRASS_NO_LIBDEFLATE"] = env
+            else: os.environ.pop("CRASS_NO_LIBDEFLATE", None)
+            assert ca.FastxFile(single).records() == ref
+            assert ca.FastxFile(multi).records() == ref
+            z = ca.FastxFile(zeros)
+            assert z.n_reads == 1 and z.max_len == 3_000_000
+            bad = bytearray(single.read_bytes())
+            bad[len(bad) // 2] ^= 0x55
+            broken = tmp_path / "broken.fq.gz"
+            broken.write_bytes(bytes(bad))
+            with pytest.raises(ca.CrassError):
+                ca.FastxFile(broken)
+    finally:
+        os.environ.pop("CRASS_NO_LIBDEFLATE", None)
+
+
 def test_header_ids_many_threads(ca, tmp_path):
     """Enough records that the name table is filled by several threads at once; a third of the names repeat
     (readsFound is keyed by the header string, crass WorkHorse.cpp:1017)."""
