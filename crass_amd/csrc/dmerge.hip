@@ -9,7 +9,7 @@
 // every token is over {A,C,G,T,N}, 23 <= length <= 64.  Anything else uses the host merge (merge.cpp).
 // An 'N' (reads with an undetermined base do produce a few such DR variants) is packed as 'A' plus a bit in a
 // 64-bit position mask that every comparison carries along; the handful of 11-mers that contain one get their
-// identity from a small all-pairs pass instead of the 22-bit code (k_dm_badk).
+// identity from a small open-addressing table instead of the 22-bit code (k_dm_pack_codes).
 //
 // All integer work on a few 10^4 short strings: no MFMA, no HBM roofline to speak of — the point of
 // running it here is that the step no longer leaves the device between pass 1 and pass 2.
