@@ -1222,6 +1222,8 @@ static int install_patterns(crass_hip_ctx *c, const StringArena &pats)
     const double tb2 = now_ms();
     DevAutomaton A{};
     A.n_states = H.n_states; A.n_sym1 = H.n_sym1;
+    A.max_pat_len = 0;
+    for (size_t i = 0; i < pats.size(); i++) A.max_pat_len = std::max<uint32_t>(A.max_pat_len, (uint32_t)pats.len(i));
     memcpy(A.sym, H.sym, 256);
     (void)hipSetDevice(c->device);
     // the packed-read scans need the 4-column table only; the full byte-symbol table goes up on demand

@@ -69,6 +69,8 @@ struct DevAutomaton {
     uint32_t n_sym1;              // symbols + 1 (symbol 0 = byte in no pattern)
     uint8_t  sym[256];            // byte -> symbol
     uint32_t acgt_ok;             // n_states <= 65535 (go4 valid)
+    uint32_t max_pat_len;         // longest pattern (= depth of the trie): a scan that starts this many bases before a
+                                  // position is in the exact state there
 };
 
 // pass-2 anchor filter: cuckoo hash set (two choices, one slot each) of every 16-mer that

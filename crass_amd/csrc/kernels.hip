@@ -1040,7 +1040,28 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
                 if (skips == 8) {
                     const uint64_t m = wbits & 0x0101010101010101ull;        // positions j, j+8, ... inside this word
                     if (m) j += (uint32_t)(__ffsll((unsigned long long)m) - 1) - 8;    // the loop adds 8: lands on it
-                    else j += ((63u - (j & 63u)) & ~7u);                            // last stride-8 position of the word
+                    else {
+                        // nothing left in this word: the lanes look at the next 64 hint words at once (a random 10 kbp read
+                        // has one or two words with a candidate out of 157; walking them one dependent load at a time was
+                        // most of this kernel's time on long reads).  64 is a multiple of the stride, so the candidates of
+                        // every later word sit at bit offsets (j mod 8) + 8k.
+                        const uint64_t resmask = 0x0101010101010101ull << (j & 7u);
+                        const uint32_t n_words = ((uint32_t)searchEnd >> 6) + 1u;
+                        uint32_t next_j = 0xFFFFFFFFu;
+                        for (uint32_t w0 = (j >> 6) + 1u; w0 < n_words; w0 += 64u) {
+                            const uint32_t w = w0 + (uint32_t)lane;
+                            const uint64_t v = w < n_words ? (pos_hint[w] & resmask) : 0ull;
+                            const uint64_t any = __ballot(v != 0ull);
+                            if (any) {
+                                const uint32_t fw = w0 + (uint32_t)(__ffsll((unsigned long long)any) - 1);
+                                const uint64_t fv = pos_hint[fw] & resmask;             // (wave-uniform reload)
+                                next_j = fw * 64u + (uint32_t)(__ffsll((unsigned long long)fv) - 1);
+                                break;
+                            }
+                        }
+                        if (next_j == 0xFFFFFFFFu) break;                           // no candidate up to searchEnd: the loop ends
+                        j = next_j - 8u;                                            // the loop adds 8: lands on it
+                    }
                 }
                 continue;
             }
@@ -2471,6 +2492,40 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
     const int lane = threadIdx.x & 63;
     const uint64_t wave_global = (blockIdx.x * (uint64_t)THREADS + threadIdx.x) >> 6;
     const uint64_t wave_total = ((uint64_t)gridDim.x * THREADS) >> 6;
+    if (W == 0 && R.pos_hint) {
+        // long reads (the engine only builds position hints for reads beyond 2 kbp): a lane walking its own 10 kbp read
+        // touches one word per 2.5 KB row, 258 GB/s; here the WAVE walks one read, lane = window, so the loads are
+        // consecutive words, and a tile's 64 reads are taken one after the other (bit k of the mask word = read k)
+        auto probe = [&](uint32_t V) {
+            return MODE == 4 ? anchor_probe_bloom(ak_lds, K.table, V, K, mask)
+                             : MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
+                                         : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
+        };
+        for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_total) {
+            uint64_t bits = 0;
+            for (int k = 0; k < 64; k++) {
+                const uint64_t r = tile * 64 + (uint64_t)k;                     // wave-uniform
+                if (r >= R.n_reads) break;
+                if (!(K.with_exc || !rd_is_exc(R, r)) || found_flag[rd_header_id(R, r)]) continue;
+                const uint32_t L = rd_len(R, r);
+                if (L < 16) continue;
+                const uint32_t *g = R.packed + rd_word_off(R, r);
+                const uint32_t nw = (L + 15) >> 4, h_max = (L - 16) >> 3;
+                for (uint32_t h0 = 0; h0 <= h_max; h0 += 64) {
+                    const uint32_t h = h0 + (uint32_t)lane;
+                    bool f = false;
+                    if (h <= h_max) {
+                        const uint32_t lo = g[h >> 1];
+                        const uint32_t V = (h & 1) ? ((lo >> 16) | (((h >> 1) + 1 < nw ? g[(h >> 1) + 1] : 0u) << 16)) : lo;
+                        f = probe(V);
+                    }
+                    if (__ballot(f)) { bits |= 1ull << k; break; }              // one window is enough to flag the read
+                }
+            }
+            if (lane == 0) hitmask[tile] = bits;
+        }
+        return;
+    }
     for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_total) {
         const uint64_t r = tile * 64 + lane;
         bool flag = false;
@@ -2658,11 +2713,64 @@ __global__ __launch_bounds__(256) void k_recruit_list(DevReads R, DevAutomaton A
     pid_by_slot[k] = pid;
 }
 
+// The same for long reads: one WAVE per flagged read.  The automaton's state at a position only depends on the last
+// max_pat_len bases (the depth of the trie), so lane l scans its own slice [l * seg, (l + 1) * seg) after a warm-up of
+// max_pat_len bases from the start state and is in the exact state for every position it reports; the first callback
+// of the whole read is the smallest reported position over the lanes (a lane per 10 kbp read walked 10 000 dependent
+// table look-ups: 2.8 ms for a few hundred reads).
+__global__ __launch_bounds__(256) void k_recruit_list_wave(DevReads R, DevAutomaton A, const uint64_t *idx, const uint32_t *d_n,
+                                                            uint64_t n_max, uint32_t *info_by_slot, uint32_t *pid_by_slot)
+{
+    CRASS_VGPR_FLOOR(24);
+    const int lane = threadIdx.x & 63;
+    const uint64_t k = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    uint64_t n = *d_n;
+    if (n > n_max) n = n_max;
+    if (k >= n) return;
+    const uint64_t r = idx[k];
+    const uint32_t L = rd_len(R, r);
+    const uint32_t *g = R.packed + rd_word_off(R, r);
+    const uint32_t symA = A.sym['A'], symC = A.sym['C'], symG = A.sym['G'], symT = A.sym['T'];
+    const uint32_t seg = (L + 63u) / 64u;
+    const uint32_t s0 = (uint32_t)lane * seg, e0 = min(L, s0 + seg);
+    uint32_t first = 0xFFFFFFFFu, ol_found = 0, pid = 0;
+    if (s0 < L) {
+        const uint32_t p0 = s0 >= A.max_pat_len ? s0 - A.max_pat_len : 0u;        // warm-up (exact from the read start anyway)
+        uint32_t state = 0, word = 0;
+        for (uint32_t i = p0; i < e0; i++) {
+            if ((i & 15u) == 0 || i == p0) word = g[i >> 4] >> ((i & 15u) * 2u);
+            const uint32_t c = word & 3u;
+            word >>= 2;
+            if (A.go4) state = A.go4[state * 4 + c];
+            else if (A.go4w) state = A.go4w[(size_t)state * 4 + c];
+            else {
+                const uint32_t sy = c == 0 ? symA : c == 1 ? symC : c == 2 ? symG : symT;
+                state = A.go16 ? (uint32_t)A.go16[(size_t)state * A.n_sym1 + sy] : A.go32[(size_t)state * A.n_sym1 + sy];
+            }
+            if (i >= s0) {
+                const uint32_t ol = A.out_len[state];
+                if (ol) { first = i; ol_found = ol; pid = A.out_pid[state]; break; }
+            }
+        }
+    }
+    uint32_t best = first;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off));
+    if (best == 0xFFFFFFFFu) { if (lane == 0) { info_by_slot[k] = 0; pid_by_slot[k] = 0; } return; }
+    if (first == best) {                                  // exactly one lane owns that position
+        info_by_slot[k] = ((best + 1) << 8) | ol_found;
+        pid_by_slot[k] = pid;
+    }
+}
+
 hipError_t launch_recruit_list(const DevReads &R, const DevAutomaton &A, const uint64_t *idx, const uint32_t *d_n,
                                uint64_t n_max, uint32_t *info_by_slot, uint32_t *pid_by_slot, hipStream_t st)
 {
     if (n_max == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_recruit_list, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    if (R.pos_hint && A.max_pat_len)                       // long reads (the engine builds position hints beyond 2 kbp)
+        hipLaunchKernelGGL(k_recruit_list_wave, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    else
+        hipLaunchKernelGGL(k_recruit_list, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);
     return hipGetLastError();
 }
 
