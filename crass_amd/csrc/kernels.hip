@@ -281,27 +281,40 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     uint32_t w[13];
 #pragma unroll
     for (int i = 0; i < 13; i++) { const uint32_t wi = tile * 4 + i; w[i] = wi < nw ? g[wi] : 0u; }
+    // X_d = R xor (R >> 2d) once per shift; the 8-mer at base p (ANY residue) has a copy at p + d  <=>  X_d has 16 zero
+    // bits from bit 2p on.  (R >> 2 rho) xor (R >> 2 rho >> 2d) = X_d >> 2 rho, so the eight residues are eight bit
+    // offsets of the same words: instead of eight {funnel shift, xor, packed min} passes, one xor and a run-of-16
+    // test by doubling (OR of 2, 4, 8, 16 neighbouring bits, the neighbour word funnelled in), AND-accumulated over
+    // the shifts: bit b of acc[k] stays 1 unless some shift had zeros at bits [32k + b, 32k + b + 16).  About 47
+    // instead of 75 instructions per shift and lane.
+    uint32_t acc[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+    for (int d = 49; d <= 97; d++) {
+        const int q = d >> 4, sh = (d & 15) * 2;
+        uint32_t x[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const uint32_t a = w[k + q], b = w[k + q + 1];
+            x[k] = (sh ? ((a >> sh) | (b << (32 - sh))) : a) ^ w[k];
+        }
+#pragma unroll
+        for (int step = 1; step <= 8; step <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) x[k] |= (x[k] >> step) | (x[k + 1] << (32 - step));     // (uses the OLD x[k + 1]: ascending k)
+            if (step < 8) x[4] |= x[4] >> step;          // only its low bits are ever funnelled into x[3]
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] &= x[k];
+    }
     uint64_t bits = 0;
-    for (uint32_t rho = 0; rho < 8; rho++) {
-        uint32_t v[12];
 #pragma unroll
-        for (int i = 0; i < 12; i++) v[i] = rho ? ((w[i] >> (2 * rho)) | (w[i + 1] << (32 - 2 * rho))) : w[i];
-        uint32_t acc[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#pragma unroll
-        for (int d = 49; d <= 97; d++) {
-            const int q = d >> 4, sh = (d & 15) * 2;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t a = v[k + q], b = v[k + q + 1];
-                const uint32_t s2 = sh ? ((a >> sh) | (b << (32 - sh))) : a;
-                acc[k] = pk_min_u16(acc[k], s2 ^ v[k]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((acc[k] & 0xFFFFu) == 0) bits |= 1ull << (16 * k + rho);
-            if ((acc[k] >> 16) == 0) bits |= 1ull << (16 * k + 8 + rho);
-        }
+    for (int k = 0; k < 4; k++) {
+        uint32_t z = ~acc[k] & 0x55555555u;             // even bit 2i set <=> position 16k + i has a copy
+        z = (z | (z >> 1)) & 0x33333333u;
+        z = (z | (z >> 2)) & 0x0F0F0F0Fu;
+        z = (z | (z >> 4)) & 0x00FF00FFu;
+        z = (z | (z >> 8)) & 0x0000FFFFu;
+        bits |= (uint64_t)z << (16 * k);
     }
     hint_bits[t] = bits;
 }
