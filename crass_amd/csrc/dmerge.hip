@@ -241,33 +241,7 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
     }
 }
 
-// ---- one atomic per BLOCK on the state words.  A device-scope atomic on ONE address retires every ~2.5-3.5 ns on this
-// part however many CUs issue them, so "every claimant adds its count to a cursor" serialises: 6.9 k claimants = 24 us
-// of a 26 us kernel at 10 M reads, 30 k = 150 us at 100 M.  block_reserve: exclusive offsets for the threads of a block
-// from one atomicAdd (wave scan by shuffles, wave totals through LDS).  Every thread of the block must call it.
-template <int THREADS>
-static __device__ __forceinline__ uint32_t block_reserve(uint32_t v, uint32_t *counter)
-{
-    __shared__ uint32_t br_tot[THREADS / 64];
-    __shared__ uint32_t br_base;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)incl, off);
-        if (lane >= off) incl += u;
-    }
-    if (lane == 63) br_tot[w] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int i = 0; i < THREADS / 64; i++) { const uint32_t x = br_tot[i]; br_tot[i] = tot; tot += x; }
-        br_base = tot ? atomicAdd(counter, tot) : 0u;
-    }
-    __syncthreads();
-    return br_base + br_tot[w] + incl - v;
-}
-
+// (block_reserve: engine_internal.h)
 // ---- 4. removeRedundantRepeats: a member is dropped iff a strictly shorter member of its group, or
 // that member's reverse complement, occurs in it (equal-length members are distinct strings; the
 // relation is transitive, so "blanked earlier" never matters).  t or rc(t) in s <=> t in s or in rc(s).

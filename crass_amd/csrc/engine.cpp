@@ -176,6 +176,7 @@ struct crass_hip_ctx {
     DevBuf<SurvOut> d_surv; DevBuf<char> d_dr; DevBuf<uint32_t> d_ss_pool; DevBuf<uint32_t> d_ss_used;
     DevBuf<RecruitOut> d_rec; DevBuf<uint32_t> d_exc_hit; DevBuf<uint64_t> d_extra;
     PinBuf<uint32_t> h_count; PinBuf<SurvOut> h_surv; PinBuf<char> h_dr; PinBuf<uint32_t> h_ss; PinBuf<uint64_t> h_idx;
+    DevBuf<SurvOut> g_surv; DevBuf<char> g_dr; DevBuf<uint32_t> g_ss;       // host-loop sink: the found records, dense
     PinBuf<RecruitOut> h_rec;
     // automaton
     DevBuf<uint16_t> a_go16; DevBuf<uint32_t> a_go32; DevBuf<uint16_t> a_out; DevBuf<uint16_t> a_go4;
@@ -554,7 +555,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_mask.release(); c->d_word_prefix.release(); c->d_block_sums.release(); c->d_idx.release(); c->d_count.release();
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
-    c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
+    c->g_surv.release(); c->g_dr.release(); c->g_ss.release(); c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
     c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->d_pos_hint.release(); c->d_pos_hint_off.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -774,31 +775,44 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                                       c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds_full,
                                       (int)std::min<uint64_t>(grid, nchunk), c->stream, 6));
         if (!exc && off == 0) HIPCHK(c, c->stamp(9, 1));
-        HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->d_surv.p, nchunk * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->d_dr.p, nchunk * stride, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
+        // only the FOUND records travel (all 1 M reads of a 10 kbp set are survivors, 5 % are found; copying every slot
+        // and every start/stop slot area was 340 MB and 10 of 39 ms per step): select -> ordered index list -> gather
+        // into dense arrays with the start/stops packed -> three counters -> exact-size copies
+        const uint64_t n_words = (nchunk + 63) / 64;
+        HIPCHK(c, c->d_fidx.ensure(nchunk)); HIPCHK(c, c->g_surv.ensure(nchunk)); HIPCHK(c, c->g_dr.ensure(nchunk * (size_t)stride + 16));
+        HIPCHK(c, c->g_ss.ensure(pool_cap));
+        HIPCHK(c, c->d_mask.ensure(n_words + 1)); HIPCHK(c, c->d_word_prefix.ensure(n_words + 1)); HIPCHK(c, c->d_block_sums.ensure((n_words + 255) / 256 + 2));
+        HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 8, c->stream));            // [2] found, [3] worst error
+        HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));              // (reused: words of packed start/stops)
+        HIPCHK(c, launch_select_found(c->d_surv.p, nchunk, c->d_mask.p, c->d_count.p + 3, c->stream));
+        HIPCHK(c, launch_compact(c->d_mask.p, n_words, nchunk, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, nchunk, c->d_count.p + 2, c->stream));
+        HIPCHK(c, launch_gather_sparse(c->d_fidx.p, c->d_count.p + 2, nchunk, c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, c->g_surv.p,
+                                       c->d_fidx.p + 0, c->g_dr.p, c->g_ss.p, (uint32_t)pool_cap, c->d_ss_used.p, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_count.p + 6, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
         const double tq0 = now_ms();
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const double tq1 = now_ms();
-        // slot mode (kernel: n_surv * ss_cap <= pool_cap): the whole slot area is live, no counter
-        const bool slot_mode = nchunk * (uint64_t)lds.ss_cap <= pool_cap;
-        const uint32_t used = slot_mode ? (uint32_t)(nchunk * lds.ss_cap) : c->h_count.p[2];
-        if (used > pool_cap) return CRASS_ERR_OVERFLOW;
-        HIPCHK(c, c->h_ss.ensure(used + 1));
-        if (used) {
-            HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->d_ss_pool.p, (size_t)used * 4, hipMemcpyDeviceToHost, c->stream));
+        if (c->h_count.p[3] == 2) return CRASS_ERR_SEARCH_FATAL;
+        if (c->h_count.p[3]) return CRASS_ERR_OVERFLOW;
+        const uint64_t nf = c->h_count.p[2];
+        const uint32_t used = c->h_count.p[6];
+        if (nf > nchunk || used > pool_cap) return CRASS_ERR_OVERFLOW;
+        HIPCHK(c, c->h_ss.ensure(used + 1)); HIPCHK(c, c->h_idx.ensure(nf + 1));
+        if (nf) {
+            HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->g_surv.p, nf * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->g_dr.p, nf * (size_t)stride, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_fidx.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
+            if (used) HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->g_ss.p, (size_t)used * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
         const double tq2 = now_ms();
         const SurvOut *so = c->h_surv.p;
         const char *drs = c->h_dr.p;
         const uint32_t *pool = c->h_ss.p;
-        for (uint64_t k = 0; k < nchunk; k++) {
-            const SurvOut &o = so[k];
-            if (o.err == 5) continue;                       // exception read in the survivor list: evaluated by the exception pass
-            if (o.err == 1) return CRASS_ERR_SEARCH_FATAL;
-            if (o.err) return CRASS_ERR_OVERFLOW;
-            if (!o.found) continue;
+        for (uint64_t q = 0; q < nf; q++) {
+            const SurvOut &o = so[q];
+            const uint64_t k = c->h_idx.p[q];                // the record's slot in the chunk
             L.read.push_back(c->read_base + (exc ? c->h_exc_read[off + k] : surv_idx_host[off + k]));
             L.low.push_back(o.low_lexi);
             L.replen.push_back(o.repeat_len);
@@ -806,7 +820,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             L.ss_off.push_back(L.ss.size());
             L.ss.insert(L.ss.end(), pool + o.ss_off, pool + o.ss_off + o.n_ss);
             L.dr_len.push_back(o.dr_len);
-            L.dr.insert(L.dr.end(), drs + k * stride, drs + (k + 1) * stride);
+            L.dr.insert(L.dr.end(), drs + q * stride, drs + (q + 1) * stride);
         }
         if (c->env.merge_profile)
             fprintf(stderr, "[crass_sink] survivors %llu: kernel+D2H wait %.3f ms, pool D2H %.3f ms, host loop %.3f ms\n",

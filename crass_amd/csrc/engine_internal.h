@@ -222,6 +222,35 @@ hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *h
 // CRASS_VGPR_FLOOR(n) marks v<n> as used (no instruction is emitted), which moves .vgpr_count to at least n + 1.
 #define CRASS_VGPR_FLOOR(N) asm volatile("" ::: "v" #N)
 
+#ifdef __HIPCC__
+// ---- one atomic per BLOCK on the state words.  A device-scope atomic on ONE address retires every ~2.5-3.5 ns on this
+// part however many CUs issue them, so "every claimant adds its count to a cursor" serialises: 6.9 k claimants = 24 us
+// of a 26 us kernel at 10 M reads, 30 k = 150 us at 100 M.  block_reserve: exclusive offsets for the threads of a block
+// from one atomicAdd (wave scan by shuffles, wave totals through LDS).  Every thread of the block must call it.
+template <int THREADS>
+static __device__ __forceinline__ uint32_t block_reserve(uint32_t v, uint32_t *counter)
+{
+    __shared__ uint32_t br_tot[THREADS / 64];
+    __shared__ uint32_t br_base;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) br_tot[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < THREADS / 64; i++) { const uint32_t x = br_tot[i]; br_tot[i] = tot; tot += x; }
+        br_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    return br_base + br_tot[w] + incl - v;
+}
+#endif
+
 // Single-pass ordered compaction (decoupled look-back): per-tile status words, a ticket counter that hands out
 // tile ids in start order (a tile only ever waits for tiles that started before it) and an epoch tag so that
 // neither needs clearing between launches.  Built by crass_hip_ctx::next_lookback().
@@ -277,6 +306,14 @@ hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint3
 // k_found_mask + compaction as one decoupled-look-back kernel (tiles of 256 survivor slots); fidx[rank] = slot
 hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_t n_max, uint32_t *d_err, unsigned long long *dd_keys,
                                 uint32_t *dd_first, uint32_t dd_size, uint64_t *fidx, uint32_t *d_nf, const Lookback &lb, hipStream_t st);
+// host-loop form of the pass-1 sink (long / ragged reads): the found records of a chunk and nothing else, ready for one
+// set of exact-size copies.  sel_mask: bit per slot = found; d_err: 2 = the reference would throw, 1 = capacity (exception
+// reads in the list, err == 5, are somebody else's business); gather: record k = slot fidx[k] with its start/stops moved to
+// a dense pool (offsets from one atomicAdd per block)
+hipError_t launch_select_found(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st);
+hipError_t launch_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out, const char *dr_chars, uint32_t dr_stride,
+                                const uint32_t *ss_pool, SurvOut *g_out, uint64_t *g_slot, char *g_dr, uint32_t *g_ss, uint32_t g_ss_cap,
+                                uint32_t *d_ss_total, hipStream_t st);
 hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st,
                              unsigned long long *dd_keys = nullptr, uint32_t *dd_first = nullptr, uint32_t dd_size = 0);   // also clears that table
 // found records -> (a) the compact hand-off blob (p1_blob_layout; device memory — the runtime copies its used bytes to

@@ -2077,6 +2077,58 @@ hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_
     return hipGetLastError();
 }
 
+// ---- host-loop sink: select + gather of the found records (engine_internal.h) ----
+__global__ __launch_bounds__(256) void k_select_found(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err)
+{
+    CRASS_VGPR_FLOOR(8);
+    const uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    bool f = false;
+    if (s < n) {
+        const SurvOut o = out[s];
+        f = o.found != 0 && o.err == 0;
+        if (o.err && o.err != 5) atomicMax(d_err, o.err == 1 ? 2u : 1u);
+    }
+    const uint64_t m = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && s < n) mask[s >> 6] = m;
+}
+__global__ __launch_bounds__(256) void k_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out, const char *dr_chars,
+                                                        uint32_t dr_stride, const uint32_t *ss_pool, SurvOut *g_out, uint64_t *g_slot, char *g_dr,
+                                                        uint32_t *g_ss, uint32_t g_ss_cap, uint32_t *d_ss_total)
+{
+    CRASS_VGPR_FLOOR(32);
+    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    uint64_t n = *d_nf;
+    if (n > n_max) n = n_max;
+    SurvOut o; o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
+    uint64_t s = 0;
+    if (k < n) { s = fidx[k]; o = out[s]; }
+    const uint32_t off = block_reserve<256>(k < n ? o.n_ss : 0u, d_ss_total);      // (every thread of the block)
+    if (k >= n) return;
+    if ((uint64_t)off + o.n_ss <= g_ss_cap)
+        for (uint32_t i = 0; i < o.n_ss; i++) g_ss[off + i] = ss_pool[o.ss_off + i];
+    o.ss_off = off;
+    g_out[k] = o;
+    g_slot[k] = s;
+    const char *src = dr_chars + s * (uint64_t)dr_stride;
+    char *dst = g_dr + k * (uint64_t)dr_stride;
+    for (uint32_t i = 0; i < dr_stride; i++) dst[i] = src[i];
+}
+hipError_t launch_select_found(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_select_found, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, mask, d_err);
+    return hipGetLastError();
+}
+hipError_t launch_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out, const char *dr_chars, uint32_t dr_stride,
+                                const uint32_t *ss_pool, SurvOut *g_out, uint64_t *g_slot, char *g_dr, uint32_t *g_ss, uint32_t g_ss_cap,
+                                uint32_t *d_ss_total, hipStream_t st)
+{
+    if (n_max == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_sparse, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, dr_chars, dr_stride, ss_pool,
+                       g_out, g_slot, g_dr, g_ss, g_ss_cap, d_ss_total);
+    return hipGetLastError();
+}
+
 hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st,
                              unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size)
 {
