@@ -51,6 +51,9 @@ EDGE_BODY(k_edge2, "v23", "v21", "", Z64)            // drop in v21, v23 unused,
 EDGE_BODY(k_edge3, "v23", "v23", "s_nop 7\n\t", Z64)   // wait states after the EXEC write
 EDGE_BODY(k_edge4, "v23", "v23", "", Z32)            // two 32-bit moves instead of v_mov_b64
 EDGE_BODY(k_edge5, "v24", "v23", "", Z64)            // 25 VGPRs
+EDGE_BODY(k_edge6, "v31", "v31", "", Z64)            // drop in v31 = last register of a 32-register allocation
+EDGE_BODY(k_edge7, "v39", "v39", "", Z64)            // drop in v39 = last register of a 40-register allocation
+EDGE_BODY(k_edge8, "v39", "v31", "", Z64)            // drop in v31, 40 registers allocated
 int main()
 {
     const uint32_t nblk = 517, n = 132344, cap = nblk * 256;
@@ -64,10 +67,11 @@ int main()
     }
     (void)hipMemcpy(lens, h.data(), cap * 4, hipMemcpyHostToDevice); (void)hipMemcpy(cs, hc.data(), cap * 16, hipMemcpyHostToDevice);
     typedef void (*kern_t)(const uint32_t *, const uint4 *, uint32_t, uint4 *, uint64_t);
-    const kern_t kerns[] = {k_edge0, k_edge1, k_edge2, k_edge3, k_edge4, k_edge5};
+    const kern_t kerns[] = {k_edge0, k_edge1, k_edge2, k_edge3, k_edge4, k_edge5, k_edge6, k_edge7, k_edge8};
     const char *names[] = {"24 VGPRs, drop in v23 (as compiled)", "32 VGPRs (dead clobber of v31)", "24 VGPRs, drop in v21 (v23 unused)",
-                           "24 VGPRs, s_nop 7 after the EXEC write", "24 VGPRs, 2x v_mov_b32 instead of v_mov_b64", "25 VGPRs (dead clobber of v24)"};
-    for (int kv = 0; kv < 6; kv++) {
+                           "24 VGPRs, s_nop 7 after the EXEC write", "24 VGPRs, 2x v_mov_b32 instead of v_mov_b64", "25 VGPRs (dead clobber of v24)",
+                           "32 VGPRs, drop in v31 (last of 32)", "40 VGPRs, drop in v39 (last of 40)", "40 VGPRs, drop in v31"};
+    for (int kv = 0; kv < 9; kv++) {
         uint64_t tot0 = 0, tot1 = 0, first_bad = ~0ull, badA = 0, badB = 0;
         for (int rep = 0; rep < 100; rep++) {
             (void)hipMemset(out, 0xFF, cap * 16);
