@@ -426,7 +426,9 @@ static __device__ __forceinline__ void dm_table_params(uint32_t n, uint32_t tab_
 // themselves into the cuckoo table.  Two-choice cuckoo insertion, all keys at once: a key is always either in the
 // table or in exactly one thread's hand (atomicExch).  0xFFFFFFFF marks a free slot; the all-T key itself is handled
 // by the last kernel.
-__global__ __launch_bounds__(256) void k_dm_key_bases_insert(DevMerge M)
+// (1 024 threads per block: the cursor atomic RETURNS a value, and returning atomics on one address retire every ~35 ns,
+// not every 3 — 2 600 blocks of 256 were 90 of this kernel's 102 us at 100 M reads)
+__global__ __launch_bounds__(1024) void k_dm_key_bases_insert(DevMerge M)
 {
     CRASS_VGPR_FLOOR(8);
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void k_dm_key_bases_insert(DevMerge M)
     if (tok < dm_ntok(M)) hs = M.ent_slot[e];
     const bool claim = hs != 0xFFFFFFFFu && (hs & 0x80000000u);      // the key's claimant allocates its entry range
     const uint32_t h = hs & 0x7FFFFFFFu;
-    const uint32_t ebase = block_reserve<256>(claim ? M.kset_cnt[h] : 0u, &M.st->ent_cursor);
+    const uint32_t ebase = block_reserve<1024>(claim ? M.kset_cnt[h] : 0u, &M.st->ent_cursor);
     if (!claim) return;
     M.kset_base[h] = ebase;
     if (!ls || (M.st->fail & ~2u)) return;
@@ -456,6 +458,14 @@ __global__ __launch_bounds__(256) void k_dm_key_bases_insert(DevMerge M)
     if (cur == 0xFFFFFFFFu) return;
     const uint32_t rsh = 32u - ls;
     uint32_t pos = ak_h(cur, M.s1, M.m1, rsh);
+    // a free slot of its own first: only a key whose two slots are both taken starts an eviction chain (every link of a
+    // chain is a dependent atomic round trip; near load 1/2 — 30 k keys in 2^16 slots at 100 M reads — exchanging
+    // unconditionally made 46 % of the keys start one and the longest took ~100 us)
+    if (atomicCAS(&M.anchor_tab[pos], 0xFFFFFFFFu, cur) == 0xFFFFFFFFu) return;
+    {
+        const uint32_t p2 = ak_h(cur, M.s2, M.m2, rsh);
+        if (p2 != pos && atomicCAS(&M.anchor_tab[p2], 0xFFFFFFFFu, cur) == 0xFFFFFFFFu) return;
+    }
     for (int kicks = 0; kicks < 1000; kicks++) {
         const uint32_t old = atomicExch(&M.anchor_tab[pos], cur);
         if (old == 0xFFFFFFFFu) return;
@@ -580,7 +590,7 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done
     hipLaunchKernelGGL(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
     const unsigned ne = (16u * M.n_tok + 255) / 256;
     hipLaunchKernelGGL(k_dm_keys, dim3(ne), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_key_bases_insert, dim3(ne), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(k_dm_key_bases_insert, dim3((16u * M.n_tok + 1023) / 1024), dim3(1024), 0, st, M);
     hipLaunchKernelGGL(k_dm_fill_finish, dim3(std::max(std::max(128u, ne), (unsigned)(((1ull << M.tab_log_alloc) + 255) / 256))), dim3(256), 0, st, M);
     return hipGetLastError();
 }
