@@ -2606,13 +2606,40 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
 #pragma unroll
                     for (int i = 0; i < W; i++) w[i] = g[i];
                     w[W] = 0;
+                    if (MODE == 4) {
+                        // Bloom filter in LDS, exact keys in global memory.  ~7 % of the windows pass the Bloom filter, i.e.
+                        // in nearly every one of the 2W-1 unrolled windows SOME lane of the wave does, and a conditional
+                        // pair of global loads per window made the wave wait for 19 round trips.  So: all Bloom tests
+                        // first (LDS only, a bit per window), then every lane resolves ITS positives one per round —
+                        // the wave needs as many rounds as its busiest lane has positives (4-5).
+                        uint32_t pm = 0;
+#pragma unroll
+                        for (int h = 0; h < 2 * W - 1; h++) {
+                            const uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
+                            const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1), h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
+                            const uint32_t b1 = h1 >> 12, b2 = h2 >> 12;
+                            const uint32_t w1 = ak_lds[b1 >> 5], w2 = ak_lds[b2 >> 5];
+                            if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0u && (uint32_t)h <= h_max) pm |= 1u << h;
+                        }
+                        while (pm) {                                   // (divergent: lanes with fewer positives idle)
+                            const uint32_t h = (uint32_t)__ffs((int)pm) - 1u;
+                            pm &= pm - 1u;
+                            const uint32_t kk = h >> 1;
+                            uint32_t lo = 0, hi = 0;
+#pragma unroll
+                            for (int i = 0; i < W; i++) { lo = kk == (uint32_t)i ? w[i] : lo; hi = kk == (uint32_t)i ? w[i + 1] : hi; }
+                            const uint32_t V = (h & 1u) ? ((lo >> 16) | (hi << 16)) : lo;
+                            const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1), h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
+                            if ((K.table[h1 >> mask] == V) | (K.table[h2 >> mask] == V)) { flag = true; pm = 0; }
+                        }
+                    } else {
 #pragma unroll
                     for (int h = 0; h < 2 * W - 1; h++) {
                         uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
-                        bool hit = MODE == 4 ? anchor_probe_bloom(ak_lds, K.table, V, K, mask)
-                                             : MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
-                                                         : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
+                        bool hit = MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
+                                             : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
                         flag = flag | (hit & ((uint32_t)h <= h_max));
+                    }
                     }
                 } else {
                     const uint32_t nw = (L + 15) >> 4;
@@ -2662,7 +2689,8 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
 template <int W, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMerge M, const uint8_t *found_flag, uint64_t *hitmask)
 {
-    if constexpr (W == 10) CRASS_VGPR_FLOOR(64);
+    if constexpr (W == 10 || W == 11) CRASS_VGPR_FLOOR(64);
+    if constexpr (W == 15) CRASS_VGPR_FLOOR(72);
     extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
     DevAnchors K;
     K.table = M.anchor_tab; K.log_size = M.st->log_size; K.mode = 0; K.s1 = M.s1; K.s2 = M.s2; K.m1 = M.m1; K.m2 = M.m2; K.n_keys = 0;
