@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <climits>
 #include <cstring>
 #include <map>
@@ -733,6 +734,10 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
     s->ksw.gapo = 5; s->ksw.gape = 2; s->ksw.minsc = 5;
     { int k = 0; for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) s->ksw.mat[k++] = i == j ? 1 : -3; s->ksw.mat[k++] = 0; } for (int j = 0; j < 5; ++j) s->ksw.mat[k++] = 0; }
     int rc = CRASS_OK;
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_ph = now_s();
+    auto lap = [&](const char *what) { if (timing) { const double t = now_s(); fprintf(stderr, "[crass_timing] consensus: %-36s %.4f s\n", what, t - t_ph); t_ph = t; } };
     auto body = [&]() -> int {
         // ---- the hand-off: records with their RH_Seq (DRLowLexi's orientation, ReadHolder.cpp:573-590), tokens, groups ----
         for (uint32_t t = 0; t < in->n_tokens; t++) { s->tok.emplace_back(in->tok_chars + in->tok_off[t], (size_t)(in->tok_off[t + 1] - in->tok_off[t])); s->reads_of.emplace_back(nullptr); }
@@ -770,6 +775,7 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
         HCHK(s, hipMemcpyAsync(s->d_rlen.p, rlen.data(), rlen.size() * 4, hipMemcpyHostToDevice, s->st));
         HCHK(s, hipMemcpyAsync(s->d_comp.p, s->comp, 128, hipMemcpyHostToDevice, s->st));
         HCHK(s, hipStreamSynchronize(s->st));
+        lap("records, RH_Seq, upload");
         s->next_gid = (int)in->n_groups + 1;
         for (uint32_t g = 0; g < in->n_groups; g++) {
             auto v = new std::vector<int>();
@@ -778,6 +784,7 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
         }
         // ---- findConsensusDRs (WorkHorse.cpp:578-611): the ORIGINAL groups in ascending GID order ----
         { const int ps = prealign_original_groups(s, (int)in->n_groups); if (ps) return ps; }
+        lap("slave alignments (one ksw batch)");
         for (int gid = 1; gid <= (int)in->n_groups && !s->error && !s->hip_err; gid++) {
             auto it = s->group.find(gid);
             if (it == s->group.end() || !it->second) continue;
@@ -785,12 +792,15 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
             if (!s->error && !s->hip_err) combine_groups(s);
         }
         if (s->hip_err) return s->hip_err == (int)hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP;
+        lap("groups (coverage, consensus, splits)");
         if (!s->error) {
             if ((uint64_t)s->dr_tab.size() > dr_room) return CRASS_ERR_OVERFLOW;
             const int us = update_all_start_stops(s);
             if (us) return us;
         }
+        lap("updateStartStops (SW + Levenshtein)");
         flatten(s);
+        lap("flatten");
         return CRASS_OK;
     };
     rc = body();
