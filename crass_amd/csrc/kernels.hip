@@ -2591,9 +2591,30 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
         }
         return;
     }
+    // uniform stride: the words of the wave's NEXT tile are requested before the current one is hashed and probed, so a
+    // wave never sits idle for the ~1-2 us of its own loads (4 waves per SIMD — the table takes 128 KB of LDS — were
+    // not enough to cover them: the kernel ran at 62 % of its VALU issue time)
+    uint32_t pre[W > 0 ? W : 1];
+    auto prefetch = [&](uint64_t tile) {
+        if (W > 0) {
+            const uint64_t rr = tile * 64 + lane;
+            if (tile < n_tiles && rr < R.n_reads) {
+                const uint32_t *gp = R.packed + rr * (uint64_t)W;
+#pragma unroll
+                for (int i = 0; i < (W > 0 ? W : 1); i++) pre[i] = gp[i];
+            }
+        }
+    };
+    prefetch(wave_global);
     for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_total) {
         const uint64_t r = tile * 64 + lane;
         bool flag = false;
+        uint32_t cur[W > 0 ? W : 1];
+        if (W > 0) {
+#pragma unroll
+            for (int i = 0; i < (W > 0 ? W : 1); i++) cur[i] = pre[i];
+            prefetch(tile + wave_total);
+        }
         // with_exc: every pattern is pure ACGT, so an occurrence in an exception read lies in a stretch whose packed
         // codes are the real bases — the probe stays a superset filter; the verification checks the bytes
         if (r < R.n_reads && (K.with_exc || !rd_is_exc(R, r)) && !found_flag[rd_header_id(R, r)]) {
@@ -2604,7 +2625,7 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                 if (W > 0) {
                     uint32_t w[W + 1];
 #pragma unroll
-                    for (int i = 0; i < W; i++) w[i] = g[i];
+                    for (int i = 0; i < W; i++) w[i] = cur[i];
                     w[W] = 0;
                     if (MODE == 4) {
                         // Bloom filter in LDS, exact keys in global memory.  ~7 % of the windows pass the Bloom filter, i.e.
@@ -2666,14 +2687,9 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
 template <int W, int THREADS, int MODE>
 __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchors K, const uint8_t *found_flag, uint64_t *hitmask)
 {
-    if constexpr (W == 0 && MODE != 1) CRASS_VGPR_FLOOR(16);
-    if constexpr (W == 6 && MODE == 0) CRASS_VGPR_FLOOR(40);
-    if constexpr (W == 6 && MODE == 1) CRASS_VGPR_FLOOR(32);
-    if constexpr (W == 6 && MODE == 2) CRASS_VGPR_FLOOR(56);
-    if constexpr ((W == 10 || W == 11) && MODE == 0) CRASS_VGPR_FLOOR(64);
-    if constexpr (W == 12 && MODE == 2) CRASS_VGPR_FLOOR(88);
-    if constexpr (W == 14 && MODE == 1) CRASS_VGPR_FLOOR(40);
-    if constexpr (W == 16 && MODE == 0) CRASS_VGPR_FLOOR(72);
+    // 1 024 threads per block and (with its table in LDS) one block per CU: four waves per SIMD whatever the register count
+    // up to 128, so one floor above every instantiation's own count keeps all of them off a multiple of 8
+    CRASS_VGPR_FLOOR(120);
     extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
     const uint32_t tsize = 1u << K.log_size;
     const uint32_t *ak_lds = K.table;                   // key sets too large for LDS are probed in global memory (L2)
@@ -2689,8 +2705,7 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
 template <int W, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMerge M, const uint8_t *found_flag, uint64_t *hitmask)
 {
-    if constexpr (W == 10 || W == 11) CRASS_VGPR_FLOOR(64);
-    if constexpr (W == 15) CRASS_VGPR_FLOOR(72);
+    CRASS_VGPR_FLOOR(120);                              // (see k_anchor_filter)
     extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
     DevAnchors K;
     K.table = M.anchor_tab; K.log_size = M.st->log_size; K.mode = 0; K.s1 = M.s1; K.s2 = M.s2; K.m1 = M.m1; K.m2 = M.m2; K.n_keys = 0;
