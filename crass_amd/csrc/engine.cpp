@@ -151,6 +151,32 @@ struct EnvSwitches {
     }
 };
 
+// ---- the context's state, in one place -----------------------------------------------------------------------------
+// Results:      have_reads -> have_pass1 -> have_merge -> have_pass2 (each API call clears everything to its right and
+//               refuses with CRASS_ERR_STATE if what it needs on its left is missing).  dense.active / q_blob_active say
+//               which representation holds pass 1's / pass 2's records (compact pinned blob vs host vectors).
+// Speculation:  five bounds learnt from the PREVIOUS call of the same stage, each 1.5 x the count seen then, each used to
+//               size and queue the next stage before the host has seen the current count.  Every one of them has the same
+//               three-step protocol: (1) the kernels read the real count on the device and never touch a slot beyond the
+//               bound, (2) the real count reaches the host with the stage's final synchronisation, (3) count > bound =>
+//               nothing of the speculative launch is used, the bound is dropped (set to 0) and the stage is repeated with
+//               the exact count.  None is ever trusted for a result.
+//                 surv_cap_hint     survivors of the seed scan        -> survivor kernels queued behind the compaction
+//                 dx_cap_hint       distinct DR strings (one GPU)     -> the device merge queued behind pass 1 (premerge)
+//                 xchg.gx_cap_hint  distinct DR strings (all ranks)   -> the same behind the exchange's de-duplication
+//                 hit_cap_hint      reads flagged by the anchor probe -> verify / finish / pack queued behind it
+//                 (recruit_exact    one-shot: the next recruit call must not speculate, it repeats an overflowed one)
+// Queued merge: premerge 0 none / 1 prepared (tables cleared by the survivor kernel: dm_prepared_n, dm_prepared_src say
+//               for which buffers) / 2 queued; crass_hip_merge ADOPTS a queued merge iff no strings were passed in and the
+//               counts fit, otherwise launches its own.  dm_prev_local: the previous merge ran on the device for this
+//               context alone (only then is the next one queued ahead of time).  dm.active: the installed pattern set is
+//               the device-built one (dm.M), not the host-built automaton / anchors; dm.host_built, dm.build_pending: the
+//               host view (c->merge) of a device merge is being / has been rebuilt by the helper thread.
+// Copies:       bulk_pending: exact-size copies of pass 1's hand-off records are in flight on copy_stream; wait_bulk()
+//               before any getter reads them (a failed copy is reported there, bulk_status).
+// Failure:      a device merge that gives up sets dm.h_st->fail; whoever sees it calls host_merge_fallback (counted in
+//               n_merge_fallbacks) and repeats pass 2.  An allocation failure anywhere returns CRASS_ERR_OOM with the
+//               context still usable (tests/test_gpu_device_merge.py::test_out_of_memory_is_reported_and_the_context_survives).
 struct crass_hip_ctx {
     crass_params prm{};
     EnvSwitches env;
