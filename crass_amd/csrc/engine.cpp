@@ -166,9 +166,10 @@ struct EnvSwitches {
 //                 xchg.gx_cap_hint  distinct DR strings (all ranks)   -> the same behind the exchange's de-duplication
 //                 hit_cap_hint      reads flagged by the anchor probe -> verify / finish / pack queued behind it
 //                 (recruit_exact    one-shot: the next recruit call must not speculate, it repeats an overflowed one)
-// Queued merge: premerge 0 none / 1 prepared (tables cleared by the survivor kernel: dm_prepared_n, dm_prepared_src say
-//               for which buffers) / 2 queued; crass_hip_merge ADOPTS a queued merge iff no strings were passed in and the
-//               counts fit, otherwise launches its own.  dm_prev_local: the previous merge ran on the device for this
+// Queued merge: premerge 0 none / 2 queued by the seed scan and valid (count within the bound), premerge_inflight: its
+//               kernels may still be running when the seed scan returns; dm_prepared_n / dm_prepared_src: the survivor
+//               kernel already cleared the merge tables for that many tokens of that buffer.  crass_hip_merge ADOPTS a
+//               queued merge iff no strings were passed in and premerge == 2, otherwise launches its own.  dm_prev_local: the previous merge ran on the device for this
 //               context alone (only then is the next one queued ahead of time).  dm.active: the installed pattern set is
 //               the device-built one (dm.M), not the host-built automaton / anchors; dm.host_built, dm.build_pending: the
 //               host view (c->merge) of a device merge is being / has been rebuilt by the helper thread.
