@@ -55,6 +55,29 @@ __global__ __launch_bounds__(256) void k_cons_cover(const uint8_t *seq, const ui
     }
 }
 
+__global__ __launch_bounds__(256) void k_cons_cover_lds(const uint8_t *seq, const uint64_t *roff, const uint32_t *rlen, const uint32_t *plc_rec,
+                                                         const int32_t *plc_pos, uint32_t n_plc, int *cov, int length)
+{
+    CRASS_VGPR_FLOOR(16);
+    extern __shared__ int cov_lds[];                    // [4][length]
+    for (int i = threadIdx.x; i < 4 * length; i += 256) cov_lds[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t q = w; q < n_plc; q += nw) {
+        const uint32_t k = plc_rec[q];
+        const uint8_t *s = seq + roff[k];
+        const int L = (int)rlen[k], pos = plc_pos[q];
+        for (int i = lane; i < L; i += WAVE) {
+            const uint8_t c = s[i];
+            const int row = (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : 0;
+            atomicAdd(&cov_lds[row * length + (i + pos)], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * length; i += 256) { const int v = cov_lds[i]; if (v) atomicAdd(&cov[i], v); }
+}
+
 // ---- ksw_i16 (ksw.c:228-317) with the SSE2 striped layout simulated lane by lane: 8 int16 lanes per vector, slen =
 // ceil(qlen / 8) vectors, query position of (vector j, lane l) = j + l * slen.  The layout is part of the result:
 // E(i+1, j) is taken from H before the lazy-F pass, and the query end is the first maximum in vector-memory order.
@@ -292,6 +315,15 @@ hipError_t launch_cons_cover(const uint8_t *seq, const uint64_t *roff, const uin
                              uint32_t n_plc, int *cov, int length, hipStream_t st)
 {
     if (!n_plc) return hipSuccess;
+    // short reads: the whole coverage array (4 rows x length columns) fits LDS, a block adds its placements there and
+    // flushes the columns it touched — all reads of a group pile onto the same ~150 columns, and as global atomics
+    // (~600 adds per address) that was 54 us per group
+    const size_t lds = (size_t)length * 16;
+    if (lds <= 64 * 1024) {
+        const uint32_t nb = std::max<uint32_t>(1u, std::min<uint32_t>((n_plc + 63) / 64, 64u));
+        hipLaunchKernelGGL(k_cons_cover_lds, dim3(nb), dim3(256), lds, st, seq, roff, rlen, plc_rec, plc_pos, n_plc, cov, length);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_cons_cover, dim3(std::min<uint32_t>((n_plc + 3) / 4, 8192u)), dim3(256), 0, st, seq, roff, rlen, plc_rec, plc_pos, n_plc, cov, length);
     return hipGetLastError();
 }
