@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -816,26 +817,46 @@ bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint
     const double p2 = prof_now();
     const uint32_t n_distinct = m.tokens.size();
     m.next_free_gid = (int)n_groups + 1;
-    // members by group, token order inside a group (stable counting sort) = the sequence the reference sorts
+    // members by group, token order inside a group (stable counting sort) = the sequence the reference sorts.  Chunks of
+    // the token range count and scatter on the host pool: chunk c's members of group g go behind those of the chunks
+    // before it, so the order inside a group stays the token order.
+    const unsigned host_threads = 16;
+    const size_t n_chunks = n_distinct >= 8192 && (uint64_t)n_groups * 8 <= n_distinct ? 8 : 1;
+    const size_t per_chunk = (n_distinct + n_chunks - 1) / n_chunks;
+    std::vector<uint32_t> hist(n_chunks * ((size_t)n_groups + 1), 0);
+    std::atomic<int> bad_gid{0};
+    parallel_tasks(n_chunks, host_threads, [&](size_t c) {
+        uint32_t *h = hist.data() + c * ((size_t)n_groups + 1);
+        const uint32_t lo = (uint32_t)(c * per_chunk), hi = (uint32_t)std::min<size_t>(n_distinct, (c + 1) * per_chunk);
+        for (uint32_t t = lo; t < hi; t++) {
+            const uint32_t g = gid_of[t];
+            if (g == 0 || g > n_groups) { bad_gid.store(1, std::memory_order_relaxed); return; }
+            h[g - 1]++;
+        }
+    });
+    if (bad_gid.load()) { m.clear(); return false; }
     std::vector<uint32_t> goff(n_groups + 1, 0);
-    for (uint32_t t = 0; t < n_distinct; t++) {
-        const uint32_t g = gid_of[t];
-        if (g == 0 || g > n_groups) { m.clear(); return false; }
-        goff[g]++;
+    {   // hist[c][g] -> first slot of chunk c's members of group g
+        uint32_t at = 0;
+        for (uint32_t g = 0; g < n_groups; g++) {
+            goff[g] = at;
+            for (size_t c = 0; c < n_chunks; c++) { uint32_t &h = hist[c * ((size_t)n_groups + 1) + g]; const uint32_t k = h; h = at; at += k; }
+        }
+        goff[n_groups] = at;
     }
-    for (uint32_t g = 0; g < n_groups; g++) goff[g + 1] += goff[g];
-    std::vector<Member> members(n_distinct);
+    std::unique_ptr<Member[]> members(new Member[n_distinct ? n_distinct : 1]);
     m.grp_tokens.resize(n_distinct);
     m.grp_off.resize(n_groups + 1);
     for (uint32_t g = 0; g <= n_groups; g++) m.grp_off[g] = goff[g];
-    {
-        std::vector<uint32_t> cur(goff.begin(), goff.end() - 1);
-        for (uint32_t t = 0; t < n_distinct; t++) {
+    parallel_tasks(n_chunks, host_threads, [&](size_t c) {
+        uint32_t *cur = hist.data() + c * ((size_t)n_groups + 1);
+        const uint32_t lo = (uint32_t)(c * per_chunk), hi = (uint32_t)std::min<size_t>(n_distinct, (c + 1) * per_chunk);
+        for (uint32_t t = lo; t < hi; t++) {
             const uint32_t q = cur[gid_of[t] - 1]++;
             members[q] = Member{t, (uint32_t)m.tokens.strings.len(t), blank[t] != 0};
             m.grp_tokens[q] = t + 2;
         }
-    }
+    });
     m.groups.assign(n_groups, {});
     const double p2b = prof_now();
     // per group: the reference's sort by length + partition (the same std:: calls on the same sequence, so the same
@@ -844,10 +865,10 @@ bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint
     std::vector<uint64_t> kept_chars(n_groups + 1, 0);
     const size_t gchunk = n_distinct >= 4096 ? 1 : std::max<size_t>(n_groups, 1);          // small sets: one task, no dispatch
     const size_t n_tasks = (n_groups + gchunk - 1) / gchunk;
-    parallel_tasks(n_tasks, 8, [&](size_t c) {
+    parallel_tasks(n_tasks, host_threads, [&](size_t c) {
         for (size_t g = c * gchunk; g < std::min<size_t>(n_groups, (c + 1) * gchunk); g++) {
             m.groups[g].assign(m.grp_tokens.begin() + goff[g], m.grp_tokens.begin() + goff[g + 1]);
-            Member *lo = members.data() + goff[g], *hi = members.data() + goff[g + 1];
+            Member *lo = members.get() + goff[g], *hi = members.get() + goff[g + 1];
             std::sort(lo, hi, member_shorter_first);
             Member *mid = std::partition(lo, hi, member_kept);
             kept[g + 1] = (uint32_t)(mid - lo);
@@ -867,9 +888,9 @@ bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint
     m.pat_token.resize(n_pat);
     const unsigned char *ctab = comp_table();
     std::atomic<int> need_lookup{0};
-    parallel_tasks(n_tasks, 8, [&](size_t c) {
+    parallel_tasks(n_tasks, host_threads, [&](size_t c) {
         for (size_t g = c * gchunk; g < std::min<size_t>(n_groups, (c + 1) * gchunk); g++) {
-            const Member *lo = members.data() + goff[g];
+            const Member *lo = members.get() + goff[g];
             const uint32_t k = kept[g + 1] - kept[g];
             const size_t p0 = 2 * (size_t)kept[g];                     // first pattern of the group
             uint64_t at = 2 * kept_chars[g];
