@@ -63,6 +63,16 @@ def test_synthetic_device_vs_host(ca, L, n_dr, n):
     assert_same_pipeline(dev, orc.pipeline(seqs))
 
 
+def test_host_view_of_a_large_merge_matches_the_host_merge(ca):
+    """>= 8192 distinct DR strings: the host view of a device merge is then built by token-range chunks on the host pool
+    (merge.cpp, merge_from_device_finish); tokens, groups, pattern order and pass-2 records against the host merge"""
+    seqs = synth_reads(ca, 1_500_000, read_len=150, n_dr=50, crispr_per_million=250000)
+    dev, host = both_paths(ca, seqs)
+    assert len(dev.tokens) >= 8192
+    assert_same_paths(dev, host)
+    assert dev.n_groups >= 50
+
+
 def test_group_size_cap_falls_back(ca):
     """a group beyond the device merge's size cap (its per-group steps are quadratic) must end in the host merge"""
     seqs = synth_reads(ca, 40000, read_len=150, n_dr=2, crispr_per_million=300000)
