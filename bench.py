@@ -55,7 +55,7 @@ CONFIGS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="BASELINE.json configs[i]; 0 = configs[1] at N=1, configs[2] at N>1")
@@ -238,16 +238,24 @@ def main():
     for _ in range(2):                                   # (settle into the timed configuration)
         step()
     kern = {names[dom][0]: [], "ms_merge_host": [], "ms_sink_host": []}
+    import gc
+    gc.collect()
+    gc.disable()                                         # (no collector pauses inside the timed region)
+    step_marks = [0.0] * (args.steps + 1)                # a step ends with its records in host memory: wall-clock marks between steps
     sync()
     t0 = time.perf_counter()
+    step_marks[0] = t0
     for it in range(args.steps):
         e = eng_b if (args.alternate and it & 1) else eng
         step(e)
         c = e.counters()
         for k in kern:
             kern[k].append(c[k])
+        step_marks[it + 1] = time.perf_counter()
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
+    per_step = np.diff(np.asarray(step_marks)) * 1e3
     eng.set_timing_focus(7)
     tot_p1, tot_p2 = None, None
     c = eng.counters()
@@ -334,6 +342,9 @@ def main():
                    "merge_fallbacks": int(c.get("n_merge_fallbacks", 0)),      # device merges redone on the host: must stay 0
                    "synth_gen_s": round(t_gen, 2)},
         "first_call_ms": round(first_call_ms, 3),
+        # this rank's wall clock between step ends inside the timed region (value / ms_per_step are the contract's total / K)
+        "step_ms": {"median": round(float(np.median(per_step)), 4), "min": round(float(per_step.min()), 4),
+                    "p90": round(float(np.percentile(per_step, 90)), 4), "max": round(float(per_step.max()), 4)},
         "timed_batches": "two resident batches, alternating" if args.alternate else
                          "one resident batch repeated (speculation bounds learnt from the previous, identical step; "
                          "first_call_ms = the same step on a fresh context; --alternate switches batches)",
