@@ -9,6 +9,6 @@ for rep in 1 2 3; do
     python bench.py --cpu-sample 0 "${args[@]}" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$(basename $l .so)', 'ms_per_step', d['ms_per_step'], d['roofline'].get('stages_ms_scouting_steps'))"
+print('$(basename $l .so)', 'ms_per_step', d['ms_per_step'], d.get('step_ms'), d['roofline'].get('stages_ms_scouting_steps'))"
   done
 done
