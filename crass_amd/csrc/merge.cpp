@@ -682,6 +682,7 @@ private:
 } // namespace
 
 void host_pool_warm() { HostPool::get().warm(); }
+void host_parallel_for(size_t n_tasks, unsigned max_threads, const std::function<void(size_t)> &fn) { HostPool::get().run(n_tasks, max_threads, fn); }
 
 static double prof_now()
 {

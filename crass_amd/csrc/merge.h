@@ -4,6 +4,7 @@
 #pragma once
 #include <stdint.h>
 #include <string>
+#include <functional>
 #include <vector>
 #include <unordered_map>
 
@@ -70,6 +71,8 @@ struct MergeResult {
 // Wake the host worker pool ahead of a merge (its workers then poll for a few milliseconds): call it while
 // waiting for the device so that the wake-up latency is hidden.
 void host_pool_warm();
+// fn(task) for task in [0, n_tasks) on the same pool (caller included), at most max_threads threads
+void host_parallel_for(size_t n_tasks, unsigned max_threads, const std::function<void(size_t)> &fn);
 
 // addReadHolder's token assignment (libcrispr.cpp:1137-1143) for every candidate DR in read
 // order, then createNonRedundantSet (WorkHorse.cpp:648-709).
