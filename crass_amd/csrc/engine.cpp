@@ -147,7 +147,7 @@ template <typename T> struct PinBuf {
 struct EnvSwitches {
     bool no_lookback = false, no_pos_hints = false, merge_profile = false, no_lane_kernel = false;
     bool host_merge = false, no_speculation = false, exc_separate = false, dm_inject_fail = false, dm_init_late = false;
-    uint32_t row_cap = 2048, dm_group_cap = 16384, surv_debug = 0;
+    uint32_t row_cap = 1024, dm_group_cap = 16384, surv_debug = 0;
     int stage_timing = -1;
     uint64_t pool_cap_bytes = 0;                     // tests: device allocations beyond this total fail with hipErrorOutOfMemory
     void read()
@@ -157,7 +157,7 @@ struct EnvSwitches {
         merge_profile = on("CRASS_MERGE_PROFILE"); no_lane_kernel = on("CRASS_NO_LANE_KERNEL"); host_merge = on("CRASS_HOST_MERGE");
         no_speculation = on("CRASS_NO_SPECULATION"); exc_separate = on("CRASS_EXC_SEPARATE"); dm_init_late = on("CRASS_DM_INIT_LATE");
         dm_inject_fail = on("CRASS_DM_INJECT_FAIL");
-        row_cap = 2048; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
+        row_cap = 1024; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
         dm_group_cap = 16384; if (const char *e = getenv("CRASS_DM_GROUP_CAP")) dm_group_cap = (uint32_t)std::max(1, atoi(e));
         surv_debug = 0; if (const char *e = getenv("CRASS_SURV_DEBUG")) surv_debug = (uint32_t)atoi(e);
         stage_timing = -1; if (const char *e = getenv("CRASS_STAGE_TIMING")) stage_timing = std::min(2, std::max(0, atoi(e)));
@@ -779,7 +779,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                          const uint64_t *surv_idx_host)
 {
     if (n_total == 0) return CRASS_OK;
-    // Long reads: the Levenshtein fallback rows are sized for 2 k-long strings (spacers are a few dozen bases), which
+    // Long reads: the Levenshtein fallback rows are sized for 1 k-long strings (spacers are a few dozen bases), which
     // is what lets several waves share a CU's LDS; a read that needs longer rows comes back with err == 6 and is
     // redone by a second launch with the uncapped layout.
     const SurvLds lds_full = survivor_lds_layout(c->max_len, c->dp);

@@ -202,6 +202,7 @@ struct SurvLds {
     uint32_t ss_cap;              // entries (uint32)
     uint32_t row_elems;           // uint16 entries per Levenshtein boundary row
     uint32_t words_cap;           // uint32 entries of the packed-read copy
+    uint32_t hint_words;          // uint64 entries of the read's per-position seed hints (long reads)
     uint32_t total_bytes;
 };
 

@@ -1170,13 +1170,88 @@ static __device__ int dr_low_lexi(RH &h, char *dr_out, int dr_stride, int &was_l
     return (int)dlen;
 }
 
-static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *seq, uint32_t *words, int L, int lane)
+// words of the read a wave works on NEXT, requested while it searches the current one (wave-per-read kernel, long reads:
+// a 10 kbp read is ten dependent rounds of loads per lane otherwise — 5.0 of the kernel's 12.3 ms at 1 M x 10 kbp)
+#define SV_PREFETCH_WORDS 12                      // per lane: reads up to 12 * 64 * 16 = 12 288 bases are covered completely
+#define SV_PREFETCH_HINTS (SV_PREFETCH_WORDS / 4)  // 64-bit hint words per lane for the same reads (one bit per position)
+struct ReadPrefetch {
+    uint32_t w[SV_PREFETCH_WORDS];
+    uint64_t hw[SV_PREFETCH_HINTS];
+    uint64_t r;                                   // the read these words belong to (~0: none)
+};
+static __device__ __forceinline__ void prefetch_read(const DevReads &R, uint64_t r, int lane, ReadPrefetch &pf)
+{
+    const uint32_t *g = R.packed + rd_word_off(R, r);
+    const int L = (int)rd_len(R, r);
+    const int nw = (L + 15) >> 4;
+#pragma unroll
+    for (int i = 0; i < SV_PREFETCH_WORDS; i++) {
+        const int wi = lane + i * WAVE;
+        pf.w[i] = wi < nw ? g[wi] : 0u;
+    }
+    if (R.pos_hint) {
+        const uint64_t *ph = R.pos_hint + R.pos_hint_off[r];
+        const int nh = (L + 63) >> 6;
+#pragma unroll
+        for (int i = 0; i < SV_PREFETCH_HINTS; i++) {
+            const int wi = lane + i * WAVE;
+            pf.hw[i] = wi < nh ? ph[wi] : 0ull;
+        }
+    }
+    pf.r = r;
+}
+// the read's per-position hint words into LDS: search_core looks at one of them per seed candidate and scans them for the
+// next candidate — as global loads these were some 25 dependent round trips per 10 kbp read
+static __device__ void load_hints_to_lds(const DevReads &R, uint64_t r, int L, uint64_t *l_hint, int lane, const ReadPrefetch &pf)
+{
+    const uint64_t *ph = R.pos_hint + R.pos_hint_off[r];
+    const int nh = (L + 63) >> 6;
+    int first = lane;
+    if (pf.r == r) {
+#pragma unroll
+        for (int i = 0; i < SV_PREFETCH_HINTS; i++) {
+            const int wi = lane + i * WAVE;
+            if (wi < nh) l_hint[wi] = pf.hw[i];
+        }
+        first = lane + SV_PREFETCH_HINTS * WAVE;
+    }
+    for (int wi = first; wi < nh; wi += WAVE) l_hint[wi] = ph[wi];
+}
+
+static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *seq, uint32_t *words, int L, int lane,
+                                        const ReadPrefetch *pf = nullptr)
 {
     const uint32_t *g = R.packed + rd_word_off(R, r);
     const uint32_t lut = ('A') | ('C' << 8) | ('G' << 16) | ('T' << 24);
     const int nw = (L + 15) >> 4;
     if (lane == 0) words[nw] = 0;                 // lds_code reads one word past the last
-    for (int wi = lane; wi < nw; wi += WAVE) {
+    const bool have = pf && pf->r == r;           // wave-uniform
+    int first = lane;
+    if (have) {
+#pragma unroll
+        for (int i = 0; i < SV_PREFETCH_WORDS; i++) {
+            const int wi = lane + i * WAVE;
+            if (wi < nw) {
+                const uint32_t v = pf->w[i];
+                words[wi] = v;
+                uint32_t o[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t x = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t c = (v >> (2 * (4 * q + k))) & 3u;
+                        x |= ((lut >> (8 * c)) & 0xFFu) << (8 * k);
+                    }
+                    o[q] = x;
+                }
+                uint32_t *dst = reinterpret_cast<uint32_t *>(seq + 16 * wi);
+                dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+            }
+        }
+        first = lane + SV_PREFETCH_WORDS * WAVE;
+    }
+    for (int wi = first; wi < nw; wi += WAVE) {
         uint32_t v = g[wi];
         words[wi] = v;
         uint32_t o[4];
@@ -1214,6 +1289,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
     uint32_t *l_words = reinterpret_cast<uint32_t *>(h.rowB + lds.row_elems);
     h.words = EXC ? nullptr : l_words;
     h.sims = reinterpret_cast<float *>(l_words + lds.words_cap);
+    uint64_t *l_hint = reinterpret_cast<uint64_t *>(h.sims + lds.ss_cap);
     h.cmask = (1u << (2 * P.window)) - 1u;
     // EXC with punt_only == 5: exception reads that sit in the survivor list (slot s, read surv_idx[s])
     uint64_t n_surv = (EXC && punt_only != 5) ? R.n_exc : (uint64_t)(*d_n_surv);
@@ -1221,6 +1297,8 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
     // punt mode: only the reads an earlier launch handed over (err == punt_only: 4 from the lane kernel, 6 = row buffer).  Each wave looks at 64 slots at once and
     // then walks the (rare) flagged ones, instead of every wave polling its slots one dependent load at a time.
     uint64_t punt_base = (uint64_t)blockIdx.x * WAVE, punt_mask = 0;
+    ReadPrefetch pf;
+    pf.r = ~0ull;
     for (uint64_t s = blockIdx.x;; ) {
         if (punt_only) {
             while (punt_mask == 0) {
@@ -1256,12 +1334,18 @@ __global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, c
                 continue;
             }
             L = (int)rd_len(R, r);
-            load_read_to_lds(R, r, h.seq, l_words, L, lane);
+            load_read_to_lds(R, r, h.seq, l_words, L, lane, &pf);
+            if (R.pos_hint) load_hints_to_lds(R, r, L, l_hint, lane, pf);
+            pf.r = ~0ull;
+            if (!punt_only && s + gridDim.x < n_surv) {         // the next read of this wave: its words travel during the search
+                const uint64_t r2 = surv_idx[s + gridDim.x];
+                if (!rd_is_exc(R, r2)) prefetch_read(R, r2, lane, pf);
+            }
         }
         wave_sync();
         h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
         const uint32_t hint = (!EXC && seed_hint) ? seed_hint[r] : 0xFFFFFFFFu;
-        const uint64_t *ph = (!EXC && R.pos_hint) ? R.pos_hint + R.pos_hint_off[r] : nullptr;
+        const uint64_t *ph = (!EXC && R.pos_hint) ? l_hint : nullptr;      // (staged in LDS above)
         int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane, ph);
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
@@ -2349,7 +2433,8 @@ SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P, uint32_t row_l
     l.ss_cap = ((2 * reps) + 3u) & ~3u;
     l.row_elems = ((std::min(max_len, row_len_cap) + 8) + 7u) & ~7u;
     l.words_cap = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
-    l.total_bytes = l.seq_bytes + l.ss_cap * 4 + 2 * l.row_elems * 2 + l.words_cap * 4 + l.ss_cap * 4;
+    l.hint_words = ((max_len + 63) / 64 + 2 + 1u) & ~1u;
+    l.total_bytes = l.seq_bytes + l.ss_cap * 4 + 2 * l.row_elems * 2 + l.words_cap * 4 + l.ss_cap * 4 + l.hint_words * 8;
     return l;
 }
 
