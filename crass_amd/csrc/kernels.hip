@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     // bits from bit 2p on.  (R >> 2 rho) xor (R >> 2 rho >> 2d) = X_d >> 2 rho, so the eight residues are eight bit
     // offsets of the same words: instead of eight {funnel shift, xor, packed min} passes, one xor and a run-of-16
     // test by doubling (OR of 2, 4, 8, 16 neighbouring bits, the neighbour word funnelled in), AND-accumulated over
-    // the shifts: bit b of acc[k] stays 1 unless some shift had zeros at bits [32k + b, 32k + b + 16).  About 47
+    // the shifts: odd bit b of acc[k] stays 1 unless some shift had zeros at bits [32k + b - 1, 32k + b + 15).  About 47
     // instead of 75 instructions per shift and lane.
     uint32_t acc[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll
@@ -297,8 +297,13 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
             const uint32_t a = w[k + q], b = w[k + q + 1];
             x[k] = (sh ? ((a >> sh) | (b << (32 - sh))) : a) ^ w[k];
         }
+        // first the two bits of a base into its ODD bit (x | x << 1: one v_lshl_or per word, and no neighbour word — bit 0
+        // of a word is an even bit); the three doubling steps that follow shift by even amounts, so the odd bits never
+        // see what the even bits hold
 #pragma unroll
-        for (int step = 1; step <= 8; step <<= 1) {
+        for (int k = 0; k < 5; k++) asm("v_lshl_or_b32 %0, %1, 1, %1" : "=v"(x[k]) : "v"(x[k]));     // (hipcc 7.2 splits x | x << 1 into a shift and a v_bitop3 here)
+#pragma unroll
+        for (int step = 2; step <= 8; step <<= 1) {
 #pragma unroll
             for (int k = 0; k < 4; k++) x[k] |= (x[k] >> step) | (x[k + 1] << (32 - step));     // (uses the OLD x[k + 1]: ascending k)
             if (step < 8) x[4] |= x[4] >> step;          // only its low bits are ever funnelled into x[3]
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     uint64_t bits = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        uint32_t z = ~acc[k] & 0x55555555u;             // even bit 2i set <=> position 16k + i has a copy
+        uint32_t z = (~acc[k] >> 1) & 0x55555555u;      // odd bit 2i+1 of acc clear <=> position 16k + i has a copy
         z = (z | (z >> 1)) & 0x33333333u;
         z = (z | (z >> 2)) & 0x0F0F0F0Fu;
         z = (z | (z >> 4)) & 0x00FF00FFu;
@@ -2661,14 +2666,26 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                 if (L < 16) continue;
                 const uint32_t *g = R.packed + rd_word_off(R, r);
                 const uint32_t nw = (L + 15) >> 4, h_max = (L - 16) >> 3;
-                for (uint32_t h0 = 0; h0 <= h_max; h0 += 64) {
-                    const uint32_t h = h0 + (uint32_t)lane;
+                // a lane takes FOUR consecutive windows (halfword positions 4q .. 4q+3 = words 2q, 2q+1 and the low half of
+                // 2q+2): three loads serve four probes, one ballot decides 256 windows, and the words of the next round are
+                // requested before this round is probed (one window per lane and round was 20 dependent round trips per
+                // 10 kbp read: 3.3 ms for 1 M reads)
+                auto fetch3 = [&](uint32_t q, uint32_t &a, uint32_t &b, uint32_t &c3) {
+                    const uint32_t w0 = 2u * q;
+                    a = w0 < nw ? g[w0] : 0u; b = w0 + 1u < nw ? g[w0 + 1u] : 0u; c3 = w0 + 2u < nw ? g[w0 + 2u] : 0u;
+                };
+                uint32_t na, nb, nc;
+                fetch3((uint32_t)lane, na, nb, nc);
+                for (uint32_t h0 = 0; h0 <= h_max; h0 += 256) {
+                    const uint32_t q = (h0 >> 2) + (uint32_t)lane;
+                    const uint32_t a = na, b = nb, c3 = nc;
+                    if (h0 + 256 <= h_max) fetch3(q + 64u, na, nb, nc);
+                    const uint32_t h = 4u * q;
                     bool f = false;
-                    if (h <= h_max) {
-                        const uint32_t lo = g[h >> 1];
-                        const uint32_t V = (h & 1) ? ((lo >> 16) | (((h >> 1) + 1 < nw ? g[(h >> 1) + 1] : 0u) << 16)) : lo;
-                        f = probe(V);
-                    }
+                    if (h <= h_max) f = probe(a);
+                    if (h + 1u <= h_max) f = f | probe((a >> 16) | (b << 16));
+                    if (h + 2u <= h_max) f = f | probe(b);
+                    if (h + 3u <= h_max) f = f | probe((b >> 16) | (c3 << 16));
                     if (__ballot(f)) { bits |= 1ull << k; break; }              // one window is enough to flag the read
                 }
             }
