@@ -795,7 +795,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     HIPCHK(c, c->d_ss_pool.ensure(pool_cap));
     HIPCHK(c, c->h_surv.ensure(chunk_cap));
     HIPCHK(c, c->h_dr.ensure(chunk_cap * c->dr_stride));
-    const int grid = 256 * 32;
+    const int grid = 256 * 64;      // waves striding over the reads: 6 resident per CU at 10 kbp; 1 536 / 8 192 / 16 384 / 65 536 blocks: 11.5 / 8.6 / 8.2 / 9.1 ms
     const uint32_t stride = c->dr_stride;
     L.reserve(L.size() + n_total / 2 + 16, stride);
     for (uint64_t off = 0; off < n_total; off += chunk_cap) {
