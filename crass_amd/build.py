@@ -39,7 +39,11 @@ def build(force=False, verbose=False):
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     from . import vgpr_guard
-    vgpr_guard.check(LIB)          # no kernel may use the last VGPR of its allocation (engine_internal.h, CRASS_VGPR_FLOOR)
+    try:
+        vgpr_guard.check(LIB)      # no kernel may use the last VGPR of its allocation (engine_internal.h, CRASS_VGPR_FLOOR)
+    except Exception:
+        os.replace(LIB, LIB + ".rejected")      # a library that failed the check must not be loadable by accident
+        raise
     return LIB
 
 

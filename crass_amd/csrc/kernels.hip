@@ -1175,6 +1175,24 @@ static __device__ int dr_low_lexi(RH &h, char *dr_out, int dr_stride, int &was_l
     return (int)dlen;
 }
 
+// 16 bases of a packed word as ASCII, four letters per output word: the byte of four codes is placed in both 16-bit
+// halves (v_perm), the upper half shifted by 4 (v_pk_lshrrev_b16), `u | u << 6` puts each half's second code into its
+// upper byte, and the 2-bit codes select from the letters with a second v_perm: 5 instructions per 4 bases instead of ~20
+static __device__ __forceinline__ void word_to_ascii(uint32_t v, uint32_t o[4])
+{
+    const uint32_t letters = ('A') | ('C' << 8) | ('G' << 16) | ('T' << 24);
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t t = __builtin_amdgcn_perm(0u, v, 0x0C000C00u | ((uint32_t)q << 16) | (uint32_t)q);   // [b, 0, b, 0], b = byte q of v
+        us2 u2 = __builtin_bit_cast(us2, t);
+        u2.y = (unsigned short)(u2.y >> 4);
+        const uint32_t u = __builtin_bit_cast(uint32_t, u2);
+        const uint32_t sel = (u | (u << 6)) & 0x03030303u;
+        o[q] = __builtin_amdgcn_perm(0u, letters, sel);
+    }
+}
+
 // words of the read a wave works on NEXT, requested while it searches the current one (wave-per-read kernel, long reads:
 // a 10 kbp read is ten dependent rounds of loads per lane otherwise — 5.0 of the kernel's 12.3 ms at 1 M x 10 kbp)
 #define SV_PREFETCH_WORDS 12                      // per lane: reads up to 12 * 64 * 16 = 12 288 bases are covered completely
@@ -1227,7 +1245,6 @@ static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *
                                         const ReadPrefetch *pf = nullptr)
 {
     const uint32_t *g = R.packed + rd_word_off(R, r);
-    const uint32_t lut = ('A') | ('C' << 8) | ('G' << 16) | ('T' << 24);
     const int nw = (L + 15) >> 4;
     if (lane == 0) words[nw] = 0;                 // lds_code reads one word past the last
     const bool have = pf && pf->r == r;           // wave-uniform
@@ -1240,16 +1257,7 @@ static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *
                 const uint32_t v = pf->w[i];
                 words[wi] = v;
                 uint32_t o[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    uint32_t x = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        uint32_t c = (v >> (2 * (4 * q + k))) & 3u;
-                        x |= ((lut >> (8 * c)) & 0xFFu) << (8 * k);
-                    }
-                    o[q] = x;
-                }
+                word_to_ascii(v, o);
                 uint32_t *dst = reinterpret_cast<uint32_t *>(seq + 16 * wi);
                 dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
             }
@@ -1260,28 +1268,22 @@ static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *
         uint32_t v = g[wi];
         words[wi] = v;
         uint32_t o[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t c = (v >> (2 * (4 * q + k))) & 3u;
-                x |= ((lut >> (8 * c)) & 0xFFu) << (8 * k);
-            }
-            o[q] = x;
-        }
+        word_to_ascii(v, o);
         uint32_t *dst = reinterpret_cast<uint32_t *>(seq + 16 * wi);   // seq region is 16-B aligned and padded
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
     }
 }
 
 template <bool EXC>
-__global__ __launch_bounds__(WAVE, 4) void k_survivor(DevReads R, DevParams P, const uint64_t *surv_idx,
+// (two waves per SIMD asked for, i.e. up to 256 VGPRs: with one wave per block and 14-58 KB of LDS per block the LDS decides
+// the residency — and the next read's prefetched words did not fit the 128 registers of a 4-wave target without spilling)
+__global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, const uint64_t *surv_idx,
                                                    const uint32_t *d_n_surv, uint64_t n_max, SurvOut *out,
                                                    char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                                    uint32_t ss_pool_cap, uint32_t *d_ss_used,
                                                    uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds, int punt_only)
 {
+    CRASS_VGPR_FLOOR(128);                       // (the <false> instantiation came out at exactly 128: engine_internal.h)
     extern __shared__ __attribute__((aligned(16))) uint8_t sv_lds[];
     const int lane = threadIdx.x;
     RH h;
