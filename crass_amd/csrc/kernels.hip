@@ -1236,7 +1236,6 @@ static __device__ __forceinline__ void prefetch_read(const DevReads &R, uint64_t
 // next candidate — as global loads these were some 25 dependent round trips per 10 kbp read
 static __device__ void load_hints_to_lds(const DevReads &R, uint64_t r, int L, uint64_t *l_hint, int lane, const ReadPrefetch &pf)
 {
-    const uint64_t *ph = R.pos_hint + R.pos_hint_off[r];
     const int nh = (L + 63) >> 6;
     int first = lane;
     if (pf.r == r) {
@@ -1246,7 +1245,9 @@ static __device__ void load_hints_to_lds(const DevReads &R, uint64_t r, int L, u
             if (wi < nh) l_hint[wi] = pf.hw[i];
         }
         first = lane + SV_PREFETCH_HINTS * WAVE;
+        if (nh <= SV_PREFETCH_HINTS * WAVE) return;      // (wave-uniform: nothing left, and no look-up of the read's offset)
     }
+    const uint64_t *ph = R.pos_hint + R.pos_hint_off[r];
     for (int wi = first; wi < nh; wi += WAVE) l_hint[wi] = ph[wi];
 }
 
@@ -1315,6 +1316,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
     uint64_t punt_base = (uint64_t)blockIdx.x * WAVE, punt_mask = 0;
     ReadPrefetch pf;
     pf.r = ~0ull;
+    uint64_t next_s = ~0ull, next_r = 0;
     for (uint64_t s = blockIdx.x;; ) {
         if (punt_only) {
             while (punt_mask == 0) {
@@ -1343,7 +1345,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
             L = (int)(R.exc_off[e + 1] - o0);
             for (int i = lane; i < L; i += WAVE) h.seq[i] = R.exc_bytes[o0 + i];
         } else {
-            r = surv_idx[s];
+            r = (next_s == s) ? next_r : surv_idx[s];           // (the prefetch below already looked it up)
             if (!punt_only && rd_is_exc(R, r)) {                // left to the exception pass
                 if (lane == 0) { SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = 5; out[s] = x; }
                 s += gridDim.x;
@@ -1355,6 +1357,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
             pf.r = ~0ull;
             if (!punt_only && s + gridDim.x < n_surv) {         // the next read of this wave: its words travel during the search
                 const uint64_t r2 = surv_idx[s + gridDim.x];
+                next_s = s + gridDim.x; next_r = r2;
                 if (!rd_is_exc(R, r2)) prefetch_read(R, r2, lane, pf);
             }
         }
