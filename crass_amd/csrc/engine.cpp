@@ -265,6 +265,7 @@ struct crass_hip_ctx {
     } dense;
     DevBuf<uint64_t> d_fidx;
     DevBuf<uint64_t> d_pos_hint, d_pos_hint_off; uint64_t n_pos_hint_words = 0;     // long reads: per-position seed hints
+    DevBuf<uint32_t> d_pos_hint_blk; bool pos_hint_blk = false;                       // ragged lengths: read of every 256th hint word
     // device-side DR de-duplication (single-GPU merge fast path)
     DevBuf<unsigned long long> dd_keys; DevBuf<uint32_t> dd_first, dd_slot, dd_rep; DevBuf<uint64_t> dd_hash;
     PinBuf<uint32_t> h_rep; PinBuf<uint64_t> h_hash;
@@ -598,7 +599,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
     c->g_surv.release(); c->g_dr.release(); c->g_ss.release(); c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
-    c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->d_pos_hint.release(); c->d_pos_hint_off.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
+    c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->d_pos_hint.release(); c->d_pos_hint_off.release(); c->d_pos_hint_blk.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -649,6 +650,18 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     HIPCHK(c, hipMemcpy(c->d_pos_hint_off.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
     c->n_pos_hint_words = at;
     c->R.pos_hint = c->d_pos_hint.p; c->R.pos_hint_off = c->d_pos_hint_off.p;
+    c->pos_hint_blk = false;
+    if (lengths && n <= 0xFFFFFFFFull) {                // ragged: the read of every block's first hint word (k_hint_positions)
+        std::vector<uint32_t> blk((at + 255) / 256 + 1, 0);
+        uint64_t r = 0;
+        for (uint64_t b = 0; b * 256 < at; b++) {
+            while (r + 1 < n && off[r + 1] <= b * 256) r++;
+            blk[b] = (uint32_t)r;
+        }
+        HIPCHK(c, c->d_pos_hint_blk.ensure(blk.size()));
+        HIPCHK(c, hipMemcpy(c->d_pos_hint_blk.p, blk.data(), blk.size() * 4, hipMemcpyHostToDevice));
+        c->pos_hint_blk = true;
+    }
     return CRASS_OK;
 }
 
@@ -1108,7 +1121,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         // all non-exception reads survive: mask = ~exc_mask (exc_mask is 32-bit words of the same bit order)
         HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0xFF, n_words * 8, c->stream));
         if (c->R.pos_hint) {
-            hipError_t he = launch_hint_positions(c->R, c->dp, c->d_pos_hint_off.p, c->n_pos_hint_words, c->d_pos_hint.p, c->stream);
+            hipError_t he = launch_hint_positions(c->R, c->dp, c->d_pos_hint_off.p, c->pos_hint_blk ? c->d_pos_hint_blk.p : nullptr, c->n_pos_hint_words, c->d_pos_hint.p, c->stream);
             if (he != hipSuccess) { c->last_hip = (int)he; return CRASS_ERR_HIP; }
         }
     }

@@ -211,8 +211,8 @@ hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t
                                  uint32_t max_len, hipStream_t st);
 // per-position seed hints for long / ragged packed reads (default window and DR/spacer bounds only):
 // hint_off[n_reads + 1] = prefix sums of ceil(L/64) (device), n_words = hint_off[n_reads] (host-known)
-hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, uint64_t n_words, uint64_t *hint_bits,
-                                 hipStream_t st);
+hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
+                                 uint64_t *hint_bits, hipStream_t st);      // blk_read[b] = read of tile 256 b (ragged lengths; else nullptr)
 hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st);
 // ---- "last VGPR of the allocation" guard ----
 // Observed on the MI355X pool (minimal reproduction: profiles/ubench/vgpr_edge2.hip, write-up in DESIGN.md): a wave

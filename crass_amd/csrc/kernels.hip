@@ -266,7 +266,7 @@ hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *h
 // residue j is on.  One lane per 64 positions (4 seed words + 7 halo words), a superset like the short-read
 // filter (padding bases and the right clamp are ignored).  Default window / bounds only.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, uint64_t n_words, uint64_t *hint_bits)
+__global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words, uint64_t *hint_bits)
 {
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n_words) return;
@@ -278,6 +278,12 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
         const uint32_t per_read = (R.uniform_len + 63u) >> 6;
         r = t / per_read;
         tile = (uint32_t)(t - r * per_read);
+    } else if (blk_read) {
+        // ragged lengths: the host noted the read of every block's first tile (blk_read[b] = read of tile 256 b); a long read
+        // has dozens of tiles, so the tile's own read is a few steps further (short reads mixed in: more steps, same result)
+        r = blk_read[blockIdx.x];
+        while (r + 1 < R.n_reads && hint_off[r + 1] <= t) r++;
+        tile = (uint32_t)(t - hint_off[r]);
     } else {
         uint64_t lo = 0, hi = R.n_reads;                                // invariant: hint_off[lo] <= t < hint_off[hi]
         while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (hint_off[mid] <= t) lo = mid; else hi = mid; }
@@ -333,12 +339,12 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     hint_bits[t] = bits;
 }
 
-hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, uint64_t n_words, uint64_t *hint_bits,
-                                 hipStream_t st)
+hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
+                                 uint64_t *hint_bits, hipStream_t st)
 {
     if (P.window != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return hipErrorNotSupported;
     if (n_words == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_hint_positions, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, R, hint_off, n_words, hint_bits);
+    hipLaunchKernelGGL(k_hint_positions, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, R, hint_off, blk_read, n_words, hint_bits);
     return hipGetLastError();
 }
 
