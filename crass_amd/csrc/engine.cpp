@@ -1521,7 +1521,10 @@ static int build_host_merge(crass_hip_ctx *c)
 {
     crass_hip_ctx::DM &d = c->dm;
     if (!d.active || d.host_built) return CRASS_OK;
-    (void)hipSetDevice(c->device);
+    {   // once per thread and device: the helper thread runs this for every step
+        static thread_local int tl_device = -1;
+        if (tl_device != c->device) { (void)hipSetDevice(c->device); tl_device = c->device; }
+    }
     // local merge: the token strings and the candidates' tokens only need pass 1's outputs, which the host has
     // already waited for — that half of the host view is built while the merge kernels are still running
     // (the gathered form too: the global distinct list and every gathered row's rank in it were written to pinned memory

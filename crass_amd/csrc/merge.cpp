@@ -350,6 +350,29 @@ private:
     {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         unsigned n = std::min<unsigned>(hw, 16);
+        // The workers poll between the jobs of a burst, i.e. they burn their cores while a search is running.  Under a CPU
+        // quota (cgroup cpu.max: the GPU boxes give a 256-thread host 16 CPUs per 100 ms) a process that exceeds it is
+        // frozen until the period ends: 15 pollers + the caller + the helper thread did, and every ~137th step took
+        // 3-4 ms (tools/step_spikes.py).  So: at most half the quota, shared between the ranks of this node.
+        {
+            double quota_cpus = 0;
+            if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+                char q[64] = {0}; long long per = 0;
+                if (fscanf(f, "%63s %lld", q, &per) == 2 && per > 0 && q[0] != 'm') quota_cpus = (double)atoll(q) / (double)per;
+                fclose(f);
+            } else {
+                long long q = -1, per = 0;                                              // cgroup v1
+                if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+                if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+                if (q > 0 && per > 0) quota_cpus = (double)q / (double)per;
+            }
+            if (quota_cpus > 0) {
+                int ranks = 1;
+                if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+                const unsigned cap = (unsigned)std::max(2.0, quota_cpus * 0.5 / ranks);
+                n = std::min(n, cap);
+            }
+        }
         if (const char *e = getenv("CRASS_HOST_THREADS")) n = (unsigned)std::max(1, atoi(e));    // 1 = everything on the caller
         if (const char *e = getenv("CRASS_POOL_POLL_US")) poll_us_ = atoll(e);
         // a small (possibly oversubscribed) host must not be starved by polling workers: yield often there
