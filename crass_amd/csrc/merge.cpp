@@ -371,6 +371,7 @@ private:
                 if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
                 const unsigned cap = (unsigned)std::max(2.0, quota_cpus * 0.5 / ranks);
                 n = std::min(n, cap);
+                if (quota_cpus / ranks < 4.0) poll_us_ = 100;          // hardly any room: the workers sleep between bursts
             }
         }
         if (const char *e = getenv("CRASS_HOST_THREADS")) n = (unsigned)std::max(1, atoi(e));    // 1 = everything on the caller
