@@ -355,17 +355,7 @@ private:
         // frozen until the period ends: 15 pollers + the caller + the helper thread did, and every ~137th step took
         // 3-4 ms (tools/step_spikes.py).  So: at most half the quota, shared between the ranks of this node.
         {
-            double quota_cpus = 0;
-            if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
-                char q[64] = {0}; long long per = 0;
-                if (fscanf(f, "%63s %lld", q, &per) == 2 && per > 0 && q[0] != 'm') quota_cpus = (double)atoll(q) / (double)per;
-                fclose(f);
-            } else {
-                long long q = -1, per = 0;                                              // cgroup v1
-                if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
-                if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
-                if (q > 0 && per > 0) quota_cpus = (double)q / (double)per;
-            }
+            const double quota_cpus = host_cpu_quota();
             if (quota_cpus > 0) {
                 int ranks = 1;
                 if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
@@ -704,6 +694,26 @@ private:
 };
 
 } // namespace
+
+// CPUs the cgroup's quota gives this process per period (cgroup v2 cpu.max, else v1 cfs_quota/cfs_period); 0 = no quota
+double host_cpu_quota()
+{
+    static const double q = [] {
+        double quota_cpus = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                           // "<quota|max> <period>"
+            char qs[64] = {0}; long long per = 0;
+            if (fscanf(f, "%63s %lld", qs, &per) == 2 && per > 0 && qs[0] != 'm') quota_cpus = (double)atoll(qs) / (double)per;
+            fclose(f);
+        } else {
+            long long qq = -1, per = 0;
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &qq) != 1) qq = -1; fclose(g); }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+            if (qq > 0 && per > 0) quota_cpus = (double)qq / (double)per;
+        }
+        return quota_cpus;
+    }();
+    return q;
+}
 
 void host_pool_warm() { HostPool::get().warm(); }
 void host_parallel_for(size_t n_tasks, unsigned max_threads, const std::function<void(size_t)> &fn) { HostPool::get().run(n_tasks, max_threads, fn); }

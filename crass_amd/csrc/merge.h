@@ -71,6 +71,8 @@ struct MergeResult {
 // Wake the host worker pool ahead of a merge (its workers then poll for a few milliseconds): call it while
 // waiting for the device so that the wake-up latency is hidden.
 void host_pool_warm();
+// CPUs the cgroup quota allows this process (0: none); thread counts of the host pool and of the ingest follow it
+double host_cpu_quota();
 // fn(task) for task in [0, n_tasks) on the same pool (caller included), at most max_threads threads
 void host_parallel_for(size_t n_tasks, unsigned max_threads, const std::function<void(size_t)> &fn);
 
