@@ -283,6 +283,32 @@ def test_full_size_properties(ca):
     assert np.array_equal(c1.read_idx[:k], small.rec_read[:small.n_pass1])
 
 
+def test_long_reads_ragged_mid_size(ca):
+    """6 000 reads of 2.1-12 kbp (42 M bases): the hint kernel finds a tile's read from a per-block index when the lengths
+    differ, the wave kernel prefetches reads of differing length, the sink fills its arrays in parallel"""
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    drs = [acgt[rng.integers(0, 4, size=int(rng.integers(28, 38)))] for _ in range(12)]
+    seqs = []
+    for i in range(6000):
+        L = int(rng.integers(2100, 12001))
+        s = acgt[rng.integers(0, 4, size=L)]
+        if i % 20 == 0:
+            dr = drs[int(rng.integers(0, len(drs)))]
+            pos = int(rng.integers(0, max(1, L - 2000)))
+            for _ in range(int(rng.integers(3, 40))):
+                unit = np.concatenate([dr, acgt[rng.integers(0, 4, size=int(rng.integers(30, 39)))]])
+                if pos + len(unit) > L:
+                    break
+                s[pos:pos + len(unit)] = unit
+                pos += len(unit)
+        seqs.append(s.tobytes())
+    gpu = ca.search_pipeline(seqs)
+    ref = orc.pipeline(seqs)
+    assert_same_pipeline(gpu, ref)
+    assert gpu.n_pass1 >= 200
+
+
 def test_long_reads_position_hints(ca):
     """reads beyond the per-read filter get one seed-hint bit per base (k_hint_positions); the hinted seed loop
     must visit exactly the seeds that matter, on and off the stride lattice (rejected candidates move j off it):
