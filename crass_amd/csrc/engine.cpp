@@ -54,6 +54,22 @@ public:
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [this] { return !busy_; });
     }
+    // The caller is about to wait for the job: if the helper has not even picked it up yet (its wake-up is normally
+    // ~50 us, but on a busy or CPU-limited host it was seen to take 4-14 ms — every slow step of tools/step_spikes.py was
+    // this wait), the caller runs the job itself instead.  Returns false when the helper has it (then: wait()).
+    bool run_here_if_not_started()
+    {
+        std::function<void()> job;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (!(busy_ && job_)) return false;
+            job = std::move(job_); job_ = nullptr;          // the helper's wait predicate (busy_ && job_) stays false: it sleeps on
+        }
+        job();
+        { std::lock_guard<std::mutex> lk(m_); busy_ = false; }
+        cv_.notify_all();
+        return true;
+    }
     void stop()
     {
         if (!started_) return;
@@ -463,7 +479,7 @@ void crass_hip_ctx::widen_p1() const
 // the helper thread owns c->merge while a host-view build is in flight: wait for it before touching that state
 static void quiesce_worker(crass_hip_ctx *c)
 {
-    if (c->dm.build_pending) { c->worker.wait(); c->dm.build_pending = false; }
+    if (c->dm.build_pending) { if (!c->worker.run_here_if_not_started()) c->worker.wait(); c->dm.build_pending = false; }
 }
 
 #define HIPCHK(ctx, call)                                                       \
@@ -1509,7 +1525,7 @@ static int ensure_host_merge(crass_hip_ctx *c)
 {
     crass_hip_ctx::DM &d = c->dm;
     if (d.build_pending) {                              // started by the merge call on the helper thread
-        c->worker.wait();
+        if (!c->worker.run_here_if_not_started()) c->worker.wait();
         d.build_pending = false;
         if (d.build_status == CRASS_ERR_HIP || d.build_status == CRASS_ERR_OOM) return d.build_status;
         if (d.build_status == CRASS_ERR_STATE) return CRASS_ERR_STATE;
