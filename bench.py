@@ -9,10 +9,10 @@ findSingletons).  Packed reads are already resident in HBM when the timed region
 the timed region ends with the ordered candidate / recruit records, tokens, groups and
 pattern list in host memory.
 
-Workloads (BASELINE.json `configs`, selected with --config, default by --gpus):
-  --config 1  configs[1]: 10 M x 150 bp, 50 seeded DRs, one GPU               (default at N=1)
-  --config 2  configs[2]: 100 M x 150 bp sharded over the ranks, STRONG scaling (default at N>1;
-              `--gpus 1 --config 2` is the one-GPU base of that curve)
+Workloads (BASELINE.json `configs`, selected with --config):
+  --config 2  configs[2]: 100 M x 150 bp sharded over the ranks, STRONG scaling — the configuration the metric and
+              its targets are quoted on, and the DEFAULT AT EVERY --gpus N (N = 1 is the base of the scaling curve)
+  --config 1  configs[1]: 10 M x 150 bp, 50 seeded DRs, one GPU
   --config 3  configs[3]: 1 M x 10 kbp long reads, arrays of 20-60 repeats in 5 % of them
   --config 4  configs[4]: 200 M x 150 bp, 500 seeded DRs, 4 GC classes
   --total-reads T  strong scaling over T reads (rank r holds reads [r*T/N, (r+1)*T/N))
@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
-                    help="BASELINE.json configs[i]; 0 = configs[1] at N=1, configs[2] at N>1")
+                    help="BASELINE.json configs[i]; 0 = configs[2] (100 M reads, strong scaling) at every N")
     ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: reads of the whole job, sharded over the ranks")
     ap.add_argument("--reads", type=int, default=0, help="weak scaling: reads per GPU")
     ap.add_argument("--read-len", type=int, default=0)
@@ -69,6 +69,7 @@ def parse():
                     help="N>1 strong scaling: skip the untimed one-GPU run of the whole job on rank 0 (speedup_vs_1gpu)")
     ap.add_argument("--alternate", action="store_true", help="alternate between two resident batches (speculation bounds "
                     "are then learnt from a different batch than the one being processed)")
+    ap.add_argument("--single-shots", type=int, default=3, help="N=1: fresh contexts timed for single_shot_ms (0 = skip)")
     ap.add_argument("--check", action="store_true", help="also verify the GPU result against the oracle on the CPU sample")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
@@ -147,7 +148,7 @@ def main():
     coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
     # ---- workload ----
-    cfg_id = args.config or (1 if world == 1 else 2)
+    cfg_id = args.config or 2
     cfg = dict(CONFIGS[cfg_id])
     L = args.read_len or cfg["read_len"]
     n_dr = args.n_dr or cfg["n_dr"]
@@ -158,6 +159,8 @@ def main():
         total = args.total_reads or cfg["total"]
         first, end = total * rank // world, total * (rank + 1) // world
         n = end - first
+        # one job split over the ranks: configs[2] (and any --total-reads) is a strong-scaling workload at every N
+        # incl. 1; the other configs are single-GPU workloads (per-GPU work fixed: "weak")
         scaling = "strong" if world > 1 or args.total_reads or cfg_id == 2 else "weak"
     custom = bool(args.reads or args.total_reads or args.read_len or args.n_dr or args.gc_classes >= 0)
     W = (L + 15) // 16
@@ -296,12 +299,12 @@ def main():
     # they were taken on THIS kernel source (hash recorded by profiles/summarize_pmc.py) and this workload
     traffic, traffic_src, valu_issue = None, None, None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pm = _pmc_file(n, L)
         key = {"seed_scan_filter": "k_filter_fast", "survivor": "k_survivor", "recruit_scan": "k_anchor_filter"}[dom]
         if pm.get("source_hash") == source_hash() and pm.get("reads") == n and pm.get("read_len") == L:
             for k, v in pm["per_launch"].items():
                 if k.startswith(key):
-                    traffic, traffic_src = v["hbm_bytes"], "profiles/r02_pmc_traffic.json (committed PMC passes, same kernel source hash)"
+                    traffic, traffic_src = v["hbm_bytes"], "profiles/%s (committed PMC passes, same kernel source hash)" % pm["_file"]
                     if "sq" in v and v["sq"].get("SQ_INSTS_VALU"):
                         # what actually bounds this kernel: a wave64 VALU instruction occupies its SIMD for 4 cycles, the chip
                         # has 256 CUs x 4 SIMDs and holds at most 2.4 GHz (MI355X_MICROARCH.md)
@@ -310,7 +313,7 @@ def main():
                         valu_issue = {"insts_valu_per_launch": int(insts), "cycles_per_wave64_inst": 4, "simds": 1024, "clock_ghz": 2.4,
                                       "bound_ms": round(bound_ms, 4), "frac": round(bound_ms / dom_ms, 4) if dom_ms > 0 else None,
                                       "note": "the kernel is VALU-issue bound, not HBM bound: frac = VALU issue time at peak clock / measured launch time"}
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         pass
     path_bytes = 2 * bytes_per_read_per_pass             # both passes read every base once at 2 bits
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -352,6 +355,30 @@ def main():
     }
     if rccl_ranks is not None:
         out["rccl_ranks"] = rccl_ranks
+
+    # ---- the single-shot truth: a crass run scans each read set ONCE.  A FRESH context (no learnt bounds; its pools are
+    #      sized from the read count when the reads are loaded), reads resident, ONE step, wall clock.  Outside the timed
+    #      region. ----
+    if world == 1 and args.single_shots > 0 and not args.alternate:
+        shots = []
+        for _ in range(args.single_shots):
+            e1 = ca.SearchEngine(device=local_rank)
+            e1.set_stage_timing(0)
+            e1.load_packed_uniform(words, n, L, read_index_base=first)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(e1)
+            torch.cuda.synchronize()
+            shots.append((time.perf_counter() - t1) * 1e3)
+            c1 = e1.counters()
+            assert (c1["n_pass1_found"], c1["n_pass2_found"]) == (c["n_pass1_found"], c["n_pass2_found"]), "single shot differs"
+            e1.close()
+        out["single_shot_ms"] = round(float(np.median(shots)), 3)
+        out["single_shot_value"] = round(total / (out["single_shot_ms"] * 1e-3), 1)
+        out["single_shot"] = {"ms_all": [round(x, 3) for x in shots], "contexts": len(shots),
+                              "vs_steady_state": round(out["single_shot_ms"] / ms_per_step, 3),
+                              "note": "one step on a fresh context (crass_hip_create + crass_hip_load_reads outside, as for "
+                                      "`value`: reads resident in HBM); no learnt speculation bounds, nothing warmed"}
 
     # ---- strong scaling: the same job on ONE GPU (rank 0, untimed part of the run; the other ranks wait) ----
     if world > 1 and scaling == "strong" and not args.no_strong_base and args.dist_backend == "nccl":
@@ -447,6 +474,20 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _pmc_file(n, L):
+    """the committed PMC summary (profiles/r*_pmc_traffic*.json) taken on this workload, newest round first"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        try:
+            pm = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if pm.get("reads") == n and pm.get("read_len") == L:
+            pm["_file"] = os.path.basename(f)
+            return pm
+    return None
 
 
 def _cpu_model():

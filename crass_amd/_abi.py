@@ -170,6 +170,7 @@ SYMBOLS = {
     "crass_unpack_ascii": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
 }
 
+ABI_VERSION = 2        # CRASS_HIP_ABI_VERSION of include/crass_hip.h these struct layouts mirror
 _lib = None
 
 
@@ -187,5 +188,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
+    if lib.crass_hip_abi_version() != ABI_VERSION:
+        raise RuntimeError("crass_amd: %s has ABI version %d, these bindings were written for %d (struct layouts differ): rebuild"
+                           % (LIB_PATH, lib.crass_hip_abi_version(), ABI_VERSION))
     _lib = lib
     return lib

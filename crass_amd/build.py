@@ -21,29 +21,62 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the MI355X engine cannot be built")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+OBJ = os.path.join(CSRC, "_obj")
+HEADERS = ["engine_internal.h", "consensus_internal.h", "merge.h", os.path.join("..", "..", "include", "crass_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+LIBS = ["-lz", "-lpthread", "-ldl"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build():
+    return _stale(LIB, [os.path.join(CSRC, d) for d in DEPS])
 
 
 def build(force=False, verbose=False):
+    """One object per source (compiled in parallel, only the stale ones), then one link; the objects live in
+    csrc/_obj (git-ignored).  Every kernel is compiled for gfx950 only."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", LIB]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-lz", "-lpthread", "-ldl"]
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = []
+    for s, p in jobs:
+        out, _ = p.communicate()
+        if out.strip():
+            print(out, file=sys.stderr, end="")
+        if p.returncode:
+            failed.append(s)
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    tmp = LIB + ".tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + LIBS
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     from . import vgpr_guard
     try:
-        vgpr_guard.check(LIB)      # no kernel may use the last VGPR of its allocation (engine_internal.h, CRASS_VGPR_FLOOR)
+        vgpr_guard.check(tmp)      # no kernel may use the last VGPR of its allocation (engine_internal.h, CRASS_VGPR_FLOOR)
     except Exception:
-        os.replace(LIB, LIB + ".rejected")      # a library that failed the check must not be loadable by accident
+        os.replace(tmp, LIB + ".rejected")      # a library that failed the check must not be loadable by accident
         raise
+    os.replace(tmp, LIB)
     return LIB
 
 

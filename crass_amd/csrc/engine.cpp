@@ -163,6 +163,7 @@ template <typename T> struct PinBuf {
 struct EnvSwitches {
     bool no_lookback = false, no_pos_hints = false, merge_profile = false, no_lane_kernel = false;
     bool host_merge = false, no_speculation = false, exc_separate = false, dm_inject_fail = false, dm_init_late = false;
+    bool no_presize = false;                         // A/B switch: no first-call bounds / pool sizing at crass_hip_load_reads
     uint32_t row_cap = 1024, dm_group_cap = 16384, surv_debug = 0;
     int stage_timing = -1;
     uint64_t pool_cap_bytes = 0;                     // tests: device allocations beyond this total fail with hipErrorOutOfMemory
@@ -172,7 +173,7 @@ struct EnvSwitches {
         no_lookback = on("CRASS_NO_LOOKBACK"); no_pos_hints = on("CRASS_NO_POS_HINTS");
         merge_profile = on("CRASS_MERGE_PROFILE"); no_lane_kernel = on("CRASS_NO_LANE_KERNEL"); host_merge = on("CRASS_HOST_MERGE");
         no_speculation = on("CRASS_NO_SPECULATION"); exc_separate = on("CRASS_EXC_SEPARATE"); dm_init_late = on("CRASS_DM_INIT_LATE");
-        dm_inject_fail = on("CRASS_DM_INJECT_FAIL");
+        dm_inject_fail = on("CRASS_DM_INJECT_FAIL"); no_presize = on("CRASS_NO_PRESIZE");
         row_cap = 1024; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
         dm_group_cap = 16384; if (const char *e = getenv("CRASS_DM_GROUP_CAP")) dm_group_cap = (uint32_t)std::max(1, atoi(e));
         surv_debug = 0; if (const char *e = getenv("CRASS_SURV_DEBUG")) surv_debug = (uint32_t)atoi(e);
@@ -681,6 +682,8 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     return CRASS_OK;
 }
 
+static int first_call_bounds(crass_hip_ctx *c);
+
 static void reset_results(crass_hip_ctx *c)
 {
     quiesce_worker(c);
@@ -759,6 +762,8 @@ int crass_hip_load_reads(crass_hip_ctx *c, const crass_reads *h)
     if (s) return s;
     s = setup_pos_hints(c, h->uniform_len ? nullptr : h->lengths, h->uniform_len, n);
     if (s) return s;
+    s = first_call_bounds(c);
+    if (s) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnt.n_reads = n; c->cnt.n_exceptions = h->n_exceptions; c->cnt.bytes_reads_device = total_words * 4;
     return CRASS_OK;
@@ -790,6 +795,8 @@ int crass_hip_attach_device_reads(crass_hip_ctx *c, const crass_reads *d)
     int s = alloc_scratch(c);
     if (s) return s;
     s = setup_pos_hints(c, nullptr, d->uniform_len, d->n_reads);
+    if (s) return s;
+    s = first_call_bounds(c);
     if (s) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnt.n_reads = d->n_reads; c->cnt.n_exceptions = 0;
@@ -932,6 +939,33 @@ static uint64_t survivor_bound(uint64_t n_surv)        // the speculative bound 
 static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok);
 static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok, bool prepared = false);
 
+// every buffer the dense pass-1 sink touches for up to n_alloc survivors (crass_hip_load_reads sizes them for the first
+// call's bound, so that the first seed scan of a context does not allocate; ensure() is a no-op when a buffer is large enough)
+static int ensure_dense_buffers(crass_hip_ctx *c, uint64_t n_alloc, uint64_t pool_cap, const SurvLds &lds, bool dedupe)
+{
+    crass_hip_ctx::P1Dense &D = c->dense;
+    const uint32_t stride = c->dr_stride;
+    HIPCHK(c, c->d_surv.ensure(n_alloc));
+    HIPCHK(c, c->d_dr.ensure(n_alloc * stride));
+    HIPCHK(c, c->d_ss_pool.ensure(std::max<uint64_t>(pool_cap, n_alloc * (uint64_t)lds.ss_cap)));
+    HIPCHK(c, c->d_fidx.ensure(n_alloc));
+    HIPCHK(c, D.d_dr_len.ensure(n_alloc + 8)); HIPCHK(c, D.d_dr.ensure(n_alloc * stride + 16));
+    const uint32_t ss_elem = c->max_len <= 256 ? 1u : 2u;            // read positions fit a byte
+    HIPCHK(c, D.h_blob.ensure(p1_blob_layout(n_alloc, lds.ss_cap, ss_elem).total + 64));
+    HIPCHK(c, D.d_blob.ensure(D.h_blob.n));
+    if (dedupe) {
+        uint32_t tsize_alloc = 1024;
+        while (tsize_alloc < n_alloc * 2) tsize_alloc <<= 1;
+        HIPCHK(c, c->dd_keys.ensure(tsize_alloc)); HIPCHK(c, c->dd_first.ensure(tsize_alloc));
+        HIPCHK(c, c->dd_slot.ensure(n_alloc)); HIPCHK(c, c->dd_hash.ensure(n_alloc));
+        HIPCHK(c, c->dd_rep.ensure(n_alloc)); HIPCHK(c, c->h_rep.ensure(n_alloc)); HIPCHK(c, c->h_hash.ensure(n_alloc));
+        HIPCHK(c, c->h_dmap.ensure(n_alloc)); HIPCHK(c, c->h_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(n_alloc));
+        HIPCHK(c, c->h_dx_hash.ensure(n_alloc));
+        HIPCHK(c, c->dd_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_alloc));
+    }
+    return CRASS_OK;
+}
+
 static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t *d_nsurv, bool *overflow)
 {
     *overflow = false;
@@ -945,14 +979,9 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     // crass_hip_seed_scan), so that the second call of a context does not re-allocate everything
     const bool speculative = (d_nsurv == c->d_count.p);          // n_surv is already such a bound
     const uint64_t n_alloc = speculative ? n_surv : std::max<uint64_t>(n_surv, survivor_bound(n_surv));
-    HIPCHK(c, c->d_surv.ensure(n_alloc));
-    HIPCHK(c, c->d_dr.ensure(n_alloc * stride));
-    HIPCHK(c, c->d_ss_pool.ensure(std::max<uint64_t>(pool_cap, n_alloc * (uint64_t)lds.ss_cap)));
-    HIPCHK(c, c->d_fidx.ensure(n_alloc));
-    HIPCHK(c, D.d_dr_len.ensure(n_alloc + 8)); HIPCHK(c, D.d_dr.ensure(n_alloc * stride + 16));
     const uint32_t ss_elem = c->max_len <= 256 ? 1u : 2u;            // read positions fit a byte
-    HIPCHK(c, D.h_blob.ensure(p1_blob_layout(n_alloc, lds.ss_cap, ss_elem).total + 64));
-    HIPCHK(c, D.d_blob.ensure(D.h_blob.n));
+    const bool dedupe = n_surv < (1u << 24);
+    { const int as = ensure_dense_buffers(c, n_alloc, pool_cap, lds, dedupe); if (as) return as; }
     // [2] = found count, [3] = worst error, [4] = n distinct, [5] = de-duplication mismatch flag
     if (!speculative) {                                 // (speculative launch: cleared by the filter's compaction, see seed scan)
         HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 16, c->stream));
@@ -961,7 +990,6 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     // The merge that will follow this stage is sized here already when the previous call's merge ran on the device (its
     // kernels read the token count from the device and are sized by a bound): the survivor kernel then clears the
     // merge's tables on its way, and the merge is queued right behind pass 1's tail further down.
-    const bool dedupe = n_surv < (1u << 24);
     c->dm_prepared_n = 0; c->dm_prepared_src = nullptr;
     const DevMerge *init_merge = nullptr;
     if (speculative && dedupe && c->prm.lowDRsize >= 23 && stride <= 64 && !c->env.host_merge && !c->env.no_speculation && !c->env.dm_init_late) {
@@ -1000,12 +1028,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     HIPCHK(c, c->stamp(9, 1));
     const uint64_t n_words = (n_surv + 63) / 64;
     uint32_t tsize = 1024;
-    if (dedupe) {
-        while (tsize < n_surv * 2) tsize <<= 1;
-        uint32_t tsize_alloc = tsize;
-        while (tsize_alloc < n_alloc * 2) tsize_alloc <<= 1;
-        HIPCHK(c, c->dd_keys.ensure(tsize_alloc)); HIPCHK(c, c->dd_first.ensure(tsize_alloc));
-    }
+    if (dedupe) while (tsize < n_surv * 2) tsize <<= 1;
     Lookback lbf;
     if (const Lookback *lb = c->next_lookback_elems(n_surv, &lbf)) {
         // found flags -> ranks in one pass (also clears the de-duplication table)
@@ -1016,7 +1039,6 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
                                     dedupe ? c->dd_keys.p : nullptr, dedupe ? c->dd_first.p : nullptr, tsize));
         HIPCHK(c, launch_compact(c->d_mask.p, n_words, n_surv, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, n_surv, c->d_count.p + 2, c->stream));
     }
-    if (dedupe) { HIPCHK(c, c->dd_slot.ensure(n_alloc)); HIPCHK(c, c->dd_hash.ensure(n_alloc)); }
     // the gather assembles the hand-off blob and inserts every candidate's DR string into the de-duplication table
     HIPCHK(c, launch_gather_found(c->d_fidx.p, c->d_count.p + 2, n_surv, c->d_surv.p, c->d_idx.p, c->read_base, c->d_dr.p, stride,
                                   c->d_ss_pool.p, lds.ss_cap, ss_elem, D.d_blob.p, D.d_dr_len.p, D.d_dr.p, c->stream,
@@ -1026,11 +1048,6 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     c->have_rep = false;
     c->have_dev_tokens = false;
     if (dedupe) {
-        HIPCHK(c, c->dd_slot.ensure(n_alloc));
-        HIPCHK(c, c->dd_rep.ensure(n_alloc)); HIPCHK(c, c->dd_hash.ensure(n_alloc)); HIPCHK(c, c->h_rep.ensure(n_alloc)); HIPCHK(c, c->h_hash.ensure(n_alloc));
-        HIPCHK(c, c->h_dmap.ensure(n_alloc)); HIPCHK(c, c->h_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(n_alloc));
-        HIPCHK(c, c->h_dx_hash.ensure(n_alloc));
-        HIPCHK(c, c->dd_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_alloc));
         // distinct strings in first-occurrence order and every candidate's rank among them, exact
         Lookback lbd;
         HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->dd_slot.p, c->dd_first.p, c->d_mask.p,
@@ -1101,6 +1118,86 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     } else D.lay.total = 0;
     D.n = nf;
     D.active = true;
+    return CRASS_OK;
+}
+
+// every buffer pass 2's tail touches for up to h_alloc flagged reads (+ n_exc exception reads scanned byte-wise)
+static int ensure_recruit_buffers(crass_hip_ctx *c, uint64_t h_alloc, uint64_t n_exc, bool dev_sink, bool anchors)
+{
+    const uint64_t s_alloc = h_alloc + n_exc;
+    HIPCHK(c, c->d_rec.ensure(s_alloc + 1));
+    HIPCHK(c, c->d_dr.ensure((s_alloc + 1) * c->dr_stride));
+    if (!dev_sink) {                           // host sink only
+        HIPCHK(c, c->h_rec.ensure(s_alloc + 1));
+        HIPCHK(c, c->h_dr.ensure((s_alloc + 1) * c->dr_stride));
+        HIPCHK(c, c->h_idx.ensure(h_alloc + 1));
+    }
+    if (anchors) {
+        HIPCHK(c, c->d_slot_info.ensure(h_alloc + 1));
+        HIPCHK(c, c->d_slot_pid.ensure(h_alloc + 1));
+    }
+    if (dev_sink) {
+        HIPCHK(c, c->h_qblob.ensure(p2_blob_layout(h_alloc).total + 64));
+        HIPCHK(c, c->d_fidx.ensure(h_alloc + 1));
+    }
+    return CRASS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The first call of a context.  The three speculation bounds (survivors, distinct DR strings, flagged reads) are
+// normally learnt from the previous call; a crass run scans each read set ONCE, so crass_hip_load_reads sets them from
+// the read set itself — the expected pass rate of the seed filter on random sequence plus an allowance for real
+// arrays — and sizes every pool for them.  The first seed scan / merge / recruit then neither allocates nor waits
+// for a count before queueing the next stage; a bound that turns out too small repeats the stage with the exact
+// count, exactly like a learnt one.  CRASS_NO_PRESIZE / CRASS_NO_SPECULATION switch this off.
+// ------------------------------------------------------------------------------------------
+static int first_call_bounds(crass_hip_ctx *c)
+{
+    c->surv_cap_hint = 0; c->hit_cap_hint = 0; c->dx_cap_hint = 0; c->dm_prev_local = false; c->premerge = 0;
+    c->recruit_exact = false;
+    const uint64_t n = c->R.n_reads;
+    if (c->env.no_presize || c->env.no_speculation || n == 0 || c->max_len > 2048) return CRASS_OK;
+    if (c->R.n_exc && c->env.exc_separate) return CRASS_OK;
+    const DevParams &P = c->dp;
+    const SurvLds lds = survivor_lds_layout(c->max_len, P);
+    if (lds.total_bytes > 160 * 1024 || lds.ss_cap > 64 || (c->dr_stride & 15)) return CRASS_OK;
+    // seed filter on random sequence: every lattice seed has ~(highDR+highSp-lowDR-lowSp+1) candidate positions, each
+    // an equal w-mer with probability 4^-w (libcrispr.cpp:295-339); + 2 % of the reads for real arrays; x 1.5
+    const uint32_t min_len = P.lowDR + P.lowSp + P.window + 1;
+    const double seeds = c->max_len > min_len ? (double)(c->max_len - min_len) / P.skips + 1.0 : 1.0;
+    const double cand = (double)(P.highDR + P.highSp - P.lowDR - P.lowSp + 1);
+    double rate = seeds * cand / (double)(1ull << (2 * P.window)) + 0.02;
+    if (rate > 1.0) rate = 1.0;
+    uint64_t surv = survivor_bound((uint64_t)((double)n * rate));
+    if (surv > n + 65536) surv = survivor_bound(n * 2 / 3);       // (1.5 x inside: the bound never needs to exceed n)
+    const uint64_t pool_cap = std::max<uint64_t>(surv * (uint64_t)lds.ss_cap, 1u << 16);
+    if (surv > kDenseMaxSurvivors || pool_cap >= (1ull << 31)) return CRASS_OK;
+    // keep the pools a small part of the device: ~(20 + 2*stride + 4*ss_cap + 100) bytes per survivor slot
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return CRASS_OK;
+    const uint64_t per = 140ull + 3ull * c->dr_stride + 6ull * lds.ss_cap;
+    if (surv * per > free_b / 4) return CRASS_OK;
+    const bool dedupe = surv < (1u << 24);
+    int s = ensure_dense_buffers(c, surv, pool_cap, lds, dedupe);
+    if (s) return s;
+    c->surv_cap_hint = surv;
+    // look-back status words for the largest launch of a step (the masks over all reads), cleared once
+    { Lookback lb; (void)c->next_lookback((n + 63) / 64, &lb); (void)c->next_lookback_elems(surv, &lb); }
+    // distinct DR strings: a few hundred per million reads on metagenome-like input; the device merge is queued
+    // behind pass 1 for this many
+    if (dedupe && c->prm.lowDRsize >= 23 && c->dr_stride <= 64 && !c->env.host_merge) {
+        const uint64_t dx = std::min<uint64_t>(1u << 20, std::max<uint64_t>(16384, (n / 1024 + 4095) & ~4095ull));
+        s = device_merge_prepare(c, c->dd_dx_chars.p, c->dd_dx_len.p, dx, c->d_count.p + 4);
+        if (s) return s;
+        c->dx_cap_hint = (uint32_t)dx;
+        c->dm_prev_local = true;
+    }
+    // reads flagged by the anchor probe: reads of arrays that pass 1 did not find (+ ~0 false positives)
+    const uint64_t hits = hit_bound(n / 64);
+    s = ensure_recruit_buffers(c, hits, 0, true, true);
+    if (s) return s;
+    c->hit_cap_hint = hits;
+    host_pool_warm();
     return CRASS_OK;
 }
 
@@ -2002,17 +2099,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const uint64_t n_slots = n_hits + n_exc;
     // (sized for the bound the next call will speculate with, so that it does not re-allocate)
     const uint64_t h_alloc = spec ? n_hits : std::max<uint64_t>(n_hits, hit_bound(n_hits));
-    const uint64_t s_alloc = h_alloc + n_exc;
-    HIPCHK(c, c->d_rec.ensure(s_alloc + 1));
-    HIPCHK(c, c->d_dr.ensure((s_alloc + 1) * c->dr_stride));
-    if (!(dmp && n_exc == 0)) {                // host sink only
-        HIPCHK(c, c->h_rec.ensure(s_alloc + 1));
-        HIPCHK(c, c->h_dr.ensure((s_alloc + 1) * c->dr_stride));
-        HIPCHK(c, c->h_idx.ensure(h_alloc + 1));
-    }
+    { const int as = ensure_recruit_buffers(c, h_alloc, n_exc, dmp && n_exc == 0, anchors); if (as) return as; }
     if (anchors) {
-        HIPCHK(c, c->d_slot_info.ensure(h_alloc + 1));
-        HIPCHK(c, c->d_slot_pid.ensure(h_alloc + 1));
         if (dmp) HIPCHK(c, launch_dm_verify(c->R, c->dm.M, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->d_slot_pid.p, c->stream));
         else HIPCHK(c, launch_recruit_list(c->R, c->A, c->d_idx.p, c->d_count.p, n_hits, c->d_slot_info.p, c->d_slot_pid.p, c->stream));
     }
@@ -2031,8 +2119,6 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     if (dev_sink) {
         c->q_lay = p2_blob_layout(n_hits);
         c->q_wide_ready = false;
-        HIPCHK(c, c->h_qblob.ensure(p2_blob_layout(h_alloc).total + 64));
-        HIPCHK(c, c->d_fidx.ensure(h_alloc + 1));
         Lookback lbq;
         if (n_hits) {
             HIPCHK(c, launch_pack_p2_blob(c->d_rec.p, c->d_idx.p, c->read_base, c->d_count.p, n_hits, c->d_mask.p,

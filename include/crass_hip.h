@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRASS_HIP_ABI_VERSION 1
+#define CRASS_HIP_ABI_VERSION 2   /* 2: crass_counters, crass_fastx and crass_synth_spec grew (round 2); group API (round 3) */
 
 /* ---- status codes (reference: crispr::exception -> exit code) ---- */
 enum {
