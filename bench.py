@@ -20,9 +20,11 @@ Workloads (BASELINE.json `configs`, selected with --config):
 
 Launching:
     python bench.py                                  # N=1
-    python bench.py --gpus N                         # spawns N rank processes itself (one per GPU)
+    python bench.py --gpus N                         # --launcher group (default): ONE process, N contexts, the engine itself
+                                                     # issues the RCCL all-gather (crass_hip_group_*, ncclCommInitAll)
+    python bench.py --gpus N --launcher torch        # spawns N rank processes (one per GPU), RCCL through torch.distributed
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N            # the same, as a rank of an external launcher
+        --master-port P bench.py --gpus N            # as the ranks of an external launcher: always the torch form
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -71,6 +73,11 @@ def parse():
                     "are then learnt from a different batch than the one being processed)")
     ap.add_argument("--single-shots", type=int, default=3, help="N=1: fresh contexts timed for single_shot_ms (0 = skip)")
     ap.add_argument("--check", action="store_true", help="also verify the GPU result against the oracle on the CPU sample")
+    ap.add_argument("--launcher", default="group", choices=["group", "torch"],
+                    help="N>1 from a plain interpreter: group = one process drives N contexts through crass_hip_group_* (C++ RCCL); "
+                         "torch = one process per GPU over torch.distributed.  Under an external launcher (WORLD_SIZE set) always torch")
+    ap.add_argument("--local-copies", action="store_true", help="testing only (group launcher): every context on cuda:0, device copies "
+                    "instead of the collective")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     return ap.parse_args()
@@ -117,7 +124,8 @@ def source_hash():
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    group_mode = args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.launcher == "group"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not group_mode:
         spawn_ranks(args)
     import numpy as np
     import torch
@@ -127,7 +135,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    n_gpus = args.gpus
+    if world != args.gpus and not group_mode:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
@@ -158,7 +167,7 @@ def main():
     else:                                                   # strong scaling: the job's reads are split over the ranks
         total = args.total_reads or cfg["total"]
         first, end = total * rank // world, total * (rank + 1) // world
-        n = end - first
+        n = end - first                                     # (group launcher: world == 1, this process holds the whole job)
         # one job split over the ranks: configs[2] (and any --total-reads) is a strong-scaling workload at every N
         # incl. 1; the other configs are single-GPU workloads (per-GPU work fixed: "weak")
         scaling = "strong" if world > 1 or args.total_reads or cfg_id == 2 else "weak"
@@ -170,8 +179,17 @@ def main():
     words = ca.synth_packed(spec, first, n)
     t_gen = time.time() - t0
 
-    eng = ca.SearchEngine(device=local_rank)
-    eng.load_packed_uniform(words, n, L, read_index_base=first)     # H2D once; resident for every step
+    if group_mode:
+        if args.reads:
+            print("bench.py: --launcher group shards ONE job (strong scaling); use --total-reads", file=sys.stderr)
+            sys.exit(2)
+        devs = [0] * n_gpus if args.local_copies else list(range(n_gpus))
+        eng = _GroupRunner(ca.SearchGroup(devs, local_copies=args.local_copies), n_gpus)
+        eng.g.load_packed_uniform(words, n, L, read_index_base=first)   # sharded by contiguous read ranges, H2D once
+        scaling = "strong"
+    else:
+        eng = ca.SearchEngine(device=local_rank)
+        eng.load_packed_uniform(words, n, L, read_index_base=first)     # H2D once; resident for every step
     engs = [eng]
     if args.alternate:                                      # a second resident batch (the next reads of the same stream)
         eng_b = ca.SearchEngine(device=local_rank)
@@ -185,6 +203,9 @@ def main():
         xg = GatheredExchange(eng, dist, coll_dev)          # one RCCL all-gather of fixed-size device buffers per step
 
     def step(e=eng):
+        if isinstance(e, _GroupRunner):
+            e.g.step()                                      # pass 1 on every shard -> ONE ncclAllGather -> merge -> pass 2, in C++
+            return
         e.seed_scan(fetch=False)
         if xg is not None:
             while not xg.step():                            # capacity raised (first steps only): repeat the seed scan
@@ -204,13 +225,17 @@ def main():
     def sync():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if group_mode and not args.local_copies:
+            for d in range(n_gpus):
+                torch.cuda.synchronize(d)
+        else:
+            torch.cuda.synchronize()
 
     # first call of a fresh context (no speculation bounds, buffers not yet allocated): reported, never part of `value`
     sync()
     t0 = time.perf_counter()
     step()
-    torch.cuda.synchronize()
+    sync()
     first_call_ms = (time.perf_counter() - t0) * 1e3
     for _ in range(max(0, args.warmup - 1)):
         step()
@@ -272,6 +297,10 @@ def main():
         tot_p1, tot_p2 = int(tot[0].item()), int(tot[1].item())
         if args.dist_backend == "nccl":
             rccl_ranks = int(tot[2].item())              # ranks that took part in an RCCL all-reduce
+    if group_mode:
+        tot_p1, tot_p2 = eng.totals()
+        rccl_ranks = eng.g.rccl_ranks
+        n = eng.reads_rank0                                  # the roofline below is rank 0's kernel on rank 0's shard
     ms_per_step = dt * 1e3 / args.steps
     value = total * args.steps / dt if not args.reads else world * n * args.steps / dt
 
@@ -318,7 +347,7 @@ def main():
     path_bytes = 2 * bytes_per_read_per_pass             # both passes read every base once at 2 bits
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu_issue": valu_issue,
-                "path_frac": round(value / world * path_bytes / (HBM_PEAK_GBS * 1e9), 5),
+                "path_frac": round(value / n_gpus * path_bytes / (HBM_PEAK_GBS * 1e9), 5),
                 "path_frac_note": "whole path per GPU: reads/s/GPU x %d B / 8 TB/s (SURVEY 8d)" % path_bytes,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(dom_ms, 4),
                 "per_kernel": per_kernel, "host_ms": {"merge": round(avg["ms_merge_host"], 3), "sink": round(avg["ms_sink_host"], 3)},
@@ -326,17 +355,19 @@ def main():
                 "stages_ms_scouting_steps": stages}
 
     workload = "%d synthetic %d bp reads%s, %d seeded DRs%s (%s%s); pass1 + merge + pass2" % (
-        total, L, "" if world == 1 else " sharded over %d GPUs" % world, n_dr,
+        total, L, "" if n_gpus == 1 else " sharded over %d GPUs" % n_gpus, n_dr,
         ", arrays of %d-%d repeats in %.0f %% of the reads" % (cfg["arrays"] + (cfg["cpm"] / 1e4,)) if cfg["arrays"][1]
         else ", %.0f %% CRISPR reads" % (cfg["cpm"] / 1e4),
         cfg["name"], ", modified by command-line options" if custom else "")
     out = {
         "metric": "reads/sec through DR search+recruit, 150bp synthetic, 1/2/4/8 MI355X",
-        "value": round(value, 1), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 1), "unit": "reads/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": workload, "baseline_config": cfg_id, "total_reads": total, "reads_per_gpu": n, "read_len": L,
-                   "n_dr": n_dr, "parallelism": "read-shards x%d" % world,
+                   "n_dr": n_dr, "parallelism": "read-shards x%d" % n_gpus,
+                   "launcher": ("group: one process, %d contexts, RCCL all-gather issued by the engine (crass_hip_group_*)" % n_gpus) if group_mode
+                               else ("torch.distributed: one process per GPU" if world > 1 else "single context"),
                    "pass1_found": int(c["n_pass1_found"]) if tot_p1 is None else tot_p1,
                    "pass2_found": int(c["n_pass2_found"]) if tot_p2 is None else tot_p2,
                    "patterns": int(c["n_patterns"]), "ac_states": int(c["ac_states"]),
@@ -359,7 +390,7 @@ def main():
     # ---- the single-shot truth: a crass run scans each read set ONCE.  A FRESH context (no learnt bounds; its pools are
     #      sized from the read count when the reads are loaded), reads resident, ONE step, wall clock.  Outside the timed
     #      region. ----
-    if world == 1 and args.single_shots > 0 and not args.alternate:
+    if world == 1 and not group_mode and args.single_shots > 0 and not args.alternate:
         shots = []
         for _ in range(args.single_shots):
             e1 = ca.SearchEngine(device=local_rank)
@@ -381,11 +412,11 @@ def main():
                                       "`value`: reads resident in HBM); no learnt speculation bounds, nothing warmed"}
 
     # ---- strong scaling: the same job on ONE GPU (rank 0, untimed part of the run; the other ranks wait) ----
-    if world > 1 and scaling == "strong" and not args.no_strong_base and args.dist_backend == "nccl":
+    if (world > 1 or group_mode) and scaling == "strong" and not args.no_strong_base and args.dist_backend == "nccl":
         base = None
         if rank == 0:
             try:
-                w_all = ca.synth_packed(spec, 0, total)
+                w_all = words if group_mode else ca.synth_packed(spec, 0, total)
                 e1 = ca.SearchEngine(device=local_rank)
                 e1.load_packed_uniform(w_all, total, L, read_index_base=0)
                 del w_all
@@ -408,12 +439,13 @@ def main():
             out["one_gpu_same_job"] = base
             if base and "value" in base:
                 out["speedup_vs_1gpu"] = round(value / base["value"], 3)
-        dist.barrier()
+        if dist is not None:
+            dist.barrier()
 
     # ---- CPU baseline: the oracle (single core, same algorithm class as the reference) on a
     #      bounded prefix of the SAME stream; rank 0 at N=1 only ----
     cpu_sample = cfg["cpu_sample"] if args.cpu_sample < 0 else args.cpu_sample
-    if rank == 0 and world == 1 and cpu_sample > 0:
+    if rank == 0 and world == 1 and not group_mode and cpu_sample > 0:
         from tests import orc
         m = min(cpu_sample, n)
         asc = ca.unpack_ascii(words, W, L, m)
@@ -474,6 +506,35 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+class _GroupRunner:
+    """bench.py's view of a crass_hip_group: stage timing and counters are rank 0's (the other ranks record no events)"""
+
+    def __init__(self, grp, n_gpus):
+        self.g, self.n_gpus = grp, n_gpus
+        for r in range(1, n_gpus):
+            grp.rank_set_stage_timing(r, 0)
+
+    @property
+    def reads_rank0(self):
+        return int(self.g.rank_counters(0)["n_reads"])
+
+    def set_stage_timing(self, level):
+        self.g.rank_set_stage_timing(0, level)
+
+    def set_timing_focus(self, k):
+        self.g.rank_set_timing_focus(0, k)
+
+    def counters(self):
+        return self.g.rank_counters(0)
+
+    def totals(self):
+        cs = [self.g.rank_counters(r) for r in range(self.n_gpus)]
+        return sum(int(c["n_pass1_found"]) for c in cs), sum(int(c["n_pass2_found"]) for c in cs)
+
+    def close(self):
+        self.g.close()
 
 
 def _pmc_file(n, L):

@@ -120,6 +120,23 @@ class ConsView(C.Structure):
                 ("tok_has_list", C.POINTER(C.c_uint8)), ("counters", ConsCounters)]
 
 
+class GraphInput(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("gid", C.c_void_p), ("dr_chars", C.c_void_p), ("dr_off", C.c_void_p), ("grp_rec_off", C.c_void_p),
+                ("n_rec", C.c_uint64), ("hdr_chars", C.c_void_p), ("hdr_off", C.c_void_p), ("com_chars", C.c_void_p), ("com_off", C.c_void_p),
+                ("seq_chars", C.c_void_p), ("seq_off", C.c_void_p), ("rec_nss", C.c_void_p), ("rec_ss_off", C.c_void_p), ("ss_pool", C.c_void_p)]
+
+
+class OutputOpts(C.Structure):
+    _fields_ = [("out_dir", C.c_char_p), ("timestamp", C.c_char_p), ("command_line", C.c_char_p), ("cwd", C.c_char_p),
+                ("log_to_screen", C.c_int32), ("cov_cutoff", C.c_int32), ("node_kmer", C.c_int32), ("show_singles", C.c_int32),
+                ("long_description", C.c_int32)]
+
+
+class OutputsView(C.Structure):
+    _fields_ = [("n_files", C.c_uint32), ("name", C.POINTER(C.c_char_p)), ("data", C.POINTER(C.c_void_p)), ("size", u64p),
+                ("n_groups_kept", C.c_uint32), ("kept_gid", C.POINTER(C.c_int32)), ("stdout_text", C.c_char_p)]
+
+
 # every exported symbol of include/crass_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "crass_hip_abi_version": (C.c_int, []),
@@ -165,6 +182,26 @@ SYMBOLS = {
     "crass_hip_consensus_view": (C.c_int, [C.c_void_p, C.POINTER(ConsView)]),
     "crass_hip_consensus_free": (None, [C.c_void_p]),
     "crass_fastx_find": (C.c_uint64, [C.POINTER(Fastx), C.c_char_p, C.c_uint64]),
+    "crass_hip_set_host_view": (C.c_int, [C.c_void_p, C.c_int]),
+    "crass_hip_group_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
+    "crass_hip_group_destroy": (None, [C.c_void_p]),
+    "crass_hip_group_size": (C.c_int, [C.c_void_p]),
+    "crass_hip_group_rccl_ranks": (C.c_int, [C.c_void_p]),
+    "crass_hip_group_last_error": (C.c_char_p, []),
+    "crass_hip_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "crass_hip_group_load_reads": (C.c_int, [C.c_void_p, C.POINTER(Reads)]),
+    "crass_hip_group_seed_scan": (C.c_int, [C.c_void_p]),
+    "crass_hip_group_merge": (C.c_int, [C.c_void_p]),
+    "crass_hip_group_recruit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "crass_hip_group_set_patterns": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), u32p, C.c_uint32]),
+    "crass_hip_group_step": (C.c_int, [C.c_void_p]),
+    "crass_hip_group_get_candidates": (C.c_int, [C.c_void_p, C.POINTER(Candidates)]),
+    "crass_hip_group_get_merge": (C.c_int, [C.c_void_p, C.POINTER(MergeView)]),
+    "crass_hip_group_get_recruits": (C.c_int, [C.c_void_p, C.POINTER(Recruits)]),
+    "crass_build_outputs": (C.c_int, [C.POINTER(GraphInput), C.POINTER(OutputOpts), C.POINTER(C.c_void_p)]),
+    "crass_outputs_get": (C.c_int, [C.c_void_p, C.POINTER(OutputsView)]),
+    "crass_outputs_write": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "crass_outputs_free": (None, [C.c_void_p]),
     "crass_synth_default": (None, [C.POINTER(SynthSpec)]),
     "crass_synth_packed": (C.c_int, [C.POINTER(SynthSpec), C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]),
     "crass_unpack_ascii": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),

@@ -12,12 +12,15 @@
 #include <iostream>
 #include <memory>
 #include <unordered_map>
+#include <vector>
 
 namespace crass_hip {
 
 namespace {
 
 int g_device = -1;
+std::vector<int> g_devices;             // setDevices(): more than one entry shards every read set over a group of contexts
+bool g_local_copies = false;            // tests: several contexts on one GPU (CRASS_GROUP_LOCAL_COPIES)
 
 int device()
 {
@@ -75,10 +78,12 @@ struct FileState {
     crass_fastx fx{};
     crass_packed pk{};
     crass_hip_ctx *ctx = nullptr;
+    crass_hip_group *grp = nullptr;      // setDevices() named several GPUs: the file's reads are sharded over them
     bool unique_headers = true;
     uint64_t n_found_own = 0;
     ~FileState()
     {
+        if (grp) crass_hip_group_destroy(grp);
         if (ctx) crass_hip_destroy(ctx);
         crass_free_packed(&pk);
         crass_free_fastx(&fx);
@@ -109,12 +114,20 @@ FileState &open_file(const char *path, const options &opts)
     // thread while this one reads, parses and packs the file
     crass_params p = to_params(opts);
     const int dev = device();
+    const std::vector<int> devs = g_devices;
+    const bool local = g_local_copies;
+    struct Made { int rc = 0; crass_hip_ctx *c = nullptr; crass_hip_group *g = nullptr; };
     struct PendingCtx {
-        std::future<std::pair<int, crass_hip_ctx *>> fut;
-        std::pair<int, crass_hip_ctx *> get() { return fut.get(); }
-        ~PendingCtx() { if (fut.valid()) { auto r = fut.get(); if (r.second) crass_hip_destroy(r.second); } }    // (an exception on the way)
+        std::future<Made> fut;
+        Made get() { return fut.get(); }
+        ~PendingCtx() { if (fut.valid()) { Made r = fut.get(); if (r.c) crass_hip_destroy(r.c); if (r.g) crass_hip_group_destroy(r.g); } }    // (an exception on the way)
     } pending;
-    pending.fut = std::async(std::launch::async, [p, dev]() { crass_hip_ctx *c = nullptr; const int rc = crass_hip_create(&p, dev, &c); return std::make_pair(rc, c); });
+    pending.fut = std::async(std::launch::async, [p, dev, devs, local]() {
+        Made m;
+        if (devs.size() > 1) m.rc = crass_hip_group_create(&p, devs.data(), (int)devs.size(), local ? CRASS_GROUP_LOCAL_COPIES : 0u, &m.g);
+        else m.rc = crass_hip_create(&p, devs.size() == 1 ? devs[0] : dev, &m.c);
+        return m;
+    });
     int rc = crass_read_fastx(path, &f->fx);
     const double t1 = now();
     if (rc == CRASS_ERR_IO) {
@@ -126,13 +139,15 @@ FileState &open_file(const char *path, const options &opts)
     const double t2 = now();
     for (uint64_t i = 0; i < f->fx.n_reads; i++) if (f->fx.header_id[i] != i) { f->unique_headers = false; break; }
     {
-        auto made = pending.get();
-        f->ctx = made.second;
-        chk(made.first, "crass_hip_create");
+        Made made = pending.get();
+        f->ctx = made.c; f->grp = made.g;
+        if (made.rc == CRASS_ERR_RCCL) CRASS_THROW(std::string("crass_hip_group_create: ") + crass_hip_group_last_error());
+        chk(made.rc, devs.size() > 1 ? "crass_hip_group_create" : "crass_hip_create");
     }
     crass_reads r = f->pk.reads;
     r.header_id = f->unique_headers ? nullptr : f->fx.header_id;
-    chk(crass_hip_load_reads(f->ctx, &r), "crass_hip_load_reads");
+    if (f->grp) chk(crass_hip_group_load_reads(f->grp, &r), "crass_hip_group_load_reads");
+    else chk(crass_hip_load_reads(f->ctx, &r), "crass_hip_load_reads");
     if (timing)
         fprintf(stderr, "[crass_timing] %s: %llu reads; read+parse %.3f s, 2-bit pack %.3f s, wait for the context + H2D %.3f s\n", path,
                 (unsigned long long)f->fx.n_reads, t1 - t0, t2 - t1, now() - t2);
@@ -171,7 +186,8 @@ std::string StringCheck::getString(StringToken token) const
     return it->second;
 }
 
-void setDevice(int d) { g_device = d; }
+void setDevice(int d) { g_device = d; g_devices.clear(); }
+void setDevices(const std::vector<int> &devices, bool local_copies) { g_devices = devices; g_local_copies = local_copies; }
 void releaseDeviceReads() { session().clear(); }
 
 void clearReadMap(ReadMap *m)
@@ -219,13 +235,15 @@ int searchFile(const char *inputFastq, const options &opts, ReadMap *mReads, Str
 {
     FileState &f = open_file(inputFastq, opts);
     try {
-        chk(crass_hip_seed_scan(f.ctx), "crass_hip_seed_scan");
+        if (f.grp) chk(crass_hip_group_seed_scan(f.grp), "crass_hip_group_seed_scan");
+        else chk(crass_hip_seed_scan(f.ctx), "crass_hip_seed_scan");
     } catch (exception &e) {
         std::cerr << e.what() << std::endl;
         CRASS_THROW("Fatal error in search algorithm!");
     }
     crass_candidates c;
-    chk(crass_hip_get_candidates(f.ctx, &c), "crass_hip_get_candidates");
+    if (f.grp) chk(crass_hip_group_get_candidates(f.grp, &c), "crass_hip_group_get_candidates");
+    else chk(crass_hip_get_candidates(f.ctx, &c), "crass_hip_get_candidates");
     for (uint64_t k = 0; k < c.n; k++) {
         const uint64_t i = c.read_idx[k];
         ReadHolder *h = new ReadHolder();
@@ -302,13 +320,15 @@ void findSingletons(const char *inputFastq, const options &opts, std::vector<std
     std::vector<const char *> pp;
     std::vector<uint32_t> pl;
     for (const auto &s : *nonRedundantPatterns) { pp.push_back(s.data()); pl.push_back((uint32_t)s.size()); }
-    chk(crass_hip_set_patterns(f.ctx, pp.data(), pl.data(), (uint32_t)pp.size()), "crass_hip_set_patterns");
+    if (f.grp) chk(crass_hip_group_set_patterns(f.grp, pp.data(), pl.data(), (uint32_t)pp.size()), "crass_hip_group_set_patterns");
+    else chk(crass_hip_set_patterns(f.ctx, pp.data(), pl.data(), (uint32_t)pp.size()), "crass_hip_set_patterns");
     // readsFound is keyed by header (libcrispr.cpp:411): headers found in OTHER files must suppress recruitment here too.
     // The device already knows this file's own pass-1 hits (their count is n_found_own: with one input file, or as long
     // as every entry of readsFound is this file's, there is nothing to add); otherwise every header of readsFound is
     // resolved through the table the reader built for header_id (crass_fastx_find) — no second name index — and the
     // engine sets the flags with one upload + one kernel.
     std::vector<uint64_t> extra;
+    // (a group of contexts: a shard only knows its own pass-1 hits, so every found header is named whenever headers repeat)
     if (readsFound.size() != f.n_found_own || !f.unique_headers) {
         extra.reserve(readsFound.size());
         for (const auto &kv : readsFound) {
@@ -316,9 +336,14 @@ void findSingletons(const char *inputFastq, const options &opts, std::vector<std
             if (i != UINT64_MAX) extra.push_back(i);
         }
     }
-    chk(crass_hip_recruit(f.ctx, extra.empty() ? nullptr : extra.data(), extra.size()), "crass_hip_recruit");
     crass_recruits r;
-    chk(crass_hip_get_recruits(f.ctx, &r), "crass_hip_get_recruits");
+    if (f.grp) {
+        chk(crass_hip_group_recruit(f.grp, extra.empty() ? nullptr : extra.data(), extra.size()), "crass_hip_group_recruit");
+        chk(crass_hip_group_get_recruits(f.grp, &r), "crass_hip_group_get_recruits");
+    } else {
+        chk(crass_hip_recruit(f.ctx, extra.empty() ? nullptr : extra.data(), extra.size()), "crass_hip_recruit");
+        chk(crass_hip_get_recruits(f.ctx, &r), "crass_hip_get_recruits");
+    }
     for (uint64_t k = 0; k < r.n; k++) {
         ReadHolder *h = new ReadHolder();
         fill_from_record(*h, f, r.read_idx[k], r.low_lexi[k] != 0);
@@ -331,9 +356,212 @@ void findSingletons(const char *inputFastq, const options &opts, std::vector<std
     std::cout << "\r[crass_singletonFinder]: Processed " << g_read_counter_p2 << " ..." << difftime(now, startTime) << " sec" << std::flush;
 }
 
-} // namespace crass_hip
 
-namespace crass_hip {
+// ------------------------------------------------------------------------------------------------------------------
+// The first half of WorkHorse::parseSeqFiles (WorkHorse.cpp:336-398) in ONE call, on the device(s) end to end: every
+// file's reads form one read set in (file, read) order, pass 1 runs over all of it, createNonRedundantSet runs ON THE
+// GPU (dmerge.hip; with several devices the distinct candidate DR strings cross in one RCCL all-gather issued by the
+// engine), pass 2 runs over all of it.  Same effects on the hand-off state as the three calls of the seam.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct JobFiles {
+    std::vector<crass_fastx> fx;
+    std::vector<uint64_t> base;                 // first job-level read index of every file (+ total)
+    std::vector<uint8_t> seq; std::vector<uint64_t> seq_off, header_id;     // concatenation (several files only)
+    crass_packed pk{};
+    ~JobFiles() { crass_free_packed(&pk); for (auto &f : fx) crass_free_fastx(&f); }
+    void locate(uint64_t i, size_t &file, uint64_t &local) const
+    {
+        file = (size_t)(std::upper_bound(base.begin(), base.end(), i) - base.begin()) - 1;
+        local = i - base[file];
+    }
+};
+
+void fill_holder(ReadHolder &h, const crass_fastx &fx, uint64_t i, bool low_lexi)
+{
+    std::string seq((const char *)fx.seq + fx.seq_off[i], fx.seq_off[i + 1] - fx.seq_off[i]);
+    h.RH_Seq = low_lexi ? seq : revcomp(seq);
+    h.RH_Header.assign((const char *)fx.name + fx.name_off[i], fx.name_off[i + 1] - fx.name_off[i]);
+    if (fx.has_comment[i]) h.RH_Comment.assign((const char *)fx.comment + fx.comment_off[i], fx.comment_off[i + 1] - fx.comment_off[i]);
+    if (fx.has_qual[i]) { h.RH_Qual.assign((const char *)fx.qual + fx.qual_off[i], fx.qual_off[i + 1] - fx.qual_off[i]); h.RH_IsFasta = false; }
+    h.RH_WasLowLexi = low_lexi;
+}
+} // namespace
+
+int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mReads, StringCheck *mStringCheck,
+                     DR_Cluster_Map &mDR2GIDMap, std::map<int, bool> &mGroupMap, GroupKmerMap &groupKmerCountsMap,
+                     int &nextFreeGID, lookupTable &patternsHash, lookupTable &readsFound, Vecstr *nonRedundantPatterns,
+                     time_t &time_start)
+{
+    if (mStringCheck->mNextFreeToken != 1 || !mReads->empty()) CRASS_THROW("searchAndRecruit needs a fresh StringCheck / ReadMap (it is the whole search stage)");
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    crass_params p = to_params(opts);
+    std::vector<int> devs = g_devices;
+    if (devs.empty()) devs.push_back(device());
+    const bool local = g_local_copies;
+    // contexts (HIP start-up, code objects, RCCL communicators) come up on their own thread while this one reads the files
+    struct Made { int rc = 0; crass_hip_ctx *c = nullptr; crass_hip_group *g = nullptr; };
+    struct Pending {
+        std::future<Made> fut; Made m; bool got = false;
+        Made &get() { if (!got) { m = fut.get(); got = true; } return m; }
+        ~Pending() { if (fut.valid() || got) { Made &r = get(); if (r.g) crass_hip_group_destroy(r.g); if (r.c) crass_hip_destroy(r.c); } }
+    } dev;
+    dev.fut = std::async(std::launch::async, [p, devs, local]() {
+        Made m;
+        if (devs.size() > 1) m.rc = crass_hip_group_create(&p, devs.data(), (int)devs.size(), local ? CRASS_GROUP_LOCAL_COPIES : 0u, &m.g);
+        else m.rc = crass_hip_create(&p, devs[0], &m.c);
+        return m;
+    });
+    JobFiles J;
+    J.fx.resize(seqFiles.size());
+    J.base.assign(1, 0);
+    int max_len = 0;
+    for (size_t f = 0; f < seqFiles.size(); f++) {
+        const int rc = crass_read_fastx(seqFiles[f].c_str(), &J.fx[f]);
+        if (rc == CRASS_ERR_IO) CRASS_THROW(std::string("Could not open FASTQ ") + seqFiles[f] + " for reading.");
+        chk(rc, "crass_read_fastx");
+        J.base.push_back(J.base.back() + J.fx[f].n_reads);
+        max_len = std::max(max_len, (int)J.fx[f].max_len);
+    }
+    const uint64_t n = J.base.back();
+    const double t1 = now();
+    const uint8_t *seq = nullptr; const uint64_t *off = nullptr; const uint64_t *hid = nullptr;
+    if (seqFiles.size() == 1) {
+        seq = J.fx[0].seq; off = J.fx[0].seq_off;
+        for (uint64_t i = 0; i < n; i++) if (J.fx[0].header_id[i] != i) { hid = J.fx[0].header_id; break; }
+    } else {
+        // one read set in (file, read) order; header ids across files: the first read of the JOB with the same name
+        // (readsFound is keyed by the header string whatever file it came from, libcrispr.cpp:138,411)
+        J.seq_off.assign(1, 0); J.seq_off.reserve(n + 1); J.header_id.resize(n);
+        uint64_t bytes = 0;
+        for (auto &f : J.fx) bytes += f.n_reads ? f.seq_off[f.n_reads] : 0;
+        J.seq.resize(bytes);
+        uint64_t at = 0;
+        bool any = false;
+        for (size_t f = 0; f < J.fx.size(); f++) {
+            const crass_fastx &x = J.fx[f];
+            if (x.n_reads) memcpy(J.seq.data() + at, x.seq, x.seq_off[x.n_reads]);
+            for (uint64_t i = 0; i < x.n_reads; i++) {
+                J.seq_off.push_back(at + x.seq_off[i + 1]);
+                uint64_t g = J.base[f] + x.header_id[i];
+                if (x.header_id[i] == i)                      // first of its name in this file: did an earlier file have it?
+                    for (size_t e = 0; e < f; e++) {
+                        const uint64_t q = crass_fastx_find(&J.fx[e], (const char *)x.name + x.name_off[i], x.name_off[i + 1] - x.name_off[i]);
+                        if (q != UINT64_MAX) { g = J.base[e] + q; break; }
+                    }
+                else g = J.header_id[J.base[f] + x.header_id[i]];      // same as the first of its name in this file
+                J.header_id[J.base[f] + i] = g;
+                any = any || g != J.base[f] + i;
+            }
+            at += x.n_reads ? x.seq_off[x.n_reads] : 0;
+        }
+        seq = J.seq.data(); off = J.seq_off.data(); hid = any ? J.header_id.data() : nullptr;
+    }
+    chk(crass_pack_reads(seq, off, n, 2, &J.pk), "crass_pack_reads");
+    const double t2 = now();
+    Made &made = dev.get();
+    if (made.rc == CRASS_ERR_RCCL) CRASS_THROW(std::string("crass_hip_group_create: ") + crass_hip_group_last_error());
+    chk(made.rc, made.g ? "crass_hip_group_create" : "crass_hip_create");
+    crass_reads r = J.pk.reads;
+    r.header_id = hid;
+    crass_candidates c; crass_merge_view v; crass_recruits q;
+    try {
+        if (made.g) {
+            chk(crass_hip_group_load_reads(made.g, &r), "crass_hip_group_load_reads");
+            const int s = crass_hip_group_step(made.g);
+            if (s == CRASS_ERR_RCCL) CRASS_THROW(std::string("crass_hip_group_step: ") + crass_hip_group_last_error());
+            chk(s, "crass_hip_group_step");
+            chk(crass_hip_group_get_candidates(made.g, &c), "crass_hip_group_get_candidates");
+            chk(crass_hip_group_get_merge(made.g, &v), "crass_hip_group_get_merge");
+            chk(crass_hip_group_get_recruits(made.g, &q), "crass_hip_group_get_recruits");
+        } else {
+            chk(crass_hip_load_reads(made.c, &r), "crass_hip_load_reads");
+            chk(crass_hip_seed_scan(made.c), "crass_hip_seed_scan");
+            chk(crass_hip_merge(made.c, nullptr, nullptr, 0, 0), "crass_hip_merge");
+            chk(crass_hip_recruit(made.c, nullptr, 0), "crass_hip_recruit");
+            chk(crass_hip_get_candidates(made.c, &c), "crass_hip_get_candidates");
+            chk(crass_hip_get_merge(made.c, &v), "crass_hip_get_merge");
+            chk(crass_hip_get_recruits(made.c, &q), "crass_hip_get_recruits");
+        }
+    } catch (exception &e) {
+        std::cerr << e.what() << std::endl;
+        CRASS_THROW("Fatal error in search algorithm!");
+    }
+    const double t3 = now();
+    time_t tnow; time(&tnow);
+    g_read_counter_p1 += (int)n;
+    std::cout << "\r[crass_patternFinder]: Processed " << g_read_counter_p1 << " ..." << difftime(tnow, time_start) << " sec" << std::endl;
+    // ---- the hand-off ----
+    // StringCheck: tokens 2.. in discovery order (the engine's token t is the reference's token t)
+    for (uint32_t t = 0; t < v.n_tokens; t++) {
+        const StringToken st = mStringCheck->addString(std::string(v.tok_chars + v.tok_off[t], (size_t)(v.tok_off[t + 1] - v.tok_off[t])));
+        (*mReads)[st] = new ReadList();
+    }
+    if (v.n_candidates != c.n) CRASS_THROW("candidate / token count mismatch");
+    for (uint64_t k = 0; k < c.n; k++) {
+        size_t f; uint64_t i;
+        J.locate(c.read_idx[k], f, i);
+        ReadHolder *h = new ReadHolder();
+        fill_holder(*h, J.fx[f], i, c.low_lexi[k] != 0);
+        h->RH_StartStops.assign(c.ss_pool + c.ss_off[k], c.ss_pool + c.ss_off[k] + c.n_ss[k]);
+        h->RH_RepeatLength = (int)c.repeat_len[k];
+        (*mReads)[(StringToken)v.cand_token[k]]->push_back(h);
+        const StartStopList &ss = h->RH_StartStops;         // patternsHash[tmp_holder.repeatStringAt(0)] on the UN-oriented holder (libcrispr.cpp:137)
+        patternsHash[c.low_lexi[k] ? h->repeatStringAt(0) : revcomp(h->RH_Seq.substr(ss[ss.size() - 2], ss[ss.size() - 1] - ss[ss.size() - 2] + 1))] = true;
+        readsFound[h->RH_Header] = true;
+    }
+    // createNonRedundantSet's outputs: groups (GID -> tokens), per-group k-mer counts, the pattern list
+    const int gid_base = nextFreeGID;
+    for (uint32_t g = 0; g < v.n_groups; g++) {
+        const int gid = gid_base + (int)g;
+        mGroupMap[gid] = true;
+        DR_Cluster *cl = new DR_Cluster();
+        std::map<std::string, int> *counts = new std::map<std::string, int>();
+        for (uint64_t w = v.grp_off[g]; w < v.grp_off[g + 1]; w++) {
+            const uint32_t t = v.grp_tokens[w];
+            cl->push_back((StringToken)t);
+            const std::string dr(v.tok_chars + v.tok_off[t - 2], (size_t)(v.tok_off[t - 1] - v.tok_off[t - 2]));
+            for (size_t i = 0; i + 11 <= dr.size(); i++) {                  // local_kmer_CountMap (WorkHorse.cpp:1547-1560,1620-1625)
+                std::string km = dr.substr(i, 11), rc = revcomp(km);
+                (*counts)[km < rc ? km : rc] += 1;
+            }
+        }
+        mDR2GIDMap[gid] = cl;
+        groupKmerCountsMap[gid] = counts;
+    }
+    nextFreeGID = gid_base + (int)v.n_groups;
+    std::cout << "[crass_clusterCore]: " << v.n_tokens << " variants mapped to " << mDR2GIDMap.size() << " clusters" << std::endl;
+    std::cout << "[crass_clusterCore]: creating non-redundant set" << std::endl;
+    if (nonRedundantPatterns) {
+        nonRedundantPatterns->clear();
+        for (uint32_t i = 0; i < v.n_patterns; i++) nonRedundantPatterns->push_back(std::string(v.pat_chars + v.pat_off[i], (size_t)(v.pat_off[i + 1] - v.pat_off[i])));
+    }
+    if (v.n_patterns) std::cout << "[crass_clusterCore]: " << v.n_patterns << " non-redundant patterns." << std::endl;
+    for (uint64_t k = 0; k < q.n; k++) {
+        size_t f; uint64_t i;
+        J.locate(q.read_idx[k], f, i);
+        ReadHolder *h = new ReadHolder();
+        fill_holder(*h, J.fx[f], i, q.low_lexi[k] != 0);
+        h->RH_StartStops.push_back(q.start[k]);
+        h->RH_StartStops.push_back(q.end[k]);
+        StringToken st = (StringToken)q.token[k];
+        if (st < 2 || !mReads->count(st)) {                 // (not expected with the engine's own pattern set: addReadHolder's general form)
+            const std::string dr(q.dr_chars + k * (uint64_t)q.dr_stride, q.dr_len[k]);
+            st = mStringCheck->getToken(dr);
+            if (0 == st) { st = mStringCheck->addString(dr); (*mReads)[st] = new ReadList(); }
+        }
+        (*mReads)[st]->push_back(h);
+    }
+    g_read_counter_p2 += (int)n;
+    time(&tnow);
+    std::cout << "\r[crass_singletonFinder]: Processed " << g_read_counter_p2 << " ..." << difftime(tnow, time_start) << " sec" << std::endl;
+    if (timing)
+        fprintf(stderr, "[crass_timing] searchAndRecruit: %llu reads on %zu device(s); read+parse %.3f s, pack %.3f s, device (H2D + pass 1 + merge + pass 2) %.3f s, hand-off %.3f s\n",
+                (unsigned long long)n, devs.size(), t1 - t0, t2 - t1, t3 - t2, now() - t3);
+    return max_len;
+}
 
 int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map &mDR2GIDMap, std::map<int, std::string> &mTrueDRs,
                      GroupKmerMap &groupKmerCountsMap, int &nextFreeGID, int mMaxReadLength, const options &opts)

@@ -124,6 +124,22 @@ int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map 
 void releaseDeviceReads();
 // which GPU the adapter uses (default 0, or $CRASS_HIP_DEVICE)
 void setDevice(int device);
+// several GPUs: every read set is sharded over them by contiguous read ranges (crass_hip_group_*, include/crass_hip.h); with
+// searchAndRecruit the DR merge runs on the devices and the candidate DR strings cross in ONE RCCL all-gather issued by the
+// engine.  local_copies: tests only — several contexts on one GPU, device copies instead of the collective.
+void setDevices(const std::vector<int> &devices, bool local_copies = false);
+
+// The first half of WorkHorse::parseSeqFiles (WorkHorse.cpp:336-398: searchFile over every file, createNonRedundantSet,
+// findSingletons over every file) as ONE call that stays on the device(s) from the packed reads to the ordered hand-off —
+// the form that lets the engine run the DR merge on the GPU and, with setDevices(), shard the reads over several GPUs.
+// Effects on mReads / mStringCheck / mDR2GIDMap / mGroupMap / groupKmerCountsMap / nextFreeGID / patternsHash / readsFound
+// are those of the three calls (same tokens, same GIDs, same vector orders); *nonRedundantPatterns receives the pattern
+// list (may be NULL).  Returns the maximum read length (searchFile's return value, max over the files).  Needs a fresh
+// StringCheck and ReadMap, which is what parseSeqFiles starts from.
+int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mReads, StringCheck *mStringCheck,
+                     DR_Cluster_Map &mDR2GIDMap, std::map<int, bool> &mGroupMap, GroupKmerMap &groupKmerCountsMap,
+                     int &nextFreeGID, lookupTable &patternsHash, lookupTable &readsFound, Vecstr *nonRedundantPatterns,
+                     time_t &time_start);
 
 // clean-up helpers with the ownership rules of WorkHorse::clearReadMap (WorkHorse.cpp:127-162)
 void clearReadMap(ReadMap *m);

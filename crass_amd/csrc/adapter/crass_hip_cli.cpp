@@ -22,7 +22,12 @@ static void usage()
 {
     std::cout << "crass-hip (MI355X search stage of crass 1.0.1)\n"
                  "usage: crass-hip [-d minDR] [-D maxDR] [-s minSpacer] [-S maxSpacer] [-w window] [-n minRepeats]\n"
-                 "                 [-k kmerClust] [-l logLevel] [-g] [-o outdir] <reads.f[aq][.gz]> ...\n";
+                 "                 [-k kmerClust] [-l logLevel] [-g] [-o outdir] [--gpus N | --devices a,b,..] [--seam]\n"
+                 "                 <reads.f[aq][.gz]> ...\n"
+                 "  --gpus N       shard the reads over GPUs 0..N-1 (one RCCL all-gather of the candidate DR strings per job)\n"
+                 "  --devices L    the same with an explicit device list\n"
+                 "  --seam         drive the engine through crass's three calls (searchFile / createNonRedundantSet /\n"
+                 "                 findSingletons: the DR merge then runs on the host) instead of the one-call device path\n";
 }
 
 int main(int argc, char *argv[])
@@ -34,7 +39,11 @@ int main(int argc, char *argv[])
         {"windowLength", required_argument, nullptr, 'w'}, {"minNumRepeats", required_argument, nullptr, 'n'},
         {"kmerCount", required_argument, nullptr, 'k'}, {"logLevel", required_argument, nullptr, 'l'},
         {"logToScreen", no_argument, nullptr, 'g'}, {"outDir", required_argument, nullptr, 'o'},
+        {"gpus", required_argument, nullptr, 1001}, {"devices", required_argument, nullptr, 1002}, {"seam", no_argument, nullptr, 1003},
+        {"local-copies", no_argument, nullptr, 1004},
         {"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
+    std::vector<int> devices;
+    bool seam = false, local_copies = false;
     int c, idx = 0;
     while ((c = getopt_long(argc, argv, "d:D:s:S:w:n:k:l:go:h", long_options, &idx)) != -1) {
         switch (c) {
@@ -81,6 +90,21 @@ int main(int argc, char *argv[])
                 opts.output_fastq = optarg;
                 if (opts.output_fastq[opts.output_fastq.length() - 1] != '/') opts.output_fastq += '/';
                 break;
+            case 1001: {
+                const int ng = atoi(optarg);
+                if (ng < 1 || ng > 64) { std::cerr << "crass [ERROR]: --gpus needs a device count between 1 and 64" << std::endl; return 1; }
+                devices.clear();
+                for (int d = 0; d < ng; d++) devices.push_back(d);
+                break;
+            }
+            case 1002: {
+                devices.clear();
+                for (const char *q = optarg; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+                if (devices.empty()) { std::cerr << "crass [ERROR]: --devices needs a comma-separated device list" << std::endl; return 1; }
+                break;
+            }
+            case 1003: seam = true; break;
+            case 1004: local_copies = true; break;      // (tests: several contexts on one GPU)
             case 'h': usage(); return 0;
             default: usage(); return 1;
         }
@@ -122,21 +146,30 @@ int main(int argc, char *argv[])
     auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[crass_timing] cli: %-28s %.3f s (at %.3f s)\n", what, t - t_prev, t - t_main); t_prev = t; } };
     try {
         time_t start_time; time(&start_time);
-        for (const auto &f : seqFiles) {
-            int max_len = searchFile(f.c_str(), opts, &mReads, &mStringCheck, patterns_lookup, reads_found, start_time);
-            mMaxReadLength = std::max(mMaxReadLength, max_len);
-        }
-        std::cout << std::endl;
-        lap("searchFile (ingest + pass 1)");
+        if (!devices.empty()) setDevices(devices, local_copies);
         int next_free_GID = 1;
-        Vecstr *nr = createNonRedundantSet(mReads, mStringCheck, mDR2GIDMap, mGroupMap, group_kmer_counts_map, next_free_GID, opts);
-        if (nr->size() > 0) {
-            std::cout << "[crass_clusterCore]: " << nr->size() << " non-redundant patterns." << std::endl;
-            time(&start_time);
-            for (const auto &f : seqFiles) findSingletons(f.c_str(), opts, nr, reads_found, &mReads, &mStringCheck, start_time);
+        Vecstr *nr = nullptr;
+        if (seam) {
+            for (const auto &f : seqFiles) {
+                int max_len = searchFile(f.c_str(), opts, &mReads, &mStringCheck, patterns_lookup, reads_found, start_time);
+                mMaxReadLength = std::max(mMaxReadLength, max_len);
+            }
+            std::cout << std::endl;
+            lap("searchFile (ingest + pass 1)");
+            nr = createNonRedundantSet(mReads, mStringCheck, mDR2GIDMap, mGroupMap, group_kmer_counts_map, next_free_GID, opts);
+            if (nr->size() > 0) {
+                std::cout << "[crass_clusterCore]: " << nr->size() << " non-redundant patterns." << std::endl;
+                time(&start_time);
+                for (const auto &f : seqFiles) findSingletons(f.c_str(), opts, nr, reads_found, &mReads, &mStringCheck, start_time);
+            }
+            std::cout << std::endl;
+            lap("merge + findSingletons");
+        } else {
+            nr = new Vecstr();
+            mMaxReadLength = searchAndRecruit(seqFiles, opts, &mReads, &mStringCheck, mDR2GIDMap, mGroupMap, group_kmer_counts_map, next_free_GID,
+                                              patterns_lookup, reads_found, nr, start_time);
+            lap("searchAndRecruit (ingest + pass 1 + merge + pass 2)");
         }
-        std::cout << std::endl;
-        lap("merge + findSingletons");
         size_t n_reads = 0;
         for (auto &kv : mReads) n_reads += kv.second->size();
         std::cout << "[crass_patternFinder]: Found " << n_reads << " reads" << std::endl;

@@ -294,6 +294,7 @@ struct crass_hip_ctx {
     uint64_t n_dx = 0;
     bool have_dev_tokens = false;
     uint32_t n_cu = 0;
+    bool host_view_light = false;              // crass_hip_set_host_view: a device merge's host view = the own candidates' tokens only
     HostWorker worker;
     uint64_t surv_cap_hint = 0;
     uint64_t hit_cap_hint = 0;                // speculative bound for pass 2's flagged reads (0: none yet)
@@ -512,6 +513,7 @@ const char *crass_hip_strerror(int s)
         case CRASS_ERR_SEARCH_FATAL: return "Fatal error in search algorithm!";
         case CRASS_ERR_OVERFLOW: return "device pool overflow";
         case CRASS_ERR_IO: return "I/O error";
+        case CRASS_ERR_RCCL: return "RCCL call failed (crass_hip_group_last_error())";
         default: return "unknown status";
     }
 }
@@ -585,6 +587,14 @@ int crass_hip_set_stage_timing(crass_hip_ctx *c, int level)
 {
     if (!c || level < 0 || level > 2) return CRASS_ERR_INVALID_ARG;
     c->timing_level = level;
+    return CRASS_OK;
+}
+
+int crass_hip_set_host_view(crass_hip_ctx *c, int light)
+{
+    if (!c || light < 0 || light > 1) return CRASS_ERR_INVALID_ARG;
+    quiesce_worker(c);
+    c->host_view_light = light != 0;
     return CRASS_OK;
 }
 
@@ -1649,6 +1659,23 @@ static int build_host_merge(crass_hip_ctx *c)
         for (uint64_t k = 0; k < d.n_cand; k++) d.cand_map[k] = d.h_gmap.p[d.my_off + c->h_dmap.p[k]];
         cmap = d.cand_map.data();
     }
+    if (c->host_view_light) {
+        // a rank of a group other than rank 0: tokens, groups and patterns are read from rank 0's view (they are identical on
+        // every rank); what is this rank's own are its candidates' tokens
+        c->merge.clear();
+        c->merge.cand_token.resize(d.n_cand);
+        for (uint64_t k = 0; k < d.n_cand; k++) {
+            if (cmap[k] >= d.n_tok) { c->merge.clear(); return CRASS_ERR_STATE; }
+            c->merge.cand_token[k] = cmap[k] + 2;
+        }
+        HIPCHK(c, hipEventSynchronize(d.ev_done));
+        if (d.h_st.p->fail) return CRASS_ERR_STATE;
+        d.host_built = true;
+        c->n_installed_patterns = d.h_st.p->n_patterns;
+        c->cnt.n_patterns = d.h_st.p->n_patterns; c->cnt.ac_states = 0; c->cnt.anchor_keys = d.h_st.p->n_keys;
+        c->cnt.ms_merge_device = 0;
+        return CRASS_OK;
+    }
     if (!merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand)) return CRASS_ERR_STATE;
     host_pool_warm();                                   // the second half fans out over the pool: wake it while the device is busy
     const double tb0 = now_ms();
@@ -1865,6 +1892,23 @@ int crass_hip_merge_distinct(crass_hip_ctx *c, const char *dr_chars, const uint1
     return merge_global_host(c, dr_chars, dr_len, dr_stride, n_global, my_offset, t0);
 }
 
+// every buffer crass_hip_merge_gathered touches for up to n_max gathered rows
+static int ensure_gathered_buffers(crass_hip_ctx *c, uint64_t n_max)
+{
+    crass_hip_ctx::DM &d = c->dm;
+    const uint32_t stride = c->dr_stride, n = (uint32_t)n_max;
+    uint32_t tsize = 1024;
+    while (tsize < n * 2) tsize <<= 1;
+    const uint64_t n_words = (n_max + 63) / 64;
+    HIPCHK(c, d.g_chars.ensure(n_max * (size_t)stride + 16)); HIPCHK(c, d.g_len.ensure(n_max + 1));
+    HIPCHK(c, d.g_keys.ensure(tsize)); HIPCHK(c, d.g_first.ensure(tsize)); HIPCHK(c, d.g_slot.ensure(n)); HIPCHK(c, d.g_rep.ensure(n));
+    HIPCHK(c, d.g_hash.ensure(n)); HIPCHK(c, d.g_mask.ensure(n_words + 1)); HIPCHK(c, d.g_prefix.ensure(n_words + 1));
+    HIPCHK(c, d.g_bsum.ensure((n_words + 255) / 256 + 2)); HIPCHK(c, d.g_idx.ensure(n));
+    HIPCHK(c, d.gx_chars.ensure((size_t)n * stride + 16)); HIPCHK(c, d.gx_len.ensure(n));
+    HIPCHK(c, d.h_gmap.ensure(n)); HIPCHK(c, d.h_gx_chars.ensure((size_t)n * stride + 16)); HIPCHK(c, d.h_gx_len.ensure(n)); HIPCHK(c, d.h_gx_hash.ensure(n));
+    return CRASS_OK;
+}
+
 int crass_hip_exchange_setup(crass_hip_ctx *c, uint32_t world, uint32_t rank, uint64_t cap_rows, crass_exchange *o)
 {
     if (!c || !o || world == 0 || rank >= world || cap_rows == 0 || cap_rows > (1u << 22)) return CRASS_ERR_INVALID_ARG;
@@ -1874,6 +1918,21 @@ int crass_hip_exchange_setup(crass_hip_ctx *c, uint32_t world, uint32_t rank, ui
     HIPCHK(c, X.send.ensure(X.send_bytes())); HIPCHK(c, X.xinfo.ensure(8)); HIPCHK(c, X.h_xinfo.ensure(8));
     HIPCHK(c, hipMemset(X.send.p, 0, X.send_bytes()));
     X.active = true;
+    X.gx_cap_hint = 0;
+    // first call (see first_call_bounds): a bound for the GLOBAL distinct list from the job's size (every rank holds ~1/world
+    // of the reads), and the buffers of crass_hip_merge_gathered sized now rather than inside the first step
+    if (c->have_reads && c->surv_cap_hint && c->dx_cap_hint && !c->env.no_presize && !c->env.no_speculation) {
+        const uint64_t n_max = (uint64_t)world * cap_rows;
+        const uint64_t n_job = (uint64_t)world * c->R.n_reads;
+        const uint64_t gx = std::min<uint64_t>(std::min<uint64_t>(n_max, 1u << 20), std::max<uint64_t>(16384, (n_job / 1024 + 4095) & ~4095ull));
+        if (n_max <= (1u << 22)) {
+            int s = ensure_gathered_buffers(c, n_max);
+            if (s) return s;
+            s = device_merge_prepare(c, c->dm.gx_chars.p, c->dm.gx_len.p, gx, c->d_count.p + 4);
+            if (s) return s;
+            X.gx_cap_hint = (uint32_t)gx;
+        }
+    }
     o->d_send = X.send.p; o->send_bytes = X.send_bytes(); o->slot_bytes = X.slot; o->cap_rows = X.cap;
     return CRASS_OK;
 }
@@ -1901,12 +1960,7 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     if (dev) {
         uint32_t tsize = 1024;
         while (tsize < n * 2) tsize <<= 1;
-        const uint64_t n_words = (n_max + 63) / 64;
-        HIPCHK(c, d.g_keys.ensure(tsize)); HIPCHK(c, d.g_first.ensure(tsize)); HIPCHK(c, d.g_slot.ensure(n)); HIPCHK(c, d.g_rep.ensure(n));
-        HIPCHK(c, d.g_hash.ensure(n)); HIPCHK(c, d.g_mask.ensure(n_words + 1)); HIPCHK(c, d.g_prefix.ensure(n_words + 1));
-        HIPCHK(c, d.g_bsum.ensure((n_words + 255) / 256 + 2)); HIPCHK(c, d.g_idx.ensure(n));
-        HIPCHK(c, d.gx_chars.ensure((size_t)n * stride + 16)); HIPCHK(c, d.gx_len.ensure(n));
-        HIPCHK(c, d.h_gmap.ensure(n)); HIPCHK(c, d.h_gx_chars.ensure((size_t)n * stride + 16)); HIPCHK(c, d.h_gx_len.ensure(n)); HIPCHK(c, d.h_gx_hash.ensure(n));
+        { const int as = ensure_gathered_buffers(c, n_max); if (as) return as; }
         HIPCHK(c, hipMemsetAsync(c->d_count.p + 4, 0, 8, c->stream));
         // the global count lives on the device (xinfo[0]); n_max bounds it
         HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, X.xinfo.p, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p, d.g_rep.p,

@@ -485,6 +485,149 @@ class SearchEngine:
         return dist, sim
 
 
+class SearchGroup:
+    """Several GPUs from one process (crass_hip_group_*): contiguous read shards, one RCCL all-gather of the distinct
+    candidate DR strings per step issued by the engine, one host view for the group.  devices: list of device
+    indices; local_copies=True replaces the collective by device copies (tests: several contexts on one GPU)."""
+
+    GROUP_LOCAL_COPIES = 1
+
+    def __init__(self, devices, params=None, local_copies=False):
+        self.lib = _abi.load()
+        self.params = params or default_params()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        st = self.lib.crass_hip_group_create(C.byref(self.params), devs, len(devices), self.GROUP_LOCAL_COPIES if local_copies else 0,
+                                             C.byref(h))
+        if st != 0:
+            raise CrassError(st, "crass_hip_group_create [%s]" % self.lib.crass_hip_group_last_error().decode())
+        self.h = h
+        self.n = len(devices)
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.crass_hip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, st, where):
+        if st != 0:
+            raise CrassError(st, "%s [%s]" % (where, self.lib.crass_hip_group_last_error().decode()))
+
+    @property
+    def rccl_ranks(self):
+        return int(self.lib.crass_hip_group_rccl_ranks(self.h))
+
+    def load_reads(self, packed, header_id=None, read_index_base=0):
+        r = _abi.Reads()
+        C.memmove(C.byref(r), C.byref(packed.reads), C.sizeof(r))
+        hid = None
+        if header_id is not None:
+            hid = np.ascontiguousarray(header_id, dtype=np.uint64)
+            r.header_id = hid.ctypes.data
+        r.read_index_base = int(read_index_base)
+        self._chk(self.lib.crass_hip_group_load_reads(self.h, C.byref(r)), "crass_hip_group_load_reads")
+
+    def load_packed_uniform(self, words, n_reads, read_len, read_index_base=0):
+        r = _abi.Reads()
+        r.n_reads = int(n_reads)
+        r.packed = words.ctypes.data
+        r.stride_words = (int(read_len) + 15) // 16
+        r.uniform_len = int(read_len)
+        r.read_index_base = int(read_index_base)
+        self._chk(self.lib.crass_hip_group_load_reads(self.h, C.byref(r)), "crass_hip_group_load_reads")
+
+    def seed_scan(self):
+        self._chk(self.lib.crass_hip_group_seed_scan(self.h), "crass_hip_group_seed_scan")
+
+    def merge(self):
+        self._chk(self.lib.crass_hip_group_merge(self.h), "crass_hip_group_merge")
+
+    def recruit(self, extra_found=None):
+        if extra_found is not None and len(extra_found):
+            ef = np.ascontiguousarray(extra_found, dtype=np.uint64)
+            self._chk(self.lib.crass_hip_group_recruit(self.h, ef.ctypes.data, len(ef)), "crass_hip_group_recruit")
+        else:
+            self._chk(self.lib.crass_hip_group_recruit(self.h, None, 0), "crass_hip_group_recruit")
+
+    def set_patterns(self, patterns):
+        arr = (C.c_char_p * len(patterns))(*patterns)
+        lens = (C.c_uint32 * len(patterns))(*[len(p) for p in patterns])
+        self._chk(self.lib.crass_hip_group_set_patterns(self.h, arr, lens, len(patterns)), "crass_hip_group_set_patterns")
+
+    def step(self):
+        self._chk(self.lib.crass_hip_group_step(self.h), "crass_hip_group_step")
+
+    def candidates(self):
+        v = _abi.Candidates()
+        self._chk(self.lib.crass_hip_group_get_candidates(self.h, C.byref(v)), "crass_hip_group_get_candidates")
+        return CandidateSet(v)
+
+    def merge_view(self):
+        v = _abi.MergeView()
+        self._chk(self.lib.crass_hip_group_get_merge(self.h, C.byref(v)), "crass_hip_group_get_merge")
+        return MergeResult(v)
+
+    def recruits(self):
+        v = _abi.Recruits()
+        self._chk(self.lib.crass_hip_group_get_recruits(self.h, C.byref(v)), "crass_hip_group_get_recruits")
+        return RecruitSet(v)
+
+    def rank_counters(self, rank):
+        c = _abi.Counters()
+        _chk(self.lib.crass_hip_get_counters(C.c_void_p(self.lib.crass_hip_group_ctx(self.h, int(rank))), C.byref(c)), "crass_hip_get_counters")
+        return c.asdict()
+
+    def rank_set_stage_timing(self, rank, level):
+        _chk(self.lib.crass_hip_set_stage_timing(C.c_void_p(self.lib.crass_hip_group_ctx(self.h, int(rank))), int(level)), "crass_hip_set_stage_timing")
+
+    def rank_set_timing_focus(self, rank, kernels):
+        _chk(self.lib.crass_hip_set_timing_focus(C.c_void_p(self.lib.crass_hip_group_ctx(self.h, int(rank))), int(kernels)), "crass_hip_set_timing_focus")
+
+    def result(self):
+        """the whole job's hand-off as a PipelineResult (same fields as search_pipeline's)"""
+        cand, merge, rec = self.candidates(), self.merge_view(), self.recruits()
+        res = PipelineResult(cand, merge, rec, cand.max_read_len)
+        res.counters = [self.rank_counters(r) for r in range(self.n)]
+        return res
+
+
+def search_pipeline_group(seqs, devices, headers=None, params=None, local_copies=False, pad_uniform=0, fused=True):
+    """search_pipeline over a group of contexts (one per entry of `devices`)"""
+    packed = PackedReads(seqs, pad_uniform)
+    header_id = None
+    if headers is not None:
+        first = {}
+        header_id = np.empty(len(headers), np.uint64)
+        for i, h in enumerate(headers):
+            header_id[i] = first.setdefault(h, i)
+        if np.all(header_id == np.arange(len(headers), dtype=np.uint64)):
+            header_id = None
+    g = SearchGroup(devices, params, local_copies)
+    try:
+        g.load_reads(packed, header_id)
+        if fused:
+            g.step()
+        else:
+            g.seed_scan(); g.merge(); g.recruit()
+        return g.result()
+    finally:
+        g.close()
+        packed.close()
+
+
 class PipelineResult:
     """Same field names as tests/orc.PipelineResult so parity tests compare attribute by attribute."""
 
@@ -622,3 +765,47 @@ def consensus(seqs, res, params=None, device=0):
         return ConsensusResult(v)
     finally:
         lib.crass_hip_consensus_free(h)
+
+
+def build_outputs(groups, out_dir="./", timestamp="", command_line="", cwd="", log_to_screen=True, cov_cutoff=0, write_to=None):
+    """crass_build_outputs (WorkHorse::buildGraph ... outputResults): groups = [(gid, true_dr bytes, [(header, comment or None, seq,
+    start_stops), ...])] in ascending GID, the reads in buildGraph's order.  Returns (files {name: bytes}, kept gids, stdout text);
+    write_to: also write the files into that directory (crass_outputs_write)."""
+    lib = _abi.load()
+    gid = np.array([g for g, _, _ in groups], np.int32)
+    dr_buf, dr_off = concat([d for _, d, _ in groups])
+    recs = [r for _, _, rs in groups for r in rs]
+    goff = np.zeros(len(groups) + 1, np.uint64)
+    if groups:
+        goff[1:] = np.cumsum([len(rs) for _, _, rs in groups], dtype=np.uint64)
+    hb, ho = concat([r[0] for r in recs])
+    cb, co = concat([(r[1] or b"") for r in recs])
+    sb, so = concat([r[2] for r in recs])
+    nss = np.array([len(r[3]) for r in recs], np.uint32)
+    ssoff = np.zeros(len(recs), np.uint64)
+    if len(recs) > 1:
+        ssoff[1:] = np.cumsum(nss[:-1], dtype=np.uint64)
+    pool = np.array([v for r in recs for v in r[3]] or [0], np.uint32)
+
+    def ptr(a):
+        return a.ctypes.data if a.size else None
+    gi = _abi.GraphInput(len(groups), ptr(gid), ptr(dr_buf), dr_off.ctypes.data, goff.ctypes.data, len(recs), ptr(hb), ho.ctypes.data,
+                         ptr(cb) if cb.size else None, co.ctypes.data, ptr(sb), so.ctypes.data, ptr(nss), ptr(ssoff), pool.ctypes.data)
+    if cb.size == 0:
+        cz = np.zeros(1, np.uint8)                  # (no comment bytes at all: an empty but valid buffer)
+        gi.com_chars = cz.ctypes.data
+    oo = _abi.OutputOpts(out_dir.encode() if isinstance(out_dir, str) else out_dir, timestamp.encode(), command_line.encode(), cwd.encode(),
+                         1 if log_to_screen else 0, int(cov_cutoff), 0, 0, 0)
+    h = C.c_void_p()
+    _chk(lib.crass_build_outputs(C.byref(gi), C.byref(oo), C.byref(h)), "crass_build_outputs")
+    try:
+        v = _abi.OutputsView()
+        _chk(lib.crass_outputs_get(h, C.byref(v)), "crass_outputs_get")
+        files = {v.name[i].decode(): C.string_at(v.data[i], int(v.size[i])) for i in range(v.n_files)}
+        kept = [int(v.kept_gid[i]) for i in range(v.n_groups_kept)]
+        text = v.stdout_text.decode()
+        if write_to is not None:
+            _chk(lib.crass_outputs_write(h, str(write_to).encode()), "crass_outputs_write")
+        return files, kept, text
+    finally:
+        lib.crass_outputs_free(h)

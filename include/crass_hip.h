@@ -42,7 +42,8 @@ enum {
     CRASS_ERR_SEARCH_FATAL  = 7,   /* the reference would have thrown "Fatal error in search
                                       algorithm!" (libcrispr.cpp:141-149)                    */
     CRASS_ERR_OVERFLOW      = 8,   /* an internal device pool overflowed                     */
-    CRASS_ERR_IO            = 9    /* file could not be opened / parsed                      */
+    CRASS_ERR_IO            = 9,   /* file could not be opened / parsed                      */
+    CRASS_ERR_RCCL          = 10   /* an RCCL call failed (crass_hip_group_last_error())     */
 };
 
 /* implementation limits of the device path (checked by crass_hip_create) */
@@ -289,6 +290,53 @@ typedef struct {
 } crass_counters;
 int crass_hip_get_counters(const crass_hip_ctx *ctx, crass_counters *out);
 
+/* ---- several GPUs from ONE process (north_star: "C++ host code ... RCCL all-gather over xGMI") ----
+ * A group owns one context per device.  The reads shard by contiguous ranges in input order (rank r holds reads
+ * [r*n/N, (r+1)*n/N), WorkHorse.cpp:336-393: pass 1 covers every read before pass 2 starts), every rank runs pass 1 on its
+ * shard, ONE collective — ncclAllGather inside ncclGroupStart/ncclGroupEnd on the contexts' streams, communicators from
+ * ncclCommInitAll — moves every rank's distinct candidate DR strings to every rank (the fixed-size buffers of
+ * crass_hip_exchange_setup), each rank merges the rank-ordered concatenation on its device (identical tokens, groups,
+ * pattern set and pass-2 index everywhere: no broadcast of tables) and recruits on its shard.  The host view of the
+ * merge (crass_merge_view) is built ONCE for the group, by rank 0.  There is no reference counterpart: crass is a
+ * single-threaded program; what the group replaces is the same three calls of WorkHorse::parseSeqFiles
+ * (searchFile / createNonRedundantSet / findSingletons, WorkHorse.cpp:340,370,386) over all reads.
+ * flags: CRASS_GROUP_LOCAL_COPIES replaces the collective by plain device copies (required when a device is listed more
+ * than once — RCCL refuses duplicate devices — which is how the group is tested on a one-GPU box).
+ * Duplicate headers (readsFound is keyed by header, libcrispr.cpp:138,411) are honoured across shards: pass-1 hits of a
+ * header that also occurs in another shard are marked found there before pass 2.
+ * Call order as for a context: load_reads -> seed_scan -> merge -> recruit (or step = the three in one dispatch).
+ * One host thread calls the group; the group runs one helper thread per additional rank.                              */
+typedef struct crass_hip_group crass_hip_group;
+#define CRASS_GROUP_LOCAL_COPIES 1u
+int  crass_hip_group_create(const crass_params *p, const int *devices, int n_devices, unsigned flags, crass_hip_group **out);
+void crass_hip_group_destroy(crass_hip_group *g);
+int  crass_hip_group_size(const crass_hip_group *g);
+/* ranks of the RCCL communicator (ncclCommCount), 0 when the collective is the local-copy stand-in */
+int  crass_hip_group_rccl_ranks(const crass_hip_group *g);
+/* text of the last RCCL / group error of this process ("" if none); valid until the next group call */
+const char *crass_hip_group_last_error(void);
+/* rank r's context, for the per-rank getters (crass_hip_get_counters, crass_hip_get_candidates, ...); owned by the group */
+crass_hip_ctx *crass_hip_group_ctx(crass_hip_group *g, int rank);
+int  crass_hip_group_load_reads(crass_hip_group *g, const crass_reads *host_reads);
+int  crass_hip_group_seed_scan(crass_hip_group *g);
+int  crass_hip_group_merge(crass_hip_group *g);
+/* extra_found: further found headers as job-level read indices (crass_hip_recruit's argument), routed to the shards */
+int  crass_hip_group_recruit(crass_hip_group *g, const uint64_t *extra_found, uint64_t n_extra);
+/* an explicit pattern list on every rank instead of the group's own merge (the seam's findSingletons, whose pattern list
+ * comes from the caller's createNonRedundantSet; crass_hip_set_patterns).  Found headers of OTHER shards are then the
+ * caller's to pass (extra_found): it holds readsFound.                                                          */
+int  crass_hip_group_set_patterns(crass_hip_group *g, const char *const *patterns, const uint32_t *lengths, uint32_t n);
+int  crass_hip_group_step(crass_hip_group *g);         /* seed_scan + merge + recruit, one dispatch per rank */
+/* the hand-off of the whole job, in global read order (rank order == read order): views into group-owned memory, valid
+ * until the next group call.  get_merge: tokens / groups / patterns from rank 0's host view, cand_token for the
+ * candidates of all ranks (the order of crass_hip_group_get_candidates).                                          */
+int  crass_hip_group_get_candidates(crass_hip_group *g, crass_candidates *out);
+int  crass_hip_group_get_merge(crass_hip_group *g, crass_merge_view *out);
+int  crass_hip_group_get_recruits(crass_hip_group *g, crass_recruits *out);
+/* Which host view a context builds after a device merge: 0 (default) the full one, 1 only its own candidates' tokens
+ * (ranks other than 0 of a group: tokens, groups and patterns are identical on every rank and are read from rank 0). */
+int  crass_hip_set_host_view(crass_hip_ctx *ctx, int light);
+
 /* ---- the stage right behind the hot path: true-DR consensus + start/stop repair ----
  * replaces: int WorkHorse::findConsensusDRs(GroupKmerMap&, int& nextFreeGID)  (WorkHorse.cpp:578-611, called at :403), i.e.
  * per DR group parseGroupedDRs (:1135-1379): Aligner (Aligner.cpp:73-468 over ksw_align, ksw.c:330-360) -> consensus and
@@ -338,6 +386,47 @@ typedef struct crass_cons crass_cons;
 int  crass_hip_consensus(const crass_params *p, int device, const crass_cons_input *in, crass_cons **out);
 int  crass_hip_consensus_view(const crass_cons *c, crass_cons_view *v);
 void crass_hip_consensus_free(crass_cons *c);
+
+/* ---- the stages behind findConsensusDRs: spacer graph + crass's output files ----
+ * replaces, for a caller that wants crass's outputs from the hand-off: WorkHorse::buildGraph / cleanGraph / makeSpacerGraphs /
+ * cleanSpacerGraphs / splitIntoContigs / generateFlankers / removeLowConfidenceNodeManagers (WorkHorse.cpp:196-277 ->
+ * NodeManager.cpp, CrisprNode.cpp, SpacerInstance.cpp) and WorkHorse::outputResults (WorkHorse.cpp:1900-2249: crass.crispr
+ * through crispr::xml::writer, Group_<gid>_<DR>.fa through NodeManager::dumpReads, Spacers_<gid>_<DR>_spacers.gv and
+ * crass.<timestamp>.keys.gv through printSpacerGraph / printSpacerKey).  Host code (<= 10^4 reads per group; serial graph
+ * work), no GPU needed.  Input: the groups that have a true DR after crass_hip_consensus, ascending GID, and for each the
+ * ReadHolders in buildGraph's order (WorkHorse.cpp:454-505: for every token of mDR2GIDMap[GID], mReads[token] in list
+ * order) with RH_Seq as it stands after the consensus stage.
+ * The reference's own output depends on heap addresses where a graph has forks or bubbles (edge maps keyed by CrisprNode*):
+ * creation order is used there (oracle/crass_graph.py: parity unpinned for these two rows).            */
+typedef struct {
+    uint32_t n_groups; const int32_t *gid; const char *dr_chars; const uint64_t *dr_off;      /* true DR of group g            */
+    const uint64_t *grp_rec_off;                                  /* [n_groups+1]: records of group g, in buildGraph's order  */
+    uint64_t n_rec;
+    const char *hdr_chars; const uint64_t *hdr_off;               /* RH_Header                                                  */
+    const char *com_chars; const uint64_t *com_off;               /* RH_Comment (may be NULL: no comments)                      */
+    const char *seq_chars; const uint64_t *seq_off;               /* RH_Seq                                                     */
+    const uint32_t *rec_nss; const uint64_t *rec_ss_off; const uint32_t *ss_pool;              /* RH_StartStops                 */
+} crass_graph_input;
+typedef struct {
+    const char *out_dir;          /* options::output_fastq as crass holds it (with the trailing '/'), only used in names/urls  */
+    const char *timestamp;        /* mTimeStamp, crass.cpp:476-479 ("%d_%m_%Y_%H%M%S")                                          */
+    const char *command_line;     /* mCommandLine, crass.cpp:508-512 (every argv followed by a blank)                           */
+    const char *cwd;              /* getcwd() (WorkHorse.cpp:2104)                                                              */
+    int32_t log_to_screen;        /* options::logToScreen: no <file type="log"> entry                                           */
+    int32_t cov_cutoff;           /* options::covCutoff, default 3 (crassDefines.h:126); <= 0: default                         */
+    int32_t node_kmer;            /* options::cNodeKmerLength, default 7 (crassDefines.h:111); <= 0: default                   */
+    int32_t show_singles, long_description;                       /* options::showSingles / longDescription, default 0         */
+} crass_output_opts;
+typedef struct crass_outputs crass_outputs;
+typedef struct {
+    uint32_t n_files; const char *const *name; const char *const *data; const uint64_t *size;  /* file contents in memory      */
+    uint32_t n_groups_kept; const int32_t *kept_gid;              /* the groups in crass.crispr                                 */
+    const char *stdout_text;                                      /* what crass prints to stdout in these stages                */
+} crass_outputs_view;
+int  crass_build_outputs(const crass_graph_input *in, const crass_output_opts *opts, crass_outputs **out);
+int  crass_outputs_get(const crass_outputs *o, crass_outputs_view *v);
+int  crass_outputs_write(const crass_outputs *o, const char *dir);                              /* every file into dir          */
+void crass_outputs_free(crass_outputs *o);
 
 /* raw stream handle (hipStream_t) the context launches on, for callers that time with HIP
  * events or want to order their own work (torch.cuda.ExternalStream) */

@@ -413,3 +413,24 @@ def consensus(seqs, res, params=None):
     out = ConsResult(v)
     lib().orc_consensus_free(h)
     return out
+
+
+RC_TABLE = bytes.maketrans(b"ACGTNacgtn", b"TGCANtgcan")
+
+
+def graph_groups(recs, ref, con):
+    """the hand-off of the consensus stage as crass_build_outputs / oracle/crass_graph.py take it: [(gid, true DR, [(header,
+    comment, RH_Seq, start_stops), ...])] in ascending GID, reads in WorkHorse::buildGraph's order (WorkHorse.cpp:454-505).
+    recs: tests/fastx records (name, comment, seq, qual); ref: pipeline result; con: consensus result of this module."""
+    groups = []
+    for gid, dr, toks in zip(con.gids, con.true_drs, con.groups):
+        reads = []
+        for t in toks:
+            for k in (con.reads_of[t - 2] or []):
+                i = int(ref.rec_read[k])
+                s = recs[i][2]
+                if int(con.rec_rc[k]):
+                    s = s.translate(RC_TABLE)[::-1]
+                reads.append((recs[i][0], recs[i][1], s, con.ss(k)))
+        groups.append((int(gid), dr, reads))
+    return groups

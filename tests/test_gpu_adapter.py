@@ -46,10 +46,16 @@ def parse_handoff(path):
     return out
 
 
+# the one-call device path (default), crass's three calls (--seam), and both over a group of contexts sharing the one GPU
+MODES = {"device": [], "seam": ["--seam"], "group3": ["--devices", "0,0,0", "--local-copies"],
+         "seam-group2": ["--seam", "--devices", "0,0", "--local-copies"]}
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
 @pytest.mark.parametrize("fname", ["Ill100.fx.gz", "front_offset_bug.fa.gz", "CN_gDC.fa.gz", "poor_dr_ext.fa.gz"])
-def test_cli_handoff_matches_oracle(cli, tmp_path, fname):
+def test_cli_handoff_matches_oracle(cli, tmp_path, fname, mode):
     path = os.path.join(DATA, fname)
-    r = subprocess.run([cli, "-o", str(tmp_path), path], capture_output=True, timeout=300)
+    r = subprocess.run([cli, "-o", str(tmp_path)] + MODES[mode] + [path], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     so = r.stdout.decode()
     assert "[crass_patternFinder]: Processed" in so and "[crass_clusterCore]:" in so and "[crass_singletonFinder]:" in so
@@ -103,11 +109,12 @@ def test_cli_option_validation(cli, tmp_path):
     assert open(tmp_path / "a" / "crass_hip_handoff.tsv", "rb").read() == open(tmp_path / "b" / "crass_hip_handoff.tsv", "rb").read()
 
 
-def test_cli_two_files_cross_file_headers(cli, tmp_path):
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_cli_two_files_cross_file_headers(cli, tmp_path, mode):
     """readsFound is shared across files (WorkHorse.cpp:329-393): a header found in file 1's pass 1
     suppresses recruitment of the same header in file 2."""
     f1 = os.path.join(DATA, "Ill.nr.miss.fa.gz")
-    r = subprocess.run([cli, "-o", str(tmp_path), f1, f1], capture_output=True, timeout=300)
+    r = subprocess.run([cli, "-o", str(tmp_path)] + MODES[mode] + [f1, f1], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     h = parse_handoff(os.path.join(str(tmp_path), "crass_hip_handoff.tsv"))
     recs = fastx.read_fastx(f1)
@@ -117,6 +124,12 @@ def test_cli_two_files_cross_file_headers(cli, tmp_path):
     n = sum(len(v) for v in h["reads"].values())
     assert n == ref.n_pass1 + ref.n_pass2
     assert [h["tokens"][t] for t in sorted(h["tokens"])] == ref.tokens
+    assert [h["groups"][g] for g in sorted(h["groups"])] == ref.groups and sorted(h["patterns"]) == sorted(ref.patterns)
+    got = {t: [(x["header"], x["low"], x["ss"]) for x in v] for t, v in h["reads"].items()}
+    want = collections.defaultdict(list)
+    for k in range(ref.n_pass1 + ref.n_pass2):
+        want[int(ref.rec_token[k])].append((hdrs[int(ref.rec_read[k])], int(ref.rec_lowlexi[k]), ref.ss(k)))
+    assert got == dict(want)
 
 
 def parse_consensus(path):
