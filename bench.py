@@ -330,7 +330,7 @@ def main():
     try:
         pm = _pmc_file(n, L)
         key = {"seed_scan_filter": "k_filter_fast", "survivor": "k_survivor", "recruit_scan": "k_anchor_filter"}[dom]
-        if pm.get("source_hash") == source_hash() and pm.get("reads") == n and pm.get("read_len") == L:
+        if pm and pm.get("source_hash") == source_hash() and pm.get("reads") == n and pm.get("read_len") == L:
             for k, v in pm["per_launch"].items():
                 if k.startswith(key):
                     traffic, traffic_src = v["hbm_bytes"], "profiles/%s (committed PMC passes, same kernel source hash)" % pm["_file"]

@@ -57,10 +57,12 @@ class Counters(C.Structure):
                 ("ms_pass2_total", C.c_float), ("ms_merge_host", C.c_float), ("ms_sink_host", C.c_float),
                 ("bytes_reads_device", C.c_uint64), ("anchor_keys", C.c_uint32), ("anchor_table_kind", C.c_uint32),
                 ("used_device_merge", C.c_uint32), ("ms_merge_device", C.c_float),
-                ("n_merge_fallbacks", C.c_uint32), ("last_fallback_bits", C.c_uint32)]
+                ("n_merge_fallbacks", C.c_uint32), ("last_fallback_bits", C.c_uint32), ("n_bound_overflows", C.c_uint32 * 4)]
 
     def asdict(self):
-        return {f[0]: getattr(self, f[0]) for f in self._fields_}
+        d = {f[0]: getattr(self, f[0]) for f in self._fields_}
+        d["n_bound_overflows"] = list(self.n_bound_overflows)
+        return d
 
 
 class DistinctDev(C.Structure):

@@ -13,6 +13,7 @@
 #include <memory>
 #include <unordered_map>
 #include <vector>
+#include <unistd.h>
 
 namespace crass_hip {
 
@@ -640,6 +641,66 @@ int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map 
     for (auto &kv : groupKmerCountsMap) { delete kv.second; kv.second = nullptr; }      // "delete the kmer count lists" (WorkHorse.cpp:603-607)
     crass_hip_consensus_free(h);
     return 0;
+}
+
+int buildGraphsAndOutput(ReadMap &mReads, DR_Cluster_Map &mDR2GIDMap, std::map<int, std::string> &mTrueDRs, const options &opts,
+                         const std::string &timeStamp, const std::string &commandLine)
+{
+    // buildGraph's order (WorkHorse.cpp:454-505): groups in ascending GID that have a cluster and a true DR; for every token of
+    // the cluster, the token's ReadHolders in list order
+    std::vector<int32_t> gid;
+    std::string dr, hdr, com, seq;
+    std::vector<uint64_t> dr_off(1, 0), grp_rec_off(1, 0), hdr_off(1, 0), com_off(1, 0), seq_off(1, 0), rec_ss_off;
+    std::vector<uint32_t> rec_nss, ss_pool;
+    for (auto &kv : mDR2GIDMap) {
+        if (!kv.second) continue;
+        auto td = mTrueDRs.find(kv.first);
+        if (td == mTrueDRs.end()) continue;
+        gid.push_back(kv.first);
+        dr += td->second; dr_off.push_back(dr.size());
+        for (StringToken t : *kv.second) {
+            auto it = mReads.find(t);
+            if (it == mReads.end() || !it->second) continue;
+            for (ReadHolder *h : *it->second) {
+                if (!h) continue;
+                hdr += h->RH_Header; hdr_off.push_back(hdr.size());
+                com += h->RH_Comment; com_off.push_back(com.size());
+                seq += h->RH_Seq; seq_off.push_back(seq.size());
+                rec_nss.push_back((uint32_t)h->RH_StartStops.size());
+                rec_ss_off.push_back(ss_pool.size());
+                ss_pool.insert(ss_pool.end(), h->RH_StartStops.begin(), h->RH_StartStops.end());
+            }
+        }
+        grp_rec_off.push_back(rec_nss.size());
+    }
+    if (ss_pool.empty()) ss_pool.push_back(0);
+    if (com.empty()) com.push_back('\0');
+    if (hdr.empty()) hdr.push_back('\0');
+    if (seq.empty()) seq.push_back('\0');
+    if (dr.empty()) dr.push_back('\0');
+    rec_nss.push_back(0); rec_ss_off.push_back(0); gid.push_back(0);      // (never empty arrays)
+    crass_graph_input in{};
+    in.n_groups = (uint32_t)(dr_off.size() - 1); in.gid = gid.data(); in.dr_chars = dr.data(); in.dr_off = dr_off.data();
+    in.grp_rec_off = grp_rec_off.data(); in.n_rec = hdr_off.size() - 1;
+    in.hdr_chars = hdr.data(); in.hdr_off = hdr_off.data(); in.com_chars = com.data(); in.com_off = com_off.data();
+    in.seq_chars = seq.data(); in.seq_off = seq_off.data(); in.rec_nss = rec_nss.data(); in.rec_ss_off = rec_ss_off.data(); in.ss_pool = ss_pool.data();
+    char cwd[4096];
+    if (!getcwd(cwd, sizeof cwd)) cwd[0] = 0;
+    crass_output_opts oo{};
+    oo.out_dir = opts.output_fastq.c_str(); oo.timestamp = timeStamp.c_str(); oo.command_line = commandLine.c_str(); oo.cwd = cwd;
+    oo.log_to_screen = opts.logToScreen ? 1 : 0; oo.cov_cutoff = opts.covCutoff; oo.node_kmer = opts.cNodeKmerLength;
+    oo.show_singles = opts.showSingles ? 1 : 0; oo.long_description = opts.longDescription ? 1 : 0;
+    crass_outputs *res = nullptr;
+    const int rc = crass_build_outputs(&in, &oo, &res);
+    if (rc != CRASS_OK) { std::cerr << "[ERROR]: building the spacer graphs failed: " << crass_hip_strerror(rc) << std::endl; return -1; }
+    crass_outputs_view v{};
+    (void)crass_outputs_get(res, &v);
+    std::cout << v.stdout_text << std::flush;
+    const int wrc = crass_outputs_write(res, opts.output_fastq.c_str());
+    const int n = (int)v.n_groups_kept;
+    crass_outputs_free(res);
+    if (wrc != CRASS_OK) { std::cerr << "[ERROR]: cannot write the output files to " << opts.output_fastq << std::endl; return -1; }
+    return n;
 }
 
 } // namespace crass_hip

@@ -42,7 +42,10 @@ struct options {
     int kmer_clust_size = 6;
     unsigned int searchWindowLength = 8, minNumRepeats = 2;
     bool logToScreen = false;
-    int covCutoff = 3;
+    int covCutoff = 3;                 // -f, CRASS_DEF_COVCUTOFF (crassDefines.h:126)
+    int cNodeKmerLength = 7;           // -K, CRASS_DEF_NODE_KMER_SIZE (:111)
+    bool showSingles = false;          // -G (:138)
+    bool longDescription = false;      // -L (:137)
 };
 
 typedef int StringToken;
@@ -118,6 +121,15 @@ void addReadHolder(ReadMap *mReads, StringCheck *mStringCheck, ReadHolder &tmpRe
 // Returns 0, or 1 where the reference's caller would have seen an exception (parseSeqFiles then returns 1).
 int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map &mDR2GIDMap, std::map<int, std::string> &mTrueDRs,
                      GroupKmerMap &groupKmerCountsMap, int &nextFreeGID, int mMaxReadLength, const options &opts);
+
+// Everything behind findConsensusDRs: WorkHorse::buildGraph, cleanGraph, makeSpacerGraphs,
+// cleanSpacerGraphs, splitIntoContigs, generateFlankers, removeLowConfidenceNodeManagers and outputResults
+// (WorkHorse.cpp:196-316, 454-577, 1642-1729, 1900-2249) over the hand-off state: writes <outdir>crass.crispr,
+// Group_<gid>_<DR>.fa, Spacers_<gid>_<DR>_spacers.gv and crass.<timestamp>.keys.gv (crass_build_outputs, include/crass_hip.h)
+// and prints what crass prints in these stages.  timeStamp / commandLine: WorkHorse's mTimeStamp / mCommandLine
+// (crass.cpp:476-479,508-512).  Returns the number of CRISPRs written, or -1 on error.
+int buildGraphsAndOutput(ReadMap &mReads, DR_Cluster_Map &mDR2GIDMap, std::map<int, std::string> &mTrueDRs, const options &opts,
+                         const std::string &timeStamp, const std::string &commandLine);
 
 // reads of every file searched so far stay resident on the GPU between searchFile() and
 // findSingletons(); call this once the pipeline is past the search stage.

@@ -2,10 +2,12 @@
 // MI355X engine through the adapter.  Mirrors the call sequence of WorkHorse::parseSeqFiles
 // (WorkHorse.cpp:321-414) and the stdout tags crass prints; the options are the subset of
 // crass's getopt string that the search path reads (-d -D -s -S -w -n -k -l -g -o; crass.cpp:198).
-// Instead of the downstream spacer-graph / XML stages (out of scope), it writes the hand-off —
-// every ReadHolder of mReads, the token table, the DR groups and the pattern list — as a
-// line-oriented text dump (<outdir>/crass_hip_handoff.tsv) that the parity tests diff against
-// the oracle.
+// Behind the search it runs crass's remaining stages over the hand-off — true DRs (findConsensusDRs), spacer graphs and
+// the output files of WorkHorse::outputResults: <outdir>crass.crispr, Group_<gid>_<DR>.fa, Spacers_*_spacers.gv,
+// crass.<timestamp>.keys.gv (and crass.<timestamp>.log unless -g) — so that it drops in for the crass binary.  With
+// --dump-handoff it also writes the hand-off itself — every ReadHolder of mReads, the token table, the DR groups and the
+// pattern list — as line-oriented text (<outdir>crass_hip_handoff.tsv / crass_hip_consensus.tsv) that the parity tests
+// diff against the oracle.
 #include "crass_adapter.h"
 
 #include <cstdio>
@@ -22,7 +24,8 @@ static void usage()
 {
     std::cout << "crass-hip (MI355X search stage of crass 1.0.1)\n"
                  "usage: crass-hip [-d minDR] [-D maxDR] [-s minSpacer] [-S maxSpacer] [-w window] [-n minRepeats]\n"
-                 "                 [-k kmerClust] [-l logLevel] [-g] [-o outdir] [--gpus N | --devices a,b,..] [--seam]\n"
+                 "                 [-k kmerClust] [-f covCutoff] [-K nodeKmer] [-G] [-L] [-l logLevel] [-g] [-o outdir]\n"
+                 "                 [--gpus N | --devices a,b,..] [--seam] [--dump-handoff]\n"
                  "                 <reads.f[aq][.gz]> ...\n"
                  "  --gpus N       shard the reads over GPUs 0..N-1 (one RCCL all-gather of the candidate DR strings per job)\n"
                  "  --devices L    the same with an explicit device list\n"
@@ -40,12 +43,15 @@ int main(int argc, char *argv[])
         {"kmerCount", required_argument, nullptr, 'k'}, {"logLevel", required_argument, nullptr, 'l'},
         {"logToScreen", no_argument, nullptr, 'g'}, {"outDir", required_argument, nullptr, 'o'},
         {"gpus", required_argument, nullptr, 1001}, {"devices", required_argument, nullptr, 1002}, {"seam", no_argument, nullptr, 1003},
-        {"local-copies", no_argument, nullptr, 1004},
+        {"local-copies", no_argument, nullptr, 1004}, {"dump-handoff", no_argument, nullptr, 1005}, {"timestamp", required_argument, nullptr, 1006},
+        {"covCutoff", required_argument, nullptr, 'f'}, {"kmerNodes", required_argument, nullptr, 'K'}, {"showSingltons", no_argument, nullptr, 'G'},
+        {"longDescription", no_argument, nullptr, 'L'},
         {"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
     std::vector<int> devices;
-    bool seam = false, local_copies = false;
+    bool seam = false, local_copies = false, dump_handoff = false;
+    std::string timestamp;
     int c, idx = 0;
-    while ((c = getopt_long(argc, argv, "d:D:s:S:w:n:k:l:go:h", long_options, &idx)) != -1) {
+    while ((c = getopt_long(argc, argv, "d:D:s:S:w:n:k:l:go:hf:K:GL", long_options, &idx)) != -1) {
         switch (c) {
             case 'd':
                 opts.lowDRsize = (unsigned)atoi(optarg);
@@ -105,6 +111,12 @@ int main(int argc, char *argv[])
             }
             case 1003: seam = true; break;
             case 1004: local_copies = true; break;      // (tests: several contexts on one GPU)
+            case 1005: dump_handoff = true; break;
+            case 1006: timestamp = optarg; break;       // (tests: a fixed mTimeStamp)
+            case 'f': opts.covCutoff = atoi(optarg); break;                // crass.cpp:280-282
+            case 'K': opts.cNodeKmerLength = atoi(optarg); break;          // crass.cpp:302-304
+            case 'G': opts.showSingles = true; break;
+            case 'L': opts.longDescription = true; break;
             case 'h': usage(); return 0;
             default: usage(); return 1;
         }
@@ -130,6 +142,14 @@ int main(int argc, char *argv[])
     }
     if (optind >= argc) { std::cerr << "crass [ERROR]: No input files were provided. Try ./crass-hip -h for help." << std::endl; return 1; }
     std::vector<std::string> seqFiles(argv + optind, argv + argc);
+    if (timestamp.empty()) {                    // crass.cpp:471-479
+        char buffer[80];
+        time_t rawtime; time(&rawtime);
+        strftime(buffer, 80, "%d_%m_%Y_%H%M%S", localtime(&rawtime));
+        timestamp = buffer;
+    }
+    std::string cmd_line;                       // crass.cpp:508-512
+    for (int i = 0; i < argc; ++i) { cmd_line += argv[i]; cmd_line += ' '; }
 
     ReadMap mReads;
     StringCheck mStringCheck;
@@ -175,6 +195,7 @@ int main(int argc, char *argv[])
         std::cout << "[crass_patternFinder]: Found " << n_reads << " reads" << std::endl;
 
         // ---- hand-off dump ----
+        if (dump_handoff) {
         std::ofstream out((opts.output_fastq + "crass_hip_handoff.tsv").c_str());
         out << "#max_read_length\t" << mMaxReadLength << "\n#next_free_GID\t" << next_free_GID << "\n";
         for (auto &kv : mStringCheck.mT2S_map) out << "T\t" << kv.first << "\t" << kv.second << "\n";
@@ -187,15 +208,17 @@ int main(int argc, char *argv[])
                 for (size_t i = 0; i < h->RH_StartStops.size(); i++) out << (i ? "," : "") << h->RH_StartStops[i];
                 out << "\t" << h->RH_Seq << "\t" << h->RH_Comment << "\t" << h->RH_Qual << "\n";
             }
-        delete nr;
         out.close();
         lap("hand-off dump");
+        }
+        delete nr;
         // ---- the stage behind the search: true DRs + repaired start/stops (WorkHorse.cpp:403) ----
         std::map<int, std::string> mTrueDRs;
         if (findConsensusDRs(mReads, mStringCheck, mDR2GIDMap, mTrueDRs, group_kmer_counts_map, next_free_GID, mMaxReadLength, opts)) {
             std::cerr << "[ERROR]: Wierd stuff happend when trying to get the 'true' direct repeat" << std::endl;     // WorkHorse.cpp:405
             rc = 2;
         } else {
+            if (dump_handoff) {
             std::ofstream con((opts.output_fastq + "crass_hip_consensus.tsv").c_str());
             con << "#next_free_GID\t" << next_free_GID << "\n";
             for (auto &kv : mStringCheck.mT2S_map) con << "T\t" << kv.first << "\t" << kv.second << "\n";
@@ -209,9 +232,17 @@ int main(int argc, char *argv[])
                     con << "\t" << h->RH_Seq << "\n";
                 }
             }
+            }
             std::cout << "[crass_consensus]: " << mTrueDRs.size() << " true direct repeats" << std::endl;
+            lap("findConsensusDRs + dump");
+            // ---- spacer graphs + crass's output files (WorkHorse.cpp:196-316) ----
+            if (!opts.logToScreen) {                // the log file crass.cpp:484-496 opens; <file type="log"> of the XML names it
+                std::ofstream lg((opts.output_fastq + "crass." + timestamp + ".log").c_str());
+                lg << "crass-hip (MI355X search stage) " << cmd_line << "\n" << n_reads << " reads found, " << mTrueDRs.size() << " true direct repeats\n";
+            }
+            if (buildGraphsAndOutput(mReads, mDR2GIDMap, mTrueDRs, opts, timestamp, cmd_line) < 0) rc = 2;
+            lap("spacer graphs + outputs");
         }
-        lap("findConsensusDRs + dump");
     } catch (std::exception &e) {
         std::cerr << e.what() << std::endl;
         rc = 2;            // doWork -> 2 -> process exit code 2

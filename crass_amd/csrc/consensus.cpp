@@ -778,9 +778,16 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
         lap("records, RH_Seq, upload");
         s->next_gid = (int)in->n_groups + 1;
         for (uint32_t g = 0; g < in->n_groups; g++) {
-            auto v = new std::vector<int>();
-            for (uint64_t q = in->grp_off[g]; q < in->grp_off[g + 1]; q++) v->push_back((int)in->grp_tokens[q]);
-            s->group[(int)g + 1].reset(v);
+            // a GID without tokens is a NULL entry of mDR2GIDMap (or a key missing from groupKmerCountsMap): the reference
+            // `continue`s over it (WorkHorse.cpp:592-595), so it must not become an (empty) group here
+            if (in->grp_off[g + 1] < in->grp_off[g]) return CRASS_ERR_INVALID_ARG;
+            if (in->grp_off[g + 1] == in->grp_off[g]) continue;
+            std::unique_ptr<std::vector<int>> v(new std::vector<int>());
+            for (uint64_t q = in->grp_off[g]; q < in->grp_off[g + 1]; q++) {
+                if (in->grp_tokens[q] < 2 || in->grp_tokens[q] > in->n_tokens + 1) return CRASS_ERR_INVALID_ARG;      // indexes s->tok[tok - 2]
+                v->push_back((int)in->grp_tokens[q]);
+            }
+            s->group[(int)g + 1] = std::move(v);
         }
         // ---- findConsensusDRs (WorkHorse.cpp:578-611): the ORIGINAL groups in ascending GID order ----
         { const int ps = prealign_original_groups(s, (int)in->n_groups); if (ps) return ps; }

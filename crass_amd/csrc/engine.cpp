@@ -65,11 +65,12 @@ public:
             if (!(busy_ && job_)) return false;
             job = std::move(job_); job_ = nullptr;          // the helper's wait predicate (busy_ && job_) stays false: it sleeps on
         }
-        job();
+        try { job(); } catch (...) { failed_.store(true, std::memory_order_relaxed); }      // (the job records its own status; this only keeps busy_ honest)
         { std::lock_guard<std::mutex> lk(m_); busy_ = false; }
         cv_.notify_all();
         return true;
     }
+    bool take_failed() { return failed_.exchange(false, std::memory_order_relaxed); }
     void stop()
     {
         if (!started_) return;
@@ -90,11 +91,12 @@ private:
                 if (quit_) return;
                 job = std::move(job_); job_ = nullptr;
             }
-            job();
+            try { job(); } catch (...) { failed_.store(true, std::memory_order_relaxed); }
             { std::lock_guard<std::mutex> lk(m_); busy_ = false; }
             cv_.notify_all();
         }
     }
+    std::atomic<bool> failed_{false};
     std::thread th_;
     std::mutex m_;
     std::condition_variable cv_;
@@ -164,6 +166,8 @@ struct EnvSwitches {
     bool no_lookback = false, no_pos_hints = false, merge_profile = false, no_lane_kernel = false;
     bool host_merge = false, no_speculation = false, exc_separate = false, dm_inject_fail = false, dm_init_late = false;
     bool no_presize = false;                         // A/B switch: no first-call bounds / pool sizing at crass_hip_load_reads
+    uint64_t test_bounds[4] = {0, 0, 0, 0};          // tests: CRASS_TEST_BOUNDS="survivors,distinct,flagged,gathered" replaces the
+                                                     // first-call bounds (0 = computed), so that every overflow path can be forced
     uint32_t row_cap = 1024, dm_group_cap = 16384, surv_debug = 0;
     int stage_timing = -1;
     uint64_t pool_cap_bytes = 0;                     // tests: device allocations beyond this total fail with hipErrorOutOfMemory
@@ -178,6 +182,8 @@ struct EnvSwitches {
         dm_group_cap = 16384; if (const char *e = getenv("CRASS_DM_GROUP_CAP")) dm_group_cap = (uint32_t)std::max(1, atoi(e));
         surv_debug = 0; if (const char *e = getenv("CRASS_SURV_DEBUG")) surv_debug = (uint32_t)atoi(e);
         stage_timing = -1; if (const char *e = getenv("CRASS_STAGE_TIMING")) stage_timing = std::min(2, std::max(0, atoi(e)));
+        for (auto &b : test_bounds) b = 0;
+        if (const char *e = getenv("CRASS_TEST_BOUNDS")) { int k = 0; for (const char *q = e; *q && k < 4; k++) { test_bounds[k] = (uint64_t)atoll(q); while (*q && *q != ',') q++; if (*q == ',') q++; } }
         pool_cap_bytes = 0; if (const char *e = getenv("CRASS_POOL_CAP_MB")) pool_cap_bytes = (uint64_t)std::max(1ll, atoll(e)) << 20;
     }
 };
@@ -326,6 +332,10 @@ struct crass_hip_ctx {
         bool active = false, host_built = false;
         int build_status = 0;                       // result of the host-view build that runs on `worker`
         bool build_pending = false;
+        // what the build found out, written by whichever thread runs it and copied into the context's own fields
+        // (n_installed_patterns, cnt.*, last_hip) by the CALLING thread once the build is known to be over (apply_build_result):
+        // the helper thread never writes a field the caller may read without waiting for it
+        struct BuildResult { bool valid = false; uint32_t n_patterns = 0, n_keys = 0; float ms_device = 0; int hip = 0; } br;
         uint64_t n_cand = 0;
         // what the host view is rebuilt from: the distinct list (pinned host copy) and every own candidate's index in it
         const char *hx_chars = nullptr; const uint16_t *hx_len = nullptr; uint64_t n_tok = 0;
@@ -379,6 +389,7 @@ struct crass_hip_ctx {
 
     crass_counters cnt{};
     uint32_t n_merge_fallbacks = 0, last_fallback_bits = 0;
+    uint32_t n_bound_overflows[4] = {0, 0, 0, 0};   // speculation bounds that turned out too small (stage repeated): survivors, distinct, flagged, gathered
     hipEvent_t ev[12]{};
     // stage timing (crass_hip_set_stage_timing): an event record costs ~6 us of stream time, 14 of them 8 % of a 1 ms step.
     // 0 none, 1 the three large kernels only (seed scan, survivors, pass-2 scan), 2 every stage
@@ -413,6 +424,21 @@ struct crass_hip_ctx {
         out->status = lb_status.p; out->ticket = lb_ticket.p; out->ticket_base = lb_base; out->epoch = lb_epoch; out->fail = h_lb_fail.p;
         lb_base += (uint32_t)n_tiles;
         return out;
+    }
+    // allocation only (crass_hip_load_reads): hands out no tickets — a launch that never runs must not move the ticket base
+    void prealloc_lookback(uint64_t n_tiles)
+    {
+        if (!lb_on || n_tiles == 0 || n_tiles > (1u << 24)) return;
+        if (!lb_status.p || lb_status.n < n_tiles) {
+            if (lb_status.ensure(std::max<uint64_t>(n_tiles * 2, 4096)) != hipSuccess) return;
+            if (hipMemsetAsync(lb_status.p, 0, lb_status.n * 8, stream) != hipSuccess) return;
+            // (a re-allocated status array starts a new life: epochs of the old one mean nothing in it)
+        }
+        if (!lb_ticket.p) {
+            if (lb_ticket.ensure(4) != hipSuccess || h_lb_fail.ensure(4) != hipSuccess) return;
+            if (hipMemsetAsync(lb_ticket.p, 0, 16, stream) != hipSuccess) return;
+            h_lb_fail.p[0] = 0; lb_base = 0;
+        }
     }
     // after a synchronisation: a look-back spin that gave up invalidates the stage (never expected)
     int lookback_ok()
@@ -481,7 +507,13 @@ void crass_hip_ctx::widen_p1() const
 // the helper thread owns c->merge while a host-view build is in flight: wait for it before touching that state
 static void quiesce_worker(crass_hip_ctx *c)
 {
-    if (c->dm.build_pending) { if (!c->worker.run_here_if_not_started()) c->worker.wait(); c->dm.build_pending = false; }
+    if (c->dm.build_pending) {
+        if (!c->worker.run_here_if_not_started()) c->worker.wait();
+        c->dm.build_pending = false;
+        (void)c->worker.take_failed();
+        c->dm.br.valid = false;                         // (results of a build nobody asked for any more)
+        if (c->dm.br.hip) { c->last_hip = c->dm.br.hip; c->dm.br.hip = 0; }
+    }
 }
 
 #define HIPCHK(ctx, call)                                                       \
@@ -646,7 +678,9 @@ static int validate_reads(const crass_reads *r)
 static int alloc_scratch(crass_hip_ctx *c)
 {
     const uint64_t n = c->R.n_reads;
-    const uint64_t n_words = (n + 63) / 64;
+    // (the mask / prefix scratch also serves compactions over survivor and hit SLOTS, whose launches are sized by bounds of
+    // at least 65 536 / 4 096 slots whatever the read count: never smaller than that many bits)
+    const uint64_t n_words = std::max<uint64_t>((n + 63) / 64, 1024);
     HIPCHK(c, c->d_mask.ensure(n_words + 1));
     HIPCHK(c, c->d_word_prefix.ensure(n_words + 1));
     HIPCHK(c, c->d_block_sums.ensure((n_words + 255) / 256 + 2));
@@ -1113,6 +1147,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
                 c->n_dx = c->h_count.p[4];
                 c->have_dev_tokens = true;
                 if (premerge_queued && c->n_dx > 0 && c->n_dx <= c->dx_cap_hint) c->premerge = 2;
+                else if (premerge_queued && c->n_dx > c->dx_cap_hint) c->n_bound_overflows[1]++;     // (crass_hip_merge launches its own)
             } else {
                 // (hash collision among the candidates: the host merge wants the first-occurrence map)
                 HIPCHK(c, D.h_dr_fb.ensure(nf * stride + 16)); HIPCHK(c, D.h_dr_len_fb.ensure(nf + 8));
@@ -1180,6 +1215,7 @@ static int first_call_bounds(crass_hip_ctx *c)
     if (rate > 1.0) rate = 1.0;
     uint64_t surv = survivor_bound((uint64_t)((double)n * rate));
     if (surv > n + 65536) surv = survivor_bound(n * 2 / 3);       // (1.5 x inside: the bound never needs to exceed n)
+    if (c->env.test_bounds[0]) surv = std::max<uint64_t>(64, c->env.test_bounds[0]);
     const uint64_t pool_cap = std::max<uint64_t>(surv * (uint64_t)lds.ss_cap, 1u << 16);
     if (surv > kDenseMaxSurvivors || pool_cap >= (1ull << 31)) return CRASS_OK;
     // keep the pools a small part of the device: ~(20 + 2*stride + 4*ss_cap + 100) bytes per survivor slot
@@ -1192,18 +1228,20 @@ static int first_call_bounds(crass_hip_ctx *c)
     if (s) return s;
     c->surv_cap_hint = surv;
     // look-back status words for the largest launch of a step (the masks over all reads), cleared once
-    { Lookback lb; (void)c->next_lookback((n + 63) / 64, &lb); (void)c->next_lookback_elems(surv, &lb); }
+    { const uint64_t nw = (n + 63) / 64; c->prealloc_lookback(std::max<uint64_t>((nw + lookback_tile_words(nw) - 1) / lookback_tile_words(nw), (surv + 1023) / 1024)); }
     // distinct DR strings: a few hundred per million reads on metagenome-like input; the device merge is queued
     // behind pass 1 for this many
     if (dedupe && c->prm.lowDRsize >= 23 && c->dr_stride <= 64 && !c->env.host_merge) {
-        const uint64_t dx = std::min<uint64_t>(1u << 20, std::max<uint64_t>(16384, (n / 1024 + 4095) & ~4095ull));
+        uint64_t dx = std::min<uint64_t>(1u << 20, std::max<uint64_t>(16384, (n / 1024 + 4095) & ~4095ull));
+        if (c->env.test_bounds[1]) dx = std::max<uint64_t>(16, c->env.test_bounds[1]);
         s = device_merge_prepare(c, c->dd_dx_chars.p, c->dd_dx_len.p, dx, c->d_count.p + 4);
         if (s) return s;
         c->dx_cap_hint = (uint32_t)dx;
         c->dm_prev_local = true;
     }
     // reads flagged by the anchor probe: reads of arrays that pass 1 did not find (+ ~0 false positives)
-    const uint64_t hits = hit_bound(n / 64);
+    uint64_t hits = hit_bound(n / 64);
+    if (c->env.test_bounds[2]) hits = std::max<uint64_t>(16, c->env.test_bounds[2]);
     s = ensure_recruit_buffers(c, hits, 0, true, true);
     if (s) return s;
     c->hit_cap_hint = hits;
@@ -1275,6 +1313,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
         if (s == CRASS_OK) {
             n_surv = c->h_count.p[0];
+            if (overflow) c->n_bound_overflows[0]++;
             if (overflow || n_surv == 0) {              // redo below with the exact count; undo the attempt's found flags
                 c->dense.active = false;
                 s = CRASS_ERR_STATE;
@@ -1580,11 +1619,19 @@ static int device_merge_commit(crass_hip_ctx *c, uint64_t n_tok, const char *hx_
     d.hx_chars = hx_chars; d.hx_len = hx_len; d.n_tok = n_tok;
     d.active = true; d.host_built = false; d.n_cand = c->dense.n;
     // the host view (tokens, groups, pattern list) is rebuilt by the helper thread as soon as the kernels are through
-    d.build_pending = true;
-    c->worker.submit([c] { c->dm.build_status = build_host_merge(c); });
+    // every field of the caller's side is set BEFORE the job is handed over: from submit() on, the helper thread owns
+    // c->merge and dm.br until ensure_host_merge / quiesce_worker has waited for it
     c->have_merge = true; c->have_pass2 = false;
     c->have_patterns = true; c->have_anchors = false; c->have_pat_token = false;
     c->n_installed_patterns = 2;                                  // >= 1 survivor exists; the exact count arrives with h_st
+    d.br = crass_hip_ctx::DM::BuildResult();
+    d.build_status = CRASS_OK;
+    d.build_pending = true;
+    c->worker.submit([c] {
+        int st;
+        try { st = build_host_merge(c); } catch (const std::bad_alloc &) { st = CRASS_ERR_OOM; } catch (...) { st = CRASS_ERR_STATE; }
+        c->dm.build_status = st;
+    });
     return CRASS_OK;
 }
 
@@ -1627,6 +1674,7 @@ static int host_merge_fallback(crass_hip_ctx *c)
 
 // c->merge for a merge that ran on the device: 0 ok, CRASS_ERR_STATE = the device path failed (caller falls back)
 static int build_host_merge(crass_hip_ctx *c);
+static void apply_build_result(crass_hip_ctx *c);
 
 static int ensure_host_merge(crass_hip_ctx *c)
 {
@@ -1634,12 +1682,30 @@ static int ensure_host_merge(crass_hip_ctx *c)
     if (d.build_pending) {                              // started by the merge call on the helper thread
         if (!c->worker.run_here_if_not_started()) c->worker.wait();
         d.build_pending = false;
+        if (c->worker.take_failed()) d.build_status = CRASS_ERR_OOM;        // (the job threw: std::bad_alloc is the one thing it can throw)
+        apply_build_result(c);
         if (d.build_status == CRASS_ERR_HIP || d.build_status == CRASS_ERR_OOM) return d.build_status;
         if (d.build_status == CRASS_ERR_STATE) return CRASS_ERR_STATE;
     }
-    return build_host_merge(c);
+    const int s = build_host_merge(c);
+    apply_build_result(c);
+    return s;
 }
 
+static void apply_build_result(crass_hip_ctx *c)
+{
+    crass_hip_ctx::DM::BuildResult &b = c->dm.br;
+    if (b.hip) { c->last_hip = b.hip; b.hip = 0; }
+    if (!b.valid) return;
+    b.valid = false;
+    c->n_installed_patterns = b.n_patterns;
+    c->cnt.n_patterns = b.n_patterns;
+    c->cnt.ac_states = 0;
+    c->cnt.anchor_keys = b.n_keys;
+    c->cnt.ms_merge_device = b.ms_device;
+}
+
+// runs on the helper thread OR on the caller's (never both at once): touches c->merge and dm.br only
 static int build_host_merge(crass_hip_ctx *c)
 {
     crass_hip_ctx::DM &d = c->dm;
@@ -1648,6 +1714,18 @@ static int build_host_merge(crass_hip_ctx *c)
         static thread_local int tl_device = -1;
         if (tl_device != c->device) { (void)hipSetDevice(c->device); tl_device = c->device; }
     }
+    auto wait_done = [&]() -> int {
+        const hipError_t e = hipEventSynchronize(d.ev_done);
+        if (e != hipSuccess) { d.br.hip = (int)e; return e == hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP; }
+        return CRASS_OK;
+    };
+    auto publish = [&]() {
+        d.br.n_patterns = d.h_st.p->n_patterns; d.br.n_keys = d.h_st.p->n_keys;
+        float ms = 0;
+        if (c->timing_level >= 2) (void)hipEventElapsedTime(&ms, d.ev_t0, d.ev_t1);
+        d.br.ms_device = ms;
+        d.br.valid = true;
+    };
     // local merge: the token strings and the candidates' tokens only need pass 1's outputs, which the host has
     // already waited for — that half of the host view is built while the merge kernels are still running
     // (the gathered form too: the global distinct list and every gathered row's rank in it were written to pinned memory
@@ -1668,18 +1746,17 @@ static int build_host_merge(crass_hip_ctx *c)
             if (cmap[k] >= d.n_tok) { c->merge.clear(); return CRASS_ERR_STATE; }
             c->merge.cand_token[k] = cmap[k] + 2;
         }
-        HIPCHK(c, hipEventSynchronize(d.ev_done));
+        if (const int ws = wait_done()) return ws;
         if (d.h_st.p->fail) return CRASS_ERR_STATE;
         d.host_built = true;
-        c->n_installed_patterns = d.h_st.p->n_patterns;
-        c->cnt.n_patterns = d.h_st.p->n_patterns; c->cnt.ac_states = 0; c->cnt.anchor_keys = d.h_st.p->n_keys;
-        c->cnt.ms_merge_device = 0;
+        publish();
+        d.br.ms_device = 0;
         return CRASS_OK;
     }
     if (!merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand)) return CRASS_ERR_STATE;
     host_pool_warm();                                   // the second half fans out over the pool: wake it while the device is busy
     const double tb0 = now_ms();
-    HIPCHK(c, hipEventSynchronize(d.ev_done));
+    if (const int ws = wait_done()) return ws;
     const double tb1 = now_ms();
     if (d.h_st.p->fail) return CRASS_ERR_STATE;
     if (!merge_from_device_finish_roots(c->merge, d.h_root.p, d.h_blank.p, d.gid_tmp) ||
@@ -1689,13 +1766,7 @@ static int build_host_merge(crass_hip_ctx *c)
     if (c->env.merge_profile)
         fprintf(stderr, "[crass_dm] helper: first half %.1f us, waited %.1f us for the merge kernels, second half %.1f us (done %.1f us after the pass-1 sync)\n",
                 1e3 * (tb0 - tb00), 1e3 * (tb1 - tb0), 1e3 * (now_ms() - tb1), 1e3 * (now_ms() - c->t_p1_sync));
-    c->n_installed_patterns = d.h_st.p->n_patterns;
-    c->cnt.n_patterns = d.h_st.p->n_patterns;
-    c->cnt.ac_states = 0;
-    c->cnt.anchor_keys = d.h_st.p->n_keys;
-    float ms = 0;
-    if (c->timing_level >= 2) (void)hipEventElapsedTime(&ms, d.ev_t0, d.ev_t1);
-    c->cnt.ms_merge_device = ms;
+    publish();
     return CRASS_OK;
 }
 
@@ -1924,7 +1995,8 @@ int crass_hip_exchange_setup(crass_hip_ctx *c, uint32_t world, uint32_t rank, ui
     if (c->have_reads && c->surv_cap_hint && c->dx_cap_hint && !c->env.no_presize && !c->env.no_speculation) {
         const uint64_t n_max = (uint64_t)world * cap_rows;
         const uint64_t n_job = (uint64_t)world * c->R.n_reads;
-        const uint64_t gx = std::min<uint64_t>(std::min<uint64_t>(n_max, 1u << 20), std::max<uint64_t>(16384, (n_job / 1024 + 4095) & ~4095ull));
+        uint64_t gx = std::min<uint64_t>(std::min<uint64_t>(n_max, 1u << 20), std::max<uint64_t>(16384, (n_job / 1024 + 4095) & ~4095ull));
+        if (c->env.test_bounds[3]) gx = std::min<uint64_t>(n_max, std::max<uint64_t>(16, c->env.test_bounds[3]));
         if (n_max <= (1u << 22)) {
             int s = ensure_gathered_buffers(c, n_max);
             if (s) return s;
@@ -1989,6 +2061,7 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     if (dev && n_global && c->h_count.p[5] == 0 && c->h_count.p[4] != 0 && c->h_count.p[4] <= (1u << 20) && my_off + c->n_dx <= n_global) {
         d.global = true; d.my_off = my_off; d.n_global = n_global;
         const uint32_t n_tok = c->h_count.p[4];
+        if (queued && n_tok > X.gx_cap_hint) c->n_bound_overflows[3]++;
         const int s = (queued && n_tok <= X.gx_cap_hint) ? device_merge_commit(c, n_tok, d.h_gx_chars.p, d.h_gx_len.p)
                                                          : device_merge(c, d.gx_chars.p, d.gx_len.p, n_tok, d.h_gx_chars.p, d.h_gx_len.p);
         if (s == CRASS_OK) {
@@ -2202,6 +2275,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
                 return crass_hip_recruit(c, extra_found, n_extra);
             }
             if (c->h_count.p[0] > n_hits) {             // bound too small: repeat with the exact count
+                c->n_bound_overflows[2]++;
                 c->hit_cap_hint = 0;
                 c->recruit_exact = true;
                 return crass_hip_recruit(c, extra_found, n_extra);
@@ -2368,6 +2442,7 @@ int crass_hip_get_counters(const crass_hip_ctx *c, crass_counters *o)
     *o = c->cnt;
     o->n_merge_fallbacks = c->n_merge_fallbacks;
     o->last_fallback_bits = c->last_fallback_bits;
+    for (int k = 0; k < 4; k++) o->n_bound_overflows[k] = c->n_bound_overflows[k];
     return CRASS_OK;
 }
 

@@ -287,6 +287,10 @@ typedef struct {
     uint32_t n_merge_fallbacks;     /* since crass_hip_create: device merges that gave up (key set beyond the table,
                                        cuckoo insertion, a wait that timed out, ...) and were redone on the host     */
     uint32_t last_fallback_bits;    /* the device merge's `fail` word of the last such case (0: none so far)         */
+    uint32_t n_bound_overflows[4];  /* since crass_hip_create: stages repeated because a speculation bound (sized from the read
+                                       set at load, or learnt from the previous call) was too small: [0] seed-scan survivors,
+                                       [1] distinct DR strings (queued merge), [2] reads flagged in pass 2, [3] gathered
+                                       distinct strings (multi-rank).  Results are unaffected; each is one repeated stage.  */
 } crass_counters;
 int crass_hip_get_counters(const crass_hip_ctx *ctx, crass_counters *out);
 

@@ -932,6 +932,8 @@ orc_cons *orc_consensus_run(const orc_cons_input *in, const orc_params *p)
     s->next_gid = (int)in->n_groups + 1;
     grow_groups(s, s->next_gid + 8);
     for (uint32_t g = 0; g < in->n_groups; g++) {
+        /* a GID without tokens = a NULL entry of mDR2GIDMap: the reference `continue`s over it (WorkHorse.cpp:592-595) */
+        if (in->grp_off[g + 1] == in->grp_off[g]) continue;
         s->group[g + 1] = iv_new();
         for (uint64_t q = in->grp_off[g]; q < in->grp_off[g + 1]; q++) iv_push(s->group[g + 1], (int)in->grp_tokens[q]);
     }

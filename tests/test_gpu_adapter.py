@@ -55,7 +55,7 @@ MODES = {"device": [], "seam": ["--seam"], "group3": ["--devices", "0,0,0", "--l
 @pytest.mark.parametrize("fname", ["Ill100.fx.gz", "front_offset_bug.fa.gz", "CN_gDC.fa.gz", "poor_dr_ext.fa.gz"])
 def test_cli_handoff_matches_oracle(cli, tmp_path, fname, mode):
     path = os.path.join(DATA, fname)
-    r = subprocess.run([cli, "-o", str(tmp_path)] + MODES[mode] + [path], capture_output=True, timeout=300)
+    r = subprocess.run([cli, "--dump-handoff", "-o", str(tmp_path)] + MODES[mode] + [path], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     so = r.stdout.decode()
     assert "[crass_patternFinder]: Processed" in so and "[crass_clusterCore]:" in so and "[crass_singletonFinder]:" in so
@@ -103,8 +103,8 @@ def test_cli_option_validation(cli, tmp_path):
     # -d 8 -w 9 passes the reference's own validation but leaves its seed stride undefined (unsigned wrap, libcrispr.cpp:281):
     # warned about and clamped to 2w - 1 = 17; the run then equals an explicit -d 17 -w 9 run
     (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
-    ra = subprocess.run([cli, "-d", "8", "-w", "9", "-o", str(tmp_path / "a"), path], capture_output=True, timeout=300)
-    rb = subprocess.run([cli, "-d", "17", "-w", "9", "-o", str(tmp_path / "b"), path], capture_output=True, timeout=300)
+    ra = subprocess.run([cli, "--dump-handoff", "-d", "8", "-w", "9", "-o", str(tmp_path / "a"), path], capture_output=True, timeout=300)
+    rb = subprocess.run([cli, "--dump-handoff", "-d", "17", "-w", "9", "-o", str(tmp_path / "b"), path], capture_output=True, timeout=300)
     assert ra.returncode == 0 and rb.returncode == 0 and b"changing to 17" in ra.stderr and b"changing to" not in rb.stderr
     assert open(tmp_path / "a" / "crass_hip_handoff.tsv", "rb").read() == open(tmp_path / "b" / "crass_hip_handoff.tsv", "rb").read()
 
@@ -114,7 +114,7 @@ def test_cli_two_files_cross_file_headers(cli, tmp_path, mode):
     """readsFound is shared across files (WorkHorse.cpp:329-393): a header found in file 1's pass 1
     suppresses recruitment of the same header in file 2."""
     f1 = os.path.join(DATA, "Ill.nr.miss.fa.gz")
-    r = subprocess.run([cli, "-o", str(tmp_path)] + MODES[mode] + [f1, f1], capture_output=True, timeout=300)
+    r = subprocess.run([cli, "--dump-handoff", "-o", str(tmp_path)] + MODES[mode] + [f1, f1], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     h = parse_handoff(os.path.join(str(tmp_path), "crass_hip_handoff.tsv"))
     recs = fastx.read_fastx(f1)
@@ -156,7 +156,7 @@ def test_cli_consensus_matches_oracle(cli, tmp_path, fname):
     """findConsensusDRs through the adapter (the reference's function shape over crass_hip_consensus): true DRs, groups,
     tokens and every surviving ReadHolder (orientation, repaired start/stops, sequence) against the oracle"""
     path = os.path.join(DATA, fname)
-    r = subprocess.run([cli, "-o", str(tmp_path), path], capture_output=True, timeout=300)
+    r = subprocess.run([cli, "--dump-handoff", "-o", str(tmp_path), path], capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     h = parse_consensus(os.path.join(str(tmp_path), "crass_hip_consensus.tsv"))
     recs = fastx.read_fastx(path)
@@ -176,3 +176,33 @@ def test_cli_consensus_matches_oracle(cli, tmp_path, fname):
             rc = int(con.rec_rc[k])
             want[t + 2].append(dict(header=hdrs[i], low=1 - rc, ss=con.ss(k), seq=seqs[i].translate(RC)[::-1] if rc else seqs[i]))
     assert {t: v for t, v in h["reads"].items() if v} == {t: v for t, v in want.items() if v}
+
+
+@pytest.mark.parametrize("log_to_screen", [True, False])
+@pytest.mark.parametrize("fname", ["Ill100.fx.gz", "front_offset_bug.fa.gz", "CN_gDC.fa.gz", "poor_dr_ext.fa.gz", "Ill.nr.miss.fa.gz"])
+def test_cli_writes_crass_outputs_equal_to_the_oracle(cli, tmp_path, fname, log_to_screen):
+    """SURVEY 8f rows f-4 / f-3 end to end: `crass-hip -o dir reads` leaves crass.crispr, Group_<gid>_<DR>.fa, the spacer graph
+    files and the key file in dir — byte for byte what oracle/crass_graph.py derives from the oracle's search + consensus"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import crass_graph as cg
+    path = os.path.join(DATA, fname)
+    out = str(tmp_path / "o") + "/"
+    os.mkdir(out)
+    stamp = "03_10_2026_101500"
+    cmd = [cli, "--timestamp", stamp, "-o", out] + (["-g"] if log_to_screen else []) + [path]
+    r = subprocess.run(cmd, capture_output=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()
+    recs = fastx.read_fastx(path)
+    seqs, hdrs = [x[2] for x in recs], [x[0] for x in recs]
+    ref = orc.pipeline(seqs, hdrs)
+    con = orc.consensus(seqs, ref)
+    groups = orc.graph_groups(recs, ref, con)
+    want = cg.run([(g, d, [cg.Read(*x) for x in rs]) for g, d, rs in groups], outdir=out, timestamp=stamp, cmdline=" ".join(cmd) + " ",
+                  cwd=str(tmp_path), log_to_screen=log_to_screen)
+    got = {f: open(os.path.join(out, f), "rb").read() for f in os.listdir(out) if not f.endswith(".log")}
+    assert sorted(got) == sorted(want["files"])
+    for f in got:
+        assert got[f] == want["files"][f], f
+    assert ("[crass_graphBuilder]: %d CRISPRs found!" % len(want["kept"])) in r.stdout.decode()
+    assert os.path.exists(os.path.join(out, "crass.%s.log" % stamp)) == (not log_to_screen)

@@ -113,3 +113,20 @@ def test_reads_with_n_and_reversed_slaves(ca):
     ref = orc.consensus(seqs, orc.pipeline(seqs))
     assert_same_consensus(gpu, ref)
     assert gpu.n_tokens >= search.n_tokens
+
+
+def test_a_gid_without_a_group_is_skipped_and_bad_tokens_are_refused(ca):
+    """a NULL entry of mDR2GIDMap (empty token range) is no group (WorkHorse.cpp:592-595); a group token outside the token table
+    is an invalid argument, not an out-of-bounds read"""
+    from tests.test_oracle_consensus import WithGap
+    recs = fastx.read_fastx(os.path.join(DATA, "front_offset_bug.fa.gz"))
+    seqs, hdrs = [r[2] for r in recs], [r[0] for r in recs]
+    search = ca.search_pipeline(seqs, hdrs)
+    gap = WithGap(search)
+    assert_same_consensus(ca.consensus(seqs, gap), orc.consensus(seqs, WithGap(orc.pipeline(seqs, hdrs))))
+    bad = WithGap(search)
+    bad.groups = [list(g) for g in search.groups]
+    bad.groups[0][0] = len(search.tokens) + 5
+    with pytest.raises(ca.CrassError) as e:
+        ca.consensus(seqs, bad)
+    assert e.value.status == 1

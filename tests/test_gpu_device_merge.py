@@ -155,6 +155,32 @@ def test_speculative_survivor_bound_overflow(ca):
     assert_same_pipeline(d, orc.pipeline(small))
 
 
+@pytest.mark.parametrize("which,bounds", [(0, "64,0,0,0"), (1, "0,16,0,0"), (2, "0,0,16,0")])
+def test_every_first_call_bound_overflows_cleanly(ca, which, bounds):
+    """crass_hip_load_reads sets the three speculation bounds of a context's FIRST call from the read set; each one too
+    small must be detected on the device, the stage repeated with the exact count, and the result unchanged
+    (CRASS_TEST_BOUNDS forces tiny bounds; crass_counters.n_bound_overflows says which repeat happened)"""
+    seqs = synth_reads(ca, 60000, read_len=150, n_dr=40, crispr_per_million=60000)
+    ref = orc.pipeline(seqs)
+    os.environ["CRASS_TEST_BOUNDS"] = bounds
+    try:
+        eng = ca.SearchEngine()
+        try:
+            a = ca.search_pipeline(seqs, engine=eng)
+            b = ca.search_pipeline(seqs, engine=eng)        # (the load sets the tiny bounds again)
+        finally:
+            eng.close()
+    finally:
+        os.environ.pop("CRASS_TEST_BOUNDS", None)
+    assert_same_pipeline(a, ref)
+    assert_same_pipeline(b, ref)
+    assert b.counters["n_bound_overflows"][which] >= 2 and b.counters["n_merge_fallbacks"] == 0
+    # and without the hook no bound overflows on this input: the first call is speculative end to end
+    c = ca.search_pipeline(seqs)
+    assert c.counters["n_bound_overflows"] == [0, 0, 0, 0] and c.counters["used_device_merge"] == 1
+    assert_same_pipeline(c, ref)
+
+
 def test_exception_reads_stay_on_the_device_path(ca):
     """Reads with non-ACGT bytes: screened on their packed words (a non-ACGT byte packs as 'A': still a superset),
     evaluated byte-wise in pass 1, and — the pattern set being pure ACGT — filtered and verified on the device in

@@ -102,6 +102,19 @@ def test_group_exchange_overflow_grows_the_buffers(ca):
     assert_same_pipeline(grp, orc.pipeline(seqs))
 
 
+def test_group_gathered_bound_overflow(ca):
+    """the bound for the GLOBAL distinct list (merge queued behind the exchange's de-duplication) too small: the merge is
+    launched again with the exact count, same result"""
+    seqs = synth_reads(ca, 60000, read_len=150, n_dr=40, crispr_per_million=60000)
+    os.environ["CRASS_TEST_BOUNDS"] = "0,0,0,16"
+    try:
+        grp = ca.search_pipeline_group(seqs, [0, 0], local_copies=True)
+    finally:
+        os.environ.pop("CRASS_TEST_BOUNDS", None)
+    assert_same_pipeline(grp, orc.pipeline(seqs))
+    assert all(c["n_bound_overflows"][3] >= 1 for c in grp.counters)
+
+
 def test_group_with_an_empty_shard_and_with_no_candidates(ca):
     seqs = synth_reads(ca, 3, read_len=150, crispr_per_million=1000000)
     grp = ca.search_pipeline_group(seqs, [0] * 4, local_copies=True)          # 4 ranks, 3 reads

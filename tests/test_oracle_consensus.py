@@ -108,3 +108,22 @@ def test_other_reference_inputs_run_clean(fname):
     seqs, hdrs = [r[2] for r in recs], [r[0] for r in recs]
     con = orc.consensus(seqs, orc.pipeline(seqs, hdrs))
     assert con.error == 0 and len(con.gids) >= 1
+
+
+class WithGap:
+    """a search result whose mDR2GIDMap has a NULL entry at GID 1 (every original group moves up by one)"""
+
+    def __init__(self, res):
+        self.__dict__.update(res.__dict__)
+        self.groups = [[]] + [list(g) for g in res.groups]
+
+
+def test_a_gid_without_a_group_is_skipped():
+    """WorkHorse::findConsensusDRs `continue`s over a NULL group (WorkHorse.cpp:592-595): same true DRs one GID higher"""
+    recs = fastx.read_fastx(os.path.join(DATA, "front_offset_bug.fa.gz"))
+    seqs, hdrs = [r[2] for r in recs], [r[0] for r in recs]
+    res = orc.pipeline(seqs, hdrs)
+    a, b = orc.consensus(seqs, res), orc.consensus(seqs, WithGap(res))
+    assert a.error == 0 and b.error == 0
+    assert b.gids == [g + 1 for g in a.gids] and b.true_drs == a.true_drs and b.groups == a.groups
+    assert b.next_free_gid == a.next_free_gid + 1
