@@ -127,6 +127,11 @@ def main():
     group_mode = args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.launcher == "group"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not group_mode:
         spawn_ranks(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "CRASS_HOST_THREADS" not in os.environ:
+        # one process per GPU: the job's host view (tokens, groups, patterns) is built by rank 0 alone (set_host_view below), so
+        # rank 0 takes the host-pool threads the node's CPU quota leaves and the other ranks take none
+        w, r = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0"))
+        os.environ["CRASS_HOST_THREADS"] = "1" if r > 0 else str(max(2, min(16, int(_cpu_quota() * 0.5) - (w - 1))))
     import numpy as np
     import torch
     import crass_amd as ca
@@ -201,6 +206,10 @@ def main():
     if world > 1 and args.dist_backend == "nccl":
         from crass_amd.distributed import GatheredExchange
         xg = GatheredExchange(eng, dist, coll_dev)          # one RCCL all-gather of fixed-size device buffers per step
+        if rank > 0:
+            # tokens, groups and the pattern list are identical on every rank: the job's host view is rank 0's; the other
+            # ranks keep their own candidates' tokens only (as the ranks of a crass_hip_group do)
+            eng.set_host_view(1)
 
     def step(e=eng):
         if isinstance(e, _GroupRunner):
@@ -549,6 +558,17 @@ def _pmc_file(n, L):
             pm["_file"] = os.path.basename(f)
             return pm
     return None
+
+
+def _cpu_quota():
+    """CPUs the cgroup quota gives this process (cpu.max), else the visible CPUs"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max" and int(per) > 0:
+            return int(q) / int(per)
+    except (OSError, ValueError):
+        pass
+    return float(os.cpu_count() or 1)
 
 
 def _cpu_model():

@@ -609,17 +609,150 @@ static __device__ __forceinline__ uint64_t dm_rd_off(const DevReads &R, uint64_t
 // hit a key are then taken in ascending order and their candidates compared 64 at a time.  The read's words
 // sit in LDS ([wave][word]) so that the dynamically indexed window extraction costs an LDS read.
 #define DV_MAXW 20                                   // words staged per read (reads up to 304 bases); longer reads use global loads
+#define DV_G 3                                       // reads a wave verifies side by side when their windows fit 21 lanes each
+#define DV_GL 21                                     // lanes per read in that form (reads up to 183 bases: h_max <= 20)
+
+// the candidates of one hit window (key entries [base, base + cnt)) against the read whose words `word` returns; keeps the
+// wave-uniform best (end, len, pid): ACISM's first callback = smallest end, ties -> longest pattern
+template <typename WordFn>
+static __device__ __forceinline__ void dv_candidates(const DevMerge &M, WordFn word, const uint8_t *raw, uint32_t L, uint32_t a, uint32_t cnt_s,
+                                                     uint32_t base_s, int lane, uint32_t &best_end, uint32_t &best_len, uint32_t &best_pid)
+{
+    for (uint32_t c0 = 0; c0 < cnt_s; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        uint32_t cand = 0xFFFFFFFFu, cpid = 0;                // (end << 8) | (255 - len): smaller is better
+        if (c < cnt_s) {
+            const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 4;
+            const uint64_t e0 = ent[0];
+            const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
+            if (a >= rr && a - rr + len <= L) {
+                const uint32_t start = a - rr;
+                const uint32_t w0 = start >> 4, sh = (start & 15u) * 2u;
+                uint32_t x[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) x[q] = word(w0 + q);
+                uint32_t y[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) y[q] = sh ? ((x[q] >> sh) | (x[q + 1] << (32 - sh))) : x[q];
+                const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
+                uint64_t m0, m1;
+                mask128(len, m0, m1);
+                bool eq = (v0 & m0) == ent[1] && (v1 & m1) == ent[2];
+                if (eq && raw) {
+                    uint64_t rm = 0;
+                    bool other = false;
+                    for (uint32_t i = 0; i < len; i++) {
+                        const uint8_t ch = raw[start + i];
+                        if (!((ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T'))) { rm |= 1ull << i; other |= ch != 'N'; }
+                    }
+                    eq = !other && rm == ent[3];
+                } else if (eq) eq = ent[3] == 0ull;
+                if (eq) { cand = ((start + len) << 8) | (255u - len); cpid = (uint32_t)(e0 >> 32); }
+            }
+        }
+        // wave minimum of cand (ties: any lane — equal (end, len) means equal strings)
+        uint32_t mn = cand;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+        if (mn != 0xFFFFFFFFu) {
+            const uint32_t e_end = mn >> 8, e_len = 255u - (mn & 0xFFu);
+            if (e_end < best_end || (e_end == best_end && e_len > best_len)) {
+                const uint64_t who = __ballot(cand == mn);
+                best_end = e_end; best_len = e_len;
+                best_pid = (uint32_t)__shfl((int)cpid, __ffsll((unsigned long long)who) - 1);
+            }
+        }
+    }
+}
+
+// the key set's entry range for window value V: (cnt, base), cnt == 0 when V is no key
+static __device__ __forceinline__ void dv_probe(const DevMerge &M, uint32_t V, uint32_t kmask, uint32_t &cnt, uint32_t &base)
+{
+    const unsigned long long want = (unsigned long long)V | (1ull << 32);
+    uint32_t s = kset_hash(V, M.kset_log);
+    for (;;) {
+        const unsigned long long kk = M.kset_key[s];
+        if (kk == 0ull) break;
+        if (kk == want) { cnt = M.kset_cnt[s]; base = M.kset_base[s]; break; }
+        s = (s + 1) & kmask;
+    }
+}
+
+static __device__ __forceinline__ const uint8_t *dv_raw(const DevReads &R, uint64_t r)
+{
+    if (!(R.n_exc && ((R.exc_mask[r >> 5] >> (r & 31)) & 1u))) return nullptr;
+    uint64_t lo = 0, hi = R.n_exc - 1;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (R.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
+    return R.exc_bytes + R.exc_off[lo];
+}
+
+// SHORT: every read of the set has at most 183 bases (uniform length, the short-read layouts): a wave takes DV_G reads per
+// round, DV_GL lanes each — the kernel is latency bound (index -> words -> key set -> entries: four dependent round trips
+// per read, 18 of 64 lanes busy in the one-read form), and the rounds of three reads overlap; the candidate comparison stays
+// 64 lanes wide, one hit window at a time.  100 M reads (400 k flagged): 440 us in the one-read form.
+template <bool SHORT>
 __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
                                                     uint32_t *info_by_slot, uint32_t *pid_by_slot)
 {
-    __shared__ uint32_t rw_all[4][DV_MAXW + 1];
+    __shared__ uint32_t rw_all[4][DV_G][DV_MAXW + 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t *rw = rw_all[wv];
     const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6));
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     uint64_t n = *d_n;
     if (n > n_max) n = n_max;
     const uint32_t kmask = (1u << M.kset_log) - 1u;
+    if (SHORT) {
+        const int gi = lane / DV_GL, pl = lane % DV_GL;                     // (lane 63: group 3 = idle)
+        const uint32_t L = R.uniform_len, nw = (L + 15) >> 4, h_max = (L - 16) >> 3;
+        for (uint64_t k0 = wave * DV_G; k0 < n; k0 += n_waves * DV_G) {
+            const uint64_t k = k0 + (uint64_t)gi;
+            const bool have = gi < DV_G && k < n;
+            const uint64_t r = have ? idx[k] : 0;
+            uint32_t *rw = rw_all[wv][gi < DV_G ? gi : 0];
+            if (have) {
+                const uint32_t *g = R.packed + dm_rd_off(R, r);
+                if ((uint32_t)pl < nw) rw[pl] = g[pl];
+                if ((uint32_t)pl == nw) rw[pl] = 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t cnt = 0, base = 0;
+            if (have && (uint32_t)pl <= h_max) {
+                const uint32_t wi = (uint32_t)pl >> 1;
+                const uint32_t lo = rw[wi], hi = rw[min(wi + 1, nw)];
+                dv_probe(M, (pl & 1) ? ((lo >> 16) | (hi << 16)) : lo, kmask, cnt, base);
+            }
+            uint32_t b_end[DV_G], b_len[DV_G], b_pid[DV_G];                  // wave-uniform, one per read of the round
+#pragma unroll
+            for (int q = 0; q < DV_G; q++) { b_end[q] = 0xFFFFFFFFu; b_len[q] = 0; b_pid[q] = 0; }
+            uint64_t hits = __ballot(cnt > 0);
+            while (hits) {
+                const int src = __ffsll((unsigned long long)hits) - 1;
+                hits &= hits - 1;
+                const int sg = src / DV_GL;
+                const uint32_t a = 8u * (uint32_t)(src % DV_GL);
+                const uint32_t cur_end = sg == 0 ? b_end[0] : sg == 1 ? b_end[1] : b_end[2];
+                if (cur_end <= a + 15) continue;                            // a later window of THIS read cannot end earlier
+                const uint32_t cnt_s = (uint32_t)__shfl((int)cnt, src), base_s = (uint32_t)__shfl((int)base, src);
+                const uint64_t r_s = (uint64_t)(uint32_t)__shfl((int)(uint32_t)r, src) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(r >> 32), src) << 32);
+                const uint8_t *raw = dv_raw(R, r_s);
+                const uint32_t *rws = rw_all[wv][sg];
+                uint32_t be = cur_end, bl = sg == 0 ? b_len[0] : sg == 1 ? b_len[1] : b_len[2], bp = sg == 0 ? b_pid[0] : sg == 1 ? b_pid[1] : b_pid[2];
+                dv_candidates(M, [&](uint32_t i) -> uint32_t { return rws[min(i, nw)]; }, raw, L, a, cnt_s, base_s, lane, be, bl, bp);
+#pragma unroll
+                for (int q = 0; q < DV_G; q++) if (sg == q) { b_end[q] = be; b_len[q] = bl; b_pid[q] = bp; }
+            }
+            if (have && pl == 0) {
+                const uint32_t be = gi == 0 ? b_end[0] : gi == 1 ? b_end[1] : b_end[2], bl = gi == 0 ? b_len[0] : gi == 1 ? b_len[1] : b_len[2];
+                info_by_slot[k] = bl ? ((be << 8) | bl) : 0u;
+                pid_by_slot[k] = gi == 0 ? b_pid[0] : gi == 1 ? b_pid[1] : b_pid[2];
+            }
+            __builtin_amdgcn_wave_barrier();                // the next round reuses rw
+        }
+        return;
+    }
+    uint32_t *rw = rw_all[wv][0];                       // (DV_G rows of DV_MAXW + 2 words, contiguous: room for DV_MAXW + 1)
     for (uint64_t k = wave; k < n; k += n_waves) {
         const uint64_t r = idx[k];
         const uint32_t L = dm_rd_len(R, r);
@@ -629,12 +762,7 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
         // exception read (non-ACGT bytes pack as 'A'): a bit-equal candidate only counts if its non-ACGT bytes are
         // exactly the pattern's 'N' positions and are 'N' themselves — the automaton the reference runs over the
         // bytes (libcrispr.cpp:503) matches byte for byte
-        const uint8_t *raw = nullptr;                    // wave-uniform
-        if (R.n_exc && ((R.exc_mask[r >> 5] >> (r & 31)) & 1u)) {
-            uint64_t lo = 0, hi = R.n_exc - 1;
-            while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (R.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
-            raw = R.exc_bytes + R.exc_off[lo];
-        }
+        const uint8_t *raw = dv_raw(R, r);               // wave-uniform
         if (staged) {
             if ((uint32_t)lane < nw) rw[lane] = g[lane];
             if ((uint32_t)lane == nw) rw[lane] = 0u;
@@ -656,15 +784,7 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                 if (h <= h_max) {
                     const uint32_t wi = h >> 1;
                     const uint32_t lo = word(wi), hi = word(wi + 1);
-                    const uint32_t V = (h & 1) ? ((lo >> 16) | (hi << 16)) : lo;
-                    const unsigned long long want = (unsigned long long)V | (1ull << 32);
-                    uint32_t s = kset_hash(V, M.kset_log);
-                    for (;;) {
-                        const unsigned long long kk = M.kset_key[s];
-                        if (kk == 0ull) break;
-                        if (kk == want) { cnt = M.kset_cnt[s]; base = M.kset_base[s]; break; }
-                        s = (s + 1) & kmask;
-                    }
+                    dv_probe(M, (h & 1) ? ((lo >> 16) | (hi << 16)) : lo, kmask, cnt, base);
                 }
                 uint64_t hits = __ballot(cnt > 0);
                 while (hits) {
@@ -673,51 +793,7 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                     const uint32_t a = 8 * (hb + (uint32_t)src);
                     if (best_end <= a + 15) { hits = 0; break; }              // later windows cannot end earlier
                     const uint32_t cnt_s = (uint32_t)__shfl((int)cnt, src), base_s = (uint32_t)__shfl((int)base, src);
-                    for (uint32_t c0 = 0; c0 < cnt_s; c0 += 64) {
-                        const uint32_t c = c0 + lane;
-                        uint32_t cand = 0xFFFFFFFFu, cpid = 0;                // (end << 8) | (255 - len): smaller is better
-                        if (c < cnt_s) {
-                            const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 4;
-                            const uint64_t e0 = ent[0];
-                            const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
-                            if (a >= rr && a - rr + len <= L) {
-                                const uint32_t start = a - rr;
-                                const uint32_t w0 = start >> 4, sh = (start & 15u) * 2u;
-                                uint32_t x[5];
-#pragma unroll
-                                for (int q = 0; q < 5; q++) x[q] = word(w0 + q);
-                                uint32_t y[4];
-#pragma unroll
-                                for (int q = 0; q < 4; q++) y[q] = sh ? ((x[q] >> sh) | (x[q + 1] << (32 - sh))) : x[q];
-                                const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
-                                uint64_t m0, m1;
-                                mask128(len, m0, m1);
-                                bool eq = (v0 & m0) == ent[1] && (v1 & m1) == ent[2];
-                                if (eq && raw) {
-                                    uint64_t rm = 0;
-                                    bool other = false;
-                                    for (uint32_t i = 0; i < len; i++) {
-                                        const uint8_t ch = raw[start + i];
-                                        if (!((ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T'))) { rm |= 1ull << i; other |= ch != 'N'; }
-                                    }
-                                    eq = !other && rm == ent[3];
-                                } else if (eq) eq = ent[3] == 0ull;
-                                if (eq) { cand = ((start + len) << 8) | (255u - len); cpid = (uint32_t)(e0 >> 32); }
-                            }
-                        }
-                        // wave minimum of cand (ties: any lane — equal (end, len) means equal strings)
-                        uint32_t mn = cand;
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
-                        if (mn != 0xFFFFFFFFu) {
-                            const uint32_t e_end = mn >> 8, e_len = 255u - (mn & 0xFFu);
-                            if (e_end < best_end || (e_end == best_end && e_len > best_len)) {
-                                const uint64_t who = __ballot(cand == mn);
-                                best_end = e_end; best_len = e_len;
-                                best_pid = (uint32_t)__shfl((int)cpid, __ffsll((unsigned long long)who) - 1);
-                            }
-                        }
-                    }
+                    dv_candidates(M, word, raw, L, a, cnt_s, base_s, lane, best_end, best_len, best_pid);
                 }
             }
         }
@@ -733,9 +809,13 @@ hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t
                             uint32_t *info_by_slot, uint32_t *pid_by_slot, hipStream_t st)
 {
     if (n_max == 0) return hipSuccess;
-    uint64_t nb = (n_max + 3) / 4;
+    static const bool dv_one = getenv("CRASS_DV_ONE") != nullptr;      // A/B switch, read once per process
+    // every read at most 183 bases (uniform length): three reads per wave and round
+    const bool shortr = R.uniform_len >= 16 && ((R.uniform_len - 16) >> 3) < DV_GL && ((R.uniform_len + 15) >> 4) <= DV_MAXW && !dv_one;
+    uint64_t nb = shortr ? (n_max + 4 * DV_G - 1) / (4 * DV_G) : (n_max + 3) / 4;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(k_dm_verify, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    if (shortr) hipLaunchKernelGGL(k_dm_verify<true>, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    else hipLaunchKernelGGL(k_dm_verify<false>, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
     return hipGetLastError();
 }
 

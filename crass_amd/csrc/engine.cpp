@@ -1196,7 +1196,22 @@ static int ensure_recruit_buffers(crass_hip_ctx *c, uint64_t h_alloc, uint64_t n
 // for a count before queueing the next stage; a bound that turns out too small repeats the stage with the exact
 // count, exactly like a learnt one.  CRASS_NO_PRESIZE / CRASS_NO_SPECULATION switch this off.
 // ------------------------------------------------------------------------------------------
+static int first_call_bounds_impl(crass_hip_ctx *c);
 static int first_call_bounds(crass_hip_ctx *c)
+{
+    // best effort: a pool that cannot be sized now (out of memory, a cap) just means the first call sizes things itself, as
+    // every call did before — the load itself has succeeded
+    const int s = first_call_bounds_impl(c);
+    if (s == CRASS_ERR_OOM) {
+        c->surv_cap_hint = 0; c->hit_cap_hint = 0; c->dx_cap_hint = 0; c->dm_prev_local = false; c->premerge = 0;
+        c->last_hip = 0;
+        c->dm.release();                                // (the merge tables sized for the bound: the first call sizes them exactly)
+        c->dm_prepared_n = 0; c->dm_prepared_src = nullptr;
+        return CRASS_OK;
+    }
+    return s;
+}
+static int first_call_bounds_impl(crass_hip_ctx *c)
 {
     c->surv_cap_hint = 0; c->hit_cap_hint = 0; c->dx_cap_hint = 0; c->dm_prev_local = false; c->premerge = 0;
     c->recruit_exact = false;

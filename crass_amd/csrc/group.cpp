@@ -85,6 +85,9 @@ private:
 
 enum Phase : unsigned { PH_SEED = 1, PH_MERGE = 2, PH_RECRUIT = 4, PH_LOAD = 8 };
 
+const bool g_debug = getenv("CRASS_GROUP_DEBUG") != nullptr;           // stage trace on stderr
+#define GDBG(...) do { if (g_debug) { fprintf(stderr, "[crass_group] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
 } // namespace
 
 struct crass_hip_group {
@@ -215,10 +218,13 @@ void run_rank(crass_hip_group *g, int r, unsigned phases)
     if ((phases & PH_SEED) && ok()) note(g, r, crass_hip_seed_scan(c));
     if (phases & PH_MERGE) {
         for (int attempt = 0; attempt < 6; attempt++) {
+            GDBG("rank %d attempt %d: at barrier A", r, attempt);
             g->bar->wait();                                         // every send buffer is complete
             if (r == 0) { g->need_rows.store(0); if (ok()) note(g, 0, all_gather(g)); }
             g->bar->wait();                                         // the collective is queued on every rank's stream
+            GDBG("rank %d attempt %d: merge_gathered", r, attempt);
             int s = ok() ? crass_hip_merge_gathered(c, g->recv[r]) : CRASS_OK;
+            GDBG("rank %d attempt %d: merge_gathered -> %d", r, attempt, s);
             if (s == CRASS_ERR_OVERFLOW) {
                 uint64_t need = crass_hip_exchange_needed_rows(c), cur = g->need_rows.load();
                 while (need > cur && !g->need_rows.compare_exchange_weak(cur, need)) {}
@@ -232,8 +238,11 @@ void run_rank(crass_hip_group *g, int r, unsigned phases)
             // some rank's list did not fit: larger buffers everywhere, pass 1 again (its kernel fills the send buffer)
             if (r == 0) { uint64_t cap = g->cap_rows; while (cap < need * 2) cap *= 2; g->cap_rows = cap; }
             g->bar->wait();
+            GDBG("rank %d attempt %d: %llu rows needed, exchange set up again with %llu", r, attempt, (unsigned long long)need, (unsigned long long)g->cap_rows);
             int t = setup_exchange(g, r);
+            GDBG("rank %d attempt %d: setup -> %d, pass 1 again", r, attempt, t);
             if (!t) t = crass_hip_seed_scan(c);
+            GDBG("rank %d attempt %d: pass 1 -> %d", r, attempt, t);
             note(g, r, t);
         }
         if (g->have_dups) {

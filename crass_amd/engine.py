@@ -445,6 +445,11 @@ class SearchEngine:
         """order the engine's stream behind a HIP event (raw hipEvent_t handle, e.g. torch.cuda.Event().cuda_event)"""
         _chk(self.lib.crass_hip_stream_wait_event(self.h, C.c_void_p(int(event_handle))), "crass_hip_stream_wait_event")
 
+    def set_host_view(self, light):
+        """1: after a device merge this context only builds its own candidates' tokens (ranks other than 0 of a multi-rank job:
+        tokens, groups and patterns are identical on every rank); 0: the full host view (crass_hip_set_host_view)"""
+        _chk(self.lib.crass_hip_set_host_view(self.h, 1 if light else 0), "crass_hip_set_host_view")
+
     def set_timing_focus(self, kernels):
         """level 1: bit 0 seed scan, bit 1 survivors, bit 2 pass-2 scan (crass_hip_set_timing_focus)"""
         _chk(self.lib.crass_hip_set_timing_focus(self.h, int(kernels)), "crass_hip_set_timing_focus")
