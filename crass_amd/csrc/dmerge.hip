@@ -57,6 +57,15 @@ static __device__ __forceinline__ uint32_t dm_ntok(const DevMerge &M)
     return M.d_ntok ? min(*M.d_ntok, M.n_tok) : M.n_tok;
 }
 
+// A merge whose input is unusable (a token outside ACGTN / 23..64 bases: fail bit 1; more tokens than the launch was sized
+// for: bit 64) is decided by the FIRST kernel; its results are never used (the host merges instead), so every later kernel
+// leaves at once — uniformly: the bits are set before it starts.  Without this, garbage lengths (the rows of an exchange that
+// overflowed are never unpacked) sent k_dm_redundant into a ~2^32-iteration window loop (`lenj - 22` wraps for lenj < 22).
+static __device__ __forceinline__ bool dm_abandoned(const DevMerge &M)
+{
+    return (__hip_atomic_load(&M.st->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u | 64u)) != 0u;
+}
+
 // ---- 0. initialise every word a later kernel polls, counts into or probes (dm_init_slice, engine_internal.h) ----
 __global__ __launch_bounds__(256) void k_dm_init(DevMerge M)
 {
@@ -183,6 +192,7 @@ static __device__ __forceinline__ uint32_t rset_hash(uint32_t g, uint32_t w, uin
 }
 __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
 {
+    if (dm_abandoned(M)) return;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
 // candidates that share the window's first 16 bases — instead of trying every shorter member at every shift.
 __global__ __launch_bounds__(256) void k_dm_rd_bases(DevMerge M)
 {
+    if (dm_abandoned(M)) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t hs = 0;
     if (t < dm_ntok(M)) hs = M.rd_slot[t];
@@ -264,6 +275,7 @@ __global__ __launch_bounds__(256) void k_dm_rd_bases(DevMerge M)
 }
 __global__ __launch_bounds__(256) void k_dm_rd_fill(DevMerge M)
 {
+    if (dm_abandoned(M)) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= dm_ntok(M)) return;
     const uint32_t h = M.rd_slot[t] & 0x7FFFFFFFu;
@@ -283,6 +295,7 @@ static __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 }
 __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
 {
+    if (dm_abandoned(M)) return;
     CRASS_VGPR_FLOOR(48);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
         const uint64_t *pj = M.packed + (uint64_t)j * 4;
         const uint64_t f0 = pj[0], f1 = pj[1], r0 = pj[2], r1 = pj[3];
         const uint64_t mfj = M.tmask[(uint64_t)j * 2], mrj = M.tmask[(uint64_t)j * 2 + 1];
+        if (lenj < 23u || lenj > 64u) continue;         // (cannot happen once k_dm_pack_codes has passed the token: belt and braces)
         const uint32_t nwin = lenj - 22u;               // starts 0 .. lenj-23: a member is >= 23 long and shorter than lenj
         bool found = false;
         for (uint32_t wb = 0; wb < 2 * nwin && !found; wb += 64) {
@@ -357,6 +371,7 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
 // latency, 13 + 11 us -> 48 us).
 __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
 {
+    if (dm_abandoned(M)) return;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = e >> 4, o = (e >> 3) & 1u, r = e & 7u;
     uint32_t slot = 0xFFFFFFFFu, my_key = 0xFFFFFFFFu, won = 0u;
@@ -430,6 +445,7 @@ static __device__ __forceinline__ void dm_table_params(uint32_t n, uint32_t tab_
 // not every 3 — 2 600 blocks of 256 were 90 of this kernel's 102 us at 100 M reads)
 __global__ __launch_bounds__(1024) void k_dm_key_bases_insert(DevMerge M)
 {
+    if (dm_abandoned(M)) return;
     CRASS_VGPR_FLOOR(8);
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tok = e >> 4;
@@ -483,7 +499,8 @@ __global__ __launch_bounds__(1024) void k_dm_key_bases_insert(DevMerge M)
 __global__ __launch_bounds__(256) void k_dm_fill_finish(DevMerge M)
 {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if ((w >> 4) < dm_ntok(M)) {
+    const bool dead = dm_abandoned(M);                  // (the kernels before this one left at once: only the state words are exported)
+    if (!dead && (w >> 4) < dm_ntok(M)) {
         const uint32_t hs = M.ent_slot[w];
         if (hs != 0xFFFFFFFFu) {
             const uint32_t h = hs & 0x7FFFFFFFu, pid = w >> 3, r = w & 7u, t = pid >> 1, o = pid & 1u;
@@ -496,6 +513,7 @@ __global__ __launch_bounds__(256) void k_dm_fill_finish(DevMerge M)
         }
     }
     if (w == 0) *M.h_st = *M.st;
+    if (dead) return;
     if (w < dm_ntok(M)) { M.h_root[w] = M.root_of[w]; M.h_blank[w] = M.blank[w]; }
     const uint32_t ls = M.st->log_size, k0 = M.st->k0;
     const bool fill = ls && !M.st->all_t;

@@ -2000,9 +2000,19 @@ int crass_hip_exchange_setup(crass_hip_ctx *c, uint32_t world, uint32_t rank, ui
     if (!c || !o || world == 0 || rank >= world || cap_rows == 0 || cap_rows > (1u << 22)) return CRASS_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     crass_hip_ctx::Xchg &X = c->xchg;
+    static const bool dbg = getenv("CRASS_GROUP_DEBUG") != nullptr;
+#define XDBG(msg) do { if (dbg) { fprintf(stderr, "[crass_xchg] rank %u: %s\n", rank, msg); fflush(stderr); } } while (0)
+    XDBG("setup: quiesce");
+    quiesce_worker(c);
+    XDBG("setup: stream sync");
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // (kernels of an abandoned queued merge may still be running on the old buffers)
     X.world = world; X.rank = rank; X.cap = cap_rows; X.slot = c->dr_stride + 16; X.needed = 0;
+    XDBG("setup: send buffer");
     HIPCHK(c, X.send.ensure(X.send_bytes())); HIPCHK(c, X.xinfo.ensure(8)); HIPCHK(c, X.h_xinfo.ensure(8));
-    HIPCHK(c, hipMemset(X.send.p, 0, X.send_bytes()));
+    XDBG("setup: memset");
+    HIPCHK(c, hipMemsetAsync(X.send.p, 0, X.send_bytes(), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    XDBG("setup: send buffer ready");
     X.active = true;
     X.gx_cap_hint = 0;
     // first call (see first_call_bounds): a bound for the GLOBAL distinct list from the job's size (every rank holds ~1/world
@@ -2020,6 +2030,8 @@ int crass_hip_exchange_setup(crass_hip_ctx *c, uint32_t world, uint32_t rank, ui
             X.gx_cap_hint = (uint32_t)gx;
         }
     }
+    XDBG("setup: done");
+#undef XDBG
     o->d_send = X.send.p; o->send_bytes = X.send_bytes(); o->slot_bytes = X.slot; o->cap_rows = X.cap;
     return CRASS_OK;
 }

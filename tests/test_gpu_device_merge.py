@@ -334,23 +334,26 @@ def test_out_of_memory_is_reported_and_the_context_survives(ca):
         assert ei.value.status == 6                                      # CRASS_ERR_STATE
         got = ca.search_pipeline(small, engine=eng)                      # the same context, a batch that fits
         assert_same_pipeline(got, ref)
-        # the cap can also bite later, inside the search: lift it, load, lower it below what pass 1 needs
-        # (with the pools sized at load — the default — pass 1 allocates nothing any more: the in-step allocation failure is
-        # reached with the load-time sizing switched off, which is also what a bound overflow falls back to)
+        # the cap can also bite later, inside the search: a fresh context, load under a roomy cap, lower it below what pass 1
+        # needs.  (With the pools sized at load — the default — pass 1 allocates nothing any more: the in-step allocation failure
+        # is reached with the load-time sizing switched off, which is also what an overflowing bound falls back to.)
         os.environ["CRASS_POOL_CAP_MB"] = "400"
         os.environ["CRASS_NO_PRESIZE"] = "1"
-        eng.reload_env()
-        eng.load_reads(pk_big, None)
+        eng2 = ca.SearchEngine()
+        eng2.load_reads(pk_big, None)
         os.environ["CRASS_POOL_CAP_MB"] = "1"
-        eng.reload_env()
+        eng2.reload_env()
         with pytest.raises(ca.CrassError) as ei:
-            eng.seed_scan()
+            eng2.seed_scan()
         assert ei.value.status == 5
         os.environ.pop("CRASS_POOL_CAP_MB")
         os.environ.pop("CRASS_NO_PRESIZE")
-        eng.reload_env()
-        c = eng.seed_scan()                                              # ... and the retry without the cap succeeds
+        eng2.reload_env()
+        c = eng2.seed_scan()                                             # ... and the retry without the cap succeeds
         assert c.n > 0
+        eng2.close()
+        # the first context again, after all of this
+        assert_same_pipeline(ca.search_pipeline(small, engine=eng), ref)
         eng.close(); pk_big.close(); pk_small.close()
     finally:
         os.environ.pop("CRASS_POOL_CAP_MB", None)

@@ -350,9 +350,10 @@ def _bench_line(r):
 
 
 def test_bench_spawns_its_own_ranks_strong_scaling():
-    """`python bench.py --gpus 2` from a plain interpreter (no torchrun): the parent starts the rank processes before it
-    touches the GPU; --total-reads = strong scaling (each rank holds total/N reads); totals equal the one-process run"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-gpu",
+    """`python bench.py --gpus 2 --launcher torch` from a plain interpreter (no torchrun): the parent starts the rank processes
+    before it touches the GPU; --total-reads = strong scaling (each rank holds total/N reads); totals equal the one-process run
+    (the default launcher, one process driving a group of contexts, is covered by tests/test_gpu_group.py)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher", "torch", "--dist-backend", "gloo", "--share-gpu",
                         "--total-reads", "1000000", "--steps", "2", "--warmup", "1"], capture_output=True, timeout=900)
     d = _bench_line(r)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_reads"] == 1000000
