@@ -28,7 +28,7 @@ if has ubench; then
   (cd profiles/ubench && mkdir -p bin && hipcc --offload-arch=gfx950 -O2 -o bin/vgpr_edge3 vgpr_edge3.hip && timeout 120 ./bin/vgpr_edge3) > $out/vgpr_edge3.txt 2>&1; cat $out/vgpr_edge3.txt
 fi
 if has tests; then
-  timeout 2400 python -m pytest tests -m gpu -q > $out/pytest.txt 2>&1; tail -15 $out/pytest.txt
+  timeout 2400 python -m pytest tests -m gpu -q --timeout=900 -rf > $out/pytest.txt 2>&1; tail -25 $out/pytest.txt
   grep -q " failed" $out/pytest.txt && { echo TESTS FAILED; exit 1; }
 fi
 if has bench; then
@@ -47,6 +47,22 @@ if has prof; then
   python3 $GRAFT_REPO_ROOT/tools/timeline.py $out/rp_tl 0 > $out/timeline_c2.txt 2>&1
   rm -rf $out/rp_c2 $out/rp_tl
   head -32 $out/c2_kernel_stats.csv
+fi
+if has e2e; then
+  cd $GRAFT_REPO_ROOT
+  timeout 600 bash tools/e2e_cli.sh 5000000 > $out/e2e_cli.txt 2>&1; tail -40 $out/e2e_cli.txt
+  timeout 300 python tools/consensus_timing.py 10000000 > $out/consensus_timing.json 2> $out/consensus_timing.err; tail -3 $out/consensus_timing.json
+fi
+if has sweep; then
+  cd $GRAFT_REPO_ROOT
+  timeout 900 python tools/parity_sweep.py 300 ${SEED:-43} > $out/sweep.txt 2>&1; tail -2 $out/sweep.txt
+fi
+if has other; then
+  cd $GRAFT_REPO_ROOT
+  timeout 400 python bench.py --config 3 --steps 10 --warmup 2 --cpu-sample 0 > $out/bench_c3.json 2> $out/bench_c3.err
+  timeout 600 python bench.py --config 4 --steps 10 --warmup 2 --cpu-sample 0 > $out/bench_c4.json 2> $out/bench_c4.err
+  CRASS_DV_ONE=1 timeout 400 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --single-shots 0 > $out/bench_c2_dv_one.json 2> $out/bench_c2_dv_one.err
+  summ $out/bench_c3.json $out/bench_c4.json $out/bench_c2_dv_one.json
 fi
 if has pmc; then
   cd $GRAFT_REPO_ROOT
