@@ -61,9 +61,12 @@ static __device__ __forceinline__ uint32_t dm_ntok(const DevMerge &M)
 // for: bit 64) is decided by the FIRST kernel; its results are never used (the host merges instead), so every later kernel
 // leaves at once — uniformly: the bits are set before it starts.  Without this, garbage lengths (the rows of an exchange that
 // overflowed are never unpacked) sent k_dm_redundant into a ~2^32-iteration window loop (`lenj - 22` wraps for lenj < 22).
+// (A plain load: the bits were written by an EARLIER kernel, so every cache level shows them, and a uniform address makes it one
+// scalar load per wave.  An agent-scope atomic load here — every thread of 670 k asking L2 for the same word — cost 100 us per
+// kernel at 100 M reads: k_dm_redundant 54 -> 170 us, k_dm_keys 61 -> 165 us, profiles/NOTES_r03.md.)
 static __device__ __forceinline__ bool dm_abandoned(const DevMerge &M)
 {
-    return (__hip_atomic_load(&M.st->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u | 64u)) != 0u;
+    return (M.st->fail & (1u | 64u)) != 0u;
 }
 
 // ---- 0. initialise every word a later kernel polls, counts into or probes (dm_init_slice, engine_internal.h) ----

@@ -22,7 +22,9 @@
 #include "../../include/crass_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -81,7 +83,7 @@ struct Spacer {                                             // SpacerInstance
     int rank() const { return (int)edges.size(); }
 };
 
-struct ReadRef { const char *hdr, *com, *seq; uint32_t nh, nc, ns; const uint32_t *ss; uint32_t nss; };
+struct ReadRef { const char *hdr, *com, *seq; uint32_t nh, nc, ns; const uint32_t *ss; uint32_t nss; int hst; };
 
 struct Rainbow {                                            // Rainbow.cpp:47-208, type BLUE_RED
     double lb = 0, ub = 1, upper = 0, lower = 0, mult = 0, tick = 0, red_off = 0, blue_off = 0;
@@ -117,6 +119,7 @@ struct Manager {                                            // NodeManager: one 
     std::vector<string> tok_str;                            // token t -> tok_str[t - 2]
     std::unordered_map<string, int> tok_of;
     std::vector<int> node_of_tok;                           // token -> node index or -1
+    std::vector<int> canon;                                 // token -> the FIRST token with the same string (headers may repeat)
     std::vector<Node> nodes;                                // creation order == ascending id
     std::vector<Spacer> spacers;                            // creation order
     std::unordered_map<uint32_t, int> sp_by_key;
@@ -132,7 +135,10 @@ struct Manager {                                            // NodeManager: one 
     {
         tok_str.push_back(s);
         const int t = (int)tok_str.size() + 1;
-        tok_of[s] = t;
+        canon.resize(t + 1, 0);
+        auto ins = tok_of.emplace(s, t);
+        if (ins.second) canon[t] = t;
+        else { canon[t] = canon[ins.first->second]; ins.first->second = t; }
         node_of_tok.resize(t + 1, -1);
         return t;
     }
@@ -239,6 +245,7 @@ struct Manager {                                            // NodeManager: one 
             if (c.get(&ws)) add_first(prev, ws, hst);
         }
         reads.push_back(r);
+        reads.back().hst = hst;
         return true;
     }
     void sort_spacers()
@@ -622,14 +629,18 @@ struct Manager {                                            // NodeManager: one 
     }
     string dump_reads_text()                                // dumpReads(.., showDetached = true) + ReadHolder::print
     {
-        std::set<string> names;
+        // reads_set holds header STRINGS in the reference; here: one mark per distinct string (its first token)
+        std::vector<char> mark(canon.size(), 0);
         for (auto &ks : sp_sorted) {
             Spacer &s = spacers[ks.second];
-            for (int nd : {s.leader, s.last}) for (int h : N(nd).headers) names.insert(str(h));
+            for (int nd : {s.leader, s.last}) for (int h : N(nd).headers) mark[canon[h]] = 1;
         }
+        size_t bytes = 0;
+        for (auto &r : reads) if (mark[canon[r.hst]]) bytes += (size_t)r.nh + r.nc + r.ns + 4;
         string o;
+        o.reserve(bytes);
         for (auto &r : reads) {
-            if (!names.count(string(r.hdr, r.nh))) continue;
+            if (!mark[canon[r.hst]]) continue;
             o += ">"; o.append(r.hdr, r.nh);
             if (r.nc) { o += " "; o.append(r.com, r.nc); }
             o += "\n"; o.append(r.seq, r.ns); o += "\n";
@@ -644,7 +655,16 @@ struct Xml {
     bool has_text = false;
     std::vector<std::pair<string, string>> attrs;
     std::vector<std::unique_ptr<Xml>> kids;
+    string raw;                                             // further children, already laid out as text (the long leaf lists)
     explicit Xml(const string &t) : tag(t) {}
+    // one empty-element child <tag a1="v1" [a2="v2"]/> at `level` as text; attribute names must be given in name order
+    static void leaf(string &o, int level, const char *tag, const char *a1, const string &v1, const char *a2 = nullptr, const string *v2 = nullptr)
+    {
+        o += "\n"; o.append((size_t)level * 2, ' '); o += "<"; o += tag;
+        o += " "; o += a1; o += "=\""; esc(o, v1, true); o += "\"";
+        if (a2) { o += " "; o += a2; o += "=\""; esc(o, *v2, true); o += "\""; }
+        o += "/>";
+    }
     Xml *add(const string &t) { kids.emplace_back(new Xml(t)); return kids.back().get(); }
     Xml *attr(const string &k, const string &v) { attrs.push_back(std::make_pair(k, v)); return this; }
     Xml *txt(const string &t) { text = t; has_text = true; return this; }
@@ -666,9 +686,10 @@ struct Xml {
         std::sort(attrs.begin(), attrs.end());              // DOMAttrMapImpl keeps attributes sorted by name
         for (auto &a : attrs) { o += " " + a.first + "=\""; esc(o, a.second, true); o += "\""; }
         if (has_text) { o += ">"; esc(o, text, false); o += "</" + tag + ">"; }
-        else if (!kids.empty()) {
+        else if (!kids.empty() || !raw.empty()) {
             o += ">";
             for (auto &k : kids) k->write(o, level + 1);
+            o += raw;
             if (level == 0) o += "\n";
             o += "\n"; o.append((size_t)level * 2, ' '); o += "</" + tag + ">";
         } else o += "/>";
@@ -694,6 +715,10 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
     if (in->n_groups && (!in->gid || !in->dr_chars || !in->dr_off || !in->grp_rec_off)) return CRASS_ERR_INVALID_ARG;
     if (in->n_rec && (!in->hdr_chars || !in->hdr_off || !in->seq_chars || !in->seq_off || !in->rec_nss || !in->rec_ss_off || !in->ss_pool)) return CRASS_ERR_INVALID_ARG;
     std::unique_ptr<crass_outputs> R(new crass_outputs());
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[crass_timing] outputs: %-40s %.4f s\n", what, t - t_prev); t_prev = t; } };
     const string outdir = op->out_dir ? op->out_dir : "./", stamp = op->timestamp ? op->timestamp : "", cwd = op->cwd ? op->cwd : "";
     const string package = "crass", version = "1.0.1";     // PACKAGE_NAME / PACKAGE_VERSION (configure.ac:5)
     const int kmer = op->node_kmer > 0 ? op->node_kmer : 7, cov_cutoff = op->cov_cutoff > 0 ? op->cov_cutoff : 3;
@@ -722,9 +747,11 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
     } catch (int) {
         return CRASS_ERR_SEARCH_FATAL;                       // substring_exception: the reference exit(99)s (NodeManager.cpp:216-219)
     }
+    lap("reads -> nodes and spacers");
     for (uint32_t g = 0; g < in->n_groups; g++) of_group[g] = by_dr[string(in->dr_chars + in->dr_off[g], (size_t)(in->dr_off[g + 1] - in->dr_off[g]))];
     std::vector<bool> alive(in->n_groups, true);
     for (uint32_t g = 0; g < in->n_groups; g++) if (of_group[g]->clean_graph()) return CRASS_ERR_SEARCH_FATAL;
+    lap("cleanGraph");
     for (auto &kv : by_dr) if (kv.second->build_spacer_graph()) return CRASS_ERR_SEARCH_FATAL;     // makeSpacerGraphs .. splitIntoContigs walk mDRs
     for (auto &kv : by_dr) if (kv.second->clean_spacer_graph()) return CRASS_ERR_SEARCH_FATAL;
     for (auto &kv : by_dr) kv.second->split_into_contigs();
@@ -734,6 +761,7 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
         if (m->count_and_stats(false) < cov_cutoff) alive[g] = false;
         else if (m->stdev() > 6.0) alive[g] = false;         // CRASS_DEF_STDEV_SPACER_LENGTH
     }
+    lap("spacer graphs, contigs, flankers");
     // outputResults (WorkHorse.cpp:1900-2038)
     auto put = [&](const string &name, const string &data) { R->names.push_back(name); R->data.push_back(data); };
     const string name_prefix = outdir + package + ".crispr";
@@ -758,12 +786,14 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
         Xml *sources = data->add("sources"), *drs = data->add("drs"), *sps = data->add("spacers");
         Xml *fls = m->flankers.empty() ? nullptr : data->add("flankers");
         drs->add("dr")->attr("seq", m->dr)->attr("drid", "DR1");
-        std::set<int> all_sources;
-        auto add_sources = [&](Xml *e, const Spacer &s) {
-            std::set<int> toks;
-            for (int nd : {s.leader, s.last}) for (int h : m->N(nd).headers) toks.insert(h);
-            for (int t : toks) e->add("source")->attr("soid", "SO" + std::to_string(t));
-            all_sources.insert(toks.begin(), toks.end());
+        std::vector<char> in_all(m->tok_str.size() + 2, 0);   // all_sources as marks (tokens are dense)
+        std::vector<int> toks;
+        auto add_sources = [&](Xml *e, const Spacer &s) {    // the spacer's <source soid=..> children (level 5), ascending token
+            toks.clear();
+            for (int nd : {s.leader, s.last}) for (int h : m->N(nd).headers) toks.push_back(h);
+            std::sort(toks.begin(), toks.end());
+            toks.erase(std::unique(toks.begin(), toks.end()), toks.end());
+            for (int t : toks) { Xml::leaf(e->raw, 5, "source", "soid", "SO" + std::to_string(t)); in_all[t] = 1; }
         };
         for (auto &ks : m->sp_sorted) {
             const Spacer &s = m->spacers[ks.second];
@@ -775,7 +805,8 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
                 const Spacer &s = m->spacers[fi];
                 if (m->N(s.leader).attached && m->N(s.last).attached) add_sources(fls->add("flanker")->attr("seq", m->str(s.id))->attr("flid", "FL" + std::to_string(s.id)), s);
             }
-        for (int t : all_sources) sources->add("source")->attr("accession", m->str(t))->attr("soid", "SO" + std::to_string(t));
+        for (int t = 2; t < (int)in_all.size(); t++)
+            if (in_all[t]) { const string so = "SO" + std::to_string(t); Xml::leaf(sources->raw, 4, "source", "accession", m->str(t), "soid", &so); }
         // <metadata> (WorkHorse.cpp:2090-2249)
         Xml *meta = grp->add("metadata");
         Xml *prog = meta->add("program");
@@ -811,12 +842,14 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
             }
         }
     }
+    lap("group files + XML tree");
     R->out += "[" + package + "_graphBuilder]: " + std::to_string(R->kept.size()) + " CRISPRs found!\n";
     string xml = "<?xml version=\"1.0\" encoding=\"ISO8859-1\" standalone=\"no\" ?>";
     root.write(xml, 0);
     xml += "\n";
     put(package + ".crispr", xml);
     put(package + "." + stamp + ".keys.gv", keys + "\n}\n");
+    lap("XML text");
     for (size_t i = 0; i < R->names.size(); i++) { R->name_p.push_back(R->names[i].c_str()); R->data_p.push_back(R->data[i].data()); R->sizes.push_back(R->data[i].size()); }
     *res = R.release();
     return CRASS_OK;

@@ -2136,14 +2136,17 @@ __global__ __launch_bounds__(256) void k_gather_found(const uint64_t *fidx, cons
         dd_hash[k] = h;
         const unsigned long long key = h | 1ull;             // 0 marks an empty slot
         uint32_t slot = (uint32_t)(h >> 17) & dd_mask;
-        // (looking at the slot before the CAS / atomicMin — most records carry one of a few popular strings — pays at
-        // 100 M reads, 168 -> 118 us, but costs two more round trips per record at 10 M: 21 -> 39 us.  Not done.)
+        // Looking at the slot before the CAS / atomicMin — most records carry one of a few popular strings, and atomics on one
+        // address retire one at a time — pays at 100 M reads (168 -> 118 us) but costs two more round trips per record at
+        // 10 M (21 -> 39 us): done for launches sized for more than 2^20 records (the headline workload).
+        const bool look = n_max > (1ull << 20);
         for (;;) {
-            const unsigned long long old = atomicCAS(&dd_keys[slot], 0ull, key);
+            unsigned long long old = look ? __hip_atomic_load(&dd_keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            if (old == 0ull) old = atomicCAS(&dd_keys[slot], 0ull, key);
             if (old == 0ull || old == key) break;
             slot = (slot + 1) & dd_mask;
         }
-        atomicMin(&dd_first[slot], (uint32_t)k);
+        if (!look || __hip_atomic_load(&dd_first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)k) atomicMin(&dd_first[slot], (uint32_t)k);
         dd_slot[k] = slot;
     }
 }
