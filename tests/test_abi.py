@@ -69,6 +69,38 @@ def test_param_validation(ca):
     assert b"Fatal error in search algorithm" in lib.crass_hip_strerror(7)
 
 
+def test_group_argument_validation_needs_no_gpu(ca):
+    """crass_hip_group_create refuses bad argument lists before it touches a device; a device listed twice needs the
+    local-copy stand-in (RCCL wants one rank per device) and says so in crass_hip_group_last_error()"""
+    lib = ca.load()
+    p = ca.default_params()
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.crass_hip_group_create(C.byref(p), devs, 0, 0, C.byref(h)) == 1
+    assert lib.crass_hip_group_create(C.byref(p), None, 2, 0, C.byref(h)) == 1
+    assert lib.crass_hip_group_create(C.byref(p), devs, 2, 8, C.byref(h)) == 1          # unknown flag
+    assert lib.crass_hip_group_create(C.byref(p), devs, 2, 0, C.byref(h)) == 1
+    assert b"listed twice" in lib.crass_hip_group_last_error()
+    assert lib.crass_hip_group_size(None) == 0 and lib.crass_hip_group_rccl_ranks(None) == 0
+    assert lib.crass_hip_group_step(None) == 1 and lib.crass_hip_group_recruit(None, None, 0) == 1
+    assert b"RCCL" in lib.crass_hip_strerror(10)
+    import torch
+    if not torch.cuda.is_available():                   # valid arguments, no device: the contexts cannot be created
+        assert lib.crass_hip_group_create(C.byref(p), devs, 2, 1, C.byref(h)) == 3
+
+
+def test_outputs_stage_argument_validation(ca):
+    from crass_amd import _abi
+    lib = ca.load()
+    h = C.c_void_p()
+    assert lib.crass_build_outputs(None, None, C.byref(h)) == 1
+    gi, oo = _abi.GraphInput(), _abi.OutputOpts()
+    gi.n_groups = 1                                      # a group without its arrays
+    assert lib.crass_build_outputs(C.byref(gi), C.byref(oo), C.byref(h)) == 1
+    files, kept, text = ca.build_outputs([])            # no groups: an empty but well-formed result
+    assert kept == [] and files["crass.crispr"].endswith(b'<crispr version="1.1"/>\n') and "0 CRISPRs found!" in text
+
+
 @pytest.mark.parametrize("fname", sorted(os.listdir(DATA)))
 def test_fastx_reader_matches_kseq_semantics(ca, fname):
     path = os.path.join(DATA, fname)
