@@ -338,10 +338,12 @@ def main():
     traffic, traffic_src, valu_issue = None, None, None
     try:
         pm = _pmc_file(n, L)
-        key = {"seed_scan_filter": "k_filter_fast", "survivor": "k_survivor", "recruit_scan": "k_anchor_filter"}[dom]
+        # (the seed-scan stage is k_filter_fast_impl for short uniform reads, k_hint_positions for long ones, else k_filter_general)
+        keys = {"seed_scan_filter": ("k_filter_fast", "k_hint_positions", "k_filter_general"), "survivor": ("k_survivor",),
+                "recruit_scan": ("k_anchor_filter",)}[dom]
         if pm and pm.get("source_hash") == source_hash() and pm.get("reads") == n and pm.get("read_len") == L:
-            for k, v in pm["per_launch"].items():
-                if k.startswith(key):
+            for k, v in sorted(pm["per_launch"].items(), key=lambda kv: -kv[1].get("hbm_bytes", 0)):
+                if traffic is None and k.startswith(keys):
                     traffic, traffic_src = v["hbm_bytes"], "profiles/%s (committed PMC passes, same kernel source hash)" % pm["_file"]
                     if "sq" in v and v["sq"].get("SQ_INSTS_VALU"):
                         # what actually bounds this kernel: a wave64 VALU instruction occupies its SIMD for 4 cycles, the chip

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrass_hip.so")
 SOURCES = ["kernels.hip", "dmerge.hip", "consensus.hip", "engine.cpp", "merge.cpp", "ingest.cpp", "consensus.cpp", "group.cpp", "graph.cpp"]
-DEPS = SOURCES + ["engine_internal.h", "consensus_internal.h", "merge.h", os.path.join("..", "..", "include", "crass_hip.h")]
+DEPS = SOURCES + ["engine_internal.h", "devmem.h", "consensus_internal.h", "merge.h", os.path.join("..", "..", "include", "crass_hip.h")]
 
 
 def _hipcc():
@@ -22,7 +22,7 @@ def _hipcc():
 
 
 OBJ = os.path.join(CSRC, "_obj")
-HEADERS = ["engine_internal.h", "consensus_internal.h", "merge.h", os.path.join("..", "..", "include", "crass_hip.h")]
+HEADERS = ["engine_internal.h", "devmem.h", "consensus_internal.h", "merge.h", os.path.join("..", "..", "include", "crass_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 LIBS = ["-lz", "-lpthread", "-ldl"]
 

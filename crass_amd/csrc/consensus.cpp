@@ -36,14 +36,14 @@ template <typename T> struct DBuf {
     hipError_t ensure(size_t want)
     {
         if (want <= n && p) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (p) { crass::dev_free(p); p = nullptr; n = 0; }
         if (!want) want = 1;
         want += want / 2;
-        const hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        const hipError_t e = crass::dev_alloc((void **)&p, want * sizeof(T));
         if (e == hipSuccess) n = want;
         return e;
     }
-    ~DBuf() { if (p) (void)hipFree(p); }
+    ~DBuf() { if (p) crass::dev_free(p); }
 };
 
 struct Rec {

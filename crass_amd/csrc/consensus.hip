@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_cons_sw(const uint8_t *seq, const uint6
 hipError_t launch_cons_flip(uint8_t *seq, const uint64_t *roff, const uint32_t *rlen, const uint32_t *list, uint32_t n, const uint8_t *comp, hipStream_t st)
 {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_cons_flip, dim3(std::min<uint32_t>((n + 3) / 4, 4096u)), dim3(256), 0, st, seq, roff, rlen, list, n, comp);
+    CRASS_LAUNCH(k_cons_flip, dim3(std::min<uint32_t>((n + 3) / 4, 4096u)), dim3(256), 0, st, seq, roff, rlen, list, n, comp);
     return hipGetLastError();
 }
 hipError_t launch_cons_cover(const uint8_t *seq, const uint64_t *roff, const uint32_t *rlen, const uint32_t *plc_rec, const int32_t *plc_pos,
@@ -321,10 +321,10 @@ hipError_t launch_cons_cover(const uint8_t *seq, const uint64_t *roff, const uin
     const size_t lds = (size_t)length * 16;
     if (lds <= 64 * 1024) {
         const uint32_t nb = std::max<uint32_t>(1u, std::min<uint32_t>((n_plc + 63) / 64, 64u));
-        hipLaunchKernelGGL(k_cons_cover_lds, dim3(nb), dim3(256), lds, st, seq, roff, rlen, plc_rec, plc_pos, n_plc, cov, length);
+        CRASS_LAUNCH(k_cons_cover_lds, dim3(nb), dim3(256), lds, st, seq, roff, rlen, plc_rec, plc_pos, n_plc, cov, length);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_cons_cover, dim3(std::min<uint32_t>((n_plc + 3) / 4, 8192u)), dim3(256), 0, st, seq, roff, rlen, plc_rec, plc_pos, n_plc, cov, length);
+    CRASS_LAUNCH(k_cons_cover, dim3(std::min<uint32_t>((n_plc + 3) / 4, 8192u)), dim3(256), 0, st, seq, roff, rlen, plc_rec, plc_pos, n_plc, cov, length);
     return hipGetLastError();
 }
 hipError_t launch_cons_ksw(const uint8_t *q_codes, const uint32_t *q_off, const uint32_t *q_len, const uint32_t *q_tgt, uint32_t n_str, uint32_t max_qlen,
@@ -336,14 +336,14 @@ hipError_t launch_cons_ksw(const uint8_t *q_codes, const uint32_t *q_off, const 
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cons_ksw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cons_ksw, dim3((2 * n_str + 63) / 64), dim3(64), lds, st, q_codes, q_off, q_len, q_tgt, n_str, t_codes, t_off, t_len, P, nvec_max, out);
+    CRASS_LAUNCH(k_cons_ksw, dim3((2 * n_str + 63) / 64), dim3(64), lds, st, q_codes, q_off, q_len, q_tgt, n_str, t_codes, t_off, t_len, P, nvec_max, out);
     return hipGetLastError();
 }
 hipError_t launch_cons_sw(const uint8_t *seq, const uint64_t *roff, const uint32_t *rlen, const ConsSwTask *tasks, uint32_t n_tasks,
                           const uint8_t *dr_chars, const uint32_t *dr_off, const uint32_t *dr_len, uint8_t *dirs, ConsSwOut *out, hipStream_t st)
 {
     if (!n_tasks) return hipSuccess;
-    hipLaunchKernelGGL(k_cons_sw, dim3(std::min<uint32_t>((n_tasks + 3) / 4, 16384u)), dim3(256), 0, st, seq, roff, rlen, tasks, n_tasks, dr_chars, dr_off,
+    CRASS_LAUNCH(k_cons_sw, dim3(std::min<uint32_t>((n_tasks + 3) / 4, 16384u)), dim3(256), 0, st, seq, roff, rlen, tasks, n_tasks, dr_chars, dr_off,
                        dr_len, dirs, out);
     return hipGetLastError();
 }

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void k_xg_fill(const char *dx_chars, const uin
 hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride, uint64_t cap_rows,
                           uint32_t slot_bytes, uint8_t *send, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_xg_fill, dim3((unsigned)((cap_rows + 255) / 256)), dim3(256), 0, st, dx_chars, dx_len, d_nd, stride, cap_rows, slot_bytes, send);
+    CRASS_LAUNCH(k_xg_fill, dim3((unsigned)((cap_rows + 255) / 256)), dim3(256), 0, st, dx_chars, dx_len, d_nd, stride, cap_rows, slot_bytes, send);
     return hipGetLastError();
 }
 // rank order == global read order: rank r's rows go to [off_r, off_r + n_r)
@@ -576,7 +576,9 @@ __global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t
     const uint64_t n_r = *reinterpret_cast<const uint64_t *>(recv + r * send_bytes);
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (r == 0 && i == 0) {
-        xinfo[0] = (uint32_t)total; xinfo[1] = (uint32_t)mine; xinfo[2] = mx > cap_rows ? 1u : 0u; xinfo[3] = (uint32_t)mx;
+        // (a list that did not fit: no row is unpacked, and the kernels queued behind this one see an EMPTY global list —
+        // with the sum of the headers they would walk rows of g_chars / g_len that nobody wrote)
+        xinfo[0] = mx > cap_rows ? 0u : (uint32_t)total; xinfo[1] = (uint32_t)mine; xinfo[2] = mx > cap_rows ? 1u : 0u; xinfo[3] = (uint32_t)mx;
         if (h_xinfo) { h_xinfo[0] = (uint32_t)total; h_xinfo[1] = (uint32_t)mine; h_xinfo[2] = mx > cap_rows ? 1u : 0u; h_xinfo[3] = (uint32_t)mx; }   // pinned mirror
     }
     if (mx > cap_rows || i >= n_r) return;
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
                             char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo)
 {
-    hipLaunchKernelGGL(k_xg_unpack, dim3((unsigned)((cap_rows + 255) / 256), world), dim3(256), 0, st, recv, world, rank, stride, cap_rows,
+    CRASS_LAUNCH(k_xg_unpack, dim3((unsigned)((cap_rows + 255) / 256), world), dim3(256), 0, st, recv, world, rank, stride, cap_rows,
                        slot_bytes, g_chars, g_len, xinfo, h_xinfo);
     return hipGetLastError();
 }
@@ -598,21 +600,21 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done
 {
     if (M.n_tok == 0) return hipErrorInvalidValue;
     const unsigned nb = (M.n_tok + 255) / 256;
-    if (!init_done) hipLaunchKernelGGL(k_dm_init, dim3(1024), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_pack_codes, dim3((M.n_tok + 3) / 4), dim3(256), 0, st, M);       // one wave per token
+    if (!init_done) CRASS_LAUNCH(k_dm_init, dim3(1024), dim3(256), 0, st, M);
+    CRASS_LAUNCH(k_dm_pack_codes, dim3((M.n_tok + 3) / 4), dim3(256), 0, st, M);       // one wave per token
     // every wave must be resident: at most one block per CU (16 waves of the CU's 32 wave slots, no LDS)
     unsigned gb = (M.n_tok + 15) / 16;
     if (gb > M.n_cu) gb = M.n_cu;
-    hipLaunchKernelGGL(k_dm_greedy, dim3(gb), dim3(1024), 0, st, M);
-    hipLaunchKernelGGL(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_rd_fill, dim3(nb), dim3(256), 0, st, M);
+    CRASS_LAUNCH(k_dm_greedy, dim3(gb), dim3(1024), 0, st, M);
+    CRASS_LAUNCH(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
+    CRASS_LAUNCH(k_dm_rd_fill, dim3(nb), dim3(256), 0, st, M);
     unsigned rb = (M.n_tok + 3) / 4;
     if (rb > 4096) rb = 4096;
-    hipLaunchKernelGGL(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
+    CRASS_LAUNCH(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
     const unsigned ne = (16u * M.n_tok + 255) / 256;
-    hipLaunchKernelGGL(k_dm_keys, dim3(ne), dim3(256), 0, st, M);
-    hipLaunchKernelGGL(k_dm_key_bases_insert, dim3((16u * M.n_tok + 1023) / 1024), dim3(1024), 0, st, M);
-    hipLaunchKernelGGL(k_dm_fill_finish, dim3(std::max(std::max(128u, ne), (unsigned)(((1ull << M.tab_log_alloc) + 255) / 256))), dim3(256), 0, st, M);
+    CRASS_LAUNCH(k_dm_keys, dim3(ne), dim3(256), 0, st, M);
+    CRASS_LAUNCH(k_dm_key_bases_insert, dim3((16u * M.n_tok + 1023) / 1024), dim3(1024), 0, st, M);
+    CRASS_LAUNCH(k_dm_fill_finish, dim3(std::max(std::max(128u, ne), (unsigned)(((1ull << M.tab_log_alloc) + 255) / 256))), dim3(256), 0, st, M);
     return hipGetLastError();
 }
 
@@ -835,8 +837,8 @@ hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t
     const bool shortr = R.uniform_len >= 16 && ((R.uniform_len - 16) >> 3) < DV_GL && ((R.uniform_len + 15) >> 4) <= DV_MAXW && !dv_one;
     uint64_t nb = shortr ? (n_max + 4 * DV_G - 1) / (4 * DV_G) : (n_max + 3) / 4;
     if (nb > 8192) nb = 8192;
-    if (shortr) hipLaunchKernelGGL(k_dm_verify<true>, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
-    else hipLaunchKernelGGL(k_dm_verify<false>, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    if (shortr) CRASS_LAUNCH(k_dm_verify<true>, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    else CRASS_LAUNCH(k_dm_verify<false>, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
     return hipGetLastError();
 }
 

@@ -131,14 +131,14 @@ template <typename T> struct DevBuf {
         if (want == 0) want = 1;
         const uint64_t cap = g_dev_cap.load(std::memory_order_relaxed);
         if (cap && g_dev_bytes.load(std::memory_order_relaxed) + want * sizeof(T) > cap) return hipErrorOutOfMemory;
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        hipError_t e = crass::dev_alloc((void **)&p, want * sizeof(T));
         if (e == hipSuccess) { n = want; g_dev_bytes.fetch_add(want * sizeof(T), std::memory_order_relaxed); }
         else p = nullptr;
         return e;
     }
     void release()
     {
-        if (p) { (void)hipFree(p); g_dev_bytes.fetch_sub(n * sizeof(T), std::memory_order_relaxed); }
+        if (p) { crass::dev_free(p); g_dev_bytes.fetch_sub(n * sizeof(T), std::memory_order_relaxed); }
         p = nullptr; n = 0;
     }
 };
@@ -1910,7 +1910,11 @@ static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint1
     const uint64_t my_nd = dev ? c->n_dx : c->dx_len.size();
     const uint32_t *my_map = dev ? c->h_dmap.p : c->dx_map.data();
     const size_t my_n = dev ? (size_t)c->dense.n : c->dx_map.size();
-    if (my_offset + my_nd > n_global) return CRASS_ERR_INVALID_ARG;
+    if (my_offset + my_nd > n_global) {
+        if (getenv("CRASS_GROUP_DEBUG")) fprintf(stderr, "[crass_xchg] merge_global_host: offset %llu + own %llu > global %llu (dev %d)\n",
+                                                 (unsigned long long)my_offset, (unsigned long long)my_nd, (unsigned long long)n_global, (int)dev);
+        return CRASS_ERR_INVALID_ARG;
+    }
     merge_candidates(c->merge, dr_chars, dr_len, dr_stride, n_global, c->prm.kmer_clust_size);
     // tokens of this context's own candidates through their distinct index
     std::vector<uint32_t> own(my_n);

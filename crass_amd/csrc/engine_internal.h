@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <hip/hip_runtime.h>
+#include "devmem.h"
 
 namespace crass {
 

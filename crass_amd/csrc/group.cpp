@@ -11,6 +11,7 @@
 #include "../../include/crass_hip.h"
 
 #include <hip/hip_runtime.h>
+#include "devmem.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 
@@ -150,8 +151,8 @@ int setup_exchange(crass_hip_group *g, int r)
     int s = crass_hip_exchange_setup(g->ctx[r], (uint32_t)g->n, (uint32_t)r, g->cap_rows, &g->xc[r]);
     if (s) return s;
     if (hipSetDevice(g->devices[r]) != hipSuccess) return CRASS_ERR_HIP;
-    if (g->recv[r]) { (void)hipFree(g->recv[r]); g->recv[r] = nullptr; }
-    if (hipMalloc(&g->recv[r], (size_t)g->n * g->xc[r].send_bytes) != hipSuccess) return CRASS_ERR_OOM;
+    if (g->recv[r]) { crass::dev_free(g->recv[r]); g->recv[r] = nullptr; }
+    if (crass::dev_alloc(&g->recv[r], (size_t)g->n * g->xc[r].send_bytes) != hipSuccess) return CRASS_ERR_OOM;
     return CRASS_OK;
 }
 
@@ -349,7 +350,7 @@ void crass_hip_group_destroy(crass_hip_group *g)
     g->cv.notify_all();
     for (auto &t : g->threads) t.join();
     for (int r = 0; r < g->n; r++) {
-        if (g->recv[r]) { (void)hipSetDevice(g->devices[r]); (void)hipFree(g->recv[r]); }
+        if (g->recv[r]) { (void)hipSetDevice(g->devices[r]); crass::dev_free(g->recv[r]); }
         if (g->ctx[r]) {
             (void)hipSetDevice(g->devices[r]);
             (void)hipStreamSynchronize((hipStream_t)crass_hip_stream(g->ctx[r]));

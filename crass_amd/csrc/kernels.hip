@@ -67,14 +67,14 @@ __global__ void k_mark_found(const uint64_t *idx, uint64_t n, const uint64_t *he
 hipError_t launch_mark_found(const uint64_t *idx, uint64_t n, const uint64_t *header_id, uint8_t *found_flag, hipStream_t st)
 {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_mark_found, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, n, header_id, found_flag);
+    CRASS_LAUNCH(k_mark_found, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, n, header_id, found_flag);
     return hipGetLastError();
 }
 
 hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st)
 {
     if (!n_exc) return hipSuccess;
-    hipLaunchKernelGGL(k_build_exc_mask, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, st, exc_read, n_exc, exc_mask);
+    CRASS_LAUNCH(k_build_exc_mask, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, st, exc_read, n_exc, exc_mask);
     return hipGetLastError();
 }
 
@@ -150,7 +150,7 @@ hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t
     uint64_t blocks = (n_words + FG_WAVES - 1) / FG_WAVES;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_filter_general, dim3((unsigned)blocks), dim3(FG_WAVES * WAVE), lds, st, R, P, hitmask, wpw);
+    CRASS_LAUNCH(k_filter_general, dim3((unsigned)blocks), dim3(FG_WAVES * WAVE), lds, st, R, P, hitmask, wpw);
     return hipGetLastError();
 }
 
@@ -244,11 +244,11 @@ hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *h
     if (blocks > 0x7FFFFFFFull) return hipErrorNotSupported;
     dim3 g((unsigned)blocks), b(256);
     // common uniform read lengths get the compile-time clamp
-#define FF_LEN(LL, WW) if (R.uniform_len == LL && R.stride_words == WW) { hipLaunchKernelGGL((k_filter_fast_impl<WW, 49, 97, LL>), g, b, 0, st, R, P, hitmask, seed_hint); return hipGetLastError(); }
+#define FF_LEN(LL, WW) if (R.uniform_len == LL && R.stride_words == WW) { CRASS_LAUNCH((k_filter_fast_impl<WW, 49, 97, LL>), g, b, 0, st, R, P, hitmask, seed_hint); return hipGetLastError(); }
     FF_LEN(100, 7) FF_LEN(101, 7) FF_LEN(125, 8) FF_LEN(126, 8) FF_LEN(150, 10) FF_LEN(151, 10) FF_LEN(250, 16) FF_LEN(251, 16)
 #undef FF_LEN
     switch (R.stride_words) {
-#define FF_CASE(WW) case WW: hipLaunchKernelGGL((k_filter_fast_impl<WW, 49, 97, 0>), g, b, 0, st, R, P, hitmask, seed_hint); break;
+#define FF_CASE(WW) case WW: CRASS_LAUNCH((k_filter_fast_impl<WW, 49, 97, 0>), g, b, 0, st, R, P, hitmask, seed_hint); break;
         FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8) FF_CASE(9) FF_CASE(10)
         FF_CASE(11) FF_CASE(12) FF_CASE(13) FF_CASE(14) FF_CASE(15) FF_CASE(16)
 #undef FF_CASE
@@ -344,7 +344,7 @@ hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const ui
 {
     if (P.window != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return hipErrorNotSupported;
     if (n_words == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_hint_positions, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, R, hint_off, blk_read, n_words, hint_bits);
+    CRASS_LAUNCH(k_hint_positions, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, R, hint_off, blk_read, n_words, hint_bits);
     return hipGetLastError();
 }
 
@@ -557,10 +557,10 @@ hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bit
         const uint32_t tw = lookback_tile_words(n_words);
         const uint32_t n_tiles = (uint32_t)((n_words + tw - 1) / tw);
         if (tw == 256)
-            hipLaunchKernelGGL(k_mask_compact_lb<256>, dim3(n_tiles), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
+            CRASS_LAUNCH(k_mask_compact_lb<256>, dim3(n_tiles), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
                                d_count, zero_a, n_a, zero_b, n_b, *lb, n_tiles);
         else
-            hipLaunchKernelGGL(k_mask_compact_lb<1024>, dim3(n_tiles), dim3(1024), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
+            CRASS_LAUNCH(k_mask_compact_lb<1024>, dim3(n_tiles), dim3(1024), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
                                d_count, zero_a, n_a, zero_b, n_b, *lb, n_tiles);
         return hipGetLastError();
     }
@@ -570,9 +570,9 @@ hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bit
         return hipMemsetAsync(d_count, 0, 4, st);
     }
     unsigned nb = (unsigned)((n_words + 255) / 256);
-    hipLaunchKernelGGL(k_mask_count, dim3(nb), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums);
-    hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, d_count, zero_a, n_a, zero_b, n_b);
-    hipLaunchKernelGGL(k_mask_scatter, dim3(nb), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap);
+    CRASS_LAUNCH(k_mask_count, dim3(nb), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums);
+    CRASS_LAUNCH(k_block_scan, dim3(1), dim3(1024), 0, st, block_sums, nb, d_count, zero_a, n_a, zero_b, n_b);
+    CRASS_LAUNCH(k_mask_scatter, dim3(nb), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap);
     return hipGetLastError();
 }
 
@@ -2045,7 +2045,7 @@ hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const ui
     if (!R.stride_words || R.stride_words > 16 || ss_cap > 64) return hipErrorNotSupported;
     const uint32_t wpr = R.stride_words;
     const size_t lds = (size_t)(wpr + 5) * WAVE * 4 + (size_t)ss_cap * WAVE * 2;
-    hipLaunchKernelGGL(k_survivor_lanes, dim3((unsigned)((n_surv_max + WAVE - 1) / WAVE)), dim3(WAVE), lds, st, R, P, surv_idx, d_n_surv,
+    CRASS_LAUNCH(k_survivor_lanes, dim3((unsigned)((n_surv_max + WAVE - 1) / WAVE)), dim3(WAVE), lds, st, R, P, surv_idx, d_n_surv,
                        n_surv_max, out, dr_chars, dr_stride, ss_pool, ss_cap, found_flag, seed_hint, wpr, init_merge ? *init_merge : DevMerge{},
                        init_merge ? 1 : 0);
     return hipGetLastError();
@@ -2184,7 +2184,7 @@ hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_
 {
     if (n_max == 0) return hipSuccess;
     const uint32_t n_tiles = (uint32_t)((n_max + kLbElemsPerTile - 1) / kLbElemsPerTile);
-    hipLaunchKernelGGL(k_found_compact, dim3(n_tiles), dim3(1024), 0, st, out, d_n, n_max, d_err, dd_keys, dd_first, dd_keys ? dd_size : 0u,
+    CRASS_LAUNCH(k_found_compact, dim3(n_tiles), dim3(1024), 0, st, out, d_n, n_max, d_err, dd_keys, dd_first, dd_keys ? dd_size : 0u,
                        fidx, d_nf, lb, n_tiles);
     return hipGetLastError();
 }
@@ -2228,7 +2228,7 @@ __global__ __launch_bounds__(256) void k_gather_sparse(const uint64_t *fidx, con
 hipError_t launch_select_found(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_select_found, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, mask, d_err);
+    CRASS_LAUNCH(k_select_found, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, mask, d_err);
     return hipGetLastError();
 }
 hipError_t launch_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out, const char *dr_chars, uint32_t dr_stride,
@@ -2236,7 +2236,7 @@ hipError_t launch_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint
                                 uint32_t *d_ss_total, hipStream_t st)
 {
     if (n_max == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gather_sparse, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, dr_chars, dr_stride, ss_pool,
+    CRASS_LAUNCH(k_gather_sparse, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, dr_chars, dr_stride, ss_pool,
                        g_out, g_slot, g_dr, g_ss, g_ss_cap, d_ss_total);
     return hipGetLastError();
 }
@@ -2245,7 +2245,7 @@ hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n
                              unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_found_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, d_n, n, mask, d_err, dd_keys, dd_first, dd_keys ? dd_size : 0u);
+    CRASS_LAUNCH(k_found_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, d_n, n, mask, d_err, dd_keys, dd_first, dd_keys ? dd_size : 0u);
     return hipGetLastError();
 }
 
@@ -2257,7 +2257,7 @@ hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint6
 {
     if (n_max == 0) return hipSuccess;
     if ((ss_cap & 3u) || (ss_elem != 1 && ss_elem != 2)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_gather_found, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, surv_idx,
+    CRASS_LAUNCH(k_gather_found, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, surv_idx,
                        read_base, dr_chars, dr_stride, ss_pool, ss_cap, ss_elem, h_blob, g_dr_len, g_dr,
                        dd_keys, dd_first, dd_keys ? dd_size - 1 : 0u, dd_hash, dd_slot);
     return hipGetLastError();
@@ -2294,9 +2294,9 @@ hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t str
                             bool table_cleared)
 {
     if (n == 0) return hipSuccess;
-    if (!table_cleared) hipLaunchKernelGGL(k_dr_dedupe_clear, dim3((unsigned)std::min<uint32_t>((table_size + 255) / 256, 2048u)), dim3(256), 0, st, keys, first, table_size);
+    if (!table_cleared) CRASS_LAUNCH(k_dr_dedupe_clear, dim3((unsigned)std::min<uint32_t>((table_size + 255) / 256, 2048u)), dim3(256), 0, st, keys, first, table_size);
     const unsigned nb = (n + 255) / 256;
-    hipLaunchKernelGGL(k_dr_dedupe_insert, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, keys, first, table_size - 1, hash_out, slot_tmp);
+    CRASS_LAUNCH(k_dr_dedupe_insert, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, keys, first, table_size - 1, hash_out, slot_tmp);
     (void)rep;                                  // rep[] = first occurrence of every candidate: written by k_dx_flag
     return hipGetLastError();
 }
@@ -2438,17 +2438,17 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
     const unsigned nb = (n + 255) / 256;
     if (lb) {           // two launches: flags + single-pass compaction (element-wise look-back), dense assign + gather
         const uint32_t n_tiles = (n + 1023u) / 1024u;                               // (the caller reserved that many tickets)
-        hipLaunchKernelGGL(k_dx_flag_compact, dim3(n_tiles), dim3(1024), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, dx_idx, d_nd, d_mismatch,
+        CRASS_LAUNCH(k_dx_flag_compact, dim3(n_tiles), dim3(1024), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, dx_idx, d_nd, d_mismatch,
                            *lb, n_tiles);
-        hipLaunchKernelGGL(k_dx_assign_gather, dim3(nb), dim3(256), 0, st, rep, d_n, n, (const uint32_t *)slot_of, dmap, dx_idx, d_nd, dr, dr_len,
+        CRASS_LAUNCH(k_dx_assign_gather, dim3(nb), dim3(256), 0, st, rep, d_n, n, (const uint32_t *)slot_of, dmap, dx_idx, d_nd, dr, dr_len,
                            hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len, cnt_src, cnt_dst, cnt_dst ? n_cnt : 0u);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, mask, d_mismatch);
+    CRASS_LAUNCH(k_dx_flag, dim3(nb), dim3(256), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, mask, d_mismatch);
     hipError_t e = launch_compact(mask, (n + 63) / 64, n, word_prefix, block_sums, dx_idx, n, d_nd, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap);
-    hipLaunchKernelGGL(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len,
+    CRASS_LAUNCH(k_dx_assign, dim3(nb), dim3(256), 0, st, rep, d_n, n, mask, word_prefix, block_sums, dmap);
+    CRASS_LAUNCH(k_dx_gather, dim3(nb), dim3(256), 0, st, dx_idx, d_nd, n, dr, dr_len, hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len,
                        cnt_src, cnt_dst, cnt_dst ? n_cnt : 0u);
     return hipGetLastError();
 }
@@ -2477,12 +2477,12 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
     if (exceptions) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_survivor<true>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
+        CRASS_LAUNCH(k_survivor<true>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
                            out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_survivor<false>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
+        CRASS_LAUNCH(k_survivor<false>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
                            out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only);
     }
     return hipGetLastError();
@@ -2576,9 +2576,9 @@ hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, cons
     uint64_t blocks = (n_tiles + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (A.acgt_ok && A.go4)
-        hipLaunchKernelGGL((k_recruit<false, 256>), dim3((unsigned)blocks), dim3(256), 0, st, R, A, found_flag, hitmask, hit_info);
+        CRASS_LAUNCH((k_recruit<false, 256>), dim3((unsigned)blocks), dim3(256), 0, st, R, A, found_flag, hitmask, hit_info);
     else
-        hipLaunchKernelGGL(k_recruit_wide, dim3((unsigned)blocks), dim3(256), 0, st, R, A, found_flag, hitmask, hit_info);
+        CRASS_LAUNCH(k_recruit_wide, dim3((unsigned)blocks), dim3(256), 0, st, R, A, found_flag, hitmask, hit_info);
     return hipGetLastError();
 }
 
@@ -2600,7 +2600,7 @@ hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const ui
 #define RC_LAUNCH(T)                                                                                                   \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_recruit<true, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                                                     \
-    hipLaunchKernelGGL((k_recruit<true, T>), dim3((unsigned)blocks), dim3(T), lds, st, R, A, found_flag, hitmask, hit_info);
+    CRASS_LAUNCH((k_recruit<true, T>), dim3((unsigned)blocks), dim3(T), lds, st, R, A, found_flag, hitmask, hit_info);
     if (threads == 1024) { RC_LAUNCH(1024) }
     else if (threads == 512) { RC_LAUNCH(512) }
     else { RC_LAUNCH(256) }
@@ -2869,7 +2869,7 @@ hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const 
     {                                                                                                                   \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_anchor_filter_dev<WW, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                  \
-        hipLaunchKernelGGL((k_anchor_filter_dev<WW, T>), dim3((unsigned)blocks), dim3(T), lds, st, R, M, found_flag, hitmask); \
+        CRASS_LAUNCH((k_anchor_filter_dev<WW, T>), dim3((unsigned)blocks), dim3(T), lds, st, R, M, found_flag, hitmask); \
     }
     switch (R.stride_words) {
         case 4: AKD_LAUNCH(4) break;  case 5: AKD_LAUNCH(5) break;  case 6: AKD_LAUNCH(6) break;  case 7: AKD_LAUNCH(7) break;
@@ -2899,7 +2899,7 @@ hipError_t launch_anchor_filter(const DevReads &R, const DevAnchors &K, const ui
     {                                                                                                                   \
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_anchor_filter<WW, T, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                  \
-        hipLaunchKernelGGL((k_anchor_filter<WW, T, MM>), dim3((unsigned)blocks), dim3(T), lds, st, R, K, found_flag, hitmask); \
+        CRASS_LAUNCH((k_anchor_filter<WW, T, MM>), dim3((unsigned)blocks), dim3(T), lds, st, R, K, found_flag, hitmask); \
     }
 #define AK_LAUNCH(WW)                                                                                                   \
     if (!in_lds) AK_LAUNCH_M(WW, 2) else if (K.mode == 1) AK_LAUNCH_M(WW, 1) else AK_LAUNCH_M(WW, 0)
@@ -3001,9 +3001,9 @@ hipError_t launch_recruit_list(const DevReads &R, const DevAutomaton &A, const u
 {
     if (n_max == 0) return hipSuccess;
     if (R.pos_hint && A.max_pat_len)                       // long reads (the engine builds position hints beyond 2 kbp)
-        hipLaunchKernelGGL(k_recruit_list_wave, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);
+        CRASS_LAUNCH(k_recruit_list_wave, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);
     else
-        hipLaunchKernelGGL(k_recruit_list, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);
+        CRASS_LAUNCH(k_recruit_list, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);
     return hipGetLastError();
 }
 
@@ -3032,7 +3032,7 @@ hipError_t launch_recruit_exceptions(const DevReads &R, const DevAutomaton &A, c
                                      uint32_t *exc_hit_info, hipStream_t st)
 {
     if (R.n_exc == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_recruit_exc, dim3((unsigned)((R.n_exc + 255) / 256)), dim3(256), 0, st, R, A, found_flag, exc_hit_info);
+    CRASS_LAUNCH(k_recruit_exc, dim3((unsigned)((R.n_exc + 255) / 256)), dim3(256), 0, st, R, A, found_flag, exc_hit_info);
     return hipGetLastError();
 }
 
@@ -3161,9 +3161,9 @@ hipError_t launch_recruit_finish(const DevReads &R, const uint64_t *hit_idx, con
     if (n_hits_max == 0) return hipSuccess;
     unsigned nb = (unsigned)((n_hits_max + 255) / 256);
     if (exceptions)
-        hipLaunchKernelGGL(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, 1, pid_by_slot, pat_token, out, dr_chars, dr_stride, (const uint64_t *)nullptr);
+        CRASS_LAUNCH(k_recruit_finish<true>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, 1, pid_by_slot, pat_token, out, dr_chars, dr_stride, (const uint64_t *)nullptr);
     else
-        hipLaunchKernelGGL(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, info_by_slot ? 1 : 0, pid_by_slot, pat_token, out, dr_chars, dr_stride, pat_mask);
+        CRASS_LAUNCH(k_recruit_finish<false>, dim3(nb), dim3(256), 0, st, R, hit_idx, d_n_hits, n_hits_max, hit_info, info_by_slot ? 1 : 0, pid_by_slot, pat_token, out, dr_chars, dr_stride, pat_mask);
     return hipGetLastError();
 }
 
@@ -3224,14 +3224,14 @@ hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, u
     const unsigned nb = (unsigned)((n_hits_max + 255) / 256);
     if (lb) {           // (the caller reserved nb tiles)
         const unsigned nt = (unsigned)((n_hits_max + kLbElemsPerTile - 1) / kLbElemsPerTile);
-        hipLaunchKernelGGL(k_valid_compact, dim3(nt), dim3(1024), 0, st, rec, d_n_hits, n_hits_max, vidx, d_nv, *lb, nt);
-        hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
+        CRASS_LAUNCH(k_valid_compact, dim3(nt), dim3(1024), 0, st, rec, d_n_hits, n_hits_max, vidx, d_nv, *lb, nt);
+        CRASS_LAUNCH(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_recruit_valid_mask, dim3(nb), dim3(256), 0, st, rec, d_n_hits, n_hits_max, mask);
+    CRASS_LAUNCH(k_recruit_valid_mask, dim3(nb), dim3(256), 0, st, rec, d_n_hits, n_hits_max, mask);
     hipError_t e = launch_compact(mask, (n_hits_max + 63) / 64, n_hits_max, word_prefix, block_sums, vidx, n_hits_max, d_nv, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
+    CRASS_LAUNCH(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
     return hipGetLastError();
 }
 
@@ -3290,9 +3290,9 @@ hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off,
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lev_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     // `dist` is always a device buffer here (engine.cpp allocates it even if the caller wants only sims)
-    hipLaunchKernelGGL(k_lev_batch_lanes, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, chars, a_off, a_len, b_off, b_len, n_pairs, dist, sim);
+    CRASS_LAUNCH(k_lev_batch_lanes, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, chars, a_off, a_len, b_off, b_len, n_pairs, dist, sim);
     uint64_t grid = n_pairs < 4096 ? n_pairs : 4096;
-    hipLaunchKernelGGL(k_lev_batch, dim3((unsigned)grid), dim3(WAVE), lds, st, chars, a_off, a_len, b_off, b_len, n_pairs, dist, sim, row_elems, str_bytes);
+    CRASS_LAUNCH(k_lev_batch, dim3((unsigned)grid), dim3(WAVE), lds, st, chars, a_off, a_len, b_off, b_len, n_pairs, dist, sim, row_elems, str_bytes);
     return hipGetLastError();
 }
 

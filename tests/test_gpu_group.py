@@ -102,6 +102,39 @@ def test_group_exchange_overflow_grows_the_buffers(ca):
     assert_same_pipeline(grp, orc.pipeline(seqs))
 
 
+_HYGIENE = r"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import crass_amd as ca
+from tests.test_gpu_parity import synth_reads
+ca.load()
+seqs = synth_reads(ca, 60000, read_len=150, crispr_per_million=100000, n_dr=300)
+one = ca.search_pipeline(seqs)
+os.environ["CRASS_GROUP_CAP_ROWS"] = "64"
+grp = ca.search_pipeline_group(seqs, [0, 0], local_copies=True, fused=False)
+os.environ.pop("CRASS_GROUP_CAP_ROWS")
+big = ca.search_pipeline_group(seqs, [0, 0, 0], local_copies=True, fused=True)
+for g in (grp, big):
+    assert g.tokens == one.tokens and g.groups == one.groups and g.patterns == one.patterns
+    np.testing.assert_array_equal(g.rec_read, one.rec_read)
+    np.testing.assert_array_equal(g.rec_token, one.rec_token)
+print("hygiene ok", grp.n_tokens)
+"""
+
+
+@pytest.mark.parametrize("env", [{"CRASS_POISON": "1"}, {"CRASS_GUARD_PAGES": "1"}, {"CRASS_GUARD_PAGES": "1", "CRASS_POISON": "1"}])
+def test_overflowed_exchange_reads_no_unwritten_rows(env):
+    """csrc/devmem.h's debugging allocators, in a child process (the switches are read once): fresh buffers filled with
+    0xA5 instead of zero and / or every buffer between unmapped pages.  An exchange whose lists did not fit used to leave
+    the sum of the headers as the device-side row count: the de-duplication queued behind it walked rows nobody had
+    written — harmless zeros in a young process, a wild length and a memory fault once hipMalloc recycled a block."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _HYGIENE], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "hygiene ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_group_gathered_bound_overflow(ca):
     """the bound for the GLOBAL distinct list (merge queued behind the exchange's de-duplication) too small: the merge is
     launched again with the exact count, same result"""

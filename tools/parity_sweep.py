@@ -37,20 +37,37 @@ for case in range(n_cases):
             seqs[i] = bytes(b)
     p = ca.default_params(kmer_clust_size=k)
     host = rng.random() < 0.15
-    only = os.environ.get("ONLY")                # comma-separated case indices: replay just those (same random stream)
     use_eng = rng.random() < 0.7 and k == 6
     pad = rng.choice([0, 2])
+    # a third of the cases go through a GROUP of 2-4 contexts sharing the GPU (crass_hip_group_*: contiguous shards, the
+    # exchange as device copies, one host view), sometimes with duplicate headers across the shards and a tiny exchange buffer
+    grp = rng.choice([0, 0, 2, 3, 4])
+    hdrs = None
+    if grp and rng.random() < 0.3:
+        hdrs = [b"h%d" % (i if rng.random() > 0.05 else rng.randrange(0, i + 1)) for i in range(n)]
+    small_cap = grp and rng.random() < 0.2
+    fused = bool(grp) and rng.random() < 0.5
+    tag = "L=%d n=%d n_dr=%d cpm=%d k=%d ragged=%d host=%d N=%d grp=%d%s%s%s pad=%d eng=%d" % (
+        L, n, n_dr, cpm, k, ragged, host, with_n, grp, "h" if hdrs else "", "c" if small_cap else "", "f" if fused else "", pad, use_eng)
+    only = os.environ.get("ONLY")                # comma-separated case indices: replay just those (same random stream)
     if only and case not in {int(x) for x in only.split(",")}:
         continue
+    print("run  case %d %s" % (case, tag), file=sys.stderr, flush=True)
     if host:
         os.environ["CRASS_HOST_MERGE"] = "1"
+    if small_cap:
+        os.environ["CRASS_GROUP_CAP_ROWS"] = "64"
     try:
-        gpu = ca.search_pipeline(seqs, params=p, engine=eng if use_eng else None, pad_uniform=pad)
+        if grp:
+            gpu = ca.search_pipeline_group(seqs, [0] * grp, headers=hdrs, params=p, local_copies=True, pad_uniform=pad, fused=fused)
+            gpu.counters = gpu.counters[0]
+        else:
+            gpu = ca.search_pipeline(seqs, params=p, engine=eng if use_eng else None, pad_uniform=pad)
     finally:
         os.environ.pop("CRASS_HOST_MERGE", None)
-    ref = orc.pipeline(seqs, params=orc.Params(p.lowDRsize, p.highDRsize, p.lowSpacerSize, p.highSpacerSize, p.searchWindowLength,
+        os.environ.pop("CRASS_GROUP_CAP_ROWS", None)
+    ref = orc.pipeline(seqs, hdrs, params=orc.Params(p.lowDRsize, p.highDRsize, p.lowSpacerSize, p.highSpacerSize, p.searchWindowLength,
                                                p.minNumRepeats, p.kmer_clust_size))
-    tag = "L=%d n=%d n_dr=%d cpm=%d k=%d ragged=%d host=%d N=%d" % (L, n, n_dr, cpm, k, ragged, host, with_n)
     try:
         assert_same_pipeline(gpu, ref)
         print("ok   %-60s pass1 %6d pass2 %6d groups %4d patterns %5d devmerge %d mixed tokens %d" % (

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 GPU session (staged: a failing stage stops the session before the long ones run).
-# usage: r03_session.sh <tag> [stages]   stages: smoke,ubench,tests,bench,prof,pmc (default: all)
+# usage: r03_session.sh <tag> [stages]   stages: smoke,ubench,tests,bench,prof,e2e,sweep,hygiene,other,pmc3,pmc (default: the first row)
 set -u
 tag=${1:-r03b}
 stages=${2:-smoke,ubench,tests,bench,prof,pmc}
@@ -57,12 +57,20 @@ if has sweep; then
   cd $GRAFT_REPO_ROOT
   timeout 900 python tools/parity_sweep.py 300 ${SEED:-43} > $out/sweep.txt 2>&1; tail -2 $out/sweep.txt
 fi
+if has hygiene; then
+  cd $GRAFT_REPO_ROOT
+  POISON=1 bash tools/mem_hygiene.sh $tag/hygiene > $out/hygiene.txt 2>&1; cat $out/hygiene.txt
+fi
 if has other; then
   cd $GRAFT_REPO_ROOT
   timeout 400 python bench.py --config 3 --steps 10 --warmup 2 --cpu-sample 0 > $out/bench_c3.json 2> $out/bench_c3.err
   timeout 600 python bench.py --config 4 --steps 10 --warmup 2 --cpu-sample 0 > $out/bench_c4.json 2> $out/bench_c4.err
   CRASS_DV_ONE=1 timeout 400 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --single-shots 0 > $out/bench_c2_dv_one.json 2> $out/bench_c2_dv_one.err
   summ $out/bench_c3.json $out/bench_c4.json $out/bench_c2_dv_one.json
+fi
+if has pmc3; then
+  cd $GRAFT_REPO_ROOT
+  bash tools/pmc_round.sh $tag/pmc_c3 3 1000000 10000 > $out/pmc_c3_summary.txt 2>&1; tail -30 $out/pmc_c3_summary.txt
 fi
 if has pmc; then
   cd $GRAFT_REPO_ROOT
