@@ -44,9 +44,9 @@ static __device__ __forceinline__ uint32_t kset_hash(uint32_t key, uint32_t log_
 {
     return (key * 0x9E3779B1u) >> (32u - log_size);
 }
-static __device__ __forceinline__ uint32_t ak_h(uint32_t v, uint32_t s, uint32_t m, uint32_t rsh)
+static __device__ __forceinline__ uint32_t ak_h(uint32_t v, uint32_t m, uint32_t rsh)
 {
-    return ((uint32_t)__umul24(v ^ (v >> s), m)) >> rsh;      // same hash as anchor_probe (kernels.hip)
+    return ak_hash(v, m) >> rsh;                              // same hash as anchor_probe (kernels.hip)
 }
 
 // number of tokens: M.n_tok, or — when the merge is launched before the host knows the count (crass_hip_seed_scan
@@ -470,33 +470,33 @@ __global__ __launch_bounds__(1024) void k_dm_key_bases_insert(DevMerge M)
     uint32_t cur = (uint32_t)M.kset_key[h];
     if (mode == 2) {
         // key sets beyond the LDS tiers: the exact table is probed in L2, behind a 2^20-bit Bloom filter in LDS
-        const uint32_t b1 = ((uint32_t)__umul24(cur ^ (cur >> M.s1), M.m1)) >> 12, b2 = ((uint32_t)__umul24(cur ^ (cur >> M.s2), M.m2)) >> 12;
+        const uint32_t b1 = ak_hash(cur, M.m1) >> 12, b2 = ak_hash(cur, M.m2) >> 12;
         atomicOr(&M.anchor_fp[b1 >> 5], 1u << (b1 & 31u));
         atomicOr(&M.anchor_fp[b2 >> 5], 1u << (b2 & 31u));
     }
     if (cur == 0xFFFFFFFFu) return;
     const uint32_t rsh = 32u - ls;
-    uint32_t pos = ak_h(cur, M.s1, M.m1, rsh);
+    uint32_t pos = ak_h(cur, M.m1, rsh);
     // a free slot of its own first: only a key whose two slots are both taken starts an eviction chain (every link of a
     // chain is a dependent atomic round trip; near load 1/2 — 30 k keys in 2^16 slots at 100 M reads — exchanging
     // unconditionally made 46 % of the keys start one and the longest took ~100 us)
     if (atomicCAS(&M.anchor_tab[pos], 0xFFFFFFFFu, cur) == 0xFFFFFFFFu) return;
     {
-        const uint32_t p2 = ak_h(cur, M.s2, M.m2, rsh);
+        const uint32_t p2 = ak_h(cur, M.m2, rsh);
         if (p2 != pos && atomicCAS(&M.anchor_tab[p2], 0xFFFFFFFFu, cur) == 0xFFFFFFFFu) return;
     }
     for (int kicks = 0; kicks < 1000; kicks++) {
         const uint32_t old = atomicExch(&M.anchor_tab[pos], cur);
         if (old == 0xFFFFFFFFu) return;
         cur = old;
-        const uint32_t p1 = ak_h(cur, M.s1, M.m1, rsh), p2 = ak_h(cur, M.s2, M.m2, rsh);
+        const uint32_t p1 = ak_h(cur, M.m1, rsh), p2 = ak_h(cur, M.m2, rsh);
         pos = (pos == p1) ? p2 : p1;
     }
     atomicOr(&M.st->fail, 4u);
 }
 // ---- 6c. fill the verification index: {r | len << 3 | pid << 32, pattern bits lo, pattern bits hi, N mask} — and, in the
 // same launch (both only need 6b): unused table slots get a member key, so that a probe never matches by accident;
-// tab_mode 3: fingerprint = low 16 bits of (h1 product ^ h2 product) of the slot's key, two per word; the per-token
+// tab_mode 3: 16 bits per slot = the other slot index of the slot's key (anchor_probe_fp), two per word; the per-token
 // results + state words go straight into pinned host memory (a few 10 KB over PCIe, no copy calls): the helper thread
 // rebuilds the host view from them
 __global__ __launch_bounds__(256) void k_dm_fill_finish(DevMerge M)
@@ -527,8 +527,8 @@ __global__ __launch_bounds__(256) void k_dm_fill_finish(DevMerge M)
     for (int q = 0; q < 2; q++) {
         uint32_t v = M.anchor_tab[2 * w + q];
         if (fill && v == 0xFFFFFFFFu) v = k0;           // (the slot's own thread stores the same value)
-        const uint32_t p1 = (uint32_t)__umul24(v ^ (v >> M.s1), M.m1), p2 = (uint32_t)__umul24(v ^ (v >> M.s2), M.m2);
-        out |= ((p1 ^ p2) & 0xFFFFu) << (16 * q);
+        const uint32_t p1 = ak_hash(v, M.m1) >> 16, p2 = ak_hash(v, M.m2) >> 16, slot = 2 * w + q;
+        out |= (slot == p1 ? p2 : p1) << (16 * q);       // the key's other slot (anchor_probe_fp, kernels.hip)
     }
     M.anchor_fp[w] = out;
 }

@@ -307,16 +307,20 @@ struct crass_hip_ctx {
     bool recruit_exact = false;               // the next recruit call must not speculate (it repeats an overflowed one)               // speculative survivor bound for the next seed scan (0: none yet)
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_gathered = nullptr;
+    hipEvent_t ev_premerge = nullptr;           // recorded behind a merge queued in the seed scan: the hand-off copy waits for it
     mutable bool bulk_pending = false;          // rare paths only: D2H copies of the candidates' own strings in flight on copy_stream
     // CRASS_OK, or CRASS_ERR_HIP with last_hip set: a failed copy must not be mistaken for delivered records
     int wait_bulk() const
     {
         if (!bulk_pending) return bulk_status;
         const hipError_t e = hipStreamSynchronize(copy_stream);
+        const int de = sdma_wait(dma);
         bulk_pending = false;
         if (e != hipSuccess) { last_hip = (int)e; bulk_status = CRASS_ERR_HIP; }
+        else if (de) { last_hip = (int)hipErrorUnknown; bulk_status = CRASS_ERR_HIP; }
         return bulk_status;
     }
+    SdmaCopy *dma = nullptr;                    // the hand-off records travel on a DMA engine when the HSA runtime offers one (sdma.cpp)
     mutable int bulk_status = CRASS_OK;         // sticky until the next seed scan issues new copies
     // device-side merge (dmerge.hip): clustering, non-redundant set, anchor keys and the pass-2 verification
     // index are built on the device; the host view (c->merge) is rebuilt from its per-token results while
@@ -516,6 +520,12 @@ static void quiesce_worker(crass_hip_ctx *c)
     }
 }
 
+static bool getenv_once_copy_early()                 // A/B switch: CRASS_COPY_EARLY=1 starts the hand-off copy beside the merge (the old order)
+{
+    static const bool on = getenv("CRASS_COPY_EARLY") != nullptr;
+    return on;
+}
+
 #define HIPCHK(ctx, call)                                                       \
     do {                                                                        \
         hipError_t e__ = (call);                                                \
@@ -589,6 +599,8 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
+    if (hipEventCreateWithFlags(&c->ev_premerge, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
+    c->dma = sdma_create();                             // (nullptr: the copy kernel is used)
     unsigned char tab[128];
     build_comp_table(tab);
     if (upload_comp_table(tab) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
@@ -645,12 +657,15 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->worker.stop();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    (void)sdma_wait(c->dma);                            // (before any buffer goes)
     c->lb_status.release(); c->lb_ticket.release(); c->h_lb_fail.release();
     if (c->xchg.ev_counts) (void)hipEventDestroy(c->xchg.ev_counts);
     c->dm.release(); c->h_qblob.release(); c->xchg.send.release(); c->xchg.xinfo.release(); c->xchg.h_xinfo.release();
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
     if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
+    sdma_destroy(c->dma); c->dma = nullptr;
+    if (c->ev_premerge) (void)hipEventDestroy(c->ev_premerge);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->r_packed.release(); c->r_word_off.release(); c->r_lengths.release(); c->r_header_id.release();
     c->r_exc_mask.release(); c->r_exc_read.release(); c->r_exc_off.release(); c->r_exc_bytes.release();
@@ -1116,6 +1131,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         const int ps = device_merge_enqueue(c, c->dd_dx_chars.p, c->dd_dx_len.p, c->dx_cap_hint, c->d_count.p + 4, prepared);
         if (ps) return ps;
         premerge_queued = true;
+        HIPCHK(c, hipEventRecord(c->ev_premerge, c->stream));
     }
     host_pool_warm();                                   // the merge follows: wake the host workers while the device finishes
     // (with the merge queued behind it, the host waits for pass 1 only — the event recorded above — and goes on to
@@ -1130,8 +1146,20 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     if (err == 1) return CRASS_ERR_SEARCH_FATAL;
     if (err) return CRASS_ERR_OVERFLOW;
     D.lay = p1_blob_layout(nf, lds.ss_cap, ss_elem);
-    if (nf) {           // the hand-off records: the host has waited for the gather, the copy runs beside whatever follows
-        HIPCHK(c, hipMemcpyAsync(D.h_blob.p, D.d_blob.p, D.lay.total, hipMemcpyDeviceToHost, c->copy_stream));
+    if (nf) {
+        // the hand-off records: the host has waited for the gather, the copy runs beside what follows.  As PCIe stores from
+        // shader waves (the runtime's blit kernel or ours) it cost the kernels beside it its own 0.2-0.3 ms wherever it was
+        // placed — k_dm_pack_codes 0.29 instead of 0.02 ms, or k_dm_greedy 0.27 instead of 0.06, or pass 2's filter 1.32
+        // instead of 1.11 (profiles/NOTES_r03.md).  The fall-back order keeps it away from the merge, whose kernels are
+        // short dependent chains of agent-scope loads and atomics.
+        static const bool blit = getenv("CRASS_COPY_BLIT") != nullptr;      // A/B switch: the runtime's copy (a blit kernel over every CU)
+        if (!blit && sdma_start(c->dma, D.d_blob.p, D.h_blob.p, D.lay.total)) {
+            // (a DMA engine: nothing of it runs on the CUs, it starts now)
+        } else {
+            if (premerge_queued && !getenv_once_copy_early()) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_premerge, 0));
+            if (blit) HIPCHK(c, hipMemcpyAsync(D.h_blob.p, D.d_blob.p, D.lay.total, hipMemcpyDeviceToHost, c->copy_stream));
+            else HIPCHK(c, launch_copy_to_host(D.d_blob.p, D.h_blob.p, D.lay.total, c->copy_stream));
+        }
         c->bulk_pending = true;
     }
     if (nf && !dedupe) {                                // no distinct list: the candidates' own strings travel
@@ -1515,7 +1543,7 @@ static int install_patterns(crass_hip_ctx *c, const StringArena &pats)
     if (HK.ok) {
         HIPCHK(c, c->a_anchor.ensure(HK.table.size()));
         HIPCHK(c, hipMemcpyAsync(c->a_anchor.p, HK.table.data(), HK.table.size() * 4, hipMemcpyHostToDevice, c->stream));
-        c->K.table = c->a_anchor.p; c->K.log_size = HK.log_size; c->K.mode = HK.mode; c->K.s1 = HK.s1; c->K.s2 = HK.s2; c->K.m1 = HK.m1;
+        c->K.table = c->a_anchor.p; c->K.log_size = HK.log_size; c->K.mode = HK.mode; c->K.m1 = HK.m1;
         c->K.m2 = HK.m2; c->K.n_keys = HK.n_keys;
         c->have_anchors = true;
     }
@@ -1601,7 +1629,7 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
     M.h_st = d.h_st.p; M.h_root = d.h_root.p; M.h_blank = d.h_blank.p;
     M.inject_fail = c->env.dm_inject_fail ? 1u : 0u;
     M.group_cap = c->env.dm_group_cap;
-    M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.s1 = 15; M.s2 = 13; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
+    M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
     d.M = M;
     return CRASS_OK;
 }

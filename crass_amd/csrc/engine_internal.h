@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <hip/hip_runtime.h>
 #include "devmem.h"
+#include "merge.h"
 
 namespace crass {
 
@@ -76,13 +77,13 @@ struct DevAutomaton {
 
 // pass-2 anchor filter: cuckoo hash set (two choices, one slot each) of every 16-mer that
 // starts at offset 0..7 of a pattern, as 32-bit packed values; lives in LDS.
-// h_i(V) = mul_u24(V ^ (V >> s_i), m_i) >> (32 - log_size)   (v_mul_u32_u24 is full rate)
+// h_i(V) = ak_hash(V, m_i) >> (32 - log_size)   (merge.h: one v_mad_u32_u24 per hash)
 struct DevAnchors {
     const uint32_t *table;        // [1 << log_size]; mode 0: one key per slot (unused slots hold a member key);
                                   // mode 1: two 16-bit fingerprints per slot (bucketed cuckoo, superset filter)
     uint32_t log_size;
     uint32_t mode;
-    uint32_t s1, s2, m1, m2;
+    uint32_t m1, m2;
     uint32_t n_keys;
     uint32_t with_exc;            // 1: exception reads are probed on their packed words too (pattern set known to be pure ACGT)
 };
@@ -148,7 +149,7 @@ struct DevMerge {
     uint32_t *anchor_fp;          // [1 << 15] words: tab_mode 3 = 2^16 16-bit fingerprints of the slots' keys;
                                   // tab_mode 2 = a 2^20-bit Bloom filter (2 hashes) staged in LDS in front of the L2 probes
     uint32_t tab_log_alloc;
-    uint32_t s1, s2, m1, m2;      // hash constants of the table
+    uint32_t m1, m2;              // hash multipliers of the table (ak_hash, merge.h)
     uint32_t n_cu;                // compute units of the device (bounds the grid of the kernel whose waves wait for each other)
     DevMergeState *st;
     // pinned host memory the last kernel exports to (state words, root and dropped flag per token)
@@ -305,6 +306,14 @@ hipError_t launch_levenshtein_batch(const uint8_t *chars, const uint64_t *a_off,
                                     int32_t *dist, float *sim, uint32_t max_len, hipStream_t st);
 // found_flag[header_id(idx[i])] = 1 for every listed read (readsFound entries of other input files, libcrispr.cpp:411)
 hipError_t launch_mark_found(const uint64_t *idx, uint64_t n, const uint64_t *header_id, uint8_t *found_flag, hipStream_t st);
+hipError_t launch_copy_to_host(const void *d_src, void *h_dst, uint64_t bytes, hipStream_t st);   // pinned destination, few workgroups
+// device -> pinned host on the DMA engines (sdma.cpp); nullptr / false: not available, use the copy kernel
+struct SdmaCopy;
+SdmaCopy *sdma_create();
+void sdma_destroy(SdmaCopy *s);
+bool sdma_start(SdmaCopy *s, const void *d_src, void *h_dst, size_t bytes);
+int sdma_wait(SdmaCopy *s);
+bool sdma_pending(const SdmaCopy *s);
 hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st);
 
 // k_found_mask + compaction as one decoupled-look-back kernel (tiles of 256 survivor slots); fidx[rank] = slot

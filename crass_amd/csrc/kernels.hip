@@ -71,6 +71,32 @@ hipError_t launch_mark_found(const uint64_t *idx, uint64_t n, const uint64_t *he
     return hipGetLastError();
 }
 
+// Device -> pinned host copy by a handful of workgroups (the link is the bound: ~55 GB/s needs a few hundred stores in
+// flight, not a chip).  hipMemcpyAsync takes the runtime's blit kernel for this, whose grid fills every CU with waves that
+// sit on PCIe writes: a merge kernel launched beside it on the other stream (k_dm_pack_codes, one short wave per token)
+// then waited for wave slots and took exactly as long as the copy — 0.29 ms instead of 0.03 at 100 M reads.
+__global__ __launch_bounds__(256) void k_copy_to_host(const uint4 *src, uint4 *dst, uint64_t n16, const uint8_t *src_tail, uint8_t *dst_tail, uint32_t n_tail,
+                                                      uint32_t xcd_stride)
+{
+    // workgroups go to the XCDs round-robin: with xcd_stride = 8 only the blocks of ONE XCD copy, the others leave at once
+    if (blockIdx.x % xcd_stride) return;
+    const uint32_t b = blockIdx.x / xcd_stride, nb = (gridDim.x + xcd_stride - 1) / xcd_stride;
+    const uint64_t nth = (uint64_t)nb * blockDim.x;
+    for (uint64_t i = b * (uint64_t)blockDim.x + threadIdx.x; i < n16; i += nth) dst[i] = src[i];
+    if (b == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+hipError_t launch_copy_to_host(const void *d_src, void *h_dst, uint64_t bytes, hipStream_t st)
+{
+    if (!bytes) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(h_dst)) & 15u) return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st);
+    const uint64_t n16 = bytes / 16;
+    static const uint32_t xs = [] { const char *v = getenv("CRASS_COPY_XCD_STRIDE"); return v ? (uint32_t)std::max(1, atoi(v)) : 1u; }();
+    const unsigned blocks = (unsigned)std::min<uint64_t>(32, (n16 + 255) / 256 + 1) * xs;
+    CRASS_LAUNCH(k_copy_to_host, dim3(blocks), dim3(256), 0, st, static_cast<const uint4 *>(d_src), static_cast<uint4 *>(h_dst), n16,
+                 static_cast<const uint8_t *>(d_src) + n16 * 16, static_cast<uint8_t *>(h_dst) + n16 * 16, (uint32_t)(bytes & 15u), xs);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_exc_mask(const uint64_t *exc_read, uint64_t n_exc, uint32_t *exc_mask, hipStream_t st)
 {
     if (!n_exc) return hipSuccess;
@@ -2624,15 +2650,14 @@ hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const ui
 template <int MODE>
 static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_t V, const DevAnchors &K, uint32_t rshift)
 {
-    // (cast: __umul24 is declared returning int, a plain >> would be an arithmetic shift)
-    const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1);
-    const uint32_t h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
+    const uint32_t h1 = ak_hash(V, K.m1);
+    const uint32_t h2 = ak_hash(V, K.m2);
     const uint32_t a = tab[h1 >> rshift], b = tab[h2 >> rshift];   // both probes always issued: independent reads, no branches
     if (MODE == 1) {
-        // fingerprint = low halfword of h1 ^ h2 (either product alone shares too many input bits with its own
-        // bucket index), replicated into both halves
+        // fingerprint = HIGH halfword of h1 ^ h2 (the bits that depend on every base of the key; the low halfword only
+        // sees the first eight, see anchor_probe_fp), replicated into both halves
         const uint32_t hx = h1 ^ h2;
-        const uint32_t ff = __builtin_amdgcn_perm(hx, hx, 0x01000100u);
+        const uint32_t ff = __builtin_amdgcn_perm(hx, hx, 0x03020302u);
         // a halfword of (slot ^ ff) is zero <=> that fingerprint matches; min(x, 1) per halfword keeps 1 unless zero
         const uint32_t t = pk_min_u16(a ^ ff, 0x00010001u) & pk_min_u16(b ^ ff, 0x00010001u);
         return t != 0x00010001u;
@@ -2642,8 +2667,8 @@ static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_
 // MODE 4 (device-built tables beyond the LDS tiers): 2^20-bit Bloom filter in LDS, exact keys in global memory
 static __device__ __forceinline__ bool anchor_probe_bloom(const uint32_t *bloom, const uint32_t *gtab, uint32_t V, const DevAnchors &K, uint32_t rshift)
 {
-    const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1);
-    const uint32_t h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
+    const uint32_t h1 = ak_hash(V, K.m1);
+    const uint32_t h2 = ak_hash(V, K.m2);
     const uint32_t b1 = h1 >> 12, b2 = h2 >> 12;
     const uint32_t w1 = bloom[b1 >> 5], w2 = bloom[b2 >> 5];
     bool hit = false;
@@ -2651,14 +2676,17 @@ static __device__ __forceinline__ bool anchor_probe_bloom(const uint32_t *bloom,
         hit = (gtab[h1 >> rshift] == V) | (gtab[h2 >> rshift] == V);
     return hit;
 }
-// MODE 3 (device-built tables): 2^16 slots, 16-bit fingerprints in LDS
+// MODE 3 (device-built tables): 2^16 slots, 16 bits per slot in LDS — the OTHER slot index of the key that sits there
+// (partial-key cuckoo: slot h1(K) stores h2(K) and the other way round), so a window matches when one of its two slots
+// names the other.  Sixteen bits that depend on every base of the key through an independent hash; the low halfword of
+// h1 ^ h2 — the first form — only depends on the key's first eight bases, which the hundreds of variants of one repeat
+// share: every read carrying a near-copy of a repeat then met that value in ~30 slots instead of one (k_dm_verify
+// 364 -> 464 us at 100 M reads, profiles/NOTES_r03.md).
 static __device__ __forceinline__ bool anchor_probe_fp(const uint16_t *tab, uint32_t V, const DevAnchors &K)
 {
-    const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1);
-    const uint32_t h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
-    const uint32_t a = tab[h1 >> 16], b = tab[h2 >> 16];
-    const uint32_t fp = (h1 ^ h2) & 0xFFFFu;
-    return (a == fp) | (b == fp);
+    const uint32_t i1 = ak_hash(V, K.m1) >> 16, i2 = ak_hash(V, K.m2) >> 16;
+    const uint32_t a = tab[i1], b = tab[i2];
+    return (a == i2) | (b == i1);
 }
 
 template <int W, int THREADS, int MODE>     // W = uniform stride in words (0: ragged / any stride)
@@ -2762,7 +2790,7 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
 #pragma unroll
                         for (int h = 0; h < 2 * W - 1; h++) {
                             const uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
-                            const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1), h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
+                            const uint32_t h1 = ak_hash(V, K.m1), h2 = ak_hash(V, K.m2);
                             const uint32_t b1 = h1 >> 12, b2 = h2 >> 12;
                             const uint32_t w1 = ak_lds[b1 >> 5], w2 = ak_lds[b2 >> 5];
                             if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0u && (uint32_t)h <= h_max) pm |= 1u << h;
@@ -2775,17 +2803,25 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
 #pragma unroll
                             for (int i = 0; i < W; i++) { lo = kk == (uint32_t)i ? w[i] : lo; hi = kk == (uint32_t)i ? w[i + 1] : hi; }
                             const uint32_t V = (h & 1u) ? ((lo >> 16) | (hi << 16)) : lo;
-                            const uint32_t h1 = (uint32_t)__umul24(V ^ (V >> K.s1), K.m1), h2 = (uint32_t)__umul24(V ^ (V >> K.s2), K.m2);
+                            const uint32_t h1 = ak_hash(V, K.m1), h2 = ak_hash(V, K.m2);
                             if ((K.table[h1 >> mask] == V) | (K.table[h2 >> mask] == V)) { flag = true; pm = 0; }
                         }
                     } else {
+                    // (uniform read length: the last window is a scalar, and "window inside the read" costs no vector compare)
+                    auto scan = [&](const uint32_t hm) {
 #pragma unroll
-                    for (int h = 0; h < 2 * W - 1; h++) {
-                        uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
-                        bool hit = MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
-                                             : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
-                        flag = flag | (hit & ((uint32_t)h <= h_max));
-                    }
+                        for (int h = 0; h < 2 * W - 1; h++) {
+                            uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
+                            bool hit = MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
+                                                 : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
+                            flag = flag | (hit & ((uint32_t)h <= hm));
+                            // (16 LDS reads in flight are plenty; left alone the scheduler hoists all 4W-2 of them and, from
+                            // W = 12, spills)
+                            if ((h & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    };
+                    if (R.uniform_len) scan((R.uniform_len - 16u) >> 3);
+                    else scan(h_max);
                     }
                 } else {
                     const uint32_t nw = (L + 15) >> 4;
@@ -2833,7 +2869,7 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMe
     CRASS_VGPR_FLOOR(120);                              // (see k_anchor_filter)
     extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
     DevAnchors K;
-    K.table = M.anchor_tab; K.log_size = M.st->log_size; K.mode = 0; K.s1 = M.s1; K.s2 = M.s2; K.m1 = M.m1; K.m2 = M.m2; K.n_keys = 0;
+    K.table = M.anchor_tab; K.log_size = M.st->log_size; K.mode = 0; K.m1 = M.m1; K.m2 = M.m2; K.n_keys = 0;
     K.with_exc = 1;
     if (M.st->fail != 0 || K.log_size == 0) {            // the host redoes the merge; flag nothing
         const uint64_t n_tiles = (R.n_reads + 63) / 64;

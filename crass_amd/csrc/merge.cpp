@@ -1225,11 +1225,11 @@ void build_anchors(HostAnchors &k, const StringArena &patterns)
     }
     k.n_keys = (uint32_t)keys.size();
     if (keys.empty()) { k.ok = false; return; }
-    // h_i(V) = mul_u24(V ^ (V >> s_i), m_i) >> (32 - log_size): 24-bit multiplies are full rate on
-    // the device; a few (shift, multiplier) pairs are tried until the cuckoo insertion succeeds.
-    static const uint32_t SH[][2] = {{15, 13}, {17, 11}, {14, 9}, {16, 12}};
-    static const uint32_t MU[][2] = {{0x9E3779u, 0x85EBCBu}, {0xC2B2AFu, 0x27D4EBu}, {0x7FEB35u, 0x846CA7u}, {0xB5297Bu, 0x68E31Du}};
-    auto mul24 = [](uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) & 0xFFFFFFFFull); };
+    // h_i(V) = ak_hash(V, m_i) >> (32 - log_size) (merge.h): 24-bit multiplies are full rate on the device; a few
+    // multiplier pairs are tried until the cuckoo insertion succeeds.
+    static const uint32_t MU[][2] = {{0x9E3779u, 0x85EBCBu}, {0xC2B2AFu, 0x27D4EBu}, {0x7FEB35u, 0x846CA7u}, {0xB5297Bu, 0x68E31Du},
+                                     {0xD6E8FFu, 0x3C6EF3u}, {0xA24BAFu, 0x5BD1E9u}, {0xE7037Fu, 0x4CF5ADu}, {0x93D765u, 0x2127A5u}};
+    constexpr uint32_t N_MU = sizeof(MU) / sizeof(MU[0]);
     // Tier 0: exact keys, one per slot, up to 2^15 slots (128 KB of LDS).
     // Tier 1: key sets beyond that (large shards / many ranks: one error variant per pattern adds up)
     //         keep the table in LDS as buckets of two 16-bit fingerprints: a superset filter with a
@@ -1237,10 +1237,10 @@ void build_anchors(HostAnchors &k, const StringArena &patterns)
     // Tier 2: exact keys again, probed in global memory (L2), for anything larger.
     auto try_exact = [&](uint32_t log_size) -> bool {
         const uint32_t size = 1u << log_size, rsh = 32 - log_size;
-        for (uint32_t a = 0; a < 4; a++) for (uint32_t b = 0; b < 4; b++) {
-            const uint32_t s1 = SH[a][0], s2 = SH[a][1], m1 = MU[b][0], m2 = MU[b][1];
-            auto h1 = [&](uint32_t v) { return mul24(v ^ (v >> s1), m1) >> rsh; };
-            auto h2 = [&](uint32_t v) { return mul24(v ^ (v >> s2), m2) >> rsh; };
+        for (uint32_t b = 0; b < N_MU; b++) {
+            const uint32_t m1 = MU[b][0], m2 = MU[b][1];
+            auto h1 = [&](uint32_t v) { return ak_hash(v, m1) >> rsh; };
+            auto h2 = [&](uint32_t v) { return ak_hash(v, m2) >> rsh; };
             std::vector<uint32_t> tab(size, 0);
             std::vector<char> used(size, 0);
             bool ok = true;
@@ -1259,7 +1259,7 @@ void build_anchors(HostAnchors &k, const StringArena &patterns)
             }
             if (!ok) continue;
             for (uint32_t i = 0; i < size; i++) if (!used[i]) tab[i] = keys[0];   // unused slots hold a member key
-            k.ok = true; k.mode = 0; k.log_size = log_size; k.s1 = s1; k.s2 = s2; k.m1 = m1; k.m2 = m2;
+            k.ok = true; k.mode = 0; k.log_size = log_size; k.m1 = m1; k.m2 = m2;
             k.table.swap(tab);
             return true;
         }
@@ -1267,10 +1267,10 @@ void build_anchors(HostAnchors &k, const StringArena &patterns)
     };
     auto try_buckets = [&](uint32_t log_size) -> bool {
         const uint32_t nb = 1u << log_size, rsh = 32 - log_size;
-        for (uint32_t a = 0; a < 4; a++) for (uint32_t b = 0; b < 4; b++) {
-            const uint32_t s1 = SH[a][0], s2 = SH[a][1], m1 = MU[b][0], m2 = MU[b][1];
-            auto h1 = [&](uint32_t v) { return mul24(v ^ (v >> s1), m1) >> rsh; };
-            auto h2 = [&](uint32_t v) { return mul24(v ^ (v >> s2), m2) >> rsh; };
+        for (uint32_t b = 0; b < N_MU; b++) {
+            const uint32_t m1 = MU[b][0], m2 = MU[b][1];
+            auto h1 = [&](uint32_t v) { return ak_hash(v, m1) >> rsh; };
+            auto h2 = [&](uint32_t v) { return ak_hash(v, m2) >> rsh; };
             std::vector<uint32_t> slot_key((size_t)nb * 2, 0);
             std::vector<uint8_t> fill(nb, 0);                      // occupied slots of the bucket (0..2)
             uint32_t rnd = 0x2545F491u;
@@ -1293,19 +1293,19 @@ void build_anchors(HostAnchors &k, const StringArena &patterns)
                 if (!ok) break;
             }
             if (!ok) continue;
-            // fingerprint = low 16 bits of (h1 product ^ h2 product); empty slots keep 0 (any value
+            // fingerprint = high 16 bits of (h1 ^ h2) (kernels.hip, anchor_probe); empty slots keep 0 (any value
             // there is just one more false-positive source of the same 2^-16 weight)
             std::vector<uint32_t> tab(nb, 0);
             for (uint32_t bk = 0; bk < nb; bk++) {
                 uint32_t w = 0;
                 for (uint32_t j = 0; j < fill[bk]; j++) {
                     const uint32_t v = slot_key[(size_t)bk * 2 + j];
-                    w |= ((mul24(v ^ (v >> s1), m1) ^ mul24(v ^ (v >> s2), m2)) & 0xFFFFu) << (16 * j);
+                    w |= ((ak_hash(v, m1) ^ ak_hash(v, m2)) >> 16) << (16 * j);
                 }
                 if (fill[bk] == 1) w |= w << 16;
                 tab[bk] = w;
             }
-            k.ok = true; k.mode = 1; k.log_size = log_size; k.s1 = s1; k.s2 = s2; k.m1 = m1; k.m2 = m2;
+            k.ok = true; k.mode = 1; k.log_size = log_size; k.m1 = m1; k.m2 = m2;
             k.table.swap(tab);
             return true;
         }

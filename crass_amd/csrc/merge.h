@@ -8,6 +8,25 @@
 #include <vector>
 #include <unordered_map>
 
+// Hash of the pass-2 anchor tables (host-built: merge.cpp; device-built: dmerge.hip; probed by kernels.hip): the low 24 bits
+// of the 16-mer times a 24-bit multiplier, plus the 16-mer's top byte left where it is (bits 24..31: inside the slot index
+// of every table size).  On the device that is one v_and_b32 shared by both hashes of a window and one v_mad_u32_u24 each.
+// The earlier form, mul24(V ^ (V >> s_i), m_i), took three instructions per hash (the probe kernel is VALU-bound) and folds
+// 32 bits into 24 before multiplying: on variant-rich key sets near load 1/2 it left hundreds of keys unplaced where this
+// one places all of them with a third fewer eviction chains (profiles/NOTES_r03.md).  Adding V >> 8 instead (the top byte
+// in bits 16..23) is NOT good enough: tables below 2^16 slots index with bits above those, and keys that differ only in
+// their last four bases then share both slots.
+#if defined(__HIPCC__)
+#define CRASS_HD __host__ __device__
+#else
+#define CRASS_HD
+#endif
+CRASS_HD static inline uint32_t ak_hash(uint32_t v, uint32_t m)
+{
+    // (operands known to fit 24 bits: the AMDGPU back end selects v_mad_u32_u24 for this)
+    return (v & 0xFFFFFFu) * (m & 0xFFFFFFu) + (v & 0xFF000000u);
+}
+
 namespace crass {
 
 void build_comp_table(unsigned char tab[128]);                 // SeqUtils.cpp:50-59
@@ -119,7 +138,7 @@ void build_automaton(HostAutomaton &a, const StringArena &patterns);
 // the reads (base i in bits 2i..2i+1), in a two-choice cuckoo table (see kernels.hip).
 struct HostAnchors {
     bool ok = false;                    // false: some pattern is shorter than 23 or the table would not fit
-    uint32_t log_size = 0, s1 = 0, s2 = 0, m1 = 0, m2 = 0, n_keys = 0;
+    uint32_t log_size = 0, m1 = 0, m2 = 0, n_keys = 0;
     uint32_t mode = 0;                  // 0: exact 32-bit keys; 1: buckets of two 16-bit fingerprints (see kernels.hip)
     std::vector<uint32_t> table;
 };

@@ -1,17 +1,14 @@
 #!/bin/bash
-# quick A/B session: GPU suite, then the headline bench with and without a switch (same box, back to back)
+# same-box A/B of one environment switch: r03_ab.sh <tag> <ENVVAR> [bench args]
 set -u
-out=$GRAFT_REPO_ROOT/gpurun_out/${1:-r03h}
-mkdir -p $out
-cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q --timeout=600 -rf -x > $out/pytest.txt 2>&1; tail -6 $out/pytest.txt
-B="--steps 40 --warmup 5 --cpu-sample 0 --single-shots 0"
-timeout 300 python bench.py --config 1 --cpu-sample 0 --single-shots 0 > $out/bench_c1.json 2>> $out/err.txt
-python - $out/bench_*.json <<'PY'
-import json,sys
-for f in sys.argv[1:]:
-    try:
-        d=json.loads(open(f).read().strip().splitlines()[-1]); r=d["roofline"]
-        print(f.split("/")[-1], d["ms_per_step"], d["step_ms"]["median"], r["stages_ms_scouting_steps"], d["config"]["pass2_found"])
-    except Exception as e: print(f, "ERR", e)
+tag=$1; var=$2; shift 2
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out; cd $GRAFT_REPO_ROOT
+for rep in 1 2; do
+  timeout 400 python bench.py --steps 40 --warmup 5 --cpu-sample 0 --single-shots 0 "$@" > $out/a$rep.json 2> $out/a$rep.err
+  env $var=1 timeout 400 python bench.py --steps 40 --warmup 5 --cpu-sample 0 --single-shots 0 "$@" > $out/b$rep.json 2> $out/b$rep.err
+done
+python - $out <<'PY'
+import json,sys,glob
+for f in sorted(glob.glob(sys.argv[1]+"/[ab]?.json")):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], d["ms_per_step"], d["step_ms"], d["roofline"]["host_ms"])
 PY
