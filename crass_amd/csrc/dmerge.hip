@@ -508,11 +508,13 @@ __global__ __launch_bounds__(256) void k_dm_fill_finish(DevMerge M)
         if (hs != 0xFFFFFFFFu) {
             const uint32_t h = hs & 0x7FFFFFFFu, pid = w >> 3, r = w & 7u, t = pid >> 1, o = pid & 1u;
             const uint32_t pos = M.kset_base[h] + atomicAdd(&M.kset_fill[h], 1u);
-            uint64_t *d = M.ents + (uint64_t)pos * 4;
+            // two planes of 16 bytes per entry: {meta, bases 0..31} decides nearly every comparison; {bases 32..63, N mask}
+            // (plane 2, M.ent_cap entries further) is only read for an entry whose first 32 bases equal the read's
+            uint64_t *d = M.ents + (uint64_t)pos * 2, *d2 = M.ents + ((uint64_t)M.ent_cap + pos) * 2;
             d[0] = (uint64_t)(r | ((uint32_t)M.dx_len[t] << 3)) | ((uint64_t)pid << 32);
             d[1] = M.packed[(uint64_t)t * 4 + 2 * o];
-            d[2] = M.packed[(uint64_t)t * 4 + 2 * o + 1];
-            d[3] = M.tmask[(uint64_t)t * 2 + o];
+            d2[0] = M.packed[(uint64_t)t * 4 + 2 * o + 1];
+            d2[1] = M.tmask[(uint64_t)t * 2 + o];
         }
     }
     if (w == 0) *M.h_st = *M.st;
@@ -645,7 +647,8 @@ static __device__ __forceinline__ void dv_candidates(const DevMerge &M, WordFn w
         const uint32_t c = c0 + lane;
         uint32_t cand = 0xFFFFFFFFu, cpid = 0;                // (end << 8) | (255 - len): smaller is better
         if (c < cnt_s) {
-            const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 4;
+            const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 2;
+            const uint64_t *ent2 = M.ents + ((uint64_t)M.ent_cap + base_s + c) * 2;
             const uint64_t e0 = ent[0];
             const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
             if (a >= rr && a - rr + len <= L) {
@@ -660,7 +663,9 @@ static __device__ __forceinline__ void dv_candidates(const DevMerge &M, WordFn w
                 const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
                 uint64_t m0, m1;
                 mask128(len, m0, m1);
-                bool eq = (v0 & m0) == ent[1] && (v1 & m1) == ent[2];
+                bool eq = (v0 & m0) == ent[1];
+                uint64_t e_mask = 0;
+                if (eq) { eq = (v1 & m1) == ent2[0]; e_mask = ent2[1]; }
                 if (eq && raw) {
                     uint64_t rm = 0;
                     bool other = false;
@@ -668,8 +673,8 @@ static __device__ __forceinline__ void dv_candidates(const DevMerge &M, WordFn w
                         const uint8_t ch = raw[start + i];
                         if (!((ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T'))) { rm |= 1ull << i; other |= ch != 'N'; }
                     }
-                    eq = !other && rm == ent[3];
-                } else if (eq) eq = ent[3] == 0ull;
+                    eq = !other && rm == e_mask;
+                } else if (eq) eq = e_mask == 0ull;
                 if (eq) { cand = ((start + len) << 8) | (255u - len); cpid = (uint32_t)(e0 >> 32); }
             }
         }

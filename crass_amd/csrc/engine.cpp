@@ -1617,7 +1617,7 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
     M.packed = d.packed.p; M.codes = d.codes.p; M.owner = d.owner.p; M.bk_key = d.bk_key.p; M.root_of = d.root_of.p;
     M.tmask = d.tmask.p; M.pat_mask = d.tmask.p; M.blank = d.blank.p; M.pat_token = d.pat_token.p;
     M.kset_key = d.kset_key.p; M.kset_cnt = d.kset_u32.p; M.kset_base = d.kset_u32.p + ((size_t)1 << M.kset_log);
-    M.kset_fill = d.kset_u32.p + ((size_t)2 << M.kset_log); M.ent_slot = d.ent_slot.p; M.ents = d.ents.p;
+    M.kset_fill = d.kset_u32.p + ((size_t)2 << M.kset_log); M.ent_slot = d.ent_slot.p; M.ents = d.ents.p; M.ent_cap = 16u * n;
     M.rset_key = d.rset_key.p; M.rset_cnt = d.rset_u32.p; M.rset_base = d.rset_u32.p + ((size_t)1 << M.rset_log);
     M.rset_fill = d.rset_u32.p + ((size_t)2 << M.rset_log); M.rd_slot = d.rd_slot.p; M.rents = d.rents.p;
     if (!c->n_cu) {

@@ -144,7 +144,8 @@ struct DevMerge {
     uint32_t *kset_cnt, *kset_base, *kset_fill;   // [1 << kset_log] the key's entries: ents[base .. base + cnt)
     uint32_t kset_log;
     uint32_t *ent_slot;           // [16 * n_tok] the entry's key slot | 0x80000000 when the entry claimed it; 0xFFFFFFFF: no entry
-    uint64_t *ents;               // [16 * n_tok][4] verification index, grouped by key
+    uint64_t *ents;               // verification index, grouped by key: [ent_cap][2] {meta, bases 0..31}, then [ent_cap][2] {bases 32..63, N mask}
+    uint32_t ent_cap;             // = 16 * n_tok
     uint32_t *anchor_tab;         // [1 << tab_log_alloc] cuckoo table of the keys (see DevAnchors)
     uint32_t *anchor_fp;          // [1 << 15] words: tab_mode 3 = 2^16 16-bit fingerprints of the slots' keys;
                                   // tab_mode 2 = a 2^20-bit Bloom filter (2 hashes) staged in LDS in front of the L2 probes
