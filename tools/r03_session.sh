@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 GPU session (staged: a failing stage stops the session before the long ones run).
-# usage: r03_session.sh <tag> [stages]   stages: smoke,ubench,tests,bench,prof,e2e,sweep,hygiene,other,pmc3,pmc (default: the first row)
+# usage: r03_session.sh <tag> [stages]   stages: smoke,ubench,tests,bench,prof,e2e,sweep,hygiene,other,scale,pmc3,pmc (default: the first row)
 set -u
 tag=${1:-r03b}
 stages=${2:-smoke,ubench,tests,bench,prof,pmc}
@@ -67,6 +67,10 @@ if has other; then
   timeout 600 python bench.py --config 4 --steps 10 --warmup 2 --cpu-sample 0 > $out/bench_c4.json 2> $out/bench_c4.err
   CRASS_DV_ONE=1 timeout 400 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --single-shots 0 > $out/bench_c2_dv_one.json 2> $out/bench_c2_dv_one.err
   summ $out/bench_c3.json $out/bench_c4.json $out/bench_c2_dv_one.json
+fi
+if has scale; then
+  cd $GRAFT_REPO_ROOT
+  timeout 600 python tools/scaling_projection.py > $out/scaling_projection.txt 2> $out/scaling_projection.err; tail -12 $out/scaling_projection.txt
 fi
 if has pmc3; then
   cd $GRAFT_REPO_ROOT
