@@ -56,7 +56,8 @@ Hsa &hsa()
 
 struct SdmaCopy {
     hsa_signal_t sig{};
-    bool have_sig = false, pending = false;
+    bool have_sig = false, pending = false, broken = false;
+    const void *src = nullptr; void *dst = nullptr; size_t bytes = 0;      // the copy in flight (redone by the caller's runtime if the engine fails)
 };
 
 SdmaCopy *sdma_create()
@@ -88,7 +89,7 @@ void sdma_destroy(SdmaCopy *s)
 bool sdma_start(SdmaCopy *s, const void *d_src, void *h_dst, size_t bytes)
 {
     Hsa &h = hsa();
-    if (!s || !h.ok || s->pending || !bytes) return false;
+    if (!s || !h.ok || s->pending || s->broken || !bytes) return false;
     static const bool dbg = getenv("CRASS_SDMA_DEBUG") != nullptr;
     hsa_amd_pointer_info_t si{}, di{};
     si.size = sizeof(si); di.size = sizeof(di);
@@ -103,10 +104,11 @@ bool sdma_start(SdmaCopy *s, const void *d_src, void *h_dst, size_t bytes)
     h.signal_store(s->sig, 1);
     if (h.async_copy(h_dst, di.agentOwner, d_src, si.agentOwner, bytes, 0, nullptr, s->sig) != HSA_STATUS_SUCCESS) return false;
     s->pending = true;
+    s->src = d_src; s->dst = h_dst; s->bytes = bytes;
     return true;
 }
 
-// 0: done (or nothing pending); -1: the engine reported an error
+// 0: the records are in host memory (or nothing was pending); -1: the engine reported an error and the runtime's copy failed too
 int sdma_wait(SdmaCopy *s)
 {
     if (!s || !s->pending) return 0;
@@ -115,7 +117,12 @@ int sdma_wait(SdmaCopy *s)
     do v = h.signal_wait(s->sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
     while (v >= 1);
     s->pending = false;
-    return v < 0 ? -1 : 0;
+    if (v < 0) {
+        // the engine reported an error: the records are copied again by the HIP runtime, and this context stays off the engines
+        s->broken = true;
+        return hipMemcpy(s->dst, s->src, s->bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    }
+    return 0;
 }
 
 bool sdma_pending(const SdmaCopy *s) { return s && s->pending; }

@@ -364,3 +364,31 @@ def test_one_million_reference_known_answer_on_the_hip_path(ca):
     assert (gpu.n_pass1, gpu.n_tokens, gpu.n_groups, gpu.n_patterns, gpu.n_pass1 + gpu.n_pass2) == appendix_c.KNOWN_1M
     assert gpu.counters["used_device_merge"] == 1 and gpu.counters["used_fast_filter"] == 1
     assert_same_pipeline(gpu, orc.pipeline(seqs))
+
+
+_COPY_PATHS = r"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import crass_amd as ca
+from tests import orc
+from tests.parity import assert_same_pipeline
+from tests.test_gpu_parity import synth_reads
+ca.load()
+seqs = synth_reads(ca, 80000, read_len=150, crispr_per_million=60000, n_dr=40)
+eng = ca.SearchEngine()
+ref = orc.pipeline(seqs)
+for rep in range(3):                                     # (a re-used context: the copy of step k must not leak into step k + 1)
+    assert_same_pipeline(ca.search_pipeline(seqs, engine=eng), ref)
+print("copy path ok", ref.n_pass1)
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"CRASS_NO_SDMA": "1"}, {"CRASS_NO_SDMA": "1", "CRASS_COPY_EARLY": "1"}, {"CRASS_COPY_BLIT": "1"}])
+def test_hand_off_copy_paths(env):
+    """pass 1's hand-off records reach the host on a DMA engine (csrc/sdma.cpp); the fall-backs — the library's copy kernel,
+    ordered behind the merge or beside it, and the runtime's hipMemcpyAsync — must deliver the same records (the switches
+    are read once per process: child processes)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _COPY_PATHS], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "copy path ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
