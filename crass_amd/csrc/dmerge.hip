@@ -751,30 +751,79 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                 const uint32_t lo = rw[wi], hi = rw[min(wi + 1, nw)];
                 dv_probe(M, (pl & 1) ? ((lo >> 16) | (hi << 16)) : lo, kmask, cnt, base);
             }
-            uint32_t b_end[DV_G], b_len[DV_G], b_pid[DV_G];                  // wave-uniform, one per read of the round
+            // The three reads of the round walk their hit windows SIDE BY SIDE: read g's 21 lanes compare the candidates of
+            // read g's next hit window (21 at a time) while the other two groups do the same for theirs — as many dependent
+            // {entry load, compare, reduce} steps per round as the busiest read has windows (~4), not as the three have together
+            // (~12, a quarter of the lanes busy).  be / bl / bp: the group's best so far, the same value in each of its lanes.
+            const uint8_t *raw = nullptr;                                    // exception reads (rare): the read's raw bytes
+            if (R.n_exc && have) raw = dv_raw(R, r);
+            const uint64_t hits_all = __ballot(cnt > 0);
+            uint32_t my = gi < DV_G ? (uint32_t)(hits_all >> (gi * DV_GL)) & ((1u << DV_GL) - 1u) : 0u;      // this read's hit windows
+            uint32_t be = 0xFFFFFFFFu, bl = 0, bp = 0;
+            const int g0 = (gi < DV_G ? gi : 0) * DV_GL;                     // first lane of this lane's group
+            const uint64_t gmask = gi < DV_G ? (((1ull << DV_GL) - 1ull) << g0) : 0ull;
+            const uint32_t *rws = rw_all[wv][gi < DV_G ? gi : 0];
+            while (__ballot(my != 0u)) {
+                bool act = my != 0u;
+                const int wsrc = act ? __ffs((int)my) - 1 : 0;               // the group's next hit window
+                if (act) my &= my - 1u;
+                const uint32_t a = 8u * (uint32_t)wsrc;
+                if (act && be <= a + 15u) { act = false; my = 0u; }          // no later window of this read can end earlier
+                const uint32_t cnt_s = (uint32_t)__shfl((int)cnt, g0 + wsrc), base_s = (uint32_t)__shfl((int)base, g0 + wsrc);
+                for (uint32_t c0 = 0; __ballot(act && c0 < cnt_s); c0 += DV_GL) {
+                    const uint32_t c = c0 + (uint32_t)pl;
+                    uint32_t cand = 0xFFFFFFFFu, cpid = 0;                   // (end << 8) | (255 - len): smaller is better
+                    if (act && c < cnt_s) {
+                        const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 2;
+                        const uint64_t *ent2 = M.ents + ((uint64_t)M.ent_cap + base_s + c) * 2;
+                        const uint64_t e0 = ent[0];
+                        const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
+                        if (a >= rr && a - rr + len <= L) {
+                            const uint32_t start = a - rr;
+                            const uint32_t w0 = start >> 4, sh = (start & 15u) * 2u;
+                            uint32_t x[5];
 #pragma unroll
-            for (int q = 0; q < DV_G; q++) { b_end[q] = 0xFFFFFFFFu; b_len[q] = 0; b_pid[q] = 0; }
-            uint64_t hits = __ballot(cnt > 0);
-            while (hits) {
-                const int src = __ffsll((unsigned long long)hits) - 1;
-                hits &= hits - 1;
-                const int sg = src / DV_GL;
-                const uint32_t a = 8u * (uint32_t)(src % DV_GL);
-                const uint32_t cur_end = sg == 0 ? b_end[0] : sg == 1 ? b_end[1] : b_end[2];
-                if (cur_end <= a + 15) continue;                            // a later window of THIS read cannot end earlier
-                const uint32_t cnt_s = (uint32_t)__shfl((int)cnt, src), base_s = (uint32_t)__shfl((int)base, src);
-                const uint64_t r_s = (uint64_t)(uint32_t)__shfl((int)(uint32_t)r, src) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(r >> 32), src) << 32);
-                const uint8_t *raw = dv_raw(R, r_s);
-                const uint32_t *rws = rw_all[wv][sg];
-                uint32_t be = cur_end, bl = sg == 0 ? b_len[0] : sg == 1 ? b_len[1] : b_len[2], bp = sg == 0 ? b_pid[0] : sg == 1 ? b_pid[1] : b_pid[2];
-                dv_candidates(M, [&](uint32_t i) -> uint32_t { return rws[min(i, nw)]; }, raw, L, a, cnt_s, base_s, lane, be, bl, bp);
+                            for (int q = 0; q < 5; q++) x[q] = rws[min(w0 + q, nw)];
+                            uint32_t y[4];
 #pragma unroll
-                for (int q = 0; q < DV_G; q++) if (sg == q) { b_end[q] = be; b_len[q] = bl; b_pid[q] = bp; }
+                            for (int q = 0; q < 4; q++) y[q] = sh ? ((x[q] >> sh) | (x[q + 1] << (32 - sh))) : x[q];
+                            const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
+                            uint64_t m0, m1;
+                            mask128(len, m0, m1);
+                            bool eq = (v0 & m0) == ent[1];
+                            uint64_t e_mask = 0;
+                            if (eq) { eq = (v1 & m1) == ent2[0]; e_mask = ent2[1]; }
+                            if (eq && raw) {
+                                uint64_t rm = 0;
+                                bool other = false;
+                                for (uint32_t i = 0; i < len; i++) {
+                                    const uint8_t ch = raw[start + i];
+                                    if (!((ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T'))) { rm |= 1ull << i; other |= ch != 'N'; }
+                                }
+                                eq = !other && rm == e_mask;
+                            } else if (eq) eq = e_mask == 0ull;
+                            if (eq) { cand = ((start + len) << 8) | (255u - len); cpid = (uint32_t)(e0 >> 32); }
+                        }
+                    }
+                    // minimum over the group's lanes (ties: any lane — equal (end, len) means equal strings)
+                    uint32_t mn = cand;
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) {
+                        const uint32_t o = (uint32_t)__shfl_down((int)mn, off);
+                        if (pl + off < DV_GL) mn = min(mn, o);
+                    }
+                    mn = (uint32_t)__shfl((int)mn, g0);
+                    const uint64_t who = __ballot(cand == mn) & gmask;
+                    const uint32_t pid = (uint32_t)__shfl((int)cpid, who ? __ffsll((unsigned long long)who) - 1 : 0);
+                    if (mn != 0xFFFFFFFFu) {
+                        const uint32_t e_end = mn >> 8, e_len = 255u - (mn & 0xFFu);
+                        if (e_end < be || (e_end == be && e_len > bl)) { be = e_end; bl = e_len; bp = pid; }
+                    }
+                }
             }
             if (have && pl == 0) {
-                const uint32_t be = gi == 0 ? b_end[0] : gi == 1 ? b_end[1] : b_end[2], bl = gi == 0 ? b_len[0] : gi == 1 ? b_len[1] : b_len[2];
                 info_by_slot[k] = bl ? ((be << 8) | bl) : 0u;
-                pid_by_slot[k] = gi == 0 ? b_pid[0] : gi == 1 ? b_pid[1] : b_pid[2];
+                pid_by_slot[k] = bp;
             }
             __builtin_amdgcn_wave_barrier();                // the next round reuses rw
         }

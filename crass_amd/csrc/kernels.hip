@@ -72,28 +72,23 @@ hipError_t launch_mark_found(const uint64_t *idx, uint64_t n, const uint64_t *he
 }
 
 // Device -> pinned host copy by a handful of workgroups (the link is the bound: ~55 GB/s needs a few hundred stores in
-// flight, not a chip).  hipMemcpyAsync takes the runtime's blit kernel for this, whose grid fills every CU with waves that
-// sit on PCIe writes: a merge kernel launched beside it on the other stream (k_dm_pack_codes, one short wave per token)
-// then waited for wave slots and took exactly as long as the copy — 0.29 ms instead of 0.03 at 100 M reads.
-__global__ __launch_bounds__(256) void k_copy_to_host(const uint4 *src, uint4 *dst, uint64_t n16, const uint8_t *src_tail, uint8_t *dst_tail, uint32_t n_tail,
-                                                      uint32_t xcd_stride)
+// flight, not a chip): the fall-back of the DMA-engine copy (sdma.cpp).  Like the runtime's blit kernel it costs the kernels
+// of the other stream its own duration — PCIe stores from shader waves do, however few waves issue them and on however
+// many XCDs (profiles/NOTES_r03.md §9) — so the engine orders it behind the merge kernels.
+__global__ __launch_bounds__(256) void k_copy_to_host(const uint4 *src, uint4 *dst, uint64_t n16, const uint8_t *src_tail, uint8_t *dst_tail, uint32_t n_tail)
 {
-    // workgroups go to the XCDs round-robin: with xcd_stride = 8 only the blocks of ONE XCD copy, the others leave at once
-    if (blockIdx.x % xcd_stride) return;
-    const uint32_t b = blockIdx.x / xcd_stride, nb = (gridDim.x + xcd_stride - 1) / xcd_stride;
-    const uint64_t nth = (uint64_t)nb * blockDim.x;
-    for (uint64_t i = b * (uint64_t)blockDim.x + threadIdx.x; i < n16; i += nth) dst[i] = src[i];
-    if (b == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+    const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n16; i += nth) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 hipError_t launch_copy_to_host(const void *d_src, void *h_dst, uint64_t bytes, hipStream_t st)
 {
     if (!bytes) return hipSuccess;
     if ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(h_dst)) & 15u) return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st);
     const uint64_t n16 = bytes / 16;
-    static const uint32_t xs = [] { const char *v = getenv("CRASS_COPY_XCD_STRIDE"); return v ? (uint32_t)std::max(1, atoi(v)) : 1u; }();
-    const unsigned blocks = (unsigned)std::min<uint64_t>(32, (n16 + 255) / 256 + 1) * xs;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(32, (n16 + 255) / 256 + 1);
     CRASS_LAUNCH(k_copy_to_host, dim3(blocks), dim3(256), 0, st, static_cast<const uint4 *>(d_src), static_cast<uint4 *>(h_dst), n16,
-                 static_cast<const uint8_t *>(d_src) + n16 * 16, static_cast<uint8_t *>(h_dst) + n16 * 16, (uint32_t)(bytes & 15u), xs);
+                 static_cast<const uint8_t *>(d_src) + n16 * 16, static_cast<uint8_t *>(h_dst) + n16 * 16, (uint32_t)(bytes & 15u));
     return hipGetLastError();
 }
 
