@@ -746,6 +746,8 @@ static int first_call_bounds(crass_hip_ctx *c);
 static void reset_results(crass_hip_ctx *c)
 {
     quiesce_worker(c);
+    (void)c->wait_bulk();               // (a hand-off copy still on its DMA engine: the buffers may be re-sized next, and a
+                                        // free only waits for the device's queues)
     c->have_pass1 = c->have_merge = c->have_pass2 = c->have_patterns = false;
     c->dm.active = false;
     memset(&c->cnt, 0, sizeof(c->cnt));

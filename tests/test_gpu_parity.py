@@ -366,6 +366,25 @@ def test_one_million_reference_known_answer_on_the_hip_path(ca):
     assert_same_pipeline(gpu, orc.pipeline(seqs))
 
 
+def test_reload_while_the_hand_off_copy_is_in_flight(ca):
+    """seed scans whose results are never fetched, each followed at once by a new (larger) read set: the hand-off copy of
+    the abandoned step may still be on its DMA engine when the load re-sizes the buffers it writes — the load waits for it"""
+    from crass_amd.engine import PackedReads
+    seqs = synth_reads(ca, 260000, read_len=150, crispr_per_million=150000, n_dr=30)
+    eng = ca.SearchEngine()
+    try:
+        for n in (60000, 140000, 200000, 260000):
+            packed = PackedReads(seqs[:n])
+            try:
+                eng.load_reads(packed)
+                eng.seed_scan(fetch=False)
+            finally:
+                packed.close()
+        assert_same_pipeline(ca.search_pipeline(seqs, engine=eng), orc.pipeline(seqs))
+    finally:
+        eng.close()
+
+
 _COPY_PATHS = r"""
 import os, sys
 sys.path.insert(0, os.getcwd())
