@@ -2305,13 +2305,14 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const bool dev_sink = dmp && n_exc == 0;
     c->q_blob_active = false;
     if (dev_sink) {
-        c->q_lay = p2_blob_layout(n_hits);
+        const uint32_t narrow = (c->max_len <= 255 && c->R.n_reads < (1ull << 32)) ? 1u : 0u;
+        c->q_lay = p2_blob_layout(n_hits, narrow);
         c->q_wide_ready = false;
         Lookback lbq;
         if (n_hits) {
             HIPCHK(c, launch_pack_p2_blob(c->d_rec.p, c->d_idx.p, c->read_base, c->d_count.p, n_hits, c->d_mask.p,
                                           c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 6, c->h_qblob.p, c->stream,
-                                          spec ? c->h_count.p : nullptr, c->next_lookback_elems(n_hits, &lbq)));
+                                          spec ? c->h_count.p : nullptr, c->next_lookback_elems(n_hits, &lbq), narrow));
         } else memset(c->h_qblob.p, 0, 16);
         const double th0 = now_ms();
         const int hs = ensure_host_merge(c);            // host view of the merge, rebuilt while the device verifies
@@ -2429,14 +2430,23 @@ int crass_hip_get_recruits(const crass_hip_ctx *c, crass_recruits *o)
         const uint8_t *hb = c->h_qblob.p;
         const P2Blob &b = c->q_lay;
         const uint64_t n = c->q_n;
-        const uint64_t *b_read = (const uint64_t *)(hb + b.read);
         const uint32_t *b_tok = (const uint32_t *)(hb + b.token);
         const uint16_t *b_start = (const uint16_t *)(hb + b.start), *b_end = (const uint16_t *)(hb + b.end);
-        mc->q_read.assign(b_read, b_read + n); mc->q_token.assign(b_tok, b_tok + n);
+        if (b.narrow) {
+            const uint32_t *b_read = (const uint32_t *)(hb + b.read);
+            mc->q_read.resize(n);
+            for (uint64_t k = 0; k < n; k++) mc->q_read[k] = c->read_base + b_read[k];
+        } else {
+            const uint64_t *b_read = (const uint64_t *)(hb + b.read);
+            mc->q_read.assign(b_read, b_read + n);
+        }
+        mc->q_token.assign(b_tok, b_tok + n);
         mc->q_low.assign(hb + b.low, hb + b.low + n);
         mc->q_start.resize(n); mc->q_end.resize(n); mc->q_dr_len.resize(n); mc->q_dr.assign(n * (size_t)c->dr_stride, 0);
         for (uint64_t k = 0; k < n; k++) {
-            mc->q_start[k] = b_start[k]; mc->q_end[k] = b_end[k]; mc->q_dr_len[k] = (hb + b.dr_len)[k];
+            if (b.narrow) { mc->q_start[k] = (hb + b.start)[k]; mc->q_end[k] = (hb + b.end)[k]; }
+            else { mc->q_start[k] = b_start[k]; mc->q_end[k] = b_end[k]; }
+            mc->q_dr_len[k] = (hb + b.dr_len)[k];
             const uint32_t t = b_tok[k];
             if (t >= 2 && t - 2 < c->merge.tokens.size())
                 memcpy(mc->q_dr.data() + k * (size_t)c->dr_stride, c->merge.tokens.strings.data(t - 2), c->merge.tokens.strings.len(t - 2));

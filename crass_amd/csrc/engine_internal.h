@@ -357,14 +357,17 @@ __host__ __device__ inline P1Blob p1_blob_layout(uint64_t nf, uint32_t ss_cap, u
 }
 // pass-2 hand-off blob: header (record count, 16 bytes) + compact arrays with `cap` slots each; the DR string of a
 // recruit is its token's string
-struct P2Blob { uint64_t read, token, start, end, dr_len, low, total; };
-__host__ __device__ inline P2Blob p2_blob_layout(uint64_t cap)
+struct P2Blob { uint64_t read, token, start, end, dr_len, low, total; uint32_t narrow; };
+// narrow: read sets of fewer than 2^32 reads of at most 255 bases (every short-read job) carry the LOCAL read index in four bytes
+// and the two positions in one byte each — 12 instead of 18 bytes per recruit over PCIe, which bounds the pack kernel
+__host__ __device__ inline P2Blob p2_blob_layout(uint64_t cap, uint32_t narrow = 0)
 {
     P2Blob b;
     uint64_t at = 16;
     auto sec = [&](uint64_t bytes) { const uint64_t o = at; at += (bytes + 15u) & ~15ull; return o; };
-    b.read = sec(cap * 8); b.token = sec(cap * 4); b.start = sec(cap * 2); b.end = sec(cap * 2); b.dr_len = sec(cap); b.low = sec(cap);
-    b.total = at;
+    b.read = sec(cap * (narrow ? 4 : 8)); b.token = sec(cap * 4); b.start = sec(cap * (narrow ? 1 : 2)); b.end = sec(cap * (narrow ? 1 : 2));
+    b.dr_len = sec(cap); b.low = sec(cap);
+    b.total = at; b.narrow = narrow;
     return b;
 }
 // valid hits (dr_len != 0) of the finish kernel's slots -> compacted, read-ordered compact arrays in `blob`
@@ -372,7 +375,7 @@ hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, u
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
                                uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st,
                                uint32_t *h_n_hits = nullptr,         // pinned word that receives *d_n_hits
-                               const Lookback *lb = nullptr);
+                               const Lookback *lb = nullptr, uint32_t narrow = 0);
 hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64_t *hash, uint32_t stride, const uint32_t *d_n, uint32_t n, uint32_t *rep,
                             uint32_t *slot_of, const uint32_t *first,       // slot_of: with lb, overwritten by the representatives' ranks
                             uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums, uint64_t *dx_idx, uint32_t *d_nd,

@@ -3209,7 +3209,8 @@ __global__ __launch_bounds__(256) void k_recruit_valid_mask(const RecruitOut *re
     if ((threadIdx.x & 63) == 0 && k < n_max) mask[k >> 6] = m;
 }
 __global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base, const uint64_t *vidx,
-                                                       const uint32_t *d_nv, uint64_t cap, uint8_t *blob, const uint32_t *d_n_hits, uint32_t *h_n_hits)
+                                                       const uint32_t *d_nv, uint64_t cap, uint8_t *blob, const uint32_t *d_n_hits, uint32_t *h_n_hits,
+                                                       uint32_t narrow)
 {
     const uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t nv = *d_nv;
@@ -3219,13 +3220,19 @@ __global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, con
         if (h_n_hits) *h_n_hits = *d_n_hits;            // the flagged-read count the host checks its bound against
     }
     if (q >= nv) return;
-    const P2Blob b = p2_blob_layout(cap);
+    const P2Blob b = p2_blob_layout(cap, narrow);
     const uint64_t k = vidx[q];
     const RecruitOut o = rec[k];
-    reinterpret_cast<uint64_t *>(blob + b.read)[q] = read_base + hit_idx[k];
     reinterpret_cast<uint32_t *>(blob + b.token)[q] = o.token;
-    reinterpret_cast<uint16_t *>(blob + b.start)[q] = (uint16_t)o.start;
-    reinterpret_cast<uint16_t *>(blob + b.end)[q] = (uint16_t)o.end;
+    if (narrow) {
+        reinterpret_cast<uint32_t *>(blob + b.read)[q] = (uint32_t)hit_idx[k];          // (local index: the host adds the base)
+        (blob + b.start)[q] = (uint8_t)o.start;
+        (blob + b.end)[q] = (uint8_t)o.end;
+    } else {
+        reinterpret_cast<uint64_t *>(blob + b.read)[q] = read_base + hit_idx[k];
+        reinterpret_cast<uint16_t *>(blob + b.start)[q] = (uint16_t)o.start;
+        reinterpret_cast<uint16_t *>(blob + b.end)[q] = (uint16_t)o.end;
+    }
     (blob + b.dr_len)[q] = (uint8_t)o.dr_len;
     (blob + b.low)[q] = o.low_lexi;
 }
@@ -3249,20 +3256,20 @@ __global__ __launch_bounds__(1024) void k_valid_compact(const RecruitOut *rec, c
 
 hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, uint64_t read_base,
                                const uint32_t *d_n_hits, uint64_t n_hits_max, uint64_t *mask, uint32_t *word_prefix, uint32_t *block_sums,
-                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st, uint32_t *h_n_hits, const Lookback *lb)
+                               uint64_t *vidx, uint32_t *d_nv, uint8_t *blob, hipStream_t st, uint32_t *h_n_hits, const Lookback *lb, uint32_t narrow)
 {
     if (n_hits_max == 0) return hipSuccess;
     const unsigned nb = (unsigned)((n_hits_max + 255) / 256);
     if (lb) {           // (the caller reserved nb tiles)
         const unsigned nt = (unsigned)((n_hits_max + kLbElemsPerTile - 1) / kLbElemsPerTile);
         CRASS_LAUNCH(k_valid_compact, dim3(nt), dim3(1024), 0, st, rec, d_n_hits, n_hits_max, vidx, d_nv, *lb, nt);
-        CRASS_LAUNCH(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
+        CRASS_LAUNCH(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits, narrow);
         return hipGetLastError();
     }
     CRASS_LAUNCH(k_recruit_valid_mask, dim3(nb), dim3(256), 0, st, rec, d_n_hits, n_hits_max, mask);
     hipError_t e = launch_compact(mask, (n_hits_max + 63) / 64, n_hits_max, word_prefix, block_sums, vidx, n_hits_max, d_nv, st);
     if (e != hipSuccess) return e;
-    CRASS_LAUNCH(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits);
+    CRASS_LAUNCH(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits, narrow);
     return hipGetLastError();
 }
 
