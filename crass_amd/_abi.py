@@ -57,7 +57,8 @@ class Counters(C.Structure):
                 ("ms_pass2_total", C.c_float), ("ms_merge_host", C.c_float), ("ms_sink_host", C.c_float),
                 ("bytes_reads_device", C.c_uint64), ("anchor_keys", C.c_uint32), ("anchor_table_kind", C.c_uint32),
                 ("used_device_merge", C.c_uint32), ("ms_merge_device", C.c_float),
-                ("n_merge_fallbacks", C.c_uint32), ("last_fallback_bits", C.c_uint32), ("n_bound_overflows", C.c_uint32 * 4)]
+                ("n_merge_fallbacks", C.c_uint32), ("last_fallback_bits", C.c_uint32), ("n_bound_overflows", C.c_uint32 * 4),
+                ("used_device_view", C.c_uint32), ("n_view_fallbacks", C.c_uint32)]
 
     def asdict(self):
         d = {f[0]: getattr(self, f[0]) for f in self._fields_}
@@ -209,7 +210,7 @@ SYMBOLS = {
     "crass_unpack_ascii": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
 }
 
-ABI_VERSION = 2        # CRASS_HIP_ABI_VERSION of include/crass_hip.h these struct layouts mirror
+ABI_VERSION = 3        # CRASS_HIP_ABI_VERSION of include/crass_hip.h these struct layouts mirror
 _lib = None
 
 

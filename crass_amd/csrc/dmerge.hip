@@ -535,6 +535,258 @@ __global__ __launch_bounds__(256) void k_dm_fill_finish(DevMerge M)
     M.anchor_fp[w] = out;
 }
 
+// ---- 7. the host view of the merge (crass_merge_view, include/crass_hip.h) assembled on the device ----
+// What the host used to rebuild from root_of[] / blank[] on a helper thread (token arena, mDR2GIDMap as flat arrays, the
+// pattern list of createNonRedundantSet in WorkHorse.cpp:690-697 order) — 0.6 ms for 42 k tokens, the critical path of a
+// rank whose shard of the reads is an eighth of the job.  Five small launches on a side stream, beside the merge's last
+// three kernels; the result is ONE dense blob that a DMA engine moves to pinned host memory.
+//   k_dmx_count   per root: members, survivors, survivors' characters (one atomic per distinct root and wave)
+//   k_dmx_tiles   per tile of 1024 tokens: sums of {is root, group size, survivors, survivors' chars (at roots), length}
+//   k_dmx_apply   exclusive prefixes -> GIDs (roots in token order = nextFreeGID++ order, WorkHorse.cpp:1598), group / pattern
+//                 bases, tok_off; copies the token strings; publishes the totals and the blob layout
+//   k_dmx_place   every token claims a slot in its group's member list (any order)
+//   k_dmx_rank    every member counts the members of its group that precede it — by token for grp_tokens, by (length, token)
+//                 among the survivors for the pattern list (remove_redundant's order, merge.cpp) — and writes its outputs
+// A group with more than x_group_cap members is not ranked here (the counting is quadratic in the group): ok = 0, and the
+// host builds the view as before.
+static __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+    return v;
+}
+static __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, off);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_dmx_count(DevMerge M)
+{
+    if (dm_abandoned(M)) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = t < dm_ntok(M);
+    const uint32_t r = act ? M.root_of[t] : 0u;
+    const bool kept = act && !M.blank[t];
+    const uint32_t len = kept ? M.dx_len[t] : 0u;
+    uint64_t todo = __ballot(act);
+    while (todo) {                                      // one round per distinct root among the wave's tokens
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t r0 = (uint32_t)__shfl((int)r, l);
+        const bool mine = act && r == r0;
+        const uint64_t peers = __ballot(mine);
+        const uint32_t nk = (uint32_t)__popcll(__ballot(mine && kept));
+        const uint32_t ch = wave_sum(mine ? len : 0u);
+        if (lane == l) {
+            atomicAdd(&M.x_size[r0], (uint32_t)__popcll(peers));
+            if (nk) { atomicAdd(&M.x_kept[r0], nk); atomicAdd(&M.x_kchars[r0], ch); }
+        }
+        todo &= ~peers;
+    }
+}
+
+// the five scan values of token t (zero beyond the token count)
+static __device__ __forceinline__ void dmx_vals(const DevMerge &M, uint32_t t, uint32_t n, uint32_t v[kDmxVals])
+{
+    v[0] = v[1] = v[2] = v[3] = v[4] = 0u;
+    if (t >= n) return;
+    v[4] = M.dx_len[t];
+    if (M.root_of[t] == t) { v[0] = 1u; v[1] = M.x_size[t]; v[2] = M.x_kept[t]; v[3] = M.x_kchars[t]; }
+}
+
+__global__ __launch_bounds__(1024) void k_dmx_tiles(DevMerge M)
+{
+    if (dm_abandoned(M)) return;
+    __shared__ uint32_t part[16][kDmxVals + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t v[kDmxVals];
+    dmx_vals(M, t, dm_ntok(M), v);
+    uint32_t mx = v[1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+#pragma unroll
+    for (uint32_t q = 0; q < kDmxVals; q++) { const uint32_t s = wave_sum(v[q]); if (lane == 0) part[w][q] = s; }
+    if (lane == 0) part[w][kDmxVals] = mx;
+    __syncthreads();
+    if (threadIdx.x < kDmxVals) {
+        uint32_t s = 0;
+        for (int i = 0; i < 16; i++) s += part[i][threadIdx.x];
+        M.x_tile[blockIdx.x * kDmxVals + threadIdx.x] = s;
+    }
+    if (threadIdx.x == kDmxVals) {
+        uint32_t m = 0;
+        for (int i = 0; i < 16; i++) m = max(m, part[i][kDmxVals]);
+        if (m) atomicMax(&M.x_tile[kDmxTiles * kDmxVals], m);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_dmx_apply(DevMerge M)
+{
+    __shared__ uint32_t part[16][kDmxVals], ptot[16][kDmxVals], pbef[16][kDmxVals];
+    __shared__ uint32_t before[kDmxVals], total[kDmxVals];
+    __shared__ DevViewTotals T;
+    const bool dead = dm_abandoned(M);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t n = dm_ntok(M);
+    const uint32_t n_tiles = gridDim.x, tile = blockIdx.x;
+    if (dead) {
+        if (tile == 0 && threadIdx.x == 0) { DevViewTotals z{}; *M.x_tot = z; *M.x_htot = z; }
+        return;
+    }
+    // (a) this tile's exclusive prefix and the totals, from the tile sums of the launch before (<= 1024 tiles: one per thread)
+#pragma unroll
+    for (uint32_t q = 0; q < kDmxVals; q++) {
+        const uint32_t tv = threadIdx.x < n_tiles ? M.x_tile[threadIdx.x * kDmxVals + q] : 0u;
+        const uint32_t st = wave_sum(tv), sb = wave_sum(threadIdx.x < tile ? tv : 0u);
+        if (lane == 0) { ptot[w][q] = st; pbef[w][q] = sb; }
+    }
+    __syncthreads();
+    if (threadIdx.x < kDmxVals) {
+        uint32_t a = 0, b = 0;
+        for (int i = 0; i < 16; i++) { a += ptot[i][threadIdx.x]; b += pbef[i][threadIdx.x]; }
+        total[threadIdx.x] = a; before[threadIdx.x] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DevViewTotals t{};
+        t.n_tok = n; t.n_groups = total[0]; t.n_kept = total[2]; t.tok_chars = total[4]; t.kept_chars = total[3];
+        t.max_group = M.x_tile[kDmxTiles * kDmxVals];
+        t.ok = (t.max_group <= M.x_group_cap && total[1] == n) ? 1u : 0u;
+        t.lay = view_layout(n, t.n_groups, 2ull * t.n_kept, t.tok_chars, 2ull * t.kept_chars);
+        T = t;
+        if (tile == 0) { *M.x_tot = t; if (!t.ok) *M.x_htot = t; }       // (ok: the host mirror is written by the LAST kernel, behind the blob)
+    }
+    __syncthreads();
+    if (!T.ok) return;
+    // (b) exclusive scan inside the tile
+    const uint32_t t = tile * 1024u + threadIdx.x;
+    uint32_t v[kDmxVals], ex[kDmxVals];
+    dmx_vals(M, t, n, v);
+#pragma unroll
+    for (uint32_t q = 0; q < kDmxVals; q++) {
+        const uint32_t inc = wave_incl_scan(v[q], lane);
+        ex[q] = inc - v[q];
+        if (lane == 63) part[w][q] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < kDmxVals; q++) {
+        uint32_t s = before[q];
+        for (int i = 0; i < w; i++) s += part[i][q];
+        ex[q] += s;
+    }
+    uint8_t *blob = M.x_blob;
+    uint64_t *tok_off = reinterpret_cast<uint64_t *>(blob + T.lay.tok_off);
+    uint64_t *grp_off = reinterpret_cast<uint64_t *>(blob + T.lay.grp_off);
+    if (t < n) {
+        tok_off[t] = ex[4];
+        if (v[0]) {                                      // a root: its group's dense id and bases
+            M.x_gid[t] = ex[0]; M.x_goff[t] = ex[1]; M.x_pat0[t] = 2u * ex[2]; M.x_pch0[t] = 2u * ex[3];
+            grp_off[ex[0]] = ex[1];
+        }
+    }
+    if (t == 0) {
+        tok_off[n] = T.tok_chars; grp_off[T.n_groups] = n;
+        reinterpret_cast<uint64_t *>(blob + T.lay.pat_off)[2ull * T.n_kept] = 2ull * T.kept_chars;
+    }
+    // (c) the token strings, back to back: the wave takes its 64 tokens one after the other, lane = character
+    char *tok_chars = reinterpret_cast<char *>(blob + T.lay.tok_chars);
+    const uint32_t t0 = t - (uint32_t)lane;
+    uint64_t todo = __ballot(t < n);
+    while (todo) {
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t len_l = (uint32_t)__shfl((int)v[4], l), off_l = (uint32_t)__shfl((int)ex[4], l);
+        if ((uint32_t)lane < len_l) tok_chars[off_l + lane] = M.dx_chars[(uint64_t)(t0 + l) * M.stride + lane];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dmx_place(DevMerge M)
+{
+    if (!M.x_tot->ok) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = t < M.x_tot->n_tok;
+    const uint32_t r = act ? M.root_of[t] : 0u;
+    uint32_t slot = 0;
+    uint64_t todo = __ballot(act);
+    while (todo) {                                      // one returning atomic per distinct root among the wave's tokens
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t r0 = (uint32_t)__shfl((int)r, l);
+        const bool mine = act && r == r0;
+        const uint64_t peers = __ballot(mine);
+        uint32_t base = 0;
+        if (lane == l) base = atomicAdd(&M.x_fill[r0], (uint32_t)__popcll(peers));
+        base = (uint32_t)__shfl((int)base, l);
+        if (mine) slot = base + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        todo &= ~peers;
+    }
+    if (act) M.x_members[M.x_goff[r] + slot] = ((uint32_t)(M.blank[t] ? 1u : 0u) << 27) | ((uint32_t)M.dx_len[t] << 20) | t;
+}
+
+static __device__ __forceinline__ char dmx_comp(char c)                // SeqUtils.cpp:50-59 over the device merge's alphabet
+{
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+}
+
+__global__ __launch_bounds__(256) void k_dmx_rank(DevMerge M)
+{
+    const DevViewTotals T = *M.x_tot;
+    if (!T.ok) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = i < T.n_tok;
+    uint8_t *blob = M.x_blob;
+    uint32_t t = 0, len = 0, dst_f = 0, dst_r = 0;
+    bool kept = false;
+    if (act) {
+        const uint32_t key = M.x_members[i];
+        t = key & 0xFFFFFu; len = (key >> 20) & 0x7Fu; kept = (key >> 27) == 0u;
+        const uint32_t r = M.root_of[t], g0 = M.x_goff[r], s = M.x_size[r];
+        uint32_t ra = 0, rp = 0, cp = 0;
+        const uint32_t *mem = M.x_members + g0;
+#pragma unroll 4
+        for (uint32_t j = 0; j < s; j++) {
+            const uint32_t k2 = mem[j];
+            ra += (k2 & 0xFFFFFu) < t ? 1u : 0u;
+            const bool lt = k2 < key;                   // (a survivor's key is only preceded by survivors' keys: blank is the top bit)
+            rp += lt ? 1u : 0u;
+            cp += lt ? ((k2 >> 20) & 0x7Fu) : 0u;
+        }
+        reinterpret_cast<uint32_t *>(blob + T.lay.grp_tokens)[g0 + ra] = t + 2u;
+        if (kept) {
+            const uint32_t kg = M.x_kept[r], p = M.x_pat0[r] + rp, gid1 = M.x_gid[r] + 1u;
+            dst_f = M.x_pch0[r] + cp; dst_r = dst_f + M.x_kchars[r];
+            uint64_t *pat_off = reinterpret_cast<uint64_t *>(blob + T.lay.pat_off);
+            uint32_t *pat_group = reinterpret_cast<uint32_t *>(blob + T.lay.pat_group);
+            pat_off[p] = dst_f; pat_off[p + kg] = dst_r;
+            pat_group[p] = gid1; pat_group[p + kg] = gid1;
+        }
+    }
+    // the pattern strings: every survivor and its reverse complement, lane = character
+    char *pat_chars = reinterpret_cast<char *>(blob + T.lay.pat_chars);
+    uint64_t todo = __ballot(kept);
+    while (todo) {
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t t_l = (uint32_t)__shfl((int)t, l), len_l = (uint32_t)__shfl((int)len, l);
+        const uint32_t f_l = (uint32_t)__shfl((int)dst_f, l), r_l = (uint32_t)__shfl((int)dst_r, l);
+        if ((uint32_t)lane < len_l) {
+            const char ch = M.dx_chars[(uint64_t)t_l * M.stride + lane];
+            pat_chars[f_l + lane] = ch;
+            pat_chars[r_l + (len_l - 1u - (uint32_t)lane)] = dmx_comp(ch);
+        }
+    }
+    if (i == 0) *M.x_htot = T;                          // (any thread: the host only reads the blob after the stream's event)
+}
+
+
 // ---- one-collective exchange ----
 __global__ __launch_bounds__(256) void k_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride,
                                                   uint64_t cap_rows, uint32_t slot_bytes, uint8_t *send)
@@ -598,7 +850,7 @@ hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, 
     return hipGetLastError();
 }
 
-hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done)
+hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done, hipStream_t view_st, hipEvent_t ev_fork, hipEvent_t ev_view)
 {
     if (M.n_tok == 0) return hipErrorInvalidValue;
     const unsigned nb = (M.n_tok + 255) / 256;
@@ -613,6 +865,20 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done
     unsigned rb = (M.n_tok + 3) / 4;
     if (rb > 4096) rb = 4096;
     CRASS_LAUNCH(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
+    if (M.x_on && view_st) {
+        // the view only needs root_of[] and blank[]: it is assembled beside the kernels that build pass 2's index
+        hipError_t e = hipEventRecord(ev_fork, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(view_st, ev_fork, 0);
+        if (e != hipSuccess) return e;
+        const unsigned nt = (M.n_tok + 1023) / 1024;
+        CRASS_LAUNCH(k_dmx_count, dim3(nb), dim3(256), 0, view_st, M);
+        CRASS_LAUNCH(k_dmx_tiles, dim3(nt), dim3(1024), 0, view_st, M);
+        CRASS_LAUNCH(k_dmx_apply, dim3(nt), dim3(1024), 0, view_st, M);
+        CRASS_LAUNCH(k_dmx_place, dim3(nb), dim3(256), 0, view_st, M);
+        CRASS_LAUNCH(k_dmx_rank, dim3(nb), dim3(256), 0, view_st, M);
+        e = hipEventRecord(ev_view, view_st);
+        if (e != hipSuccess) return e;
+    }
     const unsigned ne = (16u * M.n_tok + 255) / 256;
     CRASS_LAUNCH(k_dm_keys, dim3(ne), dim3(256), 0, st, M);
     CRASS_LAUNCH(k_dm_key_bases_insert, dim3((16u * M.n_tok + 1023) / 1024), dim3(1024), 0, st, M);

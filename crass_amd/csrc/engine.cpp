@@ -166,6 +166,8 @@ struct EnvSwitches {
     bool no_lookback = false, no_pos_hints = false, merge_profile = false, no_lane_kernel = false;
     bool host_merge = false, no_speculation = false, exc_separate = false, dm_inject_fail = false, dm_init_late = false;
     bool no_presize = false;                         // A/B switch: no first-call bounds / pool sizing at crass_hip_load_reads
+    bool no_device_view = false;                     // A/B switch: the host rebuilds crass_merge_view from root_of / blank (the round-3 path)
+    uint32_t view_group_cap = 32768;                 // groups beyond this many members are ranked by the host (CRASS_VIEW_GROUP_CAP)
     uint64_t test_bounds[4] = {0, 0, 0, 0};          // tests: CRASS_TEST_BOUNDS="survivors,distinct,flagged,gathered" replaces the
                                                      // first-call bounds (0 = computed), so that every overflow path can be forced
     uint32_t row_cap = 1024, dm_group_cap = 16384, surv_debug = 0;
@@ -177,7 +179,8 @@ struct EnvSwitches {
         no_lookback = on("CRASS_NO_LOOKBACK"); no_pos_hints = on("CRASS_NO_POS_HINTS");
         merge_profile = on("CRASS_MERGE_PROFILE"); no_lane_kernel = on("CRASS_NO_LANE_KERNEL"); host_merge = on("CRASS_HOST_MERGE");
         no_speculation = on("CRASS_NO_SPECULATION"); exc_separate = on("CRASS_EXC_SEPARATE"); dm_init_late = on("CRASS_DM_INIT_LATE");
-        dm_inject_fail = on("CRASS_DM_INJECT_FAIL"); no_presize = on("CRASS_NO_PRESIZE");
+        dm_inject_fail = on("CRASS_DM_INJECT_FAIL"); no_presize = on("CRASS_NO_PRESIZE"); no_device_view = on("CRASS_NO_DEVICE_VIEW");
+        view_group_cap = 32768; if (const char *e = getenv("CRASS_VIEW_GROUP_CAP")) view_group_cap = (uint32_t)std::max(1, atoi(e));
         row_cap = 1024; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
         dm_group_cap = 16384; if (const char *e = getenv("CRASS_DM_GROUP_CAP")) dm_group_cap = (uint32_t)std::max(1, atoi(e));
         surv_debug = 0; if (const char *e = getenv("CRASS_SURV_DEBUG")) surv_debug = (uint32_t)atoi(e);
@@ -350,8 +353,18 @@ struct crass_hip_ctx {
         PinBuf<uint32_t> h_gmap; PinBuf<char> h_gx_chars; PinBuf<uint16_t> h_gx_len; PinBuf<uint64_t> h_gx_hash;
         std::vector<uint32_t> cand_map;
         hipEvent_t ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+        // crass_merge_view assembled on the device (k_dmx_*, dmerge.hip): scratch, the dense blob, its totals; the blob
+        // reaches h_view on a DMA engine (dma_view) started by the helper thread once ev_view has fired
+        DevBuf<uint32_t> x_u32, x_members, x_tile; DevBuf<uint8_t> x_blob; DevBuf<DevViewTotals> x_tot;
+        PinBuf<DevViewTotals> x_htot; PinBuf<uint8_t> h_view;
+        hipStream_t view_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_view = nullptr;
+        SdmaCopy *dma_view = nullptr;
+        bool view_launched = false;                 // export kernels may be running on view_stream (ev_view orders after them)
+        bool view_ready = false;                    // h_view holds the view of the current merge (crass_hip_get_merge reads it)
+        DevViewTotals view_tot{};
         void release()
         {
+            x_u32.release(); x_members.release(); x_tile.release(); x_blob.release(); x_tot.release(); x_htot.release(); h_view.release();
             packed.release(); tmask.release(); bk_key.release(); codes.release(); owner.release(); root_of.release();
             pat_token.release(); kset_u32.release(); ent_slot.release(); anchor_tab.release(); anchor_fp.release();
             blank.release(); ents.release(); rents.release(); rset_u32.release(); rd_slot.release(); rset_key.release(); kset_key.release(); st.release(); h_st.release(); h_root.release(); h_blank.release();
@@ -362,6 +375,13 @@ struct crass_hip_ctx {
             if (ev_t0) (void)hipEventDestroy(ev_t0);
             if (ev_t1) (void)hipEventDestroy(ev_t1);
             ev_done = ev_t0 = ev_t1 = nullptr;
+            if (view_stream) (void)hipStreamSynchronize(view_stream);
+            sdma_destroy(dma_view); dma_view = nullptr;
+            if (ev_fork) (void)hipEventDestroy(ev_fork);
+            if (ev_view) (void)hipEventDestroy(ev_view);
+            if (view_stream) (void)hipStreamDestroy(view_stream);
+            ev_fork = ev_view = nullptr; view_stream = nullptr;
+            view_launched = view_ready = false;
         }
     } dm;
     // one-collective exchange (crass_hip_exchange_setup): this rank's distinct list in a fixed-size device buffer
@@ -393,6 +413,7 @@ struct crass_hip_ctx {
 
     crass_counters cnt{};
     uint32_t n_merge_fallbacks = 0, last_fallback_bits = 0;
+    std::atomic<uint32_t> n_view_fallbacks{0};      // device merges whose host view was built by the host after all (a group beyond the export's cap)
     uint32_t n_bound_overflows[4] = {0, 0, 0, 0};   // speculation bounds that turned out too small (stage repeated): survivors, distinct, flagged, gathered
     hipEvent_t ev[12]{};
     // stage timing (crass_hip_set_stage_timing): an event record costs ~6 us of stream time, 14 of them 8 % of a 1 ms step.
@@ -1305,6 +1326,8 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     c->have_pass1 = c->have_merge = c->have_pass2 = false;
     c->dm.active = false;
     c->premerge_inflight = false;
+    // (the survivor kernel clears the merge's words, x_* included: behind whatever export of a merge nobody adopted)
+    if (c->dm.view_launched) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->dm.ev_view, 0)); c->dm.view_launched = false; }
     const uint64_t n = c->R.n_reads;
     const uint64_t n_words = (n + 63) / 64;
     HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
@@ -1629,6 +1652,26 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
     }
     M.n_cu = c->n_cu;
     M.h_st = d.h_st.p; M.h_root = d.h_root.p; M.h_blank = d.h_blank.p;
+    // the host view of this merge is assembled on the device too (k_dmx_*), unless this context only reports its own
+    // candidates' tokens (ranks > 0 of a group)
+    M.x_on = (!c->env.no_device_view && !c->host_view_light && n <= (1u << 20)) ? 1u : 0u;
+    if (M.x_on) {
+        if (!d.view_stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&d.view_stream, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&d.ev_view, hipEventDisableTiming));
+            d.dma_view = sdma_create();                 // (nullptr: the runtime's copy is used)
+        }
+        const uint64_t cap = view_layout(n, n, 2ull * n, (uint64_t)n * stride, 2ull * n * stride).total;
+        HIPCHK(c, d.x_u32.ensure((size_t)n * 8)); HIPCHK(c, d.x_members.ensure(n)); HIPCHK(c, d.x_tile.ensure(kDmxTiles * kDmxVals + 4));
+        HIPCHK(c, d.x_blob.ensure(cap + 64)); HIPCHK(c, d.x_tot.ensure(1)); HIPCHK(c, d.x_htot.ensure(1));
+        if (!d.h_view.p) HIPCHK(c, d.h_view.ensure(std::max<uint64_t>(cap / 4, 1u << 16)));      // (grown by the build if a merge needs more)
+        uint32_t *x = d.x_u32.p;
+        M.x_size = x; M.x_kept = x + n; M.x_kchars = x + 2ull * n; M.x_fill = x + 3ull * n;
+        M.x_gid = x + 4ull * n; M.x_goff = x + 5ull * n; M.x_pat0 = x + 6ull * n; M.x_pch0 = x + 7ull * n;
+        M.x_members = d.x_members.p; M.x_tile = d.x_tile.p; M.x_blob = d.x_blob.p; M.x_tot = d.x_tot.p; M.x_htot = d.x_htot.p;
+        M.x_group_cap = c->env.view_group_cap;
+    }
     M.inject_fail = c->env.dm_inject_fail ? 1u : 0u;
     M.group_cap = c->env.dm_group_cap;
     M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
@@ -1646,8 +1689,10 @@ static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const ui
     crass_hip_ctx::DM &d = c->dm;
     if (!prepared) { const int ps = device_merge_prepare(c, dx_chars, dx_len, n_tok, d_ntok); if (ps) return ps; }
     const double tl0 = now_ms();
+    if (d.view_launched) HIPCHK(c, hipStreamWaitEvent(c->stream, d.ev_view, 0));     // (an abandoned merge's export still owns the x_* words)
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
-    HIPCHK(c, launch_device_merge(d.M, c->stream, prepared));
+    HIPCHK(c, launch_device_merge(d.M, c->stream, prepared, d.M.x_on ? d.view_stream : nullptr, d.ev_fork, d.ev_view));
+    d.view_launched = d.M.x_on != 0;
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
     if (c->env.merge_profile)
         fprintf(stderr, "[crass_dm] host: pass-1 sync -> merge launch start %.1f us, launching the merge kernels %.1f us\n",
@@ -1662,7 +1707,7 @@ static int device_merge_commit(crass_hip_ctx *c, uint64_t n_tok, const char *hx_
 {
     crass_hip_ctx::DM &d = c->dm;
     d.hx_chars = hx_chars; d.hx_len = hx_len; d.n_tok = n_tok;
-    d.active = true; d.host_built = false; d.n_cand = c->dense.n;
+    d.active = true; d.host_built = false; d.view_ready = false; d.n_cand = c->dense.n;
     // the host view (tokens, groups, pattern list) is rebuilt by the helper thread as soon as the kernels are through
     // every field of the caller's side is set BEFORE the job is handed over: from submit() on, the helper thread owns
     // c->merge and dm.br until ensure_host_merge / quiesce_worker has waited for it
@@ -1771,6 +1816,12 @@ static int build_host_merge(crass_hip_ctx *c)
         d.br.ms_device = ms;
         d.br.valid = true;
     };
+    // every exit waits for the view export (a few small kernels on view_stream): whoever re-uses the x_* words or the blob
+    // next must find them idle
+    struct DrainView {
+        crass_hip_ctx::DM &d;
+        ~DrainView() { if (d.view_launched && d.ev_view) (void)hipEventSynchronize(d.ev_view); }
+    } drain{d};
     // local merge: the token strings and the candidates' tokens only need pass 1's outputs, which the host has
     // already waited for — that half of the host view is built while the merge kernels are still running
     // (the gathered form too: the global distinct list and every gathered row's rank in it were written to pinned memory
@@ -1797,6 +1848,45 @@ static int build_host_merge(crass_hip_ctx *c)
         publish();
         d.br.ms_device = 0;
         return CRASS_OK;
+    }
+    if (d.M.x_on && d.view_launched) {
+        // The view itself comes from the device (k_dmx_*): what is left for the host are its own candidates' tokens (pass 1's
+        // outputs, done while the merge kernels run), one DMA copy of the blob, and pointers.
+        c->merge.clear();
+        c->merge.cand_token.resize(d.n_cand);
+        for (uint64_t k = 0; k < d.n_cand; k++) {
+            if (cmap[k] >= d.n_tok) { c->merge.clear(); return CRASS_ERR_STATE; }
+            c->merge.cand_token[k] = cmap[k] + 2;
+        }
+        const double tv0 = now_ms();
+        if (const int ws = wait_done()) return ws;
+        if (d.h_st.p->fail) return CRASS_ERR_STATE;
+        { const hipError_t e = hipEventSynchronize(d.ev_view); if (e != hipSuccess) { d.br.hip = (int)e; return CRASS_ERR_HIP; } }
+        const double tv1 = now_ms();
+        const DevViewTotals T = *d.x_htot.p;
+        if (T.ok && T.n_tok == d.n_tok && 2u * T.n_kept == d.h_st.p->n_patterns && T.n_groups >= 1 && T.lay.total <= d.x_blob.n) {
+            if (d.h_view.n < T.lay.total) {
+                const hipError_t e = d.h_view.ensure(T.lay.total + T.lay.total / 2);
+                if (e != hipSuccess) { d.br.hip = (int)e; return e == hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP; }
+            }
+            bool copied = false;
+            if (sdma_start(d.dma_view, d.x_blob.p, d.h_view.p, T.lay.total)) copied = sdma_wait(d.dma_view) == 0;
+            if (!copied) {
+                hipError_t e = hipMemcpyAsync(d.h_view.p, d.x_blob.p, T.lay.total, hipMemcpyDeviceToHost, d.view_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(d.view_stream);
+                if (e != hipSuccess) { d.br.hip = (int)e; return CRASS_ERR_HIP; }
+            }
+            d.view_tot = T;
+            d.view_ready = true;
+            d.host_built = true;
+            if (c->env.merge_profile)
+                fprintf(stderr, "[crass_dm] helper: candidates' tokens %.1f us, waited %.1f us for the merge + view kernels, blob copy (%llu bytes) %.1f us (done %.1f us after the pass-1 sync)\n",
+                        1e3 * (tv0 - tb00), 1e3 * (tv1 - tv0), (unsigned long long)T.lay.total, 1e3 * (now_ms() - tv1), 1e3 * (now_ms() - c->t_p1_sync));
+            publish();
+            return CRASS_OK;
+        }
+        // (a group beyond x_group_cap, or totals that do not add up: the host builds the view from the per-token results)
+        c->n_view_fallbacks++;
     }
     if (!merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand)) return CRASS_ERR_STATE;
     host_pool_warm();                                   // the second half fans out over the pool: wake it while the device is busy
@@ -2195,6 +2285,17 @@ int crass_hip_get_merge(const crass_hip_ctx *c, crass_merge_view *o)
         if (s == CRASS_ERR_STATE) s = host_merge_fallback(mc);
         if (s) return s;
     }
+    if (c->dm.active && c->dm.view_ready) {
+        // the arrays the device assembled (k_dmx_*), where the DMA engine put them; the candidates' tokens are the host's
+        const DevViewTotals &T = c->dm.view_tot;
+        const uint8_t *b = c->dm.h_view.p;
+        o->n_tokens = T.n_tok; o->tok_chars = (const char *)(b + T.lay.tok_chars); o->tok_off = (const uint64_t *)(b + T.lay.tok_off);
+        o->n_candidates = c->merge.cand_token.size(); o->cand_token = c->merge.cand_token.data();
+        o->n_groups = T.n_groups; o->grp_tokens = (const uint32_t *)(b + T.lay.grp_tokens); o->grp_off = (const uint64_t *)(b + T.lay.grp_off);
+        o->n_patterns = 2u * T.n_kept; o->pat_chars = (const char *)(b + T.lay.pat_chars); o->pat_off = (const uint64_t *)(b + T.lay.pat_off);
+        o->pat_group = (const uint32_t *)(b + T.lay.pat_group); o->next_free_gid = (int32_t)T.n_groups + 1;
+        return CRASS_OK;
+    }
     const MergeResult &m = c->merge;
     o->n_tokens = m.tokens.size(); o->tok_chars = m.tokens.strings.chars.data(); o->tok_off = m.tokens.strings.off.data();
     o->n_candidates = m.cand_token.size(); o->cand_token = m.cand_token.data();
@@ -2443,13 +2544,21 @@ int crass_hip_get_recruits(const crass_hip_ctx *c, crass_recruits *o)
         mc->q_token.assign(b_tok, b_tok + n);
         mc->q_low.assign(hb + b.low, hb + b.low + n);
         mc->q_start.resize(n); mc->q_end.resize(n); mc->q_dr_len.resize(n); mc->q_dr.assign(n * (size_t)c->dr_stride, 0);
+        // token strings: the device-built view (h_view) or the host-built arena
+        const bool dv = c->dm.active && c->dm.view_ready;
+        const uint8_t *vb = c->dm.h_view.p;
+        const uint64_t *v_off = dv ? (const uint64_t *)(vb + c->dm.view_tot.lay.tok_off) : nullptr;
+        const char *v_chars = dv ? (const char *)(vb + c->dm.view_tot.lay.tok_chars) : nullptr;
+        const uint32_t n_tok = dv ? c->dm.view_tot.n_tok : c->merge.tokens.size();
         for (uint64_t k = 0; k < n; k++) {
             if (b.narrow) { mc->q_start[k] = (hb + b.start)[k]; mc->q_end[k] = (hb + b.end)[k]; }
             else { mc->q_start[k] = b_start[k]; mc->q_end[k] = b_end[k]; }
             mc->q_dr_len[k] = (hb + b.dr_len)[k];
             const uint32_t t = b_tok[k];
-            if (t >= 2 && t - 2 < c->merge.tokens.size())
-                memcpy(mc->q_dr.data() + k * (size_t)c->dr_stride, c->merge.tokens.strings.data(t - 2), c->merge.tokens.strings.len(t - 2));
+            if (t >= 2 && t - 2 < n_tok) {
+                if (dv) memcpy(mc->q_dr.data() + k * (size_t)c->dr_stride, v_chars + v_off[t - 2], (size_t)(v_off[t - 1] - v_off[t - 2]));
+                else memcpy(mc->q_dr.data() + k * (size_t)c->dr_stride, c->merge.tokens.strings.data(t - 2), c->merge.tokens.strings.len(t - 2));
+            }
         }
         mc->q_wide_ready = true;
     }
@@ -2514,6 +2623,8 @@ int crass_hip_get_counters(const crass_hip_ctx *c, crass_counters *o)
     o->n_merge_fallbacks = c->n_merge_fallbacks;
     o->last_fallback_bits = c->last_fallback_bits;
     for (int k = 0; k < 4; k++) o->n_bound_overflows[k] = c->n_bound_overflows[k];
+    o->used_device_view = (c->dm.active && c->dm.view_ready) ? 1u : 0u;
+    o->n_view_fallbacks = c->n_view_fallbacks.load();
     return CRASS_OK;
 }
 

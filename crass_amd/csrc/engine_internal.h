@@ -112,6 +112,27 @@ struct DevMergeState {
 static constexpr uint32_t kDmBadSlots = 4096;       // identity table of the 11-mers with an 'N' (open addressing)
 static constexpr uint32_t kDmBadKmerCap = 2048;     // ... of which at most this many distinct ones; more -> host merge
 
+// The view's arrays in one dense blob.  Sizes are only known on the device (groups, survivors, characters): k_dmx_apply
+// evaluates the layout from the totals and publishes it (DevViewTotals) for the kernels behind it and for the host.
+struct ViewLayout { uint64_t tok_off, tok_chars, grp_off, grp_tokens, pat_off, pat_chars, pat_group, total; };
+__host__ __device__ inline ViewLayout view_layout(uint64_t n_tok, uint64_t n_groups, uint64_t n_pat, uint64_t tok_chars, uint64_t pat_chars)
+{
+    ViewLayout v;
+    uint64_t at = 0;
+    auto sec = [&](uint64_t bytes) { const uint64_t o = at; at += (bytes + 15u) & ~15ull; return o; };
+    v.tok_off = sec(8 * (n_tok + 1)); v.tok_chars = sec(tok_chars); v.grp_off = sec(8 * (n_groups + 1)); v.grp_tokens = sec(4 * n_tok);
+    v.pat_off = sec(8 * (n_pat + 1)); v.pat_chars = sec(pat_chars); v.pat_group = sec(4 * n_pat);
+    v.total = at;
+    return v;
+}
+struct DevViewTotals {
+    uint32_t ok;                  // 1: the blob holds the complete view
+    uint32_t n_tok, n_groups, n_kept, tok_chars, kept_chars, max_group, pad;
+    ViewLayout lay;
+};
+static constexpr uint32_t kDmxVals = 5;             // per-token scan values: is root, group size, survivors, survivors' chars (at roots), length
+static constexpr uint32_t kDmxTiles = 1024;         // tiles of 1024 tokens: n_tok <= 2^20
+
 // Pattern ids on the device: pid = 2 * token_index + orientation (0 = the variant, 1 = its reverse complement), i.e. the
 // pattern arrays ARE the per-token arrays (packed[t][2o..2o+1], tmask[t][o]); ids of dropped variants are simply unused.
 // (The reference's pattern ORDER — per group, survivors then reverse complements, WorkHorse.cpp:690-697 — only exists in
@@ -155,6 +176,18 @@ struct DevMerge {
     DevMergeState *st;
     // pinned host memory the last kernel exports to (state words, root and dropped flag per token)
     DevMergeState *h_st; uint32_t *h_root; uint8_t *h_blank;
+    // ---- the host view (crass_merge_view) assembled on the device: k_dmx_* (dmerge.hip) ----
+    // per ROOT token (first token of a group): members, survivors of removeRedundantRepeats, the survivors' characters,
+    // a claim cursor; then the group's dense id and its bases in the view's arrays (exclusive prefix sums in root order)
+    uint32_t *x_size, *x_kept, *x_kchars, *x_fill;                     // [n_tok] cleared by dm_init_slice
+    uint32_t *x_gid, *x_goff, *x_pat0, *x_pch0;                        // [n_tok] written by k_dmx_apply for roots
+    uint32_t *x_members;          // [n_tok] member keys (blank << 27 | len << 20 | token), grouped by group, any order inside
+    uint32_t *x_tile;             // [1024][kDmxVals] per-tile sums (tiles of 1024 tokens) + [0..3] behind them: max group size
+    uint8_t  *x_blob;             // the view's arrays, dense (view_layout over the totals), device memory
+    DevViewTotals *x_tot;         // device; x_htot: its pinned mirror
+    DevViewTotals *x_htot;
+    uint32_t x_on;                // 0: no export (the host rebuilds the view from h_root / h_blank)
+    uint32_t x_group_cap;         // a group with more members than this is not ranked here (quadratic): the host builds the view
     uint32_t inject_fail;         // tests only: start with the fail word set (exercises the fall-back to the host merge)
     uint32_t group_cap;           // a needle key with more candidates than this sets fail bit 32: removeRedundantRepeats here
                                   // compares a window with every shorter member that shares its first 16 bases, which is
@@ -171,6 +204,10 @@ static __device__ __forceinline__ void dm_init_slice(const DevMerge &M, uint64_t
     for (uint64_t i = tid; i < ((1u << 22) + kDmBadSlots) / 4; i += nth) o4[i] = ones;
     for (uint64_t i = tid; i < kDmBadSlots; i += nth) M.bk_key[i] = 0ull;
     for (uint64_t i = tid; i < M.n_tok; i += nth) M.root_of[i] = 0xFFFFFFFFu;
+    if (M.x_on) {
+        for (uint64_t i = tid; i < M.n_tok; i += nth) { M.x_size[i] = 0u; M.x_kept[i] = 0u; M.x_kchars[i] = 0u; M.x_fill[i] = 0u; }
+        if (tid < 4) M.x_tile[kDmxTiles * kDmxVals + tid] = 0u;
+    }
     const uint64_t ks = 1ull << M.kset_log;
     for (uint64_t i = tid; i < ks; i += nth) { M.kset_key[i] = 0ull; M.kset_cnt[i] = 0u; M.kset_fill[i] = 0u; }
     const uint64_t rs = 1ull << M.rset_log;
@@ -193,7 +230,10 @@ hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const ui
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
                             char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo = nullptr);   // h_xinfo: pinned mirror
 // init_done: the tables were cleared by an earlier kernel of the step (dm_init_slice)
-hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done = false);
+// view_st / ev_fork / ev_view (M.x_on): the view export runs on view_st beside the merge's last three kernels, forked behind
+// k_dm_redundant (ev_fork); ev_view is recorded behind its last kernel
+hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done = false, hipStream_t view_st = nullptr,
+                               hipEvent_t ev_fork = nullptr, hipEvent_t ev_view = nullptr);
 // pass-2 anchor filter with table parameters read from the device (M.st); flags nothing when M.st->fail
 hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st);
 hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,

@@ -550,12 +550,14 @@ void pack_dr(const char *p, size_t n, PackedDr &out)
 // the O(n^2) pairwise find() is replaced by an index of every member's leading 16 bases: for
 // ACGT-only groups the members are 2-bit packed, a window is one shift of a 128-bit integer, and
 // the index is a small open-addressing table behind a bitmap pre-filter; byte-hash index otherwise.
-// std::sort / std::partition run on the views with the reference's predicates, so the surviving
-// ORDER is what the reference produces with the same libstdc++ (the algorithms only see the
-// comparison results).
+// ORDER of the survivors: the reference sorts with std::sort and drops the blanks with std::partition, both of which
+// leave the relative order of equivalent elements unspecified (what a given libstdc++ happens to produce is an artefact
+// of its introsort; only the SET reaches pass 2, SURVEY a-14).  Every path of this library — this one, the host view of
+// a device merge below, the view the device exports itself (dmerge.hip, k_dmx_*) and the oracle — uses the one
+// permitted outcome that needs no sequential sort: length ascending, token order among equal lengths, blanks erased in place.
 void remove_redundant(std::vector<Member> &v, const StringArena &strs, const PackedDr *packed)
 {
-    std::sort(v.begin(), v.end(), member_shorter_first);
+    std::stable_sort(v.begin(), v.end(), member_shorter_first);
     if (v.size() > 1) {
         const size_t min_len = v.front().len;
         bool all_packed = min_len >= 16;
@@ -641,7 +643,7 @@ void remove_redundant(std::vector<Member> &v, const StringArena &strs, const Pac
         }
     }
     for (auto &m : v) if (m.len == 0) m.blank = true;             // empty strings never survive the partition
-    v.erase(std::partition(v.begin(), v.end(), member_kept), v.end());
+    v.erase(std::stable_partition(v.begin(), v.end(), member_kept), v.end());
 }
 
 // k-mer code -> smallest token index containing it, filled by several threads at once.
@@ -894,8 +896,7 @@ bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint
     });
     m.groups.assign(n_groups, {});
     const double p2b = prof_now();
-    // per group: the reference's sort by length + partition (the same std:: calls on the same sequence, so the same
-    // order among equal lengths)
+    // per group: sort by length (token order among equal lengths), survivors in front in that order (remove_redundant)
     std::vector<uint32_t> kept(n_groups + 1, 0);
     std::vector<uint64_t> kept_chars(n_groups + 1, 0);
     const size_t gchunk = n_distinct >= 4096 ? 1 : std::max<size_t>(n_groups, 1);          // small sets: one task, no dispatch
@@ -904,8 +905,8 @@ bool merge_from_device_finish(MergeResult &m, const uint32_t *gid_of, const uint
         for (size_t g = c * gchunk; g < std::min<size_t>(n_groups, (c + 1) * gchunk); g++) {
             m.groups[g].assign(m.grp_tokens.begin() + goff[g], m.grp_tokens.begin() + goff[g + 1]);
             Member *lo = members.get() + goff[g], *hi = members.get() + goff[g + 1];
-            std::sort(lo, hi, member_shorter_first);
-            Member *mid = std::partition(lo, hi, member_kept);
+            std::stable_sort(lo, hi, member_shorter_first);
+            Member *mid = std::stable_partition(lo, hi, member_kept);
             kept[g + 1] = (uint32_t)(mid - lo);
             uint64_t ch = 0;
             for (Member *x = lo; x < mid; x++) ch += x->len;

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define CRASS_HIP_ABI_VERSION 2   /* 2: crass_counters, crass_fastx and crass_synth_spec grew (round 2); group API (round 3) */
+#define CRASS_HIP_ABI_VERSION 3   /* 2: crass_counters, crass_fastx and crass_synth_spec grew (round 2); group API (round 3);
+                                    3: crass_counters grew (used_device_view, n_view_fallbacks) (round 4) */
 
 /* ---- status codes (reference: crispr::exception -> exit code) ---- */
 enum {
@@ -291,6 +292,10 @@ typedef struct {
                                        set at load, or learnt from the previous call) was too small: [0] seed-scan survivors,
                                        [1] distinct DR strings (queued merge), [2] reads flagged in pass 2, [3] gathered
                                        distinct strings (multi-rank).  Results are unaffected; each is one repeated stage.  */
+    uint32_t used_device_view;      /* 1: crass_merge_view's arrays (tokens, groups, pattern list) of the last merge were
+                                       assembled on the device and copied by a DMA engine; 0: built by the host            */
+    uint32_t n_view_fallbacks;      /* since crass_hip_create: device merges whose view the host built after all (a group
+                                       with more members than the export ranks on the device)                              */
 } crass_counters;
 int crass_hip_get_counters(const crass_hip_ctx *ctx, crass_counters *out);
 

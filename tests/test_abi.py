@@ -32,7 +32,7 @@ def test_header_symbols_all_exported(ca):
     for name in sorted(declared):
         assert hasattr(lib, name), "missing export: " + name
     assert declared == set(ca.SYMBOLS), declared ^ set(ca.SYMBOLS)
-    assert ca.load().crass_hip_abi_version() == 2
+    assert ca.load().crass_hip_abi_version() == 3
 
 
 def test_no_kernel_uses_the_last_vgpr_of_its_allocation(ca):
