@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_dm_fill_finish(DevMerge M)
     }
     if (w == 0) *M.h_st = *M.st;
     if (dead) return;
-    if (w < dm_ntok(M)) { M.h_root[w] = M.root_of[w]; M.h_blank[w] = M.blank[w]; }
+    if (!M.x_on && w < dm_ntok(M)) { M.h_root[w] = M.root_of[w]; M.h_blank[w] = M.blank[w]; }      // (x_on: the view comes from k_dmx_*; the host fetches these if it must)
     const uint32_t ls = M.st->log_size, k0 = M.st->k0;
     const bool fill = ls && !M.st->all_t;
     if (fill && w < (1u << ls) && M.anchor_tab[w] == 0xFFFFFFFFu) M.anchor_tab[w] = k0;
@@ -565,28 +565,39 @@ static __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_dmx_count(DevMerge M)
+// A block's tokens by root in LDS (open addressing, 2 x the tokens of a block): the global words of one root then see one
+// atomic per BLOCK instead of one per token.  The roots are early tokens, i.e. a few hundred neighbouring words: 78 k atomics on
+// them took 107 us of a launch over 42 k tokens, and 26 k returning ones 104 us (rocprofv3, round 4).
+#define DMX_BLOCK 1024
+#define DMX_SLOTS 2048
+static __device__ __forceinline__ uint32_t dmx_claim(uint32_t *hkey, uint32_t r)
+{
+    uint32_t slot = (r * 0x9E3779B1u) >> 21;            // 11 bits
+    for (;;) {
+        const uint32_t old = atomicCAS(&hkey[slot], 0xFFFFFFFFu, r);
+        if (old == 0xFFFFFFFFu || old == r) return slot;
+        slot = (slot + 1u) & (DMX_SLOTS - 1u);
+    }
+}
+
+__global__ __launch_bounds__(DMX_BLOCK) void k_dmx_count(DevMerge M)
 {
     if (dm_abandoned(M)) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool act = t < dm_ntok(M);
-    const uint32_t r = act ? M.root_of[t] : 0u;
-    const bool kept = act && !M.blank[t];
-    const uint32_t len = kept ? M.dx_len[t] : 0u;
-    uint64_t todo = __ballot(act);
-    while (todo) {                                      // one round per distinct root among the wave's tokens
-        const int l = __ffsll((unsigned long long)todo) - 1;
-        const uint32_t r0 = (uint32_t)__shfl((int)r, l);
-        const bool mine = act && r == r0;
-        const uint64_t peers = __ballot(mine);
-        const uint32_t nk = (uint32_t)__popcll(__ballot(mine && kept));
-        const uint32_t ch = wave_sum(mine ? len : 0u);
-        if (lane == l) {
-            atomicAdd(&M.x_size[r0], (uint32_t)__popcll(peers));
-            if (nk) { atomicAdd(&M.x_kept[r0], nk); atomicAdd(&M.x_kchars[r0], ch); }
-        }
-        todo &= ~peers;
+    __shared__ uint32_t hkey[DMX_SLOTS], hcnt[DMX_SLOTS], hkept[DMX_SLOTS], hch[DMX_SLOTS];
+    for (uint32_t i = threadIdx.x; i < DMX_SLOTS; i += DMX_BLOCK) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0u; hkept[i] = 0u; hch[i] = 0u; }
+    __syncthreads();
+    const uint32_t t = blockIdx.x * DMX_BLOCK + threadIdx.x;
+    if (t < dm_ntok(M)) {
+        const uint32_t slot = dmx_claim(hkey, M.root_of[t]);
+        atomicAdd(&hcnt[slot], 1u);
+        if (!M.blank[t]) { atomicAdd(&hkept[slot], 1u); atomicAdd(&hch[slot], (uint32_t)M.dx_len[t]); }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < DMX_SLOTS; i += DMX_BLOCK) {
+        const uint32_t r = hkey[i];
+        if (r == 0xFFFFFFFFu) continue;
+        atomicAdd(&M.x_size[r], hcnt[i]);
+        if (hkept[i]) { atomicAdd(&M.x_kept[r], hkept[i]); atomicAdd(&M.x_kchars[r], hch[i]); }
     }
 }
 
@@ -695,39 +706,44 @@ __global__ __launch_bounds__(1024) void k_dmx_apply(DevMerge M)
         tok_off[n] = T.tok_chars; grp_off[T.n_groups] = n;
         reinterpret_cast<uint64_t *>(blob + T.lay.pat_off)[2ull * T.n_kept] = 2ull * T.kept_chars;
     }
-    // (c) the token strings, back to back: the wave takes its 64 tokens one after the other, lane = character
+    // (c) the token strings, back to back.  Every (token, character) pair of the tile is one independent load + store (a loop
+    // over the wave's tokens with lane = character waits for each row in turn: 64 dependent round trips, 38 us of this kernel)
+    __shared__ uint32_t s_off[1024];
+    __shared__ uint8_t s_len[1024];
+    s_off[threadIdx.x] = ex[4]; s_len[threadIdx.x] = (uint8_t)v[4];
+    __syncthreads();
     char *tok_chars = reinterpret_cast<char *>(blob + T.lay.tok_chars);
-    const uint32_t t0 = t - (uint32_t)lane;
-    uint64_t todo = __ballot(t < n);
-    while (todo) {
-        const int l = __ffsll((unsigned long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t len_l = (uint32_t)__shfl((int)v[4], l), off_l = (uint32_t)__shfl((int)ex[4], l);
-        if ((uint32_t)lane < len_l) tok_chars[off_l + lane] = M.dx_chars[(uint64_t)(t0 + l) * M.stride + lane];
+    const uint32_t stride = M.stride, cpr = stride >> 3;      // 8-byte chunks per row (the stride is a multiple of 16)
+    for (uint32_t q = threadIdx.x; q < 1024u * cpr; q += 1024u) {
+        const uint32_t tk = q / cpr, c8 = (q - tk * cpr) * 8u, len = s_len[tk];
+        if (c8 >= len) continue;
+        const uint2 w = *reinterpret_cast<const uint2 *>(M.dx_chars + (uint64_t)(tile * 1024u + tk) * stride + c8);
+        char *dst = tok_chars + s_off[tk] + c8;
+        const uint32_t nb = min(8u, len - c8);
+#pragma unroll
+        for (uint32_t b = 0; b < 8; b++) if (b < nb) dst[b] = (char)(((b < 4 ? w.x : w.y) >> (8u * (b & 3u))) & 0xFFu);
     }
 }
 
-__global__ __launch_bounds__(256) void k_dmx_place(DevMerge M)
+__global__ __launch_bounds__(DMX_BLOCK) void k_dmx_place(DevMerge M)
 {
     if (!M.x_tot->ok) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t hkey[DMX_SLOTS], hcnt[DMX_SLOTS], hbase[DMX_SLOTS];
+    for (uint32_t i = threadIdx.x; i < DMX_SLOTS; i += DMX_BLOCK) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0u; }
+    __syncthreads();
+    const uint32_t t = blockIdx.x * DMX_BLOCK + threadIdx.x;
     const bool act = t < M.x_tot->n_tok;
-    const uint32_t r = act ? M.root_of[t] : 0u;
-    uint32_t slot = 0;
-    uint64_t todo = __ballot(act);
-    while (todo) {                                      // one returning atomic per distinct root among the wave's tokens
-        const int l = __ffsll((unsigned long long)todo) - 1;
-        const uint32_t r0 = (uint32_t)__shfl((int)r, l);
-        const bool mine = act && r == r0;
-        const uint64_t peers = __ballot(mine);
-        uint32_t base = 0;
-        if (lane == l) base = atomicAdd(&M.x_fill[r0], (uint32_t)__popcll(peers));
-        base = (uint32_t)__shfl((int)base, l);
-        if (mine) slot = base + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-        todo &= ~peers;
+    uint32_t r = 0, slot = 0, local = 0;
+    if (act) {
+        r = M.root_of[t];
+        slot = dmx_claim(hkey, r);
+        local = atomicAdd(&hcnt[slot], 1u);             // rank among the block's members of the group (any order)
     }
-    if (act) M.x_members[M.x_goff[r] + slot] = ((uint32_t)(M.blank[t] ? 1u : 0u) << 27) | ((uint32_t)M.dx_len[t] << 20) | t;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < DMX_SLOTS; i += DMX_BLOCK)
+        if (hkey[i] != 0xFFFFFFFFu) hbase[i] = atomicAdd(&M.x_fill[hkey[i]], hcnt[i]);      // one returning atomic per root and block
+    __syncthreads();
+    if (act) M.x_members[M.x_goff[r] + hbase[slot] + local] = ((uint32_t)(M.blank[t] ? 1u : 0u) << 27) | ((uint32_t)M.dx_len[t] << 20) | t;
 }
 
 static __device__ __forceinline__ char dmx_comp(char c)                // SeqUtils.cpp:50-59 over the device merge's alphabet
@@ -735,57 +751,88 @@ static __device__ __forceinline__ char dmx_comp(char c)                // SeqUti
     return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
 }
 
-__global__ __launch_bounds__(256) void k_dmx_rank(DevMerge M)
+// The member lists lie in GID order, so 64 consecutive entries belong to a run of consecutive groups whose lists are one
+// contiguous range [lo, hi).  A block takes 64 entries (lane = entry, the same in each of its 16 waves) and its waves share the
+// range 64 keys at a time: one coalesced load, then every key goes to all lanes through an SGPR (v_readlane) and each lane
+// counts it if it lies in its own group's part of the range; the 16 partial counts per entry meet in LDS.
+// (Measured on the way, 42 k tokens in groups of up to 1 800: a wave per 64 entries walking the whole range alone — 650 waves,
+// one per SIMD, nothing to hide the dependent adds behind — 260 us; a tile of the range in LDS read by all lanes at once 78 us
+// with 32-bit reads, 133 us with 128-bit ones (no broadcast), and the LDS it held kept pass 2's probe kernel, which stages its
+// table there, off the CUs: 144 -> 243 us.)
+#define DMX_RW 16                                    // waves per block
+__global__ __launch_bounds__(64 * DMX_RW) void k_dmx_rank(DevMerge M)
 {
     const DevViewTotals T = *M.x_tot;
-    if (!T.ok) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!T.ok || blockIdx.x * 64u >= T.n_tok) return;
+    __shared__ uint32_t acc[DMX_RW][3][64];
+    __shared__ uint32_t p_t[64], p_f[64], p_r[64];
+    __shared__ uint8_t p_len[64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 64u + (uint32_t)lane;
     const bool act = i < T.n_tok;
     uint8_t *blob = M.x_blob;
-    uint32_t t = 0, len = 0, dst_f = 0, dst_r = 0;
-    bool kept = false;
+    uint32_t key = 0, t = 0, g0 = 0, gs = 0, r = 0;
     if (act) {
-        const uint32_t key = M.x_members[i];
-        t = key & 0xFFFFFu; len = (key >> 20) & 0x7Fu; kept = (key >> 27) == 0u;
-        const uint32_t r = M.root_of[t], g0 = M.x_goff[r], s = M.x_size[r];
-        uint32_t ra = 0, rp = 0, cp = 0;
-        const uint32_t *mem = M.x_members + g0;
-#pragma unroll 4
-        for (uint32_t j = 0; j < s; j++) {
-            const uint32_t k2 = mem[j];
-            ra += (k2 & 0xFFFFFu) < t ? 1u : 0u;
-            const bool lt = k2 < key;                   // (a survivor's key is only preceded by survivors' keys: blank is the top bit)
+        key = M.x_members[i];
+        t = key & 0xFFFFFu;
+        r = M.root_of[t]; g0 = M.x_goff[r]; gs = M.x_size[r];
+    }
+    const uint64_t am = __ballot(act);                  // (never 0: the block's first entry exists)
+    const int first = __ffsll((unsigned long long)am) - 1, lastl = 63 - __clzll((unsigned long long)am);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)g0, first);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(g0 + gs), lastl);
+    uint32_t ra = 0, rp = 0, cp = 0;
+    for (uint32_t base = lo + 64u * (uint32_t)w; base < hi; base += 64u * DMX_RW) {
+        const uint32_t cur = base + (uint32_t)lane < hi ? M.x_members[base + lane] : 0u;
+        const uint32_t cnt = min(hi - base, 64u);
+        const uint32_t rel = base - g0;                 // per lane: key q of this chunk is member (rel + q) of the lane's group iff < gs
+        for (uint32_t q = 0; q < cnt; q++) {
+            const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)q);
+            const bool in = rel + q < gs;               // (unsigned: also false for keys in front of the lane's group)
+            ra += (in && (k2 & 0xFFFFFu) < t) ? 1u : 0u;
+            const bool lt = in && k2 < key;             // (a survivor's key is only preceded by survivors' keys: blank is the top bit)
             rp += lt ? 1u : 0u;
             cp += lt ? ((k2 >> 20) & 0x7Fu) : 0u;
         }
+    }
+    acc[w][0][lane] = ra; acc[w][1][lane] = rp; acc[w][2][lane] = cp;
+    if (w == 0) p_len[lane] = 0;
+    __syncthreads();
+    if (w == 0 && act) {
+        ra = rp = cp = 0;
+#pragma unroll
+        for (int k = 0; k < DMX_RW; k++) { ra += acc[k][0][lane]; rp += acc[k][1][lane]; cp += acc[k][2][lane]; }
         reinterpret_cast<uint32_t *>(blob + T.lay.grp_tokens)[g0 + ra] = t + 2u;
-        if (kept) {
+        if ((key >> 27) == 0u) {                        // a survivor: pattern p of its group, and p + (survivors of the group) = its reverse complement
             const uint32_t kg = M.x_kept[r], p = M.x_pat0[r] + rp, gid1 = M.x_gid[r] + 1u;
-            dst_f = M.x_pch0[r] + cp; dst_r = dst_f + M.x_kchars[r];
+            const uint32_t dst_f = M.x_pch0[r] + cp, dst_r = dst_f + M.x_kchars[r];
             uint64_t *pat_off = reinterpret_cast<uint64_t *>(blob + T.lay.pat_off);
             uint32_t *pat_group = reinterpret_cast<uint32_t *>(blob + T.lay.pat_group);
             pat_off[p] = dst_f; pat_off[p + kg] = dst_r;
             pat_group[p] = gid1; pat_group[p + kg] = gid1;
+            p_t[lane] = t; p_f[lane] = dst_f; p_r[lane] = dst_r; p_len[lane] = (uint8_t)((key >> 20) & 0x7Fu);
         }
     }
-    // the pattern strings: every survivor and its reverse complement, lane = character
+    __syncthreads();
+    // the pattern strings: every survivor and its reverse complement, 8 characters per thread
     char *pat_chars = reinterpret_cast<char *>(blob + T.lay.pat_chars);
-    uint64_t todo = __ballot(kept);
-    while (todo) {
-        const int l = __ffsll((unsigned long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t t_l = (uint32_t)__shfl((int)t, l), len_l = (uint32_t)__shfl((int)len, l);
-        const uint32_t f_l = (uint32_t)__shfl((int)dst_f, l), r_l = (uint32_t)__shfl((int)dst_r, l);
-        if ((uint32_t)lane < len_l) {
-            const char ch = M.dx_chars[(uint64_t)t_l * M.stride + lane];
-            pat_chars[f_l + lane] = ch;
-            pat_chars[r_l + (len_l - 1u - (uint32_t)lane)] = dmx_comp(ch);
-        }
+    const uint32_t stride = M.stride, cpr = stride >> 3;
+    for (uint32_t q = threadIdx.x; q < 64u * cpr; q += 64u * DMX_RW) {
+        const uint32_t e = q / cpr, c8 = (q - e * cpr) * 8u, len = p_len[e];
+        if (c8 >= len) continue;
+        const uint2 wd = *reinterpret_cast<const uint2 *>(M.dx_chars + (uint64_t)p_t[e] * stride + c8);
+        char *df = pat_chars + p_f[e] + c8, *dr = pat_chars + p_r[e] + (len - 1u - c8);
+        const uint32_t nb = min(8u, len - c8);
+#pragma unroll
+        for (uint32_t b2 = 0; b2 < 8; b2++)
+            if (b2 < nb) {
+                const char c = (char)(((b2 < 4 ? wd.x : wd.y) >> (8u * (b2 & 3u))) & 0xFFu);
+                df[b2] = c;
+                *(dr - b2) = dmx_comp(c);
+            }
     }
-    if (i == 0) *M.x_htot = T;                          // (any thread: the host only reads the blob after the stream's event)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *M.x_htot = T;      // (the host only reads the blob after the stream's event)
 }
-
 
 // ---- one-collective exchange ----
 __global__ __launch_bounds__(256) void k_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride,
@@ -871,11 +918,11 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done
         if (e == hipSuccess) e = hipStreamWaitEvent(view_st, ev_fork, 0);
         if (e != hipSuccess) return e;
         const unsigned nt = (M.n_tok + 1023) / 1024;
-        CRASS_LAUNCH(k_dmx_count, dim3(nb), dim3(256), 0, view_st, M);
+        CRASS_LAUNCH(k_dmx_count, dim3(nt), dim3(DMX_BLOCK), 0, view_st, M);
         CRASS_LAUNCH(k_dmx_tiles, dim3(nt), dim3(1024), 0, view_st, M);
         CRASS_LAUNCH(k_dmx_apply, dim3(nt), dim3(1024), 0, view_st, M);
-        CRASS_LAUNCH(k_dmx_place, dim3(nb), dim3(256), 0, view_st, M);
-        CRASS_LAUNCH(k_dmx_rank, dim3(nb), dim3(256), 0, view_st, M);
+        CRASS_LAUNCH(k_dmx_place, dim3(nt), dim3(DMX_BLOCK), 0, view_st, M);
+        CRASS_LAUNCH(k_dmx_rank, dim3((M.n_tok + 63) / 64), dim3(64 * DMX_RW), 0, view_st, M);
         e = hipEventRecord(ev_view, view_st);
         if (e != hipSuccess) return e;
     }

@@ -359,6 +359,7 @@ struct crass_hip_ctx {
         PinBuf<DevViewTotals> x_htot; PinBuf<uint8_t> h_view;
         hipStream_t view_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_view = nullptr;
         SdmaCopy *dma_view = nullptr;
+        bool hx_on_host = true;                     // the gathered distinct list has a pinned host copy (else: on the device only)
         bool view_launched = false;                 // export kernels may be running on view_stream (ev_view orders after them)
         bool view_ready = false;                    // h_view holds the view of the current merge (crass_hip_get_merge reads it)
         DevViewTotals view_tot{};
@@ -1657,7 +1658,12 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
     M.x_on = (!c->env.no_device_view && !c->host_view_light && n <= (1u << 20)) ? 1u : 0u;
     if (M.x_on) {
         if (!d.view_stream) {
-            HIPCHK(c, hipStreamCreateWithFlags(&d.view_stream, hipStreamNonBlocking));
+            // lowest priority: the export fills whatever the merge's own kernels and pass 2's probe leave idle (at equal priority
+            // its 1 024-thread blocks kept the probe kernel's blocks off the CUs: 144 -> 216 us for an eighth of the 100 M reads)
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            static const bool view_same_prio = getenv("CRASS_VIEW_SAME_PRIORITY") != nullptr;      // A/B switch
+            HIPCHK(c, hipStreamCreateWithPriority(&d.view_stream, hipStreamNonBlocking, view_same_prio ? 0 : prio_lo));
             HIPCHK(c, hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&d.ev_view, hipEventDisableTiming));
             d.dma_view = sdma_create();                 // (nullptr: the runtime's copy is used)
@@ -1691,7 +1697,8 @@ static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const ui
     const double tl0 = now_ms();
     if (d.view_launched) HIPCHK(c, hipStreamWaitEvent(c->stream, d.ev_view, 0));     // (an abandoned merge's export still owns the x_* words)
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
-    HIPCHK(c, launch_device_merge(d.M, c->stream, prepared, d.M.x_on ? d.view_stream : nullptr, d.ev_fork, d.ev_view));
+    static const bool view_inline = getenv("CRASS_VIEW_INLINE") != nullptr;      // A/B switch: the export on the merge's own stream
+    HIPCHK(c, launch_device_merge(d.M, c->stream, prepared, d.M.x_on ? (view_inline ? c->stream : d.view_stream) : nullptr, d.ev_fork, d.ev_view));
     d.view_launched = d.M.x_on != 0;
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
     if (c->env.merge_profile)
@@ -1888,12 +1895,25 @@ static int build_host_merge(crass_hip_ctx *c)
         // (a group beyond x_group_cap, or totals that do not add up: the host builds the view from the per-token results)
         c->n_view_fallbacks++;
     }
+    if (d.global && !d.hx_on_host) {                    // the gathered list stayed on the device: fetch it now
+        hipError_t e = hipMemcpyAsync(d.h_gx_chars.p, d.gx_chars.p, d.n_tok * (size_t)c->dr_stride, hipMemcpyDeviceToHost, d.view_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d.h_gx_len.p, d.gx_len.p, d.n_tok * 2, hipMemcpyDeviceToHost, d.view_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d.view_stream);
+        if (e != hipSuccess) { d.br.hip = (int)e; return CRASS_ERR_HIP; }
+        d.hx_on_host = true;
+    }
     if (!merge_from_device_begin(c->merge, d.hx_chars, d.hx_len, c->dr_stride, d.n_tok, cmap, d.n_cand)) return CRASS_ERR_STATE;
     host_pool_warm();                                   // the second half fans out over the pool: wake it while the device is busy
     const double tb0 = now_ms();
     if (const int ws = wait_done()) return ws;
     const double tb1 = now_ms();
     if (d.h_st.p->fail) return CRASS_ERR_STATE;
+    if (d.M.x_on) {                                     // (k_dm_fill_finish left the per-token results on the device)
+        hipError_t e = hipMemcpyAsync(d.h_root.p, d.root_of.p, d.n_tok * 4, hipMemcpyDeviceToHost, d.view_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d.h_blank.p, d.blank.p, d.n_tok, hipMemcpyDeviceToHost, d.view_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d.view_stream);
+        if (e != hipSuccess) { d.br.hip = (int)e; return CRASS_ERR_HIP; }
+    }
     if (!merge_from_device_finish_roots(c->merge, d.h_root.p, d.h_blank.p, d.gid_tmp) ||
         c->merge.patterns.size() != d.h_st.p->n_patterns)
         return CRASS_ERR_STATE;
@@ -2074,7 +2094,7 @@ static int merge_global_device(crass_hip_ctx *c, uint64_t n_global, uint64_t my_
     HIPCHK(c, hipMemcpyAsync(c->h_count.p + 4, c->d_count.p + 4, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->h_count.p[5] != 0 || c->h_count.p[4] == 0 || c->h_count.p[4] > (1u << 20)) return CRASS_ERR_STATE;
-    d.global = true; d.my_off = my_offset; d.n_global = n_global;
+    d.global = true; d.my_off = my_offset; d.n_global = n_global; d.hx_on_host = true;
     return device_merge(c, d.gx_chars.p, d.gx_len.p, c->h_count.p[4], d.h_gx_chars.p, d.h_gx_len.p);
 }
 
@@ -2189,8 +2209,12 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
         HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, X.xinfo.p, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p, d.g_rep.p,
                                    c->stream));
         Lookback lbg;
+        // the global list's pinned copy is only read by the host-built view (3.7 MB of PCIe stores from the gather kernel at
+        // 42 k tokens: 53 us); with the view exported by the device, or a light view, it stays on the device (fetch_host_list)
+        d.hx_on_host = c->env.no_device_view && !c->host_view_light;
         HIPCHK(c, launch_dx_tokens(d.g_chars.p, d.g_len.p, d.g_hash.p, stride, X.xinfo.p, n, d.g_rep.p, d.g_slot.p, d.g_first.p, d.g_mask.p, d.g_prefix.p, d.g_bsum.p,
-                                   d.g_idx.p, c->d_count.p + 4, c->d_count.p + 5, d.h_gmap.p, d.h_gx_chars.p, d.h_gx_len.p, d.h_gx_hash.p,
+                                   d.g_idx.p, c->d_count.p + 4, c->d_count.p + 5, d.h_gmap.p, d.hx_on_host ? d.h_gx_chars.p : nullptr,
+                                   d.hx_on_host ? d.h_gx_len.p : nullptr, d.hx_on_host ? d.h_gx_hash.p : nullptr,
                                    d.gx_chars.p, d.gx_len.p, c->stream,
                                    c->d_count.p, c->h_count.p, 8, c->next_lookback_tiles(((uint64_t)n + 1023) / 1024, &lbg)));   // counters leave with the last kernel
     }

@@ -2378,11 +2378,12 @@ __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const
     const uint4 *src = reinterpret_cast<const uint4 *>(dr + k * stride);
     uint4 *dst = reinterpret_cast<uint4 *>(out_chars + (uint64_t)j * stride);
     uint4 *dst2 = reinterpret_cast<uint4 *>(dev_chars + (uint64_t)j * stride);      // device copy for the device merge
-    for (uint32_t i = 0; i < stride / 16; i++) { const uint4 v = src[i]; dst[i] = v; if (dev_chars) dst2[i] = v; }
+    // (out_*: pinned host memory, or nullptr when nobody on the host reads the list — the device merge exports its own view)
+    for (uint32_t i = 0; i < stride / 16; i++) { const uint4 v = src[i]; if (out_chars) dst[i] = v; if (dev_chars) dst2[i] = v; }
     const uint16_t l = dr_len[k];
-    out_len[j] = l;
+    if (out_len) out_len[j] = l;
     if (dev_len) dev_len[j] = l;
-    out_hash[j] = hash[k];
+    if (out_hash) out_hash[j] = hash[k];
 }
 
 // k_dx_flag + compaction in one pass (decoupled look-back over tiles of 1024 candidates, one per thread: the body is a
@@ -2438,11 +2439,12 @@ __global__ __launch_bounds__(256) void k_dx_assign_gather(const uint32_t *rep, c
     const uint4 *src = reinterpret_cast<const uint4 *>(dr + k * stride);
     uint4 *dst = reinterpret_cast<uint4 *>(out_chars + (uint64_t)j * stride);
     uint4 *dst2 = reinterpret_cast<uint4 *>(dev_chars + (uint64_t)j * stride);      // device copy for the device merge
-    for (uint32_t i = 0; i < stride / 16; i++) { const uint4 v = src[i]; dst[i] = v; if (dev_chars) dst2[i] = v; }
+    // (out_*: pinned host memory, or nullptr when nobody on the host reads the list — the device merge exports its own view)
+    for (uint32_t i = 0; i < stride / 16; i++) { const uint4 v = src[i]; if (out_chars) dst[i] = v; if (dev_chars) dst2[i] = v; }
     const uint16_t l = dr_len[k];
-    out_len[j] = l;
+    if (out_len) out_len[j] = l;
     if (dev_len) dev_len[j] = l;
-    out_hash[j] = hash[k];
+    if (out_hash) out_hash[j] = hash[k];
 }
 
 // needs stride % 16 == 0; mask / word_prefix / block_sums / dx_idx are scratch of >= n bits / words.  The candidate
