@@ -29,7 +29,7 @@ inline bool trace_launches()
 }
 
 struct GuardedAllocs {
-    struct Rec { char *base; size_t reserved, mapped; hipMemGenericAllocationHandle_t h; };
+    struct Rec { char *base; size_t reserved, mapped; hipMemGenericAllocationHandle_t h; int device; };
     std::mutex mu;
     std::unordered_map<void *, Rec> live;
     static GuardedAllocs &get() { static GuardedAllocs g; return g; }
@@ -51,7 +51,7 @@ struct GuardedAllocs {
         static const size_t align = [] { const char *v = getenv("CRASS_GUARD_ALIGN"); const size_t a = v ? (size_t)atol(v) : 16; return a && !(a & (a - 1)) ? a : 16; }();
         const size_t want = (bytes + align - 1) & ~(align - 1);
         const size_t mapped = (want + gran - 1) / gran * gran;
-        Rec r{nullptr, mapped + 2 * gran, mapped, {}};
+        Rec r{nullptr, mapped + 2 * gran, mapped, {}, dev};
         void *va = nullptr;
         e = hipMemAddressReserve(&va, r.reserved, gran, nullptr, 0);
         if (e != hipSuccess) return e;
@@ -83,10 +83,15 @@ struct GuardedAllocs {
             r = it->second;
             live.erase(it);
         }
+        // on the ALLOCATION's device (a group frees buffers of several devices from one thread), restoring the caller's
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != r.device) (void)hipSetDevice(r.device);
         (void)hipDeviceSynchronize();
         const size_t gran = (r.reserved - r.mapped) / 2;
         (void)hipMemUnmap(r.base + gran, r.mapped);
         (void)hipMemRelease(r.h);
+        if (cur >= 0 && cur != r.device) (void)hipSetDevice(cur);
         // the address range stays reserved for the life of the process: no later buffer can land on it, so a kernel that
         // still holds the freed pointer faults instead of reading a stranger's data
         return true;

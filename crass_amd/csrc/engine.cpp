@@ -1024,10 +1024,26 @@ static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const ui
 
 // every buffer the dense pass-1 sink touches for up to n_alloc survivors (crass_hip_load_reads sizes them for the first
 // call's bound, so that the first seed scan of a context does not allocate; ensure() is a no-op when a buffer is large enough)
+// The mask / prefix / block-sum scratch is sized for the READ count at load; the three-kernel compactions over survivor and
+// hit SLOTS (CRASS_NO_LOOKBACK, or after a look-back give-up) write (bound + 63) / 64 words of it, and a slot bound is not
+// bounded by the read count (70 000 reads with 50 000 survivors: bound 131 072 = 2 048 words into 1 095).  Whoever sizes
+// slot buffers for a bound grows the scratch with them.  (Its contents are dead between stages: a stage's mask is consumed by
+// the compaction queued right behind it, and the release inside ensure() waits for the device.)
+static int ensure_mask_scratch(crass_hip_ctx *c, uint64_t n_bits)
+{
+    const uint64_t n_words = (n_bits + 63) / 64;
+    if (c->d_mask.n >= n_words + 1 && c->d_word_prefix.n >= n_words + 1 && c->d_block_sums.n >= (n_words + 255) / 256 + 2) return CRASS_OK;
+    HIPCHK(c, c->d_mask.ensure(n_words + 1));
+    HIPCHK(c, c->d_word_prefix.ensure(n_words + 1));
+    HIPCHK(c, c->d_block_sums.ensure((n_words + 255) / 256 + 2));
+    return CRASS_OK;
+}
+
 static int ensure_dense_buffers(crass_hip_ctx *c, uint64_t n_alloc, uint64_t pool_cap, const SurvLds &lds, bool dedupe)
 {
     crass_hip_ctx::P1Dense &D = c->dense;
     const uint32_t stride = c->dr_stride;
+    { const int ms = ensure_mask_scratch(c, n_alloc); if (ms) return ms; }
     HIPCHK(c, c->d_surv.ensure(n_alloc));
     HIPCHK(c, c->d_dr.ensure(n_alloc * stride));
     HIPCHK(c, c->d_ss_pool.ensure(std::max<uint64_t>(pool_cap, n_alloc * (uint64_t)lds.ss_cap)));
@@ -1222,6 +1238,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
 static int ensure_recruit_buffers(crass_hip_ctx *c, uint64_t h_alloc, uint64_t n_exc, bool dev_sink, bool anchors)
 {
     const uint64_t s_alloc = h_alloc + n_exc;
+    { const int ms = ensure_mask_scratch(c, h_alloc); if (ms) return ms; }
     HIPCHK(c, c->d_rec.ensure(s_alloc + 1));
     HIPCHK(c, c->d_dr.ensure((s_alloc + 1) * c->dr_stride));
     if (!dev_sink) {                           // host sink only

@@ -714,6 +714,9 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
     *res = nullptr;
     if (in->n_groups && (!in->gid || !in->dr_chars || !in->dr_off || !in->grp_rec_off)) return CRASS_ERR_INVALID_ARG;
     if (in->n_rec && (!in->hdr_chars || !in->hdr_off || !in->seq_chars || !in->seq_off || !in->rec_nss || !in->rec_ss_off || !in->ss_pool)) return CRASS_ERR_INVALID_ARG;
+    if (in->n_rec && in->com_chars && !in->com_off) return CRASS_ERR_INVALID_ARG;       // comments given without their offsets
+    // (contract, include/crass_hip.h: ss_pool holds rec_ss_off[k] + rec_nss[k] entries for every record k — the pool's length is not
+    // part of the ABI, so it cannot be checked here; start/stop VALUES are checked against the read's length where they are used)
     std::unique_ptr<crass_outputs> R(new crass_outputs());
     const bool timing = getenv("CRASS_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -17,12 +17,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -44,13 +46,29 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // thread-safe and idempotent: groups may be created from several threads.  CRASS_RCCL_LIB names the library to bind
+    // instead (tests: a name that does not exist must end in CRASS_ERR_RCCL, not in a crash)
     bool load()
     {
+        std::lock_guard<std::mutex> lk(mu);
         if (lib) return true;
+        const char *forced = getenv("CRASS_RCCL_LIB");
         const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-        for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
-        if (!lib) { set_error(std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen(librccl.so.1) failed")); return false; }
-        auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) set_error(std::string("RCCL symbol missing: ") + n); return p; };
+        std::string why;
+        if (forced && *forced) {
+            lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) { const char *e = dlerror(); why = e ? e : "dlopen failed"; }      // (dlerror() clears the state: read it ONCE)
+        } else {
+            for (const char *n : names) {
+                lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (lib) break;
+                const char *e = dlerror();
+                if (why.empty()) why = e ? e : "dlopen(librccl.so.1) failed";
+            }
+        }
+        if (!lib) { set_error("RCCL not found: " + why); return false; }
+        bool missing = false;
+        auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) { set_error(std::string("RCCL symbol missing: ") + n); missing = true; } return p; };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
         CommCount = (decltype(CommCount))sym("ncclCommCount");
@@ -58,13 +76,15 @@ struct Rccl {
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        if (!(CommInitAll && CommDestroy && CommCount && AllGather && GroupStart && GroupEnd && GetErrorString)) { dlclose(lib); lib = nullptr; return false; }
+        if (missing) { dlclose(lib); lib = nullptr; return false; }
         return true;
     }
+    std::mutex mu;
 };
 Rccl g_rccl;
 
-// sense-reversing barrier; waiters spin briefly, then yield (the ranks of a step arrive within microseconds of each other)
+// sense-reversing barrier; waiters spin briefly (the ranks of a step normally arrive within microseconds of each other), then
+// sleep on a condition variable: N - 1 cores at 100 % for as long as the slowest shard takes are not ours to burn
 class Barrier {
 public:
     explicit Barrier(int n) : n_(n) {}
@@ -73,15 +93,22 @@ public:
         const int gen = gen_.load(std::memory_order_acquire);
         if (count_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
             count_.store(0, std::memory_order_relaxed);
-            gen_.store(gen + 1, std::memory_order_release);
+            { std::lock_guard<std::mutex> lk(m_); gen_.store(gen + 1, std::memory_order_release); }
+            cv_.notify_all();
             return;
         }
-        for (unsigned spin = 0; gen_.load(std::memory_order_acquire) == gen; spin++)
+        for (unsigned spin = 0; spin < 20000; spin++) {
+            if (gen_.load(std::memory_order_acquire) != gen) return;
             if (spin > 2000) std::this_thread::yield();
+        }
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != gen; });
     }
 private:
     const int n_;
     std::atomic<int> count_{0}, gen_{0};
+    std::mutex m_;
+    std::condition_variable cv_;
 };
 
 enum Phase : unsigned { PH_SEED = 1, PH_MERGE = 2, PH_RECRUIT = 4, PH_LOAD = 8 };
@@ -105,7 +132,7 @@ struct crass_hip_group {
     // helper threads (ranks 1 .. n-1); the caller's thread is rank 0
     std::vector<std::thread> threads;
     std::mutex mu;
-    std::condition_variable cv;
+    std::condition_variable cv, cv_done;
     uint64_t job_id = 0;
     unsigned job_phases = 0;
     bool quit = false;
@@ -248,24 +275,28 @@ void run_rank(crass_hip_group *g, int r, unsigned phases)
         }
         if (g->have_dups) {
             g->bar->wait();
-            if (r == 0 && ok()) collect_extra(g);
+            if (r == 0 && ok()) { try { collect_extra(g); } catch (const std::bad_alloc &) { note(g, 0, CRASS_ERR_OOM); } }
             g->bar->wait();
         }
     }
     if ((phases & PH_RECRUIT) && ok()) {
         std::vector<uint64_t> &e = g->extra[r];
         const std::vector<uint64_t> &u = g->extra_user[r];
-        if (!u.empty()) {                                           // (this call's; extra[r] is rebuilt by the next merge)
-            std::vector<uint64_t> both(e);
-            both.insert(both.end(), u.begin(), u.end());
-            note(g, r, crass_hip_recruit(c, both.data(), both.size()));
-        } else note(g, r, crass_hip_recruit(c, e.empty() ? nullptr : e.data(), e.size()));
+        // (no barrier behind this point: an allocation failure here only ends this rank's part)
+        try {
+            if (!u.empty()) {                                       // (this call's; extra[r] is rebuilt by the next merge)
+                std::vector<uint64_t> both(e);
+                both.insert(both.end(), u.begin(), u.end());
+                note(g, r, crass_hip_recruit(c, both.data(), both.size()));
+            } else note(g, r, crass_hip_recruit(c, e.empty() ? nullptr : e.data(), e.size()));
+        } catch (const std::bad_alloc &) { note(g, r, CRASS_ERR_OOM); }
     }
 }
 
 void helper_loop(crass_hip_group *g, int r)
 {
     uint64_t seen = 0;
+    (void)hipSetDevice(g->devices[r]);                  // this thread's current device (every context call sets it again)
     for (;;) {
         unsigned phases;
         {
@@ -276,6 +307,8 @@ void helper_loop(crass_hip_group *g, int r)
         }
         run_rank(g, r, phases);
         g->done.fetch_add(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(g->mu); }      // (the waiter is either before its check or asleep: no lost wake-up)
+        g->cv_done.notify_one();
     }
 }
 
@@ -289,8 +322,12 @@ int dispatch(crass_hip_group *g, unsigned phases)
         g->cv.notify_all();
     }
     run_rank(g, 0, phases);
-    for (unsigned spin = 0; g->done.load(std::memory_order_acquire) != g->n - 1; spin++)
-        if (spin > 2000) std::this_thread::yield();
+    for (unsigned spin = 0; g->done.load(std::memory_order_acquire) != g->n - 1; spin++) {
+        if (spin > 20000) {                             // (rank 0 finished well ahead of the others: sleep until the last one reports)
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_done.wait_for(lk, std::chrono::milliseconds(2), [&] { return g->done.load(std::memory_order_acquire) == g->n - 1; });
+        } else if (spin > 2000) std::this_thread::yield();
+    }
     for (int r = 0; r < g->n; r++) if (g->status[r]) return g->status[r];
     return CRASS_OK;
 }
@@ -316,6 +353,7 @@ int crass_hip_group_create(const crass_params *p, const int *devices, int n, uns
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (devices[i] == devices[j]) dup = true;
     const bool local = (flags & CRASS_GROUP_LOCAL_COPIES) != 0;
     if (dup && !local) { set_error("a device is listed twice: RCCL needs one rank per device (CRASS_GROUP_LOCAL_COPIES for tests)"); return CRASS_ERR_INVALID_ARG; }
+    if (!local && !g_rccl.load()) return CRASS_ERR_RCCL;            // (before any context: no RCCL, no group — text in crass_hip_group_last_error)
     crass_hip_group *g = new (std::nothrow) crass_hip_group();
     if (!g) return CRASS_ERR_OOM;
     g->n = n; g->devices.assign(devices, devices + n); g->local_copies = local;
@@ -328,7 +366,6 @@ int crass_hip_group_create(const crass_params *p, const int *devices, int n, uns
         if (r > 0) (void)crass_hip_set_host_view(g->ctx[r], 1);       // ONE host view for the group: rank 0's
     }
     if (!local) {
-        if (!g_rccl.load()) { crass_hip_group_destroy(g); return CRASS_ERR_RCCL; }
         g->comms.assign(n, nullptr);
         const ncclResult_t e = g_rccl.CommInitAll(g->comms.data(), n, devices);
         if (e != ncclSuccess) { g->comms.clear(); crass_hip_group_destroy(g); return rccl_fail("ncclCommInitAll", e); }

@@ -40,8 +40,11 @@ Hsa &hsa()
     std::call_once(once, [] {
         if (getenv("CRASS_NO_SDMA")) return;                       // A/B switch
         h.lib = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h.lib) return;
-#define SYM(field, name) h.field = reinterpret_cast<decltype(h.field)>(dlsym(h.lib, #name)); if (!h.field) return;
+        if (!h.lib) { fprintf(stderr, "[crass_sdma] libhsa-runtime64.so.1 not loadable: hand-off copies use the copy kernel\n"); return; }
+        // (tested with ROCm 7.2.0 / HSA runtime 1.18: a release that drops or renames one of these says so once and the copy
+        // kernel takes over — INTEGRATION.md, "DMA engine")
+#define SYM(field, name) h.field = reinterpret_cast<decltype(h.field)>(dlsym(h.lib, #name)); \
+        if (!h.field) { fprintf(stderr, "[crass_sdma] %s missing in the HSA runtime: hand-off copies use the copy kernel\n", #name); return; }
         SYM(init, hsa_init) SYM(signal_create, hsa_signal_create) SYM(signal_destroy, hsa_signal_destroy)
         SYM(signal_store, hsa_signal_store_relaxed) SYM(signal_wait, hsa_signal_wait_scacquire)
         SYM(pointer_info, hsa_amd_pointer_info) SYM(async_copy, hsa_amd_memory_async_copy)
@@ -100,7 +103,11 @@ bool sdma_start(SdmaCopy *s, const void *d_src, void *h_dst, size_t bytes)
                      di.agentBaseAddress, di.sizeInBytes, bytes);
     // plain runtime allocations only: a range mapped with the virtual-memory API (CRASS_GUARD_PAGES, devmem.h) comes back as a
     // reserved address, and the copy call crashes on it
-    if (si.type != HSA_EXT_POINTER_TYPE_HSA || (di.type != HSA_EXT_POINTER_TYPE_HSA && di.type != HSA_EXT_POINTER_TYPE_LOCKED)) return false;
+    if (si.type != HSA_EXT_POINTER_TYPE_HSA || (di.type != HSA_EXT_POINTER_TYPE_HSA && di.type != HSA_EXT_POINTER_TYPE_LOCKED)) {
+        static bool told = false;
+        if (!told && getenv("CRASS_GUARD_PAGES") == nullptr) { told = true; fprintf(stderr, "[crass_sdma] buffers not owned by the HSA runtime (types %d / %d): copies use the copy kernel\n", (int)si.type, (int)di.type); }
+        return false;
+    }
     h.signal_store(s->sig, 1);
     if (h.async_copy(h_dst, di.agentOwner, d_src, si.agentOwner, bytes, 0, nullptr, s->sig) != HSA_STATUS_SUCCESS) return false;
     s->pending = true;
@@ -113,10 +120,17 @@ int sdma_wait(SdmaCopy *s)
 {
     if (!s || !s->pending) return 0;
     Hsa &h = hsa();
-    hsa_signal_value_t v;
-    do v = h.signal_wait(s->sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
-    while (v >= 1);
+    // bounded: a DMA engine that never signals must not hang seed_scan / recruit / destroy for ever.  The timeout is in
+    // units of the system timestamp counter (>= 1 MHz everywhere: 2^26 ticks are at most about a minute, usually under a second
+    // per slice); ten slices, then the engine counts as broken and the runtime copies the records instead.
+    hsa_signal_value_t v = 1;
+    for (int slice = 0; slice < 10 && v >= 1; slice++)
+        v = h.signal_wait(s->sig, HSA_SIGNAL_CONDITION_LT, 1, 1ull << 26, HSA_WAIT_STATE_BLOCKED);
     s->pending = false;
+    if (v >= 1) {
+        fprintf(stderr, "[crass_sdma] the DMA engine did not signal a %zu-byte copy; falling back to the runtime's copy for this context\n", s->bytes);
+        v = -1;
+    }
     if (v < 0) {
         // the engine reported an error: the records are copied again by the HIP runtime, and this context stays off the engines
         s->broken = true;

@@ -89,6 +89,28 @@ def test_group_argument_validation_needs_no_gpu(ca):
         assert lib.crass_hip_group_create(C.byref(p), devs, 2, 1, C.byref(h)) == 3
 
 
+def test_missing_rccl_is_an_error_code_not_a_crash(tmp_path):
+    """a group whose RCCL library cannot be loaded must come back with CRASS_ERR_RCCL and a text, before any device is
+    touched (the loader used to read dlerror() twice: the second read is NULL).  In a child process: the binding is per process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import crass_amd as ca\n"
+        "lib = ca.load(); p = ca.default_params(); h = C.c_void_p(); devs = (C.c_int * 2)(0, 1)\n"
+        "st = lib.crass_hip_group_create(C.byref(p), devs, 2, 0, C.byref(h))\n"
+        "print(st, lib.crass_hip_group_last_error().decode())\n"
+        "st2 = lib.crass_hip_group_create(C.byref(p), devs, 2, 0, C.byref(h))\n"
+        "print(st2)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, CRASS_RCCL_LIB=str(tmp_path / "no_such_librccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("10 RCCL not found:") and "no_such_librccl" in lines[0]
+    assert lines[1] == "10"
+
+
 def test_outputs_stage_argument_validation(ca):
     from crass_amd import _abi
     lib = ca.load()

@@ -377,3 +377,37 @@ def test_n_kmers_decide_group_membership(ca):
     assert got.counters["used_device_merge"] == 1
     assert sum(1 for t in ref.tokens if b"N" in t) >= 20
     assert_same_pipeline(got, ref)
+
+
+_SLOT_SCRATCH = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import crass_amd as ca
+from tests import orc
+from tests.parity import assert_same_pipeline
+from tests.test_gpu_parity import synth_reads
+ca.load()
+# 70 000 reads, most of them with a lattice seed hit: the survivor bound (1.5 x, rounded up to 65 536) is 131 072 slots, i.e.
+# 2 048 mask words where the scratch sized from the read count has 1 095
+seqs = synth_reads(ca, 70000, read_len=150, n_dr=30, crispr_per_million=900000)
+for rep in range(2):                                    # the second call speculates with the bound learnt from the first
+    gpu = ca.search_pipeline(seqs)
+    assert gpu.counters["n_filter_survivors"] > 46667, gpu.counters
+    assert_same_pipeline(gpu, orc.pipeline(seqs))
+with ca.SearchEngine() as eng:                          # ... and on one context, step after step
+    eng.load_reads(ca.PackedReads(seqs))
+    for _ in range(3):
+        eng.seed_scan(fetch=False); eng.merge(fetch=False); eng.recruit(fetch=False)
+    assert eng.counters()["n_pass1_found"] == gpu.n_pass1
+print("slot scratch ok")
+'''
+
+
+@pytest.mark.parametrize("env", [dict(CRASS_NO_LOOKBACK="1", CRASS_GUARD_PAGES="1"), dict(CRASS_NO_LOOKBACK="1")])
+def test_slot_compactions_fit_their_scratch(env):
+    """ADVICE r03: the three-kernel compactions (no look-back) over survivor / hit SLOTS write (bound + 63) / 64 mask words; the
+    scratch was sized from the READ count only.  In a child process, with every buffer between unmapped pages."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SLOT_SCRATCH], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and "slot scratch ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
