@@ -189,7 +189,17 @@ def main():
             print("bench.py: --launcher group shards ONE job (strong scaling); use --total-reads", file=sys.stderr)
             sys.exit(2)
         devs = [0] * n_gpus if args.local_copies else list(range(n_gpus))
-        eng = _GroupRunner(ca.SearchGroup(devs, local_copies=args.local_copies), n_gpus)
+        try:
+            grp = ca.SearchGroup(devs, local_copies=args.local_copies)
+        except ca.CrassError as ex:
+            # The group needs RCCL inside THIS process (ncclCommInitAll, one thread per device, peer access between the
+            # devices).  If it cannot be created the same job runs as one process per GPU over torch.distributed — in FRESH
+            # child processes (this one has initialised the GPU: it is never replaced by an exec); rank 0's line says so.
+            print("bench.py: group launcher unavailable (%s); running one process per GPU (torch.distributed) instead" % ex, file=sys.stderr)
+            del words
+            os.environ["CRASS_BENCH_FALLBACK"] = ("group launcher failed: %s" % ex)[:400]
+            spawn_ranks(args)                              # (exits with the children's status)
+        eng = _GroupRunner(grp, n_gpus)
         eng.g.load_packed_uniform(words, n, L, read_index_base=first)   # sharded by contiguous read ranges, H2D once
         scaling = "strong"
     else:
@@ -397,6 +407,8 @@ def main():
     }
     if rccl_ranks is not None:
         out["rccl_ranks"] = rccl_ranks
+    if os.environ.get("CRASS_BENCH_FALLBACK"):
+        out["launcher_fallback"] = os.environ["CRASS_BENCH_FALLBACK"]
 
     # ---- the single-shot truth: a crass run scans each read set ONCE.  A FRESH context (no learnt bounds; its pools are
     #      sized from the read count when the reads are loaded), reads resident, ONE step, wall clock.  Outside the timed

@@ -58,7 +58,6 @@ __global__ __launch_bounds__(256) void k_cons_cover(const uint8_t *seq, const ui
 __global__ __launch_bounds__(256) void k_cons_cover_lds(const uint8_t *seq, const uint64_t *roff, const uint32_t *rlen, const uint32_t *plc_rec,
                                                          const int32_t *plc_pos, uint32_t n_plc, int *cov, int length)
 {
-    CRASS_VGPR_FLOOR(16);
     extern __shared__ int cov_lds[];                    // [4][length]
     for (int i = threadIdx.x; i < 4 * length; i += 256) cov_lds[i] = 0;
     __syncthreads();

@@ -623,6 +623,7 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     if (hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_premerge, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     c->dma = sdma_create();                             // (nullptr: the copy kernel is used)
+    (void)warm_dmerge_module();                         // (code-object load: here, not inside the first merge)
     unsigned char tab[128];
     build_comp_table(tab);
     if (upload_comp_table(tab) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
@@ -1316,7 +1317,7 @@ static int first_call_bounds_impl(crass_hip_ctx *c)
     // distinct DR strings: a few hundred per million reads on metagenome-like input; the device merge is queued
     // behind pass 1 for this many
     if (dedupe && c->prm.lowDRsize >= 23 && c->dr_stride <= 64 && !c->env.host_merge) {
-        uint64_t dx = std::min<uint64_t>(1u << 20, std::max<uint64_t>(16384, (n / 1024 + 4095) & ~4095ull));
+        uint64_t dx = crass_hip_exchange_rows_for(n);
         if (c->env.test_bounds[1]) dx = std::max<uint64_t>(16, c->env.test_bounds[1]);
         s = device_merge_prepare(c, c->dd_dx_chars.p, c->dd_dx_len.p, dx, c->d_count.p + 4);
         if (s) return s;
@@ -2199,14 +2200,23 @@ int crass_hip_exchange_setup(crass_hip_ctx *c, uint32_t world, uint32_t rank, ui
 
 uint64_t crass_hip_exchange_needed_rows(const crass_hip_ctx *c) { return c ? c->xchg.needed : 0; }
 
+// first-call bound for a shard's distinct DR strings (first_call_bounds_impl uses the same one for the queued merge)
+static uint64_t distinct_bound_for(uint64_t n_reads)
+{
+    return std::min<uint64_t>(1u << 20, std::max<uint64_t>(16384, (n_reads / 1024 + 4095) & ~4095ull));
+}
+uint64_t crass_hip_exchange_rows_for(uint64_t n_reads) { return distinct_bound_for(n_reads); }
+
 int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
 {
     if (!c || !d_recv) return CRASS_ERR_INVALID_ARG;
     if (!c->have_pass1 || !c->xchg.active) return CRASS_ERR_STATE;
     const double t0 = now_ms();
+    auto lap = [&](const char *what) { if (c->env.merge_profile) fprintf(stderr, "[crass_xg] %-28s +%.1f us\n", what, 1e3 * (now_ms() - t0)); };
     crass_hip_ctx::Xchg &X = c->xchg;
     crass_hip_ctx::DM &d = c->dm;
     quiesce_worker(c);
+    lap("quiesced");
     d.active = false;
     c->cnt.used_device_merge = 0; c->cnt.ms_merge_device = 0;
     (void)hipSetDevice(c->device);
@@ -2216,11 +2226,13 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     HIPCHK(c, d.g_chars.ensure(n_max * (size_t)stride + 16)); HIPCHK(c, d.g_len.ensure(n_max + 1));
     HIPCHK(c, launch_xg_unpack((const uint8_t *)d_recv, X.world, X.rank, stride, X.cap, X.slot, d.g_chars.p, d.g_len.p, X.xinfo.p, c->stream,
                                X.h_xinfo.p));      // (the four counters also land in pinned host memory: no copy call)
+    lap("unpack queued");
     bool dev = device_merge_applies(c) && n_max <= (1u << 22);
     if (dev) {
         uint32_t tsize = 1024;
         while (tsize < n * 2) tsize <<= 1;
         { const int as = ensure_gathered_buffers(c, n_max); if (as) return as; }
+        lap("buffers ensured");
         HIPCHK(c, hipMemsetAsync(c->d_count.p + 4, 0, 8, c->stream));
         // the global count lives on the device (xinfo[0]); n_max bounds it
         HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, X.xinfo.p, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p, d.g_rep.p,
@@ -2237,6 +2249,7 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     }
     // As in the seed scan of the one-GPU path: when the previous step's merge ran on the device, this step's merge is
     // queued right here (token count read on the device, sized by a bound) and the host only waits for the counters.
+    lap("de-duplication queued");
     bool queued = false;
     if (dev && X.gx_cap_hint && X.gx_cap_hint <= n_max && !c->env.no_speculation) {
         if (!X.ev_counts) HIPCHK(c, hipEventCreateWithFlags(&X.ev_counts, hipEventDisableTiming));
@@ -2246,8 +2259,10 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
         const int qs = device_merge_enqueue(c, d.gx_chars.p, d.gx_len.p, X.gx_cap_hint, c->d_count.p + 4, prepared);
         if (qs) return qs;
         queued = true;
+        lap("merge queued");
         HIPCHK(c, hipEventSynchronize(X.ev_counts));
     } else HIPCHK(c, hipStreamSynchronize(c->stream));
+    lap("counts on the host");
     const uint64_t n_global = X.h_xinfo.p[0], my_off = X.h_xinfo.p[1];
     if (X.h_xinfo.p[2]) { X.needed = X.h_xinfo.p[3]; X.gx_cap_hint = 0; return CRASS_ERR_OVERFLOW; }
     if (dev && n_global && c->h_count.p[5] == 0 && c->h_count.p[4] != 0 && c->h_count.p[4] <= (1u << 20) && my_off + c->n_dx <= n_global) {
@@ -2256,6 +2271,7 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
         if (queued && n_tok > X.gx_cap_hint) c->n_bound_overflows[3]++;
         const int s = (queued && n_tok <= X.gx_cap_hint) ? device_merge_commit(c, n_tok, d.h_gx_chars.p, d.h_gx_len.p)
                                                          : device_merge(c, d.gx_chars.p, d.gx_len.p, n_tok, d.h_gx_chars.p, d.h_gx_len.p);
+        lap("committed");
         if (s == CRASS_OK) {
             c->cnt.used_device_merge = 1; c->cnt.ms_merge_host = (float)(now_ms() - t0);
             X.gx_cap_hint = (uint32_t)std::min<uint64_t>(n_max, ((uint64_t)n_tok * 3 / 2 + 4095) & ~4095ull);

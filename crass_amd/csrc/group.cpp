@@ -128,7 +128,8 @@ struct crass_hip_group {
     // exchange buffers: rank r's send buffer belongs to its context (crass_hip_exchange_setup), recv[r] is ours
     std::vector<crass_exchange> xc;
     std::vector<void *> recv;
-    uint64_t cap_rows = 16384;
+    uint64_t cap_rows = 16384;                  // rows per rank in the exchange; sized from the largest shard at load unless forced
+    bool cap_rows_forced = false;               // CRASS_GROUP_CAP_ROWS (tests: the overflow path)
     // helper threads (ranks 1 .. n-1); the caller's thread is rank 0
     std::vector<std::thread> threads;
     std::mutex mu;
@@ -354,12 +355,16 @@ int crass_hip_group_create(const crass_params *p, const int *devices, int n, uns
     const bool local = (flags & CRASS_GROUP_LOCAL_COPIES) != 0;
     if (dup && !local) { set_error("a device is listed twice: RCCL needs one rank per device (CRASS_GROUP_LOCAL_COPIES for tests)"); return CRASS_ERR_INVALID_ARG; }
     if (!local && !g_rccl.load()) return CRASS_ERR_RCCL;            // (before any context: no RCCL, no group — text in crass_hip_group_last_error)
+    if (!local && getenv("CRASS_GROUP_INJECT_RCCL_FAIL")) {         // tests: what a caller sees when ncclCommInitAll refuses (its fall-back path)
+        set_error("ncclCommInitAll: injected failure (CRASS_GROUP_INJECT_RCCL_FAIL)");
+        return CRASS_ERR_RCCL;
+    }
     crass_hip_group *g = new (std::nothrow) crass_hip_group();
     if (!g) return CRASS_ERR_OOM;
     g->n = n; g->devices.assign(devices, devices + n); g->local_copies = local;
     g->ctx.assign(n, nullptr); g->xc.assign(n, crass_exchange{}); g->recv.assign(n, nullptr); g->status.assign(n, 0);
     g->extra.resize(n); g->extra_user.resize(n); g->dup_local.resize(n);
-    if (const char *e = getenv("CRASS_GROUP_CAP_ROWS")) g->cap_rows = (uint64_t)std::max(1, atoi(e));       // (tests: force the overflow path)
+    if (const char *e = getenv("CRASS_GROUP_CAP_ROWS")) { g->cap_rows = (uint64_t)std::max(1, atoi(e)); g->cap_rows_forced = true; }      // (tests: force the overflow path)
     for (int r = 0; r < n; r++) {
         const int s = crass_hip_create(p, devices[r], &g->ctx[r]);
         if (s) { crass_hip_group_destroy(g); return s; }
@@ -472,6 +477,9 @@ int crass_hip_group_load_reads(crass_hip_group *g, const crass_reads *h)
             if (any_local_dup) s.header_id = hl.data();
         }
     }
+    // the exchange's row capacity from the largest shard (every rank must use the same one): the first step then neither
+    // overflows nor repeats pass 1
+    if (!g->cap_rows_forced) g->cap_rows = crass_hip_exchange_rows_for((n + (uint64_t)N - 1) / (uint64_t)N);
     const int st = dispatch(g, PH_LOAD);
     // (the shard views point into the caller's arrays: they are only used inside this call)
     g->sh_word_off.clear(); g->sh_exc_read.clear(); g->sh_exc_off.clear(); g->sh_header_id.clear();

@@ -199,9 +199,6 @@ static __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
 template <int W, int D0, int D1, int LCT>
 __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams P, uint64_t *hitmask, uint32_t *seed_hint)
 {
-    if constexpr (LCT == 0 && W == 6) CRASS_VGPR_FLOOR(40);           // (engine_internal.h: never the last register of the allocation)
-    if constexpr (LCT == 0 && W == 7) CRASS_VGPR_FLOOR(56);
-    if constexpr (LCT == 0 && W == 12) CRASS_VGPR_FLOOR(80);
     const uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const bool active = r < R.n_reads;
     constexpr int WX = W + (D1 >> 4) + 2;
@@ -1320,7 +1317,6 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
                                                    uint32_t ss_pool_cap, uint32_t *d_ss_used,
                                                    uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds, int punt_only)
 {
-    CRASS_VGPR_FLOOR(128);                       // (the <false> instantiation came out at exactly 128: engine_internal.h)
     extern __shared__ __attribute__((aligned(16))) uint8_t sv_lds[];
     const int lane = threadIdx.x;
     RH h;
@@ -2213,7 +2209,6 @@ hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_
 // ---- host-loop sink: select + gather of the found records (engine_internal.h) ----
 __global__ __launch_bounds__(256) void k_select_found(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err)
 {
-    CRASS_VGPR_FLOOR(8);
     const uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     bool f = false;
     if (s < n) {
@@ -2228,7 +2223,6 @@ __global__ __launch_bounds__(256) void k_gather_sparse(const uint64_t *fidx, con
                                                         uint32_t dr_stride, const uint32_t *ss_pool, SurvOut *g_out, uint64_t *g_slot, char *g_dr,
                                                         uint32_t *g_ss, uint32_t g_ss_cap, uint32_t *d_ss_total)
 {
-    CRASS_VGPR_FLOOR(32);
     const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t n = *d_nf;
     if (n > n_max) n = n_max;
@@ -2329,7 +2323,6 @@ hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t str
 __global__ __launch_bounds__(256) void k_dx_flag(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n_max,
                                                   const uint32_t *slot_of, const uint32_t *first, uint32_t *rep, uint64_t *mask, uint32_t *d_mismatch)
 {
-    CRASS_VGPR_FLOOR(16);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = min(*d_n, n_max);
     bool is_rep = false;
@@ -2521,7 +2514,6 @@ template <bool LDS_TABLE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_recruit(DevReads R, DevAutomaton A, const uint8_t *found_flag,
                                                  uint64_t *hitmask, uint32_t *hit_info)
 {
-    if constexpr (LDS_TABLE) CRASS_VGPR_FLOOR(16);
     extern __shared__ __attribute__((aligned(16))) uint16_t rc_lds[];
     const uint16_t *go4 = A.go4;
     const uint16_t *outl = A.out_len;
@@ -2845,9 +2837,10 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
 template <int W, int THREADS, int MODE>
 __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchors K, const uint8_t *found_flag, uint64_t *hitmask)
 {
-    // 1 024 threads per block and (with its table in LDS) one block per CU: four waves per SIMD whatever the register count
-    // up to 128, so one floor above every instantiation's own count keeps all of them off a multiple of 8
-    CRASS_VGPR_FLOOR(120);
+    // (1 024 threads per block and, with its table in LDS, one block per CU.  Until round 4 a CRASS_VGPR_FLOOR(120) kept every
+    // instantiation off a multiple of 8 registers: 4 waves x 128 allocated registers = a SIMD's whole file, so no wave of any
+    // other kernel could share the CU — the view export beside it then cost the probe 144 -> 216 us.  The build's guard is exact
+    // now, crass_amd/vgpr_guard.py, and these kernels hold no 64-bit shift by their last register.)
     extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
     const uint32_t tsize = 1u << K.log_size;
     const uint32_t *ak_lds = K.table;                   // key sets too large for LDS are probed in global memory (L2)
@@ -2863,7 +2856,6 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
 template <int W, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMerge M, const uint8_t *found_flag, uint64_t *hitmask)
 {
-    CRASS_VGPR_FLOOR(120);                              // (see k_anchor_filter)
     extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
     DevAnchors K;
     K.table = M.anchor_tab; K.log_size = M.st->log_size; K.mode = 0; K.m1 = M.m1; K.m2 = M.m2; K.n_keys = 0;
@@ -2987,7 +2979,6 @@ __global__ __launch_bounds__(256) void k_recruit_list(DevReads R, DevAutomaton A
 __global__ __launch_bounds__(256) void k_recruit_list_wave(DevReads R, DevAutomaton A, const uint64_t *idx, const uint32_t *d_n,
                                                             uint64_t n_max, uint32_t *info_by_slot, uint32_t *pid_by_slot)
 {
-    CRASS_VGPR_FLOOR(24);
     const int lane = threadIdx.x & 63;
     const uint64_t k = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     uint64_t n = *d_n;

@@ -113,10 +113,17 @@ class GatheredExchange:
     The row capacity adapts: when some rank's list does not fit (every rank learns that from the gathered
     headers) the buffers are enlarged and the caller repeats the seed scan."""
 
-    def __init__(self, eng, dist, device, cap_rows=16384):
+    def __init__(self, eng, dist, device, cap_rows=0):
         self.eng, self.dist, self.device = eng, dist, device
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self._ev = None
+        if not cap_rows:
+            # the same capacity on every rank, from the LARGEST shard (crass_hip_exchange_rows_for: the engine's own first-call
+            # bound for a shard's distinct DR strings), so that the first step does not overflow and repeat pass 1
+            import torch
+            n = torch.tensor([int(eng.counters()["n_reads"])], dtype=torch.int64, device=device)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            cap_rows = int(eng.lib.crass_hip_exchange_rows_for(int(n.item())))
         self._setup(cap_rows)
         # bring the communicator up now (RCCL initialises lazily on the first collective): not inside a timed step
         import torch

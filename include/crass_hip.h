@@ -203,6 +203,11 @@ typedef struct {
 int crass_hip_exchange_setup(crass_hip_ctx *ctx, uint32_t world, uint32_t rank, uint64_t cap_rows, crass_exchange *out);
 int crass_hip_merge_gathered(crass_hip_ctx *ctx, const void *d_recv);
 uint64_t crass_hip_exchange_needed_rows(const crass_hip_ctx *ctx);
+/* A row capacity for the first exchange of a job whose LARGEST shard holds n_reads reads: the bound the engine itself
+ * speculates with for a shard's distinct DR strings (a few hundred per million reads on metagenome-like input, >= 16 384).
+ * Every rank must use the same capacity; with this one the first step of a group neither overflows nor repeats pass 1
+ * (16 384 rows, the round-3 default, did at 50 M reads per rank: 18.4 ms for the first step against 4.9 in steady state). */
+uint64_t crass_hip_exchange_rows_for(uint64_t n_reads_of_largest_shard);
 
 typedef struct {
     uint32_t        n_tokens;     /* StringCheck size; tokens are 2 .. n_tokens+1                 */

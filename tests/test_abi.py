@@ -35,13 +35,34 @@ def test_header_symbols_all_exported(ca):
     assert ca.load().crass_hip_abi_version() == 3
 
 
-def test_no_kernel_uses_the_last_vgpr_of_its_allocation(ca):
-    """engine_internal.h, CRASS_VGPR_FLOOR: on the MI355X pool a wave that shares its SIMD loses the last register of its
-    VGPR allocation now and then (profiles/ubench/vgpr_edge2.hip), so no kernel's .vgpr_count may be a multiple of 8"""
+def test_no_kernel_shifts_by_the_last_vgpr_of_its_allocation(ca):
+    """engine_internal.h / crass_amd/vgpr_guard.py: on the MI355X pool a wave that shares its SIMD mis-executes a 64-bit shift whose
+    AMOUNT sits in the last register of its VGPR allocation (profiles/ubench/vgpr_edge3.hip).  The guard disassembles the shipped
+    library: no kernel may hold that pattern; the kernel that exposed it (24 registers, amount in v23) carries the one floor left"""
     from crass_amd import vgpr_guard
-    counts = vgpr_guard.kernel_vgpr_counts(ca.LIB_PATH)
-    assert len(counts) > 100 and any("k_recruit_finish" in k for k in counts)
-    assert [kv for kv in counts.items() if vgpr_guard._bad(*kv)] == []
+    counts, off, multiples, strays = vgpr_guard.analyse(ca.LIB_PATH)
+    assert len(counts) > 100 and off == [] and strays == []
+    fin = [v for k, v in counts.items() if "k_recruit_finishILb0E" in k]
+    assert fin and all(v % 8 != 0 for v in fin)
+    assert vgpr_guard.check(ca.LIB_PATH, verbose=False) == len(counts)
+
+
+def test_the_guard_finds_the_pattern_where_it_exists(tmp_path):
+    """the guard against a binary that HOLDS the pattern: the round-3 micro-benchmark's kernels with the amount in v23 of 24
+    registers are reported, its controls (amount in v21; data pair ending in v23; 32-bit ops on v23) are not"""
+    import shutil
+    import subprocess
+    from crass_amd import vgpr_guard
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "edge3")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-o", exe, os.path.join(ROOT, "profiles", "ubench", "vgpr_edge3.hip")])
+    counts, off, multiples, strays = vgpr_guard.analyse(exe)
+    bad = {o[0] for o in off}
+    assert any("k_lshr64_last" in k for k in bad) and any("lshl" in k for k in bad) and any("ashr" in k for k in bad)
+    assert not any("ctrl" in k or "data_hi" in k for k in bad)
+    assert all(o[3] == "v23" for o in off)
+    with pytest.raises(RuntimeError, match="amount from the last VGPR"):
+        vgpr_guard.check(exe)
 
 
 def test_no_gpu_means_loud_failure_not_fallback(ca):

@@ -369,6 +369,24 @@ def test_bench_spawns_its_own_ranks_strong_scaling():
     assert "error" not in cal and cal["bmp_ratio"] > 0 and cal["ac_ratio"] > 0
 
 
+def test_bench_group_failure_falls_back_to_fresh_rank_processes():
+    """`python bench.py --gpus 2` (group launcher) whose group cannot be created — here an injected
+    CRASS_ERR_RCCL — prints RCCL's text and runs the torch launcher in FRESH child processes; the line carries the reason and
+    the same totals as the one-process run"""
+    env = dict(os.environ, CRASS_GROUP_INJECT_RCCL_FAIL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-gpu",
+                        "--total-reads", "1000000", "--steps", "2", "--warmup", "1"], capture_output=True, timeout=900, env=env)
+    d = _bench_line(r)
+    assert b"group launcher unavailable" in r.stderr and b"injected failure" in r.stderr
+    assert d["n_gpus"] == 2 and d["config"]["launcher"].startswith("torch.distributed")
+    assert "injected failure" in d["launcher_fallback"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--total-reads", "1000000", "--steps", "2",
+                          "--warmup", "1", "--cpu-sample", "0", "--single-shots", "0"], capture_output=True, timeout=900)
+    d1 = _bench_line(one)
+    assert (d["config"]["pass1_found"], d["config"]["pass2_found"], d["config"]["patterns"]) == \
+        (d1["config"]["pass1_found"], d1["config"]["pass2_found"], d1["config"]["patterns"])
+
+
 def test_bench_rccl_strong_scaling_one_rank_per_gpu():
     """the RCCL form of the same launch on however many GPUs this box has (1 on the test pool: a one-rank communicator,
     `--gpus 1` under an external launcher environment)"""
