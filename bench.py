@@ -73,6 +73,8 @@ def parse():
                     "are then learnt from a different batch than the one being processed)")
     ap.add_argument("--single-shots", type=int, default=3, help="N=1: fresh contexts timed for single_shot_ms (0 = skip)")
     ap.add_argument("--check", action="store_true", help="also verify the GPU result against the oracle on the CPU sample")
+    ap.add_argument("--e2e-reads", type=int, default=-1, help="N=1: reads of the end-to-end command-line run reported as e2e_reads_per_s "
+                                                              "(FASTA on disk -> crass-hip -> output files; default 5 M for 150 bp configs, 0 = skip)")
     ap.add_argument("--launcher", default="group", choices=["group", "torch"],
                     help="N>1 from a plain interpreter: group = one process drives N contexts through crass_hip_group_* (C++ RCCL); "
                          "torch = one process per GPU over torch.distributed.  Under an external launcher (WORLD_SIZE set) always torch")
@@ -434,6 +436,26 @@ def main():
                               "note": "one step on a fresh context (crass_hip_create + crass_hip_load_reads outside, as for "
                                       "`value`: reads resident in HBM); no learnt speculation bounds, nothing warmed"}
 
+    # ---- what the adapter pays on top of a step: the ABI's wide arrays (crass_candidates / crass_merge_view / crass_recruits)
+    #      are widened from the compact blobs ON REQUEST, outside the timed region ----
+    if world == 1 and not group_mode:
+        fetch = []
+        for _ in range(3):
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nf = eng.fetch_abi()
+            fetch.append((time.perf_counter() - t1) * 1e3)
+        out["abi_fetch_ms"] = round(float(np.median(fetch)), 3)
+        out["abi_fetch"] = {"ms_all": [round(x, 3) for x in fetch], "candidates": nf[0], "tokens": nf[1], "recruits": nf[2],
+                            "note": "crass_hip_get_candidates + crass_hip_get_merge + crass_hip_get_recruits after a step (median of 3): "
+                                    "the per-record arrays of the ABI, widened from the step's compact blobs; not part of `value`"}
+        e2e_n = args.e2e_reads if args.e2e_reads >= 0 else (5_000_000 if L <= 300 and not custom else 0)
+        if e2e_n > 0 and rank == 0:
+            out["e2e"] = _e2e_cli(ca, spec, L, min(e2e_n, total))
+            if "reads_per_s" in out["e2e"]:
+                out["e2e_reads_per_s"] = out["e2e"]["reads_per_s"]
+
     # ---- strong scaling: the same job on ONE GPU (rank 0, untimed part of the run; the other ranks wait) ----
     if (world > 1 or group_mode) and scaling == "strong" and not args.no_strong_base and args.dist_backend == "nccl":
         base = None
@@ -558,6 +580,53 @@ class _GroupRunner:
 
     def close(self):
         self.g.close()
+
+
+def _e2e_cli(ca, spec, L, n):
+    """End to end through the command line (tools/e2e_cli.sh in one function): a FASTA file of n reads of the SAME synthetic stream
+    on disk -> `crass-hip -g -o DIR` (read + parse + pack + H2D + pass 1 + merge + pass 2 + hand-off + consensus + spacer graphs +
+    .crispr / Group_*.fa written), wall clock of the whole process incl. HIP start-up, best of 2; peak RSS of the child."""
+    import numpy as np
+    import resource
+    import shutil
+    import tempfile
+    cli = os.path.join(ROOT, "crass_amd", "crass-hip")
+    if not os.path.exists(cli):
+        return {"error": "crass_amd/crass-hip not built"}
+    td = tempfile.mkdtemp(prefix="crass_e2e_")
+    try:
+        w = ca.synth_packed(spec, 0, n)
+        asc = ca.unpack_ascii(w, (L + 15) // 16, L, n).reshape(n, L)
+        rec = np.empty((n, 10 + L + 1), np.uint8)
+        ids = np.char.zfill(np.arange(n).astype("S8"), 8)
+        rec[:, 0] = ord(">"); rec[:, 1:9] = np.frombuffer(ids.tobytes(), np.uint8).reshape(n, 8); rec[:, 9] = 10
+        rec[:, 10:10 + L] = asc; rec[:, 10 + L] = 10
+        fa = os.path.join(td, "e2e.fa")
+        with open(fa, "wb") as f:
+            f.write(rec.tobytes())
+        del rec, asc, w
+        walls, found = [], None
+        for _ in range(2):
+            od = os.path.join(td, "out")
+            shutil.rmtree(od, ignore_errors=True)
+            os.makedirs(od)
+            t0 = time.perf_counter()
+            p = subprocess.run([cli, "-g", "-o", od, fa], capture_output=True, timeout=600)
+            walls.append(time.perf_counter() - t0)
+            if p.returncode != 0:
+                return {"error": "crass-hip exited %d: %s" % (p.returncode, p.stderr.decode()[-300:])}
+            for line in p.stdout.decode().replace("\r", "\n").splitlines():
+                if "Found" in line and "reads" in line:
+                    found = line.strip()
+        rss = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1024.0
+        return {"reads": n, "wall_s": round(min(walls), 3), "reads_per_s": round(n / min(walls), 1), "walls_s": [round(x, 3) for x in walls],
+                "peak_rss_mb": round(rss, 1), "fasta_mb": round(n * (11 + L) / 1e6, 1), "found": found,
+                "note": "`crass-hip -g -o DIR file.fa`: process start + HIP init + read/parse/pack + H2D + pass 1 + merge + pass 2 + "
+                        "hand-off + consensus + spacer graphs + output files; PCIe- and parse-inclusive, never part of `value`"}
+    except Exception as ex:                          # a reported extra: never fails the run
+        return {"error": str(ex)[:300]}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def _pmc_file(n, L):

@@ -739,7 +739,8 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     c->n_pos_hint_words = 0;
     c->R.pos_hint = nullptr; c->R.pos_hint_off = nullptr;
     const DevParams &P = c->dp;
-    if (c->max_len <= 2048 || n == 0 || P.window != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return CRASS_OK;
+    // (skips == 8: the hints are kept per residue class mod 8 — k_hint_positions fills the lattice class, the walking wave the others)
+    if (c->max_len <= 2048 || n == 0 || P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return CRASS_OK;
     if (c->env.no_pos_hints) return CRASS_OK;             // A/B switch
     std::vector<uint64_t> off(n + 1);
     uint64_t at = 0;

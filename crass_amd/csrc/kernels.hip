@@ -275,14 +275,46 @@ hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *h
     return hipGetLastError();
 }
 
+// Hint bits of residue class rho for the 64 positions of one hint word: bit (8 i + rho) is set iff the 8-mer at that position
+// has a copy 49 .. 97 bases further on (searchCore's seed test, libcrispr.cpp:295-339; a superset: padding and the right clamp
+// are ignored).  w[0..12]: the packed words of the chunk and its halo.  R >> 2 rho puts the seeds 8h + rho on the halfword
+// lattice, where the test is the short-read filter's: for a shift d, X = R' ^ (R' >> 2d) has a zero halfword h  <=>  the 8-mer
+// at 8h (+ rho) re-occurs d further on — {v_alignbit, v_xor, v_pk_min_u16} per word and shift, 49 x 4 x 3 = 588 instructions
+// per 64 positions and CLASS (the all-classes form that k_hint_positions used until round 4 took 2 300 for the eight of them).
+static __device__ __forceinline__ uint64_t hint_bits_class(const uint32_t (&w)[13], uint32_t rho)
+{
+    uint32_t v[12];
+    const uint32_t rs = 2u * rho;
+#pragma unroll
+    for (int i = 0; i < 12; i++) v[i] = rs ? ((w[i] >> rs) | (w[i + 1] << (32u - rs))) : w[i];
+    uint32_t acc[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+    for (int d = 49; d <= 97; d++) {
+        const int q = d >> 4, sh = (d & 15) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lo = v[k + q], hi = v[k + q + 1];
+            const uint32_t x = (sh ? ((lo >> sh) | (hi << (32 - sh))) : lo) ^ v[k];
+            acc[k] = pk_min_u16(acc[k], x);
+        }
+    }
+    uint64_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if ((acc[k] & 0xFFFFu) == 0u) bits |= 1ull << (16 * k + rho);
+        if ((acc[k] >> 16) == 0u) bits |= 1ull << (16 * k + 8 + rho);
+    }
+    return bits;
+}
+
 // ------------------------------------------------------------------------------------
-// Long reads: per-POSITION seed hints.  A 10 kbp read has ~1 250 lattice seeds and, after the first
-// rejected candidate, the seed loop leaves the lattice (libcrispr.cpp:390), so a per-read filter and
-// per-lattice hints are useless there.  The same bit-parallel test is therefore run for all 8 residues
-// (R >> 2*rho puts the seeds at 8h+rho on the halfword lattice): bit p of the read's hint bitmap is clear
-// => the 8-mer at p has no copy at p+49 .. p+97 => searchCore's iteration at j = p is a no-op, whatever
-// residue j is on.  One lane per 64 positions (4 seed words + 7 halo words), a superset like the short-read
-// filter (padding bases and the right clamp are ignored).  Default window / bounds only.
+// Long reads: per-POSITION seed hints.  A 10 kbp read has ~1 250 lattice seeds and a spurious hit with p ~ 0.93, so a
+// per-read filter is useless there; and after a rejected candidate the seed loop leaves the lattice (libcrispr.cpp:390) for
+// another residue class mod 8.  Bit p of the read's hint bitmap clear => the 8-mer at p has no copy at p+49 .. p+97 =>
+// searchCore's iteration at j = p is a no-op.  This kernel fills the bits of the lattice class (p = 8 i) for every read, one
+// lane per 64 positions (4 seed words + halo); the bits of another class are computed by the walking wave itself when — and
+// from where — its read's walk moves there (wave_hints_class).  A superset like the short-read filter (padding bases and the
+// right clamp are ignored).  Default window / bounds only.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words, uint64_t *hint_bits)
 {
@@ -314,53 +346,18 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     uint32_t w[13];
 #pragma unroll
     for (int i = 0; i < 13; i++) { const uint32_t wi = tile * 4 + i; w[i] = wi < nw ? g[wi] : 0u; }
-    // X_d = R xor (R >> 2d) once per shift; the 8-mer at base p (ANY residue) has a copy at p + d  <=>  X_d has 16 zero
-    // bits from bit 2p on.  (R >> 2 rho) xor (R >> 2 rho >> 2d) = X_d >> 2 rho, so the eight residues are eight bit
-    // offsets of the same words: instead of eight {funnel shift, xor, packed min} passes, one xor and a run-of-16
-    // test by doubling (OR of 2, 4, 8, 16 neighbouring bits, the neighbour word funnelled in), AND-accumulated over
-    // the shifts: odd bit b of acc[k] stays 1 unless some shift had zeros at bits [32k + b - 1, 32k + b + 15).  About 47
-    // instead of 75 instructions per shift and lane.
-    uint32_t acc[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#pragma unroll
-    for (int d = 49; d <= 97; d++) {
-        const int q = d >> 4, sh = (d & 15) * 2;
-        uint32_t x[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const uint32_t a = w[k + q], b = w[k + q + 1];
-            x[k] = (sh ? ((a >> sh) | (b << (32 - sh))) : a) ^ w[k];
-        }
-        // first the two bits of a base into its ODD bit (x | x << 1: one v_lshl_or per word, and no neighbour word — bit 0
-        // of a word is an even bit); the three doubling steps that follow shift by even amounts, so the odd bits never
-        // see what the even bits hold
-#pragma unroll
-        for (int k = 0; k < 5; k++) asm("v_lshl_or_b32 %0, %1, 1, %1" : "=v"(x[k]) : "v"(x[k]));     // (hipcc 7.2 splits x | x << 1 into a shift and a v_bitop3 here)
-#pragma unroll
-        for (int step = 2; step <= 8; step <<= 1) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) x[k] |= (x[k] >> step) | (x[k + 1] << (32 - step));     // (uses the OLD x[k + 1]: ascending k)
-            if (step < 8) x[4] |= x[4] >> step;          // only its low bits are ever funnelled into x[3]
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) acc[k] &= x[k];
-    }
-    uint64_t bits = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t z = (~acc[k] >> 1) & 0x55555555u;      // odd bit 2i+1 of acc clear <=> position 16k + i has a copy
-        z = (z | (z >> 1)) & 0x33333333u;
-        z = (z | (z >> 2)) & 0x0F0F0F0Fu;
-        z = (z | (z >> 4)) & 0x00FF00FFu;
-        z = (z | (z >> 8)) & 0x0000FFFFu;
-        bits |= (uint64_t)z << (16 * k);
-    }
+    // the LATTICE class only (positions 8 i): searchCore walks one residue class at a time and leaves it only behind a rejected
+    // candidate (libcrispr.cpp:390,295) — 0.76 times per 10 kbp read on BASELINE configs[3] (tools/class_switches.py), so seven
+    // of the eight classes this kernel used to cover were never looked at.  The class a walk moves to is covered from there on by
+    // the wave that walks (search_core, wave_hints_class)
+    const uint64_t bits = hint_bits_class(w, 0u);
     hint_bits[t] = bits;
 }
 
 hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
                                  uint64_t *hint_bits, hipStream_t st)
 {
-    if (P.window != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return hipErrorNotSupported;
+    if (P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return hipErrorNotSupported;
     if (n_words == 0) return hipSuccess;
     CRASS_LAUNCH(k_hint_positions, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, R, hint_off, blk_read, n_words, hint_bits);
     return hipGetLastError();
@@ -1070,7 +1067,27 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
 }
 
 // searchCore, libcrispr.cpp:265-395.  1 found / 0 not / <0 error
-static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint, int lane, const uint64_t *pos_hint = nullptr)
+// Hint bits of residue class rho for the read in LDS (h.words), hint words [first_word, end): lanes over hint words, OR-ed into
+// the read's hint bitmap (classes occupy disjoint bit positions).  Called by search_core when the walk moves to a class whose
+// bits are not there yet from that point on.
+static __device__ __attribute__((noinline)) void wave_hints_class(const RH &h, uint32_t rho, uint32_t first_word, uint64_t *l_hint, int lane)
+{
+    const uint32_t nw = ((uint32_t)h.L + 15u) >> 4, nh = ((uint32_t)h.L + 63u) >> 6;
+    for (uint32_t base = first_word; base < nh; base += WAVE) {
+        const uint32_t t = base + (uint32_t)lane;
+        if (t < nh) {
+            uint32_t w[13];
+#pragma unroll
+            for (int i = 0; i < 13; i++) { const uint32_t wi = 4u * t + (uint32_t)i; w[i] = wi < nw ? h.words[wi] : 0u; }
+            l_hint[t] |= hint_bits_class(w, rho);
+        }
+    }
+    wave_sync();
+}
+
+// pos_hint (long reads, LDS): the read's per-position hint bits — the lattice class from k_hint_positions; cls_from[rho] (LDS):
+// first position from which class rho's bits are in pos_hint (0xFFFFFFFF: not at all)
+static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint, int lane, uint64_t *pos_hint = nullptr, uint32_t *cls_from = nullptr)
 {
     const uint32_t seq_length = (uint32_t)h.L;
     const uint32_t skips = o.skips;
@@ -1084,8 +1101,16 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
     uint32_t lattice_i = 0;
     for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
         if (pos_hint) {
-            // per-position hints (k_hint_positions): a clear bit makes this iteration a no-op in the reference, on
-            // or off the lattice.  With skips == 8 the next candidate in the same 64-bit word is one ffs away.
+            // per-position hints: a clear bit makes this iteration a no-op in the reference, on or off the lattice.  The walk
+            // stays on one residue class mod 8 until a rejected candidate moves it (j = back() - 1 below); the bits of the class
+            // it moves to are computed here, from this position to the end of the read (the walk only moves forward)
+            if (cls_from && j < cls_from[j & 7u]) {     // wave-uniform; never true on the lattice class
+                const uint32_t first_word = j >> 6;
+                wave_hints_class(h, j & 7u, first_word, pos_hint, lane);
+                if (lane == 0) cls_from[j & 7u] = first_word << 6;
+                wave_sync();
+            }
+            // With skips == 8 the next candidate in the same 64-bit word is one ffs away.
             const uint64_t wbits = pos_hint[j >> 6] >> (j & 63u);
             if (!(wbits & 1ull)) {
                 if (skips == 8) {
@@ -1375,20 +1400,46 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
                 continue;
             }
             L = (int)rd_len(R, r);
-            load_read_to_lds(R, r, h.seq, l_words, L, lane, &pf);
-            if (R.pos_hint) load_hints_to_lds(R, r, L, l_hint, lane, pf);
+            // long reads: a read without a single hinted LATTICE seed (39 % of random 10 kbp reads) never leaves the lattice and
+            // searchCore returns false without having looked at a base — neither does this wave (no 10 KB of LDS to fill)
+            bool no_seed = false;
+            if (R.pos_hint && !punt_only) {
+                const int nh = (L + 63) >> 6;
+                bool any = false;
+                if (pf.r == r) {
+#pragma unroll
+                    for (int i = 0; i < SV_PREFETCH_HINTS; i++) any |= (lane + i * WAVE < nh) && pf.hw[i] != 0ull;
+                    if (nh > SV_PREFETCH_HINTS * WAVE) any = true;                 // (longer than the prefetch covers: walk it)
+                } else {
+                    const uint64_t *gh = R.pos_hint + R.pos_hint_off[r];
+                    for (int wi = lane; wi < nh; wi += WAVE) any |= gh[wi] != 0ull;
+                }
+                no_seed = __ballot(any) == 0ull;
+            }
+            if (!no_seed) {
+                load_read_to_lds(R, r, h.seq, l_words, L, lane, &pf);
+                if (R.pos_hint) load_hints_to_lds(R, r, L, l_hint, lane, pf);
+            }
             pf.r = ~0ull;
             if (!punt_only && s + gridDim.x < n_surv) {         // the next read of this wave: its words travel during the search
                 const uint64_t r2 = surv_idx[s + gridDim.x];
                 next_s = s + gridDim.x; next_r = r2;
                 if (!rd_is_exc(R, r2)) prefetch_read(R, r2, lane, pf);
             }
+            if (no_seed) {
+                if (lane == 0) { SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = 0; out[s] = x; }
+                s += gridDim.x;
+                continue;
+            }
         }
         wave_sync();
         h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
         const uint32_t hint = (!EXC && seed_hint) ? seed_hint[r] : 0xFFFFFFFFu;
-        const uint64_t *ph = (!EXC && R.pos_hint) ? l_hint : nullptr;      // (staged in LDS above)
-        int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane, ph);
+        uint64_t *ph = (!EXC && R.pos_hint) ? l_hint : nullptr;            // (staged in LDS above)
+        uint32_t *cls_from = reinterpret_cast<uint32_t *>(l_hint + lds.hint_words - 4);      // (the last four hint slots: 8 x uint32)
+        if (ph && lane < 8) cls_from[lane] = lane == 0 ? 0u : 0xFFFFFFFFu;
+        wave_sync();
+        int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane, ph, ph ? cls_from : nullptr);
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
         if (f == -3) o.err = 6;                              // Levenshtein rows too short in this launch's LDS layout
@@ -2477,7 +2528,7 @@ SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P, uint32_t row_l
     l.ss_cap = ((2 * reps) + 3u) & ~3u;
     l.row_elems = ((std::min(max_len, row_len_cap) + 8) + 7u) & ~7u;
     l.words_cap = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
-    l.hint_words = ((max_len + 63) / 64 + 2 + 1u) & ~1u;
+    l.hint_words = (((max_len + 63) / 64 + 2 + 1u) & ~1u) + 4u;      // + 8 x uint32: where each residue class's hint bits start (search_core)
     l.total_bytes = l.seq_bytes + l.ss_cap * 4 + 2 * l.row_elems * 2 + l.words_cap * 4 + l.ss_cap * 4 + l.hint_words * 8;
     return l;
 }

@@ -441,6 +441,16 @@ class SearchEngine:
         _chk(self.lib.crass_hip_get_recruits(self.h, C.byref(v)), "crass_hip_get_recruits")
         return RecruitSet(v)
 
+    def fetch_abi(self):
+        """the three getters of the ABI (crass_hip_get_candidates / _get_merge / _get_recruits) and nothing else: what an adapter
+        pays on top of a step to see the wide per-record arrays (the step itself ends with compact blobs in pinned memory).
+        Returns (n_candidates, n_tokens, n_recruits)."""
+        c, m, q = _abi.Candidates(), _abi.MergeView(), _abi.Recruits()
+        _chk(self.lib.crass_hip_get_candidates(self.h, C.byref(c)), "crass_hip_get_candidates")
+        _chk(self.lib.crass_hip_get_merge(self.h, C.byref(m)), "crass_hip_get_merge")
+        _chk(self.lib.crass_hip_get_recruits(self.h, C.byref(q)), "crass_hip_get_recruits")
+        return int(c.n), int(m.n_tokens), int(q.n)
+
     def stream_wait_event(self, event_handle):
         """order the engine's stream behind a HIP event (raw hipEvent_t handle, e.g. torch.cuda.Event().cuda_event)"""
         _chk(self.lib.crass_hip_stream_wait_event(self.h, C.c_void_p(int(event_handle))), "crass_hip_stream_wait_event")

@@ -463,6 +463,7 @@ int orc_qc_found_repeats(const char *seq, int L, const uint32_t *ss, int nss, in
 
 /* searchCore, libcrispr.cpp:265-395.  lattice_only: stop at the first seed hit and
  * report it (used to state the device filter's contract). */
+static uint64_t orc_stat_rejected = 0, orc_stat_class_switches = 0;     /* (not thread safe: a single-threaded diagnostic) */
 static int search_core(rh_t *h, const orc_params *o, int lattice_only)
 {
     const char *read = h->seq;
@@ -502,11 +503,22 @@ static int search_core(rh_t *h, const orc_params *o, int lattice_only)
                 if (qc < 0) return -1;
                 if (qc) return 1;
             }
+            {   /* statistics for tools/class_switches.py only: rejected candidates, and how many of them moved j to another residue class */
+                uint32_t nj = h->ss[h->nss - 1] - 1;
+                orc_stat_rejected++;
+                if (((nj + skips) % skips) != (j % skips)) orc_stat_class_switches++;
+            }
             j = h->ss[h->nss - 1] - 1;
         }
         h->nss = 0;
     }
     return 0;
+}
+
+void orc_stats_get(uint64_t *rejected, uint64_t *class_switches, int reset)
+{
+    *rejected = orc_stat_rejected; *class_switches = orc_stat_class_switches;
+    if (reset) { orc_stat_rejected = 0; orc_stat_class_switches = 0; }
 }
 
 int orc_search_core(const char *seq, int L, const orc_params *p, uint32_t *ss, int *nss, int cap, uint32_t *repeat_len)
