@@ -186,6 +186,15 @@ SYMBOLS = {
     "crass_hip_consensus_view": (C.c_int, [C.c_void_p, C.POINTER(ConsView)]),
     "crass_hip_consensus_free": (None, [C.c_void_p]),
     "crass_fastx_find": (C.c_uint64, [C.POINTER(Fastx), C.c_char_p, C.c_uint64]),
+    "crass_name_table_create": (C.c_void_p, []),
+    "crass_name_table_destroy": (None, [C.c_void_p]),
+    "crass_name_table_reserve": (None, [C.c_void_p, C.c_uint64]),
+    "crass_name_table_first": (C.c_uint64, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64]),
+    "crass_fastx_stream_open": (C.c_int, [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "crass_fastx_stream_next": (C.c_int, [C.c_void_p, C.POINTER(Fastx)]),
+    "crass_fastx_stream_reads_done": (C.c_uint64, [C.c_void_p]),
+    "crass_fastx_stream_max_len": (C.c_uint32, [C.c_void_p]),
+    "crass_fastx_stream_close": (None, [C.c_void_p]),
     "crass_hip_set_host_view": (C.c_int, [C.c_void_p, C.c_int]),
     "crass_hip_group_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.c_uint, C.POINTER(C.c_void_p)]),
     "crass_hip_group_destroy": (None, [C.c_void_p]),

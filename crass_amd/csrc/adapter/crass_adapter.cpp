@@ -387,6 +387,139 @@ void fill_holder(ReadHolder &h, const crass_fastx &fx, uint64_t i, bool low_lexi
     if (fx.has_qual[i]) { h.RH_Qual.assign((const char *)fx.qual + fx.qual_off[i], fx.qual_off[i + 1] - fx.qual_off[i]); h.RH_IsFasta = false; }
     h.RH_WasLowLexi = low_lexi;
 }
+// ---- bounded-memory ingest (the reference's memory model: one record at a time, every input read once per pass,
+//      kseq.cpp:171-226, WorkHorse.cpp:336-393) ----
+// Whole-file ingest keeps every record's text for the hand-off (3 GB of host memory for 5 M x 150 bp); streamed ingest reads
+// the inputs in chunks (crass_fastx_stream_*), keeps the 2-bit packed reads (40 bytes per 150 bp read) + 8-12 bytes of
+// bookkeeping per read, and reads the inputs a SECOND time after the search to pick up the text of the ~1 % of reads that
+// are handed on — as the reference itself reads every file twice.  CRASS_INGEST=stream|whole forces one; default: stream when
+// holding the inputs' records would take more than a quarter of the host's available memory (want_streamed_ingest).
+struct StreamedJob {
+    std::vector<uint32_t> packed;               // uniform stride (stride > 0) or tight words + word_off
+    std::vector<uint64_t> word_off;
+    std::vector<uint32_t> lengths;              // empty while every read has length uni_len
+    std::vector<uint64_t> exc_read, exc_off{0};
+    std::vector<uint8_t> exc_bytes;
+    std::vector<uint64_t> hid;                  // job-level index of the first read with the same header
+    bool any_dup = false;
+    uint64_t n = 0;
+    uint32_t stride = 0, uni_len = 0, max_len = 0, min_len = 0xFFFFFFFFu;
+    std::vector<uint64_t> base{0};              // first job-level read index of every file (+ total)
+    size_t chunk_bytes = 0;
+
+    void reserve(uint64_t n_est, uint32_t words_per_read) { packed.reserve((size_t)n_est * words_per_read + 8); }
+    void to_ragged()                            // a read of another length arrived: tight words + offsets from here on
+    {
+        if (!stride) return;
+        const uint32_t w = (uni_len + 15) / 16;
+        std::vector<uint32_t> tight((size_t)n * w + 4, 0);
+        word_off.resize(n); lengths.assign(n, uni_len);
+        for (uint64_t i = 0; i < n; i++) { word_off[i] = i * (uint64_t)w; memcpy(tight.data() + i * (uint64_t)w, packed.data() + i * (uint64_t)stride, (size_t)w * 4); }
+        tight.resize((size_t)n * w);
+        packed.swap(tight);
+        stride = 0; uni_len = 0;
+    }
+    void append(const crass_fastx &fx)
+    {
+        crass_packed pk{};
+        chk(crass_pack_reads(fx.seq, fx.seq_off, fx.n_reads, 0, &pk), "crass_pack_reads");
+        const crass_reads &r = pk.reads;
+        const uint64_t m = r.n_reads;
+        if (n == 0 && r.uniform_len) { stride = r.stride_words; uni_len = r.uniform_len; }
+        if (stride && !(r.uniform_len == uni_len && r.stride_words == stride)) to_ragged();
+        if (stride) {
+            packed.resize((size_t)(n + m) * stride);
+            memcpy(packed.data() + (size_t)n * stride, r.packed, (size_t)m * stride * 4);
+        } else {
+            uint64_t at = packed.size();
+            for (uint64_t i = 0; i < m; i++) {
+                const uint32_t len = r.uniform_len ? r.uniform_len : r.lengths[i];
+                const uint32_t w = (len + 15) / 16;
+                const uint32_t *src = r.stride_words ? r.packed + i * (uint64_t)r.stride_words : r.packed + r.word_off[i];
+                word_off.push_back(at); lengths.push_back(len);
+                packed.insert(packed.end(), src, src + w);
+                at += w;
+            }
+        }
+        for (uint64_t e = 0; e < r.n_exceptions; e++) {
+            exc_read.push_back(n + r.exc_read[e]);
+            exc_bytes.insert(exc_bytes.end(), r.exc_bytes + r.exc_off[e], r.exc_bytes + r.exc_off[e + 1]);
+            exc_off.push_back(exc_bytes.size());
+        }
+        // header ids: kept from the first duplicate on (identity before it)
+        for (uint64_t i = 0; i < m; i++) {
+            if (!any_dup && fx.header_id[i] != n + i) { any_dup = true; hid.resize(n + i); for (uint64_t q = 0; q < n + i; q++) hid[q] = q; }
+            if (any_dup) hid.push_back(fx.header_id[i]);
+        }
+        for (uint64_t i = 0; i < m; i++) { const uint32_t l = (uint32_t)(fx.seq_off[i + 1] - fx.seq_off[i]); max_len = std::max(max_len, l); min_len = std::min(min_len, l); }
+        n += m;
+        crass_free_packed(&pk);
+    }
+    // crass_pack_reads' pad rule (mode 2) on the whole job: short reads of differing lengths take one stride when that costs
+    // at most twice the words
+    void finish(crass_reads &r)
+    {
+        if (!stride && n) {
+            uint64_t tight = 0;
+            for (uint32_t l : lengths) tight += (l + 15) / 16;
+            const uint32_t w = (max_len + 15) / 16;
+            if (max_len <= 256 && max_len >= 64 && n * (uint64_t)w <= 2 * tight) {
+                std::vector<uint32_t> padded((size_t)n * w + 4, 0);
+                for (uint64_t i = 0; i < n; i++) memcpy(padded.data() + i * (uint64_t)w, packed.data() + word_off[i], (size_t)((lengths[i] + 15) / 16) * 4);
+                packed.swap(padded);
+                std::vector<uint64_t>().swap(word_off);
+                stride = w;
+            }
+        }
+        packed.resize(packed.size() + 4, 0);                    // (the kernels may read a few words past the last read)
+        memset(&r, 0, sizeof(r));
+        r.n_reads = n; r.packed = packed.data(); r.stride_words = stride;
+        r.word_off = stride ? nullptr : word_off.data();
+        r.uniform_len = (n && min_len == max_len) ? max_len : 0;
+        r.lengths = r.uniform_len ? nullptr : lengths.data();
+        r.n_exceptions = exc_read.size(); r.exc_read = exc_read.data(); r.exc_off = exc_off.data(); r.exc_bytes = exc_bytes.data();
+        r.header_id = any_dup ? hid.data() : nullptr;
+        if (!any_dup) std::vector<uint64_t>().swap(hid);
+    }
+    void locate(uint64_t i, size_t &file, uint64_t &local) const
+    {
+        file = (size_t)(std::upper_bound(base.begin(), base.end(), i) - base.begin()) - 1;
+        local = i - base[file];
+    }
+};
+
+bool want_streamed_ingest(const Vecstr &files)
+{
+    if (const char *e = getenv("CRASS_INGEST")) {
+        if (!strcmp(e, "stream")) return true;
+        if (!strcmp(e, "whole")) return false;
+    }
+    uint64_t plain = 0, gz = 0;
+    for (const std::string &f : files) {
+        FILE *fp = fopen(f.c_str(), "rb");
+        if (!fp) continue;                                      // (the reader reports it)
+        unsigned char m[2] = {0, 0};
+        const bool is_gz = fread(m, 1, 2, fp) == 2 && m[0] == 0x1f && m[1] == 0x8b;
+        fseek(fp, 0, SEEK_END);
+        const long sz = ftell(fp);
+        fclose(fp);
+        if (sz > 0) (is_gz ? gz : plain) += (uint64_t)sz;
+    }
+    // auto: whole-file ingest holds ~3.6 bytes per byte of text while it assembles the records (file image + parsed pieces +
+    // record arrays); streamed ingest is bounded but reads every input twice (about twice the wall time of the ingest).  Stream
+    // when the whole-file footprint would exceed a quarter of the memory this host has available (8 GB if that cannot be read).
+    const uint64_t text = plain + 4 * gz;
+    uint64_t avail = 32ull << 30;
+    if (FILE *fp = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof(line), fp)) if (!strncmp(line, "MemAvailable:", 13)) { avail = (uint64_t)atoll(line + 13) << 10; break; }
+        fclose(fp);
+    }
+    return text * 36 / 10 > avail / 4;
+}
+
+// a hand-off record whose text (header, comment, sequence, quality) is still to come from its input file
+struct Fill { uint64_t idx; ReadHolder *h; bool low; };
 } // namespace
 
 int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mReads, StringCheck *mStringCheck,
@@ -415,10 +548,55 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         else m.rc = crass_hip_create(&p, devs[0], &m.c);
         return m;
     });
+    const bool streamed = want_streamed_ingest(seqFiles);
     JobFiles J;
+    StreamedJob S;
+    int max_len = 0;
+    uint64_t n = 0;
+    double t1 = t0;
+    crass_reads r;
+    if (streamed) {
+        // pass A over the inputs: chunk -> 2-bit pack -> append; the chunk's text is dropped
+        struct Names { crass_name_table *t = crass_name_table_create(); ~Names() { crass_name_table_destroy(t); } } names;
+        for (size_t f = 0; f < seqFiles.size(); f++) {
+            crass_fastx_stream *st = nullptr;
+            const int rc = crass_fastx_stream_open(seqFiles[f].c_str(), 0, names.t, S.n, &st);
+            if (rc == CRASS_ERR_IO) CRASS_THROW(std::string("Could not open FASTQ ") + seqFiles[f] + " for reading.");
+            chk(rc, "crass_fastx_stream_open");
+            struct Close { crass_fastx_stream *s; ~Close() { crass_fastx_stream_close(s); } } closer{st};
+            for (;;) {
+                crass_fastx fx;
+                chk(crass_fastx_stream_next(st, &fx), "crass_fastx_stream_next");
+                if (fx.n_reads == 0) break;
+                if (S.n == 0 && f == 0) {
+                    // one allocation for the job instead of a doubling vector (whose growth holds old + new at once): the read
+                    // count from the inputs' sizes and the first chunk's bytes per record (gzip: ~4 x its size in text)
+                    uint64_t text = 0;
+                    for (const std::string &p2 : seqFiles) {
+                        FILE *fp = fopen(p2.c_str(), "rb");
+                        if (!fp) continue;
+                        unsigned char m2[2] = {0, 0};
+                        const bool is_gz = fread(m2, 1, 2, fp) == 2 && m2[0] == 0x1f && m2[1] == 0x8b;
+                        fseek(fp, 0, SEEK_END);
+                        const long sz = ftell(fp);
+                        fclose(fp);
+                        if (sz > 0) text += (uint64_t)sz * (is_gz ? 4u : 1u);
+                    }
+                    const uint64_t rec_bytes = std::max<uint64_t>(1, (fx.seq_off[fx.n_reads] + fx.name_off[fx.n_reads] + fx.qual_off[fx.n_reads] + fx.comment_off[fx.n_reads]) / fx.n_reads + 3);
+                    const uint64_t est = text / rec_bytes + text / rec_bytes / 16 + 1024;
+                    S.reserve(est, (uint32_t)((fx.max_len + 15) / 16));
+                    crass_name_table_reserve(names.t, est);
+                }
+                S.append(fx);
+            }
+            S.base.push_back(S.n);
+        }
+        n = S.n; max_len = (int)S.max_len;
+        t1 = now();
+        S.finish(r);
+    } else {
     J.fx.resize(seqFiles.size());
     J.base.assign(1, 0);
-    int max_len = 0;
     for (size_t f = 0; f < seqFiles.size(); f++) {
         const int rc = crass_read_fastx(seqFiles[f].c_str(), &J.fx[f]);
         if (rc == CRASS_ERR_IO) CRASS_THROW(std::string("Could not open FASTQ ") + seqFiles[f] + " for reading.");
@@ -426,8 +604,8 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         J.base.push_back(J.base.back() + J.fx[f].n_reads);
         max_len = std::max(max_len, (int)J.fx[f].max_len);
     }
-    const uint64_t n = J.base.back();
-    const double t1 = now();
+    n = J.base.back();
+    t1 = now();
     const uint8_t *seq = nullptr; const uint64_t *off = nullptr; const uint64_t *hid = nullptr;
     if (seqFiles.size() == 1) {
         seq = J.fx[0].seq; off = J.fx[0].seq_off;
@@ -461,16 +639,35 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         seq = J.seq.data(); off = J.seq_off.data(); hid = any ? J.header_id.data() : nullptr;
     }
     chk(crass_pack_reads(seq, off, n, 2, &J.pk), "crass_pack_reads");
+    r = J.pk.reads;
+    r.header_id = hid;
+    }
     const double t2 = now();
+    auto rss_mb = [] {
+        long kb = 0;
+        if (FILE *f = fopen("/proc/self/status", "r")) {
+            char line[256];
+            while (fgets(line, sizeof(line), f)) if (!strncmp(line, "VmRSS:", 6)) { kb = atol(line + 6); break; }
+            fclose(f);
+        }
+        return kb / 1024.0;
+    };
+    const double rss_ingested = timing ? rss_mb() : 0;
     Made &made = dev.get();
+    const double rss_ctx = timing ? rss_mb() : 0;
     if (made.rc == CRASS_ERR_RCCL) CRASS_THROW(std::string("crass_hip_group_create: ") + crass_hip_group_last_error());
     chk(made.rc, made.g ? "crass_hip_group_create" : "crass_hip_create");
-    crass_reads r = J.pk.reads;
-    r.header_id = hid;
     crass_candidates c; crass_merge_view v; crass_recruits q;
+    // (the reads are resident on the device(s) once loaded: the host copy of a streamed job goes at once)
+    auto drop_host_reads = [&] {
+        if (!streamed) return;
+        std::vector<uint32_t>().swap(S.packed); std::vector<uint64_t>().swap(S.word_off); std::vector<uint32_t>().swap(S.lengths);
+        std::vector<uint64_t>().swap(S.hid); std::vector<uint8_t>().swap(S.exc_bytes);
+    };
     try {
         if (made.g) {
             chk(crass_hip_group_load_reads(made.g, &r), "crass_hip_group_load_reads");
+            drop_host_reads();
             const int s = crass_hip_group_step(made.g);
             if (s == CRASS_ERR_RCCL) CRASS_THROW(std::string("crass_hip_group_step: ") + crass_hip_group_last_error());
             chk(s, "crass_hip_group_step");
@@ -479,6 +676,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
             chk(crass_hip_group_get_recruits(made.g, &q), "crass_hip_group_get_recruits");
         } else {
             chk(crass_hip_load_reads(made.c, &r), "crass_hip_load_reads");
+            drop_host_reads();
             chk(crass_hip_seed_scan(made.c), "crass_hip_seed_scan");
             chk(crass_hip_merge(made.c, nullptr, nullptr, 0, 0), "crass_hip_merge");
             chk(crass_hip_recruit(made.c, nullptr, 0), "crass_hip_recruit");
@@ -501,17 +699,21 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         (*mReads)[st] = new ReadList();
     }
     if (v.n_candidates != c.n) CRASS_THROW("candidate / token count mismatch");
+    // (streamed ingest: the records' text is picked up by a second pass over the inputs, below — `fills`)
+    std::vector<Fill> fills;
+    std::vector<ReadHolder *> cand_holders(c.n);
     for (uint64_t k = 0; k < c.n; k++) {
-        size_t f; uint64_t i;
-        J.locate(c.read_idx[k], f, i);
         ReadHolder *h = new ReadHolder();
-        fill_holder(*h, J.fx[f], i, c.low_lexi[k] != 0);
+        if (streamed) fills.push_back(Fill{c.read_idx[k], h, c.low_lexi[k] != 0});
+        else {
+            size_t f; uint64_t i;
+            J.locate(c.read_idx[k], f, i);
+            fill_holder(*h, J.fx[f], i, c.low_lexi[k] != 0);
+        }
         h->RH_StartStops.assign(c.ss_pool + c.ss_off[k], c.ss_pool + c.ss_off[k] + c.n_ss[k]);
         h->RH_RepeatLength = (int)c.repeat_len[k];
         (*mReads)[(StringToken)v.cand_token[k]]->push_back(h);
-        const StartStopList &ss = h->RH_StartStops;         // patternsHash[tmp_holder.repeatStringAt(0)] on the UN-oriented holder (libcrispr.cpp:137)
-        patternsHash[c.low_lexi[k] ? h->repeatStringAt(0) : revcomp(h->RH_Seq.substr(ss[ss.size() - 2], ss[ss.size() - 1] - ss[ss.size() - 2] + 1))] = true;
-        readsFound[h->RH_Header] = true;
+        cand_holders[k] = h;
     }
     // createNonRedundantSet's outputs: groups (GID -> tokens), per-group k-mer counts, the pattern list
     const int gid_base = nextFreeGID;
@@ -541,10 +743,13 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     }
     if (v.n_patterns) std::cout << "[crass_clusterCore]: " << v.n_patterns << " non-redundant patterns." << std::endl;
     for (uint64_t k = 0; k < q.n; k++) {
-        size_t f; uint64_t i;
-        J.locate(q.read_idx[k], f, i);
         ReadHolder *h = new ReadHolder();
-        fill_holder(*h, J.fx[f], i, q.low_lexi[k] != 0);
+        if (streamed) fills.push_back(Fill{q.read_idx[k], h, q.low_lexi[k] != 0});
+        else {
+            size_t f; uint64_t i;
+            J.locate(q.read_idx[k], f, i);
+            fill_holder(*h, J.fx[f], i, q.low_lexi[k] != 0);
+        }
         h->RH_StartStops.push_back(q.start[k]);
         h->RH_StartStops.push_back(q.end[k]);
         StringToken st = (StringToken)q.token[k];
@@ -555,12 +760,47 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         }
         (*mReads)[st]->push_back(h);
     }
+    double t_fill = 0;
+    if (streamed && !fills.empty()) {
+        // pass B over the inputs (the reference reads every file a second time too, findSingletons): the text of the records
+        // that are handed on, chunk by chunk
+        const double tf0 = now();
+        std::sort(fills.begin(), fills.end(), [](const Fill &a, const Fill &b) { return a.idx < b.idx; });
+        size_t at = 0;
+        for (size_t f = 0; f < seqFiles.size() && at < fills.size(); f++) {
+            if (fills[at].idx >= S.base[f + 1]) continue;          // nothing wanted from this file
+            crass_fastx_stream *st = nullptr;
+            chk(crass_fastx_stream_open(seqFiles[f].c_str(), 0, nullptr, 0, &st), "crass_fastx_stream_open");
+            struct Close { crass_fastx_stream *s; ~Close() { crass_fastx_stream_close(s); } } closer{st};
+            uint64_t first = S.base[f];
+            while (at < fills.size() && fills[at].idx < S.base[f + 1]) {
+                crass_fastx fx;
+                chk(crass_fastx_stream_next(st, &fx), "crass_fastx_stream_next");
+                if (fx.n_reads == 0) CRASS_THROW("an input changed between the two passes over it");
+                for (; at < fills.size() && fills[at].idx < first + fx.n_reads; at++)
+                    fill_holder(*fills[at].h, fx, fills[at].idx - first, fills[at].low);
+                first += fx.n_reads;
+            }
+        }
+        if (at != fills.size()) CRASS_THROW("an input changed between the two passes over it");
+        t_fill = now() - tf0;
+    }
+    for (uint64_t k = 0; k < c.n; k++) {
+        ReadHolder *h = cand_holders[k];
+        const StartStopList &ss = h->RH_StartStops;         // patternsHash[tmp_holder.repeatStringAt(0)] on the UN-oriented holder (libcrispr.cpp:137)
+        patternsHash[c.low_lexi[k] ? h->repeatStringAt(0) : revcomp(h->RH_Seq.substr(ss[ss.size() - 2], ss[ss.size() - 1] - ss[ss.size() - 2] + 1))] = true;
+        readsFound[h->RH_Header] = true;
+    }
     g_read_counter_p2 += (int)n;
     time(&tnow);
     std::cout << "\r[crass_singletonFinder]: Processed " << g_read_counter_p2 << " ..." << difftime(tnow, time_start) << " sec" << std::endl;
     if (timing)
-        fprintf(stderr, "[crass_timing] searchAndRecruit: %llu reads on %zu device(s); read+parse %.3f s, pack %.3f s, device (H2D + pass 1 + merge + pass 2) %.3f s, hand-off %.3f s\n",
-                (unsigned long long)n, devs.size(), t1 - t0, t2 - t1, t3 - t2, now() - t3);
+        fprintf(stderr, "[crass_timing] searchAndRecruit: %llu reads on %zu device(s)%s; read+parse%s %.3f s, pack %.3f s, device (H2D + pass 1 + merge + pass 2) %.3f s, hand-off %.3f s%s\n",
+                (unsigned long long)n, devs.size(), streamed ? ", streamed ingest" : "", streamed ? "+pack (pass A)" : "", t1 - t0, t2 - t1, t3 - t2, now() - t3,
+                streamed ? (" (of which the second pass over the inputs " + std::to_string(t_fill) + " s)").c_str() : "");
+    if (timing)
+        fprintf(stderr, "[crass_timing] searchAndRecruit: resident set after ingest %.0f MB, with the device context(s) up %.0f MB, at the end %.0f MB\n",
+                rss_ingested, rss_ctx, rss_mb());
     return max_len;
 }
 

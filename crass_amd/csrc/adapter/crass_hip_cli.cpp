@@ -164,7 +164,17 @@ int main(int argc, char *argv[])
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_main = now();
     double t_prev = t_main;
-    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[crass_timing] cli: %-28s %.3f s (at %.3f s)\n", what, t - t_prev, t - t_main); t_prev = t; } };
+    // (peak resident set so far, VmHWM of /proc/self/status: where the memory of a run goes, stage by stage)
+    auto peak_rss_mb = [] {
+        long kb = 0;
+        if (FILE *f = fopen("/proc/self/status", "r")) {
+            char line[256];
+            while (fgets(line, sizeof(line), f)) if (!strncmp(line, "VmHWM:", 6)) { kb = atol(line + 6); break; }
+            fclose(f);
+        }
+        return kb / 1024.0;
+    };
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[crass_timing] cli: %-28s %.3f s (at %.3f s, peak RSS %.0f MB)\n", what, t - t_prev, t - t_main, peak_rss_mb()); t_prev = t; } };
     try {
         time_t start_time; time(&start_time);
         if (!devices.empty()) setDevices(devices, local_copies);

@@ -130,6 +130,41 @@ class FastxFile:
         return bool(np.all(self.header_id == np.arange(self.n_reads, dtype=np.uint64)))
 
 
+def stream_fastx(path, chunk_bytes=0, with_names=True):
+    """The records of a FASTA/FASTQ(.gz) file through the chunked reader (crass_fastx_stream_*): a list of (name, comment, seq, qual)
+    like FastxFile.records(), the header ids (job-level index of the first read with the same name), kseq_read's final return value
+    and the number of chunks it took."""
+    lib = _abi.load()
+    tab = C.c_void_p(lib.crass_name_table_create()) if with_names else C.c_void_p()
+    h = C.c_void_p()
+    _chk(lib.crass_fastx_stream_open(str(path).encode(), int(chunk_bytes), tab, 0, C.byref(h)), "crass_fastx_stream_open(%s)" % path)
+    recs, hid, last, chunks = [], [], -1, 0
+    try:
+        while True:
+            f = _abi.Fastx()
+            _chk(lib.crass_fastx_stream_next(h, C.byref(f)), "crass_fastx_stream_next")
+            last = int(f.last_ret)
+            n = int(f.n_reads)
+            if n == 0:
+                break
+            chunks += 1
+            so, no = _np(f.seq_off, n + 1, np.uint64), _np(f.name_off, n + 1, np.uint64)
+            co, qo = _np(f.comment_off, n + 1, np.uint64), _np(f.qual_off, n + 1, np.uint64)
+            sq, nm = _np(f.seq, int(so[-1]), np.uint8), _np(f.name, int(no[-1]), np.uint8)
+            cm, ql = _np(f.comment, int(co[-1]), np.uint8), _np(f.qual, int(qo[-1]), np.uint8)
+            hc, hq = _np(f.has_comment, n, np.uint8), _np(f.has_qual, n, np.uint8)
+            hid.extend(_np(f.header_id, n, np.uint64).tolist())
+            for i in range(n):
+                recs.append((nm[int(no[i]):int(no[i + 1])].tobytes(), cm[int(co[i]):int(co[i + 1])].tobytes() if hc[i] else None,
+                             sq[int(so[i]):int(so[i + 1])].tobytes(), ql[int(qo[i]):int(qo[i + 1])].tobytes() if hq[i] else None))
+        assert int(lib.crass_fastx_stream_reads_done(h)) == len(recs)
+    finally:
+        lib.crass_fastx_stream_close(h)
+        if with_names:
+            lib.crass_name_table_destroy(tab)
+    return recs, hid, last, chunks
+
+
 def synth_spec(**kw):
     s = _abi.SynthSpec()
     _abi.load().crass_synth_default(C.byref(s))

@@ -479,6 +479,27 @@ void crass_free_fastx(crass_fastx *f);
 /* index of the FIRST read with this header name (the key of readsFound, libcrispr.cpp:138,411), UINT64_MAX if none */
 uint64_t crass_fastx_find(const crass_fastx *f, const char *name, uint64_t len);
 
+/* The same reader as a STREAM of chunks, for inputs that should not be held in host memory as a whole — the reference's own
+ * memory model: kseq_read hands out one record at a time (kseq.cpp:171-226, libcrispr.cpp:96) and crass reads every input
+ * twice, once per pass (WorkHorse.cpp:336-393).  A chunk holds the complete records of about `chunk_bytes` of decompressed text
+ * (0: 64 MB; a record larger than a chunk grows it); the fields are those of crass_fastx, valid until the next call; n_reads == 0
+ * marks the end of the file.  kseq's cross-record state travels with the stream (stale comment / quality buffers,
+ * libcrispr.cpp:124-131).  With a name table, header_id[i] is the JOB-level index (index_base + records before it in this
+ * stream) of the first read with the same header — across chunks and, with one table for several streams, across files
+ * (readsFound is keyed by the header string, libcrispr.cpp:138,411); names are kept as 128-bit hashes only.              */
+typedef struct crass_name_table crass_name_table;
+typedef struct crass_fastx_stream crass_fastx_stream;
+crass_name_table *crass_name_table_create(void);
+void     crass_name_table_destroy(crass_name_table *t);
+void     crass_name_table_reserve(crass_name_table *t, uint64_t n_names);    /* sized once for about n_names names (optional) */
+uint64_t crass_name_table_first(crass_name_table *t, const char *name, uint64_t len, uint64_t index);
+int      crass_fastx_stream_open(const char *path, uint64_t chunk_bytes, crass_name_table *names, uint64_t index_base,
+                                 crass_fastx_stream **out);
+int      crass_fastx_stream_next(crass_fastx_stream *s, crass_fastx *chunk);
+uint64_t crass_fastx_stream_reads_done(const crass_fastx_stream *s);
+uint32_t crass_fastx_stream_max_len(const crass_fastx_stream *s);
+void     crass_fastx_stream_close(crass_fastx_stream *s);
+
 /* deterministic synthetic metagenome: counter-based, so any shard can be
  * generated independently.  Writes 2-bit packed reads with uniform stride ceil(L/16).      */
 typedef struct {

@@ -262,6 +262,38 @@ def test_parallel_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
     assert len(ref) > 1000
 
 
+@pytest.mark.parametrize("case", ["fa_single", "fa_multi", "fq", "fq_trunc", "fa_odd", "fa_crlf", "fa_noeol"])
+@pytest.mark.parametrize("chunk", [300, 4096, 65536, 0])
+def test_streaming_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
+    """the chunked reader (crass_fastx_stream_*, bounded host memory) against the byte-at-a-time kseq reference: chunks from far
+    smaller than a record (the stream grows them) to larger than the file, plain and gzipped; records, stale comment / quality
+    carry-over across chunk ends, job-level header ids through the 128-bit name table, kseq_read's final return value"""
+    text = _fastx_cases()[case]
+    plain, gz = _write_both(tmp_path, case + ".txt", text)
+    ref = fastx.read_fastx(gz)
+    first = {}
+    ref_ids = [first.setdefault(r[0], i) for i, r in enumerate(ref)]
+    whole = ca.FastxFile(plain)
+    for path in (plain, gz):
+        recs, hid, last, chunks = ca.stream_fastx(path, chunk_bytes=chunk)
+        assert recs == ref
+        assert hid == ref_ids
+        assert last == whole.last_ret
+        if chunk and chunk < len(text) // 4:
+            assert chunks > 3
+    assert len(ref) > 1000
+
+
+def test_streaming_reader_on_the_reference_inputs(ca):
+    """the five regression inputs of the reference (tests/golden/data, byte-identical to /root/reference/test/*.gz) through the
+    stream in small chunks = through the whole-file reader"""
+    for fname in ["Ill100.fx.gz", "CN_gDC.fa.gz", "front_offset_bug.fa.gz", "Ill.nr.miss.fa.gz", "poor_dr_ext.fa.gz"]:
+        path = os.path.join(DATA, fname)
+        f = ca.FastxFile(path)
+        recs, hid, last, chunks = ca.stream_fastx(path, chunk_bytes=20000)
+        assert recs == f.records() and hid == f.header_id.tolist() and last == f.last_ret and (chunks > 1 or f.n_reads < 50)
+
+
 def test_gzip_inflate_paths_agree(ca, tmp_path):
     """.gz inputs: the libdeflate fast path (whole-buffer, member by member), zlib's gzread (CRASS_NO_LIBDEFLATE) and the
     plain file give the same records — single member, several concatenated members (gzread semantics: one stream),

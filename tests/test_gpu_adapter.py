@@ -48,14 +48,23 @@ def parse_handoff(path):
 
 # the one-call device path (default), crass's three calls (--seam), and both over a group of contexts sharing the one GPU
 MODES = {"device": [], "seam": ["--seam"], "group3": ["--devices", "0,0,0", "--local-copies"],
-         "seam-group2": ["--seam", "--devices", "0,0", "--local-copies"]}
+         "seam-group2": ["--seam", "--devices", "0,0", "--local-copies"],
+         # streamed ingest (bounded host memory): the inputs are read in chunks — here far smaller than in production, so that
+         # records, stale comments and duplicate headers straddle chunk ends — and a second time for the hand-off's text
+         "stream": [], "stream-group3": ["--devices", "0,0,0", "--local-copies"]}
+MODE_ENV = {"stream": {"CRASS_INGEST": "stream", "CRASS_INGEST_CHUNK_BYTES": "30000"},
+            "stream-group3": {"CRASS_INGEST": "stream", "CRASS_INGEST_CHUNK_BYTES": "7000"}}
+
+
+def mode_env(mode):
+    return dict(os.environ, **MODE_ENV.get(mode, {"CRASS_INGEST": "whole"}))
 
 
 @pytest.mark.parametrize("mode", sorted(MODES))
 @pytest.mark.parametrize("fname", ["Ill100.fx.gz", "front_offset_bug.fa.gz", "CN_gDC.fa.gz", "poor_dr_ext.fa.gz"])
 def test_cli_handoff_matches_oracle(cli, tmp_path, fname, mode):
     path = os.path.join(DATA, fname)
-    r = subprocess.run([cli, "--dump-handoff", "-o", str(tmp_path)] + MODES[mode] + [path], capture_output=True, timeout=300)
+    r = subprocess.run([cli, "--dump-handoff", "-o", str(tmp_path)] + MODES[mode] + [path], capture_output=True, timeout=300, env=mode_env(mode))
     assert r.returncode == 0, r.stderr.decode()
     so = r.stdout.decode()
     assert "[crass_patternFinder]: Processed" in so and "[crass_clusterCore]:" in so and "[crass_singletonFinder]:" in so
@@ -114,7 +123,7 @@ def test_cli_two_files_cross_file_headers(cli, tmp_path, mode):
     """readsFound is shared across files (WorkHorse.cpp:329-393): a header found in file 1's pass 1
     suppresses recruitment of the same header in file 2."""
     f1 = os.path.join(DATA, "Ill.nr.miss.fa.gz")
-    r = subprocess.run([cli, "--dump-handoff", "-o", str(tmp_path)] + MODES[mode] + [f1, f1], capture_output=True, timeout=300)
+    r = subprocess.run([cli, "--dump-handoff", "-o", str(tmp_path)] + MODES[mode] + [f1, f1], capture_output=True, timeout=300, env=mode_env(mode))
     assert r.returncode == 0, r.stderr.decode()
     h = parse_handoff(os.path.join(str(tmp_path), "crass_hip_handoff.tsv"))
     recs = fastx.read_fastx(f1)
@@ -206,3 +215,42 @@ def test_cli_writes_crass_outputs_equal_to_the_oracle(cli, tmp_path, fname, log_
         assert got[f] == want["files"][f], f
     assert ("[crass_graphBuilder]: %d CRISPRs found!" % len(want["kept"])) in r.stdout.decode()
     assert os.path.exists(os.path.join(out, "crass.%s.log" % stamp)) == (not log_to_screen)
+
+
+def test_streamed_and_whole_ingest_write_the_same_files(cli, tmp_path):
+    """a synthetic FASTQ with comments on some records, ragged lengths, N reads and duplicate headers: the complete command line
+    (search, consensus, spacer graphs, .crispr + Group_*.fa) with streamed ingest (40 KB chunks) and with whole-file ingest —
+    byte-identical output directories"""
+    import crass_amd as ca
+    import numpy as np
+    ca.load()
+    n, L = 30000, 150
+    spec = ca.synth_spec(read_len=L, crispr_per_million=60000, n_dr=8)
+    asc = ca.unpack_ascii(ca.synth_packed(spec, 0, n), (L + 15) // 16, L, n)
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(n):
+        s = asc[i * L:(i + 1) * L].tobytes()
+        if i % 11 == 0:
+            s = s[:int(rng.integers(70, L))]
+        if i % 501 == 0:
+            s = s[:40] + b"N" + s[41:]
+        name = b"r%d" % (i if i % 97 else i // 2)
+        com = (b" c%d" % i) if (i > 30 and i % 4 == 0) else b""
+        lines.append(b"@" + name + com + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+    fq = tmp_path / "s.fq"
+    fq.write_bytes(b"".join(lines))
+    outs = {}
+    for mode, env in (("whole", {"CRASS_INGEST": "whole"}), ("stream", {"CRASS_INGEST": "stream", "CRASS_INGEST_CHUNK_BYTES": "40000"})):
+        d = tmp_path / mode
+        d.mkdir()
+        r = subprocess.run([cli, "-g", "-o", str(d), str(fq)], capture_output=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs[mode] = {f: open(d / f, "rb").read() for f in sorted(os.listdir(d))}
+        assert any(f.endswith(".crispr") for f in outs[mode]) and len(outs[mode]) >= 3
+    assert outs["whole"].keys() == outs["stream"].keys()
+    for f in outs["whole"]:
+        a, b = outs["whole"][f], outs["stream"][f]
+        # (the XML and the log record the output directory of the command line)
+        a, b = a.replace(str(tmp_path / "whole").encode(), b"DIR"), b.replace(str(tmp_path / "stream").encode(), b"DIR")
+        assert a == b, f
