@@ -860,8 +860,9 @@ hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const ui
 }
 // rank order == global read order: rank r's rows go to [off_r, off_r + n_r)
 __global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows,
-                                                    uint32_t slot_bytes, char *g_chars, uint16_t *g_len, uint32_t *xinfo, uint32_t *h_xinfo)
+                                                    uint32_t slot_bytes, char *g_chars, uint16_t *g_len, uint32_t *xinfo, uint32_t *h_xinfo, uint32_t *zero2)
 {
+    if (zero2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;      // the de-duplication's two counters (no fill launch)
     const uint64_t send_bytes = (cap_rows + 1) * (uint64_t)slot_bytes;
     const uint32_t r = blockIdx.y;
     uint64_t off = 0, total = 0, mx = 0, mine = 0;
@@ -888,10 +889,10 @@ __global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t
     g_len[off + i] = (uint16_t)src[stride / 16].x;
 }
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
-                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo)
+                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo, uint32_t *zero2)
 {
     CRASS_LAUNCH(k_xg_unpack, dim3((unsigned)((cap_rows + 255) / 256), world), dim3(256), 0, st, recv, world, rank, stride, cap_rows,
-                       slot_bytes, g_chars, g_len, xinfo, h_xinfo);
+                       slot_bytes, g_chars, g_len, xinfo, h_xinfo, zero2);
     return hipGetLastError();
 }
 

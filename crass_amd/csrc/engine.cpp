@@ -2226,7 +2226,8 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     const uint32_t n = (uint32_t)n_max;
     HIPCHK(c, d.g_chars.ensure(n_max * (size_t)stride + 16)); HIPCHK(c, d.g_len.ensure(n_max + 1));
     HIPCHK(c, launch_xg_unpack((const uint8_t *)d_recv, X.world, X.rank, stride, X.cap, X.slot, d.g_chars.p, d.g_len.p, X.xinfo.p, c->stream,
-                               X.h_xinfo.p));      // (the four counters also land in pinned host memory: no copy call)
+                               X.h_xinfo.p, c->d_count.p + 4));      // (the four counters also land in pinned host memory: no copy call;
+                                                                     //  d_count[4..5] = the de-duplication's counters, cleared on the way)
     lap("unpack queued");
     bool dev = device_merge_applies(c) && n_max <= (1u << 22);
     if (dev) {
@@ -2234,7 +2235,6 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
         while (tsize < n * 2) tsize <<= 1;
         { const int as = ensure_gathered_buffers(c, n_max); if (as) return as; }
         lap("buffers ensured");
-        HIPCHK(c, hipMemsetAsync(c->d_count.p + 4, 0, 8, c->stream));
         // the global count lives on the device (xinfo[0]); n_max bounds it
         HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, X.xinfo.p, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p, d.g_rep.p,
                                    c->stream));

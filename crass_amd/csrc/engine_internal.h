@@ -228,7 +228,8 @@ hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const ui
                           uint32_t slot_bytes, uint8_t *send, hipStream_t st);
 // xinfo (device, 8 words): [0] n_global, [1] my_offset, [2] overflow flag, [3] largest per-rank count
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
-                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo = nullptr);   // h_xinfo: pinned mirror
+                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo = nullptr,   // h_xinfo: pinned mirror
+                            uint32_t *zero2 = nullptr);                                                           // two words cleared on the way
 // init_done: the tables were cleared by an earlier kernel of the step (dm_init_slice)
 // view_st / ev_fork / ev_view (M.x_on): the view export runs on view_st beside the merge's last three kernels, forked behind
 // k_dm_redundant (ev_fork); ev_view is recorded behind its last kernel

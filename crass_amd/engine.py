@@ -808,7 +808,10 @@ def consensus(seqs, res, params=None, device=0):
                        len(res.tokens), tbuf.ctypes.data, toff.ctypes.data, len(res.groups), gt.ctypes.data, goff.ctypes.data,
                        int(res.max_read_len))
     h = C.c_void_p()
+    import time as _time
+    _t0 = _time.perf_counter()
     _chk(lib.crass_hip_consensus(C.byref(p), int(device), C.byref(i), C.byref(h)), "crass_hip_consensus")
+    consensus.last_call_s = _time.perf_counter() - _t0       # the C call alone (what an adapter pays), without this wrapper's conversions
     try:
         v = _abi.ConsView()
         _chk(lib.crass_hip_consensus_view(h, C.byref(v)), "crass_hip_consensus_view")

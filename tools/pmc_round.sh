@@ -10,7 +10,7 @@ rlen=${4:-150}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-B="--config $cfg --steps 3 --warmup 1 --cpu-sample 0 --single-shots 0"
+B="--config $cfg --steps 3 --warmup 1 --cpu-sample 0 --single-shots 0 --e2e-reads 0"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 420 rocprofv3 --pmc $c --output-format csv -d $out/rp_$c -o r -- python3 $GRAFT_REPO_ROOT/bench.py $B > $out/bench_$c.json 2> $out/$c.err
   f=$(find $out/rp_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/pmc_$c.csv; rm -rf $out/rp_$c
