@@ -282,7 +282,9 @@ struct crass_hip_ctx {
         uint32_t pack_ss_cap = 0;
         // the ABI's wide per-candidate arrays (crass_candidates), widened from the compact blob on first request
         bool wide_ready = false;
-        std::vector<uint32_t> w_replen, w_nss, w_ss; std::vector<uint64_t> w_ss_off; std::vector<uint16_t> w_dr_len; std::vector<char> w_dr;
+        // (the two large ones are filled by the host pool right after resize(): no value-initialisation pass over 85 MB)
+        std::vector<uint32_t> w_replen, w_nss; std::vector<uint32_t, NoInitAlloc<uint32_t>> w_ss; std::vector<uint64_t> w_ss_off; std::vector<uint16_t> w_dr_len;
+        std::vector<char, NoInitAlloc<char>> w_dr;
         PinBuf<char> h_dr_fb; PinBuf<uint16_t> h_dr_len_fb; bool dr_fallback = false;    // candidates' own strings (no distinct list)
         void release()
         {
@@ -408,7 +410,7 @@ struct crass_hip_ctx {
     // pass-2 results
     bool have_pass2 = false;
     std::vector<uint64_t> q_read; std::vector<uint8_t> q_low; std::vector<uint32_t> q_start, q_end, q_token;
-    std::vector<uint16_t> q_dr_len; std::vector<char> q_dr;
+    std::vector<uint16_t> q_dr_len; std::vector<char, NoInitAlloc<char>> q_dr;      // (q_dr: whoever grows it fills the new bytes)
     // ... or, when the sink ran on the device, one pinned blob (p2_blob_layout)
     PinBuf<uint8_t> h_qblob; P2Blob q_lay{}; uint64_t q_n = 0; bool q_blob_active = false, q_wide_ready = false;
 
@@ -513,20 +515,25 @@ void crass_hip_ctx::widen_p1() const
     const uint8_t *b_nss = hb + D.lay.nss, *b_ss8 = hb + D.lay.ss;
     D.w_replen.resize(n); D.w_nss.resize(n); D.w_ss_off.resize(n); D.w_ss.resize(n * (size_t)ss_cap);
     D.w_dr_len.resize(n); D.w_dr.resize(n * (size_t)stride);
-    for (uint64_t k = 0; k < n; k++) { D.w_replen[k] = b_replen[k]; D.w_nss[k] = b_nss[k]; D.w_ss_off[k] = k * (uint64_t)ss_cap; }
-    if (D.lay.ss_elem == 1) for (uint64_t i = 0; i < n * (uint64_t)ss_cap; i++) D.w_ss[i] = b_ss8[i];
-    else for (uint64_t i = 0; i < n * (uint64_t)ss_cap; i++) D.w_ss[i] = b_ss[i];
-    if (D.dr_fallback) {
-        (void)hipStreamSynchronize(copy_stream);
-        memcpy(D.w_dr.data(), D.h_dr_fb.p, n * (size_t)stride);
-        memcpy(D.w_dr_len.data(), D.h_dr_len_fb.p, n * 2);
-    } else {
-        for (uint64_t k = 0; k < n; k++) {
-            const uint32_t j = h_dmap.p[k];
-            memcpy(D.w_dr.data() + k * (size_t)stride, h_dx_chars.p + j * (size_t)stride, stride);
-            D.w_dr_len[k] = h_dx_len.p[j];
+    if (D.dr_fallback) (void)hipStreamSynchronize(copy_stream);
+    // ~150 bytes per candidate (564 k candidates at 100 M reads: 85 MB, 4.5 ms on one thread): ranges of candidates on the host pool
+    const size_t per_task = 16384;
+    host_parallel_for((size_t)((n + per_task - 1) / per_task), 16, [&](size_t t) {
+        const uint64_t k0 = t * per_task, k1 = std::min<uint64_t>(n, k0 + per_task);
+        for (uint64_t k = k0; k < k1; k++) { D.w_replen[k] = b_replen[k]; D.w_nss[k] = b_nss[k]; D.w_ss_off[k] = k * (uint64_t)ss_cap; }
+        if (D.lay.ss_elem == 1) for (uint64_t i = k0 * ss_cap; i < k1 * (uint64_t)ss_cap; i++) D.w_ss[i] = b_ss8[i];
+        else for (uint64_t i = k0 * ss_cap; i < k1 * (uint64_t)ss_cap; i++) D.w_ss[i] = b_ss[i];
+        if (D.dr_fallback) {
+            memcpy(D.w_dr.data() + k0 * (size_t)stride, D.h_dr_fb.p + k0 * (size_t)stride, (size_t)(k1 - k0) * stride);
+            memcpy(D.w_dr_len.data() + k0, D.h_dr_len_fb.p + k0, (size_t)(k1 - k0) * 2);
+        } else {
+            for (uint64_t k = k0; k < k1; k++) {
+                const uint32_t j = h_dmap.p[k];
+                memcpy(D.w_dr.data() + k * (size_t)stride, h_dx_chars.p + j * (size_t)stride, stride);
+                D.w_dr_len[k] = h_dx_len.p[j];
+            }
         }
-    }
+    });
     D.wide_ready = true;
 }
 
@@ -2559,6 +2566,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
         const char *dr = c->h_dr.p + slot * c->dr_stride;
         const size_t at = c->q_dr.size();
         c->q_dr.resize(at + c->dr_stride);
+        memset(c->q_dr.data() + at, 0, c->dr_stride);
         memcpy(c->q_dr.data() + at, dr, o.dr_len);
         uint32_t tok = o.token;
         if (!tok && c->have_merge) {
@@ -2591,33 +2599,34 @@ int crass_hip_get_recruits(const crass_hip_ctx *c, crass_recruits *o)
         const uint64_t n = c->q_n;
         const uint32_t *b_tok = (const uint32_t *)(hb + b.token);
         const uint16_t *b_start = (const uint16_t *)(hb + b.start), *b_end = (const uint16_t *)(hb + b.end);
-        if (b.narrow) {
-            const uint32_t *b_read = (const uint32_t *)(hb + b.read);
-            mc->q_read.resize(n);
-            for (uint64_t k = 0; k < n; k++) mc->q_read[k] = c->read_base + b_read[k];
-        } else {
-            const uint64_t *b_read = (const uint64_t *)(hb + b.read);
-            mc->q_read.assign(b_read, b_read + n);
-        }
-        mc->q_token.assign(b_tok, b_tok + n);
-        mc->q_low.assign(hb + b.low, hb + b.low + n);
-        mc->q_start.resize(n); mc->q_end.resize(n); mc->q_dr_len.resize(n); mc->q_dr.assign(n * (size_t)c->dr_stride, 0);
+        mc->q_read.resize(n); mc->q_token.resize(n); mc->q_low.resize(n);
+        mc->q_start.resize(n); mc->q_end.resize(n); mc->q_dr_len.resize(n); mc->q_dr.resize(n * (size_t)c->dr_stride);
         // token strings: the device-built view (h_view) or the host-built arena
         const bool dv = c->dm.active && c->dm.view_ready;
         const uint8_t *vb = c->dm.h_view.p;
         const uint64_t *v_off = dv ? (const uint64_t *)(vb + c->dm.view_tot.lay.tok_off) : nullptr;
         const char *v_chars = dv ? (const char *)(vb + c->dm.view_tot.lay.tok_chars) : nullptr;
         const uint32_t n_tok = dv ? c->dm.view_tot.n_tok : c->merge.tokens.size();
-        for (uint64_t k = 0; k < n; k++) {
-            if (b.narrow) { mc->q_start[k] = (hb + b.start)[k]; mc->q_end[k] = (hb + b.end)[k]; }
-            else { mc->q_start[k] = b_start[k]; mc->q_end[k] = b_end[k]; }
-            mc->q_dr_len[k] = (hb + b.dr_len)[k];
-            const uint32_t t = b_tok[k];
-            if (t >= 2 && t - 2 < n_tok) {
-                if (dv) memcpy(mc->q_dr.data() + k * (size_t)c->dr_stride, v_chars + v_off[t - 2], (size_t)(v_off[t - 1] - v_off[t - 2]));
-                else memcpy(mc->q_dr.data() + k * (size_t)c->dr_stride, c->merge.tokens.strings.data(t - 2), c->merge.tokens.strings.len(t - 2));
+        // ~100 bytes per recruit (436 k at 100 M reads): ranges of recruits on the host pool
+        const size_t per_task = 16384;
+        const size_t stride = c->dr_stride;
+        host_parallel_for((size_t)((n + per_task - 1) / per_task), 16, [&](size_t task) {
+            const uint64_t k0 = task * per_task, k1 = std::min<uint64_t>(n, k0 + per_task);
+            memset(mc->q_dr.data() + k0 * stride, 0, (size_t)(k1 - k0) * stride);
+            for (uint64_t k = k0; k < k1; k++) {
+                mc->q_read[k] = b.narrow ? c->read_base + ((const uint32_t *)(hb + b.read))[k] : ((const uint64_t *)(hb + b.read))[k];
+                mc->q_token[k] = b_tok[k];
+                mc->q_low[k] = (hb + b.low)[k];
+                if (b.narrow) { mc->q_start[k] = (hb + b.start)[k]; mc->q_end[k] = (hb + b.end)[k]; }
+                else { mc->q_start[k] = b_start[k]; mc->q_end[k] = b_end[k]; }
+                mc->q_dr_len[k] = (hb + b.dr_len)[k];
+                const uint32_t t = b_tok[k];
+                if (t >= 2 && t - 2 < n_tok) {
+                    if (dv) memcpy(mc->q_dr.data() + k * stride, v_chars + v_off[t - 2], (size_t)(v_off[t - 1] - v_off[t - 2]));
+                    else memcpy(mc->q_dr.data() + k * stride, c->merge.tokens.strings.data(t - 2), c->merge.tokens.strings.len(t - 2));
+                }
             }
-        }
+        });
         mc->q_wide_ready = true;
     }
     o->n = c->q_read.size(); o->read_idx = c->q_read.data(); o->low_lexi = c->q_low.data();
