@@ -170,7 +170,7 @@ struct EnvSwitches {
     uint32_t view_group_cap = 32768;                 // groups beyond this many members are ranked by the host (CRASS_VIEW_GROUP_CAP)
     uint64_t test_bounds[4] = {0, 0, 0, 0};          // tests: CRASS_TEST_BOUNDS="survivors,distinct,flagged,gathered" replaces the
                                                      // first-call bounds (0 = computed), so that every overflow path can be forced
-    uint32_t row_cap = 1024, dm_group_cap = 16384, surv_debug = 0;
+    uint32_t row_cap = 256, dm_group_cap = 16384, surv_debug = 0;     // row_cap: Levenshtein fallback rows of the long-read layout (strings beyond it: second launch, full rows)
     int stage_timing = -1;
     uint64_t pool_cap_bytes = 0;                     // tests: device allocations beyond this total fail with hipErrorOutOfMemory
     void read()
@@ -181,7 +181,7 @@ struct EnvSwitches {
         no_speculation = on("CRASS_NO_SPECULATION"); exc_separate = on("CRASS_EXC_SEPARATE"); dm_init_late = on("CRASS_DM_INIT_LATE");
         dm_inject_fail = on("CRASS_DM_INJECT_FAIL"); no_presize = on("CRASS_NO_PRESIZE"); no_device_view = on("CRASS_NO_DEVICE_VIEW");
         view_group_cap = 32768; if (const char *e = getenv("CRASS_VIEW_GROUP_CAP")) view_group_cap = (uint32_t)std::max(1, atoi(e));
-        row_cap = 1024; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
+        row_cap = 256; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
         dm_group_cap = 16384; if (const char *e = getenv("CRASS_DM_GROUP_CAP")) dm_group_cap = (uint32_t)std::max(1, atoi(e));
         surv_debug = 0; if (const char *e = getenv("CRASS_SURV_DEBUG")) surv_debug = (uint32_t)atoi(e);
         stage_timing = -1; if (const char *e = getenv("CRASS_STAGE_TIMING")) stage_timing = std::min(2, std::max(0, atoi(e)));
@@ -669,6 +669,9 @@ int crass_hip_set_host_view(crass_hip_ctx *c, int light)
     if (!c || light < 0 || light > 1) return CRASS_ERR_INVALID_ARG;
     quiesce_worker(c);
     c->host_view_light = light != 0;
+    // a merge prepared before this call (crass_hip_exchange_setup sizes one at load) would still export the view nobody reads:
+    // a light context's merges skip the k_dmx_* kernels (the next prepare decides again)
+    if (c->host_view_light) c->dm.M.x_on = 0;
     return CRASS_OK;
 }
 
@@ -907,7 +910,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                          const uint64_t *surv_idx_host)
 {
     if (n_total == 0) return CRASS_OK;
-    // Long reads: the Levenshtein fallback rows are sized for 1 k-long strings (spacers are a few dozen bases), which
+    // Long reads: the Levenshtein fallback rows are sized for 256-base strings (spacers are a few dozen bases), which
     // is what lets several waves share a CU's LDS; a read that needs longer rows comes back with err == 6 and is
     // redone by a second launch with the uncapped layout.
     const SurvLds lds_full = survivor_lds_layout(c->max_len, c->dp);

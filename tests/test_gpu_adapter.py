@@ -244,7 +244,8 @@ def test_streamed_and_whole_ingest_write_the_same_files(cli, tmp_path):
     for mode, env in (("whole", {"CRASS_INGEST": "whole"}), ("stream", {"CRASS_INGEST": "stream", "CRASS_INGEST_CHUNK_BYTES": "40000"})):
         d = tmp_path / mode
         d.mkdir()
-        r = subprocess.run([cli, "-g", "-o", str(d), str(fq)], capture_output=True, timeout=600, env=dict(os.environ, **env))
+        r = subprocess.run([cli, "-g", "--timestamp", "01_01_2026_000000", "-o", str(d), str(fq)], capture_output=True, timeout=600,
+                           env=dict(os.environ, **env))                  # (a fixed mTimeStamp: it is part of a file name)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs[mode] = {f: open(d / f, "rb").read() for f in sorted(os.listdir(d))}
         assert any(f.endswith(".crispr") for f in outs[mode]) and len(outs[mode]) >= 3
