@@ -167,6 +167,7 @@ struct EnvSwitches {
     bool host_merge = false, no_speculation = false, exc_separate = false, dm_inject_fail = false, dm_init_late = false;
     bool no_presize = false;                         // A/B switch: no first-call bounds / pool sizing at crass_hip_load_reads
     bool no_device_view = false;                     // A/B switch: the host rebuilds crass_merge_view from root_of / blank (the round-3 path)
+    bool force_device_view = false;                  // CRASS_DEVICE_VIEW=1: the device assembles it for a single context too (default: multi-rank only)
     uint32_t view_group_cap = 32768;                 // groups beyond this many members are ranked by the host (CRASS_VIEW_GROUP_CAP)
     uint64_t test_bounds[4] = {0, 0, 0, 0};          // tests: CRASS_TEST_BOUNDS="survivors,distinct,flagged,gathered" replaces the
                                                      // first-call bounds (0 = computed), so that every overflow path can be forced
@@ -179,7 +180,7 @@ struct EnvSwitches {
         no_lookback = on("CRASS_NO_LOOKBACK"); no_pos_hints = on("CRASS_NO_POS_HINTS");
         merge_profile = on("CRASS_MERGE_PROFILE"); no_lane_kernel = on("CRASS_NO_LANE_KERNEL"); host_merge = on("CRASS_HOST_MERGE");
         no_speculation = on("CRASS_NO_SPECULATION"); exc_separate = on("CRASS_EXC_SEPARATE"); dm_init_late = on("CRASS_DM_INIT_LATE");
-        dm_inject_fail = on("CRASS_DM_INJECT_FAIL"); no_presize = on("CRASS_NO_PRESIZE"); no_device_view = on("CRASS_NO_DEVICE_VIEW");
+        dm_inject_fail = on("CRASS_DM_INJECT_FAIL"); no_presize = on("CRASS_NO_PRESIZE"); no_device_view = on("CRASS_NO_DEVICE_VIEW"); force_device_view = on("CRASS_DEVICE_VIEW");
         view_group_cap = 32768; if (const char *e = getenv("CRASS_VIEW_GROUP_CAP")) view_group_cap = (uint32_t)std::max(1, atoi(e));
         row_cap = 256; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
         dm_group_cap = 16384; if (const char *e = getenv("CRASS_DM_GROUP_CAP")) dm_group_cap = (uint32_t)std::max(1, atoi(e));
@@ -326,6 +327,27 @@ struct crass_hip_ctx {
         return bulk_status;
     }
     SdmaCopy *dma = nullptr;                    // the hand-off records travel on a DMA engine when the HSA runtime offers one (sdma.cpp)
+    // The distinct list of pass 1 (every candidate's index in it, the strings, their lengths) reaches the host the same way:
+    // the de-duplication kernel used to write it straight into pinned memory — 5 MB of PCIe stores at 100 M reads, 90 us of
+    // the pass-1 tail — while its first reader (the helper thread's view build, get_candidates, the host-merge fall-backs) is
+    // a millisecond away.  dx_via_dma: three engine copies started when the counts are known; wait_dx() before any read.
+    SdmaCopy *dma_dx[3] = {nullptr, nullptr, nullptr};
+    bool dx_via_dma = false;
+    mutable std::mutex dx_mu;
+    mutable bool dx_pending = false, dx_stream_copy = false;
+    mutable int dx_status = CRASS_OK;
+    mutable bool dx_hash_valid = true;          // h_dx_hash holds the strings' TokenTable hashes (else: computed on first use)
+    int wait_dx() const
+    {
+        std::lock_guard<std::mutex> lk(dx_mu);
+        if (!dx_pending) return dx_status;
+        int bad = 0;
+        for (SdmaCopy *s : dma_dx) bad |= sdma_wait(s);
+        if (dx_stream_copy) { const hipError_t e = hipStreamSynchronize(copy_stream); if (e != hipSuccess) { last_hip = (int)e; bad = 1; } }
+        dx_pending = false; dx_stream_copy = false;
+        if (bad) { if (!last_hip) last_hip = (int)hipErrorUnknown; dx_status = CRASS_ERR_HIP; }
+        return dx_status;
+    }
     mutable int bulk_status = CRASS_OK;         // sticky until the next seed scan issues new copies
     // device-side merge (dmerge.hip): clustering, non-redundant set, anchor keys and the pass-2 verification
     // index are built on the device; the host view (c->merge) is rebuilt from its per-token results while
@@ -516,6 +538,7 @@ void crass_hip_ctx::widen_p1() const
     D.w_replen.resize(n); D.w_nss.resize(n); D.w_ss_off.resize(n); D.w_ss.resize(n * (size_t)ss_cap);
     D.w_dr_len.resize(n); D.w_dr.resize(n * (size_t)stride);
     if (D.dr_fallback) (void)hipStreamSynchronize(copy_stream);
+    else (void)wait_dx();               // (the distinct list the candidates' strings are read from)
     // ~150 bytes per candidate (564 k candidates at 100 M reads: 85 MB, 4.5 ms on one thread): ranges of candidates on the host pool
     const size_t per_task = 16384;
     host_parallel_for((size_t)((n + per_task - 1) / per_task), 16, [&](size_t t) {
@@ -630,6 +653,10 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     if (hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_premerge, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     c->dma = sdma_create();                             // (nullptr: the copy kernel is used)
+    if (c->dma && !getenv("CRASS_DX_PINNED")) {         // (A/B switch: the de-duplication kernel writes the distinct list to pinned memory itself)
+        for (auto &d : c->dma_dx) d = sdma_create();
+        c->dx_via_dma = c->dma_dx[0] && c->dma_dx[1] && c->dma_dx[2];
+    }
     (void)warm_dmerge_module();                         // (code-object load: here, not inside the first merge)
     unsigned char tab[128];
     build_comp_table(tab);
@@ -691,6 +718,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     (void)sdma_wait(c->dma);                            // (before any buffer goes)
+    (void)c->wait_dx();
     c->lb_status.release(); c->lb_ticket.release(); c->h_lb_fail.release();
     if (c->xchg.ev_counts) (void)hipEventDestroy(c->xchg.ev_counts);
     c->dm.release(); c->h_qblob.release(); c->xchg.send.release(); c->xchg.xinfo.release(); c->xchg.h_xinfo.release();
@@ -698,6 +726,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
     if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
     sdma_destroy(c->dma); c->dma = nullptr;
+    for (auto &d : c->dma_dx) { sdma_destroy(d); d = nullptr; }
     if (c->ev_premerge) (void)hipEventDestroy(c->ev_premerge);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->r_packed.release(); c->r_word_off.release(); c->r_lengths.release(); c->r_header_id.release();
@@ -1073,6 +1102,7 @@ static int ensure_dense_buffers(crass_hip_ctx *c, uint64_t n_alloc, uint64_t poo
         HIPCHK(c, c->h_dmap.ensure(n_alloc)); HIPCHK(c, c->h_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->h_dx_len.ensure(n_alloc));
         HIPCHK(c, c->h_dx_hash.ensure(n_alloc));
         HIPCHK(c, c->dd_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_alloc));
+        if (c->dx_via_dma) HIPCHK(c, c->dd_map.ensure(n_alloc));
     }
     return CRASS_OK;
 }
@@ -1161,9 +1191,10 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     if (dedupe) {
         // distinct strings in first-occurrence order and every candidate's rank among them, exact
         Lookback lbd;
+        const bool dxd = c->dx_via_dma;                 // the list stays on the device; DMA engines bring it over (below)
         HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->dd_slot.p, c->dd_first.p, c->d_mask.p,
-                                   c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
-                                   c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream,
+                                   c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, dxd ? c->dd_map.p : c->h_dmap.p,
+                                   dxd ? nullptr : c->h_dx_chars.p, dxd ? nullptr : c->h_dx_len.p, dxd ? nullptr : c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream,
                                    c->d_count.p, c->h_count.p, 8,           // (the counters leave with the last kernel: no copy call)
                                    c->next_lookback_tiles((n_surv + 1023) / 1024, &lbd)));
         if (c->xchg.active)                             // multi-rank: the list goes straight into the collective's send buffer
@@ -1226,6 +1257,20 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
             if (c->h_count.p[5] == 0) {
                 c->n_dx = c->h_count.p[4];
                 c->have_dev_tokens = true;
+                c->dx_hash_valid = !c->dx_via_dma;
+                if (c->dx_via_dma) {
+                    // (the host has waited for the kernels that wrote these: the engines start at once, beside the merge)
+                    std::lock_guard<std::mutex> lk(c->dx_mu);
+                    const void *src[3] = {c->dd_map.p, c->dd_dx_chars.p, c->dd_dx_len.p};
+                    void *dst[3] = {c->h_dmap.p, c->h_dx_chars.p, c->h_dx_len.p};
+                    const size_t bytes[3] = {(size_t)nf * 4, (size_t)c->n_dx * stride, (size_t)c->n_dx * 2};
+                    for (int q = 0; q < 3; q++) {
+                        if (!bytes[q] || sdma_start(c->dma_dx[q], src[q], dst[q], bytes[q])) continue;
+                        HIPCHK(c, hipMemcpyAsync(dst[q], src[q], bytes[q], hipMemcpyDeviceToHost, c->copy_stream));
+                        c->dx_stream_copy = true;
+                    }
+                    c->dx_pending = true;
+                }
                 if (premerge_queued && c->n_dx > 0 && c->n_dx <= c->dx_cap_hint) c->premerge = 2;
                 else if (premerge_queued && c->n_dx > c->dx_cap_hint) c->n_bound_overflows[1]++;     // (crass_hip_merge launches its own)
             } else {
@@ -1351,7 +1396,8 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     if (!c->have_reads) return CRASS_ERR_STATE;
     (void)hipSetDevice(c->device);
     (void)c->wait_bulk();               // (copies of the previous step: their records are dropped below)
-    c->bulk_status = CRASS_OK;
+    (void)c->wait_dx();                 // (... and the distinct list's: the engines read buffers this scan rewrites)
+    c->bulk_status = CRASS_OK; c->dx_status = CRASS_OK;
     quiesce_worker(c);
     c->have_pass1 = c->have_merge = c->have_pass2 = false;
     c->dm.active = false;
@@ -1684,7 +1730,11 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
     M.h_st = d.h_st.p; M.h_root = d.h_root.p; M.h_blank = d.h_blank.p;
     // the host view of this merge is assembled on the device too (k_dmx_*), unless this context only reports its own
     // candidates' tokens (ranks > 0 of a group)
-    M.x_on = (!c->env.no_device_view && !c->host_view_light && n <= (1u << 20)) ? 1u : 0u;
+    // — and only where the host's build would be on the critical path: a rank of a multi-rank job (its shard's pass 2 is shorter
+    // than the 0.6 ms the host needs for 42 k tokens).  A single context hides the host's build behind its own pass 2 (1.5 ms of
+    // device work at 100 M reads), and there the export's kernels, running beside pass 2's probe, cost the step 0.08-0.1 ms
+    // (4.65 vs 4.73-4.77 ms, same box, profiles/NOTES_r04.md): CRASS_DEVICE_VIEW=1 forces the export there (tests, A/B).
+    M.x_on = (!c->env.no_device_view && !c->host_view_light && n <= (1u << 20) && (c->xchg.active || c->env.force_device_view)) ? 1u : 0u;
     if (M.x_on) {
         if (!d.view_stream) {
             // lowest priority: the export fills whatever the merge's own kernels and pass 2's probe leave idle (at equal priority
@@ -1770,6 +1820,18 @@ static int device_merge(crass_hip_ctx *c, const char *dx_chars, const uint16_t *
     return device_merge_commit(c, n_tok, hx_chars, hx_len);
 }
 
+// the distinct list on the host, complete: the engine copies have landed and the strings' hashes are there (the host-merge
+// forms want them; with the list brought over by DMA they are computed here, on the rare paths that need them)
+static int ensure_host_distinct(crass_hip_ctx *c, bool want_hash)
+{
+    if (const int ws = c->wait_dx()) return ws;
+    if (want_hash && !c->dx_hash_valid) {
+        for (uint64_t j = 0; j < c->n_dx; j++) c->h_dx_hash.p[j] = TokenTable::hash(c->h_dx_chars.p + j * (size_t)c->dr_stride, c->h_dx_len.p[j]);
+        c->dx_hash_valid = true;
+    }
+    return CRASS_OK;
+}
+
 // host merge after all (the device path reported a condition it does not handle)
 static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n_global,
                              uint64_t my_offset, double t0);
@@ -1792,6 +1854,7 @@ static int host_merge_fallback(crass_hip_ctx *c)
         HIPCHK(c, hipMemcpy(gl.data(), d.g_len.p, gl.size() * 2, hipMemcpyDeviceToHost));
         return merge_global_host(c, gc.data(), gl.data(), c->dr_stride, d.n_global, d.my_off, t0);
     }
+    if (const int ds = ensure_host_distinct(c, true)) return ds;
     if (!merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
                              c->prm.kmer_clust_size))
         merge_candidates(c->merge, c->cand_dr(), c->cand_dr_len(), c->dr_stride, c->n_cand(), c->prm.kmer_clust_size);
@@ -1863,6 +1926,7 @@ static int build_host_merge(crass_hip_ctx *c)
     // (the gathered form too: the global distinct list and every gathered row's rank in it were written to pinned memory
     // by the de-duplication kernels, which the host has waited for before it committed the merge)
     const double tb00 = now_ms();
+    if (const int ws = c->wait_dx()) { d.br.hip = c->last_hip; return ws; }      // (the candidates' indices and the distinct strings: DMA copies)
     const uint32_t *cmap = c->h_dmap.p;
     if (d.global) {                                     // own candidate -> own distinct string -> its rank in the global list
         d.cand_map.resize(d.n_cand);
@@ -1983,6 +2047,7 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
     }
 host_path:
     c->dm_prev_local = false;
+    if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens) { if (const int ds = ensure_host_distinct(c, true)) return ds; }
     if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens &&
         merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
                             c->prm.kmer_clust_size))
@@ -2060,6 +2125,7 @@ int crass_hip_get_distinct(crass_hip_ctx *c, crass_distinct *o)
     ensure_distinct(c);
     o->dr_stride = c->dr_stride;
     if (c->dense.active && c->have_dev_tokens) {
+        if (const int ds = c->wait_dx()) return ds;
         o->n_distinct = c->n_dx; o->dr_len = c->h_dx_len.p; o->dr_chars = c->h_dx_chars.p;
         o->n_candidates = c->dense.n; o->cand_distinct = c->h_dmap.p;
     } else {
@@ -2077,6 +2143,7 @@ static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint1
     ensure_distinct(c);
     const bool dev = c->dense.active && c->have_dev_tokens;
     const uint64_t my_nd = dev ? c->n_dx : c->dx_len.size();
+    if (dev) { if (const int ds = c->wait_dx()) return ds; }
     const uint32_t *my_map = dev ? c->h_dmap.p : c->dx_map.data();
     const size_t my_n = dev ? (size_t)c->dense.n : c->dx_map.size();
     if (my_offset + my_nd > n_global) {

@@ -21,6 +21,9 @@ def ca():
 
 
 def run(ca, seqs, **env):
+    # (a single context builds the view on the host by default — it is hidden behind its own pass 2; CRASS_DEVICE_VIEW=1 makes it
+    # take the path a rank of a multi-rank job takes)
+    env = dict({"CRASS_DEVICE_VIEW": "1"}, **env)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update({k: str(v) for k, v in env.items()})
     try:
@@ -80,7 +83,12 @@ def test_repeated_steps_on_one_context(ca):
     spec = ca.synth_spec(read_len=L, crispr_per_million=30000)
     words = ca.synth_packed(spec, 0, n)
     views = []
-    with ca.SearchEngine() as eng:
+    os.environ["CRASS_DEVICE_VIEW"] = "1"
+    try:
+        eng_ctx = ca.SearchEngine()
+    finally:
+        os.environ.pop("CRASS_DEVICE_VIEW", None)
+    with eng_ctx as eng:
         eng.load_packed_uniform(words, n, L)
         for _ in range(4):
             eng.seed_scan(fetch=False)

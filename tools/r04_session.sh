@@ -31,8 +31,8 @@ if has bench; then
   timeout 400 python bench.py --config 1 --cpu-sample 0 --e2e-reads 0 > $out/bench_c1.json 2> $out/bench_c1.err
   timeout 400 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --e2e-reads 0 --alternate > $out/bench_c2_alternate.json 2> $out/bench_c2_alternate.err
   timeout 400 python bench.py --gpus 2 --local-copies --cpu-sample 0 --steps 20 > $out/bench_group2_shared.json 2> $out/bench_group2_shared.err
-  CRASS_NO_DEVICE_VIEW=1 timeout 400 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --e2e-reads 0 --single-shots 0 > $out/bench_c2_host_view.json 2> $out/bench_c2_host_view.err
-  summ $out/bench_c2_driver_style.json $out/bench_c1.json $out/bench_c2_alternate.json $out/bench_group2_shared.json $out/bench_c2_host_view.json
+  CRASS_DEVICE_VIEW=1 timeout 400 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --e2e-reads 0 --single-shots 0 > $out/bench_c2_device_view.json 2> $out/bench_c2_device_view.err
+  summ $out/bench_c2_driver_style.json $out/bench_c1.json $out/bench_c2_alternate.json $out/bench_group2_shared.json $out/bench_c2_device_view.json
 fi
 if has prof; then
   cd /tmp; export TMPDIR=/tmp
