@@ -1990,20 +1990,51 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t s
     return result;
 }
 
-__global__ __launch_bounds__(WAVE) void k_survivor_lanes(DevReads R, DevParams P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
+// SL_WAVES waves per block.  A third of the survivors are real CRISPR reads (scan, extension, QC, orientation: the whole
+// searchCore), the rest are spurious seed hits that leave after one window — and in slot order every wave holds ~21 of the former,
+// so every wave runs for as long as its slowest lane with a third of its lanes busy.  The block therefore deals its 64 x SL_WAVES
+// slots out by expected work: reads with at least two hinted lattice seeds (a repeat with a copy one unit on gives several; a
+// chance match gives one) first, in slot order, then the others.  Each lane still writes its own slot: the result arrays do not
+// notice.  PMC at 100 M reads: 318 M -> 224 M VALU wave instructions (8-wave blocks); 4 waves per block is the measured optimum
+// (590 us in slot order with one wave per block -> 550; 8 waves 593, 16 waves 754: a block holds its LDS until its slowest wave ends).
+#define SL_WAVES 4
+__global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, DevParams P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                                          uint64_t n_max, SurvOut *out, char *dr_chars, uint32_t dr_stride,
                                                          uint32_t *ss_pool, uint32_t ss_cap, uint8_t *found_flag,
-                                                         const uint32_t *seed_hint, uint32_t words_per_read, DevMerge IM, int do_init)
+                                                         const uint32_t *seed_hint, uint32_t words_per_read, DevMerge IM, int do_init, int regroup)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sl_lds[];
-    const int lane = threadIdx.x;
+    __shared__ uint16_t sl_perm[WAVE * SL_WAVES];
+    __shared__ uint32_t sl_cnt[SL_WAVES];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     // the tables of the merge that follows this stage are cleared on the way (stores next to an issue-bound kernel)
-    if (do_init) dm_init_slice(IM, blockIdx.x * (uint64_t)WAVE + lane, (uint64_t)gridDim.x * WAVE);
+    if (do_init) dm_init_slice(IM, blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
     uint64_t n_surv = *d_n_surv;
     if (n_surv > n_max) n_surv = n_max;
-    const uint64_t s = blockIdx.x * (uint64_t)WAVE + lane;
-    uint32_t *lw = sl_lds + lane;                                      // [word][lane]
-    uint16_t *lss = reinterpret_cast<uint16_t *>(sl_lds + (size_t)(words_per_read + 5) * WAVE) + lane;   // [entry][lane]
+    uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (regroup) {
+        bool heavy = false;
+        if (s < n_surv && seed_hint) {
+            const uint64_t r0 = surv_idx[s];
+            heavy = !rd_is_exc(R, r0) && __popc(seed_hint[r0]) >= 2;
+        }
+        const uint64_t hb = __ballot(heavy);
+        if (lane == 0) sl_cnt[wv] = (uint32_t)__popcll(hb);
+        __syncthreads();
+        uint32_t heavy_before = 0, heavy_total = 0;
+#pragma unroll
+        for (int k = 0; k < SL_WAVES; k++) { const uint32_t c = sl_cnt[k]; heavy_total += c; if (k < wv) heavy_before += c; }
+        const uint32_t below = (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+        const uint32_t pos = heavy ? heavy_before + below
+                                   : heavy_total + ((uint32_t)wv * WAVE - heavy_before) + ((uint32_t)lane - below);
+        sl_perm[pos] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        s = blockIdx.x * (uint64_t)blockDim.x + sl_perm[threadIdx.x];
+    }
+    const size_t wave_words = (size_t)(words_per_read + 5) * WAVE + ((size_t)ss_cap * WAVE + 1) / 2;      // this wave's part of the LDS
+    uint32_t *wbase = sl_lds + (size_t)wv * wave_words;
+    uint32_t *lw = wbase + lane;                                       // [word][lane]
+    uint16_t *lss = reinterpret_cast<uint16_t *>(wbase + (size_t)(words_per_read + 5) * WAVE) + lane;   // [entry][lane]
     if (s >= n_surv) return;
     const uint64_t r = surv_idx[s];
     if (rd_is_exc(R, r)) {                              // raw-byte read: the wave kernel's exception pass (err == 5)
@@ -2112,10 +2143,17 @@ hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const ui
     if (n_surv_max == 0) return init_merge ? hipErrorNotSupported : hipSuccess;
     if (!R.stride_words || R.stride_words > 16 || ss_cap > 64) return hipErrorNotSupported;
     const uint32_t wpr = R.stride_words;
-    const size_t lds = (size_t)(wpr + 5) * WAVE * 4 + (size_t)ss_cap * WAVE * 2;
-    CRASS_LAUNCH(k_survivor_lanes, dim3((unsigned)((n_surv_max + WAVE - 1) / WAVE)), dim3(WAVE), lds, st, R, P, surv_idx, d_n_surv,
+    const size_t wave_words = (size_t)(wpr + 5) * WAVE + ((size_t)ss_cap * WAVE + 1) / 2;
+    const size_t lds = wave_words * 4 * SL_WAVES;
+    static const bool no_regroup = getenv("CRASS_SURV_NO_REGROUP") != nullptr;      // A/B switch: lanes in slot order
+    const unsigned bt = WAVE * SL_WAVES;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor_lanes), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    CRASS_LAUNCH(k_survivor_lanes, dim3((unsigned)((n_surv_max + bt - 1) / bt)), dim3(bt), lds, st, R, P, surv_idx, d_n_surv,
                        n_surv_max, out, dr_chars, dr_stride, ss_pool, ss_cap, found_flag, seed_hint, wpr, init_merge ? *init_merge : DevMerge{},
-                       init_merge ? 1 : 0);
+                       init_merge ? 1 : 0, (seed_hint && !no_regroup) ? 1 : 0);
     return hipGetLastError();
 }
 
