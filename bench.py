@@ -587,7 +587,6 @@ def _e2e_cli(ca, spec, L, n):
     on disk -> `crass-hip -g -o DIR` (read + parse + pack + H2D + pass 1 + merge + pass 2 + hand-off + consensus + spacer graphs +
     .crispr / Group_*.fa written), wall clock of the whole process incl. HIP start-up, best of 2; peak RSS of the child."""
     import numpy as np
-    import resource
     import shutil
     import tempfile
     cli = os.path.join(ROOT, "crass_amd", "crass-hip")
@@ -612,17 +611,20 @@ def _e2e_cli(ca, spec, L, n):
             os.makedirs(od)
             log = os.path.join(td, "stdout.txt")
             t0 = time.perf_counter()
+            # (peak resident set: the command line's own VmHWM, printed with its stage times — the child's ru_maxrss would start from
+            # this process's resident set at fork time)
             with open(log, "wb") as lf:
-                p = subprocess.Popen([cli, "-g", "-o", od, fa], stdout=lf, stderr=subprocess.DEVNULL)
-                _, status, ru = os.wait4(p.pid, 0)               # (this child's own peak resident set, not the maximum over all children)
+                p = subprocess.run([cli, "-g", "-o", od, fa], stdout=lf, stderr=subprocess.STDOUT, env=dict(os.environ, CRASS_TIMING="1"))
             walls.append(time.perf_counter() - t0)
-            p.returncode = os.waitstatus_to_exitcode(status) if hasattr(os, "waitstatus_to_exitcode") else (status >> 8)
             if p.returncode != 0:
                 return {"error": "crass-hip exited %d" % p.returncode}
-            rss = max(rss, ru.ru_maxrss / 1024.0)
+            import re
             for line in open(log, "rb").read().decode().replace("\r", "\n").splitlines():
                 if "Found" in line and "reads" in line:
                     found = line.strip()
+                m = re.search(r"peak RSS (\d+) MB", line)
+                if m:
+                    rss = max(rss, float(m.group(1)))
         return {"reads": n, "wall_s": round(min(walls), 3), "reads_per_s": round(n / min(walls), 1), "walls_s": [round(x, 3) for x in walls],
                 "peak_rss_mb": round(rss, 1), "fasta_mb": round(n * (11 + L) / 1e6, 1), "found": found,
                 "note": "`crass-hip -g -o DIR file.fa`: process start + HIP init + read/parse/pack + H2D + pass 1 + merge + pass 2 + "
