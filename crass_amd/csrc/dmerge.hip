@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
                 }
                 // look before the atomic: the variants of one repeat family share most 11-mers (1 400-way contention on a
                 // few hundred addresses at 100 M reads), the owner is an early token and everybody after it only confirms
-                if (__hip_atomic_load(&M.owner[code], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > t) atomicMin(&M.owner[code], t);
-                M.codes[(uint64_t)t * M.kmax + lane] = code;
+                if (!(M.ablate & 1u) && __hip_atomic_load(&M.owner[code], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > t) atomicMin(&M.owner[code], t);
+                if (!(M.ablate & 2u)) M.codes[(uint64_t)t * M.kmax + lane] = code;
             }
         }
     }
@@ -213,6 +213,7 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
         bool gave_up = false;
         for (uint32_t spins = 0;; spins++) {
             if (valid && r == kUnres) r = __hip_atomic_load(&M.root_of[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((M.ablate & 8u) && r == kUnres) r = kNoLane;
             if (__ballot(valid && r == kUnres) == 0ull) break;
             if ((spins & 255u) == 255u) {
                 const uint32_t f = __hip_atomic_load(&M.st->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(1024) void k_dm_greedy(DevMerge M)
         if (win) root = (uint32_t)__shfl((int)r, __ffsll((unsigned long long)win) - 1);
         if (lane == 0) {
             __hip_atomic_store(&M.root_of[t], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (M.ablate & 4u) continue;
             // 4a. needle key of this member
             const uint32_t g = root + 1, w = (uint32_t)M.packed[(uint64_t)t * 4];
             const unsigned long long want = ((unsigned long long)g << 32) | w;            // g >= 1: never 0
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void k_dm_rd_bases(DevMerge M)
     const uint32_t h = hs & 0x7FFFFFFFu;
     const uint32_t cnt = claim ? M.rset_cnt[h] : 0u;
     if (cnt > M.group_cap) atomicOr(&M.st->fail, 32u);
-    const uint32_t base = block_reserve<256>(cnt, &M.st->rd_cursor);
+    const uint32_t base = block_reserve<256>(cnt, &M.hot[dm_hot(kHotRdCursor, 0)]);
     if (claim) M.rset_base[h] = base;
 }
 __global__ __launch_bounds__(256) void k_dm_rd_fill(DevMerge M)
@@ -321,18 +323,21 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
             const uint64_t w0 = shr128_lo(h0, h1, 2 * (act ? p : 0u)), w1 = shr128_hi(h1, 2 * (act ? p : 0u));
             const uint64_t wm = (o ? mrj : mfj) >> (act ? p : 0u);           // 'N' positions of the window
             uint32_t cnt = 0, base = 0;
-            if (act) {
+            if (act && !(M.ablate & 32u)) {
                 const uint32_t w = (uint32_t)w0;
                 const unsigned long long want = ((unsigned long long)g << 32) | w;
                 uint32_t h = rset_hash(g, w, M.rset_log);
                 for (;;) {
+                    // (the slot's range is requested with its key: one round trip instead of two)
                     const unsigned long long kk = M.rset_key[h];
+                    const uint32_t c_h = M.rset_cnt[h], b_h = M.rset_base[h];
                     if (kk == 0ull) break;
-                    if (kk == want) { cnt = M.rset_cnt[h]; base = M.rset_base[h]; break; }
+                    if (kk == want) { cnt = c_h; base = b_h; break; }
                     h = (h + 1) & mask;
                 }
             }
             uint64_t hits = __ballot(cnt > 0);
+            if (M.ablate & 16u) hits = 0;
             while (hits && !found) {
                 const int src = __ffsll((unsigned long long)hits) - 1;
                 hits &= hits - 1;
@@ -343,13 +348,14 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
                     const uint32_t c = c0 + lane;
                     bool hit = false;
                     if (c < cnt_s) {
-                        const uint64_t *ent = M.rents + (uint64_t)(base_s + c) * 4;
-                        const uint32_t leni = (uint32_t)ent[0] & 0xFFu;
+                        const ulonglong2 *ent = reinterpret_cast<const ulonglong2 *>(M.rents) + (uint64_t)(base_s + c) * 2;
+                        const ulonglong2 ea = ent[0], eb = ent[1];          // (the whole entry at once)
+                        const uint32_t leni = (uint32_t)ea.x & 0xFFu;
                         if (leni < lenj && p_s + leni <= lenj) {
                             uint64_t m0, m1;
                             mask128(leni, m0, m1);
                             const uint64_t lm = leni >= 64 ? ~0ull : ((1ull << leni) - 1ull);
-                            hit = (w0_s & m0) == ent[1] && (w1_s & m1) == ent[2] && (wm_s & lm) == ent[3];
+                            hit = (w0_s & m0) == ea.y && (w1_s & m1) == eb.x && (wm_s & lm) == eb.y;
                         }
                     }
                     if (__ballot(hit)) found = true;
@@ -359,11 +365,11 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
         if (lane == 0) M.blank[j] = found ? 1 : 0;
         if (!found) n_surv++;
     }
-    // (one atomic per block, see block_reserve: 9.5 k waves adding to one word were 21 us of this kernel)
+    // (one atomic per block, on the block's stripe of the counter: dm_hot, engine_internal.h)
     __shared__ uint32_t surv_w[4];
     if (lane == 0) surv_w[threadIdx.x >> 6] = n_surv;
     __syncthreads();
-    if (threadIdx.x == 0) { const uint32_t tot = surv_w[0] + surv_w[1] + surv_w[2] + surv_w[3]; if (tot) atomicAdd(&M.st->n_survivors, tot); }
+    if (threadIdx.x == 0) { const uint32_t tot = surv_w[0] + surv_w[1] + surv_w[2] + surv_w[3]; if (tot) atomicAdd(&M.hot[dm_hot(kHotSurvivors, blockIdx.x)], tot); }
 }
 
 // ---- 6a. anchor keys: every 16-mer at offset 0..7 of a pattern (see kernels.hip, pass-2 fast path).  A member that
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
     const uint32_t t = e >> 4, o = (e >> 3) & 1u, r = e & 7u;
     uint32_t slot = 0xFFFFFFFFu, my_key = 0xFFFFFFFFu, won = 0u;
     const bool in_range = t < dm_ntok(M);               // (no early return: the block meets at the end)
-    if (in_range && !M.blank[t]) {
+    if (in_range && !M.blank[t] && !(M.ablate & 512u)) {
         const uint32_t key = (uint32_t)shr128_lo(M.packed[(uint64_t)t * 4 + 2 * o], M.packed[(uint64_t)t * 4 + 2 * o + 1], 2 * r);
         const uint32_t kmask = (1u << M.kset_log) - 1u;
         const unsigned long long want = (unsigned long long)key | (1ull << 32);
@@ -386,12 +392,13 @@ __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
         bool winner = false;
         for (;;) {
             unsigned long long old = __hip_atomic_load(&M.kset_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (look first)
+            if (M.ablate & 256u) break;
             if (old == 0ull) old = atomicCAS(&M.kset_key[h], 0ull, want);
             if (old == 0ull) { winner = true; break; }
             if (old == want) break;
             h = (h + 1) & kmask;
         }
-        atomicAdd(&M.kset_cnt[h], 1u);
+        if (!(M.ablate & 64u)) atomicAdd(&M.kset_cnt[h], 1u);
         slot = winner ? (h | 0x80000000u) : h;
         if (winner) {
             my_key = key; won = 1u;
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
         }
     }
     if (in_range) M.ent_slot[e] = slot;
-    // the key count and the smallest key: one atomic each per block (see block_reserve)
+    // the key count and the smallest key: one atomic each per block, on the block's stripe (dm_hot)
     __shared__ uint32_t kc_w[4], km_w[4];
     const int lane = threadIdx.x & 63;
     const uint32_t cw = (uint32_t)__popcll(__ballot(won != 0u));
@@ -410,9 +417,9 @@ __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t tot = kc_w[0] + kc_w[1] + kc_w[2] + kc_w[3];
-        if (tot) {
-            atomicAdd(&M.st->n_keys, tot);
-            atomicMin(&M.st->k0, min(min(km_w[0], km_w[1]), min(km_w[2], km_w[3])));
+        if (tot && !(M.ablate & 128u)) {
+            atomicAdd(&M.hot[dm_hot(kHotKeys, blockIdx.x)], tot);
+            atomicMin(&M.hot[dm_hot(kHotK0, blockIdx.x)], min(min(km_w[0], km_w[1]), min(km_w[2], km_w[3])));
         }
     }
 }
@@ -451,20 +458,25 @@ __global__ __launch_bounds__(1024) void k_dm_key_bases_insert(DevMerge M)
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tok = e >> 4;
     // every thread derives the table shape from the key count (a handful of scalar instructions); thread 0 records it
-    uint32_t ls, mode;
-    dm_table_params(M.st->n_keys, M.tab_log_alloc, ls, mode);
+    uint32_t ls, mode, n_keys = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kDmHotStripes; q++) n_keys += M.hot[dm_hot(kHotKeys, q)];          // (uniform addresses: scalar loads)
+    dm_table_params(n_keys, M.tab_log_alloc, ls, mode);
     if (e == 0) {
-        if (!ls || M.st->n_keys == 0) atomicOr(&M.st->fail, 2u);
-        M.st->log_size = ls; M.st->tab_mode = mode; M.st->n_patterns = 2 * M.st->n_survivors;
+        uint32_t n_surv = 0, k0 = 0xFFFFFFFFu;
+        for (uint32_t q = 0; q < kDmHotStripes; q++) { n_surv += M.hot[dm_hot(kHotSurvivors, q)]; k0 = min(k0, M.hot[dm_hot(kHotK0, q)]); }
+        if (!ls || n_keys == 0) atomicOr(&M.st->fail, 2u);
+        M.st->log_size = ls; M.st->tab_mode = mode; M.st->n_survivors = n_surv; M.st->n_patterns = 2 * n_surv;
+        M.st->n_keys = n_keys; M.st->k0 = k0;
     }
     uint32_t hs = 0xFFFFFFFFu;
     if (tok < dm_ntok(M)) hs = M.ent_slot[e];
     const bool claim = hs != 0xFFFFFFFFu && (hs & 0x80000000u);      // the key's claimant allocates its entry range
     const uint32_t h = hs & 0x7FFFFFFFu;
-    const uint32_t ebase = block_reserve<1024>(claim ? M.kset_cnt[h] : 0u, &M.st->ent_cursor);
+    const uint32_t ebase = (M.ablate & 2048u) ? 0u : block_reserve<1024>(claim ? M.kset_cnt[h] : 0u, &M.hot[dm_hot(kHotEntCursor, 0)]);
     if (!claim) return;
     M.kset_base[h] = ebase;
-    if (!ls || (M.st->fail & ~2u)) return;
+    if (!ls || (M.st->fail & ~2u) || (M.ablate & 1024u)) return;
     uint32_t cur = (uint32_t)M.kset_key[h];
     if (mode == 2) {
         // key sets beyond the LDS tiers: the exact table is probed in L2, behind a 2^20-bit Bloom filter in LDS
@@ -967,7 +979,7 @@ static __device__ __forceinline__ void dv_candidates(const DevMerge &M, WordFn w
         if (c < cnt_s) {
             const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 2;
             const uint64_t *ent2 = M.ents + ((uint64_t)M.ent_cap + base_s + c) * 2;
-            const uint64_t e0 = ent[0];
+            const uint64_t e0 = ent[0], e1 = ent[1], f0 = ent2[0], f1 = ent2[1];      // (both planes requested at once)
             const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
             if (a >= rr && a - rr + len <= L) {
                 const uint32_t start = a - rr;
@@ -981,9 +993,8 @@ static __device__ __forceinline__ void dv_candidates(const DevMerge &M, WordFn w
                 const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
                 uint64_t m0, m1;
                 mask128(len, m0, m1);
-                bool eq = (v0 & m0) == ent[1];
-                uint64_t e_mask = 0;
-                if (eq) { eq = (v1 & m1) == ent2[0]; e_mask = ent2[1]; }
+                bool eq = (v0 & m0) == e1 && (v1 & m1) == f0;
+                const uint64_t e_mask = f1;
                 if (eq && raw) {
                     uint64_t rm = 0;
                     bool other = false;
@@ -1017,9 +1028,11 @@ static __device__ __forceinline__ void dv_probe(const DevMerge &M, uint32_t V, u
     const unsigned long long want = (unsigned long long)V | (1ull << 32);
     uint32_t s = kset_hash(V, M.kset_log);
     for (;;) {
+        // (the slot's range is requested with its key — three loads in flight, one round trip — instead of after the comparison)
         const unsigned long long kk = M.kset_key[s];
+        const uint32_t c_s = M.kset_cnt[s], b_s = M.kset_base[s];
         if (kk == 0ull) break;
-        if (kk == want) { cnt = M.kset_cnt[s]; base = M.kset_base[s]; break; }
+        if (kk == want) { cnt = c_s; base = b_s; break; }
         s = (s + 1) & kmask;
     }
 }
@@ -1036,7 +1049,7 @@ static __device__ __forceinline__ const uint8_t *dv_raw(const DevReads &R, uint6
 // round, DV_GL lanes each — the kernel is latency bound (index -> words -> key set -> entries: four dependent round trips
 // per read, 18 of 64 lanes busy in the one-read form), and the rounds of three reads overlap; the candidate comparison stays
 // 64 lanes wide, one hit window at a time.  100 M reads (400 k flagged): 440 us in the one-read form.
-template <bool SHORT>
+template <bool SHORT, int U>
 __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
                                                     uint32_t *info_by_slot, uint32_t *pid_by_slot)
 {
@@ -1050,19 +1063,31 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
     if (SHORT) {
         const int gi = lane / DV_GL, pl = lane % DV_GL;                     // (lane 63: group 3 = idle)
         const uint32_t L = R.uniform_len, nw = (L + 15) >> 4, h_max = (L - 16) >> 3;
-        for (uint64_t k0 = wave * DV_G; k0 < n; k0 += n_waves * DV_G) {
-            const uint64_t k = k0 + (uint64_t)gi;
-            const bool have = gi < DV_G && k < n;
-            const uint64_t r = have ? idx[k] : 0;
-            uint32_t *rw = rw_all[wv][gi < DV_G ? gi : 0];
-            if (have) {
-                const uint32_t *g = R.packed + dm_rd_off(R, r);
-                if ((uint32_t)pl < nw) rw[pl] = g[pl];
-                if ((uint32_t)pl == nw) rw[pl] = 0u;
-            }
+        const bool grp = gi < DV_G;
+        const uint64_t stride = n_waves * DV_G;
+        const int g0 = (grp ? gi : 0) * DV_GL;                              // first lane of this lane's group
+        const uint64_t gmask = grp ? (((1ull << DV_GL) - 1ull) << g0) : 0ull;
+        uint32_t *rw = rw_all[wv][grp ? gi : 0];
+        const ulonglong2 *ents1 = reinterpret_cast<const ulonglong2 *>(M.ents), *ents2 = ents1 + M.ent_cap;
+        // The round's two leading round trips (index -> packed words) are taken one round ahead: while this round's reads are
+        // probed and compared, the next round's words and the index of the round after are already in flight (software
+        // pipeline in registers).
+        uint64_t k = wave * DV_G + (uint64_t)gi;
+        bool have = grp && k < n;
+        uint64_t r = have ? idx[k] : 0;
+        uint32_t wreg = (have && (uint32_t)pl < nw) ? R.packed[dm_rd_off(R, r) + pl] : 0u;
+        uint64_t k_n = k + stride;
+        bool have_n = grp && k_n < n;
+        uint64_t r_n = have_n ? idx[k_n] : 0;
+        for (uint64_t k0 = wave * DV_G; k0 < n; k0 += stride) {
+            if (have && (uint32_t)pl <= nw) rw[pl] = wreg;                  // (word nw = 0: wreg is 0 there)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t wreg_n = (have_n && (uint32_t)pl < nw) ? R.packed[dm_rd_off(R, r_n) + pl] : 0u;
+            const uint64_t k_nn = k_n + stride;
+            const bool have_nn = grp && k_nn < n;
+            const uint64_t r_nn = have_nn ? idx[k_nn] : 0;
             uint32_t cnt = 0, base = 0;
             if (have && (uint32_t)pl <= h_max) {
                 const uint32_t wi = (uint32_t)pl >> 1;
@@ -1070,17 +1095,15 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                 dv_probe(M, (pl & 1) ? ((lo >> 16) | (hi << 16)) : lo, kmask, cnt, base);
             }
             // The three reads of the round walk their hit windows SIDE BY SIDE: read g's 21 lanes compare the candidates of
-            // read g's next hit window (21 at a time) while the other two groups do the same for theirs — as many dependent
-            // {entry load, compare, reduce} steps per round as the busiest read has windows (~4), not as the three have together
-            // (~12, a quarter of the lanes busy).  be / bl / bp: the group's best so far, the same value in each of its lanes.
+            // read g's next hit window (42 at a time, two per lane, both planes of both entries requested at once) while the
+            // other two groups do the same for theirs — as many dependent {entry load, compare, reduce} steps per round as the
+            // busiest read has windows (~4), not as the three have together (~12, a quarter of the lanes busy).
+            // be / bl / bp: the group's best so far, the same value in each of its lanes.
             const uint8_t *raw = nullptr;                                    // exception reads (rare): the read's raw bytes
             if (R.n_exc && have) raw = dv_raw(R, r);
             const uint64_t hits_all = __ballot(cnt > 0);
-            uint32_t my = gi < DV_G ? (uint32_t)(hits_all >> (gi * DV_GL)) & ((1u << DV_GL) - 1u) : 0u;      // this read's hit windows
+            uint32_t my = grp ? (uint32_t)(hits_all >> (gi * DV_GL)) & ((1u << DV_GL) - 1u) : 0u;      // this read's hit windows
             uint32_t be = 0xFFFFFFFFu, bl = 0, bp = 0;
-            const int g0 = (gi < DV_G ? gi : 0) * DV_GL;                     // first lane of this lane's group
-            const uint64_t gmask = gi < DV_G ? (((1ull << DV_GL) - 1ull) << g0) : 0ull;
-            const uint32_t *rws = rw_all[wv][gi < DV_G ? gi : 0];
             while (__ballot(my != 0u)) {
                 bool act = my != 0u;
                 const int wsrc = act ? __ffs((int)my) - 1 : 0;               // the group's next hit window
@@ -1088,29 +1111,36 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                 const uint32_t a = 8u * (uint32_t)wsrc;
                 if (act && be <= a + 15u) { act = false; my = 0u; }          // no later window of this read can end earlier
                 const uint32_t cnt_s = (uint32_t)__shfl((int)cnt, g0 + wsrc), base_s = (uint32_t)__shfl((int)base, g0 + wsrc);
-                for (uint32_t c0 = 0; __ballot(act && c0 < cnt_s); c0 += DV_GL) {
-                    const uint32_t c = c0 + (uint32_t)pl;
+                for (uint32_t c0 = 0; __ballot(act && c0 < cnt_s); c0 += U * DV_GL) {
                     uint32_t cand = 0xFFFFFFFFu, cpid = 0;                   // (end << 8) | (255 - len): smaller is better
-                    if (act && c < cnt_s) {
-                        const uint64_t *ent = M.ents + (uint64_t)(base_s + c) * 2;
-                        const uint64_t *ent2 = M.ents + ((uint64_t)M.ent_cap + base_s + c) * 2;
-                        const uint64_t e0 = ent[0];
+                    uint32_t cq[U];
+                    bool vq[U];
+                    ulonglong2 e1[U], e2[U];
+#pragma unroll
+                    for (int q = 0; q < U; q++) {                            // (entry 0 stands in for a lane without a candidate)
+                        cq[q] = c0 + (uint32_t)(q * DV_GL + pl);
+                        vq[q] = act && cq[q] < cnt_s;
+                        const uint32_t ei = vq[q] ? base_s + cq[q] : 0u;
+                        e1[q] = ents1[ei]; e2[q] = ents2[ei];
+                    }
+#pragma unroll
+                    for (int q = 0; q < U; q++) {
+                        const uint64_t e0 = e1[q].x;
                         const uint32_t rr = (uint32_t)e0 & 7u, len = ((uint32_t)e0 >> 3) & 0x7Fu;
-                        if (a >= rr && a - rr + len <= L) {
+                        if (vq[q] && a >= rr && a - rr + len <= L) {
                             const uint32_t start = a - rr;
                             const uint32_t w0 = start >> 4, sh = (start & 15u) * 2u;
                             uint32_t x[5];
 #pragma unroll
-                            for (int q = 0; q < 5; q++) x[q] = rws[min(w0 + q, nw)];
+                            for (int i = 0; i < 5; i++) x[i] = rw[min(w0 + i, nw)];
                             uint32_t y[4];
 #pragma unroll
-                            for (int q = 0; q < 4; q++) y[q] = sh ? ((x[q] >> sh) | (x[q + 1] << (32 - sh))) : x[q];
+                            for (int i = 0; i < 4; i++) y[i] = sh ? ((x[i] >> sh) | (x[i + 1] << (32 - sh))) : x[i];
                             const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
                             uint64_t m0, m1;
                             mask128(len, m0, m1);
-                            bool eq = (v0 & m0) == ent[1];
-                            uint64_t e_mask = 0;
-                            if (eq) { eq = (v1 & m1) == ent2[0]; e_mask = ent2[1]; }
+                            bool eq = (v0 & m0) == e1[q].y && (v1 & m1) == e2[q].x;
+                            const uint64_t e_mask = e2[q].y;
                             if (eq && raw) {
                                 uint64_t rm = 0;
                                 bool other = false;
@@ -1120,7 +1150,10 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                                 }
                                 eq = !other && rm == e_mask;
                             } else if (eq) eq = e_mask == 0ull;
-                            if (eq) { cand = ((start + len) << 8) | (255u - len); cpid = (uint32_t)(e0 >> 32); }
+                            if (eq) {
+                                const uint32_t cv = ((start + len) << 8) | (255u - len);
+                                if (cv < cand) { cand = cv; cpid = (uint32_t)(e0 >> 32); }
+                            }
                         }
                     }
                     // minimum over the group's lanes (ties: any lane — equal (end, len) means equal strings)
@@ -1144,6 +1177,8 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                 pid_by_slot[k] = bp;
             }
             __builtin_amdgcn_wave_barrier();                // the next round reuses rw
+            k = k_n; have = have_n; r = r_n; wreg = wreg_n;
+            k_n = k_nn; have_n = have_nn; r_n = r_nn;
         }
         return;
     }
@@ -1217,8 +1252,10 @@ hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t
     const bool shortr = R.uniform_len >= 16 && ((R.uniform_len - 16) >> 3) < DV_GL && ((R.uniform_len + 15) >> 4) <= DV_MAXW && !dv_one;
     uint64_t nb = shortr ? (n_max + 4 * DV_G - 1) / (4 * DV_G) : (n_max + 3) / 4;
     if (nb > 8192) nb = 8192;
-    if (shortr) CRASS_LAUNCH(k_dm_verify<true>, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
-    else CRASS_LAUNCH(k_dm_verify<false>, dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    static const bool dv_pair = getenv("CRASS_DV_SINGLE") == nullptr;  // two candidates per lane and step (CRASS_DV_SINGLE: the A/B switch, one)
+    if (shortr && dv_pair) CRASS_LAUNCH((k_dm_verify<true, 2>), dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    else if (shortr) CRASS_LAUNCH((k_dm_verify<true, 1>), dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
+    else CRASS_LAUNCH((k_dm_verify<false, 1>), dim3((unsigned)nb), dim3(256), 0, st, R, M, idx, d_n, n_max, info_by_slot, pid_by_slot);
     return hipGetLastError();
 }
 

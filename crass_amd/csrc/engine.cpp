@@ -166,6 +166,7 @@ struct EnvSwitches {
     bool no_lookback = false, no_pos_hints = false, merge_profile = false, no_lane_kernel = false;
     bool host_merge = false, no_speculation = false, exc_separate = false, dm_inject_fail = false, dm_init_late = false;
     bool no_presize = false;                         // A/B switch: no first-call bounds / pool sizing at crass_hip_load_reads
+    bool dd_full_table = false;                      // A/B switch: pass 1's de-duplication table sized for the survivor slots (the round-3 size)
     bool no_device_view = false;                     // A/B switch: the host rebuilds crass_merge_view from root_of / blank (the round-3 path)
     bool force_device_view = false;                  // CRASS_DEVICE_VIEW=1: the device assembles it for a single context too (default: multi-rank only)
     uint32_t view_group_cap = 32768;                 // groups beyond this many members are ranked by the host (CRASS_VIEW_GROUP_CAP)
@@ -180,7 +181,7 @@ struct EnvSwitches {
         no_lookback = on("CRASS_NO_LOOKBACK"); no_pos_hints = on("CRASS_NO_POS_HINTS");
         merge_profile = on("CRASS_MERGE_PROFILE"); no_lane_kernel = on("CRASS_NO_LANE_KERNEL"); host_merge = on("CRASS_HOST_MERGE");
         no_speculation = on("CRASS_NO_SPECULATION"); exc_separate = on("CRASS_EXC_SEPARATE"); dm_init_late = on("CRASS_DM_INIT_LATE");
-        dm_inject_fail = on("CRASS_DM_INJECT_FAIL"); no_presize = on("CRASS_NO_PRESIZE"); no_device_view = on("CRASS_NO_DEVICE_VIEW"); force_device_view = on("CRASS_DEVICE_VIEW");
+        dm_inject_fail = on("CRASS_DM_INJECT_FAIL"); no_presize = on("CRASS_NO_PRESIZE"); no_device_view = on("CRASS_NO_DEVICE_VIEW"); dd_full_table = on("CRASS_DD_FULL_TABLE"); force_device_view = on("CRASS_DEVICE_VIEW");
         view_group_cap = 32768; if (const char *e = getenv("CRASS_VIEW_GROUP_CAP")) view_group_cap = (uint32_t)std::max(1, atoi(e));
         row_cap = 256; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
         dm_group_cap = 16384; if (const char *e = getenv("CRASS_DM_GROUP_CAP")) dm_group_cap = (uint32_t)std::max(1, atoi(e));
@@ -356,7 +357,7 @@ struct crass_hip_ctx {
         DevBuf<uint64_t> packed, tmask; DevBuf<uint32_t> codes, owner, root_of, pat_token;
         DevBuf<uint32_t> kset_u32, ent_slot, anchor_tab, anchor_fp; DevBuf<uint8_t> blank; DevBuf<uint64_t> ents, rents; DevBuf<uint32_t> rset_u32, rd_slot;
         DevBuf<unsigned long long> rset_key, bk_key;
-        DevBuf<unsigned long long> kset_key; DevBuf<DevMergeState> st;
+        DevBuf<unsigned long long> kset_key; DevBuf<DevMergeState> st; DevBuf<uint32_t> hot;
         PinBuf<DevMergeState> h_st; PinBuf<uint32_t> h_root; PinBuf<uint8_t> h_blank;
         std::vector<uint32_t> gid_tmp;
         DevMerge M{};
@@ -392,7 +393,7 @@ struct crass_hip_ctx {
             x_u32.release(); x_members.release(); x_tile.release(); x_blob.release(); x_tot.release(); x_htot.release(); h_view.release();
             packed.release(); tmask.release(); bk_key.release(); codes.release(); owner.release(); root_of.release();
             pat_token.release(); kset_u32.release(); ent_slot.release(); anchor_tab.release(); anchor_fp.release();
-            blank.release(); ents.release(); rents.release(); rset_u32.release(); rd_slot.release(); rset_key.release(); kset_key.release(); st.release(); h_st.release(); h_root.release(); h_blank.release();
+            blank.release(); ents.release(); rents.release(); rset_u32.release(); rd_slot.release(); rset_key.release(); kset_key.release(); st.release(); hot.release(); h_st.release(); h_root.release(); h_blank.release();
             g_chars.release(); gx_chars.release(); g_len.release(); gx_len.release(); g_keys.release(); g_first.release(); g_slot.release();
             g_rep.release(); g_prefix.release(); g_bsum.release(); g_hash.release(); g_mask.release(); g_idx.release();
             h_gmap.release(); h_gx_chars.release(); h_gx_len.release(); h_gx_hash.release();
@@ -446,7 +447,7 @@ struct crass_hip_ctx {
     int timing_level = 1;
     // single-pass compaction (k_mask_compact_lb): status words + ticket counter shared by every launch of the context
     DevBuf<unsigned long long> lb_status; DevBuf<uint32_t> lb_ticket; PinBuf<uint32_t> h_lb_fail;
-    uint32_t lb_base = 0, lb_epoch = 0;
+    uint32_t lb_epoch = 0;
     bool lb_on = true;
     // nullptr: use the three-kernel form (switched off, or allocation failed)
     const Lookback *next_lookback(uint64_t n_words, Lookback *out)
@@ -467,12 +468,11 @@ struct crass_hip_ctx {
         if (!lb_ticket.p) {
             if (lb_ticket.ensure(4) != hipSuccess || h_lb_fail.ensure(4) != hipSuccess) return nullptr;
             if (hipMemsetAsync(lb_ticket.p, 0, 16, stream) != hipSuccess) return nullptr;
-            h_lb_fail.p[0] = 0; lb_base = 0;
+            h_lb_fail.p[0] = 0;
         }
         lb_epoch = (lb_epoch + 1) & 0x3FFFFFFFu;
         if (lb_epoch == 0) lb_epoch = 1;
-        out->status = lb_status.p; out->ticket = lb_ticket.p; out->ticket_base = lb_base; out->epoch = lb_epoch; out->fail = h_lb_fail.p;
-        lb_base += (uint32_t)n_tiles;
+        out->status = lb_status.p; out->ticket = lb_ticket.p; out->epoch = lb_epoch; out->fail = h_lb_fail.p;
         return out;
     }
     // allocation only (crass_hip_load_reads): hands out no tickets — a launch that never runs must not move the ticket base
@@ -487,7 +487,7 @@ struct crass_hip_ctx {
         if (!lb_ticket.p) {
             if (lb_ticket.ensure(4) != hipSuccess || h_lb_fail.ensure(4) != hipSuccess) return;
             if (hipMemsetAsync(lb_ticket.p, 0, 16, stream) != hipSuccess) return;
-            h_lb_fail.p[0] = 0; lb_base = 0;
+            h_lb_fail.p[0] = 0;
         }
     }
     // after a synchronisation: a look-back spin that gave up invalidates the stage (never expected)
@@ -500,6 +500,7 @@ struct crass_hip_ctx {
     }
     // the device merge queued by the seed scan itself, right behind pass 1 (no host round trip in between): sized by a
     // bound learnt from the previous merge, adopted by crass_hip_merge when the counts turn out to fit
+    bool dd_full_table = false;                         // a de-duplication table sized for the distinct strings overflowed once
     uint32_t dx_cap_hint = 0; bool dm_prev_local = false; int premerge = 0;      // premerge: 0 none, 2 queued and valid
     // a merge sized ahead of pass 1's survivor stage, whose kernel cleared the merge's tables (device_merge_prepare)
     uint64_t dm_prepared_n = 0; const char *dm_prepared_src = nullptr;
@@ -1170,6 +1171,15 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     const uint64_t n_words = (n_surv + 63) / 64;
     uint32_t tsize = 1024;
     if (dedupe) while (tsize < n_surv * 2) tsize <<= 1;
+    // The table holds the DISTINCT strings.  Sized for the survivor slots (the only bound that cannot fail) it is 200 MB of
+    // clearing per step at 100 M reads for 42 k strings; a speculative launch sizes it from the bound on the distinct
+    // strings the merge is sized with, and an insert that runs out of probes reports the miss (h_count[5] bit 2): the host
+    // de-duplicates that call itself and the context goes back to the full-size table.
+    if (dedupe && speculative && c->dx_cap_hint && !c->dd_full_table && !c->env.dd_full_table) {
+        uint32_t small = c->env.test_bounds[1] ? 64u : 4096u;          // (tests: a table that does overflow)
+        while (small < c->dx_cap_hint * 4ull && small < tsize) small <<= 1;
+        tsize = std::min(tsize, small);
+    }
     Lookback lbf;
     if (const Lookback *lb = c->next_lookback_elems(n_surv, &lbf)) {
         // found flags -> ranks in one pass (also clears the de-duplication table)
@@ -1183,7 +1193,8 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     // the gather assembles the hand-off blob and inserts every candidate's DR string into the de-duplication table
     HIPCHK(c, launch_gather_found(c->d_fidx.p, c->d_count.p + 2, n_surv, c->d_surv.p, c->d_idx.p, c->read_base, c->d_dr.p, stride,
                                   c->d_ss_pool.p, lds.ss_cap, ss_elem, D.d_blob.p, D.d_dr_len.p, D.d_dr.p, c->stream,
-                                  dedupe ? c->dd_keys.p : nullptr, dedupe ? c->dd_first.p : nullptr, tsize, c->dd_hash.p, c->dd_slot.p));
+                                  dedupe ? c->dd_keys.p : nullptr, dedupe ? c->dd_first.p : nullptr, tsize, c->dd_hash.p, c->dd_slot.p,
+                                  c->d_count.p + 5));
     // de-duplication and token ranks follow without a host round trip (the found count stays on the device);
     // their small outputs — all the merge needs — are written straight into pinned host memory
     c->have_rep = false;
@@ -1273,6 +1284,16 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
                 }
                 if (premerge_queued && c->n_dx > 0 && c->n_dx <= c->dx_cap_hint) c->premerge = 2;
                 else if (premerge_queued && c->n_dx > c->dx_cap_hint) c->n_bound_overflows[1]++;     // (crass_hip_merge launches its own)
+            } else if (c->h_count.p[5] & 2u) {
+                // the de-duplication table was sized for fewer distinct strings than there are: nothing of it is usable.  The
+                // candidates' own strings travel, the host de-duplicates them, and later calls size the table for the slots.
+                c->dd_full_table = true;
+                c->n_bound_overflows[1]++;
+                HIPCHK(c, D.h_dr_fb.ensure(nf * stride + 16)); HIPCHK(c, D.h_dr_len_fb.ensure(nf + 8));
+                HIPCHK(c, hipMemcpyAsync(D.h_dr_fb.p, D.d_dr.p, nf * stride, hipMemcpyDeviceToHost, c->copy_stream));
+                HIPCHK(c, hipMemcpyAsync(D.h_dr_len_fb.p, D.d_dr_len.p, nf * 2, hipMemcpyDeviceToHost, c->copy_stream));
+                D.dr_fallback = true;
+                c->bulk_pending = true;
             } else {
                 // (hash collision among the candidates: the host merge wants the first-occurrence map)
                 HIPCHK(c, D.h_dr_fb.ensure(nf * stride + 16)); HIPCHK(c, D.h_dr_len_fb.ensure(nf + 8));
@@ -1703,6 +1724,7 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
     DevMerge M{};
     M.dx_chars = dx_chars; M.dx_len = dx_len; M.stride = stride; M.n_tok = n; M.d_ntok = d_ntok;
     M.thr = (uint32_t)std::max(c->prm.kmer_clust_size, 2); M.kmax = stride - 10;
+    { const char *ab = getenv("CRASS_DM_ABLATE"); M.ablate = ab ? (uint32_t)strtoul(ab, nullptr, 0) : 0u; }      // (profiling aid, read per merge)
     M.kset_log = 10; while ((1ull << M.kset_log) < 32ull * n) M.kset_log++;
     M.tab_log_alloc = 16; while (M.tab_log_alloc < 24 && (1ull << M.tab_log_alloc) < 48ull * n) M.tab_log_alloc++;
     HIPCHK(c, d.packed.ensure((size_t)n * 4)); HIPCHK(c, d.codes.ensure((size_t)n * M.kmax)); HIPCHK(c, d.owner.ensure((1u << 22) + kDmBadSlots));
@@ -1713,7 +1735,7 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
     M.rset_log = 10; while ((1ull << M.rset_log) < 4ull * n) M.rset_log++;
     HIPCHK(c, d.rset_key.ensure((size_t)1 << M.rset_log)); HIPCHK(c, d.rset_u32.ensure((size_t)3 << M.rset_log));
     HIPCHK(c, d.rd_slot.ensure(n)); HIPCHK(c, d.rents.ensure((size_t)n * 4));
-    HIPCHK(c, d.anchor_tab.ensure((size_t)1 << M.tab_log_alloc)); HIPCHK(c, d.st.ensure(1)); HIPCHK(c, d.anchor_fp.ensure(1u << 15));
+    HIPCHK(c, d.anchor_tab.ensure((size_t)1 << M.tab_log_alloc)); HIPCHK(c, d.st.ensure(1)); HIPCHK(c, d.hot.ensure(kDmHotWords)); HIPCHK(c, d.anchor_fp.ensure(1u << 15));
     HIPCHK(c, d.h_st.ensure(1)); HIPCHK(c, d.h_root.ensure(n)); HIPCHK(c, d.h_blank.ensure(n));
     M.packed = d.packed.p; M.codes = d.codes.p; M.owner = d.owner.p; M.bk_key = d.bk_key.p; M.root_of = d.root_of.p;
     M.tmask = d.tmask.p; M.pat_mask = d.tmask.p; M.blank = d.blank.p; M.pat_token = d.pat_token.p;
@@ -1759,7 +1781,7 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
     }
     M.inject_fail = c->env.dm_inject_fail ? 1u : 0u;
     M.group_cap = c->env.dm_group_cap;
-    M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p;
+    M.anchor_tab = d.anchor_tab.p; M.anchor_fp = d.anchor_fp.p; M.m1 = 0x9E3779u; M.m2 = 0x85EBCBu; M.st = d.st.p; M.hot = d.hot.p;
     d.M = M;
     return CRASS_OK;
 }

@@ -101,13 +101,21 @@ struct DevMergeState {
                                   // 64 more tokens than the launch was sized for) -> the host merge is used instead
     uint32_t k0;                  // a member key (fills unused table slots)
     uint32_t all_t;               // the key 0xFFFFFFFF is a member
-    uint32_t ent_cursor;          // entries allocated in the verification index
-    uint32_t rd_cursor;           // entries allocated in the needle index of removeRedundantRepeats
+    uint32_t unused_a, unused_b;  // (the two range cursors moved to DevMerge::hot)
     uint32_t tab_mode;            // anchor table: 0 exact keys staged in LDS (log_size <= 15), 3 16-bit fingerprints of a
                                   // 2^16-slot table staged in LDS (anchor_fp), 2 exact keys probed in global memory
     uint32_t n_badk;              // distinct 11-mers that contain an 'N'
     uint32_t pad[5];
 };
+
+// Counters that EVERY block of a merge kernel adds to (survivors, keys, smallest key).  In DevMergeState they shared one cache
+// line with `fail`, which every wave of every kernel reads: 2 600-4 096 block atomics on that line were 43 of k_dm_keys' 61 us
+// and ~33 of k_dm_redundant's 55 (tools/dm_ablate.py, round 4).  Each counter is now 16 words in 16 different lines, a block
+// uses stripe blockIdx % 16, and the one kernel that needs the value adds the stripes up.
+// (The two range cursors — one returning atomic per block — live here as well, unstriped: a line of their own each.)
+static constexpr uint32_t kDmHotStripes = 16, kDmHotCounters = 5, kDmHotWords = kDmHotCounters * kDmHotStripes * 32;
+enum { kHotSurvivors = 0, kHotKeys = 1, kHotK0 = 2, kHotEntCursor = 3, kHotRdCursor = 4 };
+__host__ __device__ inline uint32_t dm_hot(uint32_t counter, uint32_t block) { return (counter * kDmHotStripes + (block & (kDmHotStripes - 1u))) * 32u; }
 
 static constexpr uint32_t kDmBadSlots = 4096;       // identity table of the 11-mers with an 'N' (open addressing)
 static constexpr uint32_t kDmBadKmerCap = 2048;     // ... of which at most this many distinct ones; more -> host merge
@@ -188,6 +196,8 @@ struct DevMerge {
     DevViewTotals *x_htot;
     uint32_t x_on;                // 0: no export (the host rebuilds the view from h_root / h_blank)
     uint32_t x_group_cap;         // a group with more members than this is not ranked here (quadratic): the host builds the view
+    uint32_t *hot;                // the counters every block adds to, striped: [kDmHotCounters][kDmHotStripes] words, 128 bytes apart (dm_hot)
+    uint32_t ablate;              // profiling aid (CRASS_DM_ABLATE, tools/dm_ablate.py): bits switch parts of the merge kernels OFF — results are then garbage
     uint32_t inject_fail;         // tests only: start with the fail word set (exercises the fall-back to the host merge)
     uint32_t group_cap;           // a needle key with more candidates than this sets fail bit 32: removeRedundantRepeats here
                                   // compares a window with every shorter member that shares its first 16 bases, which is
@@ -215,6 +225,10 @@ static __device__ __forceinline__ void dm_init_slice(const DevMerge &M, uint64_t
     for (uint64_t i = tid; i < (1u << 15); i += nth) M.anchor_fp[i] = 0u;
     uint4 *t4 = reinterpret_cast<uint4 *>(M.anchor_tab);
     for (uint64_t i = tid; i < (1ull << M.tab_log_alloc) / 4; i += nth) t4[i] = ones;
+    if (tid < kDmHotStripes) {
+        M.hot[dm_hot(kHotSurvivors, (uint32_t)tid)] = 0u; M.hot[dm_hot(kHotKeys, (uint32_t)tid)] = 0u; M.hot[dm_hot(kHotK0, (uint32_t)tid)] = 0xFFFFFFFFu;
+        M.hot[dm_hot(kHotEntCursor, (uint32_t)tid)] = 0u; M.hot[dm_hot(kHotRdCursor, (uint32_t)tid)] = 0u;
+    }
     if (tid == 0) {
         DevMergeState s{};
         s.k0 = 0xFFFFFFFFu;
@@ -300,17 +314,16 @@ static __device__ __forceinline__ uint32_t block_reserve(uint32_t v, uint32_t *c
 #endif
 
 // Single-pass ordered compaction (decoupled look-back): per-tile status words, a ticket counter that hands out
-// tile ids in start order (a tile only ever waits for tiles that started before it) and an epoch tag so that
-// neither needs clearing between launches.  Built by crass_hip_ctx::next_lookback().
+// tile ids in start order (a tile only ever waits for tiles that started before it; the launch's last ticket resets it)
+// and an epoch tag so that the status words need no clearing between launches.  Built by crass_hip_ctx::next_lookback().
 struct Lookback {
     unsigned long long *status;   // [>= tiles] (epoch << 34) | (flag << 32) | value; flag 1 = tile total, 2 = inclusive prefix
-    uint32_t *ticket;             // monotonically increasing; tile id = ticket - ticket_base
-    uint32_t ticket_base;
+    uint32_t *ticket;             // 0 between launches: the block that draws a launch's last ticket resets it (lb_tile_id)
     uint32_t epoch;               // 30 bits, never 0
     uint32_t *fail;               // pinned host word, set when a spin gives up (never expected; reported as an error)
 };
-// mask words per tile (one per thread): fat tiles for the masks over all reads, small ones for the short masks
-static inline uint32_t lookback_tile_words(uint64_t n_words) { return n_words >= 16384 ? 1024u : 256u; }
+// mask words per tile: fat tiles (1024 threads x 4 words) for the masks over all reads, small ones (256 x 1) for the short masks
+static inline uint32_t lookback_tile_words(uint64_t n_words) { return n_words >= 16384 ? 4096u : 256u; }
 
 // mask (n_words 64-bit words) -> ascending index list; *d_count receives the number of set bits.
 // scratch: word_prefix[n_words] u32, block_sums[(n_words+255)/256 + 1] u32
@@ -380,7 +393,10 @@ hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint6
                                const uint32_t *ss_pool, uint32_t ss_cap, uint32_t ss_elem, uint8_t *blob,
                                uint16_t *g_dr_len, char *g_dr, hipStream_t st,
                                unsigned long long *dd_keys = nullptr, uint32_t *dd_first = nullptr, uint32_t dd_size = 0,
-                               uint64_t *dd_hash = nullptr, uint32_t *dd_slot = nullptr);
+                               uint64_t *dd_hash = nullptr, uint32_t *dd_slot = nullptr, uint32_t *d_mismatch = nullptr);
+// probes after which an insert into the de-duplication table gives up (a table sized for a bound on the DISTINCT strings
+// that turned out too small): bit 2 of the mismatch word
+static constexpr uint32_t kDdMaxProbes = 256;
 // pass-1 hand-off blob: what the host needs of the nf found records, compact and packed back to back so that
 // it crosses PCIe once: read index, repeat length, start/stop count and list (read positions fit 16 bits:
 // CRASS_HIP_MAX_READ_LEN < 65536), orientation flag.  The DR string of candidate k is the distinct string

@@ -483,10 +483,20 @@ static __device__ uint32_t lb_exclusive_prefix(const Lookback &lb, uint32_t tile
     __syncthreads();
     return excl_sh;
 }
-static __device__ uint32_t lb_tile_id(const Lookback &lb)
+// A tile id per block, in start order.  n_act blocks of the launch call this (every block computes the same n_act; the
+// others have returned before): the block that draws the last ticket puts the counter back to zero for the next launch — by
+// then every other ticket of this launch has been drawn.  (The counter is ONE word for all launches of a context's stream.
+// Returning atomics on one address retire every 20-30 ns on this part however many CUs issue them — the whole cost of a
+// look-back kernel over a few thousand tiles, rocprofv3 round 4: 1 526 tiles of the read mask 32 us, 4 950 mostly EMPTY
+// tiles of the candidate list 50 us — so tiles are fat, and tiles past a device-side count draw no ticket at all.)
+static __device__ uint32_t lb_tile_id(const Lookback &lb, uint32_t n_act)
 {
     __shared__ uint32_t tile_sh;
-    if (threadIdx.x == 0) tile_sh = atomicAdd(lb.ticket, 1u) - lb.ticket_base;
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(lb.ticket, 1u);
+        if (t + 1u >= n_act) __hip_atomic_store(lb.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tile_sh = t;
+    }
     __syncthreads();
     return tile_sh;
 }
@@ -511,39 +521,50 @@ static __device__ uint32_t block_scan_t(uint32_t v, uint32_t *total)
     return base + incl - v;
 }
 
-// T mask words per tile, one per thread: 1024 for the masks over all reads (few, fat tiles), 256 for the short dense
-// masks of the later stages (more blocks for the per-word scatter loops)
-template <int T>
+// T threads x W consecutive mask words per tile: 1024 x 4 for the masks over all reads (few, fat tiles: the ticket is the
+// kernel's cost), 256 x 1 for the short dense masks of the later stages (more blocks for the per-word scatter loops)
+template <int T, int W>
 __global__ __launch_bounds__(T) void k_mask_compact_lb(const uint64_t *mask, uint64_t n_words, uint64_t n_bits, uint32_t *word_prefix,
                                                         uint32_t *block_sums, uint64_t *out_idx, uint64_t out_cap, uint32_t *d_count,
                                                         uint32_t *zero_a, uint32_t n_a, uint32_t *zero_b, uint32_t n_b, Lookback lb,
                                                         uint32_t n_tiles)
 {
-    const uint32_t tile = lb_tile_id(lb);
+    const uint32_t tile = lb_tile_id(lb, n_tiles);
     if (tile == 0) {                                    // counters the NEXT stage accumulates into
         if (threadIdx.x < n_a) zero_a[threadIdx.x] = 0u;
         if (threadIdx.x < n_b) zero_b[threadIdx.x] = 0u;
     }
-    const uint64_t wi = (uint64_t)tile * T + threadIdx.x;
-    uint64_t m = 0;
-    if (wi < n_words) {
-        m = mask[wi];
-        const uint64_t rem = n_bits - wi * 64;
-        if (rem < 64) m &= (1ull << rem) - 1ull;
+    const uint64_t w0 = ((uint64_t)tile * T + threadIdx.x) * W;
+    uint64_t m[W];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < W; q++) {
+        const uint64_t wi = w0 + q;
+        m[q] = 0;
+        if (wi < n_words) {
+            m[q] = mask[wi];
+            const uint64_t rem = n_bits - wi * 64;
+            if (rem < 64) m[q] &= (1ull << rem) - 1ull;
+        }
+        cnt += (uint32_t)__popcll(m[q]);
     }
     uint32_t total;
-    const uint32_t in_tile = block_scan_t<T>((uint32_t)__popcll(m), &total);
+    const uint32_t in_tile = block_scan_t<T>(cnt, &total);
     const uint32_t excl = lb_exclusive_prefix(lb, tile, total);
     if (tile == n_tiles - 1 && threadIdx.x == 0) *d_count = excl + total;
-    if (wi < n_words) {
-        uint64_t o = (uint64_t)excl + in_tile;
+    uint64_t o = (uint64_t)excl + in_tile;
+#pragma unroll
+    for (int q = 0; q < W; q++) {
+        const uint64_t wi = w0 + q;
+        if (wi >= n_words) break;
         if (word_prefix) {                              // same meaning as the three-kernel form: block_sums[w >> 8] + word_prefix[w]
             word_prefix[wi] = (uint32_t)o;
             if ((wi & 255u) == 0) block_sums[wi >> 8] = 0u;
         }
-        while (m) {
-            const int b = __ffsll((unsigned long long)m) - 1;
-            m &= m - 1;
+        uint64_t mm = m[q];
+        while (mm) {
+            const int b = __ffsll((unsigned long long)mm) - 1;
+            mm &= mm - 1;
             if (o < out_cap) out_idx[o] = wi * 64 + b;
             o++;
         }
@@ -572,10 +593,10 @@ hipError_t launch_compact(const uint64_t *mask, uint64_t n_words, uint64_t n_bit
         const uint32_t tw = lookback_tile_words(n_words);
         const uint32_t n_tiles = (uint32_t)((n_words + tw - 1) / tw);
         if (tw == 256)
-            CRASS_LAUNCH(k_mask_compact_lb<256>, dim3(n_tiles), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
+            CRASS_LAUNCH((k_mask_compact_lb<256, 1>), dim3(n_tiles), dim3(256), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
                                d_count, zero_a, n_a, zero_b, n_b, *lb, n_tiles);
         else
-            CRASS_LAUNCH(k_mask_compact_lb<1024>, dim3(n_tiles), dim3(1024), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
+            CRASS_LAUNCH((k_mask_compact_lb<1024, 4>), dim3(n_tiles), dim3(1024), 0, st, mask, n_words, n_bits, word_prefix, block_sums, out_idx, out_cap,
                                d_count, zero_a, n_a, zero_b, n_b, *lb, n_tiles);
         return hipGetLastError();
     }
@@ -2196,102 +2217,180 @@ static __device__ uint64_t dr_hash64(const char *p, uint32_t n)
     return h ^ (h >> 31);
 }
 
-// found records -> compact hand-off blob in pinned host memory + dense DR strings on the device + de-duplication insert
+// found records -> compact hand-off blob + dense DR strings on the device + de-duplication insert
 // (one thread per found record; see launch_gather_found in engine_internal.h)
-__global__ __launch_bounds__(256) void k_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max,
-                                                       const SurvOut *out, const uint64_t *surv_idx, uint64_t read_base,
-                                                       const char *dr_chars, uint32_t dr_stride, const uint32_t *ss_pool,
-                                                       uint32_t ss_cap, uint32_t ss_elem, uint8_t *blob, uint16_t *g_dr_len, char *g_dr,
-                                                       unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_mask,
-                                                       uint64_t *dd_hash, uint32_t *dd_slot)
+// The insert goes through LDS first: most records carry one of a few popular strings, every resident thread meets the table
+// while it is still empty, and returning atomics on one address retire one every 20-30 ns — 5.6 k compare-and-swaps on each
+// popular slot were ~100 of this kernel's 125 us at 100 M reads.  A block of 1 024 records claims its strings in an LDS table
+// (hash, smallest record index), then ONE thread per distinct string of the block goes to the global table.
+#define GF_BLOCK 1024
+#define GF_SLOTS 2048
+__global__ __launch_bounds__(GF_BLOCK) void k_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max,
+                                                            const SurvOut *out, const uint64_t *surv_idx, uint64_t read_base,
+                                                            const char *dr_chars, uint32_t dr_stride, const uint32_t *ss_pool,
+                                                            uint32_t ss_cap, uint32_t ss_elem, uint8_t *blob, uint16_t *g_dr_len, char *g_dr,
+                                                            unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_mask,
+                                                            uint64_t *dd_hash, uint32_t *dd_slot, uint32_t *d_mismatch)
 {
-    const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    __shared__ unsigned long long lkey[GF_SLOTS];
+    __shared__ uint32_t lmin[GF_SLOTS], lslot[GF_SLOTS];
+    const uint64_t k = blockIdx.x * (uint64_t)GF_BLOCK + threadIdx.x;
     uint64_t n = *d_nf;
     if (n > n_max) n = n_max;
-    if (k >= n) return;
-    const P1Blob b = p1_blob_layout(n, ss_cap, ss_elem);
-    const uint64_t s = fidx[k];
-    const SurvOut o = out[s];
-    reinterpret_cast<uint64_t *>(blob + b.read)[k] = read_base + surv_idx[s];
-    reinterpret_cast<uint16_t *>(blob + b.replen)[k] = (uint16_t)o.repeat_len;
-    (blob + b.nss)[k] = (uint8_t)o.n_ss;
-    (blob + b.low)[k] = o.low_lexi;
-    const uint32_t *ps = ss_pool + o.ss_off;
-    if (ss_elem == 1) {                                  // ss_cap is a multiple of 4: whole words
-        uint32_t *pd = reinterpret_cast<uint32_t *>(blob + b.ss + k * (uint64_t)ss_cap);
-        for (uint32_t i = 0; i < ss_cap; i += 4) {
-            uint32_t v = 0;
+    if (blockIdx.x * (uint64_t)GF_BLOCK >= n) return;    // (the launch is sized for the survivor bound)
+    if (dd_keys) {
+        for (uint32_t i = threadIdx.x; i < GF_SLOTS; i += GF_BLOCK) { lkey[i] = 0ull; lmin[i] = 0xFFFFFFFFu; }
+        __syncthreads();
+    }
+    uint32_t ls = 0;
+    if (k < n) {
+        const P1Blob b = p1_blob_layout(n, ss_cap, ss_elem);
+        const uint64_t s = fidx[k];
+        const SurvOut o = out[s];
+        reinterpret_cast<uint64_t *>(blob + b.read)[k] = read_base + surv_idx[s];
+        reinterpret_cast<uint16_t *>(blob + b.replen)[k] = (uint16_t)o.repeat_len;
+        (blob + b.nss)[k] = (uint8_t)o.n_ss;
+        (blob + b.low)[k] = o.low_lexi;
+        const uint32_t *ps = ss_pool + o.ss_off;
+        if (ss_elem == 1 && (o.ss_off & 3u) == 0u) {         // ss_cap is a multiple of 4: whole words, and 16-byte loads (slot-mode pool)
+            uint32_t *pd = reinterpret_cast<uint32_t *>(blob + b.ss + k * (uint64_t)ss_cap);
+            const uint4 *p4 = reinterpret_cast<const uint4 *>(ps);
+            for (uint32_t i = 0; i < ss_cap; i += 4) {
+                const uint4 x = p4[i >> 2];
+                const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+                uint32_t v = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < 4; q++) v |= ((i + q < o.n_ss) ? (ps[i + q] & 0xFFu) : 0u) << (8 * q);
-            pd[i >> 2] = v;
+                for (uint32_t q = 0; q < 4; q++) v |= ((i + q < o.n_ss) ? (xs[q] & 0xFFu) : 0u) << (8 * q);
+                pd[i >> 2] = v;
+            }
+        } else if (ss_elem == 1) {
+            uint32_t *pd = reinterpret_cast<uint32_t *>(blob + b.ss + k * (uint64_t)ss_cap);
+            for (uint32_t i = 0; i < ss_cap; i += 4) {
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) v |= ((i + q < o.n_ss) ? (ps[i + q] & 0xFFu) : 0u) << (8 * q);
+                pd[i >> 2] = v;
+            }
+        } else {
+            uint32_t *pd = reinterpret_cast<uint32_t *>(blob + b.ss + k * (uint64_t)ss_cap * 2);
+            for (uint32_t i = 0; i < ss_cap; i += 2) {
+                const uint32_t lo = (i < o.n_ss) ? (ps[i] & 0xFFFFu) : 0u, hi = (i + 1 < o.n_ss) ? (ps[i + 1] & 0xFFFFu) : 0u;
+                pd[i >> 1] = lo | (hi << 16);
+            }
         }
-    } else {
-        uint32_t *pd = reinterpret_cast<uint32_t *>(blob + b.ss + k * (uint64_t)ss_cap * 2);
-        for (uint32_t i = 0; i < ss_cap; i += 2) {
-            const uint32_t lo = (i < o.n_ss) ? (ps[i] & 0xFFFFu) : 0u, hi = (i + 1 < o.n_ss) ? (ps[i + 1] & 0xFFFFu) : 0u;
-            pd[i >> 1] = lo | (hi << 16);
+        g_dr_len[k] = o.dr_len;
+        // the string is copied 16 bytes at a time and hashed from the same registers (dr_hash64 over a zero-padded slot: a
+        // partial last word IS the value its byte loop assembles; 36 byte loads per record were a third of this kernel)
+        const uint4 *src = reinterpret_cast<const uint4 *>(dr_chars + s * (uint64_t)dr_stride);
+        uint4 *dst = reinterpret_cast<uint4 *>(g_dr + k * (uint64_t)dr_stride);
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)o.dr_len * 0xD6E8FEB86659FD93ull);
+        uint32_t rem = o.dr_len;
+        for (uint32_t i = 0; i < dr_stride / 16; i++) {
+            const uint4 v4 = src[i];
+            dst[i] = v4;
+            const uint64_t w2[2] = {(uint64_t)v4.x | ((uint64_t)v4.y << 32), (uint64_t)v4.z | ((uint64_t)v4.w << 32)};
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (rem >= 8) { h = (h ^ w2[q]) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; rem -= 8; }
+                else if (rem) { h = (h ^ w2[q]) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29; rem = 0; }
+            }
+        }
+        h ^= h >> 31;
+        if (dd_keys) {
+            // (the same 64-bit hash as TokenTable::hash, merge.cpp); 0 marks an empty slot
+            dd_hash[k] = h;
+            const unsigned long long key = h | 1ull;
+            ls = (uint32_t)(h >> 40) & (GF_SLOTS - 1u);
+            for (;;) {                                       // (at most 1 024 distinct keys in 2 048 slots: always ends)
+                const unsigned long long old = atomicCAS(&lkey[ls], 0ull, key);
+                if (old == 0ull || old == key) break;
+                ls = (ls + 1u) & (GF_SLOTS - 1u);
+            }
+            atomicMin(&lmin[ls], (uint32_t)k);
         }
     }
-    g_dr_len[k] = o.dr_len;
-    const uint4 *src = reinterpret_cast<const uint4 *>(dr_chars + s * (uint64_t)dr_stride);
-    uint4 *dst = reinterpret_cast<uint4 *>(g_dr + k * (uint64_t)dr_stride);
-    for (uint32_t i = 0; i < dr_stride / 16; i++) dst[i] = src[i];
-    if (dd_keys) {
-        // the DR string's slot in the de-duplication table (the table was cleared by the found-flag compaction)
-        const uint64_t h = dr_hash64(dr_chars + s * (uint64_t)dr_stride, o.dr_len);
-        dd_hash[k] = h;
-        const unsigned long long key = h | 1ull;             // 0 marks an empty slot
-        uint32_t slot = (uint32_t)(h >> 17) & dd_mask;
-        // Looking at the slot before the CAS / atomicMin — most records carry one of a few popular strings, and atomics on one
-        // address retire one at a time — pays at 100 M reads (168 -> 118 us) but costs two more round trips per record at
-        // 10 M (21 -> 39 us): done for launches sized for more than 2^20 records (the headline workload).
-        const bool look = n_max > (1ull << 20);
-        for (;;) {
+    if (!dd_keys) return;
+    __syncthreads();
+    // The global table was cleared by the found-flag compaction.  It is sized for the DISTINCT strings the caller expects
+    // (a learnt bound), not for the records: a probe sequence that outlasts kDdMaxProbes means the bound was too small.
+    // Bit 2 of the mismatch word tells the host (which then de-duplicates itself and sizes the next call's table for the
+    // records); the string keeps the occupied slot it stopped at, so that everything downstream stays in range.
+    // Looking at a slot before the CAS / atomicMin pays at 100 M reads but costs two more round trips at 10 M: done for
+    // launches sized for more than 2^20 records (the headline workload).
+    const bool look = n_max > (1ull << 20);
+    for (uint32_t i = threadIdx.x; i < GF_SLOTS; i += GF_BLOCK) {
+        const unsigned long long key = lkey[i];
+        if (key == 0ull) continue;
+        uint32_t slot = (uint32_t)(key >> 17) & dd_mask;
+        for (uint32_t probes = 0;; probes++) {
             unsigned long long old = look ? __hip_atomic_load(&dd_keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             if (old == 0ull) old = atomicCAS(&dd_keys[slot], 0ull, key);
             if (old == 0ull || old == key) break;
+            if (probes >= kDdMaxProbes) { atomicOr(d_mismatch, 2u); break; }
             slot = (slot + 1) & dd_mask;
         }
-        if (!look || __hip_atomic_load(&dd_first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)k) atomicMin(&dd_first[slot], (uint32_t)k);
-        dd_slot[k] = slot;
+        const uint32_t kmin = lmin[i];
+        if (!look || __hip_atomic_load(&dd_first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > kmin) atomicMin(&dd_first[slot], kmin);
+        lslot[i] = slot;
     }
+    __syncthreads();
+    if (k < n) dd_slot[k] = lslot[ls];
 }
 
 // k_found_mask + compaction in one pass (decoupled look-back): survivor slot s -> rank among the found records ->
 // fidx[rank] = s.  Also clears the de-duplication table of the next stage.  (The gather itself stays a dense kernel:
-// with one found record in six slots a fused body would run at a sixth of the lanes.)
+// with one found record in six slots a fused body would run at a sixth of the lanes.)  Tiles of 16 384 slots (16 per
+// thread); the launch is sized for the survivor BOUND, tiles past the device-side count leave at once.
+static constexpr uint32_t kFcPerThread = 16, kFcTile = 1024u * kFcPerThread;
+// Wave w of the block takes slots [w * 1024, (w + 1) * 1024) of the tile, 64 consecutive slots per step (one per lane: the
+// loads of a step cover one contiguous 1 280-byte run); a step's found flags are one ballot.
 __global__ __launch_bounds__(1024) void k_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_t n_max, uint32_t *d_err,
                                                          unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size,
-                                                         uint64_t *fidx, uint32_t *d_nf, Lookback lb, uint32_t n_tiles)
+                                                         uint64_t *fidx, uint32_t *d_nf, Lookback lb)
 {
-    const uint32_t tile = lb_tile_id(lb);
-    const uint64_t s0 = (uint64_t)tile * kLbElemsPerTile + 4u * threadIdx.x;
-    for (uint64_t i = (uint64_t)tile * 1024u + threadIdx.x; i < dd_size; i += (uint64_t)n_tiles * 1024u) { dd_keys[i] = 0ull; dd_first[i] = 0xFFFFFFFFu; }
     uint64_t n = *d_n;                                   // slots past the device-side count were never written
     if (n > n_max) n = n_max;
-    uint32_t fm = 0, err = 0;
+    const uint32_t n_act = n ? (uint32_t)((n + kFcTile - 1) / kFcTile) : 1u;
+    if (blockIdx.x >= n_act) return;
+    const uint32_t tile = lb_tile_id(lb, n_act);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t s0 = (uint64_t)tile * kFcTile + (uint64_t)wv * 1024u;
+    for (uint64_t i = (uint64_t)tile * 1024u + threadIdx.x; i < dd_size; i += (uint64_t)n_act * 1024u) { dd_keys[i] = 0ull; dd_first[i] = 0xFFFFFFFFu; }
+    uint32_t err = 0, cnt = 0;
+    uint64_t fm[kFcPerThread];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        if (s0 + e < n) {
-            const SurvOut o = out[s0 + e];
-            if (o.found) fm |= 1u << e;
-            err = max(err, (uint32_t)o.err);
-        }
+    for (uint32_t e = 0; e < kFcPerThread; e++) {
+        const uint64_t sl = s0 + e * 64u + (uint32_t)lane;
+        bool f = false;
+        if (sl < n) { f = out[sl].found != 0; err = max(err, (uint32_t)out[sl].err); }
+        fm[e] = __ballot(f);
+        cnt += (uint32_t)__popcll(fm[e]);                // (wave-uniform)
     }
     if (err) atomicMax(d_err, err);
-    uint32_t upto;
-    uint64_t k = lb_rank4(lb, tile, (uint32_t)__popc(fm), &upto);
-    if (tile == n_tiles - 1 && threadIdx.x == 0) *d_nf = upto;
+    // ranks: the wave's base from a scan over the 16 wave totals, then step by step
+    __shared__ uint32_t wtot[16];
+    if (lane == 0) wtot[wv] = cnt;
+    __syncthreads();
+    uint32_t wbase = 0, all = 0;
 #pragma unroll
-    for (int e = 0; e < 4; e++) if (fm & (1u << e)) fidx[k++] = s0 + e;
+    for (int q = 0; q < 16; q++) { const uint32_t t = wtot[q]; if (q < wv) wbase += t; all += t; }
+    const uint32_t excl = lb_exclusive_prefix(lb, tile, all);
+    if (tile == n_act - 1 && threadIdx.x == 0) *d_nf = excl + all;
+    uint64_t k = (uint64_t)excl + wbase;
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (uint32_t e = 0; e < kFcPerThread; e++) {
+        if ((fm[e] >> lane) & 1ull) fidx[k + (uint32_t)__popcll(fm[e] & lt)] = s0 + e * 64u + (uint32_t)lane;
+        k += (uint32_t)__popcll(fm[e]);
+    }
 }
 hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_t n_max, uint32_t *d_err, unsigned long long *dd_keys,
                                 uint32_t *dd_first, uint32_t dd_size, uint64_t *fidx, uint32_t *d_nf, const Lookback &lb, hipStream_t st)
 {
     if (n_max == 0) return hipSuccess;
-    const uint32_t n_tiles = (uint32_t)((n_max + kLbElemsPerTile - 1) / kLbElemsPerTile);
+    const uint32_t n_tiles = (uint32_t)((n_max + kFcTile - 1) / kFcTile);
     CRASS_LAUNCH(k_found_compact, dim3(n_tiles), dim3(1024), 0, st, out, d_n, n_max, d_err, dd_keys, dd_first, dd_keys ? dd_size : 0u,
-                       fidx, d_nf, lb, n_tiles);
+                       fidx, d_nf, lb);
     return hipGetLastError();
 }
 
@@ -2357,13 +2456,14 @@ hipError_t launch_gather_found(const uint64_t *fidx, const uint32_t *d_nf, uint6
                                const uint64_t *surv_idx, uint64_t read_base, const char *dr_chars, uint32_t dr_stride,
                                const uint32_t *ss_pool, uint32_t ss_cap, uint32_t ss_elem, uint8_t *h_blob,
                                uint16_t *g_dr_len, char *g_dr, hipStream_t st,
-                               unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size, uint64_t *dd_hash, uint32_t *dd_slot)
+                               unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size, uint64_t *dd_hash, uint32_t *dd_slot,
+                               uint32_t *d_mismatch)
 {
     if (n_max == 0) return hipSuccess;
     if ((ss_cap & 3u) || (ss_elem != 1 && ss_elem != 2)) return hipErrorInvalidValue;
-    CRASS_LAUNCH(k_gather_found, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, surv_idx,
+    CRASS_LAUNCH(k_gather_found, dim3((unsigned)((n_max + GF_BLOCK - 1) / GF_BLOCK)), dim3(GF_BLOCK), 0, st, fidx, d_nf, n_max, out, surv_idx,
                        read_base, dr_chars, dr_stride, ss_pool, ss_cap, ss_elem, h_blob, g_dr_len, g_dr,
-                       dd_keys, dd_first, dd_keys ? dd_size - 1 : 0u, dd_hash, dd_slot);
+                       dd_keys, dd_first, dd_keys ? dd_size - 1 : 0u, dd_hash, dd_slot, d_mismatch);
     return hipGetLastError();
 }
 
@@ -2474,11 +2574,13 @@ __global__ __launch_bounds__(256) void k_dx_gather(const uint64_t *dx_idx, const
 // ever reads its OWN slot_of entry here, so overwriting it is safe) for the assign kernel that follows.
 __global__ __launch_bounds__(1024) void k_dx_flag_compact(const char *dr, const uint16_t *dr_len, uint32_t stride, const uint32_t *d_n, uint32_t n_max,
                                                            uint32_t *slot_of, const uint32_t *first, uint32_t *rep, uint64_t *dx_idx, uint32_t *d_nd,
-                                                           uint32_t *d_mismatch, Lookback lb, uint32_t n_tiles)
+                                                           uint32_t *d_mismatch, Lookback lb)
 {
-    const uint32_t tile = lb_tile_id(lb);
-    const uint32_t k = tile * 1024u + threadIdx.x;
     const uint32_t n = min(*d_n, n_max);
+    const uint32_t n_tiles = n ? (n + 1023u) / 1024u : 1u;          // (the launch is sized for a bound: the tiles past the count leave at once)
+    if (blockIdx.x >= n_tiles) return;
+    const uint32_t tile = lb_tile_id(lb, n_tiles);
+    const uint32_t k = tile * 1024u + threadIdx.x;
     bool is_rep = false;
     if (k < n) {
         const uint32_t f = first[slot_of[k]];
@@ -2544,7 +2646,7 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
     if (lb) {           // two launches: flags + single-pass compaction (element-wise look-back), dense assign + gather
         const uint32_t n_tiles = (n + 1023u) / 1024u;                               // (the caller reserved that many tickets)
         CRASS_LAUNCH(k_dx_flag_compact, dim3(n_tiles), dim3(1024), 0, st, dr, dr_len, stride, d_n, n, slot_of, first, rep, dx_idx, d_nd, d_mismatch,
-                           *lb, n_tiles);
+                           *lb);
         CRASS_LAUNCH(k_dx_assign_gather, dim3(nb), dim3(256), 0, st, rep, d_n, n, (const uint32_t *)slot_of, dmap, dx_idx, d_nd, dr, dr_len,
                            hash, stride, out_chars, out_len, out_hash, dev_chars, dev_len, cnt_src, cnt_dst, cnt_dst ? n_cnt : 0u);
         return hipGetLastError();
@@ -3320,12 +3422,14 @@ __global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, con
 }
 // k_recruit_valid_mask + compaction in one pass (decoupled look-back): vidx[rank] = slot of the rank-th valid hit
 __global__ __launch_bounds__(1024) void k_valid_compact(const RecruitOut *rec, const uint32_t *d_n_hits, uint64_t cap, uint64_t *vidx, uint32_t *d_nv,
-                                                         Lookback lb, uint32_t n_tiles)
+                                                         Lookback lb)
 {
-    const uint32_t tile = lb_tile_id(lb);
-    const uint64_t k0 = (uint64_t)tile * kLbElemsPerTile + 4u * threadIdx.x;
     uint64_t n = *d_n_hits;
     if (n > cap) n = cap;
+    const uint32_t n_tiles = n ? (uint32_t)((n + kLbElemsPerTile - 1) / kLbElemsPerTile) : 1u;      // (sized for a bound: the tiles past the count leave at once)
+    if (blockIdx.x >= n_tiles) return;
+    const uint32_t tile = lb_tile_id(lb, n_tiles);
+    const uint64_t k0 = (uint64_t)tile * kLbElemsPerTile + 4u * threadIdx.x;
     uint32_t fm = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) if (k0 + e < n && rec[k0 + e].dr_len != 0) fm |= 1u << e;
@@ -3344,7 +3448,7 @@ hipError_t launch_pack_p2_blob(const RecruitOut *rec, const uint64_t *hit_idx, u
     const unsigned nb = (unsigned)((n_hits_max + 255) / 256);
     if (lb) {           // (the caller reserved nb tiles)
         const unsigned nt = (unsigned)((n_hits_max + kLbElemsPerTile - 1) / kLbElemsPerTile);
-        CRASS_LAUNCH(k_valid_compact, dim3(nt), dim3(1024), 0, st, rec, d_n_hits, n_hits_max, vidx, d_nv, *lb, nt);
+        CRASS_LAUNCH(k_valid_compact, dim3(nt), dim3(1024), 0, st, rec, d_n_hits, n_hits_max, vidx, d_nv, *lb);
         CRASS_LAUNCH(k_pack_p2_blob, dim3(nb), dim3(256), 0, st, rec, hit_idx, read_base, vidx, d_nv, n_hits_max, blob, d_n_hits, h_n_hits, narrow);
         return hipGetLastError();
     }

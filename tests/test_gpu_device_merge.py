@@ -181,6 +181,35 @@ def test_every_first_call_bound_overflows_cleanly(ca, which, bounds):
     assert_same_pipeline(c, ref)
 
 
+def test_dedup_table_sized_for_the_distinct_bound_overflows_cleanly(ca):
+    """Pass 1's de-duplication table is sized from the bound on the DISTINCT strings (not from the survivor slots): with a
+    bound of 16 (a 64-slot table under the test hook) and hundreds of distinct repeats every insert runs out of probes; the
+    host must de-duplicate that call itself, later calls of the context use the full-size table, results unchanged."""
+    seqs = synth_reads(ca, 80000, read_len=150, n_dr=300, crispr_per_million=80000)
+    ref = orc.pipeline(seqs)
+    assert len(ref.tokens) > 200
+    os.environ["CRASS_TEST_BOUNDS"] = "0,16,0,0"
+    try:
+        eng = ca.SearchEngine()
+        try:
+            a = ca.search_pipeline(seqs, engine=eng)
+            b = ca.search_pipeline(seqs, engine=eng)
+        finally:
+            eng.close()
+    finally:
+        os.environ.pop("CRASS_TEST_BOUNDS", None)
+    assert a.counters["n_bound_overflows"][1] >= 1
+    assert_same_pipeline(a, ref)
+    assert_same_pipeline(b, ref)
+    os.environ["CRASS_DD_FULL_TABLE"] = "1"                 # the A/B switch: the table of round 3
+    try:
+        c = ca.search_pipeline(seqs)
+    finally:
+        os.environ.pop("CRASS_DD_FULL_TABLE", None)
+    assert c.counters["n_bound_overflows"] == [0, 0, 0, 0]
+    assert_same_pipeline(c, ref)
+
+
 def test_exception_reads_stay_on_the_device_path(ca):
     """Reads with non-ACGT bytes: screened on their packed words (a non-ACGT byte packs as 'A': still a superset),
     evaluated byte-wise in pass 1, and — the pattern set being pure ACGT — filtered and verified on the device in
