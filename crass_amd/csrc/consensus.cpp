@@ -46,13 +46,30 @@ template <typename T> struct DBuf {
     ~DBuf() { if (p) crass::dev_free(p); }
 };
 
+// pinned host staging (the per-group round trip: one H2D and one D2H instead of four pageable ones)
+template <typename T> struct HBuf {
+    T *p = nullptr; size_t n = 0;
+    hipError_t ensure(size_t want)
+    {
+        if (want <= n && p) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+        if (!want) want = 1;
+        want += want / 2;
+        const hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    ~HBuf() { if (p) (void)hipHostFree(p); }
+};
+
 struct Rec {
     uint64_t read = 0, roff = 0;
     int L = 0;
     std::vector<uint32_t> ss;
     uint8_t rc = 0, alive = 1;
+    uint8_t host_rc = 0;                         // orientation of the record's characters in the HOST mirror (flipped lazily: rseq)
     // deferred updateStartStops
-    bool upd = false, upd_rev = false; int upd_front = 0; uint32_t upd_dr = 0;
+    bool upd = false, upd_rev = false; int upd_front = 0; uint32_t upd_dr = 0, upd_first = 0, upd_last = 0;
 };
 
 constexpr double kConsArrayStart = 0.5, kZoneExt = 0.55, kCollapsedCons = 0.75, kCollapsedThr = 0.30, kPartialSim = 0.85, kKmerMaxAbundance = 0.23;
@@ -79,7 +96,11 @@ struct crass_cons {
     hipStream_t st = nullptr;
     int max_read_len = 0;
     std::vector<Rec> rec;
-    std::vector<char> hseq;                       // host mirror of the records' RH_Seq, kept in step with the device copy
+    std::vector<char> hseq;                       // host mirror of the records' RH_Seq; a record's characters follow the device copy
+                                                  // only when somebody reads them (rseq: extendSlaveDR's ties)
+    HBuf<uint32_t> h_stage; HBuf<int> h_cov;      // pinned: a group's flips + placements going up, its coverage coming down
+    DBuf<uint32_t> d_stage;
+    double t_place = 0, t_flip = 0, t_sync = 0, t_cons = 0, t_ksw = 0, t_split = 0, t_fa = 0, t_fb = 0, t_fc = 0, t_fd = 0, t_pre = 0;      // CRASS_TIMING: where the group loop's time goes
     std::vector<std::string> tok;                 // token t = tok[t - 2]
     std::vector<std::unique_ptr<std::vector<int>>> reads_of;
     std::map<int, std::unique_ptr<std::vector<int>>> group;     // mDR2GIDMap (absent / nullptr = none)
@@ -111,22 +132,38 @@ int add_string(crass_cons *s, const std::string &str)
 }
 inline const std::string &tstr(const crass_cons *s, int tok) { return s->tok[tok - 2]; }
 inline std::vector<int> *rlist(crass_cons *s, int tok) { return s->reads_of[tok - 2].get(); }
-inline char *rseq(crass_cons *s, const Rec &r) { return s->hseq.data() + r.roff; }
+inline double now_sec() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// the record's characters in its CURRENT orientation (ReadHolder::reverseComplementSeq, :593-609, applied to the host mirror
+// only now: 42 k of 100 k records are flipped in a 10 M-read job and one or two of them are ever looked at)
+// one character of the record in its current orientation, whatever the host mirror's
+inline char rchar(const crass_cons *s, const Rec &r, int pos)
+{
+    const char *q = s->hseq.data() + r.roff;
+    return r.host_rc == r.rc ? q[pos] : (char)s->comp[q[r.L - 1 - pos] & 127];
+}
+inline char *rseq(crass_cons *s, Rec &r)
+{
+    char *q = s->hseq.data() + r.roff;
+    if (r.host_rc != r.rc) {
+        for (int i = 0, j = r.L - 1; i <= j; i++, j--) { const char a = q[i], b = q[j]; q[i] = (char)s->comp[b & 127]; q[j] = (char)s->comp[a & 127]; }
+        r.host_rc = r.rc;
+    }
+    return q;
+}
 
 void reverse_start_stops(Rec &r)
 {   // ReadHolder::reverseStartStops, ReadHolder.cpp:321-380
     if (r.ss.empty()) return;
-    std::vector<uint32_t> tmp; tmp.reserve(r.ss.size());
-    const int true_start_offset = r.L - (int)r.ss.back() - 1;
-    uint32_t prev_pos_fixed = (uint32_t)true_start_offset, prev_pos_orig = r.ss.back();
-    for (size_t k = r.ss.size(); k-- > 0;) { const uint32_t gap = prev_pos_orig - r.ss[k]; prev_pos_fixed += gap; tmp.push_back(prev_pos_fixed); prev_pos_orig = r.ss[k]; }
-    r.ss.swap(tmp);
+    // The reference walks the list from the back, accumulating the gaps onto L - back - 1: entry i of the new list is
+    // (L - 1 - back) + (back - ss[n-1-i]) = L - 1 - ss[n-1-i] in its 32-bit unsigned arithmetic — the list mirrored, in place
+    // (no second vector: 42 k records are turned in a 10 M-read job and every one of them allocated)
+    const uint32_t top = (uint32_t)(r.L - 1);
+    std::reverse(r.ss.begin(), r.ss.end());
+    for (auto &x : r.ss) x = top - x;
 }
 void flip_record(crass_cons *s, Aligner *al, int k)
-{   // ReadHolder::reverseComplementSeq (:593-609): host mirror now, device copy with the next sync
+{   // ReadHolder::reverseComplementSeq (:593-609): the device copy with the next sync, the host mirror when it is read (rseq)
     Rec &r = s->rec[k];
-    char *q = rseq(s, r);
-    for (int i = 0, j = r.L - 1; i <= j; i++, j--) { const char a = q[i], b = q[j]; q[i] = (char)s->comp[b & 127]; q[j] = (char)s->comp[a & 127]; }
     reverse_start_stops(r);
     r.rc = !r.rc;
     if (al) al->flips.push_back((uint32_t)k);
@@ -265,7 +302,7 @@ std::string extend_slave(crass_cons *s, int tok, int slave_len)
     std::vector<int> *l = rlist(s, tok);
     if (!l) { s->error = 4; return std::string(); }
     for (int k : *l) {
-        const Rec &r = s->rec[k];
+        Rec &r = s->rec[k];
         const int a = first_full(r, slave_len);
         if (a < 0) { s->error = 5; return std::string(); }
         if ((int)r.ss[a] - 2 < 0 || (int)r.ss[a + 1] + 2 > r.L) continue;
@@ -356,10 +393,9 @@ std::string calc_dr_consensus(crass_cons *s, int GID, Aligner &al, int &collapse
 
 int read_decision_char(crass_cons *s, const Rec &r, int dec_diff, unsigned want)
 {
-    const char *q = s->hseq.data() + r.roff;
     for (size_t k = 0; k < r.ss.size(); k += 2) {
         const int pos = (int)r.ss[k] + dec_diff;
-        if (pos > 0 && pos < r.L) { const int di = c4(q[pos]); if (di >= 0 && (want & (1u << di))) return di; }
+        if (pos > 0 && pos < r.L) { const int di = c4(rchar(s, r, pos)); if (di >= 0 && (want & (1u << di))) return di; }
     }
     return -1;
 }
@@ -421,28 +457,35 @@ void split_grouped_dr(crass_cons *s, const CMap4 &opts, Aligner &al, int collaps
     for (int k = 0; k < 4; k++) if (char_gid[k]) parse_grouped_drs(s, char_gid[k]);
 }
 
-// device: bring the records flipped on the host up to date and add the pending placements to the coverage array
+// device: bring the flipped records up to date and add the pending placements to the coverage array.  One pinned staging
+// buffer goes up ({flips, placement records, placement positions}), the coverage comes down into pinned memory: per group
+// two copies and one wait (it was four pageable uploads — each a staging copy inside the runtime — and a pageable download).
 int sync_coverage(crass_cons *s, Aligner &al)
 {
-    if (!al.flips.empty()) {
-        HCHK(s, s->d_list.ensure(al.flips.size()));
-        HCHK(s, hipMemcpyAsync(s->d_list.p, al.flips.data(), al.flips.size() * 4, hipMemcpyHostToDevice, s->st));
-        HCHK(s, launch_cons_flip(s->d_seq.p, s->d_roff.p, s->d_rlen.p, s->d_list.p, (uint32_t)al.flips.size(), s->d_comp.p, s->st));
-        s->cnt.n_flips += al.flips.size();
+    const double t0 = now_sec();
+    const size_t nf = al.flips.size(), np = al.plc_rec.size();
+    HCHK(s, s->h_stage.ensure(nf + 2 * np + 4)); HCHK(s, s->d_stage.ensure(nf + 2 * np + 4));
+    HCHK(s, s->h_cov.ensure((size_t)al.length * 4)); HCHK(s, s->d_cov.ensure((size_t)al.length * 4));
+    uint32_t *hs = s->h_stage.p;
+    if (nf) memcpy(hs, al.flips.data(), nf * 4);
+    if (np) { memcpy(hs + nf, al.plc_rec.data(), np * 4); memcpy(hs + nf + np, al.plc_pos.data(), np * 4); }
+    if (nf + np) HCHK(s, hipMemcpyAsync(s->d_stage.p, hs, (nf + 2 * np) * 4, hipMemcpyHostToDevice, s->st));
+    if (nf) {
+        HCHK(s, launch_cons_flip(s->d_seq.p, s->d_roff.p, s->d_rlen.p, s->d_stage.p, (uint32_t)nf, s->d_comp.p, s->st));
+        s->cnt.n_flips += nf;
     }
-    HCHK(s, s->d_cov.ensure((size_t)al.length * 4));
     HCHK(s, hipMemsetAsync(s->d_cov.p, 0, (size_t)al.length * 16, s->st));
-    if (!al.plc_rec.empty()) {
-        HCHK(s, s->d_plc_rec.ensure(al.plc_rec.size())); HCHK(s, s->d_plc_pos.ensure(al.plc_pos.size()));
-        HCHK(s, hipMemcpyAsync(s->d_plc_rec.p, al.plc_rec.data(), al.plc_rec.size() * 4, hipMemcpyHostToDevice, s->st));
-        HCHK(s, hipMemcpyAsync(s->d_plc_pos.p, al.plc_pos.data(), al.plc_pos.size() * 4, hipMemcpyHostToDevice, s->st));
-        HCHK(s, launch_cons_cover(s->d_seq.p, s->d_roff.p, s->d_rlen.p, s->d_plc_rec.p, s->d_plc_pos.p, (uint32_t)al.plc_rec.size(), s->d_cov.p, al.length, s->st));
-        s->cnt.n_placements += al.plc_rec.size();
+    if (np) {
+        HCHK(s, launch_cons_cover(s->d_seq.p, s->d_roff.p, s->d_rlen.p, s->d_stage.p + nf, reinterpret_cast<const int32_t *>(s->d_stage.p + nf + np), (uint32_t)np,
+                                  s->d_cov.p, al.length, s->st));
+        s->cnt.n_placements += np;
     }
-    HCHK(s, hipMemcpyAsync(al.cov.data(), s->d_cov.p, (size_t)al.length * 16, hipMemcpyDeviceToHost, s->st));
+    HCHK(s, hipMemcpyAsync(s->h_cov.p, s->d_cov.p, (size_t)al.length * 16, hipMemcpyDeviceToHost, s->st));
     HCHK(s, hipStreamSynchronize(s->st));
+    memcpy(al.cov.data(), s->h_cov.p, (size_t)al.length * 16);
     al.flips.clear(); al.plc_rec.clear(); al.plc_pos.clear();
     s->cnt.n_groups_parsed++;
+    s->t_sync += now_sec() - t0;
     return CRASS_OK;
 }
 
@@ -457,10 +500,13 @@ int parse_grouped_drs(crass_cons *s, int GID)
     al.cov.assign((size_t)al.length * 4, 0); al.cons.assign((size_t)al.length, 'N'); al.conserv.assign((size_t)al.length, 0.0f);
     // Aligner::setMasterDR :73-86
     al.master = master; al.off[master] = (int)(al.length * kConsArrayStart); al.master_len = (int)tstr(s, master).size();
+    double tq = now_sec();
     place_reads(s, al, master);
     calc_zone(s, al);
+    s->t_place += now_sec() - tq;
     if (s->error) return 0;
     // populateCoverageArray :750-798 — first every slave's two alignments in one batch ...
+    tq = now_sec();
     const std::string master_str = tstr(s, master);
     std::vector<int> slave_pos; std::vector<std::string> strs;
     for (size_t q = 0; q < g.size(); q++) if (g[q] != master) { slave_pos.push_back((int)q); strs.push_back(tstr(s, g[q])); }
@@ -469,7 +515,7 @@ int parse_grouped_drs(crass_cons *s, int GID)
     if (pre != s->pre.end() && pre->second.count == strs.size()) {         // aligned up-front with every other original group
         res.assign(s->pre_res.begin() + (long)pre->second.first, s->pre_res.begin() + (long)(pre->second.first + pre->second.count));
         s->pre.erase(pre);
-    } else if (ksw_batch(s, strs, master_str, res)) return 0;
+    } else { tq = now_sec(); const int kb = ksw_batch(s, strs, master_str, res); s->t_ksw += now_sec() - tq; if (kb) return 0; }
     std::vector<int> flags(strs.size(), 0), offs(strs.size(), 0);
     std::vector<int> tie_idx; std::vector<std::string> ext;
     for (size_t v = 0; v < strs.size(); v++) {
@@ -478,7 +524,10 @@ int parse_grouped_drs(crass_cons *s, int GID)
     }
     if (s->error) return 0;
     if (!ext.empty()) {                          // ... the ties once more with two more bases on either side (alignSlave :98-115)
-        if (ksw_batch(s, ext, master_str, res2)) return 0;
+        tq = now_sec();
+        const int kb2 = ksw_batch(s, ext, master_str, res2);
+        s->t_ksw += now_sec() - tq;
+        if (kb2) return 0;
         for (size_t e = 0; e < ext.size(); e++) {
             const int v = tie_idx[e];
             flags[v] = 0;
@@ -487,21 +536,62 @@ int parse_grouped_drs(crass_cons *s, int GID)
         }
     }
     // ... then Aligner::alignSlave's effects, in group order (new tokens are numbered in this order)
+    s->t_pre += now_sec() - tq;
+    tq = now_sec();
+    // (the bookkeeping first; then the reads themselves — turning a reversed slave's reads, finding every read's full-length
+    // repeats for the coverage array — in one pass over a flat list, so that the records can be requested ahead of their turn)
+    struct Item { const std::vector<int> *l; int cur_len, off; bool flip; };
+    std::vector<Item> items;
     for (size_t v = 0; v < strs.size() && !s->error; v++) {
         int tok = g[slave_pos[v]];
         al.off[tok] = -1;
         if (flags[v] & F_FAILED) continue;
+        bool flip = false;
         if (flags[v] & F_REVERSED) {
-            std::vector<int> *l = rlist(s, tok);
-            if (!l) { s->error = 4; break; }
-            for (int k : *l) flip_record(s, &al, k);
+            if (!rlist(s, tok)) { s->error = 4; break; }
+            flip = true;
             const int st = add_string(s, reverse_complement(strs[v]));
             s->reads_of[st - 2] = std::move(s->reads_of[tok - 2]);
             g[slave_pos[v]] = st;
             tok = st;
         }
         al.off[tok] = al.off[master] + offs[v];
-        place_reads(s, al, tok);
+        const std::vector<int> *l = rlist(s, tok);
+        if (!l) { s->error = 4; break; }                 // (place_reads' check)
+        items.push_back(Item{l, (int)tstr(s, tok).size(), al.off[tok], flip});
+    }
+    s->t_fa += now_sec() - tq;
+    if (!s->error && !items.empty()) {
+        double tb = now_sec();
+        struct Ent { int k, cur_len, off; bool flip; };
+        std::vector<Ent> ents;
+        for (const Item &it : items) for (int k : *it.l) ents.push_back(Ent{k, it.cur_len, it.off, it.flip});
+        // one pass on this thread with the records requested ahead of their turn: every record is a cache miss and its list a
+        // second one (a few hundred reads per group: waking the host pool 64 times cost more than it saved — 6.5 ms of 9.7)
+        s->t_fb += now_sec() - tb; tb = now_sec();
+        const size_t ne = ents.size();
+        for (size_t e = 0; e < ne && !s->error; e++) {
+            if (e + 16 < ne) __builtin_prefetch(&s->rec[ents[e + 16].k]);
+            if (e + 8 < ne) __builtin_prefetch(s->rec[ents[e + 8].k].ss.data());
+            Rec &r = s->rec[ents[e].k];
+            if (ents[e].flip) { reverse_start_stops(r); r.rc = !r.rc; }          // flip_record: the device copy follows with the sync
+            const int cur_len = ents[e].cur_len;
+            int a = first_full(r, cur_len);
+            if (a < 0) { s->error = 5; break; }
+            int b = a + 1;
+            do {
+                if (((int)r.ss[b] - (int)r.ss[a]) == (cur_len - 1)) {
+                    const int pos = ents[e].off - (int)r.ss[a];
+                    if (pos < 0 || pos + r.L > al.length) { s->error = 6; break; }     // "MEMORY CORRUPTION" in the reference
+                    al.plc_rec.push_back((uint32_t)ents[e].k); al.plc_pos.push_back(pos);
+                }
+                a += 2; b += 2;
+                if (a >= (int)(r.ss.size() / 2) * 2) break;
+            } while (((int)r.ss[b] - (int)r.ss[a]) == (cur_len - 1));
+        }
+        s->t_fc += now_sec() - tb; tb = now_sec();
+        for (const Ent &e : ents) if (e.flip) al.flips.push_back((uint32_t)e.k);
+        s->t_fd += now_sec() - tb;
     }
     if (s->error) return 0;
     for (size_t q = 0; q < g.size();) {          // "kill the unfounded ones"
@@ -510,11 +600,14 @@ int parse_grouped_drs(crass_cons *s, int GID)
         if (it != al.off.end() && it->second == -1 && rlist(s, tok) != nullptr) { clear_read_list(s, tok); s->reads_of[tok - 2].reset(); g.erase(g.begin() + (long)q); continue; }
         q++;
     }
+    s->t_flip += now_sec() - tq;
     if (sync_coverage(s, al)) return 0;
+    tq = now_sec();
     int collapsed_pos = -1;
     CMap4 opts;
     std::vector<uint8_t> refined((size_t)al.length + 2, 0);
     const std::string true_DR = calc_dr_consensus(s, GID, al, collapsed_pos, opts, refined);
+    s->t_cons += now_sec() - tq;
     if (s->error) return 0;
     if (true_DR.size() > (size_t)s->prm.highDRsize) { s->group[GID].reset(); return 0; }
     if (opts.size() == 0) {
@@ -532,7 +625,7 @@ int parse_grouped_drs(crass_cons *s, int GID)
         }
         al.zone_start = zs; al.zone_end = ze;
     }
-    if (opts.size() > 0) { split_grouped_dr(s, opts, al, collapsed_pos, GID); return 1; }
+    if (opts.size() > 0) { tq = now_sec(); split_grouped_dr(s, opts, al, collapsed_pos, GID); s->t_split += now_sec() - tq; return 1; }
     const std::string rcd = reverse_complement(true_DR);
     const std::string lau = true_DR < rcd ? true_DR : rcd;           // laurenize, SeqUtils.cpp:89-97
     const bool rev_comp = lau != true_DR;
@@ -577,31 +670,56 @@ int update_all_start_stops(crass_cons *s)
     const std::vector<char> &drc = s->dr_tab;
     std::vector<ConsSwTask> tasks; std::vector<uint8_t> which;          // which: 0 front, 1 back
     uint64_t dir_total = 0;
-    for (size_t k = 0; k < s->rec.size(); k++) {
-        Rec &r = s->rec[k];
-        if (!r.upd || !r.alive) continue;
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    double t_ph = now_sec();
+    auto sub = [&](const char *what) { if (timing) { const double t = now_sec(); fprintf(stderr, "[crass_timing] consensus:   updateStartStops: %-28s %.4f s\n", what, t - t_ph); t_ph = t; } };
+    // pass 1 (ranges of records on the host pool: every record's list is its own allocation, i.e. a cache miss): the pair
+    // arithmetic, and which of the two searches the record needs; pass 2 (in order): the task list and its scratch offsets
+    const size_t n_rec = s->rec.size();
+    std::vector<uint8_t> need(n_rec, 0);                 // bit 0: front search, bit 1: back search
+    {
+        const size_t per_task = 4096;
+        host_parallel_for((n_rec + per_task - 1) / per_task, 16, [&](size_t t) {
+            const size_t k1 = std::min(n_rec, (t + 1) * per_task);
+            for (size_t k = t * per_task; k < k1; k++) {
+                Rec &r = s->rec[k];
+                if (!r.upd || !r.alive) continue;
+                const int DR_length = (int)dr_len[r.upd_dr];
+                for (size_t q = 0; q + 1 < r.ss.size(); q += 2) {
+                    int usable = DR_length - 1;
+                    if (r.upd_front >= (int)r.ss[q]) { usable = DR_length - (r.upd_front - (int)r.ss[q]) - 1; r.ss[q] = 0; }
+                    else r.ss[q] -= (uint32_t)r.upd_front;
+                    r.ss[q + 1] = r.ss[q] + (uint32_t)usable;
+                    if (r.ss[q + 1] >= (uint32_t)r.L) r.ss[q + 1] = (uint32_t)r.L - 1;
+                }
+                if (r.ss.empty()) continue;
+                uint8_t nd = 0;
+                if (r.ss[0] > lowSp) nd |= 1;
+                if ((uint32_t)r.L - r.ss.back() > lowSp) nd |= 2;
+                need[k] = nd;
+                r.upd_first = r.ss[0]; r.upd_last = r.ss.back();
+            }
+        });
+    }
+    for (size_t k = 0; k < n_rec; k++) {
+        const uint8_t nd = need[k];
+        if (!nd) continue;
+        const Rec &r = s->rec[k];
         const int DR_length = (int)dr_len[r.upd_dr];
-        for (size_t q = 0; q + 1 < r.ss.size(); q += 2) {
-            int usable = DR_length - 1;
-            if (r.upd_front >= (int)r.ss[q]) { usable = DR_length - (r.upd_front - (int)r.ss[q]) - 1; r.ss[q] = 0; }
-            else r.ss[q] -= (uint32_t)r.upd_front;
-            r.ss[q + 1] = r.ss[q] + (uint32_t)usable;
-            if (r.ss[q + 1] >= (uint32_t)r.L) r.ss[q + 1] = (uint32_t)r.L - 1;
-        }
-        if (r.ss.empty()) continue;
-        if (r.ss[0] > lowSp) {
-            ConsSwTask t; t.rec = (uint32_t)k; t.dr = r.upd_dr; t.start = 0; t.len = (int)r.ss[0] - (int)lowSp; t.dir_off = dir_total;
+        if (nd & 1) {
+            ConsSwTask t; t.rec = (uint32_t)k; t.dr = r.upd_dr; t.start = 0; t.len = (int)r.upd_first - (int)lowSp; t.dir_off = dir_total;
             dir_total += cons_sw_scratch_bytes((uint32_t)t.len, (uint32_t)DR_length);
             tasks.push_back(t); which.push_back(0);
         }
-        const uint32_t end_dist = (uint32_t)r.L - r.ss.back();
-        if (end_dist > lowSp) {
-            ConsSwTask t; t.rec = (uint32_t)k; t.dr = r.upd_dr; t.start = (int)(r.ss.back() + lowSp); t.len = (int)(end_dist - lowSp); t.dir_off = dir_total;
+        if (nd & 2) {
+            const uint32_t end_dist = (uint32_t)r.L - r.upd_last;
+            ConsSwTask t; t.rec = (uint32_t)k; t.dr = r.upd_dr; t.start = (int)(r.upd_last + lowSp); t.len = (int)(end_dist - lowSp); t.dir_off = dir_total;
             dir_total += cons_sw_scratch_bytes((uint32_t)t.len, (uint32_t)DR_length);
             tasks.push_back(t); which.push_back(1);
         }
     }
     s->cnt.n_sw_tasks = tasks.size();
+    sub("pair arithmetic, task list");
     std::vector<ConsSwOut> out(tasks.size());
     std::vector<int32_t> lev(tasks.size(), 0);
     if (!tasks.empty()) {
@@ -619,17 +737,21 @@ int update_all_start_stops(crass_cons *s)
             size_t end = at; const uint64_t base = tasks[at].dir_off;
             while (end < tasks.size() && (end == at || tasks[end].dir_off + cons_sw_scratch_bytes((uint32_t)tasks[end].len, dr_len[tasks[end].dr]) - base <= budget)) end++;
             const size_t n = end - at;
-            std::vector<ConsSwTask> chunk(tasks.begin() + (long)at, tasks.begin() + (long)end);
-            for (auto &t : chunk) t.dir_off -= base;
-            const uint64_t bytes = chunk.back().dir_off + cons_sw_scratch_bytes((uint32_t)chunk.back().len, dr_len[chunk.back().dr]);
+            // (straight from / into pageable memory: pinned staging buffers would be allocated per call — measured slower, 7.0 vs 5.8 ms)
+            const bool whole = at == 0 && end == tasks.size();           // one chunk (the usual case): its offsets are already relative
+            std::vector<ConsSwTask> part;
+            if (!whole) { part.assign(tasks.begin() + (long)at, tasks.begin() + (long)end); for (auto &t : part) t.dir_off -= base; }
+            const ConsSwTask *chunk = whole ? tasks.data() : part.data();
+            const uint64_t bytes = chunk[n - 1].dir_off + cons_sw_scratch_bytes((uint32_t)chunk[n - 1].len, dr_len[chunk[n - 1].dr]);
             HCHK(s, s->d_dirs.ensure(bytes + 64)); HCHK(s, s->d_tasks.ensure(n)); HCHK(s, s->d_swout.ensure(n));
-            HCHK(s, hipMemcpyAsync(s->d_tasks.p, chunk.data(), n * sizeof(ConsSwTask), hipMemcpyHostToDevice, s->st));
+            HCHK(s, hipMemcpyAsync(s->d_tasks.p, chunk, n * sizeof(ConsSwTask), hipMemcpyHostToDevice, s->st));
             HCHK(s, launch_cons_sw(s->d_seq.p, s->d_roff.p, s->d_rlen.p, s->d_tasks.p, (uint32_t)n, s->d_drchars.p, s->d_droff.p, s->d_drlen.p, s->d_dirs.p,
                                    s->d_swout.p, s->st));
             HCHK(s, hipMemcpyAsync(out.data() + at, s->d_swout.p, n * sizeof(ConsSwOut), hipMemcpyDeviceToHost, s->st));
             HCHK(s, hipStreamSynchronize(s->st));
             at = end;
         }
+        sub("smithWaterman batch");
         // the Levenshtein filter of SmithWaterman.cpp:283 over (a_ret, b_ret), as one batch of the engine's kernel
         std::vector<uint64_t> a_off(tasks.size()), b_off(tasks.size()); std::vector<uint32_t> a_len(tasks.size()), b_len(tasks.size());
         uint32_t max_len = 1;
@@ -649,27 +771,54 @@ int update_all_start_stops(crass_cons *s)
         HCHK(s, hipMemcpyAsync(lev.data(), s->d_lev.p, n * 4, hipMemcpyDeviceToHost, s->st));
         HCHK(s, hipStreamSynchronize(s->st));
     }
-    // the decisions of updateStartStops on the alignments, front task before back task of a read (tasks are in that order)
-    for (size_t q = 0; q < tasks.size(); q++) {
+    sub("Levenshtein batch");
+    // the decisions of updateStartStops on the alignments, front task before back task of a read (tasks are in that order);
+    // ranges of tasks on the host pool, cut between records (a record's two tasks stay with one worker)
+    std::vector<size_t> cuts(1, 0);
+    { const size_t per_task = 8192;
+      for (size_t q = per_task; q < tasks.size(); q += per_task) { size_t c = q; while (c < tasks.size() && tasks[c].rec == tasks[c - 1].rec) c++; if (c > cuts.back() && c < tasks.size()) cuts.push_back(c); }
+      cuts.push_back(tasks.size()); }
+    std::vector<uint64_t> added(cuts.size(), 0);
+    std::vector<int> bad(cuts.size(), 0);
+    host_parallel_for(cuts.size() - 1, 16, [&](size_t ti) {
+    uint64_t n_added = 0;
+    for (size_t q = cuts[ti]; q < cuts[ti + 1]; q++) {
         Rec &r = s->rec[tasks[q].rec];
         const ConsSwOut &o = out[q];
-        const std::string DR(drc.data() + dr_off[tasks[q].dr], dr_len[tasks[q].dr]);
+        const char *DR = drc.data() + dr_off[tasks[q].dr];
+        const size_t DR_size = dr_len[tasks[q].dr];
         int part_s = o.a_start, part_e = o.a_end, a_len = o.a_len, b_len = o.b_len;
         const double similarity_ld = 1.0 - (lev[q] / (double)a_len);
         if (!(similarity_ld >= kPartialSim)) { part_s = 0; part_e = 0; a_len = 0; b_len = 0; }
         if (0 == part_e || part_e - part_s < kMinPartialLen) continue;
-        const std::string b_ret = DR.substr((size_t)o.b_off, (size_t)b_len);
+        // b_ret = DR.substr(b_off, b_len) (clamped to the string's end).  "DR.rfind(b_ret) + b_ret.size() == DR.size()": the LAST
+        // occurrence ends where DR ends <=> DR ends with b_ret; "0 == DR.find(b_ret)" <=> DR starts with it (no strings built:
+        // 108 k tasks each made two)
+        if ((size_t)o.b_off > DR_size) { bad[ti] = 1; return; }
+        const char *b_ret = DR + o.b_off;
+        const size_t b_size = std::min((size_t)b_len, DR_size - (size_t)o.b_off);
         if (which[q] == 0) {
-            if ((DR.rfind(b_ret) + b_ret.size()) == DR.size() && 0 == part_s) { r.ss.insert(r.ss.begin(), (uint32_t)part_e); r.ss.insert(r.ss.begin(), 0u); s->cnt.n_partials_added++; }
+            if (0 == memcmp(DR + DR_size - b_size, b_ret, b_size) && 0 == part_s) { r.ss.insert(r.ss.begin(), (uint32_t)part_e); r.ss.insert(r.ss.begin(), 0u); n_added++; }
         } else {
-            if ((r.L - 1) == part_e && 0 == DR.find(b_ret)) {
+            if ((r.L - 1) == part_e && 0 == memcmp(DR, b_ret, b_size)) {
                 uint32_t i = (uint32_t)(part_s + std::abs(a_len - b_len)), j = (uint32_t)part_e;       // startStopsAdd :263-297
                 if (j >= (uint32_t)r.L) j = (uint32_t)r.L - 1;
-                r.ss.push_back(i); r.ss.push_back(j); s->cnt.n_partials_added++;
+                r.ss.push_back(i); r.ss.push_back(j); n_added++;
             }
         }
     }
-    for (auto &r : s->rec) if (r.upd && r.alive && r.upd_rev) { reverse_start_stops(r); r.rc = !r.rc; }     // (the sequence itself is not handed back)
+    added[ti] = n_added;
+    });
+    for (size_t ti = 0; ti + 1 < cuts.size(); ti++) { s->cnt.n_partials_added += added[ti]; if (bad[ti]) { s->error = 3; return CRASS_OK; } }
+    sub("decisions");
+    {   // (the sequence itself is not handed back)
+        const size_t per_task = 8192;
+        host_parallel_for((n_rec + per_task - 1) / per_task, 16, [&](size_t t) {
+            const size_t k1 = std::min(n_rec, (t + 1) * per_task);
+            for (size_t k = t * per_task; k < k1; k++) { Rec &r = s->rec[k]; if (r.upd && r.alive && r.upd_rev) { reverse_start_stops(r); r.rc = !r.rc; } }
+        });
+    }
+    sub("final orientation");
     return CRASS_OK;
 }
 
@@ -689,12 +838,21 @@ void flatten(crass_cons *s)
     }
     const size_t nr = s->rec.size();
     s->o_alive.assign(nr, 0); s->o_rc.assign(nr, 0); s->o_token.assign(nr, 0); s->o_nss.assign(nr, 0); s->o_ss_off.assign(nr + 1, 0); s->o_ss.clear();
-    for (size_t k = 0; k < nr; k++) {
-        const Rec &r = s->rec[k];
-        s->o_alive[k] = r.alive; s->o_rc[k] = r.rc; s->o_nss[k] = (uint32_t)r.ss.size(); s->o_ss_off[k] = s->o_ss.size();
-        s->o_ss.insert(s->o_ss.end(), r.ss.begin(), r.ss.end());
+    {   // offsets in order, then the lists themselves in ranges on the host pool
+        uint64_t at = 0;
+        for (size_t k = 0; k < nr; k++) { s->o_ss_off[k] = at; at += s->rec[k].ss.size(); }
+        s->o_ss_off[nr] = at;
+        s->o_ss.resize((size_t)at);
+        const size_t per_task = 8192;
+        host_parallel_for((nr + per_task - 1) / per_task, 16, [&](size_t t) {
+            const size_t k1 = std::min(nr, (t + 1) * per_task);
+            for (size_t k = t * per_task; k < k1; k++) {
+                const Rec &r = s->rec[k];
+                s->o_alive[k] = r.alive; s->o_rc[k] = r.rc; s->o_nss[k] = (uint32_t)r.ss.size();
+                if (!r.ss.empty()) memcpy(s->o_ss.data() + s->o_ss_off[k], r.ss.data(), r.ss.size() * 4);
+            }
+        });
     }
-    s->o_ss_off[nr] = s->o_ss.size();
     s->o_tokread_off.assign(s->tok.size() + 1, 0); s->o_tokread_idx.clear(); s->o_has.assign(s->tok.size() + 1, 0);
     for (size_t t = 0; t < s->tok.size(); t++) {
         s->o_tokread_off[t] = s->o_tokread_idx.size();
@@ -744,27 +902,36 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
         s->rec.resize((size_t)in->n_rec);
         uint64_t at = 0;
         std::vector<uint64_t> roff((size_t)in->n_rec + 1); std::vector<uint32_t> rlen((size_t)in->n_rec + 1);
-        for (uint64_t k = 0; k < in->n_rec; k++) {
+        for (uint64_t k = 0; k < in->n_rec; k++) {           // offsets and the token lists: in record order
             Rec &r = s->rec[(size_t)k];
             r.read = in->rec_read[k];
             if (r.read >= in->n_reads) return CRASS_ERR_INVALID_ARG;
             r.L = (int)(in->seq_off[r.read + 1] - in->seq_off[r.read]);
             r.roff = at; at += (uint64_t)r.L;
             roff[(size_t)k] = r.roff; rlen[(size_t)k] = (uint32_t)r.L;
-            r.ss.assign(in->ss_pool + in->rec_ss_off[k], in->ss_pool + in->rec_ss_off[k] + in->rec_nss[k]);
             r.rc = in->rec_lowlexi[k] ? 0 : 1;
             const int tok = (int)in->rec_token[k];
             if (tok < 2 || tok > (int)s->tok.size() + 1) return CRASS_ERR_INVALID_ARG;
             if (!s->reads_of[tok - 2]) s->reads_of[tok - 2].reset(new std::vector<int>());
             s->reads_of[tok - 2]->push_back((int)k);
         }
+        // the records' characters and start/stop lists: ranges of records on the host pool.  The host mirror keeps the reads as
+        // they came (host_rc = 0); RH_Seq's orientation (DRLowLexi's, ReadHolder.cpp:573-590) is applied on the DEVICE, by the flip
+        // kernel over the records with rc set — the host's own copy of a record is only turned when it is read (rseq)
         s->hseq.resize((size_t)at);
-        for (uint64_t k = 0; k < in->n_rec; k++) {
-            const Rec &r = s->rec[(size_t)k];
-            const char *src = in->seqs + in->seq_off[r.read];
-            char *dst = s->hseq.data() + r.roff;
-            if (!r.rc) memcpy(dst, src, (size_t)r.L);
-            else for (int i = 0; i < r.L; i++) dst[i] = (char)s->comp[src[r.L - 1 - i] & 127];
+        std::vector<uint32_t> rc_list;
+        for (uint64_t k = 0; k < in->n_rec; k++) if (s->rec[(size_t)k].rc) rc_list.push_back((uint32_t)k);
+        {
+            const size_t per_task = 4096, n_rec = (size_t)in->n_rec;
+            host_parallel_for((n_rec + per_task - 1) / per_task, 16, [&](size_t t) {
+                const size_t k1 = std::min(n_rec, (t + 1) * per_task);
+                for (size_t k = t * per_task; k < k1; k++) {
+                    Rec &r = s->rec[k];
+                    r.ss.assign(in->ss_pool + in->rec_ss_off[k], in->ss_pool + in->rec_ss_off[k] + in->rec_nss[k]);
+                    memcpy(s->hseq.data() + r.roff, in->seqs + in->seq_off[r.read], (size_t)r.L);
+                    r.host_rc = 0;
+                }
+            });
         }
         uint64_t dr_room = 0;                              // every group may end with one true DR (<= 4 x maxL, in practice <= highDR)
         for (uint32_t g = 0; g < in->n_groups; g++) dr_room += 64;
@@ -774,6 +941,11 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
         HCHK(s, hipMemcpyAsync(s->d_roff.p, roff.data(), roff.size() * 8, hipMemcpyHostToDevice, s->st));
         HCHK(s, hipMemcpyAsync(s->d_rlen.p, rlen.data(), rlen.size() * 4, hipMemcpyHostToDevice, s->st));
         HCHK(s, hipMemcpyAsync(s->d_comp.p, s->comp, 128, hipMemcpyHostToDevice, s->st));
+        if (!rc_list.empty()) {
+            HCHK(s, s->d_list.ensure(rc_list.size()));
+            HCHK(s, hipMemcpyAsync(s->d_list.p, rc_list.data(), rc_list.size() * 4, hipMemcpyHostToDevice, s->st));
+            HCHK(s, launch_cons_flip(s->d_seq.p, s->d_roff.p, s->d_rlen.p, s->d_list.p, (uint32_t)rc_list.size(), s->d_comp.p, s->st));
+        }
         HCHK(s, hipStreamSynchronize(s->st));
         lap("records, RH_Seq, upload");
         s->next_gid = (int)in->n_groups + 1;
@@ -800,6 +972,10 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
         }
         if (s->hip_err) return s->hip_err == (int)hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP;
         lap("groups (coverage, consensus, splits)");
+        if (timing) fprintf(stderr, "[crass_timing] consensus:   of which place %.4f, slaves' effects %.4f, coverage round trip %.4f, consensus %.4f, ksw (split groups, ties) %.4f, splits (incl. their groups) %.4f s\n",
+                            s->t_place, s->t_flip, s->t_sync, s->t_cons, s->t_ksw, s->t_split);
+        if (timing) fprintf(stderr, "[crass_timing] consensus:   slaves: decisions %.4f; effects = bookkeeping %.4f + entries %.4f + records %.4f + gather %.4f s\n",
+                            s->t_pre, s->t_fa, s->t_fb, s->t_fc, s->t_fd);
         if (!s->error) {
             if ((uint64_t)s->dr_tab.size() > dr_room) return CRASS_ERR_OVERFLOW;
             const int us = update_all_start_stops(s);

@@ -313,6 +313,15 @@ struct crass_hip_ctx {
     uint64_t hit_cap_hint = 0;                // speculative bound for pass 2's flagged reads (0: none yet)
     bool recruit_exact = false;               // the next recruit call must not speculate (it repeats an overflowed one)               // speculative survivor bound for the next seed scan (0: none yet)
     hipStream_t copy_stream = nullptr;
+    // Long reads: k_hint_positions runs in kHintParts slices of the reads, the first on the main stream and the others on
+    // hint_stream BESIDE the walking kernel, which is launched slice by slice behind the slice's hints (run_survivors): the
+    // hint kernel is VALU-issue bound, the walk LDS-latency bound at two waves per SIMD.
+    static constexpr int kHintParts = 4;     // (at most; the default is two — see setup_pos_hints)
+    hipStream_t hint_stream = nullptr;
+    hipEvent_t ev_hint[kHintParts] = {nullptr, nullptr, nullptr, nullptr}, ev_hint_go = nullptr;
+    int hint_parts = 1;                         // slices of this read set (1: one launch on the main stream)
+    uint64_t hint_read_split[kHintParts + 1] = {0, 0, 0, 0, 0}, hint_word_split[kHintParts + 1] = {0, 0, 0, 0, 0};
+    bool hint_pending = false;                  // slices are in flight on hint_stream: the main stream has not waited for them yet
     hipEvent_t ev_gathered = nullptr;
     hipEvent_t ev_premerge = nullptr;           // recorded behind a merge queued in the seed scan: the hand-off copy waits for it
     mutable bool bulk_pending = false;          // rare paths only: D2H copies of the candidates' own strings in flight on copy_stream
@@ -650,6 +659,14 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     if (hipSetDevice(device) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
+    {   // lowest priority: its blocks fill what the walking kernel (two waves per SIMD: its LDS) leaves free, not the other way round
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&c->hint_stream, hipStreamNonBlocking, getenv("CRASS_HINT_SAME_PRIORITY") ? 0 : prio_lo) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
+    }
+    for (int q = 0; q < crass_hip_ctx::kHintParts; q++)
+        if (hipEventCreateWithFlags(&c->ev_hint[q], hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
+    if (hipEventCreateWithFlags(&c->ev_hint_go, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_premerge, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
@@ -718,6 +735,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->worker.stop();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->hint_stream) (void)hipStreamSynchronize(c->hint_stream);
     (void)sdma_wait(c->dma);                            // (before any buffer goes)
     (void)c->wait_dx();
     c->lb_status.release(); c->lb_ticket.release(); c->h_lb_fail.release();
@@ -726,6 +744,9 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
     if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
+    for (int q = 0; q < crass_hip_ctx::kHintParts; q++) if (c->ev_hint[q]) (void)hipEventDestroy(c->ev_hint[q]);
+    if (c->ev_hint_go) (void)hipEventDestroy(c->ev_hint_go);
+    if (c->hint_stream) (void)hipStreamDestroy(c->hint_stream);
     sdma_destroy(c->dma); c->dma = nullptr;
     for (auto &d : c->dma_dx) { sdma_destroy(d); d = nullptr; }
     if (c->ev_premerge) (void)hipEventDestroy(c->ev_premerge);
@@ -791,6 +812,16 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     c->n_pos_hint_words = at;
     c->R.pos_hint = c->d_pos_hint.p; c->R.pos_hint_off = c->d_pos_hint_off.p;
     c->pos_hint_blk = false;
+    // slices: read boundaries n i / K; slice i covers the hint words [roundup256(off[r_i]), roundup256(off[r_i+1])), so every word
+    // of a read below r_i+1 belongs to a slice <= i (CRASS_HINT_PARTS=1: the A/B switch)
+    { const char *hp = getenv("CRASS_HINT_PARTS");       // (A/B: 1 = one launch on the main stream)
+      const int want = hp ? atoi(hp) : 2;
+      c->hint_parts = (n >= 4096 && at >= (1u << 20)) ? std::min(std::max(want, 1), (int)crass_hip_ctx::kHintParts) : 1; }
+    for (int q = 0; q <= c->hint_parts; q++) {
+        const uint64_t r = q == c->hint_parts ? n : n * (uint64_t)q / (uint64_t)c->hint_parts;
+        c->hint_read_split[q] = r;
+        c->hint_word_split[q] = q == c->hint_parts ? at : ((off[r] + 255) & ~255ull);
+    }
     if (lengths && n <= 0xFFFFFFFFull) {                // ragged: the read of every block's first hint word (k_hint_positions)
         std::vector<uint32_t> blk((at + 255) / 256 + 1, 0);
         uint64_t r = 0;
@@ -936,10 +967,19 @@ static void ensure_distinct(crass_hip_ctx *c);
 // ------------------------------------------------------------------------------------------
 // runs the survivor kernel over `n_total` survivors (packed list in d_idx, or the exception
 // list) in chunks and appends every found record, in order, to `L`
+// the main stream waits for every slice of the position hints (whoever reads them without slicing its own launches)
+static int hint_wait_all(crass_hip_ctx *c)
+{
+    if (!c->hint_pending) return CRASS_OK;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_hint[c->hint_parts - 1], 0));
+    c->hint_pending = false;
+    return CRASS_OK;
+}
+
 static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip_ctx::P1List &L,
                          const uint64_t *surv_idx_host)
 {
-    if (n_total == 0) return CRASS_OK;
+    if (n_total == 0) return hint_wait_all(c);
     // Long reads: the Levenshtein fallback rows are sized for 256-base strings (spacers are a few dozen bases), which
     // is what lets several waves share a CU's LDS; a read that needs longer rows comes back with err == 6 and is
     // redone by a second launch with the uncapped layout.
@@ -968,10 +1008,30 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         }
         // for the non-exception path the count lives on the device; chunking uses a host-known bound
         if (!exc && off == 0) HIPCHK(c, c->stamp(8, 1));
-        HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
-                                  c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
-                                  c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds,
-                                  (int)std::min<uint64_t>(grid, nchunk), c->stream));
+        if (!exc && c->hint_pending && off == 0 && nchunk == n_total) {
+            // the walk, slice by slice behind the slice's hints (slot boundaries: the survivors with a read below the slice's end;
+            // the list is ascending, and 0, 1, 2, ... when no host copy of it was made)
+            uint64_t s0 = 0;
+            for (int q = 0; q < c->hint_parts; q++) {
+                const uint64_t r1 = c->hint_read_split[q + 1];
+                uint64_t s1 = q + 1 == c->hint_parts ? nchunk
+                            : (surv_idx_host ? (uint64_t)(std::lower_bound(surv_idx_host, surv_idx_host + nchunk, r1) - surv_idx_host) : std::min<uint64_t>(r1, nchunk));
+                if (q > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_hint[q], 0));
+                if (s1 > s0)
+                    HIPCHK(c, launch_survivor(R, c->dp, false, c->d_idx.p + s0, c->d_count.p + 1, s1 - s0,
+                                              c->d_surv.p + s0, c->d_dr.p + s0 * (size_t)stride, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
+                                              c->d_found.p, c->hints_valid ? c->d_hit_info.p : nullptr, lds,
+                                              (int)std::min<uint64_t>(grid, s1 - s0), c->stream));
+                s0 = s1;
+            }
+            c->hint_pending = false;
+        } else {
+            { const int hw = hint_wait_all(c); if (hw) return hw; }
+            HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
+                                      c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
+                                      c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds,
+                                      (int)std::min<uint64_t>(grid, nchunk), c->stream));
+        }
         if (capped)
             HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
                                       c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
@@ -1111,6 +1171,7 @@ static int ensure_dense_buffers(crass_hip_ctx *c, uint64_t n_alloc, uint64_t poo
 static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t *d_nsurv, bool *overflow)
 {
     *overflow = false;
+    { const int hw = hint_wait_all(c); if (hw) return hw; }
     const SurvLds lds = survivor_lds_layout(c->max_len, c->dp);
     if (lds.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
     const uint32_t stride = c->dr_stride;
@@ -1447,8 +1508,16 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         // all non-exception reads survive: mask = ~exc_mask (exc_mask is 32-bit words of the same bit order)
         HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0xFF, n_words * 8, c->stream));
         if (c->R.pos_hint) {
-            hipError_t he = launch_hint_positions(c->R, c->dp, c->d_pos_hint_off.p, c->pos_hint_blk ? c->d_pos_hint_blk.p : nullptr, c->n_pos_hint_words, c->d_pos_hint.p, c->stream);
-            if (he != hipSuccess) { c->last_hip = (int)he; return CRASS_ERR_HIP; }
+            const uint32_t *blk = c->pos_hint_blk ? c->d_pos_hint_blk.p : nullptr;
+            if (c->hint_parts > 1) { HIPCHK(c, hipEventRecord(c->ev_hint_go, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->hint_stream, c->ev_hint_go, 0)); }
+            for (int q = 0; q < c->hint_parts; q++) {
+                hipStream_t hs = q == 0 ? c->stream : c->hint_stream;
+                hipError_t he = launch_hint_positions(c->R, c->dp, c->d_pos_hint_off.p, blk, c->n_pos_hint_words, c->d_pos_hint.p, hs,
+                                                      c->hint_word_split[q], c->hint_word_split[q + 1]);
+                if (he != hipSuccess) { c->last_hip = (int)he; return CRASS_ERR_HIP; }
+                if (q > 0) HIPCHK(c, hipEventRecord(c->ev_hint[q], c->hint_stream));
+            }
+            c->hint_pending = c->hint_parts > 1;
         }
     }
     c->hints_valid = fast;

@@ -271,7 +271,8 @@ hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t
 // per-position seed hints for long / ragged packed reads (default window and DR/spacer bounds only):
 // hint_off[n_reads + 1] = prefix sums of ceil(L/64) (device), n_words = hint_off[n_reads] (host-known)
 hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
-                                 uint64_t *hint_bits, hipStream_t st);      // blk_read[b] = read of tile 256 b (ragged lengths; else nullptr)
+                                 uint64_t *hint_bits, hipStream_t st,       // blk_read[b] = read of tile 256 b (ragged lengths; else nullptr)
+                                 uint64_t w_begin = 0, uint64_t w_end = ~0ull);      // the hint words [w_begin, w_end) only; w_begin a multiple of 256
 hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st);
 // ---- "last VGPR of the allocation" guard ----
 // Observed on the MI355X pool (minimal reproductions: profiles/ubench/vgpr_edge2.hip and vgpr_edge3.hip, write-up in

@@ -316,9 +316,10 @@ static __device__ __forceinline__ uint64_t hint_bits_class(const uint32_t (&w)[1
 // from where — its read's walk moves there (wave_hints_class).  A superset like the short-read filter (padding bases and the
 // right clamp are ignored).  Default window / bounds only.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words, uint64_t *hint_bits)
+__global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t t0, uint64_t n_words, uint64_t *hint_bits)
 {
-    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    // (t0: a multiple of 256 — the launch covers the hint words [t0, n_words), see launch_hint_positions)
+    const uint64_t t = t0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n_words) return;
     // read of this tile: largest r with hint_off[r] <= t.  Reads of one length: a division (the search is 20 dependent
     // loads for 1 M reads — about three times the wave's 3.8 us of arithmetic, which six waves per SIMD only just cover)
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     } else if (blk_read) {
         // ragged lengths: the host noted the read of every block's first tile (blk_read[b] = read of tile 256 b); a long read
         // has dozens of tiles, so the tile's own read is a few steps further (short reads mixed in: more steps, same result)
-        r = blk_read[blockIdx.x];
+        r = blk_read[t >> 8];
         while (r + 1 < R.n_reads && hint_off[r + 1] <= t) r++;
         tile = (uint32_t)(t - hint_off[r]);
     } else {
@@ -355,11 +356,13 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
 }
 
 hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
-                                 uint64_t *hint_bits, hipStream_t st)
+                                 uint64_t *hint_bits, hipStream_t st, uint64_t w_begin, uint64_t w_end)
 {
     if (P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return hipErrorNotSupported;
-    if (n_words == 0) return hipSuccess;
-    CRASS_LAUNCH(k_hint_positions, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, R, hint_off, blk_read, n_words, hint_bits);
+    if (w_end > n_words) w_end = n_words;
+    if ((w_begin & 255u) != 0) return hipErrorInvalidValue;
+    if (w_begin >= w_end) return hipSuccess;
+    CRASS_LAUNCH(k_hint_positions, dim3((unsigned)((w_end - w_begin + 255) / 256)), dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits);
     return hipGetLastError();
 }
 
