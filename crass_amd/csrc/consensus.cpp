@@ -24,6 +24,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -869,6 +870,31 @@ void flatten(crass_cons *s)
 
 } // namespace
 
+// Streams are kept between calls, per device: creating one (and the hardware queue behind it, on its first launch) is
+// milliseconds — a tenth of a 10 M-read call.  A call takes one from the pool, crass_hip_consensus_free puts it back.
+namespace {
+std::mutex g_stream_mu;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;
+hipStream_t take_stream(int device)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        auto &v = g_stream_pool[device];
+        if (!v.empty()) { hipStream_t st = v.back(); v.pop_back(); return st; }
+    }
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return st;
+}
+void give_stream(int device, hipStream_t st)
+{
+    if (!st) return;
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto &v = g_stream_pool[device];
+    if (v.size() < 8) v.push_back(st); else (void)hipStreamDestroy(st);
+}
+} // namespace
+
 extern "C" {
 
 int crass_hip_consensus(const crass_params *p, int device, const crass_cons_input *in, crass_cons **out)
@@ -886,7 +912,8 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
     crass_cons *s = sp.get();
     s->prm = *p; s->device = device; s->max_read_len = (int)in->max_read_len;
     if (hipSetDevice(device) != hipSuccess) return CRASS_ERR_NO_DEVICE;
-    if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) return CRASS_ERR_HIP;
+    s->st = take_stream(device);
+    if (!s->st) return CRASS_ERR_HIP;
     build_comp_table(s->comp);
     // Aligner ctor (Aligner.h:112-136): gapo 5, gape 2, minsc 5, match 1, mismatch -3, ambiguous 0
     s->ksw.gapo = 5; s->ksw.gape = 2; s->ksw.minsc = 5;
@@ -987,7 +1014,7 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
         return CRASS_OK;
     };
     rc = body();
-    if (rc != CRASS_OK) { if (s->st) (void)hipStreamDestroy(s->st); return rc; }
+    if (rc != CRASS_OK) { if (s->st) { (void)hipStreamSynchronize(s->st); give_stream(device, s->st); s->st = nullptr; } return rc; }
     *out = sp.release();
     return CRASS_OK;
 }
@@ -1010,7 +1037,7 @@ void crass_hip_consensus_free(crass_cons *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    if (s->st) { (void)hipStreamSynchronize(s->st); (void)hipStreamDestroy(s->st); }
+    if (s->st) { (void)hipStreamSynchronize(s->st); give_stream(s->device, s->st); s->st = nullptr; }
     delete s;
 }
 

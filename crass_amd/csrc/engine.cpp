@@ -2632,7 +2632,10 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     const bool dev_sink = dmp && n_exc == 0;
     c->q_blob_active = false;
     if (dev_sink) {
-        const uint32_t narrow = (c->max_len <= 255 && c->R.n_reads < (1ull << 32)) ? 1u : 0u;
+        static const bool blob12 = getenv("CRASS_P2_BLOB12") != nullptr;      // A/B switch: the 12-byte form of round 3
+        // (the 9-byte form needs the token strings when the records are widened: a context whose host view is the light one —
+        // the ranks of a group other than the first — keeps the 12-byte form)
+        const uint32_t narrow = (c->max_len <= 255 && c->R.n_reads < (1ull << 32)) ? ((blob12 || c->host_view_light) ? 1u : 2u) : 0u;
         c->q_lay = p2_blob_layout(n_hits, narrow);
         c->q_wide_ready = false;
         Lookback lbq;
@@ -2776,16 +2779,27 @@ int crass_hip_get_recruits(const crass_hip_ctx *c, crass_recruits *o)
             memset(mc->q_dr.data() + k0 * stride, 0, (size_t)(k1 - k0) * stride);
             for (uint64_t k = k0; k < k1; k++) {
                 mc->q_read[k] = b.narrow ? c->read_base + ((const uint32_t *)(hb + b.read))[k] : ((const uint64_t *)(hb + b.read))[k];
-                mc->q_token[k] = b_tok[k];
+                const uint32_t t = b.narrow == 2 ? (b_tok[k] & 0x7FFFFFFFu) : b_tok[k];
+                mc->q_token[k] = t;
+                size_t tlen = 0;
+                if (t >= 2 && t - 2 < n_tok) {
+                    tlen = dv ? (size_t)(v_off[t - 1] - v_off[t - 2]) : (size_t)c->merge.tokens.strings.len(t - 2);
+                    if (dv) memcpy(mc->q_dr.data() + k * stride, v_chars + v_off[t - 2], tlen);
+                    else memcpy(mc->q_dr.data() + k * stride, c->merge.tokens.strings.data(t - 2), tlen);
+                }
+                if (b.narrow == 2) {
+                    // the 9-byte form: orientation in the token's top bit; the repeat is as long as its token's string and ends
+                    // at start + length - 1 in either orientation (k_recruit_finish)
+                    mc->q_low[k] = (uint8_t)(b_tok[k] >> 31);
+                    mc->q_start[k] = (hb + b.start)[k];
+                    mc->q_dr_len[k] = (uint16_t)tlen;
+                    mc->q_end[k] = mc->q_start[k] + (tlen ? (uint32_t)tlen - 1u : 0u);
+                    continue;
+                }
                 mc->q_low[k] = (hb + b.low)[k];
                 if (b.narrow) { mc->q_start[k] = (hb + b.start)[k]; mc->q_end[k] = (hb + b.end)[k]; }
                 else { mc->q_start[k] = b_start[k]; mc->q_end[k] = b_end[k]; }
                 mc->q_dr_len[k] = (hb + b.dr_len)[k];
-                const uint32_t t = b_tok[k];
-                if (t >= 2 && t - 2 < n_tok) {
-                    if (dv) memcpy(mc->q_dr.data() + k * stride, v_chars + v_off[t - 2], (size_t)(v_off[t - 1] - v_off[t - 2]));
-                    else memcpy(mc->q_dr.data() + k * stride, c->merge.tokens.strings.data(t - 2), c->merge.tokens.strings.len(t - 2));
-                }
             }
         });
         mc->q_wide_ready = true;

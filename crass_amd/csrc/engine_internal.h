@@ -418,14 +418,17 @@ __host__ __device__ inline P1Blob p1_blob_layout(uint64_t nf, uint32_t ss_cap, u
 // recruit is its token's string
 struct P2Blob { uint64_t read, token, start, end, dr_len, low, total; uint32_t narrow; };
 // narrow: read sets of fewer than 2^32 reads of at most 255 bases (every short-read job) carry the LOCAL read index in four bytes
-// and the two positions in one byte each — 12 instead of 18 bytes per recruit over PCIe, which bounds the pack kernel
+// and the two positions in one byte each — 12 instead of 18 bytes per recruit over PCIe, which bounds the pack kernel (2: see below)
 __host__ __device__ inline P2Blob p2_blob_layout(uint64_t cap, uint32_t narrow = 0)
 {
     P2Blob b;
     uint64_t at = 16;
     auto sec = [&](uint64_t bytes) { const uint64_t o = at; at += (bytes + 15u) & ~15ull; return o; };
-    b.read = sec(cap * (narrow ? 4 : 8)); b.token = sec(cap * 4); b.start = sec(cap * (narrow ? 1 : 2)); b.end = sec(cap * (narrow ? 1 : 2));
-    b.dr_len = sec(cap); b.low = sec(cap);
+    b.read = sec(cap * (narrow ? 4 : 8)); b.token = sec(cap * 4); b.start = sec(cap * (narrow ? 1 : 2));
+    // narrow == 2 (the device merge's tokens are known for every recruit): 9 bytes — the orientation flag rides in bit 31 of the
+    // token, the repeat's length is the token string's, and its end is start + length - 1 in either orientation (k_recruit_finish)
+    if (narrow == 2) { b.end = at; b.dr_len = at; b.low = at; }
+    else { b.end = sec(cap * (narrow ? 1 : 2)); b.dr_len = sec(cap); b.low = sec(cap); }
     b.total = at; b.narrow = narrow;
     return b;
 }

@@ -3410,6 +3410,12 @@ __global__ __launch_bounds__(256) void k_pack_p2_blob(const RecruitOut *rec, con
     const P2Blob b = p2_blob_layout(cap, narrow);
     const uint64_t k = vidx[q];
     const RecruitOut o = rec[k];
+    if (narrow == 2) {
+        reinterpret_cast<uint32_t *>(blob + b.token)[q] = o.token | ((uint32_t)(o.low_lexi != 0) << 31);
+        reinterpret_cast<uint32_t *>(blob + b.read)[q] = (uint32_t)hit_idx[k];
+        (blob + b.start)[q] = (uint8_t)o.start;
+        return;
+    }
     reinterpret_cast<uint32_t *>(blob + b.token)[q] = o.token;
     if (narrow) {
         reinterpret_cast<uint32_t *>(blob + b.read)[q] = (uint32_t)hit_idx[k];          // (local index: the host adds the base)
