@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
         bool have_n = grp && k_n < n;
         uint64_t r_n = have_n ? idx[k_n] : 0;
         for (uint64_t k0 = wave * DV_G; k0 < n; k0 += stride) {
-            if (have && (uint32_t)pl <= nw) rw[pl] = wreg;                  // (word nw = 0: wreg is 0 there)
+            if (have && (uint32_t)pl <= nw + 4u) rw[pl] = wreg;             // (words nw .. nw + 4 = 0 — wreg is 0 there —: a window's five words need no clamp)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
             uint32_t cnt = 0, base = 0;
             if (have && (uint32_t)pl <= h_max) {
                 const uint32_t wi = (uint32_t)pl >> 1;
-                const uint32_t lo = rw[wi], hi = rw[min(wi + 1, nw)];
+                const uint32_t lo = rw[wi], hi = rw[wi + 1];
                 dv_probe(M, (pl & 1) ? ((lo >> 16) | (hi << 16)) : lo, kmask, cnt, base);
             }
             // The three reads of the round walk their hit windows SIDE BY SIDE: read g's 21 lanes compare the candidates of
@@ -1132,10 +1132,10 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                             const uint32_t w0 = start >> 4, sh = (start & 15u) * 2u;
                             uint32_t x[5];
 #pragma unroll
-                            for (int i = 0; i < 5; i++) x[i] = rw[min(w0 + i, nw)];
+                            for (int i = 0; i < 5; i++) x[i] = rw[w0 + i];
                             uint32_t y[4];
 #pragma unroll
-                            for (int i = 0; i < 4; i++) y[i] = sh ? ((x[i] >> sh) | (x[i + 1] << (32 - sh))) : x[i];
+                            for (int i = 0; i < 4; i++) y[i] = __builtin_amdgcn_alignbit(x[i + 1], x[i], sh);
                             const uint64_t v0 = (uint64_t)y[0] | ((uint64_t)y[1] << 32), v1 = (uint64_t)y[2] | ((uint64_t)y[3] << 32);
                             uint64_t m0, m1;
                             mask128(len, m0, m1);
@@ -1156,17 +1156,20 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
                             }
                         }
                     }
-                    // minimum over the group's lanes (ties: any lane — equal (end, len) means equal strings)
-                    uint32_t mn = cand;
+                    // minimum over the group's lanes (ties: any lane — equal (end, len) means equal strings) — only when one of
+                    // them matched at all: nearly every step compares a window's variants and finds none equal, and the
+                    // reduction is a quarter of a step's instructions (the kernel is VALU-issue bound: 109 M wave instructions =
+                    // 178 of its 246 us at 100 M reads, PMC round 4)
+                    if (__ballot(cand != 0xFFFFFFFFu) & gmask) {
+                        uint32_t mn = cand;
 #pragma unroll
-                    for (int off = 16; off > 0; off >>= 1) {
-                        const uint32_t o = (uint32_t)__shfl_down((int)mn, off);
-                        if (pl + off < DV_GL) mn = min(mn, o);
-                    }
-                    mn = (uint32_t)__shfl((int)mn, g0);
-                    const uint64_t who = __ballot(cand == mn) & gmask;
-                    const uint32_t pid = (uint32_t)__shfl((int)cpid, who ? __ffsll((unsigned long long)who) - 1 : 0);
-                    if (mn != 0xFFFFFFFFu) {
+                        for (int off = 16; off > 0; off >>= 1) {
+                            const uint32_t o = (uint32_t)__shfl_down((int)mn, off);
+                            if (pl + off < DV_GL) mn = min(mn, o);
+                        }
+                        mn = (uint32_t)__shfl((int)mn, g0);
+                        const uint64_t who = __ballot(cand == mn) & gmask;
+                        const uint32_t pid = (uint32_t)__shfl((int)cpid, who ? __ffsll((unsigned long long)who) - 1 : 0);
                         const uint32_t e_end = mn >> 8, e_len = 255u - (mn & 0xFFu);
                         if (e_end < be || (e_end == be && e_len > bl)) { be = e_end; bl = e_len; bp = pid; }
                     }
