@@ -816,7 +816,10 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     // of a read below r_i+1 belongs to a slice <= i (CRASS_HINT_PARTS=1: the A/B switch)
     { const char *hp = getenv("CRASS_HINT_PARTS");       // (A/B: 1 = one launch on the main stream)
       const int want = hp ? atoi(hp) : 2;
-      c->hint_parts = (n >= 4096 && at >= (1u << 20)) ? std::min(std::max(want, 1), (int)crass_hip_ctx::kHintParts) : 1; }
+      // (two: each slice's walk is its own launch with its own ramp and tail — four slices were slower than none, 15.5 vs 14.3 ms
+      // per step on configs[3], two are 14.0; an explicit CRASS_HINT_PARTS also slices small sets: the tests)
+      const bool big = hp ? (n >= 64 && at >= 2048) : (n >= 4096 && at >= (1u << 20));
+      c->hint_parts = big ? std::min(std::max(want, 1), (int)crass_hip_ctx::kHintParts) : 1; }
     for (int q = 0; q <= c->hint_parts; q++) {
         const uint64_t r = q == c->hint_parts ? n : n * (uint64_t)q / (uint64_t)c->hint_parts;
         c->hint_read_split[q] = r;
@@ -1021,7 +1024,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                     HIPCHK(c, launch_survivor(R, c->dp, false, c->d_idx.p + s0, c->d_count.p + 1, s1 - s0,
                                               c->d_surv.p + s0, c->d_dr.p + s0 * (size_t)stride, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                               c->d_found.p, c->hints_valid ? c->d_hit_info.p : nullptr, lds,
-                                              (int)std::min<uint64_t>(grid, s1 - s0), c->stream));
+                                              (int)std::min<uint64_t>(grid, s1 - s0), c->stream, 0, s0, nchunk));
                 s0 = s1;
             }
             c->hint_pending = false;

@@ -338,7 +338,8 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            SurvOut *out, char *dr_chars, uint32_t dr_stride,
                            uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
                            uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
-                           int punt_only = 0);
+                           int punt_only = 0,
+                           uint64_t slot_base = 0, uint64_t slot_total = 0);      // a slice of a larger launch: out / dr_chars point at the slice, the start/stop pool is shared
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                  uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st,

@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
                                                    const uint32_t *d_n_surv, uint64_t n_max, SurvOut *out,
                                                    char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                                    uint32_t ss_pool_cap, uint32_t *d_ss_used,
-                                                   uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds, int punt_only)
+                                                   uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds, int punt_only, uint64_t slot_base, uint64_t slot_total)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sv_lds[];
     const int lane = threadIdx.x;
@@ -1475,8 +1475,10 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
             else {
                 // start/stop pool: a fixed slot per survivor when the pool is large enough (short reads),
                 // otherwise bump allocation (one contended atomic per found read: long reads only)
+                // (slot_base / slot_total: this launch covers the slots [slot_base, slot_base + n) of slot_total — the walk of a
+                // long-read set runs slice by slice, `out` and `dr_chars` already point at the slice, the pool is shared)
                 uint32_t off = 0;
-                if ((uint64_t)n_surv * lds.ss_cap <= ss_pool_cap) off = (uint32_t)s * lds.ss_cap;
+                if ((slot_total ? slot_total : n_surv) * lds.ss_cap <= ss_pool_cap) off = (uint32_t)(s + slot_base) * lds.ss_cap;
                 else {
                     if (lane == 0) off = atomicAdd(d_ss_used, (uint32_t)h.nss);
                     off = (uint32_t)__shfl((int)off, 0);
@@ -2680,7 +2682,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            const uint32_t *d_n_surv, uint64_t n_surv_max, SurvOut *out, char *dr_chars,
                            uint32_t dr_stride, uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
                            uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
-                           int punt_only)
+                           int punt_only, uint64_t slot_base, uint64_t slot_total)
 {
     if (n_surv_max == 0) return hipSuccess;
     hipError_t e;
@@ -2688,12 +2690,12 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
         CRASS_LAUNCH(k_survivor<true>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
         if (e != hipSuccess) return e;
         CRASS_LAUNCH(k_survivor<false>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total);
     }
     return hipGetLastError();
 }

@@ -307,6 +307,15 @@ def test_long_reads_ragged_mid_size(ca):
     ref = orc.pipeline(seqs)
     assert_same_pipeline(gpu, ref)
     assert gpu.n_pass1 >= 200
+    # the hint kernel in slices beside the walk (the default only slices sets of >= 4 096 reads): every slice count, ragged
+    # lengths — slice boundaries fall inside reads' hint words and inside the per-block read index
+    for parts in ("1", "3", "4"):
+        os.environ["CRASS_HINT_PARTS"] = parts
+        try:
+            sliced = ca.search_pipeline(seqs)
+        finally:
+            os.environ.pop("CRASS_HINT_PARTS", None)
+        assert_same_pipeline(sliced, ref)
 
 
 def test_long_reads_position_hints(ca):
@@ -352,6 +361,20 @@ def test_long_reads_position_hints(ca):
         os.environ.pop("CRASS_NO_POS_HINTS", None)
     assert_same_pipeline(plain, ref)
     assert gpu.n_pass1 > 60
+    # hint slices (CRASS_HINT_PARTS) with exception reads in the set: the survivor list then skips reads, and the walk's
+    # slices are cut by the survivors' read indices
+    noisy = [bytearray(q) for q in seqs]
+    for i in range(7, len(noisy), 11):
+        noisy[i][rng.randrange(len(noisy[i]))] = ord("N")
+    noisy = [bytes(q) for q in noisy]
+    ref_n = orc.pipeline(noisy)
+    for parts in ("2", "4"):
+        os.environ["CRASS_HINT_PARTS"] = parts
+        try:
+            sliced = ca.search_pipeline(noisy)
+        finally:
+            os.environ.pop("CRASS_HINT_PARTS", None)
+        assert_same_pipeline(sliced, ref_n)
 
 
 def test_one_million_reference_known_answer_on_the_hip_path(ca):
