@@ -659,14 +659,7 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     if (hipSetDevice(device) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
-    {   // lowest priority: its blocks fill what the walking kernel (two waves per SIMD: its LDS) leaves free, not the other way round
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        if (hipStreamCreateWithPriority(&c->hint_stream, hipStreamNonBlocking, getenv("CRASS_HINT_SAME_PRIORITY") ? 0 : prio_lo) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
-    }
-    for (int q = 0; q < crass_hip_ctx::kHintParts; q++)
-        if (hipEventCreateWithFlags(&c->ev_hint[q], hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
-    if (hipEventCreateWithFlags(&c->ev_hint_go, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
+    // (hint_stream and its events: created with the first long-read set, setup_pos_hints)
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_premerge, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
@@ -820,6 +813,17 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
       // per step on configs[3], two are 14.0; an explicit CRASS_HINT_PARTS also slices small sets: the tests)
       const bool big = hp ? (n >= 64 && at >= 2048) : (n >= 4096 && at >= (1u << 20));
       c->hint_parts = big ? std::min(std::max(want, 1), (int)crass_hip_ctx::kHintParts) : 1; }
+    if (c->hint_parts > 1 && !c->hint_stream) {
+        // lowest priority: its blocks fill what the walking kernel (two waves per SIMD: its LDS) leaves free, not the other way
+        // round.  Created with the first long-read set only: a second low-priority stream in every context changed how the
+        // runtime spreads streams over its hardware queues, and the merge's view export (its own low-priority stream) then
+        // cost a short-read step 0.5 ms instead of 0.1
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        HIPCHK(c, hipStreamCreateWithPriority(&c->hint_stream, hipStreamNonBlocking, getenv("CRASS_HINT_SAME_PRIORITY") ? 0 : prio_lo));
+        for (int q = 0; q < crass_hip_ctx::kHintParts; q++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_hint[q], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_hint_go, hipEventDisableTiming));
+    }
     for (int q = 0; q <= c->hint_parts; q++) {
         const uint64_t r = q == c->hint_parts ? n : n * (uint64_t)q / (uint64_t)c->hint_parts;
         c->hint_read_split[q] = r;
