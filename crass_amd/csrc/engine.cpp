@@ -321,6 +321,7 @@ struct crass_hip_ctx {
     hipEvent_t ev_hint[kHintParts] = {nullptr, nullptr, nullptr, nullptr}, ev_hint_go = nullptr;
     int hint_parts = 1;                         // slices of this read set (1: one launch on the main stream)
     uint64_t hint_read_split[kHintParts + 1] = {0, 0, 0, 0, 0}, hint_word_split[kHintParts + 1] = {0, 0, 0, 0, 0};
+    DevBuf<uint16_t> g_dr_len; DevBuf<uint64_t> hl_dx_idx;      // host-loop sink: dense DR lengths, scratch of the device de-duplication
     bool hint_pending = false;                  // slices are in flight on hint_stream: the main stream has not waited for them yet
     hipEvent_t ev_gathered = nullptr;
     hipEvent_t ev_premerge = nullptr;           // recorded behind a merge queued in the seed scan: the hand-off copy waits for it
@@ -432,6 +433,10 @@ struct crass_hip_ctx {
     // distinct candidate strings (multi-GPU exchange)
     std::vector<char> dx_chars; std::vector<uint16_t> dx_len; std::vector<uint32_t> dx_map; bool have_distinct = false;
     uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
+    // the distinct DR strings (token order) and every candidate's index among them came from the DEVICE: the dense sink, or the
+    // host-loop sink of a long-read set (hl_tokens: its gathered records were de-duplicated on the device beside the copies)
+    bool hl_tokens = false;
+    bool dev_tokens() const { return have_dev_tokens && (dense.active || hl_tokens); }
     void widen_p1() const;
     const char *cand_dr() const { if (dense.active) { widen_p1(); return dense.w_dr.data(); } return cand.dr.data(); }
     const uint16_t *cand_dr_len() const { if (dense.active) { widen_p1(); return dense.w_dr_len.data(); } return cand.dr_len.data(); }
@@ -983,6 +988,9 @@ static int hint_wait_all(crass_hip_ctx *c)
     return CRASS_OK;
 }
 
+static int ensure_mask_scratch(crass_hip_ctx *c, uint64_t n_bits);
+static bool getenv_once_hl_host() { static const bool v = getenv("CRASS_HL_HOST_DEDUPE") != nullptr; return v; }      // A/B switch: the round-3 host de-duplication + merge for long reads
+
 static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip_ctx::P1List &L,
                          const uint64_t *surv_idx_host)
 {
@@ -1056,8 +1064,16 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));              // (reused: words of packed start/stops)
         HIPCHK(c, launch_select_found(c->d_surv.p, nchunk, c->d_mask.p, c->d_count.p + 3, c->stream));
         HIPCHK(c, launch_compact(c->d_mask.p, n_words, nchunk, c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, nchunk, c->d_count.p + 2, c->stream));
+        // One chunk of a set without exception reads: the found records' strings are de-duplicated on the device as well (the
+        // kernels of the dense sink's tail, queued behind the first wait with the exact count, beside the copies and the host
+        // loop below) — the distinct list in token order + every candidate's index in it are what the DEVICE merge takes, so a
+        // long-read set no longer hashes 50 k strings and clusters them on the host (1.3 ms per step at 1 M x 10 kbp)
+        const bool hl_dedupe = !exc && off == 0 && nchunk == n_total && c->R.n_exc == 0 && !c->xchg.active && !c->env.host_merge &&
+                               c->prm.lowDRsize >= 23 && stride <= 64 && (stride & 15u) == 0 && nchunk < (1u << 24) && !getenv_once_hl_host();
+        if (hl_dedupe) HIPCHK(c, c->g_dr_len.ensure(nchunk));
         HIPCHK(c, launch_gather_sparse(c->d_fidx.p, c->d_count.p + 2, nchunk, c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, c->g_surv.p,
-                                       c->d_fidx.p + 0, c->g_dr.p, c->g_ss.p, (uint32_t)pool_cap, c->d_ss_used.p, c->stream));
+                                       c->d_fidx.p + 0, c->g_dr.p, c->g_ss.p, (uint32_t)pool_cap, c->d_ss_used.p, c->stream,
+                                       hl_dedupe ? c->g_dr_len.p : nullptr));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 6, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
         const double tq0 = now_ms();
@@ -1075,6 +1091,25 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_fidx.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
             if (used) HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->g_ss.p, (size_t)used * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        bool hl_queued = false;
+        if (nf && hl_dedupe) {
+            // (behind the copies above; the host loop below runs beside these kernels; their small outputs land in pinned memory)
+            uint32_t tsize = 1024;
+            while (tsize < nf * 2) tsize <<= 1;
+            HIPCHK(c, c->dd_keys.ensure(tsize)); HIPCHK(c, c->dd_first.ensure(tsize)); HIPCHK(c, c->dd_slot.ensure(nf)); HIPCHK(c, c->dd_rep.ensure(nf));
+            HIPCHK(c, c->dd_hash.ensure(nf)); HIPCHK(c, c->hl_dx_idx.ensure(nf));
+            HIPCHK(c, c->dd_dx_chars.ensure(nf * (size_t)stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(nf));
+            HIPCHK(c, c->h_dmap.ensure(nf)); HIPCHK(c, c->h_dx_chars.ensure(nf * (size_t)stride + 16)); HIPCHK(c, c->h_dx_len.ensure(nf)); HIPCHK(c, c->h_dx_hash.ensure(nf));
+            { const int ms = ensure_mask_scratch(c, nf); if (ms) return ms; }
+            HIPCHK(c, hipMemsetAsync(c->d_count.p + 4, 0, 8, c->stream));            // [4] distinct strings, [5] mismatch flag
+            HIPCHK(c, launch_dr_dedupe(c->g_dr.p, c->g_dr_len.p, stride, c->d_count.p + 2, (uint32_t)nf, c->dd_keys.p, c->dd_first.p, tsize, c->dd_hash.p,
+                                       c->dd_slot.p, c->dd_rep.p, c->stream, false));
+            HIPCHK(c, launch_dx_tokens(c->g_dr.p, c->g_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)nf, c->dd_rep.p, c->dd_slot.p, c->dd_first.p,
+                                       c->d_mask.p, c->d_word_prefix.p, c->d_block_sums.p, c->hl_dx_idx.p, c->d_count.p + 4, c->d_count.p + 5, c->h_dmap.p,
+                                       c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream,
+                                       c->d_count.p, c->h_count.p, 8, nullptr));
+            hl_queued = true;
         }
         const double tq2 = now_ms();
         const SurvOut *so = c->h_surv.p;
@@ -1103,6 +1138,14 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                 memcpy(L.dr.data() + (base + q) * (size_t)stride, drs + q * stride, stride);
             }
         });
+        if (hl_queued) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->h_count.p[5] == 0 && c->h_count.p[2] == nf && c->h_count.p[4] > 0) {
+                c->n_dx = c->h_count.p[4];
+                c->have_dev_tokens = true; c->hl_tokens = true;
+                c->dx_hash_valid = true;
+            }
+        }
         if (c->env.merge_profile)
             fprintf(stderr, "[crass_sink] survivors %llu: kernel+D2H wait %.3f ms, pool D2H %.3f ms, host loop %.3f ms\n",
                     (unsigned long long)nchunk, tq1 - tq0, tq2 - tq1, now_ms() - tq2);
@@ -1537,7 +1580,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     HIPCHK(c, c->stamp(2, 2));
     c->dense.active = false;
     c->have_rep = false;
-    c->have_dev_tokens = false;
+    c->have_dev_tokens = false; c->hl_tokens = false;
     c->have_distinct = false;
     c->cand.clear();
     const double t_sink0 = now_ms();
@@ -1781,7 +1824,7 @@ static int build_host_merge(crass_hip_ctx *c);
 static bool device_merge_applies(const crass_hip_ctx *c)
 {
     if (c->env.host_merge) return false;                 // A/B switch: force the host merge (merge.cpp)
-    return c->have_pass1 && c->dense.active && c->have_dev_tokens && c->prm.lowDRsize >= 23 &&
+    return c->have_pass1 && c->dev_tokens() && c->prm.lowDRsize >= 23 &&
            c->dr_stride <= 64 && c->n_dx <= (1u << 20);
 }
 
@@ -1891,7 +1934,7 @@ static int device_merge_commit(crass_hip_ctx *c, uint64_t n_tok, const char *hx_
 {
     crass_hip_ctx::DM &d = c->dm;
     d.hx_chars = hx_chars; d.hx_len = hx_len; d.n_tok = n_tok;
-    d.active = true; d.host_built = false; d.view_ready = false; d.n_cand = c->dense.n;
+    d.active = true; d.host_built = false; d.view_ready = false; d.n_cand = c->n_cand();
     // the host view (tokens, groups, pattern list) is rebuilt by the helper thread as soon as the kernels are through
     // every field of the caller's side is set BEFORE the job is handed over: from submit() on, the helper thread owns
     // c->merge and dm.br until ensure_host_merge / quiesce_worker has waited for it
@@ -1953,7 +1996,7 @@ static int host_merge_fallback(crass_hip_ctx *c)
         return merge_global_host(c, gc.data(), gl.data(), c->dr_stride, d.n_global, d.my_off, t0);
     }
     if (const int ds = ensure_host_distinct(c, true)) return ds;
-    if (!merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
+    if (!merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->n_cand(),
                              c->prm.kmer_clust_size))
         merge_candidates(c->merge, c->cand_dr(), c->cand_dr_len(), c->dr_stride, c->n_cand(), c->prm.kmer_clust_size);
     return finish_merge(c, t0);
@@ -2145,9 +2188,9 @@ int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_l
     }
 host_path:
     c->dm_prev_local = false;
-    if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens) { if (const int ds = ensure_host_distinct(c, true)) return ds; }
-    if (!dr_chars && c->have_pass1 && c->dense.active && c->have_dev_tokens &&
-        merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->dense.n,
+    if (!dr_chars && c->have_pass1 && c->dev_tokens()) { if (const int ds = ensure_host_distinct(c, true)) return ds; }
+    if (!dr_chars && c->have_pass1 && c->dev_tokens() &&
+        merge_from_distinct(c->merge, c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dr_stride, c->n_dx, c->h_dmap.p, c->n_cand(),
                             c->prm.kmer_clust_size))
         return finish_merge(c, t0);
     if (!dr_chars) {
@@ -2184,7 +2227,7 @@ static int finish_merge(crass_hip_ctx *c, double t0)
 static void ensure_distinct(crass_hip_ctx *c)
 {
     if (c->have_distinct) return;
-    if (c->dense.active && c->have_dev_tokens) { c->have_distinct = true; return; }   // straight from the device
+    if (c->dev_tokens()) { c->have_distinct = true; return; }   // straight from the device
     const uint64_t n = c->n_cand();
     const char *dr = c->cand_dr();
     const uint16_t *len = c->cand_dr_len();
@@ -2222,10 +2265,10 @@ int crass_hip_get_distinct(crass_hip_ctx *c, crass_distinct *o)
     if (!c->have_pass1) return CRASS_ERR_STATE;
     ensure_distinct(c);
     o->dr_stride = c->dr_stride;
-    if (c->dense.active && c->have_dev_tokens) {
+    if (c->dev_tokens()) {
         if (const int ds = c->wait_dx()) return ds;
         o->n_distinct = c->n_dx; o->dr_len = c->h_dx_len.p; o->dr_chars = c->h_dx_chars.p;
-        o->n_candidates = c->dense.n; o->cand_distinct = c->h_dmap.p;
+        o->n_candidates = c->n_cand(); o->cand_distinct = c->h_dmap.p;
     } else {
         o->n_distinct = c->dx_len.size(); o->dr_len = c->dx_len.data(); o->dr_chars = c->dx_chars.data();
         o->n_candidates = c->dx_map.size(); o->cand_distinct = c->dx_map.data();
@@ -2239,11 +2282,11 @@ static int merge_global_host(crass_hip_ctx *c, const char *dr_chars, const uint1
 {
     c->premerge = 0; c->dm_prev_local = false;          // (multi-rank: nothing is queued ahead of the exchange)
     ensure_distinct(c);
-    const bool dev = c->dense.active && c->have_dev_tokens;
+    const bool dev = c->dev_tokens();
     const uint64_t my_nd = dev ? c->n_dx : c->dx_len.size();
     if (dev) { if (const int ds = c->wait_dx()) return ds; }
     const uint32_t *my_map = dev ? c->h_dmap.p : c->dx_map.data();
-    const size_t my_n = dev ? (size_t)c->dense.n : c->dx_map.size();
+    const size_t my_n = dev ? (size_t)c->n_cand() : c->dx_map.size();
     if (my_offset + my_nd > n_global) {
         if (getenv("CRASS_GROUP_DEBUG")) fprintf(stderr, "[crass_xchg] merge_global_host: offset %llu + own %llu > global %llu (dev %d)\n",
                                                  (unsigned long long)my_offset, (unsigned long long)my_nd, (unsigned long long)n_global, (int)dev);
@@ -2470,7 +2513,7 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
 int crass_hip_get_distinct_device(crass_hip_ctx *c, crass_distinct_dev *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
-    if (!c->have_pass1 || !(c->dense.active && c->have_dev_tokens)) return CRASS_ERR_STATE;
+    if (!c->have_pass1 || !c->dev_tokens()) return CRASS_ERR_STATE;
     o->n_distinct = c->n_dx; o->dr_stride = c->dr_stride; o->d_chars = c->dd_dx_chars.p; o->d_len = c->dd_dx_len.p;
     return CRASS_OK;
 }

@@ -2414,7 +2414,7 @@ __global__ __launch_bounds__(256) void k_select_found(const SurvOut *out, uint64
 }
 __global__ __launch_bounds__(256) void k_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out, const char *dr_chars,
                                                         uint32_t dr_stride, const uint32_t *ss_pool, SurvOut *g_out, uint64_t *g_slot, char *g_dr,
-                                                        uint32_t *g_ss, uint32_t g_ss_cap, uint32_t *d_ss_total)
+                                                        uint32_t *g_ss, uint32_t g_ss_cap, uint32_t *d_ss_total, uint16_t *g_dr_len)
 {
     const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t n = *d_nf;
@@ -2429,6 +2429,7 @@ __global__ __launch_bounds__(256) void k_gather_sparse(const uint64_t *fidx, con
     o.ss_off = off;
     g_out[k] = o;
     g_slot[k] = s;
+    if (g_dr_len) g_dr_len[k] = o.dr_len;               // (dense lengths: the de-duplication that may follow on the device)
     const char *src = dr_chars + s * (uint64_t)dr_stride;
     char *dst = g_dr + k * (uint64_t)dr_stride;
     for (uint32_t i = 0; i < dr_stride; i++) dst[i] = src[i];
@@ -2441,11 +2442,11 @@ hipError_t launch_select_found(const SurvOut *out, uint64_t n, uint64_t *mask, u
 }
 hipError_t launch_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out, const char *dr_chars, uint32_t dr_stride,
                                 const uint32_t *ss_pool, SurvOut *g_out, uint64_t *g_slot, char *g_dr, uint32_t *g_ss, uint32_t g_ss_cap,
-                                uint32_t *d_ss_total, hipStream_t st)
+                                uint32_t *d_ss_total, hipStream_t st, uint16_t *g_dr_len)
 {
     if (n_max == 0) return hipSuccess;
     CRASS_LAUNCH(k_gather_sparse, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, dr_chars, dr_stride, ss_pool,
-                       g_out, g_slot, g_dr, g_ss, g_ss_cap, d_ss_total);
+                       g_out, g_slot, g_dr, g_ss, g_ss_cap, d_ss_total, g_dr_len);
     return hipGetLastError();
 }
 

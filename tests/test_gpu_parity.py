@@ -307,6 +307,9 @@ def test_long_reads_ragged_mid_size(ca):
     ref = orc.pipeline(seqs)
     assert_same_pipeline(gpu, ref)
     assert gpu.n_pass1 >= 200
+    # (no exception reads, one chunk: the found records are de-duplicated on the device and the DEVICE merge runs — the
+    # host-loop sink of long reads no longer means the host merge)
+    assert gpu.counters["used_device_merge"] == 1 and gpu.counters["n_merge_fallbacks"] == 0
     # the hint kernel in slices beside the walk (the default only slices sets of >= 4 096 reads): every slice count, ragged
     # lengths — slice boundaries fall inside reads' hint words and inside the per-block read index
     for parts in ("1", "3", "4"):
