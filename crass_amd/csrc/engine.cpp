@@ -1068,12 +1068,13 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         // kernels of the dense sink's tail, queued behind the first wait with the exact count, beside the copies and the host
         // loop below) — the distinct list in token order + every candidate's index in it are what the DEVICE merge takes, so a
         // long-read set no longer hashes 50 k strings and clusters them on the host (1.3 ms per step at 1 M x 10 kbp)
+        const bool ss16 = c->max_len < 65536;           // start/stops travel as 16-bit values
         const bool hl_dedupe = !exc && off == 0 && nchunk == n_total && c->R.n_exc == 0 && !c->xchg.active && !c->env.host_merge &&
                                c->prm.lowDRsize >= 23 && stride <= 64 && (stride & 15u) == 0 && nchunk < (1u << 24) && !getenv_once_hl_host();
         if (hl_dedupe) HIPCHK(c, c->g_dr_len.ensure(nchunk));
         HIPCHK(c, launch_gather_sparse(c->d_fidx.p, c->d_count.p + 2, nchunk, c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, c->g_surv.p,
                                        c->d_fidx.p + 0, c->g_dr.p, c->g_ss.p, (uint32_t)pool_cap, c->d_ss_used.p, c->stream,
-                                       hl_dedupe ? c->g_dr_len.p : nullptr));
+                                       hl_dedupe ? c->g_dr_len.p : nullptr, ss16 ? 1 : 0));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 6, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
         const double tq0 = now_ms();
@@ -1089,7 +1090,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->g_surv.p, nf * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->g_dr.p, nf * (size_t)stride, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_fidx.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
-            if (used) HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->g_ss.p, (size_t)used * 4, hipMemcpyDeviceToHost, c->stream));
+            if (used) HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->g_ss.p, (size_t)used * (ss16 ? 2 : 4), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
         bool hl_queued = false;
@@ -1133,7 +1134,8 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                 L.low[base + q] = o.low_lexi;
                 L.replen[base + q] = o.repeat_len;
                 L.nss[base + q] = o.n_ss;
-                memcpy(L.ss.data() + L.ss_off[base + q], pool + o.ss_off, (size_t)o.n_ss * 4);
+                if (ss16) { const uint16_t *p16 = reinterpret_cast<const uint16_t *>(pool) + o.ss_off; uint32_t *d = L.ss.data() + L.ss_off[base + q]; for (uint32_t i = 0; i < o.n_ss; i++) d[i] = p16[i]; }
+                else memcpy(L.ss.data() + L.ss_off[base + q], pool + o.ss_off, (size_t)o.n_ss * 4);
                 L.dr_len[base + q] = o.dr_len;
                 memcpy(L.dr.data() + (base + q) * (size_t)stride, drs + q * stride, stride);
             }

@@ -384,7 +384,8 @@ hipError_t launch_found_compact(const SurvOut *out, const uint32_t *d_n, uint64_
 hipError_t launch_select_found(const SurvOut *out, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st);
 hipError_t launch_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out, const char *dr_chars, uint32_t dr_stride,
                                 const uint32_t *ss_pool, SurvOut *g_out, uint64_t *g_slot, char *g_dr, uint32_t *g_ss, uint32_t g_ss_cap,
-                                uint32_t *d_ss_total, hipStream_t st, uint16_t *g_dr_len = nullptr);      // g_dr_len: the records' DR lengths, dense
+                                uint32_t *d_ss_total, hipStream_t st, uint16_t *g_dr_len = nullptr,      // g_dr_len: the records' DR lengths, dense
+                                int ss16 = 0);                                               // the packed start/stops as uint16 (positions < 65 536)
 hipError_t launch_found_mask(const SurvOut *out, const uint32_t *d_n, uint64_t n, uint64_t *mask, uint32_t *d_err, hipStream_t st,
                              unsigned long long *dd_keys = nullptr, uint32_t *dd_first = nullptr, uint32_t dd_size = 0);   // also clears that table
 // found records -> (a) the compact hand-off blob (p1_blob_layout; device memory — the runtime copies its used bytes to

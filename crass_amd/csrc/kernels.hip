@@ -2414,7 +2414,7 @@ __global__ __launch_bounds__(256) void k_select_found(const SurvOut *out, uint64
 }
 __global__ __launch_bounds__(256) void k_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out, const char *dr_chars,
                                                         uint32_t dr_stride, const uint32_t *ss_pool, SurvOut *g_out, uint64_t *g_slot, char *g_dr,
-                                                        uint32_t *g_ss, uint32_t g_ss_cap, uint32_t *d_ss_total, uint16_t *g_dr_len)
+                                                        uint32_t *g_ss, uint32_t g_ss_cap, uint32_t *d_ss_total, uint16_t *g_dr_len, int ss16)
 {
     const uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t n = *d_nf;
@@ -2424,8 +2424,12 @@ __global__ __launch_bounds__(256) void k_gather_sparse(const uint64_t *fidx, con
     if (k < n) { s = fidx[k]; o = out[s]; }
     const uint32_t off = block_reserve<256>(k < n ? o.n_ss : 0u, d_ss_total);      // (every thread of the block)
     if (k >= n) return;
-    if ((uint64_t)off + o.n_ss <= g_ss_cap)
-        for (uint32_t i = 0; i < o.n_ss; i++) g_ss[off + i] = ss_pool[o.ss_off + i];
+    // (ss16: every position of the set fits 16 bits — the packed pool then travels in half the bytes: 50 k records with 80
+    // start/stops each are 16 MB of a long-read step's 20 MB of copies)
+    if ((uint64_t)off + o.n_ss <= g_ss_cap) {
+        if (ss16) { uint16_t *g16 = reinterpret_cast<uint16_t *>(g_ss); for (uint32_t i = 0; i < o.n_ss; i++) g16[off + i] = (uint16_t)ss_pool[o.ss_off + i]; }
+        else for (uint32_t i = 0; i < o.n_ss; i++) g_ss[off + i] = ss_pool[o.ss_off + i];
+    }
     o.ss_off = off;
     g_out[k] = o;
     g_slot[k] = s;
@@ -2442,11 +2446,11 @@ hipError_t launch_select_found(const SurvOut *out, uint64_t n, uint64_t *mask, u
 }
 hipError_t launch_gather_sparse(const uint64_t *fidx, const uint32_t *d_nf, uint64_t n_max, const SurvOut *out, const char *dr_chars, uint32_t dr_stride,
                                 const uint32_t *ss_pool, SurvOut *g_out, uint64_t *g_slot, char *g_dr, uint32_t *g_ss, uint32_t g_ss_cap,
-                                uint32_t *d_ss_total, hipStream_t st, uint16_t *g_dr_len)
+                                uint32_t *d_ss_total, hipStream_t st, uint16_t *g_dr_len, int ss16)
 {
     if (n_max == 0) return hipSuccess;
     CRASS_LAUNCH(k_gather_sparse, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, fidx, d_nf, n_max, out, dr_chars, dr_stride, ss_pool,
-                       g_out, g_slot, g_dr, g_ss, g_ss_cap, d_ss_total, g_dr_len);
+                       g_out, g_slot, g_dr, g_ss, g_ss_cap, d_ss_total, g_dr_len, ss16);
     return hipGetLastError();
 }
 
