@@ -99,7 +99,7 @@ struct crass_cons {
     std::vector<Rec> rec;
     std::vector<char> hseq;                       // host mirror of the records' RH_Seq; a record's characters follow the device copy
                                                   // only when somebody reads them (rseq: extendSlaveDR's ties)
-    HBuf<uint32_t> h_stage; HBuf<int> h_cov;      // pinned: a group's flips + placements going up, its coverage coming down
+    HBuf<uint32_t> h_stage; HBuf<int> h_cov; HBuf<int32_t> h_ksw; size_t n_pre = 0;      // pinned: a group's flips + placements going up, its coverage coming down
     DBuf<uint32_t> d_stage;
     double t_place = 0, t_flip = 0, t_sync = 0, t_cons = 0, t_ksw = 0, t_split = 0, t_fa = 0, t_fb = 0, t_fc = 0, t_fd = 0, t_pre = 0;      // CRASS_TIMING: where the group loop's time goes
     std::vector<std::string> tok;                 // token t = tok[t - 2]
@@ -216,8 +216,16 @@ void calc_zone(crass_cons *s, Aligner &al)
 }
 
 // device: ksw batch — string v against master tgt[v].  res[v] = {score_f, tb_f, qb_f, score_r, tb_r, qb_r}
+// defer: the results stay in pinned memory (s->h_ksw) behind the stream's work — ksw_collect picks them up after the caller's
+// next wait on the stream (the original groups' batch runs beside the host's record set-up)
+int ksw_collect(crass_cons *s, size_t n, std::vector<std::array<int, 6>> &res)
+{
+    res.assign(n, {0, -1, -1, 0, -1, -1});
+    for (size_t v = 0; v < n; v++) for (int q = 0; q < 6; q++) res[v][q] = s->h_ksw.p[v * 6 + q];
+    return CRASS_OK;
+}
 int ksw_batch(crass_cons *s, const std::vector<std::string> &strs, const std::vector<uint32_t> &tgt, const std::vector<std::string> &masters,
-              std::vector<std::array<int, 6>> &res)
+              std::vector<std::array<int, 6>> &res, bool defer = false)
 {
     res.assign(strs.size(), {0, -1, -1, 0, -1, -1});
     if (strs.empty()) return CRASS_OK;
@@ -245,11 +253,16 @@ int ksw_batch(crass_cons *s, const std::vector<std::string> &strs, const std::ve
     HCHK(s, hipMemcpyAsync(s->d_tlen.p, tlen.data(), tlen.size() * 4, hipMemcpyHostToDevice, s->st));
     HCHK(s, launch_cons_ksw(s->d_qcodes.p, s->d_qoff.p, s->d_qlen.p, s->d_qtgt.p, (uint32_t)strs.size(), max_q, s->d_target.p, s->d_toff.p, s->d_tlen.p, s->ksw,
                             s->d_ksw_out.p, s->st));
+    s->cnt.n_ksw_alignments += 2 * strs.size(); s->cnt.n_ksw_launches++;
+    if (defer) {
+        HCHK(s, s->h_ksw.ensure(strs.size() * 6));
+        HCHK(s, hipMemcpyAsync(s->h_ksw.p, s->d_ksw_out.p, strs.size() * 6 * 4, hipMemcpyDeviceToHost, s->st));
+        return CRASS_OK;
+    }
     std::vector<int32_t> out(strs.size() * 6);
     HCHK(s, hipMemcpyAsync(out.data(), s->d_ksw_out.p, out.size() * 4, hipMemcpyDeviceToHost, s->st));
     HCHK(s, hipStreamSynchronize(s->st));
     for (size_t v = 0; v < strs.size(); v++) for (int q = 0; q < 6; q++) res[v][q] = out[v * 6 + q];
-    s->cnt.n_ksw_alignments += 2 * strs.size(); s->cnt.n_ksw_launches++;
     return CRASS_OK;
 }
 int ksw_batch(crass_cons *s, const std::vector<std::string> &strs, const std::string &master, std::vector<std::array<int, 6>> &res)
@@ -282,7 +295,8 @@ int prealign_original_groups(crass_cons *s, int n_groups)
         pre.count = strs.size() - pre.first;
         masters.push_back(s->tok[master - 2]);
     }
-    return ksw_batch(s, strs, tgt, masters, s->pre_res);
+    s->n_pre = strs.size();
+    return ksw_batch(s, strs, tgt, masters, s->pre_res, true);      // (collected by the caller behind its next wait: ksw_collect)
 }
 
 enum { F_REVERSED = 1, F_FAILED = 2, F_EQUAL = 4 };
@@ -926,6 +940,24 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
     auto body = [&]() -> int {
         // ---- the hand-off: records with their RH_Seq (DRLowLexi's orientation, ReadHolder.cpp:573-590), tokens, groups ----
         for (uint32_t t = 0; t < in->n_tokens; t++) { s->tok.emplace_back(in->tok_chars + in->tok_off[t], (size_t)(in->tok_off[t + 1] - in->tok_off[t])); s->reads_of.emplace_back(nullptr); }
+        s->next_gid = (int)in->n_groups + 1;
+        for (uint32_t g = 0; g < in->n_groups; g++) {
+            // a GID without tokens is a NULL entry of mDR2GIDMap (or a key missing from groupKmerCountsMap): the reference
+            // `continue`s over it (WorkHorse.cpp:592-595), so it must not become an (empty) group here
+            if (in->grp_off[g + 1] < in->grp_off[g]) return CRASS_ERR_INVALID_ARG;
+            if (in->grp_off[g + 1] == in->grp_off[g]) continue;
+            std::unique_ptr<std::vector<int>> v(new std::vector<int>());
+            for (uint64_t q = in->grp_off[g]; q < in->grp_off[g + 1]; q++) {
+                if (in->grp_tokens[q] < 2 || in->grp_tokens[q] > in->n_tokens + 1) return CRASS_ERR_INVALID_ARG;      // indexes s->tok[tok - 2]
+                v->push_back((int)in->grp_tokens[q]);
+            }
+            s->group[(int)g + 1] = std::move(v);
+        }
+        // ---- findConsensusDRs (WorkHorse.cpp:578-611): the ORIGINAL groups in ascending GID order.  Their slave alignments
+        // need the token strings and the groups only: the batch is launched now and runs (1.4 ms of kernel for the 10 M-read job)
+        // while the host sets the records up ----
+        { const int ps = prealign_original_groups(s, (int)in->n_groups); if (ps) return ps; }
+        lap("groups, slave alignments launched");
         s->rec.resize((size_t)in->n_rec);
         uint64_t at = 0;
         std::vector<uint64_t> roff((size_t)in->n_rec + 1); std::vector<uint32_t> rlen((size_t)in->n_rec + 1);
@@ -975,22 +1007,8 @@ int crass_hip_consensus(const crass_params *p, int device, const crass_cons_inpu
         }
         HCHK(s, hipStreamSynchronize(s->st));
         lap("records, RH_Seq, upload");
-        s->next_gid = (int)in->n_groups + 1;
-        for (uint32_t g = 0; g < in->n_groups; g++) {
-            // a GID without tokens is a NULL entry of mDR2GIDMap (or a key missing from groupKmerCountsMap): the reference
-            // `continue`s over it (WorkHorse.cpp:592-595), so it must not become an (empty) group here
-            if (in->grp_off[g + 1] < in->grp_off[g]) return CRASS_ERR_INVALID_ARG;
-            if (in->grp_off[g + 1] == in->grp_off[g]) continue;
-            std::unique_ptr<std::vector<int>> v(new std::vector<int>());
-            for (uint64_t q = in->grp_off[g]; q < in->grp_off[g + 1]; q++) {
-                if (in->grp_tokens[q] < 2 || in->grp_tokens[q] > in->n_tokens + 1) return CRASS_ERR_INVALID_ARG;      // indexes s->tok[tok - 2]
-                v->push_back((int)in->grp_tokens[q]);
-            }
-            s->group[(int)g + 1] = std::move(v);
-        }
-        // ---- findConsensusDRs (WorkHorse.cpp:578-611): the ORIGINAL groups in ascending GID order ----
-        { const int ps = prealign_original_groups(s, (int)in->n_groups); if (ps) return ps; }
-        lap("slave alignments (one ksw batch)");
+        // (the slave alignments were launched before the records were set up: their results are in pinned memory by now)
+        { const int cs = ksw_collect(s, s->n_pre, s->pre_res); if (cs) return cs; }
         for (int gid = 1; gid <= (int)in->n_groups && !s->error && !s->hip_err; gid++) {
             auto it = s->group.find(gid);
             if (it == s->group.end() || !it->second) continue;

@@ -206,7 +206,13 @@ __global__ __launch_bounds__(256) void k_cons_sw(const uint8_t *seq, const uint6
                                                   const uint8_t *dr_chars, const uint32_t *dr_off, const uint32_t *dr_len, uint8_t *dirs,
                                                   ConsSwOut *out)
 {
-    const int lane = threadIdx.x & 63;
+    // A task whose direction matrix fits kSwLdsDir bytes (every task of a short-read job: <= ~100 x 38 cells) keeps it — and its
+    // window of the read — in LDS: the traceback is one DEPENDENT byte load per step in lane 0 (each a ~1 us round trip from
+    // global memory: it was most of this kernel's 5.1 ms for 108 k tasks), and the fill reads one byte of the read per step.
+    // Larger tasks (long reads) use the global scratch as before.
+    __shared__ uint8_t sw_dir[4][kSwLdsDir];
+    __shared__ uint8_t sw_a[4][kSwLdsA];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t q = w; q < n_tasks; q += nw) {
         const ConsSwTask t = tasks[q];
@@ -215,7 +221,16 @@ __global__ __launch_bounds__(256) void k_cons_sw(const uint8_t *seq, const uint6
         const uint8_t *B = dr_chars + dr_off[t.dr];
         const int lenB = (int)dr_len[t.dr];
         const int S0 = t.start, SL = t.len, W = lenB + 1;
-        uint8_t *dir = dirs + t.dir_off;
+        const bool in_lds = cons_sw_in_lds(SL, lenB);                   // (the host sized the scratch with the same test)
+        uint8_t *dir = in_lds ? &sw_dir[wv][0] : dirs + t.dir_off;
+        const uint8_t *Aseg = A + S0;                                    // Aseg[i - 1] = the read's base of row i
+        if (in_lds) {
+            for (int x = lane; x < SL; x += WAVE) sw_a[wv][x] = A[S0 + x];
+            Aseg = &sw_a[wv][0];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         double best = -1.0; int bi = 0, bj = 0;
         if (lenB <= WAVE) {
             const int j = lane + 1;
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(256) void k_cons_sw(const uint8_t *seq, const uint6
                     const double up = (i == 1) ? 0.0 : v1;
                     if (i == 1) diag = 0.0;
                     int index;
-                    const double sim = (A[i - 1 + S0] == bch) ? 1.2 : -1.0;
+                    const double sim = (Aseg[i - 1] == bch) ? 1.2 : -1.0;
                     cell = sw_find_max(diag + sim, up + (-1.0), left + (-1.0), 0.0, index);
                     dir[(size_t)i * W + j] = (uint8_t)index;
                     if (cell > my_best) { my_best = cell; my_i = i; }
