@@ -20,6 +20,7 @@
 // dependent there; oracle/crass_graph.py states the same choice); spacers are visited through one array sorted by the
 // reference's 32-bit SpacerKey (its wrap-around included).  No Xerces: the XML is written as text.
 #include "../../include/crass_hip.h"
+#include "merge.h"            // host_parallel_for
 
 #include <algorithm>
 #include <chrono>
@@ -28,6 +29,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <set>
@@ -729,41 +731,73 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
     std::vector<std::unique_ptr<Manager>> own;
     std::map<string, Manager *> by_dr;
     std::vector<Manager *> of_group(in->n_groups, nullptr);
-    try {
-        for (uint32_t g = 0; g < in->n_groups; g++) {
-            if (g && in->gid[g] <= in->gid[g - 1]) return CRASS_ERR_INVALID_ARG;
-            own.emplace_back(new Manager());
-            Manager *m = own.back().get();
-            m->dr.assign(in->dr_chars + in->dr_off[g], (size_t)(in->dr_off[g + 1] - in->dr_off[g]));
-            m->kmer = kmer; m->out = &R->out;
-            by_dr[m->dr] = m;
-            for (uint64_t k = in->grp_rec_off[g]; k < in->grp_rec_off[g + 1]; k++) {
-                if (k >= in->n_rec) return CRASS_ERR_INVALID_ARG;
-                ReadRef r;
-                r.hdr = in->hdr_chars + in->hdr_off[k]; r.nh = (uint32_t)(in->hdr_off[k + 1] - in->hdr_off[k]);
-                r.com = in->com_chars ? in->com_chars + in->com_off[k] : nullptr; r.nc = in->com_chars ? (uint32_t)(in->com_off[k + 1] - in->com_off[k]) : 0;
-                r.seq = in->seq_chars + in->seq_off[k]; r.ns = (uint32_t)(in->seq_off[k + 1] - in->seq_off[k]);
-                r.ss = in->ss_pool + in->rec_ss_off[k]; r.nss = in->rec_nss[k];
-                (void)m->add_read(r);
+    // One NodeManager per DR group, and nothing of one group's graph depends on another's: the stages run over the groups on the
+    // host pool (64 groups of ~1 600 reads at 10 M reads: 0.16 s of a 0.9 s crass-hip run on one thread).  What the reference
+    // prints on the way is collected per stage and group and put together in the order one thread would have produced it.
+    const uint32_t ng = in->n_groups;
+    for (uint32_t g = 0; g < ng; g++) {
+        if (g && in->gid[g] <= in->gid[g - 1]) return CRASS_ERR_INVALID_ARG;
+        if (in->grp_rec_off[g + 1] > in->n_rec || in->grp_rec_off[g + 1] < in->grp_rec_off[g]) return CRASS_ERR_INVALID_ARG;
+        own.emplace_back(new Manager());
+        Manager *m = own.back().get();
+        m->dr.assign(in->dr_chars + in->dr_off[g], (size_t)(in->dr_off[g + 1] - in->dr_off[g]));
+        m->kmer = kmer;
+        by_dr[m->dr] = m;
+    }
+    for (uint32_t g = 0; g < ng; g++) of_group[g] = by_dr[own[g]->dr];
+    // (two groups with one DR string share the LAST one's manager, as the reference's map does: then one thread, in order)
+    const unsigned threads = by_dr.size() == ng ? 32u : 1u;
+    std::vector<string> logs;                                // per stage and group / manager
+    std::vector<int> bad;
+    auto stage = [&](size_t n, const std::function<int(size_t, string *)> &fn) -> int {
+        logs.assign(n, string()); bad.assign(n, 0);
+        if (threads > 1) crass::host_parallel_for(n, threads, [&](size_t i) { bad[i] = fn(i, &logs[i]); });
+        else for (size_t i = 0; i < n; i++) bad[i] = fn(i, &logs[i]);
+        for (size_t i = 0; i < n; i++) { R->out += logs[i]; if (bad[i]) return bad[i]; }
+        return 0;
+    };
+    {
+        const int st = stage(ng, [&](size_t g, string *lg) -> int {
+            Manager *m = own[g].get();
+            m->out = lg;
+            try {
+                for (uint64_t k = in->grp_rec_off[g]; k < in->grp_rec_off[g + 1]; k++) {
+                    ReadRef r;
+                    r.hdr = in->hdr_chars + in->hdr_off[k]; r.nh = (uint32_t)(in->hdr_off[k + 1] - in->hdr_off[k]);
+                    r.com = in->com_chars ? in->com_chars + in->com_off[k] : nullptr; r.nc = in->com_chars ? (uint32_t)(in->com_off[k + 1] - in->com_off[k]) : 0;
+                    r.seq = in->seq_chars + in->seq_off[k]; r.ns = (uint32_t)(in->seq_off[k + 1] - in->seq_off[k]);
+                    r.ss = in->ss_pool + in->rec_ss_off[k]; r.nss = in->rec_nss[k];
+                    (void)m->add_read(r);
+                }
+            } catch (int) {
+                return CRASS_ERR_SEARCH_FATAL;               // substring_exception: the reference exit(99)s (NodeManager.cpp:216-219)
             }
-        }
-    } catch (int) {
-        return CRASS_ERR_SEARCH_FATAL;                       // substring_exception: the reference exit(99)s (NodeManager.cpp:216-219)
+            return 0;
+        });
+        if (st) return st;
     }
     lap("reads -> nodes and spacers");
-    for (uint32_t g = 0; g < in->n_groups; g++) of_group[g] = by_dr[string(in->dr_chars + in->dr_off[g], (size_t)(in->dr_off[g + 1] - in->dr_off[g]))];
-    std::vector<bool> alive(in->n_groups, true);
-    for (uint32_t g = 0; g < in->n_groups; g++) if (of_group[g]->clean_graph()) return CRASS_ERR_SEARCH_FATAL;
+    std::vector<bool> alive(ng, true);
+    { const int st = stage(ng, [&](size_t g, string *lg) -> int { of_group[g]->out = lg; return of_group[g]->clean_graph() ? CRASS_ERR_SEARCH_FATAL : 0; }); if (st) return st; }
     lap("cleanGraph");
-    for (auto &kv : by_dr) if (kv.second->build_spacer_graph()) return CRASS_ERR_SEARCH_FATAL;     // makeSpacerGraphs .. splitIntoContigs walk mDRs
-    for (auto &kv : by_dr) if (kv.second->clean_spacer_graph()) return CRASS_ERR_SEARCH_FATAL;
-    for (auto &kv : by_dr) kv.second->split_into_contigs();
-    for (uint32_t g = 0; g < in->n_groups; g++) of_group[g]->generate_flankers();
-    for (uint32_t g = 0; g < in->n_groups; g++) {            // removeLowConfidenceNodeManagers (WorkHorse.cpp:544-573)
-        Manager *m = of_group[g];
-        if (m->count_and_stats(false) < cov_cutoff) alive[g] = false;
-        else if (m->stdev() > 6.0) alive[g] = false;         // CRASS_DEF_STDEV_SPACER_LENGTH
+    std::vector<Manager *> in_dr_order;                      // makeSpacerGraphs .. splitIntoContigs walk mDRs
+    for (auto &kv : by_dr) in_dr_order.push_back(kv.second);
+    { const int st = stage(in_dr_order.size(), [&](size_t i, string *lg) -> int { in_dr_order[i]->out = lg; return in_dr_order[i]->build_spacer_graph() ? CRASS_ERR_SEARCH_FATAL : 0; }); if (st) return st; }
+    { const int st = stage(in_dr_order.size(), [&](size_t i, string *lg) -> int { in_dr_order[i]->out = lg; return in_dr_order[i]->clean_spacer_graph() ? CRASS_ERR_SEARCH_FATAL : 0; }); if (st) return st; }
+    (void)stage(in_dr_order.size(), [&](size_t i, string *lg) -> int { in_dr_order[i]->out = lg; in_dr_order[i]->split_into_contigs(); return 0; });
+    (void)stage(ng, [&](size_t g, string *lg) -> int { of_group[g]->out = lg; of_group[g]->generate_flankers(); return 0; });
+    {
+        std::vector<uint8_t> keep(ng, 1);
+        (void)stage(ng, [&](size_t g, string *lg) -> int {   // removeLowConfidenceNodeManagers (WorkHorse.cpp:544-573)
+            Manager *m = of_group[g];
+            m->out = lg;
+            if (m->count_and_stats(false) < cov_cutoff) keep[g] = 0;
+            else if (m->stdev() > 6.0) keep[g] = 0;          // CRASS_DEF_STDEV_SPACER_LENGTH
+            return 0;
+        });
+        for (uint32_t g = 0; g < ng; g++) alive[g] = keep[g] != 0;
     }
+    for (auto &mp : own) mp->out = &R->out;                  // (from here on: one thread again where anything is printed)
     lap("spacer graphs, contigs, flankers");
     // outputResults (WorkHorse.cpp:1900-2038)
     auto put = [&](const string &name, const string &data) { R->names.push_back(name); R->data.push_back(data); };
@@ -771,19 +805,33 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
     string keys = "digraph Keys {\n";
     Xml root("crispr");
     root.attr("version", "1.1");
-    int cluster = 0;
-    for (uint32_t g = 0; g < in->n_groups; g++) {
-        if (!alive[g]) continue;
+    // per group: the spacer graph's text decides whether the group is kept (phase A); the kept groups are numbered in order
+    // (the key graph's cluster index); then the key text, the read dump and the group's XML subtree — as text — per group
+    // (phase B); the pieces are put together in group order
+    std::vector<string> gv_txt(ng), key_txt(ng), fa_txt(ng), xml_txt(ng);
+    {
+        std::vector<uint8_t> ok(ng, 0);
+        (void)stage(ng, [&](size_t g, string *lg) -> int {
+            if (!alive[g]) return 0;
+            Manager *m = of_group[g];
+            m->out = lg;
+            ok[g] = m->spacer_graph_text(m->dr, op->long_description != 0, op->show_singles != 0, &gv_txt[g]) ? 1 : 0;
+            return 0;
+        });
+        for (uint32_t g = 0; g < ng; g++) if (alive[g] && !ok[g]) alive[g] = false;
+    }
+    std::vector<int> cluster_of(ng, -1);
+    { int cluster = 0; for (uint32_t g = 0; g < ng; g++) if (alive[g]) cluster_of[g] = cluster++; }
+    (void)stage(ng, [&](size_t g, string *lg) -> int {
+        if (!alive[g]) return 0;
         Manager *m = of_group[g];
+        m->out = lg;
         const string gid = std::to_string(in->gid[g]);
-        string gv;
-        if (!m->spacer_graph_text(m->dr, op->long_description != 0, op->show_singles != 0, &gv)) { alive[g] = false; continue; }
         const string gv_name = "Spacers_" + gid + "_" + m->dr + "_spacers.gv", fa_name = "Group_" + gid + "_" + m->dr + ".fa";
-        put(gv_name, gv);
-        keys += m->spacer_key_text(cluster++, name_prefix + gid);
-        put(fa_name, m->dump_reads_text());
-        R->kept.push_back(in->gid[g]);
-        Xml *grp = root.add("group")->attr("gid", "G" + gid)->attr("drseq", m->dr);
+        key_txt[g] = m->spacer_key_text(cluster_of[g], name_prefix + gid);
+        fa_txt[g] = m->dump_reads_text();
+        Xml grp_node("group");
+        Xml *grp = grp_node.attr("gid", "G" + gid)->attr("drseq", m->dr);
         // <data> (WorkHorse.cpp:2040-2088)
         Xml *data = grp->add("data");
         Xml *sources = data->add("sources"), *drs = data->add("drs"), *sps = data->add("spacers");
@@ -844,6 +892,19 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
                 for (auto &p : part) if (p) cs->kids.push_back(std::move(p));
             }
         }
+        grp_node.write(xml_txt[g], 1);
+        return 0;
+    });
+    for (auto &mp : own) mp->out = &R->out;
+    for (uint32_t g = 0; g < ng; g++) {
+        if (!alive[g]) continue;
+        const Manager *m = of_group[g];
+        const string gid = std::to_string(in->gid[g]);
+        put("Spacers_" + gid + "_" + m->dr + "_spacers.gv", gv_txt[g]);
+        keys += key_txt[g];
+        put("Group_" + gid + "_" + m->dr + ".fa", fa_txt[g]);
+        R->kept.push_back(in->gid[g]);
+        root.raw += xml_txt[g];                              // (the children of <crispr>, already laid out as text)
     }
     lap("group files + XML tree");
     R->out += "[" + package + "_graphBuilder]: " + std::to_string(R->kept.size()) + " CRISPRs found!\n";
