@@ -631,6 +631,8 @@ struct RH {                 // ReadHolder state (ReadHolder.h:440-451), wave-uni
     float *sims;            // LDS scratch for the QC similarities (ss_cap floats)
     const uint32_t *words;  // LDS copy of the 2-bit packed read (+1 zero word), nullptr for exception reads
     uint32_t cmask;         // (1 << 2w) - 1
+    int asc_lo, asc_hi;     // packed reads: seq[] holds the ASCII bases of [asc_lo, asc_hi) only (rh_ascii), wave-uniform
+    int asc_pad;            // how far beyond the repeats found so far the byte-wise consumers may read
 };
 
 // leftmost occurrence of seq[pat, pat+plen) in seq[begin, end): PatternMatcher::bmpSearch
@@ -673,6 +675,32 @@ static __device__ __forceinline__ int rh_find(const RH &h, int begin, int end, i
 {
     if (h.words) return wave_find_packed(h.words, h.cmask, begin, end, pat, plen, lane);
     return wave_find(h.seq, begin, end, pat, plen, lane);
+}
+
+// The byte-wise consumers (extendPreRepeat's column votes, the QC's string comparisons, DRLowLexi) read the bases around the
+// repeats found so far, never far from them — a packed read's ASCII copy is expanded for that REGION when they are entered,
+// not for the whole read when it is loaded (a 10 kbp read: 10 KB of LDS writes per read against 2.5 KB for the packed words;
+// 61 % of random 10 kbp reads meet a candidate, which covers a few hundred bases).  kAscPad bounds how far the consumers
+// reach beyond the first repeat's start / the last one's end: one repeat spacing (highDR + highSp, 97 by default) for the
+// extensions; RH::asc_pad = that + 32.
+static __device__ __forceinline__ void word_to_ascii(uint32_t v, uint32_t o[4]);
+static __device__ void rh_ascii(RH &h, int lane)
+{
+    if (!h.words || h.nss < 2) return;                  // exception reads: the bytes are the read
+    int lo = (int)h.ss[0] - h.asc_pad, hi = (int)h.ss[h.nss - 1] + h.asc_pad;
+    if (lo < 0) lo = 0;
+    if (hi > h.L) hi = h.L;
+    if (lo >= h.asc_lo && hi <= h.asc_hi) return;       // (wave-uniform)
+    if (h.asc_hi > h.asc_lo) { lo = min(lo, h.asc_lo); hi = max(hi, h.asc_hi); }      // one interval: the union
+    const int w0 = lo >> 4, w1 = (hi + 15) >> 4;
+    for (int wi = w0 + lane; wi < w1; wi += WAVE) {
+        uint32_t o[4];
+        word_to_ascii(h.words[wi], o);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(h.seq + 16 * wi);   // seq region is 16-B aligned and padded
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+    }
+    h.asc_lo = w0 * 16; h.asc_hi = min(w1 * 16, h.L + 16);
+    wave_sync();
 }
 
 // ReadHolder::startStopsAdd, ReadHolder.cpp:263-297
@@ -721,6 +749,7 @@ static __device__ void scan_right(RH &h, int pat, uint32_t pattern_length, uint3
 // extendPreRepeat, libcrispr.cpp:520-772.  The per-column A/C/G/T votes run over repeats in lanes.
 static __device__ uint32_t extend_pre_repeat(RH &h, int searchWindowLength, int minSpacerLength, int lane)
 {
+    rh_ascii(h, lane);
     const uint32_t num_repeats = (uint32_t)h.nss / 2;
     h.replen = searchWindowLength;
     int cut_off = (int)(num_repeats - 1);
@@ -986,6 +1015,7 @@ static __device__ __forceinline__ bool substr_len(int L, uint32_t pos, uint32_t 
 // Internal spacer i (getAllSpacerStrings, ReadHolder.cpp:199-239) = seq[ss[2i+1]+1, ss[2i+2]).
 static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacerLength, int lane, uint32_t dbg = 0)
 {
+    rh_ascii(h, lane);
     const int num_repeats = h.nss / 2;
     if (num_repeats < 2) return -1;
     uint32_t rep_len;
@@ -1205,6 +1235,7 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
 // (<0 error) and the RH_WasLowLexi flag.
 static __device__ int dr_low_lexi(RH &h, char *dr_out, int dr_stride, int &was_low_lexi, int lane)
 {
+    rh_ascii(h, lane);
     const int num_repeats = h.nss / 2;
     int pick;
     if (num_repeats == 1) pick = 0;
@@ -1339,22 +1370,12 @@ static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *
             if (wi < nw) {
                 const uint32_t v = pf->w[i];
                 words[wi] = v;
-                uint32_t o[4];
-                word_to_ascii(v, o);
-                uint32_t *dst = reinterpret_cast<uint32_t *>(seq + 16 * wi);
-                dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
             }
         }
         first = lane + SV_PREFETCH_WORDS * WAVE;
     }
-    for (int wi = first; wi < nw; wi += WAVE) {
-        uint32_t v = g[wi];
-        words[wi] = v;
-        uint32_t o[4];
-        word_to_ascii(v, o);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(seq + 16 * wi);   // seq region is 16-B aligned and padded
-        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
-    }
+    for (int wi = first; wi < nw; wi += WAVE) words[wi] = g[wi];
+    (void)seq;                                          // (the ASCII copy: region by region, when a byte-wise consumer is entered — rh_ascii)
 }
 
 template <bool EXC>
@@ -1458,6 +1479,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
         }
         wave_sync();
         h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
+        h.asc_lo = 0; h.asc_hi = 0; h.asc_pad = (int)(P.highDR + P.highSp) + 32;
         const uint32_t hint = (!EXC && seed_hint) ? seed_hint[r] : 0xFFFFFFFFu;
         uint64_t *ph = (!EXC && R.pos_hint) ? l_hint : nullptr;            // (staged in LDS above)
         uint32_t *cls_from = reinterpret_cast<uint32_t *>(l_hint + lds.hint_words - 4);      // (the last four hint slots: 8 x uint32)
