@@ -1001,10 +1001,18 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     const SurvLds lds_full = survivor_lds_layout(c->max_len, c->dp);
     if (lds_full.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
     const uint32_t row_cap = c->env.row_cap;            // (tests: CRASS_ROW_CAP forces the second launch)
-    const SurvLds lds = survivor_lds_layout(c->max_len, c->dp, row_cap);
-    const bool capped = lds.row_elems != lds_full.row_elems;
+    // Reads beyond 2 048 bases also get an ASCII WINDOW instead of room for the whole read (the byte-wise consumers only ever
+    // read around the repeats of the candidate in hand: rh_ascii) and a start/stop list of 256 entries: 11.5 instead of 19.7 KB
+    // of LDS per wave at 10 kbp — three waves per SIMD (with 168 registers) instead of two.  An array longer than the window
+    // (> ~4.2 kbp), a 129th repeat or a string beyond the rows: the second launch.  CRASS_LONG_FULL_LAYOUT: the A/B switch.
+    static const bool long_full = getenv("CRASS_LONG_FULL_LAYOUT") != nullptr;
+    static const uint32_t win_env = getenv("CRASS_SEQ_WINDOW") ? (uint32_t)atoi(getenv("CRASS_SEQ_WINDOW")) : 0u;      // (tests: a tiny window)
+    const bool windowed = !exc && (win_env || (c->max_len > 2048 && !long_full));
+    const SurvLds lds = windowed ? survivor_lds_layout(c->max_len, c->dp, row_cap, win_env ? win_env : 4608u, 256u)
+                                 : survivor_lds_layout(c->max_len, c->dp, row_cap);
+    const bool capped = lds.row_elems != lds_full.row_elems || lds.seq_window != 0 || lds.ss_cap != lds_full.ss_cap;
     const uint64_t chunk_cap = std::min<uint64_t>(n_total, 1u << 20);
-    const uint64_t ss_per = std::min<uint64_t>(lds.ss_cap, 64);
+    const uint64_t ss_per = std::min<uint64_t>(lds_full.ss_cap, 64);
     const uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(chunk_cap * ss_per, 1u << 16), 1ull << 28);
     HIPCHK(c, c->d_surv.ensure(chunk_cap));
     HIPCHK(c, c->d_dr.ensure(chunk_cap * c->dr_stride));

@@ -263,6 +263,9 @@ struct SurvLds {
     uint32_t words_cap;           // uint32 entries of the packed-read copy
     uint32_t hint_words;          // uint64 entries of the read's per-position seed hints (long reads)
     uint32_t total_bytes;
+    uint32_t seq_window;          // != 0: seq_bytes holds an ASCII WINDOW of a packed read (rh_ascii) — a region that does not fit, like a
+                                  // start/stop list beyond ss_cap or a string beyond the rows, sends the read to the launch with the full layout (err 6)
+    uint32_t ss_slot;             // entries per survivor slot of the start/stop pool in slot mode: the FULL layout's ss_cap in every launch of a set
 };
 
 // ---- launch wrappers implemented in kernels.hip (all asynchronous on `st`) ----
@@ -452,7 +455,8 @@ hipError_t launch_dr_dedupe(const char *dr, const uint16_t *dr_len, uint32_t str
                             bool table_cleared = false);
 // row_len_cap: longest string the Levenshtein fallback rows hold in this layout (reads that need more come back
 // with err == 6 and are redone with the uncapped layout)
-SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P, uint32_t row_len_cap = 0xFFFFFFFFu);
+SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P, uint32_t row_len_cap = 0xFFFFFFFFu,
+                            uint32_t seq_window_bytes = 0, uint32_t ss_entries_cap = 0);   // the two caps of the long-read layout (0: none)
 hipError_t upload_comp_table(const unsigned char *tab128);
 
 } // namespace crass

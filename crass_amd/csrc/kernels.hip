@@ -633,6 +633,8 @@ struct RH {                 // ReadHolder state (ReadHolder.h:440-451), wave-uni
     uint32_t cmask;         // (1 << 2w) - 1
     int asc_lo, asc_hi;     // packed reads: seq[] holds the ASCII bases of [asc_lo, asc_hi) only (rh_ascii), wave-uniform
     int asc_pad;            // how far beyond the repeats found so far the byte-wise consumers may read
+    uint8_t *seq_buf;       // the LDS bytes behind seq; with a window (seq_win != 0) seq = seq_buf - asc_lo, so that seq[pos] still works
+    int seq_win;            // bytes of the ASCII window (0: the whole read fits)
 };
 
 // leftmost occurrence of seq[pat, pat+plen) in seq[begin, end): PatternMatcher::bmpSearch
@@ -691,8 +693,14 @@ static __device__ void rh_ascii(RH &h, int lane)
     if (lo < 0) lo = 0;
     if (hi > h.L) hi = h.L;
     if (lo >= h.asc_lo && hi <= h.asc_hi) return;       // (wave-uniform)
-    if (h.asc_hi > h.asc_lo) { lo = min(lo, h.asc_lo); hi = max(hi, h.asc_hi); }      // one interval: the union
     const int w0 = lo >> 4, w1 = (hi + 15) >> 4;
+    // (only the candidate in hand is ever read: an earlier candidate's region is dropped.)  With a window: the region
+    // starts at the buffer's first byte and seq is moved so that seq[pos] addresses it; a region that does not fit sends the
+    // read to the launch with the full layout
+    if (h.seq_win) {
+        if ((w1 - w0) * 16 > h.seq_win) { h.err = 6; return; }
+        h.seq = h.seq_buf - w0 * 16;
+    }
     for (int wi = w0 + lane; wi < w1; wi += WAVE) {
         uint32_t o[4];
         word_to_ascii(h.words[wi], o);
@@ -750,6 +758,7 @@ static __device__ void scan_right(RH &h, int pat, uint32_t pattern_length, uint3
 static __device__ uint32_t extend_pre_repeat(RH &h, int searchWindowLength, int minSpacerLength, int lane)
 {
     rh_ascii(h, lane);
+    if (h.err == 6) return 0;                           // (the region does not fit the ASCII window: search_core hands the read over)
     const uint32_t num_repeats = (uint32_t)h.nss / 2;
     h.replen = searchWindowLength;
     int cut_off = (int)(num_repeats - 1);
@@ -1016,6 +1025,7 @@ static __device__ __forceinline__ bool substr_len(int L, uint32_t pos, uint32_t 
 static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacerLength, int lane, uint32_t dbg = 0)
 {
     rh_ascii(h, lane);
+    if (h.err == 6) return -3;
     const int num_repeats = h.nss / 2;
     if (num_repeats < 2) return -1;
     uint32_t rep_len;
@@ -1215,6 +1225,7 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
         }
         if ((uint32_t)(h.nss / 2) >= o.minRepeats) {
             uint32_t actual_repeat_length = extend_pre_repeat(h, (int)o.window, (int)o.lowSp, lane);
+            if (h.err == 6) return -3;
             if (o.debug_stop != 3 && (actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {
                 int qc = qc_found_repeats(h, (int)o.lowSp, (int)o.highSp, lane, o.debug_stop);
                 if (qc == -3) return -3;
@@ -1381,7 +1392,7 @@ static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *
 template <bool EXC>
 // (two waves per SIMD asked for, i.e. up to 256 VGPRs: with one wave per block and 14-58 KB of LDS per block the LDS decides
 // the residency — and the next read's prefetched words did not fit the 128 registers of a 4-wave target without spilling)
-__global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, const uint64_t *surv_idx,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_survivor(DevReads R, DevParams P, const uint64_t *surv_idx,
                                                    const uint32_t *d_n_surv, uint64_t n_max, SurvOut *out,
                                                    char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                                    uint32_t ss_pool_cap, uint32_t *d_ss_used,
@@ -1391,6 +1402,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
     const int lane = threadIdx.x;
     RH h;
     h.seq = sv_lds;
+    h.seq_buf = sv_lds; h.seq_win = EXC ? 0 : (int)lds.seq_window;
     h.ss = reinterpret_cast<uint32_t *>(sv_lds + lds.seq_bytes);
     h.cap = (int)lds.ss_cap;
     h.rowA = reinterpret_cast<uint16_t *>(h.ss + lds.ss_cap);
@@ -1479,7 +1491,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
         }
         wave_sync();
         h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
-        h.asc_lo = 0; h.asc_hi = 0; h.asc_pad = (int)(P.highDR + P.highSp) + 32;
+        h.asc_lo = 0; h.asc_hi = 0; h.asc_pad = (int)(P.highDR + P.highSp) + 32; h.seq = h.seq_buf;
         const uint32_t hint = (!EXC && seed_hint) ? seed_hint[r] : 0xFFFFFFFFu;
         uint64_t *ph = (!EXC && R.pos_hint) ? l_hint : nullptr;            // (staged in LDS above)
         uint32_t *cls_from = reinterpret_cast<uint32_t *>(l_hint + lds.hint_words - 4);      // (the last four hint slots: 8 x uint32)
@@ -1488,7 +1500,9 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
         int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane, ph, ph ? cls_from : nullptr);
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
-        if (f == -3) o.err = 6;                              // Levenshtein rows too short in this launch's LDS layout
+        // (-3: Levenshtein rows too short / the ASCII window too small in this launch's LDS layout; -2 in a layout with a capped
+        // start/stop list: the same — the launch with the full layout decides)
+        if (f == -3 || (f == -2 && lds.ss_cap < lds.ss_slot)) o.err = 6;
         else if (f < 0) o.err = (f == -2) ? 2 : 1;
         if (f == 1 && P.debug_stop != 4) {
             int low = 0;
@@ -1500,7 +1514,7 @@ __global__ __launch_bounds__(WAVE, 2) void k_survivor(DevReads R, DevParams P, c
                 // (slot_base / slot_total: this launch covers the slots [slot_base, slot_base + n) of slot_total — the walk of a
                 // long-read set runs slice by slice, `out` and `dr_chars` already point at the slice, the pool is shared)
                 uint32_t off = 0;
-                if ((slot_total ? slot_total : n_surv) * lds.ss_cap <= ss_pool_cap) off = (uint32_t)(s + slot_base) * lds.ss_cap;
+                if ((slot_total ? slot_total : n_surv) * lds.ss_slot <= ss_pool_cap) off = (uint32_t)(s + slot_base) * lds.ss_slot;
                 else {
                     if (lane == 0) off = atomicAdd(d_ss_used, (uint32_t)h.nss);
                     off = (uint32_t)__shfl((int)off, 0);
@@ -2692,12 +2706,16 @@ hipError_t launch_dx_tokens(const char *dr, const uint16_t *dr_len, const uint64
     return hipGetLastError();
 }
 
-SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P, uint32_t row_len_cap)
+SurvLds survivor_lds_layout(uint32_t max_len, const DevParams &P, uint32_t row_len_cap, uint32_t seq_window_bytes, uint32_t ss_entries_cap)
 {
     SurvLds l;
     l.seq_bytes = ((max_len + 16 + 16) + 15u) & ~15u;
+    l.seq_window = 0;
+    if (seq_window_bytes && ((seq_window_bytes + 15u) & ~15u) + 32u < l.seq_bytes) { l.seq_bytes = ((seq_window_bytes + 15u) & ~15u) + 32u; l.seq_window = l.seq_bytes - 32u; }
     uint32_t reps = max_len / (P.window + P.lowSp) + 4;
     l.ss_cap = ((2 * reps) + 3u) & ~3u;
+    l.ss_slot = l.ss_cap;
+    if (ss_entries_cap && ((ss_entries_cap + 3u) & ~3u) < l.ss_cap) l.ss_cap = (ss_entries_cap + 3u) & ~3u;
     l.row_elems = ((std::min(max_len, row_len_cap) + 8) + 7u) & ~7u;
     l.words_cap = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
     l.hint_words = (((max_len + 63) / 64 + 2 + 1u) & ~1u) + 4u;      // + 8 x uint32: where each residue class's hint bits start (search_core)
