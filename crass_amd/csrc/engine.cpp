@@ -1005,8 +1005,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     // read around the repeats of the candidate in hand: rh_ascii) and a start/stop list of 256 entries: 11.5 instead of 19.7 KB
     // of LDS per wave at 10 kbp — three waves per SIMD (with 168 registers) instead of two.  An array longer than the window
     // (> ~4.2 kbp), a 129th repeat or a string beyond the rows: the second launch.  CRASS_LONG_FULL_LAYOUT: the A/B switch.
-    static const bool long_full = getenv("CRASS_LONG_FULL_LAYOUT") != nullptr;
-    static const uint32_t win_env = getenv("CRASS_SEQ_WINDOW") ? (uint32_t)atoi(getenv("CRASS_SEQ_WINDOW")) : 0u;      // (tests: a tiny window)
+    // (both read per call — once per seed scan of a long-read set —, so that a test can change them inside one process)
+    const bool long_full = getenv("CRASS_LONG_FULL_LAYOUT") != nullptr;
+    const uint32_t win_env = getenv("CRASS_SEQ_WINDOW") ? (uint32_t)atoi(getenv("CRASS_SEQ_WINDOW")) : 0u;      // (tests: a tiny window)
     const bool windowed = !exc && (win_env || (c->max_len > 2048 && !long_full));
     const SurvLds lds = windowed ? survivor_lds_layout(c->max_len, c->dp, row_cap, win_env ? win_env : 4608u, 256u)
                                  : survivor_lds_layout(c->max_len, c->dp, row_cap);

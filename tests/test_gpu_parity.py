@@ -310,6 +310,17 @@ def test_long_reads_ragged_mid_size(ca):
     # (no exception reads, one chunk: the found records are de-duplicated on the device and the DEVICE merge runs — the
     # host-loop sink of long reads no longer means the host merge)
     assert gpu.counters["used_device_merge"] == 1 and gpu.counters["n_merge_fallbacks"] == 0
+    # the walking kernel's ASCII window (long reads: room for the region around a candidate's repeats, not for the read): with
+    # 1 024 bytes every array beyond ~700 bases does not fit and goes to the second launch with the full layout; with the full
+    # layout for everybody (the A/B switch) nothing does
+    for env in ({"CRASS_SEQ_WINDOW": "1024"}, {"CRASS_LONG_FULL_LAYOUT": "1"}):
+        os.environ.update(env)
+        try:
+            alt = ca.search_pipeline(seqs)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert_same_pipeline(alt, ref)
     # the hint kernel in slices beside the walk (the default only slices sets of >= 4 096 reads): every slice count, ragged
     # lengths — slice boundaries fall inside reads' hint words and inside the per-block read index
     for parts in ("1", "3", "4"):
