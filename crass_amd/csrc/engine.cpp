@@ -432,14 +432,20 @@ struct crass_hip_ctx {
     } xchg;
     // distinct candidate strings (multi-GPU exchange)
     std::vector<char> dx_chars; std::vector<uint16_t> dx_len; std::vector<uint32_t> dx_map; bool have_distinct = false;
-    uint64_t n_cand() const { return dense.active ? dense.n : cand.size(); }
+    // host-loop sink, one chunk without exception reads: the found records reach pinned host memory on the copy stream (bulk_pending)
+    // while the merge and pass 2 are queued; the ABI's per-candidate arrays (`cand`) are filled from them when somebody asks
+    mutable std::function<void()> cand_fill;
+    hipEvent_t ev_sink_copies = nullptr;        // behind those copies on the copy stream: pass 2 re-uses one of their source buffers (d_fidx)
+    mutable uint64_t cand_pending_n = 0;
+    void materialize_cand() const { if (cand_fill) { std::function<void()> f; f.swap(cand_fill); f(); } }
+    uint64_t n_cand() const { return dense.active ? dense.n : (cand_fill ? cand_pending_n : cand.size()); }
     // the distinct DR strings (token order) and every candidate's index among them came from the DEVICE: the dense sink, or the
     // host-loop sink of a long-read set (hl_tokens: its gathered records were de-duplicated on the device beside the copies)
     bool hl_tokens = false;
     bool dev_tokens() const { return have_dev_tokens && (dense.active || hl_tokens); }
     void widen_p1() const;
-    const char *cand_dr() const { if (dense.active) { widen_p1(); return dense.w_dr.data(); } return cand.dr.data(); }
-    const uint16_t *cand_dr_len() const { if (dense.active) { widen_p1(); return dense.w_dr_len.data(); } return cand.dr_len.data(); }
+    const char *cand_dr() const { if (dense.active) { widen_p1(); return dense.w_dr.data(); } materialize_cand(); return cand.dr.data(); }
+    const uint16_t *cand_dr_len() const { if (dense.active) { widen_p1(); return dense.w_dr_len.data(); } materialize_cand(); return cand.dr_len.data(); }
     uint32_t dr_stride = 48;
     // merge
     MergeResult merge;
@@ -742,6 +748,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
     c->h_dmap.release(); c->h_dx_chars.release(); c->h_dx_len.release(); c->h_dx_hash.release();
     if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
+    if (c->ev_sink_copies) (void)hipEventDestroy(c->ev_sink_copies);
     for (int q = 0; q < crass_hip_ctx::kHintParts; q++) if (c->ev_hint[q]) (void)hipEventDestroy(c->ev_hint[q]);
     if (c->ev_hint_go) (void)hipEventDestroy(c->ev_hint_go);
     if (c->hint_stream) (void)hipStreamDestroy(c->hint_stream);
@@ -989,6 +996,7 @@ static int hint_wait_all(crass_hip_ctx *c)
 }
 
 static int ensure_mask_scratch(crass_hip_ctx *c, uint64_t n_bits);
+static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok, bool prepared);
 static bool getenv_once_hl_host() { static const bool v = getenv("CRASS_HL_HOST_DEDUPE") != nullptr; return v; }      // A/B switch: the round-3 host de-duplication + merge for long reads
 
 static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip_ctx::P1List &L,
@@ -1095,14 +1103,25 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         const uint32_t used = c->h_count.p[6];
         if (nf > nchunk || used > pool_cap) return CRASS_ERR_OVERFLOW;
         HIPCHK(c, c->h_ss.ensure(used + 1)); HIPCHK(c, c->h_idx.ensure(nf + 1));
+        // the copies: on the copy stream when the records' consumers can wait (one chunk, no exception list to merge with, slots =
+        // reads: `cand` is then filled on request, materialize_cand) — the main stream goes on with the de-duplication, the
+        // merge and pass 2 —, else on the main stream with the host loop right behind them
+        static const bool sink_eager = getenv("CRASS_SINK_EAGER") != nullptr;      // A/B switch
+        const bool lazy = !sink_eager && !exc && off == 0 && nchunk == n_total && c->R.n_exc == 0 && !surv_idx_host && &L == &c->cand && L.read.empty();
         if (nf) {
-            HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->g_surv.p, nf * sizeof(SurvOut), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->g_dr.p, nf * (size_t)stride, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_fidx.p, nf * 8, hipMemcpyDeviceToHost, c->stream));
-            if (used) HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->g_ss.p, (size_t)used * (ss16 ? 2 : 4), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipStream_t cs = lazy ? c->copy_stream : c->stream;      // (the main stream is idle: it was waited for above)
+            HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->g_surv.p, nf * sizeof(SurvOut), hipMemcpyDeviceToHost, cs));
+            HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->g_dr.p, nf * (size_t)stride, hipMemcpyDeviceToHost, cs));
+            HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_fidx.p, nf * 8, hipMemcpyDeviceToHost, cs));
+            if (used) HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->g_ss.p, (size_t)used * (ss16 ? 2 : 4), hipMemcpyDeviceToHost, cs));
+            if (lazy) {
+                if (!c->ev_sink_copies) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sink_copies, hipEventDisableTiming));
+                HIPCHK(c, hipEventRecord(c->ev_sink_copies, c->copy_stream));
+                c->bulk_pending = true;
+            }
+            else HIPCHK(c, hipStreamSynchronize(c->stream));
         }
-        bool hl_queued = false;
+        bool hl_queued = false, hl_premerge = false;
         if (nf && hl_dedupe) {
             // (behind the copies above; the host loop below runs beside these kernels; their small outputs land in pinned memory)
             uint32_t tsize = 1024;
@@ -1120,8 +1139,20 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                                        c->h_dx_chars.p, c->h_dx_len.p, c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream,
                                        c->d_count.p, c->h_count.p, 8, nullptr));
             hl_queued = true;
+            // the merge itself right behind (its kernels read the token count from the device and are sized for nf, a bound on
+            // it): it runs while the host returns from this call and enters crass_hip_merge, which adopts it
+            HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
+            c->premerge = 0; c->premerge_inflight = false;
+            if (!c->env.no_speculation && nf <= (1u << 18)) {
+                const int ps = device_merge_enqueue(c, c->dd_dx_chars.p, c->dd_dx_len.p, nf, c->d_count.p + 4, false);
+                if (ps) return ps;
+                HIPCHK(c, hipEventRecord(c->ev_premerge, c->stream));
+                hl_premerge = true;
+            }
         }
         const double tq2 = now_ms();
+        auto fill = [c, nf, ss16, stride, exc, off, surv_idx_host, &L]() {
+        if (c->wait_bulk()) return;                         // (the copies; a failed one is reported by whoever asks for the records)
         const SurvOut *so = c->h_surv.p;
         const char *drs = c->h_dr.p;
         const uint32_t *pool = c->h_ss.p;
@@ -1149,12 +1180,17 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                 memcpy(L.dr.data() + (base + q) * (size_t)stride, drs + q * stride, stride);
             }
         });
+        };
+        if (lazy && nf) { c->cand_fill = fill; c->cand_pending_n = nf; }      // (L is c->cand: it outlives this call)
+        else fill();
         if (hl_queued) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev_gathered));      // (the de-duplication's counters; the merge behind it may still run)
+            c->premerge_inflight = hl_premerge;
             if (c->h_count.p[5] == 0 && c->h_count.p[2] == nf && c->h_count.p[4] > 0) {
                 c->n_dx = c->h_count.p[4];
                 c->have_dev_tokens = true; c->hl_tokens = true;
                 c->dx_hash_valid = true;
+                if (hl_premerge) c->premerge = 2;
             }
         }
         if (c->env.merge_profile)
@@ -1593,6 +1629,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     c->have_rep = false;
     c->have_dev_tokens = false; c->hl_tokens = false;
     c->have_distinct = false;
+    c->cand_fill = nullptr; c->cand_pending_n = 0;      // (a fill nobody asked for: its records are dropped)
     c->cand.clear();
     const double t_sink0 = now_ms();
     uint64_t n_surv = 0;
@@ -1693,7 +1730,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         }
     }
     HIPCHK(c, c->stamp(4, 2));
-    if (!(c->premerge_inflight && c->dense.active)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!(c->premerge_inflight && (c->dense.active || c->hl_tokens))) HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t total = (size_t)c->n_cand();
     c->have_pass1 = true;
     if (c->xchg.active && !(c->dense.active && c->have_dev_tokens)) {
@@ -1737,6 +1774,7 @@ int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
         o->n_ss = D.w_nss.data(); o->ss_off = D.w_ss_off.data(); o->ss_pool = D.w_ss.data();
         o->dr_stride = c->dr_stride; o->dr_len = D.w_dr_len.data(); o->dr_chars = D.w_dr.data();
     } else {
+        c->materialize_cand();
         o->n = c->cand.size();
         o->read_idx = c->cand.read.data(); o->low_lexi = c->cand.low.data(); o->repeat_len = c->cand.replen.data();
         o->n_ss = c->cand.nss.data(); o->ss_off = c->cand.ss_off.data(); o->ss_pool = c->cand.ss.data();
@@ -2613,6 +2651,8 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     c->have_pass2 = false;
     c->q_blob_active = false;
     c->cnt.n_pass2_found = 0;
+    // (the host-loop sink's copies may still be reading d_fidx, which this pass writes near its end: order the stream behind them)
+    if (c->cand_fill && c->ev_sink_copies) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sink_copies, 0));
     // findSingletons is only called when the non-redundant set is non-empty (WorkHorse.cpp:373)
     if (c->n_installed_patterns == 0) { c->have_pass2 = true; return CRASS_OK; }
     if (!c->have_patterns) return CRASS_ERR_STATE;
