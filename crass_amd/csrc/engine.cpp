@@ -856,6 +856,7 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
 }
 
 static int first_call_bounds(crass_hip_ctx *c);
+static void presize_hostloop(crass_hip_ctx *c);
 
 static void reset_results(crass_hip_ctx *c)
 {
@@ -939,6 +940,7 @@ int crass_hip_load_reads(crass_hip_ctx *c, const crass_reads *h)
     if (s) return s;
     s = first_call_bounds(c);
     if (s) return s;
+    presize_hostloop(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnt.n_reads = n; c->cnt.n_exceptions = h->n_exceptions; c->cnt.bytes_reads_device = total_words * 4;
     return CRASS_OK;
@@ -973,6 +975,7 @@ int crass_hip_attach_device_reads(crass_hip_ctx *c, const crass_reads *d)
     if (s) return s;
     s = first_call_bounds(c);
     if (s) return s;
+    presize_hostloop(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnt.n_reads = d->n_reads; c->cnt.n_exceptions = 0;
     c->cnt.bytes_reads_device = d->n_reads * (uint64_t)d->stride_words * 4;
@@ -1198,6 +1201,39 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                     (unsigned long long)nchunk, tq1 - tq0, tq2 - tq1, now_ms() - tq2);
     }
     return CRASS_OK;
+}
+
+// A long-read set (position hints: no per-read filter, every read is a survivor) takes the host-loop sink; crass scans a read
+// set ONCE, so what that sink and the stages behind it allocate on their first call is allocated with the reads — best effort:
+// whatever cannot be had now is had then, as before (the first step of a 1 M x 10 kbp set: 17.4 ms against 10.3 in steady
+// state; the guesses: one found read in eight, 128 start/stops per found read)
+static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok);
+static void presize_hostloop(crass_hip_ctx *c)
+{
+    if (!c->R.pos_hint || c->env.no_presize || c->R.n_reads == 0) return;
+    const SurvLds lds_full = survivor_lds_layout(c->max_len, c->dp);
+    if (lds_full.total_bytes > 160 * 1024) return;
+    const uint64_t chunk_cap = std::min<uint64_t>(c->R.n_reads, 1u << 20);
+    const uint64_t ss_per = std::min<uint64_t>(lds_full.ss_cap, 64);
+    const uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(chunk_cap * ss_per, 1u << 16), 1ull << 28);
+    const uint32_t stride = c->dr_stride;
+    const uint64_t nf = std::min<uint64_t>(chunk_cap, std::max<uint64_t>(65536, chunk_cap / 8));
+    const uint64_t n_words = (chunk_cap + 63) / 64;
+    uint32_t tsize = 1024;
+    while (tsize < nf * 2) tsize <<= 1;
+    bool ok = true;
+    auto need = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
+    need(c->d_surv.ensure(chunk_cap)); need(c->d_dr.ensure(chunk_cap * stride)); need(c->d_ss_pool.ensure(pool_cap));
+    need(c->h_surv.ensure(chunk_cap)); need(c->h_dr.ensure(chunk_cap * stride));
+    need(c->d_fidx.ensure(chunk_cap)); need(c->g_surv.ensure(chunk_cap)); need(c->g_dr.ensure(chunk_cap * (size_t)stride + 16)); need(c->g_ss.ensure(pool_cap));
+    need(c->d_mask.ensure(n_words + 1)); need(c->d_word_prefix.ensure(n_words + 1)); need(c->d_block_sums.ensure((n_words + 255) / 256 + 2));
+    need(c->g_dr_len.ensure(chunk_cap)); need(c->h_ss.ensure(nf * 128 + 1)); need(c->h_idx.ensure(nf + 1));
+    need(c->dd_keys.ensure(tsize)); need(c->dd_first.ensure(tsize)); need(c->dd_slot.ensure(nf)); need(c->dd_rep.ensure(nf));
+    need(c->dd_hash.ensure(nf)); need(c->hl_dx_idx.ensure(nf)); need(c->dd_dx_chars.ensure(nf * (size_t)stride + 16)); need(c->dd_dx_len.ensure(nf));
+    need(c->h_dmap.ensure(nf)); need(c->h_dx_chars.ensure(nf * (size_t)stride + 16)); need(c->h_dx_len.ensure(nf)); need(c->h_dx_hash.ensure(nf));
+    if (ok && c->prm.lowDRsize >= 23 && stride <= 64 && !c->env.host_merge && !c->xchg.active)
+        (void)device_merge_prepare(c, c->dd_dx_chars.p, c->dd_dx_len.p, std::min<uint64_t>(nf, 1u << 18), nullptr);      // (the merge's tables: buffers only, nothing is launched)
+    c->last_hip = 0;
 }
 
 // 2^26 survivors = 100 M+ read shards at the ~2 % filter pass rate; the slot pool stays below 2^31 words
