@@ -1594,6 +1594,18 @@ static int first_call_bounds_impl(crass_hip_ctx *c)
         if (s) return s;
         c->dx_cap_hint = (uint32_t)dx;
         c->dm_prev_local = true;
+        // the host view of that merge (token arena, per-candidate tokens, pattern list, flat groups) is built by the helper thread
+        // while pass 2 runs; on a context's first call its containers grew and faulted their pages in there — 2.2 ms instead of
+        // 1.1 at 100 M reads, 0.5 ms of it past the end of pass 2.  They are grown and touched here, with the reads
+        // (MergeResult::clear keeps the capacity).
+        try {
+            auto touch = [](auto &v, size_t k) { v.resize(k); v.clear(); };
+            MergeResult &m = c->merge;
+            touch(m.cand_token, (size_t)(n / 128 + 4096));
+            touch(m.tokens.strings.chars, (size_t)dx * 48); touch(m.tokens.strings.off, (size_t)dx + 2); m.tokens.strings.clear();
+            touch(m.patterns.chars, (size_t)dx * 24); touch(m.patterns.off, (size_t)dx + 2); m.patterns.clear();
+            touch(m.pat_group, (size_t)dx); touch(m.pat_token, (size_t)dx); touch(m.grp_tokens, (size_t)dx); touch(m.grp_off, (size_t)dx / 4 + 16);
+        } catch (const std::bad_alloc &) { }
     }
     // reads flagged by the anchor probe: reads of arrays that pass 1 did not find (+ ~0 false positives)
     uint64_t hits = hit_bound(n / 64);
