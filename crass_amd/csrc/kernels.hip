@@ -1321,21 +1321,31 @@ static __device__ __forceinline__ void word_to_ascii(uint32_t v, uint32_t o[4])
 // a 10 kbp read is ten dependent rounds of loads per lane otherwise — 5.0 of the kernel's 12.3 ms at 1 M x 10 kbp)
 #define SV_PREFETCH_WORDS 12                      // per lane: reads up to 12 * 64 * 16 = 12 288 bases are covered completely
 #define SV_PREFETCH_HINTS (SV_PREFETCH_WORDS / 4)  // 64-bit hint words per lane for the same reads (one bit per position)
+// (the words travel 16 bytes per lane and load: a read is word-aligned, not 16-byte aligned, and the hardware takes a
+// dword-aligned global_load_dwordx4 — a quarter of the load and LDS-store instructions of the one-word form)
+typedef uint32_t sv_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+#define SV_PREFETCH_VEC (SV_PREFETCH_WORDS / 4)
 struct ReadPrefetch {
-    uint32_t w[SV_PREFETCH_WORDS];
+    uint4 v[SV_PREFETCH_VEC];                     // lane's 16-byte groups lane, lane + 64, ...: words 4 g .. 4 g + 3
     uint64_t hw[SV_PREFETCH_HINTS];
     uint64_t r;                                   // the read these words belong to (~0: none)
 };
+// group gi (words 4 gi .. 4 gi + 3) of a read of nw words at g; words past the read are 0 and never touched in memory
+static __device__ __forceinline__ uint4 sv_load_group(const uint32_t *g, int gi, int nw)
+{
+    uint4 v; v.x = v.y = v.z = v.w = 0u;
+    const int b = 4 * gi;
+    if (b + 3 < nw) { const sv_u32x4 t = *reinterpret_cast<const sv_u32x4 *>(g + b); v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w; }
+    else if (b < nw) { v.x = g[b]; if (b + 1 < nw) v.y = g[b + 1]; if (b + 2 < nw) v.z = g[b + 2]; }
+    return v;
+}
 static __device__ __forceinline__ void prefetch_read(const DevReads &R, uint64_t r, int lane, ReadPrefetch &pf)
 {
     const uint32_t *g = R.packed + rd_word_off(R, r);
     const int L = (int)rd_len(R, r);
     const int nw = (L + 15) >> 4;
 #pragma unroll
-    for (int i = 0; i < SV_PREFETCH_WORDS; i++) {
-        const int wi = lane + i * WAVE;
-        pf.w[i] = wi < nw ? g[wi] : 0u;
-    }
+    for (int i = 0; i < SV_PREFETCH_VEC; i++) pf.v[i] = sv_load_group(g, lane + i * WAVE, nw);
     if (R.pos_hint) {
         const uint64_t *ph = R.pos_hint + R.pos_hint_off[r];
         const int nh = (L + 63) >> 6;
@@ -1371,21 +1381,19 @@ static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *
 {
     const uint32_t *g = R.packed + rd_word_off(R, r);
     const int nw = (L + 15) >> 4;
-    if (lane == 0) words[nw] = 0;                 // lds_code reads one word past the last
+    const int ng = (nw + 4) >> 2;                 // groups up to and including the one that holds word nw (= 0: lds_code reads one word past the last)
     const bool have = pf && pf->r == r;           // wave-uniform
+    uint4 *w4 = reinterpret_cast<uint4 *>(words);   // (the words' LDS region is 16-byte aligned and a multiple of four words long)
     int first = lane;
     if (have) {
 #pragma unroll
-        for (int i = 0; i < SV_PREFETCH_WORDS; i++) {
-            const int wi = lane + i * WAVE;
-            if (wi < nw) {
-                const uint32_t v = pf->w[i];
-                words[wi] = v;
-            }
+        for (int i = 0; i < SV_PREFETCH_VEC; i++) {
+            const int gi = lane + i * WAVE;
+            if (gi < ng) w4[gi] = pf->v[i];
         }
-        first = lane + SV_PREFETCH_WORDS * WAVE;
+        first = lane + SV_PREFETCH_VEC * WAVE;
     }
-    for (int wi = first; wi < nw; wi += WAVE) words[wi] = g[wi];
+    for (int gi = first; gi < ng; gi += WAVE) w4[gi] = sv_load_group(g, gi, nw);
     (void)seq;                                          // (the ASCII copy: region by region, when a byte-wise consumer is entered — rh_ascii)
 }
 
