@@ -327,8 +327,14 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     uint32_t tile;
     if (R.uniform_len) {
         const uint32_t per_read = (R.uniform_len + 63u) >> 6;
-        r = t / per_read;
-        tile = (uint32_t)(t - r * per_read);
+        if ((n_words >> 32) == 0) {                                     // (a 32-bit division: a fifth of the 64-bit one's instructions)
+            const uint32_t t32 = (uint32_t)t, r32 = t32 / per_read;
+            r = r32;
+            tile = t32 - r32 * per_read;
+        } else {
+            r = t / per_read;
+            tile = (uint32_t)(t - r * per_read);
+        }
     } else if (blk_read) {
         // ragged lengths: the host noted the read of every block's first tile (blk_read[b] = read of tile 256 b); a long read
         // has dozens of tiles, so the tile's own read is a few steps further (short reads mixed in: more steps, same result)
@@ -343,10 +349,21 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     }
     const uint32_t L = rd_len(R, r);
     const uint32_t nw = (L + 15) >> 4;
-    const uint32_t *g = R.packed + rd_word_off(R, r);
+    const uint32_t *g = R.packed + rd_word_off(R, r) + tile * 4u;
+    const uint32_t rem = nw - tile * 4u;                                 // words from this tile's first to the read's end
     uint32_t w[13];
+    // 13 words: the tile's four and the halo.  A wave without a lane near its read's end (6 of 10 at 10 kbp) takes them as three
+    // 16-byte loads and a word from one address — no bound per word; the last read of the set never does (nothing is read
+    // past the reads' buffer)
+    typedef uint32_t hp_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+    if (__ballot(rem < 13u || r + 1 >= R.n_reads) == 0ull) {
+        const hp_u32x4 a = *reinterpret_cast<const hp_u32x4 *>(g), b = *reinterpret_cast<const hp_u32x4 *>(g + 4), c4 = *reinterpret_cast<const hp_u32x4 *>(g + 8);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        w[8] = c4.x; w[9] = c4.y; w[10] = c4.z; w[11] = c4.w; w[12] = g[12];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 13; i++) { const uint32_t wi = tile * 4 + i; w[i] = wi < nw ? g[wi] : 0u; }
+        for (int i = 0; i < 13; i++) w[i] = (uint32_t)i < rem ? g[i] : 0u;
+    }
     // the LATTICE class only (positions 8 i): searchCore walks one residue class at a time and leaves it only behind a rejected
     // candidate (libcrispr.cpp:390,295) — 0.76 times per 10 kbp read on BASELINE configs[3] (tools/class_switches.py), so seven
     // of the eight classes this kernel used to cover were never looked at.  The class a walk moves to is covered from there on by
