@@ -196,24 +196,66 @@ static __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
 // LCT: compile-time read length (0 = unknown).  With it, shifts that would put the window past the
 // read end (libcrispr.cpp:301-304: p <= L-9-w... i.e. d <= L-9-16k for the seeds of word k) are dropped
 // at compile time: 234 instead of 343 (word, shift) pairs at L = 150.
-template <int W, int D0, int D1, int LCT>
+// min(halfword, 1) for both halfwords: 0 where the halfword is 0, else 1.  Through the builtin the optimiser turns this into
+// two compares, two selects and a permute; the instruction itself is what is wanted.
+static __device__ __forceinline__ uint32_t pk_nonzero_u16(uint32_t a)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(0x00010001u));
+    return r;
+}
+typedef uint32_t ff_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t ff_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+// One read's row (W words, zero when r is past the end) and its exception flag.
+template <int W>
+static __device__ __forceinline__ void ff_load_row(const DevReads &R, const DevParams &P, uint64_t r, uint32_t (&w)[W], uint64_t &exc_word)
+{
+#pragma unroll
+    for (int i = 0; i < W; i++) w[i] = 0;
+    // the wave's 64 exception bits: one scalar load (the mask has a spare word, engine.cpp load_reads), off the vector memory
+    // counter so that waiting for it does not wait for the row
+    exc_word = 0;
+    const uint64_t wave_word = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r >> 38)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)(r >> 6));
+    if (!P.exc_survive && (wave_word << 6) < R.n_reads) {
+        const uint32_t *e = R.exc_mask + 2 * wave_word;
+        exc_word = (uint64_t)e[0] | ((uint64_t)e[1] << 32);
+    }
+    if (r < R.n_reads) {
+        const uint32_t *g = R.packed + r * (uint64_t)W;
+        // a row is dword-aligned only; global_load_dwordx4 takes that on gfx950, so W words are W/4 wide loads and a tail
+#pragma unroll
+        for (int i = 0; i + 4 <= W; i += 4) {
+            const ff_u32x4 v = *reinterpret_cast<const ff_u32x4 *>(g + i);
+            w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+        }
+        if ((W & 3) >= 2) {
+            const ff_u32x2 v = *reinterpret_cast<const ff_u32x2 *>(g + (W & ~3));
+            w[W & ~3] = v.x; w[(W & ~3) + 1] = v.y;
+        }
+        if (W & 1) w[W - 1] = g[W - 1];
+    }
+}
+
+// RPL: reads per lane.  A lane's reads are 256 apart (a wave still covers 64 consecutive reads, one mask word); the row of the
+// next read is loaded before the current one is scanned, so a wave's only exposed memory latency is its first load.
+template <int W, int D0, int D1, int LCT, int RPL>
 __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams P, uint64_t *hitmask, uint32_t *seed_hint)
 {
-    const uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const bool active = r < R.n_reads;
+    const uint64_t r_first = blockIdx.x * (uint64_t)(256 * RPL) + threadIdx.x;
     constexpr int WX = W + (D1 >> 4) + 2;
+    uint32_t nxt[W];
+    uint64_t nxt_exc;
+    ff_load_row<W>(R, P, r_first, nxt, nxt_exc);
+#pragma unroll
+    for (int it = 0; it < RPL; it++) {
+    const uint64_t r = r_first + (uint64_t)it * 256u;
+    const bool active = r < R.n_reads;
     uint32_t w[WX];
 #pragma unroll
-    for (int i = 0; i < WX; i++) w[i] = 0;
-    uint32_t L = 0;
-    bool exc = false;
-    if (active) {
-        const uint32_t *g = R.packed + r * (uint64_t)W;
-#pragma unroll
-        for (int i = 0; i < W; i++) w[i] = g[i];
-        L = rd_len(R, r);
-        exc = !P.exc_survive && rd_is_exc(R, r);       // see k_filter_general
-    }
+    for (int i = 0; i < WX; i++) w[i] = i < W ? nxt[i] : 0u;
+    const bool exc = (nxt_exc >> (r & 63)) & 1u;        // (exception reads are left to their own pass, see k_filter_general)
+    if (it + 1 < RPL) ff_load_row<W>(R, P, r + 256u, nxt, nxt_exc);
+    const uint32_t L = active ? rd_len(R, r) : 0u;
     // seeds live in halfwords 0 .. searchEnd/8 with searchEnd = L-58 <= 16W-58: only words < SW hold one
     constexpr int SW = ((16 * W - 58) / 8 + 2) / 2;
     uint32_t acc[SW];
@@ -234,22 +276,28 @@ __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams 
         }
     }
     bool hit = false;
-    int searchEnd = (int)(L - P.lowDR - P.lowSp - 8 - 1);
+    // a uniform-length instantiation knows the seed count at compile time (D0 = lowDR + lowSp, checked by the launcher)
+    const int searchEnd = LCT > 0 ? (LCT - D0 - 8 - 1) : (int)(L - P.lowDR - P.lowSp - 8 - 1);
     if (active && !exc && searchEnd >= 0) {
-        int n_seed = searchEnd / 8 + 1;                 // halfwords 0 .. n_seed-1 hold lattice seeds
-        uint32_t hint = 0;                              // bit h: lattice seed j = 8h may have a hit (superset)
+        const int n_seed = searchEnd / 8 + 1;           // halfwords 0 .. n_seed-1 hold lattice seeds
+        // bit h of the hint: lattice seed j = 8h may have a hit (superset).  min(halfword, 1) is 0 exactly for a hit; the words
+        // are folded two bits apart (low halfwords -> bits 2k, high -> bits 2k + 16) and the halves interleaved at the end
+        uint32_t t0 = 0, t1 = 0;                        // words 0..7 and 8..15 (a fold holds 16 seeds)
 #pragma unroll
         for (int k = 0; k < SW; k++) {
-            bool z0 = (acc[k] & 0xFFFFu) == 0 && (2 * k) < n_seed;
-            bool z1 = (acc[k] >> 16) == 0 && (2 * k + 1) < n_seed;
-            hint |= (z0 ? 1u : 0u) << (2 * k);
-            hint |= (z1 ? 1u : 0u) << (2 * k + 1);
+            if (LCT > 0 && 2 * k >= n_seed) continue;
+            const uint32_t f = pk_nonzero_u16(acc[k]);
+            if (k < 8) t0 |= f << (2 * k); else t1 |= f << (2 * (k - 8));
         }
+        uint32_t miss = (t0 | (t0 >> 15)) & 0xFFFFu;
+        if (SW > 8) miss |= (t1 | (t1 >> 15)) << 16;
+        const uint32_t hint = ~miss & (n_seed >= 32 ? 0xFFFFFFFFu : ((1u << n_seed) - 1u));
         hit = hint != 0;
         if (hit) seed_hint[r] = hint;                   // sparse: ~2 % of the lanes
     }
     uint64_t m = __ballot(hit);
     if ((threadIdx.x & 63) == 0 && active) hitmask[r >> 6] = m;
+    }
 }
 
 hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st)
@@ -260,13 +308,19 @@ hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *h
     if (!R.stride_words || R.n_reads == 0) return hipErrorNotSupported;
     uint64_t blocks = (R.n_reads + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorNotSupported;
-    dim3 g((unsigned)blocks), b(256);
-    // common uniform read lengths get the compile-time clamp
-#define FF_LEN(LL, WW) if (R.uniform_len == LL && R.stride_words == WW) { CRASS_LAUNCH((k_filter_fast_impl<WW, 49, 97, LL>), g, b, 0, st, R, P, hitmask, seed_hint); return hipGetLastError(); }
+    // common uniform read lengths get the compile-time clamp and, for big sets, RPL rows per lane with the next row in flight
+    // (CRASS_FF_RPL = 1 | 4 forces one form for every size: the A/B and the parity sweep of the other form)
+    static const int rpl_env = getenv("CRASS_FF_RPL") ? atoi(getenv("CRASS_FF_RPL")) : 0;
+    const int rpl = rpl_env ? rpl_env : (R.n_reads >= (1u << 22) ? 4 : 1);
+    dim3 g((unsigned)blocks), b(256), g4((unsigned)((blocks + 3) / 4));
+#define FF_LEN(LL, WW) if (R.uniform_len == LL && R.stride_words == WW) { \
+        if (rpl >= 4) CRASS_LAUNCH((k_filter_fast_impl<WW, 49, 97, LL, 4>), g4, b, 0, st, R, P, hitmask, seed_hint); \
+        else CRASS_LAUNCH((k_filter_fast_impl<WW, 49, 97, LL, 1>), g, b, 0, st, R, P, hitmask, seed_hint); \
+        return hipGetLastError(); }
     FF_LEN(100, 7) FF_LEN(101, 7) FF_LEN(125, 8) FF_LEN(126, 8) FF_LEN(150, 10) FF_LEN(151, 10) FF_LEN(250, 16) FF_LEN(251, 16)
 #undef FF_LEN
     switch (R.stride_words) {
-#define FF_CASE(WW) case WW: CRASS_LAUNCH((k_filter_fast_impl<WW, 49, 97, 0>), g, b, 0, st, R, P, hitmask, seed_hint); break;
+#define FF_CASE(WW) case WW: CRASS_LAUNCH((k_filter_fast_impl<WW, 49, 97, 0, 1>), g, b, 0, st, R, P, hitmask, seed_hint); break;
         FF_CASE(4) FF_CASE(5) FF_CASE(6) FF_CASE(7) FF_CASE(8) FF_CASE(9) FF_CASE(10)
         FF_CASE(11) FF_CASE(12) FF_CASE(13) FF_CASE(14) FF_CASE(15) FF_CASE(16)
 #undef FF_CASE
@@ -298,13 +352,12 @@ static __device__ __forceinline__ uint64_t hint_bits_class(const uint32_t (&w)[1
             acc[k] = pk_min_u16(acc[k], x);
         }
     }
-    uint64_t bits = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if ((acc[k] & 0xFFFFu) == 0u) bits |= 1ull << (16 * k + rho);
-        if ((acc[k] >> 16) == 0u) bits |= 1ull << (16 * k + 8 + rho);
-    }
-    return bits;
+    // halfword j of word k -> bit 16 k + 8 j + rho: min(halfword, 1) leaves the miss flags in bytes 0 and 2 of each word, one
+    // byte permute gathers those of two words into bytes 0..3
+    const uint32_t m0 = pk_nonzero_u16(acc[0]), m1 = pk_nonzero_u16(acc[1]), m2 = pk_nonzero_u16(acc[2]), m3 = pk_nonzero_u16(acc[3]);
+    const uint32_t lo = __builtin_amdgcn_perm(m1, m0, 0x06040200u) ^ 0x01010101u;
+    const uint32_t hi = __builtin_amdgcn_perm(m3, m2, 0x06040200u) ^ 0x01010101u;
+    return ((uint64_t)(hi << rho) << 32) | (uint64_t)(lo << rho);
 }
 
 // ------------------------------------------------------------------------------------

@@ -443,17 +443,19 @@ def test_slot_compactions_fit_their_scratch(env):
 
 
 @pytest.mark.parametrize("switch", ["CRASS_DV_SINGLE", "CRASS_P2_BLOB12", "CRASS_DD_FULL_TABLE", "CRASS_SURV_NO_REGROUP",
-                                    "CRASS_DX_PINNED", "CRASS_NO_LOOKBACK"])
+                                    "CRASS_DX_PINNED", "CRASS_NO_LOOKBACK", "CRASS_FF_RPL=4"])
 def test_ab_switches_keep_the_results(switch):
     """The A/B switches select the round-3 form of something (one candidate per lane in pass 2's verification, the 12-byte
     hand-off record, the full-size de-duplication table, survivors in slot order, the distinct list written to pinned memory, the
-    three-kernel compactions).  Most are read once per process, so each gets a fresh one: a short randomised sweep
+    three-kernel compactions) or, for CRASS_FF_RPL=4, the big-set form of the seed scan — four rows per lane — on small ragged
+    sets.  Most are read once per process, so each gets a fresh one: a short randomised sweep
     (tools/parity_sweep.py: HIP path == oracle, field by field) with the switch set."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env[switch] = "1"
+    name, _, value = switch.partition("=")
+    env[name] = value or "1"
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "parity_sweep.py"), "24", "77"], env=env, capture_output=True, text=True, timeout=600)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]
     assert r.returncode == 0 and "24 cases, 0 failures" in tail, tail
