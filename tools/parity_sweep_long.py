@@ -63,15 +63,22 @@ for case in range(n_cases):
         env["CRASS_SEQ_WINDOW"] = rng.choice(["512", "1024", "2048"])
     elif r < 0.4:
         env["CRASS_LONG_FULL_LAYOUT"] = "1"
-    tag = "n=%d L=%d..%d%s n_dr=%d every=%d mut=%.2f N=%d %s" % (n, lo, lo if uniform else hi, "u" if uniform else "", n_dr, every, mut, with_n,
-                                                                " ".join("%s=%s" % (k[6:], v) for k, v in sorted(env.items())))
+    # a quarter of the cases through a group of 2-3 contexts sharing the GPU (contiguous shards, the exchange as device copies)
+    grp = rng.choice([0, 0, 0, 2, 3]) if os.environ.get("LONG_SWEEP_GROUPS", "1") != "0" else 0
+    fused = bool(grp) and rng.random() < 0.5
+    tag = "n=%d L=%d..%d%s n_dr=%d every=%d mut=%.2f N=%d grp=%d%s %s" % (n, lo, lo if uniform else hi, "u" if uniform else "", n_dr, every, mut, with_n,
+                                                                grp, "f" if fused else "", " ".join("%s=%s" % (k[6:], v) for k, v in sorted(env.items())))
     only = os.environ.get("ONLY")
     if only and case not in {int(x) for x in only.split(",")}:
         continue
     print("run  case %d %s" % (case, tag), file=sys.stderr, flush=True)
     os.environ.update(env)
     try:
-        gpu = ca.search_pipeline(seqs)
+        if grp:
+            gpu = ca.search_pipeline_group(seqs, [0] * grp, local_copies=True, fused=fused)
+            gpu.counters = gpu.counters[0]
+        else:
+            gpu = ca.search_pipeline(seqs)
     finally:
         for k in env:
             os.environ.pop(k, None)
