@@ -7,7 +7,7 @@ import numpy as np
 import crass_amd as ca
 ca.load()
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-n, L = 10_000_000, 150
+n, L = int(os.environ.get("READS", "10000000")), 150
 eng = ca.SearchEngine(device=0)
 eng.load_packed_uniform(ca.synth_packed(ca.synth_spec(read_len=L), 0, n), n, L)
 for _ in range(10):
