@@ -65,6 +65,38 @@ def test_the_guard_finds_the_pattern_where_it_exists(tmp_path):
         vgpr_guard.check(exe)
 
 
+def test_the_guard_fails_closed_on_a_failed_or_partial_disassembly(ca, monkeypatch):
+    """a disassembly that fails (tool exit code) or that lacks a kernel's label must refuse the build — it used to
+    file every kernel under 'ends on a granule, no edge shift', which is only a warning"""
+    from crass_amd import vgpr_guard
+    monkeypatch.setattr(vgpr_guard, "_shift_amounts", lambda co: {})          # the object "has no disassembly"
+    with pytest.raises(RuntimeError, match="no disassembly label"):
+        vgpr_guard.analyse(ca.LIB_PATH)
+    monkeypatch.undo()
+    import subprocess
+    real = subprocess.run
+
+    def failing(cmd, *a, **k):
+        r = real(cmd, *a, **k)
+        if os.path.basename(cmd[0]) == "llvm-objdump":
+            r.returncode = 1
+        return r
+    monkeypatch.setattr(vgpr_guard.subprocess, "run", failing)
+    with pytest.raises(RuntimeError, match="llvm-objdump -d failed"):
+        vgpr_guard.analyse(ca.LIB_PATH)
+
+
+def test_the_guard_reads_the_amount_of_lshl_add_u64():
+    """v_lshl_add_u64 dst, src0, AMOUNT, src2: the fourth 64-bit shift that can shift by a VGPR on gfx950"""
+    from crass_amd import vgpr_guard
+    m = vgpr_guard.LSHL_ADD64.match("\tv_lshl_add_u64 v[2:3], v[4:5], v23, s[0:1]   // 0000: D2080002")
+    assert m and m.group(2) == "v23"
+    m = vgpr_guard.LSHL_ADD64.match("\tv_lshl_add_u64 v[2:3], v[4:5], 3, v[6:7]")
+    assert m and m.group(2) == "3"
+    m = vgpr_guard.LSHL_ADD64.match("\tv_lshl_add_u64 v[2:3], s[4:5], 0, v[6:7]")
+    assert m and m.group(2) == "0"
+
+
 def test_no_gpu_means_loud_failure_not_fallback(ca):
     import torch
     if torch.cuda.is_available():
