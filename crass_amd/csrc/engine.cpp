@@ -667,9 +667,16 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     if (c->env.stage_timing >= 0) c->timing_level = c->env.stage_timing;
     if (c->env.no_lookback) c->lb_on = false;                    // A/B switch: three-kernel compaction
     c->dr_stride = (p->highDRsize + 15u) & ~15u;
-    if (hipSetDevice(device) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
-    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CRASS_ERR_NO_DEVICE; }
+    { const hipError_t he = hipSetDevice(device);
+      if (he != hipSuccess) { fprintf(stderr, "[crass_hip] hipSetDevice(%d): %s\n", device, hipGetErrorString(he)); delete c; return CRASS_ERR_NO_DEVICE; } }
+    if (getenv("CRASS_SURV_PROF")) {                    // diagnostics: phase cycles of the wave-per-read kernel (tools/longread_phases.py)
+        void *pp = nullptr;
+        if (hipMalloc(&pp, 192 * 8) == hipSuccess && hipMemset(pp, 0, 192 * 8) == hipSuccess) c->dp.prof = (unsigned long long *)pp;
+    }
+    for (hipStream_t *sp : {&c->stream, &c->copy_stream}) {
+        const hipError_t he = hipStreamCreateWithFlags(sp, hipStreamNonBlocking);
+        if (he != hipSuccess) { fprintf(stderr, "[crass_hip] hipStreamCreateWithFlags on device %d: %s\n", device, hipGetErrorString(he)); delete c; return CRASS_ERR_NO_DEVICE; }
+    }
     // (hint_stream and its events: created with the first long-read set, setup_pos_hints)
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
@@ -1002,6 +1009,26 @@ static int ensure_mask_scratch(crass_hip_ctx *c, uint64_t n_bits);
 static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok, bool prepared);
 static bool getenv_once_hl_host() { static const bool v = getenv("CRASS_HL_HOST_DEDUPE") != nullptr; return v; }      // A/B switch: the round-3 host de-duplication + merge for long reads
 
+// CRASS_SURV_PROF: one line per category of reads (0 skipped without a hinted seed, 1 walked / nothing found, 2 found, 3 handed
+// over) with the summed cycles of the kernel's phases, then a histogram of cycles per read; the counters are cleared
+static void dump_surv_prof(crass_hip_ctx *c)
+{
+    if (!c->dp.prof) return;
+    unsigned long long v[192];
+    if (hipMemcpy(v, c->dp.prof, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return;
+    (void)hipMemset(c->dp.prof, 0, sizeof v);
+    static const char *nm[] = {"total", "stage", "find", "scan", "extend", "qc", "hints", "out", "n_cand", "n_scanfind", "n_switch", "n_qc", "loop", "n_iter", "max", "reads"};
+    for (int cat = 0; cat < 4; cat++) {
+        const unsigned long long n = v[cat * 16 + 15];
+        if (!n) continue;
+        fprintf(stderr, "[surv_prof] cat %d", cat);
+        for (int k = 0; k < 16; k++) fprintf(stderr, " %s %llu", nm[k], v[cat * 16 + k]);
+        fprintf(stderr, "\n[surv_prof] cat %d hist(log2 cycles):", cat);
+        for (int b = 0; b < 24; b++) if (v[64 + cat * 24 + b]) fprintf(stderr, " %d:%llu", b + 8, v[64 + cat * 24 + b]);
+        fprintf(stderr, "\n");
+    }
+}
+
 static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip_ctx::P1List &L,
                          const uint64_t *surv_idx_host)
 {
@@ -1031,6 +1058,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     HIPCHK(c, c->d_ss_pool.ensure(pool_cap));
     HIPCHK(c, c->h_surv.ensure(chunk_cap));
     HIPCHK(c, c->h_dr.ensure(chunk_cap * c->dr_stride));
+    // the survivor list on the device is 0, 1, 2, ... (no filter, no exception read, one chunk): the kernel is told so and needs no
+    // look-up per read
+    const bool ident_list = !exc && !surv_idx_host && c->R.n_exc == 0 && n_total <= chunk_cap;
     const int grid = 256 * 64;      // waves striding over the reads: 6 resident per CU at 10 kbp; 1 536 / 8 192 / 16 384 / 65 536 blocks: 11.5 / 8.6 / 8.2 / 9.1 ms
     const uint32_t stride = c->dr_stride;
     L.reserve(L.size() + n_total / 2 + 16, stride);
@@ -1053,7 +1083,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                             : (surv_idx_host ? (uint64_t)(std::lower_bound(surv_idx_host, surv_idx_host + nchunk, r1) - surv_idx_host) : std::min<uint64_t>(r1, nchunk));
                 if (q > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_hint[q], 0));
                 if (s1 > s0)
-                    HIPCHK(c, launch_survivor(R, c->dp, false, c->d_idx.p + s0, c->d_count.p + 1, s1 - s0,
+                    HIPCHK(c, launch_survivor(R, c->dp, false, ident_list ? nullptr : c->d_idx.p + s0, c->d_count.p + 1, s1 - s0,
                                               c->d_surv.p + s0, c->d_dr.p + s0 * (size_t)stride, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                               c->d_found.p, c->hints_valid ? c->d_hit_info.p : nullptr, lds,
                                               (int)std::min<uint64_t>(grid, s1 - s0), c->stream, 0, s0, nchunk));
@@ -1062,13 +1092,13 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             c->hint_pending = false;
         } else {
             { const int hw = hint_wait_all(c); if (hw) return hw; }
-            HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
+            HIPCHK(c, launch_survivor(R, c->dp, exc, (exc || ident_list) ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
                                       c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                       c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds,
                                       (int)std::min<uint64_t>(grid, nchunk), c->stream));
         }
         if (capped)
-            HIPCHK(c, launch_survivor(R, c->dp, exc, exc ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
+            HIPCHK(c, launch_survivor(R, c->dp, exc, (exc || ident_list) ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
                                       c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                       c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds_full,
                                       (int)std::min<uint64_t>(grid, nchunk), c->stream, 6));
@@ -1100,6 +1130,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         const double tq0 = now_ms();
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const double tq1 = now_ms();
+        dump_surv_prof(c);
         if (c->h_count.p[3] == 2) return CRASS_ERR_SEARCH_FATAL;
         if (c->h_count.p[3]) return CRASS_ERR_OVERFLOW;
         const uint64_t nf = c->h_count.p[2];

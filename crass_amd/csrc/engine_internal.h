@@ -36,6 +36,7 @@ struct DevParams {
     uint32_t debug_stop;          // diagnostics only (env CRASS_SURV_DEBUG): 0 = normal; 1..3 cut the survivor kernel short
     uint32_t exc_survive;         // 1: the filter passes every exception read on (they join the survivor list and are
                                   // evaluated byte-wise in place, so the dense pass-1 path also holds with N reads)
+    unsigned long long *prof;     // diagnostics only (env CRASS_SURV_PROF): 192 counters of the wave kernel's phases, else nullptr
 };
 
 // per-survivor output slot of the pass-1 survivor kernel

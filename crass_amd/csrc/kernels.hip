@@ -30,6 +30,14 @@ static __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A value that is the same in every lane but was read from LDS (or computed from such a read) lives in a VGPR as far as the
+// compiler knows, and everything derived from it — loop counters, branch conditions — becomes vector arithmetic under exec
+// masks.  The wave-per-read kernel's control flow is wave-uniform throughout: naming the value once puts it, and what follows
+// from it, on the scalar unit.
+static __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+static __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+static __device__ __forceinline__ uint64_t uni64(uint64_t x) { return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | (uint64_t)uni((uint32_t)x); }
+
 static __device__ __forceinline__ uint64_t rd_word_off(const DevReads &R, uint64_t r)
 {
     return R.stride_words ? r * (uint64_t)R.stride_words : R.word_off[r];
@@ -41,6 +49,12 @@ static __device__ __forceinline__ uint32_t rd_len(const DevReads &R, uint64_t r)
 static __device__ __forceinline__ bool rd_is_exc(const DevReads &R, uint64_t r)
 {
     return (R.exc_mask[r >> 5] >> (r & 31)) & 1u;
+}
+// first word of read r's position hints: reads of one length need no table look-up (a dependent global load per read in the
+// wave kernel's prefetch otherwise)
+static __device__ __forceinline__ uint64_t rd_hint_off(const DevReads &R, uint64_t r)
+{
+    return R.uniform_len ? r * (uint64_t)((R.uniform_len + 63u) >> 6) : R.pos_hint_off[r];
 }
 static __device__ __forceinline__ uint64_t rd_header_id(const DevReads &R, uint64_t r)
 {
@@ -421,7 +435,12 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     // candidate (libcrispr.cpp:390,295) — 0.76 times per 10 kbp read on BASELINE configs[3] (tools/class_switches.py), so seven
     // of the eight classes this kernel used to cover were never looked at.  The class a walk moves to is covered from there on by
     // the wave that walks (search_core, wave_hints_class)
-    const uint64_t bits = hint_bits_class(w, 0u);
+    uint64_t bits = hint_bits_class(w, 0u);
+    // seeds live at j <= searchEnd = L - 58 (searchCore's loop bound with the default bounds this kernel is launched for): the
+    // bits behind it — the zero padding matches itself — are cleared, so that a read without a real lattice hint has an all-zero
+    // bitmap and the walking wave can drop it without staging it (k_survivor, no_seed)
+    const int last = (int)L - 58 - (int)(tile * 64u);
+    bits = last < 0 ? 0ull : (last >= 63 ? bits : (bits & ((2ull << last) - 1ull)));
     hint_bits[t] = bits;
 }
 
@@ -705,7 +724,16 @@ struct RH {                 // ReadHolder state (ReadHolder.h:440-451), wave-uni
     int asc_pad;            // how far beyond the repeats found so far the byte-wise consumers may read
     uint8_t *seq_buf;       // the LDS bytes behind seq; with a window (seq_win != 0) seq = seq_buf - asc_lo, so that seq[pos] still works
     int seq_win;            // bytes of the ASCII window (0: the whole read fits)
+    unsigned long long *lprof;  // diagnostics (CRASS_SURV_PROF): this read's phase cycles / counts in LDS, nullptr normally
 };
+// phases of one read in the wave kernel (CRASS_SURV_PROF=1, tools/longread_phases.py): cycles unless named n_*
+enum { PF_TOTAL = 0, PF_STAGE, PF_FIND, PF_SCAN, PF_EXTEND, PF_QC, PF_HINTS, PF_OUT, PF_N_CAND, PF_N_SCANFIND, PF_N_SWITCH, PF_N_QC, PF_LOOP, PF_N_ITER, PF_MAX, PF_READS, PF_SLOTS };
+// LDS behind the layout: PF_SLOTS per-read slots, then 4 categories x PF_SLOTS sums of this wave, then 4 x PF_BINS histogram bins
+#define PF_BINS 24
+#define PF_LDS_WORDS (PF_SLOTS + 4 * PF_SLOTS + 4 * PF_BINS)
+#define PROF_T0(h) const unsigned long long _pt0 = (h).lprof ? (unsigned long long)__builtin_readcyclecounter() : 0ull
+#define PROF_ADD(h, ph) do { if ((h).lprof) { const unsigned long long _d = (unsigned long long)__builtin_readcyclecounter() - _pt0; if (lane == 0) (h).lprof[ph] += _d; } } while (0)
+#define PROF_CNT(h, ph) do { if ((h).lprof && lane == 0) (h).lprof[ph] += 1ull; } while (0)
 
 // leftmost occurrence of seq[pat, pat+plen) in seq[begin, end): PatternMatcher::bmpSearch
 // semantics (PatternMatcher.cpp:26-59: -1 for empty text/pattern or pattern longer than text)
@@ -733,7 +761,7 @@ static __device__ int wave_find_packed(const uint32_t *words, uint32_t cmask, in
 {
     int tlen = end - begin;
     if (tlen <= 0 || plen <= 0 || plen > tlen) return -1;
-    const uint32_t sj = lds_code(words, (uint32_t)pat, cmask);
+    const uint32_t sj = uni(lds_code(words, (uint32_t)pat, cmask));
     for (int p0 = begin; p0 + plen <= end; p0 += WAVE) {
         int p = p0 + lane;
         bool ok = (p + plen <= end) && (lds_code(words, (uint32_t)p, cmask) == sj);
@@ -759,7 +787,7 @@ static __device__ __forceinline__ void word_to_ascii(uint32_t v, uint32_t o[4]);
 static __device__ void rh_ascii(RH &h, int lane)
 {
     if (!h.words || h.nss < 2) return;                  // exception reads: the bytes are the read
-    int lo = (int)h.ss[0] - h.asc_pad, hi = (int)h.ss[h.nss - 1] + h.asc_pad;
+    int lo = (int)uni(h.ss[0]) - h.asc_pad, hi = (int)uni(h.ss[h.nss - 1]) + h.asc_pad;
     if (lo < 0) lo = 0;
     if (hi > h.L) hi = h.L;
     if (lo >= h.asc_lo && hi <= h.asc_hi) return;       // (wave-uniform)
@@ -791,12 +819,14 @@ static __device__ void rh_add(RH &h, uint32_t i, uint32_t j, int lane)
     wave_sync();
 }
 
+static __device__ void scan_right_masks(RH &h, int pat, uint32_t pattern_length, uint32_t minSpacerLength, uint32_t scanRange,
+                                        uint32_t last_repeat_index, uint32_t second_last_repeat_index, int lane);
 // scanRight, libcrispr.cpp:170-263
 static __device__ void scan_right(RH &h, int pat, uint32_t pattern_length, uint32_t minSpacerLength,
                                   uint32_t scanRange, int lane)
 {
-    uint32_t last_repeat_index = h.ss[h.nss - 2];
-    uint32_t second_last_repeat_index = h.ss[h.nss - 4];
+    uint32_t last_repeat_index = uni(h.ss[h.nss - 2]);
+    uint32_t second_last_repeat_index = uni(h.ss[h.nss - 4]);
     uint32_t repeat_spacing = last_repeat_index - second_last_repeat_index;
     const uint32_t read_length = (uint32_t)h.L;
     bool more_to_search = true;
@@ -810,6 +840,7 @@ static __device__ void scan_right(RH &h, int pat, uint32_t pattern_length, uint3
         if (end_search > read_length) end_search = read_length;
         if (begin_search >= end_search) return;
         int position = rh_find(h, (int)begin_search, (int)end_search, pat, (int)pattern_length, lane);
+        PROF_CNT(h, PF_N_SCANFIND);
         if (position >= 0) {
             uint32_t found = (uint32_t)position;        // wave_find returns absolute positions
             rh_add(h, found, found + pattern_length - 1, lane);
@@ -818,6 +849,11 @@ static __device__ void scan_right(RH &h, int pat, uint32_t pattern_length, uint3
             last_repeat_index = found;
             repeat_spacing = last_repeat_index - second_last_repeat_index;
             if (repeat_spacing < (minSpacerLength + pattern_length)) more_to_search = false;
+            else if (h.words && pattern_length <= 9u) {
+                // a third repeat: this is an array, not a chance match — the rest of the chain on match masks
+                scan_right_masks(h, pat, pattern_length, minSpacerLength, scanRange, last_repeat_index, second_last_repeat_index, lane);
+                return;
+            }
         } else {
             more_to_search = false;
         }
@@ -825,8 +861,11 @@ static __device__ void scan_right(RH &h, int pat, uint32_t pattern_length, uint3
 }
 
 // extendPreRepeat, libcrispr.cpp:520-772.  The per-column A/C/G/T votes run over repeats in lanes.
+static __device__ bool extend_pre_repeat_packed(RH &h, int searchWindowLength, int minSpacerLength, int lane);
 static __device__ uint32_t extend_pre_repeat(RH &h, int searchWindowLength, int minSpacerLength, int lane)
 {
+    // packed reads with at most 64 repeats: on the 2-bit words, no ASCII window (defined with the other packed forms below)
+    if (h.words && extend_pre_repeat_packed(h, searchWindowLength, minSpacerLength, lane)) return (uint32_t)h.replen;
     rh_ascii(h, lane);
     if (h.err == 6) return 0;                           // (the region does not fit the ASCII window: search_core hands the read over)
     const uint32_t num_repeats = (uint32_t)h.nss / 2;
@@ -1090,6 +1129,21 @@ static __device__ __forceinline__ bool substr_len(int L, uint32_t pos, uint32_t 
     return true;
 }
 
+// getStringSimilarity (PatternMatcher.cpp:197-204) of read[s0, s0+n) and read[t0, t0+m), both <= 64 bases, on the packed words:
+// ten independent LDS reads, then the bit-parallel distance runs on registers (ln_lev_regs: the lane kernel's form)
+template <typename WORD> static __device__ __forceinline__ int ln_lev_regs(uint64_t s_lo, uint64_t s_hi, int n, uint64_t t_lo, uint64_t t_hi, int m, int stop_at);
+static __device__ __forceinline__ void wv_load128(const uint32_t *words, int start, uint64_t &lo, uint64_t &hi);
+static __device__ float packed_similarity(const uint32_t *words, uint32_t s0, int n, uint32_t t0, int m)
+{
+    const float max_length = (float)(n > m ? n : m);
+    if (n < 3 || m < 3) return 0.0f;
+    if (n > m) { const uint32_t x = s0; s0 = t0; t0 = x; const int y = n; n = m; m = y; }
+    uint64_t sl, sh, tl, th;
+    wv_load128(words, (int)s0, sl, sh); wv_load128(words, (int)t0, tl, th);
+    const float edit_distance = (float)ln_lev_regs<uint64_t>(sl, sh, n, tl, th, m, -1);
+    return (float)(1.0 - (double)(edit_distance / max_length));
+}
+
 // qcFoundRepeats, libcrispr.cpp:869-1029.  1 pass / 0 fail / -1 reference would throw.
 // Internal spacer i (getAllSpacerStrings, ReadHolder.cpp:199-239) = seq[ss[2i+1]+1, ss[2i+2]).
 static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacerLength, int lane, uint32_t dbg = 0)
@@ -1099,8 +1153,9 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
     const int num_repeats = h.nss / 2;
     if (num_repeats < 2) return -1;
     uint32_t rep_len;
-    if (!substr_len(h.L, h.ss[0], h.ss[1] - h.ss[0] + 1, rep_len)) return -1;
-    const uint8_t *repeat = h.seq + h.ss[0];
+    const uint32_t rep_start = uni(h.ss[0]);
+    if (!substr_len(h.L, rep_start, uni(h.ss[1]) - rep_start + 1, rep_len)) return -1;
+    const uint8_t *repeat = h.seq + rep_start;
     if (is_low_complexity(repeat, (int)rep_len, lane)) return 0;
 
     bool is_short = (2 > (num_repeats - 1));
@@ -1128,7 +1183,11 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
             bool fb = false;
             float sim = 0.0f;
             if (valid && dbg != 5) {
-                if (q & 1) sim = lane_similarity(h.seq + a_start, (int)a_len, h.seq + b_start, (int)b_len, fb);
+                // (packed reads, strings of at most 64 bases — always, with anything like the default bounds: on the 2-bit words)
+                const bool pk = h.words && rep_len <= 64u && a_len <= 64u && b_len <= 64u;
+                if (pk) sim = (q & 1) ? packed_similarity(h.words, a_start, (int)a_len, b_start, (int)b_len)
+                                      : packed_similarity(h.words, rep_start, (int)rep_len, a_start, (int)a_len);
+                else if (q & 1) sim = lane_similarity(h.seq + a_start, (int)a_len, h.seq + b_start, (int)b_len, fb);
                 else sim = lane_similarity(repeat, (int)rep_len, h.seq + a_start, (int)a_len, fb);
             }
             if (valid) h.sims[q] = sim;
@@ -1147,22 +1206,34 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
             }
         }
         wave_sync();
-        uint32_t cur_start = h.ss[1] + 1, cur_len;
-        if (!substr_len(h.L, cur_start, h.ss[2] - cur_start, cur_len)) return -1;
-        for (int i = 0; i < nsp; i++) {
-            if ((int)cur_len < min_spacer_length) min_spacer_length = (int)cur_len;
-            if ((int)cur_len > max_spacer_length) max_spacer_length = (int)cur_len;
-            if (i + 1 < nsp) {
-                uint32_t nxt_start = h.ss[2 * i + 3] + 1, nxt_len;
-                if (!substr_len(h.L, nxt_start, h.ss[2 * i + 4] - nxt_start, nxt_len)) return -1;
+        // The sums below are taken in the reference's order (float addition does not associate), but their terms are fetched
+        // by the lanes first — lane i: spacer i's length, the two similarities of comparison i, the two length differences — and
+        // then read lane by lane: a term is a v_readlane instead of four dependent LDS reads per spacer (20 k of the QC's 128 k
+        // cycles for an array of 36 repeats)
+        for (int c0 = 0; c0 < nsp; c0 += WAVE) {
+            const int i = c0 + lane;
+            const bool vi = i < nsp, vc = i + 1 < nsp;
+            uint32_t cur_len = 0, nxt_len = 0;
+            bool bad = false;
+            if (vi) { const uint32_t cs = h.ss[2 * i + 1] + 1; bad = !substr_len(h.L, cs, h.ss[2 * i + 2] - cs, cur_len); }
+            if (vc) { const uint32_t ns = h.ss[2 * i + 3] + 1; bad = bad || !substr_len(h.L, ns, h.ss[2 * i + 4] - ns, nxt_len); }
+            if (__ballot(bad)) return -1;
+            const float t_rs = vc ? h.sims[2 * i] : 0.0f, t_ss = vc ? h.sims[2 * i + 1] : 0.0f;
+            const float t_ssl = (float)cur_len - (float)nxt_len, t_rsl = (float)rep_len - (float)cur_len;
+            int mn = vi ? (int)cur_len : 10000000, mx = vi ? (int)cur_len : 0;
+            for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
+            if (mn < min_spacer_length) min_spacer_length = mn;
+            if (mx > max_spacer_length) max_spacer_length = mx;
+            const int i_end = min(c0 + WAVE, nsp - 1);                 // comparisons i = c0 .. i_end - 1 (i + 1 < nsp)
+            for (int ii = c0; ii < i_end; ii++) {
+                const int src = ii - c0;
                 num_compared++;
-                ave_repeat_to_spacer_difference += h.sims[2 * i];
+                ave_repeat_to_spacer_difference += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_rs), src));
                 float ss_diff = 0;
-                ss_diff += h.sims[2 * i + 1];
+                ss_diff += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_ss), src));
                 ave_spacer_to_spacer_difference += ss_diff;
-                ave_spacer_to_spacer_len_difference += ((float)cur_len - (float)nxt_len);
-                ave_repeat_to_spacer_len_difference += ((float)rep_len - (float)cur_len);
-                cur_start = nxt_start; cur_len = nxt_len;
+                ave_spacer_to_spacer_len_difference += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_ssl), src));
+                ave_repeat_to_spacer_len_difference += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_rsl), src));
             }
         }
         wave_sync();
@@ -1189,7 +1260,9 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
         if ((int)sp_len < minSpacerLength) return 0;
         if ((int)sp_len > maxSpacerLength) return 0;
         bool fb = false;
-        float similarity = (dbg == 5) ? 0.0f : lane_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, fb);     // same pair in every lane
+        const bool pk = h.words && rep_len <= 64u && sp_len <= 64u;
+        float similarity = (dbg == 5) ? 0.0f : (pk ? packed_similarity(h.words, rep_start, (int)rep_len, s, (int)sp_len)
+                                                   : lane_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, fb));     // same pair in every lane
         if (fb && (int)std::max(sp_len, rep_len) + 8 > h.row_cap) return -3;
         if (fb) similarity = wave_similarity(repeat, (int)rep_len, h.seq + s, (int)sp_len, h.rowA, h.rowB, lane);
         if ((double)similarity > 0.82) return 0;
@@ -1198,6 +1271,232 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
         if (dlen > 30) return 0;
     }
     return 1;
+}
+
+// ------------------------------------------------------------------------------------
+// Packed reads in the wave kernel: scanRight, extendPreRepeat and the QC's edit distances on the 2-bit words in LDS — no
+// ASCII window, no per-base LDS round trips.  One long read costs the wave (phase counters, CRASS_SURV_PROF, 1 M x 10 kbp):
+// an array read 234 k cycles, of which the QC 128 k (two dependent LDS byte reads per DP column and lane), the scanRight chain
+// 52 k (38 finds x {two LDS round trips + a ballot + two fenced list appends}), the extension 31 k (a lane per COLUMN walks the
+// 36 repeats, two dependent LDS reads each); a read without an array 27 k, 4.3 k of them a two-repeat extension.  The forms
+// below keep the reference's decisions and arithmetic (libcrispr.cpp:170-263, 520-772, 869-1029) and change what a lane holds.
+// ------------------------------------------------------------------------------------
+template <typename WORD> static __device__ __forceinline__ int ln_lev_regs(uint64_t s_lo, uint64_t s_hi, int n, uint64_t t_lo, uint64_t t_hi, int m, int stop_at);
+static __device__ __forceinline__ int ln_run_up(uint64_t x0, uint64_t x1, int n);
+static __device__ __forceinline__ int ln_run_down(uint64_t x0, uint64_t x1, int n);
+
+// bases [start, start + 64) of the read as two 64-bit words (base `start` in bits 0-1); start >= 0.  Words past the read are
+// whatever the LDS holds there: every consumer masks by its own length.
+static __device__ __forceinline__ void wv_load128(const uint32_t *words, int start, uint64_t &lo, uint64_t &hi)
+{
+    const int wi = start >> 4;
+    const uint32_t sh = (uint32_t)(start & 15) * 2u;
+    const uint32_t a0 = words[wi], a1 = words[wi + 1], a2 = words[wi + 2], a3 = words[wi + 3], a4 = words[wi + 4];
+    const uint32_t y0 = __builtin_amdgcn_alignbit(a1, a0, sh), y1 = __builtin_amdgcn_alignbit(a2, a1, sh);
+    const uint32_t y2 = __builtin_amdgcn_alignbit(a3, a2, sh), y3 = __builtin_amdgcn_alignbit(a4, a3, sh);
+    lo = (uint64_t)y0 | ((uint64_t)y1 << 32); hi = (uint64_t)y2 | ((uint64_t)y3 << 32);
+}
+// ... the 64 bases that END before `end` (bases [end - 64, end)), base end - 64 in bits 0-1; positions before the read's
+// first base read as 0 (the callers never count them)
+static __device__ __forceinline__ void wv_load128_before(const uint32_t *words, int end, uint64_t &lo, uint64_t &hi)
+{
+    const int start = end - 64;
+    if (start >= 0) { wv_load128(words, start, lo, hi); return; }
+    uint64_t l, h2;
+    wv_load128(words, 0, l, h2);
+    const int s = -2 * start;                           // bit positions to move up: 2 .. 128
+    if (s >= 128) { lo = 0; hi = 0; }
+    else if (s >= 64) { lo = 0; hi = s == 64 ? l : (l << (s - 64)); }
+    else { hi = (h2 << s) | (l >> (64 - s)); lo = l << s; }
+}
+static __device__ __forceinline__ uint32_t wv_base(uint64_t lo, uint64_t hi, int i)     // base i of a 128-bit piece, 0 <= i < 64
+{
+    return (uint32_t)((i < 32 ? lo >> (2 * i) : hi >> (2 * (i - 32))) & 3ull);
+}
+
+// extendPreRepeat (libcrispr.cpp:520-772) on the packed words.  Two repeats: the closed form of the lane kernel (ln_extend2:
+// cut_off = 2, a column passes iff both copies agree, so the extensions are runs of equal bases).  3 .. 64 repeats: a LANE PER
+// REPEAT holds the 64 bases right of its window (then left of it) in registers and a column's vote is four ballots — the
+// columns are taken in the reference's order and stop at the first that fails.  Returns false when it does not apply (more than
+// 64 repeats: the column-parallel form below takes those).
+static __device__ bool extend_pre_repeat_packed(RH &h, int searchWindowLength, int minSpacerLength, int lane)
+{
+    const int nrep = h.nss / 2;
+    if (nrep < 2 || nrep > WAVE) return false;
+    const int L = h.L, w = searchWindowLength;
+    const uint32_t *words = h.words;
+    uint32_t right = 0, left = 0;
+    if (nrep == 2) {
+        const int j = (int)uni(h.ss[0]), p = (int)uni(h.ss[2]);
+        const int spacing = p - j;
+        int max_right = spacing - minSpacerLength;                  // (unsigned in the reference; spacing >= minSpacer + w here)
+        if (max_right > L - (p + w)) max_right = L - (p + w);       // the second copy's column must lie inside the read
+        int rr = 0;
+        while (rr < max_right) {
+            uint64_t a0, a1, b0, b1;
+            wv_load128(words, j + w + rr, a0, a1); wv_load128(words, p + w + rr, b0, b1);
+            const int n = max_right - rr < 64 ? max_right - rr : 64;
+            const int r = uni(ln_run_up(a0 ^ b0, a1 ^ b1, n));
+            rr += r;
+            if (r < n) break;
+        }
+        const int len_r = w + rr;
+        int max_left = spacing - len_r;
+        if (max_left < 0) max_left = 0;
+        if (max_left > j) max_left = j;                             // the first copy's column must lie inside the read
+        int ll = 0;
+        while (ll < max_left) {
+            const int n = max_left - ll < 64 ? max_left - ll : 64;
+            uint64_t a0, a1, b0, b1;
+            wv_load128(words, j - ll - n, a0, a1); wv_load128(words, p - ll - n, b0, b1);
+            const int r = uni(ln_run_down(a0 ^ b0, a1 ^ b1, n));
+            ll += r;
+            if (r < n) break;
+        }
+        right = (uint32_t)rr; left = (uint32_t)ll;
+    } else {
+        const int cut_off = nrep - 1;                               // (max(2, nrep - 1) with nrep >= 3)
+        const uint32_t end_index = (uint32_t)h.nss;
+        const uint32_t first_start = uni(h.ss[0]), last_start = uni(h.ss[h.nss - 2]);
+        const uint32_t seqlen = (uint32_t)L;
+        const bool mine = lane < nrep;
+        const uint32_t my_start = mine ? h.ss[2 * lane] : 0u;
+        uint32_t shortest = 0xFFFFFFFFu;
+        if (mine && lane > 0) shortest = (uint32_t)((int)my_start - (int)h.ss[2 * lane - 2]);
+        for (int off = 32; off > 0; off >>= 1) shortest = min(shortest, (uint32_t)__shfl_xor((int)shortest, off));
+        shortest = uni(shortest);
+        const uint32_t max_right = shortest - (uint32_t)minSpacerLength;
+        const int T = (int)seqlen - (int)last_start - w;           // >= 0
+        bool stop = false;
+        for (uint32_t e0 = 0; e0 < max_right && !stop; e0 += 64u) {
+            uint64_t lo = 0, hi = 0;
+            if (mine) wv_load128(words, (int)(my_start + (uint32_t)w + e0), lo, hi);
+            const uint32_t e1 = min(e0 + 64u, max_right);
+            for (uint32_t e = e0; e < e1; e++) {
+                int drops = (int)e - T + 1;
+                if (drops < 0) drops = 0;
+                const int n_part = nrep - drops;                    // DR_index_end / 2 of this iteration (:614-616)
+                const uint32_t pos = my_start + (uint32_t)w + e;
+                const bool valid = mine && lane < n_part && pos < seqlen;     // (starts ascend: behind the first repeat off the read nobody votes, :624-627)
+                const uint32_t b = wv_base(lo, hi, (int)(e - e0));
+                const int cA = __popcll(__ballot(valid && b == 0u)), cC = __popcll(__ballot(valid && b == 1u));
+                const int cG = __popcll(__ballot(valid && b == 2u)), cT = __popcll(__ballot(valid && b == 3u));
+                if ((cA >= cut_off) || (cC >= cut_off) || (cG >= cut_off) || (cT >= cut_off)) right++;
+                else { stop = true; break; }
+            }
+        }
+        const int replen_r = w + (int)right;
+        const int test_for_negative = (int)(shortest - (uint32_t)replen_r);
+        const uint32_t max_left = (test_for_negative >= 0) ? (uint32_t)test_for_negative : 0u;
+        stop = false;
+        for (uint32_t e0 = 0; e0 < max_left && !stop; e0 += 64u) {
+            uint64_t lo = 0, hi = 0;
+            if (mine) wv_load128_before(words, (int)my_start - (int)e0, lo, hi);      // bases [my_start - e0 - 64, my_start - e0)
+            const uint32_t e1 = min(e0 + 64u, max_left);
+            for (uint32_t e = e0; e < e1; e++) {
+                int drops = (int)e - (int)first_start + 1;          // iterations i <= e with firstStart - i <= 0 (:700-704)
+                if (drops < 0) drops = 0;
+                const int idx = (int)my_start - (int)e - 1;
+                const bool valid = mine && lane >= drops && idx >= 0 && idx < L;
+                const uint32_t b = wv_base(lo, hi, 63 - (int)(e - e0));
+                const int cA = __popcll(__ballot(valid && b == 0u)), cC = __popcll(__ballot(valid && b == 1u));
+                const int cG = __popcll(__ballot(valid && b == 2u)), cT = __popcll(__ballot(valid && b == 3u));
+                if ((cA >= cut_off) || (cC >= cut_off) || (cG >= cut_off) || (cT >= cut_off)) left++;
+                else { stop = true; break; }
+            }
+        }
+        (void)end_index;
+    }
+    h.replen = w + (int)right + (int)left;
+    wave_sync();
+    for (int r = 2 * lane; r + 1 < h.nss; r += 2 * WAVE) {
+        uint32_t a = h.ss[r], b = h.ss[r + 1];
+        a = (a < left) ? 0 : a - left;
+        b = (b + right >= (uint32_t)L) ? (uint32_t)L - 1 : b + right;
+        h.ss[r] = a; h.ss[r + 1] = b;
+    }
+    wave_sync();
+    return true;
+}
+
+// scanRight's chain (libcrispr.cpp:170-263) once a third repeat exists: instead of one wave-wide find per link — each a pair of
+// LDS round trips, a ballot and a fenced append — the wave marks every position of the next 4 096 bases that holds the window's
+// w-mer (lane l: the 64 positions from base + 64 l, one bit each) and then follows the chain on those masks: a link is two
+// lane reads and a find-first-set.  Entered with last / second-last repeat starts; appends to the start/stop list like rh_add.
+static __device__ void scan_right_masks(RH &h, int pat, uint32_t pattern_length, uint32_t minSpacerLength, uint32_t scanRange,
+                                        uint32_t last_repeat_index, uint32_t second_last_repeat_index, int lane)
+{
+    const uint32_t read_length = (uint32_t)h.L;
+    const uint32_t sj = uni(lds_code(h.words, (uint32_t)pat, h.cmask));
+    last_repeat_index = uni(last_repeat_index); second_last_repeat_index = uni(second_last_repeat_index);
+    uint32_t repeat_spacing = last_repeat_index - second_last_repeat_index;
+    uint32_t base = 0xFFFFFFFFu;                        // first position the masks cover (a multiple of 64); none yet
+    uint64_t mask = 0;
+    int nss = h.nss;
+    for (;;) {
+        const int candidate_repeat_index = (int)(last_repeat_index + repeat_spacing);
+        uint32_t begin_search = (uint32_t)candidate_repeat_index - scanRange;
+        uint32_t end_search = (uint32_t)candidate_repeat_index + pattern_length + scanRange;
+        const uint32_t scanRightMinBegin = last_repeat_index + pattern_length + minSpacerLength;
+        if (begin_search < scanRightMinBegin) begin_search = scanRightMinBegin;
+        if (begin_search > read_length - 1) break;
+        if (end_search > read_length) end_search = read_length;
+        if (begin_search >= end_search) break;
+        if (end_search - begin_search < pattern_length) break;          // bmpSearch: pattern longer than the text => -1 => the chain ends
+        const uint32_t last_p = end_search - pattern_length;            // the window's last start
+        if (base == 0xFFFFFFFFu || begin_search < base || last_p >= base + 4096u) {
+            base = begin_search & ~63u;
+            const uint32_t p0 = base + 64u * (uint32_t)lane;
+            uint64_t m = 0;
+            if (p0 + pattern_length <= read_length) {
+                const uint32_t wi = p0 >> 4;
+                uint32_t a[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) a[i] = h.words[wi + i];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint64_t v = ((uint64_t)a[q + 1] << 32) | a[q];
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        // (w <= 9: a window of 18 bits starting at bit 2 i <= 30 ends inside the 64-bit piece)
+                        const uint32_t c = (uint32_t)(v >> (2 * i)) & h.cmask;
+                        bits |= (uint32_t)(c == sj) << i;
+                    }
+                    m |= (uint64_t)bits << (16 * q);
+                }
+                // positions whose window would pass the read's end hold no match
+                const uint32_t n_ok = read_length - pattern_length - p0 + 1u;      // >= 1 here
+                if (n_ok < 64u) m &= (1ull << n_ok) - 1ull;
+            }
+            mask = m;
+        }
+        const uint32_t lo_i = begin_search - base, hi_i = last_p - base;      // inclusive bit range, < 4096, at most 57 wide
+        const int k0 = (int)(lo_i >> 6), k1 = (int)(hi_i >> 6);
+        const uint32_t mlo0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mask, k0), mhi0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mask >> 32), k0);
+        uint64_t m0 = (((uint64_t)mhi0 << 32) | mlo0) & (~0ull << (lo_i & 63u));
+        if (k1 == k0) m0 &= (hi_i & 63u) == 63u ? ~0ull : ((2ull << (hi_i & 63u)) - 1ull);
+        int position = -1;
+        if (m0) position = (int)(base + 64u * (uint32_t)k0) + (__ffsll((unsigned long long)m0) - 1);
+        else if (k1 > k0) {
+            const uint32_t mlo1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mask, k1), mhi1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mask >> 32), k1);
+            const uint64_t m1 = (((uint64_t)mhi1 << 32) | mlo1) & ((hi_i & 63u) == 63u ? ~0ull : ((2ull << (hi_i & 63u)) - 1ull));
+            if (m1) position = (int)(base + 64u * (uint32_t)k1) + (__ffsll((unsigned long long)m1) - 1);
+        }
+        if (position < 0) break;
+        const uint32_t found = (uint32_t)position;
+        if (nss + 2 > h.cap) { h.err = 2; break; }                      // (rh_add)
+        uint32_t stop = found + pattern_length - 1;
+        if (stop >= read_length) stop = read_length - 1;
+        if (lane == 0) { h.ss[nss] = found; h.ss[nss + 1] = stop; }
+        nss += 2;
+        second_last_repeat_index = last_repeat_index;
+        last_repeat_index = found;
+        repeat_spacing = last_repeat_index - second_last_repeat_index;
+        if (repeat_spacing < (minSpacerLength + pattern_length)) break;
+    }
+    h.nss = nss;
+    wave_sync();
 }
 
 // searchCore, libcrispr.cpp:265-395.  1 found / 0 not / <0 error
@@ -1234,18 +1533,22 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
     bool on_lattice = true;
     uint32_t lattice_i = 0;
     for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
+        PROF_CNT(h, PF_N_ITER);
         if (pos_hint) {
+            PROF_T0(h);
             // per-position hints: a clear bit makes this iteration a no-op in the reference, on or off the lattice.  The walk
             // stays on one residue class mod 8 until a rejected candidate moves it (j = back() - 1 below); the bits of the class
             // it moves to are computed here, from this position to the end of the read (the walk only moves forward)
-            if (cls_from && j < cls_from[j & 7u]) {     // wave-uniform; never true on the lattice class
+            if (cls_from && j < uni(cls_from[j & 7u])) {     // wave-uniform; never true on the lattice class
                 const uint32_t first_word = j >> 6;
+                { const unsigned long long _ph0 = h.lprof ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
                 wave_hints_class(h, j & 7u, first_word, pos_hint, lane);
+                if (h.lprof && lane == 0) { h.lprof[PF_HINTS] += (unsigned long long)__builtin_readcyclecounter() - _ph0; h.lprof[PF_N_SWITCH] += 1ull; } }
                 if (lane == 0) cls_from[j & 7u] = first_word << 6;
                 wave_sync();
             }
             // With skips == 8 the next candidate in the same 64-bit word is one ffs away.
-            const uint64_t wbits = pos_hint[j >> 6] >> (j & 63u);
+            const uint64_t wbits = uni64(pos_hint[j >> 6]) >> (j & 63u);
             if (!(wbits & 1ull)) {
                 if (skips == 8) {
                     const uint64_t m = wbits & 0x0101010101010101ull;        // positions j, j+8, ... inside this word
@@ -1264,17 +1567,19 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
                             const uint64_t any = __ballot(v != 0ull);
                             if (any) {
                                 const uint32_t fw = w0 + (uint32_t)(__ffsll((unsigned long long)any) - 1);
-                                const uint64_t fv = pos_hint[fw] & resmask;             // (wave-uniform reload)
+                                const uint64_t fv = uni64(pos_hint[fw]) & resmask;      // (wave-uniform reload)
                                 next_j = fw * 64u + (uint32_t)(__ffsll((unsigned long long)fv) - 1);
                                 break;
                             }
                         }
-                        if (next_j == 0xFFFFFFFFu) break;                           // no candidate up to searchEnd: the loop ends
+                        if (next_j == 0xFFFFFFFFu) { PROF_ADD(h, PF_LOOP); break; }          // no candidate up to searchEnd: the loop ends
                         j = next_j - 8u;                                            // the loop adds 8: lands on it
                     }
                 }
+                PROF_ADD(h, PF_LOOP);
                 continue;
             }
+            PROF_ADD(h, PF_LOOP);
         } else if (on_lattice) {
             const uint32_t li = lattice_i++;
             if (li < 32 && !((seed_hint >> li) & 1u)) continue;
@@ -1284,25 +1589,35 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
         if (endSearch >= seq_length) endSearch = seq_length - 1;
         if (endSearch < beginSearch) endSearch = beginSearch;
         if (beginSearch > seq_length) return -1;                       // substr would throw
-        int pos = rh_find(h, (int)beginSearch, (int)endSearch, (int)j, (int)o.window, lane);
+        int pos;
+        { PROF_T0(h);
+        pos = rh_find(h, (int)beginSearch, (int)endSearch, (int)j, (int)o.window, lane);
+        PROF_ADD(h, PF_FIND); PROF_CNT(h, PF_N_CAND); }
         if (o.debug_stop == 2) pos = -1;
         if (pos >= 0) {
+            PROF_T0(h);
             rh_add(h, j, j + o.window - 1, lane);
             rh_add(h, (uint32_t)pos, (uint32_t)pos + o.window - 1, lane);
             if (h.err) return -2;
             scan_right(h, (int)j, o.window, o.lowSp, 24, lane);
             if (h.err) return -2;
+            PROF_ADD(h, PF_SCAN);
         }
         if ((uint32_t)(h.nss / 2) >= o.minRepeats) {
-            uint32_t actual_repeat_length = extend_pre_repeat(h, (int)o.window, (int)o.lowSp, lane);
+            uint32_t actual_repeat_length;
+            { PROF_T0(h);
+            actual_repeat_length = extend_pre_repeat(h, (int)o.window, (int)o.lowSp, lane);
+            PROF_ADD(h, PF_EXTEND); }
             if (h.err == 6) return -3;
             if (o.debug_stop != 3 && (actual_repeat_length >= o.lowDR) && (actual_repeat_length <= o.highDR)) {
+                PROF_T0(h);
                 int qc = qc_found_repeats(h, (int)o.lowSp, (int)o.highSp, lane, o.debug_stop);
+                PROF_ADD(h, PF_QC); PROF_CNT(h, PF_N_QC);
                 if (qc == -3) return -3;
                 if (qc < 0) return -1;
                 if (qc) return 1;
             }
-            j = h.ss[h.nss - 1] - 1;
+            j = uni(h.ss[h.nss - 1]) - 1;
             on_lattice = false;
         }
         h.nss = 0;
@@ -1330,8 +1645,9 @@ static __device__ int dr_low_lexi(RH &h, char *dr_out, int dr_stride, int &was_l
         }
     } else pick = 2;
     uint32_t dlen;
-    if (!substr_len(h.L, h.ss[pick], h.ss[pick + 1] - h.ss[pick] + 1, dlen)) return -1;
-    const uint8_t *dr = h.seq + h.ss[pick];
+    const uint32_t dr_start = uni(h.ss[pick]);
+    if (!substr_len(h.L, dr_start, uni(h.ss[pick + 1]) - dr_start + 1, dlen)) return -1;
+    const uint8_t *dr = h.seq + dr_start;
     // tmp_dr < rev_comp ?  (std::string operator<, unsigned bytes; equal => not less => flip)
     int less = 0;
     for (int i0 = 0; i0 < (int)dlen; i0 += WAVE) {
@@ -1417,7 +1733,7 @@ static __device__ __forceinline__ void prefetch_read(const DevReads &R, uint64_t
 #pragma unroll
     for (int i = 0; i < SV_PREFETCH_VEC; i++) pf.v[i] = sv_load_group(g, lane + i * WAVE, nw);
     if (R.pos_hint) {
-        const uint64_t *ph = R.pos_hint + R.pos_hint_off[r];
+        const uint64_t *ph = R.pos_hint + rd_hint_off(R, r);
         const int nh = (L + 63) >> 6;
 #pragma unroll
         for (int i = 0; i < SV_PREFETCH_HINTS; i++) {
@@ -1442,7 +1758,7 @@ static __device__ void load_hints_to_lds(const DevReads &R, uint64_t r, int L, u
         first = lane + SV_PREFETCH_HINTS * WAVE;
         if (nh <= SV_PREFETCH_HINTS * WAVE) return;      // (wave-uniform: nothing left, and no look-up of the read's offset)
     }
-    const uint64_t *ph = R.pos_hint + R.pos_hint_off[r];
+    const uint64_t *ph = R.pos_hint + rd_hint_off(R, r);
     for (int wi = first; wi < nh; wi += WAVE) l_hint[wi] = ph[wi];
 }
 
@@ -1467,6 +1783,19 @@ static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *
     (void)seq;                                          // (the ASCII copy: region by region, when a byte-wise consumer is entered — rh_ascii)
 }
 
+#define PROF_READ_DONE(cat_, tot_) do { \
+            wave_sync(); \
+            if (lane == 0) { h.lprof[PF_TOTAL] = (tot_); h.lprof[PF_READS] = 1ull; } \
+            wave_sync(); \
+            unsigned long long *ws_ = h.lprof + PF_SLOTS + (cat_) * PF_SLOTS; \
+            if (lane < PF_SLOTS && lane != PF_MAX) ws_[lane] += h.lprof[lane]; \
+            if (lane == PF_MAX && (tot_) > ws_[PF_MAX]) ws_[PF_MAX] = (tot_); \
+            if (lane == 0) { int b_ = 63 - __clzll((long long)((tot_) | 1ull)) - 8; b_ = b_ < 0 ? 0 : (b_ >= PF_BINS ? PF_BINS - 1 : b_); h.lprof[5 * PF_SLOTS + (cat_) * PF_BINS + b_] += 1ull; } \
+            wave_sync(); } while (0)
+#define PROF_WAVE_FLUSH() do { if (h.lprof) { wave_sync(); \
+            for (int q_ = lane; q_ < 4 * PF_SLOTS + 4 * PF_BINS; q_ += WAVE) { \
+                const unsigned long long v_ = h.lprof[PF_SLOTS + q_]; \
+                if (v_) { if (q_ < 4 * PF_SLOTS && (q_ % PF_SLOTS) == PF_MAX) atomicMax(P.prof + q_, v_); else atomicAdd(P.prof + q_, v_); } } } } while (0)
 template <bool EXC>
 // (two waves per SIMD asked for, i.e. up to 256 VGPRs: with one wave per block and 14-58 KB of LDS per block the LDS decides
 // the residency — and the next read's prefetched words did not fit the 128 registers of a 4-wave target without spilling)
@@ -1491,6 +1820,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     h.sims = reinterpret_cast<float *>(l_words + lds.words_cap);
     uint64_t *l_hint = reinterpret_cast<uint64_t *>(h.sims + lds.ss_cap);
     h.cmask = (1u << (2 * P.window)) - 1u;
+    // diagnostics: the launch was given PF_SLOTS x 8 more bytes of LDS behind the layout (launch_survivor)
+    h.lprof = P.prof ? reinterpret_cast<unsigned long long *>(sv_lds + ((lds.total_bytes + 7u) & ~7u)) : nullptr;
+    if (h.lprof) { for (int q = lane; q < PF_LDS_WORDS; q += WAVE) h.lprof[q] = 0ull; wave_sync(); }
     // EXC with punt_only == 5: exception reads that sit in the survivor list (slot s, read surv_idx[s])
     uint64_t n_surv = (EXC && punt_only != 5) ? R.n_exc : (uint64_t)(*d_n_surv);
     if (n_surv > n_max) n_surv = n_max;
@@ -1503,7 +1835,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     for (uint64_t s = blockIdx.x;; ) {
         if (punt_only) {
             while (punt_mask == 0) {
-                if (punt_base >= n_surv) return;
+                if (punt_base >= n_surv) { PROF_WAVE_FLUSH(); return; }
                 const uint64_t q = punt_base + lane;
                 punt_mask = __ballot(q < n_surv && out[q].err == (uint8_t)punt_only);
                 if (punt_mask == 0) punt_base += (uint64_t)gridDim.x * WAVE;
@@ -1512,10 +1844,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             punt_mask &= punt_mask - 1;
             s = punt_base + b;
             if (punt_mask == 0) punt_base += (uint64_t)gridDim.x * WAVE;
-        } else if (s >= n_surv) return;
+        } else if (s >= n_surv) { PROF_WAVE_FLUSH(); return; }
         uint64_t r;
         int L;
         wave_sync();
+        const unsigned long long prof_t0 = h.lprof ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+        if (h.lprof) { if (lane < PF_SLOTS) h.lprof[lane] = 0ull; wave_sync(); }
+
         if (EXC) {
             uint64_t e = s;
             if (punt_only == 5) {
@@ -1528,8 +1863,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             L = (int)(R.exc_off[e + 1] - o0);
             for (int i = lane; i < L; i += WAVE) h.seq[i] = R.exc_bytes[o0 + i];
         } else {
-            r = (next_s == s) ? next_r : surv_idx[s];           // (the prefetch below already looked it up)
-            if (!punt_only && rd_is_exc(R, r)) {                // left to the exception pass
+            // (surv_idx == nullptr: the list is 0, 1, 2, ... — a long-read set without exception reads, every read survives)
+            r = (next_s == s) ? next_r : (surv_idx ? surv_idx[s] : s + slot_base);           // (the prefetch below already looked it up)
+            if (!punt_only && R.n_exc && rd_is_exc(R, r)) {     // left to the exception pass
                 if (lane == 0) { SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = 5; out[s] = x; }
                 s += gridDim.x;
                 continue;
@@ -1546,7 +1882,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
                     for (int i = 0; i < SV_PREFETCH_HINTS; i++) any |= (lane + i * WAVE < nh) && pf.hw[i] != 0ull;
                     if (nh > SV_PREFETCH_HINTS * WAVE) any = true;                 // (longer than the prefetch covers: walk it)
                 } else {
-                    const uint64_t *gh = R.pos_hint + R.pos_hint_off[r];
+                    const uint64_t *gh = R.pos_hint + rd_hint_off(R, r);
                     for (int wi = lane; wi < nh; wi += WAVE) any |= gh[wi] != 0ull;
                 }
                 no_seed = __ballot(any) == 0ull;
@@ -1557,17 +1893,19 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             }
             pf.r = ~0ull;
             if (!punt_only && s + gridDim.x < n_surv) {         // the next read of this wave: its words travel during the search
-                const uint64_t r2 = surv_idx[s + gridDim.x];
+                const uint64_t r2 = surv_idx ? surv_idx[s + gridDim.x] : s + gridDim.x + slot_base;
                 next_s = s + gridDim.x; next_r = r2;
-                if (!rd_is_exc(R, r2)) prefetch_read(R, r2, lane, pf);
+                if (!R.n_exc || !rd_is_exc(R, r2)) prefetch_read(R, r2, lane, pf);
             }
             if (no_seed) {
                 if (lane == 0) { SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = 0; out[s] = x; }
+                if (h.lprof) { const unsigned long long tot = (unsigned long long)__builtin_readcyclecounter() - prof_t0; PROF_READ_DONE(0, tot); }
                 s += gridDim.x;
                 continue;
             }
         }
         wave_sync();
+        if (h.lprof && lane == 0) h.lprof[PF_STAGE] = (unsigned long long)__builtin_readcyclecounter() - prof_t0;
         h.L = L; h.nss = 0; h.replen = 0; h.err = 0;
         h.asc_lo = 0; h.asc_hi = 0; h.asc_pad = (int)(P.highDR + P.highSp) + 32; h.seq = h.seq_buf;
         const uint32_t hint = (!EXC && seed_hint) ? seed_hint[r] : 0xFFFFFFFFu;
@@ -1576,6 +1914,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         if (ph && lane < 8) cls_from[lane] = lane == 0 ? 0u : 0xFFFFFFFFu;
         wave_sync();
         int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane, ph, ph ? cls_from : nullptr);
+        const unsigned long long prof_t1 = h.lprof ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
         // (-3: Levenshtein rows too short / the ASCII window too small in this launch's LDS layout; -2 in a layout with a capped
@@ -1607,6 +1946,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             }
         }
         if (lane == 0) out[s] = o;
+        if (h.lprof && lane == 0) h.lprof[PF_OUT] = (unsigned long long)__builtin_readcyclecounter() - prof_t1;
+        if (h.lprof) {
+            // category 1: walked, nothing found; 2: found; 3: handed over / error (0: skipped, no hinted seed)
+            const unsigned long long tot = (unsigned long long)__builtin_readcyclecounter() - prof_t0;
+            const int cat = o.err ? 3 : (o.found ? 2 : 1);
+            PROF_READ_DONE(cat, tot);
+        }
         if (!punt_only) s += gridDim.x;
     }
 }
@@ -2809,15 +3155,16 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
 {
     if (n_surv_max == 0) return hipSuccess;
     hipError_t e;
+    const uint32_t lds_bytes = ((lds.total_bytes + 7u) & ~7u) + (P.prof ? PF_LDS_WORDS * 8u : 0u);      // (diagnostics: the phase slots)
     if (exceptions) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        CRASS_LAUNCH(k_survivor<true>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
+        CRASS_LAUNCH(k_survivor<true>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
                            out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds.total_bytes);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        CRASS_LAUNCH(k_survivor<false>, dim3(grid), dim3(WAVE), lds.total_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
+        CRASS_LAUNCH(k_survivor<false>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
                            out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total);
     }
     return hipGetLastError();

@@ -332,6 +332,104 @@ def test_long_reads_ragged_mid_size(ca):
         assert_same_pipeline(sliced, ref)
 
 
+LONG_PARAM_SETS = [
+    dict(searchWindowLength=7), dict(lowDRsize=20, highDRsize=40), dict(lowSpacerSize=20, highSpacerSize=60),
+    dict(minNumRepeats=3), dict(searchWindowLength=9, minNumRepeats=4),
+]
+
+
+@pytest.mark.parametrize("kw", LONG_PARAM_SETS, ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_long_reads_non_default_options(ca, kw):
+    """any -w / -d / -D / -s / -S change drops the position hints (launch_hint_positions refuses them) and the
+    wave kernel walks every lattice seed — a different code path from the hinted walk, never compared with non-default options
+    before.  Ragged 2.1-9 kbp reads with arrays, damaged copies and chance repeats; -n changes what is accepted only."""
+    rng = random.Random(101)
+
+    def rs(n):
+        return bytes(rng.choice(b"ACGT") for _ in range(n))
+    drs = [rs(rng.randint(20, 40)) for _ in range(8)]
+    seqs = []
+    for i in range(240):
+        L = rng.randint(2100, 9000)
+        s = bytearray(rs(L))
+        kind = i % 5
+        if kind in (1, 2, 3):
+            dr = bytearray(rng.choice(drs))
+            reps = rng.randint(2, 5) if kind == 1 else rng.randint(6, 40)
+            arr = bytearray()
+            for _ in range(reps):
+                d = bytearray(dr)
+                if kind == 3 and rng.random() < 0.4:
+                    d[rng.randrange(len(d))] = rng.choice(b"ACGT")
+                arr += d + rs(rng.randint(18, 62))
+            at = rng.choice([0, max(0, L - len(arr)), rng.randint(0, max(0, L - len(arr)))])
+            s[at:at + len(arr)] = arr
+            s = s[:L]
+        elif kind == 4:
+            for k in range(5):
+                q = rng.randint(0, L - 200)
+                s[q + 55:q + 64] = s[q:q + 9]
+        seqs.append(bytes(s))
+    p = ca.default_params(**kw)
+    gpu = ca.search_pipeline(seqs, params=p)
+    ref = orc.pipeline(seqs, params=to_orc_params(p))
+    assert_same_pipeline(gpu, ref)
+    assert gpu.n_pass1 >= 10
+    # the windowed LDS layout's second launch under these options too
+    os.environ["CRASS_SEQ_WINDOW"] = "1024"
+    try:
+        alt = ca.search_pipeline(seqs, params=p)
+    finally:
+        os.environ.pop("CRASS_SEQ_WINDOW", None)
+    assert_same_pipeline(alt, ref)
+
+
+def test_reference_kat_reads_through_the_hip_path(ca):
+    """the 20 reads of the reference's own Catch cases (src/test/test_libcrispr.cpp, fixture
+    tests/golden/kat_libcrispr.json) through the ENGINE, each with its case's window / minimum spacer: equal to the oracle record
+    for record, and — where searchCore itself reproduces the case's seeds (it accepts the read with the case's repeats) — equal to
+    the KAT's own start_stops_out / repeat_length.  Window 11 is outside what crass accepts (-w 6..9, crass.cpp) and the engine
+    refuses it like the reference's command line does."""
+    import json
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_libcrispr.json")))
+    assert len(kat["cases"]) == 20
+    pinned = refused = 0
+    for case in kat["cases"]:
+        seq = case["read"].encode()
+        kw = dict(lowSpacerSize=case["min_spacer"])
+        if case.get("window"):
+            kw["searchWindowLength"] = case["window"]
+        p = ca.default_params(**kw)
+        if case.get("window", 8) > 9:
+            with pytest.raises(ca.CrassError):
+                ca.SearchEngine(p)
+            refused += 1
+            continue
+        # the KAT read plus filler reads, so that the lane kernel, the filter and the merge all see more than one read
+        filler = synth_reads(ca, 200, read_len=len(seq), crispr_per_million=0)
+        seqs = filler[:100] + [seq] + filler[100:]
+        gpu = ca.search_pipeline(seqs, params=p)
+        ref = orc.pipeline(seqs, params=to_orc_params(p))
+        assert_same_pipeline(gpu, ref)
+        mine = [k for k in range(gpu.n_pass1) if int(gpu.rec_read[k]) == 100]
+        if not mine:
+            continue                                     # searchCore rejects this read (QC / DR length): equal to the oracle above
+        k = mine[0]
+        o = int(gpu.rec_ss_off[k]); n = int(gpu.rec_nss[k])
+        ss = [int(x) for x in gpu.ss_pool[o:o + n]]
+        if not gpu.rec_lowlexi[k]:                       # reverseStartStops (ReadHolder.cpp:321-380): mirror back
+            ss = [len(seq) - 1 - x for x in reversed(ss)]
+        if case["func"] == "extendPreRepeat":
+            assert ss == case["start_stops_out"] and int(gpu.rec_replen[k]) == case["repeat_length"]
+            pinned += 1
+        else:
+            # scanRight's output is the list BEFORE the extension: same repeats, same starts (every case starts at base 0, so
+            # the left extension is empty)
+            assert len(ss) == case.get("size", len(case["start_stops_out"])) and ss[0::2] == case["start_stops_out"][0::2]
+            pinned += 1
+    assert refused == 3 and pinned >= 9
+
+
 def test_long_reads_position_hints(ca):
     """reads beyond the per-read filter get one seed-hint bit per base (k_hint_positions); the hinted seed loop
     must visit exactly the seeds that matter, on and off the stride lattice (rejected candidates move j off it):
