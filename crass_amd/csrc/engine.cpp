@@ -295,6 +295,7 @@ struct crass_hip_ctx {
     } dense;
     DevBuf<uint64_t> d_fidx;
     DevBuf<uint64_t> d_pos_hint, d_pos_hint_off; uint64_t n_pos_hint_words = 0;     // long reads: per-position seed hints
+    DevBuf<uint32_t> d_punt;                                                          // long reads: [0] count, [1 ..] slots the light walk handed over
     DevBuf<uint32_t> d_pos_hint_blk; bool pos_hint_blk = false;                       // ragged lengths: read of every 256th hint word
     // device-side DR de-duplication (single-GPU merge fast path)
     DevBuf<unsigned long long> dd_keys; DevBuf<uint32_t> dd_first, dd_slot, dd_rep; DevBuf<uint64_t> dd_hash;
@@ -671,7 +672,11 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
       if (he != hipSuccess) { fprintf(stderr, "[crass_hip] hipSetDevice(%d): %s\n", device, hipGetErrorString(he)); delete c; return CRASS_ERR_NO_DEVICE; } }
     if (getenv("CRASS_SURV_PROF")) {                    // diagnostics: phase cycles of the wave-per-read kernel (tools/longread_phases.py)
         void *pp = nullptr;
-        if (hipMalloc(&pp, 192 * 8) == hipSuccess && hipMemset(pp, 0, 192 * 8) == hipSuccess) c->dp.prof = (unsigned long long *)pp;
+        if (hipMalloc(&pp, (192 + 2 * 16384) * 8) == hipSuccess && hipMemset(pp, 0, (192 + 2 * 16384) * 8) == hipSuccess) {
+            c->dp.prof = (unsigned long long *)pp;
+            const unsigned long long big = ~0ull;
+            (void)hipMemcpy(c->dp.prof + 188, &big, 8, hipMemcpyHostToDevice);
+        }
     }
     for (hipStream_t *sp : {&c->stream, &c->copy_stream}) {
         const hipError_t he = hipStreamCreateWithFlags(sp, hipStreamNonBlocking);
@@ -769,7 +774,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
     c->g_surv.release(); c->g_dr.release(); c->g_ss.release(); c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
-    c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->d_pos_hint.release(); c->d_pos_hint_off.release(); c->d_pos_hint_blk.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
+    c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->d_pos_hint.release(); c->d_pos_hint_off.release(); c->d_pos_hint_blk.release(); c->d_punt.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1017,6 +1022,22 @@ static void dump_surv_prof(crass_hip_ctx *c)
     unsigned long long v[192];
     if (hipMemcpy(v, c->dp.prof, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return;
     (void)hipMemset(c->dp.prof, 0, sizeof v);
+    { const unsigned long long big = ~0ull; (void)hipMemcpy(c->dp.prof + 188, &big, 8, hipMemcpyHostToDevice); }
+    if (v[191]) fprintf(stderr, "[surv_prof] %llu waves; first start .. last start %.1f us, first start .. last end %.1f us\n", v[186], (double)(v[187] - v[188]) / 100.0, (double)(v[189] - v[188]) / 100.0);
+    if (v[186] && v[186] <= 16384) {
+        // per-wave start / end (10 ns ticks): when did the waves of the launch start, how long did they live
+        std::vector<unsigned long long> se(2 * v[186]);
+        if (hipMemcpy(se.data(), c->dp.prof + 192, se.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<double> st, life, en;
+            for (size_t k = 0; k < v[186]; k++) if (se[2 * k] && se[2 * k + 1]) { st.push_back((double)(se[2 * k] - v[188]) / 100.0); en.push_back((double)(se[2 * k + 1] - v[188]) / 100.0); life.push_back((double)(se[2 * k + 1] - se[2 * k]) / 100.0); }
+            auto pct = [](std::vector<double> &a, double q) { if (a.empty()) return 0.0; std::sort(a.begin(), a.end()); return a[(size_t)(q * (a.size() - 1))]; };
+            fprintf(stderr, "[surv_prof] per wave (us): start p10 %.0f p50 %.0f p90 %.0f max %.0f | life p10 %.0f p50 %.0f p90 %.0f max %.0f | end p10 %.0f p50 %.0f p90 %.0f max %.0f\n",
+                    pct(st, .1), pct(st, .5), pct(st, .9), pct(st, 1.), pct(life, .1), pct(life, .5), pct(life, .9), pct(life, 1.), pct(en, .1), pct(en, .5), pct(en, .9), pct(en, 1.));
+        }
+        (void)hipMemset(c->dp.prof + 192, 0, 2 * 16384 * 8);
+    }
+    if (v[185]) fprintf(stderr, "[surv_prof] slowest read: slot %llu, %llu cycles\n", v[185] & 0xFFFFFFull, v[185] >> 24);
+    if (v[191]) fprintf(stderr, "[surv_prof] waves' lifetimes: %llu shader cycles in %llu ticks of 10 ns: %.3f GHz\n", v[190], v[191], (double)v[190] / (10.0 * (double)v[191]));
     static const char *nm[] = {"total", "stage", "find", "scan", "extend", "qc", "hints", "out", "n_cand", "n_scanfind", "n_switch", "n_qc", "loop", "n_iter", "max", "reads"};
     for (int cat = 0; cat < 4; cat++) {
         const unsigned long long n = v[cat * 16 + 15];
@@ -1061,6 +1082,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     // the survivor list on the device is 0, 1, 2, ... (no filter, no exception read, one chunk): the kernel is told so and needs no
     // look-up per read
     const bool ident_list = !exc && !surv_idx_host && c->R.n_exc == 0 && n_total <= chunk_cap;
+    // ... and with position hints on top the walk is split: k_long_light for every read, the full kernel for what it hands over
+    // (CRASS_NO_LIGHT: the A/B switch; the cut-short walks of CRASS_SURV_DEBUG belong to the full kernel)
+    const bool use_light = ident_list && c->R.pos_hint && c->dp.skips == 8 && c->dp.debug_stop == 0 && !getenv("CRASS_NO_LIGHT");
     const int grid = 256 * 64;      // waves striding over the reads: 6 resident per CU at 10 kbp; 1 536 / 8 192 / 16 384 / 65 536 blocks: 11.5 / 8.6 / 8.2 / 9.1 ms
     const uint32_t stride = c->dr_stride;
     L.reserve(L.size() + n_total / 2 + 16, stride);
@@ -1072,6 +1096,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             R.exc_read = c->R.exc_read + off; R.exc_off = c->R.exc_off + off; R.n_exc = nchunk;
         }
         // for the non-exception path the count lives on the device; chunking uses a host-known bound
+        if (use_light) { HIPCHK(c, c->d_punt.ensure(nchunk + 1)); HIPCHK(c, hipMemsetAsync(c->d_punt.p, 0, 4, c->stream)); }
         if (!exc && off == 0) HIPCHK(c, c->stamp(8, 1));
         if (!exc && c->hint_pending && off == 0 && nchunk == n_total) {
             // the walk, slice by slice behind the slice's hints (slot boundaries: the survivors with a read below the slice's end;
@@ -1082,7 +1107,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                 uint64_t s1 = q + 1 == c->hint_parts ? nchunk
                             : (surv_idx_host ? (uint64_t)(std::lower_bound(surv_idx_host, surv_idx_host + nchunk, r1) - surv_idx_host) : std::min<uint64_t>(r1, nchunk));
                 if (q > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_hint[q], 0));
-                if (s1 > s0)
+                if (s1 > s0 && use_light)
+                    HIPCHK(c, launch_long_light(R, c->dp, c->d_count.p + 1, s1 - s0, c->d_surv.p + s0, s0, c->max_len, c->stream, c->d_punt.p + 1, c->d_punt.p));
+                else if (s1 > s0)
                     HIPCHK(c, launch_survivor(R, c->dp, false, ident_list ? nullptr : c->d_idx.p + s0, c->d_count.p + 1, s1 - s0,
                                               c->d_surv.p + s0, c->d_dr.p + s0 * (size_t)stride, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                               c->d_found.p, c->hints_valid ? c->d_hit_info.p : nullptr, lds,
@@ -1090,6 +1117,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                 s0 = s1;
             }
             c->hint_pending = false;
+        } else if (use_light) {
+            { const int hw = hint_wait_all(c); if (hw) return hw; }
+            HIPCHK(c, launch_long_light(R, c->dp, c->d_count.p + 1, nchunk, c->d_surv.p, 0, c->max_len, c->stream, c->d_punt.p + 1, c->d_punt.p));
         } else {
             { const int hw = hint_wait_all(c); if (hw) return hw; }
             HIPCHK(c, launch_survivor(R, c->dp, exc, (exc || ident_list) ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
@@ -1097,6 +1127,12 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                                       c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds,
                                       (int)std::min<uint64_t>(grid, nchunk), c->stream));
         }
+        // the reads the light walk handed over (an array, a candidate due for the QC: one read in 17 at 10 kbp): the full kernel
+        if (use_light)
+            HIPCHK(c, launch_survivor(R, c->dp, false, nullptr, c->d_count.p + 1, nchunk,
+                                      c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
+                                      c->d_found.p, nullptr, lds, (int)std::min<uint64_t>(256 * 12, nchunk), c->stream, 7, 0, nchunk, c->d_punt.p + 1, c->d_punt.p));
+        if (use_light && c->dp.prof) { HIPCHK(c, hipStreamSynchronize(c->stream)); dump_surv_prof(c); }      // (diagnostics: this launch's counters alone)
         if (capped)
             HIPCHK(c, launch_survivor(R, c->dp, exc, (exc || ident_list) ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
                                       c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,

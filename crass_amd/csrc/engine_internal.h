@@ -277,6 +277,10 @@ hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t
 hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
                                  uint64_t *hint_bits, hipStream_t st,       // blk_read[b] = read of tile 256 b (ragged lengths; else nullptr)
                                  uint64_t w_begin = 0, uint64_t w_end = ~0ull);      // the hint words [w_begin, w_end) only; w_begin a multiple of 256
+// long reads with position hints, an identity survivor list and no exception read: the walk of the reads without an array; a read
+// that needs the full searchCore leaves with err == 7 for launch_survivor(..., punt_only = 7)
+hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
+                             uint32_t max_len, hipStream_t st, uint32_t *punt_list, uint32_t *d_punt_n);      // punt_list[(*d_punt_n)++] = slot of a read handed over
 hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st);
 // ---- "last VGPR of the allocation" guard ----
 // Observed on the MI355X pool (minimal reproductions: profiles/ubench/vgpr_edge2.hip and vgpr_edge3.hip, write-up in
@@ -343,7 +347,8 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
                            uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
                            int punt_only = 0,
-                           uint64_t slot_base = 0, uint64_t slot_total = 0);      // a slice of a larger launch: out / dr_chars point at the slice, the start/stop pool is shared
+                           uint64_t slot_base = 0, uint64_t slot_total = 0,       // a slice of a larger launch: out / dr_chars point at the slice, the start/stop pool is shared
+                           const uint32_t *punt_list = nullptr, const uint32_t *d_punt_n = nullptr);      // punt_only with a list: exactly those slots, one per wave and turn
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                  uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st,

@@ -1168,7 +1168,45 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
         int max_spacer_length = 0;
         int num_compared = 0;
         const int nsp = num_repeats - 1;
-        // all 2*(nsp-1) similarities are independent: one pair per lane (bit-parallel DP), the float
+        // The reference walks the spacers once, summing similarities and length differences, and only then tests: spacer lengths,
+        // the two similarity averages, the two length-difference averages — every failed test is the same `return false`
+        // (:773-867).  The length tests need no edit distance, so they are taken FIRST here: a candidate that fails one of them
+        // (the common reason: every other repeat of an array missed, spacers of 100 bases) leaves without a single DP.  One read
+        // of BASELINE configs[3] spent 5.3 M cycles — 2.3 ms, the tail of the whole launch — on 54 wavefront DPs of 77 x 77 cells
+        // for a candidate whose longest spacer decides it.  (A throw in getAllSpacerStrings comes before any of it: -1.)
+        // Terms are fetched by the lanes — lane i: spacer i — and summed lane by lane in the reference's order (float addition
+        // does not associate): a term is a v_readlane instead of dependent LDS reads per spacer.
+        for (int c0 = 0; c0 < nsp; c0 += WAVE) {
+            const int i = c0 + lane;
+            const bool vi = i < nsp, vc = i + 1 < nsp;
+            uint32_t cur_len = 0, nxt_len = 0;
+            bool bad = false;
+            if (vi) { const uint32_t cs = h.ss[2 * i + 1] + 1; bad = !substr_len(h.L, cs, h.ss[2 * i + 2] - cs, cur_len); }
+            if (vc) { const uint32_t ns = h.ss[2 * i + 3] + 1; bad = bad || !substr_len(h.L, ns, h.ss[2 * i + 4] - ns, nxt_len); }
+            if (__ballot(bad)) return -1;
+            const float t_ssl = (float)cur_len - (float)nxt_len, t_rsl = (float)rep_len - (float)cur_len;
+            int mn = vi ? (int)cur_len : 10000000, mx = vi ? (int)cur_len : 0;
+            for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
+            if (mn < min_spacer_length) min_spacer_length = mn;
+            if (mx > max_spacer_length) max_spacer_length = mx;
+            const int i_end = min(c0 + WAVE, nsp - 1);                 // comparisons i = c0 .. i_end - 1 (i + 1 < nsp)
+            for (int ii = c0; ii < i_end; ii++) {
+                const int src = ii - c0;
+                num_compared++;
+                ave_spacer_to_spacer_len_difference += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_ssl), src));
+                ave_repeat_to_spacer_len_difference += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_rsl), src));
+            }
+        }
+        // num_compared == nsp-1 >= 1 here (the reference's num_compared == 0 branch needs <2 spacers)
+        ave_spacer_to_spacer_len_difference /= (float)num_compared;
+        ave_spacer_to_spacer_len_difference = fabsf(ave_spacer_to_spacer_len_difference);
+        ave_repeat_to_spacer_len_difference /= (float)num_compared;
+        ave_repeat_to_spacer_len_difference = fabsf(ave_repeat_to_spacer_len_difference);
+        if (min_spacer_length < minSpacerLength) return 0;                 // testSpacerLength :773-800
+        if (max_spacer_length > maxSpacerLength) return 0;
+        if ((int)ave_spacer_to_spacer_len_difference > 12) return 0;       // int parameter: truncation (:836)
+        if ((int)ave_repeat_to_spacer_len_difference > 30) return 0;       // (:853)
+        // all 2*(nsp-1) similarities are independent: one pair per lane (bit-parallel DP on the packed words), the float
         // sums below then consume them in the reference's order.  pair 2i = (repeat, spacer_i),
         // pair 2i+1 = (spacer_i, spacer_i+1)   (:921-950)
         const int npairs = 2 * (nsp - 1);
@@ -1206,50 +1244,24 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
             }
         }
         wave_sync();
-        // The sums below are taken in the reference's order (float addition does not associate), but their terms are fetched
-        // by the lanes first — lane i: spacer i's length, the two similarities of comparison i, the two length differences — and
-        // then read lane by lane: a term is a v_readlane instead of four dependent LDS reads per spacer (20 k of the QC's 128 k
-        // cycles for an array of 36 repeats)
-        for (int c0 = 0; c0 < nsp; c0 += WAVE) {
+        for (int c0 = 0; c0 + 1 < nsp; c0 += WAVE) {
             const int i = c0 + lane;
-            const bool vi = i < nsp, vc = i + 1 < nsp;
-            uint32_t cur_len = 0, nxt_len = 0;
-            bool bad = false;
-            if (vi) { const uint32_t cs = h.ss[2 * i + 1] + 1; bad = !substr_len(h.L, cs, h.ss[2 * i + 2] - cs, cur_len); }
-            if (vc) { const uint32_t ns = h.ss[2 * i + 3] + 1; bad = bad || !substr_len(h.L, ns, h.ss[2 * i + 4] - ns, nxt_len); }
-            if (__ballot(bad)) return -1;
+            const bool vc = i + 1 < nsp;
             const float t_rs = vc ? h.sims[2 * i] : 0.0f, t_ss = vc ? h.sims[2 * i + 1] : 0.0f;
-            const float t_ssl = (float)cur_len - (float)nxt_len, t_rsl = (float)rep_len - (float)cur_len;
-            int mn = vi ? (int)cur_len : 10000000, mx = vi ? (int)cur_len : 0;
-            for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off)); mx = max(mx, __shfl_xor(mx, off)); }
-            if (mn < min_spacer_length) min_spacer_length = mn;
-            if (mx > max_spacer_length) max_spacer_length = mx;
-            const int i_end = min(c0 + WAVE, nsp - 1);                 // comparisons i = c0 .. i_end - 1 (i + 1 < nsp)
+            const int i_end = min(c0 + WAVE, nsp - 1);
             for (int ii = c0; ii < i_end; ii++) {
                 const int src = ii - c0;
-                num_compared++;
                 ave_repeat_to_spacer_difference += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_rs), src));
                 float ss_diff = 0;
                 ss_diff += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_ss), src));
                 ave_spacer_to_spacer_difference += ss_diff;
-                ave_spacer_to_spacer_len_difference += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_ssl), src));
-                ave_repeat_to_spacer_len_difference += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_rsl), src));
             }
         }
         wave_sync();
-        // num_compared == nsp-1 >= 1 here (the reference's num_compared == 0 branch needs <2 spacers)
         ave_spacer_to_spacer_difference /= (float)num_compared;
         ave_repeat_to_spacer_difference /= (float)num_compared;
-        ave_spacer_to_spacer_len_difference /= (float)num_compared;
-        ave_spacer_to_spacer_len_difference = fabsf(ave_spacer_to_spacer_len_difference);
-        ave_repeat_to_spacer_len_difference /= (float)num_compared;
-        ave_repeat_to_spacer_len_difference = fabsf(ave_repeat_to_spacer_len_difference);
-        if (min_spacer_length < minSpacerLength) return 0;                 // testSpacerLength :773-800
-        if (max_spacer_length > maxSpacerLength) return 0;
         if ((double)ave_spacer_to_spacer_difference > 0.82) return 0;      // :802-834
         if ((double)ave_repeat_to_spacer_difference > 0.82) return 0;
-        if ((int)ave_spacer_to_spacer_len_difference > 12) return 0;       // int parameter: truncation (:836)
-        if ((int)ave_repeat_to_spacer_len_difference > 30) return 0;       // (:853)
     }
     if (is_short) {
         // spacerStringAt(0), ReadHolder.cpp:102-147 — one base short
@@ -1793,6 +1805,9 @@ static __device__ void load_read_to_lds(const DevReads &R, uint64_t r, uint8_t *
             if (lane == 0) { int b_ = 63 - __clzll((long long)((tot_) | 1ull)) - 8; b_ = b_ < 0 ? 0 : (b_ >= PF_BINS ? PF_BINS - 1 : b_); h.lprof[5 * PF_SLOTS + (cat_) * PF_BINS + b_] += 1ull; } \
             wave_sync(); } while (0)
 #define PROF_WAVE_FLUSH() do { if (h.lprof) { wave_sync(); \
+            if (lane == 0) { atomicAdd(P.prof + 190, (unsigned long long)__builtin_readcyclecounter() - wave_c0); atomicAdd(P.prof + 191, (unsigned long long)__builtin_amdgcn_s_memrealtime() - wave_r0); \
+                             atomicMax(P.prof + 189, (unsigned long long)__builtin_amdgcn_s_memrealtime()); atomicAdd(P.prof + 186, 1ull); \
+                             if (blockIdx.x < 16384) P.prof[193 + 2 * blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); } \
             for (int q_ = lane; q_ < 4 * PF_SLOTS + 4 * PF_BINS; q_ += WAVE) { \
                 const unsigned long long v_ = h.lprof[PF_SLOTS + q_]; \
                 if (v_) { if (q_ < 4 * PF_SLOTS && (q_ % PF_SLOTS) == PF_MAX) atomicMax(P.prof + q_, v_); else atomicAdd(P.prof + q_, v_); } } } } while (0)
@@ -1803,7 +1818,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
                                                    const uint32_t *d_n_surv, uint64_t n_max, SurvOut *out,
                                                    char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                                    uint32_t ss_pool_cap, uint32_t *d_ss_used,
-                                                   uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds, int punt_only, uint64_t slot_base, uint64_t slot_total)
+                                                   uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds, int punt_only, uint64_t slot_base, uint64_t slot_total,
+                                                   const uint32_t *punt_list, const uint32_t *d_punt_n)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sv_lds[];
     const int lane = threadIdx.x;
@@ -1823,17 +1839,32 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     // diagnostics: the launch was given PF_SLOTS x 8 more bytes of LDS behind the layout (launch_survivor)
     h.lprof = P.prof ? reinterpret_cast<unsigned long long *>(sv_lds + ((lds.total_bytes + 7u) & ~7u)) : nullptr;
     if (h.lprof) { for (int q = lane; q < PF_LDS_WORDS; q += WAVE) h.lprof[q] = 0ull; wave_sync(); }
+    // (the wave's lifetime on both clocks: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz — their ratio is the
+    // clock the launch really ran at; slots 190 / 191 of the counters)
+    const unsigned long long wave_c0 = h.lprof ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+    const unsigned long long wave_r0 = h.lprof ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : 0ull;
+    if (h.lprof && lane == 0) { atomicMin(P.prof + 188, wave_r0); atomicMax(P.prof + 187, wave_r0); }      // first and last wave START
+    if (h.lprof && lane == 0 && blockIdx.x < 16384) P.prof[192 + 2 * blockIdx.x] = wave_r0;
     // EXC with punt_only == 5: exception reads that sit in the survivor list (slot s, read surv_idx[s])
     uint64_t n_surv = (EXC && punt_only != 5) ? R.n_exc : (uint64_t)(*d_n_surv);
     if (n_surv > n_max) n_surv = n_max;
     // punt mode: only the reads an earlier launch handed over (err == punt_only: 4 from the lane kernel, 6 = row buffer).  Each wave looks at 64 slots at once and
     // then walks the (rare) flagged ones, instead of every wave polling its slots one dependent load at a time.
+    // ... or, with punt_list, exactly the slots on that list (k_long_light's hand-overs, in any order: every result is addressed by
+    // its slot), dealt out one at a time over a grid of resident waves — 64 slots per wave left a wave anything from none to a dozen
+    // array reads and the launch took twice its share (3.2 ms for 51 k reads at 10 kbp)
     uint64_t punt_base = (uint64_t)blockIdx.x * WAVE, punt_mask = 0;
+    uint64_t lp = blockIdx.x;
+    const uint64_t n_list = punt_list ? (uint64_t)(*d_punt_n) : 0;
     ReadPrefetch pf;
     pf.r = ~0ull;
     uint64_t next_s = ~0ull, next_r = 0;
     for (uint64_t s = blockIdx.x;; ) {
-        if (punt_only) {
+        if (punt_only && punt_list) {
+            if (lp >= n_list) { PROF_WAVE_FLUSH(); return; }
+            s = punt_list[lp];
+            lp += gridDim.x;
+        } else if (punt_only) {
             while (punt_mask == 0) {
                 if (punt_base >= n_surv) { PROF_WAVE_FLUSH(); return; }
                 const uint64_t q = punt_base + lane;
@@ -1896,6 +1927,11 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
                 const uint64_t r2 = surv_idx ? surv_idx[s + gridDim.x] : s + gridDim.x + slot_base;
                 next_s = s + gridDim.x; next_r = r2;
                 if (!R.n_exc || !rd_is_exc(R, r2)) prefetch_read(R, r2, lane, pf);
+            } else if (punt_only && punt_list && lp < n_list) { // (list mode: the slot after this one is known as well)
+                const uint64_t s2 = punt_list[lp];
+                const uint64_t r2 = surv_idx ? surv_idx[s2] : s2 + slot_base;
+                next_s = s2; next_r = r2;
+                prefetch_read(R, r2, lane, pf);
             }
             if (no_seed) {
                 if (lane == 0) { SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = 0; out[s] = x; }
@@ -1952,9 +1988,201 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             const unsigned long long tot = (unsigned long long)__builtin_readcyclecounter() - prof_t0;
             const int cat = o.err ? 3 : (o.found ? 2 : 1);
             PROF_READ_DONE(cat, tot);
+            if (lane == 0) atomicMax(P.prof + 185, (tot << 24) | (unsigned long long)((s + slot_base) & 0xFFFFFFull));      // the slowest read's slot
         }
         if (!punt_only) s += gridDim.x;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Long reads, the LIGHT walk.  19 reads in 20 of a long-read set hold no array: their searchCore (libcrispr.cpp:265-395) is a
+// walk over ~1 250 seeds of which one or two have a chance copy in range, a two-repeat candidate that the extension rejects, a
+// move to another residue class (:390) and more walking.  The full wave kernel above spends 34 k cycles on such a read — all of
+// it dependent latency (LDS round trips, fenced list appends, vector arithmetic on wave-uniform values) at three waves per SIMD,
+// because it carries the QC, the Levenshtein rows, the ASCII window and a start/stop list for the one read in 20 that needs them.
+// This kernel is that walk alone: the read's packed words in LDS (2.5 KB at 10 kbp, nothing else), the CURRENT residue class's
+// hint words in registers (lane l: words base + l, base + l + 64, ...; the lattice class from k_hint_positions, any other
+// computed here 64 words at a time as the walk reaches them), a candidate's two repeats in scalar registers, the two-repeat
+// extension in closed form.  Whatever needs more — a third repeat (an array), a candidate due for qcFoundRepeats, a read beyond
+// 12 288 bases, an error path — is HANDED OVER (err = 7) to k_survivor<false>, which redoes that read from its first base with
+// the reference's full control flow.  A read that is not handed over is decided here: not found.
+// ------------------------------------------------------------------------------------
+#define LL_HW 3                                   // hint words per lane: 192 per read = 12 288 bases
+#define LL_VEC 3                                  // 16-byte word groups per lane: 768 words
+struct LightPrefetch { uint4 v[LL_VEC]; uint64_t hw[LL_HW]; };
+
+static __device__ __forceinline__ void ll_prefetch(const DevReads &R, uint64_t r, int lane, LightPrefetch &pf)
+{
+    const uint32_t *g = R.packed + rd_word_off(R, r);
+    const int L = (int)rd_len(R, r);
+    const int nw = (L + 15) >> 4, nh = (L + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < LL_VEC; i++) pf.v[i] = sv_load_group(g, lane + i * WAVE, nw);
+    const uint64_t *ph = R.pos_hint + rd_hint_off(R, r);
+#pragma unroll
+    for (int i = 0; i < LL_HW; i++) { const int wi = lane + i * WAVE; pf.hw[i] = wi < nh ? ph[wi] : 0ull; }
+}
+
+// first hinted position >= j among the hint words held in registers (word cur_base + lane + 64 i in cur[i], the first `done`
+// words valid), 0xFFFFFFFF if none
+static __device__ __forceinline__ uint32_t ll_next_hinted(const uint64_t (&cur)[LL_HW], uint32_t cur_base, uint32_t done, uint32_t j, int lane)
+{
+    const uint32_t jw = j >> 6;
+#pragma unroll
+    for (int i = 0; i < LL_HW; i++) {
+        if (64u * (uint32_t)i >= done) break;                                   // (wave-uniform)
+        if (cur_base + 64u * (uint32_t)i + 63u < jw) continue;
+        const uint32_t t = cur_base + 64u * (uint32_t)i + (uint32_t)lane;
+        uint64_t m = (64u * (uint32_t)i + (uint32_t)lane < done) ? cur[i] : 0ull;
+        if (t < jw) m = 0ull;
+        else if (t == jw) m &= ~0ull << (j & 63u);
+        const uint64_t b = __ballot(m != 0ull);
+        if (b) {
+            const int l0 = __ffsll((unsigned long long)b) - 1;
+            const uint64_t mm = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(m >> 32), l0) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)m, l0);
+            return (cur_base + 64u * (uint32_t)i + (uint32_t)l0) * 64u + (uint32_t)(__ffsll((unsigned long long)mm) - 1);
+        }
+    }
+    return 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
+                                                     uint32_t *punt_list, uint32_t *d_punt_n)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t ll_words[];
+    const int lane = threadIdx.x;
+    uint64_t n = (uint64_t)(*d_n);
+    if (n > n_max) n = n_max;
+    const uint32_t cmask = (1u << (2 * P.window)) - 1u;
+    const int w = (int)P.window;
+    LightPrefetch pf;
+    if (blockIdx.x < n) ll_prefetch(R, blockIdx.x + slot_base, lane, pf);
+    for (uint64_t s = blockIdx.x; s < n; s += gridDim.x) {
+        const uint64_t r = s + slot_base;
+        const int L = (int)rd_len(R, r);
+        const int nw = (L + 15) >> 4, nh = (L + 63) >> 6;
+        uint64_t cur[LL_HW];
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < LL_HW; i++) { cur[i] = pf.hw[i]; any |= cur[i] != 0ull; }
+        const bool too_long = nh > LL_HW * WAVE;
+        const bool seeds = __ballot(any) != 0ull;
+        uint8_t verdict = 0;                                                     // 0: searchCore returns false; 7: handed over
+        if (too_long) verdict = 7;
+        wave_sync();                                                             // (the previous read's LDS accesses are done)
+        if (seeds && !too_long) {
+            const int ng = (nw + 4) >> 2;                                        // groups up to the one that holds word nw (= 0)
+            uint4 *w4 = reinterpret_cast<uint4 *>(ll_words);
+#pragma unroll
+            for (int i = 0; i < LL_VEC; i++) { const int gi = lane + i * WAVE; if (gi < ng) w4[gi] = pf.v[i]; }
+        }
+        if (s + gridDim.x < n) ll_prefetch(R, r + gridDim.x, lane, pf);          // the next read travels during this one's walk
+        if (seeds && !too_long) {
+            wave_sync();
+            const uint32_t seq_length = (uint32_t)L;
+            const int searchEnd = (int)(seq_length - P.lowDR - P.lowSp - P.window - 1);
+            uint32_t j = 0, rho = 0, cur_base = 0, done = (uint32_t)nh;          // the lattice class: every word is there
+            const uint32_t n_hw = searchEnd >= 0 ? ((uint32_t)searchEnd >> 6) + 1u : 0u;      // hint words that hold a seed
+            while (searchEnd >= 0 && j <= (uint32_t)searchEnd) {
+                // the class's hint words are computed 64 at a time, when the walk gets there (a class is left again after
+                // 4 000 bases one time in three: most of a class's words would never be looked at)
+                uint32_t p = ll_next_hinted(cur, cur_base, done, j, lane);
+                while (p == 0xFFFFFFFFu && cur_base + done < n_hw && done < 64u * LL_HW) {
+                    const uint32_t t = cur_base + done + (uint32_t)lane;
+                    uint64_t bits = 0ull;
+                    if (t < (uint32_t)nh) {
+                        uint32_t ww[13];
+#pragma unroll
+                        for (int i = 0; i < 13; i++) { const uint32_t wi = 4u * t + (uint32_t)i; ww[i] = wi < (uint32_t)nw ? ll_words[wi] : 0u; }
+                        bits = hint_bits_class(ww, rho);
+                    }
+                    const uint32_t round = done >> 6;
+#pragma unroll
+                    for (int i = 0; i < LL_HW; i++) if ((uint32_t)i == round) cur[i] = bits;
+                    done += 64u;
+                    p = ll_next_hinted(cur, cur_base, done, j, lane);
+                }
+                if (p == 0xFFFFFFFFu || p > (uint32_t)searchEnd) break;         // no seed left: false
+                j = p;
+                uint32_t beginSearch = j + P.lowDR + P.lowSp;
+                uint32_t endSearch = j + P.highDR + P.highSp + P.window;
+                if (endSearch >= seq_length) endSearch = seq_length - 1;
+                if (endSearch < beginSearch) endSearch = beginSearch;
+                if (beginSearch > seq_length) { verdict = 7; break; }            // (the reference throws here: the full kernel reports it)
+                const int pos = wave_find_packed(ll_words, cmask, (int)beginSearch, (int)endSearch, (int)j, w, lane);
+                if (pos < 0) { j += P.skips; continue; }                         // (the hints are a superset)
+                // two repeats at j and pos.  scanRight's first link (libcrispr.cpp:170-263): a third repeat means an array
+                {
+                    const uint32_t last = (uint32_t)pos, spacing = last - j;
+                    const int cand = (int)(last + spacing);
+                    uint32_t b3 = (uint32_t)cand - 24u, e3 = (uint32_t)cand + (uint32_t)w + 24u;
+                    const uint32_t minb = last + (uint32_t)w + P.lowSp;
+                    if (b3 < minb) b3 = minb;
+                    if (b3 <= seq_length - 1) {
+                        if (e3 > seq_length) e3 = seq_length;
+                        if (b3 < e3 && wave_find_packed(ll_words, cmask, (int)b3, (int)e3, (int)j, w, lane) >= 0) { verdict = 7; break; }
+                    }
+                }
+                if (2u < P.minRepeats) { j += P.skips; continue; }               // (-n 3 and up: two repeats are not a candidate)
+                // extendPreRepeat for two repeats, closed form (extend_pre_repeat_packed / ln_extend2)
+                uint32_t right, left;
+                {
+                    const int jj = (int)j, pp = pos, spacing = pp - jj;
+                    int max_right = spacing - (int)P.lowSp;
+                    if (max_right > L - (pp + w)) max_right = L - (pp + w);
+                    int rr = 0;
+                    while (rr < max_right) {
+                        uint64_t a0, a1, b0, b1;
+                        wv_load128(ll_words, jj + w + rr, a0, a1); wv_load128(ll_words, pp + w + rr, b0, b1);
+                        const int nn = max_right - rr < 64 ? max_right - rr : 64;
+                        const int q = uni(ln_run_up(a0 ^ b0, a1 ^ b1, nn));
+                        rr += q;
+                        if (q < nn) break;
+                    }
+                    int max_left = spacing - (w + rr);
+                    if (max_left < 0) max_left = 0;
+                    if (max_left > jj) max_left = jj;
+                    int ll = 0;
+                    while (ll < max_left) {
+                        const int nn = max_left - ll < 64 ? max_left - ll : 64;
+                        uint64_t a0, a1, b0, b1;
+                        wv_load128(ll_words, jj - ll - nn, a0, a1); wv_load128(ll_words, pp - ll - nn, b0, b1);
+                        const int q = uni(ln_run_down(a0 ^ b0, a1 ^ b1, nn));
+                        ll += q;
+                        if (q < nn) break;
+                    }
+                    right = (uint32_t)rr; left = (uint32_t)ll;
+                }
+                const uint32_t replen = (uint32_t)w + right + left;
+                if (replen >= P.lowDR && replen <= P.highDR) { verdict = 7; break; }          // due for qcFoundRepeats
+                // rejected: on behind the last repeat's (extended, clamped) end (:390)
+                uint32_t last_end = (uint32_t)pos + (uint32_t)w - 1u;
+                if (last_end >= seq_length) last_end = seq_length - 1;                       // (startStopsAdd's clamp)
+                last_end = (last_end + right >= seq_length) ? seq_length - 1 : last_end + right;
+                j = last_end - 1u + P.skips;
+                if ((j & 7u) != rho) { rho = j & 7u; cur_base = j >> 6; done = 0u; }
+            }
+        }
+        if (lane == 0) {
+            SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = verdict; out[s] = x;
+            if (verdict == 7) punt_list[atomicAdd(d_punt_n, 1u)] = (uint32_t)(s + slot_base);     // (the slot in the whole set's numbering)
+        }
+    }
+}
+
+hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
+                             uint32_t max_len, hipStream_t st, uint32_t *punt_list, uint32_t *d_punt_n)
+{
+    if (n_max == 0) return hipSuccess;
+    if (P.skips != 8 || !R.pos_hint || P.window > 9) return hipErrorNotSupported;
+    const uint32_t words_cap = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
+    const uint32_t lds_bytes = (words_cap + 16u) * 4u;                           // (+ the words a 128-base piece reads past the read's last)
+    const int grid = (int)std::min<uint64_t>(n_max, 256 * 32);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_long_light), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    CRASS_LAUNCH(k_long_light, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n);
+    return hipGetLastError();
 }
 
 
@@ -3151,7 +3379,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            const uint32_t *d_n_surv, uint64_t n_surv_max, SurvOut *out, char *dr_chars,
                            uint32_t dr_stride, uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
                            uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
-                           int punt_only, uint64_t slot_base, uint64_t slot_total)
+                           int punt_only, uint64_t slot_base, uint64_t slot_total, const uint32_t *punt_list, const uint32_t *d_punt_n)
 {
     if (n_surv_max == 0) return hipSuccess;
     hipError_t e;
@@ -3160,12 +3388,18 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         CRASS_LAUNCH(k_survivor<true>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total, punt_list, d_punt_n);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
+        static const bool occ_dbg = getenv("CRASS_OCC_DEBUG") != nullptr;
+        if (occ_dbg) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_survivor<false>), WAVE, lds_bytes);
+            fprintf(stderr, "[occ] k_survivor<false>: %d blocks per CU with %u bytes of LDS, grid %d, punt %d\n", nb, lds_bytes, grid, punt_only);
+        }
         CRASS_LAUNCH(k_survivor<false>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total, punt_list, d_punt_n);
     }
     return hipGetLastError();
 }
