@@ -495,8 +495,28 @@ def main():
         m = min(cpu_sample, n)
         asc = ca.unpack_ascii(words, W, L, m)
         off = np.arange(0, (m + 1) * L, L, dtype=np.uint64)
-        r = orc.pipeline_time(asc, off)
+        r = orc.pipeline_time_keep(asc, off)
         cpu_s = r["t_pass1"] + r["t_merge"] + r["t_pass2"]
+        # ---- parity gate (a number only counts with it): the HIP path over the SAME prefix, on a fresh context,
+        #      against the oracle run that was just timed — every record, token, group and pattern (tests/parity.py).  A mismatch
+        #      is printed in the line and the run exits non-zero. ----
+        try:
+            from tests.parity import assert_same_pipeline
+            e2 = ca.SearchEngine(device=local_rank)
+            e2.load_packed_uniform(words[:m * W], m, L)
+            cand = e2.seed_scan(); mg = e2.merge(); rec = e2.recruit(); mg = e2.merge_view()
+            gpu_res = ca.engine.PipelineResult(cand, mg, rec, cand.max_read_len)
+            e2.close()
+            try:
+                assert_same_pipeline(gpu_res, r["result"])
+                out["parity_checked"] = {"reads": int(m), "equal": True, "pass1_records": int(gpu_res.n_pass1), "pass2_records": int(gpu_res.n_pass2),
+                                         "tokens": int(gpu_res.n_tokens), "groups": int(gpu_res.n_groups), "patterns": int(gpu_res.n_patterns),
+                                         "what": "HIP path == oracle (the cpu_baseline run itself) on the sample's reads: every record field, token, group, pattern in order"}
+            except AssertionError as ex:
+                out["parity_checked"] = {"reads": int(m), "equal": False, "first_difference": str(ex)[:400]}
+        except Exception as ex:                              # (the check could not run: said so, not passed off as equal)
+            out["parity_checked"] = {"reads": int(m), "equal": None, "error": str(ex)[:400]}
+        del r["result"]
         out["cpu_baseline"] = {"value": round(m / cpu_s, 1), "unit": "reads/s", "cores": 1, "kind": "port",
                                "sample": "first %d reads of the same synthetic stream; pass1 %.2fs merge %.2fs pass2 %.2fs"
                                          % (m, r["t_pass1"], r["t_merge"], r["t_pass2"]),
@@ -551,6 +571,9 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and out.get("parity_checked", {}).get("equal") is False:
+        print("bench.py: the HIP path's results differ from the oracle's on the sample: %s" % out["parity_checked"].get("first_difference"), file=sys.stderr)
+        sys.exit(4)
 
 
 class _GroupRunner:

@@ -1446,6 +1446,8 @@ static __device__ void scan_right_masks(RH &h, int pat, uint32_t pattern_length,
     uint64_t mask = 0;
     int nss = h.nss;
     for (;;) {
+        // (the chain's state is the same in every lane; said once per link it stays on the scalar unit)
+        last_repeat_index = uni(last_repeat_index); repeat_spacing = uni(repeat_spacing); base = uni(base); nss = uni(nss);
         const int candidate_repeat_index = (int)(last_repeat_index + repeat_spacing);
         uint32_t begin_search = (uint32_t)candidate_repeat_index - scanRange;
         uint32_t end_search = (uint32_t)candidate_repeat_index + pattern_length + scanRange;
@@ -1545,6 +1547,7 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
     bool on_lattice = true;
     uint32_t lattice_i = 0;
     for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
+        j = uni(j);
         PROF_CNT(h, PF_N_ITER);
         if (pos_hint) {
             PROF_T0(h);
@@ -1740,7 +1743,7 @@ static __device__ __forceinline__ uint4 sv_load_group(const uint32_t *g, int gi,
 static __device__ __forceinline__ void prefetch_read(const DevReads &R, uint64_t r, int lane, ReadPrefetch &pf)
 {
     const uint32_t *g = R.packed + rd_word_off(R, r);
-    const int L = (int)rd_len(R, r);
+    const int L = (int)uni(rd_len(R, r));
     const int nw = (L + 15) >> 4;
 #pragma unroll
     for (int i = 0; i < SV_PREFETCH_VEC; i++) pf.v[i] = sv_load_group(g, lane + i * WAVE, nw);
@@ -1862,7 +1865,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     for (uint64_t s = blockIdx.x;; ) {
         if (punt_only && punt_list) {
             if (lp >= n_list) { PROF_WAVE_FLUSH(); return; }
-            s = punt_list[lp];
+            s = uni(punt_list[lp]);
             lp += gridDim.x;
         } else if (punt_only) {
             while (punt_mask == 0) {
@@ -1885,23 +1888,23 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         if (EXC) {
             uint64_t e = s;
             if (punt_only == 5) {
-                r = surv_idx[s];
+                r = uni64(surv_idx[s]);
                 uint64_t lo = 0, hi = R.n_exc;                  // exc_read[] is ascending: first entry >= r is r itself
                 while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (R.exc_read[mid] < r) lo = mid + 1; else hi = mid; }
                 e = lo;
-            } else r = R.exc_read[s];
-            uint64_t o0 = R.exc_off[e];
-            L = (int)(R.exc_off[e + 1] - o0);
+            } else r = uni64(R.exc_read[s]);
+            uint64_t o0 = uni64(R.exc_off[e]);
+            L = (int)uni((uint32_t)(R.exc_off[e + 1] - o0));
             for (int i = lane; i < L; i += WAVE) h.seq[i] = R.exc_bytes[o0 + i];
         } else {
             // (surv_idx == nullptr: the list is 0, 1, 2, ... — a long-read set without exception reads, every read survives)
-            r = (next_s == s) ? next_r : (surv_idx ? surv_idx[s] : s + slot_base);           // (the prefetch below already looked it up)
+            r = (next_s == s) ? next_r : (surv_idx ? uni64(surv_idx[s]) : s + slot_base);    // (the prefetch below already looked it up)
             if (!punt_only && R.n_exc && rd_is_exc(R, r)) {     // left to the exception pass
                 if (lane == 0) { SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = 5; out[s] = x; }
                 s += gridDim.x;
                 continue;
             }
-            L = (int)rd_len(R, r);
+            L = (int)uni(rd_len(R, r));
             // long reads: a read without a single hinted LATTICE seed (39 % of random 10 kbp reads) never leaves the lattice and
             // searchCore returns false without having looked at a base — neither does this wave (no 10 KB of LDS to fill)
             bool no_seed = false;
@@ -1924,12 +1927,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             }
             pf.r = ~0ull;
             if (!punt_only && s + gridDim.x < n_surv) {         // the next read of this wave: its words travel during the search
-                const uint64_t r2 = surv_idx ? surv_idx[s + gridDim.x] : s + gridDim.x + slot_base;
+                const uint64_t r2 = surv_idx ? uni64(surv_idx[s + gridDim.x]) : s + gridDim.x + slot_base;
                 next_s = s + gridDim.x; next_r = r2;
                 if (!R.n_exc || !rd_is_exc(R, r2)) prefetch_read(R, r2, lane, pf);
             } else if (punt_only && punt_list && lp < n_list) { // (list mode: the slot after this one is known as well)
-                const uint64_t s2 = punt_list[lp];
-                const uint64_t r2 = surv_idx ? surv_idx[s2] : s2 + slot_base;
+                const uint64_t s2 = uni(punt_list[lp]);
+                const uint64_t r2 = surv_idx ? uni64(surv_idx[s2]) : s2 + slot_base;
                 next_s = s2; next_r = r2;
                 prefetch_read(R, r2, lane, pf);
             }
@@ -2014,7 +2017,7 @@ struct LightPrefetch { uint4 v[LL_VEC]; uint64_t hw[LL_HW]; };
 static __device__ __forceinline__ void ll_prefetch(const DevReads &R, uint64_t r, int lane, LightPrefetch &pf)
 {
     const uint32_t *g = R.packed + rd_word_off(R, r);
-    const int L = (int)rd_len(R, r);
+    const int L = (int)uni(rd_len(R, r));
     const int nw = (L + 15) >> 4, nh = (L + 63) >> 6;
 #pragma unroll
     for (int i = 0; i < LL_VEC; i++) pf.v[i] = sv_load_group(g, lane + i * WAVE, nw);
@@ -2060,7 +2063,7 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
     if (blockIdx.x < n) ll_prefetch(R, blockIdx.x + slot_base, lane, pf);
     for (uint64_t s = blockIdx.x; s < n; s += gridDim.x) {
         const uint64_t r = s + slot_base;
-        const int L = (int)rd_len(R, r);
+        const int L = (int)uni(rd_len(R, r));
         const int nw = (L + 15) >> 4, nh = (L + 63) >> 6;
         uint64_t cur[LL_HW];
         bool any = false;
@@ -2085,6 +2088,7 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
             uint32_t j = 0, rho = 0, cur_base = 0, done = (uint32_t)nh;          // the lattice class: every word is there
             const uint32_t n_hw = searchEnd >= 0 ? ((uint32_t)searchEnd >> 6) + 1u : 0u;      // hint words that hold a seed
             while (searchEnd >= 0 && j <= (uint32_t)searchEnd) {
+                j = uni(j); rho = uni(rho); cur_base = uni(cur_base); done = uni(done);
                 // the class's hint words are computed 64 at a time, when the walk gets there (a class is left again after
                 // 4 000 bases one time in three: most of a class's words would never be looked at)
                 uint32_t p = ll_next_hinted(cur, cur_base, done, j, lane);
@@ -2110,7 +2114,7 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
                 if (endSearch >= seq_length) endSearch = seq_length - 1;
                 if (endSearch < beginSearch) endSearch = beginSearch;
                 if (beginSearch > seq_length) { verdict = 7; break; }            // (the reference throws here: the full kernel reports it)
-                const int pos = wave_find_packed(ll_words, cmask, (int)beginSearch, (int)endSearch, (int)j, w, lane);
+                const int pos = uni(wave_find_packed(ll_words, cmask, (int)beginSearch, (int)endSearch, (int)j, w, lane));
                 if (pos < 0) { j += P.skips; continue; }                         // (the hints are a superset)
                 // two repeats at j and pos.  scanRight's first link (libcrispr.cpp:170-263): a third repeat means an array
                 {

@@ -486,7 +486,10 @@ uint64_t crass_fastx_find(const crass_fastx *f, const char *name, uint64_t len);
  * marks the end of the file.  kseq's cross-record state travels with the stream (stale comment / quality buffers,
  * libcrispr.cpp:124-131).  With a name table, header_id[i] is the JOB-level index (index_base + records before it in this
  * stream) of the first read with the same header — across chunks and, with one table for several streams, across files
- * (readsFound is keyed by the header string, libcrispr.cpp:138,411); names are kept as 128-bit hashes only.              */
+ * (readsFound is keyed by the header string, libcrispr.cpp:138,411); names are kept as 128-bit hashes only (two independent
+ * 64-bit mixes, both stored and compared in full): two DIFFERENT headers of a job of n reads are taken for one with probability
+ * ~ n^2 / 2^129 (1.5e-23 at n = 1e8) — the one place of the path that is exact with that probability rather than by
+ * construction; crass_read_fastx (whole-file) compares the header strings themselves.                                       */
 typedef struct crass_name_table crass_name_table;
 typedef struct crass_fastx_stream crass_fastx_stream;
 crass_name_table *crass_name_table_create(void);

@@ -1034,6 +1034,17 @@ int orc_pipeline_time(const char *seqs, const uint64_t *seq_off, uint64_t n_read
     return err;
 }
 
+/* the timed run that also hands its result back (bench.py compares the HIP path's records with it: the parity check costs no
+ * second oracle run); the caller frees it with orc_result_free */
+orc_result *orc_pipeline_time_keep(const char *seqs, const uint64_t *seq_off, uint64_t n_reads,
+                                   const orc_params *p, double *t_pass1, double *t_merge, double *t_pass2)
+{
+    double tm[3];
+    orc_result *r = pipeline(seqs, seq_off, n_reads, NULL, NULL, p, 1, tm);
+    *t_pass1 = tm[0]; *t_merge = tm[1]; *t_pass2 = tm[2];
+    return r;
+}
+
 /* ---- CPU-baseline calibration (bench.py cpu_baseline.calibration, tools/calibrate_cpu.py) ----
  * The two hot loops of the reference on plain inputs, restated here with the oracle's leaf
  * functions; oracle/ref_shim.cpp holds the same two loops over the COMPILED reference leaves

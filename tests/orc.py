@@ -293,6 +293,23 @@ def pipeline_time(sbuf, soff, params=None):
                 n_pass1=n1.value, n_pass2=n2.value, n_patterns=npat.value)
 
 
+def pipeline_time_keep(sbuf, soff, params=None):
+    """pipeline_time that also returns the run's PipelineResult under "result" (the timed run IS the checker's run)"""
+    p = params or Params.default()
+    t = [C.c_double() for _ in range(3)]
+    L = lib()
+    L.orc_pipeline_time_keep.restype = C.c_void_p
+    r = L.orc_pipeline_time_keep(C.c_void_p(sbuf.ctypes.data), C.c_void_p(soff.ctypes.data), C.c_uint64(len(soff) - 1), C.byref(p),
+                                 C.byref(t[0]), C.byref(t[1]), C.byref(t[2]))
+    r = C.c_void_p(r)
+    v = View()
+    L.orc_result_view(r, C.byref(v))
+    out = PipelineResult(v)
+    L.orc_result_free(r)
+    return dict(error=out.error, t_pass1=t[0].value, t_merge=t[1].value, t_pass2=t[2].value,
+                n_pass1=out.n_pass1, n_pass2=out.n_pass2, n_patterns=out.n_patterns, result=out)
+
+
 def calibrate(asc, n, L, patterns, params=None):
     """Speed of the oracle's two hot leaf loops against the compiled reference's on the same reads
     (asc: uint8 [n*L], patterns: list[bytes]).  None when oracle/_ref is not available.

@@ -313,7 +313,9 @@ def test_long_reads_ragged_mid_size(ca):
     # the walking kernel's ASCII window (long reads: room for the region around a candidate's repeats, not for the read): with
     # 1 024 bytes every array beyond ~700 bases does not fit and goes to the second launch with the full layout; with the full
     # layout for everybody (the A/B switch) nothing does
-    for env in ({"CRASS_SEQ_WINDOW": "1024"}, {"CRASS_LONG_FULL_LAYOUT": "1"}):
+    # ... and without the light walk (k_long_light decides the reads without an array and hands the others to the wave kernel from
+    # a list): the wave kernel for every read, the A/B switch
+    for env in ({"CRASS_SEQ_WINDOW": "1024"}, {"CRASS_LONG_FULL_LAYOUT": "1"}, {"CRASS_NO_LIGHT": "1"}, {"CRASS_NO_LIGHT": "1", "CRASS_SEQ_WINDOW": "1024"}):
         os.environ.update(env)
         try:
             alt = ca.search_pipeline(seqs)

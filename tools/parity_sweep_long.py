@@ -63,11 +63,23 @@ for case in range(n_cases):
         env["CRASS_SEQ_WINDOW"] = rng.choice(["512", "1024", "2048"])
     elif r < 0.4:
         env["CRASS_LONG_FULL_LAYOUT"] = "1"
+    if rng.random() < 0.15:
+        env["CRASS_NO_LIGHT"] = "1"                          # the full wave kernel for every read (the A/B of k_long_light)
+    # a third of the cases with non-default options: any -w/-d/-D/-s/-S change drops the position hints and the
+    # light walk — the un-hinted wave kernel —, -n changes what is accepted only
+    kw = {}
+    if rng.random() < 0.33:
+        kw = rng.choice([dict(searchWindowLength=7), dict(searchWindowLength=6), dict(searchWindowLength=9), dict(lowDRsize=20, highDRsize=40),
+                         dict(lowSpacerSize=20, highSpacerSize=60), dict(minNumRepeats=3), dict(minNumRepeats=4), dict(searchWindowLength=9, minNumRepeats=3)])
+    params = ca.default_params(**kw) if kw else None
+    oparams = orc.Params(params.lowDRsize, params.highDRsize, params.lowSpacerSize, params.highSpacerSize, params.searchWindowLength,
+                         params.minNumRepeats, params.kmer_clust_size) if kw else None
     # a quarter of the cases through a group of 2-3 contexts sharing the GPU (contiguous shards, the exchange as device copies)
     grp = rng.choice([0, 0, 0, 2, 3]) if os.environ.get("LONG_SWEEP_GROUPS", "1") != "0" else 0
     fused = bool(grp) and rng.random() < 0.5
-    tag = "n=%d L=%d..%d%s n_dr=%d every=%d mut=%.2f N=%d grp=%d%s %s" % (n, lo, lo if uniform else hi, "u" if uniform else "", n_dr, every, mut, with_n,
-                                                                grp, "f" if fused else "", " ".join("%s=%s" % (k[6:], v) for k, v in sorted(env.items())))
+    tag = "n=%d L=%d..%d%s n_dr=%d every=%d mut=%.2f N=%d grp=%d%s %s %s" % (n, lo, lo if uniform else hi, "u" if uniform else "", n_dr, every, mut, with_n,
+                                                                grp, "f" if fused else "", " ".join("%s=%s" % (k[6:], v) for k, v in sorted(env.items())),
+                                                                ",".join("%s=%s" % kv for kv in kw.items()))
     only = os.environ.get("ONLY")
     if only and case not in {int(x) for x in only.split(",")}:
         continue
@@ -75,14 +87,14 @@ for case in range(n_cases):
     os.environ.update(env)
     try:
         if grp:
-            gpu = ca.search_pipeline_group(seqs, [0] * grp, local_copies=True, fused=fused)
+            gpu = ca.search_pipeline_group(seqs, [0] * grp, params=params, local_copies=True, fused=fused)
             gpu.counters = gpu.counters[0]
         else:
-            gpu = ca.search_pipeline(seqs)
+            gpu = ca.search_pipeline(seqs, params=params)
     finally:
         for k in env:
             os.environ.pop(k, None)
-    ref = orc.pipeline(seqs)
+    ref = orc.pipeline(seqs, params=oparams) if kw else orc.pipeline(seqs)
     try:
         assert_same_pipeline(gpu, ref)
         print("ok   %-78s pass1 %5d pass2 %5d groups %3d devmerge %d" % (tag, gpu.n_pass1, gpu.n_pass2, gpu.n_groups,
