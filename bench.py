@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--single-shots", type=int, default=3, help="N=1: fresh contexts timed for single_shot_ms (0 = skip)")
     ap.add_argument("--check", action="store_true", help="also verify the GPU result against the oracle on the CPU sample")
     ap.add_argument("--e2e-reads", type=int, default=-1, help="N=1: reads of the end-to-end command-line run reported as e2e_reads_per_s "
-                                                              "(FASTA on disk -> crass-hip -> output files; default 5 M for 150 bp configs, 0 = skip)")
+                                                              "(FASTA in tmpfs -> crass-hip -> output files; default for 150 bp configs: 50 M where the host has the memory, else 5 M; 0 = skip)")
     ap.add_argument("--launcher", default="group", choices=["group", "torch"],
                     help="N>1 from a plain interpreter: group = one process drives N contexts through crass_hip_group_* (C++ RCCL); "
                          "torch = one process per GPU over torch.distributed.  Under an external launcher (WORLD_SIZE set) always torch")
@@ -450,7 +450,7 @@ def main():
         out["abi_fetch"] = {"ms_all": [round(x, 3) for x in fetch], "candidates": nf[0], "tokens": nf[1], "recruits": nf[2],
                             "note": "crass_hip_get_candidates + crass_hip_get_merge + crass_hip_get_recruits after a step (median of 3): "
                                     "the per-record arrays of the ABI, widened from the step's compact blobs; not part of `value`"}
-        e2e_n = args.e2e_reads if args.e2e_reads >= 0 else (5_000_000 if L <= 300 and not custom else 0)
+        e2e_n = args.e2e_reads if args.e2e_reads >= 0 else (_e2e_default_reads(L) if L <= 300 and not custom else 0)
         if e2e_n > 0 and rank == 0:
             out["e2e"] = _e2e_cli(ca, spec, L, min(e2e_n, total))
             if "reads_per_s" in out["e2e"]:
@@ -605,53 +605,105 @@ class _GroupRunner:
         self.g.close()
 
 
-def _e2e_cli(ca, spec, L, n):
-    """End to end through the command line (tools/e2e_cli.sh in one function): a FASTA file of n reads of the SAME synthetic stream
-    on disk -> `crass-hip -g -o DIR` (read + parse + pack + H2D + pass 1 + merge + pass 2 + hand-off + consensus + spacer graphs +
-    .crispr / Group_*.fa written), wall clock of the whole process incl. HIP start-up, best of 2; peak RSS of the child."""
+def _e2e_dir(need_bytes):
+    """where the end-to-end input goes: tmpfs when it has the room (an 8 GB input should be read from memory, not from a disk of
+    unknown speed), else the default temporary directory"""
+    import shutil
+    try:
+        if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * need_bytes + (4 << 30):
+            return "/dev/shm"
+    except OSError:
+        pass
+    return None
+
+
+def _e2e_default_reads(L):
+    """the metric's own configuration is 100 M reads; the end-to-end leg takes 50 M of them (an 8 GB FASTA) when the host has the
+    memory (input in tmpfs + the reader's working set) and falls back to 5 M otherwise"""
+    try:
+        avail = 0
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) << 10
+        big = 50_000_000
+        if avail > 96 << 30 and _e2e_dir(big * (11 + L)) == "/dev/shm":
+            return big
+    except (OSError, ValueError):
+        pass
+    return 5_000_000
+
+
+def _e2e_cli(ca, spec, L, n, modes=("auto",)):
+    """End to end through the command line: a FASTA file of n reads of the SAME synthetic stream (written in blocks of 5 M reads,
+    into tmpfs when it has the room) -> `crass-hip -g -o DIR` (read + parse + pack + H2D + pass 1 + merge + pass 2 + hand-off +
+    consensus + spacer graphs + .crispr / Group_*.fa written), wall clock of the whole process incl. HIP start-up, best of 2; peak
+    RSS of the child.  modes: "auto" (the command line's own choice of reader: the indexed one for a plain-text input), or
+    CRASS_INGEST values ("whole", "stream", "index") for the comparison tools/e2e_big.py prints."""
     import numpy as np
+    import re
     import shutil
     import tempfile
     cli = os.path.join(ROOT, "crass_amd", "crass-hip")
     if not os.path.exists(cli):
         return {"error": "crass_amd/crass-hip not built"}
-    td = tempfile.mkdtemp(prefix="crass_e2e_")
+    td = tempfile.mkdtemp(prefix="crass_e2e_", dir=_e2e_dir(n * (11 + L)))
     try:
-        w = ca.synth_packed(spec, 0, n)
-        asc = ca.unpack_ascii(w, (L + 15) // 16, L, n).reshape(n, L)
-        rec = np.empty((n, 10 + L + 1), np.uint8)
-        ids = np.char.zfill(np.arange(n).astype("S8"), 8)
-        rec[:, 0] = ord(">"); rec[:, 1:9] = np.frombuffer(ids.tobytes(), np.uint8).reshape(n, 8); rec[:, 9] = 10
-        rec[:, 10:10 + L] = asc; rec[:, 10 + L] = 10
         fa = os.path.join(td, "e2e.fa")
+        t_gen = time.perf_counter()
         with open(fa, "wb") as f:
-            f.write(rec.tobytes())
-        del rec, asc, w
-        walls, found, rss = [], None, 0.0
-        for _ in range(2):
-            od = os.path.join(td, "out")
-            shutil.rmtree(od, ignore_errors=True)
-            os.makedirs(od)
-            log = os.path.join(td, "stdout.txt")
-            t0 = time.perf_counter()
-            # (peak resident set: the command line's own VmHWM, printed with its stage times — the child's ru_maxrss would start from
-            # this process's resident set at fork time)
-            with open(log, "wb") as lf:
-                p = subprocess.run([cli, "-g", "-o", od, fa], stdout=lf, stderr=subprocess.STDOUT, env=dict(os.environ, CRASS_TIMING="1"))
-            walls.append(time.perf_counter() - t0)
-            if p.returncode != 0:
-                return {"error": "crass-hip exited %d" % p.returncode}
-            import re
-            for line in open(log, "rb").read().decode().replace("\r", "\n").splitlines():
-                if "Found" in line and "reads" in line:
-                    found = line.strip()
-                m = re.search(r"peak RSS (\d+) MB", line)
-                if m:
-                    rss = max(rss, float(m.group(1)))
-        return {"reads": n, "wall_s": round(min(walls), 3), "reads_per_s": round(n / min(walls), 1), "walls_s": [round(x, 3) for x in walls],
-                "peak_rss_mb": round(rss, 1), "fasta_mb": round(n * (11 + L) / 1e6, 1), "found": found,
-                "note": "`crass-hip -g -o DIR file.fa`: process start + HIP init + read/parse/pack + H2D + pass 1 + merge + pass 2 + "
-                        "hand-off + consensus + spacer graphs + output files; PCIe- and parse-inclusive, never part of `value`"}
+            for first in range(0, n, 5_000_000):
+                m = min(5_000_000, n - first)
+                w = ca.synth_packed(spec, first, m)
+                asc = ca.unpack_ascii(w, (L + 15) // 16, L, m).reshape(m, L)
+                rec = np.empty((m, 10 + L + 1), np.uint8)
+                ids = np.char.zfill(np.arange(first, first + m).astype("S8"), 8)
+                rec[:, 0] = ord(">"); rec[:, 1:9] = np.frombuffer(ids.tobytes(), np.uint8).reshape(m, 8); rec[:, 9] = 10
+                rec[:, 10:10 + L] = asc; rec[:, 10 + L] = 10
+                f.write(rec.tobytes())
+                del rec, asc, w
+        t_gen = time.perf_counter() - t_gen
+        res = {}
+        for mode in modes:
+            walls, found, rss, stages = [], None, 0.0, []
+            env = dict(os.environ, CRASS_TIMING="1")
+            env.pop("CRASS_INGEST", None)
+            if mode != "auto":
+                env["CRASS_INGEST"] = mode
+            for _ in range(2):
+                od = os.path.join(td, "out")
+                shutil.rmtree(od, ignore_errors=True)
+                os.makedirs(od)
+                log = os.path.join(td, "stdout.txt")
+                t0 = time.perf_counter()
+                # (peak resident set: the command line's own VmHWM, printed with its stage times — the child's ru_maxrss would start
+                # from this process's resident set at fork time)
+                with open(log, "wb") as lf:
+                    p = subprocess.run([cli, "-g", "-o", od, fa], stdout=lf, stderr=subprocess.STDOUT, env=env)
+                walls.append(time.perf_counter() - t0)
+                if p.returncode != 0:
+                    return {"error": "crass-hip exited %d (%s)" % (p.returncode, mode)}
+                stages = []
+                for line in open(log, "rb").read().decode().replace("\r", "\n").splitlines():
+                    if "Found" in line and "reads" in line:
+                        found = line.strip()
+                    m2 = re.search(r"peak RSS (\d+) MB", line)
+                    if m2:
+                        rss = max(rss, float(m2.group(1)))
+                    if "[crass_timing]" in line and ("fastx" in line or "searchAndRecruit:" in line or "cli:" in line):
+                        stages.append(line.strip()[15:])
+            res[mode] = {"wall_s": round(min(walls), 3), "reads_per_s": round(n / min(walls), 1), "walls_s": [round(x, 3) for x in walls],
+                         "peak_rss_mb": round(rss, 1), "found": found, "stages": stages}
+        first = res[modes[0]]
+        out = {"reads": n, "wall_s": first["wall_s"], "reads_per_s": first["reads_per_s"], "walls_s": first["walls_s"],
+               "peak_rss_mb": first["peak_rss_mb"], "fasta_mb": round(n * (11 + L) / 1e6, 1), "found": first["found"],
+               "input_dir": os.path.dirname(td), "input_written_s": round(t_gen, 1), "reader": modes[0],
+               "note": "`crass-hip -g -o DIR file.fa`: process start + HIP init + read/parse/pack + H2D + pass 1 + merge + pass 2 + "
+                       "hand-off + consensus + spacer graphs + output files; PCIe- and parse-inclusive, never part of `value`"}
+        if len(modes) > 1:
+            out["by_reader"] = res
+        else:
+            out["stages"] = first["stages"]
+        return out
     except Exception as ex:                          # a reported extra: never fails the run
         return {"error": str(ex)[:300]}
     finally:

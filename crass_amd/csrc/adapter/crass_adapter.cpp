@@ -3,6 +3,7 @@
 #include "crass_adapter.h"
 #include <chrono>
 #include <future>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 
@@ -548,14 +549,35 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         else m.rc = crass_hip_create(&p, devs[0], &m.c);
         return m;
     });
-    const bool streamed = want_streamed_ingest(seqFiles);
+    // One plain-text input: the INDEXED reader (crass_index_fastx) — the file stays mapped, every read is packed as its piece is
+    // parsed and its text dropped, the records that are handed on are parsed again when the hand-off asks for them.  40 + 12 bytes
+    // of host memory per 150 bp read and no second pass over the input.  CRASS_INGEST=index|whole|stream forces a reader (index:
+    // an input it does not take is an error then); default: index for one plain-text input, else whole / stream by memory.
+    struct Index { crass_fastx_index *ix = nullptr; ~Index() { crass_fastx_index_free(ix); } } IX;
+    bool indexed = false;
+    {
+        const char *e = getenv("CRASS_INGEST");
+        const bool force = e && !strcmp(e, "index");
+        if ((force || !e) && seqFiles.size() == 1) {
+            const int rc = crass_index_fastx(seqFiles[0].c_str(), &IX.ix);
+            if (rc == CRASS_ERR_IO) CRASS_THROW(std::string("Could not open FASTQ ") + seqFiles[0] + " for reading.");
+            if (rc == CRASS_OK) indexed = true;
+            else if (rc != CRASS_ERR_UNSUPPORTED || force) chk(rc, "crass_index_fastx");
+        } else if (force) CRASS_THROW("CRASS_INGEST=index takes one input file");
+    }
+    const bool streamed = !indexed && want_streamed_ingest(seqFiles);
     JobFiles J;
     StreamedJob S;
     int max_len = 0;
     uint64_t n = 0;
     double t1 = t0;
     crass_reads r;
-    if (streamed) {
+    if (indexed) {
+        uint32_t ml = 0; int lr = 0;
+        chk(crass_fastx_index_reads(IX.ix, &r, &ml, &lr), "crass_fastx_index_reads");
+        n = r.n_reads; max_len = (int)ml;
+        t1 = now();
+    } else if (streamed) {
         // pass A over the inputs: chunk -> 2-bit pack -> append; the chunk's text is dropped
         struct Names { crass_name_table *t = crass_name_table_create(); ~Names() { crass_name_table_destroy(t); } } names;
         for (size_t f = 0; f < seqFiles.size(); f++) {
@@ -704,7 +726,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     std::vector<ReadHolder *> cand_holders(c.n);
     for (uint64_t k = 0; k < c.n; k++) {
         ReadHolder *h = new ReadHolder();
-        if (streamed) fills.push_back(Fill{c.read_idx[k], h, c.low_lexi[k] != 0});
+        if (streamed || indexed) fills.push_back(Fill{c.read_idx[k], h, c.low_lexi[k] != 0});
         else {
             size_t f; uint64_t i;
             J.locate(c.read_idx[k], f, i);
@@ -744,7 +766,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     if (v.n_patterns) std::cout << "[crass_clusterCore]: " << v.n_patterns << " non-redundant patterns." << std::endl;
     for (uint64_t k = 0; k < q.n; k++) {
         ReadHolder *h = new ReadHolder();
-        if (streamed) fills.push_back(Fill{q.read_idx[k], h, q.low_lexi[k] != 0});
+        if (streamed || indexed) fills.push_back(Fill{q.read_idx[k], h, q.low_lexi[k] != 0});
         else {
             size_t f; uint64_t i;
             J.locate(q.read_idx[k], f, i);
@@ -761,6 +783,24 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         (*mReads)[st]->push_back(h);
     }
     double t_fill = 0;
+    if (indexed && !fills.empty()) {
+        // the text of the records that are handed on, parsed from the mapping (crass_fastx_index_fetch: every core), then the
+        // holders filled — also over the cores: a holder is its own object
+        const double tf0 = now();
+        std::vector<uint64_t> want(fills.size());
+        for (size_t k = 0; k < fills.size(); k++) want[k] = fills[k].idx;
+        crass_fastx fx;
+        chk(crass_fastx_index_fetch(IX.ix, want.data(), want.size(), &fx), "crass_fastx_index_fetch");
+        struct Free { crass_fastx *f; ~Free() { crass_free_fastx(f); } } fr{&fx};
+        const size_t nf = fills.size();
+        const unsigned nt = (unsigned)std::min<size_t>(std::max<size_t>(1, nf / 4096), std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
+        std::vector<std::thread> th;
+        auto run = [&](unsigned t) { for (size_t k = nf * t / nt; k < nf * (t + 1) / nt; k++) fill_holder(*fills[k].h, fx, k, fills[k].low); };
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(run, t);
+        run(0);
+        for (auto &x : th) x.join();
+        t_fill = now() - tf0;
+    }
     if (streamed && !fills.empty()) {
         // pass B over the inputs (the reference reads every file a second time too, findSingletons): the text of the records
         // that are handed on, chunk by chunk
@@ -796,8 +836,9 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     std::cout << "\r[crass_singletonFinder]: Processed " << g_read_counter_p2 << " ..." << difftime(tnow, time_start) << " sec" << std::endl;
     if (timing)
         fprintf(stderr, "[crass_timing] searchAndRecruit: %llu reads on %zu device(s)%s; read+parse%s %.3f s, pack %.3f s, device (H2D + pass 1 + merge + pass 2) %.3f s, hand-off %.3f s%s\n",
-                (unsigned long long)n, devs.size(), streamed ? ", streamed ingest" : "", streamed ? "+pack (pass A)" : "", t1 - t0, t2 - t1, t3 - t2, now() - t3,
-                streamed ? (" (of which the second pass over the inputs " + std::to_string(t_fill) + " s)").c_str() : "");
+                (unsigned long long)n, devs.size(), streamed ? ", streamed ingest" : indexed ? ", indexed ingest" : "", (streamed || indexed) ? "+pack" : "", t1 - t0, t2 - t1, t3 - t2, now() - t3,
+                streamed ? (" (of which the second pass over the inputs " + std::to_string(t_fill) + " s)").c_str()
+                         : indexed ? (" (of which the handed-on records' text " + std::to_string(t_fill) + " s)").c_str() : "");
     if (timing)
         fprintf(stderr, "[crass_timing] searchAndRecruit: resident set after ingest %.0f MB, with the device context(s) up %.0f MB, at the end %.0f MB\n",
                 rss_ingested, rss_ctx, rss_mb());

@@ -164,6 +164,7 @@ struct FxChunk {
     uint32_t max_len = 0;
     size_t next_start = 0;     // index of the header char of the first record NOT parsed here
     size_t last_hdr = 0;       // index of the header char of the LAST record parsed here (streaming: a chunk's last record is re-read)
+    std::vector<uint64_t> hdr_pos;                                      // index of every record's header char (crass_index_fastx)
     bool ended = false;        // kseq_read returned < 0 inside this range
     int last_ret = -1;         // ... with this value
     size_t n_rec() const { return seq_end.size(); }
@@ -238,6 +239,7 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
         }
         o.name.insert(o.name.end(), data + name_st, data + name_st + name_len); o.name_end.push_back(o.name.size());
         o.last_hdr = hdr;
+        o.hdr_pos.push_back(hdr);
         o.seq_end.push_back(o.seq.size());
         if (own_c) o.comment.insert(o.comment.end(), data + com_st, data + com_st + com_len);
         o.comment_end.push_back(o.comment.size()); o.own_c.push_back(own_c ? 1 : 0);
@@ -581,6 +583,293 @@ uint64_t crass_fastx_find(const crass_fastx *f, const char *name, uint64_t len)
         }
     }
 }
+
+// ---- the same reader as an INDEX over the file image (plain-text inputs) ----
+// What the device wants from an input is its reads as 2-bit words; what the hand-off wants is the TEXT of the ~1 % of reads that
+// are handed on.  crass_read_fastx builds every record's text as arrays (3.6 bytes of host memory per byte of input while it
+// assembles them, and a serial share — page faults of 1.6 GB of fresh arrays, the ordered header table — that is larger than the
+// parallel parse).  The index keeps the file mapped and, per record, the position of its header character: the pieces are parsed
+// by the same state machine, each piece packs its own records into the job's word array at once and drops its text, the header
+// table compares names in the mapping itself, and crass_fastx_index_fetch parses the few records that are handed on, again with
+// the same state machine, when they are asked for.  gzip'd inputs and files that mix records with and without a comment /
+// quality line (kseq's stale-buffer semantics need the records in order) are left to the two readers above: CRASS_ERR_UNSUPPORTED.
+struct crass_fastx_index {
+    void *map = nullptr; size_t map_n = 0;
+    std::vector<uint64_t> hdr_pos;                     // [n]
+    PackedOwner pk;
+    std::vector<uint64_t> header_id;                   // [n] or empty (all names unique)
+    crass_reads reads{};
+    uint32_t max_len = 0;
+    int last_ret = -1;
+    bool any_c = false, any_q = false;
+    ~crass_fastx_index() { if (map && map_n) munmap(map, map_n); }
+};
+
+extern "C" {
+
+int crass_index_fastx(const char *path, crass_fastx_index **out)
+{
+    if (!path || !out) return CRASS_ERR_INVALID_ARG;
+    *out = nullptr;
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now_s();
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return CRASS_ERR_IO;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return CRASS_ERR_UNSUPPORTED; }
+    const size_t n = (size_t)st.st_size;
+    unsigned char magic[2] = {0, 0};
+    if (n >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { close(fd); return CRASS_ERR_UNSUPPORTED; }
+    std::unique_ptr<crass_fastx_index> ix(new (std::nothrow) crass_fastx_index());
+    if (!ix) { close(fd); return CRASS_ERR_OOM; }
+    if (n) {
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); return CRASS_ERR_UNSUPPORTED; }
+        ix->map = m; ix->map_n = n;
+    }
+    close(fd);
+    const uint8_t *d = (const uint8_t *)ix->map;
+    const double t1 = now_s();
+    std::vector<FxChunk> ch;
+    parse_pieces(d, n, ch);
+    const double t2 = now_s();
+    const size_t nc = ch.size();
+    std::vector<uint64_t> rec0(nc + 1, 0);
+    bool any_c = false, all_c = true, any_q = false, all_q = true;
+    uint32_t max_len = 0, min_len = 0xFFFFFFFFu;
+    for (size_t k = 0; k < nc; k++) {
+        rec0[k + 1] = rec0[k] + ch[k].n_rec();
+        for (uint8_t v : ch[k].own_c) { any_c |= v != 0; all_c &= v != 0; }
+        for (uint8_t v : ch[k].own_q) { any_q |= v != 0; all_q &= v != 0; }
+        max_len = std::max(max_len, ch[k].max_len);
+    }
+    if ((any_c && !all_c) || (any_q && !all_q)) return CRASS_ERR_UNSUPPORTED;      // stale comment / quality buffers: ordered readers
+    if (max_len > CRASS_HIP_MAX_READ_LEN) return CRASS_ERR_UNSUPPORTED;
+    const uint64_t nrec = rec0[nc];
+    ix->any_c = any_c; ix->any_q = any_q; ix->max_len = max_len; ix->last_ret = ch.empty() ? -1 : ch.back().last_ret;
+    // ---- layout: crass_pack_reads' rules (mode 2) from the lengths alone, then every piece packs into place ----
+    std::vector<uint64_t> tight0(nc + 1, 0);           // words of the pieces' reads, tightly packed
+    {
+        std::vector<uint32_t> pmin(nc, 0xFFFFFFFFu);
+        std::vector<std::thread> th;
+        auto scan = [&](size_t k) {
+            const FxChunk &c = ch[k];
+            uint64_t w = 0; uint32_t mn = 0xFFFFFFFFu;
+            for (size_t i = 0; i < c.n_rec(); i++) { const uint64_t l = c.seq_end[i] - (i ? c.seq_end[i - 1] : 0); w += (l + 15) / 16; mn = std::min<uint32_t>(mn, (uint32_t)l); }
+            tight0[k + 1] = w; pmin[k] = mn;
+        };
+        for (size_t k = 1; k < nc; k++) th.emplace_back(scan, k);
+        if (nc) scan(0);
+        for (auto &t : th) t.join();
+        for (size_t k = 0; k < nc; k++) { tight0[k + 1] += tight0[k]; min_len = std::min(min_len, pmin[k]); }
+    }
+    if (nrec == 0) min_len = 0;
+    const bool uniform_len = nrec > 0 && max_len == min_len;
+    const uint64_t padded = nrec * (uint64_t)((max_len + 15) / 16);
+    const bool pad = max_len <= 256 && max_len >= 64 && padded <= 2 * tight0[nc];
+    const uint32_t stride = (uniform_len || pad) ? std::max<uint32_t>(1, (max_len + 15) / 16) : 0;
+    PackedOwner &o = ix->pk;
+    try {
+        // (no zero fill of 2 GB on one thread: the pieces write every word they own, pad words included)
+        o.packed.resize(stride ? nrec * (uint64_t)stride + 4 : tight0[nc] + 4);
+        if (!stride) o.word_off.resize(nrec + 1);
+        if (!uniform_len) o.lengths.resize(nrec);
+        ix->hdr_pos.resize(nrec);
+    } catch (const std::bad_alloc &) { return CRASS_ERR_OOM; }
+    std::vector<uint32_t> name_len;
+    try { name_len.resize(nrec); } catch (const std::bad_alloc &) { return CRASS_ERR_OOM; }
+    std::vector<std::vector<uint64_t>> exc_parts(nc);
+    std::vector<std::vector<uint8_t>> exc_bytes_parts(nc);
+    std::vector<std::vector<uint64_t>> exc_off_parts(nc);
+    {
+        static const struct Lut { uint8_t t[256]; Lut() { memset(t, 0x80, sizeof(t)); t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; } } lut;
+        uint32_t *packed = o.packed.data();
+        auto pack_piece = [&](size_t k) {
+            FxChunk &c = ch[k];
+            uint64_t wat = tight0[k];
+            for (size_t i = 0; i < c.n_rec(); i++) {
+                const uint64_t r = rec0[k] + i;
+                const uint64_t s0 = i ? c.seq_end[i - 1] : 0;
+                const uint32_t L = (uint32_t)(c.seq_end[i] - s0);
+                const uint8_t *s = c.seq.data() + s0;
+                const uint32_t nw = (L + 15) / 16;
+                uint32_t *w = packed + (stride ? r * (uint64_t)stride : wat);
+                if (!stride) o.word_off[r] = wat;
+                if (!uniform_len) o.lengths[r] = L;
+                ix->hdr_pos[r] = c.hdr_pos[i];
+                name_len[r] = (uint32_t)(c.name_end[i] - (i ? c.name_end[i - 1] : 0));
+                uint32_t bad = 0, q0 = 0;
+                for (; q0 + 16 <= L; q0 += 16) {
+                    uint32_t acc = 0;
+                    for (int q = 0; q < 16; q++) { const uint32_t cc = lut.t[s[q0 + q]]; bad |= cc; acc |= (cc & 3u) << (2 * q); }
+                    w[q0 >> 4] = acc;
+                }
+                if (q0 < L) {
+                    uint32_t acc = 0;
+                    for (uint32_t q = 0; q0 + q < L; q++) { const uint32_t cc = lut.t[s[q0 + q]]; bad |= cc; acc |= (cc & 3u) << (2 * q); }
+                    w[q0 >> 4] = acc;
+                }
+                for (uint32_t x = nw; stride && x < stride; x++) w[x] = 0;
+                if (bad & 0x80u) {
+                    exc_parts[k].push_back(r);
+                    exc_bytes_parts[k].insert(exc_bytes_parts[k].end(), s, s + L);
+                    exc_off_parts[k].push_back(exc_bytes_parts[k].size());
+                }
+                wat += nw;
+            }
+            // the piece's text goes as soon as it is packed (peak host memory: the words + what the slowest pieces still hold)
+            std::vector<uint8_t>().swap(c.seq); std::vector<uint8_t>().swap(c.qual); std::vector<uint8_t>().swap(c.comment); std::vector<uint8_t>().swap(c.name);
+        };
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < nc; k++) th.emplace_back(pack_piece, k);
+        if (nc) pack_piece(0);
+        for (auto &t : th) t.join();
+        if (!stride) o.word_off[nrec] = tight0[nc];
+        for (size_t x = 0; x < 4; x++) o.packed[o.packed.size() - 4 + x] = 0;
+    }
+    o.exc_off.push_back(0);
+    for (size_t k = 0; k < nc; k++) {
+        const uint64_t base = o.exc_bytes.size();
+        o.exc_read.insert(o.exc_read.end(), exc_parts[k].begin(), exc_parts[k].end());
+        o.exc_bytes.insert(o.exc_bytes.end(), exc_bytes_parts[k].begin(), exc_bytes_parts[k].end());
+        for (uint64_t e : exc_off_parts[k]) o.exc_off.push_back(base + e);
+    }
+    std::vector<FxChunk>().swap(ch);
+    const double t3 = now_s();
+    // ---- header_id: first read with the same name, names compared in the mapping (exact) ----
+    bool any_dup = false;
+    if (nrec) {
+        size_t cap = 1024;
+        while (cap * 10 < nrec * 14) cap <<= 1;
+        std::unique_ptr<std::atomic<uint64_t>[]> tab(new (std::nothrow) std::atomic<uint64_t>[cap]);
+        std::vector<uint32_t> first;
+        try { first.resize(nrec); } catch (const std::bad_alloc &) { tab.reset(); }
+        if (!tab || nrec >= 0xFFFFFFFFull) return CRASS_ERR_UNSUPPORTED;
+        const unsigned ht = (unsigned)std::min<uint64_t>(hw_threads(), std::max<uint64_t>(1, nrec / 65536));
+        parallel_ranges(cap, ht, [&](uint64_t a, uint64_t b2, unsigned) { for (uint64_t i = a; i < b2; i++) tab[i].store(0, std::memory_order_relaxed); });
+        auto same_name = [&](uint64_t x, uint64_t y) {
+            return name_len[x] == name_len[y] && memcmp(d + ix->hdr_pos[x] + 1, d + ix->hdr_pos[y] + 1, name_len[x]) == 0;
+        };
+        std::vector<uint64_t> slot_of;
+        try { slot_of.resize(nrec); } catch (const std::bad_alloc &) { return CRASS_ERR_OOM; }
+        parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b2, unsigned) {
+            for (uint64_t r = a; r < b2; r++) {
+                const uint64_t h = name_hash(d + ix->hdr_pos[r] + 1, name_len[r]);
+                const uint64_t tag = ((h >> 32) | 1ull) << 32;
+                size_t i = (size_t)h & (cap - 1);
+                for (;;) {
+                    uint64_t cur = tab[i].load(std::memory_order_acquire);
+                    if (cur == 0) {
+                        if (tab[i].compare_exchange_strong(cur, tag | r, std::memory_order_acq_rel)) break;
+                    }
+                    if ((cur & 0xFFFFFFFF00000000ull) == tag && same_name((uint64_t)(uint32_t)cur, r)) {
+                        while ((uint32_t)cur > r && !tab[i].compare_exchange_weak(cur, tag | r, std::memory_order_acq_rel)) {}
+                        break;
+                    }
+                    i = (i + 1) & (cap - 1);
+                }
+                slot_of[r] = i;
+            }
+        });
+        std::atomic<int> dup{0};
+        parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b2, unsigned) {
+            bool dl = false;
+            for (uint64_t r = a; r < b2; r++) { first[r] = (uint32_t)tab[slot_of[r]].load(std::memory_order_relaxed); dl |= first[r] != r; }
+            if (dl) dup.store(1, std::memory_order_relaxed);
+        });
+        any_dup = dup.load() != 0;
+        if (any_dup) {
+            try { ix->header_id.resize(nrec); } catch (const std::bad_alloc &) { return CRASS_ERR_OOM; }
+            parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b2, unsigned) { for (uint64_t r = a; r < b2; r++) ix->header_id[r] = first[r]; });
+        }
+    }
+    crass_reads &r = ix->reads;
+    r.n_reads = nrec; r.packed = o.packed.data(); r.stride_words = stride;
+    r.word_off = stride ? nullptr : o.word_off.data();
+    r.uniform_len = uniform_len ? max_len : 0;
+    r.lengths = uniform_len ? nullptr : o.lengths.data();
+    r.n_exceptions = o.exc_read.size();
+    r.exc_read = o.exc_read.data(); r.exc_off = o.exc_off.data(); r.exc_bytes = o.exc_bytes.data();
+    r.header_id = any_dup ? ix->header_id.data() : nullptr; r.read_index_base = 0;
+    if (timing)
+        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse %.3f s, pack in place %.3f s, header ids %.3f s\n",
+                n, nc, (unsigned long long)nrec, t1 - t0, t2 - t1, t3 - t2, now_s() - t3);
+    *out = ix.release();
+    return CRASS_OK;
+}
+
+int crass_fastx_index_reads(const crass_fastx_index *ix, crass_reads *reads, uint32_t *max_len, int *last_ret)
+{
+    if (!ix || !reads) return CRASS_ERR_INVALID_ARG;
+    *reads = ix->reads;
+    if (max_len) *max_len = ix->max_len;
+    if (last_ret) *last_ret = ix->last_ret;
+    return CRASS_OK;
+}
+
+// the records idx[0 .. n) (any order, repeats allowed) as a crass_fastx of n records in that order: parsed from the mapping by
+// the reader's own state machine; header_id[k] = idx[k] (the caller knows the job-level ids)
+int crass_fastx_index_fetch(const crass_fastx_index *ix, const uint64_t *idx, uint64_t n, crass_fastx *out)
+{
+    if (!ix || !out || (n && !idx)) return CRASS_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    const uint8_t *d = (const uint8_t *)ix->map;
+    const uint64_t nrec = ix->reads.n_reads;
+    for (uint64_t k = 0; k < n; k++) if (idx[k] >= nrec) return CRASS_ERR_INVALID_ARG;
+    const unsigned nt = (unsigned)std::min<uint64_t>(std::min<unsigned>(hw_threads(), 32u), std::max<uint64_t>(1, n / 2048));
+    std::vector<FxChunk> parts(nt ? nt : 1);
+    const uint64_t per = (n + parts.size() - 1) / parts.size();
+    auto run = [&](size_t t) {
+        const uint64_t a = std::min<uint64_t>(n, t * per), b = std::min<uint64_t>(n, a + per);
+        for (uint64_t k = a; k < b; k++) {
+            const uint64_t h = ix->hdr_pos[idx[k]];
+            parse_range(d, ix->map_n, (size_t)h, (size_t)h + 1, false, parts[t]);      // exactly the record whose header character is at h
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < parts.size(); t++) th.emplace_back(run, t);
+        run(0);
+        for (auto &t : th) t.join();
+    }
+    uint64_t got = 0, seq_b = 0, name_b = 0, com_b = 0, qual_b = 0;
+    for (auto &c : parts) { got += c.n_rec(); seq_b += c.seq.size(); name_b += c.name.size(); com_b += c.comment.size(); qual_b += c.qual.size(); }
+    if (got != n) return CRASS_ERR_STATE;
+    auto alloc8 = [](uint64_t nb) { return (uint8_t *)malloc(nb + 1); };
+    auto alloc64 = [](uint64_t ne) { return (uint64_t *)malloc((ne + 1) * 8); };
+    out->n_reads = n;
+    out->seq = alloc8(seq_b); out->seq_off = alloc64(n + 1); out->name = alloc8(name_b); out->name_off = alloc64(n + 1);
+    out->comment = alloc8(com_b); out->comment_off = alloc64(n + 1); out->has_comment = alloc8(n);
+    out->qual = alloc8(qual_b); out->qual_off = alloc64(n + 1); out->has_qual = alloc8(n);
+    out->header_id = alloc64(n);
+    if (!out->seq || !out->seq_off || !out->name || !out->name_off || !out->comment || !out->comment_off || !out->has_comment ||
+        !out->qual || !out->qual_off || !out->has_qual || !out->header_id) { crass_free_fastx(out); return CRASS_ERR_OOM; }
+    out->seq_off[0] = out->name_off[0] = out->comment_off[0] = out->qual_off[0] = 0;
+    uint64_t r = 0, sq = 0, nm = 0, cm = 0, ql = 0;
+    uint32_t max_len = 0;
+    for (auto &c : parts) {
+        if (!c.seq.empty()) memcpy(out->seq + sq, c.seq.data(), c.seq.size());
+        if (!c.name.empty()) memcpy(out->name + nm, c.name.data(), c.name.size());
+        if (!c.comment.empty()) memcpy(out->comment + cm, c.comment.data(), c.comment.size());
+        if (!c.qual.empty()) memcpy(out->qual + ql, c.qual.data(), c.qual.size());
+        for (size_t i = 0; i < c.n_rec(); i++, r++) {
+            out->seq_off[r + 1] = sq + c.seq_end[i]; out->name_off[r + 1] = nm + c.name_end[i];
+            out->comment_off[r + 1] = cm + c.comment_end[i]; out->qual_off[r + 1] = ql + c.qual_end[i];
+            out->has_comment[r] = ix->any_c ? 1 : 0; out->has_qual[r] = ix->any_q ? 1 : 0;
+            out->header_id[r] = idx[r];
+        }
+        sq += c.seq.size(); nm += c.name.size(); cm += c.comment.size(); ql += c.qual.size();
+        max_len = std::max(max_len, c.max_len);
+    }
+    out->max_len = max_len;
+    out->last_ret = ix->last_ret;
+    return CRASS_OK;
+}
+
+void crass_fastx_index_free(crass_fastx_index *ix) { delete ix; }
+
+} // extern "C"
 
 // ---- the same reader as a STREAM of chunks (bounded host memory; VERDICT r03 "the reference's streaming memory model") ----
 // kseq_read hands out one record at a time from a 4 KB buffer (kseq.cpp:171-226, libcrispr.cpp:96), so crass's memory does not

@@ -40,6 +40,14 @@ def _np(ptr, n, dtype):
     return np.ctypeslib.as_array(ptr, shape=(int(n),)).view(dtype).copy()
 
 
+def _npv(addr, n, dtype):
+    """n elements of dtype at the raw address addr (a c_void_p field) as a numpy copy"""
+    if n == 0 or not addr:
+        return np.zeros(0, dtype)
+    ct = {np.uint8: C.c_uint8, np.uint32: C.c_uint32, np.uint64: C.c_uint64}[dtype]
+    return np.ctypeslib.as_array(C.cast(C.c_void_p(addr), C.POINTER(ct)), shape=(int(n),)).view(dtype).copy()
+
+
 def concat(items):
     off = np.zeros(len(items) + 1, dtype=np.uint64)
     if items:
@@ -128,6 +136,69 @@ class FastxFile:
 
     def unique_headers(self):
         return bool(np.all(self.header_id == np.arange(self.n_reads, dtype=np.uint64)))
+
+
+class FastxIndex:
+    """crass_index_fastx: a plain-text input kept mapped, its reads 2-bit packed at once, the records' text parsed on request.
+    Raises CrassError(status 2, unsupported) for gzip'd inputs and files that mix records with / without comment or quality."""
+
+    def __init__(self, path):
+        self.lib = _abi.load()
+        h = C.c_void_p()
+        _chk(self.lib.crass_index_fastx(str(path).encode(), C.byref(h)), "crass_index_fastx(%s)" % path)
+        self.h = h
+        self.reads = _abi.Reads()
+        ml, lr = C.c_uint32(), C.c_int()
+        _chk(self.lib.crass_fastx_index_reads(self.h, C.byref(self.reads), C.byref(ml), C.byref(lr)), "crass_fastx_index_reads")
+        self.max_len, self.last_ret, self.n_reads = int(ml.value), int(lr.value), int(self.reads.n_reads)
+
+    def layout(self):
+        """the packed reads as python objects: dict(stride, uniform_len, words per read (list of arrays), lengths, exceptions, header_id)"""
+        r = self.reads
+        n = self.n_reads
+        stride, uni = int(r.stride_words), int(r.uniform_len)
+        lengths = np.full(n, uni, np.uint32) if uni else _npv(r.lengths, n, np.uint32).copy()
+        if stride:
+            words = _npv(r.packed, n * stride, np.uint32).reshape(n, stride).copy() if n else np.zeros((0, stride), np.uint32)
+            per = [words[i, :(int(lengths[i]) + 15) // 16] for i in range(n)]
+        else:
+            off = _npv(r.word_off, n + 1, np.uint64)
+            allw = _npv(r.packed, int(off[n]), np.uint32).copy() if n else np.zeros(0, np.uint32)
+            per = [allw[int(off[i]):int(off[i]) + (int(lengths[i]) + 15) // 16] for i in range(n)]
+        ne = int(r.n_exceptions)
+        exc = {}
+        if ne:
+            er, eo = _npv(r.exc_read, ne, np.uint64), _npv(r.exc_off, ne + 1, np.uint64)
+            eb = _npv(r.exc_bytes, int(eo[ne]), np.uint8)
+            exc = {int(er[k]): eb[int(eo[k]):int(eo[k + 1])].tobytes() for k in range(ne)}
+        hid = _npv(r.header_id, n, np.uint64).tolist() if r.header_id else list(range(n))
+        return dict(stride=stride, uniform_len=uni, words=per, lengths=lengths.tolist(), exceptions=exc, header_id=hid)
+
+    def fetch(self, idx):
+        """records (name, comment | None, seq, qual | None) of the read indices idx, in that order"""
+        a = np.ascontiguousarray(np.asarray(idx, dtype=np.uint64))
+        f = _abi.Fastx()
+        _chk(self.lib.crass_fastx_index_fetch(self.h, a.ctypes.data, len(a), C.byref(f)), "crass_fastx_index_fetch")
+        n = int(f.n_reads)
+        so, no, co, qo = (_np(x, n + 1, np.uint64) for x in (f.seq_off, f.name_off, f.comment_off, f.qual_off))
+        sq, nm = _np(f.seq, int(so[-1]), np.uint8), _np(f.name, int(no[-1]), np.uint8)
+        cm, ql = _np(f.comment, int(co[-1]), np.uint8), _np(f.qual, int(qo[-1]), np.uint8)
+        hc, hq = _np(f.has_comment, n, np.uint8), _np(f.has_qual, n, np.uint8)
+        out = [(nm[int(no[i]):int(no[i + 1])].tobytes(), cm[int(co[i]):int(co[i + 1])].tobytes() if hc[i] else None,
+                sq[int(so[i]):int(so[i + 1])].tobytes(), ql[int(qo[i]):int(qo[i + 1])].tobytes() if hq[i] else None) for i in range(n)]
+        self.lib.crass_free_fastx(C.byref(f))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.crass_fastx_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def stream_fastx(path, chunk_bytes=0, with_names=True):

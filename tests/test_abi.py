@@ -316,6 +316,104 @@ def test_streaming_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
     assert len(ref) > 1000
 
 
+def _packed_layout(ca, seqs):
+    """what crass_pack_reads (mode 2) makes of these sequences, in FastxIndex.layout()'s form"""
+    pk = ca.PackedReads(list(seqs), pad_uniform=2)
+    r = pk.reads
+    n = int(r.n_reads)
+    from crass_amd.engine import _npv as _np
+    stride, uni = int(r.stride_words), int(r.uniform_len)
+    lengths = [uni] * n if uni else _np(r.lengths, n, np.uint32).tolist()
+    if stride:
+        words = _np(r.packed, n * stride, np.uint32).reshape(n, stride) if n else np.zeros((0, stride), np.uint32)
+        per = [words[i, :(lengths[i] + 15) // 16] for i in range(n)]
+    else:
+        off = _np(r.word_off, n + 1, np.uint64)
+        allw = _np(r.packed, int(off[n]), np.uint32) if n else np.zeros(0, np.uint32)
+        per = [allw[int(off[i]):int(off[i]) + (lengths[i] + 15) // 16] for i in range(n)]
+    ne = int(r.n_exceptions)
+    exc = {}
+    if ne:
+        er, eo = _np(r.exc_read, ne, np.uint64), _np(r.exc_off, ne + 1, np.uint64)
+        eb = _np(r.exc_bytes, int(eo[ne]), np.uint8)
+        exc = {int(er[k]): eb[int(eo[k]):int(eo[k + 1])].tobytes() for k in range(ne)}
+    return dict(stride=stride, uniform_len=uni, words=per, lengths=lengths, exceptions=exc)
+
+
+@pytest.mark.parametrize("case", ["fa_multi", "fq", "fq_trunc", "fa_odd_nocomment", "fa_crlf_nocomment", "fa_noeol", "fa_uniform", "fa_trimmed"])
+@pytest.mark.parametrize("chunk", ["256", "5000", "serial"])
+def test_indexed_fastx_reader_is_the_whole_file_reader(ca, tmp_path, case, chunk):
+    """crass_index_fastx (the input kept mapped, reads packed at once, text on request) against the whole-file reader + crass_pack_reads
+    and the byte-at-a-time kseq reference: layout (stride / ragged / padded), every read's words, lengths, exception reads with their
+    bytes, header ids, and the text of fetched records — pieces far smaller than in production; uniform-length, trimmed (padded to
+    one stride) and ragged sets, multi-line FASTA, FASTQ incl. a truncated last record, '>' inside a sequence line, CRLF"""
+    import random
+    cases = _fastx_cases()
+    rng = random.Random(5)
+    strip = lambda t: b"".join(ln.split(b" ")[0] + (b"\r\n" if ln.endswith(b"\r\n") else b"\n") if ln[:1] == b">" else ln for ln in t.splitlines(keepends=True))
+    cases["fa_odd_nocomment"] = strip(cases["fa_odd"])
+    cases["fa_crlf_nocomment"] = strip(cases["fa_crlf"])
+    # FASTQ with a comment on EVERY header (the shared cases put one on every other record: refused, see the next test), quality
+    # lines that start with '@' or '+'
+    recs = []
+    for i in range(2500):
+        sq = "".join(rng.choice("ACGTN" if rng.random() < 0.05 else "ACGT") for _ in range(rng.randint(30, 150)))
+        q = "".join(rng.choice("@+IIIHG5#!~") for _ in sq)
+        q = ("@" + q[1:]) if i % 5 == 0 else (("+" + q[1:]) if i % 7 == 0 else q)
+        recs.append("@q%d lane=%d\n%s\n+\n%s\n" % (i, i % 4, sq, q))
+    cases["fq"] = "".join(recs).encode()
+    cases["fq_trunc"] = cases["fq"][:-40]
+    cases["fa_uniform"] = "".join(">u%d\n%s\n" % (i % 1900, "".join(rng.choice("ACGT") for _ in range(150))) for i in range(2000)).encode()
+    cases["fa_trimmed"] = "".join(">t%d\n%s\n" % (i, "".join(rng.choice("ACGTN" if i % 50 == 0 else "ACGT") for _ in range(rng.randint(90, 150)))) for i in range(2000)).encode()
+    text = cases[case]
+    plain, gz = _write_both(tmp_path, case + ".txt", text)
+    ref = fastx.read_fastx(gz)
+    first = {}
+    ref_ids = [first.setdefault(r[0], i) for i, r in enumerate(ref)]
+    os.environ.pop("CRASS_FASTX_CHUNK", None)
+    os.environ.pop("CRASS_FASTX_SERIAL", None)
+    if chunk == "serial":
+        os.environ["CRASS_FASTX_SERIAL"] = "1"
+    else:
+        os.environ["CRASS_FASTX_CHUNK"] = chunk
+    try:
+        with pytest.raises(ca.CrassError):
+            ca.FastxIndex(gz)                                       # gzip'd: the other readers' job
+        ix = ca.FastxIndex(plain)
+        whole = ca.FastxFile(plain)
+    finally:
+        os.environ.pop("CRASS_FASTX_CHUNK", None)
+        os.environ.pop("CRASS_FASTX_SERIAL", None)
+    assert ix.n_reads == len(ref) and ix.max_len == whole.max_len and ix.last_ret == whole.last_ret
+    lay = ix.layout()
+    want = _packed_layout(ca, [r[2] for r in ref])
+    assert lay["stride"] == want["stride"] and lay["uniform_len"] == want["uniform_len"] and lay["lengths"] == want["lengths"]
+    assert lay["exceptions"] == want["exceptions"]
+    for i in range(len(ref)):
+        if i not in want["exceptions"]:                             # (an exception read's slot content is ignored)
+            assert np.array_equal(lay["words"][i], want["words"][i]), i
+    assert lay["header_id"] == ref_ids
+    pick = list(range(0, len(ref), 7)) + [len(ref) - 1, 0, 3, 3]
+    assert ix.fetch(pick) == [ref[i] for i in pick]
+    assert ix.fetch([]) == []
+    ix.close()
+    assert len(ref) > 1000
+    if case == "fa_trimmed":
+        assert lay["stride"] == 10 and lay["uniform_len"] == 0 and len(lay["exceptions"]) >= 30
+    if case == "fa_uniform":
+        assert lay["stride"] == 10 and lay["uniform_len"] == 150 and lay["header_id"][1900] == 0
+
+
+def test_indexed_reader_refuses_mixed_comments(ca, tmp_path):
+    """kseq's stale comment / quality buffers (libcrispr.cpp:124-131) make a record's fields depend on the records before it: a
+    file that mixes records with and without a comment is left to the ordered readers"""
+    text = _fastx_cases()["fa_single"]
+    plain, _ = _write_both(tmp_path, "mixed.fa", text)
+    with pytest.raises(ca.CrassError) as e:
+        ca.FastxIndex(plain)
+    assert e.value.status == 2
+
+
 def test_streaming_reader_on_the_reference_inputs(ca):
     """the five regression inputs of the reference (tests/golden/data, byte-identical to /root/reference/test/*.gz) through the
     stream in small chunks = through the whole-file reader"""

@@ -255,3 +255,55 @@ def test_streamed_and_whole_ingest_write_the_same_files(cli, tmp_path):
         # (the XML and the log record the output directory of the command line)
         a, b = a.replace(str(tmp_path / "whole").encode(), b"DIR"), b.replace(str(tmp_path / "stream").encode(), b"DIR")
         assert a == b, f
+
+
+@pytest.mark.parametrize("kind", ["fastq_all_comments", "fasta_plain", "fasta_multiline"])
+def test_indexed_ingest_writes_the_same_files(cli, tmp_path, kind):
+    """the indexed reader (crass_index_fastx: the input stays mapped, reads packed as their piece is parsed, the handed-on records'
+    text parsed on request) against whole-file and streamed ingest through the complete command line: byte-identical output
+    directories.  Ragged lengths, N reads, duplicate headers; FASTQ with a comment on every record, plain FASTA, multi-line FASTA;
+    pieces of 20 KB so that the index is built from dozens of pieces.  Default mode (no CRASS_INGEST) takes the index for these."""
+    import crass_amd as ca
+    import numpy as np
+    ca.load()
+    n, L = 30000, 150
+    spec = ca.synth_spec(read_len=L, crispr_per_million=60000, n_dr=8)
+    asc = ca.unpack_ascii(ca.synth_packed(spec, 0, n), (L + 15) // 16, L, n)
+    rng = np.random.default_rng(9)
+    lines = []
+    for i in range(n):
+        s = asc[i * L:(i + 1) * L].tobytes()
+        if i % 11 == 0:
+            s = s[:int(rng.integers(70, L))]
+        if i % 501 == 0:
+            s = s[:40] + b"N" + s[41:]
+        name = b"r%d" % (i if i % 97 else i // 2)
+        if kind == "fastq_all_comments":
+            lines.append(b"@" + name + (b" c%d" % i) + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+        elif kind == "fasta_plain":
+            lines.append(b">" + name + b"\n" + s + b"\n")
+        else:
+            lines.append(b">" + name + b"\n" + b"\n".join(s[k:k + 60] for k in range(0, len(s), 60)) + b"\n")
+    fx = tmp_path / ("s.fq" if kind.startswith("fastq") else "s.fa")
+    fx.write_bytes(b"".join(lines))
+    outs, errs = {}, {}
+    for mode, env in (("whole", {"CRASS_INGEST": "whole"}), ("stream", {"CRASS_INGEST": "stream", "CRASS_INGEST_CHUNK_BYTES": "40000"}),
+                      ("index", {"CRASS_INGEST": "index", "CRASS_FASTX_CHUNK": "20000"}), ("auto", {"CRASS_TIMING": "1"})):
+        d = tmp_path / mode
+        d.mkdir()
+        e = dict(os.environ, **env)
+        if mode == "auto":
+            e.pop("CRASS_INGEST", None)
+        r = subprocess.run([cli, "-g", "--timestamp", "01_01_2026_000000", "-o", str(d), str(fx)], capture_output=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs[mode] = {f: open(d / f, "rb").read() for f in sorted(os.listdir(d))}
+        errs[mode] = r.stderr.decode()
+        assert any(f.endswith(".crispr") for f in outs[mode]) and len(outs[mode]) >= 3
+    assert "indexed ingest" in errs["auto"]
+    for mode in ("stream", "index", "auto"):
+        assert outs["whole"].keys() == outs[mode].keys()
+        for f in outs["whole"]:
+            a, b = outs["whole"][f], outs[mode][f]
+            a, b = a.replace(str(tmp_path / "whole").encode(), b"DIR"), b.replace(str(tmp_path / mode).encode(), b"DIR")
+            assert a == b, (mode, f)
+
