@@ -58,6 +58,39 @@ template <typename F> void parallel_ranges(uint64_t n, unsigned nt, F f)
     for (auto &x : th) x.join();
 }
 
+// A large array that is written in full by many threads right after it is allocated: no value-initialisation (a std::vector's
+// resize() zero-fills — 2 GB of packed reads on ONE thread before the 64 that fill them start), 2 MB alignment and
+// MADV_HUGEPAGE where the kernel takes the hint (a first touch per 2 MB instead of per 4 KB: the page faults of the 3.4 GB of
+// arrays an index of 50 M reads allocates were most of its "words into place" second).
+template <typename T> struct RawBuf {
+    T *p = nullptr; size_t n = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    bool alloc(size_t count)
+    {
+        free(p); p = nullptr; n = 0;
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        if (bytes >= (8u << 20)) {
+            const size_t al = 2u << 20, rounded = (bytes + al - 1) / al * al;
+            void *q = aligned_alloc(al, rounded);
+            if (!q) return false;
+            (void)madvise(q, rounded, MADV_HUGEPAGE);
+            p = (T *)q;
+        } else {
+            p = (T *)malloc(bytes);
+            if (!p) return false;
+        }
+        n = count;
+        return true;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
 } // namespace
 
 extern "C" {
@@ -165,10 +198,55 @@ struct FxChunk {
     size_t next_start = 0;     // index of the header char of the first record NOT parsed here
     size_t last_hdr = 0;       // index of the header char of the LAST record parsed here (streaming: a chunk's last record is re-read)
     std::vector<uint64_t> hdr_pos;                                      // index of every record's header char (crass_index_fastx)
+    // pack mode (crass_index_fastx): a record's sequence is 2-bit packed the moment it is complete — while its bytes are still in
+    // the cache — and its text dropped; seq / name / comment / qual stay empty, seq_end / name_end count virtual bytes (the
+    // lengths), the name is kept as a hash
+    bool pack = false;
+    std::vector<uint32_t> words;                                        // the records' words, tightly packed (ceil(L/16) each)
+    std::vector<uint64_t> name_h;                                       // name_hash() of every record's name
+    std::vector<uint64_t> exc_rec, exc_off;                             // local indices of reads with a byte outside ACGT, ends in exc_bytes
+    std::vector<uint8_t> exc_bytes;
+    uint64_t v_seq = 0, v_name = 0;
     bool ended = false;        // kseq_read returned < 0 inside this range
     int last_ret = -1;         // ... with this value
     size_t n_rec() const { return seq_end.size(); }
 };
+
+uint64_t name_hash(const uint8_t *p, size_t n);
+// L bases -> ceil(L/16) words (A0 C1 G2 T3, base i in bits 2(i%16) of word i/16); true when a byte outside ACGT was met (it
+// packs as A: the read is an exception read and its slot's content is ignored).  Eight bases per step: the code of a letter is
+// ((c >> 1) & 3) with the two upper values exchanged, the letter a code stands for is rebuilt (0x41 + 2 b0 + 6 b1 + 11 b0 b1)
+// and compared with what was read
+inline bool pack_bases(const uint8_t *s, uint32_t L, uint32_t *w)
+{
+    uint64_t bad = 0;
+    uint32_t k = 0;
+    for (; k + 16 <= L; k += 16) {
+        uint32_t word = 0;
+        for (int half = 0; half < 2; half++) {
+            uint64_t x;
+            memcpy(&x, s + k + 8 * half, 8);
+            uint64_t t = (x >> 1) & 0x0303030303030303ull;
+            t ^= (t >> 1) & 0x0101010101010101ull;
+            const uint64_t b0 = t & 0x0101010101010101ull, b1 = (t >> 1) & 0x0101010101010101ull, b01 = b0 & b1;
+            const uint64_t recon = 0x4141414141414141ull + 2 * b0 + 6 * b1 + 11 * b01;
+            bad |= recon ^ x;
+            t = (t | (t >> 6)) & 0x000F000F000F000Full;
+            t = (t | (t >> 12)) & 0x000000FF000000FFull;
+            t = (t | (t >> 24)) & 0xFFFFull;
+            word |= (uint32_t)t << (16 * half);
+        }
+        w[k >> 4] = word;
+    }
+    if (k < L) {
+        static const struct Lut { uint8_t t[256]; Lut() { memset(t, 0x80, sizeof(t)); t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; } } lut;
+        uint32_t acc = 0, b = 0;
+        for (uint32_t q = 0; k + q < L; q++) { const uint32_t cc = lut.t[s[k + q]]; b |= cc; acc |= (cc & 3u) << (2 * q); }
+        w[k >> 4] = acc;
+        if (b & 0x80u) bad |= 1;
+    }
+    return bad != 0;
+}
 
 // Parses the records whose header character ('>' / '@') lies in [start, limit).  `start` indexes a header
 // character unless scan_first (then the parser looks for the first one, as kseq_read does at the beginning).
@@ -237,13 +315,29 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
             if (ql != sq_len) { o.seq.resize(seq_base); o.qual.resize(qual_base); o.ended = true; o.last_ret = -2; o.next_start = n; return; }
             own_q = true;
         }
-        o.name.insert(o.name.end(), data + name_st, data + name_st + name_len); o.name_end.push_back(o.name.size());
         o.last_hdr = hdr;
         o.hdr_pos.push_back(hdr);
-        o.seq_end.push_back(o.seq.size());
-        if (own_c) o.comment.insert(o.comment.end(), data + com_st, data + com_st + com_len);
-        o.comment_end.push_back(o.comment.size()); o.own_c.push_back(own_c ? 1 : 0);
-        o.qual_end.push_back(o.qual.size()); o.own_q.push_back(own_q ? 1 : 0);
+        if (o.pack) {
+            const size_t w0 = o.words.size(), nw = (sq_len + 15) / 16;
+            o.words.resize(w0 + nw);
+            if (pack_bases(o.seq.data() + seq_base, (uint32_t)sq_len, o.words.data() + w0)) {
+                o.exc_rec.push_back(o.seq_end.size());
+                o.exc_bytes.insert(o.exc_bytes.end(), o.seq.begin() + seq_base, o.seq.end());
+                o.exc_off.push_back(o.exc_bytes.size());
+            }
+            o.seq.resize(seq_base); o.qual.resize(qual_base);
+            o.v_seq += sq_len; o.v_name += name_len;
+            o.name_h.push_back(name_hash(data + name_st, name_len));
+            o.name_end.push_back(o.v_name); o.seq_end.push_back(o.v_seq);
+            o.comment_end.push_back(0); o.qual_end.push_back(0);
+        } else {
+            o.name.insert(o.name.end(), data + name_st, data + name_st + name_len); o.name_end.push_back(o.name.size());
+            o.seq_end.push_back(o.seq.size());
+            if (own_c) o.comment.insert(o.comment.end(), data + com_st, data + com_st + com_len);
+            o.comment_end.push_back(o.comment.size());
+            o.qual_end.push_back(o.qual.size());
+        }
+        o.own_c.push_back(own_c ? 1 : 0); o.own_q.push_back(own_q ? 1 : 0);
         o.max_len = std::max<uint32_t>(o.max_len, (uint32_t)sq_len);
         if (c == -1 && pos >= n) { o.ended = true; o.last_ret = -1; o.next_start = n; return; }
     }
@@ -343,7 +437,7 @@ bool inflate_with_libdeflate(const char *path, InflatedBuf &out)
 namespace {
 // the (decompressed) text d[0, n) cut into pieces at guessed record starts, every piece parsed by parse_range on its own thread;
 // accepted only if each piece ends exactly where the next one began, else parsed again in one piece (exact by construction)
-void parse_pieces(const uint8_t *d, size_t n, std::vector<FxChunk> &ch, size_t piece_bytes = 8u << 20)
+void parse_pieces(const uint8_t *d, size_t n, std::vector<FxChunk> &ch, size_t piece_bytes = 8u << 20, bool pack = false)
 {
     size_t chunk_bytes = piece_bytes;
     if (const char *e = getenv("CRASS_FASTX_CHUNK")) chunk_bytes = (size_t)std::max(64ll, atoll(e));     // tests: force small pieces
@@ -361,6 +455,7 @@ void parse_pieces(const uint8_t *d, size_t n, std::vector<FxChunk> &ch, size_t p
         }
     }
     ch.assign(starts.size(), FxChunk());
+    for (auto &c : ch) c.pack = pack;
     auto run = [&](size_t k) { parse_range(d, n, starts[k], k + 1 < starts.size() ? starts[k + 1] : n, k == 0, ch[k]); };
     if (starts.size() == 1) run(0);
     else {
@@ -372,6 +467,7 @@ void parse_pieces(const uint8_t *d, size_t n, std::vector<FxChunk> &ch, size_t p
         for (size_t k = 0; k + 1 < starts.size() && ok; k++) ok = !ch[k].ended && ch[k].next_start == starts[k + 1];
         if (!ok) {                                       // a guess was wrong or the stream ended early: one piece, exact
             ch.assign(1, FxChunk());
+            ch[0].pack = pack;
             parse_range(d, n, 0, n, true, ch[0]);
         }
     }
@@ -595,9 +691,10 @@ uint64_t crass_fastx_find(const crass_fastx *f, const char *name, uint64_t len)
 // quality line (kseq's stale-buffer semantics need the records in order) are left to the two readers above: CRASS_ERR_UNSUPPORTED.
 struct crass_fastx_index {
     void *map = nullptr; size_t map_n = 0;
-    std::vector<uint64_t> hdr_pos;                     // [n]
-    PackedOwner pk;
-    std::vector<uint64_t> header_id;                   // [n] or empty (all names unique)
+    RawBuf<uint64_t> hdr_pos;                          // [n]
+    RawBuf<uint32_t> packed; RawBuf<uint64_t> word_off; RawBuf<uint32_t> lengths;
+    PackedOwner pk;                                    // (the exception lists)
+    RawBuf<uint64_t> header_id;                        // [n] or empty (all names unique)
     crass_reads reads{};
     uint32_t max_len = 0;
     int last_ret = -1;
@@ -632,108 +729,94 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
     const uint8_t *d = (const uint8_t *)ix->map;
     const double t1 = now_s();
     std::vector<FxChunk> ch;
-    parse_pieces(d, n, ch);
+    parse_pieces(d, n, ch, 8u << 20, true);             // (pack mode: every record is packed as it is parsed, its text dropped)
     const double t2 = now_s();
     const size_t nc = ch.size();
-    std::vector<uint64_t> rec0(nc + 1, 0);
+    std::vector<uint64_t> rec0(nc + 1, 0), tight0(nc + 1, 0);
     bool any_c = false, all_c = true, any_q = false, all_q = true;
     uint32_t max_len = 0, min_len = 0xFFFFFFFFu;
-    for (size_t k = 0; k < nc; k++) {
-        rec0[k + 1] = rec0[k] + ch[k].n_rec();
-        for (uint8_t v : ch[k].own_c) { any_c |= v != 0; all_c &= v != 0; }
-        for (uint8_t v : ch[k].own_q) { any_q |= v != 0; all_q &= v != 0; }
-        max_len = std::max(max_len, ch[k].max_len);
+    {
+        std::vector<uint32_t> pmin(nc, 0xFFFFFFFFu);
+        std::vector<uint8_t> fl(nc, 0);
+        auto scan = [&](size_t k) {
+            const FxChunk &c = ch[k];
+            uint32_t mn = 0xFFFFFFFFu;
+            uint8_t f = 12;                              // bit 0 any_c, 1 any_q, 2 all_c, 3 all_q
+            for (size_t i = 0; i < c.n_rec(); i++) {
+                mn = std::min<uint32_t>(mn, (uint32_t)(c.seq_end[i] - (i ? c.seq_end[i - 1] : 0)));
+                if (c.own_c[i]) f |= 1; else f &= (uint8_t)~4;
+                if (c.own_q[i]) f |= 2; else f &= (uint8_t)~8;
+            }
+            pmin[k] = mn; fl[k] = f;
+        };
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < nc; k++) th.emplace_back(scan, k);
+        if (nc) scan(0);
+        for (auto &t : th) t.join();
+        for (size_t k = 0; k < nc; k++) {
+            rec0[k + 1] = rec0[k] + ch[k].n_rec(); tight0[k + 1] = tight0[k] + ch[k].words.size();
+            max_len = std::max(max_len, ch[k].max_len); min_len = std::min(min_len, pmin[k]);
+            if (ch[k].n_rec()) { any_c |= (fl[k] & 1) != 0; any_q |= (fl[k] & 2) != 0; all_c &= (fl[k] & 4) != 0; all_q &= (fl[k] & 8) != 0; }
+        }
     }
     if ((any_c && !all_c) || (any_q && !all_q)) return CRASS_ERR_UNSUPPORTED;      // stale comment / quality buffers: ordered readers
     if (max_len > CRASS_HIP_MAX_READ_LEN) return CRASS_ERR_UNSUPPORTED;
     const uint64_t nrec = rec0[nc];
-    ix->any_c = any_c; ix->any_q = any_q; ix->max_len = max_len; ix->last_ret = ch.empty() ? -1 : ch.back().last_ret;
-    // ---- layout: crass_pack_reads' rules (mode 2) from the lengths alone, then every piece packs into place ----
-    std::vector<uint64_t> tight0(nc + 1, 0);           // words of the pieces' reads, tightly packed
-    {
-        std::vector<uint32_t> pmin(nc, 0xFFFFFFFFu);
-        std::vector<std::thread> th;
-        auto scan = [&](size_t k) {
-            const FxChunk &c = ch[k];
-            uint64_t w = 0; uint32_t mn = 0xFFFFFFFFu;
-            for (size_t i = 0; i < c.n_rec(); i++) { const uint64_t l = c.seq_end[i] - (i ? c.seq_end[i - 1] : 0); w += (l + 15) / 16; mn = std::min<uint32_t>(mn, (uint32_t)l); }
-            tight0[k + 1] = w; pmin[k] = mn;
-        };
-        for (size_t k = 1; k < nc; k++) th.emplace_back(scan, k);
-        if (nc) scan(0);
-        for (auto &t : th) t.join();
-        for (size_t k = 0; k < nc; k++) { tight0[k + 1] += tight0[k]; min_len = std::min(min_len, pmin[k]); }
-    }
     if (nrec == 0) min_len = 0;
+    ix->any_c = any_c; ix->any_q = any_q; ix->max_len = max_len; ix->last_ret = ch.empty() ? -1 : ch.back().last_ret;
+    // ---- layout: crass_pack_reads' rules (mode 2); the pieces' words are then copied into place ----
     const bool uniform_len = nrec > 0 && max_len == min_len;
     const uint64_t padded = nrec * (uint64_t)((max_len + 15) / 16);
     const bool pad = max_len <= 256 && max_len >= 64 && padded <= 2 * tight0[nc];
     const uint32_t stride = (uniform_len || pad) ? std::max<uint32_t>(1, (max_len + 15) / 16) : 0;
     PackedOwner &o = ix->pk;
-    try {
-        // (no zero fill of 2 GB on one thread: the pieces write every word they own, pad words included)
-        o.packed.resize(stride ? nrec * (uint64_t)stride + 4 : tight0[nc] + 4);
-        if (!stride) o.word_off.resize(nrec + 1);
-        if (!uniform_len) o.lengths.resize(nrec);
-        ix->hdr_pos.resize(nrec);
-    } catch (const std::bad_alloc &) { return CRASS_ERR_OOM; }
-    std::vector<uint32_t> name_len;
-    try { name_len.resize(nrec); } catch (const std::bad_alloc &) { return CRASS_ERR_OOM; }
-    std::vector<std::vector<uint64_t>> exc_parts(nc);
-    std::vector<std::vector<uint8_t>> exc_bytes_parts(nc);
-    std::vector<std::vector<uint64_t>> exc_off_parts(nc);
+    RawBuf<uint32_t> name_len;
+    RawBuf<uint64_t> nh;
+    const size_t n_words = (size_t)(stride ? nrec * (uint64_t)stride + 4 : tight0[nc] + 4);
+    // (no zero fill: the pieces write every word they own, pad words included)
+    if (!ix->packed.alloc(n_words) || (!stride && !ix->word_off.alloc(nrec + 1)) || (!uniform_len && !ix->lengths.alloc(nrec)) ||
+        !ix->hdr_pos.alloc(nrec) || !name_len.alloc(nrec) || !nh.alloc(nrec)) return CRASS_ERR_OOM;
     {
-        static const struct Lut { uint8_t t[256]; Lut() { memset(t, 0x80, sizeof(t)); t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; } } lut;
-        uint32_t *packed = o.packed.data();
-        auto pack_piece = [&](size_t k) {
+        uint32_t *packed = ix->packed.data();
+        auto place = [&](size_t k) {
             FxChunk &c = ch[k];
-            uint64_t wat = tight0[k];
-            for (size_t i = 0; i < c.n_rec(); i++) {
+            const size_t m = c.n_rec();
+            if (m) {
+                memcpy(ix->hdr_pos.data() + rec0[k], c.hdr_pos.data(), m * 8);
+                memcpy(nh.data() + rec0[k], c.name_h.data(), m * 8);
+            }
+            if (uniform_len) { if (!c.words.empty()) memcpy(packed + rec0[k] * (uint64_t)stride, c.words.data(), c.words.size() * 4); }
+            else if (!stride && !c.words.empty()) memcpy(packed + tight0[k], c.words.data(), c.words.size() * 4);
+            uint64_t wat = 0;
+            for (size_t i = 0; i < m; i++) {
                 const uint64_t r = rec0[k] + i;
-                const uint64_t s0 = i ? c.seq_end[i - 1] : 0;
-                const uint32_t L = (uint32_t)(c.seq_end[i] - s0);
-                const uint8_t *s = c.seq.data() + s0;
+                const uint32_t L = (uint32_t)(c.seq_end[i] - (i ? c.seq_end[i - 1] : 0));
                 const uint32_t nw = (L + 15) / 16;
-                uint32_t *w = packed + (stride ? r * (uint64_t)stride : wat);
-                if (!stride) o.word_off[r] = wat;
-                if (!uniform_len) o.lengths[r] = L;
-                ix->hdr_pos[r] = c.hdr_pos[i];
                 name_len[r] = (uint32_t)(c.name_end[i] - (i ? c.name_end[i - 1] : 0));
-                uint32_t bad = 0, q0 = 0;
-                for (; q0 + 16 <= L; q0 += 16) {
-                    uint32_t acc = 0;
-                    for (int q = 0; q < 16; q++) { const uint32_t cc = lut.t[s[q0 + q]]; bad |= cc; acc |= (cc & 3u) << (2 * q); }
-                    w[q0 >> 4] = acc;
-                }
-                if (q0 < L) {
-                    uint32_t acc = 0;
-                    for (uint32_t q = 0; q0 + q < L; q++) { const uint32_t cc = lut.t[s[q0 + q]]; bad |= cc; acc |= (cc & 3u) << (2 * q); }
-                    w[q0 >> 4] = acc;
-                }
-                for (uint32_t x = nw; stride && x < stride; x++) w[x] = 0;
-                if (bad & 0x80u) {
-                    exc_parts[k].push_back(r);
-                    exc_bytes_parts[k].insert(exc_bytes_parts[k].end(), s, s + L);
-                    exc_off_parts[k].push_back(exc_bytes_parts[k].size());
+                if (!uniform_len) ix->lengths[r] = L;
+                if (!stride) ix->word_off[r] = tight0[k] + wat;
+                else if (!uniform_len) {                 // padded to one stride
+                    uint32_t *w = packed + r * (uint64_t)stride;
+                    memcpy(w, c.words.data() + wat, (size_t)nw * 4);
+                    for (uint32_t x = nw; x < stride; x++) w[x] = 0;
                 }
                 wat += nw;
             }
-            // the piece's text goes as soon as it is packed (peak host memory: the words + what the slowest pieces still hold)
-            std::vector<uint8_t>().swap(c.seq); std::vector<uint8_t>().swap(c.qual); std::vector<uint8_t>().swap(c.comment); std::vector<uint8_t>().swap(c.name);
+            std::vector<uint32_t>().swap(c.words); std::vector<uint64_t>().swap(c.hdr_pos); std::vector<uint64_t>().swap(c.name_h);
         };
         std::vector<std::thread> th;
-        for (size_t k = 1; k < nc; k++) th.emplace_back(pack_piece, k);
-        if (nc) pack_piece(0);
+        for (size_t k = 1; k < nc; k++) th.emplace_back(place, k);
+        if (nc) place(0);
         for (auto &t : th) t.join();
-        if (!stride) o.word_off[nrec] = tight0[nc];
-        for (size_t x = 0; x < 4; x++) o.packed[o.packed.size() - 4 + x] = 0;
+        if (!stride) ix->word_off[nrec] = tight0[nc];
+        for (size_t x = 0; x < 4; x++) ix->packed[n_words - 4 + x] = 0;
     }
     o.exc_off.push_back(0);
     for (size_t k = 0; k < nc; k++) {
         const uint64_t base = o.exc_bytes.size();
-        o.exc_read.insert(o.exc_read.end(), exc_parts[k].begin(), exc_parts[k].end());
-        o.exc_bytes.insert(o.exc_bytes.end(), exc_bytes_parts[k].begin(), exc_bytes_parts[k].end());
-        for (uint64_t e : exc_off_parts[k]) o.exc_off.push_back(base + e);
+        for (uint64_t e : ch[k].exc_rec) o.exc_read.push_back(rec0[k] + e);
+        o.exc_bytes.insert(o.exc_bytes.end(), ch[k].exc_bytes.begin(), ch[k].exc_bytes.end());
+        for (uint64_t e : ch[k].exc_off) o.exc_off.push_back(base + e);
     }
     std::vector<FxChunk>().swap(ch);
     const double t3 = now_s();
@@ -742,20 +825,21 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
     if (nrec) {
         size_t cap = 1024;
         while (cap * 10 < nrec * 14) cap <<= 1;
-        std::unique_ptr<std::atomic<uint64_t>[]> tab(new (std::nothrow) std::atomic<uint64_t>[cap]);
-        std::vector<uint32_t> first;
-        try { first.resize(nrec); } catch (const std::bad_alloc &) { tab.reset(); }
-        if (!tab || nrec >= 0xFFFFFFFFull) return CRASS_ERR_UNSUPPORTED;
+        static_assert(sizeof(std::atomic<uint64_t>) == 8, "the table is an array of 64-bit words");
+        RawBuf<uint64_t> tab_mem;
+        RawBuf<uint32_t> first;
+        RawBuf<uint64_t> slot_of;
+        if (nrec >= 0xFFFFFFFFull) return CRASS_ERR_UNSUPPORTED;
+        if (!tab_mem.alloc(cap) || !first.alloc(nrec) || !slot_of.alloc(nrec)) return CRASS_ERR_OOM;
+        std::atomic<uint64_t> *tab = reinterpret_cast<std::atomic<uint64_t> *>(tab_mem.data());
         const unsigned ht = (unsigned)std::min<uint64_t>(hw_threads(), std::max<uint64_t>(1, nrec / 65536));
-        parallel_ranges(cap, ht, [&](uint64_t a, uint64_t b2, unsigned) { for (uint64_t i = a; i < b2; i++) tab[i].store(0, std::memory_order_relaxed); });
+        parallel_ranges(cap, ht, [&](uint64_t a, uint64_t b2, unsigned) { for (uint64_t i = a; i < b2; i++) new (&tab[i]) std::atomic<uint64_t>(0); });
         auto same_name = [&](uint64_t x, uint64_t y) {
             return name_len[x] == name_len[y] && memcmp(d + ix->hdr_pos[x] + 1, d + ix->hdr_pos[y] + 1, name_len[x]) == 0;
         };
-        std::vector<uint64_t> slot_of;
-        try { slot_of.resize(nrec); } catch (const std::bad_alloc &) { return CRASS_ERR_OOM; }
         parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b2, unsigned) {
             for (uint64_t r = a; r < b2; r++) {
-                const uint64_t h = name_hash(d + ix->hdr_pos[r] + 1, name_len[r]);
+                const uint64_t h = nh[r];               // (hashed while the name was in the parser's hands)
                 const uint64_t tag = ((h >> 32) | 1ull) << 32;
                 size_t i = (size_t)h & (cap - 1);
                 for (;;) {
@@ -780,20 +864,20 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
         });
         any_dup = dup.load() != 0;
         if (any_dup) {
-            try { ix->header_id.resize(nrec); } catch (const std::bad_alloc &) { return CRASS_ERR_OOM; }
+            if (!ix->header_id.alloc(nrec)) return CRASS_ERR_OOM;
             parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b2, unsigned) { for (uint64_t r = a; r < b2; r++) ix->header_id[r] = first[r]; });
         }
     }
     crass_reads &r = ix->reads;
-    r.n_reads = nrec; r.packed = o.packed.data(); r.stride_words = stride;
-    r.word_off = stride ? nullptr : o.word_off.data();
+    r.n_reads = nrec; r.packed = ix->packed.data(); r.stride_words = stride;
+    r.word_off = stride ? nullptr : ix->word_off.data();
     r.uniform_len = uniform_len ? max_len : 0;
-    r.lengths = uniform_len ? nullptr : o.lengths.data();
+    r.lengths = uniform_len ? nullptr : ix->lengths.data();
     r.n_exceptions = o.exc_read.size();
     r.exc_read = o.exc_read.data(); r.exc_off = o.exc_off.data(); r.exc_bytes = o.exc_bytes.data();
     r.header_id = any_dup ? ix->header_id.data() : nullptr; r.read_index_base = 0;
     if (timing)
-        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse %.3f s, pack in place %.3f s, header ids %.3f s\n",
+        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse + pack %.3f s, words into place %.3f s, header ids %.3f s\n",
                 n, nc, (unsigned long long)nrec, t1 - t0, t2 - t1, t3 - t2, now_s() - t3);
     *out = ix.release();
     return CRASS_OK;
