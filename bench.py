@@ -82,6 +82,8 @@ def parse():
                     "instead of the collective")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--params", default="", help="crass options other than the defaults, as on crass's command line: d=20,D=40 / w=7 / s=20,S=60 / n=3 / k=5 "
+                                                  "(what a user of -d/-D/-s/-S/-w/-n gets: the fast filter and the position hints are built for the defaults)")
     return ap.parse_args()
 
 
@@ -163,6 +165,16 @@ def main():
             dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
     coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
+    # ---- options (default: crass's own) ----
+    pkw = {}
+    for kv in [x for x in args.params.split(",") if x]:
+        k, v = kv.split("=")
+        pkw[{"d": "lowDRsize", "D": "highDRsize", "s": "lowSpacerSize", "S": "highSpacerSize", "w": "searchWindowLength", "n": "minNumRepeats", "k": "kmer_clust_size"}[k]] = int(v)
+    prm = ca.default_params(**pkw) if pkw else None
+    _orc_params = None
+    if pkw:
+        from tests import orc as _orc0
+        _orc_params = _orc0.Params(prm.lowDRsize, prm.highDRsize, prm.lowSpacerSize, prm.highSpacerSize, prm.searchWindowLength, prm.minNumRepeats, prm.kmer_clust_size)
     # ---- workload ----
     cfg_id = args.config or 2
     cfg = dict(CONFIGS[cfg_id])
@@ -178,7 +190,7 @@ def main():
         # one job split over the ranks: configs[2] (and any --total-reads) is a strong-scaling workload at every N
         # incl. 1; the other configs are single-GPU workloads (per-GPU work fixed: "weak")
         scaling = "strong" if world > 1 or args.total_reads or cfg_id == 2 else "weak"
-    custom = bool(args.reads or args.total_reads or args.read_len or args.n_dr or args.gc_classes >= 0)
+    custom = bool(args.reads or args.total_reads or args.read_len or args.n_dr or args.gc_classes >= 0 or args.params)
     W = (L + 15) // 16
     spec = ca.synth_spec(read_len=L, n_dr=n_dr, gc_classes=gc, crispr_per_million=cfg["cpm"],
                          array_min_repeats=cfg["arrays"][0], array_max_repeats=cfg["arrays"][1])
@@ -205,11 +217,11 @@ def main():
         eng.g.load_packed_uniform(words, n, L, read_index_base=first)   # sharded by contiguous read ranges, H2D once
         scaling = "strong"
     else:
-        eng = ca.SearchEngine(device=local_rank)
+        eng = ca.SearchEngine(prm, local_rank)
         eng.load_packed_uniform(words, n, L, read_index_base=first)     # H2D once; resident for every step
     engs = [eng]
     if args.alternate:                                      # a second resident batch (the next reads of the same stream)
-        eng_b = ca.SearchEngine(device=local_rank)
+        eng_b = ca.SearchEngine(prm, local_rank)
         words_b = ca.synth_packed(spec, total + first, n)
         eng_b.load_packed_uniform(words_b, n, L, read_index_base=total + first)
         del words_b
@@ -397,7 +409,7 @@ def main():
                    "filter_survivors": int(n_surv),
                    "fast_filter": int(c["used_fast_filter"]), "lds_automaton": int(c["used_lds_automaton"]),
                    "merge_fallbacks": int(c.get("n_merge_fallbacks", 0)),      # device merges redone on the host: must stay 0
-                   "synth_gen_s": round(t_gen, 2)},
+                   "synth_gen_s": round(t_gen, 2), **({"params": args.params} if args.params else {})},
         "first_call_ms": round(first_call_ms, 3),
         # this rank's wall clock between step ends inside the timed region (value / ms_per_step are the contract's total / K)
         "step_ms": {"median": round(float(np.median(per_step)), 4), "min": round(float(per_step.min()), 4),
@@ -418,7 +430,7 @@ def main():
     if world == 1 and not group_mode and args.single_shots > 0 and not args.alternate:
         shots = []
         for _ in range(args.single_shots):
-            e1 = ca.SearchEngine(device=local_rank)
+            e1 = ca.SearchEngine(prm, local_rank)
             e1.set_stage_timing(0)
             e1.load_packed_uniform(words, n, L, read_index_base=first)
             torch.cuda.synchronize()
@@ -462,7 +474,7 @@ def main():
         if rank == 0:
             try:
                 w_all = words if group_mode else ca.synth_packed(spec, 0, total)
-                e1 = ca.SearchEngine(device=local_rank)
+                e1 = ca.SearchEngine(prm, local_rank)
                 e1.load_packed_uniform(w_all, total, L, read_index_base=0)
                 del w_all
                 for _ in range(3):
@@ -495,14 +507,14 @@ def main():
         m = min(cpu_sample, n)
         asc = ca.unpack_ascii(words, W, L, m)
         off = np.arange(0, (m + 1) * L, L, dtype=np.uint64)
-        r = orc.pipeline_time_keep(asc, off)
+        r = orc.pipeline_time_keep(asc, off, _orc_params)
         cpu_s = r["t_pass1"] + r["t_merge"] + r["t_pass2"]
         # ---- parity gate (a number only counts with it): the HIP path over the SAME prefix, on a fresh context,
         #      against the oracle run that was just timed — every record, token, group and pattern (tests/parity.py).  A mismatch
         #      is printed in the line and the run exits non-zero. ----
         try:
             from tests.parity import assert_same_pipeline
-            e2 = ca.SearchEngine(device=local_rank)
+            e2 = ca.SearchEngine(prm, local_rank)
             e2.load_packed_uniform(words[:m * W], m, L)
             cand = e2.seed_scan(); mg = e2.merge(); rec = e2.recruit(); mg = e2.merge_view()
             gpu_res = ca.engine.PipelineResult(cand, mg, rec, cand.max_read_len)
@@ -525,7 +537,7 @@ def main():
         # box as a built .so): PatternMatcher::bmpSearch over searchCore's windows, acism_scan over the reads
         try:
             mc = min(m, 200_000 if L <= 1000 else 4_000)
-            res = orc.pipeline((asc[:mc * L], off[:mc + 1]))
+            res = orc.pipeline((asc[:mc * L], off[:mc + 1]), params=_orc_params)
             cal = orc.calibrate(asc[:mc * L], mc, L, res.patterns)
             if cal is None:
                 cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_calibration.json")))

@@ -296,6 +296,8 @@ struct crass_hip_ctx {
     DevBuf<uint64_t> d_fidx;
     DevBuf<uint64_t> d_pos_hint, d_pos_hint_off; uint64_t n_pos_hint_words = 0;     // long reads: per-position seed hints
     DevBuf<uint32_t> d_punt;                                                          // long reads: [0] count, [1 ..] slots the light walk handed over
+    DevBuf<uint32_t> d_redo;                                                          // ... [0] count, [1 ..] slots the full kernel hands on to its full-layout launch
+    SdmaCopy *dma_sink[4] = {nullptr, nullptr, nullptr, nullptr};                     // the long-read sink's four copies on DMA engines (created with the first long-read set)
     DevBuf<uint32_t> d_pos_hint_blk; bool pos_hint_blk = false;                       // ragged lengths: read of every 256th hint word
     // device-side DR de-duplication (single-GPU merge fast path)
     DevBuf<unsigned long long> dd_keys; DevBuf<uint32_t> dd_first, dd_slot, dd_rep; DevBuf<uint64_t> dd_hash;
@@ -332,7 +334,8 @@ struct crass_hip_ctx {
     {
         if (!bulk_pending) return bulk_status;
         const hipError_t e = hipStreamSynchronize(copy_stream);
-        const int de = sdma_wait(dma);
+        int de = sdma_wait(dma);
+        for (SdmaCopy *s : dma_sink) de |= sdma_wait(s);
         bulk_pending = false;
         if (e != hipSuccess) { last_hip = (int)e; bulk_status = CRASS_ERR_HIP; }
         else if (de) { last_hip = (int)hipErrorUnknown; bulk_status = CRASS_ERR_HIP; }
@@ -765,6 +768,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     if (c->ev_hint_go) (void)hipEventDestroy(c->ev_hint_go);
     if (c->hint_stream) (void)hipStreamDestroy(c->hint_stream);
     sdma_destroy(c->dma); c->dma = nullptr;
+    for (auto &d : c->dma_sink) { sdma_destroy(d); d = nullptr; }
     for (auto &d : c->dma_dx) { sdma_destroy(d); d = nullptr; }
     if (c->ev_premerge) (void)hipEventDestroy(c->ev_premerge);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -774,7 +778,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
     c->g_surv.release(); c->g_dr.release(); c->g_ss.release(); c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
-    c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->d_pos_hint.release(); c->d_pos_hint_off.release(); c->d_pos_hint_blk.release(); c->d_punt.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
+    c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->d_pos_hint.release(); c->d_pos_hint_off.release(); c->d_pos_hint_blk.release(); c->d_punt.release(); c->d_redo.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1096,7 +1100,10 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             R.exc_read = c->R.exc_read + off; R.exc_off = c->R.exc_off + off; R.n_exc = nchunk;
         }
         // for the non-exception path the count lives on the device; chunking uses a host-known bound
-        if (use_light) { HIPCHK(c, c->d_punt.ensure(nchunk + 1)); HIPCHK(c, hipMemsetAsync(c->d_punt.p, 0, 4, c->stream)); }
+        if (use_light) {
+            HIPCHK(c, c->d_punt.ensure(nchunk + 1)); HIPCHK(c, hipMemsetAsync(c->d_punt.p, 0, 4, c->stream));
+            HIPCHK(c, c->d_redo.ensure(nchunk + 1)); HIPCHK(c, hipMemsetAsync(c->d_redo.p, 0, 4, c->stream));
+        }
         if (!exc && off == 0) HIPCHK(c, c->stamp(8, 1));
         if (!exc && c->hint_pending && off == 0 && nchunk == n_total) {
             // the walk, slice by slice behind the slice's hints (slot boundaries: the survivors with a read below the slice's end;
@@ -1131,9 +1138,14 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         if (use_light)
             HIPCHK(c, launch_survivor(R, c->dp, false, nullptr, c->d_count.p + 1, nchunk,
                                       c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
-                                      c->d_found.p, nullptr, lds, (int)std::min<uint64_t>(256 * 12, nchunk), c->stream, 7, 0, nchunk, c->d_punt.p + 1, c->d_punt.p));
+                                      c->d_found.p, nullptr, lds, (int)std::min<uint64_t>(256 * 12, nchunk), c->stream, 7, 0, nchunk, c->d_punt.p + 1, c->d_punt.p,
+                                      capped ? c->d_redo.p : nullptr));
         if (use_light && c->dp.prof) { HIPCHK(c, hipStreamSynchronize(c->stream)); dump_surv_prof(c); }      // (diagnostics: this launch's counters alone)
-        if (capped)
+        if (capped && use_light)                    // (only the full kernel can have met such a read: its list)
+            HIPCHK(c, launch_survivor(R, c->dp, false, nullptr, c->d_count.p + 1, nchunk,
+                                      c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
+                                      c->d_found.p, nullptr, lds_full, (int)std::min<uint64_t>(256 * 2, nchunk), c->stream, 6, 0, nchunk, c->d_redo.p + 1, c->d_redo.p));
+        else if (capped)
             HIPCHK(c, launch_survivor(R, c->dp, exc, (exc || ident_list) ? nullptr : c->d_idx.p + off, c->d_count.p + (exc ? 0 : 1), nchunk,
                                       c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p,
                                       c->d_found.p, (!exc && c->hints_valid) ? c->d_hit_info.p : nullptr, lds_full,
@@ -1180,10 +1192,20 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         const bool lazy = !sink_eager && !exc && off == 0 && nchunk == n_total && c->R.n_exc == 0 && !surv_idx_host && &L == &c->cand && L.read.empty();
         if (nf) {
             hipStream_t cs = lazy ? c->copy_stream : c->stream;      // (the main stream is idle: it was waited for above)
-            HIPCHK(c, hipMemcpyAsync(c->h_surv.p, c->g_surv.p, nf * sizeof(SurvOut), hipMemcpyDeviceToHost, cs));
-            HIPCHK(c, hipMemcpyAsync(c->h_dr.p, c->g_dr.p, nf * (size_t)stride, hipMemcpyDeviceToHost, cs));
-            HIPCHK(c, hipMemcpyAsync(c->h_idx.p, c->d_fidx.p, nf * 8, hipMemcpyDeviceToHost, cs));
-            if (used) HIPCHK(c, hipMemcpyAsync(c->h_ss.p, c->g_ss.p, (size_t)used * (ss16 ? 2 : 4), hipMemcpyDeviceToHost, cs));
+            // lazy: on DMA engines where the runtime offers them — as blit kernels these 12 MB of PCIe stores stretched whatever
+            // ran beside them (k_block_scan of the de-duplication: 138 us instead of 5, profiles/r05_timeline_c3.txt)
+            const void *srcs[4] = {c->g_surv.p, c->g_dr.p, c->d_fidx.p, c->g_ss.p};
+            void *dsts[4] = {c->h_surv.p, c->h_dr.p, c->h_idx.p, c->h_ss.p};
+            const size_t nbs[4] = {nf * sizeof(SurvOut), nf * (size_t)stride, nf * 8, used ? (size_t)used * (ss16 ? 2 : 4) : 0};
+            static const bool sink_blit = getenv("CRASS_COPY_BLIT") != nullptr;
+            for (int q = 0; q < 4; q++) {
+                if (!nbs[q]) continue;
+                if (lazy && !sink_blit) {
+                    if (!c->dma_sink[q]) c->dma_sink[q] = sdma_create();
+                    if (sdma_start(c->dma_sink[q], srcs[q], dsts[q], nbs[q])) continue;
+                }
+                HIPCHK(c, hipMemcpyAsync(dsts[q], srcs[q], nbs[q], hipMemcpyDeviceToHost, cs));
+            }
             if (lazy) {
                 if (!c->ev_sink_copies) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sink_copies, hipEventDisableTiming));
                 HIPCHK(c, hipEventRecord(c->ev_sink_copies, c->copy_stream));
@@ -1280,6 +1302,7 @@ static void presize_hostloop(crass_hip_ctx *c)
     if (!c->R.pos_hint || c->env.no_presize || c->R.n_reads == 0) return;
     const SurvLds lds_full = survivor_lds_layout(c->max_len, c->dp);
     if (lds_full.total_bytes > 160 * 1024) return;
+    for (auto &d : c->dma_sink) if (!d) d = sdma_create();      // (an engine's queue is created by its first copy, ~6 ms: here)
     const uint64_t chunk_cap = std::min<uint64_t>(c->R.n_reads, 1u << 20);
     const uint64_t ss_per = std::min<uint64_t>(lds_full.ss_cap, 64);
     const uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(chunk_cap * ss_per, 1u << 16), 1ull << 28);
@@ -1290,6 +1313,7 @@ static void presize_hostloop(crass_hip_ctx *c)
     while (tsize < nf * 2) tsize <<= 1;
     bool ok = true;
     auto need = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
+    need(c->d_punt.ensure(chunk_cap + 1)); need(c->d_redo.ensure(chunk_cap + 1));
     need(c->d_surv.ensure(chunk_cap)); need(c->d_dr.ensure(chunk_cap * stride)); need(c->d_ss_pool.ensure(pool_cap));
     need(c->h_surv.ensure(chunk_cap)); need(c->h_dr.ensure(chunk_cap * stride));
     need(c->d_fidx.ensure(chunk_cap)); need(c->g_surv.ensure(chunk_cap)); need(c->g_dr.ensure(chunk_cap * (size_t)stride + 16)); need(c->g_ss.ensure(pool_cap));

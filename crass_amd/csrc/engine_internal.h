@@ -76,6 +76,11 @@ struct DevAutomaton {
                                   // position is in the exact state there
 };
 
+// tab_mode 2's Bloom filter (2^20 bits = 2^15 words in LDS), blocked: word = the hash's top 15 bits, two bits inside the word from
+// its bits 12..16 and 7..11 (a shift by a register uses the low five bits of the register: no masking)
+static __host__ __device__ __forceinline__ uint32_t ak_bloom_word(uint32_t h) { return h >> 17; }
+static __host__ __device__ __forceinline__ uint32_t ak_bloom_bits(uint32_t h) { return (1u << ((h >> 12) & 31u)) | (1u << ((h >> 7) & 31u)); }
+
 // pass-2 anchor filter: cuckoo hash set (two choices, one slot each) of every 16-mer that
 // starts at offset 0..7 of a pattern, as 32-bit packed values; lives in LDS.
 // h_i(V) = ak_hash(V, m_i) >> (32 - log_size)   (merge.h: one v_mad_u32_u24 per hash)
@@ -348,7 +353,8 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
                            int punt_only = 0,
                            uint64_t slot_base = 0, uint64_t slot_total = 0,       // a slice of a larger launch: out / dr_chars point at the slice, the start/stop pool is shared
-                           const uint32_t *punt_list = nullptr, const uint32_t *d_punt_n = nullptr);      // punt_only with a list: exactly those slots, one per wave and turn
+                           const uint32_t *punt_list = nullptr, const uint32_t *d_punt_n = nullptr,       // punt_only with a list: exactly those slots, one per wave and turn
+                           uint32_t *redo_list = nullptr);      // [0] count, [1 ..] slots this launch hands on to the launch with the full layout (err 6)
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                  uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st,

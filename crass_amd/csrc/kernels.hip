@@ -1822,7 +1822,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
                                                    char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                                    uint32_t ss_pool_cap, uint32_t *d_ss_used,
                                                    uint8_t *found_flag, const uint32_t *seed_hint, SurvLds lds, int punt_only, uint64_t slot_base, uint64_t slot_total,
-                                                   const uint32_t *punt_list, const uint32_t *d_punt_n)
+                                                   const uint32_t *punt_list, const uint32_t *d_punt_n, uint32_t *redo_list)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sv_lds[];
     const int lane = threadIdx.x;
@@ -1985,6 +1985,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             }
         }
         if (lane == 0) out[s] = o;
+        // (a read this launch's layout cannot hold goes on the list of the launch with the full layout: that launch then visits
+        // exactly those slots instead of polling every slot's error byte — 68 us for 1 M slots of which none is flagged)
+        if (redo_list && o.err == 6 && lane == 0) redo_list[1u + atomicAdd(redo_list, 1u)] = (uint32_t)s;
         if (h.lprof && lane == 0) h.lprof[PF_OUT] = (unsigned long long)__builtin_readcyclecounter() - prof_t1;
         if (h.lprof) {
             // category 1: walked, nothing found; 2: found; 3: handed over / error (0: skipped, no hinted seed)
@@ -3383,7 +3386,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
                            const uint32_t *d_n_surv, uint64_t n_surv_max, SurvOut *out, char *dr_chars,
                            uint32_t dr_stride, uint32_t *ss_pool, uint32_t ss_pool_cap, uint32_t *d_ss_used,
                            uint8_t *found_flag, const uint32_t *seed_hint, const SurvLds &lds, int grid, hipStream_t st,
-                           int punt_only, uint64_t slot_base, uint64_t slot_total, const uint32_t *punt_list, const uint32_t *d_punt_n)
+                           int punt_only, uint64_t slot_base, uint64_t slot_total, const uint32_t *punt_list, const uint32_t *d_punt_n, uint32_t *redo_list)
 {
     if (n_surv_max == 0) return hipSuccess;
     hipError_t e;
@@ -3392,7 +3395,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         CRASS_LAUNCH(k_survivor<true>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total, punt_list, d_punt_n);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total, punt_list, d_punt_n, redo_list);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_survivor<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -3403,7 +3406,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
             fprintf(stderr, "[occ] k_survivor<false>: %d blocks per CU with %u bytes of LDS, grid %d, punt %d\n", nb, lds_bytes, grid, punt_only);
         }
         CRASS_LAUNCH(k_survivor<false>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, surv_idx, d_n_surv, n_surv_max,
-                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total, punt_list, d_punt_n);
+                           out, dr_chars, dr_stride, ss_pool, ss_pool_cap, d_ss_used, found_flag, seed_hint, lds, punt_only, slot_base, slot_total, punt_list, d_punt_n, redo_list);
     }
     return hipGetLastError();
 }
@@ -3561,12 +3564,10 @@ static __device__ __forceinline__ bool anchor_probe(const uint32_t *tab, uint32_
 static __device__ __forceinline__ bool anchor_probe_bloom(const uint32_t *bloom, const uint32_t *gtab, uint32_t V, const DevAnchors &K, uint32_t rshift)
 {
     const uint32_t h1 = ak_hash(V, K.m1);
-    const uint32_t h2 = ak_hash(V, K.m2);
-    const uint32_t b1 = h1 >> 12, b2 = h2 >> 12;
-    const uint32_t w1 = bloom[b1 >> 5], w2 = bloom[b2 >> 5];
+    const uint32_t wd = bloom[ak_bloom_word(h1)];
     bool hit = false;
-    if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0u)          // ~7 % of the probes at 150 k keys
-        hit = (gtab[h1 >> rshift] == V) | (gtab[h2 >> rshift] == V);
+    if (((wd >> ((h1 >> 12) & 31u)) & (wd >> ((h1 >> 7) & 31u)) & 1u) != 0u)          // ~7 % of the probes at 150 k keys
+        hit = (gtab[h1 >> rshift] == V) | (gtab[ak_hash(V, K.m2) >> rshift] == V);
     return hit;
 }
 // MODE 3 (device-built tables): 2^16 slots, 16 bits per slot in LDS — the OTHER slot index of the key that sits there
@@ -3683,10 +3684,12 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
 #pragma unroll
                         for (int h = 0; h < 2 * W - 1; h++) {
                             const uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
-                            const uint32_t h1 = ak_hash(V, K.m1), h2 = ak_hash(V, K.m2);
-                            const uint32_t b1 = h1 >> 12, b2 = h2 >> 12;
-                            const uint32_t w1 = ak_lds[b1 >> 5], w2 = ak_lds[b2 >> 5];
-                            if (((w1 >> (b1 & 31u)) & (w2 >> (b2 & 31u)) & 1u) != 0u && (uint32_t)h <= h_max) pm |= 1u << h;
+                            // (blocked Bloom: ONE hash, one LDS word, both bits from it; a shift by a register takes the register's low
+                            // five bits, so the two positions cost a shift each and the window's flag joins pm with one v_lshl_or)
+                            const uint32_t h1 = ak_hash(V, K.m1);
+                            const uint32_t wd = ak_lds[ak_bloom_word(h1)];
+                            const uint32_t bit = (wd >> ((h1 >> 12) & 31u)) & (wd >> ((h1 >> 7) & 31u)) & 1u;
+                            if ((uint32_t)h <= h_max) pm |= bit << h;
                         }
                         while (pm) {                                   // (divergent: lanes with fewer positives idle)
                             const uint32_t h = (uint32_t)__ffs((int)pm) - 1u;
