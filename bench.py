@@ -702,7 +702,7 @@ def _e2e_cli(ca, spec, L, n, modes=("auto",)):
                     if m2:
                         rss = max(rss, float(m2.group(1)))
                     if "[crass_timing]" in line and ("fastx" in line or "searchAndRecruit:" in line or "cli:" in line or "outputs:" in line or
-                                                     ("consensus: " in line and "consensus:   " not in line)):
+                                                     ("consensus: " in line and "consensus:   " not in line) or "(adapter)" in line):
                         stages.append(line.strip()[15:])
             res[mode] = {"wall_s": round(min(walls), 3), "reads_per_s": round(n / min(walls), 1), "walls_s": [round(x, 3) for x in walls],
                          "peak_rss_mb": round(rss, 1), "found": found, "stages": stages}

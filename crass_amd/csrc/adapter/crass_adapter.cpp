@@ -2,6 +2,7 @@
 // addReadHolder) implemented over the C ABI of libcrass_hip.so.  See crass_adapter.h.
 #include "crass_adapter.h"
 #include <chrono>
+#include <functional>
 #include <future>
 #include <thread>
 #include <cstdio>
@@ -849,6 +850,9 @@ int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map 
                      GroupKmerMap &groupKmerCountsMap, int &nextFreeGID, int mMaxReadLength, const options &opts)
 {
     // ---- flatten the hand-off: holders in mReads order (std::map by token, list order inside) ----
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tc0 = now();
     std::vector<ReadHolder *> holders;
     std::vector<uint64_t> seq_off(1, 0), rec_read, rec_ss_off;
     std::vector<uint8_t> rec_low;
@@ -890,10 +894,13 @@ int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map 
     in.max_read_len = (uint32_t)mMaxReadLength;
     const crass_params p = to_params(opts);
     crass_cons *h = nullptr;
+    const double tc1 = now();
     chk(crass_hip_consensus(&p, device(), &in, &h), "crass_hip_consensus");
+    const double tc2 = now();
     crass_cons_view v{};
     chk(crass_hip_consensus_view(h, &v), "crass_hip_consensus_view");
     if (v.error) { crass_hip_consensus_free(h); return 1; }
+    struct Lap { bool on; double a, b, c0; std::function<double()> nw; ~Lap() { if (on) fprintf(stderr, "[crass_timing] consensus (adapter): hand-off flattened %.3f s, crass_hip_consensus %.3f s, results written back %.3f s\n", a - c0, b - a, nw() - b); } } lap{timing, tc1, tc2, tc0, now};
     // ---- write the results back into the hand-off state ----
     for (uint32_t t = (uint32_t)n_tok; t < v.n_tokens; t++)
         mStringCheck.addString(std::string(v.tok_chars + v.tok_off[t], (size_t)(v.tok_off[t + 1] - v.tok_off[t])));
@@ -929,6 +936,9 @@ int buildGraphsAndOutput(ReadMap &mReads, DR_Cluster_Map &mDR2GIDMap, std::map<i
 {
     // buildGraph's order (WorkHorse.cpp:454-505): groups in ascending GID that have a cluster and a true DR; for every token of
     // the cluster, the token's ReadHolders in list order
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tb0 = now();
     std::vector<int32_t> gid;
     std::string dr, hdr, com, seq;
     std::vector<uint64_t> dr_off(1, 0), grp_rec_off(1, 0), hdr_off(1, 0), com_off(1, 0), seq_off(1, 0), rec_ss_off;
@@ -972,12 +982,15 @@ int buildGraphsAndOutput(ReadMap &mReads, DR_Cluster_Map &mDR2GIDMap, std::map<i
     oo.log_to_screen = opts.logToScreen ? 1 : 0; oo.cov_cutoff = opts.covCutoff; oo.node_kmer = opts.cNodeKmerLength;
     oo.show_singles = opts.showSingles ? 1 : 0; oo.long_description = opts.longDescription ? 1 : 0;
     crass_outputs *res = nullptr;
+    const double tb1 = now();
     const int rc = crass_build_outputs(&in, &oo, &res);
     if (rc != CRASS_OK) { std::cerr << "[ERROR]: building the spacer graphs failed: " << crass_hip_strerror(rc) << std::endl; return -1; }
+    const double tb2 = now();
     crass_outputs_view v{};
     (void)crass_outputs_get(res, &v);
     std::cout << v.stdout_text << std::flush;
     const int wrc = crass_outputs_write(res, opts.output_fastq.c_str());
+    if (timing) fprintf(stderr, "[crass_timing] outputs (adapter): hand-off flattened %.3f s, crass_build_outputs %.3f s, files written %.3f s\n", tb1 - tb0, tb2 - tb1, now() - tb2);
     const int n = (int)v.n_groups_kept;
     crass_outputs_free(res);
     if (wrc != CRASS_OK) { std::cerr << "[ERROR]: cannot write the output files to " << opts.output_fastq << std::endl; return -1; }

@@ -776,41 +776,59 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
     // (no zero fill: the pieces write every word they own, pad words included)
     if (!ix->packed.alloc(n_words) || (!stride && !ix->word_off.alloc(nrec + 1)) || (!uniform_len && !ix->lengths.alloc(nrec)) ||
         !ix->hdr_pos.alloc(nrec) || !name_len.alloc(nrec) || !nh.alloc(nrec)) return CRASS_ERR_OOM;
+    // the per-record arrays first (the header table below needs them), then the words — 2 GB for 50 M reads, most of this
+    // stage's time — on their own threads BESIDE the header table: both are bound by memory, neither by the other's data
+    uint32_t *packed = ix->packed.data();
     {
-        uint32_t *packed = ix->packed.data();
-        auto place = [&](size_t k) {
+        auto place_small = [&](size_t k) {
             FxChunk &c = ch[k];
             const size_t m = c.n_rec();
             if (m) {
                 memcpy(ix->hdr_pos.data() + rec0[k], c.hdr_pos.data(), m * 8);
                 memcpy(nh.data() + rec0[k], c.name_h.data(), m * 8);
             }
-            if (uniform_len) { if (!c.words.empty()) memcpy(packed + rec0[k] * (uint64_t)stride, c.words.data(), c.words.size() * 4); }
-            else if (!stride && !c.words.empty()) memcpy(packed + tight0[k], c.words.data(), c.words.size() * 4);
             uint64_t wat = 0;
             for (size_t i = 0; i < m; i++) {
                 const uint64_t r = rec0[k] + i;
                 const uint32_t L = (uint32_t)(c.seq_end[i] - (i ? c.seq_end[i - 1] : 0));
-                const uint32_t nw = (L + 15) / 16;
                 name_len[r] = (uint32_t)(c.name_end[i] - (i ? c.name_end[i - 1] : 0));
                 if (!uniform_len) ix->lengths[r] = L;
                 if (!stride) ix->word_off[r] = tight0[k] + wat;
-                else if (!uniform_len) {                 // padded to one stride
-                    uint32_t *w = packed + r * (uint64_t)stride;
-                    memcpy(w, c.words.data() + wat, (size_t)nw * 4);
-                    for (uint32_t x = nw; x < stride; x++) w[x] = 0;
-                }
-                wat += nw;
+                wat += (L + 15) / 16;
             }
-            std::vector<uint32_t>().swap(c.words); std::vector<uint64_t>().swap(c.hdr_pos); std::vector<uint64_t>().swap(c.name_h);
+            std::vector<uint64_t>().swap(c.hdr_pos); std::vector<uint64_t>().swap(c.name_h);
         };
         std::vector<std::thread> th;
-        for (size_t k = 1; k < nc; k++) th.emplace_back(place, k);
-        if (nc) place(0);
+        for (size_t k = 1; k < nc; k++) th.emplace_back(place_small, k);
+        if (nc) place_small(0);
         for (auto &t : th) t.join();
         if (!stride) ix->word_off[nrec] = tight0[nc];
-        for (size_t x = 0; x < 4; x++) ix->packed[n_words - 4 + x] = 0;
     }
+    auto place_words = [&](size_t k) {
+        FxChunk &c = ch[k];
+        if (uniform_len) { if (!c.words.empty()) memcpy(packed + rec0[k] * (uint64_t)stride, c.words.data(), c.words.size() * 4); }
+        else if (!stride) { if (!c.words.empty()) memcpy(packed + tight0[k], c.words.data(), c.words.size() * 4); }
+        else {                                           // padded to one stride
+            uint64_t wat = 0;
+            for (size_t i = 0; i < c.n_rec(); i++) {
+                const uint32_t L = (uint32_t)(c.seq_end[i] - (i ? c.seq_end[i - 1] : 0));
+                const uint32_t nw = (L + 15) / 16;
+                uint32_t *w = packed + (rec0[k] + i) * (uint64_t)stride;
+                memcpy(w, c.words.data() + wat, (size_t)nw * 4);
+                for (uint32_t x = nw; x < stride; x++) w[x] = 0;
+                wat += nw;
+            }
+        }
+        std::vector<uint32_t>().swap(c.words);
+    };
+    std::thread words_thread([&]() {
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < nc; k++) th.emplace_back(place_words, k);
+        if (nc) place_words(0);
+        for (auto &t : th) t.join();
+        for (size_t x = 0; x < 4; x++) ix->packed[n_words - 4 + x] = 0;
+    });
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_words{words_thread};
     o.exc_off.push_back(0);
     for (size_t k = 0; k < nc; k++) {
         const uint64_t base = o.exc_bytes.size();
@@ -818,7 +836,6 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
         o.exc_bytes.insert(o.exc_bytes.end(), ch[k].exc_bytes.begin(), ch[k].exc_bytes.end());
         for (uint64_t e : ch[k].exc_off) o.exc_off.push_back(base + e);
     }
-    std::vector<FxChunk>().swap(ch);
     const double t3 = now_s();
     // ---- header_id: first read with the same name, names compared in the mapping (exact) ----
     bool any_dup = false;
@@ -868,6 +885,8 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
             parallel_ranges(nrec, ht, [&](uint64_t a, uint64_t b2, unsigned) { for (uint64_t r = a; r < b2; r++) ix->header_id[r] = first[r]; });
         }
     }
+    words_thread.join();
+    std::vector<FxChunk>().swap(ch);
     crass_reads &r = ix->reads;
     r.n_reads = nrec; r.packed = ix->packed.data(); r.stride_words = stride;
     r.word_off = stride ? nullptr : ix->word_off.data();
@@ -877,7 +896,7 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
     r.exc_read = o.exc_read.data(); r.exc_off = o.exc_off.data(); r.exc_bytes = o.exc_bytes.data();
     r.header_id = any_dup ? ix->header_id.data() : nullptr; r.read_index_base = 0;
     if (timing)
-        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse + pack %.3f s, words into place %.3f s, header ids %.3f s\n",
+        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse + pack %.3f s, record arrays %.3f s, header ids beside the words' placement %.3f s\n",
                 n, nc, (unsigned long long)nrec, t1 - t0, t2 - t1, t3 - t2, now_s() - t3);
     *out = ix.release();
     return CRASS_OK;
