@@ -822,7 +822,9 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     c->R.pos_hint = nullptr; c->R.pos_hint_off = nullptr;
     const DevParams &P = c->dp;
     // (skips == 8: the hints are kept per residue class mod 8 — k_hint_positions fills the lattice class, the walking wave the others)
-    if (c->max_len <= 2048 || n == 0 || P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return CRASS_OK;
+    // (... and any shift range the hint tile's halo covers: -s / -S / -D keep the hints, launch_hint_positions)
+    if (c->max_len <= 2048 || n == 0 || P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 ||
+        P.highDR + P.highSp < P.lowDR + P.lowSp) return CRASS_OK;
     if (c->env.no_pos_hints) return CRASS_OK;             // A/B switch
     std::vector<uint64_t> off(n + 1);
     uint64_t at = 0;

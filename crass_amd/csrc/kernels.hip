@@ -314,12 +314,182 @@ __global__ __launch_bounds__(256) void k_filter_fast_impl(DevReads R, DevParams 
     }
 }
 
+// The same scan for ANY shift range (-s / -S / -D: the seed lattice and the window are the defaults', only the distances at
+// which a copy counts change): D0 = lowDR + lowSp .. D1 = highDR + highSp arrive at run time.  The fixed-range kernel indexes its
+// registers with compile-time shifts; here the WORD part of a shift (d >> 4) stays a compile-time loop — static register
+// indices —, the sixteen bit offsets inside it are sixteen copies of the three instructions behind one scalar branch each, and a
+// funnel shift takes its amount from a register as readily as from an immediate: the instructions executed are the fixed
+// kernel's for the same range.  (k_filter_general, which every non-default option set took until round 5, is a wave per 64
+// reads through LDS: 10.6 ms for 10 M reads with -s 20 -S 60 against 0.18 ms for the defaults.)
+template <int W>
+__global__ __launch_bounds__(256) void k_filter_fast_range(DevReads R, DevParams P, uint64_t *hitmask, uint32_t *seed_hint)
+{
+    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    constexpr int WX = 2 * W + 2;                       // shifts up to 16 W + 15 bases: beyond a read of this stride nothing matches
+    uint32_t row[W];
+    uint64_t exc_word;
+    ff_load_row<W>(R, P, r, row, exc_word);
+    const bool active = r < R.n_reads;
+    uint32_t w[WX];
+#pragma unroll
+    for (int i = 0; i < WX; i++) w[i] = i < W ? row[i] : 0u;
+    const bool exc = (exc_word >> (r & 63)) & 1u;
+    const uint32_t L = active ? rd_len(R, r) : 0u;
+    constexpr int SW = ((16 * W - 26) / 8 + 2) / 2;     // words that can hold a lattice seed for ANY bounds (searchEnd <= 16 W - 26: lowDR + lowSp >= 17)
+    const int D0 = (int)(P.lowDR + P.lowSp), D1 = min((int)(P.highDR + P.highSp), 16 * W + 15);
+    uint32_t acc[SW];
+#pragma unroll
+    for (int i = 0; i < SW; i++) acc[i] = 0xFFFFFFFFu;
+    const int n_seed_max = (16 * W - D0 - 9) / 8 + 1;                   // no read of this stride has a seed beyond (wave-uniform)
+#pragma unroll
+    for (int q = 0; q <= W; q++) {
+        if (16 * q + 15 < D0 || 16 * q > D1) continue;                  // (wave-uniform: a scalar branch)
+        const int sb_lo = max(0, D0 - 16 * q), sb_hi = min(15, D1 - 16 * q);
+        for (int sb = sb_lo; sb <= sb_hi; sb++) {                       // (a run-time loop: the bodies below are q x k, not q x 16 x k)
+            const uint32_t sh = (uint32_t)(2 * sb);
+#pragma unroll
+            for (int k = 0; k < SW; k++) {
+                if (2 * k >= n_seed_max) continue;
+                const uint32_t lo = w[k + q], hi = w[k + q + 1];
+                acc[k] = pk_min_u16(acc[k], __builtin_amdgcn_alignbit(hi, lo, sh) ^ w[k]);
+            }
+        }
+    }
+    bool hit = false;
+    const int searchEnd = (int)(L - P.lowDR - P.lowSp - 8 - 1);
+    if (active && !exc && searchEnd >= 0) {
+        const int n_seed = searchEnd / 8 + 1;
+        uint32_t t0 = 0, t1 = 0;
+#pragma unroll
+        for (int k = 0; k < SW; k++) {
+            const uint32_t f = pk_nonzero_u16(acc[k]);
+            if (k < 8) t0 |= f << (2 * k); else t1 |= f << (2 * (k - 8));
+        }
+        uint32_t miss = (t0 | (t0 >> 15)) & 0xFFFFu;
+        if (SW > 8) miss |= (t1 | (t1 >> 15)) << 16;
+        const uint32_t hint = ~miss & (n_seed >= 32 ? 0xFFFFFFFFu : ((1u << n_seed) - 1u));
+        hit = hint != 0;
+        if (hit) seed_hint[r] = hint;
+    }
+    const uint64_t m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && active) hitmask[r >> 6] = m;
+}
+
+// ... and for ANY window (6 .. 9) and seed lattice (-w, -d: skips = lowDR - (2 w - 1) is then no multiple of a halfword's eight
+// bases, and a w-mer no halfword).  For a shift d, X = R xor (R >> 2d) has 2 w zero bits from bit 2p  <=>  the w-mer at p
+// re-occurs at p + d: the mismatch flag of a base is the OR of its two bits, a window's flag the OR of its w bases' flags — built by
+// doubling (w = 8: windows of 1, 2, 4, 8 bases; three funnel-shift + OR pairs) —, and the flags are AND-ed over the shifts: a zero
+// at bit 2p of the result means "some shift matches at p".  11 instructions per word and shift instead of the halfword form's 3,
+// for EVERY position at once; the lattice is a mask at the end.  (k_filter_general took 7.3 ms for 10 M reads with -w 7 and 13.7 ms
+// with -d 20 -D 40, against 0.18 ms for the defaults: profiles/r05_bench_c1_params_*.json.)
+template <int W>
+__global__ __launch_bounds__(256) void k_filter_fast_any(DevReads R, DevParams P, uint64_t *hitmask, uint32_t *seed_hint)
+{
+    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    constexpr int WX = 2 * W + 3;
+    uint32_t row[W];
+    uint64_t exc_word;
+    ff_load_row<W>(R, P, r, row, exc_word);
+    const bool active = r < R.n_reads;
+    uint32_t w[WX];
+#pragma unroll
+    for (int i = 0; i < WX; i++) w[i] = i < W ? row[i] : 0u;
+    const bool exc = (exc_word >> (r & 63)) & 1u;
+    const uint32_t L = active ? rd_len(R, r) : 0u;
+    const int D0 = (int)(P.lowDR + P.lowSp), D1 = min((int)(P.highDR + P.highSp), 16 * W + 15);
+    const int wn = (int)P.window;
+    // the doubling steps that take a base's flag to a window's (wave-uniform): windows of c bases -> c + s, s = min(c, wn - c)
+    const int s1 = min(1, wn - 1), s2 = min(2, wn - 1 - s1), s3 = min(4, wn - 1 - s1 - s2), s4 = wn - 1 - s1 - s2 - s3;      // (wn <= 9: s4 <= 1)
+    uint32_t nz[W];                                      // AND over the shifts of the windows' mismatch flags (even bits)
+#pragma unroll
+    for (int i = 0; i < W; i++) nz[i] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q <= W; q++) {
+        if (16 * q + 15 < D0 || 16 * q > D1) continue;                  // (wave-uniform)
+        const int sb_lo = max(0, D0 - 16 * q), sb_hi = min(15, D1 - 16 * q);
+        for (int sb = sb_lo; sb <= sb_hi; sb++) {
+            const uint32_t sh = (uint32_t)(2 * sb);
+            uint32_t z[W + 1];
+#pragma unroll
+            for (int k = 0; k <= W; k++) {
+                const uint32_t x = __builtin_amdgcn_alignbit(w[k + q + 1], w[k + q], sh) ^ w[k];
+                z[k] = x | (x >> 1);                     // (odd bits: don't care, they stay on odd bits below)
+            }
+            // a window of wn bases reaches at most 8 bases = 16 bits into the next word: one word of halo is enough
+#pragma unroll
+            for (int k = 0; k < W; k++) z[k] |= __builtin_amdgcn_alignbit(z[k + 1], z[k], (uint32_t)(2 * s1));
+            if (s2 > 0) {
+                z[W] |= z[W] >> (2 * s1);
+#pragma unroll
+                for (int k = 0; k < W; k++) z[k] |= __builtin_amdgcn_alignbit(z[k + 1], z[k], (uint32_t)(2 * s2));
+            }
+            if (s3 > 0) {
+                z[W] |= z[W] >> (2 * s2);
+#pragma unroll
+                for (int k = 0; k < W; k++) z[k] |= __builtin_amdgcn_alignbit(z[k + 1], z[k], (uint32_t)(2 * s3));
+            }
+            if (s4 > 0) {
+                z[W] |= z[W] >> (2 * s3);
+#pragma unroll
+                for (int k = 0; k < W; k++) z[k] |= __builtin_amdgcn_alignbit(z[k + 1], z[k], (uint32_t)(2 * s4));
+            }
+#pragma unroll
+            for (int k = 0; k < W; k++) nz[k] &= z[k];
+        }
+    }
+    bool hit = false;
+    const int searchEnd = (int)(L - P.lowDR - P.lowSp - P.window - 1);
+    if (active && !exc && searchEnd >= 0) {
+        // lattice seeds j = i * skips <= searchEnd; bit i of the hint for the first 32 of them (a superset: the zero padding and the
+        // clamp of the window at the read's end are ignored, as in the halfword form)
+        const uint32_t skips = P.skips;
+        uint32_t hint = 0, more = 0;
+        uint32_t j = 0;
+        for (uint32_t i = 0; j <= (uint32_t)searchEnd; i++, j += skips) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int k = 0; k < W; k++) word = (j >> 4) == (uint32_t)k ? nz[k] : word;
+            const uint32_t m = ((word >> (2u * (j & 15u))) & 1u) ^ 1u;
+            if (i < 32u) hint |= m << i; else more |= m;
+        }
+        hit = (hint | more) != 0;
+        if (hit) seed_hint[r] = more ? 0xFFFFFFFFu : hint;      // (a hit beyond the 32nd seed: the hint only says "walk them all")
+    }
+    const uint64_t m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && active) hitmask[r >> 6] = m;
+}
+
 hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st)
 {
-    // defaults only: w = 8, skips = 8, shifts 49..97
-    if (P.window != 8 || P.skips != 8) return hipErrorNotSupported;
-    if (P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return hipErrorNotSupported;
     if (!R.stride_words || R.n_reads == 0) return hipErrorNotSupported;
+    if (P.window != 8 || P.skips != 8) {
+        // another window or seed lattice (-w, -d): the every-position form
+        if (P.window < 6 || P.window > 9 || P.skips < 1 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp < P.lowDR + P.lowSp) return hipErrorNotSupported;
+        const uint64_t nb = (R.n_reads + 255) / 256;
+        if (nb > 0x7FFFFFFFull) return hipErrorNotSupported;
+        switch (R.stride_words) {
+#define FA_CASE(WW) case WW: CRASS_LAUNCH((k_filter_fast_any<WW>), dim3((unsigned)nb), dim3(256), 0, st, R, P, hitmask, seed_hint); break;
+            FA_CASE(4) FA_CASE(5) FA_CASE(6) FA_CASE(7) FA_CASE(8) FA_CASE(9) FA_CASE(10)
+            FA_CASE(11) FA_CASE(12) FA_CASE(13) FA_CASE(14) FA_CASE(15) FA_CASE(16)
+#undef FA_CASE
+            default: return hipErrorNotSupported;
+        }
+        return hipGetLastError();
+    }
+    if (P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) {
+        // another shift range (-s / -S / -D): the run-time-range form.  (The hint word has 32 bits: reads of up to 16 words.)
+        if (P.lowDR + P.lowSp < 17 || P.highDR + P.highSp < P.lowDR + P.lowSp) return hipErrorNotSupported;
+        const uint64_t nb = (R.n_reads + 255) / 256;
+        if (nb > 0x7FFFFFFFull) return hipErrorNotSupported;
+        switch (R.stride_words) {
+#define FR_CASE(WW) case WW: CRASS_LAUNCH((k_filter_fast_range<WW>), dim3((unsigned)nb), dim3(256), 0, st, R, P, hitmask, seed_hint); break;
+            FR_CASE(4) FR_CASE(5) FR_CASE(6) FR_CASE(7) FR_CASE(8) FR_CASE(9) FR_CASE(10)
+            FR_CASE(11) FR_CASE(12) FR_CASE(13) FR_CASE(14) FR_CASE(15) FR_CASE(16)
+#undef FR_CASE
+            default: return hipErrorNotSupported;
+        }
+        return hipGetLastError();
+    }
     uint64_t blocks = (R.n_reads + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorNotSupported;
     // common uniform read lengths get the compile-time clamp and, for big sets, RPL rows per lane with the next row in flight
@@ -374,6 +544,39 @@ static __device__ __forceinline__ uint64_t hint_bits_class(const uint32_t (&w)[1
     return ((uint64_t)(hi << rho) << 32) | (uint64_t)(lo << rho);
 }
 
+// ... for any shift range D0 .. D1 <= 127 (-s / -S / -D with the defaults' lattice and window): the word part of a shift is a
+// compile-time loop, the bit offsets inside it a run-time one (k_filter_fast_range has the reasoning); the defaults keep the
+// fully unrolled form above
+static __device__ __forceinline__ uint64_t hint_bits_class_range(const uint32_t (&w)[13], uint32_t rho, int D0, int D1)
+{
+    uint32_t v[12];
+    const uint32_t rs = 2u * rho;
+#pragma unroll
+    for (int i = 0; i < 12; i++) v[i] = rs ? ((w[i] >> rs) | (w[i + 1] << (32u - rs))) : w[i];
+    uint32_t acc[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (16 * q + 15 < D0 || 16 * q > D1) continue;
+        const int sb_lo = max(0, D0 - 16 * q), sb_hi = min(15, D1 - 16 * q);
+        for (int sb = sb_lo; sb <= sb_hi; sb++) {
+            const uint32_t sh = (uint32_t)(2 * sb);
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = pk_min_u16(acc[k], __builtin_amdgcn_alignbit(v[k + q + 1], v[k + q], sh) ^ v[k]);
+        }
+    }
+    const uint32_t m0 = pk_nonzero_u16(acc[0]), m1 = pk_nonzero_u16(acc[1]), m2 = pk_nonzero_u16(acc[2]), m3 = pk_nonzero_u16(acc[3]);
+    const uint32_t lo = __builtin_amdgcn_perm(m1, m0, 0x06040200u) ^ 0x01010101u;
+    const uint32_t hi = __builtin_amdgcn_perm(m3, m2, 0x06040200u) ^ 0x01010101u;
+    return ((uint64_t)(hi << rho) << 32) | (uint64_t)(lo << rho);
+}
+// (RANGE is a template parameter of the callers: the two forms never share a kernel's register budget)
+template <bool RANGE>
+static __device__ __forceinline__ uint64_t hint_bits_any(const uint32_t (&w)[13], uint32_t rho, int D0, int D1)
+{
+    if (RANGE) return hint_bits_class_range(w, rho, D0, D1);
+    return hint_bits_class(w, rho);
+}
+
 // ------------------------------------------------------------------------------------
 // Long reads: per-POSITION seed hints.  A 10 kbp read has ~1 250 lattice seeds and a spurious hit with p ~ 0.93, so a
 // per-read filter is useless there; and after a rejected candidate the seed loop leaves the lattice (libcrispr.cpp:390) for
@@ -383,7 +586,9 @@ static __device__ __forceinline__ uint64_t hint_bits_class(const uint32_t (&w)[1
 // from where — its read's walk moves there (wave_hints_class).  A superset like the short-read filter (padding bases and the
 // right clamp are ignored).  Default window / bounds only.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t t0, uint64_t n_words, uint64_t *hint_bits)
+template <bool RANGE>
+__global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t t0, uint64_t n_words, uint64_t *hint_bits,
+                                                        int D0, int D1)
 {
     // (t0: a multiple of 256 — the launch covers the hint words [t0, n_words), see launch_hint_positions)
     const uint64_t t = t0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -435,11 +640,11 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     // candidate (libcrispr.cpp:390,295) — 0.76 times per 10 kbp read on BASELINE configs[3] (tools/class_switches.py), so seven
     // of the eight classes this kernel used to cover were never looked at.  The class a walk moves to is covered from there on by
     // the wave that walks (search_core, wave_hints_class)
-    uint64_t bits = hint_bits_class(w, 0u);
-    // seeds live at j <= searchEnd = L - 58 (searchCore's loop bound with the default bounds this kernel is launched for): the
-    // bits behind it — the zero padding matches itself — are cleared, so that a read without a real lattice hint has an all-zero
-    // bitmap and the walking wave can drop it without staging it (k_survivor, no_seed)
-    const int last = (int)L - 58 - (int)(tile * 64u);
+    uint64_t bits = hint_bits_any<RANGE>(w, 0u, D0, D1);
+    // seeds live at j <= searchEnd = L - D0 - 9 (searchCore's loop bound; 58 with the default bounds): the bits behind it — the
+    // zero padding matches itself — are cleared, so that a read without a real lattice hint has an all-zero bitmap and the
+    // walking wave can drop it without staging it (k_survivor, no_seed)
+    const int last = (int)L - D0 - 9 - (int)(tile * 64u);
     bits = last < 0 ? 0ull : (last >= 63 ? bits : (bits & ((2ull << last) - 1ull)));
     hint_bits[t] = bits;
 }
@@ -447,11 +652,16 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
 hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
                                  uint64_t *hint_bits, hipStream_t st, uint64_t w_begin, uint64_t w_end)
 {
-    if (P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97) return hipErrorNotSupported;
+    // the defaults' lattice and window; any shift range the 13-word tile covers (a copy at most 127 bases on)
+    if (P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 || P.highDR + P.highSp < P.lowDR + P.lowSp) return hipErrorNotSupported;
     if (w_end > n_words) w_end = n_words;
     if ((w_begin & 255u) != 0) return hipErrorInvalidValue;
     if (w_begin >= w_end) return hipSuccess;
-    CRASS_LAUNCH(k_hint_positions, dim3((unsigned)((w_end - w_begin + 255) / 256)), dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits);
+    const int D0 = (int)(P.lowDR + P.lowSp), D1 = (int)(P.highDR + P.highSp);
+    const dim3 hg((unsigned)((w_end - w_begin + 255) / 256));
+    static const int force_hp = getenv("CRASS_HINT_RANGE") ? atoi(getenv("CRASS_HINT_RANGE")) : 0;      // A/B: 1 = the run-time-range form for the hint kernel, 2 = for the light walk, 3 = both
+    if (D0 == 49 && D1 == 97 && !(force_hp & 1)) CRASS_LAUNCH(k_hint_positions<false>, hg, dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits, D0, D1);
+    else CRASS_LAUNCH(k_hint_positions<true>, hg, dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits, D0, D1);
     return hipGetLastError();
 }
 
@@ -1517,7 +1727,8 @@ static __device__ void scan_right_masks(RH &h, int pat, uint32_t pattern_length,
 // Hint bits of residue class rho for the read in LDS (h.words), hint words [first_word, end): lanes over hint words, OR-ed into
 // the read's hint bitmap (classes occupy disjoint bit positions).  Called by search_core when the walk moves to a class whose
 // bits are not there yet from that point on.
-static __device__ __attribute__((noinline)) void wave_hints_class(const RH &h, uint32_t rho, uint32_t first_word, uint64_t *l_hint, int lane)
+template <bool RANGE>
+static __device__ __attribute__((noinline)) void wave_hints_class(const RH &h, uint32_t rho, uint32_t first_word, uint64_t *l_hint, int lane, int D0, int D1)
 {
     const uint32_t nw = ((uint32_t)h.L + 15u) >> 4, nh = ((uint32_t)h.L + 63u) >> 6;
     for (uint32_t base = first_word; base < nh; base += WAVE) {
@@ -1526,7 +1737,7 @@ static __device__ __attribute__((noinline)) void wave_hints_class(const RH &h, u
             uint32_t w[13];
 #pragma unroll
             for (int i = 0; i < 13; i++) { const uint32_t wi = 4u * t + (uint32_t)i; w[i] = wi < nw ? h.words[wi] : 0u; }
-            l_hint[t] |= hint_bits_class(w, rho);
+            l_hint[t] |= hint_bits_any<RANGE>(w, rho, D0, D1);
         }
     }
     wave_sync();
@@ -1557,7 +1768,9 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
             if (cls_from && j < uni(cls_from[j & 7u])) {     // wave-uniform; never true on the lattice class
                 const uint32_t first_word = j >> 6;
                 { const unsigned long long _ph0 = h.lprof ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
-                wave_hints_class(h, j & 7u, first_word, pos_hint, lane);
+                { const int D0 = (int)(o.lowDR + o.lowSp), D1 = (int)(o.highDR + o.highSp);
+                  if (D0 == 49 && D1 == 97) wave_hints_class<false>(h, j & 7u, first_word, pos_hint, lane, D0, D1);
+                  else wave_hints_class<true>(h, j & 7u, first_word, pos_hint, lane, D0, D1); }
                 if (h.lprof && lane == 0) { h.lprof[PF_HINTS] += (unsigned long long)__builtin_readcyclecounter() - _ph0; h.lprof[PF_N_SWITCH] += 1ull; } }
                 if (lane == 0) cls_from[j & 7u] = first_word << 6;
                 wave_sync();
@@ -2053,6 +2266,7 @@ static __device__ __forceinline__ uint32_t ll_next_hinted(const uint64_t (&cur)[
     return 0xFFFFFFFFu;
 }
 
+template <bool RANGE>
 __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
                                                      uint32_t *punt_list, uint32_t *d_punt_n)
 {
@@ -2102,7 +2316,7 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
                         uint32_t ww[13];
 #pragma unroll
                         for (int i = 0; i < 13; i++) { const uint32_t wi = 4u * t + (uint32_t)i; ww[i] = wi < (uint32_t)nw ? ll_words[wi] : 0u; }
-                        bits = hint_bits_class(ww, rho);
+                        bits = hint_bits_any<RANGE>(ww, rho, (int)(P.lowDR + P.lowSp), (int)(P.highDR + P.highSp));
                     }
                     const uint32_t round = done >> 6;
 #pragma unroll
@@ -2186,9 +2400,13 @@ hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32
     const uint32_t words_cap = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
     const uint32_t lds_bytes = (words_cap + 16u) * 4u;                           // (+ the words a 128-base piece reads past the read's last)
     const int grid = (int)std::min<uint64_t>(n_max, 256 * 32);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_long_light), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static const int force_ll = getenv("CRASS_HINT_RANGE") ? atoi(getenv("CRASS_HINT_RANGE")) : 0;
+    const bool range = P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97 || (force_ll & 2);
+    hipError_t e = hipFuncSetAttribute(range ? reinterpret_cast<const void *>(&k_long_light<true>) : reinterpret_cast<const void *>(&k_long_light<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    CRASS_LAUNCH(k_long_light, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n);
+    if (range) CRASS_LAUNCH(k_long_light<true>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n);
+    else CRASS_LAUNCH(k_long_light<false>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n);
     return hipGetLastError();
 }
 

@@ -121,6 +121,39 @@ def test_non_default_options(ca, kw):
     assert_same_pipeline(gpu, ref)
 
 
+FAST_PARAM_SETS = [
+    dict(lowSpacerSize=20, highSpacerSize=60), dict(highDRsize=64, highSpacerSize=70), dict(lowSpacerSize=30, highSpacerSize=34),   # shift range only
+    dict(searchWindowLength=6), dict(searchWindowLength=7), dict(searchWindowLength=9),                                            # another window
+    dict(lowDRsize=20, highDRsize=40), dict(lowDRsize=30, highDRsize=60), dict(lowDRsize=15, searchWindowLength=8),                # another lattice (skips 5 / 15 / 1)
+    dict(lowDRsize=17, highDRsize=35, searchWindowLength=6, lowSpacerSize=15, highSpacerSize=45),
+]
+
+
+@pytest.mark.parametrize("kw", FAST_PARAM_SETS, ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+@pytest.mark.parametrize("L", [150, 101, 250])
+def test_bit_parallel_filter_with_non_default_options(ca, kw, L):
+    """any -w / -d / -D / -s / -S used to send every read through k_filter_general (40-80 x slower than the
+    defaults' filter).  With a uniform stride they now take the bit-parallel filter too — its run-time-range form when only the
+    distances change, the every-position form for another window or seed lattice — and the seed hints the lane kernel walks by.
+    Uniform reads and trimmed ones padded to one stride (per-lane searchEnd), N reads; parity with the oracle under the same options."""
+    rng = random.Random(len(str(kw)) + L)
+    base = synth_reads(ca, 24000, read_len=L, crispr_per_million=50000)
+    p = ca.default_params(**kw)
+    gpu = ca.search_pipeline(base, params=p, pad_uniform=2)
+    assert gpu.counters["used_fast_filter"] == 1
+    assert_same_pipeline(gpu, orc.pipeline(base, params=to_orc_params(p)))
+    assert gpu.n_pass1 > 0
+    seqs = []
+    for i, s in enumerate(base[:12000]):
+        s = bytearray(s[:rng.randint(max(40, L - 40), L)]) if rng.random() < 0.4 else bytearray(s)
+        if rng.random() < 0.02:
+            s[rng.randrange(len(s))] = ord("N")
+        seqs.append(bytes(s))
+    padded = ca.search_pipeline(seqs, params=p, pad_uniform=2)
+    assert padded.counters["used_fast_filter"] == 1
+    assert_same_pipeline(padded, orc.pipeline(seqs, params=to_orc_params(p)))
+
+
 def test_unsigned_skips_wrap_is_refused(ca):
     """-d < 2w-1 wraps the reference's unsigned `skips` (libcrispr.cpp:281-285); the reference's
     seed loop is then ill-defined (can walk backwards forever).  The engine refuses it."""

@@ -35,9 +35,17 @@ for case in range(n_cases):
             for _ in range(rng.choice([1, 1, 3])):
                 b[rng.randrange(len(b))] = rng.choice(alphabet)
             seqs[i] = bytes(b)
-    p = ca.default_params(kmer_clust_size=k)
+    # a quarter of the cases with other search options (-w / -d / -D / -s / -S / -n): the run-time-range and every-position forms of
+    # the bit-parallel filter when the stride is uniform, k_filter_general otherwise
+    okw = {}
+    if rng.random() < 0.25:
+        okw = rng.choice([dict(searchWindowLength=6), dict(searchWindowLength=7), dict(searchWindowLength=9), dict(lowDRsize=20, highDRsize=40),
+                          dict(lowDRsize=30, highDRsize=60), dict(lowSpacerSize=20, highSpacerSize=60), dict(lowSpacerSize=30, highSpacerSize=40),
+                          dict(highDRsize=64, highSpacerSize=70), dict(minNumRepeats=3), dict(lowDRsize=15, searchWindowLength=8),
+                          dict(lowDRsize=25, searchWindowLength=9, lowSpacerSize=22), dict(lowDRsize=17, highDRsize=35, searchWindowLength=6, lowSpacerSize=15, highSpacerSize=45)])
+    p = ca.default_params(kmer_clust_size=k, **okw)
     host = rng.random() < 0.15
-    use_eng = rng.random() < 0.7 and k == 6
+    use_eng = rng.random() < 0.7 and k == 6 and not okw
     pad = rng.choice([0, 2])
     # a third of the cases go through a GROUP of 2-4 contexts sharing the GPU (crass_hip_group_*: contiguous shards, the
     # exchange as device copies, one host view), sometimes with duplicate headers across the shards and a tiny exchange buffer
@@ -47,8 +55,9 @@ for case in range(n_cases):
         hdrs = [b"h%d" % (i if rng.random() > 0.05 else rng.randrange(0, i + 1)) for i in range(n)]
     small_cap = grp and rng.random() < 0.2
     fused = bool(grp) and rng.random() < 0.5
-    tag = "L=%d n=%d n_dr=%d cpm=%d k=%d ragged=%d host=%d N=%d grp=%d%s%s%s pad=%d eng=%d" % (
-        L, n, n_dr, cpm, k, ragged, host, with_n, grp, "h" if hdrs else "", "c" if small_cap else "", "f" if fused else "", pad, use_eng)
+    tag = "L=%d n=%d n_dr=%d cpm=%d k=%d ragged=%d host=%d N=%d grp=%d%s%s%s pad=%d eng=%d %s" % (
+        L, n, n_dr, cpm, k, ragged, host, with_n, grp, "h" if hdrs else "", "c" if small_cap else "", "f" if fused else "", pad, use_eng,
+        ",".join("%s=%s" % kv for kv in okw.items()))
     only = os.environ.get("ONLY")                # comma-separated case indices: replay just those (same random stream)
     if only and case not in {int(x) for x in only.split(",")}:
         continue
