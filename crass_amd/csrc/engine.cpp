@@ -1090,7 +1090,11 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     const bool ident_list = !exc && !surv_idx_host && c->R.n_exc == 0 && n_total <= chunk_cap;
     // ... and with position hints on top the walk is split: k_long_light for every read, the full kernel for what it hands over
     // (CRASS_NO_LIGHT: the A/B switch; the cut-short walks of CRASS_SURV_DEBUG belong to the full kernel)
-    const bool use_light = ident_list && c->R.pos_hint && c->dp.skips == 8 && c->dp.debug_stop == 0 && !getenv("CRASS_NO_LIGHT");
+    // ... or without position hints, for another window or seed lattice (-w / -d): k_long_light_any computes every position's bit itself
+    const uint32_t sh0 = c->dp.lowDR + c->dp.lowSp, sh1 = c->dp.highDR + c->dp.highSp;
+    const bool light_any = !c->R.pos_hint && c->max_len > 2048 && !(c->dp.window == 8 && c->dp.skips == 8) && c->dp.window >= 6 && c->dp.window <= 9 &&
+                           sh0 >= 17 && sh1 <= 127 && sh1 >= sh0 && !c->env.no_pos_hints;
+    const bool use_light = ident_list && ((c->R.pos_hint && c->dp.skips == 8 && c->dp.window == 8) || light_any) && c->dp.debug_stop == 0 && !getenv("CRASS_NO_LIGHT");
     const int grid = 256 * 64;      // waves striding over the reads: 6 resident per CU at 10 kbp; 1 536 / 8 192 / 16 384 / 65 536 blocks: 11.5 / 8.6 / 8.2 / 9.1 ms
     const uint32_t stride = c->dr_stride;
     L.reserve(L.size() + n_total / 2 + 16, stride);

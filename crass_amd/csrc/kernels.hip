@@ -1745,7 +1745,8 @@ static __device__ __attribute__((noinline)) void wave_hints_class(const RH &h, u
 
 // pos_hint (long reads, LDS): the read's per-position hint bits — the lattice class from k_hint_positions; cls_from[rho] (LDS):
 // first position from which class rho's bits are in pos_hint (0xFFFFFFFF: not at all)
-static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint, int lane, uint64_t *pos_hint = nullptr, uint32_t *cls_from = nullptr)
+static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint, int lane, uint64_t *pos_hint = nullptr, uint32_t *cls_from = nullptr,
+                                  uint32_t j_start = 0)      // j_start: the light walk has done the iterations before it (all no-ops or rejected candidates)
 {
     const uint32_t seq_length = (uint32_t)h.L;
     const uint32_t skips = o.skips;
@@ -1755,9 +1756,9 @@ static __device__ int search_core(RH &h, const DevParams &o, uint32_t seed_hint,
     // seed_hint (from the bit-parallel filter): bit i clear => lattice seed j = i*skips provably has
     // no hit, so its iteration is a no-op in the reference (no start/stops, numRepeats 0) and can be
     // skipped.  Only valid while j is still on the lattice, i.e. before the first `j = back()-1`.
-    bool on_lattice = true;
+    bool on_lattice = j_start == 0;
     uint32_t lattice_i = 0;
-    for (uint32_t j = 0; j <= (uint32_t)searchEnd; j = j + skips) {
+    for (uint32_t j = j_start; j <= (uint32_t)searchEnd; j = j + skips) {
         j = uni(j);
         PROF_CNT(h, PF_N_ITER);
         if (pos_hint) {
@@ -2165,7 +2166,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         uint32_t *cls_from = reinterpret_cast<uint32_t *>(l_hint + lds.hint_words - 4);      // (the last four hint slots: 8 x uint32)
         if (ph && lane < 8) cls_from[lane] = lane == 0 ? 0u : 0xFFFFFFFFu;
         wave_sync();
-        int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane, ph, ph ? cls_from : nullptr);
+        // (a read the light walk handed over: on from the seed it stopped at — SurvOut::repeat_len of the slot, k_long_light)
+        const uint32_t j_start = (!EXC && punt_only == 7) ? uni(out[s].repeat_len) : 0u;
+        int f = (P.debug_stop == 1) ? 0 : search_core(h, P, hint, lane, ph, ph ? cls_from : nullptr, j_start);
         const unsigned long long prof_t1 = h.lprof ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
@@ -2289,6 +2292,7 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
         const bool too_long = nh > LL_HW * WAVE;
         const bool seeds = __ballot(any) != 0ull;
         uint8_t verdict = 0;                                                     // 0: searchCore returns false; 7: handed over
+        uint32_t punt_j = 0;                                                     // ... from this seed on (the iterations before it are done)
         if (too_long) verdict = 7;
         wave_sync();                                                             // (the previous read's LDS accesses are done)
         if (seeds && !too_long) {
@@ -2330,7 +2334,7 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
                 uint32_t endSearch = j + P.highDR + P.highSp + P.window;
                 if (endSearch >= seq_length) endSearch = seq_length - 1;
                 if (endSearch < beginSearch) endSearch = beginSearch;
-                if (beginSearch > seq_length) { verdict = 7; break; }            // (the reference throws here: the full kernel reports it)
+                if (beginSearch > seq_length) { verdict = 7; punt_j = j; break; }   // (the reference throws here: the full kernel reports it)
                 const int pos = uni(wave_find_packed(ll_words, cmask, (int)beginSearch, (int)endSearch, (int)j, w, lane));
                 if (pos < 0) { j += P.skips; continue; }                         // (the hints are a superset)
                 // two repeats at j and pos.  scanRight's first link (libcrispr.cpp:170-263): a third repeat means an array
@@ -2342,7 +2346,7 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
                     if (b3 < minb) b3 = minb;
                     if (b3 <= seq_length - 1) {
                         if (e3 > seq_length) e3 = seq_length;
-                        if (b3 < e3 && wave_find_packed(ll_words, cmask, (int)b3, (int)e3, (int)j, w, lane) >= 0) { verdict = 7; break; }
+                        if (b3 < e3 && wave_find_packed(ll_words, cmask, (int)b3, (int)e3, (int)j, w, lane) >= 0) { verdict = 7; punt_j = j; break; }
                     }
                 }
                 if (2u < P.minRepeats) { j += P.skips; continue; }               // (-n 3 and up: two repeats are not a candidate)
@@ -2376,7 +2380,7 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
                     right = (uint32_t)rr; left = (uint32_t)ll;
                 }
                 const uint32_t replen = (uint32_t)w + right + left;
-                if (replen >= P.lowDR && replen <= P.highDR) { verdict = 7; break; }          // due for qcFoundRepeats
+                if (replen >= P.lowDR && replen <= P.highDR) { verdict = 7; punt_j = j; break; }          // due for qcFoundRepeats
                 // rejected: on behind the last repeat's (extended, clamped) end (:390)
                 uint32_t last_end = (uint32_t)pos + (uint32_t)w - 1u;
                 if (last_end >= seq_length) last_end = seq_length - 1;                       // (startStopsAdd's clamp)
@@ -2386,8 +2390,189 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
             }
         }
         if (lane == 0) {
-            SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = verdict; out[s] = x;
+            SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = punt_j; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = verdict; out[s] = x;
             if (verdict == 7) punt_list[atomicAdd(d_punt_n, 1u)] = (uint32_t)(s + slot_base);     // (the slot in the whole set's numbering)
+        }
+    }
+}
+
+// ---- the light walk for ANY window and seed lattice (-w / -d on long reads) ----
+// The hint forms above know one residue class mod 8 at a time; with another lattice (skips = lowDR - 2 w + 1) or window the
+// every-position form of the scan (k_filter_fast_any) gives ONE bit per base — "the w-mer here has a copy D0 .. D1 further on" —
+// for whatever lattice the walk is on, so there is no class to switch: the walking wave computes the bits of the next 64 hint words
+// when it gets there (lane = hint word: 4 packed words + halo, 11 instructions per word and shift), finds the next set bit at or
+// behind j and takes it if it lies on the lattice that starts at j.  No hint kernel, no hint array.  Everything else is
+// k_long_light.  (1 M x 10 kbp with -d 20 -D 40: 512 ms on the un-hinted wave kernel.)
+static __device__ __forceinline__ uint64_t hint_bits_every(const uint32_t (&w)[13], int wn, int D0, int D1)
+{
+    const int s1 = min(1, wn - 1), s2 = min(2, wn - 1 - s1), s3 = min(4, wn - 1 - s1 - s2), s4 = wn - 1 - s1 - s2 - s3;
+    uint32_t nz[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (16 * q + 15 < D0 || 16 * q > D1) continue;
+        const int sb_lo = max(0, D0 - 16 * q), sb_hi = min(15, D1 - 16 * q);
+        for (int sb = sb_lo; sb <= sb_hi; sb++) {
+            const uint32_t sh = (uint32_t)(2 * sb);
+            uint32_t z[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint32_t x = __builtin_amdgcn_alignbit(w[k + q + 1], w[k + q], sh) ^ w[k];
+                z[k] = x | (x >> 1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) z[k] |= __builtin_amdgcn_alignbit(z[k + 1], z[k], (uint32_t)(2 * s1));
+            if (s2 > 0) {
+                z[4] |= z[4] >> (2 * s1);
+#pragma unroll
+                for (int k = 0; k < 4; k++) z[k] |= __builtin_amdgcn_alignbit(z[k + 1], z[k], (uint32_t)(2 * s2));
+            }
+            if (s3 > 0) {
+                z[4] |= z[4] >> (2 * s2);
+#pragma unroll
+                for (int k = 0; k < 4; k++) z[k] |= __builtin_amdgcn_alignbit(z[k + 1], z[k], (uint32_t)(2 * s3));
+            }
+            if (s4 > 0) {
+                z[4] |= z[4] >> (2 * s3);
+#pragma unroll
+                for (int k = 0; k < 4; k++) z[k] |= __builtin_amdgcn_alignbit(z[k + 1], z[k], (uint32_t)(2 * s4));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) nz[k] &= z[k];
+        }
+    }
+    // bit 2p of ~nz[k] = a copy exists for position 16 k + p: the even bits of the four words, packed
+    auto even16 = [](uint32_t x) {
+        x &= 0x55555555u;
+        x = (x | (x >> 1)) & 0x33333333u;
+        x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+        x = (x | (x >> 4)) & 0x00FF00FFu;
+        x = (x | (x >> 8)) & 0x0000FFFFu;
+        return x;
+    };
+    const uint32_t lo = even16(~nz[0]) | (even16(~nz[1]) << 16), hi = even16(~nz[2]) | (even16(~nz[3]) << 16);
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+
+__global__ __launch_bounds__(WAVE) void k_long_light_any(DevReads R, DevParams P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
+                                                         uint32_t *punt_list, uint32_t *d_punt_n)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t ll_words[];
+    const int lane = threadIdx.x;
+    uint64_t n = (uint64_t)(*d_n);
+    if (n > n_max) n = n_max;
+    const uint32_t cmask = (1u << (2 * P.window)) - 1u;
+    const int w = (int)P.window;
+    const int D0 = (int)(P.lowDR + P.lowSp), D1 = (int)(P.highDR + P.highSp);
+    uint4 pfv[LL_VEC];
+    auto prefetch = [&](uint64_t r) {
+        const uint32_t *g = R.packed + rd_word_off(R, r);
+        const int nw = ((int)uni(rd_len(R, r)) + 15) >> 4;
+#pragma unroll
+        for (int i = 0; i < LL_VEC; i++) pfv[i] = sv_load_group(g, lane + i * WAVE, nw);
+    };
+    if (blockIdx.x < n) prefetch(blockIdx.x + slot_base);
+    for (uint64_t s = blockIdx.x; s < n; s += gridDim.x) {
+        const uint64_t r = s + slot_base;
+        const int L = (int)uni(rd_len(R, r));
+        const int nw = (L + 15) >> 4, nh = (L + 63) >> 6;
+        const bool too_long = nh > LL_HW * WAVE;
+        uint8_t verdict = too_long ? 7 : 0;
+        uint32_t punt_j = 0;
+        wave_sync();
+        if (!too_long) {
+            const int ng = (nw + 4) >> 2;
+            uint4 *w4 = reinterpret_cast<uint4 *>(ll_words);
+#pragma unroll
+            for (int i = 0; i < LL_VEC; i++) { const int gi = lane + i * WAVE; if (gi < ng) w4[gi] = pfv[i]; }
+        }
+        if (s + gridDim.x < n) prefetch(r + gridDim.x);
+        if (!too_long) {
+            wave_sync();
+            const uint32_t seq_length = (uint32_t)L;
+            const int searchEnd = (int)(seq_length - P.lowDR - P.lowSp - P.window - 1);
+            const uint32_t n_hw = searchEnd >= 0 ? ((uint32_t)searchEnd >> 6) + 1u : 0u;
+            uint64_t cur[LL_HW] = {};
+            uint32_t j = 0, done = 0, from = 0;          // `from`: the next position to look at (>= j); seeds are j, j + skips, ...
+            while (searchEnd >= 0 && j <= (uint32_t)searchEnd) {
+                j = uni(j); done = uni(done); from = uni(from);
+                uint32_t p = ll_next_hinted(cur, 0u, done, from, lane);
+                while (p == 0xFFFFFFFFu && done < n_hw && done < 64u * LL_HW) {
+                    const uint32_t t = done + (uint32_t)lane;
+                    uint64_t bits = 0ull;
+                    if (t < (uint32_t)nh) {
+                        uint32_t ww[13];
+#pragma unroll
+                        for (int i = 0; i < 13; i++) { const uint32_t wi = 4u * t + (uint32_t)i; ww[i] = wi < (uint32_t)nw ? ll_words[wi] : 0u; }
+                        bits = hint_bits_every(ww, w, D0, D1);
+                    }
+                    const uint32_t round = done >> 6;
+#pragma unroll
+                    for (int i = 0; i < LL_HW; i++) if ((uint32_t)i == round) cur[i] = bits;
+                    done += 64u;
+                    p = ll_next_hinted(cur, 0u, done, from, lane);
+                }
+                if (p == 0xFFFFFFFFu || p > (uint32_t)searchEnd) break;
+                if ((p - j) % P.skips != 0u) { from = p + 1u; continue; }       // a copy exists there, but it is no seed of this lattice
+                j = p;
+                uint32_t beginSearch = j + P.lowDR + P.lowSp;
+                uint32_t endSearch = j + P.highDR + P.highSp + P.window;
+                if (endSearch >= seq_length) endSearch = seq_length - 1;
+                if (endSearch < beginSearch) endSearch = beginSearch;
+                if (beginSearch > seq_length) { verdict = 7; punt_j = j; break; }
+                const int pos = uni(wave_find_packed(ll_words, cmask, (int)beginSearch, (int)endSearch, (int)j, w, lane));
+                if (pos < 0) { j += P.skips; from = j; continue; }
+                {
+                    const uint32_t last = (uint32_t)pos, spacing = last - j;
+                    const int cand = (int)(last + spacing);
+                    uint32_t b3 = (uint32_t)cand - 24u, e3 = (uint32_t)cand + (uint32_t)w + 24u;
+                    const uint32_t minb = last + (uint32_t)w + P.lowSp;
+                    if (b3 < minb) b3 = minb;
+                    if (b3 <= seq_length - 1) {
+                        if (e3 > seq_length) e3 = seq_length;
+                        if (b3 < e3 && wave_find_packed(ll_words, cmask, (int)b3, (int)e3, (int)j, w, lane) >= 0) { verdict = 7; punt_j = j; break; }
+                    }
+                }
+                if (2u < P.minRepeats) { j += P.skips; from = j; continue; }
+                uint32_t right, left;
+                {
+                    const int jj = (int)j, pp = pos, spacing = pp - jj;
+                    int max_right = spacing - (int)P.lowSp;
+                    if (max_right > L - (pp + w)) max_right = L - (pp + w);
+                    int rr = 0;
+                    while (rr < max_right) {
+                        uint64_t a0, a1, b0, b1;
+                        wv_load128(ll_words, jj + w + rr, a0, a1); wv_load128(ll_words, pp + w + rr, b0, b1);
+                        const int nn = max_right - rr < 64 ? max_right - rr : 64;
+                        const int q = uni(ln_run_up(a0 ^ b0, a1 ^ b1, nn));
+                        rr += q;
+                        if (q < nn) break;
+                    }
+                    int max_left = spacing - (w + rr);
+                    if (max_left < 0) max_left = 0;
+                    if (max_left > jj) max_left = jj;
+                    int ll = 0;
+                    while (ll < max_left) {
+                        const int nn = max_left - ll < 64 ? max_left - ll : 64;
+                        uint64_t a0, a1, b0, b1;
+                        wv_load128(ll_words, jj - ll - nn, a0, a1); wv_load128(ll_words, pp - ll - nn, b0, b1);
+                        const int q = uni(ln_run_down(a0 ^ b0, a1 ^ b1, nn));
+                        ll += q;
+                        if (q < nn) break;
+                    }
+                    right = (uint32_t)rr; left = (uint32_t)ll;
+                }
+                const uint32_t replen = (uint32_t)w + right + left;
+                if (replen >= P.lowDR && replen <= P.highDR) { verdict = 7; punt_j = j; break; }
+                uint32_t last_end = (uint32_t)pos + (uint32_t)w - 1u;
+                if (last_end >= seq_length) last_end = seq_length - 1;
+                last_end = (last_end + right >= seq_length) ? seq_length - 1 : last_end + right;
+                j = last_end - 1u + P.skips;
+                from = j;
+            }
+        }
+        if (lane == 0) {
+            SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = punt_j; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = verdict; out[s] = x;
+            if (verdict == 7) punt_list[atomicAdd(d_punt_n, 1u)] = (uint32_t)(s + slot_base);
         }
     }
 }
@@ -2396,10 +2581,18 @@ hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32
                              uint32_t max_len, hipStream_t st, uint32_t *punt_list, uint32_t *d_punt_n)
 {
     if (n_max == 0) return hipSuccess;
-    if (P.skips != 8 || !R.pos_hint || P.window > 9) return hipErrorNotSupported;
     const uint32_t words_cap = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
     const uint32_t lds_bytes = (words_cap + 16u) * 4u;                           // (+ the words a 128-base piece reads past the read's last)
     const int grid = (int)std::min<uint64_t>(n_max, 256 * 32);
+    if (!R.pos_hint) {
+        // no position hints: another window or seed lattice — the every-position form, hints computed by the walking wave
+        if (P.window < 6 || P.window > 9 || P.skips < 1 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 || P.highDR + P.highSp < P.lowDR + P.lowSp) return hipErrorNotSupported;
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_long_light_any), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e2 != hipSuccess) return e2;
+        CRASS_LAUNCH(k_long_light_any, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n);
+        return hipGetLastError();
+    }
+    if (P.skips != 8 || P.window != 8) return hipErrorNotSupported;
     static const int force_ll = getenv("CRASS_HINT_RANGE") ? atoi(getenv("CRASS_HINT_RANGE")) : 0;
     const bool range = P.lowDR + P.lowSp != 49 || P.highDR + P.highSp != 97 || (force_ll & 2);
     hipError_t e = hipFuncSetAttribute(range ? reinterpret_cast<const void *>(&k_long_light<true>) : reinterpret_cast<const void *>(&k_long_light<false>),
