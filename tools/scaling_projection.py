@@ -47,12 +47,14 @@ def rccl_allgather_us(nbytes):
         t0 = time.perf_counter()
         for _ in range(K): dist.all_gather_into_tensor(dst, src)
         torch.cuda.synchronize()
-        return 1e6 * (time.perf_counter() - t0) / K
+        us = 1e6 * (time.perf_counter() - t0) / K
+        dist.destroy_process_group()                     # (its proxy threads must not sit beside the engines' helper threads below)
+        return us
     except Exception as ex:                              # (reported, never fatal: the projection stands without it)
         print("rccl one-rank all-gather not measured: %s" % ex, flush=True)
         return None
 
-ag_us = rccl_allgather_us(1 << 20)
+ag_us = None if os.environ.get("NO_RCCL_MEASURE") else rccl_allgather_us(1 << 20)
 print("one-rank ncclAllGather of 1 MB: %s us per call" % ("%.1f" % ag_us if ag_us else "n/a"), flush=True)
 base_ms = one_gpu()
 out = {"total_reads": total, "one_gpu_ms_per_step": round(base_ms, 3), "rccl_allgather_1rank_1MB_us": ag_us and round(ag_us, 1), "projection": []}
