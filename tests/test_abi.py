@@ -474,3 +474,9 @@ def test_header_ids_many_threads(ca, tmp_path):
     f = ca.FastxFile(str(p))
     assert f.n_reads == n
     assert np.array_equal(np.asarray(f.header_id), ref_ids)
+    # the indexed reader's table: 256 shards by the hash's top byte, each filled by one thread in read order
+    ix = ca.FastxIndex(str(p))
+    from crass_amd.engine import _npv
+    assert ix.n_reads == n and ix.reads.header_id
+    assert np.array_equal(_npv(ix.reads.header_id, n, np.uint64), ref_ids)
+    ix.close()

@@ -48,7 +48,8 @@ def rccl_allgather_us(nbytes):
         for _ in range(K): dist.all_gather_into_tensor(dst, src)
         torch.cuda.synchronize()
         us = 1e6 * (time.perf_counter() - t0) / K
-        dist.destroy_process_group()                     # (its proxy threads must not sit beside the engines' helper threads below)
+        if not os.environ.get("KEEP_PG"):
+            dist.destroy_process_group()                 # (its proxy threads must not sit beside the engines' helper threads below)
         return us
     except Exception as ex:                              # (reported, never fatal: the projection stands without it)
         print("rccl one-rank all-gather not measured: %s" % ex, flush=True)
@@ -87,12 +88,20 @@ for W in worlds:
         assert engs[0].merge_gathered(recv.data_ptr(), fetch=False) is None; t.append(time.perf_counter())
         engs[0].recruit(fetch=False); t.append(time.perf_counter())
         return [1e3 * (b - a) for a, b in zip(t, t[1:])]
+    def cpu_stat():
+        try:
+            return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat"))}
+        except Exception:
+            return {}
     for _ in range(4): step()
+    cs0 = cpu_stat()
     K = 30
     acc = np.zeros(3)
     t0 = time.perf_counter()
     for _ in range(K): acc += step()
     ms = 1e3 * (time.perf_counter() - t0) / K
+    cs1 = cpu_stat()
+    print("cgroup cpu.stat over the %d timed steps: %s" % (K, {k: cs1[k] - cs0.get(k, 0) for k in cs1 if k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec")}), flush=True)
     c = engs[0].counters()
     m = engs[0].merge_view()
     # the device-copy stand-in costs ~5 us; the measured one-rank collective replaces it in the projected figure.  WEAK scaling,
