@@ -175,6 +175,9 @@ struct EnvSwitches {
     uint32_t row_cap = 256, dm_group_cap = 16384, surv_debug = 0;     // row_cap: Levenshtein fallback rows of the long-read layout (strings beyond it: second launch, full rows)
     int stage_timing = -1;
     uint64_t pool_cap_bytes = 0;                     // tests: device allocations beyond this total fail with hipErrorOutOfMemory
+    bool no_hint_filter = false;                     // A/B switch: k_filter_general where the hint bits would be the filter
+    uint32_t wave_walk_min = 800;                    // pass 2 walks a read per wave when the longest read is beyond this (CRASS_WAVE_WALK_MIN)
+    uint32_t long_min = 2048;                        // read sets whose longest read is beyond this take the long-read path (CRASS_LONG_MIN: the A/B switch)
     void read()
     {
         auto on = [](const char *n) { return getenv(n) != nullptr; };
@@ -189,6 +192,9 @@ struct EnvSwitches {
         stage_timing = -1; if (const char *e = getenv("CRASS_STAGE_TIMING")) stage_timing = std::min(2, std::max(0, atoi(e)));
         for (auto &b : test_bounds) b = 0;
         if (const char *e = getenv("CRASS_TEST_BOUNDS")) { int k = 0; for (const char *q = e; *q && k < 4; k++) { test_bounds[k] = (uint64_t)atoll(q); while (*q && *q != ',') q++; if (*q == ',') q++; } }
+        no_hint_filter = on("CRASS_NO_HINT_FILTER");
+        wave_walk_min = 800; if (const char *e = getenv("CRASS_WAVE_WALK_MIN")) wave_walk_min = (uint32_t)std::max(0, atoi(e));
+        long_min = 2048; if (const char *e = getenv("CRASS_LONG_MIN")) long_min = (uint32_t)std::max(0, atoi(e));
         pool_cap_bytes = 0; if (const char *e = getenv("CRASS_POOL_CAP_MB")) pool_cap_bytes = (uint64_t)std::max(1ll, atoll(e)) << 20;
     }
 };
@@ -323,6 +329,7 @@ struct crass_hip_ctx {
     hipStream_t hint_stream = nullptr;
     hipEvent_t ev_hint[kHintParts] = {nullptr, nullptr, nullptr, nullptr}, ev_hint_go = nullptr;
     int hint_parts = 1;                         // slices of this read set (1: one launch on the main stream)
+    bool hint_filter = false;                   // the hint bits are this set's seed-scan filter (no lane-per-read filter for its layout)
     uint64_t hint_read_split[kHintParts + 1] = {0, 0, 0, 0, 0}, hint_word_split[kHintParts + 1] = {0, 0, 0, 0, 0};
     DevBuf<uint16_t> g_dr_len; DevBuf<uint64_t> hl_dx_idx;      // host-loop sink: dense DR lengths, scratch of the device de-duplication
     bool hint_pending = false;                  // slices are in flight on hint_stream: the main stream has not waited for them yet
@@ -819,11 +826,15 @@ static int alloc_scratch(crass_hip_ctx *c)
 static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t uniform_len, uint64_t n)
 {
     c->n_pos_hint_words = 0;
-    c->R.pos_hint = nullptr; c->R.pos_hint_off = nullptr;
+    c->R.pos_hint = nullptr; c->R.pos_hint_off = nullptr; c->R.wave_walk = 0;
     const DevParams &P = c->dp;
     // (skips == 8: the hints are kept per residue class mod 8 — k_hint_positions fills the lattice class, the walking wave the others)
     // (... and any shift range the hint tile's halo covers: -s / -S / -D keep the hints, launch_hint_positions)
-    if (c->max_len <= 2048 || n == 0 || P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 ||
+    // (... and sets that stay on the filtered path but have no lane-per-read filter — reads of 257 .. 2 048 bases, strides that differ:
+    // the hint bits are their filter, crass_hip_seed_scan; CRASS_NO_HINT_FILTER: the A/B switch, back to k_filter_general)
+    const bool lane_filter = c->R.stride_words >= 4 && c->R.stride_words <= 16;
+    c->hint_filter = c->max_len <= c->env.long_min && !lane_filter && !c->env.no_hint_filter;
+    if ((c->max_len <= c->env.long_min && !c->hint_filter) || n == 0 || P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 ||
         P.highDR + P.highSp < P.lowDR + P.lowSp) return CRASS_OK;
     if (c->env.no_pos_hints) return CRASS_OK;             // A/B switch
     std::vector<uint64_t> off(n + 1);
@@ -834,6 +845,7 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     HIPCHK(c, hipMemcpy(c->d_pos_hint_off.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
     c->n_pos_hint_words = at;
     c->R.pos_hint = c->d_pos_hint.p; c->R.pos_hint_off = c->d_pos_hint_off.p;
+    c->R.wave_walk = c->max_len > std::min<uint32_t>(c->env.long_min, c->env.wave_walk_min) ? 1u : 0u;
     c->pos_hint_blk = false;
     // slices: read boundaries n i / K; slice i covers the hint words [roundup256(off[r_i]), roundup256(off[r_i+1])), so every word
     // of a read below r_i+1 belongs to a slice <= i (CRASS_HINT_PARTS=1: the A/B switch)
@@ -842,7 +854,7 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
       // (two: each slice's walk is its own launch with its own ramp and tail — four slices were slower than none, 15.5 vs 14.3 ms
       // per step on configs[3], two are 14.0; an explicit CRASS_HINT_PARTS also slices small sets: the tests)
       const bool big = hp ? (n >= 64 && at >= 2048) : (n >= 4096 && at >= (1u << 20));
-      c->hint_parts = big ? std::min(std::max(want, 1), (int)crass_hip_ctx::kHintParts) : 1; }
+      c->hint_parts = (big && !c->hint_filter) ? std::min(std::max(want, 1), (int)crass_hip_ctx::kHintParts) : 1; }
     if (c->hint_parts > 1 && !c->hint_stream) {
         // lowest priority: its blocks fill what the walking kernel (two waves per SIMD: its LDS) leaves free, not the other way
         // round.  Created with the first long-read set only: a second low-priority stream in every context changed how the
@@ -866,6 +878,7 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
             while (r + 1 < n && off[r + 1] <= b * 256) r++;
             blk[b] = (uint32_t)r;
         }
+        blk.back() = (uint32_t)(n - 1);                  // (the bisection's upper end for the last block)
         HIPCHK(c, c->d_pos_hint_blk.ensure(blk.size()));
         HIPCHK(c, hipMemcpy(c->d_pos_hint_blk.p, blk.data(), blk.size() * 4, hipMemcpyHostToDevice));
         c->pos_hint_blk = true;
@@ -1073,7 +1086,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     // (both read per call — once per seed scan of a long-read set —, so that a test can change them inside one process)
     const bool long_full = getenv("CRASS_LONG_FULL_LAYOUT") != nullptr;
     const uint32_t win_env = getenv("CRASS_SEQ_WINDOW") ? (uint32_t)atoi(getenv("CRASS_SEQ_WINDOW")) : 0u;      // (tests: a tiny window)
-    const bool windowed = !exc && (win_env || (c->max_len > 2048 && !long_full));
+    const bool windowed = !exc && (win_env || (c->max_len > c->env.long_min && !long_full));
     const SurvLds lds = windowed ? survivor_lds_layout(c->max_len, c->dp, row_cap, win_env ? win_env : 4608u, 256u)
                                  : survivor_lds_layout(c->max_len, c->dp, row_cap);
     const bool capped = lds.row_elems != lds_full.row_elems || lds.seq_window != 0 || lds.ss_cap != lds_full.ss_cap;
@@ -1092,7 +1105,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
     // (CRASS_NO_LIGHT: the A/B switch; the cut-short walks of CRASS_SURV_DEBUG belong to the full kernel)
     // ... or without position hints, for another window or seed lattice (-w / -d): k_long_light_any computes every position's bit itself
     const uint32_t sh0 = c->dp.lowDR + c->dp.lowSp, sh1 = c->dp.highDR + c->dp.highSp;
-    const bool light_any = !c->R.pos_hint && c->max_len > 2048 && !(c->dp.window == 8 && c->dp.skips == 8) && c->dp.window >= 6 && c->dp.window <= 9 &&
+    const bool light_any = !c->R.pos_hint && c->max_len > c->env.long_min && !(c->dp.window == 8 && c->dp.skips == 8) && c->dp.window >= 6 && c->dp.window <= 9 &&
                            sh0 >= 17 && sh1 <= 127 && sh1 >= sh0 && !c->env.no_pos_hints;
     const bool use_light = ident_list && ((c->R.pos_hint && c->dp.skips == 8 && c->dp.window == 8) || light_any) && c->dp.debug_stop == 0 && !getenv("CRASS_NO_LIGHT");
     const int grid = 256 * 64;      // waves striding over the reads: 6 resident per CU at 10 kbp; 1 536 / 8 192 / 16 384 / 65 536 blocks: 11.5 / 8.6 / 8.2 / 9.1 ms
@@ -1305,7 +1318,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
 static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const uint16_t *dx_len, uint64_t n_tok, const uint32_t *d_ntok);
 static void presize_hostloop(crass_hip_ctx *c)
 {
-    if (!c->R.pos_hint || c->env.no_presize || c->R.n_reads == 0) return;
+    if (!c->R.pos_hint || c->max_len <= c->env.long_min || c->env.no_presize || c->R.n_reads == 0) return;
     const SurvLds lds_full = survivor_lds_layout(c->max_len, c->dp);
     if (lds_full.total_bytes > 160 * 1024) return;
     for (auto &d : c->dma_sink) if (!d) d = sdma_create();      // (an engine's queue is created by its first copy, ~6 ms: here)
@@ -1406,7 +1419,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     if (lds.total_bytes > 160 * 1024) return CRASS_ERR_UNSUPPORTED;
     const uint32_t stride = c->dr_stride;
     const uint64_t pool_cap = std::max<uint64_t>(n_surv * (uint64_t)lds.ss_cap, 1u << 16);
-    if (n_surv == 0 || n_surv > kDenseMaxSurvivors || pool_cap >= (1ull << 31) || lds.ss_cap > 64 || (stride & 15)) return CRASS_ERR_STATE;
+    if (n_surv == 0 || n_surv > kDenseMaxSurvivors || pool_cap >= (1ull << 31) || lds.ss_cap > 128 || (stride & 15)) return CRASS_ERR_STATE;
     crass_hip_ctx::P1Dense &D = c->dense;
     // buffers are sized for the bound the NEXT call will speculate with (1.5 x this call's count, see
     // crass_hip_seed_scan), so that the second call of a context does not re-allocate everything
@@ -1448,7 +1461,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     const bool no_lanes = c->env.no_lane_kernel;
     hipError_t le = no_lanes ? hipErrorNotSupported
                              : launch_survivor_lanes(c->R, c->dp, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
-                                                     c->d_ss_pool.p, lds.ss_cap, c->d_found.p, hints, c->stream, init_merge);
+                                                     c->d_ss_pool.p, lds.ss_cap, c->d_found.p, hints, c->stream, init_merge, c->max_len);
     if (le != hipSuccess && le != hipErrorNotSupported) { c->last_hip = (int)le; return CRASS_ERR_HIP; }
     if (le == hipSuccess && init_merge) { c->dm_prepared_n = init_merge->n_tok; c->dm_prepared_src = init_merge->dx_chars; }
     HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
@@ -1654,11 +1667,11 @@ static int first_call_bounds_impl(crass_hip_ctx *c)
     c->surv_cap_hint = 0; c->hit_cap_hint = 0; c->dx_cap_hint = 0; c->dm_prev_local = false; c->premerge = 0;
     c->recruit_exact = false;
     const uint64_t n = c->R.n_reads;
-    if (c->env.no_presize || c->env.no_speculation || n == 0 || c->max_len > 2048) return CRASS_OK;
+    if (c->env.no_presize || c->env.no_speculation || n == 0 || c->max_len > c->env.long_min) return CRASS_OK;
     if (c->R.n_exc && c->env.exc_separate) return CRASS_OK;
     const DevParams &P = c->dp;
     const SurvLds lds = survivor_lds_layout(c->max_len, P);
-    if (lds.total_bytes > 160 * 1024 || lds.ss_cap > 64 || (c->dr_stride & 15)) return CRASS_OK;
+    if (lds.total_bytes > 160 * 1024 || lds.ss_cap > 128 || (c->dr_stride & 15)) return CRASS_OK;
     // seed filter on random sequence: every lattice seed has ~(highDR+highSp-lowDR-lowSp+1) candidate positions, each
     // an equal w-mer with probability 4^-w (libcrispr.cpp:295-339); + 2 % of the reads for real arrays; x 1.5
     const uint32_t min_len = P.lowDR + P.lowSp + P.window + 1;
@@ -1734,16 +1747,27 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     HIPCHK(c, c->stamp(0, 1));
     // step 1: filter.  Reads longer than 2 kbp almost surely contain a spurious lattice hit
     // (P ~ seeds*49/4^w), so the filter is skipped and every read goes to the survivor kernel.
-    bool fast = false;
-    const bool use_filter = c->max_len <= 2048;
+    bool fast = false, hint_filtered = false;
+    const bool use_filter = c->max_len <= c->env.long_min;
     // exception reads (a byte outside ACGT) join the survivor list and are evaluated byte-wise in place, so that
     // the dense pass-1 path also holds for inputs with a few N reads
     c->dp.exc_survive = (use_filter && c->R.n_exc > 0 && !c->env.exc_separate) ? 1u : 0u;
+    if (getenv("CRASS_DEBUG_FILTER")) fprintf(stderr, "[filter] max_len %u long_min %u stride %u hint_filter %d pos_hint %p words %llu\n", c->max_len, c->env.long_min, c->R.stride_words, (int)c->hint_filter, (void *)c->R.pos_hint, (unsigned long long)c->n_pos_hint_words);
     if (use_filter) {
         hipError_t fe = hipErrorNotSupported;
         // (uniform STRIDE is what the bit-parallel kernel needs; the lengths may differ — trimmed reads padded to one stride)
         if (c->R.stride_words >= 4 && c->R.stride_words <= 16) fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->d_hit_info.p, c->stream);
         if (fe == hipSuccess) fast = true;
+        else if (fe == hipErrorNotSupported && c->hint_filter && c->R.pos_hint) {
+            // no lane-per-read filter for this layout: one hint bit per lattice position (the long reads' kernel), then "any bit?" per read.
+            // The survivor kernel walks on the same bits
+            hipError_t he = launch_hint_positions(c->R, c->dp, c->d_pos_hint_off.p, c->pos_hint_blk ? c->d_pos_hint_blk.p : nullptr, c->n_pos_hint_words,
+                                                  c->d_pos_hint.p, c->stream, 0, c->n_pos_hint_words);
+            if (he == hipSuccess) he = launch_hint_filter(c->R, c->dp, c->d_pos_hint_off.p, c->d_pos_hint.p, c->d_mask.p, c->stream);
+            if (he != hipSuccess) { c->last_hip = (int)he; return CRASS_ERR_HIP; }
+            c->hint_pending = false;
+            hint_filtered = true;
+        }
         else if (fe == hipErrorNotSupported) { HIPCHK(c, launch_filter_general(c->R, c->dp, c->d_mask.p, c->max_len, c->stream)); }
         else { c->last_hip = (int)fe; return CRASS_ERR_HIP; }
     } else {
@@ -1899,7 +1923,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     c->cnt.ms_sink_host = (float)(now_ms() - t_sink0);     // includes the survivor kernel + D2H it waits for
     c->cnt.n_filter_survivors = n_surv + (c->dp.exc_survive ? 0 : c->R.n_exc);
     c->cnt.n_pass1_found = total;
-    c->cnt.used_fast_filter = fast ? 1 : 0;
+    c->cnt.used_fast_filter = fast ? 1 : (hint_filtered ? 2 : 0);
     // (the event spans are evaluated when the counters are fetched: each query costs microseconds of host time
     // between two stages)
     c->spans_p1 = true; c->span_survivors = n_surv != 0;

@@ -28,6 +28,9 @@ struct DevReads {
     // no copy in its search window (k_hint_positions); read r's bits start at word pos_hint_off[r].  May be nullptr.
     const uint64_t *pos_hint;
     const uint64_t *pos_hint_off;
+    // pass 2 walks one read per WAVE (lane = window) instead of one per lane: sets whose longest read is beyond ~800 bases
+    // (a lane walking its own long read touches one word per row; below that a wave's 256 windows per round stay mostly empty)
+    uint32_t wave_walk;
 };
 
 struct DevParams {
@@ -282,6 +285,8 @@ hipError_t launch_filter_general(const DevReads &R, const DevParams &P, uint64_t
 hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
                                  uint64_t *hint_bits, hipStream_t st,       // blk_read[b] = read of tile 256 b (ragged lengths; else nullptr)
                                  uint64_t w_begin = 0, uint64_t w_end = ~0ull);      // the hint words [w_begin, w_end) only; w_begin a multiple of 256
+// ... and those bits as the seed-scan filter of a set without a lane-per-read filter: bit r of hitmask = read r has a hint bit
+hipError_t launch_hint_filter(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint64_t *hint_bits, uint64_t *hitmask, hipStream_t st);
 // long reads with position hints, an identity survivor list and no exception read: the walk of the reads without an array; a read
 // that needs the full searchCore leaves with err == 7 for launch_survivor(..., punt_only = 7)
 hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
@@ -358,7 +363,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                  uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st,
-                                 const DevMerge *init_merge = nullptr);   // also clears that merge's tables (dm_init_slice)
+                                 const DevMerge *init_merge = nullptr, uint32_t max_len = 0);     // max_len: the rows' size when the strides differ   // also clears that merge's tables (dm_init_slice)
 hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
                                   uint64_t *hitmask, uint32_t *hit_info, hipStream_t st);
 hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,

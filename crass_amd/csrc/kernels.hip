@@ -610,8 +610,11 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     } else if (blk_read) {
         // ragged lengths: the host noted the read of every block's first tile (blk_read[b] = read of tile 256 b); a long read
         // has dozens of tiles, so the tile's own read is a few steps further (short reads mixed in: more steps, same result)
-        r = blk_read[t >> 8];
-        while (r + 1 < R.n_reads && hint_off[r + 1] <= t) r++;
+        // (... bisected between this block's first read and the next block's: reads of a few hundred bases are fifty to a block)
+        uint64_t lo = blk_read[t >> 8], hi = (uint64_t)blk_read[(t >> 8) + 1] + 1;      // invariant: hint_off[lo] <= t < hint_off[hi]
+        if (hi > R.n_reads) hi = R.n_reads;
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (hint_off[mid] <= t) lo = mid; else hi = mid; }
+        r = lo;
         tile = (uint32_t)(t - hint_off[r]);
     } else {
         uint64_t lo = 0, hi = R.n_reads;                                // invariant: hint_off[lo] <= t < hint_off[hi]
@@ -662,6 +665,34 @@ hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const ui
     static const int force_hp = getenv("CRASS_HINT_RANGE") ? atoi(getenv("CRASS_HINT_RANGE")) : 0;      // A/B: 1 = the run-time-range form for the hint kernel, 2 = for the light walk, 3 = both
     if (D0 == 49 && D1 == 97 && !(force_hp & 1)) CRASS_LAUNCH(k_hint_positions<false>, hg, dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits, D0, D1);
     else CRASS_LAUNCH(k_hint_positions<true>, hg, dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits, D0, D1);
+    return hipGetLastError();
+}
+
+// The seed-scan filter of a read set that has position hints but no lane-per-read filter (reads of 257 .. 2 048 bases, strides that
+// differ): bit r of hitmask is set iff one of read r's lattice positions has a hint bit — k_hint_positions cleared everything behind
+// searchEnd, so an all-zero bitmap proves that searchCore's seed loop (libcrispr.cpp:295-348) finds nothing.  A superset like the
+// other filters; exception reads as in k_filter_general.
+__global__ __launch_bounds__(256) void k_hint_filter(DevReads R, DevParams P, const uint64_t *hint_off, const uint64_t *hint_bits, uint64_t *hitmask)
+{
+    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
+    const bool active = r < R.n_reads;
+    bool hit = false;
+    if (active && (P.exc_survive || !rd_is_exc(R, r))) {
+        const uint64_t o0 = hint_off[r], o1 = hint_off[r + 1];
+        uint64_t any = 0;
+        for (uint64_t t = o0; t < o1; t++) any |= hint_bits[t];
+        hit = any != 0;
+    }
+    const uint64_t m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && active) hitmask[r >> 6] = m;
+}
+
+hipError_t launch_hint_filter(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint64_t *hint_bits, uint64_t *hitmask, hipStream_t st)
+{
+    if (!R.n_reads) return hipSuccess;
+    const uint64_t nb = (R.n_reads + 255) / 256;
+    if (nb > 0x7FFFFFFFull) return hipErrorNotSupported;
+    CRASS_LAUNCH(k_hint_filter, dim3((unsigned)nb), dim3(256), 0, st, R, P, hint_off, hint_bits, hitmask);
     return hipGetLastError();
 }
 
@@ -3053,7 +3084,7 @@ static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLengt
     return 1;
 }
 
-static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t seed_hint)
+static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint64_t seed_hint)
 {   // searchCore, libcrispr.cpp:265-395
     const uint32_t seq_length = (uint32_t)h.L;
     const uint32_t skips = o.skips;
@@ -3078,7 +3109,7 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t s
             // Each lane first walks (cheaply) to ITS next seed worth evaluating.  A lattice seed whose hint bit is
             // clear is a no-op iteration in the reference (no hit => no start/stops => numRepeats 0): skipping it
             // changes nothing.
-            while (on_lattice && j <= (uint32_t)searchEnd && lattice_i < 32 && !((seed_hint >> lattice_i) & 1u)) { j += skips; lattice_i++; }
+            while (on_lattice && j <= (uint32_t)searchEnd && lattice_i < 64 && !((seed_hint >> lattice_i) & 1ull)) { j += skips; lattice_i++; }
             if (j > (uint32_t)searchEnd) { out_of_seeds = true; continue; }
             if (on_lattice) lattice_i++;
             uint32_t beginSearch = j + o.lowDR + o.lowSp;
@@ -3130,6 +3161,22 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint32_t s
 // notice.  PMC at 100 M reads: 318 M -> 224 M VALU wave instructions (8-wave blocks); 4 waves per block is the measured optimum
 // (590 us in slot order with one wave per block -> 550; 8 waves 593, 16 waves 754: a block holds its LDS until its slowest wave ends).
 #define SL_WAVES 4
+// hint bit i of a lane's read = "lattice seed i may have a copy in its window", for the first 64 seeds; the others are walked.
+// From the lane-per-read filter's word (32 seeds: reads of up to 256 bases) or from the read's position hints (bit 8 i of the
+// bitmap: k_hint_positions filled the lattice class and cleared what lies behind searchEnd) — bit 0 of each byte, gathered by one
+// multiplication per 64 positions (the partial products 2^(56 + 8k - 7j) of bits 8k and multiplier terms 2^(56 - 7j) are all
+// distinct, and only those with k == j fall into the top byte)
+static __device__ __forceinline__ uint64_t ln_hint64(const DevReads &R, const uint32_t *seed_hint, uint64_t r, int L)
+{
+    if (seed_hint) return 0xFFFFFFFF00000000ull | (uint64_t)seed_hint[r];
+    if (!R.pos_hint) return ~0ull;
+    const uint64_t *ph = R.pos_hint + rd_hint_off(R, r);
+    const int nh = (L + 63) >> 6;
+    uint64_t hint = 0;
+    for (int k = 0; k < 8 && k < nh; k++)
+        hint |= (((ph[k] & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * k);
+    return hint;
+}
 __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, DevParams P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                                          uint64_t n_max, SurvOut *out, char *dr_chars, uint32_t dr_stride,
                                                          uint32_t *ss_pool, uint32_t ss_cap, uint8_t *found_flag,
@@ -3146,9 +3193,9 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
     uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (regroup) {
         bool heavy = false;
-        if (s < n_surv && seed_hint) {
+        if (s < n_surv) {
             const uint64_t r0 = surv_idx[s];
-            heavy = !rd_is_exc(R, r0) && __popc(seed_hint[r0]) >= 2;
+            heavy = !rd_is_exc(R, r0) && (seed_hint ? __popc(seed_hint[r0]) : __popcll(ln_hint64(R, nullptr, r0, (int)rd_len(R, r0)))) >= 2;
         }
         const uint64_t hb = __ballot(heavy);
         if (lane == 0) sl_cnt[wv] = (uint32_t)__popcll(hb);
@@ -3182,7 +3229,7 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
     LaneRead h;
     h.w = lw; h.ss = lss; h.L = L; h.nss = 0; h.cap = (int)ss_cap; h.replen = 0; h.punt = 0;
     h.cmask = (1u << (2 * P.window)) - 1u;
-    const uint32_t hint = seed_hint ? seed_hint[r] : 0xFFFFFFFFu;
+    const uint64_t hint = ln_hint64(R, seed_hint, r, L);
     int f = (P.debug_stop == 1) ? 0 : ln_search_core(h, P, hint);      // (1: load only)
     if (P.debug_stop == 4 && f == 1) f = 0;                           // (4: no orientation / output)
     SurvOut o;
@@ -3270,11 +3317,13 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
 
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
-                                 uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st, const DevMerge *init_merge)
+                                 uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st, const DevMerge *init_merge,
+                                 uint32_t max_len)
 {
     if (n_surv_max == 0) return init_merge ? hipErrorNotSupported : hipSuccess;
-    if (!R.stride_words || R.stride_words > 16 || ss_cap > 64) return hipErrorNotSupported;
-    const uint32_t wpr = R.stride_words;
+    // a lane holds its read's words in LDS: reads of up to 512 bases (one stride or not: the rows are addressed per read)
+    const uint32_t wpr = R.stride_words ? R.stride_words : (max_len + 15) / 16;
+    if (!wpr || wpr > 32 || ss_cap > 64) return hipErrorNotSupported;
     const size_t wave_words = (size_t)(wpr + 5) * WAVE + ((size_t)ss_cap * WAVE + 1) / 2;
     const size_t lds = wave_words * 4 * SL_WAVES;
     static const bool no_regroup = getenv("CRASS_SURV_NO_REGROUP") != nullptr;      // A/B switch: lanes in slot order
@@ -3285,7 +3334,7 @@ hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const ui
     }
     CRASS_LAUNCH(k_survivor_lanes, dim3((unsigned)((n_surv_max + bt - 1) / bt)), dim3(bt), lds, st, R, P, surv_idx, d_n_surv,
                        n_surv_max, out, dr_chars, dr_stride, ss_pool, ss_cap, found_flag, seed_hint, wpr, init_merge ? *init_merge : DevMerge{},
-                       init_merge ? 1 : 0, (seed_hint && !no_regroup) ? 1 : 0);
+                       init_merge ? 1 : 0, ((seed_hint || R.pos_hint) && !no_regroup) ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -4003,8 +4052,8 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
     const int lane = threadIdx.x & 63;
     const uint64_t wave_global = (blockIdx.x * (uint64_t)THREADS + threadIdx.x) >> 6;
     const uint64_t wave_total = ((uint64_t)gridDim.x * THREADS) >> 6;
-    if (W == 0 && R.pos_hint) {
-        // long reads (the engine only builds position hints for reads beyond 2 kbp): a lane walking its own 10 kbp read
+    if (W == 0 && R.wave_walk) {
+        // long reads: a lane walking its own 10 kbp read
         // touches one word per 2.5 KB row, 258 GB/s; here the WAVE walks one read, lane = window, so the loads are
         // consecutive words, and a tile's 64 reads are taken one after the other (bit k of the mask word = read k)
         auto probe = [&](uint32_t V) {
@@ -4342,7 +4391,7 @@ hipError_t launch_recruit_list(const DevReads &R, const DevAutomaton &A, const u
                                uint64_t n_max, uint32_t *info_by_slot, uint32_t *pid_by_slot, hipStream_t st)
 {
     if (n_max == 0) return hipSuccess;
-    if (R.pos_hint && A.max_pat_len)                       // long reads (the engine builds position hints beyond 2 kbp)
+    if (R.wave_walk && A.max_pat_len)                      // long reads
         CRASS_LAUNCH(k_recruit_list_wave, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);
     else
         CRASS_LAUNCH(k_recruit_list, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, st, R, A, idx, d_n, n_max, info_by_slot, pid_by_slot);

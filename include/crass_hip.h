@@ -276,7 +276,7 @@ typedef struct {
     uint64_t n_filter_survivors;    /* reads with a lattice seed hit (superset allowed)           */
     uint64_t n_pass1_found, n_pass2_found;
     uint32_t n_patterns, ac_states;
-    uint32_t used_fast_filter;      /* 1: bit-parallel lane-per-read kernel, 0: general           */
+    uint32_t used_fast_filter;      /* 1: bit-parallel lane-per-read kernel, 2: position hints (reads of 257 .. 2 048 bases, differing strides), 0: general */
     uint32_t used_lds_automaton;    /* pass 2: 2 = anchor filter + exact scan of flagged reads,
                                        1 = automaton in LDS over all reads, 0 = automaton in L2   */
     /* HIP-event timings of the last call, milliseconds, measured on the context's stream      */

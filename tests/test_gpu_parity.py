@@ -367,6 +367,69 @@ def test_long_reads_ragged_mid_size(ca):
         assert_same_pipeline(sliced, ref)
 
 
+def _mid_reads(rng, n, lo, hi, every=15):
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    drs = [acgt[rng.integers(0, 4, size=int(rng.integers(24, 40)))] for _ in range(9)]
+    seqs = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        s = acgt[rng.integers(0, 4, size=L)]
+        if i % every == 0:
+            dr = drs[int(rng.integers(0, len(drs)))]
+            pos = int(rng.integers(0, max(1, L // 3)))
+            for _ in range(int(rng.integers(2, 30))):
+                unit = np.concatenate([dr, acgt[rng.integers(0, 4, size=int(rng.integers(27, 45)))]])
+                if pos + len(unit) > L:
+                    break
+                s[pos:pos + len(unit)] = unit
+                pos += len(unit)
+        seqs.append(s.tobytes())
+    return seqs
+
+
+@pytest.mark.parametrize("lo,hi", [(257, 257), (300, 300), (301, 301), (500, 500), (960, 960), (1000, 1000), (2048, 2048), (40, 700), (30, 2048), (250, 320)])
+def test_mid_length_reads_take_the_hint_filter(ca, lo, hi):
+    """reads of 257 .. 2 048 bases (MiSeq 2 x 300, 454, merged pairs) and sets whose strides differ: no lane-per-read filter, the
+    position hints are the filter (k_hint_positions + k_hint_filter) and the survivor kernel walks on them; up to 2 048 bases the
+    found records stay on the dense hand-off (start/stop lists of up to 128 entries).  CRASS_NO_HINT_FILTER: k_filter_general, the
+    same records"""
+    rng = np.random.default_rng(lo * 7 + hi)
+    seqs = _mid_reads(rng, 12000 if hi <= 1000 else 5000, lo, hi)
+    gpu = ca.search_pipeline(seqs)
+    ref = orc.pipeline(seqs)
+    assert_same_pipeline(gpu, ref)
+    assert gpu.n_pass1 >= 100
+    assert gpu.counters["used_fast_filter"] == 2
+    os.environ["CRASS_NO_HINT_FILTER"] = "1"
+    try:
+        alt = ca.search_pipeline(seqs)
+    finally:
+        os.environ.pop("CRASS_NO_HINT_FILTER", None)
+    assert_same_pipeline(alt, ref)
+    assert alt.counters["used_fast_filter"] == 0
+
+
+def test_mid_length_reads_with_exception_reads_and_other_options(ca):
+    """the hint filter with reads that hold bytes outside ACGT (screened on their packed words, evaluated byte-wise) and with a
+    shift range other than the default (-s / -S: the run-time-range hint kernel); a window other than 8 has no position hints and
+    stays on the general filter"""
+    rng = np.random.default_rng(99)
+    seqs = _mid_reads(rng, 6000, 280, 900)
+    for i in range(0, len(seqs), 37):
+        b = bytearray(seqs[i])
+        for _ in range(3):
+            b[int(rng.integers(0, len(b)))] = ord("N")
+        seqs[i] = bytes(b)
+    gpu = ca.search_pipeline(seqs)
+    assert_same_pipeline(gpu, orc.pipeline(seqs))
+    assert gpu.counters["used_fast_filter"] == 2 and gpu.n_pass1 >= 50
+    for kw, want in ((dict(lowSpacerSize=20, highSpacerSize=60), 2), (dict(lowDRsize=20, highDRsize=40), 0), (dict(searchWindowLength=7), 0)):
+        prm = ca.default_params(**kw)
+        gpu = ca.search_pipeline(seqs, params=prm)
+        assert_same_pipeline(gpu, orc.pipeline(seqs, params=to_orc_params(prm)))
+        assert gpu.counters["used_fast_filter"] == want, kw
+
+
 LONG_PARAM_SETS = [
     dict(searchWindowLength=7), dict(lowDRsize=20, highDRsize=40), dict(lowSpacerSize=20, highSpacerSize=60),
     dict(minNumRepeats=3), dict(searchWindowLength=9, minNumRepeats=4),
