@@ -1759,11 +1759,11 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         if (c->R.stride_words >= 4 && c->R.stride_words <= 16) fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->d_hit_info.p, c->stream);
         if (fe == hipSuccess) fast = true;
         else if (fe == hipErrorNotSupported && c->hint_filter && c->R.pos_hint) {
-            // no lane-per-read filter for this layout: one hint bit per lattice position (the long reads' kernel), then "any bit?" per read.
+            // no lane-per-read filter for this layout: one hint bit per lattice position (the long reads' kernel), which also flags the reads that have one.
             // The survivor kernel walks on the same bits
-            hipError_t he = launch_hint_positions(c->R, c->dp, c->d_pos_hint_off.p, c->pos_hint_blk ? c->d_pos_hint_blk.p : nullptr, c->n_pos_hint_words,
-                                                  c->d_pos_hint.p, c->stream, 0, c->n_pos_hint_words);
-            if (he == hipSuccess) he = launch_hint_filter(c->R, c->dp, c->d_pos_hint_off.p, c->d_pos_hint.p, c->d_mask.p, c->stream);
+            HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, n_words * 8, c->stream));
+            const hipError_t he = launch_hint_positions(c->R, c->dp, c->d_pos_hint_off.p, c->pos_hint_blk ? c->d_pos_hint_blk.p : nullptr, c->n_pos_hint_words,
+                                                        c->d_pos_hint.p, c->stream, 0, c->n_pos_hint_words, c->d_mask.p);
             if (he != hipSuccess) { c->last_hip = (int)he; return CRASS_ERR_HIP; }
             c->hint_pending = false;
             hint_filtered = true;

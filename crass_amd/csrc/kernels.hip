@@ -588,7 +588,7 @@ static __device__ __forceinline__ uint64_t hint_bits_any(const uint32_t (&w)[13]
 // ------------------------------------------------------------------------------------
 template <bool RANGE>
 __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t t0, uint64_t n_words, uint64_t *hint_bits,
-                                                        int D0, int D1)
+                                                        int D0, int D1, uint64_t *hitmask, uint32_t exc_survive)
 {
     // (t0: a multiple of 256 — the launch covers the hint words [t0, n_words), see launch_hint_positions)
     const uint64_t t = t0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -650,10 +650,15 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
     const int last = (int)L - D0 - 9 - (int)(tile * 64u);
     bits = last < 0 ? 0ull : (last >= 63 ? bits : (bits & ((2ull << last) - 1ull)));
     hint_bits[t] = bits;
+    // the bits as the seed-scan FILTER of a set without a lane-per-read filter (reads of 257 .. 2 048 bases, strides that differ):
+    // bit r of the (cleared) hitmask = read r has a hint bit.  With everything behind searchEnd cleared, an all-zero bitmap proves
+    // that searchCore's seed loop (libcrispr.cpp:295-348) finds nothing; a superset like the other filters, exception reads as in
+    // k_filter_general.  A few per cent of the tiles hold a bit: the atomics are rare
+    if (hitmask && bits && (exc_survive || !rd_is_exc(R, r))) atomicOr(reinterpret_cast<unsigned long long *>(hitmask) + (r >> 6), 1ull << (r & 63u));
 }
 
 hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
-                                 uint64_t *hint_bits, hipStream_t st, uint64_t w_begin, uint64_t w_end)
+                                 uint64_t *hint_bits, hipStream_t st, uint64_t w_begin, uint64_t w_end, uint64_t *hitmask)
 {
     // the defaults' lattice and window; any shift range the 13-word tile covers (a copy at most 127 bases on)
     if (P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 || P.highDR + P.highSp < P.lowDR + P.lowSp) return hipErrorNotSupported;
@@ -663,36 +668,8 @@ hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const ui
     const int D0 = (int)(P.lowDR + P.lowSp), D1 = (int)(P.highDR + P.highSp);
     const dim3 hg((unsigned)((w_end - w_begin + 255) / 256));
     static const int force_hp = getenv("CRASS_HINT_RANGE") ? atoi(getenv("CRASS_HINT_RANGE")) : 0;      // A/B: 1 = the run-time-range form for the hint kernel, 2 = for the light walk, 3 = both
-    if (D0 == 49 && D1 == 97 && !(force_hp & 1)) CRASS_LAUNCH(k_hint_positions<false>, hg, dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits, D0, D1);
-    else CRASS_LAUNCH(k_hint_positions<true>, hg, dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits, D0, D1);
-    return hipGetLastError();
-}
-
-// The seed-scan filter of a read set that has position hints but no lane-per-read filter (reads of 257 .. 2 048 bases, strides that
-// differ): bit r of hitmask is set iff one of read r's lattice positions has a hint bit — k_hint_positions cleared everything behind
-// searchEnd, so an all-zero bitmap proves that searchCore's seed loop (libcrispr.cpp:295-348) finds nothing.  A superset like the
-// other filters; exception reads as in k_filter_general.
-__global__ __launch_bounds__(256) void k_hint_filter(DevReads R, DevParams P, const uint64_t *hint_off, const uint64_t *hint_bits, uint64_t *hitmask)
-{
-    const uint64_t r = blockIdx.x * 256ull + threadIdx.x;
-    const bool active = r < R.n_reads;
-    bool hit = false;
-    if (active && (P.exc_survive || !rd_is_exc(R, r))) {
-        const uint64_t o0 = hint_off[r], o1 = hint_off[r + 1];
-        uint64_t any = 0;
-        for (uint64_t t = o0; t < o1; t++) any |= hint_bits[t];
-        hit = any != 0;
-    }
-    const uint64_t m = __ballot(hit);
-    if ((threadIdx.x & 63) == 0 && active) hitmask[r >> 6] = m;
-}
-
-hipError_t launch_hint_filter(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint64_t *hint_bits, uint64_t *hitmask, hipStream_t st)
-{
-    if (!R.n_reads) return hipSuccess;
-    const uint64_t nb = (R.n_reads + 255) / 256;
-    if (nb > 0x7FFFFFFFull) return hipErrorNotSupported;
-    CRASS_LAUNCH(k_hint_filter, dim3((unsigned)nb), dim3(256), 0, st, R, P, hint_off, hint_bits, hitmask);
+    if (D0 == 49 && D1 == 97 && !(force_hp & 1)) CRASS_LAUNCH(k_hint_positions<false>, hg, dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits, D0, D1, hitmask, P.exc_survive);
+    else CRASS_LAUNCH(k_hint_positions<true>, hg, dim3(256), 0, st, R, hint_off, blk_read, w_begin, w_end, hint_bits, D0, D1, hitmask, P.exc_survive);
     return hipGetLastError();
 }
 
@@ -4180,18 +4157,27 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                     else scan(h_max);
                     }
                 } else {
+                    // (four words per round, requested together: one word per round was one dependent round trip per 16 bases — reads of
+                    // 300 .. 800 bases, lane per read, took twice the time of the register form per base)
                     const uint32_t nw = (L + 15) >> 4;
+                    auto probe = [&](uint32_t V) {
+                        return MODE == 4 ? anchor_probe_bloom(ak_lds, K.table, V, K, mask)
+                                         : MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
+                                                     : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
+                    };
                     uint32_t lo = g[0];
-                    for (uint32_t h = 0; h <= h_max; h += 2) {
-                        uint32_t hi = ((h >> 1) + 1 < nw) ? g[(h >> 1) + 1] : 0u;
-                        auto probe = [&](uint32_t V) {
-                            return MODE == 4 ? anchor_probe_bloom(ak_lds, K.table, V, K, mask)
-                                             : MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
-                                                         : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
-                        };
-                        if (probe(lo)) flag = true;
-                        if (h + 1 <= h_max && probe((lo >> 16) | (hi << 16))) flag = true;
-                        lo = hi;
+                    for (uint32_t h = 0; h <= h_max && !flag; h += 8) {
+                        const uint32_t wi = (h >> 1) + 1;
+                        uint32_t x[4];
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; q++) x[q] = wi + q < nw ? g[wi + q] : 0u;
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; q++) {
+                            const uint32_t hh = h + 2u * q;
+                            if (hh <= h_max && probe(lo)) flag = true;
+                            if (hh + 1u <= h_max && probe((lo >> 16) | (x[q] << 16))) flag = true;
+                            lo = x[q];
+                        }
                     }
                 }
             }

@@ -390,7 +390,7 @@ def _mid_reads(rng, n, lo, hi, every=15):
 @pytest.mark.parametrize("lo,hi", [(257, 257), (300, 300), (301, 301), (500, 500), (960, 960), (1000, 1000), (2048, 2048), (40, 700), (30, 2048), (250, 320)])
 def test_mid_length_reads_take_the_hint_filter(ca, lo, hi):
     """reads of 257 .. 2 048 bases (MiSeq 2 x 300, 454, merged pairs) and sets whose strides differ: no lane-per-read filter, the
-    position hints are the filter (k_hint_positions + k_hint_filter) and the survivor kernel walks on them; up to 2 048 bases the
+    position hints are the filter (k_hint_positions flags the reads that have one) and the survivor kernels walk on them; up to 2 048 bases the
     found records stay on the dense hand-off (start/stop lists of up to 128 entries).  CRASS_NO_HINT_FILTER: k_filter_general, the
     same records"""
     rng = np.random.default_rng(lo * 7 + hi)
