@@ -25,6 +25,23 @@ int g_device = -1;
 std::vector<int> g_devices;             // setDevices(): more than one entry shards every read set over a group of contexts
 bool g_local_copies = false;            // tests: several contexts on one GPU (CRASS_GROUP_LOCAL_COPIES)
 
+// what a finished search stage leaves behind (its index, its device contexts) is freed beside the next stage
+struct Reaper { std::future<void> f; void wait() { if (f.valid()) f.get(); } ~Reaper() { wait(); } } g_reaper_out, g_reaper_ctx;
+struct DeadContexts {
+    struct Item { crass_hip_ctx *c; crass_hip_group *g; crass_fastx_index *ix; };
+    std::vector<Item> v;
+    void park(crass_hip_ctx *c, crass_hip_group *g, crass_fastx_index *ix) { if (c || g || ix) v.push_back(Item{c, g, ix}); }
+    static void destroy(const std::vector<Item> &d, bool device)
+    {
+        for (auto &p : d) crass_fastx_index_free(p.ix);
+        if (device) for (auto &p : d) { if (p.g) crass_hip_group_destroy(p.g); if (p.c) crass_hip_destroy(p.c); }
+    }
+    void destroy_async() { if (v.empty()) return; g_reaper_ctx.wait(); auto d = std::move(v); v.clear(); g_reaper_ctx.f = std::async(std::launch::async, [d] { destroy(d, true); }); }
+    // (what is still parked at the process's end: the host side is freed, the device contexts go with the process — the HIP
+    // runtime may be gone by now)
+    ~DeadContexts() { g_reaper_ctx.wait(); destroy(v, false); }
+} g_dead;
+
 int device()
 {
     if (g_device >= 0) return g_device;
@@ -35,19 +52,58 @@ int device()
 const unsigned char *comp_tab()
 {
     // reverseComplement table (SeqUtils.cpp:50-59): IUPAC pairs, U->A, identity otherwise, [96] = 64
-    static unsigned char tab[128];
-    static bool ready = false;
-    if (!ready) {
-        for (int i = 0; i < 128; i++) tab[i] = (unsigned char)i;
-        const char *a = "ACBDKRSWN", *b = "TGVHMYSWN";
-        for (int i = 0; a[i]; i++) {
-            tab[(int)a[i]] = (unsigned char)b[i]; tab[(int)b[i]] = (unsigned char)a[i];
-            tab[(int)a[i] + 32] = (unsigned char)(b[i] + 32); tab[(int)b[i] + 32] = (unsigned char)(a[i] + 32);
+    // (filled once, by whichever thread gets here first: the holders are filled and written back over the cores)
+    struct Tab {
+        unsigned char t[128];
+        Tab()
+        {
+            for (int i = 0; i < 128; i++) t[i] = (unsigned char)i;
+            const char *a = "ACBDKRSWN", *b = "TGVHMYSWN";
+            for (int i = 0; a[i]; i++) {
+                t[(int)a[i]] = (unsigned char)b[i]; t[(int)b[i]] = (unsigned char)a[i];
+                t[(int)a[i] + 32] = (unsigned char)(b[i] + 32); t[(int)b[i] + 32] = (unsigned char)(a[i] + 32);
+            }
+            t['U'] = 'A'; t['u'] = 'a'; t[96] = 64;
         }
-        tab['U'] = 'A'; tab['u'] = 'a'; tab[96] = 64;
-        ready = true;
+    };
+    static const Tab tab;
+    return tab.t;
+}
+
+// fn(begin, end) over [0, n) on up to 16 threads (the hand-off's holders are objects of their own: flattening them, filling them
+// and writing results back into them is a walk over half a million heap objects — memory latency, which the cores overlap)
+// v sorted by cmp: chunks sorted on their own threads, then merged pairwise (the merges of one round beside each other)
+template <class T, class C> void par_sort(std::vector<T> &v, C cmp)
+{
+    const size_t n = v.size();
+    unsigned nt = (unsigned)std::min<size_t>(std::max<size_t>(1, n / 16384), std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
+    unsigned p2 = 1;
+    while (p2 * 2 <= nt) p2 *= 2;
+    nt = p2;
+    if (nt <= 1) { std::sort(v.begin(), v.end(), cmp); return; }
+    auto cut = [&](unsigned i) { return n * i / nt; };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back([&, t] { std::sort(v.begin() + cut(t), v.begin() + cut(t + 1), cmp); });
+        std::sort(v.begin(), v.begin() + cut(1), cmp);
+        for (auto &x : th) x.join();
     }
-    return tab;
+    for (unsigned w = 1; w < nt; w *= 2) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t + w < nt; t += 2 * w)
+            th.emplace_back([&, t, w] { std::inplace_merge(v.begin() + cut(t), v.begin() + cut(t + w), v.begin() + cut(std::min(nt, t + 2 * w)), cmp); });
+        for (auto &x : th) x.join();
+    }
+}
+
+template <class F> void par_ranges(size_t n, size_t grain, F fn)
+{
+    const unsigned nt = (unsigned)std::min<size_t>(std::max<size_t>(1, n / std::max<size_t>(1, grain)), std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u));
+    if (nt <= 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back([&fn, n, nt, t] { fn(n * t / nt, n * (t + 1) / nt); });
+    fn((size_t)0, n / nt);
+    for (auto &x : th) x.join();
 }
 
 std::string revcomp(const std::string &s)
@@ -533,6 +589,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     const bool timing = getenv("CRASS_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
+    g_dead.destroy_async();                                // (an earlier call's contexts, if no stage in between took them)
     crass_params p = to_params(opts);
     std::vector<int> devs = g_devices;
     if (devs.empty()) devs.push_back(device());
@@ -826,11 +883,24 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         if (at != fills.size()) CRASS_THROW("an input changed between the two passes over it");
         t_fill = now() - tf0;
     }
-    for (uint64_t k = 0; k < c.n; k++) {
-        ReadHolder *h = cand_holders[k];
-        const StartStopList &ss = h->RH_StartStops;         // patternsHash[tmp_holder.repeatStringAt(0)] on the UN-oriented holder (libcrispr.cpp:137)
-        patternsHash[c.low_lexi[k] ? h->repeatStringAt(0) : revcomp(h->RH_Seq.substr(ss[ss.size() - 2], ss[ss.size() - 1] - ss[ss.size() - 2] + 1))] = true;
-        readsFound[h->RH_Header] = true;
+    {
+        // patternsHash[tmp_holder.repeatStringAt(0)] on the UN-oriented holder and readsFound[header] (libcrispr.cpp:137-138) for
+        // every pass-1 record: the keys are made over the cores, sorted, and go into the maps in order with the end as the hint
+        // — half a million look-ups in a tree of strings were 0.2 s of the hand-off
+        std::vector<std::string> pat((size_t)c.n);
+        std::vector<const std::string *> hdr((size_t)c.n);
+        par_ranges((size_t)c.n, 8192, [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; k++) {
+                ReadHolder *h = cand_holders[k];
+                const StartStopList &ss = h->RH_StartStops;
+                pat[k] = c.low_lexi[k] ? h->repeatStringAt(0) : revcomp(h->RH_Seq.substr(ss[ss.size() - 2], ss[ss.size() - 1] - ss[ss.size() - 2] + 1));
+                hdr[k] = &h->RH_Header;
+            }
+        });
+        par_sort(pat, [](const std::string &x, const std::string &y) { return x < y; });
+        par_sort(hdr, [](const std::string *x, const std::string *y) { return *x < *y; });
+        for (size_t k = 0; k < pat.size(); k++) if (k == 0 || pat[k] != pat[k - 1]) patternsHash.insert(patternsHash.end(), std::make_pair(pat[k], true))->second = true;
+        for (size_t k = 0; k < hdr.size(); k++) if (k == 0 || *hdr[k] != *hdr[k - 1]) readsFound.insert(readsFound.end(), std::make_pair(*hdr[k], true))->second = true;
     }
     g_read_counter_p2 += (int)n;
     time(&tnow);
@@ -843,6 +913,18 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     if (timing)
         fprintf(stderr, "[crass_timing] searchAndRecruit: resident set after ingest %.0f MB, with the device context(s) up %.0f MB, at the end %.0f MB\n",
                 rss_ingested, rss_ctx, rss_mb());
+    // the search stage's state is freed on a thread of its own, beside a later stage: unmapping an 8 GB input, freeing the index
+    // and the device context(s) was 0.3 s between this function's last line and its caller's next one
+    {
+        crass_fastx_index *ix = IX.ix; IX.ix = nullptr;
+        Made &m = dev.get();
+        crass_hip_ctx *cx = m.c; crass_hip_group *gx = m.g;
+        m.c = nullptr; m.g = nullptr;
+        // (they wait for a stage that does not use the device — buildGraphsAndOutput, the next search, or the process's end:
+        // a context destroyed, or gigabytes that had been the source of a host-to-device copy unmapped, while the consensus stage
+        // runs made that stage's device work wait 0.3 s, whichever of its steps was in flight)
+        g_dead.park(cx, gx, ix);
+    }
     return max_len;
 }
 
@@ -858,18 +940,28 @@ int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map 
     std::vector<uint8_t> rec_low;
     std::vector<uint32_t> rec_token, rec_nss, ss_pool;
     std::string seqs;
+    // (the order: one walk over the map and its lists; sizes, then text and start/stops: over the cores)
     for (auto &kv : mReads) {
         if (!kv.second) continue;
-        for (ReadHolder *h : *kv.second) {
-            rec_read.push_back(holders.size());
-            holders.push_back(h);
-            seqs += h->RH_Seq; seq_off.push_back(seqs.size());
-            rec_low.push_back(1);                       // RH_Seq is passed as it stands: nothing to orient
-            rec_token.push_back((uint32_t)kv.first);
-            rec_nss.push_back((uint32_t)h->RH_StartStops.size());
-            rec_ss_off.push_back(ss_pool.size());
-            ss_pool.insert(ss_pool.end(), h->RH_StartStops.begin(), h->RH_StartStops.end());
-        }
+        for (ReadHolder *h : *kv.second) { holders.push_back(h); rec_token.push_back((uint32_t)kv.first); }
+    }
+    {
+        const size_t nh = holders.size();
+        rec_read.resize(nh); rec_low.assign(nh, 1);             // RH_Seq is passed as it stands: nothing to orient
+        rec_nss.resize(nh); rec_ss_off.resize(nh); seq_off.resize(nh + 1);
+        par_ranges(nh, 8192, [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; k++) { rec_read[k] = k; seq_off[k + 1] = holders[k]->RH_Seq.size(); rec_nss[k] = (uint32_t)holders[k]->RH_StartStops.size(); }
+        });
+        uint64_t ss_at = 0;
+        for (size_t k = 0; k < nh; k++) { seq_off[k + 1] += seq_off[k]; rec_ss_off[k] = ss_at; ss_at += rec_nss[k]; }
+        seqs.resize(seq_off[nh]); ss_pool.resize(ss_at);
+        par_ranges(nh, 8192, [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; k++) {
+                const ReadHolder *h = holders[k];
+                memcpy(&seqs[seq_off[k]], h->RH_Seq.data(), h->RH_Seq.size());
+                std::copy(h->RH_StartStops.begin(), h->RH_StartStops.end(), ss_pool.begin() + rec_ss_off[k]);
+            }
+        });
     }
     // tokens 2 .. mNextFreeToken must be dense for the flat token table (they are: StringCheck hands them out in order)
     std::string tok_chars; std::vector<uint64_t> tok_off(1, 0);
@@ -904,12 +996,14 @@ int findConsensusDRs(ReadMap &mReads, StringCheck &mStringCheck, DR_Cluster_Map 
     // ---- write the results back into the hand-off state ----
     for (uint32_t t = (uint32_t)n_tok; t < v.n_tokens; t++)
         mStringCheck.addString(std::string(v.tok_chars + v.tok_off[t], (size_t)(v.tok_off[t + 1] - v.tok_off[t])));
-    for (uint64_t k = 0; k < v.n_rec; k++) {
-        ReadHolder *r = holders[k];
-        if (!v.rec_alive[k]) { delete r; holders[k] = nullptr; continue; }
-        if (v.rec_rc[k]) { r->RH_Seq = revcomp(r->RH_Seq); r->RH_WasLowLexi = !r->RH_WasLowLexi; }     // ReadHolder::reverseComplementSeq
-        r->RH_StartStops.assign(v.ss_pool + v.rec_ss_off[k], v.ss_pool + v.rec_ss_off[k] + v.rec_nss[k]);
-    }
+    par_ranges((size_t)v.n_rec, 8192, [&](size_t a, size_t b) {
+        for (size_t k = a; k < b; k++) {
+            ReadHolder *r = holders[k];
+            if (!v.rec_alive[k]) { delete r; holders[k] = nullptr; continue; }
+            if (v.rec_rc[k]) { r->RH_Seq = revcomp(r->RH_Seq); r->RH_WasLowLexi = !r->RH_WasLowLexi; }     // ReadHolder::reverseComplementSeq
+            r->RH_StartStops.assign(v.ss_pool + v.rec_ss_off[k], v.ss_pool + v.rec_ss_off[k] + v.rec_nss[k]);
+        }
+    });
     for (auto &kv : mReads) { delete kv.second; kv.second = nullptr; }         // (the lists; the holders move)
     for (uint32_t t = 0; t < v.n_tokens; t++) {
         if (!v.tok_has_list[t]) { if (mReads.count((StringToken)t + 2)) mReads[(StringToken)t + 2] = nullptr; continue; }
@@ -939,10 +1033,12 @@ int buildGraphsAndOutput(ReadMap &mReads, DR_Cluster_Map &mDR2GIDMap, std::map<i
     const bool timing = getenv("CRASS_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tb0 = now();
+    g_dead.destroy_async();                                // (the search stage's device contexts: this stage runs on the host)
     std::vector<int32_t> gid;
     std::string dr, hdr, com, seq;
     std::vector<uint64_t> dr_off(1, 0), grp_rec_off(1, 0), hdr_off(1, 0), com_off(1, 0), seq_off(1, 0), rec_ss_off;
     std::vector<uint32_t> rec_nss, ss_pool;
+    std::vector<const ReadHolder *> flat;
     for (auto &kv : mDR2GIDMap) {
         if (!kv.second) continue;
         auto td = mTrueDRs.find(kv.first);
@@ -952,17 +1048,33 @@ int buildGraphsAndOutput(ReadMap &mReads, DR_Cluster_Map &mDR2GIDMap, std::map<i
         for (StringToken t : *kv.second) {
             auto it = mReads.find(t);
             if (it == mReads.end() || !it->second) continue;
-            for (ReadHolder *h : *it->second) {
-                if (!h) continue;
-                hdr += h->RH_Header; hdr_off.push_back(hdr.size());
-                com += h->RH_Comment; com_off.push_back(com.size());
-                seq += h->RH_Seq; seq_off.push_back(seq.size());
-                rec_nss.push_back((uint32_t)h->RH_StartStops.size());
-                rec_ss_off.push_back(ss_pool.size());
-                ss_pool.insert(ss_pool.end(), h->RH_StartStops.begin(), h->RH_StartStops.end());
-            }
+            for (ReadHolder *h : *it->second) if (h) flat.push_back(h);
         }
-        grp_rec_off.push_back(rec_nss.size());
+        grp_rec_off.push_back(flat.size());
+    }
+    {
+        // (the order above: one walk over the maps and lists; sizes, then the text: over the cores)
+        const size_t nh = flat.size();
+        hdr_off.resize(nh + 1); com_off.resize(nh + 1); seq_off.resize(nh + 1); rec_nss.resize(nh); rec_ss_off.resize(nh);
+        par_ranges(nh, 8192, [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; k++) {
+                const ReadHolder *h = flat[k];
+                hdr_off[k + 1] = h->RH_Header.size(); com_off[k + 1] = h->RH_Comment.size(); seq_off[k + 1] = h->RH_Seq.size();
+                rec_nss[k] = (uint32_t)h->RH_StartStops.size();
+            }
+        });
+        uint64_t ss_at = 0;
+        for (size_t k = 0; k < nh; k++) { hdr_off[k + 1] += hdr_off[k]; com_off[k + 1] += com_off[k]; seq_off[k + 1] += seq_off[k]; rec_ss_off[k] = ss_at; ss_at += rec_nss[k]; }
+        hdr.resize(hdr_off[nh]); com.resize(com_off[nh]); seq.resize(seq_off[nh]); ss_pool.resize(ss_at);
+        par_ranges(nh, 8192, [&](size_t a, size_t b) {
+            for (size_t k = a; k < b; k++) {
+                const ReadHolder *h = flat[k];
+                memcpy(&hdr[hdr_off[k]], h->RH_Header.data(), h->RH_Header.size());
+                memcpy(&com[com_off[k]], h->RH_Comment.data(), h->RH_Comment.size());
+                memcpy(&seq[seq_off[k]], h->RH_Seq.data(), h->RH_Seq.size());
+                std::copy(h->RH_StartStops.begin(), h->RH_StartStops.end(), ss_pool.begin() + rec_ss_off[k]);
+            }
+        });
     }
     if (ss_pool.empty()) ss_pool.push_back(0);
     if (com.empty()) com.push_back('\0');
@@ -992,7 +1104,8 @@ int buildGraphsAndOutput(ReadMap &mReads, DR_Cluster_Map &mDR2GIDMap, std::map<i
     const int wrc = crass_outputs_write(res, opts.output_fastq.c_str());
     if (timing) fprintf(stderr, "[crass_timing] outputs (adapter): hand-off flattened %.3f s, crass_build_outputs %.3f s, files written %.3f s\n", tb1 - tb0, tb2 - tb1, now() - tb2);
     const int n = (int)v.n_groups_kept;
-    crass_outputs_free(res);
+    g_reaper_out.wait();
+    g_reaper_out.f = std::async(std::launch::async, [res] { crass_outputs_free(res); });      // (waits for the graphs' tear-down: not on this thread)
     if (wrc != CRASS_OK) { std::cerr << "[ERROR]: cannot write the output files to " << opts.output_fastq << std::endl; return -1; }
     return n;
 }

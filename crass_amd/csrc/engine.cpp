@@ -1752,7 +1752,6 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     // exception reads (a byte outside ACGT) join the survivor list and are evaluated byte-wise in place, so that
     // the dense pass-1 path also holds for inputs with a few N reads
     c->dp.exc_survive = (use_filter && c->R.n_exc > 0 && !c->env.exc_separate) ? 1u : 0u;
-    if (getenv("CRASS_DEBUG_FILTER")) fprintf(stderr, "[filter] max_len %u long_min %u stride %u hint_filter %d pos_hint %p words %llu\n", c->max_len, c->env.long_min, c->R.stride_words, (int)c->hint_filter, (void *)c->R.pos_hint, (unsigned long long)c->n_pos_hint_words);
     if (use_filter) {
         hipError_t fe = hipErrorNotSupported;
         // (uniform STRIDE is what the bit-parallel kernel needs; the lengths may differ — trimmed reads padded to one stride)

@@ -20,6 +20,8 @@
 // dependent there; oracle/crass_graph.py states the same choice); spacers are visited through one array sorted by the
 // reference's 32-bit SpacerKey (its wrap-around included).  No Xerces: the XML is written as text.
 #include "../../include/crass_hip.h"
+#include <mutex>
+#include <thread>
 #include "merge.h"            // host_parallel_for
 
 #include <algorithm>
@@ -684,16 +686,16 @@ struct Xml {
     void write(string &o, int level)
     {
         if (level == 1) o += "\n";                          // format-pretty-print-1st-level
-        o += "\n"; o.append((size_t)level * 2, ' '); o += "<" + tag;
+        o += "\n"; o.append((size_t)level * 2, ' '); o += "<"; o += tag;
         std::sort(attrs.begin(), attrs.end());              // DOMAttrMapImpl keeps attributes sorted by name
-        for (auto &a : attrs) { o += " " + a.first + "=\""; esc(o, a.second, true); o += "\""; }
-        if (has_text) { o += ">"; esc(o, text, false); o += "</" + tag + ">"; }
+        for (auto &a : attrs) { o += " "; o += a.first; o += "=\""; esc(o, a.second, true); o += "\""; }
+        if (has_text) { o += ">"; esc(o, text, false); o += "</"; o += tag; o += ">"; }
         else if (!kids.empty() || !raw.empty()) {
             o += ">";
             for (auto &k : kids) k->write(o, level + 1);
             o += raw;
             if (level == 0) o += "\n";
-            o += "\n"; o.append((size_t)level * 2, ' '); o += "</" + tag + ">";
+            o += "\n"; o.append((size_t)level * 2, ' '); o += "</"; o += tag; o += ">";
         } else o += "/>";
     }
 };
@@ -706,6 +708,8 @@ struct crass_outputs {
     std::vector<uint64_t> sizes;
     std::vector<int32_t> kept;
     string out;
+    std::thread reaper;                                     // takes the graphs apart while the caller writes the files
+    ~crass_outputs() { if (reaper.joinable()) reaper.join(); }
 };
 
 extern "C" {
@@ -820,6 +824,8 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
         });
         for (uint32_t g = 0; g < ng; g++) if (alive[g] && !ok[g]) alive[g] = false;
     }
+    std::mutex part_mu;
+    double part_s[5] = {0, 0, 0, 0, 0};
     std::vector<int> cluster_of(ng, -1);
     { int cluster = 0; for (uint32_t g = 0; g < ng; g++) if (alive[g]) cluster_of[g] = cluster++; }
     (void)stage(ng, [&](size_t g, string *lg) -> int {
@@ -828,8 +834,11 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
         m->out = lg;
         const string gid = std::to_string(in->gid[g]);
         const string gv_name = "Spacers_" + gid + "_" + m->dr + "_spacers.gv", fa_name = "Group_" + gid + "_" + m->dr + ".fa";
+        const double tp0 = timing ? now() : 0;
         key_txt[g] = m->spacer_key_text(cluster_of[g], name_prefix + gid);
+        const double tp1 = timing ? now() : 0;
         fa_txt[g] = m->dump_reads_text();
+        const double tp2 = timing ? now() : 0;
         Xml grp_node("group");
         Xml *grp = grp_node.attr("gid", "G" + gid)->attr("drseq", m->dr);
         // <data> (WorkHorse.cpp:2040-2088)
@@ -839,22 +848,30 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
         drs->add("dr")->attr("seq", m->dr)->attr("drid", "DR1");
         std::vector<char> in_all(m->tok_str.size() + 2, 0);   // all_sources as marks (tokens are dense)
         std::vector<int> toks;
-        auto add_sources = [&](Xml *e, const Spacer &s) {    // the spacer's <source soid=..> children (level 5), ascending token
+        // a <spacer> / <flanker> element (level 4) with its <source soid=..> children (level 5, ascending token), written as text
+        // the way Xml::write lays such a node out — a group has ten thousand of them, and as nodes each was a dozen allocations;
+        // attribute names are given in name order
+        auto spacer_text = [&](string &o, const char *tag, std::initializer_list<std::pair<const char *, string>> attrs, const Spacer &s) {
+            o += "\n"; o.append(8, ' '); o += "<"; o += tag;
+            for (auto &a : attrs) { o += " "; o += a.first; o += "=\""; Xml::esc(o, a.second, true); o += "\""; }
             toks.clear();
             for (int nd : {s.leader, s.last}) for (int h : m->N(nd).headers) toks.push_back(h);
             std::sort(toks.begin(), toks.end());
             toks.erase(std::unique(toks.begin(), toks.end()), toks.end());
-            for (int t : toks) { Xml::leaf(e->raw, 5, "source", "soid", "SO" + std::to_string(t)); in_all[t] = 1; }
+            if (toks.empty()) { o += "/>"; return; }
+            o += ">";
+            for (int t : toks) { Xml::leaf(o, 5, "source", "soid", "SO" + std::to_string(t)); in_all[t] = 1; }
+            o += "\n"; o.append(8, ' '); o += "</"; o += tag; o += ">";
         };
         for (auto &ks : m->sp_sorted) {
             const Spacer &s = m->spacers[ks.second];
             if (m->N(s.leader).attached && m->N(s.last).attached && !s.flanker)
-                add_sources(sps->add("spacer")->attr("seq", m->str(s.id))->attr("spid", "SP" + std::to_string(s.id))->attr("cov", std::to_string(s.count)), s);
+                spacer_text(sps->raw, "spacer", {{"cov", std::to_string(s.count)}, {"seq", m->str(s.id)}, {"spid", "SP" + std::to_string(s.id)}}, s);
         }
         if (fls)
             for (int fi : m->flankers) {
                 const Spacer &s = m->spacers[fi];
-                if (m->N(s.leader).attached && m->N(s.last).attached) add_sources(fls->add("flanker")->attr("seq", m->str(s.id))->attr("flid", "FL" + std::to_string(s.id)), s);
+                if (m->N(s.leader).attached && m->N(s.last).attached) spacer_text(fls->raw, "flanker", {{"flid", "FL" + std::to_string(s.id)}, {"seq", m->str(s.id)}}, s);
             }
         for (int t = 2; t < (int)in_all.size(); t++)
             if (in_all[t]) { const string so = "SO" + std::to_string(t); Xml::leaf(sources->raw, 4, "source", "accession", m->str(t), "soid", &so); }
@@ -869,11 +886,18 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
         meta->add("file")->attr("type", "sequence")->attr("url", absdir + outdir + fa_name);
         // <assembly> (NodeManager.cpp:1560-1706)
         Xml *asmb = grp->add("assembly");
+        // (the spacers of every contig, in sp_sorted's order: one pass — every contig looking through every spacer is quadratic,
+        // and a metagenome's group has thousands of one-spacer contigs)
+        std::vector<std::vector<int>> of_contig((size_t)std::max(0, m->next_contig) + 1);
+        for (auto &ks : m->sp_sorted) {
+            const Spacer &s = m->spacers[ks.second];
+            if (s.contig >= 1 && s.contig <= m->next_contig && m->sp_attached(s)) of_contig[(size_t)s.contig].push_back(ks.second);
+        }
+        const double tp3 = timing ? now() : 0;
         for (int cn = 1; cn <= m->next_contig; cn++) {
             Xml *ce = asmb->add("contig")->attr("cid", "C" + std::to_string(cn));
-            for (auto &ks : m->sp_sorted) {
-                Spacer &s = m->spacers[ks.second];
-                if (s.contig != cn || !m->sp_attached(s)) continue;
+            for (int si : of_contig[(size_t)cn]) {
+                Spacer &s = m->spacers[si];
                 const string pre = s.flanker ? "FL" : "SP";
                 Xml *cs = ce->add("cspacer")->attr("spid", pre + std::to_string(s.id));
                 std::unique_ptr<Xml> part[4];                // bspacers, fspacers, bflankers, fflankers
@@ -892,9 +916,13 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
                 for (auto &p : part) if (p) cs->kids.push_back(std::move(p));
             }
         }
+        const double tp4 = timing ? now() : 0;
         grp_node.write(xml_txt[g], 1);
+        if (timing) { const double tp5 = now(); std::lock_guard<std::mutex> lk(part_mu); part_s[0] += tp1 - tp0; part_s[1] += tp2 - tp1; part_s[2] += tp3 - tp2; part_s[3] += tp4 - tp3; part_s[4] += tp5 - tp4; }
         return 0;
     });
+    if (timing) fprintf(stderr, "[crass_timing] outputs: per-group parts, summed over the groups: key text %.3f s, read dump %.3f s, <data> %.3f s, <assembly> %.3f s, XML text %.3f s\n",
+                        part_s[0], part_s[1], part_s[2], part_s[3], part_s[4]);
     for (auto &mp : own) mp->out = &R->out;
     for (uint32_t g = 0; g < ng; g++) {
         if (!alive[g]) continue;
@@ -904,12 +932,29 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
         keys += key_txt[g];
         put("Group_" + gid + "_" + m->dr + ".fa", std::move(fa_txt[g]));
         R->kept.push_back(in->gid[g]);
-        root.raw += xml_txt[g];                              // (the children of <crispr>, already laid out as text)
     }
     lap("group files + XML tree");
     R->out += "[" + package + "_graphBuilder]: " + std::to_string(R->kept.size()) + " CRISPRs found!\n";
+    // the document: <crispr>'s children are the groups' subtrees, already laid out as text — put together once, in a string of
+    // the final size (a 50 M-read job's .crispr is 100 MB: through Xml::write it was copied three times into growing strings)
     string xml = "<?xml version=\"1.0\" encoding=\"ISO8859-1\" standalone=\"no\" ?>";
-    root.write(xml, 0);
+    {
+        size_t total = 0;
+        for (uint32_t g = 0; g < ng; g++) if (alive[g]) total += xml_txt[g].size();
+        if (total == 0) root.write(xml, 0);
+        else {
+            string open_tag, close_tag;
+            root.raw = "\x01";                              // (a placeholder child: the opening and closing text around it)
+            root.write(open_tag, 0);
+            const size_t cut = open_tag.find('\x01');
+            close_tag = open_tag.substr(cut + 1);
+            open_tag.resize(cut);
+            xml.reserve(xml.size() + open_tag.size() + total + close_tag.size() + 2);
+            xml += open_tag;
+            for (uint32_t g = 0; g < ng; g++) if (alive[g]) { xml += xml_txt[g]; string().swap(xml_txt[g]); }
+            xml += close_tag;
+        }
+    }
     xml += "\n";
     put(package + ".crispr", std::move(xml));
     put(package + "." + stamp + ".keys.gv", keys + "\n}\n");
@@ -917,8 +962,17 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
     for (size_t i = 0; i < R->names.size(); i++) { R->name_p.push_back(R->names[i].c_str()); R->data_p.push_back(R->data[i].data()); R->sizes.push_back(R->data[i].size()); }
     // the managers go on the host pool as they were built: one thread freeing 50 graphs of 10 k reads each (node maps, spacer
     // strings) was 0.4 s of a 50 M-read run — after the last stage had been timed
-    if (threads > 1) crass::host_parallel_for(own.size(), threads, [&](size_t i) { own[i].reset(); });
-    lap("tear-down");
+    // ... and beside the caller's next step (crass_outputs_get / _write; crass_outputs_free waits for it)
+    {
+        auto *dead = new std::vector<std::unique_ptr<Manager>>();
+        dead->swap(own);
+        const unsigned thr = threads;
+        R->reaper = std::thread([dead, thr] {
+            if (thr > 1) crass::host_parallel_for(dead->size(), thr, [&](size_t i) { (*dead)[i].reset(); });
+            delete dead;
+        });
+    }
+    lap("tear-down handed on");
     *res = R.release();
     return CRASS_OK;
 }

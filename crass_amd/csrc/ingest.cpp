@@ -62,15 +62,26 @@ template <typename F> void parallel_ranges(uint64_t n, unsigned nt, F f)
 // resize() zero-fills — 2 GB of packed reads on ONE thread before the 64 that fill them start), 2 MB alignment and
 // MADV_HUGEPAGE where the kernel takes the hint (a first touch per 2 MB instead of per 4 KB: the page faults of the 3.4 GB of
 // arrays an index of 50 M reads allocates were most of its "words into place" second).
+// Giving gigabytes back: one munmap of 8 GB holds the address space's lock for a quarter of a second, and every other thread of
+// the process that touches a fresh page (the next stage's buffers) waits for it.  MADV_DONTNEED drops the pages under the SHARED
+// lock, slice by slice; the unmapping that follows finds nothing left to do.
+inline void drop_pages(void *p, size_t bytes)
+{
+    const size_t page = 4096, slice = 64u << 20;
+    uintptr_t a = ((uintptr_t)p + page - 1) & ~(uintptr_t)(page - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)(page - 1);
+    for (; a < e; a += slice) (void)madvise((void *)a, std::min<size_t>(slice, e - a), MADV_DONTNEED);
+}
+
 template <typename T> struct RawBuf {
     T *p = nullptr; size_t n = 0;
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p); }
+    void release() { if (p && n * sizeof(T) >= (8u << 20)) drop_pages(p, n * sizeof(T)); free(p); p = nullptr; n = 0; }
+    ~RawBuf() { release(); }
     bool alloc(size_t count)
     {
-        free(p); p = nullptr; n = 0;
+        release();
         const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
         if (bytes >= (8u << 20)) {
             const size_t al = 2u << 20, rounded = (bytes + al - 1) / al * al;
@@ -204,12 +215,18 @@ struct FxChunk {
     bool pack = false;
     std::vector<uint32_t> words;                                        // the records' words, tightly packed (ceil(L/16) each)
     std::vector<uint64_t> name_h;                                       // name_hash() of every record's name
+    // (pack mode keeps 24 bytes per record beside its words — header position, name hash, the two lengths — and the comment /
+    // quality flags per piece: the eight per-record vectors of the other mode were 50 bytes, 2.5 GB for 50 M reads, written by the
+    // parsers and freed again — 0.4 s on one thread — before the reads had even been looked at)
+    std::vector<uint32_t> len32, nlen32;                                // sequence / name length of every record
+    uint8_t pk_flags = 12;                                              // bit 0 any comment, 1 any quality, 2 all comment, 3 all quality
+    uint32_t pk_min_len = 0xFFFFFFFFu;
     std::vector<uint64_t> exc_rec, exc_off;                             // local indices of reads with a byte outside ACGT, ends in exc_bytes
     std::vector<uint8_t> exc_bytes;
     uint64_t v_seq = 0, v_name = 0;
     bool ended = false;        // kseq_read returned < 0 inside this range
     int last_ret = -1;         // ... with this value
-    size_t n_rec() const { return seq_end.size(); }
+    size_t n_rec() const { return pack ? len32.size() : seq_end.size(); }
 };
 
 uint64_t name_hash(const uint8_t *p, size_t n);
@@ -285,7 +302,25 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
         }
         const size_t seq_base = o.seq.size();
         c = -1;
-        while (pos < n) {
+        // pack mode, the common record: the sequence on ONE line of pure ACGT with the next header (or the '+' line) right behind
+        // it — packed straight from the mapping (pack_bases also tells whether a byte was anything else: then the general
+        // path below takes the record from the same position, as it does for wrapped lines, the last record and odd spacing)
+        bool packed_in_place = false;
+        size_t fast_len = 0;
+        if (o.pack && pos < n) {
+            const uint8_t *p = data + pos;
+            const void *nlp = memchr(p, '\n', n - pos);
+            if (nlp) {
+                const size_t len = (size_t)((const uint8_t *)nlp - p), nx = pos + len + 1;
+                if (len && len < (1u << 30) && nx < n && (data[nx] == '>' || data[nx] == '@' || data[nx] == '+')) {
+                    const size_t w0 = o.words.size(), nw = (len + 15) / 16;
+                    o.words.resize(w0 + nw);
+                    if (!pack_bases(p, (uint32_t)len, o.words.data() + w0)) { packed_in_place = true; fast_len = len; c = data[nx]; pos = nx + 1; }
+                    else o.words.resize(w0);
+                }
+            }
+        }
+        while (!packed_in_place && pos < n) {
             // fast path: a run of sequence bytes up to the end of the line.  The line's end comes from memchr; the bytes before
             // it are then checked eight at a time against a table of the bytes that END such a run ('>', '+', '@', anything
             // outside 33..126) — a sequence line has none, and one that does is walked byte by byte as before
@@ -309,7 +344,7 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
             if (c >= 33 && c <= 126) o.seq.push_back((uint8_t)c);       // isgraph
             c = -1;
         }
-        const size_t sq_len = o.seq.size() - seq_base;
+        const size_t sq_len = packed_in_place ? fast_len : o.seq.size() - seq_base;
         if (c == '>' || c == '@') last_char = c;
         bool own_q = false;
         const size_t qual_base = o.qual.size();
@@ -331,18 +366,23 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
         o.last_hdr = hdr;
         o.hdr_pos.push_back(hdr);
         if (o.pack) {
-            const size_t w0 = o.words.size(), nw = (sq_len + 15) / 16;
-            o.words.resize(w0 + nw);
-            if (pack_bases(o.seq.data() + seq_base, (uint32_t)sq_len, o.words.data() + w0)) {
-                o.exc_rec.push_back(o.seq_end.size());
-                o.exc_bytes.insert(o.exc_bytes.end(), o.seq.begin() + seq_base, o.seq.end());
-                o.exc_off.push_back(o.exc_bytes.size());
+            if (!packed_in_place) {
+                const size_t w0 = o.words.size(), nw = (sq_len + 15) / 16;
+                o.words.resize(w0 + nw);
+                if (pack_bases(o.seq.data() + seq_base, (uint32_t)sq_len, o.words.data() + w0)) {
+                    o.exc_rec.push_back(o.len32.size());
+                    o.exc_bytes.insert(o.exc_bytes.end(), o.seq.begin() + seq_base, o.seq.end());
+                    o.exc_off.push_back(o.exc_bytes.size());
+                }
+                o.seq.resize(seq_base);
             }
-            o.seq.resize(seq_base); o.qual.resize(qual_base);
+            o.qual.resize(qual_base);
             o.v_seq += sq_len; o.v_name += name_len;
             o.name_h.push_back(name_hash(data + name_st, name_len));
-            o.name_end.push_back(o.v_name); o.seq_end.push_back(o.v_seq);
-            o.comment_end.push_back(0); o.qual_end.push_back(0);
+            o.len32.push_back((uint32_t)sq_len); o.nlen32.push_back((uint32_t)name_len);
+            if (own_c) o.pk_flags |= 1; else o.pk_flags &= (uint8_t)~4;
+            if (own_q) o.pk_flags |= 2; else o.pk_flags &= (uint8_t)~8;
+            o.pk_min_len = std::min<uint32_t>(o.pk_min_len, (uint32_t)sq_len);
         } else {
             o.name.insert(o.name.end(), data + name_st, data + name_st + name_len); o.name_end.push_back(o.name.size());
             o.seq_end.push_back(o.seq.size());
@@ -350,7 +390,7 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
             o.comment_end.push_back(o.comment.size());
             o.qual_end.push_back(o.qual.size());
         }
-        o.own_c.push_back(own_c ? 1 : 0); o.own_q.push_back(own_q ? 1 : 0);
+        if (!o.pack) { o.own_c.push_back(own_c ? 1 : 0); o.own_q.push_back(own_q ? 1 : 0); }
         o.max_len = std::max<uint32_t>(o.max_len, (uint32_t)sq_len);
         if (c == -1 && pos >= n) { o.ended = true; o.last_ret = -1; o.next_start = n; return; }
     }
@@ -712,7 +752,8 @@ struct crass_fastx_index {
     uint32_t max_len = 0;
     int last_ret = -1;
     bool any_c = false, any_q = false;
-    ~crass_fastx_index() { if (map && map_n) munmap(map, map_n); }
+    std::thread reaper;                                // frees the parsers' pieces beside whatever the caller does next
+    ~crass_fastx_index() { if (reaper.joinable()) reaper.join(); if (map && map_n) { drop_pages(map, map_n); munmap(map, map_n); } }
 };
 
 extern "C" {
@@ -751,29 +792,11 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
     std::vector<uint64_t> rec0(nc + 1, 0), tight0(nc + 1, 0);
     bool any_c = false, all_c = true, any_q = false, all_q = true;
     uint32_t max_len = 0, min_len = 0xFFFFFFFFu;
-    {
-        std::vector<uint32_t> pmin(nc, 0xFFFFFFFFu);
-        std::vector<uint8_t> fl(nc, 0);
-        auto scan = [&](size_t k) {
-            const FxChunk &c = ch[k];
-            uint32_t mn = 0xFFFFFFFFu;
-            uint8_t f = 12;                              // bit 0 any_c, 1 any_q, 2 all_c, 3 all_q
-            for (size_t i = 0; i < c.n_rec(); i++) {
-                mn = std::min<uint32_t>(mn, (uint32_t)(c.seq_end[i] - (i ? c.seq_end[i - 1] : 0)));
-                if (c.own_c[i]) f |= 1; else f &= (uint8_t)~4;
-                if (c.own_q[i]) f |= 2; else f &= (uint8_t)~8;
-            }
-            pmin[k] = mn; fl[k] = f;
-        };
-        std::vector<std::thread> th;
-        for (size_t k = 1; k < nc; k++) th.emplace_back(scan, k);
-        if (nc) scan(0);
-        for (auto &t : th) t.join();
-        for (size_t k = 0; k < nc; k++) {
-            rec0[k + 1] = rec0[k] + ch[k].n_rec(); tight0[k + 1] = tight0[k] + ch[k].words.size();
-            max_len = std::max(max_len, ch[k].max_len); min_len = std::min(min_len, pmin[k]);
-            if (ch[k].n_rec()) { any_c |= (fl[k] & 1) != 0; any_q |= (fl[k] & 2) != 0; all_c &= (fl[k] & 4) != 0; all_q &= (fl[k] & 8) != 0; }
-        }
+    for (size_t k = 0; k < nc; k++) {                    // (the pieces kept their own minimum length and comment / quality flags)
+        rec0[k + 1] = rec0[k] + ch[k].n_rec(); tight0[k + 1] = tight0[k] + ch[k].words.size();
+        max_len = std::max(max_len, ch[k].max_len); min_len = std::min(min_len, ch[k].pk_min_len);
+        const uint8_t f = ch[k].pk_flags;
+        if (ch[k].n_rec()) { any_c |= (f & 1) != 0; any_q |= (f & 2) != 0; all_c &= (f & 4) != 0; all_q &= (f & 8) != 0; }
     }
     if ((any_c && !all_c) || (any_q && !all_q)) return CRASS_ERR_UNSUPPORTED;      // stale comment / quality buffers: ordered readers
     if (max_len > CRASS_HIP_MAX_READ_LEN) return CRASS_ERR_UNSUPPORTED;
@@ -806,13 +829,13 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
             uint64_t wat = 0;
             for (size_t i = 0; i < m; i++) {
                 const uint64_t r = rec0[k] + i;
-                const uint32_t L = (uint32_t)(c.seq_end[i] - (i ? c.seq_end[i - 1] : 0));
-                name_len[r] = (uint32_t)(c.name_end[i] - (i ? c.name_end[i - 1] : 0));
+                const uint32_t L = c.len32[i];
+                name_len[r] = c.nlen32[i];
                 if (!uniform_len) ix->lengths[r] = L;
                 if (!stride) ix->word_off[r] = tight0[k] + wat;
                 wat += (L + 15) / 16;
             }
-            std::vector<uint64_t>().swap(c.hdr_pos); std::vector<uint64_t>().swap(c.name_h);
+            std::vector<uint64_t>().swap(c.hdr_pos); std::vector<uint64_t>().swap(c.name_h); std::vector<uint32_t>().swap(c.nlen32);
         };
         std::vector<std::thread> th;
         for (size_t k = 1; k < nc; k++) th.emplace_back(place_small, k);
@@ -827,7 +850,7 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
         else {                                           // padded to one stride
             uint64_t wat = 0;
             for (size_t i = 0; i < c.n_rec(); i++) {
-                const uint32_t L = (uint32_t)(c.seq_end[i] - (i ? c.seq_end[i - 1] : 0));
+                const uint32_t L = c.len32[i];
                 const uint32_t nw = (L + 15) / 16;
                 uint32_t *w = packed + (rec0[k] + i) * (uint64_t)stride;
                 memcpy(w, c.words.data() + wat, (size_t)nw * 4);
@@ -837,12 +860,15 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
         }
         std::vector<uint32_t>().swap(c.words);
     };
+    double t_words = 0;
     std::thread words_thread([&]() {
+        const double tw0 = now_s();
         std::vector<std::thread> th;
         for (size_t k = 1; k < nc; k++) th.emplace_back(place_words, k);
         if (nc) place_words(0);
         for (auto &t : th) t.join();
         for (size_t x = 0; x < 4; x++) ix->packed[n_words - 4 + x] = 0;
+        t_words = now_s() - tw0;
     });
     struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_words{words_thread};
     o.exc_off.push_back(0);
@@ -864,7 +890,9 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
         constexpr unsigned SH = 256;
         const unsigned ht = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw_threads(), 64u), nrec / 65536));
         RawBuf<uint32_t> order, first;
-        if (!order.alloc(nrec) || !first.alloc(nrec)) return CRASS_ERR_OOM;
+        RawBuf<uint64_t> order_h;                         // the hashes in shard order too: the shard's thread then reads them in a stream
+                                                          // (looked up per record they were 50 M cache misses, most of this stage)
+        if (!order.alloc(nrec) || !first.alloc(nrec) || !order_h.alloc(nrec)) return CRASS_ERR_OOM;
         std::vector<uint64_t> cnt((size_t)ht * SH, 0);
         const uint64_t per = (nrec + ht - 1) / ht;
         auto range = [&](unsigned t, uint64_t &a2, uint64_t &b2) { a2 = std::min<uint64_t>(nrec, t * per); b2 = std::min<uint64_t>(nrec, a2 + per); };
@@ -886,7 +914,7 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
         }
         {
             std::vector<std::thread> th;
-            auto scatter = [&](unsigned t) { uint64_t a2, b2; range(t, a2, b2); uint64_t *c = cnt.data() + (size_t)t * SH; for (uint64_t r = a2; r < b2; r++) order[c[nh[r] >> 56]++] = (uint32_t)r; };
+            auto scatter = [&](unsigned t) { uint64_t a2, b2; range(t, a2, b2); uint64_t *c = cnt.data() + (size_t)t * SH; for (uint64_t r = a2; r < b2; r++) { const uint64_t h = nh[r], at = c[h >> 56]++; order[at] = (uint32_t)r; order_h[at] = h; } };
             for (unsigned t = 1; t < ht; t++) th.emplace_back(scatter, t);
             scatter(0);
             for (auto &x : th) x.join();
@@ -911,7 +939,7 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
                     tab.assign(cap, 0);
                     for (uint64_t q = sh_begin[sh]; q < sh_begin[sh + 1]; q++) {
                         const uint64_t r = order[q];
-                        const uint64_t h = nh[r];
+                        const uint64_t h = order_h[q];
                         const uint64_t tag = (h << 8) & 0xFFFFFFFF00000000ull;      // 32 hash bits below the shard's byte
                         size_t i = (size_t)(h >> 8) & (cap - 1);
                         for (;;) {
@@ -934,8 +962,16 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
             parallel_ranges(nrec, ht, [&](uint64_t a2, uint64_t b2, unsigned) { for (uint64_t r = a2; r < b2; r++) ix->header_id[r] = first[r]; });
         }
     }
+    const double t_hdr = now_s() - t3;
     words_thread.join();
-    std::vector<FxChunk>().swap(ch);
+    const double t4 = now_s();
+    // (what is left of the pieces — a gigabyte of per-record vectors for 50 M reads — is handed back to the allocator on a thread
+    // of its own: 0.4 s on this one)
+    {
+        std::vector<FxChunk> *dead = new std::vector<FxChunk>();
+        dead->swap(ch);
+        ix->reaper = std::thread([dead] { delete dead; });
+    }
     crass_reads &r = ix->reads;
     r.n_reads = nrec; r.packed = ix->packed.data(); r.stride_words = stride;
     r.word_off = stride ? nullptr : ix->word_off.data();
@@ -945,8 +981,8 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
     r.exc_read = o.exc_read.data(); r.exc_off = o.exc_off.data(); r.exc_bytes = o.exc_bytes.data();
     r.header_id = any_dup ? ix->header_id.data() : nullptr; r.read_index_base = 0;
     if (timing)
-        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse + pack %.3f s, record arrays %.3f s, header ids beside the words' placement %.3f s\n",
-                n, nc, (unsigned long long)nrec, t1 - t0, t2 - t1, t3 - t2, now_s() - t3);
+        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse + pack %.3f s, record arrays %.3f s, header ids %.3f s beside the words' placement %.3f s: %.3f s, pieces freed %.3f s\n",
+                n, nc, (unsigned long long)nrec, t1 - t0, t2 - t1, t3 - t2, t_hdr, t_words, t4 - t3, now_s() - t4);
     *out = ix.release();
     return CRASS_OK;
 }
