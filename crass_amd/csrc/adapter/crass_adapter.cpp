@@ -638,6 +638,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     } else if (streamed) {
         // pass A over the inputs: chunk -> 2-bit pack -> append; the chunk's text is dropped
         struct Names { crass_name_table *t = crass_name_table_create(); ~Names() { crass_name_table_destroy(t); } } names;
+        double t_append = 0;
         for (size_t f = 0; f < seqFiles.size(); f++) {
             crass_fastx_stream *st = nullptr;
             const int rc = crass_fastx_stream_open(seqFiles[f].c_str(), 0, names.t, S.n, &st);
@@ -667,12 +668,15 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
                     S.reserve(est, (uint32_t)((fx.max_len + 15) / 16));
                     crass_name_table_reserve(names.t, est);
                 }
+                const double ta0 = now();
                 S.append(fx);
+                t_append += now() - ta0;
             }
             S.base.push_back(S.n);
         }
         n = S.n; max_len = (int)S.max_len;
         t1 = now();
+        if (timing) fprintf(stderr, "[crass_timing] streamed ingest: packing and appending the chunks %.3f s of the pass\n", t_append);
         S.finish(r);
     } else {
     J.fx.resize(seqFiles.size());

@@ -9,6 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <thread>
@@ -71,6 +75,16 @@ inline void drop_pages(void *p, size_t bytes)
     uintptr_t a = ((uintptr_t)p + page - 1) & ~(uintptr_t)(page - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)(page - 1);
     for (; a < e; a += slice) (void)madvise((void *)a, std::min<size_t>(slice, e - a), MADV_DONTNEED);
 }
+
+// an array that is asked for again and again with about the same size: grown, never shrunk, not initialised
+template <typename T> struct KeepBuf {
+    T *p = nullptr; size_t cap = 0;
+    KeepBuf() = default;
+    KeepBuf(const KeepBuf &) = delete;
+    KeepBuf &operator=(const KeepBuf &) = delete;
+    ~KeepBuf() { free(p); }
+    T *ensure(size_t n) { if (n > cap) { free(p); cap = n + n / 8 + 64; p = (T *)malloc(cap * sizeof(T)); if (!p) cap = 0; } return p; }
+};
 
 template <typename T> struct RawBuf {
     T *p = nullptr; size_t n = 0;
@@ -227,6 +241,15 @@ struct FxChunk {
     bool ended = false;        // kseq_read returned < 0 inside this range
     int last_ret = -1;         // ... with this value
     size_t n_rec() const { return pack ? len32.size() : seq_end.size(); }
+    // as new, with the vectors' memory kept (a stream parses chunk after chunk into the same pieces: 64 MB of vectors allocated and
+    // given back per chunk were most of a chunk's time outside its parse)
+    void reset(bool pk)
+    {
+        seq.clear(); name.clear(); comment.clear(); qual.clear(); seq_end.clear(); name_end.clear(); comment_end.clear(); qual_end.clear();
+        own_c.clear(); own_q.clear(); hdr_pos.clear(); words.clear(); name_h.clear(); len32.clear(); nlen32.clear();
+        exc_rec.clear(); exc_off.clear(); exc_bytes.clear();
+        max_len = 0; next_start = 0; last_hdr = 0; pack = pk; pk_flags = 12; pk_min_len = 0xFFFFFFFFu; v_seq = 0; v_name = 0; ended = false; last_ret = -1;
+    }
 };
 
 uint64_t name_hash(const uint8_t *p, size_t n);
@@ -507,8 +530,8 @@ void parse_pieces(const uint8_t *d, size_t n, std::vector<FxChunk> &ch, size_t p
             if (g > starts.back()) starts.push_back(g);
         }
     }
-    ch.assign(starts.size(), FxChunk());
-    for (auto &c : ch) c.pack = pack;
+    ch.resize(starts.size());
+    for (auto &c : ch) c.reset(pack);
     auto run = [&](size_t k) { parse_range(d, n, starts[k], k + 1 < starts.size() ? starts[k + 1] : n, k == 0, ch[k]); };
     if (starts.size() == 1) run(0);
     else {
@@ -1085,8 +1108,8 @@ inline Hash128 name_hash128(const uint8_t *p, size_t n)
 // two independent 64-bit mixes, BOTH stored and compared in full (round 4 kept 64 + 32 bits while saying 128: VERDICT r04 weak 1c).
 // Two different names of a job of n reads meet in both with probability ~ n^2 / 2^129 (1.5e-23 at n = 1e8); the whole-file reader
 // (crass_read_fastx) compares the names themselves.  29 bytes per distinct name at load <= 0.7.
-struct crass_name_table {
-    // 20 bytes per slot: 128 hash bits and a 32-bit index (jobs of up to 2^32 - 2 reads; beyond that a 64-bit side table)
+// One sub-table: 20 bytes per slot, 128 hash bits and a 32-bit index (jobs of up to 2^32 - 2 reads; beyond that a 64-bit side table)
+struct NameSubTable {
     std::vector<uint64_t> ha, hb; std::vector<uint32_t> idx;     // idx == 0xFFFFFFFF: empty
     std::vector<uint64_t> idx_wide;                              // (only once an index does not fit 32 bits)
     size_t used = 0;
@@ -1094,7 +1117,7 @@ struct crass_name_table {
     uint64_t get_idx(size_t j) const { return wide ? idx_wide[j] : idx[j]; }
     void grow(size_t min_cap = 0)
     {
-        size_t cap = ha.empty() ? (1u << 16) : ha.size() * 2;
+        size_t cap = ha.empty() ? (1u << 12) : ha.size() * 2;
         while (cap < min_cap) cap *= 2;
         std::vector<uint64_t> a(cap), b(cap), xw(wide ? cap : 0);
         std::vector<uint32_t> x(cap, 0xFFFFFFFFu);
@@ -1122,13 +1145,127 @@ struct crass_name_table {
             if (ha[j] == h.a && hb[j] == b32) return get_idx(j);
         }
     }
-    uint64_t first(const uint8_t *name, size_t len, uint64_t index) { return first_hashed(name_hash128(name, len), index); }
 };
 
+// The job's names -> the first read that carried each.  64 sub-tables by the hash's top bits: a chunk's names are dealt to their
+// sub-tables in read order (a counting sort of the chunk's record numbers) and every sub-table is filled by ONE thread — the first
+// occurrence is simply the first insert, and the 50 M serial inserts of a streamed job (3 s of its 8.5 s ingest) spread over the
+// cores.
+struct crass_name_table {
+    static constexpr unsigned SH = 64;
+    NameSubTable sub[SH];
+    static unsigned shard(const Hash128 &h) { return (unsigned)(h.a >> 58); }
+    uint64_t first_hashed(Hash128 h, uint64_t index) { return sub[shard(h)].first_hashed(h, index); }
+    uint64_t first(const uint8_t *name, size_t len, uint64_t index) { return first_hashed(name_hash128(name, len), index); }
+    void reserve(uint64_t n_names)
+    {
+        const uint64_t per = n_names / SH + n_names / SH / 8 + 64;
+        size_t want = 1u << 12;
+        while ((per + 1) * 10 > want * 7) want *= 2;
+        parallel_ranges(SH, std::min<unsigned>(hw_threads(), 16u), [&](uint64_t a, uint64_t b, unsigned) { for (uint64_t k = a; k < b; k++) if (want > sub[k].ha.size()) sub[k].grow(want); });
+        for (auto &t : sub) if (want > t.ha.size()) t.grow(want);      // (parallel_ranges runs small counts on one thread)
+    }
+    // out[q] = first read of the job named like read base + q, for q in [0, n): the table as if the names had been inserted in order
+    void first_batch(const Hash128 *hs, uint64_t n, uint64_t base, uint64_t *out)
+    {
+        const unsigned nt = (unsigned)std::min<uint64_t>(std::min<unsigned>(hw_threads(), 16u), n / 8192);
+        if (nt <= 1) { for (uint64_t q = 0; q < n; q++) out[q] = first_hashed(hs[q], base + q); return; }
+        std::vector<uint32_t> order(n);
+        std::vector<uint64_t> cnt((size_t)nt * SH, 0), sh_begin(SH + 1, 0);
+        const uint64_t per = (n + nt - 1) / nt;
+        auto range = [&](unsigned t, uint64_t &a, uint64_t &b) { a = std::min<uint64_t>(n, t * per); b = std::min<uint64_t>(n, a + per); };
+        auto run = [&](const std::function<void(unsigned)> &fn) { std::vector<std::thread> th; for (unsigned t = 1; t < nt; t++) th.emplace_back(fn, t); fn(0); for (auto &x : th) x.join(); };
+        run([&](unsigned t) { uint64_t a, b; range(t, a, b); uint64_t *c = cnt.data() + (size_t)t * SH; for (uint64_t q = a; q < b; q++) c[shard(hs[q])]++; });
+        { uint64_t at = 0; for (unsigned sh = 0; sh < SH; sh++) { sh_begin[sh] = at; for (unsigned t = 0; t < nt; t++) { const uint64_t c = cnt[(size_t)t * SH + sh]; cnt[(size_t)t * SH + sh] = at; at += c; } } sh_begin[SH] = at; }
+        run([&](unsigned t) { uint64_t a, b; range(t, a, b); uint64_t *c = cnt.data() + (size_t)t * SH; for (uint64_t q = a; q < b; q++) order[c[shard(hs[q])]++] = (uint32_t)q; });
+        std::atomic<unsigned> next{0};
+        run([&](unsigned) {
+            for (;;) {
+                const unsigned sh = next.fetch_add(1, std::memory_order_relaxed);
+                if (sh >= SH) break;
+                NameSubTable &T = sub[sh];
+                for (uint64_t p = sh_begin[sh]; p < sh_begin[sh + 1]; p++) { const uint64_t q = order[p]; out[q] = T.first_hashed(hs[q], base + q); }
+            }
+        });
+    }
+};
+
+static double stream_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct crass_fastx_stream {
     gzFile fp = nullptr;
-    std::vector<uint8_t> buf;                       // the carried tail followed by the bytes read for this chunk
+    std::vector<uint8_t> buf;                       // the carried tail (the record a chunk's end cut: parsed again with the next chunk)
     size_t carry = 0, chunk_bytes = 64u << 20;
+    // The file is read (and inflated) one block AHEAD on a thread of its own: reading 64 MB was 13 ms of a chunk's 23 in the
+    // second pass of a streamed job, and most of a gzip input's time.  A block has room in front of its bytes for the carried tail,
+    // so a chunk is parsed where it was read.
+    struct Block { std::unique_ptr<uint8_t[]> p; size_t gap = 0, len = 0; bool last = false; };
+    std::thread rd;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Block> ready;
+    bool rd_stop = false, rd_err = false, rd_done = false;
+    // what a chunk needs is kept from chunk to chunk: the pieces, the arrays handed out (crass_fastx's pointers: valid until the
+    // next call), the blocks of the reader thread
+    std::vector<FxChunk> ch;
+    KeepBuf<uint8_t> k_seq, k_name, k_hasc, k_hasq, k_com, k_qual;
+    KeepBuf<uint64_t> k_seq_off, k_name_off, k_com_off, k_qual_off, k_hid;
+    std::vector<std::unique_ptr<uint8_t[]>> pool;    // (under mu)
+    double t_wait = 0, t_parse = 0, t_asm = 0, t_names = 0, t_read = 0;      // CRASS_TIMING: where the chunks' time went
+    uint64_t n_chunks = 0;
+    void reader()
+    {
+        const size_t gap = std::min<size_t>(1u << 20, chunk_bytes);
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return ready.size() < 2 || rd_stop; });
+                if (rd_stop) break;
+            }
+            Block b;
+            b.gap = gap;
+            const double tr0 = stream_now();
+            { std::lock_guard<std::mutex> lk(mu); if (!pool.empty()) { b.p = std::move(pool.back()); pool.pop_back(); } }
+            if (!b.p) b.p.reset(new (std::nothrow) uint8_t[gap + chunk_bytes]);
+            bool err = !b.p;
+            size_t at = 0;
+            while (!err && at < chunk_bytes) {
+                const int got = gzread(fp, b.p.get() + gap + at, (unsigned)std::min<size_t>(chunk_bytes - at, 1u << 30));
+                if (got < 0) { err = true; break; }
+                if (got == 0) { b.last = true; break; }
+                at += (size_t)got;
+            }
+            b.len = at;
+            t_read += stream_now() - tr0;
+            const bool last = b.last;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (err) rd_err = true; else ready.push_back(std::move(b));
+                if (err || last) rd_done = true;
+            }
+            cv.notify_all();
+            if (err || last) break;
+        }
+        { std::lock_guard<std::mutex> lk(mu); rd_done = true; }
+        cv.notify_all();
+    }
+    bool take(Block &b)                             // false: read error
+    {
+        if (!rd.joinable()) rd = std::thread([this] { reader(); });
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !ready.empty() || rd_done; });
+        if (ready.empty()) { if (rd_err) return false; b = Block(); b.last = true; return true; }
+        b = std::move(ready.front());
+        ready.pop_front();
+        lk.unlock();
+        cv.notify_all();
+        return true;
+    }
+    void stop_reader()
+    {
+        { std::lock_guard<std::mutex> lk(mu); rd_stop = true; }
+        cv.notify_all();
+        if (rd.joinable()) rd.join();
+    }
     bool eof = false, finished = false;
     bool any_c = false, any_q = false;              // some earlier record had its own comment / quality: later ones inherit
     std::string stale_c, stale_q;
@@ -1145,9 +1282,7 @@ crass_name_table *crass_name_table_create(void) { return new (std::nothrow) cras
 void crass_name_table_reserve(crass_name_table *t, uint64_t n_names)
 {
     if (!t) return;
-    size_t want = 1u << 16;
-    while ((n_names + 1) * 10 > want * 7) want *= 2;
-    if (want > t->ha.size()) t->grow(want);
+    t->reserve(n_names);
 }
 void crass_name_table_destroy(crass_name_table *t) { delete t; }
 uint64_t crass_name_table_first(crass_name_table *t, const char *name, uint64_t len, uint64_t index)
@@ -1175,8 +1310,11 @@ int crass_fastx_stream_open(const char *path, uint64_t chunk_bytes, crass_name_t
 void crass_fastx_stream_close(crass_fastx_stream *s)
 {
     if (!s) return;
+    s->stop_reader();
+    if (getenv("CRASS_TIMING"))
+        fprintf(stderr, "[crass_timing] fastx stream: %llu chunks, %llu records: waiting for a block %.3f s (reading them, beside: %.3f s), parse %.3f s, assemble %.3f s, names %.3f s\n",
+                (unsigned long long)s->n_chunks, (unsigned long long)s->n_done, s->t_wait, s->t_read, s->t_parse, s->t_asm, s->t_names);
     if (s->fp) gzclose(s->fp);
-    crass_free_fastx(&s->cur);
     delete s;
 }
 
@@ -1189,29 +1327,51 @@ uint32_t crass_fastx_stream_max_len(const crass_fastx_stream *s) { return s ? s-
 int crass_fastx_stream_next(crass_fastx_stream *s, crass_fastx *out)
 {
     if (!s || !out) return CRASS_ERR_INVALID_ARG;
-    crass_free_fastx(&s->cur);
+    memset(&s->cur, 0, sizeof(s->cur));                  // (its arrays belong to the stream)
     memset(out, 0, sizeof(*out));
     out->last_ret = s->final_ret;
     if (s->finished) return CRASS_OK;
-    std::vector<FxChunk> ch;
+    std::vector<FxChunk> &ch = s->ch;
     size_t n_keep_pieces = 0, consumed = 0;
     bool drop_last = false;
+    // the chunk's bytes: the carried tail (s->buf) followed by the next block, in the block's own memory when the tail fits the
+    // room in front of it
+    const uint8_t *data = s->buf.data();
+    size_t n = s->buf.size();
+    std::unique_ptr<uint8_t[]> hold;
+    bool hold_is_block = false;
+    struct GiveBack {                                    // a block goes back to the reader's pool when the chunk is done with it
+        crass_fastx_stream *s; std::unique_ptr<uint8_t[]> &h; bool &is_block;
+        ~GiveBack() { if (h && is_block) { std::lock_guard<std::mutex> lk(s->mu); if (s->pool.size() < 3) s->pool.push_back(std::move(h)); } }
+    } give_back{s, hold, hold_is_block};
     for (;;) {
-        // fill: the carried tail is already at the front of buf
-        const size_t want = s->carry + s->chunk_bytes;
         if (!s->eof) {
-            s->buf.resize(want);
-            size_t at = s->carry;
-            while (at < want) {
-                const int got = gzread(s->fp, s->buf.data() + at, (unsigned)std::min<size_t>(want - at, 1u << 30));
-                if (got < 0) return CRASS_ERR_IO;
-                if (got == 0) { s->eof = true; break; }
-                at += (size_t)got;
+            crass_fastx_stream::Block b;
+            const double tw0 = stream_now();
+            if (!s->take(b)) return CRASS_ERR_IO;
+            s->t_wait += stream_now() - tw0;
+            if (b.last) s->eof = true;
+            if (b.p && n <= b.gap) {
+                if (n) memcpy(b.p.get() + b.gap - n, data, n);
+                data = b.p.get() + b.gap - n;
+                n += b.len;
+                if (hold && hold_is_block) { std::lock_guard<std::mutex> lk(s->mu); if (s->pool.size() < 3) s->pool.push_back(std::move(hold)); }
+                hold = std::move(b.p);                  // (what data pointed into until now — the tail, or an earlier block — is done with)
+                hold_is_block = true;
+            } else if (b.len) {
+                std::unique_ptr<uint8_t[]> big(new (std::nothrow) uint8_t[n + b.len]);
+                if (!big) return CRASS_ERR_OOM;
+                if (n) memcpy(big.get(), data, n);
+                memcpy(big.get() + n, b.p.get() + b.gap, b.len);
+                data = big.get();
+                n += b.len;
+                hold = std::move(big);
+                hold_is_block = false;
             }
-            s->buf.resize(at);
         }
-        const size_t n = s->buf.size();
-        parse_pieces(s->buf.data(), n, ch, 2u << 20);          // (2 MB pieces: a 64 MB chunk still keeps 32 threads busy)
+        const double tp0 = stream_now();
+        parse_pieces(data, n, ch, 2u << 20);                   // (2 MB pieces: a 64 MB chunk still keeps 32 threads busy)
+        s->t_parse += stream_now() - tp0;
         size_t total = 0;
         for (auto &c : ch) total += c.n_rec();
         if (s->eof) { n_keep_pieces = ch.size(); consumed = n; drop_last = false; break; }
@@ -1224,26 +1384,95 @@ int crass_fastx_stream_next(crass_fastx_stream *s, crass_fastx *out)
             drop_last = true;
             break;
         }
-        s->carry = n;                                   // keep everything, read another chunk's worth behind it
-        s->chunk_bytes *= 2;
+        // (keep everything, read another block behind it)
     }
     // ---- assemble the chunk's records in order (kseq's stale comment / quality buffers travel with the stream) ----
+    const double ta0 = stream_now();
+    s->n_chunks++;
     uint64_t nrec = 0, seq_b = 0, name_b = 0;
     for (size_t k = 0; k < n_keep_pieces; k++) { nrec += ch[k].n_rec(); seq_b += ch[k].seq.size(); name_b += ch[k].name.size(); }
     if (drop_last) nrec--;
-    auto alloc8 = [](uint64_t nb) { return (uint8_t *)malloc(nb + 1); };
-    auto alloc64 = [](uint64_t ne) { return (uint64_t *)malloc((ne + 1) * 8); };
     crass_fastx &o = s->cur;
     o.n_reads = nrec;
-    o.seq = alloc8(seq_b); o.seq_off = alloc64(nrec + 1); o.name = alloc8(name_b); o.name_off = alloc64(nrec + 1);
-    o.has_comment = alloc8(nrec); o.has_qual = alloc8(nrec); o.comment_off = alloc64(nrec + 1); o.qual_off = alloc64(nrec + 1);
-    o.header_id = alloc64(nrec);
+    o.seq = s->k_seq.ensure(seq_b + 1); o.seq_off = s->k_seq_off.ensure(nrec + 1); o.name = s->k_name.ensure(name_b + 1); o.name_off = s->k_name_off.ensure(nrec + 1);
+    o.has_comment = s->k_hasc.ensure(nrec + 1); o.has_qual = s->k_hasq.ensure(nrec + 1); o.comment_off = s->k_com_off.ensure(nrec + 1); o.qual_off = s->k_qual_off.ensure(nrec + 1);
+    o.header_id = s->k_hid.ensure(nrec + 1);
     if (!o.seq || !o.seq_off || !o.name || !o.name_off || !o.has_comment || !o.has_qual || !o.comment_off || !o.qual_off || !o.header_id) return CRASS_ERR_OOM;
     o.seq_off[0] = o.name_off[0] = o.comment_off[0] = o.qual_off[0] = 0;
     std::vector<uint8_t> com_bytes, qual_bytes;
     uint64_t r = 0, sq = 0, nm = 0;
     uint32_t max_len = 0;
-    for (size_t k = 0; k < n_keep_pieces && r < nrec; k++) {
+    // The common layouts — no record of the chunk (and none before it) has a comment / a quality string, or every one has its own —
+    // need no record-by-record walk: every piece's fields are already concatenated in record order, so a piece is four block copies
+    // and its offsets, and the pieces go side by side.  (kseq's stale buffers — a record WITHOUT a comment inherits the last one
+    // seen — make the general case sequential: the loop below.  It was 4 s of a streamed 50 M-read job on one thread.)
+    bool assembled = false;
+    {
+        bool all_c = true, none_c = true, all_q = true, none_q = true;
+        for (size_t k = 0; k < n_keep_pieces; k++) {
+            for (uint8_t v : ch[k].own_c) { all_c &= v != 0; none_c &= v == 0; }
+            for (uint8_t v : ch[k].own_q) { all_q &= v != 0; none_q &= v == 0; }
+        }
+        const bool c_ok = (none_c && !s->any_c) || all_c, q_ok = (none_q && !s->any_q) || all_q;
+        if (c_ok && q_ok && nrec && !getenv("CRASS_STREAM_SERIAL_ASSEMBLE")) {
+            const bool with_c = all_c && !none_c, with_q = all_q && !none_q;
+            const size_t np = n_keep_pieces;
+            std::vector<uint64_t> cnt(np, 0), r0(np + 1, 0), sq0(np + 1, 0), nm0(np + 1, 0), cm0(np + 1, 0), ql0(np + 1, 0);
+            uint64_t left = nrec;
+            for (size_t k = 0; k < np; k++) {
+                const FxChunk &c = ch[k];
+                const uint64_t m = std::min<uint64_t>(c.n_rec(), left);
+                left -= m; cnt[k] = m;
+                r0[k + 1] = r0[k] + m;
+                sq0[k + 1] = sq0[k] + (m ? c.seq_end[m - 1] : 0); nm0[k + 1] = nm0[k] + (m ? c.name_end[m - 1] : 0);
+                cm0[k + 1] = cm0[k] + ((with_c && m) ? c.comment_end[m - 1] : 0); ql0[k + 1] = ql0[k] + ((with_q && m) ? c.qual_end[m - 1] : 0);
+            }
+            o.comment = s->k_com.ensure(cm0[np] + 1); o.qual = s->k_qual.ensure(ql0[np] + 1);
+            if (!o.comment || !o.qual) return CRASS_ERR_OOM;
+            std::vector<uint32_t> pmax(np, 0);
+            auto piece = [&](size_t k) {
+                const FxChunk &c = ch[k];
+                const uint64_t m = cnt[k];
+                if (!m) return;
+                memcpy(o.seq + sq0[k], c.seq.data(), c.seq_end[m - 1]);
+                memcpy(o.name + nm0[k], c.name.data(), c.name_end[m - 1]);
+                if (with_c && c.comment_end[m - 1]) memcpy(o.comment + cm0[k], c.comment.data(), c.comment_end[m - 1]);
+                if (with_q && c.qual_end[m - 1]) memcpy(o.qual + ql0[k], c.qual.data(), c.qual_end[m - 1]);
+                uint32_t mx = 0;
+                for (uint64_t i = 0; i < m; i++) {
+                    const uint64_t rr = r0[k] + i;
+                    o.seq_off[rr + 1] = sq0[k] + c.seq_end[i]; o.name_off[rr + 1] = nm0[k] + c.name_end[i];
+                    o.comment_off[rr + 1] = with_c ? cm0[k] + c.comment_end[i] : 0; o.qual_off[rr + 1] = with_q ? ql0[k] + c.qual_end[i] : 0;
+                    o.has_comment[rr] = with_c ? 1 : 0; o.has_qual[rr] = with_q ? 1 : 0;
+                    o.header_id[rr] = rr;
+                    mx = std::max<uint32_t>(mx, (uint32_t)(c.seq_end[i] - (i ? c.seq_end[i - 1] : 0)));
+                }
+                pmax[k] = mx;
+            };
+            {
+                std::vector<std::thread> th;
+                const unsigned nt = (unsigned)std::min<size_t>(np, std::min<unsigned>(hw_threads(), 32u));
+                std::atomic<size_t> next{0};
+                auto work = [&]() { for (;;) { const size_t k = next.fetch_add(1, std::memory_order_relaxed); if (k >= np) break; piece(k); } };
+                for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+                work();
+                for (auto &x : th) x.join();
+            }
+            for (size_t k = 0; k < np; k++) max_len = std::max(max_len, pmax[k]);
+            // the stream's stale buffers as the record-by-record walk would leave them: the last kept record's own strings
+            for (size_t k = np; k-- > 0;) {
+                if (!cnt[k]) continue;
+                const FxChunk &c = ch[k];
+                const uint64_t i = cnt[k] - 1;
+                if (with_c) { const uint64_t b0 = i ? c.comment_end[i - 1] : 0; s->stale_c.assign((const char *)c.comment.data() + b0, c.comment_end[i] - b0); s->any_c = true; }
+                if (with_q) { const uint64_t b0 = i ? c.qual_end[i - 1] : 0; s->stale_q.assign((const char *)c.qual.data() + b0, c.qual_end[i] - b0); s->any_q = true; }
+                break;
+            }
+            r = nrec;
+            assembled = true;
+        }
+    }
+    for (size_t k = 0; !assembled && k < n_keep_pieces && r < nrec; k++) {
         const FxChunk &c = ch[k];
         for (size_t i = 0; i < c.n_rec() && r < nrec; i++, r++) {
             const uint64_t s0 = i ? c.seq_end[i - 1] : 0, n0 = i ? c.name_end[i - 1] : 0;
@@ -1264,18 +1493,23 @@ int crass_fastx_stream_next(crass_fastx_stream *s, crass_fastx *out)
             o.header_id[r] = r;
         }
     }
+    const double tn0 = stream_now();
+    s->t_asm += tn0 - ta0;
     if (s->names && nrec) {
         // the names' hashes on every core, the table itself in read order (first occurrence wins)
         std::vector<Hash128> hs(nrec);
         parallel_ranges(nrec, std::min<unsigned>(hw_threads(), 32u), [&](uint64_t a, uint64_t b2, unsigned) {
             for (uint64_t q = a; q < b2; q++) hs[q] = name_hash128(o.name + o.name_off[q], (size_t)(o.name_off[q + 1] - o.name_off[q]));
         });
-        for (uint64_t q = 0; q < nrec; q++) o.header_id[q] = s->names->first_hashed(hs[q], s->index_base + s->n_done + q);
+        s->names->first_batch(hs.data(), nrec, s->index_base + s->n_done, o.header_id);
     }
-    o.comment = alloc8(com_bytes.size()); o.qual = alloc8(qual_bytes.size());
-    if (!o.comment || !o.qual) return CRASS_ERR_OOM;
-    if (!com_bytes.empty()) memcpy(o.comment, com_bytes.data(), com_bytes.size());
-    if (!qual_bytes.empty()) memcpy(o.qual, qual_bytes.data(), qual_bytes.size());
+    s->t_names += stream_now() - tn0;
+    if (!assembled) {
+        o.comment = s->k_com.ensure(com_bytes.size() + 1); o.qual = s->k_qual.ensure(qual_bytes.size() + 1);
+        if (!o.comment || !o.qual) return CRASS_ERR_OOM;
+        if (!com_bytes.empty()) memcpy(o.comment, com_bytes.data(), com_bytes.size());
+        if (!qual_bytes.empty()) memcpy(o.qual, qual_bytes.data(), qual_bytes.size());
+    }
     o.max_len = max_len;
     s->max_len = std::max(s->max_len, max_len);
     o.last_ret = s->eof ? ch.back().last_ret : 0;
@@ -1283,10 +1517,9 @@ int crass_fastx_stream_next(crass_fastx_stream *s, crass_fastx *out)
     s->n_done += nrec;
     // the carry: from the header of the record that was left for the next chunk
     if (drop_last) {
-        const size_t tail = s->buf.size() - consumed;
-        memmove(s->buf.data(), s->buf.data() + consumed, tail);
-        s->buf.resize(tail);
-        s->carry = tail;
+        std::vector<uint8_t> tail(data + consumed, data + n);      // (data may point into s->buf itself)
+        s->buf.swap(tail);
+        s->carry = s->buf.size();
     } else { s->buf.clear(); s->carry = 0; s->finished = true; }
     *out = o;
     return CRASS_OK;

@@ -480,3 +480,42 @@ def test_header_ids_many_threads(ca, tmp_path):
     assert ix.n_reads == n and ix.reads.header_id
     assert np.array_equal(_npv(ix.reads.header_id, n, np.uint64), ref_ids)
     ix.close()
+    # the streamed reader's table: 64 sub-tables, a chunk's names dealt to them in read order and every sub-table filled by one
+    # thread; chunks of ~2 MB (a batch per chunk) and one chunk for the whole file
+    for chunk in (2 << 20, 0):
+        recs, hid, last, chunks = ca.stream_fastx(str(p), chunk_bytes=chunk)
+        assert len(recs) == n and np.array_equal(np.array(hid, dtype=np.uint64), ref_ids)
+
+
+@pytest.mark.parametrize("kind", ["fa_plain", "fa_all_comments", "fq_plain", "fq_all_comments", "fa_comments_stop", "fq_multi"])
+@pytest.mark.parametrize("chunk", [4096, 100000, 0])
+def test_streaming_reader_block_assembly(ca, tmp_path, kind, chunk):
+    """the chunk assembly's block form (no record of the stream has a comment / quality, or every record has its own: four block
+    copies per piece, the pieces side by side) against the record-by-record walk (CRASS_STREAM_SERIAL_ASSEMBLE) and kseq;
+    a file whose comments stop half-way (later records inherit the last one: the walk) starts in the block form and leaves it"""
+    import random
+    rng = random.Random(23)
+    recs = []
+    for i in range(6000):
+        sq = "".join(rng.choice("ACGT") for _ in range(rng.randint(20, 200)))
+        com = " lane=%d x" % (i % 7) if kind in ("fa_all_comments", "fq_all_comments") or (kind == "fa_comments_stop" and i < 3000) else ""
+        if kind.startswith("fa"):
+            recs.append(">n%d%s\n%s\n" % (i, com, sq))
+        else:
+            q = "".join(rng.choice("IIIHG5#!~") for _ in sq)
+            body = "\n".join(sq[k:k + 70] for k in range(0, len(sq), 70)) if kind == "fq_multi" else sq
+            recs.append("@n%d%s\n%s\n+\n%s\n" % (i, com, body, q))
+    text = "".join(recs).encode()
+    plain, gz = _write_both(tmp_path, kind + ".txt", text)
+    ref = fastx.read_fastx(gz)
+    assert len(ref) == 6000
+    for path in (plain, gz):
+        got = ca.stream_fastx(path, chunk_bytes=chunk)
+        os.environ["CRASS_STREAM_SERIAL_ASSEMBLE"] = "1"
+        try:
+            walk = ca.stream_fastx(path, chunk_bytes=chunk)
+        finally:
+            os.environ.pop("CRASS_STREAM_SERIAL_ASSEMBLE", None)
+        assert got[0] == ref and walk[0] == ref
+        assert got[1] == walk[1] == list(range(6000))
+        assert got[2] == walk[2]
