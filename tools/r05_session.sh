@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-5 GPU evidence session (staged): r05_session.sh <tag> [stages]
-# stages: smoke,tests,bench,params,prof,long,e2e,sweep,hygiene,other,scale,pmc3,pmc4,pmc
+# stages: smoke,tests,bench,params,prof,long,e2e,sweep,hygiene,other,scale,lens,pmc3,pmc4,pmc
 # Every stage that gates the ones behind it is judged by its EXIT STATUS (a collection error, a timeout kill or a
 # crashed interpreter is not "no ' failed' line"); rocprofv3 runs of bench.py carry --e2e-reads 0 (no child process inside a profile).
 set -u
@@ -90,6 +90,11 @@ fi
 if has scale; then
   timeout 900 python tools/scaling_projection.py 100000000 2 4 8 > $out/scaling_projection.txt 2> $out/scaling_projection.err; tail -5 $out/scaling_projection.txt
   bash tools/tl_sp.sh $tag/tl8 8 > $out/timeline_sp8.txt 2>&1; tail -45 $out/timeline_sp8.txt
+fi
+if has lens; then
+  # ms per 1.5 Gbases against the read length: lane-per-read filter (<= 256 bases), position hints as the filter (257 .. 2 048), long-read path
+  bash tools/len_sweep.sh $tag/len_sweep > $out/len_sweep.txt 2>&1; cat $out/len_sweep.txt
+  LENS="300 500 1000" CRASS_NO_HINT_FILTER=1 bash tools/len_sweep.sh $tag/len_sweep_general > $out/len_sweep_general_filter.txt 2>&1; cat $out/len_sweep_general_filter.txt
 fi
 if has pmc3; then
   bash tools/pmc_round.sh $tag/pmc_c3 3 1000000 10000 > $out/pmc_c3_summary.txt 2>&1; tail -30 $out/pmc_c3_summary.txt
