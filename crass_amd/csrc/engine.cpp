@@ -680,6 +680,11 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     c->dr_stride = (p->highDRsize + 15u) & ~15u;
     { const hipError_t he = hipSetDevice(device);
       if (he != hipSuccess) { fprintf(stderr, "[crass_hip] hipSetDevice(%d): %s\n", device, hipGetErrorString(he)); delete c; return CRASS_ERR_NO_DEVICE; } }
+    if (const char *e = getenv("CRASS_WAIT")) {           // A/B: how a host thread waits for the device (spin | yield | block)
+        const unsigned f = !strcmp(e, "spin") ? hipDeviceScheduleSpin : !strcmp(e, "yield") ? hipDeviceScheduleYield : !strcmp(e, "block") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+        const hipError_t fe = hipSetDeviceFlags(f);
+        if (fe != hipSuccess) fprintf(stderr, "[crass_hip] hipSetDeviceFlags(%s): %s\n", e, hipGetErrorString(fe));
+    }
     if (getenv("CRASS_SURV_PROF")) {                    // diagnostics: phase cycles of the wave-per-read kernel (tools/longread_phases.py)
         void *pp = nullptr;
         if (hipMalloc(&pp, (192 + 2 * 16384) * 8) == hipSuccess && hipMemset(pp, 0, (192 + 2 * 16384) * 8) == hipSuccess) {

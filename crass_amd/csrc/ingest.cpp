@@ -330,6 +330,7 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
         // path below takes the record from the same position, as it does for wrapped lines, the last record and odd spacing)
         bool packed_in_place = false;
         size_t fast_len = 0;
+        const size_t words_base = o.words.size();       // (a record that turns out truncated takes its words back)
         if (o.pack && pos < n) {
             const uint8_t *p = data + pos;
             const void *nlp = memchr(p, '\n', n - pos);
@@ -373,17 +374,33 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
         const size_t qual_base = o.qual.size();
         if (c == '+') {
             const void *nl = pos < n ? memchr(data + pos, '\n', n - pos) : nullptr;
-            if (!nl) { o.seq.resize(seq_base); o.ended = true; o.last_ret = -2; o.next_start = n; return; }
+            if (!nl) { o.seq.resize(seq_base); o.words.resize(words_base); o.ended = true; o.last_ret = -2; o.next_start = n; return; }
             pos = (size_t)((const uint8_t *)nl - data) + 1;
             // `while ((c = ks_getc(ks)) != -1 && seq->qual.l < seq->seq.l)`: consumes one byte past the quality
             size_t ql = 0;
-            while (pos < n) {
+            // the common record: the quality string on ONE line, as long as the sequence, every byte in 33 .. 127 — checked eight
+            // bytes at a time and taken as a block (pack mode: not taken at all); the byte behind it is the one kseq's loop consumes
+            if (sq_len && pos + sq_len < n && data[pos + sq_len] == '\n') {
+                const uint8_t *q = data + pos;
+                const uint64_t H = 0x8080808080808080ull, L21 = 0x2121212121212121ull;
+                uint64_t bad = 0;
+                size_t i = 0;
+                for (; i + 8 <= sq_len; i += 8) { uint64_t x; memcpy(&x, q + i, 8); bad |= (~((x | H) - L21) | x) & H; }
+                for (; i < sq_len; i++) bad |= (uint64_t)(q[i] < 33 || q[i] > 127);
+                if (!bad) {
+                    if (!o.pack) o.qual.insert(o.qual.end(), q, q + sq_len);
+                    ql = sq_len;
+                    pos += sq_len + 1;
+                }
+            }
+            if (sq_len == 0 && pos < n) pos++;                           // (an empty sequence: the loop's one look still consumes a byte)
+            while (ql < sq_len && pos < n) {
                 const int ch = data[pos++];
-                if (!(ql < sq_len)) break;
                 if (ch >= 33 && ch <= 127) { o.qual.push_back((uint8_t)ch); ql++; }
+                if (!(ql < sq_len)) { if (pos < n) pos++; break; }       // (... and one byte past the quality)
             }
             last_char = 0;
-            if (ql != sq_len) { o.seq.resize(seq_base); o.qual.resize(qual_base); o.ended = true; o.last_ret = -2; o.next_start = n; return; }
+            if (ql != sq_len) { o.seq.resize(seq_base); o.qual.resize(qual_base); o.words.resize(words_base); o.ended = true; o.last_ret = -2; o.next_start = n; return; }
             own_q = true;
         }
         o.last_hdr = hdr;

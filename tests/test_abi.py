@@ -256,6 +256,25 @@ def _fastx_cases():
             q = "+" + q[1:]
         recs.append("@q%d%s\n%s\n+\n%s\n" % (i, " lane=%d" % (i % 4) if i % 2 else "", s, q))
     cases["fq"] = "".join(recs)
+    # c2. FASTQ odds and ends: an empty sequence, a quality string wrapped over lines, blanks inside one (skipped by kseq), bytes
+    # beyond 127 in one, a quality line longer than the sequence (the rest is skipped as the next record is looked for)
+    recs = []
+    for i in range(1200):
+        s = seq(rng.randint(10, 120))
+        q = "".join(rng.choice("IIIHG5#!~") for _ in s)
+        k = i % 12
+        if k == 3:
+            s, q = "", ""
+        elif k == 5 and len(q) > 20:
+            q = q[:7] + "\n" + q[7:15] + "\n" + q[15:]
+        elif k == 7 and len(q) > 4:
+            q = q[:3] + " " + q[3:]
+        elif k == 9:
+            q = q + "IIII"
+        elif k == 11 and len(q) > 4:
+            q = q[:2] + "\t" + q[2:]
+        recs.append("@e%d\n%s\n+\n%s\n" % (i, s, q))
+    cases["fq_edge"] = "".join(recs)
     # d. the same, truncated inside the last quality line
     cases["fq_trunc"] = cases["fq"][:-40]
     # e. '>' inside a sequence line (ends the record there in kseq): the pieces cannot line up, one-piece parse
@@ -266,7 +285,7 @@ def _fastx_cases():
     return {k: v.encode() for k, v in cases.items()}
 
 
-@pytest.mark.parametrize("case", ["fa_single", "fa_multi", "fq", "fq_trunc", "fa_odd", "fa_crlf", "fa_noeol"])
+@pytest.mark.parametrize("case", ["fa_single", "fa_multi", "fq", "fq_edge", "fq_trunc", "fa_odd", "fa_crlf", "fa_noeol"])
 @pytest.mark.parametrize("chunk", ["256", "5000", "serial"])
 def test_parallel_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
     """the block-parallel reader against the byte-at-a-time kseq reference, with pieces far smaller than in
@@ -294,7 +313,7 @@ def test_parallel_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
     assert len(ref) > 1000
 
 
-@pytest.mark.parametrize("case", ["fa_single", "fa_multi", "fq", "fq_trunc", "fa_odd", "fa_crlf", "fa_noeol"])
+@pytest.mark.parametrize("case", ["fa_single", "fa_multi", "fq", "fq_edge", "fq_trunc", "fa_odd", "fa_crlf", "fa_noeol"])
 @pytest.mark.parametrize("chunk", [300, 4096, 65536, 0])
 def test_streaming_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
     """the chunked reader (crass_fastx_stream_*, bounded host memory) against the byte-at-a-time kseq reference: chunks from far
@@ -340,7 +359,7 @@ def _packed_layout(ca, seqs):
     return dict(stride=stride, uniform_len=uni, words=per, lengths=lengths, exceptions=exc)
 
 
-@pytest.mark.parametrize("case", ["fa_multi", "fq", "fq_trunc", "fa_odd_nocomment", "fa_crlf_nocomment", "fa_noeol", "fa_uniform", "fa_trimmed"])
+@pytest.mark.parametrize("case", ["fa_multi", "fq", "fq_edge", "fq_trunc", "fa_odd_nocomment", "fa_crlf_nocomment", "fa_noeol", "fa_uniform", "fa_trimmed"])
 @pytest.mark.parametrize("chunk", ["256", "5000", "serial"])
 def test_indexed_fastx_reader_is_the_whole_file_reader(ca, tmp_path, case, chunk):
     """crass_index_fastx (the input kept mapped, reads packed at once, text on request) against the whole-file reader + crass_pack_reads

@@ -19,6 +19,12 @@ if stages:
 marks = np.zeros(K + 1)
 parts = np.zeros((K, 3))
 dev = []
+def _cpu_stat():
+    try:
+        return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat"))}
+    except Exception:
+        return {}
+cs0 = _cpu_stat()
 cpu0 = time.process_time()
 marks[0] = time.perf_counter()
 for i in range(K):
@@ -28,6 +34,8 @@ for i in range(K):
     if stages:
         c = eng.counters()
         dev.append((c["ms_pass1_total"], c["ms_merge_device"], c["ms_pass2_total"]))
+cs1 = _cpu_stat()
+print("cgroup cpu.stat over the loop:", {k: cs1[k] - cs0.get(k, 0) for k in cs1 if k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec")})
 print("CPUs kept busy by this process during the loop: %.1f" % ((time.process_time() - cpu0) / (marks[-1] - marks[0])))
 d = np.diff(marks) * 1e3
 med = float(np.median(d))
