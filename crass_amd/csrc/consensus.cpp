@@ -99,7 +99,7 @@ struct crass_cons {
     std::vector<Rec> rec;
     std::vector<char> hseq;                       // host mirror of the records' RH_Seq; a record's characters follow the device copy
                                                   // only when somebody reads them (rseq: extendSlaveDR's ties)
-    HBuf<uint32_t> h_stage; HBuf<int> h_cov; HBuf<int32_t> h_ksw; size_t n_pre = 0;      // pinned: a group's flips + placements going up, its coverage coming down
+    HBuf<uint32_t> h_stage; HBuf<int> h_cov; HBuf<int32_t> h_ksw; HBuf<uint8_t> h_ksw_in; size_t n_pre = 0;      // pinned: a group's flips + placements going up, its coverage coming down
     DBuf<uint32_t> d_stage;
     double t_place = 0, t_flip = 0, t_sync = 0, t_cons = 0, t_ksw = 0, t_split = 0, t_fa = 0, t_fb = 0, t_fc = 0, t_fd = 0, t_pre = 0;      // CRASS_TIMING: where the group loop's time goes
     std::vector<std::string> tok;                 // token t = tok[t - 2]
@@ -229,28 +229,39 @@ int ksw_batch(crass_cons *s, const std::vector<std::string> &strs, const std::ve
 {
     res.assign(strs.size(), {0, -1, -1, 0, -1, -1});
     if (strs.empty()) return CRASS_OK;
-    std::vector<uint8_t> codes, tcodes;
-    std::vector<uint32_t> off(strs.size()), len(strs.size()), toff(masters.size()), tlen(masters.size());
+    // the batch's seven small arrays go up from ONE pinned staging buffer that belongs to the batch's owner: the copies are queued,
+    // not waited for (defer), and what they read must outlive this function (function-local pageable vectors only worked because
+    // the runtime's copy from pageable memory happens to block the host)
+    size_t n_codes = 0, n_tcodes = 0;
     uint32_t max_q = 1;
-    for (size_t v = 0; v < strs.size(); v++) {
-        off[v] = (uint32_t)codes.size(); len[v] = (uint32_t)strs[v].size(); max_q = std::max(max_q, len[v]);
-        for (char ch : strs[v]) codes.push_back(nt4(ch));
+    for (const std::string &q : strs) { n_codes += q.size(); max_q = std::max(max_q, (uint32_t)q.size()); }
+    for (const std::string &m : masters) n_tcodes += m.size();
+    auto up4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
+    const size_t nq = strs.size(), nm = masters.size();
+    const size_t o_codes = 0, o_off = up4(std::max<size_t>(n_codes, 1)), o_len = o_off + nq * 4, o_tgt = o_len + nq * 4, o_tcodes = o_tgt + nq * 4,
+                 o_toff = o_tcodes + up4(std::max<size_t>(n_tcodes, 1)), o_tlen = o_toff + nm * 4, total = o_tlen + nm * 4;
+    if (total + 8 > s->h_ksw_in.n) HCHK(s, hipStreamSynchronize(s->st));       // (growing frees the old buffer: nothing may still read it)
+    HCHK(s, s->h_ksw_in.ensure(total + 8));
+    uint8_t *hb = s->h_ksw_in.p;
+    uint8_t *codes = hb + o_codes, *tcodes = hb + o_tcodes;
+    uint32_t *off = reinterpret_cast<uint32_t *>(hb + o_off), *len = reinterpret_cast<uint32_t *>(hb + o_len), *tg = reinterpret_cast<uint32_t *>(hb + o_tgt),
+             *toff = reinterpret_cast<uint32_t *>(hb + o_toff), *tlen = reinterpret_cast<uint32_t *>(hb + o_tlen);
+    codes[0] = 0; tcodes[0] = 0;
+    {
+        size_t at = 0;
+        for (size_t v = 0; v < nq; v++) { off[v] = (uint32_t)at; len[v] = (uint32_t)strs[v].size(); tg[v] = tgt[v]; for (char ch : strs[v]) codes[at++] = nt4(ch); }
+        at = 0;
+        for (size_t m = 0; m < nm; m++) { toff[m] = (uint32_t)at; tlen[m] = (uint32_t)masters[m].size(); for (char ch : masters[m]) tcodes[at++] = nt4(ch); }
     }
-    for (size_t m = 0; m < masters.size(); m++) {
-        toff[m] = (uint32_t)tcodes.size(); tlen[m] = (uint32_t)masters[m].size();
-        for (char ch : masters[m]) tcodes.push_back(nt4(ch));
-    }
-    if (codes.empty()) codes.push_back(0);
-    if (tcodes.empty()) tcodes.push_back(0);
-    HCHK(s, s->d_qcodes.ensure(codes.size())); HCHK(s, s->d_qoff.ensure(off.size())); HCHK(s, s->d_qlen.ensure(len.size())); HCHK(s, s->d_qtgt.ensure(tgt.size()));
-    HCHK(s, s->d_target.ensure(tcodes.size())); HCHK(s, s->d_toff.ensure(toff.size())); HCHK(s, s->d_tlen.ensure(tlen.size())); HCHK(s, s->d_ksw_out.ensure(strs.size() * 6));
-    HCHK(s, hipMemcpyAsync(s->d_qcodes.p, codes.data(), codes.size(), hipMemcpyHostToDevice, s->st));
-    HCHK(s, hipMemcpyAsync(s->d_qoff.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, s->st));
-    HCHK(s, hipMemcpyAsync(s->d_qlen.p, len.data(), len.size() * 4, hipMemcpyHostToDevice, s->st));
-    HCHK(s, hipMemcpyAsync(s->d_qtgt.p, tgt.data(), tgt.size() * 4, hipMemcpyHostToDevice, s->st));
-    HCHK(s, hipMemcpyAsync(s->d_target.p, tcodes.data(), tcodes.size(), hipMemcpyHostToDevice, s->st));
-    HCHK(s, hipMemcpyAsync(s->d_toff.p, toff.data(), toff.size() * 4, hipMemcpyHostToDevice, s->st));
-    HCHK(s, hipMemcpyAsync(s->d_tlen.p, tlen.data(), tlen.size() * 4, hipMemcpyHostToDevice, s->st));
+    HCHK(s, s->d_qcodes.ensure(std::max<size_t>(n_codes, 1))); HCHK(s, s->d_qoff.ensure(nq)); HCHK(s, s->d_qlen.ensure(nq)); HCHK(s, s->d_qtgt.ensure(nq));
+    HCHK(s, s->d_target.ensure(std::max<size_t>(n_tcodes, 1))); HCHK(s, s->d_toff.ensure(nm)); HCHK(s, s->d_tlen.ensure(nm)); HCHK(s, s->d_ksw_out.ensure(nq * 6));
+    HCHK(s, hipMemcpyAsync(s->d_qcodes.p, codes, std::max<size_t>(n_codes, 1), hipMemcpyHostToDevice, s->st));
+    HCHK(s, hipMemcpyAsync(s->d_qoff.p, off, nq * 4, hipMemcpyHostToDevice, s->st));
+    HCHK(s, hipMemcpyAsync(s->d_qlen.p, len, nq * 4, hipMemcpyHostToDevice, s->st));
+    HCHK(s, hipMemcpyAsync(s->d_qtgt.p, tg, nq * 4, hipMemcpyHostToDevice, s->st));
+    HCHK(s, hipMemcpyAsync(s->d_target.p, tcodes, std::max<size_t>(n_tcodes, 1), hipMemcpyHostToDevice, s->st));
+    HCHK(s, hipMemcpyAsync(s->d_toff.p, toff, nm * 4, hipMemcpyHostToDevice, s->st));
+    HCHK(s, hipMemcpyAsync(s->d_tlen.p, tlen, nm * 4, hipMemcpyHostToDevice, s->st));
     HCHK(s, launch_cons_ksw(s->d_qcodes.p, s->d_qoff.p, s->d_qlen.p, s->d_qtgt.p, (uint32_t)strs.size(), max_q, s->d_target.p, s->d_toff.p, s->d_tlen.p, s->ksw,
                             s->d_ksw_out.p, s->st));
     s->cnt.n_ksw_alignments += 2 * strs.size(); s->cnt.n_ksw_launches++;
@@ -557,26 +568,9 @@ int parse_grouped_drs(crass_cons *s, int GID)
     // repeats for the coverage array — in one pass over a flat list, so that the records can be requested ahead of their turn)
     struct Item { const std::vector<int> *l; int cur_len, off; bool flip; };
     std::vector<Item> items;
-    for (size_t v = 0; v < strs.size() && !s->error; v++) {
-        int tok = g[slave_pos[v]];
-        al.off[tok] = -1;
-        if (flags[v] & F_FAILED) continue;
-        bool flip = false;
-        if (flags[v] & F_REVERSED) {
-            if (!rlist(s, tok)) { s->error = 4; break; }
-            flip = true;
-            const int st = add_string(s, reverse_complement(strs[v]));
-            s->reads_of[st - 2] = std::move(s->reads_of[tok - 2]);
-            g[slave_pos[v]] = st;
-            tok = st;
-        }
-        al.off[tok] = al.off[master] + offs[v];
-        const std::vector<int> *l = rlist(s, tok);
-        if (!l) { s->error = 4; break; }                 // (place_reads' check)
-        items.push_back(Item{l, (int)tstr(s, tok).size(), al.off[tok], flip});
-    }
-    s->t_fa += now_sec() - tq;
-    if (!s->error && !items.empty()) {
+    // the reads of the slaves queued so far (run once behind the loop — or before a move below destroys a list that is queued)
+    auto run_items = [&]() {
+        if (s->error || items.empty()) { items.clear(); return; }
         double tb = now_sec();
         struct Ent { int k, cur_len, off; bool flip; };
         std::vector<Ent> ents;
@@ -607,7 +601,31 @@ int parse_grouped_drs(crass_cons *s, int GID)
         s->t_fc += now_sec() - tb; tb = now_sec();
         for (const Ent &e : ents) if (e.flip) al.flips.push_back((uint32_t)e.k);
         s->t_fd += now_sec() - tb;
+        items.clear();
+    };
+    for (size_t v = 0; v < strs.size() && !s->error; v++) {
+        int tok = g[slave_pos[v]];
+        al.off[tok] = -1;
+        if (flags[v] & F_FAILED) continue;
+        bool flip = false;
+        if (flags[v] & F_REVERSED) {
+            if (!rlist(s, tok)) { s->error = 4; break; }
+            flip = true;
+            const int st = add_string(s, reverse_complement(strs[v]));
+            // (the reverse complement may BE a token that already has a list — a group holding X and rc(X) — and that list may be
+            // queued above: its reads are placed first, as the reference's slave-by-slave order has it, before the move frees it)
+            if (s->reads_of[st - 2]) run_items();
+            s->reads_of[st - 2] = std::move(s->reads_of[tok - 2]);
+            g[slave_pos[v]] = st;
+            tok = st;
+        }
+        al.off[tok] = al.off[master] + offs[v];
+        const std::vector<int> *l = rlist(s, tok);
+        if (!l) { s->error = 4; break; }                 // (place_reads' check)
+        items.push_back(Item{l, (int)tstr(s, tok).size(), al.off[tok], flip});
     }
+    s->t_fa += now_sec() - tq;
+    run_items();
     if (s->error) return 0;
     for (size_t q = 0; q < g.size();) {          // "kill the unfounded ones"
         const int tok = g[q];
