@@ -330,6 +330,7 @@ struct crass_hip_ctx {
     hipEvent_t ev_hint[kHintParts] = {nullptr, nullptr, nullptr, nullptr}, ev_hint_go = nullptr;
     int hint_parts = 1;                         // slices of this read set (1: one launch on the main stream)
     bool hint_filter = false;                   // the hint bits are this set's seed-scan filter (no lane-per-read filter for its layout)
+    bool hint_filter_any = false;               // ... in their every-position form (another window or seed lattice): computed for the filter, not kept
     uint64_t hint_read_split[kHintParts + 1] = {0, 0, 0, 0, 0}, hint_word_split[kHintParts + 1] = {0, 0, 0, 0, 0};
     DevBuf<uint16_t> g_dr_len; DevBuf<uint64_t> hl_dx_idx;      // host-loop sink: dense DR lengths, scratch of the device de-duplication
     bool hint_pending = false;                  // slices are in flight on hint_stream: the main stream has not waited for them yet
@@ -839,18 +840,25 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     // the hint bits are their filter, crass_hip_seed_scan; CRASS_NO_HINT_FILTER: the A/B switch, back to k_filter_general)
     const bool lane_filter = c->R.stride_words >= 4 && c->R.stride_words <= 16;
     c->hint_filter = c->max_len <= c->env.long_min && !lane_filter && !c->env.no_hint_filter;
-    if ((c->max_len <= c->env.long_min && !c->hint_filter) || n == 0 || P.window != 8 || P.skips != 8 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 ||
-        P.highDR + P.highSp < P.lowDR + P.lowSp) return CRASS_OK;
+    c->hint_filter_any = false;
+    const bool shifts_ok = P.lowDR + P.lowSp >= 17 && P.highDR + P.highSp <= 127 && P.highDR + P.highSp >= P.lowDR + P.lowSp;
+    const bool lattice_hints = P.window == 8 && P.skips == 8 && shifts_ok;
+    // (... under another window or seed lattice those sets get the every-position form of the bits as their filter, nothing kept:
+    // launch_hint_filter_any; the tiles' read index is all that is set up for it)
+    const bool any_filter = c->hint_filter && !lattice_hints && shifts_ok && P.window >= 6 && P.window <= 9 && P.skips >= 1;
+    if ((c->max_len <= c->env.long_min && !c->hint_filter) || n == 0 || !(lattice_hints || any_filter)) return CRASS_OK;
     if (c->env.no_pos_hints) return CRASS_OK;             // A/B switch
     std::vector<uint64_t> off(n + 1);
     uint64_t at = 0;
     for (uint64_t i = 0; i < n; i++) { off[i] = at; at += ((uint64_t)(lengths ? lengths[i] : uniform_len) + 63) / 64; }
     off[n] = at;
-    HIPCHK(c, c->d_pos_hint_off.ensure(n + 1)); HIPCHK(c, c->d_pos_hint.ensure(at + 1));
+    HIPCHK(c, c->d_pos_hint_off.ensure(n + 1));
+    if (lattice_hints) HIPCHK(c, c->d_pos_hint.ensure(at + 1));
     HIPCHK(c, hipMemcpy(c->d_pos_hint_off.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
     c->n_pos_hint_words = at;
-    c->R.pos_hint = c->d_pos_hint.p; c->R.pos_hint_off = c->d_pos_hint_off.p;
-    c->R.wave_walk = c->max_len > std::min<uint32_t>(c->env.long_min, c->env.wave_walk_min) ? 1u : 0u;
+    c->hint_filter_any = any_filter;
+    if (lattice_hints) { c->R.pos_hint = c->d_pos_hint.p; c->R.pos_hint_off = c->d_pos_hint_off.p; }
+    if (lattice_hints) c->R.wave_walk = c->max_len > std::min<uint32_t>(c->env.long_min, c->env.wave_walk_min) ? 1u : 0u;
     c->pos_hint_blk = false;
     // slices: read boundaries n i / K; slice i covers the hint words [roundup256(off[r_i]), roundup256(off[r_i+1])), so every word
     // of a read below r_i+1 belongs to a slice <= i (CRASS_HINT_PARTS=1: the A/B switch)
@@ -1770,6 +1778,13 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
                                                         c->d_pos_hint.p, c->stream, 0, c->n_pos_hint_words, c->d_mask.p);
             if (he != hipSuccess) { c->last_hip = (int)he; return CRASS_ERR_HIP; }
             c->hint_pending = false;
+            hint_filtered = true;
+        }
+        else if (fe == hipErrorNotSupported && c->hint_filter_any && c->n_pos_hint_words) {
+            HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, n_words * 8, c->stream));
+            const hipError_t he = launch_hint_filter_any(c->R, c->dp, c->d_pos_hint_off.p, c->pos_hint_blk ? c->d_pos_hint_blk.p : nullptr, c->n_pos_hint_words,
+                                                         c->d_mask.p, c->stream);
+            if (he != hipSuccess) { c->last_hip = (int)he; return CRASS_ERR_HIP; }
             hint_filtered = true;
         }
         else if (fe == hipErrorNotSupported) { HIPCHK(c, launch_filter_general(c->R, c->dp, c->d_mask.p, c->max_len, c->stream)); }

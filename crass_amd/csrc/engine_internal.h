@@ -286,6 +286,9 @@ hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const ui
                                  uint64_t *hint_bits, hipStream_t st,       // blk_read[b] = read of tile 256 b (ragged lengths; else nullptr)
                                  uint64_t w_begin = 0, uint64_t w_end = ~0ull,       // the hint words [w_begin, w_end) only; w_begin a multiple of 256
                                  uint64_t *hitmask = nullptr);      // ... and the bits as the seed-scan filter (cleared by the caller): bit r = read r has a hint bit
+// ... the same under another window or seed lattice: every position's bit computed on the spot, nothing kept (window 6 .. 9, shifts 17 .. 127)
+hipError_t launch_hint_filter_any(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
+                                  uint64_t *hitmask, hipStream_t st);
 // long reads with position hints, an identity survivor list and no exception read: the walk of the reads without an array; a read
 // that needs the full searchCore leaves with err == 7 for launch_survivor(..., punt_only = 7)
 hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,

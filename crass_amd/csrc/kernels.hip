@@ -586,17 +586,12 @@ static __device__ __forceinline__ uint64_t hint_bits_any(const uint32_t (&w)[13]
 // from where — its read's walk moves there (wave_hints_class).  A superset like the short-read filter (padding bases and the
 // right clamp are ignored).  Default window / bounds only.
 // ------------------------------------------------------------------------------------
-template <bool RANGE>
-__global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t t0, uint64_t n_words, uint64_t *hint_bits,
-                                                        int D0, int D1, uint64_t *hitmask, uint32_t exc_survive)
+// the read a hint tile (64 positions) belongs to and the tile's number inside it: largest r with hint_off[r] <= t
+static __device__ __forceinline__ void hint_tile_read(const DevReads &R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t t, uint64_t n_words,
+                                                      uint64_t &r, uint32_t &tile)
 {
-    // (t0: a multiple of 256 — the launch covers the hint words [t0, n_words), see launch_hint_positions)
-    const uint64_t t = t0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (t >= n_words) return;
-    // read of this tile: largest r with hint_off[r] <= t.  Reads of one length: a division (the search is 20 dependent
+    // Reads of one length: a division (the search is 20 dependent
     // loads for 1 M reads — about three times the wave's 3.8 us of arithmetic, which six waves per SIMD only just cover)
-    uint64_t r;
-    uint32_t tile;
     if (R.uniform_len) {
         const uint32_t per_read = (R.uniform_len + 63u) >> 6;
         if ((n_words >> 32) == 0) {                                     // (a 32-bit division: a fifth of the 64-bit one's instructions)
@@ -622,6 +617,18 @@ __global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64
         r = lo;
         tile = (uint32_t)(t - hint_off[r]);
     }
+}
+
+template <bool RANGE>
+__global__ __launch_bounds__(256) void k_hint_positions(DevReads R, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t t0, uint64_t n_words, uint64_t *hint_bits,
+                                                        int D0, int D1, uint64_t *hitmask, uint32_t exc_survive)
+{
+    // (t0: a multiple of 256 — the launch covers the hint words [t0, n_words), see launch_hint_positions)
+    const uint64_t t = t0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n_words) return;
+    uint64_t r;
+    uint32_t tile;
+    hint_tile_read(R, hint_off, blk_read, t, n_words, r, tile);
     const uint32_t L = rd_len(R, r);
     const uint32_t nw = (L + 15) >> 4;
     const uint32_t *g = R.packed + rd_word_off(R, r) + tile * 4u;
@@ -2459,6 +2466,54 @@ static __device__ __forceinline__ uint64_t hint_bits_every(const uint32_t (&w)[1
     };
     const uint32_t lo = even16(~nz[0]) | (even16(~nz[1]) << 16), hi = even16(~nz[2]) | (even16(~nz[3]) << 16);
     return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+
+// The seed-scan FILTER of reads of 257 .. 2 048 bases (and of sets whose strides differ) under another window or seed lattice
+// (-w, -d): no position hints are kept for those (the walks' hint forms know the default lattice), so a tile's bits are computed,
+// cut to the lattice positions j = i * skips <= searchEnd, and only the read's bit in the (cleared) filter mask is set.  A superset
+// like every filter here; 11 instructions per word and shift for every position — four times the lattice-class kernel, a fifth of
+// k_filter_general, which these sets took until now.
+__global__ __launch_bounds__(256) void k_hint_filter_any(DevReads R, DevParams P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
+                                                         uint64_t *hitmask)
+{
+    const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= n_words) return;
+    uint64_t r;
+    uint32_t tile;
+    hint_tile_read(R, hint_off, blk_read, t, n_words, r, tile);
+    const uint32_t L = rd_len(R, r);
+    const int D0 = (int)(P.lowDR + P.lowSp), D1 = (int)(P.highDR + P.highSp);
+    const int last = (int)L - D0 - (int)P.window - 1 - (int)(tile * 64u);        // searchEnd, counted from this tile's first position
+    if (last < 0) return;
+    const uint32_t nw = (L + 15) >> 4;
+    const uint32_t *g = R.packed + rd_word_off(R, r) + tile * 4u;
+    const uint32_t rem = nw - tile * 4u;
+    uint32_t w[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) w[i] = (uint32_t)i < rem ? g[i] : 0u;
+    uint64_t bits = hint_bits_every(w, (int)P.window, D0, D1);
+    if (last < 63) bits &= (2ull << last) - 1ull;
+    // the lattice: positions that are multiples of skips
+    const uint32_t skips = P.skips;
+    if (skips > 1) {
+        const uint64_t p0 = (uint64_t)tile * 64u;
+        uint32_t b = (uint32_t)((skips - (uint32_t)(p0 % skips)) % skips);
+        uint64_t m = 0;
+        for (; b < 64u; b += skips) m |= 1ull << b;
+        bits &= m;
+    }
+    if (bits && (P.exc_survive || !rd_is_exc(R, r))) atomicOr(reinterpret_cast<unsigned long long *>(hitmask) + (r >> 6), 1ull << (r & 63u));
+}
+
+hipError_t launch_hint_filter_any(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
+                                  uint64_t *hitmask, hipStream_t st)
+{
+    if (P.window < 6 || P.window > 9 || P.skips < 1 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 || P.highDR + P.highSp < P.lowDR + P.lowSp) return hipErrorNotSupported;
+    if (!n_words) return hipSuccess;
+    const uint64_t nb = (n_words + 255) / 256;
+    if (nb > 0x7FFFFFFFull) return hipErrorNotSupported;
+    CRASS_LAUNCH(k_hint_filter_any, dim3((unsigned)nb), dim3(256), 0, st, R, P, hint_off, blk_read, n_words, hitmask);
+    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(WAVE) void k_long_light_any(DevReads R, DevParams P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,

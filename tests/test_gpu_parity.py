@@ -411,8 +411,9 @@ def test_mid_length_reads_take_the_hint_filter(ca, lo, hi):
 
 def test_mid_length_reads_with_exception_reads_and_other_options(ca):
     """the hint filter with reads that hold bytes outside ACGT (screened on their packed words, evaluated byte-wise) and with a
-    shift range other than the default (-s / -S: the run-time-range hint kernel); a window other than 8 has no position hints and
-    stays on the general filter"""
+    shift range other than the default (-s / -S: the run-time-range hint kernel); another window or seed lattice (-w, -d) has no
+    position hints to walk on but the same bits in their every-position form as its filter (k_hint_filter_any); a shift beyond
+    127 bases is outside both forms' tile: the general filter"""
     rng = np.random.default_rng(99)
     seqs = _mid_reads(rng, 6000, 280, 900)
     for i in range(0, len(seqs), 37):
@@ -423,7 +424,9 @@ def test_mid_length_reads_with_exception_reads_and_other_options(ca):
     gpu = ca.search_pipeline(seqs)
     assert_same_pipeline(gpu, orc.pipeline(seqs))
     assert gpu.counters["used_fast_filter"] == 2 and gpu.n_pass1 >= 50
-    for kw, want in ((dict(lowSpacerSize=20, highSpacerSize=60), 2), (dict(lowDRsize=20, highDRsize=40), 0), (dict(searchWindowLength=7), 0)):
+    for kw, want in ((dict(lowSpacerSize=20, highSpacerSize=60), 2), (dict(lowDRsize=20, highDRsize=40), 2), (dict(searchWindowLength=7), 2),
+                     (dict(searchWindowLength=6), 2), (dict(searchWindowLength=9, minNumRepeats=4), 2), (dict(lowDRsize=15, highDRsize=30), 2),
+                     (dict(lowSpacerSize=8, highSpacerSize=30, lowDRsize=15), 2), (dict(highDRsize=64, highSpacerSize=70), 0)):
         prm = ca.default_params(**kw)
         gpu = ca.search_pipeline(seqs, params=prm)
         assert_same_pipeline(gpu, orc.pipeline(seqs, params=to_orc_params(prm)))
