@@ -187,6 +187,7 @@ SYMBOLS = {
     "crass_hip_consensus_free": (None, [C.c_void_p]),
     "crass_fastx_find": (C.c_uint64, [C.POINTER(Fastx), C.c_char_p, C.c_uint64]),
     "crass_index_fastx": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "crass_index_fastx_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p)]),
     "crass_fastx_index_reads": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "crass_fastx_index_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Fastx)]),
     "crass_fastx_index_free": (None, [C.c_void_p]),

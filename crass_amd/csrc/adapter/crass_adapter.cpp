@@ -610,21 +610,27 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         else m.rc = crass_hip_create(&p, devs[0], &m.c);
         return m;
     });
-    // One plain-text input: the INDEXED reader (crass_index_fastx) — the file stays mapped, every read is packed as its piece is
-    // parsed and its text dropped, the records that are handed on are parsed again when the hand-off asks for them.  40 + 12 bytes
-    // of host memory per 150 bp read and no second pass over the input.  CRASS_INGEST=index|whole|stream forces a reader (index:
-    // an input it does not take is an error then); default: index for one plain-text input, else whole / stream by memory.
+    // The INDEXED reader (crass_index_fastx_files) — every input stays mapped (a gzip'd one: inflated once), every read is packed as
+    // its piece is parsed and its text dropped, the records that are handed on are parsed again when the hand-off asks for them.
+    // 40 + 12 bytes of host memory per 150 bp read and no second pass over the inputs; several inputs (paired-end files) are one read
+    // set in (file, read) order with header ids across them.  CRASS_INGEST=index|whole|stream forces a reader (index: an input it
+    // does not take is an error then); default: the index, and for what it does not take stream / whole (want_streamed_ingest).
     struct Index { crass_fastx_index *ix = nullptr; ~Index() { crass_fastx_index_free(ix); } } IX;
     bool indexed = false;
     {
         const char *e = getenv("CRASS_INGEST");
         const bool force = e && !strcmp(e, "index");
-        if ((force || !e) && seqFiles.size() == 1) {
-            const int rc = crass_index_fastx(seqFiles[0].c_str(), &IX.ix);
-            if (rc == CRASS_ERR_IO) CRASS_THROW(std::string("Could not open FASTQ ") + seqFiles[0] + " for reading.");
+        if ((force || !e) && !seqFiles.empty()) {
+            std::vector<const char *> paths;
+            for (const std::string &f : seqFiles) paths.push_back(f.c_str());
+            const int rc = crass_index_fastx_files(paths.data(), (uint32_t)paths.size(), &IX.ix);
+            if (rc == CRASS_ERR_IO) {
+                for (const std::string &f : seqFiles) if (access(f.c_str(), R_OK) != 0) CRASS_THROW(std::string("Could not open FASTQ ") + f + " for reading.");
+                CRASS_THROW(std::string("Could not open FASTQ ") + seqFiles[0] + " for reading.");
+            }
             if (rc == CRASS_OK) indexed = true;
-            else if (rc != CRASS_ERR_UNSUPPORTED || force) chk(rc, "crass_index_fastx");
-        } else if (force) CRASS_THROW("CRASS_INGEST=index takes one input file");
+            else if (rc != CRASS_ERR_UNSUPPORTED || force) chk(rc, "crass_index_fastx_files");
+        }
     }
     const bool streamed = !indexed && want_streamed_ingest(seqFiles);
     JobFiles J;

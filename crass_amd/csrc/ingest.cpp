@@ -783,7 +783,22 @@ uint64_t crass_fastx_find(const crass_fastx *f, const char *name, uint64_t len)
 // the same state machine, when they are asked for.  gzip'd inputs and files that mix records with and without a comment /
 // quality line (kseq's stale-buffer semantics need the records in order) are left to the two readers above: CRASS_ERR_UNSUPPORTED.
 struct crass_fastx_index {
-    void *map = nullptr; size_t map_n = 0;
+    // the text: per input a mapped file or, for a gzip'd input, its inflated image.  A record's header position is kept as a position
+    // in the inputs' concatenation (base = the bytes of the inputs before it)
+    struct File {
+        void *map = nullptr; size_t n = 0; uint8_t *own = nullptr;     // own: the inflated image (then map points at it)
+        uint64_t base = 0;
+        bool any_c = false, any_q = false;
+        int last_ret = -1;
+    };
+    std::vector<File> files;
+    const File &file_of(uint64_t pos) const
+    {
+        size_t f = files.size() - 1;
+        while (f > 0 && files[f].base > pos) f--;
+        return files[f];
+    }
+    const uint8_t *text(uint64_t pos) const { const File &f = file_of(pos); return (const uint8_t *)f.map + (pos - f.base); }
     RawBuf<uint64_t> hdr_pos;                          // [n]
     RawBuf<uint32_t> packed; RawBuf<uint64_t> word_off; RawBuf<uint32_t> lengths;
     PackedOwner pk;                                    // (the exception lists)
@@ -791,58 +806,103 @@ struct crass_fastx_index {
     crass_reads reads{};
     uint32_t max_len = 0;
     int last_ret = -1;
-    bool any_c = false, any_q = false;
     std::thread reaper;                                // frees the parsers' pieces beside whatever the caller does next
-    ~crass_fastx_index() { if (reaper.joinable()) reaper.join(); if (map && map_n) { drop_pages(map, map_n); munmap(map, map_n); } }
+    ~crass_fastx_index()
+    {
+        if (reaper.joinable()) reaper.join();
+        for (File &f : files) {
+            if (f.own) { drop_pages(f.own, f.n); free(f.own); }
+            else if (f.map && f.n) { drop_pages(f.map, f.n); munmap(f.map, f.n); }
+        }
+    }
 };
 
 extern "C" {
 
-int crass_index_fastx(const char *path, crass_fastx_index **out)
+int crass_index_fastx(const char *path, crass_fastx_index **out) { return crass_index_fastx_files(&path, 1, out); }
+
+int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fastx_index **out)
 {
-    if (!path || !out) return CRASS_ERR_INVALID_ARG;
+    if (!paths || !n_paths || !out) return CRASS_ERR_INVALID_ARG;
+    for (uint32_t f = 0; f < n_paths; f++) if (!paths[f]) return CRASS_ERR_INVALID_ARG;
     *out = nullptr;
     const bool timing = getenv("CRASS_TIMING") != nullptr;
     auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now_s();
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) return CRASS_ERR_IO;
-    struct stat st;
-    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return CRASS_ERR_UNSUPPORTED; }
-    const size_t n = (size_t)st.st_size;
-    unsigned char magic[2] = {0, 0};
-    if (n >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { close(fd); return CRASS_ERR_UNSUPPORTED; }
     std::unique_ptr<crass_fastx_index> ix(new (std::nothrow) crass_fastx_index());
-    if (!ix) { close(fd); return CRASS_ERR_OOM; }
-    if (n) {
-        // (no MAP_POPULATE: one thread filling 2 M page-table entries was 0.25 s for 8 GB; the 64 piece parsers take the
-        // faults of their own pieces)
-        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) { close(fd); return CRASS_ERR_UNSUPPORTED; }
-        (void)madvise(m, n, MADV_WILLNEED);
-        ix->map = m; ix->map_n = n;
+    if (!ix) return CRASS_ERR_OOM;
+    ix->files.resize(n_paths);
+    size_t n = 0;                                        // bytes of text, all inputs
+    for (uint32_t f = 0; f < n_paths; f++) {
+        crass_fastx_index::File &F = ix->files[f];
+        F.base = n;
+        const int fd = open(paths[f], O_RDONLY);
+        if (fd < 0) return CRASS_ERR_IO;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return CRASS_ERR_UNSUPPORTED; }
+        const size_t fn = (size_t)st.st_size;
+        unsigned char magic[2] = {0, 0};
+        const bool gz = fn >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (gz) {
+            // a gzip'd input: its inflated image takes the mapping's place (libdeflate, whole buffer; without the library the
+            // whole-file reader's zlib path takes the input).  1 x the text + the packed reads instead of the whole-file reader's
+            // ~3.6 x, and none of its assemble / pack passes
+            // (only if the text — about four times the file — fits half of what this host has available: the bounded readers otherwise)
+            uint64_t avail = 0;
+            if (FILE *fp = fopen("/proc/meminfo", "r")) {
+                char line[256];
+                while (fgets(line, sizeof(line), fp)) if (!strncmp(line, "MemAvailable:", 13)) { avail = (uint64_t)atoll(line + 13) << 10; break; }
+                fclose(fp);
+            }
+            close(fd);
+            if (avail && (uint64_t)fn * 4 > avail / 2) return CRASS_ERR_UNSUPPORTED;
+            InflatedBuf inflated;
+            if (!inflate_with_libdeflate(paths[f], inflated)) return CRASS_ERR_UNSUPPORTED;
+            F.own = inflated.p; F.map = inflated.p; F.n = inflated.n;
+            inflated.p = nullptr;
+        } else {
+            if (fn) {
+                // (no MAP_POPULATE: one thread filling 2 M page-table entries was 0.25 s for 8 GB; the 64 piece parsers take the
+                // faults of their own pieces)
+                void *m = mmap(nullptr, fn, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) { close(fd); return CRASS_ERR_UNSUPPORTED; }
+                (void)madvise(m, fn, MADV_WILLNEED);
+                F.map = m; F.n = fn;
+            }
+            close(fd);
+        }
+        n += F.n;
     }
-    close(fd);
-    const uint8_t *d = (const uint8_t *)ix->map;
     const double t1 = now_s();
+    // every input parsed in pieces (pack mode: every record is packed as it is parsed, its text dropped); the pieces of all inputs in
+    // (input, position) order are the job's reads in (file, read) order
     std::vector<FxChunk> ch;
-    parse_pieces(d, n, ch, 8u << 20, true);             // (pack mode: every record is packed as it is parsed, its text dropped)
+    std::vector<uint32_t> piece_file;
+    for (uint32_t f = 0; f < n_paths; f++) {
+        crass_fastx_index::File &F = ix->files[f];
+        std::vector<FxChunk> cf;
+        parse_pieces((const uint8_t *)F.map, F.n, cf, 8u << 20, true);
+        bool any_c = false, all_c = true, any_q = false, all_q = true;
+        for (FxChunk &c : cf) {                         // (the pieces kept their own comment / quality flags)
+            const uint8_t fl = c.pk_flags;
+            if (c.n_rec()) { any_c |= (fl & 1) != 0; any_q |= (fl & 2) != 0; all_c &= (fl & 4) != 0; all_q &= (fl & 8) != 0; }
+        }
+        if ((any_c && !all_c) || (any_q && !all_q)) return CRASS_ERR_UNSUPPORTED;      // stale comment / quality buffers: ordered readers
+        F.any_c = any_c; F.any_q = any_q; F.last_ret = cf.empty() ? -1 : cf.back().last_ret;
+        for (FxChunk &c : cf) { ch.emplace_back(std::move(c)); piece_file.push_back(f); }
+    }
     const double t2 = now_s();
     const size_t nc = ch.size();
     std::vector<uint64_t> rec0(nc + 1, 0), tight0(nc + 1, 0);
-    bool any_c = false, all_c = true, any_q = false, all_q = true;
     uint32_t max_len = 0, min_len = 0xFFFFFFFFu;
-    for (size_t k = 0; k < nc; k++) {                    // (the pieces kept their own minimum length and comment / quality flags)
+    for (size_t k = 0; k < nc; k++) {                    // (the pieces kept their own minimum length)
         rec0[k + 1] = rec0[k] + ch[k].n_rec(); tight0[k + 1] = tight0[k] + ch[k].words.size();
         max_len = std::max(max_len, ch[k].max_len); min_len = std::min(min_len, ch[k].pk_min_len);
-        const uint8_t f = ch[k].pk_flags;
-        if (ch[k].n_rec()) { any_c |= (f & 1) != 0; any_q |= (f & 2) != 0; all_c &= (f & 4) != 0; all_q &= (f & 8) != 0; }
     }
-    if ((any_c && !all_c) || (any_q && !all_q)) return CRASS_ERR_UNSUPPORTED;      // stale comment / quality buffers: ordered readers
     if (max_len > CRASS_HIP_MAX_READ_LEN) return CRASS_ERR_UNSUPPORTED;
     const uint64_t nrec = rec0[nc];
     if (nrec == 0) min_len = 0;
-    ix->any_c = any_c; ix->any_q = any_q; ix->max_len = max_len; ix->last_ret = ch.empty() ? -1 : ch.back().last_ret;
+    ix->max_len = max_len; ix->last_ret = ix->files.back().last_ret;
     // ---- layout: crass_pack_reads' rules (mode 2); the pieces' words are then copied into place ----
     const bool uniform_len = nrec > 0 && max_len == min_len;
     const uint64_t padded = nrec * (uint64_t)((max_len + 15) / 16);
@@ -863,7 +923,9 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
             FxChunk &c = ch[k];
             const size_t m = c.n_rec();
             if (m) {
-                memcpy(ix->hdr_pos.data() + rec0[k], c.hdr_pos.data(), m * 8);
+                const uint64_t fb = ix->files[piece_file[k]].base;
+                uint64_t *hp = ix->hdr_pos.data() + rec0[k];
+                for (size_t i = 0; i < m; i++) hp[i] = fb + c.hdr_pos[i];
                 memcpy(nh.data() + rec0[k], c.name_h.data(), m * 8);
             }
             uint64_t wat = 0;
@@ -960,7 +1022,7 @@ int crass_index_fastx(const char *path, crass_fastx_index **out)
             for (auto &x : th) x.join();
         }
         auto same_name = [&](uint64_t x, uint64_t y) {
-            return name_len[x] == name_len[y] && memcmp(d + ix->hdr_pos[x] + 1, d + ix->hdr_pos[y] + 1, name_len[x]) == 0;
+            return name_len[x] == name_len[y] && memcmp(ix->text(ix->hdr_pos[x]) + 1, ix->text(ix->hdr_pos[y]) + 1, name_len[x]) == 0;
         };
         std::atomic<unsigned> next_shard{0};
         std::atomic<int> dup{0};
@@ -1042,7 +1104,6 @@ int crass_fastx_index_fetch(const crass_fastx_index *ix, const uint64_t *idx, ui
 {
     if (!ix || !out || (n && !idx)) return CRASS_ERR_INVALID_ARG;
     memset(out, 0, sizeof(*out));
-    const uint8_t *d = (const uint8_t *)ix->map;
     const uint64_t nrec = ix->reads.n_reads;
     for (uint64_t k = 0; k < n; k++) if (idx[k] >= nrec) return CRASS_ERR_INVALID_ARG;
     const unsigned nt = (unsigned)std::min<uint64_t>(std::min<unsigned>(hw_threads(), 32u), std::max<uint64_t>(1, n / 2048));
@@ -1052,7 +1113,9 @@ int crass_fastx_index_fetch(const crass_fastx_index *ix, const uint64_t *idx, ui
         const uint64_t a = std::min<uint64_t>(n, t * per), b = std::min<uint64_t>(n, a + per);
         for (uint64_t k = a; k < b; k++) {
             const uint64_t h = ix->hdr_pos[idx[k]];
-            parse_range(d, ix->map_n, (size_t)h, (size_t)h + 1, false, parts[t]);      // exactly the record whose header character is at h
+            const crass_fastx_index::File &F = ix->file_of(h);
+            const size_t lh = (size_t)(h - F.base);
+            parse_range((const uint8_t *)F.map, F.n, lh, lh + 1, false, parts[t]);      // exactly the record whose header character is at h
         }
     };
     {
@@ -1084,7 +1147,7 @@ int crass_fastx_index_fetch(const crass_fastx_index *ix, const uint64_t *idx, ui
         for (size_t i = 0; i < c.n_rec(); i++, r++) {
             out->seq_off[r + 1] = sq + c.seq_end[i]; out->name_off[r + 1] = nm + c.name_end[i];
             out->comment_off[r + 1] = cm + c.comment_end[i]; out->qual_off[r + 1] = ql + c.qual_end[i];
-            out->has_comment[r] = ix->any_c ? 1 : 0; out->has_qual[r] = ix->any_q ? 1 : 0;
+            { const crass_fastx_index::File &F = ix->file_of(ix->hdr_pos[idx[r]]); out->has_comment[r] = F.any_c ? 1 : 0; out->has_qual[r] = F.any_q ? 1 : 0; }
             out->header_id[r] = idx[r];
         }
         sq += c.seq.size(); nm += c.name.size(); cm += c.comment.size(); ql += c.qual.size();

@@ -139,13 +139,18 @@ class FastxFile:
 
 
 class FastxIndex:
-    """crass_index_fastx: a plain-text input kept mapped, its reads 2-bit packed at once, the records' text parsed on request.
-    Raises CrassError(status 2, unsupported) for gzip'd inputs and files that mix records with / without comment or quality."""
+    """crass_index_fastx(_files): the input(s) kept mapped (plain text) or inflated once (gzip), the reads 2-bit packed at once, the
+    records' text parsed on request; a list of paths = one read set in (file, read) order with header ids across the files.
+    Raises CrassError(status 2, unsupported) for files that mix records with / without comment or quality."""
 
     def __init__(self, path):
         self.lib = _abi.load()
         h = C.c_void_p()
-        _chk(self.lib.crass_index_fastx(str(path).encode(), C.byref(h)), "crass_index_fastx(%s)" % path)
+        if isinstance(path, (list, tuple)):
+            arr = (C.c_char_p * len(path))(*[str(p).encode() for p in path])
+            _chk(self.lib.crass_index_fastx_files(arr, len(path), C.byref(h)), "crass_index_fastx_files(%s)" % (path,))
+        else:
+            _chk(self.lib.crass_index_fastx(str(path).encode(), C.byref(h)), "crass_index_fastx(%s)" % path)
         self.h = h
         self.reads = _abi.Reads()
         ml, lr = C.c_uint32(), C.c_int()

@@ -479,17 +479,23 @@ void crass_free_fastx(crass_fastx *f);
 /* index of the FIRST read with this header name (the key of readsFound, libcrispr.cpp:138,411), UINT64_MAX if none */
 uint64_t crass_fastx_find(const crass_fastx *f, const char *name, uint64_t len);
 
-/* The same reader as an INDEX over a plain-text input kept mapped: the records are parsed by the same state machine, every read is
+/* The same reader as an INDEX over an input kept mapped (plain text) or inflated once (gzip, through libdeflate when the runtime
+ * library is there): the records are parsed by the same state machine, every read is
  * 2-bit packed at once (crass_pack_reads' layout rules, mode 2) and its text dropped; what stays is the packed reads, the
  * position of every record's header character, and header_id (first read with the same header, names compared in the mapping:
  * exact).  crass_fastx_index_fetch parses the records that are handed on (the ~1 % that pass 1 / pass 2 find) when they are
  * asked for.  replaces: the getFileHandle / kseq_read loops of searchFile + findSingletons (libcrispr.cpp:84-131, 471-487) and
  * the ReadHolder fields they fill (seq, header, comment, quality) for the reads that reach addReadHolder.  Host memory: 40 bytes
- * of words + 12 of bookkeeping per 150 bp read instead of ~330.  CRASS_ERR_UNSUPPORTED: a gzip'd input, a file that mixes
+ * of words + 12 of bookkeeping per 150 bp read instead of ~330.  CRASS_ERR_UNSUPPORTED: a gzip'd input without libdeflate or whose text would not fit half the available memory, a file that mixes
  * records with and without a comment / quality line (kseq's stale buffers, libcrispr.cpp:124-131, need the records in order), a
  * file that cannot be mapped — the two readers around this one take those.                                                      */
 typedef struct crass_fastx_index crass_fastx_index;
 int  crass_index_fastx(const char *path, crass_fastx_index **out);
+/* ... over SEVERAL inputs (paired-end files, lanes): the job's reads in (file, read) order in one packed set, header ids across the
+ * inputs (the first read of the JOB with the same header: readsFound is keyed by the header string whatever file it came from,
+ * libcrispr.cpp:138,411), every input plain text or gzip'd on its own.  max_len / last_ret of crass_fastx_index_reads: the longest
+ * read of all inputs, kseq_read's final return value on the LAST one.                                                              */
+int  crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fastx_index **out);
 /* the packed reads (host pointers owned by the index), the longest read, kseq_read's final return value */
 int  crass_fastx_index_reads(const crass_fastx_index *ix, crass_reads *reads, uint32_t *max_len, int *last_ret);
 /* records idx[0 .. n) (any order) as a crass_fastx of n records in that order; header_id[k] = idx[k]; free with crass_free_fastx */

@@ -396,10 +396,19 @@ def test_indexed_fastx_reader_is_the_whole_file_reader(ca, tmp_path, case, chunk
     else:
         os.environ["CRASS_FASTX_CHUNK"] = chunk
     try:
-        with pytest.raises(ca.CrassError):
-            ca.FastxIndex(gz)                                       # gzip'd: the other readers' job
         ix = ca.FastxIndex(plain)
+        try:
+            C.CDLL("libdeflate.so.0")
+            ixz = ca.FastxIndex(gz)                                 # gzip'd: the same index over the inflated image (libdeflate)
+        except OSError:
+            ixz = None                                              # (no libdeflate on this host: refused, as below)
         whole = ca.FastxFile(plain)
+        os.environ["CRASS_NO_LIBDEFLATE"] = "1"
+        try:
+            with pytest.raises(ca.CrassError):
+                ca.FastxIndex(gz)                                   # ... without the library: the other readers' job
+        finally:
+            os.environ.pop("CRASS_NO_LIBDEFLATE", None)
     finally:
         os.environ.pop("CRASS_FASTX_CHUNK", None)
         os.environ.pop("CRASS_FASTX_SERIAL", None)
@@ -416,11 +425,59 @@ def test_indexed_fastx_reader_is_the_whole_file_reader(ca, tmp_path, case, chunk
     assert ix.fetch(pick) == [ref[i] for i in pick]
     assert ix.fetch([]) == []
     ix.close()
+    if ixz is not None:
+        layz = ixz.layout()
+        assert ixz.n_reads == len(ref) and ixz.max_len == whole.max_len and ixz.last_ret == whole.last_ret
+        assert all(layz[k] == lay[k] for k in ("stride", "uniform_len", "lengths", "exceptions", "header_id"))
+        assert all(np.array_equal(a, b) for a, b in zip(layz["words"], lay["words"]))
+        assert ixz.fetch(pick) == [ref[i] for i in pick]
+        ixz.close()
     assert len(ref) > 1000
     if case == "fa_trimmed":
         assert lay["stride"] == 10 and lay["uniform_len"] == 0 and len(lay["exceptions"]) >= 30
     if case == "fa_uniform":
         assert lay["stride"] == 10 and lay["uniform_len"] == 150 and lay["header_id"][1900] == 0
+
+
+def test_indexed_reader_over_several_inputs(ca, tmp_path):
+    """crass_index_fastx_files: paired-end style inputs — one read set in (file, read) order, header ids across the files (mates
+    that share a name; readsFound is keyed by the header string whatever file it came from, libcrispr.cpp:138,411), a FASTQ next to
+    a gzip'd FASTA next to a multi-line FASTA, fetch across the files; against the whole-file reader file by file"""
+    import random
+    rng = random.Random(31)
+    def sq(n):
+        return "".join(rng.choice("ACGTN" if rng.random() < 0.03 else "ACGT") for _ in range(n))
+    t1 = "".join("@p%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in ((i, sq(rng.randint(40, 150))) for i in range(1500)))
+    t2 = "".join(">p%d\n%s\n" % (i if i % 3 else 5000 + i, sq(rng.randint(40, 150))) for i in range(1500))        # two thirds share file 1's names
+    s3 = [sq(rng.randint(100, 400)) for _ in range(700)]
+    t3 = "".join(">m%d desc\n%s\n" % (i % 650, "\n".join(s[k:k + 60] for k in range(0, len(s), 60))) for i, s in enumerate(s3))
+    p1, g1 = _write_both(tmp_path, "a.fq", t1.encode())
+    _, p2 = _write_both(tmp_path, "b.fa", t2.encode())
+    p3, g3 = _write_both(tmp_path, "c.fa", t3.encode())
+    os.environ["CRASS_FASTX_CHUNK"] = "3000"
+    try:
+        ix = ca.FastxIndex([p1, p2, p3])
+    finally:
+        os.environ.pop("CRASS_FASTX_CHUNK", None)
+    ref = fastx.read_fastx(g1) + fastx.read_fastx(p2) + fastx.read_fastx(g3)
+    assert ix.n_reads == len(ref) == 3700
+    first = {}
+    ref_ids = [first.setdefault(r[0], i) for i, r in enumerate(ref)]
+    lay = ix.layout()
+    want = _packed_layout(ca, [r[2] for r in ref])
+    assert lay["stride"] == want["stride"] and lay["uniform_len"] == want["uniform_len"] and lay["lengths"] == want["lengths"]
+    assert lay["exceptions"] == want["exceptions"] and lay["header_id"] == ref_ids and sum(1 for i, h in enumerate(ref_ids) if h != i) > 900
+    for i in range(len(ref)):
+        if i not in want["exceptions"]:
+            assert np.array_equal(lay["words"][i], want["words"][i]), i
+    pick = list(range(0, len(ref), 11)) + [len(ref) - 1, 0, 1499, 1500, 2999, 3000]
+    assert ix.fetch(pick) == [ref[i] for i in pick]
+    ix.close()
+    # one input among them that the index does not take (comments on some records only): the whole job is refused
+    mixed, _ = _write_both(tmp_path, "mixed.fa", _fastx_cases()["fa_single"])
+    with pytest.raises(ca.CrassError) as e:
+        ca.FastxIndex([p1, mixed])
+    assert e.value.status == 2
 
 
 def test_indexed_reader_refuses_mixed_comments(ca, tmp_path):

@@ -257,7 +257,7 @@ def test_streamed_and_whole_ingest_write_the_same_files(cli, tmp_path):
         assert a == b, f
 
 
-@pytest.mark.parametrize("kind", ["fastq_all_comments", "fasta_plain", "fasta_multiline"])
+@pytest.mark.parametrize("kind", ["fastq_all_comments", "fasta_plain", "fasta_multiline", "fasta_gz", "fastq_gz", "fasta_two_files"])
 def test_indexed_ingest_writes_the_same_files(cli, tmp_path, kind):
     """the indexed reader (crass_index_fastx: the input stays mapped, reads packed as their piece is parsed, the handed-on records'
     text parsed on request) against whole-file and streamed ingest through the complete command line: byte-identical output
@@ -278,14 +278,27 @@ def test_indexed_ingest_writes_the_same_files(cli, tmp_path, kind):
         if i % 501 == 0:
             s = s[:40] + b"N" + s[41:]
         name = b"r%d" % (i if i % 97 else i // 2)
-        if kind == "fastq_all_comments":
+        if kind in ("fastq_all_comments", "fastq_gz"):
             lines.append(b"@" + name + (b" c%d" % i) + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
-        elif kind == "fasta_plain":
+        elif kind in ("fasta_plain", "fasta_gz", "fasta_two_files"):
             lines.append(b">" + name + b"\n" + s + b"\n")
         else:
             lines.append(b">" + name + b"\n" + b"\n".join(s[k:k + 60] for k in range(0, len(s), 60)) + b"\n")
-    fx = tmp_path / ("s.fq" if kind.startswith("fastq") else "s.fa")
-    fx.write_bytes(b"".join(lines))
+    fx = tmp_path / (("s.fq" if kind.startswith("fastq") else "s.fa") + (".gz" if kind.endswith("_gz") else ""))
+    inputs = [str(fx)]
+    if kind == "fasta_two_files":                                # (paired-end style: one read set in (file, read) order, names shared across the files)
+        import gzip
+        fx2 = tmp_path / "s2.fa.gz"
+        fx.write_bytes(b"".join(lines[:n // 2]))
+        with gzip.open(fx2, "wb", compresslevel=1) as fh:
+            fh.write(b"".join(lines[n // 2:]))
+        inputs = [str(fx), str(fx2)]
+    elif kind.endswith("_gz"):                                   # (gzip'd: the index is built over the inflated image)
+        import gzip
+        with gzip.open(fx, "wb", compresslevel=1) as fh:
+            fh.write(b"".join(lines))
+    else:
+        fx.write_bytes(b"".join(lines))
     outs, errs = {}, {}
     for mode, env in (("whole", {"CRASS_INGEST": "whole"}), ("stream", {"CRASS_INGEST": "stream", "CRASS_INGEST_CHUNK_BYTES": "40000"}),
                       ("index", {"CRASS_INGEST": "index", "CRASS_FASTX_CHUNK": "20000"}), ("auto", {"CRASS_TIMING": "1"})):
@@ -294,7 +307,7 @@ def test_indexed_ingest_writes_the_same_files(cli, tmp_path, kind):
         e = dict(os.environ, **env)
         if mode == "auto":
             e.pop("CRASS_INGEST", None)
-        r = subprocess.run([cli, "-g", "--timestamp", "01_01_2026_000000", "-o", str(d), str(fx)], capture_output=True, timeout=600, env=e)
+        r = subprocess.run([cli, "-g", "--timestamp", "01_01_2026_000000", "-o", str(d)] + inputs, capture_output=True, timeout=600, env=e)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs[mode] = {f: open(d / f, "rb").read() for f in sorted(os.listdir(d))}
         errs[mode] = r.stderr.decode()
