@@ -133,7 +133,7 @@ int crass_pack_reads(const uint8_t *seqs, const uint64_t *off, uint64_t n, int p
         min_len = std::min<uint32_t>(min_len, (uint32_t)l);
     }
     if (n == 0) min_len = 0;
-    const bool uniform_len = (n > 0 && max_len == min_len);
+    const bool uniform_len = (n > 0 && max_len == min_len && max_len > 0);       // (uniform_len == 0 says "lengths differ": a set of empty reads keeps its lengths array)
     uint32_t stride = 0;
     if (pad_uniform == 2) {
         // auto: short reads of differing lengths (trimmed Illumina data) are padded to one stride when that costs at
@@ -913,7 +913,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
     if (nrec == 0) min_len = 0;
     ix->max_len = max_len; ix->last_ret = ix->files.back().last_ret;
     // ---- layout: crass_pack_reads' rules (mode 2); the pieces' words are then copied into place ----
-    const bool uniform_len = nrec > 0 && max_len == min_len;
+    const bool uniform_len = nrec > 0 && max_len == min_len && max_len > 0;       // (uniform_len == 0 says "lengths differ": a set of empty reads keeps its lengths array)
     const uint64_t padded = nrec * (uint64_t)((max_len + 15) / 16);
     const bool pad = max_len <= 256 && max_len >= 64 && padded <= 2 * tight0[nc];
     const uint32_t stride = (uniform_len || pad) ? std::max<uint32_t>(1, (max_len + 15) / 16) : 0;

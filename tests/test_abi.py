@@ -480,6 +480,76 @@ def test_indexed_reader_over_several_inputs(ca, tmp_path):
     assert e.value.status == 2
 
 
+def test_readers_on_random_record_soup(ca, tmp_path):
+    """300 small random FASTA / FASTQ-like texts — wrapped and unwrapped lines, blank lines, CRLF, lower case and N, '>' '+' '@' in odd
+    places, comments on some / all / no headers, quality strings wrapped, too short, too long, a truncated tail — through the
+    whole-file reader, the streamed reader (tiny chunks) and, where it takes the file, the index (tiny pieces; its records packed in
+    place or through the general path): all == the byte-at-a-time kseq reference"""
+    import random
+    rng = random.Random(20251003)
+    n_index = n_refused = 0
+    for case in range(300):
+        fq = rng.random() < 0.5
+        com_mode = rng.choice(["none", "all", "some"])
+        eol = "\r\n" if rng.random() < 0.15 else "\n"
+        wrap = rng.choice([0, 0, 7, 60])
+        nasty = rng.random() < 0.25                              # ('>' '+' '@' inside sequence lines end a record there: mostly files the index refuses)
+        parts = []
+        for i in range(rng.randint(1, 40)):
+            L = rng.choice([0, 1, 5, 16, 17, 31, 64, rng.randint(1, 200)])
+            alpha = rng.choice(["ACGT", "ACGT", "ACGT", "ACGTN", "acgtACGT", "ACGT>", "ACGT+", "ACGT@", "ACG T"] if nasty else ["ACGT", "ACGT", "ACGT", "ACGTN", "acgtACGT", "ACG T"])
+            s = "".join(rng.choice(alpha) for _ in range(L))
+            body = eol.join(s[k:k + wrap] for k in range(0, len(s), wrap)) if wrap and s else s
+            com = " c%d x" % i if com_mode == "all" or (com_mode == "some" and rng.random() < 0.5) else ""
+            if rng.random() < 0.1:
+                body += eol                                         # a blank line behind the sequence
+            if fq:
+                ql = len(s.replace(" ", "")) + (rng.choice([0, 0, 0, 0, -1, 2]) if nasty else 0)
+                q = "".join(rng.choice("IIIH5#!~@+>") for _ in range(max(0, ql)))
+                if rng.random() < 0.2 and len(q) > 6:
+                    q = q[:5] + eol + q[5:]
+                parts.append("@r%d%s%s%s%s+%s%s%s" % (i, com, eol, body, eol, eol, q, eol))
+            else:
+                parts.append(">r%d%s%s%s%s" % (i % 13 if rng.random() < 0.3 else i, com, eol, body, eol))
+        text = "".join(parts)
+        if rng.random() < 0.2:
+            text = text[:max(1, len(text) - rng.randint(1, 30))]
+        if rng.random() < 0.1:
+            text = "junk before the first record" + eol + text
+        plain, gz = _write_both(tmp_path, "soup%d.txt" % case, text.encode())
+        ref = fastx.read_fastx(gz)
+        first = {}
+        ref_ids = [first.setdefault(r[0], i) for i, r in enumerate(ref)]
+        os.environ["CRASS_FASTX_CHUNK"] = str(rng.choice([64, 200, 1000]))
+        try:
+            whole = ca.FastxFile(plain)
+            assert whole.records() == ref, (case, text)
+            assert whole.header_id.tolist() == ref_ids, case
+            recs, hid, last, _ = ca.stream_fastx(plain, chunk_bytes=rng.choice([256, 300, 1000, 0]))
+            assert recs == ref and hid == ref_ids and last == whole.last_ret, (case, text)
+            try:
+                ix = ca.FastxIndex(plain)
+            except ca.CrassError as e:
+                assert e.status == 2, case                           # mixed comments / qualities: the ordered readers' file
+                n_refused += 1
+                continue
+        finally:
+            os.environ.pop("CRASS_FASTX_CHUNK", None)
+        n_index += 1
+        assert ix.n_reads == len(ref) and ix.last_ret == whole.last_ret, (case, text)
+        lay = ix.layout()
+        want = _packed_layout(ca, [r[2] for r in ref]) if ref else None
+        if ref:
+            assert lay["lengths"] == want["lengths"] and lay["exceptions"] == want["exceptions"] and lay["header_id"] == ref_ids, (case, text)
+            assert lay["stride"] == want["stride"] and lay["uniform_len"] == want["uniform_len"], (case, text)
+            for i in range(len(ref)):
+                if i not in want["exceptions"]:
+                    assert np.array_equal(lay["words"][i], want["words"][i]), (case, i, text)
+            assert ix.fetch(list(range(len(ref)))) == ref, (case, text)
+        ix.close()
+    assert n_index >= 120 and n_refused >= 20, (n_index, n_refused)
+
+
 def test_indexed_reader_refuses_mixed_comments(ca, tmp_path):
     """kseq's stale comment / quality buffers (libcrispr.cpp:124-131) make a record's fields depend on the records before it: a
     file that mixes records with and without a comment is left to the ordered readers"""
