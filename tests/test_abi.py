@@ -550,6 +550,64 @@ def test_readers_on_random_record_soup(ca, tmp_path):
     assert n_index >= 120 and n_refused >= 20, (n_index, n_refused)
 
 
+def _write_bgzf(path, data, block=60000, eof_block=True):
+    """BGZF as bgzip writes it (SAM spec 4.1): gzip members of <= 64 KB with the 'BC' extra field holding the member's size - 1"""
+    import struct, zlib
+    with open(path, "wb") as f:
+        chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof_block else [])
+        for c in chunks:
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            d = co.compress(c) + co.flush()
+            bsize = 12 + 6 + len(d) + 8 - 1
+            assert bsize < 65536
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + d +
+                    struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c) & 0xFFFFFFFF))
+
+
+def test_bgzf_inputs_are_inflated_member_by_member(ca, tmp_path):
+    """a BGZF input (bgzip; the .fastq.gz of Illumina's converters): its members' sizes are read from their headers and trailers and the
+    members inflated side by side — the same records as through the serial path (CRASS_NO_BGZF), zlib (CRASS_NO_LIBDEFLATE) and the
+    reference reader; a damaged member and a member without the size field fall back to the serial path and its verdict"""
+    import random
+    rng = random.Random(3)
+    recs = []
+    for i in range(60000):
+        s = "".join(rng.choice("ACGT") for _ in range(rng.randint(80, 150)))
+        recs.append("@b%d\n%s\n+\n%s\n" % (i, s, "".join(rng.choice("IH5#") for _ in s)))
+    text = "".join(recs).encode()
+    bg = str(tmp_path / "reads.fq.gz")
+    _write_bgzf(bg, text, block=rng.choice([30000, 60000, 65000]))
+    assert os.path.getsize(bg) > 70 * 20000                  # (more than 64 members: the side-by-side path)
+    ref = fastx.read_fastx(bg)
+    assert len(ref) == 60000
+    got = {}
+    for env in ({}, {"CRASS_NO_BGZF": "1"}, {"CRASS_NO_LIBDEFLATE": "1"}):
+        os.environ.update(env)
+        try:
+            f = ca.FastxFile(bg)
+            got[tuple(env)] = f.records()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert got[tuple(env)] == ref
+    ix = ca.FastxIndex(bg)
+    assert ix.n_reads == 60000 and ix.fetch([0, 59999, 31234]) == [ref[0], ref[59999], ref[31234]]
+    ix.close()
+    # a member whose deflate data is damaged: the side-by-side path gives up, the serial path reports what zlib / gzip report
+    raw = bytearray(open(bg, "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    bad = tmp_path / "bad.fq.gz"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(ca.CrassError):
+        ca.FastxFile(str(bad))
+    # plain gzip in front of BGZF members (cat a.gz b.bgzf): not BGZF from the start, the serial path reads both
+    import gzip
+    mixed = tmp_path / "mixed.fq.gz"
+    head = "".join(recs[:500]).encode()
+    mixed.write_bytes(gzip.compress(head) + open(bg, "rb").read())
+    assert ca.FastxFile(str(mixed)).records() == fastx.read_fastx(str(mixed))
+
+
 def test_indexed_reader_refuses_mixed_comments(ca, tmp_path):
     """kseq's stale comment / quality buffers (libcrispr.cpp:124-131) make a record's fields depend on the records before it: a
     file that mixes records with and without a comment is left to the ordered readers"""

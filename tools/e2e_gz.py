@@ -26,8 +26,24 @@ try:
                 f1.write(b)
     subprocess.check_call("gzip -1 -c %s > %s" % (fa, gz), shell=True)
     subprocess.check_call("tail -c +%d %s | gzip -1 -c > %s" % (os.path.getsize(h1) + 1, fa, h2), shell=True)
+    # the same text as BGZF (bgzip's format; what Illumina's converters write): members of <= 64 KB that carry their own sizes
+    import struct, zlib
+    from concurrent.futures import ThreadPoolExecutor
+    bg = os.path.join(td, "all.bgzf.fa.gz")
+    def member(c):
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        d = co.compress(c) + co.flush()
+        return b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 12 + 6 + len(d) + 8 - 1) + d + struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c))
+    with open(fa, "rb") as f, open(bg, "wb") as g, ThreadPoolExecutor(16) as ex:
+        while True:
+            blob = f.read(64 << 20)
+            if not blob:
+                break
+            for m in ex.map(member, [blob[i:i + 60000] for i in range(0, len(blob), 60000)]):
+                g.write(m)
+        g.write(member(b""))
     cli = os.path.join(os.path.dirname(os.path.abspath(ca.__file__)), "crass-hip")
-    for label, inputs, modes in (("one gzip'd input", [gz], ("auto", "whole", "stream")), ("two inputs (plain + gzip'd)", [h1, h2], ("auto", "whole", "stream")),
+    for label, inputs, modes in (("one gzip'd input", [gz], ("auto", "whole", "stream")), ("one BGZF input", [bg], ("auto", "whole")), ("two inputs (plain + gzip'd)", [h1, h2], ("auto", "whole", "stream")),
                                  ("the same reads, one plain input", [fa], ("auto",))):
         for mode in modes:
             env = dict(os.environ, CRASS_TIMING="1")
