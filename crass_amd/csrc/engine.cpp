@@ -832,7 +832,7 @@ static int alloc_scratch(crass_hip_ctx *c)
 static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t uniform_len, uint64_t n)
 {
     c->n_pos_hint_words = 0;
-    c->R.pos_hint = nullptr; c->R.pos_hint_off = nullptr; c->R.wave_walk = 0;
+    c->R.pos_hint = nullptr; c->R.pos_hint_off = nullptr; c->R.wave_walk = 0; c->R.hint_all = 0;
     const DevParams &P = c->dp;
     // (skips == 8: the hints are kept per residue class mod 8 — k_hint_positions fills the lattice class, the walking wave the others)
     // (... and any shift range the hint tile's halo covers: -s / -S / -D keep the hints, launch_hint_positions)
@@ -852,13 +852,13 @@ static int setup_pos_hints(crass_hip_ctx *c, const uint32_t *lengths, uint32_t u
     uint64_t at = 0;
     for (uint64_t i = 0; i < n; i++) { off[i] = at; at += ((uint64_t)(lengths ? lengths[i] : uniform_len) + 63) / 64; }
     off[n] = at;
-    HIPCHK(c, c->d_pos_hint_off.ensure(n + 1));
-    if (lattice_hints) HIPCHK(c, c->d_pos_hint.ensure(at + 1));
+    HIPCHK(c, c->d_pos_hint_off.ensure(n + 1)); HIPCHK(c, c->d_pos_hint.ensure(at + 1));
     HIPCHK(c, hipMemcpy(c->d_pos_hint_off.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice));
     c->n_pos_hint_words = at;
     c->hint_filter_any = any_filter;
-    if (lattice_hints) { c->R.pos_hint = c->d_pos_hint.p; c->R.pos_hint_off = c->d_pos_hint_off.p; }
-    if (lattice_hints) c->R.wave_walk = c->max_len > std::min<uint32_t>(c->env.long_min, c->env.wave_walk_min) ? 1u : 0u;
+    c->R.pos_hint = c->d_pos_hint.p; c->R.pos_hint_off = c->d_pos_hint_off.p;
+    c->R.hint_all = any_filter ? 1u : 0u;               // (every position's bit, written by the filter launch itself)
+    c->R.wave_walk = c->max_len > std::min<uint32_t>(c->env.long_min, c->env.wave_walk_min) ? 1u : 0u;
     c->pos_hint_blk = false;
     // slices: read boundaries n i / K; slice i covers the hint words [roundup256(off[r_i]), roundup256(off[r_i+1])), so every word
     // of a read below r_i+1 belongs to a slice <= i (CRASS_HINT_PARTS=1: the A/B switch)
@@ -1770,7 +1770,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         // (uniform STRIDE is what the bit-parallel kernel needs; the lengths may differ — trimmed reads padded to one stride)
         if (c->R.stride_words >= 4 && c->R.stride_words <= 16) fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->d_hit_info.p, c->stream);
         if (fe == hipSuccess) fast = true;
-        else if (fe == hipErrorNotSupported && c->hint_filter && c->R.pos_hint) {
+        else if (fe == hipErrorNotSupported && c->hint_filter && c->R.pos_hint && !c->hint_filter_any) {
             // no lane-per-read filter for this layout: one hint bit per lattice position (the long reads' kernel), which also flags the reads that have one.
             // The survivor kernel walks on the same bits
             HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, n_words * 8, c->stream));
@@ -1783,7 +1783,8 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         else if (fe == hipErrorNotSupported && c->hint_filter_any && c->n_pos_hint_words) {
             HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, n_words * 8, c->stream));
             const hipError_t he = launch_hint_filter_any(c->R, c->dp, c->d_pos_hint_off.p, c->pos_hint_blk ? c->d_pos_hint_blk.p : nullptr, c->n_pos_hint_words,
-                                                         c->d_mask.p, c->stream);
+                                                         c->d_mask.p, c->d_pos_hint.p, c->stream);
+            c->hint_pending = false;
             if (he != hipSuccess) { c->last_hip = (int)he; return CRASS_ERR_HIP; }
             hint_filtered = true;
         }

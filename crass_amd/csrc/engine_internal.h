@@ -31,6 +31,9 @@ struct DevReads {
     // pass 2 walks one read per WAVE (lane = window) instead of one per lane: sets whose longest read is beyond ~800 bases
     // (a lane walking its own long read touches one word per row; below that a wave's 256 windows per round stay mostly empty)
     uint32_t wave_walk;
+    // pos_hint holds a bit for EVERY position (the every-position form, another window or seed lattice: k_hint_filter_any), not
+    // the default lattice's residue class 0 with the others filled in by the walking wave
+    uint32_t hint_all;
 };
 
 struct DevParams {
@@ -288,7 +291,7 @@ hipError_t launch_hint_positions(const DevReads &R, const DevParams &P, const ui
                                  uint64_t *hitmask = nullptr);      // ... and the bits as the seed-scan filter (cleared by the caller): bit r = read r has a hint bit
 // ... the same under another window or seed lattice: every position's bit computed on the spot, nothing kept (window 6 .. 9, shifts 17 .. 127)
 hipError_t launch_hint_filter_any(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
-                                  uint64_t *hitmask, hipStream_t st);
+                                  uint64_t *hitmask, uint64_t *hint_bits, hipStream_t st);      // hint_bits: every position's bit, kept for the survivors' walks
 // long reads with position hints, an identity survivor list and no exception read: the walk of the reads without an array; a read
 // that needs the full searchCore leaves with err == 7 for launch_survivor(..., punt_only = 7)
 hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,

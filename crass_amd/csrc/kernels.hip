@@ -2179,7 +2179,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         const uint32_t hint = (!EXC && seed_hint) ? seed_hint[r] : 0xFFFFFFFFu;
         uint64_t *ph = (!EXC && R.pos_hint) ? l_hint : nullptr;            // (staged in LDS above)
         uint32_t *cls_from = reinterpret_cast<uint32_t *>(l_hint + lds.hint_words - 4);      // (the last four hint slots: 8 x uint32)
-        if (ph && lane < 8) cls_from[lane] = lane == 0 ? 0u : 0xFFFFFFFFu;
+        if (ph && lane < 8) cls_from[lane] = (lane == 0 || R.hint_all) ? 0u : 0xFFFFFFFFu;      // (hint_all: every class is there from the start)
         wave_sync();
         // (a read the light walk handed over: on from the seed it stopped at — SurvOut::repeat_len of the slot, k_long_light)
         const uint32_t j_start = (!EXC && punt_only == 7) ? uni(out[s].repeat_len) : 0u;
@@ -2474,7 +2474,7 @@ static __device__ __forceinline__ uint64_t hint_bits_every(const uint32_t (&w)[1
 // like every filter here; 11 instructions per word and shift for every position — four times the lattice-class kernel, a fifth of
 // k_filter_general, which these sets took until now.
 __global__ __launch_bounds__(256) void k_hint_filter_any(DevReads R, DevParams P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
-                                                         uint64_t *hitmask)
+                                                         uint64_t *hitmask, uint64_t *hint_bits)
 {
     const uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (t >= n_words) return;
@@ -2484,7 +2484,7 @@ __global__ __launch_bounds__(256) void k_hint_filter_any(DevReads R, DevParams P
     const uint32_t L = rd_len(R, r);
     const int D0 = (int)(P.lowDR + P.lowSp), D1 = (int)(P.highDR + P.highSp);
     const int last = (int)L - D0 - (int)P.window - 1 - (int)(tile * 64u);        // searchEnd, counted from this tile's first position
-    if (last < 0) return;
+    if (last < 0) { hint_bits[t] = 0ull; return; }
     const uint32_t nw = (L + 15) >> 4;
     const uint32_t *g = R.packed + rd_word_off(R, r) + tile * 4u;
     const uint32_t rem = nw - tile * 4u;
@@ -2493,6 +2493,9 @@ __global__ __launch_bounds__(256) void k_hint_filter_any(DevReads R, DevParams P
     for (int i = 0; i < 13; i++) w[i] = (uint32_t)i < rem ? g[i] : 0u;
     uint64_t bits = hint_bits_every(w, (int)P.window, D0, D1);
     if (last < 63) bits &= (2ull << last) - 1ull;
+    // every position's bit is kept: the survivors' walks step over the positions whose bit is clear, on the lattice and — behind a
+    // rejected candidate — off it (DevReads.hint_all)
+    hint_bits[t] = bits;
     // the lattice: positions that are multiples of skips
     const uint32_t skips = P.skips;
     if (skips > 1) {
@@ -2506,13 +2509,13 @@ __global__ __launch_bounds__(256) void k_hint_filter_any(DevReads R, DevParams P
 }
 
 hipError_t launch_hint_filter_any(const DevReads &R, const DevParams &P, const uint64_t *hint_off, const uint32_t *blk_read, uint64_t n_words,
-                                  uint64_t *hitmask, hipStream_t st)
+                                  uint64_t *hitmask, uint64_t *hint_bits, hipStream_t st)
 {
     if (P.window < 6 || P.window > 9 || P.skips < 1 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 || P.highDR + P.highSp < P.lowDR + P.lowSp) return hipErrorNotSupported;
     if (!n_words) return hipSuccess;
     const uint64_t nb = (n_words + 255) / 256;
     if (nb > 0x7FFFFFFFull) return hipErrorNotSupported;
-    CRASS_LAUNCH(k_hint_filter_any, dim3((unsigned)nb), dim3(256), 0, st, R, P, hint_off, blk_read, n_words, hitmask);
+    CRASS_LAUNCH(k_hint_filter_any, dim3((unsigned)nb), dim3(256), 0, st, R, P, hint_off, blk_read, n_words, hitmask, hint_bits);
     return hipGetLastError();
 }
 
@@ -3198,12 +3201,18 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint64_t s
 // bitmap: k_hint_positions filled the lattice class and cleared what lies behind searchEnd) — bit 0 of each byte, gathered by one
 // multiplication per 64 positions (the partial products 2^(56 + 8k - 7j) of bits 8k and multiplier terms 2^(56 - 7j) are all
 // distinct, and only those with k == j fall into the top byte)
-static __device__ __forceinline__ uint64_t ln_hint64(const DevReads &R, const uint32_t *seed_hint, uint64_t r, int L)
+static __device__ __forceinline__ uint64_t ln_hint64(const DevReads &R, const uint32_t *seed_hint, uint64_t r, int L, uint32_t skips)
 {
     if (seed_hint) return 0xFFFFFFFF00000000ull | (uint64_t)seed_hint[r];
     if (!R.pos_hint) return ~0ull;
     const uint64_t *ph = R.pos_hint + rd_hint_off(R, r);
     const int nh = (L + 63) >> 6;
+    if (R.hint_all) {
+        // every position has a bit (another window or seed lattice): seed i sits at i * skips
+        uint64_t hint = 0;
+        for (uint32_t i = 0, p = 0; i < 64u && (int)p < L; i++, p += skips) hint |= ((ph[p >> 6] >> (p & 63u)) & 1ull) << i;
+        return hint;
+    }
     uint64_t hint = 0;
     for (int k = 0; k < 8 && k < nh; k++)
         hint |= (((ph[k] & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * k);
@@ -3227,7 +3236,7 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
         bool heavy = false;
         if (s < n_surv) {
             const uint64_t r0 = surv_idx[s];
-            heavy = !rd_is_exc(R, r0) && (seed_hint ? __popc(seed_hint[r0]) : __popcll(ln_hint64(R, nullptr, r0, (int)rd_len(R, r0)))) >= 2;
+            heavy = !rd_is_exc(R, r0) && (seed_hint ? __popc(seed_hint[r0]) : __popcll(ln_hint64(R, nullptr, r0, (int)rd_len(R, r0), P.skips))) >= 2;
         }
         const uint64_t hb = __ballot(heavy);
         if (lane == 0) sl_cnt[wv] = (uint32_t)__popcll(hb);
@@ -3261,7 +3270,7 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
     LaneRead h;
     h.w = lw; h.ss = lss; h.L = L; h.nss = 0; h.cap = (int)ss_cap; h.replen = 0; h.punt = 0;
     h.cmask = (1u << (2 * P.window)) - 1u;
-    const uint64_t hint = ln_hint64(R, seed_hint, r, L);
+    const uint64_t hint = ln_hint64(R, seed_hint, r, L, P.skips);
     int f = (P.debug_stop == 1) ? 0 : ln_search_core(h, P, hint);      // (1: load only)
     if (P.debug_stop == 4 && f == 1) f = 0;                           // (4: no orientation / output)
     SurvOut o;
