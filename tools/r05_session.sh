@@ -95,6 +95,12 @@ if has lens; then
   # ms per 1.5 Gbases against the read length: lane-per-read filter (<= 256 bases), position hints as the filter (257 .. 2 048), long-read path
   bash tools/len_sweep.sh $tag/len_sweep > $out/len_sweep.txt 2>&1; cat $out/len_sweep.txt
   LENS="300 500 1000" CRASS_NO_HINT_FILTER=1 bash tools/len_sweep.sh $tag/len_sweep_general > $out/len_sweep_general_filter.txt 2>&1; cat $out/len_sweep_general_filter.txt
+  # ... the same lengths under another window / seed lattice (the hint bits' every-position form), with and without it
+  : > $out/len_sweep_params.txt
+  for L in 300 1000; do n=$((1500000000 / L)); for p in w=7 d=20,D=40; do for e in CRASS_X=1 CRASS_NO_HINT_FILTER=1; do
+    env $e python bench.py --read-len $L --total-reads $n --params $p --steps 5 --warmup 2 --cpu-sample 20000 --single-shots 0 --e2e-reads 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('L=$L $p $e', 'ms/step', d['ms_per_step'], {k:v['avg_launch_ms'] for k,v in d['roofline']['per_kernel'].items()}, 'fast_filter', d['config'].get('fast_filter'), 'parity', (d.get('parity_checked') or {}).get('equal'))" >> $out/len_sweep_params.txt
+  done; done; done
+  cat $out/len_sweep_params.txt
 fi
 if has pmc3; then
   bash tools/pmc_round.sh $tag/pmc_c3 3 1000000 10000 > $out/pmc_c3_summary.txt 2>&1; tail -30 $out/pmc_c3_summary.txt
