@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrass_hip.so")
-SOURCES = ["kernels.hip", "dmerge.hip", "consensus.hip", "engine.cpp", "merge.cpp", "ingest.cpp", "consensus.cpp", "group.cpp", "graph.cpp", "sdma.cpp"]
+SOURCES = ["kernels.hip", "dmerge.hip", "consensus.hip", "engine.cpp", "merge.cpp", "ingest.cpp", "consensus.cpp", "group.cpp", "graph.cpp", "sdma.cpp", "pgzip.cpp"]
 DEPS = SOURCES + ["engine_internal.h", "devmem.h", "consensus_internal.h", "merge.h", os.path.join("..", "..", "include", "crass_hip.h")]
 
 

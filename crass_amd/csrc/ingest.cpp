@@ -40,6 +40,9 @@ struct PackedOwner {
     std::vector<uint8_t> exc_bytes;
 };
 
+}
+namespace crass { bool parallel_gunzip(const uint8_t *in, size_t n, uint8_t **out_p, size_t *out_n, unsigned threads); }      // pgzip.cpp
+namespace {
 unsigned hw_threads()
 {
     unsigned n = std::thread::hardware_concurrency();
@@ -559,6 +562,31 @@ bool inflate_with_libdeflate(const char *path, InflatedBuf &out)
                 munmap(m, csz); out.p = buf; out.n = (size_t)ooff[nb]; return true;
             }
             free(buf);                                    // (a member that is not what its header says: the serial path decides)
+        }
+    }
+    bool pg_fits = true;
+    {
+        // (its symbols are two bytes per byte of text, held beside the text: only where three times the text — about four times the
+        // file each — fits half of the available memory)
+        uint64_t avail = 0;
+        if (FILE *fp = fopen("/proc/meminfo", "r")) {
+            char line[256];
+            while (fgets(line, sizeof(line), fp)) if (!strncmp(line, "MemAvailable:", 13)) { avail = (uint64_t)atoll(line + 13) << 10; break; }
+            fclose(fp);
+        }
+        if (avail && (uint64_t)csz * 12 > avail / 2) pg_fits = false;
+    }
+    if (pg_fits && !getenv("CRASS_NO_PGZIP")) {
+        // one member, large: inflated by several threads from block starts found in the middle of the stream (pgzip.cpp); its own
+        // checks (length, CRC-32) decide, and anything it does not take comes back here
+        uint8_t *pb = nullptr; size_t pn = 0;
+        const double tp0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (crass::parallel_gunzip(in, csz, &pb, &pn, std::min<unsigned>(hw_threads(), 16u))) {
+            if (getenv("CRASS_TIMING")) fprintf(stderr, "[crass_timing] inflate: one member, %zu -> %zu bytes on several threads, %.3f s\n", csz, pn,
+                                                std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tp0);
+            munmap(m, csz);
+            out.p = pb; out.n = pn;
+            return true;
         }
     }
     uint32_t isize;                                       // size of the last member modulo 2^32: a first guess only

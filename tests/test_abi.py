@@ -608,6 +608,67 @@ def test_bgzf_inputs_are_inflated_member_by_member(ca, tmp_path):
     assert ca.FastxFile(str(mixed)).records() == fastx.read_fastx(str(mixed))
 
 
+@pytest.mark.parametrize("level", [1, 6, 9])
+@pytest.mark.parametrize("kind", ["random_fasta", "repeats", "fastq", "wrapped"])
+def test_one_gzip_member_inflated_by_several_threads(ca, tmp_path, kind, level):
+    """csrc/pgzip.cpp: a gzip member entered at block starts found in the middle of the stream, the unknown 32 KB in front of a chunk
+    carried as markers and resolved afterwards, accepted only with the trailer's length and CRC-32.  Thresholds lowered so that a
+    few megabytes are cut into dozens of chunks, some shorter than a window: the same records as the serial path (zlib /
+    libdeflate) for literal-heavy text, long-distance repeats, quality strings, wrapped lines; several members and a damaged
+    stream go back to the serial path and its verdict"""
+    import gzip, random
+    rng = random.Random(hash((kind, level)) & 0xFFFF)
+    recs = []
+    if kind == "random_fasta":
+        for i in range(40000):
+            recs.append(">r%d\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(150))))
+    elif kind == "repeats":
+        pool = ["".join(rng.choice("ACGT") for _ in range(rng.randint(100, 250))) for _ in range(60)]
+        for i in range(90000):
+            recs.append(">r%d\n%s\n" % (i % 977, pool[(i * 7 + i // 11) % len(pool)]))
+    elif kind == "fastq":
+        for i in range(30000):
+            s = "".join(rng.choice("ACGT") for _ in range(rng.randint(50, 150)))
+            recs.append("@q%d l=%d\n%s\n+\n%s\n" % (i, i % 8, s, "".join(rng.choice("FFFFF:,#") for _ in s)))
+    else:
+        for i in range(8000):
+            s = "".join(rng.choice("ACGTN") for _ in range(rng.randint(300, 1200)))
+            recs.append(">w%d\n%s\n" % (i, "\n".join(s[k:k + 70] for k in range(0, len(s), 70))))
+    text = "".join(recs).encode()
+    gz = tmp_path / "one.gz"
+    gz.write_bytes(gzip.compress(text, level))
+    os.environ["CRASS_NO_PGZIP"] = "1"
+    try:
+        want = ca.FastxFile(str(gz)).records()
+    finally:
+        os.environ.pop("CRASS_NO_PGZIP", None)
+    os.environ["CRASS_TIMING"] = "1"
+    for chunk in ("16384", "100000", "400000"):
+        os.environ.update({"CRASS_PGZIP_MIN_BYTES": "1000", "CRASS_PGZIP_CHUNK_BYTES": chunk})
+        try:
+            got = ca.FastxFile(str(gz)).records()
+        finally:
+            for k in ("CRASS_PGZIP_MIN_BYTES", "CRASS_PGZIP_CHUNK_BYTES"):
+                os.environ.pop(k, None)
+        assert got == want, chunk
+    os.environ.pop("CRASS_TIMING", None)
+    if kind == "random_fasta" and level == 6:
+        os.environ.update({"CRASS_PGZIP_MIN_BYTES": "1000", "CRASS_PGZIP_CHUNK_BYTES": "100000"})
+        try:
+            two = tmp_path / "two.gz"
+            two.write_bytes(gzip.compress(text[:len(text) // 2], level) + gzip.compress(text[len(text) // 2:], level))
+            assert ca.FastxFile(str(two)).records() == want       # several members: the serial path reads them all
+            raw = bytearray(gz.read_bytes())
+            raw[len(raw) // 3] ^= 0x10
+            bad = tmp_path / "bad.gz"
+            bad.write_bytes(bytes(raw))
+            with pytest.raises(ca.CrassError):
+                ca.FastxFile(str(bad))
+        finally:
+            for k in ("CRASS_PGZIP_MIN_BYTES", "CRASS_PGZIP_CHUNK_BYTES"):
+                os.environ.pop(k, None)
+
+
 def test_indexed_reader_refuses_mixed_comments(ca, tmp_path):
     """kseq's stale comment / quality buffers (libcrispr.cpp:124-131) make a record's fields depend on the records before it: a
     file that mixes records with and without a comment is left to the ordered readers"""
