@@ -537,7 +537,10 @@ bool inflate_with_libdeflate(const char *path, InflatedBuf &out)
         std::vector<uint64_t> ioff, ooff;
         if (!getenv("CRASS_NO_BGZF") && bgzf_walk(in, csz, ioff, ooff) && ioff.size() > 64) {
             const size_t nb = ioff.size() - 1;
-            uint8_t *buf = (uint8_t *)malloc((size_t)ooff[nb] + 1);
+            // (2 MB-aligned, MADV_HUGEPAGE: a gigabyte of first touches in 4 KB pages is a good part of what is left)
+            const size_t al = 2u << 20, bytes = ((size_t)ooff[nb] + 1 + al - 1) / al * al;
+            uint8_t *buf = (uint8_t *)aligned_alloc(al, bytes);
+            if (buf) (void)madvise(buf, bytes, MADV_HUGEPAGE);
             std::atomic<int> bad{buf ? 0 : 1};
             if (buf) {
                 const unsigned nt = (unsigned)std::min<size_t>(std::min<unsigned>(hw_threads(), 32u), nb / 32);
