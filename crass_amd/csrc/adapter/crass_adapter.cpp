@@ -787,9 +787,12 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     std::cout << "\r[crass_patternFinder]: Processed " << g_read_counter_p1 << " ..." << difftime(tnow, time_start) << " sec" << std::endl;
     // ---- the hand-off ----
     // StringCheck: tokens 2.. in discovery order (the engine's token t is the reference's token t)
+    std::vector<ReadList *> list_of((size_t)v.n_tokens + 2, nullptr);      // (tokens are dense: no look-up in the map per record)
     for (uint32_t t = 0; t < v.n_tokens; t++) {
         const StringToken st = mStringCheck->addString(std::string(v.tok_chars + v.tok_off[t], (size_t)(v.tok_off[t + 1] - v.tok_off[t])));
-        (*mReads)[st] = new ReadList();
+        ReadList *l = new ReadList();
+        (*mReads)[st] = l;
+        if ((size_t)st < list_of.size()) list_of[(size_t)st] = l;
     }
     if (v.n_candidates != c.n) CRASS_THROW("candidate / token count mismatch");
     // (streamed ingest: the records' text is picked up by a second pass over the inputs, below — `fills`)
@@ -805,27 +808,38 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         }
         h->RH_StartStops.assign(c.ss_pool + c.ss_off[k], c.ss_pool + c.ss_off[k] + c.n_ss[k]);
         h->RH_RepeatLength = (int)c.repeat_len[k];
-        (*mReads)[(StringToken)v.cand_token[k]]->push_back(h);
+        { const size_t tk = (size_t)v.cand_token[k]; ReadList *l = tk < list_of.size() ? list_of[tk] : nullptr; (l ? l : (*mReads)[(StringToken)tk])->push_back(h); }
         cand_holders[k] = h;
     }
     // createNonRedundantSet's outputs: groups (GID -> tokens), per-group k-mer counts, the pattern list
     const int gid_base = nextFreeGID;
-    for (uint32_t g = 0; g < v.n_groups; g++) {
-        const int gid = gid_base + (int)g;
-        mGroupMap[gid] = true;
-        DR_Cluster *cl = new DR_Cluster();
-        std::map<std::string, int> *counts = new std::map<std::string, int>();
-        for (uint64_t w = v.grp_off[g]; w < v.grp_off[g + 1]; w++) {
-            const uint32_t t = v.grp_tokens[w];
-            cl->push_back((StringToken)t);
-            const std::string dr(v.tok_chars + v.tok_off[t - 2], (size_t)(v.tok_off[t - 1] - v.tok_off[t - 2]));
-            for (size_t i = 0; i + 11 <= dr.size(); i++) {                  // local_kmer_CountMap (WorkHorse.cpp:1547-1560,1620-1625)
-                std::string km = dr.substr(i, 11), rc = revcomp(km);
-                (*counts)[km < rc ? km : rc] += 1;
+    {
+        // a group's cluster and its 11-mer counts depend on the group alone: built over the cores (a million map operations for the
+        // 42 k tokens of a 50 M-read job), put into the job's maps in GID order
+        std::vector<DR_Cluster *> cls(v.n_groups, nullptr);
+        std::vector<std::map<std::string, int> *> cnts(v.n_groups, nullptr);
+        par_ranges((size_t)v.n_groups, 1, [&](size_t a, size_t b) {
+            for (size_t g = a; g < b; g++) {
+                DR_Cluster *cl = new DR_Cluster();
+                std::map<std::string, int> *counts = new std::map<std::string, int>();
+                for (uint64_t w = v.grp_off[g]; w < v.grp_off[g + 1]; w++) {
+                    const uint32_t t = v.grp_tokens[w];
+                    cl->push_back((StringToken)t);
+                    const std::string dr(v.tok_chars + v.tok_off[t - 2], (size_t)(v.tok_off[t - 1] - v.tok_off[t - 2]));
+                    for (size_t i = 0; i + 11 <= dr.size(); i++) {                  // local_kmer_CountMap (WorkHorse.cpp:1547-1560,1620-1625)
+                        std::string km = dr.substr(i, 11), rc = revcomp(km);
+                        (*counts)[km < rc ? km : rc] += 1;
+                    }
+                }
+                cls[g] = cl; cnts[g] = counts;
             }
+        });
+        for (uint32_t g = 0; g < v.n_groups; g++) {
+            const int gid = gid_base + (int)g;
+            mGroupMap[gid] = true;
+            mDR2GIDMap[gid] = cls[g];
+            groupKmerCountsMap[gid] = cnts[g];
         }
-        mDR2GIDMap[gid] = cl;
-        groupKmerCountsMap[gid] = counts;
     }
     nextFreeGID = gid_base + (int)v.n_groups;
     std::cout << "[crass_clusterCore]: " << v.n_tokens << " variants mapped to " << mDR2GIDMap.size() << " clusters" << std::endl;
@@ -846,6 +860,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         h->RH_StartStops.push_back(q.start[k]);
         h->RH_StartStops.push_back(q.end[k]);
         StringToken st = (StringToken)q.token[k];
+        if (st >= 2 && (size_t)st < list_of.size() && list_of[(size_t)st]) { list_of[(size_t)st]->push_back(h); continue; }
         if (st < 2 || !mReads->count(st)) {                 // (not expected with the engine's own pattern set: addReadHolder's general form)
             const std::string dr(q.dr_chars + k * (uint64_t)q.dr_stride, q.dr_len[k]);
             st = mStringCheck->getToken(dr);
