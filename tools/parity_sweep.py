@@ -17,6 +17,9 @@ t_start = time.time()
 for case in range(n_cases):
     L = rng.choice([75, 100, 101, 125, 150, 150, 150, 151, 250, 251, 64, 200])
     n = rng.choice([3000, 20000, 60000, 150000])
+    if rng.random() < 0.25:                      # reads between the lane-per-read filter and the long-read path: the hint filter
+        L = rng.choice([257, 300, 301, 400, 512, 513, 700, 1000, 1500, 2048])
+        n = max(1000, min(n, 9_000_000 // L))
     n_dr = rng.choice([1, 3, 10, 50, 200, 1500])
     cpm = rng.choice([2000, 10000, 50000, 300000])
     k = rng.choice([6, 6, 6, 4, 8, 12])
