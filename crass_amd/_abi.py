@@ -191,6 +191,7 @@ SYMBOLS = {
     "crass_fastx_index_reads": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "crass_fastx_index_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Fastx)]),
     "crass_fastx_index_free": (None, [C.c_void_p]),
+    "crass_fastx_index_drop_text": (None, [C.c_void_p]),
     "crass_name_table_create": (C.c_void_p, []),
     "crass_name_table_destroy": (None, [C.c_void_p]),
     "crass_name_table_reserve": (None, [C.c_void_p, C.c_uint64]),

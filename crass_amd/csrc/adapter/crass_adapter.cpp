@@ -36,7 +36,8 @@ struct DeadContexts {
         for (auto &p : d) crass_fastx_index_free(p.ix);
         if (device) for (auto &p : d) { if (p.g) crass_hip_group_destroy(p.g); if (p.c) crass_hip_destroy(p.c); }
     }
-    void destroy_async() { if (v.empty()) return; g_reaper_ctx.wait(); auto d = std::move(v); v.clear(); g_reaper_ctx.f = std::async(std::launch::async, [d] { destroy(d, true); }); }
+    bool leave = false;                                     // leaveTeardownToProcessEnd()
+    void destroy_async() { if (v.empty() || leave) return; g_reaper_ctx.wait(); auto d = std::move(v); v.clear(); g_reaper_ctx.f = std::async(std::launch::async, [d] { destroy(d, true); }); }
     // (what is still parked at the process's end: the host side is freed, the device contexts go with the process — the HIP
     // runtime may be gone by now)
     ~DeadContexts() { g_reaper_ctx.wait(); destroy(v, false); }
@@ -246,6 +247,7 @@ std::string StringCheck::getString(StringToken token) const
 }
 
 void setDevice(int d) { g_device = d; g_devices.clear(); }
+void leaveTeardownToProcessEnd(bool yes) { g_dead.leave = yes; }
 void setDevices(const std::vector<int> &devices, bool local_copies) { g_devices = devices; g_local_copies = local_copies; }
 void releaseDeviceReads() { session().clear(); }
 
@@ -887,6 +889,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         for (auto &x : th) x.join();
         t_fill = now() - tf0;
     }
+    if (indexed) crass_fastx_index_drop_text(IX.ix);       // (the inputs' mappings, over the cores and now: not by the thread that frees the rest later)
     if (streamed && !fills.empty()) {
         // pass B over the inputs (the reference reads every file a second time too, findSingletons): the text of the records
         // that are handed on, chunk by chunk

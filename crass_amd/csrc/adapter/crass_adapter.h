@@ -136,6 +136,10 @@ int buildGraphsAndOutput(ReadMap &mReads, DR_Cluster_Map &mDR2GIDMap, std::map<i
 void releaseDeviceReads();
 // which GPU the adapter uses (default 0, or $CRASS_HIP_DEVICE)
 void setDevice(int device);
+// a process that ends right behind the output stage (the command line) tells the adapter so: what the search stage leaves behind
+// (the index of the inputs, the device contexts) is then left to the process's end instead of being freed on a thread beside the
+// output stage, whose allocations wait for every unmapping (0.25 s of a 2.6 s run at 50 M reads).  Default: freed.
+void leaveTeardownToProcessEnd(bool yes);
 // several GPUs: every read set is sharded over them by contiguous read ranges (crass_hip_group_*, include/crass_hip.h); with
 // searchAndRecruit the DR merge runs on the devices and the candidate DR strings cross in ONE RCCL all-gather issued by the
 // engine.  local_copies: tests only — several contexts on one GPU, device copies instead of the collective.

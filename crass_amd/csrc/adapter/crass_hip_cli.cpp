@@ -178,6 +178,7 @@ int main(int argc, char *argv[])
     try {
         time_t start_time; time(&start_time);
         if (!devices.empty()) setDevices(devices, local_copies);
+        if (!getenv("CRASS_RELEASE_AT_EXIT")) leaveTeardownToProcessEnd(true);      // (this process ends behind its outputs: see the end of main)
         int next_free_GID = 1;
         Vecstr *nr = nullptr;
         if (seam) {

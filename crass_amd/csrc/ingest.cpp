@@ -903,6 +903,8 @@ struct crass_fastx_index {
     // in the inputs' concatenation (base = the bytes of the inputs before it)
     struct File {
         void *map = nullptr; size_t n = 0; uint8_t *own = nullptr;     // own: the inflated image (then map points at it)
+        int fd = -1;                                                   // a plain file stays open: its mapping goes when the index is built, the
+                                                                       // handed-on records are read from the file (crass_fastx_index_fetch)
         uint64_t base = 0;
         bool any_c = false, any_q = false;
         int last_ret = -1;
@@ -929,6 +931,7 @@ struct crass_fastx_index {
         for (File &f : files) {
             if (f.own) { drop_pages(f.own, f.n); free(f.own); }
             else if (f.map && f.n) { drop_pages(f.map, f.n); munmap(f.map, f.n); }
+            if (f.fd >= 0) close(f.fd);
         }
     }
 };
@@ -985,7 +988,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
                 (void)madvise(m, fn, MADV_WILLNEED);
                 F.map = m; F.n = fn;
             }
-            close(fd);
+            F.fd = fd;
         }
     };
     {
@@ -1234,13 +1237,24 @@ int crass_fastx_index_fetch(const crass_fastx_index *ix, const uint64_t *idx, ui
     const unsigned nt = (unsigned)std::min<uint64_t>(std::min<unsigned>(hw_threads(), 32u), std::max<uint64_t>(1, n / 2048));
     std::vector<FxChunk> parts(nt ? nt : 1);
     const uint64_t per = (n + parts.size() - 1) / parts.size();
+    std::atomic<bool> io_fail{false};
     auto run = [&](size_t t) {
         const uint64_t a = std::min<uint64_t>(n, t * per), b = std::min<uint64_t>(n, a + per);
+        std::vector<uint8_t> rb;
         for (uint64_t k = a; k < b; k++) {
             const uint64_t h = ix->hdr_pos[idx[k]];
             const crass_fastx_index::File &F = ix->file_of(h);
             const size_t lh = (size_t)(h - F.base);
-            parse_range((const uint8_t *)F.map, F.n, lh, lh + 1, false, parts[t]);      // exactly the record whose header character is at h
+            if (F.map) { parse_range((const uint8_t *)F.map, F.n, lh, lh + 1, false, parts[t]); continue; }      // exactly the record whose header character is at h
+            // (the mapping is gone: the record's bytes — from its header character to the next record's, or to the file's end — from the file)
+            uint64_t e = F.base + F.n;
+            if (idx[k] + 1 < nrec && ix->hdr_pos[idx[k] + 1] < e) e = ix->hdr_pos[idx[k] + 1];
+            const size_t len = (size_t)(e - h);
+            rb.resize(len);
+            size_t got = 0;
+            while (got < len) { const ssize_t g = pread(F.fd, rb.data() + got, len - got, (off_t)(lh + got)); if (g <= 0) break; got += (size_t)g; }
+            if (got != len) { io_fail.store(true); return; }
+            parse_range(rb.data(), len, 0, 1, false, parts[t]);
         }
     };
     {
@@ -1249,6 +1263,7 @@ int crass_fastx_index_fetch(const crass_fastx_index *ix, const uint64_t *idx, ui
         run(0);
         for (auto &t : th) t.join();
     }
+    if (io_fail.load()) return CRASS_ERR_IO;
     uint64_t got = 0, seq_b = 0, name_b = 0, com_b = 0, qual_b = 0;
     for (auto &c : parts) { got += c.n_rec(); seq_b += c.seq.size(); name_b += c.name.size(); com_b += c.comment.size(); qual_b += c.qual.size(); }
     if (got != n) return CRASS_ERR_STATE;
@@ -1284,6 +1299,33 @@ int crass_fastx_index_fetch(const crass_fastx_index *ix, const uint64_t *idx, ui
 }
 
 void crass_fastx_index_free(crass_fastx_index *ix) { delete ix; }
+
+// A plain file's mapping has done most of its work once the hand-off has fetched its records: 2 M page-table entries for 8 GB, taken
+// down side by side (the pages dropped under the shared lock by sixteen threads, then an unmapping that finds nothing) instead of by
+// one thread beside a later stage, whose allocations waited for it a quarter of a second.  Records fetched after this are read from
+// the file (pread: four times slower per record, which is why the hand-off fetches first).
+void crass_fastx_index_drop_text(crass_fastx_index *ix)
+{
+    if (!ix) return;
+    for (crass_fastx_index::File &F : ix->files) {
+        if (F.own || !F.map || !F.n || F.fd < 0) continue;
+        const size_t slice = 64u << 20, ns = (F.n + slice - 1) / slice;
+        uint8_t *mp = (uint8_t *)F.map;
+        const size_t fn = F.n;
+        {
+            const unsigned nt = (unsigned)std::min<size_t>(std::min<unsigned>(hw_threads(), 16u), ns);
+            std::atomic<size_t> next{0};
+            auto drop = [&]() { for (;;) { const size_t q = next.fetch_add(1); if (q >= ns) break; (void)madvise(mp + q * slice, std::min<size_t>(slice, fn - q * slice), MADV_DONTNEED); } };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; t++) th.emplace_back(drop);
+            drop();
+            for (auto &x : th) x.join();
+        }
+        munmap(F.map, F.n);
+        F.map = nullptr;
+    }
+}
+
 
 } // extern "C"
 

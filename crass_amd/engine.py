@@ -194,6 +194,10 @@ class FastxIndex:
         self.lib.crass_free_fastx(C.byref(f))
         return out
 
+    def drop_text(self):
+        """give the plain-text inputs' mappings back (crass_fastx_index_drop_text); later fetches read from the files"""
+        self.lib.crass_fastx_index_drop_text(self.h)
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.crass_fastx_index_free(self.h)

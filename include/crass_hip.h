@@ -501,6 +501,9 @@ int  crass_fastx_index_reads(const crass_fastx_index *ix, crass_reads *reads, ui
 /* records idx[0 .. n) (any order) as a crass_fastx of n records in that order; header_id[k] = idx[k]; free with crass_free_fastx */
 int  crass_fastx_index_fetch(const crass_fastx_index *ix, const uint64_t *idx, uint64_t n, crass_fastx *out);
 void crass_fastx_index_free(crass_fastx_index *ix);
+/* the mappings of the plain-text inputs given back now, over the cores (page tables of gigabytes are slow to take down and block the
+ * process's other allocations meanwhile); records fetched afterwards are read from the files — a hand-off fetches what it needs first */
+void crass_fastx_index_drop_text(crass_fastx_index *ix);
 
 /* The same reader as a STREAM of chunks, for inputs that should not be held in host memory as a whole — the reference's own
  * memory model: kseq_read hands out one record at a time (kseq.cpp:171-226, libcrispr.cpp:96) and crass reads every input

@@ -424,6 +424,9 @@ def test_indexed_fastx_reader_is_the_whole_file_reader(ca, tmp_path, case, chunk
     pick = list(range(0, len(ref), 7)) + [len(ref) - 1, 0, 3, 3]
     assert ix.fetch(pick) == [ref[i] for i in pick]
     assert ix.fetch([]) == []
+    ix.drop_text()                                                  # (the mapping given back: the same records, read from the file)
+    assert ix.fetch(pick) == [ref[i] for i in pick]
+    assert ix.fetch(list(range(len(ref)))) == ref
     ix.close()
     if ixz is not None:
         layz = ixz.layout()
