@@ -1681,8 +1681,8 @@ int crass_fastx_stream_next(crass_fastx_stream *s, crass_fastx *out)
                 const FxChunk &c = ch[k];
                 const uint64_t m = cnt[k];
                 if (!m) return;
-                memcpy(o.seq + sq0[k], c.seq.data(), c.seq_end[m - 1]);
-                memcpy(o.name + nm0[k], c.name.data(), c.name_end[m - 1]);
+                if (c.seq_end[m - 1]) memcpy(o.seq + sq0[k], c.seq.data(), c.seq_end[m - 1]);
+                if (c.name_end[m - 1]) memcpy(o.name + nm0[k], c.name.data(), c.name_end[m - 1]);
                 if (with_c && c.comment_end[m - 1]) memcpy(o.comment + cm0[k], c.comment.data(), c.comment_end[m - 1]);
                 if (with_q && c.qual_end[m - 1]) memcpy(o.qual + ql0[k], c.qual.data(), c.qual_end[m - 1]);
                 uint32_t mx = 0;
