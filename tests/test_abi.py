@@ -672,6 +672,48 @@ def test_one_gzip_member_inflated_by_several_threads(ca, tmp_path, kind, level):
                 os.environ.pop(k, None)
 
 
+def test_several_thread_inflate_on_arbitrary_bytes(ca):
+    """csrc/pgzip.cpp called directly (its C++ symbol) on data that is not sequence text: incompressible bytes (stored blocks), tiny
+    alphabets and long runs (long matches at every distance, fixed-Huffman blocks at the ends), a mix — every zlib level and strategy,
+    chunks down to 4 KB: byte-identical to zlib's inflate, or not taken"""
+    import random, zlib
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(ca.__file__)), "libcrass_hip.so"))
+    fn = getattr(lib, "_ZN5crass15parallel_gunzipEPKhmPPhPmj")
+    fn.restype = C.c_bool
+    fn.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    rng = random.Random(77)
+    def gz(data, level, strategy):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 9, strategy)
+        return co.compress(data) + co.flush()
+    kinds = {
+        "random": lambda n: rng.randbytes(n),
+        "runs": lambda n: b"".join(bytes([rng.randrange(4)]) * rng.randrange(1, 5000) for _ in range(n // 2500)),
+        "text": lambda n: b"".join(rng.choice([b"ACGT", b"GGGA", b"TTTTTTTT", b"\n>r\n"]) for _ in range(n // 5)),
+        "mixed": lambda n: b"".join((rng.randbytes(rng.randrange(1, 70000)) if rng.random() < 0.3 else bytes([65 + rng.randrange(3)]) * rng.randrange(1, 90000)) for _ in range(n // 40000)),
+    }
+    taken = 0
+    os.environ["CRASS_PGZIP_MIN_BYTES"] = "100"
+    try:
+        for kind, make in kinds.items():
+            for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (0, zlib.Z_DEFAULT_STRATEGY)):
+                data = make(3_000_000)
+                blob = gz(data, level, strategy)
+                for chunk in ("4096", "50000"):
+                    os.environ["CRASS_PGZIP_CHUNK_BYTES"] = chunk
+                    out, n = C.c_void_p(), C.c_size_t()
+                    if fn(blob, len(blob), C.byref(out), C.byref(n), 4):
+                        got = C.string_at(out, n.value)
+                        libc.free(out)
+                        assert got == data, (kind, level, strategy, chunk)
+                        taken += 1
+    finally:
+        os.environ.pop("CRASS_PGZIP_MIN_BYTES", None); os.environ.pop("CRASS_PGZIP_CHUNK_BYTES", None)
+    print("several-thread inflate taken in %d of 48 cases" % taken)
+    assert taken >= 20, taken
+
+
 def test_indexed_reader_refuses_mixed_comments(ca, tmp_path):
     """kseq's stale comment / quality buffers (libcrispr.cpp:124-131) make a record's fields depend on the records before it: a
     file that mixes records with and without a comment is left to the ordered readers"""
