@@ -701,7 +701,7 @@ def _e2e_cli(ca, spec, L, n, modes=("auto",)):
                     m2 = re.search(r"peak RSS (\d+) MB", line)
                     if m2:
                         rss = max(rss, float(m2.group(1)))
-                    if "[crass_timing]" in line and ("fastx" in line or "searchAndRecruit:" in line or "cli:" in line or "outputs:" in line or
+                    if "[crass_timing]" in line and ("fastx" in line or "searchAndRecruit:" in line or "hand-off:" in line or "inflate:" in line or "cli:" in line or "outputs:" in line or
                                                      ("consensus: " in line and "consensus:   " not in line) or "(adapter)" in line):
                         stages.append(line.strip()[15:])
             res[mode] = {"wall_s": round(min(walls), 3), "reads_per_s": round(n / min(walls), 1), "walls_s": [round(x, 3) for x in walls],

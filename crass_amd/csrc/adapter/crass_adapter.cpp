@@ -788,6 +788,8 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     g_read_counter_p1 += (int)n;
     std::cout << "\r[crass_patternFinder]: Processed " << g_read_counter_p1 << " ..." << difftime(tnow, time_start) << " sec" << std::endl;
     // ---- the hand-off ----
+    double th[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int thi = 0; double th_prev = now();
+    auto hlap = [&]() { const double t = now(); if (thi < 8) th[thi++] = t - th_prev; th_prev = t; };
     // StringCheck: tokens 2.. in discovery order (the engine's token t is the reference's token t)
     std::vector<ReadList *> list_of((size_t)v.n_tokens + 2, nullptr);      // (tokens are dense: no look-up in the map per record)
     for (uint32_t t = 0; t < v.n_tokens; t++) {
@@ -796,6 +798,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         (*mReads)[st] = l;
         if ((size_t)st < list_of.size()) list_of[(size_t)st] = l;
     }
+    hlap();      // 0: tokens
     if (v.n_candidates != c.n) CRASS_THROW("candidate / token count mismatch");
     // (streamed ingest: the records' text is picked up by a second pass over the inputs, below — `fills`)
     std::vector<Fill> fills;
@@ -813,6 +816,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         { const size_t tk = (size_t)v.cand_token[k]; ReadList *l = tk < list_of.size() ? list_of[tk] : nullptr; (l ? l : (*mReads)[(StringToken)tk])->push_back(h); }
         cand_holders[k] = h;
     }
+    hlap();      // 1: candidate holders
     // createNonRedundantSet's outputs: groups (GID -> tokens), per-group k-mer counts, the pattern list
     const int gid_base = nextFreeGID;
     {
@@ -851,6 +855,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         for (uint32_t i = 0; i < v.n_patterns; i++) nonRedundantPatterns->push_back(std::string(v.pat_chars + v.pat_off[i], (size_t)(v.pat_off[i + 1] - v.pat_off[i])));
     }
     if (v.n_patterns) std::cout << "[crass_clusterCore]: " << v.n_patterns << " non-redundant patterns." << std::endl;
+    hlap();      // 2: groups, patterns
     for (uint64_t k = 0; k < q.n; k++) {
         ReadHolder *h = new ReadHolder();
         if (streamed || indexed) fills.push_back(Fill{q.read_idx[k], h, q.low_lexi[k] != 0});
@@ -870,6 +875,7 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         }
         (*mReads)[st]->push_back(h);
     }
+    hlap();      // 3: recruit holders
     double t_fill = 0;
     if (indexed && !fills.empty()) {
         // the text of the records that are handed on, parsed from the mapping (crass_fastx_index_fetch: every core), then the
@@ -889,7 +895,9 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         for (auto &x : th) x.join();
         t_fill = now() - tf0;
     }
-    if (indexed) crass_fastx_index_drop_text(IX.ix);       // (the inputs' mappings, over the cores and now: not by the thread that frees the rest later)
+    hlap();      // 4: text
+    if (indexed) crass_fastx_index_drop_text(IX.ix);
+    hlap();      // 5: mappings dropped       // (the inputs' mappings, over the cores and now: not by the thread that frees the rest later)
     if (streamed && !fills.empty()) {
         // pass B over the inputs (the reference reads every file a second time too, findSingletons): the text of the records
         // that are handed on, chunk by chunk
@@ -933,6 +941,8 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
         for (size_t k = 0; k < pat.size(); k++) if (k == 0 || pat[k] != pat[k - 1]) patternsHash.insert(patternsHash.end(), std::make_pair(pat[k], true))->second = true;
         for (size_t k = 0; k < hdr.size(); k++) if (k == 0 || *hdr[k] != *hdr[k - 1]) readsFound.insert(readsFound.end(), std::make_pair(*hdr[k], true))->second = true;
     }
+    hlap();      // 6: patternsHash / readsFound
+    if (timing) fprintf(stderr, "[crass_timing] hand-off: tokens %.3f, candidate holders %.3f, groups + patterns %.3f, recruit holders %.3f, text %.3f, mappings dropped %.3f, (streamed pass B +) patternsHash / readsFound %.3f s\n", th[0], th[1], th[2], th[3], th[4], th[5], th[6]);
     g_read_counter_p2 += (int)n;
     time(&tnow);
     std::cout << "\r[crass_singletonFinder]: Processed " << g_read_counter_p2 << " ..." << difftime(tnow, time_start) << " sec" << std::endl;
