@@ -2841,7 +2841,12 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     c->q_blob_active = false;
     c->cnt.n_pass2_found = 0;
     // (the host-loop sink's copies may still be reading d_fidx, which this pass writes near its end: order the stream behind them)
-    if (c->cand_fill && c->ev_sink_copies) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sink_copies, 0));
+    // The event covers the copies that went over copy_stream; the ones on DMA engines (dma_sink[]) are behind no stream event, so
+    // the order seed_scan -> set_patterns -> recruit (no merge / get_candidates in between, which wait themselves) waits here.
+    if (c->cand_fill) {
+        if (c->ev_sink_copies) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sink_copies, 0));
+        if (const int bs = c->wait_bulk()) return bs;
+    }
     // findSingletons is only called when the non-redundant set is non-empty (WorkHorse.cpp:373)
     if (c->n_installed_patterns == 0) { c->have_pass2 = true; return CRASS_OK; }
     if (!c->have_patterns) return CRASS_ERR_STATE;

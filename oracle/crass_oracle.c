@@ -72,18 +72,30 @@ static int str_less(const char *a, size_t na, const char *b, size_t nb)
 /* ------------------------------------------------------------------------- */
 
 /* PatternMatcher.cpp:26-59 + computeBmpLast :99-109 */
-/* work counters for tools/longread_phases.py only (not thread safe: a single-threaded diagnostic; relaxed adds otherwise harmless):
+/* work counters for tools/longread_phases.py only, compiled in with -DORC_WORK_COUNTERS (the tool builds its own copy of this
+ * file; per thread).  The library the tests and bench.py time carries none: in round 5 they were plain globals, and 64 threads of
+ * the all-cores baseline writing one cache line twelve times per read ran at 1.5 x one core.
  * [0] bmpSearch calls, [1] of them hits inside searchCore's seed loop, [2] calls from scanRight, [3] extension columns voted on,
  * [4] column votes x repeats (bases read), [5] similarity (Levenshtein) calls, [6] qcFoundRepeats calls, [7] Levenshtein cells */
-static uint64_t orc_work[8];
+#ifdef ORC_WORK_COUNTERS
+static _Thread_local uint64_t orc_work[8];
+#define ORC_WORK(i, n) (orc_work[i] += (uint64_t)(n))
 void orc_work_get(uint64_t *out8, int reset)
 {
     for (int i = 0; i < 8; i++) { out8[i] = orc_work[i]; if (reset) orc_work[i] = 0; }
 }
+#else
+#define ORC_WORK(i, n) ((void)0)
+void orc_work_get(uint64_t *out8, int reset)
+{
+    (void)reset;
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+}
+#endif
 
 int orc_bmp_search(const char *text, size_t textSize, const char *pattern, size_t patternSize)
 {
-    orc_work[0]++;
+    ORC_WORK(0, 1);
     if (textSize == 0 || patternSize == 0) return -1;
     if (patternSize > textSize) return -1;
     int bmpLast[128];
@@ -140,7 +152,7 @@ float orc_similarity(const char *s1, int n, const char *s2, int m)
 {
     float max_length = (float)(size_t)(n > m ? n : m);
     if (n < 3 || m < 3) return 0;
-    orc_work[5]++; orc_work[7] += (uint64_t)n * (uint64_t)m;
+    ORC_WORK(5, 1); ORC_WORK(7, (uint64_t)n * (uint64_t)m);
     float edit_distance = (float)orc_levenshtein(s1, n, s2, m);
     return (float)(1.0 - (double)(edit_distance / max_length));
 }
@@ -197,7 +209,7 @@ static void scan_right(rh_t *h, const char *pattern, uint32_t pattern_length,
         if (begin_search > read_length - 1) return;
         if (end_search > read_length) end_search = read_length;
         if (begin_search >= end_search) return;
-        orc_work[2]++;
+        ORC_WORK(2, 1);
         position = orc_bmp_search(h->seq + begin_search, end_search - begin_search, pattern, pattern_length);
         if (position >= 0) {
             rh_add(h, begin_search + (uint32_t)position, begin_search + (uint32_t)position + pattern_length - 1);
@@ -247,7 +259,7 @@ static uint32_t extend_pre_repeat(rh_t *h, int searchWindowLength, int minSpacer
     while (max_right_extension_length > 0) {
         if ((last_repeat_start_index + (uint32_t)searchWindowLength + right_extension_length) >= seqlen)
             DR_index_end -= 2;
-        orc_work[3]++; orc_work[4] += DR_index_end / 2;
+        ORC_WORK(3, 1); ORC_WORK(4, DR_index_end / 2);
         for (uint32_t k = 0; k < DR_index_end; k += 2) {
             if ((h->ss[k] + (uint32_t)h->repeat_len) >= seqlen) {
                 k = DR_index_end;     /* then k += 2 ends the loop */
@@ -278,7 +290,7 @@ static uint32_t extend_pre_repeat(rh_t *h, int searchWindowLength, int minSpacer
     while (left_extension_length < max_left_extension_length) {
         if ((int)first_repeat_start_index - (int)left_extension_length <= 0)
             DR_index_start += 2;
-        orc_work[3]++; orc_work[4] += (end_index - DR_index_start) / 2;
+        ORC_WORK(3, 1); ORC_WORK(4, (end_index - DR_index_start) / 2);
         for (uint32_t k = DR_index_start; k < end_index; k += 2) {
             int idx = (int)(h->ss[k] - left_extension_length - 1);
             switch (h->seq[idx]) {
@@ -392,7 +404,7 @@ static int get_all_spacers(const rh_t *h, span_t *out, int cap, int *n_out)
 /* qcFoundRepeats, libcrispr.cpp:869-1029 (+ test* helpers :773-867) */
 static int qc_found_repeats(const rh_t *h, int minSpacerLength, int maxSpacerLength)
 {
-    orc_work[6]++;
+    ORC_WORK(6, 1);
     int num_repeats = h->nss / 2;
     if (num_repeats < 2) return -1;
     /* repeatStringAt(0), ReadHolder.cpp:99 */
@@ -504,7 +516,7 @@ static int search_core(rh_t *h, const orc_params *o, int lattice_only)
         int pattern_in_text_index = orc_bmp_search(text, tlen, pattern, plen);
         if (pattern_in_text_index >= 0) {
             if (lattice_only) return 1;
-            orc_work[1]++;
+            ORC_WORK(1, 1);
             rh_add(h, j, j + o->searchWindowLength - 1);
             uint32_t found = beginSearch + (uint32_t)pattern_in_text_index;
             rh_add(h, found, found + o->searchWindowLength - 1);

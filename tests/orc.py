@@ -73,12 +73,13 @@ class ConsView(C.Structure):
 
 _lib = None
 _ref = None
+ORACLE_LIB_OVERRIDE = None      # tools/longread_phases.py: its own build of the oracle with the work counters compiled in
 
 
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        path = ORACLE_LIB_OVERRIDE or os.path.join(ORACLE_DIR, "liboracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -18,6 +18,13 @@ L = 10000
 spec = ca.synth_spec(read_len=L, n_dr=50, crispr_per_million=50000, array_min_repeats=20, array_max_repeats=60)
 
 # ---- oracle side: work per read ----
+# the work counters are compiled in only here (-DORC_WORK_COUNTERS): the library the tests and bench.py time carries none
+import subprocess, tempfile
+_od = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+_so = os.path.join(tempfile.mkdtemp(prefix="orc_work_"), "liboracle_work.so")
+subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-ffp-contract=off", "-D_POSIX_C_SOURCE=200809L", "-DORC_WORK_COUNTERS",
+                       "-shared", "-o", _so, os.path.join(_od, "crass_oracle.c"), os.path.join(_od, "crass_consensus.c"), "-lm"])
+orc.ORACLE_LIB_OVERRIDE = _so
 lib = orc.lib()
 lib.orc_work_get.argtypes = [C.POINTER(C.c_uint64), C.c_int]
 w = ca.synth_packed(spec, 0, n_orc)

@@ -58,6 +58,10 @@ def rccl_allgather_us(nbytes):
 ag_us = None if os.environ.get("NO_RCCL_MEASURE") else rccl_allgather_us(1 << 20)
 print("one-rank ncclAllGather of 1 MB: %s us per call" % ("%.1f" % ag_us if ag_us else "n/a"), flush=True)
 base_ms = one_gpu()
+# the weak-scaling baselines (the shard as a job of its own) run HERE, before any rank step: tools/tl_sp.sh traces the LAST step of
+# the process, which must be the last world's rank step (round 5 ran them behind it and the committed "N = 8" timeline was the
+# 12.5 M-read baseline's)
+small_ms_of = {W: one_gpu(total // W) for W in worlds}
 out = {"total_reads": total, "one_gpu_ms_per_step": round(base_ms, 3), "rccl_allgather_1rank_1MB_us": ag_us and round(ag_us, 1), "projection": []}
 print("one GPU, %d reads: %.3f ms/step" % (total, base_ms), flush=True)
 for W in worlds:
@@ -109,7 +113,7 @@ for W in worlds:
     # job): efficiency = that small job's step / a rank's step — what the global DR set (exchange, de-duplication, the merge over
     # every rank's strings, a W times larger pattern set in pass 2) costs a rank on top of its own shard
     ms_rccl = ms + ((ag_us - 5.0) / 1e3 if ag_us else 0.0)
-    small_ms = one_gpu(total // W)                       # the same shard as a job of its own on one GPU
+    small_ms = small_ms_of[W]                            # the same shard as a job of its own on one GPU (measured up front)
     row = {"world": W, "reads_per_rank": total // W, "rank0_ms_per_step": round(ms, 3), "rank0_ms_with_measured_allgather": round(ms_rccl, 3),
            "projected_speedup_with_measured_allgather": round(base_ms / ms_rccl, 2),
            "weak_scaling": {"reads_per_rank": total // W, "one_gpu_ms_on_that_many_reads": round(small_ms, 3), "efficiency": round(small_ms / ms_rccl, 3)},
