@@ -162,6 +162,7 @@ SYMBOLS = {
     "crass_hip_exchange_setup": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Exchange)]),
     "crass_hip_merge_gathered": (C.c_int, [C.c_void_p, C.c_void_p]),
     "crass_hip_exchange_needed_rows": (C.c_uint64, [C.c_void_p]),
+    "crass_hip_exchange_set_deferred": (C.c_int, [C.c_void_p, C.c_int]),
     "crass_hip_exchange_rows_for": (C.c_uint64, [C.c_uint64]),
     "crass_hip_get_distinct_device": (C.c_int, [C.c_void_p, C.POINTER(DistinctDev)]),
     "crass_hip_merge_distinct_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
     const int lane = threadIdx.x & 63;
     const uint32_t t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (t == 0 && lane == 0 && M.d_ntok && *M.d_ntok > M.n_tok) atomicOr(&M.st->fail, 64u);      // more tokens than the launch was sized for
+    if (t == 0 && lane == 0 && M.flag_pre) stage_flag_store(M.flag_pre, M.flag_pre_val);          // (everything in front of the merge is complete)
     if (t < dm_ntok(M)) {
         const uint32_t len = M.dx_len[t];
         if (len > 64 || len < 23 || M.stride > 64) { if (lane == 0) atomicOr(&M.st->fail, 1u); }
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(1024) void k_dmx_apply(DevMerge M)
     const uint32_t n = dm_ntok(M);
     const uint32_t n_tiles = gridDim.x, tile = blockIdx.x;
     if (dead) {
-        if (tile == 0 && threadIdx.x == 0) { DevViewTotals z{}; *M.x_tot = z; *M.x_htot = z; }
+        if (tile == 0 && threadIdx.x == 0) { DevViewTotals z{}; *M.x_tot = z; M.x_htot[0] = z; M.x_htot[1] = z; }
         return;
     }
     // (a) this tile's exclusive prefix and the totals, from the tile sums of the launch before (<= 1024 tiles: one per thread)
@@ -683,7 +684,10 @@ __global__ __launch_bounds__(1024) void k_dmx_apply(DevMerge M)
         t.ok = (t.max_group <= M.x_group_cap && total[1] == n) ? 1u : 0u;
         t.lay = view_layout(n, t.n_groups, 2ull * t.n_kept, t.tok_chars, 2ull * t.kept_chars);
         T = t;
-        if (tile == 0) { *M.x_tot = t; if (!t.ok) *M.x_htot = t; }       // (ok: the host mirror is written by the LAST kernel, behind the blob)
+        // (ok: the host mirror is written by the LAST kernel, behind the blob; x_htot[1] is this kernel's: the host starts the copy
+        // of the token half of the blob — tok_off, the token strings, grp_off: everything in front of lay.grp_tokens is complete
+        // when this kernel ends — while the kernels behind it rank the members)
+        if (tile == 0) { *M.x_tot = t; if (!t.ok) M.x_htot[0] = t; M.x_htot[1] = t; }
     }
     __syncthreads();
     if (!T.ok) return;
@@ -771,6 +775,98 @@ static __device__ __forceinline__ char dmx_comp(char c)                // SeqUti
 // one per SIMD, nothing to hide the dependent adds behind — 260 us; a tile of the range in LDS read by all lanes at once 78 us
 // with 32-bit reads, 133 us with 128-bit ones (no broadcast), and the LDS it held kept pass 2's probe kernel, which stages its
 // table there, off the CUs: 144 -> 243 us.)
+// A group of 65 .. DMX_SORT_MAX members is ranked by SORTING its member list in LDS, one block per group: by (blank, length,
+// token) — the survivors come first, in the pattern list's order, and a scan over their lengths gives every pattern's
+// characters' place — then by token for grp_tokens.  Two bitonic sorts of <= 2 048 keys (66 steps each at the most) instead of
+// group-size^2 comparisons: 42 k tokens in 64 groups of up to 1 800 were 27-50 M counting steps over every CU, 65 us alone and
+// 93 us beside pass 2's probe, which lost 50 us to them (profiles/NOTES_r06.md).
+// (2 048 keys: 16 KB of LDS for the two arrays — pass 2's probe holds 128 KB of a CU's 160 KB, and with 32 KB here whichever of
+// the two kernels reached a CU first kept the other off it: the probe took 149 or 190 us depending on the launch's luck)
+#define DMX_SORT_MAX 2048u
+static __device__ __forceinline__ void dmx_bitonic(uint32_t *keys, uint32_t n_pad)
+{
+    for (uint32_t k = 2; k <= n_pad; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = keys[i], b = keys[l];
+                    const bool up = (i & k) == 0u;
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+__global__ __launch_bounds__(1024) void k_dmx_sort(DevMerge M)
+{
+    const DevViewTotals T = *M.x_tot;
+    if (!T.ok) return;
+    __shared__ uint32_t keys[DMX_SORT_MAX], dstf[DMX_SORT_MAX];
+    __shared__ uint32_t wtot[16];
+    uint8_t *blob = M.x_blob;
+    const uint64_t *grp_off = reinterpret_cast<const uint64_t *>(blob + T.lay.grp_off);
+    uint64_t *pat_off = reinterpret_cast<uint64_t *>(blob + T.lay.pat_off);
+    uint32_t *pat_group = reinterpret_cast<uint32_t *>(blob + T.lay.pat_group);
+    uint32_t *grp_tokens = reinterpret_cast<uint32_t *>(blob + T.lay.grp_tokens);
+    char *pat_chars = reinterpret_cast<char *>(blob + T.lay.pat_chars);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t stride = M.stride, cpr = stride >> 3;
+    for (uint32_t gid = blockIdx.x; gid < T.n_groups; gid += gridDim.x) {
+        const uint32_t g0 = (uint32_t)grp_off[gid], gs = (uint32_t)grp_off[gid + 1] - g0;
+        if (gs <= 64u || gs > M.x_sort_max) continue;                   // (uniform: k_dmx_rank takes those)
+        uint32_t n_pad = 128;
+        while (n_pad < gs) n_pad <<= 1;
+        for (uint32_t i = threadIdx.x; i < n_pad; i += 1024u) keys[i] = i < gs ? M.x_members[g0 + i] : 0xFFFFFFFFu;
+        __syncthreads();
+        dmx_bitonic(keys, n_pad);
+        const uint32_t r = M.root_of[keys[0] & 0xFFFFFu];
+        const uint32_t kg = M.x_kept[r], pat0 = M.x_pat0[r], pch0 = M.x_pch0[r], kch = M.x_kchars[r], gid1 = M.x_gid[r] + 1u;
+        // survivors = the first kg keys (blank is the top bit): pattern rank = position, characters in front = scan of the lengths
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < kg; base += 1024u) {
+            const uint32_t j = base + threadIdx.x;
+            const uint32_t len = j < kg ? (keys[j] >> 20) & 0x7Fu : 0u;
+            const uint32_t inc = wave_incl_scan(len, lane);
+            if (lane == 63) wtot[w] = inc;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { const uint32_t v = wtot[q]; if (q < w) before += v; all += v; }
+            if (j < kg) {
+                const uint32_t df = pch0 + carry + before + inc - len, p = pat0 + j;
+                dstf[j] = df;
+                pat_off[p] = df; pat_off[p + kg] = df + kch;
+                pat_group[p] = gid1; pat_group[p + kg] = gid1;
+            }
+            carry += all;
+            __syncthreads();
+        }
+        // the pattern strings: every survivor and its reverse complement, 8 characters per thread and step
+        for (uint32_t q = threadIdx.x; q < kg * cpr; q += 1024u) {
+            const uint32_t e = q / cpr, c8 = (q - e * cpr) * 8u, key = keys[e], len = (key >> 20) & 0x7Fu;
+            if (c8 >= len) continue;
+            const uint2 wd = *reinterpret_cast<const uint2 *>(M.dx_chars + (uint64_t)(key & 0xFFFFFu) * stride + c8);
+            char *df = pat_chars + dstf[e] + c8, *dr = pat_chars + dstf[e] + kch + (len - 1u - c8);
+            const uint32_t nb = min(8u, len - c8);
+#pragma unroll
+            for (uint32_t b2 = 0; b2 < 8; b2++)
+                if (b2 < nb) {
+                    const char c = (char)(((b2 < 4 ? wd.x : wd.y) >> (8u * (b2 & 3u))) & 0xFFu);
+                    df[b2] = c;
+                    *(dr - b2) = dmx_comp(c);
+                }
+        }
+        __syncthreads();
+        // by token: grp_tokens
+        for (uint32_t i = threadIdx.x; i < n_pad; i += 1024u) { const uint32_t k2 = keys[i]; keys[i] = k2 == 0xFFFFFFFFu ? k2 : (k2 & 0xFFFFFu); }
+        __syncthreads();
+        dmx_bitonic(keys, n_pad);
+        for (uint32_t i = threadIdx.x; i < gs; i += 1024u) grp_tokens[g0 + i] = keys[i] + 2u;
+        __syncthreads();                                                // (the next group reuses keys / dstf)
+    }
+}
+
 #define DMX_RW 16                                    // waves per block
 __global__ __launch_bounds__(64 * DMX_RW) void k_dmx_rank(DevMerge M)
 {
@@ -793,7 +889,11 @@ __global__ __launch_bounds__(64 * DMX_RW) void k_dmx_rank(DevMerge M)
         t = key & 0xFFFFFu;
         r = M.root_of[t]; g0 = M.x_goff[r]; gs = M.x_size[r];
     }
-    const uint64_t am = __ballot(act);                  // (never 0: the block's first entry exists)
+    // groups of 65 .. DMX_SORT_MAX members are ranked by k_dmx_sort (a sort in LDS): this kernel's counting is quadratic in the
+    // group.  Such a group cannot lie strictly inside a chunk, so the other lanes' groups still form one contiguous range
+    const bool part = act && (gs <= 64u || gs > M.x_sort_max);
+    const uint64_t am = __ballot(part);
+    if (am == 0ull) continue;                           // (uniform over the block: every wave holds the same 64 entries)
     const int first = __ffsll((unsigned long long)am) - 1, lastl = 63 - __clzll((unsigned long long)am);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)g0, first);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(g0 + gs), lastl);
@@ -814,7 +914,7 @@ __global__ __launch_bounds__(64 * DMX_RW) void k_dmx_rank(DevMerge M)
     acc[w][0][lane] = ra; acc[w][1][lane] = rp; acc[w][2][lane] = cp;
     if (w == 0) p_len[lane] = 0;
     __syncthreads();
-    if (w == 0 && act) {
+    if (w == 0 && part) {
         ra = rp = cp = 0;
 #pragma unroll
         for (int k = 0; k < DMX_RW; k++) { ra += acc[k][0][lane]; rp += acc[k][1][lane]; cp += acc[k][2][lane]; }
@@ -853,14 +953,18 @@ __global__ __launch_bounds__(64 * DMX_RW) void k_dmx_rank(DevMerge M)
 }
 
 // ---- one-collective exchange ----
+static constexpr uint64_t kXgRedo = 1ull << 63;      // header count, bit 63: this rank's pass 1 has to be repeated (deferred pass 1)
 __global__ __launch_bounds__(256) void k_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride,
-                                                  uint64_t cap_rows, uint32_t slot_bytes, uint8_t *send)
+                                                  uint64_t cap_rows, uint32_t slot_bytes, uint8_t *send, const uint32_t *p1c, uint64_t surv_bound,
+                                                  uint32_t *h_flag, uint32_t flag_val)
 {
+    if (h_flag && blockIdx.x == 0 && threadIdx.x == 0) stage_flag_store(h_flag, flag_val);      // (pass 1's kernels in front of this one are complete)
     const uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t nd = *d_nd;
     if (j == 0) {
         uint64_t *h = reinterpret_cast<uint64_t *>(send);
-        h[0] = nd;
+        const bool redo = p1c && (p1c[0] > surv_bound || p1c[0] == 0u || p1c[3] != 0u || (p1c[2] != 0u && p1c[5] != 0u));
+        h[0] = nd | (redo ? kXgRedo : 0ull);
         reinterpret_cast<uint32_t *>(send)[2] = stride;
         reinterpret_cast<uint32_t *>(send)[3] = (uint32_t)cap_rows;
     }
@@ -873,33 +977,46 @@ __global__ __launch_bounds__(256) void k_xg_fill(const char *dx_chars, const uin
     dst[stride / 16] = tail;
 }
 hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride, uint64_t cap_rows,
-                          uint32_t slot_bytes, uint8_t *send, hipStream_t st)
+                          uint32_t slot_bytes, uint8_t *send, hipStream_t st, const uint32_t *p1_counts, uint64_t surv_bound, uint32_t *h_flag, uint32_t flag_val)
 {
-    CRASS_LAUNCH(k_xg_fill, dim3((unsigned)((cap_rows + 255) / 256)), dim3(256), 0, st, dx_chars, dx_len, d_nd, stride, cap_rows, slot_bytes, send);
+    CRASS_LAUNCH(k_xg_fill, dim3((unsigned)((cap_rows + 255) / 256)), dim3(256), 0, st, dx_chars, dx_len, d_nd, stride, cap_rows, slot_bytes, send,
+                 p1_counts, surv_bound, h_flag, flag_val);
     return hipGetLastError();
 }
 // rank order == global read order: rank r's rows go to [off_r, off_r + n_r)
 __global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows,
-                                                    uint32_t slot_bytes, char *g_chars, uint16_t *g_len, uint32_t *xinfo, uint32_t *h_xinfo, uint32_t *zero2)
+                                                    uint32_t slot_bytes, char *g_chars, uint16_t *g_len, uint32_t *xinfo, uint32_t *h_xinfo, uint32_t *zero2,
+                                                    unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size)
 {
     if (zero2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;      // the de-duplication's two counters (no fill launch)
+    // the table of the de-duplication that follows is cleared on the way (its own launch was 5-6 us of a rank's step)
+    if (dd_keys) {
+        const uint64_t nth = (uint64_t)gridDim.x * gridDim.y * blockDim.x;
+        for (uint64_t i = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < dd_size; i += nth) { dd_keys[i] = 0ull; dd_first[i] = 0xFFFFFFFFu; }
+    }
     const uint64_t send_bytes = (cap_rows + 1) * (uint64_t)slot_bytes;
     const uint32_t r = blockIdx.y;
     uint64_t off = 0, total = 0, mx = 0, mine = 0;
+    bool redo = false;                                          // some rank's (deferred) pass 1 has to be repeated: nothing is unpacked
     for (uint32_t q = 0; q < world; q++) {                      // a handful of ranks: every thread sums the headers
-        const uint64_t nq = *reinterpret_cast<const uint64_t *>(recv + q * send_bytes);
+        uint64_t nq = *reinterpret_cast<const uint64_t *>(recv + q * send_bytes);
+        redo |= (nq & kXgRedo) != 0ull;
+        nq &= ~kXgRedo;
         if (q < r) off += nq;
         if (q < rank) mine += nq;
         total += nq;
         mx = nq > mx ? nq : mx;
     }
-    const uint64_t n_r = *reinterpret_cast<const uint64_t *>(recv + r * send_bytes);
+    if (redo && mx <= cap_rows) mx = cap_rows + 1;              // (reported as a list that did not fit; the rows asked for stay within what there is: below)
+    const uint64_t n_r = *reinterpret_cast<const uint64_t *>(recv + r * send_bytes) & ~kXgRedo;
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (r == 0 && i == 0) {
         // (a list that did not fit: no row is unpacked, and the kernels queued behind this one see an EMPTY global list —
         // with the sum of the headers they would walk rows of g_chars / g_len that nobody wrote)
-        xinfo[0] = mx > cap_rows ? 0u : (uint32_t)total; xinfo[1] = (uint32_t)mine; xinfo[2] = mx > cap_rows ? 1u : 0u; xinfo[3] = (uint32_t)mx;
-        if (h_xinfo) { h_xinfo[0] = (uint32_t)total; h_xinfo[1] = (uint32_t)mine; h_xinfo[2] = mx > cap_rows ? 1u : 0u; h_xinfo[3] = (uint32_t)mx; }   // pinned mirror
+        // ([3]: the rows the largest list needs; 1 when the lists fit and only a pass 1 has to be repeated — the caller keeps its capacity)
+        const uint32_t need = redo && mx == cap_rows + 1 ? 1u : (uint32_t)mx;
+        xinfo[0] = mx > cap_rows ? 0u : (uint32_t)total; xinfo[1] = (uint32_t)mine; xinfo[2] = mx > cap_rows ? 1u : 0u; xinfo[3] = need;
+        if (h_xinfo) { h_xinfo[0] = (uint32_t)total; h_xinfo[1] = (uint32_t)mine; h_xinfo[2] = mx > cap_rows ? 1u : 0u; h_xinfo[3] = need; }   // pinned mirror
     }
     if (mx > cap_rows || i >= n_r) return;
     const uint8_t *row = recv + r * send_bytes + (i + 1) * (uint64_t)slot_bytes;
@@ -909,14 +1026,16 @@ __global__ __launch_bounds__(256) void k_xg_unpack(const uint8_t *recv, uint32_t
     g_len[off + i] = (uint16_t)src[stride / 16].x;
 }
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
-                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo, uint32_t *zero2)
+                            char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo, uint32_t *zero2,
+                            unsigned long long *dd_keys, uint32_t *dd_first, uint32_t dd_size)
 {
     CRASS_LAUNCH(k_xg_unpack, dim3((unsigned)((cap_rows + 255) / 256), world), dim3(256), 0, st, recv, world, rank, stride, cap_rows,
-                       slot_bytes, g_chars, g_len, xinfo, h_xinfo, zero2);
+                       slot_bytes, g_chars, g_len, xinfo, h_xinfo, zero2, dd_keys, dd_first, dd_keys ? dd_size : 0u);
     return hipGetLastError();
 }
 
-hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done, hipStream_t view_st, hipEvent_t ev_fork, hipEvent_t ev_view)
+hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done, hipStream_t view_st, hipEvent_t ev_fork, hipEvent_t ev_view,
+                               hipEvent_t ev_apply)
 {
     if (M.n_tok == 0) return hipErrorInvalidValue;
     const unsigned nb = (M.n_tok + 255) / 256;
@@ -940,7 +1059,9 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done
         CRASS_LAUNCH(k_dmx_count, dim3(nt), dim3(DMX_BLOCK), 0, view_st, M);
         CRASS_LAUNCH(k_dmx_tiles, dim3(nt), dim3(1024), 0, view_st, M);
         CRASS_LAUNCH(k_dmx_apply, dim3(nt), dim3(1024), 0, view_st, M);
+        if (ev_apply) { e = hipEventRecord(ev_apply, view_st); if (e != hipSuccess) return e; }
         CRASS_LAUNCH(k_dmx_place, dim3(nt), dim3(DMX_BLOCK), 0, view_st, M);
+        CRASS_LAUNCH(k_dmx_sort, dim3(std::min<unsigned>((M.n_tok + 64) / 65, std::max(1u, M.n_cu))), dim3(1024), 0, view_st, M);      // (a sorted group has >= 65 members)
         CRASS_LAUNCH(k_dmx_rank, dim3(std::min<unsigned>((M.n_tok + 63) / 64, std::max(1u, M.n_cu))), dim3(64 * DMX_RW), 0, view_st, M);
         e = hipEventRecord(ev_view, view_st);
         if (e != hipSuccess) return e;

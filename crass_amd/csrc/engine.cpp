@@ -170,6 +170,7 @@ struct EnvSwitches {
     bool no_device_view = false;                     // A/B switch: the host rebuilds crass_merge_view from root_of / blank (the round-3 path)
     bool force_device_view = false;                  // CRASS_DEVICE_VIEW=1: the device assembles it for a single context too (default: multi-rank only)
     uint32_t view_group_cap = 32768;                 // groups beyond this many members are ranked by the host (CRASS_VIEW_GROUP_CAP)
+    uint32_t view_sort_max = 2048;                   // groups of 65 .. this many members are ranked by a sort in LDS (k_dmx_sort; CRASS_VIEW_SORT_MAX: tests)
     uint64_t test_bounds[4] = {0, 0, 0, 0};          // tests: CRASS_TEST_BOUNDS="survivors,distinct,flagged,gathered" replaces the
                                                      // first-call bounds (0 = computed), so that every overflow path can be forced
     uint32_t row_cap = 256, dm_group_cap = 16384, surv_debug = 0;     // row_cap: Levenshtein fallback rows of the long-read layout (strings beyond it: second launch, full rows)
@@ -186,6 +187,7 @@ struct EnvSwitches {
         no_speculation = on("CRASS_NO_SPECULATION"); exc_separate = on("CRASS_EXC_SEPARATE"); dm_init_late = on("CRASS_DM_INIT_LATE");
         dm_inject_fail = on("CRASS_DM_INJECT_FAIL"); no_presize = on("CRASS_NO_PRESIZE"); no_device_view = on("CRASS_NO_DEVICE_VIEW"); dd_full_table = on("CRASS_DD_FULL_TABLE"); force_device_view = on("CRASS_DEVICE_VIEW");
         view_group_cap = 32768; if (const char *e = getenv("CRASS_VIEW_GROUP_CAP")) view_group_cap = (uint32_t)std::max(1, atoi(e));
+        view_sort_max = 2048; if (const char *e = getenv("CRASS_VIEW_SORT_MAX")) view_sort_max = (uint32_t)std::min(2048, std::max(64, atoi(e)));
         row_cap = 256; if (const char *e = getenv("CRASS_ROW_CAP")) row_cap = (uint32_t)std::max(1, atoi(e));
         dm_group_cap = 16384; if (const char *e = getenv("CRASS_DM_GROUP_CAP")) dm_group_cap = (uint32_t)std::max(1, atoi(e));
         surv_debug = 0; if (const char *e = getenv("CRASS_SURV_DEBUG")) surv_debug = (uint32_t)atoi(e);
@@ -400,14 +402,16 @@ struct crass_hip_ctx {
         PinBuf<uint32_t> h_gmap; PinBuf<char> h_gx_chars; PinBuf<uint16_t> h_gx_len; PinBuf<uint64_t> h_gx_hash;
         std::vector<uint32_t> cand_map;
         hipEvent_t ev_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+        uint32_t want_post = 0;                     // the stage flag value pass 2's probe stores for this merge (h_flags[2])
         // crass_merge_view assembled on the device (k_dmx_*, dmerge.hip): scratch, the dense blob, its totals; the blob
         // reaches h_view on a DMA engine (dma_view) started by the helper thread once ev_view has fired
         DevBuf<uint32_t> x_u32, x_members, x_tile; DevBuf<uint8_t> x_blob; DevBuf<DevViewTotals> x_tot;
         PinBuf<DevViewTotals> x_htot; PinBuf<uint8_t> h_view;
-        hipStream_t view_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_view = nullptr;
-        SdmaCopy *dma_view = nullptr;
+        hipStream_t view_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_view = nullptr, ev_apply = nullptr;
+        SdmaCopy *dma_view = nullptr, *dma_view2 = nullptr;      // (the blob travels in two pieces: the token half behind k_dmx_apply, the rest behind the last kernel)
         bool hx_on_host = true;                     // the gathered distinct list has a pinned host copy (else: on the device only)
         bool view_launched = false;                 // export kernels may be running on view_stream (ev_view orders after them)
+        bool apply_recorded = false;                // ev_apply was recorded behind this merge's k_dmx_apply
         bool view_ready = false;                    // h_view holds the view of the current merge (crass_hip_get_merge reads it)
         DevViewTotals view_tot{};
         void release()
@@ -425,6 +429,9 @@ struct crass_hip_ctx {
             ev_done = ev_t0 = ev_t1 = nullptr;
             if (view_stream) (void)hipStreamSynchronize(view_stream);
             sdma_destroy(dma_view); dma_view = nullptr;
+            sdma_destroy(dma_view2); dma_view2 = nullptr;
+            if (ev_apply) (void)hipEventDestroy(ev_apply);
+            ev_apply = nullptr;
             if (ev_fork) (void)hipEventDestroy(ev_fork);
             if (ev_view) (void)hipEventDestroy(ev_view);
             if (view_stream) (void)hipStreamDestroy(view_stream);
@@ -475,8 +482,8 @@ struct crass_hip_ctx {
     uint32_t n_bound_overflows[4] = {0, 0, 0, 0};   // speculation bounds that turned out too small (stage repeated): survivors, distinct, flagged, gathered
     hipEvent_t ev[12]{};
     // stage timing (crass_hip_set_stage_timing): an event record costs ~6 us of stream time, 14 of them 8 % of a 1 ms step.
-    // 0 none, 1 the three large kernels only (seed scan, survivors, pass-2 scan), 2 every stage
-    int timing_level = 1;
+    // 0 none (the default: a crass run reads no stage times), 1 the three large kernels only (seed scan, survivors, pass-2 scan), 2 every stage
+    int timing_level = 0;
     // single-pass compaction (k_mask_compact_lb): status words + ticket counter shared by every launch of the context
     DevBuf<unsigned long long> lb_status; DevBuf<uint32_t> lb_ticket; PinBuf<uint32_t> h_lb_fail;
     uint32_t lb_epoch = 0;
@@ -539,6 +546,36 @@ struct crass_hip_ctx {
     bool premerge_inflight = false;                 // merge kernels may still be running when the seed scan returns
     double t_p1_sync = 0;                           // CRASS_MERGE_PROFILE: host time line between pass 1 and the merge
     bool spans_p1 = false, spans_p2 = false, span_survivors = false;     // spans to evaluate at the next counters fetch
+    // Deferred pass-1 tail (crass_hip_exchange_set_deferred; a rank of a multi-rank job): crass_hip_seed_scan queues pass 1 up to the
+    // kernel that fills the exchange's send buffer and RETURNS — the caller queues the collective and crass_hip_merge_gathered its
+    // kernels behind it on the same stream, and only then does the host wait for pass 1's counters (p1_finish).  The ~60 us the
+    // device idled between pass 1's last kernel and the exchange (host wake-up, the collective's and the unpack's launches) are
+    // gone.  The counters of the deferred stage land in h_count[16..24) (the exchange's kernels rewrite h_count[0..8) meanwhile).
+    // A launch that turns out unusable (bound too small, no device-resident distinct list) was marked by k_xg_fill in the send
+    // buffer's header from the same counters: every rank then sees an exchange that "did not fit" and the step is repeated, this
+    // context's next seed scan running synchronously (force_sync).
+    // Stage flags (DevMerge::flag_pre, engine_internal.h): pinned words stored by the first kernel of a stage; the host polls them
+    // where it used to wait for an event recorded between two kernels.  [0] pass 1 complete (k_xg_fill, deferred pass 1),
+    // [1] everything in front of the merge complete (k_dm_pack_codes), [2] the merge complete (pass 2's probe).  A poll that runs
+    // out of its budget falls back to a stream synchronisation (CRASS_NO_POLL: the events of round 5, the A/B switch).
+    PinBuf<uint32_t> h_flags; uint32_t flag_seq = 0, want_p1 = 0, want_pre = 0, want_post = 0; bool poll_on = false;
+    mutable std::atomic<uint32_t> n_poll_timeouts{0};
+    bool poll_flag(int k, uint32_t want, double budget_ms) const
+    {
+        const volatile uint32_t *f = h_flags.p + k;
+        const double t0 = now_ms();
+        for (uint32_t it = 0;; it++) {
+            if ((int32_t)(*f - want) >= 0) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
+            __builtin_ia32_pause();
+            if ((it & 255u) == 255u && now_ms() - t0 > budget_ms) { n_poll_timeouts++; return false; }
+        }
+    }
+    struct P1Deferred {
+        bool enabled = false, active = false, finishing = false, force_sync = false;
+        uint64_t n_bound = 0; uint32_t ss_cap = 0, ss_elem = 1;
+        bool fast = false, hint_filtered = false;
+    } p1d;
+    const uint32_t *p1_counts() const { return p1d.finishing ? h_count.p + 16 : h_count.p; }
     // level 1 only: which of the three large kernels are bracketed (bit 0 seed scan, 1 survivors, 2 pass-2 scan)
     unsigned timing_focus = 7;
     bool timed(int i, int level) const
@@ -700,6 +737,9 @@ int crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out)
     }
     // (hint_stream and its events: created with the first long-read set, setup_pos_hints)
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
+    if (c->h_flags.ensure(8) != hipSuccess) { delete c; return CRASS_ERR_OOM; }
+    memset(c->h_flags.p, 0, 32);
+    c->poll_on = getenv("CRASS_NO_POLL") == nullptr;
     if (hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ev_premerge, hipEventDisableTiming) != hipSuccess) { delete c; return CRASS_ERR_HIP; }
     c->dma = sdma_create();                             // (nullptr: the copy kernel is used)
@@ -770,7 +810,8 @@ void crass_hip_destroy(crass_hip_ctx *c)
     if (c->hint_stream) (void)hipStreamSynchronize(c->hint_stream);
     (void)sdma_wait(c->dma);                            // (before any buffer goes)
     (void)c->wait_dx();
-    c->lb_status.release(); c->lb_ticket.release(); c->h_lb_fail.release();
+    if (getenv("CRASS_POLL_REPORT")) fprintf(stderr, "[crass_hip] stage-flag polls that ran out of their budget: %u (of %u flags)\n", c->n_poll_timeouts.load(), c->flag_seq);
+    c->lb_status.release(); c->lb_ticket.release(); c->h_lb_fail.release(); c->h_flags.release();
     if (c->xchg.ev_counts) (void)hipEventDestroy(c->xchg.ev_counts);
     c->dm.release(); c->h_qblob.release(); c->xchg.send.release(); c->xchg.xinfo.release(); c->xchg.h_xinfo.release();
     c->dd_map.release(); c->dd_dx_chars.release(); c->dd_dx_len.release(); c->dd_dx_hash.release();
@@ -822,7 +863,7 @@ static int alloc_scratch(crass_hip_ctx *c)
     HIPCHK(c, c->d_found.ensure(n + 1));
     HIPCHK(c, c->d_hit_info.ensure(n + 1));
     HIPCHK(c, c->d_ss_used.ensure(4));
-    HIPCHK(c, c->h_count.ensure(8));
+    HIPCHK(c, c->h_count.ensure(32));      // [0..8) the stage counters, [16..24) those of a deferred pass 1 (p1d)
     HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
     return CRASS_OK;
 }
@@ -905,6 +946,7 @@ static void presize_hostloop(crass_hip_ctx *c);
 static void reset_results(crass_hip_ctx *c)
 {
     quiesce_worker(c);
+    if (c->p1d.active) { (void)hipStreamSynchronize(c->stream); c->p1d.active = false; }      // (a deferred pass 1 nobody finished)
     (void)c->wait_bulk();               // (a hand-off copy still on its DMA engine: the buffers may be re-sized next, and a
                                         // free only waits for the device's queues)
     c->have_pass1 = c->have_merge = c->have_pass2 = c->have_patterns = false;
@@ -1424,7 +1466,10 @@ static int ensure_dense_buffers(crass_hip_ctx *c, uint64_t n_alloc, uint64_t poo
     return CRASS_OK;
 }
 
-static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t *d_nsurv, bool *overflow)
+static int dense_after_sync(crass_hip_ctx *c, uint64_t n_surv, uint32_t ss_cap, uint32_t ss_elem, bool dedupe, bool premerge_queued, bool *overflow);
+// defer: the launch is queued and the function returns WITHOUT waiting for it (c->p1d holds what dense_after_sync needs) — a rank
+// of a multi-rank job, whose exchange and merge can be queued behind pass 1 before the host has seen a count (p1_finish)
+static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t *d_nsurv, bool *overflow, bool defer = false)
 {
     *overflow = false;
     { const int hw = hint_wait_all(c); if (hw) return hw; }
@@ -1440,6 +1485,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     const uint64_t n_alloc = speculative ? n_surv : std::max<uint64_t>(n_surv, survivor_bound(n_surv));
     const uint32_t ss_elem = c->max_len <= 256 ? 1u : 2u;            // read positions fit a byte
     const bool dedupe = n_surv < (1u << 24);
+    const bool defer_ok = defer && dedupe && speculative && c->xchg.active;
     { const int as = ensure_dense_buffers(c, n_alloc, pool_cap, lds, dedupe); if (as) return as; }
     // [2] = found count, [3] = worst error, [4] = n distinct, [5] = de-duplication mismatch flag
     if (!speculative) {                                 // (speculative launch: cleared by the filter's compaction, see seed scan)
@@ -1523,40 +1569,61 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
         HIPCHK(c, launch_dx_tokens(D.d_dr.p, D.d_dr_len.p, c->dd_hash.p, stride, c->d_count.p + 2, (uint32_t)n_surv, c->dd_rep.p, c->dd_slot.p, c->dd_first.p, c->d_mask.p,
                                    c->d_word_prefix.p, c->d_block_sums.p, c->d_fidx.p, c->d_count.p + 4, c->d_count.p + 5, dxd ? c->dd_map.p : c->h_dmap.p,
                                    dxd ? nullptr : c->h_dx_chars.p, dxd ? nullptr : c->h_dx_len.p, dxd ? nullptr : c->h_dx_hash.p, c->dd_dx_chars.p, c->dd_dx_len.p, c->stream,
-                                   c->d_count.p, c->h_count.p, 8,           // (the counters leave with the last kernel: no copy call)
+                                   c->d_count.p, defer_ok ? c->h_count.p + 16 : c->h_count.p, 8,           // (the counters leave with the last kernel: no copy call)
                                    c->next_lookback_tiles((n_surv + 1023) / 1024, &lbd)));
         if (c->xchg.active)                             // multi-rank: the list goes straight into the collective's send buffer
-            HIPCHK(c, launch_xg_fill(c->dd_dx_chars.p, c->dd_dx_len.p, c->d_count.p + 4, stride, c->xchg.cap, c->xchg.slot, c->xchg.send.p, c->stream));
+            HIPCHK(c, launch_xg_fill(c->dd_dx_chars.p, c->dd_dx_len.p, c->d_count.p + 4, stride, c->xchg.cap, c->xchg.slot, c->xchg.send.p, c->stream,
+                                     defer_ok ? c->d_count.p : nullptr, n_surv,
+                                     (defer_ok && c->poll_on) ? c->h_flags.p : nullptr, (defer_ok && c->poll_on) ? (c->want_p1 = ++c->flag_seq) : 0u));
     }
     if (!dedupe) HIPCHK(c, hipMemcpyAsync(c->h_count.p, c->d_count.p, 32, hipMemcpyDeviceToHost, c->stream));
     bool premerge_queued = false;
     c->premerge = 0;
     D.wide_ready = false; D.dr_fallback = false;
     D.pack_ss_cap = lds.ss_cap;
-    HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
     // The merge itself is queued here too when the previous call's merge ran on the device: its kernels read the token
     // count from the device (d_count[4]) and are sized by a bound; crass_hip_merge adopts the result if the counts fit.
-    if (speculative && dedupe && !c->xchg.active && c->dm_prev_local && c->dx_cap_hint && c->prm.lowDRsize >= 23 && stride <= 64 &&
-        !c->env.host_merge && !c->env.no_speculation) {
+    const bool will_premerge = speculative && dedupe && !c->xchg.active && c->dm_prev_local && c->dx_cap_hint && c->prm.lowDRsize >= 23 && stride <= 64 &&
+                               !c->env.host_merge && !c->env.no_speculation;
+    // (what the host waits for when the merge is queued behind pass 1, or pass 1 deferred: a stage flag — else this event)
+    if (!c->poll_on && (will_premerge || defer_ok)) HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
+    if (will_premerge) {
         const bool prepared = c->dm_prepared_n == c->dx_cap_hint && c->dm_prepared_src == c->dd_dx_chars.p;
         const int ps = device_merge_enqueue(c, c->dd_dx_chars.p, c->dd_dx_len.p, c->dx_cap_hint, c->d_count.p + 4, prepared);
         if (ps) return ps;
         premerge_queued = true;
-        HIPCHK(c, hipEventRecord(c->ev_premerge, c->stream));
+        // (only the fall-back order of the hand-off copy — no DMA engine — waits for this event)
+        if (!c->poll_on || !c->dma) HIPCHK(c, hipEventRecord(c->ev_premerge, c->stream));
     }
     host_pool_warm();                                   // the merge follows: wake the host workers while the device finishes
+    if (defer_ok) {
+        c->p1d.active = true; c->p1d.n_bound = n_surv; c->p1d.ss_cap = lds.ss_cap; c->p1d.ss_elem = ss_elem;
+        return CRASS_OK;
+    }
+    return dense_after_sync(c, n_surv, lds.ss_cap, ss_elem, dedupe, premerge_queued, overflow);
+}
+
+// the host's half of the dense pass-1 tail: waits for the kernels queued by run_survivors_dense, reads the counters they left in
+// pinned memory, starts the hand-off copies
+static int dense_after_sync(crass_hip_ctx *c, uint64_t n_surv, uint32_t ss_cap, uint32_t ss_elem, bool dedupe, bool premerge_queued, bool *overflow)
+{
+    crass_hip_ctx::P1Dense &D = c->dense;
+    const uint32_t stride = c->dr_stride;
     // (with the merge queued behind it, the host waits for pass 1 only — the event recorded above — and goes on to
     // adopt the merge and queue pass 2 while the merge kernels run)
-    if (premerge_queued) HIPCHK(c, hipEventSynchronize(c->ev_gathered));
-    else HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (premerge_queued || c->p1d.finishing) {
+        if (!c->poll_on) HIPCHK(c, hipEventSynchronize(c->ev_gathered));
+        else if (!c->poll_flag(c->p1d.finishing ? 0 : 1, c->p1d.finishing ? c->want_p1 : c->want_pre, 200.0)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else HIPCHK(c, hipStreamSynchronize(c->stream));
     c->premerge_inflight = premerge_queued;
     c->t_p1_sync = now_ms();
-    if (c->h_count.p[0] > n_surv) { *overflow = true; return CRASS_OK; }
-    const uint64_t nf = c->h_count.p[2];
-    const uint32_t err = c->h_count.p[3];
+    const uint32_t *hc = c->p1_counts();
+    if (hc[0] > n_surv) { *overflow = true; return CRASS_OK; }
+    const uint64_t nf = hc[2];
+    const uint32_t err = hc[3];
     if (err == 1) return CRASS_ERR_SEARCH_FATAL;
     if (err) return CRASS_ERR_OVERFLOW;
-    D.lay = p1_blob_layout(nf, lds.ss_cap, ss_elem);
+    D.lay = p1_blob_layout(nf, ss_cap, ss_elem);
     if (nf) {
         // the hand-off records: the host has waited for the gather, the copy runs beside what follows.  As PCIe stores from
         // shader waves (the runtime's blit kernel or ours) it cost the kernels beside it its own 0.2-0.3 ms wherever it was
@@ -1582,8 +1649,8 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     }
     if (nf) {
         if (dedupe) {
-            if (c->h_count.p[5] == 0) {
-                c->n_dx = c->h_count.p[4];
+            if (hc[5] == 0) {
+                c->n_dx = hc[4];
                 c->have_dev_tokens = true;
                 c->dx_hash_valid = !c->dx_via_dma;
                 if (c->dx_via_dma) {
@@ -1601,7 +1668,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
                 }
                 if (premerge_queued && c->n_dx > 0 && c->n_dx <= c->dx_cap_hint) c->premerge = 2;
                 else if (premerge_queued && c->n_dx > c->dx_cap_hint) c->n_bound_overflows[1]++;     // (crass_hip_merge launches its own)
-            } else if (c->h_count.p[5] & 2u) {
+            } else if (hc[5] & 2u) {
                 // the de-duplication table was sized for fewer distinct strings than there are: nothing of it is usable.  The
                 // candidates' own strings travel, the host de-duplicates them, and later calls size the table for the slots.
                 c->dd_full_table = true;
@@ -1752,11 +1819,14 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     c->have_pass1 = c->have_merge = c->have_pass2 = false;
     c->dm.active = false;
     c->premerge_inflight = false;
+    c->p1d.active = false;                  // (a deferred pass 1 nobody finished: its kernels are ahead of this scan's on the stream, its results dropped)
+    const bool defer_p1 = c->p1d.enabled && !c->p1d.force_sync && c->xchg.active;
+    c->p1d.force_sync = false;
     // (the survivor kernel clears the merge's words, x_* included: behind whatever export of a merge nobody adopted)
     if (c->dm.view_launched) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->dm.ev_view, 0)); c->dm.view_launched = false; }
     const uint64_t n = c->R.n_reads;
     const uint64_t n_words = (n + 63) / 64;
-    HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));
+    bool found_cleared = false;                 // (the fixed-range filter kernel clears the found flags on its way)
     HIPCHK(c, c->stamp(0, 1));
     // step 1: filter.  Reads longer than 2 kbp almost surely contain a spurious lattice hit
     // (P ~ seeds*49/4^w), so the filter is skipped and every read goes to the survivor kernel.
@@ -1768,7 +1838,10 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     if (use_filter) {
         hipError_t fe = hipErrorNotSupported;
         // (uniform STRIDE is what the bit-parallel kernel needs; the lengths may differ — trimmed reads padded to one stride)
-        if (c->R.stride_words >= 4 && c->R.stride_words <= 16) fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->d_hit_info.p, c->stream);
+        static const bool found_memset = getenv("CRASS_FOUND_MEMSET") != nullptr;      // A/B switch: the fill kernel in front of the scan
+        if (c->R.stride_words >= 4 && c->R.stride_words <= 16)
+            fe = launch_filter_fast(c->R, c->dp, c->d_mask.p, c->d_hit_info.p, c->stream, found_memset ? nullptr : c->d_found.p, &found_cleared);
+        if (fe != hipSuccess) found_cleared = false;
         if (fe == hipSuccess) fast = true;
         else if (fe == hipErrorNotSupported && c->hint_filter && c->R.pos_hint && !c->hint_filter_any) {
             // no lane-per-read filter for this layout: one hint bit per lattice position (the long reads' kernel), which also flags the reads that have one.
@@ -1807,6 +1880,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
         }
     }
     c->hints_valid = fast;
+    if (!found_cleared) HIPCHK(c, hipMemsetAsync(c->d_found.p, 0, n + 1, c->stream));      // (in front of the survivor kernels, which set them)
     HIPCHK(c, c->stamp(1, 1));
     // step 2: ordered compaction
     // (the scan kernel also clears the survivor stage's counters: d_count[2..6) and the start/stop pool cursor)
@@ -1830,8 +1904,15 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     if (use_filter && exc_ok && c->surv_cap_hint && !c->env.no_speculation) {
         bool overflow = false;
         HIPCHK(c, c->stamp(3, 2));
-        s = run_survivors_dense(c, c->surv_cap_hint, c->d_count.p, &overflow);
+        s = run_survivors_dense(c, c->surv_cap_hint, c->d_count.p, &overflow, defer_p1);
         if (s != CRASS_OK && s != CRASS_ERR_STATE) return s;
+        if (s == CRASS_OK && c->p1d.active) {
+            // queued up to the send buffer's fill kernel, not waited for: p1_finish does the rest when the caller has queued the
+            // exchange and crass_hip_merge_gathered its kernels (or when anybody asks for pass 1's results)
+            c->p1d.fast = fast; c->p1d.hint_filtered = hint_filtered;
+            HIPCHK(c, c->stamp(4, 2));
+            return CRASS_OK;
+        }
         if (s == CRASS_OK) {
             n_surv = c->h_count.p[0];
             if (overflow) c->n_bound_overflows[0]++;
@@ -1950,9 +2031,59 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     return c->lookback_ok();
 }
 
+// The host's half of a deferred pass 1 (p1d).  CRASS_OK: the context is where a synchronous crass_hip_seed_scan leaves it.
+// kP1Redo: the speculative launch cannot be used — k_xg_fill marked the send buffer from the same counters, so every rank of the
+// job sees an exchange that did not fit and repeats the step; this context's next seed scan runs synchronously.
+static constexpr int kP1Redo = 1000;
+static int p1_finish(crass_hip_ctx *c)
+{
+    if (!c->p1d.active) return CRASS_OK;
+    c->p1d.active = false;
+    c->p1d.finishing = true;
+    bool overflow = false;
+    const int s = dense_after_sync(c, c->p1d.n_bound, c->p1d.ss_cap, c->p1d.ss_elem, true, false, &overflow);
+    const uint64_t n_surv = c->h_count.p[16];
+    c->p1d.finishing = false;
+    if (s != CRASS_OK) { c->p1d.force_sync = true; (void)hipStreamSynchronize(c->stream); return s; }
+    if (overflow) c->n_bound_overflows[0]++;
+    c->surv_cap_hint = survivor_bound(n_surv);
+    const bool usable = !overflow && n_surv != 0 && c->dense.active && (c->dense.n == 0 || c->have_dev_tokens);
+    if (!usable) {
+        c->dense.active = false; c->have_dev_tokens = false;
+        c->p1d.force_sync = true;
+        HIPCHK(c, hipStreamSynchronize(c->stream));       // (whatever was queued behind the launch worked on nothing usable)
+        return kP1Redo;
+    }
+    c->have_pass1 = true;
+    c->cnt.ms_sink_host = 0;
+    c->cnt.n_filter_survivors = n_surv + (c->dp.exc_survive ? 0 : c->R.n_exc);
+    c->cnt.n_pass1_found = c->n_cand();
+    c->cnt.used_fast_filter = c->p1d.fast ? 1 : (c->p1d.hint_filtered ? 2 : 0);
+    c->spans_p1 = true; c->span_survivors = n_surv != 0;
+    return c->lookback_ok();
+}
+// every entry point that reads pass 1's results, other than crass_hip_merge_gathered: a launch that cannot be used is repeated
+// here, synchronously (the send buffer is refilled; a caller that had already gathered it sees the redo mark in what it gathered)
+static int settle_p1(crass_hip_ctx *c)
+{
+    if (!c->p1d.active) return CRASS_OK;
+    const int s = p1_finish(c);
+    if (s == kP1Redo) return crass_hip_seed_scan(c);
+    return s;
+}
+
+int crass_hip_exchange_set_deferred(crass_hip_ctx *c, int on)
+{
+    if (!c) return CRASS_ERR_INVALID_ARG;
+    if (!on) { const int s = settle_p1(c); if (s) return s; }
+    c->p1d.enabled = on != 0 && !c->env.no_speculation && getenv("CRASS_NO_DEFER_P1") == nullptr;
+    return CRASS_OK;
+}
+
 int crass_hip_get_candidates(const crass_hip_ctx *c, crass_candidates *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    if (c->p1d.active) { const int ds = settle_p1(const_cast<crass_hip_ctx *>(c)); if (ds) return ds; }
     if (!c->have_pass1) return CRASS_ERR_STATE;
     if (const int bs = c->wait_bulk()) return bs;
     if (c->dense.active) {
@@ -2124,17 +2255,20 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
             HIPCHK(c, hipStreamCreateWithPriority(&d.view_stream, hipStreamNonBlocking, view_same_prio ? 0 : prio_lo));
             HIPCHK(c, hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&d.ev_view, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&d.ev_apply, hipEventDisableTiming));
             d.dma_view = sdma_create();                 // (nullptr: the runtime's copy is used)
+            d.dma_view2 = sdma_create();
         }
         const uint64_t cap = view_layout(n, n, 2ull * n, (uint64_t)n * stride, 2ull * n * stride).total;
         HIPCHK(c, d.x_u32.ensure((size_t)n * 8)); HIPCHK(c, d.x_members.ensure(n)); HIPCHK(c, d.x_tile.ensure(kDmxTiles * kDmxVals + 4));
-        HIPCHK(c, d.x_blob.ensure(cap + 64)); HIPCHK(c, d.x_tot.ensure(1)); HIPCHK(c, d.x_htot.ensure(1));
+        HIPCHK(c, d.x_blob.ensure(cap + 64)); HIPCHK(c, d.x_tot.ensure(1)); HIPCHK(c, d.x_htot.ensure(2));      // (x_htot[1]: the totals as k_dmx_apply published them)
         if (!d.h_view.p) HIPCHK(c, d.h_view.ensure(std::max<uint64_t>(cap / 4, 1u << 16)));      // (grown by the build if a merge needs more)
         uint32_t *x = d.x_u32.p;
         M.x_size = x; M.x_kept = x + n; M.x_kchars = x + 2ull * n; M.x_fill = x + 3ull * n;
         M.x_gid = x + 4ull * n; M.x_goff = x + 5ull * n; M.x_pat0 = x + 6ull * n; M.x_pch0 = x + 7ull * n;
         M.x_members = d.x_members.p; M.x_tile = d.x_tile.p; M.x_blob = d.x_blob.p; M.x_tot = d.x_tot.p; M.x_htot = d.x_htot.p;
         M.x_group_cap = c->env.view_group_cap;
+        M.x_sort_max = c->env.view_sort_max;
     }
     M.inject_fail = c->env.dm_inject_fail ? 1u : 0u;
     M.group_cap = c->env.dm_group_cap;
@@ -2155,15 +2289,20 @@ static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const ui
     const double tl0 = now_ms();
     if (d.view_launched) HIPCHK(c, hipStreamWaitEvent(c->stream, d.ev_view, 0));     // (an abandoned merge's export still owns the x_* words)
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
+    d.M.flag_pre = c->poll_on ? c->h_flags.p + 1 : nullptr; d.M.flag_pre_val = c->want_pre = ++c->flag_seq;
+    d.M.flag_post = c->poll_on ? c->h_flags.p + 2 : nullptr; d.M.flag_post_val = d.want_post = ++c->flag_seq;
     static const bool view_inline = getenv("CRASS_VIEW_INLINE") != nullptr;      // A/B switch: the export on the merge's own stream
-    HIPCHK(c, launch_device_merge(d.M, c->stream, prepared, d.M.x_on ? (view_inline ? c->stream : d.view_stream) : nullptr, d.ev_fork, d.ev_view));
+    HIPCHK(c, launch_device_merge(d.M, c->stream, prepared, d.M.x_on ? (view_inline ? c->stream : d.view_stream) : nullptr, d.ev_fork, d.ev_view,
+                                  view_inline ? nullptr : d.ev_apply));
+    d.apply_recorded = d.M.x_on && !view_inline;
     d.view_launched = d.M.x_on != 0;
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t1, c->stream));
     if (c->env.merge_profile)
         fprintf(stderr, "[crass_dm] host: pass-1 sync -> merge launch start %.1f us, launching the merge kernels %.1f us\n",
                 1e3 * (tl0 - c->t_p1_sync), 1e3 * (now_ms() - tl0));
-    // the per-token results the host view is rebuilt from (a few 10 KB)
-    HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
+    // the per-token results the host view is rebuilt from (a few 10 KB): the helper thread polls the stage flag that pass 2's
+    // probe stores, or waits for this event
+    if (!c->poll_on) HIPCHK(c, hipEventRecord(d.ev_done, c->stream));
     return CRASS_OK;
 }
 
@@ -2283,7 +2422,10 @@ static int build_host_merge(crass_hip_ctx *c)
         if (tl_device != c->device) { (void)hipSetDevice(c->device); tl_device = c->device; }
     }
     auto wait_done = [&]() -> int {
-        const hipError_t e = hipEventSynchronize(d.ev_done);
+        // (the probe of pass 2 is normally queued right behind the merge; a caller that asks for the merge's view without running
+        // pass 2 gets it after the poll's budget)
+        if (c->poll_on && c->poll_flag(2, d.want_post, 1.0)) return CRASS_OK;
+        const hipError_t e = c->poll_on ? hipStreamSynchronize(c->stream) : hipEventSynchronize(d.ev_done);
         if (e != hipSuccess) { d.br.hip = (int)e; return e == hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP; }
         return CRASS_OK;
     };
@@ -2338,18 +2480,38 @@ static int build_host_merge(crass_hip_ctx *c)
             c->merge.cand_token[k] = cmap[k] + 2;
         }
         const double tv0 = now_ms();
+        // the token half of the blob (tok_off, the token strings, grp_off: ~70 % of its bytes) is complete behind k_dmx_apply: its
+        // copy starts now, beside the kernels that rank the members; what is left for the end is the second piece (2.25 MB in one
+        // piece were 50 us behind the last kernel, the end of a rank's step at 100 M reads over 8 GPUs)
+        uint64_t early = 0;
+        static const bool one_piece = getenv("CRASS_VIEW_ONE_COPY") != nullptr;      // A/B switch
+        if (d.apply_recorded && !one_piece && d.dma_view && d.dma_view2) {
+            const hipError_t e = hipEventSynchronize(d.ev_apply);
+            if (e != hipSuccess) { d.br.hip = (int)e; return CRASS_ERR_HIP; }
+            const DevViewTotals E = d.x_htot.p[1];
+            if (E.ok && E.n_tok == d.n_tok && E.lay.total <= d.x_blob.n && E.lay.grp_tokens <= E.lay.total) {
+                if (d.h_view.n < E.lay.total) {
+                    const hipError_t e2 = d.h_view.ensure(E.lay.total + E.lay.total / 2);
+                    if (e2 != hipSuccess) { d.br.hip = (int)e2; return e2 == hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP; }
+                }
+                if (sdma_start(d.dma_view2, d.x_blob.p, d.h_view.p, E.lay.grp_tokens)) early = E.lay.grp_tokens;
+            }
+        }
+        struct EarlyCopy { SdmaCopy *s; bool on; ~EarlyCopy() { if (on) (void)sdma_wait(s); } } early_guard{d.dma_view2, early != 0};      // (no exit leaves it in flight)
         if (const int ws = wait_done()) return ws;
         if (d.h_st.p->fail) return CRASS_ERR_STATE;
         { const hipError_t e = hipEventSynchronize(d.ev_view); if (e != hipSuccess) { d.br.hip = (int)e; return CRASS_ERR_HIP; } }
         const double tv1 = now_ms();
         const DevViewTotals T = *d.x_htot.p;
         if (T.ok && T.n_tok == d.n_tok && 2u * T.n_kept == d.h_st.p->n_patterns && T.n_groups >= 1 && T.lay.total <= d.x_blob.n) {
+            if (early && (d.h_view.n < T.lay.total || early != T.lay.grp_tokens)) { (void)sdma_wait(d.dma_view2); early_guard.on = false; early = 0; }   // (never expected)
             if (d.h_view.n < T.lay.total) {
                 const hipError_t e = d.h_view.ensure(T.lay.total + T.lay.total / 2);
                 if (e != hipSuccess) { d.br.hip = (int)e; return e == hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP; }
             }
             bool copied = false;
-            if (sdma_start(d.dma_view, d.x_blob.p, d.h_view.p, T.lay.total)) copied = sdma_wait(d.dma_view) == 0;
+            if (sdma_start(d.dma_view, d.x_blob.p + early, d.h_view.p + early, T.lay.total - early)) copied = sdma_wait(d.dma_view) == 0;
+            if (early) { early_guard.on = false; if (sdma_wait(d.dma_view2) != 0) { copied = false; early = 0; } }
             if (!copied) {
                 hipError_t e = hipMemcpyAsync(d.h_view.p, d.x_blob.p, T.lay.total, hipMemcpyDeviceToHost, d.view_stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(d.view_stream);
@@ -2400,6 +2562,7 @@ static int build_host_merge(crass_hip_ctx *c)
 int crass_hip_merge(crass_hip_ctx *c, const char *dr_chars, const uint16_t *dr_len, uint32_t dr_stride, uint64_t n)
 {
     if (!c) return CRASS_ERR_INVALID_ARG;
+    if (c->p1d.active) { const int ds = settle_p1(c); if (ds) return ds; }
     const double t0 = now_ms();
     quiesce_worker(c);
     c->dm.active = false;
@@ -2500,6 +2663,7 @@ static void ensure_distinct(crass_hip_ctx *c)
 int crass_hip_get_distinct(crass_hip_ctx *c, crass_distinct *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    if (c->p1d.active) { const int ds = settle_p1(c); if (ds) return ds; }
     if (!c->have_pass1) return CRASS_ERR_STATE;
     ensure_distinct(c);
     o->dr_stride = c->dr_stride;
@@ -2577,6 +2741,7 @@ int crass_hip_merge_distinct(crass_hip_ctx *c, const char *dr_chars, const uint1
                              uint64_t n_global, uint64_t my_offset)
 {
     if (!c || (n_global && (!dr_chars || !dr_len || !dr_stride))) return CRASS_ERR_INVALID_ARG;
+    if (c->p1d.active) { const int ds = settle_p1(c); if (ds) return ds; }
     if (!c->have_pass1) return CRASS_ERR_STATE;
     const double t0 = now_ms();
     quiesce_worker(c);
@@ -2623,6 +2788,7 @@ int crass_hip_exchange_setup(crass_hip_ctx *c, uint32_t world, uint32_t rank, ui
 #define XDBG(msg) do { if (dbg) { fprintf(stderr, "[crass_xchg] rank %u: %s\n", rank, msg); fflush(stderr); } } while (0)
     XDBG("setup: quiesce");
     quiesce_worker(c);
+    c->p1d.active = false;                              // (a deferred pass 1 nobody finished: dropped; the stream is waited for below)
     XDBG("setup: stream sync");
     HIPCHK(c, hipStreamSynchronize(c->stream));          // (kernels of an abandoned queued merge may still be running on the old buffers)
     X.world = world; X.rank = rank; X.cap = cap_rows; X.slot = c->dr_stride + 16; X.needed = 0;
@@ -2667,7 +2833,8 @@ uint64_t crass_hip_exchange_rows_for(uint64_t n_reads) { return distinct_bound_f
 int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
 {
     if (!c || !d_recv) return CRASS_ERR_INVALID_ARG;
-    if (!c->have_pass1 || !c->xchg.active) return CRASS_ERR_STATE;
+    const bool deferred = c->p1d.active;                // pass 1 is still running (or its counters unread): p1_finish below
+    if ((!c->have_pass1 && !deferred) || !c->xchg.active) return CRASS_ERR_STATE;
     const double t0 = now_ms();
     auto lap = [&](const char *what) { if (c->env.merge_profile) fprintf(stderr, "[crass_xg] %-28s +%.1f us\n", what, 1e3 * (now_ms() - t0)); };
     crass_hip_ctx::Xchg &X = c->xchg;
@@ -2681,19 +2848,21 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     const uint64_t n_max = X.world * X.cap;
     const uint32_t n = (uint32_t)n_max;
     HIPCHK(c, d.g_chars.ensure(n_max * (size_t)stride + 16)); HIPCHK(c, d.g_len.ensure(n_max + 1));
+    // (deferred: what device_merge_applies asks of pass 1's results is checked once they are known)
+    bool dev = (deferred ? (!c->env.host_merge && c->prm.lowDRsize >= 23 && c->dr_stride <= 64) : device_merge_applies(c)) && n_max <= (1u << 22);
+    uint32_t tsize = 1024;
+    while (tsize < n * 2) tsize <<= 1;
+    if (dev) { const int as = ensure_gathered_buffers(c, n_max); if (as) return as; }
+    lap("buffers ensured");
     HIPCHK(c, launch_xg_unpack((const uint8_t *)d_recv, X.world, X.rank, stride, X.cap, X.slot, d.g_chars.p, d.g_len.p, X.xinfo.p, c->stream,
-                               X.h_xinfo.p, c->d_count.p + 4));      // (the four counters also land in pinned host memory: no copy call;
+                               X.h_xinfo.p, c->d_count.p + 4,        // (the four counters also land in pinned host memory: no copy call;
                                                                      //  d_count[4..5] = the de-duplication's counters, cleared on the way)
+                               dev ? d.g_keys.p : nullptr, dev ? d.g_first.p : nullptr, tsize));      // (... and its table)
     lap("unpack queued");
-    bool dev = device_merge_applies(c) && n_max <= (1u << 22);
     if (dev) {
-        uint32_t tsize = 1024;
-        while (tsize < n * 2) tsize <<= 1;
-        { const int as = ensure_gathered_buffers(c, n_max); if (as) return as; }
-        lap("buffers ensured");
         // the global count lives on the device (xinfo[0]); n_max bounds it
         HIPCHK(c, launch_dr_dedupe(d.g_chars.p, d.g_len.p, stride, X.xinfo.p, n, d.g_keys.p, d.g_first.p, tsize, d.g_hash.p, d.g_slot.p, d.g_rep.p,
-                                   c->stream));
+                                   c->stream, true));
         Lookback lbg;
         // the global list's pinned copy is only read by the host-built view (3.7 MB of PCIe stores from the gather kernel at
         // 42 k tokens: 53 us); with the view exported by the device, or a light view, it stays on the device (fetch_host_list)
@@ -2709,16 +2878,30 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     lap("de-duplication queued");
     bool queued = false;
     if (dev && X.gx_cap_hint && X.gx_cap_hint <= n_max && !c->env.no_speculation) {
-        if (!X.ev_counts) HIPCHK(c, hipEventCreateWithFlags(&X.ev_counts, hipEventDisableTiming));
-        HIPCHK(c, hipEventRecord(X.ev_counts, c->stream));
+        if (!c->poll_on) {
+            if (!X.ev_counts) HIPCHK(c, hipEventCreateWithFlags(&X.ev_counts, hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(X.ev_counts, c->stream));
+        }
         const bool prepared = c->dm_prepared_n == X.gx_cap_hint && c->dm_prepared_src == d.gx_chars.p;
         c->dm_prepared_n = 0;                               // (a repeated exchange after an overflow starts from scratch)
         const int qs = device_merge_enqueue(c, d.gx_chars.p, d.gx_len.p, X.gx_cap_hint, c->d_count.p + 4, prepared);
         if (qs) return qs;
         queued = true;
         lap("merge queued");
-        HIPCHK(c, hipEventSynchronize(X.ev_counts));
-    } else HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (deferred) {
+        // everything of this step up to the merge is queued: now the host looks at pass 1
+        const int fs = p1_finish(c);
+        lap("pass 1 finished");
+        if (fs == kP1Redo) { X.needed = 1; X.gx_cap_hint = 0; return CRASS_ERR_OVERFLOW; }      // (every rank finds the mark in what it gathered)
+        if (fs) return fs;
+        if (dev && !device_merge_applies(c)) {          // (no device-resident distinct list after all, e.g. no candidate in this shard)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            dev = false; queued = false;
+        }
+    }
+    if (queued && !c->poll_on) HIPCHK(c, hipEventSynchronize(X.ev_counts));
+    else if (!(queued && c->poll_flag(1, c->want_pre, 200.0))) HIPCHK(c, hipStreamSynchronize(c->stream));      // (the merge's first kernel stores the flag)
     lap("counts on the host");
     const uint64_t n_global = X.h_xinfo.p[0], my_off = X.h_xinfo.p[1];
     if (X.h_xinfo.p[2]) { X.needed = X.h_xinfo.p[3]; X.gx_cap_hint = 0; return CRASS_ERR_OVERFLOW; }
@@ -2751,6 +2934,7 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
 int crass_hip_get_distinct_device(crass_hip_ctx *c, crass_distinct_dev *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
+    if (c->p1d.active) { const int ds = settle_p1(c); if (ds) return ds; }
     if (!c->have_pass1 || !c->dev_tokens()) return CRASS_ERR_STATE;
     o->n_distinct = c->n_dx; o->dr_stride = c->dr_stride; o->d_chars = c->dd_dx_chars.p; o->d_len = c->dd_dx_len.p;
     return CRASS_OK;
@@ -2760,6 +2944,7 @@ int crass_hip_merge_distinct_device(crass_hip_ctx *c, const char *d_chars, const
                                     uint64_t n_global, uint64_t my_offset)
 {
     if (!c || (n_global && (!d_chars || !d_len || !dr_stride))) return CRASS_ERR_INVALID_ARG;
+    if (c->p1d.active) { const int ds = settle_p1(c); if (ds) return ds; }
     if (!c->have_pass1) return CRASS_ERR_STATE;
     if (dr_stride != c->dr_stride) return CRASS_ERR_INVALID_ARG;
     const double t0 = now_ms();
@@ -2836,6 +3021,7 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     if (!c) return CRASS_ERR_INVALID_ARG;
     if (!c->have_reads) return CRASS_ERR_STATE;
     (void)hipSetDevice(c->device);
+    if (c->p1d.active) { const int ds = settle_p1(c); if (ds) return ds; }
     c->q_read.clear(); c->q_low.clear(); c->q_start.clear(); c->q_end.clear(); c->q_token.clear(); c->q_dr_len.clear(); c->q_dr.clear();
     c->have_pass2 = false;
     c->q_blob_active = false;
@@ -3143,6 +3329,7 @@ int crass_hip_get_counters(const crass_hip_ctx *c, crass_counters *o)
 {
     if (!c || !o) return CRASS_ERR_INVALID_ARG;
     crass_hip_ctx *m = const_cast<crass_hip_ctx *>(c);
+    if (m->p1d.active) { const int ds = settle_p1(m); if (ds) return ds; }
     if (m->spans_p1) {
         m->spans_p1 = false;
         m->cnt.ms_filter = c->span(0, 1, 1);

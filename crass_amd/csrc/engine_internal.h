@@ -208,6 +208,12 @@ struct DevMerge {
     DevViewTotals *x_htot;
     uint32_t x_on;                // 0: no export (the host rebuilds the view from h_root / h_blank)
     uint32_t x_group_cap;         // a group with more members than this is not ranked here (quadratic): the host builds the view
+    // stage flags (engine.cpp: crass_hip_ctx::h_flags): pinned host words that the FIRST kernel of a stage stores at system scope
+    // — everything queued in front of that kernel is then complete — for the host to poll instead of an event recorded
+    // between two kernels (~6 us of stream time each).  flag_pre: k_dm_pack_codes; flag_post: pass 2's probe
+    uint32_t *flag_pre; uint32_t flag_pre_val;
+    uint32_t *flag_post; uint32_t flag_post_val;
+    uint32_t x_sort_max;          // groups of 65 .. this many members (<= 2048) are ranked by k_dmx_sort, the others by k_dmx_rank
     uint32_t *hot;                // the counters every block adds to, striped: [kDmHotCounters][kDmHotStripes] words, 128 bytes apart (dm_hot)
     uint32_t ablate;              // profiling aid (CRASS_DM_ABLATE, tools/dm_ablate.py): bits switch parts of the merge kernels OFF — results are then garbage
     uint32_t inject_fail;         // tests only: start with the fail word set (exercises the fall-back to the host merge)
@@ -249,18 +255,30 @@ static __device__ __forceinline__ void dm_init_slice(const DevMerge &M, uint64_t
     }
 }
 
+// a stage flag's store: every write of the kernels in front of this one is visible to the host that sees it
+static __device__ __forceinline__ void stage_flag_store(uint32_t *flag, uint32_t val)
+{
+    __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // one-collective exchange (see crass_hip_exchange_setup): fill this rank's send buffer / unpack the gathered buffers
+// p1_counts / surv_bound (a deferred pass 1, engine.cpp p1d): the stage's device counters — [0] survivors, [2] found records,
+// [3] worst error, [5] de-duplication flags — are checked HERE, by the kernel that fills the send buffer: a launch the host will
+// find unusable (more survivors than the bound, none, an error, no exact distinct list) sets bit 63 of the header's count, which
+// every rank's k_xg_unpack reports as an exchange that did not fit
 hipError_t launch_xg_fill(const char *dx_chars, const uint16_t *dx_len, const uint32_t *d_nd, uint32_t stride, uint64_t cap_rows,
-                          uint32_t slot_bytes, uint8_t *send, hipStream_t st);
+                          uint32_t slot_bytes, uint8_t *send, hipStream_t st, const uint32_t *p1_counts = nullptr, uint64_t surv_bound = 0,
+                          uint32_t *h_flag = nullptr, uint32_t flag_val = 0);      // h_flag: stage flag "pass 1 is complete" (see DevMerge::flag_pre)
 // xinfo (device, 8 words): [0] n_global, [1] my_offset, [2] overflow flag, [3] largest per-rank count
 hipError_t launch_xg_unpack(const uint8_t *recv, uint32_t world, uint32_t rank, uint32_t stride, uint64_t cap_rows, uint32_t slot_bytes,
                             char *g_chars, uint16_t *g_len, uint32_t *xinfo, hipStream_t st, uint32_t *h_xinfo = nullptr,   // h_xinfo: pinned mirror
-                            uint32_t *zero2 = nullptr);                                                           // two words cleared on the way
+                            uint32_t *zero2 = nullptr,                                                            // two words cleared on the way
+                            unsigned long long *dd_keys = nullptr, uint32_t *dd_first = nullptr, uint32_t dd_size = 0);  // ... and the de-duplication table that follows
 // init_done: the tables were cleared by an earlier kernel of the step (dm_init_slice)
 // view_st / ev_fork / ev_view (M.x_on): the view export runs on view_st beside the merge's last three kernels, forked behind
 // k_dm_redundant (ev_fork); ev_view is recorded behind its last kernel
 hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done = false, hipStream_t view_st = nullptr,
-                               hipEvent_t ev_fork = nullptr, hipEvent_t ev_view = nullptr);
+                               hipEvent_t ev_fork = nullptr, hipEvent_t ev_view = nullptr,
+                               hipEvent_t ev_apply = nullptr);     // ev_apply: behind k_dmx_apply (the blob's token half is complete)
 // pass-2 anchor filter with table parameters read from the device (M.st); flags nothing when M.st->fail
 hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const uint8_t *found_flag, uint64_t *hitmask, hipStream_t st);
 hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t *idx, const uint32_t *d_n, uint64_t n_max,
@@ -296,7 +314,10 @@ hipError_t launch_hint_filter_any(const DevReads &R, const DevParams &P, const u
 // that needs the full searchCore leaves with err == 7 for launch_survivor(..., punt_only = 7)
 hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
                              uint32_t max_len, hipStream_t st, uint32_t *punt_list, uint32_t *d_punt_n);      // punt_list[(*d_punt_n)++] = slot of a read handed over
-hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st);
+// clear_found / cleared: the fixed-range kernel also zeroes the n_reads + 1 found flags on its way (*cleared says whether the form
+// that was launched did: the caller clears them itself otherwise)
+hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st,
+                              uint8_t *clear_found = nullptr, bool *cleared = nullptr);
 // ---- "last VGPR of the allocation" guard ----
 // Observed on the MI355X pool (minimal reproductions: profiles/ubench/vgpr_edge2.hip and vgpr_edge3.hip, write-up in
 // DESIGN.md 3.9): a wave that is NOT the first wave on its SIMD mis-executes a 64-bit shift (v_lshrrev_b64 / v_lshlrev_b64 /

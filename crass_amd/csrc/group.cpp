@@ -128,6 +128,7 @@ struct crass_hip_group {
     // exchange buffers: rank r's send buffer belongs to its context (crass_hip_exchange_setup), recv[r] is ours
     std::vector<crass_exchange> xc;
     std::vector<void *> recv;
+    std::vector<hipEvent_t> ev_send;            // local copies only: behind rank r's pass 1 on its stream (the seed scans return before their kernels end)
     uint64_t cap_rows = 16384;                  // rows per rank in the exchange; sized from the largest shard at load unless forced
     bool cap_rows_forced = false;               // CRASS_GROUP_CAP_ROWS (tests: the overflow path)
     // helper threads (ranks 1 .. n-1); the caller's thread is rank 0
@@ -181,7 +182,10 @@ int setup_exchange(crass_hip_group *g, int r)
     if (hipSetDevice(g->devices[r]) != hipSuccess) return CRASS_ERR_HIP;
     if (g->recv[r]) { crass::dev_free(g->recv[r]); g->recv[r] = nullptr; }
     if (crass::dev_alloc(&g->recv[r], (size_t)g->n * g->xc[r].send_bytes) != hipSuccess) return CRASS_ERR_OOM;
-    return CRASS_OK;
+    // the seed scan returns with pass 1 queued; the collective and the merge's kernels are queued behind it before the host looks
+    // at a counter (include/crass_hip.h).  CRASS_GROUP_SYNC_P1: the A/B switch (the round-5 order: wait, then exchange)
+    const bool sync_p1 = getenv("CRASS_GROUP_SYNC_P1") != nullptr;        // (read per set-up: the tests flip it)
+    return crass_hip_exchange_set_deferred(g->ctx[r], sync_p1 ? 0 : 1);
 }
 
 // rank 0's thread, between two barriers: every rank's send buffer is complete (its seed scan has returned)
@@ -189,9 +193,18 @@ int all_gather(crass_hip_group *g)
 {
     const size_t bytes = (size_t)g->xc[0].send_bytes;
     if (g->local_copies) {
+        // (every rank's stream reads every other rank's send buffer: ordered behind that rank's pass 1 by an event — a collective
+        // orders this by itself)
+        for (int s = 0; s < g->n; s++) {
+            if (hipSetDevice(g->devices[s]) != hipSuccess) return CRASS_ERR_HIP;
+            if (!g->ev_send[s] && hipEventCreateWithFlags(&g->ev_send[s], hipEventDisableTiming) != hipSuccess) return CRASS_ERR_HIP;
+            if (hipEventRecord(g->ev_send[s], (hipStream_t)crass_hip_stream(g->ctx[s])) != hipSuccess) return CRASS_ERR_HIP;
+        }
         for (int r = 0; r < g->n; r++) {
             if (hipSetDevice(g->devices[r]) != hipSuccess) return CRASS_ERR_HIP;
             hipStream_t st = (hipStream_t)crass_hip_stream(g->ctx[r]);
+            for (int s = 0; s < g->n; s++)
+                if (s != r && hipStreamWaitEvent(st, g->ev_send[s], 0) != hipSuccess) return CRASS_ERR_HIP;
             for (int s = 0; s < g->n; s++)
                 if (hipMemcpyAsync((char *)g->recv[r] + (size_t)s * bytes, g->xc[s].d_send, bytes, hipMemcpyDefault, st) != hipSuccess) return CRASS_ERR_HIP;
         }
@@ -362,7 +375,7 @@ int crass_hip_group_create(const crass_params *p, const int *devices, int n, uns
     crass_hip_group *g = new (std::nothrow) crass_hip_group();
     if (!g) return CRASS_ERR_OOM;
     g->n = n; g->devices.assign(devices, devices + n); g->local_copies = local;
-    g->ctx.assign(n, nullptr); g->xc.assign(n, crass_exchange{}); g->recv.assign(n, nullptr); g->status.assign(n, 0);
+    g->ctx.assign(n, nullptr); g->xc.assign(n, crass_exchange{}); g->recv.assign(n, nullptr); g->status.assign(n, 0); g->ev_send.assign(n, nullptr);
     g->extra.resize(n); g->extra_user.resize(n); g->dup_local.resize(n);
     if (const char *e = getenv("CRASS_GROUP_CAP_ROWS")) { g->cap_rows = (uint64_t)std::max(1, atoi(e)); g->cap_rows_forced = true; }      // (tests: force the overflow path)
     for (int r = 0; r < n; r++) {
@@ -398,6 +411,7 @@ void crass_hip_group_destroy(crass_hip_group *g)
             (void)hipStreamSynchronize((hipStream_t)crass_hip_stream(g->ctx[r]));
         }
     }
+    for (int r = 0; r < g->n; r++) if (g->ev_send[r]) { (void)hipSetDevice(g->devices[r]); (void)hipEventDestroy(g->ev_send[r]); }
     for (auto cm : g->comms) if (cm) (void)g_rccl.CommDestroy(cm);
     for (auto c : g->ctx) if (c) crass_hip_destroy(c);
     delete g->bar;

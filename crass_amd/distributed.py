@@ -113,10 +113,15 @@ class GatheredExchange:
     The row capacity adapts: when some rank's list does not fit (every rank learns that from the gathered
     headers) the buffers are enlarged and the caller repeats the seed scan."""
 
-    def __init__(self, eng, dist, device, cap_rows=0):
+    def __init__(self, eng, dist, device, cap_rows=0, deferred=True):
         self.eng, self.dist, self.device = eng, dist, device
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self._ev = None
+        # deferred: eng.seed_scan() returns with pass 1 still queued, the collective is issued with the ENGINE's stream as torch's
+        # current stream (the process group orders itself against the current stream on both sides), merge_gathered queues its
+        # kernels behind it — no host wait and no idle device between pass 1 and the exchange (crass_hip_exchange_set_deferred)
+        self.deferred = bool(deferred)
+        self._ext = None
         if not cap_rows:
             # the same capacity on every rank, from the LARGEST shard (crass_hip_exchange_rows_for: the engine's own first-call
             # bound for a shard's distinct DR strings), so that the first step does not overflow and repeat pass 1
@@ -136,16 +141,25 @@ class GatheredExchange:
         ptr, nbytes = self.eng.exchange_setup(self.world, self.rank, self.cap_rows)
         self.send = torch.as_tensor(_DevView(ptr, (nbytes,), "|u1"), device=self.device)
         self.recv = torch.empty((self.world * nbytes,), dtype=torch.uint8, device=self.device)
+        if self.deferred:
+            if self._ext is None:
+                self._ext = torch.cuda.ExternalStream(int(self.eng.stream_handle()), device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()      # (recv's allocation belongs to the stream that was current)
+            self.eng.exchange_set_deferred(True)
 
     def step(self):
         """after eng.seed_scan(): True when merged, False when the capacity was raised (repeat the seed scan)"""
         import torch
-        self.dist.all_gather_into_tensor(self.recv, self.send)
-        # the engine reads recv on its own stream: ordered behind the collective by an event, no host wait
-        if self._ev is None:
-            self._ev = torch.cuda.Event()
-        self._ev.record(torch.cuda.current_stream(self.device))
-        self.eng.stream_wait_event(self._ev.cuda_event)
+        if self.deferred:
+            with torch.cuda.stream(self._ext):
+                self.dist.all_gather_into_tensor(self.recv, self.send)
+        else:
+            self.dist.all_gather_into_tensor(self.recv, self.send)
+            # the engine reads recv on its own stream: ordered behind the collective by an event, no host wait
+            if self._ev is None:
+                self._ev = torch.cuda.Event()
+            self._ev.record(torch.cuda.current_stream(self.device))
+            self.eng.stream_wait_event(self._ev.cuda_event)
         need = self.eng.merge_gathered(self.recv.data_ptr(), fetch=False)
         if need is None:
             return True

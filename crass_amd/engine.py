@@ -524,6 +524,10 @@ class SearchEngine:
         _chk(self.lib.crass_hip_exchange_setup(self.h, int(world), int(rank), int(cap_rows), C.byref(x)), "crass_hip_exchange_setup")
         return int(x.d_send), int(x.send_bytes)
 
+    def exchange_set_deferred(self, on=True):
+        """seed_scan() returns with pass 1 still queued; the collective goes on the engine's stream (crass_hip_exchange_set_deferred)"""
+        _chk(self.lib.crass_hip_exchange_set_deferred(self.h, 1 if on else 0), "crass_hip_exchange_set_deferred")
+
     def merge_gathered(self, d_recv_ptr, fetch=True):
         """merge from the all-gathered send buffers (device pointer).  Returns None, or the number of rows the
         exchange needs when some rank's list did not fit (set up again, repeat seed scan + collective)."""
@@ -580,7 +584,7 @@ class SearchEngine:
         _chk(self.lib.crass_hip_set_timing_focus(self.h, int(kernels)), "crass_hip_set_timing_focus")
 
     def set_stage_timing(self, level):
-        """0 none, 1 the three large kernels (default), 2 every stage — see crass_hip_set_stage_timing."""
+        """0 none (default), 1 the three large kernels, 2 every stage — see crass_hip_set_stage_timing."""
         _chk(self.lib.crass_hip_set_stage_timing(self.h, int(level)), "crass_hip_set_stage_timing")
 
     def reload_env(self):

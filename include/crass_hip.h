@@ -96,8 +96,9 @@ typedef struct {
 /* replaces: the `options` argument of searchFile/findSingletons */
 int  crass_hip_create(const crass_params *p, int device, crass_hip_ctx **out);
 /* Stage timing with HIP events on the context's stream.  An event record costs ~6 us of stream time, so the
- * default (1) times only the three large kernels (counters ms_filter, ms_survivor, ms_recruit); 2 adds every
- * stage (ms_compact, ms_pass1_total, ms_merge_device, ms_recruit_finish, ms_pass2_total), 0 times nothing.
+ * default (0) times nothing; 1 times the three large kernels (counters ms_filter, ms_survivor, ms_recruit); 2 adds every
+ * stage (ms_compact, ms_pass1_total, ms_merge_device, ms_recruit_finish, ms_pass2_total).  (Until round 6 the default was 1:
+ * six records = ~35 us of every step of every caller, 3.5 % of a rank's step at 100 M reads over 8 GPUs.)
  * Environment override at creation: CRASS_STAGE_TIMING=0|1|2.  (No reference counterpart: crass has no timers.) */
 int  crass_hip_set_stage_timing(crass_hip_ctx *ctx, int level);
 /* The A/B and test switches of the environment (CRASS_HOST_MERGE, CRASS_NO_SPECULATION, CRASS_DM_*, ...) are read once,
@@ -203,6 +204,17 @@ typedef struct {
 int crass_hip_exchange_setup(crass_hip_ctx *ctx, uint32_t world, uint32_t rank, uint64_t cap_rows, crass_exchange *out);
 int crass_hip_merge_gathered(crass_hip_ctx *ctx, const void *d_recv);
 uint64_t crass_hip_exchange_needed_rows(const crass_hip_ctx *ctx);
+/* on != 0: from the next call on, crass_hip_seed_scan of a context with an exchange set up QUEUES pass 1 up to the kernel that
+ * fills the send buffer and returns without waiting for it; the caller queues its collective on the context's stream
+ * (crass_hip_stream) — or on a stream ordered behind it — and calls crass_hip_merge_gathered, which queues its own kernels behind
+ * the collective and only then waits for pass 1's counters.  The device no longer idles between pass 1 and the exchange while
+ * the host wakes up, launches the collective and the unpack (~60 us of a rank's ~1 ms step at 100 M reads over 8 GPUs).  Any
+ * other call that reads pass 1's results settles the pending scan first.  A scan whose speculative launch turns out unusable
+ * (more survivors than its bound, no device-resident distinct list) marks its send buffer on the device: every rank's
+ * crass_hip_merge_gathered then returns CRASS_ERR_OVERFLOW exactly as for a list that did not fit (needed rows <= the capacity
+ * in use), and the repeated seed scan of the marked rank runs synchronously.  Off by default; crass_hip_group_* and
+ * crass_amd.distributed.GatheredExchange switch it on.  (No reference counterpart: crass is single-threaded, TODO.md:18.) */
+int crass_hip_exchange_set_deferred(crass_hip_ctx *ctx, int on);
 /* A row capacity for the first exchange of a job whose LARGEST shard holds n_reads reads: the bound the engine itself
  * speculates with for a shard's distinct DR strings (a few hundred per million reads on metagenome-like input, >= 16 384).
  * Every rank must use the same capacity; with this one the first step of a group neither overflows nor repeats pass 1

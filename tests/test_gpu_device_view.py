@@ -67,6 +67,19 @@ def test_large_view(ca):
     assert_same_view(dev, host)
 
 
+def test_groups_on_both_sides_of_the_sorted_range(ca):
+    """k_dmx_sort ranks the groups of 65 .. 4 096 members (two sorts in LDS), k_dmx_rank the smaller and the larger ones (counting):
+    a set with one group beyond 4 096 members beside small ones"""
+    seqs = synth_reads(ca, 600_000, read_len=150, n_dr=1, crispr_per_million=400000)
+    seqs += synth_reads(ca, 200000, read_len=150, n_dr=40, crispr_per_million=60000)
+    dev = run(ca, seqs, CRASS_VIEW_SORT_MAX=512)        # (the range's upper end lowered: a group of 4 097 members takes millions of reads)
+    host = run(ca, seqs, CRASS_NO_DEVICE_VIEW=1)
+    sizes = sorted(len(g) for g in host.groups)
+    assert sizes[-1] > 512 and sizes[0] <= 64, sizes
+    assert dev.counters["used_device_view"] == 1
+    assert_same_view(dev, host)
+
+
 def test_group_beyond_the_rank_cap_is_built_by_the_host(ca):
     seqs = synth_reads(ca, 60000, read_len=150, n_dr=2, crispr_per_million=300000)
     dev = run(ca, seqs, CRASS_VIEW_GROUP_CAP=8)

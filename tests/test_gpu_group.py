@@ -148,6 +148,67 @@ def test_group_gathered_bound_overflow(ca):
     assert all(c["n_bound_overflows"][3] >= 1 for c in grp.counters)
 
 
+def test_group_deferred_pass1_whose_survivor_bound_overflows_is_repeated_by_every_rank(ca):
+    """the ranks' seed scans return with pass 1 still queued (crass_hip_exchange_set_deferred), the exchange and the merge are
+    queued behind it; a survivor bound that turns out too small is seen by the kernel that fills the send buffer, which marks the
+    header: every rank's merge reports an exchange that did not fit and the step is repeated (synchronously on the marked ranks)"""
+    seqs = synth_reads(ca, 90000, read_len=150, n_dr=40, crispr_per_million=60000)
+    ref = orc.pipeline(seqs)
+    os.environ["CRASS_TEST_BOUNDS"] = "64,0,0,0"
+    try:
+        grp = ca.search_pipeline_group(seqs, [0, 0, 0], local_copies=True)
+    finally:
+        os.environ.pop("CRASS_TEST_BOUNDS", None)
+    assert_same_pipeline(grp, ref)
+    assert all(c["n_bound_overflows"][0] >= 1 for c in grp.counters)
+    # the A/B switch: the round-5 order (every seed scan waits for its pass 1 before the exchange is queued)
+    os.environ["CRASS_GROUP_SYNC_P1"] = "1"
+    try:
+        sync = ca.search_pipeline_group(seqs, [0, 0, 0], local_copies=True)
+    finally:
+        os.environ.pop("CRASS_GROUP_SYNC_P1", None)
+    assert_same_pipeline(sync, ref)
+
+
+def test_deferred_seed_scan_is_settled_by_whoever_reads_pass1(ca):
+    """one context with an exchange set up (world of one) in deferred mode: crass_hip_seed_scan returns with pass 1 queued; the
+    getters settle it; merge_gathered — on the context's own send buffer, which IS the gathered buffer of a world of one —
+    finishes it after queueing its kernels"""
+    seqs = synth_reads(ca, 50000, read_len=150, n_dr=30, crispr_per_million=50000)
+    ref = orc.pipeline(seqs)
+    eng = ca.SearchEngine(device=0)
+    eng.load_reads(ca.PackedReads(seqs))
+    ptr, nbytes = eng.exchange_setup(1, 0, 16384)
+    eng.exchange_set_deferred(True)
+    for it in range(3):
+        eng.seed_scan(fetch=False)
+        if it == 1:
+            cand = eng.candidates()                 # settles the pending scan
+            assert cand.n == ref.n_pass1
+        assert eng.merge_gathered(ptr, fetch=False) is None
+        cand = eng.candidates(); mg = eng.merge_view(); rec = eng.recruit(); mg = eng.merge_view()
+        assert_same_pipeline(ca.engine.PipelineResult(cand, mg, rec, cand.max_read_len), ref)
+    eng.close()
+    # a bound that is too small: the send buffer carries the mark, merge_gathered reports it like a list that did not fit
+    os.environ["CRASS_TEST_BOUNDS"] = "64,0,0,0"
+    try:
+        eng = ca.SearchEngine(device=0)
+        eng.load_reads(ca.PackedReads(seqs))
+        ptr, nbytes = eng.exchange_setup(1, 0, 16384)
+        eng.exchange_set_deferred(True)
+        eng.seed_scan(fetch=False)
+        need = eng.merge_gathered(ptr, fetch=False)
+        assert need is not None and need <= 16384
+        eng.seed_scan(fetch=False)                  # (synchronous this time)
+        assert eng.merge_gathered(ptr, fetch=False) is None
+        cand = eng.candidates(); mg = eng.merge_view(); rec = eng.recruit(); mg = eng.merge_view()
+        assert_same_pipeline(ca.engine.PipelineResult(cand, mg, rec, cand.max_read_len), ref)
+        assert eng.counters()["n_bound_overflows"][0] >= 1
+        eng.close()
+    finally:
+        os.environ.pop("CRASS_TEST_BOUNDS", None)
+
+
 def test_group_with_an_empty_shard_and_with_no_candidates(ca):
     seqs = synth_reads(ca, 3, read_len=150, crispr_per_million=1000000)
     grp = ca.search_pipeline_group(seqs, [0] * 4, local_copies=True)          # 4 ranks, 3 reads

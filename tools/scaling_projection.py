@@ -84,11 +84,22 @@ for W in worlds:
         while cap < 2 * need: cap *= 2
     nb = sends[0].numel()
     ev = torch.cuda.Event()
+    sync_p1 = bool(os.environ.get("SP_SYNC_P1"))       # A/B: the round-5 order (the seed scan waits for pass 1, then the exchange is queued)
+    ext = torch.cuda.ExternalStream(int(engs[0].stream_handle()), device=dev)
+    torch.cuda.synchronize()
+    engs[0].set_stage_timing(0)                        # (no event records between the kernels: the library's default since round 6)
+    if not sync_p1: engs[0].exchange_set_deferred(True)
     def step():
         t = [time.perf_counter()]
         engs[0].seed_scan(fetch=False); t.append(time.perf_counter())
-        recv[:nb].copy_(sends[0])                      # stands in for the all-gather (rank 0's slot refreshed)
-        ev.record(torch.cuda.current_stream(dev)); engs[0].stream_wait_event(ev.cuda_event)
+        if sync_p1:
+            recv[:nb].copy_(sends[0])                      # stands in for the all-gather (rank 0's slot refreshed)
+            ev.record(torch.cuda.current_stream(dev)); engs[0].stream_wait_event(ev.cuda_event)
+        else:
+            # the seed scan has returned with pass 1 still queued: the stand-in for the collective goes on the engine's stream, as
+            # the group's ncclAllGather does (crass_hip_exchange_set_deferred)
+            with torch.cuda.stream(ext):
+                recv[:nb].copy_(sends[0])
         assert engs[0].merge_gathered(recv.data_ptr(), fetch=False) is None; t.append(time.perf_counter())
         engs[0].recruit(fetch=False); t.append(time.perf_counter())
         return [1e3 * (b - a) for a, b in zip(t, t[1:])]
