@@ -441,12 +441,33 @@ def main():
             c1 = e1.counters()
             assert (c1["n_pass1_found"], c1["n_pass2_found"]) == (c["n_pass1_found"], c["n_pass2_found"]), "single shot differs"
             e1.close()
+        # ... and the same with the DEVICE kept busy in front of the fresh context's step (steps of the resident context): what is
+        # left of the difference is the fresh context's; the rest is the device's clocks, which take ~30 ms of work to come up after
+        # an idle period — a load (host packing, H2D copies) is one (tools/idle_effect.py: a steady-state step behind a 50 ms pause
+        # costs 1.12 x a back-to-back one, the same as a fresh context's)
+        busy = []
+        for _ in range(args.single_shots):
+            e1 = ca.SearchEngine(prm, local_rank)
+            e1.set_stage_timing(0)
+            e1.load_packed_uniform(words, n, L, read_index_base=first)
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(e1)
+            torch.cuda.synchronize()
+            busy.append((time.perf_counter() - t1) * 1e3)
+            e1.close()
         out["single_shot_ms"] = round(float(np.median(shots)), 3)
         out["single_shot_value"] = round(total / (out["single_shot_ms"] * 1e-3), 1)
         out["single_shot"] = {"ms_all": [round(x, 3) for x in shots], "contexts": len(shots),
                               "vs_steady_state": round(out["single_shot_ms"] / ms_per_step, 3),
+                              "busy_device_ms_all": [round(x, 3) for x in busy], "busy_device_ms": round(float(np.median(busy)), 3),
+                              "busy_device_vs_steady_state": round(float(np.median(busy)) / ms_per_step, 3),
                               "note": "one step on a fresh context (crass_hip_create + crass_hip_load_reads outside, as for "
-                                      "`value`: reads resident in HBM); no learnt speculation bounds, nothing warmed"}
+                                      "`value`: reads resident in HBM); no learnt speculation bounds, nothing warmed.  busy_device: the "
+                                      "same with ten steps of the resident context queued right in front of it — the device's clocks are "
+                                      "up; the difference to single_shot_ms is the idle device's, not the fresh context's"}
 
     # ---- what the adapter pays on top of a step: the ABI's wide arrays (crass_candidates / crass_merge_view / crass_recruits)
     #      are widened from the compact blobs ON REQUEST, outside the timed region ----

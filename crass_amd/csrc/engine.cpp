@@ -169,6 +169,7 @@ struct EnvSwitches {
     bool dd_full_table = false;                      // A/B switch: pass 1's de-duplication table sized for the survivor slots (the round-3 size)
     bool no_device_view = false;                     // A/B switch: the host rebuilds crass_merge_view from root_of / blank (the round-3 path)
     bool force_device_view = false;                  // CRASS_DEVICE_VIEW=1: the device assembles it for a single context too (default: multi-rank only)
+    bool no_warm_launch = false;                     // CRASS_NO_WARM_LAUNCH: the A/B switch of first_call_bounds' empty launch
     uint32_t view_group_cap = 32768;                 // groups beyond this many members are ranked by the host (CRASS_VIEW_GROUP_CAP)
     uint32_t view_sort_max = 2048;                   // groups of 65 .. this many members are ranked by a sort in LDS (k_dmx_sort; CRASS_VIEW_SORT_MAX: tests)
     uint64_t test_bounds[4] = {0, 0, 0, 0};          // tests: CRASS_TEST_BOUNDS="survivors,distinct,flagged,gathered" replaces the
@@ -197,6 +198,7 @@ struct EnvSwitches {
         no_hint_filter = on("CRASS_NO_HINT_FILTER");
         wave_walk_min = 800; if (const char *e = getenv("CRASS_WAVE_WALK_MIN")) wave_walk_min = (uint32_t)std::max(0, atoi(e));
         long_min = 2048; if (const char *e = getenv("CRASS_LONG_MIN")) long_min = (uint32_t)std::max(0, atoi(e));
+        no_warm_launch = getenv("CRASS_NO_WARM_LAUNCH") != nullptr;
         pool_cap_bytes = 0; if (const char *e = getenv("CRASS_POOL_CAP_MB")) pool_cap_bytes = (uint64_t)std::max(1ll, atoll(e)) << 20;
     }
 };
@@ -1803,6 +1805,16 @@ static int first_call_bounds_impl(crass_hip_ctx *c)
     s = ensure_recruit_buffers(c, hits, 0, true, true);
     if (s) return s;
     c->hit_cap_hint = hits;
+    // The wave-per-read survivor kernel spills a few registers, i.e. needs scratch memory: the runtime sets a queue's scratch up
+    // at the first dispatch that asks for it — the device sat idle for ~160 us in front of that launch and the launch itself
+    // took 130 us instead of 20 (a fresh context's step at 100 M reads: 4.77-4.87 ms against 4.45-4.55 for its later steps,
+    // profiles/r06_single_shot_timeline.txt).  An empty launch of the same shape here, with the reads, takes that off the step.
+    if (!c->env.no_warm_launch) {
+        HIPCHK(c, hipMemsetAsync(c->d_count.p, 0, 32, c->stream));
+        HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, c->d_count.p + 1, surv, c->d_surv.p, c->d_dr.p, c->dr_stride,
+                                  c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, nullptr, lds,
+                                  (int)std::min<uint64_t>(256 * 32, surv), c->stream, 4));
+    }
     host_pool_warm();
     return CRASS_OK;
 }
