@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_dm_pack_codes(DevMerge M)
     if (t == 0 && lane == 0 && M.flag_pre) stage_flag_store(M.flag_pre, M.flag_pre_val);          // (everything in front of the merge is complete)
     if (t < dm_ntok(M)) {
         const uint32_t len = M.dx_len[t];
-        if (len > 64 || len < 23 || M.stride > 64) { if (lane == 0) atomicOr(&M.st->fail, 1u); }
+        if (len > 64 || len < M.min_len || M.min_len < kDevMinDR || M.stride > 64) { if (lane == 0) atomicOr(&M.st->fail, 1u); }
         else {
             const bool in = (uint32_t)lane < len;
             const uint32_t ch = in ? (uint32_t)(uint8_t)M.dx_chars[(uint64_t)t * M.stride + lane] : 0u;
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
         const uint64_t *pj = M.packed + (uint64_t)j * 4;
         const uint64_t f0 = pj[0], f1 = pj[1], r0 = pj[2], r1 = pj[3];
         const uint64_t mfj = M.tmask[(uint64_t)j * 2], mrj = M.tmask[(uint64_t)j * 2 + 1];
-        if (lenj < 23u || lenj > 64u) continue;         // (cannot happen once k_dm_pack_codes has passed the token: belt and braces)
-        const uint32_t nwin = lenj - 22u;               // starts 0 .. lenj-23: a member is >= 23 long and shorter than lenj
+        if (lenj < M.min_len || lenj > 64u) continue;   // (cannot happen once k_dm_pack_codes has passed the token: belt and braces)
+        const uint32_t nwin = lenj - (M.min_len - 1u);  // starts 0 .. lenj - min_len: a member is >= min_len (23 by default) long and shorter than lenj
         bool found = false;
         for (uint32_t wb = 0; wb < 2 * nwin && !found; wb += 64) {
             const uint32_t wq = wb + lane;
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
     const uint32_t t = e >> 4, o = (e >> 3) & 1u, r = e & 7u;
     uint32_t slot = 0xFFFFFFFFu, my_key = 0xFFFFFFFFu, won = 0u;
     const bool in_range = t < dm_ntok(M);               // (no early return: the block meets at the end)
-    if (in_range && !M.blank[t] && !(M.ablate & 512u)) {
+    // (anchor windows every 4 bases — patterns of 19 .. 22 bases — : offsets 0 .. 3 only; the entry numbering stays 16 per token)
+    if (in_range && !M.blank[t] && r < (1u << M.akey_shift) && !(M.ablate & 512u)) {
         const uint32_t key = (uint32_t)shr128_lo(M.packed[(uint64_t)t * 4 + 2 * o], M.packed[(uint64_t)t * 4 + 2 * o + 1], 2 * r);
         const uint32_t kmask = (1u << M.kset_log) - 1u;
         const unsigned long long want = (unsigned long long)key | (1ull << 32);
@@ -1332,21 +1333,22 @@ __global__ __launch_bounds__(256) void k_dm_verify(DevReads R, DevMerge M, const
         };
         uint32_t best_end = 0xFFFFFFFFu, best_len = 0, best_pid = 0;      // wave-uniform
         if (L >= 16) {
-            const uint32_t h_max = (L - 16) >> 3;
+            const uint32_t ash = M.akey_shift;                              // windows every 8 (or, patterns of 19 .. 22 bases, 4) bases
+            const uint32_t h_max = (L - 16) >> ash;
             for (uint32_t hb = 0; hb <= h_max; hb += 64) {
-                if (best_end <= 8 * hb + 15) break;
+                if (best_end <= (hb << ash) + 15) break;
                 const uint32_t h = hb + lane;
                 uint32_t cnt = 0, base = 0;
                 if (h <= h_max) {
-                    const uint32_t wi = h >> 1;
+                    const uint32_t pos = h << ash, wi = pos >> 4;
                     const uint32_t lo = word(wi), hi = word(wi + 1);
-                    dv_probe(M, (h & 1) ? ((lo >> 16) | (hi << 16)) : lo, kmask, cnt, base);
+                    dv_probe(M, __builtin_amdgcn_alignbit(hi, lo, (pos & 15u) * 2u), kmask, cnt, base);
                 }
                 uint64_t hits = __ballot(cnt > 0);
                 while (hits) {
                     const int src = __ffsll((unsigned long long)hits) - 1;
                     hits &= hits - 1;
-                    const uint32_t a = 8 * (hb + (uint32_t)src);
+                    const uint32_t a = (hb + (uint32_t)src) << ash;
                     if (best_end <= a + 15) { hits = 0; break; }              // later windows cannot end earlier
                     const uint32_t cnt_s = (uint32_t)__shfl((int)cnt, src), base_s = (uint32_t)__shfl((int)base, src);
                     dv_candidates(M, word, raw, L, a, cnt_s, base_s, lane, best_end, best_len, best_pid);
@@ -1375,7 +1377,7 @@ hipError_t launch_dm_verify(const DevReads &R, const DevMerge &M, const uint64_t
     if (n_max == 0) return hipSuccess;
     static const bool dv_one = getenv("CRASS_DV_ONE") != nullptr;      // A/B switch, read once per process
     // every read at most 183 bases (uniform length): three reads per wave and round
-    const bool shortr = R.uniform_len >= 16 && ((R.uniform_len - 16) >> 3) < DV_GL && ((R.uniform_len + 15) >> 4) <= DV_MAXW && !dv_one;
+    const bool shortr = M.akey_shift == 3 && R.uniform_len >= 16 && ((R.uniform_len - 16) >> 3) < DV_GL && ((R.uniform_len + 15) >> 4) <= DV_MAXW && !dv_one;
     uint64_t nb = shortr ? (n_max + 4 * DV_G - 1) / (4 * DV_G) : (n_max + 3) / 4;
     if (nb > 8192) nb = 8192;
     static const bool dv_pair = getenv("CRASS_DV_SINGLE") == nullptr;  // two candidates per lane and step (CRASS_DV_SINGLE: the A/B switch, one)

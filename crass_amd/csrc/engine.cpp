@@ -1244,7 +1244,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         // long-read set no longer hashes 50 k strings and clusters them on the host (1.3 ms per step at 1 M x 10 kbp)
         const bool ss16 = c->max_len < 65536;           // start/stops travel as 16-bit values
         const bool hl_dedupe = !exc && off == 0 && nchunk == n_total && c->R.n_exc == 0 && !c->xchg.active && !c->env.host_merge &&
-                               c->prm.lowDRsize >= 23 && stride <= 64 && (stride & 15u) == 0 && nchunk < (1u << 24) && !getenv_once_hl_host();
+                               c->prm.lowDRsize >= (int)kDevMinDR && stride <= 64 && (stride & 15u) == 0 && nchunk < (1u << 24) && !getenv_once_hl_host();
         if (hl_dedupe) HIPCHK(c, c->g_dr_len.ensure(nchunk));
         HIPCHK(c, launch_gather_sparse(c->d_fidx.p, c->d_count.p + 2, nchunk, c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, c->g_surv.p,
                                        c->d_fidx.p + 0, c->g_dr.p, c->g_ss.p, (uint32_t)pool_cap, c->d_ss_used.p, c->stream,
@@ -1398,7 +1398,7 @@ static void presize_hostloop(crass_hip_ctx *c)
     need(c->dd_keys.ensure(tsize)); need(c->dd_first.ensure(tsize)); need(c->dd_slot.ensure(nf)); need(c->dd_rep.ensure(nf));
     need(c->dd_hash.ensure(nf)); need(c->hl_dx_idx.ensure(nf)); need(c->dd_dx_chars.ensure(nf * (size_t)stride + 16)); need(c->dd_dx_len.ensure(nf));
     need(c->h_dmap.ensure(nf)); need(c->h_dx_chars.ensure(nf * (size_t)stride + 16)); need(c->h_dx_len.ensure(nf)); need(c->h_dx_hash.ensure(nf));
-    if (ok && c->prm.lowDRsize >= 23 && stride <= 64 && !c->env.host_merge && !c->xchg.active)
+    if (ok && c->prm.lowDRsize >= (int)kDevMinDR && stride <= 64 && !c->env.host_merge && !c->xchg.active)
         (void)device_merge_prepare(c, c->dd_dx_chars.p, c->dd_dx_len.p, std::min<uint64_t>(nf, 1u << 18), nullptr);      // (the merge's tables: buffers only, nothing is launched)
     c->last_hip = 0;
 }
@@ -1499,7 +1499,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     // merge's tables on its way, and the merge is queued right behind pass 1's tail further down.
     c->dm_prepared_n = 0; c->dm_prepared_src = nullptr;
     const DevMerge *init_merge = nullptr;
-    if (speculative && dedupe && c->prm.lowDRsize >= 23 && stride <= 64 && !c->env.host_merge && !c->env.no_speculation && !c->env.dm_init_late) {
+    if (speculative && dedupe && c->prm.lowDRsize >= (int)kDevMinDR && stride <= 64 && !c->env.host_merge && !c->env.no_speculation && !c->env.dm_init_late) {
         const char *src = nullptr; const uint16_t *src_len = nullptr; uint64_t bound = 0;
         if (!c->xchg.active && c->dm_prev_local && c->dx_cap_hint) {
             HIPCHK(c, c->dd_dx_chars.ensure(n_alloc * stride + 16)); HIPCHK(c, c->dd_dx_len.ensure(n_alloc));
@@ -1585,7 +1585,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     D.pack_ss_cap = lds.ss_cap;
     // The merge itself is queued here too when the previous call's merge ran on the device: its kernels read the token
     // count from the device (d_count[4]) and are sized by a bound; crass_hip_merge adopts the result if the counts fit.
-    const bool will_premerge = speculative && dedupe && !c->xchg.active && c->dm_prev_local && c->dx_cap_hint && c->prm.lowDRsize >= 23 && stride <= 64 &&
+    const bool will_premerge = speculative && dedupe && !c->xchg.active && c->dm_prev_local && c->dx_cap_hint && c->prm.lowDRsize >= (int)kDevMinDR && stride <= 64 &&
                                !c->env.host_merge && !c->env.no_speculation;
     // (what the host waits for when the merge is queued behind pass 1, or pass 1 deferred: a stage flag — else this event)
     if (!c->poll_on && (will_premerge || defer_ok)) HIPCHK(c, hipEventRecord(c->ev_gathered, c->stream));
@@ -1779,7 +1779,7 @@ static int first_call_bounds_impl(crass_hip_ctx *c)
     { const uint64_t nw = (n + 63) / 64; c->prealloc_lookback(std::max<uint64_t>((nw + lookback_tile_words(nw) - 1) / lookback_tile_words(nw), (surv + 1023) / 1024)); }
     // distinct DR strings: a few hundred per million reads on metagenome-like input; the device merge is queued
     // behind pass 1 for this many
-    if (dedupe && c->prm.lowDRsize >= 23 && c->dr_stride <= 64 && !c->env.host_merge) {
+    if (dedupe && c->prm.lowDRsize >= (int)kDevMinDR && c->dr_stride <= 64 && !c->env.host_merge) {
         uint64_t dx = crass_hip_exchange_rows_for(n);
         if (c->env.test_bounds[1]) dx = std::max<uint64_t>(16, c->env.test_bounds[1]);
         s = device_merge_prepare(c, c->dd_dx_chars.p, c->dd_dx_len.p, dx, c->d_count.p + 4);
@@ -2205,7 +2205,7 @@ static int build_host_merge(crass_hip_ctx *c);
 static bool device_merge_applies(const crass_hip_ctx *c)
 {
     if (c->env.host_merge) return false;                 // A/B switch: force the host merge (merge.cpp)
-    return c->have_pass1 && c->dev_tokens() && c->prm.lowDRsize >= 23 &&
+    return c->have_pass1 && c->dev_tokens() && c->prm.lowDRsize >= (int)kDevMinDR &&
            c->dr_stride <= 64 && c->n_dx <= (1u << 20);
 }
 
@@ -2224,6 +2224,7 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
     DevMerge M{};
     M.dx_chars = dx_chars; M.dx_len = dx_len; M.stride = stride; M.n_tok = n; M.d_ntok = d_ntok;
     M.thr = (uint32_t)std::max(c->prm.kmer_clust_size, 2); M.kmax = stride - 10;
+    M.min_len = (uint32_t)c->prm.lowDRsize; M.akey_shift = M.min_len >= 23u ? 3u : 2u;
     { const char *ab = getenv("CRASS_DM_ABLATE"); M.ablate = ab ? (uint32_t)strtoul(ab, nullptr, 0) : 0u; }      // (profiling aid, read per merge)
     M.kset_log = 10; while ((1ull << M.kset_log) < 32ull * n) M.kset_log++;
     M.tab_log_alloc = 16; while (M.tab_log_alloc < 24 && (1ull << M.tab_log_alloc) < 48ull * n) M.tab_log_alloc++;
@@ -2861,7 +2862,7 @@ int crass_hip_merge_gathered(crass_hip_ctx *c, const void *d_recv)
     const uint32_t n = (uint32_t)n_max;
     HIPCHK(c, d.g_chars.ensure(n_max * (size_t)stride + 16)); HIPCHK(c, d.g_len.ensure(n_max + 1));
     // (deferred: what device_merge_applies asks of pass 1's results is checked once they are known)
-    bool dev = (deferred ? (!c->env.host_merge && c->prm.lowDRsize >= 23 && c->dr_stride <= 64) : device_merge_applies(c)) && n_max <= (1u << 22);
+    bool dev = (deferred ? (!c->env.host_merge && c->prm.lowDRsize >= (int)kDevMinDR && c->dr_stride <= 64) : device_merge_applies(c)) && n_max <= (1u << 22);
     uint32_t tsize = 1024;
     while (tsize < n * 2) tsize <<= 1;
     if (dev) { const int as = ensure_gathered_buffers(c, n_max); if (as) return as; }

@@ -157,11 +157,18 @@ static constexpr uint32_t kDmxTiles = 1024;         // tiles of 1024 tokens: n_t
 // pattern arrays ARE the per-token arrays (packed[t][2o..2o+1], tmask[t][o]); ids of dropped variants are simply unused.
 // (The reference's pattern ORDER — per group, survivors then reverse complements, WorkHorse.cpp:690-697 — only exists in
 // the host view; pass 2 depends on the set alone, SURVEY a-14.)
+// The device merge and pass 2's anchor probe take DR strings of kDevMinDR .. 64 bases.  The anchor argument: a pattern P that
+// occurs at offset o of a read contains the read's aligned 16-base window at a = ceil_A(o) iff |P| >= 16 + A - 1 — every 8 bases
+// for |P| >= 23 (crass's default lowDRsize), every 4 bases for |P| >= 19 (-d 19 .. 22: four keys per pattern instead of eight,
+// twice the windows per read).  Shorter patterns (-d 8 .. 18) take the host merge and the byte-wise automaton kernels.
+static constexpr uint32_t kDevMinDR = 19;
 struct DevMerge {
     // input: distinct candidate DR strings in first-occurrence (= token) order
     const char *dx_chars; const uint16_t *dx_len;
     uint32_t stride, n_tok;
     const uint32_t *d_ntok;       // nullptr, or the device-side token count (n_tok is then the bound the launch is sized for)
+    uint32_t min_len;             // lowDRsize: no token is shorter (kDevMinDR <= min_len)
+    uint32_t akey_shift;          // log2 of the anchor windows' alignment: 3 (every 8 bases: min_len >= 23) or 2 (every 4: min_len >= 19)
     uint32_t thr;                 // max(kmer_clust_size, 2): sightings of a group that decide membership
     uint32_t kmax;                // k-mer slots per token (stride - 10)
     // per token

@@ -13,6 +13,7 @@
 // the pass-2 automaton is staged in LDS when it fits.  Compile with -ffp-contract=off:
 // qcFoundRepeats' float evaluation order is part of the parity contract.
 #include "engine_internal.h"
+#include <type_traits>
 #include <algorithm>
 
 namespace crass {
@@ -4092,10 +4093,14 @@ static __device__ __forceinline__ bool anchor_probe_fp(const uint16_t *tab, uint
     return (a == i2) | (b == i1);
 }
 
-template <int W, int THREADS, int MODE>     // W = uniform stride in words (0: ragged / any stride)
+// ASH: log2 of the windows' alignment — 3: every 8 bases (halfword positions; patterns of >= 23 bases), 2: every 4 bases (byte
+// positions; patterns of 19 .. 22 bases, `-d 19` .. `-d 22`: twice the windows per read, see kDevMinDR)
+template <int W, int THREADS, int MODE, int ASH = 3>     // W = uniform stride in words (0: ragged / any stride)
 static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, const DevAnchors &K, const uint32_t *ak_lds,
                                                           const uint8_t *found_flag, uint64_t *hitmask)
 {
+    constexpr uint32_t PW = 16u >> ASH;              // windows per packed word (2 or 4)
+    constexpr uint32_t WB = 32u / PW;                // bits between two windows (16 or 8)
     const uint32_t mask = 32u - K.log_size;          // right shift that keeps the top log_size bits
     const uint64_t n_tiles = (R.n_reads + 63) / 64;
     const int lane = threadIdx.x & 63;
@@ -4119,7 +4124,7 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                 const uint32_t L = rd_len(R, r);
                 if (L < 16) continue;
                 const uint32_t *g = R.packed + rd_word_off(R, r);
-                const uint32_t nw = (L + 15) >> 4, h_max = (L - 16) >> 3;
+                const uint32_t nw = (L + 15) >> 4, h_max = (L - 16) >> ASH;
                 // a lane takes FOUR consecutive windows (halfword positions 4q .. 4q+3 = words 2q, 2q+1 and the low half of
                 // 2q+2): three loads serve four probes, one ballot decides 256 windows, and the words of the next round are
                 // requested before this round is probed (one window per lane and round was 20 dependent round trips per
@@ -4130,16 +4135,19 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                 };
                 uint32_t na, nb, nc;
                 fetch3((uint32_t)lane, na, nb, nc);
-                for (uint32_t h0 = 0; h0 <= h_max; h0 += 256) {
-                    const uint32_t q = (h0 >> 2) + (uint32_t)lane;
+                // (windows every 4 bases: the same three words serve EIGHT probes per lane)
+                constexpr uint32_t PL = 2u * PW;                                // windows per lane and round
+                for (uint32_t h0 = 0; h0 <= h_max; h0 += 64u * PL) {
+                    const uint32_t q = (h0 / PL) + (uint32_t)lane;
                     const uint32_t a = na, b = nb, c3 = nc;
-                    if (h0 + 256 <= h_max) fetch3(q + 64u, na, nb, nc);
-                    const uint32_t h = 4u * q;
+                    if (h0 + 64u * PL <= h_max) fetch3(q + 64u, na, nb, nc);
+                    const uint32_t h = PL * q;
                     bool f = false;
-                    if (h <= h_max) f = probe(a);
-                    if (h + 1u <= h_max) f = f | probe((a >> 16) | (b << 16));
-                    if (h + 2u <= h_max) f = f | probe(b);
-                    if (h + 3u <= h_max) f = f | probe((b >> 16) | (c3 << 16));
+#pragma unroll
+                    for (uint32_t i = 0; i < PL; i++) {
+                        const uint32_t V = i < PW ? __builtin_amdgcn_alignbit(b, a, (i * WB) & 31u) : __builtin_amdgcn_alignbit(c3, b, ((i - PW) * WB) & 31u);
+                        if (h + i <= h_max) f = f | probe(V);
+                    }
                     if (__ballot(f)) { bits |= 1ull << k; break; }              // one window is enough to flag the read
                 }
             }
@@ -4177,7 +4185,7 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
             const uint32_t L = rd_len(R, r);
             const uint32_t *g = R.packed + rd_word_off(R, r);
             if (L >= 16) {
-                const uint32_t h_max = (L - 16) >> 3;            // last halfword position whose 16-mer is inside the read
+                const uint32_t h_max = (L - 16) >> ASH;          // last window position (halfword, or byte) whose 16-mer is inside the read
                 if (W > 0) {
                     uint32_t w[W + 1];
 #pragma unroll
@@ -4189,25 +4197,26 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                         // pair of global loads per window made the wave wait for 19 round trips.  So: all Bloom tests
                         // first (LDS only, a bit per window), then every lane resolves ITS positives one per round —
                         // the wave needs as many rounds as its busiest lane has positives (4-5).
-                        uint32_t pm = 0;
+                        typedef typename std::conditional<ASH == 3, uint32_t, uint64_t>::type pm_t;      // (up to 61 windows every 4 bases)
+                        pm_t pm = 0;
 #pragma unroll
-                        for (int h = 0; h < 2 * W - 1; h++) {
-                            const uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
+                        for (int h = 0; h < (int)PW * (W - 1) + 1; h++) {
+                            const uint32_t V = __builtin_amdgcn_alignbit(w[h / (int)PW + 1], w[h / (int)PW], ((uint32_t)h % PW) * WB);
                             // (blocked Bloom: ONE hash, one LDS word, both bits from it; a shift by a register takes the register's low
                             // five bits, so the two positions cost a shift each and the window's flag joins pm with one v_lshl_or)
                             const uint32_t h1 = ak_hash(V, K.m1);
                             const uint32_t wd = ak_lds[ak_bloom_word(h1)];
                             const uint32_t bit = (wd >> ((h1 >> 12) & 31u)) & (wd >> ((h1 >> 7) & 31u)) & 1u;
-                            if ((uint32_t)h <= h_max) pm |= bit << h;
+                            if ((uint32_t)h <= h_max) pm |= (pm_t)bit << h;
                         }
                         while (pm) {                                   // (divergent: lanes with fewer positives idle)
-                            const uint32_t h = (uint32_t)__ffs((int)pm) - 1u;
+                            const uint32_t h = (uint32_t)(ASH == 3 ? __ffs((int)(uint32_t)pm) : __ffsll((unsigned long long)pm)) - 1u;
                             pm &= pm - 1u;
-                            const uint32_t kk = h >> 1;
+                            const uint32_t kk = h / PW;
                             uint32_t lo = 0, hi = 0;
 #pragma unroll
                             for (int i = 0; i < W; i++) { lo = kk == (uint32_t)i ? w[i] : lo; hi = kk == (uint32_t)i ? w[i + 1] : hi; }
-                            const uint32_t V = (h & 1u) ? ((lo >> 16) | (hi << 16)) : lo;
+                            const uint32_t V = __builtin_amdgcn_alignbit(hi, lo, (h % PW) * WB);
                             const uint32_t h1 = ak_hash(V, K.m1), h2 = ak_hash(V, K.m2);
                             if ((K.table[h1 >> mask] == V) | (K.table[h2 >> mask] == V)) { flag = true; pm = 0; }
                         }
@@ -4215,8 +4224,8 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                     // (uniform read length: the last window is a scalar, and "window inside the read" costs no vector compare)
                     auto scan = [&](const uint32_t hm) {
 #pragma unroll
-                        for (int h = 0; h < 2 * W - 1; h++) {
-                            uint32_t V = (h & 1) ? ((w[h >> 1] >> 16) | (w[(h >> 1) + 1] << 16)) : w[h >> 1];
+                        for (int h = 0; h < (int)PW * (W - 1) + 1; h++) {
+                            uint32_t V = __builtin_amdgcn_alignbit(w[h / (int)PW + 1], w[h / (int)PW], ((uint32_t)h % PW) * WB);
                             bool hit = MODE == 3 ? anchor_probe_fp(reinterpret_cast<const uint16_t *>(ak_lds), V, K)
                                                  : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
                             flag = flag | (hit & ((uint32_t)h <= hm));
@@ -4225,7 +4234,7 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                             if ((h & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                         }
                     };
-                    if (R.uniform_len) scan((R.uniform_len - 16u) >> 3);
+                    if (R.uniform_len) scan((R.uniform_len - 16u) >> ASH);
                     else scan(h_max);
                     }
                 } else {
@@ -4238,16 +4247,16 @@ static __device__ __forceinline__ void anchor_filter_body(const DevReads &R, con
                                                      : anchor_probe<(MODE == 3 || MODE == 4) ? 0 : MODE>(ak_lds, V, K, mask);
                     };
                     uint32_t lo = g[0];
-                    for (uint32_t h = 0; h <= h_max && !flag; h += 8) {
-                        const uint32_t wi = (h >> 1) + 1;
+                    for (uint32_t h = 0; h <= h_max && !flag; h += 4u * PW) {
+                        const uint32_t wi = (h / PW) + 1;
                         uint32_t x[4];
 #pragma unroll
                         for (uint32_t q = 0; q < 4; q++) x[q] = wi + q < nw ? g[wi + q] : 0u;
 #pragma unroll
                         for (uint32_t q = 0; q < 4; q++) {
-                            const uint32_t hh = h + 2u * q;
-                            if (hh <= h_max && probe(lo)) flag = true;
-                            if (hh + 1u <= h_max && probe((lo >> 16) | (x[q] << 16))) flag = true;
+#pragma unroll
+                            for (uint32_t i = 0; i < PW; i++)
+                                if (h + PW * q + i <= h_max && probe(__builtin_amdgcn_alignbit(x[q], lo, i * WB))) flag = true;
                             lo = x[q];
                         }
                     }
@@ -4291,19 +4300,23 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMe
         for (uint64_t t = blockIdx.x * (uint64_t)THREADS + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * THREADS) hitmask[t] = 0ull;
         return;
     }
+    const bool a4 = M.akey_shift == 2u;                 // (uniform) windows every 4 bases: patterns of 19 .. 22 bases
     if (K.log_size <= 15) {
         const uint32_t tsize = 1u << K.log_size;
         for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds_buf[i] = K.table[i];
         __syncthreads();
-        anchor_filter_body<W, THREADS, 0>(R, K, ak_lds_buf, found_flag, hitmask);
+        if (a4) anchor_filter_body<W, THREADS, 0, 2>(R, K, ak_lds_buf, found_flag, hitmask);
+        else anchor_filter_body<W, THREADS, 0>(R, K, ak_lds_buf, found_flag, hitmask);
     } else if (M.st->tab_mode == 3) {
         for (uint32_t i = threadIdx.x; i < (1u << 15); i += THREADS) ak_lds_buf[i] = M.anchor_fp[i];
         __syncthreads();
-        anchor_filter_body<W, THREADS, 3>(R, K, ak_lds_buf, found_flag, hitmask);
+        if (a4) anchor_filter_body<W, THREADS, 3, 2>(R, K, ak_lds_buf, found_flag, hitmask);
+        else anchor_filter_body<W, THREADS, 3>(R, K, ak_lds_buf, found_flag, hitmask);
     } else {
         for (uint32_t i = threadIdx.x; i < (1u << 15); i += THREADS) ak_lds_buf[i] = M.anchor_fp[i];
         __syncthreads();
-        anchor_filter_body<W, THREADS, 4>(R, K, ak_lds_buf, found_flag, hitmask);
+        if (a4) anchor_filter_body<W, THREADS, 4, 2>(R, K, ak_lds_buf, found_flag, hitmask);
+        else anchor_filter_body<W, THREADS, 4>(R, K, ak_lds_buf, found_flag, hitmask);
     }
 }
 

@@ -154,6 +154,35 @@ def test_bit_parallel_filter_with_non_default_options(ca, kw, L):
     assert_same_pipeline(padded, orc.pipeline(seqs, params=to_orc_params(p)))
 
 
+@pytest.mark.parametrize("low", [19, 20, 22])
+@pytest.mark.parametrize("L", [150, 101, 300])
+def test_short_repeats_take_the_device_merge_and_the_anchor_probe(ca, low, L):
+    """-d 19 .. 22 (crass accepts -d >= 8, crass.cpp:264-271): DR strings below 23 bases.  Until round 6 they took the host merge
+    and the byte-wise automaton kernels (pass 2 at 77 x the defaults' cost); now the device merge takes strings from 19 bases and
+    pass 2 probes 16-base windows every 4 bases (every pattern of >= 19 bases contains one), verified exactly.  Reads whose
+    repeats ARE that short, beside longer ones; uniform, ragged and N reads; groups of contexts."""
+    rng = random.Random(low * 1000 + L)
+    seqs = synth_reads(ca, 30000, read_len=L, n_dr=40, dr_len_min=low, dr_len_max=low + 6, spacer_len_min=26, spacer_len_max=34, crispr_per_million=60000)
+    seqs += synth_reads(ca, 10000, read_len=L, n_dr=20, crispr_per_million=40000)
+    p = ca.default_params(lowDRsize=low, highDRsize=low + 22)
+    gpu = ca.search_pipeline(seqs, params=p)
+    ref = orc.pipeline(seqs, params=to_orc_params(p))
+    assert_same_pipeline(gpu, ref)
+    assert gpu.counters["used_device_merge"] == 1 and gpu.counters["used_lds_automaton"] == 2      # (2: anchor probe + exact verification)
+    assert min(len(t) for t in gpu.tokens) < 23 and gpu.n_pass2 > 0
+    rag = []
+    for q in seqs[:16000]:
+        q = bytearray(q[:rng.randint(max(60, L - 50), L)]) if rng.random() < 0.5 else bytearray(q)
+        if rng.random() < 0.02:
+            q[rng.randrange(len(q))] = ord("N")
+        rag.append(bytes(q))
+    gpu = ca.search_pipeline(rag, params=p)
+    assert_same_pipeline(gpu, orc.pipeline(rag, params=to_orc_params(p)))
+    assert gpu.counters["used_device_merge"] == 1
+    grp = ca.search_pipeline_group(seqs[:24000], [0, 0], params=p, local_copies=True)
+    assert_same_pipeline(grp, orc.pipeline(seqs[:24000], params=to_orc_params(p)))
+
+
 def test_unsigned_skips_wrap_is_refused(ca):
     """-d < 2w-1 wraps the reference's unsigned `skips` (libcrispr.cpp:281-285); the reference's
     seed loop is then ill-defined (can walk backwards forever).  The engine refuses it."""
