@@ -1518,7 +1518,8 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     HIPCHK(c, c->stamp(8, 1));
     // lane-per-read kernel for uniform short reads; whatever it punts (err == 4) and every other
     // layout goes through the wave-per-read kernel
-    const uint32_t *hints = c->hints_valid ? c->d_hit_info.p : nullptr;
+    static const bool no_hints_dbg = getenv("CRASS_SURV_NO_HINTS") != nullptr;      // (timing experiments only: the lanes walk every lattice seed)
+    const uint32_t *hints = (c->hints_valid && !no_hints_dbg) ? c->d_hit_info.p : nullptr;
     const bool no_lanes = c->env.no_lane_kernel;
     hipError_t le = no_lanes ? hipErrorNotSupported
                              : launch_survivor_lanes(c->R, c->dp, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,

@@ -3233,6 +3233,7 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
     extern __shared__ __attribute__((aligned(16))) uint32_t sl_lds[];
     __shared__ uint16_t sl_perm[WAVE * SL_WAVES];
     __shared__ uint32_t sl_cnt[SL_WAVES];
+    __shared__ uint32_t sl_hint[WAVE * SL_WAVES];       // the slots' filter hints, read once (for the regrouping) and handed to whoever gets the slot
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     // the tables of the merge that follows this stage are cleared on the way (stores next to an issue-bound kernel)
     if (do_init) dm_init_slice(IM, blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
@@ -3243,7 +3244,9 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
         bool heavy = false;
         if (s < n_surv) {
             const uint64_t r0 = surv_idx[s];
-            heavy = !rd_is_exc(R, r0) && (seed_hint ? __popc(seed_hint[r0]) : __popcll(ln_hint64(R, nullptr, r0, (int)rd_len(R, r0), P.skips))) >= 2;
+            const uint32_t h0 = seed_hint ? seed_hint[r0] : 0u;
+            sl_hint[threadIdx.x] = h0;
+            heavy = !rd_is_exc(R, r0) && (seed_hint ? __popc(h0) : __popcll(ln_hint64(R, nullptr, r0, (int)rd_len(R, r0), P.skips))) >= 2;
         }
         const uint64_t hb = __ballot(heavy);
         if (lane == 0) sl_cnt[wv] = (uint32_t)__popcll(hb);
@@ -3260,6 +3263,7 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
         __syncthreads();
         s = blockIdx.x * (uint64_t)blockDim.x + sl_perm[threadIdx.x];
     }
+    const bool hint_in_lds = regroup && seed_hint;
     const size_t wave_words = (size_t)(words_per_read + 5) * WAVE + ((size_t)ss_cap * WAVE + 1) / 2;      // this wave's part of the LDS
     uint32_t *wbase = sl_lds + (size_t)wv * wave_words;
     uint32_t *lw = wbase + lane;                                       // [word][lane]
@@ -3275,11 +3279,21 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
     const int L = (int)rd_len(R, r);
     const uint32_t *g = R.packed + rd_word_off(R, r);
     const int nw = (L + 15) >> 4;
-    for (int i = 0; i < (int)words_per_read + 5; i++) lw[i * WAVE] = (i < nw) ? g[i] : 0u;      // (ln_load128 reads up to 4 words past a base)
+    // (a row is dword-aligned only, which global_load_dwordx4 takes on gfx950 — ff_load_row: three or four wide loads per lane
+    // instead of ten to sixteen single words, every one of which was 64 lines' worth of look-ups for the wave)
+    {
+        int i = 0;
+        for (; i + 4 <= nw; i += 4) {
+            const ff_u32x4 v = *reinterpret_cast<const ff_u32x4 *>(g + i);
+            lw[i * WAVE] = v.x; lw[(i + 1) * WAVE] = v.y; lw[(i + 2) * WAVE] = v.z; lw[(i + 3) * WAVE] = v.w;
+        }
+        for (; i < nw; i++) lw[i * WAVE] = g[i];
+        for (; i < (int)words_per_read + 5; i++) lw[i * WAVE] = 0u;                             // (ln_load128 reads up to 4 words past a base)
+    }
     LaneRead h;
     h.w = lw; h.ss = lss; h.L = L; h.nss = 0; h.cap = (int)ss_cap; h.replen = 0; h.punt = 0;
     h.cmask = (1u << (2 * P.window)) - 1u;
-    const uint64_t hint = ln_hint64(R, seed_hint, r, L, P.skips);
+    const uint64_t hint = hint_in_lds ? (0xFFFFFFFF00000000ull | (uint64_t)sl_hint[(uint32_t)(s - blockIdx.x * (uint64_t)blockDim.x)]) : ln_hint64(R, seed_hint, r, L, P.skips);
     int f = (P.debug_stop == 1) ? 0 : ln_search_core(h, P, hint);      // (1: load only)
     if (P.debug_stop == 4 && f == 1) f = 0;                           // (4: no orientation / output)
     SurvOut o;
