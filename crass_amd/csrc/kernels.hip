@@ -3126,12 +3126,138 @@ static __device__ int ln_qc(LaneRead &h, int minSpacerLength, int maxSpacerLengt
     return 1;
 }
 
-static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint64_t seed_hint)
+// ---- the QC's threshold tests as TASKS of the block (k_survivor_lanes) ----
+// qcFoundRepeats spends its time in one or two "similarity > 0.82" tests per candidate (two repeats: repeat vs spacer; three:
+// spacer vs spacer, repeat vs spacer) — bit-parallel edit distances of ~40 columns.  Run by the candidate's own lane they
+// occupied the third of a block's lanes that hold real CRISPR reads, once or twice in a row, while the other lanes of the block
+// — reads that a chance seed hit let through — had long finished: 180 of the lane kernel's 520 us at 100 M reads.  The tests are
+// therefore QUEUED in LDS by the candidates' lanes and run by ALL lanes of the block, a test per lane (any lane reads any
+// lane's words: the rows are LDS), tests whose shorter string has at most 32 bases on 32-bit words from the queue's front, the
+// others on 64-bit words from its back.  The decisions stay with the candidate's lane, in the reference's order.
+struct QcTask { uint32_t a, b; };                 // a: owner thread (8) | s0 (9) | n (7) | d_no (7);  b: t0 (9) | m (7)
+struct QcPool {
+    QcTask *task;                                 // [2 * threads of the block]: 32-bit tests from the front, 64-bit ones from the back
+    uint8_t *res;                                 // [2 * threads]: by task slot, 1 = "similarity above the cut"
+    uint32_t *cnt;                                // [0] 32-bit tests queued, [1] 64-bit tests queued
+    const uint32_t *rows;                         // the block's LDS rows (sl_lds)
+    uint32_t wave_words;                          // words per wave's part of it
+    uint32_t cap;                                 // 2 * threads
+};
+// what a lane remembers between queueing its tests and reading their results
+struct QcPending { int kind; uint32_t slot_a, slot_b; uint32_t cur_len, nxt_len, rep_len, sp_len; };
+
+// "(double)getStringSimilarity(a, b) > 0.82" as a queued test; returns the task's slot, or 0xFFFFFFFF with *now = the answer when
+// it needs no distance (a string below three bases: similarity 0)
+static __device__ uint32_t qc_enqueue_above(const QcPool &q, int s0, int n, int t0, int m, bool *now)
+{
+    *now = false;
+    if (n < 3 || m < 3) { *now = 0.0 > 0.82; return 0xFFFFFFFFu; }
+    if (n > m) { int x = s0; s0 = t0; t0 = x; x = n; n = m; m = x; }
+    const float max_length = (float)m;
+    int d_no = 0;
+    while (d_no <= m && (double)(float)(1.0 - (double)((float)d_no / max_length)) > 0.82) d_no++;
+    uint32_t slot;
+    if (n <= 32) slot = atomicAdd(&q.cnt[0], 1u);
+    else slot = q.cap - 1u - atomicAdd(&q.cnt[1], 1u);
+    QcTask t;
+    t.a = (uint32_t)threadIdx.x | ((uint32_t)s0 << 8) | ((uint32_t)n << 17) | ((uint32_t)d_no << 24);
+    t.b = (uint32_t)t0 | ((uint32_t)m << 9);
+    q.task[slot] = t;
+    return slot;
+}
+
+// one queued test, by whichever lane drew it
+template <typename WORD>
+static __device__ __forceinline__ void qc_run_task(const QcPool &q, uint32_t slot)
+{
+    const QcTask t = q.task[slot];
+    const uint32_t owner = t.a & 0xFFu;
+    const int s0 = (int)((t.a >> 8) & 0x1FFu), n = (int)((t.a >> 17) & 0x7Fu), d_no = (int)(t.a >> 24);
+    const int t0 = (int)(t.b & 0x1FFu), m = (int)(t.b >> 9);
+    LaneRead ho;
+    ho.w = q.rows + (size_t)(owner >> 6) * q.wave_words + (owner & 63u);
+    uint64_t sl, sh, tl, th;
+    ln_load128(ho, s0, sl, sh); ln_load128(ho, t0, tl, th);
+    const int d = ln_lev_regs<WORD>(sl, sh, n, tl, th, m, d_no);
+    q.res[slot] = (double)(float)(1.0 - (double)((float)d / (float)m)) > 0.82 ? 1 : 0;
+}
+
+// qcFoundRepeats (libcrispr.cpp:869-1029) up to its similarity tests: -1 / 0 / 1 = decided here (ln_qc's values); 2 = the
+// candidate's tests are queued (pd says which), qc_pool_end decides.  Candidates of four repeats or more, and strings beyond
+// 64 bases, take ln_qc as before (rare at these read lengths).
+static __device__ int qc_pool_begin(LaneRead &h, int minSpacerLength, int maxSpacerLength, uint32_t dbg, const QcPool &q, QcPending &pd)
+{
+    pd.kind = 0;
+    const int num_repeats = h.nss / 2;
+    if (dbg == 5 || dbg == 6 || num_repeats < 2 || num_repeats > 3) return ln_qc(h, minSpacerLength, maxSpacerLength, dbg);
+    uint32_t rep_len;
+    const uint32_t rep_start = ln_ss(h, 0);
+    if (!substr_len(h.L, rep_start, ln_ss(h, 1) - rep_start + 1, rep_len)) return -1;
+    if (rep_len > 64) return ln_qc(h, minSpacerLength, maxSpacerLength, dbg);
+    {   // isRepeatLowComplexity (:1031-1069); packed reads hold A/C/G/T only
+        uint64_t lo, hi, p0, p1;
+        ln_load128(h, (int)rep_start, lo, hi);
+        ln_planes(lo, hi, (int)rep_len, p0, p1);
+        const int c3 = __popcll(p0 & p1), c1 = __popcll(p0 & ~p1), c2 = __popcll(~p0 & p1), c0 = (int)rep_len - c1 - c2 - c3;
+        const int cut_off = (int)((double)(int)rep_len * 0.75);
+        if (c0 > cut_off || c3 > cut_off || c2 > cut_off || c1 > cut_off) return 0;
+    }
+    if (num_repeats == 3) {
+        uint32_t cur_start = ln_ss(h, 1) + 1, cur_len;
+        if (!substr_len(h.L, cur_start, ln_ss(h, 2) - cur_start, cur_len)) return -1;
+        uint32_t nxt_start = ln_ss(h, 3) + 1, nxt_len;
+        if (!substr_len(h.L, nxt_start, ln_ss(h, 4) - nxt_start, nxt_len)) return -1;
+        const int mn = (int)(cur_len < nxt_len ? cur_len : nxt_len), mx = (int)(cur_len > nxt_len ? cur_len : nxt_len);
+        if (mn < minSpacerLength || mx > maxSpacerLength) return 0;
+        if (cur_len > 64 || nxt_len > 64) return ln_qc(h, minSpacerLength, maxSpacerLength, dbg);
+        bool a_now, b_now;
+        pd.slot_a = qc_enqueue_above(q, (int)cur_start, (int)cur_len, (int)nxt_start, (int)nxt_len, &a_now);
+        if (pd.slot_a == 0xFFFFFFFFu && a_now) return 0;
+        pd.slot_b = qc_enqueue_above(q, (int)rep_start, (int)rep_len, (int)cur_start, (int)cur_len, &b_now);
+        if (pd.slot_b == 0xFFFFFFFFu && b_now) return 0;          // (its own test only: a queued first test is not waited for — both "return 0")
+        pd.kind = 3; pd.cur_len = cur_len; pd.nxt_len = nxt_len; pd.rep_len = rep_len;
+        return 2;
+    }
+    // two repeats
+    uint32_t s = ln_ss(h, 1) + 1;
+    uint32_t e = ln_ss(h, 2) - 1;
+    uint32_t sp_len;
+    if (!substr_len(h.L, s, e - s, sp_len)) return -1;
+    if ((int)sp_len < minSpacerLength) return 0;
+    if ((int)sp_len > maxSpacerLength) return 0;
+    if (sp_len > 64) return ln_qc(h, minSpacerLength, maxSpacerLength, dbg);
+    bool now;
+    pd.slot_a = qc_enqueue_above(q, (int)rep_start, (int)rep_len, (int)s, (int)sp_len, &now);
+    if (pd.slot_a == 0xFFFFFFFFu && now) return 0;
+    pd.slot_b = 0xFFFFFFFFu;
+    pd.kind = 2; pd.sp_len = sp_len; pd.rep_len = rep_len;
+    return 2;
+}
+// ... and from the tests' results on (same values as ln_qc)
+static __device__ int qc_pool_end(const QcPool &q, const QcPending &pd)
+{
+    const bool a = pd.slot_a != 0xFFFFFFFFu && q.res[pd.slot_a] != 0;
+    if (pd.kind == 3) {
+        if (a) return 0;
+        const bool b = pd.slot_b != 0xFFFFFFFFu && q.res[pd.slot_b] != 0;
+        if (b) return 0;
+        if ((int)fabsf(((float)pd.cur_len - (float)pd.nxt_len) / 1.0f) > 12) return 0;
+        if ((int)fabsf(((float)pd.rep_len - (float)pd.cur_len) / 1.0f) > 30) return 0;
+        return 1;
+    }
+    if (a) return 0;
+    int dlen = (int)pd.sp_len - (int)pd.rep_len;
+    if (dlen < 0) dlen = -dlen;
+    if (dlen > 30) return 0;
+    return 1;
+}
+
+// active: this thread holds a read (the others only take part in the block's barriers and run queued tests)
+static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint64_t seed_hint, bool active, const QcPool &pool)
 {   // searchCore, libcrispr.cpp:265-395
     const uint32_t seq_length = (uint32_t)h.L;
     const uint32_t skips = o.skips;
     int searchEnd = (int)(seq_length - o.lowDR - o.lowSp - o.window - 1);
-    if (searchEnd < 0) return 0;
     h.nss = 0;
     bool on_lattice = true;
     uint32_t lattice_i = 0;
@@ -3142,7 +3268,7 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint64_t s
     // sequence of events per read is the reference's; what changes is that the QC code — by far the longest stretch —
     // is issued once per round for the whole wave instead of once per seed iteration in which some lane needs it
     // (lanes reach their first QC in different iterations: 51 us of the kernel's 117 were QC issue slots).
-    bool finished = false; int result = 0;                  // this lane's searchCore has returned `result`
+    bool finished = !active || searchEnd < 0; int result = 0;      // this lane's searchCore has returned `result`
     for (;;) {
         bool ready = false, error = false, out_of_seeds = false;
         // (wave-uniform loop condition: the lanes leave this loop TOGETHER, whatever the compiler makes of the control flow)
@@ -3178,9 +3304,24 @@ static __device__ int ln_search_core(LaneRead &h, const DevParams &o, uint64_t s
         }
         if (!finished && error) { finished = true; result = -1; }
         if (!finished && out_of_seeds) { finished = true; result = 0; }
-        if (!__any((int)(!finished))) break;
+        // From here on the BLOCK moves together (three barriers per round, one or two rounds): the lanes that hold a candidate
+        // queue its similarity tests, every lane of the block runs queued tests, the candidates' lanes decide.
+        if (!__syncthreads_or((int)(!finished))) break;
+        QcPending pd;
+        pd.kind = 0;
+        int qc = 0;
+        if (!finished) qc = qc_pool_begin(h, (int)o.lowSp, (int)o.highSp, o.debug_stop, pool, pd);
+        __syncthreads();
+        {
+            const uint32_t n32 = pool.cnt[0], n64 = pool.cnt[1];
+            for (uint32_t t = threadIdx.x; t < n32; t += blockDim.x) qc_run_task<uint32_t>(pool, t);
+            // (the 64-bit tests from the block's last lanes downwards: the waves that took 32-bit tests take these last)
+            for (uint32_t t = blockDim.x - 1u - threadIdx.x; t < n64; t += blockDim.x) qc_run_task<uint64_t>(pool, pool.cap - 1u - t);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { pool.cnt[0] = 0u; pool.cnt[1] = 0u; }      // (the next round queues behind this round's first barrier)
         if (!finished) {
-            int qc = ln_qc(h, (int)o.lowSp, (int)o.highSp, o.debug_stop);
+            if (qc == 2) qc = qc_pool_end(pool, pd);
             if (h.punt) { finished = true; result = 0; }
             else if (qc < 0) { finished = true; result = -1; }
             else if (qc) { finished = true; result = 1; }
@@ -3268,16 +3409,23 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
     uint32_t *wbase = sl_lds + (size_t)wv * wave_words;
     uint32_t *lw = wbase + lane;                                       // [word][lane]
     uint16_t *lss = reinterpret_cast<uint16_t *>(wbase + (size_t)(words_per_read + 5) * WAVE) + lane;   // [entry][lane]
-    if (s >= n_surv) return;
-    const uint64_t r = surv_idx[s];
-    if (rd_is_exc(R, r)) {                              // raw-byte read: the wave kernel's exception pass (err == 5)
+    // (no thread leaves before the end: the block's lanes run the candidates' queued similarity tests together, QcPool)
+    __shared__ QcTask sl_task[2 * WAVE * SL_WAVES];
+    __shared__ uint8_t sl_res[2 * WAVE * SL_WAVES];
+    __shared__ uint32_t sl_qcnt[2];
+    if (threadIdx.x < 2) sl_qcnt[threadIdx.x] = 0u;      // (the first queueing is behind ln_search_core's first barrier)
+    QcPool pool;
+    pool.task = sl_task; pool.res = sl_res; pool.cnt = sl_qcnt; pool.rows = sl_lds; pool.wave_words = (uint32_t)wave_words; pool.cap = 2 * WAVE * SL_WAVES;
+    bool active = s < n_surv;
+    const uint64_t r = active ? surv_idx[s] : 0;
+    if (active && rd_is_exc(R, r)) {                    // raw-byte read: the wave kernel's exception pass (err == 5)
         SurvOut o;
         o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 5;
         out[s] = o;
-        return;
+        active = false;
     }
-    const int L = (int)rd_len(R, r);
-    const uint32_t *g = R.packed + rd_word_off(R, r);
+    const int L = active ? (int)rd_len(R, r) : 0;
+    const uint32_t *g = R.packed + (active ? rd_word_off(R, r) : 0);
     const int nw = (L + 15) >> 4;
     // (a row is dword-aligned only, which global_load_dwordx4 takes on gfx950 — ff_load_row: three or four wide loads per lane
     // instead of ten to sixteen single words, every one of which was 64 lines' worth of look-ups for the wave)
@@ -3293,8 +3441,9 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
     LaneRead h;
     h.w = lw; h.ss = lss; h.L = L; h.nss = 0; h.cap = (int)ss_cap; h.replen = 0; h.punt = 0;
     h.cmask = (1u << (2 * P.window)) - 1u;
-    const uint64_t hint = hint_in_lds ? (0xFFFFFFFF00000000ull | (uint64_t)sl_hint[(uint32_t)(s - blockIdx.x * (uint64_t)blockDim.x)]) : ln_hint64(R, seed_hint, r, L, P.skips);
-    int f = (P.debug_stop == 1) ? 0 : ln_search_core(h, P, hint);      // (1: load only)
+    const uint64_t hint = !active ? 0ull : hint_in_lds ? (0xFFFFFFFF00000000ull | (uint64_t)sl_hint[(uint32_t)(s - blockIdx.x * (uint64_t)blockDim.x)]) : ln_hint64(R, seed_hint, r, L, P.skips);
+    int f = (P.debug_stop == 1) ? 0 : ln_search_core(h, P, hint, active, pool);      // (1: load only)
+    if (!active) return;
     if (P.debug_stop == 4 && f == 1) f = 0;                           // (4: no orientation / output)
     SurvOut o;
     o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
