@@ -3410,6 +3410,7 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
     uint32_t *lw = wbase + lane;                                       // [word][lane]
     uint16_t *lss = reinterpret_cast<uint16_t *>(wbase + (size_t)(words_per_read + 5) * WAVE) + lane;   // [entry][lane]
     // (no thread leaves before the end: the block's lanes run the candidates' queued similarity tests together, QcPool)
+    static_assert(WAVE * SL_WAVES <= 256, "QcTask keeps the owner's thread index in 8 bits");
     __shared__ QcTask sl_task[2 * WAVE * SL_WAVES];
     __shared__ uint8_t sl_res[2 * WAVE * SL_WAVES];
     __shared__ uint32_t sl_qcnt[2];
