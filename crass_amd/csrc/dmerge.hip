@@ -1044,7 +1044,8 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done
     CRASS_LAUNCH(k_dm_pack_codes, dim3((M.n_tok + 3) / 4), dim3(256), 0, st, M);       // one wave per token
     // every wave must be resident: at most one block per CU (16 waves of the CU's 32 wave slots, no LDS)
     unsigned gb = (M.n_tok + 15) / 16;
-    if (gb > M.n_cu) gb = M.n_cu;
+    static const unsigned greedy_per_cu = getenv("CRASS_DM_GREEDY_PER_CU") ? (unsigned)std::max(1, atoi(getenv("CRASS_DM_GREEDY_PER_CU"))) : 1u;      // (experiment)
+    if (gb > M.n_cu * greedy_per_cu) gb = M.n_cu * greedy_per_cu;
     CRASS_LAUNCH(k_dm_greedy, dim3(gb), dim3(1024), 0, st, M);
     CRASS_LAUNCH(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
     CRASS_LAUNCH(k_dm_rd_fill, dim3(nb), dim3(256), 0, st, M);
