@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) void k_dm_redundant(DevMerge M)
 // latency, 13 + 11 us -> 48 us).
 __global__ __launch_bounds__(256) void k_dm_keys(DevMerge M)
 {
+    if (M.flag_blank && blockIdx.x == 0 && threadIdx.x == 0) stage_flag_store(M.flag_blank, M.flag_blank_val);      // (k_dm_redundant is complete: blank[] is final)
     if (dm_abandoned(M)) return;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = e >> 4, o = (e >> 3) & 1u, r = e & 7u;
@@ -597,21 +598,21 @@ static __device__ __forceinline__ uint32_t dmx_claim(uint32_t *hkey, uint32_t r)
 __global__ __launch_bounds__(DMX_BLOCK) void k_dmx_count(DevMerge M)
 {
     if (dm_abandoned(M)) return;
-    __shared__ uint32_t hkey[DMX_SLOTS], hcnt[DMX_SLOTS], hkept[DMX_SLOTS], hch[DMX_SLOTS];
-    for (uint32_t i = threadIdx.x; i < DMX_SLOTS; i += DMX_BLOCK) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0u; hkept[i] = 0u; hch[i] = 0u; }
+    // (group sizes only: the export runs behind k_dm_greedy, beside the kernels that decide which members survive — the pattern
+    // list, which needs blank[], is put together by the host from this view and blank[]; see launch_device_merge)
+    __shared__ uint32_t hkey[DMX_SLOTS], hcnt[DMX_SLOTS];
+    for (uint32_t i = threadIdx.x; i < DMX_SLOTS; i += DMX_BLOCK) { hkey[i] = 0xFFFFFFFFu; hcnt[i] = 0u; }
     __syncthreads();
     const uint32_t t = blockIdx.x * DMX_BLOCK + threadIdx.x;
     if (t < dm_ntok(M)) {
         const uint32_t slot = dmx_claim(hkey, M.root_of[t]);
         atomicAdd(&hcnt[slot], 1u);
-        if (!M.blank[t]) { atomicAdd(&hkept[slot], 1u); atomicAdd(&hch[slot], (uint32_t)M.dx_len[t]); }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < DMX_SLOTS; i += DMX_BLOCK) {
         const uint32_t r = hkey[i];
         if (r == 0xFFFFFFFFu) continue;
         atomicAdd(&M.x_size[r], hcnt[i]);
-        if (hkept[i]) { atomicAdd(&M.x_kept[r], hkept[i]); atomicAdd(&M.x_kchars[r], hch[i]); }
     }
 }
 
@@ -621,7 +622,7 @@ static __device__ __forceinline__ void dmx_vals(const DevMerge &M, uint32_t t, u
     v[0] = v[1] = v[2] = v[3] = v[4] = 0u;
     if (t >= n) return;
     v[4] = M.dx_len[t];
-    if (M.root_of[t] == t) { v[0] = 1u; v[1] = M.x_size[t]; v[2] = M.x_kept[t]; v[3] = M.x_kchars[t]; }
+    if (M.root_of[t] == t) { v[0] = 1u; v[1] = M.x_size[t]; }      // (v[2], v[3] — survivors and their characters — stay 0: the host's part)
 }
 
 __global__ __launch_bounds__(1024) void k_dmx_tiles(DevMerge M)
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(DMX_BLOCK) void k_dmx_place(DevMerge M)
     for (uint32_t i = threadIdx.x; i < DMX_SLOTS; i += DMX_BLOCK)
         if (hkey[i] != 0xFFFFFFFFu) hbase[i] = atomicAdd(&M.x_fill[hkey[i]], hcnt[i]);      // one returning atomic per root and block
     __syncthreads();
-    if (act) M.x_members[M.x_goff[r] + hbase[slot] + local] = ((uint32_t)(M.blank[t] ? 1u : 0u) << 27) | ((uint32_t)M.dx_len[t] << 20) | t;
+    if (act) M.x_members[M.x_goff[r] + hbase[slot] + local] = t;
 }
 
 static __device__ __forceinline__ char dmx_comp(char c)                // SeqUtils.cpp:50-59 over the device merge's alphabet
@@ -776,11 +777,11 @@ static __device__ __forceinline__ char dmx_comp(char c)                // SeqUti
 // one per SIMD, nothing to hide the dependent adds behind — 260 us; a tile of the range in LDS read by all lanes at once 78 us
 // with 32-bit reads, 133 us with 128-bit ones (no broadcast), and the LDS it held kept pass 2's probe kernel, which stages its
 // table there, off the CUs: 144 -> 243 us.)
-// A group of 65 .. DMX_SORT_MAX members is ranked by SORTING its member list in LDS, one block per group: by (blank, length,
-// token) — the survivors come first, in the pattern list's order, and a scan over their lengths gives every pattern's
-// characters' place — then by token for grp_tokens.  Two bitonic sorts of <= 2 048 keys (66 steps each at the most) instead of
-// group-size^2 comparisons: 42 k tokens in 64 groups of up to 1 800 were 27-50 M counting steps over every CU, 65 us alone and
-// 93 us beside pass 2's probe, which lost 50 us to them (profiles/NOTES_r06.md).
+// A group of 65 .. DMX_SORT_MAX members is ranked by SORTING its member list in LDS, one block per group, by token (grp_tokens):
+// a bitonic sort of <= 2 048 keys (66 steps at the most) instead of group-size^2 comparisons — 42 k tokens in 64 groups of up to
+// 1 800 were 27-50 M counting steps over every CU, 65 us alone and 93 us beside pass 2's probe, which lost 50 us to them
+// (profiles/NOTES_r06.md).  The pattern list's order (length, then token, among the survivors) is the host's business since the
+// export moved in front of k_dm_redundant.
 // (2 048 keys: 16 KB of LDS for the two arrays — pass 2's probe holds 128 KB of a CU's 160 KB, and with 32 KB here whichever of
 // the two kernels reached a CU first kept the other off it: the probe took 149 or 190 us depending on the launch's luck)
 #define DMX_SORT_MAX 2048u
@@ -803,154 +804,95 @@ __global__ __launch_bounds__(1024) void k_dmx_sort(DevMerge M)
 {
     const DevViewTotals T = *M.x_tot;
     if (!T.ok) return;
-    __shared__ uint32_t keys[DMX_SORT_MAX], dstf[DMX_SORT_MAX];
-    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t keys[DMX_SORT_MAX];
     uint8_t *blob = M.x_blob;
     const uint64_t *grp_off = reinterpret_cast<const uint64_t *>(blob + T.lay.grp_off);
-    uint64_t *pat_off = reinterpret_cast<uint64_t *>(blob + T.lay.pat_off);
-    uint32_t *pat_group = reinterpret_cast<uint32_t *>(blob + T.lay.pat_group);
     uint32_t *grp_tokens = reinterpret_cast<uint32_t *>(blob + T.lay.grp_tokens);
-    char *pat_chars = reinterpret_cast<char *>(blob + T.lay.pat_chars);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t stride = M.stride, cpr = stride >> 3;
     for (uint32_t gid = blockIdx.x; gid < T.n_groups; gid += gridDim.x) {
         const uint32_t g0 = (uint32_t)grp_off[gid], gs = (uint32_t)grp_off[gid + 1] - g0;
-        if (gs <= 64u || gs > M.x_sort_max) continue;                   // (uniform: k_dmx_rank takes those)
+        if (gs <= 64u || gs > M.x_sort_max) continue;                   // (uniform: the waves' loop below / k_dmx_rank take those)
         uint32_t n_pad = 128;
         while (n_pad < gs) n_pad <<= 1;
         for (uint32_t i = threadIdx.x; i < n_pad; i += 1024u) keys[i] = i < gs ? M.x_members[g0 + i] : 0xFFFFFFFFu;
         __syncthreads();
         dmx_bitonic(keys, n_pad);
-        const uint32_t r = M.root_of[keys[0] & 0xFFFFFu];
-        const uint32_t kg = M.x_kept[r], pat0 = M.x_pat0[r], pch0 = M.x_pch0[r], kch = M.x_kchars[r], gid1 = M.x_gid[r] + 1u;
-        // survivors = the first kg keys (blank is the top bit): pattern rank = position, characters in front = scan of the lengths
-        uint32_t carry = 0;
-        for (uint32_t base = 0; base < kg; base += 1024u) {
-            const uint32_t j = base + threadIdx.x;
-            const uint32_t len = j < kg ? (keys[j] >> 20) & 0x7Fu : 0u;
-            const uint32_t inc = wave_incl_scan(len, lane);
-            if (lane == 63) wtot[w] = inc;
-            __syncthreads();
-            uint32_t before = 0, all = 0;
-#pragma unroll
-            for (int q = 0; q < 16; q++) { const uint32_t v = wtot[q]; if (q < w) before += v; all += v; }
-            if (j < kg) {
-                const uint32_t df = pch0 + carry + before + inc - len, p = pat0 + j;
-                dstf[j] = df;
-                pat_off[p] = df; pat_off[p + kg] = df + kch;
-                pat_group[p] = gid1; pat_group[p + kg] = gid1;
-            }
-            carry += all;
-            __syncthreads();
-        }
-        // the pattern strings: every survivor and its reverse complement, 8 characters per thread and step
-        for (uint32_t q = threadIdx.x; q < kg * cpr; q += 1024u) {
-            const uint32_t e = q / cpr, c8 = (q - e * cpr) * 8u, key = keys[e], len = (key >> 20) & 0x7Fu;
-            if (c8 >= len) continue;
-            const uint2 wd = *reinterpret_cast<const uint2 *>(M.dx_chars + (uint64_t)(key & 0xFFFFFu) * stride + c8);
-            char *df = pat_chars + dstf[e] + c8, *dr = pat_chars + dstf[e] + kch + (len - 1u - c8);
-            const uint32_t nb = min(8u, len - c8);
-#pragma unroll
-            for (uint32_t b2 = 0; b2 < 8; b2++)
-                if (b2 < nb) {
-                    const char c = (char)(((b2 < 4 ? wd.x : wd.y) >> (8u * (b2 & 3u))) & 0xFFu);
-                    df[b2] = c;
-                    *(dr - b2) = dmx_comp(c);
-                }
-        }
-        __syncthreads();
-        // by token: grp_tokens
-        for (uint32_t i = threadIdx.x; i < n_pad; i += 1024u) { const uint32_t k2 = keys[i]; keys[i] = k2 == 0xFFFFFFFFu ? k2 : (k2 & 0xFFFFFu); }
-        __syncthreads();
-        dmx_bitonic(keys, n_pad);
         for (uint32_t i = threadIdx.x; i < gs; i += 1024u) grp_tokens[g0 + i] = keys[i] + 2u;
-        __syncthreads();                                                // (the next group reuses keys / dstf)
+        __syncthreads();                                                // (the next group reuses keys)
+    }
+    // groups of up to 64 members: a wave each, a member per lane, every lane counting the smaller tokens of its group
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 16u + (threadIdx.x >> 6), n_waves = gridDim.x * 16u;
+    for (uint32_t gid = wave; gid < T.n_groups; gid += n_waves) {
+        const uint32_t g0 = (uint32_t)grp_off[gid], gs = (uint32_t)grp_off[gid + 1] - g0;
+        if (gs > 64u) continue;
+        const uint32_t t = (uint32_t)lane < gs ? M.x_members[g0 + lane] : 0xFFFFFFFFu;
+        uint32_t ra = 0;
+        for (uint32_t q = 0; q < gs; q++) ra += (uint32_t)__builtin_amdgcn_readlane((int)t, (int)q) < t ? 1u : 0u;
+        if ((uint32_t)lane < gs) grp_tokens[g0 + ra] = t + 2u;
     }
 }
 
+// the groups k_dmx_sort leaves out (more than x_sort_max members): every member counts the members of its group with a smaller
+// token.  The member lists lie in GID order, so 64 consecutive entries belong to a run of consecutive groups whose
+// lists are one contiguous range [lo, hi): a block takes 64 entries (lane = entry, the same in each of its 16 waves) and its
+// waves share the range 64 keys at a time — one coalesced load, every key to all lanes through an SGPR (v_readlane), each lane
+// counting it if it lies in its own group's part of the range; the 16 partial counts per entry meet in LDS.
 #define DMX_RW 16                                    // waves per block
 __global__ __launch_bounds__(64 * DMX_RW) void k_dmx_rank(DevMerge M)
 {
-    const DevViewTotals T = *M.x_tot;
-    if (!T.ok) return;
-    __shared__ uint32_t acc[DMX_RW][3][64];
-    __shared__ uint32_t p_t[64], p_f[64], p_r[64];
-    __shared__ uint8_t p_len[64];
+    // (the totals are read field by field: a private copy of the struct is "promoted" to LDS by the compiler — 80 bytes x 1 024
+    // threads = 80 KB for this kernel, which then could not share a CU with pass 2's probe (128 KB) and sat out the probe's
+    // whole 150 us behind it, whatever its stream's priority)
+    const DevViewTotals *TT = M.x_tot;
+    if (!TT->ok) return;
+    const uint32_t t_ntok = TT->n_tok;
+    const uint64_t t_grp_tokens = TT->lay.grp_tokens;
+    auto publish = [&]() {
+        if (blockIdx.x == 0 && threadIdx.x < sizeof(DevViewTotals) / 4)
+            reinterpret_cast<uint32_t *>(M.x_htot)[threadIdx.x] = reinterpret_cast<const uint32_t *>(TT)[threadIdx.x];      // (the host only reads the blob after the stream's event)
+    };
+    if (TT->max_group <= M.x_sort_max) { publish(); return; }      // (nothing for this kernel: k_dmx_sort has ranked every group)
+    __shared__ uint32_t acc[DMX_RW][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // at most one block per CU, each walking several 64-entry chunks: 650 blocks of 1 024 threads took every wave slot of the
-    // CUs they landed on, and pass 2's probe kernel (one 1 024-thread block per CU) queued behind them — 144 -> 212 us for an
-    // eighth of the 100 M reads; with half of every CU's slots left alone the probe no longer notices
-    for (uint32_t chunk = blockIdx.x; chunk * 64u < T.n_tok; chunk += gridDim.x) {
-    const uint32_t i = chunk * 64u + (uint32_t)lane;
-    const bool act = i < T.n_tok;
     uint8_t *blob = M.x_blob;
-    uint32_t key = 0, t = 0, g0 = 0, gs = 0, r = 0;
-    if (act) {
-        key = M.x_members[i];
-        t = key & 0xFFFFFu;
-        r = M.root_of[t]; g0 = M.x_goff[r]; gs = M.x_size[r];
-    }
-    // groups of 65 .. DMX_SORT_MAX members are ranked by k_dmx_sort (a sort in LDS): this kernel's counting is quadratic in the
-    // group.  Such a group cannot lie strictly inside a chunk, so the other lanes' groups still form one contiguous range
-    const bool part = act && (gs <= 64u || gs > M.x_sort_max);
-    const uint64_t am = __ballot(part);
-    if (am == 0ull) continue;                           // (uniform over the block: every wave holds the same 64 entries)
-    const int first = __ffsll((unsigned long long)am) - 1, lastl = 63 - __clzll((unsigned long long)am);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)g0, first);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(g0 + gs), lastl);
-    uint32_t ra = 0, rp = 0, cp = 0;
-    for (uint32_t base = lo + 64u * (uint32_t)w; base < hi; base += 64u * DMX_RW) {
-        const uint32_t cur = base + (uint32_t)lane < hi ? M.x_members[base + lane] : 0u;
-        const uint32_t cnt = min(hi - base, 64u);
-        const uint32_t rel = base - g0;                 // per lane: key q of this chunk is member (rel + q) of the lane's group iff < gs
-        for (uint32_t q = 0; q < cnt; q++) {
-            const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)q);
-            const bool in = rel + q < gs;               // (unsigned: also false for keys in front of the lane's group)
-            ra += (in && (k2 & 0xFFFFFu) < t) ? 1u : 0u;
-            const bool lt = in && k2 < key;             // (a survivor's key is only preceded by survivors' keys: blank is the top bit)
-            rp += lt ? 1u : 0u;
-            cp += lt ? ((k2 >> 20) & 0x7Fu) : 0u;
+    for (uint32_t chunk = blockIdx.x; chunk * 64u < t_ntok; chunk += gridDim.x) {
+        const uint32_t i = chunk * 64u + (uint32_t)lane;
+        const bool act = i < t_ntok;
+        uint32_t t = 0, g0 = 0, gs = 0;
+        if (act) {
+            t = M.x_members[i];
+            const uint32_t r = M.root_of[t];
+            g0 = M.x_goff[r]; gs = M.x_size[r];
         }
-    }
-    acc[w][0][lane] = ra; acc[w][1][lane] = rp; acc[w][2][lane] = cp;
-    if (w == 0) p_len[lane] = 0;
-    __syncthreads();
-    if (w == 0 && part) {
-        ra = rp = cp = 0;
-#pragma unroll
-        for (int k = 0; k < DMX_RW; k++) { ra += acc[k][0][lane]; rp += acc[k][1][lane]; cp += acc[k][2][lane]; }
-        reinterpret_cast<uint32_t *>(blob + T.lay.grp_tokens)[g0 + ra] = t + 2u;
-        if ((key >> 27) == 0u) {                        // a survivor: pattern p of its group, and p + (survivors of the group) = its reverse complement
-            const uint32_t kg = M.x_kept[r], p = M.x_pat0[r] + rp, gid1 = M.x_gid[r] + 1u;
-            const uint32_t dst_f = M.x_pch0[r] + cp, dst_r = dst_f + M.x_kchars[r];
-            uint64_t *pat_off = reinterpret_cast<uint64_t *>(blob + T.lay.pat_off);
-            uint32_t *pat_group = reinterpret_cast<uint32_t *>(blob + T.lay.pat_group);
-            pat_off[p] = dst_f; pat_off[p + kg] = dst_r;
-            pat_group[p] = gid1; pat_group[p + kg] = gid1;
-            p_t[lane] = t; p_f[lane] = dst_f; p_r[lane] = dst_r; p_len[lane] = (uint8_t)((key >> 20) & 0x7Fu);
-        }
-    }
-    __syncthreads();
-    // the pattern strings: every survivor and its reverse complement, 8 characters per thread
-    char *pat_chars = reinterpret_cast<char *>(blob + T.lay.pat_chars);
-    const uint32_t stride = M.stride, cpr = stride >> 3;
-    for (uint32_t q = threadIdx.x; q < 64u * cpr; q += 64u * DMX_RW) {
-        const uint32_t e = q / cpr, c8 = (q - e * cpr) * 8u, len = p_len[e];
-        if (c8 >= len) continue;
-        const uint2 wd = *reinterpret_cast<const uint2 *>(M.dx_chars + (uint64_t)p_t[e] * stride + c8);
-        char *df = pat_chars + p_f[e] + c8, *dr = pat_chars + p_r[e] + (len - 1u - c8);
-        const uint32_t nb = min(8u, len - c8);
-#pragma unroll
-        for (uint32_t b2 = 0; b2 < 8; b2++)
-            if (b2 < nb) {
-                const char c = (char)(((b2 < 4 ? wd.x : wd.y) >> (8u * (b2 & 3u))) & 0xFFu);
-                df[b2] = c;
-                *(dr - b2) = dmx_comp(c);
+        // (the lanes of a chunk that belong to such groups: their lists form one contiguous range, groups of up to x_sort_max members
+        // in between are skipped by the per-lane test below)
+        const bool part = act && gs > M.x_sort_max;
+        const uint64_t am = __ballot(part);
+        if (am == 0ull) continue;                       // (uniform over the block: every wave holds the same 64 entries)
+        const int first = __ffsll((unsigned long long)am) - 1, lastl = 63 - __clzll((unsigned long long)am);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)g0, first);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(g0 + gs), lastl);
+        uint32_t ra = 0;
+        for (uint32_t base = lo + 64u * (uint32_t)w; base < hi; base += 64u * DMX_RW) {
+            const uint32_t cur = base + (uint32_t)lane < hi ? M.x_members[base + lane] : 0u;
+            const uint32_t cnt = min(hi - base, 64u);
+            const uint32_t rel = base - g0;             // per lane: key q of this chunk is member (rel + q) of the lane's group iff < gs
+            for (uint32_t q = 0; q < cnt; q++) {
+                const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)q);
+                ra += (rel + q < gs && k2 < t) ? 1u : 0u;      // (unsigned: also false for keys in front of the lane's group)
             }
+        }
+        acc[w][lane] = ra;
+        __syncthreads();
+        if (w == 0 && part) {
+            ra = 0;
+#pragma unroll
+            for (int k = 0; k < DMX_RW; k++) ra += acc[k][lane];
+            reinterpret_cast<uint32_t *>(blob + t_grp_tokens)[g0 + ra] = t + 2u;
+        }
+        __syncthreads();                                // (the next chunk reuses acc)
     }
-    __syncthreads();                                    // (the next chunk reuses acc / p_*)
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *M.x_htot = T;      // (the host only reads the blob after the stream's event)
+    publish();
 }
 
 // ---- one-collective exchange ----
@@ -1047,13 +989,12 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done
     static const unsigned greedy_per_cu = getenv("CRASS_DM_GREEDY_PER_CU") ? (unsigned)std::max(1, atoi(getenv("CRASS_DM_GREEDY_PER_CU"))) : 1u;      // (experiment)
     if (gb > M.n_cu * greedy_per_cu) gb = M.n_cu * greedy_per_cu;
     CRASS_LAUNCH(k_dm_greedy, dim3(gb), dim3(1024), 0, st, M);
-    CRASS_LAUNCH(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
-    CRASS_LAUNCH(k_dm_rd_fill, dim3(nb), dim3(256), 0, st, M);
-    unsigned rb = (M.n_tok + 3) / 4;
-    if (rb > 4096) rb = 4096;
-    CRASS_LAUNCH(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
     if (M.x_on && view_st) {
-        // the view only needs root_of[] and blank[]: it is assembled beside the kernels that build pass 2's index
+        // The view's device part — tokens, groups, every group's tokens in order — only needs root_of[]: it is assembled beside
+        // removeRedundantRepeats and the kernels that build pass 2's index, and is through before pass 2's probe starts (forked
+        // behind k_dm_redundant, as until round 6, its last kernels ran beside the probe and the verification: + 40 us for them
+        // and a view that was ready 20 us after the step's last kernel).  The pattern list needs blank[] as well: the host puts
+        // it together from this view and blank[] (build_host_merge), which k_dm_keys' stage flag announces.
         hipError_t e = hipEventRecord(ev_fork, st);
         if (e == hipSuccess) e = hipStreamWaitEvent(view_st, ev_fork, 0);
         if (e != hipSuccess) return e;
@@ -1068,6 +1009,11 @@ hipError_t launch_device_merge(const DevMerge &M, hipStream_t st, bool init_done
         e = hipEventRecord(ev_view, view_st);
         if (e != hipSuccess) return e;
     }
+    CRASS_LAUNCH(k_dm_rd_bases, dim3(nb), dim3(256), 0, st, M);
+    CRASS_LAUNCH(k_dm_rd_fill, dim3(nb), dim3(256), 0, st, M);
+    unsigned rb = (M.n_tok + 3) / 4;
+    if (rb > 4096) rb = 4096;
+    CRASS_LAUNCH(k_dm_redundant, dim3(rb), dim3(256), 0, st, M);
     const unsigned ne = (16u * M.n_tok + 255) / 256;
     CRASS_LAUNCH(k_dm_keys, dim3(ne), dim3(256), 0, st, M);
     CRASS_LAUNCH(k_dm_key_bases_insert, dim3((16u * M.n_tok + 1023) / 1024), dim3(1024), 0, st, M);

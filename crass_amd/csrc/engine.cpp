@@ -410,7 +410,8 @@ struct crass_hip_ctx {
         DevBuf<uint32_t> x_u32, x_members, x_tile; DevBuf<uint8_t> x_blob; DevBuf<DevViewTotals> x_tot;
         PinBuf<DevViewTotals> x_htot; PinBuf<uint8_t> h_view;
         hipStream_t view_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_view = nullptr, ev_apply = nullptr;
-        SdmaCopy *dma_view = nullptr, *dma_view2 = nullptr;      // (the blob travels in two pieces: the token half behind k_dmx_apply, the rest behind the last kernel)
+        SdmaCopy *dma_view = nullptr, *dma_view2 = nullptr, *dma_view3 = nullptr;
+        uint32_t want_blank = 0;                    // the stage flag value k_dm_keys stores for this merge (h_flags[3]): blank[] is final      // (the blob travels in two pieces: the token half behind k_dmx_apply, the rest behind the last kernel)
         bool hx_on_host = true;                     // the gathered distinct list has a pinned host copy (else: on the device only)
         bool view_launched = false;                 // export kernels may be running on view_stream (ev_view orders after them)
         bool apply_recorded = false;                // ev_apply was recorded behind this merge's k_dmx_apply
@@ -432,6 +433,7 @@ struct crass_hip_ctx {
             if (view_stream) (void)hipStreamSynchronize(view_stream);
             sdma_destroy(dma_view); dma_view = nullptr;
             sdma_destroy(dma_view2); dma_view2 = nullptr;
+            sdma_destroy(dma_view3); dma_view3 = nullptr;
             if (ev_apply) (void)hipEventDestroy(ev_apply);
             ev_apply = nullptr;
             if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -2272,6 +2274,7 @@ static int device_merge_prepare(crass_hip_ctx *c, const char *dx_chars, const ui
             HIPCHK(c, hipEventCreateWithFlags(&d.ev_apply, hipEventDisableTiming));
             d.dma_view = sdma_create();                 // (nullptr: the runtime's copy is used)
             d.dma_view2 = sdma_create();
+            d.dma_view3 = sdma_create();
         }
         const uint64_t cap = view_layout(n, n, 2ull * n, (uint64_t)n * stride, 2ull * n * stride).total;
         HIPCHK(c, d.x_u32.ensure((size_t)n * 8)); HIPCHK(c, d.x_members.ensure(n)); HIPCHK(c, d.x_tile.ensure(kDmxTiles * kDmxVals + 4));
@@ -2305,6 +2308,7 @@ static int device_merge_enqueue(crass_hip_ctx *c, const char *dx_chars, const ui
     if (c->timing_level >= 2) HIPCHK(c, hipEventRecord(d.ev_t0, c->stream));
     d.M.flag_pre = c->poll_on ? c->h_flags.p + 1 : nullptr; d.M.flag_pre_val = c->want_pre = ++c->flag_seq;
     d.M.flag_post = c->poll_on ? c->h_flags.p + 2 : nullptr; d.M.flag_post_val = d.want_post = ++c->flag_seq;
+    d.M.flag_blank = c->poll_on ? c->h_flags.p + 3 : nullptr; d.M.flag_blank_val = d.want_blank = ++c->flag_seq;
     static const bool view_inline = getenv("CRASS_VIEW_INLINE") != nullptr;      // A/B switch: the export on the merge's own stream
     HIPCHK(c, launch_device_merge(d.M, c->stream, prepared, d.M.x_on ? (view_inline ? c->stream : d.view_stream) : nullptr, d.ev_fork, d.ev_view,
                                   view_inline ? nullptr : d.ev_apply));
@@ -2494,52 +2498,144 @@ static int build_host_merge(crass_hip_ctx *c)
             c->merge.cand_token[k] = cmap[k] + 2;
         }
         const double tv0 = now_ms();
-        // the token half of the blob (tok_off, the token strings, grp_off: ~70 % of its bytes) is complete behind k_dmx_apply: its
-        // copy starts now, beside the kernels that rank the members; what is left for the end is the second piece (2.25 MB in one
-        // piece were 50 us behind the last kernel, the end of a rank's step at 100 M reads over 8 GPUs)
-        uint64_t early = 0;
-        static const bool one_piece = getenv("CRASS_VIEW_ONE_COPY") != nullptr;      // A/B switch
-        if (d.apply_recorded && !one_piece && d.dma_view && d.dma_view2) {
+        // The device's part of the view (k_dmx_*, forked behind k_dm_greedy): tok_off, the token strings, grp_off — complete
+        // behind k_dmx_apply, copied first, beside the kernels that order the members — and grp_tokens, complete behind the
+        // export's last kernel.  The PATTERN LIST (per group the survivors by length then token, then their reverse
+        // complements: WorkHorse.cpp:690-697, remove_redundant's order) is put together here, from that view and blank[],
+        // which k_dm_redundant has finished when k_dm_keys' stage flag shows — while the device builds pass 2's index and
+        // runs pass 2.  (Until round 6 the export ran behind k_dm_redundant and ranked the patterns too: its last kernels
+        // shared the CUs with pass 2's probe and verification, and the view was ready ~20 us after the step's last kernel.)
+        auto hipfail = [&](hipError_t e) { d.br.hip = (int)e; return e == hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP; };
+        bool usable = d.apply_recorded && d.dma_view && d.dma_view2 && d.dma_view3;
+        DevViewTotals E{};
+        if (usable) {
             const hipError_t e = hipEventSynchronize(d.ev_apply);
-            if (e != hipSuccess) { d.br.hip = (int)e; return CRASS_ERR_HIP; }
-            const DevViewTotals E = d.x_htot.p[1];
-            if (E.ok && E.n_tok == d.n_tok && E.lay.total <= d.x_blob.n && E.lay.grp_tokens <= E.lay.total) {
-                if (d.h_view.n < E.lay.total) {
-                    const hipError_t e2 = d.h_view.ensure(E.lay.total + E.lay.total / 2);
-                    if (e2 != hipSuccess) { d.br.hip = (int)e2; return e2 == hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP; }
+            if (e != hipSuccess) return hipfail(e);
+            E = d.x_htot.p[1];
+            usable = E.ok && E.n_tok == d.n_tok && E.n_groups >= 1 && E.lay.total <= d.x_blob.n && E.lay.grp_tokens <= E.lay.pat_off && E.lay.pat_off <= E.lay.total;
+        }
+        if (usable) {
+            // room for the whole view whatever survives (every token a pattern, twice): grown before the first copy lands
+            const uint64_t room = view_layout(E.n_tok, E.n_groups, 2ull * E.n_tok, E.tok_chars, 2ull * E.tok_chars).total;
+            if (d.h_view.n < room) { const hipError_t e2 = d.h_view.ensure(room + room / 4); if (e2 != hipSuccess) return hipfail(e2); }
+            bool ok = sdma_start(d.dma_view2, d.x_blob.p, d.h_view.p, E.lay.grp_tokens);
+            struct Guard { SdmaCopy *s; bool on; ~Guard() { if (on) (void)sdma_wait(s); } } g2{d.dma_view2, ok}, g1{d.dma_view, false}, g3{d.dma_view3, false};
+            // blank[]: final when k_dm_redundant is through (the flag is k_dm_keys'); a poll that runs out waits for the merge
+            if (!(c->poll_on && c->poll_flag(3, d.want_blank, 2.0))) { if (const int ws = wait_done()) return ws; }
+            g3.on = ok && sdma_start(d.dma_view3, d.blank.p, d.h_blank.p, d.n_tok);
+            ok = ok && g3.on;
+            { const hipError_t e = hipEventSynchronize(d.ev_view); if (e != hipSuccess) return hipfail(e); }
+            const DevViewTotals T0 = *d.x_htot.p;
+            usable = T0.ok && T0.n_tok == d.n_tok && T0.n_groups == E.n_groups && T0.lay.grp_tokens == E.lay.grp_tokens && T0.lay.pat_off == E.lay.pat_off;
+            if (usable) {
+                g1.on = ok && sdma_start(d.dma_view, d.x_blob.p + E.lay.grp_tokens, d.h_view.p + E.lay.grp_tokens, E.lay.pat_off - E.lay.grp_tokens);
+                ok = ok && g1.on;
+                if (g1.on) { g1.on = false; ok = sdma_wait(d.dma_view) == 0 && ok; }
+                if (g2.on) { g2.on = false; ok = sdma_wait(d.dma_view2) == 0 && ok; }
+                if (g3.on) { g3.on = false; ok = sdma_wait(d.dma_view3) == 0 && ok; }
+                if (!ok) {                              // (no engine: the runtime's copies, behind the export on its stream)
+                    hipError_t e = hipMemcpyAsync(d.h_view.p, d.x_blob.p, E.lay.pat_off, hipMemcpyDeviceToHost, d.view_stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(d.h_blank.p, d.blank.p, d.n_tok, hipMemcpyDeviceToHost, d.view_stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(d.view_stream);
+                    if (e != hipSuccess) return hipfail(e);
                 }
-                if (sdma_start(d.dma_view2, d.x_blob.p, d.h_view.p, E.lay.grp_tokens)) early = E.lay.grp_tokens;
+                const double tv1 = now_ms();
+                // ---- the pattern list ----
+                uint8_t *hb = d.h_view.p;
+                const uint64_t *tok_off = reinterpret_cast<const uint64_t *>(hb + E.lay.tok_off), *grp_off = reinterpret_cast<const uint64_t *>(hb + E.lay.grp_off);
+                const char *tok_chars = reinterpret_cast<const char *>(hb + E.lay.tok_chars);
+                const uint32_t *grp_tokens = reinterpret_cast<const uint32_t *>(hb + E.lay.grp_tokens);
+                const uint8_t *blank = d.h_blank.p;
+                // (over the host pool: a group's part of the list depends on the groups in front of it only through two offsets —
+                // one thread took 1.1 ms for 13 k patterns of 42 k tokens; chunks of groups of ~equal member counts)
+                const uint32_t NG = E.n_groups;
+                const size_t n_chunks = std::min<size_t>(64, NG);
+                std::vector<uint32_t> chunk_g0(n_chunks + 1, NG);
+                {
+                    size_t cidx = 0;
+                    for (uint32_t g = 0; g < NG && cidx < n_chunks; g++)
+                        if (grp_off[g] * n_chunks >= (uint64_t)cidx * E.n_tok) chunk_g0[cidx++] = g;
+                    for (; cidx < n_chunks; cidx++) chunk_g0[cidx] = NG;
+                    chunk_g0[n_chunks] = NG;
+                }
+                std::vector<uint64_t> ck(n_chunks + 1, 0), cc(n_chunks + 1, 0);     // kept tokens / their characters per chunk
+                std::atomic<int> bad{0};
+                bool sane = grp_off[NG] == E.n_tok;
+                if (sane) host_parallel_for(n_chunks, 64, [&](size_t ci) {
+                    uint64_t k = 0, chs = 0;
+                    for (uint64_t i = grp_off[chunk_g0[ci]], e = chunk_g0[ci + 1] < NG ? grp_off[chunk_g0[ci + 1]] : E.n_tok; i < e; i++) {
+                        const uint32_t t = grp_tokens[i] - 2u;
+                        if (t >= E.n_tok) { bad = 1; return; }
+                        const uint64_t len = tok_off[t + 1] - tok_off[t];
+                        if (len > 64) { bad = 1; return; }
+                        if (!blank[t]) { k++; chs += len; }
+                    }
+                    ck[ci + 1] = k; cc[ci + 1] = chs;
+                });
+                sane = sane && !bad.load();
+                for (size_t ci = 0; ci < n_chunks; ci++) { ck[ci + 1] += ck[ci]; cc[ci + 1] += cc[ci]; }
+                const uint64_t n_kept = ck[n_chunks], kept_chars = cc[n_chunks];
+                if (sane) {
+                    DevViewTotals T = T0;
+                    T.n_kept = (uint32_t)n_kept; T.kept_chars = (uint32_t)kept_chars;
+                    T.lay = view_layout(E.n_tok, E.n_groups, 2ull * n_kept, E.tok_chars, 2ull * kept_chars);
+                    uint64_t *pat_off = reinterpret_cast<uint64_t *>(hb + T.lay.pat_off);
+                    char *pat_chars = reinterpret_cast<char *>(hb + T.lay.pat_chars);
+                    uint32_t *pat_group = reinterpret_cast<uint32_t *>(hb + T.lay.pat_group);
+                    host_parallel_for(n_chunks, 64, [&](size_t ci) {
+                        static thread_local std::vector<uint32_t> order;        // a group's survivors by length, then token
+                        static const struct Comp { char t[256]; Comp() { for (int i = 0; i < 256; i++) t[i] = (char)i; t['A'] = 'T'; t['C'] = 'G'; t['G'] = 'C'; t['T'] = 'A'; } } comp;   // SeqUtils.cpp:50-59 over the device merge's alphabet
+                        uint64_t p = 2ull * ck[ci], ch = 2ull * cc[ci];
+                        for (uint32_t g = chunk_g0[ci]; g < chunk_g0[ci + 1]; g++) {
+                            const uint64_t m0 = grp_off[g], m1 = grp_off[g + 1];
+                            uint32_t cnt[66] = {0};
+                            uint32_t kg = 0;
+                            for (uint64_t i = m0; i < m1; i++) {
+                                const uint32_t t = grp_tokens[i] - 2u;
+                                if (blank[t]) continue;
+                                cnt[tok_off[t + 1] - tok_off[t] + 1]++; kg++;
+                            }
+                            for (int l = 1; l < 66; l++) cnt[l] += cnt[l - 1];
+                            order.resize(kg);
+                            for (uint64_t i = m0; i < m1; i++) {             // (token order inside a length: the list is sorted by token)
+                                const uint32_t t = grp_tokens[i] - 2u;
+                                if (!blank[t]) order[cnt[tok_off[t + 1] - tok_off[t]]++] = t;
+                            }
+                            uint64_t chr = ch;
+                            for (uint32_t j = 0; j < kg; j++) chr += tok_off[order[j] + 1] - tok_off[order[j]];
+                            for (uint32_t j = 0; j < kg; j++) {
+                                const uint32_t t = order[j];
+                                const uint64_t len = tok_off[t + 1] - tok_off[t];
+                                const char *src = tok_chars + tok_off[t];
+                                pat_off[p + j] = ch; pat_group[p + j] = g + 1u;
+                                pat_off[p + kg + j] = chr; pat_group[p + kg + j] = g + 1u;
+                                memcpy(pat_chars + ch, src, len);
+                                char *dst = pat_chars + chr;
+                                for (uint64_t q = 0; q < len; q++) dst[q] = comp.t[(unsigned char)src[len - 1 - q]];      // reverseComplement
+                                ch += len; chr += len;
+                            }
+                            p += 2ull * kg; ch = chr;
+                        }
+                    });
+                    pat_off[2ull * n_kept] = 2ull * kept_chars;
+                    const double tv2 = now_ms();
+                    if (const int ws = wait_done()) return ws;
+                    if (d.h_st.p->fail) return CRASS_ERR_STATE;
+                    if (sane && 2u * T.n_kept == d.h_st.p->n_patterns) {
+                        d.view_tot = T;
+                        d.view_ready = true;
+                        d.host_built = true;
+                        if (c->env.merge_profile)
+                            fprintf(stderr, "[crass_dm] helper: candidates' tokens %.1f us, the device's part of the view in host memory %.1f us later, pattern list %.1f us (done %.1f us after the pass-1 sync; the merge's state %.1f us after that)\n",
+                                    1e3 * (tv0 - tb00), 1e3 * (tv1 - tv0), 1e3 * (tv2 - tv1), 1e3 * (tv2 - c->t_p1_sync), 1e3 * (now_ms() - tv2));
+                        publish();
+                        return CRASS_OK;
+                    }
+                }
             }
         }
-        struct EarlyCopy { SdmaCopy *s; bool on; ~EarlyCopy() { if (on) (void)sdma_wait(s); } } early_guard{d.dma_view2, early != 0};      // (no exit leaves it in flight)
         if (const int ws = wait_done()) return ws;
         if (d.h_st.p->fail) return CRASS_ERR_STATE;
-        { const hipError_t e = hipEventSynchronize(d.ev_view); if (e != hipSuccess) { d.br.hip = (int)e; return CRASS_ERR_HIP; } }
-        const double tv1 = now_ms();
-        const DevViewTotals T = *d.x_htot.p;
-        if (T.ok && T.n_tok == d.n_tok && 2u * T.n_kept == d.h_st.p->n_patterns && T.n_groups >= 1 && T.lay.total <= d.x_blob.n) {
-            if (early && (d.h_view.n < T.lay.total || early != T.lay.grp_tokens)) { (void)sdma_wait(d.dma_view2); early_guard.on = false; early = 0; }   // (never expected)
-            if (d.h_view.n < T.lay.total) {
-                const hipError_t e = d.h_view.ensure(T.lay.total + T.lay.total / 2);
-                if (e != hipSuccess) { d.br.hip = (int)e; return e == hipErrorOutOfMemory ? CRASS_ERR_OOM : CRASS_ERR_HIP; }
-            }
-            bool copied = false;
-            if (sdma_start(d.dma_view, d.x_blob.p + early, d.h_view.p + early, T.lay.total - early)) copied = sdma_wait(d.dma_view) == 0;
-            if (early) { early_guard.on = false; if (sdma_wait(d.dma_view2) != 0) { copied = false; early = 0; } }
-            if (!copied) {
-                hipError_t e = hipMemcpyAsync(d.h_view.p, d.x_blob.p, T.lay.total, hipMemcpyDeviceToHost, d.view_stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(d.view_stream);
-                if (e != hipSuccess) { d.br.hip = (int)e; return CRASS_ERR_HIP; }
-            }
-            d.view_tot = T;
-            d.view_ready = true;
-            d.host_built = true;
-            if (c->env.merge_profile)
-                fprintf(stderr, "[crass_dm] helper: candidates' tokens %.1f us, waited %.1f us for the merge + view kernels, blob copy (%llu bytes) %.1f us (done %.1f us after the pass-1 sync)\n",
-                        1e3 * (tv0 - tb00), 1e3 * (tv1 - tv0), (unsigned long long)T.lay.total, 1e3 * (now_ms() - tv1), 1e3 * (now_ms() - c->t_p1_sync));
-            publish();
-            return CRASS_OK;
-        }
         // (a group beyond x_group_cap, or totals that do not add up: the host builds the view from the per-token results)
         c->n_view_fallbacks++;
     }

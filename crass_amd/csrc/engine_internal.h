@@ -220,6 +220,7 @@ struct DevMerge {
     // between two kernels (~6 us of stream time each).  flag_pre: k_dm_pack_codes; flag_post: pass 2's probe
     uint32_t *flag_pre; uint32_t flag_pre_val;
     uint32_t *flag_post; uint32_t flag_post_val;
+    uint32_t *flag_blank; uint32_t flag_blank_val;  // k_dm_keys: blank[] is final (the host builds the view's pattern list from it)
     uint32_t x_sort_max;          // groups of 65 .. this many members (<= 2048) are ranked by k_dmx_sort, the others by k_dmx_rank
     uint32_t *hot;                // the counters every block adds to, striped: [kDmHotCounters][kDmHotStripes] words, 128 bytes apart (dm_hot)
     uint32_t ablate;              // profiling aid (CRASS_DM_ABLATE, tools/dm_ablate.py): bits switch parts of the merge kernels OFF — results are then garbage

@@ -4451,7 +4451,9 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter(DevReads R, DevAnchor
 }
 
 // the same filter when the key table was built on the device (dmerge.hip): its size is only known there
-template <int W, int THREADS>
+// (ASH is a template parameter of the KERNEL: with both forms in one kernel the default one was allocated the other's registers —
+// 99 instead of 56 — and no other kernel's waves fitted beside its four per SIMD any more)
+template <int W, int THREADS, int ASH>
 __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMerge M, const uint8_t *found_flag, uint64_t *hitmask)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ak_lds_buf[];
@@ -4464,23 +4466,19 @@ __global__ __launch_bounds__(THREADS) void k_anchor_filter_dev(DevReads R, DevMe
         for (uint64_t t = blockIdx.x * (uint64_t)THREADS + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * THREADS) hitmask[t] = 0ull;
         return;
     }
-    const bool a4 = M.akey_shift == 2u;                 // (uniform) windows every 4 bases: patterns of 19 .. 22 bases
     if (K.log_size <= 15) {
         const uint32_t tsize = 1u << K.log_size;
         for (uint32_t i = threadIdx.x; i < tsize; i += THREADS) ak_lds_buf[i] = K.table[i];
         __syncthreads();
-        if (a4) anchor_filter_body<W, THREADS, 0, 2>(R, K, ak_lds_buf, found_flag, hitmask);
-        else anchor_filter_body<W, THREADS, 0>(R, K, ak_lds_buf, found_flag, hitmask);
+        anchor_filter_body<W, THREADS, 0, ASH>(R, K, ak_lds_buf, found_flag, hitmask);
     } else if (M.st->tab_mode == 3) {
         for (uint32_t i = threadIdx.x; i < (1u << 15); i += THREADS) ak_lds_buf[i] = M.anchor_fp[i];
         __syncthreads();
-        if (a4) anchor_filter_body<W, THREADS, 3, 2>(R, K, ak_lds_buf, found_flag, hitmask);
-        else anchor_filter_body<W, THREADS, 3>(R, K, ak_lds_buf, found_flag, hitmask);
+        anchor_filter_body<W, THREADS, 3, ASH>(R, K, ak_lds_buf, found_flag, hitmask);
     } else {
         for (uint32_t i = threadIdx.x; i < (1u << 15); i += THREADS) ak_lds_buf[i] = M.anchor_fp[i];
         __syncthreads();
-        if (a4) anchor_filter_body<W, THREADS, 4, 2>(R, K, ak_lds_buf, found_flag, hitmask);
-        else anchor_filter_body<W, THREADS, 4>(R, K, ak_lds_buf, found_flag, hitmask);
+        anchor_filter_body<W, THREADS, 4, ASH>(R, K, ak_lds_buf, found_flag, hitmask);
     }
 }
 
@@ -4493,12 +4491,13 @@ hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const 
     uint64_t blocks = (n_tiles + (T / 64) - 1) / (T / 64);
     if (blocks > 256) blocks = 256;
     hipError_t e;
-#define AKD_LAUNCH(WW)                                                                                                  \
+#define AKD_LAUNCH1(WW, AA)                                                                                             \
     {                                                                                                                   \
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_anchor_filter_dev<WW, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_anchor_filter_dev<WW, T, AA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                  \
-        CRASS_LAUNCH((k_anchor_filter_dev<WW, T>), dim3((unsigned)blocks), dim3(T), lds, st, R, M, found_flag, hitmask); \
+        CRASS_LAUNCH((k_anchor_filter_dev<WW, T, AA>), dim3((unsigned)blocks), dim3(T), lds, st, R, M, found_flag, hitmask); \
     }
+#define AKD_LAUNCH(WW) { if (M.akey_shift == 2u) AKD_LAUNCH1(WW, 2) else AKD_LAUNCH1(WW, 3) }
     switch (R.stride_words) {
         case 4: AKD_LAUNCH(4) break;  case 5: AKD_LAUNCH(5) break;  case 6: AKD_LAUNCH(6) break;  case 7: AKD_LAUNCH(7) break;
         case 8: AKD_LAUNCH(8) break;  case 9: AKD_LAUNCH(9) break;  case 10: AKD_LAUNCH(10) break; case 11: AKD_LAUNCH(11) break;
@@ -4507,6 +4506,7 @@ hipError_t launch_anchor_filter_dev(const DevReads &R, const DevMerge &M, const 
         default: AKD_LAUNCH(0) break;
     }
 #undef AKD_LAUNCH
+#undef AKD_LAUNCH1
     return hipGetLastError();
 }
 
