@@ -169,6 +169,7 @@ struct EnvSwitches {
     bool dd_full_table = false;                      // A/B switch: pass 1's de-duplication table sized for the survivor slots (the round-3 size)
     bool no_device_view = false;                     // A/B switch: the host rebuilds crass_merge_view from root_of / blank (the round-3 path)
     bool force_device_view = false;                  // CRASS_DEVICE_VIEW=1: the device assembles it for a single context too (default: multi-rank only)
+    bool no_dense_light = false;                     // CRASS_NO_DENSE_LIGHT: the A/B switch of the light walk over the dense path's survivors
     bool no_warm_launch = false;                     // CRASS_NO_WARM_LAUNCH: the A/B switch of first_call_bounds' empty launch
     uint32_t view_group_cap = 32768;                 // groups beyond this many members are ranked by the host (CRASS_VIEW_GROUP_CAP)
     uint32_t view_sort_max = 2048;                   // groups of 65 .. this many members are ranked by a sort in LDS (k_dmx_sort; CRASS_VIEW_SORT_MAX: tests)
@@ -199,6 +200,7 @@ struct EnvSwitches {
         wave_walk_min = 800; if (const char *e = getenv("CRASS_WAVE_WALK_MIN")) wave_walk_min = (uint32_t)std::max(0, atoi(e));
         long_min = 2048; if (const char *e = getenv("CRASS_LONG_MIN")) long_min = (uint32_t)std::max(0, atoi(e));
         no_warm_launch = getenv("CRASS_NO_WARM_LAUNCH") != nullptr;
+        no_dense_light = getenv("CRASS_NO_DENSE_LIGHT") != nullptr;
         pool_cap_bytes = 0; if (const char *e = getenv("CRASS_POOL_CAP_MB")) pool_cap_bytes = (uint64_t)std::max(1ll, atoll(e)) << 20;
     }
 };
@@ -1528,6 +1530,25 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
                                                      c->d_ss_pool.p, lds.ss_cap, c->d_found.p, hints, c->stream, init_merge, c->max_len);
     if (le != hipSuccess && le != hipErrorNotSupported) { c->last_hip = (int)le; return CRASS_ERR_HIP; }
     if (le == hipSuccess && init_merge) { c->dm_prepared_n = init_merge->n_tok; c->dm_prepared_src = init_merge->dx_chars; }
+    // Reads the lane kernel does not take (513 .. 2 048 bases): the long reads' LIGHT walk over the survivor list first — nearly every
+    // survivor of such a set is a chance seed hit that ends without a candidate (a quarter of 1 000-base reads pass a 7-base window's
+    // filter) — and the full wave kernel only for what it hands over, from the seed it stopped at.  Position hints of the default
+    // lattice: k_long_light on them; another window or lattice: k_long_light_any, which works the bits out as it walks.
+    bool light_done = false;
+    if (le == hipErrorNotSupported && !no_lanes && c->dp.debug_stop == 0 && !c->env.no_dense_light && c->max_len <= 12288 && c->dp.window >= 6 && c->dp.window <= 9) {
+        DevReads RL = c->R;
+        const bool lattice = c->R.pos_hint && !c->R.hint_all && c->dp.skips == 8 && c->dp.window == 8;
+        if (!lattice && !c->R.hint_all) RL.pos_hint = nullptr;
+        HIPCHK(c, c->d_punt.ensure(n_surv + 1)); HIPCHK(c, hipMemsetAsync(c->d_punt.p, 0, 4, c->stream));
+        const hipError_t ll = launch_long_light(RL, c->dp, d_nsurv, n_surv, c->d_surv.p, 0, c->max_len, c->stream, c->d_punt.p + 1, c->d_punt.p, c->d_idx.p);
+        if (ll == hipSuccess) {
+            light_done = true;
+            HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
+                                      c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, hints, lds,
+                                      (int)std::min<uint64_t>(256 * 12, n_surv), c->stream, 7, 0, 0, c->d_punt.p + 1, c->d_punt.p));
+        } else if (ll != hipErrorNotSupported) { c->last_hip = (int)ll; return CRASS_ERR_HIP; }
+    }
+    if (!light_done)
     HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
                               c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, hints, lds,
                               (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, le == hipSuccess ? 4 : 0));

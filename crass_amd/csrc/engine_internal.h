@@ -321,7 +321,7 @@ hipError_t launch_hint_filter_any(const DevReads &R, const DevParams &P, const u
 // long reads with position hints, an identity survivor list and no exception read: the walk of the reads without an array; a read
 // that needs the full searchCore leaves with err == 7 for launch_survivor(..., punt_only = 7)
 hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
-                             uint32_t max_len, hipStream_t st, uint32_t *punt_list, uint32_t *d_punt_n);      // punt_list[(*d_punt_n)++] = slot of a read handed over
+                             uint32_t max_len, hipStream_t st, uint32_t *punt_list, uint32_t *d_punt_n, const uint64_t *surv_idx = nullptr);      // punt_list[(*d_punt_n)++] = slot of a read handed over
 // clear_found / cleared: the fixed-range kernel also zeroes the n_reads + 1 found flags on its way (*cleared says whether the form
 // that was launched did: the caller clears them itself otherwise)
 hipError_t launch_filter_fast(const DevReads &R, const DevParams &P, uint64_t *hitmask, uint32_t *seed_hint, hipStream_t st,

@@ -2292,8 +2292,10 @@ static __device__ __forceinline__ uint32_t ll_next_hinted(const uint64_t (&cur)[
 }
 
 template <bool RANGE>
+// surv_idx (optional): slot s holds read surv_idx[s] — the dense path's survivor list (reads of 513 .. 2 048 bases, whose
+// survivors the lane kernel does not take: until round 6 every one of them was a walk of the full wave kernel); nullptr: s + slot_base
 __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
-                                                     uint32_t *punt_list, uint32_t *d_punt_n)
+                                                     uint32_t *punt_list, uint32_t *d_punt_n, const uint64_t *surv_idx)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ll_words[];
     const int lane = threadIdx.x;
@@ -2302,9 +2304,15 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
     const uint32_t cmask = (1u << (2 * P.window)) - 1u;
     const int w = (int)P.window;
     LightPrefetch pf;
-    if (blockIdx.x < n) ll_prefetch(R, blockIdx.x + slot_base, lane, pf);
+    auto read_of = [&](uint64_t sl) -> uint64_t { return surv_idx ? uni64(surv_idx[sl]) : sl + slot_base; };
+    if (blockIdx.x < n) ll_prefetch(R, read_of(blockIdx.x), lane, pf);
     for (uint64_t s = blockIdx.x; s < n; s += gridDim.x) {
-        const uint64_t r = s + slot_base;
+        const uint64_t r = read_of(s);
+        if (surv_idx && R.n_exc && rd_is_exc(R, r)) {                             // an exception read in the list: left to the exception pass
+            if (lane == 0) { SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = 5; out[s] = x; }
+            if (s + gridDim.x < n) ll_prefetch(R, read_of(s + gridDim.x), lane, pf);
+            continue;
+        }
         const int L = (int)uni(rd_len(R, r));
         const int nw = (L + 15) >> 4, nh = (L + 63) >> 6;
         uint64_t cur[LL_HW];
@@ -2323,7 +2331,7 @@ __global__ __launch_bounds__(WAVE) void k_long_light(DevReads R, DevParams P, co
 #pragma unroll
             for (int i = 0; i < LL_VEC; i++) { const int gi = lane + i * WAVE; if (gi < ng) w4[gi] = pf.v[i]; }
         }
-        if (s + gridDim.x < n) ll_prefetch(R, r + gridDim.x, lane, pf);          // the next read travels during this one's walk
+        if (s + gridDim.x < n) ll_prefetch(R, read_of(s + gridDim.x), lane, pf);  // the next read travels during this one's walk
         if (seeds && !too_long) {
             wave_sync();
             const uint32_t seq_length = (uint32_t)L;
@@ -2527,7 +2535,7 @@ hipError_t launch_hint_filter_any(const DevReads &R, const DevParams &P, const u
 }
 
 __global__ __launch_bounds__(WAVE) void k_long_light_any(DevReads R, DevParams P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
-                                                         uint32_t *punt_list, uint32_t *d_punt_n)
+                                                         uint32_t *punt_list, uint32_t *d_punt_n, const uint64_t *surv_idx)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ll_words[];
     const int lane = threadIdx.x;
@@ -2543,9 +2551,15 @@ __global__ __launch_bounds__(WAVE) void k_long_light_any(DevReads R, DevParams P
 #pragma unroll
         for (int i = 0; i < LL_VEC; i++) pfv[i] = sv_load_group(g, lane + i * WAVE, nw);
     };
-    if (blockIdx.x < n) prefetch(blockIdx.x + slot_base);
+    auto read_of = [&](uint64_t sl) -> uint64_t { return surv_idx ? uni64(surv_idx[sl]) : sl + slot_base; };
+    if (blockIdx.x < n) prefetch(read_of(blockIdx.x));
     for (uint64_t s = blockIdx.x; s < n; s += gridDim.x) {
-        const uint64_t r = s + slot_base;
+        const uint64_t r = read_of(s);
+        if (surv_idx && R.n_exc && rd_is_exc(R, r)) {                             // an exception read in the list: left to the exception pass
+            if (lane == 0) { SurvOut x; x.found = 0; x.n_ss = 0; x.repeat_len = 0; x.ss_off = 0; x.dr_len = 0; x.low_lexi = 0; x.err = 5; out[s] = x; }
+            if (s + gridDim.x < n) prefetch(read_of(s + gridDim.x));
+            continue;
+        }
         const int L = (int)uni(rd_len(R, r));
         const int nw = (L + 15) >> 4, nh = (L + 63) >> 6;
         const bool too_long = nh > LL_HW * WAVE;
@@ -2558,13 +2572,14 @@ __global__ __launch_bounds__(WAVE) void k_long_light_any(DevReads R, DevParams P
 #pragma unroll
             for (int i = 0; i < LL_VEC; i++) { const int gi = lane + i * WAVE; if (gi < ng) w4[gi] = pfv[i]; }
         }
-        if (s + gridDim.x < n) prefetch(r + gridDim.x);
+        if (s + gridDim.x < n) prefetch(read_of(s + gridDim.x));
         if (!too_long) {
             wave_sync();
             const uint32_t seq_length = (uint32_t)L;
             const int searchEnd = (int)(seq_length - P.lowDR - P.lowSp - P.window - 1);
             const uint32_t n_hw = searchEnd >= 0 ? ((uint32_t)searchEnd >> 6) + 1u : 0u;
             uint64_t cur[LL_HW] = {};
+            const uint64_t *stored = (R.pos_hint && R.hint_all) ? R.pos_hint + rd_hint_off(R, r) : nullptr;
             uint32_t j = 0, done = 0, from = 0;          // `from`: the next position to look at (>= j); seeds are j, j + skips, ...
             while (searchEnd >= 0 && j <= (uint32_t)searchEnd) {
                 j = uni(j); done = uni(done); from = uni(from);
@@ -2573,10 +2588,13 @@ __global__ __launch_bounds__(WAVE) void k_long_light_any(DevReads R, DevParams P
                     const uint32_t t = done + (uint32_t)lane;
                     uint64_t bits = 0ull;
                     if (t < (uint32_t)nh) {
-                        uint32_t ww[13];
+                        if (stored) bits = stored[t];              // (every position's bit is there already: k_hint_filter_any kept them, DevReads.hint_all)
+                        else {
+                            uint32_t ww[13];
 #pragma unroll
-                        for (int i = 0; i < 13; i++) { const uint32_t wi = 4u * t + (uint32_t)i; ww[i] = wi < (uint32_t)nw ? ll_words[wi] : 0u; }
-                        bits = hint_bits_every(ww, w, D0, D1);
+                            for (int i = 0; i < 13; i++) { const uint32_t wi = 4u * t + (uint32_t)i; ww[i] = wi < (uint32_t)nw ? ll_words[wi] : 0u; }
+                            bits = hint_bits_every(ww, w, D0, D1);
+                        }
                     }
                     const uint32_t round = done >> 6;
 #pragma unroll
@@ -2651,18 +2669,19 @@ __global__ __launch_bounds__(WAVE) void k_long_light_any(DevReads R, DevParams P
 }
 
 hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32_t *d_n, uint64_t n_max, SurvOut *out, uint64_t slot_base,
-                             uint32_t max_len, hipStream_t st, uint32_t *punt_list, uint32_t *d_punt_n)
+                             uint32_t max_len, hipStream_t st, uint32_t *punt_list, uint32_t *d_punt_n, const uint64_t *surv_idx)
 {
     if (n_max == 0) return hipSuccess;
     const uint32_t words_cap = (((max_len + 15) / 16 + 2) + 3u) & ~3u;
     const uint32_t lds_bytes = (words_cap + 16u) * 4u;                           // (+ the words a 128-base piece reads past the read's last)
     const int grid = (int)std::min<uint64_t>(n_max, 256 * 32);
-    if (!R.pos_hint) {
-        // no position hints: another window or seed lattice — the every-position form, hints computed by the walking wave
+    if (!R.pos_hint || R.hint_all) {
+        // no position hints of the default lattice: another window or seed lattice — the every-position form, hints computed by the
+        // walking wave (or read, where the filter kept every position's bit: hint_all)
         if (P.window < 6 || P.window > 9 || P.skips < 1 || P.lowDR + P.lowSp < 17 || P.highDR + P.highSp > 127 || P.highDR + P.highSp < P.lowDR + P.lowSp) return hipErrorNotSupported;
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_long_light_any), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e2 != hipSuccess) return e2;
-        CRASS_LAUNCH(k_long_light_any, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n);
+        CRASS_LAUNCH(k_long_light_any, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n, surv_idx);
         return hipGetLastError();
     }
     if (P.skips != 8 || P.window != 8) return hipErrorNotSupported;
@@ -2671,8 +2690,8 @@ hipError_t launch_long_light(const DevReads &R, const DevParams &P, const uint32
     hipError_t e = hipFuncSetAttribute(range ? reinterpret_cast<const void *>(&k_long_light<true>) : reinterpret_cast<const void *>(&k_long_light<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    if (range) CRASS_LAUNCH(k_long_light<true>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n);
-    else CRASS_LAUNCH(k_long_light<false>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n);
+    if (range) CRASS_LAUNCH(k_long_light<true>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n, surv_idx);
+    else CRASS_LAUNCH(k_long_light<false>, dim3(grid), dim3(WAVE), lds_bytes, st, R, P, d_n, n_max, out, slot_base, punt_list, d_punt_n, surv_idx);
     return hipGetLastError();
 }
 
