@@ -1365,14 +1365,16 @@ static __device__ __forceinline__ bool substr_len(int L, uint32_t pos, uint32_t 
 // ten independent LDS reads, then the bit-parallel distance runs on registers (ln_lev_regs: the lane kernel's form)
 template <typename WORD> static __device__ __forceinline__ int ln_lev_regs(uint64_t s_lo, uint64_t s_hi, int n, uint64_t t_lo, uint64_t t_hi, int m, int stop_at);
 static __device__ __forceinline__ void wv_load128(const uint32_t *words, int start, uint64_t &lo, uint64_t &hi);
-static __device__ float packed_similarity(const uint32_t *words, uint32_t s0, int n, uint32_t t0, int m)
+// narrow: every lane of the wave holds a pair whose shorter string has at most 32 bases (or none) — the distance then runs on 32-bit
+// words, half the instructions (the caller's ballot: the choice is the wave's, not the lane's)
+static __device__ float packed_similarity(const uint32_t *words, uint32_t s0, int n, uint32_t t0, int m, bool narrow = false)
 {
     const float max_length = (float)(n > m ? n : m);
     if (n < 3 || m < 3) return 0.0f;
     if (n > m) { const uint32_t x = s0; s0 = t0; t0 = x; const int y = n; n = m; m = y; }
     uint64_t sl, sh, tl, th;
     wv_load128(words, (int)s0, sl, sh); wv_load128(words, (int)t0, tl, th);
-    const float edit_distance = (float)ln_lev_regs<uint64_t>(sl, sh, n, tl, th, m, -1);
+    const float edit_distance = narrow ? (float)ln_lev_regs<uint32_t>(sl, sh, n, tl, th, m, -1) : (float)ln_lev_regs<uint64_t>(sl, sh, n, tl, th, m, -1);
     return (float)(1.0 - (double)(edit_distance / max_length));
 }
 
@@ -1441,11 +1443,17 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
         // all 2*(nsp-1) similarities are independent: one pair per lane (bit-parallel DP on the packed words), the float
         // sums below then consume them in the reference's order.  pair 2i = (repeat, spacer_i),
         // pair 2i+1 = (spacer_i, spacer_i+1)   (:921-950)
-        const int npairs = 2 * (nsp - 1);
-        for (int q0 = 0; q0 < npairs; q0 += WAVE) {
-            const int q = q0 + lane;
-            const bool valid = q < npairs;
-            const int i = valid ? (q >> 1) : 0;
+        // A round of 64 lanes takes pairs of ONE kind — first the (repeat, spacer) pairs, then the (spacer, spacer) pairs: the
+        // two kinds side by side in one round were two executions of the distance loop with half the lanes each, and the rounds of
+        // the first kind share their shorter string's bound — a repeat of up to 32 bases puts the whole round on 32-bit words.
+        // (QC was 46 % of the full kernel's cycles on the array reads of BASELINE configs[3]; NOTES r06.)
+        const int per_kind = nsp - 1, rounds_per_kind = (per_kind + WAVE - 1) / WAVE;
+        for (int rd = 0; rd < 2 * rounds_per_kind; rd++) {
+            const int kind = rd >= rounds_per_kind ? 1 : 0;
+            const int i_l = (rd - kind * rounds_per_kind) * WAVE + lane;
+            const bool valid = i_l < per_kind;
+            const int q = valid ? 2 * i_l + kind : 0;
+            const int i = valid ? i_l : 0;
             uint32_t a_start = h.ss[2 * i + 1] + 1, a_len = 0, b_start = h.ss[2 * i + 3] + 1, b_len = 0;
             bool bad = !substr_len(h.L, a_start, h.ss[2 * i + 2] - a_start, a_len);
             bad = bad || !substr_len(h.L, b_start, h.ss[2 * i + 4] - b_start, b_len);
@@ -1455,17 +1463,17 @@ static __device__ int qc_found_repeats(RH &h, int minSpacerLength, int maxSpacer
             if (valid && dbg != 5) {
                 // (packed reads, strings of at most 64 bases — always, with anything like the default bounds: on the 2-bit words)
                 const bool pk = h.words && rep_len <= 64u && a_len <= 64u && b_len <= 64u;
-                if (pk) sim = (q & 1) ? packed_similarity(h.words, a_start, (int)a_len, b_start, (int)b_len)
-                                      : packed_similarity(h.words, rep_start, (int)rep_len, a_start, (int)a_len);
-                else if (q & 1) sim = lane_similarity(h.seq + a_start, (int)a_len, h.seq + b_start, (int)b_len, fb);
-                else sim = lane_similarity(repeat, (int)rep_len, h.seq + a_start, (int)a_len, fb);
+                const uint32_t x0 = kind ? a_start : rep_start, xn = kind ? a_len : rep_len, y0 = kind ? b_start : a_start, yn = kind ? b_len : a_len;
+                const bool narrow = __ballot(valid && pk && min(xn, yn) > 32u) == 0ull;      // (wave-uniform)
+                if (pk) sim = packed_similarity(h.words, x0, (int)xn, y0, (int)yn, narrow);
+                else sim = lane_similarity(h.seq + x0, (int)xn, h.seq + y0, (int)yn, fb);
             }
             if (valid) h.sims[q] = sim;
             uint64_t fbmask = __ballot(valid && fb);
             while (fbmask) {                              // rare: > 64-long or non-ACGT shorter string
                 const int src = __ffsll((unsigned long long)fbmask) - 1;
                 fbmask &= fbmask - 1;
-                const int qq = q0 + src, ii = qq >> 1;
+                const int qq = 2 * ((rd - kind * rounds_per_kind) * WAVE + src) + kind, ii = qq >> 1;      // (lane src's pair)
                 uint32_t as = h.ss[2 * ii + 1] + 1, al = 0, bs = h.ss[2 * ii + 3] + 1, bl = 0;
                 (void)substr_len(h.L, as, h.ss[2 * ii + 2] - as, al);
                 (void)substr_len(h.L, bs, h.ss[2 * ii + 4] - bs, bl);
