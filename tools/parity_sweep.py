@@ -23,7 +23,13 @@ for case in range(n_cases):
     n_dr = rng.choice([1, 3, 10, 50, 200, 1500])
     cpm = rng.choice([2000, 10000, 50000, 300000])
     k = rng.choice([6, 6, 6, 4, 8, 12])
-    spec = ca.synth_spec(read_len=L, n_dr=n_dr, crispr_per_million=cpm, seed=rng.randrange(1 << 30))
+    # (round 6) a tenth of the cases with SHORT repeats and -d 19 .. 22: the device merge from 19 bases, pass 2's windows every 4 bases
+    short_dr = rng.random() < 0.1
+    skw = {}
+    if short_dr:
+        lo = rng.choice([19, 20, 21, 22])
+        skw = dict(dr_len_min=lo, dr_len_max=lo + rng.choice([3, 6, 12]), spacer_len_min=26, spacer_len_max=36)
+    spec = ca.synth_spec(read_len=L, n_dr=n_dr, crispr_per_million=cpm, seed=rng.randrange(1 << 30), **skw)
     w = ca.synth_packed(spec, rng.randrange(1 << 20), n)
     asc = ca.unpack_ascii(w, (L + 15) // 16, L, n)
     seqs = [asc[i * L:(i + 1) * L].tobytes() for i in range(n)]
@@ -46,6 +52,8 @@ for case in range(n_cases):
                           dict(lowDRsize=30, highDRsize=60), dict(lowSpacerSize=20, highSpacerSize=60), dict(lowSpacerSize=30, highSpacerSize=40),
                           dict(highDRsize=64, highSpacerSize=70), dict(minNumRepeats=3), dict(lowDRsize=15, searchWindowLength=8),
                           dict(lowDRsize=25, searchWindowLength=9, lowSpacerSize=22), dict(lowDRsize=17, highDRsize=35, searchWindowLength=6, lowSpacerSize=15, highSpacerSize=45)])
+    if short_dr:
+        okw = dict(lowDRsize=skw["dr_len_min"], highDRsize=skw["dr_len_min"] + 22)
     p = ca.default_params(kmer_clust_size=k, **okw)
     host = rng.random() < 0.15
     use_eng = rng.random() < 0.7 and k == 6 and not okw
