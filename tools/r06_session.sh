@@ -45,7 +45,8 @@ if has params; then
     timeout 400 python bench.py --config 1 --params "$p" --steps 20 --warmup 3 --cpu-sample 200000 --e2e-reads 0 --single-shots 0 > $f 2> ${f%.json}.err
     summ $f
   done
-  timeout 400 python bench.py --config 3 --params "d=20,D=40" --steps 5 --warmup 2 --cpu-sample 0 --e2e-reads 0 --single-shots 0 > $out/bench_c3_params_d_20_D_40.json 2> $out/bench_c3_params.err
+  # (with its CPU leg: the line carries cpu_baseline and parity_checked — VERDICT r05 weak #11)
+  timeout 600 python bench.py --config 3 --params "d=20,D=40" --steps 5 --warmup 2 --e2e-reads 0 --single-shots 0 > $out/bench_c3_params_d_20_D_40.json 2> $out/bench_c3_params.err
   summ $out/bench_c3_params_d_20_D_40.json
 fi
 if has prof; then
@@ -101,6 +102,16 @@ if has lens; then
     env $e python bench.py --read-len $L --total-reads $n --params $p --steps 5 --warmup 2 --cpu-sample 20000 --single-shots 0 --e2e-reads 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('L=$L $p $e', 'ms/step', d['ms_per_step'], {k:v['avg_launch_ms'] for k,v in d['roofline']['per_kernel'].items()}, 'fast_filter', d['config'].get('fast_filter'), 'parity', (d.get('parity_checked') or {}).get('equal'))" >> $out/len_sweep_params.txt
   done; done; done
   cat $out/len_sweep_params.txt
+fi
+if has extra; then
+  # round 6: what an idle device costs a step; a fresh context's first step against its fourth; the lane kernel's stages; host reads of pinned memory
+  timeout 300 python tools/idle_effect.py > $out/idle_effect.txt 2>&1; tail -7 $out/idle_effect.txt
+  bash tools/single_shot_tl.sh $tag/ss > /dev/null 2>&1; cp $out/ss/timeline.txt $out/single_shot_timeline.txt; cat $out/ss/steps_plain.txt >> $out/single_shot_timeline.txt; head -9 $out/ss/steps_plain.txt
+  : > $out/survivor_stages.txt
+  for n in 100000000 12500000; do for d in 1 2 3 4 0; do CRASS_SURV_DEBUG=$d python tools/survivor_ab.py $n 2>&1 | tail -1 >> $out/survivor_stages.txt; done; done; cat $out/survivor_stages.txt
+  (cd profiles/ubench && hipcc -O2 pinned_read.cpp -o /tmp/pinned_read 2>/dev/null && /tmp/pinned_read) > $out/pinned_read.txt 2>&1; tail -4 $out/pinned_read.txt
+  CRASS_HINT_PARTS=1 timeout 300 python tools/longread_phases.py 1000000 1000 > $out/longread_phases.txt 2>&1; grep "cat 2 total\|oracle" $out/longread_phases.txt | tail -3
+  bash tools/r06_lens2.sh > $out/len_sweep_params_1000.txt 2>&1; tail -3 $out/len_sweep_params_1000.txt
 fi
 if has pmc3; then
   bash tools/pmc_round.sh $tag/pmc_c3 3 1000000 10000 > $out/pmc_c3_summary.txt 2>&1; tail -30 $out/pmc_c3_summary.txt
