@@ -446,7 +446,7 @@ def test_slot_compactions_fit_their_scratch(env):
                                     "CRASS_DX_PINNED", "CRASS_NO_LOOKBACK", "CRASS_FF_RPL=4",
                                     # round 6: events instead of the polled stage flags; the ranks' seed scans waiting for pass 1; the found
                                     # flags cleared by a fill kernel; no light walk over the dense path's survivors; the view in one copy
-                                    "CRASS_NO_POLL", "CRASS_NO_DEFER_P1", "CRASS_FOUND_MEMSET", "CRASS_NO_DENSE_LIGHT", "CRASS_VIEW_ONE_COPY",
+                                    "CRASS_NO_POLL", "CRASS_NO_DEFER_P1", "CRASS_FOUND_MEMSET", "CRASS_NO_DENSE_LIGHT", "CRASS_NO_WARM_LAUNCH",
                                     "CRASS_STAGE_TIMING=2"])
 def test_ab_switches_keep_the_results(switch):
     """The A/B switches select the round-3 form of something (one candidate per lane in pass 2's verification, the 12-byte
