@@ -1495,7 +1495,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     { const int as = ensure_dense_buffers(c, n_alloc, pool_cap, lds, dedupe); if (as) return as; }
     // [2] = found count, [3] = worst error, [4] = n distinct, [5] = de-duplication mismatch flag
     if (!speculative) {                                 // (speculative launch: cleared by the filter's compaction, see seed scan)
-        HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 16, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 20, c->stream));      // ([6]: the lane kernel's punt count)
         HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));
     }
     // The merge that will follow this stage is sized here already when the previous call's merge ran on the device (its
@@ -1527,7 +1527,7 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     const bool no_lanes = c->env.no_lane_kernel;
     hipError_t le = no_lanes ? hipErrorNotSupported
                              : launch_survivor_lanes(c->R, c->dp, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
-                                                     c->d_ss_pool.p, lds.ss_cap, c->d_found.p, hints, c->stream, init_merge, c->max_len);
+                                                     c->d_ss_pool.p, lds.ss_cap, c->d_found.p, hints, c->stream, init_merge, c->max_len, c->d_count.p + 6);
     if (le != hipSuccess && le != hipErrorNotSupported) { c->last_hip = (int)le; return CRASS_ERR_HIP; }
     if (le == hipSuccess && init_merge) { c->dm_prepared_n = init_merge->n_tok; c->dm_prepared_src = init_merge->dx_chars; }
     // Reads the lane kernel does not take (513 .. 2 048 bases): the long reads' LIGHT walk over the survivor list first — nearly every
@@ -1551,7 +1551,8 @@ static int run_survivors_dense(crass_hip_ctx *c, uint64_t n_surv, const uint32_t
     if (!light_done)
     HIPCHK(c, launch_survivor(c->R, c->dp, false, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
                               c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, hints, lds,
-                              (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, le == hipSuccess ? 4 : 0));
+                              (int)std::min<uint64_t>(256 * 32, n_surv), c->stream, le == hipSuccess ? 4 : 0, 0, 0, nullptr,
+                              le == hipSuccess ? c->d_count.p + 6 : nullptr));      // (the lane kernel's punt count: none -> the launch leaves at once)
     if (c->R.n_exc)                                     // exception reads in the list (err == 5): raw bytes, same slots
         HIPCHK(c, launch_survivor(c->R, c->dp, true, c->d_idx.p, d_nsurv, n_surv, c->d_surv.p, c->d_dr.p, stride,
                                   c->d_ss_pool.p, (uint32_t)pool_cap, c->d_ss_used.p, c->d_found.p, nullptr, lds,
@@ -1922,7 +1923,7 @@ int crass_hip_seed_scan(crass_hip_ctx *c)
     // (the scan kernel also clears the survivor stage's counters: d_count[2..6) and the start/stop pool cursor)
     Lookback lbs;
     HIPCHK(c, launch_compact(c->d_mask.p, n_words, n, c->d_word_prefix.p, c->d_block_sums.p, c->d_idx.p, n, c->d_count.p, c->stream,
-                             c->d_count.p + 2, 4, c->d_ss_used.p, 1, c->next_lookback(n_words, &lbs)));
+                             c->d_count.p + 2, 5, c->d_ss_used.p, 1, c->next_lookback(n_words, &lbs)));      // ([2..6) + [6], the lane kernel's punt count)
     HIPCHK(c, c->stamp(2, 2));
     c->dense.active = false;
     c->have_rep = false;

@@ -397,7 +397,7 @@ hipError_t launch_survivor(const DevReads &R, const DevParams &P, bool exception
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                  uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st,
-                                 const DevMerge *init_merge = nullptr, uint32_t max_len = 0);     // max_len: the rows' size when the strides differ   // also clears that merge's tables (dm_init_slice)
+                                 const DevMerge *init_merge = nullptr, uint32_t max_len = 0, uint32_t *punt_cnt = nullptr);     // max_len: the rows' size when the strides differ   // also clears that merge's tables (dm_init_slice)
 hipError_t launch_recruit_general(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,
                                   uint64_t *hitmask, uint32_t *hit_info, hipStream_t st);
 hipError_t launch_recruit_lds(const DevReads &R, const DevAutomaton &A, const uint8_t *found_flag,

@@ -2100,6 +2100,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     // ... or, with punt_list, exactly the slots on that list (k_long_light's hand-overs, in any order: every result is addressed by
     // its slot), dealt out one at a time over a grid of resident waves — 64 slots per wave left a wave anything from none to a dozen
     // array reads and the launch took twice its share (3.2 ms for 51 k reads at 10 kbp)
+    // (the lane kernel's punts, counted by it: usually none — the scan of every slot's error byte for them was 10-17 us of the step)
+    if (!EXC && punt_only == 4 && !punt_list && d_punt_n && *d_punt_n == 0u) { PROF_WAVE_FLUSH(); return; }
     uint64_t punt_base = (uint64_t)blockIdx.x * WAVE, punt_mask = 0;
     uint64_t lp = blockIdx.x;
     const uint64_t n_list = punt_list ? (uint64_t)(*d_punt_n) : 0;
@@ -3396,7 +3398,8 @@ static __device__ __forceinline__ uint64_t ln_hint64(const DevReads &R, const ui
 __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, DevParams P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                                          uint64_t n_max, SurvOut *out, char *dr_chars, uint32_t dr_stride,
                                                          uint32_t *ss_pool, uint32_t ss_cap, uint8_t *found_flag,
-                                                         const uint32_t *seed_hint, uint32_t words_per_read, DevMerge IM, int do_init, int regroup)
+                                                         const uint32_t *seed_hint, uint32_t words_per_read, DevMerge IM, int do_init, int regroup,
+                                                         uint32_t *punt_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t sl_lds[];
     __shared__ uint16_t sl_perm[WAVE * SL_WAVES];
@@ -3475,7 +3478,7 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
     if (P.debug_stop == 4 && f == 1) f = 0;                           // (4: no orientation / output)
     SurvOut o;
     o.found = 0; o.n_ss = 0; o.repeat_len = 0; o.ss_off = 0; o.dr_len = 0; o.low_lexi = 0; o.err = 0;
-    if (h.punt) o.err = 4;
+    if (h.punt) { o.err = 4; if (punt_cnt) atomicAdd(punt_cnt, 1u); }      // (counted: the wave kernel's launch behind this one leaves at once when there is none)
     else if (f < 0) o.err = 1;
     else if (f == 1) {
         // ReadHolder::DRLowLexi (ReadHolder.cpp:513-591): representative repeat, orientation
@@ -3559,7 +3562,7 @@ __global__ __launch_bounds__(WAVE * SL_WAVES) void k_survivor_lanes(DevReads R, 
 hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const uint64_t *surv_idx, const uint32_t *d_n_surv,
                                  uint64_t n_surv_max, SurvOut *out, char *dr_chars, uint32_t dr_stride, uint32_t *ss_pool,
                                  uint32_t ss_cap, uint8_t *found_flag, const uint32_t *seed_hint, hipStream_t st, const DevMerge *init_merge,
-                                 uint32_t max_len)
+                                 uint32_t max_len, uint32_t *punt_cnt)
 {
     if (n_surv_max == 0) return init_merge ? hipErrorNotSupported : hipSuccess;
     // a lane holds its read's words in LDS: reads of up to 512 bases (one stride or not: the rows are addressed per read)
@@ -3575,7 +3578,7 @@ hipError_t launch_survivor_lanes(const DevReads &R, const DevParams &P, const ui
     }
     CRASS_LAUNCH(k_survivor_lanes, dim3((unsigned)((n_surv_max + bt - 1) / bt)), dim3(bt), lds, st, R, P, surv_idx, d_n_surv,
                        n_surv_max, out, dr_chars, dr_stride, ss_pool, ss_cap, found_flag, seed_hint, wpr, init_merge ? *init_merge : DevMerge{},
-                       init_merge ? 1 : 0, ((seed_hint || R.pos_hint) && !no_regroup) ? 1 : 0);
+                       init_merge ? 1 : 0, ((seed_hint || R.pos_hint) && !no_regroup) ? 1 : 0, punt_cnt);
     return hipGetLastError();
 }
 
