@@ -407,8 +407,8 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
             own_q = true;
         }
         o.last_hdr = hdr;
-        o.hdr_pos.push_back(hdr);
         if (o.pack) {
+            o.hdr_pos.push_back(hdr);                     // (the index's: the whole-file and streamed readers never read it — 8 bytes per record)
             if (!packed_in_place) {
                 const size_t w0 = o.words.size(), nw = (sq_len + 15) / 16;
                 o.words.resize(w0 + nw);
@@ -577,7 +577,13 @@ bool inflate_with_libdeflate(const char *path, InflatedBuf &out)
             while (fgets(line, sizeof(line), fp)) if (!strncmp(line, "MemAvailable:", 13)) { avail = (uint64_t)atoll(line + 13) << 10; break; }
             fclose(fp);
         }
-        if (avail && (uint64_t)csz * 12 > avail / 2) pg_fits = false;
+        // (the text: the trailer's ISIZE where it can be believed — a single member below 4 GB of text —, else eight times the file:
+        // FASTA and quality-binned FASTQ compress 6-8 x, and a guess of four let the several-thread inflate start on hosts where
+        // three times the real text did not fit)
+        uint32_t isz = 0;
+        memcpy(&isz, in + csz - 4, 4);
+        const uint64_t text = (csz < (1ull << 29) && (uint64_t)isz >= csz) ? (uint64_t)isz : (uint64_t)csz * 8;
+        if (avail && text * 3 > avail / 2) pg_fits = false;
     }
     if (pg_fits && !getenv("CRASS_NO_PGZIP")) {
         // one member, large: inflated by several threads from block starts found in the middle of the stream (pgzip.cpp); its own
@@ -1587,6 +1593,7 @@ int crass_fastx_stream_next(crass_fastx_stream *s, crass_fastx *out)
     size_t n = s->buf.size();
     std::unique_ptr<uint8_t[]> hold;
     bool hold_is_block = false;
+    size_t big_cap = 0, want = 0;
     struct GiveBack {                                    // a block goes back to the reader's pool when the chunk is done with it
         crass_fastx_stream *s; std::unique_ptr<uint8_t[]> &h; bool &is_block;
         ~GiveBack() { if (h && is_block) { std::lock_guard<std::mutex> lk(s->mu); if (s->pool.size() < 3) s->pool.push_back(std::move(h)); } }
@@ -1606,15 +1613,27 @@ int crass_fastx_stream_next(crass_fastx_stream *s, crass_fastx *out)
                 hold = std::move(b.p);                  // (what data pointed into until now — the tail, or an earlier block — is done with)
                 hold_is_block = true;
             } else if (b.len) {
-                std::unique_ptr<uint8_t[]> big(new (std::nothrow) uint8_t[n + b.len]);
-                if (!big) return CRASS_ERR_OOM;
-                if (n) memcpy(big.get(), data, n);
-                memcpy(big.get() + n, b.p.get() + b.gap, b.len);
-                data = big.get();
-                n += b.len;
-                hold = std::move(big);
-                hold_is_block = false;
+                // the tail does not fit in front of the block: an owned buffer, grown geometrically and appended to in place (a
+                // record k blocks long is then copied O(k) bytes over, not O(k^2))
+                if (!hold_is_block && hold && n + b.len <= big_cap) {
+                    memcpy(hold.get() + n, b.p.get() + b.gap, b.len);
+                    n += b.len;
+                } else {
+                    const size_t cap = std::max<size_t>(2 * (n + b.len), (size_t)1 << 20);
+                    std::unique_ptr<uint8_t[]> big(new (std::nothrow) uint8_t[cap]);
+                    if (!big) return CRASS_ERR_OOM;
+                    if (n) memcpy(big.get(), data, n);
+                    memcpy(big.get() + n, b.p.get() + b.gap, b.len);
+                    data = big.get();
+                    n += b.len;
+                    if (hold && hold_is_block) { std::lock_guard<std::mutex> lk(s->mu); if (s->pool.size() < 3) s->pool.push_back(std::move(hold)); }
+                    hold = std::move(big);
+                    hold_is_block = false;
+                    big_cap = cap;
+                }
+                { std::lock_guard<std::mutex> lk(s->mu); if (s->pool.size() < 3) s->pool.push_back(std::move(b.p)); }
             }
+            if (n < want && !s->eof) continue;           // (a chunk that parsed short is parsed again only once it has doubled)
         }
         const double tp0 = stream_now();
         parse_pieces(data, n, ch, 2u << 20);                   // (2 MB pieces: a 64 MB chunk still keeps 32 threads busy)
@@ -1631,7 +1650,9 @@ int crass_fastx_stream_next(crass_fastx_stream *s, crass_fastx *out)
             drop_last = true;
             break;
         }
-        // (keep everything, read another block behind it)
+        // (keep everything, read more behind it — twice the bytes before the next parse, so that a read k blocks long is parsed
+        // O(log k) times)
+        want = 2 * n;
     }
     // ---- assemble the chunk's records in order (kseq's stale comment / quality buffers travel with the stream) ----
     const double ta0 = stream_now();

@@ -346,6 +346,11 @@ bool parallel_gunzip(const uint8_t *in, size_t n, uint8_t **out_p, size_t *out_n
                 bool wait_more = false;
                 for (unsigned j = k + 1; j < nc; j++) {
                     if (ch[j].nominal > pos) { if (!ch[j].ready.load()) wait_more = false; break; }     // (a chunk whose search starts behind pos cannot start at pos)
+                    // A chunk that no thread has fetched yet is never waited for: if every thread stood behind such a chunk (a
+                    // crafted stream whose in-flight chunks all began on false block starts) nobody would ever fetch it.  This
+                    // thread decodes on through its range instead; should the chunk turn out to start here after all, it is
+                    // decoded twice and left out of the chain.
+                    if (!ch[j].ready.load() && j >= next.load()) break;
                     while (!ch[j].ready.load() && !fail.load()) std::this_thread::yield();
                     if (ch[j].start.load() == pos) { hit = (int)j; break; }
                 }

@@ -335,6 +335,23 @@ def test_streaming_fastx_reader_is_kseq_exact(ca, tmp_path, case, chunk):
     assert len(ref) > 1000
 
 
+def test_streaming_reader_grows_geometrically_for_a_record_far_longer_than_the_chunk(ca, tmp_path):
+    """a record k blocks long was copied and parsed k times (O(k^2)); the stream now asks for twice the bytes before
+    it parses again.  3 MB records through 300-byte chunks (10^4 blocks each) finish in seconds and come back whole"""
+    import random, time
+    rng = random.Random(5)
+    recs = [(">r%d c%d" % (i, i), "".join(rng.choice("ACGT") for _ in range(n))) for i, n in enumerate([3_000_000, 70, 1_500_000, 3, 90])]
+    text = "".join("%s\n%s\n" % (h, "\n".join(sq[k:k + 70] for k in range(0, len(sq), 70))) for h, sq in recs)
+    plain, gz = _write_both(tmp_path, "long.fa", text.encode())
+    ref = fastx.read_fastx(gz)
+    t0 = time.perf_counter()
+    for path in (plain, gz):
+        got, hid, last, chunks = ca.stream_fastx(path, chunk_bytes=300)
+        assert got == ref
+        assert hid == list(range(len(recs)))
+    assert time.perf_counter() - t0 < 30
+
+
 def _packed_layout(ca, seqs):
     """what crass_pack_reads (mode 2) makes of these sequences, in FastxIndex.layout()'s form"""
     pk = ca.PackedReads(list(seqs), pad_uniform=2)
