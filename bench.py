@@ -708,17 +708,24 @@ def _e2e_cli(ca, spec, L, n, modes=("auto",)):
                 os.makedirs(od)
                 log = os.path.join(td, "stdout.txt")
                 t0 = time.perf_counter()
+                e0 = time.time()
                 # (peak resident set: the command line's own VmHWM, printed with its stage times — the child's ru_maxrss would start
                 # from this process's resident set at fork time)
                 with open(log, "wb") as lf:
                     p = subprocess.run([cli, "-g", "-o", od, fa], stdout=lf, stderr=subprocess.STDOUT, env=env)
                 walls.append(time.perf_counter() - t0)
+                e1 = time.time()
                 if p.returncode != 0:
                     return {"error": "crass-hip exited %d (%s)" % (p.returncode, mode)}
                 stages = []
                 for line in open(log, "rb").read().decode().replace("\r", "\n").splitlines():
                     if "Found" in line and "reads" in line:
                         found = line.strip()
+                    m3 = re.search(r"cli: (main entered|_exit called) at epoch ([0-9.]+)", line)
+                    if m3:                              # what the process spends outside main (loader / address-space + KFD tear-down)
+                        stages.append("cli: spawn -> main %.3f s" % (float(m3.group(2)) - e0) if m3.group(1) == "main entered"
+                                      else "cli: _exit -> reaped by the parent %.3f s" % (e1 - float(m3.group(2))))
+                        continue
                     m2 = re.search(r"peak RSS (\d+) MB", line)
                     if m2:
                         rss = max(rss, float(m2.group(1)))

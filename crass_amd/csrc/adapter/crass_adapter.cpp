@@ -957,7 +957,13 @@ int searchAndRecruit(const Vecstr &seqFiles, const options &opts, ReadMap *mRead
     // the search stage's state is freed on a thread of its own, beside a later stage: unmapping an 8 GB input, freeing the index
     // and the device context(s) was 0.3 s between this function's last line and its caller's next one
     {
-        crass_fastx_index *ix = IX.ix; IX.ix = nullptr;
+        // (the index goes here and now, its gigabytes handed back over sixteen threads — crass_fastx_index_free, ~20 ms for the 2.3 GB
+        // of a 50 M-read job — not by ONE thread at the process's end (0.2 s) or beside a later stage.  The device is idle: every
+        // result has been fetched)
+        const double tf0 = now();
+        crass_fastx_index_free(IX.ix); IX.ix = nullptr;
+        if (timing) fprintf(stderr, "[crass_timing] searchAndRecruit: index freed %.3f s\n", now() - tf0);
+        crass_fastx_index *ix = nullptr;
         Made &m = dev.get();
         crass_hip_ctx *cx = m.c; crass_hip_group *gx = m.g;
         m.c = nullptr; m.g = nullptr;

@@ -18,6 +18,11 @@
 #include <iostream>
 #include <chrono>
 #include <unistd.h>
+#include <algorithm>
+#include <vector>
+#include <cstdint>
+#include <map>
+#include <string>
 
 using namespace crass_hip;
 
@@ -32,6 +37,54 @@ static void usage()
                  "  --devices L    the same with an explicit device list\n"
                  "  --seam         drive the engine through crass's three calls (searchFile / createNonRedundantSet /\n"
                  "                 findSingletons: the DR merge then runs on the host) instead of the one-call device path\n";
+}
+
+// CRASS_SMAPS_AT_EXIT=1: the mappings with the largest resident sets, at the end of every stage (what the kernel takes back at _exit)
+static void dump_smaps(const char *tag)
+{
+    if (!getenv("CRASS_SMAPS_AT_EXIT")) return;
+    FILE *f = fopen("/proc/self/smaps", "r");
+    if (!f) return;
+    struct Reg { std::string name; long rss = 0, huge = 0, size = 0; };
+    std::vector<Reg> regs;
+    char line[512];
+    while (fgets(line, sizeof(line), f)) {
+        unsigned long a, b;
+        if (sscanf(line, "%lx-%lx ", &a, &b) == 2 && !strstr(line, "kB")) { regs.emplace_back(); regs.back().name = line; regs.back().name.erase(regs.back().name.find_last_not_of("\n") + 1); }
+        else if (!regs.empty()) {
+            if (!strncmp(line, "Rss:", 4)) regs.back().rss = atol(line + 4);
+            else if (!strncmp(line, "Size:", 5)) regs.back().size = atol(line + 5);
+            else if (!strncmp(line, "AnonHugePages:", 14)) regs.back().huge = atol(line + 14);
+        }
+    }
+    fclose(f);
+    std::sort(regs.begin(), regs.end(), [](const Reg &x, const Reg &y) { return x.rss > y.rss; });
+    long tot = 0, huge = 0, n50 = 0, r50 = 0;
+    for (auto &r : regs) { tot += r.rss; huge += r.huge; if (r.size >= (40 << 10) && r.size <= (65 << 10)) { n50++; r50 += r.rss; } }
+    fprintf(stderr, "[crass_timing] smaps at %s: %zu mappings, %ld MB resident (%ld MB in huge pages); %ld mappings of 40..65 MB hold %ld MB\n", tag, regs.size(), tot >> 10, huge >> 10, n50, r50 >> 10);
+    {   // (by size class: count, resident MB)
+        std::map<long, std::pair<long, long>> hist;
+        for (auto &r : regs) { long c = 1; while (c < (r.size >> 10)) c <<= 1; hist[c].first++; hist[c].second += r.rss; }
+        std::string h;
+        for (auto &kv : hist) if (kv.second.second >> 10) h += " <=" + std::to_string(kv.first) + "MB:" + std::to_string(kv.second.first) + "x/" + std::to_string(kv.second.second >> 10) + "MB";
+        fprintf(stderr, "[crass_timing] smaps %s by size class (count / resident):%s\n", tag, h.c_str());
+    }
+    if (getenv("CRASS_SMAPS_PEEK")) {
+        int shown = 0;
+        for (auto &r : regs) {
+            if (r.huge || r.rss < (12 << 10) || r.name.find("rw-p") == std::string::npos || shown >= 24) continue;
+            unsigned long a = 0, b = 0;
+            sscanf(r.name.c_str(), "%lx-%lx", &a, &b);
+            const uint32_t *w = (const uint32_t *)a;
+            const size_t nw = (b - a) / 4;
+            std::string h;
+            char buf[32];
+            for (size_t off : {(size_t)0, (size_t)1024, nw / 2, nw - 1024}) { h += " |"; for (int k = 0; k < 8; k++) { snprintf(buf, sizeof(buf), " %08x", w[off + k]); h += buf; } }
+            fprintf(stderr, "[crass_timing] peek %s %ld MB:%s\n", r.name.substr(0, 25).c_str(), r.size >> 10, h.c_str());
+            shown++;
+        }
+    }
+    for (size_t i = 0; i < regs.size() && i < 6; i++) fprintf(stderr, "[crass_timing] smaps %s: rss %6ld MB (huge %6ld MB) of %6ld MB  %s\n", tag, regs[i].rss >> 10, regs[i].huge >> 10, regs[i].size >> 10, regs[i].name.c_str());
 }
 
 int main(int argc, char *argv[])
@@ -174,11 +227,18 @@ int main(int argc, char *argv[])
         }
         return kb / 1024.0;
     };
+    // (wall-clock stamps of main's first and last line: what the process spends before and after them — loader, static
+    // constructors; address-space and KFD tear-down — is the difference to the parent's own clock, tools/e2e_big.py)
+    auto epoch = [] { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); };
+    if (timing) fprintf(stderr, "[crass_timing] cli: main entered at epoch %.6f\n", epoch());
     auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[crass_timing] cli: %-28s %.3f s (at %.3f s, peak RSS %.0f MB)\n", what, t - t_prev, t - t_main, peak_rss_mb()); t_prev = t; } };
     try {
         time_t start_time; time(&start_time);
         if (!devices.empty()) setDevices(devices, local_copies);
-        if (!getenv("CRASS_RELEASE_AT_EXIT")) leaveTeardownToProcessEnd(true);      // (this process ends behind its outputs: see the end of main)
+        // (this process ends behind its outputs: see the end of main.  CRASS_TEARDOWN=async: the search stage's contexts and index
+        // are handed back by a thread beside the output stage — which runs on the host — instead of by the kernel at _exit)
+        const char *td_mode = getenv("CRASS_TEARDOWN");
+        if (!getenv("CRASS_RELEASE_AT_EXIT") && !(td_mode && !strcmp(td_mode, "async"))) leaveTeardownToProcessEnd(true);
         int next_free_GID = 1;
         Vecstr *nr = nullptr;
         if (seam) {
@@ -201,6 +261,7 @@ int main(int argc, char *argv[])
             mMaxReadLength = searchAndRecruit(seqFiles, opts, &mReads, &mStringCheck, mDR2GIDMap, mGroupMap, group_kmer_counts_map, next_free_GID,
                                               patterns_lookup, reads_found, nr, start_time);
             lap("searchAndRecruit (ingest + pass 1 + merge + pass 2)");
+            dump_smaps("search done");
         }
         size_t n_reads = 0;
         for (auto &kv : mReads) n_reads += kv.second->size();
@@ -247,6 +308,7 @@ int main(int argc, char *argv[])
             }
             std::cout << "[crass_consensus]: " << mTrueDRs.size() << " true direct repeats" << std::endl;
             lap("findConsensusDRs + dump");
+            dump_smaps("consensus done");
             // ---- spacer graphs + crass's output files (WorkHorse.cpp:196-316) ----
             if (!opts.logToScreen) {                // the log file crass.cpp:484-496 opens; <file type="log"> of the XML names it
                 std::ofstream lg((opts.output_fastq + "crass." + timestamp + ".log").c_str());
@@ -265,6 +327,8 @@ int main(int argc, char *argv[])
         // the orderly tear-down (leak checks)
         std::cout.flush(); std::cerr.flush(); fflush(nullptr);
         lap("exit without tear-down");
+        dump_smaps("exit");
+        if (timing) { fprintf(stderr, "[crass_timing] cli: _exit called at epoch %.6f\n", epoch()); fflush(stderr); }
         _exit(rc);
     }
     releaseDeviceReads();

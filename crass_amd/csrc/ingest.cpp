@@ -72,11 +72,24 @@ template <typename F> void parallel_ranges(uint64_t n, unsigned nt, F f)
 // Giving gigabytes back: one munmap of 8 GB holds the address space's lock for a quarter of a second, and every other thread of
 // the process that touches a fresh page (the next stage's buffers) waits for it.  MADV_DONTNEED drops the pages under the SHARED
 // lock, slice by slice; the unmapping that follows finds nothing left to do.
+// Gigabytes at once go side by side: the kernel hands pages back (and clears them) at ~13 GB/s per thread in 4 KB pages, 27 GB/s in
+// 2 MB pages — 6 GB were 0.46 s on one thread, 0.11 s on sixteen (profiles/r06_exit_cost.txt); more threads than that meet on the
+// zone locks and are slower again.
 inline void drop_pages(void *p, size_t bytes)
 {
     const size_t page = 4096, slice = 64u << 20;
-    uintptr_t a = ((uintptr_t)p + page - 1) & ~(uintptr_t)(page - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)(page - 1);
-    for (; a < e; a += slice) (void)madvise((void *)a, std::min<size_t>(slice, e - a), MADV_DONTNEED);
+    const uintptr_t a0 = ((uintptr_t)p + page - 1) & ~(uintptr_t)(page - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)(page - 1);
+    if (e <= a0) return;
+    const size_t ns = (e - a0 + slice - 1) / slice;
+    auto drop = [&](size_t q) { const uintptr_t a = a0 + q * slice; (void)madvise((void *)a, std::min<size_t>(slice, e - a), MADV_DONTNEED); };
+    const unsigned nt = (unsigned)std::min<size_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), ns / 2);
+    if (nt <= 1) { for (size_t q = 0; q < ns; q++) drop(q); return; }
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (;;) { const size_t q = next.fetch_add(1, std::memory_order_relaxed); if (q >= ns) break; drop(q); } };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
 }
 
 // an array that is asked for again and again with about the same size: grown, never shrunk, not initialised
@@ -113,6 +126,56 @@ template <typename T> struct RawBuf {
         n = count;
         return true;
     }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
+// A per-record array a parser appends to without knowing its final size (a piece of an input: ~10^6 records).  A std::vector doubles
+// by allocate + copy + free: every doubling touches fresh pages, and what it frees stays in its thread's malloc arena (glibc's
+// mmap threshold moves up to 32 MB with the first large free) — 64 parsers left 1.8 GB of such arenas behind, resident until the
+// process's end.  This one is a mapping of its own from 1 MB on: grown by mremap (page tables move, no byte is copied or touched
+// again), MADV_HUGEPAGE, handed back to the kernel the moment it is released; no value-initialisation.
+template <typename T> struct GrowBuf {
+    T *p = nullptr; size_t n = 0, cap = 0;
+    bool mapped = false;
+    GrowBuf() = default;
+    GrowBuf(const GrowBuf &o) { assign(o); }
+    GrowBuf &operator=(const GrowBuf &o) { if (this != &o) { n = 0; assign(o); } return *this; }
+    GrowBuf(GrowBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap), mapped(o.mapped) { o.p = nullptr; o.n = o.cap = 0; o.mapped = false; }
+    GrowBuf &operator=(GrowBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; mapped = o.mapped; o.p = nullptr; o.n = o.cap = 0; o.mapped = false; } return *this; }
+    ~GrowBuf() { release(); }
+    void release()
+    {
+        if (p) { if (mapped) munmap(p, cap * sizeof(T)); else free(p); }
+        p = nullptr; n = cap = 0; mapped = false;
+    }
+    void assign(const GrowBuf &o) { resize(o.n); if (o.n) memcpy(p, o.p, o.n * sizeof(T)); }
+    void grow(size_t want)
+    {
+        static const size_t kMap = 1u << 20, kHuge = 2u << 20;
+        size_t bytes = std::max<size_t>(std::max(want, cap * 2) * sizeof(T), 4096);
+        if (bytes < kMap) {
+            T *q = (T *)realloc(p, bytes);
+            if (!q) throw std::bad_alloc();
+            p = q; cap = bytes / sizeof(T);
+            return;
+        }
+        bytes = (bytes + kHuge - 1) / kHuge * kHuge;
+        void *q;
+        if (mapped) q = mremap(p, cap * sizeof(T), bytes, MREMAP_MAYMOVE);
+        else q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(q, bytes, MADV_HUGEPAGE);
+        if (!mapped) { if (n) memcpy(q, p, n * sizeof(T)); free(p); mapped = true; }
+        p = (T *)q; cap = bytes / sizeof(T);
+    }
+    void push_back(const T &v) { if (n == cap) grow(n + 1); p[n++] = v; }
+    void resize(size_t m) { if (m > cap) grow(m); n = m; }           // (new elements are NOT initialised)
+    void clear() { n = 0; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
     T *data() { return p; }
     const T *data() const { return p; }
     T &operator[](size_t i) { return p[i]; }
@@ -225,17 +288,17 @@ struct FxChunk {
     uint32_t max_len = 0;
     size_t next_start = 0;     // index of the header char of the first record NOT parsed here
     size_t last_hdr = 0;       // index of the header char of the LAST record parsed here (streaming: a chunk's last record is re-read)
-    std::vector<uint64_t> hdr_pos;                                      // index of every record's header char (crass_index_fastx)
+    GrowBuf<uint64_t> hdr_pos;                                          // index of every record's header char (crass_index_fastx)
     // pack mode (crass_index_fastx): a record's sequence is 2-bit packed the moment it is complete — while its bytes are still in
     // the cache — and its text dropped; seq / name / comment / qual stay empty, seq_end / name_end count virtual bytes (the
     // lengths), the name is kept as a hash
     bool pack = false;
-    std::vector<uint32_t> words;                                        // the records' words, tightly packed (ceil(L/16) each)
-    std::vector<uint64_t> name_h;                                       // name_hash() of every record's name
+    GrowBuf<uint32_t> words;                                            // the records' words, tightly packed (ceil(L/16) each)
+    GrowBuf<uint64_t> name_h;                                           // name_hash() of every record's name
     // (pack mode keeps 24 bytes per record beside its words — header position, name hash, the two lengths — and the comment /
     // quality flags per piece: the eight per-record vectors of the other mode were 50 bytes, 2.5 GB for 50 M reads, written by the
     // parsers and freed again — 0.4 s on one thread — before the reads had even been looked at)
-    std::vector<uint32_t> len32, nlen32;                                // sequence / name length of every record
+    GrowBuf<uint32_t> len32, nlen32;                                    // sequence / name length of every record
     uint8_t pk_flags = 12;                                              // bit 0 any comment, 1 any quality, 2 all comment, 3 all quality
     uint32_t pk_min_len = 0xFFFFFFFFu;
     std::vector<uint64_t> exc_rec, exc_off;                             // local indices of reads with a byte outside ACGT, ends in exc_bytes
@@ -1071,7 +1134,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
                 if (!stride) ix->word_off[r] = tight0[k] + wat;
                 wat += (L + 15) / 16;
             }
-            std::vector<uint64_t>().swap(c.hdr_pos); std::vector<uint64_t>().swap(c.name_h); std::vector<uint32_t>().swap(c.nlen32);
+            c.hdr_pos.release(); c.name_h.release(); c.nlen32.release();
         };
         std::vector<std::thread> th;
         for (size_t k = 1; k < nc; k++) th.emplace_back(place_small, k);
@@ -1094,7 +1157,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
                 wat += nw;
             }
         }
-        std::vector<uint32_t>().swap(c.words);
+        c.words.release();
     };
     double t_words = 0;
     std::thread words_thread([&]() {
@@ -1121,6 +1184,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
     // occurrence is simply the first insert, no atomics — and are independent.  Records reach their shard by a stable counting
     // sort of the record indices (two streaming passes over the hashes).
     bool any_dup = false;
+    double th_ph[4] = {t3, t3, t3, t3};
     if (nrec) {
         if (nrec >= 0xFFFFFFFFull) return CRASS_ERR_UNSUPPORTED;
         constexpr unsigned SH = 256;
@@ -1130,6 +1194,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
                                                           // (looked up per record they were 50 M cache misses, most of this stage)
         if (!order.alloc(nrec) || !first.alloc(nrec) || !order_h.alloc(nrec)) return CRASS_ERR_OOM;
         std::vector<uint64_t> cnt((size_t)ht * SH, 0);
+        th_ph[0] = now_s();
         const uint64_t per = (nrec + ht - 1) / ht;
         auto range = [&](unsigned t, uint64_t &a2, uint64_t &b2) { a2 = std::min<uint64_t>(nrec, t * per); b2 = std::min<uint64_t>(nrec, a2 + per); };
         {
@@ -1139,6 +1204,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
             count(0);
             for (auto &x : th) x.join();
         }
+        th_ph[1] = now_s();
         std::vector<uint64_t> sh_begin(SH + 1, 0);
         {   // shard-major, thread-minor: a shard's records stay in read order
             uint64_t at = 0;
@@ -1155,6 +1221,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
             scatter(0);
             for (auto &x : th) x.join();
         }
+        th_ph[2] = now_s();
         auto same_name = [&](uint64_t x, uint64_t y) {
             return name_len[x] == name_len[y] && memcmp(ix->text(ix->hdr_pos[x]) + 1, ix->text(ix->hdr_pos[y]) + 1, name_len[x]) == 0;
         };
@@ -1192,6 +1259,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
             work();
             for (auto &x : th) x.join();
         }
+        th_ph[3] = now_s();
         any_dup = dup.load() != 0;
         if (any_dup) {
             if (!ix->header_id.alloc(nrec)) return CRASS_ERR_OOM;
@@ -1217,8 +1285,8 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
     r.exc_read = o.exc_read.data(); r.exc_off = o.exc_off.data(); r.exc_bytes = o.exc_bytes.data();
     r.header_id = any_dup ? ix->header_id.data() : nullptr; r.read_index_base = 0;
     if (timing)
-        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse + pack %.3f s, record arrays %.3f s, header ids %.3f s beside the words' placement %.3f s: %.3f s, pieces freed %.3f s\n",
-                n, nc, (unsigned long long)nrec, t1 - t0, t2 - t1, t3 - t2, t_hdr, t_words, t4 - t3, now_s() - t4);
+        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse + pack %.3f s, record arrays %.3f s, header ids %.3f s (arrays %.3f, count %.3f, scatter %.3f, shards %.3f) beside the words' placement %.3f s: %.3f s, pieces freed %.3f s\n",
+                n, nc, (unsigned long long)nrec, t1 - t0, t2 - t1, t3 - t2, t_hdr, th_ph[0] - t3, th_ph[1] - th_ph[0], th_ph[2] - th_ph[1], th_ph[3] - th_ph[2], t_words, t4 - t3, now_s() - t4);
     *out = ix.release();
     return CRASS_OK;
 }
