@@ -18,6 +18,7 @@
 #include <iostream>
 #include <chrono>
 #include <unistd.h>
+#include <sys/resource.h>
 #include <algorithm>
 #include <vector>
 #include <cstdint>
@@ -231,7 +232,22 @@ int main(int argc, char *argv[])
     // constructors; address-space and KFD tear-down — is the difference to the parent's own clock, tools/e2e_big.py)
     auto epoch = [] { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); };
     if (timing) fprintf(stderr, "[crass_timing] cli: main entered at epoch %.6f\n", epoch());
-    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[crass_timing] cli: %-28s %.3f s (at %.3f s, peak RSS %.0f MB)\n", what, t - t_prev, t - t_main, peak_rss_mb()); t_prev = t; } };
+    // (CPU seconds of the whole process, user + system: under a cgroup CPU quota — the GPU boxes give 16 CPUs per 100 ms — a stage's
+    // wall time is its CPU seconds / 16 however many threads it starts)
+    auto cpu_s = [](double *sys) {
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        if (sys) *sys = ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec;
+        return ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec;
+    };
+    double cpu_prev_u = 0, cpu_prev_s = 0;
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const double t = now();
+        double sy = 0; const double us = cpu_s(&sy);
+        fprintf(stderr, "[crass_timing] cli: %-28s %.3f s (at %.3f s, peak RSS %.0f MB; CPU %.2f s user + %.2f s system)\n", what, t - t_prev, t - t_main, peak_rss_mb(), us - cpu_prev_u, sy - cpu_prev_s);
+        t_prev = t; cpu_prev_u = us; cpu_prev_s = sy;
+    };
     try {
         time_t start_time; time(&start_time);
         if (!devices.empty()) setDevices(devices, local_copies);

@@ -19,10 +19,12 @@
 #include <unordered_map>
 #include <vector>
 #include <zlib.h>
+#include <immintrin.h>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/resource.h>
 #include <unistd.h>
 
 namespace {
@@ -63,6 +65,14 @@ template <typename F> void parallel_ranges(uint64_t n, unsigned nt, F f)
         th.emplace_back([=]() { f(a, b, t); });
     }
     for (auto &x : th) x.join();
+}
+
+// CPU seconds of the process so far (user + system): under a cgroup CPU quota a stage's wall time is its CPU seconds over the quota
+inline double cpu_seconds()
+{
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    return ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec + ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec;
 }
 
 // A large array that is written in full by many threads right after it is allocated: no value-initialisation (a std::vector's
@@ -151,6 +161,9 @@ template <typename T> struct GrowBuf {
         if (p) { if (mapped) munmap(p, cap * sizeof(T)); else free(p); }
         p = nullptr; n = cap = 0; mapped = false;
     }
+    // the pages go back under the address space's SHARED lock (several threads side by side); release() then unmaps nothing but
+    // page tables
+    void drop() { if (p && mapped) (void)madvise(p, cap * sizeof(T), MADV_DONTNEED); release(); }
     void assign(const GrowBuf &o) { resize(o.n); if (o.n) memcpy(p, o.p, o.n * sizeof(T)); }
     void grow(size_t want)
     {
@@ -323,10 +336,76 @@ uint64_t name_hash(const uint8_t *p, size_t n);
 // packs as A: the read is an exception read and its slot's content is ignored).  Eight bases per step: the code of a letter is
 // ((c >> 1) & 3) with the two upper values exchanged, the letter a code stands for is rebuilt (0x41 + 2 b0 + 6 b1 + 11 b0 b1)
 // and compared with what was read
+// 32 bases per step (AVX2, where the CPU has it): the code as above, checked by looking the letter up again (pshufb) and comparing;
+// four codes become a byte through two multiply-adds (t0 + 4 t1, then + 16 (t2 + 4 t3)), the bytes of a 128-bit half are its word.
+// The parsers of an index are bound by CPU seconds, not threads (a 16-CPU quota on a 256-thread host): packing was a quarter of
+// the 130 ns they spent per 150-base record.
+__attribute__((target("avx2"))) inline uint32_t pack_bases_avx2(const uint8_t *s, uint32_t L, uint32_t *w, uint64_t &bad)
+{
+    const __m256i three = _mm256_set1_epi8(3), one = _mm256_set1_epi8(1);
+    const __m256i letters = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    __m256i ok = _mm256_set1_epi8(-1);
+    uint32_t k = 0;
+    for (; k + 32 <= L; k += 32) {
+        const __m256i x = _mm256_loadu_si256((const __m256i *)(s + k));
+        __m256i t = _mm256_and_si256(_mm256_srli_epi16(x, 1), three);
+        t = _mm256_xor_si256(t, _mm256_and_si256(_mm256_srli_epi16(t, 1), one));
+        ok = _mm256_and_si256(ok, _mm256_cmpeq_epi8(_mm256_shuffle_epi8(letters, t), x));
+        const __m256i p2 = _mm256_maddubs_epi16(t, _mm256_set1_epi16(0x0401));            // t0 + 4 t1 per 16-bit lane
+        const __m256i p4 = _mm256_madd_epi16(p2, _mm256_set1_epi32(0x00100001));           // + 16 (t2 + 4 t3) per 32-bit lane
+        const __m256i by = _mm256_shuffle_epi8(p4, pick);
+        w[k >> 4] = (uint32_t)_mm256_cvtsi256_si32(by);
+        w[(k >> 4) + 1] = (uint32_t)_mm256_extract_epi32(by, 4);
+    }
+    if (_mm256_movemask_epi8(ok) != -1) bad |= 1;
+    return k;
+}
+
+// The common record's sequence line in ONE pass: 32 bytes are loaded, looked at for the line's end and packed (the line's length
+// comes out of the same loads memchr would have made).  true: the line was pure ACGT up to a '\n' at p[*len] and its words have
+// been appended to `words` (the tail past the last base is zero); false: anything else — a byte outside ACGT, no line end within
+// `avail - 32` bytes — with `words` as it was: the caller's general path takes the record.
+__attribute__((target("avx2"))) inline bool pack_line_avx2(const uint8_t *p, size_t avail, GrowBuf<uint32_t> &words, size_t *len)
+{
+    alignas(32) static const uint8_t lane_mask[64] = {255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255,
+                                                      255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const __m256i three = _mm256_set1_epi8(3), one = _mm256_set1_epi8(1), nl = _mm256_set1_epi8('\n');
+    const __m256i letters = _mm256_setr_epi8('A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'G', 'T', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const size_t w0 = words.size();
+    size_t k = 0;
+    for (;; k += 32) {
+        if (k + 32 > avail || k >= (1u << 30)) { words.resize(w0); return false; }
+        const size_t wi = w0 + (k >> 4);
+        if (wi + 2 > words.cap) { words.n = wi; words.grow(wi + 2); }
+        const __m256i x = _mm256_loadu_si256((const __m256i *)(p + k));
+        const uint32_t nlm = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, nl));
+        __m256i t = _mm256_and_si256(_mm256_srli_epi16(x, 1), three);
+        t = _mm256_xor_si256(t, _mm256_and_si256(_mm256_srli_epi16(t, 1), one));
+        const uint32_t okm = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(letters, t), x));
+        uint32_t rem = 32;
+        if (nlm) {
+            rem = (uint32_t)__builtin_ctz(nlm);
+            const uint32_t lm = (1u << rem) - 1u;
+            if ((okm & lm) != lm) { words.resize(w0); return false; }
+            t = _mm256_and_si256(t, _mm256_loadu_si256((const __m256i *)(lane_mask + 32 - rem)));
+        } else if (okm != 0xFFFFFFFFu) { words.resize(w0); return false; }
+        const __m256i p2 = _mm256_maddubs_epi16(t, _mm256_set1_epi16(0x0401));
+        const __m256i p4 = _mm256_madd_epi16(p2, _mm256_set1_epi32(0x00100001));
+        const __m256i by = _mm256_shuffle_epi8(p4, pick);
+        words.p[wi] = (uint32_t)_mm256_cvtsi256_si32(by);
+        words.p[wi + 1] = (uint32_t)_mm256_extract_epi32(by, 4);
+        if (nlm) { *len = k + rem; words.n = w0 + (k + rem + 15) / 16; return true; }
+    }
+}
+
 inline bool pack_bases(const uint8_t *s, uint32_t L, uint32_t *w)
 {
     uint64_t bad = 0;
     uint32_t k = 0;
+    static const bool have_avx2 = __builtin_cpu_supports("avx2") && !getenv("CRASS_NO_AVX2");
+    if (have_avx2 && L >= 32) k = pack_bases_avx2(s, L, w, bad);
     for (; k + 16 <= L; k += 16) {
         uint32_t word = 0;
         for (int half = 0; half < 2; half++) {
@@ -375,6 +454,13 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
         }
         if (pos >= n) { o.ended = true; o.last_ret = -1; o.next_start = n; return; }      // ks_getuntil < 0 at EOF
         size_t st = pos;
+        if (pos + 16 <= n) {                              // (the name's end — the first isspace() byte — sixteen bytes at a look)
+            const __m128i x = _mm_loadu_si128((const __m128i *)(data + pos));
+            const __m128i sp = _mm_or_si128(_mm_cmpeq_epi8(x, _mm_set1_epi8(' ')),
+                                            _mm_cmpeq_epi8(_mm_min_epu8(_mm_sub_epi8(x, _mm_set1_epi8('\t')), _mm_set1_epi8(4)), _mm_sub_epi8(x, _mm_set1_epi8('\t'))));
+            const unsigned m = (unsigned)_mm_movemask_epi8(sp);
+            pos += m ? (size_t)__builtin_ctz(m) : 16;
+        }
         while (pos < n && !is_space(data[pos])) pos++;
         const size_t name_st = st, name_len = pos - st;
         int c = pos < n ? data[pos] : -1;
@@ -397,7 +483,15 @@ void parse_range(const uint8_t *data, size_t n, size_t start, size_t limit, bool
         bool packed_in_place = false;
         size_t fast_len = 0;
         const size_t words_base = o.words.size();       // (a record that turns out truncated takes its words back)
-        if (o.pack && pos < n) {
+        static const bool line_avx2 = __builtin_cpu_supports("avx2") && !getenv("CRASS_NO_AVX2");
+        if (o.pack && pos < n && line_avx2) {
+            size_t len = 0;
+            if (pack_line_avx2(data + pos, n - pos, o.words, &len)) {
+                const size_t nx = pos + len + 1;
+                if (len && nx < n && (data[nx] == '>' || data[nx] == '@' || data[nx] == '+')) { packed_in_place = true; fast_len = len; c = data[nx]; pos = nx + 1; }
+                else o.words.resize(words_base);
+            }
+        } else if (o.pack && pos < n) {
             const uint8_t *p = data + pos;
             const void *nlp = memchr(p, '\n', n - pos);
             if (nlp) {
@@ -993,10 +1087,8 @@ struct crass_fastx_index {
     crass_reads reads{};
     uint32_t max_len = 0;
     int last_ret = -1;
-    std::thread reaper;                                // frees the parsers' pieces beside whatever the caller does next
     ~crass_fastx_index()
     {
-        if (reaper.joinable()) reaper.join();
         for (File &f : files) {
             if (f.own) { drop_pages(f.own, f.n); free(f.own); }
             else if (f.map && f.n) { drop_pages(f.map, f.n); munmap(f.map, f.n); }
@@ -1070,7 +1162,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
     for (uint32_t f = 0; f < n_paths; f++) if (frc[f] != CRASS_OK) return frc[f];
     size_t n = 0;                                        // bytes of text, all inputs
     for (uint32_t f = 0; f < n_paths; f++) { ix->files[f].base = n; n += ix->files[f].n; }
-    const double t1 = now_s();
+    const double t1 = now_s(), c1 = cpu_seconds();
     // every input parsed in pieces (pack mode: every record is packed as it is parsed, its text dropped); the pieces of all inputs in
     // (input, position) order are the job's reads in (file, read) order
     std::vector<FxChunk> ch;
@@ -1088,7 +1180,7 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
         F.any_c = any_c; F.any_q = any_q; F.last_ret = cf.empty() ? -1 : cf.back().last_ret;
         for (FxChunk &c : cf) { ch.emplace_back(std::move(c)); piece_file.push_back(f); }
     }
-    const double t2 = now_s();
+    const double t2 = now_s(), c2 = cpu_seconds();
     const size_t nc = ch.size();
     std::vector<uint64_t> rec0(nc + 1, 0), tight0(nc + 1, 0);
     uint32_t max_len = 0, min_len = 0xFFFFFFFFu;
@@ -1107,11 +1199,16 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
     const uint32_t stride = (uniform_len || pad) ? std::max<uint32_t>(1, (max_len + 15) / 16) : 0;
     PackedOwner &o = ix->pk;
     RawBuf<uint32_t> name_len;
-    RawBuf<uint64_t> nh;
+    // shards of the header table (below): by the hash's top 12 bits — ~12 k names per shard for 50 M reads, a 256 KB table that
+    // stays in the filling core's L2 (256 shards of 4 MB tables spent 0.12 s on L3 / memory latency; CRASS_HDR_SHARD_BITS: the A/B)
+    unsigned shard_bits = nrec >= (1u << 22) ? 12 : 8;
+    if (const char *e = getenv("CRASS_HDR_SHARD_BITS")) shard_bits = (unsigned)std::min(14, std::max(1, atoi(e)));
+    const unsigned SH = 1u << shard_bits, shard_shift = 64 - shard_bits, low_shift = shard_shift - 32;
+    std::vector<uint64_t> cnt(nc * (size_t)SH, 0);     // [piece][shard]: records of the piece whose name hash starts with the shard's byte
     const size_t n_words = (size_t)(stride ? nrec * (uint64_t)stride + 4 : tight0[nc] + 4);
     // (no zero fill: the pieces write every word they own, pad words included)
     if (!ix->packed.alloc(n_words) || (!stride && !ix->word_off.alloc(nrec + 1)) || (!uniform_len && !ix->lengths.alloc(nrec)) ||
-        !ix->hdr_pos.alloc(nrec) || !name_len.alloc(nrec) || !nh.alloc(nrec)) return CRASS_ERR_OOM;
+        !ix->hdr_pos.alloc(nrec) || !name_len.alloc(nrec)) return CRASS_ERR_OOM;
     // the per-record arrays first (the header table below needs them), then the words — 2 GB for 50 M reads, most of this
     // stage's time — on their own threads BESIDE the header table: both are bound by memory, neither by the other's data
     uint32_t *packed = ix->packed.data();
@@ -1123,7 +1220,9 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
                 const uint64_t fb = ix->files[piece_file[k]].base;
                 uint64_t *hp = ix->hdr_pos.data() + rec0[k];
                 for (size_t i = 0; i < m; i++) hp[i] = fb + c.hdr_pos[i];
-                memcpy(nh.data() + rec0[k], c.name_h.data(), m * 8);
+                uint64_t *cs = cnt.data() + k * SH;         // (the header table's counting pass: the hashes are read here anyway)
+                const uint64_t *nhk = c.name_h.data();
+                for (size_t i = 0; i < m; i++) cs[nhk[i] >> shard_shift]++;
             }
             uint64_t wat = 0;
             for (size_t i = 0; i < m; i++) {
@@ -1134,7 +1233,8 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
                 if (!stride) ix->word_off[r] = tight0[k] + wat;
                 wat += (L + 15) / 16;
             }
-            c.hdr_pos.release(); c.name_h.release(); c.nlen32.release();
+            // (the pieces' arrays go with the pieces, at the end: sixty-four threads unmapping at once, here, meet on the address
+            // space's lock — 0.08 s; the name hashes are read once more, by the header table's scatter)
         };
         std::vector<std::thread> th;
         for (size_t k = 1; k < nc; k++) th.emplace_back(place_small, k);
@@ -1157,7 +1257,6 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
                 wat += nw;
             }
         }
-        c.words.release();
     };
     double t_words = 0;
     std::thread words_thread([&]() {
@@ -1185,40 +1284,40 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
     // sort of the record indices (two streaming passes over the hashes).
     bool any_dup = false;
     double th_ph[4] = {t3, t3, t3, t3};
+    RawBuf<uint32_t> order, order_h;                     // (released behind the words' placement, below: not beside it)
     if (nrec) {
         if (nrec >= 0xFFFFFFFFull) return CRASS_ERR_UNSUPPORTED;
-        constexpr unsigned SH = 256;
         const unsigned ht = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw_threads(), 64u), nrec / 65536));
-        RawBuf<uint32_t> order, first;
-        RawBuf<uint64_t> order_h;                         // the hashes in shard order too: the shard's thread then reads them in a stream
-                                                          // (looked up per record they were 50 M cache misses, most of this stage)
-        if (!order.alloc(nrec) || !first.alloc(nrec) || !order_h.alloc(nrec)) return CRASS_ERR_OOM;
-        std::vector<uint64_t> cnt((size_t)ht * SH, 0);
+        // order_h: the hashes in shard order too — the 32 bits below the shard's — so that the shard's thread reads them in a stream
+        // (looked up per record they were 50 M cache misses, most of this stage)
+        if (!order.alloc(nrec) || !order_h.alloc(nrec)) return CRASS_ERR_OOM;
         th_ph[0] = now_s();
-        const uint64_t per = (nrec + ht - 1) / ht;
-        auto range = [&](unsigned t, uint64_t &a2, uint64_t &b2) { a2 = std::min<uint64_t>(nrec, t * per); b2 = std::min<uint64_t>(nrec, a2 + per); };
-        {
-            std::vector<std::thread> th;
-            auto count = [&](unsigned t) { uint64_t a2, b2; range(t, a2, b2); uint64_t *c = cnt.data() + (size_t)t * SH; for (uint64_t r = a2; r < b2; r++) c[nh[r] >> 56]++; };
-            for (unsigned t = 1; t < ht; t++) th.emplace_back(count, t);
-            count(0);
-            for (auto &x : th) x.join();
-        }
+        // (counted per piece while the record arrays were placed, above: no pass of its own, and no job-wide copy of the hashes)
         th_ph[1] = now_s();
         std::vector<uint64_t> sh_begin(SH + 1, 0);
-        {   // shard-major, thread-minor: a shard's records stay in read order
+        {   // shard-major, piece-minor: a shard's records stay in read order
             uint64_t at = 0;
             for (unsigned sh = 0; sh < SH; sh++) {
                 sh_begin[sh] = at;
-                for (unsigned t = 0; t < ht; t++) { const uint64_t c = cnt[(size_t)t * SH + sh]; cnt[(size_t)t * SH + sh] = at; at += c; }
+                for (size_t k = 0; k < nc; k++) { const uint64_t c = cnt[k * SH + sh]; cnt[k * SH + sh] = at; at += c; }
             }
             sh_begin[SH] = at;
         }
         {
+            std::atomic<size_t> next_piece{0};
+            auto scatter = [&]() {
+                for (;;) {
+                    const size_t k = next_piece.fetch_add(1, std::memory_order_relaxed);
+                    if (k >= nc) break;
+                    uint64_t *c = cnt.data() + k * SH;
+                    const uint64_t *nhk = ch[k].name_h.data();
+                    const size_t m = ch[k].n_rec();
+                    for (size_t i = 0; i < m; i++) { const uint64_t h = nhk[i], at = c[h >> shard_shift]++; order[at] = (uint32_t)(rec0[k] + i); order_h[at] = (uint32_t)(h >> low_shift); }
+                }
+            };
             std::vector<std::thread> th;
-            auto scatter = [&](unsigned t) { uint64_t a2, b2; range(t, a2, b2); uint64_t *c = cnt.data() + (size_t)t * SH; for (uint64_t r = a2; r < b2; r++) { const uint64_t h = nh[r], at = c[h >> 56]++; order[at] = (uint32_t)r; order_h[at] = h; } };
-            for (unsigned t = 1; t < ht; t++) th.emplace_back(scatter, t);
-            scatter(0);
+            for (unsigned t = 1; t < std::min<size_t>(ht, nc); t++) th.emplace_back(scatter);
+            scatter();
             for (auto &x : th) x.join();
         }
         th_ph[2] = now_s();
@@ -1226,12 +1325,14 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
             return name_len[x] == name_len[y] && memcmp(ix->text(ix->hdr_pos[x]) + 1, ix->text(ix->hdr_pos[y]) + 1, name_len[x]) == 0;
         };
         std::atomic<unsigned> next_shard{0};
-        std::atomic<int> dup{0};
+        std::mutex dup_mu;
+        std::vector<std::pair<uint32_t, uint32_t>> dups;
         {
             std::vector<std::thread> th;
             auto work = [&]() {
                 std::vector<uint64_t> tab;                // (tag | record index + 1), 0 = empty
-                bool dl = false;
+                std::vector<std::pair<uint32_t, uint32_t>> mine;      // (record, the first record of its name): the repeats only — a
+                                                          // first[] entry written per record was 50 M scattered cache lines
                 for (;;) {
                     const unsigned sh = next_shard.fetch_add(1, std::memory_order_relaxed);
                     if (sh >= SH) break;
@@ -1242,39 +1343,52 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
                     tab.assign(cap, 0);
                     for (uint64_t q = sh_begin[sh]; q < sh_begin[sh + 1]; q++) {
                         const uint64_t r = order[q];
-                        const uint64_t h = order_h[q];
-                        const uint64_t tag = (h << 8) & 0xFFFFFFFF00000000ull;      // 32 hash bits below the shard's byte
-                        size_t i = (size_t)(h >> 8) & (cap - 1);
+                        const uint64_t tag = (uint64_t)order_h[q] << 32;          // the 32 hash bits below the shard's
+                        size_t i = (size_t)order_h[q] & (cap - 1);
                         for (;;) {
                             const uint64_t cur = tab[i];
-                            if (cur == 0) { tab[i] = tag | (r + 1); first[r] = (uint32_t)r; break; }
-                            if ((cur & 0xFFFFFFFF00000000ull) == tag && same_name((uint32_t)cur - 1u, r)) { first[r] = (uint32_t)cur - 1u; dl = true; break; }
+                            if (cur == 0) { tab[i] = tag | (r + 1); break; }
+                            if ((cur & 0xFFFFFFFF00000000ull) == tag && same_name((uint32_t)cur - 1u, r)) { mine.emplace_back((uint32_t)r, (uint32_t)cur - 1u); break; }
                             i = (i + 1) & (cap - 1);
                         }
                     }
                 }
-                if (dl) dup.store(1, std::memory_order_relaxed);
+                if (!mine.empty()) { std::lock_guard<std::mutex> lk(dup_mu); dups.insert(dups.end(), mine.begin(), mine.end()); }
             };
             for (unsigned t = 1; t < ht; t++) th.emplace_back(work);
             work();
             for (auto &x : th) x.join();
         }
         th_ph[3] = now_s();
-        any_dup = dup.load() != 0;
+        any_dup = !dups.empty();
         if (any_dup) {
             if (!ix->header_id.alloc(nrec)) return CRASS_ERR_OOM;
-            parallel_ranges(nrec, ht, [&](uint64_t a2, uint64_t b2, unsigned) { for (uint64_t r = a2; r < b2; r++) ix->header_id[r] = first[r]; });
+            parallel_ranges(nrec, ht, [&](uint64_t a2, uint64_t b2, unsigned) { for (uint64_t r = a2; r < b2; r++) ix->header_id[r] = r; });
+            for (const auto &d : dups) ix->header_id[d.first] = d.second;
         }
     }
     const double t_hdr = now_s() - t3;
     words_thread.join();
     const double t4 = now_s();
-    // (what is left of the pieces — a gigabyte of per-record vectors for 50 M reads — is handed back to the allocator on a thread
-    // of its own: 0.4 s on this one)
+    order.release(); order_h.release();
+    // (the pieces — 3.4 GB of per-record arrays and words for 50 M reads — are handed back here, over sixteen threads: their pages
+    // dropped under the shared lock side by side, ~25 ms.  One thread doing it beside whatever the caller does next took 0.15 s and
+    // the caller's host-to-device copy, which pins its source through the same address-space lock, waited for it)
     {
-        std::vector<FxChunk> *dead = new std::vector<FxChunk>();
-        dead->swap(ch);
-        ix->reaper = std::thread([dead] { delete dead; });
+        std::atomic<size_t> next_piece{0};
+        auto drop = [&]() {
+            for (;;) {
+                const size_t k = next_piece.fetch_add(1, std::memory_order_relaxed);
+                if (k >= nc) break;
+                FxChunk &c = ch[k];
+                c.words.drop(); c.hdr_pos.drop(); c.name_h.drop(); c.len32.drop(); c.nlen32.drop();
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < std::min<size_t>(std::min<unsigned>(hw_threads(), 16u), nc); t++) th.emplace_back(drop);
+        drop();
+        for (auto &x : th) x.join();
+        std::vector<FxChunk>().swap(ch);
     }
     crass_reads &r = ix->reads;
     r.n_reads = nrec; r.packed = ix->packed.data(); r.stride_words = stride;
@@ -1285,8 +1399,8 @@ int crass_index_fastx_files(const char *const *paths, uint32_t n_paths, crass_fa
     r.exc_read = o.exc_read.data(); r.exc_off = o.exc_off.data(); r.exc_bytes = o.exc_bytes.data();
     r.header_id = any_dup ? ix->header_id.data() : nullptr; r.read_index_base = 0;
     if (timing)
-        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse + pack %.3f s, record arrays %.3f s, header ids %.3f s (arrays %.3f, count %.3f, scatter %.3f, shards %.3f) beside the words' placement %.3f s: %.3f s, pieces freed %.3f s\n",
-                n, nc, (unsigned long long)nrec, t1 - t0, t2 - t1, t3 - t2, t_hdr, th_ph[0] - t3, th_ph[1] - th_ph[0], th_ph[2] - th_ph[1], th_ph[3] - th_ph[2], t_words, t4 - t3, now_s() - t4);
+        fprintf(stderr, "[crass_timing] fastx index: %zu bytes, %zu pieces, %llu records: map %.3f s, parse + pack %.3f s (%.2f CPU s), record arrays %.3f s, header ids %.3f s (arrays %.3f, count %.3f, scatter %.3f, shards %.3f) beside the words' placement %.3f s: %.3f s, pieces freed %.3f s; %.2f CPU s behind the parse\n",
+                n, nc, (unsigned long long)nrec, t1 - t0, t2 - t1, c2 - c1, t3 - t2, t_hdr, th_ph[0] - t3, th_ph[1] - th_ph[0], th_ph[2] - th_ph[1], th_ph[3] - th_ph[2], t_words, t4 - t3, now_s() - t4, cpu_seconds() - c2);
     *out = ix.release();
     return CRASS_OK;
 }

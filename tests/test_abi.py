@@ -352,6 +352,64 @@ def test_streaming_reader_grows_geometrically_for_a_record_far_longer_than_the_c
     assert time.perf_counter() - t0 < 30
 
 
+@pytest.mark.parametrize("bits", ["1", "8", "12", "14"])
+def test_indexed_reader_header_ids_with_any_shard_count(ca, tmp_path, bits):
+    """the header table of the indexed reader is sharded by the name hash's top bits (12 for jobs of millions of reads, 8 below);
+    CRASS_HDR_SHARD_BITS forces a count: names repeated within and across pieces get the first record of their name either way"""
+    import random
+    rng = random.Random(int(bits))
+    names = ["n%d" % rng.randrange(3000) for _ in range(9000)]
+    text = "".join(">%s\n%s\n" % (nm, "".join(rng.choice("ACGT") for _ in range(rng.randint(40, 90)))) for nm in names).encode()
+    plain, _ = _write_both(tmp_path, "dups.fa", text)
+    first = {}
+    ref_ids = [first.setdefault(nm, i) for i, nm in enumerate(names)]
+    os.environ["CRASS_HDR_SHARD_BITS"] = bits
+    os.environ["CRASS_FASTX_CHUNK"] = "20000"
+    try:
+        ix = ca.FastxIndex(plain)
+    finally:
+        os.environ.pop("CRASS_HDR_SHARD_BITS", None)
+        os.environ.pop("CRASS_FASTX_CHUNK", None)
+    assert ix.n_reads == len(names)
+    assert ix.layout()["header_id"] == ref_ids
+
+
+@pytest.mark.parametrize("avx2", [True, False])
+def test_indexed_reader_packs_every_line_length(ca, tmp_path, avx2):
+    """the index packs the common record's sequence line in one pass of 32-byte steps that also finds the line's end (AVX2; the
+    scalar path with CRASS_NO_AVX2): every length 1 .. 200 — block boundaries, the last block's masked lanes, the record at the very
+    end of the file — and lines with one byte outside ACGT at any place (the general path takes them: exception reads)"""
+    import random
+    rng = random.Random(77)
+    seqs = []
+    for L in range(1, 201):
+        seqs.append("".join(rng.choice("ACGT") for _ in range(L)))
+        bad = list("".join(rng.choice("ACGT") for _ in range(L)))
+        bad[rng.randrange(L)] = rng.choice("NacgtRY-")
+        seqs.append("".join(bad))
+    rng.shuffle(seqs)
+    text = "".join(">s%d\n%s\n" % (i, sq) for i, sq in enumerate(seqs)).encode()
+    plain, _ = _write_both(tmp_path, "lens.fa", text)
+    if not avx2:
+        os.environ["CRASS_NO_AVX2"] = "1"
+    try:
+        import subprocess, sys, json
+        # (the switch is read once per process: a process of its own)
+        code = ("import sys, json; sys.path.insert(0, %r); import crass_amd as ca; ca.load(); ix = ca.FastxIndex(%r); lay = ix.layout(); "
+                "print(json.dumps({'n': int(ix.n_reads), 'lengths': [int(x) for x in lay['lengths']], 'exc': sorted(int(x) for x in lay['exceptions']), "
+                "'words': [[int(v) for v in w] for w in lay['words']]}))") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), plain)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+        got = json.loads(out.strip().splitlines()[-1])
+    finally:
+        os.environ.pop("CRASS_NO_AVX2", None)
+    want = _packed_layout(ca, [sq.encode() for sq in seqs])
+    assert got["n"] == len(seqs) and got["lengths"] == want["lengths"]
+    assert got["exc"] == sorted(want["exceptions"]) and len(got["exc"]) >= 150
+    for i in range(len(seqs)):
+        if i not in want["exceptions"]:
+            assert got["words"][i] == [int(v) for v in want["words"][i]], (i, len(seqs[i]))
+
+
 def _packed_layout(ca, seqs):
     """what crass_pack_reads (mode 2) makes of these sequences, in FastxIndex.layout()'s form"""
     pk = ca.PackedReads(list(seqs), pad_uniform=2)
