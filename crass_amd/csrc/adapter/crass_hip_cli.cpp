@@ -18,6 +18,7 @@
 #include <iostream>
 #include <chrono>
 #include <unistd.h>
+#include <thread>
 #include <sys/resource.h>
 #include <algorithm>
 #include <vector>
@@ -206,6 +207,10 @@ int main(int argc, char *argv[])
     std::string cmd_line;                       // crass.cpp:508-512
     for (int i = 0; i < argc; ++i) { cmd_line += argv[i]; cmd_line += ' '; }
 
+    // This process runs every stage ONCE: its host pool may be as wide as the box's CPU quota allows (the engine's default — half the
+    // quota — is for a caller that steps in a loop with the pool's workers polling between the steps; the output stage's per-group
+    // work went from 0.43 to 0.33 s at 50 M reads)
+    setenv("CRASS_HOST_THREADS", std::to_string(std::min(16u, std::max(1u, std::thread::hardware_concurrency()))).c_str(), 0);
     ReadMap mReads;
     StringCheck mStringCheck;
     DR_Cluster_Map mDR2GIDMap;

@@ -39,6 +39,15 @@ def both(ca, groups, outdir="out/", log_to_screen=True):
     for name in files:
         assert files[name] == o["files"][name], name
     assert text.splitlines() == o["stdout"]
+    # ... and crass_outputs_write puts the same bytes on disk (every file cut into slices that several threads write)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        files2, _, _ = ca.build_outputs(groups, out_dir=outdir, timestamp=OPTS["timestamp"], command_line=OPTS["cmdline"], cwd=OPTS["cwd"],
+                                        log_to_screen=log_to_screen, write_to=td)
+        assert sorted(os.listdir(td)) == sorted(files2)
+        for name in files2:
+            with open(os.path.join(td, name), "rb") as f:
+                assert f.read() == files[name], name
     return o, files
 
 
