@@ -18,6 +18,7 @@
 #include <iostream>
 #include <chrono>
 #include <unistd.h>
+#include <fcntl.h>
 #include <thread>
 #include <sys/resource.h>
 #include <algorithm>
@@ -91,6 +92,10 @@ static void dump_smaps(const char *tag)
 
 int main(int argc, char *argv[])
 {
+    // The descriptor table is grown ONCE, now, while this process has a single thread: later every doubling of it (the HIP runtime's
+    // device and event descriptors, a hundred output files) waits for an RCU grace period, 30 .. 50 ms each, because the table is
+    // shared with other threads by then (fs/file.c expand_fdtable)
+    { const int hi = fcntl(0, F_DUPFD, 4000); if (hi >= 0) close(hi); }
     options opts;
     static struct option long_options[] = {
         {"minDR", required_argument, nullptr, 'd'}, {"maxDR", required_argument, nullptr, 'D'},
@@ -245,13 +250,26 @@ int main(int argc, char *argv[])
         if (sys) *sys = ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec;
         return ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec;
     };
+    // (... and how often the quota froze the cgroup: periods in which it ran dry, cpu.stat's nr_throttled)
+    auto throttled = [] {
+        long n = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.stat", "r")) {
+            char line[128];
+            while (fgets(line, sizeof(line), f)) if (!strncmp(line, "nr_throttled ", 13)) { n = atol(line + 13); break; }
+            fclose(f);
+        }
+        return n;
+    };
     double cpu_prev_u = 0, cpu_prev_s = 0;
+    long thr_prev = timing ? throttled() : 0;
     auto lap = [&](const char *what) {
         if (!timing) return;
         const double t = now();
         double sy = 0; const double us = cpu_s(&sy);
-        fprintf(stderr, "[crass_timing] cli: %-28s %.3f s (at %.3f s, peak RSS %.0f MB; CPU %.2f s user + %.2f s system)\n", what, t - t_prev, t - t_main, peak_rss_mb(), us - cpu_prev_u, sy - cpu_prev_s);
-        t_prev = t; cpu_prev_u = us; cpu_prev_s = sy;
+        const long th = throttled();
+        fprintf(stderr, "[crass_timing] cli: %-28s %.3f s (at %.3f s, peak RSS %.0f MB; CPU %.2f s user + %.2f s system, %ld quota period(s) ran dry)\n", what, t - t_prev, t - t_main, peak_rss_mb(),
+                us - cpu_prev_u, sy - cpu_prev_s, th - thr_prev);
+        t_prev = t; cpu_prev_u = us; cpu_prev_s = sy; thr_prev = th;
     };
     try {
         time_t start_time; time(&start_time);

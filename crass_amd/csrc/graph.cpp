@@ -729,8 +729,14 @@ struct crass_outputs {
     std::vector<uint64_t> sizes;
     std::vector<int32_t> kept;
     string out;
-    std::thread reaper;                                     // takes the graphs apart while the caller writes the files
-    ~crass_outputs() { if (reaper.joinable()) reaper.join(); for (Blob &b : blob) free(b.p); }
+    std::vector<std::unique_ptr<Manager>> dead;             // the groups' graphs: taken apart with the outputs
+    unsigned dead_threads = 1;
+    ~crass_outputs()
+    {
+        if (dead_threads > 1) crass::host_parallel_for(dead.size(), dead_threads, [&](size_t i) { dead[i].reset(); });
+        dead.clear();
+        for (Blob &b : blob) free(b.p);
+    }
 };
 
 extern "C" {
@@ -983,7 +989,11 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
             bl.n = at;
             bl.p = (char *)malloc(at ? at : 1);
             if (!bl.p) return CRASS_ERR_OOM;
-            team_for(piece.size(), 8, [&](size_t i) { if (!piece[i].first->empty()) memcpy(bl.p + piece[i].second, piece[i].first->data(), piece[i].first->size()); });
+            team_for(piece.size(), 8, [&](size_t i) {
+                string *t = const_cast<string *>(piece[i].first);
+                if (!t->empty()) memcpy(bl.p + piece[i].second, t->data(), t->size());
+                string().swap(*t);                          // (a group's text goes back as soon as it has been copied, by the thread that copied it)
+            });
             put(package + ".crispr", string());
             R->blob.back() = bl;
         }
@@ -994,18 +1004,12 @@ int crass_build_outputs(const crass_graph_input *in, const crass_output_opts *op
         const bool bl = R->blob[i].p != nullptr;
         R->name_p.push_back(R->names[i].c_str()); R->data_p.push_back(bl ? R->blob[i].p : R->data[i].data()); R->sizes.push_back(bl ? R->blob[i].n : R->data[i].size());
     }
-    // the managers go on the host pool as they were built: one thread freeing 50 graphs of 10 k reads each (node maps, spacer
-    // strings) was 0.4 s of a 50 M-read run — after the last stage had been timed
-    // ... and beside the caller's next step (crass_outputs_get / _write; crass_outputs_free waits for it)
-    {
-        auto *dead = new std::vector<std::unique_ptr<Manager>>();
-        dead->swap(own);
-        const unsigned thr = threads;
-        R->reaper = std::thread([dead, thr] {
-            if (thr > 1) crass::host_parallel_for(dead->size(), thr, [&](size_t i) { (*dead)[i].reset(); });
-            delete dead;
-        });
-    }
+    // the managers are taken apart when the outputs are freed (crass_outputs_free: on the host pool, as they were built — one thread
+    // freeing 50 graphs of 10 k reads each, node maps and spacer strings, was 0.4 s of a 50 M-read run).  Not here beside the
+    // caller's crass_outputs_write: sixteen threads of tear-down and the writers together ran into the box's CPU quota, and a
+    // process that ends behind its outputs never needs it
+    R->dead.swap(own);
+    R->dead_threads = threads;
     lap("tear-down handed on");
     *res = R.release();
     return CRASS_OK;
@@ -1024,34 +1028,54 @@ int crass_outputs_write(const crass_outputs *o, const char *dir)
     if (!o) return CRASS_ERR_INVALID_ARG;
     string d = dir ? dir : "./";
     if (!d.empty() && d[d.size() - 1] != '/') d += '/';
-    // every file is created (and cut to nothing) first, in order; its bytes then go out in slices of 8 MB from eight threads —
-    // 200 MB of group files and crass.crispr through one thread's fwrite were 0.12 s of a 50 M-read run
+    // eight threads create and write a file each, the largest first (a hundred group files and crass.crispr, 400 MB, through one
+    // thread's fopen / fwrite were 0.12 s of a 50 M-read run — most of it the files' creation, 1.7 ms each on the GPU boxes; slices of
+    // ONE file from several threads meet on the file's lock and were slower than that)
     const size_t nf = o->names.size();
     std::vector<int> fd(nf, -1);
-    struct Slice { size_t file, off, len; };
-    std::vector<Slice> sl;
     int rc = CRASS_OK;
-    for (size_t i = 0; i < nf && rc == CRASS_OK; i++) {
-        fd[i] = open((d + o->names[i]).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
-        if (fd[i] < 0) { rc = CRASS_ERR_IO; break; }
-        const size_t n = o->sizes[i], step = 8u << 20;
-        for (size_t off = 0; off < n; off += step) sl.push_back(Slice{i, off, std::min(step, n - off)});
-    }
+    const bool timing = getenv("CRASS_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tw0 = now();
+    std::vector<size_t> order(nf);
+    for (size_t i = 0; i < nf; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return o->sizes[x] > o->sizes[y]; });
     std::atomic<int> bad{0};
+    const double tw1 = now();
+    double t_big = 0, t_open_sum = 0, t_open_max = 0, t_wr_sum = 0;
+    std::mutex tm_mu;
     if (rc == CRASS_OK)
-        team_for(sl.size(), 8, [&](size_t k) {
-            const Slice &x = sl[k];
-            const char *p = o->data_p[x.file] + x.off;
-            size_t left = x.len, off = x.off;
+        team_for(nf, 8, [&](size_t k) {
+            const size_t i = order[k];
+            const double tf0 = k == 0 ? now() : 0;
+            const double to0 = timing ? now() : 0;
+            fd[i] = open((d + o->names[i]).c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);      // (1.7 ms per file on the GPU boxes: by its writer)
+            if (timing) { const double dt = now() - to0; std::lock_guard<std::mutex> lk(tm_mu); t_open_sum += dt; t_open_max = std::max(t_open_max, dt); }
+            if (fd[i] < 0) { bad.store(1); return; }
+            const char *p = o->data_p[i];
+            size_t left = o->sizes[i];
             while (left) {
-                const ssize_t w = pwrite(fd[x.file], p, left, (off_t)off);
+                const ssize_t w = write(fd[i], p, left);
                 if (w < 0 && errno == EINTR) continue;
                 if (w <= 0) { bad.store(1); return; }
-                p += w; off += (size_t)w; left -= (size_t)w;
+                p += w; left -= (size_t)w;
             }
+            // (closed at once: a hundred descriptors held until the end grow the process's descriptor table, and in a process with
+            // threads every doubling of that table waits for an RCU grace period — 30 .. 50 ms each, 0.1 s of this call)
+            if (close(fd[i]) != 0) bad.store(1);
+            fd[i] = -1;
+            if (k == 0) t_big = now() - tf0;
+            if (timing) { const double dt = now() - to0; std::lock_guard<std::mutex> lk(tm_mu); t_wr_sum += dt; }
         });
+    const double tw2 = now();
     for (size_t i = 0; i < nf; i++) if (fd[i] >= 0 && close(fd[i]) != 0) rc = CRASS_ERR_IO;
     if (bad.load()) rc = CRASS_ERR_IO;
+    if (timing) {
+        uint64_t total = 0;
+        for (size_t i = 0; i < nf; i++) total += o->sizes[i];
+        fprintf(stderr, "[crass_timing] outputs: %zu files, %.1f MB: sorted %.4f s, created + written %.4f s (the largest, %.1f MB: %.4f s), closed %.4f s; opens: %.4f s summed, slowest %.4f s; open + write summed over the files %.4f s\n", nf, total / 1e6, tw1 - tw0, tw2 - tw1,
+                nf ? o->sizes[order[0]] / 1e6 : 0.0, t_big, now() - tw2, t_open_sum, t_open_max, t_wr_sum);
+    }
     return rc;
 }
 
