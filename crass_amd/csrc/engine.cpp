@@ -306,6 +306,7 @@ struct crass_hip_ctx {
         }
     } dense;
     DevBuf<uint64_t> d_fidx;
+    DevBuf<uint64_t> g_fidx;                        // host-loop sink: the found records' slots, gathered (a source of the sink's copies)
     DevBuf<uint64_t> d_pos_hint, d_pos_hint_off; uint64_t n_pos_hint_words = 0;     // long reads: per-position seed hints
     DevBuf<uint32_t> d_punt;                                                          // long reads: [0] count, [1 ..] slots the light walk handed over
     DevBuf<uint32_t> d_redo;                                                          // ... [0] count, [1 ..] slots the full kernel hands on to its full-layout launch
@@ -837,7 +838,7 @@ void crass_hip_destroy(crass_hip_ctx *c)
     c->d_mask.release(); c->d_word_prefix.release(); c->d_block_sums.release(); c->d_idx.release(); c->d_count.release();
     c->d_found.release(); c->d_hit_info.release(); c->d_surv.release(); c->d_dr.release(); c->d_ss_pool.release();
     c->d_ss_used.release(); c->d_rec.release(); c->d_exc_hit.release(); c->d_extra.release();
-    c->g_surv.release(); c->g_dr.release(); c->g_ss.release(); c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
+    c->g_surv.release(); c->g_dr.release(); c->g_ss.release(); c->g_fidx.release(); c->h_count.release(); c->h_surv.release(); c->h_dr.release(); c->h_ss.release(); c->h_idx.release(); c->h_rec.release();
     c->a_go4w.release(); c->a_go16.release(); c->a_go32.release(); c->a_out.release(); c->a_go4.release(); c->dense.release(); c->d_fidx.release(); c->d_pos_hint.release(); c->d_pos_hint_off.release(); c->d_pos_hint_blk.release(); c->d_punt.release(); c->d_redo.release(); c->dd_keys.release(); c->dd_first.release(); c->dd_slot.release(); c->dd_rep.release(); c->dd_hash.release(); c->h_rep.release(); c->h_hash.release(); c->a_anchor.release(); c->d_slot_info.release(); c->d_slot_pid.release(); c->a_out_pid.release(); c->a_pat_token.release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1236,7 +1237,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
         // into dense arrays with the start/stops packed -> three counters -> exact-size copies
         const uint64_t n_words = (nchunk + 63) / 64;
         HIPCHK(c, c->d_fidx.ensure(nchunk)); HIPCHK(c, c->g_surv.ensure(nchunk)); HIPCHK(c, c->g_dr.ensure(nchunk * (size_t)stride + 16));
-        HIPCHK(c, c->g_ss.ensure(pool_cap));
+        HIPCHK(c, c->g_ss.ensure(pool_cap)); HIPCHK(c, c->g_fidx.ensure(nchunk));
         HIPCHK(c, c->d_mask.ensure(n_words + 1)); HIPCHK(c, c->d_word_prefix.ensure(n_words + 1)); HIPCHK(c, c->d_block_sums.ensure((n_words + 255) / 256 + 2));
         HIPCHK(c, hipMemsetAsync(c->d_count.p + 2, 0, 8, c->stream));            // [2] found, [3] worst error
         HIPCHK(c, hipMemsetAsync(c->d_ss_used.p, 0, 4, c->stream));              // (reused: words of packed start/stops)
@@ -1251,7 +1252,7 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
                                c->prm.lowDRsize >= (int)kDevMinDR && stride <= 64 && (stride & 15u) == 0 && nchunk < (1u << 24) && !getenv_once_hl_host();
         if (hl_dedupe) HIPCHK(c, c->g_dr_len.ensure(nchunk));
         HIPCHK(c, launch_gather_sparse(c->d_fidx.p, c->d_count.p + 2, nchunk, c->d_surv.p, c->d_dr.p, stride, c->d_ss_pool.p, c->g_surv.p,
-                                       c->d_fidx.p + 0, c->g_dr.p, c->g_ss.p, (uint32_t)pool_cap, c->d_ss_used.p, c->stream,
+                                       c->g_fidx.p, c->g_dr.p, c->g_ss.p, (uint32_t)pool_cap, c->d_ss_used.p, c->stream,
                                        hl_dedupe ? c->g_dr_len.p : nullptr, ss16 ? 1 : 0));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 2, c->d_count.p + 2, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_count.p + 6, c->d_ss_used.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1274,7 +1275,9 @@ static int run_survivors(crass_hip_ctx *c, bool exc, uint64_t n_total, crass_hip
             hipStream_t cs = lazy ? c->copy_stream : c->stream;      // (the main stream is idle: it was waited for above)
             // lazy: on DMA engines where the runtime offers them — as blit kernels these 12 MB of PCIe stores stretched whatever
             // ran beside them (k_block_scan of the de-duplication: 138 us instead of 5, profiles/r05_timeline_c3.txt)
-            const void *srcs[4] = {c->g_surv.p, c->g_dr.p, c->d_fidx.p, c->g_ss.p};
+            // (the records' slots are gathered into a buffer of their own, g_fidx: d_fidx is written again by pass 2, and the copies
+            // below may still be reading when it is queued — crass_hip_recruit used to wait for them, 0.5 ms of a long-read step)
+            const void *srcs[4] = {c->g_surv.p, c->g_dr.p, c->g_fidx.p, c->g_ss.p};
             void *dsts[4] = {c->h_surv.p, c->h_dr.p, c->h_idx.p, c->h_ss.p};
             const size_t nbs[4] = {nf * sizeof(SurvOut), nf * (size_t)stride, nf * 8, used ? (size_t)used * (ss16 ? 2 : 4) : 0};
             static const bool sink_blit = getenv("CRASS_COPY_BLIT") != nullptr;
@@ -1397,6 +1400,7 @@ static void presize_hostloop(crass_hip_ctx *c)
     need(c->d_surv.ensure(chunk_cap)); need(c->d_dr.ensure(chunk_cap * stride)); need(c->d_ss_pool.ensure(pool_cap));
     need(c->h_surv.ensure(chunk_cap)); need(c->h_dr.ensure(chunk_cap * stride));
     need(c->d_fidx.ensure(chunk_cap)); need(c->g_surv.ensure(chunk_cap)); need(c->g_dr.ensure(chunk_cap * (size_t)stride + 16)); need(c->g_ss.ensure(pool_cap));
+    need(c->g_fidx.ensure(chunk_cap));
     need(c->d_mask.ensure(n_words + 1)); need(c->d_word_prefix.ensure(n_words + 1)); need(c->d_block_sums.ensure((n_words + 255) / 256 + 2));
     need(c->g_dr_len.ensure(chunk_cap)); need(c->h_ss.ensure(nf * 128 + 1)); need(c->h_idx.ensure(nf + 1));
     need(c->dd_keys.ensure(tsize)); need(c->dd_first.ensure(tsize)); need(c->dd_slot.ensure(nf)); need(c->dd_rep.ensure(nf));
@@ -3158,13 +3162,9 @@ int crass_hip_recruit(crass_hip_ctx *c, const uint64_t *extra_found, uint64_t n_
     c->have_pass2 = false;
     c->q_blob_active = false;
     c->cnt.n_pass2_found = 0;
-    // (the host-loop sink's copies may still be reading d_fidx, which this pass writes near its end: order the stream behind them)
-    // The event covers the copies that went over copy_stream; the ones on DMA engines (dma_sink[]) are behind no stream event, so
-    // the order seed_scan -> set_patterns -> recruit (no merge / get_candidates in between, which wait themselves) waits here.
-    if (c->cand_fill) {
-        if (c->ev_sink_copies) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sink_copies, 0));
-        if (const int bs = c->wait_bulk()) return bs;
-    }
+    // (the host-loop sink's copies — over copy_stream or on DMA engines — may still be running: their sources, g_surv / g_dr /
+    // g_fidx / g_ss, are the sink's own and nothing in this pass writes them, so nobody waits here.  Round 5 gathered the slots
+    // in place in d_fidx, which this pass writes near its end, and the wait that needed was 0.5 ms of a 1 M x 10 kbp step)
     // findSingletons is only called when the non-redundant set is non-empty (WorkHorse.cpp:373)
     if (c->n_installed_patterns == 0) { c->have_pass2 = true; return CRASS_OK; }
     if (!c->have_patterns) return CRASS_ERR_STATE;
