@@ -149,22 +149,6 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
-        sys.exit(3)
-    if args.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
-    coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
-
     # ---- options (default: crass's own) ----
     pkw = {}
     for kv in [x for x in args.params.split(",") if x]:
@@ -194,6 +178,30 @@ def main():
     W = (L + 15) // 16
     spec = ca.synth_spec(read_len=L, n_dr=n_dr, gc_classes=gc, crispr_per_million=cfg["cpm"],
                          array_min_repeats=cfg["arrays"][0], array_max_repeats=cfg["arrays"][1])
+    # ---- end to end through the command line FIRST, while this process has not touched the GPU and has no engine, no pool threads
+    #      and no pinned buffers of its own: what a user of `crass-hip` gets.  (Run behind the timed steps, beside this process's
+    #      resident engine, the same child took 2.0 s instead of 1.6-1.7: profiles/NOTES_r06.md.) ----
+    e2e_early = None
+    if world == 1 and not group_mode and rank == 0 and torch.cuda.device_count() > 0:      # (counting devices does not initialise one)
+        e2e_n = args.e2e_reads if args.e2e_reads >= 0 else (_e2e_default_reads(L) if L <= 300 and not custom else 0)
+        if e2e_n > 0:
+            e2e_early = _e2e_cli(ca, spec, L, min(e2e_n, total))
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    if args.share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
+    coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
+
     t0 = time.time()
     words = ca.synth_packed(spec, first, n)
     t_gen = time.time() - t0
@@ -483,9 +491,8 @@ def main():
         out["abi_fetch"] = {"ms_all": [round(x, 3) for x in fetch], "candidates": nf[0], "tokens": nf[1], "recruits": nf[2],
                             "note": "crass_hip_get_candidates + crass_hip_get_merge + crass_hip_get_recruits after a step (median of 3): "
                                     "the per-record arrays of the ABI, widened from the step's compact blobs; not part of `value`"}
-        e2e_n = args.e2e_reads if args.e2e_reads >= 0 else (_e2e_default_reads(L) if L <= 300 and not custom else 0)
-        if e2e_n > 0 and rank == 0:
-            out["e2e"] = _e2e_cli(ca, spec, L, min(e2e_n, total))
+        if e2e_early is not None:                            # (measured at the start of this run, see above)
+            out["e2e"] = e2e_early
             if "reads_per_s" in out["e2e"]:
                 out["e2e_reads_per_s"] = out["e2e"]["reads_per_s"]
 
