@@ -27,6 +27,7 @@
 #include <vector>
 #include <sys/mman.h>
 #include <zlib.h>
+#include <dlfcn.h>
 
 namespace crass {
 
@@ -442,7 +443,16 @@ bool parallel_gunzip(const uint8_t *in, size_t n, uint8_t **out_p, size_t *out_n
         std::vector<size_t> cut(np + 1);
         for (unsigned t = 0; t <= np; t++) cut[t] = total * t / np;
         std::vector<std::thread> th;
+        // (libdeflate's CRC-32 where the library is there — carry-less multiplies, ~10 GB/s per core; zlib's table walk is ~1 GB/s,
+        // 0.35 s of an 8 GB input on sixteen threads.  The same polynomial: the pieces still combine through crc32_combine)
+        typedef uint32_t (*crc_fn)(uint32_t, const void *, size_t);
+        static const crc_fn ld_crc = [] {
+            if (getenv("CRASS_NO_LIBDEFLATE")) return (crc_fn) nullptr;
+            void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+            return h ? (crc_fn)dlsym(h, "libdeflate_crc32") : (crc_fn) nullptr;
+        }();
         auto one = [&](unsigned t) {
+            if (ld_crc) { crcs[t] = ld_crc(0, out + cut[t], cut[t + 1] - cut[t]); return; }
             uLong c = crc32(0L, Z_NULL, 0);
             for (size_t a = cut[t]; a < cut[t + 1];) { const size_t m = std::min<size_t>(cut[t + 1] - a, 1u << 30); c = crc32(c, out + a, (uInt)m); a += m; }
             crcs[t] = c;
