@@ -1,6 +1,6 @@
 // exit_cost.cpp — what a process's END costs after _exit(): anonymous host memory (4 KB pages or THP), device memory, pinned host
 // memory, a HIP context alone.  The parent (tools/exit_cost.py) measures _exit -> reaped.
-//   exit_cost <host_gb> <thp 0|1> <dev_gb> <pinned_gb> <hip 0|1> [drop_threads]   (drop_threads: MADV_DONTNEED the host memory in
+//   exit_cost <host_gb> <thp 0|1> <dev_gb> <pinned_gb> <hip 0|1> [drop_threads [streams]]   (drop_threads: MADV_DONTNEED the host memory in
 //   64 MB slices over that many threads before _exit, and print how long that took)
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -27,6 +27,12 @@ int main(int argc, char **argv)
         if (hipSetDevice(0) != hipSuccess) return 3;
         hipFree(nullptr);
         if (dev) { void *d = nullptr; if (hipMalloc(&d, dev) != hipSuccess || hipMemset(d, 1, dev) != hipSuccess) return 4; hipDeviceSynchronize(); }
+        if (argc > 7) {                                   // n streams, each made to own a hardware queue by a small fill
+            const int ns = atoi(argv[7]);
+            void *d = nullptr;
+            if (hipMalloc(&d, 4096) != hipSuccess) return 6;
+            for (int i = 0; i < ns; i++) { hipStream_t st; if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return 7; (void)hipMemsetAsync(d, 0, 4096, st); (void)hipStreamSynchronize(st); }
+        }
         if (pin) { void *h = nullptr; if (hipHostMalloc(&h, pin, hipHostMallocDefault) != hipSuccess) return 5; for (size_t i = 0; i < pin; i += 4096) ((char *)h)[i] = 1; }
     }
     if (argc > 6 && host) {
