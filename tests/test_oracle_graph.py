@@ -182,3 +182,15 @@ def test_xml_escapes_and_attribute_order(ca):
     assert 'accession="read' in x and "&amp;&lt;&quot;>" in x
     assert '<group drseq="%s" gid="G7">' % dr.decode() in x and '<dr drid="DR1" seq="' in x
     ET.fromstring(x)
+
+
+def test_outputs_write_reports_a_directory_it_cannot_write_to(ca, tmp_path):
+    """crass_outputs_write creates and writes every file on its own threads: a directory that does not exist is CRASS_ERR_IO (the
+    reference's writers fail the same way, WorkHorse.cpp:1900-2038), and nothing is left half-written elsewhere"""
+    groups = [(1, b"GTTTCAATCCACGCGCCCACGCGGGGCGCGAC", [])]
+    with pytest.raises(ca.CrassError):
+        ca.build_outputs(groups, out_dir="out/", timestamp=OPTS["timestamp"], command_line=OPTS["cmdline"], cwd=OPTS["cwd"],
+                         log_to_screen=True, write_to=str(tmp_path / "no" / "such" / "dir"))
+    files, kept, _ = ca.build_outputs(groups, out_dir="out/", timestamp=OPTS["timestamp"], command_line=OPTS["cmdline"], cwd=OPTS["cwd"],
+                                      log_to_screen=True, write_to=str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == sorted(files)
