@@ -904,3 +904,31 @@ def test_streaming_reader_block_assembly(ca, tmp_path, kind, chunk):
         assert got[0] == ref and walk[0] == ref
         assert got[1] == walk[1] == list(range(6000))
         assert got[2] == walk[2]
+
+
+def test_command_line_option_checks_need_no_gpu(ca, tmp_path):
+    """crass-hip validates its options the way crass.cpp:264-400 does before anything touches a device: usage, the missing input,
+    bounds that cross, values crass replaces with its defaults (with crass's warnings) — all without a GPU; a run that gets as far as
+    the search on a host without one fails loudly (there is no CPU path)"""
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.abspath(ca.__file__)), "crass-hip")
+    if not os.path.exists(cli):
+        pytest.skip("crass-hip not built")
+    run = lambda *a: subprocess.run([cli] + list(a), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    r = run("-h")
+    assert r.returncode == 0 and "usage: crass-hip" in r.stdout
+    r = run()
+    assert r.returncode == 1 and "No input files were provided" in r.stderr
+    r = run("-d", "50", "-D", "40", "x.fa")
+    assert r.returncode == 1 and "lower direct repeat bound is bigger" in r.stderr
+    r = run("-s", "60", "-S", "50", "x.fa")
+    assert r.returncode == 1 and "lower spacer bound is bigger" in r.stderr
+    r = run("-n", "1", "x.fa")
+    assert r.returncode == 1 and "cannot be less than 2" in r.stderr
+    fa = tmp_path / "r.fa"
+    fa.write_text(">a\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    import torch
+    if torch.cuda.device_count() == 0:
+        r = run("-g", "-d", "5", "-w", "12", "-o", str(tmp_path), str(fa))      # (-d < 8 and -w outside 6..9: warned about and replaced)
+        assert "changing to 23" in r.stderr and "Changing window length to 8" in r.stderr
+        assert r.returncode != 0                             # no device: the search stage throws, the process reports it
