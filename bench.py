@@ -705,7 +705,13 @@ def _e2e_cli(ca, spec, L, n, modes=("auto",)):
         res = {}
         for mode in modes:
             walls, found, rss, stages = [], None, 0.0, []
+            # glibc.malloc.hugetlb=1: malloc's arenas in 2 MB pages (ReadHolders, graphs, every temporary string: 1.31-1.38 s instead of
+            # 1.55-1.7 for 50 M reads).  `crass-hip` restarts itself once with this tunable when it safely can (nothing preloaded, no
+            # device file open: crass_hip_cli.cpp); a GPU box preloads a guard library into every process, so the command line stays
+            # as it was started there and the tunable is given to it here, as INTEGRATION.md tells a user to
             env = dict(os.environ, CRASS_TIMING="1")
+            if "glibc.malloc.hugetlb" not in env.get("GLIBC_TUNABLES", ""):
+                env["GLIBC_TUNABLES"] = (env["GLIBC_TUNABLES"] + ":" if env.get("GLIBC_TUNABLES") else "") + "glibc.malloc.hugetlb=1"
             env.pop("CRASS_INGEST", None)
             if mode != "auto":
                 env["CRASS_INGEST"] = mode
@@ -728,6 +734,9 @@ def _e2e_cli(ca, spec, L, n, modes=("auto",)):
                 for line in open(log, "rb").read().decode().replace("\r", "\n").splitlines():
                     if "Found" in line and "reads" in line:
                         found = line.strip()
+                    if "cli: GLIBC_TUNABLES=" in line:
+                        stages.append(line.strip()[15:])
+                        continue
                     m3 = re.search(r"cli: (main entered|_exit called) at epoch ([0-9.]+)", line)
                     if m3:                              # what the process spends outside main (loader / address-space + KFD tear-down)
                         stages.append("cli: spawn -> main %.3f s" % (float(m3.group(2)) - e0) if m3.group(1) == "main entered"
@@ -745,7 +754,7 @@ def _e2e_cli(ca, spec, L, n, modes=("auto",)):
         out = {"reads": n, "wall_s": first["wall_s"], "reads_per_s": first["reads_per_s"], "walls_s": first["walls_s"],
                "peak_rss_mb": first["peak_rss_mb"], "fasta_mb": round(n * (11 + L) / 1e6, 1), "found": first["found"],
                "input_dir": os.path.dirname(td), "input_written_s": round(t_gen, 1), "reader": modes[0],
-               "note": "`crass-hip -g -o DIR file.fa`: process start + HIP init + read/parse/pack + H2D + pass 1 + merge + pass 2 + "
+               "note": "`GLIBC_TUNABLES=glibc.malloc.hugetlb=1 crass-hip -g -o DIR file.fa`: process start + HIP init + read/parse/pack + H2D + pass 1 + merge + pass 2 + "
                        "hand-off + consensus + spacer graphs + output files; PCIe- and parse-inclusive, never part of `value`"}
         if len(modes) > 1:
             out["by_reader"] = res
